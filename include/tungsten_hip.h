@@ -1,0 +1,256 @@
+/*
+ * tungsten_hip.h -- C-ABI boundary of the MI355X-native `path_tracer_hip` integrator.
+ *
+ * This is the thin extern "C" shim the north star asks for: plain pointers and sizes,
+ * no C++/torch types.  It is what a Tungsten maintainer would bind from the reference's
+ * C++11 host.  Each entry point names the reference interface it
+ * replaces (paths relative to the reference tree, src/core/...):
+ *
+ *   tghip_upload_scene      <- TraceableScene::TraceableScene (renderer/TraceableScene.hpp:57-137):
+ *                              the Embree top-level + per-mesh scenes (primitives/TriangleMesh.cpp:524-572)
+ *                              become one flattened BVH2 + SoA record stream in HBM.
+ *   tghip_render_pass/_wait <- PathTraceIntegrator::startRender / waitForCompletion
+ *                              (integrators/path_tracer/PathTraceIntegrator.cpp:220-244) and, inside them,
+ *                              renderTile (:136-156) -> PathTracer::traceSample (PathTracer.cpp:14-149).
+ *   tghip_abort             <- PathTraceIntegrator::abortRender (PathTraceIntegrator.cpp:246-256).
+ *   tghip_download_framebuffer <- OutputBuffer<Vec3f>::addSample / operator[] (cameras/OutputBuffer.hpp:104-144).
+ *   tghip_trace_rays        <- TraceableScene::intersect (renderer/TraceableScene.hpp:170-192), batched.
+ *   tghip_get_counters      <- (no reference analogue; feeds the roofline model).
+ *
+ * Ownership: the caller owns every host array (borrowed for the duration of the call; the
+ * shim copies with hipMemcpyAsync); the shim owns device memory behind the opaque handle.
+ * All functions return 0 on success and a negative TGHIP_E_* code on failure (message via
+ * tghip_last_error); nothing throws across the boundary.  One handle per device; calls on
+ * one handle must be serialised by the caller; different handles may be driven from
+ * different host threads.
+ *
+ * The flattened scene structs below are also the input of the CPU oracle (oracle/oracle.c),
+ * so that the checker and the HIP path consume bit-identical inputs.
+ */
+#ifndef TUNGSTEN_HIP_H_
+#define TUNGSTEN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGHIP_ABI_VERSION 1
+
+/* ---- error codes ------------------------------------------------------------------ */
+enum {
+    TGHIP_OK            =  0,
+    TGHIP_E_INVALID     = -1,  /* bad argument / inconsistent description */
+    TGHIP_E_NODEVICE    = -2,  /* no HIP device / hipSetDevice failed     */
+    TGHIP_E_HIP         = -3,  /* a HIP runtime call failed               */
+    TGHIP_E_NOSCENE     = -4,  /* render/trace before upload              */
+    TGHIP_E_ABORTED     = -5,  /* pass was aborted via tghip_abort        */
+    TGHIP_E_UNSUPPORTED = -6   /* feature outside the hot-path scope      */
+};
+
+/* ---- flattened geometry -------------------------------------------------------------
+ * One BVH2 over all finite primitives in world space (the reference bakes transforms into
+ * _tfVerts, TriangleMesh.cpp:542-552).  64-byte nodes; a child reference is either an
+ * internal node index (>= 0) or a leaf (bit 31 set): count = (ref >> 27) & 15, first record
+ * = ref & 0x07FFFFFF.  Leaves are contiguous runs of 48-byte primitive records. */
+typedef struct TgHipBvhNode {
+    float   lo0[3], hi0[3];   /* child 0 bounds */
+    float   lo1[3], hi1[3];   /* child 1 bounds */
+    int32_t child0, child1;
+    uint32_t pad[2];
+} TgHipBvhNode;               /* 64 B */
+
+#define TGHIP_LEAF_FLAG        0x80000000u
+#define TGHIP_LEAF_COUNT(ref)  (((uint32_t)(ref) >> 27) & 15u)
+#define TGHIP_LEAF_FIRST(ref)  ((uint32_t)(ref) & 0x07FFFFFFu)
+#define TGHIP_MAKE_LEAF(first, count) (int32_t)(TGHIP_LEAF_FLAG | ((uint32_t)(count) << 27) | (uint32_t)(first))
+#define TGHIP_MAX_LEAF         15
+#define TGHIP_MAX_BVH_DEPTH    48   /* builder guarantees depth <= this (device stack size) */
+
+/* record kinds (meta >> 29) */
+enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3 };
+#define TGHIP_REC_KIND(meta)   ((uint32_t)(meta) >> 29)
+#define TGHIP_REC_OBJECT(meta) ((uint32_t)(meta) & 0x1FFFFFFFu)
+
+/* 48-byte primitive record = three float4:
+ *   triangle: a = v0, b = v1 - v0, c = v2 - v0                (p0,p1 unused)
+ *   quad    : a = base, b = edge0, c = edge1, p0/p1 = 1/|edge0|^2, 1/|edge1|^2   (Quad.cpp:298-316)
+ *   cube / sphere: geometry lives in objects[TGHIP_REC_OBJECT(meta)]; a,b,c unused */
+typedef struct TgHipPrimRec {
+    float a[3]; uint32_t meta;
+    float b[3]; float p0;
+    float c[3]; float p1;
+} TgHipPrimRec;               /* 48 B */
+
+/* 64-byte per-triangle shading attributes, same index as the record (denormalised from the
+ * reference's Vertex{pos,normal,uv}/TriangleI{v0,v1,v2,material}, primitives/Vertex.hpp:10-13,
+ * Triangle.hpp:14-28, so that one hit costs one 64-B gather).  Normals are already multiplied
+ * by the normal matrix (TriangleMesh.cpp:542-549). */
+typedef struct TgHipTriAttr {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    int32_t bsdf;             /* global bsdf index = mesh._bsdfs[clamp(tri.material)] */
+} TgHipTriAttr;               /* 64 B */
+
+/* ---- objects (one per reference Primitive) ------------------------------------------ */
+enum { TGHIP_OBJ_MESH = 0, TGHIP_OBJ_QUAD = 1, TGHIP_OBJ_CUBE = 2, TGHIP_OBJ_SPHERE = 3,
+       TGHIP_OBJ_INFINITE_SPHERE = 4 };
+#define TGHIP_OBJF_SMOOTH   1u   /* mesh "smooth": Ns interpolated (TriangleMesh.cpp:344-355) */
+#define TGHIP_OBJF_SAMPLE   2u   /* infinite_sphere "sample" (InfiniteSphere.cpp:117-122)      */
+
+typedef struct TgHipObject {
+    int32_t  type;            /* TGHIP_OBJ_*                                      */
+    int32_t  bsdf;            /* bsdf index (quad/cube/sphere); -1 for infinite   */
+    int32_t  emission;        /* texture index of the radiance, -1 = not emissive */
+    int32_t  light;           /* index in lights[] if samplable emitter, else -1  */
+    uint32_t flags;
+    float    area, inv_area;  /* quad/cube/mesh total area                        */
+    int32_t  first_light_tri; /* mesh emitters: offset into light_tris (unused yet) */
+    float    base[3], edge0[3], edge1[3], normal[3]; /* quad (Quad.cpp:298-316)    */
+    float    inv_uv_sq[2];
+    float    pos[3], scale[3];                       /* cube half-extent / sphere radius in scale[0] */
+    float    rot[9];                                 /* row-major 3x3 rotation (cube; infinite sphere _rotTransform) */
+    float    face_cdf[3];                            /* cube (Cube.cpp:353-370)    */
+    float    pad[3];
+} TgHipObject;
+
+/* ---- BSDFs ---------------------------------------------------------------------------- */
+enum { TGHIP_BSDF_LAMBERT = 0, TGHIP_BSDF_NULL = 1, TGHIP_BSDF_ROUGH_CONDUCTOR = 2,
+       TGHIP_BSDF_SMOOTH_COAT = 3, TGHIP_BSDF_DIELECTRIC = 4, TGHIP_BSDF_ROUGH_DIELECTRIC = 5,
+       TGHIP_BSDF_MIRROR = 6, TGHIP_BSDF_CONDUCTOR = 7, TGHIP_BSDF_PLASTIC = 8,
+       TGHIP_BSDF_ROUGH_PLASTIC = 9, TGHIP_BSDF_MIXED = 10, TGHIP_BSDF_TRANSPARENCY = 11,
+       TGHIP_BSDF_FORWARD = 12, TGHIP_BSDF_ERROR = 13 };
+enum { TGHIP_DIST_BECKMANN = 0, TGHIP_DIST_PHONG = 1, TGHIP_DIST_GGX = 2 };
+/* lobe bits, identical to bsdfs/BsdfLobes.hpp:13-33 */
+enum { TGHIP_LOBE_GLOSSY_R = 1, TGHIP_LOBE_GLOSSY_T = 2, TGHIP_LOBE_DIFFUSE_R = 4, TGHIP_LOBE_DIFFUSE_T = 8,
+       TGHIP_LOBE_SPECULAR_R = 16, TGHIP_LOBE_SPECULAR_T = 32, TGHIP_LOBE_ANISOTROPIC = 64,
+       TGHIP_LOBE_FORWARD = 128 };
+
+typedef struct TgHipBsdf {
+    int32_t  type;            /* TGHIP_BSDF_*                               */
+    uint32_t lobes;           /* after prepareForRender                      */
+    int32_t  albedo;          /* texture index                               */
+    int32_t  distribution;    /* TGHIP_DIST_*                                */
+    int32_t  roughness;       /* texture index (scalar)                      */
+    int32_t  sub0, sub1;      /* substrate / bsdf0,bsdf1 / base              */
+    int32_t  tex1;            /* ratio / alpha texture                       */
+    float    ior, thickness, avg_transmittance, diffuse_fresnel;
+    int32_t  enable_refraction;
+    float    eta[3], k[3], sigma_a[3], scaled_sigma_a[3];
+    float    pad[2];
+} TgHipBsdf;
+
+/* ---- textures ------------------------------------------------------------------------- */
+enum { TGHIP_TEX_CONSTANT = 0, TGHIP_TEX_CHECKER = 1, TGHIP_TEX_BITMAP = 2 };
+#define TGHIP_TEXF_LINEAR 1u
+#define TGHIP_TEXF_CLAMP  2u
+#define TGHIP_TEXF_RGB    4u
+#define TGHIP_TEXF_VALID  8u
+
+typedef struct TgHipTexture {
+    int32_t  type;
+    uint32_t flags;
+    int32_t  w, h;
+    float    value[3];        /* constant value                              */
+    float    scale;           /* bitmap _scale                               */
+    float    on_color[3];  int32_t res_u;
+    float    off_color[3]; int32_t res_v;
+    float    avg[3];          /* Texture::average()                          */
+    float    pad;
+    int64_t  texel_offset;    /* float offset into texels (3 per texel if RGB, else 1) */
+    int64_t  dist_offset;     /* float offset into dist: marginalPdf[h] marginalCdf[h+1] pdf[w*h] cdf[(w+1)*h]; -1 = none
+                                 (sampling/Distribution2D.hpp:18-83 built by BitmapTexture::makeSamplable, BitmapTexture.cpp:400-431) */
+} TgHipTexture;
+
+/* ---- camera (cameras/PinholeCamera.cpp:28-86, Camera.cpp:44-68, ReconstructionFilter) ---- */
+enum { TGHIP_FILTER_DIRAC = 0, TGHIP_FILTER_BOX = 1, TGHIP_FILTER_TABULATED = 2 };
+typedef struct TgHipCamera {
+    float   pos[3];
+    float   plane_dist;
+    float   xf[9];            /* row-major upper 3x3 of Camera::_transform (right axis negated) */
+    float   ratio, pixel_size_x;
+    int32_t res_x, res_y;
+    int32_t filter_type;
+    float   filter_width, filter_bin_size;
+    float   filter_cdf[32];   /* ReconstructionFilter::_cdf (RFILTER_RESOLUTION = 31) */
+} TgHipCamera;
+
+/* ---- integrator settings (TraceSettings.hpp:23-39, PathTracerSettings.hpp:25-43) -------- */
+typedef struct TgHipSettings {
+    int32_t min_bounces, max_bounces;
+    int32_t enable_light_sampling, enable_two_sided_shading, enable_consistency_checks;
+    int32_t pad[3];
+} TgHipSettings;
+
+typedef struct TgHipSceneDesc {
+    uint32_t abi_version;     /* TGHIP_ABI_VERSION */
+    uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
+    const TgHipBvhNode *nodes;
+    const TgHipPrimRec *recs;
+    const TgHipTriAttr *tri_attrs;        /* num_recs entries (unused for non-triangles) */
+    const TgHipObject  *objects;
+    const int32_t      *lights;           /* object indices, TraceableScene::_lights order (TraceableScene.hpp:86-102) */
+    const int32_t      *infinite_lights;  /* object indices, TraceableScene::_infiniteLights */
+    const TgHipBsdf    *bsdfs;
+    const TgHipTexture *textures;
+    const float        *texels;  uint64_t num_texel_floats;
+    const float        *dist;    uint64_t num_dist_floats;
+    TgHipCamera   camera;
+    TgHipSettings settings;
+    float         bounds_lo[3], bounds_hi[3];
+} TgHipSceneDesc;
+
+/* ---- passes ------------------------------------------------------------------------------
+ * A pass renders samples [spp_begin, spp_end) of every pixel owned by this shard.  Ownership
+ * follows the reference's 16x16 tile dicing (PathTraceIntegrator.cpp:27-42): tile t (row-major)
+ * belongs to shard (t % shard_count).  Random numbers are a counter-based PCG stream keyed by
+ * (seed, pixelIndex, sampleIndex) -- see DESIGN.md "RNG". */
+typedef struct TgHipPassDesc {
+    uint32_t spp_begin, spp_end;
+    uint32_t seed;
+    uint32_t shard_index, shard_count;   /* 0,1 = whole image */
+    uint32_t flags;                      /* reserved */
+} TgHipPassDesc;
+
+typedef struct TgHipCounters {
+    uint64_t samples;           /* camera paths completed                         */
+    uint64_t closest_rays;      /* closest-hit queries (extension rays)           */
+    uint64_t shadow_rays;       /* shadow-type closest-hit queries                */
+    uint64_t nodes_visited;     /* BVH nodes fetched, all rays (0 unless counting is enabled) */
+    uint64_t prims_tested;      /* primitive records tested, all rays                          */
+    uint64_t iterations;        /* wavefront iterations                           */
+    double   ms_trace_closest, ms_trace_shadow, ms_shade, ms_other, ms_total;  /* HIP-event time, last pass set */
+    uint64_t launches_trace_closest, launches_trace_shadow, launches_shade;
+} TgHipCounters;
+
+/* closest-hit query record for tghip_trace_rays (and the oracle's equivalent) */
+typedef struct TgHipRay { float o[3], tmin, d[3], tmax; } TgHipRay;          /* 32 B */
+typedef struct TgHipHit { float t, u, v; int32_t rec; } TgHipHit;            /* 16 B; rec = -1 on miss */
+
+typedef struct tghip_ctx tghip_ctx;
+
+tghip_ctx  *tghip_create(int device_ordinal);
+void        tghip_destroy(tghip_ctx *ctx);
+const char *tghip_last_error(tghip_ctx *ctx);      /* ctx may be NULL: last create error */
+int         tghip_device_count(void);
+
+int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *scene);
+int tghip_render_pass(tghip_ctx *ctx, const TgHipPassDesc *pass);   /* asynchronous */
+int tghip_wait(tghip_ctx *ctx);
+int tghip_abort(tghip_ctx *ctx);
+int tghip_clear_framebuffer(tghip_ctx *ctx);
+/* Use caller-owned DEVICE buffers (e.g. a torch tensor) as framebuffer: sum = W*H*3 floats,
+ * count = W*H uint32.  Pass NULLs to go back to the internal buffers. */
+int tghip_bind_framebuffer(tghip_ctx *ctx, float *dev_rgb_sum, uint32_t *dev_count);
+int tghip_download_framebuffer(tghip_ctx *ctx, float *rgb_sum, uint32_t *count, size_t npixels);
+int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch);
+int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
+int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);
+int tghip_reset_counters(tghip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TUNGSTEN_HIP_H_ */

@@ -1,0 +1,1873 @@
+/*
+ * oracle/oracle.c -- TEST INFRASTRUCTURE.  NOT PRODUCT CODE.
+ *
+ * A scalar CPU restatement of the reference's forward path tracer (tunabrain/tungsten,
+ * src/core/integrators/path_tracer + TraceBase + the BSDF/primitive/texture/sampling code it
+ * calls), written in plain C99 directly from the reference's algorithm, each function citing
+ * the reference file:line it follows.  It consumes the same flattened scene description the
+ * HIP path uploads (include/tungsten_hip.h), so checker and product see identical inputs.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product path (tungsten_amd/, csrc/) never links, imports or calls it.
+ *
+ * Pinning: tests/golden/ holds outputs of the *reference itself* (built from /root/reference by
+ * oracle/Makefile.ref and driven by oracle/ref_harness.cpp, which injects the same
+ * counter-based random stream into the reference's PathTracer::traceSample); tests/test_oracle_*.py
+ * check this file against them.  See DESIGN.md "Oracle".
+ *
+ * Numerics: float everywhere, the reference's constants (PI = 3.1415926536f, math/Angle.hpp:8),
+ * same operation order where it matters; compiled with -ffp-contract=off.
+ */
+#include "../include/tungsten_hip.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define O_PI          3.1415926536f
+#define O_TWO_PI      (O_PI*2.0f)
+#define O_INV_PI      (1.0f/O_PI)
+#define O_INV_TWO_PI  (0.5f*O_INV_PI)
+#define O_INV_FOUR_PI (0.25f*O_INV_PI)
+
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 vs(float s) { return V(s, s, s); }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V(a.x*b.x, a.y*b.y, a.z*b.z); }
+static inline v3 vdiv(v3 a, v3 b) { return V(a.x/b.x, a.y/b.y, a.z/b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x*s, a.y*s, a.z*s); }
+static inline v3 vdivs(v3 a, float s) { return V(a.x/s, a.y/s, a.z/s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float vdot(v3 a, v3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+static inline v3 vcross(v3 a, v3 b) { return V(a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }
+static inline float vlensq(v3 a) { return a.x*a.x + a.y*a.y + a.z*a.z; }
+static inline float vlen(v3 a) { return sqrtf(vlensq(a)); }
+static inline v3 vnorm(v3 a) { float inv = 1.0f/vlen(a); return V(a.x*inv, a.y*inv, a.z*inv); }   /* Vec.hpp:168-175 */
+static inline float vmax3(v3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
+static inline float vavg(v3 a) { return (a.x + a.y + a.z)*(1.0f/3.0f); }                           /* Vec.hpp avg() */
+static inline float vsum(v3 a) { return a.x + a.y + a.z; }
+static inline int viszero(v3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }            /* Vec == scalar: all components (Vec.hpp:429-435) */
+static inline v3 vexp(v3 a) { return V(expf(a.x), expf(a.y), expf(a.z)); }
+static inline v3 ld3(const float *p) { return V(p[0], p[1], p[2]); }
+static inline float sqr(float x) { return x*x; }
+static inline float fclamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* ---------------------------------------------------------------------------------------------
+ * Random numbers.  The reference draws from one sequential PCG stream per 16x16 tile
+ * (PathTraceIntegrator.cpp:27-42, UniformPathSampler.hpp), which cannot be reproduced by a
+ * parallel renderer.  Oracle and HIP path (and oracle/ref_harness.cpp, which injects it into the
+ * reference) use the same PCG-XSH-RR 64/32 generator (UniformSampler.hpp:40-47) but keyed per
+ * (seed, pixelIndex, sampleIndex): DESIGN.md "RNG".
+ * ------------------------------------------------------------------------------------------- */
+static inline uint32_t hash32(uint32_t x)   /* MathUtil.hpp:120-128 */
+{
+    x = ~x + (x << 15);
+    x = x ^ (x >> 12);
+    x = x + (x << 2);
+    x = x ^ (x >> 4);
+    x = x * 2057;
+    x = x ^ (x >> 16);
+    return x;
+}
+
+typedef struct {
+    uint64_t state, inc;
+    const float *replay;   /* when non-NULL, next1D() returns these numbers instead (unit tests) */
+    int replay_pos, replay_n;
+    uint32_t draws;
+} Sampler;
+
+static void sampler_start(Sampler *s, uint32_t seed, uint32_t pixelIndex, uint32_t sampleIndex)
+{
+    uint32_t a = hash32(seed) ^ pixelIndex;
+    uint32_t b = hash32(a) + sampleIndex;
+    uint32_t hi = hash32(b), lo = hash32(b ^ 0x9E3779B9u);
+    s->state = ((uint64_t)hi << 32) | lo;
+    s->inc = ((uint64_t)pixelIndex << 1) | 1u;
+    s->replay = NULL; s->replay_pos = s->replay_n = 0; s->draws = 0;
+}
+
+static inline uint32_t sampler_nextI(Sampler *s)   /* UniformSampler.hpp:40-47 */
+{
+    uint64_t oldState = s->state;
+    s->state = oldState*6364136223846793005ULL + s->inc;
+    uint32_t xorShifted = (uint32_t)(((oldState >> 18u) ^ oldState) >> 27u);
+    uint32_t rot = (uint32_t)(oldState >> 59u);
+    return (xorShifted >> rot) | (xorShifted << ((uint32_t)(-(int32_t)rot) & 31));
+}
+
+static inline float normalizedUint(uint32_t i)   /* BitManip.hpp:47-50 */
+{
+    union { uint32_t u; float f; } c;
+    c.u = (i >> 9u) | 0x3F800000u;
+    return c.f - 1.0f;
+}
+
+static inline float next1D(Sampler *s)
+{
+    s->draws++;
+    if (s->replay) {
+        float v = s->replay_pos < s->replay_n ? s->replay[s->replay_pos] : 0.5f;
+        s->replay_pos++;
+        return v;
+    }
+    return normalizedUint(sampler_nextI(s));
+}
+static inline int nextBoolean(Sampler *s, float pTrue) { return next1D(s) < pTrue; }   /* UniformPathSampler.hpp:39-42 */
+
+/* ---------------------------------------------------------------------------------------------
+ * Sample warps (sampling/SampleWarp.hpp)
+ * ------------------------------------------------------------------------------------------- */
+static v3 cosineHemisphere(float xi0, float xi1)   /* SampleWarp.hpp:42-52 */
+{
+    float phi = xi0*O_TWO_PI;
+    float r = sqrtf(xi1);
+    return V(cosf(phi)*r, sinf(phi)*r, sqrtf(fmaxf(1.0f - xi1, 0.0f)));
+}
+static inline float cosineHemispherePdf(v3 p) { return fabsf(p.z)*O_INV_PI; }   /* :54-57 */
+static v3 uniformSphere(float xi0, float xi1)      /* SampleWarp.hpp:96-107 */
+{
+    float phi = xi0*O_TWO_PI;
+    float z = xi1*2.0f - 1.0f;
+    float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
+    return V(cosf(phi)*r, sinf(phi)*r, z);
+}
+static inline float powerHeuristic(float pdf0, float pdf1) { return (pdf0*pdf0)/(pdf0*pdf0 + pdf1*pdf1); }   /* :189-192 */
+
+/* TangentFrame(n) -- Duff et al. ONB (math/TangentFrame.hpp:22-31) */
+typedef struct { v3 normal, tangent, bitangent; } Frame;
+static Frame frame_from_normal(v3 n)
+{
+    Frame f;
+    f.normal = n;
+    float sign = copysignf(1.0f, n.z);
+    const float a = -1.0f/(sign + n.z);
+    const float b = n.x*n.y*a;
+    f.tangent = V(1.0f + sign*n.x*n.x*a, sign*b, -sign*n.x);
+    f.bitangent = V(b, sign + n.y*n.y*a, -n.y);
+    return f;
+}
+static inline v3 toLocal(const Frame *f, v3 p) { return V(vdot(f->tangent, p), vdot(f->bitangent, p), vdot(f->normal, p)); }
+static inline v3 toGlobal(const Frame *f, v3 p)
+{
+    return vadd(vadd(vscale(f->tangent, p.x), vscale(f->bitangent, p.y)), vscale(f->normal, p.z));
+}
+static inline v3 mat3_mul(const float *m, v3 p)      /* row-major 3x3 times vector (Mat4f::transformVector) */
+{
+    return V(m[0]*p.x + m[1]*p.y + m[2]*p.z, m[3]*p.x + m[4]*p.y + m[5]*p.z, m[6]*p.x + m[7]*p.y + m[8]*p.z);
+}
+static inline v3 mat3_tmul(const float *m, v3 p)     /* transpose(m) times vector (= _invRot*p) */
+{
+    return V(m[0]*p.x + m[3]*p.y + m[6]*p.z, m[1]*p.x + m[4]*p.y + m[7]*p.z, m[2]*p.x + m[5]*p.y + m[8]*p.z);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Textures (textures/ConstantTexture, CheckerTexture.cpp:64-69, BitmapTexture.cpp:298-352)
+ * ------------------------------------------------------------------------------------------- */
+static v3 bitmap_texel(const TgHipSceneDesc *s, const TgHipTexture *t, int x, int y)
+{
+    const float *tex = s->texels + t->texel_offset;
+    if (t->flags & TGHIP_TEXF_RGB) {
+        const float *p = tex + ((size_t)x + (size_t)y*t->w)*3;
+        return V(p[0], p[1], p[2]);
+    } else {
+        return vs(tex[(size_t)x + (size_t)y*t->w]);
+    }
+}
+
+static v3 texture_eval(const TgHipSceneDesc *s, int texIdx, float u0, float v0)
+{
+    const TgHipTexture *t = &s->textures[texIdx];
+    if (t->type == TGHIP_TEX_CONSTANT)
+        return ld3(t->value);
+    if (t->type == TGHIP_TEX_CHECKER) {
+        int ui = (int)(u0*(float)t->res_u), vi = (int)(v0*(float)t->res_v);
+        int on = (ui ^ vi) & 1;
+        return on ? ld3(t->on_color) : ld3(t->off_color);
+    }
+    /* bitmap */
+    int w = t->w, h = t->h;
+    float u = u0*w;
+    float v = (1.0f - v0)*h;
+    int linear = (t->flags & TGHIP_TEXF_LINEAR) && (t->flags & TGHIP_TEXF_VALID);
+    if (linear) { u -= 0.5f; v -= 0.5f; }
+    int iu0 = u < 0.0f ? -(int)(-u) - 1 : (int)u;
+    int iv0 = v < 0.0f ? -(int)(-v) - 1 : (int)v;
+    int iu1 = iu0 + 1, iv1 = iv0 + 1;
+    u -= iu0; v -= iv0;
+    if (!(t->flags & TGHIP_TEXF_CLAMP)) {
+        iu0 = ((iu0 % w) + w) % w; iu1 = ((iu1 % w) + w) % w;
+        iv0 = ((iv0 % h) + h) % h; iv1 = ((iv1 % h) + h) % h;
+    } else {
+        iu0 = iu0 < 0 ? 0 : (iu0 > w - 1 ? w - 1 : iu0); iu1 = iu1 < 0 ? 0 : (iu1 > w - 1 ? w - 1 : iu1);
+        iv0 = iv0 < 0 ? 0 : (iv0 > h - 1 ? h - 1 : iv0); iv1 = iv1 < 0 ? 0 : (iv1 > h - 1 ? h - 1 : iv1);
+    }
+    if (!linear)
+        return bitmap_texel(s, t, iu0, iv0);      /* sic: unfiltered lookups ignore _scale (BitmapTexture.cpp:327-332) */
+    v3 x00 = bitmap_texel(s, t, iu0, iv0), x01 = bitmap_texel(s, t, iu1, iv0);
+    v3 x10 = bitmap_texel(s, t, iu0, iv1), x11 = bitmap_texel(s, t, iu1, iv1);
+    v3 top = vadd(vscale(x00, 1.0f - u), vscale(x01, u));
+    v3 bot = vadd(vscale(x10, 1.0f - u), vscale(x11, u));
+    v3 r = vadd(vscale(top, 1.0f - v), vscale(bot, v));
+    return vscale(r, t->scale);
+}
+
+/* Distribution2D::warp / pdf (sampling/Distribution2D.hpp:68-83) over the flattened tables */
+typedef struct { const float *mpdf, *mcdf, *pdf, *cdf; int w, h; } Dist2D;
+static Dist2D dist_of(const TgHipSceneDesc *s, const TgHipTexture *t)
+{
+    Dist2D d;
+    d.w = t->w; d.h = t->h;
+    d.mpdf = s->dist + t->dist_offset;
+    d.mcdf = d.mpdf + t->h;
+    d.pdf = d.mcdf + t->h + 1;
+    d.cdf = d.pdf + (size_t)t->w*t->h;
+    return d;
+}
+static int upper_bound_idx(const float *a, int n, float x)   /* std::upper_bound: first element > x */
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+static void dist_warp(const Dist2D *d, float *u, float *v, int *row, int *column)
+{
+    *row = upper_bound_idx(d->mcdf, d->h + 1, *v) - 1;
+    *v = fclamp((*v - d->mcdf[*row])/d->mpdf[*row], 0.0f, 1.0f);
+    const float *rowStart = d->cdf + (size_t)(*row)*(d->w + 1);
+    *column = upper_bound_idx(rowStart, d->w + 1, *u) - 1;
+    int idxC = *row*(d->w + 1) + *column;
+    int idxP = *row*d->w + *column;
+    *u = fclamp((*u - d->cdf[idxC])/d->pdf[idxP], 0.0f, 1.0f);
+}
+static float dist_pdf(const Dist2D *d, int row, int column)
+{
+    row = row < 0 ? 0 : (row > d->h - 1 ? d->h - 1 : row);
+    column = column < 0 ? 0 : (column > d->w - 1 ? d->w - 1 : column);
+    return d->pdf[(size_t)row*d->w + column]*d->mpdf[row];
+}
+/* BitmapTexture::sample / pdf (BitmapTexture.cpp:433-455) */
+static void bitmap_sample(const TgHipSceneDesc *s, const TgHipTexture *t, float xi0, float xi1, float *u, float *v)
+{
+    Dist2D d = dist_of(s, t);
+    int row, column;
+    float nu = xi0, nv = xi1;
+    dist_warp(&d, &nu, &nv, &row, &column);
+    *u = (nu + column)/t->w;
+    *v = 1.0f - (nv + row)/t->h;
+}
+static float bitmap_pdf(const TgHipSceneDesc *s, const TgHipTexture *t, float u, float v)
+{
+    Dist2D d = dist_of(s, t);
+    return dist_pdf(&d, (int)((1.0f - v)*t->h), (int)(u*t->w))*t->w*t->h;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Fresnel + microfacet helpers (bsdfs/Fresnel.hpp:75-138, bsdfs/Microfacet.hpp:27-130)
+ * ------------------------------------------------------------------------------------------- */
+static float dielectricReflectanceT(float eta, float cosThetaI, float *cosThetaT)
+{
+    if (cosThetaI < 0.0f) {
+        eta = 1.0f/eta;
+        cosThetaI = -cosThetaI;
+    }
+    float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+    if (sinThetaTSq > 1.0f) {
+        *cosThetaT = 0.0f;
+        return 1.0f;
+    }
+    *cosThetaT = sqrtf(fmaxf(1.0f - sinThetaTSq, 0.0f));
+    float Rs = (eta*cosThetaI - *cosThetaT)/(eta*cosThetaI + *cosThetaT);
+    float Rp = (eta**cosThetaT - cosThetaI)/(eta**cosThetaT + cosThetaI);
+    return (Rs*Rs + Rp*Rp)*0.5f;
+}
+static float dielectricReflectance(float eta, float cosThetaI) { float t; return dielectricReflectanceT(eta, cosThetaI, &t); }
+
+static float conductorReflectance1(float eta, float k, float cosThetaI)
+{
+    float cosThetaISq = cosThetaI*cosThetaI;
+    float sinThetaISq = fmaxf(1.0f - cosThetaISq, 0.0f);
+    float sinThetaIQu = sinThetaISq*sinThetaISq;
+    float innerTerm = eta*eta - k*k - sinThetaISq;
+    float aSqPlusBSq = sqrtf(fmaxf(innerTerm*innerTerm + 4.0f*eta*eta*k*k, 0.0f));
+    float a = sqrtf(fmaxf((aSqPlusBSq + innerTerm)*0.5f, 0.0f));
+    float Rs = ((aSqPlusBSq + cosThetaISq) - (2.0f*a*cosThetaI))/
+               ((aSqPlusBSq + cosThetaISq) + (2.0f*a*cosThetaI));
+    float Rp = ((cosThetaISq*aSqPlusBSq + sinThetaIQu) - (2.0f*a*cosThetaI*sinThetaISq))/
+               ((cosThetaISq*aSqPlusBSq + sinThetaIQu) + (2.0f*a*cosThetaI*sinThetaISq));
+    return 0.5f*(Rs + Rs*Rp);
+}
+static v3 conductorReflectance(const float *eta, const float *k, float cosThetaI)
+{
+    return V(conductorReflectance1(eta[0], k[0], cosThetaI), conductorReflectance1(eta[1], k[1], cosThetaI),
+             conductorReflectance1(eta[2], k[2], cosThetaI));
+}
+
+static float mf_roughnessToAlpha(int dist, float roughness)
+{
+    const float MinAlpha = 1e-3f;
+    roughness = fmaxf(roughness, MinAlpha);
+    if (dist == TGHIP_DIST_PHONG)
+        return 2.0f/(roughness*roughness) - 2.0f;
+    return roughness;
+}
+static float mf_D(int dist, float alpha, v3 m)
+{
+    if (m.z <= 0.0f)
+        return 0.0f;
+    switch (dist) {
+    case TGHIP_DIST_BECKMANN: {
+        float alphaSq = alpha*alpha;
+        float cosThetaSq = m.z*m.z;
+        float tanThetaSq = fmaxf(1.0f - cosThetaSq, 0.0f)/cosThetaSq;
+        float cosThetaQu = cosThetaSq*cosThetaSq;
+        return O_INV_PI*expf(-tanThetaSq/alphaSq)/(alphaSq*cosThetaQu);
+    }
+    case TGHIP_DIST_PHONG:
+        return (alpha + 2.0f)*O_INV_TWO_PI*(float)pow((double)m.z, (double)alpha);
+    case TGHIP_DIST_GGX: {
+        float alphaSq = alpha*alpha;
+        float cosThetaSq = m.z*m.z;
+        float tanThetaSq = fmaxf(1.0f - cosThetaSq, 0.0f)/cosThetaSq;
+        float cosThetaQu = cosThetaSq*cosThetaSq;
+        return alphaSq*O_INV_PI/(cosThetaQu*sqr(alphaSq + tanThetaSq));
+    }
+    }
+    return 0.0f;
+}
+static float mf_G1(int dist, float alpha, v3 v, v3 m)
+{
+    if (vdot(v, m)*v.z <= 0.0f)
+        return 0.0f;
+    switch (dist) {
+    case TGHIP_DIST_BECKMANN: {
+        float cosThetaSq = v.z*v.z;
+        float tanTheta = fabsf(sqrtf(fmaxf(1.0f - cosThetaSq, 0.0f))/v.z);
+        float a = 1.0f/(alpha*tanTheta);
+        if (a < 1.6f)
+            return (3.535f*a + 2.181f*a*a)/(1.0f + 2.276f*a + 2.577f*a*a);
+        return 1.0f;
+    }
+    case TGHIP_DIST_PHONG: {
+        float cosThetaSq = v.z*v.z;
+        float tanTheta = fabsf(sqrtf(fmaxf(1.0f - cosThetaSq, 0.0f))/v.z);
+        float a = sqrtf(0.5f*alpha + 1.0f)/tanTheta;
+        if (a < 1.6f)
+            return (3.535f*a + 2.181f*a*a)/(1.0f + 2.276f*a + 2.577f*a*a);
+        return 1.0f;
+    }
+    case TGHIP_DIST_GGX: {
+        float alphaSq = alpha*alpha;
+        float cosThetaSq = v.z*v.z;
+        float tanThetaSq = fmaxf(1.0f - cosThetaSq, 0.0f)/cosThetaSq;
+        return 2.0f/(1.0f + sqrtf(1.0f + alphaSq*tanThetaSq));
+    }
+    }
+    return 0.0f;
+}
+static float mf_G(int dist, float alpha, v3 i, v3 o, v3 m) { return mf_G1(dist, alpha, i, m)*mf_G1(dist, alpha, o, m); }
+static float mf_pdf(int dist, float alpha, v3 m) { return mf_D(dist, alpha, m)*m.z; }
+static v3 mf_sample(int dist, float alpha, float xi0, float xi1)
+{
+    float phi = xi1*O_TWO_PI;
+    float cosTheta = 0.0f;
+    switch (dist) {
+    case TGHIP_DIST_BECKMANN: {
+        float tanThetaSq = -alpha*alpha*logf(1.0f - xi0);
+        cosTheta = 1.0f/sqrtf(1.0f + tanThetaSq);
+        break;
+    }
+    case TGHIP_DIST_PHONG:
+        cosTheta = (float)pow((double)xi0, 1.0/((double)alpha + 2.0));
+        break;
+    case TGHIP_DIST_GGX: {
+        float tanThetaSq = alpha*alpha*xi0/(1.0f - xi0);
+        cosTheta = 1.0f/sqrtf(1.0f + tanThetaSq);
+        break;
+    }
+    }
+    float r = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
+    return V(cosf(phi)*r, sinf(phi)*r, cosTheta);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * BSDFs.  One event struct (samplerecords/SurfaceScatterEvent.hpp:14-44) and three entry
+ * points per BSDF, dispatched on the tagged union; nested BSDFs recurse.
+ * ------------------------------------------------------------------------------------------- */
+#define LOBE_ALL            (TGHIP_LOBE_GLOSSY_R | TGHIP_LOBE_GLOSSY_T | TGHIP_LOBE_DIFFUSE_R | TGHIP_LOBE_DIFFUSE_T | \
+                             TGHIP_LOBE_SPECULAR_R | TGHIP_LOBE_SPECULAR_T | TGHIP_LOBE_ANISOTROPIC)   /* BsdfLobes.hpp:28-31 */
+#define LOBE_SPECULAR       (TGHIP_LOBE_SPECULAR_R | TGHIP_LOBE_SPECULAR_T)
+#define LOBE_TRANSMISSIVE   (TGHIP_LOBE_GLOSSY_T | TGHIP_LOBE_DIFFUSE_T | TGHIP_LOBE_SPECULAR_T)
+#define LOBE_ALL_BUT_SPECULAR (~(uint32_t)(LOBE_SPECULAR | TGHIP_LOBE_FORWARD))                     /* BsdfLobes.hpp:32 */
+
+typedef struct {
+    v3 wi, wo, weight;
+    float pdf;
+    uint32_t requested, sampled;
+    float u, v;              /* info->uv for texture lookups */
+    Sampler *sampler;
+} Event;
+
+static const float DiracAcceptanceThreshold = 1e-3f;   /* Bsdf.hpp:27 */
+static int checkReflectionConstraint(v3 wi, v3 wo)     /* Bsdf.hpp:45-48 */
+{
+    return fabsf(wi.z*wo.z - wi.x*wo.x - wi.y*wo.y - 1.0f) < DiracAcceptanceThreshold;
+}
+static int checkRefractionConstraint(v3 wi, v3 wo, float eta, float cosThetaT)   /* Bsdf.hpp:50-54 */
+{
+    float dotP = -wi.x*wo.x*eta - wi.y*wo.y*eta - copysignf(cosThetaT, wi.z)*wo.z;
+    return fabsf(dotP - 1.0f) < DiracAcceptanceThreshold;
+}
+static inline float sgnE(float v) { return v < 0.0f ? -1.0f : 1.0f; }   /* RoughDielectricBsdf.cpp:13-16 */
+
+static v3 bsdf_albedo(const TgHipSceneDesc *s, const TgHipBsdf *b, const Event *e) { return texture_eval(s, b->albedo, e->u, e->v); }
+static float bsdf_roughness(const TgHipSceneDesc *s, const TgHipBsdf *b, const Event *e) { return texture_eval(s, b->roughness, e->u, e->v).x; }
+
+static v3 bsdf_eval(const TgHipSceneDesc *s, int bi, const Event *e);
+static int bsdf_sample(const TgHipSceneDesc *s, int bi, Event *e);
+static float bsdf_pdf(const TgHipSceneDesc *s, int bi, const Event *e);
+
+/* RoughDielectricBsdf::sampleBase/evalBase/pdfBase (RoughDielectricBsdf.cpp:55-131, 133-166, 200-236) */
+static int rd_sampleBase(Event *e, int sampleR, int sampleT, float roughness, float ior, int dist)
+{
+    float wiDotN = e->wi.z;
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
+    float sampleRoughness = (1.2f - 0.2f*sqrtf(fabsf(wiDotN)))*roughness;
+    float alpha = mf_roughnessToAlpha(dist, roughness);
+    float sampleAlpha = mf_roughnessToAlpha(dist, sampleRoughness);
+
+    float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+    v3 m = mf_sample(dist, sampleAlpha, xi0, xi1);
+    float pm = mf_pdf(dist, sampleAlpha, m);
+    if (pm < 1e-10f)
+        return 0;
+
+    float wiDotM = vdot(e->wi, m);
+    float cosThetaT = 0.0f;
+    float F = dielectricReflectanceT(1.0f/ior, wiDotM, &cosThetaT);
+    float etaM = wiDotM < 0.0f ? ior : 1.0f/ior;
+
+    int reflect;
+    if (sampleR && sampleT) {
+        reflect = nextBoolean(e->sampler, F);
+    } else if (sampleT) {
+        if (F == 1.0f)
+            return 0;
+        reflect = 0;
+    } else if (sampleR) {
+        reflect = 1;
+    } else {
+        return 0;
+    }
+
+    if (reflect)
+        e->wo = vsub(vscale(m, 2.0f*wiDotM), e->wi);
+    else
+        e->wo = vsub(vscale(m, etaM*wiDotM - sgnE(wiDotM)*cosThetaT), vscale(e->wi, etaM));
+
+    float woDotN = e->wo.z;
+    int reflected = wiDotN*woDotN > 0.0f;
+    if (reflected != reflect)
+        return 0;
+
+    float woDotM = vdot(e->wo, m);
+    float G = mf_G(dist, alpha, e->wi, e->wo, m);
+    float D = mf_D(dist, alpha, m);
+    e->weight = vs(fabsf(wiDotM)*G*D/(fabsf(wiDotN)*pm));
+
+    if (reflect) {
+        e->pdf = pm*0.25f/fabsf(wiDotM);
+        e->sampled = TGHIP_LOBE_GLOSSY_R;
+    } else {
+        e->pdf = pm*fabsf(woDotM)/sqr(eta*wiDotM + woDotM);
+        e->sampled = TGHIP_LOBE_GLOSSY_T;
+    }
+    if (sampleR && sampleT) {
+        if (reflect) e->pdf *= F;
+        else e->pdf *= 1.0f - F;
+    } else {
+        if (reflect) e->weight = vscale(e->weight, F);
+        else e->weight = vscale(e->weight, 1.0f - F);
+    }
+    return 1;
+}
+static v3 rd_evalBase(const Event *e, int sampleR, int sampleT, float roughness, float ior, int dist)
+{
+    float wiDotN = e->wi.z, woDotN = e->wo.z;
+    int reflect = wiDotN*woDotN >= 0.0f;
+    if ((reflect && !sampleR) || (!reflect && !sampleT))
+        return vs(0.0f);
+    float alpha = mf_roughnessToAlpha(dist, roughness);
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
+    v3 m;
+    if (reflect)
+        m = vscale(vnorm(vadd(e->wi, e->wo)), sgnE(wiDotN));
+    else
+        m = vneg(vnorm(vadd(vscale(e->wi, eta), e->wo)));
+    float wiDotM = vdot(e->wi, m), woDotM = vdot(e->wo, m);
+    float F = dielectricReflectance(1.0f/ior, wiDotM);
+    float G = mf_G(dist, alpha, e->wi, e->wo, m);
+    float D = mf_D(dist, alpha, m);
+    if (reflect) {
+        float fr = (F*G*D*0.25f)/fabsf(wiDotN);
+        return vs(fr);
+    } else {
+        float fs = fabsf(wiDotM*woDotM)*(1.0f - F)*G*D/(sqr(eta*wiDotM + woDotM)*fabsf(wiDotN));
+        return vs(fs);
+    }
+}
+static float rd_pdfBase(const Event *e, int sampleR, int sampleT, float roughness, float ior, int dist)
+{
+    float wiDotN = e->wi.z, woDotN = e->wo.z;
+    int reflect = wiDotN*woDotN >= 0.0f;
+    if ((reflect && !sampleR) || (!reflect && !sampleT))
+        return 0.0f;
+    float sampleRoughness = (1.2f - 0.2f*sqrtf(fabsf(wiDotN)))*roughness;
+    float sampleAlpha = mf_roughnessToAlpha(dist, sampleRoughness);
+    float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
+    v3 m;
+    if (reflect)
+        m = vscale(vnorm(vadd(e->wi, e->wo)), sgnE(wiDotN));
+    else
+        m = vneg(vnorm(vadd(vscale(e->wi, eta), e->wo)));
+    float wiDotM = vdot(e->wi, m), woDotM = vdot(e->wo, m);
+    float F = dielectricReflectance(1.0f/ior, wiDotM);
+    float pm = mf_pdf(dist, sampleAlpha, m);
+    float pdf;
+    if (reflect)
+        pdf = pm*0.25f/fabsf(wiDotM);
+    else
+        pdf = pm*fabsf(woDotM)/sqr(eta*wiDotM + woDotM);
+    if (sampleR && sampleT) {
+        if (reflect) pdf *= F;
+        else pdf *= 1.0f - F;
+    }
+    return pdf;
+}
+
+/* diffuse substrate term shared by Plastic / RoughPlastic */
+static v3 plastic_substrate(const TgHipBsdf *b, v3 diffuseAlbedo)
+{
+    v3 denom = vsub(vs(1.0f), vscale(diffuseAlbedo, b->diffuse_fresnel));
+    return vdiv(diffuseAlbedo, denom);
+}
+
+static v3 bsdf_eval(const TgHipSceneDesc *s, int bi, const Event *e)
+{
+    const TgHipBsdf *b = &s->bsdfs[bi];
+    switch (b->type) {
+    case TGHIP_BSDF_LAMBERT:   /* LambertBsdf.cpp:40-47 */
+    case TGHIP_BSDF_ERROR:
+        if (!(e->requested & TGHIP_LOBE_DIFFUSE_R)) return vs(0.0f);
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vs(0.0f);
+        return vscale(vscale(bsdf_albedo(s, b, e), O_INV_PI), e->wo.z);
+    case TGHIP_BSDF_NULL:      /* NullBsdf.cpp:24-27 */
+        return vs(0.0f);
+    case TGHIP_BSDF_FORWARD:   /* ForwardBsdf.cpp:25-28 */
+        return (e->requested == TGHIP_LOBE_FORWARD && -e->wi.x == e->wo.x && -e->wi.y == e->wo.y && -e->wi.z == e->wo.z)
+            ? vs(1.0f) : vs(0.0f);
+    case TGHIP_BSDF_MIRROR:    /* MirrorBsdf.cpp:39-46 */
+        if ((e->requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e->wi, e->wo))
+            return bsdf_albedo(s, b, e);
+        return vs(0.0f);
+    case TGHIP_BSDF_CONDUCTOR: /* ConductorBsdf.cpp:68-75 */
+        if ((e->requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e->wi, e->wo))
+            return vmul(bsdf_albedo(s, b, e), conductorReflectance(b->eta, b->k, e->wi.z));
+        return vs(0.0f);
+    case TGHIP_BSDF_ROUGH_CONDUCTOR: { /* RoughConductorBsdf.cpp:93-109 */
+        if (!(e->requested & TGHIP_LOBE_GLOSSY_R)) return vs(0.0f);
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vs(0.0f);
+        float roughness = bsdf_roughness(s, b, e);
+        float alpha = mf_roughnessToAlpha(b->distribution, roughness);
+        v3 hr = vnorm(vadd(e->wi, e->wo));
+        float cosThetaM = vdot(e->wi, hr);
+        v3 F = conductorReflectance(b->eta, b->k, cosThetaM);
+        float G = mf_G(b->distribution, alpha, e->wi, e->wo, hr);
+        float D = mf_D(b->distribution, alpha, hr);
+        float fr = (G*D*0.25f)/e->wi.z;
+        return vmul(bsdf_albedo(s, b, e), vscale(F, fr));
+    }
+    case TGHIP_BSDF_SMOOTH_COAT: { /* SmoothCoatBsdf.cpp:146-177 */
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vs(0.0f);
+        int evalR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int evalT = (e->requested & s->bsdfs[b->sub0].lobes) != 0;
+        v3 wi = e->wi, wo = e->wo;
+        float eta = 1.0f/b->ior;
+        float cosThetaTi, cosThetaTo;
+        float Fi = dielectricReflectanceT(eta, wi.z, &cosThetaTi);
+        float Fo = dielectricReflectanceT(eta, wo.z, &cosThetaTo);
+        if (evalR && checkReflectionConstraint(wi, wo)) {
+            return vs(Fi);
+        } else if (evalT) {
+            Event q = *e;
+            q.wi = V(wi.x*eta, wi.y*eta, copysignf(cosThetaTi, wi.z));
+            q.wo = V(wo.x*eta, wo.y*eta, copysignf(cosThetaTo, wo.z));
+            float laplacian = eta*eta*wo.z/cosThetaTo;
+            v3 substrateF = bsdf_eval(s, b->sub0, &q);
+            v3 ssa = ld3(b->scaled_sigma_a);
+            if (vmax3(ssa) > 0.0f)
+                substrateF = vmul(substrateF, vexp(vscale(ssa, -1.0f/cosThetaTo - 1.0f/cosThetaTi)));
+            return vscale(substrateF, laplacian*(1.0f - Fi)*(1.0f - Fo));
+        }
+        return vs(0.0f);
+    }
+    case TGHIP_BSDF_DIELECTRIC: { /* DielectricBsdf.cpp:88-108 */
+        int evalR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int evalT = (e->requested & TGHIP_LOBE_SPECULAR_T) && b->enable_refraction;
+        float eta = e->wi.z < 0.0f ? b->ior : 1.0f/b->ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectanceT(eta, fabsf(e->wi.z), &cosThetaT);
+        if (e->wi.z*e->wo.z >= 0.0f) {
+            if (evalR && checkReflectionConstraint(e->wi, e->wo))
+                return vscale(bsdf_albedo(s, b, e), F);
+            return vs(0.0f);
+        } else {
+            if (evalT && checkRefractionConstraint(e->wi, e->wo, eta, cosThetaT))
+                return vscale(bsdf_albedo(s, b, e), 1.0f - F);
+            return vs(0.0f);
+        }
+    }
+    case TGHIP_BSDF_ROUGH_DIELECTRIC: { /* RoughDielectricBsdf.cpp:247-254 */
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_GLOSSY_T) && b->enable_refraction;
+        float roughness = bsdf_roughness(s, b, e);
+        return vmul(rd_evalBase(e, sampleR, sampleT, roughness, b->ior, b->distribution), bsdf_albedo(s, b, e));
+    }
+    case TGHIP_BSDF_PLASTIC: { /* PlasticBsdf.cpp:125-151 */
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vs(0.0f);
+        int evalR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int evalT = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        float eta = 1.0f/b->ior;
+        float Fi = dielectricReflectance(eta, e->wi.z);
+        float Fo = dielectricReflectance(eta, e->wo.z);
+        if (evalR && checkReflectionConstraint(e->wi, e->wo)) {
+            return vs(Fi);
+        } else if (evalT) {
+            v3 diffuseAlbedo = bsdf_albedo(s, b, e);
+            v3 brdf = vscale(plastic_substrate(b, diffuseAlbedo), (1.0f - Fi)*(1.0f - Fo)*eta*eta*e->wo.z*O_INV_PI);
+            v3 ssa = ld3(b->scaled_sigma_a);
+            if (vmax3(ssa) > 0.0f)
+                brdf = vmul(brdf, vexp(vscale(ssa, -1.0f/e->wo.z - 1.0f/e->wi.z)));
+            return brdf;
+        }
+        return vs(0.0f);
+    }
+    case TGHIP_BSDF_ROUGH_PLASTIC: { /* RoughPlasticBsdf.cpp:114-141 */
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        if (!sampleR && !sampleT) return vs(0.0f);
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vs(0.0f);
+        v3 glossyR = vs(0.0f);
+        if (sampleR)
+            glossyR = rd_evalBase(e, 1, 0, bsdf_roughness(s, b, e), b->ior, b->distribution);
+        v3 diffuseR = vs(0.0f);
+        if (sampleT) {
+            float eta = 1.0f/b->ior;
+            float Fi = dielectricReflectance(eta, e->wi.z);
+            float Fo = dielectricReflectance(eta, e->wo.z);
+            v3 diffuseAlbedo = bsdf_albedo(s, b, e);
+            diffuseR = vscale(plastic_substrate(b, diffuseAlbedo), (1.0f - Fi)*(1.0f - Fo)*eta*eta*e->wo.z*O_INV_PI);
+            v3 ssa = ld3(b->scaled_sigma_a);
+            if (vmax3(ssa) > 0.0f)
+                diffuseR = vmul(diffuseR, vexp(vscale(ssa, -1.0f/e->wo.z - 1.0f/e->wi.z)));
+        }
+        return vadd(glossyR, diffuseR);
+    }
+    case TGHIP_BSDF_MIXED: { /* MixedBsdf.cpp:101-105 */
+        float ratio = texture_eval(s, b->tex1, e->u, e->v).x;
+        v3 f0 = bsdf_eval(s, b->sub0, e), f1 = bsdf_eval(s, b->sub1, e);
+        return vmul(bsdf_albedo(s, b, e), vadd(vscale(f0, ratio), vscale(f1, 1.0f - ratio)));
+    }
+    case TGHIP_BSDF_TRANSPARENCY: /* TransparencyBsdf.cpp:48-54 */
+        if (e->requested == TGHIP_LOBE_FORWARD)
+            return (-e->wi.x == e->wo.x && -e->wi.y == e->wo.y && -e->wi.z == e->wo.z)
+                ? vs(1.0f - texture_eval(s, b->tex1, e->u, e->v).x) : vs(0.0f);
+        return bsdf_eval(s, b->sub0, e);
+    }
+    return vs(0.0f);
+}
+
+static int mixed_adjustedRatio(const TgHipSceneDesc *s, const TgHipBsdf *b, const Event *e, float *ratio)   /* MixedBsdf.cpp:17-31 */
+{
+    int sample0 = (e->requested & s->bsdfs[b->sub0].lobes) != 0;
+    int sample1 = (e->requested & s->bsdfs[b->sub1].lobes) != 0;
+    if (sample0 && sample1) *ratio = texture_eval(s, b->tex1, e->u, e->v).x;
+    else if (sample0) *ratio = 1.0f;
+    else if (sample1) *ratio = 0.0f;
+    else return 0;
+    return 1;
+}
+
+static int bsdf_sample(const TgHipSceneDesc *s, int bi, Event *e)
+{
+    const TgHipBsdf *b = &s->bsdfs[bi];
+    switch (b->type) {
+    case TGHIP_BSDF_LAMBERT:   /* LambertBsdf.cpp:27-38 */
+    case TGHIP_BSDF_ERROR: {
+        if (!(e->requested & TGHIP_LOBE_DIFFUSE_R)) return 0;
+        if (e->wi.z <= 0.0f) return 0;
+        float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+        e->wo = cosineHemisphere(xi0, xi1);
+        e->pdf = cosineHemispherePdf(e->wo);
+        e->weight = bsdf_albedo(s, b, e);
+        e->sampled = TGHIP_LOBE_DIFFUSE_R;
+        return 1;
+    }
+    case TGHIP_BSDF_NULL:
+    case TGHIP_BSDF_FORWARD:
+        return 0;
+    case TGHIP_BSDF_MIRROR:    /* MirrorBsdf.cpp:28-37 */
+        if (!(e->requested & TGHIP_LOBE_SPECULAR_R)) return 0;
+        e->wo = V(-e->wi.x, -e->wi.y, e->wi.z);
+        e->pdf = 1.0f;
+        e->sampled = TGHIP_LOBE_SPECULAR_R;
+        e->weight = bsdf_albedo(s, b, e);
+        return 1;
+    case TGHIP_BSDF_CONDUCTOR: /* ConductorBsdf.cpp:56-66 */
+        if (!(e->requested & TGHIP_LOBE_SPECULAR_R)) return 0;
+        e->wo = V(-e->wi.x, -e->wi.y, e->wi.z);
+        e->pdf = 1.0f;
+        e->weight = vmul(bsdf_albedo(s, b, e), conductorReflectance(b->eta, b->k, e->wi.z));
+        e->sampled = TGHIP_LOBE_SPECULAR_R;
+        return 1;
+    case TGHIP_BSDF_ROUGH_CONDUCTOR: { /* RoughConductorBsdf.cpp:60-91 */
+        if (!(e->requested & TGHIP_LOBE_GLOSSY_R)) return 0;
+        if (e->wi.z <= 0.0f) return 0;
+        float roughness = bsdf_roughness(s, b, e);
+        float sampleRoughness = roughness;
+        float alpha = mf_roughnessToAlpha(b->distribution, roughness);
+        float sampleAlpha = mf_roughnessToAlpha(b->distribution, sampleRoughness);
+        float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+        v3 m = mf_sample(b->distribution, sampleAlpha, xi0, xi1);
+        float wiDotM = vdot(e->wi, m);
+        e->wo = vsub(vscale(m, 2.0f*wiDotM), e->wi);
+        if (wiDotM <= 0.0f || e->wo.z <= 0.0f)
+            return 0;
+        float G = mf_G(b->distribution, alpha, e->wi, e->wo, m);
+        float D = mf_D(b->distribution, alpha, m);
+        float mPdf = mf_pdf(b->distribution, sampleAlpha, m);
+        float pdf = mPdf*0.25f/wiDotM;
+        float weight = wiDotM*G*D/(e->wi.z*mPdf);
+        v3 F = conductorReflectance(b->eta, b->k, wiDotM);
+        e->pdf = pdf;
+        e->weight = vmul(bsdf_albedo(s, b, e), vscale(F, weight));
+        e->sampled = TGHIP_LOBE_GLOSSY_R;
+        return 1;
+    }
+    case TGHIP_BSDF_SMOOTH_COAT: { /* SmoothCoatBsdf.cpp:41-100 */
+        if (e->wi.z <= 0.0f) return 0;
+        int sampleR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int sampleT = (e->requested & s->bsdfs[b->sub0].lobes) != 0;
+        if (!sampleR && !sampleT) return 0;
+        v3 wi = e->wi;
+        float eta = 1.0f/b->ior;
+        float cosThetaTi;
+        float Fi = dielectricReflectanceT(eta, wi.z, &cosThetaTi);
+        float substrateWeight = b->avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability;
+        if (sampleR && sampleT) specularProbability = specularWeight/(specularWeight + substrateWeight);
+        else if (sampleR) specularProbability = 1.0f;
+        else specularProbability = 0.0f;
+
+        if (sampleR && nextBoolean(e->sampler, specularProbability)) {
+            e->wo = V(-wi.x, -wi.y, wi.z);
+            e->pdf = specularProbability;
+            e->weight = vs(Fi/specularProbability);
+            e->sampled = TGHIP_LOBE_SPECULAR_R;
+        } else {
+            v3 originalWi = wi;
+            e->wi = V(wi.x*eta, wi.y*eta, cosThetaTi);
+            int success = bsdf_sample(s, b->sub0, e);
+            e->wi = originalWi;
+            if (!success) return 0;
+            float cosThetaTo;
+            float Fo = dielectricReflectanceT(b->ior, e->wo.z, &cosThetaTo);
+            if (Fo == 1.0f) return 0;
+            float cosThetaSubstrate = e->wo.z;
+            e->wo = V(e->wo.x*b->ior, e->wo.y*b->ior, cosThetaTo);
+            e->weight = vscale(e->weight, (1.0f - Fi)*(1.0f - Fo));
+            v3 ssa = ld3(b->scaled_sigma_a);
+            if (vmax3(ssa) > 0.0f)
+                e->weight = vmul(e->weight, vexp(vscale(ssa, -1.0f/cosThetaSubstrate - 1.0f/cosThetaTi)));
+            e->weight = vdivs(e->weight, 1.0f - specularProbability);
+            e->pdf *= 1.0f - specularProbability;
+            e->pdf *= eta*eta*cosThetaTo/cosThetaSubstrate;
+        }
+        return 1;
+    }
+    case TGHIP_BSDF_DIELECTRIC: { /* DielectricBsdf.cpp:49-86 */
+        int sampleR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_SPECULAR_T) && b->enable_refraction;
+        float eta = e->wi.z < 0.0f ? b->ior : 1.0f/b->ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectanceT(eta, fabsf(e->wi.z), &cosThetaT);
+        float reflectionProbability;
+        if (sampleR && sampleT) reflectionProbability = F;
+        else if (sampleR) reflectionProbability = 1.0f;
+        else if (sampleT) reflectionProbability = 0.0f;
+        else return 0;
+        if (nextBoolean(e->sampler, reflectionProbability)) {
+            e->wo = V(-e->wi.x, -e->wi.y, e->wi.z);
+            e->pdf = reflectionProbability;
+            e->sampled = TGHIP_LOBE_SPECULAR_R;
+            e->weight = sampleT ? vs(1.0f) : vs(F);
+        } else {
+            if (F == 1.0f) return 0;
+            e->wo = V(-e->wi.x*eta, -e->wi.y*eta, -copysignf(cosThetaT, e->wi.z));
+            e->pdf = 1.0f - reflectionProbability;
+            e->sampled = TGHIP_LOBE_SPECULAR_T;
+            e->weight = sampleR ? vs(1.0f) : vs(1.0f - F);
+        }
+        e->weight = vmul(e->weight, bsdf_albedo(s, b, e));
+        return 1;
+    }
+    case TGHIP_BSDF_ROUGH_DIELECTRIC: { /* RoughDielectricBsdf.cpp:238-245 */
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_GLOSSY_T) && b->enable_refraction;
+        float roughness = bsdf_roughness(s, b, e);
+        int result = rd_sampleBase(e, sampleR, sampleT, roughness, b->ior, b->distribution);
+        e->weight = vmul(e->weight, bsdf_albedo(s, b, e));
+        return result;
+    }
+    case TGHIP_BSDF_PLASTIC: { /* PlasticBsdf.cpp:45-87 */
+        if (e->wi.z <= 0.0f) return 0;
+        int sampleR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        v3 wi = e->wi;
+        float eta = 1.0f/b->ior;
+        float Fi = dielectricReflectance(eta, wi.z);
+        float substrateWeight = b->avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability;
+        if (sampleR && sampleT) specularProbability = specularWeight/(specularWeight + substrateWeight);
+        else if (sampleR) specularProbability = 1.0f;
+        else if (sampleT) specularProbability = 0.0f;
+        else return 0;
+        if (sampleR && nextBoolean(e->sampler, specularProbability)) {
+            e->wo = V(-wi.x, -wi.y, wi.z);
+            e->pdf = specularProbability;
+            e->weight = vs(Fi/specularProbability);
+            e->sampled = TGHIP_LOBE_SPECULAR_R;
+        } else {
+            float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+            v3 wo = cosineHemisphere(xi0, xi1);
+            float Fo = dielectricReflectance(eta, wo.z);
+            v3 diffuseAlbedo = bsdf_albedo(s, b, e);
+            e->wo = wo;
+            e->weight = vscale(plastic_substrate(b, diffuseAlbedo), (1.0f - Fi)*(1.0f - Fo)*eta*eta);
+            v3 ssa = ld3(b->scaled_sigma_a);
+            if (vmax3(ssa) > 0.0f)
+                e->weight = vmul(e->weight, vexp(vscale(ssa, -1.0f/e->wo.z - 1.0f/e->wi.z)));
+            e->pdf = cosineHemispherePdf(e->wo)*(1.0f - specularProbability);
+            e->weight = vdivs(e->weight, 1.0f - specularProbability);
+            e->sampled = TGHIP_LOBE_DIFFUSE_R;
+        }
+        return 1;
+    }
+    case TGHIP_BSDF_ROUGH_PLASTIC: { /* RoughPlasticBsdf.cpp:54-112 */
+        if (e->wi.z <= 0.0f) return 0;
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        if (!sampleR && !sampleT) return 0;
+        v3 wi = e->wi;
+        float eta = 1.0f/b->ior;
+        float Fi = dielectricReflectance(eta, wi.z);
+        float substrateW = vavg(ld3(s->textures[b->albedo].avg));     /* _substrateWeight = _albedo->average().avg() */
+        float substrateWeight = substrateW*b->avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability = specularWeight/(specularWeight + substrateWeight);
+        if (sampleR && (nextBoolean(e->sampler, specularProbability) || !sampleT)) {
+            float roughness = bsdf_roughness(s, b, e);
+            if (!rd_sampleBase(e, 1, 0, roughness, b->ior, b->distribution))
+                return 0;
+            if (sampleT) {
+                v3 diffuseAlbedo = bsdf_albedo(s, b, e);
+                float Fo = dielectricReflectance(eta, e->wo.z);
+                v3 brdfSubstrate = vscale(vscale(vscale(plastic_substrate(b, diffuseAlbedo), (1.0f - Fi)*(1.0f - Fo)*eta*eta), O_INV_PI), e->wo.z);
+                v3 brdfSpecular = vscale(e->weight, e->pdf);
+                float pdfSubstrate = cosineHemispherePdf(e->wo)*(1.0f - specularProbability);
+                float pdfSpecular = e->pdf*specularProbability;
+                e->weight = vdivs(vadd(brdfSpecular, brdfSubstrate), pdfSpecular + pdfSubstrate);
+                e->pdf = pdfSpecular + pdfSubstrate;
+            }
+            return 1;
+        } else {
+            float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+            v3 wo = cosineHemisphere(xi0, xi1);
+            float Fo = dielectricReflectance(eta, wo.z);
+            v3 diffuseAlbedo = bsdf_albedo(s, b, e);
+            e->wo = wo;
+            e->weight = vscale(plastic_substrate(b, diffuseAlbedo), (1.0f - Fi)*(1.0f - Fo)*eta*eta);
+            v3 ssa = ld3(b->scaled_sigma_a);
+            if (vmax3(ssa) > 0.0f)
+                e->weight = vmul(e->weight, vexp(vscale(ssa, -1.0f/e->wo.z - 1.0f/e->wi.z)));
+            e->pdf = cosineHemispherePdf(e->wo);
+            if (sampleR) {
+                v3 brdfSubstrate = vscale(e->weight, e->pdf);
+                float pdfSubstrate = e->pdf*(1.0f - specularProbability);
+                float r = bsdf_roughness(s, b, e);
+                v3 brdfSpecular = rd_evalBase(e, 1, 0, r, b->ior, b->distribution);
+                float pdfSpecular = rd_pdfBase(e, 1, 0, r, b->ior, b->distribution);
+                pdfSpecular *= specularProbability;
+                e->weight = vdivs(vadd(brdfSpecular, brdfSubstrate), pdfSpecular + pdfSubstrate);
+                e->pdf = pdfSpecular + pdfSubstrate;
+            }
+            e->sampled = TGHIP_LOBE_DIFFUSE_R;
+        }
+        return 1;
+    }
+    case TGHIP_BSDF_MIXED: { /* MixedBsdf.cpp:70-99 */
+        float ratio;
+        if (!mixed_adjustedRatio(s, b, e, &ratio)) return 0;
+        if (nextBoolean(e->sampler, ratio)) {
+            if (!bsdf_sample(s, b->sub0, e)) return 0;
+            float pdf0 = e->pdf*ratio;
+            float pdf1 = bsdf_pdf(s, b->sub1, e)*(1.0f - ratio);
+            v3 f = vadd(vscale(vscale(e->weight, e->pdf), ratio), vscale(bsdf_eval(s, b->sub1, e), 1.0f - ratio));
+            e->pdf = pdf0 + pdf1;
+            e->weight = vdivs(f, e->pdf);
+        } else {
+            if (!bsdf_sample(s, b->sub1, e)) return 0;
+            float pdf0 = bsdf_pdf(s, b->sub0, e)*ratio;
+            float pdf1 = e->pdf*(1.0f - ratio);
+            v3 f = vadd(vscale(bsdf_eval(s, b->sub0, e), ratio), vscale(vscale(e->weight, e->pdf), 1.0f - ratio));
+            e->pdf = pdf0 + pdf1;
+            e->weight = vdivs(f, e->pdf);
+        }
+        e->weight = vmul(e->weight, bsdf_albedo(s, b, e));
+        return 1;
+    }
+    case TGHIP_BSDF_TRANSPARENCY: /* TransparencyBsdf.cpp:43-46 */
+        return bsdf_sample(s, b->sub0, e);
+    }
+    return 0;
+}
+
+static float bsdf_pdf(const TgHipSceneDesc *s, int bi, const Event *e)
+{
+    const TgHipBsdf *b = &s->bsdfs[bi];
+    switch (b->type) {
+    case TGHIP_BSDF_LAMBERT:   /* LambertBsdf.cpp:61-68 */
+    case TGHIP_BSDF_ERROR:
+        if (!(e->requested & TGHIP_LOBE_DIFFUSE_R)) return 0.0f;
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+        return cosineHemispherePdf(e->wo);
+    case TGHIP_BSDF_NULL:
+    case TGHIP_BSDF_FORWARD:
+        return 0.0f;
+    case TGHIP_BSDF_MIRROR:
+    case TGHIP_BSDF_CONDUCTOR:  /* MirrorBsdf.cpp:57-64, ConductorBsdf.cpp:82-89 */
+        return ((e->requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e->wi, e->wo)) ? 1.0f : 0.0f;
+    case TGHIP_BSDF_ROUGH_CONDUCTOR: { /* RoughConductorBsdf.cpp:127-143 */
+        if (!(e->requested & TGHIP_LOBE_GLOSSY_R)) return 0.0f;
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+        float roughness = bsdf_roughness(s, b, e);
+        float sampleAlpha = mf_roughnessToAlpha(b->distribution, roughness);
+        v3 hr = vnorm(vadd(e->wi, e->wo));
+        return mf_pdf(b->distribution, sampleAlpha, hr)*0.25f/vdot(e->wi, hr);
+    }
+    case TGHIP_BSDF_SMOOTH_COAT: { /* SmoothCoatBsdf.cpp:179-214 */
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+        int sampleR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int sampleT = (e->requested & s->bsdfs[b->sub0].lobes) != 0;
+        v3 wi = e->wi, wo = e->wo;
+        float eta = 1.0f/b->ior;
+        float cosThetaTi, cosThetaTo;
+        float Fi = dielectricReflectanceT(eta, wi.z, &cosThetaTi);
+        dielectricReflectanceT(eta, wo.z, &cosThetaTo);
+        Event q = *e;
+        q.wi = V(wi.x*eta, wi.y*eta, copysignf(cosThetaTi, wi.z));
+        q.wo = V(wo.x*eta, wo.y*eta, copysignf(cosThetaTo, wo.z));
+        if (sampleR && sampleT) {
+            float substrateWeight = b->avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            float specularProbability = specularWeight/(specularWeight + substrateWeight);
+            if (checkReflectionConstraint(wi, wo))
+                return specularProbability;
+            return bsdf_pdf(s, b->sub0, &q)*(1.0f - specularProbability)*eta*eta*fabsf(wo.z/cosThetaTo);
+        } else if (sampleT) {
+            return bsdf_pdf(s, b->sub0, &q)*eta*eta*fabsf(wo.z/cosThetaTo);
+        } else if (sampleR) {
+            return checkReflectionConstraint(wi, wo) ? 1.0f : 0.0f;
+        }
+        return 0.0f;
+    }
+    case TGHIP_BSDF_DIELECTRIC: { /* DielectricBsdf.cpp:143-164 */
+        int sampleR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_SPECULAR_T) && b->enable_refraction;
+        float eta = e->wi.z < 0.0f ? b->ior : 1.0f/b->ior;
+        float cosThetaT = 0.0f;
+        float F = dielectricReflectanceT(eta, fabsf(e->wi.z), &cosThetaT);
+        if (e->wi.z*e->wo.z >= 0.0f) {
+            if (sampleR && checkReflectionConstraint(e->wi, e->wo)) return sampleT ? F : 1.0f;
+            return 0.0f;
+        } else {
+            if (sampleT && checkRefractionConstraint(e->wi, e->wo, eta, cosThetaT)) return sampleR ? 1.0f - F : 1.0f;
+            return 0.0f;
+        }
+    }
+    case TGHIP_BSDF_ROUGH_DIELECTRIC: { /* RoughDielectricBsdf.cpp:265-272 */
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_GLOSSY_T) && b->enable_refraction;
+        return rd_pdfBase(e, sampleR, sampleT, bsdf_roughness(s, b, e), b->ior, b->distribution);
+    }
+    case TGHIP_BSDF_PLASTIC: { /* PlasticBsdf.cpp:153-177 */
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+        int sampleR = (e->requested & TGHIP_LOBE_SPECULAR_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        if (sampleR && sampleT) {
+            float Fi = dielectricReflectance(1.0f/b->ior, e->wi.z);
+            float substrateWeight = b->avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            float specularProbability = specularWeight/(specularWeight + substrateWeight);
+            if (checkReflectionConstraint(e->wi, e->wo)) return specularProbability;
+            return cosineHemispherePdf(e->wo)*(1.0f - specularProbability);
+        } else if (sampleT) {
+            return cosineHemispherePdf(e->wo);
+        } else if (sampleR) {
+            return checkReflectionConstraint(e->wi, e->wo) ? 1.0f : 0.0f;
+        }
+        return 0.0f;
+    }
+    case TGHIP_BSDF_ROUGH_PLASTIC: { /* RoughPlasticBsdf.cpp:185-213 */
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        if (!sampleR && !sampleT) return 0.0f;
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+        float glossyPdf = 0.0f;
+        if (sampleR) glossyPdf = rd_pdfBase(e, 1, 0, bsdf_roughness(s, b, e), b->ior, b->distribution);
+        float diffusePdf = 0.0f;
+        if (sampleT) diffusePdf = cosineHemispherePdf(e->wo);
+        if (sampleT && sampleR) {
+            float Fi = dielectricReflectance(1.0f/b->ior, e->wi.z);
+            float substrateW = vavg(ld3(s->textures[b->albedo].avg));
+            float substrateWeight = substrateW*b->avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            float specularProbability = specularWeight/(specularWeight + substrateWeight);
+            diffusePdf *= (1.0f - specularProbability);
+            glossyPdf *= specularProbability;
+        }
+        return glossyPdf + diffusePdf;
+    }
+    case TGHIP_BSDF_MIXED: { /* MixedBsdf.cpp:124-130 */
+        float ratio;
+        if (!mixed_adjustedRatio(s, b, e, &ratio)) return 0.0f;
+        return bsdf_pdf(s, b->sub0, e)*ratio + bsdf_pdf(s, b->sub1, e)*(1.0f - ratio);
+    }
+    case TGHIP_BSDF_TRANSPARENCY:
+        return bsdf_pdf(s, b->sub0, e);
+    }
+    return 0.0f;
+}
+
+/* Bsdf::eta (Bsdf.hpp:99-103; DielectricBsdf.cpp:166-174, RoughDielectricBsdf.cpp:274-280) */
+static float bsdf_eta(const TgHipSceneDesc *s, int bi, const Event *e)
+{
+    const TgHipBsdf *b = &s->bsdfs[bi];
+    if (b->type == TGHIP_BSDF_DIELECTRIC || b->type == TGHIP_BSDF_ROUGH_DIELECTRIC) {
+        if (e->wi.z*e->wo.z >= 0.0f) return 1.0f;
+        return e->wi.z < 0.0f ? b->ior : 1.0f/b->ior;
+    }
+    return 1.0f;
+}
+/* radiance-transport wrappers (adjoint == false): Bsdf.hpp:71-97 */
+static v3 bsdf_eval_rt(const TgHipSceneDesc *s, int bi, const Event *e) { return vscale(bsdf_eval(s, bi, e), sqr(bsdf_eta(s, bi, e))); }
+static int bsdf_sample_rt(const TgHipSceneDesc *s, int bi, Event *e)
+{
+    if (!bsdf_sample(s, bi, e)) return 0;
+    e->weight = vscale(e->weight, sqr(bsdf_eta(s, bi, e)));
+    return 1;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Geometry: rays, BVH2 traversal, primitive tests
+ * ------------------------------------------------------------------------------------------- */
+typedef struct { v3 o, d; float tmin, tmax; } Ray;
+typedef struct { uint64_t nodes, prims, rays; } TravStats;
+
+/* Quad::intersect (Quad.cpp:71-98) on a record; returns 1 and shrinks *tmax on a hit */
+static int quad_test(const TgHipPrimRec *r, const TgHipObject *o, const Ray *ray, float tmax, float *t, float *l0, float *l1, int *backSide)
+{
+    v3 n = ld3(o->normal);
+    float nDotW = vdot(ray->d, n);
+    if (fabsf(nDotW) < 1e-6f)
+        return 0;
+    v3 base = ld3(r->a);
+    float tt = vdot(n, vsub(base, ray->o))/nDotW;
+    if (tt < ray->tmin || tt > tmax)
+        return 0;
+    v3 q = vadd(ray->o, vscale(ray->d, tt));
+    v3 v = vsub(q, base);
+    float a = vdot(v, ld3(r->b))*r->p0;
+    float b = vdot(v, ld3(r->c))*r->p1;
+    if (a < 0.0f || a > 1.0f || b < 0.0f || b > 1.0f)
+        return 0;
+    *t = tt; *l0 = a; *l1 = b; *backSide = nDotW >= 0.0f;
+    return 1;
+}
+
+/* Cube::intersect (Cube.cpp:94-125) */
+static int cube_test(const TgHipObject *o, const Ray *ray, float tmax, float *t, int *backSide)
+{
+    v3 p = mat3_tmul(o->rot, vsub(ray->o, ld3(o->pos)));
+    v3 d = mat3_tmul(o->rot, ray->d);
+    float pa[3] = {p.x, p.y, p.z}, da[3] = {d.x, d.y, d.z};
+    float ttMin = ray->tmin, ttMax = tmax;
+    for (int i = 0; i < 3; ++i) {
+        float invD = 1.0f/da[i];
+        float relMin = -o->scale[i] - pa[i];
+        float relMax = o->scale[i] - pa[i];
+        if (invD >= 0.0f) {
+            ttMin = fmaxf(ttMin, relMin*invD);
+            ttMax = fminf(ttMax, relMax*invD);
+        } else {
+            ttMax = fminf(ttMax, relMin*invD);
+            ttMin = fmaxf(ttMin, relMax*invD);
+        }
+    }
+    if (ttMin <= ttMax) {
+        if (ttMin > ray->tmin && ttMin < tmax) { *t = ttMin; *backSide = 0; return 1; }
+        else if (ttMax > ray->tmin && ttMax < tmax) { *t = ttMax; *backSide = 1; return 1; }
+    }
+    return 0;
+}
+
+/* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113),
+ * with exact division in place of rcp+Newton (:43-49).  Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c. */
+static int tri_test(const TgHipPrimRec *r, const Ray *ray, float tmax, float *t, float *u, float *v)
+{
+    v3 v0 = ld3(r->a);
+    v3 e1 = vneg(ld3(r->b)), e2 = ld3(r->c);
+    v3 Ng = vcross(e1, e2);
+    v3 C = vsub(v0, ray->o);
+    v3 R = vcross(ray->d, C);
+    float den = vdot(Ng, ray->d);
+    float absDen = fabsf(den);
+    float sgn = den < 0.0f ? -1.0f : 1.0f;     /* xor with the sign mask */
+    float U = vdot(R, e2)*sgn;
+    float Vv = vdot(R, e1)*sgn;
+    if (!(den != 0.0f && U >= 0.0f && Vv >= 0.0f && U + Vv <= absDen))
+        return 0;
+    float T = vdot(Ng, C)*sgn;
+    if (!(T > absDen*ray->tmin && T < absDen*tmax))
+        return 0;
+    *t = T/absDen; *u = U/absDen; *v = Vv/absDen;
+    return 1;
+}
+
+static inline int box_test(const float *lo, const float *hi, const Ray *ray, v3 invD, float tmax, float *tEntry)
+{
+    float t0x = (lo[0] - ray->o.x)*invD.x, t1x = (hi[0] - ray->o.x)*invD.x;
+    float t0y = (lo[1] - ray->o.y)*invD.y, t1y = (hi[1] - ray->o.y)*invD.y;
+    float t0z = (lo[2] - ray->o.z)*invD.z, t1z = (hi[2] - ray->o.z)*invD.z;
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), ray->tmin));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+    tf *= 1.0000004f;     /* conservative: never cull a primitive the exact test would accept */
+    *tEntry = tn;
+    return tn <= tf;
+}
+
+/* TraceableScene::intersect (renderer/TraceableScene.hpp:170-192): closest hit over all finite
+ * primitives.  The reference does it with Embree BVH4s; we walk the flattened BVH2, near child first. */
+static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hit, TravStats *st)
+{
+    int32_t stack[TGHIP_MAX_BVH_DEPTH + 2];
+    int sp = 0;
+    float tmax = ray->tmax;
+    hit->rec = -1; hit->t = tmax; hit->u = hit->v = 0.0f;
+    v3 invD = V(1.0f/ray->d.x, 1.0f/ray->d.y, 1.0f/ray->d.z);
+    int32_t cur = 0;
+    if (st) st->rays++;
+    for (;;) {
+        if (cur >= 0) {
+            const TgHipBvhNode *n = &s->nodes[cur];
+            if (st) st->nodes++;
+            float e0, e1;
+            int h0 = box_test(n->lo0, n->hi0, ray, invD, tmax, &e0);
+            int h1 = box_test(n->lo1, n->hi1, ray, invD, tmax, &e1);
+            if (h0 && h1) {
+                if (e1 < e0) { stack[sp++] = n->child0; cur = n->child1; }
+                else { stack[sp++] = n->child1; cur = n->child0; }
+                continue;
+            } else if (h0) { cur = n->child0; continue; }
+            else if (h1) { cur = n->child1; continue; }
+        } else {
+            uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+            for (uint32_t i = first; i < first + count; ++i) {
+                const TgHipPrimRec *r = &s->recs[i];
+                if (st) st->prims++;
+                float t, u = 0.0f, v = 0.0f; int back = 0;
+                int ok = 0;
+                switch (TGHIP_REC_KIND(r->meta)) {
+                case TGHIP_REC_TRIANGLE: ok = tri_test(r, ray, tmax, &t, &u, &v); break;
+                case TGHIP_REC_QUAD: ok = quad_test(r, &s->objects[TGHIP_REC_OBJECT(r->meta)], ray, tmax, &t, &u, &v, &back); break;
+                case TGHIP_REC_CUBE: ok = cube_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, tmax, &t, &back); u = (float)back; break;
+                default: break;
+                }
+                if (ok) { tmax = t; hit->t = t; hit->u = u; hit->v = v; hit->rec = (int32_t)i; }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return hit->rec >= 0;
+}
+
+/* IntersectionInfo (primitives/IntersectionInfo.hpp:11-22) + what hitBackside() needs */
+typedef struct {
+    v3 Ng, Ns, p, w;
+    float u, v, epsilon;
+    int object, bsdf, backSide;
+} Info;
+
+static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const TgHipHit *hit, Info *info)
+{
+    const TgHipPrimRec *r = &s->recs[hit->rec];
+    int objIdx = (int)TGHIP_REC_OBJECT(r->meta);
+    const TgHipObject *o = &s->objects[objIdx];
+    info->object = objIdx;
+    info->p = vadd(ray->o, vscale(ray->d, hit->t));      /* TraceableScene.hpp:184 */
+    info->w = ray->d;
+    info->epsilon = 5e-4f;                               /* DefaultEpsilon, TraceableScene.hpp:39 */
+    switch (TGHIP_REC_KIND(r->meta)) {
+    case TGHIP_REC_TRIANGLE: {   /* TriangleMesh.cpp:317-355, 80-106 */
+        const TgHipTriAttr *a = &s->tri_attrs[hit->rec];
+        v3 NgU = vcross(ld3(r->b), ld3(r->c));
+        info->backSide = vdot(NgU, ray->d) > 0.0f;
+        info->Ng = vnorm(NgU);
+        float u = hit->u, v = hit->v;
+        if (o->flags & TGHIP_OBJF_SMOOTH) {
+            v3 n = vadd(vadd(vscale(ld3(a->n0), 1.0f - u - v), vscale(ld3(a->n1), u)), vscale(ld3(a->n2), v));
+            info->Ns = vnorm(n);
+        } else {
+            info->Ns = info->Ng;
+        }
+        info->u = (1.0f - u - v)*a->uv0[0] + u*a->uv1[0] + v*a->uv2[0];
+        info->v = (1.0f - u - v)*a->uv0[1] + u*a->uv1[1] + v*a->uv2[1];
+        info->bsdf = a->bsdf;
+        break;
+    }
+    case TGHIP_REC_QUAD:         /* Quad.cpp:123-131 */
+        info->Ng = info->Ns = ld3(o->normal);
+        info->u = hit->u; info->v = hit->v;
+        info->bsdf = o->bsdf;
+        info->backSide = vdot(ray->d, ld3(o->normal)) >= 0.0f;
+        break;
+    case TGHIP_REC_CUBE: {       /* Cube.cpp:157-170 */
+        v3 p = mat3_tmul(o->rot, vsub(info->p, ld3(o->pos)));
+        float pa[3] = {p.x, p.y, p.z};
+        float ex[3] = {fabsf(p.x) - o->scale[0], fabsf(p.y) - o->scale[1], fabsf(p.z) - o->scale[2]};
+        int dim = ex[0] > ex[1] ? (ex[0] > ex[2] ? 0 : 2) : (ex[1] > ex[2] ? 1 : 2);   /* Vec::maxDim */
+        float n[3] = {0.0f, 0.0f, 0.0f};
+        n[dim] = pa[dim] < 0.0f ? -1.0f : 1.0f;
+        float uvw[3];
+        for (int i = 0; i < 3; ++i) uvw[i] = (pa[i]/o->scale[i])*0.5f + 0.5f;
+        info->Ns = info->Ng = mat3_mul(o->rot, V(n[0], n[1], n[2]));
+        info->u = uvw[(dim + 1) % 3]; info->v = uvw[(dim + 2) % 3];
+        info->bsdf = o->bsdf;
+        info->backSide = hit->u != 0.0f;
+        break;
+    }
+    default:
+        info->Ng = info->Ns = V(0, 1, 0); info->u = info->v = 0; info->bsdf = o->bsdf; info->backSide = 0;
+        break;
+    }
+}
+
+/* InfiniteSphere::directionToUV (InfiniteSphere.cpp:27-39) */
+static void inf_directionToUV(const TgHipObject *o, v3 wi, float *u, float *v, float *sinTheta)
+{
+    v3 wLocal = mat3_tmul(o->rot, wi);
+    if (sinTheta) *sinTheta = sqrtf(fmaxf(1.0f - wLocal.y*wLocal.y, 0.0f));
+    *u = atan2f(wLocal.z, wLocal.x)*O_INV_TWO_PI + 0.5f;
+    *v = acosf(-wLocal.y)*O_INV_PI;
+}
+static v3 inf_uvToDirection(const TgHipObject *o, float u, float v, float *sinTheta)   /* :41-51 */
+{
+    float phi = (u - 0.5f)*O_TWO_PI;
+    float theta = v*O_PI;
+    *sinTheta = sinf(theta);
+    return mat3_mul(o->rot, V(cosf(phi)**sinTheta, -cosf(theta), sinf(phi)**sinTheta));
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * The integrator: TraceBase + PathTracer
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    const TgHipSceneDesc *s;
+    Sampler *sampler;
+    TravStats *st;
+    uint64_t shadow_rays, closest_rays;
+} Ctx;
+
+typedef struct { Frame frame; v3 wi; int flipped; } Local;   /* the part of SurfaceScatterEvent that persists */
+
+static Local makeLocalScatterEvent(const Ctx *c, const Info *info, const Ray *ray)   /* TraceBase.cpp:24-51 */
+{
+    Local l;
+    l.frame = frame_from_normal(info->Ns);      /* Primitive::setupTangentFrame without bump/anisotropy (Primitive.cpp:125-133) */
+    int hitBackside = vdot(l.frame.normal, ray->d) > 0.0f;
+    int isTransmissive = (c->s->bsdfs[info->bsdf].lobes & LOBE_TRANSMISSIVE) != 0;
+    l.flipped = c->s->settings.enable_two_sided_shading && hitBackside && !isTransmissive;
+    if (l.flipped) {
+        l.frame.normal = vneg(l.frame.normal);
+        l.frame.tangent = vneg(l.frame.tangent);
+    }
+    l.wi = toLocal(&l.frame, vneg(ray->d));
+    return l;
+}
+
+static int isConsistent(const Ctx *c, const Info *info, const Local *l, v3 woLocal, v3 w)   /* TraceBase.cpp:53-60 */
+{
+    if (!c->s->settings.enable_consistency_checks)
+        return 1;
+    int geometricBackside = vdot(w, info->Ng) < 0.0f;
+    int shadingBackside = (woLocal.z < 0.0f) ^ l->flipped;
+    return geometricBackside == shadingBackside;
+}
+
+static Event make_event(const Ctx *c, const Info *info, const Local *l, uint32_t requested)
+{
+    Event e;
+    e.wi = l->wi; e.wo = vs(0.0f); e.weight = vs(1.0f); e.pdf = 1.0f;
+    e.requested = requested; e.sampled = 0;
+    e.u = info->u; e.v = info->v;
+    e.sampler = c->sampler;
+    return e;
+}
+
+/* TraceBase::generalizedShadowRay (TraceBase.cpp:62-125) without media.  `endCap` is an object index. */
+static v3 generalizedShadowRay(Ctx *c, Ray *ray, int endCap, int bounce)
+{
+    float initialFarT = ray->tmax;
+    v3 throughput = vs(1.0f);
+    for (;;) {
+        TgHipHit hit;
+        Info info;
+        c->shadow_rays++;
+        int hitAny = scene_intersect(c->s, ray, &hit, c->st);
+        int hitObject = -1;
+        if (hitAny) {
+            intersection_info(c->s, ray, &hit, &info);
+            hitObject = info.object;
+        }
+        int didHit = hitAny && hitObject != endCap;
+        if (didHit) {
+            if (!(c->s->bsdfs[info.bsdf].lobes & TGHIP_LOBE_FORWARD))
+                return vs(0.0f);
+            Local l = makeLocalScatterEvent(c, &info, ray);
+            Event fe = make_event(c, &info, &l, TGHIP_LOBE_FORWARD);   /* makeForwardEvent */
+            fe.wo = vneg(fe.wi);
+            v3 transparency = bsdf_eval_rt(c->s, info.bsdf, &fe);
+            if (viszero(transparency))
+                return vs(0.0f);
+            throughput = vmul(throughput, transparency);
+            bounce++;
+            if (bounce >= c->s->settings.max_bounces)
+                return vs(0.0f);
+        }
+        if (!hitAny || hitObject == endCap)
+            return bounce >= c->s->settings.min_bounces ? throughput : vs(0.0f);
+        ray->o = vadd(ray->o, vscale(ray->d, hit.t));      /* ray.hitpoint(): farT was set to the hit */
+        initialFarT -= hit.t;
+        ray->tmin = info.epsilon;
+        ray->tmax = initialFarT;
+    }
+}
+
+/* light.intersect + intersectionInfo + evalDirect for the light kinds in scope.
+ * Returns 0 if the ray misses the light.  (Quad.cpp:71-131,235-238; InfiniteSphere.cpp:77-104,241-244) */
+typedef struct { float t, u, v; int backSide; v3 w; } LightHit;
+static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, LightHit *lh)
+{
+    const TgHipObject *o = &s->objects[objIdx];
+    lh->w = ray->d;
+    if (o->type == TGHIP_OBJ_QUAD) {
+        TgHipPrimRec r;
+        memset(&r, 0, sizeof(r));
+        memcpy(r.a, o->base, 12); memcpy(r.b, o->edge0, 12); memcpy(r.c, o->edge1, 12);
+        r.p0 = o->inv_uv_sq[0]; r.p1 = o->inv_uv_sq[1];
+        return quad_test(&r, o, ray, ray->tmax, &lh->t, &lh->u, &lh->v, &lh->backSide);
+    } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE) {
+        lh->t = ray->tmax; lh->backSide = 0;
+        inf_directionToUV(o, ray->d, &lh->u, &lh->v, NULL);
+        return 1;
+    }
+    return 0;
+}
+static v3 light_evalDirect(const TgHipSceneDesc *s, int objIdx, const LightHit *lh)
+{
+    const TgHipObject *o = &s->objects[objIdx];
+    if (o->emission < 0) return vs(0.0f);
+    if (lh->backSide) return vs(0.0f);
+    return texture_eval(s, o->emission, lh->u, lh->v);
+}
+/* Quad::directPdf (Quad.cpp:216-223), InfiniteSphere::directPdf (InfiniteSphere.cpp:218-229) */
+static float light_directPdf(const TgHipSceneDesc *s, int objIdx, const LightHit *lh, v3 p)
+{
+    const TgHipObject *o = &s->objects[objIdx];
+    if (o->type == TGHIP_OBJ_QUAD) {
+        v3 n = ld3(o->normal);
+        float cosTheta = fabsf(vdot(n, lh->w));
+        float t = vdot(n, vsub(ld3(o->base), p))/vdot(n, lh->w);
+        return t*t/(cosTheta*o->area);
+    } else {
+        const TgHipTexture *t = &s->textures[o->emission];
+        if (t->type != TGHIP_TEX_BITMAP)       /* _emission->isConstant() (checker envmaps are outside the scope) */
+            return O_INV_FOUR_PI;
+        float sinTheta, u, v;
+        inf_directionToUV(o, lh->w, &u, &v, &sinTheta);
+        return O_INV_PI*O_INV_TWO_PI*bitmap_pdf(s, t, u, v)/sinTheta;
+    }
+}
+/* Quad::sampleDirect (Quad.cpp:172-187), InfiniteSphere::sampleDirect (InfiniteSphere.cpp:161-176) */
+static int light_sampleDirect(const TgHipSceneDesc *s, int objIdx, v3 p, Sampler *smp, v3 *d, float *dist, float *pdf)
+{
+    const TgHipObject *o = &s->objects[objIdx];
+    if (o->type == TGHIP_OBJ_QUAD) {
+        v3 n = ld3(o->normal);
+        if (vdot(n, vsub(p, ld3(o->base))) <= 0.0f)
+            return 0;
+        float xi0 = next1D(smp), xi1 = next1D(smp);
+        v3 q = vadd(vadd(ld3(o->base), vscale(ld3(o->edge0), xi0)), vscale(ld3(o->edge1), xi1));
+        v3 dd = vsub(q, p);
+        float rSq = vlensq(dd);
+        *dist = sqrtf(rSq);
+        dd = vdivs(dd, *dist);
+        float cosTheta = -vdot(n, dd);
+        *pdf = rSq/(cosTheta*o->area);
+        *d = dd;
+        return 1;
+    } else {
+        const TgHipTexture *t = &s->textures[o->emission];
+        float xi0 = next1D(smp), xi1 = next1D(smp);
+        if (t->type != TGHIP_TEX_BITMAP) {
+            *d = uniformSphere(xi0, xi1);
+            *dist = INFINITY;
+            *pdf = O_INV_FOUR_PI;
+            return 1;
+        }
+        float u, v, sinTheta;
+        bitmap_sample(s, t, xi0, xi1, &u, &v);
+        *d = inf_uvToDirection(o, u, v, &sinTheta);
+        *pdf = O_INV_PI*O_INV_TWO_PI*bitmap_pdf(s, t, u, v)/sinTheta;
+        *dist = INFINITY;
+        return *pdf != 0.0f;
+    }
+}
+/* Quad::approximateRadiance (Quad.cpp:256-279), InfiniteSphere::approximateRadiance (InfiniteSphere.cpp:261-266) */
+static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p)
+{
+    const TgHipObject *o = &s->objects[objIdx];
+    if (o->type == TGHIP_OBJ_QUAD) {
+        if (o->emission < 0) return 0.0f;
+        v3 R0 = vsub(ld3(o->base), p);
+        if (vdot(R0, ld3(o->normal)) >= 0.0f)
+            return 0.0f;
+        v3 R1 = vadd(R0, ld3(o->edge0));
+        v3 R2 = vadd(R1, ld3(o->edge1));
+        v3 R3 = vadd(R0, ld3(o->edge1));
+        v3 n0 = vnorm(vcross(R0, R1)), n1 = vnorm(vcross(R1, R2)), n2 = vnorm(vcross(R2, R3)), n3 = vnorm(vcross(R3, R0));
+        float Q = acosf(vdot(n0, n1)) + acosf(vdot(n1, n2)) + acosf(vdot(n2, n3)) + acosf(vdot(n3, n0));
+        return (O_TWO_PI - fabsf(Q))*vmax3(ld3(s->textures[o->emission].avg));
+    } else {
+        if (o->emission < 0 || !(o->flags & TGHIP_OBJF_SAMPLE)) return 0.0f;
+        return O_TWO_PI*vmax3(ld3(s->textures[o->emission].avg));
+    }
+}
+
+/* TraceBase::attenuatedEmission (TraceBase.cpp:144-174) for non-Dirac lights */
+static v3 attenuatedEmission(Ctx *c, int lightObj, float expectedDist, int bounce, Ray *ray, LightHit *lh)
+{
+    const float fudgeFactor = 1.0f + 1e-3f;
+    if (!light_intersect(c->s, lightObj, ray, lh) || lh->t*fudgeFactor < expectedDist)
+        return vs(0.0f);
+    ray->tmax = lh->t;
+    v3 shadow = generalizedShadowRay(c, ray, lightObj, bounce);
+    if (viszero(shadow))
+        return vs(0.0f);
+    return vmul(shadow, light_evalDirect(c->s, lightObj, lh));
+}
+
+/* TraceBase::lightSample (TraceBase.cpp:246-285) */
+static v3 lightSample(Ctx *c, int lightObj, const Info *info, const Local *l, int bounce)
+{
+    v3 d; float dist, pdf;
+    if (!light_sampleDirect(c->s, lightObj, info->p, c->sampler, &d, &dist, &pdf))
+        return vs(0.0f);
+    Event e = make_event(c, info, l, LOBE_ALL_BUT_SPECULAR);
+    e.wo = toLocal(&l->frame, d);
+    if (!isConsistent(c, info, l, e.wo, d))
+        return vs(0.0f);
+    v3 f = bsdf_eval_rt(c->s, info->bsdf, &e);
+    if (viszero(f))
+        return vs(0.0f);
+    Ray ray = {info->p, d, info->epsilon, INFINITY};
+    LightHit lh;
+    v3 em = attenuatedEmission(c, lightObj, dist, bounce, &ray, &lh);
+    if (viszero(em))
+        return vs(0.0f);
+    v3 lightF = vdivs(vmul(f, em), pdf);
+    lightF = vscale(lightF, powerHeuristic(pdf, bsdf_pdf(c->s, info->bsdf, &e)));
+    return lightF;
+}
+
+/* TraceBase::bsdfSample (TraceBase.cpp:287-321) */
+static v3 bsdfSample(Ctx *c, int lightObj, const Info *info, const Local *l, int bounce)
+{
+    Event e = make_event(c, info, l, LOBE_ALL_BUT_SPECULAR);
+    if (!bsdf_sample_rt(c->s, info->bsdf, &e))
+        return vs(0.0f);
+    if (viszero(e.weight))
+        return vs(0.0f);
+    v3 wo = toGlobal(&l->frame, e.wo);
+    if (!isConsistent(c, info, l, e.wo, wo))
+        return vs(0.0f);
+    Ray ray = {info->p, wo, info->epsilon, INFINITY};
+    LightHit lh;
+    v3 em = attenuatedEmission(c, lightObj, -1.0f, bounce, &ray, &lh);
+    if (viszero(em))
+        return vs(0.0f);
+    v3 bsdfF = vmul(em, e.weight);
+    bsdfF = vscale(bsdfF, powerHeuristic(e.pdf, light_directPdf(c->s, lightObj, &lh, info->p)));
+    return bsdfF;
+}
+
+/* TraceBase::chooseLight (TraceBase.cpp:416-459); returns the light's object index or -1 */
+static int chooseLight(Ctx *c, v3 p, float *weight)
+{
+    const TgHipSceneDesc *s = c->s;
+    int n = (int)s->num_lights;
+    if (n == 0) return -1;
+    if (n == 1) { *weight = 1.0f; return s->lights[0]; }
+    float lightPdf[64];
+    if (n > 64) n = 64;
+    float total = 0.0f;
+    unsigned numNonNegative = 0;
+    for (int i = 0; i < n; ++i) {
+        lightPdf[i] = light_approximateRadiance(s, s->lights[i], p);
+        if (lightPdf[i] >= 0.0f) { total += lightPdf[i]; numNonNegative++; }
+    }
+    if (numNonNegative == 0) {
+        for (int i = 0; i < n; ++i) lightPdf[i] = 1.0f;
+        total = (float)n;
+    } else if ((int)numNonNegative < n) {
+        for (int i = 0; i < n; ++i) {
+            float uniformWeight = (total == 0.0f ? 1.0f : total)/numNonNegative;
+            if (lightPdf[i] < 0.0f) { lightPdf[i] = uniformWeight; total += uniformWeight; }
+        }
+    }
+    if (total == 0.0f) return -1;
+    float t = next1D(c->sampler)*total;
+    for (int i = 0; i < n; ++i) {
+        if (t < lightPdf[i] || i == n - 1) { *weight = total/lightPdf[i]; return s->lights[i]; }
+        t -= lightPdf[i];
+    }
+    return -1;
+}
+
+/* TraceBase::estimateDirect + sampleDirect (TraceBase.cpp:483-494, 383-400) */
+static v3 estimateDirect(Ctx *c, const Info *info, const Local *l, int bounce)
+{
+    float weight;
+    int light = chooseLight(c, info->p, &weight);
+    if (light < 0)
+        return vs(0.0f);
+    uint32_t lobes = c->s->bsdfs[info->bsdf].lobes;
+    int pureSpecular = lobes != 0 && (lobes & ~(uint32_t)LOBE_SPECULAR) == 0;
+    if (pureSpecular || lobes == TGHIP_LOBE_FORWARD)
+        return vs(0.0f);
+    v3 result = lightSample(c, light, info, l, bounce);
+    result = vadd(result, bsdfSample(c, light, info, l, bounce));    /* no Dirac lights in scope */
+    return vscale(result, weight);
+}
+
+/* PathTracer::traceSample (PathTracer.cpp:14-149) with media == [] */
+static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
+{
+    const TgHipSceneDesc *s = c->s;
+    const TgHipCamera *cam = &s->camera;
+    const int maxBounces = s->settings.max_bounces, minBounces = s->settings.min_bounces;
+    const int nee = s->settings.enable_light_sampling;
+
+    /* PinholeCamera::samplePosition/sampleDirection (PinholeCamera.cpp:53-86) */
+    float xi0 = next1D(c->sampler), xi1 = next1D(c->sampler);
+    float fu, fv;
+    if (cam->filter_type == TGHIP_FILTER_DIRAC) { fu = fv = 0.0f; }
+    else if (cam->filter_type == TGHIP_FILTER_BOX) { fu = xi0 - 0.5f; fv = xi1 - 0.5f; }
+    else {
+        /* ReconstructionFilter::sample (ReconstructionFilter.hpp:86-103) */
+        float xi[2] = {xi0, xi1}, out[2];
+        for (int k = 0; k < 2; ++k) {
+            float x = xi[k];
+            int negative = x < 0.5f;
+            x = negative ? x*2.0f : (x - 0.5f)*2.0f;
+            int idx = 31 - 1;
+            for (int i = 0; i < 31 - 1; ++i) {
+                if (x < cam->filter_cdf[i]) { idx = i; break; }
+            }
+            float pdf = cam->filter_cdf[idx] - cam->filter_cdf[idx - 1];
+            float u = cam->filter_bin_size*(idx + (x - cam->filter_cdf[idx - 1])/pdf);
+            out[k] = negative ? -u : u;
+        }
+        fu = out[0]; fv = out[1];
+    }
+    v3 localD = vnorm(V(-1.0f + ((float)px + 0.5f + fu)*2.0f*cam->pixel_size_x,
+                        cam->ratio - ((float)py + 0.5f + fv)*2.0f*cam->pixel_size_x,
+                        cam->plane_dist));
+    Ray ray;
+    ray.o = ld3(cam->pos);
+    ray.d = mat3_mul(cam->xf, localD);
+    ray.tmin = 1e-4f; ray.tmax = INFINITY;            /* Ray ctor defaults, math/Ray.hpp:24 */
+
+    v3 throughput = vs(1.0f), emission = vs(0.0f);
+    TgHipHit hit;
+    Info info;
+    int bounce = 0;
+    c->closest_rays++;
+    int didHit = scene_intersect(s, &ray, &hit, c->st);
+    if (didHit) intersection_info(s, &ray, &hit, &info);
+    int wasSpecular = 1;
+    while (didHit && bounce < maxBounces) {
+        Local l = makeLocalScatterEvent(c, &info, &ray);
+
+        /* TraceBase::handleSurface (TraceBase.cpp:516-568) */
+        Event fe = make_event(c, &info, &l, TGHIP_LOBE_FORWARD);
+        fe.wo = vneg(fe.wi);
+        v3 transparency = bsdf_eval_rt(s, info.bsdf, &fe);
+        float transparencyScalar = vavg(transparency);
+        v3 wo;
+        if (nextBoolean(c->sampler, transparencyScalar)) {
+            wo = ray.d;
+            throughput = vmul(throughput, vdivs(transparency, transparencyScalar));
+        } else {
+            if (nee && bounce < maxBounces - 1)
+                emission = vadd(emission, vmul(estimateDirect(c, &info, &l, bounce + 1), throughput));
+            const TgHipObject *o = &s->objects[info.object];
+            if (o->emission >= 0 && bounce >= minBounces) {
+                if (!nee || wasSpecular || o->light < 0) {
+                    LightHit lh; lh.u = info.u; lh.v = info.v; lh.backSide = info.backSide;
+                    emission = vadd(emission, vmul(light_evalDirect(s, info.object, &lh), throughput));
+                }
+            }
+            Event e = make_event(c, &info, &l, LOBE_ALL);
+            if (!bsdf_sample_rt(s, info.bsdf, &e))
+                return emission;
+            wo = toGlobal(&l.frame, e.wo);
+            if (!isConsistent(c, &info, &l, e.wo, wo))
+                return emission;
+            throughput = vmul(throughput, e.weight);
+            wasSpecular = (e.sampled & LOBE_SPECULAR) != 0;
+        }
+        v3 hp = vadd(ray.o, vscale(ray.d, hit.t));      /* ray.hitpoint() */
+        ray.o = hp; ray.d = wo; ray.tmin = info.epsilon; ray.tmax = INFINITY;
+
+        if (vmax3(throughput) == 0.0f)
+            break;
+        float roulettePdf = fmaxf(fabsf(throughput.x), fmaxf(fabsf(throughput.y), fabsf(throughput.z)));
+        if (bounce > 2 && roulettePdf < 0.1f) {
+            if (nextBoolean(c->sampler, roulettePdf))
+                throughput = vdivs(throughput, roulettePdf);
+            else
+                return emission;
+        }
+        if (isnan(vsum(ray.d) + vsum(ray.o)))
+            return vs(0.0f);
+        if (isnan(vsum(throughput) + vsum(emission)))
+            return vs(0.0f);
+
+        bounce++;
+        if (bounce < maxBounces) {
+            c->closest_rays++;
+            didHit = scene_intersect(s, &ray, &hit, c->st);
+            if (didHit) intersection_info(s, &ray, &hit, &info);
+        }
+    }
+    /* handleInfiniteLights (TraceBase.cpp:570-578, TraceableScene.hpp:194-209): the last infinite light wins */
+    if (bounce >= minBounces && bounce < maxBounces && s->num_infinite_lights > 0) {
+        int objIdx = s->infinite_lights[s->num_infinite_lights - 1];
+        const TgHipObject *o = &s->objects[objIdx];
+        if (!nee || wasSpecular || !(o->flags & TGHIP_OBJF_SAMPLE)) {
+            float u, v;
+            inf_directionToUV(o, ray.d, &u, &v, NULL);
+            emission = vadd(emission, vmul(throughput, texture_eval(s, o->emission, u, v)));
+        }
+    }
+    if (isnan(vsum(throughput) + vsum(emission)))
+        return vs(0.0f);
+    return emission;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Exported entry points
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t samples, closest_rays, shadow_rays, nodes_visited, prims_tested;
+} OracleCounters;
+
+void oracle_trace_sample(const TgHipSceneDesc *s, uint32_t seed, uint32_t px, uint32_t py, uint32_t sampleIndex, float *rgb)
+{
+    Sampler smp;
+    sampler_start(&smp, seed, px + py*(uint32_t)s->camera.res_x, sampleIndex);
+    Ctx c = {s, &smp, NULL, 0, 0};
+    v3 r = traceSample(&c, px, py);
+    rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
+}
+
+/* One pass over the shard's pixels, renderTile semantics (PathTraceIntegrator.cpp:136-156) with the
+ * framebuffer kept as sum + count (OutputBuffer.hpp:104-107 drops NaN/Inf samples without counting). */
+int oracle_render(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb_sum, uint32_t *count,
+                  OracleCounters *counters, int nthreads)
+{
+    int w = s->camera.res_x, h = s->camera.res_y;
+    int tilesX = (w + 15)/16;
+    uint32_t shardCount = pass->shard_count ? pass->shard_count : 1;
+    uint64_t tot[5] = {0, 0, 0, 0, 0};
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+    #pragma omp parallel
+    {
+        uint64_t loc[5] = {0, 0, 0, 0, 0};
+        TravStats st = {0, 0, 0};
+        #pragma omp for schedule(dynamic, 1)
+        for (int y = 0; y < h; ++y) {
+            for (int x = 0; x < w; ++x) {
+                uint32_t tile = (uint32_t)((y/16)*tilesX + x/16);
+                if (tile % shardCount != pass->shard_index)
+                    continue;
+                uint32_t pixelIndex = (uint32_t)(x + y*w);
+                for (uint32_t sidx = pass->spp_begin; sidx < pass->spp_end; ++sidx) {
+                    Sampler smp;
+                    sampler_start(&smp, pass->seed, pixelIndex, sidx);
+                    Ctx c = {s, &smp, counters ? &st : NULL, 0, 0};
+                    v3 r = traceSample(&c, (uint32_t)x, (uint32_t)y);
+                    loc[0]++; loc[1] += c.closest_rays; loc[2] += c.shadow_rays;
+                    if (isnan(r.x) || isnan(r.y) || isnan(r.z) || isinf(r.x) || isinf(r.y) || isinf(r.z))
+                        continue;
+                    rgb_sum[pixelIndex*3 + 0] += r.x;
+                    rgb_sum[pixelIndex*3 + 1] += r.y;
+                    rgb_sum[pixelIndex*3 + 2] += r.z;
+                    count[pixelIndex]++;
+                }
+            }
+        }
+        loc[3] = st.nodes; loc[4] = st.prims;
+        #pragma omp critical
+        { for (int i = 0; i < 5; ++i) tot[i] += loc[i]; }
+    }
+    if (counters) {
+        counters->samples += tot[0]; counters->closest_rays += tot[1]; counters->shadow_rays += tot[2];
+        counters->nodes_visited += tot[3]; counters->prims_tested += tot[4];
+    }
+    return 0;
+}
+
+/* batched TraceableScene::intersect; also returns the exact visit counts that feed the
+ * algorithmic-bytes model of the traversal kernel */
+int oracle_trace_rays(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *hits, size_t n,
+                      uint64_t *nodes_visited, uint64_t *prims_tested)
+{
+    TravStats st = {0, 0, 0};
+    for (size_t i = 0; i < n; ++i) {
+        Ray r = {ld3(rays[i].o), ld3(rays[i].d), rays[i].tmin, rays[i].tmax};
+        scene_intersect(s, &r, &hits[i], &st);
+    }
+    if (nodes_visited) *nodes_visited = st.nodes;
+    if (prims_tested) *prims_tested = st.prims;
+    return 0;
+}
+
+/* ---- unit-level hooks for the L1 parity tests (tests/test_oracle_units.py) ---------------- */
+void oracle_rng_stream(uint32_t seed, uint32_t pixelIndex, uint32_t sampleIndex, int n, float *out)
+{
+    Sampler smp;
+    sampler_start(&smp, seed, pixelIndex, sampleIndex);
+    for (int i = 0; i < n; ++i) out[i] = next1D(&smp);
+}
+
+void oracle_camera_ray(const TgHipSceneDesc *s, uint32_t px, uint32_t py, float xi0, float xi1, float *o, float *d)
+{
+    /* re-uses traceSample's prologue through a replay sampler */
+    const TgHipCamera *cam = &s->camera;
+    float xi[2] = {xi0, xi1}, out[2] = {0, 0};
+    if (cam->filter_type == TGHIP_FILTER_BOX) { out[0] = xi0 - 0.5f; out[1] = xi1 - 0.5f; }
+    else if (cam->filter_type == TGHIP_FILTER_TABULATED) {
+        for (int k = 0; k < 2; ++k) {
+            float x = xi[k];
+            int negative = x < 0.5f;
+            x = negative ? x*2.0f : (x - 0.5f)*2.0f;
+            int idx = 30;
+            for (int i = 0; i < 30; ++i) if (x < cam->filter_cdf[i]) { idx = i; break; }
+            float pdf = cam->filter_cdf[idx] - cam->filter_cdf[idx - 1];
+            float u = cam->filter_bin_size*(idx + (x - cam->filter_cdf[idx - 1])/pdf);
+            out[k] = negative ? -u : u;
+        }
+    }
+    v3 localD = vnorm(V(-1.0f + ((float)px + 0.5f + out[0])*2.0f*cam->pixel_size_x,
+                        cam->ratio - ((float)py + 0.5f + out[1])*2.0f*cam->pixel_size_x, cam->plane_dist));
+    v3 dd = mat3_mul(cam->xf, localD);
+    o[0] = cam->pos[0]; o[1] = cam->pos[1]; o[2] = cam->pos[2];
+    d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+}
+
+/* eval + pdf of bsdf `bi` for local directions wi, wo at texture coordinate uv, radiance transport */
+void oracle_bsdf_eval(const TgHipSceneDesc *s, int bi, const float *wi, const float *wo, const float *uv,
+                      uint32_t requested, float *f, float *pdf)
+{
+    Event e;
+    memset(&e, 0, sizeof(e));
+    e.wi = ld3(wi); e.wo = ld3(wo); e.weight = vs(1.0f); e.pdf = 1.0f;
+    e.requested = requested; e.u = uv[0]; e.v = uv[1];
+    v3 r = bsdf_eval_rt(s, bi, &e);
+    f[0] = r.x; f[1] = r.y; f[2] = r.z;
+    *pdf = bsdf_pdf(s, bi, &e);
+}
+
+/* sample bsdf `bi` with the given uniform numbers; returns 0 if sampling failed */
+int oracle_bsdf_sample(const TgHipSceneDesc *s, int bi, const float *wi, const float *uv, uint32_t requested,
+                       const float *xi, int nxi, float *wo, float *weight, float *pdf, uint32_t *sampledLobe, int *consumed)
+{
+    Sampler smp;
+    memset(&smp, 0, sizeof(smp));
+    smp.replay = xi; smp.replay_n = nxi;
+    Event e;
+    memset(&e, 0, sizeof(e));
+    e.wi = ld3(wi); e.weight = vs(1.0f); e.pdf = 1.0f;
+    e.requested = requested; e.u = uv[0]; e.v = uv[1]; e.sampler = &smp;
+    int ok = bsdf_sample_rt(s, bi, &e);
+    wo[0] = e.wo.x; wo[1] = e.wo.y; wo[2] = e.wo.z;
+    weight[0] = e.weight.x; weight[1] = e.weight.y; weight[2] = e.weight.z;
+    *pdf = e.pdf; *sampledLobe = e.sampled;
+    if (consumed) *consumed = smp.replay_pos;
+    return ok;
+}
+
+/* light sampleDirect for light slot `li` from point p; returns 0 when the sample is rejected */
+int oracle_light_sample(const TgHipSceneDesc *s, int li, const float *p, float xi0, float xi1, float *d, float *dist, float *pdf)
+{
+    float xi[2] = {xi0, xi1};
+    Sampler smp;
+    memset(&smp, 0, sizeof(smp));
+    smp.replay = xi; smp.replay_n = 2;
+    v3 dd = vs(0.0f);
+    int ok = light_sampleDirect(s, s->lights[li], ld3(p), &smp, &dd, dist, pdf);
+    d[0] = dd.x; d[1] = dd.y; d[2] = dd.z;
+    return ok;
+}
+
+void oracle_texture_eval(const TgHipSceneDesc *s, int tex, float u, float v, float *rgb)
+{
+    v3 r = texture_eval(s, tex, u, v);
+    rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
+}

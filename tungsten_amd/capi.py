@@ -1,0 +1,156 @@
+"""ctypes mirror of include/tungsten_hip.h and include/tungsten_host.h.
+
+This module only *describes* the C-ABI (struct layouts, prototypes) and loads the in-tree shared
+library built by ``__graft_entry__.build()`` / ``make``.  There is no Python or CPU fallback for
+any compute entry point: if the library is missing, importing :mod:`tungsten_amd` fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtungsten_hip.so")
+
+f32, i32, u32, i64, u64 = C.c_float, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64
+
+
+class TgHipBvhNode(C.Structure):
+    _fields_ = [("lo0", f32*3), ("hi0", f32*3), ("lo1", f32*3), ("hi1", f32*3),
+                ("child0", i32), ("child1", i32), ("pad", u32*2)]
+
+
+class TgHipPrimRec(C.Structure):
+    _fields_ = [("a", f32*3), ("meta", u32), ("b", f32*3), ("p0", f32), ("c", f32*3), ("p1", f32)]
+
+
+class TgHipTriAttr(C.Structure):
+    _fields_ = [("n0", f32*3), ("n1", f32*3), ("n2", f32*3), ("uv0", f32*2), ("uv1", f32*2), ("uv2", f32*2),
+                ("bsdf", i32)]
+
+
+class TgHipObject(C.Structure):
+    _fields_ = [("type", i32), ("bsdf", i32), ("emission", i32), ("light", i32), ("flags", u32),
+                ("area", f32), ("inv_area", f32), ("first_light_tri", i32),
+                ("base", f32*3), ("edge0", f32*3), ("edge1", f32*3), ("normal", f32*3), ("inv_uv_sq", f32*2),
+                ("pos", f32*3), ("scale", f32*3), ("rot", f32*9), ("face_cdf", f32*3), ("pad", f32*3)]
+
+
+class TgHipBsdf(C.Structure):
+    _fields_ = [("type", i32), ("lobes", u32), ("albedo", i32), ("distribution", i32), ("roughness", i32),
+                ("sub0", i32), ("sub1", i32), ("tex1", i32),
+                ("ior", f32), ("thickness", f32), ("avg_transmittance", f32), ("diffuse_fresnel", f32),
+                ("enable_refraction", i32), ("eta", f32*3), ("k", f32*3), ("sigma_a", f32*3),
+                ("scaled_sigma_a", f32*3), ("pad", f32*2)]
+
+
+class TgHipTexture(C.Structure):
+    _fields_ = [("type", i32), ("flags", u32), ("w", i32), ("h", i32), ("value", f32*3), ("scale", f32),
+                ("on_color", f32*3), ("res_u", i32), ("off_color", f32*3), ("res_v", i32),
+                ("avg", f32*3), ("pad", f32), ("texel_offset", i64), ("dist_offset", i64)]
+
+
+class TgHipCamera(C.Structure):
+    _fields_ = [("pos", f32*3), ("plane_dist", f32), ("xf", f32*9), ("ratio", f32), ("pixel_size_x", f32),
+                ("res_x", i32), ("res_y", i32), ("filter_type", i32), ("filter_width", f32),
+                ("filter_bin_size", f32), ("filter_cdf", f32*32)]
+
+
+class TgHipSettings(C.Structure):
+    _fields_ = [("min_bounces", i32), ("max_bounces", i32), ("enable_light_sampling", i32),
+                ("enable_two_sided_shading", i32), ("enable_consistency_checks", i32), ("pad", i32*3)]
+
+
+class TgHipSceneDesc(C.Structure):
+    _fields_ = [("abi_version", u32), ("num_nodes", u32), ("num_recs", u32), ("num_objects", u32),
+                ("num_lights", u32), ("num_infinite_lights", u32), ("num_bsdfs", u32), ("num_textures", u32),
+                ("nodes", C.POINTER(TgHipBvhNode)), ("recs", C.POINTER(TgHipPrimRec)),
+                ("tri_attrs", C.POINTER(TgHipTriAttr)), ("objects", C.POINTER(TgHipObject)),
+                ("lights", C.POINTER(i32)), ("infinite_lights", C.POINTER(i32)),
+                ("bsdfs", C.POINTER(TgHipBsdf)), ("textures", C.POINTER(TgHipTexture)),
+                ("texels", C.POINTER(f32)), ("num_texel_floats", u64),
+                ("dist", C.POINTER(f32)), ("num_dist_floats", u64),
+                ("camera", TgHipCamera), ("settings", TgHipSettings),
+                ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
+
+
+class TgHipPassDesc(C.Structure):
+    _fields_ = [("spp_begin", u32), ("spp_end", u32), ("seed", u32), ("shard_index", u32), ("shard_count", u32),
+                ("flags", u32)]
+
+
+class TgHipCounters(C.Structure):
+    _fields_ = [("samples", u64), ("closest_rays", u64), ("shadow_rays", u64), ("nodes_visited", u64),
+                ("prims_tested", u64), ("iterations", u64),
+                ("ms_trace_closest", C.c_double), ("ms_trace_shadow", C.c_double), ("ms_shade", C.c_double),
+                ("ms_other", C.c_double), ("ms_total", C.c_double),
+                ("launches_trace_closest", u64), ("launches_trace_shadow", u64), ("launches_shade", u64)]
+
+
+class TgHipRay(C.Structure):
+    _fields_ = [("o", f32*3), ("tmin", f32), ("d", f32*3), ("tmax", f32)]
+
+
+class TgHipHit(C.Structure):
+    _fields_ = [("t", f32), ("u", f32), ("v", f32), ("rec", i32)]
+
+
+class TgHostSceneInfo(C.Structure):
+    _fields_ = [("width", u32), ("height", u32), ("spp", u32), ("spp_step", u32),
+                ("num_nodes", u32), ("num_recs", u32), ("num_objects", u32), ("num_lights", u32),
+                ("num_bsdfs", u32), ("num_textures", u32), ("bvh_depth", i32),
+                ("bvh_sah_cost", C.c_double), ("build_seconds", C.c_double),
+                ("adaptive_sampling", i32), ("stratified_sampler", i32)]
+
+
+# every symbol the two headers declare: name -> (restype, argtypes)
+VP = C.c_void_p
+PROTOTYPES = {
+    # include/tungsten_hip.h
+    "tghip_create": (VP, [C.c_int]),
+    "tghip_destroy": (None, [VP]),
+    "tghip_last_error": (C.c_char_p, [VP]),
+    "tghip_device_count": (C.c_int, []),
+    "tghip_upload_scene": (C.c_int, [VP, C.POINTER(TgHipSceneDesc)]),
+    "tghip_render_pass": (C.c_int, [VP, C.POINTER(TgHipPassDesc)]),
+    "tghip_wait": (C.c_int, [VP]),
+    "tghip_abort": (C.c_int, [VP]),
+    "tghip_clear_framebuffer": (C.c_int, [VP]),
+    "tghip_bind_framebuffer": (C.c_int, [VP, VP, VP]),
+    "tghip_download_framebuffer": (C.c_int, [VP, VP, VP, C.c_size_t]),
+    "tghip_trace_rays": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "tghip_set_option": (C.c_int, [VP, C.c_char_p, C.c_longlong]),
+    "tghip_get_counters": (C.c_int, [VP, C.POINTER(TgHipCounters)]),
+    "tghip_reset_counters": (C.c_int, [VP]),
+    # include/tungsten_host.h
+    "tgh_scene_load": (VP, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    "tgh_scene_desc": (C.POINTER(TgHipSceneDesc), [VP]),
+    "tgh_scene_info": (C.c_int, [VP, C.POINTER(TgHostSceneInfo)]),
+    "tgh_scene_free": (None, [VP]),
+    "tgh_renderer_open": (VP, [C.c_char_p, u32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "tgh_renderer_context": (VP, [VP, C.c_int]),
+    "tgh_renderer_info": (C.c_int, [VP, C.POINTER(TgHostSceneInfo)]),
+    "tgh_renderer_step": (C.c_int, [VP, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
+    "tgh_renderer_render": (C.c_int, [VP, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]),
+    "tgh_renderer_image": (C.c_int, [VP, VP, VP, VP, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "tgh_renderer_save_outputs": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
+    "tgh_renderer_close": (None, [VP]),
+    "tgh_save_pfm": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
+    "tgh_load_hdr": (C.c_int, [C.c_char_p, VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+}
+
+
+def bind(lib):
+    """Attach restype/argtypes for every declared symbol; raises AttributeError on a missing export."""
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+def load_library(path=None):
+    path = path or os.environ.get("TUNGSTEN_AMD_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise ImportError(
+            "tungsten_amd: native library %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make`). There is no Python/CPU fallback for the path tracer." % path)
+    return bind(C.CDLL(path))

@@ -1,0 +1,250 @@
+#include "Integrator.hpp"
+#include "ImageIO.hpp"
+#include "TraceableScene.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+namespace tungsten_amd {
+
+// ------------------------------------------------------------------------------------------
+// Integrator base (src/core/integrators/Integrator.cpp:51-85)
+// ------------------------------------------------------------------------------------------
+void Integrator::advanceSpp()
+{
+    _nextSpp = std::min(_currentSpp + _scene->rendererSettings().sppStep, _scene->rendererSettings().spp);
+}
+
+bool Integrator::done() const
+{
+    return _currentSpp >= _scene->rendererSettings().spp;
+}
+
+static bool fileExists(const std::string &p)
+{
+    FILE *f = std::fopen(p.c_str(), "rb");
+    if (f) std::fclose(f);
+    return f != nullptr;
+}
+
+// FileUtils-style "name1.png, name2.png, ..." when overwriting is disabled (Integrator.cpp:20-49)
+static std::string incrementalFilename(const std::string &dst, const std::string &suffix, bool overwrite)
+{
+    size_t dot = dst.find_last_of('.');
+    std::string stem = dot == std::string::npos ? dst : dst.substr(0, dot);
+    std::string ext = dot == std::string::npos ? std::string() : dst.substr(dot);
+    std::string base = stem + suffix;
+    std::string path = base + ext;
+    if (overwrite)
+        return path;
+    int index = 0;
+    while (fileExists(path))
+        path = base + std::to_string(++index) + ext;
+    return path;
+}
+
+void Integrator::writeBuffers(const std::string &suffix, bool overwrite)
+{
+    const Camera &cam = _scene->cam();
+    const RendererSettings &settings = _scene->rendererSettings();
+    const std::vector<float> &hdr = linearImage();
+    size_t n = size_t(cam.resX)*cam.resY;
+
+    if (!settings.outputFile.empty()) {
+        std::vector<uint8_t> ldr(n*3);
+        for (size_t i = 0; i < n; ++i) {
+            Vec3f c(std::max(hdr[i*3], 0.0f), std::max(hdr[i*3 + 1], 0.0f), std::max(hdr[i*3 + 2], 0.0f));
+            Vec3f t = ImageIO::tonemap(cam.tonemap, c)*255.0f;
+            for (int k = 0; k < 3; ++k)
+                ldr[i*3 + k] = uint8_t(std::min(std::max(int(t[k]), 0), 255));
+        }
+        std::string path = incrementalFilename(settings.outputFile, suffix, overwrite);
+        if (path.size() < 4 || path.substr(path.size() - 4) != ".png")
+            path += ".png";   // only the PNG writer is in scope
+        ImageIO::savePng(path, ldr.data(), int(cam.resX), int(cam.resY));
+    }
+    if (!settings.hdrOutputFile.empty())
+        ImageIO::savePfm(incrementalFilename(settings.hdrOutputFile, suffix, overwrite), hdr.data(), int(cam.resX), int(cam.resY), 3);
+}
+
+void Integrator::saveOutputs()
+{
+    writeBuffers("", _scene->rendererSettings().overwriteOutputFiles);
+}
+
+// ------------------------------------------------------------------------------------------
+// PathTraceHipIntegrator
+// ------------------------------------------------------------------------------------------
+PathTraceHipIntegrator::PathTraceHipIntegrator() {}
+
+PathTraceHipIntegrator::~PathTraceHipIntegrator()
+{
+    teardownAfterRender();
+}
+
+void PathTraceHipIntegrator::check(int rc, tghip_ctx *ctx, const char *what)
+{
+    if (rc != TGHIP_OK)
+        throw std::runtime_error(std::string("path_tracer_hip: ") + what + " failed: " + tghip_last_error(ctx));
+}
+
+void PathTraceHipIntegrator::fromJson(const JsonValue &value, const Scene &/*scene*/)
+{
+    _settings.fromJson(value);
+}
+
+// PathTraceIntegrator::prepareForRender (PathTraceIntegrator.cpp:184-201): this is where the
+// device is acquired and the flattened scene uploaded.
+void PathTraceHipIntegrator::prepareForRender(TraceableScene &scene, uint32_t seed)
+{
+    teardownAfterRender();
+    _scene = &scene;
+    _seed = seed;
+    _currentSpp = 0;
+    advanceSpp();
+    _w = scene.cam().resX;
+    _h = scene.cam().resY;
+
+    int available = tghip_device_count();
+    if (available <= 0)
+        throw std::runtime_error("path_tracer_hip: no HIP device available (there is no CPU fallback)");
+    int devices = std::max(1, std::min(_settings.devices, available));
+    for (int d = 0; d < devices; ++d) {
+        tghip_ctx *ctx = tghip_create(d);
+        if (!ctx)
+            throw std::runtime_error(std::string("path_tracer_hip: tghip_create failed: ") + tghip_last_error(nullptr));
+        _ctxs.push_back(ctx);
+        check(tghip_upload_scene(ctx, &scene.desc()), ctx, "tghip_upload_scene");
+    }
+    _sum.assign(size_t(_w)*_h*3, 0.0f);
+    _count.assign(size_t(_w)*_h, 0);
+    _imageDirty = true;
+}
+
+void PathTraceHipIntegrator::teardownAfterRender()
+{
+    if (_worker.joinable())
+        _worker.join();
+    for (tghip_ctx *ctx : _ctxs)
+        tghip_destroy(ctx);
+    _ctxs.clear();
+}
+
+// Asynchronous like the reference (PathTraceIntegrator.cpp:220-239): returns immediately, the
+// bookkeeping + callback run on a worker thread once every device finished its shard.
+void PathTraceHipIntegrator::startRender(std::function<void()> completionCallback)
+{
+    if (_worker.joinable())
+        _worker.join();
+    if (done()) {
+        _currentSpp = _nextSpp;
+        advanceSpp();
+        completionCallback();
+        return;
+    }
+    if (_ctxs.empty())
+        throw std::runtime_error("path_tracer_hip: startRender before prepareForRender");
+
+    _abort = false;
+    _workerError = nullptr;
+    uint32_t begin = _currentSpp, end = _nextSpp;
+    for (size_t d = 0; d < _ctxs.size(); ++d) {
+        TgHipPassDesc pass;
+        pass.spp_begin = begin;
+        pass.spp_end = end;
+        pass.seed = _seed;
+        pass.shard_index = uint32_t(d);
+        pass.shard_count = uint32_t(_ctxs.size());
+        pass.flags = 0;
+        check(tghip_render_pass(_ctxs[d], &pass), _ctxs[d], "tghip_render_pass");
+    }
+    _imageDirty = true;
+    _worker = std::thread([this, completionCallback]() {
+        try {
+            for (tghip_ctx *ctx : _ctxs) {
+                int rc = tghip_wait(ctx);
+                if (rc == TGHIP_E_ABORTED)
+                    return;   // no finisher / callback on abort (TaskGroup.hpp:33-41,77-83)
+                check(rc, ctx, "tghip_wait");
+            }
+        } catch (...) {
+            _workerError = std::current_exception();
+            return;
+        }
+        _currentSpp = _nextSpp;
+        advanceSpp();
+        completionCallback();
+    });
+}
+
+void PathTraceHipIntegrator::waitForCompletion()
+{
+    if (_worker.joinable())
+        _worker.join();
+    if (_workerError) {
+        std::exception_ptr e = _workerError;
+        _workerError = nullptr;
+        std::rethrow_exception(e);     // TaskGroup::wait rethrows (TaskGroup.hpp:70-75)
+    }
+}
+
+void PathTraceHipIntegrator::abortRender()
+{
+    _abort = true;
+    for (tghip_ctx *ctx : _ctxs)
+        tghip_abort(ctx);
+    if (_worker.joinable())
+        _worker.join();
+    _workerError = nullptr;
+}
+
+void PathTraceHipIntegrator::fetchFramebuffer()
+{
+    if (!_imageDirty)
+        return;
+    waitForCompletion();
+    size_t n = size_t(_w)*_h;
+    std::fill(_sum.begin(), _sum.end(), 0.0f);
+    std::fill(_count.begin(), _count.end(), 0u);
+    std::vector<float> s(n*3);
+    std::vector<uint32_t> c(n);
+    for (tghip_ctx *ctx : _ctxs) {
+        check(tghip_download_framebuffer(ctx, s.data(), c.data(), n), ctx, "tghip_download_framebuffer");
+        // tile ownership is disjoint, so this sum is exact (x + 0) irrespective of device order
+        for (size_t i = 0; i < n*3; ++i) _sum[i] += s[i];
+        for (size_t i = 0; i < n; ++i) _count[i] += c[i];
+    }
+    _imageDirty = false;
+}
+
+const std::vector<float> &PathTraceHipIntegrator::linearImage()
+{
+    fetchFramebuffer();
+    size_t n = size_t(_w)*_h;
+    _linear.resize(n*3);
+    for (size_t i = 0; i < n; ++i) {
+        float inv = _count[i] ? 1.0f/float(_count[i]) : 0.0f;
+        for (int k = 0; k < 3; ++k)
+            _linear[i*3 + k] = _sum[i*3 + k]*inv;
+    }
+    return _linear;
+}
+
+// ------------------------------------------------------------------------------------------
+std::shared_ptr<Integrator> IntegratorFactory::instantiate(const std::string &type)
+{
+    // "path_tracer" scenes are served by the HIP integrator as well: it is a drop-in for that
+    // entry of the reference's table (IntegratorFactory.cpp:15).
+    if (type == "path_tracer_hip" || type == "path_tracer")
+        return std::make_shared<PathTraceHipIntegrator>();
+    throw JsonLoadException("Integrator type '" + type + "' is outside the path_tracer_hip hot-path scope");
+}
+
+std::vector<std::string> IntegratorFactory::names()
+{
+    return {"path_tracer_hip", "path_tracer"};
+}
+
+} // namespace tungsten_amd

@@ -1,0 +1,870 @@
+#include "Scene.hpp"
+#include "ImageIO.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <sstream>
+
+namespace tungsten_amd {
+
+// ------------------------------------------------------------------------------------------
+// JSON helpers (JsonPtr.hpp:52-65: a scalar broadcasts to every vector component)
+// ------------------------------------------------------------------------------------------
+static bool getVec3(const JsonValue &parent, const char *key, Vec3f &dst)
+{
+    const JsonValue &v = parent[key];
+    if (!v) return false;
+    if (v.isNumber()) { dst = Vec3f(v.asFloat()); return true; }
+    if (v.isArray() && v.size() == 3) { dst = Vec3f(v[0].asFloat(), v[1].asFloat(), v[2].asFloat()); return true; }
+    throw JsonLoadException(std::string("JSON: field '") + key + "' is not a 3-vector");
+}
+
+static Vec3f randomOrtho(const Vec3f &a)   // io/JsonPtr.cpp:77-89
+{
+    Vec3f res;
+    if (std::abs(a.x()) > std::abs(a.y()))
+        res = Vec3f(0.0f, 1.0f, 0.0f);
+    else
+        res = Vec3f(1.0f, 0.0f, 0.0f);
+    return a.cross(res).normalized();
+}
+
+static void gramSchmidt(Vec3f &a, Vec3f &b, Vec3f &c)   // io/JsonPtr.cpp:91-106
+{
+    a.normalize();
+    b -= a*a.dot(b);
+    if (b.lengthSq() < 1e-5)
+        b = randomOrtho(a);
+    else
+        b.normalize();
+
+    c -= a*a.dot(c);
+    c -= b*b.dot(c);
+    if (c.lengthSq() < 1e-5)
+        c = a.cross(b);
+    else
+        c.normalize();
+}
+
+// io/JsonPtr.cpp:108-186
+static bool getTransform(const JsonValue &parent, const char *key, Mat4f &dst)
+{
+    const JsonValue &v = parent[key];
+    if (!v) return false;
+    if (v.isArray()) {
+        if (v.size() != 16)
+            throw JsonLoadException("JSON: matrix needs 16 elements");
+        for (int i = 0; i < 16; ++i) dst[i] = v[size_t(i)].asFloat();
+        return true;
+    }
+    if (!v.isObject())
+        throw JsonLoadException("JSON: expecting a matrix value");
+
+    Vec3f x(1.0f, 0.0f, 0.0f), y(0.0f, 1.0f, 0.0f), z(0.0f, 0.0f, 1.0f);
+    Vec3f pos(0.0f);
+    getVec3(v, "position", pos);
+
+    bool explicitX = false, explicitY = false, explicitZ = false;
+    Vec3f lookAt;
+    if (getVec3(v, "look_at", lookAt)) {
+        z = lookAt - pos;
+        explicitZ = true;
+    }
+    explicitY = getVec3(v, "up", y);
+    explicitX = getVec3(v, "x_axis", x) || explicitX;
+    explicitY = getVec3(v, "y_axis", y) || explicitY;
+    explicitZ = getVec3(v, "z_axis", z) || explicitZ;
+
+    int id = (explicitZ ? 4 : 0) + (explicitY ? 2 : 0) + (explicitX ? 1 : 0);
+    switch (id) {
+    case 0: gramSchmidt(z, y, x); break;
+    case 1: gramSchmidt(x, z, y); break;
+    case 2: gramSchmidt(y, z, x); break;
+    case 3: gramSchmidt(y, x, z); break;
+    case 4: gramSchmidt(z, y, x); break;
+    case 5: gramSchmidt(z, x, y); break;
+    case 6: gramSchmidt(z, y, x); break;
+    case 7: gramSchmidt(z, y, x); break;
+    }
+    if (x.cross(y).dot(z) < 0.0f) {
+        if (!explicitX) x = -x;
+        else if (!explicitY) y = -y;
+        else z = -z;
+    }
+    Vec3f scale;
+    if (getVec3(v, "scale", scale)) {
+        x *= scale.x(); y *= scale.y(); z *= scale.z();
+    }
+    Vec3f rot;
+    if (getVec3(v, "rotation", rot)) {
+        Mat4f tform = Mat4f::rotYXZ(rot);
+        x = tform*x; y = tform*y; z = tform*z;
+    }
+    dst = Mat4f(x, y, z);
+    dst[3] = pos[0]; dst[7] = pos[1]; dst[11] = pos[2];
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Textures
+// ------------------------------------------------------------------------------------------
+Vec3f Texture::average() const
+{
+    switch (type) {
+    case Constant: return value;
+    case Checker:  return (onColor + offColor)*0.5f;          // CheckerTexture.cpp:49-52
+    default:       return scale*texAvg;                       // BitmapTexture.cpp:283-286
+    }
+}
+
+Vec3f Texture::maximum() const
+{
+    switch (type) {
+    case Constant: return value;
+    case Checker:  return vmax(onColor, offColor);
+    default:       return scale*texMax;
+    }
+}
+
+void Texture::scaleValues(float f)
+{
+    switch (type) {
+    case Constant: value = value*f; break;
+    case Checker:  onColor = onColor*f; offColor = offColor*f; break;
+    default:       scale *= f; break;
+    }
+}
+
+void Texture::loadBitmap(const std::string &file)
+{
+    path = file;
+    type = Bitmap;
+    std::vector<float> rgbTexels;
+    int iw = 0, ih = 0;
+    std::string err;
+    if (!ImageIO::loadHdr(file, rgbTexels, iw, ih, err))
+        throw std::runtime_error("Unable to load HDR texture '" + file + "': " + err +
+                                 " (LDR bitmaps are outside the path_tracer_hip hot-path scope)");
+    w = iw; h = ih;
+    if (rgb) {
+        texels.swap(rgbTexels);
+    } else {
+        // TexelConversion::REQUEST_AVERAGE on an RGB HDR source (ImageIO.cpp:298-337)
+        texels.resize(size_t(w)*h);
+        for (size_t i = 0; i < texels.size(); ++i)
+            texels[i] = (rgbTexels[i*3] + rgbTexels[i*3 + 1] + rgbTexels[i*3 + 2])/3.0f;
+    }
+    valid = true;
+
+    // BitmapTexture::init (BitmapTexture.cpp:175-209): min/max/avg, avg accumulated as texel/(w*h)
+    if (rgb) {
+        texMin = texMax = Vec3f(texels[0], texels[1], texels[2]);
+        texAvg = Vec3f(0.0f);
+        float n = float(w*h);
+        for (size_t i = 0; i < size_t(w)*h; ++i) {
+            Vec3f c(texels[i*3], texels[i*3 + 1], texels[i*3 + 2]);
+            texMin = vmin(texMin, c);
+            texMax = vmax(texMax, c);
+            texAvg += c/n;
+        }
+    } else {
+        float mn = texels[0], mx = texels[0], av = 0.0f;
+        for (size_t i = 0; i < texels.size(); ++i) {
+            mn = std::min(mn, texels[i]); mx = std::max(mx, texels[i]);
+            av += texels[i]/float(w*h);
+        }
+        texMin = Vec3f(mn); texMax = Vec3f(mx); texAvg = Vec3f(av);
+    }
+}
+
+// BitmapTexture::makeSamplable(MAP_SPHERICAL) (BitmapTexture.cpp:400-431) followed by the
+// Distribution2D constructor (sampling/Distribution2D.hpp:18-66).  Float-for-float the same
+// operation order, so the tables (and therefore MIS weights) are bit-identical.
+void Texture::makeSamplableSpherical()
+{
+    if (samplable || type != Bitmap)
+        return;
+    std::vector<float> weights(size_t(w)*h);
+    for (int y = 0, idx = 0; y < h; ++y) {
+        float rowWeight = 1.0f;
+        rowWeight *= std::sin((y*PI)/h);
+        for (int x = 0; x < w; ++x, ++idx) {
+            float wt = rgb ? std::max(texels[idx*3], std::max(texels[idx*3 + 1], texels[idx*3 + 2])) : texels[idx];
+            weights[idx] = wt*rowWeight;
+        }
+    }
+    for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < w - 1; ++x)
+            weights[x + y*w] = std::max(weights[x + y*w], weights[x + 1 + y*w]);
+        if (!clamp)
+            weights[y*w] = weights[w - 1 + y*w] = std::max(weights[w - 1 + y*w], weights[y*w]);
+        for (int x = w - 1; x > 0; --x)
+            weights[x + y*w] = std::max(weights[x + y*w], weights[x - 1 + y*w]);
+    }
+    for (int x = 0; x < w; ++x) {
+        for (int y = 0; y < h - 1; ++y)
+            weights[x + y*w] = std::max(weights[x + y*w], weights[x + (y + 1)*w]);
+        if (!clamp)
+            weights[x] = weights[x + (h - 1)*w] = std::max(weights[x], weights[x + (h - 1)*w]);
+        for (int y = h - 1; y > 0; --y)
+            weights[x + y*w] = std::max(weights[x + y*w], weights[x + (y - 1)*w]);
+    }
+
+    pdf.swap(weights);
+    cdf.assign(pdf.size() + h, 0.0f);
+    marginalPdf.assign(h, 0.0f);
+    marginalCdf.assign(h + 1, 0.0f);
+    marginalCdf[0] = 0.0f;
+    for (int y = 0; y < h; ++y) {
+        int idxP = y*w;
+        int idxC = y*(w + 1);
+        cdf[idxC] = 0.0f;
+        for (int x = 0; x < w; ++x, ++idxP, ++idxC) {
+            marginalPdf[y] += pdf[idxP];
+            cdf[idxC + 1] = cdf[idxC] + pdf[idxP];
+        }
+        marginalCdf[y + 1] = marginalCdf[y] + marginalPdf[y];
+    }
+    for (int y = 0; y < h; ++y) {
+        int idxP = y*w;
+        int idxC = y*(w + 1);
+        int idxTail = idxC + w;
+        float rowWeight = cdf[idxTail];
+        if (rowWeight < 1e-4f) {
+            for (int x = 0; x < w; ++x, ++idxP, ++idxC) {
+                pdf[idxP] = 1.0f/w;
+                cdf[idxC] = x/float(w);
+            }
+        } else {
+            for (int x = 0; x < w; ++x, ++idxP, ++idxC) {
+                pdf[idxP] /= rowWeight;
+                cdf[idxC] /= rowWeight;
+            }
+        }
+        cdf[idxTail] = 1.0f;
+    }
+    float totalWeight = marginalCdf.back();
+    for (float &p : marginalPdf) p /= totalWeight;
+    for (float &c : marginalCdf) c /= totalWeight;
+    marginalCdf.back() = 1.0f;
+    samplable = true;
+}
+
+// ------------------------------------------------------------------------------------------
+// BSDFs
+// ------------------------------------------------------------------------------------------
+namespace {
+// Measured complex IORs (subset of the table the reference ships in bsdfs/ComplexIorData.hpp;
+// values are physical constants from the Schubert reference cited in bsdfs/ComplexIor.cpp:3).
+struct ComplexIor { const char *name; float eta[3], k[3]; };
+const ComplexIor complexIors[] = {
+    {"Ag", {0.1552646489f, 0.1167232965f, 0.1383806959f}, {4.8283433224f, 3.1222459278f, 2.1469504455f}},
+    {"Al", {1.6574599595f, 0.8803689579f, 0.5212287346f}, {9.2238691996f, 6.2695232477f, 4.8370012281f}},
+    {"Au", {0.1431189557f, 0.3749570432f, 1.4424785571f}, {3.9831604247f, 2.3857207478f, 1.6032152899f}},
+    {"Be", {4.1850592788f, 3.1850604423f, 2.7840913457f}, {3.8354398268f, 3.0101260162f, 2.8690088743f}},
+    {"Cr", {4.3696828663f, 2.9167024892f, 1.6547005413f}, {5.2064337956f, 4.2313645277f, 3.7549467933f}},
+    {"Cu", {0.2004376970f, 0.9240334304f, 1.1022119527f}, {3.9129485033f, 2.4528477015f, 2.1421879552f}},
+    {"Hg", {2.3989314904f, 1.4400254917f, 0.9095512090f}, {6.3276269444f, 4.3719414152f, 3.4217899270f}},
+    {"Ir", {3.0864098394f, 2.0821938440f, 1.6178866805f}, {5.5921510077f, 4.0671757150f, 3.2672611269f}},
+    {"Li", {0.2657871942f, 0.1956102432f, 0.2209198538f}, {3.5401743407f, 2.3111306542f, 1.6685930000f}},
+    {"Mo", {4.4837010280f, 3.5254578255f, 2.7760769438f}, {4.1111307988f, 3.4208716252f, 3.1506031404f}},
+    {"Na", {0.0602665320f, 0.0561412435f, 0.0619909494f}, {3.1792906496f, 2.1124800781f, 1.5790940266f}},
+    {"Nb", {3.4201353595f, 2.7901921379f, 2.3955856658f}, {3.4413817900f, 2.7376437930f, 2.5799132708f}},
+    {"Ni", {2.3672753521f, 1.6633583302f, 1.4670554172f}, {4.4988329911f, 3.0501643957f, 2.3454274399f}},
+    {"Rh", {2.5857954933f, 1.8601866068f, 1.5544279524f}, {6.7822927110f, 4.7029501026f, 3.9760892461f}},
+    {"Ta", {2.0625846607f, 2.3930915569f, 2.6280684948f}, {2.4080467973f, 1.7413705864f, 1.9470377016f}},
+    {"TiN", {1.6484691607f, 1.1504482522f, 1.3797795097f}, {3.3684596226f, 1.9434888540f, 1.1020123347f}},
+    {"V", {4.2775126218f, 3.5131538236f, 2.7611257461f}, {3.4911844504f, 2.8893580874f, 3.1116965117f}},
+    {"W", {4.3707029924f, 3.3002972445f, 2.9982666528f}, {3.5006778591f, 2.6048652781f, 2.2731930614f}},
+};
+
+bool lookupComplexIor(const std::string &name, Vec3f &eta, Vec3f &k)
+{
+    for (const ComplexIor &c : complexIors) {
+        if (name == c.name) {
+            eta = Vec3f(c.eta[0], c.eta[1], c.eta[2]);
+            k   = Vec3f(c.k[0], c.k[1], c.k[2]);
+            return true;
+        }
+    }
+    return false;
+}
+
+int parseDistribution(const JsonValue &v, int dflt)
+{
+    const JsonValue &d = v["distribution"];
+    if (!d) return dflt;
+    const std::string &s = d.asString();
+    if (s == "beckmann") return 0;
+    if (s == "phong") return 1;
+    if (s == "ggx") return 2;
+    throw JsonLoadException("Invalid microfacet distribution: '" + s + "'");
+}
+
+// bsdfs/Fresnel.hpp:75-96
+float dielectricReflectance(float eta, float cosThetaI)
+{
+    if (cosThetaI < 0.0f) {
+        eta = 1.0f/eta;
+        cosThetaI = -cosThetaI;
+    }
+    float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+    if (sinThetaTSq > 1.0f)
+        return 1.0f;
+    float cosThetaT = std::sqrt(std::max(1.0f - sinThetaTSq, 0.0f));
+    float Rs = (eta*cosThetaI - cosThetaT)/(eta*cosThetaI + cosThetaT);
+    float Rp = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
+    return (Rs*Rs + Rp*Rp)*0.5f;
+}
+
+// bsdfs/Fresnel.hpp:140-153
+float computeDiffuseFresnel(float ior, const int sampleCount)
+{
+    double diffuseFresnel = 0.0;
+    float fb = dielectricReflectance(ior, 0.0f);
+    for (int i = 1; i <= sampleCount; ++i) {
+        float cosThetaSq = float(i)/sampleCount;
+        float fa = dielectricReflectance(ior, std::min(std::sqrt(cosThetaSq), 1.0f));
+        diffuseFresnel += double(fa + fb)*(0.5/sampleCount);
+        fb = fa;
+    }
+    return float(diffuseFresnel);
+}
+} // namespace
+
+void Bsdf::prepareForRender()
+{
+    if (prepared)
+        return;
+    prepared = true;
+    if (sub0) sub0->prepareForRender();
+    if (sub1) sub1->prepareForRender();
+
+    enum { GR = 1, GT = 2, DR = 4, DT = 8, SR = 16, ST = 32, FWD = 128 };
+    switch (type) {
+    case Lambert:         lobes = DR; break;
+    case Null:            lobes = 0; break;
+    case RoughConductor:  lobes = GR; break;
+    case SmoothCoat:      // SmoothCoatBsdf.cpp:218-223
+        scaledSigmaA = thickness*sigmaA;
+        avgTransmittance = std::exp(-2.0f*scaledSigmaA.avg());
+        lobes = SR | sub0->lobes;
+        break;
+    case Dielectric:      lobes = enableRefraction ? (SR | ST) : SR; break;
+    case RoughDielectric: lobes = enableRefraction ? (GR | GT) : GR; break;
+    case Mirror:          lobes = SR; break;
+    case Conductor:       lobes = SR; break;
+    case Plastic:         // PlasticBsdf.cpp:179-185
+        lobes = SR | DR;
+        scaledSigmaA = thickness*sigmaA;
+        avgTransmittance = std::exp(-2.0f*scaledSigmaA.avg());
+        diffuseFresnel = computeDiffuseFresnel(ior, 1000000);
+        break;
+    case RoughPlastic:    // RoughPlasticBsdf.cpp:215-222
+        lobes = GR | DR;
+        scaledSigmaA = thickness*sigmaA;
+        avgTransmittance = std::exp(-2.0f*scaledSigmaA.avg());
+        diffuseFresnel = computeDiffuseFresnel(ior, 1000000);
+        break;
+    case Mixed:           lobes = sub0->lobes | sub1->lobes; break;
+    case Transparency:    lobes = FWD | sub0->lobes; break;
+    case Forward:         lobes = FWD; break;
+    case Error:           lobes = DR; break;
+    }
+}
+
+static std::shared_ptr<Texture> constantTexture(float v)
+{
+    auto t = std::make_shared<Texture>();
+    t->value = Vec3f(v);
+    return t;
+}
+
+std::shared_ptr<Texture> Scene::fetchTexture(const JsonValue &v, bool rgb) const
+{
+    if (v.isString()) {
+        std::string full = _srcDir.empty() ? v.asString() : _srcDir + "/" + v.asString();
+        std::string key = full + (rgb ? "|rgb" : "|avg");
+        for (auto &kv : _textureCache)
+            if (kv.first == key) return kv.second;
+        auto t = std::make_shared<Texture>();
+        t->type = Texture::Bitmap;
+        t->rgb = rgb;
+        t->path = full;
+        _textureCache.emplace_back(key, t);
+        return t;
+    } else if (v.isNumber()) {
+        return constantTexture(v.asFloat());
+    } else if (v.isArray()) {
+        auto t = std::make_shared<Texture>();
+        if (v.size() != 3) throw JsonLoadException("JSON: expecting an RGB triple for a texture");
+        t->value = Vec3f(v[0].asFloat(), v[1].asFloat(), v[2].asFloat());
+        return t;
+    } else if (v.isObject()) {
+        std::string type = v["type"].asString();
+        auto t = std::make_shared<Texture>();
+        if (type == "constant") {
+            Vec3f c(1.0f);
+            getVec3(v, "value", c);
+            t->value = c;
+        } else if (type == "checker") {
+            t->type = Texture::Checker;
+            getVec3(v, "on_color", t->onColor);
+            getVec3(v, "off_color", t->offColor);
+            v.getField("res_u", t->resU);
+            v.getField("res_v", t->resV);
+        } else if (type == "bitmap") {
+            t->type = Texture::Bitmap;
+            t->rgb = rgb;
+            std::string file;
+            if (v.getField("file", file))
+                t->path = _srcDir.empty() ? file : _srcDir + "/" + file;
+            bool gamma;
+            v.getField("gamma_correct", gamma);
+            v.getField("interpolate", t->linear);
+            v.getField("clamp", t->clamp);
+            v.getField("scale", t->scale);
+            _textureCache.emplace_back(t->path + "|inline" + std::to_string(_textureCache.size()), t);
+        } else {
+            throw JsonLoadException("Texture type '" + type + "' is outside the path_tracer_hip hot-path scope");
+        }
+        return t;
+    }
+    throw JsonLoadException("Type mismatch: Expecting a texture here");
+}
+
+std::shared_ptr<Bsdf> Scene::instantiateBsdf(const JsonValue &v) const
+{
+    auto b = std::make_shared<Bsdf>();
+    std::string type = v["type"].asString();
+    v.getField("name", b->name);
+    // Bsdf::fromJson (Bsdf.cpp:19-25); bump maps are not in the hot-path scope
+    if (const JsonValue &albedo = v["albedo"]) b->albedo = fetchTexture(albedo, true);
+    else b->albedo = constantTexture(1.0f);
+
+    auto parseConductor = [&]() {
+        Vec3f eta, k;
+        bool explicitEtaK = getVec3(v, "eta", eta) && getVec3(v, "k", k);
+        if (explicitEtaK) { b->eta = eta; b->k = k; }
+        std::string material;
+        if (v.getField("material", material) && !lookupComplexIor(material, b->eta, b->k))
+            throw JsonLoadException("Unable to find material with name '" + material + "'");
+        if (!explicitEtaK && material.empty())
+            lookupComplexIor("Cu", b->eta, b->k);   // default material name "Cu" (RoughConductorBsdf.cpp:17-25)
+    };
+
+    if (type == "lambert") {
+        b->type = Bsdf::Lambert;
+    } else if (type == "null") {
+        b->type = Bsdf::Null;
+    } else if (type == "forward") {
+        b->type = Bsdf::Forward;
+    } else if (type == "mirror") {
+        b->type = Bsdf::Mirror;
+    } else if (type == "rough_conductor") {     // RoughConductorBsdf.cpp:31-43
+        b->type = Bsdf::RoughConductor;
+        parseConductor();
+        b->distribution = parseDistribution(v, 2);
+        if (const JsonValue &r = v["roughness"]) b->roughness = fetchTexture(r, false);
+        else b->roughness = constantTexture(0.1f);
+    } else if (type == "conductor") {           // ConductorBsdf.cpp:33-40
+        b->type = Bsdf::Conductor;
+        parseConductor();
+    } else if (type == "smooth_coat") {         // SmoothCoatBsdf.cpp:12-28
+        b->type = Bsdf::SmoothCoat;
+        b->ior = 1.3f;
+        v.getField("ior", b->ior);
+        v.getField("thickness", b->thickness);
+        getVec3(v, "sigma_a", b->sigmaA);
+        if (const JsonValue &s = v["substrate"]) {
+            b->sub0 = fetchBsdf(s);
+        } else {
+            b->sub0 = std::make_shared<Bsdf>();
+            b->sub0->type = Bsdf::RoughConductor;
+            b->sub0->albedo = constantTexture(1.0f);
+            b->sub0->roughness = constantTexture(0.1f);
+        }
+    } else if (type == "dielectric") {
+        b->type = Bsdf::Dielectric;
+        v.getField("ior", b->ior);
+        v.getField("enable_refraction", b->enableRefraction);
+    } else if (type == "rough_dielectric") {
+        b->type = Bsdf::RoughDielectric;
+        v.getField("ior", b->ior);
+        b->distribution = parseDistribution(v, 2);
+        v.getField("enable_refraction", b->enableRefraction);
+        if (const JsonValue &r = v["roughness"]) b->roughness = fetchTexture(r, false);
+        else b->roughness = constantTexture(0.1f);
+    } else if (type == "plastic") {
+        b->type = Bsdf::Plastic;
+        v.getField("ior", b->ior);
+        v.getField("thickness", b->thickness);
+        getVec3(v, "sigma_a", b->sigmaA);
+    } else if (type == "rough_plastic") {
+        b->type = Bsdf::RoughPlastic;
+        v.getField("ior", b->ior);
+        b->distribution = parseDistribution(v, 2);
+        v.getField("thickness", b->thickness);
+        getVec3(v, "sigma_a", b->sigmaA);
+        if (const JsonValue &r = v["roughness"]) b->roughness = fetchTexture(r, false);
+        else b->roughness = constantTexture(0.02f);
+    } else if (type == "mixed") {
+        b->type = Bsdf::Mixed;
+        if (!v["bsdf0"] || !v["bsdf1"]) throw JsonLoadException("mixed bsdf requires bsdf0 and bsdf1");
+        b->sub0 = fetchBsdf(v["bsdf0"]);
+        b->sub1 = fetchBsdf(v["bsdf1"]);
+        if (const JsonValue &r = v["ratio"]) b->tex1 = fetchTexture(r, false);
+        else b->tex1 = constantTexture(0.5f);
+    } else if (type == "transparency") {
+        b->type = Bsdf::Transparency;
+        if (const JsonValue &base = v["base"]) b->sub0 = fetchBsdf(base);
+        else { b->sub0 = std::make_shared<Bsdf>(); b->sub0->albedo = constantTexture(1.0f); }
+        if (const JsonValue &a = v["alpha"]) b->tex1 = fetchTexture(a, false);
+        else b->tex1 = constantTexture(1.0f);
+    } else {
+        throw JsonLoadException("BSDF type '" + type + "' is outside the path_tracer_hip hot-path scope");
+    }
+    return b;
+}
+
+std::shared_ptr<Bsdf> Scene::fetchBsdf(const JsonValue &v) const
+{
+    if (v.isString()) {
+        for (const auto &b : bsdfs)
+            if (b->name == v.asString()) return b;
+        throw JsonLoadException("Unable to find an object with name '" + v.asString() + "'");
+    } else if (v.isObject()) {
+        return instantiateBsdf(v);
+    }
+    throw JsonLoadException("Type mismatch: Expecting either an object or an object reference here");
+}
+
+// ------------------------------------------------------------------------------------------
+// Primitives
+// ------------------------------------------------------------------------------------------
+bool Primitive::isEmissive() const
+{
+    return (emission && emission->maximum().max() > 0.0f) || (power && power->maximum().max() > 0.0f);
+}
+
+float Primitive::powerToRadianceFactor() const
+{
+    switch (type) {
+    case InfiniteSphere: return INV_FOUR_PI;           // InfiniteSphere.cpp:59-62
+    default:             return INV_PI*invArea;        // Quad.cpp:50-53, Cube.cpp, TriangleMesh.cpp:108-111
+    }
+}
+
+std::shared_ptr<Primitive> Scene::instantiatePrimitive(const JsonValue &v) const
+{
+    auto p = std::make_shared<Primitive>();
+    std::string type = v["type"].asString();
+    v.getField("name", p->name);
+    getTransform(v, "transform", p->transform);
+    if (const JsonValue &e = v["emission"]) p->emission = fetchTexture(e, true);
+    if (const JsonValue &pw = v["power"]) p->power = fetchTexture(pw, true);
+    if (v["int_medium"] || v["ext_medium"])
+        throw JsonLoadException("participating media are a 'next' row of the hot-path scope (SURVEY.md 8f2)");
+
+    auto defaultBsdf = [&]() {   // Primitive::_defaultBsdf = LambertBsdf (Primitive.cpp:11)
+        auto b = std::make_shared<Bsdf>();
+        b->albedo = constantTexture(1.0f);
+        return b;
+    };
+
+    if (type == "mesh") {
+        p->type = Primitive::Mesh;
+        v.getField("file", p->file);
+        v.getField("smooth", p->smooth);
+        v.getField("backface_culling", p->backfaceCulling);
+        v.getField("recompute_normals", p->recomputeNormals);
+        if (const JsonValue &b = v["bsdf"]) {
+            if (b.isArray())
+                for (size_t i = 0; i < b.size(); ++i) p->bsdfs.push_back(fetchBsdf(b[i]));
+            else
+                p->bsdfs.push_back(fetchBsdf(b));
+        } else {
+            p->bsdfs.push_back(defaultBsdf());
+        }
+    } else if (type == "quad" || type == "cube" || type == "sphere") {
+        p->type = type == "quad" ? Primitive::Quad : type == "cube" ? Primitive::Cube : Primitive::Sphere;
+        if (const JsonValue &b = v["bsdf"]) p->bsdfs.push_back(fetchBsdf(b));
+        else p->bsdfs.push_back(defaultBsdf());
+    } else if (type == "infinite_sphere") {
+        p->type = Primitive::InfiniteSphere;
+        v.getField("sample", p->doSample);
+    } else {
+        throw JsonLoadException("Primitive type '" + type + "' is outside the path_tracer_hip hot-path scope");
+    }
+    return p;
+}
+
+void Primitive::loadResources(const std::string &sceneDir)
+{
+    if (type != Mesh || file.empty())
+        return;
+    std::string full = sceneDir.empty() ? file : sceneDir + "/" + file;
+    std::string err;
+    if (!MeshIO::load(full, verts, tris, err))
+        throw std::runtime_error("Unable to load triangle mesh at '" + full + "': " + err);
+    if (recomputeNormals)
+        MeshIO::recomputeNormals(verts, tris);
+}
+
+void Primitive::prepareForRender()
+{
+    switch (type) {
+    case Quad: {   // Quad.cpp:298-316
+        base = transform*Vec3f(0.0f);
+        edge0 = transform.transformVector(Vec3f(1.0f, 0.0f, 0.0f));
+        edge1 = transform.transformVector(Vec3f(0.0f, 0.0f, 1.0f));
+        base -= edge0*0.5f;
+        base -= edge1*0.5f;
+        Vec3f n = edge1.cross(edge0);
+        area = n.length();
+        invArea = 1.0f/area;
+        n /= area;
+        normal = n;
+        invUvSq[0] = 1.0f/edge0.lengthSq();
+        invUvSq[1] = 1.0f/edge1.lengthSq();
+        bounds = Box3f();
+        bounds.grow(base); bounds.grow(base + edge0); bounds.grow(base + edge1); bounds.grow(base + edge0 + edge1);
+        break;
+    } case Cube: { // Cube.cpp:353-370
+        pos = transform*Vec3f(0.0f);
+        scale = Mat4f::scale(transform.extractScaleVec())*Vec3f(0.5f);
+        rot = transform.extractRotation();
+        invRot = rot.transpose();
+        faceCdf = 4.0f*Vec3f(scale.y()*scale.z(), scale.z()*scale.x(), scale.x()*scale.y());
+        faceCdf[1] += faceCdf[0];
+        faceCdf[2] += faceCdf[1];
+        area = 2.0f*faceCdf[2];
+        invArea = 1.0f/area;
+        bounds = Box3f();
+        for (int i = 0; i < 8; ++i)
+            bounds.grow(pos + rot*Vec3f((i & 1 ? scale.x() : -scale.x()), (i & 2 ? scale.y() : -scale.y()), (i & 4 ? scale.z() : -scale.z())));
+        break;
+    } case Sphere: { // Sphere.cpp:285-295
+        pos = transform*Vec3f(0.0f);
+        float radius = (Mat4f::scale(transform.extractScaleVec())*Vec3f(1.0f)).max();
+        scale = Vec3f(radius);
+        rot = transform.extractRotation();
+        invRot = rot.transpose();
+        area = 4.0f*PI*radius*radius;
+        invArea = 1.0f/area;
+        bounds = Box3f();
+        bounds.grow(pos - Vec3f(radius)); bounds.grow(pos + Vec3f(radius));
+        break;
+    } case InfiniteSphere: { // InfiniteSphere.cpp:280-286
+        rot = transform.extractRotation();
+        invRot = rot.transpose();
+        break;
+    } case Mesh: { // TriangleMesh.cpp:524-572
+        bounds = Box3f();
+        for (MeshTriangle &t : tris)
+            t.material = std::min(std::max(t.material, 0), int(bsdfs.size()) - 1);
+        tfVerts.resize(verts.size());
+        Mat4f normalTform = transform.toNormalMatrix();
+        for (size_t i = 0; i < verts.size(); ++i) {
+            Vec3f p = transform*Vec3f(verts[i].pos[0], verts[i].pos[1], verts[i].pos[2]);
+            Vec3f n = normalTform.transformVector(Vec3f(verts[i].normal[0], verts[i].normal[1], verts[i].normal[2]));
+            for (int k = 0; k < 3; ++k) { tfVerts[i].pos[k] = p[k]; tfVerts[i].normal[k] = n[k]; }
+            tfVerts[i].uv[0] = verts[i].uv[0]; tfVerts[i].uv[1] = verts[i].uv[1];
+            bounds.grow(p);
+        }
+        area = 0.0f;
+        for (const MeshTriangle &t : tris) {
+            Vec3f p0(tfVerts[t.v0].pos[0], tfVerts[t.v0].pos[1], tfVerts[t.v0].pos[2]);
+            Vec3f p1(tfVerts[t.v1].pos[0], tfVerts[t.v1].pos[1], tfVerts[t.v1].pos[2]);
+            Vec3f p2(tfVerts[t.v2].pos[0], tfVerts[t.v2].pos[1], tfVerts[t.v2].pos[2]);
+            area += (p1 - p0).cross(p2 - p0).length()*0.5f;   // MathUtil::triangleArea
+        }
+        invArea = 1.0f/area;
+        break;
+    }
+    }
+    // Primitive::prepareForRender (Primitive.cpp:102-108)
+    if (power) {
+        emission = std::make_shared<Texture>(*power);
+        emission->scaleValues(powerToRadianceFactor());
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Camera
+// ------------------------------------------------------------------------------------------
+Camera::Camera()
+{
+    // Camera::Camera(Mat4f(), Vec2u(1000, 563)) (Camera.cpp:16-35)
+    pos = transform*Vec3f(0.0f, 0.0f, 2.0f);
+    lookAt = transform*Vec3f(0.0f, 0.0f, -1.0f);
+    up = transform*Vec3f(0.0f, 1.0f, 0.0f);
+    transform.setRight(-transform.right());
+    for (float &c : filterCdf) c = 0.0f;
+    precompute();
+}
+
+void Camera::fromJson(const JsonValue &v)
+{
+    v.getField("tonemap", tonemap);
+    const JsonValue &res = v["resolution"];
+    if (res) {
+        if (res.isNumber()) { resX = resY = unsigned(res.asDouble()); }
+        else { resX = unsigned(res[0].asDouble()); resY = unsigned(res[1].asDouble()); }
+    }
+    if (v["medium"])
+        throw JsonLoadException("camera media are a 'next' row of the hot-path scope (SURVEY.md 8f2)");
+    v.getField("reconstruction_filter", filterName);
+
+    if (v["transform"]) {   // Camera.cpp:55-66
+        getTransform(v, "transform", transform);
+        pos = transform.translation();
+        lookAt = transform.fwd() + pos;
+        up = transform.up();
+        getVec3(v["transform"], "up", up);
+        getVec3(v["transform"], "look_at", lookAt);
+        transform.setRight(-transform.right());
+    }
+    std::string type = "pinhole";
+    v.getField("type", type);
+    if (type != "pinhole")
+        throw JsonLoadException("Camera type '" + type + "' is outside the path_tracer_hip hot-path scope");
+    v.getField("fov", fovDeg);
+    precompute();
+}
+
+void Camera::precompute()
+{
+    ratio = resY/float(resX);
+    pixelSizeX = 1.0f/resX;
+    float fovRad = fovDeg*(PI/180.0f);            // Angle::degToRad
+    planeDist = 1.0f/std::tan(fovRad*0.5f);       // PinholeCamera.cpp:28-35
+
+    // ReconstructionFilter::precompute (ReconstructionFilter.cpp:34-58)
+    enum { RES = 31 };
+    auto mitchell = [](float x) {
+        const float B = 1.0f/3.0f, C = 1.0f/3.0f;
+        if (x < 1.0f)
+            return 1.0f/6.0f*((12.0f - 9.0f*B - 6.0f*C)*x*x*x + (-18.0f + 12.0f*B + 6.0f*C)*x*x + (6.0f - 2.0f*B));
+        else if (x < 2.0f)
+            return 1.0f/6.0f*((-B - 6.0f*C)*x*x*x + (6.0f*B + 30.0f*C)*x*x + (-12.0f*B - 48.0f*C)*x + (8.0f*B + 24.0f*C));
+        return 0.0f;
+    };
+    auto catmull = [](float x) {
+        if (x < 1.0f) return 1.0f/6.0f*((12.0f - 3.0f)*x*x*x + (-18.0f + 3.0f)*x*x + 6.0f);
+        else if (x < 2.0f) return 1.0f/6.0f*(-3.0f*x*x*x + 15.0f*x*x - 24.0f*x + 12.0f);
+        return 0.0f;
+    };
+    auto lanczos = [](float x) {
+        if (x == 0.0f) return 1.0f;
+        else if (x < 2.0f) return std::sin(PI*x)*std::sin(PI*x/2.0f)/(PI*PI*x*x/2.0f);
+        return 0.0f;
+    };
+    std::function<float(float)> eval;
+    if (filterName == "dirac")      { filterType = 0; filterWidth = 0.0f; }
+    else if (filterName == "box")   { filterType = 1; filterWidth = 0.5f; }
+    else if (filterName == "tent")  { filterType = 2; filterWidth = 1.0f; eval = [](float x) { return 1.0f - std::abs(x); }; }
+    else if (filterName == "gaussian") { filterType = 2; filterWidth = 2.0f;
+        eval = [](float x) { const float Alpha = 2.0f; return std::max(std::exp(-Alpha*x*x) - std::exp(-Alpha*4.0f), 0.0f); }; }
+    else if (filterName == "mitchell_netravali") { filterType = 2; filterWidth = 2.0f; eval = [=](float x) { return mitchell(std::abs(x)); }; }
+    else if (filterName == "catmull_rom") { filterType = 2; filterWidth = 2.0f; eval = [=](float x) { return catmull(std::abs(x)); }; }
+    else if (filterName == "lanczos") { filterType = 2; filterWidth = 2.0f; eval = [=](float x) { return lanczos(std::abs(x)); }; }
+    else throw JsonLoadException("Invalid reconstruction filter: '" + filterName + "'");
+
+    filterBinSize = filterWidth/RES;
+    for (float &c : filterCdf) c = 0.0f;
+    if (filterType != 2)
+        return;
+    float filter[RES + 1];
+    float filterSum = 0.0f;
+    for (int i = 0; i < RES; ++i) {
+        filter[i] = eval((i*filterWidth)/RES);
+        filterSum += filter[i];
+    }
+    filterCdf[0] = 0.0f;
+    for (int i = 1; i < RES; ++i)
+        filterCdf[i] = filterCdf[i - 1] + filter[i - 1]/filterSum;
+    filterCdf[RES] = 1.0f;
+}
+
+void RendererSettings::fromJson(const JsonValue &v)
+{
+    v.getField("output_file", outputFile);
+    v.getField("hdr_output_file", hdrOutputFile);
+    v.getField("resume_render_file", resumeRenderFile);
+    v.getField("overwrite_output_files", overwriteOutputFiles);
+    v.getField("adaptive_sampling", useAdaptiveSampling);
+    v.getField("enable_resume_render", enableResumeRender);
+    v.getField("stratified_sampler", useSobol);
+    v.getField("scene_bvh", useSceneBvh);
+    v.getField("spp", spp);
+    v.getField("spp_step", sppStep);
+}
+
+void IntegratorSettings::fromJson(const JsonValue &v)
+{
+    v.getField("type", type);
+    v.getField("min_bounces", minBounces);
+    v.getField("max_bounces", maxBounces);
+    v.getField("enable_consistency_checks", enableConsistencyChecks);
+    v.getField("enable_two_sided_shading", enableTwoSidedShading);
+    v.getField("enable_light_sampling", enableLightSampling);
+    v.getField("enable_volume_light_sampling", enableVolumeLightSampling);
+    v.getField("low_order_scattering", lowOrderScattering);
+    v.getField("include_surfaces", includeSurfaces);
+    v.getField("devices", devices);
+}
+
+// ------------------------------------------------------------------------------------------
+// Scene
+// ------------------------------------------------------------------------------------------
+void Scene::fromJson(const JsonValue &root)
+{
+    if (const JsonValue &media = root["media"])
+        if (media.isArray() && media.size() > 0)
+            throw JsonLoadException("participating media are a 'next' row of the hot-path scope (SURVEY.md 8f2)");
+
+    // bsdfs may reference earlier bsdfs by name (Scene.cpp:236-253 loads them in file order)
+    if (const JsonValue &jb = root["bsdfs"])
+        for (size_t i = 0; i < jb.size(); ++i)
+            bsdfs.push_back(instantiateBsdf(jb[i]));
+    if (const JsonValue &jp = root["primitives"])
+        for (size_t i = 0; i < jp.size(); ++i)
+            primitives.push_back(instantiatePrimitive(jp[i]));
+    if (const JsonValue &cam = root["camera"])
+        camera.fromJson(cam);
+    if (const JsonValue &integ = root["integrator"])
+        integrator.fromJson(integ);
+    if (const JsonValue &rend = root["renderer"])
+        renderer.fromJson(rend);
+}
+
+void Scene::loadResources()
+{
+    for (auto &p : primitives)
+        p->loadResources(_srcDir);
+    for (auto &kv : _textureCache)
+        if (!kv.second->valid)
+            kv.second->loadBitmap(kv.second->path);
+}
+
+std::unique_ptr<Scene> Scene::load(const std::string &jsonPath)
+{
+    std::ifstream in(jsonPath.c_str(), std::ios::binary);
+    if (!in)
+        throw std::runtime_error("Unable to open file at '" + jsonPath + "'");
+    std::stringstream ss;
+    ss << in.rdbuf();
+    JsonValue root = JsonValue::parse(ss.str());
+
+    std::unique_ptr<Scene> scene(new Scene());
+    size_t slash = jsonPath.find_last_of('/');
+    scene->_srcDir = slash == std::string::npos ? std::string() : jsonPath.substr(0, slash);
+    scene->fromJson(root);
+    scene->loadResources();
+    return scene;
+}
+
+} // namespace tungsten_amd

@@ -1,0 +1,169 @@
+// Host-side scene model: reads Tungsten's JSON scene format and prepares the render-time
+// quantities the reference computes in its prepareForRender() methods.  No intersection
+// or shading code lives here -- that is all on the GPU (csrc/hip) -- these classes only
+// hold parameters and mirror the reference's loading semantics:
+//   Scene::load/fromJson        src/core/io/Scene.cpp:236-253,378-391
+//   Primitive::fromJson         src/core/primitives/Primitive.cpp:22-32
+//   Bsdf::fromJson              src/core/bsdfs/Bsdf.cpp:19-25
+//   Camera::fromJson            src/core/cameras/Camera.cpp:44-68
+//   RendererSettings::fromJson  src/core/renderer/RendererSettings.hpp:49-76
+#ifndef TGAMD_SCENE_HPP_
+#define TGAMD_SCENE_HPP_
+
+#include "Json.hpp"
+#include "Math.hpp"
+
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace tungsten_amd {
+
+// ---- textures (src/core/textures) ---------------------------------------------------
+struct Texture
+{
+    enum Type { Constant = 0, Checker = 1, Bitmap = 2 };
+    Type type = Constant;
+    Vec3f value = Vec3f(1.0f);                 // ConstantTexture
+    Vec3f onColor = Vec3f(0.8f), offColor = Vec3f(0.2f); // CheckerTexture.cpp:11-30
+    int resU = 20, resV = 20;
+    // BitmapTexture (HDR float texels only: .hdr / .pfm)
+    std::string path;
+    int w = 0, h = 0;
+    bool rgb = true, linear = true, clamp = false, valid = false;
+    float scale = 1.0f;
+    std::vector<float> texels;                 // rgb ? 3*w*h : w*h
+    Vec3f texMin, texMax, texAvg;
+    // Distribution2D (sampling/Distribution2D.hpp), built by makeSamplable(MAP_SPHERICAL)
+    bool samplable = false;
+    std::vector<float> marginalPdf, marginalCdf, pdf, cdf;
+
+    bool isConstant() const { return type == Constant; }
+    Vec3f average() const;
+    Vec3f maximum() const;
+    void scaleValues(float f);
+    void makeSamplableSpherical();             // BitmapTexture.cpp:400-431
+    void loadBitmap(const std::string &file);  // BitmapTexture::loadResources + init
+};
+
+// ---- BSDFs (src/core/bsdfs) ------------------------------------------------------------
+struct Bsdf
+{
+    enum Type { Lambert = 0, Null = 1, RoughConductor = 2, SmoothCoat = 3, Dielectric = 4, RoughDielectric = 5,
+                Mirror = 6, Conductor = 7, Plastic = 8, RoughPlastic = 9, Mixed = 10, Transparency = 11,
+                Forward = 12, Error = 13 };
+    std::string name;
+    Type type = Lambert;
+    unsigned lobes = 0;
+    std::shared_ptr<Texture> albedo, roughness, tex1;
+    std::shared_ptr<Bsdf> sub0, sub1;
+    int distribution = 2;                       // 0 beckmann, 1 phong, 2 ggx
+    float ior = 1.5f, thickness = 1.0f;
+    bool enableRefraction = true;
+    Vec3f eta = Vec3f(0.200438f, 0.924033f, 1.10221f), k = Vec3f(3.91295f, 2.45285f, 2.14219f);
+    Vec3f sigmaA = Vec3f(0.0f), scaledSigmaA = Vec3f(0.0f);
+    float avgTransmittance = 1.0f, diffuseFresnel = 0.0f;
+    bool prepared = false;
+
+    bool unnamed() const { return name.empty(); }
+    void prepareForRender();
+};
+
+// ---- primitives (src/core/primitives) ----------------------------------------------------
+struct MeshVertex { float pos[3], normal[3], uv[2]; };          // Vertex.hpp:10-13 (32 B, .wo3 layout)
+struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp:14-28 (16 B)
+
+struct Primitive
+{
+    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4 };
+    std::string name;
+    Type type = Quad;
+    Mat4f transform;
+    std::shared_ptr<Texture> emission, power;
+    std::vector<std::shared_ptr<Bsdf>> bsdfs;
+    // mesh
+    std::string file;
+    bool smooth = false, backfaceCulling = false, recomputeNormals = false;
+    std::vector<MeshVertex> verts, tfVerts;
+    std::vector<MeshTriangle> tris;
+    // infinite sphere
+    bool doSample = true;
+
+    // prepared (prepareForRender of the respective reference class)
+    Vec3f base, edge0, edge1, normal; float invUvSq[2] = {0, 0};  // Quad.cpp:298-316
+    Vec3f pos, scale; Mat4f rot, invRot; Vec3f faceCdf;            // Cube.cpp:353-370 / Sphere / InfiniteSphere.cpp:280-286
+    float area = 0.0f, invArea = 0.0f;
+    Box3f bounds;
+
+    bool isInfinite() const { return type == InfiniteSphere; }
+    bool isDirac() const { return type == Mesh && (verts.empty() || tris.empty()); }
+    bool isEmissive() const;       // Primitive.hpp:111-115
+    bool isSamplable() const { return type == InfiniteSphere ? doSample : true; }
+    float powerToRadianceFactor() const;
+    void loadResources(const std::string &sceneDir);
+    void prepareForRender();
+};
+
+// ---- camera ------------------------------------------------------------------------------
+struct Camera
+{
+    std::string tonemap = "gamma";
+    std::string filterName = "tent";
+    unsigned resX = 1000, resY = 563;
+    Mat4f transform;
+    Vec3f pos, lookAt, up;
+    float fovDeg = 60.0f;
+    // precompute()
+    float ratio = 0, pixelSizeX = 0, planeDist = 0;
+    // ReconstructionFilter::precompute (cameras/ReconstructionFilter.cpp:34-58)
+    int filterType = 2; float filterWidth = 1.0f, filterBinSize = 0; float filterCdf[32];
+
+    Camera();
+    void fromJson(const JsonValue &v);
+    void precompute();
+};
+
+struct RendererSettings   // renderer/RendererSettings.hpp:15-107
+{
+    std::string outputFile = "TungstenRender.png", hdrOutputFile, resumeRenderFile = "TungstenRenderState.dat";
+    bool overwriteOutputFiles = true, useAdaptiveSampling = true, enableResumeRender = false, useSobol = true, useSceneBvh = true;
+    unsigned spp = 32, sppStep = 16;
+    void fromJson(const JsonValue &v);
+};
+
+struct IntegratorSettings // TraceSettings.hpp:15-39 + PathTracerSettings.hpp:17-43
+{
+    std::string type = "path_tracer";
+    int minBounces = 0, maxBounces = 64;
+    bool enableConsistencyChecks = false, enableTwoSidedShading = true;
+    bool enableLightSampling = true, enableVolumeLightSampling = true, lowOrderScattering = true, includeSurfaces = true;
+    int devices = 1;             // path_tracer_hip extension: GPUs used by one integrator
+    void fromJson(const JsonValue &v);
+};
+
+class Scene
+{
+    std::string _srcDir;
+    mutable std::vector<std::pair<std::string, std::shared_ptr<Texture>>> _textureCache;
+
+    std::shared_ptr<Texture> fetchTexture(const JsonValue &v, bool rgb) const;  // Scene.cpp:127-151
+    std::shared_ptr<Bsdf> fetchBsdf(const JsonValue &v) const;                  // Scene.cpp:82-93
+    std::shared_ptr<Bsdf> instantiateBsdf(const JsonValue &v) const;
+    std::shared_ptr<Primitive> instantiatePrimitive(const JsonValue &v) const;
+
+public:
+    std::vector<std::shared_ptr<Bsdf>> bsdfs;
+    std::vector<std::shared_ptr<Primitive>> primitives;
+    Camera camera;
+    IntegratorSettings integrator;
+    RendererSettings renderer;
+
+    static std::unique_ptr<Scene> load(const std::string &jsonPath);   // Scene::load + loadResources
+    void fromJson(const JsonValue &root);
+    void loadResources();
+    const std::string &srcDir() const { return _srcDir; }
+};
+
+} // namespace tungsten_amd
+
+#endif

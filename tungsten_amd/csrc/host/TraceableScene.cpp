@@ -1,0 +1,297 @@
+#include "TraceableScene.hpp"
+#include "BvhBuilder.hpp"
+#include "Integrator.hpp"
+
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <stdexcept>
+
+namespace tungsten_amd {
+
+TraceableScene::TraceableScene(Scene &scene, Integrator *integrator, uint32_t seed)
+: _scene(scene), _integrator(integrator), _seed(seed)
+{
+    std::memset(&_desc, 0, sizeof(_desc));
+    flatten();
+    if (_integrator)
+        _integrator->prepareForRender(*this, seed);    // TraceableScene.hpp:136
+}
+
+TraceableScene::~TraceableScene()
+{
+    if (_integrator)
+        _integrator->teardownAfterRender();            // TraceableScene.hpp:141
+}
+
+static void copy3(float *dst, const Vec3f &v) { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; }
+static void copyRot(float *dst, const Mat4f &m)
+{
+    dst[0] = m[0]; dst[1] = m[1]; dst[2] = m[2];
+    dst[3] = m[4]; dst[4] = m[5]; dst[5] = m[6];
+    dst[6] = m[8]; dst[7] = m[9]; dst[8] = m[10];
+}
+
+void TraceableScene::flatten()
+{
+    auto t0 = std::chrono::steady_clock::now();
+
+    // ---- prepareForRender pass (TraceableScene.hpp:64-102) -----------------------------------
+    _scene.camera.precompute();
+    for (auto &b : _scene.bsdfs)
+        b->prepareForRender();
+    _allPrims = _scene.primitives;
+    int lightCount = 0;
+    for (auto &p : _allPrims) {
+        p->prepareForRender();
+        for (auto &b : p->bsdfs)
+            b->prepareForRender();
+        if (p->isEmissive())
+            lightCount++;
+    }
+    if (lightCount == 0) {
+        // default white environment (TraceableScene.hpp:97-102)
+        auto defaultLight = std::make_shared<Primitive>();
+        defaultLight->type = Primitive::InfiniteSphere;
+        defaultLight->name = "<default light>";
+        defaultLight->emission = std::make_shared<Texture>();
+        defaultLight->emission->value = Vec3f(1.0f);
+        defaultLight->prepareForRender();
+        _allPrims.push_back(defaultLight);
+    }
+
+    // ---- tables indexed by pointer -----------------------------------------------------------
+    std::map<const Texture *, int32_t> texIndex;
+    auto addTexture = [&](const std::shared_ptr<Texture> &t) -> int32_t {
+        if (!t) return -1;
+        auto it = texIndex.find(t.get());
+        if (it != texIndex.end()) return it->second;
+        TgHipTexture d;
+        std::memset(&d, 0, sizeof(d));
+        d.type = int32_t(t->type);
+        copy3(d.value, t->value);
+        copy3(d.on_color, t->onColor);
+        copy3(d.off_color, t->offColor);
+        d.res_u = t->resU; d.res_v = t->resV;
+        d.scale = t->scale;
+        copy3(d.avg, t->average());
+        d.texel_offset = -1;
+        d.dist_offset = -1;
+        if (t->type == Texture::Bitmap) {
+            d.w = t->w; d.h = t->h;
+            d.flags = (t->linear ? TGHIP_TEXF_LINEAR : 0) | (t->clamp ? TGHIP_TEXF_CLAMP : 0) |
+                      (t->rgb ? TGHIP_TEXF_RGB : 0) | (t->valid ? TGHIP_TEXF_VALID : 0);
+            d.texel_offset = int64_t(_texels.size());
+            _texels.insert(_texels.end(), t->texels.begin(), t->texels.end());
+        }
+        int32_t idx = int32_t(_textures.size());
+        _textures.push_back(d);
+        texIndex[t.get()] = idx;
+        return idx;
+    };
+    auto addDistribution = [&](const std::shared_ptr<Texture> &t) {
+        if (!t || t->type != Texture::Bitmap) return;
+        t->makeSamplableSpherical();
+        TgHipTexture &d = _textures[size_t(texIndex[t.get()])];
+        if (d.dist_offset >= 0) return;
+        d.dist_offset = int64_t(_dist.size());
+        _dist.insert(_dist.end(), t->marginalPdf.begin(), t->marginalPdf.end());
+        _dist.insert(_dist.end(), t->marginalCdf.begin(), t->marginalCdf.end());
+        _dist.insert(_dist.end(), t->pdf.begin(), t->pdf.end());
+        _dist.insert(_dist.end(), t->cdf.begin(), t->cdf.end());
+    };
+
+    std::map<const Bsdf *, int32_t> bsdfIndex;
+    std::function<int32_t(const std::shared_ptr<Bsdf> &)> addBsdf = [&](const std::shared_ptr<Bsdf> &b) -> int32_t {
+        if (!b) return -1;
+        auto it = bsdfIndex.find(b.get());
+        if (it != bsdfIndex.end()) return it->second;
+        b->prepareForRender();
+        int32_t idx = int32_t(_bsdfs.size());
+        bsdfIndex[b.get()] = idx;
+        _bsdfs.emplace_back();
+        TgHipBsdf d;
+        std::memset(&d, 0, sizeof(d));
+        d.type = int32_t(b->type);
+        d.lobes = b->lobes;
+        d.albedo = addTexture(b->albedo);
+        d.distribution = b->distribution;
+        d.roughness = addTexture(b->roughness);
+        d.sub0 = addBsdf(b->sub0);
+        d.sub1 = addBsdf(b->sub1);
+        d.tex1 = addTexture(b->tex1);
+        d.ior = b->ior; d.thickness = b->thickness;
+        d.avg_transmittance = b->avgTransmittance;
+        d.diffuse_fresnel = b->diffuseFresnel;
+        d.enable_refraction = b->enableRefraction ? 1 : 0;
+        copy3(d.eta, b->eta); copy3(d.k, b->k);
+        copy3(d.sigma_a, b->sigmaA); copy3(d.scaled_sigma_a, b->scaledSigmaA);
+        _bsdfs[size_t(idx)] = d;
+        return idx;
+    };
+    for (auto &b : _scene.bsdfs)
+        addBsdf(b);
+
+    // ---- objects, light lists, records -------------------------------------------------------
+    std::vector<Box3f> recBounds;
+    _sceneBounds = Box3f();
+    for (size_t pi = 0; pi < _allPrims.size(); ++pi) {
+        Primitive &p = *_allPrims[pi];
+        TgHipObject o;
+        std::memset(&o, 0, sizeof(o));
+        o.type = int32_t(p.type);
+        o.bsdf = p.bsdfs.empty() ? -1 : addBsdf(p.bsdfs[0]);
+        for (size_t i = 1; i < p.bsdfs.size(); ++i) addBsdf(p.bsdfs[i]);
+        bool emissive = p.isEmissive();
+        o.emission = emissive ? addTexture(p.emission) : -1;
+        o.light = -1;
+        o.first_light_tri = -1;
+        o.flags = (p.smooth ? TGHIP_OBJF_SMOOTH : 0) | (p.doSample ? TGHIP_OBJF_SAMPLE : 0);
+        o.area = p.area; o.inv_area = p.invArea;
+        copy3(o.base, p.base); copy3(o.edge0, p.edge0); copy3(o.edge1, p.edge1); copy3(o.normal, p.normal);
+        o.inv_uv_sq[0] = p.invUvSq[0]; o.inv_uv_sq[1] = p.invUvSq[1];
+        copy3(o.pos, p.pos); copy3(o.scale, p.scale);
+        copyRot(o.rot, p.rot);
+        copy3(o.face_cdf, p.faceCdf);
+
+        if (emissive) {
+            if (p.isSamplable()) {
+                if (p.type == Primitive::Mesh || p.type == Primitive::Sphere || p.type == Primitive::Cube)
+                    throw std::runtime_error("emissive '" + p.name + "': mesh/sphere/cube emitters are not yet inside the "
+                                             "path_tracer_hip hot-path scope (quad and infinite_sphere lights are)");
+                o.light = int32_t(_lights.size());
+                _lights.push_back(int32_t(pi));
+            }
+            if (p.isInfinite())
+                _infiniteLights.push_back(int32_t(pi));
+        }
+        _objects.push_back(o);
+
+        if (p.isInfinite() || p.isDirac())
+            continue;
+        _sceneBounds.grow(p.bounds);
+
+        uint32_t objMeta = uint32_t(pi);
+        if (pi >= (1u << 29))
+            throw std::runtime_error("too many primitives");
+        switch (p.type) {
+        case Primitive::Quad: {
+            TgHipPrimRec r;
+            std::memset(&r, 0, sizeof(r));
+            copy3(r.a, p.base); copy3(r.b, p.edge0); copy3(r.c, p.edge1);
+            r.p0 = p.invUvSq[0]; r.p1 = p.invUvSq[1];
+            r.meta = (uint32_t(TGHIP_REC_QUAD) << 29) | objMeta;
+            _recs.push_back(r);
+            _triAttrs.emplace_back();
+            std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
+            _triAttrs.back().bsdf = o.bsdf;
+            recBounds.push_back(p.bounds);
+            break;
+        } case Primitive::Cube: case Primitive::Sphere: {
+            TgHipPrimRec r;
+            std::memset(&r, 0, sizeof(r));
+            copy3(r.a, p.pos); copy3(r.b, p.scale);
+            r.meta = (uint32_t(p.type == Primitive::Cube ? TGHIP_REC_CUBE : TGHIP_REC_SPHERE) << 29) | objMeta;
+            _recs.push_back(r);
+            _triAttrs.emplace_back();
+            std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
+            _triAttrs.back().bsdf = o.bsdf;
+            recBounds.push_back(p.bounds);
+            break;
+        } case Primitive::Mesh: {
+            std::vector<int32_t> meshBsdfs;
+            for (auto &b : p.bsdfs) meshBsdfs.push_back(addBsdf(b));
+            for (const MeshTriangle &t : p.tris) {
+                const MeshVertex &a = p.tfVerts[t.v0], &b = p.tfVerts[t.v1], &c = p.tfVerts[t.v2];
+                Vec3f p0(a.pos[0], a.pos[1], a.pos[2]), p1(b.pos[0], b.pos[1], b.pos[2]), p2(c.pos[0], c.pos[1], c.pos[2]);
+                TgHipPrimRec r;
+                std::memset(&r, 0, sizeof(r));
+                copy3(r.a, p0); copy3(r.b, p1 - p0); copy3(r.c, p2 - p0);
+                r.meta = (uint32_t(TGHIP_REC_TRIANGLE) << 29) | objMeta;
+                _recs.push_back(r);
+                TgHipTriAttr at;
+                std::memcpy(at.n0, a.normal, 12); std::memcpy(at.n1, b.normal, 12); std::memcpy(at.n2, c.normal, 12);
+                std::memcpy(at.uv0, a.uv, 8); std::memcpy(at.uv1, b.uv, 8); std::memcpy(at.uv2, c.uv, 8);
+                at.bsdf = meshBsdfs[size_t(t.material)];
+                _triAttrs.push_back(at);
+                Box3f bb;
+                bb.grow(p0); bb.grow(p1); bb.grow(p2);
+                recBounds.push_back(bb);
+            }
+            break;
+        } default:
+            break;
+        }
+    }
+    if (_recs.size() >= (1u << 27))
+        throw std::runtime_error("too many primitive records for the 27-bit leaf encoding");
+
+    // lights that are sampled need their 2-D distribution (TraceBase ctor -> makeSamplable,
+    // integrators/TraceBase.cpp:5-22; InfiniteSphere.cpp:124-129)
+    for (int32_t li : _lights)
+        if (_allPrims[size_t(li)]->type == Primitive::InfiniteSphere)
+            addDistribution(_allPrims[size_t(li)]->emission);
+
+    // ---- BVH ---------------------------------------------------------------------------------
+    BvhBuildResult bvh = buildBvh(recBounds, 4);
+    if (bvh.maxDepth > TGHIP_MAX_BVH_DEPTH - 1)
+        throw std::runtime_error("BVH deeper than the device traversal stack");
+    std::vector<TgHipPrimRec> recs(_recs.size());
+    std::vector<TgHipTriAttr> attrs(_recs.size());
+    for (size_t i = 0; i < bvh.order.size(); ++i) {
+        recs[i] = _recs[bvh.order[i]];
+        attrs[i] = _triAttrs[bvh.order[i]];
+    }
+    _recs.swap(recs);
+    _triAttrs.swap(attrs);
+    _nodes.swap(bvh.nodes);
+    _bvhDepth = bvh.maxDepth;
+    _bvhSah = bvh.sahCost;
+
+    // ---- camera / settings -------------------------------------------------------------------
+    const Camera &cam = _scene.camera;
+    TgHipCamera &c = _desc.camera;
+    copy3(c.pos, cam.pos);
+    c.plane_dist = cam.planeDist;
+    copyRot(c.xf, cam.transform);
+    c.ratio = cam.ratio;
+    c.pixel_size_x = cam.pixelSizeX;
+    c.res_x = int32_t(cam.resX); c.res_y = int32_t(cam.resY);
+    c.filter_type = cam.filterType;
+    c.filter_width = cam.filterWidth;
+    c.filter_bin_size = cam.filterBinSize;
+    std::memcpy(c.filter_cdf, cam.filterCdf, sizeof(c.filter_cdf));
+
+    const IntegratorSettings &is = _scene.integrator;
+    _desc.settings.min_bounces = is.minBounces;
+    _desc.settings.max_bounces = is.maxBounces;
+    _desc.settings.enable_light_sampling = is.enableLightSampling ? 1 : 0;
+    _desc.settings.enable_two_sided_shading = is.enableTwoSidedShading ? 1 : 0;
+    _desc.settings.enable_consistency_checks = is.enableConsistencyChecks ? 1 : 0;
+
+    _desc.abi_version = TGHIP_ABI_VERSION;
+    _desc.num_nodes = uint32_t(_nodes.size());
+    _desc.num_recs = uint32_t(_recs.size());
+    _desc.num_objects = uint32_t(_objects.size());
+    _desc.num_lights = uint32_t(_lights.size());
+    _desc.num_infinite_lights = uint32_t(_infiniteLights.size());
+    _desc.num_bsdfs = uint32_t(_bsdfs.size());
+    _desc.num_textures = uint32_t(_textures.size());
+    _desc.nodes = _nodes.data();
+    _desc.recs = _recs.data();
+    _desc.tri_attrs = _triAttrs.data();
+    _desc.objects = _objects.data();
+    _desc.lights = _lights.data();
+    _desc.infinite_lights = _infiniteLights.data();
+    _desc.bsdfs = _bsdfs.data();
+    _desc.textures = _textures.data();
+    _desc.texels = _texels.data(); _desc.num_texel_floats = _texels.size();
+    _desc.dist = _dist.data();     _desc.num_dist_floats = _dist.size();
+    copy3(_desc.bounds_lo, _sceneBounds.lo);
+    copy3(_desc.bounds_hi, _sceneBounds.hi);
+
+    _buildSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+} // namespace tungsten_amd

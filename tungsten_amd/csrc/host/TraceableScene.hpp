@@ -1,0 +1,60 @@
+// Render-time flattened scene.  Same role as the reference's TraceableScene
+// (src/core/renderer/TraceableScene.hpp:25-274): prepares every object, builds the light lists
+// (:86-110, incl. the default white environment when the scene has no emitter :97-102) and owns
+// the acceleration structure.  The *backend* differs: instead of an Embree user-geometry scene
+// over Primitives plus one Embree scene per mesh (:112-134, TriangleMesh.cpp:524-572) it builds
+// one flat BVH2 over SoA primitive records and hands the integrator a TgHipSceneDesc to upload.
+#ifndef TGAMD_TRACEABLESCENE_HPP_
+#define TGAMD_TRACEABLESCENE_HPP_
+
+#include "Scene.hpp"
+#include "../../../include/tungsten_hip.h"
+
+#include <vector>
+
+namespace tungsten_amd {
+
+class Integrator;
+
+class TraceableScene
+{
+    Scene &_scene;
+    Integrator *_integrator;
+    uint32_t _seed;
+
+    std::vector<TgHipBvhNode> _nodes;
+    std::vector<TgHipPrimRec> _recs;
+    std::vector<TgHipTriAttr> _triAttrs;
+    std::vector<TgHipObject> _objects;
+    std::vector<int32_t> _lights, _infiniteLights;
+    std::vector<TgHipBsdf> _bsdfs;
+    std::vector<TgHipTexture> _textures;
+    std::vector<float> _texels, _dist;
+    std::vector<std::shared_ptr<Primitive>> _allPrims;   // scene primitives (+ default light)
+    TgHipSceneDesc _desc;
+    Box3f _sceneBounds;
+    int _bvhDepth = 0;
+    double _bvhSah = 0.0, _buildSeconds = 0.0;
+
+    void flatten();
+
+public:
+    // integrator may be null (description-only use, e.g. by the oracle tests)
+    TraceableScene(Scene &scene, Integrator *integrator, uint32_t seed);
+    ~TraceableScene();
+
+    const TgHipSceneDesc &desc() const { return _desc; }
+    Scene &scene() { return _scene; }
+    const Camera &cam() const { return _scene.camera; }
+    const RendererSettings &rendererSettings() const { return _scene.renderer; }
+    const Box3f &bounds() const { return _sceneBounds; }
+    int bvhDepth() const { return _bvhDepth; }
+    double bvhSahCost() const { return _bvhSah; }
+    double buildSeconds() const { return _buildSeconds; }
+    size_t numLights() const { return _lights.size(); }
+    uint32_t seed() const { return _seed; }
+};
+
+} // namespace tungsten_amd
+
+#endif

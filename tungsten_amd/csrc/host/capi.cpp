@@ -1,0 +1,199 @@
+// extern "C" view of the host classes (include/tungsten_host.h).
+#include "../../../include/tungsten_host.h"
+
+#include "ImageIO.hpp"
+#include "Integrator.hpp"
+#include "Scene.hpp"
+#include "TraceableScene.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+using namespace tungsten_amd;
+
+struct tgh_scene
+{
+    std::unique_ptr<Scene> scene;
+    std::unique_ptr<TraceableScene> flattened;
+};
+
+struct tgh_renderer
+{
+    std::unique_ptr<Scene> scene;
+    std::shared_ptr<Integrator> integrator;
+    std::unique_ptr<TraceableScene> flattened;
+};
+
+static void setErr(char *err, size_t errlen, const std::string &msg)
+{
+    if (err && errlen) {
+        std::snprintf(err, errlen, "%s", msg.c_str());
+    }
+}
+
+static void fillInfo(Scene &scene, TraceableScene &ts, TgHostSceneInfo *out)
+{
+    std::memset(out, 0, sizeof(*out));
+    out->width = scene.camera.resX; out->height = scene.camera.resY;
+    out->spp = scene.renderer.spp; out->spp_step = scene.renderer.sppStep;
+    const TgHipSceneDesc &d = ts.desc();
+    out->num_nodes = d.num_nodes; out->num_recs = d.num_recs; out->num_objects = d.num_objects;
+    out->num_lights = d.num_lights; out->num_bsdfs = d.num_bsdfs; out->num_textures = d.num_textures;
+    out->bvh_depth = ts.bvhDepth(); out->bvh_sah_cost = ts.bvhSahCost(); out->build_seconds = ts.buildSeconds();
+    out->adaptive_sampling = scene.renderer.useAdaptiveSampling ? 1 : 0;
+    out->stratified_sampler = scene.renderer.useSobol ? 1 : 0;
+}
+
+extern "C" {
+
+tgh_scene *tgh_scene_load(const char *json_path, char *err, size_t errlen)
+{
+    try {
+        std::unique_ptr<tgh_scene> s(new tgh_scene());
+        s->scene = Scene::load(json_path);
+        s->flattened.reset(new TraceableScene(*s->scene, nullptr, 0));
+        return s.release();
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return nullptr;
+    }
+}
+
+const TgHipSceneDesc *tgh_scene_desc(tgh_scene *s) { return s ? &s->flattened->desc() : nullptr; }
+
+int tgh_scene_info(tgh_scene *s, TgHostSceneInfo *out)
+{
+    if (!s || !out) return -1;
+    fillInfo(*s->scene, *s->flattened, out);
+    return 0;
+}
+
+void tgh_scene_free(tgh_scene *s) { delete s; }
+
+tgh_renderer *tgh_renderer_open(const char *json_path, uint32_t seed, int spp_override, int devices,
+                                char *err, size_t errlen)
+{
+    try {
+        std::unique_ptr<tgh_renderer> r(new tgh_renderer());
+        r->scene = Scene::load(json_path);
+        if (spp_override > 0) {
+            // CLI --spp override (Shared.hpp:238-241); a single pass unless the scene asks otherwise
+            r->scene->renderer.spp = uint32_t(spp_override);
+        }
+        if (devices > 0)
+            r->scene->integrator.devices = devices;
+        r->integrator = IntegratorFactory::instantiate(r->scene->integrator.type);
+        // Scene::fromJson parsed the "integrator" block (Scene.cpp:251); hand it to the plugin
+        if (PathTraceHipIntegrator *hip = dynamic_cast<PathTraceHipIntegrator *>(r->integrator.get()))
+            hip->setSettings(r->scene->integrator);
+        r->flattened.reset(new TraceableScene(*r->scene, r->integrator.get(), seed));   // Scene::makeTraceable
+        return r.release();
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return nullptr;
+    }
+}
+
+tghip_ctx *tgh_renderer_context(tgh_renderer *r, int device)
+{
+    if (!r) return nullptr;
+    PathTraceHipIntegrator *hip = dynamic_cast<PathTraceHipIntegrator *>(r->integrator.get());
+    return hip ? hip->context(size_t(device)) : nullptr;
+}
+
+int tgh_renderer_info(tgh_renderer *r, TgHostSceneInfo *out)
+{
+    if (!r || !out) return -1;
+    fillInfo(*r->scene, *r->flattened, out);
+    return 0;
+}
+
+int tgh_renderer_step(tgh_renderer *r, int *done_out, char *err, size_t errlen)
+{
+    if (!r) return -1;
+    try {
+        r->integrator->startRender([]() {});
+        r->integrator->waitForCompletion();
+        if (done_out) *done_out = r->integrator->done() ? 1 : 0;
+        return 0;
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return -1;
+    }
+}
+
+int tgh_renderer_render(tgh_renderer *r, double *seconds, char *err, size_t errlen)
+{
+    if (!r) return -1;
+    try {
+        auto t0 = std::chrono::steady_clock::now();
+        while (!r->integrator->done()) {       // Shared.hpp:283-293
+            r->integrator->startRender([]() {});
+            r->integrator->waitForCompletion();
+        }
+        if (seconds)
+            *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return -1;
+    }
+}
+
+int tgh_renderer_image(tgh_renderer *r, float *rgb_mean, float *rgb_sum, uint32_t *count, size_t npixels,
+                       char *err, size_t errlen)
+{
+    if (!r) return -1;
+    try {
+        PathTraceHipIntegrator *hip = dynamic_cast<PathTraceHipIntegrator *>(r->integrator.get());
+        const std::vector<float> &img = r->integrator->linearImage();
+        if (img.size() != npixels*3) { setErr(err, errlen, "pixel count mismatch"); return -1; }
+        if (rgb_mean) std::memcpy(rgb_mean, img.data(), img.size()*sizeof(float));
+        if (hip && rgb_sum) std::memcpy(rgb_sum, hip->sumBuffer().data(), npixels*3*sizeof(float));
+        if (hip && count) std::memcpy(count, hip->countBuffer().data(), npixels*sizeof(uint32_t));
+        return 0;
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return -1;
+    }
+}
+
+int tgh_renderer_save_outputs(tgh_renderer *r, char *err, size_t errlen)
+{
+    if (!r) return -1;
+    try {
+        r->integrator->saveOutputs();
+        return 0;
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return -1;
+    }
+}
+
+void tgh_renderer_close(tgh_renderer *r)
+{
+    if (!r) return;
+    r->flattened.reset();     // ~TraceableScene -> integrator.teardownAfterRender (TraceableScene.hpp:139-160)
+    delete r;
+}
+
+int tgh_save_pfm(const char *path, const float *rgb, int w, int h)
+{
+    return ImageIO::savePfm(path, rgb, w, h, 3) ? 0 : -1;
+}
+
+int tgh_load_hdr(const char *path, float *rgb, int *w, int *h)
+{
+    std::vector<float> data;
+    std::string err;
+    int iw = 0, ih = 0;
+    if (!ImageIO::loadHdr(path, data, iw, ih, err)) return -1;
+    if (w) *w = iw;
+    if (h) *h = ih;
+    if (rgb) std::memcpy(rgb, data.data(), data.size()*sizeof(float));
+    return 0;
+}
+
+} // extern "C"
