@@ -1,0 +1,49 @@
+# Builds the in-tree native artefacts:
+#   tungsten_amd/lib/libtungsten_hip.so   product: C++11 host side + HIP kernels + extern "C" shim (gfx950)
+#   tungsten_amd/lib/tungsten_hip         product: CLI (same role as the reference's `tungsten` binary)
+#   oracle/liboracle.so                   TEST INFRASTRUCTURE: CPU restatement (never linked by the product)
+#   oracle/_ref/*                         TEST INFRASTRUCTURE: the reference itself (only where /root/reference exists)
+HIPCC    ?= hipcc
+CC       ?= gcc
+ARCH     ?= gfx950
+LIBDIR   := tungsten_amd/lib
+OBJDIR   := build/obj
+HOSTSRC  := $(wildcard tungsten_amd/csrc/host/*.cpp)
+HOSTLIB  := $(filter-out tungsten_amd/csrc/host/main.cpp,$(HOSTSRC))
+HOSTOBJ  := $(patsubst tungsten_amd/csrc/host/%.cpp,$(OBJDIR)/host_%.o,$(HOSTLIB))
+HIPSRC   := tungsten_amd/csrc/hip/tungsten_hip.hip
+HIPHDR   := $(wildcard tungsten_amd/csrc/hip/*.h) include/tungsten_hip.h
+# -ffp-contract=off: no FMA contraction, so device arithmetic rounds like the CPU reference/oracle
+# (DESIGN.md "Numerics"); TG_FAST=1 allows contraction.
+FPFLAGS  := $(if $(TG_FAST),-ffp-contract=fast,-ffp-contract=off)
+HOSTFLAGS:= -std=c++11 -O2 -fPIC -Wall -Wextra -Wno-unused-parameter
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -Wno-unused-result
+
+all: $(LIBDIR)/libtungsten_hip.so $(LIBDIR)/tungsten_hip oracle/liboracle.so
+
+$(OBJDIR)/host_%.o: tungsten_amd/csrc/host/%.cpp $(wildcard tungsten_amd/csrc/host/*.hpp) include/tungsten_hip.h include/tungsten_host.h
+	@mkdir -p $(OBJDIR)
+	g++ $(HOSTFLAGS) -c $< -o $@
+
+$(OBJDIR)/tungsten_hip.o: $(HIPSRC) $(HIPHDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/libtungsten_hip.so: $(HOSTOBJ) $(OBJDIR)/tungsten_hip.o
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lpthread
+
+$(LIBDIR)/tungsten_hip: tungsten_amd/csrc/host/main.cpp $(LIBDIR)/libtungsten_hip.so
+	g++ $(HOSTFLAGS) $< -o $@ -L$(LIBDIR) -ltungsten_hip -Wl,-rpath,'$$ORIGIN' -lpthread
+
+oracle/liboracle.so: oracle/oracle.c include/tungsten_hip.h
+	$(CC) -std=c99 -O2 -ffp-contract=off -fopenmp -fPIC -shared $< -o $@ -lm
+
+# the reference itself, only where its sources are mounted
+ref:
+	@if [ -d /root/reference/src ]; then $(MAKE) -f oracle/Makefile.ref -j$$(nproc) all; else echo "no /root/reference: keeping prebuilt oracle/_ref"; fi
+
+clean:
+	rm -rf build $(LIBDIR) oracle/liboracle.so
+
+.PHONY: all ref clean

@@ -1,0 +1,92 @@
+"""ctypes access to oracle/liboracle.so -- TEST INFRASTRUCTURE (checker only, never the thing measured)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from tungsten_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_lib = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+
+
+class OracleCounters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("nodes_visited", C.c_uint64), ("prims_tested", C.c_uint64)]
+
+
+DESC_P = C.POINTER(capi.TgHipSceneDesc)
+_lib.oracle_trace_sample.argtypes = [DESC_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+_lib.oracle_render.argtypes = [DESC_P, C.POINTER(capi.TgHipPassDesc), C.c_void_p, C.c_void_p, C.POINTER(OracleCounters), C.c_int]
+_lib.oracle_render.restype = C.c_int
+_lib.oracle_trace_rays.argtypes = [DESC_P, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+_lib.oracle_rng_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+_lib.oracle_camera_ray.argtypes = [DESC_P, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+_lib.oracle_bsdf_eval.argtypes = [DESC_P, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]
+_lib.oracle_bsdf_sample.argtypes = [DESC_P, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_int)]
+_lib.oracle_bsdf_sample.restype = C.c_int
+_lib.oracle_light_sample.argtypes = [DESC_P, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+_lib.oracle_light_sample.restype = C.c_int
+_lib.oracle_texture_eval.argtypes = [DESC_P, C.c_int, C.c_float, C.c_float, C.c_void_p]
+
+
+def render(desc, width, height, spp_begin, spp_end, seed, shard_index=0, shard_count=1, threads=0, counters=None):
+    """Returns (sum[H,W,3], count[H,W]) like the device framebuffer."""
+    ssum = np.zeros((height, width, 3), np.float32)
+    count = np.zeros((height, width), np.uint32)
+    p = capi.TgHipPassDesc(spp_begin, spp_end, seed & 0xFFFFFFFF, shard_index, shard_count, 0)
+    c = counters if counters is not None else OracleCounters()
+    _lib.oracle_render(desc, C.byref(p), ssum.ctypes.data, count.ctypes.data, C.byref(c), threads)
+    return ssum, count
+
+
+def trace_sample(desc, seed, px, py, sample):
+    rgb = (C.c_float*3)()
+    _lib.oracle_trace_sample(desc, seed & 0xFFFFFFFF, px, py, sample, rgb)
+    return np.array(rgb[:], np.float32)
+
+
+def trace_rays(desc, rays):
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+    hits = np.empty(rays.shape[0], dtype=[("t", np.float32), ("u", np.float32), ("v", np.float32), ("rec", np.int32)])
+    nodes, prims = C.c_uint64(0), C.c_uint64(0)
+    _lib.oracle_trace_rays(desc, rays.ctypes.data, hits.ctypes.data, rays.shape[0], C.byref(nodes), C.byref(prims))
+    return hits, nodes.value, prims.value
+
+
+def rng_stream(seed, pixel, sample, n):
+    out = np.empty(n, np.float32)
+    _lib.oracle_rng_stream(seed & 0xFFFFFFFF, pixel, sample, n, out.ctypes.data)
+    return out
+
+
+def camera_ray(desc, px, py, xi0, xi1):
+    o, d = np.empty(3, np.float32), np.empty(3, np.float32)
+    _lib.oracle_camera_ray(desc, px, py, xi0, xi1, o.ctypes.data, d.ctypes.data)
+    return o, d
+
+
+def bsdf_eval(desc, bsdf, wi, wo, uv, requested):
+    wi, wo, uv = [np.ascontiguousarray(v, np.float32) for v in (wi, wo, uv)]
+    f = np.empty(3, np.float32)
+    pdf = C.c_float(0)
+    _lib.oracle_bsdf_eval(desc, bsdf, wi.ctypes.data, wo.ctypes.data, uv.ctypes.data, requested & 0xFFFFFFFF, f.ctypes.data, C.byref(pdf))
+    return f, pdf.value
+
+
+def bsdf_sample(desc, bsdf, wi, uv, requested, xi):
+    wi, uv, xi = [np.ascontiguousarray(v, np.float32) for v in (wi, uv, xi)]
+    wo, weight = np.empty(3, np.float32), np.empty(3, np.float32)
+    pdf, lobe, consumed = C.c_float(0), C.c_uint32(0), C.c_int(0)
+    ok = _lib.oracle_bsdf_sample(desc, bsdf, wi.ctypes.data, uv.ctypes.data, requested & 0xFFFFFFFF, xi.ctypes.data, len(xi),
+                                 wo.ctypes.data, weight.ctypes.data, C.byref(pdf), C.byref(lobe), C.byref(consumed))
+    return bool(ok), wo, weight, pdf.value, lobe.value, consumed.value
+
+
+def light_sample(desc, light, p, xi0, xi1):
+    p = np.ascontiguousarray(p, np.float32)
+    d = np.empty(3, np.float32)
+    dist, pdf = C.c_float(0), C.c_float(0)
+    ok = _lib.oracle_light_sample(desc, light, p.ctypes.data, xi0, xi1, d.ctypes.data, C.byref(dist), C.byref(pdf))
+    return bool(ok), d, dist.value, pdf.value

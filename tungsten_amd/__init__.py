@@ -1,0 +1,149 @@
+"""tungsten_amd -- MI355X-native `path_tracer_hip` integrator behind Tungsten's plugin surface.
+
+Python here is only a ctypes convenience layer over the C-ABI (include/tungsten_hip.h,
+include/tungsten_host.h) for tests and bench.py; all rendering happens in the native library
+(C++11 host + HIP kernels for gfx950).  Importing the package fails if that library is missing:
+there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+from .capi import (TgHipCounters, TgHipHit, TgHipPassDesc, TgHipRay, TgHipSceneDesc, TgHostSceneInfo)
+
+lib = capi.load_library()
+
+DEFAULT_SEED = 0xBA5EBA11  # src/tungsten/Shared.hpp:246
+
+
+class TungstenError(RuntimeError):
+    pass
+
+
+def device_count():
+    return int(lib.tghip_device_count())
+
+
+class FlattenedScene(object):
+    """Scene::load + loadResources + TraceableScene flattening (no device needed)."""
+
+    def __init__(self, json_path):
+        err = C.create_string_buffer(1024)
+        self._h = lib.tgh_scene_load(os.fsencode(json_path), err, len(err))
+        if not self._h:
+            raise TungstenError(err.value.decode(errors="replace"))
+        self.desc = lib.tgh_scene_desc(self._h)
+        info = TgHostSceneInfo()
+        lib.tgh_scene_info(self._h, C.byref(info))
+        self.info = info
+
+    @property
+    def width(self):
+        return int(self.info.width)
+
+    @property
+    def height(self):
+        return int(self.info.height)
+
+    def close(self):
+        if self._h:
+            lib.tgh_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Renderer(object):
+    """makeTraceable(seed) with the path_tracer_hip integrator + the CLI render loop."""
+
+    def __init__(self, json_path, seed=DEFAULT_SEED, spp=0, devices=0):
+        err = C.create_string_buffer(1024)
+        self._err = err
+        self._h = lib.tgh_renderer_open(os.fsencode(json_path), seed & 0xFFFFFFFF, int(spp), int(devices), err, len(err))
+        if not self._h:
+            raise TungstenError(err.value.decode(errors="replace"))
+        info = TgHostSceneInfo()
+        lib.tgh_renderer_info(self._h, C.byref(info))
+        self.info = info
+        self.width, self.height = int(info.width), int(info.height)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise TungstenError(self._err.value.decode(errors="replace"))
+
+    def context(self, device=0):
+        return lib.tgh_renderer_context(self._h, device)
+
+    def set_option(self, key, value, device=0):
+        rc = lib.tghip_set_option(self.context(device), key.encode(), int(value))
+        if rc != 0:
+            raise TungstenError(lib.tghip_last_error(self.context(device)).decode())
+
+    def step(self):
+        done = C.c_int(0)
+        self._check(lib.tgh_renderer_step(self._h, C.byref(done), self._err, len(self._err)))
+        return bool(done.value)
+
+    def render(self):
+        """while (!done) { startRender; waitForCompletion }; returns wall seconds of the loop."""
+        secs = C.c_double(0.0)
+        self._check(lib.tgh_renderer_render(self._h, C.byref(secs), self._err, len(self._err)))
+        return secs.value
+
+    def image(self):
+        """(mean, sum, count): mean radiance [H,W,3], raw radiance sums [H,W,3], sample counts [H,W]."""
+        n = self.width*self.height
+        mean = np.empty((self.height, self.width, 3), np.float32)
+        ssum = np.empty((self.height, self.width, 3), np.float32)
+        count = np.empty((self.height, self.width), np.uint32)
+        self._check(lib.tgh_renderer_image(self._h, mean.ctypes.data, ssum.ctypes.data, count.ctypes.data, n,
+                                           self._err, len(self._err)))
+        return mean, ssum, count
+
+    def counters(self, device=0):
+        c = TgHipCounters()
+        lib.tghip_get_counters(self.context(device), C.byref(c))
+        return c
+
+    def reset_counters(self, device=0):
+        lib.tghip_reset_counters(self.context(device))
+
+    def trace_rays(self, rays, repeats=1, device=0):
+        """Batched TraceableScene::intersect: rays [N,8] float32 (o, tmin, d, tmax) -> hits (t,u,v,rec)."""
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+        hits = np.empty(rays.shape[0], dtype=[("t", np.float32), ("u", np.float32), ("v", np.float32), ("rec", np.int32)])
+        ms = C.c_double(0.0)
+        rc = lib.tghip_trace_rays(self.context(device), rays.ctypes.data, hits.ctypes.data, rays.shape[0], int(repeats), C.byref(ms))
+        if rc != 0:
+            raise TungstenError(lib.tghip_last_error(self.context(device)).decode())
+        return hits, ms.value
+
+    def save_outputs(self):
+        self._check(lib.tgh_renderer_save_outputs(self._h, self._err, len(self._err)))
+
+    def close(self):
+        if self._h:
+            lib.tgh_renderer_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def load_pfm(path):
+    with open(path, "rb") as f:
+        magic = f.readline().strip()
+        w, h = [int(v) for v in f.readline().split()]
+        scale = float(f.readline())
+        ch = 3 if magic == b"PF" else 1
+        data = np.frombuffer(f.read(w*h*ch*4), dtype="<f4" if scale < 0 else ">f4").reshape(h, w, ch)
+    return np.ascontiguousarray(data[::-1]).astype(np.float32)

@@ -1,0 +1,958 @@
+// path_tracer_hip: kernels + the extern "C" shim declared in include/tungsten_hip.h.
+// gfx950 (MI355X) only.  See pt_kernels.h for the execution model and DESIGN.md for the layout.
+#include "pt_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// =============================================================================================
+// Kernels
+// =============================================================================================
+
+// (Re)initialises every slot of a chunk: pixel assignment, sample range, zeroed accumulators.
+__global__ __launch_bounds__(256) void k_init(PathState st, PassParams pp)
+{
+    uint32_t slot = blockIdx.x*blockDim.x + threadIdx.x;
+    if (slot == 0) {
+        st.ctr->n_ext[0] = st.ctr->n_ext[1] = 0;
+        st.ctr->n_shadow[0] = st.ctr->n_shadow[1] = 0;
+    }
+    if (slot >= st.num_slots)
+        return;
+    uint32_t x, y, stream;
+    bool valid = slotPixel(pp, slot, x, y, stream);
+    uint32_t first = pp.spp_begin + stream;
+    valid = valid && first < pp.spp_end;
+    st.pixel[slot] = valid ? x + y*pp.width : 0xFFFFFFFFu;
+    st.samp[slot] = make_uint2(first, pp.spp_end);
+    st.acc[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+    st.emi[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    st.thr[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, valid ? ST_FRESH : ST_DONE)));
+}
+
+// Finalises finished paths (OutputBuffer::addSample semantics, cameras/OutputBuffer.hpp:104-107: NaN/Inf
+// samples are dropped without counting), regenerates the slot's next camera path, and compacts
+// the live slots into the extension queue of the next iteration.
+__global__ __launch_bounds__(256) void k_advance(DeviceScene s, PathState st, PassParams pp, int nextParity)
+{
+    const uint32_t stride = gridDim.x*blockDim.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        st.ctr->n_shadow[nextParity] = 0;
+    uint32_t finished = 0;
+    const bool aborted = st.ctr->abort_flag != 0;
+    for (uint32_t base = blockIdx.x*blockDim.x; base < st.num_slots; base += stride) {
+        uint32_t slot = base + threadIdx.x;
+        bool push = false;
+        if (slot < st.num_slots) {
+            float4 thr = st.thr[slot];
+            uint32_t flags = __float_as_uint(thr.w);
+            uint32_t state = FLAG_STATE(flags);
+            if (state == ST_ACTIVE) {
+                push = !aborted;
+            } else if (state != ST_DONE) {
+                uint2 samp = st.samp[slot];
+                if (state != ST_FRESH) {
+                    f3 em = xyz(st.emi[slot]);
+                    if (state == ST_TERMINATED_BLACK || isnan(sum3(em)))
+                        em = splat3(0.0f);                       // PathTracer.cpp:119-122,130-131
+                    float4 acc = st.acc[slot];
+                    bool finite = !(isinf(em.x) || isinf(em.y) || isinf(em.z));
+                    if (finite) {
+                        acc.x += em.x; acc.y += em.y; acc.z += em.z;
+                        acc.w = __uint_as_float(__float_as_uint(acc.w) + 1u);
+                        st.acc[slot] = acc;
+                    }
+                    finished++;
+                    samp.x += pp.streams;
+                }
+                if (samp.x < samp.y && !aborted) {
+                    uint32_t pixel = st.pixel[slot];
+                    Rng rng = rngStart(pp.seed, pixel, samp.x);   // PathSampleGenerator::startPath
+                    f3 o, d;
+                    cameraRay(s.camera, pixel % pp.width, pixel/pp.width, rng, o, d);
+                    st.ray_o[slot] = mk4(o, 1e-4f);               // Ray ctor default nearT (math/Ray.hpp:24)
+                    st.ray_d[slot] = mk4(d, PT_INF);
+                    st.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    st.emi[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
+                    push = true;
+                } else {
+                    st.thr[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
+                }
+                st.samp[slot] = samp;
+            }
+        }
+        queuePush(push, slot, st.q_ext, &st.ctr->n_ext[nextParity]);
+    }
+    waveAddStat(&st.ctr->samples, finished);
+}
+
+template<bool COUNT>
+__global__ __launch_bounds__(256) void k_trace_closest(DeviceScene s, PathState st, int parity)
+{
+    extern __shared__ int ldsStack[];
+    const uint32_t n = st.ctr->n_ext[parity];
+    const uint32_t stride = gridDim.x*blockDim.x;
+    uint32_t nodes = 0, prims = 0, rays = 0;
+    for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t slot = st.q_ext[i];
+        float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
+        RayD ray;
+        ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
+        st.hit[slot] = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+        rays++;
+    }
+    waveAddStat(&st.ctr->closest_rays, rays);
+    if (COUNT) {
+        waveAddStat(&st.ctr->nodes_visited, nodes);
+        waveAddStat(&st.ctr->prims_tested, prims);
+    }
+}
+
+// stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
+template<bool COUNT>
+__global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 *rays, float4 *hits, uint32_t n, PathCounters *ctr)
+{
+    extern __shared__ int ldsStack[];
+    const uint32_t stride = gridDim.x*blockDim.x;
+    uint32_t nodes = 0, prims = 0;
+    for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += stride) {
+        float4 ro = rays[i*2 + 0], rd = rays[i*2 + 1];
+        RayD ray;
+        ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
+        hits[i] = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+    }
+    if (COUNT) {
+        waveAddStat(&ctr->nodes_visited, nodes);
+        waveAddStat(&ctr->prims_tested, prims);
+    }
+}
+
+// PathTracer::traceSample's loop body for one vertex: TraceBase::handleSurface (TraceBase.cpp:516-568)
+// with estimateDirect split into "compute the unoccluded contribution here, test visibility in
+// k_trace_shadow", plus the loop epilogue (PathTracer.cpp:108-129).
+__global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, int parity)
+{
+    const uint32_t n = st.ctr->n_ext[parity];
+    const uint32_t stride = gridDim.x*blockDim.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        st.ctr->n_ext[parity ^ 1] = 0;
+    const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
+    const bool nee = s.settings.enable_light_sampling != 0;
+
+    for (uint32_t base = blockIdx.x*blockDim.x; base < n; base += stride) {
+        uint32_t i = base + threadIdx.x;
+        bool hasShadow = false;
+        uint32_t slot = 0;
+        if (i < n) {
+            slot = st.q_ext[i];
+            float4 ro = st.ray_o[slot], rd = st.ray_d[slot], hit = st.hit[slot], thr4 = st.thr[slot];
+            f3 em = xyz(st.emi[slot]);
+            uint2 rs = st.rng[slot];
+            uint32_t pixel = st.pixel[slot];
+            Rng rng;
+            rng.state = ((uint64_t)rs.y << 32) | rs.x;
+            rng.inc = ((uint64_t)pixel << 1) | 1u;
+            RayD ray;
+            ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
+            f3 throughput = xyz(thr4);
+            uint32_t flags = __float_as_uint(thr4.w);
+            int bounce = (int)FLAG_BOUNCE(flags);
+            bool wasSpecular = (flags & FLAG_SPECULAR) != 0;
+            uint32_t state = ST_ACTIVE;
+
+            if (__float_as_int(hit.w) < 0) {
+                // path escaped: TraceBase::handleInfiniteLights (TraceBase.cpp:570-578); the last infinite light wins
+                if (bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0) {
+                    int objIdx = s.infinite_lights[s.num_infinite_lights - 1];
+                    const TgHipObject &o = s.objects[objIdx];
+                    if (!nee || wasSpecular || !(o.flags & TGHIP_OBJF_SAMPLE)) {
+                        float u, v, sinTheta;
+                        infDirectionToUV(o, ray.d, u, v, sinTheta);
+                        em = em + throughput*textureEval(s, o.emission, u, v);
+                    }
+                }
+                state = isnan(sum3(throughput) + sum3(em)) ? ST_TERMINATED_BLACK : ST_TERMINATED;
+            } else {
+                Info info;
+                intersectionInfo(s, ray, hit, info);
+                const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
+
+                // TraceBase::makeLocalScatterEvent (TraceBase.cpp:24-51)
+                Frame frame = frameFromNormal(info.Ns);
+                bool hitBackside = dot(frame.normal, ray.d) > 0.0f;
+                bool flipped = s.settings.enable_two_sided_shading && hitBackside && !(lobes & LOBE_TRANSMISSIVE);
+                if (flipped) {
+                    frame.normal = -frame.normal;
+                    frame.tangent = -frame.tangent;
+                }
+                Event ev;
+                ev.wi = toLocal(frame, -ray.d);
+                ev.u = info.u; ev.v = info.v; ev.rng = &rng;
+                const bool consistency = s.settings.enable_consistency_checks != 0;
+                auto isConsistent = [&](f3 woLocal, f3 w) {      // TraceBase.cpp:53-60
+                    if (!consistency) return true;
+                    bool geometricBackside = dot(w, info.Ng) < 0.0f;
+                    bool shadingBackside = (woLocal.z < 0.0f) != flipped;
+                    return geometricBackside == shadingBackside;
+                };
+
+                f3 transparency = splat3(0.0f);
+                if (lobes & TGHIP_LOBE_FORWARD) {
+                    ev.wo = -ev.wi; ev.requested = TGHIP_LOBE_FORWARD;
+                    transparency = bsdfEval(s, info.bsdf, ev);
+                }
+                float transparencyScalar = avg3(transparency);
+                f3 wo;
+                bool alive = true;
+                if (rngNextBoolean(rng, transparencyScalar)) {
+                    wo = ray.d;
+                    throughput = throughput*(transparency/transparencyScalar);
+                } else {
+                    f3 pending = splat3(0.0f);
+                    // ---- next-event estimation: TraceBase::estimateDirect (TraceBase.cpp:483-494) ----
+                    if (nee && bounce < maxBounces - 1) {
+                        float lightWeight = 1.0f;
+                        int light = chooseLight(s, rng, info.p, lightWeight);
+                        bool pureSpecular = lobes != 0 && (lobes & ~(uint32_t)LOBE_SPECULAR) == 0;
+                        if (light >= 0 && !pureSpecular && lobes != TGHIP_LOBE_FORWARD) {
+                            uint32_t tag = (uint32_t)light | ((uint32_t)(bounce + 1) << 24);
+                            bool q0 = false, q1 = false;
+                            // lightSample (TraceBase.cpp:246-285)
+                            {
+                                f3 d; float dist, pdf;
+                                if (lightSampleDirect(s, light, info.p, rng, d, dist, pdf)) {
+                                    ev.wo = toLocal(frame, d);
+                                    ev.requested = LOBE_ALL_BUT_SPECULAR;
+                                    if (isConsistent(ev.wo, d)) {
+                                        f3 f = bsdfEval(s, info.bsdf, ev);
+                                        if (!isZero(f)) {
+                                            RayD sr; sr.o = info.p; sr.d = d; sr.tmin = 5e-4f; sr.tmax = PT_INF;
+                                            LightHit lh;
+                                            // attenuatedEmission's analytic hit + distance check (TraceBase.cpp:155-162)
+                                            if (lightIntersect(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist)) {
+                                                f3 e = lightEvalDirect(s, light, lh.u, lh.v, lh.backSide);
+                                                if (!isZero(e)) {
+                                                    f3 lightF = f*e/pdf;
+                                                    lightF = lightF*powerHeuristic(pdf, bsdfPdf(s, info.bsdf, ev));
+                                                    st.sh_d0[slot] = mk4(d, lh.t);
+                                                    st.sh_c0[slot] = mk4(lightF, __uint_as_float(tag));
+                                                    q0 = true;
+                                                }
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            // bsdfSample (TraceBase.cpp:287-321)
+                            {
+                                ev.requested = LOBE_ALL_BUT_SPECULAR;
+                                ev.weight = splat3(1.0f); ev.pdf = 1.0f;
+                                if (bsdfSample(s, info.bsdf, ev) && !isZero(ev.weight)) {
+                                    f3 wog = toGlobal(frame, ev.wo);
+                                    if (isConsistent(ev.wo, wog)) {
+                                        RayD sr; sr.o = info.p; sr.d = wog; sr.tmin = 5e-4f; sr.tmax = PT_INF;
+                                        LightHit lh;
+                                        if (lightIntersect(s, light, sr, lh)) {
+                                            f3 e = lightEvalDirect(s, light, lh.u, lh.v, lh.backSide);
+                                            if (!isZero(e)) {
+                                                f3 bsdfF = e*ev.weight;
+                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightDirectPdf(s, light, wog, info.p));
+                                                st.sh_d1[slot] = mk4(wog, lh.t);
+                                                st.sh_c1[slot] = mk4(bsdfF, __uint_as_float(tag));
+                                                q1 = true;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                            if (q0 || q1) {
+                                hasShadow = true;
+                                if (!q0) st.sh_c0[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                                if (!q1) st.sh_c1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                                st.sh_o[slot] = mk4(info.p, 5e-4f);
+                                st.sh_w[slot] = mk4(throughput, lightWeight);
+                            }
+                        }
+                    }
+                    // emission of the surface itself (TraceBase.cpp:540-543)
+                    {
+                        const TgHipObject &o = s.objects[info.object];
+                        if (o.emission >= 0 && bounce >= minBounces && (!nee || wasSpecular || o.light < 0))
+                            pending = lightEvalDirect(s, info.object, info.u, info.v, info.backSide)*throughput;
+                    }
+                    if (hasShadow)
+                        st.sh_p[slot] = mk4(pending, 0.0f);      // added after the NEE term, like the reference
+                    else
+                        em = em + pending;
+
+                    // continuation: bsdf.sample(event, adjoint = false) with all lobes (TraceBase.cpp:546-558)
+                    ev.requested = LOBE_ALL;
+                    ev.weight = splat3(1.0f); ev.pdf = 1.0f;
+                    if (!bsdfSample(s, info.bsdf, ev)) {
+                        alive = false;
+                    } else {
+                        wo = toGlobal(frame, ev.wo);
+                        if (!isConsistent(ev.wo, wo)) {
+                            alive = false;
+                        } else {
+                            throughput = throughput*ev.weight;
+                            wasSpecular = (ev.sampled & LOBE_SPECULAR) != 0;
+                        }
+                    }
+                }
+
+                if (!alive) {
+                    state = ST_TERMINATED;
+                } else {
+                    f3 hp = ray.o + ray.d*hit.x;                 // ray.hitpoint()
+                    ray.o = hp; ray.d = wo; ray.tmin = 5e-4f; ray.tmax = PT_INF;
+                    // loop epilogue (PathTracer.cpp:108-126)
+                    if (max3(throughput) == 0.0f) {
+                        state = ST_TERMINATED;                   // the env term after `break` is throughput*L = 0
+                    } else {
+                        float roulettePdf = fmaxf(fabsf(throughput.x), fmaxf(fabsf(throughput.y), fabsf(throughput.z)));
+                        bool killed = false;
+                        if (bounce > 2 && roulettePdf < 0.1f) {
+                            if (rngNextBoolean(rng, roulettePdf))
+                                throughput = throughput/roulettePdf;
+                            else
+                                killed = true;
+                        }
+                        if (killed) {
+                            state = ST_TERMINATED;
+                        } else if (isnan(sum3(ray.d) + sum3(ray.o)) || isnan(sum3(throughput) + sum3(em))) {
+                            state = ST_TERMINATED_BLACK;
+                        } else {
+                            bounce++;
+                            state = bounce < maxBounces ? ST_ACTIVE : ST_TERMINATED;
+                        }
+                    }
+                }
+                if (state == ST_ACTIVE) {
+                    st.ray_o[slot] = mk4(ray.o, ray.tmin);
+                    st.ray_d[slot] = mk4(ray.d, ray.tmax);
+                    st.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                }
+            }
+            st.emi[slot] = mk4(em, 0.0f);
+            st.thr[slot] = mk4(throughput, __uint_as_float(FLAG_MAKE(bounce, wasSpecular, state)));
+        }
+        queuePush(hasShadow, slot, st.q_shadow, &st.ctr->n_shadow[parity]);
+    }
+}
+
+// TraceBase::generalizedShadowRay (TraceBase.cpp:62-125) for the shadow rays queued by k_shade:
+// a closest-hit query up to the light; unoccluded iff nothing is hit or the closest hit is the
+// light itself (endCap); surfaces with a forward lobe attenuate and the ray continues.
+template<bool COUNT>
+__global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState st, int parity)
+{
+    extern __shared__ int ldsStack[];
+    const uint32_t n = st.ctr->n_shadow[parity];
+    const uint32_t stride = gridDim.x*blockDim.x;
+    uint32_t nodes = 0, prims = 0, rays = 0;
+    for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t slot = st.q_shadow[i];
+        float4 so = st.sh_o[slot];
+        f3 result = splat3(0.0f);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float4 c = r == 0 ? st.sh_c0[slot] : st.sh_c1[slot];
+            uint32_t tag = __float_as_uint(c.w);
+            if (tag == 0xFFFFFFFFu)
+                continue;
+            float4 sd = r == 0 ? st.sh_d0[slot] : st.sh_d1[slot];
+            int endCap = (int)(tag & 0xFFFFFFu);
+            int bounce = (int)(tag >> 24);
+            RayD ray;
+            ray.o = xyz(so); ray.d = xyz(sd); ray.tmin = so.w; ray.tmax = sd.w;
+            float remaining = ray.tmax;
+            f3 transmittance = splat3(1.0f);
+            for (;;) {
+                float4 hit = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+                rays++;
+                int ri = __float_as_int(hit.w);
+                int hitObject = -1;
+                if (ri >= 0)
+                    hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(s.recs[ri*3].w));
+                if (ri < 0 || hitObject == endCap) {
+                    if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
+                    break;
+                }
+                Info info;
+                intersectionInfo(s, ray, hit, info);
+                const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
+                if (!(lobes & TGHIP_LOBE_FORWARD)) { transmittance = splat3(0.0f); break; }
+                Frame frame = frameFromNormal(info.Ns);
+                bool hitBackside = dot(frame.normal, ray.d) > 0.0f;
+                if (s.settings.enable_two_sided_shading && hitBackside && !(lobes & LOBE_TRANSMISSIVE)) {
+                    frame.normal = -frame.normal;
+                    frame.tangent = -frame.tangent;
+                }
+                Event fe;
+                fe.wi = toLocal(frame, -ray.d); fe.wo = -fe.wi;
+                fe.requested = TGHIP_LOBE_FORWARD; fe.u = info.u; fe.v = info.v; fe.rng = nullptr;
+                f3 transparency = bsdfEval(s, info.bsdf, fe);
+                if (isZero(transparency)) { transmittance = splat3(0.0f); break; }
+                transmittance = transmittance*transparency;
+                bounce++;
+                if (bounce >= s.settings.max_bounces) { transmittance = splat3(0.0f); break; }
+                ray.o = ray.o + ray.d*hit.x;
+                remaining -= hit.x;
+                ray.tmin = 5e-4f;
+                ray.tmax = remaining;
+            }
+            if (!isZero(transmittance))
+                result = result + xyz(c)*transmittance;
+        }
+        float4 w = st.sh_w[slot];
+        f3 em = xyz(st.emi[slot]);
+        em = em + (result*w.w)*xyz(w);                           // emission += estimateDirect(...)*throughput
+        em = em + xyz(st.sh_p[slot]);
+        st.emi[slot] = mk4(em, 0.0f);
+    }
+    waveAddStat(&st.ctr->shadow_rays, rays);
+    if (COUNT) {
+        waveAddStat(&st.ctr->nodes_visited, nodes);
+        waveAddStat(&st.ctr->prims_tested, prims);
+    }
+}
+
+// Sums the K per-stream partial sums of every pixel slot in fixed order into the framebuffer
+// (deterministic; no float atomics anywhere on the accumulation path).
+__global__ __launch_bounds__(256) void k_resolve(PathState st, PassParams pp, float *fbSum, uint32_t *fbCount)
+{
+    uint32_t j = blockIdx.x*blockDim.x + threadIdx.x;
+    if (j >= pp.pix_slots)
+        return;
+    uint32_t pixel = st.pixel[j];
+    if (pixel == 0xFFFFFFFFu) {
+        // stream 0 invalid means the pixel is outside the image (or the pass is empty)
+        uint32_t x, y, stream;
+        if (!slotPixel(pp, j, x, y, stream))
+            return;
+        pixel = x + y*pp.width;
+    }
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < pp.streams; ++k) {
+        float4 a = st.acc[(size_t)k*pp.pix_slots + j];
+        sx += a.x; sy += a.y; sz += a.z;
+        cnt += __float_as_uint(a.w);
+    }
+    fbSum[(size_t)pixel*3 + 0] += sx;
+    fbSum[(size_t)pixel*3 + 1] += sy;
+    fbSum[(size_t)pixel*3 + 2] += sz;
+    fbCount[pixel] += cnt;
+}
+
+// =============================================================================================
+// Host-side shim
+// =============================================================================================
+namespace {
+
+std::mutex g_errMutex;
+std::string g_createError = "no error";
+
+struct DeviceBuffers {
+    std::vector<void *> allocs;
+    ~DeviceBuffers() { release(); }
+    void release() { for (void *p : allocs) (void)hipFree(p); allocs.clear(); }
+};
+
+} // namespace
+
+struct tghip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    std::string error = "no error";
+
+    // scene
+    bool haveScene = false;
+    DeviceBuffers sceneMem;
+    DeviceScene scene;
+    int bvhDepth = 0;
+    uint32_t width = 0, height = 0;
+
+    // framebuffer
+    float *fbSum = nullptr;
+    uint32_t *fbCount = nullptr;
+    float *extSum = nullptr;
+    uint32_t *extCount = nullptr;
+
+    // path pool
+    DeviceBuffers poolMem;
+    PathState pool;
+    uint32_t poolSlots = 0;
+    PathCounters *hostCtr = nullptr;      // pinned mirror for the loop condition
+
+    // options
+    long long maxSlots = 1ll << 21;       // target pool size
+    bool countTraversal = false;
+    int checkInterval = 4;                // wavefront iterations between host-side liveness checks
+    int blocksPerCu = 4;
+
+    // async pass state
+    bool passPending = false;
+    int passResult = TGHIP_OK;
+    TgHipPassDesc pendingPass;
+
+    // counters
+    TgHipCounters counters;
+    hipEvent_t evA = nullptr, evB = nullptr;
+};
+
+#define HIP_TRY(ctx, call)                                                                  \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (ctx)->error = std::string(#call) + ": " + hipGetErrorString(e_);               \
+            return TGHIP_E_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+
+template<typename T>
+static int uploadArray(tghip_ctx *ctx, DeviceBuffers &mem, const T *src, size_t count, const T **dst)
+{
+    size_t bytes = std::max<size_t>(count, 1)*sizeof(T);
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, bytes));
+    mem.allocs.push_back(p);
+    if (count)
+        HIP_TRY(ctx, hipMemcpyAsync(p, src, count*sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    *dst = static_cast<const T *>(p);
+    return TGHIP_OK;
+}
+
+template<typename T>
+static int allocArray(tghip_ctx *ctx, DeviceBuffers &mem, size_t count, T **dst)
+{
+    void *p = nullptr;
+    HIP_TRY(ctx, hipMalloc(&p, std::max<size_t>(count, 1)*sizeof(T)));
+    mem.allocs.push_back(p);
+    *dst = static_cast<T *>(p);
+    return TGHIP_OK;
+}
+
+static int bsdfDepth(const TgHipSceneDesc *s, int bi, int depth)
+{
+    if (bi < 0 || depth > 16) return depth;
+    const TgHipBsdf &b = s->bsdfs[bi];
+    int d = depth + 1;
+    if (b.type == TGHIP_BSDF_SMOOTH_COAT || b.type == TGHIP_BSDF_TRANSPARENCY)
+        return bsdfDepth(s, b.sub0, d);
+    if (b.type == TGHIP_BSDF_MIXED)
+        return std::max(bsdfDepth(s, b.sub0, d), bsdfDepth(s, b.sub1, d));
+    return d;
+}
+
+static int bvhDepthOf(const TgHipSceneDesc *s)
+{
+    // iterative depth computation over the flattened tree (also validates child references)
+    std::vector<std::pair<int32_t, int>> stack;
+    stack.emplace_back(0, 1);
+    int depth = 0;
+    size_t visited = 0;
+    while (!stack.empty()) {
+        auto cur = stack.back();
+        stack.pop_back();
+        if (cur.first < 0) {
+            uint32_t first = TGHIP_LEAF_FIRST(cur.first), count = TGHIP_LEAF_COUNT(cur.first);
+            if (first + count > s->num_recs) return -1;
+            continue;
+        }
+        if (uint32_t(cur.first) >= s->num_nodes || ++visited > s->num_nodes) return -1;
+        depth = std::max(depth, cur.second);
+        stack.emplace_back(s->nodes[cur.first].child0, cur.second + 1);
+        stack.emplace_back(s->nodes[cur.first].child1, cur.second + 1);
+    }
+    return depth;
+}
+
+static int ensurePool(tghip_ctx *ctx, uint32_t slots)
+{
+    if (ctx->poolSlots >= slots)
+        return TGHIP_OK;
+    ctx->poolMem.release();
+    ctx->poolSlots = 0;
+    PathState &p = ctx->pool;
+    int rc;
+#define POOL_ALLOC(field, n) if ((rc = allocArray(ctx, ctx->poolMem, (n), &p.field)) != TGHIP_OK) return rc
+    POOL_ALLOC(ray_o, slots); POOL_ALLOC(ray_d, slots); POOL_ALLOC(hit, slots); POOL_ALLOC(thr, slots);
+    POOL_ALLOC(emi, slots); POOL_ALLOC(acc, slots); POOL_ALLOC(rng, slots); POOL_ALLOC(samp, slots);
+    POOL_ALLOC(pixel, slots);
+    POOL_ALLOC(sh_o, slots); POOL_ALLOC(sh_d0, slots); POOL_ALLOC(sh_c0, slots); POOL_ALLOC(sh_d1, slots);
+    POOL_ALLOC(sh_c1, slots); POOL_ALLOC(sh_w, slots); POOL_ALLOC(sh_p, slots);
+    POOL_ALLOC(q_ext, slots); POOL_ALLOC(q_shadow, slots);
+    POOL_ALLOC(ctr, 1);
+#undef POOL_ALLOC
+    HIP_TRY(ctx, hipMemsetAsync(p.ctr, 0, sizeof(PathCounters), ctx->stream));
+    ctx->poolSlots = slots;
+    return TGHIP_OK;
+}
+
+extern "C" {
+
+int tghip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+tghip_ctx *tghip_create(int device_ordinal)
+{
+    int n = tghip_device_count();
+    if (device_ordinal < 0 || device_ordinal >= n) {
+        std::lock_guard<std::mutex> lock(g_errMutex);
+        g_createError = n == 0 ? "no HIP device available" : "device ordinal out of range";
+        return nullptr;
+    }
+    tghip_ctx *ctx = new tghip_ctx();
+    ctx->device = device_ordinal;
+    std::memset(&ctx->counters, 0, sizeof(ctx->counters));
+    std::memset(&ctx->pool, 0, sizeof(ctx->pool));
+    std::memset(&ctx->scene, 0, sizeof(ctx->scene));
+    hipError_t e = hipSetDevice(device_ordinal);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_ordinal);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evA);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->evB);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->hostCtr), sizeof(PathCounters), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lock(g_errMutex);
+        g_createError = std::string("tghip_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void tghip_destroy(tghip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->sceneMem.release();
+    ctx->poolMem.release();
+    if (ctx->fbSum) (void)hipFree(ctx->fbSum);
+    if (ctx->fbCount) (void)hipFree(ctx->fbCount);
+    if (ctx->hostCtr) (void)hipHostFree(ctx->hostCtr);
+    if (ctx->evA) (void)hipEventDestroy(ctx->evA);
+    if (ctx->evB) (void)hipEventDestroy(ctx->evB);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *tghip_last_error(tghip_ctx *ctx)
+{
+    if (!ctx) {
+        std::lock_guard<std::mutex> lock(g_errMutex);
+        static thread_local std::string copy;
+        copy = g_createError;
+        return copy.c_str();
+    }
+    return ctx->error.c_str();
+}
+
+int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
+{
+    if (!ctx || !key) return TGHIP_E_INVALID;
+    std::string k(key);
+    if (k == "count_traversal") ctx->countTraversal = value != 0;
+    else if (k == "max_slots") ctx->maxSlots = std::max<long long>(value, 256);
+    else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
+    else if (k == "blocks_per_cu") ctx->blocksPerCu = int(std::min<long long>(std::max<long long>(value, 1), 8));
+    else { ctx->error = "unknown option '" + k + "'"; return TGHIP_E_INVALID; }
+    return TGHIP_OK;
+}
+
+int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
+{
+    if (!ctx || !sd) return TGHIP_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (sd->abi_version != TGHIP_ABI_VERSION) { ctx->error = "scene description ABI version mismatch"; return TGHIP_E_INVALID; }
+    if (sd->num_nodes == 0 || !sd->nodes) { ctx->error = "scene has no BVH"; return TGHIP_E_INVALID; }
+    if (sd->camera.res_x <= 0 || sd->camera.res_y <= 0) { ctx->error = "invalid camera resolution"; return TGHIP_E_INVALID; }
+    if (sd->num_lights > 16) { ctx->error = "more than 16 sampled lights are not supported"; return TGHIP_E_UNSUPPORTED; }
+    if (sd->num_objects >= (1u << 24)) { ctx->error = "too many objects"; return TGHIP_E_UNSUPPORTED; }
+    int depth = bvhDepthOf(sd);
+    if (depth < 0 || depth > TGHIP_MAX_BVH_DEPTH) { ctx->error = "malformed or too deep BVH"; return TGHIP_E_INVALID; }
+    for (uint32_t i = 0; i < sd->num_bsdfs; ++i)
+        if (bsdfDepth(sd, int(i), 0) > PT_MAX_BSDF_DEPTH) { ctx->error = "BSDF nesting deeper than 3 is not supported"; return TGHIP_E_UNSUPPORTED; }
+    for (uint32_t i = 0; i < sd->num_recs; ++i)
+        if (TGHIP_REC_KIND(sd->recs[i].meta) == TGHIP_REC_SPHERE) { ctx->error = "sphere primitives are a 'next' row (SURVEY.md 8f4)"; return TGHIP_E_UNSUPPORTED; }
+    for (uint32_t i = 0; i < sd->num_lights; ++i) {
+        int t = sd->objects[sd->lights[i]].type;
+        if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE) { ctx->error = "only quad and infinite_sphere emitters are sampled"; return TGHIP_E_UNSUPPORTED; }
+    }
+
+    if (ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sceneMem.release();
+    ctx->haveScene = false;
+    DeviceScene &s = ctx->scene;
+    std::memset(&s, 0, sizeof(s));
+    int rc;
+    const TgHipBvhNode *dn; const TgHipPrimRec *dr; const TgHipTriAttr *da;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->nodes, sd->num_nodes, &dn)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->recs, sd->num_recs, &dr)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->tri_attrs, sd->num_recs, &da)) != TGHIP_OK) return rc;
+    s.nodes = reinterpret_cast<const float4 *>(dn);
+    s.recs = reinterpret_cast<const float4 *>(dr);
+    s.tri_attrs = reinterpret_cast<const float4 *>(da);
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->objects, sd->num_objects, &s.objects)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->lights, sd->num_lights, &s.lights)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->infinite_lights, sd->num_infinite_lights, &s.infinite_lights)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->bsdfs, sd->num_bsdfs, &s.bsdfs)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->textures, sd->num_textures, &s.textures)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->texels, sd->num_texel_floats, &s.texels)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->dist, sd->num_dist_floats, &s.dist)) != TGHIP_OK) return rc;
+    s.num_nodes = sd->num_nodes; s.num_recs = sd->num_recs; s.num_objects = sd->num_objects;
+    s.num_lights = sd->num_lights; s.num_infinite_lights = sd->num_infinite_lights;
+    s.num_bsdfs = sd->num_bsdfs; s.num_textures = sd->num_textures;
+    s.camera = sd->camera;
+    s.settings = sd->settings;
+    ctx->bvhDepth = depth;
+
+    // framebuffer
+    if (ctx->width != uint32_t(sd->camera.res_x) || ctx->height != uint32_t(sd->camera.res_y) || !ctx->fbSum) {
+        if (ctx->fbSum) (void)hipFree(ctx->fbSum);
+        if (ctx->fbCount) (void)hipFree(ctx->fbCount);
+        ctx->fbSum = nullptr; ctx->fbCount = nullptr;
+        ctx->width = uint32_t(sd->camera.res_x); ctx->height = uint32_t(sd->camera.res_y);
+        size_t npix = size_t(ctx->width)*ctx->height;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->fbSum), npix*3*sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->fbCount), npix*sizeof(uint32_t)));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->haveScene = true;
+    return tghip_clear_framebuffer(ctx);
+}
+
+int tghip_clear_framebuffer(tghip_ctx *ctx)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t npix = size_t(ctx->width)*ctx->height;
+    float *sum = ctx->extSum ? ctx->extSum : ctx->fbSum;
+    uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
+    HIP_TRY(ctx, hipMemsetAsync(sum, 0, npix*3*sizeof(float), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(cnt, 0, npix*sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
+int tghip_bind_framebuffer(tghip_ctx *ctx, float *dev_rgb_sum, uint32_t *dev_count)
+{
+    if (!ctx) return TGHIP_E_INVALID;
+    if ((dev_rgb_sum == nullptr) != (dev_count == nullptr)) { ctx->error = "bind both buffers or neither"; return TGHIP_E_INVALID; }
+    ctx->extSum = dev_rgb_sum;
+    ctx->extCount = dev_count;
+    return TGHIP_OK;
+}
+
+static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*ctx->blocksPerCu; }
+
+// Runs the wavefront loop for one chunk of pixel slots until every slot is drained.
+static int runChunk(tghip_ctx *ctx, const PassParams &pp, uint32_t slots)
+{
+    PathState st = ctx->pool;
+    st.num_slots = slots;
+    const DeviceScene &s = ctx->scene;
+    const int grid = launchGrid(ctx);
+    const size_t ldsBytes = size_t(ctx->bvhDepth + 1)*256*sizeof(int);
+    const bool count = ctx->countTraversal;
+
+    hipLaunchKernelGGL(k_init, dim3((slots + 255)/256), dim3(256), 0, ctx->stream, st, pp);
+    int parity = 0;
+    hipLaunchKernelGGL(k_advance, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp, parity);
+    for (;;) {
+        for (int it = 0; it < ctx->checkInterval; ++it) {
+            if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
+            else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
+            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, ctx->stream, s, st, parity);
+            if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
+            else       hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
+            hipLaunchKernelGGL(k_advance, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp, parity ^ 1);
+            parity ^= 1;
+            ctx->counters.iterations++;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->hostCtr, st.ctr, sizeof(PathCounters), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->hostCtr->n_ext[parity] == 0)
+            break;
+    }
+    float *sum = ctx->extSum ? ctx->extSum : ctx->fbSum;
+    uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
+    hipLaunchKernelGGL(k_resolve, dim3((pp.pix_slots + 255)/256), dim3(256), 0, ctx->stream, st, pp, sum, cnt);
+    HIP_TRY(ctx, hipGetLastError());
+    return ctx->hostCtr->abort_flag ? TGHIP_E_ABORTED : TGHIP_OK;
+}
+
+// The pass itself is driven synchronously from tghip_wait (the integrator calls it from its worker
+// thread, which gives the reference's "startRender returns immediately" contract).
+int tghip_render_pass(tghip_ctx *ctx, const TgHipPassDesc *pass)
+{
+    if (!ctx || !pass) return TGHIP_E_INVALID;
+    if (!ctx->haveScene) { ctx->error = "render before upload"; return TGHIP_E_NOSCENE; }
+    if (pass->spp_end < pass->spp_begin || (pass->shard_count && pass->shard_index >= pass->shard_count)) {
+        ctx->error = "invalid pass description";
+        return TGHIP_E_INVALID;
+    }
+    ctx->passPending = true;
+    ctx->passResult = TGHIP_OK;
+    ctx->pendingPass = *pass;
+    return TGHIP_OK;
+}
+
+int tghip_wait(tghip_ctx *ctx)
+{
+    if (!ctx) return TGHIP_E_INVALID;
+    if (!ctx->passPending)
+        return ctx->passResult;
+    ctx->passPending = false;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const TgHipPassDesc pass = ctx->pendingPass;
+    const uint32_t shardCount = pass.shard_count ? pass.shard_count : 1;
+    const uint32_t w = ctx->width, h = ctx->height;
+    const uint32_t tilesX = (w + 15)/16, tilesY = (h + 15)/16;
+    const uint32_t numTiles = tilesX*tilesY;
+    const uint32_t ownedTiles = numTiles > pass.shard_index ? (numTiles - pass.shard_index + shardCount - 1)/shardCount : 0;
+    const uint32_t spp = pass.spp_end - pass.spp_begin;
+    if (ownedTiles == 0 || spp == 0)
+        return ctx->passResult = TGHIP_OK;
+
+    // pool geometry: whole tiles (256 pixel slots each) x K sample streams per pixel
+    const uint64_t maxSlots = uint64_t(ctx->maxSlots);
+    uint32_t tilesPerChunk = uint32_t(std::min<uint64_t>(ownedTiles, std::max<uint64_t>(1, maxSlots/256)));
+    uint32_t streams = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(spp, maxSlots/(uint64_t(tilesPerChunk)*256))));
+    uint32_t slots = tilesPerChunk*256*streams;
+    int rc = ensurePool(ctx, slots);
+    if (rc != TGHIP_OK) return ctx->passResult = rc;
+    HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.ctr->abort_flag, 0, sizeof(uint32_t), ctx->stream));
+
+    HIP_TRY(ctx, hipEventRecord(ctx->evA, ctx->stream));
+    for (uint32_t first = 0; first < ownedTiles; first += tilesPerChunk) {
+        PassParams pp;
+        pp.spp_begin = pass.spp_begin; pp.spp_end = pass.spp_end; pp.seed = pass.seed;
+        pp.streams = streams;
+        pp.pix_slots = tilesPerChunk*256;
+        pp.first_tile = first;
+        pp.shard_index = pass.shard_index; pp.shard_count = shardCount;
+        pp.tiles_x = tilesX; pp.num_tiles = numTiles;
+        pp.width = w; pp.height = h;
+        rc = runChunk(ctx, pp, slots);
+        if (rc != TGHIP_OK) break;
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->evB, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evA, ctx->evB));
+    ctx->counters.ms_total += ms;
+    return ctx->passResult = rc;
+}
+
+int tghip_abort(tghip_ctx *ctx)
+{
+    if (!ctx) return TGHIP_E_INVALID;
+    if (!ctx->pool.ctr) return TGHIP_OK;
+    // device-visible flag polled by the persistent k_advance grid; written from a second stream so it
+    // does not queue behind the running pass
+    static const uint32_t one = 1;
+    hipStream_t side = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    hipError_t e = hipMemcpyAsync(&ctx->pool.ctr->abort_flag, &one, sizeof(one), hipMemcpyHostToDevice, side);
+    if (e == hipSuccess) e = hipStreamSynchronize(side);
+    (void)hipStreamDestroy(side);
+    if (e != hipSuccess) { ctx->error = hipGetErrorString(e); return TGHIP_E_HIP; }
+    return TGHIP_OK;
+}
+
+int tghip_download_framebuffer(tghip_ctx *ctx, float *rgb_sum, uint32_t *count, size_t npixels)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    if (npixels != size_t(ctx->width)*ctx->height) { ctx->error = "pixel count mismatch"; return TGHIP_E_INVALID; }
+    int rc = tghip_wait(ctx);
+    if (rc != TGHIP_OK && rc != TGHIP_E_ABORTED) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const float *sum = ctx->extSum ? ctx->extSum : ctx->fbSum;
+    const uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
+    if (rgb_sum) HIP_TRY(ctx, hipMemcpyAsync(rgb_sum, sum, npixels*3*sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (count) HIP_TRY(ctx, hipMemcpyAsync(count, cnt, npixels*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
+int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    if (n == 0) return TGHIP_OK;
+    if (!rays || !hits || n > 0x7FFFFFFFu) { ctx->error = "invalid ray batch"; return TGHIP_E_INVALID; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float4 *dRays = nullptr, *dHits = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dRays), n*sizeof(TgHipRay)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dHits), n*sizeof(TgHipHit));
+    if (e != hipSuccess) { (void)hipFree(dRays); ctx->error = hipGetErrorString(e); return TGHIP_E_HIP; }
+    int rc = ensurePool(ctx, 256);
+    if (rc != TGHIP_OK) { (void)hipFree(dRays); (void)hipFree(dHits); return rc; }
+    (void)hipMemcpyAsync(dRays, rays, n*sizeof(TgHipRay), hipMemcpyHostToDevice, ctx->stream);
+    const int grid = int(std::min<size_t>(size_t(launchGrid(ctx)), (n + 255)/256));
+    const size_t ldsBytes = size_t(ctx->bvhDepth + 1)*256*sizeof(int);
+    repeats = std::max(repeats, 1);
+    (void)hipEventRecord(ctx->evA, ctx->stream);
+    for (int r = 0; r < repeats; ++r) {
+        if (ctx->countTraversal && r == 0)
+            hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.ctr);
+        else
+            hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.ctr);
+    }
+    (void)hipEventRecord(ctx->evB, ctx->stream);
+    (void)hipMemcpyAsync(hits, dHits, n*sizeof(TgHipHit), hipMemcpyDeviceToHost, ctx->stream);
+    e = hipStreamSynchronize(ctx->stream);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->evA, ctx->evB);
+    (void)hipFree(dRays); (void)hipFree(dHits);
+    if (e != hipSuccess) { ctx->error = hipGetErrorString(e); return TGHIP_E_HIP; }
+    if (ms_per_launch) *ms_per_launch = double(ms)/repeats;
+    return TGHIP_OK;
+}
+
+int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out)
+{
+    if (!ctx || !out) return TGHIP_E_INVALID;
+    if (ctx->pool.ctr) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->hostCtr, ctx->pool.ctr, sizeof(PathCounters), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->counters.samples = ctx->hostCtr->samples;
+        ctx->counters.closest_rays = ctx->hostCtr->closest_rays;
+        ctx->counters.shadow_rays = ctx->hostCtr->shadow_rays;
+        ctx->counters.nodes_visited = ctx->hostCtr->nodes_visited;
+        ctx->counters.prims_tested = ctx->hostCtr->prims_tested;
+    }
+    *out = ctx->counters;
+    return TGHIP_OK;
+}
+
+int tghip_reset_counters(tghip_ctx *ctx)
+{
+    if (!ctx) return TGHIP_E_INVALID;
+    std::memset(&ctx->counters, 0, sizeof(ctx->counters));
+    if (ctx->pool.ctr) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.ctr->samples, 0, 5*sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return TGHIP_OK;
+}
+
+} // extern "C"
