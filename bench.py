@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the path_tracer_hip hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete render of the workload through the C-ABI: tghip_clear_framebuffer +
+tghip_render_pass(spp 0..S) + tghip_wait on every rank's tile shard (16x16 tiles dealt round-robin,
+SURVEY.md 8e) and, for N > 1, the RCCL sum-reduce of the float framebuffer to rank 0.  The scene is
+flattened and uploaded before the timed region (inputs resident in HBM); the framebuffer stays in HBM.
+
+Workload at every N: BASELINE.json configs[1], Cornell box 1280x720 at 256 spp (fixed total work =>
+"scaling": "strong").  `--scene materialtest` benches configs[2]'s scene at 1280x720 (the metric's own
+wording) when its assets are present.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest accumulated time:
+achieved = algorithmic bytes per launch / average launch duration, both from the timed region (HIP events
+recorded by the shim on the stream the kernels run on; byte model in DESIGN.md "Roofline").  `cpu_baseline`
+times the reference itself (oracle/_ref/tungsten, kind "reference") or, when that binary is absent, the
+oracle port, on a bounded sample of the same workload on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "materialtest"])
+    ap.add_argument("--res", default="1280x720")
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--opt", action="append", default=[], help="shim option key=value (tghip_set_option)")
+    return ap.parse_args()
+
+
+# ---- algorithmic bytes (DESIGN.md "Roofline") ------------------------------------------
+NODE_B, REC_B = 64, 48          # TgHipBvhNode, TgHipPrimRec
+RAY_B, HIT_B = 32, 16           # (o,tmin,d,tmax), (t,u,v,rec)
+
+
+def kernel_bytes(c):
+    """Algorithmic bytes moved by each kernel class over everything the counters cover."""
+    nodes_sh, prims_sh = c["nodes_visited_shadow"], c["prims_tested_shadow"]
+    nodes_cl, prims_cl = c["nodes_visited"] - nodes_sh, c["prims_tested"] - prims_sh
+    paths = c["closest_rays"]            # path vertices processed by k_shade == extension rays
+    return {
+        # queue index + ray in + hit out + BVH nodes and primitive records actually visited
+        "k_trace_closest": paths*(4 + RAY_B + HIT_B) + NODE_B*nodes_cl + REC_B*prims_cl,
+        # queue index, shadow origin, per shadow ray (dir+contribution), throughput/pending, radiance read+write
+        "k_trace_shadow": c["shadow_slots"]*(4 + 16 + 16 + 16 + 32) + c["shadow_rays"]*32 + NODE_B*nodes_sh + REC_B*prims_sh,
+        # the 128-B path-state record read + written once per vertex (ray, hit, throughput, radiance, rng, pixel)
+        # plus the 64-B attribute gather of triangle hits and the shadow-ray records it emits
+        "k_shade": paths*(4 + RAY_B + HIT_B + 16 + 16 + 8 + 4) + paths*(16 + 16) + c["closest_rays_alive"]*(RAY_B + 8)
+                   + c["shadow_slots"]*(4 + 16 + 64 + 16 + 16),
+    }
+
+
+def counters_dict(c):
+    d = {k: getattr(c, k) for k, _ in c._fields_}
+    return d
+
+
+def main():
+    a = parse_args()
+    import numpy as np
+    import torch
+    import tungsten_amd as tg
+    import scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (a.gpus, world))
+    if not torch.cuda.is_available() or tg.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible -- the path tracer has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    w, h = [int(v) for v in a.res.split("x")]
+    spp = a.spp
+    tmp = tempfile.mkdtemp(prefix="tg_bench_")
+    try:
+        if a.scene == "materialtest":
+            if not scenes.have_materialtest():
+                raise SystemExit("bench.py: materialtest assets missing (oracle/_ref/data; run __graft_entry__.build() where the reference is mounted)")
+            path = scenes.materialtest(tmp, resolution=(w, h), spp=spp)
+            workload = "materialtest.json (3 meshes 80768 tris + quad, smooth_coat/rough_conductor/lambert, envmap MIS) %dx%d @ %d spp" % (w, h, spp)
+        else:
+            path = scenes.cornell(tmp, resolution=(w, h), spp=spp)
+            workload = "BASELINE configs[1]: cornell-box (5 quads + 2 cubes + quad light, Lambert) %dx%d @ %d spp" % (w, h, spp)
+
+        t0 = time.time()
+        flat = tg.FlattenedScene(path)
+        t_flatten = time.time() - t0
+        lib = tg.lib
+        ctx = lib.tghip_create(local)
+        if not ctx:
+            raise SystemExit("tghip_create: " + lib.tghip_last_error(None).decode())
+
+        def check(rc, what):
+            if rc != 0:
+                raise SystemExit("%s failed (%d): %s" % (what, rc, lib.tghip_last_error(ctx).decode()))
+        t0 = time.time()
+        check(lib.tghip_upload_scene(ctx, flat.desc), "tghip_upload_scene")
+        t_upload = time.time() - t0
+        for kv in a.opt:
+            k, v = kv.split("=")
+            check(lib.tghip_set_option(ctx, k.encode(), int(v)), "tghip_set_option")
+
+        # framebuffer lives in torch tensors so that RCCL (torch.distributed) can reduce it in place
+        fb_sum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+        fb_cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+        check(lib.tghip_bind_framebuffer(ctx, fb_sum.data_ptr(), fb_cnt.data_ptr()), "tghip_bind_framebuffer")
+        pass_desc = tg.TgHipPassDesc(0, spp, tg.DEFAULT_SEED, rank, world, 0)
+
+        def step():
+            check(lib.tghip_clear_framebuffer(ctx), "tghip_clear_framebuffer")
+            check(lib.tghip_render_pass(ctx, C.byref(pass_desc)), "tghip_render_pass")
+            check(lib.tghip_wait(ctx), "tghip_wait")
+            if dist is not None:
+                # the exchange step: float framebuffer sum-reduce over xGMI (tile ownership is disjoint -> exact)
+                dist.reduce(fb_sum, dst=0, op=dist.ReduceOp.SUM)
+                dist.reduce(fb_cnt, dst=0, op=dist.ReduceOp.SUM)
+
+        def fence():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(a.warmup):
+            step()
+        timing = not a.no_kernel_timing
+        check(lib.tghip_reset_counters(ctx), "tghip_reset_counters")
+        check(lib.tghip_set_option(ctx, b"time_kernels", 1 if timing else 0), "tghip_set_option")
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        timed = tg.TgHipCounters()
+        lib.tghip_get_counters(ctx, C.byref(timed))
+        timed = counters_dict(timed)
+        check(lib.tghip_set_option(ctx, b"time_kernels", 0), "tghip_set_option")
+
+        # sanity of the result of the last timed step (rank 0 holds the reduced image)
+        ok = True
+        if rank == 0:
+            cnt = fb_cnt.cpu().numpy()
+            img = (fb_sum/fb_cnt.clamp(min=1).unsqueeze(-1)).cpu().numpy()
+            ok = bool((cnt == spp).all() and np.isfinite(img).all())
+            image_mean = [float(v) for v in img.mean(axis=(0, 1))]
+
+        total_samples = float(w)*h*spp*a.steps
+        value = total_samples/elapsed*1e-6
+
+        out = None
+        if rank == 0:
+            # one untimed counting step: exact node / primitive visit counts of the same (deterministic) render
+            check(lib.tghip_set_option(ctx, b"count_traversal", 1), "tghip_set_option")
+            check(lib.tghip_reset_counters(ctx), "tghip_reset_counters")
+            check(lib.tghip_clear_framebuffer(ctx), "clear")
+            check(lib.tghip_render_pass(ctx, C.byref(pass_desc)), "render")
+            check(lib.tghip_wait(ctx), "wait")
+            cc = tg.TgHipCounters()
+            lib.tghip_get_counters(ctx, C.byref(cc))
+            cc = counters_dict(cc)
+            check(lib.tghip_set_option(ctx, b"count_traversal", 0), "tghip_set_option")
+            cc["closest_rays_alive"] = max(cc["closest_rays"] - cc["samples"], 0)
+            per_step_bytes = kernel_bytes(cc)
+
+            kernels = {}
+            ms = {"k_trace_closest": timed["ms_trace_closest"], "k_shade": timed["ms_shade"],
+                  "k_trace_shadow": timed["ms_trace_shadow"]}
+            launches = {"k_trace_closest": timed["launches_trace_closest"], "k_shade": timed["launches_shade"],
+                        "k_trace_shadow": timed["launches_trace_shadow"]}
+            for k in ms:
+                if launches[k] and ms[k] > 0:
+                    bytes_per_launch = per_step_bytes[k]*a.steps/launches[k]
+                    avg_s = ms[k]*1e-3/launches[k]
+                    kernels[k] = {"ms_total": round(ms[k], 3), "launches": int(launches[k]), "avg_us": round(avg_s*1e6, 2),
+                                  "bytes_per_launch": round(bytes_per_launch), "gbs": round(bytes_per_launch/avg_s*1e-9, 1)}
+            roofline = None
+            if kernels:
+                dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
+                kd = kernels[dom]
+                roofline = {"bound": "hbm", "kernel": dom, "achieved": kd["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(kd["gbs"]/HBM_PEAK_GBS, 4), "traffic": None,
+                            "bytes_per_launch": kd["bytes_per_launch"], "avg_launch_us": kd["avg_us"], "launches": kd["launches"],
+                            "timing": "HIP events per launch on the shim's stream, over the timed region"}
+                tr = os.path.join(ROOT, "profiles", "traffic.json")
+                if os.path.exists(tr):
+                    try:
+                        t = json.load(open(tr)).get("%s/%s" % (a.scene, dom))
+                        if t:
+                            roofline["traffic"] = t["hbm_bytes_per_launch"]
+                            roofline["traffic_source"] = t.get("source")
+                    except Exception:
+                        pass
+
+            cpu = None
+            if not a.no_cpu_baseline and world == 1:
+                cpu = cpu_baseline(a, path, flat, w, h, tmp)
+
+            out = {
+                "metric": "Msamples/s (W*H*spp/s), path_tracer render loop",
+                "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": round(elapsed/a.steps*1e3, 3), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic (scene shipped in-tree, fixed seed 0xBA5EBA11)",
+                "config": {"workload": workload, "width": w, "height": h, "spp": spp, "sampler": "uniform (counter-based PCG)",
+                           "adaptive_sampling": False, "max_bounces": int(flat.desc.contents.settings.max_bounces),
+                           "parallelism": "tile-shard x%d%s" % (world, " + RCCL framebuffer reduce" if world > 1 else "")},
+                "roofline": roofline, "cpu_baseline": cpu,
+                "kernels": kernels,
+                "rays_per_sample": round((cc["closest_rays"] + cc["shadow_rays"])/max(cc["samples"], 1), 3),
+                "nodes_per_ray": round(cc["nodes_visited"]/max(cc["closest_rays"] + cc["shadow_rays"], 1), 2),
+                "prims_per_ray": round(cc["prims_tested"]/max(cc["closest_rays"] + cc["shadow_rays"], 1), 2),
+                "bvh": {"nodes": int(flat.info.num_nodes), "records": int(flat.info.num_recs), "depth": int(flat.info.bvh_depth)},
+                "kernel_ms_total": round(timed["ms_total"], 2), "wavefront_iterations": int(timed["iterations"]),
+                "setup_s": {"flatten_and_bvh": round(t_flatten, 3), "upload": round(t_upload, 3)},
+                "result_ok": ok, "image_mean": image_mean,
+            }
+        lib.tghip_bind_framebuffer(ctx, None, None)
+        lib.tghip_destroy(ctx)
+        flat.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+            if not ok:
+                raise SystemExit("bench.py: rendered image failed the sanity check")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline(a, path, flat, w, h, tmp):
+    """The reference's own CPU/Embree path (oracle/_ref/tungsten) on all host cores, same scene at the same
+    resolution with fewer spp (bounded sample); falls back to the oracle port when the binary is absent."""
+    import tungsten_amd as tg
+    cores = os.cpu_count() or 1
+    ref = os.path.join(ROOT, "oracle", "_ref", "tungsten")
+    # rough CPU rates (Msamples/s per core) to size the sample: cornell ~0.7, materialtest ~0.35
+    per_core = 0.7 if a.scene == "cornell" else 0.3
+    budget = a.cpu_seconds*per_core*cores*1e6
+    s_spp = int(max(1, min(a.spp, budget//(w*h))))
+    if os.path.exists(ref) and os.access(ref, os.X_OK):
+        try:
+            t0 = time.time()
+            p = subprocess.run([ref, "-t", str(cores), "-s", str(tg.DEFAULT_SEED), "--spp", str(s_spp),
+                                "-e", os.path.join(tmp, "cpu.pfm"), "-o", os.path.join(tmp, "cpu.png"), path],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd=tmp, timeout=600)
+            wall = time.time() - t0
+            m = re.search(r"Render time\s+([0-9.eE+-]+)s", p.stdout)
+            if p.returncode == 0 and m:
+                secs = float(m.group(1))
+                return {"value": round(w*h*s_spp/secs*1e-6, 3), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                        "sample": "%dx%d @ %d spp of the same scene, reference binary `tungsten -t %d`, its own 'Render time' %.2f s (wall %.1f s)"
+                                  % (w, h, s_spp, cores, secs, wall)}
+        except Exception:
+            pass
+    import oracle_lib
+    s_spp = max(1, s_spp//2)
+    t0 = time.time()
+    oracle_lib.render(flat.desc, w, h, 0, s_spp, tg.DEFAULT_SEED, threads=cores)
+    secs = time.time() - t0
+    return {"value": round(w*h*s_spp/secs*1e-6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d @ %d spp of the same scene, oracle/oracle.c with OpenMP on %d threads, %.2f s" % (w, h, s_spp, cores, secs)}
+
+
+if __name__ == "__main__":
+    main()

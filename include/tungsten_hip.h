@@ -223,6 +223,9 @@ typedef struct TgHipCounters {
     uint64_t iterations;        /* wavefront iterations                           */
     double   ms_trace_closest, ms_trace_shadow, ms_shade, ms_other, ms_total;  /* HIP-event time, last pass set */
     uint64_t launches_trace_closest, launches_trace_shadow, launches_shade;
+    uint64_t nodes_visited_shadow; /* the shadow-ray share of nodes_visited / prims_tested (counting enabled) */
+    uint64_t prims_tested_shadow;
+    uint64_t shadow_slots;         /* path vertices that queued at least one shadow ray */
 } TgHipCounters;
 
 /* closest-hit query record for tghip_trace_rays (and the oracle's equivalent) */

@@ -1,0 +1,191 @@
+"""Pins oracle/oracle.c (the CPU restatement, TEST INFRASTRUCTURE) against outputs of the reference
+itself committed under tests/golden/ (tools/make_golden.py: oracle/ref_harness.cpp links the reference's
+libcore.a and drives its PathTracer::traceSample with the shared counter-based random stream).
+
+Tolerances: integers / RNG exact; deterministic floats rel 1e-5 (t: 1e-4, Embree's rcp+Newton,
+triangle_intersector_moeller.h:45-48); per-sample radiance rel 1e-3 for all but a small fraction of
+samples -- a path is a chaotic function of its hits, so an ulp-level difference at an edge or a Fresnel
+coin flip sends the path elsewhere; the fraction allowed is stated per case below."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenes
+import tungsten_amd as tg
+
+G = scenes.GOLDEN
+ALL_BUT_SPECULAR = 0x4F   # BsdfLobes.hpp:13-33
+
+
+def close(a, b, rel, floor=1e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() <= rel*max(np.abs(b).max(), floor) + 1e-7
+
+
+def flat_bsdf_index(scene_json, scene_index):
+    """Index of scene bsdf #i in the flattened table (nested inline bsdfs are appended depth-first,
+    TraceableScene.cpp addBsdf)."""
+    bsdfs = scene_json["bsdfs"]
+    names = {b.get("name"): i for i, b in enumerate(bsdfs)}
+    order = {}
+    counter = [0]
+
+    def add(b, key):
+        if isinstance(b, str):
+            b, key = bsdfs[names[b]], ("top", names[b])
+        if key in order:
+            return
+        order[key] = counter[0]
+        counter[0] += 1
+        for k in ("substrate", "bsdf0", "bsdf1", "base"):
+            if k in b:
+                add(b[k], (key, k))
+    for i, b in enumerate(bsdfs):
+        add(b, ("top", i))
+    return order[("top", scene_index)]
+
+
+def _needs_materialtest(name):
+    if "materialtest" in name and not scenes.have_materialtest():
+        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+
+
+# fraction of samples allowed to diverge (chaotic path divergence, see module docstring)
+DIVERGE = {"zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
+           "materialtest_rough_dielectric": 2e-2}
+
+
+@pytest.mark.parametrize("name", sorted(scenes.GOLDEN_CASES))
+def test_oracle_matches_reference_per_sample(name, tmp_path):
+    _needs_materialtest(name)
+    mk, kw = scenes.GOLDEN_CASES[name]
+    gold = np.load(os.path.join(G, name + "_samples.npz"))
+    ref = gold["samples"]
+    seed = int(gold["seed"])
+    h, w, spp, _ = ref.shape
+    flat = tg.FlattenedScene(mk(tmp_path, name=name + ".json", **kw))
+    assert (flat.width, flat.height) == (w, h)
+    got = np.empty_like(ref)
+    for y in range(h):
+        for x in range(w):
+            for s in range(spp):
+                got[y, x, s] = oracle_lib.trace_sample(flat.desc, seed, x, y, s)
+    flat.close()
+    err = np.abs(got - ref).max(axis=-1)
+    bad = err > 1e-3*(np.abs(ref).max(axis=-1) + 1e-3)
+    frac = bad.mean()
+    assert frac <= DIVERGE.get(name, 0.0), "%s: %.4f%% of samples differ from the reference" % (name, 100*frac)
+    # the mean image is insensitive to the few divergent paths
+    assert np.allclose(got.mean(axis=(0, 1, 2)), ref.mean(axis=(0, 1, 2)), rtol=0.03)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "materialtest", "zoo_a", "zoo_b", "zoo_c"])
+def test_oracle_units(scene, tmp_path):
+    _needs_materialtest(scene)
+    with open(os.path.join(G, scene + "_units.json")) as f:
+        u = json.load(f)
+    if scene == "cornell":
+        path = scenes.cornell(tmp_path, resolution=(96, 54), spp=1)
+    elif scene == "materialtest":
+        path = scenes.materialtest(tmp_path, resolution=(96, 54), spp=1)
+    else:
+        path = scenes.cornell_zoo(tmp_path, scene, resolution=(96, 54), spp=1)
+    with open(path) as f:
+        sj = json.load(f)
+    flat = tg.FlattenedScene(path)
+    d = flat.desc
+
+    # RNG: PCG-XSH-RR + hash32 keyed by (seed, pixel, sample) -- integer work, exact
+    for r in u["rng"]:
+        got = oracle_lib.rng_stream(r["seed"], r["pixel"], r["sample"], 16)
+        assert (got == np.array(r["values"], np.float32)).all()
+
+    # camera rays + closest hits
+    rays, want = [], []
+    for r in u["rays"]:
+        if "px" in r:
+            o, dd = oracle_lib.camera_ray(d, r["px"], r["py"], r["xi"][0], r["xi"][1])
+            assert close(o, r["o"], 1e-6) and close(dd, r["d"], 2e-6), r
+        rays.append(r["o"] + [r["tmin"]] + r["d"] + [np.inf])
+        want.append(r)
+    hits, nodes, prims = oracle_lib.trace_rays(d, np.array(rays, np.float32))
+    assert nodes > 0 and prims > 0
+    mism = 0
+    for hgot, r in zip(hits, want):
+        if bool(r["hit"]) != (hgot["rec"] >= 0):
+            mism += 1
+            continue
+        if r["hit"] and not close(hgot["t"], r["t"], 1e-4):
+            mism += 1
+    assert mism <= len(want)//100, "%d of %d closest hits differ" % (mism, len(want))
+
+    # BSDF eval / pdf / sample
+    for b in u["bsdfs"]:
+        bi = flat_bsdf_index(sj, b["index"])
+        assert d.contents.bsdfs[bi].lobes == b["lobes"], b["name"]
+        for c in b["cases"]:
+            f, pdf = oracle_lib.bsdf_eval(d, bi, c["wi"], c["wo"], c["uv"], c["requested"])
+            assert close(f, c["f"], 2e-4), (b["name"], c, f)
+            assert close(pdf, c["pdf"], 2e-4), (b["name"], c, pdf)
+            ok, wo, weight, spdf, lobe, consumed = oracle_lib.bsdf_sample(d, bi, c["wi"], c["uv"], c["requested"], c["xi"])
+            assert ok == bool(c["sample_ok"]), (b["name"], c)
+            assert consumed == c["consumed"], (b["name"], c)
+            if ok:
+                assert close(wo, c["s_wo"], 2e-4) and close(weight, c["s_weight"], 1e-3), (b["name"], c, wo, weight)
+                assert close(spdf, c["s_pdf"], 1e-3) and lobe == c["s_lobe"], (b["name"], c, spdf, lobe)
+
+    # lights: sampleDirect
+    for L in u["lights"]:
+        for c in L["cases"]:
+            ok, dd, dist, pdf = oracle_lib.light_sample(d, L["index"], c["p"], c["xi"][0], c["xi"][1])
+            assert ok == bool(c["ok"]), c
+            if ok:
+                assert close(dd, c["d"], 1e-5), c
+                assert close(pdf, c["pdf"], 2e-4), (c, pdf)
+                if c["dist"] < 1e29:
+                    assert close(dist, c["dist"], 1e-5), c
+    flat.close()
+
+
+@pytest.mark.parametrize("scene,spp", [("cornell", 2048), ("materialtest", 512)])
+def test_oracle_converges_to_the_unmodified_reference_binary(scene, spp, tmp_path):
+    """Statistical anchor: the oracle with the counter-based stream against `tungsten -s seed`
+    with its own per-tile sampler at high spp.  8x8-box-downsampled means within 5 sigma of the oracle's own
+    standard error + 1% of the value; whole-image mean within 1.2%."""
+    _needs_materialtest(scene)
+    gold = np.load(os.path.join(G, scene + "_converged.npz"))
+    ref = gold["mean"]
+    mk = scenes.cornell if scene == "cornell" else scenes.materialtest
+    flat = tg.FlattenedScene(mk(tmp_path, resolution=(64, 36), spp=spp))
+    h, w = flat.height, flat.width
+    halves = []
+    for k in range(2):
+        s, c = oracle_lib.render(flat.desc, w, h, k*spp//2, (k + 1)*spp//2, tg.DEFAULT_SEED)
+        halves.append(s/np.maximum(c, 1)[..., None])
+    flat.close()
+    got = 0.5*(halves[0] + halves[1])
+
+    def pool(a):
+        return a[:32, :64].reshape(4, 8, 8, 8, 3).mean(axis=(1, 3))
+    sigma = np.abs(pool(halves[0]) - pool(halves[1]))/2.0          # standard error estimate of the full render
+    err = np.abs(pool(got) - pool(ref))
+    assert (err <= 5*sigma + 0.01*pool(ref) + 2e-3).all(), float((err/(5*sigma + 0.01*pool(ref) + 2e-3)).max())
+    assert np.allclose(got.mean(axis=(0, 1)), ref.mean(axis=(0, 1)), rtol=0.012)
+
+
+def test_oracle_shards_partition_the_image(tmp_path):
+    """Tile sharding (16x16 tiles round-robin, PathTraceIntegrator.cpp:27-42): shards are disjoint and their sum is
+    the unsharded render, bit-exactly."""
+    flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(80, 45), spp=2))
+    whole, wc = oracle_lib.render(flat.desc, 80, 45, 0, 2, 7)
+    acc, cnt = np.zeros_like(whole), np.zeros_like(wc)
+    for i in range(3):
+        s, c = oracle_lib.render(flat.desc, 80, 45, 0, 2, 7, shard_index=i, shard_count=3)
+        assert ((c > 0) & (cnt > 0)).sum() == 0
+        acc += s
+        cnt += c
+    flat.close()
+    assert (acc == whole).all() and (cnt == wc).all() and (wc == 2).all()

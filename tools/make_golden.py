@@ -1,0 +1,86 @@
+"""Generates tests/golden/ by running the REFERENCE ITSELF (oracle/_ref/, built from /root/reference by
+oracle/Makefile.ref).  TEST INFRASTRUCTURE; run in the build container only (needs oracle/_ref):
+
+    python tools/make_golden.py
+
+Outputs (all small, committed):
+  <case>_samples.npz   radiance of every individual sample, float32[h][w][spp][3], from the reference's own
+                       PathTracer::traceSample driven by oracle/ref_harness.cpp with the counter-based
+                       random stream (seed, pixel, sample) that oracle.c and the HIP kernels also use
+  <scene>_units.json   known answers of the deterministic building blocks (rng, camera rays, closest hits,
+                       bsdf eval/pdf/sample, light sampleDirect/directPdf/evalDirect)
+  <scene>_converged.npz  mean image of the unmodified reference binary (`tungsten -s <seed>`, its own
+                       per-tile sampler) at high spp: the statistical anchor
+The scene variants are produced by tests/scenes.py, which the tests call again with the same arguments.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenes  # noqa: E402
+import tungsten_amd as tg  # noqa: E402
+
+REF = os.path.join(ROOT, "oracle", "_ref")
+HARNESS = os.path.join(REF, "ref_harness")
+TUNGSTEN = os.path.join(REF, "tungsten")
+SEED = tg.DEFAULT_SEED
+
+
+def samples(path, w, h, spp, out):
+    tmp = out + ".bin"
+    subprocess.check_call([HARNESS, "samples", path, str(SEED), str(spp), tmp], stdout=subprocess.DEVNULL)
+    a = np.fromfile(tmp, np.float32).reshape(h, w, spp, 3)
+    os.remove(tmp)
+    np.savez_compressed(out, samples=a, seed=np.uint32(SEED))
+    print("%-40s %s mean %s" % (os.path.basename(out), a.shape, a.mean(axis=(0, 1, 2))))
+
+
+def units(path, out):
+    subprocess.check_call([HARNESS, "units", path, out], cwd=os.path.dirname(path), stdout=subprocess.DEVNULL)
+    print("%-40s %d bytes" % (os.path.basename(out), os.path.getsize(out)))
+
+
+def converged(path, spp, out, tmp):
+    stem = os.path.join(tmp, "conv_" + os.path.basename(out))   # unique: the reference renames instead of overwriting
+    pfm = stem + ".pfm"
+    subprocess.check_call([TUNGSTEN, "-t", str(os.cpu_count()), "-s", str(SEED), "--spp", str(spp), "-e", pfm, "-o",
+                           stem + ".png", path], stdout=subprocess.DEVNULL, cwd=tmp)
+    img = tg.load_pfm(pfm)
+    np.savez_compressed(out, mean=img, spp=np.uint32(spp))
+    print("%-40s %s mean %s" % (os.path.basename(out), img.shape, img.mean(axis=(0, 1))))
+
+
+def main():
+    if not os.path.exists(HARNESS):
+        raise SystemExit("oracle/_ref/ref_harness missing: run `python -c 'import __graft_entry__ as g; g.build()'` where /root/reference exists")
+    os.makedirs(scenes.GOLDEN, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="tg_golden_")
+    g = lambda n: os.path.join(scenes.GOLDEN, n)
+    try:
+        for name, (mk, kw) in scenes.GOLDEN_CASES.items():
+            p = mk(tmp, name=name + ".json", **kw)
+            with open(p) as f:
+                sc = json.load(f)
+            w, h = sc["camera"]["resolution"]
+            samples(p, w, h, sc["renderer"]["spp"], g(name + "_samples.npz"))
+        units(scenes.cornell(tmp, name="u_cornell.json", resolution=(96, 54), spp=1), g("cornell_units.json"))
+        units(scenes.materialtest(tmp, name="u_materialtest.json", resolution=(96, 54), spp=1), g("materialtest_units.json"))
+        for which in ("zoo_a", "zoo_b", "zoo_c"):
+            units(scenes.cornell_zoo(tmp, which, name="u_%s.json" % which, resolution=(96, 54), spp=1), g(which + "_units.json"))
+        converged(scenes.cornell(tmp, name="c_cornell.json", resolution=(64, 36), spp=4096), 4096, g("cornell_converged.npz"), tmp)
+        converged(scenes.materialtest(tmp, name="c_materialtest.json", resolution=(64, 36), spp=1024), 1024,
+                  g("materialtest_converged.npz"), tmp)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

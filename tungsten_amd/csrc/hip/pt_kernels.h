@@ -29,6 +29,7 @@ struct PathCounters {
     uint32_t abort_flag;      // set by tghip_abort; polled by k_advance
     uint32_t pad[3];
     unsigned long long samples, closest_rays, shadow_rays, nodes_visited, prims_tested;
+    unsigned long long nodes_visited_shadow, prims_tested_shadow, shadow_slots;
 };
 
 struct PathState {

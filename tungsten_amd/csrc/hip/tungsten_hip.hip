@@ -356,9 +356,10 @@ __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState s
     extern __shared__ int ldsStack[];
     const uint32_t n = st.ctr->n_shadow[parity];
     const uint32_t stride = gridDim.x*blockDim.x;
-    uint32_t nodes = 0, prims = 0, rays = 0;
+    uint32_t nodes = 0, prims = 0, rays = 0, slots = 0;
     for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += stride) {
         uint32_t slot = st.q_shadow[i];
+        slots++;
         float4 so = st.sh_o[slot];
         f3 result = splat3(0.0f);
 #pragma unroll
@@ -418,9 +419,12 @@ __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState s
         st.emi[slot] = mk4(em, 0.0f);
     }
     waveAddStat(&st.ctr->shadow_rays, rays);
+    waveAddStat(&st.ctr->shadow_slots, slots);
     if (COUNT) {
         waveAddStat(&st.ctr->nodes_visited, nodes);
         waveAddStat(&st.ctr->prims_tested, prims);
+        waveAddStat(&st.ctr->nodes_visited_shadow, nodes);
+        waveAddStat(&st.ctr->prims_tested_shadow, prims);
     }
 }
 
@@ -498,6 +502,8 @@ struct tghip_ctx {
     bool countTraversal = false;
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
     int blocksPerCu = 4;
+    bool timeKernels = false;             // HIP events around every launch of the wavefront loop (bench.py roofline)
+    std::vector<hipEvent_t> evPool;
 
     // async pass state
     bool passPending = false;
@@ -648,6 +654,7 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->hostCtr) (void)hipHostFree(ctx->hostCtr);
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
+    for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -670,6 +677,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     if (k == "count_traversal") ctx->countTraversal = value != 0;
     else if (k == "max_slots") ctx->maxSlots = std::max<long long>(value, 256);
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
+    else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "blocks_per_cu") ctx->blocksPerCu = int(std::min<long long>(std::max<long long>(value, 1), 8));
     else { ctx->error = "unknown option '" + k + "'"; return TGHIP_E_INVALID; }
     return TGHIP_OK;
@@ -771,22 +779,53 @@ static int runChunk(tghip_ctx *ctx, const PassParams &pp, uint32_t slots)
     const size_t ldsBytes = size_t(ctx->bvhDepth + 1)*256*sizeof(int);
     const bool count = ctx->countTraversal;
 
+    // optional per-launch timing: one event pair per kernel launch of a check interval, read back at the
+    // interval's host sync (events live on ctx->stream, the stream the kernels are launched on)
+    const bool timing = ctx->timeKernels;
+    const size_t evNeeded = size_t(ctx->checkInterval)*4*2;
+    if (timing) {
+        while (ctx->evPool.size() < evNeeded) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(ctx, hipEventCreate(&e));
+            ctx->evPool.push_back(e);
+        }
+    }
+    size_t evUsed = 0;
+    auto tic = [&]() { if (timing) (void)hipEventRecord(ctx->evPool[evUsed++], ctx->stream); };
+
     hipLaunchKernelGGL(k_init, dim3((slots + 255)/256), dim3(256), 0, ctx->stream, st, pp);
     int parity = 0;
     hipLaunchKernelGGL(k_advance, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp, parity);
     for (;;) {
+        evUsed = 0;
         for (int it = 0; it < ctx->checkInterval; ++it) {
+            tic();
             if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
             else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
+            tic(); tic();
             hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, ctx->stream, s, st, parity);
+            tic(); tic();
             if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
             else       hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
+            tic(); tic();
             hipLaunchKernelGGL(k_advance, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp, parity ^ 1);
+            tic();
             parity ^= 1;
             ctx->counters.iterations++;
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->hostCtr, st.ctr, sizeof(PathCounters), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (timing) {
+            double *acc[4] = {&ctx->counters.ms_trace_closest, &ctx->counters.ms_shade, &ctx->counters.ms_trace_shadow, &ctx->counters.ms_other};
+            for (size_t k = 0; k + 1 < evUsed; k += 2) {
+                float ms = 0.0f;
+                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[k], ctx->evPool[k + 1]));
+                *acc[(k/2) % 4] += ms;
+            }
+            ctx->counters.launches_trace_closest += evUsed/8;
+            ctx->counters.launches_trace_shadow += evUsed/8;
+            ctx->counters.launches_shade += evUsed/8;
+        }
         if (ctx->hostCtr->n_ext[parity] == 0)
             break;
     }
@@ -938,6 +977,9 @@ int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out)
         ctx->counters.shadow_rays = ctx->hostCtr->shadow_rays;
         ctx->counters.nodes_visited = ctx->hostCtr->nodes_visited;
         ctx->counters.prims_tested = ctx->hostCtr->prims_tested;
+        ctx->counters.nodes_visited_shadow = ctx->hostCtr->nodes_visited_shadow;
+        ctx->counters.prims_tested_shadow = ctx->hostCtr->prims_tested_shadow;
+        ctx->counters.shadow_slots = ctx->hostCtr->shadow_slots;
     }
     *out = ctx->counters;
     return TGHIP_OK;
@@ -949,7 +991,7 @@ int tghip_reset_counters(tghip_ctx *ctx)
     std::memset(&ctx->counters, 0, sizeof(ctx->counters));
     if (ctx->pool.ctr) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.ctr->samples, 0, 5*sizeof(unsigned long long), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.ctr->samples, 0, 8*sizeof(unsigned long long), ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     return TGHIP_OK;
