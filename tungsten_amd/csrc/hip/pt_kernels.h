@@ -5,31 +5,53 @@
 //               handleInfiniteLights}          (integrators/TraceBase.cpp)
 //   TraceableScene::intersect + Embree         (renderer/TraceableScene.hpp:170-192)
 //
-// Execution model (DESIGN.md "Kernels"): a fixed pool of path slots lives in HBM as SoA arrays.
-// Each slot owns one (pixel, sample-stream) and regenerates a new camera path when its current
-// path ends, so the pool stays full until the pass drains.  One wavefront iteration is
-//     k_trace_closest -> k_shade -> k_trace_shadow -> k_advance
-// with persistent grids (sized to the machine, striding over queues) and wave-ballot compaction
-// into the extension / shadow queues.  BVH2 traversal keeps its per-lane node stack in LDS.
+// Execution model (DESIGN.md "Kernels"): the machine is partitioned into G persistent workgroups ("lanes of
+// the wavefront tracer", G = CUs x blocks_per_cu, the same G for every kernel of a pass).  Workgroup b owns
+//   * a private range of path slots in HBM (SoA arrays, slot = b*slots_per_block + local),
+//   * private queue segments for those slots (extension / per-class shading / shadow), whose lengths live in
+//     the workgroup's BlockCtl record, and
+//   * a private, finely interleaved share of the pass's work items (item = pixel x chunk of sample indices).
+// Nothing is shared between workgroups, so there is not a single global atomic on the hot path: queue pushes and
+// work-item fetches are wave-aggregated (ballot + prefix popcount) LDS atomics, and the counts are carried from
+// one kernel to the next through BlockCtl.  (Same-address global atomics saturate at ~88/us on MI355X --
+// MI355X_MICROARCH.md "dequeue" -- which is what bounded the first version of this tracer.)
+// A slot that finishes its item flushes the item's radiance sum to partial[item] and takes the workgroup's next
+// item, so the pool stays full until the pass drains however uneven the path lengths are; partial[] is reduced
+// per pixel in fixed chunk order by k_resolve, which keeps the image bit-reproducible.
+// One wavefront iteration is
+//     k_trace_closest -> k_shade<simple> [-> k_shade<complex>] -> k_trace_shadow
+//   k_trace_closest  BVH2 closest hit for the extension queue (per-lane node stack in LDS); bins each path by the
+//                    shading class of the surface it hit into one queue per class ("sort by material").
+//   k_shade<M>       handleSurface for one class, compiled for the BSDF type set M only; emits <= 2 shadow
+//                    rays and the continuation ray; finished paths are finalised and regenerated in place.
+//   k_trace_shadow   generalizedShadowRay for the queued shadow rays; finishes the paths that were waiting
+//                    for their last shadow result.
 #ifndef TGAMD_PT_KERNELS_H_
 #define TGAMD_PT_KERNELS_H_
 
 #include "pt_scene.h"
 
 // ---- slot state ------------------------------------------------------------------------------
-enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3, ST_FRESH = 4 };
+enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 #define FLAG_BOUNCE(f)      ((f) & 0xFFu)
 #define FLAG_SPECULAR       0x100u
 #define FLAG_STATE(f)       (((f) >> 16) & 7u)
 #define FLAG_MAKE(bounce, spec, state) ((uint32_t)(bounce) | ((spec) ? FLAG_SPECULAR : 0u) | ((uint32_t)(state) << 16))
 
-struct PathCounters {
-    uint32_t n_ext[2];        // extension-queue length, by iteration parity
-    uint32_t n_shadow[2];     // shadow-queue length, by iteration parity
-    uint32_t abort_flag;      // set by tghip_abort; polled by k_advance
+#define PT_NUM_CLASSES 2          // shading classes: 0 = diffuse/null/miss, 1 = everything else
+#define PT_ITEM_GROUP  64u        // consecutive work items handed to one workgroup (a wave's worth of pixels)
+
+struct BlockCtl {                 // one per persistent workgroup; only that workgroup touches it
+    uint32_t n_ext;               // extension-queue segment length
+    uint32_t n_shade[PT_NUM_CLASSES];
+    uint32_t n_shadow;
+    uint32_t item_cursor;         // workgroup-local linear index of the next work item
     uint32_t pad[3];
-    unsigned long long samples, closest_rays, shadow_rays, nodes_visited, prims_tested;
-    unsigned long long nodes_visited_shadow, prims_tested_shadow, shadow_slots;
+    unsigned long long samples, closest_rays, shadow_rays, shadow_slots;
+};                                // 64 B
+
+struct BlockStats {               // traversal statistics (count_traversal option), one per workgroup
+    unsigned long long nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow;
 };
 
 struct PathState {
@@ -38,25 +60,32 @@ struct PathState {
     float4 *hit;       // t, u, v, record index (int bits; -1 = miss)
     float4 *thr;       // throughput.rgb, flags (uint bits)
     float4 *emi;       // radiance of the sample in flight
-    float4 *acc;       // per-slot sum of finished samples, count (uint bits)
+    float4 *acc;       // sum of the finished samples of the slot's current work item, count (uint bits)
     uint2  *rng;       // PCG state
-    uint2  *samp;      // next sample index, end
-    uint32_t *pixel;   // pixel index or 0xFFFFFFFF
+    uint2  *samp;      // current sample index, end of the item's sample range
+    uint32_t *pixel;   // pixel index of the current item
+    uint32_t *item;    // current work item
     float4 *sh_o;      // shadow origin.xyz, epsilon
     float4 *sh_d0, *sh_c0;   // light-sample shadow ray: dir.xyz, tmax | unoccluded contribution, endCap|bounce bits
     float4 *sh_d1, *sh_c1;   // bsdf-sample shadow ray
     float4 *sh_w;      // throughput at the NEE vertex, light-selection weight
-    float4 *sh_p;      // emission picked up at the same vertex (added after the NEE term)
-    uint32_t *q_ext, *q_shadow;
-    PathCounters *ctr;
-    uint32_t num_slots;
+    float4 *sh_p;      // emission picked up at the same vertex (added after the NEE term), path flags (uint bits)
+    uint32_t *q_ext, *q_shadow;            // queue segments: workgroup b uses [b*slots_per_block, (b+1)*slots_per_block)
+    uint32_t *q_shade[PT_NUM_CLASSES];
+    float4 *partial;   // per work item: radiance sum, count (uint bits)
+    BlockCtl *ctl;
+    BlockStats *stats;
+    uint32_t *live;    // [0] = tag of the last iteration that left work in some extension queue; [1] = abort flag
+    uint32_t num_slots, slots_per_block;
 };
 
 struct PassParams {
     uint32_t spp_begin, spp_end, seed;
-    uint32_t streams;          // sample streams per pixel (K)
-    uint32_t pix_slots;        // pixel slots in this chunk (= tiles in chunk * 256)
-    uint32_t first_tile;       // first owned tile of the chunk (index into the shard's tile list)
+    uint32_t chunk;            // samples per work item
+    uint32_t chunks;           // items per pixel slot = ceil((spp_end - spp_begin)/chunk)
+    uint32_t pix_slots;        // pixel slots in this batch (= tiles in batch * 256)
+    uint32_t total_items;      // pix_slots*chunks
+    uint32_t first_tile;       // first owned tile of the batch (index into the shard's tile list)
     uint32_t shard_index, shard_count;
     uint32_t tiles_x, num_tiles;
     uint32_t width, height;
@@ -64,7 +93,7 @@ struct PassParams {
 
 PT_DEV uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// wave-aggregated queue push: one atomic per wave (ballot + prefix popcount)
+// wave-aggregated queue push: one (LDS) atomic per wave (ballot + prefix popcount); `queue` is the workgroup's segment
 PT_DEV void queuePush(bool push, uint32_t value, uint32_t *queue, uint32_t *counter)
 {
     unsigned long long mask = __ballot(push);
@@ -81,13 +110,13 @@ PT_DEV void queuePush(bool push, uint32_t value, uint32_t *queue, uint32_t *coun
         queue[base + prefix] = value;
 }
 
-PT_DEV bool slotPixel(const PassParams &pp, uint32_t slot, uint32_t &x, uint32_t &y, uint32_t &stream)
+// pixel slot j of the batch -> image pixel (16x16 tile dicing, PathTraceIntegrator.cpp:27-42; tiles of a shard
+// are dealt round-robin).  False for slots of an edge tile that fall outside the image.
+PT_DEV bool slotPixel(const PassParams &pp, uint32_t j, uint32_t &x, uint32_t &y)
 {
-    stream = slot/pp.pix_slots;
-    uint32_t j = slot - stream*pp.pix_slots;
     uint32_t tileLocal = j >> 8, inTile = j & 255u;
     uint32_t tile = pp.shard_index + (pp.first_tile + tileLocal)*pp.shard_count;
-    if (tile >= pp.num_tiles || stream >= pp.streams)
+    if (tile >= pp.num_tiles)
         return false;
     uint32_t tx = tile % pp.tiles_x, ty = tile/pp.tiles_x;
     x = tx*16u + (inTile & 15u);
@@ -176,13 +205,13 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
     return hit;
 }
 
-// wave-reduced statistics add (one atomic per wave per counter)
-PT_DEV void waveAddStat(unsigned long long *dst, uint32_t v)
+// wave-reduced statistics add into a workgroup-local (LDS) counter
+PT_DEV void waveAddStat(uint32_t *dst, uint32_t v)
 {
     for (int off = 32; off > 0; off >>= 1)
         v += __shfl_down(v, off);
     if (laneId() == 0 && v)
-        atomicAdd(dst, (unsigned long long)v);
+        atomicAdd(dst, v);
 }
 
 #endif

@@ -21,6 +21,7 @@ struct DeviceScene {
     const TgHipTexture *textures;
     const float        *texels;
     const float        *dist;
+    const uint8_t      *rec_class;    // shading class of each primitive record's bsdf (built at upload, DESIGN.md "Kernels")
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
     TgHipCamera   camera;
     TgHipSettings settings;
@@ -343,31 +344,40 @@ PT_DEV f3 absorb(const TgHipBsdf &b, f3 f, float cosA, float cosB)
     return f;
 }
 
-template<int D> struct BsdfOps;
+// M is the compile-time set of BSDF types (bit = 1 << TGHIP_BSDF_*) a kernel variant has to handle: cases
+// outside M fold away, which is what keeps the Lambert-only shading kernel small (DESIGN.md "Kernels").
+#define BSDF_BIT(t) (1u << (t))
+#define BSDF_MASK_ALL 0xFFFFFFFFu
+template<int D, uint32_t M> struct BsdfOps;
 
-template<int D>
+template<int D, uint32_t M>
 struct BsdfOps {
-    typedef BsdfOps<D + 1> Next;
+    typedef BsdfOps<D + 1, M> Next;
 
     static __device__ f3 eval(const DeviceScene &s, int bi, const Event &e)
     {
         const TgHipBsdf &b = s.bsdfs[bi];
         switch (b.type) {
         case TGHIP_BSDF_LAMBERT: case TGHIP_BSDF_ERROR:        /* LambertBsdf.cpp:40-47 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_ERROR)))) return splat3(0.0f);
             if (!(e.requested & TGHIP_LOBE_DIFFUSE_R)) return splat3(0.0f);
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
             return bsdfAlbedo(s, b, e)*PT_INV_PI*e.wo.z;
         case TGHIP_BSDF_FORWARD:                               /* ForwardBsdf.cpp:25-28 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_FORWARD)))) return splat3(0.0f);
             return (e.requested == TGHIP_LOBE_FORWARD && isExactReverse(e.wi, e.wo)) ? splat3(1.0f) : splat3(0.0f);
         case TGHIP_BSDF_MIRROR:                                /* MirrorBsdf.cpp:39-46 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_MIRROR)))) return splat3(0.0f);
             if ((e.requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e.wi, e.wo))
                 return bsdfAlbedo(s, b, e);
             return splat3(0.0f);
         case TGHIP_BSDF_CONDUCTOR:                             /* ConductorBsdf.cpp:68-75 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_CONDUCTOR)))) return splat3(0.0f);
             if ((e.requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e.wi, e.wo))
                 return bsdfAlbedo(s, b, e)*conductorReflectance(b.eta, b.k, e.wi.z);
             return splat3(0.0f);
         case TGHIP_BSDF_ROUGH_CONDUCTOR: {                     /* RoughConductorBsdf.cpp:93-109 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return splat3(0.0f);
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return splat3(0.0f);
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
             float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness(s, b, e));
@@ -380,6 +390,7 @@ struct BsdfOps {
             return bsdfAlbedo(s, b, e)*(F*fr);
         }
         case TGHIP_BSDF_SMOOTH_COAT: {                         /* SmoothCoatBsdf.cpp:146-177 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT)))) return splat3(0.0f);
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
             bool evalR = (e.requested & TGHIP_LOBE_SPECULAR_R) != 0;
             bool evalT = (e.requested & s.bsdfs[b.sub0].lobes) != 0;
@@ -400,6 +411,7 @@ struct BsdfOps {
             return splat3(0.0f);
         }
         case TGHIP_BSDF_DIELECTRIC: {                          /* DielectricBsdf.cpp:88-108 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_DIELECTRIC)))) return splat3(0.0f);
             bool evalR = (e.requested & TGHIP_LOBE_SPECULAR_R) != 0;
             bool evalT = (e.requested & TGHIP_LOBE_SPECULAR_T) && b.enable_refraction;
             float eta = e.wi.z < 0.0f ? b.ior : 1.0f/b.ior;
@@ -415,11 +427,13 @@ struct BsdfOps {
             return splat3(0.0f);
         }
         case TGHIP_BSDF_ROUGH_DIELECTRIC: {                    /* RoughDielectricBsdf.cpp:247-254 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return splat3(0.0f);
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
             return rdEvalBase(e, sampleR, sampleT, bsdfRoughness(s, b, e), b.ior, b.distribution)*bsdfAlbedo(s, b, e);
         }
         case TGHIP_BSDF_PLASTIC: case TGHIP_BSDF_ROUGH_PLASTIC: {   /* PlasticBsdf.cpp:125-151, RoughPlasticBsdf.cpp:114-141 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_PLASTIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_PLASTIC)))) return splat3(0.0f);
             bool rough = b.type == TGHIP_BSDF_ROUGH_PLASTIC;
             bool evalR = (e.requested & (rough ? TGHIP_LOBE_GLOSSY_R : TGHIP_LOBE_SPECULAR_R)) != 0;
             bool evalT = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
@@ -445,11 +459,13 @@ struct BsdfOps {
             return rough ? glossyR + diffuseR : diffuseR;
         }
         case TGHIP_BSDF_MIXED: {                               /* MixedBsdf.cpp:101-105 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_MIXED)))) return splat3(0.0f);
             float ratio = textureEval(s, b.tex1, e.u, e.v).x;
             f3 f0 = Next::eval(s, b.sub0, e), f1 = Next::eval(s, b.sub1, e);
             return bsdfAlbedo(s, b, e)*(f0*ratio + f1*(1.0f - ratio));
         }
         case TGHIP_BSDF_TRANSPARENCY:                          /* TransparencyBsdf.cpp:48-54 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_TRANSPARENCY)))) return splat3(0.0f);
             if (e.requested == TGHIP_LOBE_FORWARD)
                 return isExactReverse(e.wi, e.wo) ? splat3(1.0f - textureEval(s, b.tex1, e.u, e.v).x) : splat3(0.0f);
             return Next::eval(s, b.sub0, e);
@@ -474,6 +490,7 @@ struct BsdfOps {
         const TgHipBsdf &b = s.bsdfs[bi];
         switch (b.type) {
         case TGHIP_BSDF_LAMBERT: case TGHIP_BSDF_ERROR: {      /* LambertBsdf.cpp:27-38 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_ERROR)))) return false;
             if (!(e.requested & TGHIP_LOBE_DIFFUSE_R)) return false;
             if (e.wi.z <= 0.0f) return false;
             float xi0 = rngNext1D(*e.rng), xi1 = rngNext1D(*e.rng);
@@ -484,6 +501,7 @@ struct BsdfOps {
             return true;
         }
         case TGHIP_BSDF_MIRROR:                                /* MirrorBsdf.cpp:28-37 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_MIRROR)))) return false;
             if (!(e.requested & TGHIP_LOBE_SPECULAR_R)) return false;
             e.wo = mk3(-e.wi.x, -e.wi.y, e.wi.z);
             e.pdf = 1.0f;
@@ -491,6 +509,7 @@ struct BsdfOps {
             e.weight = bsdfAlbedo(s, b, e);
             return true;
         case TGHIP_BSDF_CONDUCTOR:                             /* ConductorBsdf.cpp:56-66 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_CONDUCTOR)))) return false;
             if (!(e.requested & TGHIP_LOBE_SPECULAR_R)) return false;
             e.wo = mk3(-e.wi.x, -e.wi.y, e.wi.z);
             e.pdf = 1.0f;
@@ -498,6 +517,7 @@ struct BsdfOps {
             e.sampled = TGHIP_LOBE_SPECULAR_R;
             return true;
         case TGHIP_BSDF_ROUGH_CONDUCTOR: {                     /* RoughConductorBsdf.cpp:60-91 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return false;
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return false;
             if (e.wi.z <= 0.0f) return false;
             float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness(s, b, e));
@@ -518,6 +538,7 @@ struct BsdfOps {
             return true;
         }
         case TGHIP_BSDF_SMOOTH_COAT: {                         /* SmoothCoatBsdf.cpp:41-100 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT)))) return false;
             if (e.wi.z <= 0.0f) return false;
             bool sampleR = (e.requested & TGHIP_LOBE_SPECULAR_R) != 0;
             bool sampleT = (e.requested & s.bsdfs[b.sub0].lobes) != 0;
@@ -552,6 +573,7 @@ struct BsdfOps {
             return true;
         }
         case TGHIP_BSDF_DIELECTRIC: {                          /* DielectricBsdf.cpp:49-86 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_DIELECTRIC)))) return false;
             bool sampleR = (e.requested & TGHIP_LOBE_SPECULAR_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_SPECULAR_T) && b.enable_refraction;
             float eta = e.wi.z < 0.0f ? b.ior : 1.0f/b.ior;
@@ -578,6 +600,7 @@ struct BsdfOps {
             return true;
         }
         case TGHIP_BSDF_ROUGH_DIELECTRIC: {                    /* RoughDielectricBsdf.cpp:238-245 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return false;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
             bool result = rdSampleBase(e, sampleR, sampleT, bsdfRoughness(s, b, e), b.ior, b.distribution);
@@ -585,6 +608,7 @@ struct BsdfOps {
             return result;
         }
         case TGHIP_BSDF_PLASTIC: {                             /* PlasticBsdf.cpp:45-87 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_PLASTIC)))) return false;
             if (e.wi.z <= 0.0f) return false;
             bool sampleR = (e.requested & TGHIP_LOBE_SPECULAR_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
@@ -613,6 +637,7 @@ struct BsdfOps {
             return true;
         }
         case TGHIP_BSDF_ROUGH_PLASTIC: {                       /* RoughPlasticBsdf.cpp:54-112 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_PLASTIC)))) return false;
             if (e.wi.z <= 0.0f) return false;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
@@ -656,6 +681,7 @@ struct BsdfOps {
             return true;
         }
         case TGHIP_BSDF_MIXED: {                               /* MixedBsdf.cpp:70-99 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_MIXED)))) return false;
             float ratio;
             if (!mixedRatio(s, b, e, ratio)) return false;
             if (rngNextBoolean(*e.rng, ratio)) {
@@ -677,6 +703,7 @@ struct BsdfOps {
             return true;
         }
         case TGHIP_BSDF_TRANSPARENCY:                          /* TransparencyBsdf.cpp:43-46 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_TRANSPARENCY)))) return false;
             return Next::sample(s, b.sub0, e);
         default:                                               /* null, forward */
             return false;
@@ -688,12 +715,15 @@ struct BsdfOps {
         const TgHipBsdf &b = s.bsdfs[bi];
         switch (b.type) {
         case TGHIP_BSDF_LAMBERT: case TGHIP_BSDF_ERROR:        /* LambertBsdf.cpp:61-68 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_ERROR)))) return 0.0f;
             if (!(e.requested & TGHIP_LOBE_DIFFUSE_R)) return 0.0f;
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
             return cosineHemispherePdf(e.wo);
         case TGHIP_BSDF_MIRROR: case TGHIP_BSDF_CONDUCTOR:
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_MIRROR) | BSDF_BIT(TGHIP_BSDF_CONDUCTOR)))) return 0.0f;
             return ((e.requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e.wi, e.wo)) ? 1.0f : 0.0f;
         case TGHIP_BSDF_ROUGH_CONDUCTOR: {                     /* RoughConductorBsdf.cpp:127-143 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return 0.0f;
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return 0.0f;
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
             float sampleAlpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness(s, b, e));
@@ -701,6 +731,7 @@ struct BsdfOps {
             return mfPdf(b.distribution, sampleAlpha, hr)*0.25f/dot(e.wi, hr);
         }
         case TGHIP_BSDF_SMOOTH_COAT: {                         /* SmoothCoatBsdf.cpp:179-214 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT)))) return 0.0f;
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
             bool sampleR = (e.requested & TGHIP_LOBE_SPECULAR_R) != 0;
             bool sampleT = (e.requested & s.bsdfs[b.sub0].lobes) != 0;
@@ -725,6 +756,7 @@ struct BsdfOps {
             return 0.0f;
         }
         case TGHIP_BSDF_DIELECTRIC: {                          /* DielectricBsdf.cpp:143-164 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_DIELECTRIC)))) return 0.0f;
             bool sampleR = (e.requested & TGHIP_LOBE_SPECULAR_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_SPECULAR_T) && b.enable_refraction;
             float eta = e.wi.z < 0.0f ? b.ior : 1.0f/b.ior;
@@ -738,11 +770,13 @@ struct BsdfOps {
             return 0.0f;
         }
         case TGHIP_BSDF_ROUGH_DIELECTRIC: {
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return 0.0f;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
             return rdPdfBase(e, sampleR, sampleT, bsdfRoughness(s, b, e), b.ior, b.distribution);
         }
         case TGHIP_BSDF_PLASTIC: {                             /* PlasticBsdf.cpp:153-177 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_PLASTIC)))) return 0.0f;
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
             bool sampleR = (e.requested & TGHIP_LOBE_SPECULAR_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
@@ -760,6 +794,7 @@ struct BsdfOps {
             return 0.0f;
         }
         case TGHIP_BSDF_ROUGH_PLASTIC: {                       /* RoughPlasticBsdf.cpp:185-213 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_PLASTIC)))) return 0.0f;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
             if (!sampleR && !sampleT) return 0.0f;
@@ -777,11 +812,13 @@ struct BsdfOps {
             return glossyPdf + diffusePdf;
         }
         case TGHIP_BSDF_MIXED: {                               /* MixedBsdf.cpp:124-130 */
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_MIXED)))) return 0.0f;
             float ratio;
             if (!mixedRatio(s, b, e, ratio)) return 0.0f;
             return Next::pdf(s, b.sub0, e)*ratio + Next::pdf(s, b.sub1, e)*(1.0f - ratio);
         }
         case TGHIP_BSDF_TRANSPARENCY:
+            if (!(M & (BSDF_BIT(TGHIP_BSDF_TRANSPARENCY)))) return 0.0f;
             return Next::pdf(s, b.sub0, e);
         default:
             return 0.0f;
@@ -790,7 +827,7 @@ struct BsdfOps {
 };
 
 // nesting deeper than PT_MAX_BSDF_DEPTH is rejected at upload time; terminate the template chain
-template<> struct BsdfOps<PT_MAX_BSDF_DEPTH> {
+template<uint32_t M> struct BsdfOps<PT_MAX_BSDF_DEPTH, M> {
     static __device__ f3 eval(const DeviceScene &, int, const Event &) { return splat3(0.0f); }
     static __device__ bool sample(const DeviceScene &, int, Event &) { return false; }
     static __device__ float pdf(const DeviceScene &, int, const Event &) { return 0.0f; }
@@ -807,12 +844,20 @@ PT_DEV float bsdfEta(const DeviceScene &s, int bi, const Event &e)
     return 1.0f;
 }
 /* radiance-transport wrappers (adjoint == false, Bsdf.hpp:71-97) */
-PT_DEV f3 bsdfEval(const DeviceScene &s, int bi, const Event &e) { return BsdfOps<0>::eval(s, bi, e)*sqr(bsdfEta(s, bi, e)); }
-PT_DEV float bsdfPdf(const DeviceScene &s, int bi, const Event &e) { return BsdfOps<0>::pdf(s, bi, e); }
+template<uint32_t M>
+PT_DEV f3 bsdfEval(const DeviceScene &s, int bi, const Event &e)
+{
+    f3 f = BsdfOps<0, M>::eval(s, bi, e);
+    if (M & (BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC))) f = f*sqr(bsdfEta(s, bi, e));
+    return f;
+}
+template<uint32_t M>
+PT_DEV float bsdfPdf(const DeviceScene &s, int bi, const Event &e) { return BsdfOps<0, M>::pdf(s, bi, e); }
+template<uint32_t M>
 PT_DEV bool bsdfSample(const DeviceScene &s, int bi, Event &e)
 {
-    if (!BsdfOps<0>::sample(s, bi, e)) return false;
-    e.weight = e.weight*sqr(bsdfEta(s, bi, e));
+    if (!BsdfOps<0, M>::sample(s, bi, e)) return false;
+    if (M & (BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC))) e.weight = e.weight*sqr(bsdfEta(s, bi, e));
     return true;
 }
 
@@ -1089,28 +1134,19 @@ PT_DEV int chooseLight(const DeviceScene &s, Rng &rng, f3 p, float &weight)
     int n = (int)s.num_lights;
     if (n == 0) return -1;
     if (n == 1) { weight = 1.0f; return s.lights[0]; }
-    float lightPdf[16];
+    // Only quad and infinite-sphere emitters are sampled (tghip_upload_scene rejects the rest), and their
+    // approximateRadiance is never negative ("unknown"), so TraceBase.cpp:434-446's uniform-share branch cannot
+    // trigger.  Two passes over the lights instead of a per-lane pdf array (which would live in scratch).
     n = min(n, 16);
     float total = 0.0f;
-    int numNonNegative = 0;
-    for (int i = 0; i < n; ++i) {
-        lightPdf[i] = lightApproximateRadiance(s, s.lights[i], p);
-        if (lightPdf[i] >= 0.0f) { total += lightPdf[i]; numNonNegative++; }
-    }
-    if (numNonNegative == 0) {
-        for (int i = 0; i < n; ++i) lightPdf[i] = 1.0f;
-        total = (float)n;
-    } else if (numNonNegative < n) {
-        for (int i = 0; i < n; ++i) {
-            float uniformWeight = (total == 0.0f ? 1.0f : total)/numNonNegative;
-            if (lightPdf[i] < 0.0f) { lightPdf[i] = uniformWeight; total += uniformWeight; }
-        }
-    }
+    for (int i = 0; i < n; ++i)
+        total += lightApproximateRadiance(s, s.lights[i], p);
     if (total == 0.0f) return -1;
     float t = rngNext1D(rng)*total;
     for (int i = 0; i < n; ++i) {
-        if (t < lightPdf[i] || i == n - 1) { weight = total/lightPdf[i]; return s.lights[i]; }
-        t -= lightPdf[i];
+        float pdf = lightApproximateRadiance(s, s.lights[i], p);
+        if (t < pdf || i == n - 1) { weight = total/pdf; return s.lights[i]; }
+        t -= pdf;
     }
     return -1;
 }

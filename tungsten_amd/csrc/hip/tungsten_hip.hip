@@ -14,111 +14,193 @@
 // Kernels
 // =============================================================================================
 
-// (Re)initialises every slot of a chunk: pixel assignment, sample range, zeroed accumulators.
-__global__ __launch_bounds__(256) void k_init(PathState st, PassParams pp)
-{
-    uint32_t slot = blockIdx.x*blockDim.x + threadIdx.x;
-    if (slot == 0) {
-        st.ctr->n_ext[0] = st.ctr->n_ext[1] = 0;
-        st.ctr->n_shadow[0] = st.ctr->n_shadow[1] = 0;
-    }
-    if (slot >= st.num_slots)
-        return;
-    uint32_t x, y, stream;
-    bool valid = slotPixel(pp, slot, x, y, stream);
-    uint32_t first = pp.spp_begin + stream;
-    valid = valid && first < pp.spp_end;
-    st.pixel[slot] = valid ? x + y*pp.width : 0xFFFFFFFFu;
-    st.samp[slot] = make_uint2(first, pp.spp_end);
-    st.acc[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
-    st.emi[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    st.thr[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, valid ? ST_FRESH : ST_DONE)));
-}
+// BSDF type sets of the shading-kernel variants (pt_scene.h BsdfOps<D, M>)
+#define MASK_SIMPLE  (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_NULL) | BSDF_BIT(TGHIP_BSDF_ERROR))
+#define MASK_COAT    (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR) | BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT) | \
+                      BSDF_BIT(TGHIP_BSDF_MIRROR) | BSDF_BIT(TGHIP_BSDF_CONDUCTOR))
+#define MASK_GLASS   (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC) | \
+                      BSDF_BIT(TGHIP_BSDF_MIRROR))
 
-// Finalises finished paths (OutputBuffer::addSample semantics, cameras/OutputBuffer.hpp:104-107: NaN/Inf
-// samples are dropped without counting), regenerates the slot's next camera path, and compacts
-// the live slots into the extension queue of the next iteration.
-__global__ __launch_bounds__(256) void k_advance(DeviceScene s, PathState st, PassParams pp, int nextParity)
+// Finalises the finished sample of every lane with `finished` set (OutputBuffer::addSample semantics,
+// cameras/OutputBuffer.hpp:104-107: NaN/Inf samples are dropped without counting; PathTracer.cpp:119-122,
+// 130-131: NaN radiance turns the sample black), moves the slot to its next sample or -- when its work item is
+// exhausted -- flushes the item's sum and takes the workgroup's next item (`cursor` = the workgroup's LDS item
+// cursor), and generates the next camera path in place.  `fresh` lanes own nothing yet (pass start).  Must be
+// called by all lanes of the wave.  Returns true for lanes that now hold a new active path.
+PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams &pp, bool finished, bool fresh,
+                     uint32_t slot, f3 em, bool black, uint32_t *cursor, bool aborted, uint32_t &finishedCount)
 {
-    const uint32_t stride = gridDim.x*blockDim.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        st.ctr->n_shadow[nextParity] = 0;
-    uint32_t finished = 0;
-    const bool aborted = st.ctr->abort_flag != 0;
-    for (uint32_t base = blockIdx.x*blockDim.x; base < st.num_slots; base += stride) {
-        uint32_t slot = base + threadIdx.x;
-        bool push = false;
-        if (slot < st.num_slots) {
-            float4 thr = st.thr[slot];
-            uint32_t flags = __float_as_uint(thr.w);
-            uint32_t state = FLAG_STATE(flags);
-            if (state == ST_ACTIVE) {
-                push = !aborted;
-            } else if (state != ST_DONE) {
-                uint2 samp = st.samp[slot];
-                if (state != ST_FRESH) {
-                    f3 em = xyz(st.emi[slot]);
-                    if (state == ST_TERMINATED_BLACK || isnan(sum3(em)))
-                        em = splat3(0.0f);                       // PathTracer.cpp:119-122,130-131
-                    float4 acc = st.acc[slot];
-                    bool finite = !(isinf(em.x) || isinf(em.y) || isinf(em.z));
-                    if (finite) {
-                        acc.x += em.x; acc.y += em.y; acc.z += em.z;
-                        acc.w = __uint_as_float(__float_as_uint(acc.w) + 1u);
-                        st.acc[slot] = acc;
-                    }
-                    finished++;
-                    samp.x += pp.streams;
+    uint2 samp = make_uint2(0u, 0u);
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+    uint32_t pixel = 0, item = 0;
+    bool want = fresh;
+    if (finished) {
+        samp = st.samp[slot];
+        acc = st.acc[slot];
+        pixel = st.pixel[slot];
+        item = st.item[slot];
+        if (black || isnan(sum3(em)))
+            em = splat3(0.0f);
+        if (!(isinf(em.x) || isinf(em.y) || isinf(em.z))) {
+            acc.x += em.x; acc.y += em.y; acc.z += em.z;
+            acc.w = __uint_as_float(__float_as_uint(acc.w) + 1u);
+        }
+        finishedCount++;
+        samp.x++;
+        if (samp.x >= samp.y || aborted) {
+            st.partial[item] = acc;
+            want = true;
+        }
+    }
+    bool dead = false;
+    for (;;) {
+        unsigned long long mask = __ballot(want);
+        if (mask == 0ull)
+            break;
+        uint32_t lane = laneId();
+        uint32_t base = 0;
+        int leader = __ffsll((long long)mask) - 1;
+        if ((int)lane == leader)
+            base = atomicAdd(cursor, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader);
+        if (want) {
+            // workgroup-local index L -> item: groups of PT_ITEM_GROUP consecutive items are dealt round-robin
+            uint32_t L = base + __popcll(mask & ((1ull << lane) - 1ull));
+            uint64_t w64 = ((uint64_t)(L/PT_ITEM_GROUP)*gridDim.x + blockIdx.x)*PT_ITEM_GROUP + (L % PT_ITEM_GROUP);
+            if (w64 >= pp.total_items || aborted) {
+                want = false;
+                dead = true;
+            } else {
+                uint32_t w = (uint32_t)w64;
+                uint32_t c = w/pp.pix_slots, j = w - c*pp.pix_slots;
+                uint32_t x, y;
+                if (slotPixel(pp, j, x, y)) {
+                    want = false;
+                    item = w;
+                    pixel = x + y*pp.width;
+                    samp.x = pp.spp_begin + c*pp.chunk;
+                    samp.y = min(samp.x + pp.chunk, pp.spp_end);
+                    acc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
                 }
-                if (samp.x < samp.y && !aborted) {
-                    uint32_t pixel = st.pixel[slot];
-                    Rng rng = rngStart(pp.seed, pixel, samp.x);   // PathSampleGenerator::startPath
-                    f3 o, d;
-                    cameraRay(s.camera, pixel % pp.width, pixel/pp.width, rng, o, d);
-                    st.ray_o[slot] = mk4(o, 1e-4f);               // Ray ctor default nearT (math/Ray.hpp:24)
-                    st.ray_d[slot] = mk4(d, PT_INF);
-                    st.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-                    st.emi[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
-                    push = true;
-                } else {
-                    st.thr[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
-                }
-                st.samp[slot] = samp;
             }
         }
-        queuePush(push, slot, st.q_ext, &st.ctr->n_ext[nextParity]);
     }
-    waveAddStat(&st.ctr->samples, finished);
+    bool push = false;
+    if (finished || fresh) {
+        if (dead) {
+            st.thr[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
+        } else {
+            Rng rng = rngStart(pp.seed, pixel, samp.x);          // PathSampleGenerator::startPath
+            f3 o, d;
+            cameraRay(s.camera, pixel % pp.width, pixel/pp.width, rng, o, d);
+            st.ray_o[slot] = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
+            st.ray_d[slot] = mk4(d, PT_INF);
+            st.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+            st.emi[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
+            st.samp[slot] = samp;
+            st.acc[slot] = acc;
+            st.pixel[slot] = pixel;
+            st.item[slot] = item;
+            push = true;
+        }
+    }
+    return push;
+}
+
+// Workgroup-local counters staged in LDS for the duration of one kernel (loaded from / stored to BlockCtl).
+struct BlockLds {
+    uint32_t n_ext, n_shade[PT_NUM_CLASSES], n_shadow, cursor;
+    uint32_t samples, closest_rays, shadow_rays, shadow_slots;
+    uint32_t nodes, prims;
+};
+
+PT_DEV void blockBegin(BlockLds &L, const BlockCtl &c)
+{
+    if (threadIdx.x == 0) {
+        L.n_ext = c.n_ext; L.n_shade[0] = c.n_shade[0]; L.n_shade[1] = c.n_shade[1]; L.n_shadow = c.n_shadow;
+        L.cursor = c.item_cursor;
+        L.samples = L.closest_rays = L.shadow_rays = L.shadow_slots = L.nodes = L.prims = 0;
+    }
+    __syncthreads();
+}
+
+// Pass start: every slot takes its first work item.
+__global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, PassParams pp)
+{
+    __shared__ BlockLds L;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    if (threadIdx.x == 0) {
+        L.n_ext = 0; L.cursor = 0; L.samples = 0;
+    }
+    __syncthreads();
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    uint32_t *seg = st.q_ext + first;
+    uint32_t finishedCount = 0;
+    for (uint32_t base = 0; base < st.slots_per_block; base += blockDim.x) {
+        uint32_t local = base + threadIdx.x;
+        uint32_t slot = first + local;
+        bool fresh = local < st.slots_per_block && slot < st.num_slots;
+        bool push = nextPath(s, st, pp, false, fresh, slot, splat3(0.0f), false, &L.cursor, false, finishedCount);
+        queuePush(push, slot, seg, &L.n_ext);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl.n_ext = L.n_ext; ctl.n_shade[0] = 0; ctl.n_shade[1] = 0; ctl.n_shadow = 0;
+        ctl.item_cursor = L.cursor;
+        if (L.n_ext > 0) st.live[0] = 1u;
+    }
 }
 
 template<bool COUNT>
-__global__ __launch_bounds__(256) void k_trace_closest(DeviceScene s, PathState st, int parity)
+__global__ __launch_bounds__(256) void k_trace_closest(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsStack[];
-    const uint32_t n = st.ctr->n_ext[parity];
-    const uint32_t stride = gridDim.x*blockDim.x;
+    __shared__ BlockLds L;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    blockBegin(L, ctl);
+    const uint32_t n = ctl.n_ext;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    const uint32_t *seg = st.q_ext + first;
     uint32_t nodes = 0, prims = 0, rays = 0;
-    for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t slot = st.q_ext[i];
-        float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
-        RayD ray;
-        ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-        st.hit[slot] = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
-        rays++;
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t slot = 0;
+        int cls = -1;
+        if (i < n) {
+            slot = seg[i];
+            float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
+            RayD ray;
+            ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
+            float4 hit = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+            st.hit[slot] = hit;
+            int ri = __float_as_int(hit.w);
+            cls = ri < 0 ? 0 : (int)s.rec_class[ri];
+            rays++;
+        }
+        // sort by material: one shading queue per class (wave ballot + prefix popcount, one LDS atomic per wave)
+        queuePush(cls == 0, slot, st.q_shade[0] + first, &L.n_shade[0]);
+        queuePush(cls == 1, slot, st.q_shade[1] + first, &L.n_shade[1]);
     }
-    waveAddStat(&st.ctr->closest_rays, rays);
-    if (COUNT) {
-        waveAddStat(&st.ctr->nodes_visited, nodes);
-        waveAddStat(&st.ctr->prims_tested, prims);
+    waveAddStat(&L.closest_rays, rays);
+    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl.n_ext = 0;                           // consumed; refilled by k_shade / k_trace_shadow
+        ctl.n_shade[0] = L.n_shade[0]; ctl.n_shade[1] = L.n_shade[1];
+        ctl.closest_rays += L.closest_rays;
+        if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
     }
 }
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
 template<bool COUNT>
-__global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 *rays, float4 *hits, uint32_t n, PathCounters *ctr)
+__global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 *rays, float4 *hits, uint32_t n, BlockStats *stats)
 {
     extern __shared__ int ldsStack[];
+    __shared__ uint32_t ldsNodes, ldsPrims;
+    if (threadIdx.x == 0) { ldsNodes = 0; ldsPrims = 0; }
+    __syncthreads();
     const uint32_t stride = gridDim.x*blockDim.x;
     uint32_t nodes = 0, prims = 0;
     for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -128,31 +210,40 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
         hits[i] = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
     }
     if (COUNT) {
-        waveAddStat(&ctr->nodes_visited, nodes);
-        waveAddStat(&ctr->prims_tested, prims);
+        waveAddStat(&ldsNodes, nodes);
+        waveAddStat(&ldsPrims, prims);
+        __syncthreads();
+        if (threadIdx.x == 0) { stats[blockIdx.x].nodes_visited += ldsNodes; stats[blockIdx.x].prims_tested += ldsPrims; }
     }
 }
 
 // PathTracer::traceSample's loop body for one vertex: TraceBase::handleSurface (TraceBase.cpp:516-568)
 // with estimateDirect split into "compute the unoccluded contribution here, test visibility in
-// k_trace_shadow", plus the loop epilogue (PathTracer.cpp:108-129).
-__global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, int parity)
+// k_trace_shadow", plus the loop epilogue (PathTracer.cpp:108-129).  M = BSDF types this variant handles.
+template<uint32_t M>
+__global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, PassParams pp, int cls)
 {
-    const uint32_t n = st.ctr->n_ext[parity];
-    const uint32_t stride = gridDim.x*blockDim.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        st.ctr->n_ext[parity ^ 1] = 0;
+    __shared__ BlockLds L;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    blockBegin(L, ctl);
+    const uint32_t n = ctl.n_shade[cls];
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    const uint32_t *seg = st.q_shade[cls] + first;
+    const bool aborted = st.live[1] != 0;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
     const bool nee = s.settings.enable_light_sampling != 0;
+    uint32_t finishedCount = 0;
 
-    for (uint32_t base = blockIdx.x*blockDim.x; base < n; base += stride) {
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
         uint32_t i = base + threadIdx.x;
-        bool hasShadow = false;
+        bool hasShadow = false, finished = false, survives = false, black = false;
         uint32_t slot = 0;
+        f3 em = splat3(0.0f);
         if (i < n) {
-            slot = st.q_ext[i];
+            f3 pendingOut = splat3(0.0f);
+            slot = seg[i];
             float4 ro = st.ray_o[slot], rd = st.ray_d[slot], hit = st.hit[slot], thr4 = st.thr[slot];
-            f3 em = xyz(st.emi[slot]);
+            em = xyz(st.emi[slot]);
             uint2 rs = st.rng[slot];
             uint32_t pixel = st.pixel[slot];
             Rng rng;
@@ -205,7 +296,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, int 
                 f3 transparency = splat3(0.0f);
                 if (lobes & TGHIP_LOBE_FORWARD) {
                     ev.wo = -ev.wi; ev.requested = TGHIP_LOBE_FORWARD;
-                    transparency = bsdfEval(s, info.bsdf, ev);
+                    transparency = bsdfEval<M>(s, info.bsdf, ev);
                 }
                 float transparencyScalar = avg3(transparency);
                 f3 wo;
@@ -230,7 +321,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, int 
                                     ev.wo = toLocal(frame, d);
                                     ev.requested = LOBE_ALL_BUT_SPECULAR;
                                     if (isConsistent(ev.wo, d)) {
-                                        f3 f = bsdfEval(s, info.bsdf, ev);
+                                        f3 f = bsdfEval<M>(s, info.bsdf, ev);
                                         if (!isZero(f)) {
                                             RayD sr; sr.o = info.p; sr.d = d; sr.tmin = 5e-4f; sr.tmax = PT_INF;
                                             LightHit lh;
@@ -239,7 +330,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, int 
                                                 f3 e = lightEvalDirect(s, light, lh.u, lh.v, lh.backSide);
                                                 if (!isZero(e)) {
                                                     f3 lightF = f*e/pdf;
-                                                    lightF = lightF*powerHeuristic(pdf, bsdfPdf(s, info.bsdf, ev));
+                                                    lightF = lightF*powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
                                                     st.sh_d0[slot] = mk4(d, lh.t);
                                                     st.sh_c0[slot] = mk4(lightF, __uint_as_float(tag));
                                                     q0 = true;
@@ -253,7 +344,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, int 
                             {
                                 ev.requested = LOBE_ALL_BUT_SPECULAR;
                                 ev.weight = splat3(1.0f); ev.pdf = 1.0f;
-                                if (bsdfSample(s, info.bsdf, ev) && !isZero(ev.weight)) {
+                                if (bsdfSample<M>(s, info.bsdf, ev) && !isZero(ev.weight)) {
                                     f3 wog = toGlobal(frame, ev.wo);
                                     if (isConsistent(ev.wo, wog)) {
                                         RayD sr; sr.o = info.p; sr.d = wog; sr.tmin = 5e-4f; sr.tmax = PT_INF;
@@ -286,15 +377,16 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, int 
                         if (o.emission >= 0 && bounce >= minBounces && (!nee || wasSpecular || o.light < 0))
                             pending = lightEvalDirect(s, info.object, info.u, info.v, info.backSide)*throughput;
                     }
-                    if (hasShadow)
-                        st.sh_p[slot] = mk4(pending, 0.0f);      // added after the NEE term, like the reference
-                    else
+                    // with a shadow ray pending, `pending` is added after the NEE term by k_trace_shadow, like the reference
+                    if (!hasShadow)
                         em = em + pending;
+                    else
+                        pendingOut = pending;
 
                     // continuation: bsdf.sample(event, adjoint = false) with all lobes (TraceBase.cpp:546-558)
                     ev.requested = LOBE_ALL;
                     ev.weight = splat3(1.0f); ev.pdf = 1.0f;
-                    if (!bsdfSample(s, info.bsdf, ev)) {
+                    if (!bsdfSample<M>(s, info.bsdf, ev)) {
                         alive = false;
                     } else {
                         wo = toGlobal(frame, ev.wo);
@@ -340,113 +432,163 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, int 
                     st.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                 }
             }
-            st.emi[slot] = mk4(em, 0.0f);
-            st.thr[slot] = mk4(throughput, __uint_as_float(FLAG_MAKE(bounce, wasSpecular, state)));
+            const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state);
+            survives = state == ST_ACTIVE;
+            black = state == ST_TERMINATED_BLACK;
+            if (hasShadow) {
+                // k_trace_shadow adds the NEE term, then finishes the path if it ended here
+                st.emi[slot] = mk4(em, 0.0f);
+                st.sh_p[slot] = mk4(pendingOut, __uint_as_float(newFlags));
+            } else if (survives) {
+                st.emi[slot] = mk4(em, 0.0f);
+            } else {
+                finished = true;
+            }
+            if (survives)
+                st.thr[slot] = mk4(throughput, __uint_as_float(newFlags));
         }
-        queuePush(hasShadow, slot, st.q_shadow, &st.ctr->n_shadow[parity]);
+        queuePush(hasShadow, slot, st.q_shadow + first, &L.n_shadow);
+        bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
+        queuePush(survives || regenerated, slot, st.q_ext + first, &L.n_ext);
+    }
+    waveAddStat(&L.samples, finishedCount);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl.n_shade[cls] = 0;                    // consumed
+        ctl.n_ext = L.n_ext; ctl.n_shadow = L.n_shadow;
+        ctl.item_cursor = L.cursor;
+        ctl.samples += L.samples;
     }
 }
 
 // TraceBase::generalizedShadowRay (TraceBase.cpp:62-125) for the shadow rays queued by k_shade:
 // a closest-hit query up to the light; unoccluded iff nothing is hit or the closest hit is the
-// light itself (endCap); surfaces with a forward lobe attenuate and the ray continues.
-template<bool COUNT>
-__global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState st, int parity)
+// light itself (endCap); surfaces with a forward lobe attenuate and the ray continues (FORWARD variant only:
+// scenes without a forward-lobe BSDF run the lean variant).
+template<bool COUNT, bool FORWARD>
+__global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsStack[];
-    const uint32_t n = st.ctr->n_shadow[parity];
-    const uint32_t stride = gridDim.x*blockDim.x;
-    uint32_t nodes = 0, prims = 0, rays = 0, slots = 0;
-    for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += stride) {
-        uint32_t slot = st.q_shadow[i];
-        slots++;
-        float4 so = st.sh_o[slot];
-        f3 result = splat3(0.0f);
+    __shared__ BlockLds L;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    blockBegin(L, ctl);
+    const uint32_t n = ctl.n_shadow;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    const uint32_t *seg = st.q_shadow + first;
+    const bool aborted = st.live[1] != 0;
+    uint32_t nodes = 0, prims = 0, rays = 0, slots = 0, finishedCount = 0;
+    for (uint32_t base = 0; base < n; base += blockDim.x) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t slot = 0;
+        bool finished = false, black = false;
+        f3 em = splat3(0.0f);
+        if (i < n) {
+            slot = seg[i];
+            slots++;
+            float4 so = st.sh_o[slot];
+            f3 result = splat3(0.0f);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float4 c = r == 0 ? st.sh_c0[slot] : st.sh_c1[slot];
-            uint32_t tag = __float_as_uint(c.w);
-            if (tag == 0xFFFFFFFFu)
-                continue;
-            float4 sd = r == 0 ? st.sh_d0[slot] : st.sh_d1[slot];
-            int endCap = (int)(tag & 0xFFFFFFu);
-            int bounce = (int)(tag >> 24);
-            RayD ray;
-            ray.o = xyz(so); ray.d = xyz(sd); ray.tmin = so.w; ray.tmax = sd.w;
-            float remaining = ray.tmax;
-            f3 transmittance = splat3(1.0f);
-            for (;;) {
-                float4 hit = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
-                rays++;
-                int ri = __float_as_int(hit.w);
-                int hitObject = -1;
-                if (ri >= 0)
-                    hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(s.recs[ri*3].w));
-                if (ri < 0 || hitObject == endCap) {
-                    if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
-                    break;
+            for (int r = 0; r < 2; ++r) {
+                float4 c = r == 0 ? st.sh_c0[slot] : st.sh_c1[slot];
+                uint32_t tag = __float_as_uint(c.w);
+                if (tag == 0xFFFFFFFFu)
+                    continue;
+                float4 sd = r == 0 ? st.sh_d0[slot] : st.sh_d1[slot];
+                int endCap = (int)(tag & 0xFFFFFFu);
+                int bounce = (int)(tag >> 24);
+                RayD ray;
+                ray.o = xyz(so); ray.d = xyz(sd); ray.tmin = so.w; ray.tmax = sd.w;
+                float remaining = ray.tmax;
+                f3 transmittance = splat3(1.0f);
+                for (;;) {
+                    float4 hit = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+                    rays++;
+                    int ri = __float_as_int(hit.w);
+                    int hitObject = -1;
+                    if (ri >= 0)
+                        hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(s.recs[ri*3].w));
+                    if (ri < 0 || hitObject == endCap) {
+                        if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
+                        break;
+                    }
+                    if (!FORWARD) { transmittance = splat3(0.0f); break; }
+                    Info info;
+                    intersectionInfo(s, ray, hit, info);
+                    const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
+                    if (!(lobes & TGHIP_LOBE_FORWARD)) { transmittance = splat3(0.0f); break; }
+                    Frame frame = frameFromNormal(info.Ns);
+                    bool hitBackside = dot(frame.normal, ray.d) > 0.0f;
+                    if (s.settings.enable_two_sided_shading && hitBackside && !(lobes & LOBE_TRANSMISSIVE)) {
+                        frame.normal = -frame.normal;
+                        frame.tangent = -frame.tangent;
+                    }
+                    Event fe;
+                    fe.wi = toLocal(frame, -ray.d); fe.wo = -fe.wi;
+                    fe.requested = TGHIP_LOBE_FORWARD; fe.u = info.u; fe.v = info.v; fe.rng = nullptr;
+                    f3 transparency = bsdfEval<FORWARD ? BSDF_MASK_ALL : 0u>(s, info.bsdf, fe);
+                    if (isZero(transparency)) { transmittance = splat3(0.0f); break; }
+                    transmittance = transmittance*transparency;
+                    bounce++;
+                    if (bounce >= s.settings.max_bounces) { transmittance = splat3(0.0f); break; }
+                    ray.o = ray.o + ray.d*hit.x;
+                    remaining -= hit.x;
+                    ray.tmin = 5e-4f;
+                    ray.tmax = remaining;
                 }
-                Info info;
-                intersectionInfo(s, ray, hit, info);
-                const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
-                if (!(lobes & TGHIP_LOBE_FORWARD)) { transmittance = splat3(0.0f); break; }
-                Frame frame = frameFromNormal(info.Ns);
-                bool hitBackside = dot(frame.normal, ray.d) > 0.0f;
-                if (s.settings.enable_two_sided_shading && hitBackside && !(lobes & LOBE_TRANSMISSIVE)) {
-                    frame.normal = -frame.normal;
-                    frame.tangent = -frame.tangent;
-                }
-                Event fe;
-                fe.wi = toLocal(frame, -ray.d); fe.wo = -fe.wi;
-                fe.requested = TGHIP_LOBE_FORWARD; fe.u = info.u; fe.v = info.v; fe.rng = nullptr;
-                f3 transparency = bsdfEval(s, info.bsdf, fe);
-                if (isZero(transparency)) { transmittance = splat3(0.0f); break; }
-                transmittance = transmittance*transparency;
-                bounce++;
-                if (bounce >= s.settings.max_bounces) { transmittance = splat3(0.0f); break; }
-                ray.o = ray.o + ray.d*hit.x;
-                remaining -= hit.x;
-                ray.tmin = 5e-4f;
-                ray.tmax = remaining;
+                if (!isZero(transmittance))
+                    result = result + xyz(c)*transmittance;
             }
-            if (!isZero(transmittance))
-                result = result + xyz(c)*transmittance;
+            float4 w = st.sh_w[slot];
+            float4 p = st.sh_p[slot];
+            em = xyz(st.emi[slot]);
+            em = em + (result*w.w)*xyz(w);                       // emission += estimateDirect(...)*throughput
+            em = em + xyz(p);
+            uint32_t state = FLAG_STATE(__float_as_uint(p.w));
+            if (state == ST_ACTIVE) {
+                st.emi[slot] = mk4(em, 0.0f);
+            } else {
+                finished = true;
+                black = state == ST_TERMINATED_BLACK;
+            }
         }
-        float4 w = st.sh_w[slot];
-        f3 em = xyz(st.emi[slot]);
-        em = em + (result*w.w)*xyz(w);                           // emission += estimateDirect(...)*throughput
-        em = em + xyz(st.sh_p[slot]);
-        st.emi[slot] = mk4(em, 0.0f);
+        bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
+        queuePush(regenerated, slot, st.q_ext + first, &L.n_ext);
     }
-    waveAddStat(&st.ctr->shadow_rays, rays);
-    waveAddStat(&st.ctr->shadow_slots, slots);
-    if (COUNT) {
-        waveAddStat(&st.ctr->nodes_visited, nodes);
-        waveAddStat(&st.ctr->prims_tested, prims);
-        waveAddStat(&st.ctr->nodes_visited_shadow, nodes);
-        waveAddStat(&st.ctr->prims_tested_shadow, prims);
+    waveAddStat(&L.samples, finishedCount);
+    waveAddStat(&L.shadow_rays, rays);
+    waveAddStat(&L.shadow_slots, slots);
+    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl.n_shadow = 0;                        // consumed
+        ctl.n_ext = L.n_ext;
+        ctl.item_cursor = L.cursor;
+        ctl.samples += L.samples; ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
+        if (COUNT) {
+            BlockStats &bs = st.stats[blockIdx.x];
+            bs.nodes_visited += L.nodes; bs.prims_tested += L.prims;
+            bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
+        }
+        // last kernel of the iteration: tell the host whether any extension queue still holds work
+        if (L.n_ext > 0) st.live[0] = iterTag;
     }
 }
 
-// Sums the K per-stream partial sums of every pixel slot in fixed order into the framebuffer
+// Sums the per-item partial sums of every pixel slot in fixed chunk order into the framebuffer
 // (deterministic; no float atomics anywhere on the accumulation path).
 __global__ __launch_bounds__(256) void k_resolve(PathState st, PassParams pp, float *fbSum, uint32_t *fbCount)
 {
     uint32_t j = blockIdx.x*blockDim.x + threadIdx.x;
     if (j >= pp.pix_slots)
         return;
-    uint32_t pixel = st.pixel[j];
-    if (pixel == 0xFFFFFFFFu) {
-        // stream 0 invalid means the pixel is outside the image (or the pass is empty)
-        uint32_t x, y, stream;
-        if (!slotPixel(pp, j, x, y, stream))
-            return;
-        pixel = x + y*pp.width;
-    }
+    uint32_t x, y;
+    if (!slotPixel(pp, j, x, y))
+        return;
+    uint32_t pixel = x + y*pp.width;
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
     uint32_t cnt = 0;
-    for (uint32_t k = 0; k < pp.streams; ++k) {
-        float4 a = st.acc[(size_t)k*pp.pix_slots + j];
+    for (uint32_t c = 0; c < pp.chunks; ++c) {
+        float4 a = st.partial[(size_t)c*pp.pix_slots + j];
         sx += a.x; sy += a.y; sz += a.z;
         cnt += __float_as_uint(a.w);
     }
@@ -495,10 +637,22 @@ struct tghip_ctx {
     DeviceBuffers poolMem;
     PathState pool;
     uint32_t poolSlots = 0;
-    PathCounters *hostCtr = nullptr;      // pinned mirror for the loop condition
+    uint32_t poolGrid = 0;                // persistent workgroups the pool is laid out for
+    uint32_t *hostLive = nullptr;         // pinned mirror of PathState::live for the loop condition
+    std::vector<BlockCtl> hostCtl;        // scratch for tghip_get_counters
+    std::vector<BlockStats> hostStats;
 
     // options
-    long long maxSlots = 1ll << 21;       // target pool size
+    long long maxSlots = 1ll << 20;       // path pool size
+    long long maxItems = 1ll << 26;       // work items per batch (partial-sum buffer = 16 B each)
+    int chunkSamples = 4;                 // samples per work item
+    size_t partialCap = 0;
+    float4 *partial = nullptr;
+
+    // shading classes of the uploaded scene (rec_class) and the kernel variants chosen for them
+    bool haveComplex = false;             // some primitive record uses a class-1 BSDF
+    uint32_t complexMask = 0;             // union of the BSDF types inside class-1 materials
+    bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
     bool countTraversal = false;
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
     int blocksPerCu = 4;
@@ -559,6 +713,19 @@ static int bsdfDepth(const TgHipSceneDesc *s, int bi, int depth)
     return d;
 }
 
+// set of BSDF types (bit = 1 << type) in the subtree of bsdf `bi`
+static uint32_t bsdfTypeMask(const TgHipSceneDesc *s, int bi, int depth)
+{
+    if (bi < 0 || uint32_t(bi) >= s->num_bsdfs || depth > 16) return 0;
+    const TgHipBsdf &b = s->bsdfs[bi];
+    uint32_t m = 1u << uint32_t(b.type);
+    if (b.type == TGHIP_BSDF_SMOOTH_COAT || b.type == TGHIP_BSDF_TRANSPARENCY)
+        m |= bsdfTypeMask(s, b.sub0, depth + 1);
+    if (b.type == TGHIP_BSDF_MIXED)
+        m |= bsdfTypeMask(s, b.sub0, depth + 1) | bsdfTypeMask(s, b.sub1, depth + 1);
+    return m;
+}
+
 static int bvhDepthOf(const TgHipSceneDesc *s)
 {
     // iterative depth computation over the flattened tree (also validates child references)
@@ -582,25 +749,69 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
     return depth;
 }
 
-static int ensurePool(tghip_ctx *ctx, uint32_t slots)
+static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*ctx->blocksPerCu; }
+
+// Adds the per-workgroup statistics on the device to ctx->counters and zeroes them there.
+static int foldCounters(tghip_ctx *ctx)
 {
-    if (ctx->poolSlots >= slots)
+    if (!ctx->poolSlots)
         return TGHIP_OK;
+    const size_t g = ctx->poolGrid;
+    ctx->hostCtl.resize(g);
+    ctx->hostStats.resize(g);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->hostCtl.data(), ctx->pool.ctl, g*sizeof(BlockCtl), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(ctx->hostStats.data(), ctx->pool.stats, g*sizeof(BlockStats), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < g; ++b) {
+        BlockCtl &c = ctx->hostCtl[b];
+        ctx->counters.samples += c.samples; ctx->counters.closest_rays += c.closest_rays;
+        ctx->counters.shadow_rays += c.shadow_rays; ctx->counters.shadow_slots += c.shadow_slots;
+        c.samples = c.closest_rays = c.shadow_rays = c.shadow_slots = 0;
+        const BlockStats &t = ctx->hostStats[b];
+        ctx->counters.nodes_visited += t.nodes_visited; ctx->counters.prims_tested += t.prims_tested;
+        ctx->counters.nodes_visited_shadow += t.nodes_visited_shadow; ctx->counters.prims_tested_shadow += t.prims_tested_shadow;
+    }
+    // no pass is running here (calls on one handle are serialised), so the records can be written back whole
+    HIP_TRY(ctx, hipMemcpy(ctx->pool.ctl, ctx->hostCtl.data(), g*sizeof(BlockCtl), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemset(ctx->pool.stats, 0, g*sizeof(BlockStats)));
+    return TGHIP_OK;
+}
+
+// Pool layout: `grid` persistent workgroups x slotsPerBlock slots (a multiple of 64); queue segments and the
+// per-workgroup control records are laid out the same way.
+static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
+{
+    const uint32_t grid = uint32_t(launchGrid(ctx));
+    uint32_t perBlock = (wantSlots + grid - 1)/grid;
+    perBlock = std::max<uint32_t>(64u, (perBlock + 63u)/64u*64u);
+    const uint32_t slots = perBlock*grid;
+    PathState &p = ctx->pool;
+    if (ctx->poolSlots >= slots && ctx->poolGrid == grid) {
+        p.num_slots = slots;
+        p.slots_per_block = perBlock;
+        return TGHIP_OK;
+    }
+    int rc = foldCounters(ctx);                  // the per-workgroup statistics live in the pool
+    if (rc != TGHIP_OK) return rc;
     ctx->poolMem.release();
     ctx->poolSlots = 0;
-    PathState &p = ctx->pool;
-    int rc;
 #define POOL_ALLOC(field, n) if ((rc = allocArray(ctx, ctx->poolMem, (n), &p.field)) != TGHIP_OK) return rc
     POOL_ALLOC(ray_o, slots); POOL_ALLOC(ray_d, slots); POOL_ALLOC(hit, slots); POOL_ALLOC(thr, slots);
     POOL_ALLOC(emi, slots); POOL_ALLOC(acc, slots); POOL_ALLOC(rng, slots); POOL_ALLOC(samp, slots);
-    POOL_ALLOC(pixel, slots);
+    POOL_ALLOC(pixel, slots); POOL_ALLOC(item, slots);
     POOL_ALLOC(sh_o, slots); POOL_ALLOC(sh_d0, slots); POOL_ALLOC(sh_c0, slots); POOL_ALLOC(sh_d1, slots);
     POOL_ALLOC(sh_c1, slots); POOL_ALLOC(sh_w, slots); POOL_ALLOC(sh_p, slots);
     POOL_ALLOC(q_ext, slots); POOL_ALLOC(q_shadow, slots);
-    POOL_ALLOC(ctr, 1);
+    for (int c = 0; c < PT_NUM_CLASSES; ++c) POOL_ALLOC(q_shade[c], slots);
+    POOL_ALLOC(ctl, grid); POOL_ALLOC(stats, grid); POOL_ALLOC(live, 2);
 #undef POOL_ALLOC
-    HIP_TRY(ctx, hipMemsetAsync(p.ctr, 0, sizeof(PathCounters), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(p.ctl, 0, sizeof(BlockCtl)*grid, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(p.stats, 0, sizeof(BlockStats)*grid, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(p.live, 0, 2*sizeof(uint32_t), ctx->stream));
+    p.num_slots = slots;
+    p.slots_per_block = perBlock;
     ctx->poolSlots = slots;
+    ctx->poolGrid = grid;
     return TGHIP_OK;
 }
 
@@ -632,7 +843,7 @@ tghip_ctx *tghip_create(int device_ordinal)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->evA);
     if (e == hipSuccess) e = hipEventCreate(&ctx->evB);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->hostCtr), sizeof(PathCounters), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->hostLive), 2*sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         std::lock_guard<std::mutex> lock(g_errMutex);
         g_createError = std::string("tghip_create: ") + hipGetErrorString(e);
@@ -651,7 +862,8 @@ void tghip_destroy(tghip_ctx *ctx)
     ctx->poolMem.release();
     if (ctx->fbSum) (void)hipFree(ctx->fbSum);
     if (ctx->fbCount) (void)hipFree(ctx->fbCount);
-    if (ctx->hostCtr) (void)hipHostFree(ctx->hostCtr);
+    if (ctx->partial) (void)hipFree(ctx->partial);
+    if (ctx->hostLive) (void)hipHostFree(ctx->hostLive);
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
@@ -676,6 +888,8 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     std::string k(key);
     if (k == "count_traversal") ctx->countTraversal = value != 0;
     else if (k == "max_slots") ctx->maxSlots = std::max<long long>(value, 256);
+    else if (k == "max_items") ctx->maxItems = std::max<long long>(value, 256);
+    else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "blocks_per_cu") ctx->blocksPerCu = int(std::min<long long>(std::max<long long>(value, 1), 8));
@@ -723,6 +937,26 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->textures, sd->num_textures, &s.textures)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->texels, sd->num_texel_floats, &s.texels)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->dist, sd->num_dist_floats, &s.dist)) != TGHIP_OK) return rc;
+    // shading classes ("sort by material"): class 0 = BSDFs made of lambert/null only, class 1 = the rest
+    {
+        std::vector<uint32_t> typeMask(sd->num_bsdfs, 0u);
+        std::vector<uint8_t> recClass(std::max<uint32_t>(sd->num_recs, 1u), 0);
+        ctx->haveComplex = false; ctx->complexMask = 0; ctx->haveForward = false;
+        for (uint32_t i = 0; i < sd->num_bsdfs; ++i) {
+            typeMask[i] = bsdfTypeMask(sd, int(i), 0);
+            if (sd->bsdfs[i].lobes & TGHIP_LOBE_FORWARD) ctx->haveForward = true;
+        }
+        for (uint32_t i = 0; i < sd->num_recs; ++i) {
+            uint32_t meta = sd->recs[i].meta;
+            int bi = TGHIP_REC_KIND(meta) == TGHIP_REC_TRIANGLE ? sd->tri_attrs[i].bsdf : sd->objects[TGHIP_REC_OBJECT(meta)].bsdf;
+            if (bi < 0 || uint32_t(bi) >= sd->num_bsdfs) { ctx->error = "primitive record without a valid bsdf"; return TGHIP_E_INVALID; }
+            bool simple = (typeMask[size_t(bi)] & ~MASK_SIMPLE) == 0 && !(sd->bsdfs[bi].lobes & TGHIP_LOBE_FORWARD);
+            recClass[i] = simple ? 0 : 1;
+            if (!simple) { ctx->haveComplex = true; ctx->complexMask |= typeMask[size_t(bi)]; }
+        }
+        if ((rc = uploadArray(ctx, ctx->sceneMem, recClass.data(), recClass.size(), &s.rec_class)) != TGHIP_OK) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // recClass goes out of scope
+    }
     s.num_nodes = sd->num_nodes; s.num_recs = sd->num_recs; s.num_objects = sd->num_objects;
     s.num_lights = sd->num_lights; s.num_infinite_lights = sd->num_infinite_lights;
     s.num_bsdfs = sd->num_bsdfs; s.num_textures = sd->num_textures;
@@ -767,22 +1001,38 @@ int tghip_bind_framebuffer(tghip_ctx *ctx, float *dev_rgb_sum, uint32_t *dev_cou
     return TGHIP_OK;
 }
 
-static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*ctx->blocksPerCu; }
+extern "C++" {
+template<uint32_t M>
+static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
+{
+    hipLaunchKernelGGL(k_shade<M>, dim3(grid), dim3(256), 0, ctx->stream, ctx->scene, st, pp, cls);
+}
 
-// Runs the wavefront loop for one chunk of pixel slots until every slot is drained.
-static int runChunk(tghip_ctx *ctx, const PassParams &pp, uint32_t slots)
+template<bool COUNT>
+static void launchShadow(tghip_ctx *ctx, int grid, size_t ldsBytes, const PathState &st, const PassParams &pp, uint32_t iterTag)
+{
+    if (ctx->haveForward)
+        hipLaunchKernelGGL((k_trace_shadow<COUNT, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
+    else
+        hipLaunchKernelGGL((k_trace_shadow<COUNT, false>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
+}
+
+} // extern "C++"
+
+// Runs the wavefront loop for one batch of work items until every slot is drained.
+static int runBatch(tghip_ctx *ctx, const PassParams &pp)
 {
     PathState st = ctx->pool;
-    st.num_slots = slots;
+    st.partial = ctx->partial;
     const DeviceScene &s = ctx->scene;
-    const int grid = launchGrid(ctx);
+    const int grid = int(ctx->poolGrid);
     const size_t ldsBytes = size_t(ctx->bvhDepth + 1)*256*sizeof(int);
     const bool count = ctx->countTraversal;
 
     // optional per-launch timing: one event pair per kernel launch of a check interval, read back at the
     // interval's host sync (events live on ctx->stream, the stream the kernels are launched on)
     const bool timing = ctx->timeKernels;
-    const size_t evNeeded = size_t(ctx->checkInterval)*4*2;
+    const size_t evNeeded = size_t(ctx->checkInterval)*3*2;
     if (timing) {
         while (ctx->evPool.size() < evNeeded) {
             hipEvent_t e = nullptr;
@@ -793,47 +1043,56 @@ static int runChunk(tghip_ctx *ctx, const PassParams &pp, uint32_t slots)
     size_t evUsed = 0;
     auto tic = [&]() { if (timing) (void)hipEventRecord(ctx->evPool[evUsed++], ctx->stream); };
 
-    hipLaunchKernelGGL(k_init, dim3((slots + 255)/256), dim3(256), 0, ctx->stream, st, pp);
-    int parity = 0;
-    hipLaunchKernelGGL(k_advance, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp, parity);
+    HIP_TRY(ctx, hipMemsetAsync(st.partial, 0, size_t(pp.total_items)*sizeof(float4), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(st.live, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_start, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp);
+    uint32_t iterTag = 1;                        // k_start publishes tag 1 when it queued anything
+    bool first = true;
     for (;;) {
         evUsed = 0;
+        {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->hostLive, st.live, 2*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (timing && !first) {
+                double *acc[3] = {&ctx->counters.ms_trace_closest, &ctx->counters.ms_shade, &ctx->counters.ms_trace_shadow};
+                size_t pairs = size_t(ctx->checkInterval)*3;
+                for (size_t k = 0; k < pairs; ++k) {
+                    float ms = 0.0f;
+                    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[2*k], ctx->evPool[2*k + 1]));
+                    *acc[k % 3] += ms;
+                }
+                ctx->counters.launches_trace_closest += ctx->checkInterval;
+                ctx->counters.launches_trace_shadow += ctx->checkInterval;
+                ctx->counters.launches_shade += ctx->checkInterval;
+            }
+            if (ctx->hostLive[0] != iterTag)
+                break;                           // the last iteration left every extension queue empty
+        }
+        first = false;
         for (int it = 0; it < ctx->checkInterval; ++it) {
+            ++iterTag;
             tic();
-            if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
-            else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
+            if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
+            else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
             tic(); tic();
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(256), 0, ctx->stream, s, st, parity);
+            launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
+            if (ctx->haveComplex) {
+                if ((ctx->complexMask & ~MASK_COAT) == 0)       launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
+                else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
+                else                                            launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 1);
+            }
             tic(); tic();
-            if (count) hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
-            else       hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st, parity);
-            tic(); tic();
-            hipLaunchKernelGGL(k_advance, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp, parity ^ 1);
+            if (count) launchShadow<true>(ctx, grid, ldsBytes, st, pp, iterTag);
+            else       launchShadow<false>(ctx, grid, ldsBytes, st, pp, iterTag);
             tic();
-            parity ^= 1;
             ctx->counters.iterations++;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->hostCtr, st.ctr, sizeof(PathCounters), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        if (timing) {
-            double *acc[4] = {&ctx->counters.ms_trace_closest, &ctx->counters.ms_shade, &ctx->counters.ms_trace_shadow, &ctx->counters.ms_other};
-            for (size_t k = 0; k + 1 < evUsed; k += 2) {
-                float ms = 0.0f;
-                HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[k], ctx->evPool[k + 1]));
-                *acc[(k/2) % 4] += ms;
-            }
-            ctx->counters.launches_trace_closest += evUsed/8;
-            ctx->counters.launches_trace_shadow += evUsed/8;
-            ctx->counters.launches_shade += evUsed/8;
-        }
-        if (ctx->hostCtr->n_ext[parity] == 0)
-            break;
     }
     float *sum = ctx->extSum ? ctx->extSum : ctx->fbSum;
     uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
     hipLaunchKernelGGL(k_resolve, dim3((pp.pix_slots + 255)/256), dim3(256), 0, ctx->stream, st, pp, sum, cnt);
     HIP_TRY(ctx, hipGetLastError());
-    return ctx->hostCtr->abort_flag ? TGHIP_E_ABORTED : TGHIP_OK;
+    return ctx->hostLive[1] ? TGHIP_E_ABORTED : TGHIP_OK;
 }
 
 // The pass itself is driven synchronously from tghip_wait (the integrator calls it from its worker
@@ -869,27 +1128,47 @@ int tghip_wait(tghip_ctx *ctx)
     if (ownedTiles == 0 || spp == 0)
         return ctx->passResult = TGHIP_OK;
 
-    // pool geometry: whole tiles (256 pixel slots each) x K sample streams per pixel
-    const uint64_t maxSlots = uint64_t(ctx->maxSlots);
-    uint32_t tilesPerChunk = uint32_t(std::min<uint64_t>(ownedTiles, std::max<uint64_t>(1, maxSlots/256)));
-    uint32_t streams = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(spp, maxSlots/(uint64_t(tilesPerChunk)*256))));
-    uint32_t slots = tilesPerChunk*256*streams;
+    // Batches: work items = (pixel slot of an owned tile) x (chunk of `chunkSamples` sample indices).  One batch
+    // holds at most maxItems items (16 B of partial sum each); larger passes are split by sample range first,
+    // then by tiles.
+    const uint32_t chunk = uint32_t(std::max(ctx->chunkSamples, 1));
+    const uint64_t maxItems = uint64_t(std::max<long long>(ctx->maxItems, 256));
+    const uint32_t chunksAll = (spp + chunk - 1)/chunk;
+    uint32_t tilesPerBatch = ownedTiles, chunksPerBatch = chunksAll;
+    if (uint64_t(ownedTiles)*256*chunksAll > maxItems) {
+        chunksPerBatch = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(chunksAll, maxItems/(uint64_t(ownedTiles)*256))));
+        if (uint64_t(ownedTiles)*256*chunksPerBatch > maxItems)
+            tilesPerBatch = uint32_t(std::max<uint64_t>(1, maxItems/(256ull*chunksPerBatch)));
+    }
+    const uint64_t batchItems = uint64_t(tilesPerBatch)*256*chunksPerBatch;
+    const uint32_t slots = uint32_t(std::min<uint64_t>(uint64_t(ctx->maxSlots), batchItems));
     int rc = ensurePool(ctx, slots);
     if (rc != TGHIP_OK) return ctx->passResult = rc;
-    HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.ctr->abort_flag, 0, sizeof(uint32_t), ctx->stream));
+    if (ctx->partialCap < batchItems) {
+        if (ctx->partial) (void)hipFree(ctx->partial);
+        ctx->partial = nullptr; ctx->partialCap = 0;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->partial), batchItems*sizeof(float4)));
+        ctx->partialCap = batchItems;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.live[1], 0, sizeof(uint32_t), ctx->stream));   // abort flag
 
     HIP_TRY(ctx, hipEventRecord(ctx->evA, ctx->stream));
-    for (uint32_t first = 0; first < ownedTiles; first += tilesPerChunk) {
-        PassParams pp;
-        pp.spp_begin = pass.spp_begin; pp.spp_end = pass.spp_end; pp.seed = pass.seed;
-        pp.streams = streams;
-        pp.pix_slots = tilesPerChunk*256;
-        pp.first_tile = first;
-        pp.shard_index = pass.shard_index; pp.shard_count = shardCount;
-        pp.tiles_x = tilesX; pp.num_tiles = numTiles;
-        pp.width = w; pp.height = h;
-        rc = runChunk(ctx, pp, slots);
-        if (rc != TGHIP_OK) break;
+    for (uint32_t sppFirst = pass.spp_begin; sppFirst < pass.spp_end && rc == TGHIP_OK; sppFirst += chunksPerBatch*chunk) {
+        const uint32_t sppLast = uint32_t(std::min<uint64_t>(uint64_t(sppFirst) + uint64_t(chunksPerBatch)*chunk, pass.spp_end));
+        for (uint32_t first = 0; first < ownedTiles; first += tilesPerBatch) {
+            PassParams pp;
+            pp.spp_begin = sppFirst; pp.spp_end = sppLast; pp.seed = pass.seed;
+            pp.chunk = chunk;
+            pp.chunks = (sppLast - sppFirst + chunk - 1)/chunk;
+            pp.pix_slots = std::min(tilesPerBatch, ownedTiles - first)*256;
+            pp.total_items = pp.pix_slots*pp.chunks;
+            pp.first_tile = first;
+            pp.shard_index = pass.shard_index; pp.shard_count = shardCount;
+            pp.tiles_x = tilesX; pp.num_tiles = numTiles;
+            pp.width = w; pp.height = h;
+            rc = runBatch(ctx, pp);
+            if (rc != TGHIP_OK) break;
+        }
     }
     HIP_TRY(ctx, hipEventRecord(ctx->evB, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -902,14 +1181,14 @@ int tghip_wait(tghip_ctx *ctx)
 int tghip_abort(tghip_ctx *ctx)
 {
     if (!ctx) return TGHIP_E_INVALID;
-    if (!ctx->pool.ctr) return TGHIP_OK;
-    // device-visible flag polled by the persistent k_advance grid; written from a second stream so it
+    if (!ctx->poolSlots) return TGHIP_OK;
+    // device-visible flag polled whenever a slot asks for new work; written from a second stream so it
     // does not queue behind the running pass
     static const uint32_t one = 1;
     hipStream_t side = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    hipError_t e = hipMemcpyAsync(&ctx->pool.ctr->abort_flag, &one, sizeof(one), hipMemcpyHostToDevice, side);
+    hipError_t e = hipMemcpyAsync(&ctx->pool.live[1], &one, sizeof(one), hipMemcpyHostToDevice, side);
     if (e == hipSuccess) e = hipStreamSynchronize(side);
     (void)hipStreamDestroy(side);
     if (e != hipSuccess) { ctx->error = hipGetErrorString(e); return TGHIP_E_HIP; }
@@ -941,7 +1220,7 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dRays), n*sizeof(TgHipRay)));
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&dHits), n*sizeof(TgHipHit));
     if (e != hipSuccess) { (void)hipFree(dRays); ctx->error = hipGetErrorString(e); return TGHIP_E_HIP; }
-    int rc = ensurePool(ctx, 256);
+    int rc = ensurePool(ctx, ctx->poolSlots ? ctx->pool.num_slots : 256);   // the traversal statistics live in the pool
     if (rc != TGHIP_OK) { (void)hipFree(dRays); (void)hipFree(dHits); return rc; }
     (void)hipMemcpyAsync(dRays, rays, n*sizeof(TgHipRay), hipMemcpyHostToDevice, ctx->stream);
     const int grid = int(std::min<size_t>(size_t(launchGrid(ctx)), (n + 255)/256));
@@ -950,9 +1229,9 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
     (void)hipEventRecord(ctx->evA, ctx->stream);
     for (int r = 0; r < repeats; ++r) {
         if (ctx->countTraversal && r == 0)
-            hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.ctr);
+            hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
         else
-            hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.ctr);
+            hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
     }
     (void)hipEventRecord(ctx->evB, ctx->stream);
     (void)hipMemcpyAsync(hits, dHits, n*sizeof(TgHipHit), hipMemcpyDeviceToHost, ctx->stream);
@@ -968,19 +1247,9 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out)
 {
     if (!ctx || !out) return TGHIP_E_INVALID;
-    if (ctx->pool.ctr) {
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->hostCtr, ctx->pool.ctr, sizeof(PathCounters), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->counters.samples = ctx->hostCtr->samples;
-        ctx->counters.closest_rays = ctx->hostCtr->closest_rays;
-        ctx->counters.shadow_rays = ctx->hostCtr->shadow_rays;
-        ctx->counters.nodes_visited = ctx->hostCtr->nodes_visited;
-        ctx->counters.prims_tested = ctx->hostCtr->prims_tested;
-        ctx->counters.nodes_visited_shadow = ctx->hostCtr->nodes_visited_shadow;
-        ctx->counters.prims_tested_shadow = ctx->hostCtr->prims_tested_shadow;
-        ctx->counters.shadow_slots = ctx->hostCtr->shadow_slots;
-    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = foldCounters(ctx);
+    if (rc != TGHIP_OK) return rc;
     *out = ctx->counters;
     return TGHIP_OK;
 }
@@ -988,12 +1257,10 @@ int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out)
 int tghip_reset_counters(tghip_ctx *ctx)
 {
     if (!ctx) return TGHIP_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = foldCounters(ctx);
+    if (rc != TGHIP_OK) return rc;
     std::memset(&ctx->counters, 0, sizeof(ctx->counters));
-    if (ctx->pool.ctr) {
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.ctr->samples, 0, 8*sizeof(unsigned long long), ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
     return TGHIP_OK;
 }
 
