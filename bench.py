@@ -136,16 +136,15 @@ def main():
         fb_sum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
         fb_cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
         check(lib.tghip_bind_framebuffer(ctx, fb_sum.data_ptr(), fb_cnt.data_ptr()), "tghip_bind_framebuffer")
-        pass_desc = tg.TgHipPassDesc(0, spp, tg.DEFAULT_SEED, rank, world, 0)
+        from tungsten_amd import dist as tgdist
+        pass_desc = tgdist.shard_pass(rank, world, 0, spp, tg.DEFAULT_SEED)
 
         def step():
             check(lib.tghip_clear_framebuffer(ctx), "tghip_clear_framebuffer")
             check(lib.tghip_render_pass(ctx, C.byref(pass_desc)), "tghip_render_pass")
             check(lib.tghip_wait(ctx), "tghip_wait")
-            if dist is not None:
-                # the exchange step: float framebuffer sum-reduce over xGMI (tile ownership is disjoint -> exact)
-                dist.reduce(fb_sum, dst=0, op=dist.ReduceOp.SUM)
-                dist.reduce(fb_cnt, dst=0, op=dist.ReduceOp.SUM)
+            # the exchange step: float framebuffer sum-reduce over xGMI (tile ownership is disjoint -> exact)
+            tgdist.reduce_framebuffer(fb_sum, fb_cnt, dst=0)
 
         def fence():
             if dist is not None:

@@ -1,0 +1,69 @@
+"""The N > 1 path on CPU: 2 ranks over gloo run the same tile sharding + framebuffer reduce bench.py uses on
+GPUs (tungsten_amd/dist.py), with the oracle standing in for the device renderer.  Rank 0 must end up with
+the unsharded image, bit for bit (disjoint tile ownership => exact reduction)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import tungsten_amd as tg
+from tungsten_amd import dist as tgdist
+import oracle_lib, scenes
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+tmp = sys.argv[2]
+path = scenes.cornell(tmp, name="r%d.json" % rank, resolution=(80, 45), spp=2)
+flat = tg.FlattenedScene(path)
+p = tgdist.shard_pass(rank, world, 0, 2, 1234)
+s, c = oracle_lib.render(flat.desc, 80, 45, p.spp_begin, p.spp_end, p.seed, shard_index=p.shard_index, shard_count=p.shard_count)
+# every pixel this rank owns lies in one of its tiles, and nothing else was touched
+owned = np.zeros((45, 80), bool)
+for t in tgdist.owned_tiles(rank, world, 80, 45):
+    ty, tx = divmod(t, 5)
+    owned[ty*16:ty*16 + 16, tx*16:tx*16 + 16] = True
+assert ((c > 0) == owned).all()
+fs, fc = torch.from_numpy(s), torch.from_numpy(c.astype(np.int32))
+tgdist.reduce_framebuffer(fs, fc, dst=0)
+if rank == 0:
+    ws, wc = oracle_lib.render(flat.desc, 80, 45, 0, 2, 1234)
+    assert (fs.numpy() == ws).all() and (fc.numpy() == wc.astype(np.int32)).all()
+    print("DIST_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_tile_shard_and_reduce(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path/"worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "DIST_OK" in outs[0]
+
+
+def test_shard_pass_validation():
+    from tungsten_amd import dist as tgdist
+    import pytest
+    p = tgdist.shard_pass(3, 8, 0, 256, 0xBA5EBA11)
+    assert (p.shard_index, p.shard_count, p.spp_end) == (3, 8, 256)
+    with pytest.raises(ValueError):
+        tgdist.shard_pass(8, 8, 0, 1, 0)
+    tiles = [t for r in range(8) for t in tgdist.owned_tiles(r, 8, 1280, 720)]
+    assert sorted(tiles) == list(range(80*45))

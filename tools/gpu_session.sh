@@ -1,20 +1,28 @@
 #!/bin/bash
-# One GPU-box session: parity tests, bench lines, rocprofv3 kernel stats.  Usage: tools/gpu_session.sh <tag>
+# One GPU-box session: parity tests, bench lines, rocprofv3 kernel stats + HBM counters.  Usage: tools/gpu_session.sh <tag>
 tag=${1:-session}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 echo "== pytest -m gpu"
 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > $out/pytest.log 2>&1; echo "pytest rc=$?"
-tail -25 $out/pytest.log
-echo "== bench cornell"
-timeout 600 python bench.py > $out/bench_cornell.json 2> $out/bench_cornell.err; echo "rc=$?"; cat $out/bench_cornell.json; tail -5 $out/bench_cornell.err
-echo "== bench materialtest"
-timeout 600 python bench.py --scene materialtest --spp 64 > $out/bench_materialtest.json 2> $out/bench_materialtest.err; echo "rc=$?"; cat $out/bench_materialtest.json; tail -5 $out/bench_materialtest.err
-echo "== rocprof cornell"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o cornell -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/prof_cornell.log 2>&1; echo "rc=$?"
-cat $out/prof/cornell_kernel_stats.csv 2>/dev/null | head -12
-echo "== rocprof materialtest"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o materialtest -- python bench.py --scene materialtest --spp 64 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/prof_materialtest.log 2>&1; echo "rc=$?"
-cat $out/prof/materialtest_kernel_stats.csv 2>/dev/null | head -12
-rm -f $out/prof/*results.db $out/prof/*kernel_trace.csv
+tail -5 $out/pytest.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+for scene in cornell materialtest; do
+  spp=256; [ $scene = materialtest ] && spp=64
+  echo "== bench $scene"
+  timeout 600 python bench.py --scene $scene --spp $spp > $out/bench_$scene.json 2> $out/bench_$scene.err; echo "rc=$?"; cat $out/bench_$scene.json; tail -3 $out/bench_$scene.err
+  echo "== rocprof stats $scene"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$scene -o stats -- python bench.py --scene $scene --spp $spp --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/prof_$scene.log 2>&1; echo "rc=$?"
+  f=$(find $out/prof_$scene -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/${scene}_kernel_stats.csv && head -8 $f
+  find $out/prof_$scene -name '*kernel_trace.csv' -delete; find $out/prof_$scene -name '*.db' -delete
+  echo "== rocprof pmc $scene"
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${scene}_$c -o pmc -- python bench.py --scene $scene --spp 16 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing > $out/pmc_${scene}_$c.log 2>&1; echo "$c rc=$?"
+  done
+  ff=$(find $out/pmc_${scene}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
+  fw=$(find $out/pmc_${scene}_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+  [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_traffic.py $scene $ff $fw $out/traffic.json
+  find $out -name '*counter_collection.csv' -delete; find $out -name '*.db' -delete
+done

@@ -655,7 +655,7 @@ struct tghip_ctx {
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
     bool countTraversal = false;
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
-    int blocksPerCu = 4;
+    int blocksPerCu = 0;                  // persistent workgroups per CU; 0 = as many as the traversal stacks leave LDS for (<= 8)
     bool timeKernels = false;             // HIP events around every launch of the wavefront loop (bench.py roofline)
     std::vector<hipEvent_t> evPool;
 
@@ -749,7 +749,16 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
     return depth;
 }
 
-static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*ctx->blocksPerCu; }
+static int launchGrid(const tghip_ctx *ctx)
+{
+    int perCu = ctx->blocksPerCu;
+    if (perCu <= 0) {
+        // 160 KB of LDS per CU (MI355X_MICROARCH.md); every traversal workgroup holds 256 node stacks of bvhDepth+1 ints
+        size_t lds = size_t(ctx->bvhDepth + 1)*256*sizeof(int) + 256;
+        perCu = int(std::min<size_t>(8, std::max<size_t>(1, (160u*1024u)/lds)));
+    }
+    return ctx->prop.multiProcessorCount*perCu;
+}
 
 // Adds the per-workgroup statistics on the device to ctx->counters and zeroes them there.
 static int foldCounters(tghip_ctx *ctx)
@@ -892,7 +901,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
-    else if (k == "blocks_per_cu") ctx->blocksPerCu = int(std::min<long long>(std::max<long long>(value, 1), 8));
+    else if (k == "blocks_per_cu") ctx->blocksPerCu = int(std::min<long long>(std::max<long long>(value, 0), 8));
     else { ctx->error = "unknown option '" + k + "'"; return TGHIP_E_INVALID; }
     return TGHIP_OK;
 }
