@@ -68,6 +68,11 @@ typedef struct TgHipBvhNode {
 #define TGHIP_MAKE_LEAF(first, count) (int32_t)(TGHIP_LEAF_FLAG | ((uint32_t)(count) << 27) | (uint32_t)(first))
 #define TGHIP_MAX_LEAF         15
 #define TGHIP_MAX_BVH_DEPTH    48   /* builder guarantees depth <= this (device stack size) */
+/* Scenes with at most this many primitive records are intersected as a flat list in record order (every ray
+ * tests every record; the wave walks the list uniformly, so record data comes through the scalar cache) instead of
+ * through the BVH -- the analogue of the reference's top-level Embree scene over a handful of user-geometry
+ * primitives (TraceableScene.hpp:112-134).  The oracle follows the same rule so that visit counts agree. */
+#define TGHIP_FLAT_MAX_RECS    16
 
 /* record kinds (meta >> 29) */
 enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3 };

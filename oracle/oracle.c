@@ -1177,15 +1177,35 @@ static inline int box_test(const float *lo, const float *hi, const Ray *ray, v3 
 
 /* TraceableScene::intersect (renderer/TraceableScene.hpp:170-192): closest hit over all finite
  * primitives.  The reference does it with Embree BVH4s; we walk the flattened BVH2, near child first. */
+static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float *tmax, TgHipHit *hit, TravStats *st)
+{
+    const TgHipPrimRec *r = &s->recs[i];
+    if (st) st->prims++;
+    float t, u = 0.0f, v = 0.0f; int back = 0;
+    int ok = 0;
+    switch (TGHIP_REC_KIND(r->meta)) {
+    case TGHIP_REC_TRIANGLE: ok = tri_test(r, ray, *tmax, &t, &u, &v); break;
+    case TGHIP_REC_QUAD: ok = quad_test(r, &s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &u, &v, &back); break;
+    case TGHIP_REC_CUBE: ok = cube_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
+    default: break;
+    }
+    if (ok) { *tmax = t; hit->t = t; hit->u = u; hit->v = v; hit->rec = (int32_t)i; }
+}
+
 static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hit, TravStats *st)
 {
     int32_t stack[TGHIP_MAX_BVH_DEPTH + 2];
     int sp = 0;
     float tmax = ray->tmax;
     hit->rec = -1; hit->t = tmax; hit->u = hit->v = 0.0f;
+    if (st) st->rays++;
+    if (s->num_recs <= TGHIP_FLAT_MAX_RECS) {           /* flat list (include/tungsten_hip.h) */
+        for (uint32_t i = 0; i < s->num_recs; ++i)
+            test_rec(s, i, ray, &tmax, hit, st);
+        return hit->rec >= 0;
+    }
     v3 invD = V(1.0f/ray->d.x, 1.0f/ray->d.y, 1.0f/ray->d.z);
     int32_t cur = 0;
-    if (st) st->rays++;
     for (;;) {
         if (cur >= 0) {
             const TgHipBvhNode *n = &s->nodes[cur];
@@ -1201,19 +1221,8 @@ static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hi
             else if (h1) { cur = n->child1; continue; }
         } else {
             uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
-            for (uint32_t i = first; i < first + count; ++i) {
-                const TgHipPrimRec *r = &s->recs[i];
-                if (st) st->prims++;
-                float t, u = 0.0f, v = 0.0f; int back = 0;
-                int ok = 0;
-                switch (TGHIP_REC_KIND(r->meta)) {
-                case TGHIP_REC_TRIANGLE: ok = tri_test(r, ray, tmax, &t, &u, &v); break;
-                case TGHIP_REC_QUAD: ok = quad_test(r, &s->objects[TGHIP_REC_OBJECT(r->meta)], ray, tmax, &t, &u, &v, &back); break;
-                case TGHIP_REC_CUBE: ok = cube_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, tmax, &t, &back); u = (float)back; break;
-                default: break;
-                }
-                if (ok) { tmax = t; hit->t = t; hit->u = u; hit->v = v; hit->rec = (int32_t)i; }
-            }
+            for (uint32_t i = first; i < first + count; ++i)
+                test_rec(s, i, ray, &tmax, hit, st);
         }
         if (sp == 0) break;
         cur = stack[--sp];

@@ -112,7 +112,7 @@ def test_oracle_units(scene, tmp_path):
         rays.append(r["o"] + [r["tmin"]] + r["d"] + [np.inf])
         want.append(r)
     hits, nodes, prims = oracle_lib.trace_rays(d, np.array(rays, np.float32))
-    assert nodes > 0 and prims > 0
+    assert prims > 0 and (nodes > 0 or flat.desc.contents.num_recs <= 16)   # flat-list rule (TGHIP_FLAT_MAX_RECS)
     mism = 0
     for hgot, r in zip(hits, want):
         if bool(r["hit"]) != (hgot["rec"] >= 0):

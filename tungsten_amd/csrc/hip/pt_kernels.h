@@ -11,9 +11,9 @@
 //   * private queue segments for those slots (extension / per-class shading / shadow), whose lengths live in
 //     the workgroup's BlockCtl record, and
 //   * a private, finely interleaved share of the pass's work items (item = pixel x chunk of sample indices).
-// Nothing is shared between workgroups, so there is not a single global atomic on the hot path: queue pushes and
-// work-item fetches are wave-aggregated (ballot + prefix popcount) LDS atomics, and the counts are carried from
-// one kernel to the next through BlockCtl.  (Same-address global atomics saturate at ~88/us on MI355X --
+// Nothing is shared between workgroups, so there is not a single global atomic on the hot path: queue pushes are
+// LDS bit-sets, work-item fetches wave-aggregated (ballot + prefix popcount) LDS atomics, and queue contents are
+// carried from one kernel to the next as per-workgroup bitmaps.  (Same-address global atomics saturate at ~88/us on MI355X --
 // MI355X_MICROARCH.md "dequeue" -- which is what bounded the first version of this tracer.)
 // A slot that finishes its item flushes the item's radiance sum to partial[item] and takes the workgroup's next
 // item, so the pool stays full until the pass drains however uneven the path lengths are; partial[] is reduced
@@ -40,42 +40,47 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 
 #define PT_NUM_CLASSES 2          // shading classes: 0 = diffuse/null/miss, 1 = everything else
 #define PT_ITEM_GROUP  64u        // consecutive work items handed to one workgroup (a wave's worth of pixels)
+#define PT_MAX_SLOTS_PER_BLOCK 2048u
+#define PT_MAX_WORDS   (PT_MAX_SLOTS_PER_BLOCK/32u)
+
+// The four queues of a workgroup are BITMAPS over its slot range (one bit per slot), not index lists: a consumer
+// expands its bitmap into the ascending list of set slots, so every kernel walks its slots in memory order and
+// the 16-byte-per-slot SoA accesses of a wave land in consecutive cache lines.  (Index lists in arrival order
+// made each wave touch ~50 different 64-B lines per access and half of all DRAM writes partial-line.)
+enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_COUNT = 4 };
 
 struct BlockCtl {                 // one per persistent workgroup; only that workgroup touches it
-    uint32_t n_ext;               // extension-queue segment length
-    uint32_t n_shade[PT_NUM_CLASSES];
-    uint32_t n_shadow;
     uint32_t item_cursor;         // workgroup-local linear index of the next work item
-    uint32_t pad[3];
+    uint32_t pad[7];
     unsigned long long samples, closest_rays, shadow_rays, shadow_slots;
 };                                // 64 B
 
 struct BlockStats {               // traversal statistics (count_traversal option), one per workgroup
     unsigned long long nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow;
+    unsigned long long prof[12];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds, tools/gpu_profile_sections.sh)
 };
 
 struct PathState {
-    float4 *ray_o;     // origin.xyz, tmin
-    float4 *ray_d;     // dir.xyz, tmax
-    float4 *hit;       // t, u, v, record index (int bits; -1 = miss)
-    float4 *thr;       // throughput.rgb, flags (uint bits)
-    float4 *emi;       // radiance of the sample in flight
-    float4 *acc;       // sum of the finished samples of the slot's current work item, count (uint bits)
-    uint2  *rng;       // PCG state
-    uint2  *samp;      // current sample index, end of the item's sample range
-    uint32_t *pixel;   // pixel index of the current item
-    uint32_t *item;    // current work item
-    float4 *sh_o;      // shadow origin.xyz, epsilon
-    float4 *sh_d0, *sh_c0;   // light-sample shadow ray: dir.xyz, tmax | unoccluded contribution, endCap|bounce bits
-    float4 *sh_d1, *sh_c1;   // bsdf-sample shadow ray
-    float4 *sh_w;      // throughput at the NEE vertex, light-selection weight
-    float4 *sh_p;      // emission picked up at the same vertex (added after the NEE term), path flags (uint bits)
-    uint32_t *q_ext, *q_shadow;            // queue segments: workgroup b uses [b*slots_per_block, (b+1)*slots_per_block)
-    uint32_t *q_shade[PT_NUM_CLASSES];
-    float4 *partial;   // per work item: radiance sum, count (uint bits)
+    float4 * __restrict__ ray_o;     // origin.xyz, tmin
+    float4 * __restrict__ ray_d;     // dir.xyz, tmax
+    float4 * __restrict__ hit;       // t, u, v, record index (int bits; -1 = miss)
+    float4 * __restrict__ thr;       // throughput.rgb, flags (uint bits)
+    float4 * __restrict__ emi;       // radiance of the sample in flight
+    float4 * __restrict__ acc;       // sum of the finished samples of the slot's current work item, count (uint bits)
+    uint2 * __restrict__ rng;       // PCG state
+    uint2 * __restrict__ samp;      // current sample index, end of the item's sample range
+    uint32_t * __restrict__ pixel;   // pixel index of the current item
+    uint32_t * __restrict__ item;    // current work item
+    float4 * __restrict__ sh_o;      // shadow origin.xyz, epsilon
+    float4 * __restrict__ sh_d0, * __restrict__ sh_c0;   // light-sample shadow ray: dir.xyz, tmax | unoccluded contribution, endCap|bounce bits
+    float4 * __restrict__ sh_d1, * __restrict__ sh_c1;   // bsdf-sample shadow ray
+    float4 * __restrict__ sh_w;      // throughput at the NEE vertex, light-selection weight
+    float4 * __restrict__ sh_p;      // emission picked up at the same vertex (added after the NEE term), path flags (uint bits)
+    uint32_t * __restrict__ bm[Q_COUNT];   // queue bitmaps: workgroup b uses words [b*slots_per_block/32, (b+1)*slots_per_block/32)
+    float4 * __restrict__ partial;   // per work item: radiance sum, count (uint bits)
     BlockCtl *ctl;
     BlockStats *stats;
-    uint32_t *live;    // [0] = tag of the last iteration that left work in some extension queue; [1] = abort flag
+    uint32_t * __restrict__ live;    // [0] = tag of the last iteration that left work in some extension queue; [1] = abort flag
     uint32_t num_slots, slots_per_block;
 };
 
@@ -93,21 +98,144 @@ struct PassParams {
 
 PT_DEV uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// wave-aggregated queue push: one (LDS) atomic per wave (ballot + prefix popcount); `queue` is the workgroup's segment
-PT_DEV void queuePush(bool push, uint32_t value, uint32_t *queue, uint32_t *counter)
+// ---- small scene tables in LDS --------------------------------------------------------------------
+// The shading kernels chase object -> bsdf -> texture -> light records per lane.  Those tables are tiny, but the
+// vector L1 is flushed continuously by the streaming path state, so every dependent lookup pays L2 latency.
+// When the tables fit, each workgroup copies them into LDS once and the lookups become LDS reads (through
+// generic pointers; the big arrays -- records, attributes, texels, CDFs -- stay in global memory).
+#define PT_LDS_TABLE_BYTES 12288u
+PT_DEV DeviceScene stageSceneTables(const DeviceScene &s, unsigned char *lds)
 {
-    unsigned long long mask = __ballot(push);
-    if (mask == 0ull)
-        return;
-    uint32_t lane = laneId();
-    uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t base = 0;
-    int leader = __ffsll((long long)mask) - 1;
-    if ((int)lane == leader)
-        base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
+    const uint32_t szObj = s.num_objects*(uint32_t)sizeof(TgHipObject);
+    const uint32_t szBsdf = s.num_bsdfs*(uint32_t)sizeof(TgHipBsdf);
+    const uint32_t szTex = s.num_textures*(uint32_t)sizeof(TgHipTexture);
+    const uint32_t szLights = (s.num_lights + s.num_infinite_lights)*(uint32_t)sizeof(int32_t);
+    const uint32_t offBsdf = (szObj + 15u) & ~15u;
+    const uint32_t offTex = (offBsdf + szBsdf + 15u) & ~15u;
+    const uint32_t offLights = (offTex + szTex + 15u) & ~15u;
+    const uint32_t total = offLights + szLights;
+    if (total > PT_LDS_TABLE_BYTES)
+        return s;                                            // uniform decision: too large, keep the global tables
+    uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
+    auto copy = [&](uint32_t off, const void *src, uint32_t bytes) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
+        for (uint32_t i = threadIdx.x; i < bytes/4u; i += blockDim.x)
+            dst[off/4u + i] = w[i];
+    };
+    copy(0, s.objects, szObj);
+    copy(offBsdf, s.bsdfs, szBsdf);
+    copy(offTex, s.textures, szTex);
+    copy(offLights, s.lights, s.num_lights*(uint32_t)sizeof(int32_t));
+    copy(offLights + s.num_lights*(uint32_t)sizeof(int32_t), s.infinite_lights, s.num_infinite_lights*(uint32_t)sizeof(int32_t));
+    __syncthreads();
+    DeviceScene r = s;
+    r.objects = reinterpret_cast<const TgHipObject *>(lds);
+    r.bsdfs = reinterpret_cast<const TgHipBsdf *>(lds + offBsdf);
+    r.textures = reinterpret_cast<const TgHipTexture *>(lds + offTex);
+    r.lights = reinterpret_cast<const int32_t *>(lds + offLights);
+    r.infinite_lights = r.lights + s.num_lights;
+    return r;
+}
+
+// Workgroup-local state staged in LDS for the duration of one kernel.
+struct BlockLds {
+    uint32_t bm[Q_COUNT][PT_MAX_WORDS];     // queue bitmaps being built / consumed
+    uint32_t prefix[PT_MAX_WORDS];
+    uint32_t n;                                      // length of the consumed queue
+    uint32_t cursor;
+    uint32_t samples, closest_rays, shadow_rays, shadow_slots, nodes, prims;
+};
+
+// push: set the slot's bit in queue q (LDS atomic OR)
+PT_DEV void queuePush(bool push, uint32_t localSlot, BlockLds &L, int q)
+{
     if (push)
-        queue[base + prefix] = value;
+        atomicOr(&L.bm[q][localSlot >> 5], 1u << (localSlot & 31u));
+}
+
+// Kernel prologue: loads the bitmaps this kernel appends to (bit mask `appendMask` over Q_*), expands the
+// consumed queue `q` (-1 = none) into order[0 .. L.n) (ascending local slot indices; `order` = LDS scratch of
+// slots_per_block entries), and resets the statistics.  All threads must call it.
+PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, int q, uint32_t appendMask, unsigned short *order)
+{
+    const uint32_t W = st.slots_per_block >> 5;
+    const uint32_t t = threadIdx.x;
+    if (t < W) {
+#pragma unroll
+        for (int k = 0; k < Q_COUNT; ++k) {
+            bool load = k == q || ((appendMask >> k) & 1u);
+            L.bm[k][t] = load ? st.bm[k][blockIdx.x*W + t] : 0u;
+        }
+    }
+    if (t == 0) {
+        L.cursor = ctl.item_cursor;
+        L.samples = L.closest_rays = L.shadow_rays = L.shadow_slots = L.nodes = L.prims = 0;
+        L.n = 0;
+    }
+    __syncthreads();
+    if (q >= 0) {
+        // exclusive prefix of the per-word popcounts (W <= 64: one wave)
+        if (t < 64) {
+            uint32_t c = t < W ? (uint32_t)__popc(L.bm[q][t]) : 0u;
+            uint32_t inc = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                uint32_t v = __shfl_up(inc, off);
+                if ((int)t >= off) inc += v;
+            }
+            if (t < W) L.prefix[t] = inc - c;
+            if (t == 63) L.n = inc;
+        }
+        __syncthreads();
+        if (t < W) {
+            uint32_t bits = L.bm[q][t], off = L.prefix[t];
+            while (bits) {
+                uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
+                order[off++] = (unsigned short)(t*32u + b);
+                bits &= bits - 1u;
+            }
+            L.bm[q][t] = 0u;                     // consumed
+        }
+        __syncthreads();
+    }
+}
+
+// A thread's entries order[k*256 + tid], k < 8, packed two per register, so that the LDS scratch holding `order`
+// can be reused (as the traversal stack) once every thread has fetched its share.
+struct OrderRegs { uint32_t p[4]; };
+PT_DEV OrderRegs orderPreload(const unsigned short *order, uint32_t n)
+{
+    OrderRegs r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t i0 = (uint32_t)(2*k)*256u + threadIdx.x, i1 = (uint32_t)(2*k + 1)*256u + threadIdx.x;
+        uint32_t lo = i0 < n ? order[i0] : 0u, hi = i1 < n ? order[i1] : 0u;
+        r.p[k] = lo | (hi << 16);
+    }
+    __syncthreads();
+    return r;
+}
+PT_DEV uint32_t orderGet(const OrderRegs &r, uint32_t k)   // k is wave-uniform
+{
+    uint32_t w = (k >> 1) == 0 ? r.p[0] : (k >> 1) == 1 ? r.p[1] : (k >> 1) == 2 ? r.p[2] : r.p[3];
+    return (k & 1u) ? (w >> 16) : (w & 0xFFFFu);
+}
+
+// Kernel epilogue: writes back the consumed (now empty) and appended bitmaps.  Returns (to thread 0..W-1) nothing;
+// `anyExt` tells whether the extension queue holds work.
+PT_DEV bool queuesEnd(BlockLds &L, const PathState &st, int q, uint32_t appendMask)
+{
+    __syncthreads();
+    const uint32_t W = st.slots_per_block >> 5;
+    const uint32_t t = threadIdx.x;
+    uint32_t ext = 0;
+    if (t < W) {
+#pragma unroll
+        for (int k = 0; k < Q_COUNT; ++k)
+            if (k == q || ((appendMask >> k) & 1u))
+                st.bm[k][blockIdx.x*W + t] = L.bm[k][t];
+        ext = L.bm[Q_EXT][t];
+    }
+    return __syncthreads_or(ext != 0u) != 0;
 }
 
 // pixel slot j of the batch -> image pixel (16x16 tile dicing, PathTraceIntegrator.cpp:27-42; tiles of a shard
@@ -130,12 +258,19 @@ PT_DEV float filterSample1D(const TgHipCamera &cam, float xi)
 {
     bool negative = xi < 0.5f;
     xi = negative ? xi*2.0f : (xi - 0.5f)*2.0f;
+    // first i in [0, 30) with xi < cdf[i], else 30 (cdf[0] = 0, so i >= 1).  Walking downwards with selects keeps
+    // every table index a compile-time constant (the table sits in SGPRs; a per-lane index would not).
     int idx = 30;
-    for (int i = 0; i < 30; ++i) {
-        if (xi < cam.filter_cdf[i]) { idx = i; break; }
+    float hi = cam.filter_cdf[30], lo = cam.filter_cdf[29];
+#pragma unroll
+    for (int i = 29; i >= 1; --i) {
+        bool below = xi < cam.filter_cdf[i];
+        idx = below ? i : idx;
+        hi = below ? cam.filter_cdf[i] : hi;
+        lo = below ? cam.filter_cdf[i - 1] : lo;
     }
-    float pdf = cam.filter_cdf[idx] - cam.filter_cdf[idx - 1];
-    float u = cam.filter_bin_size*(idx + (xi - cam.filter_cdf[idx - 1])/pdf);
+    float pdf = hi - lo;
+    float u = cam.filter_bin_size*(idx + (xi - lo)/pdf);
     return negative ? -u : u;
 }
 PT_DEV void cameraRay(const TgHipCamera &cam, uint32_t px, uint32_t py, Rng &rng, f3 &o, f3 &d)
@@ -165,12 +300,21 @@ PT_DEV bool boxTest(f3 lo, f3 hi, const RayD &ray, f3 invD, float tmax, float &t
 }
 
 // `stack` is this lane's column of the workgroup's LDS stack: stack[level*stride]
-template<bool COUNT>
+// FLAT: the scene has <= TGHIP_FLAT_MAX_RECS records; every lane walks the whole record list in step, so the
+// record (and quad/cube object) loads have wave-uniform addresses and go through the scalar cache.
+template<bool COUNT, bool FLAT>
 PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack, int stride,
                               uint32_t &nodesVisited, uint32_t &primsTested)
 {
     float tmax = ray.tmax;
     float4 hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+    if (FLAT) {
+        const uint32_t n = s.num_recs;
+        for (uint32_t i = 0; i < n; ++i)
+            testRecord<true>(s, i, ray, tmax, hit);
+        if (COUNT) primsTested += n;
+        return hit;
+    }
     f3 invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
     int sp = 0;
     int cur = 0;
@@ -194,7 +338,7 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
             uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
             for (uint32_t i = first; i < first + count; ++i) {
                 if (COUNT) primsTested++;
-                testRecord(s, i, ray, tmax, hit);
+                testRecord<false>(s, i, ray, tmax, hit);
             }
         }
         if (sp == 0)
@@ -203,6 +347,67 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
         cur = stack[sp*stride];
     }
     return hit;
+}
+
+// Any-hit query for shadow rays in scenes without forward-lobe BSDFs: true iff some record of an object other
+// than `endCap` (the light the ray was aimed at) is hit inside (tmin, tmax).  Equivalent to
+// generalizedShadowRay's closest-hit formulation there (TraceBase.cpp:79,114-115), but the
+// traversal stops at the first occluder.
+template<bool COUNT, bool FLAT>
+PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, int *stack, int stride,
+                             uint32_t &nodesVisited, uint32_t &primsTested)
+{
+    float4 hit;
+    uint32_t meta;
+    if (FLAT) {
+        const uint32_t n = s.num_recs;
+        bool occluded = false;
+        for (uint32_t i = 0; i < n; ++i) {
+            float tmax = ray.tmax;
+            if (!occluded) {
+                if (COUNT) primsTested++;
+                if (testRecord<true>(s, i, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                    occluded = true;
+            }
+            if (__ballot(!occluded) == 0ull)
+                break;                            // every active lane has found its occluder
+        }
+        return occluded;
+    }
+    f3 invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
+    int sp = 0;
+    int cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *n = s.nodes + (size_t)cur*4;
+            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (COUNT) nodesVisited++;
+            float e0, e1;
+            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, ray.tmax, e0);
+            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, ray.tmax, e1);
+            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (h0 && h1) {
+                if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
+                else { stack[sp*stride] = c1; cur = c0; }
+                sp++;
+                continue;
+            } else if (h0) { cur = c0; continue; }
+            else if (h1) { cur = c1; continue; }
+        } else {
+            uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+            for (uint32_t i = first; i < first + count; ++i) {
+                if (COUNT) primsTested++;
+                float tmax = ray.tmax;
+                if (testRecord<false>(s, i, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                    return true;
+            }
+        }
+        if (sp == 0)
+            break;
+        sp--;
+        cur = stack[sp*stride];
+    }
+    return false;
 }
 
 // wave-reduced statistics add into a workgroup-local (LDS) counter

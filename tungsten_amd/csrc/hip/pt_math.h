@@ -23,7 +23,12 @@ struct f3 { float x, y, z; };
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 splat3(float s) { return mk3(s, s, s); }
-PT_DEV f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+template<typename P> PT_DEV f3 ld3(P p) { return mk3(p[0], p[1], p[2]); }   // P: pointer to float in any address space
+
+// Pointer into the constant address space: a load through it with a wave-uniform address is a scalar-cache
+// (s_load) access instead of a vector memory instruction (used by the flat-list traversal, pt_kernels.h).
+#define PT_CONST_AS __attribute__((address_space(4)))
+template<typename T> PT_DEV const PT_CONST_AS T *asConst(const T *p) { return (const PT_CONST_AS T *)p; }
 PT_DEV f3 xyz(float4 v) { return mk3(v.x, v.y, v.z); }
 PT_DEV float4 mk4(f3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 PT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -47,11 +52,11 @@ PT_DEV float sqr(float x) { return x*x; }
 PT_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 /* row-major 3x3 times vector and transpose times vector */
-PT_DEV f3 mat3Mul(const float *m, f3 p)
+template<typename P> PT_DEV f3 mat3Mul(P m, f3 p)
 {
     return mk3(m[0]*p.x + m[1]*p.y + m[2]*p.z, m[3]*p.x + m[4]*p.y + m[5]*p.z, m[6]*p.x + m[7]*p.y + m[8]*p.z);
 }
-PT_DEV f3 mat3TMul(const float *m, f3 p)
+template<typename P> PT_DEV f3 mat3TMul(P m, f3 p)
 {
     return mk3(m[0]*p.x + m[3]*p.y + m[6]*p.z, m[1]*p.x + m[4]*p.y + m[7]*p.z, m[2]*p.x + m[5]*p.y + m[8]*p.z);
 }

@@ -11,17 +11,17 @@
 #include "../../../include/tungsten_hip.h"
 
 struct DeviceScene {
-    const float4       *nodes;        // 4 x float4 per TgHipBvhNode
-    const float4       *recs;         // 3 x float4 per TgHipPrimRec
-    const float4       *tri_attrs;    // 4 x float4 per TgHipTriAttr
-    const TgHipObject  *objects;
-    const int32_t      *lights;
-    const int32_t      *infinite_lights;
-    const TgHipBsdf    *bsdfs;
-    const TgHipTexture *textures;
-    const float        *texels;
-    const float        *dist;
-    const uint8_t      *rec_class;    // shading class of each primitive record's bsdf (built at upload, DESIGN.md "Kernels")
+    const float4 * __restrict__ nodes;        // 4 x float4 per TgHipBvhNode
+    const float4 * __restrict__ recs;         // 3 x float4 per TgHipPrimRec
+    const float4 * __restrict__ tri_attrs;    // 4 x float4 per TgHipTriAttr
+    const TgHipObject * __restrict__ objects;
+    const int32_t * __restrict__ lights;
+    const int32_t * __restrict__ infinite_lights;
+    const TgHipBsdf * __restrict__ bsdfs;
+    const TgHipTexture * __restrict__ textures;
+    const float * __restrict__ texels;
+    const float * __restrict__ dist;
+    const uint8_t * __restrict__ rec_class;    // shading class of each primitive record's bsdf (built at upload, DESIGN.md "Kernels")
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
     TgHipCamera   camera;
     TgHipSettings settings;
@@ -909,8 +909,10 @@ PT_DEV bool quadTest(f3 base, f3 edge0, f3 edge1, float invUvSq0, float invUvSq1
 }
 
 /* Cube::intersect (Cube.cpp:94-125) */
-PT_DEV bool cubeTest(const TgHipObject &o, const RayD &ray, float tmax, float &t, bool &backSide)
+template<typename OP>   // OP: pointer to TgHipObject (generic or constant address space)
+PT_DEV bool cubeTest(OP op, const RayD &ray, float tmax, float &t, bool &backSide)
 {
+    const auto &o = *op;
     f3 p = mat3TMul(o.rot, ray.o - ld3(o.pos));
     f3 d = mat3TMul(o.rot, ray.d);
     float pa[3] = {p.x, p.y, p.z}, da[3] = {d.x, d.y, d.z};
@@ -935,10 +937,21 @@ PT_DEV bool cubeTest(const TgHipObject &o, const RayD &ray, float tmax, float &t
     return false;
 }
 
-/* Tests record `ri` against the ray; on a hit updates (tmax, hit) -- the leaf body of both traversal kernels */
-PT_DEV void testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit)
+/* Tests record `ri` against the ray; on a hit updates (tmax, hit) -- the leaf body of both traversal kernels.
+ * UNIFORM: `ri` is the same for every lane (flat-list traversal), so the record and its object are fetched
+ * through the constant address space, i.e. with scalar loads. */
+template<bool UNIFORM>
+PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit, uint32_t &hitMeta)
 {
-    float4 r0 = s.recs[ri*3 + 0], r1 = s.recs[ri*3 + 1], r2 = s.recs[ri*3 + 2];
+    float4 r0, r1, r2;
+    if (UNIFORM) {
+        const PT_CONST_AS float *rp = asConst(reinterpret_cast<const float *>(s.recs)) + ri*12;
+        r0 = make_float4(rp[0], rp[1], rp[2], rp[3]);
+        r1 = make_float4(rp[4], rp[5], rp[6], rp[7]);
+        r2 = make_float4(rp[8], rp[9], rp[10], rp[11]);
+    } else {
+        r0 = s.recs[ri*3 + 0]; r1 = s.recs[ri*3 + 1]; r2 = s.recs[ri*3 + 2];
+    }
     uint32_t meta = __float_as_uint(r0.w);
     uint32_t kind = TGHIP_REC_KIND(meta);
     float t, u = 0.0f, v = 0.0f;
@@ -946,11 +959,12 @@ PT_DEV void testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
     if (kind == TGHIP_REC_TRIANGLE) {
         ok = triTest(xyz(r0), xyz(r1), xyz(r2), ray, tmax, t, u, v);
     } else if (kind == TGHIP_REC_QUAD) {
-        const TgHipObject &o = s.objects[TGHIP_REC_OBJECT(meta)];
-        ok = quadTest(xyz(r0), xyz(r1), xyz(r2), r1.w, r2.w, ld3(o.normal), ray, tmax, t, u, v);
+        f3 n = UNIFORM ? ld3(asConst(s.objects)[TGHIP_REC_OBJECT(meta)].normal) : ld3(s.objects[TGHIP_REC_OBJECT(meta)].normal);
+        ok = quadTest(xyz(r0), xyz(r1), xyz(r2), r1.w, r2.w, n, ray, tmax, t, u, v);
     } else if (kind == TGHIP_REC_CUBE) {
         bool back;
-        ok = cubeTest(s.objects[TGHIP_REC_OBJECT(meta)], ray, tmax, t, back);
+        if (UNIFORM) ok = cubeTest(asConst(s.objects) + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
+        else         ok = cubeTest(s.objects + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
         u = back ? 1.0f : 0.0f;
     } else {
         ok = false;
@@ -958,7 +972,15 @@ PT_DEV void testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
     if (ok) {
         tmax = t;
         hit = make_float4(t, u, v, __int_as_float((int)ri));
+        hitMeta = meta;
     }
+    return ok;
+}
+template<bool UNIFORM>
+PT_DEV void testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit)
+{
+    uint32_t meta;
+    (void)testRecord<UNIFORM>(s, ri, ray, tmax, hit, meta);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -8,11 +8,24 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 // =============================================================================================
 // Kernels
 // =============================================================================================
+
+// Section timers of the shading kernel (development aid; compiled in only with -DPT_PROFILE): s_memtime per
+// wave at section boundaries, summed per workgroup into BlockStats::prof and printed by tghip_destroy.
+#ifdef PT_PROFILE
+#define PROF_DECL unsigned long long profT = clock64(), profAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(n) do { unsigned long long t_ = clock64(); profAcc[n] += t_ - profT; profT = t_; } while (0)
+#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&(stats).prof[k_], profAcc[k_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(n)
+#define PROF_FLUSH(stats)
+#endif
 
 // BSDF type sets of the shading-kernel variants (pt_scene.h BsdfOps<D, M>)
 #define MASK_SIMPLE  (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_NULL) | BSDF_BIT(TGHIP_BSDF_ERROR))
@@ -108,93 +121,73 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
     return push;
 }
 
-// Workgroup-local counters staged in LDS for the duration of one kernel (loaded from / stored to BlockCtl).
-struct BlockLds {
-    uint32_t n_ext, n_shade[PT_NUM_CLASSES], n_shadow, cursor;
-    uint32_t samples, closest_rays, shadow_rays, shadow_slots;
-    uint32_t nodes, prims;
-};
-
-PT_DEV void blockBegin(BlockLds &L, const BlockCtl &c)
-{
-    if (threadIdx.x == 0) {
-        L.n_ext = c.n_ext; L.n_shade[0] = c.n_shade[0]; L.n_shade[1] = c.n_shade[1]; L.n_shadow = c.n_shadow;
-        L.cursor = c.item_cursor;
-        L.samples = L.closest_rays = L.shadow_rays = L.shadow_slots = L.nodes = L.prims = 0;
-    }
-    __syncthreads();
-}
-
 // Pass start: every slot takes its first work item.
 __global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, PassParams pp)
 {
     __shared__ BlockLds L;
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    if (threadIdx.x == 0) {
-        L.n_ext = 0; L.cursor = 0; L.samples = 0;
-    }
+    if (threadIdx.x == 0) ctl.item_cursor = 0;
     __syncthreads();
+    queuesBegin(L, st, ctl, -1, 0u, nullptr);
     const uint32_t first = blockIdx.x*st.slots_per_block;
-    uint32_t *seg = st.q_ext + first;
     uint32_t finishedCount = 0;
     for (uint32_t base = 0; base < st.slots_per_block; base += blockDim.x) {
         uint32_t local = base + threadIdx.x;
         uint32_t slot = first + local;
         bool fresh = local < st.slots_per_block && slot < st.num_slots;
         bool push = nextPath(s, st, pp, false, fresh, slot, splat3(0.0f), false, &L.cursor, false, finishedCount);
-        queuePush(push, slot, seg, &L.n_ext);
+        queuePush(push, local, L, Q_EXT);
     }
-    __syncthreads();
+    bool any = queuesEnd(L, st, -1, 0xFu);       // every bitmap is (re)initialised here
     if (threadIdx.x == 0) {
-        ctl.n_ext = L.n_ext; ctl.n_shade[0] = 0; ctl.n_shade[1] = 0; ctl.n_shadow = 0;
         ctl.item_cursor = L.cursor;
-        if (L.n_ext > 0) st.live[0] = 1u;
+        if (any) st.live[0] = 1u;
     }
 }
 
-template<bool COUNT>
+template<bool COUNT, bool FLAT>
 __global__ __launch_bounds__(256) void k_trace_closest(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsStack[];
     __shared__ BlockLds L;
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    blockBegin(L, ctl);
-    const uint32_t n = ctl.n_ext;
+    // the dynamic LDS region first holds the expanded queue, then (after orderPreload's barrier) the node stacks
+    queuesBegin(L, st, ctl, Q_EXT, 0u, reinterpret_cast<unsigned short *>(ldsStack));   // the shading queues are empty here
+    const uint32_t n = L.n;
+    const OrderRegs ord = orderPreload(reinterpret_cast<unsigned short *>(ldsStack), n);
     const uint32_t first = blockIdx.x*st.slots_per_block;
-    const uint32_t *seg = st.q_ext + first;
     uint32_t nodes = 0, prims = 0, rays = 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x) {
+    for (uint32_t base = 0, k = 0; base < n; base += blockDim.x, ++k) {
         uint32_t i = base + threadIdx.x;
-        uint32_t slot = 0;
+        uint32_t slot = 0, local = 0;
         int cls = -1;
         if (i < n) {
-            slot = seg[i];
+            local = orderGet(ord, k);
+            slot = first + local;
             float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
             RayD ray;
             ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-            float4 hit = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+            float4 hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
             st.hit[slot] = hit;
             int ri = __float_as_int(hit.w);
             cls = ri < 0 ? 0 : (int)s.rec_class[ri];
             rays++;
         }
-        // sort by material: one shading queue per class (wave ballot + prefix popcount, one LDS atomic per wave)
-        queuePush(cls == 0, slot, st.q_shade[0] + first, &L.n_shade[0]);
-        queuePush(cls == 1, slot, st.q_shade[1] + first, &L.n_shade[1]);
+        // sort by material: one shading queue per class
+        queuePush(cls == 0, local, L, Q_SHADE0);
+        queuePush(cls == 1, local, L, Q_SHADE1);
     }
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    __syncthreads();
+    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1));
     if (threadIdx.x == 0) {
-        ctl.n_ext = 0;                           // consumed; refilled by k_shade / k_trace_shadow
-        ctl.n_shade[0] = L.n_shade[0]; ctl.n_shade[1] = L.n_shade[1];
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
     }
 }
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
-template<bool COUNT>
+template<bool COUNT, bool FLAT>
 __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 *rays, float4 *hits, uint32_t n, BlockStats *stats)
 {
     extern __shared__ int ldsStack[];
@@ -207,7 +200,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
         float4 ro = rays[i*2 + 0], rd = rays[i*2 + 1];
         RayD ray;
         ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-        hits[i] = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+        hits[i] = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
     }
     if (COUNT) {
         waveAddStat(&ldsNodes, nodes);
@@ -220,28 +213,36 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
 // PathTracer::traceSample's loop body for one vertex: TraceBase::handleSurface (TraceBase.cpp:516-568)
 // with estimateDirect split into "compute the unoccluded contribution here, test visibility in
 // k_trace_shadow", plus the loop epilogue (PathTracer.cpp:108-129).  M = BSDF types this variant handles.
-template<uint32_t M>
-__global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, PassParams pp, int cls)
+// W = waves per SIMD the register allocator must leave room for (occupancy vs spilling: 3 costs the
+// Lambert-only variant 12 B of scratch, the others stay at 2)
+template<uint32_t M, int W>
+__global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, PassParams pp, int cls)
 {
     __shared__ BlockLds L;
+    __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
+    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    blockBegin(L, ctl);
-    const uint32_t n = ctl.n_shade[cls];
+    const int qIn = cls == 0 ? Q_SHADE0 : Q_SHADE1;
+    queuesBegin(L, st, ctl, qIn, (1u << Q_EXT) | (1u << Q_SHADOW), order);
+    const DeviceScene s = stageSceneTables(sg, ldsTables);
+    const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
-    const uint32_t *seg = st.q_shade[cls] + first;
     const bool aborted = st.live[1] != 0;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
     const bool nee = s.settings.enable_light_sampling != 0;
     uint32_t finishedCount = 0;
+    PROF_DECL;
 
     for (uint32_t base = 0; base < n; base += blockDim.x) {
         uint32_t i = base + threadIdx.x;
+        PROF(0);
         bool hasShadow = false, finished = false, survives = false, black = false;
-        uint32_t slot = 0;
+        uint32_t slot = 0, local = 0;
         f3 em = splat3(0.0f);
         if (i < n) {
             f3 pendingOut = splat3(0.0f);
-            slot = seg[i];
+            local = order[i];
+            slot = first + local;
             float4 ro = st.ray_o[slot], rd = st.ray_d[slot], hit = st.hit[slot], thr4 = st.thr[slot];
             em = xyz(st.emi[slot]);
             uint2 rs = st.rng[slot];
@@ -270,9 +271,11 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, Pass
                 }
                 state = isnan(sum3(throughput) + sum3(em)) ? ST_TERMINATED_BLACK : ST_TERMINATED;
             } else {
+                PROF(1);
                 Info info;
                 intersectionInfo(s, ray, hit, info);
                 const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
+                PROF(2);
 
                 // TraceBase::makeLocalScatterEvent (TraceBase.cpp:24-51)
                 Frame frame = frameFromNormal(info.Ns);
@@ -371,6 +374,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, Pass
                             }
                         }
                     }
+                    PROF(3);
                     // emission of the surface itself (TraceBase.cpp:540-543)
                     {
                         const TgHipObject &o = s.objects[info.object];
@@ -399,6 +403,7 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, Pass
                     }
                 }
 
+                PROF(4);
                 if (!alive) {
                     state = ST_TERMINATED;
                 } else {
@@ -447,15 +452,18 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, Pass
             if (survives)
                 st.thr[slot] = mk4(throughput, __uint_as_float(newFlags));
         }
-        queuePush(hasShadow, slot, st.q_shadow + first, &L.n_shadow);
+        PROF(5);
+        queuePush(hasShadow, local, L, Q_SHADOW);
+        PROF(6);
         bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
-        queuePush(survives || regenerated, slot, st.q_ext + first, &L.n_ext);
+        PROF(7);
+        queuePush(survives || regenerated, local, L, Q_EXT);
+        PROF(8);
     }
+    PROF_FLUSH(st.stats[blockIdx.x]);
     waveAddStat(&L.samples, finishedCount);
-    __syncthreads();
+    queuesEnd(L, st, qIn, (1u << Q_EXT) | (1u << Q_SHADOW));
     if (threadIdx.x == 0) {
-        ctl.n_shade[cls] = 0;                    // consumed
-        ctl.n_ext = L.n_ext; ctl.n_shadow = L.n_shadow;
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples;
     }
@@ -465,25 +473,26 @@ __global__ __launch_bounds__(256) void k_shade(DeviceScene s, PathState st, Pass
 // a closest-hit query up to the light; unoccluded iff nothing is hit or the closest hit is the
 // light itself (endCap); surfaces with a forward lobe attenuate and the ray continues (FORWARD variant only:
 // scenes without a forward-lobe BSDF run the lean variant).
-template<bool COUNT, bool FORWARD>
+template<bool COUNT, bool FORWARD, bool FLAT>
 __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsStack[];
     __shared__ BlockLds L;
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    blockBegin(L, ctl);
-    const uint32_t n = ctl.n_shadow;
+    queuesBegin(L, st, ctl, Q_SHADOW, 1u << Q_EXT, reinterpret_cast<unsigned short *>(ldsStack));
+    const uint32_t n = L.n;
+    const OrderRegs ord = orderPreload(reinterpret_cast<unsigned short *>(ldsStack), n);
     const uint32_t first = blockIdx.x*st.slots_per_block;
-    const uint32_t *seg = st.q_shadow + first;
     const bool aborted = st.live[1] != 0;
     uint32_t nodes = 0, prims = 0, rays = 0, slots = 0, finishedCount = 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x) {
+    for (uint32_t base = 0, k = 0; base < n; base += blockDim.x, ++k) {
         uint32_t i = base + threadIdx.x;
-        uint32_t slot = 0;
+        uint32_t slot = 0, local = 0;
         bool finished = false, black = false;
         f3 em = splat3(0.0f);
         if (i < n) {
-            slot = seg[i];
+            local = orderGet(ord, k);
+            slot = first + local;
             slots++;
             float4 so = st.sh_o[slot];
             f3 result = splat3(0.0f);
@@ -500,8 +509,15 @@ __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState s
                 ray.o = xyz(so); ray.d = xyz(sd); ray.tmin = so.w; ray.tmax = sd.w;
                 float remaining = ray.tmax;
                 f3 transmittance = splat3(1.0f);
+                if (!FORWARD) {
+                    // no surface of this scene lets light through: any occluder ends the query
+                    rays++;
+                    if (traverseOccluded<COUNT, FLAT>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims)
+                        || bounce < s.settings.min_bounces)
+                        transmittance = splat3(0.0f);
+                } else
                 for (;;) {
-                    float4 hit = traverseClosest<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+                    float4 hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
                     rays++;
                     int ri = __float_as_int(hit.w);
                     int hitObject = -1;
@@ -511,7 +527,6 @@ __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState s
                         if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
                         break;
                     }
-                    if (!FORWARD) { transmittance = splat3(0.0f); break; }
                     Info info;
                     intersectionInfo(s, ray, hit, info);
                     const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
@@ -552,16 +567,14 @@ __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState s
             }
         }
         bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
-        queuePush(regenerated, slot, st.q_ext + first, &L.n_ext);
+        queuePush(regenerated, local, L, Q_EXT);
     }
     waveAddStat(&L.samples, finishedCount);
     waveAddStat(&L.shadow_rays, rays);
     waveAddStat(&L.shadow_slots, slots);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    __syncthreads();
+    const bool anyExt = queuesEnd(L, st, Q_SHADOW, 1u << Q_EXT);
     if (threadIdx.x == 0) {
-        ctl.n_shadow = 0;                        // consumed
-        ctl.n_ext = L.n_ext;
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples; ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
         if (COUNT) {
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState s
             bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
         }
         // last kernel of the iteration: tell the host whether any extension queue still holds work
-        if (L.n_ext > 0) st.live[0] = iterTag;
+        if (anyExt) st.live[0] = iterTag;
     }
 }
 
@@ -643,7 +656,7 @@ struct tghip_ctx {
     std::vector<BlockStats> hostStats;
 
     // options
-    long long maxSlots = 1ll << 20;       // path pool size
+    long long maxSlots = 1ll << 21;       // path pool size
     long long maxItems = 1ll << 26;       // work items per batch (partial-sum buffer = 16 B each)
     int chunkSamples = 4;                 // samples per work item
     size_t partialCap = 0;
@@ -678,8 +691,8 @@ struct tghip_ctx {
         }                                                                                   \
     } while (0)
 
-template<typename T>
-static int uploadArray(tghip_ctx *ctx, DeviceBuffers &mem, const T *src, size_t count, const T **dst)
+template<typename T, typename P>
+static int uploadArray(tghip_ctx *ctx, DeviceBuffers &mem, const T *src, size_t count, P *dst)   // P = (restrict-qualified) const T *
 {
     size_t bytes = std::max<size_t>(count, 1)*sizeof(T);
     void *p = nullptr;
@@ -749,12 +762,22 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
     return depth;
 }
 
+// Dynamic LDS of the traversal kernels: 256 node stacks of bvhDepth ints (a root-to-leaf walk pushes at most one
+// far child per internal level), aliased with the expanded queue (2 B per slot) that is consumed before traversal
+// starts.  Flat-list scenes need no stack.
+static size_t traceLdsBytes(const tghip_ctx *ctx)
+{
+    const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
+    size_t stack = flat ? 0 : size_t(std::max(ctx->bvhDepth, 1))*256*sizeof(int);
+    return std::max<size_t>(stack, size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short));
+}
+
 static int launchGrid(const tghip_ctx *ctx)
 {
     int perCu = ctx->blocksPerCu;
     if (perCu <= 0) {
         // 160 KB of LDS per CU (MI355X_MICROARCH.md); every traversal workgroup holds 256 node stacks of bvhDepth+1 ints
-        size_t lds = size_t(ctx->bvhDepth + 1)*256*sizeof(int) + 256;
+        size_t lds = traceLdsBytes(ctx) + sizeof(BlockLds) + 256;
         perCu = int(std::min<size_t>(8, std::max<size_t>(1, (160u*1024u)/lds)));
     }
     return ctx->prop.multiProcessorCount*perCu;
@@ -780,6 +803,14 @@ static int foldCounters(tghip_ctx *ctx)
         ctx->counters.nodes_visited += t.nodes_visited; ctx->counters.prims_tested += t.prims_tested;
         ctx->counters.nodes_visited_shadow += t.nodes_visited_shadow; ctx->counters.prims_tested_shadow += t.prims_tested_shadow;
     }
+#ifdef PT_PROFILE
+    {
+        unsigned long long tot[12] = {0};
+        for (size_t b = 0; b < g; ++b) for (int k = 0; k < 12; ++k) tot[k] += ctx->hostStats[b].prof[k];
+        unsigned long long sum = 0; for (int k = 0; k < 12; ++k) sum += tot[k];
+        if (sum) { std::fprintf(stderr, "[PT_PROFILE] k_shade wave-cycles by section:"); for (int k = 0; k < 9; ++k) std::fprintf(stderr, " s%d=%.1f%%", k, 100.0*double(tot[k])/double(sum)); std::fprintf(stderr, " total=%llu\n", sum); }
+    }
+#endif
     // no pass is running here (calls on one handle are serialised), so the records can be written back whole
     HIP_TRY(ctx, hipMemcpy(ctx->pool.ctl, ctx->hostCtl.data(), g*sizeof(BlockCtl), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemset(ctx->pool.stats, 0, g*sizeof(BlockStats)));
@@ -792,7 +823,7 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
 {
     const uint32_t grid = uint32_t(launchGrid(ctx));
     uint32_t perBlock = (wantSlots + grid - 1)/grid;
-    perBlock = std::max<uint32_t>(64u, (perBlock + 63u)/64u*64u);
+    perBlock = std::min<uint32_t>(PT_MAX_SLOTS_PER_BLOCK, std::max<uint32_t>(64u, (perBlock + 63u)/64u*64u));
     const uint32_t slots = perBlock*grid;
     PathState &p = ctx->pool;
     if (ctx->poolSlots >= slots && ctx->poolGrid == grid) {
@@ -804,14 +835,14 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     if (rc != TGHIP_OK) return rc;
     ctx->poolMem.release();
     ctx->poolSlots = 0;
-#define POOL_ALLOC(field, n) if ((rc = allocArray(ctx, ctx->poolMem, (n), &p.field)) != TGHIP_OK) return rc
+#define POOL_ALLOC(field, n) do { std::remove_reference<decltype(*p.field)>::type *tmp_ = nullptr; \
+        if ((rc = allocArray(ctx, ctx->poolMem, (n), &tmp_)) != TGHIP_OK) return rc; p.field = tmp_; } while (0)
     POOL_ALLOC(ray_o, slots); POOL_ALLOC(ray_d, slots); POOL_ALLOC(hit, slots); POOL_ALLOC(thr, slots);
     POOL_ALLOC(emi, slots); POOL_ALLOC(acc, slots); POOL_ALLOC(rng, slots); POOL_ALLOC(samp, slots);
     POOL_ALLOC(pixel, slots); POOL_ALLOC(item, slots);
     POOL_ALLOC(sh_o, slots); POOL_ALLOC(sh_d0, slots); POOL_ALLOC(sh_c0, slots); POOL_ALLOC(sh_d1, slots);
     POOL_ALLOC(sh_c1, slots); POOL_ALLOC(sh_w, slots); POOL_ALLOC(sh_p, slots);
-    POOL_ALLOC(q_ext, slots); POOL_ALLOC(q_shadow, slots);
-    for (int c = 0; c < PT_NUM_CLASSES; ++c) POOL_ALLOC(q_shade[c], slots);
+    for (int q = 0; q < Q_COUNT; ++q) POOL_ALLOC(bm[q], slots/32);
     POOL_ALLOC(ctl, grid); POOL_ALLOC(stats, grid); POOL_ALLOC(live, 2);
 #undef POOL_ALLOC
     HIP_TRY(ctx, hipMemsetAsync(p.ctl, 0, sizeof(BlockCtl)*grid, ctx->stream));
@@ -1014,16 +1045,17 @@ extern "C++" {
 template<uint32_t M>
 static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
-    hipLaunchKernelGGL(k_shade<M>, dim3(grid), dim3(256), 0, ctx->stream, ctx->scene, st, pp, cls);
+    hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? 3 : 2)>), dim3(grid), dim3(256), 0, ctx->stream, ctx->scene, st, pp, cls);
 }
 
 template<bool COUNT>
 static void launchShadow(tghip_ctx *ctx, int grid, size_t ldsBytes, const PathState &st, const PassParams &pp, uint32_t iterTag)
 {
-    if (ctx->haveForward)
-        hipLaunchKernelGGL((k_trace_shadow<COUNT, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
-    else
-        hipLaunchKernelGGL((k_trace_shadow<COUNT, false>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
+    const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
+#define SHADOW_LAUNCH(FWD, FLAT) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, FLAT>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
+    if (ctx->haveForward) { if (flat) SHADOW_LAUNCH(true, true); else SHADOW_LAUNCH(true, false); }
+    else                  { if (flat) SHADOW_LAUNCH(false, true); else SHADOW_LAUNCH(false, false); }
+#undef SHADOW_LAUNCH
 }
 
 } // extern "C++"
@@ -1035,8 +1067,9 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     st.partial = ctx->partial;
     const DeviceScene &s = ctx->scene;
     const int grid = int(ctx->poolGrid);
-    const size_t ldsBytes = size_t(ctx->bvhDepth + 1)*256*sizeof(int);
     const bool count = ctx->countTraversal;
+    const bool flat = s.num_recs <= TGHIP_FLAT_MAX_RECS;
+    const size_t ldsBytes = traceLdsBytes(ctx);
 
     // optional per-launch timing: one event pair per kernel launch of a check interval, read back at the
     // interval's host sync (events live on ctx->stream, the stream the kernels are launched on)
@@ -1081,8 +1114,13 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
         for (int it = 0; it < ctx->checkInterval; ++it) {
             ++iterTag;
             tic();
-            if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
-            else       hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
+            if (flat) {
+                if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
+                else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
+            } else {
+                if (count) hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
+                else       hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
+            }
             tic(); tic();
             launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
             if (ctx->haveComplex) {
@@ -1233,14 +1271,16 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
     if (rc != TGHIP_OK) { (void)hipFree(dRays); (void)hipFree(dHits); return rc; }
     (void)hipMemcpyAsync(dRays, rays, n*sizeof(TgHipRay), hipMemcpyHostToDevice, ctx->stream);
     const int grid = int(std::min<size_t>(size_t(launchGrid(ctx)), (n + 255)/256));
-    const size_t ldsBytes = size_t(ctx->bvhDepth + 1)*256*sizeof(int);
+    const size_t ldsBytes = traceLdsBytes(ctx);
     repeats = std::max(repeats, 1);
     (void)hipEventRecord(ctx->evA, ctx->stream);
     for (int r = 0; r < repeats; ++r) {
-        if (ctx->countTraversal && r == 0)
-            hipLaunchKernelGGL(k_trace_rays<true>, dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
-        else
-            hipLaunchKernelGGL(k_trace_rays<false>, dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
+        const bool cnt = ctx->countTraversal && r == 0;
+        const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
+#define RAYS_LAUNCH(C, F) hipLaunchKernelGGL((k_trace_rays<C, F>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats)
+        if (cnt) { if (flat) RAYS_LAUNCH(true, true); else RAYS_LAUNCH(true, false); }
+        else     { if (flat) RAYS_LAUNCH(false, true); else RAYS_LAUNCH(false, false); }
+#undef RAYS_LAUNCH
     }
     (void)hipEventRecord(ctx->evB, ctx->stream);
     (void)hipMemcpyAsync(hits, dHits, n*sizeof(TgHipHit), hipMemcpyDeviceToHost, ctx->stream);
