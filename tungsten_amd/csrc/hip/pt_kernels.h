@@ -47,7 +47,9 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 // expands its bitmap into the ascending list of set slots, so every kernel walks its slots in memory order and
 // the 16-byte-per-slot SoA accesses of a wave land in consecutive cache lines.  (Index lists in arrival order
 // made each wave touch ~50 different 64-B lines per access and half of all DRAM writes partial-line.)
-enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_COUNT = 4 };
+// Q_EXT holds bounced (continuation) rays, Q_EXTP freshly generated camera rays: the traversal kernel walks them as
+// two separate runs so that the coherent primaries are not interleaved lane by lane with incoherent bounces.
+enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_COUNT = 5 };
 
 struct BlockCtl {                 // one per persistent workgroup; only that workgroup touches it
     uint32_t item_cursor;         // workgroup-local linear index of the next work item
@@ -154,16 +156,18 @@ PT_DEV void queuePush(bool push, uint32_t localSlot, BlockLds &L, int q)
 }
 
 // Kernel prologue: loads the bitmaps this kernel appends to (bit mask `appendMask` over Q_*), expands the
-// consumed queue `q` (-1 = none) into order[0 .. L.n) (ascending local slot indices; `order` = LDS scratch of
-// slots_per_block entries), and resets the statistics.  All threads must call it.
-PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, int q, uint32_t appendMask, unsigned short *order)
+// consumed queue `q` (-1 = none), followed by the optional second consumed queue `q2`, into order[0 .. L.n)
+// (ascending local slot indices per queue; `order` = LDS scratch of slots_per_block entries), and resets the
+// statistics.  All threads must call it.
+PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, int q, uint32_t appendMask, unsigned short *order,
+                        int q2 = -1)
 {
     const uint32_t W = st.slots_per_block >> 5;
     const uint32_t t = threadIdx.x;
     if (t < W) {
 #pragma unroll
         for (int k = 0; k < Q_COUNT; ++k) {
-            bool load = k == q || ((appendMask >> k) & 1u);
+            bool load = k == q || k == q2 || ((appendMask >> k) & 1u);
             L.bm[k][t] = load ? st.bm[k][blockIdx.x*W + t] : 0u;
         }
     }
@@ -173,41 +177,47 @@ PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, i
         L.n = 0;
     }
     __syncthreads();
-    if (q >= 0) {
+    uint32_t done = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int qq = pass == 0 ? q : q2;
+        if (qq < 0)
+            continue;                            // uniform
         // exclusive prefix of the per-word popcounts (W <= 64: one wave)
         if (t < 64) {
-            uint32_t c = t < W ? (uint32_t)__popc(L.bm[q][t]) : 0u;
+            uint32_t c = t < W ? (uint32_t)__popc(L.bm[qq][t]) : 0u;
             uint32_t inc = c;
             for (int off = 1; off < 64; off <<= 1) {
                 uint32_t v = __shfl_up(inc, off);
                 if ((int)t >= off) inc += v;
             }
             if (t < W) L.prefix[t] = inc - c;
-            if (t == 63) L.n = inc;
+            if (t == 63) L.n = done + inc;
         }
         __syncthreads();
         if (t < W) {
-            uint32_t bits = L.bm[q][t], off = L.prefix[t];
+            uint32_t bits = L.bm[qq][t], off = done + L.prefix[t];
             while (bits) {
                 uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
                 order[off++] = (unsigned short)(t*32u + b);
                 bits &= bits - 1u;
             }
-            L.bm[q][t] = 0u;                     // consumed
+            L.bm[qq][t] = 0u;                    // consumed
         }
         __syncthreads();
+        done = L.n;
     }
 }
 
-// A thread's entries order[k*256 + tid], k < 8, packed two per register, so that the LDS scratch holding `order`
-// can be reused (as the traversal stack) once every thread has fetched its share.
-struct OrderRegs { uint32_t p[4]; };
+// A thread's entries order[k*blockDim + tid], k < 16, packed two per register, so that the LDS scratch holding
+// `order` can be reused (as the traversal stack) once every thread has fetched its share (needs
+// slots_per_block <= 16*blockDim).
+struct OrderRegs { uint32_t p[8]; };
 PT_DEV OrderRegs orderPreload(const unsigned short *order, uint32_t n)
 {
     OrderRegs r;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        uint32_t i0 = (uint32_t)(2*k)*256u + threadIdx.x, i1 = (uint32_t)(2*k + 1)*256u + threadIdx.x;
+    for (int k = 0; k < 8; ++k) {
+        uint32_t i0 = (uint32_t)(2*k)*blockDim.x + threadIdx.x, i1 = (uint32_t)(2*k + 1)*blockDim.x + threadIdx.x;
         uint32_t lo = i0 < n ? order[i0] : 0u, hi = i1 < n ? order[i1] : 0u;
         r.p[k] = lo | (hi << 16);
     }
@@ -216,13 +226,15 @@ PT_DEV OrderRegs orderPreload(const unsigned short *order, uint32_t n)
 }
 PT_DEV uint32_t orderGet(const OrderRegs &r, uint32_t k)   // k is wave-uniform
 {
-    uint32_t w = (k >> 1) == 0 ? r.p[0] : (k >> 1) == 1 ? r.p[1] : (k >> 1) == 2 ? r.p[2] : r.p[3];
+    uint32_t h = k >> 1, w = r.p[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) w = h == (uint32_t)j ? r.p[j] : w;
     return (k & 1u) ? (w >> 16) : (w & 0xFFFFu);
 }
 
 // Kernel epilogue: writes back the consumed (now empty) and appended bitmaps.  Returns (to thread 0..W-1) nothing;
 // `anyExt` tells whether the extension queue holds work.
-PT_DEV bool queuesEnd(BlockLds &L, const PathState &st, int q, uint32_t appendMask)
+PT_DEV bool queuesEnd(BlockLds &L, const PathState &st, int q, uint32_t appendMask, int q2 = -1)
 {
     __syncthreads();
     const uint32_t W = st.slots_per_block >> 5;
@@ -231,9 +243,9 @@ PT_DEV bool queuesEnd(BlockLds &L, const PathState &st, int q, uint32_t appendMa
     if (t < W) {
 #pragma unroll
         for (int k = 0; k < Q_COUNT; ++k)
-            if (k == q || ((appendMask >> k) & 1u))
+            if (k == q || k == q2 || ((appendMask >> k) & 1u))
                 st.bm[k][blockIdx.x*W + t] = L.bm[k][t];
-        ext = L.bm[Q_EXT][t];
+        ext = L.bm[Q_EXT][t] | L.bm[Q_EXTP][t];
     }
     return __syncthreads_or(ext != 0u) != 0;
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -40,6 +41,7 @@
 // exhausted -- flushes the item's sum and takes the workgroup's next item (`cursor` = the workgroup's LDS item
 // cursor), and generates the next camera path in place.  `fresh` lanes own nothing yet (pass start).  Must be
 // called by all lanes of the wave.  Returns true for lanes that now hold a new active path.
+template<bool CONVERGED = true>
 PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams &pp, bool finished, bool fresh,
                      uint32_t slot, f3 em, bool black, uint32_t *cursor, bool aborted, uint32_t &finishedCount)
 {
@@ -67,18 +69,27 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
     }
     bool dead = false;
     for (;;) {
-        unsigned long long mask = __ballot(want);
-        if (mask == 0ull)
-            break;
-        uint32_t lane = laneId();
-        uint32_t base = 0;
-        int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane == leader)
-            base = atomicAdd(cursor, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
+        uint32_t base = 0, rank = 0;
+        if (CONVERGED) {
+            // one LDS atomic per wave
+            unsigned long long mask = __ballot(want);
+            if (mask == 0ull)
+                break;
+            uint32_t lane = laneId();
+            int leader = __ffsll((long long)mask) - 1;
+            if ((int)lane == leader)
+                base = atomicAdd(cursor, (uint32_t)__popcll(mask));
+            base = __shfl(base, leader);
+            rank = __popcll(mask & ((1ull << lane) - 1ull));
+        } else {
+            // called from divergent code (dynamic-fetch traversal): one LDS atomic per lane
+            if (!want)
+                break;
+            base = atomicAdd(cursor, 1u);
+        }
         if (want) {
             // workgroup-local index L -> item: groups of PT_ITEM_GROUP consecutive items are dealt round-robin
-            uint32_t L = base + __popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t L = base + rank;
             uint64_t w64 = ((uint64_t)(L/PT_ITEM_GROUP)*gridDim.x + blockIdx.x)*PT_ITEM_GROUP + (L % PT_ITEM_GROUP);
             if (w64 >= pp.total_items || aborted) {
                 want = false;
@@ -136,9 +147,9 @@ __global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, Pass
         uint32_t slot = first + local;
         bool fresh = local < st.slots_per_block && slot < st.num_slots;
         bool push = nextPath(s, st, pp, false, fresh, slot, splat3(0.0f), false, &L.cursor, false, finishedCount);
-        queuePush(push, local, L, Q_EXT);
+        queuePush(push, local, L, Q_EXTP);
     }
-    bool any = queuesEnd(L, st, -1, 0xFu);       // every bitmap is (re)initialised here
+    bool any = queuesEnd(L, st, -1, (1u << Q_COUNT) - 1u);   // every bitmap is (re)initialised here
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
         if (any) st.live[0] = 1u;
@@ -146,13 +157,13 @@ __global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, Pass
 }
 
 template<bool COUNT, bool FLAT>
-__global__ __launch_bounds__(256) void k_trace_closest(DeviceScene s, PathState st)
+__global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsStack[];
     __shared__ BlockLds L;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     // the dynamic LDS region first holds the expanded queue, then (after orderPreload's barrier) the node stacks
-    queuesBegin(L, st, ctl, Q_EXT, 0u, reinterpret_cast<unsigned short *>(ldsStack));   // the shading queues are empty here
+    queuesBegin(L, st, ctl, Q_EXTP, 0u, reinterpret_cast<unsigned short *>(ldsStack), Q_EXT);   // the shading queues are empty here
     const uint32_t n = L.n;
     const OrderRegs ord = orderPreload(reinterpret_cast<unsigned short *>(ldsStack), n);
     const uint32_t first = blockIdx.x*st.slots_per_block;
@@ -179,7 +190,115 @@ __global__ __launch_bounds__(256) void k_trace_closest(DeviceScene s, PathState 
     }
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1));
+    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1), Q_EXTP);
+    if (threadIdx.x == 0) {
+        ctl.closest_rays += L.closest_rays;
+        if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
+    }
+}
+
+// BVH closest hit with dynamic ray fetch ("persistent threads" inside the workgroup): a lane whose ray has
+// finished does not idle until the slowest lane of its wave is done -- once fewer than 3/4 of the wave's lanes
+// are busy, the idle lanes take the next rays of the workgroup's queue (one wave-aggregated LDS atomic) and join
+// the traversal loop.  One loop iteration advances every busy lane by one BVH node or one leaf.
+// Dynamic LDS: [expanded queue, 2 B per slot][node stacks, bvhDepth ints per thread].
+template<bool COUNT>
+__global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathState st)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
+    int *stack = ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2 + threadIdx.x;
+    const int stride = (int)blockDim.x;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    if (threadIdx.x == 0) fetchNext = 0;
+    queuesBegin(L, st, ctl, Q_EXTP, 0u, order, Q_EXT);
+    const uint32_t n = L.n;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    uint32_t nodes = 0, prims = 0, rays = 0;
+
+    bool busy = false;
+    uint32_t slot = 0, local = 0;
+    RayD ray; ray.o = splat3(0.0f); ray.d = splat3(1.0f); ray.tmin = 0.0f; ray.tmax = 0.0f;
+    f3 invD = splat3(1.0f);
+    float tmax = 0.0f;
+    float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    int cur = 0, sp = 0;
+    bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
+    for (;;) {
+        unsigned long long busyMask = __ballot(busy);
+        if (!exhausted && __popcll(busyMask) <= 48) {
+            // refill the idle lanes
+            unsigned long long want = ~busyMask;
+            uint32_t lane = laneId();
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
+            base = __shfl(base, 0);
+            if (!busy) {
+                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    local = order[i];
+                    slot = first + local;
+                    float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
+                    ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
+                    invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
+                    tmax = ray.tmax;
+                    hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+                    cur = 0; sp = 0;
+                    busy = true;
+                    rays++;
+                }
+            }
+            if (base + (uint32_t)__popcll(want) >= n)
+                exhausted = true;
+            busyMask = __ballot(busy);
+        }
+        if (busyMask == 0ull)
+            break;
+        if (busy) {
+            bool pop = true;
+            if (cur >= 0) {
+                const float4 *nd = s.nodes + (size_t)cur*4;
+                float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                if (COUNT) nodes++;
+                float e0, e1;
+                bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, tmax, e0);
+                bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, tmax, e1);
+                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (h0 && h1) {
+                    if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
+                    else { stack[sp*stride] = c1; cur = c0; }
+                    sp++;
+                    pop = false;
+                } else if (h0) { cur = c0; pop = false; }
+                else if (h1) { cur = c1; pop = false; }
+            } else {
+                uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+                for (uint32_t r = firstRec; r < firstRec + count; ++r) {
+                    if (COUNT) prims++;
+                    testRecord<false>(s, r, ray, tmax, hit);
+                }
+            }
+            if (pop) {
+                if (sp == 0) {
+                    // finished: publish the hit and bin the path by shading class
+                    st.hit[slot] = hit;
+                    int ri = __float_as_int(hit.w);
+                    int cls = ri < 0 ? 0 : (int)s.rec_class[ri];
+                    queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
+                    busy = false;
+                } else {
+                    sp--;
+                    cur = stack[sp*stride];
+                }
+            }
+        }
+    }
+    waveAddStat(&L.closest_rays, rays);
+    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
+    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1), Q_EXTP);
     if (threadIdx.x == 0) {
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
@@ -223,7 +342,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     BlockCtl &ctl = st.ctl[blockIdx.x];
     const int qIn = cls == 0 ? Q_SHADE0 : Q_SHADE1;
-    queuesBegin(L, st, ctl, qIn, (1u << Q_EXT) | (1u << Q_SHADOW), order);
+    queuesBegin(L, st, ctl, qIn, (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW), order);
     const DeviceScene s = stageSceneTables(sg, ldsTables);
     const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
@@ -457,12 +576,13 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
         PROF(6);
         bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
         PROF(7);
-        queuePush(survives || regenerated, local, L, Q_EXT);
+        queuePush(survives, local, L, Q_EXT);
+        queuePush(regenerated, local, L, Q_EXTP);
         PROF(8);
     }
     PROF_FLUSH(st.stats[blockIdx.x]);
     waveAddStat(&L.samples, finishedCount);
-    queuesEnd(L, st, qIn, (1u << Q_EXT) | (1u << Q_SHADOW));
+    queuesEnd(L, st, qIn, (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW));
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples;
@@ -474,12 +594,12 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
 // light itself (endCap); surfaces with a forward lobe attenuate and the ray continues (FORWARD variant only:
 // scenes without a forward-lobe BSDF run the lean variant).
 template<bool COUNT, bool FORWARD, bool FLAT>
-__global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+__global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsStack[];
     __shared__ BlockLds L;
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    queuesBegin(L, st, ctl, Q_SHADOW, 1u << Q_EXT, reinterpret_cast<unsigned short *>(ldsStack));
+    queuesBegin(L, st, ctl, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP), reinterpret_cast<unsigned short *>(ldsStack));
     const uint32_t n = L.n;
     const OrderRegs ord = orderPreload(reinterpret_cast<unsigned short *>(ldsStack), n);
     const uint32_t first = blockIdx.x*st.slots_per_block;
@@ -567,13 +687,13 @@ __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState s
             }
         }
         bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
-        queuePush(regenerated, local, L, Q_EXT);
+        queuePush(regenerated, local, L, Q_EXTP);
     }
     waveAddStat(&L.samples, finishedCount);
     waveAddStat(&L.shadow_rays, rays);
     waveAddStat(&L.shadow_slots, slots);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    const bool anyExt = queuesEnd(L, st, Q_SHADOW, 1u << Q_EXT);
+    const bool anyExt = queuesEnd(L, st, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP));
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples; ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
@@ -583,6 +703,190 @@ __global__ __launch_bounds__(256) void k_trace_shadow(DeviceScene s, PathState s
             bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
         }
         // last kernel of the iteration: tell the host whether any extension queue still holds work
+        if (anyExt) st.live[0] = iterTag;
+    }
+}
+
+// Shadow rays of BVH scenes without forward-lobe BSDFs, with dynamic fetch like k_trace_closest_dyn: the unit of
+// work is a shadow slot (<= 2 any-hit rays, traced one after the other); idle lanes take the workgroup's next slots
+// once fewer than 3/4 of the wave is busy.  A finished slot adds the NEE term to its path's radiance; paths that
+// had ended at that vertex are collected in an LDS list and finalised + regenerated after the traversal loop
+// (keeping nextPath out of the loop holds the loop at 5 waves per SIMD).
+// Dynamic LDS: [expanded queue, 2 B per slot][finished list, 2 B per slot][node stacks, bvhDepth ints per thread].
+template<bool COUNT>
+__global__ __launch_bounds__(512) void k_trace_shadow_dyn(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext, finishedN;
+    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
+    unsigned short *finishedList = order + PT_MAX_SLOTS_PER_BLOCK;
+    int *stack = ldsDyn + PT_MAX_SLOTS_PER_BLOCK + threadIdx.x;
+    const int stride = (int)blockDim.x;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    if (threadIdx.x == 0) { fetchNext = 0; finishedN = 0; }
+    queuesBegin(L, st, ctl, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP), order);
+    const uint32_t n = L.n;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    const int minBounces = s.settings.min_bounces;
+    uint32_t nodes = 0, prims = 0, rays = 0, slots = 0;
+
+    bool busy = false;
+    uint32_t slot = 0, local = 0;
+    int r = 0;                                   // ray of the slot being traced (0: light sample, 1: bsdf sample)
+    f3 so = splat3(0.0f);
+    float eps = 0.0f;
+    f3 result = splat3(0.0f);
+    RayD ray; ray.o = splat3(0.0f); ray.d = splat3(1.0f); ray.tmin = 0.0f; ray.tmax = 0.0f;
+    f3 invD = splat3(1.0f);
+    f3 contrib = splat3(0.0f);
+    int endCap = -1;
+    int cur = 0, sp = 0;
+    bool exhausted = false;
+
+    // sets up ray `r` (or the next valid one) of the current slot; returns false when the slot has no ray left
+    auto setupRay = [&]() -> bool {
+        for (; r < 2; ++r) {
+            float4 c = r == 0 ? st.sh_c0[slot] : st.sh_c1[slot];
+            uint32_t tag = __float_as_uint(c.w);
+            if (tag == 0xFFFFFFFFu)
+                continue;
+            float4 sd = r == 0 ? st.sh_d0[slot] : st.sh_d1[slot];
+            endCap = (int)(tag & 0xFFFFFFu);
+            int bounce = (int)(tag >> 24);
+            rays++;
+            if (bounce < minBounces)
+                continue;                        // contributes nothing (TraceBase.cpp:114-115 with minBounces)
+            contrib = xyz(c);
+            ray.o = so; ray.d = xyz(sd); ray.tmin = eps; ray.tmax = sd.w;
+            invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
+            cur = 0; sp = 0;
+            return true;
+        }
+        return false;
+    };
+    // NEE term -> path radiance; paths that ended at this vertex go on the finished list
+    auto finishSlot = [&]() {
+        float4 w = st.sh_w[slot];
+        float4 p = st.sh_p[slot];
+        f3 em = xyz(st.emi[slot]);
+        em = em + (result*w.w)*xyz(w);           // emission += estimateDirect(...)*throughput
+        em = em + xyz(p);
+        st.emi[slot] = mk4(em, 0.0f);
+        if (FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE)
+            finishedList[atomicAdd(&finishedN, 1u)] = (unsigned short)local;
+        busy = false;
+    };
+
+    for (;;) {
+        unsigned long long busyMask = __ballot(busy);
+        if (!exhausted && __popcll(busyMask) <= 48) {
+            unsigned long long want = ~busyMask;
+            uint32_t lane = laneId();
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
+            base = __shfl(base, 0);
+            if (!busy) {
+                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    local = order[i];
+                    slot = first + local;
+                    slots++;
+                    float4 o4 = st.sh_o[slot];
+                    so = xyz(o4); eps = o4.w;
+                    result = splat3(0.0f);
+                    r = 0;
+                    busy = true;
+                    if (!setupRay())
+                        finishSlot();
+                }
+            }
+            if (base + (uint32_t)__popcll(want) >= n)
+                exhausted = true;
+            busyMask = __ballot(busy);
+        }
+        if (busyMask == 0ull)
+            break;
+        if (busy) {
+            bool pop = true, occluded = false;
+            if (cur >= 0) {
+                const float4 *nd = s.nodes + (size_t)cur*4;
+                float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                if (COUNT) nodes++;
+                float e0, e1;
+                bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, ray.tmax, e0);
+                bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, ray.tmax, e1);
+                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                if (h0 && h1) {
+                    if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
+                    else { stack[sp*stride] = c1; cur = c0; }
+                    sp++;
+                    pop = false;
+                } else if (h0) { cur = c0; pop = false; }
+                else if (h1) { cur = c1; pop = false; }
+            } else {
+                uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+                for (uint32_t q = firstRec; q < firstRec + count && !occluded; ++q) {
+                    if (COUNT) prims++;
+                    float tmax = ray.tmax;
+                    float4 hit;
+                    uint32_t meta;
+                    if (testRecord<false>(s, q, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                        occluded = true;
+                }
+            }
+            bool rayDone = occluded;
+            if (!occluded && pop) {
+                if (sp == 0) {
+                    result = result + contrib;   // nothing in the way: transmittance 1
+                    rayDone = true;
+                } else {
+                    sp--;
+                    cur = stack[sp*stride];
+                }
+            }
+            if (rayDone) {
+                r++;
+                if (!setupRay())
+                    finishSlot();
+            }
+        }
+    }
+    waveAddStat(&L.shadow_rays, rays);
+    waveAddStat(&L.shadow_slots, slots);
+    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
+
+    // finalise + regenerate the paths that were waiting for their last shadow result
+    __syncthreads();
+    const uint32_t nf = finishedN;
+    const bool aborted = st.live[1] != 0;
+    uint32_t finishedCount = 0;
+    for (uint32_t base = 0; base < nf; base += blockDim.x) {
+        uint32_t i = base + threadIdx.x;
+        bool fin = i < nf;
+        uint32_t loc = 0, sl = 0;
+        f3 em = splat3(0.0f);
+        bool black = false;
+        if (fin) {
+            loc = finishedList[i];
+            sl = first + loc;
+            em = xyz(st.emi[sl]);
+            black = FLAG_STATE(__float_as_uint(st.sh_p[sl].w)) == ST_TERMINATED_BLACK;
+        }
+        bool regenerated = nextPath(s, st, pp, fin, false, sl, em, black, &L.cursor, aborted, finishedCount);
+        queuePush(regenerated, loc, L, Q_EXTP);
+    }
+    waveAddStat(&L.samples, finishedCount);
+    const bool anyExt = queuesEnd(L, st, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP));
+    if (threadIdx.x == 0) {
+        ctl.item_cursor = L.cursor;
+        ctl.samples += L.samples; ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
+        if (COUNT) {
+            BlockStats &bs = st.stats[blockIdx.x];
+            bs.nodes_visited += L.nodes; bs.prims_tested += L.prims;
+            bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
+        }
         if (anyExt) st.live[0] = iterTag;
     }
 }
@@ -668,7 +972,13 @@ struct tghip_ctx {
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
     bool countTraversal = false;
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
-    int blocksPerCu = 0;                  // persistent workgroups per CU; 0 = as many as the traversal stacks leave LDS for (<= 8)
+    int blocksPerCuOpt = 0;               // "blocks_per_cu" option; 0 = auto (see chooseThreads)
+    int blocksPerCu = 4;                  // persistent workgroups per CU (the same grid for every kernel of a pass)
+    // threads per workgroup, per kernel: chosen at upload so that `blocksPerCu` workgroups of EVERY kernel are
+    // resident at once (no second scheduling round), i.e. each kernel runs at its own best occupancy on one grid
+    int thrClosest = 256, thrShadow = 256, thrShadeSimple = 192, thrShadeComplex = 128;
+    int thrOverride[4] = {0, 0, 0, 0};
+    bool dynamicFetch = true;             // BVH scenes: closest-hit kernel with dynamic ray fetch (k_trace_closest_dyn)
     bool timeKernels = false;             // HIP events around every launch of the wavefront loop (bench.py roofline)
     std::vector<hipEvent_t> evPool;
 
@@ -762,25 +1072,35 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
     return depth;
 }
 
-// Dynamic LDS of the traversal kernels: 256 node stacks of bvhDepth ints (a root-to-leaf walk pushes at most one
-// far child per internal level), aliased with the expanded queue (2 B per slot) that is consumed before traversal
-// starts.  Flat-list scenes need no stack.
-static size_t traceLdsBytes(const tghip_ctx *ctx)
+// Dynamic LDS of the traversal kernels: one node stack of bvhDepth ints per thread (a root-to-leaf walk pushes at
+// most one far child per internal level), aliased with the expanded queue (2 B per slot) that is consumed before
+// traversal starts.  Flat-list scenes need no stack.
+static size_t traceLdsBytes(const tghip_ctx *ctx, int threads)
 {
     const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
-    size_t stack = flat ? 0 : size_t(std::max(ctx->bvhDepth, 1))*256*sizeof(int);
+    size_t stack = flat ? 0 : size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
     return std::max<size_t>(stack, size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short));
 }
 
-static int launchGrid(const tghip_ctx *ctx)
+// dynamic-fetch traversal kernels keep the expanded queue next to the stacks
+static size_t dynLdsBytes(const tghip_ctx *ctx, int threads, bool finishedList = false)
 {
-    int perCu = ctx->blocksPerCu;
-    if (perCu <= 0) {
-        // 160 KB of LDS per CU (MI355X_MICROARCH.md); every traversal workgroup holds 256 node stacks of bvhDepth+1 ints
-        size_t lds = traceLdsBytes(ctx) + sizeof(BlockLds) + 256;
-        perCu = int(std::min<size_t>(8, std::max<size_t>(1, (160u*1024u)/lds)));
+    return size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short)*(finishedList ? 2 : 1) + size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
+}
+
+static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*std::max(ctx->blocksPerCu, 1); }
+
+// Largest workgroup size (multiple of 64, <= maxThreads) at which `blocksPerCu` workgroups of `kernel` fit on a CU.
+template<typename K>
+static int pickThreads(const tghip_ctx *ctx, K kernel, int maxThreads, int ldsMode)   // 0: no dynamic LDS, 1: traceLdsBytes, 2/3: dynLdsBytes without/with finished list
+{
+    for (int t = maxThreads; t >= 128; t -= 64) {
+        int nb = 0;
+        size_t lds = ldsMode == 1 ? traceLdsBytes(ctx, t) : ldsMode == 2 ? dynLdsBytes(ctx, t) : ldsMode == 3 ? dynLdsBytes(ctx, t, true) : 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), t, lds) == hipSuccess && nb >= ctx->blocksPerCu)
+            return t;
     }
-    return ctx->prop.multiProcessorCount*perCu;
+    return 128;
 }
 
 // Adds the per-workgroup statistics on the device to ctx->counters and zeroes them there.
@@ -853,6 +1173,39 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     ctx->poolSlots = slots;
     ctx->poolGrid = grid;
     return TGHIP_OK;
+}
+
+// Picks the workgroup size of each kernel of the wavefront loop for the uploaded scene (see tghip_ctx::thr*).
+static void chooseThreads(tghip_ctx *ctx)
+{
+    const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
+    // Measured (profiles/README.md): BVH scenes are latency-bound and run best with every workgroup of every
+    // kernel resident at once (4 per CU, workgroup size per kernel = that kernel's occupancy limit / 4); flat-list
+    // scenes are streaming-bound and prefer 8 small workgroups per CU that the dispatcher load-balances.
+    ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : (flat ? 8 : 4);
+    if (flat && ctx->blocksPerCuOpt == 0) {
+        ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
+    } else {
+    ctx->thrClosest = flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
+                    : ctx->dynamicFetch ? pickThreads(ctx, k_trace_closest_dyn<false>, 320, 2)   // 20 waves/CU measured best (profiles/README.md)
+                                        : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
+    if (!flat && !ctx->haveForward && ctx->dynamicFetch)
+        ctx->thrShadow = pickThreads(ctx, k_trace_shadow_dyn<false>, 512, 3);
+    else if (ctx->haveForward)
+        ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, true, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, true, false>, 512, 1);
+    else
+        ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, false, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, false, false>, 512, 1);
+    ctx->thrShadeSimple = pickThreads(ctx, k_shade<MASK_SIMPLE, 3>, 256, 0);
+    if ((ctx->complexMask & ~MASK_COAT) == 0)       ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2>, 256, 0);
+    else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2>, 256, 0);
+    else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2>, 256, 0);
+    }
+    int *dst[4] = {&ctx->thrClosest, &ctx->thrShadow, &ctx->thrShadeSimple, &ctx->thrShadeComplex};
+    for (int i = 0; i < 4; ++i)
+        if (ctx->thrOverride[i] >= 64) *dst[i] = std::min(ctx->thrOverride[i]/64*64, i < 2 ? 512 : 256);
+    if (std::getenv("TGHIP_VERBOSE"))
+        std::fprintf(stderr, "[tghip] grid %d x threads closest %d shadow %d shade %d/%d (flat %d, forward %d, complex mask 0x%x)\n",
+                     launchGrid(ctx), ctx->thrClosest, ctx->thrShadow, ctx->thrShadeSimple, ctx->thrShadeComplex, int(flat), int(ctx->haveForward), ctx->complexMask);
 }
 
 extern "C" {
@@ -932,7 +1285,12 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
-    else if (k == "blocks_per_cu") ctx->blocksPerCu = int(std::min<long long>(std::max<long long>(value, 0), 8));
+    else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "dynamic_fetch") { ctx->dynamicFetch = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "threads_closest") { ctx->thrOverride[0] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "threads_shadow") { ctx->thrOverride[1] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "threads_shade_simple") { ctx->thrOverride[2] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "threads_shade_complex") { ctx->thrOverride[3] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
     else { ctx->error = "unknown option '" + k + "'"; return TGHIP_E_INVALID; }
     return TGHIP_OK;
 }
@@ -1016,6 +1374,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->haveScene = true;
+    chooseThreads(ctx);
     return tghip_clear_framebuffer(ctx);
 }
 
@@ -1045,14 +1404,21 @@ extern "C++" {
 template<uint32_t M>
 static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
-    hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? 3 : 2)>), dim3(grid), dim3(256), 0, ctx->stream, ctx->scene, st, pp, cls);
+    hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? 3 : 2)>), dim3(grid), dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0,
+                       ctx->stream, ctx->scene, st, pp, cls);
 }
 
 template<bool COUNT>
-static void launchShadow(tghip_ctx *ctx, int grid, size_t ldsBytes, const PathState &st, const PassParams &pp, uint32_t iterTag)
+static void launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, uint32_t iterTag)
 {
+    const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrShadow);
     const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
-#define SHADOW_LAUNCH(FWD, FLAT) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, FLAT>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
+    if (!flat && !ctx->haveForward && ctx->dynamicFetch) {
+        hipLaunchKernelGGL(k_trace_shadow_dyn<COUNT>, dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow, true), ctx->stream,
+                           ctx->scene, st, pp, iterTag);
+        return;
+    }
+#define SHADOW_LAUNCH(FWD, FLAT) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, FLAT>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
     if (ctx->haveForward) { if (flat) SHADOW_LAUNCH(true, true); else SHADOW_LAUNCH(true, false); }
     else                  { if (flat) SHADOW_LAUNCH(false, true); else SHADOW_LAUNCH(false, false); }
 #undef SHADOW_LAUNCH
@@ -1069,7 +1435,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = s.num_recs <= TGHIP_FLAT_MAX_RECS;
-    const size_t ldsBytes = traceLdsBytes(ctx);
+    const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
     // optional per-launch timing: one event pair per kernel launch of a check interval, read back at the
     // interval's host sync (events live on ctx->stream, the stream the kernels are launched on)
@@ -1115,11 +1481,17 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             ++iterTag;
             tic();
             if (flat) {
-                if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
-                else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
+                if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
+                else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
             } else {
-                if (count) hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
-                else       hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid), dim3(256), ldsBytes, ctx->stream, s, st);
+                if (ctx->dynamicFetch) {
+                    const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
+                    if (count) hipLaunchKernelGGL(k_trace_closest_dyn<true>, dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->stream, s, st);
+                    else       hipLaunchKernelGGL(k_trace_closest_dyn<false>, dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->stream, s, st);
+                } else {
+                    if (count) hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
+                    else       hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
+                }
             }
             tic(); tic();
             launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
@@ -1129,8 +1501,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 else                                            launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 1);
             }
             tic(); tic();
-            if (count) launchShadow<true>(ctx, grid, ldsBytes, st, pp, iterTag);
-            else       launchShadow<false>(ctx, grid, ldsBytes, st, pp, iterTag);
+            if (count) launchShadow<true>(ctx, grid, st, pp, iterTag);
+            else       launchShadow<false>(ctx, grid, st, pp, iterTag);
             tic();
             ctx->counters.iterations++;
         }
@@ -1271,7 +1643,7 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
     if (rc != TGHIP_OK) { (void)hipFree(dRays); (void)hipFree(dHits); return rc; }
     (void)hipMemcpyAsync(dRays, rays, n*sizeof(TgHipRay), hipMemcpyHostToDevice, ctx->stream);
     const int grid = int(std::min<size_t>(size_t(launchGrid(ctx)), (n + 255)/256));
-    const size_t ldsBytes = traceLdsBytes(ctx);
+    const size_t ldsBytes = traceLdsBytes(ctx, 256);
     repeats = std::max(repeats, 1);
     (void)hipEventRecord(ctx->evA, ctx->stream);
     for (int r = 0; r < repeats; ++r) {
