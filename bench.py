@@ -58,20 +58,22 @@ NODE_B, REC_B = 64, 48          # TgHipBvhNode, TgHipPrimRec
 RAY_B, HIT_B = 32, 16           # (o,tmin,d,tmax), (t,u,v,rec)
 
 
-def kernel_bytes(c):
-    """Algorithmic bytes moved by each kernel class over everything the counters cover."""
+def kernel_bytes(c, flat):
+    """Algorithmic bytes moved by each kernel class over everything the counters cover.
+    flat: the scene is traversed as a flat record list whose loads are wave-uniform (one fetch per 64 rays)."""
     nodes_sh, prims_sh = c["nodes_visited_shadow"], c["prims_tested_shadow"]
     nodes_cl, prims_cl = c["nodes_visited"] - nodes_sh, c["prims_tested"] - prims_sh
+    rec_b = REC_B/64.0 if flat else REC_B
     paths = c["closest_rays"]            # path vertices processed by k_shade == extension rays
     return {
-        # queue index + ray in + hit out + BVH nodes and primitive records actually visited
-        "k_trace_closest": paths*(4 + RAY_B + HIT_B) + NODE_B*nodes_cl + REC_B*prims_cl,
-        # queue index, shadow origin, per shadow ray (dir+contribution), throughput/pending, radiance read+write
-        "k_trace_shadow": c["shadow_slots"]*(4 + 16 + 16 + 16 + 32) + c["shadow_rays"]*32 + NODE_B*nodes_sh + REC_B*prims_sh,
-        # the 128-B path-state record read + written once per vertex (ray, hit, throughput, radiance, rng, pixel)
-        # plus the 64-B attribute gather of triangle hits and the shadow-ray records it emits
-        "k_shade": paths*(4 + RAY_B + HIT_B + 16 + 16 + 8 + 4) + paths*(16 + 16) + c["closest_rays_alive"]*(RAY_B + 8)
-                   + c["shadow_slots"]*(4 + 16 + 64 + 16 + 16),
+        # ray in + hit out + BVH nodes and primitive records actually visited
+        "k_trace_closest": paths*(RAY_B + HIT_B) + NODE_B*nodes_cl + rec_b*prims_cl,
+        # shadow origin, throughput/pending, radiance read+write per slot; direction+contribution per ray
+        "k_trace_shadow": c["shadow_slots"]*(16 + 16 + 16 + 32) + c["shadow_rays"]*32 + NODE_B*nodes_sh + rec_b*prims_sh,
+        # path state read once per vertex (ray, hit, throughput, radiance, rng, pixel) and written back (throughput,
+        # radiance; ray + rng when the path continues), plus the shadow records a vertex emits
+        "k_shade": paths*(RAY_B + HIT_B + 16 + 16 + 8 + 4) + paths*(16 + 16) + c["closest_rays_alive"]*(RAY_B + 8)
+                   + c["shadow_slots"]*(16 + 64 + 16 + 16),
     }
 
 
@@ -195,7 +197,7 @@ def main():
             cc = counters_dict(cc)
             check(lib.tghip_set_option(ctx, b"count_traversal", 0), "tghip_set_option")
             cc["closest_rays_alive"] = max(cc["closest_rays"] - cc["samples"], 0)
-            per_step_bytes = kernel_bytes(cc)
+            per_step_bytes = kernel_bytes(cc, int(flat.info.num_recs) <= 16)
 
             kernels = {}
             ms = {"k_trace_closest": timed["ms_trace_closest"], "k_shade": timed["ms_shade"],

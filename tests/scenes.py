@@ -123,6 +123,12 @@ def _mt_material(bsdf):
     return edit
 
 
+def _two_lights(scene):
+    """A second, differently coloured quad light low on the left wall: exercises TraceBase::chooseLight (TraceBase.cpp:416-459)."""
+    scene["primitives"].append({"name": "light2", "type": "quad", "bsdf": "light", "emission": [3, 9, 14],
+                                "transform": {"position": [-0.98, 0.6, 0.2], "scale": [0.3, 0.3, 0.3], "rotation": [0, 0, -90]}})
+
+
 # name -> (builder, kwargs): every per-sample golden under tests/golden/<name>_samples.npz (tools/make_golden.py)
 GOLDEN_CASES = {
     "cornell": (cornell, dict(resolution=(48, 27), spp=8)),
@@ -132,11 +138,14 @@ GOLDEN_CASES = {
     "cornell_minb2": (cornell, dict(resolution=(32, 18), spp=8, integrator={"min_bounces": 2})),
     "cornell_onesided": (cornell, dict(resolution=(32, 18), spp=8, integrator={"enable_two_sided_shading": False})),
     "cornell_box_filter": (cornell, dict(resolution=(32, 18), spp=8, edit=lambda s: s["camera"].update(reconstruction_filter="box"))),
+    "cornell_two_lights": (cornell, dict(resolution=(32, 18), spp=8, edit=_two_lights)),
     "zoo_a": (lambda t, **kw: cornell_zoo(t, "zoo_a", **kw), dict(resolution=(48, 27), spp=8)),
     "zoo_b": (lambda t, **kw: cornell_zoo(t, "zoo_b", **kw), dict(resolution=(48, 27), spp=8)),
     "zoo_c": (lambda t, **kw: cornell_zoo(t, "zoo_c", **kw), dict(resolution=(48, 27), spp=8)),
     "materialtest": (materialtest, dict(resolution=(64, 36), spp=4)),
     "materialtest_dielectric": (materialtest, dict(resolution=(48, 27), spp=4, edit=_mt_material({"type": "dielectric", "ior": 1.5, "albedo": 1}))),
+    "materialtest_transparency": (materialtest, dict(resolution=(48, 27), spp=4, edit=_mt_material(
+        {"type": "transparency", "alpha": 0.5, "albedo": 1, "base": {"type": "lambert", "albedo": [0.8, 0.5, 0.3]}}))),
     "materialtest_rough_dielectric": (materialtest, dict(resolution=(48, 27), spp=4, edit=_mt_material(
         {"type": "rough_dielectric", "ior": 1.5, "distribution": "ggx", "roughness": 0.1, "albedo": 1}))),
 }
