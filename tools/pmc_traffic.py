@@ -20,7 +20,7 @@ def per_kernel(path, counter):
             if row.get("Counter_Name") != counter:
                 continue
             k = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
-            k = re.sub(r"<.*", "", k)
+            k = re.sub(r"<.*", "", k).replace("_dyn", "")   # kernel class: the dynamic-fetch variants count as their class
             sums[k] += float(row["Counter_Value"])
             n[k] += 1
     return {k: (sums[k]/n[k], n[k]) for k in sums}
