@@ -62,29 +62,47 @@ struct BlockStats {               // traversal statistics (count_traversal optio
     unsigned long long prof[12];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds, tools/gpu_profile_sections.sh)
 };
 
+// Per-slot state: A_COUNT arrays of 16-byte elements in ONE allocation, array a at byte offset a*stride (stride =
+// 16 B x pool slots).  One base pointer + one 32-bit per-lane offset address every array, which keeps the kernels'
+// SGPR (base pointers) and VGPR (64-bit addresses) budgets small.
+enum {
+    A_RAY_O = 0,   // origin.xyz, tmin
+    A_RAY_D,       // dir.xyz, tmax
+    A_HIT,         // t, u, v, record index (int bits; -1 = miss)
+    A_THR,         // throughput.rgb, flags (uint bits)
+    A_EMI,         // radiance of the sample in flight
+    A_ACC,         // sum of the finished samples of the slot's current work item, count (uint bits)
+    A_MISC,        // uint4: PCG state lo, hi | pixel index | work item
+    A_SAMP,        // uint4: current sample index, end of the item's sample range, -, -
+    A_SH_O,        // shadow origin.xyz, epsilon
+    A_SH_D0, A_SH_C0,   // light-sample shadow ray: dir.xyz, tmax | unoccluded contribution, endCap|bounce bits
+    A_SH_D1, A_SH_C1,   // bsdf-sample shadow ray
+    A_SH_W,        // throughput at the NEE vertex, light-selection weight
+    A_SH_P,        // emission picked up at the same vertex (added after the NEE term), path flags (uint bits)
+    A_COUNT
+};
+
 struct PathState {
-    float4 * __restrict__ ray_o;     // origin.xyz, tmin
-    float4 * __restrict__ ray_d;     // dir.xyz, tmax
-    float4 * __restrict__ hit;       // t, u, v, record index (int bits; -1 = miss)
-    float4 * __restrict__ thr;       // throughput.rgb, flags (uint bits)
-    float4 * __restrict__ emi;       // radiance of the sample in flight
-    float4 * __restrict__ acc;       // sum of the finished samples of the slot's current work item, count (uint bits)
-    uint2 * __restrict__ rng;       // PCG state
-    uint2 * __restrict__ samp;      // current sample index, end of the item's sample range
-    uint32_t * __restrict__ pixel;   // pixel index of the current item
-    uint32_t * __restrict__ item;    // current work item
-    float4 * __restrict__ sh_o;      // shadow origin.xyz, epsilon
-    float4 * __restrict__ sh_d0, * __restrict__ sh_c0;   // light-sample shadow ray: dir.xyz, tmax | unoccluded contribution, endCap|bounce bits
-    float4 * __restrict__ sh_d1, * __restrict__ sh_c1;   // bsdf-sample shadow ray
-    float4 * __restrict__ sh_w;      // throughput at the NEE vertex, light-selection weight
-    float4 * __restrict__ sh_p;      // emission picked up at the same vertex (added after the NEE term), path flags (uint bits)
-    uint32_t * __restrict__ bm[Q_COUNT];   // queue bitmaps: workgroup b uses words [b*slots_per_block/32, (b+1)*slots_per_block/32)
-    float4 * __restrict__ partial;   // per work item: radiance sum, count (uint bits)
-    BlockCtl *ctl;
-    BlockStats *stats;
-    uint32_t * __restrict__ live;    // [0] = tag of the last iteration that left work in some extension queue; [1] = abort flag
+    char * __restrict__ pool;              // A_COUNT x stride bytes
+    uint32_t stride;                       // bytes per array
+    uint32_t * __restrict__ bm;            // queue bitmaps: queue q of workgroup b = words [q*bmStride + b*slots_per_block/32, ...)
+    uint32_t bmStride;                     // words per queue
+    float4 * __restrict__ partial;         // per work item: radiance sum, count (uint bits)
+    BlockCtl * __restrict__ ctl;
+    BlockStats * __restrict__ stats;
+    uint32_t * __restrict__ live;          // [0] = tag of the last iteration that left work in some extension queue; [1] = abort flag
     uint32_t num_slots, slots_per_block;
 };
+
+PT_DEV float4 &slotF4(const PathState &st, uint32_t a, uint32_t slot)
+{
+    return *reinterpret_cast<float4 *>(st.pool + (size_t)(a*st.stride + slot*16u));
+}
+PT_DEV uint4 &slotU4(const PathState &st, uint32_t a, uint32_t slot)
+{
+    return *reinterpret_cast<uint4 *>(st.pool + (size_t)(a*st.stride + slot*16u));
+}
+
 
 struct PassParams {
     uint32_t spp_begin, spp_end, seed;
@@ -168,7 +186,7 @@ PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, i
 #pragma unroll
         for (int k = 0; k < Q_COUNT; ++k) {
             bool load = k == q || k == q2 || ((appendMask >> k) & 1u);
-            L.bm[k][t] = load ? st.bm[k][blockIdx.x*W + t] : 0u;
+            L.bm[k][t] = load ? st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + t] : 0u;
         }
     }
     if (t == 0) {
@@ -244,7 +262,7 @@ PT_DEV bool queuesEnd(BlockLds &L, const PathState &st, int q, uint32_t appendMa
 #pragma unroll
         for (int k = 0; k < Q_COUNT; ++k)
             if (k == q || k == q2 || ((appendMask >> k) & 1u))
-                st.bm[k][blockIdx.x*W + t] = L.bm[k][t];
+                st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + t] = L.bm[k][t];
         ext = L.bm[Q_EXT][t] | L.bm[Q_EXTP][t];
     }
     return __syncthreads_or(ext != 0u) != 0;
@@ -266,7 +284,8 @@ PT_DEV bool slotPixel(const PassParams &pp, uint32_t j, uint32_t &x, uint32_t &y
 
 // PinholeCamera::sampleDirection + ReconstructionFilter::sample (PinholeCamera.cpp:70-86,
 // ReconstructionFilter.hpp:86-103,152-169).  Consumes two random numbers.
-PT_DEV float filterSample1D(const TgHipCamera &cam, float xi)
+typedef const PT_CONST_AS TgHipCamera &CameraRef;   // constant address space: uniform loads become s_load
+PT_DEV float filterSample1D(CameraRef cam, float xi)
 {
     bool negative = xi < 0.5f;
     xi = negative ? xi*2.0f : (xi - 0.5f)*2.0f;
@@ -285,7 +304,7 @@ PT_DEV float filterSample1D(const TgHipCamera &cam, float xi)
     float u = cam.filter_bin_size*(idx + (xi - lo)/pdf);
     return negative ? -u : u;
 }
-PT_DEV void cameraRay(const TgHipCamera &cam, uint32_t px, uint32_t py, Rng &rng, f3 &o, f3 &d)
+PT_DEV void cameraRay(CameraRef cam, uint32_t px, uint32_t py, Rng &rng, f3 &o, f3 &d)
 {
     float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
     float fu = 0.0f, fv = 0.0f;
@@ -332,7 +351,7 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
     int cur = 0;
     for (;;) {
         if (cur >= 0) {
-            const float4 *n = s.nodes + (size_t)cur*4;
+            const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
             float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             if (COUNT) nodesVisited++;
             float e0, e1;
@@ -391,7 +410,7 @@ PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, 
     int cur = 0;
     for (;;) {
         if (cur >= 0) {
-            const float4 *n = s.nodes + (size_t)cur*4;
+            const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
             float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             if (COUNT) nodesVisited++;
             float e0, e1;

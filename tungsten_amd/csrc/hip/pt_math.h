@@ -19,6 +19,18 @@
 
 #define PT_DEV __device__ __forceinline__
 
+// base[idx] with the byte offset computed in 32 bits: lets the compiler address with "SGPR base + 32-bit VGPR
+// offset" (one offset register shared by every 16-byte-per-slot array) instead of materialising a 64-bit address
+// per array.  Arrays indexed this way must stay below 4 GiB (checked at upload / pool allocation).
+template<typename T> PT_DEV T &at32(T *base, uint32_t idx)
+{
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + (size_t)(idx*(uint32_t)sizeof(T)));
+}
+template<typename T> PT_DEV const T &at32(const T *base, uint32_t idx)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(idx*(uint32_t)sizeof(T)));
+}
+
 struct f3 { float x, y, z; };
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }

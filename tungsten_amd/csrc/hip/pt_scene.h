@@ -23,7 +23,7 @@ struct DeviceScene {
     const float * __restrict__ dist;
     const uint8_t * __restrict__ rec_class;    // shading class of each primitive record's bsdf (built at upload, DESIGN.md "Kernels")
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
-    TgHipCamera   camera;
+    const TgHipCamera * __restrict__ camera;   // in device memory (56 dwords: read through the scalar cache where it is used, not held in SGPRs)
     TgHipSettings settings;
 };
 
@@ -34,6 +34,18 @@ struct DeviceScene {
 #define LOBE_SPECULAR         (TGHIP_LOBE_SPECULAR_R | TGHIP_LOBE_SPECULAR_T)
 #define LOBE_TRANSMISSIVE     (TGHIP_LOBE_GLOSSY_T | TGHIP_LOBE_DIFFUSE_T | TGHIP_LOBE_SPECULAR_T)
 #define LOBE_ALL_BUT_SPECULAR (~(uint32_t)(LOBE_SPECULAR | TGHIP_LOBE_FORWARD))
+
+// M is the compile-time set of BSDF types (bit = 1 << TGHIP_BSDF_*) a kernel variant has to handle: cases
+// outside M fold away, which is what keeps the Lambert-only shading kernel small (DESIGN.md "Kernels").
+#define BSDF_BIT(t) (1u << (t))
+#define BSDF_MASK_ALL 0xFFFFFFFFu
+// The upper bits of M say which scene FEATURES a shading-kernel variant has to handle (all set in BSDF_MASK_ALL);
+// code for absent features folds away like BSDF types do.
+#define FEAT_BITMAP     (1u << 24)   /* bitmap textures (incl. environment maps)                      */
+#define FEAT_INFINITE   (1u << 25)   /* infinite-sphere emitters                                       */
+#define FEAT_MULTILIGHT (1u << 26)   /* more than one sampled light (TraceBase::chooseLight's pdf loop) */
+#define FEAT_TRIANGLES  (1u << 27)   /* triangle records (attribute gather, smooth normals)            */
+#define FEAT_ALL        (FEAT_BITMAP | FEAT_INFINITE | FEAT_MULTILIGHT | FEAT_TRIANGLES)
 
 // ---------------------------------------------------------------------------------------------
 // Textures (ConstantTexture, CheckerTexture.cpp:64-69, BitmapTexture.cpp:298-352)
@@ -48,6 +60,17 @@ PT_DEV f3 bitmapTexel(const DeviceScene &s, const TgHipTexture &t, int x, int y)
     return splat3(tex[(size_t)x + (size_t)y*t.w]);
 }
 
+// i mod n for n > 0 and any i, result in [0, n): float-reciprocal quotient + fix-up instead of integer division
+PT_DEV int wrapIndex(int i, int n)
+{
+    int q = (int)floorf((float)i/(float)n);
+    int r = i - q*n;
+    if (r < 0) r += n;
+    if (r >= n) r -= n;
+    return r;
+}
+
+template<uint32_t M>
 PT_DEV f3 textureEval(const DeviceScene &s, int texIdx, float u0, float v0)
 {
     const TgHipTexture &t = s.textures[texIdx];
@@ -57,6 +80,8 @@ PT_DEV f3 textureEval(const DeviceScene &s, int texIdx, float u0, float v0)
         int ui = (int)(u0*(float)t.res_u), vi = (int)(v0*(float)t.res_v);
         return ((ui ^ vi) & 1) ? ld3(t.on_color) : ld3(t.off_color);
     }
+    if (!(M & FEAT_BITMAP))
+        return splat3(0.0f);
     int w = t.w, h = t.h;
     float u = u0*w;
     float v = (1.0f - v0)*h;
@@ -67,8 +92,8 @@ PT_DEV f3 textureEval(const DeviceScene &s, int texIdx, float u0, float v0)
     int iu1 = iu0 + 1, iv1 = iv0 + 1;
     u -= iu0; v -= iv0;
     if (!(t.flags & TGHIP_TEXF_CLAMP)) {
-        iu0 = ((iu0 % w) + w) % w; iu1 = ((iu1 % w) + w) % w;
-        iv0 = ((iv0 % h) + h) % h; iv1 = ((iv1 % h) + h) % h;
+        iu0 = wrapIndex(iu0, w); iu1 = wrapIndex(iu1, w);
+        iv0 = wrapIndex(iv0, h); iv1 = wrapIndex(iv1, h);
     } else {
         iu0 = min(max(iu0, 0), w - 1); iu1 = min(max(iu1, 0), w - 1);
         iv0 = min(max(iv0, 0), h - 1); iv1 = min(max(iv1, 0), h - 1);
@@ -232,8 +257,8 @@ PT_DEV bool checkRefractionConstraint(f3 wi, f3 wo, float eta, float cosThetaT) 
 PT_DEV float sgnE(float v) { return v < 0.0f ? -1.0f : 1.0f; }
 PT_DEV bool isExactReverse(f3 wi, f3 wo) { return -wi.x == wo.x && -wi.y == wo.y && -wi.z == wo.z; }
 
-PT_DEV f3 bsdfAlbedo(const DeviceScene &s, const TgHipBsdf &b, const Event &e) { return textureEval(s, b.albedo, e.u, e.v); }
-PT_DEV float bsdfRoughness(const DeviceScene &s, const TgHipBsdf &b, const Event &e) { return textureEval(s, b.roughness, e.u, e.v).x; }
+template<uint32_t M> PT_DEV f3 bsdfAlbedo(const DeviceScene &s, const TgHipBsdf &b, const Event &e) { return textureEval<M>(s, b.albedo, e.u, e.v); }
+template<uint32_t M> PT_DEV float bsdfRoughness(const DeviceScene &s, const TgHipBsdf &b, const Event &e) { return textureEval<M>(s, b.roughness, e.u, e.v).x; }
 
 // RoughDielectricBsdf::sampleBase / evalBase / pdfBase (RoughDielectricBsdf.cpp:55-131,133-166,200-236)
 PT_DEV bool rdSampleBase(Event &e, bool sampleR, bool sampleT, float roughness, float ior, int dist)
@@ -344,10 +369,6 @@ PT_DEV f3 absorb(const TgHipBsdf &b, f3 f, float cosA, float cosB)
     return f;
 }
 
-// M is the compile-time set of BSDF types (bit = 1 << TGHIP_BSDF_*) a kernel variant has to handle: cases
-// outside M fold away, which is what keeps the Lambert-only shading kernel small (DESIGN.md "Kernels").
-#define BSDF_BIT(t) (1u << (t))
-#define BSDF_MASK_ALL 0xFFFFFFFFu
 template<int D, uint32_t M> struct BsdfOps;
 
 template<int D, uint32_t M>
@@ -362,32 +383,32 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_ERROR)))) return splat3(0.0f);
             if (!(e.requested & TGHIP_LOBE_DIFFUSE_R)) return splat3(0.0f);
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
-            return bsdfAlbedo(s, b, e)*PT_INV_PI*e.wo.z;
+            return bsdfAlbedo<M>(s, b, e)*PT_INV_PI*e.wo.z;
         case TGHIP_BSDF_FORWARD:                               /* ForwardBsdf.cpp:25-28 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_FORWARD)))) return splat3(0.0f);
             return (e.requested == TGHIP_LOBE_FORWARD && isExactReverse(e.wi, e.wo)) ? splat3(1.0f) : splat3(0.0f);
         case TGHIP_BSDF_MIRROR:                                /* MirrorBsdf.cpp:39-46 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_MIRROR)))) return splat3(0.0f);
             if ((e.requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e.wi, e.wo))
-                return bsdfAlbedo(s, b, e);
+                return bsdfAlbedo<M>(s, b, e);
             return splat3(0.0f);
         case TGHIP_BSDF_CONDUCTOR:                             /* ConductorBsdf.cpp:68-75 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_CONDUCTOR)))) return splat3(0.0f);
             if ((e.requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e.wi, e.wo))
-                return bsdfAlbedo(s, b, e)*conductorReflectance(b.eta, b.k, e.wi.z);
+                return bsdfAlbedo<M>(s, b, e)*conductorReflectance(b.eta, b.k, e.wi.z);
             return splat3(0.0f);
         case TGHIP_BSDF_ROUGH_CONDUCTOR: {                     /* RoughConductorBsdf.cpp:93-109 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return splat3(0.0f);
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return splat3(0.0f);
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
-            float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness(s, b, e));
+            float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness<M>(s, b, e));
             f3 hr = normalized(e.wi + e.wo);
             float cosThetaM = dot(e.wi, hr);
             f3 F = conductorReflectance(b.eta, b.k, cosThetaM);
             float G = mfG(b.distribution, alpha, e.wi, e.wo, hr);
             float Dm = mfD(b.distribution, alpha, hr);
             float fr = (G*Dm*0.25f)/e.wi.z;
-            return bsdfAlbedo(s, b, e)*(F*fr);
+            return bsdfAlbedo<M>(s, b, e)*(F*fr);
         }
         case TGHIP_BSDF_SMOOTH_COAT: {                         /* SmoothCoatBsdf.cpp:146-177 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT)))) return splat3(0.0f);
@@ -419,18 +440,18 @@ struct BsdfOps {
             float F = dielectricReflectance(eta, fabsf(e.wi.z), cosThetaT);
             if (e.wi.z*e.wo.z >= 0.0f) {
                 if (evalR && checkReflectionConstraint(e.wi, e.wo))
-                    return bsdfAlbedo(s, b, e)*F;
+                    return bsdfAlbedo<M>(s, b, e)*F;
                 return splat3(0.0f);
             }
             if (evalT && checkRefractionConstraint(e.wi, e.wo, eta, cosThetaT))
-                return bsdfAlbedo(s, b, e)*(1.0f - F);
+                return bsdfAlbedo<M>(s, b, e)*(1.0f - F);
             return splat3(0.0f);
         }
         case TGHIP_BSDF_ROUGH_DIELECTRIC: {                    /* RoughDielectricBsdf.cpp:247-254 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return splat3(0.0f);
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
-            return rdEvalBase(e, sampleR, sampleT, bsdfRoughness(s, b, e), b.ior, b.distribution)*bsdfAlbedo(s, b, e);
+            return rdEvalBase(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, b.distribution)*bsdfAlbedo<M>(s, b, e);
         }
         case TGHIP_BSDF_PLASTIC: case TGHIP_BSDF_ROUGH_PLASTIC: {   /* PlasticBsdf.cpp:125-151, RoughPlasticBsdf.cpp:114-141 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_PLASTIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_PLASTIC)))) return splat3(0.0f);
@@ -450,9 +471,9 @@ struct BsdfOps {
             }
             f3 glossyR = splat3(0.0f), diffuseR = splat3(0.0f);
             if (rough && evalR)
-                glossyR = rdEvalBase(e, true, false, bsdfRoughness(s, b, e), b.ior, b.distribution);
+                glossyR = rdEvalBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, b.distribution);
             if (evalT) {
-                f3 diffuseAlbedo = bsdfAlbedo(s, b, e);
+                f3 diffuseAlbedo = bsdfAlbedo<M>(s, b, e);
                 diffuseR = plasticSubstrate(b, diffuseAlbedo)*((1.0f - Fi)*(1.0f - Fo)*eta*eta*e.wo.z*PT_INV_PI);
                 diffuseR = absorb(b, diffuseR, e.wo.z, e.wi.z);
             }
@@ -460,14 +481,14 @@ struct BsdfOps {
         }
         case TGHIP_BSDF_MIXED: {                               /* MixedBsdf.cpp:101-105 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_MIXED)))) return splat3(0.0f);
-            float ratio = textureEval(s, b.tex1, e.u, e.v).x;
+            float ratio = textureEval<M>(s, b.tex1, e.u, e.v).x;
             f3 f0 = Next::eval(s, b.sub0, e), f1 = Next::eval(s, b.sub1, e);
-            return bsdfAlbedo(s, b, e)*(f0*ratio + f1*(1.0f - ratio));
+            return bsdfAlbedo<M>(s, b, e)*(f0*ratio + f1*(1.0f - ratio));
         }
         case TGHIP_BSDF_TRANSPARENCY:                          /* TransparencyBsdf.cpp:48-54 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_TRANSPARENCY)))) return splat3(0.0f);
             if (e.requested == TGHIP_LOBE_FORWARD)
-                return isExactReverse(e.wi, e.wo) ? splat3(1.0f - textureEval(s, b.tex1, e.u, e.v).x) : splat3(0.0f);
+                return isExactReverse(e.wi, e.wo) ? splat3(1.0f - textureEval<M>(s, b.tex1, e.u, e.v).x) : splat3(0.0f);
             return Next::eval(s, b.sub0, e);
         default:
             return splat3(0.0f);
@@ -478,7 +499,7 @@ struct BsdfOps {
     {
         bool sample0 = (e.requested & s.bsdfs[b.sub0].lobes) != 0;
         bool sample1 = (e.requested & s.bsdfs[b.sub1].lobes) != 0;
-        if (sample0 && sample1) ratio = textureEval(s, b.tex1, e.u, e.v).x;
+        if (sample0 && sample1) ratio = textureEval<M>(s, b.tex1, e.u, e.v).x;
         else if (sample0) ratio = 1.0f;
         else if (sample1) ratio = 0.0f;
         else return false;
@@ -496,7 +517,7 @@ struct BsdfOps {
             float xi0 = rngNext1D(*e.rng), xi1 = rngNext1D(*e.rng);
             e.wo = cosineHemisphere(xi0, xi1);
             e.pdf = cosineHemispherePdf(e.wo);
-            e.weight = bsdfAlbedo(s, b, e);
+            e.weight = bsdfAlbedo<M>(s, b, e);
             e.sampled = TGHIP_LOBE_DIFFUSE_R;
             return true;
         }
@@ -506,21 +527,21 @@ struct BsdfOps {
             e.wo = mk3(-e.wi.x, -e.wi.y, e.wi.z);
             e.pdf = 1.0f;
             e.sampled = TGHIP_LOBE_SPECULAR_R;
-            e.weight = bsdfAlbedo(s, b, e);
+            e.weight = bsdfAlbedo<M>(s, b, e);
             return true;
         case TGHIP_BSDF_CONDUCTOR:                             /* ConductorBsdf.cpp:56-66 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_CONDUCTOR)))) return false;
             if (!(e.requested & TGHIP_LOBE_SPECULAR_R)) return false;
             e.wo = mk3(-e.wi.x, -e.wi.y, e.wi.z);
             e.pdf = 1.0f;
-            e.weight = bsdfAlbedo(s, b, e)*conductorReflectance(b.eta, b.k, e.wi.z);
+            e.weight = bsdfAlbedo<M>(s, b, e)*conductorReflectance(b.eta, b.k, e.wi.z);
             e.sampled = TGHIP_LOBE_SPECULAR_R;
             return true;
         case TGHIP_BSDF_ROUGH_CONDUCTOR: {                     /* RoughConductorBsdf.cpp:60-91 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return false;
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return false;
             if (e.wi.z <= 0.0f) return false;
-            float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness(s, b, e));
+            float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness<M>(s, b, e));
             float xi0 = rngNext1D(*e.rng), xi1 = rngNext1D(*e.rng);
             f3 m = mfSample(b.distribution, alpha, xi0, xi1);
             float wiDotM = dot(e.wi, m);
@@ -533,7 +554,7 @@ struct BsdfOps {
             float weight = wiDotM*G*Dm/(e.wi.z*mPdf);
             f3 F = conductorReflectance(b.eta, b.k, wiDotM);
             e.pdf = mPdf*0.25f/wiDotM;
-            e.weight = bsdfAlbedo(s, b, e)*(F*weight);
+            e.weight = bsdfAlbedo<M>(s, b, e)*(F*weight);
             e.sampled = TGHIP_LOBE_GLOSSY_R;
             return true;
         }
@@ -596,15 +617,15 @@ struct BsdfOps {
                 e.sampled = TGHIP_LOBE_SPECULAR_T;
                 e.weight = sampleR ? splat3(1.0f) : splat3(1.0f - F);
             }
-            e.weight = e.weight*bsdfAlbedo(s, b, e);
+            e.weight = e.weight*bsdfAlbedo<M>(s, b, e);
             return true;
         }
         case TGHIP_BSDF_ROUGH_DIELECTRIC: {                    /* RoughDielectricBsdf.cpp:238-245 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return false;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
-            bool result = rdSampleBase(e, sampleR, sampleT, bsdfRoughness(s, b, e), b.ior, b.distribution);
-            e.weight = e.weight*bsdfAlbedo(s, b, e);
+            bool result = rdSampleBase(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, b.distribution);
+            e.weight = e.weight*bsdfAlbedo<M>(s, b, e);
             return result;
         }
         case TGHIP_BSDF_PLASTIC: {                             /* PlasticBsdf.cpp:45-87 */
@@ -628,7 +649,7 @@ struct BsdfOps {
                 f3 wo = cosineHemisphere(xi0, xi1);
                 float Fo = dielectricReflectance(eta, wo.z);
                 e.wo = wo;
-                e.weight = plasticSubstrate(b, bsdfAlbedo(s, b, e))*((1.0f - Fi)*(1.0f - Fo)*eta*eta);
+                e.weight = plasticSubstrate(b, bsdfAlbedo<M>(s, b, e))*((1.0f - Fi)*(1.0f - Fo)*eta*eta);
                 e.weight = absorb(b, e.weight, e.wo.z, e.wi.z);
                 e.pdf = cosineHemispherePdf(e.wo)*(1.0f - specularProbability);
                 e.weight = e.weight/(1.0f - specularProbability);
@@ -648,11 +669,11 @@ struct BsdfOps {
             float substrateWeight = substrateW*b.avg_transmittance*(1.0f - Fi);
             float specularProbability = Fi/(Fi + substrateWeight);
             if (sampleR && (rngNextBoolean(*e.rng, specularProbability) || !sampleT)) {
-                if (!rdSampleBase(e, true, false, bsdfRoughness(s, b, e), b.ior, b.distribution))
+                if (!rdSampleBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, b.distribution))
                     return false;
                 if (sampleT) {
                     float Fo = dielectricReflectance(eta, e.wo.z);
-                    f3 brdfSubstrate = plasticSubstrate(b, bsdfAlbedo(s, b, e))*((1.0f - Fi)*(1.0f - Fo)*eta*eta)*PT_INV_PI*e.wo.z;
+                    f3 brdfSubstrate = plasticSubstrate(b, bsdfAlbedo<M>(s, b, e))*((1.0f - Fi)*(1.0f - Fo)*eta*eta)*PT_INV_PI*e.wo.z;
                     f3 brdfSpecular = e.weight*e.pdf;
                     float pdfSubstrate = cosineHemispherePdf(e.wo)*(1.0f - specularProbability);
                     float pdfSpecular = e.pdf*specularProbability;
@@ -665,13 +686,13 @@ struct BsdfOps {
             f3 wo = cosineHemisphere(xi0, xi1);
             float Fo = dielectricReflectance(eta, wo.z);
             e.wo = wo;
-            e.weight = plasticSubstrate(b, bsdfAlbedo(s, b, e))*((1.0f - Fi)*(1.0f - Fo)*eta*eta);
+            e.weight = plasticSubstrate(b, bsdfAlbedo<M>(s, b, e))*((1.0f - Fi)*(1.0f - Fo)*eta*eta);
             e.weight = absorb(b, e.weight, e.wo.z, e.wi.z);
             e.pdf = cosineHemispherePdf(e.wo);
             if (sampleR) {
                 f3 brdfSubstrate = e.weight*e.pdf;
                 float pdfSubstrate = e.pdf*(1.0f - specularProbability);
-                float r = bsdfRoughness(s, b, e);
+                float r = bsdfRoughness<M>(s, b, e);
                 f3 brdfSpecular = rdEvalBase(e, true, false, r, b.ior, b.distribution);
                 float pdfSpecular = rdPdfBase(e, true, false, r, b.ior, b.distribution)*specularProbability;
                 e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
@@ -699,7 +720,7 @@ struct BsdfOps {
                 e.pdf = pdf0 + pdf1;
                 e.weight = f/e.pdf;
             }
-            e.weight = e.weight*bsdfAlbedo(s, b, e);
+            e.weight = e.weight*bsdfAlbedo<M>(s, b, e);
             return true;
         }
         case TGHIP_BSDF_TRANSPARENCY:                          /* TransparencyBsdf.cpp:43-46 */
@@ -726,7 +747,7 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return 0.0f;
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return 0.0f;
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
-            float sampleAlpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness(s, b, e));
+            float sampleAlpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness<M>(s, b, e));
             f3 hr = normalized(e.wi + e.wo);
             return mfPdf(b.distribution, sampleAlpha, hr)*0.25f/dot(e.wi, hr);
         }
@@ -773,7 +794,7 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return 0.0f;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
-            return rdPdfBase(e, sampleR, sampleT, bsdfRoughness(s, b, e), b.ior, b.distribution);
+            return rdPdfBase(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, b.distribution);
         }
         case TGHIP_BSDF_PLASTIC: {                             /* PlasticBsdf.cpp:153-177 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_PLASTIC)))) return 0.0f;
@@ -799,7 +820,7 @@ struct BsdfOps {
             bool sampleT = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
             if (!sampleR && !sampleT) return 0.0f;
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
-            float glossyPdf = sampleR ? rdPdfBase(e, true, false, bsdfRoughness(s, b, e), b.ior, b.distribution) : 0.0f;
+            float glossyPdf = sampleR ? rdPdfBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, b.distribution) : 0.0f;
             float diffusePdf = sampleT ? cosineHemispherePdf(e.wo) : 0.0f;
             if (sampleT && sampleR) {
                 float Fi = dielectricReflectance(1.0f/b.ior, e.wi.z);
@@ -950,7 +971,7 @@ PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
         r1 = make_float4(rp[4], rp[5], rp[6], rp[7]);
         r2 = make_float4(rp[8], rp[9], rp[10], rp[11]);
     } else {
-        r0 = s.recs[ri*3 + 0]; r1 = s.recs[ri*3 + 1]; r2 = s.recs[ri*3 + 2];
+        r0 = at32(s.recs, ri*3u + 0u); r1 = at32(s.recs, ri*3u + 1u); r2 = at32(s.recs, ri*3u + 2u);
     }
     uint32_t meta = __float_as_uint(r0.w);
     uint32_t kind = TGHIP_REC_KIND(meta);
@@ -993,18 +1014,20 @@ struct Info {
     bool backSide;
 };
 
+template<uint32_t M>
 PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, Info &info)
 {
     int ri = __float_as_int(hit.w);
-    float4 r0 = s.recs[ri*3 + 0], r1 = s.recs[ri*3 + 1], r2 = s.recs[ri*3 + 2];
+    const uint32_t rj = (uint32_t)ri;
+    float4 r0 = at32(s.recs, rj*3u + 0u), r1 = at32(s.recs, rj*3u + 1u), r2 = at32(s.recs, rj*3u + 2u);
     uint32_t meta = __float_as_uint(r0.w);
     int objIdx = (int)TGHIP_REC_OBJECT(meta);
     const TgHipObject &o = s.objects[objIdx];
     info.object = objIdx;
     info.p = ray.o + ray.d*hit.x;                      /* TraceableScene.hpp:184 */
     uint32_t kind = TGHIP_REC_KIND(meta);
-    if (kind == TGHIP_REC_TRIANGLE) {                  /* TriangleMesh.cpp:317-355, 80-106 */
-        float4 a0 = s.tri_attrs[ri*4 + 0], a1 = s.tri_attrs[ri*4 + 1], a2 = s.tri_attrs[ri*4 + 2], a3 = s.tri_attrs[ri*4 + 3];
+    if ((M & FEAT_TRIANGLES) && kind == TGHIP_REC_TRIANGLE) {   /* TriangleMesh.cpp:317-355, 80-106 */
+        float4 a0 = at32(s.tri_attrs, rj*4u + 0u), a1 = at32(s.tri_attrs, rj*4u + 1u), a2 = at32(s.tri_attrs, rj*4u + 2u), a3 = at32(s.tri_attrs, rj*4u + 3u);
         f3 NgU = cross(xyz(r1), xyz(r2));
         info.backSide = dot(NgU, ray.d) > 0.0f;
         info.Ng = normalized(NgU);
@@ -1061,10 +1084,11 @@ PT_DEV f3 infUvToDirection(const TgHipObject &o, float u, float v, float &sinThe
 struct LightHit { float t, u, v; bool backSide; };
 
 /* light.intersect(ray) + intersectionInfo: analytic hit test that precedes the shadow ray (TraceBase.cpp:155-162) */
+template<uint32_t M>
 PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, LightHit &lh)
 {
     const TgHipObject &o = s.objects[objIdx];
-    if (o.type == TGHIP_OBJ_QUAD) {
+    if (!(M & FEAT_INFINITE) || o.type == TGHIP_OBJ_QUAD) {
         f3 n = ld3(o.normal);
         if (!quadTest(ld3(o.base), ld3(o.edge0), ld3(o.edge1), o.inv_uv_sq[0], o.inv_uv_sq[1], n, ray, ray.tmax, lh.t, lh.u, lh.v))
             return false;
@@ -1076,32 +1100,35 @@ PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, Li
     infDirectionToUV(o, ray.d, lh.u, lh.v, sinTheta);
     return true;
 }
+template<uint32_t M>
 PT_DEV f3 lightEvalDirect(const DeviceScene &s, int objIdx, float u, float v, bool backSide)
 {
     const TgHipObject &o = s.objects[objIdx];
     if (o.emission < 0 || backSide) return splat3(0.0f);
-    return textureEval(s, o.emission, u, v);
+    return textureEval<M>(s, o.emission, u, v);
 }
+template<uint32_t M>
 PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p)
 {
     const TgHipObject &o = s.objects[objIdx];
-    if (o.type == TGHIP_OBJ_QUAD) {
+    if (!(M & FEAT_INFINITE) || o.type == TGHIP_OBJ_QUAD) {
         f3 n = ld3(o.normal);
         float cosTheta = fabsf(dot(n, w));
         float t = dot(n, ld3(o.base) - p)/dot(n, w);
         return t*t/(cosTheta*o.area);
     }
     const TgHipTexture &t = s.textures[o.emission];
-    if (t.type != TGHIP_TEX_BITMAP)
+    if (!(M & FEAT_BITMAP) || t.type != TGHIP_TEX_BITMAP)
         return PT_INV_FOUR_PI;
     float sinTheta, u, v;
     infDirectionToUV(o, w, u, v, sinTheta);
     return PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, t, u, v)/sinTheta;
 }
+template<uint32_t M>
 PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, f3 &d, float &dist, float &pdf)
 {
     const TgHipObject &o = s.objects[objIdx];
-    if (o.type == TGHIP_OBJ_QUAD) {
+    if (!(M & FEAT_INFINITE) || o.type == TGHIP_OBJ_QUAD) {
         f3 n = ld3(o.normal);
         if (dot(n, p - ld3(o.base)) <= 0.0f)
             return false;
@@ -1119,7 +1146,7 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
     const TgHipTexture &t = s.textures[o.emission];
     float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
     dist = PT_INF;
-    if (t.type != TGHIP_TEX_BITMAP) {
+    if (!(M & FEAT_BITMAP) || t.type != TGHIP_TEX_BITMAP) {
         d = uniformSphere(xi0, xi1);
         pdf = PT_INV_FOUR_PI;
         return true;
@@ -1130,10 +1157,11 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
     pdf = PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, t, u, v)/sinTheta;
     return pdf != 0.0f;
 }
+template<uint32_t M>
 PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
 {
     const TgHipObject &o = s.objects[objIdx];
-    if (o.type == TGHIP_OBJ_QUAD) {
+    if (!(M & FEAT_INFINITE) || o.type == TGHIP_OBJ_QUAD) {
         if (o.emission < 0) return 0.0f;
         f3 R0 = ld3(o.base) - p;
         if (dot(R0, ld3(o.normal)) >= 0.0f)
@@ -1151,22 +1179,23 @@ PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
 }
 
 /* TraceBase::chooseLight (TraceBase.cpp:416-459); returns the object index of the light or -1 */
+template<uint32_t M>
 PT_DEV int chooseLight(const DeviceScene &s, Rng &rng, f3 p, float &weight)
 {
     int n = (int)s.num_lights;
     if (n == 0) return -1;
-    if (n == 1) { weight = 1.0f; return s.lights[0]; }
+    if (!(M & FEAT_MULTILIGHT) || n == 1) { weight = 1.0f; return s.lights[0]; }
     // Only quad and infinite-sphere emitters are sampled (tghip_upload_scene rejects the rest), and their
     // approximateRadiance is never negative ("unknown"), so TraceBase.cpp:434-446's uniform-share branch cannot
     // trigger.  Two passes over the lights instead of a per-lane pdf array (which would live in scratch).
     n = min(n, 16);
     float total = 0.0f;
     for (int i = 0; i < n; ++i)
-        total += lightApproximateRadiance(s, s.lights[i], p);
+        total += lightApproximateRadiance<M>(s, s.lights[i], p);
     if (total == 0.0f) return -1;
     float t = rngNext1D(rng)*total;
     for (int i = 0; i < n; ++i) {
-        float pdf = lightApproximateRadiance(s, s.lights[i], p);
+        float pdf = lightApproximateRadiance<M>(s, s.lights[i], p);
         if (t < pdf || i == n - 1) { weight = total/pdf; return s.lights[i]; }
         t -= pdf;
     }

@@ -29,7 +29,12 @@
 #endif
 
 // BSDF type sets of the shading-kernel variants (pt_scene.h BsdfOps<D, M>)
-#define MASK_SIMPLE  (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_NULL) | BSDF_BIT(TGHIP_BSDF_ERROR))
+#define TYPES_SIMPLE (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_NULL) | BSDF_BIT(TGHIP_BSDF_ERROR))
+#define MASK_SIMPLE  (TYPES_SIMPLE | FEAT_ALL)
+#define MASK_LEAN    TYPES_SIMPLE        /* analytic primitives, constant/checker textures, one area light (Cornell box) */
+#ifndef LEAN_WAVES
+#define LEAN_WAVES   3
+#endif
 #define MASK_COAT    (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR) | BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT) | \
                       BSDF_BIT(TGHIP_BSDF_MIRROR) | BSDF_BIT(TGHIP_BSDF_CONDUCTOR))
 #define MASK_GLASS   (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC) | \
@@ -50,10 +55,11 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
     uint32_t pixel = 0, item = 0;
     bool want = fresh;
     if (finished) {
-        samp = st.samp[slot];
-        acc = st.acc[slot];
-        pixel = st.pixel[slot];
-        item = st.item[slot];
+        uint4 sm = slotU4(st, A_SAMP, slot), misc = slotU4(st, A_MISC, slot);
+        samp = make_uint2(sm.x, sm.y);
+        acc = slotF4(st, A_ACC, slot);
+        pixel = misc.z;
+        item = misc.w;
         if (black || isnan(sum3(em)))
             em = splat3(0.0f);
         if (!(isinf(em.x) || isinf(em.y) || isinf(em.z))) {
@@ -63,7 +69,7 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
         finishedCount++;
         samp.x++;
         if (samp.x >= samp.y || aborted) {
-            st.partial[item] = acc;
+            at32(st.partial, item) = acc;
             want = true;
         }
     }
@@ -112,20 +118,18 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
     bool push = false;
     if (finished || fresh) {
         if (dead) {
-            st.thr[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
+            slotF4(st, A_THR, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
         } else {
             Rng rng = rngStart(pp.seed, pixel, samp.x);          // PathSampleGenerator::startPath
             f3 o, d;
-            cameraRay(s.camera, pixel % pp.width, pixel/pp.width, rng, o, d);
-            st.ray_o[slot] = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
-            st.ray_d[slot] = mk4(d, PT_INF);
-            st.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-            st.emi[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            st.thr[slot] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
-            st.samp[slot] = samp;
-            st.acc[slot] = acc;
-            st.pixel[slot] = pixel;
-            st.item[slot] = item;
+            cameraRay(*asConst(s.camera), pixel % pp.width, pixel/pp.width, rng, o, d);
+            slotF4(st, A_RAY_O, slot) = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
+            slotF4(st, A_RAY_D, slot) = mk4(d, PT_INF);
+            slotU4(st, A_MISC, slot) = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, item);
+            slotF4(st, A_EMI, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            slotF4(st, A_THR, slot) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
+            slotU4(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, 0u, 0u);
+            slotF4(st, A_ACC, slot) = acc;
             push = true;
         }
     }
@@ -175,13 +179,13 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
         if (i < n) {
             local = orderGet(ord, k);
             slot = first + local;
-            float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
+            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
             RayD ray;
             ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
             float4 hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
-            st.hit[slot] = hit;
+            slotF4(st, A_HIT, slot) = hit;
             int ri = __float_as_int(hit.w);
-            cls = ri < 0 ? 0 : (int)s.rec_class[ri];
+            cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
             rays++;
         }
         // sort by material: one shading queue per class
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
                 if (i < n) {
                     local = order[i];
                     slot = first + local;
-                    float4 ro = st.ray_o[slot], rd = st.ray_d[slot];
+                    float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
                     ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
                     invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
                     tmax = ray.tmax;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
         if (busy) {
             bool pop = true;
             if (cur >= 0) {
-                const float4 *nd = s.nodes + (size_t)cur*4;
+                const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
                 float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
                 if (COUNT) nodes++;
                 float e0, e1;
@@ -284,9 +288,9 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
             if (pop) {
                 if (sp == 0) {
                     // finished: publish the hit and bin the path by shading class
-                    st.hit[slot] = hit;
+                    slotF4(st, A_HIT, slot) = hit;
                     int ri = __float_as_int(hit.w);
-                    int cls = ri < 0 ? 0 : (int)s.rec_class[ri];
+                    int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
                     queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
                     busy = false;
                 } else {
@@ -362,10 +366,11 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             f3 pendingOut = splat3(0.0f);
             local = order[i];
             slot = first + local;
-            float4 ro = st.ray_o[slot], rd = st.ray_d[slot], hit = st.hit[slot], thr4 = st.thr[slot];
-            em = xyz(st.emi[slot]);
-            uint2 rs = st.rng[slot];
-            uint32_t pixel = st.pixel[slot];
+            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot), hit = slotF4(st, A_HIT, slot), thr4 = slotF4(st, A_THR, slot);
+            em = xyz(slotF4(st, A_EMI, slot));
+            uint4 misc = slotU4(st, A_MISC, slot);
+            uint2 rs = make_uint2(misc.x, misc.y);
+            uint32_t pixel = misc.z;
             Rng rng;
             rng.state = ((uint64_t)rs.y << 32) | rs.x;
             rng.inc = ((uint64_t)pixel << 1) | 1u;
@@ -379,20 +384,20 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
 
             if (__float_as_int(hit.w) < 0) {
                 // path escaped: TraceBase::handleInfiniteLights (TraceBase.cpp:570-578); the last infinite light wins
-                if (bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0) {
+                if ((M & FEAT_INFINITE) && bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0) {
                     int objIdx = s.infinite_lights[s.num_infinite_lights - 1];
                     const TgHipObject &o = s.objects[objIdx];
                     if (!nee || wasSpecular || !(o.flags & TGHIP_OBJF_SAMPLE)) {
                         float u, v, sinTheta;
                         infDirectionToUV(o, ray.d, u, v, sinTheta);
-                        em = em + throughput*textureEval(s, o.emission, u, v);
+                        em = em + throughput*textureEval<M>(s, o.emission, u, v);
                     }
                 }
                 state = isnan(sum3(throughput) + sum3(em)) ? ST_TERMINATED_BLACK : ST_TERMINATED;
             } else {
                 PROF(1);
                 Info info;
-                intersectionInfo(s, ray, hit, info);
+                intersectionInfo<M>(s, ray, hit, info);
                 const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
                 PROF(2);
 
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     // ---- next-event estimation: TraceBase::estimateDirect (TraceBase.cpp:483-494) ----
                     if (nee && bounce < maxBounces - 1) {
                         float lightWeight = 1.0f;
-                        int light = chooseLight(s, rng, info.p, lightWeight);
+                        int light = chooseLight<M>(s, rng, info.p, lightWeight);
                         bool pureSpecular = lobes != 0 && (lobes & ~(uint32_t)LOBE_SPECULAR) == 0;
                         if (light >= 0 && !pureSpecular && lobes != TGHIP_LOBE_FORWARD) {
                             uint32_t tag = (uint32_t)light | ((uint32_t)(bounce + 1) << 24);
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                             // lightSample (TraceBase.cpp:246-285)
                             {
                                 f3 d; float dist, pdf;
-                                if (lightSampleDirect(s, light, info.p, rng, d, dist, pdf)) {
+                                if (lightSampleDirect<M>(s, light, info.p, rng, d, dist, pdf)) {
                                     ev.wo = toLocal(frame, d);
                                     ev.requested = LOBE_ALL_BUT_SPECULAR;
                                     if (isConsistent(ev.wo, d)) {
@@ -448,13 +453,13 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                             RayD sr; sr.o = info.p; sr.d = d; sr.tmin = 5e-4f; sr.tmax = PT_INF;
                                             LightHit lh;
                                             // attenuatedEmission's analytic hit + distance check (TraceBase.cpp:155-162)
-                                            if (lightIntersect(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist)) {
-                                                f3 e = lightEvalDirect(s, light, lh.u, lh.v, lh.backSide);
+                                            if (lightIntersect<M>(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist)) {
+                                                f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
                                                 if (!isZero(e)) {
                                                     f3 lightF = f*e/pdf;
                                                     lightF = lightF*powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
-                                                    st.sh_d0[slot] = mk4(d, lh.t);
-                                                    st.sh_c0[slot] = mk4(lightF, __uint_as_float(tag));
+                                                    slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
+                                                    slotF4(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
                                                     q0 = true;
                                                 }
                                             }
@@ -471,13 +476,13 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                     if (isConsistent(ev.wo, wog)) {
                                         RayD sr; sr.o = info.p; sr.d = wog; sr.tmin = 5e-4f; sr.tmax = PT_INF;
                                         LightHit lh;
-                                        if (lightIntersect(s, light, sr, lh)) {
-                                            f3 e = lightEvalDirect(s, light, lh.u, lh.v, lh.backSide);
+                                        if (lightIntersect<M>(s, light, sr, lh)) {
+                                            f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
                                             if (!isZero(e)) {
                                                 f3 bsdfF = e*ev.weight;
-                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightDirectPdf(s, light, wog, info.p));
-                                                st.sh_d1[slot] = mk4(wog, lh.t);
-                                                st.sh_c1[slot] = mk4(bsdfF, __uint_as_float(tag));
+                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightDirectPdf<M>(s, light, wog, info.p));
+                                                slotF4(st, A_SH_D1, slot) = mk4(wog, lh.t);
+                                                slotF4(st, A_SH_C1, slot) = mk4(bsdfF, __uint_as_float(tag));
                                                 q1 = true;
                                             }
                                         }
@@ -486,10 +491,10 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                             }
                             if (q0 || q1) {
                                 hasShadow = true;
-                                if (!q0) st.sh_c0[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                                if (!q1) st.sh_c1[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                                st.sh_o[slot] = mk4(info.p, 5e-4f);
-                                st.sh_w[slot] = mk4(throughput, lightWeight);
+                                if (!q0) slotF4(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                                if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                                slotF4(st, A_SH_O, slot) = mk4(info.p, 5e-4f);
+                                slotF4(st, A_SH_W, slot) = mk4(throughput, lightWeight);
                             }
                         }
                     }
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     {
                         const TgHipObject &o = s.objects[info.object];
                         if (o.emission >= 0 && bounce >= minBounces && (!nee || wasSpecular || o.light < 0))
-                            pending = lightEvalDirect(s, info.object, info.u, info.v, info.backSide)*throughput;
+                            pending = lightEvalDirect<M>(s, info.object, info.u, info.v, info.backSide)*throughput;
                     }
                     // with a shadow ray pending, `pending` is added after the NEE term by k_trace_shadow, like the reference
                     if (!hasShadow)
@@ -551,9 +556,9 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     }
                 }
                 if (state == ST_ACTIVE) {
-                    st.ray_o[slot] = mk4(ray.o, ray.tmin);
-                    st.ray_d[slot] = mk4(ray.d, ray.tmax);
-                    st.rng[slot] = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    slotF4(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
+                    slotF4(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
+                    *reinterpret_cast<uint2 *>(&slotU4(st, A_MISC, slot)) = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                 }
             }
             const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state);
@@ -561,15 +566,15 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             black = state == ST_TERMINATED_BLACK;
             if (hasShadow) {
                 // k_trace_shadow adds the NEE term, then finishes the path if it ended here
-                st.emi[slot] = mk4(em, 0.0f);
-                st.sh_p[slot] = mk4(pendingOut, __uint_as_float(newFlags));
+                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
+                slotF4(st, A_SH_P, slot) = mk4(pendingOut, __uint_as_float(newFlags));
             } else if (survives) {
-                st.emi[slot] = mk4(em, 0.0f);
+                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
             } else {
                 finished = true;
             }
             if (survives)
-                st.thr[slot] = mk4(throughput, __uint_as_float(newFlags));
+                slotF4(st, A_THR, slot) = mk4(throughput, __uint_as_float(newFlags));
         }
         PROF(5);
         queuePush(hasShadow, local, L, Q_SHADOW);
@@ -614,15 +619,15 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
             local = orderGet(ord, k);
             slot = first + local;
             slots++;
-            float4 so = st.sh_o[slot];
+            float4 so = slotF4(st, A_SH_O, slot);
             f3 result = splat3(0.0f);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                float4 c = r == 0 ? st.sh_c0[slot] : st.sh_c1[slot];
+                float4 c = r == 0 ? slotF4(st, A_SH_C0, slot) : slotF4(st, A_SH_C1, slot);
                 uint32_t tag = __float_as_uint(c.w);
                 if (tag == 0xFFFFFFFFu)
                     continue;
-                float4 sd = r == 0 ? st.sh_d0[slot] : st.sh_d1[slot];
+                float4 sd = r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot);
                 int endCap = (int)(tag & 0xFFFFFFu);
                 int bounce = (int)(tag >> 24);
                 RayD ray;
@@ -642,13 +647,13 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     int ri = __float_as_int(hit.w);
                     int hitObject = -1;
                     if (ri >= 0)
-                        hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(s.recs[ri*3].w));
+                        hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)ri*3u).w));
                     if (ri < 0 || hitObject == endCap) {
                         if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
                         break;
                     }
                     Info info;
-                    intersectionInfo(s, ray, hit, info);
+                    intersectionInfo<BSDF_MASK_ALL>(s, ray, hit, info);
                     const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
                     if (!(lobes & TGHIP_LOBE_FORWARD)) { transmittance = splat3(0.0f); break; }
                     Frame frame = frameFromNormal(info.Ns);
@@ -673,14 +678,14 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 if (!isZero(transmittance))
                     result = result + xyz(c)*transmittance;
             }
-            float4 w = st.sh_w[slot];
-            float4 p = st.sh_p[slot];
-            em = xyz(st.emi[slot]);
+            float4 w = slotF4(st, A_SH_W, slot);
+            float4 p = slotF4(st, A_SH_P, slot);
+            em = xyz(slotF4(st, A_EMI, slot));
             em = em + (result*w.w)*xyz(w);                       // emission += estimateDirect(...)*throughput
             em = em + xyz(p);
             uint32_t state = FLAG_STATE(__float_as_uint(p.w));
             if (state == ST_ACTIVE) {
-                st.emi[slot] = mk4(em, 0.0f);
+                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
             } else {
                 finished = true;
                 black = state == ST_TERMINATED_BLACK;
@@ -747,11 +752,11 @@ __global__ __launch_bounds__(512) void k_trace_shadow_dyn(DeviceScene s, PathSta
     // sets up ray `r` (or the next valid one) of the current slot; returns false when the slot has no ray left
     auto setupRay = [&]() -> bool {
         for (; r < 2; ++r) {
-            float4 c = r == 0 ? st.sh_c0[slot] : st.sh_c1[slot];
+            float4 c = r == 0 ? slotF4(st, A_SH_C0, slot) : slotF4(st, A_SH_C1, slot);
             uint32_t tag = __float_as_uint(c.w);
             if (tag == 0xFFFFFFFFu)
                 continue;
-            float4 sd = r == 0 ? st.sh_d0[slot] : st.sh_d1[slot];
+            float4 sd = r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot);
             endCap = (int)(tag & 0xFFFFFFu);
             int bounce = (int)(tag >> 24);
             rays++;
@@ -767,12 +772,12 @@ __global__ __launch_bounds__(512) void k_trace_shadow_dyn(DeviceScene s, PathSta
     };
     // NEE term -> path radiance; paths that ended at this vertex go on the finished list
     auto finishSlot = [&]() {
-        float4 w = st.sh_w[slot];
-        float4 p = st.sh_p[slot];
-        f3 em = xyz(st.emi[slot]);
+        float4 w = slotF4(st, A_SH_W, slot);
+        float4 p = slotF4(st, A_SH_P, slot);
+        f3 em = xyz(slotF4(st, A_EMI, slot));
         em = em + (result*w.w)*xyz(w);           // emission += estimateDirect(...)*throughput
         em = em + xyz(p);
-        st.emi[slot] = mk4(em, 0.0f);
+        slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
         if (FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE)
             finishedList[atomicAdd(&finishedN, 1u)] = (unsigned short)local;
         busy = false;
@@ -793,7 +798,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow_dyn(DeviceScene s, PathSta
                     local = order[i];
                     slot = first + local;
                     slots++;
-                    float4 o4 = st.sh_o[slot];
+                    float4 o4 = slotF4(st, A_SH_O, slot);
                     so = xyz(o4); eps = o4.w;
                     result = splat3(0.0f);
                     r = 0;
@@ -811,7 +816,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow_dyn(DeviceScene s, PathSta
         if (busy) {
             bool pop = true, occluded = false;
             if (cur >= 0) {
-                const float4 *nd = s.nodes + (size_t)cur*4;
+                const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
                 float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
                 if (COUNT) nodes++;
                 float e0, e1;
@@ -871,8 +876,8 @@ __global__ __launch_bounds__(512) void k_trace_shadow_dyn(DeviceScene s, PathSta
         if (fin) {
             loc = finishedList[i];
             sl = first + loc;
-            em = xyz(st.emi[sl]);
-            black = FLAG_STATE(__float_as_uint(st.sh_p[sl].w)) == ST_TERMINATED_BLACK;
+            em = xyz(slotF4(st, A_EMI, sl));
+            black = FLAG_STATE(__float_as_uint(slotF4(st, A_SH_P, sl).w)) == ST_TERMINATED_BLACK;
         }
         bool regenerated = nextPath(s, st, pp, fin, false, sl, em, black, &L.cursor, aborted, finishedCount);
         queuePush(regenerated, loc, L, Q_EXTP);
@@ -905,7 +910,7 @@ __global__ __launch_bounds__(256) void k_resolve(PathState st, PassParams pp, fl
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
     uint32_t cnt = 0;
     for (uint32_t c = 0; c < pp.chunks; ++c) {
-        float4 a = st.partial[(size_t)c*pp.pix_slots + j];
+        float4 a = at32(st.partial, c*pp.pix_slots + j);
         sx += a.x; sy += a.y; sz += a.z;
         cnt += __float_as_uint(a.w);
     }
@@ -970,6 +975,7 @@ struct tghip_ctx {
     bool haveComplex = false;             // some primitive record uses a class-1 BSDF
     uint32_t complexMask = 0;             // union of the BSDF types inside class-1 materials
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
+    bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
     int blocksPerCuOpt = 0;               // "blocks_per_cu" option; 0 = auto (see chooseThreads)
@@ -978,6 +984,7 @@ struct tghip_ctx {
     // resident at once (no second scheduling round), i.e. each kernel runs at its own best occupancy on one grid
     int thrClosest = 256, thrShadow = 256, thrShadeSimple = 192, thrShadeComplex = 128;
     int thrOverride[4] = {0, 0, 0, 0};
+    long long poolPad = 9472;             // bytes between the per-slot arrays of the pool (multiple of 16)
     bool dynamicFetch = true;             // BVH scenes: closest-hit kernel with dynamic ray fetch (k_trace_closest_dyn)
     bool timeKernels = false;             // HIP events around every launch of the wavefront loop (bench.py roofline)
     std::vector<hipEvent_t> evPool;
@@ -1157,12 +1164,14 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     ctx->poolSlots = 0;
 #define POOL_ALLOC(field, n) do { std::remove_reference<decltype(*p.field)>::type *tmp_ = nullptr; \
         if ((rc = allocArray(ctx, ctx->poolMem, (n), &tmp_)) != TGHIP_OK) return rc; p.field = tmp_; } while (0)
-    POOL_ALLOC(ray_o, slots); POOL_ALLOC(ray_d, slots); POOL_ALLOC(hit, slots); POOL_ALLOC(thr, slots);
-    POOL_ALLOC(emi, slots); POOL_ALLOC(acc, slots); POOL_ALLOC(rng, slots); POOL_ALLOC(samp, slots);
-    POOL_ALLOC(pixel, slots); POOL_ALLOC(item, slots);
-    POOL_ALLOC(sh_o, slots); POOL_ALLOC(sh_d0, slots); POOL_ALLOC(sh_c0, slots); POOL_ALLOC(sh_d1, slots);
-    POOL_ALLOC(sh_c1, slots); POOL_ALLOC(sh_w, slots); POOL_ALLOC(sh_p, slots);
-    for (int q = 0; q < Q_COUNT; ++q) POOL_ALLOC(bm[q], slots/32);
+    // arrays are skewed by an odd number of 256-byte units so that element i of different arrays does not map to
+    // the same HBM channel (a power-of-two array stride made the kernels' speed depend on allocation luck)
+    const uint64_t strideBytes = uint64_t(slots)*16u + uint64_t(ctx->poolPad);
+    if (strideBytes*A_COUNT >= (1ull << 32)) { ctx->error = "path pool too large for 32-bit slot offsets"; return TGHIP_E_INVALID; }
+    POOL_ALLOC(pool, size_t(strideBytes)*A_COUNT);
+    p.stride = uint32_t(strideBytes);
+    POOL_ALLOC(bm, size_t(slots/32)*Q_COUNT);
+    p.bmStride = slots/32;
     POOL_ALLOC(ctl, grid); POOL_ALLOC(stats, grid); POOL_ALLOC(live, 2);
 #undef POOL_ALLOC
     HIP_TRY(ctx, hipMemsetAsync(p.ctl, 0, sizeof(BlockCtl)*grid, ctx->stream));
@@ -1195,7 +1204,7 @@ static void chooseThreads(tghip_ctx *ctx)
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, true, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, true, false>, 512, 1);
     else
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, false, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, false, false>, 512, 1);
-    ctx->thrShadeSimple = pickThreads(ctx, k_shade<MASK_SIMPLE, 3>, 256, 0);
+    ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, 3>, 256, 0);
     if ((ctx->complexMask & ~MASK_COAT) == 0)       ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2>, 256, 0);
     else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2>, 256, 0);
     else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2>, 256, 0);
@@ -1286,6 +1295,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "dynamic_fetch") { ctx->dynamicFetch = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "threads_closest") { ctx->thrOverride[0] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "threads_shadow") { ctx->thrOverride[1] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
@@ -1352,13 +1362,17 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             recClass[i] = simple ? 0 : 1;
             if (!simple) { ctx->haveComplex = true; ctx->complexMask |= typeMask[size_t(bi)]; }
         }
+        bool lean = sd->num_infinite_lights == 0 && sd->num_lights <= 1;
+        for (uint32_t i = 0; i < sd->num_textures && lean; ++i) lean = sd->textures[i].type != TGHIP_TEX_BITMAP;
+        for (uint32_t i = 0; i < sd->num_recs && lean; ++i) lean = TGHIP_REC_KIND(sd->recs[i].meta) != TGHIP_REC_TRIANGLE;
+        ctx->leanScene = lean;
         if ((rc = uploadArray(ctx, ctx->sceneMem, recClass.data(), recClass.size(), &s.rec_class)) != TGHIP_OK) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // recClass goes out of scope
     }
     s.num_nodes = sd->num_nodes; s.num_recs = sd->num_recs; s.num_objects = sd->num_objects;
     s.num_lights = sd->num_lights; s.num_infinite_lights = sd->num_infinite_lights;
     s.num_bsdfs = sd->num_bsdfs; s.num_textures = sd->num_textures;
-    s.camera = sd->camera;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, &sd->camera, 1, &s.camera)) != TGHIP_OK) return rc;
     s.settings = sd->settings;
     ctx->bvhDepth = depth;
 
@@ -1404,7 +1418,7 @@ extern "C++" {
 template<uint32_t M>
 static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
-    hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? 3 : 2)>), dim3(grid), dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0,
+    hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? 3 : M == MASK_LEAN ? LEAN_WAVES : 2)>), dim3(grid), dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0,
                        ctx->stream, ctx->scene, st, pp, cls);
 }
 
@@ -1494,7 +1508,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
+            if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
+            else                launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
             if (ctx->haveComplex) {
                 if ((ctx->complexMask & ~MASK_COAT) == 0)       launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
