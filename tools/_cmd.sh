@@ -1,4 +1,3 @@
-for i in 1 2; do
-bash tools/gpu_tune.sh r1s materialtest 64 "max_slots=2097152" "max_slots=2097152 pool_pad=0" "max_slots=2097152 pool_pad=4352"
-bash tools/gpu_tune.sh r1s cornell 256 "max_slots=2097152" "max_slots=2097152 pool_pad=0" "max_slots=2097152 pool_pad=4352"
-done
+bash tools/gpu_tune.sh r1v materialtest 64 "max_slots=2097152" "max_slots=2097152"
+TUNGSTEN_AMD_LIB=$PWD/tungsten_amd/lib/libtungsten_hip_s2.so bash tools/gpu_tune.sh r1v materialtest 64 "max_slots=2097152" "max_slots=2097152 threads_shade_simple=128" "max_slots=2097152"
+bash tools/gpu_tune.sh r1v cornell 256 "max_slots=2097152"

@@ -114,6 +114,7 @@ struct PassParams {
     uint32_t shard_index, shard_count;
     uint32_t tiles_x, num_tiles;
     uint32_t width, height;
+    uint32_t iter_tag;         // wavefront iteration number (liveness reporting of the fused flat-scene kernels)
 };
 
 PT_DEV uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

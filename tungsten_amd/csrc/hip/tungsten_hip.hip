@@ -32,8 +32,11 @@
 #define TYPES_SIMPLE (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_NULL) | BSDF_BIT(TGHIP_BSDF_ERROR))
 #define MASK_SIMPLE  (TYPES_SIMPLE | FEAT_ALL)
 #define MASK_LEAN    TYPES_SIMPLE        /* analytic primitives, constant/checker textures, one area light (Cornell box) */
+#ifndef SIMPLE_WAVES
+#define SIMPLE_WAVES 3
+#endif
 #ifndef LEAN_WAVES
-#define LEAN_WAVES   3
+#define LEAN_WAVES   2   /* measured: 2 waves/SIMD without scratch beats 3 with 108 B of scratch (kernel is VALU-bound) */
 #endif
 #define MASK_COAT    (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR) | BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT) | \
                       BSDF_BIT(TGHIP_BSDF_MIRROR) | BSDF_BIT(TGHIP_BSDF_CONDUCTOR))
@@ -338,35 +341,59 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
 // k_trace_shadow", plus the loop epilogue (PathTracer.cpp:108-129).  M = BSDF types this variant handles.
 // W = waves per SIMD the register allocator must leave room for (occupancy vs spilling: 3 costs the
 // Lambert-only variant 12 B of scratch, the others stay at 2)
-template<uint32_t M, int W>
+// FUSE (flat-list scenes without forward-lobe BSDFs only -- the whole scene is a handful of records read through the
+// scalar cache, so a separate traversal launch would spend its time on path-state traffic):
+//   FUSE_TRACE   the kernel consumes the extension queues itself, intersects the ray inline, shades class-0 hits
+//                and forwards class-1 hits (hit record stored) to the class-1 shading queue;
+//   FUSE_SHADOW  the <= 2 shadow rays of a vertex are any-hit tested inline instead of being queued for
+//                k_trace_shadow, so the NEE term is added on the spot and no shadow record is written.
+#define FUSE_TRACE  1
+#define FUSE_SHADOW 2
+template<uint32_t M, int W, int FUSE>
 __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, PassParams pp, int cls)
 {
     __shared__ BlockLds L;
     __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
     __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    const int qIn = cls == 0 ? Q_SHADE0 : Q_SHADE1;
-    queuesBegin(L, st, ctl, qIn, (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW), order);
+    const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : cls == 0 ? Q_SHADE0 : Q_SHADE1;
+    const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : -1;
+    const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? (1u << Q_SHADE1) : 0u);
+    queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2);
     const DeviceScene s = stageSceneTables(sg, ldsTables);
     const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const bool aborted = st.live[1] != 0;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
     const bool nee = s.settings.enable_light_sampling != 0;
-    uint32_t finishedCount = 0;
+    uint32_t finishedCount = 0, fusedClosest = 0, fusedShadow = 0, fusedPrims = 0, fusedNodes = 0;
     PROF_DECL;
 
     for (uint32_t base = 0; base < n; base += blockDim.x) {
         uint32_t i = base + threadIdx.x;
         PROF(0);
-        bool hasShadow = false, finished = false, survives = false, black = false;
+        bool hasShadow = false, finished = false, survives = false, black = false, toComplex = false;
         uint32_t slot = 0, local = 0;
         f3 em = splat3(0.0f);
         if (i < n) {
             f3 pendingOut = splat3(0.0f);
             local = order[i];
             slot = first + local;
-            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot), hit = slotF4(st, A_HIT, slot), thr4 = slotF4(st, A_THR, slot);
+            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot), hit, thr4 = slotF4(st, A_THR, slot);
+            if (FUSE & FUSE_TRACE) {
+                // TraceableScene::intersect inline: the flat record list, walked uniformly by the wave
+                RayD r0;
+                r0.o = xyz(ro); r0.d = xyz(rd); r0.tmin = ro.w; r0.tmax = rd.w;
+                hit = traverseClosest<true, true>(sg, r0, nullptr, 0, fusedNodes, fusedPrims);
+                fusedClosest++;
+                int ri = __float_as_int(hit.w);
+                toComplex = ri >= 0 && at32(sg.rec_class, (uint32_t)ri) != 0;
+                if (toComplex)
+                    slotF4(st, A_HIT, slot) = hit;           // shaded by the class-1 launch that follows
+            } else {
+                hit = slotF4(st, A_HIT, slot);
+            }
+          if (!toComplex) {
             em = xyz(slotF4(st, A_EMI, slot));
             uint4 misc = slotU4(st, A_MISC, slot);
             uint2 rs = make_uint2(misc.x, misc.y);
@@ -441,6 +468,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                         if (light >= 0 && !pureSpecular && lobes != TGHIP_LOBE_FORWARD) {
                             uint32_t tag = (uint32_t)light | ((uint32_t)(bounce + 1) << 24);
                             bool q0 = false, q1 = false;
+                            f3 inlineResult = splat3(0.0f);
                             // lightSample (TraceBase.cpp:246-285)
                             {
                                 f3 d; float dist, pdf;
@@ -458,8 +486,15 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                                 if (!isZero(e)) {
                                                     f3 lightF = f*e/pdf;
                                                     lightF = lightF*powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
-                                                    slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
-                                                    slotF4(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
+                                                    if (FUSE & FUSE_SHADOW) {
+                                                        sr.tmax = lh.t;
+                                                        fusedShadow++;
+                                                        if (!traverseOccluded<true, true>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
+                                                            inlineResult = inlineResult + lightF;
+                                                    } else {
+                                                        slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
+                                                        slotF4(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
+                                                    }
                                                     q0 = true;
                                                 }
                                             }
@@ -481,15 +516,25 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                             if (!isZero(e)) {
                                                 f3 bsdfF = e*ev.weight;
                                                 bsdfF = bsdfF*powerHeuristic(ev.pdf, lightDirectPdf<M>(s, light, wog, info.p));
-                                                slotF4(st, A_SH_D1, slot) = mk4(wog, lh.t);
-                                                slotF4(st, A_SH_C1, slot) = mk4(bsdfF, __uint_as_float(tag));
+                                                if (FUSE & FUSE_SHADOW) {
+                                                    sr.tmax = lh.t;
+                                                    fusedShadow++;
+                                                    if (!traverseOccluded<true, true>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
+                                                        inlineResult = inlineResult + bsdfF;
+                                                } else {
+                                                    slotF4(st, A_SH_D1, slot) = mk4(wog, lh.t);
+                                                    slotF4(st, A_SH_C1, slot) = mk4(bsdfF, __uint_as_float(tag));
+                                                }
                                                 q1 = true;
                                             }
                                         }
                                     }
                                 }
                             }
-                            if (q0 || q1) {
+                            if ((FUSE & FUSE_SHADOW) && (q0 || q1)) {
+                                // emission += estimateDirect(...)*throughput, like k_trace_shadow
+                                em = em + (inlineResult*lightWeight)*throughput;
+                            } else if (q0 || q1) {
                                 hasShadow = true;
                                 if (!q0) slotF4(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
                                 if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
@@ -575,8 +620,10 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             }
             if (survives)
                 slotF4(st, A_THR, slot) = mk4(throughput, __uint_as_float(newFlags));
+          }
         }
         PROF(5);
+        if (FUSE & FUSE_TRACE) queuePush(toComplex, local, L, Q_SHADE1);
         queuePush(hasShadow, local, L, Q_SHADOW);
         PROF(6);
         bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
@@ -587,10 +634,21 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     }
     PROF_FLUSH(st.stats[blockIdx.x]);
     waveAddStat(&L.samples, finishedCount);
-    queuesEnd(L, st, qIn, (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW));
+    if (FUSE) {
+        waveAddStat(&L.closest_rays, fusedClosest);
+        waveAddStat(&L.shadow_rays, fusedShadow);
+        waveAddStat(&L.prims, fusedPrims);
+    }
+    const bool anyExt = queuesEnd(L, st, qIn, appendMask, qIn2);
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples;
+        if (FUSE) {
+            ctl.closest_rays += L.closest_rays; ctl.shadow_rays += L.shadow_rays;
+            st.stats[blockIdx.x].prims_tested += L.prims;
+            // fused mode has no k_trace_shadow launch: the last shading launch of the iteration reports liveness
+            if (anyExt) st.live[0] = (uint32_t)pp.iter_tag;
+        }
     }
 }
 
@@ -984,6 +1042,7 @@ struct tghip_ctx {
     // resident at once (no second scheduling round), i.e. each kernel runs at its own best occupancy on one grid
     int thrClosest = 256, thrShadow = 256, thrShadeSimple = 192, thrShadeComplex = 128;
     int thrOverride[4] = {0, 0, 0, 0};
+    bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
     long long poolPad = 9472;             // bytes between the per-slot arrays of the pool (multiple of 16)
     bool dynamicFetch = true;             // BVH scenes: closest-hit kernel with dynamic ray fetch (k_trace_closest_dyn)
     bool timeKernels = false;             // HIP events around every launch of the wavefront loop (bench.py roofline)
@@ -1204,10 +1263,10 @@ static void chooseThreads(tghip_ctx *ctx)
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, true, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, true, false>, 512, 1);
     else
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, false, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, false, false>, 512, 1);
-    ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, 3>, 256, 0);
-    if ((ctx->complexMask & ~MASK_COAT) == 0)       ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2>, 256, 0);
-    else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2>, 256, 0);
-    else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2>, 256, 0);
+    ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES, 0>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>, 256, 0);
+    if ((ctx->complexMask & ~MASK_COAT) == 0)       ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2, 0>, 256, 0);
+    else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
+    else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     }
     int *dst[4] = {&ctx->thrClosest, &ctx->thrShadow, &ctx->thrShadeSimple, &ctx->thrShadeComplex};
     for (int i = 0; i < 4; ++i)
@@ -1295,6 +1354,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
     else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "dynamic_fetch") { ctx->dynamicFetch = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "threads_closest") { ctx->thrOverride[0] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
@@ -1415,11 +1475,11 @@ int tghip_bind_framebuffer(tghip_ctx *ctx, float *dev_rgb_sum, uint32_t *dev_cou
 }
 
 extern "C++" {
-template<uint32_t M>
+template<uint32_t M, int FUSE = 0>
 static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
-    hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? 3 : M == MASK_LEAN ? LEAN_WAVES : 2)>), dim3(grid), dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0,
-                       ctx->stream, ctx->scene, st, pp, cls);
+    hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? SIMPLE_WAVES : M == MASK_LEAN ? LEAN_WAVES : 2), FUSE>), dim3(grid),
+                       dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0, ctx->stream, ctx->scene, st, pp, cls);
 }
 
 template<bool COUNT>
@@ -1449,6 +1509,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = s.num_recs <= TGHIP_FLAT_MAX_RECS;
+    const bool fused = flat && !ctx->haveForward && ctx->fuseFlatOpt;
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
     // optional per-launch timing: one event pair per kernel launch of a check interval, read back at the
@@ -1493,6 +1554,22 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
         first = false;
         for (int it = 0; it < ctx->checkInterval; ++it) {
             ++iterTag;
+            if (fused) {
+                // flat-list scene: intersection and shadow tests happen inside the shading launches
+                PassParams ppi = pp;
+                ppi.iter_tag = iterTag;
+                tic(); tic(); tic();
+                if (ctx->leanScene) launchShade<MASK_LEAN, FUSE_TRACE | FUSE_SHADOW>(ctx, grid, st, ppi, 0);
+                else                launchShade<MASK_SIMPLE, FUSE_TRACE | FUSE_SHADOW>(ctx, grid, st, ppi, 0);
+                if (ctx->haveComplex) {
+                    if ((ctx->complexMask & ~MASK_COAT) == 0)       launchShade<MASK_COAT, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
+                    else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
+                    else                                            launchShade<BSDF_MASK_ALL, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
+                }
+                tic(); tic(); tic();
+                ctx->counters.iterations++;
+                continue;
+            }
             tic();
             if (flat) {
                 if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
