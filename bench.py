@@ -11,12 +11,13 @@ SURVEY.md 8e) and, for N > 1, the RCCL sum-reduce of the float framebuffer to ra
 flattened and uploaded before the timed region (inputs resident in HBM); the framebuffer stays in HBM.
 
 Workload at every N: BASELINE.json configs[1], Cornell box 1280x720 at 256 spp (fixed total work =>
-"scaling": "strong").  `--scene materialtest` benches configs[2]'s scene at 1280x720 (the metric's own
-wording) when its assets are present.
+"scaling": "strong").  At N = 1 the same line carries, under "extra", a shorter run of the scene the metric
+names (materialtest.json at 1280x720, 64 spp) when its assets are present; `--scene materialtest` makes
+that scene the headline workload instead.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest accumulated time:
 achieved = algorithmic bytes per launch / average launch duration, both from the timed region (HIP events
-recorded by the shim on the stream the kernels run on; byte model in DESIGN.md "Roofline").  `cpu_baseline`
+recorded by the shim on the stream the kernels run on; byte model in DESIGN.md section 5).  `cpu_baseline`
 times the reference itself (oracle/_ref/tungsten, kind "reference") or, when that binary is absent, the
 oracle port, on a bounded sample of the same workload on this box's host cores.
 """
@@ -45,82 +46,100 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="cornell", choices=["cornell", "materialtest"])
     ap.add_argument("--res", default="1280x720")
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--spp", type=int, default=0, help="default: 256 (cornell) / 64 (materialtest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary materialtest run")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--opt", action="append", default=[], help="shim option key=value (tghip_set_option)")
     return ap.parse_args()
 
 
-# ---- algorithmic bytes (DESIGN.md "Roofline") ------------------------------------------
+# ---- algorithmic bytes -------------------------------------------
 NODE_B, REC_B = 64, 48          # TgHipBvhNode, TgHipPrimRec
 RAY_B, HIT_B = 32, 16           # (o,tmin,d,tmax), (t,u,v,rec)
+STATE_R = RAY_B + 16 + 16 + 16  # ray, throughput+flags, radiance, rng+pixel+item read per shaded vertex
+STATE_W = 16 + 16               # throughput+flags, radiance written back per shaded vertex
 
 
-def kernel_bytes(c, flat):
-    """Algorithmic bytes moved by each kernel class over everything the counters cover (DESIGN.md section 5).
-    flat: the scene is traversed as a flat record list whose loads are wave-uniform (one fetch per 64 rays)."""
+def kernel_bytes(c, flat, fused):
+    """Algorithmic bytes moved by each kernel class over everything the counters cover.
+    flat: the scene is a flat record list whose loads are wave-uniform (one fetch per 64 rays);
+    fused: (flat scenes) intersection and shadow tests run inside k_shade, no hit / shadow records exist."""
     nodes_sh, prims_sh = c["nodes_visited_shadow"], c["prims_tested_shadow"]
     nodes_cl, prims_cl = c["nodes_visited"] - nodes_sh, c["prims_tested"] - prims_sh
     rec_b = REC_B/64.0 if flat else REC_B
-    paths = c["closest_rays"]            # path vertices processed by k_shade == extension rays
+    paths = c["closest_rays"]            # path vertices == extension rays
+    alive = max(c["closest_rays"] - c["samples"], 0)
+    regen = c["samples"]*(RAY_B + 16 + 16 + 16 + 16 + 16)   # a finished sample rewrites the whole slot record
+    if fused:
+        return {"k_shade": paths*(STATE_R + STATE_W) + alive*(RAY_B + 8) + regen + rec_b*c["prims_tested"]}
     return {
         # ray in + hit out + BVH nodes and primitive records actually visited
         "k_trace_closest": paths*(RAY_B + HIT_B) + NODE_B*nodes_cl + rec_b*prims_cl,
         # shadow origin, throughput/pending, radiance read+write per slot; direction+contribution per ray
         "k_trace_shadow": c["shadow_slots"]*(16 + 16 + 16 + 32) + c["shadow_rays"]*32 + NODE_B*nodes_sh + rec_b*prims_sh,
-        # path state read once per vertex (ray, hit, throughput, radiance, rng, pixel) and written back (throughput,
-        # radiance; ray + rng when the path continues), plus the shadow records a vertex emits
-        "k_shade": paths*(RAY_B + HIT_B + 16 + 16 + 8 + 4) + paths*(16 + 16) + c["closest_rays_alive"]*(RAY_B + 8)
-                   + c["shadow_slots"]*(16 + 64 + 16 + 16),
+        # path state read once per vertex and written back (+ ray and rng when the path continues), plus the
+        # shadow records a vertex emits
+        "k_shade": paths*(STATE_R + HIT_B + STATE_W) + alive*(RAY_B + 8) + c["shadow_slots"]*(16 + 64 + 16 + 16),
     }
 
 
 def counters_dict(c):
-    d = {k: getattr(c, k) for k, _ in c._fields_}
-    return d
+    return {k: getattr(c, k) for k, _ in c._fields_}
 
 
-def main():
-    a = parse_args()
-    import numpy as np
-    import torch
-    import tungsten_amd as tg
-    import scenes
+class Bench(object):
+    def __init__(self, a):
+        import torch
+        import tungsten_amd as tg
+        self.a, self.torch, self.tg = a, torch, tg
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != a.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (a.gpus, self.world))
+        if not torch.cuda.is_available() or tg.device_count() < 1:
+            raise SystemExit("bench.py: no HIP device visible -- the path tracer has no CPU fallback")
+        torch.cuda.set_device(self.local)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
+            self.dist = dist
+        self.tmp = tempfile.mkdtemp(prefix="tg_bench_")
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (a.gpus, world))
-    if not torch.cuda.is_available() or tg.device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible -- the path tracer has no CPU fallback")
-    torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+        shutil.rmtree(self.tmp, ignore_errors=True)
 
-    w, h = [int(v) for v in a.res.split("x")]
-    spp = a.spp
-    tmp = tempfile.mkdtemp(prefix="tg_bench_")
-    try:
-        if a.scene == "materialtest":
+    def fence(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, scene, w, h, spp, steps, warmup, cpu):
+        """Times `steps` renders of `scene`; returns the result dict on rank 0 (None elsewhere)."""
+        import numpy as np
+        import scenes
+        from tungsten_amd import dist as tgdist
+        a, tg, torch, lib = self.a, self.tg, self.torch, self.tg.lib
+        if scene == "materialtest":
             if not scenes.have_materialtest():
                 raise SystemExit("bench.py: materialtest assets missing (oracle/_ref/data; run __graft_entry__.build() where the reference is mounted)")
-            path = scenes.materialtest(tmp, resolution=(w, h), spp=spp)
+            path = scenes.materialtest(self.tmp, resolution=(w, h), spp=spp)
             workload = "materialtest.json (3 meshes 80768 tris + quad, smooth_coat/rough_conductor/lambert, envmap MIS) %dx%d @ %d spp" % (w, h, spp)
         else:
-            path = scenes.cornell(tmp, resolution=(w, h), spp=spp)
+            path = scenes.cornell(self.tmp, resolution=(w, h), spp=spp)
             workload = "BASELINE configs[1]: cornell-box (5 quads + 2 cubes + quad light, Lambert) %dx%d @ %d spp" % (w, h, spp)
 
         t0 = time.time()
         flat = tg.FlattenedScene(path)
         t_flatten = time.time() - t0
-        lib = tg.lib
-        ctx = lib.tghip_create(local)
+        ctx = lib.tghip_create(self.local)
         if not ctx:
             raise SystemExit("tghip_create: " + lib.tghip_last_error(None).decode())
 
@@ -138,8 +157,7 @@ def main():
         fb_sum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
         fb_cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
         check(lib.tghip_bind_framebuffer(ctx, fb_sum.data_ptr(), fb_cnt.data_ptr()), "tghip_bind_framebuffer")
-        from tungsten_amd import dist as tgdist
-        pass_desc = tgdist.shard_pass(rank, world, 0, spp, tg.DEFAULT_SEED)
+        pass_desc = tgdist.shard_pass(self.rank, self.world, 0, spp, tg.DEFAULT_SEED)
 
         def step():
             check(lib.tghip_clear_framebuffer(ctx), "tghip_clear_framebuffer")
@@ -148,45 +166,34 @@ def main():
             # the exchange step: float framebuffer sum-reduce over xGMI (tile ownership is disjoint -> exact)
             tgdist.reduce_framebuffer(fb_sum, fb_cnt, dst=0)
 
-        def fence():
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-        for _ in range(a.warmup):
+        for _ in range(warmup):
             step()
-        timing = not a.no_kernel_timing
         check(lib.tghip_reset_counters(ctx), "tghip_reset_counters")
-        check(lib.tghip_set_option(ctx, b"time_kernels", 1 if timing else 0), "tghip_set_option")
-        fence()
+        check(lib.tghip_set_option(ctx, b"time_kernels", 0 if a.no_kernel_timing else 1), "tghip_set_option")
+        self.fence()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        for _ in range(steps):
             step()
-        fence()
+        self.fence()
         elapsed = time.perf_counter() - t0
-        if dist is not None:
+        if self.dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
         timed = tg.TgHipCounters()
         lib.tghip_get_counters(ctx, C.byref(timed))
         timed = counters_dict(timed)
         check(lib.tghip_set_option(ctx, b"time_kernels", 0), "tghip_set_option")
 
-        # sanity of the result of the last timed step (rank 0 holds the reduced image)
-        ok = True
-        if rank == 0:
+        out = None
+        if self.rank == 0:
+            # sanity of the result of the last timed step (rank 0 holds the reduced image)
             cnt = fb_cnt.cpu().numpy()
             img = (fb_sum/fb_cnt.clamp(min=1).unsqueeze(-1)).cpu().numpy()
             ok = bool((cnt == spp).all() and np.isfinite(img).all())
-            image_mean = [float(v) for v in img.mean(axis=(0, 1))]
+            value = float(w)*h*spp*steps/elapsed*1e-6
 
-        total_samples = float(w)*h*spp*a.steps
-        value = total_samples/elapsed*1e-6
-
-        out = None
-        if rank == 0:
-            # one untimed counting step: exact node / primitive visit counts of the same (deterministic) render
+            # one untimed counting step: exact node / record visit counts of the same (deterministic) render
             check(lib.tghip_set_option(ctx, b"count_traversal", 1), "tghip_set_option")
             check(lib.tghip_reset_counters(ctx), "tghip_reset_counters")
             check(lib.tghip_clear_framebuffer(ctx), "clear")
@@ -196,17 +203,17 @@ def main():
             lib.tghip_get_counters(ctx, C.byref(cc))
             cc = counters_dict(cc)
             check(lib.tghip_set_option(ctx, b"count_traversal", 0), "tghip_set_option")
-            cc["closest_rays_alive"] = max(cc["closest_rays"] - cc["samples"], 0)
-            per_step_bytes = kernel_bytes(cc, int(flat.info.num_recs) <= 16)
+            is_flat = int(flat.info.num_recs) <= 16
+            fused = is_flat and cc["shadow_slots"] == 0 and cc["shadow_rays"] > 0
+            per_step_bytes = kernel_bytes(cc, is_flat, fused)
 
             kernels = {}
-            ms = {"k_trace_closest": timed["ms_trace_closest"], "k_shade": timed["ms_shade"],
-                  "k_trace_shadow": timed["ms_trace_shadow"]}
+            ms = {"k_trace_closest": timed["ms_trace_closest"], "k_shade": timed["ms_shade"], "k_trace_shadow": timed["ms_trace_shadow"]}
             launches = {"k_trace_closest": timed["launches_trace_closest"], "k_shade": timed["launches_shade"],
                         "k_trace_shadow": timed["launches_trace_shadow"]}
-            for k in ms:
+            for k in per_step_bytes:
                 if launches[k] and ms[k] > 0:
-                    bytes_per_launch = per_step_bytes[k]*a.steps/launches[k]
+                    bytes_per_launch = per_step_bytes[k]*steps/launches[k]
                     avg_s = ms[k]*1e-3/launches[k]
                     kernels[k] = {"ms_total": round(ms[k], 3), "launches": int(launches[k]), "avg_us": round(avg_s*1e6, 2),
                                   "bytes_per_launch": round(bytes_per_launch), "gbs": round(bytes_per_launch/avg_s*1e-9, 1)}
@@ -214,71 +221,62 @@ def main():
             if kernels:
                 dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
                 kd = kernels[dom]
-                roofline = {"bound": "hbm", "kernel": dom, "achieved": kd["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(kd["gbs"]/HBM_PEAK_GBS, 4), "traffic": None,
-                            "bytes_per_launch": kd["bytes_per_launch"], "avg_launch_us": kd["avg_us"], "launches": kd["launches"],
+                roofline = {"bound": "hbm", "kernel": dom + (" (trace + shade + shadow fused, flat-list scene)" if fused else ""),
+                            "achieved": kd["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kd["gbs"]/HBM_PEAK_GBS, 4),
+                            "traffic": None, "bytes_per_launch": kd["bytes_per_launch"], "avg_launch_us": kd["avg_us"],
+                            "launches": kd["launches"],
                             "timing": "HIP events per launch on the shim's stream, over the timed region"}
+                if fused:
+                    roofline["note"] = ("VALU-bound, not HBM-bound: exact fp32 division/sqrt/sin/cos and -ffp-contract=off for parity "
+                                        "with the CPU reference (DESIGN.md sections 5, 7)")
                 tr = os.path.join(ROOT, "profiles", "traffic.json")
                 if os.path.exists(tr):
                     try:
-                        t = json.load(open(tr)).get("%s/%s" % (a.scene, dom))
+                        t = json.load(open(tr)).get("%s/%s" % (scene, dom))
                         if t:
                             roofline["traffic"] = t["hbm_bytes_per_launch"]
                             roofline["traffic_source"] = t.get("source")
                     except Exception:
                         pass
-
-            cpu = None
-            if not a.no_cpu_baseline and world == 1:
-                cpu = cpu_baseline(a, path, flat, w, h, tmp)
-
+            rays = max(cc["closest_rays"] + cc["shadow_rays"], 1)
             out = {
-                "metric": "Msamples/s (W*H*spp/s), path_tracer render loop",
-                "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": round(elapsed/a.steps*1e3, 3), "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic (scene shipped in-tree, fixed seed 0xBA5EBA11)",
+                "value": round(value, 2), "ms_per_step": round(elapsed/steps*1e3, 3),
                 "config": {"workload": workload, "width": w, "height": h, "spp": spp, "sampler": "uniform (counter-based PCG)",
                            "adaptive_sampling": False, "max_bounces": int(flat.desc.contents.settings.max_bounces),
-                           "parallelism": "tile-shard x%d%s" % (world, " + RCCL framebuffer reduce" if world > 1 else "")},
-                "roofline": roofline, "cpu_baseline": cpu,
+                           "parallelism": "tile-shard x%d%s" % (self.world, " + RCCL framebuffer reduce" if self.world > 1 else "")},
+                "roofline": roofline,
+                "cpu_baseline": cpu_baseline(a, scene, path, flat, w, h, spp, self.tmp) if cpu else None,
                 "kernels": kernels,
-                "rays_per_sample": round((cc["closest_rays"] + cc["shadow_rays"])/max(cc["samples"], 1), 3),
-                "nodes_per_ray": round(cc["nodes_visited"]/max(cc["closest_rays"] + cc["shadow_rays"], 1), 2),
-                "prims_per_ray": round(cc["prims_tested"]/max(cc["closest_rays"] + cc["shadow_rays"], 1), 2),
-                "bvh": {"nodes": int(flat.info.num_nodes), "records": int(flat.info.num_recs), "depth": int(flat.info.bvh_depth)},
+                "rays_per_sample": round(rays/max(cc["samples"], 1), 3),
+                "nodes_per_ray": round(cc["nodes_visited"]/rays, 2), "prims_per_ray": round(cc["prims_tested"]/rays, 2),
+                "bvh": {"nodes": int(flat.info.num_nodes), "records": int(flat.info.num_recs), "depth": int(flat.info.bvh_depth),
+                        "flat_list": is_flat},
                 "kernel_ms_total": round(timed["ms_total"], 2), "wavefront_iterations": int(timed["iterations"]),
                 "setup_s": {"flatten_and_bvh": round(t_flatten, 3), "upload": round(t_upload, 3)},
-                "result_ok": ok, "image_mean": image_mean,
+                "result_ok": ok, "image_mean": [round(float(v), 6) for v in img.mean(axis=(0, 1))],
             }
         lib.tghip_bind_framebuffer(ctx, None, None)
         lib.tghip_destroy(ctx)
         flat.close()
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        if rank == 0:
-            print(json.dumps(out))
-            if not ok:
-                raise SystemExit("bench.py: rendered image failed the sanity check")
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        return out
 
 
-def cpu_baseline(a, path, flat, w, h, tmp):
+def cpu_baseline(a, scene, path, flat, w, h, spp, tmp):
     """The reference's own CPU/Embree path (oracle/_ref/tungsten) on all host cores, same scene at the same
     resolution with fewer spp (bounded sample); falls back to the oracle port when the binary is absent."""
     import tungsten_amd as tg
     cores = os.cpu_count() or 1
     ref = os.path.join(ROOT, "oracle", "_ref", "tungsten")
-    # rough CPU rates (Msamples/s per core) to size the sample: cornell ~0.7, materialtest ~0.35
-    per_core = 0.7 if a.scene == "cornell" else 0.3
-    budget = a.cpu_seconds*per_core*cores*1e6
-    s_spp = int(max(1, min(a.spp, budget//(w*h))))
+    # rough CPU rates (Msamples/s per core) to size the sample: cornell ~0.7, materialtest ~0.3; the reference stops
+    # scaling long before 256 threads (its tile pool), so cap the estimate at 32 cores' worth
+    per_core = 0.7 if scene == "cornell" else 0.3
+    budget = a.cpu_seconds*per_core*min(cores, 32)*1e6
+    s_spp = int(max(1, min(spp, budget//(w*h))))
     if os.path.exists(ref) and os.access(ref, os.X_OK):
         try:
             t0 = time.time()
             p = subprocess.run([ref, "-t", str(cores), "-s", str(tg.DEFAULT_SEED), "--spp", str(s_spp),
-                                "-e", os.path.join(tmp, "cpu.pfm"), "-o", os.path.join(tmp, "cpu.png"), path],
+                                "-e", os.path.join(tmp, "cpu_%s.pfm" % scene), "-o", os.path.join(tmp, "cpu_%s.png" % scene), path],
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd=tmp, timeout=600)
             wall = time.time() - t0
             m = re.search(r"Render time\s+([0-9.eE+-]+)s", p.stdout)
@@ -296,6 +294,38 @@ def cpu_baseline(a, path, flat, w, h, tmp):
     secs = time.time() - t0
     return {"value": round(w*h*s_spp/secs*1e-6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "%dx%d @ %d spp of the same scene, oracle/oracle.c with OpenMP on %d threads, %.2f s" % (w, h, s_spp, cores, secs)}
+
+
+def main():
+    a = parse_args()
+    import scenes
+    b = Bench(a)
+    try:
+        w, h = [int(v) for v in a.res.split("x")]
+        spp = a.spp or (256 if a.scene == "cornell" else 64)
+        cpu = not a.no_cpu_baseline and b.world == 1
+        res = b.run(a.scene, w, h, spp, a.steps, a.warmup, cpu)
+        extra = None
+        if a.scene == "cornell" and b.world == 1 and not a.no_extra and scenes.have_materialtest():
+            # the scene BASELINE.json's metric names, on the same line (shorter run: 64 spp, 2 steps)
+            m = b.run("materialtest", 1280, 720, 64, 2, 1, cpu)
+            if b.rank == 0:
+                keys = ("value", "ms_per_step", "config", "roofline", "cpu_baseline", "kernels", "rays_per_sample", "nodes_per_ray",
+                        "prims_per_ray", "bvh", "result_ok")
+                extra = {"materialtest_1280x720_64spp": dict({k: m[k] for k in keys}, unit="Msamples/s", steps=2, warmup=1)}
+        if b.rank == 0:
+            out = {"metric": "Msamples/s (W*H*spp/s), path_tracer render loop", "value": res["value"], "unit": "Msamples/s",
+                   "n_gpus": b.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                   "data": "synthetic (scene shipped in-tree, fixed seed 0xBA5EBA11)"}
+            out.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step")})
+            if extra:
+                out["extra"] = extra
+            print(json.dumps(out))
+            if not res["result_ok"]:
+                raise SystemExit("bench.py: rendered image failed the sanity check")
+    finally:
+        b.close()
 
 
 if __name__ == "__main__":

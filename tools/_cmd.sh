@@ -1,3 +1,8 @@
-bash tools/gpu_tune.sh r1v materialtest 64 "max_slots=2097152" "max_slots=2097152"
-TUNGSTEN_AMD_LIB=$PWD/tungsten_amd/lib/libtungsten_hip_s2.so bash tools/gpu_tune.sh r1v materialtest 64 "max_slots=2097152" "max_slots=2097152 threads_shade_simple=128" "max_slots=2097152"
-bash tools/gpu_tune.sh r1v cornell 256 "max_slots=2097152"
+python bench.py 2>gpurun_out/bench_err.log | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+e = d.pop('extra', {})
+print(json.dumps(d)[:1800])
+for k, v in e.items(): print(k, json.dumps(v)[:1500])
+"
+tail -3 gpurun_out/bench_err.log
