@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "materialtest"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "materialtest", "mesh1m"])
     ap.add_argument("--res", default="1280x720")
     ap.add_argument("--spp", type=int, default=0, help="default: 256 (cornell) / 64 (materialtest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--opt", action="append", default=[], help="shim option key=value (tghip_set_option)")
+    ap.add_argument("--emulate-shards", type=int, default=0,
+                    help="development aid: on ONE GPU render only shard 0 of N tile shards (what each rank of an N-GPU run does)")
     return ap.parse_args()
 
 
@@ -132,6 +134,10 @@ class Bench(object):
                 raise SystemExit("bench.py: materialtest assets missing (oracle/_ref/data; run __graft_entry__.build() where the reference is mounted)")
             path = scenes.materialtest(self.tmp, resolution=(w, h), spp=spp)
             workload = "materialtest.json (3 meshes 80768 tris + quad, smooth_coat/rough_conductor/lambert, envmap MIS) %dx%d @ %d spp" % (w, h, spp)
+        elif scene == "mesh1m":
+            path = scenes.mesh1m(self.tmp, resolution=(w, h), spp=spp)
+            workload = ("BASELINE configs[3] on one GPU: procedurally generated 998 000-triangle mesh (fixed seed 1) + floor quad, rough_conductor, "
+                        "HDRI environment + MIS, %dx%d @ %d spp" % (w, h, spp))
         else:
             path = scenes.cornell(self.tmp, resolution=(w, h), spp=spp)
             workload = "BASELINE configs[1]: cornell-box (5 quads + 2 cubes + quad light, Lambert) %dx%d @ %d spp" % (w, h, spp)
@@ -158,6 +164,8 @@ class Bench(object):
         fb_cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
         check(lib.tghip_bind_framebuffer(ctx, fb_sum.data_ptr(), fb_cnt.data_ptr()), "tghip_bind_framebuffer")
         pass_desc = tgdist.shard_pass(self.rank, self.world, 0, spp, tg.DEFAULT_SEED)
+        if a.emulate_shards > 1 and self.world == 1:
+            pass_desc = tgdist.shard_pass(0, a.emulate_shards, 0, spp, tg.DEFAULT_SEED)
 
         def step():
             check(lib.tghip_clear_framebuffer(ctx), "tghip_clear_framebuffer")
@@ -190,7 +198,7 @@ class Bench(object):
             # sanity of the result of the last timed step (rank 0 holds the reduced image)
             cnt = fb_cnt.cpu().numpy()
             img = (fb_sum/fb_cnt.clamp(min=1).unsqueeze(-1)).cpu().numpy()
-            ok = bool((cnt == spp).all() and np.isfinite(img).all())
+            ok = bool(((cnt == spp).all() or a.emulate_shards > 1) and np.isfinite(img).all())
             value = float(w)*h*spp*steps/elapsed*1e-6
 
             # one untimed counting step: exact node / record visit counts of the same (deterministic) render
@@ -269,7 +277,7 @@ def cpu_baseline(a, scene, path, flat, w, h, spp, tmp):
     ref = os.path.join(ROOT, "oracle", "_ref", "tungsten")
     # rough CPU rates (Msamples/s per core) to size the sample: cornell ~0.7, materialtest ~0.3; the reference stops
     # scaling long before 256 threads (its tile pool), so cap the estimate at 32 cores' worth
-    per_core = 0.7 if scene == "cornell" else 0.3
+    per_core = 0.7 if scene == "cornell" else 0.3 if scene == "materialtest" else 0.15
     budget = a.cpu_seconds*per_core*min(cores, 32)*1e6
     s_spp = int(max(1, min(spp, budget//(w*h))))
     if os.path.exists(ref) and os.access(ref, os.X_OK):
@@ -303,6 +311,8 @@ def main():
     try:
         w, h = [int(v) for v in a.res.split("x")]
         spp = a.spp or (256 if a.scene == "cornell" else 64)
+        if a.scene == "mesh1m" and a.res == "1280x720":
+            w, h = 1920, 1080
         cpu = not a.no_cpu_baseline and b.world == 1
         res = b.run(a.scene, w, h, spp, a.steps, a.warmup, cpu)
         extra = None

@@ -149,3 +149,82 @@ GOLDEN_CASES = {
     "materialtest_rough_dielectric": (materialtest, dict(resolution=(48, 27), spp=4, edit=_mt_material(
         {"type": "rough_dielectric", "ior": 1.5, "distribution": "ggx", "roughness": 0.1, "albedo": 1}))),
 }
+
+
+# ---- BASELINE.json configs[3]: a procedurally generated ~1M-triangle mesh under an HDRI (or constant) environment ----
+def write_wo3(path, verts, tris):
+    """MeshIO .wo3 (io/MeshIO.cpp:12-28): u64 numVerts, Vertex{pos3, normal3, uv2} f32, u64 numTris, TriangleI{v0,v1,v2 u32, material i32}."""
+    import numpy as np
+    with open(path, "wb") as f:
+        f.write(np.uint64(len(verts)).tobytes())
+        f.write(np.ascontiguousarray(verts, np.float32).tobytes())
+        f.write(np.uint64(len(tris)).tobytes())
+        f.write(np.ascontiguousarray(tris, np.int32).tobytes())
+
+
+def displaced_sphere(n_lat=500, n_lon=1000, seed=1):
+    """Lat-long sphere of radius ~0.45 displaced by a fixed-seed sum of sines: 2*n_lat*n_lon - 2*n_lon triangles
+    (n_lat=500, n_lon=1000 -> 998 000), vertex normals from the analytic gradient direction (unnormalised mix), uv = (u, v)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    k = rs.randint(2, 9, size=(6, 2)).astype(np.float64)
+    ph = rs.rand(6)*6.283
+    amp = 0.02*rs.rand(6)
+    v = (np.arange(n_lat + 1)/n_lat)[:, None]
+    u = (np.arange(n_lon)/n_lon)[None, :]
+    theta, phi = v*np.pi, u*2*np.pi
+    r = 0.45 + sum(amp[i]*np.sin(k[i, 0]*theta + ph[i])*np.cos(k[i, 1]*phi) for i in range(6))
+    st, ct = np.sin(theta), np.cos(theta)
+    pos = np.stack([r*st*np.cos(phi), r*ct + 0.5, r*st*np.sin(phi)], axis=-1)
+    nrm = np.stack([st*np.cos(phi), ct + 0*phi, st*np.sin(phi)], axis=-1)
+    uv = np.stack([u + 0*v, v + 0*u], axis=-1)
+    verts = np.concatenate([pos, nrm, uv], axis=-1).reshape(-1, 8).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n_lat), np.arange(n_lon), indexing="ij")
+    a = i*n_lon + j
+    b = i*n_lon + (j + 1) % n_lon
+    c = (i + 1)*n_lon + j
+    d = (i + 1)*n_lon + (j + 1) % n_lon
+    t1 = np.stack([a, c, b, 0*a], axis=-1)[1:]            # the first latitude row is degenerate on top ...
+    t2 = np.stack([b, c, d, 0*a], axis=-1)[:-1]           # ... and the last at the bottom
+    tris = np.concatenate([t1.reshape(-1, 4), t2.reshape(-1, 4)]).astype(np.int32)
+    return verts, tris
+
+
+def mesh1m(tmpdir, resolution=(1920, 1080), spp=512, name="mesh1m.json", n_lat=500, n_lon=1000, **kw):
+    """~1M-triangle smooth mesh on a checkered floor, lit by the materialtest HDRI with MIS when its assets are
+    present (else a constant environment), rough-conductor material."""
+    import json
+    tmpdir = str(tmpdir)
+    wo3 = os.path.join(tmpdir, "blob_%d_%d.wo3" % (n_lat, n_lon))
+    if not os.path.exists(wo3):
+        verts, tris = displaced_sphere(n_lat, n_lon)
+        write_wo3(wo3, verts, tris)
+    env = {"name": "Env", "type": "infinite_sphere", "sample": True, "bsdf": {"albedo": 1, "type": "null"}, "emission": 1.0}
+    if have_materialtest():
+        link = os.path.join(tmpdir, "envmap.hdr")
+        if not os.path.exists(link):
+            os.symlink(os.path.join(MATERIALTEST_DIR, "envmap.hdr"), link)
+        env["emission"] = "envmap.hdr"
+    scene = {
+        "media": [],
+        "bsdfs": [dict({"name": "metal", "albedo": 1, "type": "rough_conductor", "distribution": "ggx", "roughness": 0.2}, **_CU),
+                  {"name": "floor", "type": "lambert", "albedo": dict(_CHECKER, res_u=20, res_v=20)}],
+        "primitives": [
+            {"name": "Floor", "type": "quad", "bsdf": "floor", "transform": {"position": [0, 0, 0], "scale": [6, 1, 6]}},
+            env,
+            {"name": "Blob", "type": "mesh", "file": os.path.basename(wo3), "smooth": True, "bsdf": "metal", "transform": {}},
+        ],
+        "camera": {"tonemap": "filmic", "resolution": list(resolution), "reconstruction_filter": "tent", "type": "pinhole", "fov": 35,
+                   "transform": {"position": [1.6, 1.3, 1.9], "look_at": [0, 0.45, 0], "up": [0, 1, 0]}},
+        "integrator": {"type": "path_tracer", "min_bounces": 0, "max_bounces": 64, "enable_consistency_checks": False,
+                       "enable_two_sided_shading": True, "enable_light_sampling": True},
+        "renderer": {"output_file": "", "hdr_output_file": "", "overwrite_output_files": True, "adaptive_sampling": False,
+                     "stratified_sampler": False, "scene_bvh": True, "spp": spp, "spp_step": kw.pop("spp_step", spp)},
+    }
+    path = os.path.join(tmpdir, name)
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
+
+
+GOLDEN_CASES["mesh1m"] = (mesh1m, dict(resolution=(48, 27), spp=4))

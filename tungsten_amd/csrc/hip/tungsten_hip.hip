@@ -1374,6 +1374,10 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if (sd->camera.res_x <= 0 || sd->camera.res_y <= 0) { ctx->error = "invalid camera resolution"; return TGHIP_E_INVALID; }
     if (sd->num_lights > 16) { ctx->error = "more than 16 sampled lights are not supported"; return TGHIP_E_UNSUPPORTED; }
     if (sd->num_objects >= (1u << 24)) { ctx->error = "too many objects"; return TGHIP_E_UNSUPPORTED; }
+    if (sd->num_recs >= (1u << 26) || sd->num_nodes >= (1u << 26)) {   // 64-B attribute / node records behind 32-bit byte offsets (at32)
+        ctx->error = "more than 2^26 primitive records or BVH nodes are not supported";
+        return TGHIP_E_UNSUPPORTED;
+    }
     int depth = bvhDepthOf(sd);
     if (depth < 0 || depth > TGHIP_MAX_BVH_DEPTH) { ctx->error = "malformed or too deep BVH"; return TGHIP_E_INVALID; }
     for (uint32_t i = 0; i < sd->num_bsdfs; ++i)
