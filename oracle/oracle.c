@@ -1140,6 +1140,46 @@ static int cube_test(const TgHipObject *o, const Ray *ray, float tmax, float *t,
     return 0;
 }
 
+/* Sphere::intersect (Sphere.cpp:69-94); radius in scale[0] */
+static int sphere_test(const TgHipObject *o, const Ray *ray, float tmax, float *t, int *backSide)
+{
+    v3 p = vsub(ray->o, ld3(o->pos));
+    float B = vdot(p, ray->d);
+    float C = vlensq(p) - o->scale[0]*o->scale[0];
+    float detSq = B*B - C;
+    if (detSq >= 0.0f) {
+        float det = sqrtf(detSq);
+        float tt = -B - det;
+        if (tt < tmax && tt > ray->tmin) { *t = tt; *backSide = 0; return 1; }
+        tt = -B + det;
+        if (tt < tmax && tt > ray->tmin) { *t = tt; *backSide = 1; return 1; }
+    }
+    return 0;
+}
+
+/* uv and normal of a point on a cube / sphere (Cube.cpp:157-170, Sphere.cpp:120-129) */
+static void cube_surface(const TgHipObject *o, v3 hp, v3 *n, float *u, float *v)
+{
+    v3 p = mat3_tmul(o->rot, vsub(hp, ld3(o->pos)));
+    float pa[3] = {p.x, p.y, p.z};
+    float ex[3] = {fabsf(p.x) - o->scale[0], fabsf(p.y) - o->scale[1], fabsf(p.z) - o->scale[2]};
+    int dim = ex[0] > ex[1] ? (ex[0] > ex[2] ? 0 : 2) : (ex[1] > ex[2] ? 1 : 2);   /* Vec::maxDim */
+    float nn[3] = {0.0f, 0.0f, 0.0f};
+    nn[dim] = pa[dim] < 0.0f ? -1.0f : 1.0f;
+    float uvw[3];
+    for (int i = 0; i < 3; ++i) uvw[i] = (pa[i]/o->scale[i])*0.5f + 0.5f;
+    *n = mat3_mul(o->rot, V(nn[0], nn[1], nn[2]));
+    *u = uvw[(dim + 1) % 3]; *v = uvw[(dim + 2) % 3];
+}
+static void sphere_surface(const TgHipObject *o, v3 hp, v3 *n, float *u, float *v)
+{
+    *n = vdivs(vsub(hp, ld3(o->pos)), o->scale[0]);
+    v3 localN = mat3_tmul(o->rot, *n);
+    *u = atan2f(localN.y, localN.x)*O_INV_TWO_PI + 0.5f;
+    *v = acosf(fclamp(localN.z, -1.0f, 1.0f))*O_INV_PI;
+    if (isnan(*u)) *u = 0.0f;
+}
+
 /* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113),
  * with exact division in place of rcp+Newton (:43-49).  Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c. */
 static int tri_test(const TgHipPrimRec *r, const Ray *ray, float tmax, float *t, float *u, float *v)
@@ -1187,6 +1227,7 @@ static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float 
     case TGHIP_REC_TRIANGLE: ok = tri_test(r, ray, *tmax, &t, &u, &v); break;
     case TGHIP_REC_QUAD: ok = quad_test(r, &s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &u, &v, &back); break;
     case TGHIP_REC_CUBE: ok = cube_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
+    case TGHIP_REC_SPHERE: ok = sphere_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
     default: break;
     }
     if (ok) { *tmax = t; hit->t = t; hit->u = u; hit->v = v; hit->rec = (int32_t)i; }
@@ -1270,21 +1311,18 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const TgH
         info->bsdf = o->bsdf;
         info->backSide = vdot(ray->d, ld3(o->normal)) >= 0.0f;
         break;
-    case TGHIP_REC_CUBE: {       /* Cube.cpp:157-170 */
-        v3 p = mat3_tmul(o->rot, vsub(info->p, ld3(o->pos)));
-        float pa[3] = {p.x, p.y, p.z};
-        float ex[3] = {fabsf(p.x) - o->scale[0], fabsf(p.y) - o->scale[1], fabsf(p.z) - o->scale[2]};
-        int dim = ex[0] > ex[1] ? (ex[0] > ex[2] ? 0 : 2) : (ex[1] > ex[2] ? 1 : 2);   /* Vec::maxDim */
-        float n[3] = {0.0f, 0.0f, 0.0f};
-        n[dim] = pa[dim] < 0.0f ? -1.0f : 1.0f;
-        float uvw[3];
-        for (int i = 0; i < 3; ++i) uvw[i] = (pa[i]/o->scale[i])*0.5f + 0.5f;
-        info->Ns = info->Ng = mat3_mul(o->rot, V(n[0], n[1], n[2]));
-        info->u = uvw[(dim + 1) % 3]; info->v = uvw[(dim + 2) % 3];
+    case TGHIP_REC_CUBE:         /* Cube.cpp:157-170 */
+        cube_surface(o, info->p, &info->Ng, &info->u, &info->v);
+        info->Ns = info->Ng;
         info->bsdf = o->bsdf;
         info->backSide = hit->u != 0.0f;
         break;
-    }
+    case TGHIP_REC_SPHERE:       /* Sphere.cpp:120-129 */
+        sphere_surface(o, info->p, &info->Ng, &info->u, &info->v);
+        info->Ns = info->Ng;
+        info->bsdf = o->bsdf;
+        info->backSide = hit->u != 0.0f;
+        break;
     default:
         info->Ng = info->Ns = V(0, 1, 0); info->u = info->v = 0; info->bsdf = o->bsdf; info->backSide = 0;
         break;
@@ -1394,11 +1432,13 @@ static v3 generalizedShadowRay(Ctx *c, Ray *ray, int endCap, int bounce)
 
 /* light.intersect + intersectionInfo + evalDirect for the light kinds in scope.
  * Returns 0 if the ray misses the light.  (Quad.cpp:71-131,235-238; InfiniteSphere.cpp:77-104,241-244) */
-typedef struct { float t, u, v; int backSide; v3 w; } LightHit;
+typedef struct { float t, u, v; int backSide; v3 w; v3 n; v3 o; } LightHit;   /* n: surface normal (cube), o: ray origin */
 static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, LightHit *lh)
 {
     const TgHipObject *o = &s->objects[objIdx];
     lh->w = ray->d;
+    lh->o = ray->o;
+    lh->n = V(0.0f, 0.0f, 0.0f);
     if (o->type == TGHIP_OBJ_QUAD) {
         TgHipPrimRec r;
         memset(&r, 0, sizeof(r));
@@ -1408,6 +1448,14 @@ static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, 
     } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE) {
         lh->t = ray->tmax; lh->backSide = 0;
         inf_directionToUV(o, ray->d, &lh->u, &lh->v, NULL);
+        return 1;
+    } else if (o->type == TGHIP_OBJ_CUBE) {            /* Cube::intersect + intersectionInfo */
+        if (!cube_test(o, ray, ray->tmax, &lh->t, &lh->backSide)) return 0;
+        cube_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), &lh->n, &lh->u, &lh->v);
+        return 1;
+    } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere::intersect + intersectionInfo */
+        if (!sphere_test(o, ray, ray->tmax, &lh->t, &lh->backSide)) return 0;
+        sphere_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), &lh->n, &lh->u, &lh->v);
         return 1;
     }
     return 0;
@@ -1428,6 +1476,13 @@ static float light_directPdf(const TgHipSceneDesc *s, int objIdx, const LightHit
         float cosTheta = fabsf(vdot(n, lh->w));
         float t = vdot(n, vsub(ld3(o->base), p))/vdot(n, lh->w);
         return t*t/(cosTheta*o->area);
+    } else if (o->type == TGHIP_OBJ_CUBE) {            /* Cube.cpp:291-295 */
+        v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
+        return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
+    } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere.cpp:216-222 */
+        float dist = vlen(vsub(ld3(o->pos), p));
+        float cosTheta = sqrtf(fmaxf(dist*dist - o->scale[0]*o->scale[0], 0.0f))/dist;
+        return O_INV_TWO_PI/(1.0f - cosTheta);         /* SampleWarp::uniformSphericalCapPdf */
     } else {
         const TgHipTexture *t = &s->textures[o->emission];
         if (t->type != TGHIP_TEX_BITMAP)       /* _emission->isConstant() (checker envmaps are outside the scope) */
@@ -1454,6 +1509,53 @@ static int light_sampleDirect(const TgHipSceneDesc *s, int objIdx, v3 p, Sampler
         float cosTheta = -vdot(n, dd);
         *pdf = rSq/(cosTheta*o->area);
         *d = dd;
+        return 1;
+    } else if (o->type == TGHIP_OBJ_CUBE) {            /* Cube::sampleDirect / samplePosition / sampleFace (Cube.cpp:229-245, 189-213, 42-55) */
+        float u = next1D(smp);
+        float uOrig = u;
+        int dim;
+        u *= o->face_cdf[2];
+        if (u < o->face_cdf[0]) { u /= o->face_cdf[0]; dim = 0; }
+        else if (u < o->face_cdf[1]) { u = (u - o->face_cdf[0])/(o->face_cdf[1] - o->face_cdf[0]); dim = 1; }
+        else { u = (u - o->face_cdf[1])/(o->face_cdf[2] - o->face_cdf[1]); dim = 2; }
+        (void)uOrig;
+        int sAx = (dim + 1) % 3, tAx = (dim + 2) % 3;
+        float xi0 = next1D(smp), xi1 = next1D(smp);
+        float nn[3] = {0.0f, 0.0f, 0.0f}, pp[3] = {0.0f, 0.0f, 0.0f};
+        nn[dim] = u < 0.5f ? -1.0f : 1.0f;             /* u is the value sampleFace left behind (it takes u by reference) */
+        pp[dim] = nn[dim]*o->scale[dim];
+        pp[sAx] = (xi0*2.0f - 1.0f)*o->scale[sAx];
+        pp[tAx] = (xi1*2.0f - 1.0f)*o->scale[tAx];
+        v3 q = vadd(mat3_mul(o->rot, V(pp[0], pp[1], pp[2])), ld3(o->pos));
+        v3 Ng = mat3_mul(o->rot, V(nn[0], nn[1], nn[2]));
+        v3 L = vsub(q, p);
+        float rSq = vlensq(L);
+        *dist = sqrtf(rSq);
+        *d = vdivs(L, *dist);
+        float cosTheta = -vdot(Ng, *d);
+        if (cosTheta <= 0.0f)
+            return 0;
+        *pdf = rSq/(cosTheta*o->area);
+        return 1;
+    } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere::sampleDirect (Sphere.cpp:173-194) */
+        v3 L = vsub(ld3(o->pos), p);
+        float dd = vlen(L);
+        float C = dd*dd - o->scale[0]*o->scale[0];
+        if (C <= 0.0f)
+            return 0;
+        L = vnorm(L);
+        float cosTheta = sqrtf(C)/dd;
+        float xi0 = next1D(smp), xi1 = next1D(smp);
+        float phi = xi0*O_TWO_PI;                      /* SampleWarp::uniformSphericalCap (SampleWarp.hpp:119-129) */
+        float z = xi1*(1.0f - cosTheta) + cosTheta;
+        float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
+        v3 local = V(cosf(phi)*r, sinf(phi)*r, z);
+        float B = dd*local.z;
+        float det = sqrtf(fmaxf(B*B - C, 0.0f));
+        *dist = B - det;
+        Frame frame = frame_from_normal(L);
+        *d = toGlobal(&frame, local);
+        *pdf = O_INV_TWO_PI/(1.0f - cosTheta);
         return 1;
     } else {
         const TgHipTexture *t = &s->textures[o->emission];
@@ -1487,6 +1589,17 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
         v3 n0 = vnorm(vcross(R0, R1)), n1 = vnorm(vcross(R1, R2)), n2 = vnorm(vcross(R2, R3)), n3 = vnorm(vcross(R3, R0));
         float Q = acosf(vdot(n0, n1)) + acosf(vdot(n1, n2)) + acosf(vdot(n2, n3)) + acosf(vdot(n3, n0));
         return (O_TWO_PI - fabsf(Q))*vmax3(ld3(s->textures[o->emission].avg));
+    } else if (o->type == TGHIP_OBJ_CUBE) {            /* Cube.cpp:326-330 */
+        v3 lp = mat3_tmul(o->rot, vsub(p, ld3(o->pos)));
+        v3 ap = V(fmaxf(fabsf(lp.x), 0.0f), fmaxf(fabsf(lp.y), 0.0f), fmaxf(fabsf(lp.z), 0.0f));
+        float dSq = vlensq(ap);
+        return vmax3(ld3(s->textures[o->emission].avg))*o->face_cdf[2]/dSq;
+    } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere.cpp:266-271, 33-40 */
+        if (o->emission < 0) return 0.0f;
+        v3 L = vsub(ld3(o->pos), p);
+        float dd = vlen(L);
+        float cosTheta = sqrtf(fmaxf(dd*dd - o->scale[0]*o->scale[0], 0.0f))/dd;
+        return O_TWO_PI*(1.0f - cosTheta)*vmax3(ld3(s->textures[o->emission].avg));
     } else {
         if (o->emission < 0 || !(o->flags & TGHIP_OBJF_SAMPLE)) return 0.0f;
         return O_TWO_PI*vmax3(ld3(s->textures[o->emission].avg));

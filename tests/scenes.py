@@ -93,9 +93,22 @@ ZOO = {
 }
 
 
+def _zoo_d_edit(scene):
+    """Sphere primitive + sphere and cube emitters as sampled lights (a16): a glass sphere, an
+    emissive sphere and an emissive cube next to the quad light (three lights -> chooseLight's pdf loop)."""
+    scene["bsdfs"].append({"name": "glass", "type": "dielectric", "ior": 1.5, "albedo": 1})
+    scene["primitives"] += [
+        {"name": "ball", "type": "sphere", "bsdf": "glass", "transform": {"position": [0.45, 0.95, 0.35], "scale": 0.28, "rotation": [10, 40, 0]}},
+        {"name": "bulb", "type": "sphere", "bsdf": "light", "emission": {"type": "checker", "on_color": [6, 3, 1], "off_color": [1, 3, 6], "res_u": 6, "res_v": 3},
+         "transform": {"position": [-0.55, 1.45, 0.1], "scale": 0.12, "rotation": [0, 25, 15]}},
+        {"name": "brick", "type": "cube", "bsdf": "light", "emission": [2, 5, 3],
+         "transform": {"position": [0.6, 0.12, 0.6], "scale": [0.2, 0.12, 0.16], "rotation": [0, 30, 0]}},
+    ]
+
+
 def cornell_zoo(tmpdir, which, **kw):
     """Cornell box with the named bsdfs replaced (same geometry, same light)."""
-    repl = ZOO[which]
+    repl = ZOO.get(which, {})
 
     def edit(scene):
         for i, b in enumerate(scene["bsdfs"]):
@@ -107,6 +120,8 @@ def cornell_zoo(tmpdir, which, **kw):
 
     def both(scene):
         edit(scene)
+        if which == "zoo_d":
+            _zoo_d_edit(scene)
         if user:
             user(scene)
     return variant(CORNELL, str(tmpdir), kw.pop("name", which + ".json"), edit=both, **kw)
@@ -142,6 +157,7 @@ GOLDEN_CASES = {
     "zoo_a": (lambda t, **kw: cornell_zoo(t, "zoo_a", **kw), dict(resolution=(48, 27), spp=8)),
     "zoo_b": (lambda t, **kw: cornell_zoo(t, "zoo_b", **kw), dict(resolution=(48, 27), spp=8)),
     "zoo_c": (lambda t, **kw: cornell_zoo(t, "zoo_c", **kw), dict(resolution=(48, 27), spp=8)),
+    "zoo_d": (lambda t, **kw: cornell_zoo(t, "zoo_d", **kw), dict(resolution=(48, 27), spp=8)),
     "materialtest": (materialtest, dict(resolution=(64, 36), spp=4)),
     "materialtest_dielectric": (materialtest, dict(resolution=(48, 27), spp=4, edit=_mt_material({"type": "dielectric", "ior": 1.5, "albedo": 1}))),
     "materialtest_transparency": (materialtest, dict(resolution=(48, 27), spp=4, edit=_mt_material(

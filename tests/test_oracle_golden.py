@@ -54,7 +54,7 @@ def _needs_materialtest(name):
 
 
 # fraction of samples allowed to diverge (chaotic path divergence, see module docstring)
-DIVERGE = {"zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
+DIVERGE = {"zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "zoo_d": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
            "materialtest_rough_dielectric": 2e-2, "materialtest_transparency": 5e-3, "cornell_two_lights": 1e-3, "mesh1m": 1e-2}
 
 
@@ -82,7 +82,7 @@ def test_oracle_matches_reference_per_sample(name, tmp_path):
     assert np.allclose(got.mean(axis=(0, 1, 2)), ref.mean(axis=(0, 1, 2)), rtol=0.03)
 
 
-@pytest.mark.parametrize("scene", ["cornell", "materialtest", "zoo_a", "zoo_b", "zoo_c"])
+@pytest.mark.parametrize("scene", ["cornell", "materialtest", "zoo_a", "zoo_b", "zoo_c", "zoo_d"])
 def test_oracle_units(scene, tmp_path):
     _needs_materialtest(scene)
     with open(os.path.join(G, scene + "_units.json")) as f:

@@ -1,8 +1,3 @@
-for n in 1 2 4 8; do
-python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extra --emulate-shards $n 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print('shards $n: ms_per_step %.2f  iters %d' % (d['ms_per_step'], d['wavefront_iterations']))"
-python bench.py --scene materialtest --steps 4 --warmup 1 --no-cpu-baseline --no-extra --emulate-shards $n 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print('  materialtest shards $n: ms_per_step %.2f  iters %d' % (d['ms_per_step'], d['wavefront_iterations']))"
-done
+python -m pytest tests -m gpu -q -x --timeout 900 2>&1 | tail -8
+bash tools/gpu_tune.sh r1w cornell 256 "max_slots=2097152"
+bash tools/gpu_tune.sh r1w materialtest 64 "max_slots=2097152"

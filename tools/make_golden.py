@@ -73,7 +73,7 @@ def main():
             samples(p, w, h, sc["renderer"]["spp"], g(name + "_samples.npz"))
         units(scenes.cornell(tmp, name="u_cornell.json", resolution=(96, 54), spp=1), g("cornell_units.json"))
         units(scenes.materialtest(tmp, name="u_materialtest.json", resolution=(96, 54), spp=1), g("materialtest_units.json"))
-        for which in ("zoo_a", "zoo_b", "zoo_c"):
+        for which in ("zoo_a", "zoo_b", "zoo_c", "zoo_d"):
             units(scenes.cornell_zoo(tmp, which, name="u_%s.json" % which, resolution=(96, 54), spp=1), g(which + "_units.json"))
         converged(scenes.cornell(tmp, name="c_cornell.json", resolution=(64, 36), spp=4096), 4096, g("cornell_converged.npz"), tmp)
         converged(scenes.materialtest(tmp, name="c_materialtest.json", resolution=(64, 36), spp=1024), 1024,

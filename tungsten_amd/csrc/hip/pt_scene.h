@@ -45,7 +45,8 @@ struct DeviceScene {
 #define FEAT_INFINITE   (1u << 25)   /* infinite-sphere emitters                                       */
 #define FEAT_MULTILIGHT (1u << 26)   /* more than one sampled light (TraceBase::chooseLight's pdf loop) */
 #define FEAT_TRIANGLES  (1u << 27)   /* triangle records (attribute gather, smooth normals)            */
-#define FEAT_ALL        (FEAT_BITMAP | FEAT_INFINITE | FEAT_MULTILIGHT | FEAT_TRIANGLES)
+#define FEAT_SOLIDS     (1u << 28)   /* sphere records; sphere / cube emitters as sampled lights       */
+#define FEAT_ALL        (FEAT_BITMAP | FEAT_INFINITE | FEAT_MULTILIGHT | FEAT_TRIANGLES | FEAT_SOLIDS)
 
 // ---------------------------------------------------------------------------------------------
 // Textures (ConstantTexture, CheckerTexture.cpp:64-69, BitmapTexture.cpp:298-352)
@@ -958,6 +959,49 @@ PT_DEV bool cubeTest(OP op, const RayD &ray, float tmax, float &t, bool &backSid
     return false;
 }
 
+/* Sphere::intersect (Sphere.cpp:69-94); radius in scale[0] */
+template<typename OP>
+PT_DEV bool sphereTest(OP op, const RayD &ray, float tmax, float &t, bool &backSide)
+{
+    const auto &o = *op;
+    f3 p = ray.o - ld3(o.pos);
+    float B = dot(p, ray.d);
+    float C = lengthSq(p) - o.scale[0]*o.scale[0];
+    float detSq = B*B - C;
+    if (detSq >= 0.0f) {
+        float det = sqrtf(detSq);
+        float tt = -B - det;
+        if (tt < tmax && tt > ray.tmin) { t = tt; backSide = false; return true; }
+        tt = -B + det;
+        if (tt < tmax && tt > ray.tmin) { t = tt; backSide = true; return true; }
+    }
+    return false;
+}
+
+/* normal and uv of a point on a cube / sphere (Cube.cpp:157-170, Sphere.cpp:120-129) */
+PT_DEV void cubeSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v)
+{
+    f3 p = mat3TMul(o.rot, hp - ld3(o.pos));
+    float pa[3] = {p.x, p.y, p.z};
+    float ex[3] = {fabsf(p.x) - o.scale[0], fabsf(p.y) - o.scale[1], fabsf(p.z) - o.scale[2]};
+    int dim = ex[0] > ex[1] ? (ex[0] > ex[2] ? 0 : 2) : (ex[1] > ex[2] ? 1 : 2);
+    float nn[3] = {0.0f, 0.0f, 0.0f};
+    nn[dim] = pa[dim] < 0.0f ? -1.0f : 1.0f;
+    float uvw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) uvw[i] = (pa[i]/o.scale[i])*0.5f + 0.5f;
+    n = mat3Mul(o.rot, mk3(nn[0], nn[1], nn[2]));
+    u = uvw[(dim + 1) % 3]; v = uvw[(dim + 2) % 3];
+}
+PT_DEV void sphereSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v)
+{
+    n = (hp - ld3(o.pos))/o.scale[0];
+    f3 localN = mat3TMul(o.rot, n);
+    u = atan2f(localN.y, localN.x)*PT_INV_TWO_PI + 0.5f;
+    v = acosf(clampf(localN.z, -1.0f, 1.0f))*PT_INV_PI;
+    if (isnan(u)) u = 0.0f;
+}
+
 /* Tests record `ri` against the ray; on a hit updates (tmax, hit) -- the leaf body of both traversal kernels.
  * UNIFORM: `ri` is the same for every lane (flat-list traversal), so the record and its object are fetched
  * through the constant address space, i.e. with scalar loads. */
@@ -987,8 +1031,11 @@ PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
         if (UNIFORM) ok = cubeTest(asConst(s.objects) + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
         else         ok = cubeTest(s.objects + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
         u = back ? 1.0f : 0.0f;
-    } else {
-        ok = false;
+    } else {                                           /* TGHIP_REC_SPHERE */
+        bool back;
+        if (UNIFORM) ok = sphereTest(asConst(s.objects) + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
+        else         ok = sphereTest(s.objects + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
+        u = back ? 1.0f : 0.0f;
     }
     if (ok) {
         tmax = t;
@@ -1046,18 +1093,14 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         info.u = hit.y; info.v = hit.z;
         info.bsdf = o.bsdf;
         info.backSide = dot(ray.d, info.Ng) >= 0.0f;
-    } else {                                           /* Cube.cpp:157-170 */
-        f3 p = mat3TMul(o.rot, info.p - ld3(o.pos));
-        float pa[3] = {p.x, p.y, p.z};
-        float ex[3] = {fabsf(p.x) - o.scale[0], fabsf(p.y) - o.scale[1], fabsf(p.z) - o.scale[2]};
-        int dim = ex[0] > ex[1] ? (ex[0] > ex[2] ? 0 : 2) : (ex[1] > ex[2] ? 1 : 2);
-        float n[3] = {0.0f, 0.0f, 0.0f};
-        n[dim] = pa[dim] < 0.0f ? -1.0f : 1.0f;
-        float uvw[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) uvw[i] = (pa[i]/o.scale[i])*0.5f + 0.5f;
-        info.Ns = info.Ng = mat3Mul(o.rot, mk3(n[0], n[1], n[2]));
-        info.u = uvw[(dim + 1) % 3]; info.v = uvw[(dim + 2) % 3];
+    } else if (!(M & FEAT_SOLIDS) || kind == TGHIP_REC_CUBE) {   /* Cube.cpp:157-170 */
+        cubeSurface(o, info.p, info.Ng, info.u, info.v);
+        info.Ns = info.Ng;
+        info.bsdf = o.bsdf;
+        info.backSide = hit.y != 0.0f;
+    } else {                                           /* Sphere.cpp:120-129 */
+        sphereSurface(o, info.p, info.Ng, info.u, info.v);
+        info.Ns = info.Ng;
         info.bsdf = o.bsdf;
         info.backSide = hit.y != 0.0f;
     }
@@ -1081,18 +1124,29 @@ PT_DEV f3 infUvToDirection(const TgHipObject &o, float u, float v, float &sinThe
     return mat3Mul(o.rot, mk3(cosf(phi)*sinTheta, -cosf(theta), sinf(phi)*sinTheta));
 }
 
-struct LightHit { float t, u, v; bool backSide; };
+struct LightHit { float t, u, v; bool backSide; f3 n; };   /* n: surface normal at the hit (cube lights) */
 
 /* light.intersect(ray) + intersectionInfo: analytic hit test that precedes the shadow ray (TraceBase.cpp:155-162) */
 template<uint32_t M>
 PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, LightHit &lh)
 {
     const TgHipObject &o = s.objects[objIdx];
-    if (!(M & FEAT_INFINITE) || o.type == TGHIP_OBJ_QUAD) {
+    lh.n = splat3(0.0f);
+    if (!(M & (FEAT_INFINITE | FEAT_SOLIDS)) || o.type == TGHIP_OBJ_QUAD) {
         f3 n = ld3(o.normal);
         if (!quadTest(ld3(o.base), ld3(o.edge0), ld3(o.edge1), o.inv_uv_sq[0], o.inv_uv_sq[1], n, ray, ray.tmax, lh.t, lh.u, lh.v))
             return false;
         lh.backSide = dot(ray.d, n) >= 0.0f;
+        return true;
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube::intersect + intersectionInfo */
+        if (!cubeTest(&o, ray, ray.tmax, lh.t, lh.backSide)) return false;
+        cubeSurface(o, ray.o + ray.d*lh.t, lh.n, lh.u, lh.v);
+        return true;
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_SPHERE) {     /* Sphere::intersect + intersectionInfo */
+        if (!sphereTest(&o, ray, ray.tmax, lh.t, lh.backSide)) return false;
+        sphereSurface(o, ray.o + ray.d*lh.t, lh.n, lh.u, lh.v);
         return true;
     }
     float sinTheta;
@@ -1107,15 +1161,25 @@ PT_DEV f3 lightEvalDirect(const DeviceScene &s, int objIdx, float u, float v, bo
     if (o.emission < 0 || backSide) return splat3(0.0f);
     return textureEval<M>(s, o.emission, u, v);
 }
+/* directPdf of the light for direction w from p; lh = lightIntersect's result for that ray */
 template<uint32_t M>
-PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p)
+PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p, const LightHit &lh)
 {
     const TgHipObject &o = s.objects[objIdx];
-    if (!(M & FEAT_INFINITE) || o.type == TGHIP_OBJ_QUAD) {
+    if (!(M & (FEAT_INFINITE | FEAT_SOLIDS)) || o.type == TGHIP_OBJ_QUAD) {
         f3 n = ld3(o.normal);
         float cosTheta = fabsf(dot(n, w));
         float t = dot(n, ld3(o.base) - p)/dot(n, w);
         return t*t/(cosTheta*o.area);
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube.cpp:291-295 */
+        f3 hp = p + w*lh.t;
+        return lengthSq(p - hp)/(-dot(w, lh.n)*o.area);
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_SPHERE) {     /* Sphere.cpp:216-222 */
+        float dist = length(ld3(o.pos) - p);
+        float cosTheta = sqrtf(fmaxf(dist*dist - o.scale[0]*o.scale[0], 0.0f))/dist;
+        return PT_INV_TWO_PI/(1.0f - cosTheta);
     }
     const TgHipTexture &t = s.textures[o.emission];
     if (!(M & FEAT_BITMAP) || t.type != TGHIP_TEX_BITMAP)
@@ -1128,6 +1192,53 @@ template<uint32_t M>
 PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, f3 &d, float &dist, float &pdf)
 {
     const TgHipObject &o = s.objects[objIdx];
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube::sampleDirect / samplePosition / sampleFace (Cube.cpp:229-245,189-213,42-55) */
+        float u = rngNext1D(rng);
+        int dim;
+        u *= o.face_cdf[2];
+        if (u < o.face_cdf[0]) { u /= o.face_cdf[0]; dim = 0; }
+        else if (u < o.face_cdf[1]) { u = (u - o.face_cdf[0])/(o.face_cdf[1] - o.face_cdf[0]); dim = 1; }
+        else { u = (u - o.face_cdf[1])/(o.face_cdf[2] - o.face_cdf[1]); dim = 2; }
+        float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
+        float sgn = u < 0.5f ? -1.0f : 1.0f;
+        float a = (xi0*2.0f - 1.0f), b = (xi1*2.0f - 1.0f);
+        // p[dim] = sgn*scale[dim], p[(dim+1)%3] = a*scale[..], p[(dim+2)%3] = b*scale[..]
+        f3 pp = dim == 0 ? mk3(sgn*o.scale[0], a*o.scale[1], b*o.scale[2])
+              : dim == 1 ? mk3(b*o.scale[0], sgn*o.scale[1], a*o.scale[2])
+                         : mk3(a*o.scale[0], b*o.scale[1], sgn*o.scale[2]);
+        f3 nn = dim == 0 ? mk3(sgn, 0.0f, 0.0f) : dim == 1 ? mk3(0.0f, sgn, 0.0f) : mk3(0.0f, 0.0f, sgn);
+        f3 q = mat3Mul(o.rot, pp) + ld3(o.pos);
+        f3 Ng = mat3Mul(o.rot, nn);
+        f3 L = q - p;
+        float rSq = lengthSq(L);
+        dist = sqrtf(rSq);
+        d = L/dist;
+        float cosTheta = -dot(Ng, d);
+        if (cosTheta <= 0.0f)
+            return false;
+        pdf = rSq/(cosTheta*o.area);
+        return true;
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_SPHERE) {     /* Sphere::sampleDirect (Sphere.cpp:173-194) */
+        f3 L = ld3(o.pos) - p;
+        float dd = length(L);
+        float C = dd*dd - o.scale[0]*o.scale[0];
+        if (C <= 0.0f)
+            return false;
+        L = normalized(L);
+        float cosTheta = sqrtf(C)/dd;
+        float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
+        float phi = xi0*PT_TWO_PI;                             /* SampleWarp::uniformSphericalCap */
+        float z = xi1*(1.0f - cosTheta) + cosTheta;
+        float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
+        f3 local = mk3(cosf(phi)*r, sinf(phi)*r, z);
+        float B = dd*local.z;
+        float det = sqrtf(fmaxf(B*B - C, 0.0f));
+        dist = B - det;
+        d = toGlobal(frameFromNormal(L), local);
+        pdf = PT_INV_TWO_PI/(1.0f - cosTheta);
+        return true;
+    }
     if (!(M & FEAT_INFINITE) || o.type == TGHIP_OBJ_QUAD) {
         f3 n = ld3(o.normal);
         if (dot(n, p - ld3(o.base)) <= 0.0f)
@@ -1161,6 +1272,17 @@ template<uint32_t M>
 PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
 {
     const TgHipObject &o = s.objects[objIdx];
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube.cpp:326-330 */
+        f3 lp = mat3TMul(o.rot, p - ld3(o.pos));
+        f3 ap = mk3(fmaxf(fabsf(lp.x), 0.0f), fmaxf(fabsf(lp.y), 0.0f), fmaxf(fabsf(lp.z), 0.0f));
+        return max3(ld3(s.textures[o.emission].avg))*o.face_cdf[2]/lengthSq(ap);
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_SPHERE) {     /* Sphere.cpp:266-271, 33-40 */
+        if (o.emission < 0) return 0.0f;
+        float dd = length(ld3(o.pos) - p);
+        float cosTheta = sqrtf(fmaxf(dd*dd - o.scale[0]*o.scale[0], 0.0f))/dd;
+        return PT_TWO_PI*(1.0f - cosTheta)*max3(ld3(s.textures[o.emission].avg));
+    }
     if (!(M & FEAT_INFINITE) || o.type == TGHIP_OBJ_QUAD) {
         if (o.emission < 0) return 0.0f;
         f3 R0 = ld3(o.base) - p;

@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                             f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
                                             if (!isZero(e)) {
                                                 f3 bsdfF = e*ev.weight;
-                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightDirectPdf<M>(s, light, wog, info.p));
+                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightDirectPdf<M>(s, light, wog, info.p, lh));
                                                 if (FUSE & FUSE_SHADOW) {
                                                     sr.tmax = lh.t;
                                                     fusedShadow++;
@@ -1382,11 +1382,12 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if (depth < 0 || depth > TGHIP_MAX_BVH_DEPTH) { ctx->error = "malformed or too deep BVH"; return TGHIP_E_INVALID; }
     for (uint32_t i = 0; i < sd->num_bsdfs; ++i)
         if (bsdfDepth(sd, int(i), 0) > PT_MAX_BSDF_DEPTH) { ctx->error = "BSDF nesting deeper than 3 is not supported"; return TGHIP_E_UNSUPPORTED; }
-    for (uint32_t i = 0; i < sd->num_recs; ++i)
-        if (TGHIP_REC_KIND(sd->recs[i].meta) == TGHIP_REC_SPHERE) { ctx->error = "sphere primitives are a 'next' row (SURVEY.md 8f4)"; return TGHIP_E_UNSUPPORTED; }
     for (uint32_t i = 0; i < sd->num_lights; ++i) {
         int t = sd->objects[sd->lights[i]].type;
-        if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE) { ctx->error = "only quad and infinite_sphere emitters are sampled"; return TGHIP_E_UNSUPPORTED; }
+        if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE) {
+            ctx->error = "only quad, cube, sphere and infinite_sphere emitters are sampled (mesh emitters are not)";
+            return TGHIP_E_UNSUPPORTED;
+        }
     }
 
     if (ctx->stream) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1428,7 +1429,9 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         }
         bool lean = sd->num_infinite_lights == 0 && sd->num_lights <= 1;
         for (uint32_t i = 0; i < sd->num_textures && lean; ++i) lean = sd->textures[i].type != TGHIP_TEX_BITMAP;
-        for (uint32_t i = 0; i < sd->num_recs && lean; ++i) lean = TGHIP_REC_KIND(sd->recs[i].meta) != TGHIP_REC_TRIANGLE;
+        for (uint32_t i = 0; i < sd->num_recs && lean; ++i)
+            lean = TGHIP_REC_KIND(sd->recs[i].meta) == TGHIP_REC_QUAD || TGHIP_REC_KIND(sd->recs[i].meta) == TGHIP_REC_CUBE;
+        for (uint32_t i = 0; i < sd->num_lights && lean; ++i) lean = sd->objects[sd->lights[i]].type == TGHIP_OBJ_QUAD;
         ctx->leanScene = lean;
         if ((rc = uploadArray(ctx, ctx->sceneMem, recClass.data(), recClass.size(), &s.rec_class)) != TGHIP_OK) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // recClass goes out of scope

@@ -157,9 +157,9 @@ void TraceableScene::flatten()
 
         if (emissive) {
             if (p.isSamplable()) {
-                if (p.type == Primitive::Mesh || p.type == Primitive::Sphere || p.type == Primitive::Cube)
-                    throw std::runtime_error("emissive '" + p.name + "': mesh/sphere/cube emitters are not yet inside the "
-                                             "path_tracer_hip hot-path scope (quad and infinite_sphere lights are)");
+                if (p.type == Primitive::Mesh)
+                    throw std::runtime_error("emissive '" + p.name + "': mesh emitters are not yet inside the path_tracer_hip "
+                                             "hot-path scope (quad, cube, sphere and infinite_sphere lights are)");
                 o.light = int32_t(_lights.size());
                 _lights.push_back(int32_t(pi));
             }
