@@ -9,17 +9,17 @@ timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > $out/pytest.log 
 tail -5 $out/pytest.log
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
-for scene in cornell materialtest; do
-  spp=256; [ $scene = materialtest ] && spp=64
+for scene in cornell materialtest mesh1m; do
+  spp=256; [ $scene = materialtest ] && spp=64; [ $scene = mesh1m ] && spp=32
   echo "== bench $scene"
-  timeout 600 python bench.py --scene $scene --spp $spp > $out/bench_$scene.json 2> $out/bench_$scene.err; echo "rc=$?"; cat $out/bench_$scene.json; tail -3 $out/bench_$scene.err
+  timeout 600 python bench.py --scene $scene --spp $spp --no-extra > $out/bench_$scene.json 2> $out/bench_$scene.err; echo "rc=$?"; cat $out/bench_$scene.json; tail -3 $out/bench_$scene.err
   echo "== rocprof stats $scene"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$scene -o stats -- python bench.py --scene $scene --spp $spp --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing > $out/prof_$scene.log 2>&1; echo "rc=$?"
   f=$(find $out/prof_$scene -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/${scene}_kernel_stats.csv && head -8 $f
   find $out/prof_$scene -name '*kernel_trace.csv' -delete; find $out/prof_$scene -name '*.db' -delete
   echo "== rocprof pmc $scene"
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${scene}_$c -o pmc -- python bench.py --scene $scene --spp 16 --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-kernel-timing > $out/pmc_${scene}_$c.log 2>&1; echo "$c rc=$?"
+    timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${scene}_$c -o pmc -- python bench.py --scene $scene --spp $(( spp / 4 )) --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-kernel-timing > $out/pmc_${scene}_$c.log 2>&1; echo "$c rc=$?"
   done
   ff=$(find $out/pmc_${scene}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
   fw=$(find $out/pmc_${scene}_WRITE_SIZE -name '*counter_collection.csv' | head -1)

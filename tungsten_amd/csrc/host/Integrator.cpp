@@ -162,12 +162,20 @@ void PathTraceHipIntegrator::startRender(std::function<void()> completionCallbac
     }
     _imageDirty = true;
     _worker = std::thread([this, completionCallback]() {
+        // one host thread per device drives that device's wavefront loop (tghip_wait blocks until the shard is
+        // done; different handles may be driven from different threads, include/tungsten_hip.h)
+        std::vector<int> rcs(_ctxs.size(), TGHIP_OK);
+        std::vector<std::thread> drivers;
+        for (size_t d = 1; d < _ctxs.size(); ++d)
+            drivers.emplace_back([this, d, &rcs]() { rcs[d] = tghip_wait(_ctxs[d]); });
+        rcs[0] = tghip_wait(_ctxs[0]);
+        for (std::thread &t : drivers)
+            t.join();
         try {
-            for (tghip_ctx *ctx : _ctxs) {
-                int rc = tghip_wait(ctx);
-                if (rc == TGHIP_E_ABORTED)
+            for (size_t d = 0; d < _ctxs.size(); ++d) {
+                if (rcs[d] == TGHIP_E_ABORTED)
                     return;   // no finisher / callback on abort (TaskGroup.hpp:33-41,77-83)
-                check(rc, ctx, "tghip_wait");
+                check(rcs[d], _ctxs[d], "tghip_wait");
             }
         } catch (...) {
             _workerError = std::current_exception();
