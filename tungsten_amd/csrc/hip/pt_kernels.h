@@ -178,24 +178,13 @@ PT_DEV void queuePush(bool push, uint32_t localSlot, BlockLds &L, int q)
 // consumed queue `q` (-1 = none), followed by the optional second consumed queue `q2`, into order[0 .. L.n)
 // (ascending local slot indices per queue; `order` = LDS scratch of slots_per_block entries), and resets the
 // statistics.  All threads must call it.
-PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, int q, uint32_t appendMask, unsigned short *order,
-                        int q2 = -1)
+// Expands queue q, followed by the optional queue q2, from the LDS bitmaps into order[0 .. L.n) and clears them
+// (consumed).  All threads must call it; it ends with a barrier.
+PT_DEV void queuesExpand(BlockLds &L, const PathState &st, int q, int q2, unsigned short *order)
 {
     const uint32_t W = st.slots_per_block >> 5;
     const uint32_t t = threadIdx.x;
-    if (t < W) {
-#pragma unroll
-        for (int k = 0; k < Q_COUNT; ++k) {
-            bool load = k == q || k == q2 || ((appendMask >> k) & 1u);
-            L.bm[k][t] = load ? st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + t] : 0u;
-        }
-    }
-    if (t == 0) {
-        L.cursor = ctl.item_cursor;
-        L.samples = L.closest_rays = L.shadow_rays = L.shadow_slots = L.nodes = L.prims = 0;
-        L.n = 0;
-    }
-    __syncthreads();
+    if (t == 0) L.n = 0;
     uint32_t done = 0;
     for (int pass = 0; pass < 2; ++pass) {
         const int qq = pass == 0 ? q : q2;
@@ -225,6 +214,27 @@ PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, i
         __syncthreads();
         done = L.n;
     }
+}
+
+PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, int q, uint32_t appendMask, unsigned short *order,
+                        int q2 = -1)
+{
+    const uint32_t W = st.slots_per_block >> 5;
+    const uint32_t t = threadIdx.x;
+    if (t < W) {
+#pragma unroll
+        for (int k = 0; k < Q_COUNT; ++k) {
+            bool load = k == q || k == q2 || ((appendMask >> k) & 1u);
+            L.bm[k][t] = load ? st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + t] : 0u;
+        }
+    }
+    if (t == 0) {
+        L.cursor = ctl.item_cursor;
+        L.samples = L.closest_rays = L.shadow_rays = L.shadow_slots = L.nodes = L.prims = 0;
+        L.n = 0;
+    }
+    __syncthreads();
+    queuesExpand(L, st, q, q2, order);
 }
 
 // A thread's entries order[k*blockDim + tid], k < 16, packed two per register, so that the LDS scratch holding

@@ -347,8 +347,12 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
 //                and forwards class-1 hits (hit record stored) to the class-1 shading queue;
 //   FUSE_SHADOW  the <= 2 shadow rays of a vertex are any-hit tested inline instead of being queued for
 //                k_trace_shadow, so the NEE term is added on the spot and no shadow record is written.
+//   FUSE_LOOP    (with both of the above, scenes without class-1 materials) the workgroup runs its slots to completion
+//                inside ONE launch: nothing it reads or writes is shared with another workgroup, so the wavefront
+//                iterations need no grid-wide synchronisation -- the queues simply stay in LDS between iterations.
 #define FUSE_TRACE  1
 #define FUSE_SHADOW 2
+#define FUSE_LOOP   4
 template<uint32_t M, int W, int FUSE>
 __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, PassParams pp, int cls)
 {
@@ -361,14 +365,15 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? (1u << Q_SHADE1) : 0u);
     queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2);
     const DeviceScene s = stageSceneTables(sg, ldsTables);
-    const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
-    const bool aborted = st.live[1] != 0;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
     const bool nee = s.settings.enable_light_sampling != 0;
     uint32_t finishedCount = 0, fusedClosest = 0, fusedShadow = 0, fusedPrims = 0, fusedNodes = 0;
     PROF_DECL;
 
+  for (;;) {                                     // one wavefront iteration per turn (a single turn unless FUSE_LOOP)
+    const uint32_t n = L.n;
+    const bool aborted = __hip_atomic_load(&st.live[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     for (uint32_t base = 0; base < n; base += blockDim.x) {
         uint32_t i = base + threadIdx.x;
         PROF(0);
@@ -632,6 +637,13 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
         queuePush(regenerated, local, L, Q_EXTP);
         PROF(8);
     }
+    if (!(FUSE & FUSE_LOOP))
+        break;
+    __syncthreads();                             // every push of this iteration is in the LDS bitmaps
+    queuesExpand(L, st, qIn, qIn2, order);
+    if (L.n == 0)
+        break;
+  }
     PROF_FLUSH(st.stats[blockIdx.x]);
     waveAddStat(&L.samples, finishedCount);
     if (FUSE) {
@@ -1042,6 +1054,7 @@ struct tghip_ctx {
     // resident at once (no second scheduling round), i.e. each kernel runs at its own best occupancy on one grid
     int thrClosest = 256, thrShadow = 256, thrShadeSimple = 192, thrShadeComplex = 128;
     int thrOverride[4] = {0, 0, 0, 0};
+    bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
     long long poolPad = 9472;             // bytes between the per-slot arrays of the pool (multiple of 16)
     bool dynamicFetch = true;             // BVH scenes: closest-hit kernel with dynamic ray fetch (k_trace_closest_dyn)
@@ -1355,6 +1368,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
+    else if (k == "run_to_completion") ctx->loopOpt = value != 0;
     else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "dynamic_fetch") { ctx->dynamicFetch = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "threads_closest") { ctx->thrOverride[0] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
@@ -1517,6 +1531,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const bool count = ctx->countTraversal;
     const bool flat = s.num_recs <= TGHIP_FLAT_MAX_RECS;
     const bool fused = flat && !ctx->haveForward && ctx->fuseFlatOpt;
+    const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
     // optional per-launch timing: one event pair per kernel launch of a check interval, read back at the
@@ -1538,6 +1553,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     hipLaunchKernelGGL(k_start, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp);
     uint32_t iterTag = 1;                        // k_start publishes tag 1 when it queued anything
     bool first = true;
+    int roundIters = ctx->checkInterval;         // launches of the wavefront loop between two host checks
     for (;;) {
         evUsed = 0;
         {
@@ -1545,29 +1561,34 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (timing && !first) {
                 double *acc[3] = {&ctx->counters.ms_trace_closest, &ctx->counters.ms_shade, &ctx->counters.ms_trace_shadow};
-                size_t pairs = size_t(ctx->checkInterval)*3;
+                size_t pairs = size_t(roundIters)*3;
                 for (size_t k = 0; k < pairs; ++k) {
                     float ms = 0.0f;
                     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[2*k], ctx->evPool[2*k + 1]));
                     *acc[k % 3] += ms;
                 }
-                ctx->counters.launches_trace_closest += ctx->checkInterval;
-                ctx->counters.launches_trace_shadow += ctx->checkInterval;
-                ctx->counters.launches_shade += ctx->checkInterval;
+                ctx->counters.launches_trace_closest += roundIters;
+                ctx->counters.launches_trace_shadow += roundIters;
+                ctx->counters.launches_shade += roundIters;
             }
             if (ctx->hostLive[0] != iterTag)
                 break;                           // the last iteration left every extension queue empty
         }
         first = false;
-        for (int it = 0; it < ctx->checkInterval; ++it) {
+        roundIters = runToCompletion ? 1 : ctx->checkInterval;
+        for (int it = 0; it < roundIters; ++it) {
             ++iterTag;
             if (fused) {
                 // flat-list scene: intersection and shadow tests happen inside the shading launches
                 PassParams ppi = pp;
                 ppi.iter_tag = iterTag;
                 tic(); tic(); tic();
-                if (ctx->leanScene) launchShade<MASK_LEAN, FUSE_TRACE | FUSE_SHADOW>(ctx, grid, st, ppi, 0);
-                else                launchShade<MASK_SIMPLE, FUSE_TRACE | FUSE_SHADOW>(ctx, grid, st, ppi, 0);
+                if (runToCompletion) {
+                    if (ctx->leanScene) launchShade<MASK_LEAN, FUSE_TRACE | FUSE_SHADOW | FUSE_LOOP>(ctx, grid, st, ppi, 0);
+                    else                launchShade<MASK_SIMPLE, FUSE_TRACE | FUSE_SHADOW | FUSE_LOOP>(ctx, grid, st, ppi, 0);
+                }
+                else if (ctx->leanScene) launchShade<MASK_LEAN, FUSE_TRACE | FUSE_SHADOW>(ctx, grid, st, ppi, 0);
+                else                     launchShade<MASK_SIMPLE, FUSE_TRACE | FUSE_SHADOW>(ctx, grid, st, ppi, 0);
                 if (ctx->haveComplex) {
                     if ((ctx->complexMask & ~MASK_COAT) == 0)       launchShade<MASK_COAT, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
                     else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
