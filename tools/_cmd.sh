@@ -1,2 +1,3 @@
-python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -6
-bash tools/gpu_tune.sh r1z cornell 256 "max_slots=2097152 blocks_per_cu=2" "max_slots=2097152 blocks_per_cu=4" "max_slots=4194304 blocks_per_cu=8" "max_slots=2097152 blocks_per_cu=8 threads_shade_simple=128" "max_slots=2097152 blocks_per_cu=8 threads_shade_simple=192"
+python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -4
+bash tools/gpu_tune.sh r2a materialtest 64 "max_slots=2097152" "max_slots=2097152"
+bash tools/gpu_tune.sh r2a mesh1m 32 "max_slots=2097152"

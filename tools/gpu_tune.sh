@@ -7,7 +7,7 @@ for o in "$@"; do
   args=""
   for kv in $o; do args="$args --opt $kv"; done
   echo "== $scene $o"
-  timeout 300 python bench.py --scene $scene --spp $spp --steps 2 --warmup 1 --no-cpu-baseline --no-extra $args 2>>$out/err.log | python -c "
+  timeout 300 python bench.py --scene $scene --spp $spp --res $([ $scene = mesh1m ] && echo 1920x1080 || echo 1280x720) --steps 2 --warmup 1 --no-cpu-baseline --no-extra $args 2>>$out/err.log | python -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l)

@@ -22,6 +22,8 @@ struct DeviceScene {
     const float * __restrict__ texels;
     const float * __restrict__ dist;
     const uint8_t * __restrict__ rec_class;    // shading class of each primitive record's bsdf (built at upload, DESIGN.md "Kernels")
+    const uint16_t * __restrict__ guide;       // CDF guide tables of the samplable bitmaps (built at upload, bitmapSample)
+    const int32_t * __restrict__ tex_guide;    // per texture: offset of its tables in `guide`, -1 = none
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
     const TgHipCamera * __restrict__ camera;   // in device memory (56 dwords: read through the scalar cache where it is used, not held in SGPRs)
     TgHipSettings settings;
@@ -123,16 +125,34 @@ PT_DEV float bitmapPdf(const DeviceScene &s, const TgHipTexture &t, float u, flo
     column = min(max(column, 0), t.w - 1);
     return pdf[(size_t)row*t.w + column]*mpdf[row]*t.w*t.h;
 }
-PT_DEV void bitmapSample(const DeviceScene &s, const TgHipTexture &t, float xi0, float xi1, float &u, float &v)   /* :433-439 */
+// Guide tables (built by the shim at upload) make the two CDF inversions of Distribution2D::warp short dependent
+// chains instead of 9- and 10-step binary searches over L2-resident arrays: for a CDF a[0..n] and B buckets,
+// g[b] = upper_bound(a, b/B), so for x in [b/B, (b+1)/B) the answer lies in [g[b], g[b+1]].  B is a power of two
+// (x*B is exact), and the final search inside the window is the same upper_bound, so the result is identical.
+#define PT_GUIDE_MARGINAL 512
+#define PT_GUIDE_ROW      256
+PT_DEV int upperBoundGuided(const float *a, const uint16_t *g, int buckets, float x)
+{
+    int b = min((int)(x*(float)buckets), buckets - 1);
+    int lo = g[b], hi = g[b + 1];
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+PT_DEV void bitmapSample(const DeviceScene &s, int texIdx, const TgHipTexture &t, float xi0, float xi1, float &u, float &v)   /* :433-439 */
 {
     const float *mpdf = s.dist + t.dist_offset;
     const float *mcdf = mpdf + t.h;
     const float *pdf = mcdf + t.h + 1;
     const float *cdf = pdf + (size_t)t.w*t.h;
-    int row = upperBoundIdx(mcdf, t.h + 1, xi1) - 1;
+    const int go = s.tex_guide[texIdx];
+    int row;
+    if (go >= 0) row = upperBoundGuided(mcdf, s.guide + go, PT_GUIDE_MARGINAL, xi1) - 1;
+    else         row = upperBoundIdx(mcdf, t.h + 1, xi1) - 1;
     float nv = clampf((xi1 - mcdf[row])/mpdf[row], 0.0f, 1.0f);
     const float *rowStart = cdf + (size_t)row*(t.w + 1);
-    int column = upperBoundIdx(rowStart, t.w + 1, xi0) - 1;
+    int column;
+    if (go >= 0) column = upperBoundGuided(rowStart, s.guide + go + (PT_GUIDE_MARGINAL + 1) + row*(PT_GUIDE_ROW + 1), PT_GUIDE_ROW, xi0) - 1;
+    else         column = upperBoundIdx(rowStart, t.w + 1, xi0) - 1;
     float nu = clampf((xi0 - rowStart[column])/pdf[(size_t)row*t.w + column], 0.0f, 1.0f);
     u = (nu + column)/t.w;
     v = 1.0f - (nv + row)/t.h;
@@ -1263,7 +1283,7 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         return true;
     }
     float u, v, sinTheta;
-    bitmapSample(s, t, xi0, xi1, u, v);
+    bitmapSample(s, o.emission, t, xi0, xi1, u, v);
     d = infUvToDirection(o, u, v, sinTheta);
     pdf = PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, t, u, v)/sinTheta;
     return pdf != 0.0f;

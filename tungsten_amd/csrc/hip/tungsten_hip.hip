@@ -1424,6 +1424,37 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->textures, sd->num_textures, &s.textures)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->texels, sd->num_texel_floats, &s.texels)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->dist, sd->num_dist_floats, &s.dist)) != TGHIP_OK) return rc;
+    // CDF guide tables for the samplable bitmaps (pt_scene.h: upperBoundGuided)
+    {
+        std::vector<uint16_t> guide;
+        std::vector<int32_t> texGuide(std::max<uint32_t>(sd->num_textures, 1u), -1);
+        auto build = [&](const float *a, int n, int buckets) {   // g[b] = upper_bound(a[0..n], b/buckets)
+            int idx = 0;
+            for (int b = 0; b <= buckets; ++b) {
+                float x = float(b)/float(buckets);
+                while (idx <= n && a[idx] <= x) ++idx;
+                guide.push_back(uint16_t(std::min(idx, n + 1)));
+            }
+        };
+        for (uint32_t i = 0; i < sd->num_textures; ++i) {
+            const TgHipTexture &t = sd->textures[i];
+            if (t.type != TGHIP_TEX_BITMAP || t.dist_offset < 0 || t.w <= 0 || t.h <= 0 || t.w >= 65535 || t.h >= 65535)
+                continue;
+            if (guide.size() + size_t(PT_GUIDE_MARGINAL + 1) + size_t(t.h)*(PT_GUIDE_ROW + 1) >= (1u << 31))
+                continue;
+            texGuide[i] = int32_t(guide.size());
+            const float *mpdf = sd->dist + t.dist_offset;
+            const float *mcdf = mpdf + t.h;
+            const float *cdf = mcdf + (t.h + 1) + size_t(t.w)*t.h;
+            build(mcdf, t.h, PT_GUIDE_MARGINAL);
+            for (int y = 0; y < t.h; ++y)
+                build(cdf + size_t(y)*(t.w + 1), t.w, PT_GUIDE_ROW);
+        }
+        if (guide.empty()) guide.push_back(0);
+        if ((rc = uploadArray(ctx, ctx->sceneMem, guide.data(), guide.size(), &s.guide)) != TGHIP_OK) return rc;
+        if ((rc = uploadArray(ctx, ctx->sceneMem, texGuide.data(), texGuide.size(), &s.tex_guide)) != TGHIP_OK) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the vectors go out of scope
+    }
     // shading classes ("sort by material"): class 0 = BSDFs made of lambert/null only, class 1 = the rest
     {
         std::vector<uint32_t> typeMask(sd->num_bsdfs, 0u);
