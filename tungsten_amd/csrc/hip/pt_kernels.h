@@ -5,27 +5,31 @@
 //               handleInfiniteLights}          (integrators/TraceBase.cpp)
 //   TraceableScene::intersect + Embree         (renderer/TraceableScene.hpp:170-192)
 //
-// Execution model (DESIGN.md "Kernels"): the machine is partitioned into G persistent workgroups ("lanes of
-// the wavefront tracer", G = CUs x blocks_per_cu, the same G for every kernel of a pass).  Workgroup b owns
-//   * a private range of path slots in HBM (SoA arrays, slot = b*slots_per_block + local),
-//   * private queue segments for those slots (extension / per-class shading / shadow), whose lengths live in
-//     the workgroup's BlockCtl record, and
+// Execution model: the machine is partitioned into G persistent workgroups (G = CUs x
+// blocks_per_cu, the same G for every kernel of a pass).  Workgroup b owns
+//   * a private range of path slots in HBM (slot = b*slots_per_block + local; 15 arrays of 16 B per slot in one
+//     allocation, addressed as "one base + 32-bit offset"),
+//   * private queues over those slots -- one BITMAP per queue, expanded by the consumer into the ascending list of
+//     set slots so that every kernel walks its slots in memory order -- and
 //   * a private, finely interleaved share of the pass's work items (item = pixel x chunk of sample indices).
 // Nothing is shared between workgroups, so there is not a single global atomic on the hot path: queue pushes are
-// LDS bit-sets, work-item fetches wave-aggregated (ballot + prefix popcount) LDS atomics, and queue contents are
-// carried from one kernel to the next as per-workgroup bitmaps.  (Same-address global atomics saturate at ~88/us on MI355X --
-// MI355X_MICROARCH.md "dequeue" -- which is what bounded the first version of this tracer.)
+// LDS bit-sets, work-item fetches wave-aggregated LDS atomics, and queue contents travel from one kernel to the next
+// as per-workgroup bitmaps.  (Same-address global atomics saturate at ~88/us on MI355X -- MI355X_MICROARCH.md
+// "dequeue" -- which is what bounded the first version of this tracer.)
 // A slot that finishes its item flushes the item's radiance sum to partial[item] and takes the workgroup's next
 // item, so the pool stays full until the pass drains however uneven the path lengths are; partial[] is reduced
 // per pixel in fixed chunk order by k_resolve, which keeps the image bit-reproducible.
-// One wavefront iteration is
-//     k_trace_closest -> k_shade<simple> [-> k_shade<complex>] -> k_trace_shadow
-//   k_trace_closest  BVH2 closest hit for the extension queue (per-lane node stack in LDS); bins each path by the
-//                    shading class of the surface it hit into one queue per class ("sort by material").
-//   k_shade<M>       handleSurface for one class, compiled for the BSDF type set M only; emits <= 2 shadow
-//                    rays and the continuation ray; finished paths are finalised and regenerated in place.
-//   k_trace_shadow   generalizedShadowRay for the queued shadow rays; finishes the paths that were waiting
-//                    for their last shadow result.
+// One wavefront iteration of a BVH scene is
+//     k_trace_closest_dyn -> k_shade<simple> [-> k_shade<complex>] -> k_trace_shadow_dyn
+//   k_trace_closest_dyn  BVH2 closest hit (per-lane node stack in LDS, dynamic ray fetch); bins each path by the
+//                        shading class of the surface it hit into one queue per class ("sort by material").
+//   k_shade<M, W, FUSE>  handleSurface for one class, compiled for the BSDF type / scene feature set M only; emits
+//                        <= 2 shadow rays and the continuation ray; finished paths are finalised and regenerated
+//                        in place.
+//   k_trace_shadow_dyn   generalizedShadowRay for the queued shadow rays (any-hit, dynamic fetch); finishes the
+//                        paths that were waiting for their last shadow result.
+// Flat-list scenes (<= TGHIP_FLAT_MAX_RECS records) intersect inside k_shade (FUSE flags) and, without class-1
+// materials, run every workgroup to completion in a single launch.
 #ifndef TGAMD_PT_KERNELS_H_
 #define TGAMD_PT_KERNELS_H_
 

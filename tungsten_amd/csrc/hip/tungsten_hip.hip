@@ -788,8 +788,11 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
 // had ended at that vertex are collected in an LDS list and finalised + regenerated after the traversal loop
 // (keeping nextPath out of the loop holds the loop at 5 waves per SIMD).
 // Dynamic LDS: [expanded queue, 2 B per slot][finished list, 2 B per slot][node stacks, bvhDepth ints per thread].
+#ifndef SHADOW_DYN_BOUNDS
+#define SHADOW_DYN_BOUNDS __launch_bounds__(512)
+#endif
 template<bool COUNT>
-__global__ __launch_bounds__(512) void k_trace_shadow_dyn(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+__global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsDyn[];
     __shared__ BlockLds L;
