@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 1
+#define TGHIP_ABI_VERSION 2
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -112,13 +112,14 @@ typedef struct TgHipObject {
     int32_t  light;           /* index in lights[] if samplable emitter, else -1  */
     uint32_t flags;
     float    area, inv_area;  /* quad/cube/mesh total area                        */
-    int32_t  first_light_tri; /* mesh emitters: offset into light_tris (unused yet) */
+    int32_t  first_light_tri; /* sampled mesh emitters: float offset of the mesh's block in light_tris, else -1 */
     float    base[3], edge0[3], edge1[3], normal[3]; /* quad (Quad.cpp:298-316)    */
     float    inv_uv_sq[2];
     float    pos[3], scale[3];                       /* cube half-extent / sphere radius in scale[0] */
     float    rot[9];                                 /* row-major 3x3 rotation (cube; infinite sphere _rotTransform) */
     float    face_cdf[3];                            /* cube (Cube.cpp:353-370)    */
-    float    pad[3];
+    int32_t  num_light_tris;  /* sampled mesh emitters: triangles in the block (TriangleMesh::makeSamplable) */
+    float    pad[2];
 } TgHipObject;
 
 /* ---- BSDFs ---------------------------------------------------------------------------- */
@@ -202,6 +203,10 @@ typedef struct TgHipSceneDesc {
     const TgHipTexture *textures;
     const float        *texels;  uint64_t num_texel_floats;
     const float        *dist;    uint64_t num_dist_floats;
+    /* sampled mesh emitters (TriangleMesh.cpp:395-409): per mesh a block of floats at objects[].first_light_tri:
+     * cdf[n + 1] of the triangle areas (Distribution1D: normalised, last = 1), then n x 9 floats p0,p1,p2 (world space,
+     * the mesh's own triangle order); objects[].area is the total area */
+    const float        *light_tris;  uint64_t num_light_tri_floats;
     TgHipCamera   camera;
     TgHipSettings settings;
     float         bounds_lo[3], bounds_hi[3];

@@ -1233,7 +1233,8 @@ static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float 
     if (ok) { *tmax = t; hit->t = t; hit->u = u; hit->v = v; hit->rec = (int32_t)i; }
 }
 
-static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hit, TravStats *st)
+/* objFilter >= 0: only records of that object are tested (a mesh light's own rtcIntersect, TriangleMesh.cpp:317-335) */
+static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hit, TravStats *st, int objFilter)
 {
     int32_t stack[TGHIP_MAX_BVH_DEPTH + 2];
     int sp = 0;
@@ -1242,7 +1243,8 @@ static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hi
     if (st) st->rays++;
     if (s->num_recs <= TGHIP_FLAT_MAX_RECS) {           /* flat list (include/tungsten_hip.h) */
         for (uint32_t i = 0; i < s->num_recs; ++i)
-            test_rec(s, i, ray, &tmax, hit, st);
+            if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
+                test_rec(s, i, ray, &tmax, hit, st);
         return hit->rec >= 0;
     }
     v3 invD = V(1.0f/ray->d.x, 1.0f/ray->d.y, 1.0f/ray->d.z);
@@ -1263,12 +1265,17 @@ static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hi
         } else {
             uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
             for (uint32_t i = first; i < first + count; ++i)
-                test_rec(s, i, ray, &tmax, hit, st);
+                if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
+                    test_rec(s, i, ray, &tmax, hit, st);
         }
         if (sp == 0) break;
         cur = stack[--sp];
     }
     return hit->rec >= 0;
+}
+static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hit, TravStats *st)
+{
+    return scene_intersect_obj(s, ray, hit, st, -1);
 }
 
 /* IntersectionInfo (primitives/IntersectionInfo.hpp:11-22) + what hitBackside() needs */
@@ -1457,6 +1464,13 @@ static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, 
         if (!sphere_test(o, ray, ray->tmax, &lh->t, &lh->backSide)) return 0;
         sphere_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), &lh->n, &lh->u, &lh->v);
         return 1;
+    } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh::intersect + intersectionInfo: the mesh's own BVH */
+        TgHipHit hit;
+        if (!scene_intersect_obj(s, ray, &hit, NULL, objIdx)) return 0;
+        Info info;
+        intersection_info(s, ray, &hit, &info);
+        lh->t = hit.t; lh->u = info.u; lh->v = info.v; lh->backSide = info.backSide; lh->n = info.Ng;
+        return 1;
     }
     return 0;
 }
@@ -1477,6 +1491,9 @@ static float light_directPdf(const TgHipSceneDesc *s, int objIdx, const LightHit
         float t = vdot(n, vsub(ld3(o->base), p))/vdot(n, lh->w);
         return t*t/(cosTheta*o->area);
     } else if (o->type == TGHIP_OBJ_CUBE) {            /* Cube.cpp:291-295 */
+        v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
+        return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
+    } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:469-473 */
         v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
         return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
     } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere.cpp:216-222 */
@@ -1533,6 +1550,27 @@ static int light_sampleDirect(const TgHipSceneDesc *s, int objIdx, v3 p, Sampler
         *dist = sqrtf(rSq);
         *d = vdivs(L, *dist);
         float cosTheta = -vdot(Ng, *d);
+        if (cosTheta <= 0.0f)
+            return 0;
+        *pdf = rSq/(cosTheta*o->area);
+        return 1;
+    } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh::sampleDirect / samplePosition (TriangleMesh.cpp:411-462) */
+        const float *cdf = s->light_tris + o->first_light_tri;
+        const float *tris = cdf + o->num_light_tris + 1;
+        float u = next1D(smp);
+        int idx = upper_bound_idx(cdf, o->num_light_tris + 1, u) - 1;     /* Distribution1D::warp */
+        const float *t = tris + (size_t)idx*9;
+        v3 p0 = ld3(t), p1 = ld3(t + 3), p2 = ld3(t + 6);
+        v3 normal = vnorm(vcross(vsub(p1, p0), vsub(p2, p0)));
+        float xi0 = next1D(smp), xi1 = next1D(smp);
+        float uSqrt = sqrtf(xi0);                                           /* SampleWarp::uniformTriangleUv */
+        float alpha = 1.0f - uSqrt, beta = (1.0f - xi1)*uSqrt;
+        v3 q = vadd(vadd(vscale(p0, alpha), vscale(p1, beta)), vscale(p2, 1.0f - alpha - beta));
+        v3 L = vsub(q, p);
+        float rSq = vlensq(L);
+        *dist = sqrtf(rSq);
+        *d = vdivs(L, *dist);
+        float cosTheta = -vdot(normal, *d);
         if (cosTheta <= 0.0f)
             return 0;
         *pdf = rSq/(cosTheta*o->area);
@@ -1594,6 +1632,8 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
         v3 ap = V(fmaxf(fabsf(lp.x), 0.0f), fmaxf(fabsf(lp.y), 0.0f), fmaxf(fabsf(lp.z), 0.0f));
         float dSq = vlensq(ap);
         return vmax3(ld3(s->textures[o->emission].avg))*o->face_cdf[2]/dSq;
+    } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:514-517: "unknown" */
+        return -1.0f;
     } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere.cpp:266-271, 33-40 */
         if (o->emission < 0) return 0.0f;
         v3 L = vsub(ld3(o->pos), p);

@@ -144,6 +144,35 @@ def _two_lights(scene):
                                 "transform": {"position": [-0.98, 0.6, 0.2], "scale": [0.3, 0.3, 0.3], "rotation": [0, 0, -90]}})
 
 
+def cornell_mesh_light(tmpdir, big=True, **kw):
+    """Cornell box whose quad light is replaced by an emissive triangle mesh (sampled: TriangleMesh::sampleDirect,
+    TriangleMesh.cpp:411-473): a 168-triangle blob (BVH traversal) or a 2-triangle panel (flat-list traversal)."""
+    import numpy as np
+    tmpdir = str(tmpdir)
+    if big:
+        verts, tris = displaced_sphere(8, 12, seed=3)
+        verts = verts.copy()
+        verts[:, 0:3] = (verts[:, 0:3] - [0, 0.5, 0])*0.5          # radius ~0.22 around the origin
+        tris = tris[:, [0, 2, 1, 3]]                               # front faces (the emitting side) outwards
+        name = "lamp_blob.wo3"
+    else:
+        verts = np.array([[-1, 0, -1, 0, -1, 0, 0, 0], [1, 0, -1, 0, -1, 0, 1, 0], [1, 0, 1, 0, -1, 0, 1, 1], [-1, 0, 1, 0, -1, 0, 0, 1]], np.float32)
+        tris = np.array([[0, 1, 2, 0], [0, 2, 3, 0]], np.int32)
+        name = "lamp_panel.wo3"
+    write_wo3(os.path.join(tmpdir, name), verts, tris)
+    user = kw.pop("edit", None)
+
+    def edit(scene):
+        scene["primitives"] = [p for p in scene["primitives"] if p["name"] != "light"]
+        scene["primitives"].append({"name": "lamp", "type": "mesh", "file": name, "smooth": False, "bsdf": "light",
+                                    "emission": [9, 7, 4] if big else [17, 12, 4],
+                                    "transform": {"position": [0.1, 1.55, 0.0] if big else [-0.005, 1.98, -0.03],
+                                                  "scale": [1, 1, 1] if big else [0.235, 1, 0.19]}})
+        if user:
+            user(scene)
+    return variant(CORNELL, tmpdir, kw.pop("name", "mesh_light.json"), edit=edit, **kw)
+
+
 # name -> (builder, kwargs): every per-sample golden under tests/golden/<name>_samples.npz (tools/make_golden.py)
 GOLDEN_CASES = {
     "cornell": (cornell, dict(resolution=(48, 27), spp=8)),
@@ -154,6 +183,9 @@ GOLDEN_CASES = {
     "cornell_onesided": (cornell, dict(resolution=(32, 18), spp=8, integrator={"enable_two_sided_shading": False})),
     "cornell_box_filter": (cornell, dict(resolution=(32, 18), spp=8, edit=lambda s: s["camera"].update(reconstruction_filter="box"))),
     "cornell_two_lights": (cornell, dict(resolution=(32, 18), spp=8, edit=_two_lights)),
+    "cornell_mesh_light": (cornell_mesh_light, dict(resolution=(32, 18), spp=8)),
+    "cornell_mesh_light_flat": (lambda t, **kw: cornell_mesh_light(t, big=False, **kw), dict(resolution=(32, 18), spp=8)),
+    "cornell_mesh_and_quad_light": (cornell_mesh_light, dict(resolution=(32, 18), spp=8, edit=_two_lights)),
     "zoo_a": (lambda t, **kw: cornell_zoo(t, "zoo_a", **kw), dict(resolution=(48, 27), spp=8)),
     "zoo_b": (lambda t, **kw: cornell_zoo(t, "zoo_b", **kw), dict(resolution=(48, 27), spp=8)),
     "zoo_c": (lambda t, **kw: cornell_zoo(t, "zoo_c", **kw), dict(resolution=(48, 27), spp=8)),

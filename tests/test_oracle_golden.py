@@ -55,7 +55,7 @@ def _needs_materialtest(name):
 
 # fraction of samples allowed to diverge (chaotic path divergence, see module docstring)
 DIVERGE = {"zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "zoo_d": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
-           "materialtest_rough_dielectric": 2e-2, "materialtest_transparency": 5e-3, "cornell_two_lights": 1e-3, "mesh1m": 1e-2}
+           "materialtest_rough_dielectric": 2e-2, "materialtest_transparency": 5e-3, "cornell_two_lights": 1e-3, "cornell_mesh_light": 2e-3, "cornell_mesh_light_flat": 2e-3, "cornell_mesh_and_quad_light": 2e-3, "mesh1m": 1e-2}
 
 
 @pytest.mark.parametrize("name", sorted(scenes.GOLDEN_CASES))

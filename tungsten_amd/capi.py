@@ -31,7 +31,7 @@ class TgHipObject(C.Structure):
     _fields_ = [("type", i32), ("bsdf", i32), ("emission", i32), ("light", i32), ("flags", u32),
                 ("area", f32), ("inv_area", f32), ("first_light_tri", i32),
                 ("base", f32*3), ("edge0", f32*3), ("edge1", f32*3), ("normal", f32*3), ("inv_uv_sq", f32*2),
-                ("pos", f32*3), ("scale", f32*3), ("rot", f32*9), ("face_cdf", f32*3), ("pad", f32*3)]
+                ("pos", f32*3), ("scale", f32*3), ("rot", f32*9), ("face_cdf", f32*3), ("num_light_tris", i32), ("pad", f32*2)]
 
 
 class TgHipBsdf(C.Structure):
@@ -68,6 +68,7 @@ class TgHipSceneDesc(C.Structure):
                 ("bsdfs", C.POINTER(TgHipBsdf)), ("textures", C.POINTER(TgHipTexture)),
                 ("texels", C.POINTER(f32)), ("num_texel_floats", u64),
                 ("dist", C.POINTER(f32)), ("num_dist_floats", u64),
+                ("light_tris", C.POINTER(f32)), ("num_light_tri_floats", u64),
                 ("camera", TgHipCamera), ("settings", TgHipSettings),
                 ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
 

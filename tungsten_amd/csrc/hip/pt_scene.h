@@ -22,6 +22,7 @@ struct DeviceScene {
     const float * __restrict__ texels;
     const float * __restrict__ dist;
     const uint8_t * __restrict__ rec_class;    // shading class of each primitive record's bsdf (built at upload, DESIGN.md "Kernels")
+    const float * __restrict__ light_tris;     // sampled mesh emitters: cdf + triangles (include/tungsten_hip.h)
     const uint16_t * __restrict__ guide;       // CDF guide tables of the samplable bitmaps (built at upload, bitmapSample)
     const int32_t * __restrict__ tex_guide;    // per texture: offset of its tables in `guide`, -1 = none
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
@@ -49,6 +50,7 @@ struct DeviceScene {
 #define FEAT_TRIANGLES  (1u << 27)   /* triangle records (attribute gather, smooth normals)            */
 #define FEAT_SOLIDS     (1u << 28)   /* sphere records; sphere / cube emitters as sampled lights       */
 #define FEAT_ALL        (FEAT_BITMAP | FEAT_INFINITE | FEAT_MULTILIGHT | FEAT_TRIANGLES | FEAT_SOLIDS)
+#define FEAT_MESHLIGHT  (1u << 29)   /* triangle-mesh emitters as sampled lights: only in BSDF_MASK_ALL variants */
 
 // ---------------------------------------------------------------------------------------------
 // Textures (ConstantTexture, CheckerTexture.cpp:64-69, BitmapTexture.cpp:298-352)
@@ -1212,6 +1214,28 @@ template<uint32_t M>
 PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, f3 &d, float &dist, float &pdf)
 {
     const TgHipObject &o = s.objects[objIdx];
+    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_MESH) {    /* TriangleMesh::sampleDirect / samplePosition (TriangleMesh.cpp:411-462) */
+        const float *cdf = s.light_tris + o.first_light_tri;
+        const float *tris = cdf + o.num_light_tris + 1;
+        float u = rngNext1D(rng);
+        int idx = upperBoundIdx(cdf, o.num_light_tris + 1, u) - 1;     /* Distribution1D::warp */
+        const float *t = tris + (size_t)idx*9;
+        f3 p0 = ld3(t), p1 = ld3(t + 3), p2 = ld3(t + 6);
+        f3 normal = normalized(cross(p1 - p0, p2 - p0));
+        float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
+        float uSqrt = sqrtf(xi0);                                      /* SampleWarp::uniformTriangleUv */
+        float alpha = 1.0f - uSqrt, beta = (1.0f - xi1)*uSqrt;
+        f3 q = p0*alpha + p1*beta + p2*(1.0f - alpha - beta);
+        f3 L = q - p;
+        float rSq = lengthSq(L);
+        dist = sqrtf(rSq);
+        d = L/dist;
+        float cosTheta = -dot(normal, d);
+        if (cosTheta <= 0.0f)
+            return false;
+        pdf = rSq/(cosTheta*o.area);
+        return true;
+    }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube::sampleDirect / samplePosition / sampleFace (Cube.cpp:229-245,189-213,42-55) */
         float u = rngNext1D(rng);
         int dim;
@@ -1292,6 +1316,8 @@ template<uint32_t M>
 PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
 {
     const TgHipObject &o = s.objects[objIdx];
+    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_MESH)      /* TriangleMesh.cpp:514-517: "unknown" */
+        return -1.0f;
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube.cpp:326-330 */
         f3 lp = mat3TMul(o.rot, p - ld3(o.pos));
         f3 ap = mk3(fmaxf(fabsf(lp.x), 0.0f), fmaxf(fabsf(lp.y), 0.0f), fmaxf(fabsf(lp.z), 0.0f));
@@ -1327,10 +1353,41 @@ PT_DEV int chooseLight(const DeviceScene &s, Rng &rng, f3 p, float &weight)
     int n = (int)s.num_lights;
     if (n == 0) return -1;
     if (!(M & FEAT_MULTILIGHT) || n == 1) { weight = 1.0f; return s.lights[0]; }
-    // Only quad and infinite-sphere emitters are sampled (tghip_upload_scene rejects the rest), and their
-    // approximateRadiance is never negative ("unknown"), so TraceBase.cpp:434-446's uniform-share branch cannot
-    // trigger.  Two passes over the lights instead of a per-lane pdf array (which would live in scratch).
     n = min(n, 16);
+    if (M & FEAT_MESHLIGHT) {
+        // mesh emitters answer "unknown" (-1) and receive the mean of the known weights (TraceBase.cpp:434-446).  The
+        // reference fills a pdf array in order; here the weights are re-evaluated instead of stored per lane.
+        float total = 0.0f;
+        int numNonNegative = 0;
+        for (int i = 0; i < n; ++i) {
+            float w = lightApproximateRadiance<M>(s, s.lights[i], p);
+            if (w >= 0.0f) { total += w; numNonNegative++; }
+        }
+        const bool allUnknown = numNonNegative == 0;
+        float knownTotal = total;
+        if (allUnknown) {
+            total = (float)n;
+        } else if (numNonNegative < n) {
+            for (int i = 0; i < n; ++i)
+                if (lightApproximateRadiance<M>(s, s.lights[i], p) < 0.0f)
+                    total += (total == 0.0f ? 1.0f : total)/numNonNegative;   // uses the running total, like the reference's loop
+        }
+        if (total == 0.0f) return -1;
+        float t = rngNext1D(rng)*total;
+        float running = knownTotal;
+        for (int i = 0; i < n; ++i) {
+            float w = lightApproximateRadiance<M>(s, s.lights[i], p);
+            float pdf;
+            if (allUnknown) pdf = 1.0f;
+            else if (w < 0.0f) { pdf = (running == 0.0f ? 1.0f : running)/numNonNegative; running += pdf; }
+            else pdf = w;
+            if (t < pdf || i == n - 1) { weight = total/pdf; return s.lights[i]; }
+            t -= pdf;
+        }
+        return -1;
+    }
+    // Without mesh emitters approximateRadiance is never negative ("unknown"), so the uniform-share branch cannot
+    // trigger.  Two passes over the lights instead of a per-lane pdf array (which would live in scratch).
     float total = 0.0f;
     for (int i = 0; i < n; ++i)
         total += lightApproximateRadiance<M>(s, s.lights[i], p);

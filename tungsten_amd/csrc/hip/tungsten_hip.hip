@@ -474,6 +474,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                             uint32_t tag = (uint32_t)light | ((uint32_t)(bounce + 1) << 24);
                             bool q0 = false, q1 = false;
                             f3 inlineResult = splat3(0.0f);
+                            const bool meshLight = (M & FEAT_MESHLIGHT) && s.objects[light].type == TGHIP_OBJ_MESH;
                             // lightSample (TraceBase.cpp:246-285)
                             {
                                 f3 d; float dist, pdf;
@@ -482,7 +483,15 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                     ev.requested = LOBE_ALL_BUT_SPECULAR;
                                     if (isConsistent(ev.wo, d)) {
                                         f3 f = bsdfEval<M>(s, info.bsdf, ev);
-                                        if (!isZero(f)) {
+                                        if ((M & FEAT_MESHLIGHT) && !isZero(f) && meshLight) {
+                                            // mesh emitter: whether the ray reaches the light, and with which emission, is only
+                                            // known after the scene traversal (TriangleMesh::intersect is a BVH query), so the
+                                            // shadow kernel completes f*e/pdf * powerHeuristic from these factors
+                                            float k = powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev))/pdf;
+                                            slotF4(st, A_SH_D0, slot) = mk4(d, dist);
+                                            slotF4(st, A_SH_C0, slot) = mk4(f*k, __uint_as_float(tag));
+                                            q0 = true;
+                                        } else if (!isZero(f)) {
                                             RayD sr; sr.o = info.p; sr.d = d; sr.tmin = 5e-4f; sr.tmax = PT_INF;
                                             LightHit lh;
                                             // attenuatedEmission's analytic hit + distance check (TraceBase.cpp:155-162)
@@ -513,7 +522,13 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                 ev.weight = splat3(1.0f); ev.pdf = 1.0f;
                                 if (bsdfSample<M>(s, info.bsdf, ev) && !isZero(ev.weight)) {
                                     f3 wog = toGlobal(frame, ev.wo);
-                                    if (isConsistent(ev.wo, wog)) {
+                                    if ((M & FEAT_MESHLIGHT) && meshLight) {
+                                        if (isConsistent(ev.wo, wog)) {
+                                            slotF4(st, A_SH_D1, slot) = mk4(wog, ev.pdf);          // directPdf needs the hit
+                                            slotF4(st, A_SH_C1, slot) = mk4(ev.weight, __uint_as_float(tag));
+                                            q1 = true;
+                                        }
+                                    } else if (isConsistent(ev.wo, wog)) {
                                         RayD sr; sr.o = info.p; sr.d = wog; sr.tmin = 5e-4f; sr.tmax = PT_INF;
                                         LightHit lh;
                                         if (lightIntersect<M>(s, light, sr, lh)) {
@@ -710,7 +725,11 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     if (traverseOccluded<COUNT, FLAT>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims)
                         || bounce < s.settings.min_bounces)
                         transmittance = splat3(0.0f);
-                } else
+                } else {
+                const bool meshLight = s.objects[endCap].type == TGHIP_OBJ_MESH;
+                f3 meshFactor = splat3(0.0f);                  // mesh emitters: e (light ray) or e*powerHeuristic (bsdf ray)
+                float travelled = 0.0f;
+                if (meshLight) { ray.tmax = PT_INF; remaining = PT_INF; }   // sd.w carries the expected distance / the bsdf pdf
                 for (;;) {
                     float4 hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
                     rays++;
@@ -718,8 +737,24 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     int hitObject = -1;
                     if (ri >= 0)
                         hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)ri*3u).w));
+                    if (meshLight && ri < 0) { transmittance = splat3(0.0f); break; }   // the ray never reaches the mesh
                     if (ri < 0 || hitObject == endCap) {
                         if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
+                        if (meshLight) {
+                            // attenuatedEmission on a mesh light (TraceBase.cpp:144-174, TriangleMesh.cpp:344-355,469-473,493-496)
+                            Info li;
+                            intersectionInfo<BSDF_MASK_ALL>(s, ray, hit, li);
+                            const TgHipObject &lo = s.objects[endCap];
+                            f3 e = lightEvalDirect<BSDF_MASK_ALL>(s, endCap, li.u, li.v, li.backSide);
+                            float total = travelled + hit.x;
+                            if (r == 0) {
+                                if (total*(1.0f + 1e-3f) < sd.w) e = splat3(0.0f);        // a nearer part of the mesh than the sampled point
+                                meshFactor = e;
+                            } else {
+                                float directPdf = lengthSq(xyz(so) - li.p)/(-dot(ray.d, li.Ng)*lo.area);
+                                meshFactor = e*powerHeuristic(sd.w, directPdf);
+                            }
+                        }
                         break;
                     }
                     Info info;
@@ -741,9 +776,12 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     bounce++;
                     if (bounce >= s.settings.max_bounces) { transmittance = splat3(0.0f); break; }
                     ray.o = ray.o + ray.d*hit.x;
+                    travelled += hit.x;
                     remaining -= hit.x;
                     ray.tmin = 5e-4f;
                     ray.tmax = remaining;
+                }
+                if (meshLight) transmittance = transmittance*meshFactor;
                 }
                 if (!isZero(transmittance))
                     result = result + xyz(c)*transmittance;
@@ -1048,6 +1086,7 @@ struct tghip_ctx {
     bool haveComplex = false;             // some primitive record uses a class-1 BSDF
     uint32_t complexMask = 0;             // union of the BSDF types inside class-1 materials
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
+    bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, BSDF_MASK_ALL shading
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
@@ -1273,14 +1312,16 @@ static void chooseThreads(tghip_ctx *ctx)
     ctx->thrClosest = flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
                     : ctx->dynamicFetch ? pickThreads(ctx, k_trace_closest_dyn<false>, 320, 2)   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
-    if (!flat && !ctx->haveForward && ctx->dynamicFetch)
+    if (!flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->dynamicFetch)
         ctx->thrShadow = pickThreads(ctx, k_trace_shadow_dyn<false>, 512, 3);
-    else if (ctx->haveForward)
+    else if (ctx->haveForward || ctx->haveMeshLight)
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, true, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, true, false>, 512, 1);
     else
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, false, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, false, false>, 512, 1);
-    ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES, 0>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>, 256, 0);
-    if ((ctx->complexMask & ~MASK_COAT) == 0)       ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2, 0>, 256, 0);
+    if (ctx->haveMeshLight) ctx->thrShadeSimple = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
+    else ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES, 0>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>, 256, 0);
+    if (ctx->haveMeshLight)                         ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
+    else if ((ctx->complexMask & ~MASK_COAT) == 0)  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2, 0>, 256, 0);
     else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
     else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     }
@@ -1401,8 +1442,15 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         if (bsdfDepth(sd, int(i), 0) > PT_MAX_BSDF_DEPTH) { ctx->error = "BSDF nesting deeper than 3 is not supported"; return TGHIP_E_UNSUPPORTED; }
     for (uint32_t i = 0; i < sd->num_lights; ++i) {
         int t = sd->objects[sd->lights[i]].type;
-        if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE) {
-            ctx->error = "only quad, cube, sphere and infinite_sphere emitters are sampled (mesh emitters are not)";
+        if (t == TGHIP_OBJ_MESH) {
+            const TgHipObject &lo = sd->objects[sd->lights[i]];
+            if (lo.first_light_tri < 0 || lo.num_light_tris <= 0 || !sd->light_tris ||
+                uint64_t(lo.first_light_tri) + uint64_t(lo.num_light_tris)*10u + 1u > sd->num_light_tri_floats) {
+                ctx->error = "sampled mesh emitter without a valid light_tris block";
+                return TGHIP_E_INVALID;
+            }
+        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE) {
+            ctx->error = "unknown emitter type";
             return TGHIP_E_UNSUPPORTED;
         }
     }
@@ -1427,6 +1475,10 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->textures, sd->num_textures, &s.textures)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->texels, sd->num_texel_floats, &s.texels)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->dist, sd->num_dist_floats, &s.dist)) != TGHIP_OK) return rc;
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->light_tris, sd->num_light_tri_floats, &s.light_tris)) != TGHIP_OK) return rc;
+    ctx->haveMeshLight = false;
+    for (uint32_t i = 0; i < sd->num_lights; ++i)
+        if (sd->objects[sd->lights[i]].type == TGHIP_OBJ_MESH) ctx->haveMeshLight = true;
     // CDF guide tables for the samplable bitmaps (pt_scene.h: upperBoundGuided)
     {
         std::vector<uint16_t> guide;
@@ -1542,13 +1594,14 @@ static void launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
 {
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrShadow);
     const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
-    if (!flat && !ctx->haveForward && ctx->dynamicFetch) {
+    const bool closestWalk = ctx->haveForward || ctx->haveMeshLight;   // shadow rays are closest-hit walks, not any-hit queries
+    if (!flat && !closestWalk && ctx->dynamicFetch) {
         hipLaunchKernelGGL(k_trace_shadow_dyn<COUNT>, dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow, true), ctx->stream,
                            ctx->scene, st, pp, iterTag);
         return;
     }
 #define SHADOW_LAUNCH(FWD, FLAT) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, FLAT>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
-    if (ctx->haveForward) { if (flat) SHADOW_LAUNCH(true, true); else SHADOW_LAUNCH(true, false); }
+    if (closestWalk) { if (flat) SHADOW_LAUNCH(true, true); else SHADOW_LAUNCH(true, false); }
     else                  { if (flat) SHADOW_LAUNCH(false, true); else SHADOW_LAUNCH(false, false); }
 #undef SHADOW_LAUNCH
 }
@@ -1564,7 +1617,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = s.num_recs <= TGHIP_FLAT_MAX_RECS;
-    const bool fused = flat && !ctx->haveForward && ctx->fuseFlatOpt;
+    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt;
     const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
@@ -1647,10 +1700,12 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
-            else                launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
+            if (ctx->haveMeshLight)  launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling
+            else if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
+            else                     launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
             if (ctx->haveComplex) {
-                if ((ctx->complexMask & ~MASK_COAT) == 0)       launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
+                if (ctx->haveMeshLight)                         launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 1);
+                else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
                 else                                            launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 1);
             }

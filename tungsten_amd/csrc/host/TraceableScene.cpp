@@ -157,9 +157,34 @@ void TraceableScene::flatten()
 
         if (emissive) {
             if (p.isSamplable()) {
-                if (p.type == Primitive::Mesh)
-                    throw std::runtime_error("emissive '" + p.name + "': mesh emitters are not yet inside the path_tracer_hip "
-                                             "hot-path scope (quad, cube, sphere and infinite_sphere lights are)");
+                if (p.type == Primitive::Mesh) {
+                    // TriangleMesh::makeSamplable (TriangleMesh.cpp:395-409) + Distribution1D (sampling/Distribution1D.hpp:16-30)
+                    const size_t n = p.tris.size();
+                    if (n == 0)
+                        throw std::runtime_error("emissive mesh '" + p.name + "' has no triangles");
+                    std::vector<float> areas(n), cdf(n + 1);
+                    float totalArea = 0.0f;
+                    for (size_t i = 0; i < n; ++i) {
+                        const MeshVertex &a = p.tfVerts[p.tris[i].v0], &b = p.tfVerts[p.tris[i].v1], &c = p.tfVerts[p.tris[i].v2];
+                        Vec3f p0(a.pos[0], a.pos[1], a.pos[2]), p1(b.pos[0], b.pos[1], b.pos[2]), p2(c.pos[0], c.pos[1], c.pos[2]);
+                        areas[i] = (p1 - p0).cross(p2 - p0).length()*0.5f;      // MathUtil::triangleArea
+                        totalArea += areas[i];
+                    }
+                    cdf[0] = 0.0f;
+                    for (size_t i = 0; i < n; ++i) cdf[i + 1] = cdf[i] + areas[i];
+                    float totalWeight = cdf[n];
+                    for (float &c : cdf) c /= totalWeight;
+                    cdf[n] = 1.0f;
+                    o.first_light_tri = int32_t(_lightTris.size());
+                    o.num_light_tris = int32_t(n);
+                    o.area = totalArea; o.inv_area = 1.0f/totalArea;
+                    _lightTris.insert(_lightTris.end(), cdf.begin(), cdf.end());
+                    for (size_t i = 0; i < n; ++i) {
+                        const MeshVertex *v[3] = {&p.tfVerts[p.tris[i].v0], &p.tfVerts[p.tris[i].v1], &p.tfVerts[p.tris[i].v2]};
+                        for (int k = 0; k < 3; ++k)
+                            _lightTris.insert(_lightTris.end(), v[k]->pos, v[k]->pos + 3);
+                    }
+                }
                 o.light = int32_t(_lights.size());
                 _lights.push_back(int32_t(pi));
             }
@@ -288,6 +313,7 @@ void TraceableScene::flatten()
     _desc.textures = _textures.data();
     _desc.texels = _texels.data(); _desc.num_texel_floats = _texels.size();
     _desc.dist = _dist.data();     _desc.num_dist_floats = _dist.size();
+    _desc.light_tris = _lightTris.data(); _desc.num_light_tri_floats = _lightTris.size();
     copy3(_desc.bounds_lo, _sceneBounds.lo);
     copy3(_desc.bounds_hi, _sceneBounds.hi);
 

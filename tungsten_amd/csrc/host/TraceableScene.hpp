@@ -29,7 +29,7 @@ class TraceableScene
     std::vector<int32_t> _lights, _infiniteLights;
     std::vector<TgHipBsdf> _bsdfs;
     std::vector<TgHipTexture> _textures;
-    std::vector<float> _texels, _dist;
+    std::vector<float> _texels, _dist, _lightTris;
     std::vector<std::shared_ptr<Primitive>> _allPrims;   // scene primitives (+ default light)
     TgHipSceneDesc _desc;
     Box3f _sceneBounds;
