@@ -1,6 +1,7 @@
 #include "BvhBuilder.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -9,7 +10,8 @@ namespace tungsten_amd {
 namespace {
 
 const int NumBins = 32;
-const float TraversalCost = 1.0f;
+// SAH constants; TGH_BVH_TRAV_COST / TGH_BVH_MAX_LEAF override them for tuning experiments (profiles/README.md)
+static float TraversalCost = 1.0f;
 const float IntersectionCost = 1.0f;
 
 struct Ref { Box3f box; Vec3f centroid; uint32_t prim; };
@@ -156,6 +158,8 @@ struct Builder
 
 BvhBuildResult buildBvh(const std::vector<Box3f> &primBounds, int maxLeafSize)
 {
+    if (const char *e = std::getenv("TGH_BVH_TRAV_COST")) TraversalCost = float(std::atof(e));
+    if (const char *e = std::getenv("TGH_BVH_MAX_LEAF")) maxLeafSize = std::atoi(e);
     Builder b;
     b.maxLeaf = std::min(std::max(maxLeafSize, 1), int(TGHIP_MAX_LEAF));
     b.refs.resize(primBounds.size());
