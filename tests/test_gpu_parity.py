@@ -278,3 +278,16 @@ def test_integrator_loop_and_outputs(tmp_path):
     r.close()
     assert os.path.getsize(png) > 1000
     assert np.allclose(tg.load_pfm(pfm), mean, rtol=1e-6, atol=1e-7)
+
+
+def test_large_passes_are_split_into_batches(tmp_path):
+    """A pass whose work items exceed `max_items` is split by sample range first, then by tiles (tghip_wait): every
+    pixel still receives exactly spp samples and the image equals the unsplit render up to summation order."""
+    path = scenes.cornell(tmp_path, resolution=(320, 180), spp=16)
+    base, _, cnt, c0 = gpu_render(path)
+    assert (cnt == 16).all()
+    for max_items in (1 << 16, 1 << 13):        # 230 400 items in one piece; forces sample-range and tile splits
+        img, _, cnt2, c = gpu_render(path, max_items=max_items)
+        assert (cnt2 == 16).all()
+        assert c.samples == 320*180*16
+        assert np.allclose(img, base, rtol=1e-5, atol=1e-6)

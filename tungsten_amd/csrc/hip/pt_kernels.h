@@ -96,6 +96,7 @@ struct PathState {
     BlockStats * __restrict__ stats;
     uint32_t * __restrict__ live;          // [0] = tag of the last iteration that left work in some extension queue; [1] = abort flag
     uint32_t num_slots, slots_per_block;
+    uint32_t leaf_batch;                   // dynamic-fetch traversal: lanes waiting at a leaf before the leaf code runs (1 = at once)
 };
 
 PT_DEV float4 &slotF4(const PathState &st, uint32_t a, uint32_t slot)

@@ -264,42 +264,52 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
         }
         if (busyMask == 0ull)
             break;
-        if (busy) {
-            bool pop = true;
-            if (cur >= 0) {
-                const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
-                float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                if (COUNT) nodes++;
-                float e0, e1;
-                bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, tmax, e0);
-                bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, tmax, e1);
-                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                if (h0 && h1) {
-                    if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
-                    else { stack[sp*stride] = c1; cur = c0; }
-                    sp++;
-                    pop = false;
-                } else if (h0) { cur = c0; pop = false; }
-                else if (h1) { cur = c1; pop = false; }
-            } else {
-                uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
-                for (uint32_t r = firstRec; r < firstRec + count; ++r) {
-                    if (COUNT) prims++;
-                    testRecord<false>(s, r, ray, tmax, hit);
+        // "while-while": lanes take node steps until they reach a leaf, then wait; the (long) leaf code runs only when
+        // enough lanes have one to process -- otherwise every iteration would pay for both the node and the leaf path
+        // with a handful of active lanes each.
+        bool pop = false;
+        if (busy && cur >= 0) {
+            const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
+            float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            if (COUNT) nodes++;
+            float e0, e1;
+            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, tmax, e0);
+            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, tmax, e1);
+            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (h0 && h1) {
+                if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
+                else { stack[sp*stride] = c1; cur = c0; }
+                sp++;
+            } else if (h0) { cur = c0; }
+            else if (h1) { cur = c1; }
+            else pop = true;
+        }
+        {
+            unsigned long long atLeaf = __ballot(busy && cur < 0 && !pop);
+            unsigned long long atNode = __ballot(busy && (cur >= 0 || pop));
+            // process leaves when a good part of the wave waits for it, or nobody has node work left
+            if (atLeaf != 0ull && ((uint32_t)__popcll(atLeaf) >= st.leaf_batch || atNode == 0ull)) {
+                if (busy && cur < 0 && !pop) {
+                    uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+                    for (uint32_t r = firstRec; r < firstRec + count; ++r) {
+                        if (COUNT) prims++;
+                        testRecord<false>(s, r, ray, tmax, hit);
+                    }
+                    pop = true;
                 }
             }
-            if (pop) {
-                if (sp == 0) {
-                    // finished: publish the hit and bin the path by shading class
-                    slotF4(st, A_HIT, slot) = hit;
-                    int ri = __float_as_int(hit.w);
-                    int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
-                    queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
-                    busy = false;
-                } else {
-                    sp--;
-                    cur = stack[sp*stride];
-                }
+        }
+        if (busy && pop) {
+            if (sp == 0) {
+                // finished: publish the hit and bin the path by shading class
+                slotF4(st, A_HIT, slot) = hit;
+                int ri = __float_as_int(hit.w);
+                int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
+                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
+                busy = false;
+            } else {
+                sp--;
+                cur = stack[sp*stride];
             }
         }
     }
@@ -1098,6 +1108,7 @@ struct tghip_ctx {
     int thrOverride[4] = {0, 0, 0, 0};
     bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
+    int leafBatch = 1;                    // "leaf_batch" (PathState::leaf_batch)
     long long poolPad = 9472;             // bytes between the per-slot arrays of the pool (multiple of 16)
     bool dynamicFetch = true;             // BVH scenes: closest-hit kernel with dynamic ray fetch (k_trace_closest_dyn)
     bool timeKernels = false;             // HIP events around every launch of the wavefront loop (bench.py roofline)
@@ -1411,6 +1422,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
     else if (k == "run_to_completion") ctx->loopOpt = value != 0;
     else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
@@ -1613,6 +1625,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
 {
     PathState st = ctx->pool;
     st.partial = ctx->partial;
+    st.leaf_batch = uint32_t(ctx->leafBatch);
     const DeviceScene &s = ctx->scene;
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
