@@ -173,6 +173,20 @@ def cornell_mesh_light(tmpdir, big=True, **kw):
     return variant(CORNELL, tmpdir, kw.pop("name", "mesh_light.json"), edit=edit, **kw)
 
 
+def _many_cubes(scene):
+    """300 small cubes and spheres scattered over the floor: analytic primitives inside a real BVH (not the flat-list path), and
+    object/bsdf tables too large for the shading kernels' LDS staging (the global-memory fallback)."""
+    import random
+    rnd = random.Random(7)
+    mats = ["leftWall", "rightWall", "floor", "backWall"]
+    for i in range(300):
+        x, z = rnd.uniform(-0.9, 0.9), rnd.uniform(-0.9, 0.9)
+        sz = rnd.uniform(0.02, 0.05)
+        scene["primitives"].append({"name": "c%d" % i, "type": "cube" if i % 3 else "sphere", "bsdf": mats[i % 4],
+                                    "transform": {"position": [x, sz, z], "scale": [2*sz, 2*sz, 2*sz] if i % 3 else sz,
+                                                  "rotation": [0, rnd.uniform(0, 90), 0]}})
+
+
 # name -> (builder, kwargs): every per-sample golden under tests/golden/<name>_samples.npz (tools/make_golden.py)
 GOLDEN_CASES = {
     "cornell": (cornell, dict(resolution=(48, 27), spp=8)),
@@ -183,6 +197,7 @@ GOLDEN_CASES = {
     "cornell_onesided": (cornell, dict(resolution=(32, 18), spp=8, integrator={"enable_two_sided_shading": False})),
     "cornell_box_filter": (cornell, dict(resolution=(32, 18), spp=8, edit=lambda s: s["camera"].update(reconstruction_filter="box"))),
     "cornell_two_lights": (cornell, dict(resolution=(32, 18), spp=8, edit=_two_lights)),
+    "cornell_many_cubes": (cornell, dict(resolution=(32, 18), spp=8, edit=_many_cubes)),
     "cornell_mesh_light": (cornell_mesh_light, dict(resolution=(32, 18), spp=8)),
     "cornell_mesh_light_flat": (lambda t, **kw: cornell_mesh_light(t, big=False, **kw), dict(resolution=(32, 18), spp=8)),
     "cornell_mesh_and_quad_light": (cornell_mesh_light, dict(resolution=(32, 18), spp=8, edit=_two_lights)),
