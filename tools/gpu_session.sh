@@ -18,8 +18,9 @@ for scene in cornell materialtest mesh1m; do
   f=$(find $out/prof_$scene -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $out/${scene}_kernel_stats.csv && head -8 $f
   find $out/prof_$scene -name '*kernel_trace.csv' -delete; find $out/prof_$scene -name '*.db' -delete
   echo "== rocprof pmc $scene"
+  pmcspp=$(( spp / 4 )); [ $scene = cornell ] && pmcspp=$spp   # the Cornell render is ONE launch: collect at the bench's spp
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${scene}_$c -o pmc -- python bench.py --scene $scene --spp $(( spp / 4 )) --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-kernel-timing > $out/pmc_${scene}_$c.log 2>&1; echo "$c rc=$?"
+    timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${scene}_$c -o pmc -- python bench.py --scene $scene --spp $pmcspp --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-kernel-timing > $out/pmc_${scene}_$c.log 2>&1; echo "$c rc=$?"
   done
   ff=$(find $out/pmc_${scene}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
   fw=$(find $out/pmc_${scene}_WRITE_SIZE -name '*counter_collection.csv' | head -1)
