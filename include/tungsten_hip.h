@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 2
+#define TGHIP_ABI_VERSION 3
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -207,6 +207,9 @@ typedef struct TgHipSceneDesc {
      * cdf[n + 1] of the triangle areas (Distribution1D: normalised, last = 1), then n x 9 floats p0,p1,p2 (world space,
      * the mesh's own triangle order); objects[].area is the total area */
     const float        *light_tris;  uint64_t num_light_tri_floats;
+    /* generator matrices of the Sobol' sequence, TGHIP_SOBOL_DIMS x TGHIP_SOBOL_BITS words -- the host's own copy of
+     * sobol::Matrices::matrices (thirdparty/sobol/sobol.h:30-35); NULL/0 unless passes use TGHIP_PASS_SOBOL */
+    const uint32_t     *sobol_matrices;  uint64_t num_sobol_words;
     TgHipCamera   camera;
     TgHipSettings settings;
     float         bounds_lo[3], bounds_hi[3];
@@ -217,11 +220,30 @@ typedef struct TgHipSceneDesc {
  * follows the reference's 16x16 tile dicing (PathTraceIntegrator.cpp:27-42): tile t (row-major)
  * belongs to shard (t % shard_count).  Random numbers are a counter-based PCG stream keyed by
  * (seed, pixelIndex, sampleIndex) -- see DESIGN.md "RNG". */
+#define TGHIP_SOBOL_DIMS 1024u
+#define TGHIP_SOBOL_BITS 52u
+#define TGHIP_TILE_SIZE 16u              /* PathTraceIntegrator::TileSize */
+#define TGHIP_VARIANCE_TILE_SIZE 4u      /* PathTraceIntegrator::VarianceTileSize: one SampleRecord per 4x4 pixels */
+/* pass flags */
+#define TGHIP_PASS_SOBOL   1u   /* next1D/next2D come from the scrambled Sobol' sequence exactly as SobolPathSampler does
+                                   (sampling/SobolPathSampler.hpp:20-79: scramble = tile seed ^ hash32(pixel), permuted index,
+                                   one dimension per draw up to 1024); booleans and later dimensions come from the
+                                   counter-based PCG stream (the reference uses a sequential per-tile stream there) */
+#define TGHIP_PASS_RECORDS 2u   /* keep the per-4x4-pixel SampleRecords (path_tracer/SampleRecord.hpp:46-65) up to date */
+
+/* the device-resident part of SampleRecord: Welford mean / running variance of the sample luminance,
+ * accumulated in the reference's order (tile row-major pixel order, then sample index: PathTraceIntegrator.cpp:136-156) */
+typedef struct TgHipSampleRecord { uint32_t sample_count; float mean, running_variance; } TgHipSampleRecord;
+
 typedef struct TgHipPassDesc {
     uint32_t spp_begin, spp_end;
     uint32_t seed;
     uint32_t shard_index, shard_count;   /* 0,1 = whole image */
-    uint32_t flags;                      /* reserved */
+    uint32_t flags;                      /* TGHIP_PASS_* */
+    /* host arrays, borrowed until tghip_wait returns; NULL when unused */
+    const uint32_t *tile_seeds;          /* TGHIP_PASS_SOBOL: SobolPathSampler seed per 16x16 tile, dice order */
+    const uint32_t *record_index;        /* adaptive sampling: per SampleRecord (ceil(W/4) x ceil(H/4), row-major) the first */
+    const uint32_t *record_count;        /*   sample index and the samples per pixel of this pass; then spp_begin/spp_end are ignored */
 } TgHipPassDesc;
 
 typedef struct TgHipCounters {
@@ -258,6 +280,10 @@ int tghip_clear_framebuffer(tghip_ctx *ctx);
  * count = W*H uint32.  Pass NULLs to go back to the internal buffers. */
 int tghip_bind_framebuffer(tghip_ctx *ctx, float *dev_rgb_sum, uint32_t *dev_count);
 int tghip_download_framebuffer(tghip_ctx *ctx, float *rgb_sum, uint32_t *count, size_t npixels);
+/* SampleRecords (TGHIP_PASS_RECORDS): n = ceil(W/4)*ceil(H/4); cleared by tghip_clear_framebuffer.  Records of tiles
+ * this context never rendered stay zero; upload restores a resumed / merged state. */
+int tghip_download_records(tghip_ctx *ctx, TgHipSampleRecord *out, size_t n);
+int tghip_upload_records(tghip_ctx *ctx, const TgHipSampleRecord *in, size_t n);
 int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);

@@ -46,6 +46,30 @@ int  tgh_renderer_image(tgh_renderer *r, float *rgb_mean, float *rgb_sum, uint32
 int  tgh_renderer_save_outputs(tgh_renderer *r, char *err, size_t errlen);
 void tgh_renderer_close(tgh_renderer *r);
 
+/* ---- pass scheduling (PathTraceIntegrator.cpp:27-134) -------------------------------------------------
+ * SampleRecord as the integrator holds it (path_tracer/SampleRecord.hpp:13-16).  sample_count, mean and
+ * running_variance are accumulated on the device (TGHIP_PASS_RECORDS); the rest is host state. */
+typedef struct TgHostSampleRecord {
+    uint32_t sample_count, next_sample_count, sample_index;
+    float    adaptive_weight, mean, running_variance;
+} TgHostSampleRecord;
+
+/* records of the renderer after the last pass: n = ceil(W/4)*ceil(H/4) */
+int  tgh_renderer_records(tgh_renderer *r, TgHostSampleRecord *out, size_t n, char *err, size_t errlen);
+
+/* The scheduler on its own (no device): tile seeds + generateWork over caller-supplied record statistics. */
+typedef struct tgh_scheduler tgh_scheduler;
+tgh_scheduler *tgh_scheduler_create(uint32_t width, uint32_t height, uint32_t seed);
+size_t tgh_scheduler_num_tiles(tgh_scheduler *s);
+size_t tgh_scheduler_num_records(tgh_scheduler *s);
+const uint32_t *tgh_scheduler_tile_seeds(tgh_scheduler *s);
+TgHostSampleRecord *tgh_scheduler_records(tgh_scheduler *s);   /* mutable view */
+/* returns 1 when the pass has work, 0 when not (PathTraceIntegrator.cpp:108-134) */
+int  tgh_scheduler_generate_work(tgh_scheduler *s, uint32_t current_spp, uint32_t next_spp, int adaptive);
+void tgh_scheduler_free(tgh_scheduler *s);
+/* the Sobol' generator matrices the host hands to the device (NULL + message when the data file is missing) */
+const uint32_t *tgh_sobol_matrices(size_t *num_words, char *err, size_t errlen);
+
 /* file-format helpers used by the tests */
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h);
 int tgh_load_hdr(const char *path, float *rgb /* may be NULL to query size */, int *w, int *h);

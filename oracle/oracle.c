@@ -82,7 +82,12 @@ typedef struct {
     const float *replay;   /* when non-NULL, next1D() returns these numbers instead (unit tests) */
     int replay_pos, replay_n;
     uint32_t draws;
+    /* SobolPathSampler state (sampling/SobolPathSampler.hpp:14-18); sobol == NULL: uniform sampler */
+    const uint32_t *sobol;
+    uint32_t scramble, index, dimension;
+    float *log; int log_n, log_cap;   /* debugging: every number drawn (oracle_trace_sample_log) */
 } Sampler;
+static inline float sampler_log(Sampler *s, float v) { if (s->log && s->log_n < s->log_cap) s->log[s->log_n++] = v; return v; }
 
 static void sampler_start(Sampler *s, uint32_t seed, uint32_t pixelIndex, uint32_t sampleIndex)
 {
@@ -92,6 +97,29 @@ static void sampler_start(Sampler *s, uint32_t seed, uint32_t pixelIndex, uint32
     s->state = ((uint64_t)hi << 32) | lo;
     s->inc = ((uint64_t)pixelIndex << 1) | 1u;
     s->replay = NULL; s->replay_pos = s->replay_n = 0; s->draws = 0;
+    s->sobol = NULL; s->scramble = s->index = s->dimension = 0;
+    s->log = NULL; s->log_n = s->log_cap = 0;
+}
+
+/* SobolPathSampler::startPath (SobolPathSampler.hpp:47-52); the supplemental stream (booleans, dimensions >= 1024)
+ * is the counter-based one above instead of the reference's sequential per-tile UniformSampler */
+static void sampler_start_sobol(Sampler *s, const uint32_t *matrices, uint32_t tileSeed, uint32_t seed, uint32_t pixelIndex, uint32_t sampleIndex)
+{
+    sampler_start(s, seed, pixelIndex, sampleIndex);
+    s->sobol = matrices;
+    s->scramble = tileSeed ^ hash32(pixelIndex);
+    s->index = sampleIndex;
+    s->dimension = 0;
+}
+
+/* sobol::sample (thirdparty/sobol/sobol.h:39-53): XOR of the generator-matrix columns selected by the index bits */
+static inline uint32_t sobol_sample(const uint32_t *matrices, uint64_t index, uint32_t dimension, uint32_t scramble)
+{
+    uint32_t result = scramble;
+    for (uint32_t i = dimension*TGHIP_SOBOL_BITS; index; index >>= 1, ++i)
+        if (index & 1)
+            result ^= matrices[i];
+    return result;
 }
 
 static inline uint32_t sampler_nextI(Sampler *s)   /* UniformSampler.hpp:40-47 */
@@ -110,7 +138,7 @@ static inline float normalizedUint(uint32_t i)   /* BitManip.hpp:47-50 */
     return c.f - 1.0f;
 }
 
-static inline float next1D(Sampler *s)
+static inline float nextSupplemental(Sampler *s)
 {
     s->draws++;
     if (s->replay) {
@@ -118,9 +146,19 @@ static inline float next1D(Sampler *s)
         s->replay_pos++;
         return v;
     }
-    return normalizedUint(sampler_nextI(s));
+    return sampler_log(s, normalizedUint(sampler_nextI(s)));
 }
-static inline int nextBoolean(Sampler *s, float pTrue) { return next1D(s) < pTrue; }   /* UniformPathSampler.hpp:39-42 */
+static inline float next1D(Sampler *s)   /* UniformPathSampler.hpp:44-47 / SobolPathSampler.hpp:64-69 */
+{
+    if (s->sobol && s->dimension < TGHIP_SOBOL_DIMS) {
+        uint32_t permuted = (s->index & ~0xFFu) | ((s->index + s->scramble) & 0xFFu);   /* permutedIndex(), :20-23 */
+        s->draws++;
+        return sampler_log(s, normalizedUint(sobol_sample(s->sobol, permuted, s->dimension++, s->scramble)));
+    }
+    return nextSupplemental(s);
+}
+/* UniformPathSampler.hpp:39-42 / SobolPathSampler.hpp:54-57 (always the supplemental stream) */
+static inline int nextBoolean(Sampler *s, float pTrue) { return nextSupplemental(s) < pTrue; }
 
 /* ---------------------------------------------------------------------------------------------
  * Sample warps (sampling/SampleWarp.hpp)
@@ -1884,14 +1922,56 @@ void oracle_trace_sample(const TgHipSceneDesc *s, uint32_t seed, uint32_t px, ui
     rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
 }
 
-/* One pass over the shard's pixels, renderTile semantics (PathTraceIntegrator.cpp:136-156) with the
- * framebuffer kept as sum + count (OutputBuffer.hpp:104-107 drops NaN/Inf samples without counting). */
-int oracle_render(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb_sum, uint32_t *count,
-                  OracleCounters *counters, int nthreads)
+/* SampleRecord::addSample (path_tracer/SampleRecord.hpp:46-58) */
+static inline void record_add(TgHipSampleRecord *r, v3 c)
+{
+    float x = c.x*0.2126f + c.y*0.7152f + c.z*0.0722f;   /* Vec3f::luminance (math/Vec.hpp:195-199) */
+    r->sample_count++;
+    float delta = x - r->mean;
+    r->mean += delta/(float)r->sample_count;
+    r->running_variance += delta*(x - r->mean);
+}
+
+/* one path under the Sobol' sampler of the tile with seed tileSeed (SobolPathSampler + PathTracer::traceSample) */
+void oracle_trace_sample_sobol(const TgHipSceneDesc *s, uint32_t seed, uint32_t tileSeed, uint32_t px, uint32_t py, uint32_t sampleIndex, float *rgb)
+{
+    Sampler smp;
+    sampler_start_sobol(&smp, s->sobol_matrices, tileSeed, seed, px + py*(uint32_t)s->camera.res_x, sampleIndex);
+    Ctx c = {s, &smp, NULL, 0, 0};
+    v3 r = traceSample(&c, px, py);
+    rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
+}
+
+/* debugging aid: one path with the Sobol' sampler, logging the numbers it draws; returns how many */
+int oracle_trace_sample_log(const TgHipSceneDesc *s, uint32_t seed, uint32_t tileSeed, int sobol, uint32_t px, uint32_t py, uint32_t sampleIndex,
+                            float *rgb, float *log, int log_cap)
+{
+    Sampler smp;
+    uint32_t pixelIndex = px + py*(uint32_t)s->camera.res_x;
+    if (sobol) sampler_start_sobol(&smp, s->sobol_matrices, tileSeed, seed, pixelIndex, sampleIndex);
+    else       sampler_start(&smp, seed, pixelIndex, sampleIndex);
+    smp.log = log; smp.log_cap = log_cap;
+    Ctx c = {s, &smp, NULL, 0, 0};
+    v3 r = traceSample(&c, px, py);
+    rgb[0] = r.x; rgb[1] = r.y; rgb[2] = r.z;
+    return smp.log_n;
+}
+
+/* One pass over the shard's tiles, renderTile semantics (PathTraceIntegrator.cpp:136-156) with the
+ * framebuffer kept as sum + count (OutputBuffer.hpp:104-107 drops NaN/Inf samples without counting).
+ * records (may be NULL): the SampleRecords, updated in the reference's order when TGHIP_PASS_RECORDS is set. */
+int oracle_render_records(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb_sum, uint32_t *count,
+                          TgHipSampleRecord *records, OracleCounters *counters, int nthreads)
 {
     int w = s->camera.res_x, h = s->camera.res_y;
-    int tilesX = (w + 15)/16;
+    int tilesX = (w + 15)/16, tilesY = (h + 15)/16;
+    int varW = (w + 3)/4;
     uint32_t shardCount = pass->shard_count ? pass->shard_count : 1;
+    const int sobol = (pass->flags & TGHIP_PASS_SOBOL) != 0;
+    if (sobol && (!s->sobol_matrices || s->num_sobol_words < (uint64_t)TGHIP_SOBOL_DIMS*TGHIP_SOBOL_BITS || !pass->tile_seeds))
+        return -1;
+    if (!(pass->flags & TGHIP_PASS_RECORDS))
+        records = NULL;
     uint64_t tot[5] = {0, 0, 0, 0, 0};
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -1903,24 +1983,35 @@ int oracle_render(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb
         uint64_t loc[5] = {0, 0, 0, 0, 0};
         TravStats st = {0, 0, 0};
         #pragma omp for schedule(dynamic, 1)
-        for (int y = 0; y < h; ++y) {
-            for (int x = 0; x < w; ++x) {
-                uint32_t tile = (uint32_t)((y/16)*tilesX + x/16);
-                if (tile % shardCount != pass->shard_index)
-                    continue;
-                uint32_t pixelIndex = (uint32_t)(x + y*w);
-                for (uint32_t sidx = pass->spp_begin; sidx < pass->spp_end; ++sidx) {
-                    Sampler smp;
-                    sampler_start(&smp, pass->seed, pixelIndex, sidx);
-                    Ctx c = {s, &smp, counters ? &st : NULL, 0, 0};
-                    v3 r = traceSample(&c, (uint32_t)x, (uint32_t)y);
-                    loc[0]++; loc[1] += c.closest_rays; loc[2] += c.shadow_rays;
-                    if (isnan(r.x) || isnan(r.y) || isnan(r.z) || isinf(r.x) || isinf(r.y) || isinf(r.z))
-                        continue;
-                    rgb_sum[pixelIndex*3 + 0] += r.x;
-                    rgb_sum[pixelIndex*3 + 1] += r.y;
-                    rgb_sum[pixelIndex*3 + 2] += r.z;
-                    count[pixelIndex]++;
+        for (int tile = 0; tile < tilesX*tilesY; ++tile) {
+            if ((uint32_t)tile % shardCount != pass->shard_index)
+                continue;
+            int x0 = (tile % tilesX)*16, y0 = (tile/tilesX)*16;
+            for (int y = y0; y < y0 + 16 && y < h; ++y) {
+                for (int x = x0; x < x0 + 16 && x < w; ++x) {
+                    uint32_t pixelIndex = (uint32_t)(x + y*w);
+                    uint32_t rec = (uint32_t)(x/4 + (y/4)*varW);
+                    uint32_t begin = pass->spp_begin, end = pass->spp_end;
+                    if (pass->record_count) {
+                        begin = pass->record_index[rec];
+                        end = begin + pass->record_count[rec];
+                    }
+                    for (uint32_t sidx = begin; sidx < end; ++sidx) {
+                        Sampler smp;
+                        if (sobol) sampler_start_sobol(&smp, s->sobol_matrices, pass->tile_seeds[tile], pass->seed, pixelIndex, sidx);
+                        else       sampler_start(&smp, pass->seed, pixelIndex, sidx);
+                        Ctx c = {s, &smp, counters ? &st : NULL, 0, 0};
+                        v3 r = traceSample(&c, (uint32_t)x, (uint32_t)y);
+                        loc[0]++; loc[1] += c.closest_rays; loc[2] += c.shadow_rays;
+                        if (records)
+                            record_add(&records[rec], r);
+                        if (isnan(r.x) || isnan(r.y) || isnan(r.z) || isinf(r.x) || isinf(r.y) || isinf(r.z))
+                            continue;
+                        rgb_sum[pixelIndex*3 + 0] += r.x;
+                        rgb_sum[pixelIndex*3 + 1] += r.y;
+                        rgb_sum[pixelIndex*3 + 2] += r.z;
+                        count[pixelIndex]++;
+                    }
                 }
             }
         }
@@ -1933,6 +2024,168 @@ int oracle_render(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb
         counters->nodes_visited += tot[3]; counters->prims_tested += tot[4];
     }
     return 0;
+}
+
+int oracle_render(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb_sum, uint32_t *count,
+                  OracleCounters *counters, int nthreads)
+{
+    return oracle_render_records(s, pass, rgb_sum, count, NULL, counters, nthreads);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * The pass scheduler of PathTraceIntegrator (PathTraceIntegrator.cpp:27-134, 184-239) + SampleRecord.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {   /* path_tracer/SampleRecord.hpp:13-16 */
+    uint32_t sampleCount, nextSampleCount, sampleIndex;
+    float adaptiveWeight, mean, runningVariance;
+} OracleRecord;
+
+typedef struct { uint64_t state; } HostSampler;   /* UniformSampler with sequence 0 (UniformSampler.hpp:22-26) */
+static uint32_t host_nextI(HostSampler *u)
+{
+    uint64_t oldState = u->state;
+    u->state = oldState*6364136223846793005ULL + 1u;
+    uint32_t xorShifted = (uint32_t)(((oldState >> 18u) ^ oldState) >> 27u);
+    uint32_t rot = (uint32_t)(oldState >> 59u);
+    return (xorShifted >> rot) | (xorShifted << ((uint32_t)(-(int32_t)rot) & 31));
+}
+
+static float record_errorEstimate(const OracleRecord *r)   /* SampleRecord.hpp:60-68 */
+{
+    float variance = r->runningVariance/(float)(r->sampleCount - 1u);
+    float m2 = r->mean*r->mean;
+    return variance/((float)r->sampleCount*(m2 > 1e-3f ? m2 : 1e-3f));
+}
+
+static int cmp_float(const void *a, const void *b)
+{
+    float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* PathTraceIntegrator::generateWork (:108-134) with errorPercentile95 (:44-60), dilateAdaptiveWeights (:62-88)
+ * and distributeAdaptiveSamples (:90-112).  Returns 0 when there is nothing to render this pass. */
+static int generate_work(OracleRecord *rec, int varW, int varH, int w, int h, HostSampler *smp,
+                         uint32_t currentSpp, uint32_t nextSpp, int adaptive)
+{
+    int n = varW*varH;
+    for (int i = 0; i < n; ++i)
+        rec[i].sampleIndex += rec[i].nextSampleCount;
+    int sppCount = (int)(nextSpp - currentSpp);
+    if (adaptive && currentSpp >= 16u) {
+        float *errors = (float *)malloc(sizeof(float)*(size_t)n);
+        int ne = 0;
+        for (int i = 0; i < n; ++i) {
+            rec[i].adaptiveWeight = record_errorEstimate(&rec[i]);
+            if (rec[i].adaptiveWeight > 0.0f)
+                errors[ne++] = rec[i].adaptiveWeight;
+        }
+        float maxError = 0.0f;
+        if (ne) {
+            qsort(errors, (size_t)ne, sizeof(float), cmp_float);
+            maxError = errors[((size_t)ne*95)/100];
+        }
+        free(errors);
+        if (maxError == 0.0f)
+            return 0;
+        for (int i = 0; i < n; ++i)
+            rec[i].adaptiveWeight = rec[i].adaptiveWeight < maxError ? rec[i].adaptiveWeight : maxError;
+#define MAXW(a, b) ((a) > (b) ? (a) : (b))
+        for (int y = 0; y < varH; ++y)
+            for (int x = 0; x < varW; ++x) {
+                int idx = x + y*varW;
+                if (y < varH - 1) rec[idx].adaptiveWeight = MAXW(rec[idx].adaptiveWeight, rec[idx + varW].adaptiveWeight);
+                if (x < varW - 1) rec[idx].adaptiveWeight = MAXW(rec[idx].adaptiveWeight, rec[idx + 1].adaptiveWeight);
+            }
+        for (int y = varH - 1; y >= 0; --y)
+            for (int x = varW - 1; x >= 0; --x) {
+                int idx = x + y*varW;
+                if (y > 0) rec[idx].adaptiveWeight = MAXW(rec[idx].adaptiveWeight, rec[idx - varW].adaptiveWeight);
+                if (x > 0) rec[idx].adaptiveWeight = MAXW(rec[idx].adaptiveWeight, rec[idx - 1].adaptiveWeight);
+            }
+#undef MAXW
+        double totalWeight = 0.0;
+        for (int i = 0; i < n; ++i)
+            totalWeight += rec[i].adaptiveWeight;
+        int adaptiveBudget = (sppCount - 1)*w*h;
+        int budgetPerTile = adaptiveBudget/16;
+        float weightToSampleFactor = (float)((double)budgetPerTile/totalWeight);
+        float pixelPdf = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            float fractionalSamples = rec[i].adaptiveWeight*weightToSampleFactor;
+            int adaptiveSamples = (int)fractionalSamples;
+            pixelPdf += fractionalSamples - (float)adaptiveSamples;
+            if (normalizedUint(host_nextI(smp)) < pixelPdf) {
+                adaptiveSamples++;
+                pixelPdf -= 1.0f;
+            }
+            rec[i].nextSampleCount = (uint32_t)(adaptiveSamples + 1);
+        }
+    } else {
+        for (int i = 0; i < n; ++i)
+            rec[i].nextSampleCount = (uint32_t)sppCount;
+    }
+    return 1;
+}
+
+/* the scheduler alone, for pinning against the reference's dumps: state = the integrator's _sampler after dicing */
+int oracle_generate_work(OracleRecord *rec, int w, int h, uint64_t *sampler_state, uint32_t currentSpp, uint32_t nextSpp, int adaptive)
+{
+    HostSampler smp = {*sampler_state};
+    int r = generate_work(rec, (w + 3)/4, (h + 3)/4, w, h, &smp, currentSpp, nextSpp, adaptive);
+    *sampler_state = smp.state;
+    return r;
+}
+
+/* diceTiles (:27-42) after prepareForRender's `_sampler = UniformSampler(MathUtil::hash32(seed))` (:187): one
+ * SobolPathSampler/UniformPathSampler seed per tile; returns the sampler state afterwards */
+uint64_t oracle_dice_tiles(int w, int h, uint32_t seed, uint32_t *tile_seeds)
+{
+    HostSampler smp = {hash32(seed)};
+    int tiles = ((w + 15)/16)*((h + 15)/16);
+    for (int i = 0; i < tiles; ++i)
+        tile_seeds[i] = hash32(host_nextI(&smp));
+    return smp.state;
+}
+
+/* The whole render loop of the CLI (Shared.hpp:281-315: while (!done) { startRender; waitForCompletion; }).
+ * records_out: max_passes x (varW*varH) records, dumped after every pass; returns the number of passes. */
+int oracle_integrate(const TgHipSceneDesc *s, uint32_t seed, uint32_t spp, uint32_t sppStep, int adaptive, int sobol,
+                     float *rgb_sum, uint32_t *count, OracleRecord *records_out, int max_passes, uint32_t *pass_spp, int nthreads)
+{
+    int w = s->camera.res_x, h = s->camera.res_y;
+    int varW = (w + 3)/4, varH = (h + 3)/4, n = varW*varH;
+    int tiles = ((w + 15)/16)*((h + 15)/16);
+    uint32_t *tileSeeds = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)tiles);
+    HostSampler smp = {oracle_dice_tiles(w, h, seed, tileSeeds)};
+    OracleRecord *rec = (OracleRecord *)calloc((size_t)n, sizeof(OracleRecord));
+    TgHipSampleRecord *dev = (TgHipSampleRecord *)calloc((size_t)n, sizeof(TgHipSampleRecord));
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)n), *cnt = (uint32_t *)malloc(sizeof(uint32_t)*(size_t)n);
+    uint32_t currentSpp = 0, nextSpp = sppStep < spp ? sppStep : spp;   /* Integrator::advanceSpp (Integrator.cpp:51-54) */
+    int passes = 0, rc = 0;
+    while (currentSpp < spp) {
+        if (generate_work(rec, varW, varH, w, h, &smp, currentSpp, nextSpp, adaptive)) {
+            for (int i = 0; i < n; ++i) { idx[i] = rec[i].sampleIndex; cnt[i] = rec[i].nextSampleCount; }
+            TgHipPassDesc pass;
+            memset(&pass, 0, sizeof(pass));
+            pass.spp_begin = currentSpp; pass.spp_end = nextSpp; pass.seed = seed;
+            pass.shard_index = 0; pass.shard_count = 1;
+            pass.flags = TGHIP_PASS_RECORDS | (sobol ? TGHIP_PASS_SOBOL : 0u);
+            pass.tile_seeds = tileSeeds; pass.record_index = idx; pass.record_count = cnt;
+            rc = oracle_render_records(s, &pass, rgb_sum, count, dev, NULL, nthreads);
+            if (rc) break;
+            for (int i = 0; i < n; ++i) { rec[i].sampleCount = dev[i].sample_count; rec[i].mean = dev[i].mean; rec[i].runningVariance = dev[i].running_variance; }
+        }
+        currentSpp = nextSpp;
+        nextSpp = currentSpp + sppStep < spp ? currentSpp + sppStep : spp;
+        if (passes < max_passes) {
+            if (records_out) memcpy(records_out + (size_t)passes*(size_t)n, rec, sizeof(OracleRecord)*(size_t)n);
+            if (pass_spp) pass_spp[passes] = currentSpp;
+        }
+        passes++;
+    }
+    free(tileSeeds); free(rec); free(dev); free(idx); free(cnt);
+    return rc ? rc : passes;
 }
 
 /* batched TraceableScene::intersect; also returns the exact visit counts that feed the

@@ -2,7 +2,7 @@
 // *reference implementation* (libcore.a etc. built by oracle/Makefile.ref from /root/reference)
 // and produces the golden vectors under tests/golden/ that pin oracle/oracle.c:
 //
-//   ref_harness render  <scene.json> <seed> <spp> <out.pfm> [threads]
+//   ref_harness render  <scene.json> <seed> <spp> <out.pfm> [threads] [first sample]
 //       mean radiance per pixel from the reference's own PathTracer::traceSample, with the
 //       random numbers supplied by GraftPathSampler below -- the same counter-based stream
 //       (keyed by seed, pixelIndex, sampleIndex) the oracle and the HIP kernels use.  Because the
@@ -13,9 +13,46 @@
 //       float32[h][w][spp][3] radiance of every individual sample.
 //   ref_harness units   <scene.json> <out.json>
 //       known-answer vectors of the deterministic building blocks (L1 in SURVEY.md 8c).
+//   ref_harness integrate <scene.json> <seed> <out.bin> [threads]
+//       the reference's OWN PathTraceIntegrator pass loop (diceTiles, generateWork, adaptive sampling,
+//       SampleRecord, OutputBuffer) with the tile samplers swapped for the shared counter-based ones
+//       (GraftPathSampler / GraftSobolPathSampler).  Dumps the SampleRecords after every pass and the
+//       final image.
+//   ref_harness sobol-table <out.bin>
+//       the 1024 x 52 generator matrices of the Sobol' sequence (sobol::Matrices::matrices) as u32.
 //
 // Nothing here is copied from the reference; it only calls its public classes.
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <functional>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+#include "sampling/PathSampleGenerator.hpp"
+#include "sampling/UniformSampler.hpp"
+#include "thread/TaskGroup.hpp"
+#include "integrators/Integrator.hpp"
+#include "integrators/ImageTile.hpp"
+#include "integrators/path_tracer/PathTracerSettings.hpp"
+#include "integrators/path_tracer/SampleRecord.hpp"
+#include "integrators/path_tracer/PathTracer.hpp"
+#include "math/MathUtil.hpp"
+#include <sobol/sobol.h>
+// The integrate command inspects the integrator's tiles and SampleRecords, which the reference keeps
+// private: open the two class definitions up (every standard/other header they use is already included).
+#define private public
+#define protected public
+#define class struct
+#include "sampling/SobolPathSampler.hpp"
 #include "integrators/path_tracer/PathTraceIntegrator.hpp"
+#undef private
+#undef protected
+#undef class
 #include "integrators/path_tracer/PathTracer.hpp"
 #include "primitives/EmbreeUtil.hpp"
 #include "primitives/InfiniteSphere.hpp"
@@ -37,6 +74,8 @@
 #include <vector>
 
 using namespace Tungsten;
+
+static std::vector<std::pair<char, float>> *g_drawLog = nullptr;   // `draws` command: every number a path consumed
 
 // The counter-based stream shared with oracle/oracle.c (sampler_start) and the HIP kernels.
 class GraftPathSampler : public PathSampleGenerator
@@ -71,12 +110,53 @@ public:
         draws++;
         if (_useReplay)
             return _replayPos < _replay.size() ? _replay[_replayPos++] : (++_replayPos, 0.5f);
-        return _sampler.next1D();
+        float v = _sampler.next1D();
+        if (g_drawLog) g_drawLog->push_back(std::make_pair('u', v));
+        return v;
     }
     virtual bool nextBoolean(float pTrue) override final { return next1D() < pTrue; }
     virtual int nextDiscrete(int numChoices) override final { return int(next1D()*numChoices); }
     virtual Vec2f next2D() override final { float a = next1D(); float b = next1D(); return Vec2f(a, b); }
     virtual UniformSampler &uniformGenerator() override final { return _sampler; }
+};
+
+// SobolPathSampler (sampling/SobolPathSampler.hpp:20-79) with its sequential per-tile supplemental
+// stream (booleans, dimensions >= 1024) replaced by the counter-based stream above; the Sobol'
+// dimensions themselves are the reference's: same tile seed, scramble, permuted index.
+class GraftSobolPathSampler : public PathSampleGenerator
+{
+    GraftPathSampler _supplemental;
+    uint32 _tileSeed, _scramble = 0, _index = 0, _dimension = 0;
+
+public:
+    GraftSobolPathSampler(uint32 tileSeed, uint32 seed) : _supplemental(seed), _tileSeed(tileSeed) {}
+    void setTileSeed(uint32 tileSeed) { _tileSeed = tileSeed; }
+    uint64 draws() const { return _supplemental.draws; }
+
+    virtual void startPath(uint32 pixelId, uint32 sample) override
+    {
+        _scramble = _tileSeed ^ MathUtil::hash32(pixelId);
+        _index = sample;
+        _dimension = 0;
+        _supplemental.startPath(pixelId, sample);
+    }
+    virtual void advancePath() override {}
+    virtual void saveState(OutputStreamHandle &) override {}
+    virtual void loadState(InputStreamHandle &) override {}
+
+    virtual float next1D() override final
+    {
+        if (_dimension >= 1024)
+            return _supplemental.next1D();
+        uint32 permuted = (_index & ~0xFFu) | ((_index + _scramble) & 0xFFu);
+        float v = BitManip::normalizedUint(sobol::sample(permuted, _dimension++, _scramble));
+        if (g_drawLog) g_drawLog->push_back(std::make_pair('s', v));
+        return v;
+    }
+    virtual bool nextBoolean(float pTrue) override final { return _supplemental.next1D() < pTrue; }
+    virtual int nextDiscrete(int numChoices) override final { return int(_supplemental.next1D()*numChoices); }
+    virtual Vec2f next2D() override final { float a = next1D(); float b = next1D(); return Vec2f(a, b); }
+    virtual UniformSampler &uniformGenerator() override final { return _supplemental.uniformGenerator(); }
 };
 
 struct Loaded
@@ -119,6 +199,17 @@ static int cmdRender(int argc, char **argv, bool dumpSamples)
     Loaded L;
     if (!loadScene(argv[2], seed, L)) return 1;
     int w = L.scene->camera()->resolution().x(), h = L.scene->camera()->resolution().y();
+    // "stratified_sampler": true -> the tiles' SobolPathSampler seeds, exactly as diceTiles draws them
+    // (PathTraceIntegrator.cpp:27-42 after :187); [first sample] optional 7th argument
+    const bool sobol = L.scene->rendererSettings().useSobol();
+    const int firstSample = argc > 7 ? std::atoi(argv[7]) : 0;
+    std::vector<uint32> tileSeeds;
+    {
+        UniformSampler dice(MathUtil::hash32(seed));
+        for (int ty = 0; ty < (h + 15)/16; ++ty)
+            for (int tx = 0; tx < (w + 15)/16; ++tx)
+                tileSeeds.push_back(MathUtil::hash32(dice.nextI()));
+    }
 
     std::vector<float> mean(size_t(w)*h*3, 0.0f);
     std::vector<float> samples;
@@ -128,14 +219,17 @@ static int cmdRender(int argc, char **argv, bool dumpSamples)
     for (int t = 0; t < threads; ++t) {
         pool.emplace_back([&, t]() {
             PathTracer tracer(L.ts.get(), L.pti->settings(), uint32(t));
-            GraftPathSampler sampler(seed);
+            GraftPathSampler uniformSampler(seed);
+            GraftSobolPathSampler sobolSampler(0, seed);
+            PathSampleGenerator &sampler = sobol ? static_cast<PathSampleGenerator &>(sobolSampler) : uniformSampler;
             for (int y = t; y < h; y += threads) {
                 for (int x = 0; x < w; ++x) {
                     uint32 pixelIndex = uint32(x + y*w);
+                    sobolSampler.setTileSeed(tileSeeds[size_t(y/16)*size_t((w + 15)/16) + size_t(x/16)]);
                     float sum[3] = {0, 0, 0};
                     uint32 count = 0;
                     for (int s = 0; s < spp; ++s) {
-                        sampler.startPath(pixelIndex, uint32(s));
+                        sampler.startPath(pixelIndex, uint32(firstSample + s));
                         Vec3f c = tracer.traceSample(Vec2u(uint32(x), uint32(y)), sampler);
                         if (dumpSamples)
                             for (int k = 0; k < 3; ++k) samples[((size_t(pixelIndex))*spp + s)*3 + k] = c[k];
@@ -147,7 +241,7 @@ static int cmdRender(int argc, char **argv, bool dumpSamples)
                     for (int k = 0; k < 3; ++k) mean[size_t(pixelIndex)*3 + k] = count ? sum[k]/float(count) : 0.0f;
                 }
             }
-            draws[t] = sampler.draws;
+            draws[t] = uniformSampler.draws + sobolSampler.draws();
         });
     }
     for (auto &t : pool) t.join();
@@ -163,6 +257,99 @@ static int cmdRender(int argc, char **argv, bool dumpSamples)
         ImageIO::saveHdr(Path(argv[5]), mean.data(), w, h, 3);
     }
     return 0;
+}
+
+// ---- the reference's own pass loop ----------------------------------------------------------
+// out.bin: u32 w, h, varianceW, varianceH, passes, useSobol; u32 tileSeeds[tiles] (0 for the uniform sampler);
+// per pass: u32 currentSpp (after the pass), then per record {u32 sampleCount, nextSampleCount, sampleIndex;
+// f32 adaptiveWeight, mean, runningVariance}; finally f32 image[h][w][3] (Camera::getLinear) .
+static int cmdIntegrate(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    uint32 seed = uint32(std::strtoul(argv[3], nullptr, 0));
+    int threads = argc > 5 ? std::atoi(argv[5]) : int(std::thread::hardware_concurrency());
+    if (threads < 1) threads = 1;
+    ThreadUtils::startThreads(threads);
+    Loaded L;
+    if (!loadScene(argv[2], seed, L)) return 1;
+    PathTraceIntegrator &pti = *L.pti;
+    bool sobol = L.scene->rendererSettings().useSobol();
+    std::vector<uint32> tileSeeds;
+    for (ImageTile &tile : pti._tiles) {
+        if (sobol) {
+            uint32 tileSeed = static_cast<SobolPathSampler *>(tile.sampler.get())->_seed;
+            tileSeeds.push_back(tileSeed);
+            tile.sampler.reset(new GraftSobolPathSampler(tileSeed, seed));
+        } else {
+            tileSeeds.push_back(0);
+            tile.sampler.reset(new GraftPathSampler(seed));
+        }
+    }
+    std::vector<char> passes;
+    uint32 numPasses = 0;
+    auto put = [&](const void *p, size_t n) { passes.insert(passes.end(), (const char *)p, (const char *)p + n); };
+    while (!pti.done()) {
+        pti.startRender([]() {});
+        pti.waitForCompletion();
+        uint32 spp = pti.currentSpp();
+        put(&spp, 4);
+        for (const SampleRecord &r : pti._samples) {
+            put(&r.sampleCount, 4); put(&r.nextSampleCount, 4); put(&r.sampleIndex, 4);
+            put(&r.adaptiveWeight, 4); put(&r.mean, 4); put(&r.runningVariance, 4);
+        }
+        numPasses++;
+    }
+    uint32 w = pti._w, h = pti._h;
+    std::ofstream out(argv[4], std::ios::binary);
+    uint32 header[6] = {w, h, pti._varianceW, pti._varianceH, numPasses, sobol ? 1u : 0u};
+    out.write((const char *)header, sizeof(header));
+    out.write((const char *)tileSeeds.data(), std::streamsize(tileSeeds.size()*4));
+    out.write(passes.data(), std::streamsize(passes.size()));
+    for (uint32 y = 0; y < h; ++y)
+        for (uint32 x = 0; x < w; ++x) {
+            Vec3f c = L.scene->camera()->getLinear(x, y);
+            out.write((const char *)c.data(), 12);
+        }
+    std::fprintf(stderr, "ref_harness: integrate %ux%u, %u passes, %s sampler, adaptive %d\n", w, h, numPasses,
+                 sobol ? "sobol" : "uniform", int(L.scene->rendererSettings().useAdaptiveSampling()));
+    return 0;
+}
+
+// ref_harness draws <scene.json> <seed> <px> <py> <sample>: the random numbers one path consumes, in order
+// ('s' = Sobol' dimension, 'u' = counter-based uniform stream), then its radiance.  Debugging aid.
+static int cmdDraws(int argc, char **argv)
+{
+    if (argc < 7) return 2;
+    uint32 seed = uint32(std::strtoul(argv[3], nullptr, 0));
+    uint32 px = uint32(std::atoi(argv[4])), py = uint32(std::atoi(argv[5])), sample = uint32(std::atoi(argv[6]));
+    ThreadUtils::startThreads(1);
+    Loaded L;
+    if (!loadScene(argv[2], seed, L)) return 1;
+    uint32 w = L.scene->camera()->resolution().x(), h = L.scene->camera()->resolution().y();
+    UniformSampler dice(MathUtil::hash32(seed));
+    uint32 tileSeed = 0, tile = (py/16)*((w + 15)/16) + px/16;
+    for (uint32 t = 0; t <= tile && t < ((w + 15)/16)*((h + 15)/16); ++t)
+        tileSeed = MathUtil::hash32(dice.nextI());
+    PathTracer tracer(L.ts.get(), L.pti->settings(), 0);
+    GraftPathSampler uniformSampler(seed);
+    GraftSobolPathSampler sobolSampler(tileSeed, seed);
+    PathSampleGenerator &sampler = L.scene->rendererSettings().useSobol() ? static_cast<PathSampleGenerator &>(sobolSampler) : uniformSampler;
+    std::vector<std::pair<char, float>> log;
+    g_drawLog = &log;
+    sampler.startPath(px + py*w, sample);
+    Vec3f c = tracer.traceSample(Vec2u(px, py), sampler);
+    g_drawLog = nullptr;
+    for (auto &d : log) std::printf("%c %.9g\n", d.first, d.second);
+    std::printf("radiance %.9g %.9g %.9g\n", c.x(), c.y(), c.z());
+    return 0;
+}
+
+static int cmdSobolTable(int argc, char **argv)
+{
+    if (argc < 3) return 2;
+    std::ofstream out(argv[2], std::ios::binary);
+    out.write((const char *)sobol::Matrices::matrices, std::streamsize(sobol::Matrices::num_dimensions*sobol::Matrices::size*4));
+    return out ? 0 : 1;
 }
 
 // ---- known-answer vectors -------------------------------------------------------------------
@@ -347,7 +534,7 @@ static int cmdUnits(int argc, char **argv)
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: ref_harness render|samples|units ...\n");
+        std::fprintf(stderr, "usage: ref_harness render|samples|units|integrate|sobol-table ...\n");
         return 2;
     }
     EmbreeUtil::initDevice();
@@ -356,6 +543,9 @@ int main(int argc, char **argv)
     if (cmd == "render") rc = cmdRender(argc, argv, false);
     else if (cmd == "samples") rc = cmdRender(argc, argv, true);
     else if (cmd == "units") rc = cmdUnits(argc, argv);
+    else if (cmd == "integrate") rc = cmdIntegrate(argc, argv);
+    else if (cmd == "sobol-table") rc = cmdSobolTable(argc, argv);
+    else if (cmd == "draws") rc = cmdDraws(argc, argv);
     if (rc == 2) std::fprintf(stderr, "ref_harness: bad arguments\n");
     return rc;
 }

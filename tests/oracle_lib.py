@@ -17,6 +17,7 @@ class OracleCounters(C.Structure):
 
 DESC_P = C.POINTER(capi.TgHipSceneDesc)
 _lib.oracle_trace_sample.argtypes = [DESC_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+_lib.oracle_trace_sample_sobol.argtypes = [DESC_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
 _lib.oracle_render.argtypes = [DESC_P, C.POINTER(capi.TgHipPassDesc), C.c_void_p, C.c_void_p, C.POINTER(OracleCounters), C.c_int]
 _lib.oracle_render.restype = C.c_int
 _lib.oracle_trace_rays.argtypes = [DESC_P, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -31,6 +32,69 @@ _lib.oracle_light_sample.restype = C.c_int
 _lib.oracle_texture_eval.argtypes = [DESC_P, C.c_int, C.c_float, C.c_float, C.c_void_p]
 
 
+RECORD_DTYPE = np.dtype([("sample_count", np.uint32), ("next_sample_count", np.uint32), ("sample_index", np.uint32),
+                         ("adaptive_weight", np.float32), ("mean", np.float32), ("running_variance", np.float32)])
+DEVICE_RECORD_DTYPE = np.dtype([("sample_count", np.uint32), ("mean", np.float32), ("running_variance", np.float32)])
+_lib.oracle_render_records.argtypes = [DESC_P, C.POINTER(capi.TgHipPassDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OracleCounters), C.c_int]
+_lib.oracle_render_records.restype = C.c_int
+_lib.oracle_generate_work.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32, C.c_int]
+_lib.oracle_generate_work.restype = C.c_int
+_lib.oracle_dice_tiles.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_void_p]
+_lib.oracle_dice_tiles.restype = C.c_uint64
+_lib.oracle_integrate.argtypes = [DESC_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int]
+_lib.oracle_integrate.restype = C.c_int
+
+
+def dice_tiles(width, height, seed):
+    """(tile seeds, state of the integrator's sampler afterwards)."""
+    seeds = np.zeros(((width + 15)//16)*((height + 15)//16), np.uint32)
+    state = _lib.oracle_dice_tiles(width, height, seed & 0xFFFFFFFF, seeds.ctypes.data)
+    return seeds, int(state)
+
+
+def generate_work(records, width, height, sampler_state, current_spp, next_spp, adaptive):
+    """In-place PathTraceIntegrator::generateWork on a RECORD_DTYPE array; returns (has work, new sampler state)."""
+    assert records.dtype == RECORD_DTYPE and records.flags.c_contiguous
+    st = C.c_uint64(sampler_state)
+    r = _lib.oracle_generate_work(records.ctypes.data, width, height, C.byref(st), current_spp, next_spp, int(bool(adaptive)))
+    return bool(r), int(st.value)
+
+
+def render_pass(desc, width, height, seed, spp_begin=0, spp_end=0, flags=0, tile_seeds=None, record_index=None, record_count=None,
+                records=None, ssum=None, count=None, shard_index=0, shard_count=1, threads=0):
+    """oracle_render_records with the full TgHipPassDesc; accumulates into ssum/count/records when given."""
+    ssum = np.zeros((height, width, 3), np.float32) if ssum is None else ssum
+    count = np.zeros((height, width), np.uint32) if count is None else count
+    p = capi.TgHipPassDesc(spp_begin, spp_end, seed & 0xFFFFFFFF, shard_index, shard_count, flags)
+    keep = []
+    for name, arr in (("tile_seeds", tile_seeds), ("record_index", record_index), ("record_count", record_count)):
+        if arr is not None:
+            a = np.ascontiguousarray(arr, np.uint32)
+            keep.append(a)
+            setattr(p, name, a.ctypes.data_as(C.POINTER(C.c_uint32)))
+    rc = _lib.oracle_render_records(desc, C.byref(p), ssum.ctypes.data, count.ctypes.data,
+                                    records.ctypes.data if records is not None else None, None, threads)
+    if rc != 0:
+        raise RuntimeError("oracle_render_records failed (%d)" % rc)
+    return ssum, count
+
+
+def integrate(desc, width, height, seed, spp, spp_step, adaptive, sobol, threads=0):
+    """The whole CLI render loop; returns (sum, count, records[passes, vh, vw], spp after each pass)."""
+    vw, vh = (width + 3)//4, (height + 3)//4
+    max_passes = (spp + spp_step - 1)//spp_step
+    ssum = np.zeros((height, width, 3), np.float32)
+    count = np.zeros((height, width), np.uint32)
+    rec = np.zeros((max_passes, vh, vw), RECORD_DTYPE)
+    pass_spp = np.zeros(max_passes, np.uint32)
+    n = _lib.oracle_integrate(desc, seed & 0xFFFFFFFF, spp, spp_step, int(bool(adaptive)), int(bool(sobol)), ssum.ctypes.data, count.ctypes.data,
+                              rec.ctypes.data, max_passes, pass_spp.ctypes.data, threads)
+    if n < 0:
+        raise RuntimeError("oracle_integrate failed (%d)" % n)
+    return ssum, count, rec[:n], pass_spp[:n]
+
+
 def render(desc, width, height, spp_begin, spp_end, seed, shard_index=0, shard_count=1, threads=0, counters=None):
     """Returns (sum[H,W,3], count[H,W]) like the device framebuffer."""
     ssum = np.zeros((height, width, 3), np.float32)
@@ -41,9 +105,13 @@ def render(desc, width, height, spp_begin, spp_end, seed, shard_index=0, shard_c
     return ssum, count
 
 
-def trace_sample(desc, seed, px, py, sample):
+def trace_sample(desc, seed, px, py, sample, tile_seed=None):
+    """One PathTracer::traceSample; tile_seed selects the Sobol' sampler of that tile (needs sobol_matrices in desc)."""
     rgb = (C.c_float*3)()
-    _lib.oracle_trace_sample(desc, seed & 0xFFFFFFFF, px, py, sample, rgb)
+    if tile_seed is None:
+        _lib.oracle_trace_sample(desc, seed & 0xFFFFFFFF, px, py, sample, rgb)
+    else:
+        _lib.oracle_trace_sample_sobol(desc, seed & 0xFFFFFFFF, int(tile_seed), px, py, sample, rgb)
     return np.array(rgb[:], np.float32)
 
 

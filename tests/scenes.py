@@ -291,3 +291,19 @@ def mesh1m(tmpdir, resolution=(1920, 1080), spp=512, name="mesh1m.json", n_lat=5
 
 
 GOLDEN_CASES["mesh1m"] = (mesh1m, dict(resolution=(48, 27), spp=4))
+
+# "stratified_sampler": true -- SobolPathSampler dimensions with the tiles' own seeds
+_SOBOL = {"stratified_sampler": True}
+GOLDEN_CASES["cornell_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, renderer=_SOBOL))
+GOLDEN_CASES["zoo_b_sobol"] = (lambda t, **kw: cornell_zoo(t, "zoo_b", **kw), dict(resolution=(48, 27), spp=8, renderer=_SOBOL))
+GOLDEN_CASES["materialtest_sobol"] = (materialtest, dict(resolution=(64, 36), spp=4, renderer=_SOBOL))
+
+# The reference's own PathTraceIntegrator pass loop (`ref_harness integrate`): SampleRecords after every pass + the image.
+INTEGRATE_CASES = {
+    "cornell_adaptive": (cornell, dict(resolution=(70, 42), spp=72, spp_step=16, renderer={"adaptive_sampling": True})),
+    "cornell_adaptive_sobol": (cornell, dict(resolution=(70, 42), spp=64, spp_step=16,
+                                             renderer={"adaptive_sampling": True, "stratified_sampler": True})),
+    # the renderer block as materialtest.json ships it (materialtest.json:188-190): Sobol' + adaptive, spp_step 16
+    "materialtest_as_shipped": (materialtest, dict(resolution=(64, 36), spp=48, spp_step=16,
+                                                   renderer={"adaptive_sampling": True, "stratified_sampler": True})),
+}

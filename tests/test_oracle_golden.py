@@ -54,7 +54,7 @@ def _needs_materialtest(name):
 
 
 # fraction of samples allowed to diverge (chaotic path divergence, see module docstring)
-DIVERGE = {"zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "zoo_d": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
+DIVERGE = {"cornell_sobol": 1e-4, "zoo_b_sobol": 3e-3, "materialtest_sobol": 5e-3, "zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "zoo_d": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
            "materialtest_rough_dielectric": 2e-2, "materialtest_transparency": 5e-3, "cornell_two_lights": 1e-3, "cornell_mesh_light": 2e-3, "cornell_mesh_light_flat": 2e-3, "cornell_mesh_and_quad_light": 2e-3, "mesh1m": 1e-2}
 
 
@@ -68,11 +68,14 @@ def test_oracle_matches_reference_per_sample(name, tmp_path):
     h, w, spp, _ = ref.shape
     flat = tg.FlattenedScene(mk(tmp_path, name=name + ".json", **kw))
     assert (flat.width, flat.height) == (w, h)
+    # "stratified_sampler": true scenes draw from the SobolPathSampler of the pixel's 16x16 tile
+    tile_seeds = oracle_lib.dice_tiles(w, h, seed)[0] if flat.info.stratified_sampler else None
     got = np.empty_like(ref)
     for y in range(h):
         for x in range(w):
+            ts = None if tile_seeds is None else tile_seeds[(y//16)*((w + 15)//16) + x//16]
             for s in range(spp):
-                got[y, x, s] = oracle_lib.trace_sample(flat.desc, seed, x, y, s)
+                got[y, x, s] = oracle_lib.trace_sample(flat.desc, seed, x, y, s, tile_seed=ts)
     flat.close()
     err = np.abs(got - ref).max(axis=-1)
     bad = err > 1e-3*(np.abs(ref).max(axis=-1) + 1e-3)

@@ -6,7 +6,12 @@ oracle/Makefile.ref).  TEST INFRASTRUCTURE; run in the build container only (nee
 Outputs (all small, committed):
   <case>_samples.npz   radiance of every individual sample, float32[h][w][spp][3], from the reference's own
                        PathTracer::traceSample driven by oracle/ref_harness.cpp with the counter-based
-                       random stream (seed, pixel, sample) that oracle.c and the HIP kernels also use
+                       random stream (seed, pixel, sample) that oracle.c and the HIP kernels also use; `*_sobol` cases
+                       ("stratified_sampler": true) draw next1D/next2D from the tiles' SobolPathSampler sequence
+  <case>_integrate.npz the SampleRecords after every pass (sampleCount, nextSampleCount, sampleIndex, adaptiveWeight,
+                       mean, runningVariance) and the final image of the reference's OWN PathTraceIntegrator loop
+                       (diceTiles, generateWork, adaptive sampling, OutputBuffer), tile samplers swapped for the
+                       counter-based ones; plus the tile seeds diceTiles drew
   <scene>_units.json   known answers of the deterministic building blocks (rng, camera rays, closest hits,
                        bsdf eval/pdf/sample, light sampleDirect/directPdf/evalDirect)
   <scene>_converged.npz  mean image of the unmodified reference binary (`tungsten -s <seed>`, its own
@@ -43,6 +48,33 @@ def samples(path, w, h, spp, out):
     print("%-40s %s mean %s" % (os.path.basename(out), a.shape, a.mean(axis=(0, 1, 2))))
 
 
+def integrate(path, out):
+    """SampleRecords after every pass + final image of the reference's own PathTraceIntegrator loop."""
+    tmp = out + ".bin"
+    subprocess.check_call([HARNESS, "integrate", path, str(SEED), tmp], cwd=os.path.dirname(path), stdout=subprocess.DEVNULL)
+    b = open(tmp, "rb").read()
+    os.remove(tmp)
+    w, h, vw, vh, passes, sobol = np.frombuffer(b, np.uint32, 6, 0)
+    tiles = ((w + 15)//16)*((h + 15)//16)
+    off = 24
+    tile_seeds = np.frombuffer(b, np.uint32, tiles, off).copy()
+    off += tiles*4
+    rec_dtype = np.dtype([("sample_count", "<u4"), ("next_sample_count", "<u4"), ("sample_index", "<u4"),
+                          ("adaptive_weight", "<f4"), ("mean", "<f4"), ("running_variance", "<f4")])
+    pass_spp, records = [], []
+    for _ in range(passes):
+        pass_spp.append(np.frombuffer(b, np.uint32, 1, off)[0])
+        off += 4
+        records.append(np.frombuffer(b, rec_dtype, vw*vh, off).reshape(vh, vw).copy())
+        off += vw*vh*rec_dtype.itemsize
+    image = np.frombuffer(b, np.float32, w*h*3, off).reshape(h, w, 3).copy()
+    assert off + image.nbytes == len(b)
+    np.savez_compressed(out, tile_seeds=tile_seeds, pass_spp=np.array(pass_spp, np.uint32), records=np.stack(records), image=image,
+                        sobol=np.uint32(sobol), seed=np.uint32(SEED))
+    print("%-40s %d passes, counts of the last pass %d..%d, image mean %s" % (
+        os.path.basename(out), passes, records[-1]["next_sample_count"].min(), records[-1]["next_sample_count"].max(), image.mean(axis=(0, 1))))
+
+
 def units(path, out):
     subprocess.check_call([HARNESS, "units", path, out], cwd=os.path.dirname(path), stdout=subprocess.DEVNULL)
     print("%-40s %d bytes" % (os.path.basename(out), os.path.getsize(out)))
@@ -71,6 +103,8 @@ def main():
                 sc = json.load(f)
             w, h = sc["camera"]["resolution"]
             samples(p, w, h, sc["renderer"]["spp"], g(name + "_samples.npz"))
+        for name, (mk, kw) in scenes.INTEGRATE_CASES.items():
+            integrate(mk(tmp, name=name + ".json", **kw), g(name + "_integrate.npz"))
         units(scenes.cornell(tmp, name="u_cornell.json", resolution=(96, 54), spp=1), g("cornell_units.json"))
         units(scenes.materialtest(tmp, name="u_materialtest.json", resolution=(96, 54), spp=1), g("materialtest_units.json"))
         for which in ("zoo_a", "zoo_b", "zoo_c", "zoo_d"):

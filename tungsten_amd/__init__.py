@@ -15,6 +15,8 @@ from .capi import (TgHipCounters, TgHipHit, TgHipPassDesc, TgHipRay, TgHipSceneD
 
 lib = capi.load_library()
 
+RECORD_DTYPE = np.dtype([("sample_count", np.uint32), ("next_sample_count", np.uint32), ("sample_index", np.uint32),
+                         ("adaptive_weight", np.float32), ("mean", np.float32), ("running_variance", np.float32)])
 DEFAULT_SEED = 0xBA5EBA11  # src/tungsten/Shared.hpp:246
 
 
@@ -124,6 +126,13 @@ class Renderer(object):
             raise TungstenError(lib.tghip_last_error(self.context(device)).decode())
         return hits, ms.value
 
+    def records(self):
+        """The integrator's SampleRecords (one per 4x4 pixels) after the last pass, as a structured array [vh, vw]."""
+        vw, vh = (self.width + 3)//4, (self.height + 3)//4
+        rec = np.zeros(vw*vh, RECORD_DTYPE)
+        self._check(lib.tgh_renderer_records(self._h, rec.ctypes.data, rec.size, self._err, len(self._err)))
+        return rec.reshape(vh, vw)
+
     def save_outputs(self):
         self._check(lib.tgh_renderer_save_outputs(self._h, self._err, len(self._err)))
 
@@ -137,6 +146,50 @@ class Renderer(object):
             self.close()
         except Exception:
             pass
+
+
+class PassScheduler(object):
+    """PathTraceIntegrator's pass scheduling without a device: tile seeds + generateWork over SampleRecords."""
+
+    def __init__(self, width, height, seed=DEFAULT_SEED):
+        self._h = lib.tgh_scheduler_create(int(width), int(height), seed & 0xFFFFFFFF)
+        self.num_tiles = int(lib.tgh_scheduler_num_tiles(self._h))
+        self.num_records = int(lib.tgh_scheduler_num_records(self._h))
+
+    @property
+    def tile_seeds(self):
+        return np.ctypeslib.as_array(lib.tgh_scheduler_tile_seeds(self._h), shape=(self.num_tiles,)).copy()
+
+    @property
+    def records(self):
+        """Mutable view of the records (write sample_count / mean / running_variance, read the rest)."""
+        buf = (C.c_char*(self.num_records*RECORD_DTYPE.itemsize)).from_address(
+            C.addressof(lib.tgh_scheduler_records(self._h).contents))
+        return np.frombuffer(buf, RECORD_DTYPE)
+
+    def generate_work(self, current_spp, next_spp, adaptive):
+        return bool(lib.tgh_scheduler_generate_work(self._h, int(current_spp), int(next_spp), int(bool(adaptive))))
+
+    def close(self):
+        if self._h:
+            lib.tgh_scheduler_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sobol_matrices():
+    """The 1024 x 52 Sobol' generator matrices the host hands to the device."""
+    n = C.c_size_t(0)
+    err = C.create_string_buffer(1024)
+    p = lib.tgh_sobol_matrices(C.byref(n), err, len(err))
+    if not p:
+        raise TungstenError(err.value.decode(errors="replace"))
+    return np.ctypeslib.as_array(p, shape=(n.value,)).reshape(1024, 52)
 
 
 def load_pfm(path):

@@ -69,13 +69,27 @@ class TgHipSceneDesc(C.Structure):
                 ("texels", C.POINTER(f32)), ("num_texel_floats", u64),
                 ("dist", C.POINTER(f32)), ("num_dist_floats", u64),
                 ("light_tris", C.POINTER(f32)), ("num_light_tri_floats", u64),
+                ("sobol_matrices", C.POINTER(u32)), ("num_sobol_words", u64),
                 ("camera", TgHipCamera), ("settings", TgHipSettings),
                 ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
 
 
+TGHIP_PASS_SOBOL, TGHIP_PASS_RECORDS = 1, 2
+
+
 class TgHipPassDesc(C.Structure):
     _fields_ = [("spp_begin", u32), ("spp_end", u32), ("seed", u32), ("shard_index", u32), ("shard_count", u32),
-                ("flags", u32)]
+                ("flags", u32),
+                ("tile_seeds", C.POINTER(u32)), ("record_index", C.POINTER(u32)), ("record_count", C.POINTER(u32))]
+
+
+class TgHipSampleRecord(C.Structure):
+    _fields_ = [("sample_count", u32), ("mean", f32), ("running_variance", f32)]
+
+
+class TgHostSampleRecord(C.Structure):
+    _fields_ = [("sample_count", u32), ("next_sample_count", u32), ("sample_index", u32),
+                ("adaptive_weight", f32), ("mean", f32), ("running_variance", f32)]
 
 
 class TgHipCounters(C.Structure):
@@ -118,6 +132,8 @@ PROTOTYPES = {
     "tghip_clear_framebuffer": (C.c_int, [VP]),
     "tghip_bind_framebuffer": (C.c_int, [VP, VP, VP]),
     "tghip_download_framebuffer": (C.c_int, [VP, VP, VP, C.c_size_t]),
+    "tghip_download_records": (C.c_int, [VP, VP, C.c_size_t]),
+    "tghip_upload_records": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_trace_rays": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "tghip_set_option": (C.c_int, [VP, C.c_char_p, C.c_longlong]),
     "tghip_get_counters": (C.c_int, [VP, C.POINTER(TgHipCounters)]),
@@ -135,6 +151,15 @@ PROTOTYPES = {
     "tgh_renderer_image": (C.c_int, [VP, VP, VP, VP, C.c_size_t, C.c_char_p, C.c_size_t]),
     "tgh_renderer_save_outputs": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
     "tgh_renderer_close": (None, [VP]),
+    "tgh_renderer_records": (C.c_int, [VP, VP, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "tgh_scheduler_create": (VP, [u32, u32, u32]),
+    "tgh_scheduler_num_tiles": (C.c_size_t, [VP]),
+    "tgh_scheduler_num_records": (C.c_size_t, [VP]),
+    "tgh_scheduler_tile_seeds": (C.POINTER(u32), [VP]),
+    "tgh_scheduler_records": (C.POINTER(TgHostSampleRecord), [VP]),
+    "tgh_scheduler_generate_work": (C.c_int, [VP, u32, u32, C.c_int]),
+    "tgh_scheduler_free": (None, [VP]),
+    "tgh_sobol_matrices": (C.POINTER(u32), [C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
     "tgh_save_pfm": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
     "tgh_load_hdr": (C.c_int, [C.c_char_p, VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

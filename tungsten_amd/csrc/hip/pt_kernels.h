@@ -120,6 +120,14 @@ struct PassParams {
     uint32_t tiles_x, num_tiles;
     uint32_t width, height;
     uint32_t iter_tag;         // wavefront iteration number (liveness reporting of the fused flat-scene kernels)
+    // ---- TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes (read only by the kernels' `EXT` code paths) ----
+    uint32_t flags;            // TGHIP_PASS_*
+    uint32_t variance_w;       // SampleRecords per image row = ceil(width/4)
+    const uint32_t *tile_seeds;   // SobolPathSampler seed per 16x16 tile (device copy of TgHipPassDesc::tile_seeds)
+    // per SampleRecord (nullptr unless TGHIP_PASS_RECORDS): first sample index, samples per pixel this pass, and the
+    // offset of the record's 16 x count block in `lum`; spp_begin/spp_end are then RELATIVE to the record's first index
+    const uint32_t *rec_index, *rec_count, *rec_lum;
+    float *lum;                // luminance of every sample of the pass, in the order SampleRecord::addSample saw them
 };
 
 PT_DEV uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
@@ -320,9 +328,8 @@ PT_DEV float filterSample1D(CameraRef cam, float xi)
     float u = cam.filter_bin_size*(idx + (xi - lo)/pdf);
     return negative ? -u : u;
 }
-PT_DEV void cameraRay(CameraRef cam, uint32_t px, uint32_t py, Rng &rng, f3 &o, f3 &d)
+PT_DEV void cameraRay(CameraRef cam, uint32_t px, uint32_t py, float xi0, float xi1, f3 &o, f3 &d)
 {
-    float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
     float fu = 0.0f, fv = 0.0f;
     if (cam.filter_type == TGHIP_FILTER_BOX) { fu = xi0 - 0.5f; fv = xi1 - 0.5f; }
     else if (cam.filter_type == TGHIP_FILTER_TABULATED) { fu = filterSample1D(cam, xi0); fv = filterSample1D(cam, xi1); }

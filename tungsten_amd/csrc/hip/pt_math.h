@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../../include/tungsten_hip.h"
+
 #define PT_PI          3.1415926536f            /* math/Angle.hpp:8 */
 #define PT_TWO_PI      (PT_PI*2.0f)
 #define PT_INV_PI      (1.0f/PT_PI)
@@ -102,7 +104,14 @@ PT_DEV uint32_t hash32(uint32_t x)   /* math/MathUtil.hpp:120-128 */
     return x;
 }
 
-struct Rng { uint64_t state, inc; };
+// PathSampleGenerator state of one path.  state/inc: the counter-based PCG stream (DESIGN.md "RNG").  The other
+// fields are SobolPathSampler's (sampling/SobolPathSampler.hpp:14-18) and only live in kernel variants compiled
+// with FEAT_QMC; `sobol` == nullptr selects the uniform sampler.
+struct Rng {
+    uint64_t state, inc;
+    const uint32_t *sobol;     // generator matrices, TGHIP_SOBOL_DIMS x TGHIP_SOBOL_BITS words
+    uint32_t scramble, index, dim;
+};
 
 PT_DEV Rng rngStart(uint32_t seed, uint32_t pixelIndex, uint32_t sampleIndex)
 {
@@ -112,6 +121,8 @@ PT_DEV Rng rngStart(uint32_t seed, uint32_t pixelIndex, uint32_t sampleIndex)
     Rng r;
     r.state = ((uint64_t)hi << 32) | lo;
     r.inc = ((uint64_t)pixelIndex << 1) | 1u;
+    r.sobol = nullptr;
+    r.scramble = r.index = r.dim = 0u;
     return r;
 }
 PT_DEV uint32_t rngNextI(Rng &r)
@@ -126,7 +137,30 @@ PT_DEV float rngNext1D(Rng &r)       /* BitManip::normalizedUint (math/BitManip.
 {
     return __uint_as_float((rngNextI(r) >> 9u) | 0x3F800000u) - 1.0f;
 }
+// booleans always come from the PCG stream (UniformPathSampler.hpp:39-42; SobolPathSampler.hpp:54-57 uses its
+// supplemental sampler)
 PT_DEV bool rngNextBoolean(Rng &r, float pTrue) { return rngNext1D(r) < pTrue; }
+
+// sobol::sample (thirdparty/sobol/sobol.h:39-53): XOR of the generator-matrix columns the index bits select
+PT_DEV uint32_t sobolSample(const uint32_t *matrices, uint32_t index, uint32_t dimension, uint32_t scramble)
+{
+    uint32_t result = scramble;
+    const uint32_t *col = matrices + dimension*TGHIP_SOBOL_BITS;
+    for (; index; index >>= 1, ++col)
+        if (index & 1u)
+            result ^= *col;
+    return result;
+}
+// SobolPathSampler::next1D (SobolPathSampler.hpp:64-69) when QMC and the path runs the Sobol' sampler
+template<bool QMC>
+PT_DEV float rngNext1DT(Rng &r)
+{
+    if (QMC && r.sobol != nullptr && r.dim < TGHIP_SOBOL_DIMS) {
+        uint32_t permuted = (r.index & ~0xFFu) | ((r.index + r.scramble) & 0xFFu);   // permutedIndex() :20-23
+        return __uint_as_float((sobolSample(r.sobol, permuted, r.dim++, r.scramble) >> 9u) | 0x3F800000u) - 1.0f;
+    }
+    return rngNext1D(r);
+}
 
 /* ---- sample warps (sampling/SampleWarp.hpp) ---- */
 PT_DEV f3 cosineHemisphere(float xi0, float xi1)

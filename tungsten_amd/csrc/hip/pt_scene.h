@@ -25,6 +25,7 @@ struct DeviceScene {
     const float * __restrict__ light_tris;     // sampled mesh emitters: cdf + triangles (include/tungsten_hip.h)
     const uint16_t * __restrict__ guide;       // CDF guide tables of the samplable bitmaps (built at upload, bitmapSample)
     const int32_t * __restrict__ tex_guide;    // per texture: offset of its tables in `guide`, -1 = none
+    const uint32_t * __restrict__ sobol;       // Sobol' generator matrices (nullptr unless the scene carries them)
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
     const TgHipCamera * __restrict__ camera;   // in device memory (56 dwords: read through the scalar cache where it is used, not held in SGPRs)
     TgHipSettings settings;
@@ -50,7 +51,11 @@ struct DeviceScene {
 #define FEAT_TRIANGLES  (1u << 27)   /* triangle records (attribute gather, smooth normals)            */
 #define FEAT_SOLIDS     (1u << 28)   /* sphere records; sphere / cube emitters as sampled lights       */
 #define FEAT_ALL        (FEAT_BITMAP | FEAT_INFINITE | FEAT_MULTILIGHT | FEAT_TRIANGLES | FEAT_SOLIDS)
-#define FEAT_MESHLIGHT  (1u << 29)   /* triangle-mesh emitters as sampled lights: only in BSDF_MASK_ALL variants */
+#define FEAT_MESHLIGHT  (1u << 29)   /* triangle-mesh emitters as sampled lights: only in the MASK_FULL / BSDF_MASK_ALL variants */
+#define FEAT_QMC        (1u << 30)   /* TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes: only in BSDF_MASK_ALL variants */
+#define MASK_FULL       (BSDF_MASK_ALL & ~FEAT_QMC)
+// next1D of the path's sampler inside code templated on M
+#define RNG1D(r) rngNext1DT<(M & FEAT_QMC) != 0>(r)
 
 // ---------------------------------------------------------------------------------------------
 // Textures (ConstantTexture, CheckerTexture.cpp:64-69, BitmapTexture.cpp:298-352)
@@ -284,14 +289,14 @@ template<uint32_t M> PT_DEV f3 bsdfAlbedo(const DeviceScene &s, const TgHipBsdf 
 template<uint32_t M> PT_DEV float bsdfRoughness(const DeviceScene &s, const TgHipBsdf &b, const Event &e) { return textureEval<M>(s, b.roughness, e.u, e.v).x; }
 
 // RoughDielectricBsdf::sampleBase / evalBase / pdfBase (RoughDielectricBsdf.cpp:55-131,133-166,200-236)
-PT_DEV bool rdSampleBase(Event &e, bool sampleR, bool sampleT, float roughness, float ior, int dist)
+template<uint32_t M> PT_DEV bool rdSampleBase(Event &e, bool sampleR, bool sampleT, float roughness, float ior, int dist)
 {
     float wiDotN = e.wi.z;
     float eta = wiDotN < 0.0f ? ior : 1.0f/ior;
     float sampleRoughness = (1.2f - 0.2f*sqrtf(fabsf(wiDotN)))*roughness;
     float alpha = mfRoughnessToAlpha(dist, roughness);
     float sampleAlpha = mfRoughnessToAlpha(dist, sampleRoughness);
-    float xi0 = rngNext1D(*e.rng), xi1 = rngNext1D(*e.rng);
+    float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
     f3 m = mfSample(dist, sampleAlpha, xi0, xi1);
     float pm = mfPdf(dist, sampleAlpha, m);
     if (pm < 1e-10f)
@@ -537,7 +542,7 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_ERROR)))) return false;
             if (!(e.requested & TGHIP_LOBE_DIFFUSE_R)) return false;
             if (e.wi.z <= 0.0f) return false;
-            float xi0 = rngNext1D(*e.rng), xi1 = rngNext1D(*e.rng);
+            float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
             e.wo = cosineHemisphere(xi0, xi1);
             e.pdf = cosineHemispherePdf(e.wo);
             e.weight = bsdfAlbedo<M>(s, b, e);
@@ -565,7 +570,7 @@ struct BsdfOps {
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return false;
             if (e.wi.z <= 0.0f) return false;
             float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness<M>(s, b, e));
-            float xi0 = rngNext1D(*e.rng), xi1 = rngNext1D(*e.rng);
+            float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
             f3 m = mfSample(b.distribution, alpha, xi0, xi1);
             float wiDotM = dot(e.wi, m);
             e.wo = m*(2.0f*wiDotM) - e.wi;
@@ -647,7 +652,7 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return false;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
-            bool result = rdSampleBase(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, b.distribution);
+            bool result = rdSampleBase<M>(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, b.distribution);
             e.weight = e.weight*bsdfAlbedo<M>(s, b, e);
             return result;
         }
@@ -668,7 +673,7 @@ struct BsdfOps {
                 e.weight = splat3(Fi/specularProbability);
                 e.sampled = TGHIP_LOBE_SPECULAR_R;
             } else {
-                float xi0 = rngNext1D(*e.rng), xi1 = rngNext1D(*e.rng);
+                float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
                 f3 wo = cosineHemisphere(xi0, xi1);
                 float Fo = dielectricReflectance(eta, wo.z);
                 e.wo = wo;
@@ -692,7 +697,7 @@ struct BsdfOps {
             float substrateWeight = substrateW*b.avg_transmittance*(1.0f - Fi);
             float specularProbability = Fi/(Fi + substrateWeight);
             if (sampleR && (rngNextBoolean(*e.rng, specularProbability) || !sampleT)) {
-                if (!rdSampleBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, b.distribution))
+                if (!rdSampleBase<M>(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, b.distribution))
                     return false;
                 if (sampleT) {
                     float Fo = dielectricReflectance(eta, e.wo.z);
@@ -705,7 +710,7 @@ struct BsdfOps {
                 }
                 return true;
             }
-            float xi0 = rngNext1D(*e.rng), xi1 = rngNext1D(*e.rng);
+            float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
             f3 wo = cosineHemisphere(xi0, xi1);
             float Fo = dielectricReflectance(eta, wo.z);
             e.wo = wo;
@@ -1217,12 +1222,12 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
     if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_MESH) {    /* TriangleMesh::sampleDirect / samplePosition (TriangleMesh.cpp:411-462) */
         const float *cdf = s.light_tris + o.first_light_tri;
         const float *tris = cdf + o.num_light_tris + 1;
-        float u = rngNext1D(rng);
+        float u = RNG1D(rng);
         int idx = upperBoundIdx(cdf, o.num_light_tris + 1, u) - 1;     /* Distribution1D::warp */
         const float *t = tris + (size_t)idx*9;
         f3 p0 = ld3(t), p1 = ld3(t + 3), p2 = ld3(t + 6);
         f3 normal = normalized(cross(p1 - p0, p2 - p0));
-        float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
+        float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
         float uSqrt = sqrtf(xi0);                                      /* SampleWarp::uniformTriangleUv */
         float alpha = 1.0f - uSqrt, beta = (1.0f - xi1)*uSqrt;
         f3 q = p0*alpha + p1*beta + p2*(1.0f - alpha - beta);
@@ -1237,13 +1242,13 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         return true;
     }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube::sampleDirect / samplePosition / sampleFace (Cube.cpp:229-245,189-213,42-55) */
-        float u = rngNext1D(rng);
+        float u = RNG1D(rng);
         int dim;
         u *= o.face_cdf[2];
         if (u < o.face_cdf[0]) { u /= o.face_cdf[0]; dim = 0; }
         else if (u < o.face_cdf[1]) { u = (u - o.face_cdf[0])/(o.face_cdf[1] - o.face_cdf[0]); dim = 1; }
         else { u = (u - o.face_cdf[1])/(o.face_cdf[2] - o.face_cdf[1]); dim = 2; }
-        float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
+        float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
         float sgn = u < 0.5f ? -1.0f : 1.0f;
         float a = (xi0*2.0f - 1.0f), b = (xi1*2.0f - 1.0f);
         // p[dim] = sgn*scale[dim], p[(dim+1)%3] = a*scale[..], p[(dim+2)%3] = b*scale[..]
@@ -1271,7 +1276,7 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
             return false;
         L = normalized(L);
         float cosTheta = sqrtf(C)/dd;
-        float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
+        float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
         float phi = xi0*PT_TWO_PI;                             /* SampleWarp::uniformSphericalCap */
         float z = xi1*(1.0f - cosTheta) + cosTheta;
         float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
@@ -1287,7 +1292,7 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         f3 n = ld3(o.normal);
         if (dot(n, p - ld3(o.base)) <= 0.0f)
             return false;
-        float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
+        float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
         f3 q = ld3(o.base) + ld3(o.edge0)*xi0 + ld3(o.edge1)*xi1;
         f3 dd = q - p;
         float rSq = lengthSq(dd);
@@ -1299,7 +1304,7 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         return true;
     }
     const TgHipTexture &t = s.textures[o.emission];
-    float xi0 = rngNext1D(rng), xi1 = rngNext1D(rng);
+    float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
     dist = PT_INF;
     if (!(M & FEAT_BITMAP) || t.type != TGHIP_TEX_BITMAP) {
         d = uniformSphere(xi0, xi1);
@@ -1373,7 +1378,7 @@ PT_DEV int chooseLight(const DeviceScene &s, Rng &rng, f3 p, float &weight)
                     total += (total == 0.0f ? 1.0f : total)/numNonNegative;   // uses the running total, like the reference's loop
         }
         if (total == 0.0f) return -1;
-        float t = rngNext1D(rng)*total;
+        float t = RNG1D(rng)*total;
         float running = knownTotal;
         for (int i = 0; i < n; ++i) {
             float w = lightApproximateRadiance<M>(s, s.lights[i], p);
@@ -1392,7 +1397,7 @@ PT_DEV int chooseLight(const DeviceScene &s, Rng &rng, f3 p, float &weight)
     for (int i = 0; i < n; ++i)
         total += lightApproximateRadiance<M>(s, s.lights[i], p);
     if (total == 0.0f) return -1;
-    float t = rngNext1D(rng)*total;
+    float t = RNG1D(rng)*total;
     for (int i = 0; i < n; ++i) {
         float pdf = lightApproximateRadiance<M>(s, s.lights[i], p);
         if (t < pdf || i == n - 1) { weight = total/pdf; return s.lights[i]; }

@@ -49,22 +49,41 @@
 // exhausted -- flushes the item's sum and takes the workgroup's next item (`cursor` = the workgroup's LDS item
 // cursor), and generates the next camera path in place.  `fresh` lanes own nothing yet (pass start).  Must be
 // called by all lanes of the wave.  Returns true for lanes that now hold a new active path.
-template<bool CONVERGED = true>
+// SobolPathSampler::startPath (sampling/SobolPathSampler.hpp:47-52) for a path that starts or resumes at
+// dimension `dim`: the tile's sampler seed (PathTraceIntegrator.cpp:27-42) scrambled by the pixel.
+PT_DEV void rngStartSobol(Rng &rng, const DeviceScene &s, const PassParams &pp, uint32_t px, uint32_t py, uint32_t pixel,
+                          uint32_t sample, uint32_t dim)
+{
+    uint32_t tile = (px >> 4) + (py >> 4)*pp.tiles_x;
+    rng.sobol = s.sobol;
+    rng.scramble = at32(pp.tile_seeds, tile) ^ hash32(pixel);
+    rng.index = sample;
+    rng.dim = dim;
+}
+
+// EXT: the pass may carry TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS state (checked at run time through pp.flags /
+// pp.rec_count); false compiles those paths out (the specialised shading variants, DESIGN.md "Kernels").
+template<bool CONVERGED = true, bool EXT = true>
 PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams &pp, bool finished, bool fresh,
                      uint32_t slot, f3 em, bool black, uint32_t *cursor, bool aborted, uint32_t &finishedCount)
 {
     uint2 samp = make_uint2(0u, 0u);
     float4 acc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
     uint32_t pixel = 0, item = 0;
+    uint32_t lumBase = 0;                  // EXT: index of sample `s` of this work item in pp.lum is lumBase + s
+    const bool records = EXT && pp.rec_count != nullptr;
     bool want = fresh;
     if (finished) {
         uint4 sm = slotU4(st, A_SAMP, slot), misc = slotU4(st, A_MISC, slot);
         samp = make_uint2(sm.x, sm.y);
+        lumBase = EXT ? sm.w : 0u;
         acc = slotF4(st, A_ACC, slot);
         pixel = misc.z;
         item = misc.w;
         if (black || isnan(sum3(em)))
             em = splat3(0.0f);
+        if (records)   // SampleRecord::addSample(c) input (SampleRecord.hpp:55-58; Vec3f::luminance, math/Vec.hpp:195-199)
+            at32(pp.lum, lumBase + samp.x) = em.x*0.2126f + em.y*0.7152f + em.z*0.0722f;
         if (!(isinf(em.x) || isinf(em.y) || isinf(em.z))) {
             acc.x += em.x; acc.y += em.y; acc.z += em.z;
             acc.w = __uint_as_float(__float_as_uint(acc.w) + 1u);
@@ -108,12 +127,25 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
                 uint32_t c = w/pp.pix_slots, j = w - c*pp.pix_slots;
                 uint32_t x, y;
                 if (slotPixel(pp, j, x, y)) {
-                    want = false;
-                    item = w;
-                    pixel = x + y*pp.width;
-                    samp.x = pp.spp_begin + c*pp.chunk;
-                    samp.y = min(samp.x + pp.chunk, pp.spp_end);
-                    acc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+                    uint32_t rel = pp.spp_begin + c*pp.chunk, relEnd = pp.spp_end, first = 0u;
+                    bool take = true;
+                    if (records) {
+                        // renderTile (PathTraceIntegrator.cpp:142-147): the pixel's record says which samples it traces
+                        uint32_t rec = (x >> 2) + (y >> 2)*pp.variance_w;
+                        uint32_t cnt = at32(pp.rec_count, rec);
+                        first = at32(pp.rec_index, rec);
+                        relEnd = min(relEnd, cnt);
+                        take = rel < relEnd;                     // this pixel has no samples in the chunk: next item
+                        lumBase = at32(pp.rec_lum, rec) + (((y & 3u) << 2) | (x & 3u))*cnt - first;
+                    }
+                    if (take) {
+                        want = false;
+                        item = w;
+                        pixel = x + y*pp.width;
+                        samp.x = first + rel;
+                        samp.y = first + min(rel + pp.chunk, relEnd);
+                        acc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+                    }
                 }
             }
         }
@@ -124,14 +156,18 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             slotF4(st, A_THR, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
         } else {
             Rng rng = rngStart(pp.seed, pixel, samp.x);          // PathSampleGenerator::startPath
+            const uint32_t px = pixel % pp.width, py = pixel/pp.width;
+            if (EXT && (pp.flags & TGHIP_PASS_SOBOL))
+                rngStartSobol(rng, s, pp, px, py, pixel, samp.x, 0u);
+            float xi0 = rngNext1DT<EXT>(rng), xi1 = rngNext1DT<EXT>(rng);
             f3 o, d;
-            cameraRay(*asConst(s.camera), pixel % pp.width, pixel/pp.width, rng, o, d);
+            cameraRay(*asConst(s.camera), px, py, xi0, xi1, o, d);
             slotF4(st, A_RAY_O, slot) = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
             slotF4(st, A_RAY_D, slot) = mk4(d, PT_INF);
             slotU4(st, A_MISC, slot) = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, item);
             slotF4(st, A_EMI, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             slotF4(st, A_THR, slot) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
-            slotU4(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, 0u, 0u);
+            slotU4(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, EXT ? rng.dim : 0u, lumBase);   // .z: next Sobol' dimension
             slotF4(st, A_ACC, slot) = acc;
             push = true;
         }
@@ -416,6 +452,12 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             Rng rng;
             rng.state = ((uint64_t)rs.y << 32) | rs.x;
             rng.inc = ((uint64_t)pixel << 1) | 1u;
+            rng.sobol = nullptr;
+            rng.scramble = rng.index = rng.dim = 0u;
+            if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL)) {
+                uint4 sm = slotU4(st, A_SAMP, slot);             // .x = sample index, .z = next dimension
+                rngStartSobol(rng, s, pp, pixel % pp.width, pixel/pp.width, pixel, sm.x, sm.z);
+            }
             RayD ray;
             ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
             f3 throughput = xyz(thr4);
@@ -634,6 +676,8 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     slotF4(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
                     slotF4(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
                     *reinterpret_cast<uint2 *>(&slotU4(st, A_MISC, slot)) = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                    if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL))
+                        slotU4(st, A_SAMP, slot).z = rng.dim;
                 }
             }
             const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state);
@@ -656,7 +700,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
         if (FUSE & FUSE_TRACE) queuePush(toComplex, local, L, Q_SHADE1);
         queuePush(hasShadow, local, L, Q_SHADOW);
         PROF(6);
-        bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
+        bool regenerated = nextPath<true, (M & FEAT_QMC) != 0>(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
         PROF(7);
         queuePush(survives, local, L, Q_EXT);
         queuePush(regenerated, local, L, Q_EXTP);
@@ -1041,6 +1085,34 @@ __global__ __launch_bounds__(256) void k_resolve(PathState st, PassParams pp, fl
     fbCount[pixel] += cnt;
 }
 
+// SampleRecord::addSample (path_tracer/SampleRecord.hpp:46-58) over the luminances the pass wrote, one thread per
+// record, in the order the reference's renderTile visits them (PathTraceIntegrator.cpp:136-156: the tile's pixels
+// row by row, each pixel's samples in index order), so mean and running variance round exactly like the CPU's.
+__global__ __launch_bounds__(64) void k_records(PassParams pp, TgHipSampleRecord *records, uint32_t numRecords)
+{
+    uint32_t r = blockIdx.x*blockDim.x + threadIdx.x;
+    if (r >= numRecords)
+        return;
+    uint32_t rx = r % pp.variance_w, ry = r/pp.variance_w;
+    uint32_t tile = (rx >> 2) + (ry >> 2)*pp.tiles_x;
+    if (tile % pp.shard_count != pp.shard_index)
+        return;
+    const uint32_t cnt = pp.rec_count[r], base = pp.rec_lum[r];
+    TgHipSampleRecord rec = records[r];
+    for (uint32_t py = 0; py < 4u && ry*4u + py < pp.height; ++py)
+        for (uint32_t px = 0; px < 4u && rx*4u + px < pp.width; ++px) {
+            const float *lum = pp.lum + (size_t)base + (size_t)((py << 2) | px)*cnt;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float x = lum[i];
+                rec.sample_count++;
+                float delta = x - rec.mean;
+                rec.mean += delta/(float)rec.sample_count;
+                rec.running_variance += delta*(x - rec.mean);
+            }
+        }
+    records[r] = rec;
+}
+
 // =============================================================================================
 // Host-side shim
 // =============================================================================================
@@ -1076,6 +1148,14 @@ struct tghip_ctx {
     float *extSum = nullptr;
     uint32_t *extCount = nullptr;
 
+    // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS state
+    DeviceBuffers extMem;                 // tile seeds + per-record pass arrays (sized at upload)
+    uint32_t *dTileSeeds = nullptr, *dRecIndex = nullptr, *dRecCount = nullptr, *dRecLum = nullptr;
+    TgHipSampleRecord *dRecords = nullptr;   // SampleRecords, ceil(W/4) x ceil(H/4)
+    float *lum = nullptr;                 // per-sample luminance of the running pass
+    size_t lumCap = 0;
+    std::vector<uint32_t> hostRecLum, hostRecIndex, hostRecCount;
+
     // path pool
     DeviceBuffers poolMem;
     PathState pool;
@@ -1096,7 +1176,7 @@ struct tghip_ctx {
     bool haveComplex = false;             // some primitive record uses a class-1 BSDF
     uint32_t complexMask = 0;             // union of the BSDF types inside class-1 materials
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
-    bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, BSDF_MASK_ALL shading
+    bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, MASK_FULL shading
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
@@ -1105,6 +1185,7 @@ struct tghip_ctx {
     // threads per workgroup, per kernel: chosen at upload so that `blocksPerCu` workgroups of EVERY kernel are
     // resident at once (no second scheduling round), i.e. each kernel runs at its own best occupancy on one grid
     int thrClosest = 256, thrShadow = 256, thrShadeSimple = 192, thrShadeComplex = 128;
+    int thrShadeExt = 128;                // k_shade<BSDF_MASK_ALL>: the variant of TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes
     int thrOverride[4] = {0, 0, 0, 0};
     bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
@@ -1318,8 +1399,9 @@ static void chooseThreads(tghip_ctx *ctx)
     // scenes are streaming-bound and prefer 8 small workgroups per CU that the dispatcher load-balances.
     ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : (flat ? 8 : 4);
     if (flat && ctx->blocksPerCuOpt == 0) {
-        ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
+        ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = ctx->thrShadeExt = 256;
     } else {
+    ctx->thrShadeExt = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     ctx->thrClosest = flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
                     : ctx->dynamicFetch ? pickThreads(ctx, k_trace_closest_dyn<false>, 320, 2)   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
@@ -1329,12 +1411,12 @@ static void chooseThreads(tghip_ctx *ctx)
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, true, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, true, false>, 512, 1);
     else
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, false, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, false, false>, 512, 1);
-    if (ctx->haveMeshLight) ctx->thrShadeSimple = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
+    if (ctx->haveMeshLight) ctx->thrShadeSimple = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     else ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES, 0>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>, 256, 0);
-    if (ctx->haveMeshLight)                         ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
+    if (ctx->haveMeshLight)                         ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     else if ((ctx->complexMask & ~MASK_COAT) == 0)  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2, 0>, 256, 0);
     else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
-    else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
+    else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     }
     int *dst[4] = {&ctx->thrClosest, &ctx->thrShadow, &ctx->thrShadeSimple, &ctx->thrShadeComplex};
     for (int i = 0; i < 4; ++i)
@@ -1389,6 +1471,8 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->sceneMem.release();
     ctx->poolMem.release();
+    ctx->extMem.release();
+    if (ctx->lum) (void)hipFree(ctx->lum);
     if (ctx->fbSum) (void)hipFree(ctx->fbSum);
     if (ctx->fbCount) (void)hipFree(ctx->fbCount);
     if (ctx->partial) (void)hipFree(ctx->partial);
@@ -1552,6 +1636,11 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     s.num_lights = sd->num_lights; s.num_infinite_lights = sd->num_infinite_lights;
     s.num_bsdfs = sd->num_bsdfs; s.num_textures = sd->num_textures;
     if ((rc = uploadArray(ctx, ctx->sceneMem, &sd->camera, 1, &s.camera)) != TGHIP_OK) return rc;
+    s.sobol = nullptr;
+    if (sd->sobol_matrices) {
+        if (sd->num_sobol_words != uint64_t(TGHIP_SOBOL_DIMS)*TGHIP_SOBOL_BITS) { ctx->error = "sobol_matrices must hold 1024 x 52 words"; return TGHIP_E_INVALID; }
+        if ((rc = uploadArray(ctx, ctx->sceneMem, sd->sobol_matrices, size_t(sd->num_sobol_words), &s.sobol)) != TGHIP_OK) return rc;
+    }
     s.settings = sd->settings;
     ctx->bvhDepth = depth;
 
@@ -1564,6 +1653,15 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         size_t npix = size_t(ctx->width)*ctx->height;
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->fbSum), npix*3*sizeof(float)));
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->fbCount), npix*sizeof(uint32_t)));
+        // tile seeds, SampleRecords and the per-record pass arrays
+        ctx->extMem.release();
+        const size_t tiles = size_t((ctx->width + 15)/16)*((ctx->height + 15)/16);
+        const size_t recs = size_t((ctx->width + 3)/4)*((ctx->height + 3)/4);
+        if ((rc = allocArray(ctx, ctx->extMem, tiles, &ctx->dTileSeeds)) != TGHIP_OK) return rc;
+        if ((rc = allocArray(ctx, ctx->extMem, recs, &ctx->dRecIndex)) != TGHIP_OK) return rc;
+        if ((rc = allocArray(ctx, ctx->extMem, recs, &ctx->dRecCount)) != TGHIP_OK) return rc;
+        if ((rc = allocArray(ctx, ctx->extMem, recs, &ctx->dRecLum)) != TGHIP_OK) return rc;
+        if ((rc = allocArray(ctx, ctx->extMem, recs, &ctx->dRecords)) != TGHIP_OK) return rc;
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->haveScene = true;
@@ -1580,6 +1678,8 @@ int tghip_clear_framebuffer(tghip_ctx *ctx)
     uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
     HIP_TRY(ctx, hipMemsetAsync(sum, 0, npix*3*sizeof(float), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(cnt, 0, npix*sizeof(uint32_t), ctx->stream));
+    const size_t recs = size_t((ctx->width + 3)/4)*((ctx->height + 3)/4);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dRecords, 0, recs*sizeof(TgHipSampleRecord), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TGHIP_OK;
 }
@@ -1597,8 +1697,9 @@ extern "C++" {
 template<uint32_t M, int FUSE = 0>
 static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
+    const int threads = M == BSDF_MASK_ALL ? ctx->thrShadeExt : cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex;
     hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? SIMPLE_WAVES : M == MASK_LEAN ? LEAN_WAVES : 2), FUSE>), dim3(grid),
-                       dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0, ctx->stream, ctx->scene, st, pp, cls);
+                       dim3(threads), 0, ctx->stream, ctx->scene, st, pp, cls);
 }
 
 template<bool COUNT>
@@ -1630,7 +1731,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = s.num_recs <= TGHIP_FLAT_MAX_RECS;
-    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt;
+    const bool ext = pp.flags != 0;              // Sobol' sampler / SampleRecords: the general shading variant, unfused
+    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ext;
     const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
@@ -1692,7 +1794,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 if (ctx->haveComplex) {
                     if ((ctx->complexMask & ~MASK_COAT) == 0)       launchShade<MASK_COAT, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
                     else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
-                    else                                            launchShade<BSDF_MASK_ALL, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
+                    else                                            launchShade<MASK_FULL, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
                 }
                 tic(); tic(); tic();
                 ctx->counters.iterations++;
@@ -1713,14 +1815,16 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            if (ctx->haveMeshLight)  launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling
+            if (ext)                 launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 0);
+            else if (ctx->haveMeshLight)  launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling
             else if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
             else                     launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
             if (ctx->haveComplex) {
-                if (ctx->haveMeshLight)                         launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 1);
+                if (ext)                                        launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 1);
+                else if (ctx->haveMeshLight)                    launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
-                else                                            launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 1);
+                else                                            launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
             }
             tic(); tic();
             if (count) launchShadow<true>(ctx, grid, st, pp, iterTag);
@@ -1746,6 +1850,15 @@ int tghip_render_pass(tghip_ctx *ctx, const TgHipPassDesc *pass)
         ctx->error = "invalid pass description";
         return TGHIP_E_INVALID;
     }
+    if (pass->flags & ~(TGHIP_PASS_SOBOL | TGHIP_PASS_RECORDS)) { ctx->error = "unknown pass flags"; return TGHIP_E_INVALID; }
+    if ((pass->flags & TGHIP_PASS_SOBOL) && (!ctx->scene.sobol || !pass->tile_seeds)) {
+        ctx->error = "TGHIP_PASS_SOBOL needs sobol_matrices in the scene description and tile_seeds in the pass";
+        return TGHIP_E_INVALID;
+    }
+    if ((pass->record_count != nullptr) != (pass->record_index != nullptr) || (pass->record_count && !(pass->flags & TGHIP_PASS_RECORDS))) {
+        ctx->error = "record_index and record_count go together and need TGHIP_PASS_RECORDS";
+        return TGHIP_E_INVALID;
+    }
     ctx->passPending = true;
     ctx->passResult = TGHIP_OK;
     ctx->pendingPass = *pass;
@@ -1765,7 +1878,52 @@ int tghip_wait(tghip_ctx *ctx)
     const uint32_t tilesX = (w + 15)/16, tilesY = (h + 15)/16;
     const uint32_t numTiles = tilesX*tilesY;
     const uint32_t ownedTiles = numTiles > pass.shard_index ? (numTiles - pass.shard_index + shardCount - 1)/shardCount : 0;
-    const uint32_t spp = pass.spp_end - pass.spp_begin;
+    uint32_t spp = pass.spp_end - pass.spp_begin, sppBegin = pass.spp_begin;
+    PassParams base{};
+    base.flags = pass.flags;
+    base.variance_w = (w + 3)/4;
+    if (pass.flags & TGHIP_PASS_SOBOL) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dTileSeeds, pass.tile_seeds, size_t(numTiles)*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        base.tile_seeds = ctx->dTileSeeds;
+    }
+    const uint32_t numRecords = base.variance_w*((h + 3)/4);
+    if (pass.flags & TGHIP_PASS_RECORDS) {
+        // per record: first sample index, samples per pixel, offset of its 16 x count luminance block.  The sample
+        // range of the batches below becomes relative to each record's first index: [0, max count of an owned record).
+        std::vector<uint32_t> &idx = ctx->hostRecIndex, &cnt = ctx->hostRecCount, &off = ctx->hostRecLum;
+        idx.resize(numRecords); cnt.resize(numRecords); off.resize(numRecords);
+        uint64_t total = 0;
+        uint32_t maxCount = 0;
+        for (uint32_t r = 0; r < numRecords; ++r) {
+            uint32_t rx = r % base.variance_w, ry = r/base.variance_w;
+            bool owned = ((rx >> 2) + (ry >> 2)*tilesX) % shardCount == pass.shard_index;
+            idx[r] = pass.record_index ? pass.record_index[r] : pass.spp_begin;
+            cnt[r] = pass.record_count ? pass.record_count[r] : spp;
+            off[r] = uint32_t(total);
+            if (owned) {
+                total += uint64_t(cnt[r])*16u;
+                maxCount = std::max(maxCount, cnt[r]);
+            }
+            if (total >= (1ull << 32)) {
+                ctx->error = "pass too large for SampleRecord keeping (more than 2^32 samples per device): lower spp_step";
+                return ctx->passResult = TGHIP_E_UNSUPPORTED;
+            }
+        }
+        spp = maxCount;
+        sppBegin = 0;
+        if (ctx->lumCap < total) {
+            if (ctx->lum) (void)hipFree(ctx->lum);
+            ctx->lum = nullptr; ctx->lumCap = 0;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->lum), std::max<uint64_t>(total, 1)*sizeof(float)));
+            ctx->lumCap = total;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dRecIndex, idx.data(), numRecords*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dRecCount, cnt.data(), numRecords*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dRecLum, off.data(), numRecords*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        base.rec_index = ctx->dRecIndex; base.rec_count = ctx->dRecCount; base.rec_lum = ctx->dRecLum;
+        base.lum = ctx->lum;
+    }
+    const uint32_t sppEnd = sppBegin + spp;
     if (ownedTiles == 0 || spp == 0)
         return ctx->passResult = TGHIP_OK;
 
@@ -1794,10 +1952,10 @@ int tghip_wait(tghip_ctx *ctx)
     HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.live[1], 0, sizeof(uint32_t), ctx->stream));   // abort flag
 
     HIP_TRY(ctx, hipEventRecord(ctx->evA, ctx->stream));
-    for (uint32_t sppFirst = pass.spp_begin; sppFirst < pass.spp_end && rc == TGHIP_OK; sppFirst += chunksPerBatch*chunk) {
-        const uint32_t sppLast = uint32_t(std::min<uint64_t>(uint64_t(sppFirst) + uint64_t(chunksPerBatch)*chunk, pass.spp_end));
+    for (uint32_t sppFirst = sppBegin; sppFirst < sppEnd && rc == TGHIP_OK; sppFirst += chunksPerBatch*chunk) {
+        const uint32_t sppLast = uint32_t(std::min<uint64_t>(uint64_t(sppFirst) + uint64_t(chunksPerBatch)*chunk, sppEnd));
         for (uint32_t first = 0; first < ownedTiles; first += tilesPerBatch) {
-            PassParams pp;
+            PassParams pp = base;
             pp.spp_begin = sppFirst; pp.spp_end = sppLast; pp.seed = pass.seed;
             pp.chunk = chunk;
             pp.chunks = (sppLast - sppFirst + chunk - 1)/chunk;
@@ -1810,6 +1968,14 @@ int tghip_wait(tghip_ctx *ctx)
             rc = runBatch(ctx, pp);
             if (rc != TGHIP_OK) break;
         }
+    }
+    if ((pass.flags & TGHIP_PASS_RECORDS) && rc == TGHIP_OK) {
+        PassParams pp = base;
+        pp.shard_index = pass.shard_index; pp.shard_count = shardCount;
+        pp.tiles_x = tilesX; pp.num_tiles = numTiles;
+        pp.width = w; pp.height = h;
+        hipLaunchKernelGGL(k_records, dim3((numRecords + 63)/64), dim3(64), 0, ctx->stream, pp, ctx->dRecords, numRecords);
+        HIP_TRY(ctx, hipGetLastError());
     }
     HIP_TRY(ctx, hipEventRecord(ctx->evB, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1847,6 +2013,30 @@ int tghip_download_framebuffer(tghip_ctx *ctx, float *rgb_sum, uint32_t *count, 
     const uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
     if (rgb_sum) HIP_TRY(ctx, hipMemcpyAsync(rgb_sum, sum, npixels*3*sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     if (count) HIP_TRY(ctx, hipMemcpyAsync(count, cnt, npixels*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
+int tghip_download_records(tghip_ctx *ctx, TgHipSampleRecord *out, size_t n)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    if (!out || n != size_t((ctx->width + 3)/4)*((ctx->height + 3)/4)) { ctx->error = "record count mismatch"; return TGHIP_E_INVALID; }
+    int rc = tghip_wait(ctx);
+    if (rc != TGHIP_OK && rc != TGHIP_E_ABORTED) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->dRecords, n*sizeof(TgHipSampleRecord), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
+int tghip_upload_records(tghip_ctx *ctx, const TgHipSampleRecord *in, size_t n)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    if (!in || n != size_t((ctx->width + 3)/4)*((ctx->height + 3)/4)) { ctx->error = "record count mismatch"; return TGHIP_E_INVALID; }
+    int rc = tghip_wait(ctx);
+    if (rc != TGHIP_OK && rc != TGHIP_E_ABORTED) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dRecords, in, n*sizeof(TgHipSampleRecord), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TGHIP_OK;
 }

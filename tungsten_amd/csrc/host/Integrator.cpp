@@ -121,6 +121,12 @@ void PathTraceHipIntegrator::prepareForRender(TraceableScene &scene, uint32_t se
     _sum.assign(size_t(_w)*_h*3, 0.0f);
     _count.assign(size_t(_w)*_h, 0);
     _imageDirty = true;
+
+    // PathTraceIntegrator.cpp:187,196-200: the integrator's own sampler, tile dicing, one SampleRecord per 4x4 pixels
+    _useSobol = scene.rendererSettings().useSobol;
+    _useAdaptive = scene.rendererSettings().useAdaptiveSampling;
+    _scheduler.reset(_w, _h, seed);
+    _deviceRecords.assign(_ctxs.size(), std::vector<TgHipSampleRecord>(_useAdaptive ? _scheduler.records().size() : 0));
 }
 
 void PathTraceHipIntegrator::teardownAfterRender()
@@ -138,14 +144,15 @@ void PathTraceHipIntegrator::startRender(std::function<void()> completionCallbac
 {
     if (_worker.joinable())
         _worker.join();
-    if (done()) {
+    if (!done() && _ctxs.empty())
+        throw std::runtime_error("path_tracer_hip: startRender before prepareForRender");
+    // PathTraceIntegrator::startRender (:220-227): nothing to do when done or when generateWork finds no work
+    if (done() || !_scheduler.generateWork(_currentSpp, _nextSpp, _useAdaptive)) {
         _currentSpp = _nextSpp;
         advanceSpp();
         completionCallback();
         return;
     }
-    if (_ctxs.empty())
-        throw std::runtime_error("path_tracer_hip: startRender before prepareForRender");
 
     _abort = false;
     _workerError = nullptr;
@@ -157,7 +164,16 @@ void PathTraceHipIntegrator::startRender(std::function<void()> completionCallbac
         pass.seed = _seed;
         pass.shard_index = uint32_t(d);
         pass.shard_count = uint32_t(_ctxs.size());
-        pass.flags = 0;
+        pass.flags = (_useSobol ? TGHIP_PASS_SOBOL : 0u) | (_useAdaptive ? TGHIP_PASS_RECORDS : 0u);
+        pass.tile_seeds = _useSobol ? _scheduler.tileSeeds().data() : nullptr;
+        pass.record_index = pass.record_count = nullptr;
+        if (_useAdaptive) {
+            // renderTile (:136-156): every pixel of a record traces samples [sampleIndex, sampleIndex + nextSampleCount)
+            if (d == 0)
+                _scheduler.passArrays(_recordIndex, _recordCount);
+            pass.record_index = _recordIndex.data();
+            pass.record_count = _recordCount.data();
+        }
         check(tghip_render_pass(_ctxs[d], &pass), _ctxs[d], "tghip_render_pass");
     }
     _imageDirty = true;
@@ -176,6 +192,14 @@ void PathTraceHipIntegrator::startRender(std::function<void()> completionCallbac
                 if (rcs[d] == TGHIP_E_ABORTED)
                     return;   // no finisher / callback on abort (TaskGroup.hpp:33-41,77-83)
                 check(rcs[d], _ctxs[d], "tghip_wait");
+            }
+            if (_useAdaptive) {
+                std::vector<const TgHipSampleRecord *> sources;
+                for (size_t d = 0; d < _ctxs.size(); ++d) {
+                    check(tghip_download_records(_ctxs[d], _deviceRecords[d].data(), _deviceRecords[d].size()), _ctxs[d], "tghip_download_records");
+                    sources.push_back(_deviceRecords[d].data());
+                }
+                _scheduler.absorb(sources.data(), sources.size());
             }
         } catch (...) {
             _workerError = std::current_exception();

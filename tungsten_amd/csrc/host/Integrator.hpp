@@ -12,6 +12,7 @@
 #define TGAMD_INTEGRATOR_HPP_
 
 #include "Scene.hpp"
+#include "Sampling.hpp"
 #include "../../../include/tungsten_hip.h"
 
 #include <atomic>
@@ -67,6 +68,11 @@ class PathTraceHipIntegrator : public Integrator
     std::exception_ptr _workerError;      // like the reference's pool thread (TaskGroup.hpp:55-75)
     std::atomic<bool> _abort{false};
 
+    PassScheduler _scheduler;             // tile seeds, SampleRecords, adaptive sample distribution
+    bool _useSobol = false, _useAdaptive = false;
+    std::vector<uint32_t> _recordIndex, _recordCount;      // borrowed by the device until the pass completes
+    std::vector<std::vector<TgHipSampleRecord>> _deviceRecords;
+
     std::vector<float> _sum;              // host copy of the device framebuffer (sum, count)
     std::vector<uint32_t> _count;
     std::vector<float> _linear;
@@ -89,6 +95,7 @@ public:
 
     const IntegratorSettings &settings() const { return _settings; }
     void setSettings(const IntegratorSettings &s) { _settings = s; }
+    const PassScheduler &scheduler() const { return _scheduler; }
     tghip_ctx *context(size_t i = 0) { return i < _ctxs.size() ? _ctxs[i] : nullptr; }
     // raw accumulation buffers (sum of radiance and sample count per pixel)
     const std::vector<float> &sumBuffer() { fetchFramebuffer(); return _sum; }

@@ -1,0 +1,80 @@
+// Host half of the sampling machinery around the device path tracer:
+//   * UniformSampler        -- the integrator's own PCG stream (sampling/UniformSampler.hpp:11-72), used for
+//                              tile seeds and the stochastic rounding of adaptive sample counts;
+//   * SobolMatrices         -- the generator matrices sobol::sample reads (thirdparty/sobol/sobol.h:30-35); this
+//                              repository does not carry the reference's 53 000-line table as source, it loads
+//                              the same 1024 x 52 words from a data file (tungsten_amd/data/README.md);
+//   * PassScheduler         -- diceTiles / generateWork / errorPercentile95 / dilateAdaptiveWeights /
+//                              distributeAdaptiveSamples of PathTraceIntegrator
+//                              (integrators/path_tracer/PathTraceIntegrator.cpp:27-134) over SampleRecords
+//                              (path_tracer/SampleRecord.hpp:11-69).  The Welford accumulation itself runs on
+//                              the device (TGHIP_PASS_RECORDS); this class owns what happens between passes.
+#ifndef TGAMD_SAMPLING_HPP_
+#define TGAMD_SAMPLING_HPP_
+
+#include "../../../include/tungsten_hip.h"
+#include "../../../include/tungsten_host.h"
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace tungsten_amd {
+
+class UniformSampler
+{
+    uint64_t _state, _sequence;
+
+public:
+    explicit UniformSampler(uint64_t seed = 0xBA5EBA11ull, uint64_t sequence = 0) : _state(seed), _sequence(sequence) {}
+
+    uint32_t nextI();
+    float next1D();
+    uint64_t state() const { return _state; }
+    void setState(uint64_t s) { _state = s; }
+};
+
+struct SobolMatrices
+{
+    // Loads (once per process) the TGHIP_SOBOL_DIMS x TGHIP_SOBOL_BITS words from $TUNGSTEN_HIP_SOBOL_MATRICES or
+    // from data/sobol_matrices_1024x52.bin next to the library; throws std::runtime_error when absent or malformed.
+    static const std::vector<uint32_t> &get();
+    static std::string defaultPath();
+};
+
+class PassScheduler
+{
+    uint32_t _w = 0, _h = 0, _varianceW = 0, _varianceH = 0;
+    UniformSampler _sampler;
+    std::vector<uint32_t> _tileSeeds;
+    std::vector<TgHostSampleRecord> _samples;
+
+    float errorPercentile95();
+    void dilateAdaptiveWeights();
+    void distributeAdaptiveSamples(int spp);
+
+public:
+    static const uint32_t TileSize = TGHIP_TILE_SIZE, VarianceTileSize = TGHIP_VARIANCE_TILE_SIZE, AdaptiveThreshold = 16;
+
+    PassScheduler() {}
+    // prepareForRender (:184-201): _sampler = UniformSampler(hash32(seed)), diceTiles, one record per 4x4 pixels
+    void reset(uint32_t w, uint32_t h, uint32_t seed);
+
+    bool generateWork(uint32_t currentSpp, uint32_t nextSpp, bool enableAdaptive);
+    // takes the device's Welford state after a pass; `owner` (may be null) selects per record which of
+    // `numSources` arrays holds it (tile-sharded multi-device renders)
+    void absorb(const TgHipSampleRecord *const *sources, size_t numSources);
+
+    uint32_t varianceW() const { return _varianceW; }
+    uint32_t varianceH() const { return _varianceH; }
+    const std::vector<uint32_t> &tileSeeds() const { return _tileSeeds; }
+    std::vector<TgHostSampleRecord> &records() { return _samples; }
+    const std::vector<TgHostSampleRecord> &records() const { return _samples; }
+    UniformSampler &sampler() { return _sampler; }
+    // per-record arrays in the layout TgHipPassDesc wants
+    void passArrays(std::vector<uint32_t> &index, std::vector<uint32_t> &count) const;
+};
+
+} // namespace tungsten_amd
+
+#endif

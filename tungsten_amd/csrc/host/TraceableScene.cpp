@@ -1,4 +1,5 @@
 #include "TraceableScene.hpp"
+#include "Sampling.hpp"
 #include "BvhBuilder.hpp"
 #include "Integrator.hpp"
 
@@ -316,6 +317,12 @@ void TraceableScene::flatten()
     _desc.texels = _texels.data(); _desc.num_texel_floats = _texels.size();
     _desc.dist = _dist.data();     _desc.num_dist_floats = _dist.size();
     _desc.light_tris = _lightTris.data(); _desc.num_light_tri_floats = _lightTris.size();
+    if (_scene.renderer.useSobol) {
+        // RendererSettings::useSobol (renderer/RendererSettings.hpp:172-175): tiles get SobolPathSamplers
+        const std::vector<uint32_t> &matrices = SobolMatrices::get();
+        _desc.sobol_matrices = matrices.data();
+        _desc.num_sobol_words = matrices.size();
+    }
     copy3(_desc.bounds_lo, _sceneBounds.lo);
     copy3(_desc.bounds_hi, _sceneBounds.hi);
 

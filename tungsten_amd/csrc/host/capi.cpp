@@ -3,6 +3,7 @@
 
 #include "ImageIO.hpp"
 #include "Integrator.hpp"
+#include "Sampling.hpp"
 #include "Scene.hpp"
 #include "TraceableScene.hpp"
 
@@ -17,6 +18,11 @@ struct tgh_scene
 {
     std::unique_ptr<Scene> scene;
     std::unique_ptr<TraceableScene> flattened;
+};
+
+struct tgh_scheduler
+{
+    PassScheduler scheduler;
 };
 
 struct tgh_renderer
@@ -177,6 +183,47 @@ void tgh_renderer_close(tgh_renderer *r)
     if (!r) return;
     r->flattened.reset();     // ~TraceableScene -> integrator.teardownAfterRender (TraceableScene.hpp:139-160)
     delete r;
+}
+
+int tgh_renderer_records(tgh_renderer *r, TgHostSampleRecord *out, size_t n, char *err, size_t errlen)
+{
+    if (!r || !out) return -1;
+    PathTraceHipIntegrator *hip = dynamic_cast<PathTraceHipIntegrator *>(r->integrator.get());
+    if (!hip) { setErr(err, errlen, "not a path_tracer_hip renderer"); return -1; }
+    const std::vector<TgHostSampleRecord> &rec = hip->scheduler().records();
+    if (rec.size() != n) { setErr(err, errlen, "record count mismatch"); return -1; }
+    std::memcpy(out, rec.data(), n*sizeof(TgHostSampleRecord));
+    return 0;
+}
+
+tgh_scheduler *tgh_scheduler_create(uint32_t width, uint32_t height, uint32_t seed)
+{
+    tgh_scheduler *s = new tgh_scheduler();
+    s->scheduler.reset(width, height, seed);
+    return s;
+}
+size_t tgh_scheduler_num_tiles(tgh_scheduler *s) { return s ? s->scheduler.tileSeeds().size() : 0; }
+size_t tgh_scheduler_num_records(tgh_scheduler *s) { return s ? s->scheduler.records().size() : 0; }
+const uint32_t *tgh_scheduler_tile_seeds(tgh_scheduler *s) { return s ? s->scheduler.tileSeeds().data() : nullptr; }
+TgHostSampleRecord *tgh_scheduler_records(tgh_scheduler *s) { return s ? s->scheduler.records().data() : nullptr; }
+int tgh_scheduler_generate_work(tgh_scheduler *s, uint32_t current_spp, uint32_t next_spp, int adaptive)
+{
+    if (!s) return -1;
+    return s->scheduler.generateWork(current_spp, next_spp, adaptive != 0) ? 1 : 0;
+}
+void tgh_scheduler_free(tgh_scheduler *s) { delete s; }
+
+const uint32_t *tgh_sobol_matrices(size_t *num_words, char *err, size_t errlen)
+{
+    try {
+        const std::vector<uint32_t> &t = SobolMatrices::get();
+        if (num_words) *num_words = t.size();
+        return t.data();
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        if (num_words) *num_words = 0;
+        return nullptr;
+    }
 }
 
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h)
