@@ -62,7 +62,7 @@ def generate_work(records, width, height, sampler_state, current_spp, next_spp, 
 
 
 def render_pass(desc, width, height, seed, spp_begin=0, spp_end=0, flags=0, tile_seeds=None, record_index=None, record_count=None,
-                records=None, ssum=None, count=None, shard_index=0, shard_count=1, threads=0):
+                records=None, ssum=None, count=None, shard_index=0, shard_count=1, threads=0, counters=None):
     """oracle_render_records with the full TgHipPassDesc; accumulates into ssum/count/records when given."""
     ssum = np.zeros((height, width, 3), np.float32) if ssum is None else ssum
     count = np.zeros((height, width), np.uint32) if count is None else count
@@ -74,7 +74,8 @@ def render_pass(desc, width, height, seed, spp_begin=0, spp_end=0, flags=0, tile
             keep.append(a)
             setattr(p, name, a.ctypes.data_as(C.POINTER(C.c_uint32)))
     rc = _lib.oracle_render_records(desc, C.byref(p), ssum.ctypes.data, count.ctypes.data,
-                                    records.ctypes.data if records is not None else None, None, threads)
+                                    records.ctypes.data if records is not None else None,
+                                    C.byref(counters) if counters is not None else None, threads)
     if rc != 0:
         raise RuntimeError("oracle_render_records failed (%d)" % rc)
     return ssum, count
