@@ -1,11 +1,12 @@
 #!/bin/bash
-out=gpurun_out/ad2; mkdir -p $out; export TMPDIR=/tmp
-for i in 1 2; do
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof$i -o stats -- python bench.py --scene materialtest --spp 64 --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-timing > $out/prof$i.log 2>&1
-f=$(find $out/prof$i -name '*kernel_stats.csv' | head -1); head -6 $f | cut -c1-150
-find $out/prof$i -name '*kernel_trace.csv' -delete; find $out/prof$i -name '*.db' -delete
-done
-for i in 1 2 3; do
-timeout 300 python bench.py --scene materialtest --spp 64 --no-extra --no-cpu-baseline | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('materialtest',d['value'],d['ms_per_step'],{k:v['avg_us'] for k,v in d['kernels'].items()})"
-done
+out=gpurun_out/ad3; mkdir -p $out
+timeout 1200 python -m pytest tests -m gpu -q --timeout 600 -x > $out/pytest.log 2>&1; echo "pytest rc=$?"
+tail -5 $out/pytest.log
+python tools/bench_as_shipped.py --scene materialtest
+python tools/bench_as_shipped.py --scene materialtest --no-sobol
+python tools/bench_as_shipped.py --scene materialtest --no-adaptive
+python tools/bench_as_shipped.py --scene materialtest --no-adaptive --no-sobol
+python tools/bench_as_shipped.py --scene cornell --spp 256 --spp-step 16
+python tools/bench_as_shipped.py --scene cornell --spp 256 --spp-step 16 --no-sobol
+python tools/bench_as_shipped.py --scene cornell --spp 256 --spp-step 16 --no-adaptive
+python tools/bench_as_shipped.py --scene cornell --spp 256 --spp-step 16 --no-adaptive --no-sobol

@@ -1,0 +1,55 @@
+"""Times the whole integrator loop (tgh_renderer_render: passes of spp_step samples, Sobol' sampler and adaptive sampling
+as the scene's renderer block says) -- the "as shipped" configuration of a scene, next to bench.py's fixed-spp metric.
+
+    python tools/bench_as_shipped.py [--scene materialtest|cornell] [--width 1280 --height 720] [--spp 64] [--spp-step 16]
+                                     [--no-sobol] [--no-adaptive] [--repeats 3]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import scenes  # noqa: E402
+import tungsten_amd as tg  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="materialtest")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--spp-step", type=int, default=16)
+    ap.add_argument("--no-sobol", action="store_true")
+    ap.add_argument("--no-adaptive", action="store_true")
+    ap.add_argument("--repeats", type=int, default=3)
+    a = ap.parse_args()
+    tmp = tempfile.mkdtemp(prefix="tg_shipped_")
+    mk = {"materialtest": scenes.materialtest, "cornell": scenes.cornell}[a.scene]
+    path = mk(tmp, resolution=(a.width, a.height), spp=a.spp, spp_step=a.spp_step,
+              renderer={"adaptive_sampling": not a.no_adaptive, "stratified_sampler": not a.no_sobol})
+    best = None
+    for _ in range(a.repeats):
+        r = tg.Renderer(path)
+        t0 = time.perf_counter()
+        secs = r.render()
+        wall = time.perf_counter() - t0
+        c = r.counters()
+        mean, ssum, count = r.image()
+        r.close()
+        res = {"scene": a.scene, "width": a.width, "height": a.height, "spp": a.spp, "spp_step": a.spp_step,
+               "sobol": not a.no_sobol, "adaptive": not a.no_adaptive, "samples": int(c.samples), "seconds": round(secs, 4),
+               "wall_seconds": round(wall, 4), "msamples_per_s": round(c.samples/secs*1e-6, 2),
+               "count_min": int(count.min()), "count_max": int(count.max()), "image_mean": [round(float(v), 6) for v in mean.mean(axis=(0, 1))]}
+        if best is None or res["seconds"] < best["seconds"]:
+            best = res
+    print(json.dumps(best))
+
+
+if __name__ == "__main__":
+    main()

@@ -52,7 +52,7 @@ struct DeviceScene {
 #define FEAT_SOLIDS     (1u << 28)   /* sphere records; sphere / cube emitters as sampled lights       */
 #define FEAT_ALL        (FEAT_BITMAP | FEAT_INFINITE | FEAT_MULTILIGHT | FEAT_TRIANGLES | FEAT_SOLIDS)
 #define FEAT_MESHLIGHT  (1u << 29)   /* triangle-mesh emitters as sampled lights: only in the MASK_FULL / BSDF_MASK_ALL variants */
-#define FEAT_QMC        (1u << 30)   /* TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes: only in BSDF_MASK_ALL variants */
+#define FEAT_QMC        (1u << 30)   /* TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes: every variant has a twin with this bit (launchShade) */
 #define MASK_FULL       (BSDF_MASK_ALL & ~FEAT_QMC)
 // next1D of the path's sampler inside code templated on M
 #define RNG1D(r) rngNext1DT<(M & FEAT_QMC) != 0>(r)

@@ -1185,7 +1185,6 @@ struct tghip_ctx {
     // threads per workgroup, per kernel: chosen at upload so that `blocksPerCu` workgroups of EVERY kernel are
     // resident at once (no second scheduling round), i.e. each kernel runs at its own best occupancy on one grid
     int thrClosest = 256, thrShadow = 256, thrShadeSimple = 192, thrShadeComplex = 128;
-    int thrShadeExt = 128;                // k_shade<BSDF_MASK_ALL>: the variant of TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes
     int thrOverride[4] = {0, 0, 0, 0};
     bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
@@ -1399,9 +1398,8 @@ static void chooseThreads(tghip_ctx *ctx)
     // scenes are streaming-bound and prefer 8 small workgroups per CU that the dispatcher load-balances.
     ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : (flat ? 8 : 4);
     if (flat && ctx->blocksPerCuOpt == 0) {
-        ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = ctx->thrShadeExt = 256;
+        ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
     } else {
-    ctx->thrShadeExt = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     ctx->thrClosest = flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
                     : ctx->dynamicFetch ? pickThreads(ctx, k_trace_closest_dyn<false>, 320, 2)   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
@@ -1694,12 +1692,19 @@ int tghip_bind_framebuffer(tghip_ctx *ctx, float *dev_rgb_sum, uint32_t *dev_cou
 }
 
 extern "C++" {
+template<uint32_t M, int FUSE>
+static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
+{
+    constexpr uint32_t B = M & ~FEAT_QMC;
+    hipLaunchKernelGGL((k_shade<M, (B == MASK_SIMPLE ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : 2), FUSE>), dim3(grid),
+                       dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0, ctx->stream, ctx->scene, st, pp, cls);
+}
+// TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
 template<uint32_t M, int FUSE = 0>
 static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
-    const int threads = M == BSDF_MASK_ALL ? ctx->thrShadeExt : cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex;
-    hipLaunchKernelGGL((k_shade<M, (M == MASK_SIMPLE ? SIMPLE_WAVES : M == MASK_LEAN ? LEAN_WAVES : 2), FUSE>), dim3(grid),
-                       dim3(threads), 0, ctx->stream, ctx->scene, st, pp, cls);
+    if (pp.flags) launchShadeVariant<M | FEAT_QMC, FUSE>(ctx, grid, st, pp, cls);
+    else          launchShadeVariant<M, FUSE>(ctx, grid, st, pp, cls);
 }
 
 template<bool COUNT>
@@ -1731,8 +1736,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = s.num_recs <= TGHIP_FLAT_MAX_RECS;
-    const bool ext = pp.flags != 0;              // Sobol' sampler / SampleRecords: the general shading variant, unfused
-    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ext;
+    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt;
     const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
@@ -1815,13 +1819,11 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            if (ext)                 launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 0);
-            else if (ctx->haveMeshLight)  launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling
+            if (ctx->haveMeshLight)  launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling
             else if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
             else                     launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
             if (ctx->haveComplex) {
-                if (ext)                                        launchShade<BSDF_MASK_ALL>(ctx, grid, st, pp, 1);
-                else if (ctx->haveMeshLight)                    launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
+                if (ctx->haveMeshLight)                         launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
                 else                                            launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
