@@ -75,14 +75,19 @@ typedef struct TgHipBvhNode {
 #define TGHIP_FLAT_MAX_RECS    16
 
 /* record kinds (meta >> 29) */
-enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3 };
+enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3, TGHIP_REC_INSTANCE = 4 };
 #define TGHIP_REC_KIND(meta)   ((uint32_t)(meta) >> 29)
 #define TGHIP_REC_OBJECT(meta) ((uint32_t)(meta) & 0x1FFFFFFFu)
 
 /* 48-byte primitive record = three float4:
  *   triangle: a = v0, b = v1 - v0, c = v2 - v0                (p0,p1 unused)
  *   quad    : a = base, b = edge0, c = edge1, p0/p1 = 1/|edge0|^2, 1/|edge1|^2   (Quad.cpp:298-316)
- *   cube / sphere: geometry lives in objects[TGHIP_REC_OBJECT(meta)]; a,b,c unused */
+ *   cube / sphere: geometry lives in objects[TGHIP_REC_OBJECT(meta)]; a,b,c unused
+ *   instance: one rigid placement of a master mesh (primitives/Instance.cpp:290-344): a = _instancePos[i],
+ *             (p0, b) = _instanceRot[i] as quaternion (w; x, y, z), c[0] = bits of the master's BVH root node index
+ *             (uint32), c[1] = bits of the instance number i; the object is the `instances` primitive.  The master's
+ *             triangle records (in master space, i.e. with the master's own transform applied) and its BVH2 subtree
+ *             follow the top-level ones in recs / tri_attrs / nodes and are reachable only through instance records. */
 typedef struct TgHipPrimRec {
     float a[3]; uint32_t meta;
     float b[3]; float p0;
@@ -101,7 +106,7 @@ typedef struct TgHipTriAttr {
 
 /* ---- objects (one per reference Primitive) ------------------------------------------ */
 enum { TGHIP_OBJ_MESH = 0, TGHIP_OBJ_QUAD = 1, TGHIP_OBJ_CUBE = 2, TGHIP_OBJ_SPHERE = 3,
-       TGHIP_OBJ_INFINITE_SPHERE = 4 };
+       TGHIP_OBJ_INFINITE_SPHERE = 4, TGHIP_OBJ_INSTANCES = 5 };
 #define TGHIP_OBJF_SMOOTH   1u   /* mesh "smooth": Ns interpolated (TriangleMesh.cpp:344-355) */
 #define TGHIP_OBJF_SAMPLE   2u   /* infinite_sphere "sample" (InfiniteSphere.cpp:117-122)      */
 
@@ -210,6 +215,8 @@ typedef struct TgHipSceneDesc {
     /* generator matrices of the Sobol' sequence, TGHIP_SOBOL_DIMS x TGHIP_SOBOL_BITS words -- the host's own copy of
      * sobol::Matrices::matrices (thirdparty/sobol/sobol.h:30-35); NULL/0 unless passes use TGHIP_PASS_SOBOL */
     const uint32_t     *sobol_matrices;  uint64_t num_sobol_words;
+    uint32_t num_instances;               /* instance records among recs (0: single-level scene) */
+    uint32_t num_top_recs;                /* records of the top-level BVH = recs[0, num_top_recs); the rest belong to masters */
     TgHipCamera   camera;
     TgHipSettings settings;
     float         bounds_lo[3], bounds_hi[3];

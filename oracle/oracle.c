@@ -1255,7 +1255,25 @@ static inline int box_test(const float *lo, const float *hi, const Ray *ray, v3 
 
 /* TraceableScene::intersect (renderer/TraceableScene.hpp:170-192): closest hit over all finite
  * primitives.  The reference does it with Embree BVH4s; we walk the flattened BVH2, near child first. */
-static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float *tmax, TgHipHit *hit, TravStats *st)
+/* closest hit so far: TgHipHit plus the instance record the hit triangle was reached through (-1: none) */
+typedef struct { float t, u, v; int32_t rec; int32_t inst; } Hit;
+
+/* Quaternion<float>::operator*(Vec3) (math/Quaternion.hpp:78-88); q = (w, x, y, z) */
+static v3 quat_rotate(const float *q, v3 o)
+{
+    float tx = 2.0f*(q[2]*o.z - q[3]*o.y);
+    float ty = 2.0f*(q[3]*o.x - q[1]*o.z);
+    float tz = 2.0f*(q[1]*o.y - q[2]*o.x);
+    return V(o.x + q[0]*tx + q[2]*tz - q[3]*ty,
+             o.y + q[0]*ty + q[3]*tx - q[1]*tz,
+             o.z + q[0]*tz + q[1]*ty - q[2]*tx);
+}
+static void instance_quat(const TgHipPrimRec *r, float *q) { q[0] = r->p0; q[1] = r->b[0]; q[2] = r->b[1]; q[3] = r->b[2]; }
+static void instance_inv_quat(const TgHipPrimRec *r, float *q) { q[0] = r->p0; q[1] = -r->b[0]; q[2] = -r->b[1]; q[3] = -r->b[2]; }   /* conjugate() :42-45 */
+
+static void bvh_walk(const TgHipSceneDesc *s, int32_t root, const Ray *ray, float *tmax, Hit *hit, TravStats *st, int objFilter, int32_t inst);
+
+static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float *tmax, Hit *hit, TravStats *st, int objFilter, int32_t inst)
 {
     const TgHipPrimRec *r = &s->recs[i];
     if (st) st->prims++;
@@ -1266,34 +1284,36 @@ static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float 
     case TGHIP_REC_QUAD: ok = quad_test(r, &s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &u, &v, &back); break;
     case TGHIP_REC_CUBE: ok = cube_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
     case TGHIP_REC_SPHERE: ok = sphere_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
+    case TGHIP_REC_INSTANCE: {
+        /* Instance::intersect (primitives/Instance.cpp:290-311): the ray goes into the master's space -- rotation and
+         * translation only, so distances along it are unchanged -- and the master's own intersect shortens it */
+        float q[4];
+        instance_inv_quat(r, q);
+        Ray local = {quat_rotate(q, vsub(ray->o, ld3(r->a))), quat_rotate(q, ray->d), ray->tmin, *tmax};
+        uint32_t root;
+        memcpy(&root, &r->c[0], 4);
+        bvh_walk(s, (int32_t)root, &local, tmax, hit, st, -1, (int32_t)i);
+        return;
+    }
     default: break;
     }
-    if (ok) { *tmax = t; hit->t = t; hit->u = u; hit->v = v; hit->rec = (int32_t)i; }
+    (void)objFilter;
+    if (ok) { *tmax = t; hit->t = t; hit->u = u; hit->v = v; hit->rec = (int32_t)i; hit->inst = inst; }
 }
 
-/* objFilter >= 0: only records of that object are tested (a mesh light's own rtcIntersect, TriangleMesh.cpp:317-335) */
-static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hit, TravStats *st, int objFilter)
+static void bvh_walk(const TgHipSceneDesc *s, int32_t root, const Ray *ray, float *tmax, Hit *hit, TravStats *st, int objFilter, int32_t inst)
 {
     int32_t stack[TGHIP_MAX_BVH_DEPTH + 2];
     int sp = 0;
-    float tmax = ray->tmax;
-    hit->rec = -1; hit->t = tmax; hit->u = hit->v = 0.0f;
-    if (st) st->rays++;
-    if (s->num_recs <= TGHIP_FLAT_MAX_RECS) {           /* flat list (include/tungsten_hip.h) */
-        for (uint32_t i = 0; i < s->num_recs; ++i)
-            if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
-                test_rec(s, i, ray, &tmax, hit, st);
-        return hit->rec >= 0;
-    }
     v3 invD = V(1.0f/ray->d.x, 1.0f/ray->d.y, 1.0f/ray->d.z);
-    int32_t cur = 0;
+    int32_t cur = root;
     for (;;) {
         if (cur >= 0) {
             const TgHipBvhNode *n = &s->nodes[cur];
             if (st) st->nodes++;
             float e0, e1;
-            int h0 = box_test(n->lo0, n->hi0, ray, invD, tmax, &e0);
-            int h1 = box_test(n->lo1, n->hi1, ray, invD, tmax, &e1);
+            int h0 = box_test(n->lo0, n->hi0, ray, invD, *tmax, &e0);
+            int h1 = box_test(n->lo1, n->hi1, ray, invD, *tmax, &e1);
             if (h0 && h1) {
                 if (e1 < e0) { stack[sp++] = n->child0; cur = n->child1; }
                 else { stack[sp++] = n->child1; cur = n->child0; }
@@ -1304,14 +1324,29 @@ static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, TgHipHit
             uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
             for (uint32_t i = first; i < first + count; ++i)
                 if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
-                    test_rec(s, i, ray, &tmax, hit, st);
+                    test_rec(s, i, ray, tmax, hit, st, objFilter, inst);
         }
         if (sp == 0) break;
         cur = stack[--sp];
     }
+}
+
+/* objFilter >= 0: only records of that object are tested (a mesh light's own rtcIntersect, TriangleMesh.cpp:317-335) */
+static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, Hit *hit, TravStats *st, int objFilter)
+{
+    float tmax = ray->tmax;
+    hit->rec = -1; hit->inst = -1; hit->t = tmax; hit->u = hit->v = 0.0f;
+    if (st) st->rays++;
+    if (s->num_recs <= TGHIP_FLAT_MAX_RECS && s->num_instances == 0) {           /* flat list (include/tungsten_hip.h) */
+        for (uint32_t i = 0; i < s->num_recs; ++i)
+            if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
+                test_rec(s, i, ray, &tmax, hit, st, objFilter, -1);
+        return hit->rec >= 0;
+    }
+    bvh_walk(s, 0, ray, &tmax, hit, st, objFilter, -1);
     return hit->rec >= 0;
 }
-static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, TgHipHit *hit, TravStats *st)
+static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, Hit *hit, TravStats *st)
 {
     return scene_intersect_obj(s, ray, hit, st, -1);
 }
@@ -1323,7 +1358,7 @@ typedef struct {
     int object, bsdf, backSide;
 } Info;
 
-static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const TgHipHit *hit, Info *info)
+static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit *hit, Info *info)
 {
     const TgHipPrimRec *r = &s->recs[hit->rec];
     int objIdx = (int)TGHIP_REC_OBJECT(r->meta);
@@ -1336,7 +1371,13 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const TgH
     case TGHIP_REC_TRIANGLE: {   /* TriangleMesh.cpp:317-355, 80-106 */
         const TgHipTriAttr *a = &s->tri_attrs[hit->rec];
         v3 NgU = vcross(ld3(r->b), ld3(r->c));
-        info->backSide = vdot(NgU, ray->d) > 0.0f;
+        v3 dLocal = ray->d;
+        if (hit->inst >= 0) {       /* the master was intersected with the ray in its own space (Instance.cpp:295-297) */
+            float qi[4];
+            instance_inv_quat(&s->recs[hit->inst], qi);
+            dLocal = quat_rotate(qi, ray->d);
+        }
+        info->backSide = vdot(NgU, dLocal) > 0.0f;
         info->Ng = vnorm(NgU);
         float u = hit->u, v = hit->v;
         if (o->flags & TGHIP_OBJF_SMOOTH) {
@@ -1371,6 +1412,18 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const TgH
     default:
         info->Ng = info->Ns = V(0, 1, 0); info->u = info->v = 0; info->bsdf = o->bsdf; info->backSide = 0;
         break;
+    }
+    if (hit->inst >= 0) {
+        /* Instance::intersectionInfo (primitives/Instance.cpp:337-346): the master's normals go to world space; info.p,
+         * which TraceableScene::intersect already set to the WORLD-space hit point (TraceableScene.hpp:184), is transformed
+         * once more -- the reference's behaviour, reproduced as it is (NEE and MIS are evaluated from that point) */
+        const TgHipPrimRec *ir = &s->recs[hit->inst];
+        float q[4];
+        instance_quat(ir, q);
+        info->Ng = quat_rotate(q, info->Ng);
+        info->Ns = quat_rotate(q, info->Ns);
+        info->p = vadd(ld3(ir->a), quat_rotate(q, info->p));
+        info->object = (int)TGHIP_REC_OBJECT(ir->meta);
     }
 }
 
@@ -1442,7 +1495,7 @@ static v3 generalizedShadowRay(Ctx *c, Ray *ray, int endCap, int bounce)
     float initialFarT = ray->tmax;
     v3 throughput = vs(1.0f);
     for (;;) {
-        TgHipHit hit;
+        Hit hit;
         Info info;
         c->shadow_rays++;
         int hitAny = scene_intersect(c->s, ray, &hit, c->st);
@@ -1503,7 +1556,7 @@ static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, 
         sphere_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), &lh->n, &lh->u, &lh->v);
         return 1;
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh::intersect + intersectionInfo: the mesh's own BVH */
-        TgHipHit hit;
+        Hit hit;
         if (!scene_intersect_obj(s, ray, &hit, NULL, objIdx)) return 0;
         Info info;
         intersection_info(s, ray, &hit, &info);
@@ -1829,7 +1882,7 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
     ray.tmin = 1e-4f; ray.tmax = INFINITY;            /* Ray ctor defaults, math/Ray.hpp:24 */
 
     v3 throughput = vs(1.0f), emission = vs(0.0f);
-    TgHipHit hit;
+    Hit hit;
     Info info;
     int bounce = 0;
     c->closest_rays++;
@@ -2196,7 +2249,9 @@ int oracle_trace_rays(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *h
     TravStats st = {0, 0, 0};
     for (size_t i = 0; i < n; ++i) {
         Ray r = {ld3(rays[i].o), ld3(rays[i].d), rays[i].tmin, rays[i].tmax};
-        scene_intersect(s, &r, &hits[i], &st);
+        Hit h;
+        scene_intersect(s, &r, &h, &st);
+        hits[i].t = h.t; hits[i].u = h.u; hits[i].v = h.v; hits[i].rec = h.rec;   /* the instance is not reported */
     }
     if (nodes_visited) *nodes_visited = st.nodes;
     if (prims_tested) *prims_tested = st.prims;

@@ -42,6 +42,9 @@
 #include "integrators/path_tracer/SampleRecord.hpp"
 #include "integrators/path_tracer/PathTracer.hpp"
 #include "math/MathUtil.hpp"
+#include "math/Quaternion.hpp"
+#include "bvh/BinaryBvh.hpp"
+#include "primitives/Primitive.hpp"
 #include <sobol/sobol.h>
 // The integrate command inspects the integrator's tiles and SampleRecords, which the reference keeps
 // private: open the two class definitions up (every standard/other header they use is already included).
@@ -50,6 +53,7 @@
 #define class struct
 #include "sampling/SobolPathSampler.hpp"
 #include "integrators/path_tracer/PathTraceIntegrator.hpp"
+#include "primitives/Instance.hpp"
 #undef private
 #undef protected
 #undef class
@@ -175,6 +179,12 @@ static bool loadScene(const char *path, uint32 seed, Loaded &out)
         out.scene.reset(Scene::load(scenePath, nullptr, &out.dir));
         out.scene->loadResources();
         DirectoryChange context(out.dir);
+        // Scene::loadResources only reaches the scene's own primitives and Instance::loadResources (Instance.cpp:265-282)
+        // does not forward to its masters: load the master meshes here, as code that builds Instances in memory would.
+        for (const std::shared_ptr<Primitive> &p : out.scene->primitives())
+            if (Instance *inst = dynamic_cast<Instance *>(p.get()))
+                for (std::shared_ptr<Primitive> &m : inst->_master)
+                    m->loadResources();
         out.ts.reset(out.scene->makeTraceable(seed));
     } catch (const std::exception &e) {
         std::fprintf(stderr, "ref_harness: %s\n", e.what());

@@ -292,6 +292,46 @@ def mesh1m(tmpdir, resolution=(1920, 1080), spp=512, name="mesh1m.json", n_lat=5
 
 GOLDEN_CASES["mesh1m"] = (mesh1m, dict(resolution=(48, 27), spp=4))
 
+def cornell_instances(tmpdir, count=40, smooth=(True, False), **kw):
+    """Cornell box whose two boxes are replaced by `count` rigid instances of two small master meshes (an `instances`
+    primitive, primitives/Instance.cpp): one smooth-shaded rough-conductor blob, one flat-shaded two-material blob; the
+    `instances` primitive itself carries a transform too (Instance::prepareForRender composes it, :400-404)."""
+    import random
+    tmpdir = str(tmpdir)
+    for k, (n_lat, n_lon, seed) in enumerate(((7, 10, 11), (5, 8, 12))):
+        verts, tris = displaced_sphere(n_lat, n_lon, seed=seed)
+        verts = verts.copy()
+        verts[:, 1] -= 0.5                                     # centre the master on its origin
+        tris = tris[:, [0, 2, 1, 3]].copy()
+        if k == 1:
+            tris[::2, 3] = 1                                   # every other triangle uses the second bsdf
+        write_wo3(os.path.join(tmpdir, "inst_master%d.wo3" % k), verts, tris)
+    rnd = random.Random(5)
+    inst = []
+    for i in range(count):
+        inst.append({"id": i % 2, "transform": {"position": [rnd.uniform(-0.8, 0.8), rnd.uniform(0.1, 1.5), rnd.uniform(-0.8, 0.8)],
+                                                "rotation": [rnd.uniform(0, 360), rnd.uniform(0, 360), rnd.uniform(0, 360)]}})
+    user = kw.pop("edit", None)
+
+    def edit(scene):
+        scene["primitives"] = [p for p in scene["primitives"] if p["name"] not in ("shortBox", "tallBox")]
+        scene["bsdfs"].append(dict({"name": "copper", "type": "rough_conductor", "distribution": "ggx", "roughness": 0.25, "albedo": 1}, **_CU))
+        scene["primitives"].append({
+            "name": "swarm", "type": "instances",
+            "transform": {"position": [0.05, 0.1, -0.05], "rotation": [0, 20, 0]},
+            "masters": [
+                {"name": "m0", "type": "mesh", "file": "inst_master0.wo3", "smooth": smooth[0], "bsdf": "copper",
+                 "transform": {"scale": 0.3, "rotation": [15, 0, 30]}},
+                {"name": "m1", "type": "mesh", "file": "inst_master1.wo3", "smooth": smooth[1], "bsdf": ["leftWall", "rightWall"],
+                 "transform": {"scale": [0.22, 0.3, 0.22], "position": [0, 0.02, 0]}}],
+            "instances": inst})
+        if user:
+            user(scene)
+    return variant(CORNELL, tmpdir, kw.pop("name", "instances.json"), edit=edit, **kw)
+
+
+GOLDEN_CASES["cornell_instances"] = (cornell_instances, dict(resolution=(48, 27), spp=8))
+
 # "stratified_sampler": true -- SobolPathSampler dimensions with the tiles' own seeds (SURVEY.md 8 a20)
 _SOBOL = {"stratified_sampler": True}
 GOLDEN_CASES["cornell_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, renderer=_SOBOL))

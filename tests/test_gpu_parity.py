@@ -64,7 +64,7 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
     assert (count == ocount).all() and (count == spp).all()
     assert c.samples == flat.width*flat.height*spp == oc.samples
     omean = osum/np.maximum(ocount, 1)[..., None]
-    loose = "dielectric" in name or "transparency" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m")
+    loose = "dielectric" in name or "transparency" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances")
     compare(mean, omean, max_bad=0.03 if loose else 0.01, mean_rel=2e-2 if loose else 5e-3)
     # ray counts agree up to the divergent paths
     assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 0.01*oc.closest_rays
@@ -73,15 +73,20 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
         # while the oracle only counts the ones whose light.intersect succeeded)
         assert abs(int(c.shadow_rays) - int(oc.shadow_rays)) <= 0.01*oc.shadow_rays + 2
     ref = np.load(os.path.join(scenes.GOLDEN, name + "_samples.npz"))["samples"].mean(axis=2)
-    compare(mean, ref, max_bad=0.04 if loose else 0.012, mean_rel=2e-2 if loose else 5e-3)
+    if name == "cornell_instances":
+        # ~2.5 % of the reference's paths take a farther instance for a nearer one (Instance.cpp:296, see
+        # tests/test_oracle_golden.py); with 8 samples per pixel that touches about every fifth pixel
+        compare(mean, ref, max_bad=0.3, mean_rel=3e-2)
+    else:
+        compare(mean, ref, max_bad=0.04 if loose else 0.012, mean_rel=2e-2 if loose else 5e-3)
 
 
-@pytest.mark.parametrize("scene", ["cornell", "materialtest", "mesh1m"])
+@pytest.mark.parametrize("scene", ["cornell", "materialtest", "mesh1m", "instances"])
 def test_trace_rays_matches_oracle_exactly(scene, tmp_path):
     """TraceableScene::intersect batched: identical record, t/u/v rel 1e-5, and IDENTICAL node/primitive visit
     counts (the counters that feed the roofline's algorithmic bytes)."""
     _skip_mt(scene)
-    mk = {"cornell": scenes.cornell, "materialtest": scenes.materialtest, "mesh1m": scenes.mesh1m}[scene]
+    mk = {"cornell": scenes.cornell, "materialtest": scenes.materialtest, "mesh1m": scenes.mesh1m, "instances": scenes.cornell_instances}[scene]
     path = mk(tmp_path, resolution=(64, 36), spp=1)
     flat = tg.FlattenedScene(path)
     d = flat.desc.contents

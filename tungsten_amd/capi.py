@@ -70,6 +70,7 @@ class TgHipSceneDesc(C.Structure):
                 ("dist", C.POINTER(f32)), ("num_dist_floats", u64),
                 ("light_tris", C.POINTER(f32)), ("num_light_tri_floats", u64),
                 ("sobol_matrices", C.POINTER(u32)), ("num_sobol_words", u64),
+                ("num_instances", u32), ("num_top_recs", u32),
                 ("camera", TgHipCamera), ("settings", TgHipSettings),
                 ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
 

@@ -464,6 +464,144 @@ PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, 
     return false;
 }
 
+// ---- two-level traversal: scenes with TGHIP_REC_INSTANCE records (primitives/Instance.cpp:290-328) -------------------
+// The top-level BVH holds one record per instance (always alone in its leaf).  Reaching one sends the ray into the
+// master's space (rotation + translation: distances along the ray are unchanged) and walks the master's subtree on the
+// same stack; when the stack is back at the level it had on entry the walk is in world space again.  Unlike the
+// reference -- whose Instance::intersect hands the master a ray with farT = infinity (Ray::scatter's default,
+// Instance.cpp:296) and so lets a farther instance visited later override a nearer hit -- this returns the nearest hit.
+struct InstanceWalk {
+    RayD world, ray;
+    f3 invD;
+    int instSp, curInst;
+};
+PT_DEV void instanceEnter(const DeviceScene &s, uint32_t ri, InstanceWalk &w, int sp, int &cur)
+{
+    float4 r0 = at32(s.recs, ri*3u + 0u), r1 = at32(s.recs, ri*3u + 1u), r2 = at32(s.recs, ri*3u + 2u);
+    f3 qc = -xyz(r1);                                   // conjugate(): the inverse rotation
+    w.ray.o = quatRotate(r1.w, qc, w.world.o - xyz(r0));
+    w.ray.d = quatRotate(r1.w, qc, w.world.d);
+    w.invD = mk3(1.0f/w.ray.d.x, 1.0f/w.ray.d.y, 1.0f/w.ray.d.z);
+    w.curInst = (int)ri;
+    w.instSp = sp;
+    cur = (int)__float_as_uint(r2.x);
+}
+PT_DEV void instanceLeave(InstanceWalk &w)
+{
+    w.ray.o = w.world.o; w.ray.d = w.world.d;
+    w.invD = mk3(1.0f/w.ray.d.x, 1.0f/w.ray.d.y, 1.0f/w.ray.d.z);
+    w.instSp = -1; w.curInst = -1;
+}
+
+template<bool COUNT>
+PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &worldRay, int *stack, int stride,
+                                  uint32_t &nodesVisited, uint32_t &primsTested, int &hitInst)
+{
+    InstanceWalk w;
+    w.world = worldRay; w.ray = worldRay;
+    w.invD = mk3(1.0f/worldRay.d.x, 1.0f/worldRay.d.y, 1.0f/worldRay.d.z);
+    w.instSp = -1; w.curInst = -1;
+    float tmax = worldRay.tmax;
+    float4 hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+    hitInst = -1;
+    int sp = 0, cur = 0;
+    for (;;) {
+        bool entered = false;
+        if (cur >= 0) {
+            const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
+            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (COUNT) nodesVisited++;
+            float e0, e1;
+            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w.ray, w.invD, tmax, e0);
+            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w.ray, w.invD, tmax, e1);
+            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (h0 && h1) {
+                if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
+                else { stack[sp*stride] = c1; cur = c0; }
+                sp++;
+                continue;
+            } else if (h0) { cur = c0; continue; }
+            else if (h1) { cur = c1; continue; }
+        } else {
+            uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+            for (uint32_t i = first; i < first + count; ++i) {
+                if (COUNT) primsTested++;
+                if (w.curInst < 0 && TGHIP_REC_KIND(__float_as_uint(at32(s.recs, i*3u).w)) == TGHIP_REC_INSTANCE) {
+                    instanceEnter(s, i, w, sp, cur);
+                    entered = true;
+                    break;
+                }
+                uint32_t meta;
+                if (testRecord<false>(s, i, w.ray, tmax, hit, meta))
+                    hitInst = w.curInst;
+            }
+        }
+        if (entered)
+            continue;
+        if (w.instSp >= 0 && sp == w.instSp)
+            instanceLeave(w);
+        if (sp == 0)
+            break;
+        sp--;
+        cur = stack[sp*stride];
+    }
+    return hit;
+}
+
+template<bool COUNT>
+PT_DEV bool traverseOccludedInst(const DeviceScene &s, const RayD &worldRay, int endCap, int *stack, int stride,
+                                 uint32_t &nodesVisited, uint32_t &primsTested)
+{
+    InstanceWalk w;
+    w.world = worldRay; w.ray = worldRay;
+    w.invD = mk3(1.0f/worldRay.d.x, 1.0f/worldRay.d.y, 1.0f/worldRay.d.z);
+    w.instSp = -1; w.curInst = -1;
+    float4 hit;
+    int sp = 0, cur = 0;
+    for (;;) {
+        bool entered = false;
+        if (cur >= 0) {
+            const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
+            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (COUNT) nodesVisited++;
+            float e0, e1;
+            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w.ray, w.invD, worldRay.tmax, e0);
+            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w.ray, w.invD, worldRay.tmax, e1);
+            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (h0 && h1) {
+                if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
+                else { stack[sp*stride] = c1; cur = c0; }
+                sp++;
+                continue;
+            } else if (h0) { cur = c0; continue; }
+            else if (h1) { cur = c1; continue; }
+        } else {
+            uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+            for (uint32_t i = first; i < first + count; ++i) {
+                if (COUNT) primsTested++;
+                if (w.curInst < 0 && TGHIP_REC_KIND(__float_as_uint(at32(s.recs, i*3u).w)) == TGHIP_REC_INSTANCE) {
+                    instanceEnter(s, i, w, sp, cur);
+                    entered = true;
+                    break;
+                }
+                uint32_t meta;
+                float tmax = worldRay.tmax;
+                if (testRecord<false>(s, i, w.ray, tmax, hit, meta) && (w.curInst >= 0 || (int)TGHIP_REC_OBJECT(meta) != endCap))
+                    return true;
+            }
+        }
+        if (entered)
+            continue;
+        if (w.instSp >= 0 && sp == w.instSp)
+            instanceLeave(w);
+        if (sp == 0)
+            break;
+        sp--;
+        cur = stack[sp*stride];
+    }
+    return false;
+}
+
 // wave-reduced statistics add into a workgroup-local (LDS) counter
 PT_DEV void waveAddStat(uint32_t *dst, uint32_t v)
 {

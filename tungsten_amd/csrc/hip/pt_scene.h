@@ -27,6 +27,7 @@ struct DeviceScene {
     const int32_t * __restrict__ tex_guide;    // per texture: offset of its tables in `guide`, -1 = none
     const uint32_t * __restrict__ sobol;       // Sobol' generator matrices (nullptr unless the scene carries them)
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
+    uint32_t num_instances;                    // instance records (0: single-level scene, A_EMI.w carries nothing)
     const TgHipCamera * __restrict__ camera;   // in device memory (56 dwords: read through the scalar cache where it is used, not held in SGPRs)
     TgHipSettings settings;
 };
@@ -53,6 +54,7 @@ struct DeviceScene {
 #define FEAT_ALL        (FEAT_BITMAP | FEAT_INFINITE | FEAT_MULTILIGHT | FEAT_TRIANGLES | FEAT_SOLIDS)
 #define FEAT_MESHLIGHT  (1u << 29)   /* triangle-mesh emitters as sampled lights: only in the MASK_FULL / BSDF_MASK_ALL variants */
 #define FEAT_QMC        (1u << 30)   /* TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes: every variant has a twin with this bit (launchShade) */
+#define FEAT_INSTANCES  (1u << 31)   /* hits reached through an instance record (primitives/Instance.cpp): only in MASK_FULL / BSDF_MASK_ALL */
 #define MASK_FULL       (BSDF_MASK_ALL & ~FEAT_QMC)
 // next1D of the path's sampler inside code templated on M
 #define RNG1D(r) rngNext1DT<(M & FEAT_QMC) != 0>(r)
@@ -1088,8 +1090,20 @@ struct Info {
     bool backSide;
 };
 
+// Quaternion<float>::operator*(Vec3) (math/Quaternion.hpp:78-88); q = (w, x, y, z)
+PT_DEV f3 quatRotate(float qw, f3 q, f3 o)
+{
+    float tx = 2.0f*(q.y*o.z - q.z*o.y);
+    float ty = 2.0f*(q.z*o.x - q.x*o.z);
+    float tz = 2.0f*(q.x*o.y - q.y*o.x);
+    return mk3(o.x + qw*tx + q.y*tz - q.z*ty,
+               o.y + qw*ty + q.z*tx - q.x*tz,
+               o.z + qw*tz + q.x*ty - q.y*tx);
+}
+
+// hitInst: record index of the instance the hit triangle was reached through, -1 = none (only read under FEAT_INSTANCES)
 template<uint32_t M>
-PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, Info &info)
+PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, Info &info, int hitInst = -1)
 {
     int ri = __float_as_int(hit.w);
     const uint32_t rj = (uint32_t)ri;
@@ -1103,7 +1117,12 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
     if ((M & FEAT_TRIANGLES) && kind == TGHIP_REC_TRIANGLE) {   /* TriangleMesh.cpp:317-355, 80-106 */
         float4 a0 = at32(s.tri_attrs, rj*4u + 0u), a1 = at32(s.tri_attrs, rj*4u + 1u), a2 = at32(s.tri_attrs, rj*4u + 2u), a3 = at32(s.tri_attrs, rj*4u + 3u);
         f3 NgU = cross(xyz(r1), xyz(r2));
-        info.backSide = dot(NgU, ray.d) > 0.0f;
+        f3 dLocal = ray.d;
+        if ((M & FEAT_INSTANCES) && hitInst >= 0) {    /* the master was intersected in its own space (Instance.cpp:295-297) */
+            float4 q = at32(s.recs, (uint32_t)hitInst*3u + 1u);
+            dLocal = quatRotate(q.w, -xyz(q), ray.d);
+        }
+        info.backSide = dot(NgU, dLocal) > 0.0f;
         info.Ng = normalized(NgU);
         float u = hit.y, v = hit.z;
         if (o.flags & TGHIP_OBJF_SMOOTH) {
@@ -1130,6 +1149,15 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         info.Ns = info.Ng;
         info.bsdf = o.bsdf;
         info.backSide = hit.y != 0.0f;
+    }
+    if ((M & FEAT_INSTANCES) && hitInst >= 0) {
+        /* Instance::intersectionInfo (primitives/Instance.cpp:337-346): normals to world space; info.p -- already the
+         * WORLD-space hit point (TraceableScene.hpp:184) -- is transformed once more, as the reference does */
+        float4 i0 = at32(s.recs, (uint32_t)hitInst*3u + 0u), i1 = at32(s.recs, (uint32_t)hitInst*3u + 1u);
+        info.Ng = quatRotate(i1.w, xyz(i1), info.Ng);
+        info.Ns = quatRotate(i1.w, xyz(i1), info.Ns);
+        info.p = xyz(i0) + quatRotate(i1.w, xyz(i1), info.p);
+        info.object = (int)TGHIP_REC_OBJECT(__float_as_uint(i0.w));
     }
 }
 

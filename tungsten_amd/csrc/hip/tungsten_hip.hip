@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, Pass
     }
 }
 
-template<bool COUNT, bool FLAT>
+// INST: the scene has instance records (two-level traversal; the instance of a hit goes to the spare word A_EMI.w)
+template<bool COUNT, bool FLAT, bool INST = false>
 __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsStack[];
@@ -221,7 +222,14 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
             float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
             RayD ray;
             ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-            float4 hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+            float4 hit;
+            if (INST) {
+                int hitInst;
+                hit = traverseClosestInst<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst);
+                slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
+            } else {
+                hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+            }
             slotF4(st, A_HIT, slot) = hit;
             int ri = __float_as_int(hit.w);
             cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
 }
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
-template<bool COUNT, bool FLAT>
+template<bool COUNT, bool FLAT, bool INST = false>
 __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 *rays, float4 *hits, uint32_t n, BlockStats *stats)
 {
     extern __shared__ int ldsStack[];
@@ -372,7 +380,9 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
         float4 ro = rays[i*2 + 0], rd = rays[i*2 + 1];
         RayD ray;
         ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-        hits[i] = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+        int hitInst;      // TgHipHit reports the record that was hit, not the instance it was reached through
+        hits[i] = INST ? traverseClosestInst<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
+                       : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
     }
     if (COUNT) {
         waveAddStat(&ldsNodes, nodes);
@@ -445,7 +455,9 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                 hit = slotF4(st, A_HIT, slot);
             }
           if (!toComplex) {
-            em = xyz(slotF4(st, A_EMI, slot));
+            float4 em4 = slotF4(st, A_EMI, slot);
+            em = xyz(em4);
+            const int hitInst = ((M & FEAT_INSTANCES) && s.num_instances) ? __float_as_int(em4.w) : -1;   // written by k_trace_closest<.., INST>
             uint4 misc = slotU4(st, A_MISC, slot);
             uint2 rs = make_uint2(misc.x, misc.y);
             uint32_t pixel = misc.z;
@@ -481,7 +493,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             } else {
                 PROF(1);
                 Info info;
-                intersectionInfo<M>(s, ray, hit, info);
+                intersectionInfo<M>(s, ray, hit, info, hitInst);
                 const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
                 PROF(2);
 
@@ -737,7 +749,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
 // a closest-hit query up to the light; unoccluded iff nothing is hit or the closest hit is the
 // light itself (endCap); surfaces with a forward lobe attenuate and the ray continues (FORWARD variant only:
 // scenes without a forward-lobe BSDF run the lean variant).
-template<bool COUNT, bool FORWARD, bool FLAT>
+template<bool COUNT, bool FORWARD, bool FLAT, bool INST = false>
 __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsStack[];
@@ -776,7 +788,8 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 if (!FORWARD) {
                     // no surface of this scene lets light through: any occluder ends the query
                     rays++;
-                    if (traverseOccluded<COUNT, FLAT>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims)
+                    if ((INST ? traverseOccludedInst<COUNT>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims)
+                              : traverseOccluded<COUNT, FLAT>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims))
                         || bounce < s.settings.min_bounces)
                         transmittance = splat3(0.0f);
                 } else {
@@ -785,12 +798,14 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 float travelled = 0.0f;
                 if (meshLight) { ray.tmax = PT_INF; remaining = PT_INF; }   // sd.w carries the expected distance / the bsdf pdf
                 for (;;) {
-                    float4 hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+                    int hitInst = -1;
+                    float4 hit = INST ? traverseClosestInst<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
+                                      : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
                     rays++;
                     int ri = __float_as_int(hit.w);
                     int hitObject = -1;
-                    if (ri >= 0)
-                        hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)ri*3u).w));
+                    if (ri >= 0)      // geometry reached through an instance belongs to the `instances` primitive (never a light)
+                        hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)(hitInst >= 0 ? hitInst : ri)*3u).w));
                     if (meshLight && ri < 0) { transmittance = splat3(0.0f); break; }   // the ray never reaches the mesh
                     if (ri < 0 || hitObject == endCap) {
                         if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
@@ -812,7 +827,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                         break;
                     }
                     Info info;
-                    intersectionInfo<BSDF_MASK_ALL>(s, ray, hit, info);
+                    intersectionInfo<BSDF_MASK_ALL>(s, ray, hit, info, hitInst);
                     const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
                     if (!(lobes & TGHIP_LOBE_FORWARD)) { transmittance = splat3(0.0f); break; }
                     Frame frame = frameFromNormal(info.Ns);
@@ -1177,6 +1192,7 @@ struct tghip_ctx {
     uint32_t complexMask = 0;             // union of the BSDF types inside class-1 materials
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
     bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, MASK_FULL shading
+    bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
@@ -1261,19 +1277,24 @@ static uint32_t bsdfTypeMask(const TgHipSceneDesc *s, int bi, int depth)
     return m;
 }
 
-static int bvhDepthOf(const TgHipSceneDesc *s)
+// Depth of the subtree under `root` (also validates child references).  Instance records met on the way are collected in
+// `instanceRecs` when given; without it (a master's subtree) they are an error, as is an instance sharing its leaf.
+static int subtreeDepth(const TgHipSceneDesc *s, int32_t root, size_t &visited, std::vector<uint32_t> *instanceRecs)
 {
-    // iterative depth computation over the flattened tree (also validates child references)
     std::vector<std::pair<int32_t, int>> stack;
-    stack.emplace_back(0, 1);
+    stack.emplace_back(root, 1);
     int depth = 0;
-    size_t visited = 0;
     while (!stack.empty()) {
         auto cur = stack.back();
         stack.pop_back();
         if (cur.first < 0) {
             uint32_t first = TGHIP_LEAF_FIRST(cur.first), count = TGHIP_LEAF_COUNT(cur.first);
             if (first + count > s->num_recs) return -1;
+            for (uint32_t i = first; i < first + count; ++i)
+                if (TGHIP_REC_KIND(s->recs[i].meta) == TGHIP_REC_INSTANCE) {
+                    if (!instanceRecs || count != 1) return -1;
+                    instanceRecs->push_back(i);
+                }
             continue;
         }
         if (uint32_t(cur.first) >= s->num_nodes || ++visited > s->num_nodes) return -1;
@@ -1284,12 +1305,39 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
     return depth;
 }
 
+// Stack depth the traversal needs: the top-level tree, plus -- with instances -- the deepest master subtree above it.
+static int bvhDepthOf(const TgHipSceneDesc *s)
+{
+    size_t visited = 0;
+    std::vector<uint32_t> inst;
+    int depth = subtreeDepth(s, 0, visited, &inst);
+    if (depth < 0 || inst.size() != s->num_instances) return -1;
+    std::vector<uint32_t> roots;
+    for (uint32_t i : inst) {
+        uint32_t root;
+        std::memcpy(&root, &s->recs[i].c[0], 4);
+        if (root == 0 || root >= s->num_nodes) return -1;
+        roots.push_back(root);
+    }
+    std::sort(roots.begin(), roots.end());
+    roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
+    int master = 0;
+    for (uint32_t root : roots) {
+        int d = subtreeDepth(s, int32_t(root), visited, nullptr);
+        if (d < 0) return -1;
+        master = std::max(master, d);
+    }
+    return roots.empty() ? depth : depth + master + 1;
+}
+
+static bool isFlat(const tghip_ctx *ctx) { return ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS && !ctx->haveInstances; }
+
 // Dynamic LDS of the traversal kernels: one node stack of bvhDepth ints per thread (a root-to-leaf walk pushes at
 // most one far child per internal level), aliased with the expanded queue (2 B per slot) that is consumed before
 // traversal starts.  Flat-list scenes need no stack.
 static size_t traceLdsBytes(const tghip_ctx *ctx, int threads)
 {
-    const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
+    const bool flat = isFlat(ctx);
     size_t stack = flat ? 0 : size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
     return std::max<size_t>(stack, size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short));
 }
@@ -1392,7 +1440,7 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
 // Picks the workgroup size of each kernel of the wavefront loop for the uploaded scene (see tghip_ctx::thr*).
 static void chooseThreads(tghip_ctx *ctx)
 {
-    const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
+    const bool flat = isFlat(ctx);
     // Measured (profiles/README.md): BVH scenes are latency-bound and run best with every workgroup of every
     // kernel resident at once (4 per CU, workgroup size per kernel = that kernel's occupancy limit / 4); flat-list
     // scenes are streaming-bound and prefer 8 small workgroups per CU that the dispatcher load-balances.
@@ -1400,18 +1448,24 @@ static void chooseThreads(tghip_ctx *ctx)
     if (flat && ctx->blocksPerCuOpt == 0) {
         ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
     } else {
+    const bool inst = ctx->haveInstances;
+    const bool dyn = ctx->dynamicFetch && !inst;               // the dynamic-fetch kernels are single-level
     ctx->thrClosest = flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
-                    : ctx->dynamicFetch ? pickThreads(ctx, k_trace_closest_dyn<false>, 320, 2)   // 20 waves/CU measured best (profiles/README.md)
+                    : inst ? pickThreads(ctx, k_trace_closest<false, false, true>, 512, 1)
+                    : dyn ? pickThreads(ctx, k_trace_closest_dyn<false>, 320, 2)   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
-    if (!flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->dynamicFetch)
+    if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
         ctx->thrShadow = pickThreads(ctx, k_trace_shadow_dyn<false>, 512, 3);
+    else if (inst)
+        ctx->thrShadow = (ctx->haveForward || ctx->haveMeshLight) ? pickThreads(ctx, k_trace_shadow<false, true, false, true>, 512, 1)
+                                                                   : pickThreads(ctx, k_trace_shadow<false, false, false, true>, 512, 1);
     else if (ctx->haveForward || ctx->haveMeshLight)
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, true, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, true, false>, 512, 1);
     else
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, false, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, false, false>, 512, 1);
-    if (ctx->haveMeshLight) ctx->thrShadeSimple = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
+    if (ctx->haveMeshLight || inst) ctx->thrShadeSimple = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     else ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES, 0>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>, 256, 0);
-    if (ctx->haveMeshLight)                         ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
+    if (ctx->haveMeshLight || inst)                 ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     else if ((ctx->complexMask & ~MASK_COAT) == 0)  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2, 0>, 256, 0);
     else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
     else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
@@ -1571,6 +1625,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->dist, sd->num_dist_floats, &s.dist)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->light_tris, sd->num_light_tri_floats, &s.light_tris)) != TGHIP_OK) return rc;
     ctx->haveMeshLight = false;
+    ctx->haveInstances = sd->num_instances > 0;
     for (uint32_t i = 0; i < sd->num_lights; ++i)
         if (sd->objects[sd->lights[i]].type == TGHIP_OBJ_MESH) ctx->haveMeshLight = true;
     // CDF guide tables for the samplable bitmaps (pt_scene.h: upperBoundGuided)
@@ -1615,6 +1670,9 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         }
         for (uint32_t i = 0; i < sd->num_recs; ++i) {
             uint32_t meta = sd->recs[i].meta;
+            if (TGHIP_REC_KIND(meta) == TGHIP_REC_INSTANCE)
+                continue;                    // never a hit record itself: hits are the master's triangles
+            if (TGHIP_REC_KIND(meta) > TGHIP_REC_INSTANCE) { ctx->error = "unknown primitive record kind"; return TGHIP_E_INVALID; }
             int bi = TGHIP_REC_KIND(meta) == TGHIP_REC_TRIANGLE ? sd->tri_attrs[i].bsdf : sd->objects[TGHIP_REC_OBJECT(meta)].bsdf;
             if (bi < 0 || uint32_t(bi) >= sd->num_bsdfs) { ctx->error = "primitive record without a valid bsdf"; return TGHIP_E_INVALID; }
             bool simple = (typeMask[size_t(bi)] & ~MASK_SIMPLE) == 0 && !(sd->bsdfs[bi].lobes & TGHIP_LOBE_FORWARD);
@@ -1633,6 +1691,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     s.num_nodes = sd->num_nodes; s.num_recs = sd->num_recs; s.num_objects = sd->num_objects;
     s.num_lights = sd->num_lights; s.num_infinite_lights = sd->num_infinite_lights;
     s.num_bsdfs = sd->num_bsdfs; s.num_textures = sd->num_textures;
+    s.num_instances = sd->num_instances;
     if ((rc = uploadArray(ctx, ctx->sceneMem, &sd->camera, 1, &s.camera)) != TGHIP_OK) return rc;
     s.sobol = nullptr;
     if (sd->sobol_matrices) {
@@ -1711,8 +1770,13 @@ template<bool COUNT>
 static void launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, uint32_t iterTag)
 {
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrShadow);
-    const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
+    const bool flat = isFlat(ctx);
     const bool closestWalk = ctx->haveForward || ctx->haveMeshLight;   // shadow rays are closest-hit walks, not any-hit queries
+    if (ctx->haveInstances) {
+        if (closestWalk) hipLaunchKernelGGL((k_trace_shadow<COUNT, true, false, true>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
+        else             hipLaunchKernelGGL((k_trace_shadow<COUNT, false, false, true>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
+        return;
+    }
     if (!flat && !closestWalk && ctx->dynamicFetch) {
         hipLaunchKernelGGL(k_trace_shadow_dyn<COUNT>, dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow, true), ctx->stream,
                            ctx->scene, st, pp, iterTag);
@@ -1735,7 +1799,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const DeviceScene &s = ctx->scene;
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
-    const bool flat = s.num_recs <= TGHIP_FLAT_MAX_RECS;
+    const bool flat = isFlat(ctx);
     const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt;
     const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
@@ -1808,6 +1872,9 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             if (flat) {
                 if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
                 else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
+            } else if (ctx->haveInstances) {
+                if (count) hipLaunchKernelGGL((k_trace_closest<true, false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
+                else       hipLaunchKernelGGL((k_trace_closest<false, false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
             } else {
                 if (ctx->dynamicFetch) {
                     const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
@@ -1819,11 +1886,11 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            if (ctx->haveMeshLight)  launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling
+            if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling / instance transforms
             else if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
             else                     launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
             if (ctx->haveComplex) {
-                if (ctx->haveMeshLight)                         launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
+                if (ctx->haveMeshLight || ctx->haveInstances)   launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
                 else                                            launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
@@ -2062,10 +2129,14 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
     (void)hipEventRecord(ctx->evA, ctx->stream);
     for (int r = 0; r < repeats; ++r) {
         const bool cnt = ctx->countTraversal && r == 0;
-        const bool flat = ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS;
+        const bool flat = isFlat(ctx);
 #define RAYS_LAUNCH(C, F) hipLaunchKernelGGL((k_trace_rays<C, F>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats)
-        if (cnt) { if (flat) RAYS_LAUNCH(true, true); else RAYS_LAUNCH(true, false); }
-        else     { if (flat) RAYS_LAUNCH(false, true); else RAYS_LAUNCH(false, false); }
+        if (ctx->haveInstances) {
+            if (cnt) hipLaunchKernelGGL((k_trace_rays<true, false, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
+            else     hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
+        }
+        else if (cnt) { if (flat) RAYS_LAUNCH(true, true); else RAYS_LAUNCH(true, false); }
+        else          { if (flat) RAYS_LAUNCH(false, true); else RAYS_LAUNCH(false, false); }
 #undef RAYS_LAUNCH
     }
     (void)hipEventRecord(ctx->evB, ctx->stream);

@@ -130,6 +130,57 @@ struct Mat4f
     }
 };
 
+// math/Quaternion.hpp:13-170 (w, x, y, z), the operations Instance uses
+struct QuaternionF
+{
+    float v[4];
+    QuaternionF() { v[0] = 1.0f; v[1] = v[2] = v[3] = 0.0f; }
+    QuaternionF(float w, float x, float y, float z) { v[0] = w; v[1] = x; v[2] = y; v[3] = z; }
+    QuaternionF(float theta, const Vec3f &u)                       // :32-40
+    {
+        float cosTheta = std::cos(theta/2.0f), sinTheta = std::sin(theta/2.0f);
+        v[0] = cosTheta; v[1] = u[0]*sinTheta; v[2] = u[1]*sinTheta; v[3] = u[2]*sinTheta;
+    }
+    float operator[](int i) const { return v[i]; }
+    QuaternionF conjugate() const { return QuaternionF(v[0], -v[1], -v[2], -v[3]); }
+    QuaternionF operator*(const QuaternionF &o) const              // :68-76
+    {
+        return QuaternionF(
+            v[0]*o[0] - v[1]*o[1] - v[2]*o[2] - v[3]*o[3],
+            v[0]*o[1] + v[1]*o[0] + v[2]*o[3] - v[3]*o[2],
+            v[0]*o[2] - v[1]*o[3] + v[2]*o[0] + v[3]*o[1],
+            v[0]*o[3] + v[1]*o[2] - v[2]*o[1] + v[3]*o[0]);
+    }
+    Vec3f operator*(const Vec3f &o) const                          // :78-88
+    {
+        float tx = 2.0f*(v[2]*o[2] - v[3]*o[1]);
+        float ty = 2.0f*(v[3]*o[0] - v[1]*o[2]);
+        float tz = 2.0f*(v[1]*o[1] - v[2]*o[0]);
+        return Vec3f(
+            o[0] + v[0]*tx + v[2]*tz - v[3]*ty,
+            o[1] + v[0]*ty + v[3]*tx - v[1]*tz,
+            o[2] + v[0]*tz + v[1]*ty - v[2]*tx);
+    }
+    static QuaternionF fromMatrix(const Mat4f &m)                  // :112-150; a(i, j) = row i, column j
+    {
+        auto a = [&m](int i, int j) { return m[i*4 + j]; };
+        float trace = a(0, 0) + a(1, 1) + a(2, 2);
+        if (trace > 0.0f) {
+            float s = 0.5f/std::sqrt(trace + 1.0f);
+            return QuaternionF(0.25f/s, (a(2, 1) - a(1, 2))*s, (a(0, 2) - a(2, 0))*s, (a(1, 0) - a(0, 1))*s);
+        } else if (a(0, 0) > a(1, 1) && a(0, 0) > a(2, 2)) {
+            float s = 2.0f*std::sqrt(1.0f + a(0, 0) - a(1, 1) - a(2, 2));
+            return QuaternionF((a(2, 1) - a(1, 2))/s, 0.25f*s, (a(0, 1) + a(1, 0))/s, (a(0, 2) + a(2, 0))/s);
+        } else if (a(1, 1) > a(2, 2)) {
+            float s = 2.0f*std::sqrt(1.0f + a(1, 1) - a(0, 0) - a(2, 2));
+            return QuaternionF((a(0, 2) - a(2, 0))/s, (a(0, 1) + a(1, 0))/s, 0.25f*s, (a(1, 2) + a(2, 1))/s);
+        } else {
+            float s = 2.0f*std::sqrt(1.0f + a(2, 2) - a(0, 0) - a(1, 1));
+            return QuaternionF((a(1, 0) - a(0, 1))/s, (a(0, 2) + a(2, 0))/s, (a(1, 2) + a(2, 1))/s, 0.25f*s);
+        }
+    }
+};
+
 // math/MathUtil.hpp:120-128
 static inline uint32_t hash32(uint32_t x)
 {

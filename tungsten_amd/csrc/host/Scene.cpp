@@ -541,6 +541,18 @@ std::shared_ptr<Bsdf> Scene::fetchBsdf(const JsonValue &v) const
     throw JsonLoadException("Type mismatch: Expecting either an object or an object reference here");
 }
 
+std::shared_ptr<Primitive> Scene::fetchPrimitive(const JsonValue &v) const
+{
+    if (v.isString()) {
+        for (const auto &p : primitives)
+            if (p->name == v.asString()) return p;
+        throw JsonLoadException("Unable to find an object with name '" + v.asString() + "'");
+    } else if (v.isObject()) {
+        return instantiatePrimitive(v);
+    }
+    throw JsonLoadException("Type mismatch: Expecting either an object or an object reference here");
+}
+
 // ------------------------------------------------------------------------------------------
 // Primitives
 // ------------------------------------------------------------------------------------------
@@ -595,14 +607,95 @@ std::shared_ptr<Primitive> Scene::instantiatePrimitive(const JsonValue &v) const
     } else if (type == "infinite_sphere") {
         p->type = Primitive::InfiniteSphere;
         v.getField("sample", p->doSample);
+    } else if (type == "instances") {
+        // Instance::fromJson (Instance.cpp:60-93)
+        p->type = Primitive::Instances;
+        if (p->emission || p->power)
+            throw JsonLoadException("emissive 'instances' primitives are outside the path_tracer_hip hot-path scope");
+        if (const JsonValue &m = v["masters"])
+            for (size_t i = 0; i < m.size(); ++i)
+                p->masters.push_back(fetchPrimitive(m[i]));
+        for (const auto &m : p->masters)
+            if (m->type != Primitive::Mesh)
+                throw JsonLoadException("'instances' masters other than triangle meshes are outside the path_tracer_hip hot-path scope");
+        if (v["instancesA"] || v["instancesB"])
+            throw JsonLoadException("interpolated instance files (instancesA/instancesB) are outside the path_tracer_hip hot-path scope");
+        if (const JsonValue &inst = v["instances"]) {
+            if (inst.isString()) {
+                p->instanceFile = inst.asString();
+            } else {
+                for (size_t i = 0; i < inst.size(); ++i) {
+                    unsigned id = 0;
+                    inst[i].getField("id", id);
+                    Mat4f transform;
+                    getTransform(inst[i], "transform", transform);
+                    p->instanceId.push_back(uint8_t(id));
+                    p->instancePos.push_back(transform.translation());                                  // extractTranslationVec
+                    p->instanceRot.push_back(QuaternionF::fromMatrix(transform.extractRotation()));
+                }
+            }
+        }
     } else {
         throw JsonLoadException("Primitive type '" + type + "' is outside the path_tracer_hip hot-path scope");
     }
     return p;
 }
 
+// Instance.cpp:205-232 (loadInstances) with loadLossyInstance / loadLosslessInstance (:133-171)
+static void loadInstanceFile(const std::string &path, std::vector<Vec3f> &pos, std::vector<QuaternionF> &rot, std::vector<uint8_t> &ids)
+{
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f)
+        throw std::runtime_error("Unable to load instances at '" + path + "'");
+    auto rd = [&](void *dst, size_t n) { if (std::fread(dst, 1, n, f) != n) { std::fclose(f); throw std::runtime_error("Truncated instance file '" + path + "'"); } };
+    uint32_t count = 0, compressed = 0;
+    float b[6];
+    rd(&count, 4); rd(&compressed, 4); rd(b, 24);     // Box3f = min, max
+    Vec3f lo(b[0], b[1], b[2]), hi(b[3], b[4], b[5]);
+    pos.resize(count); rot.resize(count); ids.resize(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        if (compressed & 1u) {
+            uint32_t a, bb, c;
+            rd(&a, 4); rd(&bb, 4); rd(&c, 4);
+            const uint32_t mask = (1u << 21) - 1;
+            uint32_t x = a >> 11, y = ((a << 10) | (bb >> 22)) & mask, z = (bb >> 1) & mask;
+            uint32_t r = c & 255u, axisX = (c >> 8) & 4095u, axisY = (c >> 20) & 4095u;
+            float axisXf = (axisX/float(1 << 12))*2.0f - 1.0f, axisYf = (axisY/float(1 << 12))*2.0f - 1.0f;
+            float rotW = TWO_PI*r/(1 << 8);
+            Vec3f w(axisXf, axisYf, std::sqrt(std::max(1 - axisXf*axisXf - axisYf*axisYf, 0.0f)));
+            Vec3f t = Vec3f(float(x), float(y), float(z))/float(1 << 21);
+            pos[i] = lo*(Vec3f(1.0f) - t) + hi*t;                                                   // lerp (MathUtil.hpp:60-64)
+            rot[i] = QuaternionF(rotW, w);
+        } else {
+            float pw[6];
+            rd(pw, 24);
+            pos[i] = Vec3f(pw[0], pw[1], pw[2]);
+            Vec3f w(pw[3], pw[4], pw[5]);
+            float angle = w.length();
+            w = angle > 0 ? w/angle : Vec3f(0.0f, 1.0f, 0.0f);
+            rot[i] = QuaternionF(angle, w);
+        }
+    }
+    rd(ids.data(), count);
+    std::fclose(f);
+}
+
 void Primitive::loadResources(const std::string &sceneDir)
 {
+    if (type == Instances) {
+        // Instance::loadResources (Instance.cpp:265-282) reads the instance file only -- it does NOT forward to its masters,
+        // and Scene::loadResources (io/Scene.cpp:281-293) only walks the scene's own primitives, so a master mesh named in
+        // JSON never gets its triangles in an unmodified reference (Instance works there for masters built in memory).  Here
+        // the masters are loaded; oracle/ref_harness.cpp does the same on the reference's objects before rendering goldens.
+        for (auto &m : masters)
+            m->loadResources(sceneDir);
+        if (!instanceFile.empty())
+            loadInstanceFile(sceneDir.empty() ? instanceFile : sceneDir + "/" + instanceFile, instancePos, instanceRot, instanceId);
+        for (uint8_t id : instanceId)
+            if (id >= masters.size())
+                throw std::runtime_error("instance refers to master " + std::to_string(int(id)) + " of " + std::to_string(masters.size()));
+        return;
+    }
     if (type != Mesh || file.empty())
         return;
     std::string full = sceneDir.empty() ? file : sceneDir + "/" + file;
@@ -660,6 +753,32 @@ void Primitive::prepareForRender()
     } case InfiniteSphere: { // InfiniteSphere.cpp:280-286
         rot = transform.extractRotation();
         invRot = rot.transpose();
+        break;
+    } case Instances: { // Instance.cpp:392-428
+        for (auto &m : masters) {
+            m->prepareForRender();
+            for (auto &b : m->bsdfs)
+                b->prepareForRender();
+        }
+        QuaternionF tRot = QuaternionF::fromMatrix(transform.extractRotation());
+        bounds = Box3f();
+        instanceBounds.assign(instancePos.size(), Box3f());
+        for (size_t i = 0; i < instancePos.size(); ++i) {
+            instancePos[i] = transform*instancePos[i];
+            instanceRot[i] = tRot*instanceRot[i];
+            const Box3f &bLocal = masters[instanceId[i]]->bounds;
+            if (masters[instanceId[i]]->tris.empty() || masters[instanceId[i]]->verts.empty())
+                continue;
+            Box3f bGlobal;
+            for (int x = 0; x < 2; ++x)
+                for (int y = 0; y < 2; ++y)
+                    for (int z = 0; z < 2; ++z) {
+                        Vec3f t = Vec3f(float(x), float(y), float(z));
+                        bGlobal.grow(instancePos[i] + instanceRot[i]*(bLocal.lo*(Vec3f(1.0f) - t) + bLocal.hi*t));   // lerp(min, max, t)
+                    }
+            bounds.grow(bGlobal);
+            instanceBounds[i] = bGlobal;
+        }
         break;
     } case Mesh: { // TriangleMesh.cpp:524-572
         bounds = Box3f();

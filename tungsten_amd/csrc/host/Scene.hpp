@@ -75,7 +75,7 @@ struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp
 
 struct Primitive
 {
-    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4 };
+    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5 };
     std::string name;
     Type type = Quad;
     Mat4f transform;
@@ -88,6 +88,13 @@ struct Primitive
     std::vector<MeshTriangle> tris;
     // infinite sphere
     bool doSample = true;
+    // instances (primitives/Instance.hpp:13-31): rigid placements (position + rotation) of master primitives
+    std::vector<std::shared_ptr<Primitive>> masters;
+    std::string instanceFile;
+    std::vector<Vec3f> instancePos;
+    std::vector<QuaternionF> instanceRot;
+    std::vector<uint8_t> instanceId;
+    std::vector<Box3f> instanceBounds;      // prepareForRender: world-space box of every instance (Instance.cpp:411-423)
 
     // prepared (prepareForRender of the respective reference class)
     Vec3f base, edge0, edge1, normal; float invUvSq[2] = {0, 0};  // Quad.cpp:298-316
@@ -98,7 +105,7 @@ struct Primitive
     bool isInfinite() const { return type == InfiniteSphere; }
     bool isDirac() const { return type == Mesh && (verts.empty() || tris.empty()); }
     bool isEmissive() const;       // Primitive.hpp:111-115
-    bool isSamplable() const { return type == InfiniteSphere ? doSample : true; }
+    bool isSamplable() const { return type == InfiniteSphere ? doSample : type != Instances; }   // Instance.cpp:357-360
     float powerToRadianceFactor() const;
     void loadResources(const std::string &sceneDir);
     void prepareForRender();
@@ -150,6 +157,7 @@ class Scene
     std::shared_ptr<Bsdf> fetchBsdf(const JsonValue &v) const;                  // Scene.cpp:82-93
     std::shared_ptr<Bsdf> instantiateBsdf(const JsonValue &v) const;
     std::shared_ptr<Primitive> instantiatePrimitive(const JsonValue &v) const;
+    std::shared_ptr<Primitive> fetchPrimitive(const JsonValue &v) const;          // Scene.cpp:82-93
 
 public:
     std::vector<std::shared_ptr<Bsdf>> bsdfs;

@@ -136,6 +136,8 @@ void TraceableScene::flatten()
 
     // ---- objects, light lists, records -------------------------------------------------------
     std::vector<Box3f> recBounds;
+    std::vector<std::shared_ptr<Primitive>> masterPrims;   // distinct master meshes of all `instances` primitives
+    uint32_t numInstances = 0;
     _sceneBounds = Box3f();
     for (size_t pi = 0; pi < _allPrims.size(); ++pi) {
         Primitive &p = *_allPrims[pi];
@@ -246,6 +248,34 @@ void TraceableScene::flatten()
                 recBounds.push_back(bb);
             }
             break;
+        } case Primitive::Instances: {
+            // one top-level record per instance (Instance.cpp:392-428 builds a BVH over exactly these boxes); the master's
+            // index among `masterPrims` sits in c[1]'s slot until the sub-BVH roots are known (patched below)
+            for (size_t i = 0; i < p.instancePos.size(); ++i) {
+                const std::shared_ptr<Primitive> &m = p.masters[p.instanceId[i]];
+                if (m->tris.empty() || m->verts.empty())
+                    continue;                       // an empty master (e.g. an inline mesh, see Primitive::loadResources) is never hit
+                size_t mi = 0;
+                while (mi < masterPrims.size() && masterPrims[mi] != m) ++mi;
+                if (mi == masterPrims.size())
+                    masterPrims.push_back(m);
+                TgHipPrimRec r;
+                std::memset(&r, 0, sizeof(r));
+                copy3(r.a, p.instancePos[i]);
+                r.p0 = p.instanceRot[i][0];
+                r.b[0] = p.instanceRot[i][1]; r.b[1] = p.instanceRot[i][2]; r.b[2] = p.instanceRot[i][3];
+                uint32_t masterSlot = uint32_t(mi), number = uint32_t(i);
+                std::memcpy(&r.c[0], &masterSlot, 4);
+                std::memcpy(&r.c[1], &number, 4);
+                r.meta = (uint32_t(TGHIP_REC_INSTANCE) << 29) | objMeta;
+                _recs.push_back(r);
+                _triAttrs.emplace_back();
+                std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
+                _triAttrs.back().bsdf = -1;
+                recBounds.push_back(p.instanceBounds[i]);
+                numInstances++;
+            }
+            break;
         } default:
             break;
         }
@@ -262,7 +292,8 @@ void TraceableScene::flatten()
     // ---- BVH ---------------------------------------------------------------------------------
     // Leaf size, measured on MI355X (profiles/README.md): single-record leaves are 5 % faster while the tree fits the
     // 4 MiB-per-XCD L2 (materialtest: 80 K records), leaves of <= 4 are 3 % faster once it does not (1 M records).
-    BvhBuildResult bvh = buildBvh(recBounds, recBounds.size() < (1u << 18) ? 1 : 4);
+    // (instance records always sit alone in their leaf: the traversal enters a master from a leaf and returns to its parent)
+    BvhBuildResult bvh = buildBvh(recBounds, (numInstances || recBounds.size() < (1u << 18)) ? 1 : 4);
     if (bvh.maxDepth > TGHIP_MAX_BVH_DEPTH - 1)
         throw std::runtime_error("BVH deeper than the device traversal stack");
     std::vector<TgHipPrimRec> recs(_recs.size());
@@ -276,6 +307,84 @@ void TraceableScene::flatten()
     _nodes.swap(bvh.nodes);
     _bvhDepth = bvh.maxDepth;
     _bvhSah = bvh.sahCost;
+    const uint32_t numTopRecs = uint32_t(_recs.size());
+
+    // ---- masters of instanced geometry: records in master space + one BVH2 subtree each, behind the top level ----
+    // (the reference keeps an Embree scene per master mesh and transforms the ray into it, Instance.cpp:290-311)
+    std::vector<uint32_t> masterRoot(masterPrims.size(), 0);
+    int masterDepth = 0;
+    for (size_t mi = 0; mi < masterPrims.size(); ++mi) {
+        Primitive &m = *masterPrims[mi];
+        // the master's object record (smooth flag, first bsdf); it is not a scene object of its own unless the scene also lists it
+        size_t objIndex = 0;
+        while (objIndex < _allPrims.size() && _allPrims[objIndex] != masterPrims[mi]) ++objIndex;
+        if (objIndex == _allPrims.size()) {
+            TgHipObject o;
+            std::memset(&o, 0, sizeof(o));
+            o.type = TGHIP_OBJ_MESH;
+            o.bsdf = m.bsdfs.empty() ? -1 : addBsdf(m.bsdfs[0]);
+            o.emission = -1; o.light = -1; o.first_light_tri = -1;
+            o.flags = m.smooth ? TGHIP_OBJF_SMOOTH : 0;
+            o.area = m.area; o.inv_area = m.invArea;
+            objIndex = _objects.size();
+            _objects.push_back(o);
+        }
+        std::vector<int32_t> meshBsdfs;
+        for (auto &b : m.bsdfs) meshBsdfs.push_back(addBsdf(b));
+        std::vector<TgHipPrimRec> mrecs;
+        std::vector<TgHipTriAttr> mattrs;
+        std::vector<Box3f> mbounds;
+        for (const MeshTriangle &t : m.tris) {
+            const MeshVertex &a = m.tfVerts[t.v0], &b = m.tfVerts[t.v1], &c = m.tfVerts[t.v2];
+            Vec3f p0(a.pos[0], a.pos[1], a.pos[2]), p1(b.pos[0], b.pos[1], b.pos[2]), p2(c.pos[0], c.pos[1], c.pos[2]);
+            TgHipPrimRec r;
+            std::memset(&r, 0, sizeof(r));
+            copy3(r.a, p0); copy3(r.b, p1 - p0); copy3(r.c, p2 - p0);
+            r.meta = (uint32_t(TGHIP_REC_TRIANGLE) << 29) | uint32_t(objIndex);
+            mrecs.push_back(r);
+            TgHipTriAttr at;
+            std::memcpy(at.n0, a.normal, 12); std::memcpy(at.n1, b.normal, 12); std::memcpy(at.n2, c.normal, 12);
+            std::memcpy(at.uv0, a.uv, 8); std::memcpy(at.uv1, b.uv, 8); std::memcpy(at.uv2, c.uv, 8);
+            at.bsdf = meshBsdfs[size_t(t.material)];
+            mattrs.push_back(at);
+            Box3f bb;
+            bb.grow(p0); bb.grow(p1); bb.grow(p2);
+            mbounds.push_back(bb);
+        }
+        BvhBuildResult sub = buildBvh(mbounds, mbounds.size() < (1u << 18) ? 1 : 4);
+        const uint32_t recBase = uint32_t(_recs.size()), nodeBase = uint32_t(_nodes.size());
+        if (uint64_t(recBase) + mrecs.size() >= (1u << 27))
+            throw std::runtime_error("too many primitive records for the 27-bit leaf encoding");
+        for (size_t i = 0; i < sub.order.size(); ++i) {
+            _recs.push_back(mrecs[sub.order[i]]);
+            _triAttrs.push_back(mattrs[sub.order[i]]);
+        }
+        auto relocate = [&](int32_t ref) -> int32_t {
+            if (ref >= 0) return ref + int32_t(nodeBase);
+            return TGHIP_MAKE_LEAF(TGHIP_LEAF_FIRST(ref) + recBase, TGHIP_LEAF_COUNT(ref));
+        };
+        for (TgHipBvhNode n : sub.nodes) {
+            n.child0 = relocate(n.child0);
+            n.child1 = relocate(n.child1);
+            _nodes.push_back(n);
+        }
+        masterRoot[mi] = nodeBase;
+        masterDepth = std::max(masterDepth, sub.maxDepth);
+    }
+    if (numInstances) {
+        for (uint32_t i = 0; i < numTopRecs; ++i) {
+            if (TGHIP_REC_KIND(_recs[i].meta) != TGHIP_REC_INSTANCE) continue;
+            uint32_t slot;
+            std::memcpy(&slot, &_recs[i].c[0], 4);
+            std::memcpy(&_recs[i].c[0], &masterRoot[slot], 4);
+        }
+        // one device stack holds the top-level walk and, above it, the walk of the master being visited
+        _bvhDepth += masterDepth + 1;
+        if (_bvhDepth > TGHIP_MAX_BVH_DEPTH - 1)
+            throw std::runtime_error("instanced BVH deeper than the device traversal stack");
+    }
+    _desc.num_instances = numInstances;
+    _desc.num_top_recs = numTopRecs;
 
     // ---- camera / settings -------------------------------------------------------------------
     const Camera &cam = _scene.camera;

@@ -29,3 +29,8 @@ def reduce_framebuffer(fb_sum, fb_count, dst=0, group=None):
         return
     dist.reduce(fb_sum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     dist.reduce(fb_count, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    if fb_sum.is_cuda:
+        # The collectives run on RCCL's own stream and the shim renders on its own HIP stream: the next
+        # tghip_clear_framebuffer / pass must not start before the reduce has consumed (root: produced) the buffers.
+        import torch
+        torch.cuda.current_stream(fb_sum.device).synchronize()
