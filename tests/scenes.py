@@ -330,6 +330,60 @@ def cornell_instances(tmpdir, count=40, smooth=(True, False), **kw):
     return variant(CORNELL, tmpdir, kw.pop("name", "instances.json"), edit=edit, **kw)
 
 
+def instances10k(tmpdir, resolution=(1920, 1080), spp=64, name="instances10k.json", count=10000, n_lat=100, n_lon=100, **kw):
+    """BASELINE configs[4] in spirit: `count` rigid instances of a ~20 000-triangle master mesh on a jittered grid (seed 1),
+    bsdfs cycling lambert / rough_conductor / dielectric / plastic (one master per bsdf: an instance inherits its master's),
+    lit by the materialtest HDRI with MIS when available (else a constant environment)."""
+    import json
+    import random
+    tmpdir = str(tmpdir)
+    wo3 = os.path.join(tmpdir, "blob_%d_%d.wo3" % (n_lat, n_lon))
+    if not os.path.exists(wo3):
+        verts, tris = displaced_sphere(n_lat, n_lon)
+        verts = verts.copy()
+        verts[:, 1] -= 0.5
+        write_wo3(wo3, verts, tris)
+    env = {"name": "Env", "type": "infinite_sphere", "sample": True, "bsdf": {"albedo": 1, "type": "null"}, "emission": 1.0}
+    if have_materialtest():
+        link = os.path.join(tmpdir, "envmap.hdr")
+        if not os.path.exists(link):
+            os.symlink(os.path.join(MATERIALTEST_DIR, "envmap.hdr"), link)
+        env["emission"] = "envmap.hdr"
+    rnd = random.Random(1)
+    side = int(round(count**0.5))
+    inst = []
+    for i in range(count):
+        gx, gz = i % side, i//side
+        inst.append({"id": i % 4, "transform": {"position": [(gx - side/2 + rnd.uniform(-0.3, 0.3))*1.1, 0.5 + rnd.uniform(0, 0.4), (gz - side/2 + rnd.uniform(-0.3, 0.3))*1.1],
+                                                "rotation": [rnd.uniform(0, 360), rnd.uniform(0, 360), rnd.uniform(0, 360)]}})
+    mats = ["diffuse", "metal", "glass", "plastic"]
+    scene = {
+        "media": [],
+        "bsdfs": [{"name": "diffuse", "type": "lambert", "albedo": [0.7, 0.4, 0.3]},
+                  dict({"name": "metal", "albedo": 1, "type": "rough_conductor", "distribution": "ggx", "roughness": 0.2}, **_CU),
+                  {"name": "glass", "type": "dielectric", "ior": 1.5, "albedo": 1},
+                  {"name": "plastic", "type": "plastic", "ior": 1.5, "thickness": 1.0, "sigma_a": [0.2, 0.4, 0.1], "albedo": [0.3, 0.5, 0.7]},
+                  {"name": "floor", "type": "lambert", "albedo": dict(_CHECKER, res_u=200, res_v=200)}],
+        "primitives": [
+            {"name": "Floor", "type": "quad", "bsdf": "floor", "transform": {"position": [0, 0, 0], "scale": [1.2*side, 1, 1.2*side]}},
+            env,
+            {"name": "Swarm", "type": "instances",
+             "masters": [{"name": "m%d" % k, "type": "mesh", "file": os.path.basename(wo3), "smooth": True, "bsdf": mats[k], "transform": {}} for k in range(4)],
+             "instances": inst},
+        ],
+        "camera": {"tonemap": "filmic", "resolution": list(resolution), "reconstruction_filter": "tent", "type": "pinhole", "fov": 40,
+                   "transform": {"position": [0.35*side, 0.25*side, 0.55*side], "look_at": [0, 0.5, 0], "up": [0, 1, 0]}},
+        "integrator": {"type": "path_tracer", "min_bounces": 0, "max_bounces": 64, "enable_consistency_checks": False,
+                       "enable_two_sided_shading": True, "enable_light_sampling": True},
+        "renderer": {"output_file": "", "hdr_output_file": "", "overwrite_output_files": True, "adaptive_sampling": False,
+                     "stratified_sampler": False, "scene_bvh": True, "spp": spp, "spp_step": kw.pop("spp_step", spp)},
+    }
+    path = os.path.join(tmpdir, name)
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
+
+
 GOLDEN_CASES["cornell_instances"] = (cornell_instances, dict(resolution=(48, 27), spp=8))
 
 # "stratified_sampler": true -- SobolPathSampler dimensions with the tiles' own seeds (SURVEY.md 8 a20)
