@@ -1,7 +1,10 @@
 #!/bin/bash
-out=gpurun_out/inst2; mkdir -p $out
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout 600 -k "many_instances or instances" > $out/pytest.log 2>&1; echo "pytest rc=$?"
-tail -15 $out/pytest.log
-timeout 600 python bench.py --scene instances10k --spp 32 --no-extra --cpu-seconds 10 > $out/bench_instances10k.json 2> $out/bench.err; echo "bench rc=$?"; tail -3 $out/bench.err
-python -c "
-import json;d=json.loads(open('$out/bench_instances10k.json').read());print(d['value'],d['ms_per_step'],d['kernels'],d['cpu_baseline'],d['bvh'],d['rays_per_sample'],d['nodes_per_ray'],d['prims_per_ray'])"
+out=gpurun_out/direct1; mkdir -p $out
+timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $out/pytest.log 2>&1; echo "pytest rc=$?"
+tail -5 $out/pytest.log
+for i in 1 2; do
+timeout 300 python bench.py --scene cornell --spp 256 --no-extra --no-cpu-baseline | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print('cornell',d['value'],d['ms_per_step'],d['result_ok'],{k:v['avg_us'] for k,v in d['kernels'].items()})"
+done
+timeout 300 python bench.py --scene cornell --spp 256 --no-extra --no-cpu-baseline --emulate-shards 8 | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print('cornell shard 1/8',d['value'],d['ms_per_step'])"

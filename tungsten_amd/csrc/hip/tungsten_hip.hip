@@ -427,18 +427,36 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     uint32_t finishedCount = 0, fusedClosest = 0, fusedShadow = 0, fusedPrims = 0, fusedNodes = 0;
     PROF_DECL;
 
+    // FUSE_LOOP runs without queues: a finished path is regenerated in place, so a slot stays busy until the workgroup's
+    // work items run out.  Thread t owns slots t, t + blockDim, ... for the whole launch (consecutive lanes = consecutive
+    // slots: every state access is a full cache line), `idle` has one bit per owned slot that has nothing left to do,
+    // and every wave leaves the loop on its own -- no barrier, no bitmap traffic between the wavefront iterations.
+    constexpr bool DIRECT = (FUSE & FUSE_LOOP) != 0;
+    uint32_t idle = 0;
+    if (DIRECT) {
+        // queuesBegin expanded (and thereby cleared) the extension queues into order[0, L.n): turn that list back into
+        // a bitmap of busy slots (in the unused Q_SHADE0 words) each thread can look its own slots up in
+        for (uint32_t i = threadIdx.x; i < L.n; i += blockDim.x)
+            queuePush(true, order[i], L, Q_SHADE0);
+        __syncthreads();
+        for (uint32_t k = 0, local = threadIdx.x; k < 32u; ++k, local += blockDim.x) {
+            bool queued = local < st.slots_per_block && ((L.bm[Q_SHADE0][local >> 5] >> (local & 31u)) & 1u);
+            idle |= queued ? 0u : (1u << k);
+        }
+    }
+
   for (;;) {                                     // one wavefront iteration per turn (a single turn unless FUSE_LOOP)
-    const uint32_t n = L.n;
+    const uint32_t n = DIRECT ? st.slots_per_block : L.n;
     const bool aborted = __hip_atomic_load(&st.live[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    for (uint32_t base = 0; base < n; base += blockDim.x) {
+    for (uint32_t base = 0, turn = 0; base < n; base += blockDim.x, ++turn) {
         uint32_t i = base + threadIdx.x;
         PROF(0);
         bool hasShadow = false, finished = false, survives = false, black = false, toComplex = false;
         uint32_t slot = 0, local = 0;
         f3 em = splat3(0.0f);
-        if (i < n) {
+        if (DIRECT ? !((idle >> turn) & 1u) : i < n) {
             f3 pendingOut = splat3(0.0f);
-            local = order[i];
+            local = DIRECT ? i : order[i];
             slot = first + local;
             float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot), hit, thr4 = slotF4(st, A_THR, slot);
             if (FUSE & FUSE_TRACE) {
@@ -709,22 +727,32 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
           }
         }
         PROF(5);
-        if (FUSE & FUSE_TRACE) queuePush(toComplex, local, L, Q_SHADE1);
-        queuePush(hasShadow, local, L, Q_SHADOW);
+        if (!DIRECT) {
+            if (FUSE & FUSE_TRACE) queuePush(toComplex, local, L, Q_SHADE1);
+            queuePush(hasShadow, local, L, Q_SHADOW);
+        }
         PROF(6);
         bool regenerated = nextPath<true, (M & FEAT_QMC) != 0>(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
         PROF(7);
-        queuePush(survives, local, L, Q_EXT);
-        queuePush(regenerated, local, L, Q_EXTP);
+        if (DIRECT) {
+            if (finished && !regenerated) idle |= 1u << turn;   // the work items ran out: nothing left for this slot
+        } else {
+            queuePush(survives, local, L, Q_EXT);
+            queuePush(regenerated, local, L, Q_EXTP);
+        }
         PROF(8);
     }
-    if (!(FUSE & FUSE_LOOP))
+    if (!DIRECT)
         break;
-    __syncthreads();                             // every push of this iteration is in the LDS bitmaps
-    queuesExpand(L, st, qIn, qIn2, order);
-    if (L.n == 0)
-        break;
+    if (__ballot(idle != 0xFFFFFFFFu) == 0ull)
+        break;                                   // every slot of this wave has drained
   }
+    if (DIRECT) {
+        // nothing is queued any more: the bitmaps go back empty
+        __syncthreads();
+        for (uint32_t w = threadIdx.x; w < (uint32_t)Q_COUNT*(st.slots_per_block >> 5); w += blockDim.x)
+            L.bm[w/(st.slots_per_block >> 5)][w % (st.slots_per_block >> 5)] = 0u;
+    }
     PROF_FLUSH(st.stats[blockIdx.x]);
     waveAddStat(&L.samples, finishedCount);
     if (FUSE) {
