@@ -1210,6 +1210,7 @@ struct tghip_ctx {
 
     // options
     long long maxSlots = 1ll << 21;       // path pool size
+    bool maxSlotsSet = false;             // "max_slots" was given explicitly
     long long maxItems = 1ll << 26;       // work items per batch (partial-sum buffer = 16 B each)
     int chunkSamples = 4;                 // samples per work item
     size_t partialCap = 0;
@@ -1580,7 +1581,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     if (!ctx || !key) return TGHIP_E_INVALID;
     std::string k(key);
     if (k == "count_traversal") ctx->countTraversal = value != 0;
-    else if (k == "max_slots") ctx->maxSlots = std::max<long long>(value, 256);
+    else if (k == "max_slots") { ctx->maxSlots = std::max<long long>(value, 256); ctx->maxSlotsSet = true; }
     else if (k == "max_items") ctx->maxItems = std::max<long long>(value, 256);
     else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
@@ -2037,7 +2038,16 @@ int tghip_wait(tghip_ctx *ctx)
             tilesPerBatch = uint32_t(std::max<uint64_t>(1, maxItems/(256ull*chunksPerBatch)));
     }
     const uint64_t batchItems = uint64_t(tilesPerBatch)*256*chunksPerBatch;
-    const uint32_t slots = uint32_t(std::min<uint64_t>(uint64_t(ctx->maxSlots), batchItems));
+    uint64_t wantSlots = std::min<uint64_t>(uint64_t(ctx->maxSlots), batchItems);
+    {
+        // the run-to-completion kernel (runBatch) gives every thread its own slots for the whole launch: one slot per
+        // thread keeps the whole path state (112 B x 0.5 M slots) inside the Infinity Cache -- measured +5 % over four
+        const bool flat = isFlat(ctx);
+        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->haveComplex && ctx->loopOpt;
+        if (loop && !ctx->maxSlotsSet)
+            wantSlots = std::min<uint64_t>(wantSlots, uint64_t(launchGrid(ctx))*uint64_t(ctx->thrShadeSimple));
+    }
+    const uint32_t slots = uint32_t(wantSlots);
     int rc = ensurePool(ctx, slots);
     if (rc != TGHIP_OK) return ctx->passResult = rc;
     if (ctx->partialCap < batchItems) {
