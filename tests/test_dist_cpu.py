@@ -41,6 +41,64 @@ dist.destroy_process_group()
 '''
 
 
+ADAPTIVE_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import tungsten_amd as tg
+from tungsten_amd import dist as tgdist
+import oracle_lib, scenes
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+W, H, SPP, STEP, SEED = 70, 42, 48, 16, 1234
+path = scenes.cornell(sys.argv[2], name="a%d.json" % rank, resolution=(W, H), spp=SPP, spp_step=STEP,
+                      renderer={"adaptive_sampling": True, "stratified_sampler": True})
+flat = tg.FlattenedScene(path)
+ssum = np.zeros((H, W, 3), np.float32); count = np.zeros((H, W), np.uint32)
+records = np.zeros(((W + 3)//4)*((H + 3)//4), oracle_lib.DEVICE_RECORD_DTYPE)
+def render_pass(p):      # the oracle stands in for tghip_render_pass + tghip_wait on this rank's device
+    rc = oracle_lib._lib.oracle_render_records(flat.desc, p, ssum.ctypes.data, count.ctypes.data, records.ctypes.data, None, 2)
+    assert rc == 0
+sch = tgdist.render_loop(render_pass, lambda: records, W, H, SPP, STEP, SEED, rank=rank, world=world, adaptive=True, sobol=True)
+fs, fc = torch.from_numpy(ssum), torch.from_numpy(count.astype(np.int32))
+tgdist.reduce_framebuffer(fs, fc, dst=0)
+if rank == 0:
+    ws, wc, wrec, _ = oracle_lib.integrate(flat.desc, W, H, SEED, SPP, STEP, True, True)
+    final = sch.records.reshape(wrec[-1].shape)
+    for f in ("sample_count", "next_sample_count", "sample_index", "mean", "running_variance"):
+        assert (final[f] == wrec[-1][f]).all(), f
+    assert (fc.numpy() == wc.astype(np.int32)).all() and (fs.numpy() == ws).all()
+    assert int(wc.max()) > int(wc.min())        # the schedule really was adaptive
+    print("ADAPTIVE_DIST_OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _run_two_ranks(tmp_path, source, token):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path/"worker.py"
+    script.write_text(source)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert token in outs[0]
+
+
+def test_two_rank_adaptive_pass_loop(tmp_path):
+    """Adaptive sampling + Sobol' across 2 ranks: each rank renders its tiles of every pass, the ranks exchange the
+    SampleRecords (tungsten_amd/dist.py: merge_records) and run the same scheduler; records, sample counts and framebuffer
+    must equal the single-process loop's bit for bit."""
+    _run_two_ranks(tmp_path, ADAPTIVE_WORKER, "ADAPTIVE_DIST_OK")
+
+
 def test_two_rank_tile_shard_and_reduce(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -186,3 +186,28 @@ def test_sobol_pass_is_deterministic_and_differs_from_uniform(tmp_path):
     p.tile_seeds = seeds.ctypes.data_as(C.POINTER(C.c_uint32))
     assert tg.lib.tghip_render_pass(r.context(), C.byref(p)) != 0
     r.close()
+
+
+def test_adaptive_full_size_properties(tmp_path):
+    """BASELINE resolution (1280x720), Sobol' + adaptive as materialtest ships them, through size-independent properties:
+    every pixel got exactly the samples its record scheduled, the records counted all of them, the sample budget of every
+    adaptive pass is the reference's (PathTraceIntegrator.cpp:93-95), the records' Welford mean equals the mean luminance
+    of the framebuffer, and a second render reproduces the first bit for bit."""
+    w, h, spp, step = 1280, 720, 48, 16
+    path = scenes.cornell(tmp_path, resolution=(w, h), spp=spp, spp_step=step, renderer={"adaptive_sampling": True, "stratified_sampler": True})
+    per_pass, mean, ssum, count, c = _render_passes(path)
+    assert len(per_pass) == spp//step
+    prec = _pixel_record(w, h)
+    scheduled = sum(p["next_sample_count"].astype(np.int64) for p in per_pass)
+    assert (count.astype(np.int64) == scheduled.ravel()[prec]).all()
+    assert (per_pass[-1]["sample_count"].astype(np.int64) == scheduled*16).all()           # 1280x720: every record is a full 4x4
+    assert c.samples == int(scheduled.sum())*16
+    assert (per_pass[0]["next_sample_count"] == step).all()
+    for p in per_pass[1:]:
+        n = p["next_sample_count"].astype(np.int64)
+        assert n.min() >= 1 and n.max() > step                                            # adaptive: at least one, some many more
+        assert abs(int(n.sum()) - ((step - 1)*w*h//16 + n.size)) <= n.size                 # budget + one guaranteed sample per pixel
+    lum_sum = np.bincount(prec.ravel(), weights=(ssum.astype(np.float64) @ LUM).ravel(), minlength=scheduled.size).reshape(scheduled.shape)
+    assert np.allclose(per_pass[-1]["mean"], lum_sum/per_pass[-1]["sample_count"], rtol=3e-4, atol=1e-6)
+    again = _render_passes(path)
+    assert again[0][-1].tobytes() == per_pass[-1].tobytes() and again[2].tobytes() == ssum.tobytes()

@@ -22,6 +22,10 @@ for scene in cornell materialtest mesh1m; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 900 rocprofv3 --pmc $c --output-format csv -d $out/pmc_${scene}_$c -o pmc -- python bench.py --scene $scene --spp $pmcspp --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-kernel-timing > $out/pmc_${scene}_$c.log 2>&1; echo "$c rc=$?"
   done
+  # where the waves spend their cycles (SQ block, its own pass)
+  timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $out/pmc_${scene}_SQ -o pmc -- python bench.py --scene $scene --spp $pmcspp --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-kernel-timing > $out/pmc_${scene}_SQ.log 2>&1; echo "SQ rc=$?"
+  fs=$(find $out/pmc_${scene}_SQ -name '*counter_collection.csv' | head -1)
+  [ -n "$fs" ] && python tools/pmc_sq.py $scene $fs $out/sq_counters.json
   ff=$(find $out/pmc_${scene}_FETCH_SIZE -name '*counter_collection.csv' | head -1)
   fw=$(find $out/pmc_${scene}_WRITE_SIZE -name '*counter_collection.csv' | head -1)
   [ -n "$ff" ] && [ -n "$fw" ] && python tools/pmc_traffic.py $scene $ff $fw $out/traffic.json

@@ -34,3 +34,60 @@ def reduce_framebuffer(fb_sum, fb_count, dst=0, group=None):
         # tghip_clear_framebuffer / pass must not start before the reduce has consumed (root: produced) the buffers.
         import torch
         torch.cuda.current_stream(fb_sum.device).synchronize()
+
+
+def merge_records(records, group=None):
+    """SampleRecords (TGHIP_PASS_RECORDS) of a tile-sharded pass: every record is non-zero on exactly the rank that owns
+    its tile, so an all-reduce(SUM) of the three fields hands every rank the complete, bit-exact set (x + 0).
+    `records`: structured numpy array with sample_count (u32), mean, running_variance (f32); returned merged."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return records
+    counts = torch.from_numpy(np.ascontiguousarray(records["sample_count"]).astype(np.int64))
+    stats = torch.from_numpy(np.stack([records["mean"], records["running_variance"]]).astype(np.float32))
+    if dist.get_backend(group) == "nccl":
+        counts, stats = counts.cuda(), stats.cuda()
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    out = records.copy()
+    out["sample_count"] = counts.cpu().numpy().astype(np.uint32)
+    out["mean"], out["running_variance"] = stats.cpu().numpy()
+    return out
+
+
+def render_loop(render_pass, download_records, width, height, spp, spp_step, seed, rank=0, world=1, adaptive=True, sobol=False,
+                group=None):
+    """The integrator's pass loop (PathTraceIntegrator::startRender / generateWork, PathTraceIntegrator.cpp:108-134,220-239)
+    for one-process-per-GPU renders: every rank runs the same deterministic PassScheduler, renders its own tiles of each
+    pass and the ranks exchange the SampleRecords of the pass (merge_records) before the next generateWork.
+
+    render_pass(TgHipPassDesc) renders one pass on this rank (tghip_render_pass + tghip_wait, or a stand-in);
+    download_records() returns this rank's device records (tghip_download_records layout).  Returns the scheduler."""
+    import ctypes as C
+    import numpy as np
+    from . import PassScheduler
+    sch = PassScheduler(width, height, seed)
+    tile_seeds = np.ascontiguousarray(sch.tile_seeds)
+    cur = 0
+    while cur < spp:
+        nxt = min(cur + spp_step, spp)
+        if sch.generate_work(cur, nxt, adaptive):
+            rec = sch.records
+            p = shard_pass(rank, world, cur, nxt, seed)
+            p.flags = (capi.TGHIP_PASS_SOBOL if sobol else 0) | (capi.TGHIP_PASS_RECORDS if adaptive else 0)
+            index = np.ascontiguousarray(rec["sample_index"])
+            count = np.ascontiguousarray(rec["next_sample_count"])
+            if sobol:
+                p.tile_seeds = tile_seeds.ctypes.data_as(C.POINTER(C.c_uint32))
+            if adaptive:
+                p.record_index = index.ctypes.data_as(C.POINTER(C.c_uint32))
+                p.record_count = count.ctypes.data_as(C.POINTER(C.c_uint32))
+            render_pass(p)
+            if adaptive:
+                merged = merge_records(download_records(), group=group)
+                for f in ("sample_count", "mean", "running_variance"):
+                    rec[f] = merged[f]
+        cur = nxt
+    return sch
