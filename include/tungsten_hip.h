@@ -177,6 +177,7 @@ typedef struct TgHipTexture {
 
 /* ---- camera (cameras/PinholeCamera.cpp:28-86, Camera.cpp:44-68, ReconstructionFilter) ---- */
 enum { TGHIP_FILTER_DIRAC = 0, TGHIP_FILTER_BOX = 1, TGHIP_FILTER_TABULATED = 2 };
+enum { TGHIP_CAMERA_PINHOLE = 0, TGHIP_CAMERA_THINLENS = 1 };   /* cameras/PinholeCamera.cpp, cameras/ThinlensCamera.cpp */
 typedef struct TgHipCamera {
     float   pos[3];
     float   plane_dist;
@@ -186,6 +187,10 @@ typedef struct TgHipCamera {
     int32_t filter_type;
     float   filter_width, filter_bin_size;
     float   filter_cdf[32];   /* ReconstructionFilter::_cdf (RFILTER_RESOLUTION = 31) */
+    /* thin lens (cameras/ThinlensCamera.cpp:85-126) with the default disk aperture (textures/DiskTexture.cpp:78-86) */
+    int32_t type;             /* TGHIP_CAMERA_*                                   */
+    float   focus_dist, aperture_size, cat_eye;
+    float   inv_xf[12];       /* rows 0..2 of Camera::_invTransform (3x4, row-major, translation in column 3) */
 } TgHipCamera;
 
 /* ---- integrator settings (TraceSettings.hpp:23-39, PathTracerSettings.hpp:25-43) -------- */

@@ -1851,6 +1851,20 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
     const int maxBounces = s->settings.max_bounces, minBounces = s->settings.min_bounces;
     const int nee = s->settings.enable_light_sampling;
 
+    /* ThinlensCamera::samplePosition (ThinlensCamera.cpp:85-97) draws the lens point first; the aperture is the default
+     * DiskTexture: sample = uniformDisk(xi).xy*0.5 + 0.5 (DiskTexture.cpp:78-81, SampleWarp.hpp:64-69) */
+    const int thinlens = cam->type == TGHIP_CAMERA_THINLENS;
+    v3 lensP = ld3(cam->pos);
+    if (thinlens) {
+        float l0 = next1D(c->sampler), l1 = next1D(c->sampler);
+        float phi = l0*O_TWO_PI, r = sqrtf(l1);
+        float ax = (cosf(phi)*r*0.5f + 0.5f)*2.0f - 1.0f, ay = (sinf(phi)*r*0.5f + 0.5f)*2.0f - 1.0f;
+        ax *= cam->aperture_size; ay *= cam->aperture_size;
+        /* _transform*Vec3f(ax, ay, 0) (Mat4f::operator*(Vec3f)) */
+        lensP = V(cam->xf[0]*ax + cam->xf[1]*ay + cam->xf[2]*0.0f + cam->pos[0],
+                  cam->xf[3]*ax + cam->xf[4]*ay + cam->xf[5]*0.0f + cam->pos[1],
+                  cam->xf[6]*ax + cam->xf[7]*ay + cam->xf[8]*0.0f + cam->pos[2]);
+    }
     /* PinholeCamera::samplePosition/sampleDirection (PinholeCamera.cpp:53-86) */
     float xi0 = next1D(c->sampler), xi1 = next1D(c->sampler);
     float fu, fv;
@@ -1873,11 +1887,31 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
         }
         fu = out[0]; fv = out[1];
     }
-    v3 localD = vnorm(V(-1.0f + ((float)px + 0.5f + fu)*2.0f*cam->pixel_size_x,
-                        cam->ratio - ((float)py + 0.5f + fv)*2.0f*cam->pixel_size_x,
-                        cam->plane_dist));
+    v3 localD;
+    if (thinlens) {
+        /* ThinlensCamera::sampleDirection (ThinlensCamera.cpp:106-133); note: no + 0.5 on the pixel here */
+        v3 planePos = V(-1.0f + ((float)px + fu)*2.0f*cam->pixel_size_x,
+                        cam->ratio - ((float)py + fv)*2.0f*cam->pixel_size_x,
+                        cam->plane_dist);
+        planePos = vscale(planePos, cam->focus_dist/planePos.z);
+        const float *m = cam->inv_xf;
+        v3 lensPos = V(m[0]*lensP.x + m[1]*lensP.y + m[2]*lensP.z + m[3],
+                       m[4]*lensP.x + m[5]*lensP.y + m[6]*lensP.z + m[7],
+                       m[8]*lensP.x + m[9]*lensP.y + m[10]*lensP.z + m[11]);
+        localD = vnorm(vsub(planePos, lensPos));
+        if (cam->cat_eye > 0.0f) {
+            float k = cam->cat_eye*cam->plane_dist;
+            float dx = lensPos.x - k*localD.x/localD.z, dy = lensPos.y - k*localD.y/localD.z;
+            if (dx*dx + dy*dy > sqr(cam->aperture_size))
+                return vs(0.0f);                          /* sampleDirection fails: PathTracer.cpp:27-28 */
+        }
+    } else {
+        localD = vnorm(V(-1.0f + ((float)px + 0.5f + fu)*2.0f*cam->pixel_size_x,
+                         cam->ratio - ((float)py + 0.5f + fv)*2.0f*cam->pixel_size_x,
+                         cam->plane_dist));
+    }
     Ray ray;
-    ray.o = ld3(cam->pos);
+    ray.o = lensP;
     ray.d = mat3_mul(cam->xf, localD);
     ray.tmin = 1e-4f; ray.tmax = INFINITY;            /* Ray ctor defaults, math/Ray.hpp:24 */
 

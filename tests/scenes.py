@@ -386,6 +386,18 @@ def instances10k(tmpdir, resolution=(1920, 1080), spp=64, name="instances10k.jso
 
 GOLDEN_CASES["cornell_instances"] = (cornell_instances, dict(resolution=(48, 27), spp=8))
 
+def _thinlens(cateye):
+    def edit(scene):
+        scene["camera"].update(type="thinlens", focus_distance=6.0, aperture_size=0.12, cateye=cateye)
+    return edit
+
+
+# thin-lens camera with the default disk aperture (cameras/ThinlensCamera.cpp), without and with cat-eye vignetting (which makes
+# some direction samples fail -> black samples, PathTracer.cpp:27-28)
+GOLDEN_CASES["cornell_thinlens"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.0)))
+GOLDEN_CASES["cornell_thinlens_cateye"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.35)))
+GOLDEN_CASES["cornell_thinlens_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.0), renderer={"stratified_sampler": True}))
+
 # "stratified_sampler": true -- SobolPathSampler dimensions with the tiles' own seeds
 _SOBOL = {"stratified_sampler": True}
 GOLDEN_CASES["cornell_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, renderer=_SOBOL))

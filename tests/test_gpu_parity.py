@@ -67,7 +67,12 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
     loose = "dielectric" in name or "transparency" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances")
     compare(mean, omean, max_bad=0.03 if loose else 0.01, mean_rel=2e-2 if loose else 5e-3)
     # ray counts agree up to the divergent paths
-    assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 0.01*oc.closest_rays
+    if "cateye" in name:
+        # a vignetted camera sample (ThinlensCamera.cpp:119-124) is a black sample without a ray in the reference; the device
+        # gives it zero throughput and lets its primary ray find that out, i.e. traces one ray more per such sample
+        assert 0 <= int(c.closest_rays) - int(oc.closest_rays) <= oc.samples
+    else:
+        assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 0.01*oc.closest_rays
     if "mesh" not in name or name == "mesh1m":
         # (a sampled mesh emitter's visibility query doubles as its light.intersect, so the device traces every such ray,
         # while the oracle only counts the ones whose light.intersect succeeded)

@@ -1,12 +1,8 @@
 #!/bin/bash
-out=gpurun_out/direct2; mkdir -p $out
+out=gpurun_out/lens2; mkdir -p $out
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $out/pytest.log 2>&1; echo "pytest rc=$?"
-tail -3 $out/pytest.log
-for i in 1 2; do
+tail -4 $out/pytest.log
+for i in 1 2 3; do
 timeout 300 python bench.py --scene cornell --spp 256 --no-extra --no-cpu-baseline | python -c "
 import json,sys;d=json.loads(sys.stdin.read());print('cornell',d['value'],d['ms_per_step'],d['result_ok'])"
-done
-for n in 2 4 8; do
-timeout 300 python bench.py --scene cornell --spp 256 --no-extra --no-cpu-baseline --emulate-shards $n | python -c "
-import json,sys;d=json.loads(sys.stdin.read());print('cornell shard 1/$n',d['ms_per_step'])"
 done

@@ -109,6 +109,7 @@ PT_DEV uint4 &slotU4(const PathState &st, uint32_t a, uint32_t slot)
 }
 
 
+#define PT_PASS_THINLENS 0x100u   /* internal pass flag: the scene's camera is a thin lens (nextPath's EXT variants sample the lens) */
 struct PassParams {
     uint32_t spp_begin, spp_end, seed;
     uint32_t chunk;            // samples per work item
@@ -121,7 +122,7 @@ struct PassParams {
     uint32_t width, height;
     uint32_t iter_tag;         // wavefront iteration number (liveness reporting of the fused flat-scene kernels)
     // ---- TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes (read only by the kernels' `EXT` code paths) ----
-    uint32_t flags;            // TGHIP_PASS_*
+    uint32_t flags;            // TGHIP_PASS_* | PT_PASS_*
     uint32_t variance_w;       // SampleRecords per image row = ceil(width/4)
     const uint32_t *tile_seeds;   // SobolPathSampler seed per 16x16 tile (device copy of TgHipPassDesc::tile_seeds)
     // per SampleRecord (nullptr unless TGHIP_PASS_RECORDS): first sample index, samples per pixel this pass, and the
@@ -328,16 +329,45 @@ PT_DEV float filterSample1D(CameraRef cam, float xi)
     float u = cam.filter_bin_size*(idx + (xi - lo)/pdf);
     return negative ? -u : u;
 }
-PT_DEV void cameraRay(CameraRef cam, uint32_t px, uint32_t py, float xi0, float xi1, f3 &o, f3 &d)
+// l0, l1: the lens sample a thin-lens camera draws first (ThinlensCamera::samplePosition, cameras/ThinlensCamera.cpp:85-97,
+// default DiskTexture aperture); xi0, xi1: the pixel-filter sample.  False when the direction sample fails (cat-eye
+// vignetting, :119-124): PathTracer::traceSample then returns black for the sample (PathTracer.cpp:27-28).
+template<bool LENS>
+PT_DEV bool cameraRay(CameraRef cam, bool lens, uint32_t px, uint32_t py, float l0, float l1, float xi0, float xi1, f3 &o, f3 &d)
 {
     float fu = 0.0f, fv = 0.0f;
     if (cam.filter_type == TGHIP_FILTER_BOX) { fu = xi0 - 0.5f; fv = xi1 - 0.5f; }
     else if (cam.filter_type == TGHIP_FILTER_TABULATED) { fu = filterSample1D(cam, xi0); fv = filterSample1D(cam, xi1); }
+    if (LENS && lens) {
+        float phi = l0*PT_TWO_PI, r = sqrtf(l1);                       // SampleWarp::uniformDisk (SampleWarp.hpp:64-69)
+        float ax = ((cosf(phi)*r*0.5f + 0.5f)*2.0f - 1.0f)*cam.aperture_size;
+        float ay = ((sinf(phi)*r*0.5f + 0.5f)*2.0f - 1.0f)*cam.aperture_size;
+        o = mk3(cam.xf[0]*ax + cam.xf[1]*ay + cam.xf[2]*0.0f + cam.pos[0],
+                cam.xf[3]*ax + cam.xf[4]*ay + cam.xf[5]*0.0f + cam.pos[1],
+                cam.xf[6]*ax + cam.xf[7]*ay + cam.xf[8]*0.0f + cam.pos[2]);
+        f3 planePos = mk3(-1.0f + ((float)px + fu)*2.0f*cam.pixel_size_x,       // no + 0.5 here (ThinlensCamera.cpp:110-114)
+                          cam.ratio - ((float)py + fv)*2.0f*cam.pixel_size_x,
+                          cam.plane_dist);
+        planePos = planePos*(cam.focus_dist/planePos.z);
+        f3 lensPos = mk3(cam.inv_xf[0]*o.x + cam.inv_xf[1]*o.y + cam.inv_xf[2]*o.z + cam.inv_xf[3],
+                         cam.inv_xf[4]*o.x + cam.inv_xf[5]*o.y + cam.inv_xf[6]*o.z + cam.inv_xf[7],
+                         cam.inv_xf[8]*o.x + cam.inv_xf[9]*o.y + cam.inv_xf[10]*o.z + cam.inv_xf[11]);
+        f3 localD = normalized(planePos - lensPos);
+        d = mat3Mul(cam.xf, localD);
+        if (cam.cat_eye > 0.0f) {
+            float k = cam.cat_eye*cam.plane_dist;
+            float dx = lensPos.x - k*localD.x/localD.z, dy = lensPos.y - k*localD.y/localD.z;
+            if (dx*dx + dy*dy > cam.aperture_size*cam.aperture_size)
+                return false;
+        }
+        return true;
+    }
     f3 localD = normalized(mk3(-1.0f + ((float)px + 0.5f + fu)*2.0f*cam.pixel_size_x,
                                cam.ratio - ((float)py + 0.5f + fv)*2.0f*cam.pixel_size_x,
                                cam.plane_dist));
     o = ld3(cam.pos);
     d = mat3Mul(cam.xf, localD);
+    return true;
 }
 
 // ---- BVH2 traversal (closest hit) ----------------------------------------------------------

@@ -159,14 +159,21 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             const uint32_t px = pixel % pp.width, py = pixel/pp.width;
             if (EXT && (pp.flags & TGHIP_PASS_SOBOL))
                 rngStartSobol(rng, s, pp, px, py, pixel, samp.x, 0u);
+            CameraRef cam = *asConst(s.camera);
+            // thin-lens scenes run the EXT variants (the shim sets PT_PASS_THINLENS): the pinhole-only variants stay as lean as they were
+            const bool lens = EXT && (pp.flags & PT_PASS_THINLENS) != 0u;
+            float l0 = 0.0f, l1 = 0.0f;
+            if (lens) { l0 = rngNext1DT<EXT>(rng); l1 = rngNext1DT<EXT>(rng); }   // the lens point is sampled first
             float xi0 = rngNext1DT<EXT>(rng), xi1 = rngNext1DT<EXT>(rng);
             f3 o, d;
-            cameraRay(*asConst(s.camera), px, py, xi0, xi1, o, d);
+            const bool cameraOk = cameraRay<EXT>(cam, lens, px, py, l0, l1, xi0, xi1, o, d);
             slotF4(st, A_RAY_O, slot) = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
-            slotF4(st, A_RAY_D, slot) = mk4(d, PT_INF);
+            slotF4(st, A_RAY_D, slot) = mk4(d, cameraOk ? PT_INF : -1.0f);   // a failed camera sample: the ray can hit nothing ...
             slotU4(st, A_MISC, slot) = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, item);
             slotF4(st, A_EMI, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            slotF4(st, A_THR, slot) = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
+            // ... and carries no throughput, so the escaped path adds nothing: a black sample (PathTracer.cpp:27-28)
+            const float t0 = cameraOk ? 1.0f : 0.0f;
+            slotF4(st, A_THR, slot) = make_float4(t0, t0, t0, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
             slotU4(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, EXT ? rng.dim : 0u, lumBase);   // .z: next Sobol' dimension
             slotF4(st, A_ACC, slot) = acc;
             push = true;
@@ -1221,6 +1228,7 @@ struct tghip_ctx {
     uint32_t complexMask = 0;             // union of the BSDF types inside class-1 materials
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
     bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, MASK_FULL shading
+    bool thinlens = false;                // thin-lens camera: passes run the EXT kernel variants (PT_PASS_THINLENS)
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
@@ -1655,6 +1663,8 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->light_tris, sd->num_light_tri_floats, &s.light_tris)) != TGHIP_OK) return rc;
     ctx->haveMeshLight = false;
     ctx->haveInstances = sd->num_instances > 0;
+    ctx->thinlens = sd->camera.type == TGHIP_CAMERA_THINLENS;
+    if (sd->camera.type != TGHIP_CAMERA_PINHOLE && sd->camera.type != TGHIP_CAMERA_THINLENS) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
     for (uint32_t i = 0; i < sd->num_lights; ++i)
         if (sd->objects[sd->lights[i]].type == TGHIP_OBJ_MESH) ctx->haveMeshLight = true;
     // CDF guide tables for the samplable bitmaps (pt_scene.h: upperBoundGuided)
@@ -1978,7 +1988,7 @@ int tghip_wait(tghip_ctx *ctx)
     const uint32_t ownedTiles = numTiles > pass.shard_index ? (numTiles - pass.shard_index + shardCount - 1)/shardCount : 0;
     uint32_t spp = pass.spp_end - pass.spp_begin, sppBegin = pass.spp_begin;
     PassParams base{};
-    base.flags = pass.flags;
+    base.flags = pass.flags | (ctx->thinlens ? PT_PASS_THINLENS : 0u);
     base.variance_w = (w + 3)/4;
     if (pass.flags & TGHIP_PASS_SOBOL) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->dTileSeeds, pass.tile_seeds, size_t(numTiles)*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));

@@ -75,6 +75,33 @@ struct Mat4f
     }
     float operator[](int i) const { return a[i]; }
     float &operator[](int i) { return a[i]; }
+    // math/Mat4f.hpp:75-107: cofactor expansion, then one multiplication by 1/det
+    Mat4f invert() const
+    {
+        Mat4f inv;
+        inv[ 0] =  a[5]*a[10]*a[15] - a[5]*a[11]*a[14] - a[9]*a[6]*a[15] + a[9]*a[7]*a[14] + a[13]*a[6]*a[11] - a[13]*a[7]*a[10];
+        inv[ 1] = -a[1]*a[10]*a[15] + a[1]*a[11]*a[14] + a[9]*a[2]*a[15] - a[9]*a[3]*a[14] - a[13]*a[2]*a[11] + a[13]*a[3]*a[10];
+        inv[ 2] =  a[1]*a[ 6]*a[15] - a[1]*a[ 7]*a[14] - a[5]*a[2]*a[15] + a[5]*a[3]*a[14] + a[13]*a[2]*a[ 7] - a[13]*a[3]*a[ 6];
+        inv[ 3] = -a[1]*a[ 6]*a[11] + a[1]*a[ 7]*a[10] + a[5]*a[2]*a[11] - a[5]*a[3]*a[10] - a[ 9]*a[2]*a[ 7] + a[ 9]*a[3]*a[ 6];
+        inv[ 4] = -a[4]*a[10]*a[15] + a[4]*a[11]*a[14] + a[8]*a[6]*a[15] - a[8]*a[7]*a[14] - a[12]*a[6]*a[11] + a[12]*a[7]*a[10];
+        inv[ 5] =  a[0]*a[10]*a[15] - a[0]*a[11]*a[14] - a[8]*a[2]*a[15] + a[8]*a[3]*a[14] + a[12]*a[2]*a[11] - a[12]*a[3]*a[10];
+        inv[ 6] = -a[0]*a[ 6]*a[15] + a[0]*a[ 7]*a[14] + a[4]*a[2]*a[15] - a[4]*a[3]*a[14] - a[12]*a[2]*a[ 7] + a[12]*a[3]*a[ 6];
+        inv[ 8] =  a[4]*a[ 9]*a[15] - a[4]*a[11]*a[13] - a[8]*a[5]*a[15] + a[8]*a[7]*a[13] + a[12]*a[5]*a[11] - a[12]*a[7]*a[ 9];
+        inv[ 7] =  a[0]*a[ 6]*a[11] - a[0]*a[ 7]*a[10] - a[4]*a[2]*a[11] + a[4]*a[3]*a[10] + a[ 8]*a[2]*a[ 7] - a[ 8]*a[3]*a[ 6];
+        inv[ 9] = -a[0]*a[ 9]*a[15] + a[0]*a[11]*a[13] + a[8]*a[1]*a[15] - a[8]*a[3]*a[13] - a[12]*a[1]*a[11] + a[12]*a[3]*a[ 9];
+        inv[10] =  a[0]*a[ 5]*a[15] - a[0]*a[ 7]*a[13] - a[4]*a[1]*a[15] + a[4]*a[3]*a[13] + a[12]*a[1]*a[ 7] - a[12]*a[3]*a[ 5];
+        inv[11] = -a[0]*a[ 5]*a[11] + a[0]*a[ 7]*a[ 9] + a[4]*a[1]*a[11] - a[4]*a[3]*a[ 9] - a[ 8]*a[1]*a[ 7] + a[ 8]*a[3]*a[ 5];
+        inv[12] = -a[4]*a[ 9]*a[14] + a[4]*a[10]*a[13] + a[8]*a[5]*a[14] - a[8]*a[6]*a[13] - a[12]*a[5]*a[10] + a[12]*a[6]*a[ 9];
+        inv[13] =  a[0]*a[ 9]*a[14] - a[0]*a[10]*a[13] - a[8]*a[1]*a[14] + a[8]*a[2]*a[13] + a[12]*a[1]*a[10] - a[12]*a[2]*a[ 9];
+        inv[14] = -a[0]*a[ 5]*a[14] + a[0]*a[ 6]*a[13] + a[4]*a[1]*a[14] - a[4]*a[2]*a[13] - a[12]*a[1]*a[ 6] + a[12]*a[2]*a[ 5];
+        inv[15] =  a[0]*a[ 5]*a[10] - a[0]*a[ 6]*a[ 9] - a[4]*a[1]*a[10] + a[4]*a[2]*a[ 9] + a[ 8]*a[1]*a[ 6] - a[ 8]*a[2]*a[ 5];
+        float det = a[0]*inv[0] + a[1]*inv[4] + a[2]*inv[8] + a[3]*inv[12];
+        if (det == 0.0f)
+            return Mat4f();
+        float invDet = 1.0f/det;
+        for (int i = 0; i < 16; ++i) inv[i] = inv[i]*invDet;
+        return inv;
+    }
     Vec3f right() const { return Vec3f(a[0], a[4], a[8]); }
     Vec3f up()    const { return Vec3f(a[1], a[5], a[9]); }
     Vec3f fwd()   const { return Vec3f(a[2], a[6], a[10]); }

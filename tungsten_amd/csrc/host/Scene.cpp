@@ -848,8 +848,21 @@ void Camera::fromJson(const JsonValue &v)
     }
     std::string type = "pinhole";
     v.getField("type", type);
-    if (type != "pinhole")
+    if (type == "thinlens") {       // ThinlensCamera::fromJson (cameras/ThinlensCamera.cpp:52-66)
+        thinlens = true;
+        v.getField("focus_distance", focusDist);
+        v.getField("aperture_size", apertureSize);
+        v.getField("cateye", catEye);
+        if (v["focus_pivot"])
+            throw JsonLoadException("thinlens 'focus_pivot' is outside the path_tracer_hip hot-path scope");
+        if (const JsonValue &ap = v["aperture"]) {
+            std::string apType;
+            if (!ap.isObject() || !ap.getField("type", apType) || apType != "disk")
+                throw JsonLoadException("thinlens apertures other than the default 'disk' texture are outside the path_tracer_hip hot-path scope");
+        }
+    } else if (type != "pinhole") {
         throw JsonLoadException("Camera type '" + type + "' is outside the path_tracer_hip hot-path scope");
+    }
     v.getField("fov", fovDeg);
     precompute();
 }
@@ -858,6 +871,7 @@ void Camera::precompute()
 {
     ratio = resY/float(resX);
     pixelSizeX = 1.0f/resX;
+    invTransform = transform.invert();             // Camera::precompute (cameras/Camera.cpp:37-42)
     float fovRad = fovDeg*(PI/180.0f);            // Angle::degToRad
     planeDist = 1.0f/std::tan(fovRad*0.5f);       // PinholeCamera.cpp:28-35
 

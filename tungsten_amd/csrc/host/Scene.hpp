@@ -120,6 +120,10 @@ struct Camera
     Mat4f transform;
     Vec3f pos, lookAt, up;
     float fovDeg = 60.0f;
+    // cameras/ThinlensCamera.cpp:16-27 (type "thinlens"; the aperture is the default DiskTexture)
+    bool thinlens = false;
+    float focusDist = 1.0f, apertureSize = 0.001f, catEye = 0.0f;
+    Mat4f invTransform;
     // precompute()
     float ratio = 0, pixelSizeX = 0, planeDist = 0;
     // ReconstructionFilter::precompute (cameras/ReconstructionFilter.cpp:34-58)

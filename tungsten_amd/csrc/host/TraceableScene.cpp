@@ -399,6 +399,11 @@ void TraceableScene::flatten()
     c.filter_width = cam.filterWidth;
     c.filter_bin_size = cam.filterBinSize;
     std::memcpy(c.filter_cdf, cam.filterCdf, sizeof(c.filter_cdf));
+    c.type = cam.thinlens ? TGHIP_CAMERA_THINLENS : TGHIP_CAMERA_PINHOLE;
+    c.focus_dist = cam.focusDist;
+    c.aperture_size = cam.apertureSize;
+    c.cat_eye = cam.catEye;
+    for (int i = 0; i < 12; ++i) c.inv_xf[i] = cam.invTransform[i];
 
     const IntegratorSettings &is = _scene.integrator;
     _desc.settings.min_bounces = is.minBounces;
