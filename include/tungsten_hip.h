@@ -292,6 +292,8 @@ int tghip_clear_framebuffer(tghip_ctx *ctx);
  * count = W*H uint32.  Pass NULLs to go back to the internal buffers. */
 int tghip_bind_framebuffer(tghip_ctx *ctx, float *dev_rgb_sum, uint32_t *dev_count);
 int tghip_download_framebuffer(tghip_ctx *ctx, float *rgb_sum, uint32_t *count, size_t npixels);
+/* restores a saved framebuffer (OutputBuffer::deserialize, cameras/OutputBuffer.hpp:191-200): resume of an interrupted render */
+int tghip_upload_framebuffer(tghip_ctx *ctx, const float *rgb_sum, const uint32_t *count, size_t npixels);
 /* SampleRecords (TGHIP_PASS_RECORDS): n = ceil(W/4)*ceil(H/4); cleared by tghip_clear_framebuffer.  Records of tiles
  * this context never rendered stay zero; upload restores a resumed / merged state. */
 int tghip_download_records(tghip_ctx *ctx, TgHipSampleRecord *out, size_t n);

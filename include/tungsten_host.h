@@ -24,6 +24,7 @@ typedef struct TgHostSceneInfo {
     int32_t  bvh_depth;
     double   bvh_sah_cost, build_seconds;
     int32_t  adaptive_sampling, stratified_sampler;
+    uint32_t current_spp;      /* tgh_renderer_info only: Integrator::currentSpp() */
 } TgHostSceneInfo;
 
 /* Scene::load + loadResources + flatten (Scene.cpp:378-391,281-306; TraceableScene.hpp:57-137) */
@@ -44,6 +45,11 @@ int  tgh_renderer_render(tgh_renderer *r, double *seconds, char *err, size_t err
 int  tgh_renderer_image(tgh_renderer *r, float *rgb_mean, float *rgb_sum, uint32_t *count, size_t npixels,
                         char *err, size_t errlen);
 int  tgh_renderer_save_outputs(tgh_renderer *r, char *err, size_t errlen);
+/* Integrator::saveRenderResumeData / resumeRender (integrators/Integrator.cpp:108-162) on renderer.resume_render_file:
+ * current spp, sampler flags, a hash of the flattened scene, the framebuffer and the integrator state (SampleRecords,
+ * the scheduler's sampler).  *resumed_out = 1 when a matching state was found and restored (call before the first step). */
+int  tgh_renderer_save_resume_data(tgh_renderer *r, char *err, size_t errlen);
+int  tgh_renderer_resume(tgh_renderer *r, int *resumed_out, char *err, size_t errlen);
 void tgh_renderer_close(tgh_renderer *r);
 
 /* ---- pass scheduling (PathTraceIntegrator.cpp:27-134) -------------------------------------------------

@@ -211,3 +211,44 @@ def test_adaptive_full_size_properties(tmp_path):
     assert np.allclose(per_pass[-1]["mean"], lum_sum/per_pass[-1]["sample_count"], rtol=3e-4, atol=1e-6)
     again = _render_passes(path)
     assert again[0][-1].tobytes() == per_pass[-1].tobytes() and again[2].tobytes() == ssum.tobytes()
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_resume_reproduces_the_uninterrupted_render(adaptive, tmp_path):
+    """Integrator::saveRenderResumeData / resumeRender (Integrator.cpp:108-162): render half the passes, save the state,
+    resume in a NEW renderer (fresh device context) and finish -- framebuffer, sample counts and SampleRecords must equal
+    the uninterrupted render bit for bit; a state saved for another scene or sampler configuration is refused."""
+    w, h, spp, step = 70, 42, 64, 16
+    state = str(tmp_path/"state.dat")
+    rend = {"adaptive_sampling": adaptive, "stratified_sampler": True, "enable_resume_render": True, "resume_render_file": state}
+    path = scenes.cornell(tmp_path, resolution=(w, h), spp=spp, spp_step=step, renderer=rend)
+    full = _render_passes(path)
+
+    r = tg.Renderer(path, seed=SEED)
+    assert not r.resume()                              # nothing saved yet
+    r.step(); r.step()
+    assert r.current_spp == 2*step
+    r.save_resume_data()
+    r.close()
+
+    r = tg.Renderer(path, seed=SEED)
+    assert r.resume() and r.current_spp == 2*step
+    done = False
+    while not done:
+        done = r.step()
+    mean, ssum, count = r.image()
+    rec = r.records().copy()
+    r.close()
+    assert (count == full[3]).all() and ssum.tobytes() == full[2].tobytes()
+    assert rec.tobytes() == full[0][-1].tobytes()
+
+    # the same file does not resume a different scene, nor the same scene under another sampler
+    other = scenes.cornell(tmp_path, name="other.json", resolution=(w, h), spp=spp, spp_step=step, renderer=rend,
+                           integrator={"max_bounces": 3})
+    r = tg.Renderer(other, seed=SEED)
+    assert not r.resume() and r.current_spp == 0
+    r.close()
+    rend2 = dict(rend, stratified_sampler=False)
+    r = tg.Renderer(scenes.cornell(tmp_path, name="uniform.json", resolution=(w, h), spp=spp, spp_step=step, renderer=rend2), seed=SEED)
+    assert not r.resume()
+    r.close()

@@ -126,6 +126,22 @@ class Renderer(object):
             raise TungstenError(lib.tghip_last_error(self.context(device)).decode())
         return hits, ms.value
 
+    def save_resume_data(self):
+        """Integrator::saveRenderResumeData: writes renderer.resume_render_file."""
+        self._check(lib.tgh_renderer_save_resume_data(self._h, self._err, len(self._err)))
+
+    def resume(self):
+        """Integrator::resumeRender: True when a saved state of this very scene was found and restored."""
+        ok = C.c_int(0)
+        self._check(lib.tgh_renderer_resume(self._h, C.byref(ok), self._err, len(self._err)))
+        return bool(ok.value)
+
+    @property
+    def current_spp(self):
+        info = TgHostSceneInfo()
+        lib.tgh_renderer_info(self._h, C.byref(info))
+        return int(info.current_spp)
+
     def records(self):
         """The integrator's SampleRecords (one per 4x4 pixels) after the last pass, as a structured array [vh, vw]."""
         vw, vh = (self.width + 3)//4, (self.height + 3)//4

@@ -116,7 +116,7 @@ class TgHostSceneInfo(C.Structure):
                 ("num_nodes", u32), ("num_recs", u32), ("num_objects", u32), ("num_lights", u32),
                 ("num_bsdfs", u32), ("num_textures", u32), ("bvh_depth", i32),
                 ("bvh_sah_cost", C.c_double), ("build_seconds", C.c_double),
-                ("adaptive_sampling", i32), ("stratified_sampler", i32)]
+                ("adaptive_sampling", i32), ("stratified_sampler", i32), ("current_spp", u32)]
 
 
 # every symbol the two headers declare: name -> (restype, argtypes)
@@ -134,6 +134,7 @@ PROTOTYPES = {
     "tghip_clear_framebuffer": (C.c_int, [VP]),
     "tghip_bind_framebuffer": (C.c_int, [VP, VP, VP]),
     "tghip_download_framebuffer": (C.c_int, [VP, VP, VP, C.c_size_t]),
+    "tghip_upload_framebuffer": (C.c_int, [VP, VP, VP, C.c_size_t]),
     "tghip_download_records": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_upload_records": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_trace_rays": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
@@ -153,6 +154,8 @@ PROTOTYPES = {
     "tgh_renderer_image": (C.c_int, [VP, VP, VP, VP, C.c_size_t, C.c_char_p, C.c_size_t]),
     "tgh_renderer_save_outputs": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
     "tgh_renderer_close": (None, [VP]),
+    "tgh_renderer_save_resume_data": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
+    "tgh_renderer_resume": (C.c_int, [VP, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "tgh_renderer_records": (C.c_int, [VP, VP, C.c_size_t, C.c_char_p, C.c_size_t]),
     "tgh_scheduler_create": (VP, [u32, u32, u32]),
     "tgh_scheduler_num_tiles": (C.c_size_t, [VP]),

@@ -2134,6 +2134,21 @@ int tghip_download_framebuffer(tghip_ctx *ctx, float *rgb_sum, uint32_t *count, 
     return TGHIP_OK;
 }
 
+int tghip_upload_framebuffer(tghip_ctx *ctx, const float *rgb_sum, const uint32_t *count, size_t npixels)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    if (!rgb_sum || !count || npixels != size_t(ctx->width)*ctx->height) { ctx->error = "pixel count mismatch"; return TGHIP_E_INVALID; }
+    int rc = tghip_wait(ctx);
+    if (rc != TGHIP_OK && rc != TGHIP_E_ABORTED) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *sum = ctx->extSum ? ctx->extSum : ctx->fbSum;
+    uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
+    HIP_TRY(ctx, hipMemcpyAsync(sum, rgb_sum, npixels*3*sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(cnt, count, npixels*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
 int tghip_download_records(tghip_ctx *ctx, TgHipSampleRecord *out, size_t n)
 {
     if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;

@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <fstream>
 #include <stdexcept>
 
 namespace tungsten_amd {
@@ -72,6 +74,97 @@ void Integrator::writeBuffers(const std::string &suffix, bool overwrite)
 void Integrator::saveOutputs()
 {
     writeBuffers("", _scene->rendererSettings().overwriteOutputFiles);
+}
+
+void Integrator::saveCheckpoint()
+{
+    writeBuffers("_checkpoint", true);
+}
+
+// The reference hashes the scene's JSON serialisation minus the renderer block (Integrator.cpp:92-106): everything that
+// determines the image except how long it is rendered.  Here the same role is played by a hash of the flattened scene
+// (every array the device gets + camera + integrator settings), which changes exactly when the rendered scene changes.
+static uint64_t fnv1a(uint64_t h, const void *data, size_t bytes)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+static uint64_t sceneHash(const TgHipSceneDesc &d)
+{
+    uint64_t h = 14695981039346656037ull;
+    h = fnv1a(h, d.nodes, size_t(d.num_nodes)*sizeof(TgHipBvhNode));
+    h = fnv1a(h, d.recs, size_t(d.num_recs)*sizeof(TgHipPrimRec));
+    h = fnv1a(h, d.tri_attrs, size_t(d.num_recs)*sizeof(TgHipTriAttr));
+    h = fnv1a(h, d.objects, size_t(d.num_objects)*sizeof(TgHipObject));
+    h = fnv1a(h, d.lights, size_t(d.num_lights)*sizeof(int32_t));
+    h = fnv1a(h, d.infinite_lights, size_t(d.num_infinite_lights)*sizeof(int32_t));
+    h = fnv1a(h, d.bsdfs, size_t(d.num_bsdfs)*sizeof(TgHipBsdf));
+    h = fnv1a(h, d.textures, size_t(d.num_textures)*sizeof(TgHipTexture));
+    h = fnv1a(h, d.texels, size_t(d.num_texel_floats)*sizeof(float));
+    h = fnv1a(h, d.light_tris, size_t(d.num_light_tri_floats)*sizeof(float));
+    h = fnv1a(h, &d.camera, sizeof(d.camera));
+    h = fnv1a(h, &d.settings, sizeof(d.settings));
+    return h;
+}
+
+static const char ResumeMagic[8] = {'T', 'G', 'H', 'I', 'P', 'R', 'S', '1'};
+
+// Integrator::saveRenderResumeData (Integrator.cpp:108-128): header (current spp + the two sampler switches a resumed render
+// must agree on), scene hash, framebuffers, integrator state.
+void Integrator::saveRenderResumeData()
+{
+    const RendererSettings &rs = _scene->rendererSettings();
+    std::ofstream out(rs.resumeRenderFile.c_str(), std::ios::binary);
+    if (!out)
+        return;                                   // the reference only logs this (Integrator.cpp:112-115)
+    std::vector<float> sum;
+    std::vector<uint32_t> count;
+    currentFramebuffer(sum, count);
+    uint32_t header[5] = {_currentSpp, rs.useAdaptiveSampling ? 1u : 0u, rs.useSobol ? 1u : 0u, _scene->cam().resX, _scene->cam().resY};
+    uint64_t hash = sceneHash(_scene->desc());
+    out.write(ResumeMagic, sizeof(ResumeMagic));
+    out.write(reinterpret_cast<const char *>(header), sizeof(header));
+    out.write(reinterpret_cast<const char *>(&hash), sizeof(hash));
+    out.write(reinterpret_cast<const char *>(sum.data()), std::streamsize(sum.size()*sizeof(float)));
+    out.write(reinterpret_cast<const char *>(count.data()), std::streamsize(count.size()*sizeof(uint32_t)));
+    saveState(out);
+}
+
+// Integrator::resumeRender (Integrator.cpp:130-162): false (and nothing touched) unless the file belongs to this scene
+// and to the same sampler configuration.
+bool Integrator::resumeRender()
+{
+    const RendererSettings &rs = _scene->rendererSettings();
+    std::ifstream in(rs.resumeRenderFile.c_str(), std::ios::binary);
+    if (!in)
+        return false;
+    char magic[8];
+    uint32_t header[5];
+    uint64_t hash = 0;
+    in.read(magic, sizeof(magic));
+    in.read(reinterpret_cast<char *>(header), sizeof(header));
+    in.read(reinterpret_cast<char *>(&hash), sizeof(hash));
+    if (!in || std::memcmp(magic, ResumeMagic, sizeof(magic)) != 0)
+        return false;
+    if (header[1] != (rs.useAdaptiveSampling ? 1u : 0u) || header[2] != (rs.useSobol ? 1u : 0u))
+        return false;
+    if (header[3] != _scene->cam().resX || header[4] != _scene->cam().resY || hash != sceneHash(_scene->desc()))
+        return false;
+    size_t n = size_t(header[3])*header[4];
+    std::vector<float> sum(n*3);
+    std::vector<uint32_t> count(n);
+    in.read(reinterpret_cast<char *>(sum.data()), std::streamsize(sum.size()*sizeof(float)));
+    in.read(reinterpret_cast<char *>(count.data()), std::streamsize(count.size()*sizeof(uint32_t)));
+    if (!in)
+        return false;
+    restoreFramebuffer(sum, count);
+    loadState(in);
+    if (!in)
+        throw std::runtime_error("path_tracer_hip: truncated render resume state '" + rs.resumeRenderFile + "'");
+    _currentSpp = header[0];
+    advanceSpp();
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -249,6 +342,59 @@ void PathTraceHipIntegrator::fetchFramebuffer()
         for (size_t i = 0; i < n; ++i) _count[i] += c[i];
     }
     _imageDirty = false;
+}
+
+void PathTraceHipIntegrator::currentFramebuffer(std::vector<float> &sum, std::vector<uint32_t> &count)
+{
+    fetchFramebuffer();
+    sum = _sum;
+    count = _count;
+}
+
+// The merged framebuffer goes to the first device, the others restart from zero: ownership of a pixel only matters for
+// the samples still to come, the final image is the sum over devices either way.
+void PathTraceHipIntegrator::restoreFramebuffer(const std::vector<float> &sum, const std::vector<uint32_t> &count)
+{
+    waitForCompletion();
+    for (size_t d = 0; d < _ctxs.size(); ++d) {
+        check(tghip_clear_framebuffer(_ctxs[d]), _ctxs[d], "tghip_clear_framebuffer");
+        if (d == 0)
+            check(tghip_upload_framebuffer(_ctxs[d], sum.data(), count.data(), count.size()), _ctxs[d], "tghip_upload_framebuffer");
+    }
+    _imageDirty = true;
+}
+
+// PathTraceIntegrator::saveState / loadState (PathTraceIntegrator.cpp:158-172): the SampleRecords, then the sampler state.
+// (The reference stores one sequential sampler per tile; the per-path streams here are counter-based and need none, the
+// integrator's own sampler -- the one distributeAdaptiveSamples draws from -- is stored instead.)
+void PathTraceHipIntegrator::saveState(std::ostream &out)
+{
+    const std::vector<TgHostSampleRecord> &rec = _scheduler.records();
+    uint64_t n = rec.size(), state = const_cast<PassScheduler &>(_scheduler).sampler().state();
+    out.write(reinterpret_cast<const char *>(&n), sizeof(n));
+    out.write(reinterpret_cast<const char *>(rec.data()), std::streamsize(n*sizeof(TgHostSampleRecord)));
+    out.write(reinterpret_cast<const char *>(&state), sizeof(state));
+}
+
+void PathTraceHipIntegrator::loadState(std::istream &in)
+{
+    uint64_t n = 0, state = 0;
+    in.read(reinterpret_cast<char *>(&n), sizeof(n));
+    std::vector<TgHostSampleRecord> &rec = _scheduler.records();
+    if (!in || n != rec.size()) { in.setstate(std::ios::failbit); return; }
+    in.read(reinterpret_cast<char *>(rec.data()), std::streamsize(n*sizeof(TgHostSampleRecord)));
+    in.read(reinterpret_cast<char *>(&state), sizeof(state));
+    if (!in) return;
+    _scheduler.sampler().setState(state);
+    if (_useAdaptive) {
+        // every device gets the complete Welford state; each keeps updating the records of its own tiles
+        std::vector<TgHipSampleRecord> dev(rec.size());
+        for (size_t i = 0; i < rec.size(); ++i) {
+            dev[i].sample_count = rec[i].sample_count; dev[i].mean = rec[i].mean; dev[i].running_variance = rec[i].running_variance;
+        }
+        for (tghip_ctx *ctx : _ctxs)
+            check(tghip_upload_records(ctx, dev.data(), dev.size()), ctx, "tghip_upload_records");
+    }
 }
 
 const std::vector<float> &PathTraceHipIntegrator::linearImage()

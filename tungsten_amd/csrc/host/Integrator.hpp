@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <functional>
+#include <iosfwd>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -47,11 +48,19 @@ public:
     virtual void waitForCompletion() = 0;
     virtual void abortRender() = 0;
     virtual bool supportsResumeRender() const { return false; }
+    // resume payload behind the framebuffers (Integrator.hpp:25-26); the framebuffer itself goes through these two
+    virtual void saveState(std::ostream &) {}
+    virtual void loadState(std::istream &) {}
+    virtual void restoreFramebuffer(const std::vector<float> &, const std::vector<uint32_t> &) {}
+    virtual void currentFramebuffer(std::vector<float> &sum, std::vector<uint32_t> &count) { sum.clear(); count.clear(); }
 
     // per-pixel mean radiance, row-major, y down (Camera::getLinear, cameras/Camera.hpp:163-172)
     virtual const std::vector<float> &linearImage() = 0;
 
     void saveOutputs();                                                   // Integrator.cpp:82-85
+    void saveCheckpoint();                                                // Integrator.cpp:87-90
+    void saveRenderResumeData();                                          // Integrator.cpp:108-128
+    bool resumeRender();                                                  // Integrator.cpp:130-162
     bool done() const;                                                    // Integrator.hpp:44-47
     uint32_t currentSpp() const { return _currentSpp; }
     uint32_t nextSpp() const { return _nextSpp; }
@@ -92,6 +101,11 @@ public:
     void waitForCompletion() override;
     void abortRender() override;
     const std::vector<float> &linearImage() override;
+    bool supportsResumeRender() const override { return true; }          // PathTraceIntegrator.cpp:215-218
+    void saveState(std::ostream &out) override;                           // PathTraceIntegrator.cpp:158-172 (records + samplers)
+    void loadState(std::istream &in) override;
+    void restoreFramebuffer(const std::vector<float> &sum, const std::vector<uint32_t> &count) override;
+    void currentFramebuffer(std::vector<float> &sum, std::vector<uint32_t> &count) override;
 
     const IntegratorSettings &settings() const { return _settings; }
     void setSettings(const IntegratorSettings &s) { _settings = s; }

@@ -113,6 +113,7 @@ int tgh_renderer_info(tgh_renderer *r, TgHostSceneInfo *out)
 {
     if (!r || !out) return -1;
     fillInfo(*r->scene, *r->flattened, out);
+    out->current_spp = r->integrator->currentSpp();
     return 0;
 }
 
@@ -183,6 +184,31 @@ void tgh_renderer_close(tgh_renderer *r)
     if (!r) return;
     r->flattened.reset();     // ~TraceableScene -> integrator.teardownAfterRender (TraceableScene.hpp:139-160)
     delete r;
+}
+
+int tgh_renderer_save_resume_data(tgh_renderer *r, char *err, size_t errlen)
+{
+    if (!r) return -1;
+    try {
+        r->integrator->saveRenderResumeData();
+        return 0;
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return -1;
+    }
+}
+
+int tgh_renderer_resume(tgh_renderer *r, int *resumed_out, char *err, size_t errlen)
+{
+    if (!r) return -1;
+    try {
+        bool ok = r->integrator->supportsResumeRender() && r->integrator->resumeRender();
+        if (resumed_out) *resumed_out = ok ? 1 : 0;
+        return 0;
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return -1;
+    }
 }
 
 int tgh_renderer_records(tgh_renderer *r, TgHostSampleRecord *out, size_t n, char *err, size_t errlen)
