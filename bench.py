@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="cornell", choices=["cornell", "materialtest", "mesh1m", "instances10k"])
+    ap.add_argument("--material", default="shipped", choices=["shipped", "dielectric", "rough_dielectric"],
+                    help="materialtest only: the \"Material\" bsdf (BASELINE configs[2] names rough-conductor -- the shipped one -- and dielectric)")
     ap.add_argument("--res", default="1280x720")
     ap.add_argument("--spp", type=int, default=0, help="default: 256 (cornell) / 64 (materialtest)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,8 +134,14 @@ class Bench(object):
         if scene == "materialtest":
             if not scenes.have_materialtest():
                 raise SystemExit("bench.py: materialtest assets missing (oracle/_ref/data; run __graft_entry__.build() where the reference is mounted)")
-            path = scenes.materialtest(self.tmp, resolution=(w, h), spp=spp)
-            workload = "materialtest.json (3 meshes 80768 tris + quad, smooth_coat/rough_conductor/lambert, envmap MIS) %dx%d @ %d spp" % (w, h, spp)
+            edit = None
+            if a.material == "dielectric":
+                edit = scenes._mt_material({"type": "dielectric", "ior": 1.5, "albedo": 1})
+            elif a.material == "rough_dielectric":
+                edit = scenes._mt_material({"type": "rough_dielectric", "ior": 1.5, "distribution": "ggx", "roughness": 0.1, "albedo": 1})
+            path = scenes.materialtest(self.tmp, resolution=(w, h), spp=spp, edit=edit)
+            workload = "materialtest.json (3 meshes 80768 tris + quad, smooth_coat/%s/lambert, envmap MIS) %dx%d @ %d spp" % (
+                "rough_conductor" if a.material == "shipped" else a.material, w, h, spp)
         elif scene == "mesh1m":
             path = scenes.mesh1m(self.tmp, resolution=(w, h), spp=spp)
             workload = ("BASELINE configs[3] on one GPU: procedurally generated 998 000-triangle mesh (fixed seed 1) + floor quad, rough_conductor, "

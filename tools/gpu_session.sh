@@ -9,6 +9,25 @@ timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > $out/pytest.log 
 tail -5 $out/pytest.log
 echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+echo "== BASELINE configs[2]: materialtest 1920x1080 @ 1024 spp, rough conductor (shipped) and dielectric, one step each"
+for mat in shipped dielectric; do
+  timeout 600 python bench.py --scene materialtest --material $mat --res 1920x1080 --spp 1024 --steps 1 --warmup 0 --no-extra --no-cpu-baseline > $out/bench_c3_$mat.json 2> $out/bench_c3_$mat.err; echo "rc=$?"
+  python -c "import json;d=json.loads(open('$out/bench_c3_$mat.json').read());print('$mat',d['value'],d['ms_per_step'],d['result_ok'],{k:(v['avg_us'],v['gbs']) for k,v in d['kernels'].items()})"
+done
+echo "== instances10k 1920x1080 @ 32 spp and 3840x2160 @ 16 spp"
+timeout 600 python bench.py --scene instances10k --spp 32 --no-extra --cpu-seconds 8 > $out/bench_instances10k.json 2> $out/bench_instances10k.err; echo "rc=$?"; cut -c1-700 $out/bench_instances10k.json
+timeout 600 python bench.py --scene instances10k --res 3840x2160 --spp 16 --steps 2 --warmup 1 --no-extra --no-cpu-baseline > $out/bench_instances10k_4k.json 2> $out/bench_instances10k_4k.err; echo "rc=$?"; cut -c1-300 $out/bench_instances10k_4k.json
+echo "== strong-scaling emulation (shard 0 of N on one GPU)"
+for scene in cornell materialtest; do
+  spp=256; [ $scene = materialtest ] && spp=64
+  for n in 1 2 4 8; do
+    timeout 300 python bench.py --scene $scene --spp $spp --no-extra --no-cpu-baseline --no-kernel-timing --emulate-shards $n | python -c "import json,sys;d=json.loads(sys.stdin.read());print('$scene shard 1/$n',d['ms_per_step'])"
+  done
+done | tee $out/emulated_scaling.txt
+echo "== as shipped (Sobol + adaptive, passes of 16 spp)"
+for args in "--scene materialtest" "--scene materialtest --no-sobol --no-adaptive" "--scene cornell --spp 256" "--scene cornell --spp 256 --no-sobol --no-adaptive"; do
+  python tools/bench_as_shipped.py $args
+done | tee $out/as_shipped.jsonl
 for scene in cornell materialtest mesh1m; do
   spp=256; [ $scene = materialtest ] && spp=64; [ $scene = mesh1m ] && spp=32
   echo "== bench $scene"
