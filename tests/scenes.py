@@ -10,6 +10,32 @@ MATERIALTEST_DIR = os.path.join(ROOT, "oracle", "_ref", "data", "materialtest")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+WATER_DIR = os.path.join(ROOT, "oracle", "_ref", "data", "water-caustic")
+
+
+def have_water_caustic():
+    return os.path.exists(os.path.join(WATER_DIR, "scene.json"))
+
+
+def water_caustic(tmpdir, **kw):
+    """data/example-scenes/water-caustic of the reference (Cornell box + smooth 67 000-triangle dielectric water surface),
+    rendered with the path tracer instead of its shipped progressive photon mapper (same max_bounces = 8)."""
+    for f in os.listdir(WATER_DIR):
+        if f.endswith(".json"):
+            continue
+        link = os.path.join(str(tmpdir), f)
+        if not os.path.exists(link):
+            os.symlink(os.path.join(WATER_DIR, f), link)
+    user = kw.pop("edit", None)
+
+    def edit(scene):
+        keep = {k: scene["integrator"][k] for k in ("min_bounces", "max_bounces", "enable_consistency_checks", "enable_two_sided_shading")}
+        scene["integrator"] = dict(keep, type="path_tracer", enable_light_sampling=True)
+        if user:
+            user(scene)
+    return variant(os.path.join(WATER_DIR, "scene.json"), str(tmpdir), kw.pop("name", "water_caustic.json"), edit=edit, **kw)
+
+
 def have_materialtest():
     return os.path.exists(os.path.join(MATERIALTEST_DIR, "materialtest.json"))
 
@@ -397,6 +423,8 @@ def _thinlens(cateye):
 GOLDEN_CASES["cornell_thinlens"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.0)))
 GOLDEN_CASES["cornell_thinlens_cateye"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.35)))
 GOLDEN_CASES["cornell_thinlens_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.0), renderer={"stratified_sampler": True}))
+
+GOLDEN_CASES["water_caustic"] = (water_caustic, dict(resolution=(64, 36), spp=4))
 
 # "stratified_sampler": true -- SobolPathSampler dimensions with the tiles' own seeds
 _SOBOL = {"stratified_sampler": True}
