@@ -247,7 +247,7 @@ class Bench(object):
                             "launches": kd["launches"],
                             "timing": "HIP events per launch on the shim's stream, over the timed region"}
                 if fused:
-                    roofline["note"] = ("VALU-bound, not HBM-bound: exact fp32 division/sqrt/sin/cos and -ffp-contract=off for parity "
+                    roofline["note"] = ("instruction-bound, not HBM-bound (profiles/sq_counters.json): exact fp32 division/sqrt/sin/cos and -ffp-contract=off for parity "
                                         "with the CPU reference (DESIGN.md sections 5, 7)")
                 tr = os.path.join(ROOT, "profiles", "traffic.json")
                 if os.path.exists(tr):
