@@ -1,12 +1,7 @@
 #!/bin/bash
-out=gpurun_out/resume1; mkdir -p $out
-timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > $out/pytest.log 2>&1; echo "pytest rc=$?"
-tail -12 $out/pytest.log
-cd /tmp && cp -r $GRAFT_REPO_ROOT/scenes/cornell-box /tmp/cb && python - <<'PY'
-import json
-s=json.load(open('/tmp/cb/scene.json')); s['renderer'].update(spp=64, spp_step=16, enable_resume_render=True, resume_render_file='/tmp/cb/state.dat', output_file='/tmp/cb/o.png', hdr_output_file='/tmp/cb/o.pfm')
-s['camera']['resolution']=[320,180]
-json.dump(s, open('/tmp/cb/s.json','w'))
-PY
-$GRAFT_REPO_ROOT/tungsten_amd/lib/tungsten_hip /tmp/cb/s.json | tail -4
-$GRAFT_REPO_ROOT/tungsten_amd/lib/tungsten_hip /tmp/cb/s.json | tail -4
+for t in 256 192 384; do
+timeout 300 python bench.py --scene materialtest --no-extra --no-cpu-baseline --spp 64 --opt threads_shadow=$t | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print('materialtest shadow threads $t',d['value'],d['ms_per_step'],d['result_ok'],{k:v['avg_us'] for k,v in d['kernels'].items()})"
+done
+timeout 300 python bench.py --scene mesh1m --no-extra --no-cpu-baseline --spp 32 --opt threads_shadow=256 | python -c "
+import json,sys;d=json.loads(sys.stdin.read());print('mesh1m 256',d['value'],d['ms_per_step'],d['result_ok'],{k:v['avg_us'] for k,v in d['kernels'].items()})"

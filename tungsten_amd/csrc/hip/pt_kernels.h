@@ -53,7 +53,8 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 // made each wave touch ~50 different 64-B lines per access and half of all DRAM writes partial-line.)
 // Q_EXT holds bounced (continuation) rays, Q_EXTP freshly generated camera rays: the traversal kernel walks them as
 // two separate runs so that the coherent primaries are not interleaved lane by lane with incoherent bounces.
-enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_COUNT = 5 };
+// Q_FIN: paths whose last vertex was waiting for a shadow result of the dynamic-fetch shadow kernel (k_finish regenerates them)
+enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_FIN = 5, Q_COUNT = 6 };
 
 struct BlockCtl {                 // one per persistent workgroup; only that workgroup touches it
     uint32_t item_cursor;         // workgroup-local linear index of the next work item

@@ -927,9 +927,10 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
 // Shadow rays of BVH scenes without forward-lobe BSDFs, with dynamic fetch like k_trace_closest_dyn: the unit of
 // work is a shadow slot (<= 2 any-hit rays, traced one after the other); idle lanes take the workgroup's next slots
 // once fewer than 3/4 of the wave is busy.  A finished slot adds the NEE term to its path's radiance; paths that
-// had ended at that vertex are collected in an LDS list and finalised + regenerated after the traversal loop
-// (keeping nextPath out of the loop holds the loop at 5 waves per SIMD).
-// Dynamic LDS: [expanded queue, 2 B per slot][finished list, 2 B per slot][node stacks, bvhDepth ints per thread].
+// had ended at that vertex go to the Q_FIN queue and are finalised + regenerated by k_finish, a launch of its own:
+// nextPath (camera ray, filter table, item bookkeeping) needs 112 VGPRs, the traversal loop 82 -- kept apart, this
+// kernel runs 5 waves per SIMD instead of 4.
+// Dynamic LDS: [expanded queue, 2 B per slot][node stacks, bvhDepth ints per thread].
 #ifndef SHADOW_DYN_BOUNDS
 #define SHADOW_DYN_BOUNDS __launch_bounds__(512)
 #endif
@@ -938,14 +939,13 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
 {
     extern __shared__ int ldsDyn[];
     __shared__ BlockLds L;
-    __shared__ uint32_t fetchNext, finishedN;
+    __shared__ uint32_t fetchNext;
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
-    unsigned short *finishedList = order + PT_MAX_SLOTS_PER_BLOCK;
-    int *stack = ldsDyn + PT_MAX_SLOTS_PER_BLOCK + threadIdx.x;
+    int *stack = ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2 + threadIdx.x;
     const int stride = (int)blockDim.x;
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    if (threadIdx.x == 0) { fetchNext = 0; finishedN = 0; }
-    queuesBegin(L, st, ctl, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP), order);
+    if (threadIdx.x == 0) fetchNext = 0;
+    queuesBegin(L, st, ctl, Q_SHADOW, 1u << Q_FIN, order);
     const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const int minBounces = s.settings.min_bounces;
@@ -993,8 +993,7 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
         em = em + (result*w.w)*xyz(w);           // emission += estimateDirect(...)*throughput
         em = em + xyz(p);
         slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
-        if (FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE)
-            finishedList[atomicAdd(&finishedN, 1u)] = (unsigned short)local;
+        queuePush(FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE, local, L, Q_FIN);
         busy = false;
     };
 
@@ -1077,9 +1076,28 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
     waveAddStat(&L.shadow_slots, slots);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
 
-    // finalise + regenerate the paths that were waiting for their last shadow result
-    __syncthreads();
-    const uint32_t nf = finishedN;
+    queuesEnd(L, st, Q_SHADOW, 1u << Q_FIN);
+    if (threadIdx.x == 0) {
+        ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
+        if (COUNT) {
+            BlockStats &bs = st.stats[blockIdx.x];
+            bs.nodes_visited += L.nodes; bs.prims_tested += L.prims;
+            bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
+        }
+    }
+}
+
+// Second half of the dynamic-fetch shadow step: finalises the paths that had ended at the vertex whose shadow rays
+// k_trace_shadow_dyn just resolved (Q_FIN), regenerates their slots and reports whether the workgroup has extension
+// rays for the next iteration.
+__global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+{
+    __shared__ BlockLds L;
+    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    queuesBegin(L, st, ctl, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP), order);
+    const uint32_t nf = L.n;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
     const bool aborted = st.live[1] != 0;
     uint32_t finishedCount = 0;
     for (uint32_t base = 0; base < nf; base += blockDim.x) {
@@ -1089,7 +1107,7 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
         f3 em = splat3(0.0f);
         bool black = false;
         if (fin) {
-            loc = finishedList[i];
+            loc = order[i];
             sl = first + loc;
             em = xyz(slotF4(st, A_EMI, sl));
             black = FLAG_STATE(__float_as_uint(slotF4(st, A_SH_P, sl).w)) == ST_TERMINATED_BLACK;
@@ -1098,15 +1116,10 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
         queuePush(regenerated, loc, L, Q_EXTP);
     }
     waveAddStat(&L.samples, finishedCount);
-    const bool anyExt = queuesEnd(L, st, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP));
+    const bool anyExt = queuesEnd(L, st, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP));
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
-        ctl.samples += L.samples; ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
-        if (COUNT) {
-            BlockStats &bs = st.stats[blockIdx.x];
-            bs.nodes_visited += L.nodes; bs.prims_tested += L.prims;
-            bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
-        }
+        ctl.samples += L.samples;
         if (anyExt) st.live[0] = iterTag;
     }
 }
@@ -1380,20 +1393,20 @@ static size_t traceLdsBytes(const tghip_ctx *ctx, int threads)
 }
 
 // dynamic-fetch traversal kernels keep the expanded queue next to the stacks
-static size_t dynLdsBytes(const tghip_ctx *ctx, int threads, bool finishedList = false)
+static size_t dynLdsBytes(const tghip_ctx *ctx, int threads)
 {
-    return size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short)*(finishedList ? 2 : 1) + size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
+    return size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short) + size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
 }
 
 static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*std::max(ctx->blocksPerCu, 1); }
 
 // Largest workgroup size (multiple of 64, <= maxThreads) at which `blocksPerCu` workgroups of `kernel` fit on a CU.
 template<typename K>
-static int pickThreads(const tghip_ctx *ctx, K kernel, int maxThreads, int ldsMode)   // 0: no dynamic LDS, 1: traceLdsBytes, 2/3: dynLdsBytes without/with finished list
+static int pickThreads(const tghip_ctx *ctx, K kernel, int maxThreads, int ldsMode)   // 0: no dynamic LDS, 1: traceLdsBytes, 2: dynLdsBytes
 {
     for (int t = maxThreads; t >= 128; t -= 64) {
         int nb = 0;
-        size_t lds = ldsMode == 1 ? traceLdsBytes(ctx, t) : ldsMode == 2 ? dynLdsBytes(ctx, t) : ldsMode == 3 ? dynLdsBytes(ctx, t, true) : 0;
+        size_t lds = ldsMode == 1 ? traceLdsBytes(ctx, t) : ldsMode == 2 ? dynLdsBytes(ctx, t) : 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), t, lds) == hipSuccess && nb >= ctx->blocksPerCu)
             return t;
     }
@@ -1492,7 +1505,7 @@ static void chooseThreads(tghip_ctx *ctx)
                     : dyn ? pickThreads(ctx, k_trace_closest_dyn<false>, 320, 2)   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
     if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
-        ctx->thrShadow = pickThreads(ctx, k_trace_shadow_dyn<false>, 512, 3);
+        ctx->thrShadow = pickThreads(ctx, k_trace_shadow_dyn<false>, 256, 2);   // measured: 192 / 256 / 320 / 384 threads = 525 / 462 / 633 / 619 us per launch
     else if (inst)
         ctx->thrShadow = (ctx->haveForward || ctx->haveMeshLight) ? pickThreads(ctx, k_trace_shadow<false, true, false, true>, 512, 1)
                                                                    : pickThreads(ctx, k_trace_shadow<false, false, false, true>, 512, 1);
@@ -1805,8 +1818,9 @@ static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const Pas
     else          launchShadeVariant<M, FUSE>(ctx, grid, st, pp, cls);
 }
 
+// true when the shadow step needs its second half, k_finish (the dynamic-fetch kernel does not regenerate paths itself)
 template<bool COUNT>
-static void launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, uint32_t iterTag)
+static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, uint32_t iterTag)
 {
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrShadow);
     const bool flat = isFlat(ctx);
@@ -1814,17 +1828,18 @@ static void launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
     if (ctx->haveInstances) {
         if (closestWalk) hipLaunchKernelGGL((k_trace_shadow<COUNT, true, false, true>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
         else             hipLaunchKernelGGL((k_trace_shadow<COUNT, false, false, true>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
-        return;
+        return false;
     }
     if (!flat && !closestWalk && ctx->dynamicFetch) {
-        hipLaunchKernelGGL(k_trace_shadow_dyn<COUNT>, dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow, true), ctx->stream,
+        hipLaunchKernelGGL(k_trace_shadow_dyn<COUNT>, dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
                            ctx->scene, st, pp, iterTag);
-        return;
+        return true;
     }
 #define SHADOW_LAUNCH(FWD, FLAT) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, FLAT>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
     if (closestWalk) { if (flat) SHADOW_LAUNCH(true, true); else SHADOW_LAUNCH(true, false); }
     else                  { if (flat) SHADOW_LAUNCH(false, true); else SHADOW_LAUNCH(false, false); }
 #undef SHADOW_LAUNCH
+    return false;
 }
 
 } // extern "C++"
@@ -1935,9 +1950,10 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 else                                            launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
             }
             tic(); tic();
-            if (count) launchShadow<true>(ctx, grid, st, pp, iterTag);
-            else       launchShadow<false>(ctx, grid, st, pp, iterTag);
+            const bool finish = count ? launchShadow<true>(ctx, grid, st, pp, iterTag) : launchShadow<false>(ctx, grid, st, pp, iterTag);
             tic();
+            if (finish)
+                hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp, iterTag);
             ctx->counters.iterations++;
         }
     }
