@@ -75,14 +75,15 @@ typedef struct TgHipBvhNode {
 #define TGHIP_FLAT_MAX_RECS    16
 
 /* record kinds (meta >> 29) */
-enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3, TGHIP_REC_INSTANCE = 4 };
+enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3, TGHIP_REC_INSTANCE = 4,
+       TGHIP_REC_DISK = 5 };
 #define TGHIP_REC_KIND(meta)   ((uint32_t)(meta) >> 29)
 #define TGHIP_REC_OBJECT(meta) ((uint32_t)(meta) & 0x1FFFFFFFu)
 
 /* 48-byte primitive record = three float4:
  *   triangle: a = v0, b = v1 - v0, c = v2 - v0                (p0,p1 unused)
  *   quad    : a = base, b = edge0, c = edge1, p0/p1 = 1/|edge0|^2, 1/|edge1|^2   (Quad.cpp:298-316)
- *   cube / sphere: geometry lives in objects[TGHIP_REC_OBJECT(meta)]; a,b,c unused
+ *   cube / sphere / disk: geometry lives in objects[TGHIP_REC_OBJECT(meta)]; a,b,c unused
  *   instance: one rigid placement of a master mesh (primitives/Instance.cpp:290-344): a = _instancePos[i],
  *             (p0, b) = _instanceRot[i] as quaternion (w; x, y, z), c[0] = bits of the master's BVH root node index
  *             (uint32), c[1] = bits of the instance number i; the object is the `instances` primitive.  The master's
@@ -106,7 +107,7 @@ typedef struct TgHipTriAttr {
 
 /* ---- objects (one per reference Primitive) ------------------------------------------ */
 enum { TGHIP_OBJ_MESH = 0, TGHIP_OBJ_QUAD = 1, TGHIP_OBJ_CUBE = 2, TGHIP_OBJ_SPHERE = 3,
-       TGHIP_OBJ_INFINITE_SPHERE = 4, TGHIP_OBJ_INSTANCES = 5 };
+       TGHIP_OBJ_INFINITE_SPHERE = 4, TGHIP_OBJ_INSTANCES = 5, TGHIP_OBJ_DISK = 6 };
 #define TGHIP_OBJF_SMOOTH   1u   /* mesh "smooth": Ns interpolated (TriangleMesh.cpp:344-355) */
 #define TGHIP_OBJF_SAMPLE   2u   /* infinite_sphere "sample" (InfiniteSphere.cpp:117-122)      */
 
@@ -120,7 +121,9 @@ typedef struct TgHipObject {
     int32_t  first_light_tri; /* sampled mesh emitters: float offset of the mesh's block in light_tris, else -1 */
     float    base[3], edge0[3], edge1[3], normal[3]; /* quad (Quad.cpp:298-316)    */
     float    inv_uv_sq[2];
-    float    pos[3], scale[3];                       /* cube half-extent / sphere radius in scale[0] */
+    float    pos[3], scale[3];                       /* cube half-extent / sphere radius in scale[0] /
+                                                        disk (Disk.cpp:303-315): pos = _center, normal = _n, scale = {_r, _cosApex, -}, edge0 = _frame.tangent,
+                                                        edge1 = _frame.bitangent, base = _coneBase */
     float    rot[9];                                 /* row-major 3x3 rotation (cube; infinite sphere _rotTransform) */
     float    face_cdf[3];                            /* cube (Cube.cpp:353-370)    */
     int32_t  num_light_tris;  /* sampled mesh emitters: triangles in the block (TriangleMesh::makeSamplable) */

@@ -1196,6 +1196,31 @@ static int sphere_test(const TgHipObject *o, const Ray *ray, float tmax, float *
 }
 
 /* uv and normal of a point on a cube / sphere (Cube.cpp:157-170, Sphere.cpp:120-129) */
+/* Disk::intersect (Disk.cpp:63-85); u = rSq for intersectionInfo, back = -nDotW < _cosApex */
+static int disk_test(const TgHipObject *o, const Ray *ray, float tmax, float *t, float *rSq, int *backSide)
+{
+    v3 n = ld3(o->normal), center = ld3(o->pos);
+    float nDotW = vdot(ray->d, n);
+    float tt = vdot(n, vsub(center, ray->o))/nDotW;
+    if (tt < ray->tmin || tt > tmax)
+        return 0;
+    v3 q = vadd(ray->o, vscale(ray->d, tt));
+    v3 v = vsub(q, center);
+    float r2 = vlensq(v);
+    if (r2 > o->scale[0]*o->scale[0])
+        return 0;
+    *t = tt; *rSq = r2; *backSide = -nDotW < o->scale[1];
+    return 1;
+}
+/* Disk::intersectionInfo (Disk.cpp:114-129); hp = the stored hit point ray.pos + t*ray.dir */
+static void disk_surface(const TgHipObject *o, v3 hp, float rSq, float *u, float *v)
+{
+    v3 d = vsub(hp, ld3(o->pos));
+    float x = vdot(d, ld3(o->edge1)), y = vdot(d, ld3(o->edge0));      /* bitangent, tangent */
+    *v = sqrtf(rSq)/o->scale[0];
+    *u = (x == 0.0f && y == 0.0f) ? 0.0f : (atan2f(y, x)*O_INV_TWO_PI + 0.5f);
+}
+
 static void cube_surface(const TgHipObject *o, v3 hp, v3 *n, float *u, float *v)
 {
     v3 p = mat3_tmul(o->rot, vsub(hp, ld3(o->pos)));
@@ -1284,6 +1309,7 @@ static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float 
     case TGHIP_REC_QUAD: ok = quad_test(r, &s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &u, &v, &back); break;
     case TGHIP_REC_CUBE: ok = cube_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
     case TGHIP_REC_SPHERE: ok = sphere_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
+    case TGHIP_REC_DISK: ok = disk_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &v, &back); u = (float)back; break;   /* v carries rSq */
     case TGHIP_REC_INSTANCE: {
         /* Instance::intersect (primitives/Instance.cpp:290-311): the ray goes into the master's space -- rotation and
          * translation only, so distances along it are unchanged -- and the master's own intersect shortens it */
@@ -1406,6 +1432,12 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit
     case TGHIP_REC_SPHERE:       /* Sphere.cpp:120-129 */
         sphere_surface(o, info->p, &info->Ng, &info->u, &info->v);
         info->Ns = info->Ng;
+        info->bsdf = o->bsdf;
+        info->backSide = hit->u != 0.0f;
+        break;
+    case TGHIP_REC_DISK:         /* Disk.cpp:114-129 */
+        info->Ng = info->Ns = ld3(o->normal);
+        disk_surface(o, info->p, hit->v, &info->u, &info->v);
         info->bsdf = o->bsdf;
         info->backSide = hit->u != 0.0f;
         break;
@@ -1555,6 +1587,12 @@ static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, 
         if (!sphere_test(o, ray, ray->tmax, &lh->t, &lh->backSide)) return 0;
         sphere_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), &lh->n, &lh->u, &lh->v);
         return 1;
+    } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::intersect + intersectionInfo */
+        float rSq;
+        if (!disk_test(o, ray, ray->tmax, &lh->t, &rSq, &lh->backSide)) return 0;
+        disk_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), rSq, &lh->u, &lh->v);
+        lh->n = ld3(o->normal);
+        return 1;
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh::intersect + intersectionInfo: the mesh's own BVH */
         Hit hit;
         if (!scene_intersect_obj(s, ray, &hit, NULL, objIdx)) return 0;
@@ -1587,6 +1625,11 @@ static float light_directPdf(const TgHipSceneDesc *s, int objIdx, const LightHit
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:469-473 */
         v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
         return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
+    } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::directPdf (Disk.cpp:228-235) */
+        v3 n = ld3(o->normal);
+        float cosTheta = fabsf(vdot(n, lh->w));
+        float t = vdot(n, vsub(ld3(o->pos), p))/vdot(n, lh->w);
+        return t*t/(cosTheta*o->scale[0]*o->scale[0]*O_PI);
     } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere.cpp:216-222 */
         float dist = vlen(vsub(ld3(o->pos), p));
         float cosTheta = sqrtf(fmaxf(dist*dist - o->scale[0]*o->scale[0], 0.0f))/dist;
@@ -1666,6 +1709,23 @@ static int light_sampleDirect(const TgHipSceneDesc *s, int objIdx, v3 p, Sampler
             return 0;
         *pdf = rSq/(cosTheta*o->area);
         return 1;
+    } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::sampleDirect (Disk.cpp:178-194) */
+        v3 n = ld3(o->normal), center = ld3(o->pos);
+        if (vdot(n, vsub(p, center)) < 0.0f)
+            return 0;
+        float xi0 = next1D(smp), xi1 = next1D(smp);
+        float phi = xi0*O_TWO_PI, rr = sqrtf(xi1);     /* SampleWarp::uniformDisk */
+        float lx = cosf(phi)*rr*o->scale[0], ly = sinf(phi)*rr*o->scale[0];
+        v3 q = vadd(vadd(center, vscale(ld3(o->edge1), lx)), vscale(ld3(o->edge0), ly));   /* lQ.x*bitangent + lQ.y*tangent */
+        v3 L = vsub(q, p);
+        float rSq = vlensq(L);
+        *dist = sqrtf(rSq);
+        *d = vdivs(L, *dist);
+        if (-vdot(*d, n) < o->scale[1])
+            return 0;
+        float cosTheta = -vdot(n, *d);
+        *pdf = rSq/(cosTheta*o->scale[0]*o->scale[0]*O_PI);
+        return 1;
     } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere::sampleDirect (Sphere.cpp:173-194) */
         v3 L = vsub(ld3(o->pos), p);
         float dd = vlen(L);
@@ -1725,6 +1785,21 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
         return vmax3(ld3(s->textures[o->emission].avg))*o->face_cdf[2]/dSq;
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:514-517: "unknown" */
         return -1.0f;
+    } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::approximateRadiance (Disk.cpp:253-281) */
+        if (o->emission < 0) return 0.0f;
+        v3 n = ld3(o->normal);
+        v3 coneD = vsub(p, ld3(o->base));
+        if (vdot(coneD, n)/vlen(coneD) < o->scale[1])
+            return 0.0f;
+        v3 dd = vsub(ld3(o->pos), p);
+        v3 e0 = vscale(ld3(o->edge0), o->scale[0]), e1 = vscale(ld3(o->edge1), o->scale[0]);
+        v3 R0 = vsub(vsub(dd, e0), e1);
+        v3 R1 = vadd(R0, vscale(e0, 2.0f));
+        v3 R2 = vadd(R1, vscale(e1, 2.0f));
+        v3 R3 = vadd(R0, vscale(e1, 2.0f));
+        v3 n0 = vnorm(vcross(R0, R1)), n1 = vnorm(vcross(R1, R2)), n2 = vnorm(vcross(R2, R3)), n3 = vnorm(vcross(R3, R0));
+        float Q = acosf(vdot(n0, n1)) + acosf(vdot(n1, n2)) + acosf(vdot(n2, n3)) + acosf(vdot(n3, n0));
+        return (O_TWO_PI - fabsf(Q))*vmax3(ld3(s->textures[o->emission].avg));
     } else if (o->type == TGHIP_OBJ_SPHERE) {          /* Sphere.cpp:266-271, 33-40 */
         if (o->emission < 0) return 0.0f;
         v3 L = vsub(ld3(o->pos), p);

@@ -424,6 +424,21 @@ GOLDEN_CASES["cornell_thinlens"] = (cornell, dict(resolution=(48, 27), spp=8, ed
 GOLDEN_CASES["cornell_thinlens_cateye"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.35)))
 GOLDEN_CASES["cornell_thinlens_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.0), renderer={"stratified_sampler": True}))
 
+def _disks(scene):
+    """The quad light becomes a downward disk spot light with a 65 degree emission cone (primitives/Disk.cpp); a checkered,
+    non-emissive disk leans against the tall box; a second, small disk light shines sideways from the left wall."""
+    scene["primitives"] = [p for p in scene["primitives"] if p["name"] != "light"]
+    scene["bsdfs"].append({"name": "checkers", "type": "lambert", "albedo": _CHECKER})
+    scene["primitives"] += [
+        {"name": "spot", "type": "disk", "bsdf": "light", "emission": [30, 22, 8], "cone_angle": 65,
+         "transform": {"position": [-0.005, 1.97, -0.03], "scale": 0.3, "rotation": [180, 0, 0]}},
+        {"name": "plate", "type": "disk", "bsdf": "checkers",
+         "transform": {"position": [0.35, 0.45, 0.55], "scale": 0.35, "rotation": [60, 25, 10]}},
+        {"name": "sidelight", "type": "disk", "bsdf": "light", "emission": [2, 6, 9],
+         "transform": {"position": [-0.97, 0.8, 0.3], "scale": 0.15, "rotation": [0, 0, -90]}}]
+
+
+GOLDEN_CASES["cornell_disks"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_disks))
 GOLDEN_CASES["water_caustic"] = (water_caustic, dict(resolution=(64, 36), spp=4))
 
 # "stratified_sampler": true -- SobolPathSampler dimensions with the tiles' own seeds (SURVEY.md 8 a20)

@@ -387,7 +387,7 @@ PT_DEV bool boxTest(f3 lo, f3 hi, const RayD &ray, f3 invD, float tmax, float &t
 // `stack` is this lane's column of the workgroup's LDS stack: stack[level*stride]
 // FLAT: the scene has <= TGHIP_FLAT_MAX_RECS records; every lane walks the whole record list in step, so the
 // record (and quad/cube object) loads have wave-uniform addresses and go through the scalar cache.
-template<bool COUNT, bool FLAT>
+template<bool COUNT, bool FLAT, uint32_t KINDS = KINDS_ALL>
 PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack, int stride,
                               uint32_t &nodesVisited, uint32_t &primsTested)
 {
@@ -396,7 +396,7 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
     if (FLAT) {
         const uint32_t n = s.num_recs;
         for (uint32_t i = 0; i < n; ++i)
-            testRecord<true>(s, i, ray, tmax, hit);
+            testRecord<true, KINDS>(s, i, ray, tmax, hit);
         if (COUNT) primsTested += n;
         return hit;
     }
@@ -423,7 +423,7 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
             uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
             for (uint32_t i = first; i < first + count; ++i) {
                 if (COUNT) primsTested++;
-                testRecord<false>(s, i, ray, tmax, hit);
+                testRecord<false, KINDS>(s, i, ray, tmax, hit);
             }
         }
         if (sp == 0)
@@ -438,7 +438,7 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
 // than `endCap` (the light the ray was aimed at) is hit inside (tmin, tmax).  Equivalent to
 // generalizedShadowRay's closest-hit formulation there (TraceBase.cpp:79,114-115), but the
 // traversal stops at the first occluder.
-template<bool COUNT, bool FLAT>
+template<bool COUNT, bool FLAT, uint32_t KINDS = KINDS_ALL>
 PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, int *stack, int stride,
                              uint32_t &nodesVisited, uint32_t &primsTested)
 {
@@ -451,7 +451,7 @@ PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, 
             float tmax = ray.tmax;
             if (!occluded) {
                 if (COUNT) primsTested++;
-                if (testRecord<true>(s, i, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                if (testRecord<true, KINDS>(s, i, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
                     occluded = true;
             }
             if (__ballot(!occluded) == 0ull)
@@ -483,7 +483,7 @@ PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, 
             for (uint32_t i = first; i < first + count; ++i) {
                 if (COUNT) primsTested++;
                 float tmax = ray.tmax;
-                if (testRecord<false>(s, i, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                if (testRecord<false, KINDS>(s, i, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
                     return true;
             }
         }

@@ -1007,6 +1007,32 @@ PT_DEV bool sphereTest(OP op, const RayD &ray, float tmax, float &t, bool &backS
     return false;
 }
 
+/* Disk::intersect (Disk.cpp:63-85): pos = _center, normal = _n, scale = {_r, _cosApex}; backSide = outside the emission cone */
+template<typename OP>
+PT_DEV bool diskTest(OP op, const RayD &ray, float tmax, float &t, float &rSq, bool &backSide)
+{
+    const auto &o = *op;
+    f3 n = ld3(o.normal), center = ld3(o.pos);
+    float nDotW = dot(ray.d, n);
+    float tt = dot(n, center - ray.o)/nDotW;
+    if (tt < ray.tmin || tt > tmax)
+        return false;
+    f3 v = (ray.o + ray.d*tt) - center;
+    float r2 = lengthSq(v);
+    if (r2 > o.scale[0]*o.scale[0])
+        return false;
+    t = tt; rSq = r2; backSide = -nDotW < o.scale[1];
+    return true;
+}
+/* Disk::intersectionInfo (Disk.cpp:114-129): uv of the hit point; edge0 = tangent, edge1 = bitangent */
+PT_DEV void diskSurface(const TgHipObject &o, f3 hp, float rSq, float &u, float &v)
+{
+    f3 d = hp - ld3(o.pos);
+    float x = dot(d, ld3(o.edge1)), y = dot(d, ld3(o.edge0));
+    v = sqrtf(rSq)/o.scale[0];
+    u = (x == 0.0f && y == 0.0f) ? 0.0f : (atan2f(y, x)*PT_INV_TWO_PI + 0.5f);
+}
+
 /* normal and uv of a point on a cube / sphere (Cube.cpp:157-170, Sphere.cpp:120-129) */
 PT_DEV void cubeSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v)
 {
@@ -1034,7 +1060,12 @@ PT_DEV void sphereSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v
 /* Tests record `ri` against the ray; on a hit updates (tmax, hit) -- the leaf body of both traversal kernels.
  * UNIFORM: `ri` is the same for every lane (flat-list traversal), so the record and its object are fetched
  * through the constant address space, i.e. with scalar loads. */
-template<bool UNIFORM>
+// KINDS: the record kinds the scene (or the kernel variant) can contain; tests of absent kinds fold away, which keeps
+// the hot traversal kernels of triangle scenes at their register budget whatever analytic primitives exist elsewhere.
+#define KIND_BIT(k)   (1u << (k))
+#define KINDS_ALL     0x3Fu
+#define KINDS_MESH    (KIND_BIT(TGHIP_REC_TRIANGLE) | KIND_BIT(TGHIP_REC_QUAD))   /* triangle meshes + quads (materialtest) */
+template<bool UNIFORM, uint32_t KINDS = KINDS_ALL>
 PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit, uint32_t &hitMeta)
 {
     float4 r0, r1, r2;
@@ -1050,21 +1081,28 @@ PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
     uint32_t kind = TGHIP_REC_KIND(meta);
     float t, u = 0.0f, v = 0.0f;
     bool ok;
-    if (kind == TGHIP_REC_TRIANGLE) {
+    if ((KINDS & KIND_BIT(TGHIP_REC_TRIANGLE)) && (kind == TGHIP_REC_TRIANGLE || KINDS == KIND_BIT(TGHIP_REC_TRIANGLE))) {
         ok = triTest(xyz(r0), xyz(r1), xyz(r2), ray, tmax, t, u, v);
-    } else if (kind == TGHIP_REC_QUAD) {
+    } else if ((KINDS & KIND_BIT(TGHIP_REC_QUAD)) && kind == TGHIP_REC_QUAD) {
         f3 n = UNIFORM ? ld3(asConst(s.objects)[TGHIP_REC_OBJECT(meta)].normal) : ld3(s.objects[TGHIP_REC_OBJECT(meta)].normal);
         ok = quadTest(xyz(r0), xyz(r1), xyz(r2), r1.w, r2.w, n, ray, tmax, t, u, v);
-    } else if (kind == TGHIP_REC_CUBE) {
+    } else if ((KINDS & KIND_BIT(TGHIP_REC_CUBE)) && kind == TGHIP_REC_CUBE) {
         bool back;
         if (UNIFORM) ok = cubeTest(asConst(s.objects) + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
         else         ok = cubeTest(s.objects + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
         u = back ? 1.0f : 0.0f;
-    } else {                                           /* TGHIP_REC_SPHERE */
+    } else if ((KINDS & KIND_BIT(TGHIP_REC_DISK)) && kind == TGHIP_REC_DISK) {   /* v carries the squared distance from the centre */
+        bool back;
+        if (UNIFORM) ok = diskTest(asConst(s.objects) + TGHIP_REC_OBJECT(meta), ray, tmax, t, v, back);
+        else         ok = diskTest(s.objects + TGHIP_REC_OBJECT(meta), ray, tmax, t, v, back);
+        u = back ? 1.0f : 0.0f;
+    } else if ((KINDS & KIND_BIT(TGHIP_REC_SPHERE)) && kind == TGHIP_REC_SPHERE) {
         bool back;
         if (UNIFORM) ok = sphereTest(asConst(s.objects) + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
         else         ok = sphereTest(s.objects + TGHIP_REC_OBJECT(meta), ray, tmax, t, back);
         u = back ? 1.0f : 0.0f;
+    } else {
+        ok = false;                                    /* instance records are entered, not tested (traverseClosestInst) */
     }
     if (ok) {
         tmax = t;
@@ -1073,11 +1111,11 @@ PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
     }
     return ok;
 }
-template<bool UNIFORM>
+template<bool UNIFORM, uint32_t KINDS = KINDS_ALL>
 PT_DEV void testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit)
 {
     uint32_t meta;
-    (void)testRecord<UNIFORM>(s, ri, ray, tmax, hit, meta);
+    (void)testRecord<UNIFORM, KINDS>(s, ri, ray, tmax, hit, meta);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1139,6 +1177,11 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         info.u = hit.y; info.v = hit.z;
         info.bsdf = o.bsdf;
         info.backSide = dot(ray.d, info.Ng) >= 0.0f;
+    } else if ((M & FEAT_SOLIDS) && kind == TGHIP_REC_DISK) {    /* Disk.cpp:114-129 */
+        info.Ng = info.Ns = ld3(o.normal);
+        diskSurface(o, info.p, hit.z, info.u, info.v);
+        info.bsdf = o.bsdf;
+        info.backSide = hit.y != 0.0f;
     } else if (!(M & FEAT_SOLIDS) || kind == TGHIP_REC_CUBE) {   /* Cube.cpp:157-170 */
         cubeSurface(o, info.p, info.Ng, info.u, info.v);
         info.Ns = info.Ng;
@@ -1199,6 +1242,13 @@ PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, Li
         cubeSurface(o, ray.o + ray.d*lh.t, lh.n, lh.u, lh.v);
         return true;
     }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_DISK) {       /* Disk::intersect + intersectionInfo */
+        float rSq;
+        if (!diskTest(&o, ray, ray.tmax, lh.t, rSq, lh.backSide)) return false;
+        diskSurface(o, ray.o + ray.d*lh.t, rSq, lh.u, lh.v);
+        lh.n = ld3(o.normal);
+        return true;
+    }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_SPHERE) {     /* Sphere::intersect + intersectionInfo */
         if (!sphereTest(&o, ray, ray.tmax, lh.t, lh.backSide)) return false;
         sphereSurface(o, ray.o + ray.d*lh.t, lh.n, lh.u, lh.v);
@@ -1230,6 +1280,12 @@ PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p, const 
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube.cpp:291-295 */
         f3 hp = p + w*lh.t;
         return lengthSq(p - hp)/(-dot(w, lh.n)*o.area);
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_DISK) {       /* Disk::directPdf (Disk.cpp:228-235) */
+        f3 n = ld3(o.normal);
+        float cosTheta = fabsf(dot(n, w));
+        float t = dot(n, ld3(o.pos) - p)/dot(n, w);
+        return t*t/(cosTheta*o.scale[0]*o.scale[0]*PT_PI);
     }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_SPHERE) {     /* Sphere.cpp:216-222 */
         float dist = length(ld3(o.pos) - p);
@@ -1267,6 +1323,24 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         if (cosTheta <= 0.0f)
             return false;
         pdf = rSq/(cosTheta*o.area);
+        return true;
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_DISK) {       /* Disk::sampleDirect (Disk.cpp:178-194) */
+        f3 n = ld3(o.normal), center = ld3(o.pos);
+        if (dot(n, p - center) < 0.0f)
+            return false;
+        float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
+        float phi = xi0*PT_TWO_PI, rr = sqrtf(xi1);                    /* SampleWarp::uniformDisk */
+        float lx = cosf(phi)*rr*o.scale[0], ly = sinf(phi)*rr*o.scale[0];
+        f3 q = center + ld3(o.edge1)*lx + ld3(o.edge0)*ly;
+        f3 L = q - p;
+        float rSq = lengthSq(L);
+        dist = sqrtf(rSq);
+        d = L/dist;
+        if (-dot(d, n) < o.scale[1])
+            return false;
+        float cosTheta = -dot(n, d);
+        pdf = rSq/(cosTheta*o.scale[0]*o.scale[0]*PT_PI);
         return true;
     }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube::sampleDirect / samplePosition / sampleFace (Cube.cpp:229-245,189-213,42-55) */
@@ -1355,6 +1429,23 @@ PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
         f3 lp = mat3TMul(o.rot, p - ld3(o.pos));
         f3 ap = mk3(fmaxf(fabsf(lp.x), 0.0f), fmaxf(fabsf(lp.y), 0.0f), fmaxf(fabsf(lp.z), 0.0f));
         return max3(ld3(s.textures[o.emission].avg))*o.face_cdf[2]/lengthSq(ap);
+    }
+    if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_DISK) {       /* Disk::approximateRadiance (Disk.cpp:253-281) */
+        if (o.emission < 0) return 0.0f;
+        f3 n = ld3(o.normal);
+        f3 coneD = p - ld3(o.base);
+        if (dot(coneD, n)/length(coneD) < o.scale[1])
+            return 0.0f;
+        f3 dd = ld3(o.pos) - p;
+        f3 e0 = ld3(o.edge0)*o.scale[0], e1 = ld3(o.edge1)*o.scale[0];
+        f3 R0 = dd - e0 - e1;
+        f3 R1 = R0 + e0*2.0f;
+        f3 R2 = R1 + e1*2.0f;
+        f3 R3 = R0 + e1*2.0f;
+        f3 n0 = normalized(cross(R0, R1)), n1 = normalized(cross(R1, R2));
+        f3 n2 = normalized(cross(R2, R3)), n3 = normalized(cross(R3, R0));
+        float Q = acosf(dot(n0, n1)) + acosf(dot(n1, n2)) + acosf(dot(n2, n3)) + acosf(dot(n3, n0));
+        return (PT_TWO_PI - fabsf(Q))*max3(ld3(s.textures[o.emission].avg));
     }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_SPHERE) {     /* Sphere.cpp:266-271, 33-40 */
         if (o.emission < 0) return 0.0f;

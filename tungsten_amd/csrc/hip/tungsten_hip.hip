@@ -260,7 +260,8 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
 // are busy, the idle lanes take the next rays of the workgroup's queue (one wave-aggregated LDS atomic) and join
 // the traversal loop.  One loop iteration advances every busy lane by one BVH node or one leaf.
 // Dynamic LDS: [expanded queue, 2 B per slot][node stacks, bvhDepth ints per thread].
-template<bool COUNT>
+// SOLIDS: the scene has cube / sphere / disk records somewhere; without them only triangle and quad tests are compiled in
+template<bool COUNT, bool SOLIDS = true>
 __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsDyn[];
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
                     uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
                     for (uint32_t r = firstRec; r < firstRec + count; ++r) {
                         if (COUNT) prims++;
-                        testRecord<false>(s, r, ray, tmax, hit);
+                        testRecord<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, r, ray, tmax, hit);
                     }
                     pop = true;
                 }
@@ -413,6 +414,12 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
 //   FUSE_LOOP    (with both of the above, scenes without class-1 materials) the workgroup runs its slots to completion
 //                inside ONE launch: nothing it reads or writes is shared with another workgroup, so the wavefront
 //                iterations need no grid-wide synchronisation -- the queues simply stay in LDS between iterations.
+// record kinds a shading variant's fused traversal has to test: the lean variant's scenes hold quads and cubes only
+constexpr uint32_t shadeKinds(uint32_t M)
+{
+    return (M & FEAT_SOLIDS) ? KINDS_ALL
+                             : (KIND_BIT(TGHIP_REC_QUAD) | KIND_BIT(TGHIP_REC_CUBE) | ((M & FEAT_TRIANGLES) ? KIND_BIT(TGHIP_REC_TRIANGLE) : 0u));
+}
 #define FUSE_TRACE  1
 #define FUSE_SHADOW 2
 #define FUSE_LOOP   4
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                 // TraceableScene::intersect inline: the flat record list, walked uniformly by the wave
                 RayD r0;
                 r0.o = xyz(ro); r0.d = xyz(rd); r0.tmin = ro.w; r0.tmax = rd.w;
-                hit = traverseClosest<true, true>(sg, r0, nullptr, 0, fusedNodes, fusedPrims);
+                hit = traverseClosest<true, true, shadeKinds(M)>(sg, r0, nullptr, 0, fusedNodes, fusedPrims);
                 fusedClosest++;
                 int ri = __float_as_int(hit.w);
                 toComplex = ri >= 0 && at32(sg.rec_class, (uint32_t)ri) != 0;
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                                     if (FUSE & FUSE_SHADOW) {
                                                         sr.tmax = lh.t;
                                                         fusedShadow++;
-                                                        if (!traverseOccluded<true, true>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
+                                                        if (!traverseOccluded<true, true, shadeKinds(M)>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
                                                             inlineResult = inlineResult + lightF;
                                                     } else {
                                                         slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                                 if (FUSE & FUSE_SHADOW) {
                                                     sr.tmax = lh.t;
                                                     fusedShadow++;
-                                                    if (!traverseOccluded<true, true>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
+                                                    if (!traverseOccluded<true, true, shadeKinds(M)>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
                                                         inlineResult = inlineResult + bsdfF;
                                                 } else {
                                                     slotF4(st, A_SH_D1, slot) = mk4(wog, lh.t);
@@ -934,7 +941,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
 #ifndef SHADOW_DYN_BOUNDS
 #define SHADOW_DYN_BOUNDS __launch_bounds__(512)
 #endif
-template<bool COUNT>
+template<bool COUNT, bool SOLIDS = true>
 __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsDyn[];
@@ -1051,7 +1058,7 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
                     float tmax = ray.tmax;
                     float4 hit;
                     uint32_t meta;
-                    if (testRecord<false>(s, q, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                    if (testRecord<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, q, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
                         occluded = true;
                 }
             }
@@ -1242,6 +1249,7 @@ struct tghip_ctx {
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
     bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, MASK_FULL shading
     bool thinlens = false;                // thin-lens camera: passes run the EXT kernel variants (PT_PASS_THINLENS)
+    bool haveSolids = false;              // cube / sphere / disk records: the dynamic-fetch kernels' SOLIDS variants
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
@@ -1502,10 +1510,10 @@ static void chooseThreads(tghip_ctx *ctx)
     const bool dyn = ctx->dynamicFetch && !inst;               // the dynamic-fetch kernels are single-level
     ctx->thrClosest = flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
                     : inst ? pickThreads(ctx, k_trace_closest<false, false, true>, 512, 1)
-                    : dyn ? pickThreads(ctx, k_trace_closest_dyn<false>, 320, 2)   // 20 waves/CU measured best (profiles/README.md)
+                    : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
     if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
-        ctx->thrShadow = pickThreads(ctx, k_trace_shadow_dyn<false>, 256, 2);   // measured: 192 / 256 / 320 / 384 threads = 525 / 462 / 633 / 619 us per launch
+        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_dyn<false, true>, 256, 2) : pickThreads(ctx, k_trace_shadow_dyn<false, false>, 256, 2);   // measured: 192 / 256 / 320 / 384 threads = 525 / 462 / 633 / 619 us per launch
     else if (inst)
         ctx->thrShadow = (ctx->haveForward || ctx->haveMeshLight) ? pickThreads(ctx, k_trace_shadow<false, true, false, true>, 512, 1)
                                                                    : pickThreads(ctx, k_trace_shadow<false, false, false, true>, 512, 1);
@@ -1647,7 +1655,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 ctx->error = "sampled mesh emitter without a valid light_tris block";
                 return TGHIP_E_INVALID;
             }
-        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE) {
+        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE && t != TGHIP_OBJ_DISK) {
             ctx->error = "unknown emitter type";
             return TGHIP_E_UNSUPPORTED;
         }
@@ -1715,7 +1723,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     {
         std::vector<uint32_t> typeMask(sd->num_bsdfs, 0u);
         std::vector<uint8_t> recClass(std::max<uint32_t>(sd->num_recs, 1u), 0);
-        ctx->haveComplex = false; ctx->complexMask = 0; ctx->haveForward = false;
+        ctx->haveComplex = false; ctx->complexMask = 0; ctx->haveForward = false; ctx->haveSolids = false;
         for (uint32_t i = 0; i < sd->num_bsdfs; ++i) {
             typeMask[i] = bsdfTypeMask(sd, int(i), 0);
             if (sd->bsdfs[i].lobes & TGHIP_LOBE_FORWARD) ctx->haveForward = true;
@@ -1724,7 +1732,8 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             uint32_t meta = sd->recs[i].meta;
             if (TGHIP_REC_KIND(meta) == TGHIP_REC_INSTANCE)
                 continue;                    // never a hit record itself: hits are the master's triangles
-            if (TGHIP_REC_KIND(meta) > TGHIP_REC_INSTANCE) { ctx->error = "unknown primitive record kind"; return TGHIP_E_INVALID; }
+            if (TGHIP_REC_KIND(meta) > TGHIP_REC_DISK) { ctx->error = "unknown primitive record kind"; return TGHIP_E_INVALID; }
+            if (TGHIP_REC_KIND(meta) != TGHIP_REC_TRIANGLE && TGHIP_REC_KIND(meta) != TGHIP_REC_QUAD) ctx->haveSolids = true;
             int bi = TGHIP_REC_KIND(meta) == TGHIP_REC_TRIANGLE ? sd->tri_attrs[i].bsdf : sd->objects[TGHIP_REC_OBJECT(meta)].bsdf;
             if (bi < 0 || uint32_t(bi) >= sd->num_bsdfs) { ctx->error = "primitive record without a valid bsdf"; return TGHIP_E_INVALID; }
             bool simple = (typeMask[size_t(bi)] & ~MASK_SIMPLE) == 0 && !(sd->bsdfs[bi].lobes & TGHIP_LOBE_FORWARD);
@@ -1831,8 +1840,10 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
         return false;
     }
     if (!flat && !closestWalk && ctx->dynamicFetch) {
-        hipLaunchKernelGGL(k_trace_shadow_dyn<COUNT>, dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
-                           ctx->scene, st, pp, iterTag);
+        if (ctx->haveSolids) hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, true>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
+                                                ctx->scene, st, pp, iterTag);
+        else                 hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, false>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
+                                                ctx->scene, st, pp, iterTag);
         return true;
     }
 #define SHADOW_LAUNCH(FWD, FLAT) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, FLAT>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
@@ -1932,8 +1943,10 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             } else {
                 if (ctx->dynamicFetch) {
                     const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
-                    if (count) hipLaunchKernelGGL(k_trace_closest_dyn<true>, dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->stream, s, st);
-                    else       hipLaunchKernelGGL(k_trace_closest_dyn<false>, dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->stream, s, st);
+#define CLOSEST_DYN(C, S) hipLaunchKernelGGL((k_trace_closest_dyn<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->stream, s, st)
+                    if (ctx->haveSolids) { if (count) CLOSEST_DYN(true, true); else CLOSEST_DYN(false, true); }
+                    else                 { if (count) CLOSEST_DYN(true, false); else CLOSEST_DYN(false, false); }
+#undef CLOSEST_DYN
                 } else {
                     if (count) hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
                     else       hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);

@@ -604,6 +604,11 @@ std::shared_ptr<Primitive> Scene::instantiatePrimitive(const JsonValue &v) const
         p->type = type == "quad" ? Primitive::Quad : type == "cube" ? Primitive::Cube : Primitive::Sphere;
         if (const JsonValue &b = v["bsdf"]) p->bsdfs.push_back(fetchBsdf(b));
         else p->bsdfs.push_back(defaultBsdf());
+    } else if (type == "disk") {          // Disk::fromJson (Disk.cpp:43-50)
+        p->type = Primitive::Disk;
+        v.getField("cone_angle", p->coneAngle);
+        if (const JsonValue &b = v["bsdf"]) p->bsdfs.push_back(fetchBsdf(b));
+        else p->bsdfs.push_back(defaultBsdf());
     } else if (type == "infinite_sphere") {
         p->type = Primitive::InfiniteSphere;
         v.getField("sample", p->doSample);
@@ -749,6 +754,26 @@ void Primitive::prepareForRender()
         invArea = 1.0f/area;
         bounds = Box3f();
         bounds.grow(pos - Vec3f(radius)); bounds.grow(pos + Vec3f(radius));
+        break;
+    } case Disk: { // Disk.cpp:303-315, bounds :283-291
+        pos = transform*Vec3f(0.0f);
+        float r = (Mat4f::scale(transform.extractScaleVec())*Vec3f(1.0f, 0.0f, 1.0f)).max();
+        normal = transform.transformVector(Vec3f(0.0f, 1.0f, 0.0f)).normalized();
+        area = r*r*PI;
+        invArea = 1.0f/area;
+        {   // TangentFrame(n) (math/TangentFrame.hpp:22-31)
+            float sign = copysignf(1.0f, normal.z());
+            const float a = -1.0f/(sign + normal.z());
+            const float b = normal.x()*normal.y()*a;
+            edge0 = Vec3f(1.0f + sign*normal.x()*normal.x()*a, sign*b, -sign*normal.x());   // tangent
+            edge1 = Vec3f(b, sign + normal.y()*normal.y()*a, -normal.y());                  // bitangent
+        }
+        float coneRad = coneAngle*(PI/180.0f);
+        scale = Vec3f(r, std::cos(coneRad), 0.0f);
+        base = pos - normal/std::sin(coneRad);                                              // _coneBase
+        bounds = Box3f();
+        bounds.grow(pos - edge0*r - edge1*r); bounds.grow(pos + edge0*r - edge1*r);
+        bounds.grow(pos + edge0*r + edge1*r); bounds.grow(pos - edge0*r + edge1*r);
         break;
     } case InfiniteSphere: { // InfiniteSphere.cpp:280-286
         rot = transform.extractRotation();

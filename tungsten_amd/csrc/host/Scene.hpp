@@ -75,7 +75,7 @@ struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp
 
 struct Primitive
 {
-    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5 };
+    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6 };
     std::string name;
     Type type = Quad;
     Mat4f transform;
@@ -88,6 +88,8 @@ struct Primitive
     std::vector<MeshTriangle> tris;
     // infinite sphere
     bool doSample = true;
+    // disk (primitives/Disk.hpp): emission confined to a cone around the normal
+    float coneAngle = 90.0f;
     // instances (primitives/Instance.hpp:13-31): rigid placements (position + rotation) of master primitives
     std::vector<std::shared_ptr<Primitive>> masters;
     std::string instanceFile;
