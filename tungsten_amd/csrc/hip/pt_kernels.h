@@ -129,6 +129,14 @@ struct PassParams {
     // per SampleRecord (nullptr unless TGHIP_PASS_RECORDS): first sample index, samples per pixel this pass, and the
     // offset of the record's 16 x count block in `lum`; spp_begin/spp_end are then RELATIVE to the record's first index
     const uint32_t *rec_index, *rec_count, *rec_lum;
+    // Work items of a record pass are enumerated without gaps: the owned records are sorted by descending sample count,
+    // so the pixels that still have samples in chunk c are a PREFIX of the sorted pixel list (16 per record).  Item
+    // w (+ item_base) -> chunk c with rec_chunk_start[c] <= w < rec_chunk_start[c + 1] (rec_hint[w/64] = c of item
+    // 64*(w/64)), pixel slot j = w - rec_chunk_start[c] -> record rec_sorted[j/16], pixel j%16 of it.
+    const uint32_t *rec_sorted, *rec_chunk_start, *rec_hint;
+    uint32_t item_base;        // first item of this batch in the pass's enumeration
+    uint32_t num_sorted;       // owned records
+    uint32_t num_chunks;       // chunks of the record with the most samples
     float *lum;                // luminance of every sample of the pass, in the order SampleRecord::addSample saw them
 };
 

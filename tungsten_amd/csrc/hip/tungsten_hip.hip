@@ -124,19 +124,34 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
                 dead = true;
             } else {
                 uint32_t w = (uint32_t)w64;
-                uint32_t c = w/pp.pix_slots, j = w - c*pp.pix_slots;
-                uint32_t x, y;
-                if (slotPixel(pp, j, x, y)) {
+                uint32_t c, j, x, y;
+                bool inImage;
+                uint32_t recOfItem = 0;
+                if (records) {
+                    // gap-free enumeration of a record pass (PassParams): chunk from the hint table, then the sorted pixel list
+                    uint32_t wAbs = w + pp.item_base;
+                    c = at32(pp.rec_hint, wAbs >> 6);
+                    while (wAbs >= at32(pp.rec_chunk_start, c + 1u)) ++c;
+                    j = wAbs - at32(pp.rec_chunk_start, c);
+                    recOfItem = at32(pp.rec_sorted, j >> 4);
+                    x = (recOfItem % pp.variance_w)*4u + (j & 3u);
+                    y = (recOfItem/pp.variance_w)*4u + ((j >> 2) & 3u);
+                    inImage = x < pp.width && y < pp.height;   // records on the right / bottom edge reach past the image
+                } else {
+                    c = w/pp.pix_slots; j = w - c*pp.pix_slots;
+                    inImage = slotPixel(pp, j, x, y);
+                }
+                if (inImage) {
                     uint32_t rel = pp.spp_begin + c*pp.chunk, relEnd = pp.spp_end, first = 0u;
                     bool take = true;
                     if (records) {
                         // renderTile (PathTraceIntegrator.cpp:142-147): the pixel's record says which samples it traces
-                        uint32_t rec = (x >> 2) + (y >> 2)*pp.variance_w;
-                        uint32_t cnt = at32(pp.rec_count, rec);
-                        first = at32(pp.rec_index, rec);
-                        relEnd = min(relEnd, cnt);
-                        take = rel < relEnd;                     // this pixel has no samples in the chunk: next item
-                        lumBase = at32(pp.rec_lum, rec) + (((y & 3u) << 2) | (x & 3u))*cnt - first;
+                        uint32_t cnt = at32(pp.rec_count, recOfItem);
+                        first = at32(pp.rec_index, recOfItem);
+                        rel = c*pp.chunk;
+                        relEnd = cnt;
+                        take = rel < relEnd;                     // (always, by construction of the enumeration)
+                        lumBase = at32(pp.rec_lum, recOfItem) + (((y & 3u) << 2) | (x & 3u))*cnt - first;
                     }
                     if (take) {
                         want = false;
@@ -1155,6 +1170,37 @@ __global__ __launch_bounds__(256) void k_resolve(PathState st, PassParams pp, fl
     fbCount[pixel] += cnt;
 }
 
+// k_resolve of a record pass (gap-free item enumeration, PassParams): one thread per pixel slot of the sorted record list
+// sums the pixel's items of this batch in chunk order.
+__global__ __launch_bounds__(256) void k_resolve_records(PathState st, PassParams pp, float *fbSum, uint32_t *fbCount)
+{
+    uint32_t j = blockIdx.x*blockDim.x + threadIdx.x;
+    if (j >= pp.num_sorted*16u)
+        return;
+    uint32_t rec = pp.rec_sorted[j >> 4];
+    uint32_t x = (rec % pp.variance_w)*4u + (j & 3u), y = (rec/pp.variance_w)*4u + ((j >> 2) & 3u);
+    if (x >= pp.width || y >= pp.height)
+        return;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    uint32_t cnt = 0;
+    for (uint32_t c = 0; c < pp.num_chunks; ++c) {
+        uint32_t start = pp.rec_chunk_start[c];
+        if (j >= pp.rec_chunk_start[c + 1u] - start)
+            break;                               // chunks only get shorter: the pixel has no further items
+        uint32_t w = start + j;
+        if (w < pp.item_base || w - pp.item_base >= pp.total_items)
+            continue;                            // item of another batch
+        float4 a = at32(st.partial, w - pp.item_base);
+        sx += a.x; sy += a.y; sz += a.z;
+        cnt += __float_as_uint(a.w);
+    }
+    uint32_t pixel = x + y*pp.width;
+    fbSum[(size_t)pixel*3 + 0] += sx;
+    fbSum[(size_t)pixel*3 + 1] += sy;
+    fbSum[(size_t)pixel*3 + 2] += sz;
+    fbCount[pixel] += cnt;
+}
+
 // SampleRecord::addSample (path_tracer/SampleRecord.hpp:46-58) over the luminances the pass wrote, one thread per
 // record, in the order the reference's renderTile visits them (PathTraceIntegrator.cpp:136-156: the tile's pixels
 // row by row, each pixel's samples in index order), so mean and running variance round exactly like the CPU's.
@@ -1224,7 +1270,9 @@ struct tghip_ctx {
     TgHipSampleRecord *dRecords = nullptr;   // SampleRecords, ceil(W/4) x ceil(H/4)
     float *lum = nullptr;                 // per-sample luminance of the running pass
     size_t lumCap = 0;
-    std::vector<uint32_t> hostRecLum, hostRecIndex, hostRecCount;
+    std::vector<uint32_t> hostRecLum, hostRecIndex, hostRecCount, hostSorted, hostChunkStart, hostHint;
+    uint32_t *dSorted = nullptr, *dChunkStart = nullptr, *dHint = nullptr;   // gap-free item enumeration of record passes
+    size_t sortedCap = 0, chunkStartCap = 0, hintCap = 0;
 
     // path pool
     DeviceBuffers poolMem;
@@ -1583,6 +1631,9 @@ void tghip_destroy(tghip_ctx *ctx)
     ctx->poolMem.release();
     ctx->extMem.release();
     if (ctx->lum) (void)hipFree(ctx->lum);
+    if (ctx->dSorted) (void)hipFree(ctx->dSorted);
+    if (ctx->dChunkStart) (void)hipFree(ctx->dChunkStart);
+    if (ctx->dHint) (void)hipFree(ctx->dHint);
     if (ctx->fbSum) (void)hipFree(ctx->fbSum);
     if (ctx->fbCount) (void)hipFree(ctx->fbCount);
     if (ctx->partial) (void)hipFree(ctx->partial);
@@ -1972,7 +2023,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     }
     float *sum = ctx->extSum ? ctx->extSum : ctx->fbSum;
     uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
-    hipLaunchKernelGGL(k_resolve, dim3((pp.pix_slots + 255)/256), dim3(256), 0, ctx->stream, st, pp, sum, cnt);
+    if (pp.rec_sorted) hipLaunchKernelGGL(k_resolve_records, dim3((pp.num_sorted*16u + 255)/256), dim3(256), 0, ctx->stream, st, pp, sum, cnt);
+    else               hipLaunchKernelGGL(k_resolve, dim3((pp.pix_slots + 255)/256), dim3(256), 0, ctx->stream, st, pp, sum, cnt);
     HIP_TRY(ctx, hipGetLastError());
     return ctx->hostLive[1] ? TGHIP_E_ABORTED : TGHIP_OK;
 }
@@ -2064,19 +2116,73 @@ int tghip_wait(tghip_ctx *ctx)
     if (ownedTiles == 0 || spp == 0)
         return ctx->passResult = TGHIP_OK;
 
-    // Batches: work items = (pixel slot of an owned tile) x (chunk of `chunkSamples` sample indices).  One batch
-    // holds at most maxItems items (16 B of partial sum each); larger passes are split by sample range first,
-    // then by tiles.
     const uint32_t chunk = uint32_t(std::max(ctx->chunkSamples, 1));
     const uint64_t maxItems = uint64_t(std::max<long long>(ctx->maxItems, 256));
+    const bool recordPass = (pass.flags & TGHIP_PASS_RECORDS) != 0;
+    uint64_t recordItems = 0;
+    if (recordPass) {
+        // Gap-free work items for uneven per-record sample counts (PassParams): owned records sorted by descending count,
+        // chunk c covers the first chunkStart[c + 1] - chunkStart[c] pixel slots of that order.
+        std::vector<uint32_t> &sorted = ctx->hostSorted, &start = ctx->hostChunkStart, &hint = ctx->hostHint;
+        const std::vector<uint32_t> &cnt = ctx->hostRecCount;
+        sorted.clear();
+        for (uint32_t r = 0; r < numRecords; ++r) {
+            uint32_t rx = r % base.variance_w, ry = r/base.variance_w;
+            if (((rx >> 2) + (ry >> 2)*tilesX) % shardCount == pass.shard_index && cnt[r] > 0)
+                sorted.push_back(r);
+        }
+        std::stable_sort(sorted.begin(), sorted.end(), [&cnt](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+        const uint32_t numChunks = (spp + chunk - 1)/chunk;
+        start.assign(size_t(numChunks) + 2, 0u);
+        size_t alive = sorted.size();                // records with cnt > c*chunk: a prefix of `sorted`
+        for (uint32_t c = 0; c < numChunks; ++c) {
+            while (alive > 0 && cnt[sorted[alive - 1]] <= uint64_t(c)*chunk) --alive;
+            recordItems += uint64_t(alive)*16u;
+            if (recordItems >= (1ull << 32)) {
+                ctx->error = "pass too large for SampleRecord keeping (more than 2^32 work items per device): lower spp_step";
+                return ctx->passResult = TGHIP_E_UNSUPPORTED;
+            }
+            start[c + 1] = uint32_t(recordItems);
+        }
+        start[numChunks + 1] = 0xFFFFFFFFu;          // sentinel for the device's `while (w >= start[c + 1])`
+        hint.resize(size_t((recordItems + 63)/64) + 1);
+        for (size_t g = 0, c = 0; g < hint.size(); ++g) {
+            while (c + 1 < numChunks && uint64_t(g)*64 >= start[c + 1]) ++c;
+            hint[g] = uint32_t(c);
+        }
+        auto upload = [&](uint32_t *&dev, size_t &cap, const std::vector<uint32_t> &src) -> int {
+            if (cap < src.size()) {
+                if (dev) (void)hipFree(dev);
+                dev = nullptr; cap = 0;
+                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dev), std::max<size_t>(src.size(), 1)*sizeof(uint32_t)));
+                cap = src.size();
+            }
+            if (!src.empty())
+                HIP_TRY(ctx, hipMemcpyAsync(dev, src.data(), src.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            return TGHIP_OK;
+        };
+        int urc;
+        if ((urc = upload(ctx->dSorted, ctx->sortedCap, sorted)) != TGHIP_OK) return ctx->passResult = urc;
+        if ((urc = upload(ctx->dChunkStart, ctx->chunkStartCap, start)) != TGHIP_OK) return ctx->passResult = urc;
+        if ((urc = upload(ctx->dHint, ctx->hintCap, hint)) != TGHIP_OK) return ctx->passResult = urc;
+        base.rec_sorted = ctx->dSorted; base.rec_chunk_start = ctx->dChunkStart; base.rec_hint = ctx->dHint;
+        base.num_sorted = uint32_t(sorted.size());
+        base.num_chunks = numChunks;
+        if (recordItems == 0)
+            return ctx->passResult = TGHIP_OK;
+    }
+
+    // Batches: work items = (pixel slot of an owned tile) x (chunk of `chunkSamples` sample indices).  One batch
+    // holds at most maxItems items (16 B of partial sum each); larger passes are split by sample range first,
+    // then by tiles.  (Record passes: consecutive ranges of the gap-free enumeration above.)
     const uint32_t chunksAll = (spp + chunk - 1)/chunk;
     uint32_t tilesPerBatch = ownedTiles, chunksPerBatch = chunksAll;
-    if (uint64_t(ownedTiles)*256*chunksAll > maxItems) {
+    if (!recordPass && uint64_t(ownedTiles)*256*chunksAll > maxItems) {
         chunksPerBatch = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(chunksAll, maxItems/(uint64_t(ownedTiles)*256))));
         if (uint64_t(ownedTiles)*256*chunksPerBatch > maxItems)
             tilesPerBatch = uint32_t(std::max<uint64_t>(1, maxItems/(256ull*chunksPerBatch)));
     }
-    const uint64_t batchItems = uint64_t(tilesPerBatch)*256*chunksPerBatch;
+    const uint64_t batchItems = recordPass ? std::min<uint64_t>(recordItems, maxItems) : uint64_t(tilesPerBatch)*256*chunksPerBatch;
     uint64_t wantSlots = std::min<uint64_t>(uint64_t(ctx->maxSlots), batchItems);
     {
         // the run-to-completion kernel (runBatch) gives every thread its own slots for the whole launch: one slot per
@@ -2098,7 +2204,21 @@ int tghip_wait(tghip_ctx *ctx)
     HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.live[1], 0, sizeof(uint32_t), ctx->stream));   // abort flag
 
     HIP_TRY(ctx, hipEventRecord(ctx->evA, ctx->stream));
-    for (uint32_t sppFirst = sppBegin; sppFirst < sppEnd && rc == TGHIP_OK; sppFirst += chunksPerBatch*chunk) {
+    for (uint64_t w0 = 0; recordPass && w0 < recordItems && rc == TGHIP_OK; w0 += batchItems) {
+        PassParams pp = base;
+        pp.spp_begin = 0; pp.spp_end = spp; pp.seed = pass.seed;
+        pp.chunk = chunk;
+        pp.chunks = chunksAll;
+        pp.pix_slots = 1;                            // unused by the record enumeration
+        pp.item_base = uint32_t(w0);
+        pp.total_items = uint32_t(std::min<uint64_t>(batchItems, recordItems - w0));
+        pp.first_tile = 0;
+        pp.shard_index = pass.shard_index; pp.shard_count = shardCount;
+        pp.tiles_x = tilesX; pp.num_tiles = numTiles;
+        pp.width = w; pp.height = h;
+        rc = runBatch(ctx, pp);
+    }
+    for (uint32_t sppFirst = sppBegin; !recordPass && sppFirst < sppEnd && rc == TGHIP_OK; sppFirst += chunksPerBatch*chunk) {
         const uint32_t sppLast = uint32_t(std::min<uint64_t>(uint64_t(sppFirst) + uint64_t(chunksPerBatch)*chunk, sppEnd));
         for (uint32_t first = 0; first < ownedTiles; first += tilesPerBatch) {
             PassParams pp = base;
