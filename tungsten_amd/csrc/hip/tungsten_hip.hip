@@ -33,7 +33,10 @@
 #define MASK_SIMPLE  (TYPES_SIMPLE | FEAT_ALL)
 #define MASK_LEAN    TYPES_SIMPLE        /* analytic primitives, constant/checker textures, one area light (Cornell box) */
 #ifndef SIMPLE_WAVES
-#define SIMPLE_WAVES 3
+#define SIMPLE_WAVES 3   /* measured: 4 waves/SIMD (128 VGPRs, spills) is 10 % slower on materialtest's k_shade */
+#endif
+#ifndef COAT_WAVES
+#define COAT_WAVES   2   /* measured: 3 waves/SIMD is neutral on materialtest (480 vs 476 us), +3 % on mesh1m's k_shade */
 #endif
 #ifndef LEAN_WAVES
 #define LEAN_WAVES   2   /* measured: 2 waves/SIMD without scratch beats 3 with 108 B of scratch (kernel is VALU-bound) */
@@ -1572,7 +1575,7 @@ static void chooseThreads(tghip_ctx *ctx)
     if (ctx->haveMeshLight || inst) ctx->thrShadeSimple = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     else ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES, 0>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>, 256, 0);
     if (ctx->haveMeshLight || inst)                 ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
-    else if ((ctx->complexMask & ~MASK_COAT) == 0)  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, 2, 0>, 256, 0);
+    else if ((ctx->complexMask & ~MASK_COAT) == 0)  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, COAT_WAVES, 0>, 256, 0);
     else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
     else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     }
@@ -1867,7 +1870,7 @@ template<uint32_t M, int FUSE>
 static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
     constexpr uint32_t B = M & ~FEAT_QMC;
-    hipLaunchKernelGGL((k_shade<M, (B == MASK_SIMPLE ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : 2), FUSE>), dim3(grid),
+    hipLaunchKernelGGL((k_shade<M, (B == MASK_SIMPLE ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
                        dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0, ctx->stream, ctx->scene, st, pp, cls);
 }
 // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
