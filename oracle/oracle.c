@@ -1579,6 +1579,10 @@ static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, 
         lh->t = ray->tmax; lh->backSide = 0;
         inf_directionToUV(o, ray->d, &lh->u, &lh->v, NULL);
         return 1;
+    } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {     /* InfiniteSphereCap::intersect + intersectionInfo (:60-90) */
+        if (vdot(ray->d, ld3(o->normal)) < o->scale[0]) return 0;
+        lh->t = ray->tmax; lh->backSide = 0; lh->u = lh->v = 0.0f;
+        return 1;
     } else if (o->type == TGHIP_OBJ_CUBE) {            /* Cube::intersect + intersectionInfo */
         if (!cube_test(o, ray, ray->tmax, &lh->t, &lh->backSide)) return 0;
         cube_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), &lh->n, &lh->u, &lh->v);
@@ -1625,6 +1629,8 @@ static float light_directPdf(const TgHipSceneDesc *s, int objIdx, const LightHit
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:469-473 */
         v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
         return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
+    } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {     /* :214-218: uniformSphericalCapPdf */
+        return O_INV_TWO_PI/(1.0f - o->scale[0]);
     } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::directPdf (Disk.cpp:228-235) */
         v3 n = ld3(o->normal);
         float cosTheta = fabsf(vdot(n, lh->w));
@@ -1709,6 +1715,17 @@ static int light_sampleDirect(const TgHipSceneDesc *s, int objIdx, v3 p, Sampler
             return 0;
         *pdf = rSq/(cosTheta*o->area);
         return 1;
+    } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {     /* InfiniteSphereCap::sampleDirect (:130-138) */
+        float xi0 = next1D(smp), xi1 = next1D(smp);
+        float phi = xi0*O_TWO_PI;                      /* SampleWarp::uniformSphericalCap */
+        float z = xi1*(1.0f - o->scale[0]) + o->scale[0];
+        float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
+        v3 local = V(cosf(phi)*r, sinf(phi)*r, z);
+        Frame frame = {ld3(o->normal), ld3(o->edge0), ld3(o->edge1)};
+        *d = toGlobal(&frame, local);
+        *dist = INFINITY;
+        *pdf = O_INV_TWO_PI/(1.0f - o->scale[0]);
+        return 1;
     } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::sampleDirect (Disk.cpp:178-194) */
         v3 n = ld3(o->normal), center = ld3(o->pos);
         if (vdot(n, vsub(p, center)) < 0.0f)
@@ -1785,6 +1802,9 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
         return vmax3(ld3(s->textures[o->emission].avg))*o->face_cdf[2]/dSq;
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:514-517: "unknown" */
         return -1.0f;
+    } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {     /* :220-225 */
+        if (o->emission < 0 || !(o->flags & TGHIP_OBJF_SAMPLE)) return 0.0f;
+        return O_TWO_PI*(1.0f - o->scale[0])*vmax3(ld3(s->textures[o->emission].avg));
     } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::approximateRadiance (Disk.cpp:253-281) */
         if (o->emission < 0) return 0.0f;
         v3 n = ld3(o->normal);
@@ -2055,12 +2075,19 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
     }
     /* handleInfiniteLights (TraceBase.cpp:570-578, TraceableScene.hpp:194-209): the last infinite light wins */
     if (bounce >= minBounces && bounce < maxBounces && s->num_infinite_lights > 0) {
-        int objIdx = s->infinite_lights[s->num_infinite_lights - 1];
-        const TgHipObject *o = &s->objects[objIdx];
-        if (!nee || wasSpecular || !(o->flags & TGHIP_OBJF_SAMPLE)) {
-            float u, v;
-            inf_directionToUV(o, ray.d, &u, &v, NULL);
-            emission = vadd(emission, vmul(throughput, texture_eval(s, o->emission, u, v)));
+        int objIdx = -1;
+        for (uint32_t i = 0; i < s->num_infinite_lights; ++i) {      /* every infinite light is asked; the last hit stays in `data` */
+            const TgHipObject *c = &s->objects[s->infinite_lights[i]];
+            if (c->type != TGHIP_OBJ_INFINITE_SPHERE_CAP || vdot(ray.d, ld3(c->normal)) >= c->scale[0])
+                objIdx = s->infinite_lights[i];
+        }
+        if (objIdx >= 0) {
+            const TgHipObject *o = &s->objects[objIdx];
+            if (!nee || wasSpecular || !(o->flags & TGHIP_OBJF_SAMPLE)) {
+                float u = 0.0f, v = 0.0f;
+                if (o->type == TGHIP_OBJ_INFINITE_SPHERE) inf_directionToUV(o, ray.d, &u, &v, NULL);
+                emission = vadd(emission, vmul(throughput, texture_eval(s, o->emission, u, v)));
+            }
         }
     }
     if (isnan(vsum(throughput) + vsum(emission)))

@@ -438,6 +438,21 @@ def _disks(scene):
          "transform": {"position": [-0.97, 0.8, 0.3], "scale": 0.15, "rotation": [0, 0, -90]}}]
 
 
+def _sun_and_sky(scene):
+    """Roofless Cornell box under a constant sky (infinite_sphere) and a sun (infinite_sphere_cap, 8 degrees, tilted): two
+    infinite lights, both sampled -- chooseLight between them, cap hits on escaping specular/BSDF-sampled paths, the
+    "last infinite light that is hit wins" rule of TraceableScene::intersectInfinites."""
+    scene["primitives"] = [p for p in scene["primitives"] if p["name"] not in ("light", "ceiling")]
+    for i, b in enumerate(scene["bsdfs"]):
+        if b["name"] == "tallBox":
+            scene["bsdfs"][i] = {"name": "tallBox", "type": "mirror", "albedo": [0.9, 0.9, 0.95]}
+    scene["primitives"] += [
+        {"name": "sky", "type": "infinite_sphere", "emission": [0.25, 0.35, 0.6], "sample": True},
+        {"name": "sun", "type": "infinite_sphere_cap", "emission": [60, 52, 40], "cap_angle": 8, "sample": True,
+         "transform": {"rotation": [25, 0, -20]}}]
+
+
+GOLDEN_CASES["cornell_sun_sky"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_sun_and_sky))
 GOLDEN_CASES["cornell_disks"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_disks))
 GOLDEN_CASES["water_caustic"] = (water_caustic, dict(resolution=(64, 36), spp=4))
 

@@ -1254,6 +1254,11 @@ PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, Li
         sphereSurface(o, ray.o + ray.d*lh.t, lh.n, lh.u, lh.v);
         return true;
     }
+    if (o.type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {            /* InfiniteSphereCap::intersect + intersectionInfo (:60-90) */
+        if (dot(ray.d, ld3(o.normal)) < o.scale[0]) return false;
+        lh.t = ray.tmax; lh.backSide = false; lh.u = 0.0f; lh.v = 0.0f;
+        return true;
+    }
     float sinTheta;
     lh.t = ray.tmax; lh.backSide = false;
     infDirectionToUV(o, ray.d, lh.u, lh.v, sinTheta);
@@ -1292,6 +1297,8 @@ PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p, const 
         float cosTheta = sqrtf(fmaxf(dist*dist - o.scale[0]*o.scale[0], 0.0f))/dist;
         return PT_INV_TWO_PI/(1.0f - cosTheta);
     }
+    if (o.type == TGHIP_OBJ_INFINITE_SPHERE_CAP)               /* uniformSphericalCapPdf (InfiniteSphereCap.cpp:214-218) */
+        return PT_INV_TWO_PI/(1.0f - o.scale[0]);
     const TgHipTexture &t = s.textures[o.emission];
     if (!(M & FEAT_BITMAP) || t.type != TGHIP_TEX_BITMAP)
         return PT_INV_FOUR_PI;
@@ -1405,6 +1412,17 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         d = dd;
         return true;
     }
+    if (o.type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {            /* InfiniteSphereCap::sampleDirect (:130-138) */
+        float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
+        float phi = xi0*PT_TWO_PI;                                     /* SampleWarp::uniformSphericalCap */
+        float z = xi1*(1.0f - o.scale[0]) + o.scale[0];
+        float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
+        f3 local = mk3(cosf(phi)*r, sinf(phi)*r, z);
+        d = ld3(o.edge0)*local.x + ld3(o.edge1)*local.y + ld3(o.normal)*local.z;   /* TangentFrame::toGlobal */
+        dist = PT_INF;
+        pdf = PT_INV_TWO_PI/(1.0f - o.scale[0]);
+        return true;
+    }
     const TgHipTexture &t = s.textures[o.emission];
     float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
     dist = PT_INF;
@@ -1467,6 +1485,8 @@ PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
         return (PT_TWO_PI - fabsf(Q))*max3(ld3(s.textures[o.emission].avg));
     }
     if (o.emission < 0 || !(o.flags & TGHIP_OBJF_SAMPLE)) return 0.0f;
+    if (o.type == TGHIP_OBJ_INFINITE_SPHERE_CAP)               /* InfiniteSphereCap.cpp:220-225 */
+        return PT_TWO_PI*(1.0f - o.scale[0])*max3(ld3(s.textures[o.emission].avg));
     return PT_TWO_PI*max3(ld3(s.textures[o.emission].avg));
 }
 

@@ -531,12 +531,20 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             if (__float_as_int(hit.w) < 0) {
                 // path escaped: TraceBase::handleInfiniteLights (TraceBase.cpp:570-578); the last infinite light wins
                 if ((M & FEAT_INFINITE) && bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0) {
-                    int objIdx = s.infinite_lights[s.num_infinite_lights - 1];
-                    const TgHipObject &o = s.objects[objIdx];
-                    if (!nee || wasSpecular || !(o.flags & TGHIP_OBJF_SAMPLE)) {
-                        float u, v, sinTheta;
-                        infDirectionToUV(o, ray.d, u, v, sinTheta);
-                        em = em + throughput*textureEval<M>(s, o.emission, u, v);
+                    // intersectInfinites (TraceableScene.hpp:194-209): every infinite light is asked, the last hit stays
+                    int objIdx = -1;
+                    for (uint32_t li = 0; li < s.num_infinite_lights; ++li) {
+                        const TgHipObject &c = s.objects[s.infinite_lights[li]];
+                        if (c.type != TGHIP_OBJ_INFINITE_SPHERE_CAP || dot(ray.d, ld3(c.normal)) >= c.scale[0])
+                            objIdx = s.infinite_lights[li];
+                    }
+                    if (objIdx >= 0) {
+                        const TgHipObject &o = s.objects[objIdx];
+                        if (!nee || wasSpecular || !(o.flags & TGHIP_OBJF_SAMPLE)) {
+                            float u = 0.0f, v = 0.0f, sinTheta;
+                            if (o.type == TGHIP_OBJ_INFINITE_SPHERE) infDirectionToUV(o, ray.d, u, v, sinTheta);
+                            em = em + throughput*textureEval<M>(s, o.emission, u, v);
+                        }
                     }
                 }
                 state = isnan(sum3(throughput) + sum3(em)) ? ST_TERMINATED_BLACK : ST_TERMINATED;
@@ -1709,7 +1717,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 ctx->error = "sampled mesh emitter without a valid light_tris block";
                 return TGHIP_E_INVALID;
             }
-        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE && t != TGHIP_OBJ_DISK) {
+        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE && t != TGHIP_OBJ_DISK && t != TGHIP_OBJ_INFINITE_SPHERE_CAP) {
             ctx->error = "unknown emitter type";
             return TGHIP_E_UNSUPPORTED;
         }

@@ -565,6 +565,7 @@ float Primitive::powerToRadianceFactor() const
 {
     switch (type) {
     case InfiniteSphere: return INV_FOUR_PI;           // InfiniteSphere.cpp:59-62
+    case InfiniteSphereCap: return INV_TWO_PI/(1.0f - scale[0]);   // InfiniteSphereCap.cpp:36-39
     default:             return INV_PI*invArea;        // Quad.cpp:50-53, Cube.cpp, TriangleMesh.cpp:108-111
     }
 }
@@ -612,6 +613,12 @@ std::shared_ptr<Primitive> Scene::instantiatePrimitive(const JsonValue &v) const
     } else if (type == "infinite_sphere") {
         p->type = Primitive::InfiniteSphere;
         v.getField("sample", p->doSample);
+    } else if (type == "infinite_sphere_cap") {      // InfiniteSphereCap::fromJson (InfiniteSphereCap.cpp:41-50)
+        p->type = Primitive::InfiniteSphereCap;
+        v.getField("sample", p->doSample);
+        v.getField("cap_angle", p->capAngleDeg);
+        if (v["skydome"])
+            throw JsonLoadException("infinite_sphere_cap 'skydome' pivots (procedural sky) are outside the path_tracer_hip hot-path scope");
     } else if (type == "instances") {
         // Instance::fromJson (Instance.cpp:60-93)
         p->type = Primitive::Instances;
@@ -778,6 +785,15 @@ void Primitive::prepareForRender()
     } case InfiniteSphere: { // InfiniteSphere.cpp:280-286
         rot = transform.extractRotation();
         invRot = rot.transpose();
+        break;
+    } case InfiniteSphereCap: { // InfiniteSphereCap.cpp:233-249
+        normal = transform.transformVector(Vec3f(0.0f, 1.0f, 0.0f)).normalized();      // _capDir
+        scale = Vec3f(std::cos(capAngleDeg*(PI/180.0f)), 0.0f, 0.0f);                  // _cosCapAngle
+        float sign = copysignf(1.0f, normal.z());                                     // TangentFrame(_capDir)
+        const float a = -1.0f/(sign + normal.z());
+        const float b = normal.x()*normal.y()*a;
+        edge0 = Vec3f(1.0f + sign*normal.x()*normal.x()*a, sign*b, -sign*normal.x());
+        edge1 = Vec3f(b, sign + normal.y()*normal.y()*a, -normal.y());
         break;
     } case Instances: { // Instance.cpp:392-428
         for (auto &m : masters) {

@@ -75,7 +75,7 @@ struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp
 
 struct Primitive
 {
-    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6 };
+    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6, InfiniteSphereCap = 7 };
     std::string name;
     Type type = Quad;
     Mat4f transform;
@@ -90,6 +90,8 @@ struct Primitive
     bool doSample = true;
     // disk (primitives/Disk.hpp): emission confined to a cone around the normal
     float coneAngle = 90.0f;
+    // infinite sphere cap (primitives/InfiniteSphereCap.hpp): emission from directions within cap_angle of the transform's up axis
+    float capAngleDeg = 10.0f;
     // instances (primitives/Instance.hpp:13-31): rigid placements (position + rotation) of master primitives
     std::vector<std::shared_ptr<Primitive>> masters;
     std::string instanceFile;
@@ -104,10 +106,10 @@ struct Primitive
     float area = 0.0f, invArea = 0.0f;
     Box3f bounds;
 
-    bool isInfinite() const { return type == InfiniteSphere; }
+    bool isInfinite() const { return type == InfiniteSphere || type == InfiniteSphereCap; }
     bool isDirac() const { return type == Mesh && (verts.empty() || tris.empty()); }
     bool isEmissive() const;       // Primitive.hpp:111-115
-    bool isSamplable() const { return type == InfiniteSphere ? doSample : type != Instances; }   // Instance.cpp:357-360
+    bool isSamplable() const { return (type == InfiniteSphere || type == InfiniteSphereCap) ? doSample : type != Instances; }   // Instance.cpp:357-360
     float powerToRadianceFactor() const;
     void loadResources(const std::string &sceneDir);
     void prepareForRender();
