@@ -108,7 +108,8 @@ typedef struct TgHipTriAttr {
 /* ---- objects (one per reference Primitive) ------------------------------------------ */
 enum { TGHIP_OBJ_MESH = 0, TGHIP_OBJ_QUAD = 1, TGHIP_OBJ_CUBE = 2, TGHIP_OBJ_SPHERE = 3,
        TGHIP_OBJ_INFINITE_SPHERE = 4, TGHIP_OBJ_INSTANCES = 5, TGHIP_OBJ_DISK = 6,
-       TGHIP_OBJ_INFINITE_SPHERE_CAP = 7 };   /* sun-like emitter: normal = _capDir, scale[0] = _cosCapAngle, edge0/edge1 = _capFrame tangent/bitangent (InfiniteSphereCap.cpp:233-249) */
+       TGHIP_OBJ_INFINITE_SPHERE_CAP = 7,     /* sun-like emitter: normal = _capDir, scale[0] = _cosCapAngle, edge0/edge1 = _capFrame tangent/bitangent (InfiniteSphereCap.cpp:233-249) */
+       TGHIP_OBJ_POINT = 8 };                 /* Dirac point light (primitives/Point.cpp): pos = _pos, scale = _power as Point.cpp:186 leaves it; never hit, sampled without random numbers */
 #define TGHIP_OBJF_SMOOTH   1u   /* mesh "smooth": Ns interpolated (TriangleMesh.cpp:344-355) */
 #define TGHIP_OBJF_SAMPLE   2u   /* infinite_sphere "sample" (InfiniteSphere.cpp:117-122)      */
 

@@ -1629,6 +1629,8 @@ static float light_directPdf(const TgHipSceneDesc *s, int objIdx, const LightHit
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:469-473 */
         v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
         return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
+    } else if (o->type == TGHIP_OBJ_POINT) {           /* Point::directPdf (Point.cpp:117-121) */
+        return vlensq(vsub(p, ld3(o->pos)));
     } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {     /* :214-218: uniformSphericalCapPdf */
         return O_INV_TWO_PI/(1.0f - o->scale[0]);
     } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::directPdf (Disk.cpp:228-235) */
@@ -1714,6 +1716,13 @@ static int light_sampleDirect(const TgHipSceneDesc *s, int objIdx, v3 p, Sampler
         if (cosTheta <= 0.0f)
             return 0;
         *pdf = rSq/(cosTheta*o->area);
+        return 1;
+    } else if (o->type == TGHIP_OBJ_POINT) {           /* Point::sampleDirect (Point.cpp:93-101): no random numbers */
+        v3 L = vsub(ld3(o->pos), p);
+        float rSq = vlensq(L);
+        *dist = sqrtf(rSq);
+        *d = vdivs(L, *dist);
+        *pdf = rSq;
         return 1;
     } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {     /* InfiniteSphereCap::sampleDirect (:130-138) */
         float xi0 = next1D(smp), xi1 = next1D(smp);
@@ -1802,6 +1811,9 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
         return vmax3(ld3(s->textures[o->emission].avg))*o->face_cdf[2]/dSq;
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:514-517: "unknown" */
         return -1.0f;
+    } else if (o->type == TGHIP_OBJ_POINT) {           /* Point::approximateRadiance (Point.cpp:166-169) */
+        /* scale = Point::_power as prepareForRender left it (Point.cpp:186): 0 for a light given by "power" */
+        return O_INV_FOUR_PI*vmax3(ld3(o->scale))/vlensq(vsub(ld3(o->pos), p));
     } else if (o->type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {     /* :220-225 */
         if (o->emission < 0 || !(o->flags & TGHIP_OBJF_SAMPLE)) return 0.0f;
         return O_TWO_PI*(1.0f - o->scale[0])*vmax3(ld3(s->textures[o->emission].avg));
@@ -1836,8 +1848,11 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
 static v3 attenuatedEmission(Ctx *c, int lightObj, float expectedDist, int bounce, Ray *ray, LightHit *lh)
 {
     const float fudgeFactor = 1.0f + 1e-3f;
-    if (!light_intersect(c->s, lightObj, ray, lh) || lh->t*fudgeFactor < expectedDist)
+    if (c->s->objects[lightObj].type == TGHIP_OBJ_POINT) {       /* light.isDirac(): ray.setFarT(expectedDist) (:157-158) */
+        lh->t = expectedDist; lh->u = lh->v = 0.0f; lh->backSide = 0;
+    } else if (!light_intersect(c->s, lightObj, ray, lh) || lh->t*fudgeFactor < expectedDist) {
         return vs(0.0f);
+    }
     ray->tmax = lh->t;
     v3 shadow = generalizedShadowRay(c, ray, lightObj, bounce);
     if (viszero(shadow))
@@ -1864,7 +1879,8 @@ static v3 lightSample(Ctx *c, int lightObj, const Info *info, const Local *l, in
     if (viszero(em))
         return vs(0.0f);
     v3 lightF = vdivs(vmul(f, em), pdf);
-    lightF = vscale(lightF, powerHeuristic(pdf, bsdf_pdf(c->s, info->bsdf, &e)));
+    if (c->s->objects[lightObj].type != TGHIP_OBJ_POINT)         /* !light.isDirac() (:281-282) */
+        lightF = vscale(lightF, powerHeuristic(pdf, bsdf_pdf(c->s, info->bsdf, &e)));
     return lightF;
 }
 
@@ -1934,7 +1950,8 @@ static v3 estimateDirect(Ctx *c, const Info *info, const Local *l, int bounce)
     if (pureSpecular || lobes == TGHIP_LOBE_FORWARD)
         return vs(0.0f);
     v3 result = lightSample(c, light, info, l, bounce);
-    result = vadd(result, bsdfSample(c, light, info, l, bounce));    /* no Dirac lights in scope */
+    if (c->s->objects[light].type != TGHIP_OBJ_POINT)             /* !light.isDirac() (TraceBase.cpp:396-397) */
+        result = vadd(result, bsdfSample(c, light, info, l, bounce));
     return vscale(result, weight);
 }
 

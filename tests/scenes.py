@@ -452,6 +452,18 @@ def _sun_and_sky(scene):
          "transform": {"rotation": [25, 0, -20]}}]
 
 
+def _point_lights(scene):
+    """Two Dirac point lights (primitives/Point.cpp; one given by emission, one by power) next to the dimmed quad light:
+    sampled without random numbers and without MIS, never hit by a ray (TraceBase.cpp:157-158, 281-282, 396-397)."""
+    for p in scene["primitives"]:
+        if p["name"] == "light":
+            p["emission"] = [4, 3, 1]
+    scene["primitives"] += [
+        {"name": "bulb", "type": "point", "emission": [0.9, 0.5, 0.2], "transform": {"position": [-0.5, 0.4, 0.5]}},
+        {"name": "bulb2", "type": "point", "power": [3, 6, 9], "transform": {"position": [0.55, 1.5, 0.3]}}]
+
+
+GOLDEN_CASES["cornell_point_lights"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_point_lights))
 GOLDEN_CASES["cornell_sun_sky"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_sun_and_sky))
 GOLDEN_CASES["cornell_disks"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_disks))
 GOLDEN_CASES["water_caustic"] = (water_caustic, dict(resolution=(64, 36), spp=4))

@@ -1299,6 +1299,8 @@ PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p, const 
     }
     if (o.type == TGHIP_OBJ_INFINITE_SPHERE_CAP)               /* uniformSphericalCapPdf (InfiniteSphereCap.cpp:214-218) */
         return PT_INV_TWO_PI/(1.0f - o.scale[0]);
+    if (o.type == TGHIP_OBJ_POINT)                             /* Point::directPdf (Point.cpp:117-121) */
+        return lengthSq(p - ld3(o.pos));
     const TgHipTexture &t = s.textures[o.emission];
     if (!(M & FEAT_BITMAP) || t.type != TGHIP_TEX_BITMAP)
         return PT_INV_FOUR_PI;
@@ -1412,6 +1414,14 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         d = dd;
         return true;
     }
+    if (o.type == TGHIP_OBJ_POINT) {                          /* Point::sampleDirect (Point.cpp:93-101): draws nothing */
+        f3 L = ld3(o.pos) - p;
+        float rSq = lengthSq(L);
+        dist = sqrtf(rSq);
+        d = L/dist;
+        pdf = rSq;
+        return true;
+    }
     if (o.type == TGHIP_OBJ_INFINITE_SPHERE_CAP) {            /* InfiniteSphereCap::sampleDirect (:130-138) */
         float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
         float phi = xi0*PT_TWO_PI;                                     /* SampleWarp::uniformSphericalCap */
@@ -1483,6 +1493,10 @@ PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
         f3 n2 = normalized(cross(R2, R3)), n3 = normalized(cross(R3, R0));
         float Q = acosf(dot(n0, n1)) + acosf(dot(n1, n2)) + acosf(dot(n2, n3)) + acosf(dot(n3, n0));
         return (PT_TWO_PI - fabsf(Q))*max3(ld3(s.textures[o.emission].avg));
+    }
+    if (o.type == TGHIP_OBJ_POINT) {                           /* Point::approximateRadiance (Point.cpp:166-169) */
+        /* scale = Point::_power as prepareForRender left it (Point.cpp:186): 0 for a light given by "power" */
+        return PT_INV_FOUR_PI*max3(ld3(o.scale))/lengthSq(ld3(o.pos) - p);
     }
     if (o.emission < 0 || !(o.flags & TGHIP_OBJF_SAMPLE)) return 0.0f;
     if (o.type == TGHIP_OBJ_INFINITE_SPHERE_CAP)               /* InfiniteSphereCap.cpp:220-225 */

@@ -597,6 +597,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                             bool q0 = false, q1 = false;
                             f3 inlineResult = splat3(0.0f);
                             const bool meshLight = (M & FEAT_MESHLIGHT) && s.objects[light].type == TGHIP_OBJ_MESH;
+                            const bool diracLight = (M & FEAT_SOLIDS) && s.objects[light].type == TGHIP_OBJ_POINT;
                             // lightSample (TraceBase.cpp:246-285)
                             {
                                 f3 d; float dist, pdf;
@@ -616,12 +617,17 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                         } else if (!isZero(f)) {
                                             RayD sr; sr.o = info.p; sr.d = d; sr.tmin = 5e-4f; sr.tmax = PT_INF;
                                             LightHit lh;
-                                            // attenuatedEmission's analytic hit + distance check (TraceBase.cpp:155-162)
-                                            if (lightIntersect<M>(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist)) {
+                                            // attenuatedEmission's analytic hit + distance check (TraceBase.cpp:155-162); a Dirac light
+                                            // (point) is not intersected: the shadow ray simply ends at the sampled distance
+                                            bool reached;
+                                            if (diracLight) { lh.t = dist; lh.u = 0.0f; lh.v = 0.0f; lh.backSide = false; lh.n = splat3(0.0f); reached = true; }
+                                            else reached = lightIntersect<M>(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist);
+                                            if (reached) {
                                                 f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
                                                 if (!isZero(e)) {
                                                     f3 lightF = f*e/pdf;
-                                                    lightF = lightF*powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
+                                                    if (!diracLight)                              // no MIS against a Dirac light (:281-282)
+                                                        lightF = lightF*powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
                                                     if (FUSE & FUSE_SHADOW) {
                                                         sr.tmax = lh.t;
                                                         fusedShadow++;
@@ -638,8 +644,8 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                     }
                                 }
                             }
-                            // bsdfSample (TraceBase.cpp:287-321)
-                            {
+                            // bsdfSample (TraceBase.cpp:287-321); not for Dirac lights (:396-397)
+                            if (!diracLight) {
                                 ev.requested = LOBE_ALL_BUT_SPECULAR;
                                 ev.weight = splat3(1.0f); ev.pdf = 1.0f;
                                 if (bsdfSample<M>(s, info.bsdf, ev) && !isZero(ev.weight)) {
@@ -1717,7 +1723,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 ctx->error = "sampled mesh emitter without a valid light_tris block";
                 return TGHIP_E_INVALID;
             }
-        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE && t != TGHIP_OBJ_DISK && t != TGHIP_OBJ_INFINITE_SPHERE_CAP) {
+        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE && t != TGHIP_OBJ_DISK && t != TGHIP_OBJ_INFINITE_SPHERE_CAP && t != TGHIP_OBJ_POINT) {
             ctx->error = "unknown emitter type";
             return TGHIP_E_UNSUPPORTED;
         }

@@ -566,6 +566,7 @@ float Primitive::powerToRadianceFactor() const
     switch (type) {
     case InfiniteSphere: return INV_FOUR_PI;           // InfiniteSphere.cpp:59-62
     case InfiniteSphereCap: return INV_TWO_PI/(1.0f - scale[0]);   // InfiniteSphereCap.cpp:36-39
+    case Point:          return INV_FOUR_PI;           // Point.cpp:25-28
     default:             return INV_PI*invArea;        // Quad.cpp:50-53, Cube.cpp, TriangleMesh.cpp:108-111
     }
 }
@@ -613,6 +614,8 @@ std::shared_ptr<Primitive> Scene::instantiatePrimitive(const JsonValue &v) const
     } else if (type == "infinite_sphere") {
         p->type = Primitive::InfiniteSphere;
         v.getField("sample", p->doSample);
+    } else if (type == "point") {                     // Point::fromJson (Point.cpp:30-33)
+        p->type = Primitive::Point;
     } else if (type == "infinite_sphere_cap") {      // InfiniteSphereCap::fromJson (InfiniteSphereCap.cpp:41-50)
         p->type = Primitive::InfiniteSphereCap;
         v.getField("sample", p->doSample);
@@ -785,6 +788,13 @@ void Primitive::prepareForRender()
     } case InfiniteSphere: { // InfiniteSphere.cpp:280-286
         rot = transform.extractRotation();
         invRot = rot.transpose();
+        break;
+    } case Point: {           // Point.cpp:183-189
+        pos = transform.translation();
+        // Point::_power (a Vec3f hiding Primitive::_power) is taken from _emission BEFORE Primitive::prepareForRender turns
+        // a "power" texture into _emission (Point.cpp:186-188): a point light given by "power" keeps _power = 0, so
+        // approximateRadiance weighs it 0 and chooseLight never picks it. Reproduced as it is.
+        scale = (emission && !power) ? emission->average()*(4.0f*PI) : Vec3f(0.0f);
         break;
     } case InfiniteSphereCap: { // InfiniteSphereCap.cpp:233-249
         normal = transform.transformVector(Vec3f(0.0f, 1.0f, 0.0f)).normalized();      // _capDir

@@ -75,7 +75,7 @@ struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp
 
 struct Primitive
 {
-    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6, InfiniteSphereCap = 7 };
+    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6, InfiniteSphereCap = 7, Point = 8 };
     std::string name;
     Type type = Quad;
     Mat4f transform;
@@ -107,7 +107,7 @@ struct Primitive
     Box3f bounds;
 
     bool isInfinite() const { return type == InfiniteSphere || type == InfiniteSphereCap; }
-    bool isDirac() const { return type == Mesh && (verts.empty() || tris.empty()); }
+    bool isDirac() const { return type == Point || (type == Mesh && (verts.empty() || tris.empty())); }   // Point.cpp:156-159, TriangleMesh.cpp
     bool isEmissive() const;       // Primitive.hpp:111-115
     bool isSamplable() const { return (type == InfiniteSphere || type == InfiniteSphereCap) ? doSample : type != Instances; }   // Instance.cpp:357-360
     float powerToRadianceFactor() const;
