@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 3
+#define TGHIP_ABI_VERSION 4
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -129,7 +129,8 @@ typedef struct TgHipObject {
     float    rot[9];                                 /* row-major 3x3 rotation (cube; infinite sphere _rotTransform) */
     float    face_cdf[3];                            /* cube (Cube.cpp:353-370)    */
     int32_t  num_light_tris;  /* sampled mesh emitters: triangles in the block (TriangleMesh::makeSamplable) */
-    float    pad[2];
+    int32_t  int_medium, ext_medium;  /* Primitive::_intMedium/_extMedium (Primitive.cpp:30-31) as indices into media[], -1 = none;
+                                         the primitive overrides the path's medium iff either is set (Primitive.hpp:172-183) */
 } TgHipObject;
 
 /* ---- BSDFs ---------------------------------------------------------------------------- */
@@ -157,6 +158,17 @@ typedef struct TgHipBsdf {
     float    eta[3], k[3], sigma_a[3], scaled_sigma_a[3];
     float    pad[2];
 } TgHipBsdf;
+
+/* ---- participating media (media/HomogeneousMedium.cpp with the default ExponentialTransmittance) -------- */
+enum { TGHIP_PHASE_ISOTROPIC = 0, TGHIP_PHASE_HENYEY_GREENSTEIN = 1 };   /* phasefunctions/{Isotropic,HenyeyGreenstein}PhaseFunction.cpp */
+typedef struct TgHipMedium {
+    float   sigma_a[3], sigma_s[3], sigma_t[3];   /* after prepareForRender: material sigma x density (HomogeneousMedium.cpp:43-49) */
+    int32_t absorption_only;                      /* _sigmaS == 0 */
+    int32_t max_bounce;                           /* Medium::_maxBounce (Medium.cpp:16, 29) */
+    int32_t phase_type;                           /* TGHIP_PHASE_* */
+    float   phase_g;                              /* Henyey-Greenstein asymmetry */
+    float   pad[3];
+} TgHipMedium;                /* 64 B */
 
 /* ---- textures ------------------------------------------------------------------------- */
 enum { TGHIP_TEX_CONSTANT = 0, TGHIP_TEX_CHECKER = 1, TGHIP_TEX_BITMAP = 2 };
@@ -196,13 +208,15 @@ typedef struct TgHipCamera {
     int32_t type;             /* TGHIP_CAMERA_*                                   */
     float   focus_dist, aperture_size, cat_eye;
     float   inv_xf[12];       /* rows 0..2 of Camera::_invTransform (3x4, row-major, translation in column 3) */
+    int32_t medium;           /* Camera::_medium (Camera.cpp:49-50): index into media[], -1 = none */
 } TgHipCamera;
 
 /* ---- integrator settings (TraceSettings.hpp:23-39, PathTracerSettings.hpp:25-43) -------- */
 typedef struct TgHipSettings {
     int32_t min_bounces, max_bounces;
     int32_t enable_light_sampling, enable_two_sided_shading, enable_consistency_checks;
-    int32_t pad[3];
+    int32_t enable_volume_light_sampling;   /* PathTracerSettings.hpp:13,38; low_order_scattering / include_surfaces must keep their defaults (true) */
+    int32_t pad[2];
 } TgHipSettings;
 
 typedef struct TgHipSceneDesc {
@@ -227,6 +241,7 @@ typedef struct TgHipSceneDesc {
     const uint32_t     *sobol_matrices;  uint64_t num_sobol_words;
     uint32_t num_instances;               /* instance records among recs (0: single-level scene) */
     uint32_t num_top_recs;                /* records of the top-level BVH = recs[0, num_top_recs); the rest belong to masters */
+    const TgHipMedium  *media;  uint32_t num_media;   /* Scene::_media; NULL/0 = the scene has no participating media */
     TgHipCamera   camera;
     TgHipSettings settings;
     float         bounds_lo[3], bounds_hi[3];

@@ -1521,8 +1521,98 @@ static Event make_event(const Ctx *c, const Info *info, const Local *l, uint32_t
     return e;
 }
 
-/* TraceBase::generalizedShadowRay (TraceBase.cpp:62-125) without media.  `endCap` is an object index. */
-static v3 generalizedShadowRay(Ctx *c, Ray *ray, int endCap, int bounce)
+/* ---- participating media: HomogeneousMedium with ExponentialTransmittance (media/HomogeneousMedium.cpp,
+ * transmittances/ExponentialTransmittance.cpp).  The reference evaluates exp through fmath's table-based
+ * approximation (math/FastMath.hpp:14-27); expf here, inside the float tolerance of the parity tests. ---- */
+typedef struct { int firstScatter; int bounce; } MediumState;     /* Medium.hpp:30-47 */
+typedef struct { v3 p; float t; v3 weight; int exited; int medium; } MediumSample;
+static inline v3 vexpneg(v3 tau) { return V(expf(-tau.x), expf(-tau.y), expf(-tau.z)); }
+
+/* Primitive::selectMedium (Primitive.hpp:177-183) */
+static int selectMedium(const TgHipObject *o, int current, int geometricBackside)
+{
+    if (o->int_medium >= 0 || o->ext_medium >= 0)
+        return geometricBackside ? o->int_medium : o->ext_medium;
+    return current;
+}
+
+/* HomogeneousMedium::sampleDistance (HomogeneousMedium.cpp:66-107); sigmaBar = 1, every transmittance variant = exp(-tau) */
+static int medium_sampleDistance(const TgHipSceneDesc *s, int medium, Sampler *smp, const Ray *ray, MediumState *state, MediumSample *ms)
+{
+    const TgHipMedium *m = &s->media[medium];
+    if (state->bounce > m->max_bounce)
+        return 0;
+    float maxT = ray->tmax;
+    v3 sigmaT = ld3(m->sigma_t);
+    if (m->absorption_only) {
+        if (maxT == INFINITY)
+            return 0;
+        ms->t = maxT;
+        ms->weight = vexpneg(vscale(sigmaT, ms->t));
+        ms->exited = 1;
+    } else {
+        int component = (int)(nextSupplemental(smp)*3);           /* sampler.nextDiscrete(3) */
+        float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
+        float t = -logf(1.0f - next1D(smp))/sigmaTc;              /* ExponentialTransmittance::sample* (:46-53) */
+        ms->t = fminf(t, maxT);
+        ms->exited = t >= maxT;
+        v3 tau = vscale(sigmaT, ms->t);
+        ms->weight = vexpneg(tau);
+        float pdf;
+        if (ms->exited) {
+            pdf = vavg(vexpneg(tau));                              /* surfaceProbability(tau).avg() */
+        } else {
+            pdf = vavg(vmul(sigmaT, vexpneg(tau)));                /* (sigmaT*mediumPdf(tau)).avg() */
+            ms->weight = vmul(ms->weight, ld3(m->sigma_s));
+        }
+        ms->weight = vdivs(ms->weight, pdf);
+        state->firstScatter = 0; state->bounce++;                  /* state.advance() */
+    }
+    ms->p = vadd(ray->o, vscale(ray->d, ms->t));
+    ms->medium = medium;
+    return 1;
+}
+
+/* HomogeneousMedium::transmittance (:109-116) */
+static v3 medium_transmittance(const TgHipSceneDesc *s, int medium, float farT)
+{
+    if (farT == INFINITY)
+        return vs(0.0f);
+    return vexpneg(vscale(ld3(s->media[medium].sigma_t), farT));
+}
+
+/* PhaseFunction::eval / pdf / sample (phasefunctions/IsotropicPhaseFunction.cpp:17-41, HenyeyGreensteinPhaseFunction.cpp:16-63) */
+static float phase_hg(float g, float cosTheta)
+{
+    float term = 1.0f + g*g - 2.0f*g*cosTheta;
+    return O_INV_FOUR_PI*(1.0f - g*g)/(term*sqrtf(term));
+}
+static float phase_eval(const TgHipMedium *m, v3 wi, v3 wo)   /* eval == pdf for both phase functions */
+{
+    if (m->phase_type == TGHIP_PHASE_HENYEY_GREENSTEIN)
+        return phase_hg(m->phase_g, vdot(wi, wo));
+    return O_INV_FOUR_PI;
+}
+static void phase_sample(const TgHipMedium *m, Sampler *smp, v3 wi, v3 *w, float *pdf)   /* weight = 1 */
+{
+    float xi0 = next1D(smp), xi1 = next1D(smp);                    /* next2D */
+    float g = m->phase_g;
+    if (m->phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN || g == 0.0f) {
+        *w = uniformSphere(xi0, xi1);
+        *pdf = O_INV_FOUR_PI;
+    } else {
+        float phi = xi0*O_TWO_PI;
+        float cosTheta = (1.0f + g*g - sqr((1.0f - g*g)/(1.0f + g*(xi1*2.0f - 1.0f))))/(2.0f*g);
+        float sinTheta = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
+        Frame f = frame_from_normal(wi);
+        *w = toGlobal(&f, V(cosf(phi)*sinTheta, sinf(phi)*sinTheta, cosTheta));
+        *pdf = phase_hg(g, cosTheta);
+    }
+}
+
+/* TraceBase::generalizedShadowRay (TraceBase.cpp:62-125).  `endCap` is an object index, `medium` the medium the ray
+ * starts in (-1 = none). */
+static v3 generalizedShadowRay(Ctx *c, Ray *ray, int medium, int endCap, int bounce)
 {
     float initialFarT = ray->tmax;
     v3 throughput = vs(1.0f);
@@ -1551,8 +1641,11 @@ static v3 generalizedShadowRay(Ctx *c, Ray *ray, int endCap, int bounce)
             if (bounce >= c->s->settings.max_bounces)
                 return vs(0.0f);
         }
+        if (medium >= 0)                                   /* :103-112; ray.farT() is the hit distance when anything was hit */
+            throughput = vmul(throughput, medium_transmittance(c->s, medium, hitAny ? hit.t : ray->tmax));
         if (!hitAny || hitObject == endCap)
             return bounce >= c->s->settings.min_bounces ? throughput : vs(0.0f);
+        medium = selectMedium(&c->s->objects[info.object], medium, !info.backSide);     /* :115 */
         ray->o = vadd(ray->o, vscale(ray->d, hit.t));      /* ray.hitpoint(): farT was set to the hit */
         initialFarT -= hit.t;
         ray->tmin = info.epsilon;
@@ -1845,7 +1938,7 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
 }
 
 /* TraceBase::attenuatedEmission (TraceBase.cpp:144-174) for non-Dirac lights */
-static v3 attenuatedEmission(Ctx *c, int lightObj, float expectedDist, int bounce, Ray *ray, LightHit *lh)
+static v3 attenuatedEmission(Ctx *c, int lightObj, int medium, float expectedDist, int bounce, Ray *ray, LightHit *lh)
 {
     const float fudgeFactor = 1.0f + 1e-3f;
     if (c->s->objects[lightObj].type == TGHIP_OBJ_POINT) {       /* light.isDirac(): ray.setFarT(expectedDist) (:157-158) */
@@ -1854,14 +1947,14 @@ static v3 attenuatedEmission(Ctx *c, int lightObj, float expectedDist, int bounc
         return vs(0.0f);
     }
     ray->tmax = lh->t;
-    v3 shadow = generalizedShadowRay(c, ray, lightObj, bounce);
+    v3 shadow = generalizedShadowRay(c, ray, medium, lightObj, bounce);
     if (viszero(shadow))
         return vs(0.0f);
     return vmul(shadow, light_evalDirect(c->s, lightObj, lh));
 }
 
 /* TraceBase::lightSample (TraceBase.cpp:246-285) */
-static v3 lightSample(Ctx *c, int lightObj, const Info *info, const Local *l, int bounce)
+static v3 lightSample(Ctx *c, int lightObj, const Info *info, const Local *l, int medium, int bounce)
 {
     v3 d; float dist, pdf;
     if (!light_sampleDirect(c->s, lightObj, info->p, c->sampler, &d, &dist, &pdf))
@@ -1873,9 +1966,10 @@ static v3 lightSample(Ctx *c, int lightObj, const Info *info, const Local *l, in
     v3 f = bsdf_eval_rt(c->s, info->bsdf, &e);
     if (viszero(f))
         return vs(0.0f);
+    medium = selectMedium(&c->s->objects[info->object], medium, vdot(d, info->Ng) < 0.0f);   /* :260-261 */
     Ray ray = {info->p, d, info->epsilon, INFINITY};
     LightHit lh;
-    v3 em = attenuatedEmission(c, lightObj, dist, bounce, &ray, &lh);
+    v3 em = attenuatedEmission(c, lightObj, medium, dist, bounce, &ray, &lh);
     if (viszero(em))
         return vs(0.0f);
     v3 lightF = vdivs(vmul(f, em), pdf);
@@ -1885,7 +1979,7 @@ static v3 lightSample(Ctx *c, int lightObj, const Info *info, const Local *l, in
 }
 
 /* TraceBase::bsdfSample (TraceBase.cpp:287-321) */
-static v3 bsdfSample(Ctx *c, int lightObj, const Info *info, const Local *l, int bounce)
+static v3 bsdfSample(Ctx *c, int lightObj, const Info *info, const Local *l, int medium, int bounce)
 {
     Event e = make_event(c, info, l, LOBE_ALL_BUT_SPECULAR);
     if (!bsdf_sample_rt(c->s, info->bsdf, &e))
@@ -1895,9 +1989,10 @@ static v3 bsdfSample(Ctx *c, int lightObj, const Info *info, const Local *l, int
     v3 wo = toGlobal(&l->frame, e.wo);
     if (!isConsistent(c, info, l, e.wo, wo))
         return vs(0.0f);
+    medium = selectMedium(&c->s->objects[info->object], medium, vdot(wo, info->Ng) < 0.0f);  /* :302-303 */
     Ray ray = {info->p, wo, info->epsilon, INFINITY};
     LightHit lh;
-    v3 em = attenuatedEmission(c, lightObj, -1.0f, bounce, &ray, &lh);
+    v3 em = attenuatedEmission(c, lightObj, medium, -1.0f, bounce, &ray, &lh);
     if (viszero(em))
         return vs(0.0f);
     v3 bsdfF = vmul(em, e.weight);
@@ -1939,7 +2034,7 @@ static int chooseLight(Ctx *c, v3 p, float *weight)
 }
 
 /* TraceBase::estimateDirect + sampleDirect (TraceBase.cpp:483-494, 383-400) */
-static v3 estimateDirect(Ctx *c, const Info *info, const Local *l, int bounce)
+static v3 estimateDirect(Ctx *c, const Info *info, const Local *l, int medium, int bounce)
 {
     float weight;
     int light = chooseLight(c, info->p, &weight);
@@ -1949,13 +2044,53 @@ static v3 estimateDirect(Ctx *c, const Info *info, const Local *l, int bounce)
     int pureSpecular = lobes != 0 && (lobes & ~(uint32_t)LOBE_SPECULAR) == 0;
     if (pureSpecular || lobes == TGHIP_LOBE_FORWARD)
         return vs(0.0f);
-    v3 result = lightSample(c, light, info, l, bounce);
+    v3 result = lightSample(c, light, info, l, medium, bounce);
     if (c->s->objects[light].type != TGHIP_OBJ_POINT)             /* !light.isDirac() (TraceBase.cpp:396-397) */
-        result = vadd(result, bsdfSample(c, light, info, l, bounce));
+        result = vadd(result, bsdfSample(c, light, info, l, medium, bounce));
     return vscale(result, weight);
 }
 
-/* PathTracer::traceSample (PathTracer.cpp:14-149) with media == [] */
+/* TraceBase::volumeEstimateDirect + volumeSampleDirect + volumeLightSample + volumePhaseSample (TraceBase.cpp:323-381, 402-414, 471-481) */
+static v3 volumeEstimateDirect(Ctx *c, const MediumSample *ms, int medium, int bounce, v3 parentDir)
+{
+    const TgHipMedium *m = &c->s->media[ms->medium];
+    float weight;
+    int light = chooseLight(c, ms->p, &weight);
+    if (light < 0)
+        return vs(0.0f);
+    const int dirac = c->s->objects[light].type == TGHIP_OBJ_POINT;
+    v3 result = vs(0.0f);
+    {   /* volumeLightSample */
+        v3 d; float dist, pdf;
+        if (light_sampleDirect(c->s, light, ms->p, c->sampler, &d, &dist, &pdf)) {
+            float f = phase_eval(m, parentDir, d);
+            if (f != 0.0f) {
+                Ray ray = {ms->p, d, 0.0f, INFINITY};              /* parentRay.scatter(p, d, 0.0f) */
+                LightHit lh;
+                v3 e = attenuatedEmission(c, light, medium, dist, bounce, &ray, &lh);
+                if (!viszero(e)) {
+                    v3 lightF = vdivs(vscale(e, f), pdf);
+                    if (!dirac)
+                        lightF = vscale(lightF, powerHeuristic(pdf, phase_eval(m, parentDir, d)));
+                    result = vadd(result, lightF);
+                }
+            }
+        }
+    }
+    if (!dirac) {   /* volumePhaseSample */
+        v3 w; float pdf;
+        phase_sample(m, c->sampler, parentDir, &w, &pdf);
+        Ray ray = {ms->p, w, 0.0f, INFINITY};
+        LightHit lh;
+        v3 e = attenuatedEmission(c, light, medium, -1.0f, bounce, &ray, &lh);
+        if (!viszero(e))
+            result = vadd(result, vscale(e, powerHeuristic(pdf, light_directPdf(c->s, light, &lh, ms->p))));
+    }
+    return vscale(result, weight);
+}
+
+/* PathTracer::traceSample (PathTracer.cpp:14-149); low_order_scattering and include_surfaces at their defaults */
+
 static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
 {
     const TgHipSceneDesc *s = c->s;
@@ -2031,11 +2166,27 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
     Hit hit;
     Info info;
     int bounce = 0;
+    int medium = s->num_media ? cam->medium : -1;      /* _scene->cam().medium() */
+    MediumState state = {1, 0};                         /* state.reset() */
+    const int volumeNee = s->settings.enable_volume_light_sampling;
     c->closest_rays++;
     int didHit = scene_intersect(s, &ray, &hit, c->st);
     if (didHit) intersection_info(s, &ray, &hit, &info);
     int wasSpecular = 1;
-    while (didHit && bounce < maxBounces) {
+    while ((didHit || medium >= 0) && bounce < maxBounces) {
+        int hitSurface = 1;
+        MediumSample ms;
+        if (medium >= 0) {
+            Ray seg = ray;
+            seg.tmax = didHit ? hit.t : INFINITY;          /* ray.farT() after _scene->intersect */
+            if (!medium_sampleDistance(s, medium, c->sampler, &seg, &state, &ms))
+                return emission;
+            throughput = vmul(throughput, ms.weight);      /* mediumSample.emission = 0 */
+            hitSurface = ms.exited;
+            if (hitSurface && !didHit)
+                break;
+        }
+        if (hitSurface) {
         Local l = makeLocalScatterEvent(c, &info, &ray);
 
         /* TraceBase::handleSurface (TraceBase.cpp:516-568) */
@@ -2049,7 +2200,7 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
             throughput = vmul(throughput, vdivs(transparency, transparencyScalar));
         } else {
             if (nee && bounce < maxBounces - 1)
-                emission = vadd(emission, vmul(estimateDirect(c, &info, &l, bounce + 1), throughput));
+                emission = vadd(emission, vmul(estimateDirect(c, &info, &l, medium, bounce + 1), throughput));
             const TgHipObject *o = &s->objects[info.object];
             if (o->emission >= 0 && bounce >= minBounces) {
                 if (!nee || wasSpecular || o->light < 0) {
@@ -2066,8 +2217,19 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
             throughput = vmul(throughput, e.weight);
             wasSpecular = (e.sampled & LOBE_SPECULAR) != 0;
         }
+        medium = selectMedium(&s->objects[info.object], medium, vdot(wo, info.Ng) < 0.0f);   /* :561-563 */
+        state.firstScatter = 1; state.bounce = 0;
         v3 hp = vadd(ray.o, vscale(ray.d, hit.t));      /* ray.hitpoint() */
         ray.o = hp; ray.d = wo; ray.tmin = info.epsilon; ray.tmax = INFINITY;
+        } else {
+            /* TraceBase::handleVolume (TraceBase.cpp:496-514) */
+            wasSpecular = !volumeNee;
+            if (volumeNee && bounce < maxBounces - 1)
+                emission = vadd(emission, vmul(throughput, volumeEstimateDirect(c, &ms, medium, bounce + 1, ray.d)));
+            v3 w; float pdf;
+            phase_sample(&s->media[ms.medium], c->sampler, ray.d, &w, &pdf);
+            ray.o = ms.p; ray.d = w; ray.tmin = 0.0f; ray.tmax = INFINITY;     /* ray.scatter(p, w, 0.0f); weight = 1 */
+        }
 
         if (vmax3(throughput) == 0.0f)
             break;

@@ -463,6 +463,50 @@ def _point_lights(scene):
         {"name": "bulb2", "type": "point", "power": [3, 6, 9], "transform": {"position": [0.55, 1.5, 0.3]}}]
 
 
+def _replace_bsdf(scene, name, bsdf):
+    for i, b in enumerate(scene["bsdfs"]):
+        if b["name"] == name:
+            scene["bsdfs"][i] = dict(bsdf, name=name)
+
+
+def _prim(scene, name):
+    return next(p for p in scene["primitives"] if p["name"] == name)
+
+
+def _fog(scene):
+    """The camera sits in a homogeneous, isotropically scattering medium that no primitive overrides: every segment of every
+    path samples a distance (media/HomogeneousMedium.cpp:66-107), volume NEE + phase-function MIS (TraceBase.cpp:323-381)."""
+    scene["media"] = scene.get("media", []) + [{"name": "fog", "type": "homogeneous", "sigma_a": [0.02, 0.03, 0.05], "sigma_s": [0.25, 0.22, 0.2]}]
+    scene["camera"]["medium"] = "fog"
+
+
+def _smoke(scene):
+    """Media behind boundaries: the tall box becomes a forward-BSDF container of dense, forward-scattering (Henyey-Greenstein)
+    smoke, the short box tinted glass (dielectric + absorption-only interior): selectMedium on refraction, shadow rays that
+    cross boundaries and pick up transmittance (TraceBase.cpp:62-125), absorption-only distance sampling."""
+    scene["media"] = scene.get("media", []) + [
+        {"name": "smoke", "type": "homogeneous", "sigma_a": [0.4, 0.5, 0.8], "sigma_s": [3.0, 3.0, 2.5], "density": 1.5,
+         "phase_function": {"type": "henyey_greenstein", "g": 0.6}},
+        {"name": "tint", "type": "homogeneous", "sigma_a": [2.0, 0.6, 0.3], "sigma_s": 0.0}]
+    _replace_bsdf(scene, "tallBox", {"type": "forward", "albedo": 1})
+    _replace_bsdf(scene, "shortBox", {"type": "dielectric", "ior": 1.45, "albedo": 1})
+    _prim(scene, "tallBox")["int_medium"] = "smoke"
+    _prim(scene, "shortBox")["int_medium"] = "tint"
+
+
+def _fog_and_smoke(scene):
+    """Both: the boxes override the camera's fog with their interior and restore it (ext_medium) on the way out."""
+    _fog(scene)
+    _smoke(scene)
+    for n in ("tallBox", "shortBox"):
+        _prim(scene, n)["ext_medium"] = "fog"
+    scene["integrator"]["max_bounces"] = 12
+
+
+# participating media (SURVEY.md 8 f2): homogeneous media with exponential transmittance
+GOLDEN_CASES["cornell_fog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog))
+GOLDEN_CASES["cornell_smoke"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_smoke))
+GOLDEN_CASES["cornell_fog_smoke_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog_and_smoke, renderer={"stratified_sampler": True}))
 GOLDEN_CASES["cornell_point_lights"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_point_lights))
 GOLDEN_CASES["cornell_sun_sky"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_sun_and_sky))
 GOLDEN_CASES["cornell_disks"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_disks))

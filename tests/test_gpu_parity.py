@@ -66,7 +66,7 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
     assert (count == ocount).all() and (count == spp).all()
     assert c.samples == flat.width*flat.height*spp == oc.samples
     omean = osum/np.maximum(ocount, 1)[..., None]
-    loose = "dielectric" in name or "transparency" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances", "water_caustic")
+    loose = "dielectric" in name or "transparency" in name or "smoke" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances", "water_caustic")
     compare(mean, omean, max_bad=0.03 if loose else 0.01, mean_rel=2e-2 if loose else 5e-3)
     # ray counts agree up to the divergent paths
     if "cateye" in name:

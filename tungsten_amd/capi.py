@@ -31,7 +31,7 @@ class TgHipObject(C.Structure):
     _fields_ = [("type", i32), ("bsdf", i32), ("emission", i32), ("light", i32), ("flags", u32),
                 ("area", f32), ("inv_area", f32), ("first_light_tri", i32),
                 ("base", f32*3), ("edge0", f32*3), ("edge1", f32*3), ("normal", f32*3), ("inv_uv_sq", f32*2),
-                ("pos", f32*3), ("scale", f32*3), ("rot", f32*9), ("face_cdf", f32*3), ("num_light_tris", i32), ("pad", f32*2)]
+                ("pos", f32*3), ("scale", f32*3), ("rot", f32*9), ("face_cdf", f32*3), ("num_light_tris", i32), ("int_medium", i32), ("ext_medium", i32)]
 
 
 class TgHipBsdf(C.Structure):
@@ -48,16 +48,21 @@ class TgHipTexture(C.Structure):
                 ("avg", f32*3), ("pad", f32), ("texel_offset", i64), ("dist_offset", i64)]
 
 
+class TgHipMedium(C.Structure):
+    _fields_ = [("sigma_a", f32*3), ("sigma_s", f32*3), ("sigma_t", f32*3), ("absorption_only", i32), ("max_bounce", i32),
+                ("phase_type", i32), ("phase_g", f32), ("pad", f32*3)]
+
+
 class TgHipCamera(C.Structure):
     _fields_ = [("pos", f32*3), ("plane_dist", f32), ("xf", f32*9), ("ratio", f32), ("pixel_size_x", f32),
                 ("res_x", i32), ("res_y", i32), ("filter_type", i32), ("filter_width", f32),
                 ("filter_bin_size", f32), ("filter_cdf", f32*32),
-                ("type", i32), ("focus_dist", f32), ("aperture_size", f32), ("cat_eye", f32), ("inv_xf", f32*12)]
+                ("type", i32), ("focus_dist", f32), ("aperture_size", f32), ("cat_eye", f32), ("inv_xf", f32*12), ("medium", i32)]
 
 
 class TgHipSettings(C.Structure):
     _fields_ = [("min_bounces", i32), ("max_bounces", i32), ("enable_light_sampling", i32),
-                ("enable_two_sided_shading", i32), ("enable_consistency_checks", i32), ("pad", i32*3)]
+                ("enable_two_sided_shading", i32), ("enable_consistency_checks", i32), ("enable_volume_light_sampling", i32), ("pad", i32*2)]
 
 
 class TgHipSceneDesc(C.Structure):
@@ -72,6 +77,7 @@ class TgHipSceneDesc(C.Structure):
                 ("light_tris", C.POINTER(f32)), ("num_light_tri_floats", u64),
                 ("sobol_matrices", C.POINTER(u32)), ("num_sobol_words", u64),
                 ("num_instances", u32), ("num_top_recs", u32),
+                ("media", C.POINTER(TgHipMedium)), ("num_media", u32),
                 ("camera", TgHipCamera), ("settings", TgHipSettings),
                 ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
 

@@ -41,6 +41,14 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 #define FLAG_SPECULAR       0x100u
 #define FLAG_STATE(f)       (((f) >> 16) & 7u)
 #define FLAG_MAKE(bounce, spec, state) ((uint32_t)(bounce) | ((spec) ? FLAG_SPECULAR : 0u) | ((uint32_t)(state) << 16))
+// media scenes (FEAT_MEDIA variants only): the medium the path is in, as index + 1 (0 = none), and MediumState::bounce
+// (scatter events since the last surface, Medium.hpp:30-47)
+#define FLAG_MEDIUM(f)         ((int)(((f) >> 9) & 0x7Fu) - 1)
+#define FLAG_MEDIUM_BOUNCE(f)  (((f) >> 19) & 0xFFu)
+#define FLAG_MEDIUM_BITS(medium, mbounce) ((((uint32_t)((medium) + 1)) & 0x7Fu) << 9 | (((uint32_t)(mbounce)) & 0xFFu) << 19)
+#define PT_MAX_MEDIA 126u
+// shadow-ray tag of a media scene: light object (16 bits) | medium the ray starts in + 1 (8 bits) | bounce (8 bits)
+#define SHADOW_TAG_MEDIA(light, medium, bounce) ((uint32_t)(light) | ((uint32_t)((medium) + 1) << 16) | ((uint32_t)(bounce) << 24))
 
 #define PT_NUM_CLASSES 2          // shading classes: 0 = diffuse/null/miss, 1 = everything else
 #define PT_ITEM_GROUP  64u        // consecutive work items handed to one workgroup (a wave's worth of pixels)
@@ -111,6 +119,7 @@ PT_DEV uint4 &slotU4(const PathState &st, uint32_t a, uint32_t slot)
 
 
 #define PT_PASS_THINLENS 0x100u   /* internal pass flag: the scene's camera is a thin lens (nextPath's EXT variants sample the lens) */
+#define PT_PASS_MEDIA    0x200u   /* internal pass flag: the scene has participating media (new paths start in the camera's medium) */
 struct PassParams {
     uint32_t spp_begin, spp_end, seed;
     uint32_t chunk;            // samples per work item

@@ -28,6 +28,8 @@ struct DeviceScene {
     const uint32_t * __restrict__ sobol;       // Sobol' generator matrices (nullptr unless the scene carries them)
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
     uint32_t num_instances;                    // instance records (0: single-level scene, A_EMI.w carries nothing)
+    const TgHipMedium * __restrict__ media;    // participating media (nullptr / 0: none)
+    uint32_t num_media;
     const TgHipCamera * __restrict__ camera;   // in device memory (56 dwords: read through the scalar cache where it is used, not held in SGPRs)
     TgHipSettings settings;
 };
@@ -55,7 +57,8 @@ struct DeviceScene {
 #define FEAT_MESHLIGHT  (1u << 29)   /* triangle-mesh emitters as sampled lights: only in the MASK_FULL / BSDF_MASK_ALL variants */
 #define FEAT_QMC        (1u << 30)   /* TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes: every variant has a twin with this bit (launchShade) */
 #define FEAT_INSTANCES  (1u << 31)   /* hits reached through an instance record (primitives/Instance.cpp): only in MASK_FULL / BSDF_MASK_ALL */
-#define MASK_FULL       (BSDF_MASK_ALL & ~FEAT_QMC)
+#define FEAT_MEDIA      (1u << 23)   /* participating media (media/HomogeneousMedium.cpp): only in the BSDF_MASK_ALL variant */
+#define MASK_FULL       (BSDF_MASK_ALL & ~(FEAT_QMC | FEAT_MEDIA))
 // next1D of the path's sampler inside code templated on M
 #define RNG1D(r) rngNext1DT<(M & FEAT_QMC) != 0>(r)
 
@@ -1557,6 +1560,86 @@ PT_DEV int chooseLight(const DeviceScene &s, Rng &rng, f3 p, float &weight)
         t -= pdf;
     }
     return -1;
+}
+
+// ---- participating media: HomogeneousMedium with ExponentialTransmittance (media/HomogeneousMedium.cpp:43-131,
+// transmittances/ExponentialTransmittance.cpp:26-53).  Every transmittance variant is exp(-tau) and sigmaBar = 1, so
+// MediumState::firstScatter has no effect and only MediumState::bounce is carried (path flags, pt_kernels.h). ----
+PT_DEV int selectMedium(const TgHipObject &o, int current, bool geometricBackside)   /* Primitive.hpp:177-183 */
+{
+    if (o.int_medium >= 0 || o.ext_medium >= 0)
+        return geometricBackside ? o.int_medium : o.ext_medium;
+    return current;
+}
+
+/* HomogeneousMedium::sampleDistance (:66-107).  maxT = ray.farT(); false = the path ends here ("return emission") */
+template<uint32_t M>
+PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, float maxT, uint32_t &stateBounce, f3 &weight, float &t, bool &exited)
+{
+    const TgHipMedium &m = s.media[medium];
+    if ((int)stateBounce > m.max_bounce)
+        return false;
+    const f3 sigmaT = ld3(m.sigma_t);
+    if (m.absorption_only) {
+        if (maxT == PT_INF)
+            return false;
+        t = maxT;
+        weight = exp3(-(sigmaT*t));
+        exited = true;
+    } else {
+        int component = (int)(rngNext1D(rng)*3);                     /* sampler.nextDiscrete(3): the supplemental stream */
+        float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
+        float tt = -logf(1.0f - RNG1D(rng))/sigmaTc;
+        t = fminf(tt, maxT);
+        exited = tt >= maxT;
+        f3 e = exp3(-(sigmaT*t));
+        float pdf;
+        if (exited) {
+            pdf = avg3(e);
+            weight = e;
+        } else {
+            pdf = avg3(sigmaT*e);
+            weight = e*ld3(m.sigma_s);
+        }
+        weight = weight/pdf;
+        stateBounce++;                                               /* state.advance() */
+    }
+    return true;
+}
+
+PT_DEV f3 mediumTransmittance(const DeviceScene &s, int medium, float farT)   /* HomogeneousMedium::transmittance (:109-116) */
+{
+    if (farT == PT_INF)
+        return splat3(0.0f);
+    return exp3(-(ld3(s.media[medium].sigma_t)*farT));
+}
+
+/* PhaseFunction::eval == pdf (IsotropicPhaseFunction.cpp:17-41, HenyeyGreensteinPhaseFunction.cpp:16-43, 80-83) */
+PT_DEV float phaseHG(float g, float cosTheta)
+{
+    float term = 1.0f + g*g - 2.0f*g*cosTheta;
+    return PT_INV_FOUR_PI*(1.0f - g*g)/(term*sqrtf(term));
+}
+PT_DEV float phaseEval(const TgHipMedium &m, f3 wi, f3 wo)
+{
+    return m.phase_type == TGHIP_PHASE_HENYEY_GREENSTEIN ? phaseHG(m.phase_g, dot(wi, wo)) : PT_INV_FOUR_PI;
+}
+template<uint32_t M>
+PT_DEV void phaseSample(const TgHipMedium &m, Rng &rng, f3 wi, f3 &w, float &pdf)   /* sample.weight = 1 */
+{
+    float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
+    const float g = m.phase_g;
+    if (m.phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN || g == 0.0f) {
+        w = uniformSphere(xi0, xi1);
+        pdf = PT_INV_FOUR_PI;
+    } else {
+        float phi = xi0*PT_TWO_PI;
+        float cosTheta = (1.0f + g*g - sqr((1.0f - g*g)/(1.0f + g*(xi1*2.0f - 1.0f))))/(2.0f*g);
+        float sinTheta = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
+        Frame f = frameFromNormal(wi);
+        w = toGlobal(f, mk3(cosf(phi)*sinTheta, sinf(phi)*sinTheta, cosTheta));
+        pdf = phaseHG(g, cosTheta);
+    }
 }
 
 #endif

@@ -191,7 +191,10 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             slotF4(st, A_EMI, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             // ... and carries no throughput, so the escaped path adds nothing: a black sample (PathTracer.cpp:27-28)
             const float t0 = cameraOk ? 1.0f : 0.0f;
-            slotF4(st, A_THR, slot) = make_float4(t0, t0, t0, __uint_as_float(FLAG_MAKE(0, 1, ST_ACTIVE)));   // wasSpecular starts true
+            uint32_t f0 = FLAG_MAKE(0, 1, ST_ACTIVE);                       // wasSpecular starts true
+            if (EXT && (pp.flags & PT_PASS_MEDIA))
+                f0 |= FLAG_MEDIUM_BITS(cam.medium, 0);                      // _scene->cam().medium(), state.reset() (PathTracer.cpp:38-41)
+            slotF4(st, A_THR, slot) = make_float4(t0, t0, t0, __uint_as_float(f0));
             slotU4(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, EXT ? rng.dim : 0u, lumBase);   // .z: next Sobol' dimension
             slotF4(st, A_ACC, slot) = acc;
             push = true;
@@ -528,7 +531,130 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             bool wasSpecular = (flags & FLAG_SPECULAR) != 0;
             uint32_t state = ST_ACTIVE;
 
-            if (__float_as_int(hit.w) < 0) {
+            // loop epilogue (PathTracer.cpp:108-126) for a path that goes on from `o` in direction `d`
+            auto continuePath = [&](f3 o, f3 d, float tmin) {
+                ray.o = o; ray.d = d; ray.tmin = tmin; ray.tmax = PT_INF;
+                if (max3(throughput) == 0.0f) {
+                    state = ST_TERMINATED;                   // the env term after `break` is throughput*L = 0
+                } else {
+                    float roulettePdf = fmaxf(fabsf(throughput.x), fmaxf(fabsf(throughput.y), fabsf(throughput.z)));
+                    bool killed = false;
+                    if (bounce > 2 && roulettePdf < 0.1f) {
+                        if (rngNextBoolean(rng, roulettePdf))
+                            throughput = throughput/roulettePdf;
+                        else
+                            killed = true;
+                    }
+                    if (killed) {
+                        state = ST_TERMINATED;
+                    } else if (isnan(sum3(ray.d) + sum3(ray.o)) || isnan(sum3(throughput) + sum3(em))) {
+                        state = ST_TERMINATED_BLACK;
+                    } else {
+                        bounce++;
+                        state = bounce < maxBounces ? ST_ACTIVE : ST_TERMINATED;
+                    }
+                }
+            };
+
+            // participating media (PathTracer.cpp:48-61): a path inside a medium samples a distance along the segment first
+            int med = -1;
+            uint32_t medBounce = 0;
+            bool volumeEvent = false, mediumEnd = false;
+            f3 volP = splat3(0.0f);
+            if (M & FEAT_MEDIA) {
+                med = FLAG_MEDIUM(flags);
+                medBounce = FLAG_MEDIUM_BOUNCE(flags);
+                if (med >= 0) {
+                    f3 w; float t; bool exited;
+                    if (!mediumSampleDistance<M>(s, med, rng, __float_as_int(hit.w) >= 0 ? hit.x : PT_INF, medBounce, w, t, exited)) {
+                        mediumEnd = true;                    // "return emission"
+                    } else {
+                        throughput = throughput*w;           // mediumSample.emission = 0
+                        volumeEvent = !exited;
+                        volP = ray.o + ray.d*t;
+                    }
+                }
+            }
+
+            if ((M & FEAT_MEDIA) && mediumEnd) {
+                state = ST_TERMINATED;
+            } else if ((M & FEAT_MEDIA) && volumeEvent) {
+                // TraceBase::handleVolume (TraceBase.cpp:496-514) with volumeEstimateDirect / volumeSampleDirect /
+                // volumeLightSample / volumePhaseSample (:323-381, 402-414, 471-481)
+                const TgHipMedium &mm = s.media[med];
+                const bool volumeNee = s.settings.enable_volume_light_sampling != 0;
+                wasSpecular = !volumeNee;
+                if (volumeNee && bounce < maxBounces - 1) {
+                    float lightWeight = 1.0f;
+                    int light = chooseLight<M>(s, rng, volP, lightWeight);
+                    if (light >= 0) {
+                        const uint32_t tag = SHADOW_TAG_MEDIA(light, med, bounce + 1);   // the medium is not re-selected at a volume vertex
+                        bool q0 = false, q1 = false;
+                        const bool meshLight = s.objects[light].type == TGHIP_OBJ_MESH;
+                        const bool diracLight = s.objects[light].type == TGHIP_OBJ_POINT;
+                        {
+                            f3 d; float dist, pdf;
+                            if (lightSampleDirect<M>(s, light, volP, rng, d, dist, pdf)) {
+                                float f = phaseEval(mm, ray.d, d);
+                                if (f != 0.0f && meshLight) {
+                                    float k = powerHeuristic(pdf, f)/pdf;                  // phase pdf == phase value
+                                    slotF4(st, A_SH_D0, slot) = mk4(d, dist);
+                                    slotF4(st, A_SH_C0, slot) = mk4(splat3(f*k), __uint_as_float(tag));
+                                    q0 = true;
+                                } else if (f != 0.0f) {
+                                    RayD sr; sr.o = volP; sr.d = d; sr.tmin = 0.0f; sr.tmax = PT_INF;   // parentRay.scatter(p, d, 0.0f)
+                                    LightHit lh;
+                                    bool reached;
+                                    if (diracLight) { lh.t = dist; lh.u = 0.0f; lh.v = 0.0f; lh.backSide = false; lh.n = splat3(0.0f); reached = true; }
+                                    else reached = lightIntersect<M>(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist);
+                                    if (reached) {
+                                        f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
+                                        if (!isZero(e)) {
+                                            f3 lightF = e*f/pdf;
+                                            if (!diracLight)
+                                                lightF = lightF*powerHeuristic(pdf, f);
+                                            slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
+                                            slotF4(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
+                                            q0 = true;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        if (!diracLight) {
+                            f3 w; float ppdf;
+                            phaseSample<M>(mm, rng, ray.d, w, ppdf);
+                            if (meshLight) {
+                                slotF4(st, A_SH_D1, slot) = mk4(w, ppdf);                      // directPdf needs the hit
+                                slotF4(st, A_SH_C1, slot) = mk4(splat3(1.0f), __uint_as_float(tag));
+                                q1 = true;
+                            } else {
+                                RayD sr; sr.o = volP; sr.d = w; sr.tmin = 0.0f; sr.tmax = PT_INF;
+                                LightHit lh;
+                                if (lightIntersect<M>(s, light, sr, lh)) {
+                                    f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
+                                    if (!isZero(e)) {
+                                        f3 phaseF = e*powerHeuristic(ppdf, lightDirectPdf<M>(s, light, w, volP, lh));
+                                        slotF4(st, A_SH_D1, slot) = mk4(w, lh.t);
+                                        slotF4(st, A_SH_C1, slot) = mk4(phaseF, __uint_as_float(tag));
+                                        q1 = true;
+                                    }
+                                }
+                            }
+                        }
+                        if (q0 || q1) {
+                            hasShadow = true;
+                            if (!q0) slotF4(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                            if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                            slotF4(st, A_SH_O, slot) = mk4(volP, 0.0f);
+                            slotF4(st, A_SH_W, slot) = mk4(throughput, lightWeight);
+                        }
+                    }
+                }
+                f3 w; float ppdf;
+                phaseSample<M>(mm, rng, ray.d, w, ppdf);         // the continuation; throughput *= 1
+                continuePath(volP, w, 0.0f);
+            } else if (__float_as_int(hit.w) < 0) {
                 // path escaped: TraceBase::handleInfiniteLights (TraceBase.cpp:570-578); the last infinite light wins
                 if ((M & FEAT_INFINITE) && bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0) {
                     // intersectInfinites (TraceableScene.hpp:194-209): every infinite light is asked, the last hit stays
@@ -594,6 +720,10 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                         bool pureSpecular = lobes != 0 && (lobes & ~(uint32_t)LOBE_SPECULAR) == 0;
                         if (light >= 0 && !pureSpecular && lobes != TGHIP_LOBE_FORWARD) {
                             uint32_t tag = (uint32_t)light | ((uint32_t)(bounce + 1) << 24);
+                            // media scenes: each shadow ray starts in the medium on its side of the surface (TraceBase.cpp:260-261, 302-303)
+                            auto mediaTag = [&](f3 dir) {
+                                return SHADOW_TAG_MEDIA(light, selectMedium(s.objects[info.object], med, dot(dir, info.Ng) < 0.0f), bounce + 1);
+                            };
                             bool q0 = false, q1 = false;
                             f3 inlineResult = splat3(0.0f);
                             const bool meshLight = (M & FEAT_MESHLIGHT) && s.objects[light].type == TGHIP_OBJ_MESH;
@@ -602,6 +732,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                             {
                                 f3 d; float dist, pdf;
                                 if (lightSampleDirect<M>(s, light, info.p, rng, d, dist, pdf)) {
+                                    if (M & FEAT_MEDIA) tag = mediaTag(d);
                                     ev.wo = toLocal(frame, d);
                                     ev.requested = LOBE_ALL_BUT_SPECULAR;
                                     if (isConsistent(ev.wo, d)) {
@@ -650,6 +781,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                 ev.weight = splat3(1.0f); ev.pdf = 1.0f;
                                 if (bsdfSample<M>(s, info.bsdf, ev) && !isZero(ev.weight)) {
                                     f3 wog = toGlobal(frame, ev.wo);
+                                    if (M & FEAT_MEDIA) tag = mediaTag(wog);
                                     if ((M & FEAT_MESHLIGHT) && meshLight) {
                                         if (isConsistent(ev.wo, wog)) {
                                             slotF4(st, A_SH_D1, slot) = mk4(wog, ev.pdf);          // directPdf needs the hit
@@ -725,38 +857,21 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     state = ST_TERMINATED;
                 } else {
                     f3 hp = ray.o + ray.d*hit.x;                 // ray.hitpoint()
-                    ray.o = hp; ray.d = wo; ray.tmin = 5e-4f; ray.tmax = PT_INF;
-                    // loop epilogue (PathTracer.cpp:108-126)
-                    if (max3(throughput) == 0.0f) {
-                        state = ST_TERMINATED;                   // the env term after `break` is throughput*L = 0
-                    } else {
-                        float roulettePdf = fmaxf(fabsf(throughput.x), fmaxf(fabsf(throughput.y), fabsf(throughput.z)));
-                        bool killed = false;
-                        if (bounce > 2 && roulettePdf < 0.1f) {
-                            if (rngNextBoolean(rng, roulettePdf))
-                                throughput = throughput/roulettePdf;
-                            else
-                                killed = true;
-                        }
-                        if (killed) {
-                            state = ST_TERMINATED;
-                        } else if (isnan(sum3(ray.d) + sum3(ray.o)) || isnan(sum3(throughput) + sum3(em))) {
-                            state = ST_TERMINATED_BLACK;
-                        } else {
-                            bounce++;
-                            state = bounce < maxBounces ? ST_ACTIVE : ST_TERMINATED;
-                        }
+                    if (M & FEAT_MEDIA) {                        // TraceBase.cpp:561-563
+                        med = selectMedium(s.objects[info.object], med, dot(wo, info.Ng) < 0.0f);
+                        medBounce = 0;                           // state.reset()
                     }
-                }
-                if (state == ST_ACTIVE) {
-                    slotF4(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
-                    slotF4(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
-                    *reinterpret_cast<uint2 *>(&slotU4(st, A_MISC, slot)) = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-                    if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL))
-                        slotU4(st, A_SAMP, slot).z = rng.dim;
+                    continuePath(hp, wo, 5e-4f);
                 }
             }
-            const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state);
+            if (state == ST_ACTIVE) {
+                slotF4(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
+                slotF4(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
+                *reinterpret_cast<uint2 *>(&slotU4(st, A_MISC, slot)) = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL))
+                    slotU4(st, A_SAMP, slot).z = rng.dim;
+            }
+            const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state) | ((M & FEAT_MEDIA) ? FLAG_MEDIUM_BITS(med, medBounce) : 0u);
             survives = state == ST_ACTIVE;
             black = state == ST_TERMINATED_BLACK;
             if (hasShadow) {
@@ -855,6 +970,8 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 float4 sd = r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot);
                 int endCap = (int)(tag & 0xFFFFFFu);
                 int bounce = (int)(tag >> 24);
+                int medium = -1;                               // media scenes (always the FORWARD walk): SHADOW_TAG_MEDIA
+                if (FORWARD && s.num_media) { endCap = (int)(tag & 0xFFFFu); medium = (int)((tag >> 16) & 0xFFu) - 1; }
                 RayD ray;
                 ray.o = xyz(so); ray.d = xyz(sd); ray.tmin = so.w; ray.tmax = sd.w;
                 float remaining = ray.tmax;
@@ -881,6 +998,8 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     if (ri >= 0)      // geometry reached through an instance belongs to the `instances` primitive (never a light)
                         hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)(hitInst >= 0 ? hitInst : ri)*3u).w));
                     if (meshLight && ri < 0) { transmittance = splat3(0.0f); break; }   // the ray never reaches the mesh
+                    if (medium >= 0)                             // TraceBase.cpp:103-112: ray.farT() is the hit distance when anything was hit
+                        transmittance = transmittance*mediumTransmittance(s, medium, ri >= 0 ? hit.x : ray.tmax);
                     if (ri < 0 || hitObject == endCap) {
                         if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
                         if (meshLight) {
@@ -918,6 +1037,8 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     transmittance = transmittance*transparency;
                     bounce++;
                     if (bounce >= s.settings.max_bounces) { transmittance = splat3(0.0f); break; }
+                    if (s.num_media)                             // :115
+                        medium = selectMedium(s.objects[info.object], medium, !info.backSide);
                     ray.o = ray.o + ray.d*hit.x;
                     travelled += hit.x;
                     remaining -= hit.x;
@@ -1315,6 +1436,7 @@ struct tghip_ctx {
     bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, MASK_FULL shading
     bool thinlens = false;                // thin-lens camera: passes run the EXT kernel variants (PT_PASS_THINLENS)
     bool haveSolids = false;              // cube / sphere / disk records: the dynamic-fetch kernels' SOLIDS variants
+    bool haveMedia = false;               // participating media: BSDF_MASK_ALL shading (the only FEAT_MEDIA variant), closest-hit shadow walk, never fused
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
@@ -1592,6 +1714,7 @@ static void chooseThreads(tghip_ctx *ctx)
     else if ((ctx->complexMask & ~MASK_COAT) == 0)  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, COAT_WAVES, 0>, 256, 0);
     else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
     else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
+    if (ctx->haveMedia) ctx->thrShadeSimple = ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     }
     int *dst[4] = {&ctx->thrClosest, &ctx->thrShadow, &ctx->thrShadeSimple, &ctx->thrShadeComplex};
     for (int i = 0; i < 4; ++i)
@@ -1752,6 +1875,22 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->light_tris, sd->num_light_tri_floats, &s.light_tris)) != TGHIP_OK) return rc;
     ctx->haveMeshLight = false;
     ctx->haveInstances = sd->num_instances > 0;
+    ctx->haveMedia = sd->num_media > 0;
+    if (ctx->haveMedia) {
+        if (!sd->media || sd->num_media > PT_MAX_MEDIA) { ctx->error = "more than 126 media are not supported"; return TGHIP_E_UNSUPPORTED; }
+        if (sd->num_objects >= (1u << 16)) { ctx->error = "media scenes support at most 65535 primitives"; return TGHIP_E_UNSUPPORTED; }
+        if (sd->camera.medium >= int32_t(sd->num_media)) { ctx->error = "camera medium out of range"; return TGHIP_E_INVALID; }
+        for (uint32_t i = 0; i < sd->num_objects; ++i)
+            if (sd->objects[i].int_medium >= int32_t(sd->num_media) || sd->objects[i].ext_medium >= int32_t(sd->num_media)) {
+                ctx->error = "primitive medium out of range";
+                return TGHIP_E_INVALID;
+            }
+        for (uint32_t i = 0; i < sd->num_media; ++i)
+            if (sd->media[i].phase_type != TGHIP_PHASE_ISOTROPIC && sd->media[i].phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN) {
+                ctx->error = "unknown phase function";
+                return TGHIP_E_UNSUPPORTED;
+            }
+    }
     ctx->thinlens = sd->camera.type == TGHIP_CAMERA_THINLENS;
     if (sd->camera.type != TGHIP_CAMERA_PINHOLE && sd->camera.type != TGHIP_CAMERA_THINLENS) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
     for (uint32_t i = 0; i < sd->num_lights; ++i)
@@ -1821,6 +1960,10 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     s.num_lights = sd->num_lights; s.num_infinite_lights = sd->num_infinite_lights;
     s.num_bsdfs = sd->num_bsdfs; s.num_textures = sd->num_textures;
     s.num_instances = sd->num_instances;
+    s.media = nullptr;
+    s.num_media = sd->num_media;
+    if (sd->num_media && (rc = uploadArray(ctx, ctx->sceneMem, sd->media, size_t(sd->num_media), &s.media)) != TGHIP_OK) return rc;
+    if (ctx->haveMedia) ctx->haveForward = true;   // shadow rays pick up transmittance segment by segment: the closest-hit walk
     if ((rc = uploadArray(ctx, ctx->sceneMem, &sd->camera, 1, &s.camera)) != TGHIP_OK) return rc;
     s.sobol = nullptr;
     if (sd->sobol_matrices) {
@@ -2021,10 +2164,14 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling / instance transforms
+            if (ctx->haveMedia) {                                  // the one variant with FEAT_MEDIA, for both classes
+                launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 0);
+                if (ctx->haveComplex) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 1);
+            }
+            else if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling / instance transforms
             else if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
             else                     launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
-            if (ctx->haveComplex) {
+            if (ctx->haveComplex && !ctx->haveMedia) {
                 if (ctx->haveMeshLight || ctx->haveInstances)   launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
@@ -2086,7 +2233,7 @@ int tghip_wait(tghip_ctx *ctx)
     const uint32_t ownedTiles = numTiles > pass.shard_index ? (numTiles - pass.shard_index + shardCount - 1)/shardCount : 0;
     uint32_t spp = pass.spp_end - pass.spp_begin, sppBegin = pass.spp_begin;
     PassParams base{};
-    base.flags = pass.flags | (ctx->thinlens ? PT_PASS_THINLENS : 0u);
+    base.flags = pass.flags | (ctx->thinlens ? PT_PASS_THINLENS : 0u) | (ctx->haveMedia ? PT_PASS_MEDIA : 0u);
     base.variance_w = (w + 3)/4;
     if (pass.flags & TGHIP_PASS_SOBOL) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->dTileSeeds, pass.tile_seeds, size_t(numTiles)*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));

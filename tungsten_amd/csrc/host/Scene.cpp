@@ -541,6 +541,55 @@ std::shared_ptr<Bsdf> Scene::fetchBsdf(const JsonValue &v) const
     throw JsonLoadException("Type mismatch: Expecting either an object or an object reference here");
 }
 
+// ------------------------------------------------------------------------------------------
+// Media: homogeneous medium with exponential transmittance and an isotropic / Henyey-Greenstein phase function
+// (media/HomogeneousMedium.cpp:19-26, Medium.cpp:20-30); everything else is rejected by name
+// ------------------------------------------------------------------------------------------
+void Medium::prepareForRender()   // HomogeneousMedium.cpp:43-49
+{
+    sigmaA = materialSigmaA*density;
+    sigmaS = materialSigmaS*density;
+    sigmaT = sigmaA + sigmaS;
+    absorptionOnly = sigmaS.x() == 0.0f && sigmaS.y() == 0.0f && sigmaS.z() == 0.0f;
+}
+
+std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
+{
+    auto m = std::make_shared<Medium>();
+    std::string type = v["type"].asString();
+    if (type != "homogeneous")
+        throw JsonLoadException("medium type '" + type + "' is not supported by path_tracer_hip (homogeneous only)");
+    v.getField("name", m->name);
+    getVec3(v, "sigma_a", m->materialSigmaA);
+    getVec3(v, "sigma_s", m->materialSigmaS);
+    v.getField("density", m->density);
+    v.getField("max_bounces", m->maxBounce);
+    if (const JsonValue &t = v["transmittance"]) {
+        std::string tt = t.isString() ? t.asString() : t["type"].asString();
+        if (tt != "exponential")
+            throw JsonLoadException("transmittance '" + tt + "' is not supported by path_tracer_hip (exponential only)");
+    }
+    if (const JsonValue &ph = v["phase_function"]) {
+        std::string pt = ph.isString() ? ph.asString() : ph["type"].asString();
+        if (pt == "isotropic") m->phaseType = 0;
+        else if (pt == "henyey_greenstein") { m->phaseType = 1; if (ph.isObject()) ph.getField("g", m->phaseG); }
+        else throw JsonLoadException("phase function '" + pt + "' is not supported by path_tracer_hip");
+    }
+    return m;
+}
+
+std::shared_ptr<Medium> Scene::fetchMedium(const JsonValue &v) const
+{
+    if (v.isString()) {
+        for (const auto &m : media)
+            if (m->name == v.asString()) return m;
+        throw JsonLoadException("Unable to find an object with name '" + v.asString() + "'");
+    } else if (v.isObject()) {
+        return instantiateMedium(v);
+    }
+    throw JsonLoadException("Type mismatch: Expecting either an object or an object reference here");
+}
+
 std::shared_ptr<Primitive> Scene::fetchPrimitive(const JsonValue &v) const
 {
     if (v.isString()) {
@@ -579,8 +628,8 @@ std::shared_ptr<Primitive> Scene::instantiatePrimitive(const JsonValue &v) const
     getTransform(v, "transform", p->transform);
     if (const JsonValue &e = v["emission"]) p->emission = fetchTexture(e, true);
     if (const JsonValue &pw = v["power"]) p->power = fetchTexture(pw, true);
-    if (v["int_medium"] || v["ext_medium"])
-        throw JsonLoadException("participating media are a 'next' row of the hot-path scope (SURVEY.md 8f2)");
+    if (const JsonValue &m = v["int_medium"]) p->intMedium = fetchMedium(m);   // Primitive.cpp:30-31
+    if (const JsonValue &m = v["ext_medium"]) p->extMedium = fetchMedium(m);
 
     auto defaultBsdf = [&]() {   // Primitive::_defaultBsdf = LambertBsdf (Primitive.cpp:11)
         auto b = std::make_shared<Bsdf>();
@@ -876,7 +925,7 @@ Camera::Camera()
     precompute();
 }
 
-void Camera::fromJson(const JsonValue &v)
+void Camera::fromJson(const JsonValue &v, const Scene &scene)
 {
     v.getField("tonemap", tonemap);
     const JsonValue &res = v["resolution"];
@@ -884,8 +933,7 @@ void Camera::fromJson(const JsonValue &v)
         if (res.isNumber()) { resX = resY = unsigned(res.asDouble()); }
         else { resX = unsigned(res[0].asDouble()); resY = unsigned(res[1].asDouble()); }
     }
-    if (v["medium"])
-        throw JsonLoadException("camera media are a 'next' row of the hot-path scope (SURVEY.md 8f2)");
+    if (const JsonValue &m = v["medium"]) medium = scene.fetchMedium(m);       // Camera.cpp:49-50
     v.getField("reconstruction_filter", filterName);
 
     if (v["transform"]) {   // Camera.cpp:55-66
@@ -1006,9 +1054,10 @@ void IntegratorSettings::fromJson(const JsonValue &v)
 // ------------------------------------------------------------------------------------------
 void Scene::fromJson(const JsonValue &root)
 {
-    if (const JsonValue &media = root["media"])
-        if (media.isArray() && media.size() > 0)
-            throw JsonLoadException("participating media are a 'next' row of the hot-path scope (SURVEY.md 8f2)");
+    // media first: primitives and the camera refer to them by name (Scene.cpp:236-253)
+    if (const JsonValue &jm = root["media"])
+        for (size_t i = 0; i < jm.size(); ++i)
+            media.push_back(instantiateMedium(jm[i]));
 
     // bsdfs may reference earlier bsdfs by name (Scene.cpp:236-253 loads them in file order)
     if (const JsonValue &jb = root["bsdfs"])
@@ -1018,7 +1067,7 @@ void Scene::fromJson(const JsonValue &root)
         for (size_t i = 0; i < jp.size(); ++i)
             primitives.push_back(instantiatePrimitive(jp[i]));
     if (const JsonValue &cam = root["camera"])
-        camera.fromJson(cam);
+        camera.fromJson(cam, *this);
     if (const JsonValue &integ = root["integrator"])
         integrator.fromJson(integ);
     if (const JsonValue &rend = root["renderer"])

@@ -69,6 +69,21 @@ struct Bsdf
     void prepareForRender();
 };
 
+// ---- participating media (src/core/media, phasefunctions, transmittances) ----------------
+struct Medium   // media/HomogeneousMedium.{hpp,cpp} + Medium.cpp; transmittance = the default ExponentialTransmittance
+{
+    std::string name;
+    Vec3f materialSigmaA = Vec3f(0.0f), materialSigmaS = Vec3f(0.0f);
+    float density = 1.0f;
+    int maxBounce = 1024;
+    int phaseType = 0;          // 0 isotropic, 1 henyey_greenstein
+    float phaseG = 0.0f;
+    // prepareForRender (HomogeneousMedium.cpp:43-49)
+    Vec3f sigmaA, sigmaS, sigmaT;
+    bool absorptionOnly = false;
+    void prepareForRender();
+};
+
 // ---- primitives (src/core/primitives) ----------------------------------------------------
 struct MeshVertex { float pos[3], normal[3], uv[2]; };          // Vertex.hpp:10-13 (32 B, .wo3 layout)
 struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp:14-28 (16 B)
@@ -81,6 +96,7 @@ struct Primitive
     Mat4f transform;
     std::shared_ptr<Texture> emission, power;
     std::vector<std::shared_ptr<Bsdf>> bsdfs;
+    std::shared_ptr<Medium> intMedium, extMedium;   // Primitive.cpp:30-31
     // mesh
     std::string file;
     bool smooth = false, backfaceCulling = false, recomputeNormals = false;
@@ -128,13 +144,14 @@ struct Camera
     bool thinlens = false;
     float focusDist = 1.0f, apertureSize = 0.001f, catEye = 0.0f;
     Mat4f invTransform;
+    std::shared_ptr<Medium> medium;                 // Camera.cpp:49-50
     // precompute()
     float ratio = 0, pixelSizeX = 0, planeDist = 0;
     // ReconstructionFilter::precompute (cameras/ReconstructionFilter.cpp:34-58)
     int filterType = 2; float filterWidth = 1.0f, filterBinSize = 0; float filterCdf[32];
 
     Camera();
-    void fromJson(const JsonValue &v);
+    void fromJson(const JsonValue &v, const class Scene &scene);
     void precompute();
 };
 
@@ -166,8 +183,11 @@ class Scene
     std::shared_ptr<Bsdf> instantiateBsdf(const JsonValue &v) const;
     std::shared_ptr<Primitive> instantiatePrimitive(const JsonValue &v) const;
     std::shared_ptr<Primitive> fetchPrimitive(const JsonValue &v) const;          // Scene.cpp:82-93
+    std::shared_ptr<Medium> instantiateMedium(const JsonValue &v) const;
 
 public:
+    std::shared_ptr<Medium> fetchMedium(const JsonValue &v) const;               // Scene.cpp:105-108
+    std::vector<std::shared_ptr<Medium>> media;
     std::vector<std::shared_ptr<Bsdf>> bsdfs;
     std::vector<std::shared_ptr<Primitive>> primitives;
     Camera camera;

@@ -134,6 +134,27 @@ void TraceableScene::flatten()
     for (auto &b : _scene.bsdfs)
         addBsdf(b);
 
+    // ---- media (Scene::_media; inline media of primitives / the camera are added on first use) ----
+    std::vector<const Medium *> mediumKeys;
+    auto addMedium = [&](const std::shared_ptr<Medium> &m) -> int32_t {
+        if (!m) return -1;
+        for (size_t i = 0; i < mediumKeys.size(); ++i)
+            if (mediumKeys[i] == m.get()) return int32_t(i);
+        m->prepareForRender();
+        TgHipMedium d;
+        std::memset(&d, 0, sizeof(d));
+        copy3(d.sigma_a, m->sigmaA); copy3(d.sigma_s, m->sigmaS); copy3(d.sigma_t, m->sigmaT);
+        d.absorption_only = m->absorptionOnly ? 1 : 0;
+        d.max_bounce = m->maxBounce;
+        d.phase_type = m->phaseType;
+        d.phase_g = m->phaseG;
+        mediumKeys.push_back(m.get());
+        _media.push_back(d);
+        return int32_t(_media.size() - 1);
+    };
+    for (auto &m : _scene.media)
+        addMedium(m);
+
     // ---- objects, light lists, records -------------------------------------------------------
     std::vector<Box3f> recBounds;
     std::vector<std::shared_ptr<Primitive>> masterPrims;   // distinct master meshes of all `instances` primitives
@@ -157,6 +178,8 @@ void TraceableScene::flatten()
         copy3(o.pos, p.pos); copy3(o.scale, p.scale);
         copyRot(o.rot, p.rot);
         copy3(o.face_cdf, p.faceCdf);
+        o.int_medium = addMedium(p.intMedium);
+        o.ext_medium = addMedium(p.extMedium);
 
         if (emissive) {
             if (p.isSamplable()) {
@@ -322,6 +345,7 @@ void TraceableScene::flatten()
             TgHipObject o;
             std::memset(&o, 0, sizeof(o));
             o.type = TGHIP_OBJ_MESH;
+            o.int_medium = o.ext_medium = -1;
             o.bsdf = m.bsdfs.empty() ? -1 : addBsdf(m.bsdfs[0]);
             o.emission = -1; o.light = -1; o.first_light_tri = -1;
             o.flags = m.smooth ? TGHIP_OBJF_SMOOTH : 0;
@@ -404,6 +428,7 @@ void TraceableScene::flatten()
     c.aperture_size = cam.apertureSize;
     c.cat_eye = cam.catEye;
     for (int i = 0; i < 12; ++i) c.inv_xf[i] = cam.invTransform[i];
+    c.medium = addMedium(cam.medium);
 
     const IntegratorSettings &is = _scene.integrator;
     _desc.settings.min_bounces = is.minBounces;
@@ -411,6 +436,9 @@ void TraceableScene::flatten()
     _desc.settings.enable_light_sampling = is.enableLightSampling ? 1 : 0;
     _desc.settings.enable_two_sided_shading = is.enableTwoSidedShading ? 1 : 0;
     _desc.settings.enable_consistency_checks = is.enableConsistencyChecks ? 1 : 0;
+    _desc.settings.enable_volume_light_sampling = is.enableVolumeLightSampling ? 1 : 0;
+    if (!_media.empty() && (!is.lowOrderScattering || !is.includeSurfaces))
+        throw std::runtime_error("path_tracer_hip renders media with low_order_scattering and include_surfaces at their defaults (true) only");
 
     _desc.abi_version = TGHIP_ABI_VERSION;
     _desc.num_nodes = uint32_t(_nodes.size());
@@ -428,6 +456,8 @@ void TraceableScene::flatten()
     _desc.infinite_lights = _infiniteLights.data();
     _desc.bsdfs = _bsdfs.data();
     _desc.textures = _textures.data();
+    _desc.media = _media.empty() ? nullptr : _media.data();
+    _desc.num_media = uint32_t(_media.size());
     _desc.texels = _texels.data(); _desc.num_texel_floats = _texels.size();
     _desc.dist = _dist.data();     _desc.num_dist_floats = _dist.size();
     _desc.light_tris = _lightTris.data(); _desc.num_light_tri_floats = _lightTris.size();

@@ -28,6 +28,7 @@ class TraceableScene
     std::vector<TgHipObject> _objects;
     std::vector<int32_t> _lights, _infiniteLights;
     std::vector<TgHipBsdf> _bsdfs;
+    std::vector<TgHipMedium> _media;
     std::vector<TgHipTexture> _textures;
     std::vector<float> _texels, _dist, _lightTris;
     std::vector<std::shared_ptr<Primitive>> _allPrims;   // scene primitives (+ default light)
