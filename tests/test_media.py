@@ -1,0 +1,96 @@
+"""Participating media: analytic properties of the homogeneous medium that hold at any size, checked on
+the oracle (CPU) and on the HIP path (gpu).  The per-sample parity with the reference is in test_oracle_golden.py /
+test_gpu_parity.py (cases cornell_fog, cornell_smoke, cornell_fog_smoke_sobol)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenes
+import tungsten_amd as tg
+
+SEED = tg.DEFAULT_SEED
+SIGMA = [0.05, 0.11, 0.23]
+EMISSION = [2.0, 3.0, 4.0]
+
+
+def _panel(sigma_a, sigma_s=0.0):
+    """An emissive, non-reflecting panel filling the view of the Cornell camera, which sits in a homogeneous medium."""
+    def edit(scene):
+        scene["primitives"] = [{"name": "panel", "type": "quad", "bsdf": {"type": "null"}, "emission": EMISSION,
+                                "transform": {"position": [0, 1, 0], "scale": [60, 1, 60], "rotation": [90, 0, 0]}}]
+        if sigma_a is not None:
+            scene["media"] = [{"name": "haze", "type": "homogeneous", "sigma_a": sigma_a, "sigma_s": sigma_s}]
+            scene["camera"]["medium"] = "haze"
+    return edit
+
+
+def _oracle_image(path, spp):
+    flat = tg.FlattenedScene(path)
+    osum, ocount = oracle_lib.render(flat.desc, flat.width, flat.height, 0, spp, SEED)
+    flat.close()
+    return osum/np.maximum(ocount, 1)[..., None]
+
+
+def _gpu_image(path, spp):
+    r = tg.Renderer(path, seed=SEED)
+    r.render()
+    mean = r.image()[0]
+    r.close()
+    return mean
+
+
+def _beer_lambert(render, tmp_path, res):
+    clear = render(scenes.cornell(tmp_path, name="clear.json", resolution=res, spp=1, edit=_panel(None)), 1)
+    hazy = render(scenes.cornell(tmp_path, name="hazy.json", resolution=res, spp=1, edit=_panel(SIGMA)), 1)
+    assert np.allclose(clear, np.array(EMISSION, np.float32)[None, None], rtol=1e-6), "the panel does not fill the view"
+    # an absorption-only medium draws no random numbers (HomogeneousMedium.cpp:76-82): both renders take the same camera
+    # sample, so per pixel hazy/clear = exp(-sigma_a t) with t the distance to the panel along that sample's ray
+    t = -np.log(hazy/clear)/np.array(SIGMA)[None, None]
+    assert np.allclose(t[..., 0], t[..., 1], rtol=2e-4) and np.allclose(t[..., 0], t[..., 2], rtol=2e-4)
+    h, w = t.shape[:2]
+    dist = 6.8                                            # camera (0, 1, 6.8) to the panel's plane z = 0
+    assert t.min() >= dist*(1 - 1e-4)
+    assert abs(t[h//2 - 1:h//2 + 1, w//2 - 1:w//2 + 1].mean() - dist) < 2e-3*dist
+    assert t.max() > 1.05*dist                            # oblique rays travel farther
+
+
+def _single_scatter_is_darker_and_not_black(render, tmp_path, res, spp):
+    """With scattering the panel is seen through extinction sigma_a + sigma_s, and light scattered towards the camera adds
+    radiance back: the image lies between the absorption-only images for sigma_a + sigma_s and for sigma_a alone."""
+    sa, ss = [0.02, 0.02, 0.02], [0.08, 0.08, 0.08]
+    img = render(scenes.cornell(tmp_path, name="scatter.json", resolution=res, spp=spp, edit=_panel(sa, ss)), spp)
+    lo = render(scenes.cornell(tmp_path, name="lo.json", resolution=res, spp=1, edit=_panel([0.1, 0.1, 0.1])), 1)
+    hi = render(scenes.cornell(tmp_path, name="hi.json", resolution=res, spp=1, edit=_panel(sa)), 1)
+    m, l, h = img.mean(axis=(0, 1)), lo.mean(axis=(0, 1)), hi.mean(axis=(0, 1))
+    assert (m > l*1.02).all() and (m < h*0.98).all(), (l, m, h)
+
+
+def test_oracle_beer_lambert(tmp_path):
+    _beer_lambert(_oracle_image, tmp_path, (48, 27))
+
+
+def test_oracle_scattering_between_bounds(tmp_path):
+    _single_scatter_is_darker_and_not_black(_oracle_image, tmp_path, (32, 18), 64)
+
+
+@pytest.mark.gpu
+def test_gpu_beer_lambert_full_size(tmp_path):
+    _beer_lambert(_gpu_image, tmp_path, (1280, 720))
+
+
+@pytest.mark.gpu
+def test_gpu_scattering_between_bounds(tmp_path):
+    _single_scatter_is_darker_and_not_black(_gpu_image, tmp_path, (320, 180), 64)
+
+
+def test_unsupported_media_are_rejected(tmp_path):
+    def voxel(scene):
+        scene["media"] = [{"name": "v", "type": "voxel", "sigma_a": 1, "sigma_s": 1}]
+    with pytest.raises(Exception):
+        tg.FlattenedScene(scenes.cornell(tmp_path, name="voxel.json", resolution=(16, 9), spp=1, edit=voxel)).close()
+
+    def low_order(scene):
+        _panel([0.1, 0.1, 0.1])(scene)
+        scene["integrator"]["low_order_scattering"] = False
+    with pytest.raises(Exception):
+        tg.FlattenedScene(scenes.cornell(tmp_path, name="low.json", resolution=(16, 9), spp=1, edit=low_order)).close()
