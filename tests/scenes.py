@@ -526,4 +526,7 @@ INTEGRATE_CASES = {
     # the renderer block as materialtest.json ships it (materialtest.json:188-190): Sobol' + adaptive, spp_step 16
     "materialtest_as_shipped": (materialtest, dict(resolution=(64, 36), spp=48, spp_step=16,
                                                    renderer={"adaptive_sampling": True, "stratified_sampler": True})),
+    # participating media under the adaptive pass loop with the Sobol' sampler
+    "cornell_fog_smoke_adaptive": (cornell, dict(resolution=(48, 28), spp=48, spp_step=16, edit=_fog_and_smoke,
+                                                 renderer={"adaptive_sampling": True, "stratified_sampler": True})),
 }
