@@ -263,6 +263,22 @@ typedef struct TgHipSceneDesc {
                                    counter-based PCG stream (the reference uses a sequential per-tile stream there) */
 #define TGHIP_PASS_RECORDS 2u   /* keep the per-4x4-pixel SampleRecords (path_tracer/SampleRecord.hpp:46-65) up to date */
 
+#define TGHIP_PASS_AUX     4u   /* keep the auxiliary output buffers (TgHipAuxPixel) up to date: depth / normal / albedo / visibility of the
+                                   first non-specular vertex (PathTracer.cpp:78-96, 133-140) and the colour, each with its A/B halves and
+                                   sample variance (cameras/OutputBuffer.hpp:90-132) */
+
+/* auxiliary outputs (cameras/OutputBufferSettings.cpp:8-14) and their channels in TgHipAuxPixel */
+enum { TGHIP_AUX_COLOR = 0, TGHIP_AUX_DEPTH = 1, TGHIP_AUX_NORMAL = 2, TGHIP_AUX_ALBEDO = 3, TGHIP_AUX_VISIBILITY = 4, TGHIP_AUX_OUTPUTS = 5 };
+#define TGHIP_AUX_CHANNELS 11u   /* color rgb 0-2 | depth 3 | normal xyz 4-6 | albedo rgb 7-9 | visibility 10 */
+/* OutputBuffer state of one pixel for all five outputs, kept as if two_buffer_variance and sample_variance were both on
+ * (OutputBuffer.hpp:90-132: _bufferA = running mean of the samples with even index, _bufferB = odd, _variance = Welford sum
+ * against the mean of both, _sampleCount per output -- an output skips the samples that did not record it).  The host
+ * derives what a scene's OutputBufferSettings ask for: mean = (A nA + B nB)/n. */
+typedef struct TgHipAuxPixel {
+    float    a[11], b[11], variance[11];
+    uint32_t count[5];
+} TgHipAuxPixel;              /* 152 B */
+
 /* the device-resident part of SampleRecord: Welford mean / running variance of the sample luminance,
  * accumulated in the reference's order (tile row-major pixel order, then sample index: PathTraceIntegrator.cpp:136-156) */
 typedef struct TgHipSampleRecord { uint32_t sample_count; float mean, running_variance; } TgHipSampleRecord;
@@ -318,6 +334,10 @@ int tghip_upload_framebuffer(tghip_ctx *ctx, const float *rgb_sum, const uint32_
  * this context never rendered stay zero; upload restores a resumed / merged state. */
 int tghip_download_records(tghip_ctx *ctx, TgHipSampleRecord *out, size_t n);
 int tghip_upload_records(tghip_ctx *ctx, const TgHipSampleRecord *in, size_t n);
+/* auxiliary output buffers (TGHIP_PASS_AUX), one TgHipAuxPixel per image pixel; allocated by the first TGHIP_PASS_AUX pass,
+ * cleared by tghip_clear_framebuffer (Camera::serializeOutputBuffers / deserializeOutputBuffers, Camera.cpp:222-238) */
+int tghip_download_aux(tghip_ctx *ctx, TgHipAuxPixel *out, size_t npixels);
+int tghip_upload_aux(tghip_ctx *ctx, const TgHipAuxPixel *in, size_t npixels);
 int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);

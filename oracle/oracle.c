@@ -1478,11 +1478,18 @@ static v3 inf_uvToDirection(const TgHipObject *o, float u, float v, float *sinTh
 /* ---------------------------------------------------------------------------------------------
  * The integrator: TraceBase + PathTracer
  * ------------------------------------------------------------------------------------------- */
+/* what one sample adds to the output buffers (PathTracer.cpp:78-96, 133-140): v = depth | normal | albedo | visibility
+ * in TgHipAuxPixel channel order (3..10), has[output] = whether the sample recorded it */
+typedef struct AuxSample { int has[TGHIP_AUX_OUTPUTS]; float v[TGHIP_AUX_CHANNELS]; } AuxSample;
+
 typedef struct {
     const TgHipSceneDesc *s;
     Sampler *sampler;
     TravStats *st;
     uint64_t shadow_rays, closest_rays;
+    struct AuxSample *aux;          /* auxiliary output values of the sample in flight (NULL: _trackOutputValues off) */
+    v3 *visRequest;                 /* handleSurface's `transmittance` out-parameter (TraceBase.cpp:520): where lightSample's shadow result goes */
+    v3 *transmittanceOut;           /* = visRequest while lightSample's attenuatedEmission runs (:275), else NULL (bsdfSample / volume: nullptr) */
 } Ctx;
 
 typedef struct { Frame frame; v3 wi; int flipped; } Local;   /* the part of SurfaceScatterEvent that persists */
@@ -1948,6 +1955,8 @@ static v3 attenuatedEmission(Ctx *c, int lightObj, int medium, float expectedDis
     }
     ray->tmax = lh->t;
     v3 shadow = generalizedShadowRay(c, ray, medium, lightObj, bounce);
+    if (c->transmittanceOut)                               /* if (transmittance) *transmittance = shadow (:169-170) */
+        *c->transmittanceOut = shadow;
     if (viszero(shadow))
         return vs(0.0f);
     return vmul(shadow, light_evalDirect(c->s, lightObj, lh));
@@ -1969,7 +1978,9 @@ static v3 lightSample(Ctx *c, int lightObj, const Info *info, const Local *l, in
     medium = selectMedium(&c->s->objects[info->object], medium, vdot(d, info->Ng) < 0.0f);   /* :260-261 */
     Ray ray = {info->p, d, info->epsilon, INFINITY};
     LightHit lh;
+    c->transmittanceOut = c->visRequest;
     v3 em = attenuatedEmission(c, lightObj, medium, dist, bounce, &ray, &lh);
+    c->transmittanceOut = NULL;
     if (viszero(em))
         return vs(0.0f);
     v3 lightF = vdivs(vmul(f, em), pdf);
@@ -2167,6 +2178,8 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
     Info info;
     int bounce = 0;
     int medium = s->num_media ? cam->medium : -1;      /* _scene->cam().medium() */
+    int recorded = 0;                                   /* recordedOutputValues */
+    float hitDistance = 0.0f;
     MediumState state = {1, 0};                         /* state.reset() */
     const int volumeNee = s->settings.enable_volume_light_sampling;
     c->closest_rays++;
@@ -2187,20 +2200,25 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
                 break;
         }
         if (hitSurface) {
+        hitDistance += hit.t;                              /* PathTracer.cpp:64 */
         Local l = makeLocalScatterEvent(c, &info, &ray);
 
-        /* TraceBase::handleSurface (TraceBase.cpp:516-568) */
+        /* TraceBase::handleSurface (TraceBase.cpp:516-568); terminate = it returned false */
         Event fe = make_event(c, &info, &l, TGHIP_LOBE_FORWARD);
         fe.wo = vneg(fe.wi);
         v3 transparency = bsdf_eval_rt(s, info.bsdf, &fe);
         float transparencyScalar = vavg(transparency);
-        v3 wo;
+        v3 wo = ray.d;
+        v3 transmittance = vs(-1.0f);
+        int terminate = 0;
         if (nextBoolean(c->sampler, transparencyScalar)) {
-            wo = ray.d;
             throughput = vmul(throughput, vdivs(transparency, transparencyScalar));
         } else {
-            if (nee && bounce < maxBounces - 1)
+            if (nee && bounce < maxBounces - 1) {
+                c->visRequest = c->aux ? &transmittance : NULL;
                 emission = vadd(emission, vmul(estimateDirect(c, &info, &l, medium, bounce + 1), throughput));
+                c->visRequest = NULL;
+            }
             const TgHipObject *o = &s->objects[info.object];
             if (o->emission >= 0 && bounce >= minBounces) {
                 if (!nee || wasSpecular || o->light < 0) {
@@ -2209,14 +2227,37 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
                 }
             }
             Event e = make_event(c, &info, &l, LOBE_ALL);
-            if (!bsdf_sample_rt(s, info.bsdf, &e))
-                return emission;
-            wo = toGlobal(&l.frame, e.wo);
-            if (!isConsistent(c, &info, &l, e.wo, wo))
-                return emission;
-            throughput = vmul(throughput, e.weight);
-            wasSpecular = (e.sampled & LOBE_SPECULAR) != 0;
+            if (!bsdf_sample_rt(s, info.bsdf, &e)) {
+                terminate = 1;
+            } else {
+                wo = toGlobal(&l.frame, e.wo);
+                if (!isConsistent(c, &info, &l, e.wo, wo)) {
+                    terminate = 1;
+                } else {
+                    throughput = vmul(throughput, e.weight);
+                    wasSpecular = (e.sampled & LOBE_SPECULAR) != 0;
+                }
+            }
         }
+        if (c->aux && !recorded && (!wasSpecular || terminate)) {      /* PathTracer.cpp:78-96 */
+            AuxSample *a = c->aux;
+            a->has[TGHIP_AUX_DEPTH] = 1;  a->v[3] = hitDistance;
+            a->has[TGHIP_AUX_NORMAL] = 1; a->v[4] = info.Ns.x; a->v[5] = info.Ns.y; a->v[6] = info.Ns.z;
+            int ab = info.bsdf;                                         /* TransparencyBsdf: its base's albedo */
+            if (s->bsdfs[ab].type == TGHIP_BSDF_TRANSPARENCY) ab = s->bsdfs[ab].sub0;
+            v3 albedo = texture_eval(s, s->bsdfs[ab].albedo, info.u, info.v);
+            if (s->objects[info.object].emission >= 0) {                /* isEmissive(): + evalDirect */
+                LightHit lh; lh.u = info.u; lh.v = info.v; lh.backSide = info.backSide;
+                albedo = vadd(albedo, light_evalDirect(s, info.object, &lh));
+            }
+            a->has[TGHIP_AUX_ALBEDO] = 1; a->v[7] = albedo.x; a->v[8] = albedo.y; a->v[9] = albedo.z;
+            if (transmittance.x != -1.0f || transmittance.y != -1.0f || transmittance.z != -1.0f) {
+                a->has[TGHIP_AUX_VISIBILITY] = 1; a->v[10] = vavg(transmittance);
+            }
+            recorded = 1;
+        }
+        if (terminate)
+            return emission;
         medium = selectMedium(&s->objects[info.object], medium, vdot(wo, info.Ng) < 0.0f);   /* :561-563 */
         state.firstScatter = 1; state.bounce = 0;
         v3 hp = vadd(ray.o, vscale(ray.d, hit.t));      /* ray.hitpoint() */
@@ -2253,8 +2294,9 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
         }
     }
     /* handleInfiniteLights (TraceBase.cpp:570-578, TraceableScene.hpp:194-209): the last infinite light wins */
+    int objIdx = -1;                                   /* info.primitive after intersectInfinites, when it was asked */
+    v3 envAlbedo = vs(0.0f);
     if (bounce >= minBounces && bounce < maxBounces && s->num_infinite_lights > 0) {
-        int objIdx = -1;
         for (uint32_t i = 0; i < s->num_infinite_lights; ++i) {      /* every infinite light is asked; the last hit stays in `data` */
             const TgHipObject *c = &s->objects[s->infinite_lights[i]];
             if (c->type != TGHIP_OBJ_INFINITE_SPHERE_CAP || vdot(ray.d, ld3(c->normal)) >= c->scale[0])
@@ -2262,15 +2304,21 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
         }
         if (objIdx >= 0) {
             const TgHipObject *o = &s->objects[objIdx];
-            if (!nee || wasSpecular || !(o->flags & TGHIP_OBJF_SAMPLE)) {
-                float u = 0.0f, v = 0.0f;
-                if (o->type == TGHIP_OBJ_INFINITE_SPHERE) inf_directionToUV(o, ray.d, &u, &v, NULL);
-                emission = vadd(emission, vmul(throughput, texture_eval(s, o->emission, u, v)));
-            }
+            float u = 0.0f, v = 0.0f;
+            if (o->type == TGHIP_OBJ_INFINITE_SPHERE) inf_directionToUV(o, ray.d, &u, &v, NULL);
+            envAlbedo = texture_eval(s, o->emission, u, v);              /* info.primitive->evalDirect(data, info) */
+            if (!nee || wasSpecular || !(o->flags & TGHIP_OBJF_SAMPLE))
+                emission = vadd(emission, vmul(throughput, envAlbedo));
         }
     }
     if (isnan(vsum(throughput) + vsum(emission)))
         return vs(0.0f);
+    if (c->aux && !recorded) {                          /* PathTracer.cpp:133-140 */
+        AuxSample *a = c->aux;
+        if (bounce == 0) { a->has[TGHIP_AUX_DEPTH] = 1; a->v[3] = 0.0f; }
+        a->has[TGHIP_AUX_NORMAL] = 1; a->v[4] = -ray.d.x; a->v[5] = -ray.d.y; a->v[6] = -ray.d.z;
+        if (objIdx >= 0) { a->has[TGHIP_AUX_ALBEDO] = 1; a->v[7] = envAlbedo.x; a->v[8] = envAlbedo.y; a->v[9] = envAlbedo.z; }
+    }
     return emission;
 }
 
@@ -2328,8 +2376,45 @@ int oracle_trace_sample_log(const TgHipSceneDesc *s, uint32_t seed, uint32_t til
 /* One pass over the shard's tiles, renderTile semantics (PathTraceIntegrator.cpp:136-156) with the
  * framebuffer kept as sum + count (OutputBuffer.hpp:104-107 drops NaN/Inf samples without counting).
  * records (may be NULL): the SampleRecords, updated in the reference's order when TGHIP_PASS_RECORDS is set. */
+/* OutputBuffer<T>::addSample (cameras/OutputBuffer.hpp:104-132) with _bufferB and _variance present, on the channels
+ * [ch0, ch0 + nch) of one pixel; c = the sample's value */
+static void aux_add(TgHipAuxPixel *px, int output, int ch0, int nch, const float *c)
+{
+    for (int k = 0; k < nch; ++k)
+        if (isnan(c[k]) || isinf(c[k]))
+            return;
+    uint32_t sampleIdx = px->count[output]++;
+    for (int k = 0; k < nch; ++k) {
+        float *a = &px->a[ch0 + k], *b = &px->b[ch0 + k], *var = &px->variance[ch0 + k];
+        float curr;
+        if (sampleIdx > 0) {
+            uint32_t sampleCountA = (sampleIdx + 1)/2, sampleCountB = sampleIdx/2;
+            curr = (*a*(float)sampleCountA + *b*(float)sampleCountB)/(float)sampleIdx;
+        } else {
+            curr = *a;
+        }
+        float delta = c[k] - curr;
+        curr += delta/(float)(sampleIdx + 1);
+        *var += delta*(c[k] - curr);
+        float *feature = (sampleIdx & 1) ? b : a;
+        uint32_t perBufferSampleCount = sampleIdx/2 + 1;
+        *feature += (c[k] - *feature)/(float)perBufferSampleCount;
+    }
+}
+
+int oracle_render_aux(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb_sum, uint32_t *count,
+                      TgHipSampleRecord *records, TgHipAuxPixel *aux, OracleCounters *counters, int nthreads);
+
 int oracle_render_records(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb_sum, uint32_t *count,
                           TgHipSampleRecord *records, OracleCounters *counters, int nthreads)
+{
+    return oracle_render_aux(s, pass, rgb_sum, count, records, NULL, counters, nthreads);
+}
+
+/* aux (may be NULL; used when TGHIP_PASS_AUX is set): one TgHipAuxPixel per image pixel, updated per sample in the
+ * reference's order (each pixel's samples in index order: renderTile, PathTraceIntegrator.cpp:136-156) */
+int oracle_render_aux(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float *rgb_sum, uint32_t *count,
+                      TgHipSampleRecord *records, TgHipAuxPixel *aux, OracleCounters *counters, int nthreads)
 {
     int w = s->camera.res_x, h = s->camera.res_y;
     int tilesX = (w + 15)/16, tilesY = (h + 15)/16;
@@ -2340,6 +2425,8 @@ int oracle_render_records(const TgHipSceneDesc *s, const TgHipPassDesc *pass, fl
         return -1;
     if (!(pass->flags & TGHIP_PASS_RECORDS))
         records = NULL;
+    if (!(pass->flags & TGHIP_PASS_AUX))
+        aux = NULL;
     uint64_t tot[5] = {0, 0, 0, 0, 0};
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -2369,8 +2456,20 @@ int oracle_render_records(const TgHipSceneDesc *s, const TgHipPassDesc *pass, fl
                         if (sobol) sampler_start_sobol(&smp, s->sobol_matrices, pass->tile_seeds[tile], pass->seed, pixelIndex, sidx);
                         else       sampler_start(&smp, pass->seed, pixelIndex, sidx);
                         Ctx c = {s, &smp, counters ? &st : NULL, 0, 0};
+                        AuxSample as;
+                        memset(&as, 0, sizeof(as));
+                        c.aux = aux ? &as : NULL;
                         v3 r = traceSample(&c, (uint32_t)x, (uint32_t)y);
                         loc[0]++; loc[1] += c.closest_rays; loc[2] += c.shadow_rays;
+                        if (aux) {                       /* the addSample calls inside traceSample, then the colour (:148-152) */
+                            TgHipAuxPixel *px = &aux[pixelIndex];
+                            if (as.has[TGHIP_AUX_DEPTH]) aux_add(px, TGHIP_AUX_DEPTH, 3, 1, &as.v[3]);
+                            if (as.has[TGHIP_AUX_NORMAL]) aux_add(px, TGHIP_AUX_NORMAL, 4, 3, &as.v[4]);
+                            if (as.has[TGHIP_AUX_ALBEDO]) aux_add(px, TGHIP_AUX_ALBEDO, 7, 3, &as.v[7]);
+                            if (as.has[TGHIP_AUX_VISIBILITY]) aux_add(px, TGHIP_AUX_VISIBILITY, 10, 1, &as.v[10]);
+                            float col[3] = {r.x, r.y, r.z};
+                            aux_add(px, TGHIP_AUX_COLOR, 0, 3, col);
+                        }
                         if (records)
                             record_add(&records[rec], r);
                         if (isnan(r.x) || isnan(r.y) || isnan(r.z) || isinf(r.x) || isinf(r.y) || isinf(r.z))
@@ -2518,8 +2617,19 @@ uint64_t oracle_dice_tiles(int w, int h, uint32_t seed, uint32_t *tile_seeds)
 
 /* The whole render loop of the CLI (Shared.hpp:281-315: while (!done) { startRender; waitForCompletion; }).
  * records_out: max_passes x (varW*varH) records, dumped after every pass; returns the number of passes. */
+int oracle_integrate_aux(const TgHipSceneDesc *s, uint32_t seed, uint32_t spp, uint32_t sppStep, int adaptive, int sobol,
+                         float *rgb_sum, uint32_t *count, OracleRecord *records_out, int max_passes, uint32_t *pass_spp,
+                         TgHipAuxPixel *aux, int nthreads);
 int oracle_integrate(const TgHipSceneDesc *s, uint32_t seed, uint32_t spp, uint32_t sppStep, int adaptive, int sobol,
                      float *rgb_sum, uint32_t *count, OracleRecord *records_out, int max_passes, uint32_t *pass_spp, int nthreads)
+{
+    return oracle_integrate_aux(s, seed, spp, sppStep, adaptive, sobol, rgb_sum, count, records_out, max_passes, pass_spp, NULL, nthreads);
+}
+
+/* aux (may be NULL): the scene's output buffers (renderer.output_buffers), W x H TgHipAuxPixel, zero-initialised by the caller */
+int oracle_integrate_aux(const TgHipSceneDesc *s, uint32_t seed, uint32_t spp, uint32_t sppStep, int adaptive, int sobol,
+                         float *rgb_sum, uint32_t *count, OracleRecord *records_out, int max_passes, uint32_t *pass_spp,
+                         TgHipAuxPixel *aux, int nthreads)
 {
     int w = s->camera.res_x, h = s->camera.res_y;
     int varW = (w + 3)/4, varH = (h + 3)/4, n = varW*varH;
@@ -2538,9 +2648,9 @@ int oracle_integrate(const TgHipSceneDesc *s, uint32_t seed, uint32_t spp, uint3
             memset(&pass, 0, sizeof(pass));
             pass.spp_begin = currentSpp; pass.spp_end = nextSpp; pass.seed = seed;
             pass.shard_index = 0; pass.shard_count = 1;
-            pass.flags = TGHIP_PASS_RECORDS | (sobol ? TGHIP_PASS_SOBOL : 0u);
+            pass.flags = TGHIP_PASS_RECORDS | (sobol ? TGHIP_PASS_SOBOL : 0u) | (aux ? TGHIP_PASS_AUX : 0u);
             pass.tile_seeds = tileSeeds; pass.record_index = idx; pass.record_count = cnt;
-            rc = oracle_render_records(s, &pass, rgb_sum, count, dev, NULL, nthreads);
+            rc = oracle_render_aux(s, &pass, rgb_sum, count, dev, aux, NULL, nthreads);
             if (rc) break;
             for (int i = 0; i < n; ++i) { rec[i].sampleCount = dev[i].sample_count; rec[i].mean = dev[i].mean; rec[i].runningVariance = dev[i].running_variance; }
         }

@@ -320,6 +320,14 @@ static int cmdIntegrate(int argc, char **argv)
             Vec3f c = L.scene->camera()->getLinear(x, y);
             out.write((const char *)c.data(), 12);
         }
+    // scenes with renderer.output_buffers: Camera::serializeOutputBuffers (Camera.cpp:222-229) appended -- per requested
+    // output, in the order color, depth, normal, albedo, visibility: _bufferA, [_bufferB], [_variance], _sampleCount
+    if (!L.scene->rendererSettings().renderOutputs().empty()) {
+        OutputStreamHandle handle(new std::ostringstream(std::ios::binary));
+        L.scene->camera()->serializeOutputBuffers(handle);
+        std::string blob = static_cast<std::ostringstream *>(handle.get())->str();
+        out.write(blob.data(), std::streamsize(blob.size()));
+    }
     std::fprintf(stderr, "ref_harness: integrate %ux%u, %u passes, %s sampler, adaptive %d\n", w, h, numPasses,
                  sobol ? "sobol" : "uniform", int(L.scene->rendererSettings().useAdaptiveSampling()));
     return 0;

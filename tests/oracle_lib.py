@@ -96,6 +96,27 @@ def integrate(desc, width, height, seed, spp, spp_step, adaptive, sobol, threads
     return ssum, count, rec[:n], pass_spp[:n]
 
 
+AUX_DTYPE = np.dtype([("a", np.float32, 11), ("b", np.float32, 11), ("variance", np.float32, 11), ("count", np.uint32, 5)])
+
+
+def integrate_aux(desc, width, height, seed, spp, spp_step, adaptive, sobol, threads=0):
+    """integrate() for a scene with renderer.output_buffers: additionally returns the output buffers, [H, W] of AUX_DTYPE
+    (include/tungsten_hip.h: TgHipAuxPixel)."""
+    vw, vh = (width + 3)//4, (height + 3)//4
+    max_passes = (spp + spp_step - 1)//spp_step
+    ssum = np.zeros((height, width, 3), np.float32)
+    count = np.zeros((height, width), np.uint32)
+    rec = np.zeros((max_passes, vh, vw), RECORD_DTYPE)
+    pass_spp = np.zeros(max_passes, np.uint32)
+    aux = np.zeros((height, width), AUX_DTYPE)
+    n = _lib.oracle_integrate_aux(desc, C.c_uint32(seed & 0xFFFFFFFF), C.c_uint32(spp), C.c_uint32(spp_step), int(bool(adaptive)), int(bool(sobol)),
+                                  C.c_void_p(ssum.ctypes.data), C.c_void_p(count.ctypes.data), C.c_void_p(rec.ctypes.data), max_passes,
+                                  C.c_void_p(pass_spp.ctypes.data), C.c_void_p(aux.ctypes.data), threads)
+    if n < 0:
+        raise RuntimeError("oracle_integrate_aux failed (%d)" % n)
+    return ssum, count, rec[:n], pass_spp[:n], aux
+
+
 def render(desc, width, height, spp_begin, spp_end, seed, shard_index=0, shard_count=1, threads=0, counters=None):
     """Returns (sum[H,W,3], count[H,W]) like the device framebuffer."""
     ssum = np.zeros((height, width, 3), np.float32)

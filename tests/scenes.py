@@ -519,6 +519,15 @@ GOLDEN_CASES["zoo_b_sobol"] = (lambda t, **kw: cornell_zoo(t, "zoo_b", **kw), di
 GOLDEN_CASES["materialtest_sobol"] = (materialtest, dict(resolution=(64, 36), spp=4, renderer=_SOBOL))
 
 # The reference's own PathTraceIntegrator pass loop (`ref_harness integrate`): SampleRecords after every pass + the image.
+OUTPUT_TYPES = ("color", "depth", "normal", "albedo", "visibility")
+
+
+def _outputs(scene):
+    scene["primitives"] = [p for p in scene["primitives"] if p["name"] != "ceiling"]
+    scene["primitives"].append({"name": "sky", "type": "infinite_sphere", "emission": [0.25, 0.35, 0.6], "sample": True})
+    scene["renderer"]["output_buffers"] = [{"type": t, "two_buffer_variance": True, "sample_variance": True} for t in OUTPUT_TYPES]
+
+
 INTEGRATE_CASES = {
     "cornell_adaptive": (cornell, dict(resolution=(70, 42), spp=72, spp_step=16, renderer={"adaptive_sampling": True})),
     "cornell_adaptive_sobol": (cornell, dict(resolution=(70, 42), spp=64, spp_step=16,
@@ -529,4 +538,12 @@ INTEGRATE_CASES = {
     # participating media under the adaptive pass loop with the Sobol' sampler
     "cornell_fog_smoke_adaptive": (cornell, dict(resolution=(48, 28), spp=48, spp_step=16, edit=_fog_and_smoke,
                                                  renderer={"adaptive_sampling": True, "stratified_sampler": True})),
+}
+
+# renderer.output_buffers: all five outputs with their A/B halves and sample variance (cameras/OutputBuffer.hpp), on a scene with
+# specular first vertices (glass, mirror), a textured floor, an emitter in view and a sky for escaping paths; two passes of the
+# reference's integrator loop with the Sobol' sampler (adaptive sampling off, so that every pixel takes exactly spp samples)
+OUTPUT_CASES = {
+    "zoo_a_outputs": (lambda t, **kw: cornell_zoo(t, "zoo_a", **kw), dict(resolution=(48, 28), spp=32, spp_step=16, edit=_outputs,
+                                                                       renderer={"adaptive_sampling": False, "stratified_sampler": True})),
 }

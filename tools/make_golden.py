@@ -68,9 +68,24 @@ def integrate(path, out):
         records.append(np.frombuffer(b, rec_dtype, vw*vh, off).reshape(vh, vw).copy())
         off += vw*vh*rec_dtype.itemsize
     image = np.frombuffer(b, np.float32, w*h*3, off).reshape(h, w, 3).copy()
-    assert off + image.nbytes == len(b)
+    off += image.nbytes
+    extra = {}
+    if off < len(b):
+        # renderer.output_buffers (all five outputs, two_buffer_variance and sample_variance on): Camera::serializeOutputBuffers,
+        # per output _bufferA, _bufferB, _variance, _sampleCount -> channel layout of TgHipAuxPixel (include/tungsten_hip.h)
+        n = int(w)*int(h)
+        a, bb, var, cnt = [], [], [], []
+        for ch in (3, 1, 3, 3, 1):                      # color, depth, normal, albedo, visibility
+            for dst in (a, bb, var):
+                dst.append(np.frombuffer(b, np.float32, n*ch, off).reshape(h, w, ch).copy())
+                off += n*ch*4
+            cnt.append(np.frombuffer(b, np.uint32, n, off).reshape(h, w, 1).copy())
+            off += n*4
+        extra = dict(aux_a=np.concatenate(a, axis=2), aux_b=np.concatenate(bb, axis=2), aux_variance=np.concatenate(var, axis=2),
+                     aux_count=np.concatenate(cnt, axis=2))
+    assert off == len(b)
     np.savez_compressed(out, tile_seeds=tile_seeds, pass_spp=np.array(pass_spp, np.uint32), records=np.stack(records), image=image,
-                        sobol=np.uint32(sobol), seed=np.uint32(SEED))
+                        sobol=np.uint32(sobol), seed=np.uint32(SEED), **extra)
     print("%-40s %d passes, counts of the last pass %d..%d, image mean %s" % (
         os.path.basename(out), passes, records[-1]["next_sample_count"].min(), records[-1]["next_sample_count"].max(), image.mean(axis=(0, 1))))
 
@@ -103,7 +118,7 @@ def main():
                 sc = json.load(f)
             w, h = sc["camera"]["resolution"]
             samples(p, w, h, sc["renderer"]["spp"], g(name + "_samples.npz"))
-        for name, (mk, kw) in scenes.INTEGRATE_CASES.items():
+        for name, (mk, kw) in list(scenes.INTEGRATE_CASES.items()) + list(scenes.OUTPUT_CASES.items()):
             integrate(mk(tmp, name=name + ".json", **kw), g(name + "_integrate.npz"))
         units(scenes.cornell(tmp, name="u_cornell.json", resolution=(96, 54), spp=1), g("cornell_units.json"))
         units(scenes.materialtest(tmp, name="u_materialtest.json", resolution=(96, 54), spp=1), g("materialtest_units.json"))
