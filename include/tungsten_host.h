@@ -63,6 +63,10 @@ typedef struct TgHostSampleRecord {
 /* records of the renderer after the last pass: n = ceil(W/4)*ceil(H/4) */
 int  tgh_renderer_records(tgh_renderer *r, TgHostSampleRecord *out, size_t n, char *err, size_t errlen);
 
+/* the renderer's auxiliary output buffers (renderer.output_buffers; cameras/OutputBuffer.hpp), one TgHipAuxPixel per pixel,
+ * merged over its devices; all zero when the scene requests none */
+int  tgh_renderer_output_buffers(tgh_renderer *r, TgHipAuxPixel *out, size_t npixels, char *err, size_t errlen);
+
 /* The scheduler on its own (no device): tile seeds + generateWork over caller-supplied record statistics. */
 typedef struct tgh_scheduler tgh_scheduler;
 tgh_scheduler *tgh_scheduler_create(uint32_t width, uint32_t height, uint32_t seed);

@@ -42,7 +42,7 @@ def test_product_library_does_not_link_the_oracle():
 
 def test_ctypes_layout_matches_the_headers(tmp_path):
     structs = ["TgHipBvhNode", "TgHipPrimRec", "TgHipTriAttr", "TgHipObject", "TgHipBsdf", "TgHipTexture", "TgHipMedium", "TgHipCamera",
-               "TgHipSettings", "TgHipSceneDesc", "TgHipPassDesc", "TgHipCounters", "TgHipRay", "TgHipHit", "TgHostSceneInfo"]
+               "TgHipSettings", "TgHipSceneDesc", "TgHipPassDesc", "TgHipAuxPixel", "TgHipCounters", "TgHipRay", "TgHipHit", "TgHostSceneInfo"]
     src = '#include <stdio.h>\n#include "tungsten_host.h"\nint main(void){\n'
     for s in structs:
         src += 'printf("%s %%zu\\n", sizeof(%s));\n' % (s, s)

@@ -15,6 +15,7 @@ from .capi import (TgHipCounters, TgHipHit, TgHipPassDesc, TgHipRay, TgHipSceneD
 
 lib = capi.load_library()
 
+AUX_DTYPE = np.dtype([("a", np.float32, 11), ("b", np.float32, 11), ("variance", np.float32, 11), ("count", np.uint32, 5)])
 RECORD_DTYPE = np.dtype([("sample_count", np.uint32), ("next_sample_count", np.uint32), ("sample_index", np.uint32),
                          ("adaptive_weight", np.float32), ("mean", np.float32), ("running_variance", np.float32)])
 DEFAULT_SEED = 0xBA5EBA11  # src/tungsten/Shared.hpp:246
@@ -148,6 +149,13 @@ class Renderer(object):
         rec = np.zeros(vw*vh, RECORD_DTYPE)
         self._check(lib.tgh_renderer_records(self._h, rec.ctypes.data, rec.size, self._err, len(self._err)))
         return rec.reshape(vh, vw)
+
+    def output_buffers(self):
+        """The auxiliary output buffers (renderer.output_buffers) as a structured array [H, W] of AUX_DTYPE: per output the
+        A / B halves, the Welford variance sum and the sample count (include/tungsten_hip.h: TgHipAuxPixel)."""
+        aux = np.zeros(self.width*self.height, AUX_DTYPE)
+        self._check(lib.tgh_renderer_output_buffers(self._h, aux.ctypes.data, aux.size, self._err, len(self._err)))
+        return aux.reshape(self.height, self.width)
 
     def save_outputs(self):
         self._check(lib.tgh_renderer_save_outputs(self._h, self._err, len(self._err)))

@@ -82,7 +82,11 @@ class TgHipSceneDesc(C.Structure):
                 ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
 
 
-TGHIP_PASS_SOBOL, TGHIP_PASS_RECORDS = 1, 2
+TGHIP_PASS_SOBOL, TGHIP_PASS_RECORDS, TGHIP_PASS_AUX = 1, 2, 4
+
+
+class TgHipAuxPixel(C.Structure):
+    _fields_ = [("a", f32*11), ("b", f32*11), ("variance", f32*11), ("count", u32*5)]
 
 
 class TgHipPassDesc(C.Structure):
@@ -143,6 +147,8 @@ PROTOTYPES = {
     "tghip_upload_framebuffer": (C.c_int, [VP, VP, VP, C.c_size_t]),
     "tghip_download_records": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_upload_records": (C.c_int, [VP, VP, C.c_size_t]),
+    "tghip_download_aux": (C.c_int, [VP, VP, C.c_size_t]),
+    "tghip_upload_aux": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_trace_rays": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "tghip_set_option": (C.c_int, [VP, C.c_char_p, C.c_longlong]),
     "tghip_get_counters": (C.c_int, [VP, C.POINTER(TgHipCounters)]),
@@ -163,6 +169,7 @@ PROTOTYPES = {
     "tgh_renderer_save_resume_data": (C.c_int, [VP, C.c_char_p, C.c_size_t]),
     "tgh_renderer_resume": (C.c_int, [VP, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]),
     "tgh_renderer_records": (C.c_int, [VP, VP, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "tgh_renderer_output_buffers": (C.c_int, [VP, VP, C.c_size_t, C.c_char_p, C.c_size_t]),
     "tgh_scheduler_create": (VP, [u32, u32, u32]),
     "tgh_scheduler_num_tiles": (C.c_size_t, [VP]),
     "tgh_scheduler_num_records": (C.c_size_t, [VP]),

@@ -46,6 +46,7 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 #define FLAG_MEDIUM(f)         ((int)(((f) >> 9) & 0x7Fu) - 1)
 #define FLAG_MEDIUM_BOUNCE(f)  (((f) >> 19) & 0xFFu)
 #define FLAG_MEDIUM_BITS(medium, mbounce) ((((uint32_t)((medium) + 1)) & 0x7Fu) << 9 | (((uint32_t)(mbounce)) & 0xFFu) << 19)
+#define FLAG_AUX_RECORDED      (1u << 27)   /* TGHIP_PASS_AUX: recordedOutputValues (PathTracer.cpp:46) */
 #define PT_MAX_MEDIA 126u
 // shadow-ray tag of a media scene: light object (16 bits) | medium the ray starts in + 1 (8 bits) | bounce (8 bits)
 #define SHADOW_TAG_MEDIA(light, medium, bounce) ((uint32_t)(light) | ((uint32_t)((medium) + 1) << 16) | ((uint32_t)(bounce) << 24))
@@ -92,6 +93,10 @@ enum {
     A_SH_D1, A_SH_C1,   // bsdf-sample shadow ray
     A_SH_W,        // throughput at the NEE vertex, light-selection weight
     A_SH_P,        // emission picked up at the same vertex (added after the NEE term), path flags (uint bits)
+    // TGHIP_PASS_AUX passes only: what the sample in flight adds to the auxiliary output buffers; NaN = not recorded
+    // (OutputBuffer::addSample drops NaN values without counting them, cameras/OutputBuffer.hpp:106-107)
+    A_AUX0,        // normal.xyz | depth -- until the values are recorded (FLAG_AUX_RECORDED), .w is the running hitDistance
+    A_AUX1,        // albedo.rgb | visibility (+inf = waiting for the light sample's shadow ray of the recording vertex)
     A_COUNT
 };
 
@@ -147,7 +152,33 @@ struct PassParams {
     uint32_t num_sorted;       // owned records
     uint32_t num_chunks;       // chunks of the record with the most samples
     float *lum;                // luminance of every sample of the pass, in the order SampleRecord::addSample saw them
+    TgHipAuxPixel *aux;        // TGHIP_PASS_AUX: the auxiliary output buffers, one record per image pixel
 };
+
+// OutputBuffer<T>::addSample (cameras/OutputBuffer.hpp:104-132) with _bufferB and _variance present, on the channels
+// [ch0, ch0 + N) of one pixel.  A TGHIP_PASS_AUX pass hands all samples of a pixel to ONE slot in index order (chunk = the
+// whole pass), and passes follow each other, so every pixel sees its samples in the reference's order.
+PT_DEV void auxAdd3(TgHipAuxPixel &px, int output, int ch0, int n, float c0, float c1, float c2)   // n = 1 or 3 channels
+{
+    if (isnan(c0) || isinf(c0) || (n == 3 && (isnan(c1) || isinf(c1) || isnan(c2) || isinf(c2))))
+        return;
+    const uint32_t sampleIdx = px.count[output]++;
+    for (int k = 0; k < n; ++k) {
+        const float c = k == 0 ? c0 : k == 1 ? c1 : c2;
+        float a = px.a[ch0 + k], b = px.b[ch0 + k];
+        float curr = a;
+        if (sampleIdx > 0) {
+            uint32_t sampleCountA = (sampleIdx + 1u)/2u, sampleCountB = sampleIdx/2u;
+            curr = (a*(float)sampleCountA + b*(float)sampleCountB)/(float)sampleIdx;
+        }
+        float delta = c - curr;
+        curr += delta/(float)(sampleIdx + 1u);
+        px.variance[ch0 + k] += delta*(c - curr);
+        const uint32_t perBufferSampleCount = sampleIdx/2u + 1u;
+        if (sampleIdx & 1u) px.b[ch0 + k] = b + (c - b)/(float)perBufferSampleCount;
+        else                px.a[ch0 + k] = a + (c - a)/(float)perBufferSampleCount;
+    }
+}
 
 PT_DEV uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

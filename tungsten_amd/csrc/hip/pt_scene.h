@@ -58,7 +58,8 @@ struct DeviceScene {
 #define FEAT_QMC        (1u << 30)   /* TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes: every variant has a twin with this bit (launchShade) */
 #define FEAT_INSTANCES  (1u << 31)   /* hits reached through an instance record (primitives/Instance.cpp): only in MASK_FULL / BSDF_MASK_ALL */
 #define FEAT_MEDIA      (1u << 23)   /* participating media (media/HomogeneousMedium.cpp): only in the BSDF_MASK_ALL variant */
-#define MASK_FULL       (BSDF_MASK_ALL & ~(FEAT_QMC | FEAT_MEDIA))
+#define FEAT_AUX        (1u << 22)   /* TGHIP_PASS_AUX passes (auxiliary output buffers): only in the BSDF_MASK_ALL variant */
+#define MASK_FULL       (BSDF_MASK_ALL & ~(FEAT_QMC | FEAT_MEDIA | FEAT_AUX))
 // next1D of the path's sampler inside code templated on M
 #define RNG1D(r) rngNext1DT<(M & FEAT_QMC) != 0>(r)
 

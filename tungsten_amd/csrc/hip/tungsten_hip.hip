@@ -91,6 +91,18 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             acc.x += em.x; acc.y += em.y; acc.z += em.z;
             acc.w = __uint_as_float(__float_as_uint(acc.w) + 1u);
         }
+        if constexpr (EXT) {
+            if (pp.flags & TGHIP_PASS_AUX) {
+                // the addSample calls of traceSample (PathTracer.cpp:78-96, 133-140), then the colour (PathTraceIntegrator.cpp:152)
+                TgHipAuxPixel &px = pp.aux[pixel];
+                float4 a0 = slotF4(st, A_AUX0, slot), a1 = slotF4(st, A_AUX1, slot);
+                auxAdd3(px, TGHIP_AUX_DEPTH, 3, 1, a0.w, 0.0f, 0.0f);
+                auxAdd3(px, TGHIP_AUX_NORMAL, 4, 3, a0.x, a0.y, a0.z);
+                auxAdd3(px, TGHIP_AUX_ALBEDO, 7, 3, a1.x, a1.y, a1.z);
+                auxAdd3(px, TGHIP_AUX_VISIBILITY, 10, 1, a1.w, 0.0f, 0.0f);
+                auxAdd3(px, TGHIP_AUX_COLOR, 0, 3, em.x, em.y, em.z);
+            }
+        }
         finishedCount++;
         samp.x++;
         if (samp.x >= samp.y || aborted) {
@@ -195,6 +207,11 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             if (EXT && (pp.flags & PT_PASS_MEDIA))
                 f0 |= FLAG_MEDIUM_BITS(cam.medium, 0);                      // _scene->cam().medium(), state.reset() (PathTracer.cpp:38-41)
             slotF4(st, A_THR, slot) = make_float4(t0, t0, t0, __uint_as_float(f0));
+            if (EXT && (pp.flags & TGHIP_PASS_AUX)) {                          // nothing recorded yet, hitDistance = 0
+                const float nan = __uint_as_float(0x7FC00000u);
+                slotF4(st, A_AUX0, slot) = make_float4(nan, nan, nan, 0.0f);
+                slotF4(st, A_AUX1, slot) = make_float4(nan, nan, nan, nan);
+            }
             slotU4(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, EXT ? rng.dim : 0u, lumBase);   // .z: next Sobol' dimension
             slotF4(st, A_ACC, slot) = acc;
             push = true;
@@ -441,6 +458,29 @@ constexpr uint32_t shadeKinds(uint32_t M)
     return (M & FEAT_SOLIDS) ? KINDS_ALL
                              : (KIND_BIT(TGHIP_REC_QUAD) | KIND_BIT(TGHIP_REC_CUBE) | ((M & FEAT_TRIANGLES) ? KIND_BIT(TGHIP_REC_TRIANGLE) : 0u));
 }
+// TGHIP_PASS_AUX: output values of a sample that leaves the loop of traceSample without having recorded any (PathTracer.cpp:133-140).
+// `asked`: handleInfiniteLights ran for direction `dir` (so info.primitive is the infinite light it found, if any).
+template<uint32_t M>
+PT_DEV void auxPostLoop(const DeviceScene &s, f3 dir, bool asked, int bounce, float4 &aux0, float4 &aux1)
+{
+    aux0 = mk4(-dir, bounce == 0 ? 0.0f : __uint_as_float(0x7FC00000u));
+    if (asked && (M & FEAT_INFINITE)) {
+        int objIdx = -1;
+        for (uint32_t li = 0; li < s.num_infinite_lights; ++li) {
+            const TgHipObject &c = s.objects[s.infinite_lights[li]];
+            if (c.type != TGHIP_OBJ_INFINITE_SPHERE_CAP || dot(dir, ld3(c.normal)) >= c.scale[0])
+                objIdx = s.infinite_lights[li];
+        }
+        if (objIdx >= 0) {                       // info.primitive->isInfinite(): + evalDirect
+            const TgHipObject &o = s.objects[objIdx];
+            float u = 0.0f, v = 0.0f, sinTheta;
+            if (o.type == TGHIP_OBJ_INFINITE_SPHERE) infDirectionToUV(o, dir, u, v, sinTheta);
+            f3 e = textureEval<M>(s, o.emission, u, v);
+            aux1.x = e.x; aux1.y = e.y; aux1.z = e.z;
+        }
+    }
+}
+
 #define FUSE_TRACE  1
 #define FUSE_SHADOW 2
 #define FUSE_LOOP   4
@@ -531,11 +571,21 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             bool wasSpecular = (flags & FLAG_SPECULAR) != 0;
             uint32_t state = ST_ACTIVE;
 
+            // auxiliary output buffers (TGHIP_PASS_AUX; PathTracer.cpp:46-47, 78-96, 133-140)
+            const bool auxOn = (M & FEAT_AUX) && (pp.flags & TGHIP_PASS_AUX) != 0u;
+            bool recorded = auxOn && (flags & FLAG_AUX_RECORDED) != 0u;   // recordedOutputValues
+            bool auxStore = false;                           // aux0 / aux1 changed
+            int loopExit = 0;                                // the while loop was left: 1 = by `break` (bounce not advanced), 2 = bounce limit
+            float4 aux0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), aux1 = aux0;
+            if constexpr ((M & FEAT_AUX) != 0u) {
+                if (auxOn && !recorded) { aux0 = slotF4(st, A_AUX0, slot); aux1 = slotF4(st, A_AUX1, slot); }
+            }
             // loop epilogue (PathTracer.cpp:108-126) for a path that goes on from `o` in direction `d`
             auto continuePath = [&](f3 o, f3 d, float tmin) {
                 ray.o = o; ray.d = d; ray.tmin = tmin; ray.tmax = PT_INF;
                 if (max3(throughput) == 0.0f) {
                     state = ST_TERMINATED;                   // the env term after `break` is throughput*L = 0
+                    if constexpr ((M & FEAT_AUX) != 0u) loopExit = 1;
                 } else {
                     float roulettePdf = fmaxf(fabsf(throughput.x), fmaxf(fabsf(throughput.y), fabsf(throughput.z)));
                     bool killed = false;
@@ -552,6 +602,13 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     } else {
                         bounce++;
                         state = bounce < maxBounces ? ST_ACTIVE : ST_TERMINATED;
+                        if constexpr ((M & FEAT_AUX) != 0u) { if (state != ST_ACTIVE) loopExit = 2; }
+                    }
+                }
+                if constexpr ((M & FEAT_AUX) != 0u) {
+                    if (auxOn && !recorded && loopExit) {    // the sample leaves the loop without having recorded its output values
+                        auxPostLoop<M>(s, ray.d, loopExit == 1 && bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0, bounce, aux0, aux1);
+                        recorded = true; auxStore = true;
                     }
                 }
             };
@@ -674,8 +731,17 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     }
                 }
                 state = isnan(sum3(throughput) + sum3(em)) ? ST_TERMINATED_BLACK : ST_TERMINATED;
+                if constexpr ((M & FEAT_AUX) != 0u) {
+                    if (auxOn && !recorded && state == ST_TERMINATED) {   // (a NaN sample returns before the block at :133)
+                        auxPostLoop<M>(s, ray.d, bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0, bounce, aux0, aux1);
+                        recorded = true; auxStore = true;
+                    }
+                }
             } else {
                 PROF(1);
+                if constexpr ((M & FEAT_AUX) != 0u) {
+                    if (auxOn && !recorded) { aux0.w += hit.x; auxStore = true; }   // hitDistance += ray.farT() (PathTracer.cpp:64)
+                }
                 Info info;
                 intersectionInfo<M>(s, ray, hit, info, hitInst);
                 const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
@@ -700,6 +766,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     return geometricBackside == shadingBackside;
                 };
 
+                bool auxVisPending = false;
                 f3 transparency = splat3(0.0f);
                 if (lobes & TGHIP_LOBE_FORWARD) {
                     ev.wo = -ev.wi; ev.requested = TGHIP_LOBE_FORWARD;
@@ -755,8 +822,12 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                             else reached = lightIntersect<M>(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist);
                                             if (reached) {
                                                 f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
-                                                if (!isZero(e)) {
-                                                    f3 lightF = f*e/pdf;
+                                                // TGHIP_PASS_AUX: attenuatedEmission reports the shadow ray's transmittance even when the
+                                                // light shows a black side (TraceBase.cpp:169-170): the ray is traced for the visibility output
+                                                bool wantVis = false;
+                                                if constexpr ((M & FEAT_AUX) != 0u) wantVis = auxOn && !recorded;
+                                                if (!isZero(e) || wantVis) {
+                                                    f3 lightF = f*e/pdf;                          // (zero for a black e)
                                                     if (!diracLight)                              // no MIS against a Dirac light (:281-282)
                                                         lightF = lightF*powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
                                                     if (FUSE & FUSE_SHADOW) {
@@ -816,6 +887,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                 em = em + (inlineResult*lightWeight)*throughput;
                             } else if (q0 || q1) {
                                 hasShadow = true;
+                                auxVisPending = q0;
                                 if (!q0) slotF4(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
                                 if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
                                 slotF4(st, A_SH_O, slot) = mk4(info.p, 5e-4f);
@@ -853,6 +925,18 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                 }
 
                 PROF(4);
+                if constexpr ((M & FEAT_AUX) != 0u) if (auxOn && !recorded && (!wasSpecular || !alive)) {       // PathTracer.cpp:78-96
+                    int ab = info.bsdf;                          // TransparencyBsdf: its base's albedo
+                    if (s.bsdfs[ab].type == TGHIP_BSDF_TRANSPARENCY) ab = s.bsdfs[ab].sub0;
+                    f3 albedo = textureEval<M>(s, s.bsdfs[ab].albedo, info.u, info.v);
+                    if (s.objects[info.object].emission >= 0)    // isEmissive(): + evalDirect
+                        albedo = albedo + lightEvalDirect<M>(s, info.object, info.u, info.v, info.backSide);
+                    aux0 = mk4(info.Ns, aux0.w);                 // .w = hitDistance
+                    // visibility = transmittance of this vertex' light sample, if it got as far as its shadow ray: pending
+                    aux1 = mk4(albedo, auxVisPending ? PT_INF : __uint_as_float(0x7FC00000u));
+                    recorded = true;
+                    auxStore = true;
+                }
                 if (!alive) {
                     state = ST_TERMINATED;
                 } else {
@@ -871,7 +955,15 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                 if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL))
                     slotU4(st, A_SAMP, slot).z = rng.dim;
             }
-            const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state) | ((M & FEAT_MEDIA) ? FLAG_MEDIUM_BITS(med, medBounce) : 0u);
+            if constexpr ((M & FEAT_AUX) != 0u) if (auxOn) {
+                if (!recorded && state != ST_ACTIVE) {       // the sample returned early: it adds nothing (hitDistance is not a depth)
+                    aux0.w = __uint_as_float(0x7FC00000u);
+                    auxStore = true;
+                }
+                if (auxStore) { slotF4(st, A_AUX0, slot) = aux0; slotF4(st, A_AUX1, slot) = aux1; }
+            }
+            const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state) | ((M & FEAT_MEDIA) ? FLAG_MEDIUM_BITS(med, medBounce) : 0u)
+                                    | (recorded ? FLAG_AUX_RECORDED : 0u);
             survives = state == ST_ACTIVE;
             black = state == ST_TERMINATED_BLACK;
             if (hasShadow) {
@@ -976,6 +1068,8 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 ray.o = xyz(so); ray.d = xyz(sd); ray.tmin = so.w; ray.tmax = sd.w;
                 float remaining = ray.tmax;
                 f3 transmittance = splat3(1.0f);
+                bool visValid = true;                          // TGHIP_PASS_AUX: attenuatedEmission got as far as its shadow ray
+                f3 shadowT = splat3(0.0f);                     // ... whose result this is (before the emission is applied)
                 if (!FORWARD) {
                     // no surface of this scene lets light through: any occluder ends the query
                     rays++;
@@ -997,7 +1091,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     int hitObject = -1;
                     if (ri >= 0)      // geometry reached through an instance belongs to the `instances` primitive (never a light)
                         hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)(hitInst >= 0 ? hitInst : ri)*3u).w));
-                    if (meshLight && ri < 0) { transmittance = splat3(0.0f); break; }   // the ray never reaches the mesh
+                    if (meshLight && ri < 0) { transmittance = splat3(0.0f); visValid = false; break; }   // the ray never reaches the mesh
                     if (medium >= 0)                             // TraceBase.cpp:103-112: ray.farT() is the hit distance when anything was hit
                         transmittance = transmittance*mediumTransmittance(s, medium, ri >= 0 ? hit.x : ray.tmax);
                     if (ri < 0 || hitObject == endCap) {
@@ -1010,7 +1104,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                             f3 e = lightEvalDirect<BSDF_MASK_ALL>(s, endCap, li.u, li.v, li.backSide);
                             float total = travelled + hit.x;
                             if (r == 0) {
-                                if (total*(1.0f + 1e-3f) < sd.w) e = splat3(0.0f);        // a nearer part of the mesh than the sampled point
+                                if (total*(1.0f + 1e-3f) < sd.w) { e = splat3(0.0f); visValid = false; }   // a nearer part of the mesh than the sampled point
                                 meshFactor = e;
                             } else {
                                 float directPdf = lengthSq(xyz(so) - li.p)/(-dot(ray.d, li.Ng)*lo.area);
@@ -1045,7 +1139,14 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     ray.tmin = 5e-4f;
                     ray.tmax = remaining;
                 }
+                shadowT = transmittance;
                 if (meshLight) transmittance = transmittance*meshFactor;
+                }
+                if (!FORWARD) shadowT = transmittance;
+                if (r == 0 && (pp.flags & TGHIP_PASS_AUX)) {   // the visibility output of the vertex that recorded (PathTracer.cpp:93-94)
+                    float4 &a1 = slotF4(st, A_AUX1, slot);
+                    if (isinf(a1.w))
+                        a1.w = visValid ? avg3(shadowT) : __uint_as_float(0x7FC00000u);
                 }
                 if (!isZero(transmittance))
                     result = result + xyz(c)*transmittance;
@@ -1436,6 +1537,9 @@ struct tghip_ctx {
     bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, MASK_FULL shading
     bool thinlens = false;                // thin-lens camera: passes run the EXT kernel variants (PT_PASS_THINLENS)
     bool haveSolids = false;              // cube / sphere / disk records: the dynamic-fetch kernels' SOLIDS variants
+    TgHipAuxPixel *dAux = nullptr;        // auxiliary output buffers (allocated by the first TGHIP_PASS_AUX pass)
+    bool auxPass = false;                 // the pass being rendered keeps them: BSDF_MASK_ALL shading, no fused / dynamic-fetch shadow kernels
+    int thrShadeAll = 256;                // workgroup size of k_shade<BSDF_MASK_ALL> (media scenes, TGHIP_PASS_AUX passes)
     bool haveMedia = false;               // participating media: BSDF_MASK_ALL shading (the only FEAT_MEDIA variant), closest-hit shadow walk, never fused
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
@@ -1716,6 +1820,7 @@ static void chooseThreads(tghip_ctx *ctx)
     else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     if (ctx->haveMedia) ctx->thrShadeSimple = ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     }
+    ctx->thrShadeAll = flat && ctx->blocksPerCuOpt == 0 ? 256 : pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     int *dst[4] = {&ctx->thrClosest, &ctx->thrShadow, &ctx->thrShadeSimple, &ctx->thrShadeComplex};
     for (int i = 0; i < 4; ++i)
         if (ctx->thrOverride[i] >= 64) *dst[i] = std::min(ctx->thrOverride[i]/64*64, i < 2 ? 512 : 256);
@@ -1776,6 +1881,7 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->dHint) (void)hipFree(ctx->dHint);
     if (ctx->fbSum) (void)hipFree(ctx->fbSum);
     if (ctx->fbCount) (void)hipFree(ctx->fbCount);
+    if (ctx->dAux) (void)hipFree(ctx->dAux);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->hostLive) (void)hipHostFree(ctx->hostLive);
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
@@ -1977,7 +2083,8 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if (ctx->width != uint32_t(sd->camera.res_x) || ctx->height != uint32_t(sd->camera.res_y) || !ctx->fbSum) {
         if (ctx->fbSum) (void)hipFree(ctx->fbSum);
         if (ctx->fbCount) (void)hipFree(ctx->fbCount);
-        ctx->fbSum = nullptr; ctx->fbCount = nullptr;
+        if (ctx->dAux) (void)hipFree(ctx->dAux);
+        ctx->fbSum = nullptr; ctx->fbCount = nullptr; ctx->dAux = nullptr;
         ctx->width = uint32_t(sd->camera.res_x); ctx->height = uint32_t(sd->camera.res_y);
         size_t npix = size_t(ctx->width)*ctx->height;
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->fbSum), npix*3*sizeof(float)));
@@ -2009,6 +2116,7 @@ int tghip_clear_framebuffer(tghip_ctx *ctx)
     HIP_TRY(ctx, hipMemsetAsync(cnt, 0, npix*sizeof(uint32_t), ctx->stream));
     const size_t recs = size_t((ctx->width + 3)/4)*((ctx->height + 3)/4);
     HIP_TRY(ctx, hipMemsetAsync(ctx->dRecords, 0, recs*sizeof(TgHipSampleRecord), ctx->stream));
+    if (ctx->dAux) HIP_TRY(ctx, hipMemsetAsync(ctx->dAux, 0, npix*sizeof(TgHipAuxPixel), ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TGHIP_OK;
 }
@@ -2028,7 +2136,7 @@ static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, co
 {
     constexpr uint32_t B = M & ~FEAT_QMC;
     hipLaunchKernelGGL((k_shade<M, (B == MASK_SIMPLE ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
-                       dim3(cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0, ctx->stream, ctx->scene, st, pp, cls);
+                       dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0, ctx->stream, ctx->scene, st, pp, cls);
 }
 // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
 template<uint32_t M, int FUSE = 0>
@@ -2050,7 +2158,7 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
         else             hipLaunchKernelGGL((k_trace_shadow<COUNT, false, false, true>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
         return false;
     }
-    if (!flat && !closestWalk && ctx->dynamicFetch) {
+    if (!flat && !closestWalk && ctx->dynamicFetch && !ctx->auxPass) {   // (the dynamic-fetch kernel does not report transmittances)
         if (ctx->haveSolids) hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, true>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
                                                 ctx->scene, st, pp, iterTag);
         else                 hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, false>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
@@ -2076,7 +2184,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = isFlat(ctx);
-    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt;
+    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->auxPass;
     const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
@@ -2164,14 +2272,14 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            if (ctx->haveMedia) {                                  // the one variant with FEAT_MEDIA, for both classes
+            if (ctx->haveMedia || ctx->auxPass) {                  // the one variant with FEAT_MEDIA / FEAT_AUX, for both classes
                 launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 0);
                 if (ctx->haveComplex) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 1);
             }
             else if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling / instance transforms
             else if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
             else                     launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
-            if (ctx->haveComplex && !ctx->haveMedia) {
+            if (ctx->haveComplex && !ctx->haveMedia && !ctx->auxPass) {
                 if (ctx->haveMeshLight || ctx->haveInstances)   launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
@@ -2203,7 +2311,7 @@ int tghip_render_pass(tghip_ctx *ctx, const TgHipPassDesc *pass)
         ctx->error = "invalid pass description";
         return TGHIP_E_INVALID;
     }
-    if (pass->flags & ~(TGHIP_PASS_SOBOL | TGHIP_PASS_RECORDS)) { ctx->error = "unknown pass flags"; return TGHIP_E_INVALID; }
+    if (pass->flags & ~(TGHIP_PASS_SOBOL | TGHIP_PASS_RECORDS | TGHIP_PASS_AUX)) { ctx->error = "unknown pass flags"; return TGHIP_E_INVALID; }
     if ((pass->flags & TGHIP_PASS_SOBOL) && (!ctx->scene.sobol || !pass->tile_seeds)) {
         ctx->error = "TGHIP_PASS_SOBOL needs sobol_matrices in the scene description and tile_seeds in the pass";
         return TGHIP_E_INVALID;
@@ -2280,7 +2388,15 @@ int tghip_wait(tghip_ctx *ctx)
     if (ownedTiles == 0 || spp == 0)
         return ctx->passResult = TGHIP_OK;
 
-    const uint32_t chunk = uint32_t(std::max(ctx->chunkSamples, 1));
+    // TGHIP_PASS_AUX: one work item per pixel, so that a pixel's samples reach OutputBuffer::addSample in index order (auxAdd)
+    ctx->auxPass = (pass.flags & TGHIP_PASS_AUX) != 0;
+    const uint32_t chunk = ctx->auxPass ? std::max(spp, 1u) : uint32_t(std::max(ctx->chunkSamples, 1));
+    if (ctx->auxPass && !ctx->dAux) {
+        const size_t npix = size_t(w)*h;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dAux), npix*sizeof(TgHipAuxPixel)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dAux, 0, npix*sizeof(TgHipAuxPixel), ctx->stream));
+    }
+    base.aux = ctx->dAux;
     const uint64_t maxItems = uint64_t(std::max<long long>(ctx->maxItems, 256));
     const bool recordPass = (pass.flags & TGHIP_PASS_RECORDS) != 0;
     uint64_t recordItems = 0;
@@ -2352,7 +2468,7 @@ int tghip_wait(tghip_ctx *ctx)
         // the run-to-completion kernel (runBatch) gives every thread its own slots for the whole launch: one slot per
         // thread keeps the whole path state (112 B x 0.5 M slots) inside the Infinity Cache -- measured +5 % over four
         const bool flat = isFlat(ctx);
-        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->haveComplex && ctx->loopOpt;
+        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->haveComplex && ctx->loopOpt && !ctx->auxPass;
         if (loop && !ctx->maxSlotsSet)
             wantSlots = std::min<uint64_t>(wantSlots, uint64_t(launchGrid(ctx))*uint64_t(ctx->thrShadeSimple));
     }
@@ -2482,6 +2598,32 @@ int tghip_upload_records(tghip_ctx *ctx, const TgHipSampleRecord *in, size_t n)
     if (rc != TGHIP_OK && rc != TGHIP_E_ABORTED) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dRecords, in, n*sizeof(TgHipSampleRecord), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
+int tghip_download_aux(tghip_ctx *ctx, TgHipAuxPixel *out, size_t npixels)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    if (!out || npixels != size_t(ctx->width)*ctx->height) { ctx->error = "pixel count mismatch"; return TGHIP_E_INVALID; }
+    int rc = tghip_wait(ctx);
+    if (rc != TGHIP_OK && rc != TGHIP_E_ABORTED) return rc;
+    if (!ctx->dAux) { std::memset(out, 0, npixels*sizeof(TgHipAuxPixel)); return TGHIP_OK; }   // no TGHIP_PASS_AUX pass yet
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->dAux, npixels*sizeof(TgHipAuxPixel), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
+int tghip_upload_aux(tghip_ctx *ctx, const TgHipAuxPixel *in, size_t npixels)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    if (!in || npixels != size_t(ctx->width)*ctx->height) { ctx->error = "pixel count mismatch"; return TGHIP_E_INVALID; }
+    int rc = tghip_wait(ctx);
+    if (rc != TGHIP_OK && rc != TGHIP_E_ABORTED) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->dAux) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dAux), npixels*sizeof(TgHipAuxPixel)));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dAux, in, npixels*sizeof(TgHipAuxPixel), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TGHIP_OK;
 }

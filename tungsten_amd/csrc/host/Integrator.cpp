@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <stdexcept>
 
 namespace tungsten_amd {
@@ -69,6 +70,83 @@ void Integrator::writeBuffers(const std::string &suffix, bool overwrite)
     }
     if (!settings.hdrOutputFile.empty())
         ImageIO::savePfm(incrementalFilename(settings.hdrOutputFile, suffix, overwrite), hdr.data(), int(cam.resX), int(cam.resY), 3);
+    if (suffix.empty() && !settings.outputs.empty())   // Integrator.cpp:78-79
+        saveOutputBuffers();
+}
+
+// OutputBuffer<T>::save for every requested output (cameras/OutputBuffer.hpp:146-189, saveLdr :56-86).  The device keeps
+// every output as A / B halves + Welford sum; what a buffer without two_buffer_variance would hold in _bufferA is the
+// mean of both halves.
+void Integrator::saveOutputBuffers()
+{
+    const Camera &cam = _scene->cam();
+    const int w = int(cam.resX), h = int(cam.resY);
+    const size_t n = size_t(w)*h;
+    std::vector<TgHipAuxPixel> aux;
+    currentOutputBuffers(aux);
+    if (aux.size() != n)
+        return;
+    static const int first[5] = {0, 3, 4, 7, 10}, channels[5] = {3, 1, 3, 3, 1};
+    auto withTag = [](const std::string &file, const char *tag) {
+        size_t dot = file.find_last_of('.');
+        return dot == std::string::npos ? file + tag : file.substr(0, dot) + tag + file.substr(dot);
+    };
+    for (const OutputBufferSettings &b : _scene->rendererSettings().outputs) {
+        const int ch0 = first[b.type], nch = channels[b.type];
+        std::vector<float> mean(n*nch), bufA(n*nch), bufB(n*nch), var(n*nch);
+        for (size_t i = 0; i < n; ++i) {
+            const TgHipAuxPixel &p = aux[i];
+            uint32_t cnt = p.count[b.type], cntA = (cnt + 1)/2, cntB = cnt/2;
+            for (int k = 0; k < nch; ++k) {
+                float a = p.a[ch0 + k], bb = p.b[ch0 + k];
+                bufA[i*nch + k] = a; bufB[i*nch + k] = bb;
+                mean[i*nch + k] = (a*float(cntA) + bb*float(cntB))/float(std::max(cnt, 1u));      // operator[] (:134-144)
+                var[i*nch + k] = p.variance[ch0 + k]/float(cnt*std::max(1u, cnt - 1));             // save() (:178-181)
+            }
+        }
+        auto saveHdr = [&](const std::string &file, const std::vector<float> &img) {
+            if (!file.empty()) ImageIO::savePfm(file, img.data(), w, h, nch);
+        };
+        auto saveLdr = [&](const std::string &file, const std::vector<float> &img, bool rescale) {   // OutputBuffer::saveLdr
+            if (file.empty()) return;
+            float minimum = 0.0f, maximum = 0.0f;
+            if (b.type == TGHIP_AUX_DEPTH) {
+                for (size_t i = 0; i < n; ++i)
+                    if (img[i] != std::numeric_limits<float>::infinity()) maximum = std::max(maximum, img[i]);
+            } else if (b.type == TGHIP_AUX_NORMAL) {
+                minimum = -1.0f; maximum = 1.0f;
+            } else {
+                rescale = false;
+            }
+            std::vector<uint8_t> ldr(n*3);
+            for (size_t i = 0; i < n; ++i) {
+                bool bad = false;
+                float f[3];
+                for (int k = 0; k < 3; ++k) {
+                    f[k] = img[i*nch + (nch == 3 ? k : 0)];
+                    if (rescale) f[k] = (f[k] - minimum)/(maximum - minimum);
+                }
+                float avg = nch == 3 ? (f[0] + f[1] + f[2])/3.0f : f[0];
+                bad = std::isnan(avg) || std::isinf(avg);
+                for (int k = 0; k < 3; ++k)
+                    ldr[i*3 + k] = bad ? 255 : uint8_t(std::min(std::max(int(f[k]*255.0f), 0), 255));
+            }
+            ImageIO::savePng(file, ldr.data(), w, h);
+        };
+        if (b.twoBufferVariance) {
+            saveHdr(b.hdrOutputFile, mean);
+            if (!b.hdrOutputFile.empty()) { saveHdr(withTag(b.hdrOutputFile, "A"), bufA); saveHdr(withTag(b.hdrOutputFile, "B"), bufB); }
+            saveLdr(b.ldrOutputFile, mean, true);
+            if (!b.ldrOutputFile.empty()) { saveLdr(withTag(b.ldrOutputFile, "A"), bufA, true); saveLdr(withTag(b.ldrOutputFile, "B"), bufB, true); }
+        } else {
+            saveHdr(b.hdrOutputFile, mean);
+            saveLdr(b.ldrOutputFile, mean, true);
+        }
+        if (b.sampleVariance) {
+            if (!b.hdrOutputFile.empty()) saveHdr(withTag(b.hdrOutputFile, "Variance"), var);
+            if (!b.ldrOutputFile.empty()) saveLdr(withTag(b.ldrOutputFile, "Variance"), var, false);
+        }
+    }
 }
 
 void Integrator::saveOutputs()
@@ -128,6 +206,11 @@ void Integrator::saveRenderResumeData()
     out.write(reinterpret_cast<const char *>(&hash), sizeof(hash));
     out.write(reinterpret_cast<const char *>(sum.data()), std::streamsize(sum.size()*sizeof(float)));
     out.write(reinterpret_cast<const char *>(count.data()), std::streamsize(count.size()*sizeof(uint32_t)));
+    if (!rs.outputs.empty()) {                    // Camera::serializeOutputBuffers (Camera.cpp:222-229)
+        std::vector<TgHipAuxPixel> aux;
+        currentOutputBuffers(aux);
+        out.write(reinterpret_cast<const char *>(aux.data()), std::streamsize(aux.size()*sizeof(TgHipAuxPixel)));
+    }
     saveState(out);
 }
 
@@ -158,7 +241,16 @@ bool Integrator::resumeRender()
     in.read(reinterpret_cast<char *>(count.data()), std::streamsize(count.size()*sizeof(uint32_t)));
     if (!in)
         return false;
+    std::vector<TgHipAuxPixel> aux;
+    if (!rs.outputs.empty()) {
+        aux.resize(n);
+        in.read(reinterpret_cast<char *>(aux.data()), std::streamsize(n*sizeof(TgHipAuxPixel)));
+        if (!in)
+            return false;
+    }
     restoreFramebuffer(sum, count);
+    if (!aux.empty())
+        restoreOutputBuffers(aux);
     loadState(in);
     if (!in)
         throw std::runtime_error("path_tracer_hip: truncated render resume state '" + rs.resumeRenderFile + "'");
@@ -218,6 +310,7 @@ void PathTraceHipIntegrator::prepareForRender(TraceableScene &scene, uint32_t se
     // PathTraceIntegrator.cpp:187,196-200: the integrator's own sampler, tile dicing, one SampleRecord per 4x4 pixels
     _useSobol = scene.rendererSettings().useSobol;
     _useAdaptive = scene.rendererSettings().useAdaptiveSampling;
+    _useAux = !scene.rendererSettings().outputs.empty();   // PathTracer::_trackOutputValues (PathTracer.cpp:10)
     _scheduler.reset(_w, _h, seed);
     _deviceRecords.assign(_ctxs.size(), std::vector<TgHipSampleRecord>(_useAdaptive ? _scheduler.records().size() : 0));
 }
@@ -257,7 +350,7 @@ void PathTraceHipIntegrator::startRender(std::function<void()> completionCallbac
         pass.seed = _seed;
         pass.shard_index = uint32_t(d);
         pass.shard_count = uint32_t(_ctxs.size());
-        pass.flags = (_useSobol ? TGHIP_PASS_SOBOL : 0u) | (_useAdaptive ? TGHIP_PASS_RECORDS : 0u);
+        pass.flags = (_useSobol ? TGHIP_PASS_SOBOL : 0u) | (_useAdaptive ? TGHIP_PASS_RECORDS : 0u) | (_useAux ? TGHIP_PASS_AUX : 0u);
         pass.tile_seeds = _useSobol ? _scheduler.tileSeeds().data() : nullptr;
         pass.record_index = pass.record_count = nullptr;
         if (_useAdaptive) {
@@ -349,6 +442,41 @@ void PathTraceHipIntegrator::currentFramebuffer(std::vector<float> &sum, std::ve
     fetchFramebuffer();
     sum = _sum;
     count = _count;
+}
+
+// Every pixel's record lives on the device that owns its tile; the others hold zeros there, so adding is exact.
+void PathTraceHipIntegrator::currentOutputBuffers(std::vector<TgHipAuxPixel> &aux)
+{
+    waitForCompletion();
+    const size_t n = size_t(_w)*_h;
+    aux.assign(n, TgHipAuxPixel());
+    std::memset(aux.data(), 0, n*sizeof(TgHipAuxPixel));
+    std::vector<TgHipAuxPixel> dev(n);
+    for (tghip_ctx *ctx : _ctxs) {
+        check(tghip_download_aux(ctx, dev.data(), n), ctx, "tghip_download_aux");
+        if (_ctxs.size() == 1) { aux.swap(dev); break; }
+        for (size_t i = 0; i < n; ++i) {
+            for (int k = 0; k < 11; ++k) { aux[i].a[k] += dev[i].a[k]; aux[i].b[k] += dev[i].b[k]; aux[i].variance[k] += dev[i].variance[k]; }
+            for (int k = 0; k < 5; ++k) aux[i].count[k] += dev[i].count[k];
+        }
+    }
+}
+
+// Resume: a pixel's running means must continue on the device that renders its tile, so every device gets the whole state
+// and only ever touches (and later reports) its own pixels -- the others are cleared again when the buffers are merged.
+void PathTraceHipIntegrator::restoreOutputBuffers(const std::vector<TgHipAuxPixel> &aux)
+{
+    waitForCompletion();
+    const uint32_t tilesX = (_w + 15)/16;
+    for (size_t d = 0; d < _ctxs.size(); ++d) {
+        std::vector<TgHipAuxPixel> mine(aux);
+        if (_ctxs.size() > 1)
+            for (uint32_t y = 0; y < _h; ++y)
+                for (uint32_t x = 0; x < _w; ++x)
+                    if (((x/16) + (y/16)*tilesX) % _ctxs.size() != d)
+                        std::memset(&mine[size_t(x) + size_t(y)*_w], 0, sizeof(TgHipAuxPixel));
+        check(tghip_upload_aux(_ctxs[d], mine.data(), mine.size()), _ctxs[d], "tghip_upload_aux");
+    }
 }
 
 // The merged framebuffer goes to the first device, the others restart from zero: ownership of a pixel only matters for

@@ -53,6 +53,10 @@ public:
     virtual void loadState(std::istream &) {}
     virtual void restoreFramebuffer(const std::vector<float> &, const std::vector<uint32_t> &) {}
     virtual void currentFramebuffer(std::vector<float> &sum, std::vector<uint32_t> &count) { sum.clear(); count.clear(); }
+    // the auxiliary output buffers (renderer.output_buffers; Camera::serialize/deserializeOutputBuffers, Camera.cpp:222-238)
+    virtual void currentOutputBuffers(std::vector<TgHipAuxPixel> &aux) { aux.clear(); }
+    virtual void restoreOutputBuffers(const std::vector<TgHipAuxPixel> &) {}
+    void saveOutputBuffers();                                             // Camera::saveOutputBuffers (Camera.cpp:213-220)
 
     // per-pixel mean radiance, row-major, y down (Camera::getLinear, cameras/Camera.hpp:163-172)
     virtual const std::vector<float> &linearImage() = 0;
@@ -79,6 +83,7 @@ class PathTraceHipIntegrator : public Integrator
 
     PassScheduler _scheduler;             // tile seeds, SampleRecords, adaptive sample distribution
     bool _useSobol = false, _useAdaptive = false;
+    bool _useAux = false;                 // the scene asks for output buffers: passes carry TGHIP_PASS_AUX
     std::vector<uint32_t> _recordIndex, _recordCount;      // borrowed by the device until the pass completes
     std::vector<std::vector<TgHipSampleRecord>> _deviceRecords;
 
@@ -106,6 +111,8 @@ public:
     void loadState(std::istream &in) override;
     void restoreFramebuffer(const std::vector<float> &sum, const std::vector<uint32_t> &count) override;
     void currentFramebuffer(std::vector<float> &sum, std::vector<uint32_t> &count) override;
+    void currentOutputBuffers(std::vector<TgHipAuxPixel> &aux) override;
+    void restoreOutputBuffers(const std::vector<TgHipAuxPixel> &aux) override;
 
     const IntegratorSettings &settings() const { return _settings; }
     void setSettings(const IntegratorSettings &s) { _settings = s; }

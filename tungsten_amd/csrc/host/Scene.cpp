@@ -1033,6 +1033,23 @@ void RendererSettings::fromJson(const JsonValue &v)
     v.getField("scene_bvh", useSceneBvh);
     v.getField("spp", spp);
     v.getField("spp_step", sppStep);
+    if (const JsonValue &o = v["output_buffers"]) {   // OutputBufferSettings::fromJson (OutputBufferSettings.cpp:23-30)
+        static const char *names[5] = {"color", "depth", "normal", "albedo", "visibility"};
+        for (size_t i = 0; i < o.size(); ++i) {
+            OutputBufferSettings b;
+            std::string type = o[i]["type"].asString();
+            b.type = -1;
+            for (int k = 0; k < 5; ++k)
+                if (type == names[k]) b.type = k;
+            if (b.type < 0)
+                throw JsonLoadException("Unknown output buffer type '" + type + "'");
+            o[i].getField("ldr_output_file", b.ldrOutputFile);
+            o[i].getField("hdr_output_file", b.hdrOutputFile);
+            o[i].getField("two_buffer_variance", b.twoBufferVariance);
+            o[i].getField("sample_variance", b.sampleVariance);
+            outputs.push_back(b);
+        }
+    }
 }
 
 void IntegratorSettings::fromJson(const JsonValue &v)

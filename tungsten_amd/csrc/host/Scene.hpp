@@ -155,8 +155,16 @@ struct Camera
     void precompute();
 };
 
+struct OutputBufferSettings   // cameras/OutputBufferSettings.{hpp,cpp}
+{
+    int type = 0;                            // TGHIP_AUX_*: color, depth, normal, albedo, visibility
+    std::string ldrOutputFile, hdrOutputFile;
+    bool twoBufferVariance = false, sampleVariance = false;
+};
+
 struct RendererSettings   // renderer/RendererSettings.hpp:15-107
 {
+    std::vector<OutputBufferSettings> outputs;   // "output_buffers" (RendererSettings.hpp:70-75)
     std::string outputFile = "TungstenRender.png", hdrOutputFile, resumeRenderFile = "TungstenRenderState.dat";
     bool overwriteOutputFiles = true, useAdaptiveSampling = true, enableResumeRender = false, useSobol = true, useSceneBvh = true;
     unsigned spp = 32, sppStep = 16;

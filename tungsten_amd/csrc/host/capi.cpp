@@ -222,6 +222,21 @@ int tgh_renderer_records(tgh_renderer *r, TgHostSampleRecord *out, size_t n, cha
     return 0;
 }
 
+int tgh_renderer_output_buffers(tgh_renderer *r, TgHipAuxPixel *out, size_t npixels, char *err, size_t errlen)
+{
+    if (!r || !out) return -1;
+    try {
+        std::vector<TgHipAuxPixel> aux;
+        r->integrator->currentOutputBuffers(aux);
+        if (aux.size() != npixels) { setErr(err, errlen, "pixel count mismatch"); return -1; }
+        std::memcpy(out, aux.data(), npixels*sizeof(TgHipAuxPixel));
+        return 0;
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return -1;
+    }
+}
+
 tgh_scheduler *tgh_scheduler_create(uint32_t width, uint32_t height, uint32_t seed)
 {
     tgh_scheduler *s = new tgh_scheduler();
