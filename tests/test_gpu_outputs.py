@@ -88,3 +88,28 @@ def test_gpu_output_files_are_written(tmp_path):
                 assert os.path.exists(os.path.join(str(tmp_path), t + tag + ext)), t + tag + ext
     depth_a = tg.load_pfm(os.path.join(str(tmp_path), "depthA.pfm"))
     assert np.allclose(depth_a.reshape(36, 64, -1)[..., 0], aux["a"][..., 3], rtol=1e-6)
+
+
+def test_resume_keeps_the_output_buffers(tmp_path):
+    """Camera::serializeOutputBuffers / deserializeOutputBuffers inside the resume file (Integrator.cpp:118-121, 152-155):
+    render two of four passes, save, resume in a new renderer, finish -- every output buffer equals the uninterrupted
+    render bit for bit (each pixel's running means continue where they stopped)."""
+    state = str(tmp_path/"state.dat")
+    rend = {"adaptive_sampling": True, "stratified_sampler": True, "enable_resume_render": True, "resume_render_file": state}
+    kw = dict(resolution=(70, 42), spp=64, spp_step=16, renderer=rend, edit=scenes._outputs)
+    path = scenes.cornell(tmp_path, **kw)
+    full = _render(path, tg.DEFAULT_SEED)
+
+    r = tg.Renderer(path, seed=tg.DEFAULT_SEED)
+    r.step(); r.step()
+    r.save_resume_data()
+    r.close()
+    r = tg.Renderer(path, seed=tg.DEFAULT_SEED)
+    assert r.resume() and r.current_spp == 32
+    while not r.step():
+        pass
+    mean, ssum, count = r.image()
+    aux = r.output_buffers()
+    r.close()
+    assert ssum.tobytes() == full[1].tobytes() and (count == full[2]).all()
+    assert aux.tobytes() == full[3].tobytes()
