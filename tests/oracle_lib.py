@@ -44,6 +44,11 @@ _lib.oracle_dice_tiles.restype = C.c_uint64
 _lib.oracle_integrate.argtypes = [DESC_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_int]
 _lib.oracle_integrate.restype = C.c_int
+_lib.oracle_render_aux.argtypes = [DESC_P, C.POINTER(capi.TgHipPassDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(OracleCounters), C.c_int]
+_lib.oracle_render_aux.restype = C.c_int
+_lib.oracle_integrate_aux.argtypes = [DESC_P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_int]
+_lib.oracle_integrate_aux.restype = C.c_int
 
 
 def dice_tiles(width, height, seed):

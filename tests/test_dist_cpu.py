@@ -56,14 +56,21 @@ path = scenes.cornell(sys.argv[2], name="a%d.json" % rank, resolution=(W, H), sp
 flat = tg.FlattenedScene(path)
 ssum = np.zeros((H, W, 3), np.float32); count = np.zeros((H, W), np.uint32)
 records = np.zeros(((W + 3)//4)*((H + 3)//4), oracle_lib.DEVICE_RECORD_DTYPE)
+aux = np.zeros((H, W), oracle_lib.AUX_DTYPE)
+import ctypes as C
 def render_pass(p):      # the oracle stands in for tghip_render_pass + tghip_wait on this rank's device
-    rc = oracle_lib._lib.oracle_render_records(flat.desc, p, ssum.ctypes.data, count.ctypes.data, records.ctypes.data, None, 2)
+    rc = oracle_lib._lib.oracle_render_aux(flat.desc, p, C.c_void_p(ssum.ctypes.data), C.c_void_p(count.ctypes.data), C.c_void_p(records.ctypes.data),
+                                           C.c_void_p(aux.ctypes.data), None, 2)
     assert rc == 0
-sch = tgdist.render_loop(render_pass, lambda: records, W, H, SPP, STEP, SEED, rank=rank, world=world, adaptive=True, sobol=True)
+sch = tgdist.render_loop(render_pass, lambda: records, W, H, SPP, STEP, SEED, rank=rank, world=world, adaptive=True, sobol=True,
+                         output_buffers=True)
+merged_aux = tgdist.reduce_output_buffers(aux, dst=0)
 fs, fc = torch.from_numpy(ssum), torch.from_numpy(count.astype(np.int32))
 tgdist.reduce_framebuffer(fs, fc, dst=0)
 if rank == 0:
-    ws, wc, wrec, _ = oracle_lib.integrate(flat.desc, W, H, SEED, SPP, STEP, True, True)
+    ws, wc, wrec, _, waux = oracle_lib.integrate_aux(flat.desc, W, H, SEED, SPP, STEP, True, True)
+    assert merged_aux.tobytes() == waux.tobytes()      # the output buffers of both ranks' tiles, bit for bit
+    assert (merged_aux["count"][..., 0] == wc).all()
     final = sch.records.reshape(wrec[-1].shape)
     for f in ("sample_count", "next_sample_count", "sample_index", "mean", "running_variance"):
         assert (final[f] == wrec[-1][f]).all(), f
@@ -95,7 +102,8 @@ def _run_two_ranks(tmp_path, source, token):
 def test_two_rank_adaptive_pass_loop(tmp_path):
     """Adaptive sampling + Sobol' across 2 ranks: each rank renders its tiles of every pass, the ranks exchange the
     SampleRecords (tungsten_amd/dist.py: merge_records) and run the same scheduler; records, sample counts and framebuffer
-    must equal the single-process loop's bit for bit."""
+    must equal the single-process loop's bit for bit -- and so must the auxiliary output buffers (TGHIP_PASS_AUX passes,
+    tungsten_amd/dist.py: reduce_output_buffers)."""
     _run_two_ranks(tmp_path, ADAPTIVE_WORKER, "ADAPTIVE_DIST_OK")
 
 

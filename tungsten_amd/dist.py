@@ -57,8 +57,30 @@ def merge_records(records, group=None):
     return out
 
 
+def reduce_output_buffers(aux, dst=0, group=None):
+    """Auxiliary output buffers (TGHIP_PASS_AUX) of a tile-sharded render: structured numpy array [H, W] of AUX_DTYPE
+    (TgHipAuxPixel).  A pixel's record is non-zero only on the rank that owns its tile, so a sum-reduce to rank `dst`
+    assembles the complete buffers exactly (x + 0).  Returns the merged array (meaningful on `dst`)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return aux
+    floats = torch.from_numpy(np.concatenate([aux["a"], aux["b"], aux["variance"]], axis=-1).astype(np.float32))
+    counts = torch.from_numpy(np.ascontiguousarray(aux["count"]).astype(np.int64))
+    if dist.get_backend(group) == "nccl":
+        floats, counts = floats.cuda(), counts.cuda()
+    dist.reduce(floats, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    dist.reduce(counts, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    out = aux.copy()
+    f = floats.cpu().numpy()
+    out["a"], out["b"], out["variance"] = f[..., 0:11], f[..., 11:22], f[..., 22:33]
+    out["count"] = counts.cpu().numpy().astype(np.uint32)
+    return out
+
+
 def render_loop(render_pass, download_records, width, height, spp, spp_step, seed, rank=0, world=1, adaptive=True, sobol=False,
-                group=None):
+                group=None, output_buffers=False):
     """The integrator's pass loop (PathTraceIntegrator::startRender / generateWork, PathTraceIntegrator.cpp:108-134,220-239)
     for one-process-per-GPU renders: every rank runs the same deterministic PassScheduler, renders its own tiles of each
     pass and the ranks exchange the SampleRecords of the pass (merge_records) before the next generateWork.
@@ -76,7 +98,8 @@ def render_loop(render_pass, download_records, width, height, spp, spp_step, see
         if sch.generate_work(cur, nxt, adaptive):
             rec = sch.records
             p = shard_pass(rank, world, cur, nxt, seed)
-            p.flags = (capi.TGHIP_PASS_SOBOL if sobol else 0) | (capi.TGHIP_PASS_RECORDS if adaptive else 0)
+            p.flags = ((capi.TGHIP_PASS_SOBOL if sobol else 0) | (capi.TGHIP_PASS_RECORDS if adaptive else 0)
+                       | (capi.TGHIP_PASS_AUX if output_buffers else 0))     # renderer.output_buffers: reduce_output_buffers afterwards
             index = np.ascontiguousarray(rec["sample_index"])
             count = np.ascontiguousarray(rec["next_sample_count"])
             if sobol:
