@@ -1528,9 +1528,9 @@ static Event make_event(const Ctx *c, const Info *info, const Local *l, uint32_t
     return e;
 }
 
-/* ---- participating media: HomogeneousMedium with ExponentialTransmittance (media/HomogeneousMedium.cpp,
- * transmittances/ExponentialTransmittance.cpp).  The reference evaluates exp through fmath's table-based
- * approximation (math/FastMath.hpp:14-27); expf here, inside the float tolerance of the parity tests. ---- */
+/* ---- participating media: HomogeneousMedium (media/HomogeneousMedium.cpp) with the exponential, linear, quadratic,
+ * double-exponential, pulse and Erlang transmittances (transmittances/*.cpp).  The reference evaluates the exponential one through
+ * fmath's table-based exp (math/FastMath.hpp:14-27); expf here, inside the float tolerance of the parity tests. ---- */
 typedef struct { int firstScatter; int bounce; } MediumState;     /* Medium.hpp:30-47 */
 typedef struct { v3 p; float t; v3 weight; int exited; int medium; } MediumSample;
 static inline v3 vexpneg(v3 tau) { return V(expf(-tau.x), expf(-tau.y), expf(-tau.z)); }
@@ -1543,7 +1543,138 @@ static int selectMedium(const TgHipObject *o, int current, int geometricBackside
     return current;
 }
 
-/* HomogeneousMedium::sampleDistance (HomogeneousMedium.cpp:66-107); sigmaBar = 1, every transmittance variant = exp(-tau) */
+/* ---- transmittances (transmittances/*.cpp): the four kernels surfaceSurface / surfaceMedium / mediumSurface / mediumMedium
+ * of one channel, sigmaBar and the two distance samplers.  k: 0 = SS, 1 = SM, 2 = MS, 3 = MM. ---- */
+static float trans_kernel(const TgHipMedium *m, int k, float tau)
+{
+    const float *p = m->trans_p;
+    switch (m->trans_type) {
+    case TGHIP_TRANS_LINEAR: {                          /* LinearTransmittance.cpp:32-57 */
+        float maxT = p[0];
+        if (k == 0) return 1.0f - fminf(tau/maxT, 1.0f);
+        if (k == 1) return tau > maxT ? 0.0f : 1.0f/maxT;
+        if (k == 2) return tau > maxT ? 0.0f : 1.0f;
+        return fabsf(tau - maxT) < 1e-3f ? 1.0f : 0.0f;
+    }
+    case TGHIP_TRANS_QUADRATIC: {                       /* QuadraticTransmittance.cpp:32-52 */
+        float maxT = p[0], t = fminf(tau/maxT, 1.0f);
+        if (k == 0) return 1.0f - 2.0f*t + t*t;
+        if (k == 1) return (2.0f/maxT)*(1.0f - t);
+        if (k == 2) return 1.0f - t;
+        return tau > maxT ? 0.0f : 1.0f/maxT;
+    }
+    case TGHIP_TRANS_DOUBLE_EXPONENTIAL: {              /* DoubleExponentialTransmittance.cpp:34-49 */
+        float a = p[0], b = p[1], ea = expf(-a*tau), eb = expf(-b*tau);
+        if (k == 0) return 0.5f*(ea + eb);
+        if (k == 1) return 0.5f*(a*ea + b*eb);
+        if (k == 2) return (a*ea + b*eb)/(a + b);
+        return (sqr(a)*ea + sqr(b)*eb)/(a + b);
+    }
+    case TGHIP_TRANS_PULSE: {                           /* PulseTransmittance.cpp:45-82 */
+        float a = p[0], b = p[1], n = p[2];
+        int num = (int)n;
+        if (k == 0) {
+            float idxF = n*(tau - a)/(b - a) + 0.5f;
+            idxF = fminf(fmaxf(idxF, 0.0f), n);
+            int idx = (int)idxF;
+            float height = (float)(num - idx)/n;
+            float cellIntegral = height*(idxF - (float)idx);
+            if (idx > 0) cellIntegral += ((float)idx - 0.5f) - (float)(idx*(idx - 1))/(2.0f*n);
+            else         cellIntegral -= 0.5f;
+            return 1.0f - (2.0f/n)*cellIntegral;
+        }
+        if (k == 1 || k == 2) {
+            int idx = (int)(n*(tau - a)/(b - a) + 0.5f);
+            idx = idx < 0 ? 0 : (idx > num ? num : idx);
+            float ms = 1.0f - (float)idx/n;
+            return k == 2 ? ms : 2.0f/(b - a)*ms;
+        }
+        float idxF = fminf(fmaxf(n*(tau - a)/(b - a), 0.0f), n);
+        int idx = (int)idxF;
+        return (1.0f/n)*(fabsf(idxF - (float)idx - 0.5f) < 1e-3f ? 1.0f : 0.0f);
+    }
+    case TGHIP_TRANS_ERLANG: {                          /* ErlangTransmittance.cpp:32-47 */
+        float l = p[0], e = expf(-l*tau);
+        if (k == 0) return 0.5f*e*(2.0f + l*tau);
+        if (k == 1) return e*(1.0f + l*tau)*l*0.5f;
+        if (k == 2) return e*(1.0f + l*tau);
+        return sqr(l)*tau*e;
+    }
+    default:                                            /* ExponentialTransmittance.cpp:26-41 (FastMath::exp in the reference) */
+        return expf(-tau);
+    }
+}
+static float trans_sigmaBar(const TgHipMedium *m)
+{
+    switch (m->trans_type) {
+    case TGHIP_TRANS_LINEAR: return 1.0f/m->trans_p[0];
+    case TGHIP_TRANS_QUADRATIC: return 2.0f/m->trans_p[0];
+    case TGHIP_TRANS_DOUBLE_EXPONENTIAL: return 0.5f*(m->trans_p[0] + m->trans_p[1]);
+    case TGHIP_TRANS_PULSE: return 2.0f/(m->trans_p[1] - m->trans_p[0]);
+    case TGHIP_TRANS_ERLANG: return m->trans_p[0]*0.5f;
+    default: return 1.0f;
+    }
+}
+static v3 trans_kernel3(const TgHipMedium *m, int k, v3 tau) { return V(trans_kernel(m, k, tau.x), trans_kernel(m, k, tau.y), trans_kernel(m, k, tau.z)); }
+/* Transmittance::eval / surfaceProbability / mediumPdf (Transmittance.hpp:22-43) */
+static v3 trans_eval(const TgHipMedium *m, v3 tau, int startOnSurface, int endOnSurface)
+{
+    if (startOnSurface && endOnSurface) return trans_kernel3(m, 0, tau);
+    if (!startOnSurface && !endOnSurface) return vdivs(trans_kernel3(m, 3, tau), trans_sigmaBar(m));
+    return trans_kernel3(m, 2, tau);
+}
+/* Transmittance::sample = sampleSurface / sampleMedium */
+static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface)
+{
+    const float *p = m->trans_p;
+    switch (m->trans_type) {
+    case TGHIP_TRANS_LINEAR:                            /* :67-74 */
+        return startOnSurface ? p[0]*next1D(smp) : p[0];
+    case TGHIP_TRANS_QUADRATIC:                         /* :59-66 */
+        return startOnSurface ? p[0]*(1.0f - sqrtf(1.0f - next1D(smp))) : p[0]*next1D(smp);
+    case TGHIP_TRANS_DOUBLE_EXPONENTIAL: {              /* :56-65 */
+        float t = -logf(1.0f - next1D(smp));
+        float pa = startOnSurface ? 0.5f : p[0]/(p[0] + p[1]);
+        return nextBoolean(smp, pa) ? t/p[0] : t/p[1];
+    }
+    case TGHIP_TRANS_PULSE: {                           /* :89-108 */
+        float a = p[0], b = p[1], n = p[2];
+        int num = (int)n;
+        if (!startOnSurface)
+            return a + (0.5f + (float)(int)(next1D(smp)*n))/n*(b - a);
+        float xi = next1D(smp)*n*0.5f;
+        float delta = 1.0f/n;
+        for (int i = 0; i < num; ++i) {
+            float h0 = 1.0f - ((float)i + 0.0f)*delta;
+            float h1 = 1.0f - ((float)i + 1.0f)*delta;
+            xi -= h0*0.5f;
+            if (xi < 0.0f)
+                return a + ((float)i + 0.0f + 0.5f*next1D(smp))*(b - a)*delta;
+            xi -= h1*0.5f;
+            if (xi < 0.0f)
+                return a + ((float)i + 0.5f + 0.5f*next1D(smp))*(b - a)*delta;
+        }
+        return 0.0f;
+    }
+    case TGHIP_TRANS_ERLANG: {                          /* :54-68 */
+        if (!startOnSurface) {
+            float x0 = next1D(smp), x1 = next1D(smp);
+            return -1.0f/p[0]*logf(x0*x1);
+        }
+        float xi = next1D(smp);
+        float x = 0.5f;
+        for (int i = 0; i < 10; ++i) {
+            x += (xi - (1.0f - trans_kernel(m, 0, x)))/trans_kernel(m, 1, x);
+            x = fmaxf(x, 0.0f);
+        }
+        return x;
+    }
+    default:                                            /* ExponentialTransmittance.cpp:46-53 */
+        return -logf(1.0f - next1D(smp));
+    }
+}
+
+/* HomogeneousMedium::sampleDistance (HomogeneousMedium.cpp:66-107); state.firstScatter plays "startOnSurface" */
 static int medium_sampleDistance(const TgHipSceneDesc *s, int medium, Sampler *smp, const Ray *ray, MediumState *state, MediumSample *ms)
 {
     const TgHipMedium *m = &s->media[medium];
@@ -1555,22 +1686,22 @@ static int medium_sampleDistance(const TgHipSceneDesc *s, int medium, Sampler *s
         if (maxT == INFINITY)
             return 0;
         ms->t = maxT;
-        ms->weight = vexpneg(vscale(sigmaT, ms->t));
+        ms->weight = trans_eval(m, vscale(sigmaT, ms->t), state->firstScatter, 1);
         ms->exited = 1;
     } else {
         int component = (int)(nextSupplemental(smp)*3);           /* sampler.nextDiscrete(3) */
         float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
-        float t = -logf(1.0f - next1D(smp))/sigmaTc;              /* ExponentialTransmittance::sample* (:46-53) */
+        float t = trans_sample(m, smp, state->firstScatter)/sigmaTc;
         ms->t = fminf(t, maxT);
         ms->exited = t >= maxT;
         v3 tau = vscale(sigmaT, ms->t);
-        ms->weight = vexpneg(tau);
+        ms->weight = trans_eval(m, tau, state->firstScatter, ms->exited);
         float pdf;
         if (ms->exited) {
-            pdf = vavg(vexpneg(tau));                              /* surfaceProbability(tau).avg() */
+            pdf = vavg(trans_kernel3(m, state->firstScatter ? 0 : 2, tau));               /* surfaceProbability(tau, firstScatter).avg() */
         } else {
-            pdf = vavg(vmul(sigmaT, vexpneg(tau)));                /* (sigmaT*mediumPdf(tau)).avg() */
-            ms->weight = vmul(ms->weight, ld3(m->sigma_s));
+            pdf = vavg(vmul(sigmaT, trans_kernel3(m, state->firstScatter ? 1 : 3, tau)));  /* (sigmaT*mediumPdf(tau, firstScatter)).avg() */
+            ms->weight = vmul(ms->weight, vscale(ld3(m->sigma_s), trans_sigmaBar(m)));
         }
         ms->weight = vdivs(ms->weight, pdf);
         state->firstScatter = 0; state->bounce++;                  /* state.advance() */
@@ -1581,11 +1712,11 @@ static int medium_sampleDistance(const TgHipSceneDesc *s, int medium, Sampler *s
 }
 
 /* HomogeneousMedium::transmittance (:109-116) */
-static v3 medium_transmittance(const TgHipSceneDesc *s, int medium, float farT)
+static v3 medium_transmittance(const TgHipSceneDesc *s, int medium, float farT, int startOnSurface, int endOnSurface)
 {
     if (farT == INFINITY)
         return vs(0.0f);
-    return vexpneg(vscale(ld3(s->media[medium].sigma_t), farT));
+    return trans_eval(&s->media[medium], vscale(ld3(s->media[medium].sigma_t), farT), startOnSurface, endOnSurface);
 }
 
 /* PhaseFunction::eval / pdf / sample (phasefunctions/IsotropicPhaseFunction.cpp:17-41, HenyeyGreensteinPhaseFunction.cpp:16-63) */
@@ -1594,8 +1725,11 @@ static float phase_hg(float g, float cosTheta)
     float term = 1.0f + g*g - 2.0f*g*cosTheta;
     return O_INV_FOUR_PI*(1.0f - g*g)/(term*sqrtf(term));
 }
-static float phase_eval(const TgHipMedium *m, v3 wi, v3 wo)   /* eval == pdf for both phase functions */
+static float phase_rayleigh(float cosTheta) { return (3.0f/(16.0f*O_PI))*(1.0f + cosTheta*cosTheta); }   /* RayleighPhaseFunction.cpp:14-17 */
+static float phase_eval(const TgHipMedium *m, v3 wi, v3 wo)   /* eval == pdf for every phase function */
 {
+    if (m->phase_type == TGHIP_PHASE_RAYLEIGH)
+        return phase_rayleigh(vdot(wi, wo));
     if (m->phase_type == TGHIP_PHASE_HENYEY_GREENSTEIN)
         return phase_hg(m->phase_g, vdot(wi, wo));
     return O_INV_FOUR_PI;
@@ -1604,7 +1738,17 @@ static void phase_sample(const TgHipMedium *m, Sampler *smp, v3 wi, v3 *w, float
 {
     float xi0 = next1D(smp), xi1 = next1D(smp);                    /* next2D */
     float g = m->phase_g;
-    if (m->phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN || g == 0.0f) {
+    if (m->phase_type == TGHIP_PHASE_RAYLEIGH) {                   /* RayleighPhaseFunction::sample (:31-49) */
+        float phi = xi0*O_TWO_PI;
+        float z = xi1*4.0f - 2.0f;
+        float invZ = sqrtf(z*z + 1.0f);
+        float u = cbrtf(z + invZ);
+        float cosTheta = u - 1.0f/u;
+        float sinTheta = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
+        Frame f = frame_from_normal(wi);
+        *w = toGlobal(&f, V(cosf(phi)*sinTheta, sinf(phi)*sinTheta, cosTheta));
+        *pdf = phase_rayleigh(cosTheta);
+    } else if (m->phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN || g == 0.0f) {
         *w = uniformSphere(xi0, xi1);
         *pdf = O_INV_FOUR_PI;
     } else {
@@ -1619,7 +1763,7 @@ static void phase_sample(const TgHipMedium *m, Sampler *smp, v3 wi, v3 *w, float
 
 /* TraceBase::generalizedShadowRay (TraceBase.cpp:62-125).  `endCap` is an object index, `medium` the medium the ray
  * starts in (-1 = none). */
-static v3 generalizedShadowRay(Ctx *c, Ray *ray, int medium, int endCap, int bounce)
+static v3 generalizedShadowRay(Ctx *c, Ray *ray, int medium, int endCap, int startsOnSurface, int bounce)
 {
     float initialFarT = ray->tmax;
     v3 throughput = vs(1.0f);
@@ -1649,10 +1793,11 @@ static v3 generalizedShadowRay(Ctx *c, Ray *ray, int medium, int endCap, int bou
                 return vs(0.0f);
         }
         if (medium >= 0)                                   /* :103-112; ray.farT() is the hit distance when anything was hit */
-            throughput = vmul(throughput, medium_transmittance(c->s, medium, hitAny ? hit.t : ray->tmax));
+            throughput = vmul(throughput, medium_transmittance(c->s, medium, hitAny ? hit.t : ray->tmax, startsOnSurface, 1));   /* endsOnSurface = true (attenuatedEmission) */
         if (!hitAny || hitObject == endCap)
             return bounce >= c->s->settings.min_bounces ? throughput : vs(0.0f);
         medium = selectMedium(&c->s->objects[info.object], medium, !info.backSide);     /* :115 */
+        startsOnSurface = 1;
         ray->o = vadd(ray->o, vscale(ray->d, hit.t));      /* ray.hitpoint(): farT was set to the hit */
         initialFarT -= hit.t;
         ray->tmin = info.epsilon;
@@ -1945,7 +2090,7 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
 }
 
 /* TraceBase::attenuatedEmission (TraceBase.cpp:144-174) for non-Dirac lights */
-static v3 attenuatedEmission(Ctx *c, int lightObj, int medium, float expectedDist, int bounce, Ray *ray, LightHit *lh)
+static v3 attenuatedEmission(Ctx *c, int lightObj, int medium, float expectedDist, int bounce, int startsOnSurface, Ray *ray, LightHit *lh)
 {
     const float fudgeFactor = 1.0f + 1e-3f;
     if (c->s->objects[lightObj].type == TGHIP_OBJ_POINT) {       /* light.isDirac(): ray.setFarT(expectedDist) (:157-158) */
@@ -1954,7 +2099,7 @@ static v3 attenuatedEmission(Ctx *c, int lightObj, int medium, float expectedDis
         return vs(0.0f);
     }
     ray->tmax = lh->t;
-    v3 shadow = generalizedShadowRay(c, ray, medium, lightObj, bounce);
+    v3 shadow = generalizedShadowRay(c, ray, medium, lightObj, startsOnSurface, bounce);
     if (c->transmittanceOut)                               /* if (transmittance) *transmittance = shadow (:169-170) */
         *c->transmittanceOut = shadow;
     if (viszero(shadow))
@@ -1979,7 +2124,7 @@ static v3 lightSample(Ctx *c, int lightObj, const Info *info, const Local *l, in
     Ray ray = {info->p, d, info->epsilon, INFINITY};
     LightHit lh;
     c->transmittanceOut = c->visRequest;
-    v3 em = attenuatedEmission(c, lightObj, medium, dist, bounce, &ray, &lh);
+    v3 em = attenuatedEmission(c, lightObj, medium, dist, bounce, 1, &ray, &lh);
     c->transmittanceOut = NULL;
     if (viszero(em))
         return vs(0.0f);
@@ -2003,7 +2148,7 @@ static v3 bsdfSample(Ctx *c, int lightObj, const Info *info, const Local *l, int
     medium = selectMedium(&c->s->objects[info->object], medium, vdot(wo, info->Ng) < 0.0f);  /* :302-303 */
     Ray ray = {info->p, wo, info->epsilon, INFINITY};
     LightHit lh;
-    v3 em = attenuatedEmission(c, lightObj, medium, -1.0f, bounce, &ray, &lh);
+    v3 em = attenuatedEmission(c, lightObj, medium, -1.0f, bounce, 1, &ray, &lh);
     if (viszero(em))
         return vs(0.0f);
     v3 bsdfF = vmul(em, e.weight);
@@ -2078,7 +2223,7 @@ static v3 volumeEstimateDirect(Ctx *c, const MediumSample *ms, int medium, int b
             if (f != 0.0f) {
                 Ray ray = {ms->p, d, 0.0f, INFINITY};              /* parentRay.scatter(p, d, 0.0f) */
                 LightHit lh;
-                v3 e = attenuatedEmission(c, light, medium, dist, bounce, &ray, &lh);
+                v3 e = attenuatedEmission(c, light, medium, dist, bounce, 0, &ray, &lh);
                 if (!viszero(e)) {
                     v3 lightF = vdivs(vscale(e, f), pdf);
                     if (!dirac)
@@ -2093,7 +2238,7 @@ static v3 volumeEstimateDirect(Ctx *c, const MediumSample *ms, int medium, int b
         phase_sample(m, c->sampler, parentDir, &w, &pdf);
         Ray ray = {ms->p, w, 0.0f, INFINITY};
         LightHit lh;
-        v3 e = attenuatedEmission(c, light, medium, -1.0f, bounce, &ray, &lh);
+        v3 e = attenuatedEmission(c, light, medium, -1.0f, bounce, 0, &ray, &lh);
         if (!viszero(e))
             result = vadd(result, vscale(e, powerHeuristic(pdf, light_directPdf(c->s, light, &lh, ms->p))));
     }

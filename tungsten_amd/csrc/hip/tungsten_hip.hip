@@ -1064,6 +1064,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 int bounce = (int)(tag >> 24);
                 int medium = -1;                               // media scenes (always the FORWARD walk): SHADOW_TAG_MEDIA
                 if (FORWARD && s.num_media) { endCap = (int)(tag & 0xFFFFu); medium = (int)((tag >> 16) & 0xFFu) - 1; }
+                bool startsOnSurface = so.w != 0.0f;           // shadow rays of a volume vertex start at tmin = 0 (parentRay.scatter(p, d, 0.0f))
                 RayD ray;
                 ray.o = xyz(so); ray.d = xyz(sd); ray.tmin = so.w; ray.tmax = sd.w;
                 float remaining = ray.tmax;
@@ -1093,7 +1094,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                         hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)(hitInst >= 0 ? hitInst : ri)*3u).w));
                     if (meshLight && ri < 0) { transmittance = splat3(0.0f); visValid = false; break; }   // the ray never reaches the mesh
                     if (medium >= 0)                             // TraceBase.cpp:103-112: ray.farT() is the hit distance when anything was hit
-                        transmittance = transmittance*mediumTransmittance(s, medium, ri >= 0 ? hit.x : ray.tmax);
+                        transmittance = transmittance*mediumTransmittance(s, medium, ri >= 0 ? hit.x : ray.tmax, startsOnSurface, true);
                     if (ri < 0 || hitObject == endCap) {
                         if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
                         if (meshLight) {
@@ -1131,8 +1132,9 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     transmittance = transmittance*transparency;
                     bounce++;
                     if (bounce >= s.settings.max_bounces) { transmittance = splat3(0.0f); break; }
-                    if (s.num_media)                             // :115
+                    if (s.num_media)                             // :115-116
                         medium = selectMedium(s.objects[info.object], medium, !info.backSide);
+                    startsOnSurface = true;
                     ray.o = ray.o + ray.d*hit.x;
                     travelled += hit.x;
                     remaining -= hit.x;
@@ -1992,7 +1994,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 return TGHIP_E_INVALID;
             }
         for (uint32_t i = 0; i < sd->num_media; ++i)
-            if (sd->media[i].phase_type != TGHIP_PHASE_ISOTROPIC && sd->media[i].phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN) {
+            if (sd->media[i].phase_type < TGHIP_PHASE_ISOTROPIC || sd->media[i].phase_type > TGHIP_PHASE_RAYLEIGH) {
                 ctx->error = "unknown phase function";
                 return TGHIP_E_UNSUPPORTED;
             }

@@ -564,15 +564,39 @@ std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
     getVec3(v, "sigma_s", m->materialSigmaS);
     v.getField("density", m->density);
     v.getField("max_bounces", m->maxBounce);
-    if (const JsonValue &t = v["transmittance"]) {
+    if (const JsonValue &t = v["transmittance"]) {   // scene.fetchTransmittance (Medium.cpp:27-28); defaults from the constructors
         std::string tt = t.isString() ? t.asString() : t["type"].asString();
-        if (tt != "exponential")
-            throw JsonLoadException("transmittance '" + tt + "' is not supported by path_tracer_hip (exponential only)");
+        const bool obj = t.isObject();
+        if (tt == "exponential") {
+            m->transType = 0;
+        } else if (tt == "linear" || tt == "quadratic") {                       // {Linear,Quadratic}Transmittance.cpp:12-22
+            m->transType = tt == "linear" ? 1 : 2;
+            m->transP[0] = 1.0f;
+            if (tt == "quadratic") m->transP[0] = 0.75f;
+            if (obj) t.getField("max_t", m->transP[0]);
+        } else if (tt == "double_exponential") {                                // DoubleExponentialTransmittance.cpp:12-23
+            m->transType = 3;
+            m->transP[0] = 0.5f; m->transP[1] = 10.0f;
+            if (obj) { t.getField("sigma_a", m->transP[0]); t.getField("sigma_b", m->transP[1]); }
+        } else if (tt == "pulse") {                                             // PulseTransmittance.cpp:12-26
+            m->transType = 4;
+            m->transP[0] = 0.0f; m->transP[1] = 1.0f; m->transP[2] = 4.0f;
+            int numPulses = 4;
+            if (obj) { t.getField("min", m->transP[0]); t.getField("max", m->transP[1]); t.getField("num_pulses", numPulses); }
+            m->transP[2] = float(numPulses);
+        } else if (tt == "erlang") {                                            // ErlangTransmittance.cpp:12-21
+            m->transType = 5;
+            m->transP[0] = 5.0f;
+            if (obj) t.getField("rate", m->transP[0]);
+        } else {
+            throw JsonLoadException("transmittance '" + tt + "' is not supported by path_tracer_hip");
+        }
     }
     if (const JsonValue &ph = v["phase_function"]) {
         std::string pt = ph.isString() ? ph.asString() : ph["type"].asString();
         if (pt == "isotropic") m->phaseType = 0;
         else if (pt == "henyey_greenstein") { m->phaseType = 1; if (ph.isObject()) ph.getField("g", m->phaseG); }
+        else if (pt == "rayleigh") m->phaseType = 2;
         else throw JsonLoadException("phase function '" + pt + "' is not supported by path_tracer_hip");
     }
     return m;

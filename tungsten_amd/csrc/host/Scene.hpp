@@ -70,14 +70,16 @@ struct Bsdf
 };
 
 // ---- participating media (src/core/media, phasefunctions, transmittances) ----------------
-struct Medium   // media/HomogeneousMedium.{hpp,cpp} + Medium.cpp; transmittance = the default ExponentialTransmittance
+struct Medium   // media/HomogeneousMedium.{hpp,cpp} + Medium.cpp + transmittances/*.cpp
 {
     std::string name;
     Vec3f materialSigmaA = Vec3f(0.0f), materialSigmaS = Vec3f(0.0f);
     float density = 1.0f;
     int maxBounce = 1024;
-    int phaseType = 0;          // 0 isotropic, 1 henyey_greenstein
+    int phaseType = 0;          // 0 isotropic, 1 henyey_greenstein, 2 rayleigh
     float phaseG = 0.0f;
+    int transType = 0;          // TGHIP_TRANS_*: exponential, linear, quadratic, double_exponential, pulse, erlang
+    float transP[3] = {0.0f, 0.0f, 0.0f};
     // prepareForRender (HomogeneousMedium.cpp:43-49)
     Vec3f sigmaA, sigmaS, sigmaT;
     bool absorptionOnly = false;

@@ -148,6 +148,8 @@ void TraceableScene::flatten()
         d.max_bounce = m->maxBounce;
         d.phase_type = m->phaseType;
         d.phase_g = m->phaseG;
+        d.trans_type = m->transType;
+        for (int k = 0; k < 3; ++k) d.trans_p[k] = m->transP[k];
         mediumKeys.push_back(m.get());
         _media.push_back(d);
         return int32_t(_media.size() - 1);
