@@ -7,7 +7,7 @@
 //
 // Execution model: the machine is partitioned into G persistent workgroups (G = CUs x
 // blocks_per_cu, the same G for every kernel of a pass).  Workgroup b owns
-//   * a private range of path slots in HBM (slot = b*slots_per_block + local; 15 arrays of 16 B per slot in one
+//   * a private range of path slots in HBM (slot = b*slots_per_block + local; 17 arrays of 16 B per slot in one
 //     allocation, addressed as "one base + 32-bit offset"),
 //   * private queues over those slots -- one BITMAP per queue, expanded by the consumer into the ascending list of
 //     set slots so that every kernel walks its slots in memory order -- and
