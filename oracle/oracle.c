@@ -1600,6 +1600,12 @@ static float trans_kernel(const TgHipMedium *m, int k, float tau)
         if (k == 2) return e*(1.0f + l*tau);
         return sqr(l)*tau*e;
     }
+    case TGHIP_TRANS_DAVIS: {                           /* DavisTransmittance.cpp:34-49 */
+        float alpha = p[0];
+        if (k == 0) return powf(1.0f + tau/alpha, -alpha);
+        if (k == 1 || k == 2) return powf(1.0f + tau/alpha, -(alpha + 1.0f));
+        return (1.0f + 1.0f/alpha)*powf(1.0f + tau/alpha, -(alpha + 2.0f));
+    }
     default:                                            /* ExponentialTransmittance.cpp:26-41 (FastMath::exp in the reference) */
         return expf(-tau);
     }
@@ -1669,6 +1675,9 @@ static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface
         }
         return x;
     }
+    case TGHIP_TRANS_DAVIS:                             /* :56-63 */
+        return startOnSurface ? p[0]*(powf(1.0f - next1D(smp), -1.0f/p[0]) - 1.0f)
+                              : p[0]*(powf(1.0f - next1D(smp), -1.0f/(1.0f + p[0])) - 1.0f);
     default:                                            /* ExponentialTransmittance.cpp:46-53 */
         return -logf(1.0f - next1D(smp));
     }

@@ -546,7 +546,7 @@ def non_exponential(tmpdir, gas, **kw):
 
 
 for _gas, _tag in (("gas1", "linear"), ("gas2", "quadratic"), ("gas3", "double_exponential"), ("gas4", "pulse"),
-                   ({"type": "erlang", "rate": 3.0}, "erlang")):
+                   ({"type": "erlang", "rate": 3.0}, "erlang"), ({"type": "davis", "alpha": 1.6}, "davis")):
     GOLDEN_CASES["non_exponential_" + _tag] = ((lambda g: lambda t, **kw: non_exponential(t, g, **kw))(_gas), dict(resolution=(48, 27), spp=8))
 def _area_lights(scene):
     """The scene's emitters are 4.7 x 3.8 mm: Quad::approximateRadiance (Quad.cpp:253-281) subtracts four arc cosines from 2 pi to get
@@ -560,6 +560,12 @@ def _area_lights(scene):
 # all four gases with emitters large enough for per-sample parity on every implementation of acosf
 GOLDEN_CASES["non_exponential_area_lights"] = (lambda t, **kw: non_exponential(t, "gas1", **kw), dict(resolution=(48, 27), spp=8, edit=_area_lights))
 GOLDEN_CASES["volumetric_caustic"] = (volumetric_caustic, dict(resolution=(48, 27), spp=8))
+def _davis_fog(scene):
+    _fog(scene)
+    scene["media"][-1]["transmittance"] = {"type": "davis", "alpha": 1.3}
+
+
+GOLDEN_CASES["cornell_fog_davis"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_davis_fog))
 GOLDEN_CASES["cornell_fog_rayleigh"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_rayleigh_fog))
 GOLDEN_CASES["cornell_fog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog))
 GOLDEN_CASES["cornell_smoke"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_smoke))

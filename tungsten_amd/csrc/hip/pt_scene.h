@@ -1627,6 +1627,11 @@ PT_DEV float transKernel(const TgHipMedium &m, int k, float tau)
         if (k == 2) return e*(1.0f + p0*tau);
         return sqr(p0)*tau*e;
     }
+    case TGHIP_TRANS_DAVIS: {                           /* DavisTransmittance.cpp:34-49 */
+        if (k == 0) return powf(1.0f + tau/p0, -p0);
+        if (k == 1 || k == 2) return powf(1.0f + tau/p0, -(p0 + 1.0f));
+        return (1.0f + 1.0f/p0)*powf(1.0f + tau/p0, -(p0 + 2.0f));
+    }
     default:                                            /* ExponentialTransmittance.cpp:26-41 */
         return expf(-tau);
     }
@@ -1694,6 +1699,8 @@ PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   
         }
         return x;
     }
+    case TGHIP_TRANS_DAVIS:
+        return startOnSurface ? p0*(powf(1.0f - RNG1D(rng), -1.0f/p0) - 1.0f) : p0*(powf(1.0f - RNG1D(rng), -1.0f/(1.0f + p0)) - 1.0f);
     default:
         return -logf(1.0f - RNG1D(rng));
     }

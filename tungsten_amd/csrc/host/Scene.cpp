@@ -588,6 +588,11 @@ std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
             m->transType = 5;
             m->transP[0] = 5.0f;
             if (obj) t.getField("rate", m->transP[0]);
+        } else if (tt == "davis") {                                             // DavisTransmittance.cpp:7-25
+            m->transType = 6;
+            m->transP[0] = 1.1f;
+            if (obj) t.getField("alpha", m->transP[0]);
+            if (m->transP[0] < 1 + 1e-6f) m->transP[0] = 1 + 1e-6f;
         } else {
             throw JsonLoadException("transmittance '" + tt + "' is not supported by path_tracer_hip");
         }
