@@ -2837,6 +2837,18 @@ int oracle_trace_rays(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *h
     return 0;
 }
 
+/* transmittance kernels and distance samplers on their own (tests/test_media.py): k = 0 SS, 1 SM, 2 MS, 3 MM */
+float oracle_trans_kernel(const TgHipMedium *m, int k, float tau) { return trans_kernel(m, k, tau); }
+float oracle_trans_sigma_bar(const TgHipMedium *m) { return trans_sigmaBar(m); }
+void oracle_trans_samples(const TgHipMedium *m, int startOnSurface, uint32_t seed, int n, float *out)
+{
+    for (int i = 0; i < n; ++i) {
+        Sampler smp;
+        sampler_start(&smp, seed, (uint32_t)i, 0);
+        out[i] = trans_sample(m, &smp, startOnSurface);
+    }
+}
+
 /* ---- unit-level hooks for the L1 parity tests (tests/test_oracle_units.py) ---------------- */
 void oracle_rng_stream(uint32_t seed, uint32_t pixelIndex, uint32_t sampleIndex, int n, float *out)
 {

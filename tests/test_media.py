@@ -94,3 +94,70 @@ def test_unsupported_media_are_rejected(tmp_path):
         scene["integrator"]["low_order_scattering"] = False
     with pytest.raises(Exception):
         tg.FlattenedScene(scenes.cornell(tmp_path, name="low.json", resolution=(16, 9), spp=1, edit=low_order)).close()
+
+
+# ---- the transmittances on their own: identities the four kernels of any Transmittance satisfy (Transmittance.hpp:22-63) ----
+import ctypes as _C
+from tungsten_amd import capi as _capi
+
+TRANSMITTANCES = {"exponential": (0, []), "linear": (1, [0.75]), "quadratic": (2, [0.75]), "double_exponential": (3, [1.0, 10.0]),
+                  "pulse": (4, [0.0, 1.0, 4.0]), "erlang": (5, [3.0]), "davis": (6, [1.6])}
+
+
+def _medium(kind):
+    m = _capi.TgHipMedium()
+    m.trans_type, p = TRANSMITTANCES[kind]
+    for i, v in enumerate(p):
+        m.trans_p[i] = v
+    return m
+
+
+def _kernel(m, k, taus):
+    f = oracle_lib._lib.oracle_trans_kernel
+    f.restype = _C.c_float
+    f.argtypes = [_C.POINTER(_capi.TgHipMedium), _C.c_int, _C.c_float]
+    return np.array([f(_C.byref(m), k, float(t)) for t in taus])
+
+
+@pytest.mark.parametrize("kind", sorted(TRANSMITTANCES))
+def test_transmittance_kernels_are_consistent(kind):
+    """surfaceMedium = -d/dtau surfaceSurface (the collision density seen from a surface), sigmaBar = surfaceMedium(0), and for
+    the transmittances without Dirac parts mediumMedium = -d/dtau mediumSurface; all kernels start at or below 1 and decay."""
+    m = _medium(kind)
+    f = oracle_lib._lib.oracle_trans_sigma_bar
+    f.restype = _C.c_float
+    f.argtypes = [_C.POINTER(_capi.TgHipMedium)]
+    sigma_bar = f(_C.byref(m))
+    taus = np.linspace(0.01, 1.4, 140)
+    h = 1e-3
+    if kind in ("linear", "quadratic"):
+        taus = taus[np.abs(taus - 0.75) > 0.02]       # the kink at max_t
+    ss = _kernel(m, 0, taus)
+    assert abs(_kernel(m, 0, [0.0])[0] - 1.0) < 1e-6 and (np.diff(ss) <= 1e-6).all() and (ss >= -1e-6).all()
+    if kind != "pulse":                              # (pulse: piecewise constant densities, compared through the samplers below)
+        dss = -(_kernel(m, 0, taus + h) - _kernel(m, 0, taus - h))/(2*h)
+        assert np.allclose(dss, _kernel(m, 1, taus), rtol=2e-2, atol=3e-3), kind
+        assert abs(_kernel(m, 1, [1e-6])[0] - sigma_bar) < 1e-3*sigma_bar
+    if kind not in ("linear", "pulse"):              # their mediumMedium is a sum of Dirac deltas
+        dms = -(_kernel(m, 2, taus + h) - _kernel(m, 2, taus - h))/(2*h)
+        assert np.allclose(dms, _kernel(m, 3, taus), rtol=2e-2, atol=3e-3), kind
+
+
+@pytest.mark.parametrize("start_on_surface", [1, 0])
+@pytest.mark.parametrize("kind", sorted(TRANSMITTANCES))
+def test_transmittance_samplers_follow_their_kernels(kind, start_on_surface):
+    """sampleSurface draws tau with P(tau > x) = surfaceSurface(x), sampleMedium with P(tau > x) = mediumSurface(x)
+    (HomogeneousMedium::sampleDistance relies on exactly that: surfaceProbability / mediumPdf)."""
+    m = _medium(kind)
+    n = 40000
+    out = np.zeros(n, np.float32)
+    f = oracle_lib._lib.oracle_trans_samples
+    f.restype = None
+    f.argtypes = [_C.POINTER(_capi.TgHipMedium), _C.c_int, _C.c_uint32, _C.c_int, _C.c_void_p]
+    f(_C.byref(m), start_on_surface, 77, n, out.ctypes.data)
+    xs = np.linspace(0.02, 1.3, 33)
+    if kind in ("linear", "pulse") and not start_on_surface:
+        xs = xs[np.abs((xs*8) % 1 - 0.5) > 0.1] if kind == "pulse" else xs[np.abs(xs - 0.75) > 0.02]   # away from the Dirac positions
+    survival = np.array([(out > x).mean() for x in xs])
+    expected = _kernel(m, 0 if start_on_surface else 2, xs)
+    assert np.allclose(survival, expected, atol=4*np.sqrt(0.25/n) + 2e-3), (kind, start_on_surface, np.abs(survival - expected).max())
