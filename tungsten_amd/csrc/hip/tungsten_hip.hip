@@ -1514,6 +1514,7 @@ struct tghip_ctx {
     std::vector<uint32_t> hostRecLum, hostRecIndex, hostRecCount, hostSorted, hostChunkStart, hostHint;
     uint32_t *dSorted = nullptr, *dChunkStart = nullptr, *dHint = nullptr;   // gap-free item enumeration of record passes
     size_t sortedCap = 0, chunkStartCap = 0, hintCap = 0;
+    std::vector<uint32_t> hostBucket, hostSortTmp;   // counting sort of the owned records by sample count
 
     // path pool
     DeviceBuffers poolMem;
@@ -2413,7 +2414,19 @@ int tghip_wait(tghip_ctx *ctx)
             if (((rx >> 2) + (ry >> 2)*tilesX) % shardCount == pass.shard_index && cnt[r] > 0)
                 sorted.push_back(r);
         }
-        std::stable_sort(sorted.begin(), sorted.end(), [&cnt](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+        // descending by count, ties in record order (a counting sort: the counts of a pass are small integers)
+        if (spp < (1u << 16)) {
+            std::vector<uint32_t> &bucket = ctx->hostBucket;
+            bucket.assign(size_t(spp) + 2, 0u);
+            for (uint32_t r : sorted) bucket[spp - cnt[r] + 1]++;
+            for (size_t i = 1; i < bucket.size(); ++i) bucket[i] += bucket[i - 1];
+            std::vector<uint32_t> &tmp = ctx->hostSortTmp;
+            tmp.resize(sorted.size());
+            for (uint32_t r : sorted) tmp[bucket[spp - cnt[r]]++] = r;
+            sorted.swap(tmp);
+        } else {
+            std::stable_sort(sorted.begin(), sorted.end(), [&cnt](uint32_t a, uint32_t b) { return cnt[a] > cnt[b]; });
+        }
         const uint32_t numChunks = (spp + chunk - 1)/chunk;
         start.assign(size_t(numChunks) + 2, 0u);
         size_t alive = sorted.size();                // records with cnt > c*chunk: a prefix of `sorted`

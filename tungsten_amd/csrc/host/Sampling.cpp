@@ -107,8 +107,10 @@ float PassScheduler::errorPercentile95()
     }
     if (errors.empty())
         return 0.0f;
-    std::sort(errors.begin(), errors.end());
-    return errors[(errors.size()*95)/100];
+    // the element std::sort would leave at this position (PathTraceIntegrator.cpp:57-59), without ordering the rest
+    const size_t k = (errors.size()*95)/100;
+    std::nth_element(errors.begin(), errors.begin() + std::ptrdiff_t(k), errors.end());
+    return errors[k];
 }
 
 static inline float maxOf(float a, float b) { return a > b ? a : b; }   // MathUtil.hpp:23-26
