@@ -76,14 +76,14 @@ typedef struct TgHipBvhNode {
 
 /* record kinds (meta >> 29) */
 enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3, TGHIP_REC_INSTANCE = 4,
-       TGHIP_REC_DISK = 5 };
+       TGHIP_REC_DISK = 5, TGHIP_REC_CYLINDER = 6 };
 #define TGHIP_REC_KIND(meta)   ((uint32_t)(meta) >> 29)
 #define TGHIP_REC_OBJECT(meta) ((uint32_t)(meta) & 0x1FFFFFFFu)
 
 /* 48-byte primitive record = three float4:
  *   triangle: a = v0, b = v1 - v0, c = v2 - v0                (p0,p1 unused)
  *   quad    : a = base, b = edge0, c = edge1, p0/p1 = 1/|edge0|^2, 1/|edge1|^2   (Quad.cpp:298-316)
- *   cube / sphere / disk: geometry lives in objects[TGHIP_REC_OBJECT(meta)]; a,b,c unused
+ *   cube / sphere / disk / cylinder: geometry lives in objects[TGHIP_REC_OBJECT(meta)]; a,b,c unused
  *   instance: one rigid placement of a master mesh (primitives/Instance.cpp:290-344): a = _instancePos[i],
  *             (p0, b) = _instanceRot[i] as quaternion (w; x, y, z), c[0] = bits of the master's BVH root node index
  *             (uint32), c[1] = bits of the instance number i; the object is the `instances` primitive.  The master's
@@ -109,7 +109,8 @@ typedef struct TgHipTriAttr {
 enum { TGHIP_OBJ_MESH = 0, TGHIP_OBJ_QUAD = 1, TGHIP_OBJ_CUBE = 2, TGHIP_OBJ_SPHERE = 3,
        TGHIP_OBJ_INFINITE_SPHERE = 4, TGHIP_OBJ_INSTANCES = 5, TGHIP_OBJ_DISK = 6,
        TGHIP_OBJ_INFINITE_SPHERE_CAP = 7,     /* sun-like emitter: normal = _capDir, scale[0] = _cosCapAngle, edge0/edge1 = _capFrame tangent/bitangent (InfiniteSphereCap.cpp:233-249) */
-       TGHIP_OBJ_POINT = 8 };                 /* Dirac point light (primitives/Point.cpp): pos = _pos, scale = _power as Point.cpp:186 leaves it; never hit, sampled without random numbers */
+       TGHIP_OBJ_POINT = 8,
+       TGHIP_OBJ_CYLINDER = 9 };              /* primitives/Cylinder.cpp:305-319: pos = _pos, rot = _rot, normal = _axis, scale = {_radius, _halfHeight, _capped ? 1 : 0} */                 /* Dirac point light (primitives/Point.cpp): pos = _pos, scale = _power as Point.cpp:186 leaves it; never hit, sampled without random numbers */
 #define TGHIP_OBJF_SMOOTH   1u   /* mesh "smooth": Ns interpolated (TriangleMesh.cpp:344-355) */
 #define TGHIP_OBJF_SAMPLE   2u   /* infinite_sphere "sample" (InfiniteSphere.cpp:117-122)      */
 

@@ -1221,6 +1221,62 @@ static void disk_surface(const TgHipObject *o, v3 hp, float rSq, float *u, float
     *u = (x == 0.0f && y == 0.0f) ? 0.0f : (atan2f(y, x)*O_INV_TWO_PI + 0.5f);
 }
 
+/* Cylinder::intersect (Cylinder.cpp:55-108): pos = _pos, rot = _rot, scale = {_radius, _halfHeight, _capped}.  cap = +-1 when a
+ * cap was hit (its sign), 0 for the side. */
+static int cylinder_test(const TgHipObject *o, const Ray *ray, float tmax, float *tOut, int *backSide, float *cap)
+{
+    const float radius = o->scale[0], halfHeight = o->scale[1], invRadius = 1.0f/radius;
+    v3 pLocal = mat3_tmul(o->rot, vsub(ray->o, ld3(o->pos)));
+    v3 dLocal = mat3_tmul(o->rot, ray->d);
+    float px = pLocal.x*invRadius, pz = pLocal.z*invRadius, dx = dLocal.x*invRadius, dz = dLocal.z*invRadius;
+    int didHit = 0;
+    float farT = tmax;
+    if (o->scale[2] != 0.0f && fabsf(dLocal.y) > 1e-6f) {
+        for (int k = 0; k < 2; ++k) {
+            float sign = k == 0 ? 1.0f : -1.0f;
+            float t = (sign*halfHeight - pLocal.y)/dLocal.y;
+            if (t > ray->tmin && t < farT) {
+                float hx = px + t*dx, hz = pz + t*dz;
+                if (hx*hx + hz*hz < 1.0f) {
+                    didHit = 1; *cap = sign; *backSide = sign*dLocal.y > 0.0f; farT = t;
+                }
+            }
+        }
+    }
+    float A = dx*dx + dz*dz, B = px*dx + pz*dz, C = px*px + pz*pz - 1.0f;
+    float detSq = B*B - A*C;
+    if (detSq >= 0.0f) {
+        float det = sqrtf(detSq);
+        for (int k = 0; k < 2; ++k) {
+            float sign = k == 0 ? 1.0f : -1.0f;
+            float t = (-B - sign*det)/A;
+            if (t > ray->tmin && t < farT) {
+                float h = pLocal.y + dLocal.y*t;
+                if (h >= -halfHeight && h <= halfHeight) {
+                    didHit = 1; *cap = 0.0f; *backSide = sign < 0.0f; farT = t;
+                }
+            }
+        }
+    }
+    if (didHit) *tOut = farT;
+    return didHit;
+}
+/* Cylinder::intersectionInfo (Cylinder.cpp:122-132) from the hit point hp and the cap flag */
+static void cylinder_surface(const TgHipObject *o, v3 hp, float cap, v3 *n, float *u, float *v)
+{
+    const float invRadius = 1.0f/o->scale[0];
+    v3 pl = mat3_tmul(o->rot, vsub(hp, ld3(o->pos)));
+    float hx = pl.x*invRadius, hz = pl.z*invRadius;
+    if (cap != 0.0f) {
+        *n = mat3_mul(o->rot, V(0.0f, cap, 0.0f));
+        *u = hx*0.5f + 0.5f; *v = hz*0.5f + 0.5f;
+    } else {
+        *n = mat3_mul(o->rot, V(hx, 0.0f, hz));
+        *u = atan2f(hz, hx)*O_INV_TWO_PI + 0.5f;
+        *v = pl.y*(0.5f/o->scale[1]) + 0.5f;
+    }
+}
+
 static void cube_surface(const TgHipObject *o, v3 hp, v3 *n, float *u, float *v)
 {
     v3 p = mat3_tmul(o->rot, vsub(hp, ld3(o->pos)));
@@ -1310,6 +1366,7 @@ static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float 
     case TGHIP_REC_CUBE: ok = cube_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
     case TGHIP_REC_SPHERE: ok = sphere_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
     case TGHIP_REC_DISK: ok = disk_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &v, &back); u = (float)back; break;   /* v carries rSq */
+    case TGHIP_REC_CYLINDER: ok = cylinder_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back, &v); u = (float)back; break;   /* v carries the cap sign */
     case TGHIP_REC_INSTANCE: {
         /* Instance::intersect (primitives/Instance.cpp:290-311): the ray goes into the master's space -- rotation and
          * translation only, so distances along it are unchanged -- and the master's own intersect shortens it */
@@ -1431,6 +1488,12 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit
         break;
     case TGHIP_REC_SPHERE:       /* Sphere.cpp:120-129 */
         sphere_surface(o, info->p, &info->Ng, &info->u, &info->v);
+        info->Ns = info->Ng;
+        info->bsdf = o->bsdf;
+        info->backSide = hit->u != 0.0f;
+        break;
+    case TGHIP_REC_CYLINDER:     /* Cylinder.cpp:122-132 */
+        cylinder_surface(o, info->p, hit->v, &info->Ng, &info->u, &info->v);
         info->Ns = info->Ng;
         info->bsdf = o->bsdf;
         info->backSide = hit->u != 0.0f;
@@ -1845,6 +1908,11 @@ static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, 
         if (!sphere_test(o, ray, ray->tmax, &lh->t, &lh->backSide)) return 0;
         sphere_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), &lh->n, &lh->u, &lh->v);
         return 1;
+    } else if (o->type == TGHIP_OBJ_CYLINDER) {        /* Cylinder::intersect + intersectionInfo */
+        float cap;
+        if (!cylinder_test(o, ray, ray->tmax, &lh->t, &lh->backSide, &cap)) return 0;
+        cylinder_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), cap, &lh->n, &lh->u, &lh->v);
+        return 1;
     } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::intersect + intersectionInfo */
         float rSq;
         if (!disk_test(o, ray, ray->tmax, &lh->t, &rSq, &lh->backSide)) return 0;
@@ -1881,6 +1949,9 @@ static float light_directPdf(const TgHipSceneDesc *s, int objIdx, const LightHit
         v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
         return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
     } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:469-473 */
+        v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
+        return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
+    } else if (o->type == TGHIP_OBJ_CYLINDER) {        /* Cylinder::directPdf (Cylinder.cpp:246-250) */
         v3 hp = vadd(lh->o, vscale(lh->w, lh->t));
         return vlensq(vsub(p, hp))/(-vdot(lh->w, lh->n)*o->area);
     } else if (o->type == TGHIP_OBJ_POINT) {           /* Point::directPdf (Point.cpp:117-121) */
@@ -1989,6 +2060,33 @@ static int light_sampleDirect(const TgHipSceneDesc *s, int objIdx, v3 p, Sampler
         *dist = INFINITY;
         *pdf = O_INV_TWO_PI/(1.0f - o->scale[0]);
         return 1;
+    } else if (o->type == TGHIP_OBJ_CYLINDER) {        /* Cylinder::sampleDirect + samplePosition (Cylinder.cpp:149-170, 181-196) */
+        const float radius = o->scale[0], halfHeight = o->scale[1];
+        v3 ng, q;
+        if (o->scale[2] != 0.0f && nextBoolean(smp, O_TWO_PI*sqr(radius)*o->inv_area)) {
+            float xi0 = next1D(smp), xi1 = next1D(smp);
+            float phi = xi0*O_TWO_PI, rr = sqrtf(xi1);     /* SampleWarp::uniformDisk */
+            float sign = nextBoolean(smp, 0.5f) ? -1.0f : 1.0f;
+            ng = V(0.0f, sign, 0.0f);
+            q = V(cosf(phi)*rr*radius, sign*halfHeight, sinf(phi)*rr*radius);
+        } else {
+            float xi0 = next1D(smp), xi1 = next1D(smp);
+            float phi = xi0*O_TWO_PI;                      /* SampleWarp::uniformCylinder */
+            float cx = cosf(phi), cy = sinf(phi), cz = xi1*2.0f - 1.0f;
+            ng = V(cx, 0.0f, cy);
+            q = V(cx*radius, cz*halfHeight, cy*radius);
+        }
+        ng = mat3_mul(o->rot, ng);
+        q = vadd(mat3_mul(o->rot, q), ld3(o->pos));
+        v3 L = vsub(q, p);
+        float rSq = vlensq(L);
+        *dist = sqrtf(rSq);
+        *d = vdivs(L, *dist);
+        float cosTheta = -vdot(ng, *d);
+        if (cosTheta <= 0.0f)
+            return 0;
+        *pdf = rSq/(cosTheta*o->area);
+        return 1;
     } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::sampleDirect (Disk.cpp:178-194) */
         v3 n = ld3(o->normal), center = ld3(o->pos);
         if (vdot(n, vsub(p, center)) < 0.0f)
@@ -2063,7 +2161,7 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
         v3 ap = V(fmaxf(fabsf(lp.x), 0.0f), fmaxf(fabsf(lp.y), 0.0f), fmaxf(fabsf(lp.z), 0.0f));
         float dSq = vlensq(ap);
         return vmax3(ld3(s->textures[o->emission].avg))*o->face_cdf[2]/dSq;
-    } else if (o->type == TGHIP_OBJ_MESH) {            /* TriangleMesh.cpp:514-517: "unknown" */
+    } else if (o->type == TGHIP_OBJ_MESH || o->type == TGHIP_OBJ_CYLINDER) {   /* TriangleMesh.cpp:514-517, Cylinder.cpp:280-284: "unknown" */
         return -1.0f;
     } else if (o->type == TGHIP_OBJ_POINT) {           /* Point::approximateRadiance (Point.cpp:166-169) */
         /* scale = Point::_power as prepareForRender left it (Point.cpp:186): 0 for a light given by "power" */

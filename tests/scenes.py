@@ -570,6 +570,24 @@ GOLDEN_CASES["cornell_fog_rayleigh"] = (cornell, dict(resolution=(48, 27), spp=8
 GOLDEN_CASES["cornell_fog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog))
 GOLDEN_CASES["cornell_smoke"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_smoke))
 GOLDEN_CASES["cornell_fog_smoke_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog_and_smoke, renderer={"stratified_sampler": True}))
+def _cylinders(scene):
+    """primitives/Cylinder.cpp: a capped checkered pillar, an open (uncapped) tilted mirror tube one can look into, and an emissive
+    tube light next to the dimmed quad light -- a sampled emitter whose approximateRadiance is "unknown" (Cylinder.cpp:280-284),
+    so chooseLight gives it the mean of the known weights (TraceBase.cpp:434-446)."""
+    for p in scene["primitives"]:
+        if p["name"] == "light":
+            p["emission"] = [6, 4.5, 1.5]
+    scene["primitives"] = [p for p in scene["primitives"] if p["name"] not in ("shortBox", "tallBox")]
+    scene["bsdfs"] += [{"name": "checkers", "type": "lambert", "albedo": _CHECKER}, {"name": "tube", "type": "mirror", "albedo": [0.9, 0.85, 0.8]}]
+    scene["primitives"] += [
+        {"name": "pillar", "type": "cylinder", "bsdf": "checkers", "transform": {"position": [-0.45, 0.5, -0.3], "scale": [0.5, 1.0, 0.5]}},
+        {"name": "pipe", "type": "cylinder", "bsdf": "tube", "capped": False,
+         "transform": {"position": [0.45, 0.35, 0.3], "scale": [0.5, 0.9, 0.5], "rotation": [70, 25, 0]}},
+        {"name": "neon", "type": "cylinder", "bsdf": "light", "emission": [3, 7, 9],
+         "transform": {"position": [0.0, 1.6, -0.6], "scale": [0.08, 1.2, 0.08], "rotation": [0, 0, 90]}}]
+
+
+GOLDEN_CASES["cornell_cylinders"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_cylinders))
 GOLDEN_CASES["cornell_point_lights"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_point_lights))
 GOLDEN_CASES["cornell_sun_sky"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_sun_and_sky))
 GOLDEN_CASES["cornell_disks"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_disks))

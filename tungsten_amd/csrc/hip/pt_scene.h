@@ -1037,6 +1037,62 @@ PT_DEV void diskSurface(const TgHipObject &o, f3 hp, float rSq, float &u, float 
     u = (x == 0.0f && y == 0.0f) ? 0.0f : (atan2f(y, x)*PT_INV_TWO_PI + 0.5f);
 }
 
+/* Cylinder::intersect (Cylinder.cpp:55-108): pos = _pos, rot = _rot, scale = {_radius, _halfHeight, _capped}; cap = +-1 when a
+ * cap was hit (its sign), 0 for the side */
+template<typename OP>
+PT_DEV bool cylinderTest(OP op, const RayD &ray, float tmax, float &tOut, bool &backSide, float &cap)
+{
+    const auto &o = *op;
+    const float radius = o.scale[0], halfHeight = o.scale[1], invRadius = 1.0f/radius;
+    f3 pLocal = mat3TMul(o.rot, ray.o - ld3(o.pos));
+    f3 dLocal = mat3TMul(o.rot, ray.d);
+    float px = pLocal.x*invRadius, pz = pLocal.z*invRadius, dx = dLocal.x*invRadius, dz = dLocal.z*invRadius;
+    bool didHit = false;
+    float farT = tmax;
+    if (o.scale[2] != 0.0f && fabsf(dLocal.y) > 1e-6f) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float sign = k == 0 ? 1.0f : -1.0f;
+            float t = (sign*halfHeight - pLocal.y)/dLocal.y;
+            if (t > ray.tmin && t < farT) {
+                float hx = px + t*dx, hz = pz + t*dz;
+                if (hx*hx + hz*hz < 1.0f) { didHit = true; cap = sign; backSide = sign*dLocal.y > 0.0f; farT = t; }
+            }
+        }
+    }
+    float A = dx*dx + dz*dz, B = px*dx + pz*dz, C = px*px + pz*pz - 1.0f;
+    float detSq = B*B - A*C;
+    if (detSq >= 0.0f) {
+        float det = sqrtf(detSq);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float sign = k == 0 ? 1.0f : -1.0f;
+            float t = (-B - sign*det)/A;
+            if (t > ray.tmin && t < farT) {
+                float h = pLocal.y + dLocal.y*t;
+                if (h >= -halfHeight && h <= halfHeight) { didHit = true; cap = 0.0f; backSide = sign < 0.0f; farT = t; }
+            }
+        }
+    }
+    if (didHit) tOut = farT;
+    return didHit;
+}
+/* Cylinder::intersectionInfo (Cylinder.cpp:122-132) from the hit point and the cap flag */
+PT_DEV void cylinderSurface(const TgHipObject &o, f3 hp, float cap, f3 &n, float &u, float &v)
+{
+    const float invRadius = 1.0f/o.scale[0];
+    f3 pl = mat3TMul(o.rot, hp - ld3(o.pos));
+    float hx = pl.x*invRadius, hz = pl.z*invRadius;
+    if (cap != 0.0f) {
+        n = mat3Mul(o.rot, mk3(0.0f, cap, 0.0f));
+        u = hx*0.5f + 0.5f; v = hz*0.5f + 0.5f;
+    } else {
+        n = mat3Mul(o.rot, mk3(hx, 0.0f, hz));
+        u = atan2f(hz, hx)*PT_INV_TWO_PI + 0.5f;
+        v = pl.y*(0.5f/o.scale[1]) + 0.5f;
+    }
+}
+
 /* normal and uv of a point on a cube / sphere (Cube.cpp:157-170, Sphere.cpp:120-129) */
 PT_DEV void cubeSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v)
 {
@@ -1067,7 +1123,7 @@ PT_DEV void sphereSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v
 // KINDS: the record kinds the scene (or the kernel variant) can contain; tests of absent kinds fold away, which keeps
 // the hot traversal kernels of triangle scenes at their register budget whatever analytic primitives exist elsewhere.
 #define KIND_BIT(k)   (1u << (k))
-#define KINDS_ALL     0x3Fu
+#define KINDS_ALL     0x7Fu
 #define KINDS_MESH    (KIND_BIT(TGHIP_REC_TRIANGLE) | KIND_BIT(TGHIP_REC_QUAD))   /* triangle meshes + quads (materialtest) */
 template<bool UNIFORM, uint32_t KINDS = KINDS_ALL>
 PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit, uint32_t &hitMeta)
@@ -1099,6 +1155,11 @@ PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
         bool back;
         if (UNIFORM) ok = diskTest(asConst(s.objects) + TGHIP_REC_OBJECT(meta), ray, tmax, t, v, back);
         else         ok = diskTest(s.objects + TGHIP_REC_OBJECT(meta), ray, tmax, t, v, back);
+        u = back ? 1.0f : 0.0f;
+    } else if ((KINDS & KIND_BIT(TGHIP_REC_CYLINDER)) && kind == TGHIP_REC_CYLINDER) {   /* v carries the cap sign */
+        bool back;
+        if (UNIFORM) ok = cylinderTest(asConst(s.objects) + TGHIP_REC_OBJECT(meta), ray, tmax, t, back, v);
+        else         ok = cylinderTest(s.objects + TGHIP_REC_OBJECT(meta), ray, tmax, t, back, v);
         u = back ? 1.0f : 0.0f;
     } else if ((KINDS & KIND_BIT(TGHIP_REC_SPHERE)) && kind == TGHIP_REC_SPHERE) {
         bool back;
@@ -1181,6 +1242,11 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         info.u = hit.y; info.v = hit.z;
         info.bsdf = o.bsdf;
         info.backSide = dot(ray.d, info.Ng) >= 0.0f;
+    } else if ((M & FEAT_SOLIDS) && kind == TGHIP_REC_CYLINDER) {   /* Cylinder.cpp:122-132 */
+        cylinderSurface(o, info.p, hit.z, info.Ng, info.u, info.v);
+        info.Ns = info.Ng;
+        info.bsdf = o.bsdf;
+        info.backSide = hit.y != 0.0f;
     } else if ((M & FEAT_SOLIDS) && kind == TGHIP_REC_DISK) {    /* Disk.cpp:114-129 */
         info.Ng = info.Ns = ld3(o.normal);
         diskSurface(o, info.p, hit.z, info.u, info.v);
@@ -1246,6 +1312,12 @@ PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, Li
         cubeSurface(o, ray.o + ray.d*lh.t, lh.n, lh.u, lh.v);
         return true;
     }
+    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::intersect + intersectionInfo (only in the variants whose chooseLight handles "unknown" weights) */
+        float cap;
+        if (!cylinderTest(&o, ray, ray.tmax, lh.t, lh.backSide, cap)) return false;
+        cylinderSurface(o, ray.o + ray.d*lh.t, cap, lh.n, lh.u, lh.v);
+        return true;
+    }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_DISK) {       /* Disk::intersect + intersectionInfo */
         float rSq;
         if (!diskTest(&o, ray, ray.tmax, lh.t, rSq, lh.backSide)) return false;
@@ -1287,6 +1359,10 @@ PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p, const 
         return t*t/(cosTheta*o.area);
     }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube.cpp:291-295 */
+        f3 hp = p + w*lh.t;
+        return lengthSq(p - hp)/(-dot(w, lh.n)*o.area);
+    }
+    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::directPdf (Cylinder.cpp:246-250) */
         f3 hp = p + w*lh.t;
         return lengthSq(p - hp)/(-dot(w, lh.n)*o.area);
     }
@@ -1333,6 +1409,34 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         dist = sqrtf(rSq);
         d = L/dist;
         float cosTheta = -dot(normal, d);
+        if (cosTheta <= 0.0f)
+            return false;
+        pdf = rSq/(cosTheta*o.area);
+        return true;
+    }
+    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::sampleDirect + samplePosition (Cylinder.cpp:149-170, 181-196) */
+        const float radius = o.scale[0], halfHeight = o.scale[1];
+        f3 ng, q;
+        if (o.scale[2] != 0.0f && rngNextBoolean(rng, PT_TWO_PI*sqr(radius)*o.inv_area)) {
+            float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
+            float phi = xi0*PT_TWO_PI, rr = sqrtf(xi1);                    /* SampleWarp::uniformDisk */
+            float sign = rngNextBoolean(rng, 0.5f) ? -1.0f : 1.0f;
+            ng = mk3(0.0f, sign, 0.0f);
+            q = mk3(cosf(phi)*rr*radius, sign*halfHeight, sinf(phi)*rr*radius);
+        } else {
+            float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
+            float phi = xi0*PT_TWO_PI;                                     /* SampleWarp::uniformCylinder */
+            float cx = cosf(phi), cy = sinf(phi), cz = xi1*2.0f - 1.0f;
+            ng = mk3(cx, 0.0f, cy);
+            q = mk3(cx*radius, cz*halfHeight, cy*radius);
+        }
+        ng = mat3Mul(o.rot, ng);
+        q = mat3Mul(o.rot, q) + ld3(o.pos);
+        f3 L = q - p;
+        float rSq = lengthSq(L);
+        dist = sqrtf(rSq);
+        d = L/dist;
+        float cosTheta = -dot(ng, d);
         if (cosTheta <= 0.0f)
             return false;
         pdf = rSq/(cosTheta*o.area);
@@ -1455,7 +1559,7 @@ template<uint32_t M>
 PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
 {
     const TgHipObject &o = s.objects[objIdx];
-    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_MESH)      /* TriangleMesh.cpp:514-517: "unknown" */
+    if ((M & FEAT_MESHLIGHT) && (o.type == TGHIP_OBJ_MESH || o.type == TGHIP_OBJ_CYLINDER))   /* TriangleMesh.cpp:514-517, Cylinder.cpp:280-284: "unknown" */
         return -1.0f;
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube.cpp:326-330 */
         f3 lp = mat3TMul(o.rot, p - ld3(o.pos));

@@ -1955,7 +1955,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 ctx->error = "sampled mesh emitter without a valid light_tris block";
                 return TGHIP_E_INVALID;
             }
-        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE && t != TGHIP_OBJ_DISK && t != TGHIP_OBJ_INFINITE_SPHERE_CAP && t != TGHIP_OBJ_POINT) {
+        } else if (t != TGHIP_OBJ_QUAD && t != TGHIP_OBJ_INFINITE_SPHERE && t != TGHIP_OBJ_CUBE && t != TGHIP_OBJ_SPHERE && t != TGHIP_OBJ_DISK && t != TGHIP_OBJ_INFINITE_SPHERE_CAP && t != TGHIP_OBJ_POINT && t != TGHIP_OBJ_CYLINDER) {
             ctx->error = "unknown emitter type";
             return TGHIP_E_UNSUPPORTED;
         }
@@ -2003,7 +2003,8 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     ctx->thinlens = sd->camera.type == TGHIP_CAMERA_THINLENS;
     if (sd->camera.type != TGHIP_CAMERA_PINHOLE && sd->camera.type != TGHIP_CAMERA_THINLENS) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
     for (uint32_t i = 0; i < sd->num_lights; ++i)
-        if (sd->objects[sd->lights[i]].type == TGHIP_OBJ_MESH) ctx->haveMeshLight = true;
+        // (cylinder emitters answer "unknown" to approximateRadiance like meshes do: same shading variants)
+        if (sd->objects[sd->lights[i]].type == TGHIP_OBJ_MESH || sd->objects[sd->lights[i]].type == TGHIP_OBJ_CYLINDER) ctx->haveMeshLight = true;
     // CDF guide tables for the samplable bitmaps (pt_scene.h: upperBoundGuided)
     {
         std::vector<uint16_t> guide;
@@ -2048,7 +2049,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             uint32_t meta = sd->recs[i].meta;
             if (TGHIP_REC_KIND(meta) == TGHIP_REC_INSTANCE)
                 continue;                    // never a hit record itself: hits are the master's triangles
-            if (TGHIP_REC_KIND(meta) > TGHIP_REC_DISK) { ctx->error = "unknown primitive record kind"; return TGHIP_E_INVALID; }
+            if (TGHIP_REC_KIND(meta) > TGHIP_REC_CYLINDER) { ctx->error = "unknown primitive record kind"; return TGHIP_E_INVALID; }
             if (TGHIP_REC_KIND(meta) != TGHIP_REC_TRIANGLE && TGHIP_REC_KIND(meta) != TGHIP_REC_QUAD) ctx->haveSolids = true;
             int bi = TGHIP_REC_KIND(meta) == TGHIP_REC_TRIANGLE ? sd->tri_attrs[i].bsdf : sd->objects[TGHIP_REC_OBJECT(meta)].bsdf;
             if (bi < 0 || uint32_t(bi) >= sd->num_bsdfs) { ctx->error = "primitive record without a valid bsdf"; return TGHIP_E_INVALID; }

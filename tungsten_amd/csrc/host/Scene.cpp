@@ -689,6 +689,11 @@ std::shared_ptr<Primitive> Scene::instantiatePrimitive(const JsonValue &v) const
         v.getField("cone_angle", p->coneAngle);
         if (const JsonValue &b = v["bsdf"]) p->bsdfs.push_back(fetchBsdf(b));
         else p->bsdfs.push_back(defaultBsdf());
+    } else if (type == "cylinder") {      // Cylinder::fromJson (Cylinder.cpp:41-48)
+        p->type = Primitive::Cylinder;
+        v.getField("capped", p->capped);
+        if (const JsonValue &b = v["bsdf"]) p->bsdfs.push_back(fetchBsdf(b));
+        else p->bsdfs.push_back(defaultBsdf());
     } else if (type == "infinite_sphere") {
         p->type = Primitive::InfiniteSphere;
         v.getField("sample", p->doSample);
@@ -862,6 +867,20 @@ void Primitive::prepareForRender()
         bounds = Box3f();
         bounds.grow(pos - edge0*r - edge1*r); bounds.grow(pos + edge0*r - edge1*r);
         bounds.grow(pos + edge0*r + edge1*r); bounds.grow(pos - edge0*r + edge1*r);
+        break;
+    } case Cylinder: { // Cylinder.cpp:305-319, bounds :286-293
+        rot = transform.extractRotation();
+        invRot = rot.transpose();
+        pos = transform*Vec3f(0.0f);
+        normal = transform.up().normalized();                                               // _axis
+        Vec3f sc = transform.extractScaleVec();
+        float radius = 0.5f*std::max(sc.x(), sc.z()), halfHeight = 0.5f*sc.y();
+        scale = Vec3f(radius, halfHeight, capped ? 1.0f : 0.0f);
+        area = 2.0f*PI*radius*radius + 2.0f*PI*radius*2.0f*halfHeight;
+        invArea = 1.0f/area;
+        bounds = Box3f();
+        bounds.grow(pos + normal*halfHeight); bounds.grow(pos - normal*halfHeight);
+        bounds.lo = bounds.lo - Vec3f(radius); bounds.hi = bounds.hi + Vec3f(radius);       // Box::grow(float)
         break;
     } case InfiniteSphere: { // InfiniteSphere.cpp:280-286
         rot = transform.extractRotation();

@@ -92,7 +92,7 @@ struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp
 
 struct Primitive
 {
-    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6, InfiniteSphereCap = 7, Point = 8 };
+    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6, InfiniteSphereCap = 7, Point = 8, Cylinder = 9 };
     std::string name;
     Type type = Quad;
     Mat4f transform;
@@ -106,6 +106,7 @@ struct Primitive
     std::vector<MeshTriangle> tris;
     // infinite sphere
     bool doSample = true;
+    bool capped = true;         // cylinder (primitives/Cylinder.hpp)
     // disk (primitives/Disk.hpp): emission confined to a cone around the normal
     float coneAngle = 90.0f;
     // infinite sphere cap (primitives/InfiniteSphereCap.hpp): emission from directions within cap_angle of the transform's up axis

@@ -241,11 +241,12 @@ void TraceableScene::flatten()
             _triAttrs.back().bsdf = o.bsdf;
             recBounds.push_back(p.bounds);
             break;
-        } case Primitive::Cube: case Primitive::Sphere: case Primitive::Disk: {
+        } case Primitive::Cube: case Primitive::Sphere: case Primitive::Disk: case Primitive::Cylinder: {
             TgHipPrimRec r;
             std::memset(&r, 0, sizeof(r));
             copy3(r.a, p.pos); copy3(r.b, p.scale);
-            r.meta = (uint32_t(p.type == Primitive::Cube ? TGHIP_REC_CUBE : p.type == Primitive::Sphere ? TGHIP_REC_SPHERE : TGHIP_REC_DISK) << 29) | objMeta;
+            r.meta = (uint32_t(p.type == Primitive::Cube ? TGHIP_REC_CUBE : p.type == Primitive::Sphere ? TGHIP_REC_SPHERE :
+                               p.type == Primitive::Disk ? TGHIP_REC_DISK : TGHIP_REC_CYLINDER) << 29) | objMeta;
             _recs.push_back(r);
             _triAttrs.emplace_back();
             std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
