@@ -572,7 +572,7 @@ PT_DEV void instanceLeave(InstanceWalk &w)
     w.instSp = -1; w.curInst = -1;
 }
 
-template<bool COUNT>
+template<bool COUNT, uint32_t KINDS = KINDS_ALL>
 PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &worldRay, int *stack, int stride,
                                   uint32_t &nodesVisited, uint32_t &primsTested, int &hitInst)
 {
@@ -611,7 +611,7 @@ PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &worldRay, in
                     break;
                 }
                 uint32_t meta;
-                if (testRecord<false>(s, i, w.ray, tmax, hit, meta))
+                if (testRecord<false, KINDS>(s, i, w.ray, tmax, hit, meta))
                     hitInst = w.curInst;
             }
         }
@@ -627,7 +627,7 @@ PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &worldRay, in
     return hit;
 }
 
-template<bool COUNT>
+template<bool COUNT, uint32_t KINDS = KINDS_ALL>
 PT_DEV bool traverseOccludedInst(const DeviceScene &s, const RayD &worldRay, int endCap, int *stack, int stride,
                                  uint32_t &nodesVisited, uint32_t &primsTested)
 {
@@ -665,7 +665,7 @@ PT_DEV bool traverseOccludedInst(const DeviceScene &s, const RayD &worldRay, int
                 }
                 uint32_t meta;
                 float tmax = worldRay.tmax;
-                if (testRecord<false>(s, i, w.ray, tmax, hit, meta) && (w.curInst >= 0 || (int)TGHIP_REC_OBJECT(meta) != endCap))
+                if (testRecord<false, KINDS>(s, i, w.ray, tmax, hit, meta) && (w.curInst >= 0 || (int)TGHIP_REC_OBJECT(meta) != endCap))
                     return true;
             }
         }

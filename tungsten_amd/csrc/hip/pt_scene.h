@@ -59,7 +59,8 @@ struct DeviceScene {
 #define FEAT_INSTANCES  (1u << 31)   /* hits reached through an instance record (primitives/Instance.cpp): only in MASK_FULL / BSDF_MASK_ALL */
 #define FEAT_MEDIA      (1u << 23)   /* participating media (media/HomogeneousMedium.cpp): only in the BSDF_MASK_ALL variant */
 #define FEAT_AUX        (1u << 22)   /* TGHIP_PASS_AUX passes (auxiliary output buffers): only in the BSDF_MASK_ALL variant */
-#define MASK_FULL       (BSDF_MASK_ALL & ~(FEAT_QMC | FEAT_MEDIA | FEAT_AUX))
+#define FEAT_CYLINDER   (1u << 21)   /* cylinder primitives / emitters (primitives/Cylinder.cpp): only in the BSDF_MASK_ALL variant */
+#define MASK_FULL       (BSDF_MASK_ALL & ~(FEAT_QMC | FEAT_MEDIA | FEAT_AUX | FEAT_CYLINDER))
 // next1D of the path's sampler inside code templated on M
 #define RNG1D(r) rngNext1DT<(M & FEAT_QMC) != 0>(r)
 
@@ -1242,7 +1243,7 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         info.u = hit.y; info.v = hit.z;
         info.bsdf = o.bsdf;
         info.backSide = dot(ray.d, info.Ng) >= 0.0f;
-    } else if ((M & FEAT_SOLIDS) && kind == TGHIP_REC_CYLINDER) {   /* Cylinder.cpp:122-132 */
+    } else if ((M & FEAT_CYLINDER) && kind == TGHIP_REC_CYLINDER) {   /* Cylinder.cpp:122-132 */
         cylinderSurface(o, info.p, hit.z, info.Ng, info.u, info.v);
         info.Ns = info.Ng;
         info.bsdf = o.bsdf;
@@ -1312,7 +1313,7 @@ PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, Li
         cubeSurface(o, ray.o + ray.d*lh.t, lh.n, lh.u, lh.v);
         return true;
     }
-    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::intersect + intersectionInfo (only in the variants whose chooseLight handles "unknown" weights) */
+    if ((M & FEAT_CYLINDER) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::intersect + intersectionInfo */
         float cap;
         if (!cylinderTest(&o, ray, ray.tmax, lh.t, lh.backSide, cap)) return false;
         cylinderSurface(o, ray.o + ray.d*lh.t, cap, lh.n, lh.u, lh.v);
@@ -1362,7 +1363,7 @@ PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p, const 
         f3 hp = p + w*lh.t;
         return lengthSq(p - hp)/(-dot(w, lh.n)*o.area);
     }
-    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::directPdf (Cylinder.cpp:246-250) */
+    if ((M & FEAT_CYLINDER) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::directPdf (Cylinder.cpp:246-250) */
         f3 hp = p + w*lh.t;
         return lengthSq(p - hp)/(-dot(w, lh.n)*o.area);
     }
@@ -1414,7 +1415,7 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         pdf = rSq/(cosTheta*o.area);
         return true;
     }
-    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::sampleDirect + samplePosition (Cylinder.cpp:149-170, 181-196) */
+    if ((M & FEAT_CYLINDER) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::sampleDirect + samplePosition (Cylinder.cpp:149-170, 181-196) */
         const float radius = o.scale[0], halfHeight = o.scale[1];
         f3 ng, q;
         if (o.scale[2] != 0.0f && rngNextBoolean(rng, PT_TWO_PI*sqr(radius)*o.inv_area)) {
@@ -1559,7 +1560,9 @@ template<uint32_t M>
 PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
 {
     const TgHipObject &o = s.objects[objIdx];
-    if ((M & FEAT_MESHLIGHT) && (o.type == TGHIP_OBJ_MESH || o.type == TGHIP_OBJ_CYLINDER))   /* TriangleMesh.cpp:514-517, Cylinder.cpp:280-284: "unknown" */
+    if ((M & FEAT_MESHLIGHT) && o.type == TGHIP_OBJ_MESH)      /* TriangleMesh.cpp:514-517: "unknown" */
+        return -1.0f;
+    if ((M & FEAT_CYLINDER) && o.type == TGHIP_OBJ_CYLINDER)   /* Cylinder.cpp:280-284: "unknown" too (the FEAT_CYLINDER variant has FEAT_MESHLIGHT's chooseLight) */
         return -1.0f;
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_CUBE) {       /* Cube.cpp:326-330 */
         f3 lp = mat3TMul(o.rot, p - ld3(o.pos));

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, Pass
 }
 
 // INST: the scene has instance records (two-level traversal; the instance of a hit goes to the spare word A_EMI.w)
-template<bool COUNT, bool FLAT, bool INST = false>
+// INST: 0 = single-level scene, 1 = instance records + every record kind, 2 = instance records in a scene of triangles and quads only
+template<bool COUNT, bool FLAT, int INST = 0>
 __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsStack[];
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
             float4 hit;
             if (INST) {
                 int hitInst;
-                hit = traverseClosestInst<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst);
+                hit = traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst);
                 slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
             } else {
                 hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
 }
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
-template<bool COUNT, bool FLAT, bool INST = false>
+template<bool COUNT, bool FLAT, int INST = 0>
 __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 *rays, float4 *hits, uint32_t n, BlockStats *stats)
 {
     extern __shared__ int ldsStack[];
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
         RayD ray;
         ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
         int hitInst;      // TgHipHit reports the record that was hit, not the instance it was reached through
-        hits[i] = INST ? traverseClosestInst<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
+        hits[i] = INST ? traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
                        : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
     }
     if (COUNT) {
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
 // record kinds a shading variant's fused traversal has to test: the lean variant's scenes hold quads and cubes only
 constexpr uint32_t shadeKinds(uint32_t M)
 {
-    return (M & FEAT_SOLIDS) ? KINDS_ALL
+    return (M & FEAT_SOLIDS) ? ((M & FEAT_CYLINDER) ? KINDS_ALL : (KINDS_ALL & ~KIND_BIT(TGHIP_REC_CYLINDER)))
                              : (KIND_BIT(TGHIP_REC_QUAD) | KIND_BIT(TGHIP_REC_CUBE) | ((M & FEAT_TRIANGLES) ? KIND_BIT(TGHIP_REC_TRIANGLE) : 0u));
 }
 // TGHIP_PASS_AUX: output values of a sample that leaves the loop of traceSample without having recorded any (PathTracer.cpp:133-140).
@@ -1030,7 +1031,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
 // a closest-hit query up to the light; unoccluded iff nothing is hit or the closest hit is the
 // light itself (endCap); surfaces with a forward lobe attenuate and the ray continues (FORWARD variant only:
 // scenes without a forward-lobe BSDF run the lean variant).
-template<bool COUNT, bool FORWARD, bool FLAT, bool INST = false>
+template<bool COUNT, bool FORWARD, bool FLAT, int INST = 0>
 __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsStack[];
@@ -1074,7 +1075,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 if (!FORWARD) {
                     // no surface of this scene lets light through: any occluder ends the query
                     rays++;
-                    if ((INST ? traverseOccludedInst<COUNT>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims)
+                    if ((INST ? traverseOccludedInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims)
                               : traverseOccluded<COUNT, FLAT>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims))
                         || bounce < s.settings.min_bounces)
                         transmittance = splat3(0.0f);
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 if (meshLight) { ray.tmax = PT_INF; remaining = PT_INF; }   // sd.w carries the expected distance / the bsdf pdf
                 for (;;) {
                     int hitInst = -1;
-                    float4 hit = INST ? traverseClosestInst<COUNT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
+                    float4 hit = INST ? traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
                                       : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
                     rays++;
                     int ri = __float_as_int(hit.w);
@@ -1543,6 +1544,7 @@ struct tghip_ctx {
     TgHipAuxPixel *dAux = nullptr;        // auxiliary output buffers (allocated by the first TGHIP_PASS_AUX pass)
     bool auxPass = false;                 // the pass being rendered keeps them: BSDF_MASK_ALL shading, no fused / dynamic-fetch shadow kernels
     int thrShadeAll = 256;                // workgroup size of k_shade<BSDF_MASK_ALL> (media scenes, TGHIP_PASS_AUX passes)
+    bool haveCylinder = false;            // cylinder primitives: BSDF_MASK_ALL shading (the only FEAT_CYLINDER variant), never fused
     bool haveMedia = false;               // participating media: BSDF_MASK_ALL shading (the only FEAT_MEDIA variant), closest-hit shadow walk, never fused
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
@@ -1803,14 +1805,15 @@ static void chooseThreads(tghip_ctx *ctx)
     const bool inst = ctx->haveInstances;
     const bool dyn = ctx->dynamicFetch && !inst;               // the dynamic-fetch kernels are single-level
     ctx->thrClosest = flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
-                    : inst ? pickThreads(ctx, k_trace_closest<false, false, true>, 512, 1)
+                    : inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest<false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_closest<false, false, 2>, 512, 1))
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
     if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
         ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_dyn<false, true>, 256, 2) : pickThreads(ctx, k_trace_shadow_dyn<false, false>, 256, 2);   // measured: 192 / 256 / 320 / 384 threads = 525 / 462 / 633 / 619 us per launch
     else if (inst)
-        ctx->thrShadow = (ctx->haveForward || ctx->haveMeshLight) ? pickThreads(ctx, k_trace_shadow<false, true, false, true>, 512, 1)
-                                                                   : pickThreads(ctx, k_trace_shadow<false, false, false, true>, 512, 1);
+        ctx->thrShadow = (ctx->haveForward || ctx->haveMeshLight)
+                       ? (ctx->haveSolids ? pickThreads(ctx, k_trace_shadow<false, true, false, 1>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, true, false, 2>, 512, 1))
+                       : (ctx->haveSolids ? pickThreads(ctx, k_trace_shadow<false, false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, false, false, 2>, 512, 1));
     else if (ctx->haveForward || ctx->haveMeshLight)
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, true, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, true, false>, 512, 1);
     else
@@ -1985,6 +1988,9 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     ctx->haveMeshLight = false;
     ctx->haveInstances = sd->num_instances > 0;
     ctx->haveMedia = sd->num_media > 0;
+    ctx->haveCylinder = false;
+    for (uint32_t i = 0; i < sd->num_objects; ++i)
+        if (sd->objects[i].type == TGHIP_OBJ_CYLINDER) ctx->haveCylinder = true;
     if (ctx->haveMedia) {
         if (!sd->media || sd->num_media > PT_MAX_MEDIA) { ctx->error = "more than 126 media are not supported"; return TGHIP_E_UNSUPPORTED; }
         if (sd->num_objects >= (1u << 16)) { ctx->error = "media scenes support at most 65535 primitives"; return TGHIP_E_UNSUPPORTED; }
@@ -2003,8 +2009,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     ctx->thinlens = sd->camera.type == TGHIP_CAMERA_THINLENS;
     if (sd->camera.type != TGHIP_CAMERA_PINHOLE && sd->camera.type != TGHIP_CAMERA_THINLENS) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
     for (uint32_t i = 0; i < sd->num_lights; ++i)
-        // (cylinder emitters answer "unknown" to approximateRadiance like meshes do: same shading variants)
-        if (sd->objects[sd->lights[i]].type == TGHIP_OBJ_MESH || sd->objects[sd->lights[i]].type == TGHIP_OBJ_CYLINDER) ctx->haveMeshLight = true;
+        if (sd->objects[sd->lights[i]].type == TGHIP_OBJ_MESH) ctx->haveMeshLight = true;
     // CDF guide tables for the samplable bitmaps (pt_scene.h: upperBoundGuided)
     {
         std::vector<uint16_t> guide;
@@ -2158,8 +2163,10 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
     const bool flat = isFlat(ctx);
     const bool closestWalk = ctx->haveForward || ctx->haveMeshLight;   // shadow rays are closest-hit walks, not any-hit queries
     if (ctx->haveInstances) {
-        if (closestWalk) hipLaunchKernelGGL((k_trace_shadow<COUNT, true, false, true>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
-        else             hipLaunchKernelGGL((k_trace_shadow<COUNT, false, false, true>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag);
+#define SHADOW_INST(FWD, I) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, false, I>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
+        if (closestWalk) { if (ctx->haveSolids) SHADOW_INST(true, 1); else SHADOW_INST(true, 2); }
+        else             { if (ctx->haveSolids) SHADOW_INST(false, 1); else SHADOW_INST(false, 2); }
+#undef SHADOW_INST
         return false;
     }
     if (!flat && !closestWalk && ctx->dynamicFetch && !ctx->auxPass) {   // (the dynamic-fetch kernel does not report transmittances)
@@ -2188,7 +2195,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = isFlat(ctx);
-    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->auxPass;
+    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->auxPass && !ctx->haveCylinder;
     const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
@@ -2261,8 +2268,10 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
                 else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
             } else if (ctx->haveInstances) {
-                if (count) hipLaunchKernelGGL((k_trace_closest<true, false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
-                else       hipLaunchKernelGGL((k_trace_closest<false, false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
+#define CLOSEST_INST(C, I) hipLaunchKernelGGL((k_trace_closest<C, false, I>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st)
+                if (ctx->haveSolids) { if (count) CLOSEST_INST(true, 1); else CLOSEST_INST(false, 1); }
+                else                 { if (count) CLOSEST_INST(true, 2); else CLOSEST_INST(false, 2); }
+#undef CLOSEST_INST
             } else {
                 if (ctx->dynamicFetch) {
                     const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
@@ -2276,14 +2285,14 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            if (ctx->haveMedia || ctx->auxPass) {                  // the one variant with FEAT_MEDIA / FEAT_AUX, for both classes
+            if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) {   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER, for both classes
                 launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 0);
                 if (ctx->haveComplex) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 1);
             }
             else if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling / instance transforms
             else if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
             else                     launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
-            if (ctx->haveComplex && !ctx->haveMedia && !ctx->auxPass) {
+            if (ctx->haveComplex && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder) {
                 if (ctx->haveMeshLight || ctx->haveInstances)   launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
@@ -2484,7 +2493,7 @@ int tghip_wait(tghip_ctx *ctx)
         // the run-to-completion kernel (runBatch) gives every thread its own slots for the whole launch: one slot per
         // thread keeps the whole path state (112 B x 0.5 M slots) inside the Infinity Cache -- measured +5 % over four
         const bool flat = isFlat(ctx);
-        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->haveComplex && ctx->loopOpt && !ctx->auxPass;
+        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->haveComplex && ctx->loopOpt && !ctx->auxPass && !ctx->haveCylinder;
         if (loop && !ctx->maxSlotsSet)
             wantSlots = std::min<uint64_t>(wantSlots, uint64_t(launchGrid(ctx))*uint64_t(ctx->thrShadeSimple));
     }
@@ -2666,8 +2675,8 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
         const bool flat = isFlat(ctx);
 #define RAYS_LAUNCH(C, F) hipLaunchKernelGGL((k_trace_rays<C, F>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats)
         if (ctx->haveInstances) {
-            if (cnt) hipLaunchKernelGGL((k_trace_rays<true, false, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
-            else     hipLaunchKernelGGL((k_trace_rays<false, false, true>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
+            if (cnt) hipLaunchKernelGGL((k_trace_rays<true, false, 1>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
+            else     hipLaunchKernelGGL((k_trace_rays<false, false, 1>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
         }
         else if (cnt) { if (flat) RAYS_LAUNCH(true, true); else RAYS_LAUNCH(true, false); }
         else          { if (flat) RAYS_LAUNCH(false, true); else RAYS_LAUNCH(false, false); }
