@@ -11,7 +11,9 @@ OBJDIR   := build/obj
 HOSTSRC  := $(wildcard tungsten_amd/csrc/host/*.cpp)
 HOSTLIB  := $(filter-out tungsten_amd/csrc/host/main.cpp,$(HOSTSRC))
 HOSTOBJ  := $(patsubst tungsten_amd/csrc/host/%.cpp,$(OBJDIR)/host_%.o,$(HOSTLIB))
-HIPSRC   := tungsten_amd/csrc/hip/tungsten_hip.hip
+# the shim + one translation unit per family of k_shade instantiations (they compile in parallel under make -j)
+HIPSRC   := $(wildcard tungsten_amd/csrc/hip/*.hip)
+HIPOBJ   := $(patsubst tungsten_amd/csrc/hip/%.hip,$(OBJDIR)/%.o,$(HIPSRC))
 HIPHDR   := $(wildcard tungsten_amd/csrc/hip/*.h) include/tungsten_hip.h
 # -ffp-contract=off: no FMA contraction, so device arithmetic rounds like the CPU reference/oracle
 # (DESIGN.md "Numerics"); TG_FAST=1 allows contraction.
@@ -25,11 +27,11 @@ $(OBJDIR)/host_%.o: tungsten_amd/csrc/host/%.cpp $(wildcard tungsten_amd/csrc/ho
 	@mkdir -p $(OBJDIR)
 	g++ $(HOSTFLAGS) -c $< -o $@
 
-$(OBJDIR)/tungsten_hip.o: $(HIPSRC) $(HIPHDR)
+$(OBJDIR)/%.o: tungsten_amd/csrc/hip/%.hip $(HIPHDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/libtungsten_hip.so: $(HOSTOBJ) $(OBJDIR)/tungsten_hip.o
+$(LIBDIR)/libtungsten_hip.so: $(HOSTOBJ) $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lpthread
 

@@ -1,0 +1,8 @@
+// Explicit instantiations of k_shade variants (see pt_wavefront.h); the extern "C" shim in tungsten_hip.hip launches them.
+#include "pt_wavefront.h"
+
+template __global__ void k_shade<MASK_FULL, 2, 0>(DeviceScene, PathState, PassParams, int);
+template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
+template __global__ void k_shade<MASK_FULL, 2, 2>(DeviceScene, PathState, PassParams, int);
+template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);
+template __global__ void k_shade<BSDF_MASK_ALL, 2, 0>(DeviceScene, PathState, PassParams, int);

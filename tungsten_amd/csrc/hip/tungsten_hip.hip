@@ -1,1479 +1,39 @@
 // path_tracer_hip: kernels + the extern "C" shim declared in include/tungsten_hip.h.
 // gfx950 (MI355X) only.  See pt_kernels.h for the execution model and DESIGN.md for the layout.
-#include "pt_kernels.h"
+#define PT_WAVEFRONT_MAIN
+#include "pt_wavefront.h"
 
-#include <hip/hip_runtime.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <string>
-#include <type_traits>
-#include <vector>
-
-// =============================================================================================
-// Kernels
-// =============================================================================================
-
-// Section timers of the shading kernel (development aid; compiled in only with -DPT_PROFILE): s_memtime per
-// wave at section boundaries, summed per workgroup into BlockStats::prof and printed by tghip_destroy.
-#ifdef PT_PROFILE
-#define PROF_DECL unsigned long long profT = clock64(), profAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PROF(n) do { unsigned long long t_ = clock64(); profAcc[n] += t_ - profT; profT = t_; } while (0)
-#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&(stats).prof[k_], profAcc[k_]); } while (0)
-#else
-#define PROF_DECL
-#define PROF(n)
-#define PROF_FLUSH(stats)
-#endif
-
-// BSDF type sets of the shading-kernel variants (pt_scene.h BsdfOps<D, M>)
-#define TYPES_SIMPLE (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_NULL) | BSDF_BIT(TGHIP_BSDF_ERROR))
-#define MASK_SIMPLE  (TYPES_SIMPLE | FEAT_ALL)
-#define MASK_LEAN    TYPES_SIMPLE        /* analytic primitives, constant/checker textures, one area light (Cornell box) */
-#ifndef SIMPLE_WAVES
-#define SIMPLE_WAVES 3   /* measured: 4 waves/SIMD (128 VGPRs, spills) is 10 % slower on materialtest's k_shade */
-#endif
-#ifndef COAT_WAVES
-#define COAT_WAVES   2   /* measured: 3 waves/SIMD is neutral on materialtest (480 vs 476 us), +3 % on mesh1m's k_shade */
-#endif
-#ifndef LEAN_WAVES
-#define LEAN_WAVES   2   /* measured: 2 waves/SIMD without scratch beats 3 with 108 B of scratch (kernel is VALU-bound) */
-#endif
-#define MASK_COAT    (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR) | BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT) | \
-                      BSDF_BIT(TGHIP_BSDF_MIRROR) | BSDF_BIT(TGHIP_BSDF_CONDUCTOR))
-#define MASK_GLASS   (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC) | \
-                      BSDF_BIT(TGHIP_BSDF_MIRROR))
-
-// Finalises the finished sample of every lane with `finished` set (OutputBuffer::addSample semantics,
-// cameras/OutputBuffer.hpp:104-107: NaN/Inf samples are dropped without counting; PathTracer.cpp:119-122,
-// 130-131: NaN radiance turns the sample black), moves the slot to its next sample or -- when its work item is
-// exhausted -- flushes the item's sum and takes the workgroup's next item (`cursor` = the workgroup's LDS item
-// cursor), and generates the next camera path in place.  `fresh` lanes own nothing yet (pass start).  Must be
-// called by all lanes of the wave.  Returns true for lanes that now hold a new active path.
-// SobolPathSampler::startPath (sampling/SobolPathSampler.hpp:47-52) for a path that starts or resumes at
-// dimension `dim`: the tile's sampler seed (PathTraceIntegrator.cpp:27-42) scrambled by the pixel.
-PT_DEV void rngStartSobol(Rng &rng, const DeviceScene &s, const PassParams &pp, uint32_t px, uint32_t py, uint32_t pixel,
-                          uint32_t sample, uint32_t dim)
-{
-    uint32_t tile = (px >> 4) + (py >> 4)*pp.tiles_x;
-    rng.sobol = s.sobol;
-    rng.scramble = at32(pp.tile_seeds, tile) ^ hash32(pixel);
-    rng.index = sample;
-    rng.dim = dim;
-}
-
-// EXT: the pass may carry TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS state (checked at run time through pp.flags /
-// pp.rec_count); false compiles those paths out (the specialised shading variants, DESIGN.md "Kernels").
-template<bool CONVERGED = true, bool EXT = true>
-PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams &pp, bool finished, bool fresh,
-                     uint32_t slot, f3 em, bool black, uint32_t *cursor, bool aborted, uint32_t &finishedCount)
-{
-    uint2 samp = make_uint2(0u, 0u);
-    float4 acc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
-    uint32_t pixel = 0, item = 0;
-    uint32_t lumBase = 0;                  // EXT: index of sample `s` of this work item in pp.lum is lumBase + s
-    const bool records = EXT && pp.rec_count != nullptr;
-    bool want = fresh;
-    if (finished) {
-        uint4 sm = slotU4(st, A_SAMP, slot), misc = slotU4(st, A_MISC, slot);
-        samp = make_uint2(sm.x, sm.y);
-        lumBase = EXT ? sm.w : 0u;
-        acc = slotF4(st, A_ACC, slot);
-        pixel = misc.z;
-        item = misc.w;
-        if (black || isnan(sum3(em)))
-            em = splat3(0.0f);
-        if (records)   // SampleRecord::addSample(c) input (SampleRecord.hpp:55-58; Vec3f::luminance, math/Vec.hpp:195-199)
-            at32(pp.lum, lumBase + samp.x) = em.x*0.2126f + em.y*0.7152f + em.z*0.0722f;
-        if (!(isinf(em.x) || isinf(em.y) || isinf(em.z))) {
-            acc.x += em.x; acc.y += em.y; acc.z += em.z;
-            acc.w = __uint_as_float(__float_as_uint(acc.w) + 1u);
-        }
-        if constexpr (EXT) {
-            if (pp.flags & TGHIP_PASS_AUX) {
-                // the addSample calls of traceSample (PathTracer.cpp:78-96, 133-140), then the colour (PathTraceIntegrator.cpp:152)
-                TgHipAuxPixel &px = pp.aux[pixel];
-                float4 a0 = slotF4(st, A_AUX0, slot), a1 = slotF4(st, A_AUX1, slot);
-                auxAdd3(px, TGHIP_AUX_DEPTH, 3, 1, a0.w, 0.0f, 0.0f);
-                auxAdd3(px, TGHIP_AUX_NORMAL, 4, 3, a0.x, a0.y, a0.z);
-                auxAdd3(px, TGHIP_AUX_ALBEDO, 7, 3, a1.x, a1.y, a1.z);
-                auxAdd3(px, TGHIP_AUX_VISIBILITY, 10, 1, a1.w, 0.0f, 0.0f);
-                auxAdd3(px, TGHIP_AUX_COLOR, 0, 3, em.x, em.y, em.z);
-            }
-        }
-        finishedCount++;
-        samp.x++;
-        if (samp.x >= samp.y || aborted) {
-            at32(st.partial, item) = acc;
-            want = true;
-        }
-    }
-    bool dead = false;
-    for (;;) {
-        uint32_t base = 0, rank = 0;
-        if (CONVERGED) {
-            // one LDS atomic per wave
-            unsigned long long mask = __ballot(want);
-            if (mask == 0ull)
-                break;
-            uint32_t lane = laneId();
-            int leader = __ffsll((long long)mask) - 1;
-            if ((int)lane == leader)
-                base = atomicAdd(cursor, (uint32_t)__popcll(mask));
-            base = __shfl(base, leader);
-            rank = __popcll(mask & ((1ull << lane) - 1ull));
-        } else {
-            // called from divergent code (dynamic-fetch traversal): one LDS atomic per lane
-            if (!want)
-                break;
-            base = atomicAdd(cursor, 1u);
-        }
-        if (want) {
-            // workgroup-local index L -> item: groups of PT_ITEM_GROUP consecutive items are dealt round-robin
-            uint32_t L = base + rank;
-            uint64_t w64 = ((uint64_t)(L/PT_ITEM_GROUP)*gridDim.x + blockIdx.x)*PT_ITEM_GROUP + (L % PT_ITEM_GROUP);
-            if (w64 >= pp.total_items || aborted) {
-                want = false;
-                dead = true;
-            } else {
-                uint32_t w = (uint32_t)w64;
-                uint32_t c, j, x, y;
-                bool inImage;
-                uint32_t recOfItem = 0;
-                if (records) {
-                    // gap-free enumeration of a record pass (PassParams): chunk from the hint table, then the sorted pixel list
-                    uint32_t wAbs = w + pp.item_base;
-                    c = at32(pp.rec_hint, wAbs >> 6);
-                    while (wAbs >= at32(pp.rec_chunk_start, c + 1u)) ++c;
-                    j = wAbs - at32(pp.rec_chunk_start, c);
-                    recOfItem = at32(pp.rec_sorted, j >> 4);
-                    x = (recOfItem % pp.variance_w)*4u + (j & 3u);
-                    y = (recOfItem/pp.variance_w)*4u + ((j >> 2) & 3u);
-                    inImage = x < pp.width && y < pp.height;   // records on the right / bottom edge reach past the image
-                } else {
-                    c = w/pp.pix_slots; j = w - c*pp.pix_slots;
-                    inImage = slotPixel(pp, j, x, y);
-                }
-                if (inImage) {
-                    uint32_t rel = pp.spp_begin + c*pp.chunk, relEnd = pp.spp_end, first = 0u;
-                    bool take = true;
-                    if (records) {
-                        // renderTile (PathTraceIntegrator.cpp:142-147): the pixel's record says which samples it traces
-                        uint32_t cnt = at32(pp.rec_count, recOfItem);
-                        first = at32(pp.rec_index, recOfItem);
-                        rel = c*pp.chunk;
-                        relEnd = cnt;
-                        take = rel < relEnd;                     // (always, by construction of the enumeration)
-                        lumBase = at32(pp.rec_lum, recOfItem) + (((y & 3u) << 2) | (x & 3u))*cnt - first;
-                    }
-                    if (take) {
-                        want = false;
-                        item = w;
-                        pixel = x + y*pp.width;
-                        samp.x = first + rel;
-                        samp.y = first + min(rel + pp.chunk, relEnd);
-                        acc = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
-                    }
-                }
-            }
-        }
-    }
-    bool push = false;
-    if (finished || fresh) {
-        if (dead) {
-            slotF4(st, A_THR, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
-        } else {
-            Rng rng = rngStart(pp.seed, pixel, samp.x);          // PathSampleGenerator::startPath
-            const uint32_t px = pixel % pp.width, py = pixel/pp.width;
-            if (EXT && (pp.flags & TGHIP_PASS_SOBOL))
-                rngStartSobol(rng, s, pp, px, py, pixel, samp.x, 0u);
-            CameraRef cam = *asConst(s.camera);
-            // thin-lens scenes run the EXT variants (the shim sets PT_PASS_THINLENS): the pinhole-only variants stay as lean as they were
-            const bool lens = EXT && (pp.flags & PT_PASS_THINLENS) != 0u;
-            float l0 = 0.0f, l1 = 0.0f;
-            if (lens) { l0 = rngNext1DT<EXT>(rng); l1 = rngNext1DT<EXT>(rng); }   // the lens point is sampled first
-            float xi0 = rngNext1DT<EXT>(rng), xi1 = rngNext1DT<EXT>(rng);
-            f3 o, d;
-            const bool cameraOk = cameraRay<EXT>(cam, lens, px, py, l0, l1, xi0, xi1, o, d);
-            slotF4(st, A_RAY_O, slot) = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
-            slotF4(st, A_RAY_D, slot) = mk4(d, cameraOk ? PT_INF : -1.0f);   // a failed camera sample: the ray can hit nothing ...
-            slotU4(st, A_MISC, slot) = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, item);
-            slotF4(st, A_EMI, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            // ... and carries no throughput, so the escaped path adds nothing: a black sample (PathTracer.cpp:27-28)
-            const float t0 = cameraOk ? 1.0f : 0.0f;
-            uint32_t f0 = FLAG_MAKE(0, 1, ST_ACTIVE);                       // wasSpecular starts true
-            if (EXT && (pp.flags & PT_PASS_MEDIA))
-                f0 |= FLAG_MEDIUM_BITS(cam.medium, 0);                      // _scene->cam().medium(), state.reset() (PathTracer.cpp:38-41)
-            slotF4(st, A_THR, slot) = make_float4(t0, t0, t0, __uint_as_float(f0));
-            if (EXT && (pp.flags & TGHIP_PASS_AUX)) {                          // nothing recorded yet, hitDistance = 0
-                const float nan = __uint_as_float(0x7FC00000u);
-                slotF4(st, A_AUX0, slot) = make_float4(nan, nan, nan, 0.0f);
-                slotF4(st, A_AUX1, slot) = make_float4(nan, nan, nan, nan);
-            }
-            slotU4(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, EXT ? rng.dim : 0u, lumBase);   // .z: next Sobol' dimension
-            slotF4(st, A_ACC, slot) = acc;
-            push = true;
-        }
-    }
-    return push;
-}
-
-// Pass start: every slot takes its first work item.
-__global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, PassParams pp)
-{
-    __shared__ BlockLds L;
-    BlockCtl &ctl = st.ctl[blockIdx.x];
-    if (threadIdx.x == 0) ctl.item_cursor = 0;
-    __syncthreads();
-    queuesBegin(L, st, ctl, -1, 0u, nullptr);
-    const uint32_t first = blockIdx.x*st.slots_per_block;
-    uint32_t finishedCount = 0;
-    for (uint32_t base = 0; base < st.slots_per_block; base += blockDim.x) {
-        uint32_t local = base + threadIdx.x;
-        uint32_t slot = first + local;
-        bool fresh = local < st.slots_per_block && slot < st.num_slots;
-        bool push = nextPath(s, st, pp, false, fresh, slot, splat3(0.0f), false, &L.cursor, false, finishedCount);
-        queuePush(push, local, L, Q_EXTP);
-    }
-    bool any = queuesEnd(L, st, -1, (1u << Q_COUNT) - 1u);   // every bitmap is (re)initialised here
-    if (threadIdx.x == 0) {
-        ctl.item_cursor = L.cursor;
-        if (any) st.live[0] = 1u;
-    }
-}
-
-// INST: the scene has instance records (two-level traversal; the instance of a hit goes to the spare word A_EMI.w)
-// INST: 0 = single-level scene, 1 = instance records + every record kind, 2 = instance records in a scene of triangles and quads only
-template<bool COUNT, bool FLAT, int INST = 0>
-__global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState st)
-{
-    extern __shared__ int ldsStack[];
-    __shared__ BlockLds L;
-    BlockCtl &ctl = st.ctl[blockIdx.x];
-    // the dynamic LDS region first holds the expanded queue, then (after orderPreload's barrier) the node stacks
-    queuesBegin(L, st, ctl, Q_EXTP, 0u, reinterpret_cast<unsigned short *>(ldsStack), Q_EXT);   // the shading queues are empty here
-    const uint32_t n = L.n;
-    const OrderRegs ord = orderPreload(reinterpret_cast<unsigned short *>(ldsStack), n);
-    const uint32_t first = blockIdx.x*st.slots_per_block;
-    uint32_t nodes = 0, prims = 0, rays = 0;
-    for (uint32_t base = 0, k = 0; base < n; base += blockDim.x, ++k) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t slot = 0, local = 0;
-        int cls = -1;
-        if (i < n) {
-            local = orderGet(ord, k);
-            slot = first + local;
-            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
-            RayD ray;
-            ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-            float4 hit;
-            if (INST) {
-                int hitInst;
-                hit = traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst);
-                slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
-            } else {
-                hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
-            }
-            slotF4(st, A_HIT, slot) = hit;
-            int ri = __float_as_int(hit.w);
-            cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
-            rays++;
-        }
-        // sort by material: one shading queue per class
-        queuePush(cls == 0, local, L, Q_SHADE0);
-        queuePush(cls == 1, local, L, Q_SHADE1);
-    }
-    waveAddStat(&L.closest_rays, rays);
-    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1), Q_EXTP);
-    if (threadIdx.x == 0) {
-        ctl.closest_rays += L.closest_rays;
-        if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
-    }
-}
-
-// BVH closest hit with dynamic ray fetch ("persistent threads" inside the workgroup): a lane whose ray has
-// finished does not idle until the slowest lane of its wave is done -- once fewer than 3/4 of the wave's lanes
-// are busy, the idle lanes take the next rays of the workgroup's queue (one wave-aggregated LDS atomic) and join
-// the traversal loop.  One loop iteration advances every busy lane by one BVH node or one leaf.
-// Dynamic LDS: [expanded queue, 2 B per slot][node stacks, bvhDepth ints per thread].
-// SOLIDS: the scene has cube / sphere / disk records somewhere; without them only triangle and quad tests are compiled in
-template<bool COUNT, bool SOLIDS = true>
-__global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathState st)
-{
-    extern __shared__ int ldsDyn[];
-    __shared__ BlockLds L;
-    __shared__ uint32_t fetchNext;
-    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
-    int *stack = ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2 + threadIdx.x;
-    const int stride = (int)blockDim.x;
-    BlockCtl &ctl = st.ctl[blockIdx.x];
-    if (threadIdx.x == 0) fetchNext = 0;
-    queuesBegin(L, st, ctl, Q_EXTP, 0u, order, Q_EXT);
-    const uint32_t n = L.n;
-    const uint32_t first = blockIdx.x*st.slots_per_block;
-    uint32_t nodes = 0, prims = 0, rays = 0;
-
-    bool busy = false;
-    uint32_t slot = 0, local = 0;
-    RayD ray; ray.o = splat3(0.0f); ray.d = splat3(1.0f); ray.tmin = 0.0f; ray.tmax = 0.0f;
-    f3 invD = splat3(1.0f);
-    float tmax = 0.0f;
-    float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-    int cur = 0, sp = 0;
-    bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
-    for (;;) {
-        unsigned long long busyMask = __ballot(busy);
-        if (!exhausted && __popcll(busyMask) <= 48) {
-            // refill the idle lanes
-            unsigned long long want = ~busyMask;
-            uint32_t lane = laneId();
-            uint32_t base = 0;
-            if (lane == 0)
-                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
-            base = __shfl(base, 0);
-            if (!busy) {
-                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
-                if (i < n) {
-                    local = order[i];
-                    slot = first + local;
-                    float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
-                    ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-                    invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
-                    tmax = ray.tmax;
-                    hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
-                    cur = 0; sp = 0;
-                    busy = true;
-                    rays++;
-                }
-            }
-            if (base + (uint32_t)__popcll(want) >= n)
-                exhausted = true;
-            busyMask = __ballot(busy);
-        }
-        if (busyMask == 0ull)
-            break;
-        // "while-while": lanes take node steps until they reach a leaf, then wait; the (long) leaf code runs only when
-        // enough lanes have one to process -- otherwise every iteration would pay for both the node and the leaf path
-        // with a handful of active lanes each.
-        bool pop = false;
-        if (busy && cur >= 0) {
-            const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
-            float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-            if (COUNT) nodes++;
-            float e0, e1;
-            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, tmax, e0);
-            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, tmax, e1);
-            int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            if (h0 && h1) {
-                if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
-                else { stack[sp*stride] = c1; cur = c0; }
-                sp++;
-            } else if (h0) { cur = c0; }
-            else if (h1) { cur = c1; }
-            else pop = true;
-        }
-        {
-            unsigned long long atLeaf = __ballot(busy && cur < 0 && !pop);
-            unsigned long long atNode = __ballot(busy && (cur >= 0 || pop));
-            // process leaves when a good part of the wave waits for it, or nobody has node work left
-            if (atLeaf != 0ull && ((uint32_t)__popcll(atLeaf) >= st.leaf_batch || atNode == 0ull)) {
-                if (busy && cur < 0 && !pop) {
-                    uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
-                    for (uint32_t r = firstRec; r < firstRec + count; ++r) {
-                        if (COUNT) prims++;
-                        testRecord<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, r, ray, tmax, hit);
-                    }
-                    pop = true;
-                }
-            }
-        }
-        if (busy && pop) {
-            if (sp == 0) {
-                // finished: publish the hit and bin the path by shading class
-                slotF4(st, A_HIT, slot) = hit;
-                int ri = __float_as_int(hit.w);
-                int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
-                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
-                busy = false;
-            } else {
-                sp--;
-                cur = stack[sp*stride];
-            }
-        }
-    }
-    waveAddStat(&L.closest_rays, rays);
-    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1), Q_EXTP);
-    if (threadIdx.x == 0) {
-        ctl.closest_rays += L.closest_rays;
-        if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
-    }
-}
-
-// stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
-template<bool COUNT, bool FLAT, int INST = 0>
-__global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 *rays, float4 *hits, uint32_t n, BlockStats *stats)
-{
-    extern __shared__ int ldsStack[];
-    __shared__ uint32_t ldsNodes, ldsPrims;
-    if (threadIdx.x == 0) { ldsNodes = 0; ldsPrims = 0; }
-    __syncthreads();
-    const uint32_t stride = gridDim.x*blockDim.x;
-    uint32_t nodes = 0, prims = 0;
-    for (uint32_t i = blockIdx.x*blockDim.x + threadIdx.x; i < n; i += stride) {
-        float4 ro = rays[i*2 + 0], rd = rays[i*2 + 1];
-        RayD ray;
-        ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-        int hitInst;      // TgHipHit reports the record that was hit, not the instance it was reached through
-        hits[i] = INST ? traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
-                       : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
-    }
-    if (COUNT) {
-        waveAddStat(&ldsNodes, nodes);
-        waveAddStat(&ldsPrims, prims);
-        __syncthreads();
-        if (threadIdx.x == 0) { stats[blockIdx.x].nodes_visited += ldsNodes; stats[blockIdx.x].prims_tested += ldsPrims; }
-    }
-}
-
-// PathTracer::traceSample's loop body for one vertex: TraceBase::handleSurface (TraceBase.cpp:516-568)
-// with estimateDirect split into "compute the unoccluded contribution here, test visibility in
-// k_trace_shadow", plus the loop epilogue (PathTracer.cpp:108-129).  M = BSDF types this variant handles.
-// W = waves per SIMD the register allocator must leave room for (occupancy vs spilling: 3 costs the
-// Lambert-only variant 12 B of scratch, the others stay at 2)
-// FUSE (flat-list scenes without forward-lobe BSDFs only -- the whole scene is a handful of records read through the
-// scalar cache, so a separate traversal launch would spend its time on path-state traffic):
-//   FUSE_TRACE   the kernel consumes the extension queues itself, intersects the ray inline, shades class-0 hits
-//                and forwards class-1 hits (hit record stored) to the class-1 shading queue;
-//   FUSE_SHADOW  the <= 2 shadow rays of a vertex are any-hit tested inline instead of being queued for
-//                k_trace_shadow, so the NEE term is added on the spot and no shadow record is written.
-//   FUSE_LOOP    (with both of the above, scenes without class-1 materials) the workgroup runs its slots to completion
-//                inside ONE launch: nothing it reads or writes is shared with another workgroup, so the wavefront
-//                iterations need no grid-wide synchronisation -- the queues simply stay in LDS between iterations.
-// record kinds a shading variant's fused traversal has to test: the lean variant's scenes hold quads and cubes only
-constexpr uint32_t shadeKinds(uint32_t M)
-{
-    return (M & FEAT_SOLIDS) ? ((M & FEAT_CYLINDER) ? KINDS_ALL : (KINDS_ALL & ~KIND_BIT(TGHIP_REC_CYLINDER)))
-                             : (KIND_BIT(TGHIP_REC_QUAD) | KIND_BIT(TGHIP_REC_CUBE) | ((M & FEAT_TRIANGLES) ? KIND_BIT(TGHIP_REC_TRIANGLE) : 0u));
-}
-// TGHIP_PASS_AUX: output values of a sample that leaves the loop of traceSample without having recorded any (PathTracer.cpp:133-140).
-// `asked`: handleInfiniteLights ran for direction `dir` (so info.primitive is the infinite light it found, if any).
-template<uint32_t M>
-PT_DEV void auxPostLoop(const DeviceScene &s, f3 dir, bool asked, int bounce, float4 &aux0, float4 &aux1)
-{
-    aux0 = mk4(-dir, bounce == 0 ? 0.0f : __uint_as_float(0x7FC00000u));
-    if (asked && (M & FEAT_INFINITE)) {
-        int objIdx = -1;
-        for (uint32_t li = 0; li < s.num_infinite_lights; ++li) {
-            const TgHipObject &c = s.objects[s.infinite_lights[li]];
-            if (c.type != TGHIP_OBJ_INFINITE_SPHERE_CAP || dot(dir, ld3(c.normal)) >= c.scale[0])
-                objIdx = s.infinite_lights[li];
-        }
-        if (objIdx >= 0) {                       // info.primitive->isInfinite(): + evalDirect
-            const TgHipObject &o = s.objects[objIdx];
-            float u = 0.0f, v = 0.0f, sinTheta;
-            if (o.type == TGHIP_OBJ_INFINITE_SPHERE) infDirectionToUV(o, dir, u, v, sinTheta);
-            f3 e = textureEval<M>(s, o.emission, u, v);
-            aux1.x = e.x; aux1.y = e.y; aux1.z = e.z;
-        }
-    }
-}
-
-#define FUSE_TRACE  1
-#define FUSE_SHADOW 2
-#define FUSE_LOOP   4
-template<uint32_t M, int W, int FUSE>
-__global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, PassParams pp, int cls)
-{
-    __shared__ BlockLds L;
-    __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
-    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
-    BlockCtl &ctl = st.ctl[blockIdx.x];
-    const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : cls == 0 ? Q_SHADE0 : Q_SHADE1;
-    const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : -1;
-    const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? (1u << Q_SHADE1) : 0u);
-    queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2);
-    const DeviceScene s = stageSceneTables(sg, ldsTables);
-    const uint32_t first = blockIdx.x*st.slots_per_block;
-    const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
-    const bool nee = s.settings.enable_light_sampling != 0;
-    uint32_t finishedCount = 0, fusedClosest = 0, fusedShadow = 0, fusedPrims = 0, fusedNodes = 0;
-    PROF_DECL;
-
-    // FUSE_LOOP runs without queues: a finished path is regenerated in place, so a slot stays busy until the workgroup's
-    // work items run out.  Thread t owns slots t, t + blockDim, ... for the whole launch (consecutive lanes = consecutive
-    // slots: every state access is a full cache line), `idle` has one bit per owned slot that has nothing left to do,
-    // and every wave leaves the loop on its own -- no barrier, no bitmap traffic between the wavefront iterations.
-    constexpr bool DIRECT = (FUSE & FUSE_LOOP) != 0;
-    uint32_t idle = 0;
-    if (DIRECT) {
-        // queuesBegin expanded (and thereby cleared) the extension queues into order[0, L.n): turn that list back into
-        // a bitmap of busy slots (in the unused Q_SHADE0 words) each thread can look its own slots up in
-        for (uint32_t i = threadIdx.x; i < L.n; i += blockDim.x)
-            queuePush(true, order[i], L, Q_SHADE0);
-        __syncthreads();
-        for (uint32_t k = 0, local = threadIdx.x; k < 32u; ++k, local += blockDim.x) {
-            bool queued = local < st.slots_per_block && ((L.bm[Q_SHADE0][local >> 5] >> (local & 31u)) & 1u);
-            idle |= queued ? 0u : (1u << k);
-        }
-    }
-
-  for (;;) {                                     // one wavefront iteration per turn (a single turn unless FUSE_LOOP)
-    const uint32_t n = DIRECT ? st.slots_per_block : L.n;
-    const bool aborted = __hip_atomic_load(&st.live[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-    for (uint32_t base = 0, turn = 0; base < n; base += blockDim.x, ++turn) {
-        uint32_t i = base + threadIdx.x;
-        PROF(0);
-        bool hasShadow = false, finished = false, survives = false, black = false, toComplex = false;
-        uint32_t slot = 0, local = 0;
-        f3 em = splat3(0.0f);
-        if (DIRECT ? !((idle >> turn) & 1u) : i < n) {
-            f3 pendingOut = splat3(0.0f);
-            local = DIRECT ? i : order[i];
-            slot = first + local;
-            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot), hit, thr4 = slotF4(st, A_THR, slot);
-            if (FUSE & FUSE_TRACE) {
-                // TraceableScene::intersect inline: the flat record list, walked uniformly by the wave
-                RayD r0;
-                r0.o = xyz(ro); r0.d = xyz(rd); r0.tmin = ro.w; r0.tmax = rd.w;
-                hit = traverseClosest<true, true, shadeKinds(M)>(sg, r0, nullptr, 0, fusedNodes, fusedPrims);
-                fusedClosest++;
-                int ri = __float_as_int(hit.w);
-                toComplex = ri >= 0 && at32(sg.rec_class, (uint32_t)ri) != 0;
-                if (toComplex)
-                    slotF4(st, A_HIT, slot) = hit;           // shaded by the class-1 launch that follows
-            } else {
-                hit = slotF4(st, A_HIT, slot);
-            }
-          if (!toComplex) {
-            float4 em4 = slotF4(st, A_EMI, slot);
-            em = xyz(em4);
-            const int hitInst = ((M & FEAT_INSTANCES) && s.num_instances) ? __float_as_int(em4.w) : -1;   // written by k_trace_closest<.., INST>
-            uint4 misc = slotU4(st, A_MISC, slot);
-            uint2 rs = make_uint2(misc.x, misc.y);
-            uint32_t pixel = misc.z;
-            Rng rng;
-            rng.state = ((uint64_t)rs.y << 32) | rs.x;
-            rng.inc = ((uint64_t)pixel << 1) | 1u;
-            rng.sobol = nullptr;
-            rng.scramble = rng.index = rng.dim = 0u;
-            if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL)) {
-                uint4 sm = slotU4(st, A_SAMP, slot);             // .x = sample index, .z = next dimension
-                rngStartSobol(rng, s, pp, pixel % pp.width, pixel/pp.width, pixel, sm.x, sm.z);
-            }
-            RayD ray;
-            ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
-            f3 throughput = xyz(thr4);
-            uint32_t flags = __float_as_uint(thr4.w);
-            int bounce = (int)FLAG_BOUNCE(flags);
-            bool wasSpecular = (flags & FLAG_SPECULAR) != 0;
-            uint32_t state = ST_ACTIVE;
-
-            // auxiliary output buffers (TGHIP_PASS_AUX; PathTracer.cpp:46-47, 78-96, 133-140)
-            const bool auxOn = (M & FEAT_AUX) && (pp.flags & TGHIP_PASS_AUX) != 0u;
-            bool recorded = auxOn && (flags & FLAG_AUX_RECORDED) != 0u;   // recordedOutputValues
-            bool auxStore = false;                           // aux0 / aux1 changed
-            int loopExit = 0;                                // the while loop was left: 1 = by `break` (bounce not advanced), 2 = bounce limit
-            float4 aux0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), aux1 = aux0;
-            if constexpr ((M & FEAT_AUX) != 0u) {
-                if (auxOn && !recorded) { aux0 = slotF4(st, A_AUX0, slot); aux1 = slotF4(st, A_AUX1, slot); }
-            }
-            // loop epilogue (PathTracer.cpp:108-126) for a path that goes on from `o` in direction `d`
-            auto continuePath = [&](f3 o, f3 d, float tmin) {
-                ray.o = o; ray.d = d; ray.tmin = tmin; ray.tmax = PT_INF;
-                if (max3(throughput) == 0.0f) {
-                    state = ST_TERMINATED;                   // the env term after `break` is throughput*L = 0
-                    if constexpr ((M & FEAT_AUX) != 0u) loopExit = 1;
-                } else {
-                    float roulettePdf = fmaxf(fabsf(throughput.x), fmaxf(fabsf(throughput.y), fabsf(throughput.z)));
-                    bool killed = false;
-                    if (bounce > 2 && roulettePdf < 0.1f) {
-                        if (rngNextBoolean(rng, roulettePdf))
-                            throughput = throughput/roulettePdf;
-                        else
-                            killed = true;
-                    }
-                    if (killed) {
-                        state = ST_TERMINATED;
-                    } else if (isnan(sum3(ray.d) + sum3(ray.o)) || isnan(sum3(throughput) + sum3(em))) {
-                        state = ST_TERMINATED_BLACK;
-                    } else {
-                        bounce++;
-                        state = bounce < maxBounces ? ST_ACTIVE : ST_TERMINATED;
-                        if constexpr ((M & FEAT_AUX) != 0u) { if (state != ST_ACTIVE) loopExit = 2; }
-                    }
-                }
-                if constexpr ((M & FEAT_AUX) != 0u) {
-                    if (auxOn && !recorded && loopExit) {    // the sample leaves the loop without having recorded its output values
-                        auxPostLoop<M>(s, ray.d, loopExit == 1 && bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0, bounce, aux0, aux1);
-                        recorded = true; auxStore = true;
-                    }
-                }
-            };
-
-            // participating media (PathTracer.cpp:48-61): a path inside a medium samples a distance along the segment first
-            int med = -1;
-            uint32_t medBounce = 0;
-            bool volumeEvent = false, mediumEnd = false;
-            f3 volP = splat3(0.0f);
-            if (M & FEAT_MEDIA) {
-                med = FLAG_MEDIUM(flags);
-                medBounce = FLAG_MEDIUM_BOUNCE(flags);
-                if (med >= 0) {
-                    f3 w; float t; bool exited;
-                    if (!mediumSampleDistance<M>(s, med, rng, __float_as_int(hit.w) >= 0 ? hit.x : PT_INF, medBounce, w, t, exited)) {
-                        mediumEnd = true;                    // "return emission"
-                    } else {
-                        throughput = throughput*w;           // mediumSample.emission = 0
-                        volumeEvent = !exited;
-                        volP = ray.o + ray.d*t;
-                    }
-                }
-            }
-
-            if ((M & FEAT_MEDIA) && mediumEnd) {
-                state = ST_TERMINATED;
-            } else if ((M & FEAT_MEDIA) && volumeEvent) {
-                // TraceBase::handleVolume (TraceBase.cpp:496-514) with volumeEstimateDirect / volumeSampleDirect /
-                // volumeLightSample / volumePhaseSample (:323-381, 402-414, 471-481)
-                const TgHipMedium &mm = s.media[med];
-                const bool volumeNee = s.settings.enable_volume_light_sampling != 0;
-                wasSpecular = !volumeNee;
-                if (volumeNee && bounce < maxBounces - 1) {
-                    float lightWeight = 1.0f;
-                    int light = chooseLight<M>(s, rng, volP, lightWeight);
-                    if (light >= 0) {
-                        const uint32_t tag = SHADOW_TAG_MEDIA(light, med, bounce + 1);   // the medium is not re-selected at a volume vertex
-                        bool q0 = false, q1 = false;
-                        const bool meshLight = s.objects[light].type == TGHIP_OBJ_MESH;
-                        const bool diracLight = s.objects[light].type == TGHIP_OBJ_POINT;
-                        {
-                            f3 d; float dist, pdf;
-                            if (lightSampleDirect<M>(s, light, volP, rng, d, dist, pdf)) {
-                                float f = phaseEval(mm, ray.d, d);
-                                if (f != 0.0f && meshLight) {
-                                    float k = powerHeuristic(pdf, f)/pdf;                  // phase pdf == phase value
-                                    slotF4(st, A_SH_D0, slot) = mk4(d, dist);
-                                    slotF4(st, A_SH_C0, slot) = mk4(splat3(f*k), __uint_as_float(tag));
-                                    q0 = true;
-                                } else if (f != 0.0f) {
-                                    RayD sr; sr.o = volP; sr.d = d; sr.tmin = 0.0f; sr.tmax = PT_INF;   // parentRay.scatter(p, d, 0.0f)
-                                    LightHit lh;
-                                    bool reached;
-                                    if (diracLight) { lh.t = dist; lh.u = 0.0f; lh.v = 0.0f; lh.backSide = false; lh.n = splat3(0.0f); reached = true; }
-                                    else reached = lightIntersect<M>(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist);
-                                    if (reached) {
-                                        f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
-                                        if (!isZero(e)) {
-                                            f3 lightF = e*f/pdf;
-                                            if (!diracLight)
-                                                lightF = lightF*powerHeuristic(pdf, f);
-                                            slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
-                                            slotF4(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
-                                            q0 = true;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                        if (!diracLight) {
-                            f3 w; float ppdf;
-                            phaseSample<M>(mm, rng, ray.d, w, ppdf);
-                            if (meshLight) {
-                                slotF4(st, A_SH_D1, slot) = mk4(w, ppdf);                      // directPdf needs the hit
-                                slotF4(st, A_SH_C1, slot) = mk4(splat3(1.0f), __uint_as_float(tag));
-                                q1 = true;
-                            } else {
-                                RayD sr; sr.o = volP; sr.d = w; sr.tmin = 0.0f; sr.tmax = PT_INF;
-                                LightHit lh;
-                                if (lightIntersect<M>(s, light, sr, lh)) {
-                                    f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
-                                    if (!isZero(e)) {
-                                        f3 phaseF = e*powerHeuristic(ppdf, lightDirectPdf<M>(s, light, w, volP, lh));
-                                        slotF4(st, A_SH_D1, slot) = mk4(w, lh.t);
-                                        slotF4(st, A_SH_C1, slot) = mk4(phaseF, __uint_as_float(tag));
-                                        q1 = true;
-                                    }
-                                }
-                            }
-                        }
-                        if (q0 || q1) {
-                            hasShadow = true;
-                            if (!q0) slotF4(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                            if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                            slotF4(st, A_SH_O, slot) = mk4(volP, 0.0f);
-                            slotF4(st, A_SH_W, slot) = mk4(throughput, lightWeight);
-                        }
-                    }
-                }
-                f3 w; float ppdf;
-                phaseSample<M>(mm, rng, ray.d, w, ppdf);         // the continuation; throughput *= 1
-                continuePath(volP, w, 0.0f);
-            } else if (__float_as_int(hit.w) < 0) {
-                // path escaped: TraceBase::handleInfiniteLights (TraceBase.cpp:570-578); the last infinite light wins
-                if ((M & FEAT_INFINITE) && bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0) {
-                    // intersectInfinites (TraceableScene.hpp:194-209): every infinite light is asked, the last hit stays
-                    int objIdx = -1;
-                    for (uint32_t li = 0; li < s.num_infinite_lights; ++li) {
-                        const TgHipObject &c = s.objects[s.infinite_lights[li]];
-                        if (c.type != TGHIP_OBJ_INFINITE_SPHERE_CAP || dot(ray.d, ld3(c.normal)) >= c.scale[0])
-                            objIdx = s.infinite_lights[li];
-                    }
-                    if (objIdx >= 0) {
-                        const TgHipObject &o = s.objects[objIdx];
-                        if (!nee || wasSpecular || !(o.flags & TGHIP_OBJF_SAMPLE)) {
-                            float u = 0.0f, v = 0.0f, sinTheta;
-                            if (o.type == TGHIP_OBJ_INFINITE_SPHERE) infDirectionToUV(o, ray.d, u, v, sinTheta);
-                            em = em + throughput*textureEval<M>(s, o.emission, u, v);
-                        }
-                    }
-                }
-                state = isnan(sum3(throughput) + sum3(em)) ? ST_TERMINATED_BLACK : ST_TERMINATED;
-                if constexpr ((M & FEAT_AUX) != 0u) {
-                    if (auxOn && !recorded && state == ST_TERMINATED) {   // (a NaN sample returns before the block at :133)
-                        auxPostLoop<M>(s, ray.d, bounce >= minBounces && bounce < maxBounces && s.num_infinite_lights > 0, bounce, aux0, aux1);
-                        recorded = true; auxStore = true;
-                    }
-                }
-            } else {
-                PROF(1);
-                if constexpr ((M & FEAT_AUX) != 0u) {
-                    if (auxOn && !recorded) { aux0.w += hit.x; auxStore = true; }   // hitDistance += ray.farT() (PathTracer.cpp:64)
-                }
-                Info info;
-                intersectionInfo<M>(s, ray, hit, info, hitInst);
-                const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
-                PROF(2);
-
-                // TraceBase::makeLocalScatterEvent (TraceBase.cpp:24-51)
-                Frame frame = frameFromNormal(info.Ns);
-                bool hitBackside = dot(frame.normal, ray.d) > 0.0f;
-                bool flipped = s.settings.enable_two_sided_shading && hitBackside && !(lobes & LOBE_TRANSMISSIVE);
-                if (flipped) {
-                    frame.normal = -frame.normal;
-                    frame.tangent = -frame.tangent;
-                }
-                Event ev;
-                ev.wi = toLocal(frame, -ray.d);
-                ev.u = info.u; ev.v = info.v; ev.rng = &rng;
-                const bool consistency = s.settings.enable_consistency_checks != 0;
-                auto isConsistent = [&](f3 woLocal, f3 w) {      // TraceBase.cpp:53-60
-                    if (!consistency) return true;
-                    bool geometricBackside = dot(w, info.Ng) < 0.0f;
-                    bool shadingBackside = (woLocal.z < 0.0f) != flipped;
-                    return geometricBackside == shadingBackside;
-                };
-
-                bool auxVisPending = false;
-                f3 transparency = splat3(0.0f);
-                if (lobes & TGHIP_LOBE_FORWARD) {
-                    ev.wo = -ev.wi; ev.requested = TGHIP_LOBE_FORWARD;
-                    transparency = bsdfEval<M>(s, info.bsdf, ev);
-                }
-                float transparencyScalar = avg3(transparency);
-                f3 wo;
-                bool alive = true;
-                if (rngNextBoolean(rng, transparencyScalar)) {
-                    wo = ray.d;
-                    throughput = throughput*(transparency/transparencyScalar);
-                } else {
-                    f3 pending = splat3(0.0f);
-                    // ---- next-event estimation: TraceBase::estimateDirect (TraceBase.cpp:483-494) ----
-                    if (nee && bounce < maxBounces - 1) {
-                        float lightWeight = 1.0f;
-                        int light = chooseLight<M>(s, rng, info.p, lightWeight);
-                        bool pureSpecular = lobes != 0 && (lobes & ~(uint32_t)LOBE_SPECULAR) == 0;
-                        if (light >= 0 && !pureSpecular && lobes != TGHIP_LOBE_FORWARD) {
-                            uint32_t tag = (uint32_t)light | ((uint32_t)(bounce + 1) << 24);
-                            // media scenes: each shadow ray starts in the medium on its side of the surface (TraceBase.cpp:260-261, 302-303)
-                            auto mediaTag = [&](f3 dir) {
-                                return SHADOW_TAG_MEDIA(light, selectMedium(s.objects[info.object], med, dot(dir, info.Ng) < 0.0f), bounce + 1);
-                            };
-                            bool q0 = false, q1 = false;
-                            f3 inlineResult = splat3(0.0f);
-                            const bool meshLight = (M & FEAT_MESHLIGHT) && s.objects[light].type == TGHIP_OBJ_MESH;
-                            const bool diracLight = (M & FEAT_SOLIDS) && s.objects[light].type == TGHIP_OBJ_POINT;
-                            // lightSample (TraceBase.cpp:246-285)
-                            {
-                                f3 d; float dist, pdf;
-                                if (lightSampleDirect<M>(s, light, info.p, rng, d, dist, pdf)) {
-                                    if (M & FEAT_MEDIA) tag = mediaTag(d);
-                                    ev.wo = toLocal(frame, d);
-                                    ev.requested = LOBE_ALL_BUT_SPECULAR;
-                                    if (isConsistent(ev.wo, d)) {
-                                        f3 f = bsdfEval<M>(s, info.bsdf, ev);
-                                        if ((M & FEAT_MESHLIGHT) && !isZero(f) && meshLight) {
-                                            // mesh emitter: whether the ray reaches the light, and with which emission, is only
-                                            // known after the scene traversal (TriangleMesh::intersect is a BVH query), so the
-                                            // shadow kernel completes f*e/pdf * powerHeuristic from these factors
-                                            float k = powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev))/pdf;
-                                            slotF4(st, A_SH_D0, slot) = mk4(d, dist);
-                                            slotF4(st, A_SH_C0, slot) = mk4(f*k, __uint_as_float(tag));
-                                            q0 = true;
-                                        } else if (!isZero(f)) {
-                                            RayD sr; sr.o = info.p; sr.d = d; sr.tmin = 5e-4f; sr.tmax = PT_INF;
-                                            LightHit lh;
-                                            // attenuatedEmission's analytic hit + distance check (TraceBase.cpp:155-162); a Dirac light
-                                            // (point) is not intersected: the shadow ray simply ends at the sampled distance
-                                            bool reached;
-                                            if (diracLight) { lh.t = dist; lh.u = 0.0f; lh.v = 0.0f; lh.backSide = false; lh.n = splat3(0.0f); reached = true; }
-                                            else reached = lightIntersect<M>(s, light, sr, lh) && !(lh.t*(1.0f + 1e-3f) < dist);
-                                            if (reached) {
-                                                f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
-                                                // TGHIP_PASS_AUX: attenuatedEmission reports the shadow ray's transmittance even when the
-                                                // light shows a black side (TraceBase.cpp:169-170): the ray is traced for the visibility output
-                                                bool wantVis = false;
-                                                if constexpr ((M & FEAT_AUX) != 0u) wantVis = auxOn && !recorded;
-                                                if (!isZero(e) || wantVis) {
-                                                    f3 lightF = f*e/pdf;                          // (zero for a black e)
-                                                    if (!diracLight)                              // no MIS against a Dirac light (:281-282)
-                                                        lightF = lightF*powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
-                                                    if (FUSE & FUSE_SHADOW) {
-                                                        sr.tmax = lh.t;
-                                                        fusedShadow++;
-                                                        if (!traverseOccluded<true, true, shadeKinds(M)>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
-                                                            inlineResult = inlineResult + lightF;
-                                                    } else {
-                                                        slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
-                                                        slotF4(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
-                                                    }
-                                                    q0 = true;
-                                                }
-                                            }
-                                        }
-                                    }
-                                }
-                            }
-                            // bsdfSample (TraceBase.cpp:287-321); not for Dirac lights (:396-397)
-                            if (!diracLight) {
-                                ev.requested = LOBE_ALL_BUT_SPECULAR;
-                                ev.weight = splat3(1.0f); ev.pdf = 1.0f;
-                                if (bsdfSample<M>(s, info.bsdf, ev) && !isZero(ev.weight)) {
-                                    f3 wog = toGlobal(frame, ev.wo);
-                                    if (M & FEAT_MEDIA) tag = mediaTag(wog);
-                                    if ((M & FEAT_MESHLIGHT) && meshLight) {
-                                        if (isConsistent(ev.wo, wog)) {
-                                            slotF4(st, A_SH_D1, slot) = mk4(wog, ev.pdf);          // directPdf needs the hit
-                                            slotF4(st, A_SH_C1, slot) = mk4(ev.weight, __uint_as_float(tag));
-                                            q1 = true;
-                                        }
-                                    } else if (isConsistent(ev.wo, wog)) {
-                                        RayD sr; sr.o = info.p; sr.d = wog; sr.tmin = 5e-4f; sr.tmax = PT_INF;
-                                        LightHit lh;
-                                        if (lightIntersect<M>(s, light, sr, lh)) {
-                                            f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
-                                            if (!isZero(e)) {
-                                                f3 bsdfF = e*ev.weight;
-                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightDirectPdf<M>(s, light, wog, info.p, lh));
-                                                if (FUSE & FUSE_SHADOW) {
-                                                    sr.tmax = lh.t;
-                                                    fusedShadow++;
-                                                    if (!traverseOccluded<true, true, shadeKinds(M)>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
-                                                        inlineResult = inlineResult + bsdfF;
-                                                } else {
-                                                    slotF4(st, A_SH_D1, slot) = mk4(wog, lh.t);
-                                                    slotF4(st, A_SH_C1, slot) = mk4(bsdfF, __uint_as_float(tag));
-                                                }
-                                                q1 = true;
-                                            }
-                                        }
-                                    }
-                                }
-                            }
-                            if ((FUSE & FUSE_SHADOW) && (q0 || q1)) {
-                                // emission += estimateDirect(...)*throughput, like k_trace_shadow
-                                em = em + (inlineResult*lightWeight)*throughput;
-                            } else if (q0 || q1) {
-                                hasShadow = true;
-                                auxVisPending = q0;
-                                if (!q0) slotF4(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                                if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                                slotF4(st, A_SH_O, slot) = mk4(info.p, 5e-4f);
-                                slotF4(st, A_SH_W, slot) = mk4(throughput, lightWeight);
-                            }
-                        }
-                    }
-                    PROF(3);
-                    // emission of the surface itself (TraceBase.cpp:540-543)
-                    {
-                        const TgHipObject &o = s.objects[info.object];
-                        if (o.emission >= 0 && bounce >= minBounces && (!nee || wasSpecular || o.light < 0))
-                            pending = lightEvalDirect<M>(s, info.object, info.u, info.v, info.backSide)*throughput;
-                    }
-                    // with a shadow ray pending, `pending` is added after the NEE term by k_trace_shadow, like the reference
-                    if (!hasShadow)
-                        em = em + pending;
-                    else
-                        pendingOut = pending;
-
-                    // continuation: bsdf.sample(event, adjoint = false) with all lobes (TraceBase.cpp:546-558)
-                    ev.requested = LOBE_ALL;
-                    ev.weight = splat3(1.0f); ev.pdf = 1.0f;
-                    if (!bsdfSample<M>(s, info.bsdf, ev)) {
-                        alive = false;
-                    } else {
-                        wo = toGlobal(frame, ev.wo);
-                        if (!isConsistent(ev.wo, wo)) {
-                            alive = false;
-                        } else {
-                            throughput = throughput*ev.weight;
-                            wasSpecular = (ev.sampled & LOBE_SPECULAR) != 0;
-                        }
-                    }
-                }
-
-                PROF(4);
-                if constexpr ((M & FEAT_AUX) != 0u) if (auxOn && !recorded && (!wasSpecular || !alive)) {       // PathTracer.cpp:78-96
-                    int ab = info.bsdf;                          // TransparencyBsdf: its base's albedo
-                    if (s.bsdfs[ab].type == TGHIP_BSDF_TRANSPARENCY) ab = s.bsdfs[ab].sub0;
-                    f3 albedo = textureEval<M>(s, s.bsdfs[ab].albedo, info.u, info.v);
-                    if (s.objects[info.object].emission >= 0)    // isEmissive(): + evalDirect
-                        albedo = albedo + lightEvalDirect<M>(s, info.object, info.u, info.v, info.backSide);
-                    aux0 = mk4(info.Ns, aux0.w);                 // .w = hitDistance
-                    // visibility = transmittance of this vertex' light sample, if it got as far as its shadow ray: pending
-                    aux1 = mk4(albedo, auxVisPending ? PT_INF : __uint_as_float(0x7FC00000u));
-                    recorded = true;
-                    auxStore = true;
-                }
-                if (!alive) {
-                    state = ST_TERMINATED;
-                } else {
-                    f3 hp = ray.o + ray.d*hit.x;                 // ray.hitpoint()
-                    if (M & FEAT_MEDIA) {                        // TraceBase.cpp:561-563
-                        med = selectMedium(s.objects[info.object], med, dot(wo, info.Ng) < 0.0f);
-                        medBounce = 0;                           // state.reset()
-                    }
-                    continuePath(hp, wo, 5e-4f);
-                }
-            }
-            if (state == ST_ACTIVE) {
-                slotF4(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
-                slotF4(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
-                *reinterpret_cast<uint2 *>(&slotU4(st, A_MISC, slot)) = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
-                if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL))
-                    slotU4(st, A_SAMP, slot).z = rng.dim;
-            }
-            if constexpr ((M & FEAT_AUX) != 0u) if (auxOn) {
-                if (!recorded && state != ST_ACTIVE) {       // the sample returned early: it adds nothing (hitDistance is not a depth)
-                    aux0.w = __uint_as_float(0x7FC00000u);
-                    auxStore = true;
-                }
-                if (auxStore) { slotF4(st, A_AUX0, slot) = aux0; slotF4(st, A_AUX1, slot) = aux1; }
-            }
-            const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state) | ((M & FEAT_MEDIA) ? FLAG_MEDIUM_BITS(med, medBounce) : 0u)
-                                    | (recorded ? FLAG_AUX_RECORDED : 0u);
-            survives = state == ST_ACTIVE;
-            black = state == ST_TERMINATED_BLACK;
-            if (hasShadow) {
-                // k_trace_shadow adds the NEE term, then finishes the path if it ended here
-                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
-                slotF4(st, A_SH_P, slot) = mk4(pendingOut, __uint_as_float(newFlags));
-            } else if (survives) {
-                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
-            } else {
-                finished = true;
-            }
-            if (survives)
-                slotF4(st, A_THR, slot) = mk4(throughput, __uint_as_float(newFlags));
-          }
-        }
-        PROF(5);
-        if (!DIRECT) {
-            if (FUSE & FUSE_TRACE) queuePush(toComplex, local, L, Q_SHADE1);
-            queuePush(hasShadow, local, L, Q_SHADOW);
-        }
-        PROF(6);
-        bool regenerated = nextPath<true, (M & FEAT_QMC) != 0>(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
-        PROF(7);
-        if (DIRECT) {
-            if (finished && !regenerated) idle |= 1u << turn;   // the work items ran out: nothing left for this slot
-        } else {
-            queuePush(survives, local, L, Q_EXT);
-            queuePush(regenerated, local, L, Q_EXTP);
-        }
-        PROF(8);
-    }
-    if (!DIRECT)
-        break;
-    if (__ballot(idle != 0xFFFFFFFFu) == 0ull)
-        break;                                   // every slot of this wave has drained
-  }
-    if (DIRECT) {
-        // nothing is queued any more: the bitmaps go back empty
-        __syncthreads();
-        for (uint32_t w = threadIdx.x; w < (uint32_t)Q_COUNT*(st.slots_per_block >> 5); w += blockDim.x)
-            L.bm[w/(st.slots_per_block >> 5)][w % (st.slots_per_block >> 5)] = 0u;
-    }
-    PROF_FLUSH(st.stats[blockIdx.x]);
-    waveAddStat(&L.samples, finishedCount);
-    if (FUSE) {
-        waveAddStat(&L.closest_rays, fusedClosest);
-        waveAddStat(&L.shadow_rays, fusedShadow);
-        waveAddStat(&L.prims, fusedPrims);
-    }
-    const bool anyExt = queuesEnd(L, st, qIn, appendMask, qIn2);
-    if (threadIdx.x == 0) {
-        ctl.item_cursor = L.cursor;
-        ctl.samples += L.samples;
-        if (FUSE) {
-            ctl.closest_rays += L.closest_rays; ctl.shadow_rays += L.shadow_rays;
-            st.stats[blockIdx.x].prims_tested += L.prims;
-            // fused mode has no k_trace_shadow launch: the last shading launch of the iteration reports liveness
-            if (anyExt) st.live[0] = (uint32_t)pp.iter_tag;
-        }
-    }
-}
-
-// TraceBase::generalizedShadowRay (TraceBase.cpp:62-125) for the shadow rays queued by k_shade:
-// a closest-hit query up to the light; unoccluded iff nothing is hit or the closest hit is the
-// light itself (endCap); surfaces with a forward lobe attenuate and the ray continues (FORWARD variant only:
-// scenes without a forward-lobe BSDF run the lean variant).
-template<bool COUNT, bool FORWARD, bool FLAT, int INST = 0>
-__global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
-{
-    extern __shared__ int ldsStack[];
-    __shared__ BlockLds L;
-    BlockCtl &ctl = st.ctl[blockIdx.x];
-    queuesBegin(L, st, ctl, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP), reinterpret_cast<unsigned short *>(ldsStack));
-    const uint32_t n = L.n;
-    const OrderRegs ord = orderPreload(reinterpret_cast<unsigned short *>(ldsStack), n);
-    const uint32_t first = blockIdx.x*st.slots_per_block;
-    const bool aborted = st.live[1] != 0;
-    uint32_t nodes = 0, prims = 0, rays = 0, slots = 0, finishedCount = 0;
-    for (uint32_t base = 0, k = 0; base < n; base += blockDim.x, ++k) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t slot = 0, local = 0;
-        bool finished = false, black = false;
-        f3 em = splat3(0.0f);
-        if (i < n) {
-            local = orderGet(ord, k);
-            slot = first + local;
-            slots++;
-            float4 so = slotF4(st, A_SH_O, slot);
-            f3 result = splat3(0.0f);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                float4 c = r == 0 ? slotF4(st, A_SH_C0, slot) : slotF4(st, A_SH_C1, slot);
-                uint32_t tag = __float_as_uint(c.w);
-                if (tag == 0xFFFFFFFFu)
-                    continue;
-                float4 sd = r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot);
-                int endCap = (int)(tag & 0xFFFFFFu);
-                int bounce = (int)(tag >> 24);
-                int medium = -1;                               // media scenes (always the FORWARD walk): SHADOW_TAG_MEDIA
-                if (FORWARD && s.num_media) { endCap = (int)(tag & 0xFFFFu); medium = (int)((tag >> 16) & 0xFFu) - 1; }
-                bool startsOnSurface = so.w != 0.0f;           // shadow rays of a volume vertex start at tmin = 0 (parentRay.scatter(p, d, 0.0f))
-                RayD ray;
-                ray.o = xyz(so); ray.d = xyz(sd); ray.tmin = so.w; ray.tmax = sd.w;
-                float remaining = ray.tmax;
-                f3 transmittance = splat3(1.0f);
-                bool visValid = true;                          // TGHIP_PASS_AUX: attenuatedEmission got as far as its shadow ray
-                f3 shadowT = splat3(0.0f);                     // ... whose result this is (before the emission is applied)
-                if (!FORWARD) {
-                    // no surface of this scene lets light through: any occluder ends the query
-                    rays++;
-                    if ((INST ? traverseOccludedInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims)
-                              : traverseOccluded<COUNT, FLAT>(s, ray, endCap, ldsStack + threadIdx.x, blockDim.x, nodes, prims))
-                        || bounce < s.settings.min_bounces)
-                        transmittance = splat3(0.0f);
-                } else {
-                const bool meshLight = s.objects[endCap].type == TGHIP_OBJ_MESH;
-                f3 meshFactor = splat3(0.0f);                  // mesh emitters: e (light ray) or e*powerHeuristic (bsdf ray)
-                float travelled = 0.0f;
-                if (meshLight) { ray.tmax = PT_INF; remaining = PT_INF; }   // sd.w carries the expected distance / the bsdf pdf
-                for (;;) {
-                    int hitInst = -1;
-                    float4 hit = INST ? traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
-                                      : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
-                    rays++;
-                    int ri = __float_as_int(hit.w);
-                    int hitObject = -1;
-                    if (ri >= 0)      // geometry reached through an instance belongs to the `instances` primitive (never a light)
-                        hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)(hitInst >= 0 ? hitInst : ri)*3u).w));
-                    if (meshLight && ri < 0) { transmittance = splat3(0.0f); visValid = false; break; }   // the ray never reaches the mesh
-                    if (medium >= 0)                             // TraceBase.cpp:103-112: ray.farT() is the hit distance when anything was hit
-                        transmittance = transmittance*mediumTransmittance(s, medium, ri >= 0 ? hit.x : ray.tmax, startsOnSurface, true);
-                    if (ri < 0 || hitObject == endCap) {
-                        if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
-                        if (meshLight) {
-                            // attenuatedEmission on a mesh light (TraceBase.cpp:144-174, TriangleMesh.cpp:344-355,469-473,493-496)
-                            Info li;
-                            intersectionInfo<BSDF_MASK_ALL>(s, ray, hit, li);
-                            const TgHipObject &lo = s.objects[endCap];
-                            f3 e = lightEvalDirect<BSDF_MASK_ALL>(s, endCap, li.u, li.v, li.backSide);
-                            float total = travelled + hit.x;
-                            if (r == 0) {
-                                if (total*(1.0f + 1e-3f) < sd.w) { e = splat3(0.0f); visValid = false; }   // a nearer part of the mesh than the sampled point
-                                meshFactor = e;
-                            } else {
-                                float directPdf = lengthSq(xyz(so) - li.p)/(-dot(ray.d, li.Ng)*lo.area);
-                                meshFactor = e*powerHeuristic(sd.w, directPdf);
-                            }
-                        }
-                        break;
-                    }
-                    Info info;
-                    intersectionInfo<BSDF_MASK_ALL>(s, ray, hit, info, hitInst);
-                    const uint32_t lobes = s.bsdfs[info.bsdf].lobes;
-                    if (!(lobes & TGHIP_LOBE_FORWARD)) { transmittance = splat3(0.0f); break; }
-                    Frame frame = frameFromNormal(info.Ns);
-                    bool hitBackside = dot(frame.normal, ray.d) > 0.0f;
-                    if (s.settings.enable_two_sided_shading && hitBackside && !(lobes & LOBE_TRANSMISSIVE)) {
-                        frame.normal = -frame.normal;
-                        frame.tangent = -frame.tangent;
-                    }
-                    Event fe;
-                    fe.wi = toLocal(frame, -ray.d); fe.wo = -fe.wi;
-                    fe.requested = TGHIP_LOBE_FORWARD; fe.u = info.u; fe.v = info.v; fe.rng = nullptr;
-                    f3 transparency = bsdfEval<FORWARD ? BSDF_MASK_ALL : 0u>(s, info.bsdf, fe);
-                    if (isZero(transparency)) { transmittance = splat3(0.0f); break; }
-                    transmittance = transmittance*transparency;
-                    bounce++;
-                    if (bounce >= s.settings.max_bounces) { transmittance = splat3(0.0f); break; }
-                    if (s.num_media)                             // :115-116
-                        medium = selectMedium(s.objects[info.object], medium, !info.backSide);
-                    startsOnSurface = true;
-                    ray.o = ray.o + ray.d*hit.x;
-                    travelled += hit.x;
-                    remaining -= hit.x;
-                    ray.tmin = 5e-4f;
-                    ray.tmax = remaining;
-                }
-                shadowT = transmittance;
-                if (meshLight) transmittance = transmittance*meshFactor;
-                }
-                if (!FORWARD) shadowT = transmittance;
-                if (r == 0 && (pp.flags & TGHIP_PASS_AUX)) {   // the visibility output of the vertex that recorded (PathTracer.cpp:93-94)
-                    float4 &a1 = slotF4(st, A_AUX1, slot);
-                    if (isinf(a1.w))
-                        a1.w = visValid ? avg3(shadowT) : __uint_as_float(0x7FC00000u);
-                }
-                if (!isZero(transmittance))
-                    result = result + xyz(c)*transmittance;
-            }
-            float4 w = slotF4(st, A_SH_W, slot);
-            float4 p = slotF4(st, A_SH_P, slot);
-            em = xyz(slotF4(st, A_EMI, slot));
-            em = em + (result*w.w)*xyz(w);                       // emission += estimateDirect(...)*throughput
-            em = em + xyz(p);
-            uint32_t state = FLAG_STATE(__float_as_uint(p.w));
-            if (state == ST_ACTIVE) {
-                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
-            } else {
-                finished = true;
-                black = state == ST_TERMINATED_BLACK;
-            }
-        }
-        bool regenerated = nextPath(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
-        queuePush(regenerated, local, L, Q_EXTP);
-    }
-    waveAddStat(&L.samples, finishedCount);
-    waveAddStat(&L.shadow_rays, rays);
-    waveAddStat(&L.shadow_slots, slots);
-    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    const bool anyExt = queuesEnd(L, st, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP));
-    if (threadIdx.x == 0) {
-        ctl.item_cursor = L.cursor;
-        ctl.samples += L.samples; ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
-        if (COUNT) {
-            BlockStats &bs = st.stats[blockIdx.x];
-            bs.nodes_visited += L.nodes; bs.prims_tested += L.prims;
-            bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
-        }
-        // last kernel of the iteration: tell the host whether any extension queue still holds work
-        if (anyExt) st.live[0] = iterTag;
-    }
-}
-
-// Shadow rays of BVH scenes without forward-lobe BSDFs, with dynamic fetch like k_trace_closest_dyn: the unit of
-// work is a shadow slot (<= 2 any-hit rays, traced one after the other); idle lanes take the workgroup's next slots
-// once fewer than 3/4 of the wave is busy.  A finished slot adds the NEE term to its path's radiance; paths that
-// had ended at that vertex go to the Q_FIN queue and are finalised + regenerated by k_finish, a launch of its own:
-// nextPath (camera ray, filter table, item bookkeeping) needs 112 VGPRs, the traversal loop 82 -- kept apart, this
-// kernel runs 5 waves per SIMD instead of 4.
-// Dynamic LDS: [expanded queue, 2 B per slot][node stacks, bvhDepth ints per thread].
-#ifndef SHADOW_DYN_BOUNDS
-#define SHADOW_DYN_BOUNDS __launch_bounds__(512)
-#endif
-template<bool COUNT, bool SOLIDS = true>
-__global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
-{
-    extern __shared__ int ldsDyn[];
-    __shared__ BlockLds L;
-    __shared__ uint32_t fetchNext;
-    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
-    int *stack = ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2 + threadIdx.x;
-    const int stride = (int)blockDim.x;
-    BlockCtl &ctl = st.ctl[blockIdx.x];
-    if (threadIdx.x == 0) fetchNext = 0;
-    queuesBegin(L, st, ctl, Q_SHADOW, 1u << Q_FIN, order);
-    const uint32_t n = L.n;
-    const uint32_t first = blockIdx.x*st.slots_per_block;
-    const int minBounces = s.settings.min_bounces;
-    uint32_t nodes = 0, prims = 0, rays = 0, slots = 0;
-
-    bool busy = false;
-    uint32_t slot = 0, local = 0;
-    int r = 0;                                   // ray of the slot being traced (0: light sample, 1: bsdf sample)
-    f3 so = splat3(0.0f);
-    float eps = 0.0f;
-    f3 result = splat3(0.0f);
-    RayD ray; ray.o = splat3(0.0f); ray.d = splat3(1.0f); ray.tmin = 0.0f; ray.tmax = 0.0f;
-    f3 invD = splat3(1.0f);
-    f3 contrib = splat3(0.0f);
-    int endCap = -1;
-    int cur = 0, sp = 0;
-    bool exhausted = false;
-
-    // sets up ray `r` (or the next valid one) of the current slot; returns false when the slot has no ray left
-    auto setupRay = [&]() -> bool {
-        for (; r < 2; ++r) {
-            float4 c = r == 0 ? slotF4(st, A_SH_C0, slot) : slotF4(st, A_SH_C1, slot);
-            uint32_t tag = __float_as_uint(c.w);
-            if (tag == 0xFFFFFFFFu)
-                continue;
-            float4 sd = r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot);
-            endCap = (int)(tag & 0xFFFFFFu);
-            int bounce = (int)(tag >> 24);
-            rays++;
-            if (bounce < minBounces)
-                continue;                        // contributes nothing (TraceBase.cpp:114-115 with minBounces)
-            contrib = xyz(c);
-            ray.o = so; ray.d = xyz(sd); ray.tmin = eps; ray.tmax = sd.w;
-            invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
-            cur = 0; sp = 0;
-            return true;
-        }
-        return false;
-    };
-    // NEE term -> path radiance; paths that ended at this vertex go on the finished list
-    auto finishSlot = [&]() {
-        float4 w = slotF4(st, A_SH_W, slot);
-        float4 p = slotF4(st, A_SH_P, slot);
-        f3 em = xyz(slotF4(st, A_EMI, slot));
-        em = em + (result*w.w)*xyz(w);           // emission += estimateDirect(...)*throughput
-        em = em + xyz(p);
-        slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
-        queuePush(FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE, local, L, Q_FIN);
-        busy = false;
-    };
-
-    for (;;) {
-        unsigned long long busyMask = __ballot(busy);
-        if (!exhausted && __popcll(busyMask) <= 48) {
-            unsigned long long want = ~busyMask;
-            uint32_t lane = laneId();
-            uint32_t base = 0;
-            if (lane == 0)
-                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
-            base = __shfl(base, 0);
-            if (!busy) {
-                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
-                if (i < n) {
-                    local = order[i];
-                    slot = first + local;
-                    slots++;
-                    float4 o4 = slotF4(st, A_SH_O, slot);
-                    so = xyz(o4); eps = o4.w;
-                    result = splat3(0.0f);
-                    r = 0;
-                    busy = true;
-                    if (!setupRay())
-                        finishSlot();
-                }
-            }
-            if (base + (uint32_t)__popcll(want) >= n)
-                exhausted = true;
-            busyMask = __ballot(busy);
-        }
-        if (busyMask == 0ull)
-            break;
-        if (busy) {
-            bool pop = true, occluded = false;
-            if (cur >= 0) {
-                const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
-                float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
-                if (COUNT) nodes++;
-                float e0, e1;
-                bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, ray.tmax, e0);
-                bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, ray.tmax, e1);
-                int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-                if (h0 && h1) {
-                    if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
-                    else { stack[sp*stride] = c1; cur = c0; }
-                    sp++;
-                    pop = false;
-                } else if (h0) { cur = c0; pop = false; }
-                else if (h1) { cur = c1; pop = false; }
-            } else {
-                uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
-                for (uint32_t q = firstRec; q < firstRec + count && !occluded; ++q) {
-                    if (COUNT) prims++;
-                    float tmax = ray.tmax;
-                    float4 hit;
-                    uint32_t meta;
-                    if (testRecord<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, q, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
-                        occluded = true;
-                }
-            }
-            bool rayDone = occluded;
-            if (!occluded && pop) {
-                if (sp == 0) {
-                    result = result + contrib;   // nothing in the way: transmittance 1
-                    rayDone = true;
-                } else {
-                    sp--;
-                    cur = stack[sp*stride];
-                }
-            }
-            if (rayDone) {
-                r++;
-                if (!setupRay())
-                    finishSlot();
-            }
-        }
-    }
-    waveAddStat(&L.shadow_rays, rays);
-    waveAddStat(&L.shadow_slots, slots);
-    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-
-    queuesEnd(L, st, Q_SHADOW, 1u << Q_FIN);
-    if (threadIdx.x == 0) {
-        ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
-        if (COUNT) {
-            BlockStats &bs = st.stats[blockIdx.x];
-            bs.nodes_visited += L.nodes; bs.prims_tested += L.prims;
-            bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
-        }
-    }
-}
-
-// Second half of the dynamic-fetch shadow step: finalises the paths that had ended at the vertex whose shadow rays
-// k_trace_shadow_dyn just resolved (Q_FIN), regenerates their slots and reports whether the workgroup has extension
-// rays for the next iteration.
-__global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
-{
-    __shared__ BlockLds L;
-    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
-    BlockCtl &ctl = st.ctl[blockIdx.x];
-    queuesBegin(L, st, ctl, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP), order);
-    const uint32_t nf = L.n;
-    const uint32_t first = blockIdx.x*st.slots_per_block;
-    const bool aborted = st.live[1] != 0;
-    uint32_t finishedCount = 0;
-    for (uint32_t base = 0; base < nf; base += blockDim.x) {
-        uint32_t i = base + threadIdx.x;
-        bool fin = i < nf;
-        uint32_t loc = 0, sl = 0;
-        f3 em = splat3(0.0f);
-        bool black = false;
-        if (fin) {
-            loc = order[i];
-            sl = first + loc;
-            em = xyz(slotF4(st, A_EMI, sl));
-            black = FLAG_STATE(__float_as_uint(slotF4(st, A_SH_P, sl).w)) == ST_TERMINATED_BLACK;
-        }
-        bool regenerated = nextPath(s, st, pp, fin, false, sl, em, black, &L.cursor, aborted, finishedCount);
-        queuePush(regenerated, loc, L, Q_EXTP);
-    }
-    waveAddStat(&L.samples, finishedCount);
-    const bool anyExt = queuesEnd(L, st, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP));
-    if (threadIdx.x == 0) {
-        ctl.item_cursor = L.cursor;
-        ctl.samples += L.samples;
-        if (anyExt) st.live[0] = iterTag;
-    }
-}
-
-// Sums the per-item partial sums of every pixel slot in fixed chunk order into the framebuffer
-// (deterministic; no float atomics anywhere on the accumulation path).
-__global__ __launch_bounds__(256) void k_resolve(PathState st, PassParams pp, float *fbSum, uint32_t *fbCount)
-{
-    uint32_t j = blockIdx.x*blockDim.x + threadIdx.x;
-    if (j >= pp.pix_slots)
-        return;
-    uint32_t x, y;
-    if (!slotPixel(pp, j, x, y))
-        return;
-    uint32_t pixel = x + y*pp.width;
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    uint32_t cnt = 0;
-    for (uint32_t c = 0; c < pp.chunks; ++c) {
-        float4 a = at32(st.partial, c*pp.pix_slots + j);
-        sx += a.x; sy += a.y; sz += a.z;
-        cnt += __float_as_uint(a.w);
-    }
-    fbSum[(size_t)pixel*3 + 0] += sx;
-    fbSum[(size_t)pixel*3 + 1] += sy;
-    fbSum[(size_t)pixel*3 + 2] += sz;
-    fbCount[pixel] += cnt;
-}
-
-// k_resolve of a record pass (gap-free item enumeration, PassParams): one thread per pixel slot of the sorted record list
-// sums the pixel's items of this batch in chunk order.
-__global__ __launch_bounds__(256) void k_resolve_records(PathState st, PassParams pp, float *fbSum, uint32_t *fbCount)
-{
-    uint32_t j = blockIdx.x*blockDim.x + threadIdx.x;
-    if (j >= pp.num_sorted*16u)
-        return;
-    uint32_t rec = pp.rec_sorted[j >> 4];
-    uint32_t x = (rec % pp.variance_w)*4u + (j & 3u), y = (rec/pp.variance_w)*4u + ((j >> 2) & 3u);
-    if (x >= pp.width || y >= pp.height)
-        return;
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    uint32_t cnt = 0;
-    for (uint32_t c = 0; c < pp.num_chunks; ++c) {
-        uint32_t start = pp.rec_chunk_start[c];
-        if (j >= pp.rec_chunk_start[c + 1u] - start)
-            break;                               // chunks only get shorter: the pixel has no further items
-        uint32_t w = start + j;
-        if (w < pp.item_base || w - pp.item_base >= pp.total_items)
-            continue;                            // item of another batch
-        float4 a = at32(st.partial, w - pp.item_base);
-        sx += a.x; sy += a.y; sz += a.z;
-        cnt += __float_as_uint(a.w);
-    }
-    uint32_t pixel = x + y*pp.width;
-    fbSum[(size_t)pixel*3 + 0] += sx;
-    fbSum[(size_t)pixel*3 + 1] += sy;
-    fbSum[(size_t)pixel*3 + 2] += sz;
-    fbCount[pixel] += cnt;
-}
-
-// SampleRecord::addSample (path_tracer/SampleRecord.hpp:46-58) over the luminances the pass wrote, one thread per
-// record, in the order the reference's renderTile visits them (PathTraceIntegrator.cpp:136-156: the tile's pixels
-// row by row, each pixel's samples in index order), so mean and running variance round exactly like the CPU's.
-__global__ __launch_bounds__(64) void k_records(PassParams pp, TgHipSampleRecord *records, uint32_t numRecords)
-{
-    uint32_t r = blockIdx.x*blockDim.x + threadIdx.x;
-    if (r >= numRecords)
-        return;
-    uint32_t rx = r % pp.variance_w, ry = r/pp.variance_w;
-    uint32_t tile = (rx >> 2) + (ry >> 2)*pp.tiles_x;
-    if (tile % pp.shard_count != pp.shard_index)
-        return;
-    const uint32_t cnt = pp.rec_count[r], base = pp.rec_lum[r];
-    TgHipSampleRecord rec = records[r];
-    for (uint32_t py = 0; py < 4u && ry*4u + py < pp.height; ++py)
-        for (uint32_t px = 0; px < 4u && rx*4u + px < pp.width; ++px) {
-            const float *lum = pp.lum + (size_t)base + (size_t)((py << 2) | px)*cnt;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                float x = lum[i];
-                rec.sample_count++;
-                float delta = x - rec.mean;
-                rec.mean += delta/(float)rec.sample_count;
-                rec.running_variance += delta*(x - rec.mean);
-            }
-        }
-    records[r] = rec;
-}
+// The k_shade variants are instantiated in shade_simple.hip / shade_class.hip / shade_full.hip (parallel compilation).
+extern template __global__ void k_shade<MASK_LEAN, LEAN_WAVES, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_LEAN | FEAT_QMC), LEAN_WAVES, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_LEAN, LEAN_WAVES, 3>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_LEAN | FEAT_QMC), LEAN_WAVES, 3>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_LEAN, LEAN_WAVES, 7>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_LEAN | FEAT_QMC), LEAN_WAVES, 7>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_SIMPLE | FEAT_QMC), SIMPLE_WAVES, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_SIMPLE, SIMPLE_WAVES, 3>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_SIMPLE | FEAT_QMC), SIMPLE_WAVES, 3>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_SIMPLE, SIMPLE_WAVES, 7>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_SIMPLE | FEAT_QMC), SIMPLE_WAVES, 7>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_COAT, COAT_WAVES, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_COAT | FEAT_QMC), COAT_WAVES, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_COAT, COAT_WAVES, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_COAT | FEAT_QMC), COAT_WAVES, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_GLASS, 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_GLASS | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_GLASS, 2, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_GLASS | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_FULL, 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_FULL, 2, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<BSDF_MASK_ALL, 2, 0>(DeviceScene, PathState, PassParams, int);
 
 // =============================================================================================
 // Host-side shim
 // =============================================================================================
+
 namespace {
 
 std::mutex g_errMutex;
