@@ -162,9 +162,9 @@ typedef struct TgHipBsdf {
 
 /* ---- participating media (media/HomogeneousMedium.cpp) ------------------------------------------------- */
 enum { TGHIP_PHASE_ISOTROPIC = 0, TGHIP_PHASE_HENYEY_GREENSTEIN = 1, TGHIP_PHASE_RAYLEIGH = 2 };   /* phasefunctions/{Isotropic,HenyeyGreenstein,Rayleigh}PhaseFunction.cpp */
-/* transmittances/{Exponential,Linear,Quadratic,DoubleExponential,Pulse,Erlang,Davis}Transmittance.cpp */
+/* transmittances/{Exponential,Linear,Quadratic,DoubleExponential,Pulse,Erlang,Davis,DavisWeinstein}Transmittance.cpp */
 enum { TGHIP_TRANS_EXPONENTIAL = 0, TGHIP_TRANS_LINEAR = 1, TGHIP_TRANS_QUADRATIC = 2, TGHIP_TRANS_DOUBLE_EXPONENTIAL = 3,
-       TGHIP_TRANS_PULSE = 4, TGHIP_TRANS_ERLANG = 5, TGHIP_TRANS_DAVIS = 6 };
+       TGHIP_TRANS_PULSE = 4, TGHIP_TRANS_ERLANG = 5, TGHIP_TRANS_DAVIS = 6, TGHIP_TRANS_DAVIS_WEINSTEIN = 7 };
 typedef struct TgHipMedium {
     float   sigma_a[3], sigma_s[3], sigma_t[3];   /* after prepareForRender: material sigma x density (HomogeneousMedium.cpp:43-49) */
     int32_t absorption_only;                      /* _sigmaS == 0 */
@@ -173,7 +173,7 @@ typedef struct TgHipMedium {
     float   phase_g;                              /* Henyey-Greenstein asymmetry */
     int32_t trans_type;                           /* TGHIP_TRANS_*: Medium::_transmittance (Medium.cpp:14, 27-28) */
     float   trans_p[3];                           /* linear / quadratic: {max_t}; double_exponential: {sigma_a, sigma_b}; pulse: {min, max, num_pulses};
-                                                     erlang: {rate}; davis: {alpha} */
+                                                     erlang: {rate}; davis: {alpha}; davis_weinstein: {h, c} */
     float   pad[3];
 } TgHipMedium;                /* 80 B */
 

@@ -1669,6 +1669,24 @@ static float trans_kernel(const TgHipMedium *m, int k, float tau)
         if (k == 1 || k == 2) return powf(1.0f + tau/alpha, -(alpha + 1.0f));
         return (1.0f + 1.0f/alpha)*powf(1.0f + tau/alpha, -(alpha + 2.0f));
     }
+    case TGHIP_TRANS_DAVIS_WEINSTEIN: {                 /* DavisWeinsteinTransmittance.cpp:39-82; NaN -> 0 */
+        float beta = 2.0f*p[0] - 1.0f;
+        float alpha = powf(tau, 1 - beta)/powf(p[1], 1 + beta);             /* computeAlpha */
+        float base = 1.0f + tau/alpha;
+        float trSurface = powf(base, -alpha), Tr;
+        if (k == 0) {
+            Tr = trSurface;
+        } else if (k == 1 || k == 2) {
+            Tr = trSurface*(beta/base - (beta - 1.0f)*alpha/tau*logf(base));
+        } else {
+            float logBase = logf(base);
+            float term1 = beta*(-1.0f + beta*(1.0f + tau) + (-1.0f + 2.0f*beta)*tau/alpha)/(tau*base*base);
+            float term2 = ((-1.0f + beta)*beta*alpha/(tau*tau)*(2.0f*tau + base)*logBase)/base;
+            float term3 = (beta - 1.0f)*alpha/tau*logBase;
+            Tr = trSurface*(term1 - term2 + term3*term3);
+        }
+        return isnan(Tr) ? 0.0f : Tr;
+    }
     default:                                            /* ExponentialTransmittance.cpp:26-41 (FastMath::exp in the reference) */
         return expf(-tau);
     }
@@ -1684,7 +1702,12 @@ static float trans_sigmaBar(const TgHipMedium *m)
     default: return 1.0f;
     }
 }
-static v3 trans_kernel3(const TgHipMedium *m, int k, v3 tau) { return V(trans_kernel(m, k, tau.x), trans_kernel(m, k, tau.y), trans_kernel(m, k, tau.z)); }
+static v3 trans_kernel3(const TgHipMedium *m, int k, v3 tau)
+{
+    if (m->trans_type == TGHIP_TRANS_DAVIS_WEINSTEIN)    /* evaluated on the first channel only (tau[0]) and broadcast (:46-49) */
+        return vs(trans_kernel(m, k, tau.x));
+    return V(trans_kernel(m, k, tau.x), trans_kernel(m, k, tau.y), trans_kernel(m, k, tau.z));
+}
 /* Transmittance::eval / surfaceProbability / mediumPdf (Transmittance.hpp:22-43) */
 static v3 trans_eval(const TgHipMedium *m, v3 tau, int startOnSurface, int endOnSurface)
 {
@@ -1741,6 +1764,16 @@ static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface
     case TGHIP_TRANS_DAVIS:                             /* :56-63 */
         return startOnSurface ? p[0]*(powf(1.0f - next1D(smp), -1.0f/p[0]) - 1.0f)
                               : p[0]*(powf(1.0f - next1D(smp), -1.0f/(1.0f + p[0])) - 1.0f);
+    case TGHIP_TRANS_DAVIS_WEINSTEIN: {                 /* :89-118: bisection on the cdf 1 - surfaceSurface / 1 - mediumSurface */
+        float xi = next1D(smp);
+        float step = 1e6f, result = step*2;
+        while (step > 1e-6) {
+            float cdf = 1.0f - trans_kernel(m, startOnSurface ? 0 : 2, result);
+            if (cdf > xi) result -= step; else result += step;
+            step /= 2;
+        }
+        return result;
+    }
     default:                                            /* ExponentialTransmittance.cpp:46-53 */
         return -logf(1.0f - next1D(smp));
     }

@@ -565,6 +565,12 @@ def _davis_fog(scene):
     scene["media"][-1]["transmittance"] = {"type": "davis", "alpha": 1.3}
 
 
+def _davis_weinstein_fog(scene):
+    _fog(scene)
+    scene["media"][-1]["transmittance"] = {"type": "davis_weinstein", "h": 0.8, "c": 1.2}
+
+
+GOLDEN_CASES["cornell_fog_davis_weinstein"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_davis_weinstein_fog))
 GOLDEN_CASES["cornell_fog_davis"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_davis_fog))
 GOLDEN_CASES["cornell_fog_rayleigh"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_rayleigh_fog))
 GOLDEN_CASES["cornell_fog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog))

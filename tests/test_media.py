@@ -101,7 +101,7 @@ import ctypes as _C
 from tungsten_amd import capi as _capi
 
 TRANSMITTANCES = {"exponential": (0, []), "linear": (1, [0.75]), "quadratic": (2, [0.75]), "double_exponential": (3, [1.0, 10.0]),
-                  "pulse": (4, [0.0, 1.0, 4.0]), "erlang": (5, [3.0]), "davis": (6, [1.6])}
+                  "pulse": (4, [0.0, 1.0, 4.0]), "erlang": (5, [3.0]), "davis": (6, [1.6]), "davis_weinstein": (7, [0.8, 1.2])}
 
 
 def _medium(kind):

@@ -1739,6 +1739,24 @@ PT_DEV float transKernel(const TgHipMedium &m, int k, float tau)
         if (k == 1 || k == 2) return powf(1.0f + tau/p0, -(p0 + 1.0f));
         return (1.0f + 1.0f/p0)*powf(1.0f + tau/p0, -(p0 + 2.0f));
     }
+    case TGHIP_TRANS_DAVIS_WEINSTEIN: {                 /* DavisWeinsteinTransmittance.cpp:39-82; NaN -> 0 */
+        float beta = 2.0f*p0 - 1.0f;
+        float alpha = powf(tau, 1 - beta)/powf(p1, 1 + beta);
+        float base = 1.0f + tau/alpha;
+        float trSurface = powf(base, -alpha), Tr;
+        if (k == 0) {
+            Tr = trSurface;
+        } else if (k == 1 || k == 2) {
+            Tr = trSurface*(beta/base - (beta - 1.0f)*alpha/tau*logf(base));
+        } else {
+            float logBase = logf(base);
+            float term1 = beta*(-1.0f + beta*(1.0f + tau) + (-1.0f + 2.0f*beta)*tau/alpha)/(tau*base*base);
+            float term2 = ((-1.0f + beta)*beta*alpha/(tau*tau)*(2.0f*tau + base)*logBase)/base;
+            float term3 = (beta - 1.0f)*alpha/tau*logBase;
+            Tr = trSurface*(term1 - term2 + term3*term3);
+        }
+        return isnan(Tr) ? 0.0f : Tr;
+    }
     default:                                            /* ExponentialTransmittance.cpp:26-41 */
         return expf(-tau);
     }
@@ -1754,7 +1772,12 @@ PT_DEV float transSigmaBar(const TgHipMedium &m)
     default: return 1.0f;
     }
 }
-PT_DEV f3 transKernel3(const TgHipMedium &m, int k, f3 tau) { return mk3(transKernel(m, k, tau.x), transKernel(m, k, tau.y), transKernel(m, k, tau.z)); }
+PT_DEV f3 transKernel3(const TgHipMedium &m, int k, f3 tau)
+{
+    if (m.trans_type == TGHIP_TRANS_DAVIS_WEINSTEIN)    /* evaluated on the first channel only and broadcast (:46-49) */
+        return splat3(transKernel(m, k, tau.x));
+    return mk3(transKernel(m, k, tau.x), transKernel(m, k, tau.y), transKernel(m, k, tau.z));
+}
 PT_DEV f3 transEval(const TgHipMedium &m, f3 tau, bool startOnSurface, bool endOnSurface)   /* Transmittance::eval (Transmittance.hpp:22-30) */
 {
     if (startOnSurface && endOnSurface) return transKernel3(m, 0, tau);
@@ -1808,6 +1831,16 @@ PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   
     }
     case TGHIP_TRANS_DAVIS:
         return startOnSurface ? p0*(powf(1.0f - RNG1D(rng), -1.0f/p0) - 1.0f) : p0*(powf(1.0f - RNG1D(rng), -1.0f/(1.0f + p0)) - 1.0f);
+    case TGHIP_TRANS_DAVIS_WEINSTEIN: {                 /* bisection on the cdf (:89-118) */
+        float xi = RNG1D(rng);
+        float step = 1e6f, result = step*2;
+        while (step > 1e-6) {
+            float cdf = 1.0f - transKernel(m, startOnSurface ? 0 : 2, result);
+            if (cdf > xi) result -= step; else result += step;
+            step /= 2;
+        }
+        return result;
+    }
     default:
         return -logf(1.0f - RNG1D(rng));
     }

@@ -593,6 +593,11 @@ std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
             m->transP[0] = 1.1f;
             if (obj) t.getField("alpha", m->transP[0]);
             if (m->transP[0] < 1 + 1e-6f) m->transP[0] = 1 + 1e-6f;
+        } else if (tt == "davis_weinstein") {                                   // DavisWeinsteinTransmittance.cpp:9-29
+            m->transType = 7;
+            m->transP[0] = 0.75f; m->transP[1] = 1.0f;
+            if (obj) { t.getField("h", m->transP[0]); t.getField("c", m->transP[1]); }
+            m->transP[0] = std::min(std::max(m->transP[0], 0.5f), 1.0f);
         } else {
             throw JsonLoadException("transmittance '" + tt + "' is not supported by path_tracer_hip");
         }
