@@ -164,7 +164,9 @@ typedef struct TgHipBsdf {
 enum { TGHIP_PHASE_ISOTROPIC = 0, TGHIP_PHASE_HENYEY_GREENSTEIN = 1, TGHIP_PHASE_RAYLEIGH = 2 };   /* phasefunctions/{Isotropic,HenyeyGreenstein,Rayleigh}PhaseFunction.cpp */
 /* transmittances/{Exponential,Linear,Quadratic,DoubleExponential,Pulse,Erlang,Davis,DavisWeinstein}Transmittance.cpp */
 enum { TGHIP_TRANS_EXPONENTIAL = 0, TGHIP_TRANS_LINEAR = 1, TGHIP_TRANS_QUADRATIC = 2, TGHIP_TRANS_DOUBLE_EXPONENTIAL = 3,
-       TGHIP_TRANS_PULSE = 4, TGHIP_TRANS_ERLANG = 5, TGHIP_TRANS_DAVIS = 6, TGHIP_TRANS_DAVIS_WEINSTEIN = 7 };
+       TGHIP_TRANS_PULSE = 4, TGHIP_TRANS_ERLANG = 5, TGHIP_TRANS_DAVIS = 6, TGHIP_TRANS_DAVIS_WEINSTEIN = 7,
+       TGHIP_TRANS_INTERPOLATED = 8 };      /* InterpolatedTransmittance.cpp: trans_p = {ratio}; its two operands _trA, _trB are the trans_type / trans_p of the
+                                               two media[] entries that FOLLOW this one (placeholders no primitive refers to; neither may be interpolated itself) */
 typedef struct TgHipMedium {
     float   sigma_a[3], sigma_s[3], sigma_t[3];   /* after prepareForRender: material sigma x density (HomogeneousMedium.cpp:43-49) */
     int32_t absorption_only;                      /* _sigmaS == 0 */

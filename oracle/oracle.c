@@ -1608,7 +1608,7 @@ static int selectMedium(const TgHipObject *o, int current, int geometricBackside
 
 /* ---- transmittances (transmittances/*.cpp): the four kernels surfaceSurface / surfaceMedium / mediumSurface / mediumMedium
  * of one channel, sigmaBar and the two distance samplers.  k: 0 = SS, 1 = SM, 2 = MS, 3 = MM. ---- */
-static float trans_kernel(const TgHipMedium *m, int k, float tau)
+static float trans_leaf_kernel(const TgHipMedium *m, int k, float tau)
 {
     const float *p = m->trans_p;
     switch (m->trans_type) {
@@ -1691,7 +1691,7 @@ static float trans_kernel(const TgHipMedium *m, int k, float tau)
         return expf(-tau);
     }
 }
-static float trans_sigmaBar(const TgHipMedium *m)
+static float trans_leaf_sigmaBar(const TgHipMedium *m)
 {
     switch (m->trans_type) {
     case TGHIP_TRANS_LINEAR: return 1.0f/m->trans_p[0];
@@ -1702,11 +1702,43 @@ static float trans_sigmaBar(const TgHipMedium *m)
     default: return 1.0f;
     }
 }
-static v3 trans_kernel3(const TgHipMedium *m, int k, v3 tau)
+static v3 trans_leaf_kernel3(const TgHipMedium *m, int k, v3 tau)
 {
     if (m->trans_type == TGHIP_TRANS_DAVIS_WEINSTEIN)    /* evaluated on the first channel only (tau[0]) and broadcast (:46-49) */
-        return vs(trans_kernel(m, k, tau.x));
-    return V(trans_kernel(m, k, tau.x), trans_kernel(m, k, tau.y), trans_kernel(m, k, tau.z));
+        return vs(trans_leaf_kernel(m, k, tau.x));
+    return V(trans_leaf_kernel(m, k, tau.x), trans_leaf_kernel(m, k, tau.y), trans_leaf_kernel(m, k, tau.z));
+}
+/* InterpolatedTransmittance (InterpolatedTransmittance.cpp:34-72): operands A = m[1], B = m[2] (include/tungsten_hip.h) */
+static inline float lerpf(float a, float b, float u) { return a*(1.0f - u) + b*u; }
+static int trans_isDirac(const TgHipMedium *m) { return m->trans_type == TGHIP_TRANS_LINEAR || m->trans_type == TGHIP_TRANS_PULSE; }
+static float trans_sigmaBar(const TgHipMedium *m)
+{
+    if (m->trans_type != TGHIP_TRANS_INTERPOLATED) return trans_leaf_sigmaBar(m);
+    return 1.0f/lerpf(1.0f/trans_leaf_sigmaBar(m + 1), 1.0f/trans_leaf_sigmaBar(m + 2), m->trans_p[0]);
+}
+/* a, b: the operands' kernel k (mediumSurface for k = 1: surfaceMedium = mediumSurface*sigmaBar) */
+static float trans_interpolate(const TgHipMedium *m, int k, float a, float b)
+{
+    const float u = m->trans_p[0];
+    if (k == 0) return trans_sigmaBar(m)*lerpf(a/trans_leaf_sigmaBar(m + 1), b/trans_leaf_sigmaBar(m + 2), u);
+    if (k == 1) return lerpf(a, b, u)*trans_sigmaBar(m);
+    if (k == 2) return lerpf(a, b, u);
+    int diracA = trans_isDirac(m + 1) && a > 0.0f, diracB = trans_isDirac(m + 2) && b > 0.0f;
+    if (diracA ^ diracB) return diracA ? a : b;
+    return lerpf(a, b, u);
+}
+static float trans_kernel(const TgHipMedium *m, int k, float tau)
+{
+    if (m->trans_type != TGHIP_TRANS_INTERPOLATED) return trans_leaf_kernel(m, k, tau);
+    int kk = k == 1 ? 2 : k;
+    return trans_interpolate(m, k, trans_leaf_kernel(m + 1, kk, tau), trans_leaf_kernel(m + 2, kk, tau));
+}
+static v3 trans_kernel3(const TgHipMedium *m, int k, v3 tau)
+{
+    if (m->trans_type != TGHIP_TRANS_INTERPOLATED) return trans_leaf_kernel3(m, k, tau);
+    int kk = k == 1 ? 2 : k;
+    v3 a = trans_leaf_kernel3(m + 1, kk, tau), b = trans_leaf_kernel3(m + 2, kk, tau);
+    return V(trans_interpolate(m, k, a.x, b.x), trans_interpolate(m, k, a.y, b.y), trans_interpolate(m, k, a.z, b.z));
 }
 /* Transmittance::eval / surfaceProbability / mediumPdf (Transmittance.hpp:22-43) */
 static v3 trans_eval(const TgHipMedium *m, v3 tau, int startOnSurface, int endOnSurface)
@@ -1716,7 +1748,7 @@ static v3 trans_eval(const TgHipMedium *m, v3 tau, int startOnSurface, int endOn
     return trans_kernel3(m, 2, tau);
 }
 /* Transmittance::sample = sampleSurface / sampleMedium */
-static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface)
+static float trans_leaf_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface)
 {
     const float *p = m->trans_p;
     switch (m->trans_type) {
@@ -1756,7 +1788,7 @@ static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface
         float xi = next1D(smp);
         float x = 0.5f;
         for (int i = 0; i < 10; ++i) {
-            x += (xi - (1.0f - trans_kernel(m, 0, x)))/trans_kernel(m, 1, x);
+            x += (xi - (1.0f - trans_leaf_kernel(m, 0, x)))/trans_leaf_kernel(m, 1, x);
             x = fmaxf(x, 0.0f);
         }
         return x;
@@ -1768,7 +1800,7 @@ static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface
         float xi = next1D(smp);
         float step = 1e6f, result = step*2;
         while (step > 1e-6) {
-            float cdf = 1.0f - trans_kernel(m, startOnSurface ? 0 : 2, result);
+            float cdf = 1.0f - trans_leaf_kernel(m, startOnSurface ? 0 : 2, result);
             if (cdf > xi) result -= step; else result += step;
             step /= 2;
         }
@@ -1777,6 +1809,12 @@ static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface
     default:                                            /* ExponentialTransmittance.cpp:46-53 */
         return -logf(1.0f - next1D(smp));
     }
+}
+
+static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface)   /* InterpolatedTransmittance.cpp:65-72 */
+{
+    if (m->trans_type != TGHIP_TRANS_INTERPOLATED) return trans_leaf_sample(m, smp, startOnSurface);
+    return nextBoolean(smp, m->trans_p[0]) ? trans_leaf_sample(m + 2, smp, startOnSurface) : trans_leaf_sample(m + 1, smp, startOnSurface);
 }
 
 /* HomogeneousMedium::sampleDistance (HomogeneousMedium.cpp:66-107); state.firstScatter plays "startOnSurface" */

@@ -571,6 +571,13 @@ def _davis_weinstein_fog(scene):
 
 
 GOLDEN_CASES["cornell_fog_davis_weinstein"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_davis_weinstein_fog))
+def _interpolated_fog(scene):
+    _fog(scene)
+    scene["media"][-1]["transmittance"] = {"type": "interpolated", "ratio": 0.35, "tr_a": {"type": "linear", "max_t": 2.0},
+                                           "tr_b": {"type": "erlang", "rate": 2.0}}
+
+
+GOLDEN_CASES["cornell_fog_interpolated"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_interpolated_fog))
 GOLDEN_CASES["cornell_fog_davis"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_davis_fog))
 GOLDEN_CASES["cornell_fog_rayleigh"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_rayleigh_fog))
 GOLDEN_CASES["cornell_fog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog))

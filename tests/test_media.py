@@ -101,15 +101,26 @@ import ctypes as _C
 from tungsten_amd import capi as _capi
 
 TRANSMITTANCES = {"exponential": (0, []), "linear": (1, [0.75]), "quadratic": (2, [0.75]), "double_exponential": (3, [1.0, 10.0]),
-                  "pulse": (4, [0.0, 1.0, 4.0]), "erlang": (5, [3.0]), "davis": (6, [1.6]), "davis_weinstein": (7, [0.8, 1.2])}
+                  "pulse": (4, [0.0, 1.0, 4.0]), "erlang": (5, [3.0]), "davis": (6, [1.6]), "davis_weinstein": (7, [0.8, 1.2]), "interpolated": (8, [0.35])}
 
 
 def _medium(kind):
-    m = _capi.TgHipMedium()
-    m.trans_type, p = TRANSMITTANCES[kind]
-    for i, v in enumerate(p):
-        m.trans_p[i] = v
-    return m
+    """The medium record of a transmittance; `interpolated`: followed by its two operands (include/tungsten_hip.h)."""
+    arr = (_capi.TgHipMedium*3)()
+    if kind == "interpolated":                       # 0.35 between linear (max_t 2) and erlang (rate 2)
+        arr[0].trans_type = 8
+        arr[0].trans_p[0] = 0.35
+        arr[1].trans_type, arr[1].trans_p[0] = 1, 2.0
+        arr[2].trans_type, arr[2].trans_p[0] = 5, 2.0
+    else:
+        arr[0].trans_type, p = TRANSMITTANCES[kind]
+        for i, v in enumerate(p):
+            arr[0].trans_p[i] = v
+    _KEEP.append(arr)
+    return arr[0]
+
+
+_KEEP = []
 
 
 def _kernel(m, k, taus):
@@ -132,13 +143,15 @@ def test_transmittance_kernels_are_consistent(kind):
     h = 1e-3
     if kind in ("linear", "quadratic"):
         taus = taus[np.abs(taus - 0.75) > 0.02]       # the kink at max_t
+    if kind == "interpolated":
+        taus = np.linspace(0.01, 1.9, 140)            # below its linear operand's max_t = 2
     ss = _kernel(m, 0, taus)
     assert abs(_kernel(m, 0, [0.0])[0] - 1.0) < 1e-6 and (np.diff(ss) <= 1e-6).all() and (ss >= -1e-6).all()
     if kind != "pulse":                              # (pulse: piecewise constant densities, compared through the samplers below)
         dss = -(_kernel(m, 0, taus + h) - _kernel(m, 0, taus - h))/(2*h)
         assert np.allclose(dss, _kernel(m, 1, taus), rtol=2e-2, atol=3e-3), kind
         assert abs(_kernel(m, 1, [1e-6])[0] - sigma_bar) < 1e-3*sigma_bar
-    if kind not in ("linear", "pulse"):              # their mediumMedium is a sum of Dirac deltas
+    if kind not in ("linear", "pulse", "interpolated"):   # their mediumMedium is (or contains) a sum of Dirac deltas
         dms = -(_kernel(m, 2, taus + h) - _kernel(m, 2, taus - h))/(2*h)
         assert np.allclose(dms, _kernel(m, 3, taus), rtol=2e-2, atol=3e-3), kind
 
@@ -148,6 +161,11 @@ def test_transmittance_kernels_are_consistent(kind):
 def test_transmittance_samplers_follow_their_kernels(kind, start_on_surface):
     """sampleSurface draws tau with P(tau > x) = surfaceSurface(x), sampleMedium with P(tau > x) = mediumSurface(x)
     (HomogeneousMedium::sampleDistance relies on exactly that: surfaceProbability / mediumPdf)."""
+    if kind == "interpolated" and start_on_surface:
+        # its sampleSurface is the ratio-mixture of the operands' samplers while surfaceSurface weights the operands by their
+        # sigmaBar (InterpolatedTransmittance.cpp:34-37, 65-68): not the same distribution unless the sigmaBars agree; the
+        # sampling weight of HomogeneousMedium::sampleDistance accounts for the difference
+        pytest.skip("the reference's interpolated sampleSurface is not distributed like its surfaceSurface")
     m = _medium(kind)
     n = 40000
     out = np.zeros(n, np.float32)
@@ -158,6 +176,8 @@ def test_transmittance_samplers_follow_their_kernels(kind, start_on_surface):
     xs = np.linspace(0.02, 1.3, 33)
     if kind in ("linear", "pulse") and not start_on_surface:
         xs = xs[np.abs((xs*8) % 1 - 0.5) > 0.1] if kind == "pulse" else xs[np.abs(xs - 0.75) > 0.02]   # away from the Dirac positions
+    if kind == "interpolated" and not start_on_surface:
+        xs = xs[np.abs(xs - 2.0) > 0.05]
     survival = np.array([(out > x).mean() for x in xs])
     expected = _kernel(m, 0 if start_on_surface else 2, xs)
     assert np.allclose(survival, expected, atol=4*np.sqrt(0.25/n) + 2e-3), (kind, start_on_surface, np.abs(survival - expected).max())

@@ -1681,7 +1681,7 @@ PT_DEV int selectMedium(const TgHipObject &o, int current, bool geometricBacksid
 
 /* The four kernels of a transmittance for one channel -- k: 0 = surfaceSurface, 1 = surfaceMedium, 2 = mediumSurface,
  * 3 = mediumMedium (transmittances/{Exponential,Linear,Quadratic,DoubleExponential,Pulse,Erlang}Transmittance.cpp) */
-PT_DEV float transKernel(const TgHipMedium &m, int k, float tau)
+PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
 {
     const float p0 = m.trans_p[0], p1 = m.trans_p[1], p2 = m.trans_p[2];
     switch (m.trans_type) {
@@ -1761,7 +1761,7 @@ PT_DEV float transKernel(const TgHipMedium &m, int k, float tau)
         return expf(-tau);
     }
 }
-PT_DEV float transSigmaBar(const TgHipMedium &m)
+PT_DEV float transLeafSigmaBar(const TgHipMedium &m)
 {
     switch (m.trans_type) {
     case TGHIP_TRANS_LINEAR: return 1.0f/m.trans_p[0];
@@ -1772,11 +1772,36 @@ PT_DEV float transSigmaBar(const TgHipMedium &m)
     default: return 1.0f;
     }
 }
-PT_DEV f3 transKernel3(const TgHipMedium &m, int k, f3 tau)
+PT_DEV f3 transLeafKernel3(const TgHipMedium &m, int k, f3 tau)
 {
     if (m.trans_type == TGHIP_TRANS_DAVIS_WEINSTEIN)    /* evaluated on the first channel only and broadcast (:46-49) */
-        return splat3(transKernel(m, k, tau.x));
-    return mk3(transKernel(m, k, tau.x), transKernel(m, k, tau.y), transKernel(m, k, tau.z));
+        return splat3(transLeafKernel(m, k, tau.x));
+    return mk3(transLeafKernel(m, k, tau.x), transLeafKernel(m, k, tau.y), transLeafKernel(m, k, tau.z));
+}
+/* InterpolatedTransmittance (InterpolatedTransmittance.cpp:34-72): its operands are the two media[] entries behind it */
+PT_DEV float lerpf(float a, float b, float u) { return a*(1.0f - u) + b*u; }
+PT_DEV bool transIsDirac(const TgHipMedium &m) { return m.trans_type == TGHIP_TRANS_LINEAR || m.trans_type == TGHIP_TRANS_PULSE; }
+PT_DEV float transSigmaBar(const TgHipMedium &m)
+{
+    if (m.trans_type != TGHIP_TRANS_INTERPOLATED) return transLeafSigmaBar(m);
+    return 1.0f/lerpf(1.0f/transLeafSigmaBar((&m)[1]), 1.0f/transLeafSigmaBar((&m)[2]), m.trans_p[0]);
+}
+PT_DEV float transInterpolate(const TgHipMedium &m, int k, float a, float b)   /* a, b: the operands' kernel k (mediumSurface for k = 1) */
+{
+    const float u = m.trans_p[0];
+    if (k == 0) return transSigmaBar(m)*lerpf(a/transLeafSigmaBar((&m)[1]), b/transLeafSigmaBar((&m)[2]), u);
+    if (k == 1) return lerpf(a, b, u)*transSigmaBar(m);
+    if (k == 2) return lerpf(a, b, u);
+    bool diracA = transIsDirac((&m)[1]) && a > 0.0f, diracB = transIsDirac((&m)[2]) && b > 0.0f;
+    if (diracA != diracB) return diracA ? a : b;
+    return lerpf(a, b, u);
+}
+PT_DEV f3 transKernel3(const TgHipMedium &m, int k, f3 tau)
+{
+    if (m.trans_type != TGHIP_TRANS_INTERPOLATED) return transLeafKernel3(m, k, tau);
+    const int kk = k == 1 ? 2 : k;
+    f3 a = transLeafKernel3((&m)[1], kk, tau), b = transLeafKernel3((&m)[2], kk, tau);
+    return mk3(transInterpolate(m, k, a.x, b.x), transInterpolate(m, k, a.y, b.y), transInterpolate(m, k, a.z, b.z));
 }
 PT_DEV f3 transEval(const TgHipMedium &m, f3 tau, bool startOnSurface, bool endOnSurface)   /* Transmittance::eval (Transmittance.hpp:22-30) */
 {
@@ -1785,7 +1810,7 @@ PT_DEV f3 transEval(const TgHipMedium &m, f3 tau, bool startOnSurface, bool endO
     return transKernel3(m, 2, tau);
 }
 template<uint32_t M>
-PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   /* sampleSurface / sampleMedium */
+PT_DEV float transLeafSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   /* sampleSurface / sampleMedium */
 {
     const float p0 = m.trans_p[0], p1 = m.trans_p[1], p2 = m.trans_p[2];
     switch (m.trans_type) {
@@ -1824,7 +1849,7 @@ PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   
         float xi = RNG1D(rng);
         float x = 0.5f;
         for (int i = 0; i < 10; ++i) {
-            x += (xi - (1.0f - transKernel(m, 0, x)))/transKernel(m, 1, x);
+            x += (xi - (1.0f - transLeafKernel(m, 0, x)))/transLeafKernel(m, 1, x);
             x = fmaxf(x, 0.0f);
         }
         return x;
@@ -1835,7 +1860,7 @@ PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   
         float xi = RNG1D(rng);
         float step = 1e6f, result = step*2;
         while (step > 1e-6) {
-            float cdf = 1.0f - transKernel(m, startOnSurface ? 0 : 2, result);
+            float cdf = 1.0f - transLeafKernel(m, startOnSurface ? 0 : 2, result);
             if (cdf > xi) result -= step; else result += step;
             step /= 2;
         }
@@ -1844,6 +1869,13 @@ PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   
     default:
         return -logf(1.0f - RNG1D(rng));
     }
+}
+
+template<uint32_t M>
+PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   /* InterpolatedTransmittance.cpp:65-72 */
+{
+    if (m.trans_type != TGHIP_TRANS_INTERPOLATED) return transLeafSample<M>(m, rng, startOnSurface);
+    return rngNextBoolean(rng, m.trans_p[0]) ? transLeafSample<M>((&m)[2], rng, startOnSurface) : transLeafSample<M>((&m)[1], rng, startOnSurface);
 }
 
 /* HomogeneousMedium::sampleDistance (:66-107).  maxT = ray.farT(); false = the path ends here ("return emission").

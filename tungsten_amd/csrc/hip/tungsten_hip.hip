@@ -560,11 +560,21 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 ctx->error = "primitive medium out of range";
                 return TGHIP_E_INVALID;
             }
-        for (uint32_t i = 0; i < sd->num_media; ++i)
+        for (uint32_t i = 0; i < sd->num_media; ++i) {
             if (sd->media[i].phase_type < TGHIP_PHASE_ISOTROPIC || sd->media[i].phase_type > TGHIP_PHASE_RAYLEIGH) {
                 ctx->error = "unknown phase function";
                 return TGHIP_E_UNSUPPORTED;
             }
+            if (sd->media[i].trans_type < TGHIP_TRANS_EXPONENTIAL || sd->media[i].trans_type > TGHIP_TRANS_INTERPOLATED) {
+                ctx->error = "unknown transmittance";
+                return TGHIP_E_UNSUPPORTED;
+            }
+            if (sd->media[i].trans_type == TGHIP_TRANS_INTERPOLATED &&
+                (i + 2 >= sd->num_media || sd->media[i + 1].trans_type == TGHIP_TRANS_INTERPOLATED || sd->media[i + 2].trans_type == TGHIP_TRANS_INTERPOLATED)) {
+                ctx->error = "an interpolated transmittance needs its two (non-interpolated) operands in the media entries behind it";
+                return TGHIP_E_INVALID;
+            }
+        }
     }
     ctx->thinlens = sd->camera.type == TGHIP_CAMERA_THINLENS;
     if (sd->camera.type != TGHIP_CAMERA_PINHOLE && sd->camera.type != TGHIP_CAMERA_THINLENS) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }

@@ -564,44 +564,55 @@ std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
     getVec3(v, "sigma_s", m->materialSigmaS);
     v.getField("density", m->density);
     v.getField("max_bounces", m->maxBounce);
-    if (const JsonValue &t = v["transmittance"]) {   // scene.fetchTransmittance (Medium.cpp:27-28); defaults from the constructors
+    // scene.fetchTransmittance (Medium.cpp:27-28); defaults from the constructors of transmittances/*.cpp
+    std::function<void(const JsonValue &, int &, float *, bool)> parseTransmittance = [&](const JsonValue &t, int &type, float *p, bool nested) {
         std::string tt = t.isString() ? t.asString() : t["type"].asString();
         const bool obj = t.isObject();
         if (tt == "exponential") {
-            m->transType = 0;
+            type = 0;
         } else if (tt == "linear" || tt == "quadratic") {                       // {Linear,Quadratic}Transmittance.cpp:12-22
-            m->transType = tt == "linear" ? 1 : 2;
-            m->transP[0] = 1.0f;
-            if (tt == "quadratic") m->transP[0] = 0.75f;
-            if (obj) t.getField("max_t", m->transP[0]);
+            type = tt == "linear" ? 1 : 2;
+            p[0] = 1.0f;
+            if (tt == "quadratic") p[0] = 0.75f;
+            if (obj) t.getField("max_t", p[0]);
         } else if (tt == "double_exponential") {                                // DoubleExponentialTransmittance.cpp:12-23
-            m->transType = 3;
-            m->transP[0] = 0.5f; m->transP[1] = 10.0f;
-            if (obj) { t.getField("sigma_a", m->transP[0]); t.getField("sigma_b", m->transP[1]); }
+            type = 3;
+            p[0] = 0.5f; p[1] = 10.0f;
+            if (obj) { t.getField("sigma_a", p[0]); t.getField("sigma_b", p[1]); }
         } else if (tt == "pulse") {                                             // PulseTransmittance.cpp:12-26
-            m->transType = 4;
-            m->transP[0] = 0.0f; m->transP[1] = 1.0f; m->transP[2] = 4.0f;
+            type = 4;
+            p[0] = 0.0f; p[1] = 1.0f; p[2] = 4.0f;
             int numPulses = 4;
-            if (obj) { t.getField("min", m->transP[0]); t.getField("max", m->transP[1]); t.getField("num_pulses", numPulses); }
-            m->transP[2] = float(numPulses);
+            if (obj) { t.getField("min", p[0]); t.getField("max", p[1]); t.getField("num_pulses", numPulses); }
+            p[2] = float(numPulses);
         } else if (tt == "erlang") {                                            // ErlangTransmittance.cpp:12-21
-            m->transType = 5;
-            m->transP[0] = 5.0f;
-            if (obj) t.getField("rate", m->transP[0]);
+            type = 5;
+            p[0] = 5.0f;
+            if (obj) t.getField("rate", p[0]);
         } else if (tt == "davis") {                                             // DavisTransmittance.cpp:7-25
-            m->transType = 6;
-            m->transP[0] = 1.1f;
-            if (obj) t.getField("alpha", m->transP[0]);
-            if (m->transP[0] < 1 + 1e-6f) m->transP[0] = 1 + 1e-6f;
+            type = 6;
+            p[0] = 1.1f;
+            if (obj) t.getField("alpha", p[0]);
+            if (p[0] < 1 + 1e-6f) p[0] = 1 + 1e-6f;
         } else if (tt == "davis_weinstein") {                                   // DavisWeinsteinTransmittance.cpp:9-29
-            m->transType = 7;
-            m->transP[0] = 0.75f; m->transP[1] = 1.0f;
-            if (obj) { t.getField("h", m->transP[0]); t.getField("c", m->transP[1]); }
-            m->transP[0] = std::min(std::max(m->transP[0], 0.5f), 1.0f);
+            type = 7;
+            p[0] = 0.75f; p[1] = 1.0f;
+            if (obj) { t.getField("h", p[0]); t.getField("c", p[1]); }
+            p[0] = std::min(std::max(p[0], 0.5f), 1.0f);
+        } else if (tt == "interpolated" && !nested) {                         // InterpolatedTransmittance.cpp:15-29
+            type = 8;
+            p[0] = 0.5f;
+            if (obj) {
+                t.getField("ratio", p[0]);
+                if (const JsonValue &a = t["tr_a"]) parseTransmittance(a, m->subType[0], m->subP[0], true);
+                if (const JsonValue &b = t["tr_b"]) parseTransmittance(b, m->subType[1], m->subP[1], true);
+            }
         } else {
             throw JsonLoadException("transmittance '" + tt + "' is not supported by path_tracer_hip");
         }
-    }
+    };
+    if (const JsonValue &t = v["transmittance"])
+        parseTransmittance(t, m->transType, m->transP, false);
     if (const JsonValue &ph = v["phase_function"]) {
         std::string pt = ph.isString() ? ph.asString() : ph["type"].asString();
         if (pt == "isotropic") m->phaseType = 0;

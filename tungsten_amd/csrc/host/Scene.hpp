@@ -80,6 +80,9 @@ struct Medium   // media/HomogeneousMedium.{hpp,cpp} + Medium.cpp + transmittanc
     float phaseG = 0.0f;
     int transType = 0;          // TGHIP_TRANS_*: exponential, linear, quadratic, double_exponential, pulse, erlang
     float transP[3] = {0.0f, 0.0f, 0.0f};
+    // interpolated (transType 8): transP[0] = ratio, operands _trA / _trB (InterpolatedTransmittance.cpp:15-29)
+    int subType[2] = {1, 5};
+    float subP[2][3] = {{1.0f, 0.0f, 0.0f}, {5.0f, 0.0f, 0.0f}};
     // prepareForRender (HomogeneousMedium.cpp:43-49)
     Vec3f sigmaA, sigmaS, sigmaT;
     bool absorptionOnly = false;

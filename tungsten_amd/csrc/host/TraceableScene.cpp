@@ -152,7 +152,19 @@ void TraceableScene::flatten()
         for (int k = 0; k < 3; ++k) d.trans_p[k] = m->transP[k];
         mediumKeys.push_back(m.get());
         _media.push_back(d);
-        return int32_t(_media.size() - 1);
+        const int32_t index = int32_t(_media.size() - 1);
+        if (m->transType == TGHIP_TRANS_INTERPOLATED) {
+            // the operands of an interpolated transmittance ride in the two entries behind it (include/tungsten_hip.h)
+            for (int k = 0; k < 2; ++k) {
+                TgHipMedium sub;
+                std::memset(&sub, 0, sizeof(sub));
+                sub.trans_type = m->subType[k];
+                for (int j = 0; j < 3; ++j) sub.trans_p[j] = m->subP[k][j];
+                mediumKeys.push_back(nullptr);
+                _media.push_back(sub);
+            }
+        }
+        return index;
     };
     for (auto &m : _scene.media)
         addMedium(m);
