@@ -254,3 +254,32 @@ def test_resume_reproduces_the_uninterrupted_render(adaptive, tmp_path):
     r = tg.Renderer(scenes.cornell(tmp_path, name="uniform.json", resolution=(w, h), spp=spp, spp_step=step, renderer=rend2), seed=SEED)
     assert not r.resume()
     r.close()
+    r = tg.Renderer(path, seed=SEED + 1)               # another sampler seed is another render
+    assert not r.resume()
+    r.close()
+
+
+def test_resume_refuses_a_changed_medium(tmp_path):
+    """The resume guard hashes every array of the flattened scene, media included (the reference hashes the whole scene JSON
+    minus the renderer block, Integrator.cpp:92-106): a state saved in thin fog does not resume in thick fog."""
+    w, h, spp, step = 48, 27, 8, 4
+    state = str(tmp_path/"state.dat")
+    rend = {"adaptive_sampling": False, "stratified_sampler": False, "enable_resume_render": True, "resume_render_file": state}
+
+    def fog(sigma):
+        def edit(scene):
+            scenes._fog(scene)
+            scene["media"][0]["sigma_s"] = sigma
+        return edit
+    path = scenes.cornell(tmp_path, name="fog_a.json", resolution=(w, h), spp=spp, spp_step=step, renderer=rend, edit=fog(0.05))
+    r = tg.Renderer(path, seed=SEED)
+    r.step()
+    r.save_resume_data()
+    r.close()
+    r = tg.Renderer(path, seed=SEED)
+    assert r.resume() and r.current_spp == step
+    r.close()
+    other = scenes.cornell(tmp_path, name="fog_b.json", resolution=(w, h), spp=spp, spp_step=step, renderer=rend, edit=fog(0.5))
+    r = tg.Renderer(other, seed=SEED)
+    assert not r.resume() and r.current_spp == 0
+    r.close()

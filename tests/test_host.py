@@ -124,6 +124,19 @@ def test_json_errors_are_reported(tmp_path):
     assert "hair" in str(e.value)
 
 
+def test_bump_maps_are_refused_not_dropped(tmp_path):
+    # Primitive::setupTangentFrame (Primitive.cpp:125-163): a varying bump texture perturbs the shading frame; a constant
+    # one changes nothing (:130).  The first is outside this integrator's scope and must not render unperturbed.
+    def checker_bump(scene):
+        scene["bsdfs"][0]["bump"] = {"type": "checker", "on_color": 1.0, "off_color": 0.0, "res_u": 4, "res_v": 4}
+    with pytest.raises(tg.TungstenError) as e:
+        tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, edit=checker_bump, name="bump.json"))
+    assert "bump" in str(e.value)
+    def constant_bump(scene):
+        scene["bsdfs"][0]["bump"] = 0.5
+    tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, edit=constant_bump, name="bump_const.json")).close()
+
+
 def test_pfm_round_trip(tmp_path):
     img = np.random.RandomState(1).rand(5, 7, 3).astype(np.float32)
     path = str(tmp_path/"a.pfm")

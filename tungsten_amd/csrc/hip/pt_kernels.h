@@ -108,7 +108,8 @@ struct PathState {
     float4 * __restrict__ partial;         // per work item: radiance sum, count (uint bits)
     BlockCtl * __restrict__ ctl;
     BlockStats * __restrict__ stats;
-    uint32_t * __restrict__ live;          // [0] = tag of the last iteration that left work in some extension queue; [1] = abort flag
+    uint32_t * __restrict__ live;          // [0] = tag of the last iteration that left work in some extension queue
+    const uint32_t * __restrict__ abort_flag;   // non-zero: tghip_abort was called (one word that lives as long as the context, outside the pool)
     uint32_t num_slots, slots_per_block;
     uint32_t leaf_batch;                   // dynamic-fetch traversal: lanes waiting at a leaf before the leaf code runs (1 = at once)
 };

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
 
   for (;;) {                                     // one wavefront iteration per turn (a single turn unless FUSE_LOOP)
     const uint32_t n = DIRECT ? st.slots_per_block : L.n;
-    const bool aborted = __hip_atomic_load(&st.live[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const bool aborted = __hip_atomic_load(st.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     for (uint32_t base = 0, turn = 0; base < n; base += blockDim.x, ++turn) {
         uint32_t i = base + threadIdx.x;
         PROF(0);
@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
     const uint32_t n = L.n;
     const OrderRegs ord = orderPreload(reinterpret_cast<unsigned short *>(ldsStack), n);
     const uint32_t first = blockIdx.x*st.slots_per_block;
-    const bool aborted = st.live[1] != 0;
+    const bool aborted = __hip_atomic_load(st.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     uint32_t nodes = 0, prims = 0, rays = 0, slots = 0, finishedCount = 0;
     for (uint32_t base = 0, k = 0; base < n; base += blockDim.x, ++k) {
         uint32_t i = base + threadIdx.x;
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, Pas
     queuesBegin(L, st, ctl, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP), order);
     const uint32_t nf = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
-    const bool aborted = st.live[1] != 0;
+    const bool aborted = __hip_atomic_load(st.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     uint32_t finishedCount = 0;
     for (uint32_t base = 0; base < nf; base += blockDim.x) {
         uint32_t i = base + threadIdx.x;

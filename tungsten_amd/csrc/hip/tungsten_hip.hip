@@ -3,6 +3,8 @@
 #define PT_WAVEFRONT_MAIN
 #include "pt_wavefront.h"
 
+#include <atomic>
+
 // The k_shade variants are instantiated in shade_simple.hip / shade_class.hip / shade_full.hip (parallel compilation).
 extern template __global__ void k_shade<MASK_LEAN, LEAN_WAVES, 0>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<(MASK_LEAN | FEAT_QMC), LEAN_WAVES, 0>(DeviceScene, PathState, PassParams, int);
@@ -123,6 +125,15 @@ struct tghip_ctx {
     bool dynamicFetch = true;             // BVH scenes: closest-hit kernel with dynamic ray fetch (k_trace_closest_dyn)
     bool timeKernels = false;             // HIP events around every launch of the wavefront loop (bench.py roofline)
     std::vector<hipEvent_t> evPool;
+
+    // abort (PathTraceIntegrator::abortRender): a host-side request flag, mirrored into one device word the kernels poll.
+    // The word is allocated once per context (never with the reallocatable pool), so tghip_abort may write it from any
+    // thread at any time; the request is cleared by tghip_render_pass only, so one that lands before the pass's kernels
+    // have started is not lost.
+    std::atomic<bool> abortRequested{false};
+    uint32_t *abortFlagDev = nullptr;
+    hipStream_t abortStream = nullptr;
+    std::mutex abortMutex;                // serialises tghip_abort callers (they share abortStream)
 
     // async pass state
     bool passPending = false;
@@ -339,11 +350,12 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     p.stride = uint32_t(strideBytes);
     POOL_ALLOC(bm, size_t(slots/32)*Q_COUNT);
     p.bmStride = slots/32;
-    POOL_ALLOC(ctl, grid); POOL_ALLOC(stats, grid); POOL_ALLOC(live, 2);
+    POOL_ALLOC(ctl, grid); POOL_ALLOC(stats, grid); POOL_ALLOC(live, 1);
 #undef POOL_ALLOC
     HIP_TRY(ctx, hipMemsetAsync(p.ctl, 0, sizeof(BlockCtl)*grid, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(p.stats, 0, sizeof(BlockStats)*grid, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(p.live, 0, 2*sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(p.live, 0, sizeof(uint32_t), ctx->stream));
+    p.abort_flag = ctx->abortFlagDev;
     p.num_slots = slots;
     p.slots_per_block = perBlock;
     ctx->poolSlots = slots;
@@ -424,6 +436,9 @@ tghip_ctx *tghip_create(int device_ordinal)
     if (e == hipSuccess) e = hipEventCreate(&ctx->evA);
     if (e == hipSuccess) e = hipEventCreate(&ctx->evB);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->hostLive), 2*sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->abortStream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->abortFlagDev), 64);
+    if (e == hipSuccess) e = hipMemset(ctx->abortFlagDev, 0, 64);
     if (e != hipSuccess) {
         std::lock_guard<std::mutex> lock(g_errMutex);
         g_createError = std::string("tghip_create: ") + hipGetErrorString(e);
@@ -450,6 +465,8 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->dAux) (void)hipFree(ctx->dAux);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->hostLive) (void)hipHostFree(ctx->hostLive);
+    if (ctx->abortFlagDev) (void)hipFree(ctx->abortFlagDev);
+    if (ctx->abortStream) (void)hipStreamDestroy(ctx->abortStream);
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
@@ -504,6 +521,39 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if (sd->num_recs >= (1u << 26) || sd->num_nodes >= (1u << 26)) {   // 64-B attribute / node records behind 32-bit byte offsets (at32)
         ctx->error = "more than 2^26 primitive records or BVH nodes are not supported";
         return TGHIP_E_UNSUPPORTED;
+    }
+    // every index the shim (or a kernel) dereferences on the caller's word: refuse a malformed description instead of
+    // reading out of bounds
+    {
+        auto bad = [&](const char *what) { ctx->error = std::string("malformed scene description: ") + what; return TGHIP_E_INVALID; };
+        if ((sd->num_recs && (!sd->recs || !sd->tri_attrs)) || (sd->num_objects && !sd->objects) || (sd->num_bsdfs && !sd->bsdfs) ||
+            (sd->num_textures && !sd->textures) || (sd->num_lights && !sd->lights) || (sd->num_infinite_lights && !sd->infinite_lights))
+            return bad("a non-empty array is NULL");
+        for (uint32_t i = 0; i < sd->num_lights; ++i)
+            if (sd->lights[i] < 0 || uint32_t(sd->lights[i]) >= sd->num_objects) return bad("lights[] entry out of range");
+        for (uint32_t i = 0; i < sd->num_infinite_lights; ++i)
+            if (sd->infinite_lights[i] < 0 || uint32_t(sd->infinite_lights[i]) >= sd->num_objects) return bad("infinite_lights[] entry out of range");
+        for (uint32_t i = 0; i < sd->num_recs; ++i) {
+            const uint32_t kind = TGHIP_REC_KIND(sd->recs[i].meta);
+            if (kind > TGHIP_REC_CYLINDER) return bad("unknown primitive record kind");
+            if (TGHIP_REC_OBJECT(sd->recs[i].meta) >= sd->num_objects) return bad("primitive record refers to an object out of range");
+        }
+        for (uint32_t i = 0; i < sd->num_objects; ++i) {
+            const TgHipObject &o = sd->objects[i];
+            if (o.bsdf < -1 || o.bsdf >= int32_t(sd->num_bsdfs)) return bad("object bsdf out of range");
+            if (o.emission < -1 || o.emission >= int32_t(sd->num_textures)) return bad("object emission texture out of range");
+            if (o.light < -1 || o.light >= int32_t(sd->num_lights)) return bad("object light index out of range");
+            if (o.int_medium < -1 || o.ext_medium < -1 || o.int_medium >= int32_t(sd->num_media) || o.ext_medium >= int32_t(sd->num_media))
+                return bad("primitive medium out of range");
+        }
+        for (uint32_t i = 0; i < sd->num_bsdfs; ++i) {
+            const TgHipBsdf &b = sd->bsdfs[i];
+            const int32_t nt = int32_t(sd->num_textures), nb = int32_t(sd->num_bsdfs);
+            if (b.albedo < -1 || b.albedo >= nt || b.roughness < -1 || b.roughness >= nt || b.tex1 < -1 || b.tex1 >= nt)
+                return bad("bsdf texture out of range");
+            if (b.sub0 < -1 || b.sub0 >= nb || b.sub1 < -1 || b.sub1 >= nb) return bad("nested bsdf out of range");
+        }
+        if (sd->camera.medium < -1 || sd->camera.medium >= int32_t(sd->num_media)) return bad("camera medium out of range");
     }
     int depth = bvhDepthOf(sd);
     if (depth < 0 || depth > TGHIP_MAX_BVH_DEPTH) { ctx->error = "malformed or too deep BVH"; return TGHIP_E_INVALID; }
@@ -758,8 +808,11 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
 // Runs the wavefront loop for one batch of work items until every slot is drained.
 static int runBatch(tghip_ctx *ctx, const PassParams &pp)
 {
+    if (ctx->abortRequested.load(std::memory_order_acquire))
+        return TGHIP_E_ABORTED;                  // aborted before this batch started: nothing to drain
     PathState st = ctx->pool;
     st.partial = ctx->partial;
+    st.abort_flag = ctx->abortFlagDev;
     st.leaf_batch = uint32_t(ctx->leafBatch);
     const DeviceScene &s = ctx->scene;
     const int grid = int(ctx->poolGrid);
@@ -792,7 +845,11 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     for (;;) {
         evUsed = 0;
         {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->hostLive, st.live, 2*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            // an abort request that arrived since the last check (or before the pass's first launch): make sure the device
+            // word is set -- in stream order, so the launches below see it and drain their slots
+            if (ctx->abortRequested.load(std::memory_order_acquire))
+                HIP_TRY(ctx, hipMemsetAsync(ctx->abortFlagDev, 0xFF, sizeof(uint32_t), ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->hostLive, st.live, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (timing && !first) {
                 double *acc[3] = {&ctx->counters.ms_trace_closest, &ctx->counters.ms_shade, &ctx->counters.ms_trace_shadow};
@@ -881,7 +938,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     if (pp.rec_sorted) hipLaunchKernelGGL(k_resolve_records, dim3((pp.num_sorted*16u + 255)/256), dim3(256), 0, ctx->stream, st, pp, sum, cnt);
     else               hipLaunchKernelGGL(k_resolve, dim3((pp.pix_slots + 255)/256), dim3(256), 0, ctx->stream, st, pp, sum, cnt);
     HIP_TRY(ctx, hipGetLastError());
-    return ctx->hostLive[1] ? TGHIP_E_ABORTED : TGHIP_OK;
+    return ctx->abortRequested.load(std::memory_order_acquire) ? TGHIP_E_ABORTED : TGHIP_OK;
 }
 
 // The pass itself is driven synchronously from tghip_wait (the integrator calls it from its worker
@@ -903,6 +960,7 @@ int tghip_render_pass(tghip_ctx *ctx, const TgHipPassDesc *pass)
         ctx->error = "record_index and record_count go together and need TGHIP_PASS_RECORDS";
         return TGHIP_E_INVALID;
     }
+    ctx->abortRequested.store(false, std::memory_order_release);   // the only place a request is cleared
     ctx->passPending = true;
     ctx->passResult = TGHIP_OK;
     ctx->pendingPass = *pass;
@@ -1076,7 +1134,8 @@ int tghip_wait(tghip_ctx *ctx)
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->partial), batchItems*sizeof(float4)));
         ctx->partialCap = batchItems;
     }
-    HIP_TRY(ctx, hipMemsetAsync(&ctx->pool.live[1], 0, sizeof(uint32_t), ctx->stream));   // abort flag
+    // the device word still holds the previous pass's abort, if any; a request for THIS pass is re-mirrored by runBatch
+    HIP_TRY(ctx, hipMemsetAsync(ctx->abortFlagDev, 0, sizeof(uint32_t), ctx->stream));
 
     HIP_TRY(ctx, hipEventRecord(ctx->evA, ctx->stream));
     for (uint64_t w0 = 0; recordPass && w0 < recordItems && rc == TGHIP_OK; w0 += batchItems) {
@@ -1129,17 +1188,16 @@ int tghip_wait(tghip_ctx *ctx)
 int tghip_abort(tghip_ctx *ctx)
 {
     if (!ctx) return TGHIP_E_INVALID;
-    if (!ctx->poolSlots) return TGHIP_OK;
-    // device-visible flag polled whenever a slot asks for new work; written from a second stream so it
-    // does not queue behind the running pass
+    // The request itself is host state: tghip_wait looks at it before every batch and at every liveness check, so it holds
+    // even when no kernel of the pass has been launched yet.  The device word (polled whenever a slot asks for new work) is
+    // written from a stream of its own so that the copy does not queue behind the running pass.
+    ctx->abortRequested.store(true, std::memory_order_release);
+    std::lock_guard<std::mutex> lock(ctx->abortMutex);
     static const uint32_t one = 1;
-    hipStream_t side = nullptr;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    hipError_t e = hipMemcpyAsync(&ctx->pool.live[1], &one, sizeof(one), hipMemcpyHostToDevice, side);
-    if (e == hipSuccess) e = hipStreamSynchronize(side);
-    (void)hipStreamDestroy(side);
-    if (e != hipSuccess) { ctx->error = hipGetErrorString(e); return TGHIP_E_HIP; }
+    hipError_t e = hipMemcpyAsync(ctx->abortFlagDev, &one, sizeof(one), hipMemcpyHostToDevice, ctx->abortStream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->abortStream);
+    if (e != hipSuccess) return TGHIP_E_HIP;    // (ctx->error belongs to the thread driving the pass)
     return TGHIP_OK;
 }
 

@@ -168,21 +168,34 @@ static uint64_t fnv1a(uint64_t h, const void *data, size_t bytes)
     for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ull; }
     return h;
 }
-static uint64_t sceneHash(const TgHipSceneDesc &d)
+// Every array and every scalar block of TgHipSceneDesc goes through this one function, plus the sampler seed.
+static uint64_t sceneHash(const TgHipSceneDesc &d, uint32_t seed)
 {
     uint64_t h = 14695981039346656037ull;
-    h = fnv1a(h, d.nodes, size_t(d.num_nodes)*sizeof(TgHipBvhNode));
-    h = fnv1a(h, d.recs, size_t(d.num_recs)*sizeof(TgHipPrimRec));
-    h = fnv1a(h, d.tri_attrs, size_t(d.num_recs)*sizeof(TgHipTriAttr));
-    h = fnv1a(h, d.objects, size_t(d.num_objects)*sizeof(TgHipObject));
-    h = fnv1a(h, d.lights, size_t(d.num_lights)*sizeof(int32_t));
-    h = fnv1a(h, d.infinite_lights, size_t(d.num_infinite_lights)*sizeof(int32_t));
-    h = fnv1a(h, d.bsdfs, size_t(d.num_bsdfs)*sizeof(TgHipBsdf));
-    h = fnv1a(h, d.textures, size_t(d.num_textures)*sizeof(TgHipTexture));
-    h = fnv1a(h, d.texels, size_t(d.num_texel_floats)*sizeof(float));
-    h = fnv1a(h, d.light_tris, size_t(d.num_light_tri_floats)*sizeof(float));
+    auto arr = [&h](const void *p, uint64_t count, size_t elem) {
+        h = fnv1a(h, &count, sizeof(count));
+        if (p && count) h = fnv1a(h, p, size_t(count)*elem);
+    };
+    arr(d.nodes, d.num_nodes, sizeof(TgHipBvhNode));
+    arr(d.recs, d.num_recs, sizeof(TgHipPrimRec));
+    arr(d.tri_attrs, d.num_recs, sizeof(TgHipTriAttr));
+    arr(d.objects, d.num_objects, sizeof(TgHipObject));
+    arr(d.lights, d.num_lights, sizeof(int32_t));
+    arr(d.infinite_lights, d.num_infinite_lights, sizeof(int32_t));
+    arr(d.bsdfs, d.num_bsdfs, sizeof(TgHipBsdf));
+    arr(d.textures, d.num_textures, sizeof(TgHipTexture));
+    arr(d.texels, d.num_texel_floats, sizeof(float));
+    arr(d.dist, d.num_dist_floats, sizeof(float));
+    arr(d.light_tris, d.num_light_tri_floats, sizeof(float));
+    arr(d.media, d.num_media, sizeof(TgHipMedium));
+    arr(nullptr, d.num_instances, 0);
+    arr(nullptr, d.num_top_recs, 0);
+    arr(nullptr, d.sobol_matrices ? d.num_sobol_words : 0, 0);   // (the matrices are a constant table)
     h = fnv1a(h, &d.camera, sizeof(d.camera));
     h = fnv1a(h, &d.settings, sizeof(d.settings));
+    h = fnv1a(h, d.bounds_lo, sizeof(d.bounds_lo));
+    h = fnv1a(h, d.bounds_hi, sizeof(d.bounds_hi));
+    h = fnv1a(h, &seed, sizeof(seed));
     return h;
 }
 
@@ -200,7 +213,7 @@ void Integrator::saveRenderResumeData()
     std::vector<uint32_t> count;
     currentFramebuffer(sum, count);
     uint32_t header[5] = {_currentSpp, rs.useAdaptiveSampling ? 1u : 0u, rs.useSobol ? 1u : 0u, _scene->cam().resX, _scene->cam().resY};
-    uint64_t hash = sceneHash(_scene->desc());
+    uint64_t hash = sceneHash(_scene->desc(), samplerSeed());
     out.write(ResumeMagic, sizeof(ResumeMagic));
     out.write(reinterpret_cast<const char *>(header), sizeof(header));
     out.write(reinterpret_cast<const char *>(&hash), sizeof(hash));
@@ -232,7 +245,7 @@ bool Integrator::resumeRender()
         return false;
     if (header[1] != (rs.useAdaptiveSampling ? 1u : 0u) || header[2] != (rs.useSobol ? 1u : 0u))
         return false;
-    if (header[3] != _scene->cam().resX || header[4] != _scene->cam().resY || hash != sceneHash(_scene->desc()))
+    if (header[3] != _scene->cam().resX || header[4] != _scene->cam().resY || hash != sceneHash(_scene->desc(), samplerSeed()))
         return false;
     size_t n = size_t(header[3])*header[4];
     std::vector<float> sum(n*3);
@@ -375,7 +388,7 @@ void PathTraceHipIntegrator::startRender(std::function<void()> completionCallbac
             t.join();
         try {
             for (size_t d = 0; d < _ctxs.size(); ++d) {
-                if (rcs[d] == TGHIP_E_ABORTED)
+                if (rcs[d] == TGHIP_E_ABORTED || _abort)
                     return;   // no finisher / callback on abort (TaskGroup.hpp:33-41,77-83)
                 check(rcs[d], _ctxs[d], "tghip_wait");
             }

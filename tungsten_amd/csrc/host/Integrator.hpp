@@ -61,6 +61,9 @@ public:
     // per-pixel mean radiance, row-major, y down (Camera::getLinear, cameras/Camera.hpp:163-172)
     virtual const std::vector<float> &linearImage() = 0;
 
+    // seed of the per-path sample streams: part of what a resume file must agree on (sceneHash)
+    virtual uint32_t samplerSeed() const { return 0; }
+
     void saveOutputs();                                                   // Integrator.cpp:82-85
     void saveCheckpoint();                                                // Integrator.cpp:87-90
     void saveRenderResumeData();                                          // Integrator.cpp:108-128
@@ -106,6 +109,7 @@ public:
     void waitForCompletion() override;
     void abortRender() override;
     const std::vector<float> &linearImage() override;
+    uint32_t samplerSeed() const override { return _seed; }
     bool supportsResumeRender() const override { return true; }          // PathTraceIntegrator.cpp:215-218
     void saveState(std::ostream &out) override;                           // PathTraceIntegrator.cpp:158-172 (records + samplers)
     void loadState(std::istream &in) override;

@@ -440,7 +440,14 @@ std::shared_ptr<Bsdf> Scene::instantiateBsdf(const JsonValue &v) const
     auto b = std::make_shared<Bsdf>();
     std::string type = v["type"].asString();
     v.getField("name", b->name);
-    // Bsdf::fromJson (Bsdf.cpp:19-25); bump maps are not in the hot-path scope
+    // Bsdf::fromJson (Bsdf.cpp:19-25).  A constant bump texture changes nothing (Primitive::setupTangentFrame ignores it,
+    // Primitive.cpp:130); a varying one perturbs the shading frame (:139-152), which this integrator does not do: refuse it
+    // rather than render the surface unperturbed.
+    if (const JsonValue &bump = v["bump"]) {
+        std::shared_ptr<Texture> t = fetchTexture(bump, false);
+        if (t && t->type != Texture::Constant)
+            throw JsonLoadException("bsdf '" + b->name + "': bump maps are outside the path_tracer_hip hot-path scope");
+    }
     if (const JsonValue &albedo = v["albedo"]) b->albedo = fetchTexture(albedo, true);
     else b->albedo = constantTexture(1.0f);
 
