@@ -10,10 +10,12 @@ tghip_render_pass(spp 0..S) + tghip_wait on every rank's tile shard (16x16 tiles
 SURVEY.md 8e) and, for N > 1, the RCCL sum-reduce of the float framebuffer to rank 0.  The scene is
 flattened and uploaded before the timed region (inputs resident in HBM); the framebuffer stays in HBM.
 
-Workload at every N: BASELINE.json configs[1], Cornell box 1280x720 at 256 spp (fixed total work =>
-"scaling": "strong").  At N = 1 the same line carries, under "extra", a shorter run of the scene the metric
-names (materialtest.json at 1280x720, 64 spp) when its assets are present; `--scene materialtest` makes
-that scene the headline workload instead.
+Workload at every N: the configuration BASELINE.json's metric is quoted on -- materialtest.json (the reference's shipped
+scene: three meshes, 80 768 triangles, smooth_coat over rough_conductor, HDRI environment + MIS) at 1280x720, 256 spp,
+uniform sampler, adaptive sampling off (fixed total work => "scaling": "strong").  At N = 1 the same line carries, under
+"extra", BASELINE configs[1] (Cornell box 1280x720 at 256 spp, a flat-list scene without BVH traversal); `--scene cornell`
+makes that the headline workload instead.  Without the materialtest assets (oracle/_ref/data, copied from the reference's
+data directory by __graft_entry__.build()) the default falls back to the Cornell box and says so in config.workload.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest accumulated time:
 achieved = algorithmic bytes per launch / average launch duration, both from the timed region (HIP events
@@ -44,15 +46,17 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "materialtest", "mesh1m", "instances10k"])
+    ap.add_argument("--scene", default="materialtest", choices=["cornell", "materialtest", "mesh1m", "instances10k"])
     ap.add_argument("--material", default="shipped", choices=["shipped", "dielectric", "rough_dielectric"],
                     help="materialtest only: the \"Material\" bsdf (BASELINE configs[2] names rough-conductor -- the shipped one -- and dielectric)")
     ap.add_argument("--res", default="1280x720")
-    ap.add_argument("--spp", type=int, default=0, help="default: 256 (cornell) / 64 (materialtest)")
+    ap.add_argument("--spp", type=int, default=0, help="default: 256 (materialtest, cornell) / 32 (mesh1m, instances10k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary materialtest run")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary Cornell-box run")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the cpu_baseline sample (three runs of two builds together)")
+    ap.add_argument("--no-traffic", dest="traffic", action="store_false",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--opt", action="append", default=[], help="shim option key=value (tghip_set_option)")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="development aid: on ONE GPU render only shard 0 of N tile shards (what each rank of an N-GPU run does)")
@@ -239,7 +243,10 @@ class Bench(object):
                                   "bytes_per_launch": round(bytes_per_launch), "gbs": round(bytes_per_launch/avg_s*1e-9, 1)}
             roofline = None
             if kernels:
-                dom = max(kernels, key=lambda k: kernels[k]["ms_total"])
+                # BVH scenes: the traversal kernel with the largest accumulated time (BASELINE.json's metric asks for the
+                # traversal kernel's achieved GB/s); flat-list scenes have one fused kernel
+                trav = [k for k in kernels if k.startswith("k_trace")]
+                dom = max(trav or list(kernels), key=lambda k: kernels[k]["ms_total"])
                 kd = kernels[dom]
                 roofline = {"bound": "hbm", "kernel": dom + (" (trace + shade + shadow fused, flat-list scene)" if fused else ""),
                             "achieved": kd["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kd["gbs"]/HBM_PEAK_GBS, 4),
@@ -249,15 +256,8 @@ class Bench(object):
                 if fused:
                     roofline["note"] = ("instruction-bound, not HBM-bound (profiles/sq_counters.json): exact fp32 division/sqrt/sin/cos and -ffp-contract=off for parity "
                                         "with the CPU reference (DESIGN.md sections 5, 7)")
-                tr = os.path.join(ROOT, "profiles", "traffic.json")
-                if os.path.exists(tr):
-                    try:
-                        t = json.load(open(tr)).get("%s/%s" % (scene, dom))
-                        if t:
-                            roofline["traffic"] = t["hbm_bytes_per_launch"]
-                            roofline["traffic_source"] = t.get("source")
-                    except Exception:
-                        pass
+                if a.traffic and self.world == 1:
+                    roofline.update(measure_traffic(a, scene, w, h, spp, dom, self.tmp))
             rays = max(cc["closest_rays"] + cc["shadow_rays"], 1)
             out = {
                 "value": round(value, 2), "ms_per_step": round(elapsed/steps*1e3, 3),
@@ -281,34 +281,95 @@ class Bench(object):
         return out
 
 
+def measure_traffic(a, scene, w, h, spp, kernel, tmp):
+    """HBM bytes per launch of `kernel`, measured in THIS run: two child runs of this script under `rocprofv3 --pmc`
+    (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots") on the same scene at a
+    fraction of the spp (counter collection serialises dispatches), then (2*FETCH_SIZE + WRITE_SIZE)*1024: KiB units, read
+    side doubled on gfx950 as MI355X_MICROARCH.md "HBM" prescribes.  Returns the roofline fields; traffic None on failure."""
+    import csv
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return {"traffic": None, "traffic_source": "rocprofv3 not found"}
+    pmc_spp = max(4, spp//8) if scene != "cornell" else spp
+    per_launch = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = os.path.join(tmp, "pmc_" + counter)
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--scene", scene, "--material", a.material, "--res", "%dx%d" % (w, h), "--spp", str(pmc_spp), "--steps", "1", "--warmup", "0",
+               "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp", env=env, timeout=300)
+        except Exception as e:
+            return {"traffic": None, "traffic_source": "rocprofv3 --pmc %s failed: %s" % (counter, e)}
+        files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+        if p.returncode != 0 or not files:
+            return {"traffic": None, "traffic_source": "rocprofv3 --pmc %s: rc %d, no counter file" % (counter, p.returncode)}
+        total, n = 0.0, 0
+        with open(files[0]) as f:
+            for row in csv.DictReader(f):
+                k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "")
+                if row.get("Counter_Name") == counter and k == kernel:
+                    total += float(row["Counter_Value"])
+                    n += 1
+        if not n:
+            return {"traffic": None, "traffic_source": "no %s dispatches in the counter file" % kernel}
+        per_launch[counter] = (total/n, n)
+        shutil.rmtree(out, ignore_errors=True)
+    f, w_ = per_launch["FETCH_SIZE"][0], per_launch["WRITE_SIZE"][0]
+    return {"traffic": round((2.0*f + w_)*1024.0),
+            "traffic_source": "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child passes at %d spp, %d launches), "
+                              "(2*FETCH + WRITE) KiB per MI355X_MICROARCH.md" % (pmc_spp, per_launch["FETCH_SIZE"][1])}
+
+
 def cpu_baseline(a, scene, path, flat, w, h, spp, tmp):
-    """The reference's own CPU/Embree path (oracle/_ref/tungsten) on all host cores, same scene at the same
-    resolution with fewer spp (bounded sample); falls back to the oracle port when the binary is absent."""
+    """The reference's own CPU/Embree path on all host cores, same scene at the same resolution with fewer spp (bounded
+    sample): oracle/_ref/avx2/tungsten (the haswell / AVX2-Embree build SURVEY.md 8d asks for) or, failing that, the default
+    SSE4.2 build oracle/_ref/tungsten; median of 3 runs, each timed by the wall clock between the binary's "Starting
+    render..." and "Finished render" log lines (its own "Render time" has 1-second granularity).  Falls back to the oracle
+    port when no reference binary is present."""
     import tungsten_amd as tg
     cores = os.cpu_count() or 1
-    ref = os.path.join(ROOT, "oracle", "_ref", "tungsten")
+    refs = [(os.path.join(ROOT, "oracle", "_ref", "avx2", "tungsten"), "haswell/AVX2-Embree build"),
+            (os.path.join(ROOT, "oracle", "_ref", "tungsten"), "SSE4.2 build (reference CMake default)")]
     # rough CPU rates (Msamples/s per core) to size the sample: cornell ~0.7, materialtest ~0.3; the reference stops
     # scaling long before 256 threads (its tile pool), so cap the estimate at 32 cores' worth
     per_core = 0.7 if scene == "cornell" else 0.3 if scene == "materialtest" else 0.15
-    budget = a.cpu_seconds*per_core*min(cores, 32)*1e6
+    budget = a.cpu_seconds/6.0*per_core*min(cores, 32)*1e6
     s_spp = int(max(1, min(spp, budget//(w*h))))
     # the unmodified reference binary never loads the mesh files of an Instance's masters (Instance.cpp:265-282), i.e. it
     # would render the instanced scene without its instances: that scene is timed with the oracle port instead
-    if scene != "instances10k" and os.path.exists(ref) and os.access(ref, os.X_OK):
+    results = []
+    for ref, build in refs:
+        if scene == "instances10k" or not (os.path.exists(ref) and os.access(ref, os.X_OK)):
+            continue
+        times = []
         try:
-            t0 = time.time()
-            p = subprocess.run([ref, "-t", str(cores), "-s", str(tg.DEFAULT_SEED), "--spp", str(s_spp),
-                                "-e", os.path.join(tmp, "cpu_%s.pfm" % scene), "-o", os.path.join(tmp, "cpu_%s.png" % scene), path],
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd=tmp, timeout=600)
-            wall = time.time() - t0
-            m = re.search(r"Render time\s+([0-9.eE+-]+)s", p.stdout)
-            if p.returncode == 0 and m:
-                secs = float(m.group(1))
-                return {"value": round(w*h*s_spp/secs*1e-6, 3), "unit": "Msamples/s", "cores": cores, "kind": "reference",
-                        "sample": "%dx%d @ %d spp of the same scene, reference binary `tungsten -t %d`, its own 'Render time' %.2f s (wall %.1f s)"
-                                  % (w, h, s_spp, cores, secs, wall)}
+            for run in range(3):
+                p = subprocess.Popen([ref, "-t", str(cores), "-s", str(tg.DEFAULT_SEED), "--spp", str(s_spp),
+                                      "-e", os.path.join(tmp, "cpu_%s.pfm" % scene), "-o", os.path.join(tmp, "cpu_%s.png" % scene), path],
+                                     stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd=tmp, bufsize=1)
+                t_start = t_end = None
+                for line in p.stdout:
+                    if "Starting render" in line:
+                        t_start = time.perf_counter()
+                    elif "Finished render" in line:
+                        t_end = time.perf_counter()
+                p.wait(timeout=600)
+                if p.returncode != 0 or t_start is None or t_end is None:
+                    raise RuntimeError("reference binary failed")
+                times.append(t_end - t_start)
         except Exception:
-            pass
+            continue
+        times.sort()
+        results.append((w*h*s_spp/times[1]*1e-6, build, times))
+    if results:
+        # both builds are timed (the AVX2 one is not always the faster one); the baseline is the better median
+        best = max(results, key=lambda r: r[0])
+        return {"value": round(best[0], 3), "unit": "Msamples/s", "cores": cores, "kind": "reference",
+                "sample": "%dx%d @ %d spp of the same scene, reference binary `tungsten -t %d`, render-loop wall clock, median of 3 runs per build: "
+                          % (w, h, s_spp, cores) + "; ".join("%s %s s => %.2f Msamples/s" % (b, " / ".join("%.2f" % t for t in ts), v)
+                                                              for v, b, ts in results)}
     import oracle_lib
     s_spp = max(1, s_spp//2)
     t0 = time.time()
@@ -324,19 +385,25 @@ def main():
     b = Bench(a)
     try:
         w, h = [int(v) for v in a.res.split("x")]
-        spp = a.spp or (256 if a.scene == "cornell" else 64)
-        if a.scene in ("mesh1m", "instances10k") and a.res == "1280x720":
+        scene = a.scene
+        if scene in ("materialtest", "mesh1m") and not scenes.have_materialtest():
+            if b.rank == 0:
+                sys.stderr.write("bench.py: materialtest assets (oracle/_ref/data) missing -- falling back to the Cornell box\n")
+            scene = "cornell"
+        spp = a.spp or (256 if scene in ("cornell", "materialtest") else 32)
+        if scene in ("mesh1m", "instances10k") and a.res == "1280x720":
             w, h = 1920, 1080
         cpu = not a.no_cpu_baseline and b.world == 1
-        res = b.run(a.scene, w, h, spp, a.steps, a.warmup, cpu)
+        res = b.run(scene, w, h, spp, a.steps, a.warmup, cpu)
         extra = None
-        if a.scene == "cornell" and b.world == 1 and not a.no_extra and scenes.have_materialtest():
-            # the scene BASELINE.json's metric names, on the same line (shorter run: 64 spp, 2 steps)
-            m = b.run("materialtest", 1280, 720, 64, 2, 1, cpu)
+        if scene == "materialtest" and b.world == 1 and not a.no_extra:
+            # BASELINE configs[1] on the same line: a flat-list scene, no traversal kernel (2 steps)
+            saved, a.traffic = a.traffic, False
+            m = b.run("cornell", 1280, 720, 256, 2, 1, False)
+            a.traffic = saved
             if b.rank == 0:
-                keys = ("value", "ms_per_step", "config", "roofline", "cpu_baseline", "kernels", "rays_per_sample", "nodes_per_ray",
-                        "prims_per_ray", "bvh", "result_ok")
-                extra = {"materialtest_1280x720_64spp": dict({k: m[k] for k in keys}, unit="Msamples/s", steps=2, warmup=1)}
+                keys = ("value", "ms_per_step", "config", "roofline", "kernels", "rays_per_sample", "prims_per_ray", "bvh", "result_ok")
+                extra = {"cornell_1280x720_256spp": dict({k: m[k] for k in keys}, unit="Msamples/s", steps=2, warmup=1)}
         if b.rank == 0:
             out = {"metric": "Msamples/s (W*H*spp/s), path_tracer render loop", "value": res["value"], "unit": "Msamples/s",
                    "n_gpus": b.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],

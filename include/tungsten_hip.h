@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 4
+#define TGHIP_ABI_VERSION 5
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -276,6 +276,10 @@ typedef struct TgHipSceneDesc {
                                    first non-specular vertex (PathTracer.cpp:78-96, 133-140) and the colour, each with its A/B halves and
                                    sample variance (cameras/OutputBuffer.hpp:90-132) */
 
+#define TGHIP_PASS_SAMPLES 8u   /* parity instrumentation: additionally keep the radiance of every individual sample of the pass -- the
+                                   return value of PathTracer::traceSample (PathTracer.cpp:14-149) for (pixel, sample index) -- in a
+                                   device buffer read back with tghip_download_samples; not with record_index / record_count */
+
 /* auxiliary outputs (cameras/OutputBufferSettings.cpp:8-14) and their channels in TgHipAuxPixel */
 enum { TGHIP_AUX_COLOR = 0, TGHIP_AUX_DEPTH = 1, TGHIP_AUX_NORMAL = 2, TGHIP_AUX_ALBEDO = 3, TGHIP_AUX_VISIBILITY = 4, TGHIP_AUX_OUTPUTS = 5 };
 #define TGHIP_AUX_CHANNELS 11u   /* color rgb 0-2 | depth 3 | normal xyz 4-6 | albedo rgb 7-9 | visibility 10 */
@@ -347,6 +351,9 @@ int tghip_upload_records(tghip_ctx *ctx, const TgHipSampleRecord *in, size_t n);
  * cleared by tghip_clear_framebuffer (Camera::serializeOutputBuffers / deserializeOutputBuffers, Camera.cpp:222-238) */
 int tghip_download_aux(tghip_ctx *ctx, TgHipAuxPixel *out, size_t npixels);
 int tghip_upload_aux(tghip_ctx *ctx, const TgHipAuxPixel *in, size_t npixels);
+/* the per-sample radiance of the last TGHIP_PASS_SAMPLES pass: nfloats = W*H*(spp_end - spp_begin)*3, laid out
+ * [pixel (row-major)][sample - spp_begin][rgb]; samples of pixels the pass's shard does not own are zero */
+int tghip_download_samples(tghip_ctx *ctx, float *rgb, size_t nfloats);
 int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);

@@ -127,6 +127,23 @@ class Renderer(object):
             raise TungstenError(lib.tghip_last_error(self.context(device)).decode())
         return hits, ms.value
 
+    def trace_samples(self, spp_begin, spp_end, seed=DEFAULT_SEED, tile_seeds=None, device=0):
+        """One TGHIP_PASS_SAMPLES pass on the device (into a cleared framebuffer): the radiance of every individual sample,
+        [H, W, spp_end - spp_begin, 3] -- PathTracer::traceSample's return value per (pixel, sample index).  With tile_seeds
+        (one per 16x16 tile) the pass draws from the Sobol' sampler (TGHIP_PASS_SOBOL)."""
+        ctx = self.context(device)
+        flags = capi.TGHIP_PASS_SAMPLES | (capi.TGHIP_PASS_SOBOL if tile_seeds is not None else 0)
+        p = TgHipPassDesc(int(spp_begin), int(spp_end), seed & 0xFFFFFFFF, 0, 1, flags)
+        if tile_seeds is not None:
+            seeds = np.ascontiguousarray(tile_seeds, np.uint32)
+            p.tile_seeds = seeds.ctypes.data_as(C.POINTER(C.c_uint32))
+        out = np.empty((self.height, self.width, int(spp_end) - int(spp_begin), 3), np.float32)
+        for rc in (lib.tghip_clear_framebuffer(ctx), lib.tghip_render_pass(ctx, C.byref(p)), lib.tghip_wait(ctx),
+                   lib.tghip_download_samples(ctx, out.ctypes.data, out.size)):
+            if rc != 0:
+                raise TungstenError(lib.tghip_last_error(ctx).decode())
+        return out
+
     def save_resume_data(self):
         """Integrator::saveRenderResumeData: writes renderer.resume_render_file."""
         self._check(lib.tgh_renderer_save_resume_data(self._h, self._err, len(self._err)))

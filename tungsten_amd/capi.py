@@ -82,7 +82,7 @@ class TgHipSceneDesc(C.Structure):
                 ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
 
 
-TGHIP_PASS_SOBOL, TGHIP_PASS_RECORDS, TGHIP_PASS_AUX = 1, 2, 4
+TGHIP_PASS_SOBOL, TGHIP_PASS_RECORDS, TGHIP_PASS_AUX, TGHIP_PASS_SAMPLES = 1, 2, 4, 8
 
 
 class TgHipAuxPixel(C.Structure):
@@ -149,6 +149,7 @@ PROTOTYPES = {
     "tghip_upload_records": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_download_aux": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_upload_aux": (C.c_int, [VP, VP, C.c_size_t]),
+    "tghip_download_samples": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_trace_rays": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "tghip_set_option": (C.c_int, [VP, C.c_char_p, C.c_longlong]),
     "tghip_get_counters": (C.c_int, [VP, C.POINTER(TgHipCounters)]),

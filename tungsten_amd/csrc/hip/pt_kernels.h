@@ -154,6 +154,8 @@ struct PassParams {
     uint32_t num_chunks;       // chunks of the record with the most samples
     float *lum;                // luminance of every sample of the pass, in the order SampleRecord::addSample saw them
     TgHipAuxPixel *aux;        // TGHIP_PASS_AUX: the auxiliary output buffers, one record per image pixel
+    float *samples;            // TGHIP_PASS_SAMPLES: radiance of every sample of the pass, [pixel][sample - samples_begin][rgb]
+    uint32_t samples_begin, samples_spp;
 };
 
 // OutputBuffer<T>::addSample (cameras/OutputBuffer.hpp:104-132) with _bufferB and _variance present, on the channels

@@ -90,6 +90,12 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             em = splat3(0.0f);
         if (records)   // SampleRecord::addSample(c) input (SampleRecord.hpp:55-58; Vec3f::luminance, math/Vec.hpp:195-199)
             at32(pp.lum, lumBase + samp.x) = em.x*0.2126f + em.y*0.7152f + em.z*0.0722f;
+        if constexpr (EXT) {
+            if (pp.flags & TGHIP_PASS_SAMPLES) {   // what traceSample returned for (pixel, sample)
+                float *dst = pp.samples + ((size_t)pixel*pp.samples_spp + (samp.x - pp.samples_begin))*3u;
+                dst[0] = em.x; dst[1] = em.y; dst[2] = em.z;
+            }
+        }
         if (!(isinf(em.x) || isinf(em.y) || isinf(em.z))) {
             acc.x += em.x; acc.y += em.y; acc.z += em.z;
             acc.w = __uint_as_float(__float_as_uint(acc.w) + 1u);

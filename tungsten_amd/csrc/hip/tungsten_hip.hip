@@ -104,6 +104,8 @@ struct tghip_ctx {
     bool thinlens = false;                // thin-lens camera: passes run the EXT kernel variants (PT_PASS_THINLENS)
     bool haveSolids = false;              // cube / sphere / disk records: the dynamic-fetch kernels' SOLIDS variants
     TgHipAuxPixel *dAux = nullptr;        // auxiliary output buffers (allocated by the first TGHIP_PASS_AUX pass)
+    float *dSamples = nullptr;            // TGHIP_PASS_SAMPLES: per-sample radiance of the last such pass
+    size_t samplesCap = 0, samplesFloats = 0;
     bool auxPass = false;                 // the pass being rendered keeps them: BSDF_MASK_ALL shading, no fused / dynamic-fetch shadow kernels
     int thrShadeAll = 256;                // workgroup size of k_shade<BSDF_MASK_ALL> (media scenes, TGHIP_PASS_AUX passes)
     bool haveCylinder = false;            // cylinder primitives: BSDF_MASK_ALL shading (the only FEAT_CYLINDER variant), never fused
@@ -463,6 +465,7 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->fbSum) (void)hipFree(ctx->fbSum);
     if (ctx->fbCount) (void)hipFree(ctx->fbCount);
     if (ctx->dAux) (void)hipFree(ctx->dAux);
+    if (ctx->dSamples) (void)hipFree(ctx->dSamples);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->hostLive) (void)hipHostFree(ctx->hostLive);
     if (ctx->abortFlagDev) (void)hipFree(ctx->abortFlagDev);
@@ -951,13 +954,17 @@ int tghip_render_pass(tghip_ctx *ctx, const TgHipPassDesc *pass)
         ctx->error = "invalid pass description";
         return TGHIP_E_INVALID;
     }
-    if (pass->flags & ~(TGHIP_PASS_SOBOL | TGHIP_PASS_RECORDS | TGHIP_PASS_AUX)) { ctx->error = "unknown pass flags"; return TGHIP_E_INVALID; }
+    if (pass->flags & ~(TGHIP_PASS_SOBOL | TGHIP_PASS_RECORDS | TGHIP_PASS_AUX | TGHIP_PASS_SAMPLES)) { ctx->error = "unknown pass flags"; return TGHIP_E_INVALID; }
     if ((pass->flags & TGHIP_PASS_SOBOL) && (!ctx->scene.sobol || !pass->tile_seeds)) {
         ctx->error = "TGHIP_PASS_SOBOL needs sobol_matrices in the scene description and tile_seeds in the pass";
         return TGHIP_E_INVALID;
     }
     if ((pass->record_count != nullptr) != (pass->record_index != nullptr) || (pass->record_count && !(pass->flags & TGHIP_PASS_RECORDS))) {
         ctx->error = "record_index and record_count go together and need TGHIP_PASS_RECORDS";
+        return TGHIP_E_INVALID;
+    }
+    if ((pass->flags & TGHIP_PASS_SAMPLES) && (pass->record_count || uint64_t(ctx->width)*ctx->height*(pass->spp_end - pass->spp_begin)*3u >= (1ull << 31))) {
+        ctx->error = "TGHIP_PASS_SAMPLES keeps W*H*spp*3 floats (< 2^31) and does not combine with per-record sample counts";
         return TGHIP_E_INVALID;
     }
     ctx->abortRequested.store(false, std::memory_order_release);   // the only place a request is cleared
@@ -1038,6 +1045,18 @@ int tghip_wait(tghip_ctx *ctx)
         HIP_TRY(ctx, hipMemsetAsync(ctx->dAux, 0, npix*sizeof(TgHipAuxPixel), ctx->stream));
     }
     base.aux = ctx->dAux;
+    if (pass.flags & TGHIP_PASS_SAMPLES) {
+        const size_t need = size_t(w)*h*spp*3u;
+        if (ctx->samplesCap < need) {
+            if (ctx->dSamples) (void)hipFree(ctx->dSamples);
+            ctx->dSamples = nullptr; ctx->samplesCap = 0;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dSamples), need*sizeof(float)));
+            ctx->samplesCap = need;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dSamples, 0, need*sizeof(float), ctx->stream));
+        ctx->samplesFloats = need;
+        base.samples = ctx->dSamples; base.samples_begin = sppBegin; base.samples_spp = spp;
+    }
     const uint64_t maxItems = uint64_t(std::max<long long>(ctx->maxItems, 256));
     const bool recordPass = (pass.flags & TGHIP_PASS_RECORDS) != 0;
     uint64_t recordItems = 0;
@@ -1277,6 +1296,18 @@ int tghip_upload_aux(tghip_ctx *ctx, const TgHipAuxPixel *in, size_t npixels)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->dAux) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dAux), npixels*sizeof(TgHipAuxPixel)));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dAux, in, npixels*sizeof(TgHipAuxPixel), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
+int tghip_download_samples(tghip_ctx *ctx, float *rgb, size_t nfloats)
+{
+    if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
+    int rc = tghip_wait(ctx);
+    if (rc != TGHIP_OK && rc != TGHIP_E_ABORTED) return rc;
+    if (!rgb || !ctx->dSamples || nfloats != ctx->samplesFloats) { ctx->error = "no TGHIP_PASS_SAMPLES pass of that size has been rendered"; return TGHIP_E_INVALID; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->dSamples, nfloats*sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TGHIP_OK;
 }
