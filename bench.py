@@ -168,12 +168,12 @@ class Bench(object):
         def check(rc, what):
             if rc != 0:
                 raise SystemExit("%s failed (%d): %s" % (what, rc, lib.tghip_last_error(ctx).decode()))
+        for kv in a.opt:                          # (before the upload: some options shape the uploaded scene)
+            k, v = kv.split("=")
+            check(lib.tghip_set_option(ctx, k.encode(), int(v)), "tghip_set_option")
         t0 = time.time()
         check(lib.tghip_upload_scene(ctx, flat.desc), "tghip_upload_scene")
         t_upload = time.time() - t0
-        for kv in a.opt:
-            k, v = kv.split("=")
-            check(lib.tghip_set_option(ctx, k.encode(), int(v)), "tghip_set_option")
 
         # framebuffer lives in torch tensors so that RCCL (torch.distributed) can reduce it in place
         fb_sum = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")

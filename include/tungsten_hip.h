@@ -74,6 +74,35 @@ typedef struct TgHipBvhNode {
  * primitives (TraceableScene.hpp:112-134).  The oracle follows the same rule so that visit counts agree. */
 #define TGHIP_FLAT_MAX_RECS    16
 
+/* ---- 8-wide BVH with quantised child boxes ------------------------------------------------------------------------
+ * What the traversal kernels of single-level scenes walk (the BVH2 above stays the structure of the two-level
+ * instance walk and of the transparency / media shadow walks).  It is the BVH2 collapsed: every wide node stands for a
+ * BVH2 node, its up to eight children for BVH2 descendants (the child with the largest box is opened until the node is
+ * full), every leaf child for ONE BVH2 leaf.  A node is 80 bytes = five 16-byte loads of ONE lane:
+ *   child box plane k of axis a = origin[a] + q * 2^(exp[a] - 127)           (q in 0..255; lower planes rounded down,
+ *                                                                              upper planes up: boxes only ever grow)
+ *   slot s holds an internal child iff imask bit s; internal children are consecutive nodes from child_base in slot order
+ *   a leaf child's records are recs[rec_base + (meta[s] & 31) ... + (meta[s] >> 5) + 1): the leaf children of one node
+ *     share one contiguous run of at most 32 records (records are ordered by wide node, breadth first)
+ *   an empty slot has qlo = 255 > qhi = 0 on every axis (no ray passes its box test)
+ * Children sit in the slot whose sign pattern (bit 0: +x, bit 1: +y, bit 2: +z) best matches the direction from the
+ * node's centre to theirs, so that visiting hit slots in ascending (slot XOR ray octant) order is roughly front to back
+ * without sorting distances (Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs through compressed wide
+ * BVHs", HPG 2017 -- the node layout here is this repository's own).  Replaces what Embree's BVH4 does for the
+ * reference (thirdparty/embree/kernels/bvh/bvh_intersector1.cpp:48-142). */
+typedef struct TgHipWideNode {
+    float    origin[3];
+    uint8_t  exp[3];          /* biased exponents of the per-axis plane spacing */
+    uint8_t  imask;
+    uint32_t child_base;
+    uint32_t rec_base;
+    uint8_t  meta[8];
+    uint8_t  qlo[3][8];       /* [axis][slot] */
+    uint8_t  qhi[3][8];
+} TgHipWideNode;              /* 80 B */
+#define TGHIP_WIDE_MAX_LEAF   4    /* records per leaf child */
+#define TGHIP_MAX_WIDE_DEPTH  32   /* builder guarantees depth <= this (device stack: one 8-byte entry per level) */
+
 /* record kinds (meta >> 29) */
 enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3, TGHIP_REC_INSTANCE = 4,
        TGHIP_REC_DISK = 5, TGHIP_REC_CYLINDER = 6 };
@@ -251,6 +280,9 @@ typedef struct TgHipSceneDesc {
     uint32_t num_instances;               /* instance records among recs (0: single-level scene) */
     uint32_t num_top_recs;                /* records of the top-level BVH = recs[0, num_top_recs); the rest belong to masters */
     const TgHipMedium  *media;  uint32_t num_media;   /* Scene::_media; NULL/0 = the scene has no participating media */
+    /* the wide BVH over recs[0, num_top_recs): wide_nodes[0] is the root; NULL/0 = the device walks the BVH2 (flat-list
+     * scenes and scenes with instance records always do) */
+    const TgHipWideNode *wide_nodes;  uint32_t num_wide_nodes;
     TgHipCamera   camera;
     TgHipSettings settings;
     float         bounds_lo[3], bounds_hi[3];

@@ -1414,6 +1414,88 @@ static void bvh_walk(const TgHipSceneDesc *s, int32_t root, const Ray *ray, floa
     }
 }
 
+/* ---- the 8-wide BVH with quantised child boxes (include/tungsten_hip.h: TgHipWideNode) ------------------------------
+ * The same per-ray machine as the device's (tungsten_amd/csrc/hip/pt_kernels.h: wideNext / wideVisit), statement for
+ * statement: the records of a node's hit leaf children are tested first (ascending record order), then its hit internal
+ * children are visited in ascending (slot XOR ray octant) order, the ones not taken yet waiting on a stack of groups;
+ * plane distances are fmaf(q, spacing/d, (origin - o)/d) -- one correctly rounded operation on both sides -- so node and
+ * record visit counts agree exactly (tests/test_gpu_parity.py::test_trace_rays_matches_oracle_exactly). */
+static int g_use_wide = 0;      /* oracle_set_wide_bvh: closest-hit queries of oracle_trace_rays walk the wide BVH */
+static inline uint32_t wide_permute(uint32_t h, uint32_t oct)
+{
+    if (oct & 1u) h = ((h & 0x55u) << 1) | ((h >> 1) & 0x55u);
+    if (oct & 2u) h = ((h & 0x33u) << 2) | ((h >> 2) & 0x33u);
+    if (oct & 4u) h = ((h & 0x0Fu) << 4) | ((h >> 4) & 0x0Fu);
+    return h;
+}
+static inline float wide_spacing(uint8_t e) { union { uint32_t u; float f; } c; c.u = (uint32_t)e << 23; return c.f; }
+static inline float wide_inv(float d) { return 1.0f/(fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d); }
+static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit *hit, TravStats *st, int objFilter)
+{
+    struct { uint32_t base, masks; } stack[TGHIP_MAX_WIDE_DEPTH + 2];
+    int sp = 0;
+    const float idir[3] = {wide_inv(ray->d.x), wide_inv(ray->d.y), wide_inv(ray->d.z)};
+    const float org[3] = {ray->o.x, ray->o.y, ray->o.z};
+    const uint32_t octInv = (idir[0] < 0.0f ? 1u : 0u) | (idir[1] < 0.0f ? 2u : 0u) | (idir[2] < 0.0f ? 4u : 0u);
+    uint32_t grpBase = 0, grpMasks = 0, triBase = 0, triMask = 0;
+    int32_t node = 0;
+    for (;;) {
+        if (triMask) {
+            uint32_t i = triBase + (uint32_t)__builtin_ctz(triMask);
+            triMask &= triMask - 1u;
+            if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
+                test_rec(s, i, ray, tmax, hit, st, objFilter, -1);
+            else if (st) st->prims++;            /* (the device fetches the record either way) */
+            continue;
+        }
+        if (node < 0) {
+            if ((grpMasks & 0xFFu) == 0u) {
+                if (sp == 0) break;
+                --sp;
+                grpBase = stack[sp].base; grpMasks = stack[sp].masks;
+            }
+            uint32_t hits = grpMasks & 0xFFu, imask = grpMasks >> 8;
+            uint32_t slot = (uint32_t)__builtin_ctz(hits) ^ octInv;
+            node = (int32_t)(grpBase + (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u)));
+            hits &= hits - 1u;
+            grpMasks = (imask << 8) | hits;
+            if (hits) { stack[sp].base = grpBase; stack[sp].masks = grpMasks; ++sp; }
+        }
+        const TgHipWideNode *n = &s->wide_nodes[node];
+        node = -1;
+        if (st) st->nodes++;
+        float adjS[3], adjO[3];
+        for (int a = 0; a < 3; ++a) {
+            adjS[a] = wide_spacing(n->exp[a])*idir[a];
+            adjO[a] = (n->origin[a] - org[a])*idir[a];
+        }
+        uint32_t hitmask = 0, tm = 0;
+        for (int sl = 0; sl < 8; ++sl) {
+            float tn = ray->tmin, tf = *tmax;
+            float tnA[3], tfA[3];
+            for (int a = 0; a < 3; ++a) {
+                const int neg = (octInv >> a) & 1u;
+                const float qn = (float)(neg ? n->qhi[a][sl] : n->qlo[a][sl]), qf = (float)(neg ? n->qlo[a][sl] : n->qhi[a][sl]);
+                tnA[a] = fmaf(qn, adjS[a], adjO[a]);
+                tfA[a] = fmaf(qf, adjS[a], adjO[a]);
+            }
+            tn = fmaxf(fmaxf(tnA[0], tnA[1]), fmaxf(tnA[2], tn));
+            tf = fminf(fminf(tfA[0], tfA[1]), fminf(tfA[2], tf));
+            tf *= 1.0000004f;
+            if (tn <= tf) {
+                hitmask |= 1u << sl;
+                const uint32_t m = n->meta[sl];
+                tm |= ((1u << (m >> 5)) - 1u) << (m & 31u);
+            }
+        }
+        grpBase = n->child_base;
+        grpMasks = ((uint32_t)n->imask << 8) | wide_permute(hitmask & n->imask, octInv);
+        triBase = n->rec_base;
+        triMask = tm;
+    }
+}
+void oracle_set_wide_bvh(int on) { g_use_wide = on; }
+
 /* objFilter >= 0: only records of that object are tested (a mesh light's own rtcIntersect, TriangleMesh.cpp:317-335) */
 static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, Hit *hit, TravStats *st, int objFilter)
 {
@@ -1426,7 +1508,10 @@ static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, Hit *hit
                 test_rec(s, i, ray, &tmax, hit, st, objFilter, -1);
         return hit->rec >= 0;
     }
-    bvh_walk(s, 0, ray, &tmax, hit, st, objFilter, -1);
+    if (g_use_wide && s->wide_nodes && s->num_instances == 0)
+        wide_walk(s, ray, &tmax, hit, st, objFilter);
+    else
+        bvh_walk(s, 0, ray, &tmax, hit, st, objFilter, -1);
     return hit->rec >= 0;
 }
 static int scene_intersect(const TgHipSceneDesc *s, const Ray *ray, Hit *hit, TravStats *st)

@@ -142,11 +142,17 @@ def trace_sample(desc, seed, px, py, sample, tile_seed=None):
     return np.array(rgb[:], np.float32)
 
 
-def trace_rays(desc, rays):
+def trace_rays(desc, rays, wide=False):
+    """Closest hits + exact node / record visit counts.  wide: walk the scene's 8-wide BVH (when it has one) with the
+    device's per-ray machine instead of the BVH2."""
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
     hits = np.empty(rays.shape[0], dtype=[("t", np.float32), ("u", np.float32), ("v", np.float32), ("rec", np.int32)])
     nodes, prims = C.c_uint64(0), C.c_uint64(0)
-    _lib.oracle_trace_rays(desc, rays.ctypes.data, hits.ctypes.data, rays.shape[0], C.byref(nodes), C.byref(prims))
+    _lib.oracle_set_wide_bvh(1 if wide else 0)
+    try:
+        _lib.oracle_trace_rays(desc, rays.ctypes.data, hits.ctypes.data, rays.shape[0], C.byref(nodes), C.byref(prims))
+    finally:
+        _lib.oracle_set_wide_bvh(0)
     return hits, nodes.value, prims.value
 
 

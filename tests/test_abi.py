@@ -41,7 +41,7 @@ def test_product_library_does_not_link_the_oracle():
 
 
 def test_ctypes_layout_matches_the_headers(tmp_path):
-    structs = ["TgHipBvhNode", "TgHipPrimRec", "TgHipTriAttr", "TgHipObject", "TgHipBsdf", "TgHipTexture", "TgHipMedium", "TgHipCamera",
+    structs = ["TgHipBvhNode", "TgHipWideNode", "TgHipPrimRec", "TgHipTriAttr", "TgHipObject", "TgHipBsdf", "TgHipTexture", "TgHipMedium", "TgHipCamera",
                "TgHipSettings", "TgHipSceneDesc", "TgHipPassDesc", "TgHipAuxPixel", "TgHipCounters", "TgHipRay", "TgHipHit", "TgHostSceneInfo"]
     src = '#include <stdio.h>\n#include "tungsten_host.h"\nint main(void){\n'
     for s in structs:
@@ -55,6 +55,7 @@ def test_ctypes_layout_matches_the_headers(tmp_path):
     for s in structs:
         assert int(got[s]) == C.sizeof(getattr(capi, s)), s
     assert int(got["camera"]) == capi.TgHipSceneDesc.camera.offset
+    assert C.sizeof(capi.TgHipWideNode) == 80
     assert C.sizeof(capi.TgHipBvhNode) == 64 and C.sizeof(capi.TgHipPrimRec) == 48 and C.sizeof(capi.TgHipTriAttr) == 64
     assert C.sizeof(capi.TgHipRay) == 32 and C.sizeof(capi.TgHipHit) == 16
 

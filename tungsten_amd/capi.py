@@ -18,6 +18,11 @@ class TgHipBvhNode(C.Structure):
                 ("child0", i32), ("child1", i32), ("pad", u32*2)]
 
 
+class TgHipWideNode(C.Structure):
+    _fields_ = [("origin", f32*3), ("exp", C.c_uint8*3), ("imask", C.c_uint8), ("child_base", u32), ("rec_base", u32),
+                ("meta", C.c_uint8*8), ("qlo", (C.c_uint8*8)*3), ("qhi", (C.c_uint8*8)*3)]
+
+
 class TgHipPrimRec(C.Structure):
     _fields_ = [("a", f32*3), ("meta", u32), ("b", f32*3), ("p0", f32), ("c", f32*3), ("p1", f32)]
 
@@ -78,6 +83,7 @@ class TgHipSceneDesc(C.Structure):
                 ("sobol_matrices", C.POINTER(u32)), ("num_sobol_words", u64),
                 ("num_instances", u32), ("num_top_recs", u32),
                 ("media", C.POINTER(TgHipMedium)), ("num_media", u32),
+                ("wide_nodes", C.POINTER(TgHipWideNode)), ("num_wide_nodes", u32),
                 ("camera", TgHipCamera), ("settings", TgHipSettings),
                 ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
 

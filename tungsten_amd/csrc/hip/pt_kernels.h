@@ -546,6 +546,134 @@ PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, 
     return false;
 }
 
+// ---- 8-wide BVH with quantised child boxes (include/tungsten_hip.h: TgHipWideNode) ---------------------------------
+// What bounds a per-lane tree walk on MI355X is the number of cache lines it pulls through the CU's vector L1 (one
+// 128-byte line every ~2 clocks from L2, tools/ubench_chase.hip; latency hides behind 4 waves per CU already), so
+// the walk is built to touch few lines per ray: one 80-byte node decides eight children at once (15.5 -> ~6 node
+// visits per ray on materialtest), and a lane asks for exactly ONE thing per loop turn -- a node or a primitive
+// record, both behind one base pointer -- so every turn of the wave costs one memory round trip, not one per kind.
+// A lane's walk is a pure function of its ray (wideNext / wideVisit below; oracle/oracle.c: wide_walk is the same
+// machine), which is what keeps the visit counts of the device and the oracle identical.
+//   group  = the hit internal children of the node visited last, in traversal order (bit p = slot p ^ octant), plus
+//            that node's imask and first-child index; drained nearest first, the rest waits on the stack
+//   triMask = the records of its hit leaf children, tested before the group is touched
+struct WideRay { f3 idir; uint32_t octInv; };
+PT_DEV WideRay wideRaySetup(const RayD &ray)
+{
+    WideRay w;
+    // no infinities: a plane distance is q*(spacing/d) + (origin - o)/d, and 0*inf would be NaN
+    auto inv = [](float d) { return 1.0f/(fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d); };
+    w.idir = mk3(inv(ray.d.x), inv(ray.d.y), inv(ray.d.z));
+    w.octInv = (w.idir.x < 0.0f ? 1u : 0u) | (w.idir.y < 0.0f ? 2u : 0u) | (w.idir.z < 0.0f ? 4u : 0u);
+    return w;
+}
+PT_DEV uint32_t widePermute(uint32_t h, uint32_t oct)      // bit (s ^ oct) of the result = bit s of h
+{
+    h = (oct & 1u) ? (((h & 0x55u) << 1) | ((h >> 1) & 0x55u)) : h;
+    h = (oct & 2u) ? (((h & 0x33u) << 2) | ((h >> 2) & 0x33u)) : h;
+    h = (oct & 4u) ? (((h & 0x0Fu) << 4) | ((h >> 4) & 0x0Fu)) : h;
+    return h;
+}
+struct WideState {
+    uint32_t grpBase, grpMasks;   // hits still to visit (bits 0-7, traversal order) | imask << 8
+    uint32_t triBase, triMask;
+    int node;                     // node to visit next; -1: take it from the group / the stack
+    int sp;
+};
+PT_DEV void wideStart(WideState &w) { w.grpBase = 0; w.grpMasks = 0; w.triBase = 0; w.triMask = 0; w.node = 0; w.sp = 0; }
+// What the lane fetches next: 1 = primitive record `idx`, 2 = node `idx`, 0 = the walk is over.
+PT_DEV int wideNext(WideState &w, uint32_t octInv, uint2 *stack, int stride, uint32_t &idx)
+{
+    if (w.triMask) {
+        idx = w.triBase + (uint32_t)__ffs((int)w.triMask) - 1u;
+        w.triMask &= w.triMask - 1u;
+        return 1;
+    }
+    if (w.node < 0) {
+        if ((w.grpMasks & 0xFFu) == 0u) {
+            if (w.sp == 0)
+                return 0;
+            w.sp--;
+            uint2 e = stack[w.sp*stride];
+            w.grpBase = e.x; w.grpMasks = e.y;
+        }
+        uint32_t hits = w.grpMasks & 0xFFu, imask = w.grpMasks >> 8;
+        uint32_t slot = ((uint32_t)__ffs((int)hits) - 1u) ^ octInv;
+        w.node = (int)(w.grpBase + (uint32_t)__popc(imask & ((1u << slot) - 1u)));
+        hits &= hits - 1u;
+        w.grpMasks = (imask << 8) | hits;
+        if (hits) { stack[w.sp*stride] = make_uint2(w.grpBase, w.grpMasks); w.sp++; }
+    }
+    idx = (uint32_t)w.node;
+    w.node = -1;
+    return 2;
+}
+// The node's 80 bytes have arrived: slab-test its eight children against [tmin, tmax], queue the hit ones.
+PT_DEV void wideVisit(WideState &w, float4 q0, float4 q1, float4 q2, float4 q3, float4 q4, f3 o, const WideRay &wr, float tmin, float tmax)
+{
+    const uint32_t ex = __float_as_uint(q0.w);
+    const f3 spacing = mk3(__uint_as_float((ex & 0xFFu) << 23), __uint_as_float(((ex >> 8) & 0xFFu) << 23), __uint_as_float(((ex >> 16) & 0xFFu) << 23));
+    const f3 adjS = spacing*wr.idir;
+    const f3 adjO = (xyz(q0) - o)*wr.idir;
+    // the planes the ray enters (near) and leaves (far) through, per axis: qlo / qhi swapped for negative directions
+    const bool nx = (wr.octInv & 1u) != 0u, ny = (wr.octInv & 2u) != 0u, nz = (wr.octInv & 4u) != 0u;
+    const uint32_t lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
+    const uint32_t lz0 = __float_as_uint(q3.x), lz1 = __float_as_uint(q3.y), hx0 = __float_as_uint(q3.z), hx1 = __float_as_uint(q3.w);
+    const uint32_t hy0 = __float_as_uint(q4.x), hy1 = __float_as_uint(q4.y), hz0 = __float_as_uint(q4.z), hz1 = __float_as_uint(q4.w);
+    const uint32_t nearX[2] = {nx ? hx0 : lx0, nx ? hx1 : lx1}, farX[2] = {nx ? lx0 : hx0, nx ? lx1 : hx1};
+    const uint32_t nearY[2] = {ny ? hy0 : ly0, ny ? hy1 : ly1}, farY[2] = {ny ? ly0 : hy0, ny ? ly1 : hy1};
+    const uint32_t nearZ[2] = {nz ? hz0 : lz0, nz ? hz1 : lz1}, farZ[2] = {nz ? lz0 : hz0, nz ? lz1 : hz1};
+    const uint32_t meta[2] = {__float_as_uint(q1.z), __float_as_uint(q1.w)};
+    uint32_t hitmask = 0u, triMask = 0u;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        const int d = sl >> 2, sh = (sl & 3)*8;
+        float tnx = fmaf((float)((nearX[d] >> sh) & 0xFFu), adjS.x, adjO.x), tfx = fmaf((float)((farX[d] >> sh) & 0xFFu), adjS.x, adjO.x);
+        float tny = fmaf((float)((nearY[d] >> sh) & 0xFFu), adjS.y, adjO.y), tfy = fmaf((float)((farY[d] >> sh) & 0xFFu), adjS.y, adjO.y);
+        float tnz = fmaf((float)((nearZ[d] >> sh) & 0xFFu), adjS.z, adjO.z), tfz = fmaf((float)((farZ[d] >> sh) & 0xFFu), adjS.z, adjO.z);
+        float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
+        float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
+        tf *= 1.0000004f;
+        const bool h = tn <= tf;
+        hitmask |= h ? (1u << sl) : 0u;
+        const uint32_t m = (meta[d] >> sh) & 0xFFu;                 // leaf: count << 5 | first record; 0: empty or internal
+        triMask |= h ? (((1u << (m >> 5)) - 1u) << (m & 31u)) : 0u;
+    }
+    const uint32_t imask = ex >> 24;
+    w.grpBase = __float_as_uint(q1.x);
+    w.grpMasks = (imask << 8) | widePermute(hitmask & imask, wr.octInv);
+    w.triBase = __float_as_uint(q1.y);
+    w.triMask = triMask;
+}
+PT_DEV const float4 *wideNodePtr(const DeviceScene &s, uint32_t idx) { return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)(idx*s.wide_stride)); }
+
+// closest hit through the wide BVH, one ray at a time (tghip_trace_rays); the dynamic-fetch kernels run the same machine
+template<bool COUNT, uint32_t KINDS = KINDS_ALL>
+PT_DEV float4 traverseClosestWide(const DeviceScene &s, const RayD &ray, uint2 *stack, int stride, uint32_t &nodesVisited, uint32_t &primsTested)
+{
+    float tmax = ray.tmax;
+    float4 hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+    const WideRay wr = wideRaySetup(ray);
+    WideState w;
+    wideStart(w);
+    for (;;) {
+        uint32_t idx;
+        const int what = wideNext(w, wr.octInv, stack, stride, idx);
+        if (what == 0)
+            break;
+        if (what == 2) {
+            const float4 *n = wideNodePtr(s, idx);
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4];
+            if (COUNT) nodesVisited++;
+            wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+        } else {
+            if (COUNT) primsTested++;
+            testRecord<false, KINDS>(s, idx, ray, tmax, hit);
+        }
+    }
+    return hit;
+}
+
 // ---- two-level traversal: scenes with TGHIP_REC_INSTANCE records (primitives/Instance.cpp:290-328) -------------------
 // The top-level BVH holds one record per instance (always alone in its leaf).  Reaching one sends the ray into the
 // master's space (rotation + translation: distances along the ray are unchanged) and walks the master's subtree on the

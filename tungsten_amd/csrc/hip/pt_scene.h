@@ -13,6 +13,9 @@
 struct DeviceScene {
     const float4 * __restrict__ nodes;        // 4 x float4 per TgHipBvhNode
     const float4 * __restrict__ recs;         // 3 x float4 per TgHipPrimRec
+    const float4 * __restrict__ wide;         // 5 x float4 per TgHipWideNode (nullptr: the scene has no wide BVH); ONE allocation with recs:
+    uint32_t recs_offset;                     //   recs == (char *)wide + recs_offset, so a lane addresses either with one 32-bit offset
+    uint32_t wide_stride;                     // bytes between wide nodes: 80, or 128 ("wide_node_stride" option: one node per cache line)
     const float4 * __restrict__ tri_attrs;    // 4 x float4 per TgHipTriAttr
     const TgHipObject * __restrict__ objects;
     const int32_t * __restrict__ lights;
@@ -1127,17 +1130,8 @@ PT_DEV void sphereSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v
 #define KINDS_ALL     0x7Fu
 #define KINDS_MESH    (KIND_BIT(TGHIP_REC_TRIANGLE) | KIND_BIT(TGHIP_REC_QUAD))   /* triangle meshes + quads (materialtest) */
 template<bool UNIFORM, uint32_t KINDS = KINDS_ALL>
-PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit, uint32_t &hitMeta)
+PT_DEV bool testRecordLoaded(const DeviceScene &s, uint32_t ri, float4 r0, float4 r1, float4 r2, const RayD &ray, float &tmax, float4 &hit, uint32_t &hitMeta)
 {
-    float4 r0, r1, r2;
-    if (UNIFORM) {
-        const PT_CONST_AS float *rp = asConst(reinterpret_cast<const float *>(s.recs)) + ri*12;
-        r0 = make_float4(rp[0], rp[1], rp[2], rp[3]);
-        r1 = make_float4(rp[4], rp[5], rp[6], rp[7]);
-        r2 = make_float4(rp[8], rp[9], rp[10], rp[11]);
-    } else {
-        r0 = at32(s.recs, ri*3u + 0u); r1 = at32(s.recs, ri*3u + 1u); r2 = at32(s.recs, ri*3u + 2u);
-    }
     uint32_t meta = __float_as_uint(r0.w);
     uint32_t kind = TGHIP_REC_KIND(meta);
     float t, u = 0.0f, v = 0.0f;
@@ -1176,6 +1170,20 @@ PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
         hitMeta = meta;
     }
     return ok;
+}
+template<bool UNIFORM, uint32_t KINDS = KINDS_ALL>
+PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit, uint32_t &hitMeta)
+{
+    float4 r0, r1, r2;
+    if (UNIFORM) {
+        const PT_CONST_AS float *rp = asConst(reinterpret_cast<const float *>(s.recs)) + ri*12;
+        r0 = make_float4(rp[0], rp[1], rp[2], rp[3]);
+        r1 = make_float4(rp[4], rp[5], rp[6], rp[7]);
+        r2 = make_float4(rp[8], rp[9], rp[10], rp[11]);
+    } else {
+        r0 = at32(s.recs, ri*3u + 0u); r1 = at32(s.recs, ri*3u + 1u); r2 = at32(s.recs, ri*3u + 2u);
+    }
+    return testRecordLoaded<UNIFORM, KINDS>(s, ri, r0, r1, r2, ray, tmax, hit, hitMeta);
 }
 template<bool UNIFORM, uint32_t KINDS = KINDS_ALL>
 PT_DEV void testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float &tmax, float4 &hit)

@@ -424,8 +424,107 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
     }
 }
 
+// Closest hit through the 8-wide BVH (pt_kernels.h) with dynamic ray fetch, for single-level BVH scenes.  One loop turn
+// advances every busy lane by ONE memory round trip: the lane asks its walk for the next thing to look at -- a node (80
+// bytes) or a primitive record (48 bytes), both inside one allocation -- loads it, and then either slab-tests the node's
+// eight children or intersects the record.  Idle lanes refill from the workgroup's queue as in k_trace_closest_dyn.
+// Dynamic LDS: [expanded queue, 2 B per slot][group stacks, wideDepth x 8 B per thread].
+template<bool COUNT, bool SOLIDS = true>
+__global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathState st)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
+    uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2) + threadIdx.x;
+    const int stride = (int)blockDim.x;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    if (threadIdx.x == 0) fetchNext = 0;
+    queuesBegin(L, st, ctl, Q_EXTP, 0u, order, Q_EXT);
+    const uint32_t n = L.n;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    uint32_t nodes = 0, prims = 0, rays = 0;
+
+    bool busy = false;
+    uint32_t slot = 0, local = 0;
+    RayD ray; ray.o = splat3(0.0f); ray.d = splat3(1.0f); ray.tmin = 0.0f; ray.tmax = 0.0f;
+    WideRay wr; wr.idir = splat3(1.0f); wr.octInv = 0u;
+    WideState w;
+    wideStart(w);
+    float tmax = 0.0f;
+    float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
+    for (;;) {
+        unsigned long long busyMask = __ballot(busy);
+        if (!exhausted && __popcll(busyMask) <= 48) {
+            unsigned long long want = ~busyMask;
+            uint32_t lane = laneId();
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
+            base = __shfl(base, 0);
+            if (!busy) {
+                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    local = order[i];
+                    slot = first + local;
+                    float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
+                    ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
+                    wr = wideRaySetup(ray);
+                    wideStart(w);
+                    tmax = ray.tmax;
+                    hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+                    busy = true;
+                    rays++;
+                }
+            }
+            if (base + (uint32_t)__popcll(want) >= n)
+                exhausted = true;
+            busyMask = __ballot(busy);
+        }
+        if (busyMask == 0ull)
+            break;
+        uint32_t idx = 0;
+        int what = 0;
+        if (busy) {
+            what = wideNext(w, wr.octInv, stack, stride, idx);
+            if (what == 0) {
+                // finished: publish the hit and bin the path by shading class
+                slotF4(st, A_HIT, slot) = hit;
+                int ri = __float_as_int(hit.w);
+                int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
+                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
+                busy = false;
+            }
+        }
+        if (what != 0) {
+            // one address per lane: a node or a record, both behind s.wide
+            const uint32_t off = what == 2 ? idx*s.wide_stride : s.recs_offset + idx*48u;
+            const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
+            float4 q0 = p[0], q1 = p[1], q2 = p[2];
+            if (what == 2) {
+                float4 q3 = p[3], q4 = p[4];
+                if (COUNT) nodes++;
+                wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+            } else {
+                if (COUNT) prims++;
+                uint32_t meta;
+                (void)testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta);
+            }
+        }
+    }
+    waveAddStat(&L.closest_rays, rays);
+    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
+    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1), Q_EXTP);
+    if (threadIdx.x == 0) {
+        ctl.closest_rays += L.closest_rays;
+        if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
+    }
+}
+
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
-template<bool COUNT, bool FLAT, int INST = 0>
+// WIDE: the scene has a wide BVH and no instances (the walk the wavefront kernels do, one ray per lane without refills)
+template<bool COUNT, bool FLAT, int INST = 0, bool WIDE = false>
 __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 *rays, float4 *hits, uint32_t n, BlockStats *stats)
 {
     extern __shared__ int ldsStack[];
@@ -439,8 +538,9 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
         RayD ray;
         ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
         int hitInst;      // TgHipHit reports the record that was hit, not the instance it was reached through
-        hits[i] = INST ? traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
-                       : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
+        if (WIDE) hits[i] = traverseClosestWide<COUNT>(s, ray, reinterpret_cast<uint2 *>(ldsStack) + threadIdx.x, blockDim.x, nodes, prims);
+        else hits[i] = INST ? traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
+                            : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
     }
     if (COUNT) {
         waveAddStat(&ldsNodes, nodes);
@@ -1338,6 +1438,148 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
                 } else {
                     sp--;
                     cur = stack[sp*stride];
+                }
+            }
+            if (rayDone) {
+                r++;
+                if (!setupRay())
+                    finishSlot();
+            }
+        }
+    }
+    waveAddStat(&L.shadow_rays, rays);
+    waveAddStat(&L.shadow_slots, slots);
+    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
+
+    queuesEnd(L, st, Q_SHADOW, 1u << Q_FIN);
+    if (threadIdx.x == 0) {
+        ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
+        if (COUNT) {
+            BlockStats &bs = st.stats[blockIdx.x];
+            bs.nodes_visited += L.nodes; bs.prims_tested += L.prims;
+            bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
+        }
+    }
+}
+
+// k_trace_shadow_dyn over the 8-wide BVH: any-hit queries, one memory round trip (a node or a record) per lane and loop
+// turn, like k_trace_closest_wide.  Dynamic LDS: [expanded queue, 2 B per slot][group stacks, wideDepth x 8 B per thread].
+template<bool COUNT, bool SOLIDS = true>
+__global__ SHADOW_DYN_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
+    uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2) + threadIdx.x;
+    const int stride = (int)blockDim.x;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    if (threadIdx.x == 0) fetchNext = 0;
+    queuesBegin(L, st, ctl, Q_SHADOW, 1u << Q_FIN, order);
+    const uint32_t n = L.n;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    const int minBounces = s.settings.min_bounces;
+    uint32_t nodes = 0, prims = 0, rays = 0, slots = 0;
+
+    bool busy = false;
+    uint32_t slot = 0, local = 0;
+    int r = 0;                                   // ray of the slot being traced (0: light sample, 1: bsdf sample)
+    f3 so = splat3(0.0f);
+    float eps = 0.0f;
+    f3 result = splat3(0.0f);
+    RayD ray; ray.o = splat3(0.0f); ray.d = splat3(1.0f); ray.tmin = 0.0f; ray.tmax = 0.0f;
+    WideRay wr; wr.idir = splat3(1.0f); wr.octInv = 0u;
+    WideState w;
+    wideStart(w);
+    f3 contrib = splat3(0.0f);
+    int endCap = -1;
+    bool exhausted = false;
+
+    // sets up ray `r` (or the next valid one) of the current slot; returns false when the slot has no ray left
+    auto setupRay = [&]() -> bool {
+        for (; r < 2; ++r) {
+            float4 c = r == 0 ? slotF4(st, A_SH_C0, slot) : slotF4(st, A_SH_C1, slot);
+            uint32_t tag = __float_as_uint(c.w);
+            if (tag == 0xFFFFFFFFu)
+                continue;
+            float4 sd = r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot);
+            endCap = (int)(tag & 0xFFFFFFu);
+            int bounce = (int)(tag >> 24);
+            rays++;
+            if (bounce < minBounces)
+                continue;                        // contributes nothing (TraceBase.cpp:114-115 with minBounces)
+            contrib = xyz(c);
+            ray.o = so; ray.d = xyz(sd); ray.tmin = eps; ray.tmax = sd.w;
+            wr = wideRaySetup(ray);
+            wideStart(w);
+            return true;
+        }
+        return false;
+    };
+    // NEE term -> path radiance; paths that ended at this vertex go on the finished list
+    auto finishSlot = [&]() {
+        float4 wgt = slotF4(st, A_SH_W, slot);
+        float4 p = slotF4(st, A_SH_P, slot);
+        f3 em = xyz(slotF4(st, A_EMI, slot));
+        em = em + (result*wgt.w)*xyz(wgt);       // emission += estimateDirect(...)*throughput
+        em = em + xyz(p);
+        slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
+        queuePush(FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE, local, L, Q_FIN);
+        busy = false;
+    };
+
+    for (;;) {
+        unsigned long long busyMask = __ballot(busy);
+        if (!exhausted && __popcll(busyMask) <= 48) {
+            unsigned long long want = ~busyMask;
+            uint32_t lane = laneId();
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
+            base = __shfl(base, 0);
+            if (!busy) {
+                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    local = order[i];
+                    slot = first + local;
+                    slots++;
+                    float4 o4 = slotF4(st, A_SH_O, slot);
+                    so = xyz(o4); eps = o4.w;
+                    result = splat3(0.0f);
+                    r = 0;
+                    busy = true;
+                    if (!setupRay())
+                        finishSlot();
+                }
+            }
+            if (base + (uint32_t)__popcll(want) >= n)
+                exhausted = true;
+            busyMask = __ballot(busy);
+        }
+        if (busyMask == 0ull)
+            break;
+        if (busy) {
+            uint32_t idx = 0;
+            const int what = wideNext(w, wr.octInv, stack, stride, idx);
+            bool rayDone = false;
+            if (what == 0) {
+                result = result + contrib;       // nothing in the way: transmittance 1
+                rayDone = true;
+            } else {
+                const uint32_t off = what == 2 ? idx*s.wide_stride : s.recs_offset + idx*48u;
+                const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
+                float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                if (what == 2) {
+                    float4 q3 = p[3], q4 = p[4];
+                    if (COUNT) nodes++;
+                    wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, ray.tmax);
+                } else {
+                    if (COUNT) prims++;
+                    float tmax = ray.tmax;
+                    float4 hit;
+                    uint32_t meta;
+                    if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                        rayDone = true;          // occluded
                 }
             }
             if (rayDone) {

@@ -60,6 +60,9 @@ struct tghip_ctx {
     DeviceBuffers sceneMem;
     DeviceScene scene;
     int bvhDepth = 0;
+    int wideDepth = 0;                    // levels of the 8-wide BVH (0: the scene has none, the kernels walk the BVH2)
+    bool wideOpt = true;                  // "wide_bvh" option: use it when the scene carries one
+    int wideStride = 80;                  // "wide_node_stride" option (80 or 128; takes effect at the next upload)
     uint32_t width = 0, height = 0;
 
     // framebuffer
@@ -257,7 +260,41 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
     return roots.empty() ? depth : depth + master + 1;
 }
 
+// Validates the wide BVH (children behind their parent, record runs inside the top-level records) and returns its depth,
+// -1 when malformed.
+static int wideDepthOf(const TgHipSceneDesc *s)
+{
+    const uint32_t n = s->num_wide_nodes;
+    const uint32_t topRecs = s->num_top_recs ? s->num_top_recs : s->num_recs;
+    std::vector<uint8_t> depth(n, 0);
+    depth[0] = 1;
+    int maxDepth = 1;
+    for (uint32_t i = 0; i < n; ++i) {
+        const TgHipWideNode &w = s->wide_nodes[i];
+        if (depth[i] == 0) return -1;                        // unreachable node: not a tree in breadth-first order
+        const uint32_t kids = uint32_t(__builtin_popcount(w.imask));
+        if (kids && (w.child_base <= i || uint64_t(w.child_base) + kids > n)) return -1;
+        for (uint32_t k = 0; k < kids; ++k) {
+            if (depth[w.child_base + k] != 0) return -1;     // two parents
+            depth[w.child_base + k] = uint8_t(depth[i] + 1);
+        }
+        if (kids) maxDepth = std::max(maxDepth, int(depth[i]) + 1);
+        if (maxDepth > TGHIP_MAX_WIDE_DEPTH) return -1;
+        for (int sl = 0; sl < 8; ++sl) {
+            if (w.imask & (1u << sl)) continue;
+            const uint32_t count = w.meta[sl] >> 5, off = w.meta[sl] & 31u;
+            if (count > TGHIP_WIDE_MAX_LEAF || off + count > 32u || (count && uint64_t(w.rec_base) + off + count > topRecs)) return -1;
+        }
+        for (int a = 0; a < 3; ++a)
+            if (w.exp[a] == 0 || w.exp[a] == 255) return -1;
+    }
+    return maxDepth;
+}
+
 static bool isFlat(const tghip_ctx *ctx) { return ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS && !ctx->haveInstances; }
+// the single-level traversal kernels walk the 8-wide BVH when the scene carries one
+static bool useWide(const tghip_ctx *ctx) { return ctx->wideDepth > 0 && ctx->wideOpt && ctx->dynamicFetch && !ctx->haveInstances && !isFlat(ctx); }
+
 
 // Dynamic LDS of the traversal kernels: one node stack of bvhDepth ints per thread (a root-to-leaf walk pushes at
 // most one far child per internal level), aliased with the expanded queue (2 B per slot) that is consumed before
@@ -275,15 +312,21 @@ static size_t dynLdsBytes(const tghip_ctx *ctx, int threads)
     return size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short) + size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
 }
 
+// the wide kernels: expanded queue + one 8-byte group entry per tree level and thread
+static size_t wideLdsBytes(const tghip_ctx *ctx, int threads)
+{
+    return size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short) + size_t(std::max(ctx->wideDepth, 1))*size_t(threads)*sizeof(uint2);
+}
+
 static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*std::max(ctx->blocksPerCu, 1); }
 
 // Largest workgroup size (multiple of 64, <= maxThreads) at which `blocksPerCu` workgroups of `kernel` fit on a CU.
 template<typename K>
-static int pickThreads(const tghip_ctx *ctx, K kernel, int maxThreads, int ldsMode)   // 0: no dynamic LDS, 1: traceLdsBytes, 2: dynLdsBytes
+static int pickThreads(const tghip_ctx *ctx, K kernel, int maxThreads, int ldsMode)   // 0: no dynamic LDS, 1: traceLdsBytes, 2: dynLdsBytes, 3: wideLdsBytes
 {
     for (int t = maxThreads; t >= 128; t -= 64) {
         int nb = 0;
-        size_t lds = ldsMode == 1 ? traceLdsBytes(ctx, t) : ldsMode == 2 ? dynLdsBytes(ctx, t) : 0;
+        size_t lds = ldsMode == 1 ? traceLdsBytes(ctx, t) : ldsMode == 2 ? dynLdsBytes(ctx, t) : ldsMode == 3 ? wideLdsBytes(ctx, t) : 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), t, lds) == hipSuccess && nb >= ctx->blocksPerCu)
             return t;
     }
@@ -378,11 +421,15 @@ static void chooseThreads(tghip_ctx *ctx)
     } else {
     const bool inst = ctx->haveInstances;
     const bool dyn = ctx->dynamicFetch && !inst;               // the dynamic-fetch kernels are single-level
-    ctx->thrClosest = flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
+    const bool wide = useWide(ctx);
+    ctx->thrClosest = wide ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 320, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 320, 3))
+                    : flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
                     : inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest<false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_closest<false, false, 2>, 512, 1))
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
-    if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
+    if (wide && !ctx->haveForward && !ctx->haveMeshLight)
+        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false>, 256, 3);
+    else if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
         ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_dyn<false, true>, 256, 2) : pickThreads(ctx, k_trace_shadow_dyn<false, false>, 256, 2);   // measured: 192 / 256 / 320 / 384 threads = 525 / 462 / 633 / 619 us per launch
     else if (inst)
         ctx->thrShadow = (ctx->haveForward || ctx->haveMeshLight)
@@ -503,6 +550,8 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
     else if (k == "run_to_completion") ctx->loopOpt = value != 0;
     else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
+    else if (k == "wide_node_stride") { if (value != 80 && value != 128) { ctx->error = "wide_node_stride is 80 or 128"; return TGHIP_E_INVALID; } ctx->wideStride = int(value); }
+    else if (k == "wide_bvh") { ctx->wideOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "dynamic_fetch") { ctx->dynamicFetch = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "threads_closest") { ctx->thrOverride[0] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "threads_shadow") { ctx->thrOverride[1] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
@@ -585,7 +634,29 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     int rc;
     const TgHipBvhNode *dn; const TgHipPrimRec *dr; const TgHipTriAttr *da;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->nodes, sd->num_nodes, &dn)) != TGHIP_OK) return rc;
-    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->recs, sd->num_recs, &dr)) != TGHIP_OK) return rc;
+    ctx->wideDepth = 0;
+    if (sd->wide_nodes && sd->num_wide_nodes && sd->num_instances == 0) {
+        // the wide nodes and the primitive records share ONE allocation, so that a lane of the wide kernels addresses
+        // "a node or a record" with one base pointer and one 32-bit offset
+        const int wd = wideDepthOf(sd);
+        if (wd < 0) { ctx->error = "malformed wide BVH"; return TGHIP_E_INVALID; }
+        const size_t stride = size_t(ctx->wideStride);
+        const size_t nodeBytes = (size_t(sd->num_wide_nodes)*stride + 127u) & ~size_t(127);
+        const size_t recBytes = std::max<size_t>(sd->num_recs, 1)*sizeof(TgHipPrimRec);
+        if (nodeBytes + recBytes < (1ull << 32)) {
+            char *p = nullptr;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p), nodeBytes + recBytes));
+            ctx->sceneMem.allocs.push_back(p);
+            HIP_TRY(ctx, hipMemcpy2DAsync(p, stride, sd->wide_nodes, sizeof(TgHipWideNode), sizeof(TgHipWideNode), sd->num_wide_nodes, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(p + nodeBytes, sd->recs, size_t(sd->num_recs)*sizeof(TgHipPrimRec), hipMemcpyHostToDevice, ctx->stream));
+            s.wide = reinterpret_cast<const float4 *>(p);
+            s.recs_offset = uint32_t(nodeBytes);
+            s.wide_stride = uint32_t(stride);
+            dr = reinterpret_cast<const TgHipPrimRec *>(p + nodeBytes);
+            ctx->wideDepth = wd;
+        }
+    }
+    if (!ctx->wideDepth && (rc = uploadArray(ctx, ctx->sceneMem, sd->recs, sd->num_recs, &dr)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->tri_attrs, sd->num_recs, &da)) != TGHIP_OK) return rc;
     s.nodes = reinterpret_cast<const float4 *>(dn);
     s.recs = reinterpret_cast<const float4 *>(dr);
@@ -792,6 +863,12 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
 #undef SHADOW_INST
         return false;
     }
+    if (useWide(ctx) && !closestWalk && !ctx->auxPass) {
+        const size_t lds = wideLdsBytes(ctx, ctx->thrShadow);
+        if (ctx->haveSolids) hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->stream, ctx->scene, st, pp, iterTag);
+        else                 hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, false>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->stream, ctx->scene, st, pp, iterTag);
+        return true;
+    }
     if (!flat && !closestWalk && ctx->dynamicFetch && !ctx->auxPass) {   // (the dynamic-fetch kernel does not report transmittances)
         if (ctx->haveSolids) hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, true>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
                                                 ctx->scene, st, pp, iterTag);
@@ -902,6 +979,12 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 if (ctx->haveSolids) { if (count) CLOSEST_INST(true, 1); else CLOSEST_INST(false, 1); }
                 else                 { if (count) CLOSEST_INST(true, 2); else CLOSEST_INST(false, 2); }
 #undef CLOSEST_INST
+            } else if (useWide(ctx)) {
+                const size_t ldsWide = wideLdsBytes(ctx, ctx->thrClosest);
+#define CLOSEST_WIDE(C, S) hipLaunchKernelGGL((k_trace_closest_wide<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->stream, s, st)
+                if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true); else CLOSEST_WIDE(false, true); }
+                else                 { if (count) CLOSEST_WIDE(true, false); else CLOSEST_WIDE(false, false); }
+#undef CLOSEST_WIDE
             } else {
                 if (ctx->dynamicFetch) {
                     const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
@@ -1333,7 +1416,12 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
         const bool cnt = ctx->countTraversal && r == 0;
         const bool flat = isFlat(ctx);
 #define RAYS_LAUNCH(C, F) hipLaunchKernelGGL((k_trace_rays<C, F>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats)
-        if (ctx->haveInstances) {
+        if (useWide(ctx)) {
+            const size_t ldsWide = size_t(std::max(ctx->wideDepth, 1))*256u*sizeof(uint2);
+            if (cnt) hipLaunchKernelGGL((k_trace_rays<true, false, 0, true>), dim3(grid), dim3(256), ldsWide, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
+            else     hipLaunchKernelGGL((k_trace_rays<false, false, 0, true>), dim3(grid), dim3(256), ldsWide, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
+        }
+        else if (ctx->haveInstances) {
             if (cnt) hipLaunchKernelGGL((k_trace_rays<true, false, 1>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
             else     hipLaunchKernelGGL((k_trace_rays<false, false, 1>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
         }

@@ -1,9 +1,11 @@
 #include "TraceableScene.hpp"
 #include "Sampling.hpp"
 #include "BvhBuilder.hpp"
+#include "WideBvh.hpp"
 #include "Integrator.hpp"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -345,6 +347,26 @@ void TraceableScene::flatten()
     _nodes.swap(bvh.nodes);
     _bvhDepth = bvh.maxDepth;
     _bvhSah = bvh.sahCost;
+    // ---- the 8-wide BVH the single-level traversal kernels walk (WideBvh.hpp): the BVH2 collapsed, records re-ordered by
+    // wide node.  Flat-list scenes are intersected without a tree, scenes with instances walk the two-level BVH2.
+    _wideNodes.clear();
+    _wideDepth = 0;
+    if (numInstances == 0 && _recs.size() > TGHIP_FLAT_MAX_RECS && !std::getenv("TGH_NO_WIDE_BVH")) {
+        std::vector<Box3f> ordered(recBounds.size());
+        for (size_t i = 0; i < bvh.order.size(); ++i)
+            ordered[i] = recBounds[bvh.order[i]];
+        WideBvhResult wide = buildWideBvh(_nodes, ordered);
+        if (!wide.nodes.empty()) {
+            for (size_t i = 0; i < wide.order.size(); ++i) {
+                recs[i] = _recs[wide.order[i]];
+                attrs[i] = _triAttrs[wide.order[i]];
+            }
+            _recs.swap(recs);
+            _triAttrs.swap(attrs);
+            _wideNodes.swap(wide.nodes);
+            _wideDepth = wide.depth;
+        }
+    }
     const uint32_t numTopRecs = uint32_t(_recs.size());
 
     // ---- masters of instanced geometry: records in master space + one BVH2 subtree each, behind the top level ----
@@ -472,6 +494,8 @@ void TraceableScene::flatten()
     _desc.bsdfs = _bsdfs.data();
     _desc.textures = _textures.data();
     _desc.media = _media.empty() ? nullptr : _media.data();
+    _desc.wide_nodes = _wideNodes.empty() ? nullptr : _wideNodes.data();
+    _desc.num_wide_nodes = uint32_t(_wideNodes.size());
     _desc.num_media = uint32_t(_media.size());
     _desc.texels = _texels.data(); _desc.num_texel_floats = _texels.size();
     _desc.dist = _dist.data();     _desc.num_dist_floats = _dist.size();

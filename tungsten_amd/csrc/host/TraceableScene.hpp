@@ -23,6 +23,7 @@ class TraceableScene
     uint32_t _seed;
 
     std::vector<TgHipBvhNode> _nodes;
+    std::vector<TgHipWideNode> _wideNodes;
     std::vector<TgHipPrimRec> _recs;
     std::vector<TgHipTriAttr> _triAttrs;
     std::vector<TgHipObject> _objects;
@@ -35,6 +36,7 @@ class TraceableScene
     TgHipSceneDesc _desc;
     Box3f _sceneBounds;
     int _bvhDepth = 0;
+    int _wideDepth = 0;
     double _bvhSah = 0.0, _buildSeconds = 0.0;
 
     void flatten();
@@ -50,6 +52,7 @@ public:
     const RendererSettings &rendererSettings() const { return _scene.renderer; }
     const Box3f &bounds() const { return _sceneBounds; }
     int bvhDepth() const { return _bvhDepth; }
+    int wideDepth() const { return _wideDepth; }
     double bvhSahCost() const { return _bvhSah; }
     double buildSeconds() const { return _buildSeconds; }
     size_t numLights() const { return _lights.size(); }
