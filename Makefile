@@ -33,7 +33,7 @@ $(OBJDIR)/%.o: tungsten_amd/csrc/hip/%.hip $(HIPHDR)
 
 $(LIBDIR)/libtungsten_hip.so: $(HOSTOBJ) $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lpthread -ldl
 
 $(LIBDIR)/tungsten_hip: tungsten_amd/csrc/host/main.cpp $(LIBDIR)/libtungsten_hip.so
 	g++ $(HOSTFLAGS) $< -o $@ -L$(LIBDIR) -ltungsten_hip -Wl,-rpath,'$$ORIGIN' -lpthread

@@ -15,6 +15,9 @@
  *   tghip_abort             <- PathTraceIntegrator::abortRender (PathTraceIntegrator.cpp:246-256).
  *   tghip_download_framebuffer <- OutputBuffer<Vec3f>::addSample / operator[] (cameras/OutputBuffer.hpp:104-144).
  *   tghip_trace_rays        <- TraceableScene::intersect (renderer/TraceableScene.hpp:170-192), batched.
+ *   tghip_reduce_framebuffers <- the merge of per-machine partial renders the reference does offline on the host
+ *                              (src/hdrmanip/hdrmanip.cpp:69-112: load N HDR images, add, divide); here the tile shards of
+ *                              one frame, summed on the device side by RCCL over xGMI.
  *   tghip_get_counters      <- (no reference analogue; feeds the roofline model).
  *
  * Ownership: the caller owns every host array (borrowed for the duration of the call; the
@@ -82,9 +85,10 @@ typedef struct TgHipBvhNode {
  *   child box plane k of axis a = origin[a] + q * 2^(exp[a] - 127)           (q in 0..255; lower planes rounded down,
  *                                                                              upper planes up: boxes only ever grow)
  *   slot s holds an internal child iff imask bit s; internal children are consecutive nodes from child_base in slot order
- *   a leaf child's records are recs[rec_base + (meta[s] & 31) ... + (meta[s] >> 5) + 1): the leaf children of one node
- *     share one contiguous run of at most 32 records (records are ordered by wide node, breadth first)
- *   an empty slot has qlo = 255 > qhi = 0 on every axis (no ray passes its box test)
+ *   leaf_valid bit 4 s + j: the leaf child in slot s has a j-th record (j < its record count <= 4); that record is
+ *     recs[rec_base + number of leaf_valid bits below it]: the leaf children of one node share one contiguous run of at
+ *     most 32 records, in slot order (records are ordered by wide node, breadth first)
+ *   an empty slot has qlo = 255 > qhi = 0 on every axis (no ray passes its box test) and no leaf_valid bits
  * Children sit in the slot whose sign pattern (bit 0: +x, bit 1: +y, bit 2: +z) best matches the direction from the
  * node's centre to theirs, so that visiting hit slots in ascending (slot XOR ray octant) order is roughly front to back
  * without sorting distances (Ylitie, Karras, Laine: "Efficient incoherent ray traversal on GPUs through compressed wide
@@ -96,7 +100,8 @@ typedef struct TgHipWideNode {
     uint8_t  imask;
     uint32_t child_base;
     uint32_t rec_base;
-    uint8_t  meta[8];
+    uint32_t leaf_valid;
+    uint32_t reserved;
     uint8_t  qlo[3][8];       /* [axis][slot] */
     uint8_t  qhi[3][8];
 } TgHipWideNode;              /* 80 B */
@@ -386,6 +391,14 @@ int tghip_upload_aux(tghip_ctx *ctx, const TgHipAuxPixel *in, size_t npixels);
 /* the per-sample radiance of the last TGHIP_PASS_SAMPLES pass: nfloats = W*H*(spp_end - spp_begin)*3, laid out
  * [pixel (row-major)][sample - spp_begin][rgb]; samples of pixels the pass's shard does not own are zero */
 int tghip_download_samples(tghip_ctx *ctx, float *rgb, size_t nfloats);
+/* Multi-GPU framebuffer merge inside one process: ctxs[0..n) are the contexts (one per device, all with the same scene
+ * uploaded) that rendered the tile shards 0..n-1 of a frame (TgHipPassDesc.shard_index/shard_count).  Their radiance sums
+ * (float32) and sample counts (uint32) are sum-reduced by RCCL (ncclReduce over xGMI, one communicator per device, created at
+ * the first call and kept) into a scratch buffer on ctxs[root]'s device and copied from there into rgb_sum / count (host,
+ * npixels = W*H; either may be NULL).  Tile ownership is disjoint, so the sums are exact (x + 0) in any reduction order; the
+ * contexts' own framebuffers are left as they are, so passes can go on accumulating.  librccl.so is loaded at the first call;
+ * TGHIP_E_UNSUPPORTED when it is missing. */
+int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rgb_sum, uint32_t *count, size_t npixels);
 int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);

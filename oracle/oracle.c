@@ -1437,11 +1437,12 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit 
     const float idir[3] = {wide_inv(ray->d.x), wide_inv(ray->d.y), wide_inv(ray->d.z)};
     const float org[3] = {ray->o.x, ray->o.y, ray->o.z};
     const uint32_t octInv = (idir[0] < 0.0f ? 1u : 0u) | (idir[1] < 0.0f ? 2u : 0u) | (idir[2] < 0.0f ? 4u : 0u);
-    uint32_t grpBase = 0, grpMasks = 0, triBase = 0, triMask = 0;
+    uint32_t grpBase = 0, grpMasks = 0, triBase = 0, triMask = 0, triValid = 0;
     int32_t node = 0;
     for (;;) {
         if (triMask) {
-            uint32_t i = triBase + (uint32_t)__builtin_ctz(triMask);
+            uint32_t b = (uint32_t)__builtin_ctz(triMask);
+            uint32_t i = triBase + (uint32_t)__builtin_popcount(triValid & ((1u << b) - 1u));
             triMask &= triMask - 1u;
             if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
                 test_rec(s, i, ray, tmax, hit, st, objFilter, -1);
@@ -1469,7 +1470,7 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit 
             adjS[a] = wide_spacing(n->exp[a])*idir[a];
             adjO[a] = (n->origin[a] - org[a])*idir[a];
         }
-        uint32_t hitmask = 0, tm = 0;
+        uint32_t hitmask = 0;
         for (int sl = 0; sl < 8; ++sl) {
             float tn = ray->tmin, tf = *tmax;
             float tnA[3], tfA[3];
@@ -1482,16 +1483,17 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit 
             tn = fmaxf(fmaxf(tnA[0], tnA[1]), fmaxf(tnA[2], tn));
             tf = fminf(fminf(tfA[0], tfA[1]), fminf(tfA[2], tf));
             tf *= 1.0000004f;
-            if (tn <= tf) {
+            if (tn <= tf)
                 hitmask |= 1u << sl;
-                const uint32_t m = n->meta[sl];
-                tm |= ((1u << (m >> 5)) - 1u) << (m & 31u);
-            }
         }
         grpBase = n->child_base;
         grpMasks = ((uint32_t)n->imask << 8) | wide_permute(hitmask & n->imask, octInv);
         triBase = n->rec_base;
-        triMask = tm;
+        triValid = n->leaf_valid;
+        triMask = 0;
+        for (int sl = 0; sl < 8; ++sl)
+            if ((hitmask & ~(uint32_t)n->imask) >> sl & 1u) triMask |= 15u << (4*sl);
+        triMask &= triValid;
     }
 }
 void oracle_set_wide_bvh(int on) { g_use_wide = on; }

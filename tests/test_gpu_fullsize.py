@@ -1,0 +1,57 @@
+"""BASELINE.json's configurations at their full image sizes, through size-independent properties: every pixel receives exactly
+spp finite, non-negative samples; the counters add up; rays per sample stay in the scene's range; and a sub-sample of pixels of
+one 16-pixel tile row agrees with the oracle tracing the same (pixel, sample) streams.
+  configs[2]  materialtest 1920x1080, the dielectric and rough-dielectric variants of its "Material" bsdf
+  configs[3]  the 998 000-triangle mesh + HDRI, 1920x1080
+  configs[4]  10 000 instances of a 19 800-triangle mesh, four materials, 3840x2160
+(The sample counts are small: the properties do not depend on them, and the 1280x720 cases of test_gpu_parity.py carry more.)"""
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenes
+import tungsten_amd as tg
+from test_gpu_parity import compare, gpu_render
+
+pytestmark = pytest.mark.gpu
+SEED = tg.DEFAULT_SEED
+
+CASES = {
+    "c3_dielectric": (lambda d, res, spp: scenes.materialtest(d, resolution=res, spp=spp, edit=scenes._mt_material({"type": "dielectric", "ior": 1.5, "albedo": 1})),
+                      (1920, 1080), 4, (3.0, 9.0), 0.05),
+    "c3_rough_dielectric": (lambda d, res, spp: scenes.materialtest(d, resolution=res, spp=spp, edit=scenes._mt_material(
+                                {"type": "rough_dielectric", "ior": 1.5, "distribution": "ggx", "roughness": 0.1, "albedo": 1})),
+                            (1920, 1080), 4, (3.0, 9.0), 0.05),
+    "c4_mesh1m": (lambda d, res, spp: scenes.mesh1m(d, resolution=res, spp=spp), (1920, 1080), 2, (2.5, 7.0), 0.05),
+    "c5_instances10k": (lambda d, res, spp: scenes.instances10k(d, resolution=res, spp=spp), (3840, 2160), 1, (2.0, 9.0), 0.08),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_baseline_configuration_at_full_size(case, tmp_path):
+    if not scenes.have_materialtest():
+        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+    mk, (w, h), spp, (rays_lo, rays_hi), max_bad = CASES[case]
+    path = mk(tmp_path, (w, h), spp)
+    mean, ssum, count, c = gpu_render(path)
+    assert mean.shape == (h, w, 3)
+    assert (count == spp).all()
+    assert c.samples == w*h*spp
+    assert np.isfinite(mean).all() and (mean >= 0).all()
+    assert rays_lo <= (c.closest_rays + c.shadow_rays)/c.samples <= rays_hi
+    # the oracle on every 8th pixel of the tile row through the middle of the image: same pixels, same random streams
+    flat = tg.FlattenedScene(path)
+    y0 = ((h//2)//16)*16
+    ys, xs = range(y0, y0 + 16, 2), range(0, w, 8)
+    om = np.zeros((len(ys), len(xs), 3), np.float32)
+    for iy, y in enumerate(ys):
+        for ix, x in enumerate(xs):
+            acc = np.zeros(3, np.float64)
+            for s in range(spp):
+                acc += oracle_lib.trace_sample(flat.desc, SEED, x, y, s)
+            om[iy, ix] = acc/spp
+    flat.close()
+    gm = mean[y0:y0 + 16:2, ::8]
+    # (one to four samples per pixel: a divergent path is a divergent pixel; the bound is the per-sample divergence of the
+    # scene's BSDFs, tests/test_gpu_samples.py, times the samples per pixel, with margin)
+    compare(gm, om, max_bad=max_bad, mean_rel=3e-2)

@@ -340,3 +340,48 @@ def test_many_instances_match_oracle(tmp_path):
     assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 0.01*oc.closest_rays
     # (exact node / record visit counts of the two-level walk: test_trace_rays_matches_oracle_exactly[instances]; a pass's
     # totals differ because the device answers shadow rays with any-hit queries, the oracle with closest-hit walks)
+
+
+def _shard_contexts(path, n, spp, seed=SEED):
+    """n contexts (device i % device_count... one per device) that each render tile shard i of n; returns (flat, ctxs)."""
+    import ctypes as C
+    flat = tg.FlattenedScene(path)
+    ctxs = []
+    for i in range(n):
+        ctx = tg.lib.tghip_create(i)
+        assert ctx, tg.lib.tghip_last_error(None)
+        assert tg.lib.tghip_upload_scene(ctx, flat.desc) == 0
+        p = tg.TgHipPassDesc(0, spp, seed, i, n, 0)
+        assert tg.lib.tghip_render_pass(ctx, C.byref(p)) == 0
+        ctxs.append(ctx)
+    return flat, ctxs
+
+
+@pytest.mark.parametrize("n", [1, 2])
+def test_rccl_framebuffer_reduce_behind_the_c_abi(n, tmp_path):
+    """tghip_reduce_framebuffers: the tile shards of n in-process contexts, one per device, summed by RCCL into
+    the root's scratch buffer -- bit-identical to the unsharded render (disjoint tiles: x + 0).  n = 1 runs the whole RCCL path
+    (library load, communicator, ncclReduce) on the one device every box has; n = 2 needs two devices."""
+    import ctypes as C
+    if tg.device_count() < n:
+        pytest.skip("needs %d HIP devices" % n)
+    w, h, spp = 200, 120, 4
+    path = scenes.cornell(tmp_path, resolution=(w, h), spp=spp)
+    whole, wsum, wcount, _ = gpu_render(path)
+    flat, ctxs = _shard_contexts(path, n, spp)
+    npix = w*h
+    s, c = np.full((npix, 3), -1, np.float32), np.full(npix, 7, np.uint32)
+    arr = (C.c_void_p*n)(*ctxs)
+    rc = tg.lib.tghip_reduce_framebuffers(arr, n, 0, s.ctypes.data, c.ctypes.data, npix)
+    assert rc == 0, tg.lib.tghip_last_error(ctxs[0])
+    assert (c.reshape(h, w) == wcount).all() and (wcount == spp).all()
+    assert s.reshape(h, w, 3).tobytes() == wsum.tobytes()
+    # the shards' own framebuffers are untouched (a second reduce gives the same image) and wrong arguments are refused
+    s2, c2 = np.empty_like(s), np.empty_like(c)
+    assert tg.lib.tghip_reduce_framebuffers(arr, n, 0, s2.ctypes.data, c2.ctypes.data, npix) == 0
+    assert s2.tobytes() == s.tobytes() and (c2 == c).all()
+    assert tg.lib.tghip_reduce_framebuffers(arr, n, n, s.ctypes.data, c.ctypes.data, npix) == -1
+    assert tg.lib.tghip_reduce_framebuffers(arr, n, 0, s.ctypes.data, c.ctypes.data, npix + 1) == -1
+    for ctx in ctxs:
+        tg.lib.tghip_destroy(ctx)
+    flat.close()

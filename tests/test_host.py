@@ -153,7 +153,7 @@ def check_wide_bvh(desc):
     exp, imask = raw[:, 12:15], raw[:, 15]
     child_base = raw[:, 16:20].copy().view(np.uint32)[:, 0]
     rec_base = raw[:, 20:24].copy().view(np.uint32)[:, 0]
-    meta = raw[:, 24:32]
+    leaf_valid = raw[:, 24:28].copy().view(np.uint32)[:, 0]
     qlo, qhi = raw[:, 32:56].reshape(n, 3, 8), raw[:, 56:80].reshape(n, 3, 8)
     spacing = np.ldexp(np.float32(1.0), exp.astype(np.int32) - 127).astype(np.float32)
     recs = _np(desc.recs, desc.num_recs, np.float32, 12)
@@ -188,7 +188,9 @@ def check_wide_bvh(desc):
                 blo, bhi = exact[child_base[i] + k]
                 k += 1
             else:
-                cnt, off = meta[i, s] >> 5, meta[i, s] & 31
+                bits = int(leaf_valid[i] >> (4*s)) & 15
+                assert bits in (0, 1, 3, 7, 15)
+                cnt, off = bin(bits).count("1"), bin(int(leaf_valid[i]) & ((1 << (4*s)) - 1)).count("1")
                 if cnt == 0:
                     assert (qlo[i, :, s] == 255).all() and (qhi[i, :, s] == 0).all()     # empty slot: no ray passes
                     continue

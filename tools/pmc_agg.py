@@ -1,14 +1,30 @@
-"""Mean of every collected PMC counter per kernel from a rocprofv3 counter_collection.csv.  usage: pmc_agg.py <csv>..."""
-import csv, re, sys
+"""Sums every counter of a rocprofv3 --pmc pass per kernel class.  usage: pmc_agg.py <counter_collection.csv> [<more.csv> ...]
+Prints one JSON object: {kernel: {counter: total, ..., "launches": n}}."""
+import csv
+import json
+import re
+import sys
 from collections import defaultdict
-acc = defaultdict(lambda: defaultdict(float)); n = defaultdict(lambda: defaultdict(int))
-for path in sys.argv[1:]:
-    with open(path) as f:
-        for row in csv.DictReader(f):
-            k = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
-            if not k.startswith("k_"): continue
-            acc[k][row["Counter_Name"]] += float(row["Counter_Value"]); n[k][row["Counter_Name"]] += 1
-for k in sorted(acc):
-    print(k)
-    for c in sorted(acc[k]):
-        print("   %-28s %16.1f  (n=%d)" % (c, acc[k][c]/n[k][c], n[k][c]))
+
+
+def main():
+    sums = defaultdict(lambda: defaultdict(float))
+    launches = defaultdict(set)
+    for path in sys.argv[1:]:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                k = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()
+                if not k.startswith("k_"):
+                    continue
+                k = re.sub(r"<.*", "", k)
+                sums[k][row["Counter_Name"]] += float(row["Counter_Value"])
+                launches[k].add(row.get("Dispatch_Id"))
+    out = {}
+    for k, c in sorted(sums.items()):
+        out[k] = {n: round(v) for n, v in sorted(c.items())}
+        out[k]["launches"] = len(launches[k])
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()

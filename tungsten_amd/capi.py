@@ -20,7 +20,7 @@ class TgHipBvhNode(C.Structure):
 
 class TgHipWideNode(C.Structure):
     _fields_ = [("origin", f32*3), ("exp", C.c_uint8*3), ("imask", C.c_uint8), ("child_base", u32), ("rec_base", u32),
-                ("meta", C.c_uint8*8), ("qlo", (C.c_uint8*8)*3), ("qhi", (C.c_uint8*8)*3)]
+                ("leaf_valid", u32), ("reserved", u32), ("qlo", (C.c_uint8*8)*3), ("qhi", (C.c_uint8*8)*3)]
 
 
 class TgHipPrimRec(C.Structure):
@@ -156,6 +156,7 @@ PROTOTYPES = {
     "tghip_download_aux": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_upload_aux": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_download_samples": (C.c_int, [VP, VP, C.c_size_t]),
+    "tghip_reduce_framebuffers": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, VP, VP, C.c_size_t]),
     "tghip_trace_rays": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "tghip_set_option": (C.c_int, [VP, C.c_char_p, C.c_longlong]),
     "tghip_get_counters": (C.c_int, [VP, C.POINTER(TgHipCounters)]),

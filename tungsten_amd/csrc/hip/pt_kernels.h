@@ -576,16 +576,18 @@ PT_DEV uint32_t widePermute(uint32_t h, uint32_t oct)      // bit (s ^ oct) of t
 }
 struct WideState {
     uint32_t grpBase, grpMasks;   // hits still to visit (bits 0-7, traversal order) | imask << 8
-    uint32_t triBase, triMask;
+    uint32_t triBase, triMask;    // records still to test: bit positions in the node's leaf_valid
+    uint32_t triValid;
     int node;                     // node to visit next; -1: take it from the group / the stack
     int sp;
 };
-PT_DEV void wideStart(WideState &w) { w.grpBase = 0; w.grpMasks = 0; w.triBase = 0; w.triMask = 0; w.node = 0; w.sp = 0; }
+PT_DEV void wideStart(WideState &w) { w.grpBase = 0; w.grpMasks = 0; w.triBase = 0; w.triMask = 0; w.triValid = 0; w.node = 0; w.sp = 0; }
 // What the lane fetches next: 1 = primitive record `idx`, 2 = node `idx`, 0 = the walk is over.
 PT_DEV int wideNext(WideState &w, uint32_t octInv, uint2 *stack, int stride, uint32_t &idx)
 {
     if (w.triMask) {
-        idx = w.triBase + (uint32_t)__ffs((int)w.triMask) - 1u;
+        const uint32_t b = (uint32_t)__ffs((int)w.triMask) - 1u;
+        idx = w.triBase + (uint32_t)__popc(w.triValid & ((1u << b) - 1u));
         w.triMask &= w.triMask - 1u;
         return 1;
     }
@@ -608,13 +610,17 @@ PT_DEV int wideNext(WideState &w, uint32_t octInv, uint2 *stack, int stride, uin
     w.node = -1;
     return 2;
 }
-// The node's 80 bytes have arrived: slab-test its eight children against [tmin, tmax], queue the hit ones.
+// The node's 80 bytes have arrived: slab-test its eight children against [tmin, tmax], queue the hit ones.  Two children per
+// v_pk_fma_f32; each half is one correctly rounded fma, as in the oracle's scalar fmaf.
+typedef float WideF2 __attribute__((ext_vector_type(2)));
 PT_DEV void wideVisit(WideState &w, float4 q0, float4 q1, float4 q2, float4 q3, float4 q4, f3 o, const WideRay &wr, float tmin, float tmax)
 {
     const uint32_t ex = __float_as_uint(q0.w);
     const f3 spacing = mk3(__uint_as_float((ex & 0xFFu) << 23), __uint_as_float(((ex >> 8) & 0xFFu) << 23), __uint_as_float(((ex >> 16) & 0xFFu) << 23));
     const f3 adjS = spacing*wr.idir;
     const f3 adjO = (xyz(q0) - o)*wr.idir;
+    const WideF2 SX = {adjS.x, adjS.x}, SY = {adjS.y, adjS.y}, SZ = {adjS.z, adjS.z};
+    const WideF2 OX = {adjO.x, adjO.x}, OY = {adjO.y, adjO.y}, OZ = {adjO.z, adjO.z};
     // the planes the ray enters (near) and leaves (far) through, per axis: qlo / qhi swapped for negative directions
     const bool nx = (wr.octInv & 1u) != 0u, ny = (wr.octInv & 2u) != 0u, nz = (wr.octInv & 4u) != 0u;
     const uint32_t lx0 = __float_as_uint(q2.x), lx1 = __float_as_uint(q2.y), ly0 = __float_as_uint(q2.z), ly1 = __float_as_uint(q2.w);
@@ -623,27 +629,32 @@ PT_DEV void wideVisit(WideState &w, float4 q0, float4 q1, float4 q2, float4 q3, 
     const uint32_t nearX[2] = {nx ? hx0 : lx0, nx ? hx1 : lx1}, farX[2] = {nx ? lx0 : hx0, nx ? lx1 : hx1};
     const uint32_t nearY[2] = {ny ? hy0 : ly0, ny ? hy1 : ly1}, farY[2] = {ny ? ly0 : hy0, ny ? ly1 : hy1};
     const uint32_t nearZ[2] = {nz ? hz0 : lz0, nz ? hz1 : lz1}, farZ[2] = {nz ? lz0 : hz0, nz ? lz1 : hz1};
-    const uint32_t meta[2] = {__float_as_uint(q1.z), __float_as_uint(q1.w)};
-    uint32_t hitmask = 0u, triMask = 0u;
+    uint32_t hitmask = 0u;
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-        const int d = sl >> 2, sh = (sl & 3)*8;
-        float tnx = fmaf((float)((nearX[d] >> sh) & 0xFFu), adjS.x, adjO.x), tfx = fmaf((float)((farX[d] >> sh) & 0xFFu), adjS.x, adjO.x);
-        float tny = fmaf((float)((nearY[d] >> sh) & 0xFFu), adjS.y, adjO.y), tfy = fmaf((float)((farY[d] >> sh) & 0xFFu), adjS.y, adjO.y);
-        float tnz = fmaf((float)((nearZ[d] >> sh) & 0xFFu), adjS.z, adjO.z), tfz = fmaf((float)((farZ[d] >> sh) & 0xFFu), adjS.z, adjO.z);
-        float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
-        float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
-        tf *= 1.0000004f;
-        const bool h = tn <= tf;
-        hitmask |= h ? (1u << sl) : 0u;
-        const uint32_t m = (meta[d] >> sh) & 0xFFu;                 // leaf: count << 5 | first record; 0: empty or internal
-        triMask |= h ? (((1u << (m >> 5)) - 1u) << (m & 31u)) : 0u;
+    for (int pr = 0; pr < 4; ++pr) {                // children 2 pr and 2 pr + 1
+        const int d = pr >> 1, sh = (pr & 1)*16;
+        auto pair = [&](uint32_t word) { WideF2 v = {(float)((word >> sh) & 0xFFu), (float)((word >> (sh + 8)) & 0xFFu)}; return v; };
+        const WideF2 tnx = __builtin_elementwise_fma(pair(nearX[d]), SX, OX), tfx = __builtin_elementwise_fma(pair(farX[d]), SX, OX);
+        const WideF2 tny = __builtin_elementwise_fma(pair(nearY[d]), SY, OY), tfy = __builtin_elementwise_fma(pair(farY[d]), SY, OY);
+        const WideF2 tnz = __builtin_elementwise_fma(pair(nearZ[d]), SZ, OZ), tfz = __builtin_elementwise_fma(pair(farZ[d]), SZ, OZ);
+        float tn0 = fmaxf(fmaxf(tnx.x, tny.x), fmaxf(tnz.x, tmin)), tn1 = fmaxf(fmaxf(tnx.y, tny.y), fmaxf(tnz.y, tmin));
+        float tf0 = fminf(fminf(tfx.x, tfy.x), fminf(tfz.x, tmax)), tf1 = fminf(fminf(tfx.y, tfy.y), fminf(tfz.y, tmax));
+        tf0 *= 1.0000004f; tf1 *= 1.0000004f;
+        hitmask |= (tn0 <= tf0) ? (1u << (2*pr)) : 0u;
+        hitmask |= (tn1 <= tf1) ? (2u << (2*pr)) : 0u;
     }
     const uint32_t imask = ex >> 24;
+    // the records of the hit leaf children: bit s -> bits 4 s .. 4 s + 3, masked by the records that exist
+    uint32_t x = hitmask & ~imask;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    x = (x << 4) - x;
     w.grpBase = __float_as_uint(q1.x);
     w.grpMasks = (imask << 8) | widePermute(hitmask & imask, wr.octInv);
     w.triBase = __float_as_uint(q1.y);
-    w.triMask = triMask;
+    w.triValid = __float_as_uint(q1.z);
+    w.triMask = x & w.triValid;
 }
 PT_DEV const float4 *wideNodePtr(const DeviceScene &s, uint32_t idx) { return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)(idx*s.wide_stride)); }
 

@@ -1220,6 +1220,10 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
     int ri = __float_as_int(hit.w);
     const uint32_t rj = (uint32_t)ri;
     float4 r0 = at32(s.recs, rj*3u + 0u), r1 = at32(s.recs, rj*3u + 1u), r2 = at32(s.recs, rj*3u + 2u);
+    // the attribute gather does not wait for the record to say "triangle": both are issued together (tri_attrs has an entry
+    // for every record), which takes one memory round trip out of the shading chain
+    float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0;
+    if (M & FEAT_TRIANGLES) { a0 = at32(s.tri_attrs, rj*4u + 0u); a1 = at32(s.tri_attrs, rj*4u + 1u); a2 = at32(s.tri_attrs, rj*4u + 2u); a3 = at32(s.tri_attrs, rj*4u + 3u); }
     uint32_t meta = __float_as_uint(r0.w);
     int objIdx = (int)TGHIP_REC_OBJECT(meta);
     const TgHipObject &o = s.objects[objIdx];
@@ -1227,7 +1231,6 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
     info.p = ray.o + ray.d*hit.x;                      /* TraceableScene.hpp:184 */
     uint32_t kind = TGHIP_REC_KIND(meta);
     if ((M & FEAT_TRIANGLES) && kind == TGHIP_REC_TRIANGLE) {   /* TriangleMesh.cpp:317-355, 80-106 */
-        float4 a0 = at32(s.tri_attrs, rj*4u + 0u), a1 = at32(s.tri_attrs, rj*4u + 1u), a2 = at32(s.tri_attrs, rj*4u + 2u), a3 = at32(s.tri_attrs, rj*4u + 3u);
         f3 NgU = cross(xyz(r1), xyz(r2));
         f3 dLocal = ray.d;
         if ((M & FEAT_INSTANCES) && hitInst >= 0) {    /* the master was intersected in its own space (Instance.cpp:295-297) */

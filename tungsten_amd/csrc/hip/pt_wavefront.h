@@ -444,6 +444,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
     const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
     uint32_t nodes = 0, prims = 0, rays = 0;
+    uint32_t turns = 0, dryTurns = 0;           // COUNT: loop turns of this wave, and those after the queue ran dry (lane utilisation, tools)
 
     bool busy = false;
     uint32_t slot = 0, local = 0;
@@ -484,17 +485,29 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
         }
         if (busyMask == 0ull)
             break;
+        if (COUNT) { turns++; dryTurns += exhausted ? 1u : 0u; }
         uint32_t idx = 0;
         int what = 0;
         if (busy) {
-            what = wideNext(w, wr.octInv, stack, stride, idx);
-            if (what == 0) {
-                // finished: publish the hit and bin the path by shading class
-                slotF4(st, A_HIT, slot) = hit;
-                int ri = __float_as_int(hit.w);
-                int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
-                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
-                busy = false;
+            // Phase vote (st.leaf_batch != 1): the slab tests of a node and the intersection of a record are ~220 and ~110
+            // VALU instructions that every lane of the wave sits through, so a turn runs only the kind the majority of
+            // the busy lanes wants next; the others keep their request for a later turn.
+            const bool wantsRecord = w.triMask != 0u;
+            bool go = true;
+            if (st.leaf_batch != 1u) {
+                const uint32_t nRec = (uint32_t)__popcll(__ballot(wantsRecord)), nNode = (uint32_t)__popcll(__ballot(!wantsRecord));
+                go = (nRec*st.leaf_batch >= nNode*2u) == wantsRecord;
+            }
+            if (go) {
+                what = wideNext(w, wr.octInv, stack, stride, idx);
+                if (what == 0) {
+                    // finished: publish the hit and bin the path by shading class
+                    slotF4(st, A_HIT, slot) = hit;
+                    int ri = __float_as_int(hit.w);
+                    int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
+                    queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
+                    busy = false;
+                }
             }
         }
         if (what != 0) {
@@ -520,6 +533,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
     }
+    if (COUNT && laneId() == 0) { atomicAdd(&st.stats[blockIdx.x].prof[10], (unsigned long long)turns); atomicAdd(&st.stats[blockIdx.x].prof[11], (unsigned long long)dryTurns); }
 }
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
@@ -1558,7 +1572,13 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState s
         }
         if (busyMask == 0ull)
             break;
-        if (busy) {
+        bool go = busy;
+        if (busy && st.leaf_batch != 1u) {           // phase vote, as in k_trace_closest_wide
+            const bool wantsRecord = w.triMask != 0u;
+            const uint32_t nRec = (uint32_t)__popcll(__ballot(wantsRecord)), nNode = (uint32_t)__popcll(__ballot(!wantsRecord));
+            go = (nRec*st.leaf_batch >= nNode*2u) == wantsRecord;
+        }
+        if (go) {
             uint32_t idx = 0;
             const int what = wideNext(w, wr.octInv, stack, stride, idx);
             bool rayDone = false;

@@ -4,6 +4,10 @@
 #include "pt_wavefront.h"
 
 #include <atomic>
+#include <map>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is loaded with dlopen at the first multi-GPU reduce
 
 // The k_shade variants are instantiated in shade_simple.hip / shade_class.hip / shade_full.hip (parallel compilation).
 extern template __global__ void k_shade<MASK_LEAN, LEAN_WAVES, 0>(DeviceScene, PathState, PassParams, int);
@@ -108,6 +112,8 @@ struct tghip_ctx {
     bool haveSolids = false;              // cube / sphere / disk records: the dynamic-fetch kernels' SOLIDS variants
     TgHipAuxPixel *dAux = nullptr;        // auxiliary output buffers (allocated by the first TGHIP_PASS_AUX pass)
     float *dSamples = nullptr;            // TGHIP_PASS_SAMPLES: per-sample radiance of the last such pass
+    float *redSum = nullptr;              // tghip_reduce_framebuffers: where the reduced image lands when this context is the root
+    uint32_t *redCount = nullptr;
     size_t samplesCap = 0, samplesFloats = 0;
     bool auxPass = false;                 // the pass being rendered keeps them: BSDF_MASK_ALL shading, no fused / dynamic-fetch shadow kernels
     int thrShadeAll = 256;                // workgroup size of k_shade<BSDF_MASK_ALL> (media scenes, TGHIP_PASS_AUX passes)
@@ -281,10 +287,10 @@ static int wideDepthOf(const TgHipSceneDesc *s)
         if (kids) maxDepth = std::max(maxDepth, int(depth[i]) + 1);
         if (maxDepth > TGHIP_MAX_WIDE_DEPTH) return -1;
         for (int sl = 0; sl < 8; ++sl) {
-            if (w.imask & (1u << sl)) continue;
-            const uint32_t count = w.meta[sl] >> 5, off = w.meta[sl] & 31u;
-            if (count > TGHIP_WIDE_MAX_LEAF || off + count > 32u || (count && uint64_t(w.rec_base) + off + count > topRecs)) return -1;
+            const uint32_t bits = (w.leaf_valid >> (4*sl)) & 15u;
+            if ((bits & (bits + 1u)) != 0u || (bits && (w.imask & (1u << sl)))) return -1;   // records 0 .. count-1 of a leaf slot
         }
+        if (w.leaf_valid && uint64_t(w.rec_base) + uint32_t(__builtin_popcount(w.leaf_valid)) > topRecs) return -1;
         for (int a = 0; a < 3; ++a)
             if (w.exp[a] == 0 || w.exp[a] == 255) return -1;
     }
@@ -352,6 +358,11 @@ static int foldCounters(tghip_ctx *ctx)
         const BlockStats &t = ctx->hostStats[b];
         ctx->counters.nodes_visited += t.nodes_visited; ctx->counters.prims_tested += t.prims_tested;
         ctx->counters.nodes_visited_shadow += t.nodes_visited_shadow; ctx->counters.prims_tested_shadow += t.prims_tested_shadow;
+    }
+    if (std::getenv("TGHIP_VERBOSE")) {
+        unsigned long long turns = 0, dry = 0;
+        for (size_t b = 0; b < g; ++b) { turns += ctx->hostStats[b].prof[10]; dry += ctx->hostStats[b].prof[11]; }
+        if (turns) std::fprintf(stderr, "[tghip] closest-hit walk: %llu wave turns (%llu after the queue ran dry)\n", turns, dry);
     }
 #ifdef PT_PROFILE
     {
@@ -513,6 +524,8 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->fbCount) (void)hipFree(ctx->fbCount);
     if (ctx->dAux) (void)hipFree(ctx->dAux);
     if (ctx->dSamples) (void)hipFree(ctx->dSamples);
+    if (ctx->redSum) (void)hipFree(ctx->redSum);
+    if (ctx->redCount) (void)hipFree(ctx->redCount);
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->hostLive) (void)hipHostFree(ctx->hostLive);
     if (ctx->abortFlagDev) (void)hipFree(ctx->abortFlagDev);
@@ -1392,6 +1405,94 @@ int tghip_download_samples(tghip_ctx *ctx, float *rgb, size_t nfloats)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(rgb, ctx->dSamples, nfloats*sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return TGHIP_OK;
+}
+
+extern "C++" {
+namespace {
+// RCCL through dlopen: single-GPU users of this library never load it
+struct RcclApi {
+    std::mutex mutex;
+    bool tried = false;
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) commInitAll = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclGroupStart) groupStart = nullptr;
+    decltype(&ncclGroupEnd) groupEnd = nullptr;
+    decltype(&ncclGetErrorString) errorString = nullptr;
+    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;   // one communicator set per device list, kept for the life of the process
+    bool load()
+    {
+        if (tried) return lib != nullptr;
+        tried = true;
+        lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!lib) return false;
+        commInitAll = reinterpret_cast<decltype(commInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        reduce = reinterpret_cast<decltype(reduce)>(dlsym(lib, "ncclReduce"));
+        groupStart = reinterpret_cast<decltype(groupStart)>(dlsym(lib, "ncclGroupStart"));
+        groupEnd = reinterpret_cast<decltype(groupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        errorString = reinterpret_cast<decltype(errorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!commInitAll || !reduce || !groupStart || !groupEnd || !errorString) { dlclose(lib); lib = nullptr; }
+        return lib != nullptr;
+    }
+} g_rccl;
+} // namespace
+} // extern "C++"
+
+int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rgb_sum, uint32_t *count, size_t npixels)
+{
+    if (!ctxs || n < 1 || root < 0 || root >= n) return TGHIP_E_INVALID;
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]) return TGHIP_E_INVALID;
+    tghip_ctx *rc = ctxs[root];
+    std::vector<int> devices;
+    for (int i = 0; i < n; ++i) {
+        tghip_ctx *c = ctxs[i];
+        if (!c->haveScene) { rc->error = "tghip_reduce_framebuffers: a context has no scene"; return TGHIP_E_NOSCENE; }
+        if (c->width != rc->width || c->height != rc->height) { rc->error = "tghip_reduce_framebuffers: the contexts render different images"; return TGHIP_E_INVALID; }
+        for (int d : devices)
+            if (d == c->device) { rc->error = "tghip_reduce_framebuffers: two contexts on one device"; return TGHIP_E_INVALID; }
+        devices.push_back(c->device);
+        int w = tghip_wait(c);
+        if (w != TGHIP_OK && w != TGHIP_E_ABORTED) return w;
+    }
+    if (npixels != size_t(rc->width)*rc->height) { rc->error = "pixel count mismatch"; return TGHIP_E_INVALID; }
+    HIP_TRY(rc, hipSetDevice(rc->device));
+    if (!rc->redSum) HIP_TRY(rc, hipMalloc(reinterpret_cast<void **>(&rc->redSum), npixels*3*sizeof(float)));
+    if (!rc->redCount) HIP_TRY(rc, hipMalloc(reinterpret_cast<void **>(&rc->redCount), npixels*sizeof(uint32_t)));
+
+    std::lock_guard<std::mutex> lock(g_rccl.mutex);
+    if (!g_rccl.load()) { rc->error = "tghip_reduce_framebuffers: librccl.so could not be loaded"; return TGHIP_E_UNSUPPORTED; }
+    auto ncclTry = [&](ncclResult_t r, const char *what) {
+        if (r == ncclSuccess) return true;
+        rc->error = std::string(what) + ": " + g_rccl.errorString(r);
+        return false;
+    };
+    std::vector<ncclComm_t> &comms = g_rccl.comms[devices];
+    if (comms.empty()) {
+        comms.resize(size_t(n));
+        if (!ncclTry(g_rccl.commInitAll(comms.data(), n, devices.data()), "ncclCommInitAll")) { g_rccl.comms.erase(devices); return TGHIP_E_HIP; }
+    }
+    // two reductions per rank (radiance sums, sample counts) in one group; every rank's calls run on its own stream
+    if (!ncclTry(g_rccl.groupStart(), "ncclGroupStart")) return TGHIP_E_HIP;
+    bool ok = true;
+    for (int i = 0; i < n && ok; ++i) {
+        tghip_ctx *c = ctxs[i];
+        const float *sum = c->extSum ? c->extSum : c->fbSum;
+        const uint32_t *cnt = c->extCount ? c->extCount : c->fbCount;
+        ok = ncclTry(g_rccl.reduce(sum, i == root ? rc->redSum : nullptr, npixels*3, ncclFloat32, ncclSum, root, comms[size_t(i)], c->stream), "ncclReduce")
+          && ncclTry(g_rccl.reduce(cnt, i == root ? rc->redCount : nullptr, npixels, ncclUint32, ncclSum, root, comms[size_t(i)], c->stream), "ncclReduce");
+    }
+    if (!ncclTry(g_rccl.groupEnd(), "ncclGroupEnd") || !ok) return TGHIP_E_HIP;
+    for (int i = 0; i < n; ++i) {
+        HIP_TRY(rc, hipSetDevice(ctxs[i]->device));
+        HIP_TRY(rc, hipStreamSynchronize(ctxs[i]->stream));
+    }
+    HIP_TRY(rc, hipSetDevice(rc->device));
+    if (rgb_sum) HIP_TRY(rc, hipMemcpyAsync(rgb_sum, rc->redSum, npixels*3*sizeof(float), hipMemcpyDeviceToHost, rc->stream));
+    if (count) HIP_TRY(rc, hipMemcpyAsync(count, rc->redCount, npixels*sizeof(uint32_t), hipMemcpyDeviceToHost, rc->stream));
+    HIP_TRY(rc, hipStreamSynchronize(rc->stream));
     return TGHIP_OK;
 }
 

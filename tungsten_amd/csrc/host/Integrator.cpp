@@ -437,6 +437,13 @@ void PathTraceHipIntegrator::fetchFramebuffer()
         return;
     waitForCompletion();
     size_t n = size_t(_w)*_h;
+    if (_ctxs.size() > 1) {
+        // the shards' framebuffers are summed on the device side (RCCL over xGMI) and cross PCIe once; when RCCL is not
+        // available the shards are downloaded one by one and added here
+        int rc = tghip_reduce_framebuffers(_ctxs.data(), int(_ctxs.size()), 0, _sum.data(), _count.data(), n);
+        if (rc == TGHIP_OK) { _imageDirty = false; return; }
+        if (rc != TGHIP_E_UNSUPPORTED) check(rc, _ctxs[0], "tghip_reduce_framebuffers");
+    }
     std::fill(_sum.begin(), _sum.end(), 0.0f);
     std::fill(_count.begin(), _count.end(), 0u);
     std::vector<float> s(n*3);

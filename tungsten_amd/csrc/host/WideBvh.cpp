@@ -210,7 +210,6 @@ WideBvhResult buildWideBvh(std::vector<TgHipBvhNode> &bvh2, const std::vector<Bo
         // ---- children: internal ones become consecutive nodes, the leaves' records one contiguous run
         node.child_base = uint32_t(out.nodes.size());
         node.rec_base = uint32_t(out.order.size());
-        uint32_t recOffset = 0;
         for (int s = 0; s < 8; ++s) {
             if (itemAt[s] < 0) continue;
             const Item &it = items[size_t(itemAt[s])];
@@ -220,12 +219,11 @@ WideBvhResult buildWideBvh(std::vector<TgHipBvhNode> &bvh2, const std::vector<Bo
                 queue.push_back({it.ref, cur.depth + 1});
             } else {
                 const uint32_t first = TGHIP_LEAF_FIRST(it.ref), count = TGHIP_LEAF_COUNT(it.ref);
-                node.meta[s] = uint8_t((count << 5) | recOffset);
+                node.leaf_valid |= ((1u << count) - 1u) << (4*s);
                 for (uint32_t r = first; r < first + count; ++r) {
                     newFirst[r] = uint32_t(out.order.size());
                     out.order.push_back(r);
                 }
-                recOffset += count;
             }
         }
         out.nodes[self] = node;
