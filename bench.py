@@ -65,12 +65,13 @@ def parse_args():
 
 # ---- algorithmic bytes -------------------------------------------
 NODE_B, REC_B = 64, 48          # TgHipBvhNode, TgHipPrimRec
+WIDE_NODE_B = 80                # TgHipWideNode
 RAY_B, HIT_B = 32, 16           # (o,tmin,d,tmax), (t,u,v,rec)
 STATE_R = RAY_B + 16 + 16 + 16  # ray, throughput+flags, radiance, rng+pixel+item read per shaded vertex
 STATE_W = 16 + 16               # throughput+flags, radiance written back per shaded vertex
 
 
-def kernel_bytes(c, flat, fused):
+def kernel_bytes(c, flat, fused, node_b=64, node_b_shadow=None):
     """Algorithmic bytes moved by each kernel class over everything the counters cover.
     flat: the scene is a flat record list whose loads are wave-uniform (one fetch per 64 rays);
     fused: (flat scenes) intersection and shadow tests run inside k_shade, no hit / shadow records exist."""
@@ -84,9 +85,9 @@ def kernel_bytes(c, flat, fused):
         return {"k_shade": paths*(STATE_R + STATE_W) + alive*(RAY_B + 8) + regen + rec_b*c["prims_tested"]}
     return {
         # ray in + hit out + BVH nodes and primitive records actually visited
-        "k_trace_closest": paths*(RAY_B + HIT_B) + NODE_B*nodes_cl + rec_b*prims_cl,
+        "k_trace_closest": paths*(RAY_B + HIT_B) + node_b*nodes_cl + rec_b*prims_cl,
         # shadow origin, throughput/pending, radiance read+write per slot; direction+contribution per ray
-        "k_trace_shadow": c["shadow_slots"]*(16 + 16 + 16 + 32) + c["shadow_rays"]*32 + NODE_B*nodes_sh + rec_b*prims_sh,
+        "k_trace_shadow": c["shadow_slots"]*(16 + 16 + 16 + 32) + c["shadow_rays"]*32 + (node_b_shadow or node_b)*nodes_sh + rec_b*prims_sh,
         # path state read once per vertex and written back (+ ray and rng when the path continues), plus the
         # shadow records a vertex emits
         "k_shade": paths*(STATE_R + HIT_B + STATE_W) + alive*(RAY_B + 8) + c["shadow_slots"]*(16 + 64 + 16 + 16),
@@ -229,7 +230,11 @@ class Bench(object):
             check(lib.tghip_set_option(ctx, b"count_traversal", 0), "tghip_set_option")
             is_flat = int(flat.info.num_recs) <= 16
             fused = is_flat and cc["shadow_slots"] == 0 and cc["shadow_rays"] > 0
-            per_step_bytes = kernel_bytes(cc, is_flat, fused)
+            # BVH scenes walk the 8-wide BVH (80-byte nodes) unless the run switched it off
+            wide = int(flat.desc.contents.num_wide_nodes) > 0 and "wide_bvh=0" not in a.opt
+            # (instanced scenes: shadow rays on the wide tree, closest-hit rays on the two-level BVH2 -- the shim's measured default)
+            inst = int(flat.desc.contents.num_instances) > 0
+            per_step_bytes = kernel_bytes(cc, is_flat, fused, WIDE_NODE_B if wide and not inst else NODE_B, WIDE_NODE_B if wide else NODE_B)
 
             kernels = {}
             ms = {"k_trace_closest": timed["ms_trace_closest"], "k_shade": timed["ms_shade"], "k_trace_shadow": timed["ms_trace_shadow"]}
@@ -270,7 +275,7 @@ class Bench(object):
                 "rays_per_sample": round(rays/max(cc["samples"], 1), 3),
                 "nodes_per_ray": round(cc["nodes_visited"]/rays, 2), "prims_per_ray": round(cc["prims_tested"]/rays, 2),
                 "bvh": {"nodes": int(flat.info.num_nodes), "records": int(flat.info.num_recs), "depth": int(flat.info.bvh_depth),
-                        "flat_list": is_flat},
+                        "flat_list": is_flat, "wide_nodes": int(flat.desc.contents.num_wide_nodes) if wide else 0},
                 "kernel_ms_total": round(timed["ms_total"], 2), "wavefront_iterations": int(timed["iterations"]),
                 "setup_s": {"flatten_and_bvh": round(t_flatten, 3), "upload": round(t_upload, 3)},
                 "result_ok": ok, "image_mean": [round(float(v), 6) for v in img.mean(axis=(0, 1))],
@@ -308,7 +313,7 @@ def measure_traffic(a, scene, w, h, spp, kernel, tmp):
         total, n = 0.0, 0
         with open(files[0]) as f:
             for row in csv.DictReader(f):
-                k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "")
+                k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "").replace("_wide", "")
                 if row.get("Counter_Name") == counter and k == kernel:
                     total += float(row["Counter_Value"])
                     n += 1

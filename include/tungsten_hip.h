@@ -120,7 +120,8 @@ enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC
  *   cube / sphere / disk / cylinder: geometry lives in objects[TGHIP_REC_OBJECT(meta)]; a,b,c unused
  *   instance: one rigid placement of a master mesh (primitives/Instance.cpp:290-344): a = _instancePos[i],
  *             (p0, b) = _instanceRot[i] as quaternion (w; x, y, z), c[0] = bits of the master's BVH root node index
- *             (uint32), c[1] = bits of the instance number i; the object is the `instances` primitive.  The master's
+ *             (uint32), c[1] = bits of the instance number i, c[2] = bits of the root node index of the master's wide
+ *             subtree (uint32; scenes with a wide BVH); the object is the `instances` primitive.  The master's
  *             triangle records (in master space, i.e. with the master's own transform applied) and its BVH2 subtree
  *             follow the top-level ones in recs / tri_attrs / nodes and are reachable only through instance records. */
 typedef struct TgHipPrimRec {
@@ -285,8 +286,8 @@ typedef struct TgHipSceneDesc {
     uint32_t num_instances;               /* instance records among recs (0: single-level scene) */
     uint32_t num_top_recs;                /* records of the top-level BVH = recs[0, num_top_recs); the rest belong to masters */
     const TgHipMedium  *media;  uint32_t num_media;   /* Scene::_media; NULL/0 = the scene has no participating media */
-    /* the wide BVH over recs[0, num_top_recs): wide_nodes[0] is the root; NULL/0 = the device walks the BVH2 (flat-list
-     * scenes and scenes with instance records always do) */
+    /* the wide BVH: wide_nodes[0] is the root of the tree over recs[0, num_top_recs); with instances every master's wide
+     * subtree follows (its root in the instance records' c[2]).  NULL/0 = the device walks the BVH2 (flat-list scenes do) */
     const TgHipWideNode *wide_nodes;  uint32_t num_wide_nodes;
     TgHipCamera   camera;
     TgHipSettings settings;

@@ -1430,22 +1430,47 @@ static inline uint32_t wide_permute(uint32_t h, uint32_t oct)
 }
 static inline float wide_spacing(uint8_t e) { union { uint32_t u; float f; } c; c.u = (uint32_t)e << 23; return c.f; }
 static inline float wide_inv(float d) { return 1.0f/(fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d); }
-static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit *hit, TravStats *st, int objFilter)
+#define WIDE_LEAVE     0xFFFFFFFFu
+#define WIDE_RECS_FLAG 0x80000000u
+static void wide_walk(const TgHipSceneDesc *s, const Ray *worldRay, float *tmax, Hit *hit, TravStats *st, int objFilter)
 {
     struct { uint32_t base, masks; } stack[TGHIP_MAX_WIDE_DEPTH + 2];
     int sp = 0;
-    const float idir[3] = {wide_inv(ray->d.x), wide_inv(ray->d.y), wide_inv(ray->d.z)};
-    const float org[3] = {ray->o.x, ray->o.y, ray->o.z};
-    const uint32_t octInv = (idir[0] < 0.0f ? 1u : 0u) | (idir[1] < 0.0f ? 2u : 0u) | (idir[2] < 0.0f ? 4u : 0u);
-    uint32_t grpBase = 0, grpMasks = 0, triBase = 0, triMask = 0, triValid = 0;
-    int32_t node = 0;
+    Ray ray = *worldRay;
+    float idir[3], org[3];
+    uint32_t octInv;
+#define WIDE_RAY_SETUP() do { idir[0] = wide_inv(ray.d.x); idir[1] = wide_inv(ray.d.y); idir[2] = wide_inv(ray.d.z); \
+        org[0] = ray.o.x; org[1] = ray.o.y; org[2] = ray.o.z; \
+        octInv = (idir[0] < 0.0f ? 1u : 0u) | (idir[1] < 0.0f ? 2u : 0u) | (idir[2] < 0.0f ? 4u : 0u); } while (0)
+    WIDE_RAY_SETUP();
+    uint32_t grpBase = 0, grpMasks = 0, triBase = 0, triMask = 0, triValid = 0, curNode = 0;
+    int32_t node = 0, curInst = -1;
     for (;;) {
         if (triMask) {
             uint32_t b = (uint32_t)__builtin_ctz(triMask);
             uint32_t i = triBase + (uint32_t)__builtin_popcount(triValid & ((1u << b) - 1u));
             triMask &= triMask - 1u;
-            if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
-                test_rec(s, i, ray, tmax, hit, st, objFilter, -1);
+            const TgHipPrimRec *r = &s->recs[i];
+            if (TGHIP_REC_KIND(r->meta) == TGHIP_REC_INSTANCE) {
+                /* wideEnterInstance: what is left of this node waits on the stack, the ray goes into the master's space */
+                if (st) st->prims++;
+                if (grpMasks & 0xFFu) { stack[sp].base = grpBase; stack[sp].masks = grpMasks; ++sp; }
+                if (triMask) { stack[sp].base = WIDE_RECS_FLAG | curNode; stack[sp].masks = triMask; ++sp; }
+                stack[sp].base = WIDE_LEAVE; stack[sp].masks = 0; ++sp;
+                grpMasks = 0; triMask = 0;
+                float q[4];
+                instance_inv_quat(r, q);
+                ray.o = quat_rotate(q, vsub(ray.o, ld3(r->a)));
+                ray.d = quat_rotate(q, ray.d);
+                WIDE_RAY_SETUP();
+                uint32_t root;
+                memcpy(&root, &r->c[2], 4);
+                node = (int32_t)root;
+                curInst = (int32_t)i;
+                continue;
+            }
+            if (objFilter < 0 || (int)TGHIP_REC_OBJECT(r->meta) == objFilter)
+                test_rec(s, i, &ray, tmax, hit, st, objFilter, curInst);
             else if (st) st->prims++;            /* (the device fetches the record either way) */
             continue;
         }
@@ -1453,6 +1478,19 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit 
             if ((grpMasks & 0xFFu) == 0u) {
                 if (sp == 0) break;
                 --sp;
+                if (stack[sp].base == WIDE_LEAVE) {              /* back to world space */
+                    ray.o = worldRay->o; ray.d = worldRay->d;
+                    WIDE_RAY_SETUP();
+                    curInst = -1;
+                    continue;
+                }
+                if (stack[sp].base & WIDE_RECS_FLAG) {           /* the rest of a top-level node's records */
+                    curNode = stack[sp].base & ~WIDE_RECS_FLAG;
+                    triMask = stack[sp].masks;
+                    triBase = s->wide_nodes[curNode].rec_base;
+                    triValid = s->wide_nodes[curNode].leaf_valid;
+                    continue;
+                }
                 grpBase = stack[sp].base; grpMasks = stack[sp].masks;
             }
             uint32_t hits = grpMasks & 0xFFu, imask = grpMasks >> 8;
@@ -1463,6 +1501,7 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit 
             if (hits) { stack[sp].base = grpBase; stack[sp].masks = grpMasks; ++sp; }
         }
         const TgHipWideNode *n = &s->wide_nodes[node];
+        curNode = (uint32_t)node;
         node = -1;
         if (st) st->nodes++;
         float adjS[3], adjO[3];
@@ -1472,7 +1511,7 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit 
         }
         uint32_t hitmask = 0;
         for (int sl = 0; sl < 8; ++sl) {
-            float tn = ray->tmin, tf = *tmax;
+            float tn = ray.tmin, tf = *tmax;
             float tnA[3], tfA[3];
             for (int a = 0; a < 3; ++a) {
                 const int neg = (octInv >> a) & 1u;
@@ -1495,6 +1534,7 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *ray, float *tmax, Hit 
             if ((hitmask & ~(uint32_t)n->imask) >> sl & 1u) triMask |= 15u << (4*sl);
         triMask &= triValid;
     }
+#undef WIDE_RAY_SETUP
 }
 void oracle_set_wide_bvh(int on) { g_use_wide = on; }
 
@@ -1510,7 +1550,7 @@ static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, Hit *hit
                 test_rec(s, i, ray, &tmax, hit, st, objFilter, -1);
         return hit->rec >= 0;
     }
-    if (g_use_wide && s->wide_nodes && s->num_instances == 0)
+    if (g_use_wide && s->wide_nodes)
         wide_walk(s, ray, &tmax, hit, st, objFilter);
     else
         bvh_walk(s, 0, ray, &tmax, hit, st, objFilter, -1);

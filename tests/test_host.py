@@ -242,10 +242,34 @@ def test_wide_bvh_is_a_conservative_collapse_of_the_bvh2(tmp_path):
     flat.close()
 
 
-def test_flat_list_and_instanced_scenes_carry_no_wide_bvh(tmp_path):
+def test_flat_list_scenes_carry_no_wide_bvh_and_instanced_scenes_a_two_level_one(tmp_path):
+    import oracle_lib
     flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1))
     assert flat.desc.contents.num_wide_nodes == 0
     flat.close()
-    flat = tg.FlattenedScene(scenes.cornell_instances(tmp_path, resolution=(16, 9), spp=1))
-    assert flat.desc.contents.num_wide_nodes == 0
+    # instances: a wide tree over the instance records + one wide subtree per master behind it; the two-level wide walk finds
+    # what the two-level BVH2 walk finds
+    flat = tg.FlattenedScene(scenes.instances10k(tmp_path, resolution=(16, 9), spp=1, count=300, n_lat=12, n_lon=12))
+    d = flat.desc.contents
+    assert d.num_instances == 300 and d.num_wide_nodes > 4
+    check_bvh_roots = set()
+    recs = _np(d.recs, d.num_recs, np.float32, 12).view(np.uint32)
+    for r in range(d.num_top_recs):
+        if recs[r][3] >> 29 == 4:
+            assert 0 < recs[r][10] < d.num_wide_nodes            # c[2]: the master's wide root
+            check_bvh_roots.add(int(recs[r][10]))
+    assert len(check_bvh_roots) == 4
+    rs = np.random.RandomState(11)
+    m = 3000
+    lo, hi = np.array(list(d.bounds_lo)), np.array(list(d.bounds_hi))
+    o = lo + (hi - lo)*rs.rand(m, 3)*1.2 - 0.1*(hi - lo)
+    dirs = rs.randn(m, 3)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    rays = np.concatenate([o, np.full((m, 1), 1e-4), dirs, np.full((m, 1), np.inf)], axis=1).astype(np.float32)
+    h2, n2, p2 = oracle_lib.trace_rays(flat.desc, rays)
+    hw, nw, pw = oracle_lib.trace_rays(flat.desc, rays, wide=True)
+    assert (h2["rec"] >= 0).sum() > m//10
+    same = h2["rec"] == hw["rec"]
+    assert same.mean() >= 0.998
+    assert np.allclose(h2["t"][same], hw["t"][same], rtol=1e-6, atol=0) and nw < 0.6*n2
     flat.close()

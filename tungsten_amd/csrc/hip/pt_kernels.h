@@ -580,9 +580,18 @@ struct WideState {
     uint32_t triValid;
     int node;                     // node to visit next; -1: take it from the group / the stack
     int sp;
+    // scenes with instance records (the INST variants): the node whose records are being tested, the instance record the walk
+    // is inside of (-1: world space)
+    uint32_t curNode;
+    int curInst;
 };
-PT_DEV void wideStart(WideState &w) { w.grpBase = 0; w.grpMasks = 0; w.triBase = 0; w.triMask = 0; w.triValid = 0; w.node = 0; w.sp = 0; }
-// What the lane fetches next: 1 = primitive record `idx`, 2 = node `idx`, 0 = the walk is over.
+PT_DEV void wideStart(WideState &w) { w.grpBase = 0; w.grpMasks = 0; w.triBase = 0; w.triMask = 0; w.triValid = 0; w.node = 0; w.sp = 0; w.curNode = 0; w.curInst = -1; }
+// Two-level scenes put two more kinds of entries on the group stack when the walk enters an instance (wideEnterInstance):
+#define WIDE_LEAVE     0xFFFFFFFFu   /* x: the master's subtree is done, the ray goes back to world space */
+#define WIDE_RECS_FLAG 0x80000000u   /* x = flag | node: records of that (top-level) node still to test, y = their triMask */
+// What the lane fetches next: 1 = primitive record `idx`, 2 = node `idx`, 0 = the walk is over; INST also 3 = leave the
+// instance (the caller restores the world-space ray), 4 = node `idx`'s record run is needed again (wideResumeRecords).
+template<bool INST = false>
 PT_DEV int wideNext(WideState &w, uint32_t octInv, uint2 *stack, int stride, uint32_t &idx)
 {
     if (w.triMask) {
@@ -597,6 +606,10 @@ PT_DEV int wideNext(WideState &w, uint32_t octInv, uint2 *stack, int stride, uin
                 return 0;
             w.sp--;
             uint2 e = stack[w.sp*stride];
+            if (INST) {
+                if (e.x == WIDE_LEAVE) return 3;
+                if (e.x & WIDE_RECS_FLAG) { idx = e.x & ~WIDE_RECS_FLAG; w.triMask = e.y; return 4; }
+            }
             w.grpBase = e.x; w.grpMasks = e.y;
         }
         uint32_t hits = w.grpMasks & 0xFFu, imask = w.grpMasks >> 8;
@@ -608,7 +621,31 @@ PT_DEV int wideNext(WideState &w, uint32_t octInv, uint2 *stack, int stride, uin
     }
     idx = (uint32_t)w.node;
     w.node = -1;
+    if (INST) w.curNode = idx;
     return 2;
+}
+// code 4: q1 = the second 16 bytes of node `idx`
+PT_DEV void wideResumeRecords(WideState &w, uint32_t idx, float4 q1)
+{
+    w.triBase = __float_as_uint(q1.y);
+    w.triValid = __float_as_uint(q1.z);
+    w.curNode = idx;
+}
+// The record just fetched (r0, r1, r2) is an instance: what is left of the current node goes on the stack, the ray into the
+// master's space (rotation + translation: distances along it are unchanged; primitives/Instance.cpp:290-311), the walk on to
+// the master's wide subtree.
+PT_DEV void wideEnterInstance(WideState &w, uint2 *stack, int stride, uint32_t recIdx, float4 r0, float4 r1, float4 r2, RayD &ray, WideRay &wr)
+{
+    if (w.grpMasks & 0xFFu) { stack[w.sp*stride] = make_uint2(w.grpBase, w.grpMasks); w.sp++; }
+    if (w.triMask) { stack[w.sp*stride] = make_uint2(WIDE_RECS_FLAG | w.curNode, w.triMask); w.sp++; }
+    stack[w.sp*stride] = make_uint2(WIDE_LEAVE, 0u); w.sp++;
+    w.grpMasks = 0u; w.triMask = 0u;
+    const f3 qc = -xyz(r1);                             // conjugate(): the inverse rotation
+    ray.o = quatRotate(r1.w, qc, ray.o - xyz(r0));
+    ray.d = quatRotate(r1.w, qc, ray.d);
+    wr = wideRaySetup(ray);
+    w.node = (int)__float_as_uint(r2.z);
+    w.curInst = (int)recIdx;
 }
 // The node's 80 bytes have arrived: slab-test its eight children against [tmin, tmax], queue the hit ones.  Two children per
 // v_pk_fma_f32; each half is one correctly rounded fma, as in the oracle's scalar fmaf.
@@ -659,17 +696,19 @@ PT_DEV void wideVisit(WideState &w, float4 q0, float4 q1, float4 q2, float4 q3, 
 PT_DEV const float4 *wideNodePtr(const DeviceScene &s, uint32_t idx) { return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)(idx*s.wide_stride)); }
 
 // closest hit through the wide BVH, one ray at a time (tghip_trace_rays); the dynamic-fetch kernels run the same machine
-template<bool COUNT, uint32_t KINDS = KINDS_ALL>
-PT_DEV float4 traverseClosestWide(const DeviceScene &s, const RayD &ray, uint2 *stack, int stride, uint32_t &nodesVisited, uint32_t &primsTested)
+template<bool COUNT, uint32_t KINDS = KINDS_ALL, bool INST = false>
+PT_DEV float4 traverseClosestWide(const DeviceScene &s, const RayD &worldRay, uint2 *stack, int stride, uint32_t &nodesVisited, uint32_t &primsTested, int &hitInst)
 {
-    float tmax = ray.tmax;
+    float tmax = worldRay.tmax;
     float4 hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
-    const WideRay wr = wideRaySetup(ray);
+    RayD ray = worldRay;
+    WideRay wr = wideRaySetup(ray);
     WideState w;
     wideStart(w);
+    hitInst = -1;
     for (;;) {
         uint32_t idx;
-        const int what = wideNext(w, wr.octInv, stack, stride, idx);
+        const int what = wideNext<INST>(w, wr.octInv, stack, stride, idx);
         if (what == 0)
             break;
         if (what == 2) {
@@ -677,9 +716,22 @@ PT_DEV float4 traverseClosestWide(const DeviceScene &s, const RayD &ray, uint2 *
             float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4];
             if (COUNT) nodesVisited++;
             wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
-        } else {
+        } else if (what == 1) {
             if (COUNT) primsTested++;
-            testRecord<false, KINDS>(s, idx, ray, tmax, hit);
+            float4 r0 = at32(s.recs, idx*3u + 0u), r1 = at32(s.recs, idx*3u + 1u), r2 = at32(s.recs, idx*3u + 2u);
+            if (INST && TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE) {
+                wideEnterInstance(w, stack, stride, idx, r0, r1, r2, ray, wr);
+            } else {
+                uint32_t meta;
+                if (testRecordLoaded<false, KINDS>(s, idx, r0, r1, r2, ray, tmax, hit, meta))
+                    hitInst = w.curInst;
+            }
+        } else if (what == 3) {
+            ray.o = worldRay.o; ray.d = worldRay.d;
+            wr = wideRaySetup(ray);
+            w.curInst = -1;
+        } else {
+            wideResumeRecords(w, idx, wideNodePtr(s, idx)[1]);
         }
     }
     return hit;

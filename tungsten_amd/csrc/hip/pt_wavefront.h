@@ -429,7 +429,9 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
 // bytes) or a primitive record (48 bytes), both inside one allocation -- loads it, and then either slab-tests the node's
 // eight children or intersects the record.  Idle lanes refill from the workgroup's queue as in k_trace_closest_dyn.
 // Dynamic LDS: [expanded queue, 2 B per slot][group stacks, wideDepth x 8 B per thread].
-template<bool COUNT, bool SOLIDS = true>
+// INST: the scene has instance records -- the walk enters the masters' wide subtrees (pt_kernels.h: wideEnterInstance); the
+// instance a hit was reached through goes to the spare word A_EMI.w, as k_trace_closest<.., INST> leaves it.
+template<bool COUNT, bool SOLIDS = true, bool INST = false>
 __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsDyn[];
@@ -454,6 +456,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
     wideStart(w);
     float tmax = 0.0f;
     float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    int hitInst = -1;
     bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
@@ -475,6 +478,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
                     wideStart(w);
                     tmax = ray.tmax;
                     hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+                    hitInst = -1;
                     busy = true;
                     rays++;
                 }
@@ -499,10 +503,11 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
                 go = (nRec*st.leaf_batch >= nNode*2u) == wantsRecord;
             }
             if (go) {
-                what = wideNext(w, wr.octInv, stack, stride, idx);
+                what = wideNext<INST>(w, wr.octInv, stack, stride, idx);
                 if (what == 0) {
                     // finished: publish the hit and bin the path by shading class
                     slotF4(st, A_HIT, slot) = hit;
+                    if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
                     int ri = __float_as_int(hit.w);
                     int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
                     queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
@@ -510,19 +515,32 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
                 }
             }
         }
-        if (what != 0) {
+        if (INST && what == 3) {
+            // the master's subtree is done: back to the world-space ray (distances along it did not change)
+            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
+            ray.o = xyz(ro); ray.d = xyz(rd);
+            wr = wideRaySetup(ray);
+            w.curInst = -1;
+        } else if (what != 0) {
             // one address per lane: a node or a record, both behind s.wide
-            const uint32_t off = what == 2 ? idx*s.wide_stride : s.recs_offset + idx*48u;
+            const uint32_t off = what != 1 ? idx*s.wide_stride : s.recs_offset + idx*48u;
             const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
             float4 q0 = p[0], q1 = p[1], q2 = p[2];
             if (what == 2) {
                 float4 q3 = p[3], q4 = p[4];
                 if (COUNT) nodes++;
                 wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+            } else if (INST && what == 4) {
+                wideResumeRecords(w, idx, q1);
             } else {
                 if (COUNT) prims++;
-                uint32_t meta;
-                (void)testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta);
+                if (INST && TGHIP_REC_KIND(__float_as_uint(q0.w)) == TGHIP_REC_INSTANCE) {
+                    wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
+                } else {
+                    uint32_t meta;
+                    if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta))
+                        hitInst = w.curInst;
+                }
             }
         }
     }
@@ -552,7 +570,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
         RayD ray;
         ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
         int hitInst;      // TgHipHit reports the record that was hit, not the instance it was reached through
-        if (WIDE) hits[i] = traverseClosestWide<COUNT>(s, ray, reinterpret_cast<uint2 *>(ldsStack) + threadIdx.x, blockDim.x, nodes, prims);
+        if (WIDE) hits[i] = traverseClosestWide<COUNT, KINDS_ALL, INST != 0>(s, ray, reinterpret_cast<uint2 *>(ldsStack) + threadIdx.x, blockDim.x, nodes, prims, hitInst);
         else hits[i] = INST ? traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst)
                             : traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
     }
@@ -1478,7 +1496,7 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
 
 // k_trace_shadow_dyn over the 8-wide BVH: any-hit queries, one memory round trip (a node or a record) per lane and loop
 // turn, like k_trace_closest_wide.  Dynamic LDS: [expanded queue, 2 B per slot][group stacks, wideDepth x 8 B per thread].
-template<bool COUNT, bool SOLIDS = true>
+template<bool COUNT, bool SOLIDS = true, bool INST = false>
 __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsDyn[];
@@ -1580,26 +1598,37 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState s
         }
         if (go) {
             uint32_t idx = 0;
-            const int what = wideNext(w, wr.octInv, stack, stride, idx);
+            const int what = wideNext<INST>(w, wr.octInv, stack, stride, idx);
             bool rayDone = false;
             if (what == 0) {
                 result = result + contrib;       // nothing in the way: transmittance 1
                 rayDone = true;
+            } else if (INST && what == 3) {
+                ray.o = so; ray.d = xyz(r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot));   // back to world space
+                wr = wideRaySetup(ray);
+                w.curInst = -1;
             } else {
-                const uint32_t off = what == 2 ? idx*s.wide_stride : s.recs_offset + idx*48u;
+                const uint32_t off = what != 1 ? idx*s.wide_stride : s.recs_offset + idx*48u;
                 const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 if (what == 2) {
                     float4 q3 = p[3], q4 = p[4];
                     if (COUNT) nodes++;
                     wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, ray.tmax);
+                } else if (INST && what == 4) {
+                    wideResumeRecords(w, idx, q1);
                 } else {
                     if (COUNT) prims++;
-                    float tmax = ray.tmax;
-                    float4 hit;
-                    uint32_t meta;
-                    if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
-                        rayDone = true;          // occluded
+                    if (INST && TGHIP_REC_KIND(__float_as_uint(q0.w)) == TGHIP_REC_INSTANCE) {
+                        wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
+                    } else {
+                        float tmax = ray.tmax;
+                        float4 hit;
+                        uint32_t meta;
+                        // geometry reached through an instance belongs to the `instances` primitive, never the light (traverseOccludedInst)
+                        if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta) && ((INST && w.curInst >= 0) || (int)TGHIP_REC_OBJECT(meta) != endCap))
+                            rayDone = true;      // occluded
+                    }
                 }
             }
             if (rayDone) {

@@ -66,6 +66,11 @@ struct tghip_ctx {
     int bvhDepth = 0;
     int wideDepth = 0;                    // levels of the 8-wide BVH (0: the scene has none, the kernels walk the BVH2)
     bool wideOpt = true;                  // "wide_bvh" option: use it when the scene carries one
+    // "wide_closest" / "wide_shadow": which kernels walk the wide BVH when the scene has one.  -1 = the measured default:
+    // both, except that closest-hit rays of instanced scenes stay on the two-level BVH2 kernel (instances10k 1080p, one MI355X:
+    // closest-hit 849 us per launch on the BVH2 against 1061 us on the wide tree -- every instance entered costs the wide
+    // walk extra turns --, shadow rays 905 against 517 us)
+    int wideClosestOpt = -1, wideShadowOpt = -1;
     int wideStride = 80;                  // "wide_node_stride" option (80 or 128; takes effect at the next upload)
     uint32_t width = 0, height = 0;
 
@@ -266,40 +271,53 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
     return roots.empty() ? depth : depth + master + 1;
 }
 
-// Validates the wide BVH (children behind their parent, record runs inside the top-level records) and returns its depth,
-// -1 when malformed.
+// Validates the wide BVH -- the top-level tree from node 0 and, with instances, the masters' subtrees behind it (roots in the
+// instance records): children behind their parent, every node in one tree, record runs inside the record array -- and returns
+// the stack depth the walk needs (-1 when malformed).
 static int wideDepthOf(const TgHipSceneDesc *s)
 {
     const uint32_t n = s->num_wide_nodes;
-    const uint32_t topRecs = s->num_top_recs ? s->num_top_recs : s->num_recs;
     std::vector<uint8_t> depth(n, 0);
     depth[0] = 1;
-    int maxDepth = 1;
+    uint32_t firstMaster = n;
+    for (uint32_t i = 0; i < s->num_recs && s->num_instances; ++i) {
+        if (TGHIP_REC_KIND(s->recs[i].meta) != TGHIP_REC_INSTANCE) continue;
+        uint32_t root;
+        std::memcpy(&root, &s->recs[i].c[2], 4);
+        if (root == 0 || root >= n) return -1;
+        depth[root] = 1;
+        firstMaster = std::min(firstMaster, root);
+    }
+    int topDepth = 1, masterDepth = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const TgHipWideNode &w = s->wide_nodes[i];
-        if (depth[i] == 0) return -1;                        // unreachable node: not a tree in breadth-first order
+        if (depth[i] == 0) return -1;                        // unreachable node: not a forest in breadth-first order
         const uint32_t kids = uint32_t(__builtin_popcount(w.imask));
         if (kids && (w.child_base <= i || uint64_t(w.child_base) + kids > n)) return -1;
+        if (kids && i < firstMaster && w.child_base + kids > firstMaster) return -1;   // the top level does not reach into a master
         for (uint32_t k = 0; k < kids; ++k) {
             if (depth[w.child_base + k] != 0) return -1;     // two parents
             depth[w.child_base + k] = uint8_t(depth[i] + 1);
         }
-        if (kids) maxDepth = std::max(maxDepth, int(depth[i]) + 1);
-        if (maxDepth > TGHIP_MAX_WIDE_DEPTH) return -1;
+        if (i < firstMaster) topDepth = std::max(topDepth, int(depth[i]) + (kids ? 1 : 0));
+        else masterDepth = std::max(masterDepth, int(depth[i]) + (kids ? 1 : 0));
+        if (topDepth > TGHIP_MAX_WIDE_DEPTH || masterDepth > TGHIP_MAX_WIDE_DEPTH) return -1;
         for (int sl = 0; sl < 8; ++sl) {
             const uint32_t bits = (w.leaf_valid >> (4*sl)) & 15u;
             if ((bits & (bits + 1u)) != 0u || (bits && (w.imask & (1u << sl)))) return -1;   // records 0 .. count-1 of a leaf slot
         }
-        if (w.leaf_valid && uint64_t(w.rec_base) + uint32_t(__builtin_popcount(w.leaf_valid)) > topRecs) return -1;
+        const uint32_t recLimit = i < firstMaster ? (s->num_top_recs ? s->num_top_recs : s->num_recs) : s->num_recs;
+        if (w.leaf_valid && uint64_t(w.rec_base) + uint32_t(__builtin_popcount(w.leaf_valid)) > recLimit) return -1;
         for (int a = 0; a < 3; ++a)
             if (w.exp[a] == 0 || w.exp[a] == 255) return -1;
     }
-    return maxDepth;
+    const int total = s->num_instances ? topDepth + masterDepth + 3 : topDepth;   // + what entering an instance parks on the stack
+    return total > TGHIP_MAX_WIDE_DEPTH ? -1 : total;
 }
 
 static bool isFlat(const tghip_ctx *ctx) { return ctx->scene.num_recs <= TGHIP_FLAT_MAX_RECS && !ctx->haveInstances; }
 // the single-level traversal kernels walk the 8-wide BVH when the scene carries one
-static bool useWide(const tghip_ctx *ctx) { return ctx->wideDepth > 0 && ctx->wideOpt && ctx->dynamicFetch && !ctx->haveInstances && !isFlat(ctx); }
+static bool useWide(const tghip_ctx *ctx) { return ctx->wideDepth > 0 && ctx->wideOpt && ctx->dynamicFetch && !isFlat(ctx); }
 
 
 // Dynamic LDS of the traversal kernels: one node stack of bvhDepth ints per thread (a root-to-leaf walk pushes at
@@ -323,6 +341,9 @@ static size_t wideLdsBytes(const tghip_ctx *ctx, int threads)
 {
     return size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short) + size_t(std::max(ctx->wideDepth, 1))*size_t(threads)*sizeof(uint2);
 }
+
+static bool wideClosest(const tghip_ctx *ctx) { return useWide(ctx) && (ctx->wideClosestOpt < 0 ? !ctx->haveInstances : ctx->wideClosestOpt != 0); }
+static bool wideShadowRays(const tghip_ctx *ctx) { return useWide(ctx) && ctx->wideShadowOpt != 0; }
 
 static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*std::max(ctx->blocksPerCu, 1); }
 
@@ -356,8 +377,10 @@ static int foldCounters(tghip_ctx *ctx)
         ctx->counters.shadow_rays += c.shadow_rays; ctx->counters.shadow_slots += c.shadow_slots;
         c.samples = c.closest_rays = c.shadow_rays = c.shadow_slots = 0;
         const BlockStats &t = ctx->hostStats[b];
-        ctx->counters.nodes_visited += t.nodes_visited; ctx->counters.prims_tested += t.prims_tested;
-        ctx->counters.nodes_visited_shadow += t.nodes_visited_shadow; ctx->counters.prims_tested_shadow += t.prims_tested_shadow;
+        if (ctx->countTraversal) {
+            ctx->counters.nodes_visited += t.nodes_visited; ctx->counters.prims_tested += t.prims_tested;
+            ctx->counters.nodes_visited_shadow += t.nodes_visited_shadow; ctx->counters.prims_tested_shadow += t.prims_tested_shadow;
+        }
     }
     if (std::getenv("TGHIP_VERBOSE")) {
         unsigned long long turns = 0, dry = 0;
@@ -433,12 +456,16 @@ static void chooseThreads(tghip_ctx *ctx)
     const bool inst = ctx->haveInstances;
     const bool dyn = ctx->dynamicFetch && !inst;               // the dynamic-fetch kernels are single-level
     const bool wide = useWide(ctx);
-    ctx->thrClosest = wide ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 320, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 320, 3))
+    const bool wideC = wideClosest(ctx), wideS = wideShadowRays(ctx);
+    ctx->thrClosest = wideC && inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true, true>, 320, 3) : pickThreads(ctx, k_trace_closest_wide<false, false, true>, 320, 3))
+                    : wideC ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 320, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 320, 3))
                     : flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
                     : inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest<false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_closest<false, false, 2>, 512, 1))
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
-    if (wide && !ctx->haveForward && !ctx->haveMeshLight)
+    if (wideS && inst && !ctx->haveForward && !ctx->haveMeshLight)
+        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<true, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<true, false, true>, 256, 3);
+    else if (wideS && !ctx->haveForward && !ctx->haveMeshLight)
         ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false>, 256, 3);
     else if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
         ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_dyn<false, true>, 256, 2) : pickThreads(ctx, k_trace_shadow_dyn<false, false>, 256, 2);   // measured: 192 / 256 / 320 / 384 threads = 525 / 462 / 633 / 619 us per launch
@@ -564,6 +591,8 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "run_to_completion") ctx->loopOpt = value != 0;
     else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "wide_node_stride") { if (value != 80 && value != 128) { ctx->error = "wide_node_stride is 80 or 128"; return TGHIP_E_INVALID; } ctx->wideStride = int(value); }
+    else if (k == "wide_closest") { ctx->wideClosestOpt = value < 0 ? -1 : value != 0; if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "wide_shadow") { ctx->wideShadowOpt = value < 0 ? -1 : value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "wide_bvh") { ctx->wideOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "dynamic_fetch") { ctx->dynamicFetch = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "threads_closest") { ctx->thrOverride[0] = int(value); if (ctx->haveScene) chooseThreads(ctx); }
@@ -648,7 +677,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     const TgHipBvhNode *dn; const TgHipPrimRec *dr; const TgHipTriAttr *da;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->nodes, sd->num_nodes, &dn)) != TGHIP_OK) return rc;
     ctx->wideDepth = 0;
-    if (sd->wide_nodes && sd->num_wide_nodes && sd->num_instances == 0) {
+    if (sd->wide_nodes && sd->num_wide_nodes) {
         // the wide nodes and the primitive records share ONE allocation, so that a lane of the wide kernels addresses
         // "a node or a record" with one base pointer and one 32-bit offset
         const int wd = wideDepthOf(sd);
@@ -869,17 +898,27 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrShadow);
     const bool flat = isFlat(ctx);
     const bool closestWalk = ctx->haveForward || ctx->haveMeshLight;   // shadow rays are closest-hit walks, not any-hit queries
-    if (ctx->haveInstances) {
+    const bool wideShadow = wideShadowRays(ctx) && !closestWalk && !ctx->auxPass;
+    if (ctx->haveInstances && !wideShadow) {
 #define SHADOW_INST(FWD, I) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, false, I>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
         if (closestWalk) { if (ctx->haveSolids) SHADOW_INST(true, 1); else SHADOW_INST(true, 2); }
         else             { if (ctx->haveSolids) SHADOW_INST(false, 1); else SHADOW_INST(false, 2); }
 #undef SHADOW_INST
         return false;
     }
-    if (useWide(ctx) && !closestWalk && !ctx->auxPass) {
+    if (wideShadow) {
         const size_t lds = wideLdsBytes(ctx, ctx->thrShadow);
-        if (ctx->haveSolids) hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->stream, ctx->scene, st, pp, iterTag);
-        else                 hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, false>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->stream, ctx->scene, st, pp, iterTag);
+#define SHADOW_WIDE(S, I) hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, S, I>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->stream, ctx->scene, st, pp, iterTag)
+        if (ctx->haveInstances) {
+            // (always the counting variant: hipcc 7.2 miscompiles k_trace_shadow_wide<false, ., true> -- occluders inside instances
+            // go missing, tools/dbg/inst_debug3.py -- while the variant that also counts its node and record visits is correct;
+            // foldCounters drops the counts when nobody asked for them)
+#define SHADOW_WIDE_INST(S) hipLaunchKernelGGL((k_trace_shadow_wide<true, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->stream, ctx->scene, st, pp, iterTag)
+            if (ctx->haveSolids) SHADOW_WIDE_INST(true); else SHADOW_WIDE_INST(false);
+#undef SHADOW_WIDE_INST
+        }
+        else                    { if (ctx->haveSolids) SHADOW_WIDE(true, false); else SHADOW_WIDE(false, false); }
+#undef SHADOW_WIDE
         return true;
     }
     if (!flat && !closestWalk && ctx->dynamicFetch && !ctx->auxPass) {   // (the dynamic-fetch kernel does not report transmittances)
@@ -987,16 +1026,21 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             if (flat) {
                 if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
                 else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
-            } else if (ctx->haveInstances) {
+            } else if (ctx->haveInstances && !wideClosest(ctx)) {
 #define CLOSEST_INST(C, I) hipLaunchKernelGGL((k_trace_closest<C, false, I>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st)
                 if (ctx->haveSolids) { if (count) CLOSEST_INST(true, 1); else CLOSEST_INST(false, 1); }
                 else                 { if (count) CLOSEST_INST(true, 2); else CLOSEST_INST(false, 2); }
 #undef CLOSEST_INST
-            } else if (useWide(ctx)) {
+            } else if (wideClosest(ctx)) {
                 const size_t ldsWide = wideLdsBytes(ctx, ctx->thrClosest);
-#define CLOSEST_WIDE(C, S) hipLaunchKernelGGL((k_trace_closest_wide<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->stream, s, st)
-                if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true); else CLOSEST_WIDE(false, true); }
-                else                 { if (count) CLOSEST_WIDE(true, false); else CLOSEST_WIDE(false, false); }
+#define CLOSEST_WIDE(C, S, I) hipLaunchKernelGGL((k_trace_closest_wide<C, S, I>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->stream, s, st)
+                if (ctx->haveInstances) {
+                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, true); else CLOSEST_WIDE(false, true, true); }
+                    else                 { if (count) CLOSEST_WIDE(true, false, true); else CLOSEST_WIDE(false, false, true); }
+                } else {
+                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, false); else CLOSEST_WIDE(false, true, false); }
+                    else                 { if (count) CLOSEST_WIDE(true, false, false); else CLOSEST_WIDE(false, false, false); }
+                }
 #undef CLOSEST_WIDE
             } else {
                 if (ctx->dynamicFetch) {
@@ -1519,8 +1563,10 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
 #define RAYS_LAUNCH(C, F) hipLaunchKernelGGL((k_trace_rays<C, F>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats)
         if (useWide(ctx)) {
             const size_t ldsWide = size_t(std::max(ctx->wideDepth, 1))*256u*sizeof(uint2);
-            if (cnt) hipLaunchKernelGGL((k_trace_rays<true, false, 0, true>), dim3(grid), dim3(256), ldsWide, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
-            else     hipLaunchKernelGGL((k_trace_rays<false, false, 0, true>), dim3(grid), dim3(256), ldsWide, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);
+#define RAYS_WIDE(C, I) hipLaunchKernelGGL((k_trace_rays<C, false, I, true>), dim3(grid), dim3(256), ldsWide, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats)
+            if (ctx->haveInstances) { if (cnt) RAYS_WIDE(true, 1); else RAYS_WIDE(false, 1); }
+            else                    { if (cnt) RAYS_WIDE(true, 0); else RAYS_WIDE(false, 0); }
+#undef RAYS_WIDE
         }
         else if (ctx->haveInstances) {
             if (cnt) hipLaunchKernelGGL((k_trace_rays<true, false, 1>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats);

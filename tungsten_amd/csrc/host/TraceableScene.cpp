@@ -348,10 +348,12 @@ void TraceableScene::flatten()
     _bvhDepth = bvh.maxDepth;
     _bvhSah = bvh.sahCost;
     // ---- the 8-wide BVH the single-level traversal kernels walk (WideBvh.hpp): the BVH2 collapsed, records re-ordered by
-    // wide node.  Flat-list scenes are intersected without a tree, scenes with instances walk the two-level BVH2.
+    // wide node.  Flat-list scenes are intersected without a tree.  With instances the top-level tree's leaves hold the
+    // instance records and every master gets a wide subtree of its own behind it (below).
     _wideNodes.clear();
     _wideDepth = 0;
-    if (numInstances == 0 && _recs.size() > TGHIP_FLAT_MAX_RECS && !std::getenv("TGH_NO_WIDE_BVH")) {
+    const bool wantWide = (_recs.size() > TGHIP_FLAT_MAX_RECS || numInstances) && !std::getenv("TGH_NO_WIDE_BVH");
+    if (wantWide) {
         std::vector<Box3f> ordered(recBounds.size());
         for (size_t i = 0; i < bvh.order.size(); ++i)
             ordered[i] = recBounds[bvh.order[i]];
@@ -371,8 +373,8 @@ void TraceableScene::flatten()
 
     // ---- masters of instanced geometry: records in master space + one BVH2 subtree each, behind the top level ----
     // (the reference keeps an Embree scene per master mesh and transforms the ray into it, Instance.cpp:290-311)
-    std::vector<uint32_t> masterRoot(masterPrims.size(), 0);
-    int masterDepth = 0;
+    std::vector<uint32_t> masterRoot(masterPrims.size(), 0), masterWideRoot(masterPrims.size(), 0);
+    int masterDepth = 0, masterWideDepth = 0;
     for (size_t mi = 0; mi < masterPrims.size(); ++mi) {
         Primitive &m = *masterPrims[mi];
         // the master's object record (smooth flag, first bsdf); it is not a scene object of its own unless the scene also lists it
@@ -416,9 +418,32 @@ void TraceableScene::flatten()
         const uint32_t recBase = uint32_t(_recs.size()), nodeBase = uint32_t(_nodes.size());
         if (uint64_t(recBase) + mrecs.size() >= (1u << 27))
             throw std::runtime_error("too many primitive records for the 27-bit leaf encoding");
-        for (size_t i = 0; i < sub.order.size(); ++i) {
-            _recs.push_back(mrecs[sub.order[i]]);
-            _triAttrs.push_back(mattrs[sub.order[i]]);
+        // the master's wide subtree (only when the top level has one): built over the master's own records, then moved behind
+        // the wide nodes and records that exist so far
+        std::vector<uint32_t> place(sub.order);              // place[i] = the master's record that goes to slot recBase + i
+        if (!_wideNodes.empty()) {
+            std::vector<Box3f> ordered(mbounds.size());
+            for (size_t i = 0; i < sub.order.size(); ++i)
+                ordered[i] = mbounds[sub.order[i]];
+            WideBvhResult wide = buildWideBvh(sub.nodes, ordered);
+            if (wide.nodes.empty()) {
+                _wideNodes.clear();                          // (a leaf too fat to collapse: the scene walks the BVH2)
+                _wideDepth = 0;
+            } else {
+                for (size_t i = 0; i < wide.order.size(); ++i)
+                    place[i] = sub.order[wide.order[i]];
+                masterWideRoot[mi] = uint32_t(_wideNodes.size());
+                for (TgHipWideNode w : wide.nodes) {
+                    w.child_base += masterWideRoot[mi];
+                    w.rec_base += recBase;
+                    _wideNodes.push_back(w);
+                }
+                masterWideDepth = std::max(masterWideDepth, wide.depth);
+            }
+        }
+        for (size_t i = 0; i < place.size(); ++i) {
+            _recs.push_back(mrecs[place[i]]);
+            _triAttrs.push_back(mattrs[place[i]]);
         }
         auto relocate = [&](int32_t ref) -> int32_t {
             if (ref >= 0) return ref + int32_t(nodeBase);
@@ -438,6 +463,12 @@ void TraceableScene::flatten()
             uint32_t slot;
             std::memcpy(&slot, &_recs[i].c[0], 4);
             std::memcpy(&_recs[i].c[0], &masterRoot[slot], 4);
+            std::memcpy(&_recs[i].c[2], &masterWideRoot[slot], 4);   // root of the master's wide subtree (0: the scene has no wide BVH)
+        }
+        // the wide walk's stack: the groups of the top level, three entries where an instance is entered, the master's groups
+        if (!_wideNodes.empty()) {
+            _wideDepth += masterWideDepth + 3;
+            if (_wideDepth > TGHIP_MAX_WIDE_DEPTH) { _wideNodes.clear(); _wideDepth = 0; }
         }
         // one device stack holds the top-level walk and, above it, the walk of the master being visited
         _bvhDepth += masterDepth + 1;
