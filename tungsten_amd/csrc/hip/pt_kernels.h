@@ -63,7 +63,9 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 // Q_EXT holds bounced (continuation) rays, Q_EXTP freshly generated camera rays: the traversal kernel walks them as
 // two separate runs so that the coherent primaries are not interleaved lane by lane with incoherent bounces.
 // Q_FIN: paths whose last vertex was waiting for a shadow result of the dynamic-fetch shadow kernel (k_finish regenerates them)
-enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_FIN = 5, Q_COUNT = 6 };
+// Q_MISS: paths whose ray left the scene -- two of five vertices of an environment-lit scene -- shaded by a launch of their own
+// (handleInfiniteLights, finalise, regenerate) so that they do not sit out the surface shading of the hits in their waves
+enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_FIN = 5, Q_MISS = 6, Q_COUNT = 7 };
 
 struct BlockCtl {                 // one per persistent workgroup; only that workgroup touches it
     uint32_t item_cursor;         // workgroup-local linear index of the next work item
@@ -73,7 +75,7 @@ struct BlockCtl {                 // one per persistent workgroup; only that wor
 
 struct BlockStats {               // traversal statistics (count_traversal option), one per workgroup
     unsigned long long nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow;
-    unsigned long long prof[12];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds, tools/gpu_profile_sections.sh)
+    unsigned long long prof[16];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds, tools/gpu_profile_sections.sh)
 };
 
 // Per-slot state: A_COUNT arrays of 16-byte elements in ONE allocation, array a at byte offset a*stride (stride =
@@ -103,6 +105,11 @@ enum {
 struct PathState {
     char * __restrict__ pool;              // A_COUNT x stride bytes
     uint32_t stride;                       // bytes per array
+    // "pool_layout" = 1: slot records instead of arrays -- the eight arrays of a path's state (A_RAY_O .. A_SAMP, 128 bytes)
+    // in ONE cache line per slot, the seven of its shadow-ray block (A_SH_O .. A_SH_P, 112 bytes) in a second one at
+    // rec_shadow, the two auxiliary-output arrays at rec_aux: a sparse queue then touches one line per slot and block
+    // instead of one partially used line per slot and ARRAY
+    uint32_t records, rec_shadow, rec_aux;
     uint32_t * __restrict__ bm;            // queue bitmaps: queue q of workgroup b = words [q*bmStride + b*slots_per_block/32, ...)
     uint32_t bmStride;                     // words per queue
     float4 * __restrict__ partial;         // per work item: radiance sum, count (uint bits)
@@ -114,13 +121,19 @@ struct PathState {
     uint32_t leaf_batch;                   // dynamic-fetch traversal: lanes waiting at a leaf before the leaf code runs (1 = at once)
 };
 
+PT_DEV uint32_t slotOffset(const PathState &st, uint32_t a, uint32_t slot)     // `a` is a literal at every call site: the selects fold
+{
+    if (st.records)
+        return a < A_SH_O ? slot*128u + a*16u : a < A_AUX0 ? st.rec_shadow + slot*128u + (a - A_SH_O)*16u : st.rec_aux + slot*32u + (a - A_AUX0)*16u;
+    return a*st.stride + slot*16u;
+}
 PT_DEV float4 &slotF4(const PathState &st, uint32_t a, uint32_t slot)
 {
-    return *reinterpret_cast<float4 *>(st.pool + (size_t)(a*st.stride + slot*16u));
+    return *reinterpret_cast<float4 *>(st.pool + (size_t)slotOffset(st, a, slot));
 }
 PT_DEV uint4 &slotU4(const PathState &st, uint32_t a, uint32_t slot)
 {
-    return *reinterpret_cast<uint4 *>(st.pool + (size_t)(a*st.stride + slot*16u));
+    return *reinterpret_cast<uint4 *>(st.pool + (size_t)slotOffset(st, a, slot));
 }
 
 
@@ -200,7 +213,14 @@ PT_DEV DeviceScene stageSceneTables(const DeviceScene &s, unsigned char *lds)
     const uint32_t offBsdf = (szObj + 15u) & ~15u;
     const uint32_t offTex = (offBsdf + szBsdf + 15u) & ~15u;
     const uint32_t offLights = (offTex + szTex + 15u) & ~15u;
-    const uint32_t total = offLights + szLights;
+    // the marginal tables of the sampled environment map (mpdf[h] mcdf[h + 1], then its 513-entry guide): the head of the
+    // envmap-sampling chain becomes LDS reads
+    const uint32_t offEnv = (offLights + szLights + 15u) & ~15u;
+    const uint32_t szEnvF = s.env_tex >= 0 ? (2u*(uint32_t)s.env_h + 1u)*4u : 0u, szEnvG = s.env_tex >= 0 ? (PT_GUIDE_MARGINAL + 1u)*2u : 0u;
+    const uint32_t offEnvG = (offEnv + szEnvF + 3u) & ~3u;
+    const uint32_t totalBase = offLights + szLights;
+    const bool envFits = s.env_tex >= 0 && ((offEnvG + szEnvG + 3u) & ~3u) <= PT_LDS_TABLE_BYTES;
+    const uint32_t total = totalBase;
     if (total > PT_LDS_TABLE_BYTES)
         return s;                                            // uniform decision: too large, keep the global tables
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
@@ -214,8 +234,16 @@ PT_DEV DeviceScene stageSceneTables(const DeviceScene &s, unsigned char *lds)
     copy(offTex, s.textures, szTex);
     copy(offLights, s.lights, s.num_lights*(uint32_t)sizeof(int32_t));
     copy(offLights + s.num_lights*(uint32_t)sizeof(int32_t), s.infinite_lights, s.num_infinite_lights*(uint32_t)sizeof(int32_t));
+    if (envFits) {
+        copy(offEnv, s.env_marginal, szEnvF);
+        copy(offEnvG, s.env_guide, (szEnvG + 3u) & ~3u);     // (the guide array is padded to a multiple of 4 bytes at upload)
+    }
     __syncthreads();
     DeviceScene r = s;
+    if (envFits) {
+        r.env_marginal = reinterpret_cast<const float *>(lds + offEnv);
+        r.env_guide = reinterpret_cast<const uint16_t *>(lds + offEnvG);
+    }
     r.objects = reinterpret_cast<const TgHipObject *>(lds);
     r.bsdfs = reinterpret_cast<const TgHipBsdf *>(lds + offBsdf);
     r.textures = reinterpret_cast<const TgHipTexture *>(lds + offTex);

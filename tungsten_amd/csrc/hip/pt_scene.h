@@ -28,6 +28,15 @@ struct DeviceScene {
     const float * __restrict__ light_tris;     // sampled mesh emitters: cdf + triangles (include/tungsten_hip.h)
     const uint16_t * __restrict__ guide;       // CDF guide tables of the samplable bitmaps (built at upload, bitmapSample)
     const int32_t * __restrict__ tex_guide;    // per texture: offset of its tables in `guide`, -1 = none
+    // Built at upload for the envmap-sampling chain (bitmapSample): per samplable bitmap the conditional (row) tables as
+    // interleaved (cdf[i], pdf[i]) pairs, (w + 1) per row, so that one 32-byte window holds what a CDF inversion needs;
+    // tex_rows[tex] = the bitmap's first pair (-1: none).  env_*: the MARGINAL tables (mpdf[h] mcdf[h + 1], guide[513]) of the
+    // texture env_tex -- the scene's first sampled environment map --, which the shading kernels copy into LDS when they fit.
+    const float2 * __restrict__ rows;
+    const int32_t * __restrict__ tex_rows;
+    int32_t env_tex, env_h;
+    const float *env_marginal;
+    const uint16_t *env_guide;
     const uint32_t * __restrict__ sobol;       // Sobol' generator matrices (nullptr unless the scene carries them)
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
     uint32_t num_instances;                    // instance records (0: single-level scene, A_EMI.w carries nothing)
@@ -133,13 +142,20 @@ PT_DEV int upperBoundIdx(const float *a, int n, float x)
     while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid + 1; else hi = mid; }
     return lo;
 }
-PT_DEV float bitmapPdf(const DeviceScene &s, const TgHipTexture &t, float u, float v)   /* BitmapTexture.cpp:452-455 */
+// what a CDF inversion already fetched for the texel it picked: bitmapPdf of the same texel needs no further loads
+struct BitmapPick { int row, column; float pdfRC, mpdfR; };
+PT_DEV float bitmapPdf(const DeviceScene &s, int texIdx, const TgHipTexture &t, float u, float v, const BitmapPick *pick = nullptr)   /* BitmapTexture.cpp:452-455 */
 {
-    const float *mpdf = s.dist + t.dist_offset;
-    const float *pdf = mpdf + t.h + t.h + 1;
     int row = (int)((1.0f - v)*t.h), column = (int)(u*t.w);
     row = min(max(row, 0), t.h - 1);
     column = min(max(column, 0), t.w - 1);
+    if (pick && pick->row == row && pick->column == column)
+        return pick->pdfRC*pick->mpdfR*t.w*t.h;
+    const float *mpdf = texIdx == s.env_tex ? s.env_marginal : s.dist + t.dist_offset;
+    const int ro = s.tex_rows[texIdx];
+    if (ro >= 0)
+        return at32(s.rows, (uint32_t)ro + (uint32_t)row*(uint32_t)(t.w + 1) + (uint32_t)column).y*mpdf[row]*t.w*t.h;
+    const float *pdf = s.dist + t.dist_offset + t.h + t.h + 1;
     return pdf[(size_t)row*t.w + column]*mpdf[row]*t.w*t.h;
 }
 // Guide tables (built by the shim at upload) make the two CDF inversions of Distribution2D::warp short dependent
@@ -155,24 +171,57 @@ PT_DEV int upperBoundGuided(const float *a, const uint16_t *g, int buckets, floa
     while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid + 1; else hi = mid; }
     return lo;
 }
-PT_DEV void bitmapSample(const DeviceScene &s, int texIdx, const TgHipTexture &t, float xi0, float xi1, float &u, float &v)   /* :433-439 */
+// The same inversion on a row of (cdf, pdf) pairs: the guide's window [lo, hi] usually spans a few entries, so the three
+// pairs from lo - 1 on (loads issued together) decide it without a dependent search loop; wider windows fall
+// back to the loop.  Returns upper_bound's index and the pair at index - 1 (the texel picked).
+PT_DEV int upperBoundGuidedPairs(const float2 *a, const uint16_t *g, int buckets, float x, int n, float2 &picked)
 {
-    const float *mpdf = s.dist + t.dist_offset;
+    int b = min((int)(x*(float)buckets), buckets - 1);
+    int lo = g[b], hi = g[b + 1];
+    // lo >= 1 (a[0] = 0 <= x) and the pairs lo - 1 .. lo + 1 exist when lo + 1 <= n
+    if (hi - lo <= 2 && lo >= 1 && lo + 1 <= n) {
+        const float2 p0 = a[lo - 1], p1 = a[lo], p2 = a[lo + 1];
+        // upper_bound over [lo, hi]: the first index whose cdf exceeds x (the binary search's answer: cdfs are non-decreasing)
+        int r = hi;
+        if (hi > lo + 1 && !(p2.x <= x)) r = lo + 1;
+        if (hi > lo && !(p1.x <= x)) r = lo;
+        picked = r == lo ? p0 : r == lo + 1 ? p1 : p2;
+        return r;
+    }
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid].x <= x) lo = mid + 1; else hi = mid; }
+    picked = a[lo - 1];
+    return lo;
+}
+PT_DEV void bitmapSample(const DeviceScene &s, int texIdx, const TgHipTexture &t, float xi0, float xi1, float &u, float &v, BitmapPick &pick)   /* :433-439 */
+{
+    const bool env = texIdx == s.env_tex;
+    const float *mpdf = env ? s.env_marginal : s.dist + t.dist_offset;
     const float *mcdf = mpdf + t.h;
-    const float *pdf = mcdf + t.h + 1;
-    const float *cdf = pdf + (size_t)t.w*t.h;
     const int go = s.tex_guide[texIdx];
+    const int ro = s.tex_rows[texIdx];
     int row;
-    if (go >= 0) row = upperBoundGuided(mcdf, s.guide + go, PT_GUIDE_MARGINAL, xi1) - 1;
+    if (go >= 0) row = upperBoundGuided(mcdf, env ? s.env_guide : s.guide + go, PT_GUIDE_MARGINAL, xi1) - 1;
     else         row = upperBoundIdx(mcdf, t.h + 1, xi1) - 1;
-    float nv = clampf((xi1 - mcdf[row])/mpdf[row], 0.0f, 1.0f);
-    const float *rowStart = cdf + (size_t)row*(t.w + 1);
+    const float mpdfR = mpdf[row];
+    float nv = clampf((xi1 - mcdf[row])/mpdfR, 0.0f, 1.0f);
     int column;
-    if (go >= 0) column = upperBoundGuided(rowStart, s.guide + go + (PT_GUIDE_MARGINAL + 1) + row*(PT_GUIDE_ROW + 1), PT_GUIDE_ROW, xi0) - 1;
-    else         column = upperBoundIdx(rowStart, t.w + 1, xi0) - 1;
-    float nu = clampf((xi0 - rowStart[column])/pdf[(size_t)row*t.w + column], 0.0f, 1.0f);
+    float cdfC, pdfC;
+    if (go >= 0 && ro >= 0) {
+        const float2 *rowStart = &at32(s.rows, (uint32_t)ro + (uint32_t)row*(uint32_t)(t.w + 1));
+        float2 picked;
+        column = upperBoundGuidedPairs(rowStart, s.guide + go + (PT_GUIDE_MARGINAL + 1) + row*(PT_GUIDE_ROW + 1), PT_GUIDE_ROW, xi0, t.w, picked) - 1;
+        cdfC = picked.x; pdfC = picked.y;
+    } else {
+        const float *pdf = s.dist + t.dist_offset + t.h + t.h + 1;
+        const float *rowStart = pdf + (size_t)t.w*t.h + (size_t)row*(t.w + 1);
+        if (go >= 0) column = upperBoundGuided(rowStart, s.guide + go + (PT_GUIDE_MARGINAL + 1) + row*(PT_GUIDE_ROW + 1), PT_GUIDE_ROW, xi0) - 1;
+        else         column = upperBoundIdx(rowStart, t.w + 1, xi0) - 1;
+        cdfC = rowStart[column]; pdfC = pdf[(size_t)row*t.w + column];
+    }
+    float nu = clampf((xi0 - cdfC)/pdfC, 0.0f, 1.0f);
     u = (nu + column)/t.w;
     v = 1.0f - (nv + row)/t.h;
+    pick.row = row; pick.column = column; pick.pdfRC = pdfC; pick.mpdfR = mpdfR;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1398,7 +1447,7 @@ PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p, const 
         return PT_INV_FOUR_PI;
     float sinTheta, u, v;
     infDirectionToUV(o, w, u, v, sinTheta);
-    return PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, t, u, v)/sinTheta;
+    return PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, o.emission, t, u, v)/sinTheta;
 }
 template<uint32_t M>
 PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, f3 &d, float &dist, float &pdf)
@@ -1562,9 +1611,10 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         return true;
     }
     float u, v, sinTheta;
-    bitmapSample(s, o.emission, t, xi0, xi1, u, v);
+    BitmapPick pick;
+    bitmapSample(s, o.emission, t, xi0, xi1, u, v, pick);
     d = infUvToDirection(o, u, v, sinTheta);
-    pdf = PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, t, u, v)/sinTheta;
+    pdf = PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, o.emission, t, u, v, &pick)/sinTheta;
     return pdf != 0.0f;
 }
 template<uint32_t M>

@@ -22,9 +22,9 @@
 // Section timers of the shading kernel (development aid; compiled in only with -DPT_PROFILE): s_memtime per
 // wave at section boundaries, summed per workgroup into BlockStats::prof and printed by tghip_destroy.
 #ifdef PT_PROFILE
-#define PROF_DECL unsigned long long profT = clock64(), profAcc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF_DECL unsigned long long profT = clock64(), profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF(n) do { unsigned long long t_ = clock64(); profAcc[n] += t_ - profT; profT = t_; } while (0)
-#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 12; ++k_) atomicAdd(&(stats).prof[k_], profAcc[k_]); } while (0)
+#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 16; ++k_) if (k_ != 10 && k_ != 11) atomicAdd(&(stats).prof[k_], profAcc[k_]); } while (0)
 #else
 #define PROF_DECL
 #define PROF(n)
@@ -289,16 +289,17 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
             }
             slotF4(st, A_HIT, slot) = hit;
             int ri = __float_as_int(hit.w);
-            cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
+            cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
             rays++;
         }
         // sort by material: one shading queue per class
         queuePush(cls == 0, local, L, Q_SHADE0);
         queuePush(cls == 1, local, L, Q_SHADE1);
+        queuePush(cls == 2, local, L, Q_MISS);
     }
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1), Q_EXTP);
+    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1) | (1u << Q_MISS), Q_EXTP);
     if (threadIdx.x == 0) {
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
@@ -406,8 +407,8 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
                 // finished: publish the hit and bin the path by shading class
                 slotF4(st, A_HIT, slot) = hit;
                 int ri = __float_as_int(hit.w);
-                int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
-                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
+                int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
+                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
                 busy = false;
             } else {
                 sp--;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
     }
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1), Q_EXTP);
+    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1) | (1u << Q_MISS), Q_EXTP);
     if (threadIdx.x == 0) {
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
@@ -509,8 +510,8 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
                     slotF4(st, A_HIT, slot) = hit;
                     if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
                     int ri = __float_as_int(hit.w);
-                    int cls = ri < 0 ? 0 : (int)at32(s.rec_class, (uint32_t)ri);
-                    queuePush(true, local, L, cls == 0 ? Q_SHADE0 : Q_SHADE1);
+                    int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
+                    queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
                     busy = false;
                 }
             }
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
     }
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1), Q_EXTP);
+    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1) | (1u << Q_MISS), Q_EXTP);
     if (threadIdx.x == 0) {
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
@@ -635,7 +636,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
     __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : cls == 0 ? Q_SHADE0 : Q_SHADE1;
+    const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS;   // cls 2: the escaped paths
     const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : -1;
     const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? (1u << Q_SHADE1) : 0u);
     queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2);
@@ -942,7 +943,9 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                             // lightSample (TraceBase.cpp:246-285)
                             {
                                 f3 d; float dist, pdf;
-                                if (lightSampleDirect<M>(s, light, info.p, rng, d, dist, pdf)) {
+                                const bool sampledLight = lightSampleDirect<M>(s, light, info.p, rng, d, dist, pdf);
+                                PROF(9);
+                                if (sampledLight) {
                                     if (M & FEAT_MEDIA) tag = mediaTag(d);
                                     ev.wo = toLocal(frame, d);
                                     ev.requested = LOBE_ALL_BUT_SPECULAR;
@@ -990,6 +993,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                     }
                                 }
                             }
+                            PROF(12);
                             // bsdfSample (TraceBase.cpp:287-321); not for Dirac lights (:396-397)
                             if (!diracLight) {
                                 ev.requested = LOBE_ALL_BUT_SPECULAR;
@@ -1026,6 +1030,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                     }
                                 }
                             }
+                            PROF(13);
                             if ((FUSE & FUSE_SHADOW) && (q0 || q1)) {
                                 // emission += estimateDirect(...)*throughput, like k_trace_shadow
                                 em = em + (inlineResult*lightWeight)*throughput;
@@ -1092,6 +1097,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                     continuePath(hp, wo, 5e-4f);
                 }
             }
+            PROF(14);
             if (state == ST_ACTIVE) {
                 slotF4(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
                 slotF4(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
@@ -1121,6 +1127,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             }
             if (survives)
                 slotF4(st, A_THR, slot) = mk4(throughput, __uint_as_float(newFlags));
+            PROF(15);
           }
         }
         PROF(5);

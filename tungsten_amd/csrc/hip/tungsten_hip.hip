@@ -137,6 +137,7 @@ struct tghip_ctx {
     bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
     int leafBatch = 1;                    // "leaf_batch" (PathState::leaf_batch)
+    bool poolRecords = false;             // "pool_layout" option: 1 = slot records (PathState::records)
     long long poolPad = 9472;             // bytes between the per-slot arrays of the pool (multiple of 16)
     bool dynamicFetch = true;             // BVH scenes: closest-hit kernel with dynamic ray fetch (k_trace_closest_dyn)
     bool timeKernels = false;             // HIP events around every launch of the wavefront loop (bench.py roofline)
@@ -389,10 +390,10 @@ static int foldCounters(tghip_ctx *ctx)
     }
 #ifdef PT_PROFILE
     {
-        unsigned long long tot[12] = {0};
-        for (size_t b = 0; b < g; ++b) for (int k = 0; k < 12; ++k) tot[k] += ctx->hostStats[b].prof[k];
-        unsigned long long sum = 0; for (int k = 0; k < 12; ++k) sum += tot[k];
-        if (sum) { std::fprintf(stderr, "[PT_PROFILE] k_shade wave-cycles by section:"); for (int k = 0; k < 9; ++k) std::fprintf(stderr, " s%d=%.1f%%", k, 100.0*double(tot[k])/double(sum)); std::fprintf(stderr, " total=%llu\n", sum); }
+        unsigned long long tot[16] = {0};
+        for (size_t b = 0; b < g; ++b) for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) tot[k] += ctx->hostStats[b].prof[k];
+        unsigned long long sum = 0; for (int k = 0; k < 16; ++k) sum += tot[k];
+        if (sum) { std::fprintf(stderr, "[PT_PROFILE] k_shade wave-cycles by section:"); for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) std::fprintf(stderr, " s%d=%.1f%%", k, 100.0*double(tot[k])/double(sum)); std::fprintf(stderr, " total=%llu\n", sum); }
     }
 #endif
     // no pass is running here (calls on one handle are serialised), so the records can be written back whole
@@ -425,8 +426,13 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     // the same HBM channel (a power-of-two array stride made the kernels' speed depend on allocation luck)
     const uint64_t strideBytes = uint64_t(slots)*16u + uint64_t(ctx->poolPad);
     if (strideBytes*A_COUNT >= (1ull << 32)) { ctx->error = "path pool too large for 32-bit slot offsets"; return TGHIP_E_INVALID; }
-    POOL_ALLOC(pool, size_t(strideBytes)*A_COUNT);
+    const uint64_t recordBytes = uint64_t(slots)*288u + 256u;   // the record layout: 128 + 128 + 32 bytes per slot
+    const bool records = ctx->poolRecords && recordBytes < (1ull << 32);
+    POOL_ALLOC(pool, size_t(std::max<uint64_t>(strideBytes*A_COUNT, records ? recordBytes : 0)));
     p.stride = uint32_t(strideBytes);
+    p.records = records ? 1u : 0u;
+    p.rec_shadow = uint32_t(uint64_t(slots)*128u + 128u);
+    p.rec_aux = uint32_t(uint64_t(slots)*256u + 256u);
     POOL_ALLOC(bm, size_t(slots/32)*Q_COUNT);
     p.bmStride = slots/32;
     POOL_ALLOC(ctl, grid); POOL_ALLOC(stats, grid); POOL_ALLOC(live, 1);
@@ -589,6 +595,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
     else if (k == "run_to_completion") ctx->loopOpt = value != 0;
+    else if (k == "pool_layout") { ctx->poolRecords = value != 0; ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "wide_node_stride") { if (value != 80 && value != 128) { ctx->error = "wide_node_stride is 80 or 128"; return TGHIP_E_INVALID; } ctx->wideStride = int(value); }
     else if (k == "wide_closest") { ctx->wideClosestOpt = value < 0 ? -1 : value != 0; if (ctx->haveScene) chooseThreads(ctx); }
@@ -775,6 +782,38 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         if (guide.empty()) guide.push_back(0);
         if ((rc = uploadArray(ctx, ctx->sceneMem, guide.data(), guide.size(), &s.guide)) != TGHIP_OK) return rc;
         if ((rc = uploadArray(ctx, ctx->sceneMem, texGuide.data(), texGuide.size(), &s.tex_guide)) != TGHIP_OK) return rc;
+        // the conditional tables of those bitmaps once more as interleaved (cdf, pdf) pairs (pt_scene.h: upperBoundGuidedPairs)
+        std::vector<float2> rows;
+        std::vector<int32_t> texRows(std::max<uint32_t>(sd->num_textures, 1u), -1);
+        for (uint32_t i = 0; i < sd->num_textures; ++i) {
+            const TgHipTexture &t = sd->textures[i];
+            if (texGuide[i] < 0 || rows.size() + size_t(t.w + 1)*size_t(t.h) >= (1u << 28))
+                continue;
+            texRows[i] = int32_t(rows.size());
+            const float *pdf = sd->dist + t.dist_offset + t.h + (t.h + 1);
+            const float *cdf = pdf + size_t(t.w)*t.h;
+            for (int y = 0; y < t.h; ++y)
+                for (int x = 0; x <= t.w; ++x)
+                    rows.push_back(make_float2(cdf[size_t(y)*(t.w + 1) + x], x < t.w ? pdf[size_t(y)*t.w + x] : 0.0f));
+        }
+        if (rows.empty()) rows.push_back(make_float2(0.0f, 0.0f));
+        if ((rc = uploadArray(ctx, ctx->sceneMem, rows.data(), rows.size(), &s.rows)) != TGHIP_OK) return rc;
+        if ((rc = uploadArray(ctx, ctx->sceneMem, texRows.data(), texRows.size(), &s.tex_rows)) != TGHIP_OK) return rc;
+        // the marginal tables of the first sampled environment map, for the shading kernels' LDS copy (stageSceneTables)
+        s.env_tex = -1; s.env_h = 0; s.env_marginal = nullptr; s.env_guide = nullptr;
+        std::vector<uint16_t> envGuide;
+        for (uint32_t li = 0; li < sd->num_lights && s.env_tex < 0; ++li) {
+            const TgHipObject &o = sd->objects[sd->lights[li]];
+            if (o.type != TGHIP_OBJ_INFINITE_SPHERE || o.emission < 0 || texGuide[size_t(o.emission)] < 0) continue;
+            const TgHipTexture &t = sd->textures[o.emission];
+            s.env_tex = o.emission;
+            s.env_h = t.h;
+            s.env_marginal = s.dist + t.dist_offset;          // mpdf[h] mcdf[h + 1] (device pointer arithmetic only)
+            envGuide.assign(guide.begin() + texGuide[size_t(o.emission)], guide.begin() + texGuide[size_t(o.emission)] + PT_GUIDE_MARGINAL + 1);
+            envGuide.push_back(0);                            // padded to whole 32-bit words
+        }
+        if (envGuide.empty()) envGuide.assign(2, 0);
+        if ((rc = uploadArray(ctx, ctx->sceneMem, envGuide.data(), envGuide.size(), &s.env_guide)) != TGHIP_OK) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the vectors go out of scope
     }
     // shading classes ("sort by material"): class 0 = BSDFs made of lambert/null only, class 1 = the rest
@@ -881,7 +920,7 @@ static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, co
 {
     constexpr uint32_t B = M & ~FEAT_QMC;
     hipLaunchKernelGGL((k_shade<M, (B == MASK_SIMPLE ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
-                       dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : cls == 0 ? ctx->thrShadeSimple : ctx->thrShadeComplex), 0, ctx->stream, ctx->scene, st, pp, cls);
+                       dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : cls == 1 ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->stream, ctx->scene, st, pp, cls);
 }
 // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
 template<uint32_t M, int FUSE = 0>
@@ -1056,12 +1095,14 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             }
             tic(); tic();
             if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) {   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER, for both classes
+                launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 2);
                 launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 0);
                 if (ctx->haveComplex) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 1);
             }
-            else if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, 0);   // the only variants with mesh-emitter sampling / instance transforms
-            else if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, 0);
-            else                     launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0);
+            // class 2 = the escaped paths (Q_MISS), with the class-0 variant: its surface code never runs there, so the launch is short
+            else if (ctx->haveMeshLight || ctx->haveInstances) { launchShade<MASK_FULL>(ctx, grid, st, pp, 2); launchShade<MASK_FULL>(ctx, grid, st, pp, 0); }   // the only variants with mesh-emitter sampling / instance transforms
+            else if (ctx->leanScene) { launchShade<MASK_LEAN>(ctx, grid, st, pp, 2); launchShade<MASK_LEAN>(ctx, grid, st, pp, 0); }
+            else                     { launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 2); launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0); }
             if (ctx->haveComplex && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder) {
                 if (ctx->haveMeshLight || ctx->haveInstances)   launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
