@@ -130,6 +130,8 @@ struct tghip_ctx {
     int checkInterval = 4;                // wavefront iterations between host-side liveness checks
     int blocksPerCuOpt = 0;               // "blocks_per_cu" option; 0 = auto (see chooseThreads)
     int blocksPerCu = 4;                  // persistent workgroups per CU (the same grid for every kernel of a pass)
+    int gridRounds = 1;                   // "grid_rounds": launch this many times the resident workgroups (each owns 1/rounds of the slots);
+                                          // the dispatcher starts the later ones as the first finish, filling the drain tail of a launch
     // threads per workgroup, per kernel: chosen at upload so that `blocksPerCu` workgroups of EVERY kernel are
     // resident at once (no second scheduling round), i.e. each kernel runs at its own best occupancy on one grid
     int thrClosest = 256, thrShadow = 256, thrShadeSimple = 192, thrShadeComplex = 128;
@@ -346,7 +348,7 @@ static size_t wideLdsBytes(const tghip_ctx *ctx, int threads)
 static bool wideClosest(const tghip_ctx *ctx) { return useWide(ctx) && (ctx->wideClosestOpt < 0 ? !ctx->haveInstances : ctx->wideClosestOpt != 0); }
 static bool wideShadowRays(const tghip_ctx *ctx) { return useWide(ctx) && ctx->wideShadowOpt != 0; }
 
-static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*std::max(ctx->blocksPerCu, 1); }
+static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCount*std::max(ctx->blocksPerCu, 1)*std::max(ctx->gridRounds, 1); }
 
 // Largest workgroup size (multiple of 64, <= maxThreads) at which `blocksPerCu` workgroups of `kernel` fit on a CU.
 template<typename K>
@@ -463,8 +465,10 @@ static void chooseThreads(tghip_ctx *ctx)
     const bool dyn = ctx->dynamicFetch && !inst;               // the dynamic-fetch kernels are single-level
     const bool wide = useWide(ctx);
     const bool wideC = wideClosest(ctx), wideS = wideShadowRays(ctx);
-    ctx->thrClosest = wideC && inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true, true>, 320, 3) : pickThreads(ctx, k_trace_closest_wide<false, false, true>, 320, 3))
-                    : wideC ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 320, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 320, 3))
+    // (wide closest-hit kernel, materialtest 1280x720x256 / mesh1m, one MI355X: 128 / 192 / 256 / 320 threads = 505 / 433 / 394 / 469 us per
+    // launch, but the shading launches behind it run 6 % faster after 192 than after 256: 579 / 571 / 552 Msamples/s for 192 / 256 / 320)
+    ctx->thrClosest = wideC && inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false, true>, 192, 3))
+                    : wideC ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 192, 3))
                     : flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
                     : inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest<false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_closest<false, false, 2>, 512, 1))
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
@@ -591,6 +595,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
+    else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
