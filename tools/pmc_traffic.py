@@ -1,4 +1,4 @@
-"""Aggregates rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/traffic.json.
+"""Aggregates rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r1/traffic.json.
 
 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024: both counters are in KiB, and on gfx950 FETCH_SIZE reports
 half of the bytes of a wide coalesced read (MI355X_MICROARCH.md "HBM"; cdna_hip_programming.md section 7), so the read
