@@ -144,7 +144,8 @@ struct PassParams {
     uint32_t chunk;            // samples per work item
     uint32_t chunks;           // items per pixel slot = ceil((spp_end - spp_begin)/chunk)
     uint32_t pix_slots;        // pixel slots in this batch (= tiles in batch * 256)
-    uint32_t total_items;      // pix_slots*chunks
+    uint32_t total_items;      // pix_slots*chunks (of this launch's workgroups: one half of the batch when the pool runs as two halves)
+    uint32_t item_begin;       // first item of this launch's workgroups within the batch
     uint32_t first_tile;       // first owned tile of the batch (index into the shard's tile list)
     uint32_t shard_index, shard_count;
     uint32_t tiles_x, num_tiles;

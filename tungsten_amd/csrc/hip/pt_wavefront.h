@@ -147,7 +147,7 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
                 want = false;
                 dead = true;
             } else {
-                uint32_t w = (uint32_t)w64;
+                uint32_t w = (uint32_t)w64 + pp.item_begin;
                 uint32_t c, j, x, y;
                 bool inImage;
                 uint32_t recOfItem = 0;
@@ -491,59 +491,100 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
         if (busyMask == 0ull)
             break;
         if (COUNT) { turns++; dryTurns += exhausted ? 1u : 0u; }
-        uint32_t idx = 0;
-        int what = 0;
-        if (busy) {
-            // Phase vote (st.leaf_batch != 1): the slab tests of a node and the intersection of a record are ~220 and ~110
-            // VALU instructions that every lane of the wave sits through, so a turn runs only the kind the majority of
-            // the busy lanes wants next; the others keep their request for a later turn.
-            const bool wantsRecord = w.triMask != 0u;
-            bool go = true;
-            if (st.leaf_batch != 1u) {
-                const uint32_t nRec = (uint32_t)__popcll(__ballot(wantsRecord)), nNode = (uint32_t)__popcll(__ballot(!wantsRecord));
-                go = (nRec*st.leaf_batch >= nNode*2u) == wantsRecord;
+        if constexpr (!INST) {
+            // What the lane looks at this turn: its next record, its next node, or -- when that record is the last one of the node
+            // visited before -- BOTH: the node to visit next does not depend on the record's outcome (the group's order is fixed),
+            // only its slab tests do, and they run after the record test; so the walk is the one wideNext defines, a record-bearing
+            // node just costs one turn less.  (leaf_batch = 9 switches the pairing off.)
+            uint32_t recIdx = 0, nodeIdx = 0;
+            bool hasRec = false, hasNode = false, finished = false;
+            if (busy) {
+                uint32_t idx = 0;
+                const int what = wideNext<false>(w, wr.octInv, stack, stride, idx);
+                if (what == 1) {
+                    hasRec = true; recIdx = idx;
+                    if (w.triMask == 0u && st.leaf_batch != 9u) {
+                        const int next = wideNext<false>(w, wr.octInv, stack, stride, idx);   // a node, or the end of the walk
+                        if (next == 2) { hasNode = true; nodeIdx = idx; } else finished = true;
+                    }
+                } else if (what == 2) { hasNode = true; nodeIdx = idx; }
+                else finished = true;
             }
-            if (go) {
-                what = wideNext<INST>(w, wr.octInv, stack, stride, idx);
-                if (what == 0) {
-                    // finished: publish the hit and bin the path by shading class
-                    slotF4(st, A_HIT, slot) = hit;
-                    if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
-                    int ri = __float_as_int(hit.w);
-                    int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
-                    queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
-                    busy = false;
-                }
+            float4 r0, r1, r2, q0, q1, q2, q3, q4;
+            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
+            if (hasNode) { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+            if (hasRec) {
+                if (COUNT) prims++;
+                uint32_t meta;
+                (void)testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta);
             }
-        }
-        if (INST && what == 3) {
-            // the master's subtree is done: back to the world-space ray (distances along it did not change)
-            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
-            ray.o = xyz(ro); ray.d = xyz(rd);
-            wr = wideRaySetup(ray);
-            w.curInst = -1;
-        } else if (what != 0) {
-            // one address per lane: a node or a record, both behind s.wide
-            const uint32_t off = what != 1 ? idx*s.wide_stride : s.recs_offset + idx*48u;
-            const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
-            float4 q0 = p[0], q1 = p[1], q2 = p[2];
-            if (what == 2) {
-                float4 q3 = p[3], q4 = p[4];
+            if (hasNode) {
                 if (COUNT) nodes++;
                 wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
-            } else if (INST && what == 4) {
-                wideResumeRecords(w, idx, q1);
-            } else {
-                if (COUNT) prims++;
-                if (INST && TGHIP_REC_KIND(__float_as_uint(q0.w)) == TGHIP_REC_INSTANCE) {
-                    wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
-                } else {
-                    uint32_t meta;
-                    if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta))
-                        hitInst = w.curInst;
+            }
+            if (finished) {
+                // publish the hit and bin the path by shading class
+                slotF4(st, A_HIT, slot) = hit;
+                int ri = __float_as_int(hit.w);
+                int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
+                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
+                busy = false;
+            }
+        } else {
+            uint32_t idx = 0;
+            int what = 0;
+            if (busy) {
+                // Phase vote (st.leaf_batch != 1): the slab tests of a node and the intersection of a record are ~220 and ~110
+                // VALU instructions that every lane of the wave sits through, so a turn runs only the kind the majority of
+                // the busy lanes wants next; the others keep their request for a later turn.
+                const bool wantsRecord = w.triMask != 0u;
+                bool go = true;
+                if (st.leaf_batch != 1u) {
+                    const uint32_t nRec = (uint32_t)__popcll(__ballot(wantsRecord)), nNode = (uint32_t)__popcll(__ballot(!wantsRecord));
+                    go = (nRec*st.leaf_batch >= nNode*2u) == wantsRecord;
+                }
+                if (go) {
+                    what = wideNext<INST>(w, wr.octInv, stack, stride, idx);
+                    if (what == 0) {
+                        // finished: publish the hit and bin the path by shading class
+                        slotF4(st, A_HIT, slot) = hit;
+                        if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
+                        int ri = __float_as_int(hit.w);
+                        int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
+                        queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
+                        busy = false;
+                    }
                 }
             }
-        }
+            if (INST && what == 3) {
+                // the master's subtree is done: back to the world-space ray (distances along it did not change)
+                float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
+                ray.o = xyz(ro); ray.d = xyz(rd);
+                wr = wideRaySetup(ray);
+                w.curInst = -1;
+            } else if (what != 0) {
+                // one address per lane: a node or a record, both behind s.wide
+                const uint32_t off = what != 1 ? idx*s.wide_stride : s.recs_offset + idx*48u;
+                const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
+                float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                if (what == 2) {
+                    float4 q3 = p[3], q4 = p[4];
+                    if (COUNT) nodes++;
+                    wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+                } else if (INST && what == 4) {
+                    wideResumeRecords(w, idx, q1);
+                } else {
+                    if (COUNT) prims++;
+                    if (INST && TGHIP_REC_KIND(__float_as_uint(q0.w)) == TGHIP_REC_INSTANCE) {
+                        wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
+                    } else {
+                        uint32_t meta;
+                        if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta))
+                            hitInst = w.curInst;
+                    }
+                }
+            }
+            }
     }
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
@@ -638,7 +679,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     BlockCtl &ctl = st.ctl[blockIdx.x];
     const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS;   // cls 2: the escaped paths
     const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : -1;
-    const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? (1u << Q_SHADE1) : 0u);
+    const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? (1u << Q_SHADE1) : 0u) | (FUSE == 0 ? (1u << Q_FIN) : 0u);
     queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2);
     const DeviceScene s = stageSceneTables(sg, ldsTables);
     const uint32_t first = blockIdx.x*st.slots_per_block;
@@ -1124,6 +1165,10 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                 slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
             } else {
                 finished = true;
+                if (FUSE == 0) {                 // k_finish finalises the sample and regenerates the slot (below)
+                    slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
+                    slotF4(st, A_SH_P, slot).w = __uint_as_float(newFlags);
+                }
             }
             if (survives)
                 slotF4(st, A_THR, slot) = mk4(throughput, __uint_as_float(newFlags));
@@ -1136,13 +1181,20 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             queuePush(hasShadow, local, L, Q_SHADOW);
         }
         PROF(6);
-        bool regenerated = nextPath<true, (M & FEAT_QMC) != 0>(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
+        // Wavefront launches (FUSE == 0) leave finalising a finished sample and starting the slot's next camera path to k_finish, the
+        // last launch of the iteration, which does so for the paths that ended at their shadow rays anyway: nextPath's camera, filter
+        // and work-item code stays out of the shading variants' register budget, and in k_finish every lane regenerates instead of
+        // the few of a shading wave whose path happened to end.  The fused flat-list launches regenerate in place.
+        bool regenerated = false;
+        if constexpr (FUSE != 0)
+            regenerated = nextPath<true, (M & FEAT_QMC) != 0>(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
         PROF(7);
         if (DIRECT) {
             if (finished && !regenerated) idle |= 1u << turn;   // the work items ran out: nothing left for this slot
         } else {
             queuePush(survives, local, L, Q_EXT);
-            queuePush(regenerated, local, L, Q_EXTP);
+            if (FUSE != 0) queuePush(regenerated, local, L, Q_EXTP);
+            else           queuePush(finished, local, L, Q_FIN);
         }
         PROF(8);
     }
@@ -1597,53 +1649,95 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState s
         }
         if (busyMask == 0ull)
             break;
-        bool go = busy;
-        if (busy && st.leaf_batch != 1u) {           // phase vote, as in k_trace_closest_wide
-            const bool wantsRecord = w.triMask != 0u;
-            const uint32_t nRec = (uint32_t)__popcll(__ballot(wantsRecord)), nNode = (uint32_t)__popcll(__ballot(!wantsRecord));
-            go = (nRec*st.leaf_batch >= nNode*2u) == wantsRecord;
-        }
-        if (go) {
-            uint32_t idx = 0;
-            const int what = wideNext<INST>(w, wr.octInv, stack, stride, idx);
-            bool rayDone = false;
-            if (what == 0) {
-                result = result + contrib;       // nothing in the way: transmittance 1
-                rayDone = true;
-            } else if (INST && what == 3) {
-                ray.o = so; ray.d = xyz(r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot));   // back to world space
-                wr = wideRaySetup(ray);
-                w.curInst = -1;
-            } else {
-                const uint32_t off = what != 1 ? idx*s.wide_stride : s.recs_offset + idx*48u;
-                const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
-                float4 q0 = p[0], q1 = p[1], q2 = p[2];
-                if (what == 2) {
-                    float4 q3 = p[3], q4 = p[4];
+        if constexpr (!INST) {
+            // a record that is the last one of its node is fetched together with the node the walk visits next (k_trace_closest_wide)
+            if (busy) {
+                uint32_t recIdx = 0, nodeIdx = 0, idx = 0;
+                bool hasRec = false, hasNode = false, walkOver = false;
+                const int what = wideNext<false>(w, wr.octInv, stack, stride, idx);
+                if (what == 1) {
+                    hasRec = true; recIdx = idx;
+                    if (w.triMask == 0u && st.leaf_batch != 9u) {
+                        const int next = wideNext<false>(w, wr.octInv, stack, stride, idx);
+                        if (next == 2) { hasNode = true; nodeIdx = idx; } else walkOver = true;
+                    }
+                } else if (what == 2) { hasNode = true; nodeIdx = idx; }
+                else walkOver = true;
+                float4 r0, r1, r2, q0, q1, q2, q3, q4;
+                if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
+                if (hasNode) { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+                bool rayDone = false;
+                if (hasRec) {
+                    if (COUNT) prims++;
+                    float tmax = ray.tmax;
+                    float4 hit;
+                    uint32_t meta;
+                    if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                        rayDone = true;          // occluded: the node fetched alongside is not visited
+                }
+                if (!rayDone && hasNode) {
                     if (COUNT) nodes++;
                     wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, ray.tmax);
-                } else if (INST && what == 4) {
-                    wideResumeRecords(w, idx, q1);
-                } else {
-                    if (COUNT) prims++;
-                    if (INST && TGHIP_REC_KIND(__float_as_uint(q0.w)) == TGHIP_REC_INSTANCE) {
-                        wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
-                    } else {
-                        float tmax = ray.tmax;
-                        float4 hit;
-                        uint32_t meta;
-                        // geometry reached through an instance belongs to the `instances` primitive, never the light (traverseOccludedInst)
-                        if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta) && ((INST && w.curInst >= 0) || (int)TGHIP_REC_OBJECT(meta) != endCap))
-                            rayDone = true;      // occluded
-                    }
+                }
+                if (!rayDone && walkOver) {
+                    result = result + contrib;   // nothing in the way: transmittance 1
+                    rayDone = true;
+                }
+                if (rayDone) {
+                    r++;
+                    if (!setupRay())
+                        finishSlot();
                 }
             }
-            if (rayDone) {
-                r++;
-                if (!setupRay())
-                    finishSlot();
+        } else {
+            bool go = busy;
+            if (busy && st.leaf_batch != 1u) {           // phase vote, as in k_trace_closest_wide
+                const bool wantsRecord = w.triMask != 0u;
+                const uint32_t nRec = (uint32_t)__popcll(__ballot(wantsRecord)), nNode = (uint32_t)__popcll(__ballot(!wantsRecord));
+                go = (nRec*st.leaf_batch >= nNode*2u) == wantsRecord;
             }
-        }
+            if (go) {
+                uint32_t idx = 0;
+                const int what = wideNext<INST>(w, wr.octInv, stack, stride, idx);
+                bool rayDone = false;
+                if (what == 0) {
+                    result = result + contrib;       // nothing in the way: transmittance 1
+                    rayDone = true;
+                } else if (INST && what == 3) {
+                    ray.o = so; ray.d = xyz(r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot));   // back to world space
+                    wr = wideRaySetup(ray);
+                    w.curInst = -1;
+                } else {
+                    const uint32_t off = what != 1 ? idx*s.wide_stride : s.recs_offset + idx*48u;
+                    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
+                    float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                    if (what == 2) {
+                        float4 q3 = p[3], q4 = p[4];
+                        if (COUNT) nodes++;
+                        wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, ray.tmax);
+                    } else if (INST && what == 4) {
+                        wideResumeRecords(w, idx, q1);
+                    } else {
+                        if (COUNT) prims++;
+                        if (INST && TGHIP_REC_KIND(__float_as_uint(q0.w)) == TGHIP_REC_INSTANCE) {
+                            wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
+                        } else {
+                            float tmax = ray.tmax;
+                            float4 hit;
+                            uint32_t meta;
+                            // geometry reached through an instance belongs to the `instances` primitive, never the light (traverseOccludedInst)
+                            if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta) && ((INST && w.curInst >= 0) || (int)TGHIP_REC_OBJECT(meta) != endCap))
+                                rayDone = true;      // occluded
+                        }
+                    }
+                }
+                if (rayDone) {
+                    r++;
+                    if (!setupRay())
+                        finishSlot();
+                }
+            }
+            }
     }
     waveAddStat(&L.shadow_rays, rays);
     waveAddStat(&L.shadow_slots, slots);

@@ -56,6 +56,11 @@ struct DeviceBuffers {
 struct tghip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // second stream of the two-half wavefront loop ("streams" option)
+    hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the half's stream)
+    hipEvent_t evHalf = nullptr, evMain = nullptr;
+    int streamsOpt = 0;                   // "streams": 1 / 2, 0 = the measured default (two for single-level BVH scenes: +5 % on materialtest and
+                                          // mesh1m; instanced scenes lose 2.5 % with two)
     hipDeviceProp_t prop;
     std::string error = "no error";
 
@@ -530,6 +535,10 @@ tghip_ctx *tghip_create(int device_ordinal)
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_ordinal);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evHalf, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evMain, hipEventDisableTiming);
+    ctx->launchStream = ctx->stream;
     if (e == hipSuccess) e = hipEventCreate(&ctx->evA);
     if (e == hipSuccess) e = hipEventCreate(&ctx->evB);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->hostLive), 2*sizeof(uint32_t), hipHostMallocDefault);
@@ -570,6 +579,9 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
+    if (ctx->evHalf) (void)hipEventDestroy(ctx->evHalf);
+    if (ctx->evMain) (void)hipEventDestroy(ctx->evMain);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -595,6 +607,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
+    else if (k == "streams") ctx->streamsOpt = value >= 2 ? 2 : value == 1 ? 1 : 0;
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -925,7 +938,7 @@ static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, co
 {
     constexpr uint32_t B = M & ~FEAT_QMC;
     hipLaunchKernelGGL((k_shade<M, (B == MASK_SIMPLE ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
-                       dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : cls == 1 ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->stream, ctx->scene, st, pp, cls);
+                       dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : cls == 1 ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->launchStream, ctx->scene, st, pp, cls);
 }
 // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
 template<uint32_t M, int FUSE = 0>
@@ -944,7 +957,7 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
     const bool closestWalk = ctx->haveForward || ctx->haveMeshLight;   // shadow rays are closest-hit walks, not any-hit queries
     const bool wideShadow = wideShadowRays(ctx) && !closestWalk && !ctx->auxPass;
     if (ctx->haveInstances && !wideShadow) {
-#define SHADOW_INST(FWD, I) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, false, I>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
+#define SHADOW_INST(FWD, I) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, false, I>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->launchStream, ctx->scene, st, pp, iterTag)
         if (closestWalk) { if (ctx->haveSolids) SHADOW_INST(true, 1); else SHADOW_INST(true, 2); }
         else             { if (ctx->haveSolids) SHADOW_INST(false, 1); else SHADOW_INST(false, 2); }
 #undef SHADOW_INST
@@ -952,12 +965,12 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
     }
     if (wideShadow) {
         const size_t lds = wideLdsBytes(ctx, ctx->thrShadow);
-#define SHADOW_WIDE(S, I) hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, S, I>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->stream, ctx->scene, st, pp, iterTag)
+#define SHADOW_WIDE(S, I) hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, S, I>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
         if (ctx->haveInstances) {
             // (always the counting variant: hipcc 7.2 miscompiles k_trace_shadow_wide<false, ., true> -- occluders inside instances
             // go missing, tools/dbg/inst_debug3.py -- while the variant that also counts its node and record visits is correct;
             // foldCounters drops the counts when nobody asked for them)
-#define SHADOW_WIDE_INST(S) hipLaunchKernelGGL((k_trace_shadow_wide<true, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->stream, ctx->scene, st, pp, iterTag)
+#define SHADOW_WIDE_INST(S) hipLaunchKernelGGL((k_trace_shadow_wide<true, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
             if (ctx->haveSolids) SHADOW_WIDE_INST(true); else SHADOW_WIDE_INST(false);
 #undef SHADOW_WIDE_INST
         }
@@ -966,13 +979,13 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
         return true;
     }
     if (!flat && !closestWalk && ctx->dynamicFetch && !ctx->auxPass) {   // (the dynamic-fetch kernel does not report transmittances)
-        if (ctx->haveSolids) hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, true>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
+        if (ctx->haveSolids) hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, true>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->launchStream,
                                                 ctx->scene, st, pp, iterTag);
-        else                 hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, false>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->stream,
+        else                 hipLaunchKernelGGL((k_trace_shadow_dyn<COUNT, false>), dim3(grid), dim3(ctx->thrShadow), dynLdsBytes(ctx, ctx->thrShadow), ctx->launchStream,
                                                 ctx->scene, st, pp, iterTag);
         return true;
     }
-#define SHADOW_LAUNCH(FWD, FLAT) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, FLAT>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->stream, ctx->scene, st, pp, iterTag)
+#define SHADOW_LAUNCH(FWD, FLAT) hipLaunchKernelGGL((k_trace_shadow<COUNT, FWD, FLAT>), dim3(grid), dim3(ctx->thrShadow), ldsBytes, ctx->launchStream, ctx->scene, st, pp, iterTag)
     if (closestWalk) { if (flat) SHADOW_LAUNCH(true, true); else SHADOW_LAUNCH(true, false); }
     else                  { if (flat) SHADOW_LAUNCH(false, true); else SHADOW_LAUNCH(false, false); }
 #undef SHADOW_LAUNCH
@@ -1010,19 +1023,106 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
         }
     }
     size_t evUsed = 0;
-    auto tic = [&]() { if (timing) (void)hipEventRecord(ctx->evPool[evUsed++], ctx->stream); };
+    auto ticMain = [&]() { if (timing) (void)hipEventRecord(ctx->evPool[evUsed++], ctx->stream); };
+    auto tic = ticMain;
 
+    // "streams" = 2: the workgroups (and with them the slots, queues and work items) are split into two halves that run the
+    // same wavefront loop on two streams, so that the drain tail of one half's kernel overlaps the other half's kernels
+    const bool halves = (ctx->streamsOpt == 2 || (ctx->streamsOpt == 0 && !ctx->haveInstances)) && !fused && !flat && grid >= 4 && grid % 2 == 0 && !st.records && !pp.rec_sorted &&
+                        pp.total_items >= 4u*PT_ITEM_GROUP;
+    PathState stHalf[2] = {st, st};
+    PassParams ppHalf[2] = {pp, pp};
+    if (halves) {
+        const uint32_t off = uint32_t(grid/2);
+        stHalf[1].pool = st.pool + size_t(off)*st.slots_per_block*16u;
+        stHalf[1].bm = st.bm + size_t(off)*(st.slots_per_block >> 5);
+        stHalf[1].ctl = st.ctl + off;
+        stHalf[1].stats = st.stats + off;
+        stHalf[0].num_slots = stHalf[1].num_slots = st.num_slots/2;
+        const uint32_t firstHalf = (pp.total_items/2 + PT_ITEM_GROUP - 1)/PT_ITEM_GROUP*PT_ITEM_GROUP;
+        ppHalf[0].total_items = firstHalf;
+        ppHalf[1].item_begin = firstHalf;
+        ppHalf[1].total_items = pp.total_items - firstHalf;
+    }
     HIP_TRY(ctx, hipMemsetAsync(st.partial, 0, size_t(pp.total_items)*sizeof(float4), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(st.live, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(k_start, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp);
+    if (halves) {
+        hipLaunchKernelGGL(k_start, dim3(grid/2), dim3(256), 0, ctx->stream, s, stHalf[0], ppHalf[0]);
+        HIP_TRY(ctx, hipEventRecord(ctx->evMain, ctx->stream));            // (the memsets above come first for stream2 as well)
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evMain, 0));
+        hipLaunchKernelGGL(k_start, dim3(grid/2), dim3(256), 0, ctx->stream2, s, stHalf[1], ppHalf[1]);
+    } else {
+        hipLaunchKernelGGL(k_start, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp);
+    }
     uint32_t iterTag = 1;                        // k_start publishes tag 1 when it queued anything
     bool first = true;
     int roundIters = ctx->checkInterval;         // launches of the wavefront loop between two host checks
+        // the launches of one wavefront iteration over the workgroups [0, grid) of `st` (the whole pool, or one half of it)
+        auto launchIteration = [&](const PathState &st, const PassParams &pp, int grid, uint32_t iterTag, bool timed) {
+            auto tic = [&]() { if (timed) ticMain(); };
+            tic();
+            if (flat) {
+                if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
+                else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
+            } else if (ctx->haveInstances && !wideClosest(ctx)) {
+#define CLOSEST_INST(C, I) hipLaunchKernelGGL((k_trace_closest<C, false, I>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st)
+                if (ctx->haveSolids) { if (count) CLOSEST_INST(true, 1); else CLOSEST_INST(false, 1); }
+                else                 { if (count) CLOSEST_INST(true, 2); else CLOSEST_INST(false, 2); }
+#undef CLOSEST_INST
+            } else if (wideClosest(ctx)) {
+                const size_t ldsWide = wideLdsBytes(ctx, ctx->thrClosest);
+#define CLOSEST_WIDE(C, S, I) hipLaunchKernelGGL((k_trace_closest_wide<C, S, I>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->launchStream, s, st)
+                if (ctx->haveInstances) {
+                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, true); else CLOSEST_WIDE(false, true, true); }
+                    else                 { if (count) CLOSEST_WIDE(true, false, true); else CLOSEST_WIDE(false, false, true); }
+                } else {
+                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, false); else CLOSEST_WIDE(false, true, false); }
+                    else                 { if (count) CLOSEST_WIDE(true, false, false); else CLOSEST_WIDE(false, false, false); }
+                }
+#undef CLOSEST_WIDE
+            } else {
+                if (ctx->dynamicFetch) {
+                    const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
+#define CLOSEST_DYN(C, S) hipLaunchKernelGGL((k_trace_closest_dyn<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->launchStream, s, st)
+                    if (ctx->haveSolids) { if (count) CLOSEST_DYN(true, true); else CLOSEST_DYN(false, true); }
+                    else                 { if (count) CLOSEST_DYN(true, false); else CLOSEST_DYN(false, false); }
+#undef CLOSEST_DYN
+                } else {
+                    if (count) hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
+                    else       hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
+                }
+            }
+            tic(); tic();
+            if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) {   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER, for both classes
+                launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 2);
+                launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 0);
+                if (ctx->haveComplex) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 1);
+            }
+            // class 2 = the escaped paths (Q_MISS), with the class-0 variant: its surface code never runs there, so the launch is short
+            else if (ctx->haveMeshLight || ctx->haveInstances) { launchShade<MASK_FULL>(ctx, grid, st, pp, 2); launchShade<MASK_FULL>(ctx, grid, st, pp, 0); }   // the only variants with mesh-emitter sampling / instance transforms
+            else if (ctx->leanScene) { launchShade<MASK_LEAN>(ctx, grid, st, pp, 2); launchShade<MASK_LEAN>(ctx, grid, st, pp, 0); }
+            else                     { launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 2); launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0); }
+            if (ctx->haveComplex && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder) {
+                if (ctx->haveMeshLight || ctx->haveInstances)   launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
+                else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
+                else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
+                else                                            launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
+            }
+            tic(); tic();
+            const bool finish = count ? launchShadow<true>(ctx, grid, st, pp, iterTag) : launchShadow<false>(ctx, grid, st, pp, iterTag);
+            tic();
+            (void)finish;                        // (always: the shading launches leave their finished paths to k_finish as well)
+            hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, ctx->launchStream, s, st, pp, iterTag);
+        };
     for (;;) {
         evUsed = 0;
         {
             // an abort request that arrived since the last check (or before the pass's first launch): make sure the device
             // word is set -- in stream order, so the launches below see it and drain their slots
+            if (halves) {                        // the main stream waits for the other half before it reads the flag
+                HIP_TRY(ctx, hipEventRecord(ctx->evHalf, ctx->stream2));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->evHalf, 0));
+            }
             if (ctx->abortRequested.load(std::memory_order_acquire))
                 HIP_TRY(ctx, hipMemsetAsync(ctx->abortFlagDev, 0xFF, sizeof(uint32_t), ctx->stream));
             HIP_TRY(ctx, hipMemcpyAsync(ctx->hostLive, st.live, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1033,11 +1133,14 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 for (size_t k = 0; k < pairs; ++k) {
                     float ms = 0.0f;
                     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[2*k], ctx->evPool[2*k + 1]));
-                    *acc[k % 3] += ms;
+                    *acc[k % 3] += halves ? 2.0*ms : ms;
                 }
-                ctx->counters.launches_trace_closest += roundIters;
-                ctx->counters.launches_trace_shadow += roundIters;
-                ctx->counters.launches_shade += roundIters;
+                // (two halves: the events bracket the launches of half 0; the other half's launches, as long on average, are
+                // counted with them so that bytes per launch and time per launch refer to the same half-pool launches)
+                const int perIter = halves ? 2 : 1;
+                ctx->counters.launches_trace_closest += roundIters*perIter;
+                ctx->counters.launches_trace_shadow += roundIters*perIter;
+                ctx->counters.launches_shade += roundIters*perIter;
             }
             if (ctx->hostLive[0] != iterTag)
                 break;                           // the last iteration left every extension queue empty
@@ -1066,59 +1169,14 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 ctx->counters.iterations++;
                 continue;
             }
-            tic();
-            if (flat) {
-                if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
-                else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
-            } else if (ctx->haveInstances && !wideClosest(ctx)) {
-#define CLOSEST_INST(C, I) hipLaunchKernelGGL((k_trace_closest<C, false, I>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st)
-                if (ctx->haveSolids) { if (count) CLOSEST_INST(true, 1); else CLOSEST_INST(false, 1); }
-                else                 { if (count) CLOSEST_INST(true, 2); else CLOSEST_INST(false, 2); }
-#undef CLOSEST_INST
-            } else if (wideClosest(ctx)) {
-                const size_t ldsWide = wideLdsBytes(ctx, ctx->thrClosest);
-#define CLOSEST_WIDE(C, S, I) hipLaunchKernelGGL((k_trace_closest_wide<C, S, I>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->stream, s, st)
-                if (ctx->haveInstances) {
-                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, true); else CLOSEST_WIDE(false, true, true); }
-                    else                 { if (count) CLOSEST_WIDE(true, false, true); else CLOSEST_WIDE(false, false, true); }
-                } else {
-                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, false); else CLOSEST_WIDE(false, true, false); }
-                    else                 { if (count) CLOSEST_WIDE(true, false, false); else CLOSEST_WIDE(false, false, false); }
-                }
-#undef CLOSEST_WIDE
+            if (halves) {
+                // two halves of the pool on two streams: the drain tail of one half's kernel overlaps the other half's kernels
+                ctx->launchStream = ctx->stream;  launchIteration(stHalf[0], ppHalf[0], grid/2, iterTag, true);
+                ctx->launchStream = ctx->stream2; launchIteration(stHalf[1], ppHalf[1], grid/2, iterTag, false);
+                ctx->launchStream = ctx->stream;
             } else {
-                if (ctx->dynamicFetch) {
-                    const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
-#define CLOSEST_DYN(C, S) hipLaunchKernelGGL((k_trace_closest_dyn<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->stream, s, st)
-                    if (ctx->haveSolids) { if (count) CLOSEST_DYN(true, true); else CLOSEST_DYN(false, true); }
-                    else                 { if (count) CLOSEST_DYN(true, false); else CLOSEST_DYN(false, false); }
-#undef CLOSEST_DYN
-                } else {
-                    if (count) hipLaunchKernelGGL((k_trace_closest<true, false>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
-                    else       hipLaunchKernelGGL((k_trace_closest<false, false>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->stream, s, st);
-                }
+                launchIteration(st, pp, grid, iterTag, true);
             }
-            tic(); tic();
-            if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) {   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER, for both classes
-                launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 2);
-                launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 0);
-                if (ctx->haveComplex) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 1);
-            }
-            // class 2 = the escaped paths (Q_MISS), with the class-0 variant: its surface code never runs there, so the launch is short
-            else if (ctx->haveMeshLight || ctx->haveInstances) { launchShade<MASK_FULL>(ctx, grid, st, pp, 2); launchShade<MASK_FULL>(ctx, grid, st, pp, 0); }   // the only variants with mesh-emitter sampling / instance transforms
-            else if (ctx->leanScene) { launchShade<MASK_LEAN>(ctx, grid, st, pp, 2); launchShade<MASK_LEAN>(ctx, grid, st, pp, 0); }
-            else                     { launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 2); launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0); }
-            if (ctx->haveComplex && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder) {
-                if (ctx->haveMeshLight || ctx->haveInstances)   launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
-                else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
-                else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
-                else                                            launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
-            }
-            tic(); tic();
-            const bool finish = count ? launchShadow<true>(ctx, grid, st, pp, iterTag) : launchShadow<false>(ctx, grid, st, pp, iterTag);
-            tic();
-            if (finish)
-                hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp, iterTag);
             ctx->counters.iterations++;
         }
     }
