@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--no-sobol", action="store_true")
     ap.add_argument("--no-adaptive", action="store_true")
     ap.add_argument("--repeats", type=int, default=3)
+    ap.add_argument("--opt", action="append", default=[], help="shim option key=value (tghip_set_option)")
     a = ap.parse_args()
     tmp = tempfile.mkdtemp(prefix="tg_shipped_")
     mk = {"materialtest": scenes.materialtest, "cornell": scenes.cornell}[a.scene]
@@ -36,6 +37,9 @@ def main():
     best = None
     for _ in range(a.repeats):
         r = tg.Renderer(path)
+        for kv in a.opt:
+            k, v = kv.split("=")
+            r.set_option(k, int(v))
         t0 = time.perf_counter()
         secs = r.render()
         wall = time.perf_counter() - t0

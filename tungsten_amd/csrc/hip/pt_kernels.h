@@ -52,7 +52,9 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 #define SHADOW_TAG_MEDIA(light, medium, bounce) ((uint32_t)(light) | ((uint32_t)((medium) + 1) << 16) | ((uint32_t)(bounce) << 24))
 
 #define PT_NUM_CLASSES 2          // shading classes: 0 = diffuse/null/miss, 1 = everything else
+#ifndef PT_ITEM_GROUP
 #define PT_ITEM_GROUP  64u        // consecutive work items handed to one workgroup (a wave's worth of pixels)
+#endif
 #define PT_MAX_SLOTS_PER_BLOCK 2048u
 #define PT_MAX_WORDS   (PT_MAX_SLOTS_PER_BLOCK/32u)
 
@@ -76,6 +78,9 @@ struct BlockCtl {                 // one per persistent workgroup; only that wor
 struct BlockStats {               // traversal statistics (count_traversal option), one per workgroup
     unsigned long long nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow;
     unsigned long long prof[16];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds, tools/gpu_profile_sections.sh)
+#ifdef PT_PROFILE
+    unsigned long long profCls[3][16];   // the same per shading class of the launch (0 / 1 / 2 = escaped paths)
+#endif
 };
 
 // Per-slot state: A_COUNT arrays of 16-byte elements in ONE allocation, array a at byte offset a*stride (stride =

@@ -24,7 +24,7 @@
 #ifdef PT_PROFILE
 #define PROF_DECL unsigned long long profT = clock64(), profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PROF(n) do { unsigned long long t_ = clock64(); profAcc[n] += t_ - profT; profT = t_; } while (0)
-#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 16; ++k_) if (k_ != 10 && k_ != 11) atomicAdd(&(stats).prof[k_], profAcc[k_]); } while (0)
+#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 16; ++k_) if (k_ != 10 && k_ != 11) { atomicAdd(&(stats).prof[k_], profAcc[k_]); atomicAdd(&(stats).profCls[cls][k_], profAcc[k_]); } } while (0)
 #else
 #define PROF_DECL
 #define PROF(n)

@@ -56,11 +56,11 @@ struct DeviceBuffers {
 struct tghip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;        // second stream of the two-half wavefront loop ("streams" option)
+    hipStream_t partStream[3] = {nullptr, nullptr, nullptr};   // streams of parts 1..3 of the split wavefront loop ("streams" option)
     hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the half's stream)
-    hipEvent_t evHalf = nullptr, evMain = nullptr;
-    int streamsOpt = 0;                   // "streams": 1 / 2, 0 = the measured default (two for single-level BVH scenes: +5 % on materialtest and
-                                          // mesh1m; instanced scenes lose 2.5 % with two)
+    hipEvent_t evPart[3] = {nullptr, nullptr, nullptr}, evMain = nullptr;
+    int streamsOpt = 0;                   // "streams": 1 .. 4 parts of the pool on as many streams, 0 = the measured default (four for single-level
+                                          // BVH scenes; instanced scenes lose 2.5 % with two)
     hipDeviceProp_t prop;
     std::string error = "no error";
 
@@ -401,6 +401,27 @@ static int foldCounters(tghip_ctx *ctx)
         for (size_t b = 0; b < g; ++b) for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) tot[k] += ctx->hostStats[b].prof[k];
         unsigned long long sum = 0; for (int k = 0; k < 16; ++k) sum += tot[k];
         if (sum) { std::fprintf(stderr, "[PT_PROFILE] k_shade wave-cycles by section:"); for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) std::fprintf(stderr, " s%d=%.1f%%", k, 100.0*double(tot[k])/double(sum)); std::fprintf(stderr, " total=%llu\n", sum); }
+        // per shading class, and how evenly the class's work is spread: per workgroup and per set of workgroups b, b + CUs, ... (one CU's, if
+        // the dispatcher deals workgroups to the CUs in order)
+        const size_t cus = size_t(ctx->prop.multiProcessorCount);
+        for (int c = 0; c < 3; ++c) {
+            unsigned long long ct[16] = {0}, csum = 0;
+            std::vector<double> perBlock(g, 0.0), perCu(std::min(cus, g), 0.0);
+            for (size_t b = 0; b < g; ++b) for (int k = 0; k < 16; ++k) { ct[k] += ctx->hostStats[b].profCls[c][k]; perBlock[b] += double(ctx->hostStats[b].profCls[c][k]); }
+            for (size_t b = 0; b < g; ++b) perCu[b % perCu.size()] += perBlock[b];
+            for (int k = 0; k < 16; ++k) csum += ct[k];
+            if (!csum) continue;
+            std::fprintf(stderr, "[PT_PROFILE] class %d:", c);
+            for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) std::fprintf(stderr, " s%d=%.1f%%", k, 100.0*double(ct[k])/double(csum));
+            auto spread = [](std::vector<double> v, const char *what) {
+                std::sort(v.begin(), v.end());
+                double mean = 0.0; for (double x : v) mean += x; mean /= double(v.size());
+                std::fprintf(stderr, " | %s min %.2f p50 %.2f p95 %.2f max %.2f of the mean", what, v.front()/mean, v[v.size()/2]/mean, v[v.size()*95/100]/mean, v.back()/mean);
+            };
+            spread(perBlock, "per workgroup");
+            spread(perCu, "per CU");
+            std::fprintf(stderr, " total=%llu\n", csum);
+        }
     }
 #endif
     // no pass is running here (calls on one handle are serialised), so the records can be written back whole
@@ -462,7 +483,12 @@ static void chooseThreads(tghip_ctx *ctx)
     // Measured (profiles/README.md): BVH scenes are latency-bound and run best with every workgroup of every
     // kernel resident at once (4 per CU, workgroup size per kernel = that kernel's occupancy limit / 4); flat-list
     // scenes are streaming-bound and prefer 8 small workgroups per CU that the dispatcher load-balances.
-    ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : (flat ? 8 : 4);
+    // Single-level BVH scenes run the loop as two half-pools on two streams (runBatch), each kernel launched with HALF the grid: with 8
+    // workgroups per CU a kernel of one half and a kernel of the other share every CU, four workgroups each, and the issue-bound walk of the
+    // one fills the memory waits of the shading of the other (materialtest 1280x720x256: 608 -> 657 Msamples/s against 4 per CU; workgroup
+    // sizes below from the same sweep, profiles/README.md).  Instanced scenes keep one stream and 4 per CU (measured: 127 against 114-120).
+    const bool paired = !flat && !ctx->haveInstances && ctx->streamsOpt != 1 && wideClosest(ctx) && wideShadowRays(ctx);
+    ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : ((flat || paired) ? 8 : 4);
     if (flat && ctx->blocksPerCuOpt == 0) {
         ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
     } else {
@@ -499,6 +525,13 @@ static void chooseThreads(tghip_ctx *ctx)
     else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
     else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     if (ctx->haveMedia) ctx->thrShadeSimple = ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
+    if (paired && ctx->blocksPerCuOpt == 0) {
+        // (closest / shadow / shade simple / shade complex, Msamples/s: 256/256/128/128 657, 192/256/128/128 634, 128/256/128/128 623,
+        //  320/256/128/128 556, 256/320/128/128 549, 256/256/256/128 646, 256/256/128/64 623; 4 per CU with 192/256/192/128: 608)
+        ctx->thrClosest = 256;
+        if (!ctx->haveForward && !ctx->haveMeshLight) ctx->thrShadow = 256;
+        ctx->thrShadeSimple = ctx->thrShadeComplex = 128;
+    }
     }
     ctx->thrShadeAll = flat && ctx->blocksPerCuOpt == 0 ? 256 : pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     int *dst[4] = {&ctx->thrClosest, &ctx->thrShadow, &ctx->thrShadeSimple, &ctx->thrShadeComplex};
@@ -535,8 +568,10 @@ tghip_ctx *tghip_create(int device_ordinal)
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_ordinal);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evHalf, hipEventDisableTiming);
+    for (int k = 0; k < 3; ++k) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->partStream[k], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evPart[k], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evMain, hipEventDisableTiming);
     ctx->launchStream = ctx->stream;
     if (e == hipSuccess) e = hipEventCreate(&ctx->evA);
@@ -579,9 +614,9 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
-    if (ctx->evHalf) (void)hipEventDestroy(ctx->evHalf);
+    for (int k = 0; k < 3; ++k) if (ctx->evPart[k]) (void)hipEventDestroy(ctx->evPart[k]);
     if (ctx->evMain) (void)hipEventDestroy(ctx->evMain);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (int k = 0; k < 3; ++k) if (ctx->partStream[k]) (void)hipStreamDestroy(ctx->partStream[k]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -607,7 +642,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
-    else if (k == "streams") ctx->streamsOpt = value >= 2 ? 2 : value == 1 ? 1 : 0;
+    else if (k == "streams") { ctx->streamsOpt = int(std::min<long long>(std::max<long long>(value, 0), 4)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1026,31 +1061,41 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     auto ticMain = [&]() { if (timing) (void)hipEventRecord(ctx->evPool[evUsed++], ctx->stream); };
     auto tic = ticMain;
 
-    // "streams" = 2: the workgroups (and with them the slots, queues and work items) are split into two halves that run the
-    // same wavefront loop on two streams, so that the drain tail of one half's kernel overlaps the other half's kernels
-    const bool halves = (ctx->streamsOpt == 2 || (ctx->streamsOpt == 0 && !ctx->haveInstances)) && !fused && !flat && grid >= 4 && grid % 2 == 0 && !st.records && !pp.rec_sorted &&
-                        pp.total_items >= 4u*PT_ITEM_GROUP;
-    PathState stHalf[2] = {st, st};
-    PassParams ppHalf[2] = {pp, pp};
+    // "streams" = N > 1: the workgroups (and with them the slots, queues and work items) are split into N parts that run the same
+    // wavefront loop on N streams: kernels of different parts share the CUs (chooseThreads), and the drain tail of one part's kernel
+    // overlaps the other parts' kernels
+    // (materialtest 1280x720x256 / mesh1m 1920x1080x32 on one box: 2 parts 656 / 398 Msamples/s, 4 parts 666 / 412)
+    int parts = ctx->streamsOpt >= 2 ? ctx->streamsOpt : (ctx->streamsOpt == 0 && !ctx->haveInstances) ? 4 : 1;
+    if (fused || flat || st.records || grid < 2*parts || grid % parts != 0 || pp.total_items < uint32_t(2*parts)*PT_ITEM_GROUP)
+        parts = 1;
+    const bool halves = parts > 1;
+    PathState stHalf[4] = {st, st, st, st};
+    PassParams ppHalf[4] = {pp, pp, pp, pp};
+    hipStream_t streamOf[4] = {ctx->stream, ctx->partStream[0], ctx->partStream[1], ctx->partStream[2]};
     if (halves) {
-        const uint32_t off = uint32_t(grid/2);
-        stHalf[1].pool = st.pool + size_t(off)*st.slots_per_block*16u;
-        stHalf[1].bm = st.bm + size_t(off)*(st.slots_per_block >> 5);
-        stHalf[1].ctl = st.ctl + off;
-        stHalf[1].stats = st.stats + off;
-        stHalf[0].num_slots = stHalf[1].num_slots = st.num_slots/2;
-        const uint32_t firstHalf = (pp.total_items/2 + PT_ITEM_GROUP - 1)/PT_ITEM_GROUP*PT_ITEM_GROUP;
-        ppHalf[0].total_items = firstHalf;
-        ppHalf[1].item_begin = firstHalf;
-        ppHalf[1].total_items = pp.total_items - firstHalf;
+        const uint32_t groups = (pp.total_items + PT_ITEM_GROUP - 1)/PT_ITEM_GROUP;
+        uint32_t itemBegin = 0;
+        for (int k = 0; k < parts; ++k) {
+            const uint32_t off = uint32_t(grid/parts)*uint32_t(k);
+            stHalf[k].pool = st.pool + size_t(off)*st.slots_per_block*16u;
+            stHalf[k].bm = st.bm + size_t(off)*(st.slots_per_block >> 5);
+            stHalf[k].ctl = st.ctl + off;
+            stHalf[k].stats = st.stats + off;
+            stHalf[k].num_slots = st.num_slots/uint32_t(parts);
+            const uint32_t itemEnd = k + 1 == parts ? pp.total_items : std::min(pp.total_items, uint32_t((uint64_t(groups)*(k + 1) + parts - 1)/parts)*PT_ITEM_GROUP);
+            ppHalf[k].item_begin = pp.item_begin + itemBegin;
+            ppHalf[k].total_items = itemEnd - itemBegin;
+            itemBegin = itemEnd;
+        }
     }
     HIP_TRY(ctx, hipMemsetAsync(st.partial, 0, size_t(pp.total_items)*sizeof(float4), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(st.live, 0, sizeof(uint32_t), ctx->stream));
     if (halves) {
-        hipLaunchKernelGGL(k_start, dim3(grid/2), dim3(256), 0, ctx->stream, s, stHalf[0], ppHalf[0]);
-        HIP_TRY(ctx, hipEventRecord(ctx->evMain, ctx->stream));            // (the memsets above come first for stream2 as well)
-        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evMain, 0));
-        hipLaunchKernelGGL(k_start, dim3(grid/2), dim3(256), 0, ctx->stream2, s, stHalf[1], ppHalf[1]);
+        HIP_TRY(ctx, hipEventRecord(ctx->evMain, ctx->stream));            // (the memsets above come first for the other streams as well)
+        for (int k = 0; k < parts; ++k) {
+            if (k) HIP_TRY(ctx, hipStreamWaitEvent(streamOf[k], ctx->evMain, 0));
+            hipLaunchKernelGGL(k_start, dim3(grid/parts), dim3(256), 0, streamOf[k], s, stHalf[k], ppHalf[k]);
+        }
     } else {
         hipLaunchKernelGGL(k_start, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp);
     }
@@ -1119,9 +1164,9 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
         {
             // an abort request that arrived since the last check (or before the pass's first launch): make sure the device
             // word is set -- in stream order, so the launches below see it and drain their slots
-            if (halves) {                        // the main stream waits for the other half before it reads the flag
-                HIP_TRY(ctx, hipEventRecord(ctx->evHalf, ctx->stream2));
-                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->evHalf, 0));
+            for (int k = 1; k < parts; ++k) {   // the main stream waits for the other parts before it reads the flag
+                HIP_TRY(ctx, hipEventRecord(ctx->evPart[k - 1], streamOf[k]));
+                HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->evPart[k - 1], 0));
             }
             if (ctx->abortRequested.load(std::memory_order_acquire))
                 HIP_TRY(ctx, hipMemsetAsync(ctx->abortFlagDev, 0xFF, sizeof(uint32_t), ctx->stream));
@@ -1133,11 +1178,11 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 for (size_t k = 0; k < pairs; ++k) {
                     float ms = 0.0f;
                     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[2*k], ctx->evPool[2*k + 1]));
-                    *acc[k % 3] += halves ? 2.0*ms : ms;
+                    *acc[k % 3] += double(parts)*ms;
                 }
-                // (two halves: the events bracket the launches of half 0; the other half's launches, as long on average, are
+                // (split loop: the events bracket the launches of part 0; the other parts' launches, as long on average, are
                 // counted with them so that bytes per launch and time per launch refer to the same half-pool launches)
-                const int perIter = halves ? 2 : 1;
+                const int perIter = parts;
                 ctx->counters.launches_trace_closest += roundIters*perIter;
                 ctx->counters.launches_trace_shadow += roundIters*perIter;
                 ctx->counters.launches_shade += roundIters*perIter;
@@ -1170,9 +1215,10 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 continue;
             }
             if (halves) {
-                // two halves of the pool on two streams: the drain tail of one half's kernel overlaps the other half's kernels
-                ctx->launchStream = ctx->stream;  launchIteration(stHalf[0], ppHalf[0], grid/2, iterTag, true);
-                ctx->launchStream = ctx->stream2; launchIteration(stHalf[1], ppHalf[1], grid/2, iterTag, false);
+                for (int k = 0; k < parts; ++k) {
+                    ctx->launchStream = streamOf[k];
+                    launchIteration(stHalf[k], ppHalf[k], grid/parts, iterTag, k == 0);
+                }
                 ctx->launchStream = ctx->stream;
             } else {
                 launchIteration(st, pp, grid, iterTag, true);

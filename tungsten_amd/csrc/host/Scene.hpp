@@ -120,7 +120,7 @@ struct Primitive
     std::vector<Vec3f> instancePos;
     std::vector<QuaternionF> instanceRot;
     std::vector<uint8_t> instanceId;
-    std::vector<Box3f> instanceBounds;      // prepareForRender: world-space box of every instance (Instance.cpp:411-423)
+    std::vector<Box3f> instanceBounds;      // prepareForRender: world-space box of every instance (tightenInstanceBounds)
 
     // prepared (prepareForRender of the respective reference class)
     Vec3f base, edge0, edge1, normal; float invUvSq[2] = {0, 0};  // Quad.cpp:298-316
@@ -135,6 +135,7 @@ struct Primitive
     float powerToRadianceFactor() const;
     void loadResources(const std::string &sceneDir);
     void prepareForRender();
+    void tightenInstanceBounds();
 };
 
 // ---- camera ------------------------------------------------------------------------------
