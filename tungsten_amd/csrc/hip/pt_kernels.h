@@ -55,7 +55,9 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 #ifndef PT_ITEM_GROUP
 #define PT_ITEM_GROUP  64u        // consecutive work items handed to one workgroup (a wave's worth of pixels)
 #endif
-#define PT_MAX_SLOTS_PER_BLOCK 2048u
+#ifndef PT_MAX_SLOTS_PER_BLOCK
+#define PT_MAX_SLOTS_PER_BLOCK 4096u
+#endif
 #define PT_MAX_WORDS   (PT_MAX_SLOTS_PER_BLOCK/32u)
 
 // The four queues of a workgroup are BITMAPS over its slot range (one bit per slot), not index lists: a consumer
@@ -259,16 +261,22 @@ PT_DEV DeviceScene stageSceneTables(const DeviceScene &s, unsigned char *lds)
 }
 
 // Workgroup-local state staged in LDS for the duration of one kernel.
-struct BlockLds {
-    uint32_t bm[Q_COUNT][PT_MAX_WORDS];     // queue bitmaps being built / consumed
-    uint32_t prefix[PT_MAX_WORDS];
+template<uint32_t WORDS>
+struct BlockLdsT {
+    uint32_t bm[Q_COUNT][WORDS];            // queue bitmaps being built / consumed
+    uint32_t prefix[WORDS];
     uint32_t n;                                      // length of the consumed queue
     uint32_t cursor;
     uint32_t samples, closest_rays, shadow_rays, shadow_slots, nodes, prims;
 };
+typedef BlockLdsT<PT_MAX_WORDS> BlockLds;
+// the static-fetch and BVH2 traversal kernels (flat-list and instanced scenes, wide BVH switched off) run with <= 2048 slots per
+// workgroup (slotCap in the shim): their deep stacks need the LDS
+typedef BlockLdsT<64u> BlockLdsSmall;
 
 // push: set the slot's bit in queue q (LDS atomic OR)
-PT_DEV void queuePush(bool push, uint32_t localSlot, BlockLds &L, int q)
+template<class LDS>
+PT_DEV void queuePush(bool push, uint32_t localSlot, LDS &L, int q)
 {
     if (push)
         atomicOr(&L.bm[q][localSlot >> 5], 1u << (localSlot & 31u));
@@ -280,7 +288,8 @@ PT_DEV void queuePush(bool push, uint32_t localSlot, BlockLds &L, int q)
 // statistics.  All threads must call it.
 // Expands queue q, followed by the optional queue q2, from the LDS bitmaps into order[0 .. L.n) and clears them
 // (consumed).  All threads must call it; it ends with a barrier.
-PT_DEV void queuesExpand(BlockLds &L, const PathState &st, int q, int q2, unsigned short *order)
+template<class LDS>
+PT_DEV void queuesExpand(LDS &L, const PathState &st, int q, int q2, unsigned short *order)
 {
     const uint32_t W = st.slots_per_block >> 5;
     const uint32_t t = threadIdx.x;
@@ -290,42 +299,48 @@ PT_DEV void queuesExpand(BlockLds &L, const PathState &st, int q, int q2, unsign
         const int qq = pass == 0 ? q : q2;
         if (qq < 0)
             continue;                            // uniform
-        // exclusive prefix of the per-word popcounts (W <= 64: one wave)
+        // exclusive prefix of the per-word popcounts: the first wave, 64 words at a time
         if (t < 64) {
-            uint32_t c = t < W ? (uint32_t)__popc(L.bm[qq][t]) : 0u;
-            uint32_t inc = c;
-            for (int off = 1; off < 64; off <<= 1) {
-                uint32_t v = __shfl_up(inc, off);
-                if ((int)t >= off) inc += v;
+            uint32_t run = done;
+            for (uint32_t base = 0; base < W; base += 64u) {
+                const uint32_t wd = base + t;
+                uint32_t c = wd < W ? (uint32_t)__popc(L.bm[qq][wd]) : 0u;
+                uint32_t inc = c;
+                for (int off = 1; off < 64; off <<= 1) {
+                    uint32_t v = __shfl_up(inc, off);
+                    if ((int)t >= off) inc += v;
+                }
+                if (wd < W) L.prefix[wd] = run + inc - c;
+                run += __shfl(inc, 63);
             }
-            if (t < W) L.prefix[t] = inc - c;
-            if (t == 63) L.n = done + inc;
+            if (t == 63) L.n = run;
         }
         __syncthreads();
-        if (t < W) {
-            uint32_t bits = L.bm[qq][t], off = done + L.prefix[t];
+        for (uint32_t wd = t; wd < W; wd += blockDim.x) {
+            uint32_t bits = L.bm[qq][wd], off = L.prefix[wd];
             while (bits) {
                 uint32_t b = (uint32_t)__ffs((int)bits) - 1u;
-                order[off++] = (unsigned short)(t*32u + b);
+                order[off++] = (unsigned short)(wd*32u + b);
                 bits &= bits - 1u;
             }
-            L.bm[qq][t] = 0u;                    // consumed
+            L.bm[qq][wd] = 0u;                   // consumed
         }
         __syncthreads();
         done = L.n;
     }
 }
 
-PT_DEV void queuesBegin(BlockLds &L, const PathState &st, const BlockCtl &ctl, int q, uint32_t appendMask, unsigned short *order,
+template<class LDS>
+PT_DEV void queuesBegin(LDS &L, const PathState &st, const BlockCtl &ctl, int q, uint32_t appendMask, unsigned short *order,
                         int q2 = -1)
 {
     const uint32_t W = st.slots_per_block >> 5;
     const uint32_t t = threadIdx.x;
-    if (t < W) {
+    for (uint32_t wd = t; wd < W; wd += blockDim.x) {
 #pragma unroll
         for (int k = 0; k < Q_COUNT; ++k) {
             bool load = k == q || k == q2 || ((appendMask >> k) & 1u);
-            L.bm[k][t] = load ? st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + t] : 0u;
+            L.bm[k][wd] = load ? st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + wd] : 0u;
         }
     }
     if (t == 0) {
@@ -363,18 +378,19 @@ PT_DEV uint32_t orderGet(const OrderRegs &r, uint32_t k)   // k is wave-uniform
 
 // Kernel epilogue: writes back the consumed (now empty) and appended bitmaps.  Returns (to thread 0..W-1) nothing;
 // `anyExt` tells whether the extension queue holds work.
-PT_DEV bool queuesEnd(BlockLds &L, const PathState &st, int q, uint32_t appendMask, int q2 = -1)
+template<class LDS>
+PT_DEV bool queuesEnd(LDS &L, const PathState &st, int q, uint32_t appendMask, int q2 = -1)
 {
     __syncthreads();
     const uint32_t W = st.slots_per_block >> 5;
     const uint32_t t = threadIdx.x;
     uint32_t ext = 0;
-    if (t < W) {
+    for (uint32_t wd = t; wd < W; wd += blockDim.x) {
 #pragma unroll
         for (int k = 0; k < Q_COUNT; ++k)
             if (k == q || k == q2 || ((appendMask >> k) & 1u))
-                st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + t] = L.bm[k][t];
-        ext = L.bm[Q_EXT][t] | L.bm[Q_EXTP][t];
+                st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + wd] = L.bm[k][wd];
+        ext |= L.bm[Q_EXT][wd] | L.bm[Q_EXTP][wd];
     }
     return __syncthreads_or(ext != 0u) != 0;
 }

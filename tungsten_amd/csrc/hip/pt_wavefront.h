@@ -261,7 +261,7 @@ template<bool COUNT, bool FLAT, int INST = 0>
 __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsStack[];
-    __shared__ BlockLds L;
+    __shared__ BlockLdsSmall L;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     // the dynamic LDS region first holds the expanded queue, then (after orderPreload's barrier) the node stacks
     queuesBegin(L, st, ctl, Q_EXTP, 0u, reinterpret_cast<unsigned short *>(ldsStack), Q_EXT);   // the shading queues are empty here
@@ -316,10 +316,10 @@ template<bool COUNT, bool SOLIDS = true>
 __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsDyn[];
-    __shared__ BlockLds L;
+    __shared__ BlockLdsSmall L;
     __shared__ uint32_t fetchNext;
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
-    int *stack = ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2 + threadIdx.x;
+    int *stack = ldsDyn + (st.slots_per_block >> 1) + threadIdx.x;
     const int stride = (int)blockDim.x;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     if (threadIdx.x == 0) fetchNext = 0;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathS
     __shared__ BlockLds L;
     __shared__ uint32_t fetchNext;
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
-    uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2) + threadIdx.x;
+    uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + (st.slots_per_block >> 1)) + threadIdx.x;
     const int stride = (int)blockDim.x;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     if (threadIdx.x == 0) fetchNext = 0;
@@ -1237,7 +1237,7 @@ template<bool COUNT, bool FORWARD, bool FLAT, int INST = 0>
 __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsStack[];
-    __shared__ BlockLds L;
+    __shared__ BlockLdsSmall L;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     queuesBegin(L, st, ctl, Q_SHADOW, (1u << Q_EXT) | (1u << Q_EXTP), reinterpret_cast<unsigned short *>(ldsStack));
     const uint32_t n = L.n;
@@ -1404,10 +1404,10 @@ template<bool COUNT, bool SOLIDS = true>
 __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsDyn[];
-    __shared__ BlockLds L;
+    __shared__ BlockLdsSmall L;
     __shared__ uint32_t fetchNext;
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
-    int *stack = ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2 + threadIdx.x;
+    int *stack = ldsDyn + (st.slots_per_block >> 1) + threadIdx.x;
     const int stride = (int)blockDim.x;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     if (threadIdx.x == 0) fetchNext = 0;
@@ -1562,7 +1562,7 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState s
     __shared__ BlockLds L;
     __shared__ uint32_t fetchNext;
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
-    uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + PT_MAX_SLOTS_PER_BLOCK/2) + threadIdx.x;
+    uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + (st.slots_per_block >> 1)) + threadIdx.x;
     const int stride = (int)blockDim.x;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     if (threadIdx.x == 0) fetchNext = 0;

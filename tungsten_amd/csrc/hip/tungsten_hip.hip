@@ -106,7 +106,12 @@ struct tghip_ctx {
     std::vector<BlockStats> hostStats;
 
     // options
-    long long maxSlots = 1ll << 21;       // path pool size
+    // path pool size.  Every kernel of an iteration costs a fixed 140-180 us on top of the time that grows with its rays -- the
+    // longest walks / the latency of one shading turn, measured by doubling the pool: materialtest closest-hit 246 -> 348 us, shadow
+    // 347 -> 518 us, k_shade 421 -> 665 us per launch for twice the rays -- so the pool is as large as the 32-bit slot offsets allow
+    // (8 M slots x 272 B = 2.2 GB of the 288 GB): 1280x720x256 669 -> 745 (4 M) -> 818 (8 M) Msamples/s, mesh1m 404 -> 472 -> 507
+    long long maxSlots = 1ll << 23;
+    int slotsPerBlockOpt = 0;             // "slots_per_block": upper bound on the slots of one workgroup (0 = PT_MAX_SLOTS_PER_BLOCK)
     bool maxSlotsSet = false;             // "max_slots" was given explicitly
     long long maxItems = 1ll << 26;       // work items per batch (partial-sum buffer = 16 B each)
     int chunkSamples = 4;                 // samples per work item
@@ -328,6 +333,21 @@ static bool isFlat(const tghip_ctx *ctx) { return ctx->scene.num_recs <= TGHIP_F
 static bool useWide(const tghip_ctx *ctx) { return ctx->wideDepth > 0 && ctx->wideOpt && ctx->dynamicFetch && !isFlat(ctx); }
 
 
+static bool wideClosest(const tghip_ctx *ctx);
+static bool wideShadowRays(const tghip_ctx *ctx);
+// Most slots a workgroup of the uploaded scene owns (the pool is sized by it, and the traversal kernels' LDS queue area): 4096 where both
+// traversal kernels are the wide ones.  The static-fetch BVH2 kernels of flat-list and instanced scenes keep a thread's queue entries in
+// 16 half registers (OrderRegs: <= 16 x threads), and their deep stacks leave less LDS: 2048, as measured (instances10k: 4096 slots with
+// the smaller workgroups that then fit are not faster).
+static uint32_t slotCap(const tghip_ctx *ctx)
+{
+    const bool allWide = !isFlat(ctx) && !ctx->haveInstances && wideClosest(ctx) && wideShadowRays(ctx) && !ctx->haveForward && !ctx->haveMeshLight;
+    uint32_t cap = allWide ? PT_MAX_SLOTS_PER_BLOCK : 2048u;      // (BlockLdsSmall in the other traversal kernels)
+    if (ctx->slotsPerBlockOpt > 0)
+        cap = std::min<uint32_t>(cap, uint32_t(ctx->slotsPerBlockOpt));
+    return std::max(cap, 64u);
+}
+
 // Dynamic LDS of the traversal kernels: one node stack of bvhDepth ints per thread (a root-to-leaf walk pushes at
 // most one far child per internal level), aliased with the expanded queue (2 B per slot) that is consumed before
 // traversal starts.  Flat-list scenes need no stack.
@@ -335,19 +355,19 @@ static size_t traceLdsBytes(const tghip_ctx *ctx, int threads)
 {
     const bool flat = isFlat(ctx);
     size_t stack = flat ? 0 : size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
-    return std::max<size_t>(stack, size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short));
+    return std::max<size_t>(stack, size_t(slotCap(ctx))*sizeof(unsigned short));
 }
 
 // dynamic-fetch traversal kernels keep the expanded queue next to the stacks
 static size_t dynLdsBytes(const tghip_ctx *ctx, int threads)
 {
-    return size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short) + size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
+    return size_t(slotCap(ctx))*sizeof(unsigned short) + size_t(std::max(ctx->bvhDepth, 1))*size_t(threads)*sizeof(int);
 }
 
 // the wide kernels: expanded queue + one 8-byte group entry per tree level and thread
 static size_t wideLdsBytes(const tghip_ctx *ctx, int threads)
 {
-    return size_t(PT_MAX_SLOTS_PER_BLOCK)*sizeof(unsigned short) + size_t(std::max(ctx->wideDepth, 1))*size_t(threads)*sizeof(uint2);
+    return size_t(slotCap(ctx))*sizeof(unsigned short) + size_t(std::max(ctx->wideDepth, 1))*size_t(threads)*sizeof(uint2);
 }
 
 static bool wideClosest(const tghip_ctx *ctx) { return useWide(ctx) && (ctx->wideClosestOpt < 0 ? !ctx->haveInstances : ctx->wideClosestOpt != 0); }
@@ -436,7 +456,10 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
 {
     const uint32_t grid = uint32_t(launchGrid(ctx));
     uint32_t perBlock = (wantSlots + grid - 1)/grid;
-    perBlock = std::min<uint32_t>(PT_MAX_SLOTS_PER_BLOCK, std::max<uint32_t>(64u, (perBlock + 63u)/64u*64u));
+    uint32_t cap = slotCap(ctx);
+    if (isFlat(ctx) || ctx->haveInstances)
+        cap = std::min<uint32_t>(cap, 16u*uint32_t(std::min(ctx->thrClosest, ctx->thrShadow))/64u*64u);   // OrderRegs
+    perBlock = std::min<uint32_t>(cap, std::max<uint32_t>(64u, (perBlock + 63u)/64u*64u));
     const uint32_t slots = perBlock*grid;
     PathState &p = ctx->pool;
     if (ctx->poolSlots >= slots && ctx->poolGrid == grid) {
@@ -639,6 +662,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     if (k == "count_traversal") ctx->countTraversal = value != 0;
     else if (k == "max_slots") { ctx->maxSlots = std::max<long long>(value, 256); ctx->maxSlotsSet = true; }
     else if (k == "max_items") ctx->maxItems = std::max<long long>(value, 256);
+    else if (k == "slots_per_block") { ctx->slotsPerBlockOpt = int(std::min<long long>(std::max<long long>(value, 0), PT_MAX_SLOTS_PER_BLOCK))/64*64; ctx->poolMem.release(); ctx->poolSlots = 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
