@@ -258,6 +258,16 @@ class Bench(object):
                             "traffic": None, "bytes_per_launch": kd["bytes_per_launch"], "avg_launch_us": kd["avg_us"],
                             "launches": kd["launches"],
                             "timing": "HIP events per launch on the shim's stream, over the timed region"}
+                # The shim runs the pool as P parts on P streams (tungsten_hip.hip: runBatch); launches of different parts share the CUs, so a
+                # launch has a fraction of the chip for its duration.  `loop` prices the whole loop instead: the algorithmic bytes of all
+                # its kernels over the wall time of the timed region.
+                parts = max(1, int(round(kd["launches"]/max(timed["iterations"], 1))))
+                if parts > 1:
+                    roofline["concurrent_parts"] = parts
+                loop_bytes = sum(per_step_bytes[k] for k in kernels)*steps
+                roofline["loop"] = {"achieved": round(loop_bytes/elapsed*1e-9, 1), "unit": "GB/s", "frac": round(loop_bytes/elapsed*1e-9/HBM_PEAK_GBS, 4),
+                                    "bytes_per_iteration": round(loop_bytes/max(timed["iterations"], 1)),
+                                    "us_per_iteration": round(elapsed/max(timed["iterations"], 1)*1e6, 1)}
                 if fused:
                     roofline["note"] = ("instruction-bound, not HBM-bound (profiles/sq_counters.json): exact fp32 division/sqrt/sin/cos and -ffp-contract=off for parity "
                                         "with the CPU reference (DESIGN.md sections 5, 7)")

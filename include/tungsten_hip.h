@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 5
+#define TGHIP_ABI_VERSION 6
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -239,6 +239,7 @@ typedef struct TgHipTexture {
 /* ---- camera (cameras/PinholeCamera.cpp:28-86, Camera.cpp:44-68, ReconstructionFilter) ---- */
 enum { TGHIP_FILTER_DIRAC = 0, TGHIP_FILTER_BOX = 1, TGHIP_FILTER_TABULATED = 2 };
 enum { TGHIP_CAMERA_PINHOLE = 0, TGHIP_CAMERA_THINLENS = 1 };   /* cameras/PinholeCamera.cpp, cameras/ThinlensCamera.cpp */
+enum { TGHIP_APERTURE_DISK = 0, TGHIP_APERTURE_BLADE = 1 };     /* textures/DiskTexture.cpp:78-81, textures/BladeTexture.cpp:110-130 */
 typedef struct TgHipCamera {
     float   pos[3];
     float   plane_dist;
@@ -248,11 +249,16 @@ typedef struct TgHipCamera {
     int32_t filter_type;
     float   filter_width, filter_bin_size;
     float   filter_cdf[32];   /* ReconstructionFilter::_cdf (RFILTER_RESOLUTION = 31) */
-    /* thin lens (cameras/ThinlensCamera.cpp:85-126) with the default disk aperture (textures/DiskTexture.cpp:78-86) */
+    /* thin lens (cameras/ThinlensCamera.cpp:85-126); the aperture texture is only ever sampled by the forward path tracer
+     * (samplePosition, :85-97): the default disk (textures/DiskTexture.cpp:78-86) or an n-blade polygon (BladeTexture.cpp:21-31, 110-130) */
     int32_t type;             /* TGHIP_CAMERA_*                                   */
     float   focus_dist, aperture_size, cat_eye;
     float   inv_xf[12];       /* rows 0..2 of Camera::_invTransform (3x4, row-major, translation in column 3) */
     int32_t medium;           /* Camera::_medium (Camera.cpp:49-50): index into media[], -1 = none */
+    int32_t aperture_type;    /* TGHIP_APERTURE_*                                  */
+    int32_t blade_count;      /* BladeTexture::_numBlades                          */
+    float   blade_angle, blade_step;   /* _angle, _bladeAngle = 2 pi / blades     */
+    float   blade_edge[2];    /* _baseEdge                                         */
 } TgHipCamera;
 
 /* ---- integrator settings (TraceSettings.hpp:23-39, PathTracerSettings.hpp:25-43) -------- */

@@ -2565,8 +2565,24 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
     v3 lensP = ld3(cam->pos);
     if (thinlens) {
         float l0 = next1D(c->sampler), l1 = next1D(c->sampler);
-        float phi = l0*O_TWO_PI, r = sqrtf(l1);
-        float ax = (cosf(phi)*r*0.5f + 0.5f)*2.0f - 1.0f, ay = (sinf(phi)*r*0.5f + 0.5f)*2.0f - 1.0f;
+        float su, sv;
+        if (cam->aperture_type == TGHIP_APERTURE_BLADE) {
+            /* BladeTexture::sample (textures/BladeTexture.cpp:110-130): a blade, then a point of its triangle */
+            float u = l0*(float)cam->blade_count;
+            int blade = (int)u;
+            u -= (float)blade;
+            float phi = cam->blade_angle + (float)blade*cam->blade_step;
+            float sinPhi = sinf(phi), cosPhi = cosf(phi);
+            float uSqrt = sqrtf(u);
+            float alpha = 1.0f - uSqrt, beta = (1.0f - l1)*uSqrt;
+            float lx = (1.0f + cam->blade_edge[0])*beta + (1.0f - alpha - beta), ly = cam->blade_edge[1]*beta;
+            su = (lx*cosPhi - ly*sinPhi)*0.5f + 0.5f;
+            sv = (ly*cosPhi + lx*sinPhi)*0.5f + 0.5f;
+        } else {
+            float phi = l0*O_TWO_PI, r = sqrtf(l1);
+            su = cosf(phi)*r*0.5f + 0.5f; sv = sinf(phi)*r*0.5f + 0.5f;
+        }
+        float ax = su*2.0f - 1.0f, ay = sv*2.0f - 1.0f;
         ax *= cam->aperture_size; ay *= cam->aperture_size;
         /* _transform*Vec3f(ax, ay, 0) (Mat4f::operator*(Vec3f)) */
         lensP = V(cam->xf[0]*ax + cam->xf[1]*ay + cam->xf[2]*0.0f + cam->pos[0],

@@ -424,6 +424,18 @@ def _thinlens(cateye):
 # some direction samples fail -> black samples, PathTracer.cpp:27-28)
 GOLDEN_CASES["cornell_thinlens"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.0)))
 GOLDEN_CASES["cornell_thinlens_cateye"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.35)))
+def _thinlens_blade(blades, angle=None):
+    def edit(scene):
+        ap = {"type": "blade", "blades": blades}
+        if angle is not None:
+            ap["angle"] = angle
+        scene["camera"].update(type="thinlens", focus_distance=6.0, aperture_size=0.12, cateye=0.0, aperture=ap)
+    return edit
+
+
+# n-blade aperture (textures/BladeTexture.cpp): the lens point is a uniform point of one of the polygon's triangles
+GOLDEN_CASES["cornell_thinlens_blade5"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_blade(5, 0.3)))
+GOLDEN_CASES["cornell_thinlens_blade6"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_blade(6)))
 GOLDEN_CASES["cornell_thinlens_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.0), renderer={"stratified_sampler": True}))
 
 def _disks(scene):

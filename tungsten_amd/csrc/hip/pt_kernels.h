@@ -441,9 +441,25 @@ PT_DEV bool cameraRay(CameraRef cam, bool lens, uint32_t px, uint32_t py, float 
     if (cam.filter_type == TGHIP_FILTER_BOX) { fu = xi0 - 0.5f; fv = xi1 - 0.5f; }
     else if (cam.filter_type == TGHIP_FILTER_TABULATED) { fu = filterSample1D(cam, xi0); fv = filterSample1D(cam, xi1); }
     if (LENS && lens) {
-        float phi = l0*PT_TWO_PI, r = sqrtf(l1);                       // SampleWarp::uniformDisk (SampleWarp.hpp:64-69)
-        float ax = ((cosf(phi)*r*0.5f + 0.5f)*2.0f - 1.0f)*cam.aperture_size;
-        float ay = ((sinf(phi)*r*0.5f + 0.5f)*2.0f - 1.0f)*cam.aperture_size;
+        float su, sv;                                                   // _aperture->sample(MAP_UNIFORM, lensUv)
+        if (cam.aperture_type == TGHIP_APERTURE_BLADE) {                // BladeTexture::sample (textures/BladeTexture.cpp:110-130)
+            float u = l0*(float)cam.blade_count;
+            int blade = (int)u;
+            u -= (float)blade;
+            float phi = cam.blade_angle + (float)blade*cam.blade_step;
+            float sinPhi = sinf(phi), cosPhi = cosf(phi);
+            float uSqrt = sqrtf(u);
+            float alpha = 1.0f - uSqrt, beta = (1.0f - l1)*uSqrt;
+            float lx = (1.0f + cam.blade_edge[0])*beta + (1.0f - alpha - beta), ly = cam.blade_edge[1]*beta;
+            su = (lx*cosPhi - ly*sinPhi)*0.5f + 0.5f;
+            sv = (ly*cosPhi + lx*sinPhi)*0.5f + 0.5f;
+        } else {
+            float phi = l0*PT_TWO_PI, r = sqrtf(l1);                   // SampleWarp::uniformDisk (SampleWarp.hpp:64-69)
+            su = cosf(phi)*r*0.5f + 0.5f;
+            sv = sinf(phi)*r*0.5f + 0.5f;
+        }
+        float ax = (su*2.0f - 1.0f)*cam.aperture_size;
+        float ay = (sv*2.0f - 1.0f)*cam.aperture_size;
         o = mk3(cam.xf[0]*ax + cam.xf[1]*ay + cam.xf[2]*0.0f + cam.pos[0],
                 cam.xf[3]*ax + cam.xf[4]*ay + cam.xf[5]*0.0f + cam.pos[1],
                 cam.xf[6]*ax + cam.xf[7]*ay + cam.xf[8]*0.0f + cam.pos[2]);

@@ -56,9 +56,9 @@ struct DeviceBuffers {
 struct tghip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t partStream[3] = {nullptr, nullptr, nullptr};   // streams of parts 1..3 of the split wavefront loop ("streams" option)
+    hipStream_t partStream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // streams of parts 1..3 of the split wavefront loop ("streams" option)
     hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the half's stream)
-    hipEvent_t evPart[3] = {nullptr, nullptr, nullptr}, evMain = nullptr;
+    hipEvent_t evPart[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, evMain = nullptr;
     int streamsOpt = 0;                   // "streams": 1 .. 4 parts of the pool on as many streams, 0 = the measured default (four for single-level
                                           // BVH scenes; instanced scenes lose 2.5 % with two)
     hipDeviceProp_t prop;
@@ -591,7 +591,7 @@ tghip_ctx *tghip_create(int device_ordinal)
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_ordinal);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 7; ++k) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->partStream[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evPart[k], hipEventDisableTiming);
     }
@@ -637,9 +637,9 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
-    for (int k = 0; k < 3; ++k) if (ctx->evPart[k]) (void)hipEventDestroy(ctx->evPart[k]);
+    for (int k = 0; k < 7; ++k) if (ctx->evPart[k]) (void)hipEventDestroy(ctx->evPart[k]);
     if (ctx->evMain) (void)hipEventDestroy(ctx->evMain);
-    for (int k = 0; k < 3; ++k) if (ctx->partStream[k]) (void)hipStreamDestroy(ctx->partStream[k]);
+    for (int k = 0; k < 7; ++k) if (ctx->partStream[k]) (void)hipStreamDestroy(ctx->partStream[k]);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -666,7 +666,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
-    else if (k == "streams") { ctx->streamsOpt = int(std::min<long long>(std::max<long long>(value, 0), 4)); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "streams") { ctx->streamsOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1093,9 +1093,9 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     if (fused || flat || st.records || grid < 2*parts || grid % parts != 0 || pp.total_items < uint32_t(2*parts)*PT_ITEM_GROUP)
         parts = 1;
     const bool halves = parts > 1;
-    PathState stHalf[4] = {st, st, st, st};
-    PassParams ppHalf[4] = {pp, pp, pp, pp};
-    hipStream_t streamOf[4] = {ctx->stream, ctx->partStream[0], ctx->partStream[1], ctx->partStream[2]};
+    PathState stHalf[8] = {st, st, st, st, st, st, st, st};
+    PassParams ppHalf[8] = {pp, pp, pp, pp, pp, pp, pp, pp};
+    hipStream_t streamOf[8] = {ctx->stream, ctx->partStream[0], ctx->partStream[1], ctx->partStream[2], ctx->partStream[3], ctx->partStream[4], ctx->partStream[5], ctx->partStream[6]};
     if (halves) {
         const uint32_t groups = (pp.total_items + PT_ITEM_GROUP - 1)/PT_ITEM_GROUP;
         uint32_t itemBegin = 0;

@@ -1076,8 +1076,22 @@ void Camera::fromJson(const JsonValue &v, const Scene &scene)
             throw JsonLoadException("thinlens 'focus_pivot' is outside the path_tracer_hip hot-path scope");
         if (const JsonValue &ap = v["aperture"]) {
             std::string apType;
-            if (!ap.isObject() || !ap.getField("type", apType) || apType != "disk")
-                throw JsonLoadException("thinlens apertures other than the default 'disk' texture are outside the path_tracer_hip hot-path scope");
+            if (ap.isObject() && ap.getField("type", apType) && apType == "blade") {
+                // BladeTexture ctor + fromJson + init (textures/BladeTexture.cpp:14-41): the default angle belongs to the default 6 blades
+                blades = 6;
+                bladeAngle = 0.5f*PI/6;
+                ap.getField("blades", blades);
+                ap.getField("angle", bladeAngle);
+                if (blades < 3)
+                    throw JsonLoadException("a blade aperture needs at least 3 blades");
+                bladeStep = TWO_PI/blades;
+                float sinAngle = std::sin(bladeStep*0.5f), cosAngle = std::cos(bladeStep*0.5f);
+                const float k = std::sin(PI/blades);                           // _baseEdge = Vec2f(-sin, cos)*2.0f*sin(pi/n)
+                bladeEdge[0] = -sinAngle*2.0f*k;
+                bladeEdge[1] = cosAngle*2.0f*k;
+            } else if (!ap.isObject() || apType != "disk") {
+                throw JsonLoadException("thinlens apertures other than the 'disk' and 'blade' textures are outside the path_tracer_hip hot-path scope");
+            }
         }
     } else if (type != "pinhole") {
         throw JsonLoadException("Camera type '" + type + "' is outside the path_tracer_hip hot-path scope");

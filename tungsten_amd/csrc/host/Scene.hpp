@@ -150,6 +150,10 @@ struct Camera
     // cameras/ThinlensCamera.cpp:16-27 (type "thinlens"; the aperture is the default DiskTexture)
     bool thinlens = false;
     float focusDist = 1.0f, apertureSize = 0.001f, catEye = 0.0f;
+    // "aperture": {"type": "blade", "blades": n, "angle": a} (textures/BladeTexture.cpp:14-41); 0 blades = the disk
+    int blades = 0;
+    float bladeAngle = 0.0f, bladeStep = 0.0f;
+    float bladeEdge[2] = {0.0f, 0.0f};
     Mat4f invTransform;
     std::shared_ptr<Medium> medium;                 // Camera.cpp:49-50
     // precompute()

@@ -495,6 +495,10 @@ void TraceableScene::flatten()
     c.focus_dist = cam.focusDist;
     c.aperture_size = cam.apertureSize;
     c.cat_eye = cam.catEye;
+    c.aperture_type = cam.blades > 0 ? TGHIP_APERTURE_BLADE : TGHIP_APERTURE_DISK;
+    c.blade_count = cam.blades;
+    c.blade_angle = cam.bladeAngle; c.blade_step = cam.bladeStep;
+    c.blade_edge[0] = cam.bladeEdge[0]; c.blade_edge[1] = cam.bladeEdge[1];
     for (int i = 0; i < 12; ++i) c.inv_xf[i] = cam.invTransform[i];
     c.medium = addMedium(cam.medium);
 
