@@ -330,16 +330,18 @@ PT_DEV void queuesExpand(LDS &L, const PathState &st, int q, int q2, unsigned sh
     }
 }
 
+// freshAppend: the appended bitmaps start empty and queuesEnd(atomicAppend) ORs them into the global ones -- for launches that run
+// concurrently with others appending to the same workgroup's queues (the shading classes, each consuming a queue of its own).
 template<class LDS>
 PT_DEV void queuesBegin(LDS &L, const PathState &st, const BlockCtl &ctl, int q, uint32_t appendMask, unsigned short *order,
-                        int q2 = -1)
+                        int q2 = -1, bool freshAppend = false)
 {
     const uint32_t W = st.slots_per_block >> 5;
     const uint32_t t = threadIdx.x;
     for (uint32_t wd = t; wd < W; wd += blockDim.x) {
 #pragma unroll
         for (int k = 0; k < Q_COUNT; ++k) {
-            bool load = k == q || k == q2 || ((appendMask >> k) & 1u);
+            bool load = k == q || k == q2 || (!freshAppend && ((appendMask >> k) & 1u));
             L.bm[k][wd] = load ? st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + wd] : 0u;
         }
     }
@@ -379,7 +381,7 @@ PT_DEV uint32_t orderGet(const OrderRegs &r, uint32_t k)   // k is wave-uniform
 // Kernel epilogue: writes back the consumed (now empty) and appended bitmaps.  Returns (to thread 0..W-1) nothing;
 // `anyExt` tells whether the extension queue holds work.
 template<class LDS>
-PT_DEV bool queuesEnd(LDS &L, const PathState &st, int q, uint32_t appendMask, int q2 = -1)
+PT_DEV bool queuesEnd(LDS &L, const PathState &st, int q, uint32_t appendMask, int q2 = -1, bool atomicAppend = false)
 {
     __syncthreads();
     const uint32_t W = st.slots_per_block >> 5;
@@ -387,9 +389,12 @@ PT_DEV bool queuesEnd(LDS &L, const PathState &st, int q, uint32_t appendMask, i
     uint32_t ext = 0;
     for (uint32_t wd = t; wd < W; wd += blockDim.x) {
 #pragma unroll
-        for (int k = 0; k < Q_COUNT; ++k)
-            if (k == q || k == q2 || ((appendMask >> k) & 1u))
+        for (int k = 0; k < Q_COUNT; ++k) {
+            if (k == q || k == q2 || (!atomicAppend && ((appendMask >> k) & 1u)))
                 st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + wd] = L.bm[k][wd];
+            else if (atomicAppend && ((appendMask >> k) & 1u) && L.bm[k][wd])
+                atomicOr(&st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + wd], L.bm[k][wd]);
+        }
         ext |= L.bm[Q_EXT][wd] | L.bm[Q_EXTP][wd];
     }
     return __syncthreads_or(ext != 0u) != 0;

@@ -680,7 +680,10 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS;   // cls 2: the escaped paths
     const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : -1;
     const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? (1u << Q_SHADE1) : 0u) | (FUSE == 0 ? (1u << Q_FIN) : 0u);
-    queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2);
+    // the wavefront launches (FUSE == 0) of the shading classes of one iteration run concurrently (runBatch): each consumes its own
+    // queue, touches its own slots, and ORs what it appends into the workgroup's global bitmaps
+    constexpr bool CONCURRENT = FUSE == 0;
+    queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2, CONCURRENT);
     const DeviceScene s = stageSceneTables(sg, ldsTables);
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
@@ -1216,8 +1219,8 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
         waveAddStat(&L.shadow_rays, fusedShadow);
         waveAddStat(&L.prims, fusedPrims);
     }
-    const bool anyExt = queuesEnd(L, st, qIn, appendMask, qIn2);
-    if (threadIdx.x == 0) {
+    const bool anyExt = queuesEnd(L, st, qIn, appendMask, qIn2, CONCURRENT);
+    if (FUSE != 0 && threadIdx.x == 0) {         // (the wavefront launches neither regenerate nor finish samples: k_finish does)
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples;
         if (FUSE) {

@@ -57,6 +57,9 @@ struct tghip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t partStream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // streams of parts 1..3 of the split wavefront loop ("streams" option)
+    hipStream_t classStream[8][2] = {};   // per part: the streams of the shading classes that run beside the part's own ("class_streams" option)
+    hipEvent_t evFork[8] = {}, evJoin[8][2] = {};
+    int classStreamsOpt = 0;              // measured: 735-800 Msamples/s against 825-830 with the classes one after the other on the part's stream
     hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the half's stream)
     hipEvent_t evPart[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, evMain = nullptr;
     int streamsOpt = 0;                   // "streams": 1 .. 4 parts of the pool on as many streams, 0 = the measured default (four for single-level
@@ -591,9 +594,18 @@ tghip_ctx *tghip_create(int device_ordinal)
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_ordinal);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    // (creation order matters: HIP deals its streams round-robin to a few hardware queues -- GPU_MAX_HW_QUEUES, 4 by default -- and
+    // streams on one hardware queue run their kernels one after the other; the part streams come first)
     for (int k = 0; k < 7; ++k) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->partStream[k], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evPart[k], hipEventDisableTiming);
+    }
+    for (int k = 0; k < 8; ++k) {
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evFork[k], hipEventDisableTiming);
+        for (int a = 0; a < 2; ++a) {
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->classStream[k][a], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evJoin[k][a], hipEventDisableTiming);
+        }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evMain, hipEventDisableTiming);
     ctx->launchStream = ctx->stream;
@@ -640,6 +652,13 @@ void tghip_destroy(tghip_ctx *ctx)
     for (int k = 0; k < 7; ++k) if (ctx->evPart[k]) (void)hipEventDestroy(ctx->evPart[k]);
     if (ctx->evMain) (void)hipEventDestroy(ctx->evMain);
     for (int k = 0; k < 7; ++k) if (ctx->partStream[k]) (void)hipStreamDestroy(ctx->partStream[k]);
+    for (int k = 0; k < 8; ++k) {
+        if (ctx->evFork[k]) (void)hipEventDestroy(ctx->evFork[k]);
+        for (int a = 0; a < 2; ++a) {
+            if (ctx->evJoin[k][a]) (void)hipEventDestroy(ctx->evJoin[k][a]);
+            if (ctx->classStream[k][a]) (void)hipStreamDestroy(ctx->classStream[k][a]);
+        }
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -667,6 +686,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "check_interval") ctx->checkInterval = int(std::max<long long>(value, 1));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "streams") { ctx->streamsOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "class_streams") ctx->classStreamsOpt = value != 0;
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1127,7 +1147,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     bool first = true;
     int roundIters = ctx->checkInterval;         // launches of the wavefront loop between two host checks
         // the launches of one wavefront iteration over the workgroups [0, grid) of `st` (the whole pool, or one half of it)
-        auto launchIteration = [&](const PathState &st, const PassParams &pp, int grid, uint32_t iterTag, bool timed) {
+        auto launchIteration = [&](const PathState &st, const PassParams &pp, int grid, uint32_t iterTag, bool timed, int part) {
             auto tic = [&]() { if (timed) ticMain(); };
             tic();
             if (flat) {
@@ -1162,20 +1182,40 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) {   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER, for both classes
-                launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 2);
-                launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 0);
-                if (ctx->haveComplex) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, 1);
-            }
-            // class 2 = the escaped paths (Q_MISS), with the class-0 variant: its surface code never runs there, so the launch is short
-            else if (ctx->haveMeshLight || ctx->haveInstances) { launchShade<MASK_FULL>(ctx, grid, st, pp, 2); launchShade<MASK_FULL>(ctx, grid, st, pp, 0); }   // the only variants with mesh-emitter sampling / instance transforms
-            else if (ctx->leanScene) { launchShade<MASK_LEAN>(ctx, grid, st, pp, 2); launchShade<MASK_LEAN>(ctx, grid, st, pp, 0); }
-            else                     { launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 2); launchShade<MASK_SIMPLE>(ctx, grid, st, pp, 0); }
-            if (ctx->haveComplex && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder) {
-                if (ctx->haveMeshLight || ctx->haveInstances)   launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
+            // The shading classes of an iteration (2 = the escaped paths, Q_MISS; 0; 1) consume queues of their own and OR what they append
+            // into the workgroup's bitmaps (k_shade: CONCURRENT), so their launches MAY run side by side on three streams ("class_streams"
+            // option).  Measured slower than one after the other (materialtest 735-800 against 825-830 Msamples/s, mesh1m 409 against 508,
+            // for 2 to 24 hardware queues): with four parts in flight the chip is not short of independent launches.
+            auto shadeClass = [&](int cls) {
+                if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, cls);   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER
+                else if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);   // the only variants with mesh-emitter sampling / instance transforms
+                else if (cls != 1) {             // class 2 runs the class-0 variant: its surface code never runs there, so the launch is short
+                    if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, cls);
+                    else                launchShade<MASK_SIMPLE>(ctx, grid, st, pp, cls);
+                }
                 else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
                 else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
                 else                                            launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
+            };
+            hipStream_t mainStream = ctx->launchStream;
+            if (ctx->classStreamsOpt != 0) {
+                hipStream_t *aux = ctx->classStream[part];
+                (void)hipEventRecord(ctx->evFork[part], mainStream);
+                const int nAux = ctx->haveComplex ? 2 : 1;
+                for (int a = 0; a < nAux; ++a) {
+                    (void)hipStreamWaitEvent(aux[a], ctx->evFork[part], 0);
+                    ctx->launchStream = aux[a];
+                    shadeClass(a == 0 ? 2 : 0);
+                    (void)hipEventRecord(ctx->evJoin[part][a], aux[a]);
+                }
+                ctx->launchStream = mainStream;
+                shadeClass(ctx->haveComplex ? 1 : 0);             // the longest launch stays on the part's own stream
+                for (int a = 0; a < nAux; ++a)
+                    (void)hipStreamWaitEvent(mainStream, ctx->evJoin[part][a], 0);
+            } else {
+                shadeClass(2);
+                shadeClass(0);
+                if (ctx->haveComplex) shadeClass(1);
             }
             tic(); tic();
             const bool finish = count ? launchShadow<true>(ctx, grid, st, pp, iterTag) : launchShadow<false>(ctx, grid, st, pp, iterTag);
@@ -1241,11 +1281,11 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             if (halves) {
                 for (int k = 0; k < parts; ++k) {
                     ctx->launchStream = streamOf[k];
-                    launchIteration(stHalf[k], ppHalf[k], grid/parts, iterTag, k == 0);
+                    launchIteration(stHalf[k], ppHalf[k], grid/parts, iterTag, k == 0, k);
                 }
                 ctx->launchStream = ctx->stream;
             } else {
-                launchIteration(st, pp, grid, iterTag, true);
+                launchIteration(st, pp, grid, iterTag, true, 0);
             }
             ctx->counters.iterations++;
         }
