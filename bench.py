@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MAX_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max engine clock
 
 
 def parse_args():
@@ -273,6 +274,19 @@ class Bench(object):
                                         "with the CPU reference (DESIGN.md sections 5, 7)")
                 if a.traffic and self.world == 1:
                     roofline.update(measure_traffic(a, scene, w, h, spp, dom, self.tmp))
+                if (a.traffic or getattr(a, "valu_pass", False)) and self.world == 1:
+                    if fused:
+                        # what this kernel IS bound by: VALU issue.  One more counter pass (SQ_INSTS_VALU per launch) against the chip's
+                        # issue rate: every SIMD starts one wave-wide VALU instruction per 4 clocks (16 lanes x 4 = 64).
+                        prop = torch.cuda.get_device_properties(0)
+                        peak = prop.multi_processor_count*4*MAX_CLOCK_HZ/4.0*1e-9
+                        v = measure_counter(a, scene, w, h, spp, dom, self.tmp, "SQ_INSTS_VALU")
+                        if v is not None:
+                            ach = v/(kd["avg_us"]*1e-6)*1e-9
+                            roofline["valu"] = {"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                                                "frac": round(ach/peak, 4), "instructions_per_launch": round(v),
+                                                "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU (one child pass); peak = CUs x 4 SIMDs x 2.4 GHz / 4 "
+                                                          "(MI355X_MICROARCH.md: max clock; sustained clocks are lower, so frac understates)"}
             rays = max(cc["closest_rays"] + cc["shadow_rays"], 1)
             out = {
                 "value": round(value, 2), "ms_per_step": round(elapsed/steps*1e3, 3),
@@ -335,6 +349,35 @@ def measure_traffic(a, scene, w, h, spp, kernel, tmp):
     return {"traffic": round((2.0*f + w_)*1024.0),
             "traffic_source": "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child passes at %d spp, %d launches), "
                               "(2*FETCH + WRITE) KiB per MI355X_MICROARCH.md" % (pmc_spp, per_launch["FETCH_SIZE"][1])}
+
+
+def measure_counter(a, scene, w, h, spp, kernel, tmp, counter):
+    """Sum of one PMC counter per launch of `kernel` (all rows of a dispatch added up), from one child run under rocprofv3; None on failure."""
+    import csv
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    out = os.path.join(tmp, "pmc_" + counter)
+    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+           "--scene", scene, "--material", a.material, "--res", "%dx%d" % (w, h), "--spp", str(spp), "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), timeout=300)
+    except Exception:
+        return None
+    files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+    if p.returncode != 0 or not files:
+        return None
+    total, ids = 0.0, set()
+    with open(files[0]) as f:
+        for row in csv.DictReader(f):
+            k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "").replace("_wide", "")
+            if row.get("Counter_Name") == counter and k == kernel:
+                total += float(row["Counter_Value"])
+                ids.add(row.get("Dispatch_Id"))
+    shutil.rmtree(out, ignore_errors=True)
+    return total/len(ids) if ids else None
 
 
 def cpu_baseline(a, scene, path, flat, w, h, spp, tmp):
@@ -414,8 +457,9 @@ def main():
         if scene == "materialtest" and b.world == 1 and not a.no_extra:
             # BASELINE configs[1] on the same line: a flat-list scene, no traversal kernel (2 steps)
             saved, a.traffic = a.traffic, False
+            a.valu_pass = saved                  # (no HBM traffic passes for the extra line, but its VALU-issue roofline)
             m = b.run("cornell", 1280, 720, 256, 2, 1, False)
-            a.traffic = saved
+            a.traffic, a.valu_pass = saved, False
             if b.rank == 0:
                 keys = ("value", "ms_per_step", "config", "roofline", "kernels", "rays_per_sample", "prims_per_ray", "bvh", "result_ok")
                 extra = {"cornell_1280x720_256spp": dict({k: m[k] for k in keys}, unit="Msamples/s", steps=2, warmup=1)}

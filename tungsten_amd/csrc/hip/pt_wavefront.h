@@ -432,8 +432,14 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
 // Dynamic LDS: [expanded queue, 2 B per slot][group stacks, wideDepth x 8 B per thread].
 // INST: the scene has instance records -- the walk enters the masters' wide subtrees (pt_kernels.h: wideEnterInstance); the
 // instance a hit was reached through goes to the spare word A_EMI.w, as k_trace_closest<.., INST> leaves it.
+#ifndef WIDE_CLOSEST_BOUNDS
+#define WIDE_CLOSEST_BOUNDS __launch_bounds__(512)
+#endif
+#ifndef WIDE_SHADOW_BOUNDS
+#define WIDE_SHADOW_BOUNDS SHADOW_DYN_BOUNDS
+#endif
 template<bool COUNT, bool SOLIDS = true, bool INST = false>
-__global__ __launch_bounds__(512) void k_trace_closest_wide(DeviceScene s, PathState st)
+__global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsDyn[];
     __shared__ BlockLds L;
@@ -1559,7 +1565,7 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
 // k_trace_shadow_dyn over the 8-wide BVH: any-hit queries, one memory round trip (a node or a record) per lane and loop
 // turn, like k_trace_closest_wide.  Dynamic LDS: [expanded queue, 2 B per slot][group stacks, wideDepth x 8 B per thread].
 template<bool COUNT, bool SOLIDS = true, bool INST = false>
-__global__ SHADOW_DYN_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+__global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsDyn[];
     __shared__ BlockLds L;
