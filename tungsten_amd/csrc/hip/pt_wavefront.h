@@ -35,6 +35,7 @@
 #define TYPES_SIMPLE (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_NULL) | BSDF_BIT(TGHIP_BSDF_ERROR))
 #define MASK_SIMPLE  (TYPES_SIMPLE | FEAT_ALL)
 #define MASK_LEAN    TYPES_SIMPLE        /* analytic primitives, constant/checker textures, one area light (Cornell box) */
+#define MASK_SIMPLE_INST (MASK_SIMPLE | FEAT_INSTANCES)   /* classes 0 and 2 of scenes with instance records (no mesh emitters) */
 #ifndef SIMPLE_WAVES
 #define SIMPLE_WAVES 3   /* measured: 4 waves/SIMD (128 VGPRs, spills) is 10 % slower on materialtest's k_shade */
 #endif

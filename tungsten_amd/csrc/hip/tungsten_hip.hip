@@ -18,6 +18,8 @@ extern template __global__ void k_shade<MASK_LEAN, LEAN_WAVES, 7>(DeviceScene, P
 extern template __global__ void k_shade<(MASK_LEAN | FEAT_QMC), LEAN_WAVES, 7>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<(MASK_SIMPLE | FEAT_QMC), SIMPLE_WAVES, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_SIMPLE_INST, SIMPLE_WAVES, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_SIMPLE_INST | FEAT_QMC), SIMPLE_WAVES, 0>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<MASK_SIMPLE, SIMPLE_WAVES, 3>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<(MASK_SIMPLE | FEAT_QMC), SIMPLE_WAVES, 3>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<MASK_SIMPLE, SIMPLE_WAVES, 7>(DeviceScene, PathState, PassParams, int);
@@ -59,6 +61,7 @@ struct tghip_ctx {
     hipStream_t partStream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // streams of parts 1..3 of the split wavefront loop ("streams" option)
     hipStream_t classStream[8][2] = {};   // per part: the streams of the shading classes that run beside the part's own ("class_streams" option)
     hipEvent_t evFork[8] = {}, evJoin[8][2] = {};
+    int instSimpleOpt = 1;                // "inst_simple": classes 0 / 2 of instanced scenes on the MASK_SIMPLE_INST variant instead of MASK_FULL
     int classStreamsOpt = 0;              // measured: 735-800 Msamples/s against 825-830 with the classes one after the other on the part's stream
     hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the half's stream)
     hipEvent_t evPart[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, evMain = nullptr;
@@ -689,6 +692,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "streams") { ctx->streamsOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "class_streams") ctx->classStreamsOpt = value != 0;
+    else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1018,7 +1022,7 @@ template<uint32_t M, int FUSE>
 static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
     constexpr uint32_t B = M & ~FEAT_QMC;
-    hipLaunchKernelGGL((k_shade<M, (B == MASK_SIMPLE ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
+    hipLaunchKernelGGL((k_shade<M, ((B == MASK_SIMPLE || B == MASK_SIMPLE_INST) ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
                        dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : cls == 1 ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->launchStream, ctx->scene, st, pp, cls);
 }
 // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
@@ -1191,7 +1195,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             // for 2 to 24 hardware queues): with four parts in flight the chip is not short of independent launches.
             auto shadeClass = [&](int cls) {
                 if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, cls);   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER
-                else if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);   // the only variants with mesh-emitter sampling / instance transforms
+                else if (ctx->haveInstances && !ctx->haveMeshLight && cls != 1 && ctx->instSimpleOpt) launchShade<MASK_SIMPLE_INST>(ctx, grid, st, pp, cls);   // Lambert / escaped paths of instanced scenes
+                else if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);   // the only variants with mesh-emitter sampling / instance transforms (every BSDF type)
                 else if (cls != 1) {             // class 2 runs the class-0 variant: its surface code never runs there, so the launch is short
                     if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, cls);
                     else                launchShade<MASK_SIMPLE>(ctx, grid, st, pp, cls);
