@@ -126,6 +126,7 @@ struct PathState {
     const uint32_t * __restrict__ abort_flag;   // non-zero: tghip_abort was called (one word that lives as long as the context, outside the pool)
     uint32_t num_slots, slots_per_block;
     uint32_t leaf_batch;                   // dynamic-fetch traversal: lanes waiting at a leaf before the leaf code runs (1 = at once)
+    uint32_t leaf_batch_bvh2;              // the same for the BVH2 dynamic-fetch kernels (k_trace_closest_dyn / k_trace_shadow_dyn)
 };
 
 PT_DEV uint32_t slotOffset(const PathState &st, uint32_t a, uint32_t slot)     // `a` is a literal at every call site: the selects fold

@@ -313,7 +313,10 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
 // the traversal loop.  One loop iteration advances every busy lane by one BVH node or one leaf.
 // Dynamic LDS: [expanded queue, 2 B per slot][node stacks, bvhDepth ints per thread].
 // SOLIDS: the scene has cube / sphere / disk records somewhere; without them only triangle and quad tests are compiled in
-template<bool COUNT, bool SOLIDS = true>
+// INST: two-level scenes -- a leaf of the top level holds one instance record; reaching it sends the ray into the master's space and
+// the walk on to the master's subtree on the same stack (traverseClosestInst is the same walk, one ray at a time); the instance a hit
+// was reached through goes to the spare word A_EMI.w
+template<bool COUNT, bool SOLIDS = true, bool INST = false>
 __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsDyn[];
@@ -336,6 +339,8 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
     float tmax = 0.0f;
     float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     int cur = 0, sp = 0;
+    f3 wo = splat3(0.0f), wd = splat3(1.0f);     // INST: the world-space ray while the walk is inside an instance
+    int instSp = -1, curInst = -1, hitInst = -1; // INST: stack level at which the instance was entered; the instance; the hit's instance
     bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
@@ -358,6 +363,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
                     tmax = ray.tmax;
                     hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
                     cur = 0; sp = 0;
+                    if (INST) { wo = ray.o; wd = ray.d; instSp = -1; curInst = -1; hitInst = -1; }
                     busy = true;
                     rays++;
                 }
@@ -392,21 +398,48 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
             unsigned long long atLeaf = __ballot(busy && cur < 0 && !pop);
             unsigned long long atNode = __ballot(busy && (cur >= 0 || pop));
             // process leaves when a good part of the wave waits for it, or nobody has node work left
-            if (atLeaf != 0ull && ((uint32_t)__popcll(atLeaf) >= st.leaf_batch || atNode == 0ull)) {
+            if (atLeaf != 0ull && ((uint32_t)__popcll(atLeaf) >= st.leaf_batch_bvh2 || atNode == 0ull)) {
                 if (busy && cur < 0 && !pop) {
                     uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
-                    for (uint32_t r = firstRec; r < firstRec + count; ++r) {
-                        if (COUNT) prims++;
-                        testRecord<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, r, ray, tmax, hit);
+                    bool entered = false;
+                    if (INST && curInst < 0) {
+                        float4 r0 = at32(s.recs, firstRec*3u);
+                        if (TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE) {   // (alone in its leaf)
+                            if (COUNT) prims++;
+                            float4 r1 = at32(s.recs, firstRec*3u + 1u), r2 = at32(s.recs, firstRec*3u + 2u);
+                            f3 qc = -xyz(r1);                   // conjugate(): the inverse rotation (instanceEnter)
+                            ray.o = quatRotate(r1.w, qc, wo - xyz(r0));
+                            ray.d = quatRotate(r1.w, qc, wd);
+                            invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
+                            curInst = (int)firstRec;
+                            instSp = sp;
+                            cur = (int)__float_as_uint(r2.x);
+                            entered = true;
+                        }
                     }
-                    pop = true;
+                    if (!entered) {
+                        for (uint32_t r = firstRec; r < firstRec + count; ++r) {
+                            if (COUNT) prims++;
+                            uint32_t meta;
+                            if (testRecord<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, r, ray, tmax, hit, meta)) {
+                                if (INST) hitInst = curInst;
+                            }
+                        }
+                        pop = true;
+                    }
                 }
             }
         }
         if (busy && pop) {
+            if (INST && instSp >= 0 && sp == instSp) {   // the master's subtree is done: back to world space (instanceLeave)
+                ray.o = wo; ray.d = wd;
+                invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
+                instSp = -1; curInst = -1;
+            }
             if (sp == 0) {
                 // finished: publish the hit and bin the path by shading class
                 slotF4(st, A_HIT, slot) = hit;
+                if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
                 int ri = __float_as_int(hit.w);
                 int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
                 queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);

@@ -61,6 +61,7 @@ struct tghip_ctx {
     hipStream_t partStream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // streams of parts 1..3 of the split wavefront loop ("streams" option)
     hipStream_t classStream[8][2] = {};   // per part: the streams of the shading classes that run beside the part's own ("class_streams" option)
     hipEvent_t evFork[8] = {}, evJoin[8][2] = {};
+    int instDynOpt = 1;                   // "inst_dyn": closest-hit rays of instanced scenes on the dynamic-fetch two-level BVH2 kernel
     int instSimpleOpt = 1;                // "inst_simple": classes 0 / 2 of instanced scenes on the MASK_SIMPLE_INST variant instead of MASK_FULL
     int classStreamsOpt = 0;              // measured: 735-800 Msamples/s against 825-830 with the classes one after the other on the part's stream
     hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the half's stream)
@@ -157,6 +158,7 @@ struct tghip_ctx {
     bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
     int leafBatch = 1;                    // "leaf_batch" (PathState::leaf_batch)
+    int leafBatchBvh2 = 0;                // "leaf_batch_bvh2" (PathState::leaf_batch_bvh2); 0 = leaf_batch, or the measured value for two-level scenes
     bool poolRecords = false;             // "pool_layout" option: 1 = slot records (PathState::records)
     long long poolPad = 9472;             // bytes between the per-slot arrays of the pool (multiple of 16)
     bool dynamicFetch = true;             // BVH scenes: closest-hit kernel with dynamic ray fetch (k_trace_closest_dyn)
@@ -532,6 +534,7 @@ static void chooseThreads(tghip_ctx *ctx)
     ctx->thrClosest = wideC && inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false, true>, 192, 3))
                     : wideC ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 192, 3))
                     : flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
+                    : (inst && ctx->dynamicFetch && ctx->instDynOpt) ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false, true>, 320, 2))
                     : inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest<false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_closest<false, false, 2>, 512, 1))
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
@@ -693,8 +696,10 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "streams") { ctx->streamsOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "class_streams") ctx->classStreamsOpt = value != 0;
     else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
+    else if (k == "inst_dyn") { ctx->instDynOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "leaf_batch_bvh2") ctx->leafBatchBvh2 = int(std::min<long long>(std::max<long long>(value, 0), 64));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
     else if (k == "run_to_completion") ctx->loopOpt = value != 0;
@@ -1088,6 +1093,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     st.partial = ctx->partial;
     st.abort_flag = ctx->abortFlagDev;
     st.leaf_batch = uint32_t(ctx->leafBatch);
+    st.leaf_batch_bvh2 = uint32_t(ctx->leafBatchBvh2 > 0 ? ctx->leafBatchBvh2 : ctx->haveInstances ? 16 : ctx->leafBatch);
     const DeviceScene &s = ctx->scene;
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
@@ -1160,6 +1166,13 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             if (flat) {
                 if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
                 else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
+            } else if (ctx->haveInstances && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt) {
+                // two-level BVH2 walk with dynamic ray fetch
+                const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
+#define CLOSEST_DYN_INST(C, S) hipLaunchKernelGGL((k_trace_closest_dyn<C, S, true>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->launchStream, s, st)
+                if (ctx->haveSolids) { if (count) CLOSEST_DYN_INST(true, true); else CLOSEST_DYN_INST(false, true); }
+                else                 { if (count) CLOSEST_DYN_INST(true, false); else CLOSEST_DYN_INST(false, false); }
+#undef CLOSEST_DYN_INST
             } else if (ctx->haveInstances && !wideClosest(ctx)) {
 #define CLOSEST_INST(C, I) hipLaunchKernelGGL((k_trace_closest<C, false, I>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st)
                 if (ctx->haveSolids) { if (count) CLOSEST_INST(true, 1); else CLOSEST_INST(false, 1); }
