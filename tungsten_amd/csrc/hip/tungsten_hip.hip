@@ -519,8 +519,11 @@ static void chooseThreads(tghip_ctx *ctx)
     // Single-level BVH scenes run the loop as two half-pools on two streams (runBatch), each kernel launched with HALF the grid: with 8
     // workgroups per CU a kernel of one half and a kernel of the other share every CU, four workgroups each, and the issue-bound walk of the
     // one fills the memory waits of the shading of the other (materialtest 1280x720x256: 608 -> 657 Msamples/s against 4 per CU; workgroup
-    // sizes below from the same sweep, profiles/README.md).  Instanced scenes keep one stream and 4 per CU (measured: 127 against 114-120).
-    const bool paired = !flat && !ctx->haveInstances && ctx->streamsOpt != 1 && wideClosest(ctx) && wideShadowRays(ctx);
+    // sizes below from the same sweep, profiles/README.md).  Instanced scenes with the dynamic-fetch closest-hit kernel: two parts, 8 per CU
+    // (instances10k: 141 -> 153 Msamples/s; with the static-fetch kernel of the first half of the round parts lost: 127 against 114-120).
+    const bool pairedInst = !flat && ctx->haveInstances && ctx->streamsOpt != 1 && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt && wideShadowRays(ctx) &&
+                            !ctx->haveForward && !ctx->haveMeshLight;
+    const bool paired = (!flat && !ctx->haveInstances && ctx->streamsOpt != 1 && wideClosest(ctx) && wideShadowRays(ctx)) || pairedInst;
     ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : ((flat || paired) ? 8 : 4);
     if (flat && ctx->blocksPerCuOpt == 0) {
         ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
@@ -562,7 +565,7 @@ static void chooseThreads(tghip_ctx *ctx)
     if (paired && ctx->blocksPerCuOpt == 0) {
         // (closest / shadow / shade simple / shade complex, Msamples/s: 256/256/128/128 657, 192/256/128/128 634, 128/256/128/128 623,
         //  320/256/128/128 556, 256/320/128/128 549, 256/256/256/128 646, 256/256/128/64 623; 4 per CU with 192/256/192/128: 608)
-        ctx->thrClosest = 256;
+        ctx->thrClosest = pairedInst ? 192 : 256;
         if (!ctx->haveForward && !ctx->haveMeshLight) ctx->thrShadow = 256;
         ctx->thrShadeSimple = ctx->thrShadeComplex = 128;
     }
@@ -1122,7 +1125,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     // wavefront loop on N streams: kernels of different parts share the CUs (chooseThreads), and the drain tail of one part's kernel
     // overlaps the other parts' kernels
     // (materialtest 1280x720x256 / mesh1m 1920x1080x32 on one box: 2 parts 656 / 398 Msamples/s, 4 parts 666 / 412)
-    int parts = ctx->streamsOpt >= 2 ? ctx->streamsOpt : (ctx->streamsOpt == 0 && !ctx->haveInstances) ? 4 : 1;
+    int parts = ctx->streamsOpt >= 2 ? ctx->streamsOpt : ctx->streamsOpt == 1 ? 1 : !ctx->haveInstances ? 4 : ctx->blocksPerCu >= 8 ? 2 : 1;
     if (fused || flat || st.records || grid < 2*parts || grid % parts != 0 || pp.total_items < uint32_t(2*parts)*PT_ITEM_GROUP)
         parts = 1;
     const bool halves = parts > 1;
