@@ -165,6 +165,40 @@ def test_passes_and_pool_geometry_do_not_change_the_image(tmp_path):
     assert (again == base).all(), "same configuration must be bit-reproducible"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["materialtest", "cornell_instances"])
+def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
+    """How the wavefront loop is scheduled -- parts of the pool on several streams, shading classes on streams of their own, slots per
+    workgroup, pool size, host check interval, the instanced scenes' closest-hit / shading variants -- moves work between launches,
+    never between (pixel, sample) streams: per-pixel sums are accumulated per work item and resolved in fixed chunk order, so every
+    configuration gives the bit-identical image."""
+    _skip_mt(scene)
+    if scene == "materialtest":
+        path = scenes.materialtest(tmp_path, resolution=(192, 108), spp=8)
+    else:
+        mk, kw = scenes.GOLDEN_CASES[scene]
+        path = mk(tmp_path, **dict(kw, resolution=(160, 90), spp=8))
+    base, _, cnt, _ = gpu_render(path)
+    assert (cnt == 8).all() and np.isfinite(base).all()
+    variants = [dict(streams=1), dict(streams=2), dict(streams=8), dict(class_streams=1), dict(streams=1, class_streams=1),
+                dict(slots_per_block=512), dict(max_slots=8192), dict(check_interval=1), dict(check_interval=16), dict(blocks_per_cu=4),
+                dict(grid_rounds=2), dict(leaf_batch=9), dict(streams=4, blocks_per_cu=4, check_interval=4)]
+    if scene == "cornell_instances":
+        variants += [dict(inst_dyn=0), dict(inst_simple=0), dict(wide_closest=1), dict(wide_shadow=0), dict(leaf_batch_bvh2=1)]
+    for opts in variants:
+        img, _, c, _ = gpu_render(path, **opts)
+        assert (c == 8).all(), opts
+        assert (img == base).all(), "image changed with %r" % (opts,)
+    # samples per work item: the same samples in other partial sums (the order of the float additions changes, nothing else); one
+    # sample per item is also the configuration in which the parts of the pool drift furthest apart (the liveness word takes the
+    # MAXIMUM of the iteration tags for that reason)
+    for chunk in (1, 2, 3):
+        for opts in (dict(chunk_samples=chunk), dict(chunk_samples=chunk, check_interval=4), dict(chunk_samples=chunk, streams=4, blocks_per_cu=4)):
+            img, _, c, _ = gpu_render(path, **opts)
+            assert (c == 8).all(), opts
+            assert np.allclose(img, base, rtol=1e-5, atol=1e-6), opts
+
+
 def test_tile_shards_partition_the_image(tmp_path):
     """The multi-GPU decomposition (16x16 tiles round-robin over shards) on one device: shard
     framebuffers are disjoint and sum to the unsharded image exactly."""

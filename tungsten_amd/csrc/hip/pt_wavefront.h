@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, Pass
     bool any = queuesEnd(L, st, -1, (1u << Q_COUNT) - 1u);   // every bitmap is (re)initialised here
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
-        if (any) st.live[0] = 1u;
+        if (any) atomicMax(&st.live[0], 1u);
     }
 }
 #endif
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             ctl.closest_rays += L.closest_rays; ctl.shadow_rays += L.shadow_rays;
             st.stats[blockIdx.x].prims_tested += L.prims;
             // fused mode has no k_trace_shadow launch: the last shading launch of the iteration reports liveness
-            if (anyExt) st.live[0] = (uint32_t)pp.iter_tag;
+            if (anyExt) atomicMax(&st.live[0], (uint32_t)pp.iter_tag);
         }
     }
 }
@@ -1429,7 +1429,7 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
             bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
         }
         // last kernel of the iteration: tell the host whether any extension queue still holds work
-        if (anyExt) st.live[0] = iterTag;
+        if (anyExt) atomicMax(&st.live[0], iterTag);   // (max: the parts of the pool run on streams of their own and pass here out of order)
     }
 }
 
@@ -1831,7 +1831,7 @@ __global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, Pas
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples;
-        if (anyExt) st.live[0] = iterTag;
+        if (anyExt) atomicMax(&st.live[0], iterTag);   // (max: the parts of the pool run on streams of their own and pass here out of order)
     }
 }
 #endif
