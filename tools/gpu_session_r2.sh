@@ -31,6 +31,8 @@ for scene in materialtest mesh1m instances10k cornell; do
   [ -n "$fs" ] && python tools/pmc_sq.py $scene $fs $out/sq_counters.json > /dev/null
   rm -rf $out/pmc_${scene}_SQ
 done
+echo "== instances10k at BASELINE configs[4]'s own size"
+timeout 300 python bench.py --scene instances10k --res 3840x2160 --spp 16 --no-extra --no-cpu-baseline --no-traffic > $out/bench_instances10k_4k.json 2> $out/bench_instances10k_4k.err; echo "rc=$?"; cut -c1-200 $out/bench_instances10k_4k.json
 echo "== emulated tile-shard scaling (shard 0 of N on one GPU, no reduce)"
 for scene in materialtest cornell; do
   for n in 1 2 4 8; do
