@@ -64,7 +64,7 @@ struct tghip_ctx {
     int instDynOpt = 1;                   // "inst_dyn": closest-hit rays of instanced scenes on the dynamic-fetch two-level BVH2 kernel
     int instSimpleOpt = 1;                // "inst_simple": classes 0 / 2 of instanced scenes on the MASK_SIMPLE_INST variant instead of MASK_FULL
     int classStreamsOpt = 0;              // measured: 735-800 Msamples/s against 825-830 with the classes one after the other on the part's stream
-    hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the half's stream)
+    hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the stream of the part being launched)
     hipEvent_t evPart[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, evMain = nullptr;
     int streamsOpt = 0;                   // "streams": 1 .. 4 parts of the pool on as many streams, 0 = the measured default (four for single-level
                                           // BVH scenes; instanced scenes lose 2.5 % with two)
@@ -513,14 +513,14 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
 static void chooseThreads(tghip_ctx *ctx)
 {
     const bool flat = isFlat(ctx);
-    // Measured (profiles/README.md): BVH scenes are latency-bound and run best with every workgroup of every
-    // kernel resident at once (4 per CU, workgroup size per kernel = that kernel's occupancy limit / 4); flat-list
-    // scenes are streaming-bound and prefer 8 small workgroups per CU that the dispatcher load-balances.
-    // Single-level BVH scenes run the loop as two half-pools on two streams (runBatch), each kernel launched with HALF the grid: with 8
-    // workgroups per CU a kernel of one half and a kernel of the other share every CU, four workgroups each, and the issue-bound walk of the
-    // one fills the memory waits of the shading of the other (materialtest 1280x720x256: 608 -> 657 Msamples/s against 4 per CU; workgroup
-    // sizes below from the same sweep, profiles/README.md).  Instanced scenes with the dynamic-fetch closest-hit kernel: two parts, 8 per CU
-    // (instances10k: 141 -> 153 Msamples/s; with the static-fetch kernel of the first half of the round parts lost: 127 against 114-120).
+    // Measured (profiles/README.md).  On one stream BVH scenes run best with every workgroup of every kernel resident at once
+    // (4 per CU, workgroup size per kernel = that kernel's occupancy limit / 4: the fallback kernels still run so); flat-list scenes are
+    // streaming-bound and prefer 8 small workgroups per CU that the dispatcher load-balances.
+    // Scenes on the wide kernels run the loop as PARTS of the pool on streams of their own (runBatch), each kernel launched with its part
+    // of the grid: with 8 workgroups per CU kernels of different parts share every CU, and the issue-bound walk of one part fills the
+    // memory waits of the shading of another (materialtest 1280x720x256: 608 -> 657 Msamples/s against 4 per CU; workgroup sizes below
+    // from the same sweep).  Instanced scenes with the dynamic-fetch closest-hit kernel: two parts, 8 per CU (instances10k: 141 -> 153
+    // Msamples/s; with the static-fetch kernel parts lost: 127 against 114-120).
     const bool pairedInst = !flat && ctx->haveInstances && ctx->streamsOpt != 1 && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt && wideShadowRays(ctx) &&
                             !ctx->haveForward && !ctx->haveMeshLight;
     const bool paired = (!flat && !ctx->haveInstances && ctx->streamsOpt != 1 && wideClosest(ctx) && wideShadowRays(ctx)) || pairedInst;
@@ -529,7 +529,7 @@ static void chooseThreads(tghip_ctx *ctx)
         ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
     } else {
     const bool inst = ctx->haveInstances;
-    const bool dyn = ctx->dynamicFetch && !inst;               // the dynamic-fetch kernels are single-level
+    const bool dyn = ctx->dynamicFetch && !inst;               // (the two-level dynamic-fetch kernel is chosen by instDynOpt below)
     const bool wide = useWide(ctx);
     const bool wideC = wideClosest(ctx), wideS = wideShadowRays(ctx);
     // (wide closest-hit kernel, materialtest 1280x720x256 / mesh1m, one MI355X: 128 / 192 / 256 / 320 threads = 505 / 433 / 394 / 469 us per
@@ -1128,33 +1128,33 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     int parts = ctx->streamsOpt >= 2 ? ctx->streamsOpt : ctx->streamsOpt == 1 ? 1 : !ctx->haveInstances ? 4 : ctx->blocksPerCu >= 8 ? 2 : 1;
     if (fused || flat || st.records || grid < 2*parts || grid % parts != 0 || pp.total_items < uint32_t(2*parts)*PT_ITEM_GROUP)
         parts = 1;
-    const bool halves = parts > 1;
-    PathState stHalf[8] = {st, st, st, st, st, st, st, st};
-    PassParams ppHalf[8] = {pp, pp, pp, pp, pp, pp, pp, pp};
+    const bool split = parts > 1;
+    PathState stPart[8] = {st, st, st, st, st, st, st, st};
+    PassParams ppPart[8] = {pp, pp, pp, pp, pp, pp, pp, pp};
     hipStream_t streamOf[8] = {ctx->stream, ctx->partStream[0], ctx->partStream[1], ctx->partStream[2], ctx->partStream[3], ctx->partStream[4], ctx->partStream[5], ctx->partStream[6]};
-    if (halves) {
+    if (split) {
         const uint32_t groups = (pp.total_items + PT_ITEM_GROUP - 1)/PT_ITEM_GROUP;
         uint32_t itemBegin = 0;
         for (int k = 0; k < parts; ++k) {
             const uint32_t off = uint32_t(grid/parts)*uint32_t(k);
-            stHalf[k].pool = st.pool + size_t(off)*st.slots_per_block*16u;
-            stHalf[k].bm = st.bm + size_t(off)*(st.slots_per_block >> 5);
-            stHalf[k].ctl = st.ctl + off;
-            stHalf[k].stats = st.stats + off;
-            stHalf[k].num_slots = st.num_slots/uint32_t(parts);
+            stPart[k].pool = st.pool + size_t(off)*st.slots_per_block*16u;
+            stPart[k].bm = st.bm + size_t(off)*(st.slots_per_block >> 5);
+            stPart[k].ctl = st.ctl + off;
+            stPart[k].stats = st.stats + off;
+            stPart[k].num_slots = st.num_slots/uint32_t(parts);
             const uint32_t itemEnd = k + 1 == parts ? pp.total_items : std::min(pp.total_items, uint32_t((uint64_t(groups)*(k + 1) + parts - 1)/parts)*PT_ITEM_GROUP);
-            ppHalf[k].item_begin = pp.item_begin + itemBegin;
-            ppHalf[k].total_items = itemEnd - itemBegin;
+            ppPart[k].item_begin = pp.item_begin + itemBegin;
+            ppPart[k].total_items = itemEnd - itemBegin;
             itemBegin = itemEnd;
         }
     }
     HIP_TRY(ctx, hipMemsetAsync(st.partial, 0, size_t(pp.total_items)*sizeof(float4), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(st.live, 0, sizeof(uint32_t), ctx->stream));
-    if (halves) {
+    if (split) {
         HIP_TRY(ctx, hipEventRecord(ctx->evMain, ctx->stream));            // (the memsets above come first for the other streams as well)
         for (int k = 0; k < parts; ++k) {
             if (k) HIP_TRY(ctx, hipStreamWaitEvent(streamOf[k], ctx->evMain, 0));
-            hipLaunchKernelGGL(k_start, dim3(grid/parts), dim3(256), 0, streamOf[k], s, stHalf[k], ppHalf[k]);
+            hipLaunchKernelGGL(k_start, dim3(grid/parts), dim3(256), 0, streamOf[k], s, stPart[k], ppPart[k]);
         }
     } else {
         hipLaunchKernelGGL(k_start, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp);
@@ -1162,7 +1162,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     uint32_t iterTag = 1;                        // k_start publishes tag 1 when it queued anything
     bool first = true;
     int roundIters = checkInterval;              // launches of the wavefront loop between two host checks
-        // the launches of one wavefront iteration over the workgroups [0, grid) of `st` (the whole pool, or one half of it)
+        // the launches of one wavefront iteration over the workgroups [0, grid) of `st` (the whole pool, or one part of it)
         auto launchIteration = [&](const PathState &st, const PassParams &pp, int grid, uint32_t iterTag, bool timed, int part) {
             auto tic = [&]() { if (timed) ticMain(); };
             tic();
@@ -1269,7 +1269,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                     *acc[k % 3] += double(parts)*ms;
                 }
                 // (split loop: the events bracket the launches of part 0; the other parts' launches, as long on average, are
-                // counted with them so that bytes per launch and time per launch refer to the same half-pool launches)
+                // counted with them so that bytes per launch and time per launch refer to the same part launches)
                 const int perIter = parts;
                 ctx->counters.launches_trace_closest += roundIters*perIter;
                 ctx->counters.launches_trace_shadow += roundIters*perIter;
@@ -1302,10 +1302,10 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 ctx->counters.iterations++;
                 continue;
             }
-            if (halves) {
+            if (split) {
                 for (int k = 0; k < parts; ++k) {
                     ctx->launchStream = streamOf[k];
-                    launchIteration(stHalf[k], ppHalf[k], grid/parts, iterTag, k == 0, k);
+                    launchIteration(stPart[k], ppPart[k], grid/parts, iterTag, k == 0, k);
                 }
                 ctx->launchStream = ctx->stream;
             } else {
