@@ -436,6 +436,12 @@ def _thinlens_blade(blades, angle=None):
 # n-blade aperture (textures/BladeTexture.cpp): the lens point is a uniform point of one of the polygon's triangles
 GOLDEN_CASES["cornell_thinlens_blade5"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_blade(5, 0.3)))
 GOLDEN_CASES["cornell_thinlens_blade6"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_blade(6)))
+def _thinlens_pivot(scene):
+    scene["camera"].update(type="thinlens", focus_distance=1.0, aperture_size=0.12, cateye=0.0, focus_pivot="tallBox")
+
+
+# focus on a primitive (ThinlensCamera.cpp:206-218): the focus distance is the distance to the origin of the named primitive's frame
+GOLDEN_CASES["cornell_thinlens_pivot"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_pivot))
 GOLDEN_CASES["cornell_thinlens_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens(0.0), renderer={"stratified_sampler": True}))
 
 def _disks(scene):

@@ -1072,8 +1072,17 @@ void Camera::fromJson(const JsonValue &v, const Scene &scene)
         v.getField("focus_distance", focusDist);
         v.getField("aperture_size", apertureSize);
         v.getField("cateye", catEye);
-        if (v["focus_pivot"])
-            throw JsonLoadException("thinlens 'focus_pivot' is outside the path_tracer_hip hot-path scope");
+        std::string focusPivot;
+        if (v.getField("focus_pivot", focusPivot) && !focusPivot.empty()) {
+            // ThinlensCamera::prepareForRender (cameras/ThinlensCamera.cpp:206-218): focus on the origin of the named primitive's frame
+            const Primitive *pivot = nullptr;
+            for (const auto &p : scene.primitives)
+                if (p->name == focusPivot) { pivot = p.get(); break; }
+            if (pivot)
+                focusDist = (pivot->transform*Vec3f(0.0f) - pos).length();
+            else
+                std::fprintf(stderr, "Warning: Focus pivot '%s' for thinlens camera not found\n", focusPivot.c_str());
+        }
         if (const JsonValue &ap = v["aperture"]) {
             std::string apType;
             if (ap.isObject() && ap.getField("type", apType) && apType == "blade") {
