@@ -61,6 +61,7 @@ struct tghip_ctx {
     hipStream_t partStream[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // streams of parts 1..3 of the split wavefront loop ("streams" option)
     hipStream_t classStream[8][2] = {};   // per part: the streams of the shading classes that run beside the part's own ("class_streams" option)
     hipEvent_t evFork[8] = {}, evJoin[8][2] = {};
+    bool shortBatch = false;              // the pass being rendered does not fill the pool once: one stream, 4 workgroups per CU (tghip_render_pass)
     int instDynOpt = 1;                   // "inst_dyn": closest-hit rays of instanced scenes on the dynamic-fetch two-level BVH2 kernel
     int instSimpleOpt = 1;                // "inst_simple": classes 0 / 2 of instanced scenes on the MASK_SIMPLE_INST variant instead of MASK_FULL
     int classStreamsOpt = 0;              // measured: 735-800 Msamples/s against 825-830 with the classes one after the other on the part's stream
@@ -521,9 +522,10 @@ static void chooseThreads(tghip_ctx *ctx)
     // memory waits of the shading of another (materialtest 1280x720x256: 608 -> 657 Msamples/s against 4 per CU; workgroup sizes below
     // from the same sweep).  Instanced scenes with the dynamic-fetch closest-hit kernel: two parts, 8 per CU (instances10k: 141 -> 153
     // Msamples/s; with the static-fetch kernel parts lost: 127 against 114-120).
-    const bool pairedInst = !flat && ctx->haveInstances && ctx->streamsOpt != 1 && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt && wideShadowRays(ctx) &&
+    const bool oneStream = ctx->streamsOpt == 1 || (ctx->streamsOpt == 0 && ctx->shortBatch);   // (shortBatch: tghip_render_pass)
+    const bool pairedInst = !flat && ctx->haveInstances && !oneStream && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt && wideShadowRays(ctx) &&
                             !ctx->haveForward && !ctx->haveMeshLight;
-    const bool paired = (!flat && !ctx->haveInstances && ctx->streamsOpt != 1 && wideClosest(ctx) && wideShadowRays(ctx)) || pairedInst;
+    const bool paired = (!flat && !ctx->haveInstances && !oneStream && wideClosest(ctx) && wideShadowRays(ctx)) || pairedInst;
     ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : ((flat || paired) ? 8 : 4);
     if (flat && ctx->blocksPerCuOpt == 0) {
         ctx->thrClosest = ctx->thrShadow = ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
@@ -1125,7 +1127,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     // wavefront loop on N streams: kernels of different parts share the CUs (chooseThreads), and the drain tail of one part's kernel
     // overlaps the other parts' kernels
     // (materialtest 1280x720x256 / mesh1m 1920x1080x32 on one box: 2 parts 656 / 398 Msamples/s, 4 parts 666 / 412)
-    int parts = ctx->streamsOpt >= 2 ? ctx->streamsOpt : ctx->streamsOpt == 1 ? 1 : !ctx->haveInstances ? 4 : ctx->blocksPerCu >= 8 ? 2 : 1;
+    int parts = ctx->streamsOpt >= 2 ? ctx->streamsOpt : (ctx->streamsOpt == 1 || ctx->shortBatch) ? 1 : !ctx->haveInstances ? 4 : ctx->blocksPerCu >= 8 ? 2 : 1;
     if (fused || flat || st.records || grid < 2*parts || grid % parts != 0 || pp.total_items < uint32_t(2*parts)*PT_ITEM_GROUP)
         parts = 1;
     const bool split = parts > 1;
@@ -1513,6 +1515,16 @@ int tghip_wait(tghip_ctx *ctx)
             tilesPerBatch = uint32_t(std::max<uint64_t>(1, maxItems/(256ull*chunksPerBatch)));
     }
     const uint64_t batchItems = recordPass ? std::min<uint64_t>(recordItems, maxItems) : uint64_t(tilesPerBatch)*256*chunksPerBatch;
+    {
+        // A pass whose work items fill less than half the pool never refills a slot: it is one long drain, every iteration of which
+        // pays the fixed cost of its launches.  Such passes (the 16-spp passes of the as-shipped materialtest: 3.7 M items) run on ONE
+        // stream with 4 workgroups per CU -- 431 against 372 Msamples/s with four parts.  (chooseThreads picks grid and workgroup sizes)
+        const bool shortBatch = 2u*batchItems <= uint64_t(ctx->maxSlots);   // (one rank's share of an 8-GPU render of the metric's workload, 7.4 M items, stays on four parts)
+        if (shortBatch != ctx->shortBatch) {
+            ctx->shortBatch = shortBatch;
+            chooseThreads(ctx);
+        }
+    }
     uint64_t wantSlots = std::min<uint64_t>(uint64_t(ctx->maxSlots), batchItems);
     {
         // the run-to-completion kernel (runBatch) gives every thread its own slots for the whole launch: one slot per
