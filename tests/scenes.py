@@ -242,6 +242,59 @@ GOLDEN_CASES = {
 }
 
 
+def write_png(path, img, color_type, depth=8, filters=(0, 1, 2, 3, 4), level=6, palette=None, idat_chunks=1):
+    """A PNG (RFC 2083) of `img` ([h, w] or [h, w, channels] integers of `depth` bits) with the given colour type, the scanline filters
+    cycling through `filters`, zlib level `level` (0 = stored blocks, 1 = mostly fixed codes, 9 = dynamic codes); test input for the
+    host's decoder (tungsten_amd/csrc/host/ImageIO.cpp: loadPng)."""
+    import struct
+    import zlib
+    import numpy as np
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color_type]
+    a = img.reshape(h, w, ch).astype(np.uint32)
+    if depth == 16:
+        rows = np.stack([(a >> 8) & 255, a & 255], axis=-1).reshape(h, -1).astype(np.uint8)
+    elif depth == 8:
+        rows = a.reshape(h, -1).astype(np.uint8)
+    else:                                       # 1 / 2 / 4 bits: packed, most significant bits first, rows padded to bytes
+        per = 8//depth
+        vals = a.reshape(h, -1)
+        pad = (-vals.shape[1]) % per
+        vals = np.concatenate([vals, np.zeros((h, pad), np.uint32)], axis=1).reshape(h, -1, per)
+        rows = sum((vals[:, :, k] << (8 - depth*(k + 1))) for k in range(per)).astype(np.uint8)
+    bpp = max(1, ch*depth//8)
+    raw = bytearray()
+    prev = np.zeros(rows.shape[1], np.int32)
+    for y in range(h):
+        cur = rows[y].astype(np.int32)
+        f = filters[y % len(filters)]
+        left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+        upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+        if f == 0: out = cur
+        elif f == 1: out = cur - left
+        elif f == 2: out = cur - prev
+        elif f == 3: out = cur - (left + prev)//2
+        else:
+            pa, pb, pc = np.abs(prev - upleft), np.abs(left - upleft), np.abs(left + prev - 2*upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            out = cur - pred
+        raw.append(f)
+        raw += bytes((out & 255).astype(np.uint8))
+        prev = cur
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    z = zlib.compress(bytes(raw), level)
+    parts = [z[i*len(z)//idat_chunks:(i + 1)*len(z)//idat_chunks] for i in range(idat_chunks)]
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, 0)))
+        if palette is not None:
+            f.write(chunk(b"PLTE", bytes(np.asarray(palette, np.uint8).reshape(-1))))
+        for p in parts:
+            f.write(chunk(b"IDAT", p))
+        f.write(chunk(b"IEND", b""))
+
+
 # ---- BASELINE.json configs[3]: a procedurally generated ~1M-triangle mesh under an HDRI (or constant) environment ----
 def write_wo3(path, verts, tris):
     """MeshIO .wo3 (io/MeshIO.cpp:12-28): u64 numVerts, Vertex{pos3, normal3, uv2} f32, u64 numTris, TriangleI{v0,v1,v2 u32, material i32}."""
@@ -436,6 +489,31 @@ def _thinlens_blade(blades, angle=None):
 # n-blade aperture (textures/BladeTexture.cpp): the lens point is a uniform point of one of the polygon's triangles
 GOLDEN_CASES["cornell_thinlens_blade5"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_blade(5, 0.3)))
 GOLDEN_CASES["cornell_thinlens_blade6"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_blade(6)))
+def cornell_png(tmpdir, **kw):
+    """The Cornell box with 8-bit bitmap textures (textures/BitmapTexture.cpp with RGB_LDR texels): a smooth colour pattern on the floor
+    (gamma-corrected, interpolated), a raw nearest-neighbour one on the back wall; the .png files are written next to the scene."""
+    import numpy as np
+    tmpdir = str(tmpdir)
+    y, x = np.mgrid[0:48, 0:64]
+    img = np.stack([(x*4) % 256, (y*5 + x) % 256, (255 - x*3 - y*2) % 256], axis=-1)
+    write_png(os.path.join(tmpdir, "floor_tex.png"), img, 2, filters=(4, 1, 2), level=9)
+    write_png(os.path.join(tmpdir, "wall_tex.png"), (img[::4, ::4] // 32)*32 + 16, 2, filters=(0,), level=6)
+
+    def edit(scene):
+        scene["bsdfs"].append({"name": "floorTex", "type": "lambert", "albedo": "floor_tex.png"})
+        scene["bsdfs"].append({"name": "wallTex", "type": "lambert",
+                               "albedo": {"type": "bitmap", "file": "wall_tex.png", "gamma_correct": False, "interpolate": False}})
+        for p in scene["primitives"]:
+            if p.get("name") == "floor":
+                p["bsdf"] = "floorTex"
+            if p.get("name") == "backWall":
+                p["bsdf"] = "wallTex"
+    return cornell(tmpdir, edit=edit, **kw)
+
+
+GOLDEN_CASES["cornell_png_textures"] = (cornell_png, dict(resolution=(48, 27), spp=8))
+
+
 def _thinlens_pivot(scene):
     scene["camera"].update(type="thinlens", focus_distance=1.0, aperture_size=0.12, cateye=0.0, focus_pivot="tallBox")
 

@@ -306,3 +306,74 @@ def test_instance_boxes_are_tight_and_lose_no_hit(tmp_path, monkeypatch):
         assert nt < 0.95*nl, (wide, nt, nl)
     tight.close()
     loose.close()
+
+
+def _bitmap_of(desc, w, h):
+    """texels (float32 [h, w, c]) of the first bitmap texture of that size in the flattened scene"""
+    d = desc.contents
+    for i in range(d.num_textures):
+        t = d.textures[i]
+        if t.type == 2 and t.w == w and t.h == h:
+            c = 3 if (t.flags & 1) else 1
+            buf = (C.c_float*(w*h*c)).from_address(C.addressof(d.texels.contents) + 4*t.texel_offset)
+            return np.frombuffer(buf, np.float32).reshape(h, w, c).copy()
+    raise AssertionError("no %dx%d bitmap in the scene" % (w, h))
+
+
+def test_png_textures_decode_to_the_floats_of_the_reference_lookup(tmp_path):
+    """8-bit textures (.png; the reference: lodepng -> ImageIO::loadLdr -> BitmapTexture::getRgb, io/ImageIO.cpp:493-526,
+    textures/BitmapTexture.cpp:139-154): the host's own inflate + PNG decoder against images written here by zlib, for every colour
+    type / bit depth / scanline filter / block type it reads; RGB requests go through the 2.2 table floor(255 (i/255)^2.2)."""
+    rs = np.random.RandomState(3)
+    w, h = 37, 23
+    lut = np.floor(255.0*(np.arange(256)/255.0)**2.2).astype(np.uint8)
+    to_f = lambda a: a.astype(np.float32)*np.float32(1.0/255.0)
+    smooth = (np.add.outer(np.arange(h)*5, np.arange(w)*3)[..., None] + np.array([0, 40, 90])) % 256      # compressible: dynamic codes, long matches
+    noise = rs.randint(0, 256, (h, w, 3))
+    cases = []
+    for name, img, level, filters, chunks in (("smooth9", smooth, 9, (0, 1, 2, 3, 4), 1), ("noise6", noise, 6, (4, 3), 3), ("stored", noise, 0, (0,), 1),
+                                                ("fixed", smooth, 1, (1,), 2)):
+        path = str(tmp_path/(name + ".png"))
+        scenes.write_png(path, img, 2, filters=filters, level=level, idat_chunks=chunks)
+        cases.append((path, to_f(lut[img]), {}))
+    # RGBA: alpha is dropped; gamma_correct off keeps the raw bytes
+    rgba = rs.randint(0, 256, (h, w, 4))
+    scenes.write_png(str(tmp_path/"rgba.png"), rgba, 6)
+    cases.append((str(tmp_path/"rgba.png"), to_f(rgba[..., :3]), {"gamma_correct": False}))
+    # grey (8 / 4 / 1 bit), grey + alpha, palette (8 / 2 bit), 16-bit RGB (the high byte counts)
+    g8 = rs.randint(0, 256, (h, w))
+    scenes.write_png(str(tmp_path/"g8.png"), g8, 0)
+    cases.append((str(tmp_path/"g8.png"), to_f(lut[np.repeat(g8[..., None], 3, -1)]), {}))
+    g4 = rs.randint(0, 16, (h, w))
+    scenes.write_png(str(tmp_path/"g4.png"), g4, 0, depth=4)
+    cases.append((str(tmp_path/"g4.png"), to_f(lut[np.repeat((g4*255//15)[..., None], 3, -1)]), {}))
+    g1 = rs.randint(0, 2, (h, w))
+    scenes.write_png(str(tmp_path/"g1.png"), g1, 0, depth=1)
+    cases.append((str(tmp_path/"g1.png"), to_f(lut[np.repeat((g1*255)[..., None], 3, -1)]), {}))
+    ga = rs.randint(0, 256, (h, w, 2))
+    scenes.write_png(str(tmp_path/"ga.png"), ga, 4)
+    cases.append((str(tmp_path/"ga.png"), to_f(lut[np.repeat(ga[..., :1], 3, -1)]), {}))
+    pal = rs.randint(0, 256, (256, 3))
+    idx = rs.randint(0, 256, (h, w))
+    scenes.write_png(str(tmp_path/"p8.png"), idx, 3, palette=pal)
+    cases.append((str(tmp_path/"p8.png"), to_f(lut[pal[idx]]), {}))
+    idx2 = rs.randint(0, 4, (h, w))
+    scenes.write_png(str(tmp_path/"p2.png"), idx2, 3, depth=2, palette=pal[:4])
+    cases.append((str(tmp_path/"p2.png"), to_f(lut[pal[idx2]]), {}))
+    rgb16 = rs.randint(0, 65536, (h, w, 3))
+    scenes.write_png(str(tmp_path/"rgb16.png"), rgb16, 2, depth=16)
+    cases.append((str(tmp_path/"rgb16.png"), to_f(lut[rgb16 >> 8]), {}))
+    for k, (png, expect, extra) in enumerate(cases):
+        def edit(scene, png=png, extra=extra):
+            scene["bsdfs"].append({"name": "tex", "type": "lambert", "albedo": dict({"type": "bitmap", "file": os.path.basename(png)}, **extra)})
+            scene["primitives"][0]["bsdf"] = "tex"
+        flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, name="png%d.json" % k, edit=edit))
+        got = _bitmap_of(flat.desc, w, h)
+        flat.close()
+        assert got.shape == expect.shape and (got == expect).all(), os.path.basename(png)
+    # a truncated file is an error, not a black texture
+    bad = str(tmp_path/"bad.png")
+    open(bad, "wb").write(open(cases[0][0], "rb").read()[:200])
+    with pytest.raises(Exception):
+        tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, name="bad.json",
+                                         edit=lambda s: (s["bsdfs"].append({"name": "tex", "type": "lambert", "albedo": os.path.basename(bad)}), s["primitives"][0].update(bsdf="tex"))))

@@ -1,6 +1,9 @@
 #include "ImageIO.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <iterator>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -215,6 +218,249 @@ Vec3f tonemap(const std::string &op, const Vec3f &c)
         return r;
     }
     throw std::runtime_error("Invalid tonemap operator: '" + op + "'");
+}
+
+
+// ---- PNG in (what the reference reads through lodepng: io/ImageIO.cpp:493-526 -> 8-bit RGBA) -----------------------
+// A plain decoder of the PNG / zlib / DEFLATE specifications (RFC 2083, 1950, 1951): colour types 0, 2, 3, 4, 6 at 8 bits (16-bit
+// samples keep their high byte, 1/2/4-bit grey and palette samples are unpacked), the five scanline filters, no interlacing.
+namespace {
+
+struct BitReader {
+    const uint8_t *p; size_t n, pos; uint32_t bitBuf; int bitCnt;
+    BitReader(const uint8_t *d, size_t len) : p(d), n(len), pos(0), bitBuf(0), bitCnt(0) {}
+    bool bits(int need, uint32_t &v) {
+        while (bitCnt < need) {
+            if (pos >= n) return false;
+            bitBuf |= uint32_t(p[pos++]) << bitCnt;
+            bitCnt += 8;
+        }
+        v = need ? bitBuf & ((1u << need) - 1u) : 0u;
+        bitBuf >>= need; bitCnt -= need;
+        return true;
+    }
+    void alignToByte() { bitBuf = 0; bitCnt = 0; }
+};
+
+// canonical Huffman code (RFC 1951 3.2.2): symbols sorted by code length, then by value
+struct Huffman {
+    uint16_t count[16], symbol[288];
+    bool build(const uint8_t *lengths, int n) {
+        std::memset(count, 0, sizeof(count));
+        for (int i = 0; i < n; ++i) count[lengths[i]]++;
+        int left = 1;
+        for (int len = 1; len < 16; ++len) { left = left*2 - count[len]; if (left < 0) return false; }
+        uint16_t offs[16]; offs[1] = 0;
+        for (int len = 1; len < 15; ++len) offs[len + 1] = uint16_t(offs[len] + count[len]);
+        for (int i = 0; i < n; ++i) if (lengths[i]) symbol[offs[lengths[i]]++] = uint16_t(i);
+        return true;
+    }
+    int decode(BitReader &br) const {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len < 16; ++len) {
+            uint32_t b;
+            if (!br.bits(1, b)) return -1;
+            code |= int(b);
+            int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        return -1;
+    }
+};
+
+bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err)
+{
+    static const uint16_t lenBase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
+    static const uint16_t lenExtra[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+    static const uint16_t distBase[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
+    static const uint16_t distExtra[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+    static const uint8_t clOrder[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+    if (n < 6) { err = "zlib stream too short"; return false; }
+    if ((src[0] & 0x0F) != 8 || ((uint32_t(src[0]) << 8) | src[1]) % 31 != 0 || (src[1] & 0x20)) { err = "not a zlib stream"; return false; }
+    BitReader br(src + 2, n - 2);
+    for (;;) {
+        uint32_t last, type;
+        if (!br.bits(1, last) || !br.bits(2, type)) { err = "truncated deflate stream"; return false; }
+        if (type == 0) {
+            br.alignToByte();
+            if (br.pos + 4 > br.n) { err = "truncated stored block"; return false; }
+            uint32_t len = br.p[br.pos] | (uint32_t(br.p[br.pos + 1]) << 8), nlen = br.p[br.pos + 2] | (uint32_t(br.p[br.pos + 3]) << 8);
+            br.pos += 4;
+            if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n) { err = "bad stored block"; return false; }
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+        } else if (type == 1 || type == 2) {
+            Huffman lit, dist;
+            uint8_t lengths[320];
+            if (type == 1) {
+                for (int i = 0; i < 144; ++i) lengths[i] = 8;
+                for (int i = 144; i < 256; ++i) lengths[i] = 9;
+                for (int i = 256; i < 280; ++i) lengths[i] = 7;
+                for (int i = 280; i < 288; ++i) lengths[i] = 8;
+                lit.build(lengths, 288);
+                for (int i = 0; i < 30; ++i) lengths[i] = 5;
+                dist.build(lengths, 30);
+            } else {
+                uint32_t hlit, hdist, hclen;
+                if (!br.bits(5, hlit) || !br.bits(5, hdist) || !br.bits(4, hclen)) { err = "truncated block header"; return false; }
+                hlit += 257; hdist += 1; hclen += 4;
+                if (hlit > 286 || hdist > 30) { err = "bad code counts"; return false; }
+                uint8_t cl[19] = {0};
+                for (uint32_t i = 0; i < hclen; ++i) { uint32_t v; if (!br.bits(3, v)) { err = "truncated code lengths"; return false; } cl[clOrder[i]] = uint8_t(v); }
+                Huffman clh;
+                if (!clh.build(cl, 19)) { err = "bad code-length code"; return false; }
+                uint32_t i = 0;
+                while (i < hlit + hdist) {
+                    int sym = clh.decode(br);
+                    if (sym < 0) { err = "bad code-length symbol"; return false; }
+                    if (sym < 16) { lengths[i++] = uint8_t(sym); continue; }
+                    uint32_t rep, prev = 0;
+                    if (sym == 16) { if (i == 0) { err = "repeat without a length"; return false; } prev = lengths[i - 1]; if (!br.bits(2, rep)) return false; rep += 3; }
+                    else if (sym == 17) { if (!br.bits(3, rep)) return false; rep += 3; }
+                    else { if (!br.bits(7, rep)) return false; rep += 11; }
+                    if (i + rep > hlit + hdist) { err = "too many code lengths"; return false; }
+                    while (rep--) lengths[i++] = uint8_t(prev);
+                }
+                if (lengths[256] == 0 || !lit.build(lengths, int(hlit)) || !dist.build(lengths + hlit, int(hdist))) { err = "bad literal / distance code"; return false; }
+            }
+            for (;;) {
+                int sym = lit.decode(br);
+                if (sym < 0) { err = "bad literal / length symbol"; return false; }
+                if (sym < 256) { out.push_back(uint8_t(sym)); continue; }
+                if (sym == 256) break;
+                sym -= 257;
+                if (sym >= 29) { err = "bad length symbol"; return false; }
+                uint32_t eb, len = lenBase[sym];
+                if (!br.bits(lenExtra[sym], eb)) { err = "truncated length"; return false; }
+                len += eb;
+                int ds = dist.decode(br);
+                if (ds < 0 || ds >= 30) { err = "bad distance symbol"; return false; }
+                uint32_t d = distBase[ds];
+                if (!br.bits(distExtra[ds], eb)) { err = "truncated distance"; return false; }
+                d += eb;
+                if (d > out.size()) { err = "distance beyond the start of the data"; return false; }
+                size_t from = out.size() - d;
+                for (uint32_t k = 0; k < len; ++k) out.push_back(out[from + k]);
+            }
+        } else { err = "reserved block type"; return false; }
+        if (last) break;
+    }
+    return true;
+}
+
+inline int paeth(int a, int b, int c) { int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+
+} // namespace
+
+bool loadPng(const std::string &path, std::vector<uint8_t> &rgba, int &w, int &h, bool &hasAlpha, std::string &err)
+{
+    std::ifstream in(path.c_str(), std::ios::binary);
+    if (!in) { err = "cannot open file"; return false; }
+    std::vector<uint8_t> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (file.size() < 8 + 25 || std::memcmp(file.data(), sig, 8) != 0) { err = "not a PNG file"; return false; }
+    auto be32 = [&](size_t o) { return (uint32_t(file[o]) << 24) | (uint32_t(file[o + 1]) << 16) | (uint32_t(file[o + 2]) << 8) | file[o + 3]; };
+    std::vector<uint8_t> idat, palette, trns;
+    int depth = 0, colorType = 0;
+    bool haveHeader = false;
+    for (size_t o = 8; o + 12 <= file.size();) {
+        const uint32_t len = be32(o);
+        if (o + 12 + size_t(len) > file.size()) { err = "truncated chunk"; return false; }
+        const std::string type(reinterpret_cast<const char *>(&file[o + 4]), 4);
+        const uint8_t *d = &file[o + 8];
+        if (crc32(&file[o + 4], size_t(len) + 4) != be32(o + 8 + len)) { err = "chunk checksum mismatch"; return false; }
+        if (type == "IHDR") {
+            if (len != 13) { err = "bad IHDR"; return false; }
+            w = int(be32(o + 8)); h = int(be32(o + 12));
+            depth = d[8]; colorType = d[9];
+            if (d[10] != 0 || d[11] != 0) { err = "unknown compression / filter method"; return false; }
+            if (d[12] != 0) { err = "interlaced PNGs are not supported"; return false; }
+            haveHeader = true;
+        } else if (type == "PLTE") palette.assign(d, d + len);
+        else if (type == "tRNS") trns.assign(d, d + len);
+        else if (type == "IDAT") idat.insert(idat.end(), d, d + len);
+        else if (type == "IEND") break;
+        o += 12 + size_t(len);
+    }
+    if (!haveHeader || w <= 0 || h <= 0 || idat.empty()) { err = "missing IHDR / IDAT"; return false; }
+    int channels;
+    switch (colorType) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: err = "unknown colour type"; return false;
+    }
+    const bool depthOk = depth == 8 || (depth == 16 && colorType != 3) || ((depth == 1 || depth == 2 || depth == 4) && (colorType == 0 || colorType == 3));
+    if (!depthOk) { err = "unsupported bit depth"; return false; }
+    if (colorType == 3 && palette.empty()) { err = "palette image without PLTE"; return false; }
+    const size_t bpp = std::max<size_t>(1, size_t(channels)*size_t(depth)/8);            // filter unit
+    const size_t stride = (size_t(w)*size_t(channels)*size_t(depth) + 7)/8;
+    std::vector<uint8_t> raw;
+    raw.reserve((stride + 1)*size_t(h));
+    if (!inflate(idat.data(), idat.size(), raw, err)) return false;
+    if (raw.size() < (stride + 1)*size_t(h)) { err = "image data too short"; return false; }
+    // scanline filters (RFC 2083 section 6), in place
+    std::vector<uint8_t> prev(stride, 0);
+    for (int y = 0; y < h; ++y) {
+        uint8_t *line = &raw[size_t(y)*(stride + 1)];
+        const int filter = line[0];
+        uint8_t *cur = line + 1;
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int v = cur[i];
+            switch (filter) {
+            case 0: break;
+            case 1: v += a; break;
+            case 2: v += b; break;
+            case 3: v += (a + b)/2; break;
+            case 4: v += paeth(a, b, c); break;
+            default: err = "unknown scanline filter"; return false;
+            }
+            cur[i] = uint8_t(v);
+        }
+        std::memcpy(prev.data(), cur, stride);
+    }
+    // to 8-bit RGBA
+    hasAlpha = colorType == 4 || colorType == 6 || !trns.empty();
+    rgba.assign(size_t(w)*h*4, 255);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t *cur = &raw[size_t(y)*(stride + 1) + 1];
+        for (int x = 0; x < w; ++x) {
+            uint8_t *dst = &rgba[(size_t(y)*w + x)*4];
+            auto sample = [&](int ch) -> int {                   // sample `ch` of pixel x at the image's bit depth
+                const size_t idx = size_t(x)*channels + ch;
+                if (depth == 8) return cur[idx];
+                if (depth == 16) return (cur[idx*2] << 8) | cur[idx*2 + 1];
+                const size_t bit = idx*size_t(depth);
+                return (cur[bit >> 3] >> (8 - depth - int(bit & 7))) & ((1 << depth) - 1);
+            };
+            auto to8 = [&](int v) -> uint8_t {
+                if (depth == 8) return uint8_t(v);
+                if (depth == 16) return uint8_t(v >> 8);
+                return uint8_t(v*255/((1 << depth) - 1));
+            };
+            if (colorType == 3) {
+                const int idx = sample(0);
+                if (size_t(idx)*3 + 2 >= palette.size()) { err = "palette index out of range"; return false; }
+                dst[0] = palette[size_t(idx)*3]; dst[1] = palette[size_t(idx)*3 + 1]; dst[2] = palette[size_t(idx)*3 + 2];
+                dst[3] = size_t(idx) < trns.size() ? trns[size_t(idx)] : 255;
+            } else if (colorType == 0 || colorType == 4) {
+                const int g = sample(0);
+                dst[0] = dst[1] = dst[2] = to8(g);
+                if (colorType == 4) dst[3] = to8(sample(1));
+                else if (trns.size() >= 2 && g == ((trns[0] << 8) | trns[1])) dst[3] = 0;
+            } else {
+                const int r = sample(0), g = sample(1), b = sample(2);
+                dst[0] = to8(r); dst[1] = to8(g); dst[2] = to8(b);
+                if (colorType == 6) dst[3] = to8(sample(3));
+                else if (trns.size() >= 6 && r == ((trns[0] << 8) | trns[1]) && g == ((trns[2] << 8) | trns[3]) && b == ((trns[4] << 8) | trns[5])) dst[3] = 0;
+            }
+        }
+    }
+    return true;
 }
 
 } // namespace ImageIO

@@ -145,11 +145,38 @@ void Texture::loadBitmap(const std::string &file)
     std::vector<float> rgbTexels;
     int iw = 0, ih = 0;
     std::string err;
-    if (!ImageIO::loadHdr(file, rgbTexels, iw, ih, err))
-        throw std::runtime_error("Unable to load HDR texture '" + file + "': " + err +
-                                 " (LDR bitmaps are outside the path_tracer_hip hot-path scope)");
+    const bool png = file.size() >= 4 && (file.compare(file.size() - 4, 4, ".png") == 0 || file.compare(file.size() - 4, 4, ".PNG") == 0);
+    if (png) {
+        // ImageIO::loadLdr (io/ImageIO.cpp:493-526) + BitmapTexture::getRgb / getScalar (textures/BitmapTexture.cpp:139-154): RGB requests
+        // keep the 8-bit channels (gamma-corrected through the 2.2 table unless "gamma_correct": false), scalar requests take the integer
+        // average of the raw channels; a lookup turns a byte into float(byte)*(1/255) -- done once here, with the same rounding
+        std::vector<uint8_t> rgba;
+        bool hasAlpha = false;
+        if (!ImageIO::loadPng(file, rgba, iw, ih, hasAlpha, err))
+            throw std::runtime_error("Unable to load PNG texture '" + file + "': " + err);
+        w = iw; h = ih;
+        uint8_t gamma[256];
+        for (int i = 0; i < 256; ++i)            // GammaCorrection[] (io/ImageIO.cpp:26-43) = floor(255 (i/255)^2.2)
+            gamma[i] = gammaCorrect ? uint8_t(255.0*std::pow(i/255.0, 2.2)) : uint8_t(i);
+        const size_t n = size_t(w)*h;
+        if (rgb) {
+            texels.resize(n*3);
+            for (size_t i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k)
+                    texels[i*3 + k] = float(gamma[rgba[i*4 + k]])*(1.0f/255.0f);
+        } else {
+            texels.resize(n);
+            for (size_t i = 0; i < n; ++i)
+                texels[i] = float(uint8_t((int(rgba[i*4]) + int(rgba[i*4 + 1]) + int(rgba[i*4 + 2]))/3))*(1.0f/255.0f);
+        }
+    } else if (!ImageIO::loadHdr(file, rgbTexels, iw, ih, err)) {
+        throw std::runtime_error("Unable to load texture '" + file + "': " + err +
+                                 " (.hdr and .png bitmaps are read; .jpg / .exr are outside the path_tracer_hip hot-path scope)");
+    }
     w = iw; h = ih;
-    if (rgb) {
+    if (png) {
+        // (converted above)
+    } else if (rgb) {
         texels.swap(rgbTexels);
     } else {
         // TexelConversion::REQUEST_AVERAGE on an RGB HDR source (ImageIO.cpp:298-337)
@@ -422,8 +449,7 @@ std::shared_ptr<Texture> Scene::fetchTexture(const JsonValue &v, bool rgb) const
             std::string file;
             if (v.getField("file", file))
                 t->path = _srcDir.empty() ? file : _srcDir + "/" + file;
-            bool gamma;
-            v.getField("gamma_correct", gamma);
+            v.getField("gamma_correct", t->gammaCorrect);
             v.getField("interpolate", t->linear);
             v.getField("clamp", t->clamp);
             v.getField("scale", t->scale);

@@ -27,10 +27,11 @@ struct Texture
     Vec3f value = Vec3f(1.0f);                 // ConstantTexture
     Vec3f onColor = Vec3f(0.8f), offColor = Vec3f(0.2f); // CheckerTexture.cpp:11-30
     int resU = 20, resV = 20;
-    // BitmapTexture (HDR float texels only: .hdr / .pfm)
+    // BitmapTexture: float texels (.hdr), or 8-bit ones (.png) converted once to the floats the reference's lookups produce
     std::string path;
     int w = 0, h = 0;
     bool rgb = true, linear = true, clamp = false, valid = false;
+    bool gammaCorrect = true;                  // LDR RGB textures only (io/ImageIO.cpp:515-518)
     float scale = 1.0f;
     std::vector<float> texels;                 // rgb ? 3*w*h : w*h
     Vec3f texMin, texMax, texAvg;
