@@ -377,3 +377,26 @@ def test_png_textures_decode_to_the_floats_of_the_reference_lookup(tmp_path):
     with pytest.raises(Exception):
         tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, name="bad.json",
                                          edit=lambda s: (s["bsdfs"].append({"name": "tex", "type": "lambert", "albedo": os.path.basename(bad)}), s["primitives"][0].update(bsdf="tex"))))
+
+
+def test_pfm_textures(tmp_path):
+    """.pfm bitmaps (io/ImageIO.cpp:298-338): rows bottom to top; a scalar file feeds all three channels of an RGB request."""
+    rs = np.random.RandomState(9)
+    w, h = 19, 11
+    rgb = rs.rand(h, w, 3).astype(np.float32)*4
+    grey = rs.rand(h, w).astype(np.float32)
+    def write(path, a):
+        with open(path, "wb") as f:
+            f.write(b"PF\n" if a.ndim == 3 else b"Pf\n")
+            f.write(("%d %d\n-1.0\n" % (w, h)).encode())
+            f.write(np.ascontiguousarray(a[::-1]).tobytes())
+    write(str(tmp_path/"c.pfm"), rgb)
+    write(str(tmp_path/"g.pfm"), grey)
+    for k, (name, expect) in enumerate((("c.pfm", rgb), ("g.pfm", np.repeat(grey[..., None], 3, -1)))):
+        def edit(scene, name=name):
+            scene["bsdfs"].append({"name": "tex", "type": "lambert", "albedo": name})
+            scene["primitives"][0]["bsdf"] = "tex"
+        flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, name="pfm%d.json" % k, edit=edit))
+        got = _bitmap_of(flat.desc, w, h)
+        flat.close()
+        assert (got == expect).all(), name

@@ -221,6 +221,29 @@ Vec3f tonemap(const std::string &op, const Vec3f &c)
 }
 
 
+// ---- PFM in (io/ImageIO.cpp:298-338): "PF" / "Pf", width height, scale, then rows bottom to top; like the reference the floats are
+// taken as they lie in the file (native byte order; the scale's sign and magnitude are ignored)
+bool loadPfm(const std::string &path, std::vector<float> &texels, int &w, int &h, int &channels, std::string &err)
+{
+    std::ifstream in(path.c_str(), std::ios::binary);
+    if (!in) { err = "cannot open file"; return false; }
+    std::string ident;
+    in >> ident;
+    if (ident == "Pf") channels = 1;
+    else if (ident == "PF") channels = 3;
+    else { err = "not a PFM file"; return false; }
+    double scale;
+    in >> w >> h >> scale;
+    std::string rest;
+    std::getline(in, rest);
+    if (!in || w <= 0 || h <= 0) { err = "bad PFM header"; return false; }
+    texels.assign(size_t(w)*h*channels, 0.0f);
+    for (int y = 0; y < h; ++y)
+        in.read(reinterpret_cast<char *>(&texels[size_t(h - y - 1)*w*channels]), std::streamsize(size_t(w)*channels*sizeof(float)));
+    if (!in) { err = "PFM data too short"; return false; }
+    return true;
+}
+
 // ---- PNG in (what the reference reads through lodepng: io/ImageIO.cpp:493-526 -> 8-bit RGBA) -----------------------
 // A plain decoder of the PNG / zlib / DEFLATE specifications (RFC 2083, 1950, 1951): colour types 0, 2, 3, 4, 6 at 8 bits (16-bit
 // samples keep their high byte, 1/2/4-bit grey and palette samples are unpacked), the five scanline filters, no interlacing.

@@ -17,6 +17,7 @@ namespace ImageIO {
 bool loadHdr(const std::string &path, std::vector<float> &rgb, int &w, int &h, std::string &err);
 // 8-bit RGBA, rows top to bottom (what io/ImageIO.cpp:493-526 hands BitmapTexture for a .png); hasAlpha: the file carries transparency
 bool loadPng(const std::string &path, std::vector<uint8_t> &rgba, int &w, int &h, bool &hasAlpha, std::string &err);
+bool loadPfm(const std::string &path, std::vector<float> &texels, int &w, int &h, int &channels, std::string &err);
 bool savePfm(const std::string &path, const float *img, int w, int h, int channels);
 bool savePng(const std::string &path, const uint8_t *rgb, int w, int h);
 Vec3f tonemap(const std::string &op, const Vec3f &c);   // cameras/Tonemap.hpp:25-48

@@ -145,6 +145,7 @@ void Texture::loadBitmap(const std::string &file)
     std::vector<float> rgbTexels;
     int iw = 0, ih = 0;
     std::string err;
+    bool scalarDone = false;
     const bool png = file.size() >= 4 && (file.compare(file.size() - 4, 4, ".png") == 0 || file.compare(file.size() - 4, 4, ".PNG") == 0);
     if (png) {
         // ImageIO::loadLdr (io/ImageIO.cpp:493-526) + BitmapTexture::getRgb / getScalar (textures/BitmapTexture.cpp:139-154): RGB requests
@@ -169,12 +170,27 @@ void Texture::loadBitmap(const std::string &file)
             for (size_t i = 0; i < n; ++i)
                 texels[i] = float(uint8_t((int(rgba[i*4]) + int(rgba[i*4 + 1]) + int(rgba[i*4 + 2]))/3))*(1.0f/255.0f);
         }
+    } else if (file.size() >= 4 && file.compare(file.size() - 4, 4, ".pfm") == 0) {
+        // ImageIO::loadPfm (io/ImageIO.cpp:298-338): a scalar file feeds all three channels of an RGB request
+        int ch = 0;
+        if (!ImageIO::loadPfm(file, rgbTexels, iw, ih, ch, err))
+            throw std::runtime_error("Unable to load PFM texture '" + file + "': " + err);
+        if (ch == 1 && !rgb) {
+            texels.swap(rgbTexels);              // a scalar request of a scalar file: the floats as they are
+            scalarDone = true;
+        } else if (ch == 1) {
+            std::vector<float> grey;
+            grey.swap(rgbTexels);
+            rgbTexels.resize(grey.size()*3);
+            for (size_t i = 0; i < grey.size(); ++i)
+                rgbTexels[i*3] = rgbTexels[i*3 + 1] = rgbTexels[i*3 + 2] = grey[i];
+        }
     } else if (!ImageIO::loadHdr(file, rgbTexels, iw, ih, err)) {
         throw std::runtime_error("Unable to load texture '" + file + "': " + err +
-                                 " (.hdr and .png bitmaps are read; .jpg / .exr are outside the path_tracer_hip hot-path scope)");
+                                 " (.hdr, .pfm and .png bitmaps are read; .jpg / .exr are outside the path_tracer_hip hot-path scope)");
     }
     w = iw; h = ih;
-    if (png) {
+    if (png || scalarDone) {
         // (converted above)
     } else if (rgb) {
         texels.swap(rgbTexels);
