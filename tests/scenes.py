@@ -514,6 +514,33 @@ def cornell_png(tmpdir, **kw):
 GOLDEN_CASES["cornell_png_textures"] = (cornell_png, dict(resolution=(48, 27), spp=8))
 
 
+def cornell_png_scalar(tmpdir, **kw):
+    """Scalar requests of 8-bit bitmaps: a rough conductor whose roughness is the integer channel average of a .png (REQUEST_AVERAGE,
+    no gamma), and a cut-out wall whose opacity is the .png's alpha channel (TransparencyBsdf: REQUEST_AUTO)."""
+    import numpy as np
+    tmpdir = str(tmpdir)
+    y, x = np.mgrid[0:32, 0:32]
+    rough = np.stack([(x*3 + 20) % 200, (y*4 + 30) % 180, (x + y)*2 % 160], axis=-1) + 10
+    write_png(os.path.join(tmpdir, "rough.png"), rough, 2, filters=(2, 4), level=9)
+    alpha = np.where(((x//4 + y//4) % 2) == 0, 255, np.where((x + y) % 3 == 0, 128, 0))
+    cut = np.stack([x*8 % 256, y*8 % 256, (x*y) % 256, alpha], axis=-1)
+    write_png(os.path.join(tmpdir, "cutout.png"), cut, 6, filters=(1, 3), level=6)
+
+    def edit(scene):
+        scene["bsdfs"].append(dict({"name": "brushed", "albedo": 1, "type": "rough_conductor", "distribution": "ggx", "roughness": "rough.png"}, **_CU))
+        scene["bsdfs"].append({"name": "cutBase", "type": "lambert", "albedo": [0.7, 0.6, 0.2]})
+        scene["bsdfs"].append({"name": "cut", "type": "transparency", "base": "cutBase", "alpha": "cutout.png"})
+        for p in scene["primitives"]:
+            if p.get("name") == "tallBox":
+                p["bsdf"] = "brushed"
+            if p.get("name") == "shortBox":
+                p["bsdf"] = "cut"
+    return cornell(tmpdir, edit=edit, **kw)
+
+
+GOLDEN_CASES["cornell_png_scalar"] = (cornell_png_scalar, dict(resolution=(48, 27), spp=8))
+
+
 def _thinlens_pivot(scene):
     scene["camera"].update(type="thinlens", focus_distance=1.0, aperture_size=0.12, cateye=0.0, focus_pivot="tallBox")
 

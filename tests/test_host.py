@@ -314,7 +314,7 @@ def _bitmap_of(desc, w, h):
     for i in range(d.num_textures):
         t = d.textures[i]
         if t.type == 2 and t.w == w and t.h == h:
-            c = 3 if (t.flags & 1) else 1
+            c = 3 if (t.flags & 4) else 1
             buf = (C.c_float*(w*h*c)).from_address(C.addressof(d.texels.contents) + 4*t.texel_offset)
             return np.frombuffer(buf, np.float32).reshape(h, w, c).copy()
     raise AssertionError("no %dx%d bitmap in the scene" % (w, h))
@@ -371,6 +371,25 @@ def test_png_textures_decode_to_the_floats_of_the_reference_lookup(tmp_path):
         got = _bitmap_of(flat.desc, w, h)
         flat.close()
         assert got.shape == expect.shape and (got == expect).all(), os.path.basename(png)
+    # scalar requests: the integer channel average without gamma (roughness, REQUEST_AVERAGE); the alpha channel for a transparency
+    # bsdf's "alpha" (REQUEST_AUTO: a .png always reports four channels, io/ImageIO.cpp:386-407)
+    def edit_scalar(scene):
+        scene["bsdfs"].append(dict({"name": "rc", "type": "rough_conductor", "albedo": 1, "roughness": "rgba.png"}, **scenes._CU))
+        scene["bsdfs"].append({"name": "cut", "type": "transparency", "base": {"type": "lambert", "albedo": 0.5}, "alpha": "rgba.png"})
+        scene["primitives"][0]["bsdf"] = "rc"
+        scene["primitives"][1]["bsdf"] = "cut"
+    flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, name="scalar.json", edit=edit_scalar))
+    d = flat.desc.contents
+    scalars = []
+    for i in range(d.num_textures):
+        t = d.textures[i]
+        if t.type == 2 and (t.w, t.h) == (w, h) and not (t.flags & 4):
+            buf = (C.c_float*(w*h)).from_address(C.addressof(d.texels.contents) + 4*t.texel_offset)
+            scalars.append(np.frombuffer(buf, np.float32).reshape(h, w).copy())
+    flat.close()
+    avg = to_f((rgba[..., 0] + rgba[..., 1] + rgba[..., 2])//3)
+    assert len(scalars) == 2
+    assert any((a == avg).all() for a in scalars) and any((a == to_f(rgba[..., 3])).all() for a in scalars)
     # a truncated file is an error, not a black texture
     bad = str(tmp_path/"bad.png")
     open(bad, "wb").write(open(cases[0][0], "rb").read()[:200])

@@ -168,7 +168,7 @@ void Texture::loadBitmap(const std::string &file)
         } else {
             texels.resize(n);
             for (size_t i = 0; i < n; ++i)
-                texels[i] = float(uint8_t((int(rgba[i*4]) + int(rgba[i*4 + 1]) + int(rgba[i*4 + 2]))/3))*(1.0f/255.0f);
+                texels[i] = float(autoAlpha ? rgba[i*4 + 3] : uint8_t((int(rgba[i*4]) + int(rgba[i*4 + 1]) + int(rgba[i*4 + 2]))/3))*(1.0f/255.0f);
         }
     } else if (file.size() >= 4 && file.compare(file.size() - 4, 4, ".pfm") == 0) {
         // ImageIO::loadPfm (io/ImageIO.cpp:298-338): a scalar file feeds all three channels of an RGB request
@@ -426,16 +426,17 @@ static std::shared_ptr<Texture> constantTexture(float v)
     return t;
 }
 
-std::shared_ptr<Texture> Scene::fetchTexture(const JsonValue &v, bool rgb) const
+std::shared_ptr<Texture> Scene::fetchTexture(const JsonValue &v, bool rgb, bool autoAlpha) const
 {
     if (v.isString()) {
         std::string full = _srcDir.empty() ? v.asString() : _srcDir + "/" + v.asString();
-        std::string key = full + (rgb ? "|rgb" : "|avg");
+        std::string key = full + (rgb ? "|rgb" : autoAlpha ? "|auto" : "|avg");
         for (auto &kv : _textureCache)
             if (kv.first == key) return kv.second;
         auto t = std::make_shared<Texture>();
         t->type = Texture::Bitmap;
         t->rgb = rgb;
+        t->autoAlpha = autoAlpha && !rgb;
         t->path = full;
         _textureCache.emplace_back(key, t);
         return t;
@@ -462,6 +463,7 @@ std::shared_ptr<Texture> Scene::fetchTexture(const JsonValue &v, bool rgb) const
         } else if (type == "bitmap") {
             t->type = Texture::Bitmap;
             t->rgb = rgb;
+            t->autoAlpha = autoAlpha && !rgb;
             std::string file;
             if (v.getField("file", file))
                 t->path = _srcDir.empty() ? file : _srcDir + "/" + file;
@@ -571,7 +573,7 @@ std::shared_ptr<Bsdf> Scene::instantiateBsdf(const JsonValue &v) const
         b->type = Bsdf::Transparency;
         if (const JsonValue &base = v["base"]) b->sub0 = fetchBsdf(base);
         else { b->sub0 = std::make_shared<Bsdf>(); b->sub0->albedo = constantTexture(1.0f); }
-        if (const JsonValue &a = v["alpha"]) b->tex1 = fetchTexture(a, false);
+        if (const JsonValue &a = v["alpha"]) b->tex1 = fetchTexture(a, false, true);   // REQUEST_AUTO (TransparencyBsdf.cpp:31)
         else b->tex1 = constantTexture(1.0f);
     } else {
         throw JsonLoadException("BSDF type '" + type + "' is outside the path_tracer_hip hot-path scope");

@@ -32,6 +32,7 @@ struct Texture
     int w = 0, h = 0;
     bool rgb = true, linear = true, clamp = false, valid = false;
     bool gammaCorrect = true;                  // LDR RGB textures only (io/ImageIO.cpp:515-518)
+    bool autoAlpha = false;                    // scalar request REQUEST_AUTO instead of REQUEST_AVERAGE (Scene::fetchTexture)
     float scale = 1.0f;
     std::vector<float> texels;                 // rgb ? 3*w*h : w*h
     Vec3f texMin, texMax, texAvg;
@@ -198,7 +199,9 @@ class Scene
     std::string _srcDir;
     mutable std::vector<std::pair<std::string, std::shared_ptr<Texture>>> _textureCache;
 
-    std::shared_ptr<Texture> fetchTexture(const JsonValue &v, bool rgb) const;  // Scene.cpp:127-151
+    // autoAlpha: TexelConversion::REQUEST_AUTO (TransparencyBsdf's "alpha"): the alpha channel where the decoder reports one -- for a .png
+    // always (io/ImageIO.cpp:386-407 decodes to RGBA and reports 4 channels) --, else the average
+    std::shared_ptr<Texture> fetchTexture(const JsonValue &v, bool rgb, bool autoAlpha = false) const;  // Scene.cpp:127-151
     std::shared_ptr<Bsdf> fetchBsdf(const JsonValue &v) const;                  // Scene.cpp:82-93
     std::shared_ptr<Bsdf> instantiateBsdf(const JsonValue &v) const;
     std::shared_ptr<Primitive> instantiatePrimitive(const JsonValue &v) const;
