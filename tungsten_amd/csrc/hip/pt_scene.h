@@ -82,9 +82,6 @@ struct DeviceScene {
 PT_DEV f3 bitmapTexel(const DeviceScene &s, const TgHipTexture &t, int x, int y)
 {
     const float *tex = s.texels + t.texel_offset;
-#ifdef EXP_TEXEL_WINDOW
-    x &= 63; y &= 63;
-#endif
     if (t.flags & TGHIP_TEXF_RGB) {
         const float *p = tex + ((size_t)x + (size_t)y*t.w)*3;
         return mk3(p[0], p[1], p[2]);
@@ -156,10 +153,6 @@ PT_DEV float bitmapPdf(const DeviceScene &s, int texIdx, const TgHipTexture &t, 
         return pick->pdfRC*pick->mpdfR*t.w*t.h;
     const float *mpdf = texIdx == s.env_tex ? s.env_marginal : s.dist + t.dist_offset;
     const int ro = s.tex_rows[texIdx];
-#ifdef EXP_PAIR_WINDOW
-    if (ro >= 0)
-        return at32(s.rows, (uint32_t)ro + (uint32_t)(row & 15)*(uint32_t)(t.w + 1) + (uint32_t)(column & 63)).y*mpdf[row]*t.w*t.h;
-#endif
     if (ro >= 0)
         return at32(s.rows, (uint32_t)ro + (uint32_t)row*(uint32_t)(t.w + 1) + (uint32_t)column).y*mpdf[row]*t.w*t.h;
     const float *pdf = s.dist + t.dist_offset + t.h + t.h + 1;
@@ -214,9 +207,6 @@ PT_DEV void bitmapSample(const DeviceScene &s, int texIdx, const TgHipTexture &t
     int column;
     float cdfC, pdfC;
     if (go >= 0 && ro >= 0) {
-#ifdef EXP_PAIR_WINDOW
-        row &= 15;
-#endif
         const float2 *rowStart = &at32(s.rows, (uint32_t)ro + (uint32_t)row*(uint32_t)(t.w + 1));
         float2 picked;
         column = upperBoundGuidedPairs(rowStart, s.guide + go + (PT_GUIDE_MARGINAL + 1) + row*(PT_GUIDE_ROW + 1), PT_GUIDE_ROW, xi0, t.w, picked) - 1;
