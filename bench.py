@@ -15,7 +15,7 @@ scene: three meshes, 80 768 triangles, smooth_coat over rough_conductor, HDRI en
 uniform sampler, adaptive sampling off (fixed total work => "scaling": "strong").  At N = 1 the same line carries, under
 "extra", BASELINE configs[1] (Cornell box 1280x720 at 256 spp, a flat-list scene without BVH traversal); `--scene cornell`
 makes that the headline workload instead.  Without the materialtest assets (oracle/_ref/data, copied from the reference's
-data directory by __graft_entry__.build()) the default falls back to the Cornell box and says so in config.workload.
+data directory by __graft_entry__.build()) the default run FAILS: there is no silent fallback to another workload.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the kernel with the largest accumulated time:
 achieved = algorithmic bytes per launch / average launch duration, both from the timed region (HIP events
@@ -60,7 +60,8 @@ def parse_args():
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--opt", action="append", default=[], help="shim option key=value (tghip_set_option)")
     ap.add_argument("--emulate-shards", type=int, default=0,
-                    help="development aid: on ONE GPU render only shard 0 of N tile shards (what each rank of an N-GPU run does)")
+                    help="development aid: on ONE GPU render and time EVERY one of N tile shards in turn (what the ranks of an N-GPU run do; "
+                         "reports max / mean / min over shards and the fixed cost of the framebuffer reduce)")
     return ap.parse_args()
 
 
@@ -182,7 +183,37 @@ class Bench(object):
         fb_cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
         check(lib.tghip_bind_framebuffer(ctx, fb_sum.data_ptr(), fb_cnt.data_ptr()), "tghip_bind_framebuffer")
         pass_desc = tgdist.shard_pass(self.rank, self.world, 0, spp, tg.DEFAULT_SEED)
+        emulated = None
         if a.emulate_shards > 1 and self.world == 1:
+            # what an N-GPU run does, on ONE GPU: every shard 0..N-1 is rendered and timed in turn (a strong-scaling run is as
+            # slow as its slowest rank, so the line's value is priced by the MAX over shards), plus the exchange step -- the
+            # RCCL reduce behind the C-ABI with one rank, i.e. its fixed cost: the device-side reduce + the PCIe download
+            def time_shard(r):
+                pd = tgdist.shard_pass(r, a.emulate_shards, 0, spp, tg.DEFAULT_SEED)
+                for _ in range(max(warmup, 1)):
+                    check(lib.tghip_clear_framebuffer(ctx), "clear"); check(lib.tghip_render_pass(ctx, C.byref(pd)), "render"); check(lib.tghip_wait(ctx), "wait")
+                self.fence()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    check(lib.tghip_clear_framebuffer(ctx), "clear"); check(lib.tghip_render_pass(ctx, C.byref(pd)), "render"); check(lib.tghip_wait(ctx), "wait")
+                self.fence()
+                return (time.perf_counter() - t0)/steps*1e3
+            per_shard = [time_shard(r) for r in range(a.emulate_shards)]
+            import numpy as _np
+            hs, hc = _np.empty((h, w, 3), _np.float32), _np.empty((h, w), _np.uint32)
+            ctxs = (C.c_void_p*1)(ctx)
+            red = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                rc = lib.tghip_reduce_framebuffers(ctxs, 1, 0, hs.ctypes.data, hc.ctypes.data, w*h)
+                red.append((time.perf_counter() - t0)*1e3)
+                if rc != 0:
+                    red = None
+                    break
+            emulated = {"shards": a.emulate_shards, "ms_per_step_by_shard": [round(t, 3) for t in per_shard],
+                        "max_ms": round(max(per_shard), 3), "mean_ms": round(sum(per_shard)/len(per_shard), 3), "min_ms": round(min(per_shard), 3),
+                        "reduce_n1_ms": round(sorted(red)[len(red)//2], 3) if red else None,
+                        "note": "value and ms_per_step below are shard 0's; the estimate of an N-GPU step is max_ms + the reduce"}
             pass_desc = tgdist.shard_pass(0, a.emulate_shards, 0, spp, tg.DEFAULT_SEED)
 
         def step():
@@ -304,6 +335,8 @@ class Bench(object):
                 "setup_s": {"flatten_and_bvh": round(t_flatten, 3), "upload": round(t_upload, 3)},
                 "result_ok": ok, "image_mean": [round(float(v), 6) for v in img.mean(axis=(0, 1))],
             }
+            if emulated:
+                out["emulated_shards"] = emulated
         lib.tghip_bind_framebuffer(ctx, None, None)
         lib.tghip_destroy(ctx)
         flat.close()
@@ -445,9 +478,9 @@ def main():
         w, h = [int(v) for v in a.res.split("x")]
         scene = a.scene
         if scene in ("materialtest", "mesh1m") and not scenes.have_materialtest():
-            if b.rank == 0:
-                sys.stderr.write("bench.py: materialtest assets (oracle/_ref/data) missing -- falling back to the Cornell box\n")
-            scene = "cornell"
+            # the headline workload is materialtest: a run without its assets is not a measurement of the metric (no silent fallback)
+            raise SystemExit("bench.py: materialtest assets (oracle/_ref/data/materialtest) missing -- run __graft_entry__.build() where the "
+                             "reference is mounted, or pass --scene cornell explicitly")
         spp = a.spp or (256 if scene in ("cornell", "materialtest") else 32)
         if scene in ("mesh1m", "instances10k") and a.res == "1280x720":
             w, h = 1920, 1080

@@ -302,9 +302,24 @@ typedef struct TgHipSceneDesc {
 
 /* ---- passes ------------------------------------------------------------------------------
  * A pass renders samples [spp_begin, spp_end) of every pixel owned by this shard.  Ownership
- * follows the reference's 16x16 tile dicing (PathTraceIntegrator.cpp:27-42): tile t (row-major)
- * belongs to shard (t % shard_count).  Random numbers are a counter-based PCG stream keyed by
- * (seed, pixelIndex, sampleIndex) -- see DESIGN.md "RNG". */
+ * follows the reference's 16x16 tile dicing (PathTraceIntegrator.cpp:27-42): tile (tx, ty) belongs to
+ * shard tghip_tile_owner(tx, ty, shard_count) = (tx + ty*skew) % shard_count -- a diagonal interleave, so
+ * that a shard's tiles are spread over the image in x AND y whatever the image width (plain t % N over
+ * row-major tiles degenerates into N vertical stripes whenever the tiles per row are a multiple of N:
+ * 1280, 1920 and 3840 pixels all are for N = 8); a shard renders its tiles in row-major order.  Random
+ * numbers are a counter-based PCG stream keyed by (seed, pixelIndex, sampleIndex) -- see DESIGN.md "RNG". */
+static inline uint32_t tghip_shard_skew(uint32_t shard_count)      /* the smallest odd prime that does not divide shard_count */
+{
+    static const uint32_t primes[6] = {3u, 5u, 7u, 11u, 13u, 17u};
+    for (int i = 0; i < 6; ++i)
+        if (shard_count % primes[i] != 0u)
+            return primes[i];
+    return 1u;
+}
+static inline uint32_t tghip_tile_owner(uint32_t tx, uint32_t ty, uint32_t shard_count)
+{
+    return shard_count <= 1u ? 0u : (tx + ty*tghip_shard_skew(shard_count)) % shard_count;
+}
 #define TGHIP_SOBOL_DIMS 1024u
 #define TGHIP_SOBOL_BITS 52u
 #define TGHIP_TILE_SIZE 16u              /* PathTraceIntegrator::TileSize */

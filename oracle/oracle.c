@@ -2905,7 +2905,7 @@ int oracle_render_aux(const TgHipSceneDesc *s, const TgHipPassDesc *pass, float 
         TravStats st = {0, 0, 0};
         #pragma omp for schedule(dynamic, 1)
         for (int tile = 0; tile < tilesX*tilesY; ++tile) {
-            if ((uint32_t)tile % shardCount != pass->shard_index)
+            if (tghip_tile_owner((uint32_t)(tile % tilesX), (uint32_t)(tile/tilesX), shardCount) != pass->shard_index)
                 continue;
             int x0 = (tile % tilesX)*16, y0 = (tile/tilesX)*16;
             for (int y = y0; y < y0 + 16 && y < h; ++y) {

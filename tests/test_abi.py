@@ -19,7 +19,8 @@ def declared_functions():
     names = []
     for h in HEADERS:
         src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        names += re.findall(r"\b(tghip_[a-z_]+|tgh_[a-z_]+)\s*\(", src)
+        inline = set(re.findall(r"static\s+inline\s+\w+\s+(tghip_[a-z_]+)\s*\(", src))   # header-only helpers (tghip_tile_owner): no symbol
+        names += [n for n in re.findall(r"\b(tghip_[a-z_]+|tgh_[a-z_]+)\s*\(", src) if n not in inline]
     return sorted(set(names))
 
 

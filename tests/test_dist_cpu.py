@@ -133,3 +133,23 @@ def test_shard_pass_validation():
         tgdist.shard_pass(8, 8, 0, 1, 0)
     tiles = [t for r in range(8) for t in tgdist.owned_tiles(r, 8, 1280, 720)]
     assert sorted(tiles) == list(range(80*45))
+
+
+def test_tile_ownership_is_a_two_dimensional_interleave():
+    """tghip_tile_owner (include/tungsten_hip.h) as mirrored by dist.tile_owner: every tile has one owner, the shards are
+    balanced to within one tile per tile row, and -- the point of the diagonal deal -- no shard is a set of vertical stripes,
+    for the BASELINE resolutions (whose tiles per row are all multiples of 8) and every world size up to 16."""
+    from tungsten_amd import dist as tgdist
+    for (w, h) in ((1280, 720), (1920, 1080), (3840, 2160), (80, 45), (333, 211)):
+        tx_n, ty_n = (w + 15)//16, (h + 15)//16
+        for world in range(1, 17):
+            lists = [tgdist.owned_tiles(r, world, w, h) for r in range(world)]
+            assert sorted(t for l in lists for t in l) == list(range(tx_n*ty_n))
+            assert all(l == sorted(l) for l in lists)                       # rendered in row-major order
+            sizes = [len(l) for l in lists]
+            assert max(sizes) - min(sizes) <= ty_n
+            if world > 1 and tx_n >= world and ty_n >= world:
+                for l in lists:
+                    cols = {t % tx_n for t in l}
+                    rows = {t//tx_n for t in l}
+                    assert len(cols) == tx_n and len(rows) == ty_n          # present in every tile column and every tile row

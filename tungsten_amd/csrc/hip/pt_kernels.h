@@ -156,6 +156,8 @@ struct PassParams {
     uint32_t item_begin;       // first item of this launch's workgroups within the batch
     uint32_t first_tile;       // first owned tile of the batch (index into the shard's tile list)
     uint32_t shard_index, shard_count;
+    uint32_t shard_skew;       // tghip_shard_skew(shard_count): tile (tx, ty) belongs to shard (tx + ty*skew) % shard_count
+    const uint32_t *owned_tiles;   // the shard's tiles in row-major order (nullptr when shard_count == 1: every tile, identity)
     uint32_t tiles_x, num_tiles;
     uint32_t width, height;
     uint32_t iter_tag;         // wavefront iteration number (liveness reporting of the fused flat-scene kernels)
@@ -401,12 +403,13 @@ PT_DEV bool queuesEnd(LDS &L, const PathState &st, int q, uint32_t appendMask, i
     return __syncthreads_or(ext != 0u) != 0;
 }
 
-// pixel slot j of the batch -> image pixel (16x16 tile dicing, PathTraceIntegrator.cpp:27-42; tiles of a shard
-// are dealt round-robin).  False for slots of an edge tile that fall outside the image.
+// pixel slot j of the batch -> image pixel (16x16 tile dicing, PathTraceIntegrator.cpp:27-42; a shard owns the tiles
+// tghip_tile_owner deals it, listed in owned_tiles).  False for slots of an edge tile that fall outside the image.
 PT_DEV bool slotPixel(const PassParams &pp, uint32_t j, uint32_t &x, uint32_t &y)
 {
     uint32_t tileLocal = j >> 8, inTile = j & 255u;
-    uint32_t tile = pp.shard_index + (pp.first_tile + tileLocal)*pp.shard_count;
+    uint32_t k = pp.first_tile + tileLocal;          // k-th owned tile (the batch never reaches past the shard's list)
+    uint32_t tile = pp.owned_tiles ? at32(pp.owned_tiles, k) : k;
     if (tile >= pp.num_tiles)
         return false;
     uint32_t tx = tile % pp.tiles_x, ty = tile/pp.tiles_x;

@@ -1905,8 +1905,7 @@ __global__ __launch_bounds__(64) void k_records(PassParams pp, TgHipSampleRecord
     if (r >= numRecords)
         return;
     uint32_t rx = r % pp.variance_w, ry = r/pp.variance_w;
-    uint32_t tile = (rx >> 2) + (ry >> 2)*pp.tiles_x;
-    if (tile % pp.shard_count != pp.shard_index)
+    if (pp.shard_count > 1u && ((rx >> 2) + (ry >> 2)*pp.shard_skew) % pp.shard_count != pp.shard_index)   // tghip_tile_owner
         return;
     const uint32_t cnt = pp.rec_count[r], base = pp.rec_lum[r];
     TgHipSampleRecord rec = records[r];

@@ -137,6 +137,12 @@ struct tghip_ctx {
     float *dSamples = nullptr;            // TGHIP_PASS_SAMPLES: per-sample radiance of the last such pass
     float *redSum = nullptr;              // tghip_reduce_framebuffers: where the reduced image lands when this context is the root
     uint32_t *redCount = nullptr;
+    size_t redCap = 0;
+    // the tiles of the shard the last pass rendered (tghip_tile_owner), on the host and on the device; key = {W, H, shard index, shard count}
+    std::vector<uint32_t> hostOwnedTiles;
+    uint32_t *dOwnedTiles = nullptr;
+    size_t ownedCap = 0;
+    uint32_t ownedKey[4] = {0, 0, 0, 0};                    // pixels redSum / redCount were allocated for (a re-upload may change the resolution)
     size_t samplesCap = 0, samplesFloats = 0;
     bool auxPass = false;                 // the pass being rendered keeps them: BSDF_MASK_ALL shading, no fused / dynamic-fetch shadow kernels
     int thrShadeAll = 256;                // workgroup size of k_shade<BSDF_MASK_ALL> (media scenes, TGHIP_PASS_AUX passes)
@@ -653,6 +659,7 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->fbCount) (void)hipFree(ctx->fbCount);
     if (ctx->dAux) (void)hipFree(ctx->dAux);
     if (ctx->dSamples) (void)hipFree(ctx->dSamples);
+    if (ctx->dOwnedTiles) (void)hipFree(ctx->dOwnedTiles);
     if (ctx->redSum) (void)hipFree(ctx->redSum);
     if (ctx->redCount) (void)hipFree(ctx->redCount);
     if (ctx->partial) (void)hipFree(ctx->partial);
@@ -1366,9 +1373,34 @@ int tghip_wait(tghip_ctx *ctx)
     const uint32_t w = ctx->width, h = ctx->height;
     const uint32_t tilesX = (w + 15)/16, tilesY = (h + 15)/16;
     const uint32_t numTiles = tilesX*tilesY;
-    const uint32_t ownedTiles = numTiles > pass.shard_index ? (numTiles - pass.shard_index + shardCount - 1)/shardCount : 0;
+    // the shard's tiles (tghip_tile_owner: a diagonal interleave), row-major; the device indexes this list (PassParams::owned_tiles)
+    const uint32_t shardSkew = tghip_shard_skew(shardCount);
+    auto ownsTile = [&](uint32_t tx, uint32_t ty) { return tghip_tile_owner(tx, ty, shardCount) == pass.shard_index; };
+    uint32_t ownedTiles = numTiles;
+    if (shardCount > 1) {
+        if (ctx->ownedKey[0] != w || ctx->ownedKey[1] != h || ctx->ownedKey[2] != pass.shard_index || ctx->ownedKey[3] != shardCount) {
+            std::vector<uint32_t> &list = ctx->hostOwnedTiles;
+            list.clear();
+            for (uint32_t ty = 0; ty < tilesY; ++ty)
+                for (uint32_t tx = 0; tx < tilesX; ++tx)
+                    if (ownsTile(tx, ty)) list.push_back(tx + ty*tilesX);
+            if (ctx->ownedCap < list.size()) {
+                if (ctx->dOwnedTiles) (void)hipFree(ctx->dOwnedTiles);
+                ctx->dOwnedTiles = nullptr; ctx->ownedCap = 0;
+                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dOwnedTiles), std::max<size_t>(list.size(), 1)*sizeof(uint32_t)));
+                ctx->ownedCap = list.size();
+            }
+            if (!list.empty())
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->dOwnedTiles, list.data(), list.size()*sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // (the list is host memory of the context; keep it simple: rare)
+            ctx->ownedKey[0] = w; ctx->ownedKey[1] = h; ctx->ownedKey[2] = pass.shard_index; ctx->ownedKey[3] = shardCount;
+        }
+        ownedTiles = uint32_t(ctx->hostOwnedTiles.size());
+    }
     uint32_t spp = pass.spp_end - pass.spp_begin, sppBegin = pass.spp_begin;
     PassParams base{};
+    base.shard_skew = shardSkew;
+    base.owned_tiles = shardCount > 1 ? ctx->dOwnedTiles : nullptr;
     base.flags = pass.flags | (ctx->thinlens ? PT_PASS_THINLENS : 0u) | (ctx->haveMedia ? PT_PASS_MEDIA : 0u);
     base.variance_w = (w + 3)/4;
     if (pass.flags & TGHIP_PASS_SOBOL) {
@@ -1385,7 +1417,7 @@ int tghip_wait(tghip_ctx *ctx)
         uint32_t maxCount = 0;
         for (uint32_t r = 0; r < numRecords; ++r) {
             uint32_t rx = r % base.variance_w, ry = r/base.variance_w;
-            bool owned = ((rx >> 2) + (ry >> 2)*tilesX) % shardCount == pass.shard_index;
+            bool owned = ownsTile(rx >> 2, ry >> 2);
             idx[r] = pass.record_index ? pass.record_index[r] : pass.spp_begin;
             cnt[r] = pass.record_count ? pass.record_count[r] : spp;
             off[r] = uint32_t(total);
@@ -1448,7 +1480,7 @@ int tghip_wait(tghip_ctx *ctx)
         sorted.clear();
         for (uint32_t r = 0; r < numRecords; ++r) {
             uint32_t rx = r % base.variance_w, ry = r/base.variance_w;
-            if (((rx >> 2) + (ry >> 2)*tilesX) % shardCount == pass.shard_index && cnt[r] > 0)
+            if (ownsTile(rx >> 2, ry >> 2) && cnt[r] > 0)
                 sorted.push_back(r);
         }
         // descending by count, ties in record order (a counting sort: the counts of a pass are small integers)
@@ -1746,15 +1778,21 @@ int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rg
         if (!c->haveScene) { rc->error = "tghip_reduce_framebuffers: a context has no scene"; return TGHIP_E_NOSCENE; }
         if (c->width != rc->width || c->height != rc->height) { rc->error = "tghip_reduce_framebuffers: the contexts render different images"; return TGHIP_E_INVALID; }
         for (int d : devices)
-            if (d == c->device) { rc->error = "tghip_reduce_framebuffers: two contexts on one device"; return TGHIP_E_INVALID; }
+            if (d == c->device) { rc->error = "tghip_reduce_framebuffers: two contexts on one device (RCCL wants one rank per device; sum on the host instead)"; return TGHIP_E_UNSUPPORTED; }
         devices.push_back(c->device);
         int w = tghip_wait(c);
         if (w != TGHIP_OK && w != TGHIP_E_ABORTED) return w;
     }
     if (npixels != size_t(rc->width)*rc->height) { rc->error = "pixel count mismatch"; return TGHIP_E_INVALID; }
     HIP_TRY(rc, hipSetDevice(rc->device));
-    if (!rc->redSum) HIP_TRY(rc, hipMalloc(reinterpret_cast<void **>(&rc->redSum), npixels*3*sizeof(float)));
-    if (!rc->redCount) HIP_TRY(rc, hipMalloc(reinterpret_cast<void **>(&rc->redCount), npixels*sizeof(uint32_t)));
+    if (rc->redCap < npixels) {                  // (first call, or the context was re-uploaded with a larger image since)
+        if (rc->redSum) (void)hipFree(rc->redSum);
+        if (rc->redCount) (void)hipFree(rc->redCount);
+        rc->redSum = nullptr; rc->redCount = nullptr; rc->redCap = 0;
+        HIP_TRY(rc, hipMalloc(reinterpret_cast<void **>(&rc->redSum), npixels*3*sizeof(float)));
+        HIP_TRY(rc, hipMalloc(reinterpret_cast<void **>(&rc->redCount), npixels*sizeof(uint32_t)));
+        rc->redCap = npixels;
+    }
 
     std::lock_guard<std::mutex> lock(g_rccl.mutex);
     if (!g_rccl.load()) { rc->error = "tghip_reduce_framebuffers: librccl.so could not be loaded"; return TGHIP_E_UNSUPPORTED; }
@@ -1769,7 +1807,7 @@ int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rg
         if (!ncclTry(g_rccl.commInitAll(comms.data(), n, devices.data()), "ncclCommInitAll")) { g_rccl.comms.erase(devices); return TGHIP_E_HIP; }
     }
     // two reductions per rank (radiance sums, sample counts) in one group; every rank's calls run on its own stream
-    if (!ncclTry(g_rccl.groupStart(), "ncclGroupStart")) return TGHIP_E_HIP;
+    if (!ncclTry(g_rccl.groupStart(), "ncclGroupStart")) { g_rccl.comms.erase(devices); return TGHIP_E_HIP; }
     bool ok = true;
     for (int i = 0; i < n && ok; ++i) {
         tghip_ctx *c = ctxs[i];
@@ -1778,7 +1816,7 @@ int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rg
         ok = ncclTry(g_rccl.reduce(sum, i == root ? rc->redSum : nullptr, npixels*3, ncclFloat32, ncclSum, root, comms[size_t(i)], c->stream), "ncclReduce")
           && ncclTry(g_rccl.reduce(cnt, i == root ? rc->redCount : nullptr, npixels, ncclUint32, ncclSum, root, comms[size_t(i)], c->stream), "ncclReduce");
     }
-    if (!ncclTry(g_rccl.groupEnd(), "ncclGroupEnd") || !ok) return TGHIP_E_HIP;
+    if (!ncclTry(g_rccl.groupEnd(), "ncclGroupEnd") || !ok) { g_rccl.comms.erase(devices); return TGHIP_E_HIP; }   // (a communicator set that failed is not reused)
     for (int i = 0; i < n; ++i) {
         HIP_TRY(rc, hipSetDevice(ctxs[i]->device));
         HIP_TRY(rc, hipStreamSynchronize(ctxs[i]->stream));

@@ -3,6 +3,7 @@
 #include "TraceableScene.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -308,9 +309,9 @@ void PathTraceHipIntegrator::prepareForRender(TraceableScene &scene, uint32_t se
     int available = tghip_device_count();
     if (available <= 0)
         throw std::runtime_error("path_tracer_hip: no HIP device available (there is no CPU fallback)");
-    int devices = std::max(1, std::min(_settings.devices, available));
+    int devices = std::max(1, _settings.shareDevices ? std::min(_settings.devices, 64) : std::min(_settings.devices, available));
     for (int d = 0; d < devices; ++d) {
-        tghip_ctx *ctx = tghip_create(d);
+        tghip_ctx *ctx = tghip_create(d % available);
         if (!ctx)
             throw std::runtime_error(std::string("path_tracer_hip: tghip_create failed: ") + tghip_last_error(nullptr));
         _ctxs.push_back(ctx);
@@ -442,7 +443,12 @@ void PathTraceHipIntegrator::fetchFramebuffer()
         // available the shards are downloaded one by one and added here
         int rc = tghip_reduce_framebuffers(_ctxs.data(), int(_ctxs.size()), 0, _sum.data(), _count.data(), n);
         if (rc == TGHIP_OK) { _imageDirty = false; return; }
-        if (rc != TGHIP_E_UNSUPPORTED) check(rc, _ctxs[0], "tghip_reduce_framebuffers");
+        // Anything else -- no librccl, several contexts on one device, a communicator that cannot be set up (no shared memory or
+        // peer access in a container), a failed reduce -- falls back to the per-device download and host sum below, which needs
+        // nothing but PCIe.  Said once.
+        static std::atomic<bool> warned(false);
+        if (rc != TGHIP_E_UNSUPPORTED && !warned.exchange(true))
+            std::fprintf(stderr, "path_tracer_hip: tghip_reduce_framebuffers failed (%s); summing the shards on the host\n", tghip_last_error(_ctxs[0]));
     }
     std::fill(_sum.begin(), _sum.end(), 0.0f);
     std::fill(_count.begin(), _count.end(), 0u);

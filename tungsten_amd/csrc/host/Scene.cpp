@@ -1251,6 +1251,7 @@ void IntegratorSettings::fromJson(const JsonValue &v)
     v.getField("low_order_scattering", lowOrderScattering);
     v.getField("include_surfaces", includeSurfaces);
     v.getField("devices", devices);
+    v.getField("share_devices", shareDevices);
 }
 
 // ------------------------------------------------------------------------------------------

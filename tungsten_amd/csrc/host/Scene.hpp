@@ -191,6 +191,9 @@ struct IntegratorSettings // TraceSettings.hpp:15-39 + PathTracerSettings.hpp:17
     bool enableConsistencyChecks = false, enableTwoSidedShading = true;
     bool enableLightSampling = true, enableVolumeLightSampling = true, lowOrderScattering = true, includeSurfaces = true;
     int devices = 1;             // path_tracer_hip extension: GPUs used by one integrator
+    bool shareDevices = false;   // path_tracer_hip extension ("share_devices"): `devices` contexts even on fewer GPUs, dealt round-robin
+                                 // (several tile shards, each driven by its own host thread, on one device: how the multi-device path
+                                 // is exercised on a single-GPU box)
     void fromJson(const JsonValue &v);
 };
 

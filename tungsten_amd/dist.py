@@ -1,5 +1,5 @@
-"""Multi-GPU decomposition of a render pass: one process per GPU, 16x16 tiles dealt round-robin
-to ranks (the reference's own dicing, integrators/path_tracer/PathTraceIntegrator.cpp:27-42), and ONE exchange
+"""Multi-GPU decomposition of a render pass: one process per GPU, 16x16 tiles (the reference's
+own dicing, integrators/path_tracer/PathTraceIntegrator.cpp:27-42) dealt to ranks along diagonals (tile_owner), and ONE exchange
 step -- the sum-reduce of the float framebuffer (+ sample counts) to the root over RCCL/xGMI
 (torch.distributed backend "nccl"; "gloo" in the CPU tests).  It is the in-process equivalent of the reference's
 manual `hdrmanip --merge` of independently rendered images (src/hdrmanip/hdrmanip.cpp:69-112).
@@ -16,10 +16,23 @@ def shard_pass(rank, world, spp_begin, spp_end, seed):
     return capi.TgHipPassDesc(spp_begin, spp_end, seed & 0xFFFFFFFF, rank, world, 0)
 
 
+def shard_skew(world):
+    """include/tungsten_hip.h: tghip_shard_skew -- the smallest odd prime that does not divide the shard count."""
+    for p in (3, 5, 7, 11, 13, 17):
+        if world % p:
+            return p
+    return 1
+
+
+def tile_owner(tx, ty, world):
+    """include/tungsten_hip.h: tghip_tile_owner -- tile (tx, ty) of the 16x16 dicing belongs to shard (tx + ty*skew) % world."""
+    return 0 if world <= 1 else (tx + ty*shard_skew(world)) % world
+
+
 def owned_tiles(rank, world, width, height):
-    """Row-major indices of the 16x16 tiles rank `rank` renders."""
-    tiles = ((width + 15)//16)*((height + 15)//16)
-    return range(rank, tiles, world)
+    """Row-major indices of the 16x16 tiles rank `rank` renders, in the order it renders them."""
+    tiles_x, tiles_y = (width + 15)//16, (height + 15)//16
+    return [tx + ty*tiles_x for ty in range(tiles_y) for tx in range(tiles_x) if tile_owner(tx, ty, world) == rank]
 
 
 def reduce_framebuffer(fb_sum, fb_count, dst=0, group=None):
