@@ -183,6 +183,14 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
     variants = [dict(streams=1), dict(streams=2), dict(streams=8), dict(class_streams=1), dict(streams=1, class_streams=1),
                 dict(slots_per_block=512), dict(max_slots=8192), dict(check_interval=1), dict(check_interval=16), dict(blocks_per_cu=4),
                 dict(grid_rounds=2), dict(leaf_batch=9), dict(streams=4, blocks_per_cu=4, check_interval=4)]
+    if scene == "materialtest":
+        # walk time-slicing of the wide traversal kernels (PathState::suspend_*): off, the default, and settings that suspend every walk
+        # after one / three / two turns of every launch -- hundreds of save / resume round trips per ray, shadow slots held and released
+        variants += [dict(suspend_lanes=0), dict(suspend_lanes=64, suspend_turns=1, suspend_min_queue=0),
+                     dict(suspend_lanes=64, suspend_turns=3, suspend_min_queue=0, streams=1, check_interval=1),
+                     dict(suspend_lanes=8, suspend_turns=2, suspend_min_queue=0), dict(suspend_lanes=16, suspend_turns=32, suspend_min_queue=64),
+                     # the sequential walk (one record OR node per turn, k_trace_*_wide<.., DECOUPLED = false>) against the default decoupled one
+                     dict(decouple=0), dict(decouple=0, suspend_lanes=64, suspend_turns=1, suspend_min_queue=0)]
     if scene == "cornell_instances":
         variants += [dict(inst_dyn=0), dict(inst_simple=0), dict(wide_closest=1), dict(wide_shadow=0), dict(leaf_batch_bvh2=1)]
     for opts in variants:
@@ -197,6 +205,29 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
             img, _, c, _ = gpu_render(path, **opts)
             assert (c == 8).all(), opts
             assert np.allclose(img, base, rtol=1e-5, atol=1e-6), opts
+
+
+@pytest.mark.gpu
+def test_suspended_walks_visit_what_uninterrupted_walks_visit(tmp_path):
+    """A suspended walk continues exactly where it stopped: ray, node-visit and record-test counts of a render that suspends every walk
+    after two turns per launch equal those of the render that never suspends (and the image is the same, bit for bit)."""
+    _skip_mt("materialtest")
+    path = scenes.materialtest(tmp_path, resolution=(160, 90), spp=4)
+    res = []
+    for opts in (dict(suspend_lanes=0), dict(suspend_lanes=64, suspend_turns=2, suspend_min_queue=0)):
+        r = tg.Renderer(path, seed=SEED)
+        r.set_option("count_traversal", 1)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        r.render()
+        mean, _, cnt = r.image()
+        c = r.counters()
+        res.append((mean.copy(), cnt.copy(), (c.samples, c.closest_rays, c.shadow_rays, c.shadow_slots, c.nodes_visited, c.prims_tested,
+                                              c.nodes_visited_shadow, c.prims_tested_shadow), c.iterations))
+        r.close()
+    assert res[0][2] == res[1][2]
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+    assert res[1][3] > res[0][3]                    # the time-sliced render really took more, shorter launches
 
 
 def test_tile_shards_partition_the_image(tmp_path):

@@ -69,7 +69,10 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 // Q_FIN: paths whose last vertex was waiting for a shadow result of the dynamic-fetch shadow kernel (k_finish regenerates them)
 // Q_MISS: paths whose ray left the scene -- two of five vertices of an environment-lit scene -- shaded by a launch of their own
 // (handleInfiniteLights, finalise, regenerate) so that they do not sit out the surface shading of the hits in their waves
-enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_FIN = 5, Q_MISS = 6, Q_COUNT = 7 };
+// Q_HOLD: extension rays of paths whose shadow slot is a SUSPENDED walk (below): the path must not reach its next vertex -- whose NEE
+// would overwrite the slot's shadow records -- before those rays are resolved, so k_trace_shadow_wide moves its bit from Q_EXT here
+// when it suspends the slot and back when the resumed walk completes
+enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_FIN = 5, Q_MISS = 6, Q_HOLD = 7, Q_COUNT = 8 };
 
 struct BlockCtl {                 // one per persistent workgroup; only that workgroup touches it
     uint32_t item_cursor;         // workgroup-local linear index of the next work item
@@ -80,6 +83,11 @@ struct BlockCtl {                 // one per persistent workgroup; only that wor
 struct BlockStats {               // traversal statistics (count_traversal option), one per workgroup
     unsigned long long nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow;
     unsigned long long prof[16];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds, tools/gpu_profile_sections.sh)
+    // count_traversal: where the waves of the wide traversal kernels spend their time ([0] closest-hit, [1] shadow), in wall_clock64 ticks
+    // (10 ns) summed over waves: 0 queue expansion, 1 loop while the workgroup's queue has rays, 2 loop after it ran dry, 3 waiting for the
+    // workgroup's other waves + write-back; 4 waves; 5 / 6 loop turns before / after dry; 7 / 8 busy lanes summed over those turns;
+    // 9 walks suspended, 10 walks resumed, 11 longest loop of a wave (max, ticks)
+    unsigned long long walk[2][12];
 #ifdef PT_PROFILE
     unsigned long long profCls[3][16];   // the same per shading class of the launch (0 / 1 / 2 = escaped paths)
 #endif
@@ -127,6 +135,16 @@ struct PathState {
     uint32_t num_slots, slots_per_block;
     uint32_t leaf_batch;                   // dynamic-fetch traversal: lanes waiting at a leaf before the leaf code runs (1 = at once)
     uint32_t leaf_batch_bvh2;              // the same for the BVH2 dynamic-fetch kernels (k_trace_closest_dyn / k_trace_shadow_dyn)
+    // Suspended walks ("walk time-slicing"): once a workgroup's queue has run dry, a wave of the wide traversal kernels that is
+    // down to <= suspend_lanes busy lanes does not run its last, longest walks to the end at a few per cent lane occupancy -- it writes
+    // the state of every walk that has had >= suspend_turns turns in this launch (WideState, the group stack, the best hit / the
+    // shadow slot's partial result) to the slot's walk arrays, re-queues the slot and ends; the next launch of the same kernel picks the
+    // walk up where it stopped, in a full wave.  A walk is a pure function of its ray, so hits and visit counts are unchanged.
+    // suspend_lanes = 0: off.  Workgroups whose queue is shorter than suspend_min_queue never suspend (the end of a pass).
+    uint32_t suspend_lanes, suspend_turns, suspend_min_queue;
+    uint32_t walk_base;                    // first of the walk arrays of the pool: +0 grpBase grpMasks triBase triMask, +1 triValid node sp -,
+                                           // +2 (shadow slots) partial result.rgb | ray index, +3 tri2Base tri2Mask tri2Valid -,
+                                           // +4.. the group stack, two 8-byte entries per array
 };
 
 PT_DEV uint32_t slotOffset(const PathState &st, uint32_t a, uint32_t slot)     // `a` is a literal at every call site: the selects fold
@@ -384,7 +402,7 @@ PT_DEV uint32_t orderGet(const OrderRegs &r, uint32_t k)   // k is wave-uniform
 // Kernel epilogue: writes back the consumed (now empty) and appended bitmaps.  Returns (to thread 0..W-1) nothing;
 // `anyExt` tells whether the extension queue holds work.
 template<class LDS>
-PT_DEV bool queuesEnd(LDS &L, const PathState &st, int q, uint32_t appendMask, int q2 = -1, bool atomicAppend = false)
+PT_DEV bool queuesEnd(LDS &L, const PathState &st, int q, uint32_t appendMask, int q2 = -1, bool atomicAppend = false, uint32_t liveMask = 0u)
 {
     __syncthreads();
     const uint32_t W = st.slots_per_block >> 5;
@@ -399,6 +417,9 @@ PT_DEV bool queuesEnd(LDS &L, const PathState &st, int q, uint32_t appendMask, i
                 atomicOr(&st.bm[(uint32_t)k*st.bmStride + blockIdx.x*W + wd], L.bm[k][wd]);
         }
         ext |= L.bm[Q_EXT][wd] | L.bm[Q_EXTP][wd];
+#pragma unroll
+        for (int k = 0; k < Q_COUNT; ++k)
+            if ((liveMask >> k) & 1u) ext |= L.bm[k][wd];     // (only bitmaps this kernel loaded: q, q2 or non-atomic appendMask)
     }
     return __syncthreads_or(ext != 0u) != 0;
 }
@@ -653,6 +674,9 @@ struct WideState {
     uint32_t grpBase, grpMasks;   // hits still to visit (bits 0-7, traversal order) | imask << 8
     uint32_t triBase, triMask;    // records still to test: bit positions in the node's leaf_valid
     uint32_t triValid;
+    // the DECOUPLED walk of the wavefront kernels (wideNextNode): records of the node visited last while the previous node's are still
+    // being tested (tri2Mask != 0: no further node is visited until they have moved up)
+    uint32_t tri2Base, tri2Mask, tri2Valid;
     int node;                     // node to visit next; -1: take it from the group / the stack
     int sp;
     // scenes with instance records (the INST variants): the node whose records are being tested, the instance record the walk
@@ -660,7 +684,7 @@ struct WideState {
     uint32_t curNode;
     int curInst;
 };
-PT_DEV void wideStart(WideState &w) { w.grpBase = 0; w.grpMasks = 0; w.triBase = 0; w.triMask = 0; w.triValid = 0; w.node = 0; w.sp = 0; w.curNode = 0; w.curInst = -1; }
+PT_DEV void wideStart(WideState &w) { w.grpBase = 0; w.grpMasks = 0; w.triBase = 0; w.triMask = 0; w.triValid = 0; w.tri2Base = 0; w.tri2Mask = 0; w.tri2Valid = 0; w.node = 0; w.sp = 0; w.curNode = 0; w.curInst = -1; }
 // Two-level scenes put two more kinds of entries on the group stack when the walk enters an instance (wideEnterInstance):
 #define WIDE_LEAVE     0xFFFFFFFFu   /* x: the master's subtree is done, the ray goes back to world space */
 #define WIDE_RECS_FLAG 0x80000000u   /* x = flag | node: records of that (top-level) node still to test, y = their triMask */
@@ -699,6 +723,30 @@ PT_DEV int wideNext(WideState &w, uint32_t octInv, uint2 *stack, int stride, uin
     if (INST) w.curNode = idx;
     return 2;
 }
+// The node half of wideNext alone (single-level scenes): the next node of the walk in `idx`, false when group and stack are empty.
+PT_DEV bool wideNextNode(WideState &w, uint32_t octInv, uint2 *stack, int stride, uint32_t &idx)
+{
+    if (w.node < 0) {
+        if ((w.grpMasks & 0xFFu) == 0u) {
+            if (w.sp == 0)
+                return false;
+            w.sp--;
+            uint2 e = stack[w.sp*stride];
+            w.grpBase = e.x; w.grpMasks = e.y;
+        }
+        uint32_t hits = w.grpMasks & 0xFFu, imask = w.grpMasks >> 8;
+        uint32_t slot = ((uint32_t)__ffs((int)hits) - 1u) ^ octInv;
+        w.node = (int)(w.grpBase + (uint32_t)__popc(imask & ((1u << slot) - 1u)));
+        hits &= hits - 1u;
+        w.grpMasks = (imask << 8) | hits;
+        if (hits) { stack[w.sp*stride] = make_uint2(w.grpBase, w.grpMasks); w.sp++; }
+    }
+    idx = (uint32_t)w.node;
+    w.node = -1;
+    return true;
+}
+// nothing left to look at: no record, no node, nothing on the stack
+PT_DEV bool wideWalkOver(const WideState &w) { return w.triMask == 0u && w.tri2Mask == 0u && w.node < 0 && (w.grpMasks & 0xFFu) == 0u && w.sp == 0; }
 // code 4: q1 = the second 16 bytes of node `idx`
 PT_DEV void wideResumeRecords(WideState &w, uint32_t idx, float4 q1)
 {
@@ -767,6 +815,33 @@ PT_DEV void wideVisit(WideState &w, float4 q0, float4 q1, float4 q2, float4 q3, 
     w.triBase = __float_as_uint(q1.y);
     w.triValid = __float_as_uint(q1.z);
     w.triMask = x & w.triValid;
+}
+// ---- suspended walks (PathState::suspend_*) -------------------------------------------------------------------------
+// The flag that a queued ray / shadow slot is a suspended walk is the sign bit of its tmin word (A_RAY_O.w / A_SH_O.w: 1e-4, 5e-4 or 0).
+#define WALK_SUSPENDED_BIT 0x80000000u
+PT_DEV void walkSave(const PathState &st, uint32_t slot, const WideState &w, const uint2 *stack, int stride)
+{
+    slotU4(st, st.walk_base, slot) = make_uint4(w.grpBase, w.grpMasks, w.triBase, w.triMask);
+    slotU4(st, st.walk_base + 1u, slot) = make_uint4(w.triValid, (uint32_t)w.node, (uint32_t)w.sp, 0u);
+    slotU4(st, st.walk_base + 3u, slot) = make_uint4(w.tri2Base, w.tri2Mask, w.tri2Valid, 0u);
+    for (int l = 0; l < w.sp; l += 2) {
+        const uint2 a = stack[l*stride], b = l + 1 < w.sp ? stack[(l + 1)*stride] : make_uint2(0u, 0u);
+        slotU4(st, st.walk_base + 4u + (uint32_t)(l >> 1), slot) = make_uint4(a.x, a.y, b.x, b.y);
+    }
+}
+PT_DEV void walkRestore(const PathState &st, uint32_t slot, WideState &w, uint2 *stack, int stride)
+{
+    const uint4 a = slotU4(st, st.walk_base, slot), b = slotU4(st, st.walk_base + 1u, slot);
+    w.grpBase = a.x; w.grpMasks = a.y; w.triBase = a.z; w.triMask = a.w;
+    w.triValid = b.x; w.node = (int)b.y; w.sp = (int)b.z;
+    const uint4 c = slotU4(st, st.walk_base + 3u, slot);
+    w.tri2Base = c.x; w.tri2Mask = c.y; w.tri2Valid = c.z;
+    w.curNode = 0; w.curInst = -1;
+    for (int l = 0; l < w.sp; l += 2) {
+        const uint4 e = slotU4(st, st.walk_base + 4u + (uint32_t)(l >> 1), slot);
+        stack[l*stride] = make_uint2(e.x, e.y);
+        if (l + 1 < w.sp) stack[(l + 1)*stride] = make_uint2(e.z, e.w);
+    }
 }
 PT_DEV const float4 *wideNodePtr(const DeviceScene &s, uint32_t idx) { return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)(idx*s.wide_stride)); }
 

@@ -31,6 +31,21 @@
 #define PROF_FLUSH(stats)
 #endif
 
+// count_traversal: time and lane-occupancy breakdown of the wide traversal kernels (BlockStats::walk)
+#define WALK_PROF_DECL unsigned long long wpLoop = COUNT ? wall_clock64() : 0ull, wpDry = 0ull, wpLoopEnd = 0ull; uint32_t wpBusy = 0, wpBusyDry = 0, wpSuspended = 0, wpResumed = 0
+#define WALK_PROF_FLUSH(K, TURNS, DRYTURNS) do { \
+        const unsigned long long wpEnd_ = wall_clock64(); \
+        if (wpDry == 0ull) wpDry = wpLoopEnd; \
+        uint32_t su_ = wpSuspended, re_ = wpResumed; \
+        for (int off_ = 32; off_ > 0; off_ >>= 1) { su_ += __shfl_down(su_, off_); re_ += __shfl_down(re_, off_); } \
+        if (laneId() == 0) { \
+            unsigned long long *wk_ = st.stats[blockIdx.x].walk[K]; \
+            atomicAdd(&wk_[0], wpLoop - wpStart); atomicAdd(&wk_[1], wpDry - wpLoop); atomicAdd(&wk_[2], wpLoopEnd - wpDry); atomicAdd(&wk_[3], wpEnd_ - wpLoopEnd); \
+            atomicAdd(&wk_[4], 1ull); atomicAdd(&wk_[5], (unsigned long long)(TURNS)); atomicAdd(&wk_[6], (unsigned long long)(DRYTURNS)); \
+            atomicAdd(&wk_[7], (unsigned long long)wpBusy); atomicAdd(&wk_[8], (unsigned long long)wpBusyDry); \
+            atomicAdd(&wk_[9], (unsigned long long)su_); atomicAdd(&wk_[10], (unsigned long long)re_); atomicMax(&wk_[11], wpLoopEnd - wpLoop); \
+        } } while (0)
+
 // BSDF type sets of the shading-kernel variants (pt_scene.h BsdfOps<D, M>)
 #define TYPES_SIMPLE (BSDF_BIT(TGHIP_BSDF_LAMBERT) | BSDF_BIT(TGHIP_BSDF_NULL) | BSDF_BIT(TGHIP_BSDF_ERROR))
 #define MASK_SIMPLE  (TYPES_SIMPLE | FEAT_ALL)
@@ -472,7 +487,11 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
 #ifndef WIDE_SHADOW_BOUNDS
 #define WIDE_SHADOW_BOUNDS SHADOW_DYN_BOUNDS
 #endif
-template<bool COUNT, bool SOLIDS = true, bool INST = false>
+// DECOUPLED (single-level scenes): a turn tests the lane's next pending record AND visits its next node -- the walk does not wait for
+// the records of the node visited last before it moves on (their outcome only tightens tmax, never what is visited next), so a ray
+// needs about max(nodes, records) turns instead of their sum; a node visited before an earlier node's records have shortened the ray
+// may report a few children more (conservative: hits unchanged, visit counts a little above the sequential walk's).
+template<bool COUNT, bool SOLIDS = true, bool INST = false, bool DECOUPLED = false>
 __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsDyn[];
@@ -483,6 +502,7 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
     const int stride = (int)blockDim.x;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     if (threadIdx.x == 0) fetchNext = 0;
+    const unsigned long long wpStart = COUNT ? wall_clock64() : 0ull;
     queuesBegin(L, st, ctl, Q_EXTP, 0u, order, Q_EXT);
     const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
@@ -498,7 +518,11 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
     float tmax = 0.0f;
     float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     int hitInst = -1;
+    uint32_t hitCls = 2;                         // DECOUPLED: shading class of the best hit's record
     bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
+    uint32_t age = 0;                            // turns this lane's walk has had in this launch (PathState::suspend_turns)
+    const bool maySuspend = !INST && st.suspend_lanes != 0u && n >= st.suspend_min_queue;
+    WALK_PROF_DECL;
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
         if (!exhausted && __popcll(busyMask) <= 48) {
@@ -515,23 +539,95 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                     slot = first + local;
                     float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
                     ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
+                    bool resumed = false;
+                    if constexpr (!INST) {
+                        resumed = (__float_as_uint(ro.w) & WALK_SUSPENDED_BIT) != 0u;   // a walk an earlier launch suspended (below)
+                        ray.tmin = __uint_as_float(__float_as_uint(ro.w) & ~WALK_SUSPENDED_BIT);
+                    }
                     wr = wideRaySetup(ray);
-                    wideStart(w);
-                    tmax = ray.tmax;
-                    hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+                    if (!resumed) {
+                        wideStart(w);
+                        tmax = ray.tmax;
+                        hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+                        rays++;
+                    } else {
+                        walkRestore(st, slot, w, stack, stride);
+                        if (COUNT) wpResumed++;
+                        hit = slotF4(st, A_HIT, slot);                      // the best hit so far
+                        tmax = hit.x;
+                        if (DECOUPLED && __float_as_int(hit.w) >= 0) hitCls = at32(s.rec_class, (uint32_t)__float_as_int(hit.w));
+                        slotF4(st, A_RAY_O, slot).w = ray.tmin;             // (the ray is an ordinary one again)
+                    }
                     hitInst = -1;
+                    age = 0;
                     busy = true;
-                    rays++;
                 }
             }
-            if (base + (uint32_t)__popcll(want) >= n)
+            if (base + (uint32_t)__popcll(want) >= n) {
                 exhausted = true;
+                if (COUNT) wpDry = wall_clock64();
+            }
             busyMask = __ballot(busy);
+        }
+        if constexpr (!INST) {
+            // The queue is dry and this wave is down to its last, longest walks: those that have had their turns in this launch are
+            // suspended -- state to the slot's walk arrays, the ray back on the extension queue -- and continue in the next launch
+            // in a full wave (PathState::suspend_*).
+            if (maySuspend && exhausted && (uint32_t)__popcll(busyMask) <= st.suspend_lanes) {
+                if (busy && age >= st.suspend_turns) {
+                    walkSave(st, slot, w, stack, stride);
+                    if (COUNT) wpSuspended++;
+                    slotF4(st, A_HIT, slot) = hit;
+                    slotF4(st, A_RAY_O, slot).w = __uint_as_float(__float_as_uint(ray.tmin) | WALK_SUSPENDED_BIT);
+                    queuePush(true, local, L, Q_EXT);
+                    busy = false;
+                }
+                busyMask = __ballot(busy);
+            }
         }
         if (busyMask == 0ull)
             break;
-        if (COUNT) { turns++; dryTurns += exhausted ? 1u : 0u; }
-        if constexpr (!INST) {
+        age++;
+        if (COUNT) { turns++; dryTurns += exhausted ? 1u : 0u; if (exhausted) wpBusyDry += (uint32_t)__popcll(busyMask); else wpBusy += (uint32_t)__popcll(busyMask); }
+        if constexpr (!INST && DECOUPLED) {
+            uint32_t recIdx = 0, nodeIdx = 0;
+            bool hasRec = false, hasNode = false, finished = false;
+            if (busy) {
+                if (w.triMask == 0u && w.tri2Mask != 0u) { w.triBase = w.tri2Base; w.triMask = w.tri2Mask; w.triValid = w.tri2Valid; w.tri2Mask = 0u; }
+                if (w.triMask) {
+                    const uint32_t b = (uint32_t)__ffs((int)w.triMask) - 1u;
+                    recIdx = w.triBase + (uint32_t)__popc(w.triValid & ((1u << b) - 1u));
+                    w.triMask &= w.triMask - 1u;
+                    hasRec = true;
+                }
+                if (w.tri2Mask == 0u)            // (room for the records of the node visited now)
+                    hasNode = wideNextNode(w, wr.octInv, stack, stride, nodeIdx);
+            }
+            float4 r0, r1, r2, q0, q1, q2, q3, q4;
+            uint32_t recCls = 0;                  // (fetched with the record: publishing a hit must not wait for a dependent load)
+            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); recCls = at32(s.rec_class, recIdx); }
+            if (hasNode) { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+            if (hasRec) {
+                if (COUNT) prims++;
+                uint32_t meta;
+                if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta))
+                    hitCls = recCls;
+            }
+            if (hasNode) {
+                if (COUNT) nodes++;
+                const uint32_t ob = w.triBase, om = w.triMask, ov = w.triValid;
+                wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+                if (om) { w.tri2Base = w.triBase; w.tri2Mask = w.triMask; w.tri2Valid = w.triValid; w.triBase = ob; w.triMask = om; w.triValid = ov; }
+            }
+            if (busy && wideWalkOver(w)) {
+                // publish the hit and bin the path by shading class (in the turn that looked at the walk's last record / node)
+                slotF4(st, A_HIT, slot) = hit;
+                const uint32_t cls = __float_as_int(hit.w) < 0 ? 2u : hitCls;
+                queuePush(true, local, L, cls == 0u ? Q_SHADE0 : cls == 1u ? Q_SHADE1 : Q_MISS);
+                busy = false;
+            }
+            (void)finished;
+        } else if constexpr (!INST) {
             // What the lane looks at this turn: its next record, its next node, or -- when that record is the last one of the node
             // visited before -- BOTH: the node to visit next does not depend on the record's outcome (the group's order is fixed),
             // only its slab tests do, and they run after the record test; so the walk is the one wideNext defines, a record-bearing
@@ -626,6 +722,7 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
             }
             }
     }
+    if (COUNT) wpLoopEnd = wall_clock64();
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
     queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1) | (1u << Q_MISS), Q_EXTP);
@@ -634,6 +731,7 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
     }
     if (COUNT && laneId() == 0) { atomicAdd(&st.stats[blockIdx.x].prof[10], (unsigned long long)turns); atomicAdd(&st.stats[blockIdx.x].prof[11], (unsigned long long)dryTurns); }
+    if (COUNT) WALK_PROF_FLUSH(0, turns - dryTurns, dryTurns);
 }
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
@@ -1609,7 +1707,11 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
     const int stride = (int)blockDim.x;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     if (threadIdx.x == 0) fetchNext = 0;
-    queuesBegin(L, st, ctl, Q_SHADOW, 1u << Q_FIN, order);
+    const unsigned long long wpStart = COUNT ? wall_clock64() : 0ull;
+    uint32_t turns = 0, dryTurns = 0;
+    // (the extension and hold queues are loaded and written back too: suspending / resolving a slot moves its path's bit between them)
+    const uint32_t appendMask = (1u << Q_FIN) | (!INST && st.suspend_lanes != 0u ? (1u << Q_EXT) | (1u << Q_HOLD) : 0u);
+    queuesBegin(L, st, ctl, Q_SHADOW, appendMask, order);
     const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const int minBounces = s.settings.min_bounces;
@@ -1628,24 +1730,28 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
     f3 contrib = splat3(0.0f);
     int endCap = -1;
     bool exhausted = false;
+    uint32_t age = 0;                            // turns this lane's slot has had in this launch (PathState::suspend_turns)
+    bool held = false;                           // the slot is a resumed one: its path's extension ray may sit in Q_HOLD
+    const bool maySuspend = !INST && st.suspend_lanes != 0u && n >= st.suspend_min_queue;
 
     // sets up ray `r` (or the next valid one) of the current slot; returns false when the slot has no ray left
-    auto setupRay = [&]() -> bool {
+    // (resume: ray `r` itself, whose suspended walk -- already in `w` -- goes on: the checks below passed when it was first set up)
+    auto setupRay = [&](bool resume = false) -> bool {
         for (; r < 2; ++r) {
             float4 c = r == 0 ? slotF4(st, A_SH_C0, slot) : slotF4(st, A_SH_C1, slot);
             uint32_t tag = __float_as_uint(c.w);
-            if (tag == 0xFFFFFFFFu)
+            if (tag == 0xFFFFFFFFu && !resume)
                 continue;
             float4 sd = r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot);
             endCap = (int)(tag & 0xFFFFFFu);
             int bounce = (int)(tag >> 24);
-            rays++;
-            if (bounce < minBounces)
+            if (!resume) rays++;
+            if (bounce < minBounces && !resume)
                 continue;                        // contributes nothing (TraceBase.cpp:114-115 with minBounces)
             contrib = xyz(c);
             ray.o = so; ray.d = xyz(sd); ray.tmin = eps; ray.tmax = sd.w;
             wr = wideRaySetup(ray);
-            wideStart(w);
+            if (!resume) wideStart(w);
             return true;
         }
         return false;
@@ -1659,9 +1765,19 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
         em = em + xyz(p);
         slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
         queuePush(FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE, local, L, Q_FIN);
+        if constexpr (!INST) {
+            if (held) {                          // the path's extension ray was held back while this slot was suspended: release it
+                const uint32_t bit = 1u << (local & 31u);
+                if (L.bm[Q_HOLD][local >> 5] & bit) {
+                    atomicAnd(&L.bm[Q_HOLD][local >> 5], ~bit);
+                    atomicOr(&L.bm[Q_EXT][local >> 5], bit);
+                }
+            }
+        }
         busy = false;
     };
 
+    WALK_PROF_DECL;
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
         if (!exhausted && __popcll(busyMask) <= 48) {
@@ -1676,22 +1792,62 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                 if (i < n) {
                     local = order[i];
                     slot = first + local;
-                    slots++;
                     float4 o4 = slotF4(st, A_SH_O, slot);
                     so = xyz(o4); eps = o4.w;
-                    result = splat3(0.0f);
-                    r = 0;
+                    bool resumed = false;
+                    if constexpr (!INST) {
+                        resumed = (__float_as_uint(o4.w) & WALK_SUSPENDED_BIT) != 0u;   // a slot an earlier launch suspended (below)
+                        eps = __uint_as_float(__float_as_uint(o4.w) & ~WALK_SUSPENDED_BIT);
+                    }
+                    held = resumed;
+                    age = 0;
                     busy = true;
-                    if (!setupRay())
-                        finishSlot();
+                    if (!resumed) {
+                        slots++;
+                        result = splat3(0.0f);
+                        r = 0;
+                        if (!setupRay())
+                            finishSlot();
+                    } else {
+                        walkRestore(st, slot, w, stack, stride);
+                        if (COUNT) wpResumed++;
+                        const float4 part = slotF4(st, st.walk_base + 2u, slot);
+                        result = xyz(part); r = __float_as_int(part.w);
+                        slotF4(st, A_SH_O, slot).w = eps;                   // (an ordinary shadow slot again)
+                        (void)setupRay(true);
+                    }
                 }
             }
-            if (base + (uint32_t)__popcll(want) >= n)
+            if (base + (uint32_t)__popcll(want) >= n) {
                 exhausted = true;
+                if (COUNT) wpDry = wall_clock64();
+            }
             busyMask = __ballot(busy);
+        }
+        if constexpr (!INST) {
+            // the queue is dry and the wave is down to its last, longest walks: suspend those that have had their turns (k_trace_closest_wide).
+            // The slot stays on the shadow queue; its path's extension ray, if it has one, waits in Q_HOLD until the slot is resolved.
+            if (maySuspend && exhausted && (uint32_t)__popcll(busyMask) <= st.suspend_lanes) {
+                if (busy && age >= st.suspend_turns) {
+                    walkSave(st, slot, w, stack, stride);
+                    if (COUNT) wpSuspended++;
+                    slotF4(st, st.walk_base + 2u, slot) = mk4(result, __int_as_float(r));
+                    slotF4(st, A_SH_O, slot).w = __uint_as_float(__float_as_uint(eps) | WALK_SUSPENDED_BIT);
+                    queuePush(true, local, L, Q_SHADOW);
+                    const uint32_t bit = 1u << (local & 31u);
+                    if (L.bm[Q_EXT][local >> 5] & bit) {
+                        atomicAnd(&L.bm[Q_EXT][local >> 5], ~bit);
+                        atomicOr(&L.bm[Q_HOLD][local >> 5], bit);
+                    }
+                    busy = false;
+                }
+                busyMask = __ballot(busy);
+            }
         }
         if (busyMask == 0ull)
             break;
+        age++;
+        if (COUNT) { turns++; dryTurns += exhausted ? 1u : 0u; if (exhausted) wpBusyDry += (uint32_t)__popcll(busyMask); else wpBusy += (uint32_t)__popcll(busyMask); }
         if constexpr (!INST) {
             // a record that is the last one of its node is fetched together with the node the walk visits next (k_trace_closest_wide)
             if (busy) {
@@ -1782,11 +1938,12 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
             }
             }
     }
+    if (COUNT) wpLoopEnd = wall_clock64();
     waveAddStat(&L.shadow_rays, rays);
     waveAddStat(&L.shadow_slots, slots);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
 
-    queuesEnd(L, st, Q_SHADOW, 1u << Q_FIN);
+    queuesEnd(L, st, Q_SHADOW, appendMask);
     if (threadIdx.x == 0) {
         ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
         if (COUNT) {
@@ -1795,6 +1952,227 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
             bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
         }
     }
+    if (COUNT) WALK_PROF_FLUSH(1, turns - dryTurns, dryTurns);
+}
+
+// k_trace_shadow_wide for single-level scenes, rebuilt around what its waves were waiting for (count_traversal: 5.0 us per loop turn
+// against 3.4 us in the closest-hit kernel for the same instruction mix): a slot's second ray used to be set up, and a finished slot's
+// NEE term added to its path, by the one or two lanes that had just got there -- global loads in divergent code, whose latency the
+// whole wave sat out in nearly every turn.  Here
+//   * both rays of a slot are fetched when the slot is (five independent loads in the refill block): the second ray's set-up is
+//     register moves;
+//   * a finished slot only marks its lane; the NEE terms of all marked lanes are added in one go right before the next refill (or,
+//     once the queue is dry, in the turn they finish), so their loads fly together and once per refill instead of once per turn;
+//   * the walk is the DECOUPLED one of k_trace_closest_wide: a pending record AND the next node per turn.
+// Same queues, same suspended-walk protocol (Q_HOLD), same results as k_trace_shadow_wide.
+template<bool COUNT, bool SOLIDS = true>
+__global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
+    uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + (st.slots_per_block >> 1)) + threadIdx.x;
+    const int stride = (int)blockDim.x;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    if (threadIdx.x == 0) fetchNext = 0;
+    const unsigned long long wpStart = COUNT ? wall_clock64() : 0ull;
+    uint32_t turns = 0, dryTurns = 0;
+    const uint32_t appendMask = (1u << Q_FIN) | (st.suspend_lanes != 0u ? (1u << Q_EXT) | (1u << Q_HOLD) : 0u);
+    queuesBegin(L, st, ctl, Q_SHADOW, appendMask, order);
+    const uint32_t n = L.n;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    const int minBounces = s.settings.min_bounces;
+    uint32_t nodes = 0, prims = 0, rays = 0, slots = 0;
+
+    bool busy = false, pendingFinish = false, held = false;
+    uint32_t slot = 0, local = 0;
+    int r = 0;                                   // ray of the slot being traced (0: light sample, 1: bsdf sample)
+    f3 so = splat3(0.0f);
+    float eps = 0.0f;
+    f3 result = splat3(0.0f);
+    float4 c1 = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu)), d1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the slot's second ray
+    RayD ray; ray.o = splat3(0.0f); ray.d = splat3(1.0f); ray.tmin = 0.0f; ray.tmax = 0.0f;
+    WideRay wr; wr.idir = splat3(1.0f); wr.octInv = 0u;
+    WideState w;
+    wideStart(w);
+    f3 contrib = splat3(0.0f);
+    int endCap = -1;
+    bool exhausted = false;
+    uint32_t age = 0;
+    const bool maySuspend = st.suspend_lanes != 0u && n >= st.suspend_min_queue;
+
+    // the lane takes ray (c, sd) if it has to be traced (k_trace_shadow_wide: setupRay)
+    auto tryRay = [&](float4 c, float4 sd, bool resume) -> bool {
+        const uint32_t tag = __float_as_uint(c.w);
+        if (tag == 0xFFFFFFFFu && !resume)
+            return false;
+        endCap = (int)(tag & 0xFFFFFFu);
+        if (!resume) {
+            rays++;
+            if ((int)(tag >> 24) < minBounces)
+                return false;                    // contributes nothing (TraceBase.cpp:114-115 with minBounces)
+        }
+        contrib = xyz(c);
+        ray.o = so; ray.d = xyz(sd); ray.tmin = eps; ray.tmax = sd.w;
+        wr = wideRaySetup(ray);
+        if (!resume) wideStart(w);
+        return true;
+    };
+    // ray r is done: on to the slot's second ray, or the slot is finished (its NEE term is added at the next refill)
+    auto nextRay = [&]() {
+        if (r == 0) {
+            r = 1;
+            if (tryRay(c1, d1, false))
+                return;
+        }
+        busy = false;
+        pendingFinish = true;
+    };
+
+    WALK_PROF_DECL;
+    for (;;) {
+        unsigned long long busyMask = __ballot(busy);
+        const bool refill = !exhausted && __popcll(busyMask) <= 48;
+        if ((refill || exhausted) && __ballot(pendingFinish) != 0ull) {
+            if (pendingFinish) {
+                // NEE term -> path radiance; paths that ended at this vertex go on the finished list
+                const float4 wgt = slotF4(st, A_SH_W, slot), p = slotF4(st, A_SH_P, slot), e4 = slotF4(st, A_EMI, slot);
+                f3 em = xyz(e4);
+                em = em + (result*wgt.w)*xyz(wgt);           // emission += estimateDirect(...)*throughput
+                em = em + xyz(p);
+                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
+                queuePush(FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE, local, L, Q_FIN);
+                if (held) {                                  // the path's extension ray was held back while this slot was suspended: release it
+                    const uint32_t bit = 1u << (local & 31u);
+                    if (L.bm[Q_HOLD][local >> 5] & bit) {
+                        atomicAnd(&L.bm[Q_HOLD][local >> 5], ~bit);
+                        atomicOr(&L.bm[Q_EXT][local >> 5], bit);
+                    }
+                }
+                pendingFinish = false;
+            }
+        }
+        if (refill) {
+            unsigned long long want = ~busyMask;
+            uint32_t lane = laneId();
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
+            base = __shfl(base, 0);
+            if (!busy) {
+                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    local = order[i];
+                    slot = first + local;
+                    const float4 o4 = slotF4(st, A_SH_O, slot), c0 = slotF4(st, A_SH_C0, slot), d0 = slotF4(st, A_SH_D0, slot);
+                    c1 = slotF4(st, A_SH_C1, slot); d1 = slotF4(st, A_SH_D1, slot);
+                    so = xyz(o4);
+                    const bool resumed = (__float_as_uint(o4.w) & WALK_SUSPENDED_BIT) != 0u;   // a slot an earlier launch suspended (below)
+                    eps = __uint_as_float(__float_as_uint(o4.w) & ~WALK_SUSPENDED_BIT);
+                    held = resumed;
+                    age = 0;
+                    busy = true;
+                    if (!resumed) {
+                        slots++;
+                        result = splat3(0.0f);
+                        r = 0;
+                        if (!tryRay(c0, d0, false))
+                            nextRay();
+                    } else {
+                        walkRestore(st, slot, w, stack, stride);
+                        if (COUNT) wpResumed++;
+                        const float4 part = slotF4(st, st.walk_base + 2u, slot);
+                        result = xyz(part); r = __float_as_int(part.w);
+                        slotF4(st, A_SH_O, slot).w = eps;                   // (an ordinary shadow slot again)
+                        (void)tryRay(r == 0 ? c0 : c1, r == 0 ? d0 : d1, true);
+                    }
+                }
+            }
+            if (base + (uint32_t)__popcll(want) >= n) {
+                exhausted = true;
+                if (COUNT) wpDry = wall_clock64();
+            }
+            busyMask = __ballot(busy);
+        }
+        // the queue is dry and the wave is down to its last, longest walks: suspend those that have had their turns (k_trace_closest_wide).
+        // The slot stays on the shadow queue; its path's extension ray, if it has one, waits in Q_HOLD until the slot is resolved.
+        if (maySuspend && exhausted && (uint32_t)__popcll(busyMask) <= st.suspend_lanes) {
+            if (busy && age >= st.suspend_turns) {
+                walkSave(st, slot, w, stack, stride);
+                if (COUNT) wpSuspended++;
+                slotF4(st, st.walk_base + 2u, slot) = mk4(result, __int_as_float(r));
+                slotF4(st, A_SH_O, slot).w = __uint_as_float(__float_as_uint(eps) | WALK_SUSPENDED_BIT);
+                queuePush(true, local, L, Q_SHADOW);
+                const uint32_t bit = 1u << (local & 31u);
+                if (L.bm[Q_EXT][local >> 5] & bit) {
+                    atomicAnd(&L.bm[Q_EXT][local >> 5], ~bit);
+                    atomicOr(&L.bm[Q_HOLD][local >> 5], bit);
+                }
+                busy = false;
+            }
+            busyMask = __ballot(busy);
+        }
+        if (busyMask == 0ull) {
+            if (__ballot(pendingFinish) != 0ull)
+                continue;                        // (the slots that finished in the last turn: added at the top of the loop)
+            break;
+        }
+        age++;
+        if (COUNT) { turns++; dryTurns += exhausted ? 1u : 0u; if (exhausted) wpBusyDry += (uint32_t)__popcll(busyMask); else wpBusy += (uint32_t)__popcll(busyMask); }
+        if (busy) {
+            uint32_t recIdx = 0, nodeIdx = 0;
+            bool hasRec = false, hasNode = false;
+            if (w.triMask == 0u && w.tri2Mask != 0u) { w.triBase = w.tri2Base; w.triMask = w.tri2Mask; w.triValid = w.tri2Valid; w.tri2Mask = 0u; }
+            if (w.triMask) {
+                const uint32_t b = (uint32_t)__ffs((int)w.triMask) - 1u;
+                recIdx = w.triBase + (uint32_t)__popc(w.triValid & ((1u << b) - 1u));
+                w.triMask &= w.triMask - 1u;
+                hasRec = true;
+            }
+            if (w.tri2Mask == 0u)
+                hasNode = wideNextNode(w, wr.octInv, stack, stride, nodeIdx);
+            float4 r0, r1, r2, q0, q1, q2, q3, q4;
+            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
+            if (hasNode) { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+            bool rayDone = false;
+            if (hasRec) {
+                if (COUNT) prims++;
+                float tmax = ray.tmax;
+                float4 hit;
+                uint32_t meta;
+                if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                    rayDone = true;              // occluded
+            }
+            if (!rayDone && hasNode) {
+                if (COUNT) nodes++;
+                const uint32_t ob = w.triBase, om = w.triMask, ov = w.triValid;
+                wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, ray.tmax);
+                if (om) { w.tri2Base = w.triBase; w.tri2Mask = w.triMask; w.tri2Valid = w.triValid; w.triBase = ob; w.triMask = om; w.triValid = ov; }
+            }
+            if (!rayDone && wideWalkOver(w)) {
+                result = result + contrib;       // nothing in the way: transmittance 1
+                rayDone = true;
+            }
+            if (rayDone)
+                nextRay();
+        }
+    }
+    if (COUNT) wpLoopEnd = wall_clock64();
+    waveAddStat(&L.shadow_rays, rays);
+    waveAddStat(&L.shadow_slots, slots);
+    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
+
+    queuesEnd(L, st, Q_SHADOW, appendMask);
+    if (threadIdx.x == 0) {
+        ctl.shadow_rays += L.shadow_rays; ctl.shadow_slots += L.shadow_slots;
+        if (COUNT) {
+            BlockStats &bs = st.stats[blockIdx.x];
+            bs.nodes_visited += L.nodes; bs.prims_tested += L.prims;
+            bs.nodes_visited_shadow += L.nodes; bs.prims_tested_shadow += L.prims;
+        }
+    }
+    if (COUNT) WALK_PROF_FLUSH(1, turns - dryTurns, dryTurns);
 }
 
 // Second half of the dynamic-fetch shadow step: finalises the paths that had ended at the vertex whose shadow rays
@@ -1806,7 +2184,9 @@ __global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, Pas
     __shared__ BlockLds L;
     __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    queuesBegin(L, st, ctl, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP), order);
+    // (Q_SHADOW is loaded for the liveness report only: it holds the slots k_trace_shadow_wide suspended, whose paths -- waiting in
+    // Q_HOLD or already ended -- keep the pass alive although no extension ray may be queued)
+    queuesBegin(L, st, ctl, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW), order);
     const uint32_t nf = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const bool aborted = __hip_atomic_load(st.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
@@ -1827,7 +2207,7 @@ __global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, Pas
         queuePush(regenerated, loc, L, Q_EXTP);
     }
     waveAddStat(&L.samples, finishedCount);
-    const bool anyExt = queuesEnd(L, st, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP));
+    const bool anyExt = queuesEnd(L, st, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW), -1, false, 1u << Q_SHADOW);
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples;

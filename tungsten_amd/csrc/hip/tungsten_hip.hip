@@ -109,6 +109,8 @@ struct tghip_ctx {
     PathState pool;
     uint32_t poolSlots = 0;
     uint32_t poolGrid = 0;                // persistent workgroups the pool is laid out for
+    uint32_t poolWalkArrays = 0;          // walk arrays the pool carries behind the A_* ones (0: walks are never suspended)
+    uint32_t poolWalkWanted = 0;          // ... and how many the scene it was laid out for asked for (more than fit the 32-bit offsets: none)
     uint32_t *hostLive = nullptr;         // pinned mirror of PathState::live for the loop condition
     std::vector<BlockCtl> hostCtl;        // scratch for tghip_get_counters
     std::vector<BlockStats> hostStats;
@@ -137,12 +139,12 @@ struct tghip_ctx {
     float *dSamples = nullptr;            // TGHIP_PASS_SAMPLES: per-sample radiance of the last such pass
     float *redSum = nullptr;              // tghip_reduce_framebuffers: where the reduced image lands when this context is the root
     uint32_t *redCount = nullptr;
-    size_t redCap = 0;
+    size_t redCap = 0;                    // pixels redSum / redCount were allocated for (a re-upload may change the resolution)
     // the tiles of the shard the last pass rendered (tghip_tile_owner), on the host and on the device; key = {W, H, shard index, shard count}
     std::vector<uint32_t> hostOwnedTiles;
     uint32_t *dOwnedTiles = nullptr;
     size_t ownedCap = 0;
-    uint32_t ownedKey[4] = {0, 0, 0, 0};                    // pixels redSum / redCount were allocated for (a re-upload may change the resolution)
+    uint32_t ownedKey[4] = {0, 0, 0, 0};
     size_t samplesCap = 0, samplesFloats = 0;
     bool auxPass = false;                 // the pass being rendered keeps them: BSDF_MASK_ALL shading, no fused / dynamic-fetch shadow kernels
     int thrShadeAll = 256;                // workgroup size of k_shade<BSDF_MASK_ALL> (media scenes, TGHIP_PASS_AUX passes)
@@ -164,6 +166,9 @@ struct tghip_ctx {
     int thrOverride[4] = {0, 0, 0, 0};
     bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
+    // "suspend_lanes" / "suspend_turns" / "suspend_min_queue" (PathState::suspend_*): walk time-slicing of the wide traversal kernels
+    int suspendLanes = 16, suspendTurns = 32, suspendMinQueue = 1024;
+    int decoupleOpt = 1;                  // "decouple": the wide kernels of single-level scenes test a record AND visit a node per turn (k_trace_closest_wide<.., DECOUPLED>)
     int leafBatch = 1;                    // "leaf_batch" (PathState::leaf_batch)
     int leafBatchBvh2 = 0;                // "leaf_batch_bvh2" (PathState::leaf_batch_bvh2); 0 = leaf_batch, or the measured value for two-level scenes
     bool poolRecords = false;             // "pool_layout" option: 1 = slot records (PathState::records)
@@ -427,6 +432,18 @@ static int foldCounters(tghip_ctx *ctx)
             ctx->counters.nodes_visited_shadow += t.nodes_visited_shadow; ctx->counters.prims_tested_shadow += t.prims_tested_shadow;
         }
     }
+    if (std::getenv("TGHIP_VERBOSE") && ctx->countTraversal) {
+        for (int k = 0; k < 2; ++k) {
+            unsigned long long t[12] = {0};
+            for (size_t b = 0; b < g; ++b) for (int i = 0; i < 12; ++i) { if (i == 11) t[i] = std::max(t[i], ctx->hostStats[b].walk[k][i]); else t[i] += ctx->hostStats[b].walk[k][i]; }
+            if (!t[4]) continue;
+            const double waves = double(t[4]), us = 0.01;
+            std::fprintf(stderr, "[tghip] %s walk, per wave launch: expand %.1f us | loop with queue %.1f us (%.1f turns, %.1f busy lanes) | dry %.1f us (%.1f turns, %.1f busy lanes) | wait+write-back %.1f us | "
+                                 "longest loop %.1f us | suspended %llu resumed %llu walks in %llu wave launches\n", k == 0 ? "closest-hit" : "shadow",
+                         double(t[0])*us/waves, double(t[1])*us/waves, double(t[5])/waves, t[5] ? double(t[7])/double(t[5]) : 0.0,
+                         double(t[2])*us/waves, double(t[6])/waves, t[6] ? double(t[8])/double(t[6]) : 0.0, double(t[3])*us/waves, double(t[11])*us, t[9], t[10], t[4]);
+        }
+    }
     if (std::getenv("TGHIP_VERBOSE")) {
         unsigned long long turns = 0, dry = 0;
         for (size_t b = 0; b < g; ++b) { turns += ctx->hostStats[b].prof[10]; dry += ctx->hostStats[b].prof[11]; }
@@ -479,11 +496,14 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     perBlock = std::min<uint32_t>(cap, std::max<uint32_t>(64u, (perBlock + 63u)/64u*64u));
     const uint32_t slots = perBlock*grid;
     PathState &p = ctx->pool;
-    if (ctx->poolSlots >= slots && ctx->poolGrid == grid) {
+    // the walk arrays behind the A_* ones (suspended walks of the wide kernels, PathState::walk_base): only where they fit the 32-bit offsets
+    uint32_t walkArrays = useWide(ctx) && !ctx->haveInstances && !ctx->poolRecords ? 4u + uint32_t(ctx->wideDepth + 1)/2u : 0u;
+    if (ctx->poolSlots >= slots && ctx->poolGrid == grid && (ctx->poolWalkWanted == walkArrays || ctx->poolWalkArrays >= walkArrays)) {
         p.num_slots = slots;
         p.slots_per_block = perBlock;
         return TGHIP_OK;
     }
+    ctx->poolWalkWanted = walkArrays;
     int rc = foldCounters(ctx);                  // the per-workgroup statistics live in the pool
     if (rc != TGHIP_OK) return rc;
     ctx->poolMem.release();
@@ -494,9 +514,12 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     // the same HBM channel (a power-of-two array stride made the kernels' speed depend on allocation luck)
     const uint64_t strideBytes = uint64_t(slots)*16u + uint64_t(ctx->poolPad);
     if (strideBytes*A_COUNT >= (1ull << 32)) { ctx->error = "path pool too large for 32-bit slot offsets"; return TGHIP_E_INVALID; }
+    if (strideBytes*(A_COUNT + walkArrays) >= (1ull << 32)) walkArrays = 0;
+    ctx->poolWalkArrays = walkArrays;
     const uint64_t recordBytes = uint64_t(slots)*288u + 256u;   // the record layout: 128 + 128 + 32 bytes per slot
     const bool records = ctx->poolRecords && recordBytes < (1ull << 32);
-    POOL_ALLOC(pool, size_t(std::max<uint64_t>(strideBytes*A_COUNT, records ? recordBytes : 0)));
+    POOL_ALLOC(pool, size_t(std::max<uint64_t>(strideBytes*(A_COUNT + walkArrays), records ? recordBytes : 0)));
+    p.walk_base = A_COUNT;
     p.stride = uint32_t(strideBytes);
     p.records = records ? 1u : 0u;
     p.rec_shadow = uint32_t(uint64_t(slots)*128u + 128u);
@@ -712,6 +735,10 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch_bvh2") ctx->leafBatchBvh2 = int(std::min<long long>(std::max<long long>(value, 0), 64));
+    else if (k == "suspend_lanes") ctx->suspendLanes = int(std::min<long long>(std::max<long long>(value, 0), 64));
+    else if (k == "suspend_turns") ctx->suspendTurns = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));   // (>= 1: every launch advances every walk)
+    else if (k == "suspend_min_queue") ctx->suspendMinQueue = int(std::min<long long>(std::max<long long>(value, 0), 1 << 20));
+    else if (k == "decouple") ctx->decoupleOpt = value != 0;
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
     else if (k == "run_to_completion") ctx->loopOpt = value != 0;
@@ -1076,6 +1103,11 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
             if (ctx->haveSolids) SHADOW_WIDE_INST(true); else SHADOW_WIDE_INST(false);
 #undef SHADOW_WIDE_INST
         }
+        else if (ctx->decoupleOpt) {
+#define SHADOW_WIDE_D(S) hipLaunchKernelGGL((k_trace_shadow_fast<COUNT, S>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
+            if (ctx->haveSolids) SHADOW_WIDE_D(true); else SHADOW_WIDE_D(false);
+#undef SHADOW_WIDE_D
+        }
         else                    { if (ctx->haveSolids) SHADOW_WIDE(true, false); else SHADOW_WIDE(false, false); }
 #undef SHADOW_WIDE
         return true;
@@ -1105,6 +1137,9 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     st.partial = ctx->partial;
     st.abort_flag = ctx->abortFlagDev;
     st.leaf_batch = uint32_t(ctx->leafBatch);
+    st.suspend_lanes = ctx->poolWalkArrays ? uint32_t(ctx->suspendLanes) : 0u;
+    st.suspend_turns = uint32_t(std::max(ctx->suspendTurns, 1));
+    st.suspend_min_queue = uint32_t(ctx->suspendMinQueue);
     st.leaf_batch_bvh2 = uint32_t(ctx->leafBatchBvh2 > 0 ? ctx->leafBatchBvh2 : ctx->haveInstances ? 16 : ctx->leafBatch);
     const DeviceScene &s = ctx->scene;
     const int grid = int(ctx->poolGrid);
@@ -1192,13 +1227,16 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
 #undef CLOSEST_INST
             } else if (wideClosest(ctx)) {
                 const size_t ldsWide = wideLdsBytes(ctx, ctx->thrClosest);
-#define CLOSEST_WIDE(C, S, I) hipLaunchKernelGGL((k_trace_closest_wide<C, S, I>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->launchStream, s, st)
+#define CLOSEST_WIDE(C, S, I, D) hipLaunchKernelGGL((k_trace_closest_wide<C, S, I, D>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->launchStream, s, st)
                 if (ctx->haveInstances) {
-                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, true); else CLOSEST_WIDE(false, true, true); }
-                    else                 { if (count) CLOSEST_WIDE(true, false, true); else CLOSEST_WIDE(false, false, true); }
+                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, true, false); else CLOSEST_WIDE(false, true, true, false); }
+                    else                 { if (count) CLOSEST_WIDE(true, false, true, false); else CLOSEST_WIDE(false, false, true, false); }
+                } else if (ctx->decoupleOpt) {
+                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, false, true); else CLOSEST_WIDE(false, true, false, true); }
+                    else                 { if (count) CLOSEST_WIDE(true, false, false, true); else CLOSEST_WIDE(false, false, false, true); }
                 } else {
-                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, false); else CLOSEST_WIDE(false, true, false); }
-                    else                 { if (count) CLOSEST_WIDE(true, false, false); else CLOSEST_WIDE(false, false, false); }
+                    if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, false, false); else CLOSEST_WIDE(false, true, false, false); }
+                    else                 { if (count) CLOSEST_WIDE(true, false, false, false); else CLOSEST_WIDE(false, false, false, false); }
                 }
 #undef CLOSEST_WIDE
             } else {
