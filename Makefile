@@ -7,7 +7,10 @@ HIPCC    ?= hipcc
 CC       ?= gcc
 ARCH     ?= gfx950
 LIBDIR   := tungsten_amd/lib
-OBJDIR   := build/obj
+# PROFILE=1: the development build with k_shade's section timers (-DPT_PROFILE) as libtungsten_hip_prof.so next to the product
+# library (TUNGSTEN_AMD_LIB=... python tools/sweep.py ...); objects of its own
+OBJDIR   := $(if $(PROFILE),build/obj_prof,build/obj)
+LIBNAME  := $(if $(PROFILE),libtungsten_hip_prof.so,libtungsten_hip.so)
 HOSTSRC  := $(wildcard tungsten_amd/csrc/host/*.cpp)
 HOSTLIB  := $(filter-out tungsten_amd/csrc/host/main.cpp,$(HOSTSRC))
 HOSTOBJ  := $(patsubst tungsten_amd/csrc/host/%.cpp,$(OBJDIR)/host_%.o,$(HOSTLIB))
@@ -19,9 +22,9 @@ HIPHDR   := $(wildcard tungsten_amd/csrc/hip/*.h) include/tungsten_hip.h
 # (DESIGN.md "Numerics"); TG_FAST=1 allows contraction.
 FPFLAGS  := $(if $(TG_FAST),-ffp-contract=fast,-ffp-contract=off)
 HOSTFLAGS:= -std=c++11 -O2 -fPIC -Wall -Wextra -Wno-unused-parameter
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -Wno-unused-result
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -Wno-unused-result $(if $(PROFILE),-DPT_PROFILE,)
 
-all: $(LIBDIR)/libtungsten_hip.so $(LIBDIR)/tungsten_hip oracle/liboracle.so
+all: $(LIBDIR)/$(LIBNAME) $(if $(PROFILE),,$(LIBDIR)/tungsten_hip oracle/liboracle.so)
 
 $(OBJDIR)/host_%.o: tungsten_amd/csrc/host/%.cpp $(wildcard tungsten_amd/csrc/host/*.hpp) include/tungsten_hip.h include/tungsten_host.h
 	@mkdir -p $(OBJDIR)
@@ -31,7 +34,7 @@ $(OBJDIR)/%.o: tungsten_amd/csrc/hip/%.hip $(HIPHDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(LIBDIR)/libtungsten_hip.so: $(HOSTOBJ) $(HIPOBJ)
+$(LIBDIR)/$(LIBNAME): $(HOSTOBJ) $(HIPOBJ)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $^ -o $@ -lpthread -ldl
 

@@ -190,7 +190,9 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
                      dict(suspend_lanes=64, suspend_turns=3, suspend_min_queue=0, streams=1, check_interval=1),
                      dict(suspend_lanes=8, suspend_turns=2, suspend_min_queue=0), dict(suspend_lanes=16, suspend_turns=32, suspend_min_queue=64),
                      # the sequential walk (one record OR node per turn, k_trace_*_wide<.., DECOUPLED = false>) against the default decoupled one
-                     dict(decouple=0), dict(decouple=0, suspend_lanes=64, suspend_turns=1, suspend_min_queue=0)]
+                     dict(decouple=0), dict(decouple=0, suspend_lanes=64, suspend_turns=1, suspend_min_queue=0),
+                     # how much of the top of the wide tree the traversal kernels keep in LDS
+                     dict(lds_nodes=0), dict(lds_nodes=1), dict(lds_nodes=9), dict(lds_nodes=585)]
     if scene == "cornell_instances":
         variants += [dict(inst_dyn=0), dict(inst_simple=0), dict(wide_closest=1), dict(wide_shadow=0), dict(leaf_batch_bvh2=1)]
     for opts in variants:

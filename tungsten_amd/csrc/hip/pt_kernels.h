@@ -142,6 +142,10 @@ struct PathState {
     // walk up where it stopped, in a full wave.  A walk is a pure function of its ray, so hits and visit counts are unchanged.
     // suspend_lanes = 0: off.  Workgroups whose queue is shorter than suspend_min_queue never suspend (the end of a pass).
     uint32_t suspend_lanes, suspend_turns, suspend_min_queue;
+    // The top of the 8-wide BVH -- nodes 0 .. lds_nodes-1 of the breadth-first array: the root, its children, ... -- is copied into LDS by the
+    // DECOUPLED traversal kernels: every ray visits them, and what bounds the walk is the rate at which the CU's vector L1 takes lane
+    // addresses (~1.1 16-byte lane-loads per clock, tools/ubench_chase.hip); ds_read_b128 does not go through it.  wide_depth: stack levels.
+    uint32_t lds_nodes, wide_depth;
     uint32_t walk_base;                    // first of the walk arrays of the pool: +0 grpBase grpMasks triBase triMask, +1 triValid node sp -,
                                            // +2 (shadow slots) partial result.rgb | ray index, +3 tri2Base tri2Mask tri2Valid -,
                                            // +4.. the group stack, two 8-byte entries per array

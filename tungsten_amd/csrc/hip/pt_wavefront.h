@@ -22,9 +22,9 @@
 // Section timers of the shading kernel (development aid; compiled in only with -DPT_PROFILE): s_memtime per
 // wave at section boundaries, summed per workgroup into BlockStats::prof and printed by tghip_destroy.
 #ifdef PT_PROFILE
-#define PROF_DECL unsigned long long profT = clock64(), profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PROF(n) do { unsigned long long t_ = clock64(); profAcc[n] += t_ - profT; profT = t_; } while (0)
-#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 16; ++k_) if (k_ != 10 && k_ != 11) { atomicAdd(&(stats).prof[k_], profAcc[k_]); atomicAdd(&(stats).profCls[cls][k_], profAcc[k_]); } } while (0)
+#define PROF_DECL unsigned long long profT = wall_clock64(), profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(n) do { unsigned long long t_ = wall_clock64(); profAcc[n] += t_ - profT; profT = t_; if ((n) == 0) profAcc[10]++; } while (0)   /* ticks of 10 ns; [10] = turns */
+#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 16; ++k_) if (k_ != 11) { if (k_ != 10) atomicAdd(&(stats).prof[k_], profAcc[k_]); atomicAdd(&(stats).profCls[cls][k_], profAcc[k_]); } } while (0)
 #else
 #define PROF_DECL
 #define PROF(n)
@@ -503,6 +503,14 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
     BlockCtl &ctl = st.ctl[blockIdx.x];
     if (threadIdx.x == 0) fetchNext = 0;
     const unsigned long long wpStart = COUNT ? wall_clock64() : 0ull;
+    // DECOUPLED: the top of the tree in LDS, behind the stacks (PathState::lds_nodes; queuesBegin's barriers publish the copy)
+    const uint32_t topCount = DECOUPLED ? st.lds_nodes : 0u;
+    const char *ldsTop = reinterpret_cast<const char *>(ldsDyn) + st.slots_per_block*2u + st.wide_depth*blockDim.x*8u;
+    if constexpr (DECOUPLED) {
+        float4 *dst = reinterpret_cast<float4 *>(const_cast<char *>(ldsTop));
+        for (uint32_t i = threadIdx.x; i < topCount*s.wide_stride/16u; i += blockDim.x)
+            dst[i] = s.wide[i];
+    }
     queuesBegin(L, st, ctl, Q_EXTP, 0u, order, Q_EXT);
     const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
@@ -518,13 +526,27 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
     float tmax = 0.0f;
     float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     int hitInst = -1;
-    uint32_t hitCls = 2;                         // DECOUPLED: shading class of the best hit's record
+    bool pendingPublish = false;                 // DECOUPLED: the walk is over, its hit is published at the next refill (below)
     bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
     uint32_t age = 0;                            // turns this lane's walk has had in this launch (PathState::suspend_turns)
     const bool maySuspend = !INST && st.suspend_lanes != 0u && n >= st.suspend_min_queue;
     WALK_PROF_DECL;
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
+        if constexpr (DECOUPLED) {
+            // Finished walks publish their hit -- and bin their path by the shading class of the record hit, a dependent load -- together,
+            // right before the lanes are refilled (once the queue is dry: in the turn they finish): one memory round trip per refill
+            // instead of one in nearly every turn, sat out by the whole wave.
+            if (((!exhausted && __popcll(busyMask) <= 48) || exhausted) && __ballot(pendingPublish) != 0ull) {
+                if (pendingPublish) {
+                    slotF4(st, A_HIT, slot) = hit;
+                    const int ri = __float_as_int(hit.w);
+                    const int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
+                    queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
+                    pendingPublish = false;
+                }
+            }
+        }
         if (!exhausted && __popcll(busyMask) <= 48) {
             unsigned long long want = ~busyMask;
             uint32_t lane = laneId();
@@ -555,7 +577,6 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                         if (COUNT) wpResumed++;
                         hit = slotF4(st, A_HIT, slot);                      // the best hit so far
                         tmax = hit.x;
-                        if (DECOUPLED && __float_as_int(hit.w) >= 0) hitCls = at32(s.rec_class, (uint32_t)__float_as_int(hit.w));
                         slotF4(st, A_RAY_O, slot).w = ray.tmin;             // (the ray is an ordinary one again)
                     }
                     hitInst = -1;
@@ -585,8 +606,11 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                 busyMask = __ballot(busy);
             }
         }
-        if (busyMask == 0ull)
+        if (busyMask == 0ull) {
+            if (DECOUPLED && __ballot(pendingPublish) != 0ull)
+                continue;                        // (the walks that ended in the last turn: published at the top of the loop)
             break;
+        }
         age++;
         if (COUNT) { turns++; dryTurns += exhausted ? 1u : 0u; if (exhausted) wpBusyDry += (uint32_t)__popcll(busyMask); else wpBusy += (uint32_t)__popcll(busyMask); }
         if constexpr (!INST && DECOUPLED) {
@@ -604,14 +628,15 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                     hasNode = wideNextNode(w, wr.octInv, stack, stride, nodeIdx);
             }
             float4 r0, r1, r2, q0, q1, q2, q3, q4;
-            uint32_t recCls = 0;                  // (fetched with the record: publishing a hit must not wait for a dependent load)
-            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); recCls = at32(s.rec_class, recIdx); }
-            if (hasNode) { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
+            if (hasNode) {
+                if (nodeIdx < topCount) { const float4 *p = reinterpret_cast<const float4 *>(ldsTop + nodeIdx*s.wide_stride); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+                else                    { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+            }
             if (hasRec) {
                 if (COUNT) prims++;
                 uint32_t meta;
-                if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta))
-                    hitCls = recCls;
+                (void)testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta);
             }
             if (hasNode) {
                 if (COUNT) nodes++;
@@ -619,12 +644,9 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                 wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
                 if (om) { w.tri2Base = w.triBase; w.tri2Mask = w.triMask; w.tri2Valid = w.triValid; w.triBase = ob; w.triMask = om; w.triValid = ov; }
             }
-            if (busy && wideWalkOver(w)) {
-                // publish the hit and bin the path by shading class (in the turn that looked at the walk's last record / node)
-                slotF4(st, A_HIT, slot) = hit;
-                const uint32_t cls = __float_as_int(hit.w) < 0 ? 2u : hitCls;
-                queuePush(true, local, L, cls == 0u ? Q_SHADE0 : cls == 1u ? Q_SHADE1 : Q_MISS);
+            if (busy && wideWalkOver(w)) {       // (in the turn that looked at the walk's last record / node)
                 busy = false;
+                pendingPublish = true;
             }
             (void)finished;
         } else if constexpr (!INST) {
@@ -1979,6 +2001,14 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast(DeviceScene s, PathState 
     const unsigned long long wpStart = COUNT ? wall_clock64() : 0ull;
     uint32_t turns = 0, dryTurns = 0;
     const uint32_t appendMask = (1u << Q_FIN) | (st.suspend_lanes != 0u ? (1u << Q_EXT) | (1u << Q_HOLD) : 0u);
+    // the top of the tree in LDS, behind the stacks (PathState::lds_nodes; queuesBegin's barriers publish the copy)
+    const uint32_t topCount = st.lds_nodes;
+    const char *ldsTop = reinterpret_cast<const char *>(ldsDyn) + st.slots_per_block*2u + st.wide_depth*blockDim.x*8u;
+    {
+        float4 *dst = reinterpret_cast<float4 *>(const_cast<char *>(ldsTop));
+        for (uint32_t i = threadIdx.x; i < topCount*s.wide_stride/16u; i += blockDim.x)
+            dst[i] = s.wide[i];
+    }
     queuesBegin(L, st, ctl, Q_SHADOW, appendMask, order);
     const uint32_t n = L.n;
     const uint32_t first = blockIdx.x*st.slots_per_block;
@@ -2134,7 +2164,10 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast(DeviceScene s, PathState 
                 hasNode = wideNextNode(w, wr.octInv, stack, stride, nodeIdx);
             float4 r0, r1, r2, q0, q1, q2, q3, q4;
             if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
-            if (hasNode) { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+            if (hasNode) {
+                if (nodeIdx < topCount) { const float4 *p = reinterpret_cast<const float4 *>(ldsTop + nodeIdx*s.wide_stride); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+                else                    { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+            }
             bool rayDone = false;
             if (hasRec) {
                 if (COUNT) prims++;

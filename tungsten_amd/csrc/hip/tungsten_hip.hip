@@ -4,6 +4,7 @@
 #include "pt_wavefront.h"
 
 #include <atomic>
+#include <chrono>
 #include <map>
 
 #include <dlfcn.h>
@@ -124,7 +125,7 @@ struct tghip_ctx {
     int slotsPerBlockOpt = 0;             // "slots_per_block": upper bound on the slots of one workgroup (0 = PT_MAX_SLOTS_PER_BLOCK)
     bool maxSlotsSet = false;             // "max_slots" was given explicitly
     long long maxItems = 1ll << 26;       // work items per batch (partial-sum buffer = 16 B each)
-    int chunkSamples = 4;                 // samples per work item
+    int chunkSamples = 0;                 // "chunk_samples": samples per work item; 0 = 4, or fewer when the pass is short (tghip_wait)
     size_t partialCap = 0;
     float4 *partial = nullptr;
 
@@ -167,7 +168,9 @@ struct tghip_ctx {
     bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
     // "suspend_lanes" / "suspend_turns" / "suspend_min_queue" (PathState::suspend_*): walk time-slicing of the wide traversal kernels
-    int suspendLanes = 16, suspendTurns = 32, suspendMinQueue = 1024;
+    int suspendLanes = 16, suspendTurns = 16, suspendMinQueue = 1024;   // (measured, profiles/README.md: materialtest +0.5 %, mesh1m +4 %)
+    int ldsNodesOpt = 73;                 // "lds_nodes": nodes of the top of the wide tree kept in LDS by those kernels (1 + 8 + 64: three levels)
+    uint32_t numWideNodes = 0;
     int decoupleOpt = 1;                  // "decouple": the wide kernels of single-level scenes test a record AND visit a node per turn (k_trace_closest_wide<.., DECOUPLED>)
     int leafBatch = 1;                    // "leaf_batch" (PathState::leaf_batch)
     int leafBatchBvh2 = 0;                // "leaf_batch_bvh2" (PathState::leaf_batch_bvh2); 0 = leaf_batch, or the measured value for two-level scenes
@@ -387,9 +390,17 @@ static size_t dynLdsBytes(const tghip_ctx *ctx, int threads)
 }
 
 // the wide kernels: expanded queue + one 8-byte group entry per tree level and thread
+// nodes of the top of the wide tree the DECOUPLED kernels keep in LDS (PathState::lds_nodes): whole levels of the breadth-first array
+static uint32_t ldsNodeCount(const tghip_ctx *ctx)
+{
+    if (!ctx->decoupleOpt || ctx->haveInstances || ctx->ldsNodesOpt == 0) return 0u;
+    const uint32_t n = ctx->scene.wide ? ctx->numWideNodes : 0u;
+    return std::min<uint32_t>(n, uint32_t(ctx->ldsNodesOpt));
+}
 static size_t wideLdsBytes(const tghip_ctx *ctx, int threads)
 {
-    return size_t(slotCap(ctx))*sizeof(unsigned short) + size_t(std::max(ctx->wideDepth, 1))*size_t(threads)*sizeof(uint2);
+    return size_t(slotCap(ctx))*sizeof(unsigned short) + size_t(std::max(ctx->wideDepth, 1))*size_t(threads)*sizeof(uint2)
+         + size_t(ldsNodeCount(ctx))*size_t(ctx->wideStride);
 }
 
 static bool wideClosest(const tghip_ctx *ctx) { return useWide(ctx) && (ctx->wideClosestOpt < 0 ? !ctx->haveInstances : ctx->wideClosestOpt != 0); }
@@ -465,8 +476,9 @@ static int foldCounters(tghip_ctx *ctx)
             for (size_t b = 0; b < g; ++b) perCu[b % perCu.size()] += perBlock[b];
             for (int k = 0; k < 16; ++k) csum += ct[k];
             if (!csum) continue;
-            std::fprintf(stderr, "[PT_PROFILE] class %d:", c);
-            for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) std::fprintf(stderr, " s%d=%.1f%%", k, 100.0*double(ct[k])/double(csum));
+            csum -= ct[10];
+            std::fprintf(stderr, "[PT_PROFILE] class %d: %llu wave turns, %.2f us per turn:", c, ct[10], ct[10] ? double(csum)*0.01/double(ct[10]) : 0.0);
+            for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) std::fprintf(stderr, " s%d=%.2fus", k, ct[10] ? double(ct[k])*0.01/double(ct[10]) : 0.0);
             auto spread = [](std::vector<double> v, const char *what) {
                 std::sort(v.begin(), v.end());
                 double mean = 0.0; for (double x : v) mean += x; mean /= double(v.size());
@@ -725,7 +737,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "max_slots") { ctx->maxSlots = std::max<long long>(value, 256); ctx->maxSlotsSet = true; }
     else if (k == "max_items") ctx->maxItems = std::max<long long>(value, 256);
     else if (k == "slots_per_block") { ctx->slotsPerBlockOpt = int(std::min<long long>(std::max<long long>(value, 0), PT_MAX_SLOTS_PER_BLOCK))/64*64; ctx->poolMem.release(); ctx->poolSlots = 0; if (ctx->haveScene) chooseThreads(ctx); }
-    else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));
+    else if (k == "chunk_samples") ctx->chunkSamples = int(std::min<long long>(std::max<long long>(value, 0), 1 << 20));
     else if (k == "check_interval") ctx->checkInterval = int(std::min<long long>(std::max<long long>(value, 0), 64));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "streams") { ctx->streamsOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
@@ -739,6 +751,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "suspend_turns") ctx->suspendTurns = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));   // (>= 1: every launch advances every walk)
     else if (k == "suspend_min_queue") ctx->suspendMinQueue = int(std::min<long long>(std::max<long long>(value, 0), 1 << 20));
     else if (k == "decouple") ctx->decoupleOpt = value != 0;
+    else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
     else if (k == "run_to_completion") ctx->loopOpt = value != 0;
@@ -831,6 +844,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     const TgHipBvhNode *dn; const TgHipPrimRec *dr; const TgHipTriAttr *da;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->nodes, sd->num_nodes, &dn)) != TGHIP_OK) return rc;
     ctx->wideDepth = 0;
+    ctx->numWideNodes = 0;
     if (sd->wide_nodes && sd->num_wide_nodes) {
         // the wide nodes and the primitive records share ONE allocation, so that a lane of the wide kernels addresses
         // "a node or a record" with one base pointer and one 32-bit offset
@@ -850,6 +864,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             s.wide_stride = uint32_t(stride);
             dr = reinterpret_cast<const TgHipPrimRec *>(p + nodeBytes);
             ctx->wideDepth = wd;
+            ctx->numWideNodes = sd->num_wide_nodes;
         }
     }
     if (!ctx->wideDepth && (rc = uploadArray(ctx, ctx->sceneMem, sd->recs, sd->num_recs, &dr)) != TGHIP_OK) return rc;
@@ -1137,6 +1152,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     st.partial = ctx->partial;
     st.abort_flag = ctx->abortFlagDev;
     st.leaf_batch = uint32_t(ctx->leafBatch);
+    st.lds_nodes = ldsNodeCount(ctx);
+    st.wide_depth = uint32_t(std::max(ctx->wideDepth, 1));
     st.suspend_lanes = ctx->poolWalkArrays ? uint32_t(ctx->suspendLanes) : 0u;
     st.suspend_turns = uint32_t(std::max(ctx->suspendTurns, 1));
     st.suspend_min_queue = uint32_t(ctx->suspendMinQueue);
@@ -1152,7 +1169,10 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     // optional per-launch timing: one event pair per kernel launch of a check interval, read back at the
     // interval's host sync (events live on ctx->stream, the stream the kernels are launched on)
     const bool timing = ctx->timeKernels;
-    const int checkInterval = ctx->checkInterval > 0 ? ctx->checkInterval : (uint64_t(pp.total_items) >= 4ull*st.num_slots ? 16 : 4);
+    // (short batches: 8 -- every check drains all streams, ~0.2 ms in which nothing runs, and most of a short pass is its drain: 27 near-empty
+    // iterations of ~150 us each for the 16-spp passes of the as-shipped materialtest, profiles/README.md; the price is <= 7 empty iterations
+    // of ~55 us after the last path has ended)
+    const int checkInterval = ctx->checkInterval > 0 ? ctx->checkInterval : (uint64_t(pp.total_items) >= 4ull*st.num_slots ? 16 : 8);
     const size_t evNeeded = size_t(checkInterval)*3*2;
     if (timing) {
         while (ctx->evPool.size() < evNeeded) {
@@ -1405,6 +1425,9 @@ int tghip_wait(tghip_ctx *ctx)
     if (!ctx->passPending)
         return ctx->passResult;
     ctx->passPending = false;
+    const bool verbose = std::getenv("TGHIP_VERBOSE") != nullptr;
+    const auto tWait0 = std::chrono::steady_clock::now();
+    auto msSince = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const TgHipPassDesc pass = ctx->pendingPass;
     const uint32_t shardCount = pass.shard_count ? pass.shard_count : 1;
@@ -1488,7 +1511,27 @@ int tghip_wait(tghip_ctx *ctx)
 
     // TGHIP_PASS_AUX: one work item per pixel, so that a pixel's samples reach OutputBuffer::addSample in index order (auxAdd)
     ctx->auxPass = (pass.flags & TGHIP_PASS_AUX) != 0;
-    const uint32_t chunk = ctx->auxPass ? std::max(spp, 1u) : uint32_t(std::max(ctx->chunkSamples, 1));
+    // Samples per work item: 4 when the pass is long (256 spp at 720p: 59 M items over 8 M slots) -- but a slot works its item's samples
+    // off one after the other, so a SHORT pass cut into 4-sample items is a few long sequential chains on a half-empty pool: the 16-spp
+    // passes of the as-shipped materialtest (3.7 M items) ran at half the throughput of one 256-spp pass.  Such passes -- and one rank's
+    // share of a multi-GPU render -- get smaller items, down to one sample each, so that the items outnumber the slots about twice.
+    uint32_t chunk = ctx->auxPass ? std::max(spp, 1u) : uint32_t(std::max(ctx->chunkSamples, 0));
+    if (chunk == 0) {
+        uint64_t passSamples = 0;
+        if (pass.flags & TGHIP_PASS_RECORDS) {
+            uint64_t c16 = 0;
+            for (uint32_t r = 0; r < numRecords; ++r) {
+                const uint32_t rx = r % base.variance_w, ry = r/base.variance_w;
+                if (ownsTile(rx >> 2, ry >> 2)) c16 += ctx->hostRecCount[r];
+            }
+            passSamples = c16*16u;
+        } else {
+            passSamples = uint64_t(ownedTiles)*256u*spp;
+        }
+        // (against the DEFAULT pool size, not the "max_slots" option: the image -- the order of its float additions -- stays a function
+        // of the pass alone, whatever the pool geometry)
+        chunk = uint32_t(std::min<uint64_t>(4, std::max<uint64_t>(1, passSamples >> 24)));
+    }
     if (ctx->auxPass && !ctx->dAux) {
         const size_t npix = size_t(w)*h;
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dAux), npix*sizeof(TgHipAuxPixel)));
@@ -1616,6 +1659,9 @@ int tghip_wait(tghip_ctx *ctx)
     // the device word still holds the previous pass's abort, if any; a request for THIS pass is re-mirrored by runBatch
     HIP_TRY(ctx, hipMemsetAsync(ctx->abortFlagDev, 0, sizeof(uint32_t), ctx->stream));
 
+    const double msSetup = msSince(tWait0);
+    const unsigned long long itersBefore = ctx->counters.iterations;
+    const auto tLoop0 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(ctx->evA, ctx->stream));
     for (uint64_t w0 = 0; recordPass && w0 < recordItems && rc == TGHIP_OK; w0 += batchItems) {
         PassParams pp = base;
@@ -1661,6 +1707,10 @@ int tghip_wait(tghip_ctx *ctx)
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evA, ctx->evB));
     ctx->counters.ms_total += ms;
+    if (verbose)
+        std::fprintf(stderr, "[tghip] pass spp [%u, %u) flags %u: %llu items of %u samples in batches of %llu, %u slots, short %d; setup %.2f ms, loop %.2f ms (%llu iterations, device %.2f ms)\n",
+                     pass.spp_begin, pass.spp_end, pass.flags, (unsigned long long)(recordPass ? recordItems : uint64_t(ownedTiles)*256*chunksAll), chunk,
+                     (unsigned long long)batchItems, ctx->pool.num_slots, int(ctx->shortBatch), msSetup, msSince(tLoop0), (unsigned long long)(ctx->counters.iterations - itersBefore), double(ms));
     return ctx->passResult = rc;
 }
 
