@@ -80,6 +80,20 @@ void tgh_scheduler_free(tgh_scheduler *s);
 /* the Sobol' generator matrices the host hands to the device (NULL + message when the data file is missing) */
 const uint32_t *tgh_sobol_matrices(size_t *num_words, char *err, size_t errlen);
 
+/* ---- the acceleration-structure half of the flattening, on its own ------------------------------------
+ * For hosts that fill a TgHipSceneDesc from their OWN scene classes -- the reference-side binding of INTEGRATION.md
+ * section 3 (oracle/ref_binding/HipSceneFlattener.cpp walks Tungsten's TraceableScene) -- and want exactly the trees this
+ * library's own loader builds: the binned-SAH BVH2 over the records' boxes (tghip nodes) collapsed into the 8-wide BVH
+ * (wide_nodes; none for flat-list scenes of <= TGHIP_FLAT_MAX_RECS records).  Replaces the rtcCommit of the reference's
+ * TraceableScene / TriangleMesh (renderer/TraceableScene.hpp:112-134, primitives/TriangleMesh.cpp:565).
+ * `recs` and `tri_attrs` (num_recs entries each, single-level scenes: no instance records) are PERMUTED IN PLACE into the
+ * order both trees refer to; bounds = 6 floats per record (lo.xyz, hi.xyz) in the caller's original order. */
+typedef struct tgh_accel tgh_accel;
+tgh_accel *tgh_accel_build(TgHipPrimRec *recs, TgHipTriAttr *tri_attrs, const float *bounds, uint32_t num_recs, char *err, size_t errlen);
+const TgHipBvhNode  *tgh_accel_nodes(tgh_accel *a, uint32_t *num_nodes);
+const TgHipWideNode *tgh_accel_wide_nodes(tgh_accel *a, uint32_t *num_wide_nodes);   /* NULL / 0: walk the BVH2 */
+void tgh_accel_free(tgh_accel *a);
+
 /* file-format helpers used by the tests */
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h);
 int tgh_load_hdr(const char *path, float *rgb /* may be NULL to query size */, int *w, int *h);

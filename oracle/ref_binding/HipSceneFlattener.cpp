@@ -1,0 +1,456 @@
+// oracle/ref_binding/HipSceneFlattener.cpp -- TEST INFRASTRUCTURE (compiled against /root/reference, never by the product).
+// See HipSceneFlattener.hpp.  Every field written here names the reference member it is read from; INTEGRATION.md section 3
+// is the table, tungsten_amd/csrc/host/TraceableScene.cpp the stand-alone equivalent.
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <mutex>
+#include <atomic>
+#include <unordered_map>
+#include <unordered_set>
+#include <sstream>
+#include <fstream>
+#include <array>
+#include <algorithm>
+
+// The flattener reads what the reference's classes computed in prepareForRender, which they keep private: open the class
+// definitions up (every standard header they use is included above, so only the reference's own declarations are affected).
+#include "OpenUp.hpp"
+#define private public
+#define protected public
+#define class struct      /* members declared before the first access specifier (enum class -> enum struct is the same thing) */
+#include "primitives/Primitive.hpp"
+#include "primitives/Quad.hpp"
+#include "primitives/Cube.hpp"
+#include "primitives/Sphere.hpp"
+#include "primitives/TriangleMesh.hpp"
+#include "primitives/InfiniteSphere.hpp"
+#include "bsdfs/Bsdf.hpp"
+#include "bsdfs/LambertBsdf.hpp"
+#include "bsdfs/NullBsdf.hpp"
+#include "bsdfs/MirrorBsdf.hpp"
+#include "bsdfs/ConductorBsdf.hpp"
+#include "bsdfs/RoughConductorBsdf.hpp"
+#include "bsdfs/DielectricBsdf.hpp"
+#include "bsdfs/RoughDielectricBsdf.hpp"
+#include "bsdfs/PlasticBsdf.hpp"
+#include "bsdfs/RoughPlasticBsdf.hpp"
+#include "bsdfs/SmoothCoatBsdf.hpp"
+#include "bsdfs/MixedBsdf.hpp"
+#include "bsdfs/TransparencyBsdf.hpp"
+#include "bsdfs/ForwardBsdf.hpp"
+#include "bsdfs/ErrorBsdf.hpp"
+#include "textures/ConstantTexture.hpp"
+#include "textures/CheckerTexture.hpp"
+#include "textures/BitmapTexture.hpp"
+#include "sampling/Distribution2D.hpp"
+#include "cameras/Camera.hpp"
+#include "cameras/PinholeCamera.hpp"
+#include "cameras/ReconstructionFilter.hpp"
+#include "renderer/TraceableScene.hpp"
+#undef private
+#undef protected
+#undef class
+#include "integrators/TraceSettings.hpp"
+#include <sobol/sobol.h>
+
+#include "HipSceneFlattener.hpp"
+
+namespace Tungsten {
+
+static void copy3(float *dst, const Vec3f &v) { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; }
+static void copyRot(float *dst, const Mat4f &m)     // row-major upper 3x3
+{
+    dst[0] = m[0]; dst[1] = m[1]; dst[2] = m[2];
+    dst[3] = m[4]; dst[4] = m[5]; dst[5] = m[6];
+    dst[6] = m[8]; dst[7] = m[9]; dst[8] = m[10];
+}
+static void refuse(const std::string &what)
+{
+    throw std::runtime_error("path_tracer_hip (reference-side flattener): " + what + " is outside its scope "
+                             "(oracle/ref_binding/HipSceneFlattener.hpp); the stand-alone host of the library renders it");
+}
+
+HipSceneFlattener::HipSceneFlattener() { std::memset(&_desc, 0, sizeof(_desc)); }
+HipSceneFlattener::~HipSceneFlattener() { if (_accel) tgh_accel_free(_accel); }
+
+int32_t HipSceneFlattener::addTexture(const Texture *t)
+{
+    if (!t) return -1;
+    auto it = _texIndex.find(t);
+    if (it != _texIndex.end()) return it->second;
+    TgHipTexture d;
+    std::memset(&d, 0, sizeof(d));
+    // (the fields of the texture kinds a record does not use keep the defaults the stand-alone host's Texture has)
+    d.value[0] = d.value[1] = d.value[2] = 1.0f;
+    d.on_color[0] = d.on_color[1] = d.on_color[2] = 0.8f;
+    d.off_color[0] = d.off_color[1] = d.off_color[2] = 0.2f;
+    d.res_u = d.res_v = 20;
+    d.scale = 1.0f;
+    d.texel_offset = -1;
+    d.dist_offset = -1;
+    if (const ConstantTexture *c = dynamic_cast<const ConstantTexture *>(t)) {
+        d.type = TGHIP_TEX_CONSTANT;
+        copy3(d.value, c->_value);
+    } else if (const CheckerTexture *c = dynamic_cast<const CheckerTexture *>(t)) {
+        d.type = TGHIP_TEX_CHECKER;
+        copy3(d.on_color, c->_onColor); copy3(d.off_color, c->_offColor);
+        d.res_u = c->_resU; d.res_v = c->_resV;
+    } else if (const BitmapTexture *b = dynamic_cast<const BitmapTexture *>(t)) {
+        d.type = TGHIP_TEX_BITMAP;
+        d.w = b->_w; d.h = b->_h;
+        d.scale = b->_scale;
+        const bool rgb = (uint32(b->_texelType) & 2u) != 0u, hdr = (uint32(b->_texelType) & 1u) != 0u;   // isRgb() / isHdr() (BitmapTexture.cpp:112-120)
+        d.flags = (b->_linear ? TGHIP_TEXF_LINEAR : 0u) | (b->_clamp ? TGHIP_TEXF_CLAMP : 0u) | (rgb ? TGHIP_TEXF_RGB : 0u) | (b->_valid ? TGHIP_TEXF_VALID : 0u);
+        d.texel_offset = int64_t(_texels.size());
+        const size_t n = size_t(b->_w)*size_t(b->_h);
+        // one texel format on the device: floats -- HDR texels as they are, 8-bit ones as the float(byte)*(1/255) that
+        // BitmapTexture::getRgb / getScalar compute at every lookup (BitmapTexture.cpp:139-154)
+        if (rgb && hdr) {
+            const Vec3f *p = static_cast<const Vec3f *>(b->_texels);
+            for (size_t i = 0; i < n; ++i) { _texels.push_back(p[i].x()); _texels.push_back(p[i].y()); _texels.push_back(p[i].z()); }
+        } else if (rgb) {
+            const uint8 *p = static_cast<const uint8 *>(b->_texels);             // Rgba: four bytes per texel (BitmapTexture.cpp:15-23)
+            for (size_t i = 0; i < n; ++i)
+                for (int k = 0; k < 3; ++k)
+                    _texels.push_back(float(p[i*4 + k])*(1.0f/255.0f));
+        } else if (hdr) {
+            const float *p = static_cast<const float *>(b->_texels);
+            _texels.insert(_texels.end(), p, p + n);
+        } else {
+            const uint8 *p = static_cast<const uint8 *>(b->_texels);
+            for (size_t i = 0; i < n; ++i) _texels.push_back(float(p[i])*(1.0f/255.0f));
+        }
+    } else {
+        refuse("a texture that is neither constant, checker nor bitmap");
+    }
+    copy3(d.avg, t->average());
+    const int32_t idx = int32_t(_textures.size());
+    _textures.push_back(d);
+    _texIndex[t] = idx;
+    return idx;
+}
+
+// the Distribution2D BitmapTexture::makeSamplable(MAP_SPHERICAL) built (BitmapTexture.cpp:400-431; TraceBase's constructor asks
+// every sampled light for it, integrators/TraceBase.cpp:5-22): copied as it is
+void HipSceneFlattener::addDistribution(const Texture *t)
+{
+    const BitmapTexture *b = dynamic_cast<const BitmapTexture *>(t);
+    if (!b) return;
+    const_cast<BitmapTexture *>(b)->makeSamplable(MAP_SPHERICAL);
+    TgHipTexture &d = _textures[size_t(_texIndex[t])];
+    if (d.dist_offset >= 0) return;
+    const Distribution2D &dist = *b->_distribution[MAP_SPHERICAL];
+    d.dist_offset = int64_t(_dist.size());
+    _dist.insert(_dist.end(), dist._marginalPdf.begin(), dist._marginalPdf.end());
+    _dist.insert(_dist.end(), dist._marginalCdf.begin(), dist._marginalCdf.end());
+    _dist.insert(_dist.end(), dist._pdf.begin(), dist._pdf.end());
+    _dist.insert(_dist.end(), dist._cdf.begin(), dist._cdf.end());
+}
+
+static int distributionOf(Microfacet::Distribution d)
+{
+    const std::string name = d.toString();
+    if (name == "beckmann") return TGHIP_DIST_BECKMANN;
+    if (name == "phong") return TGHIP_DIST_PHONG;
+    if (name == "ggx") return TGHIP_DIST_GGX;
+    refuse("microfacet distribution '" + name + "'");
+    return 0;
+}
+
+int32_t HipSceneFlattener::addBsdf(const Bsdf *b)
+{
+    if (!b) return -1;
+    auto it = _bsdfIndex.find(b);
+    if (it != _bsdfIndex.end()) return it->second;
+    if (b->_bump && !b->_bump->isConstant())
+        refuse("a bump-mapped bsdf");
+    const int32_t idx = int32_t(_bsdfs.size());
+    _bsdfIndex[b] = idx;
+    _bsdfs.emplace_back();
+    TgHipBsdf d;
+    std::memset(&d, 0, sizeof(d));
+    // defaults of the stand-alone host's Bsdf for the fields a type does not use (Scene.hpp)
+    d.distribution = TGHIP_DIST_GGX;
+    d.ior = 1.5f; d.thickness = 1.0f;
+    d.roughness = -1; d.sub0 = -1; d.sub1 = -1; d.tex1 = -1;
+    d.enable_refraction = 1;
+    d.avg_transmittance = 1.0f;
+    d.eta[0] = 0.200438f; d.eta[1] = 0.924033f; d.eta[2] = 1.10221f;
+    d.k[0] = 3.91295f; d.k[1] = 2.45285f; d.k[2] = 2.14219f;
+    d.lobes = b->_lobes._lobes;                     // BsdfLobes after prepareForRender (bits as in bsdfs/BsdfLobes.hpp:13-33)
+    d.albedo = addTexture(b->_albedo.get());
+    if (dynamic_cast<const LambertBsdf *>(b)) {
+        d.type = TGHIP_BSDF_LAMBERT;
+    } else if (dynamic_cast<const NullBsdf *>(b)) {
+        d.type = TGHIP_BSDF_NULL;
+    } else if (dynamic_cast<const MirrorBsdf *>(b)) {
+        d.type = TGHIP_BSDF_MIRROR;
+    } else if (const ConductorBsdf *c = dynamic_cast<const ConductorBsdf *>(b)) {
+        d.type = TGHIP_BSDF_CONDUCTOR;
+        copy3(d.eta, c->_eta); copy3(d.k, c->_k);
+    } else if (const RoughConductorBsdf *c = dynamic_cast<const RoughConductorBsdf *>(b)) {
+        d.type = TGHIP_BSDF_ROUGH_CONDUCTOR;
+        d.distribution = distributionOf(c->_distribution);
+        d.roughness = addTexture(c->_roughness.get());
+        copy3(d.eta, c->_eta); copy3(d.k, c->_k);
+    } else if (const DielectricBsdf *c = dynamic_cast<const DielectricBsdf *>(b)) {
+        d.type = TGHIP_BSDF_DIELECTRIC;
+        d.ior = c->_ior; d.enable_refraction = c->_enableT ? 1 : 0;
+    } else if (const RoughDielectricBsdf *c = dynamic_cast<const RoughDielectricBsdf *>(b)) {
+        d.type = TGHIP_BSDF_ROUGH_DIELECTRIC;
+        d.distribution = distributionOf(c->_distribution);
+        d.roughness = addTexture(c->_roughness.get());
+        d.ior = c->_ior; d.enable_refraction = c->_enableT ? 1 : 0;
+    } else if (const PlasticBsdf *c = dynamic_cast<const PlasticBsdf *>(b)) {
+        d.type = TGHIP_BSDF_PLASTIC;
+        d.ior = c->_ior; d.thickness = c->_thickness;
+        d.avg_transmittance = c->_avgTransmittance; d.diffuse_fresnel = c->_diffuseFresnel;
+        copy3(d.sigma_a, c->_sigmaA); copy3(d.scaled_sigma_a, c->_scaledSigmaA);
+    } else if (const RoughPlasticBsdf *c = dynamic_cast<const RoughPlasticBsdf *>(b)) {
+        d.type = TGHIP_BSDF_ROUGH_PLASTIC;
+        d.distribution = distributionOf(c->_distribution);
+        d.roughness = addTexture(c->_roughness.get());
+        d.ior = c->_ior; d.thickness = c->_thickness;
+        d.avg_transmittance = c->_avgTransmittance; d.diffuse_fresnel = c->_diffuseFresnel;
+        copy3(d.sigma_a, c->_sigmaA); copy3(d.scaled_sigma_a, c->_scaledSigmaA);
+    } else if (const SmoothCoatBsdf *c = dynamic_cast<const SmoothCoatBsdf *>(b)) {
+        d.type = TGHIP_BSDF_SMOOTH_COAT;
+        d.ior = c->_ior; d.thickness = c->_thickness;
+        d.avg_transmittance = c->_avgTransmittance;
+        copy3(d.sigma_a, c->_sigmaA); copy3(d.scaled_sigma_a, c->_scaledSigmaA);
+        d.sub0 = addBsdf(c->_substrate.get());
+    } else if (const MixedBsdf *c = dynamic_cast<const MixedBsdf *>(b)) {
+        d.type = TGHIP_BSDF_MIXED;
+        d.sub0 = addBsdf(c->_bsdf0.get());
+        d.sub1 = addBsdf(c->_bsdf1.get());
+        d.tex1 = addTexture(c->_ratio.get());
+    } else if (const TransparencyBsdf *c = dynamic_cast<const TransparencyBsdf *>(b)) {
+        d.type = TGHIP_BSDF_TRANSPARENCY;
+        d.sub0 = addBsdf(c->_base.get());
+        d.tex1 = addTexture(c->_opacity.get());
+    } else if (dynamic_cast<const ForwardBsdf *>(b)) {
+        d.type = TGHIP_BSDF_FORWARD;
+    } else if (dynamic_cast<const ErrorBsdf *>(b)) {
+        d.type = TGHIP_BSDF_ERROR;
+    } else {
+        refuse("a bsdf of a type the device has no code for");
+    }
+    _bsdfs[size_t(idx)] = d;
+    return idx;
+}
+
+void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, const std::vector<const Primitive *> &sampled)
+{
+    (void)defaultLight;
+    if (p._intMedium || p._extMedium)
+        refuse("a primitive with participating media");
+    const size_t pi = _objects.size();
+    TgHipObject o;
+    std::memset(&o, 0, sizeof(o));
+    Primitive &mp = const_cast<Primitive &>(p);          // (Primitive::bsdf(int) is not const)
+    o.bsdf = p.numBsdfs() > 0 ? addBsdf(mp.bsdf(0).get()) : -1;
+    for (int i = 1; i < p.numBsdfs(); ++i) addBsdf(mp.bsdf(i).get());
+    const bool emissive = p.isEmissive();
+    o.emission = emissive ? addTexture(p._emission.get()) : -1;
+    o.light = -1;
+    o.first_light_tri = -1;
+    o.int_medium = o.ext_medium = -1;
+    o.flags = TGHIP_OBJF_SAMPLE;                  // ("sample" is a key of the infinite sphere only; everything else keeps the default)
+    // identity rotation for the kinds that carry none (the stand-alone host's Primitive default)
+    o.rot[0] = o.rot[4] = o.rot[8] = 1.0f;
+
+    auto pushBounds = [&](const Box3f &b) {
+        for (int k = 0; k < 3; ++k) _recBounds.push_back(b.min()[k]);
+        for (int k = 0; k < 3; ++k) _recBounds.push_back(b.max()[k]);
+    };
+    auto plainRecord = [&](uint32_t kind, const Vec3f &a, const Vec3f &b, const Vec3f &c, float p0, float p1) {
+        TgHipPrimRec r;
+        std::memset(&r, 0, sizeof(r));
+        copy3(r.a, a); copy3(r.b, b); copy3(r.c, c);
+        r.p0 = p0; r.p1 = p1;
+        r.meta = (kind << 29) | uint32_t(pi);
+        _recs.push_back(r);
+        TgHipTriAttr at;
+        std::memset(&at, 0, sizeof(at));
+        at.bsdf = o.bsdf;
+        _triAttrs.push_back(at);
+    };
+
+    if (const Quad *q = dynamic_cast<const Quad *>(&p)) {                      // Quad::prepareForRender (Quad.cpp:298-316)
+        o.type = TGHIP_OBJ_QUAD;
+        copy3(o.base, q->_base); copy3(o.edge0, q->_edge0); copy3(o.edge1, q->_edge1); copy3(o.normal, q->_frame.normal);
+        o.inv_uv_sq[0] = q->_invUvSq.x(); o.inv_uv_sq[1] = q->_invUvSq.y();
+        o.area = q->_area; o.inv_area = q->_invArea;
+        plainRecord(TGHIP_REC_QUAD, q->_base, q->_edge0, q->_edge1, q->_invUvSq.x(), q->_invUvSq.y());
+        pushBounds(q->bounds());
+    } else if (const Cube *c = dynamic_cast<const Cube *>(&p)) {               // Cube.cpp:353-370
+        o.type = TGHIP_OBJ_CUBE;
+        copy3(o.pos, c->_pos); copy3(o.scale, c->_scale); copyRot(o.rot, c->_rot); copy3(o.face_cdf, c->_faceCdf);
+        o.area = c->_area; o.inv_area = c->_invArea;
+        plainRecord(TGHIP_REC_CUBE, c->_pos, c->_scale, Vec3f(0.0f), 0.0f, 0.0f);
+        pushBounds(c->bounds());
+    } else if (const Sphere *s = dynamic_cast<const Sphere *>(&p)) {           // Sphere.cpp:285-295
+        o.type = TGHIP_OBJ_SPHERE;
+        copy3(o.pos, s->_pos); copy3(o.scale, Vec3f(s->_radius)); copyRot(o.rot, s->_rot);
+        o.area = 4.0f*PI*s->_radius*s->_radius; o.inv_area = 1.0f/o.area;
+        plainRecord(TGHIP_REC_SPHERE, s->_pos, Vec3f(s->_radius), Vec3f(0.0f), 0.0f, 0.0f);
+        pushBounds(s->bounds());
+    } else if (const TriangleMesh *m = dynamic_cast<const TriangleMesh *>(&p)) {   // TriangleMesh.cpp:524-572
+        o.type = TGHIP_OBJ_MESH;
+        o.flags |= m->_smoothed ? TGHIP_OBJF_SMOOTH : 0u;
+        o.area = m->_totalArea; o.inv_area = 1.0f/m->_totalArea;
+        std::vector<int32_t> meshBsdfs;
+        for (const std::shared_ptr<Bsdf> &b : m->_bsdfs) meshBsdfs.push_back(addBsdf(b.get()));
+        if (emissive && m->isSamplable())
+            refuse("a triangle-mesh emitter");       // (light_tris block: TraceableScene.cpp of the stand-alone host)
+        for (const TriangleI &t : m->_tris) {
+            const Vertex &a = m->_tfVerts[t.v0], &b = m->_tfVerts[t.v1], &c = m->_tfVerts[t.v2];
+            TgHipPrimRec r;
+            std::memset(&r, 0, sizeof(r));
+            copy3(r.a, a.pos()); copy3(r.b, b.pos() - a.pos()); copy3(r.c, c.pos() - a.pos());
+            r.meta = (uint32_t(TGHIP_REC_TRIANGLE) << 29) | uint32_t(pi);
+            _recs.push_back(r);
+            TgHipTriAttr at;
+            copy3(at.n0, a.normal()); copy3(at.n1, b.normal()); copy3(at.n2, c.normal());
+            at.uv0[0] = a.uv().x(); at.uv0[1] = a.uv().y();
+            at.uv1[0] = b.uv().x(); at.uv1[1] = b.uv().y();
+            at.uv2[0] = c.uv().x(); at.uv2[1] = c.uv().y();
+            at.bsdf = meshBsdfs[size_t(t.material)];             // (clamped into range by prepareForRender, TriangleMesh.cpp:536-540)
+            _triAttrs.push_back(at);
+            Box3f bb;
+            bb.grow(a.pos()); bb.grow(b.pos()); bb.grow(c.pos());
+            pushBounds(bb);
+        }
+    } else if (const InfiniteSphere *s = dynamic_cast<const InfiniteSphere *>(&p)) {   // InfiniteSphere.cpp:280-286
+        o.type = TGHIP_OBJ_INFINITE_SPHERE;
+        o.flags = s->_doSample ? TGHIP_OBJF_SAMPLE : 0u;
+        copyRot(o.rot, s->_rotTransform);
+    } else {
+        refuse("a primitive that is not a quad, cube, sphere, triangle mesh or infinite sphere");
+    }
+
+    if (emissive) {
+        for (const Primitive *l : sampled)
+            if (l == &p) {
+                o.light = int32_t(_lights.size());
+                _lights.push_back(int32_t(pi));
+            }
+        if (p.isInfinite())
+            _infiniteLights.push_back(int32_t(pi));
+    }
+    _objects.push_back(o);
+}
+
+void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settings, bool enableVolumeLightSampling)
+{
+    if (!scene._media.empty() || scene._cam.medium())
+        refuse("a scene with participating media");
+
+    // named bsdfs first, in the scene's order; the primitives' own follow as they are met
+    for (const std::shared_ptr<Bsdf> &b : scene._bsdfs)
+        addBsdf(b.get());
+
+    std::vector<const Primitive *> sampled;
+    for (const std::shared_ptr<Primitive> &l : scene._lights) sampled.push_back(l.get());
+    Box3f sceneBounds;
+    for (const std::shared_ptr<Primitive> &p : scene._primitives) {
+        addPrimitive(*p, false, sampled);
+        if (!p->isInfinite() && !p->isDirac())
+            sceneBounds.grow(p->bounds());
+    }
+    // the default white environment TraceableScene adds to its light lists when the scene has no emitter (TraceableScene.hpp:97-102)
+    for (const std::shared_ptr<Primitive> &l : scene._infiniteLights) {
+        bool listed = false;
+        for (const std::shared_ptr<Primitive> &p : scene._primitives) listed = listed || p.get() == l.get();
+        if (!listed)
+            addPrimitive(*l, true, sampled);
+    }
+    if (_recs.empty())
+        refuse("a scene without finite primitives");
+
+    // sampled lights need their 2-D distribution
+    for (int32_t li : _lights) {
+        const TgHipObject &o = _objects[size_t(li)];
+        if (o.type == TGHIP_OBJ_INFINITE_SPHERE && o.emission >= 0)
+            for (const auto &kv : _texIndex)
+                if (kv.second == o.emission) addDistribution(kv.first);
+    }
+
+    char err[512] = {0};
+    _accel = tgh_accel_build(_recs.data(), _triAttrs.data(), _recBounds.data(), uint32_t(_recs.size()), err, sizeof(err));
+    if (!_accel)
+        throw std::runtime_error(std::string("path_tracer_hip: tgh_accel_build: ") + err);
+
+    // ---- camera (PinholeCamera.cpp:28-35, Camera.cpp:37-68, ReconstructionFilter.cpp:34-58) ----
+    const PinholeCamera *cam = dynamic_cast<const PinholeCamera *>(&scene._cam);
+    if (!cam)
+        refuse("a camera other than the pinhole camera");
+    TgHipCamera &c = _desc.camera;
+    std::memset(&c, 0, sizeof(c));
+    copy3(c.pos, cam->_pos);
+    c.plane_dist = cam->_planeDist;
+    copyRot(c.xf, cam->_transform);
+    c.ratio = cam->_ratio;
+    c.pixel_size_x = cam->_pixelSize.x();
+    c.res_x = int32_t(cam->_res.x()); c.res_y = int32_t(cam->_res.y());
+    const ReconstructionFilter &f = cam->_filter;
+    const std::string filterName = f._type.toString();
+    c.filter_type = filterName == "dirac" ? TGHIP_FILTER_DIRAC : filterName == "box" ? TGHIP_FILTER_BOX : TGHIP_FILTER_TABULATED;
+    c.filter_width = f._width;
+    c.filter_bin_size = f._binSize;
+    if (c.filter_type == TGHIP_FILTER_TABULATED)
+        for (int i = 0; i < 32; ++i) c.filter_cdf[i] = f._cdf[i];
+    c.type = TGHIP_CAMERA_PINHOLE;
+    // (the thin-lens fields keep the values the stand-alone host's Camera has for a pinhole camera)
+    c.focus_dist = 1.0f; c.aperture_size = 0.001f; c.cat_eye = 0.0f;
+    c.aperture_type = TGHIP_APERTURE_DISK;
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 4; ++k) c.inv_xf[r*4 + k] = cam->_invTransform[r*4 + k];
+    c.medium = -1;
+
+    _desc.settings.min_bounces = settings.minBounces;
+    _desc.settings.max_bounces = settings.maxBounces;
+    _desc.settings.enable_light_sampling = 1;         // (PathTracerSettings::enableLightSampling: set by the integrator)
+    _desc.settings.enable_two_sided_shading = settings.enableTwoSidedShading ? 1 : 0;
+    _desc.settings.enable_consistency_checks = settings.enableConsistencyChecks ? 1 : 0;
+    _desc.settings.enable_volume_light_sampling = enableVolumeLightSampling ? 1 : 0;
+
+    uint32_t numNodes = 0, numWide = 0;
+    _desc.abi_version = TGHIP_ABI_VERSION;
+    _desc.nodes = tgh_accel_nodes(_accel, &numNodes);
+    _desc.wide_nodes = tgh_accel_wide_nodes(_accel, &numWide);
+    _desc.num_nodes = numNodes;
+    _desc.num_wide_nodes = numWide;
+    _desc.num_recs = uint32_t(_recs.size());
+    _desc.num_top_recs = uint32_t(_recs.size());
+    _desc.num_objects = uint32_t(_objects.size());
+    _desc.num_lights = uint32_t(_lights.size());
+    _desc.num_infinite_lights = uint32_t(_infiniteLights.size());
+    _desc.num_bsdfs = uint32_t(_bsdfs.size());
+    _desc.num_textures = uint32_t(_textures.size());
+    _desc.recs = _recs.data();
+    _desc.tri_attrs = _triAttrs.data();
+    _desc.objects = _objects.data();
+    _desc.lights = _lights.data();
+    _desc.infinite_lights = _infiniteLights.data();
+    _desc.bsdfs = _bsdfs.data();
+    _desc.textures = _textures.data();
+    _desc.texels = _texels.data(); _desc.num_texel_floats = _texels.size();
+    _desc.dist = _dist.data();     _desc.num_dist_floats = _dist.size();
+    _desc.light_tris = _lightTris.data(); _desc.num_light_tri_floats = _lightTris.size();
+    if (scene._settings.useSobol()) {
+        // the table stays Tungsten's (thirdparty/sobol/sobol.h:30-35)
+        _desc.sobol_matrices = reinterpret_cast<const uint32_t *>(sobol::Matrices::matrices);
+        _desc.num_sobol_words = uint64_t(TGHIP_SOBOL_DIMS)*TGHIP_SOBOL_BITS;
+    }
+    copy3(_desc.bounds_lo, sceneBounds.min());
+    copy3(_desc.bounds_hi, sceneBounds.max());
+}
+
+}

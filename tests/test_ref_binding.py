@@ -1,0 +1,125 @@
+"""The compiled drop-in (INTEGRATION.md sections 2-4; oracle/ref_binding/, oracle/Makefile.ref `binding`): the REFERENCE's own
+`tungsten` program -- Scene::load, TraceableScene, the render loop of src/tungsten/Shared.hpp, Integrator::saveOutputs -- with
+"integrator": {"type": "path_tracer_hip"} registered in (a generated copy of) its IntegratorFactory table, the subclass of its
+Integrator that drives libtungsten_hip.so, and the flattener that walks its TraceableScene.
+
+* without a GPU: what that flattener makes of the reference's objects equals, array by array and byte by byte, what this
+  library's own loader makes of the same JSON (the binding writes its TgHipSceneDesc to a file before it asks for a device);
+* with one: the image the reference program writes is, bit for bit, the image of the stand-alone host.
+"""
+import ctypes as C
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import scenes
+import tungsten_amd as tg
+from tungsten_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BINARY = os.path.join(ROOT, "oracle", "_ref", "tungsten_hip_ref")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(BINARY), reason="oracle/_ref/tungsten_hip_ref not built (make -f oracle/Makefile.ref binding)")
+
+
+def hip_scene(path):
+    """The same scene with the integrator's type switched to the registered plugin name."""
+    d = json.load(open(path))
+    d["integrator"]["type"] = "path_tracer_hip"
+    out = path.replace(".json", "_hip.json")
+    json.dump(d, open(out, "w"))
+    return out
+
+
+def run_reference(path, tmp, *args, **env):
+    return subprocess.run([BINARY, "-t", "2", "-s", str(tg.DEFAULT_SEED)] + list(args) + [path], cwd=str(tmp),
+                          env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+
+
+def read_dump(path):
+    out, data = {}, open(path, "rb").read()
+    pos = 0
+    while pos < len(data):
+        n, = struct.unpack_from("<I", data, pos); pos += 4
+        name = data[pos:pos + n].decode(); pos += n
+        size, = struct.unpack_from("<Q", data, pos); pos += 8
+        out[name] = data[pos:pos + size]; pos += size
+    return out
+
+
+def own_desc(path):
+    flat = tg.FlattenedScene(path)
+    d = flat.desc.contents
+
+    def arr(ptr, count, size):
+        return C.string_at(ptr, count*size) if count and ptr else b""
+    own = {
+        "nodes": arr(d.nodes, d.num_nodes, C.sizeof(capi.TgHipBvhNode)),
+        "wide_nodes": arr(d.wide_nodes, d.num_wide_nodes, C.sizeof(capi.TgHipWideNode)),
+        "recs": arr(d.recs, d.num_recs, C.sizeof(capi.TgHipPrimRec)),
+        "tri_attrs": arr(d.tri_attrs, d.num_recs, C.sizeof(capi.TgHipTriAttr)),
+        "objects": arr(d.objects, d.num_objects, C.sizeof(capi.TgHipObject)),
+        "lights": arr(d.lights, d.num_lights, 4),
+        "infinite_lights": arr(d.infinite_lights, d.num_infinite_lights, 4),
+        "bsdfs": arr(d.bsdfs, d.num_bsdfs, C.sizeof(capi.TgHipBsdf)),
+        "textures": arr(d.textures, d.num_textures, C.sizeof(capi.TgHipTexture)),
+        "texels": arr(d.texels, d.num_texel_floats, 4),
+        "dist": arr(d.dist, d.num_dist_floats, 4),
+        "camera": bytes(d.camera),
+        "settings": bytes(d.settings),
+        "bounds": bytes(d.bounds_lo) + bytes(d.bounds_hi),
+        "sobol": arr(d.sobol_matrices, d.num_sobol_words, 4),
+    }
+    flat.close()
+    return own
+
+
+CASES = {
+    "cornell": lambda tmp: scenes.cornell(tmp, resolution=(96, 54), spp=4),
+    "cornell_as_shipped_sampler": lambda tmp: scenes.cornell(tmp, resolution=(96, 54), spp=4, renderer={"stratified_sampler": True, "adaptive_sampling": True}, spp_step=2),
+    "materialtest": lambda tmp: scenes.materialtest(tmp, resolution=(160, 90), spp=4),
+    "zoo_a": lambda tmp: scenes.GOLDEN_CASES["zoo_a"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_a"][1], resolution=(96, 54), spp=2)),
+    "zoo_b": lambda tmp: scenes.GOLDEN_CASES["zoo_b"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_b"][1], resolution=(96, 54), spp=2)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_reference_side_flattener_builds_the_scene_the_own_loader_builds(case, tmp_path):
+    if case == "materialtest" and not scenes.have_materialtest():
+        pytest.skip("materialtest assets not present")
+    path = CASES[case](str(tmp_path))
+    dump = os.path.join(str(tmp_path), "desc.bin")
+    r = run_reference(hip_scene(path), tmp_path, TGHIP_REF_DUMP_DESC=dump)
+    assert os.path.exists(dump), r.stdout
+    ref, own = read_dump(dump), own_desc(path)
+    assert sorted(ref) == sorted(own)
+    for name in sorted(own):
+        assert len(ref[name]) == len(own[name]), "%s: %d bytes from the reference-side flattener, %d from the own loader" % (name, len(ref[name]), len(own[name]))
+        if ref[name] != own[name]:
+            a, b = np.frombuffer(ref[name], np.uint8), np.frombuffer(own[name], np.uint8)
+            first = int(np.nonzero(a != b)[0][0])
+            raise AssertionError("%s differs in %d of %d bytes, first at byte %d" % (name, int((a != b).sum()), a.size, first))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["cornell", "cornell_as_shipped_sampler", "materialtest"])
+def test_reference_program_with_the_plugin_writes_the_image_of_the_own_host(case, tmp_path):
+    """tungsten (the reference's program) with "type": "path_tracer_hip" against tungsten_hip (this repository's CLI) on the same
+    scene, seed and spp: the .pfm files are identical bit for bit."""
+    if case == "materialtest" and not scenes.have_materialtest():
+        pytest.skip("materialtest assets not present")
+    path = CASES[case](str(tmp_path))
+    ref_pfm, own_pfm = os.path.join(str(tmp_path), "ref.pfm"), os.path.join(str(tmp_path), "own.pfm")
+    r = run_reference(hip_scene(path), tmp_path, "-e", ref_pfm, "-o", os.path.join(str(tmp_path), "ref.png"))
+    assert r.returncode == 0 and os.path.exists(ref_pfm), r.stdout
+    cli = os.path.join(ROOT, "tungsten_amd", "lib", "tungsten_hip")
+    o = subprocess.run([cli, "-s", str(tg.DEFAULT_SEED), "-e", own_pfm, "-o", os.path.join(str(tmp_path), "own.png"), path], cwd=str(tmp_path),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+    assert o.returncode == 0 and os.path.exists(own_pfm), o.stdout
+    a, b = open(ref_pfm, "rb").read(), open(own_pfm, "rb").read()
+    assert len(a) == len(b)
+    assert a == b, "the two programs' images differ in %d bytes" % sum(x != y for x, y in zip(a, b))

@@ -187,6 +187,10 @@ PROTOTYPES = {
     "tgh_scheduler_generate_work": (C.c_int, [VP, u32, u32, C.c_int]),
     "tgh_scheduler_free": (None, [VP]),
     "tgh_sobol_matrices": (C.POINTER(u32), [C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
+    "tgh_accel_build": (VP, [VP, VP, VP, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "tgh_accel_nodes": (VP, [VP, C.POINTER(C.c_uint32)]),
+    "tgh_accel_wide_nodes": (VP, [VP, C.POINTER(C.c_uint32)]),
+    "tgh_accel_free": (None, [VP]),
     "tgh_save_pfm": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
     "tgh_load_hdr": (C.c_int, [C.c_char_p, VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

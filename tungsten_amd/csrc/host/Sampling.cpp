@@ -178,14 +178,12 @@ bool PassScheduler::generateWork(uint32_t currentSpp, uint32_t nextSpp, bool ena
 
 void PassScheduler::absorb(const TgHipSampleRecord *const *sources, size_t numSources)
 {
-    // record (rx, ry) lies inside tile (rx/4, ry/4); tile t belongs to shard t % numSources (include/tungsten_hip.h)
+    // record (rx, ry) lies inside tile (rx/4, ry/4), which belongs to shard tghip_tile_owner(tx, ty, numSources) (include/tungsten_hip.h)
     const uint32_t recsPerTile = TileSize/VarianceTileSize;
-    const uint32_t tilesX = (_w + TileSize - 1)/TileSize;
     for (uint32_t ry = 0; ry < _varianceH; ++ry)
         for (uint32_t rx = 0; rx < _varianceW; ++rx) {
-            uint32_t tile = (ry/recsPerTile)*tilesX + rx/recsPerTile;
             size_t i = size_t(ry)*_varianceW + rx;
-            const TgHipSampleRecord &d = sources[tile % numSources][i];
+            const TgHipSampleRecord &d = sources[tghip_tile_owner(rx/recsPerTile, ry/recsPerTile, uint32_t(numSources))][i];
             _samples[i].sample_count = d.sample_count;
             _samples[i].mean = d.mean;
             _samples[i].running_variance = d.running_variance;

@@ -36,6 +36,50 @@ static void copyRot(float *dst, const Mat4f &m)
     dst[6] = m[8]; dst[7] = m[9]; dst[8] = m[10];
 }
 
+SceneAccel buildSceneAccel(std::vector<TgHipPrimRec> &_recs, std::vector<TgHipTriAttr> &_triAttrs, const std::vector<Box3f> &recBounds, bool haveInstances)
+{
+    SceneAccel out;
+    // ---- BVH ---------------------------------------------------------------------------------
+    // Leaf size, measured on MI355X (profiles/README.md): single-record leaves are 5 % faster while the tree fits the
+    // 4 MiB-per-XCD L2 (materialtest: 80 K records), leaves of <= 4 are 3 % faster once it does not (1 M records).
+    // (instance records always sit alone in their leaf: the traversal enters a master from a leaf and returns to its parent)
+    BvhBuildResult bvh = buildBvh(recBounds, (haveInstances || recBounds.size() < (1u << 18)) ? 1 : 4);
+    if (bvh.maxDepth > TGHIP_MAX_BVH_DEPTH - 1)
+        throw std::runtime_error("BVH deeper than the device traversal stack");
+    std::vector<TgHipPrimRec> recs(_recs.size());
+    std::vector<TgHipTriAttr> attrs(_recs.size());
+    for (size_t i = 0; i < bvh.order.size(); ++i) {
+        recs[i] = _recs[bvh.order[i]];
+        attrs[i] = _triAttrs[bvh.order[i]];
+    }
+    _recs.swap(recs);
+    _triAttrs.swap(attrs);
+    out.nodes.swap(bvh.nodes);
+    out.bvhDepth = bvh.maxDepth;
+    out.sahCost = bvh.sahCost;
+    // ---- the 8-wide BVH the single-level traversal kernels walk (WideBvh.hpp): the BVH2 collapsed, records re-ordered by
+    // wide node.  Flat-list scenes are intersected without a tree.  With instances the top-level tree's leaves hold the
+    // instance records and every master gets a wide subtree of its own behind it (TraceableScene::flatten).
+    const bool wantWide = (_recs.size() > TGHIP_FLAT_MAX_RECS || haveInstances) && !std::getenv("TGH_NO_WIDE_BVH");
+    if (wantWide) {
+        std::vector<Box3f> ordered(recBounds.size());
+        for (size_t i = 0; i < bvh.order.size(); ++i)
+            ordered[i] = recBounds[bvh.order[i]];
+        WideBvhResult wide = buildWideBvh(out.nodes, ordered);
+        if (!wide.nodes.empty()) {
+            for (size_t i = 0; i < wide.order.size(); ++i) {
+                recs[i] = _recs[wide.order[i]];
+                attrs[i] = _triAttrs[wide.order[i]];
+            }
+            _recs.swap(recs);
+            _triAttrs.swap(attrs);
+            out.wideNodes.swap(wide.nodes);
+            out.wideDepth = wide.depth;
+        }
+    }
+    return out;
+}
+
 void TraceableScene::flatten()
 {
     auto t0 = std::chrono::steady_clock::now();
@@ -329,45 +373,14 @@ void TraceableScene::flatten()
         if (_allPrims[size_t(li)]->type == Primitive::InfiniteSphere)
             addDistribution(_allPrims[size_t(li)]->emission);
 
-    // ---- BVH ---------------------------------------------------------------------------------
-    // Leaf size, measured on MI355X (profiles/README.md): single-record leaves are 5 % faster while the tree fits the
-    // 4 MiB-per-XCD L2 (materialtest: 80 K records), leaves of <= 4 are 3 % faster once it does not (1 M records).
-    // (instance records always sit alone in their leaf: the traversal enters a master from a leaf and returns to its parent)
-    BvhBuildResult bvh = buildBvh(recBounds, (numInstances || recBounds.size() < (1u << 18)) ? 1 : 4);
-    if (bvh.maxDepth > TGHIP_MAX_BVH_DEPTH - 1)
-        throw std::runtime_error("BVH deeper than the device traversal stack");
-    std::vector<TgHipPrimRec> recs(_recs.size());
-    std::vector<TgHipTriAttr> attrs(_recs.size());
-    for (size_t i = 0; i < bvh.order.size(); ++i) {
-        recs[i] = _recs[bvh.order[i]];
-        attrs[i] = _triAttrs[bvh.order[i]];
-    }
-    _recs.swap(recs);
-    _triAttrs.swap(attrs);
-    _nodes.swap(bvh.nodes);
-    _bvhDepth = bvh.maxDepth;
-    _bvhSah = bvh.sahCost;
-    // ---- the 8-wide BVH the single-level traversal kernels walk (WideBvh.hpp): the BVH2 collapsed, records re-ordered by
-    // wide node.  Flat-list scenes are intersected without a tree.  With instances the top-level tree's leaves hold the
-    // instance records and every master gets a wide subtree of its own behind it (below).
-    _wideNodes.clear();
-    _wideDepth = 0;
-    const bool wantWide = (_recs.size() > TGHIP_FLAT_MAX_RECS || numInstances) && !std::getenv("TGH_NO_WIDE_BVH");
-    if (wantWide) {
-        std::vector<Box3f> ordered(recBounds.size());
-        for (size_t i = 0; i < bvh.order.size(); ++i)
-            ordered[i] = recBounds[bvh.order[i]];
-        WideBvhResult wide = buildWideBvh(_nodes, ordered);
-        if (!wide.nodes.empty()) {
-            for (size_t i = 0; i < wide.order.size(); ++i) {
-                recs[i] = _recs[wide.order[i]];
-                attrs[i] = _triAttrs[wide.order[i]];
-            }
-            _recs.swap(recs);
-            _triAttrs.swap(attrs);
-            _wideNodes.swap(wide.nodes);
-            _wideDepth = wide.depth;
-        }
+    // ---- BVH2 + the 8-wide BVH the single-level traversal kernels walk ----------------------------
+    {
+        SceneAccel accel = buildSceneAccel(_recs, _triAttrs, recBounds, numInstances != 0);
+        _nodes.swap(accel.nodes);
+        _wideNodes.swap(accel.wideNodes);
+        _bvhDepth = accel.bvhDepth;
+        _wideDepth = accel.wideDepth;
+        _bvhSah = accel.sahCost;
     }
     const uint32_t numTopRecs = uint32_t(_recs.size());
 

@@ -16,6 +16,17 @@ namespace tungsten_amd {
 
 class Integrator;
 
+// The two trees over a single-level record array (TraceableScene::flatten, tgh_accel_build): binned-SAH BVH2, then its
+// collapse into the 8-wide BVH (empty for flat-list scenes).  recs / attrs are permuted in place into the trees' order.
+struct SceneAccel
+{
+    std::vector<TgHipBvhNode> nodes;
+    std::vector<TgHipWideNode> wideNodes;
+    int bvhDepth = 0, wideDepth = 0;
+    double sahCost = 0.0;
+};
+SceneAccel buildSceneAccel(std::vector<TgHipPrimRec> &recs, std::vector<TgHipTriAttr> &attrs, const std::vector<Box3f> &recBounds, bool haveInstances);
+
 class TraceableScene
 {
     Scene &_scene;

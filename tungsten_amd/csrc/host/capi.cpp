@@ -25,6 +25,11 @@ struct tgh_scheduler
     PassScheduler scheduler;
 };
 
+struct tgh_accel
+{
+    SceneAccel accel;
+};
+
 struct tgh_renderer
 {
     std::unique_ptr<Scene> scene;
@@ -265,6 +270,48 @@ const uint32_t *tgh_sobol_matrices(size_t *num_words, char *err, size_t errlen)
         if (num_words) *num_words = 0;
         return nullptr;
     }
+}
+
+tgh_accel *tgh_accel_build(TgHipPrimRec *recs, TgHipTriAttr *tri_attrs, const float *bounds, uint32_t num_recs, char *err, size_t errlen)
+{
+    try {
+        if (!recs || !tri_attrs || !bounds || num_recs == 0)
+            throw std::runtime_error("tgh_accel_build: no records");
+        std::vector<TgHipPrimRec> r(recs, recs + num_recs);
+        std::vector<TgHipTriAttr> a(tri_attrs, tri_attrs + num_recs);
+        std::vector<Box3f> b(num_recs);
+        for (uint32_t i = 0; i < num_recs; ++i) {
+            if (TGHIP_REC_KIND(r[i].meta) == TGHIP_REC_INSTANCE)
+                throw std::runtime_error("tgh_accel_build: instance records need the two-level build of this library's own loader");
+            b[i].lo = Vec3f(bounds[6*i + 0], bounds[6*i + 1], bounds[6*i + 2]);
+            b[i].hi = Vec3f(bounds[6*i + 3], bounds[6*i + 4], bounds[6*i + 5]);
+        }
+        std::unique_ptr<tgh_accel> out(new tgh_accel());
+        out->accel = buildSceneAccel(r, a, b, false);
+        std::memcpy(recs, r.data(), size_t(num_recs)*sizeof(TgHipPrimRec));
+        std::memcpy(tri_attrs, a.data(), size_t(num_recs)*sizeof(TgHipTriAttr));
+        return out.release();
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return nullptr;
+    }
+}
+
+const TgHipBvhNode *tgh_accel_nodes(tgh_accel *a, uint32_t *num_nodes)
+{
+    if (num_nodes) *num_nodes = a ? uint32_t(a->accel.nodes.size()) : 0u;
+    return a ? a->accel.nodes.data() : nullptr;
+}
+
+const TgHipWideNode *tgh_accel_wide_nodes(tgh_accel *a, uint32_t *num_wide_nodes)
+{
+    if (num_wide_nodes) *num_wide_nodes = a ? uint32_t(a->accel.wideNodes.size()) : 0u;
+    return (a && !a->accel.wideNodes.empty()) ? a->accel.wideNodes.data() : nullptr;
+}
+
+void tgh_accel_free(tgh_accel *a)
+{
+    delete a;
 }
 
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h)
