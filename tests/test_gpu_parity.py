@@ -452,3 +452,31 @@ def test_rccl_framebuffer_reduce_behind_the_c_abi(n, tmp_path):
     for ctx in ctxs:
         tg.lib.tghip_destroy(ctx)
     flat.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,adaptive", [("cornell", False), ("materialtest", False), ("materialtest", True)])
+def test_several_contexts_driven_by_host_threads_on_one_device(scene, adaptive, tmp_path):
+    """The in-process multi-device path of the integrator ("devices": N -- N contexts, each rendering its tile shard and driven by
+    its own host thread, merged by tghip_reduce_framebuffers or, as here where the contexts share a device, by the host sum)
+    exercised on ONE GPU ("share_devices"): three shards give the image of the unsharded render bit for bit, records included."""
+    import json
+    _skip_mt(scene)
+    kw = dict(resolution=(192, 108), spp=8)
+    if adaptive:      # (the scheduler starts to move samples once every record has 16: three passes of 16)
+        kw = dict(resolution=(96, 54), spp=48, spp_step=16, renderer={"adaptive_sampling": True, "stratified_sampler": True})
+    path = scenes.materialtest(tmp_path, **kw) if scene == "materialtest" else scenes.cornell(tmp_path, **kw)
+    base, _, cnt, _ = gpu_render(path)
+    d = json.load(open(path))
+    d["integrator"].update(devices=3, share_devices=True)
+    shared = os.path.join(str(tmp_path), "shared.json")
+    json.dump(d, open(shared, "w"))
+    r = tg.Renderer(shared, seed=SEED)
+    assert r.context(2), "three contexts expected"
+    r.render()
+    mean, _, count = r.image()
+    r.close()
+    assert (count == cnt).all()
+    if adaptive:
+        assert count.min() < count.max()                 # (the pass scheduler really moved samples)
+    assert (mean == base).all()
