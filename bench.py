@@ -40,6 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MAX_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max engine clock
+VALU_CYCLES_PER_WAVE64 = 2.0   # MI355X_MICROARCH.md "Per-instruction cycle constants": v_fma_f32 (wave64) = 2 cycles (the CDNA4 SIMD is 32 lanes wide)
 
 
 def parse_args():
@@ -308,19 +309,47 @@ class Bench(object):
                                         "with the CPU reference (DESIGN.md sections 5, 7)")
                 if a.traffic and self.world == 1:
                     roofline.update(measure_traffic(a, scene, w, h, spp, dom, self.tmp))
+                if a.traffic and self.world == 1 and not fused:
+                    # What the loop of a BVH scene IS bound by: none of its kernels moves bytes at a rate worth pricing
+                    # against HBM -- the trees are cache-resident -- so two more ceilings are reported next to the HBM line.
+                    #  valu:      wave-wide VALU instructions of ALL kernels of the loop (one more counter pass, SQ_INSTS_VALU, of the same
+                    #             workload) over the wall clock of the
+                    #             timed region, against the chip's issue rate: every SIMD starts one such instruction per 2 clocks.
+                    #  line_rate: BVH nodes + primitive records the traversal kernels fetch per second of wall clock, against what the
+                    #             vector L1s of the chip deliver to divergent lane addresses with the tree resident in L2
+                    #             (tools/ubench_chase.hip, profiles/r2_ubench_chase.txt: 165-174 G 64-byte node visits per second).
+                    prop = torch.cuda.get_device_properties(0)
+                    peak = prop.multi_processor_count*4*MAX_CLOCK_HZ/VALU_CYCLES_PER_WAVE64*1e-9
+                    pmc_spp = spp                    # (the pass's own spp: a shorter pass spends a larger share of its wave-instructions in its drain)
+                    v = measure_counter_all(a, scene, w, h, pmc_spp, self.tmp, "SQ_INSTS_VALU")
+                    if v:
+                        per_sample = sum(t for t, _ in v.values())/float(w*h*pmc_spp)
+                        ach = per_sample*value*1e6*1e-9
+                        roofline["valu"] = {"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
+                                            "frac": round(ach/peak, 4), "instructions_per_sample": round(per_sample, 1),
+                                            "share": {k: round(t/sum(t2 for t2, _ in v.values()), 3) for k, (t, _) in sorted(v.items())},
+                                            "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU (one child pass at %d spp) x the timed region's samples/s; "
+                                                      "peak = CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: v_fma_f32 = 2 cyc "
+                                                      "on the 32-lane SIMD; max clock, sustained clocks are lower, so frac understates)" % pmc_spp}
+                    visits = (cc["nodes_visited"] + cc["prims_tested"])*steps/elapsed*1e-9
+                    roofline["line_rate"] = {"bound": "l1-line-rate", "achieved": round(visits, 1), "peak": 170.0, "unit": "G node+record visits/s",
+                                             "frac": round(visits/170.0, 4),
+                                             "note": "visits of the whole loop over its wall clock (the traversal kernels hold the chip for about half "
+                                                     "of it, next to the shading launches of the other parts); peak = L2-resident divergent walk, "
+                                                     "tools/ubench_chase.hip; 67 G/s once the tree spills to the Infinity Cache"}
                 if (a.traffic or getattr(a, "valu_pass", False)) and self.world == 1:
                     if fused:
                         # what this kernel IS bound by: VALU issue.  One more counter pass (SQ_INSTS_VALU per launch) against the chip's
-                        # issue rate: every SIMD starts one wave-wide VALU instruction per 4 clocks (16 lanes x 4 = 64).
+                        # issue rate: every SIMD starts one wave-wide VALU instruction per 2 clocks (32 lanes x 2 = 64).
                         prop = torch.cuda.get_device_properties(0)
-                        peak = prop.multi_processor_count*4*MAX_CLOCK_HZ/4.0*1e-9
+                        peak = prop.multi_processor_count*4*MAX_CLOCK_HZ/VALU_CYCLES_PER_WAVE64*1e-9
                         v = measure_counter(a, scene, w, h, spp, dom, self.tmp, "SQ_INSTS_VALU")
                         if v is not None:
                             ach = v/(kd["avg_us"]*1e-6)*1e-9
                             roofline["valu"] = {"bound": "valu", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "G wave-instructions/s",
                                                 "frac": round(ach/peak, 4), "instructions_per_launch": round(v),
-                                                "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU (one child pass); peak = CUs x 4 SIMDs x 2.4 GHz / 4 "
-                                                          "(MI355X_MICROARCH.md: max clock; sustained clocks are lower, so frac understates)"}
+                                                "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU (one child pass); peak = CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 "
+                                                          "instruction (MI355X_MICROARCH.md: v_fma_f32 = 2 cyc on the 32-lane SIMD; max clock, sustained clocks are lower)"}
             rays = max(cc["closest_rays"] + cc["shadow_rays"], 1)
             out = {
                 "value": round(value, 2), "ms_per_step": round(elapsed/steps*1e3, 3),
@@ -374,7 +403,7 @@ def measure_traffic(a, scene, w, h, spp, kernel, tmp):
         total, n = 0.0, 0
         with open(files[0]) as f:
             for row in csv.DictReader(f):
-                k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "").replace("_wide", "")
+                k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "").replace("_wide", "").replace("_fast", "")
                 if row.get("Counter_Name") == counter and k == kernel:
                     total += float(row["Counter_Value"])
                     n += 1
@@ -386,6 +415,38 @@ def measure_traffic(a, scene, w, h, spp, kernel, tmp):
     return {"traffic": round((2.0*f + w_)*1024.0),
             "traffic_source": "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child passes at %d spp, %d launches), "
                               "(2*FETCH + WRITE) KiB per MI355X_MICROARCH.md" % (pmc_spp, per_launch["FETCH_SIZE"][1])}
+
+
+def measure_counter_all(a, scene, w, h, spp, tmp, counter):
+    """One PMC counter summed per kernel class over one child run under rocprofv3 (all rows of every dispatch added up):
+    {kernel class: (total, dispatches)}; None on failure."""
+    import csv
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    out = os.path.join(tmp, "pmc_all_" + counter)
+    cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+           "--scene", scene, "--material", a.material, "--res", "%dx%d" % (w, h), "--spp", str(spp), "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"] + [x for kv in a.opt for x in ("--opt", kv)]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp",
+                           env=dict(os.environ, TMPDIR="/tmp"), timeout=300)
+    except Exception:
+        return None
+    files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+    if p.returncode != 0 or not files:
+        return None
+    sums, ids = {}, {}
+    with open(files[0]) as f:
+        for row in csv.DictReader(f):
+            k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip())
+            if row.get("Counter_Name") != counter or not k.startswith("k_"):
+                continue
+            k = k.replace("_dyn", "").replace("_wide", "").replace("_fast", "")
+            sums[k] = sums.get(k, 0.0) + float(row["Counter_Value"])
+            ids.setdefault(k, set()).add(row.get("Dispatch_Id"))
+    shutil.rmtree(out, ignore_errors=True)
+    return {k: (v, len(ids[k])) for k, v in sums.items()} or None
 
 
 def measure_counter(a, scene, w, h, spp, kernel, tmp, counter):
@@ -409,7 +470,7 @@ def measure_counter(a, scene, w, h, spp, kernel, tmp, counter):
     total, ids = 0.0, set()
     with open(files[0]) as f:
         for row in csv.DictReader(f):
-            k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "").replace("_wide", "")
+            k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "").replace("_wide", "").replace("_fast", "")
             if row.get("Counter_Name") == counter and k == kernel:
                 total += float(row["Counter_Value"])
                 ids.add(row.get("Dispatch_Id"))
