@@ -232,6 +232,24 @@ def test_suspended_walks_visit_what_uninterrupted_walks_visit(tmp_path):
     assert res[1][3] > res[0][3]                    # the time-sliced render really took more, shorter launches
 
 
+@pytest.mark.gpu
+def test_instanced_shadow_walk_without_the_visit_counters(tmp_path):
+    """Round 2 found k_trace_shadow_wide<COUNT = false, ., INST> losing occluders inside instances (built with hipcc 7.2) while the
+    variant that also counts its node / record visits was right, and has launched the counting variant for instanced scenes since.
+    This renders the crowded instance scene with the variant under suspicion ("inst_shadow_nocount") and with the BVH2 shadow walk:
+    the day they agree bit for bit the workaround can go; until then the disagreement is on record here instead of in a comment."""
+    mk, kw = scenes.GOLDEN_CASES["cornell_instances"]
+    path = mk(tmp_path, **dict(kw, resolution=(160, 90), spp=8))
+    bvh2, _, cnt, _ = gpu_render(path, wide_shadow=0)
+    counting, _, _, _ = gpu_render(path)
+    assert (counting == bvh2).all()                       # the variant in use
+    suspect, _, _, _ = gpu_render(path, inst_shadow_nocount=1)
+    differing = float((suspect != bvh2).any(axis=-1).mean())
+    print("k_trace_shadow_wide<false, ., true>: %.2f %% of the pixels differ from the BVH2 shadow walk" % (100.0*differing))
+    if differing > 0.0:
+        pytest.xfail("the non-counting instanced shadow walk still loses occluders: %.2f %% of the pixels differ (DESIGN.md 4a)" % (100.0*differing))
+
+
 def test_tile_shards_partition_the_image(tmp_path):
     """The multi-GPU decomposition (16x16 tiles round-robin over shards) on one device: shard
     framebuffers are disjoint and sum to the unsharded image exactly."""

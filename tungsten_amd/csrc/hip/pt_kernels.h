@@ -51,7 +51,12 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 // shadow-ray tag of a media scene: light object (16 bits) | medium the ray starts in + 1 (8 bits) | bounce (8 bits)
 #define SHADOW_TAG_MEDIA(light, medium, bounce) ((uint32_t)(light) | ((uint32_t)((medium) + 1) << 16) | ((uint32_t)(bounce) << 24))
 
-#define PT_NUM_CLASSES 2          // shading classes: 0 = diffuse/null/miss, 1 = everything else
+// Shading classes ("sort by material"): the class of a record's BSDF says which k_shade variant shades a hit on it -- 0: Lambert / null
+// (MASK_SIMPLE), 1: the conductor family (MASK_COAT: rough conductor, conductor, mirror, smooth coat over those), 2: the dielectric
+// family (MASK_GLASS: dielectric, rough dielectric), 3: everything else (plastics, mixed, transparency, forward: MASK_PLASTIC when that
+// covers them, else every type); CLS_MISS: the path's ray left the scene.  One queue and one launch per class that occurs in the scene.
+#define PT_NUM_CLASSES 4
+#define CLS_MISS 4
 #ifndef PT_ITEM_GROUP
 #define PT_ITEM_GROUP  64u        // consecutive work items handed to one workgroup (a wave's worth of pixels)
 #endif
@@ -72,7 +77,8 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 // Q_HOLD: extension rays of paths whose shadow slot is a SUSPENDED walk (below): the path must not reach its next vertex -- whose NEE
 // would overwrite the slot's shadow records -- before those rays are resolved, so k_trace_shadow_wide moves its bit from Q_EXT here
 // when it suspends the slot and back when the resumed walk completes
-enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_FIN = 5, Q_MISS = 6, Q_HOLD = 7, Q_COUNT = 8 };
+enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_FIN = 5, Q_MISS = 6, Q_HOLD = 7, Q_SHADE2 = 8, Q_SHADE3 = 9, Q_COUNT = 10 };
+#define Q_SHADE_MASK ((1u << Q_SHADE0) | (1u << Q_SHADE1) | (1u << Q_SHADE2) | (1u << Q_SHADE3) | (1u << Q_MISS))   /* what a closest-hit kernel appends to */
 
 struct BlockCtl {                 // one per persistent workgroup; only that workgroup touches it
     uint32_t item_cursor;         // workgroup-local linear index of the next work item
@@ -89,7 +95,7 @@ struct BlockStats {               // traversal statistics (count_traversal optio
     // 9 walks suspended, 10 walks resumed, 11 longest loop of a wave (max, ticks)
     unsigned long long walk[2][12];
 #ifdef PT_PROFILE
-    unsigned long long profCls[3][16];   // the same per shading class of the launch (0 / 1 / 2 = escaped paths)
+    unsigned long long profCls[PT_NUM_CLASSES + 1][16];   // the same per shading class of the launch (CLS_MISS = escaped paths)
 #endif
 };
 
@@ -298,6 +304,9 @@ typedef BlockLdsT<PT_MAX_WORDS> BlockLds;
 // the static-fetch and BVH2 traversal kernels (flat-list and instanced scenes, wide BVH switched off) run with <= 2048 slots per
 // workgroup (slotCap in the shim): their deep stacks need the LDS
 typedef BlockLdsT<64u> BlockLdsSmall;
+
+// queue of the paths whose hit is of shading class `cls` (CLS_MISS: no hit)
+PT_DEV int shadeQueue(int cls) { return cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : cls == 2 ? Q_SHADE2 : cls == 3 ? Q_SHADE3 : Q_MISS; }
 
 // push: set the slot's bit in queue q (LDS atomic OR)
 template<class LDS>

@@ -64,6 +64,11 @@
                       BSDF_BIT(TGHIP_BSDF_MIRROR) | BSDF_BIT(TGHIP_BSDF_CONDUCTOR))
 #define MASK_GLASS   (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC) | \
                       BSDF_BIT(TGHIP_BSDF_MIRROR))
+#define MASK_PLASTIC (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_PLASTIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_PLASTIC))
+/* the class variants of scenes with instance records (no mesh emitters): hits reached through an instance (FEAT_INSTANCES) */
+#define MASK_COAT_INST    (MASK_COAT | FEAT_INSTANCES)
+#define MASK_GLASS_INST   (MASK_GLASS | FEAT_INSTANCES)
+#define MASK_PLASTIC_INST (MASK_PLASTIC | FEAT_INSTANCES)
 
 // Finalises the finished sample of every lane with `finished` set (OutputBuffer::addSample semantics,
 // cameras/OutputBuffer.hpp:104-107: NaN/Inf samples are dropped without counting; PathTracer.cpp:119-122,
@@ -305,17 +310,15 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
             }
             slotF4(st, A_HIT, slot) = hit;
             int ri = __float_as_int(hit.w);
-            cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
+            cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
             rays++;
         }
         // sort by material: one shading queue per class
-        queuePush(cls == 0, local, L, Q_SHADE0);
-        queuePush(cls == 1, local, L, Q_SHADE1);
-        queuePush(cls == 2, local, L, Q_MISS);
+        queuePush(cls >= 0, local, L, shadeQueue(cls));
     }
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1) | (1u << Q_MISS), Q_EXTP);
+    queuesEnd(L, st, Q_EXT, Q_SHADE_MASK, Q_EXTP);
     if (threadIdx.x == 0) {
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
@@ -456,8 +459,8 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
                 slotF4(st, A_HIT, slot) = hit;
                 if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
                 int ri = __float_as_int(hit.w);
-                int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
-                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
+                int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
+                queuePush(true, local, L, shadeQueue(cls));
                 busy = false;
             } else {
                 sp--;
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
     }
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1) | (1u << Q_MISS), Q_EXTP);
+    queuesEnd(L, st, Q_EXT, Q_SHADE_MASK, Q_EXTP);
     if (threadIdx.x == 0) {
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
@@ -541,8 +544,8 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                 if (pendingPublish) {
                     slotF4(st, A_HIT, slot) = hit;
                     const int ri = __float_as_int(hit.w);
-                    const int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
-                    queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
+                    const int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
+                    queuePush(true, local, L, shadeQueue(cls));
                     pendingPublish = false;
                 }
             }
@@ -684,8 +687,8 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                 // publish the hit and bin the path by shading class
                 slotF4(st, A_HIT, slot) = hit;
                 int ri = __float_as_int(hit.w);
-                int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
-                queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
+                int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
+                queuePush(true, local, L, shadeQueue(cls));
                 busy = false;
             }
         } else {
@@ -708,8 +711,8 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                         slotF4(st, A_HIT, slot) = hit;
                         if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
                         int ri = __float_as_int(hit.w);
-                        int cls = ri < 0 ? 2 : (int)at32(s.rec_class, (uint32_t)ri);
-                        queuePush(true, local, L, cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS);
+                        int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
+                        queuePush(true, local, L, shadeQueue(cls));
                         busy = false;
                     }
                 }
@@ -747,7 +750,7 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
     if (COUNT) wpLoopEnd = wall_clock64();
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
-    queuesEnd(L, st, Q_EXT, (1u << Q_SHADE0) | (1u << Q_SHADE1) | (1u << Q_MISS), Q_EXTP);
+    queuesEnd(L, st, Q_EXT, Q_SHADE_MASK, Q_EXTP);
     if (threadIdx.x == 0) {
         ctl.closest_rays += L.closest_rays;
         if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
@@ -792,10 +795,10 @@ __global__ __launch_bounds__(256) void k_trace_rays(DeviceScene s, const float4 
 // FUSE (flat-list scenes without forward-lobe BSDFs only -- the whole scene is a handful of records read through the
 // scalar cache, so a separate traversal launch would spend its time on path-state traffic):
 //   FUSE_TRACE   the kernel consumes the extension queues itself, intersects the ray inline, shades class-0 hits
-//                and forwards class-1 hits (hit record stored) to the class-1 shading queue;
+//                and forwards hits of the classes 1 .. 3 (hit record stored) to their shading queues;
 //   FUSE_SHADOW  the <= 2 shadow rays of a vertex are any-hit tested inline instead of being queued for
 //                k_trace_shadow, so the NEE term is added on the spot and no shadow record is written.
-//   FUSE_LOOP    (with both of the above, scenes without class-1 materials) the workgroup runs its slots to completion
+//   FUSE_LOOP    (with both of the above, scenes whose materials are all of class 0) the workgroup runs its slots to completion
 //                inside ONE launch: nothing it reads or writes is shared with another workgroup, so the wavefront
 //                iterations need no grid-wide synchronisation -- the queues simply stay in LDS between iterations.
 // record kinds a shading variant's fused traversal has to test: the lean variant's scenes hold quads and cubes only
@@ -837,9 +840,9 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
     __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : cls == 0 ? Q_SHADE0 : cls == 1 ? Q_SHADE1 : Q_MISS;   // cls 2: the escaped paths
+    const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : shadeQueue(cls);   // (CLS_MISS: the escaped paths)
     const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : -1;
-    const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? (1u << Q_SHADE1) : 0u) | (FUSE == 0 ? (1u << Q_FIN) : 0u);
+    const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? ((1u << Q_SHADE1) | (1u << Q_SHADE2) | (1u << Q_SHADE3)) : 0u) | (FUSE == 0 ? (1u << Q_FIN) : 0u);
     // the wavefront launches (FUSE == 0) of the shading classes of one iteration run concurrently (runBatch): each consumes its own
     // queue, touches its own slots, and ORs what it appends into the workgroup's global bitmaps
     constexpr bool CONCURRENT = FUSE == 0;
@@ -876,6 +879,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
         uint32_t i = base + threadIdx.x;
         PROF(0);
         bool hasShadow = false, finished = false, survives = false, black = false, toComplex = false;
+        int complexCls = 1;                      // FUSE_TRACE: the class whose launch shades the hit this launch forwards
         uint32_t slot = 0, local = 0;
         f3 em = splat3(0.0f);
         if (DIRECT ? !((idle >> turn) & 1u) : i < n) {
@@ -890,9 +894,10 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                 hit = traverseClosest<true, true, shadeKinds(M)>(sg, r0, nullptr, 0, fusedNodes, fusedPrims);
                 fusedClosest++;
                 int ri = __float_as_int(hit.w);
-                toComplex = ri >= 0 && at32(sg.rec_class, (uint32_t)ri) != 0;
+                complexCls = ri >= 0 ? (int)at32(sg.rec_class, (uint32_t)ri) : 0;
+                toComplex = complexCls != 0;
                 if (toComplex)
-                    slotF4(st, A_HIT, slot) = hit;           // shaded by the class-1 launch that follows
+                    slotF4(st, A_HIT, slot) = hit;           // shaded by its class's launch, which follows
             } else {
                 hit = slotF4(st, A_HIT, slot);
             }
@@ -1340,7 +1345,7 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
         }
         PROF(5);
         if (!DIRECT) {
-            if (FUSE & FUSE_TRACE) queuePush(toComplex, local, L, Q_SHADE1);
+            if (FUSE & FUSE_TRACE) queuePush(toComplex, local, L, shadeQueue(complexCls));
             queuePush(hasShadow, local, L, Q_SHADOW);
         }
         PROF(6);

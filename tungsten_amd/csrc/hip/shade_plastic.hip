@@ -1,0 +1,7 @@
+// Explicit instantiations of k_shade variants (see pt_wavefront.h); the extern "C" shim in tungsten_hip.hip launches them.
+#include "pt_wavefront.h"
+
+template __global__ void k_shade<MASK_PLASTIC, 2, 0>(DeviceScene, PathState, PassParams, int);
+template __global__ void k_shade<(MASK_PLASTIC | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
+template __global__ void k_shade<MASK_PLASTIC, 2, 2>(DeviceScene, PathState, PassParams, int);
+template __global__ void k_shade<(MASK_PLASTIC | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);

@@ -33,6 +33,16 @@ extern template __global__ void k_shade<MASK_GLASS, 2, 0>(DeviceScene, PathState
 extern template __global__ void k_shade<(MASK_GLASS | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<MASK_GLASS, 2, 2>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<(MASK_GLASS | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_PLASTIC, 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_PLASTIC | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_PLASTIC, 2, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_PLASTIC | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_COAT_INST, 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_COAT_INST | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_GLASS_INST, 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_GLASS_INST | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_PLASTIC_INST, 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<(MASK_PLASTIC_INST | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<MASK_FULL, 2, 0>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 0>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<MASK_FULL, 2, 2>(DeviceScene, PathState, PassParams, int);
@@ -130,8 +140,10 @@ struct tghip_ctx {
     float4 *partial = nullptr;
 
     // shading classes of the uploaded scene (rec_class) and the kernel variants chosen for them
-    bool haveComplex = false;             // some primitive record uses a class-1 BSDF
-    uint32_t complexMask = 0;             // union of the BSDF types inside class-1 materials
+    bool haveComplex = false;             // some primitive record uses a BSDF of class 1, 2 or 3
+    uint32_t complexMask = 0;             // union of the BSDF types inside those materials
+    bool classPresent[PT_NUM_CLASSES] = {false, false, false, false};   // shading classes (pt_kernels.h: PT_NUM_CLASSES) that occur among the records
+    uint32_t classMask[PT_NUM_CLASSES] = {0, 0, 0, 0};                  // ... and the BSDF types inside each
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
     bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, MASK_FULL shading
     bool thinlens = false;                // thin-lens camera: passes run the EXT kernel variants (PT_PASS_THINLENS)
@@ -165,12 +177,13 @@ struct tghip_ctx {
     // resident at once (no second scheduling round), i.e. each kernel runs at its own best occupancy on one grid
     int thrClosest = 256, thrShadow = 256, thrShadeSimple = 192, thrShadeComplex = 128;
     int thrOverride[4] = {0, 0, 0, 0};
-    bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes without class-1 materials render in ONE launch
+    bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes whose materials are all of class 0 render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
     // "suspend_lanes" / "suspend_turns" / "suspend_min_queue" (PathState::suspend_*): walk time-slicing of the wide traversal kernels
     int suspendLanes = 16, suspendTurns = 16, suspendMinQueue = 1024;   // (measured, profiles/README.md: materialtest +0.5 %, mesh1m +4 %)
     int ldsNodesOpt = 73;                 // "lds_nodes": nodes of the top of the wide tree kept in LDS by those kernels (1 + 8 + 64: three levels)
     uint32_t numWideNodes = 0;
+    int instShadowNoCountOpt = 0;         // "inst_shadow_nocount": launch k_trace_shadow_wide<COUNT = false, ., INST> (see launchShadow)
     int decoupleOpt = 1;                  // "decouple": the wide kernels of single-level scenes test a record AND visit a node per turn (k_trace_closest_wide<.., DECOUPLED>)
     int leafBatch = 1;                    // "leaf_batch" (PathState::leaf_batch)
     int leafBatchBvh2 = 0;                // "leaf_batch_bvh2" (PathState::leaf_batch_bvh2); 0 = leaf_batch, or the measured value for two-level scenes
@@ -469,7 +482,7 @@ static int foldCounters(tghip_ctx *ctx)
         // per shading class, and how evenly the class's work is spread: per workgroup and per set of workgroups b, b + CUs, ... (one CU's, if
         // the dispatcher deals workgroups to the CUs in order)
         const size_t cus = size_t(ctx->prop.multiProcessorCount);
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c <= PT_NUM_CLASSES; ++c) {
             unsigned long long ct[16] = {0}, csum = 0;
             std::vector<double> perBlock(g, 0.0), perCu(std::min(cus, g), 0.0);
             for (size_t b = 0; b < g; ++b) for (int k = 0; k < 16; ++k) { ct[k] += ctx->hostStats[b].profCls[c][k]; perBlock[b] += double(ctx->hostStats[b].profCls[c][k]); }
@@ -600,10 +613,12 @@ static void chooseThreads(tghip_ctx *ctx)
         ctx->thrShadow = flat ? pickThreads(ctx, k_trace_shadow<false, false, true>, 512, 1) : pickThreads(ctx, k_trace_shadow<false, false, false>, 512, 1);
     if (ctx->haveMeshLight || inst) ctx->thrShadeSimple = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
     else ctx->thrShadeSimple = ctx->leanScene ? pickThreads(ctx, k_shade<MASK_LEAN, LEAN_WAVES, 0>, 256, 0) : pickThreads(ctx, k_shade<MASK_SIMPLE, SIMPLE_WAVES, 0>, 256, 0);
-    if (ctx->haveMeshLight || inst)                 ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
-    else if ((ctx->complexMask & ~MASK_COAT) == 0)  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, COAT_WAVES, 0>, 256, 0);
-    else if ((ctx->complexMask & ~MASK_GLASS) == 0) ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
-    else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
+    // (one workgroup size for the launches of classes 1 .. 3: that of the largest variant among them)
+    if (ctx->haveMeshLight || inst || (ctx->classPresent[3] && (ctx->classMask[3] & ~MASK_PLASTIC) != 0))
+                                                    ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_FULL, 2, 0>, 256, 0);
+    else if (ctx->classPresent[3])                  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_PLASTIC, 2, 0>, 256, 0);
+    else if (ctx->classPresent[2])                  ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_GLASS, 2, 0>, 256, 0);
+    else                                            ctx->thrShadeComplex = pickThreads(ctx, k_shade<MASK_COAT, COAT_WAVES, 0>, 256, 0);
     if (ctx->haveMedia) ctx->thrShadeSimple = ctx->thrShadeComplex = pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
     if (paired && ctx->blocksPerCuOpt == 0) {
         // (closest / shadow / shade simple / shade complex, Msamples/s: 256/256/128/128 657, 192/256/128/128 634, 128/256/128/128 623,
@@ -750,6 +765,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "suspend_lanes") ctx->suspendLanes = int(std::min<long long>(std::max<long long>(value, 0), 64));
     else if (k == "suspend_turns") ctx->suspendTurns = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));   // (>= 1: every launch advances every walk)
     else if (k == "suspend_min_queue") ctx->suspendMinQueue = int(std::min<long long>(std::max<long long>(value, 0), 1 << 20));
+    else if (k == "inst_shadow_nocount") ctx->instShadowNoCountOpt = value != 0;
     else if (k == "decouple") ctx->decoupleOpt = value != 0;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -978,11 +994,12 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         if ((rc = uploadArray(ctx, ctx->sceneMem, envGuide.data(), envGuide.size(), &s.env_guide)) != TGHIP_OK) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the vectors go out of scope
     }
-    // shading classes ("sort by material"): class 0 = BSDFs made of lambert/null only, class 1 = the rest
+    // shading classes ("sort by material", pt_kernels.h: PT_NUM_CLASSES): 0 = BSDFs made of lambert / null only, 1 = conductor family, 2 = dielectric family, 3 = the rest
     {
         std::vector<uint32_t> typeMask(sd->num_bsdfs, 0u);
         std::vector<uint8_t> recClass(std::max<uint32_t>(sd->num_recs, 1u), 0);
         ctx->haveComplex = false; ctx->complexMask = 0; ctx->haveForward = false; ctx->haveSolids = false;
+        for (int c = 0; c < PT_NUM_CLASSES; ++c) { ctx->classPresent[c] = false; ctx->classMask[c] = 0; }
         for (uint32_t i = 0; i < sd->num_bsdfs; ++i) {
             typeMask[i] = bsdfTypeMask(sd, int(i), 0);
             if (sd->bsdfs[i].lobes & TGHIP_LOBE_FORWARD) ctx->haveForward = true;
@@ -995,9 +1012,14 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             if (TGHIP_REC_KIND(meta) != TGHIP_REC_TRIANGLE && TGHIP_REC_KIND(meta) != TGHIP_REC_QUAD) ctx->haveSolids = true;
             int bi = TGHIP_REC_KIND(meta) == TGHIP_REC_TRIANGLE ? sd->tri_attrs[i].bsdf : sd->objects[TGHIP_REC_OBJECT(meta)].bsdf;
             if (bi < 0 || uint32_t(bi) >= sd->num_bsdfs) { ctx->error = "primitive record without a valid bsdf"; return TGHIP_E_INVALID; }
-            bool simple = (typeMask[size_t(bi)] & ~MASK_SIMPLE) == 0 && !(sd->bsdfs[bi].lobes & TGHIP_LOBE_FORWARD);
-            recClass[i] = simple ? 0 : 1;
-            if (!simple) { ctx->haveComplex = true; ctx->complexMask |= typeMask[size_t(bi)]; }
+            // the smallest family that covers every type inside the material (nested ones included); forward lobes -> "everything else"
+            const uint32_t tm = typeMask[size_t(bi)];
+            const bool fwd = (sd->bsdfs[bi].lobes & TGHIP_LOBE_FORWARD) != 0;
+            const int c = (!fwd && (tm & ~MASK_SIMPLE) == 0) ? 0 : (!fwd && (tm & ~MASK_COAT) == 0) ? 1 : (!fwd && (tm & ~MASK_GLASS) == 0) ? 2 : 3;
+            recClass[i] = uint8_t(c);
+            ctx->classPresent[c] = true;
+            ctx->classMask[c] |= tm;
+            if (c != 0) { ctx->haveComplex = true; ctx->complexMask |= tm; }
         }
         bool lean = sd->num_infinite_lights == 0 && sd->num_lights <= 1;
         for (uint32_t i = 0; i < sd->num_textures && lean; ++i) lean = sd->textures[i].type != TGHIP_TEX_BITMAP;
@@ -1082,7 +1104,7 @@ static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, co
 {
     constexpr uint32_t B = M & ~FEAT_QMC;
     hipLaunchKernelGGL((k_shade<M, ((B == MASK_SIMPLE || B == MASK_SIMPLE_INST) ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
-                       dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : cls == 1 ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->launchStream, ctx->scene, st, pp, cls);
+                       dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : (cls >= 1 && cls < PT_NUM_CLASSES) ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->launchStream, ctx->scene, st, pp, cls);
 }
 // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
 template<uint32_t M, int FUSE = 0>
@@ -1090,6 +1112,27 @@ static void launchShade(tghip_ctx *ctx, int grid, const PathState &st, const Pas
 {
     if (pp.flags) launchShadeVariant<M | FEAT_QMC, FUSE>(ctx, grid, st, pp, cls);
     else          launchShadeVariant<M, FUSE>(ctx, grid, st, pp, cls);
+}
+
+// the launch of shading class `cls` (1 .. 3) of a scene without media / auxiliary outputs / cylinders / mesh emitters: the smallest variant
+// that covers the BSDF types of the class's materials (pt_kernels.h: PT_NUM_CLASSES)
+template<int FUSE>
+static void launchComplexClass(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
+{
+    const bool plasticOnly = (ctx->classMask[3] & ~MASK_PLASTIC) == 0;
+    if constexpr (FUSE == 0) {
+        if (ctx->haveInstances) {
+            if (cls == 1)                     launchShade<MASK_COAT_INST>(ctx, grid, st, pp, cls);
+            else if (cls == 2)                launchShade<MASK_GLASS_INST>(ctx, grid, st, pp, cls);
+            else if (plasticOnly)             launchShade<MASK_PLASTIC_INST>(ctx, grid, st, pp, cls);
+            else                              launchShade<MASK_FULL>(ctx, grid, st, pp, cls);
+            return;
+        }
+    }
+    if (cls == 1)         launchShade<MASK_COAT, FUSE>(ctx, grid, st, pp, cls);
+    else if (cls == 2)    launchShade<MASK_GLASS, FUSE>(ctx, grid, st, pp, cls);
+    else if (plasticOnly) launchShade<MASK_PLASTIC, FUSE>(ctx, grid, st, pp, cls);
+    else                  launchShade<MASK_FULL, FUSE>(ctx, grid, st, pp, cls);
 }
 
 // true when the shadow step needs its second half, k_finish (the dynamic-fetch kernel does not regenerate paths itself)
@@ -1115,7 +1158,10 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
             // go missing, tools/dbg/inst_debug3.py -- while the variant that also counts its node and record visits is correct;
             // foldCounters drops the counts when nobody asked for them)
 #define SHADOW_WIDE_INST(S) hipLaunchKernelGGL((k_trace_shadow_wide<true, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
-            if (ctx->haveSolids) SHADOW_WIDE_INST(true); else SHADOW_WIDE_INST(false);
+#define SHADOW_WIDE_INST_NC(S) hipLaunchKernelGGL((k_trace_shadow_wide<false, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
+            if (ctx->instShadowNoCountOpt && !COUNT) { if (ctx->haveSolids) SHADOW_WIDE_INST_NC(true); else SHADOW_WIDE_INST_NC(false); }   // ("inst_shadow_nocount": the variant under suspicion, for tests/test_gpu_parity.py)
+            else if (ctx->haveSolids) SHADOW_WIDE_INST(true); else SHADOW_WIDE_INST(false);
+#undef SHADOW_WIDE_INST_NC
 #undef SHADOW_WIDE_INST
         }
         else if (ctx->decoupleOpt) {
@@ -1272,21 +1318,21 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
             }
             tic(); tic();
-            // The shading classes of an iteration (2 = the escaped paths, Q_MISS; 0; 1) consume queues of their own and OR what they append
+            // The shading classes of an iteration (the escaped paths, Q_MISS; 0; the classes 1 .. 3 that occur) consume queues of their own and OR what they append
             // into the workgroup's bitmaps (k_shade: CONCURRENT), so their launches MAY run side by side on three streams ("class_streams"
             // option).  Measured slower than one after the other (materialtest 735-800 against 825-830 Msamples/s, mesh1m 409 against 508,
             // for 2 to 24 hardware queues): with four parts in flight the chip is not short of independent launches.
             auto shadeClass = [&](int cls) {
+                const bool simple = cls == 0 || cls == CLS_MISS;
                 if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, cls);   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER
-                else if (ctx->haveInstances && !ctx->haveMeshLight && cls != 1 && ctx->instSimpleOpt) launchShade<MASK_SIMPLE_INST>(ctx, grid, st, pp, cls);   // Lambert / escaped paths of instanced scenes
-                else if (ctx->haveMeshLight || ctx->haveInstances) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);   // the only variants with mesh-emitter sampling / instance transforms (every BSDF type)
-                else if (cls != 1) {             // class 2 runs the class-0 variant: its surface code never runs there, so the launch is short
+                else if (ctx->haveMeshLight) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);   // the only variant with mesh-emitter sampling (every BSDF type)
+                else if (ctx->haveInstances && simple && ctx->instSimpleOpt) launchShade<MASK_SIMPLE_INST>(ctx, grid, st, pp, cls);   // Lambert / escaped paths of instanced scenes
+                else if (ctx->haveInstances && (simple || !ctx->instSimpleOpt)) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);
+                else if (simple) {               // the escaped paths run the class-0 variant: its surface code never runs there, so the launch is short
                     if (ctx->leanScene) launchShade<MASK_LEAN>(ctx, grid, st, pp, cls);
                     else                launchShade<MASK_SIMPLE>(ctx, grid, st, pp, cls);
                 }
-                else if ((ctx->complexMask & ~MASK_COAT) == 0)  launchShade<MASK_COAT>(ctx, grid, st, pp, 1);
-                else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS>(ctx, grid, st, pp, 1);
-                else                                            launchShade<MASK_FULL>(ctx, grid, st, pp, 1);
+                else launchComplexClass<0>(ctx, grid, st, pp, cls);
             };
             hipStream_t mainStream = ctx->launchStream;
             if (ctx->classStreamsOpt != 0) {
@@ -1296,17 +1342,20 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 for (int a = 0; a < nAux; ++a) {
                     (void)hipStreamWaitEvent(aux[a], ctx->evFork[part], 0);
                     ctx->launchStream = aux[a];
-                    shadeClass(a == 0 ? 2 : 0);
+                    shadeClass(a == 0 ? CLS_MISS : 0);
                     (void)hipEventRecord(ctx->evJoin[part][a], aux[a]);
                 }
                 ctx->launchStream = mainStream;
-                shadeClass(ctx->haveComplex ? 1 : 0);             // the longest launch stays on the part's own stream
+                if (!ctx->haveComplex) shadeClass(0);             // the longest launches stay on the part's own stream
+                for (int c = 1; c < PT_NUM_CLASSES; ++c)
+                    if (ctx->classPresent[c]) shadeClass(c);
                 for (int a = 0; a < nAux; ++a)
                     (void)hipStreamWaitEvent(mainStream, ctx->evJoin[part][a], 0);
             } else {
-                shadeClass(2);
+                shadeClass(CLS_MISS);
                 shadeClass(0);
-                if (ctx->haveComplex) shadeClass(1);
+                for (int c = 1; c < PT_NUM_CLASSES; ++c)
+                    if (ctx->classPresent[c]) shadeClass(c);
             }
             tic(); tic();
             const bool finish = count ? launchShadow<true>(ctx, grid, st, pp, iterTag) : launchShadow<false>(ctx, grid, st, pp, iterTag);
@@ -1360,11 +1409,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 }
                 else if (ctx->leanScene) launchShade<MASK_LEAN, FUSE_TRACE | FUSE_SHADOW>(ctx, grid, st, ppi, 0);
                 else                     launchShade<MASK_SIMPLE, FUSE_TRACE | FUSE_SHADOW>(ctx, grid, st, ppi, 0);
-                if (ctx->haveComplex) {
-                    if ((ctx->complexMask & ~MASK_COAT) == 0)       launchShade<MASK_COAT, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
-                    else if ((ctx->complexMask & ~MASK_GLASS) == 0) launchShade<MASK_GLASS, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
-                    else                                            launchShade<MASK_FULL, FUSE_SHADOW>(ctx, grid, st, ppi, 1);
-                }
+                for (int c = 1; c < PT_NUM_CLASSES; ++c)
+                    if (ctx->classPresent[c]) launchComplexClass<FUSE_SHADOW>(ctx, grid, st, ppi, c);
                 tic(); tic(); tic();
                 ctx->counters.iterations++;
                 continue;
