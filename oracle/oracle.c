@@ -1720,10 +1720,41 @@ static Event make_event(const Ctx *c, const Info *info, const Local *l, uint32_t
 
 /* ---- participating media: HomogeneousMedium (media/HomogeneousMedium.cpp) with the exponential, linear, quadratic,
  * double-exponential, pulse and Erlang transmittances (transmittances/*.cpp).  The reference evaluates the exponential one through
- * fmath's table-based exp (math/FastMath.hpp:14-27); expf here, inside the float tolerance of the parity tests. ---- */
+ * fmath's table-based exp (math/FastMath.hpp:14-27), restated below (fmath_exp). ---- */
 typedef struct { int firstScatter; int bounce; } MediumState;     /* Medium.hpp:30-47 */
 typedef struct { v3 p; float t; v3 weight; int exited; int medium; } MediumSample;
-static inline v3 vexpneg(v3 tau) { return V(expf(-tau.x), expf(-tau.y), expf(-tau.z)); }
+/* FastMath::exp -> fmath::exp / exp_ps (math/FastMath.hpp:14-27; thirdparty/fmath/fmath.hpp:91-126, 221-241, 320-363): the table of
+ * 2^(i/1024) built with powf at start-up exactly as fmath's ExpVar constructor builds it, then float and integer arithmetic only */
+static uint32_t g_fmath_tbl[1024];
+static float g_fmath_a, g_fmath_b;
+__attribute__((constructor)) static void fmath_exp_init(void)
+{
+    float log_2 = logf(2.0f);
+    g_fmath_a = 1024/log_2;
+    g_fmath_b = log_2/1024;
+    for (int i = 0; i < 1024; i++) {
+        float y = powf(2.0f, (float)i/1024);
+        uint32_t bits;
+        memcpy(&bits, &y, 4);
+        g_fmath_tbl[i] = bits & 0x7FFFFFu;
+    }
+}
+const uint32_t *oracle_fmath_exp_table(void) { return g_fmath_tbl; }      /* tests/test_media.py: the device carries the same table */
+static float fmath_exp(float x)
+{
+    int32_t xi;
+    memcpy(&xi, &x, 4);
+    if ((xi & 0x7fffffff) > 0x42b00000)
+        x = fmaxf(fminf(x, 88.0f), -88.0f);
+    int32_t r = (int32_t)lrintf(x*g_fmath_a);                    /* cvtss2si / cvtps2dq: round to nearest even */
+    float t = x - (float)r*g_fmath_b;
+    uint32_t bits = ((uint32_t)((r >> 10) + 127) << 23) | g_fmath_tbl[r & 1023];
+    float f;
+    memcpy(&f, &bits, 4);
+    return (1.0f + t)*f;
+}
+float oracle_fmath_exp(float x) { return fmath_exp(x); }
+static inline v3 vexpneg(v3 tau) { return V(fmath_exp(-tau.x), fmath_exp(-tau.y), fmath_exp(-tau.z)); }
 
 /* Primitive::selectMedium (Primitive.hpp:177-183) */
 static int selectMedium(const TgHipObject *o, int current, int geometricBackside)
@@ -1814,8 +1845,8 @@ static float trans_leaf_kernel(const TgHipMedium *m, int k, float tau)
         }
         return isnan(Tr) ? 0.0f : Tr;
     }
-    default:                                            /* ExponentialTransmittance.cpp:26-41 (FastMath::exp in the reference) */
-        return expf(-tau);
+    default:                                            /* ExponentialTransmittance.cpp:26-41: FastMath::exp */
+        return fmath_exp(-tau);
     }
 }
 static float trans_leaf_sigmaBar(const TgHipMedium *m)

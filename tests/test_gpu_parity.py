@@ -233,21 +233,18 @@ def test_suspended_walks_visit_what_uninterrupted_walks_visit(tmp_path):
 
 
 @pytest.mark.gpu
-def test_instanced_shadow_walk_without_the_visit_counters(tmp_path):
-    """Round 2 found k_trace_shadow_wide<COUNT = false, ., INST> losing occluders inside instances (built with hipcc 7.2) while the
-    variant that also counts its node / record visits was right, and has launched the counting variant for instanced scenes since.
-    This renders the crowded instance scene with the variant under suspicion ("inst_shadow_nocount") and with the BVH2 shadow walk:
-    the day they agree bit for bit the workaround can go; until then the disagreement is on record here instead of in a comment."""
+def test_instanced_shadow_walk_with_and_without_the_visit_counters(tmp_path):
+    """Round 2 found k_trace_shadow_wide<COUNT = false, ., INST> losing occluders inside instances while the variant that also counts
+    its node / record visits was right, and launched the counting variant for instanced scenes.  Both are in use again (the counting
+    one under count_traversal): the crowded instance scene rendered with either, and with the BVH2 shadow walk, is one image."""
     mk, kw = scenes.GOLDEN_CASES["cornell_instances"]
     path = mk(tmp_path, **dict(kw, resolution=(160, 90), spp=8))
     bvh2, _, cnt, _ = gpu_render(path, wide_shadow=0)
-    counting, _, _, _ = gpu_render(path)
-    assert (counting == bvh2).all()                       # the variant in use
-    suspect, _, _, _ = gpu_render(path, inst_shadow_nocount=1)
-    differing = float((suspect != bvh2).any(axis=-1).mean())
-    print("k_trace_shadow_wide<false, ., true>: %.2f %% of the pixels differ from the BVH2 shadow walk" % (100.0*differing))
-    if differing > 0.0:
-        pytest.xfail("the non-counting instanced shadow walk still loses occluders: %.2f %% of the pixels differ (DESIGN.md 4a)" % (100.0*differing))
+    plain, _, _, _ = gpu_render(path)
+    counting, _, _, c = gpu_render(path, count_traversal=1)
+    assert (cnt == 8).all() and c.nodes_visited_shadow > 0
+    assert (plain == bvh2).all()
+    assert (counting == bvh2).all()
 
 
 def test_tile_shards_partition_the_image(tmp_path):

@@ -181,3 +181,25 @@ def test_transmittance_samplers_follow_their_kernels(kind, start_on_surface):
     survival = np.array([(out > x).mean() for x in xs])
     expected = _kernel(m, 0 if start_on_surface else 2, xs)
     assert np.allclose(survival, expected, atol=4*np.sqrt(0.25/n) + 2e-3), (kind, start_on_surface, np.abs(survival - expected).max())
+
+
+def test_fmath_exp_table_of_the_device_is_the_one_the_oracle_builds():
+    """ExponentialTransmittance evaluates FastMath::exp = fmath's table-based exp (math/FastMath.hpp:14-27): the oracle builds the
+    table of 2^(i/1024) with powf at load time exactly as fmath's constructor does, the device carries it as constants
+    (tungsten_amd/csrc/hip/fmath_exp_table.h) -- the same 1024 words; and the restated function is a float exp to ~1 ulp."""
+    import ctypes as C
+    import math
+    import os
+    import re
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = oracle_lib._lib
+    lib.oracle_fmath_exp_table.restype = C.POINTER(C.c_uint32)
+    lib.oracle_fmath_exp.restype = C.c_float
+    lib.oracle_fmath_exp.argtypes = [C.c_float]
+    table = [int(lib.oracle_fmath_exp_table()[i]) for i in range(1024)]
+    src = open(os.path.join(ROOT, "tungsten_amd", "csrc", "hip", "fmath_exp_table.h")).read()
+    words = [int(w, 16) for w in re.findall(r"0x([0-9a-f]{6})u", src)]
+    assert words == table
+    for x in (-80.0, -10.0, -1.0, -1e-3, 0.0, 0.5, 3.25):   # (below -87.3 the result is a denormal the table method cannot form, in the reference too)
+        assert abs(lib.oracle_fmath_exp(x)/math.exp(x) - 1.0) < 1e-5        # (fmath reduces the argument in float: ~1e-7 near 0, ~4e-6 at -80)
+    assert lib.oracle_fmath_exp(-1000.0) == lib.oracle_fmath_exp(-88.0)      # clamped like the reference

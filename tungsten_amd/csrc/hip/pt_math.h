@@ -35,6 +35,68 @@ template<typename T> PT_DEV const T &at32(const T *base, uint32_t idx)
 
 struct f3 { float x, y, z; };
 
+// ---- two library functions restated so that the device computes what the host's libm computes, bit for bit ---------------------
+// acosf as glibc 2.35 has it (sysdeps/ieee754/flt-32/e_acosf.c, the fdlibm rational approximation evaluated in float): nothing but
+// float +, -, *, / and sqrt, every one of them correctly rounded here as there (-ffp-contract=off).  Quad::approximateRadiance
+// (primitives/Quad.cpp:253-281) obtains the solid angle of a light as 2 pi minus four arc cosines; for a millimetre-sized emitter the
+// last bit of acosf moves chooseLight's weights by per cents, so "within an ulp of libm" (ocml) is not close enough.
+PT_DEV float acosfExact(float x)
+{
+    const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f,
+                pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f,
+                qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const int hx = __float_as_int(x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000)
+        return hx > 0 ? 0.0f : pi + 2.0f*pio2_lo;
+    if (ix > 0x3f800000)
+        return (x - x)/(x - x);
+    if (ix < 0x3f000000) {                       // |x| < 0.5
+        if (ix <= 0x32800000) return pio2_hi + pio2_lo;
+        const float z = x*x;
+        const float p = z*(pS0 + z*(pS1 + z*(pS2 + z*(pS3 + z*(pS4 + z*pS5)))));
+        const float q = one + z*(qS1 + z*(qS2 + z*(qS3 + z*qS4)));
+        const float r = p/q;
+        return pio2_hi - (x - (pio2_lo - x*r));
+    } else if (hx < 0) {                         // x < -0.5
+        const float z = (one + x)*0.5f;
+        const float p = z*(pS0 + z*(pS1 + z*(pS2 + z*(pS3 + z*(pS4 + z*pS5)))));
+        const float q = one + z*(qS1 + z*(qS2 + z*(qS3 + z*qS4)));
+        const float s = sqrtf(z);
+        const float r = p/q;
+        const float w = r*s - pio2_lo;
+        return pi - 2.0f*(s + w);
+    } else {                                     // x > 0.5
+        const float z = (one - x)*0.5f;
+        const float s = sqrtf(z);
+        const float df = __int_as_float(__float_as_int(s) & (int)0xfffff000);
+        const float c = (z - df*df)/(s + df);
+        const float p = z*(pS0 + z*(pS1 + z*(pS2 + z*(pS3 + z*(pS4 + z*pS5)))));
+        const float q = one + z*(qS1 + z*(qS2 + z*(qS3 + z*qS4)));
+        const float r = p/q;
+        const float w = r*s + c;
+        return 2.0f*(df + w);
+    }
+}
+// FastMath::exp -> fmath::exp / exp_ps (math/FastMath.hpp:14-27, thirdparty/fmath/fmath.hpp:221-241, 320-363): what the reference's
+// ExponentialTransmittance computes (transmittances/ExponentialTransmittance.cpp:26-41) -- a 1024-entry table of 2^(i/1024) and a
+// first-order correction, all in float and integer arithmetic, so it is reproduced exactly instead of approximated by expf.
+#include "fmath_exp_table.h"
+__device__ const uint32_t g_fmathExpTable[1024] = { FMATH_EXP_TABLE_VALUES };
+PT_DEV float fmathExp(float x)
+{
+    if ((__float_as_int(x) & 0x7fffffff) > 0x42b00000)            // |x| > 88 (compared as integers, like the reference)
+        x = fmaxf(fminf(x, 88.0f), -88.0f);
+    const float a = 1024.0f/0.693147182464599609375f, b = 0.693147182464599609375f/1024.0f;   // n/logf(2), logf(2)/n as floats
+    const int r = __float2int_rn(x*a);                             // cvtss2si: round to nearest even
+    const float t = x - (float)r*b;
+    const uint32_t bits = ((uint32_t)((r >> 10) + 127) << 23) | g_fmathExpTable[r & 1023];
+    return (1.0f + t)*__uint_as_float(bits);
+}
+// expf through the double-precision exp: the correctly rounded float in all but ~1e-9 of the cases, which is what glibc's expf
+// returns too (its error bound is 0.502 ulp) -- ocml's expf is a different last bit on a few per cent of the arguments
+PT_DEV float expfRounded(float x) { return (float)exp((double)x); }
+
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 splat3(float s) { return mk3(s, s, s); }
 template<typename P> PT_DEV f3 ld3(P p) { return mk3(p[0], p[1], p[2]); }   // P: pointer to float in any address space

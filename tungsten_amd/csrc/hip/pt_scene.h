@@ -1166,7 +1166,7 @@ PT_DEV void sphereSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v
     n = (hp - ld3(o.pos))/o.scale[0];
     f3 localN = mat3TMul(o.rot, n);
     u = atan2f(localN.y, localN.x)*PT_INV_TWO_PI + 0.5f;
-    v = acosf(clampf(localN.z, -1.0f, 1.0f))*PT_INV_PI;
+    v = acosfExact(clampf(localN.z, -1.0f, 1.0f))*PT_INV_PI;
     if (isnan(u)) u = 0.0f;
 }
 
@@ -1343,7 +1343,7 @@ PT_DEV void infDirectionToUV(const TgHipObject &o, f3 wi, float &u, float &v, fl
     f3 wLocal = mat3TMul(o.rot, wi);
     sinTheta = sqrtf(fmaxf(1.0f - wLocal.y*wLocal.y, 0.0f));
     u = atan2f(wLocal.z, wLocal.x)*PT_INV_TWO_PI + 0.5f;
-    v = acosf(-wLocal.y)*PT_INV_PI;
+    v = acosfExact(-wLocal.y)*PT_INV_PI;
 }
 PT_DEV f3 infUvToDirection(const TgHipObject &o, float u, float v, float &sinTheta)
 {
@@ -1644,7 +1644,7 @@ PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
         f3 R3 = R0 + e1*2.0f;
         f3 n0 = normalized(cross(R0, R1)), n1 = normalized(cross(R1, R2));
         f3 n2 = normalized(cross(R2, R3)), n3 = normalized(cross(R3, R0));
-        float Q = acosf(dot(n0, n1)) + acosf(dot(n1, n2)) + acosf(dot(n2, n3)) + acosf(dot(n3, n0));
+        float Q = acosfExact(dot(n0, n1)) + acosfExact(dot(n1, n2)) + acosfExact(dot(n2, n3)) + acosfExact(dot(n3, n0));
         return (PT_TWO_PI - fabsf(Q))*max3(ld3(s.textures[o.emission].avg));
     }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_SPHERE) {     /* Sphere.cpp:266-271, 33-40 */
@@ -1663,7 +1663,7 @@ PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
         f3 R3 = R0 + ld3(o.edge1);
         f3 n0 = normalized(cross(R0, R1)), n1 = normalized(cross(R1, R2));
         f3 n2 = normalized(cross(R2, R3)), n3 = normalized(cross(R3, R0));
-        float Q = acosf(dot(n0, n1)) + acosf(dot(n1, n2)) + acosf(dot(n2, n3)) + acosf(dot(n3, n0));
+        float Q = acosfExact(dot(n0, n1)) + acosfExact(dot(n1, n2)) + acosfExact(dot(n2, n3)) + acosfExact(dot(n3, n0));
         return (PT_TWO_PI - fabsf(Q))*max3(ld3(s.textures[o.emission].avg));
     }
     if (o.type == TGHIP_OBJ_POINT) {                           /* Point::approximateRadiance (Point.cpp:166-169) */
@@ -1760,7 +1760,7 @@ PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
         return tau > p0 ? 0.0f : 1.0f/p0;
     }
     case TGHIP_TRANS_DOUBLE_EXPONENTIAL: {              /* DoubleExponentialTransmittance.cpp:34-49 */
-        float ea = expf(-p0*tau), eb = expf(-p1*tau);
+        float ea = expfRounded(-p0*tau), eb = expfRounded(-p1*tau);
         if (k == 0) return 0.5f*(ea + eb);
         if (k == 1) return 0.5f*(p0*ea + p1*eb);
         if (k == 2) return (p0*ea + p1*eb)/(p0 + p1);
@@ -1789,7 +1789,7 @@ PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
         return (1.0f/n)*(fabsf(idxF - (float)idx - 0.5f) < 1e-3f ? 1.0f : 0.0f);
     }
     case TGHIP_TRANS_ERLANG: {                          /* ErlangTransmittance.cpp:32-47 */
-        float e = expf(-p0*tau);
+        float e = expfRounded(-p0*tau);
         if (k == 0) return 0.5f*e*(2.0f + p0*tau);
         if (k == 1) return e*(1.0f + p0*tau)*p0*0.5f;
         if (k == 2) return e*(1.0f + p0*tau);
@@ -1818,8 +1818,8 @@ PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
         }
         return isnan(Tr) ? 0.0f : Tr;
     }
-    default:                                            /* ExponentialTransmittance.cpp:26-41 */
-        return expf(-tau);
+    default:                                            /* ExponentialTransmittance.cpp:26-41: FastMath::exp */
+        return fmathExp(-tau);
     }
 }
 PT_DEV float transLeafSigmaBar(const TgHipMedium &m)

@@ -183,7 +183,6 @@ struct tghip_ctx {
     int suspendLanes = 16, suspendTurns = 16, suspendMinQueue = 1024;   // (measured, profiles/README.md: materialtest +0.5 %, mesh1m +4 %)
     int ldsNodesOpt = 73;                 // "lds_nodes": nodes of the top of the wide tree kept in LDS by those kernels (1 + 8 + 64: three levels)
     uint32_t numWideNodes = 0;
-    int instShadowNoCountOpt = 0;         // "inst_shadow_nocount": launch k_trace_shadow_wide<COUNT = false, ., INST> (see launchShadow)
     int decoupleOpt = 1;                  // "decouple": the wide kernels of single-level scenes test a record AND visit a node per turn (k_trace_closest_wide<.., DECOUPLED>)
     int leafBatch = 1;                    // "leaf_batch" (PathState::leaf_batch)
     int leafBatchBvh2 = 0;                // "leaf_batch_bvh2" (PathState::leaf_batch_bvh2); 0 = leaf_batch, or the measured value for two-level scenes
@@ -598,7 +597,7 @@ static void chooseThreads(tghip_ctx *ctx)
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
     if (wideS && inst && !ctx->haveForward && !ctx->haveMeshLight)
-        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<true, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<true, false, true>, 256, 3);
+        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false, true>, 256, 3);
     else if (wideS && !ctx->haveForward && !ctx->haveMeshLight)
         ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false>, 256, 3);
     else if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
@@ -765,7 +764,6 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "suspend_lanes") ctx->suspendLanes = int(std::min<long long>(std::max<long long>(value, 0), 64));
     else if (k == "suspend_turns") ctx->suspendTurns = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));   // (>= 1: every launch advances every walk)
     else if (k == "suspend_min_queue") ctx->suspendMinQueue = int(std::min<long long>(std::max<long long>(value, 0), 1 << 20));
-    else if (k == "inst_shadow_nocount") ctx->instShadowNoCountOpt = value != 0;
     else if (k == "decouple") ctx->decoupleOpt = value != 0;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1154,15 +1152,13 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
         const size_t lds = wideLdsBytes(ctx, ctx->thrShadow);
 #define SHADOW_WIDE(S, I) hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, S, I>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
         if (ctx->haveInstances) {
-            // (always the counting variant: hipcc 7.2 miscompiles k_trace_shadow_wide<false, ., true> -- occluders inside instances
-            // go missing, tools/dbg/inst_debug3.py -- while the variant that also counts its node and record visits is correct;
-            // foldCounters drops the counts when nobody asked for them)
-#define SHADOW_WIDE_INST(S) hipLaunchKernelGGL((k_trace_shadow_wide<true, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
-#define SHADOW_WIDE_INST_NC(S) hipLaunchKernelGGL((k_trace_shadow_wide<false, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
-            if (ctx->instShadowNoCountOpt && !COUNT) { if (ctx->haveSolids) SHADOW_WIDE_INST_NC(true); else SHADOW_WIDE_INST_NC(false); }   // ("inst_shadow_nocount": the variant under suspicion, for tests/test_gpu_parity.py)
-            else if (ctx->haveSolids) SHADOW_WIDE_INST(true); else SHADOW_WIDE_INST(false);
-#undef SHADOW_WIDE_INST_NC
-#undef SHADOW_WIDE_INST
+            // (Round 2 launched the counting variant here always: k_trace_shadow_wide<COUNT = false, ., INST> as compiled then lost
+            // occluders inside instances; the cause was never isolated.  As compiled from the present source -- the kernel has since
+            // gained the walk's second pending-record set, the per-lane turn counter and the shared prologue of the suspended-walk
+            // protocol -- both variants agree bit for bit with each other and with the BVH2 shadow walk on the crowded instance scene;
+            // tests/test_gpu_parity.py::test_instanced_shadow_walk_with_and_without_the_visit_counters keeps watch, so the kernel
+            // that counts nothing is the default again.)
+            if (ctx->haveSolids) SHADOW_WIDE(true, true); else SHADOW_WIDE(false, true);
         }
         else if (ctx->decoupleOpt) {
 #define SHADOW_WIDE_D(S) hipLaunchKernelGGL((k_trace_shadow_fast<COUNT, S>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
