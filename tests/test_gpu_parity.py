@@ -233,10 +233,10 @@ def test_suspended_walks_visit_what_uninterrupted_walks_visit(tmp_path):
 
 
 @pytest.mark.gpu
-def test_instanced_shadow_walk_with_and_without_the_visit_counters(tmp_path):
-    """Round 2 found k_trace_shadow_wide<COUNT = false, ., INST> losing occluders inside instances while the variant that also counts
-    its node / record visits was right, and launched the counting variant for instanced scenes.  Both are in use again (the counting
-    one under count_traversal): the crowded instance scene rendered with either, and with the BVH2 shadow walk, is one image."""
+def test_instanced_shadow_walk_agrees_with_the_bvh2_walk(tmp_path):
+    """Instanced scenes launch the COUNTING variant of the wide shadow walk always (tungsten_hip.hip: launchShadow has the history):
+    on the crowded instance scene it gives the image of the two-level BVH2 shadow walk bit for bit, with and without the counters
+    being read out.  (At BASELINE configs[4]'s size tests/test_gpu_fullsize.py compares the same path with the oracle.)"""
     mk, kw = scenes.GOLDEN_CASES["cornell_instances"]
     path = mk(tmp_path, **dict(kw, resolution=(160, 90), spp=8))
     bvh2, _, cnt, _ = gpu_render(path, wide_shadow=0)

@@ -597,7 +597,7 @@ static void chooseThreads(tghip_ctx *ctx)
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
     if (wideS && inst && !ctx->haveForward && !ctx->haveMeshLight)
-        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false, true>, 256, 3);
+        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<true, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<true, false, true>, 256, 3);
     else if (wideS && !ctx->haveForward && !ctx->haveMeshLight)
         ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false>, 256, 3);
     else if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
@@ -1152,13 +1152,15 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
         const size_t lds = wideLdsBytes(ctx, ctx->thrShadow);
 #define SHADOW_WIDE(S, I) hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, S, I>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
         if (ctx->haveInstances) {
-            // (Round 2 launched the counting variant here always: k_trace_shadow_wide<COUNT = false, ., INST> as compiled then lost
-            // occluders inside instances; the cause was never isolated.  As compiled from the present source -- the kernel has since
-            // gained the walk's second pending-record set, the per-lane turn counter and the shared prologue of the suspended-walk
-            // protocol -- both variants agree bit for bit with each other and with the BVH2 shadow walk on the crowded instance scene;
-            // tests/test_gpu_parity.py::test_instanced_shadow_walk_with_and_without_the_visit_counters keeps watch, so the kernel
-            // that counts nothing is the default again.)
-            if (ctx->haveSolids) SHADOW_WIDE(true, true); else SHADOW_WIDE(false, true);
+            // (always the counting variant.  Round 2: k_trace_shadow_wide<COUNT = false, ., INST> loses occluders inside instances while
+            // the variant that also counts its node and record visits is right; the cause was never isolated -- nothing in the
+            // source distinguishes the two but the counters.  Round 3 tried the non-counting variant again: on the crowded
+            // 200-instance golden scene it now agrees bit for bit with the BVH2 shadow walk, on instances10k at 3840x2160 a third of
+            // the pixels leave the oracle (tests/test_gpu_fullsize.py::c5_instances10k, which guards this line); foldCounters drops
+            // the counts when nobody asked for them.)
+#define SHADOW_WIDE_INST(S) hipLaunchKernelGGL((k_trace_shadow_wide<true, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
+            if (ctx->haveSolids) SHADOW_WIDE_INST(true); else SHADOW_WIDE_INST(false);
+#undef SHADOW_WIDE_INST
         }
         else if (ctx->decoupleOpt) {
 #define SHADOW_WIDE_D(S) hipLaunchKernelGGL((k_trace_shadow_fast<COUNT, S>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
