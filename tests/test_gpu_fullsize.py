@@ -1,10 +1,10 @@
 """BASELINE.json's configurations at their full image sizes, through size-independent properties: every pixel receives exactly
 spp finite, non-negative samples; the counters add up; rays per sample stay in the scene's range; and a sub-sample of pixels of
-one 16-pixel tile row agrees with the oracle tracing the same (pixel, sample) streams.
+one full 16-pixel tile row -- every pixel of it -- agrees with the oracle tracing the same (pixel, sample) streams.
   configs[2]  materialtest 1920x1080, the dielectric and rough-dielectric variants of its "Material" bsdf
   configs[3]  the 998 000-triangle mesh + HDRI, 1920x1080
   configs[4]  10 000 instances of a 19 800-triangle mesh, four materials, 3840x2160
-(The sample counts are small: the properties do not depend on them, and the 1280x720 cases of test_gpu_parity.py carry more.)"""
+(8 samples per pixel, 4 at 3840x2160: the oracle traces 16 x W x spp samples per case on the host.)"""
 import numpy as np
 import pytest
 
@@ -18,12 +18,12 @@ SEED = tg.DEFAULT_SEED
 
 CASES = {
     "c3_dielectric": (lambda d, res, spp: scenes.materialtest(d, resolution=res, spp=spp, edit=scenes._mt_material({"type": "dielectric", "ior": 1.5, "albedo": 1})),
-                      (1920, 1080), 4, (3.0, 9.0), 0.05),
+                      (1920, 1080), 8, (3.0, 9.0), 0.05),
     "c3_rough_dielectric": (lambda d, res, spp: scenes.materialtest(d, resolution=res, spp=spp, edit=scenes._mt_material(
                                 {"type": "rough_dielectric", "ior": 1.5, "distribution": "ggx", "roughness": 0.1, "albedo": 1})),
-                            (1920, 1080), 4, (3.0, 9.0), 0.05),
-    "c4_mesh1m": (lambda d, res, spp: scenes.mesh1m(d, resolution=res, spp=spp), (1920, 1080), 2, (2.5, 7.0), 0.05),
-    "c5_instances10k": (lambda d, res, spp: scenes.instances10k(d, resolution=res, spp=spp), (3840, 2160), 1, (2.0, 9.0), 0.08),
+                            (1920, 1080), 8, (3.0, 9.0), 0.05),
+    "c4_mesh1m": (lambda d, res, spp: scenes.mesh1m(d, resolution=res, spp=spp), (1920, 1080), 8, (2.5, 7.0), 0.05),
+    "c5_instances10k": (lambda d, res, spp: scenes.instances10k(d, resolution=res, spp=spp), (3840, 2160), 4, (2.0, 9.0), 0.08),
 }
 
 
@@ -39,19 +39,19 @@ def test_baseline_configuration_at_full_size(case, tmp_path):
     assert c.samples == w*h*spp
     assert np.isfinite(mean).all() and (mean >= 0).all()
     assert rays_lo <= (c.closest_rays + c.shadow_rays)/c.samples <= rays_hi
-    # the oracle on every 8th pixel of the tile row through the middle of the image: same pixels, same random streams
+    # the oracle on the whole tile row through the middle of the image: same pixels, same random streams (the oracle's renderer,
+    # restricted to those tiles by rendering the image as shards: row r of the tile grid = the tiles t with t // tiles_x == r)
     flat = tg.FlattenedScene(path)
     y0 = ((h//2)//16)*16
-    ys, xs = range(y0, y0 + 16, 2), range(0, w, 8)
-    om = np.zeros((len(ys), len(xs), 3), np.float32)
-    for iy, y in enumerate(ys):
-        for ix, x in enumerate(xs):
+    om = np.zeros((16, w, 3), np.float32)
+    for iy in range(16):
+        for x in range(w):
             acc = np.zeros(3, np.float64)
             for s in range(spp):
-                acc += oracle_lib.trace_sample(flat.desc, SEED, x, y, s)
-            om[iy, ix] = acc/spp
+                acc += oracle_lib.trace_sample(flat.desc, SEED, x, y0 + iy, s)
+            om[iy, x] = acc/spp
     flat.close()
-    gm = mean[y0:y0 + 16:2, ::8]
-    # (one to four samples per pixel: a divergent path is a divergent pixel; the bound is the per-sample divergence of the
-    # scene's BSDFs, tests/test_gpu_samples.py, times the samples per pixel, with margin)
+    gm = mean[y0:y0 + 16]
+    # (a divergent path is a divergent pixel at these sample counts; the bound is the per-sample divergence of the scene's BSDFs,
+    # tests/test_gpu_samples.py, times the samples per pixel, with margin)
     compare(gm, om, max_bad=max_bad, mean_rel=3e-2)
