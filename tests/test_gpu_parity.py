@@ -234,9 +234,9 @@ def test_suspended_walks_visit_what_uninterrupted_walks_visit(tmp_path):
 
 @pytest.mark.gpu
 def test_instanced_shadow_walk_agrees_with_the_bvh2_walk(tmp_path):
-    """Instanced scenes launch the COUNTING variant of the wide shadow walk always (tungsten_hip.hip: launchShadow has the history):
-    on the crowded instance scene it gives the image of the two-level BVH2 shadow walk bit for bit, with and without the counters
-    being read out.  (At BASELINE configs[4]'s size tests/test_gpu_fullsize.py compares the same path with the oracle.)"""
+    """The wide shadow walk of instanced scenes (k_trace_shadow_wide<., ., INST>) gives the image of the two-level BVH2 shadow walk bit
+    for bit, with and without counting its visits -- on the crowded instance scene of the goldens and on instances10k (BASELINE
+    configs[4]'s scene at 2 spp), where the variant without PT_TURN_JOIN (pt_wavefront.h) loses occluders in 44 % of the pixels."""
     mk, kw = scenes.GOLDEN_CASES["cornell_instances"]
     path = mk(tmp_path, **dict(kw, resolution=(160, 90), spp=8))
     bvh2, _, cnt, _ = gpu_render(path, wide_shadow=0)
@@ -245,6 +245,36 @@ def test_instanced_shadow_walk_agrees_with_the_bvh2_walk(tmp_path):
     assert (cnt == 8).all() and c.nodes_visited_shadow > 0
     assert (plain == bvh2).all()
     assert (counting == bvh2).all()
+    if not scenes.have_materialtest():
+        pytest.skip("instances10k needs the materialtest assets (oracle/_ref/data)")
+    big = scenes.instances10k(tmp_path, resolution=(1920, 1080), spp=2)
+    r = tg.Renderer(big, seed=SEED)
+    try:
+        images = {}
+        for name, opts in (("bvh2", dict(wide_shadow=0)), ("wide", dict(wide_shadow=1)), ("wide, counting", dict(count_traversal=1))):
+            for k, v in opts.items():
+                r.set_option(k, v)
+            images[name] = _one_pass(r, 2)
+    finally:
+        r.close()
+    assert images["bvh2"].mean() > 0.1
+    assert (images["wide"] == images["bvh2"]).all(), float((images["wide"] != images["bvh2"]).any(axis=-1).mean())
+    assert (images["wide, counting"] == images["bvh2"]).all()
+
+
+def _one_pass(r, spp, seed=SEED):
+    """one plain pass [0, spp) into a cleared framebuffer on the renderer's first context; returns the radiance sums"""
+    import ctypes as C
+    ctx = r.context()
+    n = r.width*r.height
+    ssum = np.empty((r.height, r.width, 3), np.float32)
+    cnt = np.empty((r.height, r.width), np.uint32)
+    p = tg.TgHipPassDesc(0, spp, seed & 0xFFFFFFFF, 0, 1, 0)
+    for rc in (tg.lib.tghip_clear_framebuffer(ctx), tg.lib.tghip_render_pass(ctx, C.byref(p)), tg.lib.tghip_wait(ctx),
+               tg.lib.tghip_download_framebuffer(ctx, ssum.ctypes.data, cnt.ctypes.data, n)):
+        assert rc == 0, tg.lib.tghip_last_error(ctx).decode()
+    assert (cnt == spp).all()
+    return ssum
 
 
 def test_tile_shards_partition_the_image(tmp_path):

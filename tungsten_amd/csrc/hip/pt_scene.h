@@ -1353,7 +1353,7 @@ PT_DEV f3 infUvToDirection(const TgHipObject &o, float u, float v, float &sinThe
     return mat3Mul(o.rot, mk3(cosf(phi)*sinTheta, -cosf(theta), sinf(phi)*sinTheta));
 }
 
-struct LightHit { float t, u, v; bool backSide; f3 n; };   /* n: surface normal at the hit (cube lights) */
+struct LightHit { float t, u, v; bool backSide; f3 n; float sinTheta; };   /* n: surface normal at the hit (cube lights); sinTheta: infinite sphere (below) */
 
 /* light.intersect(ray) + intersectionInfo: analytic hit test that precedes the shadow ray (TraceBase.cpp:155-162) */
 template<uint32_t M>
@@ -1396,9 +1396,8 @@ PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, Li
         lh.t = ray.tmax; lh.backSide = false; lh.u = 0.0f; lh.v = 0.0f;
         return true;
     }
-    float sinTheta;
     lh.t = ray.tmax; lh.backSide = false;
-    infDirectionToUV(o, ray.d, lh.u, lh.v, sinTheta);
+    infDirectionToUV(o, ray.d, lh.u, lh.v, lh.sinTheta);
     return true;
 }
 template<uint32_t M>
@@ -1445,9 +1444,9 @@ PT_DEV float lightDirectPdf(const DeviceScene &s, int objIdx, f3 w, f3 p, const 
     const TgHipTexture &t = s.textures[o.emission];
     if (!(M & FEAT_BITMAP) || t.type != TGHIP_TEX_BITMAP)
         return PT_INV_FOUR_PI;
-    float sinTheta, u, v;
-    infDirectionToUV(o, w, u, v, sinTheta);
-    return PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, o.emission, t, u, v)/sinTheta;
+    // (u, v, sinTheta) = infDirectionToUV(o, w): lightIntersect computed exactly that for this direction (InfiniteSphere::directPdf,
+    // InfiniteSphere.cpp:218-229, maps the direction again; same function of the same argument, same result)
+    return PT_INV_PI*PT_INV_TWO_PI*bitmapPdf(s, o.emission, t, lh.u, lh.v)/lh.sinTheta;
 }
 template<uint32_t M>
 PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, f3 &d, float &dist, float &pdf)

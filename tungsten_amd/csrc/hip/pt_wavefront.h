@@ -490,6 +490,15 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
 #ifndef WIDE_SHADOW_BOUNDS
 #define WIDE_SHADOW_BOUNDS SHADOW_DYN_BOUNDS
 #endif
+// The end of a loop turn of the two-level (INST) walks, as an instruction of its own.  Without it every path through the turn -- fourteen
+// of them in k_trace_shadow_wide<., ., INST> -- and the edge of the lanes that sit the turn out meet directly in the loop latch (one block
+// with 15 predecessors and 25 phis in the optimised IR), and the code the AMDGPU backend of ROCm 7.2 generates for that latch on gfx950
+// is wrong: on instances10k 44 % of the pixels lose occluders inside instances, differently from run to run (which lanes share a wave
+// depends on the order the waves fetch in), while the BVH2 walk, the variant that counts its visits and every variant with ANY
+// side-effecting instruction at this place (a counter, s_nop, an empty asm) agree bit for bit; waits and fences anywhere else change
+// nothing, so it is not a memory-ordering problem (tools/repro_latch_miscompile.py, profiles/r3_latch_miscompile.txt).
+// With the join the latch has two predecessors.  Costs nothing: no instruction is emitted.
+#define PT_TURN_JOIN() asm volatile("" ::: "memory")
 // DECOUPLED (single-level scenes): a turn tests the lane's next pending record AND visits its next node -- the walk does not wait for
 // the records of the node visited last before it moves on (their outcome only tightens tmax, never what is visited next), so a ray
 // needs about max(nodes, records) turns instead of their sum; a node visited before an earlier node's records have shortened the ray
@@ -745,6 +754,7 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
                     }
                 }
             }
+            PT_TURN_JOIN();
             }
     }
     if (COUNT) wpLoopEnd = wall_clock64();
@@ -1220,10 +1230,13 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
                                         RayD sr; sr.o = info.p; sr.d = wog; sr.tmin = 5e-4f; sr.tmax = PT_INF;
                                         LightHit lh;
                                         if (lightIntersect<M>(s, light, sr, lh)) {
+                                            // the emission lookup and the light's pdf lookup are issued together (both are dependent
+                                            // loads of a bitmap light); the pdf is only USED behind the !isZero(e) test, as in :312-316
                                             f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
+                                            const float lightPdf = lightDirectPdf<M>(s, light, wog, info.p, lh);
                                             if (!isZero(e)) {
                                                 f3 bsdfF = e*ev.weight;
-                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightDirectPdf<M>(s, light, wog, info.p, lh));
+                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightPdf);
                                                 if (FUSE & FUSE_SHADOW) {
                                                     sr.tmax = lh.t;
                                                     fusedShadow++;
@@ -1723,7 +1736,8 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
 
 // k_trace_shadow_dyn over the 8-wide BVH: any-hit queries, one memory round trip (a node or a record) per lane and loop
 // turn, like k_trace_closest_wide.  Dynamic LDS: [expanded queue, 2 B per slot][group stacks, wideDepth x 8 B per thread].
-template<bool COUNT, bool SOLIDS = true, bool INST = false>
+// JOIN = false (INST only) leaves PT_TURN_JOIN out: the miscompiled variant, kept for tools/repro_latch_miscompile.py
+template<bool COUNT, bool SOLIDS = true, bool INST = false, bool JOIN = true>
 __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
 {
     extern __shared__ int ldsDyn[];
@@ -1963,6 +1977,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                         finishSlot();
                 }
             }
+            if (JOIN) PT_TURN_JOIN();
             }
     }
     if (COUNT) wpLoopEnd = wall_clock64();

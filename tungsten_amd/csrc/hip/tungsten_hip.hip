@@ -95,6 +95,7 @@ struct tghip_ctx {
     // closest-hit 849 us per launch on the BVH2 against 1061 us on the wide tree -- every instance entered costs the wide
     // walk extra turns --, shadow rays 905 against 517 us)
     int wideClosestOpt = -1, wideShadowOpt = -1;
+    bool instShadowJoin = true;           // "inst_shadow_join": 0 = the instanced wide shadow kernel without PT_TURN_JOIN (the miscompiled variant; repro tool only)
     int wideStride = 80;                  // "wide_node_stride" option (80 or 128; takes effect at the next upload)
     uint32_t width = 0, height = 0;
 
@@ -181,7 +182,7 @@ struct tghip_ctx {
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
     // "suspend_lanes" / "suspend_turns" / "suspend_min_queue" (PathState::suspend_*): walk time-slicing of the wide traversal kernels
     int suspendLanes = 16, suspendTurns = 16, suspendMinQueue = 1024;   // (measured, profiles/README.md: materialtest +0.5 %, mesh1m +4 %)
-    int ldsNodesOpt = 73;                 // "lds_nodes": nodes of the top of the wide tree kept in LDS by those kernels (1 + 8 + 64: three levels)
+    int ldsNodesOpt = 0;                  // "lds_nodes": nodes of the top of the wide tree kept in LDS by those kernels (9 / 73 / 585 = two / three / four levels; measured: no gain)
     uint32_t numWideNodes = 0;
     int decoupleOpt = 1;                  // "decouple": the wide kernels of single-level scenes test a record AND visit a node per turn (k_trace_closest_wide<.., DECOUPLED>)
     int leafBatch = 1;                    // "leaf_batch" (PathState::leaf_batch)
@@ -597,7 +598,7 @@ static void chooseThreads(tghip_ctx *ctx)
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
     if (wideS && inst && !ctx->haveForward && !ctx->haveMeshLight)
-        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<true, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<true, false, true>, 256, 3);
+        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false, true>, 256, 3);
     else if (wideS && !ctx->haveForward && !ctx->haveMeshLight)
         ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false>, 256, 3);
     else if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
@@ -765,6 +766,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "suspend_turns") ctx->suspendTurns = int(std::min<long long>(std::max<long long>(value, 1), 1 << 20));   // (>= 1: every launch advances every walk)
     else if (k == "suspend_min_queue") ctx->suspendMinQueue = int(std::min<long long>(std::max<long long>(value, 0), 1 << 20));
     else if (k == "decouple") ctx->decoupleOpt = value != 0;
+    else if (k == "inst_shadow_join") ctx->instShadowJoin = value != 0;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
@@ -1152,15 +1154,12 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
         const size_t lds = wideLdsBytes(ctx, ctx->thrShadow);
 #define SHADOW_WIDE(S, I) hipLaunchKernelGGL((k_trace_shadow_wide<COUNT, S, I>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
         if (ctx->haveInstances) {
-            // (always the counting variant.  Round 2: k_trace_shadow_wide<COUNT = false, ., INST> loses occluders inside instances while
-            // the variant that also counts its node and record visits is right; the cause was never isolated -- nothing in the
-            // source distinguishes the two but the counters.  Round 3 tried the non-counting variant again: on the crowded
-            // 200-instance golden scene it now agrees bit for bit with the BVH2 shadow walk, on instances10k at 3840x2160 a third of
-            // the pixels leave the oracle (tests/test_gpu_fullsize.py::c5_instances10k, which guards this line); foldCounters drops
-            // the counts when nobody asked for them.)
-#define SHADOW_WIDE_INST(S) hipLaunchKernelGGL((k_trace_shadow_wide<true, S, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
-            if (ctx->haveSolids) SHADOW_WIDE_INST(true); else SHADOW_WIDE_INST(false);
-#undef SHADOW_WIDE_INST
+            // (rounds 2 and 3 launched the counting variant here: the non-counting one lost occluders inside instances.  The cause is the
+            // loop latch the backend generates for the turn without PT_TURN_JOIN, pt_wavefront.h; "inst_shadow_join" = 0 launches that
+            // variant for tools/repro_latch_miscompile.py)
+            if (!ctx->instShadowJoin && !ctx->haveSolids && !COUNT)
+                hipLaunchKernelGGL((k_trace_shadow_wide<false, false, true, false>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag);
+            else if (ctx->haveSolids) SHADOW_WIDE(true, true); else SHADOW_WIDE(false, true);
         }
         else if (ctx->decoupleOpt) {
 #define SHADOW_WIDE_D(S) hipLaunchKernelGGL((k_trace_shadow_fast<COUNT, S>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag)
