@@ -58,6 +58,17 @@ namespace {
 std::mutex g_errMutex;
 std::string g_createError = "no error";
 
+// The streams of a context, kept per device for the life of the process and handed from a destroyed context to the next one created:
+// HIP binds a stream to one of a few hardware queues when it is created (GPU_MAX_HW_QUEUES, 4 by default), and the streams of a context
+// created after another one was destroyed came out with a binding on which the four parts of the wavefront loop no longer ran side by
+// side (materialtest 1280x720x256: 840 Msamples/s in a process's first context, 675 in every later one; the 16-spp passes of the
+// as-shipped scene 24 ms against 35 ms).  A renderer that is opened once per frame or per scene keeps its first context's streams this way.
+struct StreamSet {
+    hipStream_t main = nullptr, part[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, abort = nullptr;
+};
+std::mutex g_streamMutex;
+std::map<int, std::vector<StreamSet>> g_freeStreams;   // device ordinal -> sets no context holds (never destroyed: they live as long as the process)
+
 struct DeviceBuffers {
     std::vector<void *> allocs;
     ~DeviceBuffers() { release(); }
@@ -662,32 +673,46 @@ tghip_ctx *tghip_create(int device_ordinal)
     std::memset(&ctx->scene, 0, sizeof(ctx->scene));
     hipError_t e = hipSetDevice(device_ordinal);
     if (e == hipSuccess) e = hipGetDeviceProperties(&ctx->prop, device_ordinal);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    // (creation order matters: HIP deals its streams round-robin to a few hardware queues -- GPU_MAX_HW_QUEUES, 4 by default -- and
-    // streams on one hardware queue run their kernels one after the other; the part streams come first)
-    for (int k = 0; k < 7; ++k) {
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->partStream[k], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evPart[k], hipEventDisableTiming);
+    {
+        // (creation order matters: HIP deals its streams round-robin to a few hardware queues and streams on one hardware queue run their
+        // kernels one after the other; the main stream and the part streams come first)
+        StreamSet set;
+        bool reused = false;
+        {
+            std::lock_guard<std::mutex> lock(g_streamMutex);
+            std::vector<StreamSet> &pool = g_freeStreams[device_ordinal];
+            if (!pool.empty()) { set = pool.back(); pool.pop_back(); reused = true; }
+        }
+        if (!reused) {
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&set.main, hipStreamNonBlocking);
+            for (int k = 0; k < 7; ++k)
+                if (e == hipSuccess) e = hipStreamCreateWithFlags(&set.part[k], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&set.abort, hipStreamNonBlocking);
+        }
+        ctx->stream = set.main;
+        for (int k = 0; k < 7; ++k) ctx->partStream[k] = set.part[k];
+        ctx->abortStream = set.abort;
     }
+    for (int k = 0; k < 7; ++k)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evPart[k], hipEventDisableTiming);
     for (int k = 0; k < 8; ++k) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evFork[k], hipEventDisableTiming);
-        for (int a = 0; a < 2; ++a) {
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->classStream[k][a], hipStreamNonBlocking);
+        for (int a = 0; a < 2; ++a)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evJoin[k][a], hipEventDisableTiming);
-        }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evMain, hipEventDisableTiming);
     ctx->launchStream = ctx->stream;
     if (e == hipSuccess) e = hipEventCreate(&ctx->evA);
     if (e == hipSuccess) e = hipEventCreate(&ctx->evB);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->hostLive), 2*sizeof(uint32_t), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->abortStream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&ctx->abortFlagDev), 64);
     if (e == hipSuccess) e = hipMemset(ctx->abortFlagDev, 0, 64);
     if (e != hipSuccess) {
-        std::lock_guard<std::mutex> lock(g_errMutex);
-        g_createError = std::string("tghip_create: ") + hipGetErrorString(e);
-        delete ctx;
+        {
+            std::lock_guard<std::mutex> lock(g_errMutex);
+            g_createError = std::string("tghip_create: ") + hipGetErrorString(e);
+        }
+        tghip_destroy(ctx);
         return nullptr;
     }
     return ctx;
@@ -715,21 +740,35 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->hostLive) (void)hipHostFree(ctx->hostLive);
     if (ctx->abortFlagDev) (void)hipFree(ctx->abortFlagDev);
-    if (ctx->abortStream) (void)hipStreamDestroy(ctx->abortStream);
     if (ctx->evA) (void)hipEventDestroy(ctx->evA);
     if (ctx->evB) (void)hipEventDestroy(ctx->evB);
     for (hipEvent_t e : ctx->evPool) (void)hipEventDestroy(e);
     for (int k = 0; k < 7; ++k) if (ctx->evPart[k]) (void)hipEventDestroy(ctx->evPart[k]);
     if (ctx->evMain) (void)hipEventDestroy(ctx->evMain);
-    for (int k = 0; k < 7; ++k) if (ctx->partStream[k]) (void)hipStreamDestroy(ctx->partStream[k]);
     for (int k = 0; k < 8; ++k) {
         if (ctx->evFork[k]) (void)hipEventDestroy(ctx->evFork[k]);
         for (int a = 0; a < 2; ++a) {
             if (ctx->evJoin[k][a]) (void)hipEventDestroy(ctx->evJoin[k][a]);
-            if (ctx->classStream[k][a]) (void)hipStreamDestroy(ctx->classStream[k][a]);
+            if (ctx->classStream[k][a]) { (void)hipStreamSynchronize(ctx->classStream[k][a]); (void)hipStreamDestroy(ctx->classStream[k][a]); }
         }
     }
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    {
+        // the streams go back to the device's free list (idle: the main stream was synchronised above, the others are waited for here)
+        StreamSet set;
+        set.main = ctx->stream; set.abort = ctx->abortStream;
+        bool complete = set.main != nullptr && set.abort != nullptr;
+        for (int k = 0; k < 7; ++k) { set.part[k] = ctx->partStream[k]; complete = complete && set.part[k] != nullptr; }
+        if (complete) {
+            for (int k = 0; k < 7; ++k) (void)hipStreamSynchronize(set.part[k]);
+            (void)hipStreamSynchronize(set.abort);
+            std::lock_guard<std::mutex> lock(g_streamMutex);
+            g_freeStreams[ctx->device].push_back(set);
+        } else {                                 // (a context whose creation failed half way)
+            if (set.main) (void)hipStreamDestroy(set.main);
+            if (set.abort) (void)hipStreamDestroy(set.abort);
+            for (int k = 0; k < 7; ++k) if (set.part[k]) (void)hipStreamDestroy(set.part[k]);
+        }
+    }
     delete ctx;
 }
 
@@ -756,7 +795,12 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "check_interval") ctx->checkInterval = int(std::min<long long>(std::max<long long>(value, 0), 64));
     else if (k == "time_kernels") ctx->timeKernels = value != 0;
     else if (k == "streams") { ctx->streamsOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
-    else if (k == "class_streams") ctx->classStreamsOpt = value != 0;
+    else if (k == "class_streams") {
+        ctx->classStreamsOpt = value != 0;
+        for (int kk = 0; kk < 8 && value != 0; ++kk)     // (created when the option is first switched on: an experiment's streams)
+            for (int a = 0; a < 2; ++a)
+                if (!ctx->classStream[kk][a]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->classStream[kk][a], hipStreamNonBlocking));
+    }
     else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
     else if (k == "inst_dyn") { ctx->instDynOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
