@@ -378,6 +378,7 @@ typedef struct TgHipCounters {
     uint64_t nodes_visited_shadow; /* the shadow-ray share of nodes_visited / prims_tested (counting enabled) */
     uint64_t prims_tested_shadow;
     uint64_t shadow_slots;         /* path vertices that queued at least one shadow ray */
+    uint64_t tail_launches;        /* batches whose last paths ran in the single-launch tail kernel (k_tail) */
 } TgHipCounters;
 
 /* closest-hit query record for tghip_trace_rays (and the oracle's equivalent) */

@@ -178,7 +178,9 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
     else:
         mk, kw = scenes.GOLDEN_CASES[scene]
         path = mk(tmp_path, **dict(kw, resolution=(160, 90), spp=8))
-    base, _, cnt, _ = gpu_render(path)
+    # (renders this small would go to the tail kernel at the first host check: the loop's variants are compared with the tail kernel off,
+    # the tail kernel's -- from the first check, from the middle of the render, on one stream and on eight -- against the same image)
+    base, _, cnt, _ = gpu_render(path, tail_kernel=0)
     assert (cnt == 8).all() and np.isfinite(base).all()
     variants = [dict(streams=1), dict(streams=2), dict(streams=8), dict(class_streams=1), dict(streams=1, class_streams=1),
                 dict(slots_per_block=512), dict(max_slots=8192), dict(check_interval=1), dict(check_interval=16), dict(blocks_per_cu=4),
@@ -195,6 +197,10 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
                      dict(lds_nodes=0), dict(lds_nodes=1), dict(lds_nodes=9), dict(lds_nodes=585)]
     if scene == "cornell_instances":
         variants += [dict(inst_dyn=0), dict(inst_simple=0), dict(wide_closest=1), dict(wide_shadow=0), dict(leaf_batch_bvh2=1)]
+    variants = [dict(v, tail_kernel=0) for v in variants]
+    variants += [dict(tail_kernel=1), dict(tail_kernel=1, streams=1), dict(tail_kernel=1, streams=8), dict(tail_kernel=1, tail_threshold=3000, check_interval=2),
+                 dict(tail_kernel=1, tail_threshold=30000, check_interval=1, streams=2), dict(tail_kernel=1, slots_per_block=512),
+                 dict(tail_kernel=1, suspend_lanes=64, suspend_turns=2, suspend_min_queue=0), dict(tail_kernel=1, max_slots=8192, tail_threshold=1 << 30)]
     for opts in variants:
         img, _, c, _ = gpu_render(path, **opts)
         assert (c == 8).all(), opts
@@ -207,6 +213,29 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
             img, _, c, _ = gpu_render(path, **opts)
             assert (c == 8).all(), opts
             assert np.allclose(img, base, rtol=1e-5, atol=1e-6), opts
+
+
+@pytest.mark.gpu
+def test_tail_kernel_traces_the_rays_the_loop_traces(tmp_path):
+    """k_tail (one launch per part in which every workgroup iterates over its own slots) against the launch-per-step loop: the same image,
+    the same samples, the same closest-hit and shadow rays -- entered at the first host check, and half way through the render."""
+    _skip_mt("materialtest")
+    path = scenes.materialtest(tmp_path, resolution=(320, 180), spp=16)
+    res = []
+    for opts in (dict(tail_kernel=0), dict(tail_kernel=1, tail_threshold=1 << 30), dict(tail_kernel=1, tail_threshold=100000, check_interval=2)):
+        r = tg.Renderer(path, seed=SEED)
+        for k, v in opts.items():
+            r.set_option(k, v)
+        r.render()
+        mean, _, cnt = r.image()
+        c = r.counters()
+        res.append((mean.copy(), cnt.copy(), (c.samples, c.closest_rays, c.shadow_rays, c.shadow_slots), c.tail_launches, c.iterations))
+        r.close()
+    assert res[0][3] == 0 and res[1][3] >= 1 and res[2][3] >= 1
+    assert res[1][4] == 0 and 0 < res[2][4] < res[0][4]          # (iterations count the loop's launches only)
+    for other in res[1:]:
+        assert other[2] == res[0][2]
+        assert (other[0] == res[0][0]).all() and (other[1] == res[0][1]).all()
 
 
 @pytest.mark.gpu

@@ -117,7 +117,7 @@ class TgHipCounters(C.Structure):
                 ("ms_trace_closest", C.c_double), ("ms_trace_shadow", C.c_double), ("ms_shade", C.c_double),
                 ("ms_other", C.c_double), ("ms_total", C.c_double),
                 ("launches_trace_closest", u64), ("launches_trace_shadow", u64), ("launches_shade", u64),
-                ("nodes_visited_shadow", u64), ("prims_tested_shadow", u64), ("shadow_slots", u64)]
+                ("nodes_visited_shadow", u64), ("prims_tested_shadow", u64), ("shadow_slots", u64), ("tail_launches", u64)]
 
 
 class TgHipRay(C.Structure):

@@ -82,7 +82,8 @@ enum { Q_EXT = 0, Q_SHADE0 = 1, Q_SHADE1 = 2, Q_SHADOW = 3, Q_EXTP = 4, Q_FIN = 
 
 struct BlockCtl {                 // one per persistent workgroup; only that workgroup touches it
     uint32_t item_cursor;         // workgroup-local linear index of the next work item
-    uint32_t pad[7];
+    uint32_t live_slots;          // slots that carried a path after the workgroup's last k_finish (extension queues + suspended shadow slots)
+    uint32_t pad[6];
     unsigned long long samples, closest_rays, shadow_rays, shadow_slots;
 };                                // 64 B
 

@@ -65,6 +65,7 @@
 #define MASK_GLASS   (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC) | \
                       BSDF_BIT(TGHIP_BSDF_MIRROR))
 #define MASK_PLASTIC (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_PLASTIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_PLASTIC))
+#define MASK_TAIL    (MASK_FULL & ~(FEAT_INSTANCES | FEAT_MESHLIGHT))   /* k_tail: every BSDF type, single-level scenes without mesh emitters */
 /* the class variants of scenes with instance records (no mesh emitters): hits reached through an instance (FEAT_INSTANCES) */
 #define MASK_COAT_INST    (MASK_COAT | FEAT_INSTANCES)
 #define MASK_GLASS_INST   (MASK_GLASS | FEAT_INSTANCES)
@@ -269,8 +270,14 @@ __global__ __launch_bounds__(256) void k_start(DeviceScene s, PathState st, Pass
         queuePush(push, local, L, Q_EXTP);
     }
     bool any = queuesEnd(L, st, -1, (1u << Q_COUNT) - 1u);   // every bitmap is (re)initialised here
+    uint32_t liveSlots = 0;                      // (BlockCtl::live_slots, as k_finish leaves it)
+    for (uint32_t wd = threadIdx.x; wd < (st.slots_per_block >> 5); wd += blockDim.x)
+        liveSlots += (uint32_t)__popc(L.bm[Q_EXTP][wd]);
+    waveAddStat(&L.nodes, liveSlots);
+    __syncthreads();
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
+        ctl.live_slots = L.nodes;
         if (any) atomicMax(&st.live[0], 1u);
     }
 }
@@ -503,12 +510,10 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
 // the records of the node visited last before it moves on (their outcome only tightens tmax, never what is visited next), so a ray
 // needs about max(nodes, records) turns instead of their sum; a node visited before an earlier node's records have shortened the ray
 // may report a few children more (conservative: hits unchanged, visit counts a little above the sequential walk's).
-template<bool COUNT, bool SOLIDS = true, bool INST = false, bool DECOUPLED = false>
-__global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathState st)
+// (the kernel's body as a function of the workgroup's LDS objects: k_trace_closest_wide below and the tail kernel, k_tail, run it)
+template<bool COUNT, bool SOLIDS, bool INST, bool DECOUPLED>
+PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, BlockLds &L, uint32_t &fetchNext, int *ldsDyn)
 {
-    extern __shared__ int ldsDyn[];
-    __shared__ BlockLds L;
-    __shared__ uint32_t fetchNext;
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
     uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + (st.slots_per_block >> 1)) + threadIdx.x;
     const int stride = (int)blockDim.x;
@@ -768,6 +773,14 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
     if (COUNT && laneId() == 0) { atomicAdd(&st.stats[blockIdx.x].prof[10], (unsigned long long)turns); atomicAdd(&st.stats[blockIdx.x].prof[11], (unsigned long long)dryTurns); }
     if (COUNT) WALK_PROF_FLUSH(0, turns - dryTurns, dryTurns);
 }
+template<bool COUNT, bool SOLIDS = true, bool INST = false, bool DECOUPLED = false>
+__global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathState st)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    traceClosestWideBody<COUNT, SOLIDS, INST, DECOUPLED>(s, st, L, fetchNext, ldsDyn);
+}
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
 // WIDE: the scene has a wide BVH and no instances (the walk the wavefront kernels do, one ray per lane without refills)
@@ -843,12 +856,11 @@ PT_DEV void auxPostLoop(const DeviceScene &s, f3 dir, bool asked, int bounce, fl
 #define FUSE_TRACE  1
 #define FUSE_SHADOW 2
 #define FUSE_LOOP   4
-template<uint32_t M, int W, int FUSE>
-__global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, PassParams pp, int cls)
+// (the kernel's body as a function of the workgroup's LDS objects: k_shade below and k_tail run it; returns whether the workgroup's
+// extension queues hold work -- the FUSE launches report it)
+template<uint32_t M, int FUSE>
+PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassParams &pp, int cls, BlockLds &L, unsigned char *ldsTables, unsigned short *order)
 {
-    __shared__ BlockLds L;
-    __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
-    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     BlockCtl &ctl = st.ctl[blockIdx.x];
     const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : shadeQueue(cls);   // (CLS_MISS: the escaped paths)
     const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : -1;
@@ -857,6 +869,8 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
     // queue, touches its own slots, and ORs what it appends into the workgroup's global bitmaps
     constexpr bool CONCURRENT = FUSE == 0;
     queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2, CONCURRENT);
+    if (CONCURRENT && L.n == 0u)
+        return false;                            // nothing of this class in the workgroup: no bitmap changes, nothing to write back
     const DeviceScene s = stageSceneTables(sg, ldsTables);
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
@@ -1408,6 +1422,15 @@ __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, 
             if (anyExt) atomicMax(&st.live[0], (uint32_t)pp.iter_tag);
         }
     }
+    return anyExt;
+}
+template<uint32_t M, int W, int FUSE>
+__global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, PassParams pp, int cls)
+{
+    __shared__ BlockLds L;
+    __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
+    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
+    (void)shadeBody<M, FUSE>(sg, st, pp, cls, L, ldsTables, order);
 }
 
 // TraceBase::generalizedShadowRay (TraceBase.cpp:62-125) for the shadow rays queued by k_shade:
@@ -2007,12 +2030,9 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
 //     once the queue is dry, in the turn they finish), so their loads fly together and once per refill instead of once per turn;
 //   * the walk is the DECOUPLED one of k_trace_closest_wide: a pending record AND the next node per turn.
 // Same queues, same suspended-walk protocol (Q_HOLD), same results as k_trace_shadow_wide.
-template<bool COUNT, bool SOLIDS = true>
-__global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+template<bool COUNT, bool SOLIDS>
+PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, uint32_t &fetchNext, int *ldsDyn)
 {
-    extern __shared__ int ldsDyn[];
-    __shared__ BlockLds L;
-    __shared__ uint32_t fetchNext;
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
     uint2 *stack = reinterpret_cast<uint2 *>(ldsDyn + (st.slots_per_block >> 1)) + threadIdx.x;
     const int stride = (int)blockDim.x;
@@ -2227,15 +2247,20 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast(DeviceScene s, PathState 
     }
     if (COUNT) WALK_PROF_FLUSH(1, turns - dryTurns, dryTurns);
 }
+template<bool COUNT, bool SOLIDS = true>
+__global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    traceShadowFastBody<COUNT, SOLIDS>(s, st, pp, L, fetchNext, ldsDyn);
+}
 
 // Second half of the dynamic-fetch shadow step: finalises the paths that had ended at the vertex whose shadow rays
 // k_trace_shadow_dyn just resolved (Q_FIN), regenerates their slots and reports whether the workgroup has extension
-// rays for the next iteration.
-#ifdef PT_WAVEFRONT_MAIN   /* non-template kernels live in the shim's translation unit only */
-__global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+// rays for the next iteration (returned; BlockCtl::live_slots = how many of its slots still carry a path).
+PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, unsigned short *order)
 {
-    __shared__ BlockLds L;
-    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     BlockCtl &ctl = st.ctl[blockIdx.x];
     // (Q_SHADOW is loaded for the liveness report only: it holds the slots k_trace_shadow_wide suspended, whose paths -- waiting in
     // Q_HOLD or already ended -- keep the pass alive although no extension ray may be queued)
@@ -2261,13 +2286,75 @@ __global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, Pas
     }
     waveAddStat(&L.samples, finishedCount);
     const bool anyExt = queuesEnd(L, st, Q_FIN, (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW), -1, false, 1u << Q_SHADOW);
+    // paths the workgroup still carries: the extension rays queued for the next iteration and the suspended shadow slots
+    uint32_t liveSlots = 0;
+    for (uint32_t wd = threadIdx.x; wd < (st.slots_per_block >> 5); wd += blockDim.x)
+        liveSlots += (uint32_t)__popc(L.bm[Q_EXT][wd] | L.bm[Q_EXTP][wd] | L.bm[Q_SHADOW][wd]);
+    waveAddStat(&L.nodes, liveSlots);            // (L.nodes: unused by this kernel otherwise)
+    __syncthreads();
     if (threadIdx.x == 0) {
         ctl.item_cursor = L.cursor;
         ctl.samples += L.samples;
-        if (anyExt) atomicMax(&st.live[0], iterTag);   // (max: the parts of the pool run on streams of their own and pass here out of order)
+        ctl.live_slots = L.nodes;
     }
+    return anyExt;
+}
+#ifdef PT_WAVEFRONT_MAIN   /* non-template kernels live in the shim's translation unit only */
+__global__ __launch_bounds__(256) void k_finish(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+{
+    __shared__ BlockLds L;
+    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
+    const bool anyExt = finishBody(s, st, pp, L, order);
+    if (threadIdx.x == 0 && anyExt)
+        atomicMax(&st.live[0], iterTag);         // (max: the parts of the pool run on streams of their own and pass here out of order)
+}
+// sums BlockCtl::live_slots over the workgroups of the pool into live[1] (launched with one workgroup at every host check)
+__global__ __launch_bounds__(256) void k_live_slots(PathState st, uint32_t grid)
+{
+    __shared__ uint32_t total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    uint32_t sum = 0;
+    for (uint32_t b = threadIdx.x; b < grid; b += blockDim.x)
+        sum += st.ctl[b].live_slots;
+    waveAddStat(&total, sum);
+    __syncthreads();
+    if (threadIdx.x == 0) st.live[1] = total;
 }
 #endif
+
+// The tail of a pass in ONE launch per part of the pool: every workgroup runs the wavefront iterations of its own slots -- closest hit,
+// the shading classes, shadow rays, finish / regenerate: the bodies of the kernels above, one after the other, through the same queue
+// bitmaps -- until its queues are empty.  Nothing a workgroup reads or writes in an iteration is shared with another workgroup, so the
+// iterations need no grid-wide synchronisation; what the launch saves is the latency of 7 near-empty launches per iteration for the ~30
+// iterations in which the last, longest paths of a pass (up to 64 bounces) run out -- the shim switches to it when few paths are left
+// (tghip_ctx::tailThreshold).  One shading variant (M: every BSDF type of the scene's classes) shades all classes; results are those of
+// the per-class launches bit for bit (tests/test_gpu_parity.py).
+template<uint32_t M, bool SOLIDS>
+__global__ __launch_bounds__(256) void k_tail(DeviceScene s, PathState st, PassParams pp, uint32_t classes)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
+    __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
+    for (;;) {
+        traceClosestWideBody<false, SOLIDS, false, true>(s, st, L, fetchNext, ldsDyn);
+        __syncthreads();
+        for (int c = -1; c < PT_NUM_CLASSES; ++c) {          // the escaped paths, then the classes that occur in the scene (bit c of `classes`)
+            if (c >= 1 && !((classes >> c) & 1u))
+                continue;
+            (void)shadeBody<M, 0>(s, st, pp, c < 0 ? CLS_MISS : c, L, ldsTables, order);
+            __syncthreads();
+        }
+        traceShadowFastBody<false, SOLIDS>(s, st, pp, L, fetchNext, ldsDyn);
+        __syncthreads();
+        const bool anyExt = finishBody(s, st, pp, L, order);
+        __syncthreads();
+        if (!anyExt)
+            break;
+    }
+}
 
 // Sums the per-item partial sums of every pixel slot in fixed chunk order into the framebuffer
 // (deterministic; no float atomics anywhere on the accumulation path).

@@ -48,6 +48,11 @@ extern template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 0>(DeviceScen
 extern template __global__ void k_shade<MASK_FULL, 2, 2>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<BSDF_MASK_ALL, 2, 0>(DeviceScene, PathState, PassParams, int);
+// k_tail: tail.hip
+extern template __global__ void k_tail<MASK_TAIL, false>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_tail<MASK_TAIL, true>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_tail<(MASK_TAIL | FEAT_QMC), false>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_tail<(MASK_TAIL | FEAT_QMC), true>(DeviceScene, PathState, PassParams, uint32_t);
 
 // =============================================================================================
 // Host-side shim
@@ -106,6 +111,12 @@ struct tghip_ctx {
     // closest-hit 849 us per launch on the BVH2 against 1061 us on the wide tree -- every instance entered costs the wide
     // walk extra turns --, shadow rays 905 against 517 us)
     int wideClosestOpt = -1, wideShadowOpt = -1;
+    // "tail_kernel" / "tail_threshold": once a host check finds at most tail_threshold paths alive in the pool, the rest of the batch runs in
+    // k_tail (one launch per part: every workgroup iterates over its own slots until they are done).  The kernel is built for latency, not
+    // throughput (one shading variant for every class, one wave per SIMD): measured, Msamples/s for thresholds off / 2 Ki / 8 Ki / 32 Ki / 128 Ki:
+    // mesh1m 605 / 625 / 611 / 575 / 514, materialtest 963 / 966 / 964 / 968 / 966, materialtest as shipped 573 / 611 / 630 / 623 / 625
+    bool tailOpt = true;
+    long long tailThreshold = 4096;
     bool instShadowJoin = true;           // "inst_shadow_join": 0 = the instanced wide shadow kernel without PT_TURN_JOIN (the miscompiled variant; repro tool only)
     int wideStride = 80;                  // "wide_node_stride" option (80 or 128; takes effect at the next upload)
     uint32_t width = 0, height = 0;
@@ -562,11 +573,11 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     p.rec_aux = uint32_t(uint64_t(slots)*256u + 256u);
     POOL_ALLOC(bm, size_t(slots/32)*Q_COUNT);
     p.bmStride = slots/32;
-    POOL_ALLOC(ctl, grid); POOL_ALLOC(stats, grid); POOL_ALLOC(live, 1);
+    POOL_ALLOC(ctl, grid); POOL_ALLOC(stats, grid); POOL_ALLOC(live, 4);
 #undef POOL_ALLOC
     HIP_TRY(ctx, hipMemsetAsync(p.ctl, 0, sizeof(BlockCtl)*grid, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(p.stats, 0, sizeof(BlockStats)*grid, ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(p.live, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(p.live, 0, 4*sizeof(uint32_t), ctx->stream));
     p.abort_flag = ctx->abortFlagDev;
     p.num_slots = slots;
     p.slots_per_block = perBlock;
@@ -811,6 +822,8 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "suspend_min_queue") ctx->suspendMinQueue = int(std::min<long long>(std::max<long long>(value, 0), 1 << 20));
     else if (k == "decouple") ctx->decoupleOpt = value != 0;
     else if (k == "inst_shadow_join") ctx->instShadowJoin = value != 0;
+    else if (k == "tail_kernel") ctx->tailOpt = value != 0;
+    else if (k == "tail_threshold") ctx->tailThreshold = value;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
@@ -1300,7 +1313,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
         }
     }
     HIP_TRY(ctx, hipMemsetAsync(st.partial, 0, size_t(pp.total_items)*sizeof(float4), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(st.live, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(st.live, 0, 4*sizeof(uint32_t), ctx->stream));
     if (split) {
         HIP_TRY(ctx, hipEventRecord(ctx->evMain, ctx->stream));            // (the memsets above come first for the other streams as well)
         for (int k = 0; k < parts; ++k) {
@@ -1310,6 +1323,12 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     } else {
         hipLaunchKernelGGL(k_start, dim3(grid), dim3(256), 0, ctx->stream, s, st, pp);
     }
+    // k_tail runs the wide single-level kernels' bodies: scenes those kernels render, passes without visit counts (per-launch timing does
+    // not see it: the few thousand rays it traces are in the counters, its one launch is in none of the three kernel classes)
+    const bool tailEligible = ctx->tailOpt && !flat && !ctx->haveInstances && wideClosest(ctx) && wideShadowRays(ctx) && ctx->decoupleOpt && !ctx->haveForward &&
+                              !ctx->haveMeshLight && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder && !count && !st.records &&
+                              st.slots_per_block <= PT_MAX_SLOTS_PER_BLOCK;
+    const uint64_t tailThreshold = uint64_t(std::max<long long>(ctx->tailThreshold, 0));
     uint32_t iterTag = 1;                        // k_start publishes tag 1 when it queued anything
     bool first = true;
     int roundIters = checkInterval;              // launches of the wavefront loop between two host checks
@@ -1415,7 +1434,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             }
             if (ctx->abortRequested.load(std::memory_order_acquire))
                 HIP_TRY(ctx, hipMemsetAsync(ctx->abortFlagDev, 0xFF, sizeof(uint32_t), ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->hostLive, st.live, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            if (tailEligible) hipLaunchKernelGGL(k_live_slots, dim3(1), dim3(256), 0, ctx->stream, st, uint32_t(grid));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->hostLive, st.live, 2*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (timing && !first) {
                 double *acc[3] = {&ctx->counters.ms_trace_closest, &ctx->counters.ms_shade, &ctx->counters.ms_trace_shadow};
@@ -1434,6 +1454,36 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             }
             if (ctx->hostLive[0] != iterTag)
                 break;                           // the last iteration left every extension queue empty
+            if (tailEligible && uint64_t(ctx->hostLive[1]) <= tailThreshold) {
+                // few paths left: each part of the pool finishes in one launch of k_tail (its workgroups iterate on their own)
+                const size_t ldsTail = wideLdsBytes(ctx, 256);
+                uint32_t classes = 1u;
+                for (int c = 1; c < PT_NUM_CLASSES; ++c)
+                    if (ctx->classPresent[c]) classes |= 1u << c;
+                for (int k = 0; k < parts; ++k) {
+                    const PathState &sp = split ? stPart[k] : st;
+                    const PassParams &ppk = split ? ppPart[k] : pp;
+                    const hipStream_t stream = split ? streamOf[k] : ctx->stream;
+                    if (k) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->evMain, 0));   // (after the main stream's check above)
+                    else if (split) HIP_TRY(ctx, hipEventRecord(ctx->evMain, ctx->stream));
+#define TAIL_LAUNCH(M, S) hipLaunchKernelGGL((k_tail<M, S>), dim3(grid/parts), dim3(256), ldsTail, stream, s, sp, ppk, classes)
+                    if (pp.flags) { if (ctx->haveSolids) TAIL_LAUNCH((MASK_TAIL | FEAT_QMC), true); else TAIL_LAUNCH((MASK_TAIL | FEAT_QMC), false); }
+                    else          { if (ctx->haveSolids) TAIL_LAUNCH(MASK_TAIL, true); else TAIL_LAUNCH(MASK_TAIL, false); }
+#undef TAIL_LAUNCH
+                }
+                for (int k = 1; k < parts; ++k) {
+                    HIP_TRY(ctx, hipEventRecord(ctx->evPart[k - 1], streamOf[k]));
+                    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->evPart[k - 1], 0));
+                }
+                ctx->counters.tail_launches++;
+                if (std::getenv("TGHIP_VERBOSE")) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    std::fprintf(stderr, "[tghip]   tail kernel after %llu iterations with %u paths alive: %.2f ms\n", (unsigned long long)(iterTag - 1), ctx->hostLive[1],
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+                }
+                break;
+            }
         }
         first = false;
         roundIters = runToCompletion ? 1 : checkInterval;
