@@ -858,7 +858,8 @@ PT_DEV void auxPostLoop(const DeviceScene &s, f3 dir, bool asked, int bounce, fl
 #define FUSE_LOOP   4
 // (the kernel's body as a function of the workgroup's LDS objects: k_shade below and k_tail run it; returns whether the workgroup's
 // extension queues hold work -- the FUSE launches report it)
-template<uint32_t M, int FUSE>
+// STAGED: sg's small tables are in LDS already (k_tail stages them once for all its iterations)
+template<uint32_t M, int FUSE, bool STAGED = false>
 PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassParams &pp, int cls, BlockLds &L, unsigned char *ldsTables, unsigned short *order)
 {
     BlockCtl &ctl = st.ctl[blockIdx.x];
@@ -871,7 +872,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
     queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2, CONCURRENT);
     if (CONCURRENT && L.n == 0u)
         return false;                            // nothing of this class in the workgroup: no bitmap changes, nothing to write back
-    const DeviceScene s = stageSceneTables(sg, ldsTables);
+    const DeviceScene s = STAGED ? sg : stageSceneTables(sg, ldsTables);
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
     const bool nee = s.settings.enable_light_sampling != 0;
@@ -2338,13 +2339,14 @@ __global__ __launch_bounds__(256) void k_tail(DeviceScene s, PathState st, PassP
     __shared__ uint32_t fetchNext;
     __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
     __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
+    const DeviceScene staged = stageSceneTables(s, ldsTables);   // (for the shading steps; the traversal steps read the scene's big arrays only)
     for (;;) {
         traceClosestWideBody<false, SOLIDS, false, true>(s, st, L, fetchNext, ldsDyn);
         __syncthreads();
         for (int c = -1; c < PT_NUM_CLASSES; ++c) {          // the escaped paths, then the classes that occur in the scene (bit c of `classes`)
             if (c >= 1 && !((classes >> c) & 1u))
                 continue;
-            (void)shadeBody<M, 0>(s, st, pp, c < 0 ? CLS_MISS : c, L, ldsTables, order);
+            (void)shadeBody<M, 0, true>(staged, st, pp, c < 0 ? CLS_MISS : c, L, ldsTables, order);
             __syncthreads();
         }
         traceShadowFastBody<false, SOLIDS>(s, st, pp, L, fetchNext, ldsDyn);
