@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 6
+#define TGHIP_ABI_VERSION 7
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -239,7 +239,8 @@ typedef struct TgHipTexture {
 /* ---- camera (cameras/PinholeCamera.cpp:28-86, Camera.cpp:44-68, ReconstructionFilter) ---- */
 enum { TGHIP_FILTER_DIRAC = 0, TGHIP_FILTER_BOX = 1, TGHIP_FILTER_TABULATED = 2 };
 enum { TGHIP_CAMERA_PINHOLE = 0, TGHIP_CAMERA_THINLENS = 1 };   /* cameras/PinholeCamera.cpp, cameras/ThinlensCamera.cpp */
-enum { TGHIP_APERTURE_DISK = 0, TGHIP_APERTURE_BLADE = 1 };     /* textures/DiskTexture.cpp:78-81, textures/BladeTexture.cpp:110-130 */
+enum { TGHIP_APERTURE_DISK = 0, TGHIP_APERTURE_BLADE = 1,       /* textures/DiskTexture.cpp:78-81, textures/BladeTexture.cpp:110-130 */
+       TGHIP_APERTURE_BITMAP = 2 };                             /* textures/BitmapTexture.cpp:433-439 with the MAP_UNIFORM distribution (:400-431) */
 typedef struct TgHipCamera {
     float   pos[3];
     float   plane_dist;
@@ -250,7 +251,8 @@ typedef struct TgHipCamera {
     float   filter_width, filter_bin_size;
     float   filter_cdf[32];   /* ReconstructionFilter::_cdf (RFILTER_RESOLUTION = 31) */
     /* thin lens (cameras/ThinlensCamera.cpp:85-126); the aperture texture is only ever sampled by the forward path tracer
-     * (samplePosition, :85-97): the default disk (textures/DiskTexture.cpp:78-86) or an n-blade polygon (BladeTexture.cpp:21-31, 110-130) */
+     * (samplePosition, :85-97): the default disk (textures/DiskTexture.cpp:78-86), an n-blade polygon (BladeTexture.cpp:21-31, 110-130) or a
+     * bitmap (BitmapTexture::sample) */
     int32_t type;             /* TGHIP_CAMERA_*                                   */
     float   focus_dist, aperture_size, cat_eye;
     float   inv_xf[12];       /* rows 0..2 of Camera::_invTransform (3x4, row-major, translation in column 3) */
@@ -259,6 +261,10 @@ typedef struct TgHipCamera {
     int32_t blade_count;      /* BladeTexture::_numBlades                          */
     float   blade_angle, blade_step;   /* _angle, _bladeAngle = 2 pi / blades     */
     float   blade_edge[2];    /* _baseEdge                                         */
+    /* TGHIP_APERTURE_BITMAP: the aperture bitmap's Distribution2D (ThinlensCamera::precompute makes it samplable with MAP_UNIFORM,
+     * cameras/ThinlensCamera.cpp:27-35): its size and the float offset of its tables in dist[], laid out like TgHipTexture::dist_offset's */
+    int32_t  aperture_w, aperture_h;
+    uint32_t aperture_dist;
 } TgHipCamera;
 
 /* ---- integrator settings (TraceSettings.hpp:23-39, PathTracerSettings.hpp:25-43) -------- */

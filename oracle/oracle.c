@@ -2609,6 +2609,20 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
             float lx = (1.0f + cam->blade_edge[0])*beta + (1.0f - alpha - beta), ly = cam->blade_edge[1]*beta;
             su = (lx*cosPhi - ly*sinPhi)*0.5f + 0.5f;
             sv = (ly*cosPhi + lx*sinPhi)*0.5f + 0.5f;
+        } else if (cam->aperture_type == TGHIP_APERTURE_BITMAP) {
+            /* BitmapTexture::sample(MAP_UNIFORM, lensUv) (textures/BitmapTexture.cpp:433-439) on the aperture's own distribution
+             * (ThinlensCamera::precompute, cameras/ThinlensCamera.cpp:27-35) */
+            Dist2D ad;
+            ad.w = cam->aperture_w; ad.h = cam->aperture_h;
+            ad.mpdf = s->dist + cam->aperture_dist;
+            ad.mcdf = ad.mpdf + ad.h;
+            ad.pdf = ad.mcdf + ad.h + 1;
+            ad.cdf = ad.pdf + (size_t)ad.w*ad.h;
+            int row, column;
+            float nu = l0, nv = l1;
+            dist_warp(&ad, &nu, &nv, &row, &column);
+            su = (nu + column)/ad.w;
+            sv = 1.0f - (nv + row)/ad.h;
         } else {
             float phi = l0*O_TWO_PI, r = sqrtf(l1);
             su = cosf(phi)*r*0.5f + 0.5f; sv = sinf(phi)*r*0.5f + 0.5f;

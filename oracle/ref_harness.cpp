@@ -54,6 +54,8 @@
 #include "sampling/SobolPathSampler.hpp"
 #include "integrators/path_tracer/PathTraceIntegrator.hpp"
 #include "primitives/Instance.hpp"
+#include "textures/BitmapTexture.hpp"
+#include "cameras/ThinlensCamera.hpp"
 #undef private
 #undef protected
 #undef class
@@ -185,6 +187,15 @@ static bool loadScene(const char *path, uint32 seed, Loaded &out)
             if (Instance *inst = dynamic_cast<Instance *>(p.get()))
                 for (std::shared_ptr<Primitive> &m : inst->_master)
                     m->loadResources();
+        // A thin-lens camera makes its aperture samplable inside fromJson (ThinlensCamera::precompute, cameras/ThinlensCamera.cpp:27-35) --
+        // for a bitmap aperture that is before Scene::loadResources has read the image, so the Distribution2D is built over 0 x 0 texels and
+        // the unmodified `tungsten` dies with SIGSEGV at the first lens sample.  Build it again now that the texels exist, as a program
+        // that assembles the camera in memory after loading the bitmap gets it.
+        if (ThinlensCamera *tl = dynamic_cast<ThinlensCamera *>(out.scene->camera().get()))
+            if (BitmapTexture *bmp = dynamic_cast<BitmapTexture *>(tl->_aperture.get())) {
+                bmp->_distribution[MAP_UNIFORM].reset();
+                tl->precompute();
+            }
         out.ts.reset(out.scene->makeTraceable(seed));
     } catch (const std::exception &e) {
         std::fprintf(stderr, "ref_harness: %s\n", e.what());

@@ -486,6 +486,23 @@ def _thinlens_blade(blades, angle=None):
     return edit
 
 
+def cornell_thinlens_bitmap(tmpdir, **kw):
+    """Thin-lens camera whose aperture is a bitmap (cameras/ThinlensCamera.cpp:62-63 + BitmapTexture::sample with the MAP_UNIFORM
+    distribution): a 24 x 20 grey-scale .png of a ring with a bright notch, written next to the scene."""
+    import numpy as np
+    tmpdir = str(tmpdir)
+    y, x = np.mgrid[0:20, 0:24]
+    r = np.hypot((x - 11.5)/11.5, (y - 9.5)/9.5)
+    img = np.where((r < 1.0) & (r > 0.45), 90 + 6*x, 0)
+    img[2:6, 10:14] = 255
+    write_png(os.path.join(tmpdir, "aperture.png"), img, 0, filters=(0, 2), level=6)
+
+    def edit(scene):
+        scene["camera"].update(type="thinlens", focus_distance=6.0, aperture_size=0.15, cateye=0.0, aperture="aperture.png")
+    return cornell(tmpdir, **dict(kw, edit=edit))
+
+
+GOLDEN_CASES["cornell_thinlens_bitmap"] = (cornell_thinlens_bitmap, dict(resolution=(48, 27), spp=8))
 # n-blade aperture (textures/BladeTexture.cpp): the lens point is a uniform point of one of the polygon's triangles
 GOLDEN_CASES["cornell_thinlens_blade5"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_blade(5, 0.3)))
 GOLDEN_CASES["cornell_thinlens_blade6"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_thinlens_blade(6)))

@@ -63,7 +63,8 @@ class TgHipCamera(C.Structure):
                 ("res_x", i32), ("res_y", i32), ("filter_type", i32), ("filter_width", f32),
                 ("filter_bin_size", f32), ("filter_cdf", f32*32),
                 ("type", i32), ("focus_dist", f32), ("aperture_size", f32), ("cat_eye", f32), ("inv_xf", f32*12), ("medium", i32),
-                ("aperture_type", i32), ("blade_count", i32), ("blade_angle", f32), ("blade_step", f32), ("blade_edge", f32*2)]
+                ("aperture_type", i32), ("blade_count", i32), ("blade_angle", f32), ("blade_step", f32), ("blade_edge", f32*2),
+                ("aperture_w", i32), ("aperture_h", i32), ("aperture_dist", u32)]
 
 
 class TgHipSettings(C.Structure):

@@ -478,8 +478,9 @@ PT_DEV float filterSample1D(CameraRef cam, float xi)
 // l0, l1: the lens sample a thin-lens camera draws first (ThinlensCamera::samplePosition, cameras/ThinlensCamera.cpp:85-97,
 // default DiskTexture aperture); xi0, xi1: the pixel-filter sample.  False when the direction sample fails (cat-eye
 // vignetting, :119-124): PathTracer::traceSample then returns black for the sample (PathTracer.cpp:27-28).
+// `dist`: the scene's Distribution2D tables (a bitmap aperture's live there, TgHipCamera::aperture_dist)
 template<bool LENS>
-PT_DEV bool cameraRay(CameraRef cam, bool lens, uint32_t px, uint32_t py, float l0, float l1, float xi0, float xi1, f3 &o, f3 &d)
+PT_DEV bool cameraRay(CameraRef cam, bool lens, uint32_t px, uint32_t py, float l0, float l1, float xi0, float xi1, f3 &o, f3 &d, const float *dist = nullptr)
 {
     float fu = 0.0f, fv = 0.0f;
     if (cam.filter_type == TGHIP_FILTER_BOX) { fu = xi0 - 0.5f; fv = xi1 - 0.5f; }
@@ -497,6 +498,22 @@ PT_DEV bool cameraRay(CameraRef cam, bool lens, uint32_t px, uint32_t py, float 
             float lx = (1.0f + cam.blade_edge[0])*beta + (1.0f - alpha - beta), ly = cam.blade_edge[1]*beta;
             su = (lx*cosPhi - ly*sinPhi)*0.5f + 0.5f;
             sv = (ly*cosPhi + lx*sinPhi)*0.5f + 0.5f;
+        } else if (cam.aperture_type == TGHIP_APERTURE_BITMAP) {
+            // BitmapTexture::sample(MAP_UNIFORM, uv) (textures/BitmapTexture.cpp:433-439) = Distribution2D::warp (sampling/Distribution2D.hpp:68-77):
+            // the row by the second number, the column by the first, each followed by the position inside the texel
+            const int w = cam.aperture_w, h = cam.aperture_h;
+            const float *mpdf = dist + cam.aperture_dist, *mcdf = mpdf + h, *pdf = mcdf + h + 1, *cdf = pdf + (size_t)w*h;
+            int lo = 0, hi = h + 1;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (mcdf[mid] <= l1) lo = mid + 1; else hi = mid; }
+            const int row = lo - 1;
+            const float nv = fminf(fmaxf((l1 - mcdf[row])/mpdf[row], 0.0f), 1.0f);
+            const float *rowCdf = cdf + (size_t)row*(w + 1);
+            lo = 0; hi = w + 1;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (rowCdf[mid] <= l0) lo = mid + 1; else hi = mid; }
+            const int column = lo - 1;
+            const float nu = fminf(fmaxf((l0 - rowCdf[column])/pdf[(size_t)row*w + column], 0.0f), 1.0f);
+            su = (nu + (float)column)/(float)w;
+            sv = 1.0f - (nv + (float)row)/(float)h;
         } else {
             float phi = l0*PT_TWO_PI, r = sqrtf(l1);                   // SampleWarp::uniformDisk (SampleWarp.hpp:64-69)
             su = cosf(phi)*r*0.5f + 0.5f;

@@ -227,7 +227,7 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             if (lens) { l0 = rngNext1DT<EXT>(rng); l1 = rngNext1DT<EXT>(rng); }   // the lens point is sampled first
             float xi0 = rngNext1DT<EXT>(rng), xi1 = rngNext1DT<EXT>(rng);
             f3 o, d;
-            const bool cameraOk = cameraRay<EXT>(cam, lens, px, py, l0, l1, xi0, xi1, o, d);
+            const bool cameraOk = cameraRay<EXT>(cam, lens, px, py, l0, l1, xi0, xi1, o, d, s.dist);
             slotF4(st, A_RAY_O, slot) = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
             slotF4(st, A_RAY_D, slot) = mk4(d, cameraOk ? PT_INF : -1.0f);   // a failed camera sample: the ray can hit nothing ...
             slotU4(st, A_MISC, slot) = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, item);

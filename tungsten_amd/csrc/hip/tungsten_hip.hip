@@ -986,6 +986,17 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     }
     ctx->thinlens = sd->camera.type == TGHIP_CAMERA_THINLENS;
     if (sd->camera.type != TGHIP_CAMERA_PINHOLE && sd->camera.type != TGHIP_CAMERA_THINLENS) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
+    if (ctx->thinlens && sd->camera.aperture_type == TGHIP_APERTURE_BITMAP) {
+        // the aperture's Distribution2D: marginalPdf[h] marginalCdf[h + 1] pdf[w h] cdf[(w + 1) h] inside dist[]
+        const uint64_t aw = uint64_t(std::max(sd->camera.aperture_w, 0)), ah = uint64_t(std::max(sd->camera.aperture_h, 0));
+        if (aw == 0 || ah == 0 || !sd->dist || uint64_t(sd->camera.aperture_dist) + ah + ah + 1 + aw*ah + (aw + 1)*ah > sd->num_dist_floats) {
+            ctx->error = "the bitmap aperture's distribution lies outside dist[]";
+            return TGHIP_E_INVALID;
+        }
+    } else if (ctx->thinlens && sd->camera.aperture_type != TGHIP_APERTURE_DISK && sd->camera.aperture_type != TGHIP_APERTURE_BLADE) {
+        ctx->error = "unknown aperture type";
+        return TGHIP_E_UNSUPPORTED;
+    }
     for (uint32_t i = 0; i < sd->num_lights; ++i)
         if (sd->objects[sd->lights[i]].type == TGHIP_OBJ_MESH) ctx->haveMeshLight = true;
     // CDF guide tables for the samplable bitmaps (pt_scene.h: upperBoundGuided)

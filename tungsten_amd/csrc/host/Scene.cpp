@@ -223,17 +223,19 @@ void Texture::loadBitmap(const std::string &file)
     }
 }
 
-// BitmapTexture::makeSamplable(MAP_SPHERICAL) (BitmapTexture.cpp:400-431) followed by the
+// BitmapTexture::makeSamplable(MAP_SPHERICAL or MAP_UNIFORM) (BitmapTexture.cpp:400-431) followed by the
 // Distribution2D constructor (sampling/Distribution2D.hpp:18-66).  Float-for-float the same
-// operation order, so the tables (and therefore MIS weights) are bit-identical.
-void Texture::makeSamplableSpherical()
+// operation order, so the tables (and therefore MIS weights) are bit-identical.  (One set of tables per texture: the environment
+// maps ask for the spherical one, a thin-lens camera's aperture bitmap -- a texture of its own -- for the uniform one.)
+void Texture::makeSamplable(bool spherical)
 {
     if (samplable || type != Bitmap)
         return;
     std::vector<float> weights(size_t(w)*h);
     for (int y = 0, idx = 0; y < h; ++y) {
         float rowWeight = 1.0f;
-        rowWeight *= std::sin((y*PI)/h);
+        if (spherical)
+            rowWeight *= std::sin((y*PI)/h);
         for (int x = 0; x < w; ++x, ++idx) {
             float wt = rgb ? std::max(texels[idx*3], std::max(texels[idx*3 + 1], texels[idx*3 + 2])) : texels[idx];
             weights[idx] = wt*rowWeight;
@@ -1143,7 +1145,10 @@ void Camera::fromJson(const JsonValue &v, const Scene &scene)
                 bladeEdge[0] = -sinAngle*2.0f*k;
                 bladeEdge[1] = cosAngle*2.0f*k;
             } else if (!ap.isObject() || apType != "disk") {
-                throw JsonLoadException("thinlens apertures other than the 'disk' and 'blade' textures are outside the path_tracer_hip hot-path scope");
+                // ThinlensCamera::fromJson: scene.fetchTexture(aperture, TexelConversion::REQUEST_AVERAGE) (cameras/ThinlensCamera.cpp:62-63)
+                apertureTex = scene.fetchTexture(ap, false);
+                if (!apertureTex || apertureTex->type != Texture::Bitmap)
+                    throw JsonLoadException("thinlens apertures other than the 'disk' and 'blade' textures and bitmaps are outside the path_tracer_hip hot-path scope");
             }
         }
     } else if (type != "pinhole") {

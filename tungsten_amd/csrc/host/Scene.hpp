@@ -44,7 +44,8 @@ struct Texture
     Vec3f average() const;
     Vec3f maximum() const;
     void scaleValues(float f);
-    void makeSamplableSpherical();             // BitmapTexture.cpp:400-431
+    void makeSamplable(bool spherical);        // BitmapTexture::makeSamplable(MAP_SPHERICAL / MAP_UNIFORM), BitmapTexture.cpp:400-431
+    void makeSamplableSpherical() { makeSamplable(true); }
     void loadBitmap(const std::string &file);  // BitmapTexture::loadResources + init
 };
 
@@ -154,6 +155,9 @@ struct Camera
     float focusDist = 1.0f, apertureSize = 0.001f, catEye = 0.0f;
     // "aperture": {"type": "blade", "blades": n, "angle": a} (textures/BladeTexture.cpp:14-41); 0 blades = the disk
     int blades = 0;
+    // "aperture": a bitmap (a file name or {"type": "bitmap", ...}; scalar request REQUEST_AVERAGE, ThinlensCamera.cpp:62-63): the lens
+    // point is drawn from the image (BitmapTexture::sample with the MAP_UNIFORM distribution)
+    std::shared_ptr<Texture> apertureTex;
     float bladeAngle = 0.0f, bladeStep = 0.0f;
     float bladeEdge[2] = {0.0f, 0.0f};
     Mat4f invTransform;
@@ -199,6 +203,7 @@ struct IntegratorSettings // TraceSettings.hpp:15-39 + PathTracerSettings.hpp:17
 
 class Scene
 {
+    friend struct Camera;                      // (a thin-lens camera's bitmap aperture goes through fetchTexture)
     std::string _srcDir;
     mutable std::vector<std::pair<std::string, std::shared_ptr<Texture>>> _textureCache;
 

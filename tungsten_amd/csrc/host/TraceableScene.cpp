@@ -509,6 +509,19 @@ void TraceableScene::flatten()
     c.aperture_size = cam.apertureSize;
     c.cat_eye = cam.catEye;
     c.aperture_type = cam.blades > 0 ? TGHIP_APERTURE_BLADE : TGHIP_APERTURE_DISK;
+    if (cam.apertureTex) {
+        // ThinlensCamera::precompute: _aperture->makeSamplable(MAP_UNIFORM) (cameras/ThinlensCamera.cpp:27-35); the forward path tracer
+        // only ever samples the aperture, so its Distribution2D is all the device gets
+        Texture &t = *cam.apertureTex;
+        t.makeSamplable(false);
+        c.aperture_type = TGHIP_APERTURE_BITMAP;
+        c.aperture_w = t.w; c.aperture_h = t.h;
+        c.aperture_dist = uint32_t(_dist.size());
+        _dist.insert(_dist.end(), t.marginalPdf.begin(), t.marginalPdf.end());
+        _dist.insert(_dist.end(), t.marginalCdf.begin(), t.marginalCdf.end());
+        _dist.insert(_dist.end(), t.pdf.begin(), t.pdf.end());
+        _dist.insert(_dist.end(), t.cdf.begin(), t.cdf.end());
+    }
     c.blade_count = cam.blades;
     c.blade_angle = cam.bladeAngle; c.blade_step = cam.bladeStep;
     c.blade_edge[0] = cam.bladeEdge[0]; c.blade_edge[1] = cam.bladeEdge[1];
