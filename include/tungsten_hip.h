@@ -148,6 +148,9 @@ enum { TGHIP_OBJ_MESH = 0, TGHIP_OBJ_QUAD = 1, TGHIP_OBJ_CUBE = 2, TGHIP_OBJ_SPH
        TGHIP_OBJ_CYLINDER = 9 };              /* primitives/Cylinder.cpp:305-319: pos = _pos, rot = _rot, normal = _axis, scale = {_radius, _halfHeight, _capped ? 1 : 0} */                 /* Dirac point light (primitives/Point.cpp): pos = _pos, scale = _power as Point.cpp:186 leaves it; never hit, sampled without random numbers */
 #define TGHIP_OBJF_SMOOTH   1u   /* mesh "smooth": Ns interpolated (TriangleMesh.cpp:344-355) */
 #define TGHIP_OBJF_SAMPLE   2u   /* infinite_sphere "sample" (InfiniteSphere.cpp:117-122)      */
+#define TGHIP_OBJF_SKYDOME  4u   /* a TGHIP_OBJ_INFINITE_SPHERE that is the `skydome` primitive (primitives/Skydome.cpp): its emission is the
+                                    512 x 256 sky image baked at prepareForRender (:279-306); directions map to the image without the
+                                    primitive's rotation (:41-60) and chooseLight weighs it with 4 pi instead of 2 pi (:240-243) */
 
 typedef struct TgHipObject {
     int32_t  type;            /* TGHIP_OBJ_*                                      */

@@ -30,6 +30,7 @@
 
 #define O_PI          3.1415926536f
 #define O_TWO_PI      (O_PI*2.0f)
+#define O_FOUR_PI     (O_PI*4.0f)
 #define O_INV_PI      (1.0f/O_PI)
 #define O_INV_TWO_PI  (0.5f*O_INV_PI)
 #define O_INV_FOUR_PI (0.25f*O_INV_PI)
@@ -1652,7 +1653,8 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit
 /* InfiniteSphere::directionToUV (InfiniteSphere.cpp:27-39) */
 static void inf_directionToUV(const TgHipObject *o, v3 wi, float *u, float *v, float *sinTheta)
 {
-    v3 wLocal = mat3_tmul(o->rot, wi);
+    /* Skydome::directionToUV (Skydome.cpp:41-50) is the same map without the primitive's rotation */
+    v3 wLocal = (o->flags & TGHIP_OBJF_SKYDOME) ? wi : mat3_tmul(o->rot, wi);
     if (sinTheta) *sinTheta = sqrtf(fmaxf(1.0f - wLocal.y*wLocal.y, 0.0f));
     *u = atan2f(wLocal.z, wLocal.x)*O_INV_TWO_PI + 0.5f;
     *v = acosf(-wLocal.y)*O_INV_PI;
@@ -1662,7 +1664,8 @@ static v3 inf_uvToDirection(const TgHipObject *o, float u, float v, float *sinTh
     float phi = (u - 0.5f)*O_TWO_PI;
     float theta = v*O_PI;
     *sinTheta = sinf(theta);
-    return mat3_mul(o->rot, V(cosf(phi)**sinTheta, -cosf(theta), sinf(phi)**sinTheta));
+    v3 wLocal = V(cosf(phi)**sinTheta, -cosf(theta), sinf(phi)**sinTheta);
+    return (o->flags & TGHIP_OBJF_SKYDOME) ? wLocal : mat3_mul(o->rot, wLocal);          /* Skydome.cpp:51-61 */
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -2421,6 +2424,8 @@ static float light_approximateRadiance(const TgHipSceneDesc *s, int objIdx, v3 p
         return O_TWO_PI*(1.0f - cosTheta)*vmax3(ld3(s->textures[o->emission].avg));
     } else {
         if (o->emission < 0 || !(o->flags & TGHIP_OBJF_SAMPLE)) return 0.0f;
+        if (o->flags & TGHIP_OBJF_SKYDOME)              /* Skydome::approximateRadiance (Skydome.cpp:240-243) */
+            return O_FOUR_PI*vmax3(ld3(s->textures[o->emission].avg));
         return O_TWO_PI*vmax3(ld3(s->textures[o->emission].avg));
     }
 }

@@ -30,6 +30,7 @@
 #include "primitives/Sphere.hpp"
 #include "primitives/TriangleMesh.hpp"
 #include "primitives/InfiniteSphere.hpp"
+#include "primitives/Skydome.hpp"
 #include "bsdfs/Bsdf.hpp"
 #include "bsdfs/LambertBsdf.hpp"
 #include "bsdfs/NullBsdf.hpp"
@@ -331,8 +332,14 @@ void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, cons
         o.type = TGHIP_OBJ_INFINITE_SPHERE;
         o.flags = s->_doSample ? TGHIP_OBJF_SAMPLE : 0u;
         copyRot(o.rot, s->_rotTransform);
+    } else if (const Skydome *sd = dynamic_cast<const Skydome *>(&p)) {
+        // Skydome.cpp:279-306: by now Tungsten has baked the sky into _sky (= _emission); the device treats the dome as an infinite sphere
+        // that maps directions to that image unrotated and weighs 4 pi in chooseLight (TGHIP_OBJF_SKYDOME)
+        o.type = TGHIP_OBJ_INFINITE_SPHERE;
+        o.flags = (sd->_doSample ? TGHIP_OBJF_SAMPLE : 0u) | TGHIP_OBJF_SKYDOME;
+        copyRot(o.rot, Mat4f());
     } else {
-        refuse("a primitive that is not a quad, cube, sphere, triangle mesh or infinite sphere");
+        refuse("a primitive that is not a quad, cube, sphere, triangle mesh, infinite sphere or skydome");
     }
 
     if (emissive) {

@@ -20,6 +20,8 @@
 //       final image.
 //   ref_harness sobol-table <out.bin>
 //       the 1024 x 52 generator matrices of the Sobol' sequence (sobol::Matrices::matrices) as u32.
+//   ref_harness sky-image <scene.json> <out.bin>
+//       the sky image the scene's skydome baked (512 x 256 x 3 float32).
 //
 // Nothing here is copied from the reference; it only calls its public classes.
 #include <atomic>
@@ -56,6 +58,7 @@
 #include "primitives/Instance.hpp"
 #include "textures/BitmapTexture.hpp"
 #include "cameras/ThinlensCamera.hpp"
+#include "primitives/Skydome.hpp"
 #undef private
 #undef protected
 #undef class
@@ -387,6 +390,26 @@ static void pv(FILE *f, const char *name, const Vec3f &v, bool comma = true)
     std::fprintf(f, "\"%s\": [%.9g, %.9g, %.9g]%s", name, v.x(), v.y(), v.z(), comma ? ", " : "");
 }
 
+// ref_harness sky-image <scene.json> <out.bin>: the 512 x 256 RGB image the scene's first skydome baked at prepareForRender
+// (Skydome::_sky, primitives/Skydome.cpp:279-306) as float32 -- what tungsten_amd/csrc/host/SkyModel.cpp restates
+static int cmdSkyImage(int argc, char **argv)
+{
+    if (argc < 4) return 2;
+    ThreadUtils::startThreads(1);
+    Loaded l;
+    if (!loadScene(argv[2], 0xBA5EBA11u, l)) return 1;
+    for (const std::shared_ptr<Primitive> &p : l.scene->primitives())
+        if (Skydome *sky = dynamic_cast<Skydome *>(p.get())) {
+            const BitmapTexture &t = *sky->_sky;
+            std::ofstream out(argv[3], std::ios::binary);
+            out.write(reinterpret_cast<const char *>(t._texels), size_t(t._w)*t._h*3*sizeof(float));
+            std::printf("ref_harness: sky image %d x %d\n", t._w, t._h);
+            return out ? 0 : 1;
+        }
+    std::fprintf(stderr, "ref_harness: the scene has no skydome\n");
+    return 1;
+}
+
 static int cmdUnits(int argc, char **argv)
 {
     if (argc < 4) return 2;
@@ -575,6 +598,7 @@ int main(int argc, char **argv)
     else if (cmd == "integrate") rc = cmdIntegrate(argc, argv);
     else if (cmd == "sobol-table") rc = cmdSobolTable(argc, argv);
     else if (cmd == "draws") rc = cmdDraws(argc, argv);
+    else if (cmd == "sky-image") rc = cmdSkyImage(argc, argv);
     if (rc == 2) std::fprintf(stderr, "ref_harness: bad arguments\n");
     return rc;
 }

@@ -594,6 +594,27 @@ def _sun_and_sky(scene):
          "transform": {"rotation": [25, 0, -20]}}]
 
 
+def _skydome(sample=True, **params):
+    """Roofless Cornell box under the procedural sky (primitives/Skydome.cpp: the Hosek-Wilkie model baked into a 512 x 256 image at
+    prepareForRender, then an image-based infinite light), the star 35 degrees off the zenith, a mirror box to see it in, and the dimmed
+    quad light lying on the floor so that chooseLight weighs two lights."""
+    def edit(scene):
+        scene["primitives"] = [p for p in scene["primitives"] if p["name"] != "ceiling"]
+        for p in scene["primitives"]:
+            if p["name"] == "light":
+                p["emission"] = [3, 2, 1]
+                p["transform"] = {"position": [0.45, 0.01, 0.55], "scale": [0.3, 0.1, 0.2], "rotation": [0, 30, 0]}
+        for i, b in enumerate(scene["bsdfs"]):
+            if b["name"] == "tallBox":
+                scene["bsdfs"][i] = {"name": "tallBox", "type": "mirror", "albedo": [0.9, 0.9, 0.95]}
+        scene["primitives"].append(dict({"name": "sky", "type": "skydome", "sample": sample, "transform": {"rotation": [30, 10, -20]}}, **params))
+    return edit
+
+
+GOLDEN_CASES["cornell_skydome"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_skydome()))
+GOLDEN_CASES["cornell_skydome_alien"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_skydome(sample=False, temperature=3400.0, turbidity=6.5, intensity=3.0)))
+
+
 def _point_lights(scene):
     """Two Dirac point lights (primitives/Point.cpp; one given by emission, one by power) next to the dimmed quad light:
     sampled without random numbers and without MIS, never hit by a ray (TraceBase.cpp:157-158, 281-282, 396-397)."""

@@ -85,7 +85,11 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
         assert 0 <= int(c.closest_rays) - int(oc.closest_rays) <= oc.samples
     else:
         assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 0.01*oc.closest_rays
-    if "mesh" not in name or name == "mesh1m":
+    if name == "cornell_skydome":
+        # the sky image is black below the horizon; the reference tests visibility before it looks the emission up (TraceBase.cpp:163-173),
+        # the device looks the emission up first and queues no shadow ray for a black one: fewer rays, the same radiance
+        assert 0 <= int(oc.shadow_rays) - int(c.shadow_rays) <= 0.4*oc.shadow_rays
+    elif "mesh" not in name or name == "mesh1m":
         # (a sampled mesh emitter's visibility query doubles as its light.intersect, so the device traces every such ray,
         # while the oracle only counts the ones whose light.intersect succeeded)
         assert abs(int(c.shadow_rays) - int(oc.shadow_rays)) <= 0.01*oc.shadow_rays + 2

@@ -419,3 +419,47 @@ def test_pfm_textures(tmp_path):
         got = _bitmap_of(flat.desc, w, h)
         flat.close()
         assert (got == expect).all(), name
+
+
+@pytest.mark.parametrize("case", ["cornell_skydome", "cornell_skydome_alien"])
+def test_skydome_image_is_the_image_the_reference_bakes(case, tmp_path):
+    """The `skydome` primitive: the host's restatement of the Hosek-Wilkie sky model and of Skydome::prepareForRender
+    (tungsten_amd/csrc/host/SkyModel.cpp over tungsten_amd/data/skydome_tables.bin) bakes the 512 x 256 image the reference bakes for
+    the same transform / temperature / turbidity / intensity -- bit for bit on every 4th row and 8th column (tests/golden/*_sky.npz,
+    dumped from the reference's own Skydome by `ref_harness sky-image`), with the same sum over all texels -- and flattens it to an
+    unrotated, sampled (or not) infinite sphere with the spherical Distribution2D."""
+    mk, kw = scenes.GOLDEN_CASES[case]
+    path = mk(tmp_path, **kw)
+    gold = np.load(os.path.join(scenes.GOLDEN, case + "_sky.npz"))
+    flat = tg.FlattenedScene(path)
+    d = flat.desc.contents
+    sky = [d.objects[i] for i in range(d.num_objects) if d.objects[i].flags & 4]
+    assert len(sky) == 1 and sky[0].type == 4                                         # TGHIP_OBJF_SKYDOME on a TGHIP_OBJ_INFINITE_SPHERE
+    t = d.textures[sky[0].emission]
+    assert (t.w, t.h) == (512, 256) and t.flags & 1 and not t.flags & 2                # interpolated, not clamped
+    tex = np.ctypeslib.as_array(d.texels, (d.num_texel_floats,))[t.texel_offset:t.texel_offset + 512*256*3].reshape(256, 512, 3)
+    assert (tex[::4, ::8] == gold["sub"]).all()
+    assert float(tex.astype(np.float64).sum()) == float(gold["total"])
+    assert (tex[130:] == 0).all() and (tex[128] == tex[127]).all() and (tex[129] == tex[127]).all()   # Skydome.cpp:302-303
+    sampled = case == "cornell_skydome"
+    assert bool(sky[0].flags & 2) == sampled and (t.dist_offset >= 0) == sampled and (sky[0].light >= 0) == sampled
+    flat.close()
+
+
+def test_bitmap_aperture_distribution(tmp_path):
+    """A thin-lens camera's bitmap aperture arrives as the Distribution2D of BitmapTexture::makeSamplable(MAP_UNIFORM) over the image's
+    grey levels (no sin(theta) row weights; the 3 x 3 dilation of BitmapTexture.cpp:413-428): marginals and rows are normalised, texels
+    next to the ring carry its weight, the far corners none."""
+    mk, kw = scenes.GOLDEN_CASES["cornell_thinlens_bitmap"]
+    flat = tg.FlattenedScene(mk(tmp_path, **kw))
+    d = flat.desc.contents
+    cam = d.camera
+    assert cam.type == 1 and cam.aperture_type == 2 and (cam.aperture_w, cam.aperture_h) == (24, 20)
+    dist = np.ctypeslib.as_array(d.dist, (d.num_dist_floats,))[cam.aperture_dist:]
+    w, h = 24, 20
+    mpdf, mcdf, pdf, cdf = dist[:h], dist[h:2*h + 1], dist[2*h + 1:2*h + 1 + w*h].reshape(h, w), dist[2*h + 1 + w*h:2*h + 1 + w*h + (w + 1)*h].reshape(h, w + 1)
+    assert abs(mcdf[-1] - 1.0) < 1e-6 and mcdf[0] == 0 and (np.diff(mcdf) >= 0).all()
+    assert np.allclose(cdf[:, -1], 1.0, atol=1e-6) and (cdf[:, 0] == 0).all()
+    assert np.allclose(mpdf.sum(), 1.0, atol=1e-5) and np.allclose(pdf.sum(axis=1), 1.0, atol=1e-5)
+    assert pdf[10, 12] == 0 and pdf[3, 11] > pdf[10, 3] > 0        # the hole of the ring; the notch is the brightest spot
+    flat.close()

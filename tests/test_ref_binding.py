@@ -84,6 +84,8 @@ CASES = {
     "materialtest": lambda tmp: scenes.materialtest(tmp, resolution=(160, 90), spp=4),
     "zoo_a": lambda tmp: scenes.GOLDEN_CASES["zoo_a"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_a"][1], resolution=(96, 54), spp=2)),
     "zoo_b": lambda tmp: scenes.GOLDEN_CASES["zoo_b"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_b"][1], resolution=(96, 54), spp=2)),
+    # the procedural sky: the reference-side flattener hands over the image Tungsten's own Skydome baked, the own loader bakes it itself
+    "skydome": lambda tmp: scenes.GOLDEN_CASES["cornell_skydome"][0](tmp, **dict(scenes.GOLDEN_CASES["cornell_skydome"][1], resolution=(96, 54), spp=2)),
 }
 
 
@@ -106,7 +108,7 @@ def test_reference_side_flattener_builds_the_scene_the_own_loader_builds(case, t
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["cornell", "cornell_as_shipped_sampler", "materialtest"])
+@pytest.mark.parametrize("case", ["cornell", "cornell_as_shipped_sampler", "materialtest", "skydome"])
 def test_reference_program_with_the_plugin_writes_the_image_of_the_own_host(case, tmp_path):
     """tungsten (the reference's program) with "type": "path_tracer_hip" against tungsten_hip (this repository's CLI) on the same
     scene, seed and spp: the .pfm files are identical bit for bit."""

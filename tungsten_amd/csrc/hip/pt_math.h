@@ -14,6 +14,7 @@
 
 #define PT_PI          3.1415926536f            /* math/Angle.hpp:8 */
 #define PT_TWO_PI      (PT_PI*2.0f)
+#define PT_FOUR_PI     (PT_PI*4.0f)
 #define PT_INV_PI      (1.0f/PT_PI)
 #define PT_INV_TWO_PI  (0.5f*PT_INV_PI)
 #define PT_INV_FOUR_PI (0.25f*PT_INV_PI)

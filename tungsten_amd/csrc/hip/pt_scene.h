@@ -1340,7 +1340,9 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
 // ---------------------------------------------------------------------------------------------
 PT_DEV void infDirectionToUV(const TgHipObject &o, f3 wi, float &u, float &v, float &sinTheta)
 {
-    f3 wLocal = mat3TMul(o.rot, wi);
+    // (a skydome maps world directions to its image as they are, Skydome.cpp:41-50; not through an identity matrix: -0 + 0 = +0 would move
+    // atan2f's branch cut)
+    f3 wLocal = (o.flags & TGHIP_OBJF_SKYDOME) ? wi : mat3TMul(o.rot, wi);
     sinTheta = sqrtf(fmaxf(1.0f - wLocal.y*wLocal.y, 0.0f));
     u = atan2f(wLocal.z, wLocal.x)*PT_INV_TWO_PI + 0.5f;
     v = acosfExact(-wLocal.y)*PT_INV_PI;
@@ -1350,7 +1352,8 @@ PT_DEV f3 infUvToDirection(const TgHipObject &o, float u, float v, float &sinThe
     float phi = (u - 0.5f)*PT_TWO_PI;
     float theta = v*PT_PI;
     sinTheta = sinf(theta);
-    return mat3Mul(o.rot, mk3(cosf(phi)*sinTheta, -cosf(theta), sinf(phi)*sinTheta));
+    const f3 wLocal = mk3(cosf(phi)*sinTheta, -cosf(theta), sinf(phi)*sinTheta);
+    return (o.flags & TGHIP_OBJF_SKYDOME) ? wLocal : mat3Mul(o.rot, wLocal);     // (Skydome.cpp:51-61)
 }
 
 struct LightHit { float t, u, v; bool backSide; f3 n; float sinTheta; };   /* n: surface normal at the hit (cube lights); sinTheta: infinite sphere (below) */
@@ -1672,6 +1675,8 @@ PT_DEV float lightApproximateRadiance(const DeviceScene &s, int objIdx, f3 p)
     if (o.emission < 0 || !(o.flags & TGHIP_OBJF_SAMPLE)) return 0.0f;
     if (o.type == TGHIP_OBJ_INFINITE_SPHERE_CAP)               /* InfiniteSphereCap.cpp:220-225 */
         return PT_TWO_PI*(1.0f - o.scale[0])*max3(ld3(s.textures[o.emission].avg));
+    if (o.flags & TGHIP_OBJF_SKYDOME)                          /* Skydome::approximateRadiance (Skydome.cpp:240-243) */
+        return PT_FOUR_PI*max3(ld3(s.textures[o.emission].avg));
     return PT_TWO_PI*max3(ld3(s.textures[o.emission].avg));
 }
 

@@ -1,4 +1,5 @@
 #include "Scene.hpp"
+#include "SkyModel.hpp"
 #include "ImageIO.hpp"
 
 #include <thread>
@@ -201,8 +202,12 @@ void Texture::loadBitmap(const std::string &file)
             texels[i] = (rgbTexels[i*3] + rgbTexels[i*3 + 1] + rgbTexels[i*3 + 2])/3.0f;
     }
     valid = true;
+    finishBitmap();
+}
 
-    // BitmapTexture::init (BitmapTexture.cpp:175-209): min/max/avg, avg accumulated as texel/(w*h)
+// BitmapTexture::init (BitmapTexture.cpp:175-209): min/max/avg, avg accumulated as texel/(w*h)
+void Texture::finishBitmap()
+{
     if (rgb) {
         texMin = texMax = Vec3f(texels[0], texels[1], texels[2]);
         texAvg = Vec3f(0.0f);
@@ -713,6 +718,7 @@ float Primitive::powerToRadianceFactor() const
 {
     switch (type) {
     case InfiniteSphere: return INV_FOUR_PI;           // InfiniteSphere.cpp:59-62
+    case Skydome:        return INV_FOUR_PI;           // Skydome.cpp:63-66
     case InfiniteSphereCap: return INV_TWO_PI/(1.0f - scale[0]);   // InfiniteSphereCap.cpp:36-39
     case Point:          return INV_FOUR_PI;           // Point.cpp:25-28
     default:             return INV_PI*invArea;        // Quad.cpp:50-53, Cube.cpp, TriangleMesh.cpp:108-111
@@ -767,6 +773,14 @@ std::shared_ptr<Primitive> Scene::instantiatePrimitive(const JsonValue &v) const
     } else if (type == "infinite_sphere") {
         p->type = Primitive::InfiniteSphere;
         v.getField("sample", p->doSample);
+    } else if (type == "skydome") {                   // Skydome::fromJson (Skydome.cpp:68-77)
+        p->type = Primitive::Skydome;
+        v.getField("temperature", p->skyTemperature);
+        v.getField("turbidity", p->skyTurbidity);
+        v.getField("intensity", p->skyIntensity);
+        v.getField("sample", p->doSample);
+        if (p->power)
+            throw JsonLoadException("a skydome with 'power' is outside the path_tracer_hip hot-path scope");
     } else if (type == "point") {                     // Point::fromJson (Point.cpp:30-33)
         p->type = Primitive::Point;
     } else if (type == "infinite_sphere_cap") {      // InfiniteSphereCap::fromJson (InfiniteSphereCap.cpp:41-50)
@@ -1002,6 +1016,19 @@ void Primitive::prepareForRender()
     } case InfiniteSphere: { // InfiniteSphere.cpp:280-286
         rot = transform.extractRotation();
         invRot = rot.transpose();
+        break;
+    } case Skydome: {        // Skydome.cpp:279-306: the sky image, baked for the direction the transform turns "up" into
+        rot = Mat4f();                                   // directions map to the image unrotated (Skydome.cpp:41-60)
+        invRot = Mat4f();
+        const Vec3f sun = transform.transformVector(Vec3f(0.0f, 1.0f, 0.0f));
+        const float sunDir[3] = {sun.x(), sun.y(), sun.z()};
+        auto sky = std::make_shared<Texture>();
+        sky->type = Texture::Bitmap;
+        sky->w = SkydomeSizeX; sky->h = SkydomeSizeY;
+        sky->rgb = true; sky->linear = true; sky->clamp = false; sky->valid = true;   // BitmapTexture(img, 512, 256, RGB_HDR, true, false)
+        sky->texels = bakeSkydomeImage(sunDir, skyTemperature, skyTurbidity, skyIntensity);
+        sky->finishBitmap();
+        emission = sky;
         break;
     } case Point: {           // Point.cpp:183-189
         pos = transform.translation();

@@ -47,6 +47,7 @@ struct Texture
     void makeSamplable(bool spherical);        // BitmapTexture::makeSamplable(MAP_SPHERICAL / MAP_UNIFORM), BitmapTexture.cpp:400-431
     void makeSamplableSpherical() { makeSamplable(true); }
     void loadBitmap(const std::string &file);  // BitmapTexture::loadResources + init
+    void finishBitmap();                       // BitmapTexture::init's statistics over `texels` (w, h, rgb set)
 };
 
 // ---- BSDFs (src/core/bsdfs) ------------------------------------------------------------
@@ -98,7 +99,8 @@ struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp
 
 struct Primitive
 {
-    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6, InfiniteSphereCap = 7, Point = 8, Cylinder = 9 };
+    // (the values of the first ten are TGHIP_OBJ_*; a Skydome is flattened to TGHIP_OBJ_INFINITE_SPHERE | TGHIP_OBJF_SKYDOME)
+    enum Type { Mesh = 0, Quad = 1, Cube = 2, Sphere = 3, InfiniteSphere = 4, Instances = 5, Disk = 6, InfiniteSphereCap = 7, Point = 8, Cylinder = 9, Skydome = 10 };
     std::string name;
     Type type = Quad;
     Mat4f transform;
@@ -112,6 +114,9 @@ struct Primitive
     std::vector<MeshTriangle> tris;
     // infinite sphere
     bool doSample = true;
+    // skydome (primitives/Skydome.cpp:18-26, 68-77): the star's temperature in kelvin, the atmosphere's turbidity, the star's brightness
+    // relative to the sun ("gamma_scale" is read and never used by the reference: fillImage is called with 1, :298)
+    float skyTemperature = 5777.0f, skyTurbidity = 3.0f, skyIntensity = 2.0f;
     bool capped = true;         // cylinder (primitives/Cylinder.hpp)
     // disk (primitives/Disk.hpp): emission confined to a cone around the normal
     float coneAngle = 90.0f;
@@ -131,10 +136,10 @@ struct Primitive
     float area = 0.0f, invArea = 0.0f;
     Box3f bounds;
 
-    bool isInfinite() const { return type == InfiniteSphere || type == InfiniteSphereCap; }
+    bool isInfinite() const { return type == InfiniteSphere || type == InfiniteSphereCap || type == Skydome; }
     bool isDirac() const { return type == Point || (type == Mesh && (verts.empty() || tris.empty())); }   // Point.cpp:156-159, TriangleMesh.cpp
     bool isEmissive() const;       // Primitive.hpp:111-115
-    bool isSamplable() const { return (type == InfiniteSphere || type == InfiniteSphereCap) ? doSample : type != Instances; }   // Instance.cpp:357-360
+    bool isSamplable() const { return isInfinite() ? doSample : type != Instances; }   // Instance.cpp:357-360
     float powerToRadianceFactor() const;
     void loadResources(const std::string &sceneDir);
     void prepareForRender();

@@ -224,14 +224,14 @@ void TraceableScene::flatten()
         Primitive &p = *_allPrims[pi];
         TgHipObject o;
         std::memset(&o, 0, sizeof(o));
-        o.type = int32_t(p.type);
+        o.type = p.type == Primitive::Skydome ? int32_t(TGHIP_OBJ_INFINITE_SPHERE) : int32_t(p.type);
         o.bsdf = p.bsdfs.empty() ? -1 : addBsdf(p.bsdfs[0]);
         for (size_t i = 1; i < p.bsdfs.size(); ++i) addBsdf(p.bsdfs[i]);
         bool emissive = p.isEmissive();
         o.emission = emissive ? addTexture(p.emission) : -1;
         o.light = -1;
         o.first_light_tri = -1;
-        o.flags = (p.smooth ? TGHIP_OBJF_SMOOTH : 0) | (p.doSample ? TGHIP_OBJF_SAMPLE : 0);
+        o.flags = (p.smooth ? TGHIP_OBJF_SMOOTH : 0) | (p.doSample ? TGHIP_OBJF_SAMPLE : 0) | (p.type == Primitive::Skydome ? TGHIP_OBJF_SKYDOME : 0);
         o.area = p.area; o.inv_area = p.invArea;
         copy3(o.base, p.base); copy3(o.edge0, p.edge0); copy3(o.edge1, p.edge1); copy3(o.normal, p.normal);
         o.inv_uv_sq[0] = p.invUvSq[0]; o.inv_uv_sq[1] = p.invUvSq[1];
@@ -370,8 +370,8 @@ void TraceableScene::flatten()
     // lights that are sampled need their 2-D distribution (TraceBase ctor -> makeSamplable,
     // integrators/TraceBase.cpp:5-22; InfiniteSphere.cpp:124-129)
     for (int32_t li : _lights)
-        if (_allPrims[size_t(li)]->type == Primitive::InfiniteSphere)
-            addDistribution(_allPrims[size_t(li)]->emission);
+        if (_allPrims[size_t(li)]->type == Primitive::InfiniteSphere || _allPrims[size_t(li)]->type == Primitive::Skydome)
+            addDistribution(_allPrims[size_t(li)]->emission);           // (Skydome::makeSamplable, Skydome.cpp:138-143)
 
     // ---- BVH2 + the 8-wide BVH the single-level traversal kernels walk ----------------------------
     {
