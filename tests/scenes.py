@@ -373,6 +373,74 @@ def mesh1m(tmpdir, resolution=(1920, 1080), spp=512, name="mesh1m.json", n_lat=5
 
 GOLDEN_CASES["mesh1m"] = (mesh1m, dict(resolution=(48, 27), spp=4))
 
+
+def tile_terraces(tmpdir, n=24, name="terraces.json", **kw):
+    """Axis-aligned geometry on exact grid coordinates -- an n x n floor of unit tiles (two triangles each) at y = 0, a second storey of
+    every other tile at y = 2 and walls of unit quads around -- placed 4096 units from the origin: zero-thickness boxes on power-of-two
+    planes, the case in which a wide-BVH child's quantised planes coincide with its box (tests of the slack WideBvh.cpp leaves)."""
+    import numpy as np
+    tmpdir = str(tmpdir)
+    verts, tris = [], []
+
+    def quad(p, e0, e1):
+        b = len(verts)
+        for q in (p, p + e0, p + e0 + e1, p + e1):
+            verts.append(list(q) + [0.0, 1.0, 0.0, 0.0, 0.0])
+        tris.extend([[b, b + 1, b + 2, 0], [b, b + 2, b + 3, 0]])
+    base = np.array([4096.0, 0.0, 4096.0])
+    ex, ey, ez = np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), np.array([0, 0, 1.0])
+    for i in range(n):
+        for j in range(n):
+            quad(base + i*ex + j*ez, ex, ez)
+            if (i + j) % 2 == 0:
+                quad(base + 2*ey + i*ex + j*ez, ex, ez)
+    for i in range(n):
+        for k in range(3):
+            quad(base + i*ex + k*ey, ex, ey)
+            quad(base + i*ez + k*ey, ez, ey)
+            quad(base + n*ez + i*ex + k*ey, ex, ey)
+            quad(base + n*ex + i*ez + k*ey, ez, ey)
+    wo3 = os.path.join(tmpdir, "terraces_%d.wo3" % n)
+    write_wo3(wo3, np.array(verts, np.float32), np.array(tris, np.int32))
+    scene = {
+        "media": [], "bsdfs": [{"name": "grey", "type": "lambert", "albedo": 0.6}],
+        "primitives": [{"name": "Terraces", "type": "mesh", "file": os.path.basename(wo3), "smooth": False, "bsdf": "grey", "transform": {}},
+                       {"name": "Env", "type": "infinite_sphere", "sample": True, "emission": 1.0}],
+        "camera": {"tonemap": "filmic", "resolution": list(kw.get("resolution", (64, 36))), "reconstruction_filter": "tent", "type": "pinhole", "fov": 50,
+                   "transform": {"position": [4096 + n/2, 9, 4096 - n], "look_at": [4096 + n/2, 1, 4096 + n/2], "up": [0, 1, 0]}},
+        "integrator": {"type": "path_tracer", "min_bounces": 0, "max_bounces": 8, "enable_consistency_checks": False,
+                       "enable_two_sided_shading": True, "enable_light_sampling": True},
+        "renderer": {"output_file": "", "hdr_output_file": "", "overwrite_output_files": True, "adaptive_sampling": False,
+                     "stratified_sampler": False, "scene_bvh": True, "spp": kw.get("spp", 4), "spp_step": kw.get("spp", 4)},
+    }
+    path = os.path.join(tmpdir, name)
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
+
+
+def terrace_rays(n=24, count=40000, seed=3):
+    """Rays at the corners, edges and faces of tile_terraces' tiles: vertical ones through exact grid points and edge midpoints, oblique
+    ones from far outside aimed at grid points (origin 1e3 - 1e4 units away: the node-origin / ray-origin cancellation), and rays starting
+    ON a tile (distance 0 to its plane)."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    g = rs.randint(0, 2*n + 1, size=(count, 2))*0.5                     # grid points and edge midpoints
+    target = np.stack([4096.0 + g[:, 0], rs.choice([0.0, 2.0], count), 4096.0 + g[:, 1]], axis=1)
+    kind = rs.randint(0, 3, count)
+    d = rs.randn(count, 3)
+    d[:, 1] = -np.abs(d[:, 1]) - 0.05
+    d[kind == 0] = [0.0, -1.0, 0.0]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = np.where(kind == 1, 10.0**rs.uniform(3, 4, count), rs.uniform(1.0, 30.0, count))
+    o = target - d*dist[:, None]
+    on = kind == 2
+    o[on] = target[on] + [0.0, 3.0, 0.0]
+    start = on & (rs.rand(count) < 0.5)
+    o[start] = target[start]                                             # start on the tile itself
+    rays = np.concatenate([o, np.full((count, 1), 1e-4), d, np.full((count, 1), np.inf)], axis=1).astype(np.float32)
+    return rays
+
 def cornell_instances(tmpdir, count=40, smooth=(True, False), **kw):
     """Cornell box whose two boxes are replaced by `count` rigid instances of two small master meshes (an `instances`
     primitive, primitives/Instance.cpp): one smooth-shaded rough-conductor blob, one flat-shaded two-material blob; the

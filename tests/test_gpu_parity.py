@@ -143,6 +143,28 @@ def test_trace_rays_matches_oracle_exactly(scene, tmp_path):
     assert (ghits["rec"] == bhits["rec"]).mean() >= 0.999
 
 
+@pytest.mark.gpu
+def test_grid_aligned_geometry_walks_like_the_oracle(tmp_path):
+    """Corner, edge and grazing rays on axis-aligned tiles at exact grid coordinates far from the origin (tests/scenes.py: tile_terraces,
+    terrace_rays; tests/test_host.py holds the wide walk to the BVH2 walk's hits there): the device's wide walk visits exactly what the
+    oracle's visits and returns its hits."""
+    path = scenes.tile_terraces(tmp_path)
+    flat = tg.FlattenedScene(path)
+    rays = scenes.terrace_rays()
+    ohits, onodes, oprims = oracle_lib.trace_rays(flat.desc, rays, wide=True)
+    r = tg.Renderer(path)
+    r.set_option("count_traversal", 1)
+    r.reset_counters()
+    ghits, _ = r.trace_rays(rays)
+    c = r.counters()
+    r.close()
+    flat.close()
+    assert (ohits["rec"] >= 0).mean() > 0.8
+    assert (ghits["rec"] == ohits["rec"]).all()
+    assert (ghits["t"] == ohits["t"]).all()
+    assert c.nodes_visited == onodes and c.prims_tested == oprims
+
+
 def test_empty_and_degenerate_ray_batches(tmp_path):
     path = scenes.cornell(tmp_path, resolution=(16, 9), spp=1)
     r = tg.Renderer(path)

@@ -30,6 +30,9 @@ static inline void rgbeToFloat(const uint8_t *rgbe, float *out)
     }
 }
 
+// Images come from scene files: untrusted input.  Nothing larger than 2^28 pixels (or 65 535 on a side) is decoded.
+static bool saneImageSize(long long w, long long h) { return w > 0 && h > 0 && w <= 65535 && h <= 65535 && w*h <= (1ll << 28); }
+
 bool loadPfm(const std::string &path, std::vector<float> &rgb, int &w, int &h, std::string &err)
 {
     std::ifstream in(path.c_str(), std::ios::binary);
@@ -41,7 +44,7 @@ bool loadPfm(const std::string &path, std::vector<float> &rgb, int &w, int &h, s
     double scale;
     in >> w >> h >> scale;
     in.get();
-    if (!in || w <= 0 || h <= 0) { err = "bad PFM header"; return false; }
+    if (!in || !saneImageSize(w, h)) { err = "bad PFM header"; return false; }
     std::vector<float> row(size_t(w)*channels);
     rgb.resize(size_t(w)*h*3);
     for (int y = 0; y < h; ++y) {
@@ -73,6 +76,7 @@ bool loadHdr(const std::string &path, std::vector<float> &rgb, int &w, int &h, s
     if (!formatOk) { err = "unsupported HDR format"; return false; }
     std::getline(in, line);
     if (std::sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2) { err = "unsupported HDR data layout"; return false; }
+    if (!saneImageSize(w, h)) { err = "image size out of range"; return false; }
 
     rgb.resize(size_t(w)*h*3);
     std::vector<uint8_t> scan(size_t(w)*4);
@@ -236,7 +240,7 @@ bool loadPfm(const std::string &path, std::vector<float> &texels, int &w, int &h
     in >> w >> h >> scale;
     std::string rest;
     std::getline(in, rest);
-    if (!in || w <= 0 || h <= 0) { err = "bad PFM header"; return false; }
+    if (!in || !saneImageSize(w, h)) { err = "bad PFM header"; return false; }
     texels.assign(size_t(w)*h*channels, 0.0f);
     for (int y = 0; y < h; ++y)
         in.read(reinterpret_cast<char *>(&texels[size_t(h - y - 1)*w*channels]), std::streamsize(size_t(w)*channels*sizeof(float)));
@@ -292,7 +296,8 @@ struct Huffman {
     }
 };
 
-bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err)
+// `limit`: the decoder stops with an error once the output would grow beyond it (the caller knows how many bytes the image needs)
+bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::string &err, size_t limit)
 {
     static const uint16_t lenBase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
     static const uint16_t lenExtra[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -311,6 +316,7 @@ bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::strin
             uint32_t len = br.p[br.pos] | (uint32_t(br.p[br.pos + 1]) << 8), nlen = br.p[br.pos + 2] | (uint32_t(br.p[br.pos + 3]) << 8);
             br.pos += 4;
             if ((len ^ 0xFFFFu) != nlen || br.pos + len > br.n) { err = "bad stored block"; return false; }
+            if (out.size() + len > limit) { err = "more image data than the header announces"; return false; }
             out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
             br.pos += len;
         } else if (type == 1 || type == 2) {
@@ -339,9 +345,9 @@ bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::strin
                     if (sym < 0) { err = "bad code-length symbol"; return false; }
                     if (sym < 16) { lengths[i++] = uint8_t(sym); continue; }
                     uint32_t rep, prev = 0;
-                    if (sym == 16) { if (i == 0) { err = "repeat without a length"; return false; } prev = lengths[i - 1]; if (!br.bits(2, rep)) return false; rep += 3; }
-                    else if (sym == 17) { if (!br.bits(3, rep)) return false; rep += 3; }
-                    else { if (!br.bits(7, rep)) return false; rep += 11; }
+                    if (sym == 16) { if (i == 0) { err = "repeat without a length"; return false; } prev = lengths[i - 1]; if (!br.bits(2, rep)) { err = "truncated code lengths"; return false; } rep += 3; }
+                    else if (sym == 17) { if (!br.bits(3, rep)) { err = "truncated code lengths"; return false; } rep += 3; }
+                    else { if (!br.bits(7, rep)) { err = "truncated code lengths"; return false; } rep += 11; }
                     if (i + rep > hlit + hdist) { err = "too many code lengths"; return false; }
                     while (rep--) lengths[i++] = uint8_t(prev);
                 }
@@ -350,7 +356,7 @@ bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::strin
             for (;;) {
                 int sym = lit.decode(br);
                 if (sym < 0) { err = "bad literal / length symbol"; return false; }
-                if (sym < 256) { out.push_back(uint8_t(sym)); continue; }
+                if (sym < 256) { if (out.size() >= limit) { err = "more image data than the header announces"; return false; } out.push_back(uint8_t(sym)); continue; }
                 if (sym == 256) break;
                 sym -= 257;
                 if (sym >= 29) { err = "bad length symbol"; return false; }
@@ -363,6 +369,7 @@ bool inflate(const uint8_t *src, size_t n, std::vector<uint8_t> &out, std::strin
                 if (!br.bits(distExtra[ds], eb)) { err = "truncated distance"; return false; }
                 d += eb;
                 if (d > out.size()) { err = "distance beyond the start of the data"; return false; }
+                if (out.size() + len > limit) { err = "more image data than the header announces"; return false; }
                 size_t from = out.size() - d;
                 for (uint32_t k = 0; k < len; ++k) out.push_back(out[from + k]);
             }
@@ -406,7 +413,8 @@ bool loadPng(const std::string &path, std::vector<uint8_t> &rgba, int &w, int &h
         else if (type == "IEND") break;
         o += 12 + size_t(len);
     }
-    if (!haveHeader || w <= 0 || h <= 0 || idat.empty()) { err = "missing IHDR / IDAT"; return false; }
+    if (!haveHeader || idat.empty()) { err = "missing IHDR / IDAT"; return false; }
+    if (!saneImageSize(w, h)) { err = "image size out of range"; return false; }
     int channels;
     switch (colorType) {
     case 0: channels = 1; break;
@@ -423,7 +431,7 @@ bool loadPng(const std::string &path, std::vector<uint8_t> &rgba, int &w, int &h
     const size_t stride = (size_t(w)*size_t(channels)*size_t(depth) + 7)/8;
     std::vector<uint8_t> raw;
     raw.reserve((stride + 1)*size_t(h));
-    if (!inflate(idat.data(), idat.size(), raw, err)) return false;
+    if (!inflate(idat.data(), idat.size(), raw, err, (stride + 1)*size_t(h))) return false;
     if (raw.size() < (stride + 1)*size_t(h)) { err = "image data too short"; return false; }
     // scanline filters (RFC 2083 section 6), in place
     std::vector<uint8_t> prev(stride, 0);

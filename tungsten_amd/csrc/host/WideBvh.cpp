@@ -179,27 +179,36 @@ WideBvhResult buildWideBvh(std::vector<TgHipBvhNode> &bvh2, const std::vector<Bo
             itemAt[bs] = bi;
         }
 
-        // ---- quantisation: lower planes round down, upper planes up, verified in the arithmetic the decoder uses
+        // ---- quantisation: lower planes round down, upper planes up -- with SLACK.  The walk computes a plane's distance as
+        // fma(q, spacing/d, (origin - o)/d) (pt_kernels.h: wideVisit): when the node's origin is far from the ray's compared with the plane's
+        // distance the two terms cancel, and the result is off by ulps of |origin - o|/d, not of the distance.  A quantised plane that
+        // coincides with its child's box -- a child on the node's own boundary, a zero-thickness axis-aligned quad on a grid plane -- would
+        // then be culled for grazing rays.  So the grid starts one step below the node's box, and every plane keeps at least a quarter of a
+        // step between itself and the box it bounds (in large nodes, the only ones where the cancellation is larger than the step-relative
+        // padding of wideVisit, a quarter step is orders of magnitude more than the error).
         TgHipWideNode node;
         std::memset(&node, 0, sizeof(node));
         for (int a = 0; a < 3; ++a) {
-            node.origin[a] = bounds.lo[a];
             uint8_t e = spacingExponent(bounds.hi[a] - bounds.lo[a]);
             for (;;) {
                 const float sp = planeSpacing(e);
+                const float org = bounds.lo[a] - sp;
                 bool fits = true;
                 for (int s = 0; s < 8 && fits; ++s) {
                     if (itemAt[s] < 0) { node.qlo[a][s] = 255; node.qhi[a][s] = 0; continue; }
                     const Box3f &b = items[size_t(itemAt[s])].box;
-                    float ql = std::floor((b.lo[a] - bounds.lo[a])/sp), qh = std::ceil((b.hi[a] - bounds.lo[a])/sp);
+                    float ql = std::floor((b.lo[a] - org)/sp), qh = std::ceil((b.hi[a] - org)/sp);
                     ql = std::min(std::max(ql, 0.0f), 255.0f);
                     qh = std::max(qh, 0.0f);
-                    while (ql > 0.0f && bounds.lo[a] + ql*sp > b.lo[a]) ql -= 1.0f;
-                    while (qh <= 255.0f && bounds.lo[a] + qh*sp < b.hi[a]) qh += 1.0f;
+                    while (ql > 0.0f && org + ql*sp > b.lo[a]) ql -= 1.0f;
+                    while (qh <= 255.0f && org + qh*sp < b.hi[a]) qh += 1.0f;
+                    if (ql > 0.0f && b.lo[a] - (org + ql*sp) < 0.25f*sp) ql -= 1.0f;
+                    if (qh <= 255.0f && (org + qh*sp) - b.hi[a] < 0.25f*sp) qh += 1.0f;
                     if (qh > 255.0f) { fits = false; break; }
                     node.qlo[a][s] = uint8_t(ql);
                     node.qhi[a][s] = uint8_t(qh);
                 }
+                node.origin[a] = org;
                 if (fits || e >= 254)
                     break;
                 ++e;
