@@ -201,9 +201,9 @@ def check_wide_bvh(desc):
                 blo, bhi = np.min([b[0] for b in boxes], axis=0), np.max([b[1] for b in boxes], axis=0)
             tol = 2e-6*np.maximum(np.abs(blo), np.abs(bhi)) + 1e-7      # (records store v0, v1 - v0, v2 - v0: the corners re-round)
             assert (dlo <= blo + tol).all() and (dhi >= bhi - tol).all(), (i, s)
-            # between a quarter of a step and two steps of slack (WideBvh.cpp: no quantised plane coincides with the box it bounds)
+            # between 1/64 of a step and two steps of slack (WideBvh.cpp: no quantised plane coincides with the box it bounds)
             assert (blo - dlo <= spacing[i]*2.001 + 1e-6*np.abs(blo)).all() and (dhi - bhi <= spacing[i]*2.001 + 1e-6*np.abs(bhi)).all()
-            assert (blo - dlo >= spacing[i]*0.249 - tol).all() and (dhi - bhi >= spacing[i]*0.249 - tol).all()
+            assert (blo - dlo >= spacing[i]/64.5 - tol).all() and (dhi - bhi >= spacing[i]/64.5 - tol).all()
             lo, hi = np.minimum(lo, blo), np.maximum(hi, bhi)
         exact[i] = (lo, hi)
     assert (seen == 1).all()
