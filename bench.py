@@ -113,12 +113,20 @@ class Bench(object):
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (a.gpus, self.world))
         if not torch.cuda.is_available() or tg.device_count() < 1:
             raise SystemExit("bench.py: no HIP device visible -- the path tracer has no CPU fallback")
+        # TG_BENCH_SHARE_DEVICE=1 (a rehearsal of the N-rank path on a box with fewer GPUs than ranks, profiles/README.md): every rank renders
+        # its shard on device LOCAL_RANK % visible devices and the exchange step goes through gloo -- RCCL wants one rank per device
+        self.shared = os.environ.get("TG_BENCH_SHARE_DEVICE", "") not in ("", "0")
+        if self.shared:
+            self.local %= torch.cuda.device_count()
         torch.cuda.set_device(self.local)
         self.dist = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
+            if self.shared:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
             self.dist = dist
         self.tmp = tempfile.mkdtemp(prefix="tg_bench_")
 
@@ -238,7 +246,7 @@ class Bench(object):
         self.fence()
         elapsed = time.perf_counter() - t0
         if self.dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.shared else "cuda")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
         timed = tg.TgHipCounters()
@@ -355,7 +363,7 @@ class Bench(object):
                 "value": round(value, 2), "ms_per_step": round(elapsed/steps*1e3, 3),
                 "config": {"workload": workload, "width": w, "height": h, "spp": spp, "sampler": "uniform (counter-based PCG)",
                            "adaptive_sampling": False, "max_bounces": int(flat.desc.contents.settings.max_bounces),
-                           "parallelism": "tile-shard x%d%s" % (self.world, " + RCCL framebuffer reduce" if self.world > 1 else "")},
+                           "parallelism": "tile-shard x%d%s" % (self.world, (" + gloo framebuffer reduce (rehearsal: ranks share a device)" if self.shared else " + RCCL framebuffer reduce") if self.world > 1 else "")},
                 "roofline": roofline,
                 "cpu_baseline": cpu_baseline(a, scene, path, flat, w, h, spp, self.tmp) if cpu else None,
                 "kernels": kernels,

@@ -40,6 +40,18 @@ def reduce_framebuffer(fb_sum, fb_count, dst=0, group=None):
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    if fb_sum.is_cuda and dist.get_backend(group) != "nccl":
+        # device buffers on a backend without device collectives (gloo: the CPU tests, and bench.py's rehearsal of N ranks on fewer GPUs):
+        # stage through the host
+        hs, hc = fb_sum.cpu(), fb_count.cpu()
+        dist.reduce(hs, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        dist.reduce(hc, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) == dst:
+            fb_sum.copy_(hs)
+            fb_count.copy_(hc)
+        import torch
+        torch.cuda.current_stream(fb_sum.device).synchronize()
+        return
     dist.reduce(fb_sum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     dist.reduce(fb_count, dst=dst, op=dist.ReduceOp.SUM, group=group)
     if fb_sum.is_cuda:
