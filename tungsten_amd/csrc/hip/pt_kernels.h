@@ -124,8 +124,13 @@ enum {
     A_COUNT
 };
 
+// The arrays sit in ONE allocation, addressed in GROUPS of eight: array a at poolg[a >> 3] + (a & 7)*stride.  Every group is below 4 GB
+// (8 x 16 B x 2^25 slots at most), so a literal `a` costs one base pointer (an SGPR pair the compiler picks at compile time) and one 32-bit
+// per-lane offset, and the pool as a whole can be larger than 4 GB (2^24 slots x (17 path + up to 20 walk arrays) = 9.9 GB).
+#define PT_POOL_GROUP_SHIFT 3u
+#define PT_POOL_GROUPS 5u                  /* (A_COUNT + 4 + (TGHIP_MAX_WIDE_DEPTH + 1)/2 + 7)/8 */
 struct PathState {
-    char * __restrict__ pool;              // A_COUNT x stride bytes
+    char * __restrict__ poolg[PT_POOL_GROUPS];   // base of arrays 8 g .. 8 g + 7
     uint32_t stride;                       // bytes per array
     // "pool_layout" = 1: slot records instead of arrays -- the eight arrays of a path's state (A_RAY_O .. A_SAMP, 128 bytes)
     // in ONE cache line per slot, the seven of its shadow-ray block (A_SH_O .. A_SH_P, 112 bytes) in a second one at
@@ -162,15 +167,16 @@ PT_DEV uint32_t slotOffset(const PathState &st, uint32_t a, uint32_t slot)     /
 {
     if (st.records)
         return a < A_SH_O ? slot*128u + a*16u : a < A_AUX0 ? st.rec_shadow + slot*128u + (a - A_SH_O)*16u : st.rec_aux + slot*32u + (a - A_AUX0)*16u;
-    return a*st.stride + slot*16u;
+    return (a & ((1u << PT_POOL_GROUP_SHIFT) - 1u))*st.stride + slot*16u;
 }
+PT_DEV char *slotBase(const PathState &st, uint32_t a) { return st.records ? st.poolg[0] : st.poolg[a >> PT_POOL_GROUP_SHIFT]; }
 PT_DEV float4 &slotF4(const PathState &st, uint32_t a, uint32_t slot)
 {
-    return *reinterpret_cast<float4 *>(st.pool + (size_t)slotOffset(st, a, slot));
+    return *reinterpret_cast<float4 *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot));
 }
 PT_DEV uint4 &slotU4(const PathState &st, uint32_t a, uint32_t slot)
 {
-    return *reinterpret_cast<uint4 *>(st.pool + (size_t)slotOffset(st, a, slot));
+    return *reinterpret_cast<uint4 *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot));
 }
 
 

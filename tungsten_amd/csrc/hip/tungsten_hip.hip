@@ -560,12 +560,17 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     // arrays are skewed by an odd number of 256-byte units so that element i of different arrays does not map to
     // the same HBM channel (a power-of-two array stride made the kernels' speed depend on allocation luck)
     const uint64_t strideBytes = uint64_t(slots)*16u + uint64_t(ctx->poolPad);
-    if (strideBytes*A_COUNT >= (1ull << 32)) { ctx->error = "path pool too large for 32-bit slot offsets"; return TGHIP_E_INVALID; }
-    if (strideBytes*(A_COUNT + walkArrays) >= (1ull << 32)) walkArrays = 0;
+    // (a group of eight arrays is addressed with a 32-bit offset from its own base, PathState::poolg)
+    const uint64_t groupArrays = 1ull << PT_POOL_GROUP_SHIFT;
+    if (strideBytes*groupArrays >= (1ull << 32)) { ctx->error = "path pool too large for 32-bit slot offsets within an array group"; return TGHIP_E_INVALID; }
+    if (A_COUNT + walkArrays > groupArrays*PT_POOL_GROUPS) walkArrays = 0;
     ctx->poolWalkArrays = walkArrays;
     const uint64_t recordBytes = uint64_t(slots)*288u + 256u;   // the record layout: 128 + 128 + 32 bytes per slot
     const bool records = ctx->poolRecords && recordBytes < (1ull << 32);
-    POOL_ALLOC(pool, size_t(std::max<uint64_t>(strideBytes*(A_COUNT + walkArrays), records ? recordBytes : 0)));
+    char *poolBase = nullptr;
+    if ((rc = allocArray(ctx, ctx->poolMem, size_t(std::max<uint64_t>(strideBytes*(A_COUNT + walkArrays), records ? recordBytes : 0)), &poolBase)) != TGHIP_OK) return rc;
+    for (uint32_t g = 0; g < PT_POOL_GROUPS; ++g)
+        p.poolg[g] = poolBase + size_t(g)*size_t(groupArrays)*size_t(strideBytes);   // (groups past the last array are never addressed)
     p.walk_base = A_COUNT;
     p.stride = uint32_t(strideBytes);
     p.records = records ? 1u : 0u;
@@ -1312,7 +1317,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
         uint32_t itemBegin = 0;
         for (int k = 0; k < parts; ++k) {
             const uint32_t off = uint32_t(grid/parts)*uint32_t(k);
-            stPart[k].pool = st.pool + size_t(off)*st.slots_per_block*16u;
+            for (uint32_t g = 0; g < PT_POOL_GROUPS; ++g)
+                stPart[k].poolg[g] = st.poolg[g] + size_t(off)*st.slots_per_block*16u;
             stPart[k].bm = st.bm + size_t(off)*(st.slots_per_block >> 5);
             stPart[k].ctl = st.ctl + off;
             stPart[k].stats = st.stats + off;
