@@ -89,7 +89,7 @@ struct BlockCtl {                 // one per persistent workgroup; only that wor
 
 struct BlockStats {               // traversal statistics (count_traversal option), one per workgroup
     unsigned long long nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow;
-    unsigned long long prof[16];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds, tools/gpu_profile_sections.sh)
+    unsigned long long prof[16];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds: `make PROFILE=1`, TGHIP_VERBOSE prints them)
     // count_traversal: where the waves of the wide traversal kernels spend their time ([0] closest-hit, [1] shadow), in wall_clock64 ticks
     // (10 ns) summed over waves: 0 queue expansion, 1 loop while the workgroup's queue has rays, 2 loop after it ran dry, 3 waiting for the
     // workgroup's other waves + write-back; 4 waves; 5 / 6 loop turns before / after dry; 7 / 8 busy lanes summed over those turns;
