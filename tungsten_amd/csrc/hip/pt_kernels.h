@@ -57,6 +57,7 @@ enum { ST_DONE = 0, ST_ACTIVE = 1, ST_TERMINATED = 2, ST_TERMINATED_BLACK = 3 };
 // covers them, else every type); CLS_MISS: the path's ray left the scene.  One queue and one launch per class that occurs in the scene.
 #define PT_NUM_CLASSES 4
 #define CLS_MISS 4
+#define CLS_0_AND_MISS 5   /* a k_shade launch that consumes the queue of class 0 and, behind it, the escaped paths' (same shading variant) */
 #ifndef PT_ITEM_GROUP
 #define PT_ITEM_GROUP  64u        // consecutive work items handed to one workgroup (a wave's worth of pixels)
 #endif
@@ -96,7 +97,7 @@ struct BlockStats {               // traversal statistics (count_traversal optio
     // 9 walks suspended, 10 walks resumed, 11 longest loop of a wave (max, ticks)
     unsigned long long walk[2][12];
 #ifdef PT_PROFILE
-    unsigned long long profCls[PT_NUM_CLASSES + 1][16];   // the same per shading class of the launch (CLS_MISS = escaped paths)
+    unsigned long long profCls[PT_NUM_CLASSES + 2][16];   // the same per shading class of the launch (CLS_MISS = escaped paths)
 #endif
 };
 

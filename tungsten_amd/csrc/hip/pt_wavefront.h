@@ -863,8 +863,10 @@ template<uint32_t M, int FUSE, bool STAGED = false>
 PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassParams &pp, int cls, BlockLds &L, unsigned char *ldsTables, unsigned short *order)
 {
     BlockCtl &ctl = st.ctl[blockIdx.x];
-    const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : shadeQueue(cls);   // (CLS_MISS: the escaped paths)
-    const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : -1;
+    // (CLS_MISS: the escaped paths.  CLS_0_AND_MISS: class 0, then the escaped paths -- one launch of the variant both run; the expanded list
+    // keeps the two runs apart, so at most one wave per workgroup mixes surface shading with escaped paths)
+    const int qIn = (FUSE & FUSE_TRACE) ? Q_EXTP : cls == CLS_0_AND_MISS ? Q_SHADE0 : shadeQueue(cls);
+    const int qIn2 = (FUSE & FUSE_TRACE) ? Q_EXT : cls == CLS_0_AND_MISS ? Q_MISS : -1;
     const uint32_t appendMask = (1u << Q_EXT) | (1u << Q_EXTP) | (1u << Q_SHADOW) | ((FUSE & FUSE_TRACE) ? ((1u << Q_SHADE1) | (1u << Q_SHADE2) | (1u << Q_SHADE3)) : 0u) | (FUSE == 0 ? (1u << Q_FIN) : 0u);
     // the wavefront launches (FUSE == 0) of the shading classes of one iteration run concurrently (runBatch): each consumes its own
     // queue, touches its own slots, and ORs what it appends into the workgroup's global bitmaps
@@ -2343,10 +2345,10 @@ __global__ __launch_bounds__(256) void k_tail(DeviceScene s, PathState st, PassP
     for (;;) {
         traceClosestWideBody<false, SOLIDS, false, true>(s, st, L, fetchNext, ldsDyn);
         __syncthreads();
-        for (int c = -1; c < PT_NUM_CLASSES; ++c) {          // the escaped paths, then the classes that occur in the scene (bit c of `classes`)
+        for (int c = 0; c < PT_NUM_CLASSES; ++c) {           // class 0 with the escaped paths, then the classes that occur in the scene (bit c of `classes`)
             if (c >= 1 && !((classes >> c) & 1u))
                 continue;
-            (void)shadeBody<M, 0, true>(staged, st, pp, c < 0 ? CLS_MISS : c, L, ldsTables, order);
+            (void)shadeBody<M, 0, true>(staged, st, pp, c == 0 ? CLS_0_AND_MISS : c, L, ldsTables, order);
             __syncthreads();
         }
         traceShadowFastBody<false, SOLIDS>(s, st, pp, L, fetchNext, ldsDyn);

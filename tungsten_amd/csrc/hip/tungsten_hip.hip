@@ -115,6 +115,7 @@ struct tghip_ctx {
     // k_tail (one launch per part: every workgroup iterates over its own slots until they are done).  The kernel is built for latency, not
     // throughput (one shading variant for every class, one wave per SIMD): measured, Msamples/s for thresholds off / 2 Ki / 8 Ki / 32 Ki / 128 Ki:
     // mesh1m 605 / 625 / 611 / 575 / 514, materialtest 963 / 966 / 964 / 968 / 966, materialtest as shipped 573 / 611 / 630 / 623 / 625
+    bool mergeMissOpt = true;             // "merge_miss"
     bool tailOpt = true;
     long long tailThreshold = 8192;
     bool instShadowJoin = true;           // "inst_shadow_join": 0 = the instanced wide shadow kernel without PT_TURN_JOIN (the miscompiled variant; repro tool only)
@@ -828,6 +829,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "decouple") ctx->decoupleOpt = value != 0;
     else if (k == "inst_shadow_join") ctx->instShadowJoin = value != 0;
     else if (k == "tail_kernel") ctx->tailOpt = value != 0;
+    else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
     else if (k == "tail_threshold") ctx->tailThreshold = value;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1400,7 +1402,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             // option).  Measured slower than one after the other (materialtest 735-800 against 825-830 Msamples/s, mesh1m 409 against 508,
             // for 2 to 24 hardware queues): with four parts in flight the chip is not short of independent launches.
             auto shadeClass = [&](int cls) {
-                const bool simple = cls == 0 || cls == CLS_MISS;
+                const bool simple = cls == 0 || cls == CLS_MISS || cls == CLS_0_AND_MISS;
                 if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, cls);   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER
                 else if (ctx->haveMeshLight) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);   // the only variant with mesh-emitter sampling (every BSDF type)
                 else if (ctx->haveInstances && simple && ctx->instSimpleOpt) launchShade<MASK_SIMPLE_INST>(ctx, grid, st, pp, cls);   // Lambert / escaped paths of instanced scenes
@@ -1429,8 +1431,9 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 for (int a = 0; a < nAux; ++a)
                     (void)hipStreamWaitEvent(mainStream, ctx->evJoin[part][a], 0);
             } else {
-                shadeClass(CLS_MISS);
-                shadeClass(0);
+                // (class 0 and the escaped paths run the same variant: one launch over both queues, "merge_miss" = 0 keeps them apart)
+                if (ctx->mergeMissOpt) shadeClass(CLS_0_AND_MISS);
+                else { shadeClass(CLS_MISS); shadeClass(0); }
                 for (int c = 1; c < PT_NUM_CLASSES; ++c)
                     if (ctx->classPresent[c]) shadeClass(c);
             }
