@@ -74,7 +74,7 @@ STATE_R = RAY_B + 16 + 16 + 16  # ray, throughput+flags, radiance, rng+pixel+ite
 STATE_W = 16 + 16               # throughput+flags, radiance written back per shaded vertex
 
 
-def kernel_bytes(c, flat, fused, node_b=64, node_b_shadow=None):
+def kernel_bytes(c, flat, fused, node_b=64, node_b_shadow=None, fold_finish=False):
     """Algorithmic bytes moved by each kernel class over everything the counters cover.
     flat: the scene is a flat record list whose loads are wave-uniform (one fetch per 64 rays);
     fused: (flat scenes) intersection and shadow tests run inside k_shade, no hit / shadow records exist."""
@@ -88,7 +88,9 @@ def kernel_bytes(c, flat, fused, node_b=64, node_b_shadow=None):
         return {"k_shade": paths*(STATE_R + STATE_W) + alive*(RAY_B + 8) + regen + rec_b*c["prims_tested"]}
     return {
         # ray in + hit out + BVH nodes and primitive records actually visited
-        "k_trace_closest": paths*(RAY_B + HIT_B) + node_b*nodes_cl + rec_b*prims_cl,
+        # (fold_finish: the launch also finalises and regenerates the slots of the samples that ended at the previous vertex -- k_finish's
+        # work rides in front of the walk: the sample's radiance and flags read, the slot record rewritten)
+        "k_trace_closest": paths*(RAY_B + HIT_B) + node_b*nodes_cl + rec_b*prims_cl + (c["samples"]*(16 + 16) + regen if fold_finish else 0),
         # shadow origin, throughput/pending, radiance read+write per slot; direction+contribution per ray
         "k_trace_shadow": c["shadow_slots"]*(16 + 16 + 16 + 32) + c["shadow_rays"]*32 + (node_b_shadow or node_b)*nodes_sh + rec_b*prims_sh,
         # path state read once per vertex and written back (+ ray and rng when the path continues), plus the
@@ -278,7 +280,9 @@ class Bench(object):
             wide = int(flat.desc.contents.num_wide_nodes) > 0 and "wide_bvh=0" not in a.opt
             # (instanced scenes: shadow rays on the wide tree, closest-hit rays on the two-level BVH2 -- the shim's measured default)
             inst = int(flat.desc.contents.num_instances) > 0
-            per_step_bytes = kernel_bytes(cc, is_flat, fused, WIDE_NODE_B if wide and not inst else NODE_B, WIDE_NODE_B if wide else NODE_B)
+            # single-level BVH scenes on the decoupled wide walk: k_finish is folded into the closest-hit launch (the shim's default)
+            fold = wide and not inst and not is_flat and "fold_finish=0" not in a.opt and "decouple=0" not in a.opt
+            per_step_bytes = kernel_bytes(cc, is_flat, fused, WIDE_NODE_B if wide and not inst else NODE_B, WIDE_NODE_B if wide else NODE_B, fold)
 
             kernels = {}
             ms = {"k_trace_closest": timed["ms_trace_closest"], "k_shade": timed["ms_shade"], "k_trace_shadow": timed["ms_trace_shadow"]}

@@ -212,7 +212,9 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
                 dict(slots_per_block=512), dict(max_slots=8192), dict(check_interval=1), dict(check_interval=16), dict(blocks_per_cu=4),
                 dict(grid_rounds=2), dict(leaf_batch=9), dict(streams=4, blocks_per_cu=4, check_interval=4),
                 # the escaped paths shaded by a launch of their own instead of behind class 0 in one launch
-                dict(merge_miss=0), dict(merge_miss=0, streams=1)]
+                dict(merge_miss=0), dict(merge_miss=0, streams=1),
+                # k_finish as a launch of its own in every iteration instead of in front of the next closest-hit launch
+                dict(fold_finish=0), dict(fold_finish=0, check_interval=1), dict(fold_finish=1, check_interval=1), dict(fold_finish=1, streams=1, check_interval=3)]
     if scene == "materialtest":
         # walk time-slicing of the wide traversal kernels (PathState::suspend_*): off, the default, and settings that suspend every walk
         # after one / three / two turns of every launch -- hundreds of save / resume round trips per ray, shadow slots held and released

@@ -781,6 +781,21 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
     __shared__ uint32_t fetchNext;
     traceClosestWideBody<COUNT, SOLIDS, INST, DECOUPLED>(s, st, L, fetchNext, ldsDyn);
 }
+// The same launch with k_finish's work of the PREVIOUS iteration in front: every workgroup first finalises the paths that ended at the last
+// vertex and regenerates their slots (finishBody, below), then traces its extension rays, the fresh camera rays among them -- one launch per
+// part and iteration less, and the streaming of the regeneration runs inside the issue-bound walk's launch.  The shim launches the stand-alone
+// k_finish only before a host check (the liveness report) and before k_tail.  Single-level scenes on the decoupled walk.
+PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, unsigned short *order);
+template<bool COUNT, bool SOLIDS>
+__global__ WIDE_CLOSEST_BOUNDS void k_finish_trace_closest_wide(DeviceScene s, PathState st, PassParams pp)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    (void)finishBody(s, st, pp, L, reinterpret_cast<unsigned short *>(ldsDyn));   // (the queue area of the dynamic LDS: slots_per_block entries)
+    __syncthreads();
+    traceClosestWideBody<COUNT, SOLIDS, false, true>(s, st, L, fetchNext, ldsDyn);
+}
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
 // WIDE: the scene has a wide BVH and no instances (the walk the wavefront kernels do, one ray per lane without refills)

@@ -115,6 +115,7 @@ struct tghip_ctx {
     // k_tail (one launch per part: every workgroup iterates over its own slots until they are done).  The kernel is built for latency, not
     // throughput (one shading variant for every class, one wave per SIMD): measured, Msamples/s for thresholds off / 2 Ki / 8 Ki / 32 Ki / 128 Ki:
     // mesh1m 605 / 625 / 611 / 575 / 514, materialtest 963 / 966 / 964 / 968 / 966, materialtest as shipped 573 / 611 / 630 / 623 / 625
+    bool foldFinishOpt = true;            // "fold_finish"
     bool mergeMissOpt = true;             // "merge_miss"
     bool tailOpt = true;
     long long tailThreshold = 8192;
@@ -830,6 +831,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "inst_shadow_join") ctx->instShadowJoin = value != 0;
     else if (k == "tail_kernel") ctx->tailOpt = value != 0;
     else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
+    else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
     else if (k == "tail_threshold") ctx->tailThreshold = value;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1348,6 +1350,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                               !ctx->haveMeshLight && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder && !count && !st.records &&
                               st.slots_per_block <= PT_MAX_SLOTS_PER_BLOCK;
     const uint64_t tailThreshold = uint64_t(std::max<long long>(ctx->tailThreshold, 0));
+    // "fold_finish": k_finish rides in front of the next iteration's closest-hit launch (single-level scenes on the decoupled wide walk)
+    const bool foldFinish = ctx->foldFinishOpt && !flat && !ctx->haveInstances && wideClosest(ctx) && ctx->decoupleOpt;
     uint32_t iterTag = 1;                        // k_start publishes tag 1 when it queued anything
     bool first = true;
     int roundIters = checkInterval;              // launches of the wavefront loop between two host checks
@@ -1376,6 +1380,12 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 if (ctx->haveInstances) {
                     if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, true, false); else CLOSEST_WIDE(false, true, true, false); }
                     else                 { if (count) CLOSEST_WIDE(true, false, true, false); else CLOSEST_WIDE(false, false, true, false); }
+                } else if (ctx->decoupleOpt && foldFinish) {
+                    // (k_finish's work of the previous iteration in front of the walk, pt_wavefront.h)
+#define CLOSEST_FIN(C, S) hipLaunchKernelGGL((k_finish_trace_closest_wide<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->launchStream, s, st, pp)
+                    if (ctx->haveSolids) { if (count) CLOSEST_FIN(true, true); else CLOSEST_FIN(false, true); }
+                    else                 { if (count) CLOSEST_FIN(true, false); else CLOSEST_FIN(false, false); }
+#undef CLOSEST_FIN
                 } else if (ctx->decoupleOpt) {
                     if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, false, true); else CLOSEST_WIDE(false, true, false, true); }
                     else                 { if (count) CLOSEST_WIDE(true, false, false, true); else CLOSEST_WIDE(false, false, false, true); }
@@ -1441,7 +1451,13 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             const bool finish = count ? launchShadow<true>(ctx, grid, st, pp, iterTag) : launchShadow<false>(ctx, grid, st, pp, iterTag);
             tic();
             (void)finish;                        // (always: the shading launches leave their finished paths to k_finish as well)
-            hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, ctx->launchStream, s, st, pp, iterTag);
+            if (!foldFinish)                     // (folded: the next iteration's closest-hit launch, or finishParts before a host check)
+                hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, ctx->launchStream, s, st, pp, iterTag);
+        };
+        // folded k_finish: the last iteration's finish as a launch of its own -- before the host reads the liveness word, before k_tail
+        auto finishParts = [&](uint32_t tag) {
+            for (int k = 0; k < parts; ++k)
+                hipLaunchKernelGGL(k_finish, dim3(grid/parts), dim3(256), 0, split ? streamOf[k] : ctx->stream, s, split ? stPart[k] : st, split ? ppPart[k] : pp, tag);
         };
     for (;;) {
         evUsed = 0;
@@ -1537,6 +1553,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             }
             ctx->counters.iterations++;
         }
+        if (foldFinish && !fused)
+            finishParts(iterTag);
     }
     float *sum = ctx->extSum ? ctx->extSum : ctx->fbSum;
     uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
