@@ -1350,6 +1350,15 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                               !ctx->haveMeshLight && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder && !count && !st.records &&
                               st.slots_per_block <= PT_MAX_SLOTS_PER_BLOCK;
     const uint64_t tailThreshold = uint64_t(std::max<long long>(ctx->tailThreshold, 0));
+    // (k_tail runs 256 threads whatever the depth of the tree: it is used only where a workgroup of it fits a CU -- its static LDS plus
+    // the walk stacks of a very deep tree may not)
+    bool tailFits = false;
+    if (tailEligible) {
+        int nb = 0;
+        const void *fn = pp.flags ? (ctx->haveSolids ? reinterpret_cast<const void *>(k_tail<(MASK_TAIL | FEAT_QMC), true>) : reinterpret_cast<const void *>(k_tail<(MASK_TAIL | FEAT_QMC), false>))
+                                  : (ctx->haveSolids ? reinterpret_cast<const void *>(k_tail<MASK_TAIL, true>) : reinterpret_cast<const void *>(k_tail<MASK_TAIL, false>));
+        tailFits = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, wideLdsBytes(ctx, 256)) == hipSuccess && nb >= 1;
+    }
     // "fold_finish": k_finish rides in front of the next iteration's closest-hit launch (single-level scenes on the decoupled wide walk)
     const bool foldFinish = ctx->foldFinishOpt && !flat && !ctx->haveInstances && wideClosest(ctx) && ctx->decoupleOpt;
     uint32_t iterTag = 1;                        // k_start publishes tag 1 when it queued anything
@@ -1490,7 +1499,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             }
             if (ctx->hostLive[0] != iterTag)
                 break;                           // the last iteration left every extension queue empty
-            if (tailEligible && uint64_t(ctx->hostLive[1]) <= tailThreshold) {
+            if (tailFits && uint64_t(ctx->hostLive[1]) <= tailThreshold) {
                 // few paths left: each part of the pool finishes in one launch of k_tail (its workgroups iterate on their own)
                 const size_t ldsTail = wideLdsBytes(ctx, 256);
                 uint32_t classes = 1u;
