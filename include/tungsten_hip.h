@@ -195,7 +195,11 @@ typedef struct TgHipBsdf {
     float    ior, thickness, avg_transmittance, diffuse_fresnel;
     int32_t  enable_refraction;
     float    eta[3], k[3], sigma_a[3], scaled_sigma_a[3];
-    float    pad[2];
+    int32_t  bump1;           /* Bsdf::_bump (bsdfs/Bsdf.cpp:19-25, scalar request): texture index + 1 of a NON-constant bump map, 0 = none
+                                 (a constant one changes nothing, Primitive.cpp:128-131); the shading frame then comes from the primitive's
+                                 tangent space and the map's derivatives (Primitive::setupTangentFrame, Primitive.cpp:125-163).  (In what
+                                 was padding up to ABI 7: a description written before carries 0.) */
+    float    pad;
 } TgHipBsdf;
 
 /* ---- participating media (media/HomogeneousMedium.cpp) ------------------------------------------------- */

@@ -1567,6 +1567,10 @@ typedef struct {
     v3 Ng, Ns, p, w;
     float u, v, epsilon;
     int object, bsdf, backSide;
+    /* Primitive::tangentSpace of the primitive that was hit (TriangleMesh.cpp:362-384, Quad.cpp:133-139, Cube.cpp:172-182, Sphere.cpp:131-137,
+     * Disk.cpp:129-140, Cylinder.cpp:135-141; Instance.cpp:348-351 has none): read by the bump-mapped shading frame only */
+    v3 T, B;
+    int hasTB;
 } Info;
 
 static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit *hit, Info *info)
@@ -1578,9 +1582,22 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit
     info->p = vadd(ray->o, vscale(ray->d, hit->t));      /* TraceableScene.hpp:184 */
     info->w = ray->d;
     info->epsilon = 5e-4f;                               /* DefaultEpsilon, TraceableScene.hpp:39 */
+    info->T = info->B = V(0.0f, 0.0f, 0.0f);
+    info->hasTB = 0;
     switch (TGHIP_REC_KIND(r->meta)) {
     case TGHIP_REC_TRIANGLE: {   /* TriangleMesh.cpp:317-355, 80-106 */
         const TgHipTriAttr *a = &s->tri_attrs[hit->rec];
+        {   /* TriangleMesh::tangentSpace (:362-384); the record holds p0, p1 - p0, p2 - p0 */
+            v3 q1 = ld3(r->b), q2 = ld3(r->c);
+            float s1 = a->uv1[0] - a->uv0[0], t1 = a->uv1[1] - a->uv0[1];
+            float s2 = a->uv2[0] - a->uv0[0], t2 = a->uv2[1] - a->uv0[1];
+            float invDet = s1*t2 - s2*t1;
+            if (!(fabsf(invDet) < 1e-6f) && hit->inst < 0) {
+                info->T = vnorm(vsub(vscale(q1, t2), vscale(q2, t1)));
+                info->B = vnorm(vsub(vscale(q2, s1), vscale(q1, s2)));
+                info->hasTB = 1;
+            }
+        }
         v3 NgU = vcross(ld3(r->b), ld3(r->c));
         v3 dLocal = ray->d;
         if (hit->inst >= 0) {       /* the master was intersected with the ray in its own space (Instance.cpp:295-297) */
@@ -1607,30 +1624,59 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit
         info->u = hit->u; info->v = hit->v;
         info->bsdf = o->bsdf;
         info->backSide = vdot(ray->d, ld3(o->normal)) >= 0.0f;
+        info->T = ld3(o->edge0); info->B = ld3(o->edge1); info->hasTB = 1;   /* Quad.cpp:133-139 */
         break;
     case TGHIP_REC_CUBE:         /* Cube.cpp:157-170 */
         cube_surface(o, info->p, &info->Ng, &info->u, &info->v);
         info->Ns = info->Ng;
         info->bsdf = o->bsdf;
         info->backSide = hit->u != 0.0f;
+        {   /* Cube::tangentSpace (:172-182) */
+            v3 lp = mat3_tmul(o->rot, vsub(info->p, ld3(o->pos)));
+            float ex[3] = {fabsf(lp.x) - o->scale[0], fabsf(lp.y) - o->scale[1], fabsf(lp.z) - o->scale[2]};
+            int dim = 0;
+            if (ex[1] > ex[dim]) dim = 1;
+            if (ex[2] > ex[dim]) dim = 2;
+            float t[3] = {0.0f, 0.0f, 0.0f}, b[3] = {0.0f, 0.0f, 0.0f};
+            t[(dim + 1) % 3] = 1.0f; b[(dim + 2) % 3] = 1.0f;
+            info->T = mat3_mul(o->rot, V(t[0], t[1], t[2]));
+            info->B = mat3_mul(o->rot, V(b[0], b[1], b[2]));
+            info->hasTB = 1;
+        }
         break;
     case TGHIP_REC_SPHERE:       /* Sphere.cpp:120-129 */
         sphere_surface(o, info->p, &info->Ng, &info->u, &info->v);
         info->Ns = info->Ng;
         info->bsdf = o->bsdf;
         info->backSide = hit->u != 0.0f;
+        {   /* Sphere::tangentSpace (:131-137) */
+            v3 localN = mat3_tmul(o->rot, info->Ng);
+            info->T = mat3_mul(o->rot, V(-localN.y, localN.x, localN.z));
+            info->B = vcross(info->Ns, info->T);
+            info->hasTB = 1;
+        }
         break;
     case TGHIP_REC_CYLINDER:     /* Cylinder.cpp:122-132 */
         cylinder_surface(o, info->p, hit->v, &info->Ng, &info->u, &info->v);
         info->Ns = info->Ng;
         info->bsdf = o->bsdf;
         info->backSide = hit->u != 0.0f;
+        info->T = ld3(o->normal); info->B = vcross(info->Ng, info->T); info->hasTB = 1;   /* Cylinder.cpp:135-141: T = _axis */
         break;
     case TGHIP_REC_DISK:         /* Disk.cpp:114-129 */
         info->Ng = info->Ns = ld3(o->normal);
         disk_surface(o, info->p, hit->v, &info->u, &info->v);
         info->bsdf = o->bsdf;
         info->backSide = hit->u != 0.0f;
+        {   /* Disk::tangentSpace (:129-140) */
+            v3 dd = vsub(info->p, ld3(o->pos));
+            if (vlensq(dd) != 0.0f) {
+                dd = vnorm(dd);
+                info->T = vcross(ld3(o->normal), dd);
+                info->B = dd;
+                info->hasTB = 1;
+            }
+        }
         break;
     default:
         info->Ng = info->Ns = V(0, 1, 0); info->u = info->v = 0; info->bsdf = o->bsdf; info->backSide = 0;
@@ -1647,6 +1693,7 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit
         info->Ns = quat_rotate(q, info->Ns);
         info->p = vadd(ld3(ir->a), quat_rotate(q, info->p));
         info->object = (int)TGHIP_REC_OBJECT(ir->meta);
+        info->hasTB = 0;                                 /* Instance::tangentSpace (Instance.cpp:348-351) */
     }
 }
 
@@ -1687,10 +1734,70 @@ typedef struct {
 
 typedef struct { Frame frame; v3 wi; int flipped; } Local;   /* the part of SurfaceScatterEvent that persists */
 
+/* BitmapTexture::derivatives (textures/BitmapTexture.cpp:359-398) of a scalar bitmap: central differences of the four texels around the
+ * lookup, interpolated; constant and checker textures have none (ConstantTexture.cpp:60-63, CheckerTexture.cpp:76-79) */
+static void texture_derivatives(const TgHipSceneDesc *s, int texIdx, float u0, float v0, float *du, float *dv)
+{
+    const TgHipTexture *t = &s->textures[texIdx];
+    *du = *dv = 0.0f;
+    if (t->type != TGHIP_TEX_BITMAP)
+        return;
+    const int w = t->w, h = t->h;
+    const float *tex = s->texels + t->texel_offset;
+    float u = u0*w - 0.5f;
+    float v = (1.0f - v0)*h - 0.5f;
+    int iu = (int)u, iv = (int)v;
+    u -= iu; v -= iv;
+    iu = ((iu % w) + w) % w;
+    iv = ((iv % h) + h) % h;
+    int x0 = iu - 1, x1 = iu, x2 = (iu + 1) % w, x3 = (iu + 2) % w;
+    int y0 = iv - 1, y1 = iv, y2 = (iv + 1) % h, y3 = (iv + 2) % h;
+    if (x0 < 0) x0 = w - 1;
+    if (y0 < 0) y0 = h - 1;
+#define TEXEL(x, y) ((t->flags & TGHIP_TEXF_RGB) ? (tex[((size_t)(x) + (size_t)(y)*w)*3] + tex[((size_t)(x) + (size_t)(y)*w)*3 + 1] + tex[((size_t)(x) + (size_t)(y)*w)*3 + 2])/3.0f : tex[(size_t)(x) + (size_t)(y)*w])
+    float a01 = TEXEL(x1, y0), a02 = TEXEL(x2, y0);
+    float a10 = TEXEL(x0, y1), a11 = TEXEL(x1, y1), a12 = TEXEL(x2, y1), a13 = TEXEL(x3, y1);
+    float a20 = TEXEL(x0, y2), a21 = TEXEL(x1, y2), a22 = TEXEL(x2, y2), a23 = TEXEL(x3, y2);
+    float a31 = TEXEL(x1, y3), a32 = TEXEL(x2, y3);
+#undef TEXEL
+    float du11 = a12 - a10, du12 = a13 - a11, du21 = a22 - a20, du22 = a23 - a21;
+    float dv11 = a21 - a01, dv21 = a31 - a11, dv12 = a22 - a02, dv22 = a32 - a12;
+    *du = ((du11*(1.0f - u) + du12*u)*(1.0f - v) + (du21*(1.0f - u) + du22*u)*v)*t->scale;
+    *dv = ((dv11*(1.0f - u) + dv12*u)*(1.0f - v) + (dv21*(1.0f - u) + dv22*u)*v)*t->scale;
+}
+
+/* Primitive::setupTangentFrame (primitives/Primitive.cpp:125-163): the frame of the shading normal -- unless the bsdf carries a
+ * non-constant bump map (TgHipBsdf::bump1): then tangent and bitangent come from the primitive's tangent space, tilted by the map's
+ * derivatives.  (Anisotropic lobes, the other reason for the long way, belong to the hair bcsdfs only.) */
+static Frame shading_frame(const TgHipSceneDesc *s, const Info *info)
+{
+    const int bump = s->bsdfs[info->bsdf].bump1 - 1;
+    if (bump < 0 || !info->hasTB)
+        return frame_from_normal(info->Ns);
+    v3 T = info->T, B = info->B, N = info->Ns;
+    float du, dv;
+    texture_derivatives(s, bump, info->u, info->v, &du, &dv);
+    T = vadd(T, vscale(info->Ns, du - vdot(info->Ns, T)));
+    B = vadd(B, vscale(info->Ns, dv - vdot(info->Ns, B)));
+    N = vcross(T, B);
+    if (N.x == 0.0f && N.y == 0.0f && N.z == 0.0f)
+        return frame_from_normal(info->Ns);
+    if (vdot(N, info->Ns) < 0.0f)
+        N = vneg(N);
+    N = vnorm(N);
+    T = vsub(T, vscale(N, vdot(N, T)));
+    if (T.x == 0.0f && T.y == 0.0f && T.z == 0.0f)
+        return frame_from_normal(info->Ns);
+    T = vnorm(T);
+    Frame f;
+    f.normal = N; f.tangent = T; f.bitangent = vcross(N, T);
+    return f;
+}
+
 static Local makeLocalScatterEvent(const Ctx *c, const Info *info, const Ray *ray)   /* TraceBase.cpp:24-51 */
 {
     Local l;
-    l.frame = frame_from_normal(info->Ns);      /* Primitive::setupTangentFrame without bump/anisotropy (Primitive.cpp:125-133) */
+    l.frame = shading_frame(c->s, info);        /* Primitive::setupTangentFrame (Primitive.cpp:125-163) */
     int hitBackside = vdot(l.frame.normal, ray->d) > 0.0f;
     int isTransmissive = (c->s->bsdfs[info->bsdf].lobes & LOBE_TRANSMISSIVE) != 0;
     l.flipped = c->s->settings.enable_two_sided_shading && hitBackside && !isTransmissive;

@@ -683,6 +683,47 @@ GOLDEN_CASES["cornell_skydome"] = (cornell, dict(resolution=(48, 27), spp=8, edi
 GOLDEN_CASES["cornell_skydome_alien"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_skydome(sample=False, temperature=3400.0, turbidity=6.5, intensity=3.0)))
 
 
+def cornell_bump(tmpdir, **kw):
+    """Bump-mapped shading frames (Primitive::setupTangentFrame, primitives/Primitive.cpp:125-163) on every primitive kind with a tangent
+    space: a grey-scale .png on the floor quad (glossy, so the frame shows), on the tall cube, on a sphere and on a small smooth mesh; a
+    checker bump -- no derivatives, but the frame still comes from the primitive's tangent space -- on the back wall."""
+    import numpy as np
+    tmpdir = str(tmpdir)
+    y, x = np.mgrid[0:40, 0:56]
+    img = (127.5 + 90.0*np.sin(x*0.55)*np.cos(y*0.4) + 30.0*np.sin((x + y)*1.3)).clip(0, 255).astype(np.uint8)
+    write_png(os.path.join(tmpdir, "bump.png"), img, 0, filters=(0, 1), level=6)
+    wo3 = os.path.join(tmpdir, "bump_blob.wo3")
+    verts, tris = displaced_sphere(10, 14, seed=5)
+    write_wo3(wo3, verts, tris)
+    user = kw.pop("edit", None)
+
+    def edit(scene):
+        for i, b in enumerate(scene["bsdfs"]):
+            if b["name"] == "floor":
+                scene["bsdfs"][i] = dict({"name": "floor", "type": "rough_conductor", "distribution": "ggx", "roughness": 0.15, "albedo": [0.8, 0.75, 0.7],
+                                          "bump": {"type": "bitmap", "file": "bump.png", "scale": 1.5}}, **_CU)
+            elif b["name"] == "tallBox":
+                scene["bsdfs"][i] = {"name": "tallBox", "type": "plastic", "ior": 1.5, "albedo": [0.3, 0.5, 0.7], "bump": "bump.png"}
+            elif b["name"] == "backWall":
+                scene["bsdfs"][i] = {"name": "backWall", "type": "rough_plastic", "ior": 1.4, "distribution": "beckmann", "roughness": 0.2, "albedo": [0.7, 0.7, 0.6],
+                                     "bump": {"type": "checker", "on_color": 1.0, "off_color": 0.0, "res_u": 6, "res_v": 6}}
+        scene["bsdfs"] += [dict({"name": "ballMat", "type": "rough_conductor", "distribution": "beckmann", "roughness": 0.1, "albedo": 1,
+                                 "bump": {"type": "bitmap", "file": "bump.png", "scale": 0.6}}, **_CU),
+                           {"name": "blobMat", "type": "rough_dielectric", "ior": 1.5, "distribution": "ggx", "roughness": 0.1, "albedo": 1,
+                            "bump": {"type": "bitmap", "file": "bump.png", "scale": 0.5, "interpolate": False}}]
+        scene["primitives"] = [p for p in scene["primitives"] if p["name"] != "shortBox"]
+        scene["primitives"] += [
+            {"name": "ball", "type": "sphere", "bsdf": "ballMat", "transform": {"position": [0.45, 0.3, 0.35], "scale": 0.3, "rotation": [20, 35, 10]}},
+            {"name": "blob", "type": "mesh", "file": "bump_blob.wo3", "smooth": True, "bsdf": "blobMat",
+             "transform": {"position": [-0.1, 0.35, 0.6], "scale": 0.7, "rotation": [10, 50, 0]}}]
+        if user:
+            user(scene)
+    return cornell(tmpdir, **dict(kw, edit=edit))
+
+
+GOLDEN_CASES["cornell_bump"] = (cornell_bump, dict(resolution=(48, 27), spp=8))
+
+
 def _point_lights(scene):
     """Two Dirac point lights (primitives/Point.cpp; one given by emission, one by power) next to the dimmed quad light:
     sampled without random numbers and without MIS, never hit by a ray (TraceBase.cpp:157-158, 281-282, 396-397)."""

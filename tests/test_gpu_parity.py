@@ -66,7 +66,7 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
     assert (count == ocount).all() and (count == spp).all()
     assert c.samples == flat.width*flat.height*spp == oc.samples
     omean = osum/np.maximum(ocount, 1)[..., None]
-    loose = "dielectric" in name or "transparency" in name or "smoke" in name or "volumetric" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances", "water_caustic")
+    loose = "dielectric" in name or "transparency" in name or "smoke" in name or "volumetric" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances", "water_caustic", "cornell_bump")
     # The shipped non-exponential scene lights each box with a 4.7 x 3.8 mm quad.  Quad::approximateRadiance (Quad.cpp:253-281) gets
     # such a light's solid angle (1e-5 sr) as 2 pi minus four arc cosines, so chooseLight's selection weights move by several per
     # cent with the last bit of acosf: with a correctly rounded acosf in place of glibc's the ORACLE itself differs from the

@@ -124,17 +124,22 @@ def test_json_errors_are_reported(tmp_path):
     assert "hair" in str(e.value)
 
 
-def test_bump_maps_are_refused_not_dropped(tmp_path):
-    # Primitive::setupTangentFrame (Primitive.cpp:125-163): a varying bump texture perturbs the shading frame; a constant
-    # one changes nothing (:130).  The first is outside this integrator's scope and must not render unperturbed.
+def test_bump_maps_reach_the_device_unless_constant(tmp_path):
+    # Primitive::setupTangentFrame (Primitive.cpp:125-163): a varying bump texture sends the shading frame through the primitive's tangent
+    # space (TgHipBsdf::bump1 = its texture index + 1); a constant one changes nothing (:128-131) and is dropped.
     def checker_bump(scene):
         scene["bsdfs"][0]["bump"] = {"type": "checker", "on_color": 1.0, "off_color": 0.0, "res_u": 4, "res_v": 4}
-    with pytest.raises(tg.TungstenError) as e:
-        tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, edit=checker_bump, name="bump.json"))
-    assert "bump" in str(e.value)
+    flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, edit=checker_bump, name="bump.json"))
+    d = flat.desc.contents
+    bumped = [d.bsdfs[i].bump1 for i in range(d.num_bsdfs) if d.bsdfs[i].bump1]
+    assert len(bumped) == 1 and d.textures[bumped[0] - 1].type == 1          # the checker
+    flat.close()
     def constant_bump(scene):
         scene["bsdfs"][0]["bump"] = 0.5
-    tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, edit=constant_bump, name="bump_const.json")).close()
+    flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1, edit=constant_bump, name="bump_const.json"))
+    d = flat.desc.contents
+    assert not any(d.bsdfs[i].bump1 for i in range(d.num_bsdfs))
+    flat.close()
 
 
 def test_pfm_round_trip(tmp_path):

@@ -44,7 +44,7 @@ class TgHipBsdf(C.Structure):
                 ("sub0", i32), ("sub1", i32), ("tex1", i32),
                 ("ior", f32), ("thickness", f32), ("avg_transmittance", f32), ("diffuse_fresnel", f32),
                 ("enable_refraction", i32), ("eta", f32*3), ("k", f32*3), ("sigma_a", f32*3),
-                ("scaled_sigma_a", f32*3), ("pad", f32*2)]
+                ("scaled_sigma_a", f32*3), ("bump1", i32), ("pad", f32)]
 
 
 class TgHipTexture(C.Structure):

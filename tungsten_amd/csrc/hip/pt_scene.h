@@ -72,7 +72,8 @@ struct DeviceScene {
 #define FEAT_MEDIA      (1u << 23)   /* participating media (media/HomogeneousMedium.cpp): only in the BSDF_MASK_ALL variant */
 #define FEAT_AUX        (1u << 22)   /* TGHIP_PASS_AUX passes (auxiliary output buffers): only in the BSDF_MASK_ALL variant */
 #define FEAT_CYLINDER   (1u << 21)   /* cylinder primitives / emitters (primitives/Cylinder.cpp): only in the BSDF_MASK_ALL variant */
-#define MASK_FULL       (BSDF_MASK_ALL & ~(FEAT_QMC | FEAT_MEDIA | FEAT_AUX | FEAT_CYLINDER))
+#define FEAT_BUMP       (1u << 20)   /* bump-mapped shading frames (Primitive::setupTangentFrame, TgHipBsdf::bump1): only in the BSDF_MASK_ALL variant */
+#define MASK_FULL       (BSDF_MASK_ALL & ~(FEAT_QMC | FEAT_MEDIA | FEAT_AUX | FEAT_CYLINDER | FEAT_BUMP))
 // next1D of the path's sampler inside code templated on M
 #define RNG1D(r) rngNext1DT<(M & FEAT_QMC) != 0>(r)
 
@@ -1249,6 +1250,10 @@ struct Info {
     float u, v;
     int object, bsdf;
     bool backSide;
+    // FEAT_BUMP variants only: Primitive::tangentSpace of the primitive that was hit (TriangleMesh.cpp:362-384, Quad.cpp:133-139, Cube.cpp:172-182,
+    // Sphere.cpp:131-137, Disk.cpp:129-140, Cylinder.cpp:135-141; an `instances` primitive has none, Instance.cpp:348-351)
+    f3 T, B;
+    bool hasTB;
 };
 
 // Quaternion<float>::operator*(Vec3) (math/Quaternion.hpp:78-88); q = (w, x, y, z)
@@ -1278,6 +1283,8 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
     const TgHipObject &o = s.objects[objIdx];
     info.object = objIdx;
     info.p = ray.o + ray.d*hit.x;                      /* TraceableScene.hpp:184 */
+    info.T = info.B = splat3(0.0f);
+    info.hasTB = false;
     uint32_t kind = TGHIP_REC_KIND(meta);
     if ((M & FEAT_TRIANGLES) && kind == TGHIP_REC_TRIANGLE) {   /* TriangleMesh.cpp:317-355, 80-106 */
         f3 NgU = cross(xyz(r1), xyz(r2));
@@ -1298,31 +1305,70 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         info.u = (1.0f - u - v)*a2.y + u*a2.w + v*a3.y;
         info.v = (1.0f - u - v)*a2.z + u*a3.x + v*a3.z;
         info.bsdf = __float_as_int(a3.w);
+        if constexpr ((M & FEAT_BUMP) != 0u) {         /* TriangleMesh::tangentSpace (:362-384); the record holds p0, p1 - p0, p2 - p0 */
+            const f3 q1 = xyz(r1), q2 = xyz(r2);
+            const float s1 = a2.w - a2.y, t1 = a3.x - a2.z;
+            const float s2 = a3.y - a2.y, t2 = a3.z - a2.z;
+            const float invDet = s1*t2 - s2*t1;
+            if (!(fabsf(invDet) < 1e-6f) && !((M & FEAT_INSTANCES) && hitInst >= 0)) {
+                info.T = normalized(q1*t2 - q2*t1);
+                info.B = normalized(q2*s1 - q1*s2);
+                info.hasTB = true;
+            }
+        }
     } else if (kind == TGHIP_REC_QUAD) {               /* Quad.cpp:123-131 */
         info.Ng = info.Ns = ld3(o.normal);
         info.u = hit.y; info.v = hit.z;
         info.bsdf = o.bsdf;
         info.backSide = dot(ray.d, info.Ng) >= 0.0f;
+        if constexpr ((M & FEAT_BUMP) != 0u) { info.T = ld3(o.edge0); info.B = ld3(o.edge1); info.hasTB = true; }   /* Quad.cpp:133-139 */
     } else if ((M & FEAT_CYLINDER) && kind == TGHIP_REC_CYLINDER) {   /* Cylinder.cpp:122-132 */
         cylinderSurface(o, info.p, hit.z, info.Ng, info.u, info.v);
         info.Ns = info.Ng;
         info.bsdf = o.bsdf;
         info.backSide = hit.y != 0.0f;
+        if constexpr ((M & FEAT_BUMP) != 0u) { info.T = ld3(o.normal); info.B = cross(info.Ng, info.T); info.hasTB = true; }   /* Cylinder.cpp:135-141: T = _axis */
     } else if ((M & FEAT_SOLIDS) && kind == TGHIP_REC_DISK) {    /* Disk.cpp:114-129 */
         info.Ng = info.Ns = ld3(o.normal);
         diskSurface(o, info.p, hit.z, info.u, info.v);
         info.bsdf = o.bsdf;
         info.backSide = hit.y != 0.0f;
+        if constexpr ((M & FEAT_BUMP) != 0u) {         /* Disk::tangentSpace (:129-140) */
+            f3 dd = info.p - ld3(o.pos);
+            if (lengthSq(dd) != 0.0f) {
+                dd = normalized(dd);
+                info.T = cross(ld3(o.normal), dd);
+                info.B = dd;
+                info.hasTB = true;
+            }
+        }
     } else if (!(M & FEAT_SOLIDS) || kind == TGHIP_REC_CUBE) {   /* Cube.cpp:157-170 */
         cubeSurface(o, info.p, info.Ng, info.u, info.v);
         info.Ns = info.Ng;
         info.bsdf = o.bsdf;
         info.backSide = hit.y != 0.0f;
+        if constexpr ((M & FEAT_BUMP) != 0u) {         /* Cube::tangentSpace (:172-182) */
+            const f3 lp = mat3TMul(o.rot, info.p - ld3(o.pos));
+            const float ex[3] = {fabsf(lp.x) - o.scale[0], fabsf(lp.y) - o.scale[1], fabsf(lp.z) - o.scale[2]};
+            int dim = 0;
+            if (ex[1] > ex[dim]) dim = 1;
+            if (ex[2] > ex[dim]) dim = 2;
+            const int dt = (dim + 1) % 3, db = (dim + 2) % 3;
+            info.T = mat3Mul(o.rot, mk3(dt == 0 ? 1.0f : 0.0f, dt == 1 ? 1.0f : 0.0f, dt == 2 ? 1.0f : 0.0f));
+            info.B = mat3Mul(o.rot, mk3(db == 0 ? 1.0f : 0.0f, db == 1 ? 1.0f : 0.0f, db == 2 ? 1.0f : 0.0f));
+            info.hasTB = true;
+        }
     } else {                                           /* Sphere.cpp:120-129 */
         sphereSurface(o, info.p, info.Ng, info.u, info.v);
         info.Ns = info.Ng;
         info.bsdf = o.bsdf;
         info.backSide = hit.y != 0.0f;
+        if constexpr ((M & FEAT_BUMP) != 0u) {         /* Sphere::tangentSpace (:131-137) */
+            const f3 localN = mat3TMul(o.rot, info.Ng);
+            info.T = mat3Mul(o.rot, mk3(-localN.y, localN.x, localN.z));
+            info.B = cross(info.Ns, info.T);
+            info.hasTB = true;
+        }
     }
     if ((M & FEAT_INSTANCES) && hitInst >= 0) {
         /* Instance::intersectionInfo (primitives/Instance.cpp:337-346): normals to world space; info.p -- already the
@@ -1332,7 +1378,69 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         info.Ns = quatRotate(i1.w, xyz(i1), info.Ns);
         info.p = xyz(i0) + quatRotate(i1.w, xyz(i1), info.p);
         info.object = (int)TGHIP_REC_OBJECT(__float_as_uint(i0.w));
+        info.hasTB = false;                            /* Instance::tangentSpace (Instance.cpp:348-351) */
     }
+}
+
+// BitmapTexture::derivatives (textures/BitmapTexture.cpp:359-398) of a scalar bitmap (bump maps are requested as scalars, Bsdf.cpp:24):
+// central differences of the four texels around the lookup, interpolated; constant and checker textures have none
+PT_DEV void textureDerivatives(const DeviceScene &s, int texIdx, float u0, float v0, float &du, float &dv)
+{
+    const TgHipTexture &t = s.textures[texIdx];
+    du = dv = 0.0f;
+    if (t.type != TGHIP_TEX_BITMAP)
+        return;
+    const int w = t.w, h = t.h;
+    float u = u0*w - 0.5f;
+    float v = (1.0f - v0)*h - 0.5f;
+    int iu = (int)u, iv = (int)v;
+    u -= iu; v -= iv;
+    iu = ((iu % w) + w) % w;
+    iv = ((iv % h) + h) % h;
+    int x0 = iu - 1, x1 = iu, x2 = (iu + 1) % w, x3 = (iu + 2) % w;
+    int y0 = iv - 1, y1 = iv, y2 = (iv + 1) % h, y3 = (iv + 2) % h;
+    if (x0 < 0) x0 = w - 1;
+    if (y0 < 0) y0 = h - 1;
+    auto texel = [&](int x, int y) { const f3 c = bitmapTexel(s, t, x, y); return (t.flags & TGHIP_TEXF_RGB) ? (c.x + c.y + c.z)/3.0f : c.x; };
+    const float a01 = texel(x1, y0), a02 = texel(x2, y0);
+    const float a10 = texel(x0, y1), a11 = texel(x1, y1), a12 = texel(x2, y1), a13 = texel(x3, y1);
+    const float a20 = texel(x0, y2), a21 = texel(x1, y2), a22 = texel(x2, y2), a23 = texel(x3, y2);
+    const float a31 = texel(x1, y3), a32 = texel(x2, y3);
+    const float du11 = a12 - a10, du12 = a13 - a11, du21 = a22 - a20, du22 = a23 - a21;
+    const float dv11 = a21 - a01, dv21 = a31 - a11, dv12 = a22 - a02, dv22 = a32 - a12;
+    du = ((du11*(1.0f - u) + du12*u)*(1.0f - v) + (du21*(1.0f - u) + du22*u)*v)*t.scale;
+    dv = ((dv11*(1.0f - u) + dv12*u)*(1.0f - v) + (dv21*(1.0f - u) + dv22*u)*v)*t.scale;
+}
+
+// Primitive::setupTangentFrame (primitives/Primitive.cpp:125-163): the frame of the shading normal -- unless the bsdf carries a non-constant
+// bump map (TgHipBsdf::bump1; FEAT_BUMP variants): then tangent and bitangent come from the primitive's tangent space, tilted by the map's
+// derivatives.  (Anisotropic lobes, the other reason for the long way, belong to the hair bcsdfs.)
+template<uint32_t M>
+PT_DEV Frame shadingFrame(const DeviceScene &s, const Info &info)
+{
+    if constexpr ((M & FEAT_BUMP) != 0u) {
+        const int bump = s.bsdfs[info.bsdf].bump1 - 1;
+        if (bump >= 0 && info.hasTB) {
+            f3 T = info.T, B = info.B, N = info.Ns;
+            float du, dv;
+            textureDerivatives(s, bump, info.u, info.v, du, dv);
+            T = T + info.Ns*(du - dot(info.Ns, T));
+            B = B + info.Ns*(dv - dot(info.Ns, B));
+            N = cross(T, B);
+            if (!(N.x == 0.0f && N.y == 0.0f && N.z == 0.0f)) {
+                if (dot(N, info.Ns) < 0.0f)
+                    N = -N;
+                N = normalized(N);
+                T = T - N*dot(N, T);
+                if (!(T.x == 0.0f && T.y == 0.0f && T.z == 0.0f)) {
+                    Frame f;
+                    f.normal = N; f.tangent = normalized(T); f.bitangent = cross(N, f.tangent);
+                    return f;
+                }
+            }
+        }
+    }
+    return frameFromNormal(info.Ns);
 }
 
 // ---------------------------------------------------------------------------------------------

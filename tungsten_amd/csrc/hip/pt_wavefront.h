@@ -1144,7 +1144,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                 PROF(2);
 
                 // TraceBase::makeLocalScatterEvent (TraceBase.cpp:24-51)
-                Frame frame = frameFromNormal(info.Ns);
+                Frame frame = shadingFrame<M>(s, info);
                 bool hitBackside = dot(frame.normal, ray.d) > 0.0f;
                 bool flipped = s.settings.enable_two_sided_shading && hitBackside && !(lobes & LOBE_TRANSMISSIVE);
                 if (flipped) {

@@ -186,7 +186,8 @@ struct tghip_ctx {
     size_t samplesCap = 0, samplesFloats = 0;
     bool auxPass = false;                 // the pass being rendered keeps them: BSDF_MASK_ALL shading, no fused / dynamic-fetch shadow kernels
     int thrShadeAll = 256;                // workgroup size of k_shade<BSDF_MASK_ALL> (media scenes, TGHIP_PASS_AUX passes)
-    bool haveCylinder = false;            // cylinder primitives: BSDF_MASK_ALL shading (the only FEAT_CYLINDER variant), never fused
+    bool haveCylinder = false;            // cylinder primitives -- or a bump-mapped bsdf (TgHipBsdf::bump1): BSDF_MASK_ALL shading (the only FEAT_CYLINDER /
+                                          // FEAT_BUMP variant), never fused
     bool haveMedia = false;               // participating media: BSDF_MASK_ALL shading (the only FEAT_MEDIA variant), closest-hit shadow walk, never fused
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
@@ -968,6 +969,10 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     ctx->haveCylinder = false;
     for (uint32_t i = 0; i < sd->num_objects; ++i)
         if (sd->objects[i].type == TGHIP_OBJ_CYLINDER) ctx->haveCylinder = true;
+    for (uint32_t i = 0; i < sd->num_bsdfs; ++i) {
+        if (sd->bsdfs[i].bump1 < 0 || uint32_t(sd->bsdfs[i].bump1) > sd->num_textures) { ctx->error = "bsdf bump map index out of range"; return TGHIP_E_INVALID; }
+        if (sd->bsdfs[i].bump1 > 0) ctx->haveCylinder = true;      // (shaded by the same one variant)
+    }
     if (ctx->haveMedia) {
         if (!sd->media || sd->num_media > PT_MAX_MEDIA) { ctx->error = "more than 126 media are not supported"; return TGHIP_E_UNSUPPORTED; }
         if (sd->num_objects >= (1u << 16)) { ctx->error = "media scenes support at most 65535 primitives"; return TGHIP_E_UNSUPPORTED; }

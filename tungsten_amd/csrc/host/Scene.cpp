@@ -435,18 +435,23 @@ static std::shared_ptr<Texture> constantTexture(float v)
 
 std::shared_ptr<Texture> Scene::fetchTexture(const JsonValue &v, bool rgb, bool autoAlpha) const
 {
-    if (v.isString()) {
-        std::string full = _srcDir.empty() ? v.asString() : _srcDir + "/" + v.asString();
-        std::string key = full + (rgb ? "|rgb" : autoAlpha ? "|auto" : "|avg");
+    // TextureCache::fetchTexture (io/TextureCache.cpp:15-39): bitmaps are shared by (file, texel conversion, gamma_correct, interpolate, clamp)
+    // -- BitmapTexture::operator< (textures/BitmapTexture.hpp:153-163) does NOT look at "scale", so of two bitmaps that differ only in their
+    // scale the one fetched first serves both.  Reproduced as it is.
+    auto cached = [&](const std::shared_ptr<Texture> &t) -> std::shared_ptr<Texture> {
+        const std::string key = t->path + (rgb ? "|rgb" : autoAlpha ? "|auto" : "|avg") + (t->gammaCorrect ? "|g" : "|-") + (t->linear ? "|l" : "|-") + (t->clamp ? "|c" : "|-");
         for (auto &kv : _textureCache)
             if (kv.first == key) return kv.second;
+        _textureCache.emplace_back(key, t);
+        return t;
+    };
+    if (v.isString()) {
         auto t = std::make_shared<Texture>();
         t->type = Texture::Bitmap;
         t->rgb = rgb;
         t->autoAlpha = autoAlpha && !rgb;
-        t->path = full;
-        _textureCache.emplace_back(key, t);
-        return t;
+        t->path = _srcDir.empty() ? v.asString() : _srcDir + "/" + v.asString();
+        return cached(t);
     } else if (v.isNumber()) {
         return constantTexture(v.asFloat());
     } else if (v.isArray()) {
@@ -478,7 +483,7 @@ std::shared_ptr<Texture> Scene::fetchTexture(const JsonValue &v, bool rgb, bool 
             v.getField("interpolate", t->linear);
             v.getField("clamp", t->clamp);
             v.getField("scale", t->scale);
-            _textureCache.emplace_back(t->path + "|inline" + std::to_string(_textureCache.size()), t);
+            return cached(t);
         } else {
             throw JsonLoadException("Texture type '" + type + "' is outside the path_tracer_hip hot-path scope");
         }
@@ -492,16 +497,15 @@ std::shared_ptr<Bsdf> Scene::instantiateBsdf(const JsonValue &v) const
     auto b = std::make_shared<Bsdf>();
     std::string type = v["type"].asString();
     v.getField("name", b->name);
-    // Bsdf::fromJson (Bsdf.cpp:19-25).  A constant bump texture changes nothing (Primitive::setupTangentFrame ignores it,
-    // Primitive.cpp:130); a varying one perturbs the shading frame (:139-152), which this integrator does not do: refuse it
-    // rather than render the surface unperturbed.
+    // Bsdf::fromJson (Bsdf.cpp:19-25): scalar request.  A constant bump texture changes nothing (Primitive::setupTangentFrame ignores it,
+    // Primitive.cpp:128-131); a varying one sends the shading frame through the primitive's tangent space and the map's derivatives (:133-162)
+    if (const JsonValue &albedo = v["albedo"]) b->albedo = fetchTexture(albedo, true);
+    else b->albedo = constantTexture(1.0f);
     if (const JsonValue &bump = v["bump"]) {
         std::shared_ptr<Texture> t = fetchTexture(bump, false);
         if (t && t->type != Texture::Constant)
-            throw JsonLoadException("bsdf '" + b->name + "': bump maps are outside the path_tracer_hip hot-path scope");
+            b->bump = t;
     }
-    if (const JsonValue &albedo = v["albedo"]) b->albedo = fetchTexture(albedo, true);
-    else b->albedo = constantTexture(1.0f);
 
     auto parseConductor = [&]() {
         Vec3f eta, k;

@@ -60,6 +60,7 @@ struct Bsdf
     Type type = Lambert;
     unsigned lobes = 0;
     std::shared_ptr<Texture> albedo, roughness, tex1;
+    std::shared_ptr<Texture> bump;              // a non-constant bump map (Bsdf::_bump), else null
     std::shared_ptr<Bsdf> sub0, sub1;
     int distribution = 2;                       // 0 beckmann, 1 phong, 2 ggx
     float ior = 1.5f, thickness = 1.0f;

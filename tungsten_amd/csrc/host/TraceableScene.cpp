@@ -168,6 +168,7 @@ void TraceableScene::flatten()
         d.sub0 = addBsdf(b->sub0);
         d.sub1 = addBsdf(b->sub1);
         d.tex1 = addTexture(b->tex1);
+        d.bump1 = b->bump ? addTexture(b->bump) + 1 : 0;
         d.ior = b->ior; d.thickness = b->thickness;
         d.avg_transmittance = b->avgTransmittance;
         d.diffuse_fresnel = b->diffuseFresnel;
