@@ -169,8 +169,6 @@ int32_t HipSceneFlattener::addBsdf(const Bsdf *b)
     if (!b) return -1;
     auto it = _bsdfIndex.find(b);
     if (it != _bsdfIndex.end()) return it->second;
-    if (b->_bump && !b->_bump->isConstant())
-        refuse("a bump-mapped bsdf");
     const int32_t idx = int32_t(_bsdfs.size());
     _bsdfIndex[b] = idx;
     _bsdfs.emplace_back();
@@ -242,6 +240,8 @@ int32_t HipSceneFlattener::addBsdf(const Bsdf *b)
     } else {
         refuse("a bsdf of a type the device has no code for");
     }
+    // a non-constant bump map: Primitive::setupTangentFrame then goes through the primitive's tangent space (Primitive.cpp:125-163)
+    d.bump1 = (b->_bump && !b->_bump->isConstant()) ? addTexture(b->_bump.get()) + 1 : 0;
     _bsdfs[size_t(idx)] = d;
     return idx;
 }

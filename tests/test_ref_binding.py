@@ -85,6 +85,8 @@ CASES = {
     "zoo_a": lambda tmp: scenes.GOLDEN_CASES["zoo_a"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_a"][1], resolution=(96, 54), spp=2)),
     "zoo_b": lambda tmp: scenes.GOLDEN_CASES["zoo_b"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_b"][1], resolution=(96, 54), spp=2)),
     # the procedural sky: the reference-side flattener hands over the image Tungsten's own Skydome baked, the own loader bakes it itself
+    # bump-mapped bsdfs sharing one .png at several scales: the reference's TextureCache decides which scale serves them all
+    "bump": lambda tmp: scenes.GOLDEN_CASES["cornell_bump"][0](tmp, **dict(scenes.GOLDEN_CASES["cornell_bump"][1], resolution=(96, 54), spp=2)),
     "skydome": lambda tmp: scenes.GOLDEN_CASES["cornell_skydome"][0](tmp, **dict(scenes.GOLDEN_CASES["cornell_skydome"][1], resolution=(96, 54), spp=2)),
 }
 
