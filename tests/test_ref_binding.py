@@ -110,7 +110,7 @@ def test_reference_side_flattener_builds_the_scene_the_own_loader_builds(case, t
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["cornell", "cornell_as_shipped_sampler", "materialtest", "skydome"])
+@pytest.mark.parametrize("case", ["cornell", "cornell_as_shipped_sampler", "materialtest", "skydome", "bump"])
 def test_reference_program_with_the_plugin_writes_the_image_of_the_own_host(case, tmp_path):
     """tungsten (the reference's program) with "type": "path_tracer_hip" against tungsten_hip (this repository's CLI) on the same
     scene, seed and spp: the .pfm files are identical bit for bit."""
