@@ -13,7 +13,7 @@ flattened and uploaded before the timed region (inputs resident in HBM); the fra
 Workload at every N: the configuration BASELINE.json's metric is quoted on -- materialtest.json (the reference's shipped
 scene: three meshes, 80 768 triangles, smooth_coat over rough_conductor, HDRI environment + MIS) at 1280x720, 256 spp,
 uniform sampler, adaptive sampling off (fixed total work => "scaling": "strong").  At N = 1 the same line carries, under
-"extra", BASELINE configs[1] (Cornell box 1280x720 at 256 spp, a flat-list scene without BVH traversal); `--scene cornell`
+"extra", BASELINE configs[1] (Cornell box 1280x720 at 256 spp, a flat-list scene without BVH traversal) and materialtest as the reference ships it (Sobol + adaptive, 64 spp in 16-spp passes); `--scene cornell`
 makes that the headline workload instead.  Without the materialtest assets (oracle/_ref/data, copied from the reference's
 data directory by __graft_entry__.build()) the default run FAILS: there is no silent fallback to another workload.
 
@@ -97,6 +97,25 @@ def kernel_bytes(c, flat, fused, node_b=64, node_b_shadow=None, fold_finish=Fals
         # shadow records a vertex emits
         "k_shade": paths*(STATE_R + HIT_B + STATE_W) + alive*(RAY_B + 8) + c["shadow_slots"]*(16 + 64 + 16 + 16),
     }
+
+
+def as_shipped(tmp, tg_mod, repeats=3):
+    import scenes
+    path = scenes.materialtest(tmp, name="as_shipped.json", resolution=(1280, 720), spp=64, spp_step=16,
+                               renderer={"adaptive_sampling": True, "stratified_sampler": True})
+    best = None
+    for _ in range(repeats):
+        r = tg_mod.Renderer(path)
+        secs = r.render()
+        c = r.counters()
+        mean, _, count = r.image()
+        r.close()
+        res = {"value": round(c.samples/secs*1e-6, 2), "unit": "Msamples/s", "seconds": round(secs, 4), "samples": int(c.samples), "passes": 4,
+               "count_min": int(count.min()), "count_max": int(count.max()), "sampler": "sobol", "adaptive_sampling": True,
+               "image_mean": [round(float(v), 6) for v in mean.mean(axis=(0, 1))]}
+        if best is None or res["seconds"] < best["seconds"]:
+            best = res
+    return best
 
 
 def counters_dict(c):
@@ -573,6 +592,12 @@ def main():
             if b.rank == 0:
                 keys = ("value", "ms_per_step", "config", "roofline", "kernels", "rays_per_sample", "prims_per_ray", "bvh", "result_ok")
                 extra = {"cornell_1280x720_256spp": dict({k: m[k] for k in keys}, unit="Msamples/s", steps=2, warmup=1)}
+                # and the metric's scene AS THE REFERENCE SHIPS IT: Sobol' sampler + adaptive sampling in 16-spp passes through the whole
+                # integrator loop (host scheduler between the passes included), 64 spp, best of three renderers (tools/bench_as_shipped.py)
+                try:
+                    extra["materialtest_as_shipped_1280x720_64spp"] = as_shipped(b.tmp, tg_mod=b.tg)
+                except Exception as e:       # (never takes the headline line down)
+                    extra["materialtest_as_shipped_1280x720_64spp"] = {"error": str(e)}
         if b.rank == 0:
             out = {"metric": "Msamples/s (W*H*spp/s), path_tracer render loop", "value": res["value"], "unit": "Msamples/s",
                    "n_gpus": b.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
