@@ -246,6 +246,21 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_fog", "cornell_smoke", "cornell_fog_smoke_sobol", "cornell_fog_rayleigh", "cornell_fog_davis",
+                                  "volumetric_caustic", "non_exponential_linear", "non_exponential_area_lights"])
+def test_lean_media_shading_variant_is_the_full_one(name, tmp_path):
+    """Media scenes whose surfaces are Lambert / null / forward / dielectric / mirror are shaded by k_shade<MASK_MEDIA> (no scratch) instead
+    of k_shade<BSDF_MASK_ALL>: a narrower instantiation of the same shadeBody -- the same image bit for bit, the same rays."""
+    mk, kw = scenes.GOLDEN_CASES[name]
+    path = mk(tmp_path, name=name + ".json", **dict(kw, resolution=(160, 90)))
+    full, _, cf, kf = gpu_render(path, media_lean=0)
+    lean, _, cl, kl = gpu_render(path, media_lean=1)
+    assert (cf == cl).all() and np.isfinite(full).all()
+    assert (full == lean).all()
+    assert (kf.closest_rays, kf.shadow_rays, kf.samples) == (kl.closest_rays, kl.shadow_rays, kl.samples)
+
+
+@pytest.mark.gpu
 def test_tail_kernel_traces_the_rays_the_loop_traces(tmp_path):
     """k_tail (one launch per part in which every workgroup iterates over its own slots) against the launch-per-step loop: the same image,
     the same samples, the same closest-hit and shadow rays -- entered at the first host check, and half way through the render."""

@@ -19,6 +19,8 @@ for name, edit in (("cornell", None), ("cornell_fog", scenes._fog), ("cornell_sm
     warm.close()
     path = scenes.cornell(tmp, name=name + ".json", resolution=(1280, 720), spp=spp, edit=edit)
     r = tg.Renderer(path, seed=tg.DEFAULT_SEED)
+    for kv in sys.argv[2:]:          # option=value pairs, e.g. media_lean=0
+        r.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     secs = r.render()
     c = r.counters()
     r.close()

@@ -1796,47 +1796,35 @@ PT_DEV int chooseLight(const DeviceScene &s, Rng &rng, f3 p, float &weight)
     if (n == 0) return -1;
     if (!(M & FEAT_MULTILIGHT) || n == 1) { weight = 1.0f; return s.lights[0]; }
     n = min(n, 16);
-    if (M & FEAT_MESHLIGHT) {
-        // mesh emitters answer "unknown" (-1) and receive the mean of the known weights (TraceBase.cpp:434-446).  The
-        // reference fills a pdf array in order; here the weights are re-evaluated instead of stored per lane.
-        float total = 0.0f;
-        int numNonNegative = 0;
-        for (int i = 0; i < n; ++i) {
-            float w = lightApproximateRadiance<M>(s, s.lights[i], p);
-            if (w >= 0.0f) { total += w; numNonNegative++; }
-        }
-        const bool allUnknown = numNonNegative == 0;
-        float knownTotal = total;
-        if (allUnknown) {
-            total = (float)n;
-        } else if (numNonNegative < n) {
-            for (int i = 0; i < n; ++i)
-                if (lightApproximateRadiance<M>(s, s.lights[i], p) < 0.0f)
-                    total += (total == 0.0f ? 1.0f : total)/numNonNegative;   // uses the running total, like the reference's loop
-        }
-        if (total == 0.0f) return -1;
-        float t = RNG1D(rng)*total;
-        float running = knownTotal;
-        for (int i = 0; i < n; ++i) {
-            float w = lightApproximateRadiance<M>(s, s.lights[i], p);
-            float pdf;
-            if (allUnknown) pdf = 1.0f;
-            else if (w < 0.0f) { pdf = (running == 0.0f ? 1.0f : running)/numNonNegative; running += pdf; }
-            else pdf = w;
-            if (t < pdf || i == n - 1) { weight = total/pdf; return s.lights[i]; }
-            t -= pdf;
-        }
-        return -1;
-    }
-    // Without mesh emitters approximateRadiance is never negative ("unknown"), so the uniform-share branch cannot
-    // trigger.  Two passes over the lights instead of a per-lane pdf array (which would live in scratch).
+    // Lights that answer "unknown" (a negative weight) receive the mean of the known weights (TraceBase.cpp:434-446): mesh and cylinder
+    // emitters always do (-1), and a quad does whenever its solid angle -- 2 pi minus four arc cosines, Quad.cpp:253-281 -- rounds to
+    // less than zero, which the few-mm emitters of the shipped non-exponential scene reach in about one light sample in 10^5.  Every
+    // variant therefore runs the full rule.  The reference fills a pdf array in order; here the weights are re-evaluated instead of
+    // stored per lane (a second time only when some light answered "unknown").
     float total = 0.0f;
-    for (int i = 0; i < n; ++i)
-        total += lightApproximateRadiance<M>(s, s.lights[i], p);
+    int numNonNegative = 0;
+    for (int i = 0; i < n; ++i) {
+        float w = lightApproximateRadiance<M>(s, s.lights[i], p);
+        if (w >= 0.0f) { total += w; numNonNegative++; }
+    }
+    const bool allUnknown = numNonNegative == 0;
+    float knownTotal = total;
+    if (allUnknown) {
+        total = (float)n;
+    } else if (numNonNegative < n) {
+        for (int i = 0; i < n; ++i)
+            if (lightApproximateRadiance<M>(s, s.lights[i], p) < 0.0f)
+                total += (total == 0.0f ? 1.0f : total)/numNonNegative;   // uses the running total, like the reference's loop
+    }
     if (total == 0.0f) return -1;
     float t = RNG1D(rng)*total;
+    float running = knownTotal;
     for (int i = 0; i < n; ++i) {
-        float pdf = lightApproximateRadiance<M>(s, s.lights[i], p);
+        float w = lightApproximateRadiance<M>(s, s.lights[i], p);
+        float pdf;
+        if (allUnknown) pdf = 1.0f;
+        else if (w < 0.0f) { pdf = (running == 0.0f ? 1.0f : running)/numNonNegative; running += pdf; }
+        else pdf = w;
         if (t < pdf || i == n - 1) { weight = total/pdf; return s.lights[i]; }
         t -= pdf;
     }

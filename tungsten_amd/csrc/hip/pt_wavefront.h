@@ -65,6 +65,10 @@
 #define MASK_GLASS   (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC) | \
                       BSDF_BIT(TGHIP_BSDF_MIRROR))
 #define MASK_PLASTIC (MASK_SIMPLE | BSDF_BIT(TGHIP_BSDF_PLASTIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_PLASTIC))
+/* media scenes whose surfaces are Lambert / null / forward / (smooth) dielectric / mirror -- every media scene the reference ships and the
+   fog / smoke goldens: 216 VGPRs without scratch where BSDF_MASK_ALL spills 292 registers to 848 B of scratch.  (Always the FEAT_QMC twin:
+   media passes carry PT_PASS_MEDIA in their flags.) */
+#define MASK_MEDIA   (MASK_SIMPLE | FEAT_MEDIA | FEAT_QMC | BSDF_BIT(TGHIP_BSDF_FORWARD) | BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_MIRROR))
 #define MASK_TAIL    (MASK_FULL & ~(FEAT_INSTANCES | FEAT_MESHLIGHT))   /* k_tail: every BSDF type, single-level scenes without mesh emitters */
 /* the class variants of scenes with instance records (no mesh emitters): hits reached through an instance (FEAT_INSTANCES) */
 #define MASK_COAT_INST    (MASK_COAT | FEAT_INSTANCES)

@@ -48,6 +48,7 @@ extern template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 0>(DeviceScen
 extern template __global__ void k_shade<MASK_FULL, 2, 2>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<BSDF_MASK_ALL, 2, 0>(DeviceScene, PathState, PassParams, int);
+extern template __global__ void k_shade<MASK_MEDIA, 2, 0>(DeviceScene, PathState, PassParams, int);   // shade_media.hip
 // k_tail: tail.hip
 extern template __global__ void k_tail<MASK_TAIL, false>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<MASK_TAIL, true>(DeviceScene, PathState, PassParams, uint32_t);
@@ -115,6 +116,8 @@ struct tghip_ctx {
     // k_tail (one launch per part: every workgroup iterates over its own slots until they are done).  The kernel is built for latency, not
     // throughput (one shading variant for every class, one wave per SIMD): measured, Msamples/s for thresholds off / 2 Ki / 8 Ki / 32 Ki / 128 Ki:
     // mesh1m 605 / 625 / 611 / 575 / 514, materialtest 963 / 966 / 964 / 968 / 966, materialtest as shipped 573 / 611 / 630 / 623 / 625
+    bool mediaSimple = false;             // a media scene whose surface BSDFs MASK_MEDIA covers (no instances, no mesh emitters)
+    bool mediaLeanOpt = true;             // "media_lean": shade such scenes with k_shade<MASK_MEDIA> instead of <BSDF_MASK_ALL>
     bool foldFinishOpt = true;            // "fold_finish"
     bool mergeMissOpt = true;             // "merge_miss"
     bool tailOpt = true;
@@ -833,6 +836,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "tail_kernel") ctx->tailOpt = value != 0;
     else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
     else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
+    else if (k == "media_lean") ctx->mediaLeanOpt = value != 0;
     else if (k == "tail_threshold") ctx->tailThreshold = value;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1103,6 +1107,11 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             ctx->classMask[c] |= tm;
             if (c != 0) { ctx->haveComplex = true; ctx->complexMask |= tm; }
         }
+        {
+            uint32_t allTypes = 0;
+            for (int c = 0; c < PT_NUM_CLASSES; ++c) allTypes |= ctx->classMask[c];
+            ctx->mediaSimple = ctx->haveMedia && !ctx->haveInstances && (allTypes & ~MASK_MEDIA & 0x3FFFu) == 0;   // (bits 0 .. 13: the BSDF types)
+        }
         bool lean = sd->num_infinite_lights == 0 && sd->num_lights <= 1;
         for (uint32_t i = 0; i < sd->num_textures && lean; ++i) lean = sd->textures[i].type != TGHIP_TEX_BITMAP;
         for (uint32_t i = 0; i < sd->num_recs && lean; ++i)
@@ -1186,7 +1195,7 @@ static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, co
 {
     constexpr uint32_t B = M & ~FEAT_QMC;
     hipLaunchKernelGGL((k_shade<M, ((B == MASK_SIMPLE || B == MASK_SIMPLE_INST) ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
-                       dim3(M == BSDF_MASK_ALL ? ctx->thrShadeAll : (cls >= 1 && cls < PT_NUM_CLASSES) ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->launchStream, ctx->scene, st, pp, cls);
+                       dim3((M == BSDF_MASK_ALL || M == MASK_MEDIA) ? ctx->thrShadeAll : (cls >= 1 && cls < PT_NUM_CLASSES) ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->launchStream, ctx->scene, st, pp, cls);
 }
 // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
 template<uint32_t M, int FUSE = 0>
@@ -1427,7 +1436,9 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             // for 2 to 24 hardware queues): with four parts in flight the chip is not short of independent launches.
             auto shadeClass = [&](int cls) {
                 const bool simple = cls == 0 || cls == CLS_MISS || cls == CLS_0_AND_MISS;
-                if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, cls);   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER
+                if (ctx->mediaSimple && ctx->mediaLeanOpt && !ctx->auxPass && !ctx->haveCylinder && !ctx->haveMeshLight)
+                    launchShadeVariant<MASK_MEDIA, 0>(ctx, grid, st, pp, cls);                      // media scenes with simple surfaces: no scratch
+                else if (ctx->haveMedia || ctx->auxPass || ctx->haveCylinder) launchShadeVariant<BSDF_MASK_ALL, 0>(ctx, grid, st, pp, cls);   // the one variant with FEAT_MEDIA / FEAT_AUX / FEAT_CYLINDER
                 else if (ctx->haveMeshLight) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);   // the only variant with mesh-emitter sampling (every BSDF type)
                 else if (ctx->haveInstances && simple && ctx->instSimpleOpt) launchShade<MASK_SIMPLE_INST>(ctx, grid, st, pp, cls);   // Lambert / escaped paths of instanced scenes
                 else if (ctx->haveInstances && (simple || !ctx->instSimpleOpt)) launchShade<MASK_FULL>(ctx, grid, st, pp, cls);
