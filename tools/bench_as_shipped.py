@@ -49,6 +49,9 @@ def main():
         res = {"scene": a.scene, "width": a.width, "height": a.height, "spp": a.spp, "spp_step": a.spp_step,
                "sobol": not a.no_sobol, "adaptive": not a.no_adaptive, "samples": int(c.samples), "seconds": round(secs, 4),
                "wall_seconds": round(wall, 4), "msamples_per_s": round(c.samples/secs*1e-6, 2),
+               "mrays_per_s": round((c.closest_rays + c.shadow_rays)/secs*1e-6, 1),
+               "closest_rays_per_sample": round(c.closest_rays/max(c.samples, 1), 4), "shadow_rays_per_sample": round(c.shadow_rays/max(c.samples, 1), 4),
+               "iterations": int(c.iterations), "tail_launches": int(c.tail_launches),
                "count_min": int(count.min()), "count_max": int(count.max()), "image_mean": [round(float(v), 6) for v in mean.mean(axis=(0, 1))]}
         if best is None or res["seconds"] < best["seconds"]:
             best = res

@@ -744,7 +744,13 @@ void tghip_destroy(tghip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    // every stream idle before the first buffer goes (the part / class streams join the main one at the end of a pass, an aborted or
+    // failed pass may have left them behind)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int k = 0; k < 7; ++k) if (ctx->partStream[k]) (void)hipStreamSynchronize(ctx->partStream[k]);
+    for (int k = 0; k < 8; ++k)
+        for (int a = 0; a < 2; ++a) if (ctx->classStream[k][a]) (void)hipStreamSynchronize(ctx->classStream[k][a]);
+    if (ctx->abortStream) (void)hipStreamSynchronize(ctx->abortStream);
     ctx->sceneMem.release();
     ctx->poolMem.release();
     ctx->extMem.release();
@@ -771,18 +777,16 @@ void tghip_destroy(tghip_ctx *ctx)
         if (ctx->evFork[k]) (void)hipEventDestroy(ctx->evFork[k]);
         for (int a = 0; a < 2; ++a) {
             if (ctx->evJoin[k][a]) (void)hipEventDestroy(ctx->evJoin[k][a]);
-            if (ctx->classStream[k][a]) { (void)hipStreamSynchronize(ctx->classStream[k][a]); (void)hipStreamDestroy(ctx->classStream[k][a]); }
+            if (ctx->classStream[k][a]) (void)hipStreamDestroy(ctx->classStream[k][a]);
         }
     }
     {
-        // the streams go back to the device's free list (idle: the main stream was synchronised above, the others are waited for here)
+        // the streams go back to the device's free list (idle: synchronised above)
         StreamSet set;
         set.main = ctx->stream; set.abort = ctx->abortStream;
         bool complete = set.main != nullptr && set.abort != nullptr;
         for (int k = 0; k < 7; ++k) { set.part[k] = ctx->partStream[k]; complete = complete && set.part[k] != nullptr; }
         if (complete) {
-            for (int k = 0; k < 7; ++k) (void)hipStreamSynchronize(set.part[k]);
-            (void)hipStreamSynchronize(set.abort);
             std::lock_guard<std::mutex> lock(g_streamMutex);
             g_freeStreams[ctx->device].push_back(set);
         } else {                                 // (a context whose creation failed half way)
