@@ -2,6 +2,7 @@
 #   tungsten_amd/lib/libtungsten_hip.so   product: C++11 host side + HIP kernels + extern "C" shim (gfx950)
 #   tungsten_amd/lib/tungsten_hip         product: CLI (same role as the reference's `tungsten` binary)
 #   oracle/liboracle.so                   TEST INFRASTRUCTURE: CPU restatement (never linked by the product)
+#   oracle/libm_host.so                   TEST INFRASTRUCTURE: csrc/hip/pt_libm.h compiled for the host (checked against the host libm)
 #   oracle/_ref/*                         TEST INFRASTRUCTURE: the reference itself (only where /root/reference exists)
 HIPCC    ?= hipcc
 CC       ?= gcc
@@ -24,7 +25,7 @@ FPFLAGS  := $(if $(TG_FAST),-ffp-contract=fast,-ffp-contract=off)
 HOSTFLAGS:= -std=c++11 -O2 -fPIC -Wall -Wextra -Wno-unused-parameter
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -Wno-unused-result $(if $(PROFILE),-DPT_PROFILE,)
 
-all: $(LIBDIR)/$(LIBNAME) $(if $(PROFILE),,$(LIBDIR)/tungsten_hip oracle/liboracle.so)
+all: $(LIBDIR)/$(LIBNAME) $(if $(PROFILE),,$(LIBDIR)/tungsten_hip oracle/liboracle.so oracle/libm_host.so)
 
 $(OBJDIR)/host_%.o: tungsten_amd/csrc/host/%.cpp $(wildcard tungsten_amd/csrc/host/*.hpp) include/tungsten_hip.h include/tungsten_host.h
 	@mkdir -p $(OBJDIR)
@@ -44,11 +45,14 @@ $(LIBDIR)/tungsten_hip: tungsten_amd/csrc/host/main.cpp $(LIBDIR)/libtungsten_hi
 oracle/liboracle.so: oracle/oracle.c include/tungsten_hip.h
 	$(CC) -std=c99 -O2 -ffp-contract=off -fopenmp -fPIC -shared $< -o $@ -lm
 
+oracle/libm_host.so: oracle/libm_host.cpp tungsten_amd/csrc/hip/pt_libm.h
+	$(CXX) -std=c++17 -O2 -ffp-contract=off -mfma -fopenmp -fPIC -shared $< -o $@ -lm
+
 # the reference itself, only where its sources are mounted
 ref:
 	@if [ -d /root/reference/src ]; then $(MAKE) -f oracle/Makefile.ref -j$$(nproc) all; else echo "no /root/reference: keeping prebuilt oracle/_ref"; fi
 
 clean:
-	rm -rf build $(LIBDIR) oracle/liboracle.so
+	rm -rf build $(LIBDIR) oracle/liboracle.so oracle/libm_host.so
 
 .PHONY: all ref clean

@@ -172,6 +172,17 @@ def _two_lights(scene):
                                 "transform": {"position": [-0.98, 0.6, 0.2], "scale": [0.3, 0.3, 0.3], "rotation": [0, 0, -90]}})
 
 
+def _speck_lights(scene):
+    """Two more quad emitters a quarter of a millimetre across, next to `light2`: from most of the box their solid angle (1e-8 sr) is
+    below the last bit of the 2 pi that Quad::approximateRadiance subtracts four arc cosines from (Quad.cpp:253-281), so the weight
+    chooseLight gets for them is rounding noise of either sign -- and a NEGATIVE weight means "unknown": the light receives the mean
+    of the known weights (TraceBase.cpp:434-446).  3.3 % of the light choices of this case (264 of 8 000 in the golden) take that branch."""
+    _two_lights(scene)
+    for i, (pos, rot) in enumerate((([0.4, 1.2, -0.3], [0, 0, 180]), ([-0.97, 1.0, -0.5], [0, 0, -90]))):
+        scene["primitives"].append({"name": "speck%d" % i, "type": "quad", "bsdf": "light", "emission": [4e6, 3e6, 2e6],
+                                    "transform": {"position": pos, "scale": [2.5e-4, 2.5e-4, 2.5e-4], "rotation": rot}})
+
+
 def cornell_mesh_light(tmpdir, big=True, **kw):
     """Cornell box whose quad light is replaced by an emissive triangle mesh (sampled: TriangleMesh::sampleDirect,
     TriangleMesh.cpp:411-473): a 168-triangle blob (BVH traversal) or a 2-triangle panel (flat-list traversal)."""
@@ -225,6 +236,7 @@ GOLDEN_CASES = {
     "cornell_onesided": (cornell, dict(resolution=(32, 18), spp=8, integrator={"enable_two_sided_shading": False})),
     "cornell_box_filter": (cornell, dict(resolution=(32, 18), spp=8, edit=lambda s: s["camera"].update(reconstruction_filter="box"))),
     "cornell_two_lights": (cornell, dict(resolution=(32, 18), spp=8, edit=_two_lights)),
+    "cornell_speck_lights": (cornell, dict(resolution=(32, 18), spp=8, edit=_speck_lights)),
     "cornell_many_cubes": (cornell, dict(resolution=(32, 18), spp=8, edit=_many_cubes)),
     "cornell_mesh_light": (cornell_mesh_light, dict(resolution=(32, 18), spp=8)),
     "cornell_mesh_light_flat": (lambda t, **kw: cornell_mesh_light(t, big=False, **kw), dict(resolution=(32, 18), spp=8)),

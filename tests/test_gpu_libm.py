@@ -1,0 +1,55 @@
+"""The device's libm (csrc/hip/pt_libm.h, pt_math.h: sinfH / cosfH / sincosfH / logfH / expfH / acosfExact -- glibc's algorithms restated)
+evaluated ON THE DEVICE through tghip_debug_libm against the host libm, bit for bit, on the arguments the kernels produce: angles
+2 pi xi and pi v, 1 - xi for the logarithm, negative optical depths for the exponential, cosines for the arc cosine."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+import tungsten_amd as tg
+from tungsten_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _host():
+    lib = C.CDLL(os.path.join(scenes.ROOT, "oracle", "libm_host.so"))
+    lib.libm_host_ref.restype = None
+    lib.libm_host_ref.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    return lib
+
+
+def test_device_libm_is_the_host_libm_bit_for_bit(tmp_path):
+    if "fma" not in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split():
+        pytest.skip("host CPU without FMA3: glibc runs its non-FMA variants here")
+    host = _host()
+    r = tg.Renderer(scenes.cornell(tmp_path, resolution=(16, 16), spp=1))
+    rng = np.random.default_rng(11)
+    n = 1 << 21
+    xi = rng.random(n, dtype=np.float32)
+    grid = (np.arange(n, dtype=np.float32) + 0.5)/n            # every 2^-21 of [0, 1): the quadrant boundaries of 2 pi xi
+    two_pi, pi = np.float32(3.1415926536*2), np.float32(3.1415926536)
+    cases = [
+        (capi.TGHIP_LIBM_SINF, [xi*two_pi, grid*two_pi, xi*pi, (xi - np.float32(0.5))*two_pi, xi*np.float32(1e-3), xi*np.float32(119.0), -xi*np.float32(119.0)]),
+        (capi.TGHIP_LIBM_COSF, [xi*two_pi, grid*two_pi, xi*pi, (xi - np.float32(0.5))*two_pi, xi*np.float32(1e-3), xi*np.float32(119.0), -xi*np.float32(119.0)]),
+        (capi.TGHIP_LIBM_SINCOS_SIN, [xi*two_pi, grid*two_pi, xi*pi, -xi*two_pi]),
+        (capi.TGHIP_LIBM_SINCOS_COS, [xi*two_pi, grid*two_pi, xi*pi, -xi*two_pi]),
+        (capi.TGHIP_LIBM_LOGF, [np.float32(1.0) - xi, np.float32(1.0) - grid, xi + np.float32(1e-30), xi*np.float32(1e30) + np.float32(1e-30), np.float32(1.0) + xi*np.float32(50.0)]),
+        (capi.TGHIP_LIBM_EXPF, [-xi*np.float32(87.9), xi*np.float32(87.9), -xi, -xi*np.float32(1e-4), -grid*np.float32(20.0)]),
+        (capi.TGHIP_LIBM_ACOSF, [xi*np.float32(2.0) - np.float32(1.0), np.float32(1.0) - xi*np.float32(1e-4), grid*np.float32(2.0) - np.float32(1.0)]),
+    ]
+    for fn, arrays in cases:
+        for x in arrays:
+            x = np.ascontiguousarray(x, np.float32)
+            got = r.debug_libm(fn, x)
+            want = np.empty_like(x)
+            host.libm_host_ref(fn, x.ctypes.data, want.ctypes.data, x.size)
+            bad = got.view(np.uint32) != want.view(np.uint32)
+            assert not bad.any(), "fn %d: %d of %d differ, first x = %r: device %r, host %r" % (fn, int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
+    # outside the restated ranges the kernels still answer sensibly (no call site gets there): sin / cos to float accuracy, exp(-inf) = 0
+    big = np.array([150.0, -1e4, 3e5], np.float32)
+    assert np.allclose(r.debug_libm(capi.TGHIP_LIBM_SINF, big), np.sin(big.astype(np.float64)), atol=2e-2)
+    assert (r.debug_libm(capi.TGHIP_LIBM_EXPF, np.array([-np.inf, -200.0], np.float32)) == 0.0).all()
+    r.close()

@@ -20,18 +20,17 @@ pytestmark = pytest.mark.gpu
 SEED = tg.DEFAULT_SEED
 TABLE = os.environ.get("TG_DIVERGE_TABLE")     # when set: append one JSON line per case (tools/gpu_session scripts)
 
-# Fraction of device samples allowed to leave the reference's path.  The device differs from the oracle's glibc arithmetic in
-# sinf / cosf / atan2f / powf / logf (ocml; acosf and the media's exp are restated exactly, pt_math.h), which is where paths fork
-# beyond the oracle's own forks (coincident surfaces, Embree's rcp + Newton division): each bound below is the oracle's bound for the case (tests/
-# test_oracle_golden.py: DIVERGE) plus a margin for those functions.
+# Fraction of device samples allowed to leave the reference's path.  The device evaluates glibc's own sinf / cosf / logf / expf / acosf
+# (csrc/hip/pt_libm.h, pt_math.h: the algorithms restated and matched bit for bit, tests/test_gpu_libm.py) and differs from the oracle's
+# arithmetic in atan2f / powf / cbrtf (ocml), which is where paths fork beyond the oracle's own forks (coincident surfaces, Embree's
+# rcp + Newton division): each bound below is the oracle's bound for the case (tests/test_oracle_golden.py: DIVERGE) plus a margin for those.
 def device_bound(name):
-    ill = name.startswith("non_exponential") and "area_lights" not in name
-    if ill:
-        # chooseLight's selection weights move by several per cent with the last bit of acosf on the 4.7 x 3.8 mm emitters
-        # (Quad::approximateRadiance, Quad.cpp:253-281): with ocml's acosf a third of the samples landed outside 1e-3 (round 2:
-        # 0.336-0.345).  The device now evaluates glibc's acosf itself (pt_math.h: acosfExact, the fdlibm float algorithm, bit for
-        # bit): 0.9-2.1 % measured, what is left being ocml's atan2f / sinf / cosf / powf in the same ill-conditioned weights.
-        return 0.03
+    if name == "non_exponential_davis":
+        # The 4.7 x 3.8 mm emitters of the shipped scene make chooseLight's weights (Quad::approximateRadiance, Quad.cpp:253-281: 2 pi minus
+        # four arc cosines) a magnifier for the last bit of everything upstream: with ocml's acosf a third of the samples of the six
+        # non-exponential cases landed outside 1e-3 (round 2), with glibc's acosf restated 0.9-2.1 %, with sinf / cosf / logf / expf
+        # restated as well NONE in five of the six cases -- and 0.39 % in this one, whose Davis transmittance calls powf (still ocml's).
+        return 0.01
     return max(3.0*ORACLE_DIVERGE.get(name, 0.0), 2e-3)
 
 

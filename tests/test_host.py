@@ -523,3 +523,38 @@ def test_image_readers_refuse_oversized_and_overlong_input(tmp_path):
     ok.write_bytes(png(4, 4, zlib.compress(b"".join(b"\0" + bytes([40*y + 10*x for x in range(4)]) for y in range(4)))))
     flat = tg.FlattenedScene(scenes.cornell(tmp_path, name="ok.json", edit=lambda s: s["bsdfs"][0].update(albedo="ok.png")))
     flat.close()
+
+
+def _libm_host():
+    import ctypes as C
+    if "fma" not in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split():
+        pytest.skip("host CPU without FMA3: glibc runs its non-FMA sinf / cosf / expf variants here")
+    path = os.path.join(scenes.ROOT, "oracle", "libm_host.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/libm_host.so not built")
+    lib = C.CDLL(path)
+    lib.libm_host_sweep.restype = C.c_ulonglong
+    lib.libm_host_sweep.argtypes = [C.c_int, C.c_uint, C.c_uint, C.c_uint]
+    for f in (lib.libm_host_eval, lib.libm_host_ref):
+        f.restype = None
+        f.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    return lib
+
+
+def test_libm_restatements_match_the_host_libm():
+    """csrc/hip/pt_libm.h -- glibc's sinf / cosf / logf / expf restated for the kernels -- compiled for the host (oracle/libm_host.cpp) against
+    the image's libm, bit for bit: every 5th float of either sign (the full sweep, stride 1, is `python tools/libm_sweep.py`: zero
+    mismatches over all 2^32 bit patterns inside the functions' ranges), and the array entry points the GPU test uses."""
+    lib = _libm_host()
+    for fn in range(6):
+        for lo, hi in ((0x00000000, 0x7F800000), (0x80000000, 0xFF800000)):
+            assert lib.libm_host_sweep(fn, lo + fn, hi, 5) == 0, (fn, hex(lo))
+    rng = np.random.default_rng(5)
+    for fn, x in ((0, rng.random(200000)*6.2831855), (1, rng.random(200000)*6.2831855), (4, rng.random(200000)*3.1415927), (5, -rng.random(200000)*100),
+                  (2, 1.0 - rng.random(200000)), (2, rng.random(200000)*1e30), (3, -rng.random(200000)*80), (3, rng.random(200000)*80)):
+        x = np.ascontiguousarray(x, np.float32)
+        got, want = np.empty_like(x), np.empty_like(x)
+        lib.libm_host_eval(fn, x.ctypes.data, got.ctypes.data, x.size)
+        lib.libm_host_ref(fn, x.ctypes.data, want.ctypes.data, x.size)
+        ok = ~np.isnan(got)                     # (outside a function's range the host build answers NaN; the device falls back to ocml there)
+        assert ok.mean() > 0.99 and (got[ok].view(np.uint32) == want[ok].view(np.uint32)).all(), fn

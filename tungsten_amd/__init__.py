@@ -127,6 +127,15 @@ class Renderer(object):
             raise TungstenError(lib.tghip_last_error(self.context(device)).decode())
         return hits, ms.value
 
+    def debug_libm(self, fn, x, device=0):
+        """The device's restatement of a host libm function (capi.TGHIP_LIBM_*) evaluated on the device: float32 in, float32 out."""
+        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        y = np.empty_like(x)
+        rc = lib.tghip_debug_libm(self.context(device), int(fn), x.ctypes.data, y.ctypes.data, x.size)
+        if rc != 0:
+            raise TungstenError(lib.tghip_last_error(self.context(device)).decode())
+        return y
+
     def trace_samples(self, spp_begin, spp_end, seed=DEFAULT_SEED, tile_seeds=None, device=0):
         """One TGHIP_PASS_SAMPLES pass on the device (into a cleared framebuffer): the radiance of every individual sample,
         [H, W, spp_end - spp_begin, 3] -- PathTracer::traceSample's return value per (pixel, sample index).  With tile_seeds

@@ -91,6 +91,8 @@ class TgHipSceneDesc(C.Structure):
 
 
 TGHIP_PASS_SOBOL, TGHIP_PASS_RECORDS, TGHIP_PASS_AUX, TGHIP_PASS_SAMPLES = 1, 2, 4, 8
+(TGHIP_LIBM_SINF, TGHIP_LIBM_COSF, TGHIP_LIBM_LOGF, TGHIP_LIBM_EXPF, TGHIP_LIBM_SINCOS_SIN, TGHIP_LIBM_SINCOS_COS,
+ TGHIP_LIBM_ACOSF) = range(7)
 
 
 class TgHipAuxPixel(C.Structure):
@@ -160,6 +162,7 @@ PROTOTYPES = {
     "tghip_download_samples": (C.c_int, [VP, VP, C.c_size_t]),
     "tghip_reduce_framebuffers": (C.c_int, [C.POINTER(VP), C.c_int, C.c_int, VP, VP, C.c_size_t]),
     "tghip_trace_rays": (C.c_int, [VP, VP, VP, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "tghip_debug_libm": (C.c_int, [VP, C.c_int, VP, VP, C.c_size_t]),
     "tghip_set_option": (C.c_int, [VP, C.c_char_p, C.c_longlong]),
     "tghip_get_counters": (C.c_int, [VP, C.POINTER(TgHipCounters)]),
     "tghip_reset_counters": (C.c_int, [VP]),

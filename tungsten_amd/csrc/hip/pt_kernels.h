@@ -499,7 +499,8 @@ PT_DEV bool cameraRay(CameraRef cam, bool lens, uint32_t px, uint32_t py, float 
             int blade = (int)u;
             u -= (float)blade;
             float phi = cam.blade_angle + (float)blade*cam.blade_step;
-            float sinPhi = sinf(phi), cosPhi = cosf(phi);
+            float sinPhi, cosPhi;
+            sincosfH(phi, sinPhi, cosPhi);
             float uSqrt = sqrtf(u);
             float alpha = 1.0f - uSqrt, beta = (1.0f - l1)*uSqrt;
             float lx = (1.0f + cam.blade_edge[0])*beta + (1.0f - alpha - beta), ly = cam.blade_edge[1]*beta;
@@ -523,8 +524,10 @@ PT_DEV bool cameraRay(CameraRef cam, bool lens, uint32_t px, uint32_t py, float 
             sv = 1.0f - (nv + (float)row)/(float)h;
         } else {
             float phi = l0*PT_TWO_PI, r = sqrtf(l1);                   // SampleWarp::uniformDisk (SampleWarp.hpp:64-69)
-            su = cosf(phi)*r*0.5f + 0.5f;
-            sv = sinf(phi)*r*0.5f + 0.5f;
+            float sinPhi, cosPhi;
+            sincosfH(phi, sinPhi, cosPhi);
+            su = cosPhi*r*0.5f + 0.5f;
+            sv = sinPhi*r*0.5f + 0.5f;
         }
         float ax = (su*2.0f - 1.0f)*cam.aperture_size;
         float ay = (sv*2.0f - 1.0f)*cam.aperture_size;

@@ -2,8 +2,9 @@
 //
 // Constants and operation order follow the reference so that the GPU consumes and produces the
 // same numbers as Tungsten's CPU code wherever IEEE arithmetic allows (division and sqrt are
-// correctly rounded under hipcc's defaults; sin/cos/exp/log/atan2/acos come from ocml and may
-// differ from glibc in the last ulps -- DESIGN.md "Numerics").
+// correctly rounded under hipcc's defaults; sinf / cosf / logf / expf / acosf are glibc's own algorithms
+// restated -- pt_libm.h, acosfExact below --; atan2f / powf / cbrtf come from ocml and may differ from
+// glibc in the last ulp -- DESIGN.md "Numerics").
 #ifndef TGAMD_PT_MATH_H_
 #define TGAMD_PT_MATH_H_
 
@@ -11,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../../include/tungsten_hip.h"
+#include "pt_libm.h"
 
 #define PT_PI          3.1415926536f            /* math/Angle.hpp:8 */
 #define PT_TWO_PI      (PT_PI*2.0f)
@@ -94,9 +96,15 @@ PT_DEV float fmathExp(float x)
     const uint32_t bits = ((uint32_t)((r >> 10) + 127) << 23) | g_fmathExpTable[r & 1023];
     return (1.0f + t)*__uint_as_float(bits);
 }
-// expf through the double-precision exp: the correctly rounded float in all but ~1e-9 of the cases, which is what glibc's expf
-// returns too (its error bound is 0.502 ulp) -- ocml's expf is a different last bit on a few per cent of the arguments
-PT_DEV float expfRounded(float x) { return (float)exp((double)x); }
+// glibc's sinf / cosf / logf / expf (pt_libm.h: matched exhaustively against the host libm).  Outside the ranges those cover -- which no
+// call site reaches: every angle here is 2 pi xi, pi v or a blade angle -- sin / cos fold the argument into [-pi, pi] in double first
+// (not glibc's Payne-Hanek result bit for bit, and cheap: ocml's large-argument path stays out of the kernels), logf / expf are ocml's.
+PT_DEV float foldAngle(float x) { const double xd = x; return (float)(xd - 6.283185307179586*__builtin_rint(xd*0.15915494309189535)); }
+PT_DEV float sinfH(float x) { return ptlibm::sinfCore(ptlibm::sincosInRange(x) ? x : foldAngle(x)); }
+PT_DEV float cosfH(float x) { return ptlibm::cosfCore(ptlibm::sincosInRange(x) ? x : foldAngle(x)); }
+PT_DEV void sincosfH(float x, float &s, float &c) { ptlibm::sincosfCore(ptlibm::sincosInRange(x) ? x : foldAngle(x), s, c); }
+PT_DEV float logfH(float x) { return ptlibm::logInRange(x) ? ptlibm::logfCore(x) : logf(x); }
+PT_DEV float expfH(float x) { return ptlibm::expInRange(x) ? ptlibm::expfCore(x) : expf(x); }
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 splat3(float s) { return mk3(s, s, s); }
@@ -124,7 +132,7 @@ PT_DEV float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 PT_DEV float avg3(f3 a) { return (a.x + a.y + a.z)*(1.0f/3.0f); }
 PT_DEV float sum3(f3 a) { return a.x + a.y + a.z; }
 PT_DEV bool isZero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }   /* Vec == scalar: all components */
-PT_DEV f3 exp3(f3 a) { return mk3(expf(a.x), expf(a.y), expf(a.z)); }
+PT_DEV f3 exp3(f3 a) { return mk3(expfH(a.x), expfH(a.y), expfH(a.z)); }
 PT_DEV float sqr(float x) { return x*x; }
 PT_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
@@ -244,7 +252,9 @@ PT_DEV f3 cosineHemisphere(float xi0, float xi1)
 {
     float phi = xi0*PT_TWO_PI;
     float r = sqrtf(xi1);
-    return mk3(cosf(phi)*r, sinf(phi)*r, sqrtf(fmaxf(1.0f - xi1, 0.0f)));
+    float sinPhi, cosPhi;
+    sincosfH(phi, sinPhi, cosPhi);
+    return mk3(cosPhi*r, sinPhi*r, sqrtf(fmaxf(1.0f - xi1, 0.0f)));
 }
 PT_DEV float cosineHemispherePdf(f3 p) { return fabsf(p.z)*PT_INV_PI; }
 PT_DEV f3 uniformSphere(float xi0, float xi1)
@@ -252,7 +262,9 @@ PT_DEV f3 uniformSphere(float xi0, float xi1)
     float phi = xi0*PT_TWO_PI;
     float z = xi1*2.0f - 1.0f;
     float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
-    return mk3(cosf(phi)*r, sinf(phi)*r, z);
+    float sinPhi, cosPhi;
+    sincosfH(phi, sinPhi, cosPhi);
+    return mk3(cosPhi*r, sinPhi*r, z);
 }
 PT_DEV float powerHeuristic(float pdf0, float pdf1) { return (pdf0*pdf0)/(pdf0*pdf0 + pdf1*pdf1); }
 

@@ -284,7 +284,7 @@ PT_DEV float mfD(int dist, float alpha, f3 m)
     float tanThetaSq = fmaxf(1.0f - cosThetaSq, 0.0f)/cosThetaSq;
     float cosThetaQu = cosThetaSq*cosThetaSq;
     if (dist == TGHIP_DIST_BECKMANN)
-        return PT_INV_PI*expf(-tanThetaSq/alphaSq)/(alphaSq*cosThetaQu);
+        return PT_INV_PI*expfH(-tanThetaSq/alphaSq)/(alphaSq*cosThetaQu);
     return alphaSq*PT_INV_PI/(cosThetaQu*sqr(alphaSq + tanThetaSq));
 }
 PT_DEV float mfG1(int dist, float alpha, f3 v, f3 m)
@@ -310,7 +310,7 @@ PT_DEV f3 mfSample(int dist, float alpha, float xi0, float xi1)
     float phi = xi1*PT_TWO_PI;
     float cosTheta;
     if (dist == TGHIP_DIST_BECKMANN) {
-        float tanThetaSq = -alpha*alpha*logf(1.0f - xi0);
+        float tanThetaSq = -alpha*alpha*logfH(1.0f - xi0);
         cosTheta = 1.0f/sqrtf(1.0f + tanThetaSq);
     } else if (dist == TGHIP_DIST_PHONG) {
         cosTheta = (float)pow((double)xi0, 1.0/((double)alpha + 2.0));
@@ -319,7 +319,9 @@ PT_DEV f3 mfSample(int dist, float alpha, float xi0, float xi1)
         cosTheta = 1.0f/sqrtf(1.0f + tanThetaSq);
     }
     float r = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
-    return mk3(cosf(phi)*r, sinf(phi)*r, cosTheta);
+    float sinPhi, cosPhi;
+    sincosfH(phi, sinPhi, cosPhi);
+    return mk3(cosPhi*r, sinPhi*r, cosTheta);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1459,8 +1461,10 @@ PT_DEV f3 infUvToDirection(const TgHipObject &o, float u, float v, float &sinThe
 {
     float phi = (u - 0.5f)*PT_TWO_PI;
     float theta = v*PT_PI;
-    sinTheta = sinf(theta);
-    const f3 wLocal = mk3(cosf(phi)*sinTheta, -cosf(theta), sinf(phi)*sinTheta);
+    float cosTheta, sinPhi, cosPhi;
+    sincosfH(theta, sinTheta, cosTheta);
+    sincosfH(phi, sinPhi, cosPhi);
+    const f3 wLocal = mk3(cosPhi*sinTheta, -cosTheta, sinPhi*sinTheta);
     return (o.flags & TGHIP_OBJF_SKYDOME) ? wLocal : mat3Mul(o.rot, wLocal);     // (Skydome.cpp:51-61)
 }
 
@@ -1593,11 +1597,14 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
             float phi = xi0*PT_TWO_PI, rr = sqrtf(xi1);                    /* SampleWarp::uniformDisk */
             float sign = rngNextBoolean(rng, 0.5f) ? -1.0f : 1.0f;
             ng = mk3(0.0f, sign, 0.0f);
-            q = mk3(cosf(phi)*rr*radius, sign*halfHeight, sinf(phi)*rr*radius);
+            float sinPhi, cosPhi;
+            sincosfH(phi, sinPhi, cosPhi);
+            q = mk3(cosPhi*rr*radius, sign*halfHeight, sinPhi*rr*radius);
         } else {
             float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
             float phi = xi0*PT_TWO_PI;                                     /* SampleWarp::uniformCylinder */
-            float cx = cosf(phi), cy = sinf(phi), cz = xi1*2.0f - 1.0f;
+            float cx, cy, cz = xi1*2.0f - 1.0f;
+            sincosfH(phi, cy, cx);
             ng = mk3(cx, 0.0f, cy);
             q = mk3(cx*radius, cz*halfHeight, cy*radius);
         }
@@ -1619,7 +1626,9 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
             return false;
         float xi0 = RNG1D(rng), xi1 = RNG1D(rng);
         float phi = xi0*PT_TWO_PI, rr = sqrtf(xi1);                    /* SampleWarp::uniformDisk */
-        float lx = cosf(phi)*rr*o.scale[0], ly = sinf(phi)*rr*o.scale[0];
+        float sinPhi, cosPhi;
+        sincosfH(phi, sinPhi, cosPhi);
+        float lx = cosPhi*rr*o.scale[0], ly = sinPhi*rr*o.scale[0];
         f3 q = center + ld3(o.edge1)*lx + ld3(o.edge0)*ly;
         f3 L = q - p;
         float rSq = lengthSq(L);
@@ -1670,7 +1679,9 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         float phi = xi0*PT_TWO_PI;                             /* SampleWarp::uniformSphericalCap */
         float z = xi1*(1.0f - cosTheta) + cosTheta;
         float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
-        f3 local = mk3(cosf(phi)*r, sinf(phi)*r, z);
+        float sinPhi, cosPhi;
+        sincosfH(phi, sinPhi, cosPhi);
+        f3 local = mk3(cosPhi*r, sinPhi*r, z);
         float B = dd*local.z;
         float det = sqrtf(fmaxf(B*B - C, 0.0f));
         dist = B - det;
@@ -1706,7 +1717,9 @@ PT_DEV bool lightSampleDirect(const DeviceScene &s, int objIdx, f3 p, Rng &rng, 
         float phi = xi0*PT_TWO_PI;                                     /* SampleWarp::uniformSphericalCap */
         float z = xi1*(1.0f - o.scale[0]) + o.scale[0];
         float r = sqrtf(fmaxf(1.0f - z*z, 0.0f));
-        f3 local = mk3(cosf(phi)*r, sinf(phi)*r, z);
+        float sinPhi, cosPhi;
+        sincosfH(phi, sinPhi, cosPhi);
+        f3 local = mk3(cosPhi*r, sinPhi*r, z);
         d = ld3(o.edge0)*local.x + ld3(o.edge1)*local.y + ld3(o.normal)*local.z;   /* TangentFrame::toGlobal */
         dist = PT_INF;
         pdf = PT_INV_TWO_PI/(1.0f - o.scale[0]);
@@ -1860,7 +1873,7 @@ PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
         return tau > p0 ? 0.0f : 1.0f/p0;
     }
     case TGHIP_TRANS_DOUBLE_EXPONENTIAL: {              /* DoubleExponentialTransmittance.cpp:34-49 */
-        float ea = expfRounded(-p0*tau), eb = expfRounded(-p1*tau);
+        float ea = expfH(-p0*tau), eb = expfH(-p1*tau);
         if (k == 0) return 0.5f*(ea + eb);
         if (k == 1) return 0.5f*(p0*ea + p1*eb);
         if (k == 2) return (p0*ea + p1*eb)/(p0 + p1);
@@ -1889,7 +1902,7 @@ PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
         return (1.0f/n)*(fabsf(idxF - (float)idx - 0.5f) < 1e-3f ? 1.0f : 0.0f);
     }
     case TGHIP_TRANS_ERLANG: {                          /* ErlangTransmittance.cpp:32-47 */
-        float e = expfRounded(-p0*tau);
+        float e = expfH(-p0*tau);
         if (k == 0) return 0.5f*e*(2.0f + p0*tau);
         if (k == 1) return e*(1.0f + p0*tau)*p0*0.5f;
         if (k == 2) return e*(1.0f + p0*tau);
@@ -1908,9 +1921,9 @@ PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
         if (k == 0) {
             Tr = trSurface;
         } else if (k == 1 || k == 2) {
-            Tr = trSurface*(beta/base - (beta - 1.0f)*alpha/tau*logf(base));
+            Tr = trSurface*(beta/base - (beta - 1.0f)*alpha/tau*logfH(base));
         } else {
-            float logBase = logf(base);
+            float logBase = logfH(base);
             float term1 = beta*(-1.0f + beta*(1.0f + tau) + (-1.0f + 2.0f*beta)*tau/alpha)/(tau*base*base);
             float term2 = ((-1.0f + beta)*beta*alpha/(tau*tau)*(2.0f*tau + base)*logBase)/base;
             float term3 = (beta - 1.0f)*alpha/tau*logBase;
@@ -1980,7 +1993,7 @@ PT_DEV float transLeafSample(const TgHipMedium &m, Rng &rng, bool startOnSurface
     case TGHIP_TRANS_QUADRATIC:
         return startOnSurface ? p0*(1.0f - sqrtf(1.0f - RNG1D(rng))) : p0*RNG1D(rng);
     case TGHIP_TRANS_DOUBLE_EXPONENTIAL: {
-        float t = -logf(1.0f - RNG1D(rng));
+        float t = -logfH(1.0f - RNG1D(rng));
         return rngNextBoolean(rng, startOnSurface ? 0.5f : p0/(p0 + p1)) ? t/p0 : t/p1;
     }
     case TGHIP_TRANS_PULSE: {
@@ -2005,7 +2018,7 @@ PT_DEV float transLeafSample(const TgHipMedium &m, Rng &rng, bool startOnSurface
     case TGHIP_TRANS_ERLANG: {
         if (!startOnSurface) {
             float x0 = RNG1D(rng), x1 = RNG1D(rng);
-            return -1.0f/p0*logf(x0*x1);
+            return -1.0f/p0*logfH(x0*x1);
         }
         float xi = RNG1D(rng);
         float x = 0.5f;
@@ -2028,7 +2041,7 @@ PT_DEV float transLeafSample(const TgHipMedium &m, Rng &rng, bool startOnSurface
         return result;
     }
     default:
-        return -logf(1.0f - RNG1D(rng));
+        return -logfH(1.0f - RNG1D(rng));
     }
 }
 
@@ -2109,7 +2122,9 @@ PT_DEV void phaseSample(const TgHipMedium &m, Rng &rng, f3 wi, f3 &w, float &pdf
         float cosTheta = u - 1.0f/u;
         float sinTheta = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
         Frame f = frameFromNormal(wi);
-        w = toGlobal(f, mk3(cosf(phi)*sinTheta, sinf(phi)*sinTheta, cosTheta));
+        float sinPhi, cosPhi;
+        sincosfH(phi, sinPhi, cosPhi);
+        w = toGlobal(f, mk3(cosPhi*sinTheta, sinPhi*sinTheta, cosTheta));
         pdf = phaseRayleigh(cosTheta);
     } else if (m.phase_type != TGHIP_PHASE_HENYEY_GREENSTEIN || g == 0.0f) {
         w = uniformSphere(xi0, xi1);
@@ -2119,7 +2134,9 @@ PT_DEV void phaseSample(const TgHipMedium &m, Rng &rng, f3 wi, f3 &w, float &pdf
         float cosTheta = (1.0f + g*g - sqr((1.0f - g*g)/(1.0f + g*(xi1*2.0f - 1.0f))))/(2.0f*g);
         float sinTheta = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
         Frame f = frameFromNormal(wi);
-        w = toGlobal(f, mk3(cosf(phi)*sinTheta, sinf(phi)*sinTheta, cosTheta));
+        float sinPhi, cosPhi;
+        sincosfH(phi, sinPhi, cosPhi);
+        w = toGlobal(f, mk3(cosPhi*sinTheta, sinPhi*sinTheta, cosTheta));
         pdf = phaseHG(g, cosTheta);
     }
 }

@@ -2120,6 +2120,47 @@ int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rg
     return TGHIP_OK;
 }
 
+// the libm restatements exactly as the shading kernels call them (pt_math.h)
+__global__ void k_debug_libm(int fn, const float *x, float *y, uint32_t n)
+{
+    const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    float s, c, r;
+    switch (fn) {
+    case TGHIP_LIBM_SINF: r = sinfH(v); break;
+    case TGHIP_LIBM_COSF: r = cosfH(v); break;
+    case TGHIP_LIBM_LOGF: r = logfH(v); break;
+    case TGHIP_LIBM_EXPF: r = expfH(v); break;
+    case TGHIP_LIBM_SINCOS_SIN: sincosfH(v, s, c); r = s; break;
+    case TGHIP_LIBM_SINCOS_COS: sincosfH(v, s, c); r = c; break;
+    default: r = acosfExact(v); break;
+    }
+    y[i] = r;
+}
+
+int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n)
+{
+    if (!ctx) return TGHIP_E_INVALID;
+    if (n == 0) return TGHIP_OK;
+    if (!x || !y || n > 0x7FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_ACOSF) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *dx = nullptr, *dy = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dx), n*sizeof(float)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dy), n*sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, n*sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_libm, dim3(uint32_t((n + 255)/256)), dim3(256), 0, ctx->stream, fn, dx, dy, uint32_t(n));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(y, dy, n*sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (e != hipSuccess) { ctx->error = hipGetErrorString(e); return TGHIP_E_HIP; }
+    return TGHIP_OK;
+}
+
 int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch)
 {
     if (!ctx || !ctx->haveScene) return TGHIP_E_NOSCENE;
