@@ -6,7 +6,8 @@
 #define PT_LIBM_TABLE static const
 #include "../tungsten_amd/csrc/hip/pt_libm.h"
 
-// fn: 0 sinf, 1 cosf, 2 logf, 3 expf, 4 / 5 the sine / cosine of sincosfCore.  Arguments outside a function's range give NaN.
+// fn: 0 sinf, 1 cosf, 2 logf, 3 expf, 4 / 5 the sine / cosine of sincosfCore, 7 atanf, 8 cbrtf (6 is acosf: pt_math.h, a HIP header -- the
+// device test covers it).  Arguments outside a function's range give NaN.
 extern "C" void libm_host_eval(int fn, const float *x, float *y, size_t n)
 {
     const float nan = __builtin_nanf("");
@@ -17,6 +18,8 @@ extern "C" void libm_host_eval(int fn, const float *x, float *y, size_t n)
         case 1: y[i] = ptlibm::sincosInRange(x[i]) ? ptlibm::cosfCore(x[i]) : nan; break;
         case 2: y[i] = ptlibm::logInRange(x[i]) ? ptlibm::logfCore(x[i]) : nan; break;
         case 3: y[i] = ptlibm::expInRange(x[i]) ? ptlibm::expfCore(x[i]) : nan; break;
+        case 7: y[i] = ptlibm::atanfCore(x[i]); break;
+        case 8: y[i] = ptlibm::cbrtfCore(x[i]); break;
         case 4: case 5:
             if (ptlibm::sincosInRange(x[i])) { ptlibm::sincosfCore(x[i], s, c); y[i] = fn == 4 ? s : c; } else y[i] = nan;
             break;
@@ -31,7 +34,8 @@ extern "C" void libm_host_eval(int fn, const float *x, float *y, size_t n)
 extern "C" void libm_host_ref(int fn, const float *x, float *y, size_t n)
 {
     for (size_t i = 0; i < n; ++i)
-        y[i] = fn == 0 || fn == 4 ? sinf(x[i]) : fn == 1 || fn == 5 ? cosf(x[i]) : fn == 2 ? logf(x[i]) : fn == 3 ? expf(x[i]) : acosf(x[i]);
+        y[i] = fn == 0 || fn == 4 ? sinf(x[i]) : fn == 1 || fn == 5 ? cosf(x[i]) : fn == 2 ? logf(x[i]) : fn == 3 ? expf(x[i]) : fn == 7 ? atanf(x[i])
+             : fn == 8 ? cbrtf(x[i]) : acosf(x[i]);
 }
 
 // every stride-th float in [lo, hi] (as bit patterns, sign bit as given) against the host libm: returns the number of mismatches
@@ -50,10 +54,54 @@ extern "C" unsigned long long libm_host_sweep(int fn, unsigned int lo, unsigned 
         case 1: if (!ptlibm::sincosInRange(x)) continue; got = ptlibm::cosfCore(x); want = cosf(x); break;
         case 2: if (!ptlibm::logInRange(x)) continue; got = ptlibm::logfCore(x); want = logf(x); break;
         case 3: if (!ptlibm::expInRange(x)) continue; got = ptlibm::expfCore(x); want = expf(x); break;
+        case 7: got = ptlibm::atanfCore(x); want = atanf(x); if (got != got && want != want) continue; break;
+        case 8: got = ptlibm::cbrtfCore(x); want = cbrtf(x); if (got != got && want != want) continue; break;
         case 4: if (!ptlibm::sincosInRange(x)) continue; ptlibm::sincosfCore(x, got, t); want = sinf(x); break;
         default: if (!ptlibm::sincosInRange(x)) continue; ptlibm::sincosfCore(x, t, got); want = cosf(x); break;
         }
         if (memcmp(&got, &want, 4) != 0) bad++;
     }
+    return bad;
+}
+
+// two-argument functions on n pseudo-random pairs (xorshift, 64 streams from `seed`): fn 0 atan2f -- a quarter of the pairs arbitrary bit
+// patterns, the rest direction components in [-1, 1], also scaled to 1e-3 and 1e-4 --, fn 1 powf -- positive normal bases (a quarter of them
+// in [1, 9): 1 + tau / p of the Davis transmittances), exponents in [-60, 60] and [-4, 4]; pairs glibc sends to its overflow / underflow
+// paths are skipped.  Returns the number of mismatches.
+static inline unsigned long long xorshift(unsigned long long *s) { *s ^= *s << 13; *s ^= *s >> 7; *s ^= *s << 17; return *s; }
+extern "C" unsigned long long libm_host_sweep2(int fn, unsigned long long n, unsigned long long seed, unsigned long long *tested)
+{
+    unsigned long long bad = 0, done = 0;
+#pragma omp parallel for reduction(+:bad, done)
+    for (int t = 0; t < 64; ++t) {
+        unsigned long long s = 0x9E3779B97F4A7C15ull*(seed*64 + t + 1);
+        for (unsigned long long i = 0; i < n/64; ++i) {
+            const unsigned long long r = xorshift(&s);
+            float x, y, got, want;
+            unsigned int lo = (unsigned int)r, hi = (unsigned int)(r >> 32);
+            if (fn == 0) {
+                const int mode = (int)(i & 3);
+                if (mode == 0) { memcpy(&x, &lo, 4); memcpy(&y, &hi, 4); }
+                else {
+                    x = (float)((r & 0xffffff)/16777216.0)*2.0f - 1.0f;
+                    y = (float)(((r >> 24) & 0xffffff)/16777216.0)*2.0f - 1.0f;
+                    if (mode == 2) y *= 1e-3f;
+                    if (mode == 3) x *= 1e-4f;
+                }
+                got = ptlibm::atan2fCore(y, x); want = atan2f(y, x);
+                if (got != got && want != want) continue;
+            } else {
+                unsigned int bx = 0x00800000u + lo % 0x7f000000u;
+                memcpy(&x, &bx, 4);
+                if ((i & 3) == 2) x = 1.0f + (float)((r >> 8) & 0xffffff)/16777216.0f*8.0f;
+                y = ((float)(hi & 0xffffff)/16777216.0f*2.0f - 1.0f)*((i & 1) ? 4.0f : 60.0f);
+                if (!ptlibm::powInRange(x, y) || !ptlibm::powfCore(x, y, got)) continue;
+                want = powf(x, y);
+            }
+            done++;
+            if (memcmp(&got, &want, 4) != 0) bad++;
+        }
+    }
+    if (tested) *tested = done;
     return bad;
 }

@@ -176,6 +176,147 @@ PT_LIBM_FN float expfCore(float x)                  // |x| < 88
     return (float)(y*s);
 }
 
+// ---- atanf / atan2f: s_atanf.c / e_atan2f.c, fdlibm's float algorithm (argument reduction to one of four intervals, odd / even split of an
+// 11-term polynomial), evaluated WITHOUT contraction: that is what the image's libm returns for every float (atanf) and for 4 x 10^8 random
+// pairs (atan2f).  Not called by the kernels yet (texture coordinates of environment maps and spheres still come from ocml's atan2f); here,
+// with powfCore and cbrtfCore below, so that the host test holds them to the host libm until the device is measured with them.
+PT_LIBM_FN float atanfCore(float x)
+{
+    const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    const float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    const float a0 = 3.3333334327e-01f, a1 = -2.0000000298e-01f, a2 = 1.4285714924e-01f, a3 = -1.1111110449e-01f, a4 = 9.0908870101e-02f,
+                a5 = -7.6918758452e-02f, a6 = 6.6610731184e-02f, a7 = -5.8335702866e-02f, a8 = 4.9768779427e-02f, a9 = -3.6531571299e-02f,
+                a10 = 1.6285819933e-02f;
+    const int32_t hx = (int32_t)f2u(x), ix = hx & 0x7fffffff;
+    if (ix >= 0x4c000000) {                         // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;
+        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+    }
+    float hi = 0.0f, lo = 0.0f;
+    bool reduced = true;
+    if (ix < 0x3ee00000) {                          // |x| < 7/16
+        if (ix < 0x31000000) return x;
+        reduced = false;
+    } else {
+        x = __builtin_fabsf(x);
+        if (ix < 0x3f980000) {
+            if (ix < 0x3f300000) { hi = hi0; lo = lo0; x = (2.0f*x - 1.0f)/(2.0f + x); }
+            else                 { hi = hi1; lo = lo1; x = (x - 1.0f)/(x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { hi = hi2; lo = lo2; x = (x - 1.5f)/(1.0f + 1.5f*x); }
+            else                 { hi = hi3; lo = lo3; x = -1.0f/x; }
+        }
+    }
+    const float z = x*x, w = z*z;
+    const float s1 = z*(a0 + w*(a2 + w*(a4 + w*(a6 + w*(a8 + w*a10)))));
+    const float s2 = w*(a1 + w*(a3 + w*(a5 + w*(a7 + w*a9))));
+    if (!reduced) return x - x*(s1 + s2);
+    const float r = hi - ((x*(s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+PT_LIBM_FN float atan2fCore(float y, float x)
+{
+    const float tiny = 1.0e-30f, pio4 = 7.8539818525e-01f, pio2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, piLo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)f2u(x), ix = hx & 0x7fffffff, hy = (int32_t)f2u(y), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return atanfCore(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);            // 2 sign(x) + sign(y)
+    if (iy == 0) return m < 2 ? y : m == 2 ? pi + tiny : -pi - tiny;
+    if (ix == 0) return hy < 0 ? -pio2 - tiny : pio2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pio4 + tiny : m == 1 ? -pio4 - tiny : m == 2 ? 3.0f*pio4 + tiny : -3.0f*pio4 - tiny;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pio2 - tiny : pio2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pio2 + 0.5f*piLo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = atanfCore(__builtin_fabsf(y/x));
+    return m == 0 ? z : m == 1 ? u2f(f2u(z) ^ 0x80000000u) : m == 2 ? pi - (z - piLo) : (z - piLo) - pi;
+}
+
+// ---- powf: e_powf.c -- log2(x) by the 16-interval table of __powf_log2_data and a degree-5 polynomial, y log2(x) in double, 2^(...) by
+// the exp2 table above; the FMA3 variant (every multiply-add fused).  x positive and normal, y finite, the result a normal float.
+PT_LIBM_TABLE double g_powfLog2Table[16][2] = {     // {1/c, log2 c}
+    {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2}, {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},
+    {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2}, {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4}, {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5},
+    {0x1p+0, 0x0p+0}, {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4}, {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+    {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3}, {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2}, {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},
+    {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+PT_LIBM_FN bool powInRange(float x, float y)
+{
+    const uint32_t ix = f2u(x), iy = f2u(y);
+    return ix - 0x00800000u < 0x7f800000u - 0x00800000u && (iy & 0x7fffffffu) < 0x7f800000u && (iy & 0x7fffffffu) != 0u;
+}
+// false when y log2(x) is outside (-126, 126): glibc's overflow / underflow paths, left to the caller's fallback
+PT_LIBM_FN bool powfCore(float x, float y, float &result)
+{
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2, A3 = -0x1.7154748bef6c8p-1, A4 = 0x1.71547652ab82bp0;
+    const uint32_t ix = f2u(x);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const uint32_t top = tmp & 0xff800000u;
+    const int k = (int32_t)top >> 23;
+    const double invc = g_powfLog2Table[i][0], logc = g_powfLog2Table[i][1];
+    const double z = (double)u2f(ix - top);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r*r;
+    double yy = __builtin_fma(A0, r, A1);
+    const double p = __builtin_fma(A2, r, A3);
+    const double r4 = r2*r2;
+    double q = __builtin_fma(A4, r, y0);
+    q = __builtin_fma(p, r2, q);
+    yy = __builtin_fma(yy, r4, q);                                 // log2(x)
+    const double ylogx = (double)y*yy;
+    if (((d2u(ylogx) >> 47) & 0xffffu) >= (d2u(126.0) >> 47))
+        return false;
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1, Shift = 0x1.8p+52/32.0;
+    double kd = ylogx + Shift;
+    const uint64_t ki = d2u(kd);
+    kd -= Shift;
+    const double rr = ylogx - kd;
+    const double s = u2d(g_exp2fTable[ki & 31u] + (ki << 47));
+    const double zz = __builtin_fma(C0, rr, C1);
+    const double rr2 = rr*rr;
+    double e = __builtin_fma(C2, rr, 1.0);
+    e = __builtin_fma(zz, rr2, e);
+    result = (float)(e*s);
+    return true;
+}
+
+// ---- cbrtf: s_cbrtf.c -- frexp, a quadratic first guess and one Halley step in double, the cube root of the exponent's remainder from a
+// five-entry table, ldexp.  (Insensitive to contraction: every fused and unfused variant gives glibc's result for every float.)
+PT_LIBM_FN float cbrtfCore(float x)
+{
+    const uint32_t ux = f2u(x) & 0x7fffffffu;
+    if (ux == 0u || ux >= 0x7f800000u)
+        return x + x;
+    // frexp: |x| = xm 2^xe, xm in [0.5, 1)
+    int xe;
+    float xm;
+    if (ux < 0x00800000u) {                         // subnormal: normalise by 2^25 first
+        const uint32_t un = f2u(u2f(ux)*0x1p25f);
+        xe = (int)(un >> 23) - 126 - 25;
+        xm = u2f((un & 0x007fffffu) | 0x3f000000u);
+    } else {
+        xe = (int)(ux >> 23) - 126;
+        xm = u2f((ux & 0x007fffffu) | 0x3f000000u);
+    }
+    const double dxm = (double)xm;
+    const float u = (float)(0.492659620528969547 + (0.697570460207922770 - 0.191502161678719066*dxm)*dxm);
+    const float t2 = u*u*u;
+    const int rem = xe % 3;                         // C remainder: sign of xe
+    const double factor = rem == -2 ? 1.0/1.5874010519681994748 : rem == -1 ? 1.0/1.2599210498948731648 : rem == 0 ? 1.0
+                        : rem == 1 ? 1.2599210498948731648 : 1.5874010519681994748;
+    const float ym = (float)((double)u*((double)t2 + 2.0*dxm)/(2.0*(double)t2 + dxm)*factor);
+    // ldexp(ym, xe / 3): ym in [0.5, 1.6), xe / 3 in [-50, 43) -- the product is a normal float, so an exact scaling by a power of two
+    const float scaled = ym*u2f((uint32_t)(xe/3 + 127) << 23);
+    return (f2u(x) >> 31) ? -scaled : scaled;
+}
+
 }  // namespace ptlibm
 
 #endif
