@@ -1262,19 +1262,24 @@ static int cylinder_test(const TgHipObject *o, const Ray *ray, float tmax, float
     if (didHit) *tOut = farT;
     return didHit;
 }
-/* Cylinder::intersectionInfo (Cylinder.cpp:122-132) from the hit point hp and the cap flag */
-static void cylinder_surface(const TgHipObject *o, v3 hp, float cap, v3 *n, float *u, float *v)
+/* Cylinder::intersectionInfo (Cylinder.cpp:122-132).  The reference keeps what Cylinder::intersect computed in the cylinder's own space --
+ * pHit = p + t d in the unit-radius cross-section, h = pLocal.y + dLocal.y t (:70-74, :92-97) -- so the normal and the uv are functions of
+ * the RAY and t, not of the world-space hit point (going through it and back costs an ulp in one sample out of ten that meet a cylinder). */
+static void cylinder_surface(const TgHipObject *o, const Ray *ray, float t, float cap, v3 *n, float *u, float *v)
 {
     const float invRadius = 1.0f/o->scale[0];
-    v3 pl = mat3_tmul(o->rot, vsub(hp, ld3(o->pos)));
-    float hx = pl.x*invRadius, hz = pl.z*invRadius;
+    v3 pLocal = mat3_tmul(o->rot, vsub(ray->o, ld3(o->pos)));
+    v3 dLocal = mat3_tmul(o->rot, ray->d);
+    float px = pLocal.x*invRadius, pz = pLocal.z*invRadius, dx = dLocal.x*invRadius, dz = dLocal.z*invRadius;
+    float hx = px + t*dx, hz = pz + t*dz;
     if (cap != 0.0f) {
         *n = mat3_mul(o->rot, V(0.0f, cap, 0.0f));
         *u = hx*0.5f + 0.5f; *v = hz*0.5f + 0.5f;
     } else {
+        float h = pLocal.y + dLocal.y*t;
         *n = mat3_mul(o->rot, V(hx, 0.0f, hz));
         *u = atan2f(hz, hx)*O_INV_TWO_PI + 0.5f;
-        *v = pl.y*(0.5f/o->scale[1]) + 0.5f;
+        *v = h*(0.5f/o->scale[1]) + 0.5f;
     }
 }
 
@@ -1657,7 +1662,7 @@ static void intersection_info(const TgHipSceneDesc *s, const Ray *ray, const Hit
         }
         break;
     case TGHIP_REC_CYLINDER:     /* Cylinder.cpp:122-132 */
-        cylinder_surface(o, info->p, hit->v, &info->Ng, &info->u, &info->v);
+        cylinder_surface(o, ray, hit->t, hit->v, &info->Ng, &info->u, &info->v);
         info->Ns = info->Ng;
         info->bsdf = o->bsdf;
         info->backSide = hit->u != 0.0f;
@@ -2250,7 +2255,7 @@ static int light_intersect(const TgHipSceneDesc *s, int objIdx, const Ray *ray, 
     } else if (o->type == TGHIP_OBJ_CYLINDER) {        /* Cylinder::intersect + intersectionInfo */
         float cap;
         if (!cylinder_test(o, ray, ray->tmax, &lh->t, &lh->backSide, &cap)) return 0;
-        cylinder_surface(o, vadd(ray->o, vscale(ray->d, lh->t)), cap, &lh->n, &lh->u, &lh->v);
+        cylinder_surface(o, ray, lh->t, cap, &lh->n, &lh->u, &lh->v);
         return 1;
     } else if (o->type == TGHIP_OBJ_DISK) {            /* Disk::intersect + intersectionInfo */
         float rSq;

@@ -65,17 +65,24 @@ def _needs_materialtest(name):
 # for a path that goes through the box); the same 0.1 % diverge with a constant opacity, none with the .png roughness alone.
 # cornell_bump: glossy / glass bsdfs on bump-perturbed normals (grazing configurations on steep bumps flip with the last bits of the hit's
 # barycentrics; with the bump on one primitive at a time: quad, sphere, checker 0, cube 0.04 %, smooth mesh 0 up to scale 0.2 and 0.17 % at 2)
-DIVERGE = {"cornell_bump": 5e-3, "cornell_png_scalar": 3e-3, "cornell_cylinders": 5e-4, "volumetric_caustic": 3e-3, "cornell_fog": 5e-4, "cornell_fog_rayleigh": 5e-4, "cornell_fog_davis": 5e-4, "cornell_fog_interpolated": 1e-3, "cornell_fog_davis_weinstein": 2e-3, "cornell_smoke": 3e-3, "cornell_fog_smoke_sobol": 3e-3, "water_caustic": 1e-2, "cornell_instances": 5e-2, "cornell_sobol": 1e-4, "zoo_b_sobol": 3e-3, "materialtest_sobol": 5e-3, "zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "zoo_d": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
+DIVERGE = {"cornell_bump": 5e-3, "cornell_png_scalar": 3e-3, "volumetric_caustic": 3e-3, "cornell_fog": 5e-4, "cornell_fog_rayleigh": 5e-4, "cornell_fog_davis": 5e-4, "cornell_fog_interpolated": 1e-3, "cornell_fog_davis_weinstein": 2e-3, "cornell_smoke": 3e-3, "cornell_fog_smoke_sobol": 3e-3, "water_caustic": 1e-2, "cornell_instances": 5e-2, "cornell_sobol": 1e-4, "zoo_b_sobol": 3e-3, "materialtest_sobol": 5e-3, "zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "zoo_d": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
            "materialtest_rough_dielectric": 2e-2, "materialtest_transparency": 5e-3, "cornell_two_lights": 1e-3, "cornell_mesh_light": 2e-3, "cornell_mesh_light_flat": 2e-3, "cornell_mesh_and_quad_light": 2e-3, "mesh1m": 1e-2}
 
 
-@pytest.mark.parametrize("name", sorted(scenes.GOLDEN_CASES))
-def test_oracle_matches_reference_per_sample(name, tmp_path):
-    _needs_materialtest(name)
-    mk, kw = scenes.GOLDEN_CASES[name]
-    gold = np.load(os.path.join(G, name + "_samples.npz"))
-    ref = gold["samples"]
-    seed = int(gold["seed"])
+# Cases in which the oracle's radiance is the reference's BIT FOR BIT in every sample (float32 ==, all three channels): the whole path -- camera,
+# filter, intersections, frames, BSDFs, light selection and sampling, MIS, Russian roulette, media, textures -- restated operation by operation.
+# The others differ in a few samples for reasons named above: coincident faces (the `*_lifted` twins below are exact), Embree's rcp + Newton
+# division in its triangle test (every case with a triangle mesh: an ulp in t in one hit out of ten), bump derivatives at texel edges.
+BIT_IDENTICAL = {"cornell", "cornell_bounce1", "cornell_bounce2", "cornell_box_filter", "cornell_cylinders", "cornell_disks", "cornell_fog_davis_weinstein",
+                 "cornell_fog_interpolated", "cornell_many_cubes", "cornell_minb2", "cornell_nee_off", "cornell_onesided", "cornell_png_textures",
+                 "cornell_point_lights", "cornell_skydome", "cornell_skydome_alien", "cornell_sobol", "cornell_speck_lights", "cornell_sun_sky",
+                 "cornell_thinlens", "cornell_thinlens_bitmap", "cornell_thinlens_blade5", "cornell_thinlens_blade6", "cornell_thinlens_cateye",
+                 "cornell_thinlens_pivot", "cornell_thinlens_sobol", "cornell_two_lights", "non_exponential_area_lights", "non_exponential_davis",
+                 "non_exponential_double_exponential", "non_exponential_erlang", "non_exponential_linear", "non_exponential_pulse",
+                 "non_exponential_quadratic", "volumetric_caustic", "zoo_c", "zoo_d"}
+
+
+def _oracle_samples(mk, kw, name, tmp_path, ref, seed):
     h, w, spp, _ = ref.shape
     flat = tg.FlattenedScene(mk(tmp_path, name=name + ".json", **kw))
     assert (flat.width, flat.height) == (w, h)
@@ -88,6 +95,31 @@ def test_oracle_matches_reference_per_sample(name, tmp_path):
             for s in range(spp):
                 got[y, x, s] = oracle_lib.trace_sample(flat.desc, seed, x, y, s, tile_seed=ts)
     flat.close()
+    return got
+
+
+@pytest.mark.parametrize("name", sorted(scenes.LIFTED_CASES))
+def test_oracle_is_the_reference_bit_for_bit_without_coincident_faces(name, tmp_path):
+    """The smoke / fog / glass-box / cutout / BSDF-zoo cases with every solid lifted a millimetre off the floor (tests/scenes.py:
+    LIFTED_CASES): no tie between a box's bottom face and the floor quad left for the traversal order to decide -- and not one of the
+    10 368 samples of a case in which the oracle's radiance is not the reference's, bit for bit."""
+    mk, kw = scenes.LIFTED_CASES[name]
+    gold = np.load(os.path.join(G, name + "_samples.npz"))
+    ref = gold["samples"]
+    got = _oracle_samples(mk, kw, name, tmp_path, ref, int(gold["seed"]))
+    assert (got.view(np.uint32) == ref.view(np.uint32)).all() or (got == ref).all()
+
+
+@pytest.mark.parametrize("name", sorted(scenes.GOLDEN_CASES))
+def test_oracle_matches_reference_per_sample(name, tmp_path):
+    _needs_materialtest(name)
+    mk, kw = scenes.GOLDEN_CASES[name]
+    gold = np.load(os.path.join(G, name + "_samples.npz"))
+    ref = gold["samples"]
+    seed = int(gold["seed"])
+    got = _oracle_samples(mk, kw, name, tmp_path, ref, seed)
+    if name in BIT_IDENTICAL:
+        assert (got == ref).all(), "%s: %d samples are not the reference's bit for bit" % (name, int((got != ref).any(axis=-1).sum()))
     err = np.abs(got - ref).max(axis=-1)
     bad = err > 1e-3*(np.abs(ref).max(axis=-1) + 1e-3)
     frac = bad.mean()

@@ -112,7 +112,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="tg_golden_")
     g = lambda n: os.path.join(scenes.GOLDEN, n)
     try:
-        for name, (mk, kw) in scenes.GOLDEN_CASES.items():
+        for name, (mk, kw) in list(scenes.GOLDEN_CASES.items()) + list(scenes.LIFTED_CASES.items()):
             p = mk(tmp, name=name + ".json", **kw)
             with open(p) as f:
                 sc = json.load(f)
