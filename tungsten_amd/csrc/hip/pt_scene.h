@@ -1133,19 +1133,24 @@ PT_DEV bool cylinderTest(OP op, const RayD &ray, float tmax, float &tOut, bool &
     if (didHit) tOut = farT;
     return didHit;
 }
-/* Cylinder::intersectionInfo (Cylinder.cpp:122-132) from the hit point and the cap flag */
-PT_DEV void cylinderSurface(const TgHipObject &o, f3 hp, float cap, f3 &n, float &u, float &v)
+/* Cylinder::intersectionInfo (Cylinder.cpp:122-132).  The reference keeps what Cylinder::intersect computed in the cylinder's own space --
+   pHit = p + t d in the unit-radius cross-section, h = pLocal.y + dLocal.y t (:70-74, :92-97) -- so the normal and the uv are functions of the
+   RAY and t (the same expressions as in cylinderTest above), not of the world-space hit point: oracle.c: cylinder_surface. */
+PT_DEV void cylinderSurface(const TgHipObject &o, const RayD &ray, float t, float cap, f3 &n, float &u, float &v)
 {
     const float invRadius = 1.0f/o.scale[0];
-    f3 pl = mat3TMul(o.rot, hp - ld3(o.pos));
-    float hx = pl.x*invRadius, hz = pl.z*invRadius;
+    const f3 pLocal = mat3TMul(o.rot, ray.o - ld3(o.pos));
+    const f3 dLocal = mat3TMul(o.rot, ray.d);
+    const float px = pLocal.x*invRadius, pz = pLocal.z*invRadius, dx = dLocal.x*invRadius, dz = dLocal.z*invRadius;
+    const float hx = px + t*dx, hz = pz + t*dz;
     if (cap != 0.0f) {
         n = mat3Mul(o.rot, mk3(0.0f, cap, 0.0f));
         u = hx*0.5f + 0.5f; v = hz*0.5f + 0.5f;
     } else {
+        const float h = pLocal.y + dLocal.y*t;
         n = mat3Mul(o.rot, mk3(hx, 0.0f, hz));
         u = atan2f(hz, hx)*PT_INV_TWO_PI + 0.5f;
-        v = pl.y*(0.5f/o.scale[1]) + 0.5f;
+        v = h*(0.5f/o.scale[1]) + 0.5f;
     }
 }
 
@@ -1325,7 +1330,7 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         info.backSide = dot(ray.d, info.Ng) >= 0.0f;
         if constexpr ((M & FEAT_BUMP) != 0u) { info.T = ld3(o.edge0); info.B = ld3(o.edge1); info.hasTB = true; }   /* Quad.cpp:133-139 */
     } else if ((M & FEAT_CYLINDER) && kind == TGHIP_REC_CYLINDER) {   /* Cylinder.cpp:122-132 */
-        cylinderSurface(o, info.p, hit.z, info.Ng, info.u, info.v);
+        cylinderSurface(o, ray, hit.x, hit.z, info.Ng, info.u, info.v);
         info.Ns = info.Ng;
         info.bsdf = o.bsdf;
         info.backSide = hit.y != 0.0f;
@@ -1491,7 +1496,7 @@ PT_DEV bool lightIntersect(const DeviceScene &s, int objIdx, const RayD &ray, Li
     if ((M & FEAT_CYLINDER) && o.type == TGHIP_OBJ_CYLINDER) {   /* Cylinder::intersect + intersectionInfo */
         float cap;
         if (!cylinderTest(&o, ray, ray.tmax, lh.t, lh.backSide, cap)) return false;
-        cylinderSurface(o, ray.o + ray.d*lh.t, cap, lh.n, lh.u, lh.v);
+        cylinderSurface(o, ray, lh.t, cap, lh.n, lh.u, lh.v);
         return true;
     }
     if ((M & FEAT_SOLIDS) && o.type == TGHIP_OBJ_DISK) {       /* Disk::intersect + intersectionInfo */
