@@ -949,3 +949,12 @@ def _lifted(base):
 
 LIFTED_CASES = {base + "_lifted": _lifted(base) for base in ("cornell_smoke", "cornell_fog_smoke_sobol", "cornell_fog", "cornell_fog_davis", "cornell_fog_rayleigh",
                                                             "cornell_png_scalar", "zoo_a", "zoo_b")}
+
+
+def _bump_without_the_mesh(scene):
+    scene["primitives"] = [p for p in scene["primitives"] if p["name"] != "blob"]
+
+
+# cornell_bump without its triangle mesh: bump-mapped frames on the quad, the cube, the sphere and the checkered wall alone -- bit-identical;
+# what is left of the full case's residual is Embree's division in the mesh's triangle test
+LIFTED_CASES["cornell_bump_no_mesh"] = (cornell_bump, dict(resolution=(48, 27), spp=8, edit=_bump_without_the_mesh))

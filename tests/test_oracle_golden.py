@@ -72,7 +72,7 @@ DIVERGE = {"cornell_bump": 5e-3, "cornell_png_scalar": 3e-3, "volumetric_caustic
 # Cases in which the oracle's radiance is the reference's BIT FOR BIT in every sample (float32 ==, all three channels): the whole path -- camera,
 # filter, intersections, frames, BSDFs, light selection and sampling, MIS, Russian roulette, media, textures -- restated operation by operation.
 # The others differ in a few samples for reasons named above: coincident faces (the `*_lifted` twins below are exact), Embree's rcp + Newton
-# division in its triangle test (every case with a triangle mesh: an ulp in t in one hit out of ten), bump derivatives at texel edges.
+# division in its triangle test (every case with a triangle mesh, `cornell_bump` included: an ulp in t in one hit out of four).
 BIT_IDENTICAL = {"cornell", "cornell_bounce1", "cornell_bounce2", "cornell_box_filter", "cornell_cylinders", "cornell_disks", "cornell_fog_davis_weinstein",
                  "cornell_fog_interpolated", "cornell_many_cubes", "cornell_minb2", "cornell_nee_off", "cornell_onesided", "cornell_png_textures",
                  "cornell_point_lights", "cornell_skydome", "cornell_skydome_alien", "cornell_sobol", "cornell_speck_lights", "cornell_sun_sky",
