@@ -9,11 +9,12 @@
 // glibc 2.35 (the image's) computes all four in DOUBLE precision with short polynomials -- the "optimized routines" algorithms
 // (sysdeps/ieee754/flt-32/s_sincosf.h, e_logf.c, e_expf.c) -- and on an x86-64 host with FMA3 runs the variants compiled with
 // contraction.  The functions below restate those algorithms with the fused operations spelt out (the kernels are compiled with
-// -ffp-contract=off, so exactly these are fused).  They were matched against the image's libm EXHAUSTIVELY on the host: every float
-// in [0, 120) for sinf / cosf, every positive float for logf, every float in (-88, 88) for expf -- zero mismatches
-// (tests/test_host.py::test_libm_restatements_match_the_host_libm runs a sample of that; oracle/libm_host.cpp is this header
-// compiled for the host).  Outside those ranges (|x| >= 120: glibc's Payne-Hanek reduction; |x| >= 88) they return ocml's value;
-// no call site gets there (phi = 2 pi xi, theta = pi v, -sigma t of a surviving path).
+// -ffp-contract=off, so exactly these are fused).  They were matched against the image's libm EXHAUSTIVELY on the host: every float32 bit
+// pattern of either sign inside a function's range -- |x| < 120 for sinf / cosf, positive normal x for logf, |x| < 88 for expf -- with zero
+// mismatches (tools/libm_sweep.py; tests/test_host.py::test_libm_restatements_match_the_host_libm runs every fifth; oracle/libm_host.cpp is
+// this header compiled for the host), and the device's results are held to the host libm by tests/test_gpu_libm.py.  Outside those ranges
+// -- which no call site reaches (phi = 2 pi xi, theta = pi v, -sigma t of a surviving path) -- pt_math.h's wrappers fold the angle in
+// double (sin / cos) or call ocml (logf / expf).
 //
 // Plain C++: no HIP header, so that the same text compiles for the host test.
 #ifndef TGAMD_PT_LIBM_H_
