@@ -16,8 +16,8 @@ extern "C" void libm_host_eval(int fn, const float *x, float *y, size_t n)
         switch (fn) {
         case 0: y[i] = ptlibm::sincosInRange(x[i]) ? ptlibm::sinfCore(x[i]) : nan; break;
         case 1: y[i] = ptlibm::sincosInRange(x[i]) ? ptlibm::cosfCore(x[i]) : nan; break;
-        case 2: y[i] = ptlibm::logInRange(x[i]) ? ptlibm::logfCore(x[i]) : nan; break;
-        case 3: y[i] = ptlibm::expInRange(x[i]) ? ptlibm::expfCore(x[i]) : nan; break;
+        case 2: y[i] = ptlibm::logfAll(x[i]); break;
+        case 3: y[i] = ptlibm::expfAll(x[i]); break;
         case 7: y[i] = ptlibm::atanfCore(x[i]); break;
         case 8: y[i] = ptlibm::cbrtfCore(x[i]); break;
         case 4: case 5:
@@ -52,8 +52,8 @@ extern "C" unsigned long long libm_host_sweep(int fn, unsigned int lo, unsigned 
         switch (fn) {
         case 0: if (!ptlibm::sincosInRange(x)) continue; got = ptlibm::sinfCore(x); want = sinf(x); break;
         case 1: if (!ptlibm::sincosInRange(x)) continue; got = ptlibm::cosfCore(x); want = cosf(x); break;
-        case 2: if (!ptlibm::logInRange(x)) continue; got = ptlibm::logfCore(x); want = logf(x); break;
-        case 3: if (!ptlibm::expInRange(x)) continue; got = ptlibm::expfCore(x); want = expf(x); break;
+        case 2: got = ptlibm::logfAll(x); want = logf(x); if (got != got && want != want) continue; break;
+        case 3: got = ptlibm::expfAll(x); want = expf(x); if (got != got && want != want) continue; break;
         case 7: got = ptlibm::atanfCore(x); want = atanf(x); if (got != got && want != want) continue; break;
         case 8: got = ptlibm::cbrtfCore(x); want = cbrtf(x); if (got != got && want != want) continue; break;
         case 4: if (!ptlibm::sincosInRange(x)) continue; ptlibm::sincosfCore(x, got, t); want = sinf(x); break;

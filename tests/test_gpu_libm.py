@@ -48,7 +48,17 @@ def test_device_libm_is_the_host_libm_bit_for_bit(tmp_path):
             host.libm_host_ref(fn, x.ctypes.data, want.ctypes.data, x.size)
             bad = got.view(np.uint32) != want.view(np.uint32)
             assert not bad.any(), "fn %d: %d of %d differ, first x = %r: device %r, host %r" % (fn, int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
-    # outside the restated ranges the kernels still answer sensibly (no call site gets there): sin / cos to float accuracy, exp(-inf) = 0
+    # logf / expf are glibc's for EVERY float (pt_libm.h: logfAll / expfAll, all 2^32 bit patterns checked on the host); here the special cases
+    # whose results are not subnormal: zeros, negatives, infinities, NaN, the overflow / underflow thresholds
+    for fn, x in ((capi.TGHIP_LIBM_LOGF, [0.0, -0.0, -1.0, -1e-30, np.inf, -np.inf, np.nan, 1.0, 3.4e38, 1.2e-38]),
+                  (capi.TGHIP_LIBM_EXPF, [0.0, -0.0, 88.0, 88.5, 88.72, 88.73, 100.0, np.inf, -np.inf, np.nan, -87.0, -87.3, -104.0, -200.0])):
+        x = np.array(x, np.float32)
+        got = r.debug_libm(fn, x)
+        want = np.empty_like(x)
+        host.libm_host_ref(fn, x.ctypes.data, want.ctypes.data, x.size)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (fn, x[~same], got[~same], want[~same])
+    # outside the restated range sin / cos still answer sensibly (no call site gets there): to float accuracy; exp(-inf) = 0
     big = np.array([150.0, -1e4, 3e5], np.float32)
     assert np.allclose(r.debug_libm(capi.TGHIP_LIBM_SINF, big), np.sin(big.astype(np.float64)), atol=2e-2)
     assert (r.debug_libm(capi.TGHIP_LIBM_EXPF, np.array([-np.inf, -200.0], np.float32)) == 0.0).all()

@@ -10,11 +10,10 @@
 // (sysdeps/ieee754/flt-32/s_sincosf.h, e_logf.c, e_expf.c) -- and on an x86-64 host with FMA3 runs the variants compiled with
 // contraction.  The functions below restate those algorithms with the fused operations spelt out (the kernels are compiled with
 // -ffp-contract=off, so exactly these are fused).  They were matched against the image's libm EXHAUSTIVELY on the host: every float32 bit
-// pattern of either sign inside a function's range -- |x| < 120 for sinf / cosf, positive normal x for logf, |x| < 88 for expf -- with zero
+// pattern of either sign -- for sinf / cosf those with |x| < 120, for logf / expf ALL of them, special cases included -- with zero
 // mismatches (tools/libm_sweep.py; tests/test_host.py::test_libm_restatements_match_the_host_libm runs every fifth; oracle/libm_host.cpp is
 // this header compiled for the host), and the device's results are held to the host libm by tests/test_gpu_libm.py.  Outside those ranges
-// -- which no call site reaches (phi = 2 pi xi, theta = pi v, -sigma t of a surviving path) -- pt_math.h's wrappers fold the angle in
-// double (sin / cos) or call ocml (logf / expf).
+// for sin / cos -- which no call site reaches (phi = 2 pi xi, theta = pi v) -- pt_math.h's wrappers fold the angle into [-pi, pi] in double.
 //
 // Plain C++: no HIP header, so that the same text compiles for the host test.
 #ifndef TGAMD_PT_LIBM_H_
@@ -92,8 +91,7 @@ PT_LIBM_TABLE double g_logfTable[16][2] = {     // {1/c, log c} of the interval 
     {0x1p+0, 0x0p+0}, {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5}, {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
     {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3}, {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3}, {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},
     {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
-PT_LIBM_FN bool logInRange(float x) { const uint32_t ix = f2u(x); return ix - 0x00800000u < 0x7f800000u - 0x00800000u; }   // positive, normal, finite
-PT_LIBM_FN float logfCore(float x)                  // x positive, normal and finite
+PT_LIBM_FN float logfCore(float x)                  // x positive, normal and finite (logfAll: every float)
 {
     const double Ln2 = 0x1.62e42fefa39efp-1, A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
     const uint32_t ix = f2u(x);
@@ -116,6 +114,20 @@ PT_LIBM_FN float logfCore(float x)                  // x positive, normal and fi
     return (float)y;
 }
 
+// every float: e_logf.c's special cases in front of the core -- log(+-0) = -inf, log(negative) = NaN, inf and NaN through, subnormals scaled
+// by 2^23 with the exponent corrected in the bit pattern
+PT_LIBM_FN float logfAll(float x)
+{
+    uint32_t ix = f2u(x);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+        if (ix*2u == 0u) return -__builtin_huge_valf();
+        if (ix == 0x7f800000u) return x;
+        if ((ix & 0x80000000u) || ix*2u >= 0xff000000u) return (x - x)/(x - x);
+        ix = f2u(x*0x1p23f) - (23u << 23);
+    }
+    return logfCore(u2f(ix));
+}
+
 // ---- expf: e_expf.c with __exp2f_data (N = 32: exp(x) = 2^(k/32) 2^(r/32), degree-3 polynomial) ----
 PT_LIBM_TABLE uint64_t g_exp2fTable[32] = {     // bits of 2^(i/32) minus i << 47
     0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
@@ -124,8 +136,7 @@ PT_LIBM_TABLE uint64_t g_exp2fTable[32] = {     // bits of 2^(i/32) minus i << 4
     0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
     0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
-PT_LIBM_FN bool expInRange(float x) { return abstop12(x) < abstop12(88.0f); }
-PT_LIBM_FN float expfCore(float x)                  // |x| < 88
+PT_LIBM_FN float expfCore(float x)                  // -103.97 < x < 88.72 (expfAll: every float)
 {
     const double N = 32.0, Shift = 0x1.8p+52, InvLn2N = 0x1.71547652b82fep+0*N;
     const double C0 = 0x1.c6af84b912394p-5/N/N/N, C1 = 0x1.ebfce50fac4f3p-3/N/N, C2 = 0x1.62e42ff0c52d6p-1/N;
@@ -142,6 +153,19 @@ PT_LIBM_FN float expfCore(float x)                  // |x| < 88
     double y = __builtin_fma(C2, r, 1.0);
     y = __builtin_fma(z, r2, y);
     return (float)(y*s);
+}
+
+// every float: e_expf.c's special cases in front of the core -- which itself covers (-103.97, 88.72): the double product rounds to the subnormal
+// float below 2^-126 -- exp(-inf) = 0, NaN and +inf through, overflow to inf above log(2^128), underflow to 0 below log(2^-150)
+PT_LIBM_FN float expfAll(float x)
+{
+    if (abstop12(x) >= abstop12(88.0f)) {
+        if (f2u(x) == 0xff800000u) return 0.0f;
+        if (abstop12(x) >= 0x7f8u) return x + x;
+        if (x > 0x1.62e42ep6f) return __builtin_huge_valf();
+        if (x < -0x1.9fe368p6f) return 0.0f;
+    }
+    return expfCore(x);
 }
 
 // ---- atanf / atan2f: s_atanf.c / e_atan2f.c, fdlibm's float algorithm (argument reduction to one of four intervals, odd / even split of an

@@ -98,13 +98,14 @@ PT_DEV float fmathExp(float x)
 }
 // glibc's sinf / cosf / logf / expf (pt_libm.h: matched exhaustively against the host libm).  Outside the ranges those cover -- which no
 // call site reaches: every angle here is 2 pi xi, pi v or a blade angle -- sin / cos fold the argument into [-pi, pi] in double first
-// (not glibc's Payne-Hanek result bit for bit, and cheap: ocml's large-argument path stays out of the kernels), logf / expf are ocml's.
+// (not glibc's Payne-Hanek result bit for bit, and cheap: ocml's large-argument path stays out of the kernels); logf / expf are glibc's for
+// every float (special cases included).
 PT_DEV float foldAngle(float x) { const double xd = x; return (float)(xd - 6.283185307179586*__builtin_rint(xd*0.15915494309189535)); }
 PT_DEV float sinfH(float x) { return ptlibm::sinfCore(ptlibm::sincosInRange(x) ? x : foldAngle(x)); }
 PT_DEV float cosfH(float x) { return ptlibm::cosfCore(ptlibm::sincosInRange(x) ? x : foldAngle(x)); }
 PT_DEV void sincosfH(float x, float &s, float &c) { ptlibm::sincosfCore(ptlibm::sincosInRange(x) ? x : foldAngle(x), s, c); }
-PT_DEV float logfH(float x) { return ptlibm::logInRange(x) ? ptlibm::logfCore(x) : logf(x); }
-PT_DEV float expfH(float x) { return ptlibm::expInRange(x) ? ptlibm::expfCore(x) : expf(x); }
+PT_DEV float logfH(float x) { return ptlibm::logfAll(x); }
+PT_DEV float expfH(float x) { return ptlibm::expfAll(x); }
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 splat3(float s) { return mk3(s, s, s); }
