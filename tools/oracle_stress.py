@@ -6,7 +6,10 @@ the reference's own per-sample radiance from the harness against oracle.c, float
 
 End of round 3: 34 of the 37 cases have no differing sample in 82 944 (36 864 for the 32 x 18 cases); cornell_fog_davis_weinstein 6 and
 cornell_fog_interpolated 4 -- none with LIFT=1e-3: a box's bottom face against the floor quad --; cornell_sobol 1: the first Sobol' point of a
-pixel on the image's 45-degree diagonal hits the seam between the ceiling and the left wall exactly (uv = (1, 0.93)), and the two quads tie."""
+pixel on the image's 45-degree diagonal hits the seam between the ceiling and the left wall exactly (uv = (1, 0.93)), and the two quads tie.
+Of the twins: cornell_bump_no_mesh 4 (a bump-perturbed frame sends the sampled direction INTO the tall box, whose bottom face coincides with
+the floor: the same tie), cornell_fog_smoke_sobol_lifted 7 samples off by ONE ulp in one channel -- paths with several scatter events in the
+smoke box inside the fog; with or without next-event estimation, with either sampler; cause not found --, the other seven none."""
 import json
 import os
 import subprocess
