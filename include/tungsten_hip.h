@@ -19,6 +19,8 @@
  *                              (src/hdrmanip/hdrmanip.cpp:69-112: load N HDR images, add, divide); here the tile shards of
  *                              one frame, summed on the device side by RCCL over xGMI.
  *   tghip_get_counters      <- (no reference analogue; feeds the roofline model).
+ *   tghip_debug_libm        <- std::sin / cos / log / exp / acos on floats as the reference's path calls them (glibc's sinf ... acosf):
+ *                              the device's restatements evaluated on the device, for the parity tests.
  *
  * Ownership: the caller owns every host array (borrowed for the duration of the call; the
  * shim copies with hipMemcpyAsync); the shim owns device memory behind the opaque handle.
