@@ -338,8 +338,22 @@ class Bench(object):
                 if fused:
                     roofline["note"] = ("instruction-bound, not HBM-bound (profiles/sq_counters.json): exact fp32 division/sqrt/sin/cos and -ffp-contract=off for parity "
                                         "with the CPU reference (DESIGN.md sections 5, 7)")
+                # every kernel class of the loop priced the same way (the headline fields above are the dominant traversal kernel's)
+                roofline["per_kernel"] = {k: {"achieved": kernels[k]["gbs"], "frac": round(kernels[k]["gbs"]/HBM_PEAK_GBS, 4),
+                                              "bytes_per_launch": kernels[k]["bytes_per_launch"], "avg_launch_us": kernels[k]["avg_us"],
+                                              "traffic": None} for k in sorted(kernels)}
                 if a.traffic and self.world == 1:
-                    roofline.update(measure_traffic(a, scene, w, h, spp, dom, self.tmp))
+                    traffic, source = measure_traffic(a, scene, w, h, spp, self.tmp)
+                    roofline["traffic_source"] = source
+                    for k in roofline["per_kernel"]:
+                        if k in traffic:
+                            roofline["per_kernel"][k]["traffic"] = traffic[k]["bytes_per_launch"]
+                            roofline["per_kernel"][k]["traffic_launches"] = traffic[k]["launches"]
+                    if dom in traffic:
+                        roofline["traffic"] = traffic[dom]["bytes_per_launch"]
+                    elif traffic:
+                        # (a counter file without the dominant kernel is a bug of the name matching, not a measurement)
+                        raise SystemExit("bench.py: no %s dispatches in the counter file; classes seen: %s" % (dom, sorted(traffic)))
                 if a.traffic and self.world == 1 and not fused:
                     # What the loop of a BVH scene IS bound by: none of its kernels moves bytes at a rate worth pricing
                     # against HBM -- the trees are cache-resident -- so two more ceilings are reported next to the HBM line.
@@ -407,45 +421,63 @@ class Bench(object):
         return out
 
 
-def measure_traffic(a, scene, w, h, spp, kernel, tmp):
-    """HBM bytes per launch of `kernel`, measured in THIS run: two child runs of this script under `rocprofv3 --pmc`
+def kernel_class(name):
+    """Kernel class of a demangled kernel name as rocprofv3 prints it ("void k_finish_trace_closest_wide<1u, 0, true>(PassParams, ...)"):
+    the key of kernel_bytes() the launch is priced under.  k_finish_trace_closest_wide is the closest-hit walk with the previous
+    iteration's finish work folded in front -- class k_trace_closest; the _dyn / _wide / _fast suffixes name walks."""
+    k = re.sub(r"<.*", "", re.sub(r"\(.*", "", name).replace("void ", "").strip())
+    if k.startswith("k_finish_trace_closest") or k.startswith("k_trace_closest"):
+        return "k_trace_closest"
+    if k.startswith("k_trace_shadow"):
+        return "k_trace_shadow"
+    if k.startswith("k_shade"):
+        return "k_shade"
+    return k
+
+
+def measure_traffic(a, scene, w, h, spp, tmp):
+    """HBM bytes per launch of every kernel class, measured in THIS run: two child runs of this script under `rocprofv3 --pmc`
     (FETCH_SIZE and WRITE_SIZE need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots") on the same scene at a
     fraction of the spp (counter collection serialises dispatches), then (2*FETCH_SIZE + WRITE_SIZE)*1024: KiB units, read
-    side doubled on gfx950 as MI355X_MICROARCH.md "HBM" prescribes.  Returns the roofline fields; traffic None on failure."""
+    side doubled on gfx950 as MI355X_MICROARCH.md "HBM" prescribes.  Returns ({class: bytes per launch}, source string);
+    ({}, reason) on failure."""
     import csv
     exe = shutil.which("rocprofv3")
     if not exe:
-        return {"traffic": None, "traffic_source": "rocprofv3 not found"}
+        return {}, "rocprofv3 not found"
     pmc_spp = max(4, spp//8) if scene != "cornell" else spp
-    per_launch = {}
+    per_class = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = os.path.join(tmp, "pmc_" + counter)
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                "--scene", scene, "--material", a.material, "--res", "%dx%d" % (w, h), "--spp", str(pmc_spp), "--steps", "1", "--warmup", "0",
-               "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"]
+               "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"] + [x for kv in a.opt for x in ("--opt", kv)]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp", env=env, timeout=300)
         except Exception as e:
-            return {"traffic": None, "traffic_source": "rocprofv3 --pmc %s failed: %s" % (counter, e)}
+            return {}, "rocprofv3 --pmc %s failed: %s" % (counter, e)
         files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
         if p.returncode != 0 or not files:
-            return {"traffic": None, "traffic_source": "rocprofv3 --pmc %s: rc %d, no counter file" % (counter, p.returncode)}
-        total, n = 0.0, 0
+            return {}, "rocprofv3 --pmc %s: rc %d, no counter file" % (counter, p.returncode)
+        sums, ids = {}, {}
         with open(files[0]) as f:
             for row in csv.DictReader(f):
-                k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "").replace("_wide", "").replace("_fast", "")
-                if row.get("Counter_Name") == counter and k == kernel:
-                    total += float(row["Counter_Value"])
-                    n += 1
-        if not n:
-            return {"traffic": None, "traffic_source": "no %s dispatches in the counter file" % kernel}
-        per_launch[counter] = (total/n, n)
+                if row.get("Counter_Name") != counter:
+                    continue
+                k = kernel_class(row["Kernel_Name"])
+                sums[k] = sums.get(k, 0.0) + float(row["Counter_Value"])
+                ids.setdefault(k, set()).add(row.get("Dispatch_Id"))
         shutil.rmtree(out, ignore_errors=True)
-    f, w_ = per_launch["FETCH_SIZE"][0], per_launch["WRITE_SIZE"][0]
-    return {"traffic": round((2.0*f + w_)*1024.0),
-            "traffic_source": "this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child passes at %d spp, %d launches), "
-                              "(2*FETCH + WRITE) KiB per MI355X_MICROARCH.md" % (pmc_spp, per_launch["FETCH_SIZE"][1])}
+        if not sums:
+            return {}, "rocprofv3 --pmc %s: the counter file holds no %s rows" % (counter, counter)
+        per_class[counter] = {k: (sums[k]/len(ids[k]), len(ids[k])) for k in sums}
+    traffic = {}
+    for k, (f, n) in per_class["FETCH_SIZE"].items():
+        if k in per_class["WRITE_SIZE"]:
+            traffic[k] = {"bytes_per_launch": round((2.0*f + per_class["WRITE_SIZE"][k][0])*1024.0), "launches": n}
+    return traffic, ("this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two child passes at %d spp), (2*FETCH + WRITE) KiB per "
+                     "MI355X_MICROARCH.md" % pmc_spp)
 
 
 def measure_counter_all(a, scene, w, h, spp, tmp, counter):
@@ -470,10 +502,9 @@ def measure_counter_all(a, scene, w, h, spp, tmp, counter):
     sums, ids = {}, {}
     with open(files[0]) as f:
         for row in csv.DictReader(f):
-            k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip())
+            k = kernel_class(row["Kernel_Name"])
             if row.get("Counter_Name") != counter or not k.startswith("k_"):
                 continue
-            k = k.replace("_dyn", "").replace("_wide", "").replace("_fast", "")
             sums[k] = sums.get(k, 0.0) + float(row["Counter_Value"])
             ids.setdefault(k, set()).add(row.get("Dispatch_Id"))
     shutil.rmtree(out, ignore_errors=True)
@@ -501,8 +532,7 @@ def measure_counter(a, scene, w, h, spp, kernel, tmp, counter):
     total, ids = 0.0, set()
     with open(files[0]) as f:
         for row in csv.DictReader(f):
-            k = re.sub(r"<.*", "", re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip()).replace("_dyn", "").replace("_wide", "").replace("_fast", "")
-            if row.get("Counter_Name") == counter and k == kernel:
+            if row.get("Counter_Name") == counter and kernel_class(row["Kernel_Name"]) == kernel:
                 total += float(row["Counter_Value"])
                 ids.add(row.get("Dispatch_Id"))
     shutil.rmtree(out, ignore_errors=True)

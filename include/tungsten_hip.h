@@ -19,7 +19,7 @@
  *                              (src/hdrmanip/hdrmanip.cpp:69-112: load N HDR images, add, divide); here the tile shards of
  *                              one frame, summed on the device side by RCCL over xGMI.
  *   tghip_get_counters      <- (no reference analogue; feeds the roofline model).
- *   tghip_debug_libm        <- std::sin / cos / log / exp / acos on floats as the reference's path calls them (glibc's sinf ... acosf):
+ *   tghip_debug_libm        <- std::sin / cos / log / exp / acos / atan2 / pow / cbrt on floats as the reference's path calls them (glibc's sinf ... cbrtf):
  *                              the device's restatements evaluated on the device, for the parity tests.
  *
  * Ownership: the caller owns every host array (borrowed for the duration of the call; the
@@ -438,11 +438,12 @@ int tghip_download_samples(tghip_ctx *ctx, float *rgb, size_t nfloats);
  * TGHIP_E_UNSUPPORTED when it is missing. */
 int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rgb_sum, uint32_t *count, size_t npixels);
 int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch);
-/* Self-test of the device's libm restatements (csrc/hip/pt_libm.h: glibc's sinf / cosf / logf / expf as the shading kernels call them,
- * pt_math.h: acosf): y[i] = fn(x[i]) evaluated ON THE DEVICE, host pointers.  fn: TGHIP_LIBM_*.  The GPU tests compare y with the host
- * libm bit for bit. */
+/* Self-test of the device's libm restatements (csrc/hip/pt_libm.h: glibc's sinf / cosf / logf / expf / atan2f / powf / cbrtf as the shading
+ * kernels call them, pt_math.h: acosf): y[i] = fn(x[i]) evaluated ON THE DEVICE, host pointers.  fn: TGHIP_LIBM_*.  The two-argument
+ * functions read their operands interleaved from x (2 n floats): ATAN2F y[i] = atan2f(x[2i], x[2i+1]), POWF y[i] = powf(x[2i], x[2i+1]).
+ * The GPU tests compare y with the host libm bit for bit. */
 enum { TGHIP_LIBM_SINF = 0, TGHIP_LIBM_COSF = 1, TGHIP_LIBM_LOGF = 2, TGHIP_LIBM_EXPF = 3, TGHIP_LIBM_SINCOS_SIN = 4, TGHIP_LIBM_SINCOS_COS = 5,
-       TGHIP_LIBM_ACOSF = 6 };
+       TGHIP_LIBM_ACOSF = 6, TGHIP_LIBM_ATAN2F = 7, TGHIP_LIBM_POWF = 8, TGHIP_LIBM_CBRTF = 9 };
 int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);

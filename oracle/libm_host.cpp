@@ -30,9 +30,15 @@ extern "C" void libm_host_eval(int fn, const float *x, float *y, size_t n)
 
 #include <math.h>
 #include <string.h>
-// the host libm itself over an array (fn as above; 6 = acosf): what the device's output is compared with
+// the host libm itself over an array (fn as above; 6 = acosf; 9 = atan2f, 10 = powf over interleaved operand pairs): what the device's
+// output is compared with
 extern "C" void libm_host_ref(int fn, const float *x, float *y, size_t n)
 {
+    if (fn == 9 || fn == 10) {                       // the two-argument functions of tghip_debug_libm: operands interleaved, n results
+        for (size_t i = 0; i < n; ++i)
+            y[i] = fn == 9 ? atan2f(x[2*i], x[2*i + 1]) : powf(x[2*i], x[2*i + 1]);
+        return;
+    }
     for (size_t i = 0; i < n; ++i)
         y[i] = fn == 0 || fn == 4 ? sinf(x[i]) : fn == 1 || fn == 5 ? cosf(x[i]) : fn == 2 ? logf(x[i]) : fn == 3 ? expf(x[i]) : fn == 7 ? atanf(x[i])
              : fn == 8 ? cbrtf(x[i]) : acosf(x[i]);
@@ -81,7 +87,16 @@ extern "C" unsigned long long libm_host_sweep2(int fn, unsigned long long n, uns
             unsigned int lo = (unsigned int)r, hi = (unsigned int)(r >> 32);
             if (fn == 0) {
                 const int mode = (int)(i & 3);
-                if (mode == 0) { memcpy(&x, &lo, 4); memcpy(&y, &hi, 4); }
+                if (mode == 0) {
+                    memcpy(&x, &lo, 4); memcpy(&y, &hi, 4);
+                    // every 16th of these: one operand replaced by a value e_atan2f.c tests for (x == 1, zeros, infinities, exponents > 60 apart)
+                    const int special = (int)((i >> 2) & 63);
+                    if (special == 0) x = 1.0f; else if (special == 1) x = 0.0f; else if (special == 2) x = -0.0f; else if (special == 3) y = 0.0f;
+                    else if (special == 4) y = -0.0f; else if (special == 5) x = __builtin_huge_valf(); else if (special == 6) x = -__builtin_huge_valf();
+                    else if (special == 7) y = __builtin_huge_valf(); else if (special == 8) y = -__builtin_huge_valf();
+                    else if (special == 9) { x = 1.0f; y = (float)((r & 0xffffff)/16777216.0)*4.0f - 2.0f; }
+                    else if (special == 10) { x = 1e-25f*(float)((r & 0xffff) + 1); y = 3e12f; } else if (special == 11) { x = -3e20f; y = 1e-19f*(float)((r & 0xffff) + 1); }
+                }
                 else {
                     x = (float)((r & 0xffffff)/16777216.0)*2.0f - 1.0f;
                     y = (float)(((r >> 24) & 0xffffff)/16777216.0)*2.0f - 1.0f;

@@ -1,4 +1,4 @@
-"""The device's libm (csrc/hip/pt_libm.h, pt_math.h: sinfH / cosfH / sincosfH / logfH / expfH / acosfExact -- glibc's algorithms restated)
+"""The device's libm (csrc/hip/pt_libm.h, pt_math.h: sinfH / cosfH / sincosfH / logfH / expfH / atan2fH / powfH / cbrtfH / acosfExact -- glibc's algorithms restated)
 evaluated ON THE DEVICE through tghip_debug_libm against the host libm, bit for bit, on the arguments the kernels produce: angles
 2 pi xi and pi v, 1 - xi for the logarithm, negative optical depths for the exponential, cosines for the arc cosine."""
 import ctypes as C
@@ -48,6 +48,37 @@ def test_device_libm_is_the_host_libm_bit_for_bit(tmp_path):
             host.libm_host_ref(fn, x.ctypes.data, want.ctypes.data, x.size)
             bad = got.view(np.uint32) != want.view(np.uint32)
             assert not bad.any(), "fn %d: %d of %d differ, first x = %r: device %r, host %r" % (fn, int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
+    # atan2f / powf / cbrtf (round 4: called by the kernels): the operands the path produces -- direction components for the texture coordinates of
+    # environment maps and spheres (all four quadrants, axes, tiny and zero components), 1 + tau/p and optical depths for the Davis
+    # transmittances, z + 1/z of the Rayleigh phase function -- and arbitrary bit patterns.  (oracle/libm_host.cpp numbers the host's
+    # functions differently: 9 = atan2f and 10 = powf over interleaved pairs, 8 = cbrtf.)
+    def pairs(a, b):
+        return np.ascontiguousarray(np.stack([a, b], axis=1), np.float32).reshape(-1)
+    sgn = np.where(rng.random(n) < 0.5, np.float32(-1.0), np.float32(1.0))
+    d1, d2 = (xi*np.float32(2.0) - np.float32(1.0)), (grid*np.float32(2.0) - np.float32(1.0))
+    zeros = np.zeros(n, np.float32)
+    bits = rng.integers(0, 1 << 32, 2*n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    two_arg = [
+        (capi.TGHIP_LIBM_ATAN2F, 9, [pairs(d1, d2), pairs(d2, d1*sgn), pairs(d1*np.float32(1e-4), d2), pairs(d1, d2*np.float32(1e-6)), pairs(zeros, d2), pairs(d1, zeros),
+                                     pairs(-zeros, d2), pairs(d1, -zeros), pairs(d1, np.ones(n, np.float32)), bits]),
+        (capi.TGHIP_LIBM_POWF, 10, [pairs(np.float32(1.0) + xi*np.float32(8.0), -(np.float32(0.5) + grid*np.float32(6.0))), pairs(xi*np.float32(20.0) + np.float32(1e-6), np.float32(1.0) - grid*np.float32(0.9)),
+                                    pairs(np.float32(1.0) - xi*np.float32(0.999), -np.float32(1.0)/(np.float32(0.1) + grid*np.float32(5.0))), pairs(xi + np.float32(0.5), d2*np.float32(60.0))]),
+    ]
+    for fn, host_fn, arrays in two_arg:
+        for x in arrays:
+            got = r.debug_libm(fn, x)
+            want = np.empty(x.size//2, np.float32)
+            host.libm_host_ref(host_fn, x.ctypes.data, want.ctypes.data, want.size)
+            bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
+            assert not bad.any(), "fn %d: %d of %d differ, first (%r, %r): device %r, host %r" % (
+                fn, int(bad.sum()), want.size, x[0::2][bad][0], x[1::2][bad][0], got[bad][0], want[bad][0])
+    for x in (xi + np.float32(1.0)/np.maximum(xi, np.float32(1e-3)), d1*np.float32(30.0), xi*np.float32(1e-30), bits[:n]):
+        x = np.ascontiguousarray(x, np.float32)
+        got = r.debug_libm(capi.TGHIP_LIBM_CBRTF, x)
+        want = np.empty_like(x)
+        host.libm_host_ref(8, x.ctypes.data, want.ctypes.data, x.size)
+        bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
+        assert not bad.any(), "cbrtf: %d of %d differ, first x = %r: device %r, host %r" % (int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
     # logf / expf are glibc's for EVERY float (pt_libm.h: logfAll / expfAll, all 2^32 bit patterns checked on the host); here the special cases
     # whose results are not subnormal: zeros, negatives, infinities, NaN, the overflow / underflow thresholds
     for fn, x in ((capi.TGHIP_LIBM_LOGF, [0.0, -0.0, -1.0, -1e-30, np.inf, -np.inf, np.nan, 1.0, 3.4e38, 1.2e-38]),

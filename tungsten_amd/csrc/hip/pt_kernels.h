@@ -513,12 +513,12 @@ PT_DEV bool cameraRay(CameraRef cam, bool lens, uint32_t px, uint32_t py, float 
             const float *mpdf = dist + cam.aperture_dist, *mcdf = mpdf + h, *pdf = mcdf + h + 1, *cdf = pdf + (size_t)w*h;
             int lo = 0, hi = h + 1;
             while (lo < hi) { int mid = (lo + hi) >> 1; if (mcdf[mid] <= l1) lo = mid + 1; else hi = mid; }
-            const int row = lo - 1;
+            const int row = min(max(lo - 1, 0), h - 1);                  // (a table that is not a CDF -- NaN, all zero -- must not index outside itself)
             const float nv = fminf(fmaxf((l1 - mcdf[row])/mpdf[row], 0.0f), 1.0f);
             const float *rowCdf = cdf + (size_t)row*(w + 1);
             lo = 0; hi = w + 1;
             while (lo < hi) { int mid = (lo + hi) >> 1; if (rowCdf[mid] <= l0) lo = mid + 1; else hi = mid; }
-            const int column = lo - 1;
+            const int column = min(max(lo - 1, 0), w - 1);
             const float nu = fminf(fmaxf((l0 - rowCdf[column])/pdf[(size_t)row*w + column], 0.0f), 1.0f);
             su = (nu + (float)column)/(float)w;
             sv = 1.0f - (nv + (float)row)/(float)h;

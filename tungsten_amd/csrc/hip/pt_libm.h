@@ -170,8 +170,8 @@ PT_LIBM_FN float expfAll(float x)
 
 // ---- atanf / atan2f: s_atanf.c / e_atan2f.c, fdlibm's float algorithm (argument reduction to one of four intervals, odd / even split of an
 // 11-term polynomial), evaluated WITHOUT contraction: that is what the image's libm returns for every float (atanf) and for 4 x 10^8 random
-// pairs (atan2f).  Not called by the kernels yet (texture coordinates of environment maps and spheres still come from ocml's atan2f); here,
-// with powfCore and cbrtfCore below, so that the host test holds them to the host libm until the device is measured with them.
+// pairs (atan2f).  Called by the kernels since round 4 (pt_math.h: atan2fH / powfH / cbrtfH): the texture coordinates of environment maps and
+// spheres, the Davis transmittances, the Rayleigh phase function.
 PT_LIBM_FN float atanfCore(float x)
 {
     const float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
@@ -180,52 +180,47 @@ PT_LIBM_FN float atanfCore(float x)
                 a5 = -7.6918758452e-02f, a6 = 6.6610731184e-02f, a7 = -5.8335702866e-02f, a8 = 4.9768779427e-02f, a9 = -3.6531571299e-02f,
                 a10 = 1.6285819933e-02f;
     const int32_t hx = (int32_t)f2u(x), ix = hx & 0x7fffffff;
-    if (ix >= 0x4c000000) {                         // |x| >= 2^25
-        if (ix > 0x7f800000) return x + x;
-        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
-    }
-    float hi = 0.0f, lo = 0.0f;
-    bool reduced = true;
-    if (ix < 0x3ee00000) {                          // |x| < 7/16
-        if (ix < 0x31000000) return x;
-        reduced = false;
-    } else {
-        x = __builtin_fabsf(x);
-        if (ix < 0x3f980000) {
-            if (ix < 0x3f300000) { hi = hi0; lo = lo0; x = (2.0f*x - 1.0f)/(2.0f + x); }
-            else                 { hi = hi1; lo = lo1; x = (x - 1.0f)/(x + 1.0f); }
-        } else {
-            if (ix < 0x401c0000) { hi = hi2; lo = lo2; x = (x - 1.5f)/(1.0f + 1.5f*x); }
-            else                 { hi = hi3; lo = lo3; x = -1.0f/x; }
-        }
-    }
-    const float z = x*x, w = z*z;
+    // One straight line for every lane (the four-interval branch nest of s_atanf.c cost the shading kernels 1 100 instructions per call
+    // site): the reduced argument is ONE quotient num/den with the operands selected per interval -- below 7/16 it is x/1, exact, i.e. x
+    // itself --, both result forms are evaluated and selected, and the special cases (|x| >= 2^25, NaN, |x| < 2^-29) override at the end.
+    const float ax = __builtin_fabsf(x);
+    const bool direct = ix < 0x3ee00000;                      // |x| < 7/16: no reduction
+    const int iv = ix < 0x3f300000 ? 0 : ix < 0x3f980000 ? 1 : ix < 0x401c0000 ? 2 : 3;
+    const float num = direct ? x : iv == 0 ? 2.0f*ax - 1.0f : iv == 1 ? ax - 1.0f : iv == 2 ? ax - 1.5f : -1.0f;
+    const float den = direct ? 1.0f : iv == 0 ? 2.0f + ax : iv == 1 ? ax + 1.0f : iv == 2 ? 1.0f + 1.5f*ax : ax;
+    const float hi = iv == 0 ? hi0 : iv == 1 ? hi1 : iv == 2 ? hi2 : hi3;
+    const float lo = iv == 0 ? lo0 : iv == 1 ? lo1 : iv == 2 ? lo2 : lo3;
+    const float t = num/den;
+    const float z = t*t, w = z*z;
     const float s1 = z*(a0 + w*(a2 + w*(a4 + w*(a6 + w*(a8 + w*a10)))));
     const float s2 = w*(a1 + w*(a3 + w*(a5 + w*(a7 + w*a9))));
-    if (!reduced) return x - x*(s1 + s2);
-    const float r = hi - ((x*(s1 + s2) - lo) - x);
-    return hx < 0 ? -r : r;
+    const float ts = t*(s1 + s2);
+    const float reduced = hi - ((ts - lo) - t);
+    float r = direct ? t - ts : hx < 0 ? -reduced : reduced;
+    if (ix < 0x31000000) r = x;                               // |x| < 2^-29
+    if (ix >= 0x4c000000) r = ix > 0x7f800000 ? x + x : hx > 0 ? hi3 + lo3 : -hi3 - lo3;   // |x| >= 2^25, NaN
+    return r;
 }
 PT_LIBM_FN float atan2fCore(float y, float x)
 {
     const float tiny = 1.0e-30f, pio4 = 7.8539818525e-01f, pio2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, piLo = -8.7422776573e-08f;
     const int32_t hx = (int32_t)f2u(x), ix = hx & 0x7fffffff, hy = (int32_t)f2u(y), iy = hy & 0x7fffffff;
-    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
-    if (hx == 0x3f800000) return atanfCore(y);
     const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);            // 2 sign(x) + sign(y)
-    if (iy == 0) return m < 2 ? y : m == 2 ? pi + tiny : -pi - tiny;
-    if (ix == 0) return hy < 0 ? -pio2 - tiny : pio2 + tiny;
-    if (ix == 0x7f800000) {
-        if (iy == 0x7f800000) return m == 0 ? pio4 + tiny : m == 1 ? -pio4 - tiny : m == 2 ? 3.0f*pio4 + tiny : -3.0f*pio4 - tiny;
-        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
-    }
-    if (iy == 0x7f800000) return hy < 0 ? -pio2 - tiny : pio2 + tiny;
+    // the general case first, the special cases of e_atan2f.c as overrides in reverse order of their tests.  (x == 1 needs none: y/1 is y, and
+    // atanfCore is odd operation by operation, so sign(y) atanf(|y|) IS atanf(y) -- checked with the rest, oracle/libm_host.cpp.)
     const int k = (iy - ix) >> 23;
-    float z;
+    float z = atanfCore(__builtin_fabsf(y/x));
+    if (hx < 0 && k < -60) z = 0.0f;
     if (k > 60) z = pio2 + 0.5f*piLo;
-    else if (hx < 0 && k < -60) z = 0.0f;
-    else z = atanfCore(__builtin_fabsf(y/x));
-    return m == 0 ? z : m == 1 ? u2f(f2u(z) ^ 0x80000000u) : m == 2 ? pi - (z - piLo) : (z - piLo) - pi;
+    float r = m == 0 ? z : m == 1 ? u2f(f2u(z) ^ 0x80000000u) : m == 2 ? pi - (z - piLo) : (z - piLo) - pi;
+    if (iy == 0x7f800000) r = hy < 0 ? -pio2 - tiny : pio2 + tiny;
+    if (ix == 0x7f800000)
+        r = iy == 0x7f800000 ? (m == 0 ? pio4 + tiny : m == 1 ? -pio4 - tiny : m == 2 ? 3.0f*pio4 + tiny : -3.0f*pio4 - tiny)
+                             : (m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny);
+    if (ix == 0) r = hy < 0 ? -pio2 - tiny : pio2 + tiny;
+    if (iy == 0) r = m < 2 ? y : m == 2 ? pi + tiny : -pi - tiny;
+    if (ix > 0x7f800000 || iy > 0x7f800000) r = x + y;
+    return r;
 }
 
 // ---- powf: e_powf.c -- log2(x) by the 16-interval table of __powf_log2_data and a degree-5 polynomial, y log2(x) in double, 2^(...) by

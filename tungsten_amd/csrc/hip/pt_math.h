@@ -3,8 +3,7 @@
 // Constants and operation order follow the reference so that the GPU consumes and produces the
 // same numbers as Tungsten's CPU code wherever IEEE arithmetic allows (division and sqrt are
 // correctly rounded under hipcc's defaults; sinf / cosf / logf / expf / acosf are glibc's own algorithms
-// restated -- pt_libm.h, acosfExact below --; atan2f / powf / cbrtf come from ocml and may differ from
-// glibc in the last ulp -- DESIGN.md "Numerics").
+// restated -- pt_libm.h: sinf / cosf / logf / expf / atan2f / powf / cbrtf; acosfExact below -- DESIGN.md "Numerics").
 #ifndef TGAMD_PT_MATH_H_
 #define TGAMD_PT_MATH_H_
 
@@ -106,6 +105,12 @@ PT_DEV float cosfH(float x) { return ptlibm::cosfCore(ptlibm::sincosInRange(x) ?
 PT_DEV void sincosfH(float x, float &s, float &c) { ptlibm::sincosfCore(ptlibm::sincosInRange(x) ? x : foldAngle(x), s, c); }
 PT_DEV float logfH(float x) { return ptlibm::logfAll(x); }
 PT_DEV float expfH(float x) { return ptlibm::expfAll(x); }
+// glibc's atan2f / powf / cbrtf (pt_libm.h; round 4: called by the kernels).  atan2f: every float pair, special cases included.  powf: the
+// core covers positive normal x, finite non-zero y and results that are normal floats -- every call site's operands (Davis transmittances:
+// base >= 1, optical depths) --; outside that (zero / subnormal / negative base, overflow, underflow: exact or saturating results) ocml's.
+PT_DEV float atan2fH(float y, float x) { return ptlibm::atan2fCore(y, x); }
+PT_DEV float powfH(float x, float y) { float r; return (ptlibm::powInRange(x, y) && ptlibm::powfCore(x, y, r)) ? r : powf(x, y); }
+PT_DEV float cbrtfH(float x) { return ptlibm::cbrtfCore(x); }
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 splat3(float s) { return mk3(s, s, s); }

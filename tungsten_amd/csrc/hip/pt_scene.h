@@ -1090,7 +1090,7 @@ PT_DEV void diskSurface(const TgHipObject &o, f3 hp, float rSq, float &u, float 
     f3 d = hp - ld3(o.pos);
     float x = dot(d, ld3(o.edge1)), y = dot(d, ld3(o.edge0));
     v = sqrtf(rSq)/o.scale[0];
-    u = (x == 0.0f && y == 0.0f) ? 0.0f : (atan2f(y, x)*PT_INV_TWO_PI + 0.5f);
+    u = (x == 0.0f && y == 0.0f) ? 0.0f : (atan2fH(y, x)*PT_INV_TWO_PI + 0.5f);
 }
 
 /* Cylinder::intersect (Cylinder.cpp:55-108): pos = _pos, rot = _rot, scale = {_radius, _halfHeight, _capped}; cap = +-1 when a
@@ -1149,7 +1149,7 @@ PT_DEV void cylinderSurface(const TgHipObject &o, const RayD &ray, float t, floa
     } else {
         const float h = pLocal.y + dLocal.y*t;
         n = mat3Mul(o.rot, mk3(hx, 0.0f, hz));
-        u = atan2f(hz, hx)*PT_INV_TWO_PI + 0.5f;
+        u = atan2fH(hz, hx)*PT_INV_TWO_PI + 0.5f;
         v = h*(0.5f/o.scale[1]) + 0.5f;
     }
 }
@@ -1173,7 +1173,7 @@ PT_DEV void sphereSurface(const TgHipObject &o, f3 hp, f3 &n, float &u, float &v
 {
     n = (hp - ld3(o.pos))/o.scale[0];
     f3 localN = mat3TMul(o.rot, n);
-    u = atan2f(localN.y, localN.x)*PT_INV_TWO_PI + 0.5f;
+    u = atan2fH(localN.y, localN.x)*PT_INV_TWO_PI + 0.5f;
     v = acosfExact(clampf(localN.z, -1.0f, 1.0f))*PT_INV_PI;
     if (isnan(u)) u = 0.0f;
 }
@@ -1459,7 +1459,7 @@ PT_DEV void infDirectionToUV(const TgHipObject &o, f3 wi, float &u, float &v, fl
     // atan2f's branch cut)
     f3 wLocal = (o.flags & TGHIP_OBJF_SKYDOME) ? wi : mat3TMul(o.rot, wi);
     sinTheta = sqrtf(fmaxf(1.0f - wLocal.y*wLocal.y, 0.0f));
-    u = atan2f(wLocal.z, wLocal.x)*PT_INV_TWO_PI + 0.5f;
+    u = atan2fH(wLocal.z, wLocal.x)*PT_INV_TWO_PI + 0.5f;
     v = acosfExact(-wLocal.y)*PT_INV_PI;
 }
 PT_DEV f3 infUvToDirection(const TgHipObject &o, float u, float v, float &sinTheta)
@@ -1914,15 +1914,15 @@ PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
         return sqr(p0)*tau*e;
     }
     case TGHIP_TRANS_DAVIS: {                           /* DavisTransmittance.cpp:34-49 */
-        if (k == 0) return powf(1.0f + tau/p0, -p0);
-        if (k == 1 || k == 2) return powf(1.0f + tau/p0, -(p0 + 1.0f));
-        return (1.0f + 1.0f/p0)*powf(1.0f + tau/p0, -(p0 + 2.0f));
+        if (k == 0) return powfH(1.0f + tau/p0, -p0);
+        if (k == 1 || k == 2) return powfH(1.0f + tau/p0, -(p0 + 1.0f));
+        return (1.0f + 1.0f/p0)*powfH(1.0f + tau/p0, -(p0 + 2.0f));
     }
     case TGHIP_TRANS_DAVIS_WEINSTEIN: {                 /* DavisWeinsteinTransmittance.cpp:39-82; NaN -> 0 */
         float beta = 2.0f*p0 - 1.0f;
-        float alpha = powf(tau, 1 - beta)/powf(p1, 1 + beta);
+        float alpha = powfH(tau, 1 - beta)/powfH(p1, 1 + beta);
         float base = 1.0f + tau/alpha;
-        float trSurface = powf(base, -alpha), Tr;
+        float trSurface = powfH(base, -alpha), Tr;
         if (k == 0) {
             Tr = trSurface;
         } else if (k == 1 || k == 2) {
@@ -2034,7 +2034,7 @@ PT_DEV float transLeafSample(const TgHipMedium &m, Rng &rng, bool startOnSurface
         return x;
     }
     case TGHIP_TRANS_DAVIS:
-        return startOnSurface ? p0*(powf(1.0f - RNG1D(rng), -1.0f/p0) - 1.0f) : p0*(powf(1.0f - RNG1D(rng), -1.0f/(1.0f + p0)) - 1.0f);
+        return startOnSurface ? p0*(powfH(1.0f - RNG1D(rng), -1.0f/p0) - 1.0f) : p0*(powfH(1.0f - RNG1D(rng), -1.0f/(1.0f + p0)) - 1.0f);
     case TGHIP_TRANS_DAVIS_WEINSTEIN: {                 /* bisection on the cdf (:89-118) */
         float xi = RNG1D(rng);
         float step = 1e6f, result = step*2;
@@ -2123,7 +2123,7 @@ PT_DEV void phaseSample(const TgHipMedium &m, Rng &rng, f3 wi, f3 &w, float &pdf
         float phi = xi0*PT_TWO_PI;
         float z = xi1*4.0f - 2.0f;
         float invZ = sqrtf(z*z + 1.0f);
-        float u = cbrtf(z + invZ);
+        float u = cbrtfH(z + invZ);
         float cosTheta = u - 1.0f/u;
         float sinTheta = sqrtf(fmaxf(1.0f - cosTheta*cosTheta, 0.0f));
         Frame f = frameFromNormal(wi);

@@ -1015,6 +1015,15 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             ctx->error = "the bitmap aperture's distribution lies outside dist[]";
             return TGHIP_E_INVALID;
         }
+        // a table that cannot be inverted (an all-black aperture: 0/0 in the marginal CDF) would send every lens sample outside it
+        const float *mcdf = sd->dist + sd->camera.aperture_dist + ah;
+        bool usable = mcdf[0] == 0.0f && mcdf[ah] > 0.0f;
+        for (uint64_t i = 0; usable && i < ah; ++i)
+            usable = std::isfinite(mcdf[i + 1]) && mcdf[i + 1] >= mcdf[i];
+        if (!usable) {
+            ctx->error = "the bitmap aperture's distribution is not a CDF (zero total weight or non-finite entries)";
+            return TGHIP_E_INVALID;
+        }
     } else if (ctx->thinlens && sd->camera.aperture_type != TGHIP_APERTURE_DISK && sd->camera.aperture_type != TGHIP_APERTURE_BLADE) {
         ctx->error = "unknown aperture type";
         return TGHIP_E_UNSUPPORTED;
@@ -2125,9 +2134,13 @@ __global__ void k_debug_libm(int fn, const float *x, float *y, uint32_t n)
 {
     const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float v = x[i];
+    const bool two = fn == TGHIP_LIBM_ATAN2F || fn == TGHIP_LIBM_POWF;
+    const float v = two ? x[2u*i] : x[i], v2 = two ? x[2u*i + 1u] : 0.0f;
     float s, c, r;
     switch (fn) {
+    case TGHIP_LIBM_ATAN2F: r = atan2fH(v, v2); break;
+    case TGHIP_LIBM_POWF: r = powfH(v, v2); break;
+    case TGHIP_LIBM_CBRTF: r = cbrtfH(v); break;
     case TGHIP_LIBM_SINF: r = sinfH(v); break;
     case TGHIP_LIBM_COSF: r = cosfH(v); break;
     case TGHIP_LIBM_LOGF: r = logfH(v); break;
@@ -2143,12 +2156,13 @@ int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n)
 {
     if (!ctx) return TGHIP_E_INVALID;
     if (n == 0) return TGHIP_OK;
-    if (!x || !y || n > 0x7FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_ACOSF) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
+    if (!x || !y || n > 0x3FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_CBRTF) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *dx = nullptr, *dy = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dx), n*sizeof(float)));
+    const size_t nx = (fn == TGHIP_LIBM_ATAN2F || fn == TGHIP_LIBM_POWF) ? 2*n : n;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dx), nx*sizeof(float)));
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&dy), n*sizeof(float));
-    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, n*sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dx, x, nx*sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_debug_libm, dim3(uint32_t((n + 255)/256)), dim3(256), 0, ctx->stream, fn, dx, dy, uint32_t(n));
         e = hipGetLastError();

@@ -185,7 +185,8 @@ std::vector<float> bakeSkydomeImage(const float sun[3], float temperature, float
             const float entry[3] = {X[i], Y[i], Z[i]};
             for (int k = 0; k < 3; ++k) {
                 weights[x][k] += (1.0f - u)*entry[k];
-                weights[x + 1][k] += u*entry[k];
+                if (x + 1 < NumSamples)          // (i = CieSamples - 1 lands exactly on the last sample: u == 0, nothing to spread)
+                    weights[x + 1][k] += u*entry[k];
             }
             if (i < CieSamples - 1)
                 ref += (Y[i] + Y[i + 1])*0.5f;

@@ -515,6 +515,8 @@ void TraceableScene::flatten()
         // only ever samples the aperture, so its Distribution2D is all the device gets
         Texture &t = *cam.apertureTex;
         t.makeSamplable(false);
+        if (t.marginalCdf.empty() || !(t.marginalCdf.back() > 0.0f) || !std::isfinite(t.marginalCdf.back()))
+            throw std::runtime_error("thin lens camera: the aperture bitmap has no non-black texel to sample");
         c.aperture_type = TGHIP_APERTURE_BITMAP;
         c.aperture_w = t.w; c.aperture_h = t.h;
         c.aperture_dist = uint32_t(_dist.size());

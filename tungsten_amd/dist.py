@@ -46,7 +46,7 @@ def reduce_framebuffer(fb_sum, fb_count, dst=0, group=None):
         hs, hc = fb_sum.cpu(), fb_count.cpu()
         dist.reduce(hs, dst=dst, op=dist.ReduceOp.SUM, group=group)
         dist.reduce(hc, dst=dst, op=dist.ReduceOp.SUM, group=group)
-        if dist.get_rank(group) == dst:
+        if dist.get_rank() == dst:                 # (`dst` of dist.reduce is a GLOBAL rank, whatever the group)
             fb_sum.copy_(hs)
             fb_count.copy_(hc)
         import torch
