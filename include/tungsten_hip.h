@@ -441,9 +441,11 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
 /* Self-test of the device's libm restatements (csrc/hip/pt_libm.h: glibc's sinf / cosf / logf / expf / atan2f / powf / cbrtf as the shading
  * kernels call them, pt_math.h: acosf): y[i] = fn(x[i]) evaluated ON THE DEVICE, host pointers.  fn: TGHIP_LIBM_*.  The two-argument
  * functions read their operands interleaved from x (2 n floats): ATAN2F y[i] = atan2f(x[2i], x[2i+1]), POWF y[i] = powf(x[2i], x[2i+1]).
- * The GPU tests compare y with the host libm bit for bit. */
+ * EMBREE_RCP / RCPPS: Embree's rcp(a) = r*(2 - r*a) and its r = Intel's RCPPS estimate as the triangle test restates them (pt_scene.h: embreeRcp,
+ * rcppsIntel).  The GPU tests compare y with the host libm / the oracle's restatement bit for bit. */
 enum { TGHIP_LIBM_SINF = 0, TGHIP_LIBM_COSF = 1, TGHIP_LIBM_LOGF = 2, TGHIP_LIBM_EXPF = 3, TGHIP_LIBM_SINCOS_SIN = 4, TGHIP_LIBM_SINCOS_COS = 5,
-       TGHIP_LIBM_ACOSF = 6, TGHIP_LIBM_ATAN2F = 7, TGHIP_LIBM_POWF = 8, TGHIP_LIBM_CBRTF = 9 };
+       TGHIP_LIBM_ACOSF = 6, TGHIP_LIBM_ATAN2F = 7, TGHIP_LIBM_POWF = 8, TGHIP_LIBM_CBRTF = 9,
+       TGHIP_LIBM_EMBREE_RCP = 10, TGHIP_LIBM_RCPPS = 11 };
 int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);

@@ -120,3 +120,11 @@ extern "C" unsigned long long libm_host_sweep2(int fn, unsigned long long n, uns
     if (tested) *tested = done;
     return bad;
 }
+
+// the host's RCPPS instruction over an array: what oracle/oracle.c: intel_rcpps restates (equal on Intel CPUs only; tests/test_host.py checks the vendor)
+#include <xmmintrin.h>
+extern "C" void libm_host_rcpps_hw(const float *x, float *y, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        y[i] = _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(x[i])));
+}

@@ -1305,8 +1305,57 @@ static void sphere_surface(const TgHipObject *o, v3 hp, v3 *n, float *u, float *
     if (isnan(*u)) *u = 0.0f;
 }
 
-/* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113),
- * with exact division in place of rcp+Newton (:43-49).  Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c. */
+/* ---- Embree's arithmetic in its triangle test, restated bit for bit (round 4) ---------------------------------------------------
+ * Two details of Embree 2.x decide the last bit of every triangle hit's t / u / v, and with them -- a path being a chaotic function of
+ * its hits -- 0.1 % (materialtest) to 1.4 % (a dielectric hero material) of the samples of every scene with a triangle mesh:
+ *  (1) its dot product associates from the right: dot(a, b) = a.x*b.x + (a.y*b.y + a.z*b.z) (common/math/vec3.h:182, madd(a.x, b.x,
+ *      madd(a.y, b.y, a.z*b.z)); without FMA in the SSE4.2 build the reference's CMake default makes: simd/vfloat4_sse2.h:263);
+ *  (2) it does not divide: t = T*rcp(absDen) with rcp(a) = r*(2 - r*a), r = _mm_rcp_ps(a) (kernels/geometry/
+ *      triangle_intersector_moeller.h:43-49, simd/vfloat4_sse2.h:166-173) -- the hardware's reciprocal ESTIMATE plus one Newton step.
+ * The estimate is the instruction's, not IEEE's: on Intel CPUs (the goldens under tests/golden/ were rendered on one) RCPPS looks the top
+ * 11 mantissa bits i up in a table whose entries are 2^25/(4097 + 2 i) rounded to the nearest integer -- a 13-bit significand --, takes
+ * the exponent from the operand and flushes denormal operands to zero (-> infinity) and denormal results to zero.  intel_rcpps below is
+ * that rule in integer arithmetic; tools/rcpps_sweep.c holds it to the instruction for every one of the 2^32 bit patterns (zero
+ * mismatches on the Xeon this repository's goldens come from; AMD's RCPPS is a different function, which is why the rule is restated
+ * instead of executed).  With (1) and (2) the oracle's radiance is the reference's BIT FOR BIT in every sample of every mesh case
+ * (tests/test_oracle_golden.py: BIT_IDENTICAL), where exact division and a left-to-right dot product left 0.1 - 1.4 % of them on other paths. */
+static inline float edot(v3 a, v3 b) { return a.x*b.x + (a.y*b.y + a.z*b.z); }
+static inline float intel_rcpps(float x)
+{
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u, e = (u >> 23) & 0xffu, i = (u >> 12) & 0x7ffu;
+    uint32_t bits;
+    if (e == 0u) bits = sign | 0x7f800000u;                               /* zeros and denormals: +-infinity */
+    else if (e == 255u) bits = (u & 0x7fffffu) ? (u | 0x00400000u) : sign;   /* NaN quieted; 1/infinity = 0 */
+    else if (e >= 253u) bits = sign;                                      /* the result would be denormal: flushed to zero */
+    else {
+        /* q = 2^25 / d rounded to nearest (d is odd: no ties): the float quotient's floor, corrected by the exact integer remainder */
+        const uint32_t d = 4097u + 2u*i;
+        int32_t q = (int32_t)(33554432.0f/(float)d);
+        int32_t r = (int32_t)(33554432u - (uint32_t)q*d);
+        if (r < 0) { q -= 1; r += (int32_t)d; }
+        if (r >= (int32_t)d) { q += 1; r -= (int32_t)d; }
+        if (2*r > (int32_t)d) q += 1;
+        bits = sign | ((253u - e) << 23) | ((uint32_t)(q - 4096) << 11);
+    }
+    float f; memcpy(&f, &bits, 4);
+    return f;
+}
+static inline float embree_rcp(float a)
+{
+    const float r = intel_rcpps(a);
+    return r*(2.0f - r*a);                       /* _mm_mul_ps(r, _mm_sub_ps(2, _mm_mul_ps(r, a))): three roundings (-ffp-contract=off) */
+}
+/* (for the tests: tests/test_host.py holds intel_rcpps to the instruction where the host has Intel's, tests/test_gpu_libm.py holds the
+ * device's restatement to this one) */
+void oracle_embree_rcp(int raw_estimate, const float *x, float *y, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        y[i] = raw_estimate ? intel_rcpps(x[i]) : embree_rcp(x[i]);
+}
+
+/* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113, finalize() :43-49),
+ * operation for operation.  Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c. */
 static int tri_test(const TgHipPrimRec *r, const Ray *ray, float tmax, float *t, float *u, float *v)
 {
     v3 v0 = ld3(r->a);
@@ -1314,17 +1363,18 @@ static int tri_test(const TgHipPrimRec *r, const Ray *ray, float tmax, float *t,
     v3 Ng = vcross(e1, e2);
     v3 C = vsub(v0, ray->o);
     v3 R = vcross(ray->d, C);
-    float den = vdot(Ng, ray->d);
+    float den = edot(Ng, ray->d);
     float absDen = fabsf(den);
     float sgn = den < 0.0f ? -1.0f : 1.0f;     /* xor with the sign mask */
-    float U = vdot(R, e2)*sgn;
-    float Vv = vdot(R, e1)*sgn;
+    float U = edot(R, e2)*sgn;
+    float Vv = edot(R, e1)*sgn;
     if (!(den != 0.0f && U >= 0.0f && Vv >= 0.0f && U + Vv <= absDen))
         return 0;
-    float T = vdot(Ng, C)*sgn;
+    float T = edot(Ng, C)*sgn;
     if (!(T > absDen*ray->tmin && T < absDen*tmax))
         return 0;
-    *t = T/absDen; *u = U/absDen; *v = Vv/absDen;
+    const float rcpAbsDen = embree_rcp(absDen);
+    *t = T*rcpAbsDen; *u = U*rcpAbsDen; *v = Vv*rcpAbsDen;
     return 1;
 }
 

@@ -79,6 +79,20 @@ def test_device_libm_is_the_host_libm_bit_for_bit(tmp_path):
         host.libm_host_ref(8, x.ctypes.data, want.ctypes.data, x.size)
         bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
         assert not bad.any(), "cbrtf: %d of %d differ, first x = %r: device %r, host %r" % (int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
+    # Embree's rcp() of its triangle test (pt_scene.h: rcppsIntel / embreeRcp) against the oracle's restatement (oracle.c: intel_rcpps / embree_rcp,
+    # itself held to the instruction by tests/test_host.py): every exponent x every table index x low mantissa bits, both signs, random patterns
+    import oracle_lib
+    e = np.arange(0, 256, dtype=np.uint32)[:, None, None] << 23
+    idx = np.arange(0, 2048, dtype=np.uint32)[None, :, None] << 12
+    low = np.array([0, 1, 0x7ff, 0xfff], np.uint32)[None, None, :]
+    pat = np.concatenate([(e | idx | low).reshape(-1), (e | idx | low).reshape(-1) | np.uint32(0x80000000), rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)])
+    x = np.ascontiguousarray(pat.view(np.float32))
+    for fn, raw in ((capi.TGHIP_LIBM_RCPPS, 1), (capi.TGHIP_LIBM_EMBREE_RCP, 0)):
+        got = r.debug_libm(fn, x)
+        want = np.empty_like(x)
+        oracle_lib._lib.oracle_embree_rcp(raw, x.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+        bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
+        assert not bad.any(), "rcp fn %d: %d of %d differ, first x = %r: device %r, oracle %r" % (fn, int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
     # logf / expf are glibc's for EVERY float (pt_libm.h: logfAll / expfAll, all 2^32 bit patterns checked on the host); here the special cases
     # whose results are not subnormal: zeros, negatives, infinities, NaN, the overflow / underflow thresholds
     for fn, x in ((capi.TGHIP_LIBM_LOGF, [0.0, -0.0, -1.0, -1e-30, np.inf, -np.inf, np.nan, 1.0, 3.4e38, 1.2e-38]),

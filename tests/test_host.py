@@ -551,7 +551,7 @@ def test_libm_restatements_match_the_host_libm():
     for fn in (0, 1, 2, 3, 4, 5, 7, 8):           # sinf, cosf, logf, expf, sincos (sin), sincos (cos), atanf, cbrtf
         for lo, hi in ((0x00000000, 0x7F800000), (0x80000000, 0xFF800000)):
             assert lib.libm_host_sweep(fn, lo + fn, hi, 5) == 0, (fn, hex(lo))
-    # the two-argument ones (restated, not yet called by the kernels): atan2f and powf on 2 x 10^7 pseudo-random pairs each
+    # the two-argument ones: atan2f and powf on 2 x 10^7 pseudo-random pairs each
     for fn in (0, 1):
         tested = C.c_ulonglong(0)
         assert lib.libm_host_sweep2(fn, 20000000, 7, C.byref(tested)) == 0 and tested.value > 8000000, fn
@@ -564,3 +564,37 @@ def test_libm_restatements_match_the_host_libm():
         lib.libm_host_ref(fn, x.ctypes.data, want.ctypes.data, x.size)
         ok = ~np.isnan(got)                     # (sin / cos outside |x| < 120: the host build answers NaN, the device folds the angle)
         assert ok.mean() > 0.99 and (got[ok].view(np.uint32) == want[ok].view(np.uint32)).all(), fn
+
+
+def test_oracle_rcpps_is_the_intel_instruction():
+    """oracle/oracle.c: intel_rcpps -- the rule behind Embree's rcp() in its triangle test (simd/vfloat4_sse2.h:166-173: RCPPS + one Newton step),
+    restated in integer arithmetic because the instruction's result is the vendor's, not IEEE's -- against the instruction itself on a host that
+    has Intel's: every exponent x every one of the 2048 table indices x mantissa bits below the index, specials, and 2 M random bit patterns
+    (tools/rcpps_sweep.c runs all 2^32: profiles/r4_rcpps_sweep.txt).  Elsewhere (AMD hosts: another RCPPS) only the rule's own properties are checked."""
+    import ctypes as C
+    import oracle_lib
+    rng = np.random.default_rng(3)
+    e = np.arange(0, 256, dtype=np.uint32)[:, None, None] << 23
+    i = np.arange(0, 2048, dtype=np.uint32)[None, :, None] << 12
+    low = np.array([0, 1, 0x7ff, 0xfff], np.uint32)[None, None, :]
+    bits = np.concatenate([(e | i | low).reshape(-1), (e | i | low).reshape(-1) | np.uint32(0x80000000),
+                           rng.integers(0, 1 << 32, 1 << 21, dtype=np.uint64).astype(np.uint32)])
+    x = np.ascontiguousarray(bits.view(np.float32))
+    est, full = np.empty_like(x), np.empty_like(x)
+    oracle_lib._lib.oracle_embree_rcp(1, x.ctypes.data_as(C.c_void_p), est.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+    oracle_lib._lib.oracle_embree_rcp(0, x.ctypes.data_as(C.c_void_p), full.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+    # the rule's own properties: |relative error| of the estimate <= 1.5 * 2^-12 (Intel's bound for RCPPS), of estimate + Newton step <= 2^-22
+    normal = np.isfinite(x) & (np.abs(x) > 1e-30) & (np.abs(x) < 1e30)
+    xd = x[normal].astype(np.float64)
+    assert np.abs(est[normal]*xd - 1.0).max() <= 1.5*2.0**-12
+    assert np.abs(full[normal]*xd - 1.0).max() <= 2.0**-22
+    if "GenuineIntel" not in open("/proc/cpuinfo").read():
+        pytest.skip("the instruction is checked on Intel hosts only (AMD's RCPPS is a different function)")
+    path = os.path.join(scenes.ROOT, "oracle", "libm_host.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/libm_host.so not built")
+    lib = C.CDLL(path)
+    hw = np.empty_like(x)
+    lib.libm_host_rcpps_hw(x.ctypes.data_as(C.c_void_p), hw.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+    same = (hw.view(np.uint32) == est.view(np.uint32))
+    assert same.all(), (int((~same).sum()), hex(int(x.view(np.uint32)[~same][0])), hex(int(hw.view(np.uint32)[~same][0])), hex(int(est.view(np.uint32)[~same][0])))

@@ -2,10 +2,10 @@
 itself committed under tests/golden/ (tools/make_golden.py: oracle/ref_harness.cpp links the reference's
 libcore.a and drives its PathTracer::traceSample with the shared counter-based random stream).
 
-Tolerances: integers / RNG exact; deterministic floats rel 1e-5 (t: 1e-4, Embree's rcp+Newton,
-triangle_intersector_moeller.h:45-48); per-sample radiance rel 1e-3 for all but a small fraction of
-samples -- a path is a chaotic function of its hits, so an ulp-level difference at an edge or a Fresnel
-coin flip sends the path elsewhere; the fraction allowed is stated per case below."""
+Tolerances: integers / RNG exact; closest-hit distances exact (Embree's rcp + Newton restated,
+triangle_intersector_moeller.h:45-48); other deterministic floats rel 1e-5; per-sample radiance BIT-IDENTICAL in 48 of the 58
+cases, and within rel 1e-3 for all but a measured handful of samples in the other ten (coincident faces; the reference's
+instance override) -- the count allowed is stated per case below."""
 import json
 import os
 
@@ -55,31 +55,30 @@ def _needs_materialtest(name):
         pytest.skip("materialtest assets (oracle/_ref/data) not present")
 
 
-# fraction of samples allowed to diverge (chaotic path divergence, see module docstring)
-# cornell_instances: the reference's Instance::intersect gives the master a ray with farT = infinity (Ray::scatter's default,
-# primitives/Instance.cpp:296), so an instance visited later in ITS bvh overrides a nearer hit; oracle and device return the
-# nearest hit.  About 2.5 % of the paths of this deliberately crowded scene see such a pair.
-# The media cases (cornell_fog*, cornell_smoke): expf against the reference's table-based fmath::exp (math/FastMath.hpp:14-27), and
-# rays leaving the glass box through its bottom face, which coincides with the floor quad (either may win the tie).
-# cornell_png_scalar: the see-through short box stands ON the floor quad (its bottom face and the floor coincide: either may win the tie
-# for a path that goes through the box); the same 0.1 % diverge with a constant opacity, none with the .png roughness alone.
-# cornell_bump: glossy / glass bsdfs on bump-perturbed normals (grazing configurations on steep bumps flip with the last bits of the hit's
-# barycentrics; with the bump on one primitive at a time: quad, sphere, checker 0, cube 0.04 %, smooth mesh 0 up to scale 0.2 and 0.17 % at 2)
-DIVERGE = {"cornell_bump": 5e-3, "cornell_png_scalar": 3e-3, "volumetric_caustic": 3e-3, "cornell_fog": 5e-4, "cornell_fog_rayleigh": 5e-4, "cornell_fog_davis": 5e-4, "cornell_fog_interpolated": 1e-3, "cornell_fog_davis_weinstein": 2e-3, "cornell_smoke": 3e-3, "cornell_fog_smoke_sobol": 3e-3, "water_caustic": 1e-2, "cornell_instances": 5e-2, "cornell_sobol": 1e-4, "zoo_b_sobol": 3e-3, "materialtest_sobol": 5e-3, "zoo_a": 3e-3, "zoo_b": 3e-3, "zoo_c": 3e-3, "zoo_d": 3e-3, "materialtest": 5e-3, "materialtest_dielectric": 2e-2,
-           "materialtest_rough_dielectric": 2e-2, "materialtest_transparency": 5e-3, "cornell_two_lights": 1e-3, "cornell_mesh_light": 2e-3, "cornell_mesh_light_flat": 2e-3, "cornell_mesh_and_quad_light": 2e-3, "mesh1m": 1e-2}
+# Samples in which the oracle leaves the reference's path (every channel within 1e-3 is "the same path"), MEASURED per case (round 4, tools/
+# device_vs_oracle.py; the oracle is plain C with every libm function and Embree's triangle arithmetic restated, so the counts do not depend on
+# the host).  Every case not listed here is in BIT_IDENTICAL.  Two causes are left, both named by experiment:
+#  * coincident faces -- the Cornell box's boxes stand ON the floor quad, so the bottom face of a see-through box (smoke, glass, cut-out, the
+#    zoo's transmissive materials) and the floor under it are hit at the same distance, and the traversal order (Embree's BVH4 there, another
+#    tree here) decides which one a ray sees; the `*_lifted` twins below, with every solid a millimetre off the floor, are exact;
+#  * cornell_instances: the reference's Instance::intersect gives the master a ray with farT = infinity (Ray::scatter's default,
+#    primitives/Instance.cpp:296), so an instance visited later in ITS bvh overrides a nearer hit.
+# The test's bound is 1.5 x the measured count + 5 samples.
+DIVERGING = {"cornell_fog": 1, "cornell_fog_davis": 2, "cornell_fog_rayleigh": 1, "cornell_fog_smoke_sobol": 9, "cornell_png_scalar": 11, "cornell_smoke": 17,
+             "zoo_a": 7, "zoo_b": 8, "zoo_b_sobol": 7, "cornell_instances": 233}
+
+
+def diverge_bound(name, samples):
+    """Largest number of divergent samples the tests accept for a case (also the device's bound, tests/test_gpu_samples.py)."""
+    return int(1.5*DIVERGING.get(name, 0)) + 5 if name in DIVERGING else 0
 
 
 # Cases in which the oracle's radiance is the reference's BIT FOR BIT in every sample (float32 ==, all three channels): the whole path -- camera,
 # filter, intersections, frames, BSDFs, light selection and sampling, MIS, Russian roulette, media, textures -- restated operation by operation.
-# The others differ in a few samples for reasons named above: coincident faces (the `*_lifted` twins below are exact), Embree's rcp + Newton
-# division in its triangle test (every case with a triangle mesh, `cornell_bump` included: an ulp in t in one hit out of four).
-BIT_IDENTICAL = {"cornell", "cornell_bounce1", "cornell_bounce2", "cornell_box_filter", "cornell_cylinders", "cornell_disks", "cornell_fog_davis_weinstein",
-                 "cornell_fog_interpolated", "cornell_many_cubes", "cornell_minb2", "cornell_nee_off", "cornell_onesided", "cornell_png_textures",
-                 "cornell_point_lights", "cornell_skydome", "cornell_skydome_alien", "cornell_sobol", "cornell_speck_lights", "cornell_sun_sky",
-                 "cornell_thinlens", "cornell_thinlens_bitmap", "cornell_thinlens_blade5", "cornell_thinlens_blade6", "cornell_thinlens_cateye",
-                 "cornell_thinlens_pivot", "cornell_thinlens_sobol", "cornell_two_lights", "non_exponential_area_lights", "non_exponential_davis",
-                 "non_exponential_double_exponential", "non_exponential_erlang", "non_exponential_linear", "non_exponential_pulse",
-                 "non_exponential_quadratic", "volumetric_caustic", "zoo_c", "zoo_d"}
+# Since round 4 that includes every case with a triangle mesh (materialtest with all its hero materials, the 998 000-triangle mesh, the water
+# caustic, mesh emitters, the bump-mapped mesh): Embree's triangle test is restated down to its right-associated dot product and its
+# RCPPS-plus-Newton reciprocal (oracle.c: edot / intel_rcpps / embree_rcp), which was what kept 0.1 - 1.4 % of their samples on other paths.
+BIT_IDENTICAL = set(scenes.GOLDEN_CASES) - set(DIVERGING)
 
 
 def _oracle_samples(mk, kw, name, tmp_path, ref, seed):
@@ -122,8 +121,8 @@ def test_oracle_matches_reference_per_sample(name, tmp_path):
         assert (got == ref).all(), "%s: %d samples are not the reference's bit for bit" % (name, int((got != ref).any(axis=-1).sum()))
     err = np.abs(got - ref).max(axis=-1)
     bad = err > 1e-3*(np.abs(ref).max(axis=-1) + 1e-3)
-    frac = bad.mean()
-    assert frac <= DIVERGE.get(name, 0.0), "%s: %.4f%% of samples differ from the reference" % (name, 100*frac)
+    assert int(bad.sum()) <= diverge_bound(name, bad.size), "%s: %d of %d samples differ from the reference (measured: %d)" % (
+        name, int(bad.sum()), bad.size, DIVERGING.get(name, 0))
     # the mean image is insensitive to the few divergent paths
     assert np.allclose(got.mean(axis=(0, 1, 2)), ref.mean(axis=(0, 1, 2)), rtol=0.03)
 
@@ -159,14 +158,12 @@ def test_oracle_units(scene, tmp_path):
         want.append(r)
     hits, nodes, prims = oracle_lib.trace_rays(d, np.array(rays, np.float32))
     assert prims > 0 and (nodes > 0 or flat.desc.contents.num_recs <= 16)   # flat-list rule (TGHIP_FLAT_MAX_RECS)
+    # (exact since round 4: Embree's triangle test is restated down to its reciprocal, and Quad / Cube / Sphere::intersect always were)
     mism = 0
     for hgot, r in zip(hits, want):
-        if bool(r["hit"]) != (hgot["rec"] >= 0):
+        if bool(r["hit"]) != (hgot["rec"] >= 0) or (r["hit"] and np.float32(r["t"]) != hgot["t"]):
             mism += 1
-            continue
-        if r["hit"] and not close(hgot["t"], r["t"], 1e-4):
-            mism += 1
-    assert mism <= len(want)//100, "%d of %d closest hits differ" % (mism, len(want))
+    assert mism == 0, "%d of %d closest hits differ" % (mism, len(want))
 
     # BSDF eval / pdf / sample
     for b in u["bsdfs"]:

@@ -977,25 +977,48 @@ PT_DEV bool bsdfSample(const DeviceScene &s, int bi, Event &e)
 // ---------------------------------------------------------------------------------------------
 struct RayD { f3 o, d; float tmin, tmax; };
 
-/* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113);
- * Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c; exact division instead of rcp+Newton. */
+/* Embree's arithmetic in its triangle test, bit for bit (oracle/oracle.c: intel_rcpps / embree_rcp / edot has the derivation): the dot product
+ * associates from the right (common/math/vec3.h:182), and t / u / v are PRODUCTS with rcp(absDen) = r*(2 - r*a), r = RCPPS(a) -- the Intel
+ * instruction's estimate: 2^25/(4097 + 2 i) rounded to an integer for the operand's top 11 mantissa bits i, the operand's exponent negated
+ * (simd/vfloat4_sse2.h:166-173).  The integer quotient comes from v_rcp_f32 and is corrected by the exact remainder, so no division is
+ * executed: cheaper than the three exact divisions this replaced.  tests/test_gpu_libm.py holds embreeRcp to the oracle's. */
+PT_DEV float dotEmbree(f3 a, f3 b) { return a.x*b.x + (a.y*b.y + a.z*b.z); }
+PT_DEV float rcppsIntel(float x)
+{
+    const uint32_t u = __float_as_uint(x), sign = u & 0x80000000u, e = (u >> 23) & 0xffu, i = (u >> 12) & 0x7ffu;
+    const uint32_t d = 4097u + 2u*i;
+    int q = (int)(33554432.0f*__builtin_amdgcn_rcpf((float)d));          // within one of the quotient's floor
+    int r = (int)(33554432u - (uint32_t)q*d);
+    if (r < 0) { q -= 1; r += (int)d; }
+    if (r >= (int)d) { q += 1; r -= (int)d; }
+    if (2*r > (int)d) q += 1;                                             // d is odd: no ties
+    uint32_t bits = sign | ((253u - e) << 23) | ((uint32_t)(q - 4096) << 11);
+    if (e >= 253u) bits = (e == 255u && (u & 0x7fffffu)) ? (u | 0x00400000u) : sign;   // denormal result / 1/inf: zero; NaN quieted
+    if (e == 0u) bits = sign | 0x7f800000u;                                // zeros and denormals: infinity
+    return __uint_as_float(bits);
+}
+PT_DEV float embreeRcp(float a) { const float r = rcppsIntel(a); return r*(2.0f - r*a); }
+
+/* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113, finalize() :43-49);
+ * Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c. */
 PT_DEV bool triTest(f3 v0, f3 b, f3 c, const RayD &ray, float tmax, float &t, float &u, float &v)
 {
     f3 e1 = -b, e2 = c;
     f3 Ng = cross(e1, e2);
     f3 C = v0 - ray.o;
     f3 R = cross(ray.d, C);
-    float den = dot(Ng, ray.d);
+    float den = dotEmbree(Ng, ray.d);
     float absDen = fabsf(den);
     float sgn = den < 0.0f ? -1.0f : 1.0f;
-    float U = dot(R, e2)*sgn;
-    float V = dot(R, e1)*sgn;
+    float U = dotEmbree(R, e2)*sgn;
+    float V = dotEmbree(R, e1)*sgn;
     if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absDen))
         return false;
-    float T = dot(Ng, C)*sgn;
+    float T = dotEmbree(Ng, C)*sgn;
     if (!(T > absDen*ray.tmin && T < absDen*tmax))
         return false;
-    t = T/absDen; u = U/absDen; v = V/absDen;
+    const float rcpAbsDen = embreeRcp(absDen);
+    t = T*rcpAbsDen; u = U*rcpAbsDen; v = V*rcpAbsDen;
     return true;
 }
 

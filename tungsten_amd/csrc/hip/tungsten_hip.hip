@@ -2141,6 +2141,8 @@ __global__ void k_debug_libm(int fn, const float *x, float *y, uint32_t n)
     case TGHIP_LIBM_ATAN2F: r = atan2fH(v, v2); break;
     case TGHIP_LIBM_POWF: r = powfH(v, v2); break;
     case TGHIP_LIBM_CBRTF: r = cbrtfH(v); break;
+    case TGHIP_LIBM_EMBREE_RCP: r = embreeRcp(v); break;
+    case TGHIP_LIBM_RCPPS: r = rcppsIntel(v); break;
     case TGHIP_LIBM_SINF: r = sinfH(v); break;
     case TGHIP_LIBM_COSF: r = cosfH(v); break;
     case TGHIP_LIBM_LOGF: r = logfH(v); break;
@@ -2156,7 +2158,7 @@ int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n)
 {
     if (!ctx) return TGHIP_E_INVALID;
     if (n == 0) return TGHIP_OK;
-    if (!x || !y || n > 0x3FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_CBRTF) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
+    if (!x || !y || n > 0x3FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_RCPPS) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *dx = nullptr, *dy = nullptr;
     const size_t nx = (fn == TGHIP_LIBM_ATAN2F || fn == TGHIP_LIBM_POWF) ? 2*n : n;
