@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--no-traffic", dest="traffic", action="store_false",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
     ap.add_argument("--opt", action="append", default=[], help="shim option key=value (tghip_set_option)")
+    ap.add_argument("--count-spp", type=int, default=0,
+                    help="spp of the untimed counting pass that feeds the byte model (default: the workload's own spp, i.e. exact counts; a lower "
+                         "value scales the counts by spp/count_spp -- for the multi-minute configurations)")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="development aid: on ONE GPU render and time EVERY one of N tile shards in turn (what the ranks of an N-GPU run do; "
                          "reports max / mean / min over shards and the fixed cost of the framebuffer reduce)")
@@ -287,11 +290,15 @@ class Bench(object):
             check(lib.tghip_set_option(ctx, b"count_traversal", 1), "tghip_set_option")
             check(lib.tghip_reset_counters(ctx), "tghip_reset_counters")
             check(lib.tghip_clear_framebuffer(ctx), "clear")
-            check(lib.tghip_render_pass(ctx, C.byref(pass_desc)), "render")
+            count_spp = min(spp, a.count_spp) if a.count_spp > 0 else spp
+            count_desc = pass_desc if count_spp == spp else tgdist.shard_pass(self.rank, self.world, 0, count_spp, tg.DEFAULT_SEED)
+            check(lib.tghip_render_pass(ctx, C.byref(count_desc)), "render")
             check(lib.tghip_wait(ctx), "wait")
             cc = tg.TgHipCounters()
             lib.tghip_get_counters(ctx, C.byref(cc))
             cc = counters_dict(cc)
+            if count_spp != spp:                 # (the first count_spp samples of every pixel stand for all of them)
+                cc = {k: (v*spp//count_spp if isinstance(v, int) else v*spp/count_spp) for k, v in cc.items()}
             check(lib.tghip_set_option(ctx, b"count_traversal", 0), "tghip_set_option")
             is_flat = int(flat.info.num_recs) <= 16
             fused = is_flat and cc["shadow_slots"] == 0 and cc["shadow_rays"] > 0
@@ -404,6 +411,7 @@ class Bench(object):
                 "roofline": roofline,
                 "cpu_baseline": cpu_baseline(a, scene, path, flat, w, h, spp, self.tmp) if cpu else None,
                 "kernels": kernels,
+                "count_pass_spp": count_spp,
                 "rays_per_sample": round(rays/max(cc["samples"], 1), 3),
                 "nodes_per_ray": round(cc["nodes_visited"]/rays, 2), "prims_per_ray": round(cc["prims_tested"]/rays, 2),
                 "bvh": {"nodes": int(flat.info.num_nodes), "records": int(flat.info.num_recs), "depth": int(flat.info.bvh_depth),

@@ -18,12 +18,12 @@ SEED = tg.DEFAULT_SEED
 
 CASES = {
     "c3_dielectric": (lambda d, res, spp: scenes.materialtest(d, resolution=res, spp=spp, edit=scenes._mt_material({"type": "dielectric", "ior": 1.5, "albedo": 1})),
-                      (1920, 1080), 8, (3.0, 9.0), 0.05),
+                      (1920, 1080), 8, (3.0, 9.0), 0.0),
     "c3_rough_dielectric": (lambda d, res, spp: scenes.materialtest(d, resolution=res, spp=spp, edit=scenes._mt_material(
                                 {"type": "rough_dielectric", "ior": 1.5, "distribution": "ggx", "roughness": 0.1, "albedo": 1})),
-                            (1920, 1080), 8, (3.0, 9.0), 0.05),
-    "c4_mesh1m": (lambda d, res, spp: scenes.mesh1m(d, resolution=res, spp=spp), (1920, 1080), 8, (2.5, 7.0), 0.05),
-    "c5_instances10k": (lambda d, res, spp: scenes.instances10k(d, resolution=res, spp=spp), (3840, 2160), 4, (2.0, 9.0), 0.08),
+                            (1920, 1080), 8, (3.0, 9.0), 0.0),
+    "c4_mesh1m": (lambda d, res, spp: scenes.mesh1m(d, resolution=res, spp=spp), (1920, 1080), 8, (2.5, 7.0), 0.0),
+    "c5_instances10k": (lambda d, res, spp: scenes.instances10k(d, resolution=res, spp=spp), (3840, 2160), 4, (2.0, 9.0), 0.0),
 }
 
 
@@ -52,6 +52,6 @@ def test_baseline_configuration_at_full_size(case, tmp_path):
             om[iy, x] = acc/spp
     flat.close()
     gm = mean[y0:y0 + 16]
-    # (a divergent path is a divergent pixel at these sample counts; the bound is the per-sample divergence of the scene's BSDFs,
-    # tests/test_gpu_samples.py, times the samples per pixel, with margin)
-    compare(gm, om, max_bad=max_bad, mean_rel=3e-2)
+    # (round 4: the device does not leave the oracle's path in any golden sample, tests/test_gpu_samples.py -- the tile row is held to that too:
+    # every one of its 30 720 / 61 440 pixels within 1e-4 of the oracle's mean)
+    compare(gm, om, pix_rel=1e-4, max_bad=max_bad, mean_rel=1e-5)

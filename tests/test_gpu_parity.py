@@ -1,11 +1,10 @@
 """Parity of the HIP path (through the C-ABI) against the CPU oracle on the same inputs, against the
 committed reference goldens, and -- at BASELINE.json's full sizes -- through size-independent properties.
 
-Tolerances (fp32 path, DESIGN.md "Numerics"): the kernels are compiled with -ffp-contract=off and follow the
-oracle's operation order, but device sinf/cosf/expf/sqrtf/division differ from glibc by ulps, and a path is a
-chaotic function of its hits; so: closest hits t/u/v rel 1e-5 with identical record ids (ties aside);
-per-pixel means rel 2e-2 on >= 99% of the pixels (stated per case), image mean rel 5e-3; integer outputs
-(sample counts, ray/visit counters) exact."""
+Tolerances (fp32 path, DESIGN.md "Numerics"): the kernels are compiled with -ffp-contract=off, follow the oracle's operation
+order and evaluate the host libm's functions and Embree's triangle arithmetic restated bit for bit; so: closest hits with identical
+record ids and t/u/v; per-pixel means within 1e-4 on EVERY pixel against the oracle (against the reference's goldens: except for
+the measured handful of divergent samples of ten cases), image mean rel 1e-5; integer outputs (sample counts, ray / visit counters) exact."""
 import os
 
 import numpy as np
@@ -66,25 +65,17 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
     assert (count == ocount).all() and (count == spp).all()
     assert c.samples == flat.width*flat.height*spp == oc.samples
     omean = osum/np.maximum(ocount, 1)[..., None]
-    loose = "dielectric" in name or "transparency" in name or "smoke" in name or "volumetric" in name or name in ("zoo_a", "zoo_b", "zoo_b_sobol", "zoo_d", "mesh1m", "cornell_instances", "water_caustic", "cornell_bump")
-    # The shipped non-exponential scene lights each box with a 4.7 x 3.8 mm quad.  Quad::approximateRadiance (Quad.cpp:253-281) gets
-    # such a light's solid angle (1e-5 sr) as 2 pi minus four arc cosines, so chooseLight's selection weights move by several per
-    # cent with the last bit of anything upstream.  The device restates glibc's acosf / sinf / cosf / logf / expf bit for bit
-    # (pt_libm.h), which holds five of the six cases -- and `cornell_speck_lights`, whose quarter-millimetre emitters have weights
-    # that are rounding noise by construction -- to the strict bounds; the Davis transmittance calls powf (ocml's): 0.39 % of that
-    # case's samples differ from the reference's (tests/test_gpu_samples.py), compared at the noise level of that effect.
-    ill = name == "non_exponential_davis"
-    if ill:
-        compare(mean, omean, pix_rel=0.25, max_bad=0.08, mean_rel=2e-2)
-    else:
-        compare(mean, omean, max_bad=0.03 if loose else 0.01, mean_rel=2e-2 if loose else 5e-3)
-    # ray counts agree up to the divergent paths
+    # Round 4: the device evaluates the host libm's own functions and Embree's own triangle arithmetic (pt_libm.h, pt_scene.h: embreeRcp), and in
+    # none of the 508 032 golden samples does it leave the oracle's path (tests/test_gpu_samples.py, profiles/r4_device_diverge.jsonl).  So the
+    # images are compared at rounding level -- the device sums a pixel's samples in chunks, the oracle one by one --: EVERY pixel within 1e-4.
+    compare(mean, omean, pix_rel=1e-4, max_bad=0.0, mean_rel=1e-5)
+    # ray counts: the same paths, so the same rays
     if "cateye" in name:
         # a vignetted camera sample (ThinlensCamera.cpp:119-124) is a black sample without a ray in the reference; the device
         # gives it zero throughput and lets its primary ray find that out, i.e. traces one ray more per such sample
         assert 0 <= int(c.closest_rays) - int(oc.closest_rays) <= oc.samples
     else:
-        assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 0.01*oc.closest_rays
+        assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 8
     if name == "cornell_skydome":
         # the sky image is black below the horizon; the reference tests visibility before it looks the emission up (TraceBase.cpp:163-173),
         # the device looks the emission up first and queues no shadow ray for a black one: fewer rays, the same radiance
@@ -92,21 +83,18 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
     elif "mesh" not in name or name == "mesh1m":
         # (a sampled mesh emitter's visibility query doubles as its light.intersect, so the device traces every such ray,
         # while the oracle only counts the ones whose light.intersect succeeded)
-        assert abs(int(c.shadow_rays) - int(oc.shadow_rays)) <= 0.01*oc.shadow_rays + 2
+        assert abs(int(c.shadow_rays) - int(oc.shadow_rays)) <= 8
+    # ... and against the reference's own per-sample output: the same, except in the oracle's ten cases with divergent samples
+    # (tests/test_oracle_golden.py: DIVERGING -- coincident faces, the reference's instance override), where at most that many pixels differ
+    from test_oracle_golden import DIVERGING, diverge_bound
     ref = np.load(os.path.join(scenes.GOLDEN, name + "_samples.npz"))["samples"].mean(axis=2)
-    if name == "cornell_instances":
-        # ~2.5 % of the reference's paths take a farther instance for a nearer one (Instance.cpp:296, see
-        # tests/test_oracle_golden.py); with 8 samples per pixel that touches about every fifth pixel
-        compare(mean, ref, max_bad=0.3, mean_rel=3e-2)
-    elif ill:
-        compare(mean, ref, pix_rel=0.25, max_bad=0.08, mean_rel=2e-2)
-    else:
-        compare(mean, ref, max_bad=0.04 if loose else 0.012, mean_rel=2e-2 if loose else 5e-3)
+    allowed = diverge_bound(name, 0)
+    compare(mean, ref, pix_rel=1e-4, max_bad=allowed/float(ref.shape[0]*ref.shape[1]), mean_rel=3e-2 if name in DIVERGING else 1e-5)
 
 
 @pytest.mark.parametrize("scene", ["cornell", "materialtest", "mesh1m", "instances"])
 def test_trace_rays_matches_oracle_exactly(scene, tmp_path):
-    """TraceableScene::intersect batched: identical record, t/u/v rel 1e-5, and IDENTICAL node/primitive visit
+    """TraceableScene::intersect batched: identical record, identical t/u/v, and IDENTICAL node/primitive visit
     counts (the counters that feed the roofline's algorithmic bytes)."""
     _skip_mt(scene)
     mk = {"cornell": scenes.cornell, "materialtest": scenes.materialtest, "mesh1m": scenes.mesh1m, "instances": scenes.cornell_instances}[scene]
@@ -134,11 +122,11 @@ def test_trace_rays_matches_oracle_exactly(scene, tmp_path):
     r.close()
     flat.close()
     same = ghits["rec"] == ohits["rec"]
-    assert same.mean() >= 0.9995, "record ids differ on %d rays" % (~same).sum()
+    assert same.all(), "record ids differ on %d rays" % (~same).sum()
     hit = same & (ohits["rec"] >= 0)
     assert hit.sum() > n//10
-    for k in ("t", "u", "v"):
-        assert np.allclose(ghits[k][hit], ohits[k][hit], rtol=1e-5, atol=1e-6), k
+    for k in ("t", "u", "v"):                   # the same operations in the same order on both sides: the same floats
+        assert (ghits[k][hit] == ohits[k][hit]).all(), (k, int((ghits[k][hit] != ohits[k][hit]).sum()))
     assert c.nodes_visited == onodes and c.prims_tested == oprims
     assert (ghits["rec"] == bhits["rec"]).mean() >= 0.999
 
@@ -411,7 +399,7 @@ def test_full_size_properties(scene, res, spp, tmp_path):
             om[iy, ix] = acc/spp
     flat.close()
     gm = mean[row0*16:row0*16 + 16, ::5]
-    compare(gm, om, max_bad=0.02, mean_rel=1e-2)
+    compare(gm, om, pix_rel=1e-4, max_bad=0.0, mean_rel=1e-5)
 
 
 def test_errors_and_abort(tmp_path):
@@ -522,8 +510,8 @@ def test_many_instances_match_oracle(tmp_path):
     osum, ocount = oracle_lib.render(flat.desc, flat.width, flat.height, 0, 4, SEED, counters=oc)
     flat.close()
     assert (count == ocount).all() and (count == 4).all()
-    compare(mean, osum/np.maximum(ocount, 1)[..., None], max_bad=0.03, mean_rel=2e-2)
-    assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 0.01*oc.closest_rays
+    compare(mean, osum/np.maximum(ocount, 1)[..., None], pix_rel=1e-4, max_bad=0.0, mean_rel=1e-5)
+    assert abs(int(c.closest_rays) - int(oc.closest_rays)) <= 8
     # (exact node / record visit counts of the two-level walk: test_trace_rays_matches_oracle_exactly[instances]; a pass's
     # totals differ because the device answers shadow rays with any-hit queries, the oracle with closest-hit walks)
 
