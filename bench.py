@@ -252,26 +252,44 @@ class Bench(object):
                         "note": "value and ms_per_step below are shard 0's; the estimate of an N-GPU step is max_ms + the reduce"}
             pass_desc = tgdist.shard_pass(0, a.emulate_shards, 0, spp, tg.DEFAULT_SEED)
 
+        split = [0.0, 0.0]                       # this rank's seconds in its shard's render / in the exchange step, over the timed region
+
         def step():
+            t_a = time.perf_counter()
             check(lib.tghip_clear_framebuffer(ctx), "tghip_clear_framebuffer")
             check(lib.tghip_render_pass(ctx, C.byref(pass_desc)), "tghip_render_pass")
             check(lib.tghip_wait(ctx), "tghip_wait")
+            t_b = time.perf_counter()
             # the exchange step: float framebuffer sum-reduce over xGMI (tile ownership is disjoint -> exact)
             tgdist.reduce_framebuffer(fb_sum, fb_cnt, dst=0)
+            split[0] += t_b - t_a
+            split[1] += time.perf_counter() - t_b
 
         for _ in range(warmup):
             step()
         check(lib.tghip_reset_counters(ctx), "tghip_reset_counters")
         check(lib.tghip_set_option(ctx, b"time_kernels", 0 if a.no_kernel_timing else 1), "tghip_set_option")
         self.fence()
+        split[0] = split[1] = 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         self.fence()
         elapsed = time.perf_counter() - t0
+        per_rank = None
         if self.dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.shared else "cuda")
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            # every rank's own clock, so that a SCALE line explains itself: the shard's render, the exchange step (which includes waiting for
+            # the slowest rank: the reduce is a collective), and the whole timed region
+            mine = torch.tensor([split[0], split[1], elapsed], dtype=torch.float64, device="cpu" if self.shared else "cuda")
+            every = [torch.zeros_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(every, mine)
+            per_rank = {"render_ms_per_step": [round(float(e[0])/steps*1e3, 3) for e in every],
+                        "reduce_ms_per_step": [round(float(e[1])/steps*1e3, 3) for e in every],
+                        "total_ms_per_step": [round(float(e[2])/steps*1e3, 3) for e in every],
+                        "note": "each rank's host clock over the timed region; reduce = the framebuffer sum-reduce to rank 0, a collective: it also "
+                                "holds the time a rank waits for the slowest one"}
             elapsed = float(t.item())
         timed = tg.TgHipCounters()
         lib.tghip_get_counters(ctx, C.byref(timed))
@@ -422,6 +440,10 @@ class Bench(object):
             }
             if emulated:
                 out["emulated_shards"] = emulated
+            if per_rank:
+                out["per_rank"] = per_rank
+            else:
+                out["render_ms_per_step"] = round(split[0]/steps*1e3, 3)
         lib.tghip_bind_framebuffer(ctx, None, None)
         if not shared:
             lib.tghip_destroy(ctx)

@@ -83,7 +83,10 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
     elif "mesh" not in name or name == "mesh1m":
         # (a sampled mesh emitter's visibility query doubles as its light.intersect, so the device traces every such ray,
         # while the oracle only counts the ones whose light.intersect succeeded)
-        assert abs(int(c.shadow_rays) - int(oc.shadow_rays)) <= 8
+        # The reference traces a light sample's shadow ray BEFORE it looks at the emission it would carry (attenuatedEmission, TraceBase.cpp:
+        # 144-174), the device queues none for a sample that reaches a black (back) side of its light: a few rays fewer (0.1-0.3 % in the Cornell
+        # box, whose light faces down), the same radiance -- never more.
+        assert 0 <= int(oc.shadow_rays) - int(c.shadow_rays) <= 0.01*oc.shadow_rays + 2
     # ... and against the reference's own per-sample output: the same, except in the oracle's ten cases with divergent samples
     # (tests/test_oracle_golden.py: DIVERGING -- coincident faces, the reference's instance override), where at most that many pixels differ
     from test_oracle_golden import DIVERGING, diverge_bound
@@ -559,6 +562,43 @@ def test_rccl_framebuffer_reduce_behind_the_c_abi(n, tmp_path):
     for ctx in ctxs:
         tg.lib.tghip_destroy(ctx)
     flat.close()
+
+
+def test_a_failing_reduce_falls_back_to_the_host_sum(tmp_path, capfd):
+    """tghip_reduce_framebuffers made to fail (the "fail_reduce" fault-injection option): the C-ABI call reports TGHIP_E_HIP with a message and
+    leaves the shards' framebuffers alone, and the integrator's exchange step (Integrator.cpp: fetchFramebuffer) falls back to per-device
+    downloads summed on the host -- the image of the unsharded render bit for bit -- and says so once on stderr."""
+    import ctypes as C
+    import json
+    w, h, spp = 200, 120, 4
+    path = scenes.cornell(tmp_path, resolution=(w, h), spp=spp)
+    whole, wsum, wcount, _ = gpu_render(path)
+    # behind the C-ABI, one rank: the working path first, then the injected failure, then the working path again
+    flat, ctxs = _shard_contexts(path, 1, spp)
+    npix = w*h
+    s, c = np.empty((npix, 3), np.float32), np.empty(npix, np.uint32)
+    arr = (C.c_void_p*1)(*ctxs)
+    assert tg.lib.tghip_reduce_framebuffers(arr, 1, 0, s.ctypes.data, c.ctypes.data, npix) == 0
+    assert tg.lib.tghip_set_option(ctxs[0], b"fail_reduce", 1) == 0
+    s2 = np.full_like(s, -1)
+    assert tg.lib.tghip_reduce_framebuffers(arr, 1, 0, s2.ctypes.data, c.ctypes.data, npix) == -3      # TGHIP_E_HIP
+    assert b"forced failure" in tg.lib.tghip_last_error(ctxs[0]) and (s2 == -1).all()
+    assert tg.lib.tghip_set_option(ctxs[0], b"fail_reduce", 0) == 0
+    assert tg.lib.tghip_reduce_framebuffers(arr, 1, 0, s2.ctypes.data, c.ctypes.data, npix) == 0 and s2.tobytes() == s.tobytes() == wsum.tobytes()
+    tg.lib.tghip_destroy(ctxs[0])
+    flat.close()
+    # through the integrator: two shards, the reduce fails, the host sums
+    d = json.load(open(path))
+    d["integrator"].update(devices=2, share_devices=True)
+    shared = os.path.join(str(tmp_path), "two.json")
+    json.dump(d, open(shared, "w"))
+    r = tg.Renderer(shared, seed=SEED)
+    r.set_option("fail_reduce", 1)
+    r.render()
+    mean, ssum, count = r.image()
+    r.close()
+    assert (count == wcount).all() and ssum.tobytes() == wsum.tobytes()
+    assert "summing the shards on the host" in capfd.readouterr().err
 
 
 @pytest.mark.gpu

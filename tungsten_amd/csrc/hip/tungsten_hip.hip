@@ -123,6 +123,7 @@ struct tghip_ctx {
     bool tailOpt = true;
     long long tailThreshold = 8192;
     bool instShadowJoin = true;           // "inst_shadow_join": 0 = the instanced wide shadow kernel without PT_TURN_JOIN (the miscompiled variant; repro tool only)
+    bool failReduce = false;              // "fail_reduce" option (fault injection for the reduce's callers)
     int wideStride = 80;                  // "wide_node_stride" option (80 or 128; takes effect at the next upload)
     uint32_t width = 0, height = 0;
 
@@ -837,6 +838,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "suspend_min_queue") ctx->suspendMinQueue = int(std::min<long long>(std::max<long long>(value, 0), 1 << 20));
     else if (k == "decouple") ctx->decoupleOpt = value != 0;
     else if (k == "inst_shadow_join") ctx->instShadowJoin = value != 0;
+    else if (k == "fail_reduce") ctx->failReduce = value != 0;   // fault injection: tghip_reduce_framebuffers with this context as a rank fails (the hosts' fallbacks are tested with it)
     else if (k == "tail_kernel") ctx->tailOpt = value != 0;
     else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
     else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
@@ -2076,6 +2078,7 @@ int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rg
     std::vector<int> devices;
     for (int i = 0; i < n; ++i) {
         tghip_ctx *c = ctxs[i];
+        if (c->failReduce) { rc->error = "tghip_reduce_framebuffers: forced failure (the \"fail_reduce\" option)"; return TGHIP_E_HIP; }
         if (!c->haveScene) { rc->error = "tghip_reduce_framebuffers: a context has no scene"; return TGHIP_E_NOSCENE; }
         if (c->width != rc->width || c->height != rc->height) { rc->error = "tghip_reduce_framebuffers: the contexts render different images"; return TGHIP_E_INVALID; }
         for (int d : devices)
