@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 7
+#define TGHIP_ABI_VERSION 8
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -60,6 +60,16 @@ enum {
  * _tfVerts, TriangleMesh.cpp:542-552).  64-byte nodes; a child reference is either an
  * internal node index (>= 0) or a leaf (bit 31 set): count = (ref >> 27) & 15, first record
  * = ref & 0x07FFFFFF.  Leaves are contiguous runs of 48-byte primitive records. */
+/* a node of the reference's own BVH over the instances of an `instances` primitive as the host's restatement of its builder
+ * produces it (bvh/BinaryBvh.hpp: TinyBvhNode): box = x: lmin rmin lmax rmax, then y, then z; count = 0: inner node, children
+ * left and left + 1; else a leaf of `count` (1 or 2) instances at slots [left, left + count) of BinaryBvh::_primIndices.
+ * Host-side only: the scene description carries these trees as TgHipBvhNode entries (see the instance-set record). */
+typedef struct TgHipInstNode {
+    float box[12];
+    uint32_t left, count;
+    uint32_t pad[2];
+} TgHipInstNode;              /* 64 B */
+
 typedef struct TgHipBvhNode {
     float   lo0[3], hi0[3];   /* child 0 bounds */
     float   lo1[3], hi1[3];   /* child 1 bounds */
@@ -72,7 +82,9 @@ typedef struct TgHipBvhNode {
 #define TGHIP_LEAF_FIRST(ref)  ((uint32_t)(ref) & 0x07FFFFFFu)
 #define TGHIP_MAKE_LEAF(first, count) (int32_t)(TGHIP_LEAF_FLAG | ((uint32_t)(count) << 27) | (uint32_t)(first))
 #define TGHIP_MAX_LEAF         15
-#define TGHIP_MAX_BVH_DEPTH    48   /* builder guarantees depth <= this (device stack size) */
+#define TGHIP_MAX_TREE_DEPTH   48   /* the builder's bound for ONE tree */
+#define TGHIP_MAX_BVH_DEPTH    96   /* builder guarantees depth <= this (device stack size; single-level trees stay below 48, the
+                                       three-level walk of scenes with instances adds the levels of its trees) */
 /* Scenes with at most this many primitive records are intersected as a flat list in record order (every ray
  * tests every record; the wave walks the list uniformly, so record data comes through the scalar cache) instead of
  * through the BVH -- the analogue of the reference's top-level Embree scene over a handful of user-geometry
@@ -112,7 +124,7 @@ typedef struct TgHipWideNode {
 
 /* record kinds (meta >> 29) */
 enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC_SPHERE = 3, TGHIP_REC_INSTANCE = 4,
-       TGHIP_REC_DISK = 5, TGHIP_REC_CYLINDER = 6 };
+       TGHIP_REC_DISK = 5, TGHIP_REC_CYLINDER = 6, TGHIP_REC_INSTANCE_SET = 7 };
 #define TGHIP_REC_KIND(meta)   ((uint32_t)(meta) >> 29)
 #define TGHIP_REC_OBJECT(meta) ((uint32_t)(meta) & 0x1FFFFFFFu)
 
@@ -125,7 +137,18 @@ enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC
  *             (uint32), c[1] = bits of the instance number i, c[2] = bits of the root node index of the master's wide
  *             subtree (uint32; scenes with a wide BVH); the object is the `instances` primitive.  The master's
  *             triangle records (in master space, i.e. with the master's own transform applied) and its BVH2 subtree
- *             follow the top-level ones in recs / tri_attrs / nodes and are reachable only through instance records. */
+ *             follow the top-level ones in recs / tri_attrs / nodes and are reachable only through instance records.
+ *             (ABI 8: c[1] = bits of the index of the instance's leaf in inst_leaf_boxes.)
+ *   instance set (ABI 8): one `instances` primitive as the reference intersects it -- Instance::intersect walks ITS OWN BVH over
+ *             the instances (bvh/BinaryBvh.hpp) and keeps the LAST hit in that tree's visiting order, each instance having
+ *             been handed a ray with farT = infinity (primitives/Instance.cpp:290-311).  a = min, b = max of the primitive's
+ *             bounds (BinaryBvh::_bounds), c[0] = bits of the root of the reference's tree, restated node for node by the host
+ *             (csrc/host/RefInstanceBvh.cpp) and stored as ordinary TgHipBvhNode entries with the reference's exact child
+ *             boxes: a node index, or -- one or two instances in all -- a leaf reference.  Leaf references of THAT tree
+ *             index inst_prims[] (BinaryBvh::_primIndices: the instance records, kind TGHIP_REC_INSTANCE, of the leaf's one
+ *             or two instances).  The closest-hit walk reaches the set through the scene's BVH2 (nodes[0]: over the
+ *             non-instance records and the sets); the wide BVH -- walked by any-hit shadow queries, for which the order is
+ *             immaterial -- holds the instance records themselves, boxed by their leaf of the reference's tree. */
 typedef struct TgHipPrimRec {
     float a[3]; uint32_t meta;
     float b[3]; float p0;
@@ -305,7 +328,12 @@ typedef struct TgHipSceneDesc {
      * sobol::Matrices::matrices (thirdparty/sobol/sobol.h:30-35); NULL/0 unless passes use TGHIP_PASS_SOBOL */
     const uint32_t     *sobol_matrices;  uint64_t num_sobol_words;
     uint32_t num_instances;               /* instance records among recs (0: single-level scene) */
-    uint32_t num_top_recs;                /* records of the top-level BVH = recs[0, num_top_recs); the rest belong to masters */
+    uint32_t num_top_recs;                /* top-level records = recs[0, num_top_recs): the non-instance and the instance records in the
+                                             wide BVH's order, then the instance-set records; the rest belong to masters */
+    /* ABI 8, scenes with instances: the leaf slots of the reference's instance trees (see the instance-set record) -> instance record,
+     * and per leaf of those trees its box as its parent stores it: lo[3], hi[3], 2 x pad (the root's bounds for a tree that is one leaf) */
+    const uint32_t     *inst_prims;       uint32_t num_inst_prims;
+    const float        *inst_leaf_boxes;  uint32_t num_inst_leaves;
     const TgHipMedium  *media;  uint32_t num_media;   /* Scene::_media; NULL/0 = the scene has no participating media */
     /* the wide BVH: wide_nodes[0] is the root of the tree over recs[0, num_top_recs); with instances every master's wide
      * subtree follows (its root in the instance records' c[2]).  NULL/0 = the device walks the BVH2 (flat-list scenes do) */

@@ -1410,6 +1410,111 @@ static void instance_inv_quat(const TgHipPrimRec *r, float *q) { q[0] = r->p0; q
 
 static void bvh_walk(const TgHipSceneDesc *s, int32_t root, const Ray *ray, float *tmax, Hit *hit, TravStats *st, int objFilter, int32_t inst);
 
+/* ---- Instance::intersect as the reference computes it (primitives/Instance.cpp:290-311) -------------------------------------------
+ * The `instances` primitive walks ITS OWN bvh over the instances (bvh/BinaryBvh.hpp:197-287, restated below statement for statement;
+ * the tree itself is restated by the host, csrc/host/RefInstanceBvh.cpp, and arrives as BVH2 nodes with the reference's exact child
+ * boxes behind the instance-set record).  Every instance whose leaf the walk reaches gets the ray in its master's space with
+ * nearT = the distance at which the ray enters that leaf's box and farT = INFINITY (Ray::scatter's default), and a hit there replaces
+ * the hit so far -- nearer or not: `ray.setFarT(localRay.farT())`.  What bounds the damage is the walk's own tMax, the MINIMUM of the
+ * hit distances so far (:274), which culls the boxes that begin behind it.  So the result is the LAST hit in the tree's visiting
+ * order among the instances whose boxes begin in front of every hit found before them -- a function of the reference's tree, its
+ * near/far rule (`minMax[0] < minMax[1]`: the RIGHT child first on a tie) and its pop test, all of which are kept here.
+ * (Rounds 1-3 returned the nearest hit instead; 2.3 % of the samples of the crowded golden scene saw another surface.) */
+static inline float ref_max(float a, float b) { return a > b ? a : b; }     /* _mm_max_ps / Tungsten::max: the second operand when unordered */
+static inline float ref_min(float a, float b) { return a < b ? a : b; }
+/* BinaryBvh::bboxIntersection (:155-178) */
+static int ref_bbox_intersection(const float *lo, const float *hi, const Ray *ray, float *tMin, float *tMax)
+{
+    const float o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};
+    float ttMin = *tMin, ttMax = *tMax;
+    for (int i = 0; i < 3; ++i) {
+        const float invD = 1.0f/d[i], relMin = lo[i] - o[i], relMax = hi[i] - o[i];
+        if (invD >= 0.0f) {
+            ttMin = ref_max(ttMin, relMin*invD);
+            ttMax = ref_min(ttMax, relMax*invD);
+        } else {
+            ttMax = ref_min(ttMax, relMin*invD);
+            ttMin = ref_max(ttMin, relMax*invD);
+        }
+    }
+    if (ttMin <= ttMax) { *tMin = ttMin; *tMax = ttMax; return 1; }
+    return 0;
+}
+/* one child of a node in BinaryBvh::trace (:231-242): entry distance and -- negated, as the reference carries it -- exit distance, clipped
+ * to [nearT, farT]; near / far planes by the sign of the direction (>= 0: keep), the products with 1/d and -1/d */
+static inline int ref_child_test(const float *lo, const float *hi, const float *o, const float *d, const float *invD, float nearT, float farT, float *tEntry)
+{
+    float tn[3], ntf[3];
+    for (int k = 0; k < 3; ++k) {
+        const float nearP = d[k] >= 0.0f ? lo[k] : hi[k], farP = d[k] >= 0.0f ? hi[k] : lo[k];
+        tn[k] = (nearP - o[k])*invD[k];
+        ntf[k] = (farP - o[k])*(-invD[k]);
+    }
+    const float tmin = ref_max(ref_max(ref_max(tn[0], tn[1]), tn[2]), nearT);
+    const float ntmax = ref_max(ref_max(ref_max(ntf[0], ntf[1]), ntf[2]), -farT);
+    *tEntry = tmin;
+    return tmin <= -ntmax;
+}
+static void instance_set_walk(const TgHipSceneDesc *s, uint32_t setRec, const Ray *ray, float *rayFarT, Hit *hit, TravStats *st)
+{
+    const TgHipPrimRec *set = &s->recs[setRec];
+    struct { int32_t node; float tMin; } stack[TGHIP_MAX_BVH_DEPTH + 2];
+    int sp = 0;
+    float tMin = ray->tmin, tMax = *rayFarT;
+    if (!ref_bbox_intersection(set->a, set->b, ray, &tMin, &tMax))
+        return;
+    const float o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};
+    const float invD[3] = {1.0f/d[0], 1.0f/d[1], 1.0f/d[2]};
+    const float nearT = ray->tmin;
+    float farT = *rayFarT;                        /* nearFar[2..3], negated: the ray's farT until the first leaf, the walk's tMax after it */
+    int32_t node;
+    memcpy(&node, &set->c[0], 4);
+    for (;;) {
+        while (node >= 0) {
+            const TgHipBvhNode *n = &s->nodes[node];
+            if (st) st->nodes++;
+            float e0, e1;
+            const int hitL = ref_child_test(n->lo0, n->hi0, o, d, invD, nearT, farT, &e0);
+            const int hitR = ref_child_test(n->lo1, n->hi1, o, d, invD, nearT, farT, &e1);
+            if (hitL && hitR) {
+                if (e0 < e1) { stack[sp].node = n->child1; stack[sp].tMin = e1; ++sp; node = n->child0; tMin = e0; }
+                else         { stack[sp].node = n->child0; stack[sp].tMin = e0; ++sp; node = n->child1; tMin = e1; }
+            } else if (hitL) { node = n->child0; tMin = e0; }
+            else if (hitR) { node = n->child1; tMin = e1; }
+            else goto pop;
+        }
+        {
+            const uint32_t first = TGHIP_LEAF_FIRST(node), count = TGHIP_LEAF_COUNT(node);
+            for (uint32_t k = first; k < first + count; ++k) {
+                /* the intersector lambda of Instance::intersect (:294-303) */
+                const uint32_t ri = s->inst_prims[k];
+                const TgHipPrimRec *r = &s->recs[ri];
+                if (st) st->prims++;
+                float q[4];
+                instance_inv_quat(r, q);
+                Ray local = {quat_rotate(q, vsub(ray->o, ld3(r->a))), quat_rotate(q, ray->d), tMin, INFINITY};
+                uint32_t root;
+                memcpy(&root, &r->c[0], 4);
+                float localFarT = INFINITY;
+                Hit lh;
+                lh.rec = -1; lh.inst = -1; lh.t = localFarT; lh.u = lh.v = 0.0f;
+                bvh_walk(s, (int32_t)root, &local, &localFarT, &lh, st, -1, (int32_t)ri);
+                if (lh.rec >= 0) { *hit = lh; *rayFarT = localFarT; }
+            }
+            tMax = ref_min(tMax, *rayFarT);
+            farT = tMax;
+        }
+pop:
+        for (;;) {
+            if (sp == 0) return;
+            --sp;
+            node = stack[sp].node;
+            tMin = stack[sp].tMin;
+            if (!(tMax < tMin)) break;
+        }
+    }
+}
+
 static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float *tmax, Hit *hit, TravStats *st, int objFilter, int32_t inst)
 {
     const TgHipPrimRec *r = &s->recs[i];
@@ -1423,17 +1528,9 @@ static void test_rec(const TgHipSceneDesc *s, uint32_t i, const Ray *ray, float 
     case TGHIP_REC_SPHERE: ok = sphere_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back); u = (float)back; break;
     case TGHIP_REC_DISK: ok = disk_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &v, &back); u = (float)back; break;   /* v carries rSq */
     case TGHIP_REC_CYLINDER: ok = cylinder_test(&s->objects[TGHIP_REC_OBJECT(r->meta)], ray, *tmax, &t, &back, &v); u = (float)back; break;   /* v carries the cap sign */
-    case TGHIP_REC_INSTANCE: {
-        /* Instance::intersect (primitives/Instance.cpp:290-311): the ray goes into the master's space -- rotation and
-         * translation only, so distances along it are unchanged -- and the master's own intersect shortens it */
-        float q[4];
-        instance_inv_quat(r, q);
-        Ray local = {quat_rotate(q, vsub(ray->o, ld3(r->a))), quat_rotate(q, ray->d), ray->tmin, *tmax};
-        uint32_t root;
-        memcpy(&root, &r->c[0], 4);
-        bvh_walk(s, (int32_t)root, &local, tmax, hit, st, -1, (int32_t)i);
+    case TGHIP_REC_INSTANCE_SET:
+        instance_set_walk(s, i, ray, tmax, hit, st);
         return;
-    }
     default: break;
     }
     (void)objFilter;
@@ -1606,7 +1703,7 @@ static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, Hit *hit
                 test_rec(s, i, ray, &tmax, hit, st, objFilter, -1);
         return hit->rec >= 0;
     }
-    if (g_use_wide && s->wide_nodes)
+    if (g_use_wide && s->wide_nodes && s->num_instances == 0)   /* (with instances the wide BVH serves any-hit queries only: closest hits are a matter of the reference's visiting order) */
         wide_walk(s, ray, &tmax, hit, st, objFilter);
     else
         bvh_walk(s, 0, ray, &tmax, hit, st, objFilter, -1);

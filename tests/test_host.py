@@ -70,7 +70,7 @@ def test_cornell_flattening(tmp_path):
     flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(64, 36), spp=4))
     d = flat.desc.contents
     assert (flat.width, flat.height) == (64, 36)
-    assert d.abi_version == 7
+    assert d.abi_version == 8
     assert d.num_objects == 8 and d.num_lights == 1 and d.num_infinite_lights == 0
     assert d.num_recs == 8                       # 6 quads + 2 cubes, analytic records (Quad.cpp / Cube.cpp)
     light = d.objects[d.lights[0]]
@@ -249,70 +249,58 @@ def test_wide_bvh_is_a_conservative_collapse_of_the_bvh2(tmp_path):
     flat.close()
 
 
-def test_flat_list_scenes_carry_no_wide_bvh_and_instanced_scenes_a_two_level_one(tmp_path):
-    import oracle_lib
+def test_flat_list_scenes_carry_no_wide_bvh_and_instanced_scenes_the_references_tree(tmp_path):
+    """Scenes with an `instances` primitive (ABI 8): the scene's BVH2 holds ONE record for the primitive, behind which the reference's own
+    tree over the instances follows (csrc/host/RefInstanceBvh.cpp restates its builder; stored as BVH2 nodes with the reference's exact
+    child boxes, leaves of one or two instances through inst_prims) -- what closest hits walk, in the reference's order --, and the wide
+    BVH holds the instance records themselves, each boxed by its leaf of that tree -- what any-hit queries walk."""
     flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(16, 9), spp=1))
     assert flat.desc.contents.num_wide_nodes == 0
     flat.close()
-    # instances: a wide tree over the instance records + one wide subtree per master behind it; the two-level wide walk finds
-    # what the two-level BVH2 walk finds
     flat = tg.FlattenedScene(scenes.instances10k(tmp_path, resolution=(16, 9), spp=1, count=300, n_lat=12, n_lon=12))
     d = flat.desc.contents
-    assert d.num_instances == 300 and d.num_wide_nodes > 4
-    check_bvh_roots = set()
+    assert d.num_instances == 300 and d.num_wide_nodes > 4 and d.num_inst_prims == 300 and 150 <= d.num_inst_leaves <= 300
     recs = _np(d.recs, d.num_recs, np.float32, 12).view(np.uint32)
-    for r in range(d.num_top_recs):
-        if recs[r][3] >> 29 == 4:
-            assert 0 < recs[r][10] < d.num_wide_nodes            # c[2]: the master's wide root
-            check_bvh_roots.add(int(recs[r][10]))
-    assert len(check_bvh_roots) == 4
-    rs = np.random.RandomState(11)
-    m = 3000
-    lo, hi = np.array(list(d.bounds_lo)), np.array(list(d.bounds_hi))
-    o = lo + (hi - lo)*rs.rand(m, 3)*1.2 - 0.1*(hi - lo)
-    dirs = rs.randn(m, 3)
-    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
-    rays = np.concatenate([o, np.full((m, 1), 1e-4), dirs, np.full((m, 1), np.inf)], axis=1).astype(np.float32)
-    h2, n2, p2 = oracle_lib.trace_rays(flat.desc, rays)
-    hw, nw, pw = oracle_lib.trace_rays(flat.desc, rays, wide=True)
-    assert (h2["rec"] >= 0).sum() > m//10
-    same = h2["rec"] == hw["rec"]
-    assert same.mean() >= 0.998
-    assert np.allclose(h2["t"][same], hw["t"][same], rtol=1e-6, atol=0) and nw < 0.6*n2
+    kinds = recs[:d.num_top_recs, 3] >> 29
+    assert (kinds == 4).sum() == 300 and (kinds == 7).sum() == 1 and kinds[d.num_top_recs - 1] == 7      # the set record follows the wide BVH's records
+    prims = _np(d.inst_prims, d.num_inst_prims, np.uint32, 1).reshape(-1)
+    assert sorted(prims.tolist()) == sorted(np.nonzero(kinds == 4)[0].tolist())                          # every instance in exactly one leaf slot
+    wide_roots = set()
+    for r in np.nonzero(kinds == 4)[0]:
+        assert 0 < recs[r][10] < d.num_wide_nodes and recs[r][9] < d.num_inst_leaves                     # c[2]: the master's wide root, c[1]: its leaf
+        wide_roots.add(int(recs[r][10]))
+    assert len(wide_roots) == 4
+    # the reference's tree behind the set record: every inner node's two boxes contain the boxes of everything below them (the builder
+    # computes them as unions), a leaf holds one or two instances, and every instance's position lies inside its leaf's box
+    nodes = _np(d.nodes, d.num_nodes, np.float32, 16)
+    refs = nodes.view(np.int32)
+    fl = recs.view(np.float32)
+    boxes = _np(d.inst_leaf_boxes, d.num_inst_leaves, np.float32, 8)
+    root = int(recs[d.num_top_recs - 1].view(np.int32)[8])
+    assert 0 < root < d.num_nodes
+    seen = []
+
+    def walk(ref, lo, hi, depth):
+        assert depth < 64
+        if ref < 0:
+            first, count = ref & 0x07FFFFFF, (ref >> 27) & 15
+            assert 1 <= count <= 2
+            for k in range(first, first + count):
+                ri = int(prims[k])
+                seen.append(ri)
+                assert (fl[ri][0:3] >= lo - 1e-4).all() and (fl[ri][0:3] <= hi + 1e-4).all()
+                leaf = boxes[recs[ri][9]]
+                assert (leaf[0:3] == lo).all() and (leaf[3:6] == hi).all()
+            return lo, hi
+        n = nodes[ref]
+        l0, h0, l1, h1 = n[0:3], n[3:6], n[6:9], n[9:12]
+        for (cl, ch), child in (((l0, h0), int(refs[ref][12])), ((l1, h1), int(refs[ref][13]))):
+            assert (cl >= lo).all() and (ch <= hi).all()
+            walk(child, cl, ch, depth + 1)
+        return lo, hi
+    walk(root, fl[d.num_top_recs - 1][0:3], fl[d.num_top_recs - 1][4:7], 0)
+    assert sorted(seen) == sorted(prims.tolist())
     flat.close()
-
-
-def test_instance_boxes_are_tight_and_lose_no_hit(tmp_path, monkeypatch):
-    """The top-level tree over the instances is built from the boxes of the masters' rotated vertices, not from the rotated corners of
-    the masters' boxes (Instance.cpp:411-423: what the reference bounds an instance by).  The box only decides how many masters a ray
-    enters in vain: every ray finds the same record at the same distance, with fewer nodes visited."""
-    import oracle_lib
-    path = scenes.instances10k(tmp_path, resolution=(16, 9), spp=1, count=400, n_lat=12, n_lon=12)
-    tight = tg.FlattenedScene(path)
-    monkeypatch.setenv("TGH_LOOSE_INSTANCE_BOUNDS", "1")
-    loose = tg.FlattenedScene(path)
-    monkeypatch.delenv("TGH_LOOSE_INSTANCE_BOUNDS")
-    d = tight.desc.contents
-    rs = np.random.RandomState(5)
-    m = 4000
-    lo, hi = np.array(list(d.bounds_lo)), np.array(list(d.bounds_hi))
-    o = lo + (hi - lo)*rs.rand(m, 3)*1.2 - 0.1*(hi - lo)
-    o[:, 1] = np.abs(o[:, 1]) + 0.2                            # above the floor, looking at the swarm from all around
-    dirs = rs.randn(m, 3)
-    dirs[:, 1] = -np.abs(dirs[:, 1])*0.3
-    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
-    rays = np.concatenate([o, np.full((m, 1), 1e-4), dirs, np.full((m, 1), np.inf)], axis=1).astype(np.float32)
-    for wide in (False, True):
-        ht, nt, _ = oracle_lib.trace_rays(tight.desc, rays, wide=wide)
-        hl, nl, _ = oracle_lib.trace_rays(loose.desc, rays, wide=wide)
-        assert (ht["rec"] >= d.num_top_recs).sum() > m//20, "too few rays reach a master for the test to mean anything"
-        # the records keep their order within the masters; top-level records may be numbered differently by the two trees
-        inside = ht["rec"] >= d.num_top_recs
-        assert (ht["rec"][inside] == hl["rec"][inside]).all() and ((hl["rec"] >= d.num_top_recs) == inside).all()
-        assert (ht["t"] == hl["t"]).all()
-        assert nt < 0.95*nl, (wide, nt, nl)
-    tight.close()
-    loose.close()
 
 
 def _bitmap_of(desc, w, h):

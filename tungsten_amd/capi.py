@@ -84,6 +84,8 @@ class TgHipSceneDesc(C.Structure):
                 ("light_tris", C.POINTER(f32)), ("num_light_tri_floats", u64),
                 ("sobol_matrices", C.POINTER(u32)), ("num_sobol_words", u64),
                 ("num_instances", u32), ("num_top_recs", u32),
+                ("inst_prims", C.POINTER(u32)), ("num_inst_prims", u32),
+                ("inst_leaf_boxes", C.POINTER(f32)), ("num_inst_leaves", u32),
                 ("media", C.POINTER(TgHipMedium)), ("num_media", u32),
                 ("wide_nodes", C.POINTER(TgHipWideNode)), ("num_wide_nodes", u32),
                 ("camera", TgHipCamera), ("settings", TgHipSettings),

@@ -577,7 +577,7 @@ PT_DEV bool boxTest(f3 lo, f3 hi, const RayD &ray, f3 invD, float tmax, float &t
 // record (and quad/cube object) loads have wave-uniform addresses and go through the scalar cache.
 template<bool COUNT, bool FLAT, uint32_t KINDS = KINDS_ALL>
 PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack, int stride,
-                              uint32_t &nodesVisited, uint32_t &primsTested)
+                              uint32_t &nodesVisited, uint32_t &primsTested, int root = 0)
 {
     float tmax = ray.tmax;
     float4 hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
@@ -590,7 +590,7 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
     }
     f3 invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
     int sp = 0;
-    int cur = 0;
+    int cur = root;
     for (;;) {
         if (cur >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
@@ -928,56 +928,132 @@ PT_DEV float4 traverseClosestWide(const DeviceScene &s, const RayD &worldRay, ui
     return hit;
 }
 
-// ---- two-level traversal: scenes with TGHIP_REC_INSTANCE records (primitives/Instance.cpp:290-328) -------------------
-// The top-level BVH holds one record per instance (always alone in its leaf).  Reaching one sends the ray into the
-// master's space (rotation + translation: distances along the ray are unchanged) and walks the master's subtree on the
-// same stack; when the stack is back at the level it had on entry the walk is in world space again.  Unlike the
-// reference -- whose Instance::intersect hands the master a ray with farT = infinity (Ray::scatter's default,
-// Instance.cpp:296) and so lets a farther instance visited later override a nearer hit -- this returns the nearest hit.
-struct InstanceWalk {
-    RayD world, ray;
-    f3 invD;
-    int instSp, curInst;
-};
-PT_DEV void instanceEnter(const DeviceScene &s, uint32_t ri, InstanceWalk &w, int sp, int &cur)
+// ---- scenes with `instances` primitives: Instance::intersect as the reference computes it (primitives/Instance.cpp:290-311) --------
+// The scene's BVH2 (nodes[0]) holds the non-instance records and one TGHIP_REC_INSTANCE_SET record per `instances` primitive.  Reaching
+// one runs BinaryBvh::trace (bvh/BinaryBvh.hpp:197-287) over the reference's OWN tree over the instances -- restated node for node by the
+// host (csrc/host/RefInstanceBvh.cpp), stored as BVH2 nodes with its exact child boxes, leaf references into inst_prims --: every
+// instance whose leaf the walk reaches gets the ray in its master's space with nearT = the distance at which the ray enters that leaf's
+// box and farT = INFINITY (Ray::scatter's default), and a hit there REPLACES the hit so far, nearer or not; the walk's own tMax is the
+// minimum of the hit distances so far and culls the boxes that begin behind it.  So the result is the last hit in that tree's visiting
+// order -- the tree, the near / far rule (`minMax[0] < minMax[1]`: the right child first on a tie), the entry distance kept with every
+// stacked node and re-checked when it is popped are all the reference's (oracle/oracle.c: instance_set_walk is the same statements).
+PT_DEV float refMax(float a, float b) { return a > b ? a : b; }      // _mm_max_ps / Tungsten::max: the SECOND operand when unordered
+PT_DEV float refMin(float a, float b) { return a < b ? a : b; }
+// BinaryBvh::bboxIntersection (:155-178)
+PT_DEV bool refBboxIntersection(f3 lo, f3 hi, const RayD &ray, float &tMin, float &tMax)
+{
+    const float o[3] = {ray.o.x, ray.o.y, ray.o.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+    float ttMin = tMin, ttMax = tMax;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float invD = 1.0f/d[i], relMin = l[i] - o[i], relMax = h[i] - o[i];
+        if (invD >= 0.0f) {
+            ttMin = refMax(ttMin, relMin*invD);
+            ttMax = refMin(ttMax, relMax*invD);
+        } else {
+            ttMax = refMin(ttMax, relMin*invD);
+            ttMin = refMax(ttMin, relMax*invD);
+        }
+    }
+    if (ttMin <= ttMax) { tMin = ttMin; tMax = ttMax; return true; }
+    return false;
+}
+// one child of a node in BinaryBvh::trace (:231-242): the entry distance and, negated as the reference carries it, the exit distance,
+// clipped to [nearT, farT]; near / far planes by the sign of the direction (>= 0: keep), products with 1/d and -1/d
+PT_DEV bool refChildTest(f3 lo, f3 hi, f3 o, f3 d, f3 invD, float nearT, float farT, float &tEntry)
+{
+    const float tnx = ((d.x >= 0.0f ? lo.x : hi.x) - o.x)*invD.x, ntfx = ((d.x >= 0.0f ? hi.x : lo.x) - o.x)*(-invD.x);
+    const float tny = ((d.y >= 0.0f ? lo.y : hi.y) - o.y)*invD.y, ntfy = ((d.y >= 0.0f ? hi.y : lo.y) - o.y)*(-invD.y);
+    const float tnz = ((d.z >= 0.0f ? lo.z : hi.z) - o.z)*invD.z, ntfz = ((d.z >= 0.0f ? hi.z : lo.z) - o.z)*(-invD.z);
+    const float tmin = refMax(refMax(refMax(tnx, tny), tnz), nearT);
+    const float ntmax = refMax(refMax(refMax(ntfx, ntfy), ntfz), -farT);
+    tEntry = tmin;
+    return tmin <= -ntmax;
+}
+// the ray in an instance's master space (Instance.cpp:295-296: rotation and translation only, so distances along it are unchanged)
+PT_DEV void instanceLocalRay(const DeviceScene &s, uint32_t ri, const RayD &world, float tmin, float tmax, RayD &local, int &masterRoot)
 {
     float4 r0 = at32(s.recs, ri*3u + 0u), r1 = at32(s.recs, ri*3u + 1u), r2 = at32(s.recs, ri*3u + 2u);
     f3 qc = -xyz(r1);                                   // conjugate(): the inverse rotation
-    w.ray.o = quatRotate(r1.w, qc, w.world.o - xyz(r0));
-    w.ray.d = quatRotate(r1.w, qc, w.world.d);
-    w.invD = mk3(1.0f/w.ray.d.x, 1.0f/w.ray.d.y, 1.0f/w.ray.d.z);
-    w.curInst = (int)ri;
-    w.instSp = sp;
-    cur = (int)__float_as_uint(r2.x);
+    local.o = quatRotate(r1.w, qc, world.o - xyz(r0));
+    local.d = quatRotate(r1.w, qc, world.d);
+    local.tmin = tmin; local.tmax = tmax;
+    masterRoot = (int)__float_as_uint(r2.x);
 }
-PT_DEV void instanceLeave(InstanceWalk &w)
+// Instance::intersect for the set record `setRec`: `tmax` is the ray's farT (it may GROW here), `hit` / `hitInst` the hit so far.
+// `stack` is the part of this lane's stack above what the caller has pushed: two words per stacked node, the master's walk above them.
+template<bool COUNT, uint32_t KINDS>
+PT_DEV void instanceSetIntersect(const DeviceScene &s, uint32_t setRec, const RayD &ray, float &tmax, float4 &hit, int &hitInst,
+                                 int *stack, int stride, uint32_t &nodesVisited, uint32_t &primsTested)
 {
-    w.ray.o = w.world.o; w.ray.d = w.world.d;
-    w.invD = mk3(1.0f/w.ray.d.x, 1.0f/w.ray.d.y, 1.0f/w.ray.d.z);
-    w.instSp = -1; w.curInst = -1;
+    const float4 s0 = at32(s.recs, setRec*3u + 0u), s1 = at32(s.recs, setRec*3u + 1u), s2 = at32(s.recs, setRec*3u + 2u);
+    if (COUNT) primsTested++;
+    float tMin = ray.tmin, tMax = tmax;
+    if (!refBboxIntersection(xyz(s0), xyz(s1), ray, tMin, tMax))
+        return;
+    const f3 invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
+    float farT = tmax;                                  // nearFar[2..3], negated: the ray's farT until the first leaf, the walk's tMax after it
+    int node = __float_as_int(s2.x);
+    int sp = 0;
+    for (;;) {
+        bool miss = false;
+        while (node >= 0) {
+            const float4 *n = &at32(s.nodes, (uint32_t)node*4u);
+            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (COUNT) nodesVisited++;
+            float e0, e1;
+            const bool hitL = refChildTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, ray.d, invD, ray.tmin, farT, e0);
+            const bool hitR = refChildTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray.o, ray.d, invD, ray.tmin, farT, e1);
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (hitL && hitR) {
+                if (e0 < e1) { stack[(2*sp)*stride] = c1; stack[(2*sp + 1)*stride] = __float_as_int(e1); ++sp; node = c0; tMin = e0; }
+                else         { stack[(2*sp)*stride] = c0; stack[(2*sp + 1)*stride] = __float_as_int(e0); ++sp; node = c1; tMin = e1; }
+            } else if (hitL) { node = c0; tMin = e0; }
+            else if (hitR) { node = c1; tMin = e1; }
+            else { miss = true; break; }
+        }
+        if (!miss) {
+            const uint32_t first = TGHIP_LEAF_FIRST(node), count = TGHIP_LEAF_COUNT(node);
+            for (uint32_t k = first; k < first + count; ++k) {
+                const uint32_t ri = s.inst_prims[k];
+                if (COUNT) primsTested++;
+                RayD local;
+                int root;
+                instanceLocalRay(s, ri, ray, tMin, PT_INF, local, root);
+                const float4 lh = traverseClosest<COUNT, false, KINDS>(s, local, stack + 2*sp*stride, stride, nodesVisited, primsTested, root);
+                if (__float_as_int(lh.w) >= 0) { hit = lh; hitInst = (int)ri; tmax = lh.x; }    // ray.setFarT(localRay.farT())
+            }
+            tMax = refMin(tMax, tmax);
+            farT = tMax;
+        }
+        for (;;) {                                       // pop: nodes that begin behind tMax are dropped
+            if (sp == 0) return;
+            --sp;
+            node = stack[(2*sp)*stride];
+            tMin = __int_as_float(stack[(2*sp + 1)*stride]);
+            if (!(tMax < tMin)) break;
+        }
+    }
 }
 
 template<bool COUNT, uint32_t KINDS = KINDS_ALL>
-PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &worldRay, int *stack, int stride,
+PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &ray, int *stack, int stride,
                                   uint32_t &nodesVisited, uint32_t &primsTested, int &hitInst)
 {
-    InstanceWalk w;
-    w.world = worldRay; w.ray = worldRay;
-    w.invD = mk3(1.0f/worldRay.d.x, 1.0f/worldRay.d.y, 1.0f/worldRay.d.z);
-    w.instSp = -1; w.curInst = -1;
-    float tmax = worldRay.tmax;
+    float tmax = ray.tmax;
     float4 hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
     hitInst = -1;
+    const f3 invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
     int sp = 0, cur = 0;
     for (;;) {
-        bool entered = false;
         if (cur >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
             float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             if (COUNT) nodesVisited++;
             float e0, e1;
-            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w.ray, w.invD, tmax, e0);
-            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w.ray, w.invD, tmax, e1);
+            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, tmax, e0);
+            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, tmax, e1);
             int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             if (h0 && h1) {
                 if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
@@ -989,21 +1065,16 @@ PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &worldRay, in
         } else {
             uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
             for (uint32_t i = first; i < first + count; ++i) {
-                if (COUNT) primsTested++;
-                if (w.curInst < 0 && TGHIP_REC_KIND(__float_as_uint(at32(s.recs, i*3u).w)) == TGHIP_REC_INSTANCE) {
-                    instanceEnter(s, i, w, sp, cur);
-                    entered = true;
-                    break;
+                if (TGHIP_REC_KIND(__float_as_uint(at32(s.recs, i*3u).w)) == TGHIP_REC_INSTANCE_SET) {
+                    instanceSetIntersect<COUNT, KINDS>(s, i, ray, tmax, hit, hitInst, stack + sp*stride, stride, nodesVisited, primsTested);
+                    continue;
                 }
+                if (COUNT) primsTested++;
                 uint32_t meta;
-                if (testRecord<false, KINDS>(s, i, w.ray, tmax, hit, meta))
-                    hitInst = w.curInst;
+                if (testRecord<false, KINDS>(s, i, ray, tmax, hit, meta))
+                    hitInst = -1;
             }
         }
-        if (entered)
-            continue;
-        if (w.instSp >= 0 && sp == w.instSp)
-            instanceLeave(w);
         if (sp == 0)
             break;
         sp--;
@@ -1012,25 +1083,71 @@ PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &worldRay, in
     return hit;
 }
 
+// Any-hit query through the BVH2 of a scene with `instances` primitives.  Instance::intersect answers "hit" as soon as ONE instance whose
+// leaf the walk reaches is hit anywhere beyond that leaf's entry distance -- its master gets farT = infinity, so geometry BEHIND the
+// light occludes it as long as its leaf's box begins in front (a property of the reference this keeps) -- and before the first hit the
+// walk's farT does not move, so which leaves are reached does not depend on the visiting order: every leaf whose box passes the
+// reference's test against [nearT, farT].
 template<bool COUNT, uint32_t KINDS = KINDS_ALL>
-PT_DEV bool traverseOccludedInst(const DeviceScene &s, const RayD &worldRay, int endCap, int *stack, int stride,
+PT_DEV bool instanceSetOccluded(const DeviceScene &s, uint32_t setRec, const RayD &ray, int *stack, int stride, uint32_t &nodesVisited, uint32_t &primsTested)
+{
+    const float4 s0 = at32(s.recs, setRec*3u + 0u), s1 = at32(s.recs, setRec*3u + 1u), s2 = at32(s.recs, setRec*3u + 2u);
+    if (COUNT) primsTested++;
+    float tMin = ray.tmin, tMax = ray.tmax;
+    if (!refBboxIntersection(xyz(s0), xyz(s1), ray, tMin, tMax))
+        return false;
+    const f3 invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
+    int node = __float_as_int(s2.x);
+    int sp = 0;
+    for (;;) {
+        bool miss = false;
+        while (node >= 0) {
+            const float4 *n = &at32(s.nodes, (uint32_t)node*4u);
+            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (COUNT) nodesVisited++;
+            float e0, e1;
+            const bool hitL = refChildTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, ray.d, invD, ray.tmin, ray.tmax, e0);
+            const bool hitR = refChildTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray.o, ray.d, invD, ray.tmin, ray.tmax, e1);
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            if (hitL && hitR) { stack[(2*sp)*stride] = c1; stack[(2*sp + 1)*stride] = __float_as_int(e1); ++sp; node = c0; tMin = e0; }
+            else if (hitL) { node = c0; tMin = e0; }
+            else if (hitR) { node = c1; tMin = e1; }
+            else { miss = true; break; }
+        }
+        if (!miss) {
+            const uint32_t first = TGHIP_LEAF_FIRST(node), count = TGHIP_LEAF_COUNT(node);
+            for (uint32_t k = first; k < first + count; ++k) {
+                const uint32_t ri = s.inst_prims[k];
+                if (COUNT) primsTested++;
+                RayD local;
+                int root;
+                instanceLocalRay(s, ri, ray, tMin, PT_INF, local, root);
+                const float4 lh = traverseClosest<COUNT, false, KINDS>(s, local, stack + 2*sp*stride, stride, nodesVisited, primsTested, root);
+                if (__float_as_int(lh.w) >= 0)
+                    return true;
+            }
+        }
+        if (sp == 0) return false;
+        --sp;
+        node = stack[(2*sp)*stride];
+        tMin = __int_as_float(stack[(2*sp + 1)*stride]);
+    }
+}
+template<bool COUNT, uint32_t KINDS = KINDS_ALL>
+PT_DEV bool traverseOccludedInst(const DeviceScene &s, const RayD &ray, int endCap, int *stack, int stride,
                                  uint32_t &nodesVisited, uint32_t &primsTested)
 {
-    InstanceWalk w;
-    w.world = worldRay; w.ray = worldRay;
-    w.invD = mk3(1.0f/worldRay.d.x, 1.0f/worldRay.d.y, 1.0f/worldRay.d.z);
-    w.instSp = -1; w.curInst = -1;
+    const f3 invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
     float4 hit;
     int sp = 0, cur = 0;
     for (;;) {
-        bool entered = false;
         if (cur >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
             float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             if (COUNT) nodesVisited++;
             float e0, e1;
-            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), w.ray, w.invD, worldRay.tmax, e0);
-            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), w.ray, w.invD, worldRay.tmax, e1);
+            bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, ray.tmax, e0);
+            bool h1 = boxTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray, invD, ray.tmax, e1);
             int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             if (h0 && h1) {
                 if (e1 < e0) { stack[sp*stride] = c0; cur = c1; }
@@ -1042,22 +1159,18 @@ PT_DEV bool traverseOccludedInst(const DeviceScene &s, const RayD &worldRay, int
         } else {
             uint32_t first = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
             for (uint32_t i = first; i < first + count; ++i) {
-                if (COUNT) primsTested++;
-                if (w.curInst < 0 && TGHIP_REC_KIND(__float_as_uint(at32(s.recs, i*3u).w)) == TGHIP_REC_INSTANCE) {
-                    instanceEnter(s, i, w, sp, cur);
-                    entered = true;
-                    break;
+                if (TGHIP_REC_KIND(__float_as_uint(at32(s.recs, i*3u).w)) == TGHIP_REC_INSTANCE_SET) {
+                    if (instanceSetOccluded<COUNT, KINDS>(s, i, ray, stack + sp*stride, stride, nodesVisited, primsTested))
+                        return true;
+                    continue;
                 }
+                if (COUNT) primsTested++;
                 uint32_t meta;
-                float tmax = worldRay.tmax;
-                if (testRecord<false, KINDS>(s, i, w.ray, tmax, hit, meta) && (w.curInst >= 0 || (int)TGHIP_REC_OBJECT(meta) != endCap))
+                float tmax = ray.tmax;
+                if (testRecord<false, KINDS>(s, i, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
                     return true;
             }
         }
-        if (entered)
-            continue;
-        if (w.instSp >= 0 && sp == w.instSp)
-            instanceLeave(w);
         if (sp == 0)
             break;
         sp--;

@@ -40,6 +40,8 @@ struct DeviceScene {
     const uint32_t * __restrict__ sobol;       // Sobol' generator matrices (nullptr unless the scene carries them)
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
     uint32_t num_instances;                    // instance records (0: single-level scene, A_EMI.w carries nothing)
+    const uint32_t * __restrict__ inst_prims;  // leaf slots of the reference's instance trees -> instance record (TgHipSceneDesc::inst_prims)
+    const float4 * __restrict__ inst_leaf_boxes;   // 2 x float4 per leaf of those trees: its box as its parent holds it (lo, hi)
     const TgHipMedium * __restrict__ media;    // participating media (nullptr / 0: none)
     uint32_t num_media;
     const TgHipCamera * __restrict__ camera;   // in device memory (56 dwords: read through the scalar cache where it is used, not held in SGPRs)

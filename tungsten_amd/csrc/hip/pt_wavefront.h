@@ -342,10 +342,9 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
 // the traversal loop.  One loop iteration advances every busy lane by one BVH node or one leaf.
 // Dynamic LDS: [expanded queue, 2 B per slot][node stacks, bvhDepth ints per thread].
 // SOLIDS: the scene has cube / sphere / disk records somewhere; without them only triangle and quad tests are compiled in
-// INST: two-level scenes -- a leaf of the top level holds one instance record; reaching it sends the ray into the master's space and
-// the walk on to the master's subtree on the same stack (traverseClosestInst is the same walk, one ray at a time); the instance a hit
-// was reached through goes to the spare word A_EMI.w
-template<bool COUNT, bool SOLIDS = true, bool INST = false>
+// (Scenes with `instances` primitives run k_trace_closest<., ., INST>: the reference's visiting order decides what such a ray hits,
+// pt_kernels.h: instanceSetIntersect.)
+template<bool COUNT, bool SOLIDS = true>
 __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathState st)
 {
     extern __shared__ int ldsDyn[];
@@ -368,8 +367,6 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
     float tmax = 0.0f;
     float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     int cur = 0, sp = 0;
-    f3 wo = splat3(0.0f), wd = splat3(1.0f);     // INST: the world-space ray while the walk is inside an instance
-    int instSp = -1, curInst = -1, hitInst = -1; // INST: stack level at which the instance was entered; the instance; the hit's instance
     bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
@@ -392,7 +389,6 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
                     tmax = ray.tmax;
                     hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
                     cur = 0; sp = 0;
-                    if (INST) { wo = ray.o; wd = ray.d; instSp = -1; curInst = -1; hitInst = -1; }
                     busy = true;
                     rays++;
                 }
@@ -430,45 +426,19 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
             if (atLeaf != 0ull && ((uint32_t)__popcll(atLeaf) >= st.leaf_batch_bvh2 || atNode == 0ull)) {
                 if (busy && cur < 0 && !pop) {
                     uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
-                    bool entered = false;
-                    if (INST && curInst < 0) {
-                        float4 r0 = at32(s.recs, firstRec*3u);
-                        if (TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE) {   // (alone in its leaf)
-                            if (COUNT) prims++;
-                            float4 r1 = at32(s.recs, firstRec*3u + 1u), r2 = at32(s.recs, firstRec*3u + 2u);
-                            f3 qc = -xyz(r1);                   // conjugate(): the inverse rotation (instanceEnter)
-                            ray.o = quatRotate(r1.w, qc, wo - xyz(r0));
-                            ray.d = quatRotate(r1.w, qc, wd);
-                            invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
-                            curInst = (int)firstRec;
-                            instSp = sp;
-                            cur = (int)__float_as_uint(r2.x);
-                            entered = true;
-                        }
+                    for (uint32_t r = firstRec; r < firstRec + count; ++r) {
+                        if (COUNT) prims++;
+                        uint32_t meta;
+                        (void)testRecord<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, r, ray, tmax, hit, meta);
                     }
-                    if (!entered) {
-                        for (uint32_t r = firstRec; r < firstRec + count; ++r) {
-                            if (COUNT) prims++;
-                            uint32_t meta;
-                            if (testRecord<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, r, ray, tmax, hit, meta)) {
-                                if (INST) hitInst = curInst;
-                            }
-                        }
-                        pop = true;
-                    }
+                    pop = true;
                 }
             }
         }
         if (busy && pop) {
-            if (INST && instSp >= 0 && sp == instSp) {   // the master's subtree is done: back to world space (instanceLeave)
-                ray.o = wo; ray.d = wd;
-                invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
-                instSp = -1; curInst = -1;
-            }
             if (sp == 0) {
                 // finished: publish the hit and bin the path by shading class
                 slotF4(st, A_HIT, slot) = hit;
-                if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
                 int ri = __float_as_int(hit.w);
                 int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
                 queuePush(true, local, L, shadeQueue(cls));
@@ -1989,7 +1959,8 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                     result = result + contrib;       // nothing in the way: transmittance 1
                     rayDone = true;
                 } else if (INST && what == 3) {
-                    ray.o = so; ray.d = xyz(r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot));   // back to world space
+                    const float4 sd = r == 0 ? slotF4(st, A_SH_D0, slot) : slotF4(st, A_SH_D1, slot);
+                    ray.o = so; ray.d = xyz(sd); ray.tmin = eps; ray.tmax = sd.w;   // back to world space (and to the ray's own [nearT, farT])
                     wr = wideRaySetup(ray);
                     w.curInst = -1;
                 } else {
@@ -2005,7 +1976,16 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                     } else {
                         if (COUNT) prims++;
                         if (INST && TGHIP_REC_KIND(__float_as_uint(q0.w)) == TGHIP_REC_INSTANCE) {
-                            wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
+                            // Instance::intersect lets the ray into an instance when it passes the box of the instance's LEAF in the
+                            // reference's own tree -- its test, its arithmetic (pt_kernels.h: refChildTest) -- and hands it on with nearT =
+                            // the entry distance and farT = INFINITY: anything the master holds beyond occludes (instanceSetOccluded)
+                            const uint32_t leaf = __float_as_uint(q2.y);
+                            const float4 blo = s.inst_leaf_boxes[2u*leaf], bhi = s.inst_leaf_boxes[2u*leaf + 1u];
+                            float tEntry;
+                            if (refChildTest(xyz(blo), xyz(bhi), ray.o, ray.d, mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z), ray.tmin, ray.tmax, tEntry)) {
+                                wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
+                                ray.tmin = tEntry; ray.tmax = PT_INF;
+                            }
                         } else {
                             float tmax = ray.tmax;
                             float4 hit;

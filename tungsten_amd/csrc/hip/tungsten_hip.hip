@@ -90,7 +90,6 @@ struct tghip_ctx {
     hipStream_t classStream[8][2] = {};   // per part: the streams of the shading classes that run beside the part's own ("class_streams" option)
     hipEvent_t evFork[8] = {}, evJoin[8][2] = {};
     bool shortBatch = false;              // the pass being rendered does not fill the pool once: one stream, 4 workgroups per CU (tghip_render_pass)
-    int instDynOpt = 1;                   // "inst_dyn": closest-hit rays of instanced scenes on the dynamic-fetch two-level BVH2 kernel
     int instSimpleOpt = 1;                // "inst_simple": classes 0 / 2 of instanced scenes on the MASK_SIMPLE_INST variant instead of MASK_FULL
     int classStreamsOpt = 0;              // measured: 735-800 Msamples/s against 825-830 with the classes one after the other on the part's stream
     hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the stream of the part being launched)
@@ -298,9 +297,10 @@ static uint32_t bsdfTypeMask(const TgHipSceneDesc *s, int bi, int depth)
     return m;
 }
 
-// Depth of the subtree under `root` (also validates child references).  Instance records met on the way are collected in
-// `instanceRecs` when given; without it (a master's subtree) they are an error, as is an instance sharing its leaf.
-static int subtreeDepth(const TgHipSceneDesc *s, int32_t root, size_t &visited, std::vector<uint32_t> *instanceRecs)
+// Depth of the subtree under `root` (also validates child references).  `level`: 0 = the scene's tree (leaves: non-instance records and
+// instance-set records, which are collected in `found`), 1 = the reference's tree behind a set record (leaves: one or two slots of
+// inst_prims; the instance records behind them are collected in `found`), 2 = a master's subtree (triangles and the like only).
+static int subtreeDepth(const TgHipSceneDesc *s, int32_t root, size_t &visited, int level, std::vector<uint32_t> *found)
 {
     std::vector<std::pair<int32_t, int>> stack;
     stack.emplace_back(root, 1);
@@ -310,12 +310,24 @@ static int subtreeDepth(const TgHipSceneDesc *s, int32_t root, size_t &visited, 
         stack.pop_back();
         if (cur.first < 0) {
             uint32_t first = TGHIP_LEAF_FIRST(cur.first), count = TGHIP_LEAF_COUNT(cur.first);
-            if (first + count > s->num_recs) return -1;
-            for (uint32_t i = first; i < first + count; ++i)
-                if (TGHIP_REC_KIND(s->recs[i].meta) == TGHIP_REC_INSTANCE) {
-                    if (!instanceRecs || count != 1) return -1;
-                    instanceRecs->push_back(i);
+            if (level == 1) {
+                if (count < 1 || count > 2 || first + count > s->num_inst_prims) return -1;
+                for (uint32_t k = first; k < first + count; ++k) {
+                    const uint32_t ri = s->inst_prims[k];
+                    if (ri >= s->num_top_recs || TGHIP_REC_KIND(s->recs[ri].meta) != TGHIP_REC_INSTANCE) return -1;
+                    found->push_back(ri);
                 }
+                continue;
+            }
+            if (first + count > s->num_recs) return -1;
+            for (uint32_t i = first; i < first + count; ++i) {
+                const uint32_t kind = TGHIP_REC_KIND(s->recs[i].meta);
+                if (kind == TGHIP_REC_INSTANCE) return -1;           // instance records are reached through their set's tree only
+                if (kind == TGHIP_REC_INSTANCE_SET) {
+                    if (level != 0 || count != 1) return -1;
+                    found->push_back(i);
+                }
+            }
             continue;
         }
         if (uint32_t(cur.first) >= s->num_nodes || ++visited > s->num_nodes) return -1;
@@ -326,29 +338,44 @@ static int subtreeDepth(const TgHipSceneDesc *s, int32_t root, size_t &visited, 
     return depth;
 }
 
-// Stack depth the traversal needs: the top-level tree, plus -- with instances -- the deepest master subtree above it.
+// Stack words the BVH2 traversal needs: the scene's tree; with `instances` primitives, above it the reference's tree over the instances
+// (two words per level: the node and the distance the ray enters it at, pt_kernels.h: instanceSetIntersect) and the deepest master subtree.
 static int bvhDepthOf(const TgHipSceneDesc *s)
 {
     size_t visited = 0;
+    std::vector<uint32_t> sets;
+    int depth = subtreeDepth(s, 0, visited, 0, &sets);
+    if (depth < 0 || (sets.empty() != (s->num_instances == 0))) return -1;
+    if (sets.empty()) return depth;
+    if (!s->inst_prims || !s->inst_leaf_boxes) return -1;
     std::vector<uint32_t> inst;
-    int depth = subtreeDepth(s, 0, visited, &inst);
-    if (depth < 0 || inst.size() != s->num_instances) return -1;
+    int ref = 0;
+    for (uint32_t set : sets) {
+        int32_t root;
+        std::memcpy(&root, &s->recs[set].c[0], 4);
+        if (root == 0) return -1;
+        int d = subtreeDepth(s, root, visited, 1, &inst);
+        if (d < 0) return -1;
+        ref = std::max(ref, d);
+    }
+    if (inst.size() != s->num_instances) return -1;
     std::vector<uint32_t> roots;
     for (uint32_t i : inst) {
-        uint32_t root;
+        uint32_t root, leaf;
         std::memcpy(&root, &s->recs[i].c[0], 4);
-        if (root == 0 || root >= s->num_nodes) return -1;
+        std::memcpy(&leaf, &s->recs[i].c[1], 4);
+        if (root == 0 || root >= s->num_nodes || leaf >= s->num_inst_leaves) return -1;
         roots.push_back(root);
     }
     std::sort(roots.begin(), roots.end());
     roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
     int master = 0;
     for (uint32_t root : roots) {
-        int d = subtreeDepth(s, int32_t(root), visited, nullptr);
+        int d = subtreeDepth(s, int32_t(root), visited, 2, nullptr);
         if (d < 0) return -1;
         master = std::max(master, d);
     }
-    return roots.empty() ? depth : depth + master + 1;
+    return depth + 2*(ref + 1) + master + 2;
 }
 
 // Validates the wide BVH -- the top-level tree from node 0 and, with instances, the masters' subtrees behind it (roots in the
@@ -611,7 +638,7 @@ static void chooseThreads(tghip_ctx *ctx)
     // from the same sweep).  Instanced scenes with the dynamic-fetch closest-hit kernel: two parts, 8 per CU (instances10k: 141 -> 153
     // Msamples/s; with the static-fetch kernel parts lost: 127 against 114-120).
     const bool oneStream = ctx->streamsOpt == 1 || (ctx->streamsOpt == 0 && ctx->shortBatch);   // (shortBatch: tghip_render_pass)
-    const bool pairedInst = !flat && ctx->haveInstances && !oneStream && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt && wideShadowRays(ctx) &&
+    const bool pairedInst = !flat && ctx->haveInstances && !oneStream && !wideClosest(ctx) && ctx->dynamicFetch && wideShadowRays(ctx) &&
                             !ctx->haveForward && !ctx->haveMeshLight;
     const bool paired = (!flat && !ctx->haveInstances && !oneStream && wideClosest(ctx) && wideShadowRays(ctx)) || pairedInst;
     ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : ((flat || paired) ? 8 : 4);
@@ -627,7 +654,6 @@ static void chooseThreads(tghip_ctx *ctx)
     ctx->thrClosest = wideC && inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false, true>, 192, 3))
                     : wideC ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 192, 3))
                     : flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
-                    : (inst && ctx->dynamicFetch && ctx->instDynOpt) ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false, true>, 320, 2))
                     : inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest<false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_closest<false, false, 2>, 512, 1))
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
@@ -829,7 +855,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
                 if (!ctx->classStream[kk][a]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->classStream[kk][a], hipStreamNonBlocking));
     }
     else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
-    else if (k == "inst_dyn") { ctx->instDynOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "inst_dyn") { }            // (round 3's dynamic-fetch kernel of the two-level nearest-hit walk: gone with that walk)
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch_bvh2") ctx->leafBatchBvh2 = int(std::min<long long>(std::max<long long>(value, 0), 64));
@@ -889,7 +915,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             if (sd->infinite_lights[i] < 0 || uint32_t(sd->infinite_lights[i]) >= sd->num_objects) return bad("infinite_lights[] entry out of range");
         for (uint32_t i = 0; i < sd->num_recs; ++i) {
             const uint32_t kind = TGHIP_REC_KIND(sd->recs[i].meta);
-            if (kind > TGHIP_REC_CYLINDER) return bad("unknown primitive record kind");
+            if (kind > TGHIP_REC_INSTANCE_SET) return bad("unknown primitive record kind");
             if (TGHIP_REC_OBJECT(sd->recs[i].meta) >= sd->num_objects) return bad("primitive record refers to an object out of range");
         }
         for (uint32_t i = 0; i < sd->num_objects; ++i) {
@@ -1107,7 +1133,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         }
         for (uint32_t i = 0; i < sd->num_recs; ++i) {
             uint32_t meta = sd->recs[i].meta;
-            if (TGHIP_REC_KIND(meta) == TGHIP_REC_INSTANCE)
+            if (TGHIP_REC_KIND(meta) == TGHIP_REC_INSTANCE || TGHIP_REC_KIND(meta) == TGHIP_REC_INSTANCE_SET)
                 continue;                    // never a hit record itself: hits are the master's triangles
             if (TGHIP_REC_KIND(meta) > TGHIP_REC_CYLINDER) { ctx->error = "unknown primitive record kind"; return TGHIP_E_INVALID; }
             if (TGHIP_REC_KIND(meta) != TGHIP_REC_TRIANGLE && TGHIP_REC_KIND(meta) != TGHIP_REC_QUAD) ctx->haveSolids = true;
@@ -1140,6 +1166,13 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     s.num_lights = sd->num_lights; s.num_infinite_lights = sd->num_infinite_lights;
     s.num_bsdfs = sd->num_bsdfs; s.num_textures = sd->num_textures;
     s.num_instances = sd->num_instances;
+    s.inst_prims = nullptr; s.inst_leaf_boxes = nullptr;
+    if (sd->num_instances) {
+        if ((rc = uploadArray(ctx, ctx->sceneMem, sd->inst_prims, size_t(sd->num_inst_prims), &s.inst_prims)) != TGHIP_OK) return rc;
+        const float4 *boxes = nullptr;
+        if ((rc = uploadArray(ctx, ctx->sceneMem, reinterpret_cast<const float4 *>(sd->inst_leaf_boxes), size_t(sd->num_inst_leaves)*2, &boxes)) != TGHIP_OK) return rc;
+        s.inst_leaf_boxes = boxes;
+    }
     s.media = nullptr;
     s.num_media = sd->num_media;
     if (sd->num_media && (rc = uploadArray(ctx, ctx->sceneMem, sd->media, size_t(sd->num_media), &s.media)) != TGHIP_OK) return rc;
@@ -1400,13 +1433,6 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             if (flat) {
                 if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
                 else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
-            } else if (ctx->haveInstances && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt) {
-                // two-level BVH2 walk with dynamic ray fetch
-                const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
-#define CLOSEST_DYN_INST(C, S) hipLaunchKernelGGL((k_trace_closest_dyn<C, S, true>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->launchStream, s, st)
-                if (ctx->haveSolids) { if (count) CLOSEST_DYN_INST(true, true); else CLOSEST_DYN_INST(false, true); }
-                else                 { if (count) CLOSEST_DYN_INST(true, false); else CLOSEST_DYN_INST(false, false); }
-#undef CLOSEST_DYN_INST
             } else if (ctx->haveInstances && !wideClosest(ctx)) {
 #define CLOSEST_INST(C, I) hipLaunchKernelGGL((k_trace_closest<C, false, I>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st)
                 if (ctx->haveSolids) { if (count) CLOSEST_INST(true, 1); else CLOSEST_INST(false, 1); }

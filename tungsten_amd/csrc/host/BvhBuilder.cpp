@@ -119,12 +119,12 @@ struct Builder
         int n = end - begin;
         maxDepth = std::max(maxDepth, depth);
 
-        bool depthExhausted = depth >= TGHIP_MAX_BVH_DEPTH - 2;
+        bool depthExhausted = depth >= TGHIP_MAX_TREE_DEPTH - 2;
         int mid = -1;
         if (n > maxLeaf || (n > 1 && !depthExhausted)) {
             if (depthExhausted && n <= TGHIP_MAX_LEAF) {
                 mid = -1;
-            } else if (depth >= TGHIP_MAX_BVH_DEPTH - 10) {
+            } else if (depth >= TGHIP_MAX_TREE_DEPTH - 10) {
                 mid = medianSplit(begin, end, centBounds);   // guarantees log2 termination below the cap
             } else {
                 mid = findSplit(begin, end, bounds, centBounds, n > maxLeaf);

@@ -129,7 +129,9 @@ struct Primitive
     std::vector<Vec3f> instancePos;
     std::vector<QuaternionF> instanceRot;
     std::vector<uint8_t> instanceId;
-    std::vector<Box3f> instanceBounds;      // prepareForRender: world-space box of every instance (tightenInstanceBounds)
+    std::vector<Box3f> instanceRefBounds;   // prepareForRender: world-space box of every instance as the reference boxes it (Instance.cpp:409-421:
+                                            // the master box's eight rotated corners): what its own BVH over the instances is built from and
+                                            // tested against (RefInstanceBvh.hpp)
 
     // prepared (prepareForRender of the respective reference class)
     Vec3f base, edge0, edge1, normal; float invUvSq[2] = {0, 0};  // Quad.cpp:298-316
@@ -144,7 +146,6 @@ struct Primitive
     float powerToRadianceFactor() const;
     void loadResources(const std::string &sceneDir);
     void prepareForRender();
-    void tightenInstanceBounds();
 };
 
 // ---- camera ------------------------------------------------------------------------------

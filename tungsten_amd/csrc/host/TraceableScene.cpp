@@ -2,6 +2,7 @@
 #include "Sampling.hpp"
 #include "BvhBuilder.hpp"
 #include "WideBvh.hpp"
+#include "RefInstanceBvh.hpp"
 #include "Integrator.hpp"
 
 #include <chrono>
@@ -44,7 +45,7 @@ SceneAccel buildSceneAccel(std::vector<TgHipPrimRec> &_recs, std::vector<TgHipTr
     // 4 MiB-per-XCD L2 (materialtest: 80 K records), leaves of <= 4 are 3 % faster once it does not (1 M records).
     // (instance records always sit alone in their leaf: the traversal enters a master from a leaf and returns to its parent)
     BvhBuildResult bvh = buildBvh(recBounds, (haveInstances || recBounds.size() < (1u << 18)) ? 1 : 4);
-    if (bvh.maxDepth > TGHIP_MAX_BVH_DEPTH - 1)
+    if (bvh.maxDepth > TGHIP_MAX_TREE_DEPTH - 1)
         throw std::runtime_error("BVH deeper than the device traversal stack");
     std::vector<TgHipPrimRec> recs(_recs.size());
     std::vector<TgHipTriAttr> attrs(_recs.size());
@@ -54,6 +55,7 @@ SceneAccel buildSceneAccel(std::vector<TgHipPrimRec> &_recs, std::vector<TgHipTr
     }
     _recs.swap(recs);
     _triAttrs.swap(attrs);
+    out.order = bvh.order;
     out.nodes.swap(bvh.nodes);
     out.bvhDepth = bvh.maxDepth;
     out.sahCost = bvh.sahCost;
@@ -73,6 +75,10 @@ SceneAccel buildSceneAccel(std::vector<TgHipPrimRec> &_recs, std::vector<TgHipTr
             }
             _recs.swap(recs);
             _triAttrs.swap(attrs);
+            std::vector<uint32_t> composed(wide.order.size());
+            for (size_t i = 0; i < wide.order.size(); ++i)
+                composed[i] = out.order[wide.order[i]];
+            out.order.swap(composed);
             out.wideNodes.swap(wide.nodes);
             out.wideDepth = wide.depth;
         }
@@ -220,6 +226,12 @@ void TraceableScene::flatten()
     std::vector<Box3f> recBounds;
     std::vector<std::shared_ptr<Primitive>> masterPrims;   // distinct master meshes of all `instances` primitives
     uint32_t numInstances = 0;
+    // `instances` primitives (ABI 8): one set record each for the scene's BVH2, their instance records for the wide BVH, and the
+    // reference's own tree over the instances (RefInstanceBvh.hpp) behind the scene's BVH2 nodes
+    struct InstanceSet { TgHipPrimRec rec; Box3f bounds; size_t firstInst; RefInstanceBvh tree; };
+    std::vector<InstanceSet> instSets;
+    std::vector<TgHipPrimRec> instRecs;
+    std::vector<Box3f> instLeafBounds;                    // per instance record: the box of its leaf in the reference's tree
     _sceneBounds = Box3f();
     for (size_t pi = 0; pi < _allPrims.size(); ++pi) {
         Primitive &p = *_allPrims[pi];
@@ -334,8 +346,13 @@ void TraceableScene::flatten()
             }
             break;
         } case Primitive::Instances: {
-            // one top-level record per instance (Instance.cpp:392-428 builds a BVH over exactly these boxes); the master's
-            // index among `masterPrims` sits in c[1]'s slot until the sub-BVH roots are known (patched below)
+            // Instance::prepareForRender (Instance.cpp:392-428): a BVH over the instances' boxes.  The reference's intersect keeps the
+            // LAST hit in that tree's visiting order (each instance gets a ray with farT = infinity), so the tree is restated node
+            // for node (RefInstanceBvh.cpp) and walked in the reference's order by the closest-hit queries; the master's index among
+            // `masterPrims` sits in c[0]'s slot until the sub-BVH roots are known (patched below)
+            InstanceSet set;
+            set.firstInst = instRecs.size();
+            std::vector<Box3f> refBoxes;
             for (size_t i = 0; i < p.instancePos.size(); ++i) {
                 const std::shared_ptr<Primitive> &m = p.masters[p.instanceId[i]];
                 if (m->tris.empty() || m->verts.empty())
@@ -349,17 +366,50 @@ void TraceableScene::flatten()
                 copy3(r.a, p.instancePos[i]);
                 r.p0 = p.instanceRot[i][0];
                 r.b[0] = p.instanceRot[i][1]; r.b[1] = p.instanceRot[i][2]; r.b[2] = p.instanceRot[i][3];
-                uint32_t masterSlot = uint32_t(mi), number = uint32_t(i);
+                uint32_t masterSlot = uint32_t(mi);
                 std::memcpy(&r.c[0], &masterSlot, 4);
-                std::memcpy(&r.c[1], &number, 4);
                 r.meta = (uint32_t(TGHIP_REC_INSTANCE) << 29) | objMeta;
-                _recs.push_back(r);
-                _triAttrs.emplace_back();
-                std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
-                _triAttrs.back().bsdf = -1;
-                recBounds.push_back(p.instanceBounds[i]);
+                instRecs.push_back(r);
+                refBoxes.push_back(p.instanceRefBounds[i]);
                 numInstances++;
             }
+            if (refBoxes.empty())
+                break;
+            set.tree = buildRefInstanceBvh(refBoxes);
+            set.bounds = set.tree.bounds;
+            std::memset(&set.rec, 0, sizeof(set.rec));
+            copy3(set.rec.a, set.bounds.lo);
+            copy3(set.rec.b, set.bounds.hi);
+            set.rec.meta = (uint32_t(TGHIP_REC_INSTANCE_SET) << 29) | objMeta;
+            // every leaf's box as its parent holds it (a tree that is one leaf: the root's bounds), for the instances of that leaf
+            instLeafBounds.resize(instRecs.size());
+            auto leafBox = [&](uint32_t leafNode, const Box3f &box) {
+                const TgHipInstNode &leaf = set.tree.nodes[leafNode];
+                const uint32_t leafIndex = uint32_t(_instLeafBoxes.size()/8);
+                for (int k = 0; k < 3; ++k) _instLeafBoxes.push_back(box.lo[k]);
+                for (int k = 0; k < 3; ++k) _instLeafBoxes.push_back(box.hi[k]);
+                _instLeafBoxes.push_back(0.0f); _instLeafBoxes.push_back(0.0f);
+                for (uint32_t k = 0; k < leaf.count; ++k) {
+                    const size_t rec = set.firstInst + set.tree.primIndices[leaf.left + k];
+                    instLeafBounds[rec] = box;
+                    std::memcpy(&instRecs[rec].c[1], &leafIndex, 4);
+                }
+            };
+            if (set.tree.nodes[0].count != 0) {
+                leafBox(0, set.bounds);
+            } else {
+                for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni) {
+                    const TgHipInstNode &n = set.tree.nodes[ni];
+                    if (n.count != 0) continue;
+                    for (uint32_t c = 0; c < 2; ++c) {
+                        if (set.tree.nodes[n.left + c].count == 0) continue;
+                        Box3f box;
+                        for (int k = 0; k < 3; ++k) { box.lo[k] = n.box[k*4 + c]; box.hi[k] = n.box[k*4 + 2 + c]; }
+                        leafBox(n.left + c, box);
+                    }
+                }
+            }
+            instSets.push_back(std::move(set));
             break;
         } default:
             break;
@@ -375,13 +425,84 @@ void TraceableScene::flatten()
             addDistribution(_allPrims[size_t(li)]->emission);           // (Skydome::makeSamplable, Skydome.cpp:138-143)
 
     // ---- BVH2 + the 8-wide BVH the single-level traversal kernels walk ----------------------------
-    {
-        SceneAccel accel = buildSceneAccel(_recs, _triAttrs, recBounds, numInstances != 0);
+    int refDepth = 0;
+    if (instSets.empty()) {
+        SceneAccel accel = buildSceneAccel(_recs, _triAttrs, recBounds, false);
         _nodes.swap(accel.nodes);
         _wideNodes.swap(accel.wideNodes);
         _bvhDepth = accel.bvhDepth;
         _wideDepth = accel.wideDepth;
         _bvhSah = accel.sahCost;
+    } else {
+        // Scenes with instances (include/tungsten_hip.h, the instance-set record).  The wide BVH -- any-hit shadow queries -- is built
+        // over the non-instance records and the instance records, every instance boxed by its LEAF of the reference's tree (what the
+        // reference tests before it hands the instance its ray); it decides the record order.  The scene's BVH2 -- closest hits -- is
+        // built over the non-instance records and one record per `instances` primitive, behind which the reference's tree follows.
+        const size_t K = _recs.size(), N = instRecs.size(), S = instSets.size();
+        std::vector<Box3f> wideBounds(recBounds);
+        for (size_t i = 0; i < N; ++i) {
+            _recs.push_back(instRecs[i]);
+            _triAttrs.emplace_back();
+            std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
+            _triAttrs.back().bsdf = -1;
+            wideBounds.push_back(instLeafBounds[i]);
+        }
+        SceneAccel accel = buildSceneAccel(_recs, _triAttrs, wideBounds, true);
+        _wideNodes.swap(accel.wideNodes);
+        _wideDepth = accel.wideDepth;
+        _bvhSah = accel.sahCost;
+        std::vector<uint32_t> slotOf(K + N);                 // caller's record -> its slot
+        for (size_t i = 0; i < accel.order.size(); ++i)
+            slotOf[accel.order[i]] = uint32_t(i);
+        for (size_t si = 0; si < S; ++si) {
+            _recs.push_back(instSets[si].rec);
+            _triAttrs.emplace_back();
+            std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
+            _triAttrs.back().bsdf = -1;
+        }
+        std::vector<Box3f> sceneBounds(recBounds);
+        for (size_t si = 0; si < S; ++si)
+            sceneBounds.push_back(instSets[si].bounds);
+        BvhBuildResult top = buildBvh(sceneBounds, 1);
+        auto finalSlot = [&](uint32_t input) { return input < K ? slotOf[input] : uint32_t(K + N + (input - K)); };
+        for (TgHipBvhNode &n : top.nodes)
+            for (int32_t *ref : {&n.child0, &n.child1})
+                if (*ref < 0)
+                    *ref = TGHIP_MAKE_LEAF(finalSlot(top.order[TGHIP_LEAF_FIRST(*ref)]), 1);
+        _nodes.swap(top.nodes);
+        _bvhDepth = top.maxDepth;
+        // the reference's trees as BVH2 nodes with its exact child boxes; their leaf references index inst_prims
+        for (size_t si = 0; si < S; ++si) {
+            const InstanceSet &set = instSets[si];
+            const uint32_t primBase = uint32_t(_instPrims.size());
+            for (uint32_t id : set.tree.primIndices)
+                _instPrims.push_back(slotOf[K + set.firstInst + id]);
+            // inner nodes only become BVH2 nodes; a leaf is a leaf reference in its parent
+            std::vector<int32_t> nodeIndex(set.tree.nodes.size(), -1);
+            int32_t next = int32_t(_nodes.size());
+            for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni)
+                if (set.tree.nodes[ni].count == 0) nodeIndex[ni] = next++;
+            auto refOf = [&](uint32_t ni) -> int32_t {
+                const TgHipInstNode &n = set.tree.nodes[ni];
+                return n.count == 0 ? nodeIndex[ni] : TGHIP_MAKE_LEAF(primBase + n.left, n.count);
+            };
+            for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni) {
+                const TgHipInstNode &n = set.tree.nodes[ni];
+                if (n.count != 0) continue;
+                TgHipBvhNode b;
+                std::memset(&b, 0, sizeof(b));
+                for (int k = 0; k < 3; ++k) {
+                    b.lo0[k] = n.box[k*4 + 0]; b.lo1[k] = n.box[k*4 + 1];
+                    b.hi0[k] = n.box[k*4 + 2]; b.hi1[k] = n.box[k*4 + 3];
+                }
+                b.child0 = refOf(n.left);
+                b.child1 = refOf(n.left + 1);
+                _nodes.push_back(b);
+            }
+            const int32_t root = refOf(0);
+            std::memcpy(&_recs[K + N + si].c[0], &root, 4);
+            refDepth = std::max(refDepth, set.tree.depth);
+        }
     }
     const uint32_t numTopRecs = uint32_t(_recs.size());
 
@@ -484,8 +605,10 @@ void TraceableScene::flatten()
             _wideDepth += masterWideDepth + 3;
             if (_wideDepth > TGHIP_MAX_WIDE_DEPTH) { _wideNodes.clear(); _wideDepth = 0; }
         }
-        // one device stack holds the top-level walk and, above it, the walk of the master being visited
-        _bvhDepth += masterDepth + 1;
+        // one device stack holds the scene's walk, above it the walk of the reference's instance tree -- two words per level: the node
+        // and the distance at which the ray enters it, which BinaryBvh::trace re-checks when it pops (bvh/BinaryBvh.hpp:277-283) --
+        // and above that the walk of the master being visited
+        _bvhDepth += 2*(refDepth + 1) + masterDepth + 2;
         if (_bvhDepth > TGHIP_MAX_BVH_DEPTH - 1)
             throw std::runtime_error("instanced BVH deeper than the device traversal stack");
     }
@@ -558,6 +681,10 @@ void TraceableScene::flatten()
     _desc.bsdfs = _bsdfs.data();
     _desc.textures = _textures.data();
     _desc.media = _media.empty() ? nullptr : _media.data();
+    _desc.inst_prims = _instPrims.empty() ? nullptr : _instPrims.data();
+    _desc.num_inst_prims = uint32_t(_instPrims.size());
+    _desc.inst_leaf_boxes = _instLeafBoxes.empty() ? nullptr : _instLeafBoxes.data();
+    _desc.num_inst_leaves = uint32_t(_instLeafBoxes.size()/8);
     _desc.wide_nodes = _wideNodes.empty() ? nullptr : _wideNodes.data();
     _desc.num_wide_nodes = uint32_t(_wideNodes.size());
     _desc.num_media = uint32_t(_media.size());

@@ -22,6 +22,7 @@ struct SceneAccel
 {
     std::vector<TgHipBvhNode> nodes;
     std::vector<TgHipWideNode> wideNodes;
+    std::vector<uint32_t> order;           // order[i] = the caller's record that ended up in slot i
     int bvhDepth = 0, wideDepth = 0;
     double sahCost = 0.0;
 };
@@ -43,6 +44,8 @@ class TraceableScene
     std::vector<TgHipMedium> _media;
     std::vector<TgHipTexture> _textures;
     std::vector<float> _texels, _dist, _lightTris;
+    std::vector<uint32_t> _instPrims;      // TgHipSceneDesc::inst_prims
+    std::vector<float> _instLeafBoxes;     // TgHipSceneDesc::inst_leaf_boxes
     std::vector<std::shared_ptr<Primitive>> _allPrims;   // scene primitives (+ default light)
     TgHipSceneDesc _desc;
     Box3f _sceneBounds;
