@@ -10,8 +10,10 @@ ARCH     ?= gfx950
 LIBDIR   := tungsten_amd/lib
 # PROFILE=1: the development build with k_shade's section timers (-DPT_PROFILE) as libtungsten_hip_prof.so next to the product
 # library (TUNGSTEN_AMD_LIB=... python tools/sweep.py ...); objects of its own
-OBJDIR   := $(if $(PROFILE),build/obj_prof,build/obj)
-LIBNAME  := $(if $(PROFILE),libtungsten_hip_prof.so,libtungsten_hip.so)
+# VARIANT=name VARFLAGS="-D..." : an experiment's build of the device code next to the product library, libtungsten_hip_<name>.so with objects
+# of its own (A/B runs within one GPU session: TUNGSTEN_AMD_LIB=tungsten_amd/lib/libtungsten_hip_<name>.so python bench.py ...)
+OBJDIR   := $(if $(PROFILE),build/obj_prof,$(if $(VARIANT),build/obj_$(VARIANT),build/obj))
+LIBNAME  := $(if $(PROFILE),libtungsten_hip_prof.so,$(if $(VARIANT),libtungsten_hip_$(VARIANT).so,libtungsten_hip.so))
 HOSTSRC  := $(wildcard tungsten_amd/csrc/host/*.cpp)
 HOSTLIB  := $(filter-out tungsten_amd/csrc/host/main.cpp,$(HOSTSRC))
 HOSTOBJ  := $(patsubst tungsten_amd/csrc/host/%.cpp,$(OBJDIR)/host_%.o,$(HOSTLIB))
@@ -23,9 +25,9 @@ HIPHDR   := $(wildcard tungsten_amd/csrc/hip/*.h) include/tungsten_hip.h
 # (DESIGN.md "Numerics"); TG_FAST=1 allows contraction.
 FPFLAGS  := $(if $(TG_FAST),-ffp-contract=fast,-ffp-contract=off)
 HOSTFLAGS:= -std=c++11 -O2 -fPIC -Wall -Wextra -Wno-unused-parameter
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -Wno-unused-result $(if $(PROFILE),-DPT_PROFILE,)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -Wno-unused-result $(if $(PROFILE),-DPT_PROFILE,) $(VARFLAGS)
 
-all: $(LIBDIR)/$(LIBNAME) $(if $(PROFILE),,$(LIBDIR)/tungsten_hip oracle/liboracle.so oracle/libm_host.so)
+all: $(LIBDIR)/$(LIBNAME) $(if $(PROFILE)$(VARIANT),,$(LIBDIR)/tungsten_hip oracle/liboracle.so oracle/libm_host.so)
 
 $(OBJDIR)/host_%.o: tungsten_amd/csrc/host/%.cpp $(wildcard tungsten_amd/csrc/host/*.hpp) include/tungsten_hip.h include/tungsten_host.h
 	@mkdir -p $(OBJDIR)

@@ -138,7 +138,7 @@ enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC
  *             subtree (uint32; scenes with a wide BVH); the object is the `instances` primitive.  The master's
  *             triangle records (in master space, i.e. with the master's own transform applied) and its BVH2 subtree
  *             follow the top-level ones in recs / tri_attrs / nodes and are reachable only through instance records.
- *             (ABI 8: c[1] = bits of the index of the instance's leaf in inst_leaf_boxes.)
+ *             (ABI 8: c[1] = bits of the first inst_prims slot of the instance's leaf in the reference's tree: its box is inst_leaf_boxes[8 c[1]].)
  *   instance set (ABI 8): one `instances` primitive as the reference intersects it -- Instance::intersect walks ITS OWN BVH over
  *             the instances (bvh/BinaryBvh.hpp) and keeps the LAST hit in that tree's visiting order, each instance having
  *             been handed a ray with farT = infinity (primitives/Instance.cpp:290-311).  a = min, b = max of the primitive's
@@ -331,9 +331,15 @@ typedef struct TgHipSceneDesc {
     uint32_t num_top_recs;                /* top-level records = recs[0, num_top_recs): the non-instance and the instance records in the
                                              wide BVH's order, then the instance-set records; the rest belong to masters */
     /* ABI 8, scenes with instances: the leaf slots of the reference's instance trees (see the instance-set record) -> instance record,
-     * and per leaf of those trees its box as its parent stores it: lo[3], hi[3], 2 x pad (the root's bounds for a tree that is one leaf) */
+     * and, at a leaf's FIRST slot, the leaf's box as its parent stores it: lo[3], pad, hi[3], pad -- two 16-byte loads; the root's bounds
+     * for a tree that is one leaf; num_inst_prims entries, the second slot of a two-instance leaf unused */
     const uint32_t     *inst_prims;       uint32_t num_inst_prims;
-    const float        *inst_leaf_boxes;  uint32_t num_inst_leaves;
+    const float        *inst_leaf_boxes;
+    /* ... and per top-level record that is an instance (indexed by the record: 8 floats at 8 x record index, num_top_recs entries, the
+     * others zero) a box -- lo[3], pad, hi[3], pad -- that holds the instance's geometry in world space and lies inside the reference's
+     * box of the instance: a ray that misses it cannot hit the instance, so its master is not walked (an optimisation only: the
+     * reference walks it and finds nothing).  The wide BVH is built from these boxes. */
+    const float        *inst_tight_boxes;
     const TgHipMedium  *media;  uint32_t num_media;   /* Scene::_media; NULL/0 = the scene has no participating media */
     /* the wide BVH: wide_nodes[0] is the root of the tree over recs[0, num_top_recs); with instances every master's wide
      * subtree follows (its root in the instance records' c[2]).  NULL/0 = the device walks the BVH2 (flat-list scenes do) */

@@ -131,7 +131,13 @@ def test_trace_rays_matches_oracle_exactly(scene, tmp_path):
     assert hit.sum() > n//10
     for k in ("t", "u", "v"):                   # the same operations in the same order on both sides: the same floats
         assert (ghits[k][hit] == ohits[k][hit]).all(), (k, int((ghits[k][hit] != ohits[k][hit]).sum()))
-    assert c.nodes_visited == onodes and c.prims_tested == oprims
+    if scene == "instances":
+        # same hits, fewer visits: the device does not walk the master of an instance whose tight box the ray misses (the reference's tree lets
+        # a ray into an instance by the box of the instance's LEAF -- the rotated corners of up to two master boxes --, walks the master and
+        # finds nothing there: pt_kernels.h: instanceReachable); the oracle walks what the reference walks
+        assert c.prims_tested <= oprims and c.nodes_visited <= 1.02*onodes
+    else:
+        assert c.nodes_visited == onodes and c.prims_tested == oprims
     assert (ghits["rec"] == bhits["rec"]).mean() >= 0.999
 
 
@@ -220,7 +226,7 @@ def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):
     if scene == "cornell_instances":
         # (wide_closest = 1 is not among them: the wide walk returns the NEAREST instance hit, the default walks the reference's own tree over
         # the instances in the reference's order and returns the LAST one, as Instance::intersect does)
-        variants += [dict(inst_simple=0), dict(wide_shadow=0), dict(leaf_batch_bvh2=1)]
+        variants += [dict(inst_dyn=0), dict(inst_simple=0), dict(wide_shadow=0), dict(leaf_batch_bvh2=1), dict(inst_dyn=0, wide_shadow=0)]
     variants = [dict(v, tail_kernel=0) for v in variants]
     variants += [dict(tail_kernel=1), dict(tail_kernel=1, streams=1), dict(tail_kernel=1, streams=8), dict(tail_kernel=1, tail_threshold=3000, check_interval=2),
                  dict(tail_kernel=1, tail_threshold=30000, check_interval=1, streams=2), dict(tail_kernel=1, slots_per_block=512),

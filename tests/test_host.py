@@ -259,7 +259,7 @@ def test_flat_list_scenes_carry_no_wide_bvh_and_instanced_scenes_the_references_
     flat.close()
     flat = tg.FlattenedScene(scenes.instances10k(tmp_path, resolution=(16, 9), spp=1, count=300, n_lat=12, n_lon=12))
     d = flat.desc.contents
-    assert d.num_instances == 300 and d.num_wide_nodes > 4 and d.num_inst_prims == 300 and 150 <= d.num_inst_leaves <= 300
+    assert d.num_instances == 300 and d.num_wide_nodes > 4 and d.num_inst_prims == 300
     recs = _np(d.recs, d.num_recs, np.float32, 12).view(np.uint32)
     kinds = recs[:d.num_top_recs, 3] >> 29
     assert (kinds == 4).sum() == 300 and (kinds == 7).sum() == 1 and kinds[d.num_top_recs - 1] == 7      # the set record follows the wide BVH's records
@@ -267,7 +267,7 @@ def test_flat_list_scenes_carry_no_wide_bvh_and_instanced_scenes_the_references_
     assert sorted(prims.tolist()) == sorted(np.nonzero(kinds == 4)[0].tolist())                          # every instance in exactly one leaf slot
     wide_roots = set()
     for r in np.nonzero(kinds == 4)[0]:
-        assert 0 < recs[r][10] < d.num_wide_nodes and recs[r][9] < d.num_inst_leaves                     # c[2]: the master's wide root, c[1]: its leaf
+        assert 0 < recs[r][10] < d.num_wide_nodes and recs[r][9] < d.num_inst_prims                      # c[2]: the master's wide root, c[1]: its leaf's first slot
         wide_roots.add(int(recs[r][10]))
     assert len(wide_roots) == 4
     # the reference's tree behind the set record: every inner node's two boxes contain the boxes of everything below them (the builder
@@ -275,7 +275,7 @@ def test_flat_list_scenes_carry_no_wide_bvh_and_instanced_scenes_the_references_
     nodes = _np(d.nodes, d.num_nodes, np.float32, 16)
     refs = nodes.view(np.int32)
     fl = recs.view(np.float32)
-    boxes = _np(d.inst_leaf_boxes, d.num_inst_leaves, np.float32, 8)
+    boxes = _np(d.inst_leaf_boxes, d.num_inst_prims, np.float32, 8)
     root = int(recs[d.num_top_recs - 1].view(np.int32)[8])
     assert 0 < root < d.num_nodes
     seen = []
@@ -289,8 +289,9 @@ def test_flat_list_scenes_carry_no_wide_bvh_and_instanced_scenes_the_references_
                 ri = int(prims[k])
                 seen.append(ri)
                 assert (fl[ri][0:3] >= lo - 1e-4).all() and (fl[ri][0:3] <= hi + 1e-4).all()
-                leaf = boxes[recs[ri][9]]
-                assert (leaf[0:3] == lo).all() and (leaf[3:6] == hi).all()
+                assert recs[ri][9] == first
+                leaf = boxes[first]
+                assert (leaf[0:3] == lo).all() and (leaf[4:7] == hi).all()
             return lo, hi
         n = nodes[ref]
         l0, h0, l1, h1 = n[0:3], n[3:6], n[6:9], n[9:12]

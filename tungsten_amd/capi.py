@@ -85,7 +85,7 @@ class TgHipSceneDesc(C.Structure):
                 ("sobol_matrices", C.POINTER(u32)), ("num_sobol_words", u64),
                 ("num_instances", u32), ("num_top_recs", u32),
                 ("inst_prims", C.POINTER(u32)), ("num_inst_prims", u32),
-                ("inst_leaf_boxes", C.POINTER(f32)), ("num_inst_leaves", u32),
+                ("inst_leaf_boxes", C.POINTER(f32)), ("inst_tight_boxes", C.POINTER(f32)),
                 ("media", C.POINTER(TgHipMedium)), ("num_media", u32),
                 ("wide_nodes", C.POINTER(TgHipWideNode)), ("num_wide_nodes", u32),
                 ("camera", TgHipCamera), ("settings", TgHipSettings),

@@ -981,8 +981,32 @@ PT_DEV void instanceLocalRay(const DeviceScene &s, uint32_t ri, const RayD &worl
     local.tmin = tmin; local.tmax = tmax;
     masterRoot = (int)__float_as_uint(r2.x);
 }
+// The distance at which the ray enters the leaf at inst_prims slot `first`, as its parent's test computed it (same box, same arithmetic:
+// the entry distance does not depend on farT).  BinaryBvh::trace keeps it with every stacked node; here it is recomputed when a stacked
+// LEAF is popped -- inner nodes need none: the children of a node that begins behind tMax all begin behind it too (float subtraction and
+// multiplication are monotonic and the builder's boxes nest), i.e. fail their own tests exactly when the reference's pop test would have
+// dropped the node -- so the stack holds one word per level.
+PT_DEV float refLeafEntry(const DeviceScene &s, uint32_t first, f3 o, f3 d, f3 invD, float nearT)
+{
+    const float4 blo = s.inst_leaf_boxes[2u*first], bhi = s.inst_leaf_boxes[2u*first + 1u];
+    float tEntry;
+    (void)refChildTest(xyz(blo), xyz(bhi), o, d, invD, nearT, PT_INF, tEntry);
+    return tEntry;
+}
+// Can the ray hit instance record `ri` at all, anywhere beyond `tmin`?  Its geometry lies inside inst_tight_boxes[ri] (padded for the
+// rounding of the world -> master transform, csrc/host/Scene.cpp: tightenInstanceBounds), so a ray that misses that box need not be
+// taken into the master: the reference takes it there and finds nothing.  An optimisation only -- two thirds of the instances the
+// reference's tree lets a ray into are entered in vain, their leaf's box being the union of the rotated CORNERS of up to two master boxes.
+PT_DEV bool instanceReachable(const DeviceScene &s, uint32_t ri, const RayD &world, f3 winvD, float tmin)
+{
+    const float4 blo = s.inst_tight_boxes[2u*ri], bhi = s.inst_tight_boxes[2u*ri + 1u];
+    RayD r = world;
+    r.tmin = tmin;
+    float e;
+    return boxTest(xyz(blo), xyz(bhi), r, winvD, PT_INF, e);
+}
 // Instance::intersect for the set record `setRec`: `tmax` is the ray's farT (it may GROW here), `hit` / `hitInst` the hit so far.
-// `stack` is the part of this lane's stack above what the caller has pushed: two words per stacked node, the master's walk above them.
+// `stack` is the part of this lane's stack above what the caller has pushed; the master's walk sits above the instance tree's.
 template<bool COUNT, uint32_t KINDS>
 PT_DEV void instanceSetIntersect(const DeviceScene &s, uint32_t setRec, const RayD &ray, float &tmax, float4 &hit, int &hitInst,
                                  int *stack, int stride, uint32_t &nodesVisited, uint32_t &primsTested)
@@ -1007,8 +1031,8 @@ PT_DEV void instanceSetIntersect(const DeviceScene &s, uint32_t setRec, const Ra
             const bool hitR = refChildTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray.o, ray.d, invD, ray.tmin, farT, e1);
             const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
             if (hitL && hitR) {
-                if (e0 < e1) { stack[(2*sp)*stride] = c1; stack[(2*sp + 1)*stride] = __float_as_int(e1); ++sp; node = c0; tMin = e0; }
-                else         { stack[(2*sp)*stride] = c0; stack[(2*sp + 1)*stride] = __float_as_int(e0); ++sp; node = c1; tMin = e1; }
+                if (e0 < e1) { stack[sp*stride] = c1; ++sp; node = c0; tMin = e0; }
+                else         { stack[sp*stride] = c0; ++sp; node = c1; tMin = e1; }
             } else if (hitL) { node = c0; tMin = e0; }
             else if (hitR) { node = c1; tMin = e1; }
             else { miss = true; break; }
@@ -1018,20 +1042,23 @@ PT_DEV void instanceSetIntersect(const DeviceScene &s, uint32_t setRec, const Ra
             for (uint32_t k = first; k < first + count; ++k) {
                 const uint32_t ri = s.inst_prims[k];
                 if (COUNT) primsTested++;
+                if (!instanceReachable(s, ri, ray, invD, tMin))
+                    continue;
                 RayD local;
                 int root;
                 instanceLocalRay(s, ri, ray, tMin, PT_INF, local, root);
-                const float4 lh = traverseClosest<COUNT, false, KINDS>(s, local, stack + 2*sp*stride, stride, nodesVisited, primsTested, root);
+                const float4 lh = traverseClosest<COUNT, false, KINDS>(s, local, stack + sp*stride, stride, nodesVisited, primsTested, root);
                 if (__float_as_int(lh.w) >= 0) { hit = lh; hitInst = (int)ri; tmax = lh.x; }    // ray.setFarT(localRay.farT())
             }
             tMax = refMin(tMax, tmax);
             farT = tMax;
         }
-        for (;;) {                                       // pop: nodes that begin behind tMax are dropped
+        for (;;) {                                       // pop: a leaf that begins behind tMax is dropped (inner nodes: see refLeafEntry)
             if (sp == 0) return;
             --sp;
-            node = stack[(2*sp)*stride];
-            tMin = __int_as_float(stack[(2*sp + 1)*stride]);
+            node = stack[sp*stride];
+            if (node >= 0) break;
+            tMin = refLeafEntry(s, TGHIP_LEAF_FIRST(node), ray.o, ray.d, invD, ray.tmin);
             if (!(tMax < tMin)) break;
         }
     }
@@ -1109,7 +1136,7 @@ PT_DEV bool instanceSetOccluded(const DeviceScene &s, uint32_t setRec, const Ray
             const bool hitL = refChildTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, ray.d, invD, ray.tmin, ray.tmax, e0);
             const bool hitR = refChildTest(mk3(n1.z, n1.w, n2.x), mk3(n2.y, n2.z, n2.w), ray.o, ray.d, invD, ray.tmin, ray.tmax, e1);
             const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
-            if (hitL && hitR) { stack[(2*sp)*stride] = c1; stack[(2*sp + 1)*stride] = __float_as_int(e1); ++sp; node = c0; tMin = e0; }
+            if (hitL && hitR) { stack[sp*stride] = c1; ++sp; node = c0; tMin = e0; }
             else if (hitL) { node = c0; tMin = e0; }
             else if (hitR) { node = c1; tMin = e1; }
             else { miss = true; break; }
@@ -1119,18 +1146,20 @@ PT_DEV bool instanceSetOccluded(const DeviceScene &s, uint32_t setRec, const Ray
             for (uint32_t k = first; k < first + count; ++k) {
                 const uint32_t ri = s.inst_prims[k];
                 if (COUNT) primsTested++;
+                if (!instanceReachable(s, ri, ray, invD, tMin))
+                    continue;
                 RayD local;
                 int root;
                 instanceLocalRay(s, ri, ray, tMin, PT_INF, local, root);
-                const float4 lh = traverseClosest<COUNT, false, KINDS>(s, local, stack + 2*sp*stride, stride, nodesVisited, primsTested, root);
+                const float4 lh = traverseClosest<COUNT, false, KINDS>(s, local, stack + sp*stride, stride, nodesVisited, primsTested, root);
                 if (__float_as_int(lh.w) >= 0)
                     return true;
             }
         }
         if (sp == 0) return false;
         --sp;
-        node = stack[(2*sp)*stride];
-        tMin = __int_as_float(stack[(2*sp + 1)*stride]);
+        node = stack[sp*stride];
+        if (node < 0) tMin = refLeafEntry(s, TGHIP_LEAF_FIRST(node), ray.o, ray.d, invD, ray.tmin);
     }
 }
 template<bool COUNT, uint32_t KINDS = KINDS_ALL>

@@ -41,7 +41,8 @@ struct DeviceScene {
     uint32_t num_nodes, num_recs, num_objects, num_lights, num_infinite_lights, num_bsdfs, num_textures;
     uint32_t num_instances;                    // instance records (0: single-level scene, A_EMI.w carries nothing)
     const uint32_t * __restrict__ inst_prims;  // leaf slots of the reference's instance trees -> instance record (TgHipSceneDesc::inst_prims)
-    const float4 * __restrict__ inst_leaf_boxes;   // 2 x float4 per leaf of those trees: its box as its parent holds it (lo, hi)
+    const float4 * __restrict__ inst_leaf_boxes;   // 2 x float4 per leaf slot: the leaf's box as its parent holds it (lo, hi), at the leaf's first slot
+    const float4 * __restrict__ inst_tight_boxes;  // 2 x float4 per top-level record: an instance record's tight world-space box (lo, hi)
     const TgHipMedium * __restrict__ media;    // participating media (nullptr / 0: none)
     uint32_t num_media;
     const TgHipCamera * __restrict__ camera;   // in device memory (56 dwords: read through the scalar cache where it is used, not held in SGPRs)
@@ -1019,8 +1020,12 @@ PT_DEV bool triTest(f3 v0, f3 b, f3 c, const RayD &ray, float tmax, float &t, fl
     float T = dotEmbree(Ng, C)*sgn;
     if (!(T > absDen*ray.tmin && T < absDen*tmax))
         return false;
+#ifdef PT_TRI_DIVIDE   /* experiment (profiles/README.md): the exact divisions rounds 1-3 ran here, to price Embree's reciprocal against them */
+    t = T/absDen; u = U/absDen; v = V/absDen;
+#else
     const float rcpAbsDen = embreeRcp(absDen);
     t = T*rcpAbsDen; u = U*rcpAbsDen; v = V*rcpAbsDen;
+#endif
     return true;
 }
 

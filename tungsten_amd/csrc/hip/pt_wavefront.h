@@ -458,6 +458,228 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
     }
 }
 
+// Closest hits of scenes with `instances` primitives, with dynamic ray fetch: the three-level walk of traverseClosestInst (pt_kernels.h) --
+// the scene's BVH2, behind an instance-set record the reference's own tree over the instances in the reference's order, behind an instance
+// its master's subtree with farT = infinity -- as ONE state machine per lane, one node or one leaf per loop turn, idle lanes refilled from
+// the workgroup's queue as in k_trace_closest_dyn.  `level`: 0 the scene's tree, 1 the instance tree, 2 a master's subtree.  All levels
+// share one stack (one word per entry: refLeafEntry says why the instance tree needs no entry distances on it).  Same results as
+// k_trace_closest<., ., INST>, hit for hit (tests/test_gpu_parity.py).
+template<bool COUNT, bool SOLIDS = true>
+__global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathState st)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLdsSmall L;
+    __shared__ uint32_t fetchNext;
+    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
+    int *stack = ldsDyn + (st.slots_per_block >> 1) + threadIdx.x;
+    const int stride = (int)blockDim.x;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    if (threadIdx.x == 0) fetchNext = 0;
+    queuesBegin(L, st, ctl, Q_EXTP, 0u, order, Q_EXT);
+    const uint32_t n = L.n;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    uint32_t nodes = 0, prims = 0, rays = 0;
+    constexpr uint32_t KINDS = SOLIDS ? KINDS_ALL : KINDS_MESH;
+
+    bool busy = false;
+    uint32_t slot = 0, local = 0;
+    RayD world; world.o = splat3(0.0f); world.d = splat3(1.0f); world.tmin = 0.0f; world.tmax = 0.0f;
+    RayD ray = world;                            // the ray of the level the walk is at (master space at level 2)
+    f3 invD = splat3(1.0f), winvD = splat3(1.0f);
+    float tmax = 0.0f;                           // the world ray's farT: the hit so far (it may GROW inside an instance set)
+    float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    int hitInst = -1;
+    int cur = 0, sp = 0, level = 0;
+    // level 1: BinaryBvh::trace's tMin / tMax / nearFar[2..3], the stack level the set was entered at
+    float refTMin = 0.0f, refTMax = 0.0f, refFarT = 0.0f;
+    int refSp = 0;
+    // the leaf of the instance tree being worked off: its slots [leafNext, leafEnd) of inst_prims, the instance inside of which the walk is
+    uint32_t leafNext = 0, leafEnd = 0;
+    int instSp = 0, curInst = -1;
+    float ltmax = 0.0f;
+    float4 lhit = hit;
+    bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
+    for (;;) {
+        unsigned long long busyMask = __ballot(busy);
+        if (!exhausted && __popcll(busyMask) <= 48) {
+            unsigned long long want = ~busyMask;
+            uint32_t lane = laneId();
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
+            base = __shfl(base, 0);
+            if (!busy) {
+                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    local = order[i];
+                    slot = first + local;
+                    float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
+                    world.o = xyz(ro); world.d = xyz(rd); world.tmin = ro.w; world.tmax = rd.w;
+                    ray = world;
+                    winvD = mk3(1.0f/world.d.x, 1.0f/world.d.y, 1.0f/world.d.z);
+                    invD = winvD;
+                    tmax = world.tmax;
+                    hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+                    hitInst = -1;
+                    cur = 0; sp = 0; level = 0;
+                    busy = true;
+                    rays++;
+                }
+            }
+            if (base + (uint32_t)__popcll(want) >= n)
+                exhausted = true;
+            busyMask = __ballot(busy);
+        }
+        if (busyMask == 0ull)
+            break;
+        bool pop = false;
+        // ---- a node: the scene's and the masters' with this library's slab test, the instance tree's with the reference's ----
+        if (busy && cur >= 0) {
+            const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
+            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            if (COUNT) nodes++;
+            const f3 lo0 = mk3(n0.x, n0.y, n0.z), hi0 = mk3(n0.w, n1.x, n1.y), lo1 = mk3(n1.z, n1.w, n2.x), hi1 = mk3(n2.y, n2.z, n2.w);
+            const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+            float e0, e1;
+            bool h0, h1, firstIs1;
+            if (level == 1) {
+                h0 = refChildTest(lo0, hi0, world.o, world.d, winvD, world.tmin, refFarT, e0);
+                h1 = refChildTest(lo1, hi1, world.o, world.d, winvD, world.tmin, refFarT, e1);
+                firstIs1 = !(e0 < e1);                                  // `minMax[0] < minMax[1]`: the right child first on a tie
+            } else {
+                const float far = level == 2 ? ltmax : tmax;
+                h0 = boxTest(lo0, hi0, ray, invD, far, e0);
+                h1 = boxTest(lo1, hi1, ray, invD, far, e1);
+                firstIs1 = e1 < e0;
+            }
+            float entry = 0.0f;
+            if (h0 && h1) {
+                stack[sp*stride] = firstIs1 ? c0 : c1;
+                sp++;
+                cur = firstIs1 ? c1 : c0;
+                entry = firstIs1 ? e1 : e0;
+            } else if (h0) { cur = c0; entry = e0; }
+            else if (h1) { cur = c1; entry = e1; }
+            else pop = true;
+            if (level == 1 && !pop) refTMin = entry;                    // BinaryBvh::trace's tMin: the distance the ray enters the child at
+        }
+        {
+            unsigned long long atLeaf = __ballot(busy && cur < 0 && !pop);
+            unsigned long long atNode = __ballot(busy && (cur >= 0 || pop));
+            // leaves are worked off when a good part of the wave waits at one, or nobody has node work left (k_trace_closest_dyn)
+            if (atLeaf != 0ull && ((uint32_t)__popcll(atLeaf) >= st.leaf_batch_bvh2 || atNode == 0ull)) {
+                if (busy && cur < 0 && !pop) {
+                    if (level == 1) {
+                        // a leaf of the instance tree: its one or two instances, one per turn
+                        if (leafNext == leafEnd) { leafNext = TGHIP_LEAF_FIRST(cur); leafEnd = leafNext + TGHIP_LEAF_COUNT(cur); }
+                        const uint32_t ri = s.inst_prims[leafNext];
+                        leafNext++;
+                        if (COUNT) prims++;
+                        if (instanceReachable(s, ri, world, winvD, refTMin)) {
+                            int root;
+                            instanceLocalRay(s, ri, world, refTMin, PT_INF, ray, root);
+                            invD = mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z);
+                            ltmax = PT_INF;
+                            lhit = make_float4(PT_INF, 0.0f, 0.0f, __int_as_float(-1));
+                            curInst = (int)ri;
+                            instSp = sp;
+                            stack[sp*stride] = cur;                     // (the leaf waits under the master's walk for its second instance / its end)
+                            sp++;
+                            cur = root;
+                            level = 2;
+                        } else if (leafNext == leafEnd) {
+                            // the leaf's last instance cannot be hit: the leaf is done (tMax = min(tMax, ray.farT()), BinaryBvh.hpp:274-275)
+                            refTMax = refMin(refTMax, tmax);
+                            refFarT = refTMax;
+                            leafNext = leafEnd = 0;
+                            pop = true;
+                        }                                               // (else: the leaf's second instance, in a turn of its own)
+                    } else {
+                        const uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+                        bool entered = false;
+                        if (level == 0) {
+                            const float4 r0 = at32(s.recs, firstRec*3u);
+                            if (TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE_SET) {   // (alone in its leaf)
+                                if (COUNT) prims++;
+                                const float4 r1 = at32(s.recs, firstRec*3u + 1u), r2 = at32(s.recs, firstRec*3u + 2u);
+                                float tMin = world.tmin, tMax = tmax;
+                                if (refBboxIntersection(xyz(r0), xyz(r1), world, tMin, tMax)) {
+                                    refTMin = tMin; refTMax = tMax; refFarT = tmax;
+                                    refSp = sp;
+                                    leafNext = leafEnd = 0;
+                                    cur = __float_as_int(r2.x);
+                                    level = 1;
+                                } else {
+                                    pop = true;
+                                }
+                                entered = true;
+                            }
+                        }
+                        if (!entered) {
+                            for (uint32_t r = firstRec; r < firstRec + count; ++r) {
+                                if (COUNT) prims++;
+                                uint32_t meta;
+                                if (level == 2) (void)testRecord<false, KINDS>(s, r, ray, ltmax, lhit, meta);
+                                else if (testRecord<false, KINDS>(s, r, ray, tmax, hit, meta)) hitInst = -1;
+                            }
+                            pop = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (busy && pop) {
+            if (level == 2 && sp == instSp + 1) {
+                // the master's subtree is done: a hit there REPLACES the hit so far (Instance.cpp:297-301); back to the leaf of the instance tree
+                if (__float_as_int(lhit.w) >= 0) { hit = lhit; hitInst = curInst; tmax = lhit.x; }
+                ray = world; invD = winvD;
+                level = 1;
+                sp--;
+                cur = stack[sp*stride];                                 // the leaf
+                if (leafNext == leafEnd) {                              // its last instance: tMax = min(tMax, ray.farT()) (BinaryBvh.hpp:274-275)
+                    refTMax = refMin(refTMax, tmax);
+                    refFarT = refTMax;
+                    leafNext = leafEnd = 0;
+                } else {
+                    pop = false;                                        // the leaf's second instance, in a turn of its own
+                }
+            }
+            if (pop && level == 1) {
+                // BinaryBvh::trace's pop (:277-283): a leaf that begins behind tMax is dropped (inner nodes: refLeafEntry)
+                for (;;) {
+                    if (sp == refSp) { level = 0; break; }              // the set is done: on with the scene's tree (pop stays set)
+                    sp--;
+                    cur = stack[sp*stride];
+                    if (cur >= 0) { pop = false; break; }
+                    refTMin = refLeafEntry(s, TGHIP_LEAF_FIRST(cur), world.o, world.d, winvD, world.tmin);
+                    if (!(refTMax < refTMin)) { pop = false; break; }
+                }
+            }
+            if (pop && level != 1) {
+                if (sp == 0) {
+                    // finished: publish the hit and bin the path by shading class
+                    slotF4(st, A_HIT, slot) = hit;
+                    slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
+                    int ri = __float_as_int(hit.w);
+                    int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
+                    queuePush(true, local, L, shadeQueue(cls));
+                    busy = false;
+                } else {
+                    sp--;
+                    cur = stack[sp*stride];
+                }
+            }
+        }
+    }
+    waveAddStat(&L.closest_rays, rays);
+    if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
+    queuesEnd(L, st, Q_EXT, Q_SHADE_MASK, Q_EXTP);
+    if (threadIdx.x == 0) {
+        ctl.closest_rays += L.closest_rays;
+        if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
+    }
+}
+
 // Closest hit through the 8-wide BVH (pt_kernels.h) with dynamic ray fetch, for single-level BVH scenes.  One loop turn
 // advances every busy lane by ONE memory round trip: the lane asks its walk for the next thing to look at -- a node (80
 // bytes) or a primitive record (48 bytes), both inside one allocation -- loads it, and then either slab-tests the node's
@@ -1970,7 +2192,9 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                     if (what == 2) {
                         float4 q3 = p[3], q4 = p[4];
                         if (COUNT) nodes++;
-                        wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, ray.tmax);
+                        // (INST: no far distance for the nodes -- what the reference clips against the ray's farT is the box of an instance's
+                        // leaf in ITS tree, tested at the record below; the geometry behind it, and so these boxes, may begin beyond farT)
+                        wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, INST ? PT_INF : ray.tmax);
                     } else if (INST && what == 4) {
                         wideResumeRecords(w, idx, q1);
                     } else {

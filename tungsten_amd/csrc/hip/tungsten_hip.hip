@@ -110,6 +110,7 @@ struct tghip_ctx {
     // both, except that closest-hit rays of instanced scenes stay on the two-level BVH2 kernel (instances10k 1080p, one MI355X:
     // closest-hit 849 us per launch on the BVH2 against 1061 us on the wide tree -- every instance entered costs the wide
     // walk extra turns --, shadow rays 905 against 517 us)
+    int instDynOpt = 1;                   // "inst_dyn": closest-hit rays of instanced scenes on the dynamic-fetch kernel (k_trace_closest_inst) instead of the static one
     int wideClosestOpt = -1, wideShadowOpt = -1;
     // "tail_kernel" / "tail_threshold": once a host check finds at most tail_threshold paths alive in the pool, the rest of the batch runs in
     // k_tail (one launch per part: every workgroup iterates over its own slots until they are done).  The kernel is built for latency, not
@@ -339,7 +340,7 @@ static int subtreeDepth(const TgHipSceneDesc *s, int32_t root, size_t &visited, 
 }
 
 // Stack words the BVH2 traversal needs: the scene's tree; with `instances` primitives, above it the reference's tree over the instances
-// (two words per level: the node and the distance the ray enters it at, pt_kernels.h: instanceSetIntersect) and the deepest master subtree.
+// and the deepest master subtree (pt_kernels.h: instanceSetIntersect).
 static int bvhDepthOf(const TgHipSceneDesc *s)
 {
     size_t visited = 0;
@@ -364,7 +365,7 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
         uint32_t root, leaf;
         std::memcpy(&root, &s->recs[i].c[0], 4);
         std::memcpy(&leaf, &s->recs[i].c[1], 4);
-        if (root == 0 || root >= s->num_nodes || leaf >= s->num_inst_leaves) return -1;
+        if (root == 0 || root >= s->num_nodes || leaf >= s->num_inst_prims) return -1;
         roots.push_back(root);
     }
     std::sort(roots.begin(), roots.end());
@@ -375,7 +376,7 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
         if (d < 0) return -1;
         master = std::max(master, d);
     }
-    return depth + 2*(ref + 1) + master + 2;
+    return depth + ref + master + 3;
 }
 
 // Validates the wide BVH -- the top-level tree from node 0 and, with instances, the masters' subtrees behind it (roots in the
@@ -638,7 +639,7 @@ static void chooseThreads(tghip_ctx *ctx)
     // from the same sweep).  Instanced scenes with the dynamic-fetch closest-hit kernel: two parts, 8 per CU (instances10k: 141 -> 153
     // Msamples/s; with the static-fetch kernel parts lost: 127 against 114-120).
     const bool oneStream = ctx->streamsOpt == 1 || (ctx->streamsOpt == 0 && ctx->shortBatch);   // (shortBatch: tghip_render_pass)
-    const bool pairedInst = !flat && ctx->haveInstances && !oneStream && !wideClosest(ctx) && ctx->dynamicFetch && wideShadowRays(ctx) &&
+    const bool pairedInst = !flat && ctx->haveInstances && !oneStream && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt && wideShadowRays(ctx) &&
                             !ctx->haveForward && !ctx->haveMeshLight;
     const bool paired = (!flat && !ctx->haveInstances && !oneStream && wideClosest(ctx) && wideShadowRays(ctx)) || pairedInst;
     ctx->blocksPerCu = ctx->blocksPerCuOpt > 0 ? ctx->blocksPerCuOpt : ((flat || paired) ? 8 : 4);
@@ -654,6 +655,7 @@ static void chooseThreads(tghip_ctx *ctx)
     ctx->thrClosest = wideC && inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false, true>, 192, 3))
                     : wideC ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 192, 3))
                     : flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
+                    : (inst && ctx->dynamicFetch && ctx->instDynOpt) ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_inst<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_inst<false, false>, 320, 2))
                     : inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest<false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_closest<false, false, 2>, 512, 1))
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
@@ -855,7 +857,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
                 if (!ctx->classStream[kk][a]) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->classStream[kk][a], hipStreamNonBlocking));
     }
     else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
-    else if (k == "inst_dyn") { }            // (round 3's dynamic-fetch kernel of the two-level nearest-hit walk: gone with that walk)
+    else if (k == "inst_dyn") { ctx->instDynOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch_bvh2") ctx->leafBatchBvh2 = int(std::min<long long>(std::max<long long>(value, 0), 64));
@@ -1166,12 +1168,16 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     s.num_lights = sd->num_lights; s.num_infinite_lights = sd->num_infinite_lights;
     s.num_bsdfs = sd->num_bsdfs; s.num_textures = sd->num_textures;
     s.num_instances = sd->num_instances;
-    s.inst_prims = nullptr; s.inst_leaf_boxes = nullptr;
+    s.inst_prims = nullptr; s.inst_leaf_boxes = nullptr; s.inst_tight_boxes = nullptr;
     if (sd->num_instances) {
         if ((rc = uploadArray(ctx, ctx->sceneMem, sd->inst_prims, size_t(sd->num_inst_prims), &s.inst_prims)) != TGHIP_OK) return rc;
         const float4 *boxes = nullptr;
-        if ((rc = uploadArray(ctx, ctx->sceneMem, reinterpret_cast<const float4 *>(sd->inst_leaf_boxes), size_t(sd->num_inst_leaves)*2, &boxes)) != TGHIP_OK) return rc;
+        if ((rc = uploadArray(ctx, ctx->sceneMem, reinterpret_cast<const float4 *>(sd->inst_leaf_boxes), size_t(sd->num_inst_prims)*2, &boxes)) != TGHIP_OK) return rc;
         s.inst_leaf_boxes = boxes;
+        if (!sd->inst_tight_boxes) { ctx->error = "scene with instances without inst_tight_boxes"; return TGHIP_E_INVALID; }
+        const float4 *tight = nullptr;
+        if ((rc = uploadArray(ctx, ctx->sceneMem, reinterpret_cast<const float4 *>(sd->inst_tight_boxes), size_t(sd->num_top_recs)*2, &tight)) != TGHIP_OK) return rc;
+        s.inst_tight_boxes = tight;
     }
     s.media = nullptr;
     s.num_media = sd->num_media;
@@ -1433,6 +1439,13 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             if (flat) {
                 if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
                 else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
+            } else if (ctx->haveInstances && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt) {
+                // the three-level walk with dynamic ray fetch
+                const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
+#define CLOSEST_DYN_INST(C, S) hipLaunchKernelGGL((k_trace_closest_inst<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->launchStream, s, st)
+                if (ctx->haveSolids) { if (count) CLOSEST_DYN_INST(true, true); else CLOSEST_DYN_INST(false, true); }
+                else                 { if (count) CLOSEST_DYN_INST(true, false); else CLOSEST_DYN_INST(false, false); }
+#undef CLOSEST_DYN_INST
             } else if (ctx->haveInstances && !wideClosest(ctx)) {
 #define CLOSEST_INST(C, I) hipLaunchKernelGGL((k_trace_closest<C, false, I>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st)
                 if (ctx->haveSolids) { if (count) CLOSEST_INST(true, 1); else CLOSEST_INST(false, 1); }
@@ -2227,7 +2240,8 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
         const bool cnt = ctx->countTraversal && r == 0;
         const bool flat = isFlat(ctx);
 #define RAYS_LAUNCH(C, F) hipLaunchKernelGGL((k_trace_rays<C, F>), dim3(grid), dim3(256), ldsBytes, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats)
-        if (useWide(ctx)) {
+        // (closest hits of a scene with `instances` primitives are a matter of the reference's visiting order: the BVH2 walk, never the wide one)
+        if (useWide(ctx) && !ctx->haveInstances) {
             const size_t ldsWide = size_t(std::max(ctx->wideDepth, 1))*256u*sizeof(uint2);
 #define RAYS_WIDE(C, I) hipLaunchKernelGGL((k_trace_rays<C, false, I, true>), dim3(grid), dim3(256), ldsWide, ctx->stream, ctx->scene, dRays, dHits, uint32_t(n), ctx->pool.stats)
             if (ctx->haveInstances) { if (cnt) RAYS_WIDE(true, 1); else RAYS_WIDE(false, 1); }

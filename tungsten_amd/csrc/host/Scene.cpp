@@ -893,6 +893,51 @@ void Primitive::loadResources(const std::string &sceneDir)
 }
 
 
+// The reference bounds an instance by the eight rotated corners of its master's box (Instance.cpp:411-423): for a
+// rotated master that box is up to sqrt(3) wider per axis than the geometry.  That box (instanceRefBounds) decides which instances the
+// reference hands a ray to, and so what the ray hits; the box of the master's rotated VERTICES (instanceBounds: exact up to rounding, padded
+// for the rounding of the device's own world -> master transform, never larger than the reference's) only says which of those instances
+// the ray can hit at all: an instance whose tight box the ray misses is not walked (pt_kernels.h), and the wide BVH of the any-hit queries
+// is built from the tight boxes.  `bounds` (the primitive's, which the scene bounds are made of) stays the reference's.
+void Primitive::tightenInstanceBounds()
+{
+    const size_t n = instancePos.size();
+    auto work = [this](size_t begin, size_t end) {
+        for (size_t i = begin; i < end; ++i) {
+            const Primitive &m = *masters[instanceId[i]];
+            if (m.tris.empty() || m.tfVerts.empty())
+                continue;
+            const QuaternionF &q = instanceRot[i];
+            const Vec3f cx = q*Vec3f(1.0f, 0.0f, 0.0f), cy = q*Vec3f(0.0f, 1.0f, 0.0f), cz = q*Vec3f(0.0f, 0.0f, 1.0f);
+            Vec3f lo(std::numeric_limits<float>::max()), hi(-std::numeric_limits<float>::max());
+            for (const MeshVertex &v : m.tfVerts) {
+                Vec3f p = cx*v.pos[0] + cy*v.pos[1] + cz*v.pos[2];
+                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+            }
+            Box3f tight;
+            for (int k = 0; k < 3; ++k) {
+                float pad = 1e-5f*(std::max(std::fabs(lo[k]), std::fabs(hi[k])) + std::fabs(instancePos[i][k])) + 1e-6f*(hi[k] - lo[k]);
+                tight.lo[k] = std::max(lo[k] + instancePos[i][k] - pad, instanceBounds[i].lo[k]);
+                tight.hi[k] = std::min(hi[k] + instancePos[i][k] + pad, instanceBounds[i].hi[k]);
+            }
+            instanceBounds[i] = tight;
+        }
+    };
+    size_t cost = 0;
+    for (size_t i = 0; i < n; ++i)
+        cost += masters[instanceId[i]]->tfVerts.size();
+    unsigned threads = cost > (1u << 22) ? std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1u;
+    if (threads == 1) {
+        work(0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back(work, n*t/threads, n*(t + 1)/threads);
+    for (std::thread &t : pool)
+        t.join();
+}
+
 void Primitive::prepareForRender()
 {
     switch (type) {
@@ -1031,6 +1076,8 @@ void Primitive::prepareForRender()
             bounds.grow(bGlobal);
             instanceRefBounds[i] = bGlobal;
         }
+        instanceBounds = instanceRefBounds;
+        tightenInstanceBounds();
         break;
     } case Mesh: { // TriangleMesh.cpp:524-572
         bounds = Box3f();

@@ -129,6 +129,7 @@ struct Primitive
     std::vector<Vec3f> instancePos;
     std::vector<QuaternionF> instanceRot;
     std::vector<uint8_t> instanceId;
+    std::vector<Box3f> instanceBounds;      // prepareForRender: tight world-space box of every instance (tightenInstanceBounds)
     std::vector<Box3f> instanceRefBounds;   // prepareForRender: world-space box of every instance as the reference boxes it (Instance.cpp:409-421:
                                             // the master box's eight rotated corners): what its own BVH over the instances is built from and
                                             // tested against (RefInstanceBvh.hpp)
@@ -146,6 +147,7 @@ struct Primitive
     float powerToRadianceFactor() const;
     void loadResources(const std::string &sceneDir);
     void prepareForRender();
+    void tightenInstanceBounds();
 };
 
 // ---- camera ------------------------------------------------------------------------------

@@ -232,6 +232,7 @@ void TraceableScene::flatten()
     std::vector<InstanceSet> instSets;
     std::vector<TgHipPrimRec> instRecs;
     std::vector<Box3f> instLeafBounds;                    // per instance record: the box of its leaf in the reference's tree
+    std::vector<Box3f> instTightBounds;                   // ... and the tight box of its geometry (Primitive::tightenInstanceBounds)
     _sceneBounds = Box3f();
     for (size_t pi = 0; pi < _allPrims.size(); ++pi) {
         Primitive &p = *_allPrims[pi];
@@ -370,6 +371,7 @@ void TraceableScene::flatten()
                 std::memcpy(&r.c[0], &masterSlot, 4);
                 r.meta = (uint32_t(TGHIP_REC_INSTANCE) << 29) | objMeta;
                 instRecs.push_back(r);
+                instTightBounds.push_back(p.instanceBounds[i]);
                 refBoxes.push_back(p.instanceRefBounds[i]);
                 numInstances++;
             }
@@ -381,18 +383,19 @@ void TraceableScene::flatten()
             copy3(set.rec.a, set.bounds.lo);
             copy3(set.rec.b, set.bounds.hi);
             set.rec.meta = (uint32_t(TGHIP_REC_INSTANCE_SET) << 29) | objMeta;
-            // every leaf's box as its parent holds it (a tree that is one leaf: the root's bounds), for the instances of that leaf
+            // every leaf's box as its parent holds it (a tree that is one leaf: the root's bounds), at the leaf's first slot of inst_prims,
+            // and that slot in the leaf's instance records
             instLeafBounds.resize(instRecs.size());
+            const size_t slotBase = _instLeafBoxes.size()/8;         // (= this set's first slot of inst_prims: one box slot per leaf slot)
+            _instLeafBoxes.resize(_instLeafBoxes.size() + 8*set.tree.primIndices.size(), 0.0f);
             auto leafBox = [&](uint32_t leafNode, const Box3f &box) {
                 const TgHipInstNode &leaf = set.tree.nodes[leafNode];
-                const uint32_t leafIndex = uint32_t(_instLeafBoxes.size()/8);
-                for (int k = 0; k < 3; ++k) _instLeafBoxes.push_back(box.lo[k]);
-                for (int k = 0; k < 3; ++k) _instLeafBoxes.push_back(box.hi[k]);
-                _instLeafBoxes.push_back(0.0f); _instLeafBoxes.push_back(0.0f);
+                const uint32_t slot = uint32_t(slotBase + leaf.left);
+                for (int k = 0; k < 3; ++k) { _instLeafBoxes[8*size_t(slot) + k] = box.lo[k]; _instLeafBoxes[8*size_t(slot) + 4 + k] = box.hi[k]; }
                 for (uint32_t k = 0; k < leaf.count; ++k) {
                     const size_t rec = set.firstInst + set.tree.primIndices[leaf.left + k];
                     instLeafBounds[rec] = box;
-                    std::memcpy(&instRecs[rec].c[1], &leafIndex, 4);
+                    std::memcpy(&instRecs[rec].c[1], &slot, 4);
                 }
             };
             if (set.tree.nodes[0].count != 0) {
@@ -435,8 +438,9 @@ void TraceableScene::flatten()
         _bvhSah = accel.sahCost;
     } else {
         // Scenes with instances (include/tungsten_hip.h, the instance-set record).  The wide BVH -- any-hit shadow queries -- is built
-        // over the non-instance records and the instance records, every instance boxed by its LEAF of the reference's tree (what the
-        // reference tests before it hands the instance its ray); it decides the record order.  The scene's BVH2 -- closest hits -- is
+        // over the non-instance records and the instance records, every instance boxed tightly (a ray that is to hit an instance passes
+        // that box somewhere along its whole length; whether the reference lets it INTO the instance is the leaf test the walk makes at
+        // the record, pt_wavefront.h); it decides the record order.  The scene's BVH2 -- closest hits -- is
         // built over the non-instance records and one record per `instances` primitive, behind which the reference's tree follows.
         const size_t K = _recs.size(), N = instRecs.size(), S = instSets.size();
         std::vector<Box3f> wideBounds(recBounds);
@@ -445,7 +449,7 @@ void TraceableScene::flatten()
             _triAttrs.emplace_back();
             std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
             _triAttrs.back().bsdf = -1;
-            wideBounds.push_back(instLeafBounds[i]);
+            wideBounds.push_back(instTightBounds[i]);
         }
         SceneAccel accel = buildSceneAccel(_recs, _triAttrs, wideBounds, true);
         _wideNodes.swap(accel.wideNodes);
@@ -454,6 +458,12 @@ void TraceableScene::flatten()
         std::vector<uint32_t> slotOf(K + N);                 // caller's record -> its slot
         for (size_t i = 0; i < accel.order.size(); ++i)
             slotOf[accel.order[i]] = uint32_t(i);
+        _instTightBoxes.assign(8*(K + N + S), 0.0f);
+        for (size_t i = 0; i < N; ++i)
+            for (int k = 0; k < 3; ++k) {
+                _instTightBoxes[8*size_t(slotOf[K + i]) + k] = instTightBounds[i].lo[k];
+                _instTightBoxes[8*size_t(slotOf[K + i]) + 4 + k] = instTightBounds[i].hi[k];
+            }
         for (size_t si = 0; si < S; ++si) {
             _recs.push_back(instSets[si].rec);
             _triAttrs.emplace_back();
@@ -605,10 +615,11 @@ void TraceableScene::flatten()
             _wideDepth += masterWideDepth + 3;
             if (_wideDepth > TGHIP_MAX_WIDE_DEPTH) { _wideNodes.clear(); _wideDepth = 0; }
         }
-        // one device stack holds the scene's walk, above it the walk of the reference's instance tree -- two words per level: the node
-        // and the distance at which the ray enters it, which BinaryBvh::trace re-checks when it pops (bvh/BinaryBvh.hpp:277-283) --
-        // and above that the walk of the master being visited
-        _bvhDepth += 2*(refDepth + 1) + masterDepth + 2;
+        // one device stack holds the scene's walk, above it the walk of the reference's instance tree and above that the walk of the
+        // master being visited.  (BinaryBvh::trace keeps the distance at which the ray enters a stacked node and re-checks it when it
+        // pops, bvh/BinaryBvh.hpp:277-283; the device recomputes it for a popped LEAF from inst_leaf_boxes and needs none for a popped
+        // inner node, whose children all fail their own tests exactly when the node's check would: pt_kernels.h)
+        _bvhDepth += refDepth + masterDepth + 3;
         if (_bvhDepth > TGHIP_MAX_BVH_DEPTH - 1)
             throw std::runtime_error("instanced BVH deeper than the device traversal stack");
     }
@@ -684,7 +695,7 @@ void TraceableScene::flatten()
     _desc.inst_prims = _instPrims.empty() ? nullptr : _instPrims.data();
     _desc.num_inst_prims = uint32_t(_instPrims.size());
     _desc.inst_leaf_boxes = _instLeafBoxes.empty() ? nullptr : _instLeafBoxes.data();
-    _desc.num_inst_leaves = uint32_t(_instLeafBoxes.size()/8);
+    _desc.inst_tight_boxes = _instTightBoxes.empty() ? nullptr : _instTightBoxes.data();
     _desc.wide_nodes = _wideNodes.empty() ? nullptr : _wideNodes.data();
     _desc.num_wide_nodes = uint32_t(_wideNodes.size());
     _desc.num_media = uint32_t(_media.size());

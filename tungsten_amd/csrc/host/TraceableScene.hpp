@@ -46,6 +46,7 @@ class TraceableScene
     std::vector<float> _texels, _dist, _lightTris;
     std::vector<uint32_t> _instPrims;      // TgHipSceneDesc::inst_prims
     std::vector<float> _instLeafBoxes;     // TgHipSceneDesc::inst_leaf_boxes
+    std::vector<float> _instTightBoxes;    // TgHipSceneDesc::inst_tight_boxes
     std::vector<std::shared_ptr<Primitive>> _allPrims;   // scene primitives (+ default light)
     TgHipSceneDesc _desc;
     Box3f _sceneBounds;
