@@ -189,6 +189,44 @@ def test_passes_and_pool_geometry_do_not_change_the_image(tmp_path):
     assert (again == base).all(), "same configuration must be bit-reproducible"
 
 
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_shards_and_batches_round_like_the_whole_pass(adaptive, tmp_path):
+    """A pass picks its work-item size by its own sample count -- one sample per item when short, four when long -- and a tile shard of a pass is
+    shorter than the pass, a pass cut into batches is several shorter ones.  k_resolve adds a pixel's samples up in ONE order whatever the
+    items (groups of four consecutive samples first, group after group into the pixel; batches hold whole groups), so the images agree BIT
+    FOR BIT: four-sample items against one-sample items, one batch against many, the sum of three shards against the whole -- at any size
+    (a reviewer's finding of round 3: at production sizes the shards of a pass used to round differently from the pass)."""
+    import ctypes as C
+    import json
+    if not scenes.have_materialtest():
+        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+    kw = dict(resolution=(192, 108), spp=22)
+    if adaptive:
+        kw = dict(resolution=(96, 54), spp=44, spp_step=22, renderer={"adaptive_sampling": True, "stratified_sampler": True})
+    path = scenes.materialtest(tmp_path, **kw)
+    images = {}
+    for name, opts in (("four", dict(chunk_samples=4)), ("one", dict(chunk_samples=1)), ("auto", dict()),
+                       ("one, batches", dict(chunk_samples=1, max_items=40000)), ("four, batches", dict(chunk_samples=4, max_items=30000)),
+                       ("one, small pool", dict(chunk_samples=1, max_slots=8192, max_items=70000))):
+        img, ssum, cnt, _ = gpu_render(path, **opts)
+        images[name] = ssum
+        assert (cnt > 0).all()
+    for name in images:
+        assert images[name].tobytes() == images["four"].tobytes(), name
+    # three shards on three contexts of the one device (each picks its own item size), summed on the host
+    d = json.load(open(path))
+    d["integrator"].update(devices=3, share_devices=True)
+    shared = os.path.join(str(tmp_path), "shared.json")
+    json.dump(d, open(shared, "w"))
+    r = tg.Renderer(shared, seed=SEED)
+    r.set_option("chunk_samples", 1, device=1)            # (one of the shards with the other item size)
+    r.set_option("chunk_samples", 4, device=2)
+    r.render()
+    _, ssum, _ = r.image()
+    r.close()
+    assert ssum.tobytes() == images["four"].tobytes()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("scene", ["materialtest", "cornell_instances"])
 def test_loop_scheduling_does_not_change_the_image(scene, tmp_path):

@@ -187,6 +187,8 @@ struct PassParams {
     uint32_t spp_begin, spp_end, seed;
     uint32_t chunk;            // samples per work item
     uint32_t chunks;           // items per pixel slot = ceil((spp_end - spp_begin)/chunk)
+    uint32_t group;            // k_resolve: partial sums added up in groups of this many before they reach the pixel (4 for one-sample items:
+                               // the sum then rounds exactly like that of four-sample items, whatever the shard or batch -- tungsten_hip.hip)
     uint32_t pix_slots;        // pixel slots in this batch (= tiles in batch * 256)
     uint32_t total_items;      // pix_slots*chunks (of this launch's workgroups: one half of the batch when the pool runs as two halves)
     uint32_t item_begin;       // first item of this launch's workgroups within the batch

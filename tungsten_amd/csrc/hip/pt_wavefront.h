@@ -2595,16 +2595,25 @@ __global__ __launch_bounds__(256) void k_resolve(PathState st, PassParams pp, fl
     if (!slotPixel(pp, j, x, y))
         return;
     uint32_t pixel = x + y*pp.width;
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    // One order of additions for a pixel's samples, whatever the items, batches and shards they were traced in: groups of four consecutive
+    // samples (counted from the pass's first) are summed first to last -- inside a four-sample item's slot, or here over four one-sample
+    // items --, and the groups are added to the pixel one after the other.  Batches hold whole groups, so splitting a pass changes nothing.
+    float sx = fbSum[(size_t)pixel*3 + 0], sy = fbSum[(size_t)pixel*3 + 1], sz = fbSum[(size_t)pixel*3 + 2];
     uint32_t cnt = 0;
-    for (uint32_t c = 0; c < pp.chunks; ++c) {
-        float4 a = at32(st.partial, c*pp.pix_slots + j);
-        sx += a.x; sy += a.y; sz += a.z;
-        cnt += __float_as_uint(a.w);
+    const uint32_t group = pp.group ? pp.group : 1u;
+    for (uint32_t c = 0; c < pp.chunks; c += group) {
+        float4 g = at32(st.partial, c*pp.pix_slots + j);
+        cnt += __float_as_uint(g.w);
+        for (uint32_t k = 1; k < group && c + k < pp.chunks; ++k) {
+            float4 a = at32(st.partial, (c + k)*pp.pix_slots + j);
+            g.x += a.x; g.y += a.y; g.z += a.z;
+            cnt += __float_as_uint(a.w);
+        }
+        sx += g.x; sy += g.y; sz += g.z;
     }
-    fbSum[(size_t)pixel*3 + 0] += sx;
-    fbSum[(size_t)pixel*3 + 1] += sy;
-    fbSum[(size_t)pixel*3 + 2] += sz;
+    fbSum[(size_t)pixel*3 + 0] = sx;
+    fbSum[(size_t)pixel*3 + 1] = sy;
+    fbSum[(size_t)pixel*3 + 2] = sz;
     fbCount[pixel] += cnt;
 }
 #endif
@@ -2621,23 +2630,31 @@ __global__ __launch_bounds__(256) void k_resolve_records(PathState st, PassParam
     uint32_t x = (rec % pp.variance_w)*4u + (j & 3u), y = (rec/pp.variance_w)*4u + ((j >> 2) & 3u);
     if (x >= pp.width || y >= pp.height)
         return;
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    uint32_t cnt = 0;
-    for (uint32_t c = 0; c < pp.num_chunks; ++c) {
-        uint32_t start = pp.rec_chunk_start[c];
-        if (j >= pp.rec_chunk_start[c + 1u] - start)
-            break;                               // chunks only get shorter: the pixel has no further items
-        uint32_t w = start + j;
-        if (w < pp.item_base || w - pp.item_base >= pp.total_items)
-            continue;                            // item of another batch
-        float4 a = at32(st.partial, w - pp.item_base);
-        sx += a.x; sy += a.y; sz += a.z;
-        cnt += __float_as_uint(a.w);
-    }
+    // (the order of additions of k_resolve: groups of pp.group items first, group after group into the pixel; a batch holds whole groups)
     uint32_t pixel = x + y*pp.width;
-    fbSum[(size_t)pixel*3 + 0] += sx;
-    fbSum[(size_t)pixel*3 + 1] += sy;
-    fbSum[(size_t)pixel*3 + 2] += sz;
+    float sx = fbSum[(size_t)pixel*3 + 0], sy = fbSum[(size_t)pixel*3 + 1], sz = fbSum[(size_t)pixel*3 + 2];
+    uint32_t cnt = 0;
+    bool done = false;
+    const uint32_t group = pp.group ? pp.group : 1u;
+    for (uint32_t c0 = 0; c0 < pp.num_chunks && !done; c0 += group) {
+        float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+        bool any = false;
+        for (uint32_t c = c0; c < c0 + group && c < pp.num_chunks; ++c) {
+            uint32_t start = pp.rec_chunk_start[c];
+            if (j >= pp.rec_chunk_start[c + 1u] - start) { done = true; break; }   // chunks only get shorter: the pixel has no further items
+            uint32_t w = start + j;
+            if (w < pp.item_base || w - pp.item_base >= pp.total_items)
+                continue;                        // item of another batch
+            float4 a = at32(st.partial, w - pp.item_base);
+            if (!any) { gx = a.x; gy = a.y; gz = a.z; any = true; }
+            else { gx += a.x; gy += a.y; gz += a.z; }
+            cnt += __float_as_uint(a.w);
+        }
+        if (any) { sx += gx; sy += gy; sz += gz; }
+    }
+    fbSum[(size_t)pixel*3 + 0] = sx;
+    fbSum[(size_t)pixel*3 + 1] = sy;
+    fbSum[(size_t)pixel*3 + 2] = sz;
     fbCount[pixel] += cnt;
 }
 #endif

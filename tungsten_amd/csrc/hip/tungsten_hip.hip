@@ -1782,10 +1782,13 @@ int tghip_wait(tghip_ctx *ctx)
         } else {
             passSamples = uint64_t(ownedTiles)*256u*spp;
         }
-        // (against the DEFAULT pool size, not the "max_slots" option: the image -- the order of its float additions -- stays a function
-        // of the pass alone, whatever the pool geometry)
-        chunk = uint32_t(std::min<uint64_t>(4, std::max<uint64_t>(1, passSamples >> 24)));
+        // One sample or four, nothing in between: k_resolve adds one-sample items up in groups of four, so both choices -- and with them
+        // the unsharded pass and every shard of it, which pick by their OWN sample counts -- round a pixel's sum alike (pt_wavefront.h:
+        // k_resolve; tests/test_gpu_parity.py::test_shards_and_batches_round_like_the_whole_pass).  An explicit "chunk_samples" of 2 or 3
+        // gives up that property, not the result's validity.
+        chunk = (passSamples >> 24) >= 3 ? 4u : 1u;
     }
+    const uint32_t group = chunk == 1u ? 4u : 1u;
     if (ctx->auxPass && !ctx->dAux) {
         const size_t npix = size_t(w)*h;
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->dAux), npix*sizeof(TgHipAuxPixel)));
@@ -1878,10 +1881,26 @@ int tghip_wait(tghip_ctx *ctx)
     uint32_t tilesPerBatch = ownedTiles, chunksPerBatch = chunksAll;
     if (!recordPass && uint64_t(ownedTiles)*256*chunksAll > maxItems) {
         chunksPerBatch = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(chunksAll, maxItems/(uint64_t(ownedTiles)*256))));
+        chunksPerBatch = std::max(group, chunksPerBatch/group*group);          // whole groups of k_resolve
         if (uint64_t(ownedTiles)*256*chunksPerBatch > maxItems)
             tilesPerBatch = uint32_t(std::max<uint64_t>(1, maxItems/(256ull*chunksPerBatch)));
     }
-    const uint64_t batchItems = recordPass ? std::min<uint64_t>(recordItems, maxItems) : uint64_t(tilesPerBatch)*256*chunksPerBatch;
+    // record passes: consecutive ranges of the gap-free enumeration that hold whole groups of chunks (the items of chunk c are
+    // [start[c], start[c + 1])), as many groups as fit maxItems, at least one
+    std::vector<uint64_t> recordBatchEnd;
+    if (recordPass) {
+        const std::vector<uint32_t> &start = ctx->hostChunkStart;
+        uint64_t begin = 0;
+        for (uint32_t c = 0; c < chunksAll; c += group) {
+            const uint64_t end = start[std::min(c + group, chunksAll)];
+            if (end - begin > maxItems && start[c] > begin) { recordBatchEnd.push_back(start[c]); begin = start[c]; }
+        }
+        recordBatchEnd.push_back(recordItems);
+    }
+    uint64_t recordBatchMax = 0;
+    for (size_t i = 0; i < recordBatchEnd.size(); ++i)
+        recordBatchMax = std::max(recordBatchMax, recordBatchEnd[i] - (i ? recordBatchEnd[i - 1] : 0));
+    const uint64_t batchItems = recordPass ? recordBatchMax : uint64_t(tilesPerBatch)*256*chunksPerBatch;
     {
         // A pass whose work items fill less than half the pool never refills a slot: it is one long drain, every iteration of which
         // pays the fixed cost of its launches.  Such passes (the 16-spp passes of the as-shipped materialtest: 3.7 M items) run on ONE
@@ -1917,14 +1936,16 @@ int tghip_wait(tghip_ctx *ctx)
     const unsigned long long itersBefore = ctx->counters.iterations;
     const auto tLoop0 = std::chrono::steady_clock::now();
     HIP_TRY(ctx, hipEventRecord(ctx->evA, ctx->stream));
-    for (uint64_t w0 = 0; recordPass && w0 < recordItems && rc == TGHIP_OK; w0 += batchItems) {
+    for (size_t bi = 0; recordPass && bi < recordBatchEnd.size() && rc == TGHIP_OK; ++bi) {
+        const uint64_t w0 = bi ? recordBatchEnd[bi - 1] : 0;
         PassParams pp = base;
         pp.spp_begin = 0; pp.spp_end = spp; pp.seed = pass.seed;
         pp.chunk = chunk;
+        pp.group = group;
         pp.chunks = chunksAll;
         pp.pix_slots = 1;                            // unused by the record enumeration
         pp.item_base = uint32_t(w0);
-        pp.total_items = uint32_t(std::min<uint64_t>(batchItems, recordItems - w0));
+        pp.total_items = uint32_t(recordBatchEnd[bi] - w0);
         pp.first_tile = 0;
         pp.shard_index = pass.shard_index; pp.shard_count = shardCount;
         pp.tiles_x = tilesX; pp.num_tiles = numTiles;
@@ -1937,6 +1958,7 @@ int tghip_wait(tghip_ctx *ctx)
             PassParams pp = base;
             pp.spp_begin = sppFirst; pp.spp_end = sppLast; pp.seed = pass.seed;
             pp.chunk = chunk;
+            pp.group = group;
             pp.chunks = (sppLast - sppFirst + chunk - 1)/chunk;
             pp.pix_slots = std::min(tilesPerBatch, ownedTiles - first)*256;
             pp.total_items = pp.pix_slots*pp.chunks;
