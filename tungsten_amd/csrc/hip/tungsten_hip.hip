@@ -1377,7 +1377,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     // wavefront loop on N streams: kernels of different parts share the CUs (chooseThreads), and the drain tail of one part's kernel
     // overlaps the other parts' kernels
     // (materialtest 1280x720x256 / mesh1m 1920x1080x32 on one box: 2 parts 656 / 398 Msamples/s, 4 parts 666 / 412)
-    int parts = ctx->streamsOpt >= 2 ? ctx->streamsOpt : (ctx->streamsOpt == 1 || ctx->shortBatch) ? 1 : !ctx->haveInstances ? 4 : ctx->blocksPerCu >= 8 ? 2 : 1;
+    // (instanced scenes: two parts in rounds 2-3; with the walk of the reference's instance tree four are 5 % faster -- profiles/r4_sweep_instances10k.jsonl)
+    int parts = ctx->streamsOpt >= 2 ? ctx->streamsOpt : (ctx->streamsOpt == 1 || ctx->shortBatch) ? 1 : (!ctx->haveInstances || ctx->blocksPerCu >= 8) ? 4 : 1;
     if (fused || flat || st.records || grid < 2*parts || grid % parts != 0 || pp.total_items < uint32_t(2*parts)*PT_ITEM_GROUP)
         parts = 1;
     const bool split = parts > 1;
