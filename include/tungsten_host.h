@@ -76,6 +76,10 @@ const uint32_t *tgh_scheduler_tile_seeds(tgh_scheduler *s);
 TgHostSampleRecord *tgh_scheduler_records(tgh_scheduler *s);   /* mutable view */
 /* returns 1 when the pass has work, 0 when not (PathTraceIntegrator.cpp:108-134) */
 int  tgh_scheduler_generate_work(tgh_scheduler *s, uint32_t current_spp, uint32_t next_spp, int adaptive);
+/* the state of the scheduler's own sampler -- the one distributeAdaptiveSamples draws from (PathTraceIntegrator.cpp:93-134) --: what a
+ * render-resume state holds next to the records (Integrator::saveState / loadState of a host that drives the scheduler through this API) */
+uint64_t tgh_scheduler_sampler_state(tgh_scheduler *s);
+void tgh_scheduler_set_sampler_state(tgh_scheduler *s, uint64_t state);
 void tgh_scheduler_free(tgh_scheduler *s);
 /* the Sobol' generator matrices the host hands to the device (NULL + message when the data file is missing) */
 const uint32_t *tgh_sobol_matrices(size_t *num_words, char *err, size_t errlen);

@@ -31,6 +31,24 @@
 #include "primitives/TriangleMesh.hpp"
 #include "primitives/InfiniteSphere.hpp"
 #include "primitives/Skydome.hpp"
+#include "primitives/Disk.hpp"
+#include "primitives/Cylinder.hpp"
+#include "primitives/Point.hpp"
+#include "primitives/InfiniteSphereCap.hpp"
+#include "media/Medium.hpp"
+#include "media/HomogeneousMedium.hpp"
+#include "transmittances/ExponentialTransmittance.hpp"
+#include "transmittances/LinearTransmittance.hpp"
+#include "transmittances/QuadraticTransmittance.hpp"
+#include "transmittances/DoubleExponentialTransmittance.hpp"
+#include "transmittances/PulseTransmittance.hpp"
+#include "transmittances/ErlangTransmittance.hpp"
+#include "transmittances/DavisTransmittance.hpp"
+#include "transmittances/DavisWeinsteinTransmittance.hpp"
+#include "transmittances/InterpolatedTransmittance.hpp"
+#include "phasefunctions/IsotropicPhaseFunction.hpp"
+#include "phasefunctions/HenyeyGreensteinPhaseFunction.hpp"
+#include "phasefunctions/RayleighPhaseFunction.hpp"
 #include "bsdfs/Bsdf.hpp"
 #include "bsdfs/LambertBsdf.hpp"
 #include "bsdfs/NullBsdf.hpp"
@@ -52,6 +70,9 @@
 #include "sampling/Distribution2D.hpp"
 #include "cameras/Camera.hpp"
 #include "cameras/PinholeCamera.hpp"
+#include "cameras/ThinlensCamera.hpp"
+#include "textures/DiskTexture.hpp"
+#include "textures/BladeTexture.hpp"
 #include "cameras/ReconstructionFilter.hpp"
 #include "renderer/TraceableScene.hpp"
 #undef private
@@ -246,11 +267,64 @@ int32_t HipSceneFlattener::addBsdf(const Bsdf *b)
     return idx;
 }
 
+// Medium / HomogeneousMedium after prepareForRender (media/HomogeneousMedium.cpp:43-49, Medium.cpp:14-30); the transmittance is a type
+// tag plus up to three parameters, the two operands of an interpolated one ride in two placeholder entries behind it (include/tungsten_hip.h)
+static void describeTransmittance(const Transmittance *t, int32_t &type, float *p, bool nested, int32_t *subType, float (*subP)[3])
+{
+    if (dynamic_cast<const ExponentialTransmittance *>(t)) { type = TGHIP_TRANS_EXPONENTIAL; }
+    else if (const LinearTransmittance *l = dynamic_cast<const LinearTransmittance *>(t)) { type = TGHIP_TRANS_LINEAR; p[0] = l->_maxT; }
+    else if (const QuadraticTransmittance *q = dynamic_cast<const QuadraticTransmittance *>(t)) { type = TGHIP_TRANS_QUADRATIC; p[0] = q->_maxT; }
+    else if (const DoubleExponentialTransmittance *d = dynamic_cast<const DoubleExponentialTransmittance *>(t)) { type = TGHIP_TRANS_DOUBLE_EXPONENTIAL; p[0] = d->_sigmaA; p[1] = d->_sigmaB; }
+    else if (const PulseTransmittance *u = dynamic_cast<const PulseTransmittance *>(t)) { type = TGHIP_TRANS_PULSE; p[0] = u->_a; p[1] = u->_b; p[2] = float(u->_numPulses); }
+    else if (const ErlangTransmittance *e = dynamic_cast<const ErlangTransmittance *>(t)) { type = TGHIP_TRANS_ERLANG; p[0] = e->_lambda; }
+    else if (const DavisTransmittance *v = dynamic_cast<const DavisTransmittance *>(t)) { type = TGHIP_TRANS_DAVIS; p[0] = v->_alpha; }
+    else if (const DavisWeinsteinTransmittance *w = dynamic_cast<const DavisWeinsteinTransmittance *>(t)) { type = TGHIP_TRANS_DAVIS_WEINSTEIN; p[0] = w->_h; p[1] = w->_c; }
+    else if (const InterpolatedTransmittance *i = dynamic_cast<const InterpolatedTransmittance *>(t)) {
+        if (nested) refuse("an interpolated transmittance inside an interpolated transmittance");
+        type = TGHIP_TRANS_INTERPOLATED;
+        p[0] = i->_u;
+        describeTransmittance(i->_trA.get(), subType[0], subP[0], true, nullptr, nullptr);
+        describeTransmittance(i->_trB.get(), subType[1], subP[1], true, nullptr, nullptr);
+    } else refuse("a transmittance of a type the device has no code for");
+}
+int32_t HipSceneFlattener::addMedium(const Medium *m)
+{
+    if (!m) return -1;
+    for (size_t i = 0; i < _mediumKeys.size(); ++i)
+        if (_mediumKeys[i] == m) return int32_t(i);
+    const HomogeneousMedium *h = dynamic_cast<const HomogeneousMedium *>(m);
+    if (!h) refuse("a medium that is not homogeneous");
+    TgHipMedium d;
+    std::memset(&d, 0, sizeof(d));
+    copy3(d.sigma_a, h->_sigmaA); copy3(d.sigma_s, h->_sigmaS); copy3(d.sigma_t, h->_sigmaT);
+    d.absorption_only = h->_absorptionOnly ? 1 : 0;
+    d.max_bounce = m->_maxBounce;
+    const PhaseFunction *ph = m->_phaseFunction.get();
+    if (dynamic_cast<const IsotropicPhaseFunction *>(ph)) d.phase_type = TGHIP_PHASE_ISOTROPIC;
+    else if (const HenyeyGreensteinPhaseFunction *g = dynamic_cast<const HenyeyGreensteinPhaseFunction *>(ph)) { d.phase_type = TGHIP_PHASE_HENYEY_GREENSTEIN; d.phase_g = g->_g; }
+    else if (dynamic_cast<const RayleighPhaseFunction *>(ph)) d.phase_type = TGHIP_PHASE_RAYLEIGH;
+    else refuse("a phase function of a type the device has no code for");
+    int32_t subType[2] = {0, 0};
+    float subP[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    describeTransmittance(m->_transmittance.get(), d.trans_type, d.trans_p, false, subType, subP);
+    _mediumKeys.push_back(m);
+    _media.push_back(d);
+    const int32_t index = int32_t(_media.size() - 1);
+    if (d.trans_type == TGHIP_TRANS_INTERPOLATED)
+        for (int k = 0; k < 2; ++k) {
+            TgHipMedium sub;
+            std::memset(&sub, 0, sizeof(sub));
+            sub.trans_type = subType[k];
+            for (int j = 0; j < 3; ++j) sub.trans_p[j] = subP[k][j];
+            _mediumKeys.push_back(nullptr);
+            _media.push_back(sub);
+        }
+    return index;
+}
+
 void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, const std::vector<const Primitive *> &sampled)
 {
     (void)defaultLight;
-    if (p._intMedium || p._extMedium)
-        refuse("a primitive with participating media");
     const size_t pi = _objects.size();
     TgHipObject o;
     std::memset(&o, 0, sizeof(o));
@@ -261,8 +335,9 @@ void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, cons
     o.emission = emissive ? addTexture(p._emission.get()) : -1;
     o.light = -1;
     o.first_light_tri = -1;
-    o.int_medium = o.ext_medium = -1;
-    o.flags = TGHIP_OBJF_SAMPLE;                  // ("sample" is a key of the infinite sphere only; everything else keeps the default)
+    o.int_medium = addMedium(p._intMedium.get());
+    o.ext_medium = addMedium(p._extMedium.get());
+    o.flags = TGHIP_OBJF_SAMPLE;                  // ("sample" is a key of the infinite lights only; everything else keeps the default)
     // identity rotation for the kinds that carry none (the stand-alone host's Primitive default)
     o.rot[0] = o.rot[4] = o.rot[8] = 1.0f;
 
@@ -308,8 +383,33 @@ void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, cons
         o.area = m->_totalArea; o.inv_area = 1.0f/m->_totalArea;
         std::vector<int32_t> meshBsdfs;
         for (const std::shared_ptr<Bsdf> &b : m->_bsdfs) meshBsdfs.push_back(addBsdf(b.get()));
-        if (emissive && m->isSamplable())
-            refuse("a triangle-mesh emitter");       // (light_tris block: TraceableScene.cpp of the stand-alone host)
+        if (emissive && m->isSamplable()) {
+            // TriangleMesh::makeSamplable (TriangleMesh.cpp:395-409) + Distribution1D (sampling/Distribution1D.hpp:16-30): cdf[n + 1] of the
+            // triangle areas, then the triangles in the mesh's own order
+            const size_t n = m->_tris.size();
+            if (n == 0) refuse("an emissive mesh without triangles");
+            std::vector<float> cdf(n + 1);
+            float totalArea = 0.0f;
+            cdf[0] = 0.0f;
+            for (size_t i = 0; i < n; ++i) {
+                const Vec3f p0 = m->_tfVerts[m->_tris[i].v0].pos(), p1 = m->_tfVerts[m->_tris[i].v1].pos(), p2 = m->_tfVerts[m->_tris[i].v2].pos();
+                const float area = (p1 - p0).cross(p2 - p0).length()*0.5f;      // MathUtil::triangleArea
+                totalArea += area;
+                cdf[i + 1] = cdf[i] + area;
+            }
+            const float totalWeight = cdf[n];
+            for (float &c : cdf) c /= totalWeight;
+            cdf[n] = 1.0f;
+            o.first_light_tri = int32_t(_lightTris.size());
+            o.num_light_tris = int32_t(n);
+            o.area = totalArea; o.inv_area = 1.0f/totalArea;
+            _lightTris.insert(_lightTris.end(), cdf.begin(), cdf.end());
+            for (size_t i = 0; i < n; ++i)
+                for (uint32 v : {m->_tris[i].v0, m->_tris[i].v1, m->_tris[i].v2}) {
+                    const Vec3f q = m->_tfVerts[v].pos();
+                    _lightTris.push_back(q.x()); _lightTris.push_back(q.y()); _lightTris.push_back(q.z());
+                }
+        }
         for (const TriangleI &t : m->_tris) {
             const Vertex &a = m->_tfVerts[t.v0], &b = m->_tfVerts[t.v1], &c = m->_tfVerts[t.v2];
             TgHipPrimRec r;
@@ -338,8 +438,35 @@ void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, cons
         o.type = TGHIP_OBJ_INFINITE_SPHERE;
         o.flags = (sd->_doSample ? TGHIP_OBJF_SAMPLE : 0u) | TGHIP_OBJF_SKYDOME;
         copyRot(o.rot, Mat4f());
+    } else if (const Disk *d = dynamic_cast<const Disk *>(&p)) {               // Disk.cpp:303-315; bounds :283-291
+        o.type = TGHIP_OBJ_DISK;
+        copy3(o.pos, d->_center); copy3(o.normal, d->_n);
+        copy3(o.edge0, d->_frame.tangent); copy3(o.edge1, d->_frame.bitangent);
+        copy3(o.scale, Vec3f(d->_r, d->_cosApex, 0.0f));
+        copy3(o.base, d->_coneBase);
+        o.area = d->_area; o.inv_area = d->_invArea;
+        plainRecord(TGHIP_REC_DISK, d->_center, Vec3f(d->_r, d->_cosApex, 0.0f), Vec3f(0.0f), 0.0f, 0.0f);
+        pushBounds(d->bounds());
+    } else if (const Cylinder *c = dynamic_cast<const Cylinder *>(&p)) {       // Cylinder.cpp:305-319; bounds :286-293
+        o.type = TGHIP_OBJ_CYLINDER;
+        copy3(o.pos, c->_pos); copy3(o.normal, c->_axis); copyRot(o.rot, c->_rot);
+        copy3(o.scale, Vec3f(c->_radius, c->_halfHeight, c->_capped ? 1.0f : 0.0f));
+        o.area = c->_area; o.inv_area = c->_invArea;
+        plainRecord(TGHIP_REC_CYLINDER, c->_pos, Vec3f(c->_radius, c->_halfHeight, c->_capped ? 1.0f : 0.0f), Vec3f(0.0f), 0.0f, 0.0f);
+        pushBounds(c->bounds());
+    } else if (const Point *pt = dynamic_cast<const Point *>(&p)) {            // Point.cpp:183-189 (a Dirac light: never intersected, no record)
+        o.type = TGHIP_OBJ_POINT;
+        copy3(o.pos, pt->_pos);
+        copy3(o.scale, pt->_power);                                            // (zero for a light given by "power": Point.cpp:186-188)
+    } else if (const InfiniteSphereCap *cap = dynamic_cast<const InfiniteSphereCap *>(&p)) {   // InfiniteSphereCap.cpp:233-249
+        if (!cap->_domeName.empty()) refuse("an infinite sphere cap that follows a skydome");
+        o.type = TGHIP_OBJ_INFINITE_SPHERE_CAP;
+        o.flags = cap->_doSample ? TGHIP_OBJF_SAMPLE : 0u;
+        copy3(o.normal, cap->_capDir);
+        copy3(o.scale, Vec3f(cap->_cosCapAngle, 0.0f, 0.0f));
+        copy3(o.edge0, cap->_capFrame.tangent); copy3(o.edge1, cap->_capFrame.bitangent);
     } else {
-        refuse("a primitive that is not a quad, cube, sphere, triangle mesh, infinite sphere or skydome");
+        refuse("a primitive that is not a quad, cube, sphere, disk, cylinder, triangle mesh, point, infinite sphere, infinite sphere cap or skydome");
     }
 
     if (emissive) {
@@ -356,8 +483,9 @@ void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, cons
 
 void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settings, bool enableVolumeLightSampling)
 {
-    if (!scene._media.empty() || scene._cam.medium())
-        refuse("a scene with participating media");
+    // the scene's named media first, in the scene's order; inline ones follow as they are met
+    for (const std::shared_ptr<Medium> &m : scene._media)
+        addMedium(m.get());
 
     // named bsdfs first, in the scene's order; the primitives' own follow as they are met
     for (const std::shared_ptr<Bsdf> &b : scene._bsdfs)
@@ -395,13 +523,15 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
         throw std::runtime_error(std::string("path_tracer_hip: tgh_accel_build: ") + err);
 
     // ---- camera (PinholeCamera.cpp:28-35, Camera.cpp:37-68, ReconstructionFilter.cpp:34-58) ----
-    const PinholeCamera *cam = dynamic_cast<const PinholeCamera *>(&scene._cam);
-    if (!cam)
-        refuse("a camera other than the pinhole camera");
+    const PinholeCamera *pin = dynamic_cast<const PinholeCamera *>(&scene._cam);
+    const ThinlensCamera *lens = dynamic_cast<const ThinlensCamera *>(&scene._cam);
+    if (!pin && !lens)
+        refuse("a camera other than the pinhole and the thin-lens camera");
+    const Camera *cam = &scene._cam;
     TgHipCamera &c = _desc.camera;
     std::memset(&c, 0, sizeof(c));
     copy3(c.pos, cam->_pos);
-    c.plane_dist = cam->_planeDist;
+    c.plane_dist = pin ? pin->_planeDist : lens->_planeDist;
     copyRot(c.xf, cam->_transform);
     c.ratio = cam->_ratio;
     c.pixel_size_x = cam->_pixelSize.x();
@@ -413,13 +543,43 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     c.filter_bin_size = f._binSize;
     if (c.filter_type == TGHIP_FILTER_TABULATED)
         for (int i = 0; i < 32; ++i) c.filter_cdf[i] = f._cdf[i];
-    c.type = TGHIP_CAMERA_PINHOLE;
-    // (the thin-lens fields keep the values the stand-alone host's Camera has for a pinhole camera)
+    c.type = pin ? TGHIP_CAMERA_PINHOLE : TGHIP_CAMERA_THINLENS;
+    // (a pinhole camera's thin-lens fields keep the values the stand-alone host's Camera has for it)
     c.focus_dist = 1.0f; c.aperture_size = 0.001f; c.cat_eye = 0.0f;
     c.aperture_type = TGHIP_APERTURE_DISK;
+    if (lens) {                                        // ThinlensCamera.cpp:27-35, 85-133; focus_pivot is resolved by ThinlensCamera::prepareForRender
+        c.focus_dist = lens->_focusDist; c.aperture_size = lens->_apertureSize; c.cat_eye = lens->_catEye;
+        const Texture *ap = lens->_aperture.get();
+        if (const BladeTexture *b = dynamic_cast<const BladeTexture *>(ap)) {          // BladeTexture.cpp:21-31
+            c.aperture_type = TGHIP_APERTURE_BLADE;
+            c.blade_count = b->_numBlades;
+            c.blade_angle = b->_angle; c.blade_step = b->_bladeAngle;
+            c.blade_edge[0] = b->_baseEdge.x(); c.blade_edge[1] = b->_baseEdge.y();
+        } else if (const BitmapTexture *b = dynamic_cast<const BitmapTexture *>(ap)) {  // makeSamplable(MAP_UNIFORM): BitmapTexture.cpp:400-431
+            // ThinlensCamera::precompute makes the aperture samplable inside fromJson, BEFORE Scene::loadResources has read the image: the
+            // reference's own distribution is built over 0 x 0 texels and never rebuilt (the unmodified program dies at its first lens
+            // sample).  The device is handed the distribution of the image that was loaded since.
+            BitmapTexture *mb = const_cast<BitmapTexture *>(b);
+            if (!mb->_distribution[MAP_UNIFORM] || mb->_distribution[MAP_UNIFORM]->_w != mb->_w || mb->_distribution[MAP_UNIFORM]->_h != mb->_h) {
+                mb->_distribution[MAP_UNIFORM].reset();
+                mb->makeSamplable(MAP_UNIFORM);
+            }
+            if (!b->_distribution[MAP_UNIFORM]) refuse("a bitmap aperture without its distribution");
+            const Distribution2D &dd = *b->_distribution[MAP_UNIFORM];
+            c.aperture_type = TGHIP_APERTURE_BITMAP;
+            c.aperture_w = dd._w; c.aperture_h = dd._h;
+            c.aperture_dist = uint32_t(_dist.size());
+            _dist.insert(_dist.end(), dd._marginalPdf.begin(), dd._marginalPdf.end());
+            _dist.insert(_dist.end(), dd._marginalCdf.begin(), dd._marginalCdf.end());
+            _dist.insert(_dist.end(), dd._pdf.begin(), dd._pdf.end());
+            _dist.insert(_dist.end(), dd._cdf.begin(), dd._cdf.end());
+        } else if (!dynamic_cast<const DiskTexture *>(ap)) {
+            refuse("an aperture that is not a disk, a blade polygon or a bitmap");
+        }
+    }
     for (int r = 0; r < 3; ++r)
         for (int k = 0; k < 4; ++k) c.inv_xf[r*4 + k] = cam->_invTransform[r*4 + k];
-    c.medium = -1;
+    c.medium = addMedium(cam->_medium.get());
 
     _desc.settings.min_bounces = settings.minBounces;
     _desc.settings.max_bounces = settings.maxBounces;
@@ -451,6 +611,8 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     _desc.texels = _texels.data(); _desc.num_texel_floats = _texels.size();
     _desc.dist = _dist.data();     _desc.num_dist_floats = _dist.size();
     _desc.light_tris = _lightTris.data(); _desc.num_light_tri_floats = _lightTris.size();
+    _desc.media = _media.empty() ? nullptr : _media.data();
+    _desc.num_media = uint32_t(_media.size());
     if (scene._settings.useSobol()) {
         // the table stays Tungsten's (thirdparty/sobol/sobol.h:30-35)
         _desc.sobol_matrices = reinterpret_cast<const uint32_t *>(sobol::Matrices::matrices);

@@ -5,11 +5,13 @@
 // the camera) and fills the TgHipSceneDesc that tghip_upload_scene takes.  The acceleration structures come from
 // libtungsten_hip.so (tgh_accel_build, include/tungsten_host.h) -- they take the place of the rtcCommit calls.
 //
-// Scope: what the BASELINE scenes and the shipped example scenes of this repository's tests use -- quad, cube, sphere, triangle
-// mesh, infinite sphere (constant or bitmap emission, sampled or not) primitives; lambert, null, mirror, conductor, rough
-// conductor, dielectric, rough dielectric, plastic, rough plastic, smooth coat, mixed, transparency, forward BSDFs, bump maps; constant,
-// checker and bitmap textures; skydomes; the pinhole camera.  Anything else is refused with a message naming the class (the stand-alone
-// host of this repository, tungsten_amd/csrc/host/TraceableScene.cpp, is the complete flattener).
+// Scope (round 4: everything the device renders but `instances`): quad, cube, sphere, disk, cylinder, triangle-mesh primitives and emitters
+// (mesh emitters with their area distribution), point lights, infinite spheres (constant or bitmap emission, sampled or not), infinite
+// sphere caps, skydomes; lambert, null, mirror, conductor, rough conductor, dielectric, rough dielectric, plastic, rough plastic, smooth
+// coat, mixed, transparency, forward BSDFs, bump maps; constant, checker and bitmap textures; homogeneous media with every transmittance
+// and phase function, on primitives and on the camera; the pinhole and the thin-lens camera (disk, blade and bitmap apertures).  Anything
+// else -- the `instances` primitive: its trees come from the stand-alone host's own flattening, tungsten_amd/csrc/host/TraceableScene.cpp
+// -- is refused with a message naming the class.
 #ifndef HIPSCENEFLATTENER_HPP_
 #define HIPSCENEFLATTENER_HPP_
 
@@ -27,6 +29,7 @@ class TraceableScene;
 class Primitive;
 class Texture;
 class Bsdf;
+class Medium;
 struct TraceSettings;
 
 class HipSceneFlattener
@@ -39,6 +42,8 @@ class HipSceneFlattener
     std::vector<TgHipTexture> _textures;
     std::vector<float> _texels, _dist, _lightTris;
     std::vector<float> _recBounds;
+    std::vector<TgHipMedium> _media;
+    std::vector<const Medium *> _mediumKeys;
     std::map<const Texture *, int32_t> _texIndex;
     std::map<const Bsdf *, int32_t> _bsdfIndex;
     tgh_accel *_accel = nullptr;
@@ -47,6 +52,7 @@ class HipSceneFlattener
     int32_t addTexture(const Texture *t);
     void addDistribution(const Texture *t);
     int32_t addBsdf(const Bsdf *b);
+    int32_t addMedium(const Medium *m);
     void addPrimitive(const Primitive &p, bool defaultLight, const std::vector<const Primitive *> &sampled);
 
 public:

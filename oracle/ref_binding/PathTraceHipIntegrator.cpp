@@ -24,6 +24,7 @@
 #undef class
 #include "renderer/TraceableScene.hpp"
 #include "io/JsonObject.hpp"
+#include "io/FileUtils.hpp"
 #include "Debug.hpp"
 
 #include "PathTraceHipIntegrator.hpp"
@@ -60,8 +61,50 @@ rapidjson::Value PathTraceHipIntegrator::toJson(Allocator &allocator) const
     };
 }
 
-void PathTraceHipIntegrator::saveState(OutputStreamHandle &/*out*/) {}
-void PathTraceHipIntegrator::loadState(InputStreamHandle &/*in*/) {}
+// Integrator::saveRenderResumeData / resumeRender (integrators/Integrator.cpp:108-162) call these behind the camera's output buffers.  The
+// reference's path tracer stores its SampleRecords and one sequential sampler per tile (PathTraceIntegrator.cpp:158-172); here: the
+// framebuffer as the device keeps it -- radiance SUMS and sample counts: the camera's colour buffer holds means, and mean x count is not the
+// sum bit for bit --, the SampleRecords, and the state of the scheduler's sampler (the per-path streams are counter-based and need none).
+void PathTraceHipIntegrator::saveState(OutputStreamHandle &out)
+{
+    const uint64 magic = 0x3452504948474E54ull;                    // "TNGHIPR4"
+    const uint64 n = uint64(_w)*_h, nr = tgh_scheduler_num_records(_scheduler), state = tgh_scheduler_sampler_state(_scheduler);
+    FileUtils::streamWrite(out, magic);
+    FileUtils::streamWrite(out, n);
+    FileUtils::streamWrite(out, _sum.data(), size_t(n)*3);
+    FileUtils::streamWrite(out, _count.data(), size_t(n));
+    FileUtils::streamWrite(out, nr);
+    FileUtils::streamWrite(out, tgh_scheduler_records(_scheduler), size_t(nr));
+    FileUtils::streamWrite(out, state);
+}
+void PathTraceHipIntegrator::loadState(InputStreamHandle &in)
+{
+    uint64 magic = 0, n = 0, nr = 0, state = 0;
+    FileUtils::streamRead(in, magic);
+    FileUtils::streamRead(in, n);
+    if (magic != 0x3452504948474E54ull || n != uint64(_w)*_h)
+        FAIL("path_tracer_hip: the render resume state was not written by this integrator for this image size");
+    FileUtils::streamRead(in, _sum.data(), size_t(n)*3);
+    FileUtils::streamRead(in, _count.data(), size_t(n));
+    FileUtils::streamRead(in, nr);
+    if (nr != tgh_scheduler_num_records(_scheduler))
+        FAIL("path_tracer_hip: the render resume state holds another number of sample records");
+    TgHostSampleRecord *rec = tgh_scheduler_records(_scheduler);
+    FileUtils::streamRead(in, rec, size_t(nr));
+    FileUtils::streamRead(in, state);
+    tgh_scheduler_set_sampler_state(_scheduler, state);
+    // the merged framebuffer goes to the first device, the others restart from zero (ownership of a pixel only matters for the samples
+    // still to come); every device gets the complete Welford state and keeps updating the records of its own tiles
+    std::vector<TgHipSampleRecord> dev(static_cast<size_t>(nr));
+    for (size_t i = 0; i < dev.size(); ++i) { dev[i].sample_count = rec[i].sample_count; dev[i].mean = rec[i].mean; dev[i].running_variance = rec[i].running_variance; }
+    for (size_t d = 0; d < _ctxs.size(); ++d) {
+        check(tghip_clear_framebuffer(_ctxs[d]), _ctxs[d], "tghip_clear_framebuffer");
+        if (d == 0)
+            check(tghip_upload_framebuffer(_ctxs[d], _sum.data(), _count.data(), size_t(n)), _ctxs[d], "tghip_upload_framebuffer");
+        if (_scene->rendererSettings().useAdaptiveSampling())
+            check(tghip_upload_records(_ctxs[d], dev.data(), dev.size()), _ctxs[d], "tghip_upload_records");
+    }
+}
 
 // PathTraceIntegrator::prepareForRender (PathTraceIntegrator.cpp:184-201): here the device is acquired and the flattened
 // scene uploaded
@@ -116,6 +159,8 @@ void PathTraceHipIntegrator::prepareForRender(TraceableScene &scene, uint32 seed
         put("settings", &d.settings, sizeof(d.settings));
         put("bounds", d.bounds_lo, 24u);
         put("sobol", d.sobol_matrices, d.num_sobol_words*4u);
+        put("media", d.media, uint64_t(d.num_media)*sizeof(TgHipMedium));
+        put("light_tris", d.light_tris, d.num_light_tri_floats*4u);
     }
 
     int available = tghip_device_count();

@@ -55,7 +55,7 @@ public:
     virtual void waitForCompletion() override;
     virtual void abortRender() override;
 
-    virtual bool supportsResumeRender() const override { return false; }   // (this test binding; INTEGRATION.md section 4 has the recipe)
+    virtual bool supportsResumeRender() const override { return true; }    // `tungsten -c / -r` (src/tungsten/Shared.hpp:256-320): saveState / loadState below
 };
 
 }

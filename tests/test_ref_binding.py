@@ -73,6 +73,8 @@ def own_desc(path):
         "settings": bytes(d.settings),
         "bounds": bytes(d.bounds_lo) + bytes(d.bounds_hi),
         "sobol": arr(d.sobol_matrices, d.num_sobol_words, 4),
+        "media": arr(d.media, d.num_media, C.sizeof(capi.TgHipMedium)),
+        "light_tris": arr(d.light_tris, d.num_light_tri_floats, 4),
     }
     flat.close()
     return own
@@ -89,6 +91,16 @@ CASES = {
     "bump": lambda tmp: scenes.GOLDEN_CASES["cornell_bump"][0](tmp, **dict(scenes.GOLDEN_CASES["cornell_bump"][1], resolution=(96, 54), spp=2)),
     "skydome": lambda tmp: scenes.GOLDEN_CASES["cornell_skydome"][0](tmp, **dict(scenes.GOLDEN_CASES["cornell_skydome"][1], resolution=(96, 54), spp=2)),
 }
+# round 4: everything else the device renders (but `instances`) -- the analytic primitives and emitters, mesh emitters, media with every
+# transmittance and phase function on primitives and on the camera, the thin-lens camera with its three apertures
+for _name in ("cornell_disks", "cornell_cylinders", "cornell_point_lights", "cornell_sun_sky", "cornell_mesh_light", "cornell_mesh_and_quad_light",
+              "cornell_fog", "cornell_smoke", "cornell_fog_smoke_sobol", "cornell_fog_rayleigh", "cornell_fog_davis", "cornell_fog_davis_weinstein",
+              "cornell_fog_interpolated", "volumetric_caustic", "non_exponential_linear", "non_exponential_pulse", "non_exponential_erlang",
+              "non_exponential_double_exponential", "non_exponential_quadratic", "cornell_thinlens", "cornell_thinlens_cateye", "cornell_thinlens_blade5",
+              "cornell_thinlens_pivot", "cornell_thinlens_bitmap"):
+    CASES[_name] = (lambda n: lambda tmp: scenes.GOLDEN_CASES[n][0](tmp, **dict(scenes.GOLDEN_CASES[n][1], resolution=(96, 54), spp=2)))(_name)
+WIDENED = ["cornell_disks", "cornell_cylinders", "cornell_point_lights", "cornell_sun_sky", "cornell_mesh_light", "cornell_fog_smoke_sobol", "volumetric_caustic",
+           "non_exponential_pulse", "cornell_thinlens_blade5", "cornell_thinlens_cateye"]
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -110,7 +122,7 @@ def test_reference_side_flattener_builds_the_scene_the_own_loader_builds(case, t
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["cornell", "cornell_as_shipped_sampler", "materialtest", "skydome", "bump"])
+@pytest.mark.parametrize("case", ["cornell", "cornell_as_shipped_sampler", "materialtest", "skydome", "bump"] + WIDENED)
 def test_reference_program_with_the_plugin_writes_the_image_of_the_own_host(case, tmp_path):
     """tungsten (the reference's program) with "type": "path_tracer_hip" against tungsten_hip (this repository's CLI) on the same
     scene, seed and spp: the .pfm files are identical bit for bit."""
@@ -127,3 +139,32 @@ def test_reference_program_with_the_plugin_writes_the_image_of_the_own_host(case
     a, b = open(ref_pfm, "rb").read(), open(own_pfm, "rb").read()
     assert len(a) == len(b)
     assert a == b, "the two programs' images differ in %d bytes" % sum(x != y for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_reference_program_resumes_a_render_through_the_plugin(adaptive, tmp_path):
+    """`tungsten` with "enable_resume_render" (src/tungsten/Shared.hpp:256-320; Integrator::saveRenderResumeData / resumeRender,
+    integrators/Integrator.cpp:108-162) and the plugin's saveState / loadState: half the samples, exit, a second run that resumes from the
+    state file and renders the rest -- the .pfm of the uninterrupted render bit for bit (the state holds the device's radiance sums, the
+    SampleRecords and the scheduler's sampler; with adaptive sampling the second run's sample distribution depends on all three)."""
+    import json
+    kw = dict(resolution=(96, 54), spp=32, spp_step=16)
+    if adaptive:
+        kw["renderer"] = {"adaptive_sampling": True, "stratified_sampler": True}
+    base = hip_scene(scenes.cornell(str(tmp_path), **kw))
+    whole = os.path.join(str(tmp_path), "whole.pfm")
+    r = run_reference(base, tmp_path, "-e", whole, "-o", os.path.join(str(tmp_path), "whole.png"))
+    assert r.returncode == 0 and os.path.exists(whole), r.stdout
+    d = json.load(open(base))
+    d["renderer"].update(enable_resume_render=True, resume_render_file="state.dat")
+    resumable = os.path.join(str(tmp_path), "resumable.json")
+    json.dump(d, open(resumable, "w"))
+    part = os.path.join(str(tmp_path), "part.pfm")
+    r1 = run_reference(resumable, tmp_path, "--spp", "16", "-e", part, "-o", os.path.join(str(tmp_path), "part.png"))
+    assert r1.returncode == 0 and os.path.exists(os.path.join(str(tmp_path), "state.dat")), r1.stdout
+    r2 = run_reference(resumable, tmp_path, "-e", part, "-o", os.path.join(str(tmp_path), "part.png"))
+    assert r2.returncode == 0 and "Resume successful" in r2.stdout, r2.stdout
+    assert "Completed 32/32 spp" in r2.stdout and "Completed 16/32 spp" not in r2.stdout, r2.stdout
+    a, b = open(whole, "rb").read(), open(part, "rb").read()
+    assert a == b, "the resumed render differs from the uninterrupted one in %d bytes" % sum(x != y for x, y in zip(a, b))

@@ -191,6 +191,8 @@ PROTOTYPES = {
     "tgh_scheduler_tile_seeds": (C.POINTER(u32), [VP]),
     "tgh_scheduler_records": (C.POINTER(TgHostSampleRecord), [VP]),
     "tgh_scheduler_generate_work": (C.c_int, [VP, u32, u32, C.c_int]),
+    "tgh_scheduler_sampler_state": (u64, [VP]),
+    "tgh_scheduler_set_sampler_state": (None, [VP, u64]),
     "tgh_scheduler_free": (None, [VP]),
     "tgh_sobol_matrices": (C.POINTER(u32), [C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
     "tgh_accel_build": (VP, [VP, VP, VP, C.c_uint32, C.c_char_p, C.c_size_t]),

@@ -257,6 +257,8 @@ int tgh_scheduler_generate_work(tgh_scheduler *s, uint32_t current_spp, uint32_t
     if (!s) return -1;
     return s->scheduler.generateWork(current_spp, next_spp, adaptive != 0) ? 1 : 0;
 }
+uint64_t tgh_scheduler_sampler_state(tgh_scheduler *s) { return s ? s->scheduler.sampler().state() : 0; }
+void tgh_scheduler_set_sampler_state(tgh_scheduler *s, uint64_t state) { if (s) s->scheduler.sampler().setState(state); }
 void tgh_scheduler_free(tgh_scheduler *s) { delete s; }
 
 const uint32_t *tgh_sobol_matrices(size_t *num_words, char *err, size_t errlen)
