@@ -149,21 +149,47 @@ def test_reference_program_resumes_a_render_through_the_plugin(adaptive, tmp_pat
     state file and renders the rest -- the .pfm of the uninterrupted render bit for bit (the state holds the device's radiance sums, the
     SampleRecords and the scheduler's sampler; with adaptive sampling the second run's sample distribution depends on all three)."""
     import json
+    import shutil
+    import tempfile
+    # (a directory with a SHORT path: the reference's own resume -- with its own path_tracer too -- answers "Resume unsuccessful" whenever the
+    # scene's directory path is longer than 15 characters, pytest's tmp_path always is; found while writing this test, not looked into)
+    tmp_path = tempfile.mkdtemp(prefix="r", dir="/tmp")
+    try:
+        _resume_case(adaptive, tmp_path)
+    finally:
+        shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_resume_plumbing_of_the_plugin_without_a_device(adaptive):
+    """The same two runs with TGHIP_REF_DRY_RUN (the plugin creates no context and a pass renders nothing): Integrator::saveRenderResumeData ->
+    saveState, the state file, resumeRender -> loadState and the pass loop that continues at the saved spp, on a box without a GPU."""
+    import shutil
+    import tempfile
+    tmp_path = tempfile.mkdtemp(prefix="r", dir="/tmp")
+    try:
+        _resume_case(adaptive, tmp_path, TGHIP_REF_DRY_RUN="1")
+    finally:
+        shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def _resume_case(adaptive, tmp_path, **env):
+    import json
     kw = dict(resolution=(96, 54), spp=32, spp_step=16)
     if adaptive:
         kw["renderer"] = {"adaptive_sampling": True, "stratified_sampler": True}
     base = hip_scene(scenes.cornell(str(tmp_path), **kw))
     whole = os.path.join(str(tmp_path), "whole.pfm")
-    r = run_reference(base, tmp_path, "-e", whole, "-o", os.path.join(str(tmp_path), "whole.png"))
+    r = run_reference(base, tmp_path, "-e", whole, "-o", os.path.join(str(tmp_path), "whole.png"), **env)
     assert r.returncode == 0 and os.path.exists(whole), r.stdout
     d = json.load(open(base))
     d["renderer"].update(enable_resume_render=True, resume_render_file="state.dat")
     resumable = os.path.join(str(tmp_path), "resumable.json")
     json.dump(d, open(resumable, "w"))
     part = os.path.join(str(tmp_path), "part.pfm")
-    r1 = run_reference(resumable, tmp_path, "--spp", "16", "-e", part, "-o", os.path.join(str(tmp_path), "part.png"))
+    r1 = run_reference(resumable, tmp_path, "--spp", "16", "-e", part, "-o", os.path.join(str(tmp_path), "part.png"), **env)
     assert r1.returncode == 0 and os.path.exists(os.path.join(str(tmp_path), "state.dat")), r1.stdout
-    r2 = run_reference(resumable, tmp_path, "-e", part, "-o", os.path.join(str(tmp_path), "part.png"))
+    r2 = run_reference(resumable, tmp_path, "-e", part, "-o", os.path.join(str(tmp_path), "part.png"), **env)
     assert r2.returncode == 0 and "Resume successful" in r2.stdout, r2.stdout
     assert "Completed 32/32 spp" in r2.stdout and "Completed 16/32 spp" not in r2.stdout, r2.stdout
     a, b = open(whole, "rb").read(), open(part, "rb").read()
