@@ -75,6 +75,7 @@ struct DeviceScene {
 #define FEAT_MEDIA      (1u << 23)   /* participating media (media/HomogeneousMedium.cpp): only in the BSDF_MASK_ALL variant */
 #define FEAT_AUX        (1u << 22)   /* TGHIP_PASS_AUX passes (auxiliary output buffers): only in the BSDF_MASK_ALL variant */
 #define FEAT_CYLINDER   (1u << 21)   /* cylinder primitives / emitters (primitives/Cylinder.cpp): only in the BSDF_MASK_ALL variant */
+#define FEAT_PHONG      (1u << 19)   /* microfacet BSDFs with the Phong distribution (pow(double, double)): only in the MASK_FULL / BSDF_MASK_ALL variants */
 #define FEAT_BUMP       (1u << 20)   /* bump-mapped shading frames (Primitive::setupTangentFrame, TgHipBsdf::bump1): only in the BSDF_MASK_ALL variant */
 #define MASK_FULL       (BSDF_MASK_ALL & ~(FEAT_QMC | FEAT_MEDIA | FEAT_AUX | FEAT_CYLINDER | FEAT_BUMP))
 // next1D of the path's sampler inside code templated on M
@@ -269,6 +270,11 @@ PT_DEV f3 conductorReflectance(const float *eta, const float *k, float cosThetaI
                conductorReflectance1(eta[2], k[2], cosThetaI));
 }
 
+// The distribution of a microfacet BSDF as a shading variant sees it.  Phong's D and sample() go through pow(double, double) (Microfacet.hpp:
+// 49-51, 100-102: 3 200 double-precision instructions and 39 VGPRs in the conductor-family variant); only the variants with FEAT_PHONG
+// carry them -- the shim puts materials with a Phong distribution into class 3 (tungsten_hip.hip: bsdfTypeMask), so the family variants
+// never see one and the compiler drops the branch.
+template<uint32_t M> PT_DEV int mfDist(int d) { return (M & FEAT_PHONG) ? d : (d == TGHIP_DIST_BECKMANN ? TGHIP_DIST_BECKMANN : TGHIP_DIST_GGX); }
 PT_DEV float mfRoughnessToAlpha(int dist, float roughness)
 {
     roughness = fmaxf(roughness, 1e-3f);
@@ -494,12 +500,12 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return splat3(0.0f);
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return splat3(0.0f);
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
-            float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness<M>(s, b, e));
+            float alpha = mfRoughnessToAlpha(mfDist<M>(b.distribution), bsdfRoughness<M>(s, b, e));
             f3 hr = normalized(e.wi + e.wo);
             float cosThetaM = dot(e.wi, hr);
             f3 F = conductorReflectance(b.eta, b.k, cosThetaM);
-            float G = mfG(b.distribution, alpha, e.wi, e.wo, hr);
-            float Dm = mfD(b.distribution, alpha, hr);
+            float G = mfG(mfDist<M>(b.distribution), alpha, e.wi, e.wo, hr);
+            float Dm = mfD(mfDist<M>(b.distribution), alpha, hr);
             float fr = (G*Dm*0.25f)/e.wi.z;
             return bsdfAlbedo<M>(s, b, e)*(F*fr);
         }
@@ -544,7 +550,7 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return splat3(0.0f);
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
-            return rdEvalBase(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, b.distribution)*bsdfAlbedo<M>(s, b, e);
+            return rdEvalBase(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution))*bsdfAlbedo<M>(s, b, e);
         }
         case TGHIP_BSDF_PLASTIC: case TGHIP_BSDF_ROUGH_PLASTIC: {   /* PlasticBsdf.cpp:125-151, RoughPlasticBsdf.cpp:114-141 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_PLASTIC) | BSDF_BIT(TGHIP_BSDF_ROUGH_PLASTIC)))) return splat3(0.0f);
@@ -564,7 +570,7 @@ struct BsdfOps {
             }
             f3 glossyR = splat3(0.0f), diffuseR = splat3(0.0f);
             if (rough && evalR)
-                glossyR = rdEvalBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, b.distribution);
+                glossyR = rdEvalBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution));
             if (evalT) {
                 f3 diffuseAlbedo = bsdfAlbedo<M>(s, b, e);
                 diffuseR = plasticSubstrate(b, diffuseAlbedo)*((1.0f - Fi)*(1.0f - Fo)*eta*eta*e.wo.z*PT_INV_PI);
@@ -634,16 +640,16 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return false;
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return false;
             if (e.wi.z <= 0.0f) return false;
-            float alpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness<M>(s, b, e));
+            float alpha = mfRoughnessToAlpha(mfDist<M>(b.distribution), bsdfRoughness<M>(s, b, e));
             float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
-            f3 m = mfSample(b.distribution, alpha, xi0, xi1);
+            f3 m = mfSample(mfDist<M>(b.distribution), alpha, xi0, xi1);
             float wiDotM = dot(e.wi, m);
             e.wo = m*(2.0f*wiDotM) - e.wi;
             if (wiDotM <= 0.0f || e.wo.z <= 0.0f)
                 return false;
-            float G = mfG(b.distribution, alpha, e.wi, e.wo, m);
-            float Dm = mfD(b.distribution, alpha, m);
-            float mPdf = mfPdf(b.distribution, alpha, m);
+            float G = mfG(mfDist<M>(b.distribution), alpha, e.wi, e.wo, m);
+            float Dm = mfD(mfDist<M>(b.distribution), alpha, m);
+            float mPdf = mfPdf(mfDist<M>(b.distribution), alpha, m);
             float weight = wiDotM*G*Dm/(e.wi.z*mPdf);
             f3 F = conductorReflectance(b.eta, b.k, wiDotM);
             e.pdf = mPdf*0.25f/wiDotM;
@@ -717,7 +723,7 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return false;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
-            bool result = rdSampleBase<M>(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, b.distribution);
+            bool result = rdSampleBase<M>(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution));
             e.weight = e.weight*bsdfAlbedo<M>(s, b, e);
             return result;
         }
@@ -762,7 +768,7 @@ struct BsdfOps {
             float substrateWeight = substrateW*b.avg_transmittance*(1.0f - Fi);
             float specularProbability = Fi/(Fi + substrateWeight);
             if (sampleR && (rngNextBoolean(*e.rng, specularProbability) || !sampleT)) {
-                if (!rdSampleBase<M>(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, b.distribution))
+                if (!rdSampleBase<M>(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution)))
                     return false;
                 if (sampleT) {
                     float Fo = dielectricReflectance(eta, e.wo.z);
@@ -786,8 +792,8 @@ struct BsdfOps {
                 f3 brdfSubstrate = e.weight*e.pdf;
                 float pdfSubstrate = e.pdf*(1.0f - specularProbability);
                 float r = bsdfRoughness<M>(s, b, e);
-                f3 brdfSpecular = rdEvalBase(e, true, false, r, b.ior, b.distribution);
-                float pdfSpecular = rdPdfBase(e, true, false, r, b.ior, b.distribution)*specularProbability;
+                f3 brdfSpecular = rdEvalBase(e, true, false, r, b.ior, mfDist<M>(b.distribution));
+                float pdfSpecular = rdPdfBase(e, true, false, r, b.ior, mfDist<M>(b.distribution))*specularProbability;
                 e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
                 e.pdf = pdfSpecular + pdfSubstrate;
             }
@@ -840,9 +846,9 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_CONDUCTOR)))) return 0.0f;
             if (!(e.requested & TGHIP_LOBE_GLOSSY_R)) return 0.0f;
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
-            float sampleAlpha = mfRoughnessToAlpha(b.distribution, bsdfRoughness<M>(s, b, e));
+            float sampleAlpha = mfRoughnessToAlpha(mfDist<M>(b.distribution), bsdfRoughness<M>(s, b, e));
             f3 hr = normalized(e.wi + e.wo);
-            return mfPdf(b.distribution, sampleAlpha, hr)*0.25f/dot(e.wi, hr);
+            return mfPdf(mfDist<M>(b.distribution), sampleAlpha, hr)*0.25f/dot(e.wi, hr);
         }
         case TGHIP_BSDF_SMOOTH_COAT: {                         /* SmoothCoatBsdf.cpp:179-214 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_SMOOTH_COAT)))) return 0.0f;
@@ -887,7 +893,7 @@ struct BsdfOps {
             if (!(M & (BSDF_BIT(TGHIP_BSDF_ROUGH_DIELECTRIC)))) return 0.0f;
             bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
             bool sampleT = (e.requested & TGHIP_LOBE_GLOSSY_T) && b.enable_refraction;
-            return rdPdfBase(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, b.distribution);
+            return rdPdfBase(e, sampleR, sampleT, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution));
         }
         case TGHIP_BSDF_PLASTIC: {                             /* PlasticBsdf.cpp:153-177 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_PLASTIC)))) return 0.0f;
@@ -913,7 +919,7 @@ struct BsdfOps {
             bool sampleT = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
             if (!sampleR && !sampleT) return 0.0f;
             if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
-            float glossyPdf = sampleR ? rdPdfBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, b.distribution) : 0.0f;
+            float glossyPdf = sampleR ? rdPdfBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution)) : 0.0f;
             float diffusePdf = sampleT ? cosineHemispherePdf(e.wo) : 0.0f;
             if (sampleT && sampleR) {
                 float Fi = dielectricReflectance(1.0f/b.ior, e.wi.z);

@@ -55,7 +55,9 @@
 #define SIMPLE_WAVES 3   /* measured: 4 waves/SIMD (128 VGPRs, spills) is 10 % slower on materialtest's k_shade */
 #endif
 #ifndef COAT_WAVES
-#define COAT_WAVES   2   /* measured: 3 waves/SIMD is neutral on materialtest (480 vs 476 us), +3 % on mesh1m's k_shade */
+#define COAT_WAVES   3   /* round 4, without Phong's pow(double) in the family variants (197 VGPRs at 2 waves/SIMD; 168 + 72 B of scratch at 3):
+                            materialtest 968.3 / 969.4 -> 977.8 / 974.5, mesh1m 616.9 / 614.2 -> 622.7 / 621.7 Msamples/s (two libraries alternated
+                            twice in one session, profiles/r4_ab_coat_waves.txt); round 3 had measured 3 waves as neutral at 223 VGPRs */
 #endif
 #ifndef LEAN_WAVES
 #define LEAN_WAVES   2   /* measured: 2 waves/SIMD without scratch beats 3 with 108 B of scratch (kernel is VALU-bound) */

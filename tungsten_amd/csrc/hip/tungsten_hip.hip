@@ -291,6 +291,8 @@ static uint32_t bsdfTypeMask(const TgHipSceneDesc *s, int bi, int depth)
     if (bi < 0 || uint32_t(bi) >= s->num_bsdfs || depth > 16) return 0;
     const TgHipBsdf &b = s->bsdfs[bi];
     uint32_t m = 1u << uint32_t(b.type);
+    if ((b.type == TGHIP_BSDF_ROUGH_CONDUCTOR || b.type == TGHIP_BSDF_ROUGH_DIELECTRIC || b.type == TGHIP_BSDF_ROUGH_PLASTIC) && b.distribution == TGHIP_DIST_PHONG)
+        m |= FEAT_PHONG;                     // outside every family mask: such a material is shaded by the full variant (pt_scene.h: mfDist)
     if (b.type == TGHIP_BSDF_SMOOTH_COAT || b.type == TGHIP_BSDF_TRANSPARENCY)
         m |= bsdfTypeMask(s, b.sub0, depth + 1);
     if (b.type == TGHIP_BSDF_MIXED)
