@@ -122,6 +122,12 @@ enum {
     // (OutputBuffer::addSample drops NaN values without counting them, cameras/OutputBuffer.hpp:106-107)
     A_AUX0,        // normal.xyz | depth -- until the values are recorded (FLAG_AUX_RECORDED), .w is the running hitDistance
     A_AUX1,        // albedo.rgb | visibility (+inf = waiting for the light sample's shadow ray of the recording vertex)
+    // PathState::nee_factors scenes only (forward lobes, media, mesh emitters: the shadow rays' transmittance is not 0 or 1, or the
+    // emission is only known after the walk): the factors of the two NEE terms apart, so that the shadow kernel can multiply them in the
+    // reference's order -- (f*(T*e))/pdf*mis and ((T*e)*weight)*mis (TraceBase.cpp:144-174, 246-321) -- instead of (f*e/pdf*mis)*T
+    A_NEE0,        // light sample: e.rgb (the light's emission towards the vertex, before the transmittance) | its pdf
+    A_NEE1,        // bsdf sample: e.rgb | -
+    A_NEE2,        // the two power-heuristic weights: light sample, bsdf sample | - | -
     A_COUNT
 };
 
@@ -135,7 +141,7 @@ struct PathState {
     uint32_t stride;                       // bytes per array
     // "pool_layout" = 1: slot records instead of arrays -- the eight arrays of a path's state (A_RAY_O .. A_SAMP, 128 bytes)
     // in ONE cache line per slot, the seven of its shadow-ray block (A_SH_O .. A_SH_P, 112 bytes) in a second one at
-    // rec_shadow, the two auxiliary-output arrays at rec_aux: a sparse queue then touches one line per slot and block
+    // rec_shadow, the two auxiliary-output arrays and the three NEE-factor arrays at rec_aux: a sparse queue then touches one line per slot and block
     // instead of one partially used line per slot and ARRAY
     uint32_t records, rec_shadow, rec_aux;
     uint32_t * __restrict__ bm;            // queue bitmaps: queue q of workgroup b = words [q*bmStride + b*slots_per_block/32, ...)
@@ -159,6 +165,7 @@ struct PathState {
     // DECOUPLED traversal kernels: every ray visits them, and what bounds the walk is the rate at which the CU's vector L1 takes lane
     // addresses (~1.1 16-byte lane-loads per clock, tools/ubench_chase.hip); ds_read_b128 does not go through it.  wide_depth: stack levels.
     uint32_t lds_nodes, wide_depth;
+    uint32_t nee_factors;                  // the shading kernels leave the factors of the NEE terms apart (A_NEE0 .. A_NEE2) for k_trace_shadow<., FORWARD>
     uint32_t walk_base;                    // first of the walk arrays of the pool: +0 grpBase grpMasks triBase triMask, +1 triValid node sp -,
                                            // +2 (shadow slots) partial result.rgb | ray index, +3 tri2Base tri2Mask tri2Valid -,
                                            // +4.. the group stack, two 8-byte entries per array
@@ -167,7 +174,7 @@ struct PathState {
 PT_DEV uint32_t slotOffset(const PathState &st, uint32_t a, uint32_t slot)     // `a` is a literal at every call site: the selects fold
 {
     if (st.records)
-        return a < A_SH_O ? slot*128u + a*16u : a < A_AUX0 ? st.rec_shadow + slot*128u + (a - A_SH_O)*16u : st.rec_aux + slot*32u + (a - A_AUX0)*16u;
+        return a < A_SH_O ? slot*128u + a*16u : a < A_AUX0 ? st.rec_shadow + slot*128u + (a - A_SH_O)*16u : st.rec_aux + slot*80u + (a - A_AUX0)*16u;
     return (a & ((1u << PT_POOL_GROUP_SHIFT) - 1u))*st.stride + slot*16u;
 }
 PT_DEV char *slotBase(const PathState &st, uint32_t a) { return st.records ? st.poolg[0] : st.poolg[a >> PT_POOL_GROUP_SHIFT]; }

@@ -1241,6 +1241,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                     if (light >= 0) {
                         const uint32_t tag = SHADOW_TAG_MEDIA(light, med, bounce + 1);   // the medium is not re-selected at a volume vertex
                         bool q0 = false, q1 = false;
+                        float mis0 = 1.0f, mis1 = 1.0f;       // (media scenes always run with st.nee_factors: the factors stay apart, A_NEE0 .. A_NEE2)
                         const bool meshLight = s.objects[light].type == TGHIP_OBJ_MESH;
                         const bool diracLight = s.objects[light].type == TGHIP_OBJ_POINT;
                         {
@@ -1248,9 +1249,10 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                             if (lightSampleDirect<M>(s, light, volP, rng, d, dist, pdf)) {
                                 float f = phaseEval(mm, ray.d, d);
                                 if (f != 0.0f && meshLight) {
-                                    float k = powerHeuristic(pdf, f)/pdf;                  // phase pdf == phase value
+                                    mis0 = powerHeuristic(pdf, f);                         // phase pdf == phase value
                                     slotF4(st, A_SH_D0, slot) = mk4(d, dist);
-                                    slotF4(st, A_SH_C0, slot) = mk4(splat3(f*k), __uint_as_float(tag));
+                                    slotF4(st, A_SH_C0, slot) = mk4(splat3(f), __uint_as_float(tag));
+                                    slotF4(st, A_NEE0, slot) = make_float4(0.0f, 0.0f, 0.0f, pdf);
                                     q0 = true;
                                 } else if (f != 0.0f) {
                                     RayD sr; sr.o = volP; sr.d = d; sr.tmin = 0.0f; sr.tmax = PT_INF;   // parentRay.scatter(p, d, 0.0f)
@@ -1261,11 +1263,11 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                     if (reached) {
                                         f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
                                         if (!isZero(e)) {
-                                            f3 lightF = e*f/pdf;
                                             if (!diracLight)
-                                                lightF = lightF*powerHeuristic(pdf, f);
+                                                mis0 = powerHeuristic(pdf, f);
                                             slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
-                                            slotF4(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
+                                            slotF4(st, A_SH_C0, slot) = mk4(splat3(f), __uint_as_float(tag));
+                                            slotF4(st, A_NEE0, slot) = mk4(e, pdf);
                                             q0 = true;
                                         }
                                     }
@@ -1285,9 +1287,10 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                 if (lightIntersect<M>(s, light, sr, lh)) {
                                     f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
                                     if (!isZero(e)) {
-                                        f3 phaseF = e*powerHeuristic(ppdf, lightDirectPdf<M>(s, light, w, volP, lh));
+                                        mis1 = powerHeuristic(ppdf, lightDirectPdf<M>(s, light, w, volP, lh));
                                         slotF4(st, A_SH_D1, slot) = mk4(w, lh.t);
-                                        slotF4(st, A_SH_C1, slot) = mk4(phaseF, __uint_as_float(tag));
+                                        slotF4(st, A_SH_C1, slot) = mk4(splat3(1.0f), __uint_as_float(tag));   // phaseSample.weight
+                                        slotF4(st, A_NEE1, slot) = mk4(e, 0.0f);
                                         q1 = true;
                                     }
                                 }
@@ -1299,6 +1302,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                             if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
                             slotF4(st, A_SH_O, slot) = mk4(volP, 0.0f);
                             slotF4(st, A_SH_W, slot) = mk4(throughput, lightWeight);
+                            slotF4(st, A_NEE2, slot) = make_float4(mis0, mis1, 0.0f, 0.0f);
                         }
                     }
                 }
@@ -1387,6 +1391,9 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                             };
                             bool q0 = false, q1 = false;
                             f3 inlineResult = splat3(0.0f);
+                            // st.nee_factors: the two terms' factors stay apart for the shadow kernel (A_NEE0 .. A_NEE2, pt_kernels.h)
+                            const bool factors = !(FUSE & FUSE_SHADOW) && st.nee_factors != 0u;
+                            float mis0 = 1.0f, mis1 = 1.0f;
                             const bool meshLight = (M & FEAT_MESHLIGHT) && s.objects[light].type == TGHIP_OBJ_MESH;
                             const bool diracLight = (M & FEAT_SOLIDS) && s.objects[light].type == TGHIP_OBJ_POINT;
                             // lightSample (TraceBase.cpp:246-285)
@@ -1404,9 +1411,11 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                             // mesh emitter: whether the ray reaches the light, and with which emission, is only
                                             // known after the scene traversal (TriangleMesh::intersect is a BVH query), so the
                                             // shadow kernel completes f*e/pdf * powerHeuristic from these factors
-                                            float k = powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev))/pdf;
+                                            // (a scene with a mesh emitter always runs with nee_factors)
+                                            mis0 = powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
                                             slotF4(st, A_SH_D0, slot) = mk4(d, dist);
-                                            slotF4(st, A_SH_C0, slot) = mk4(f*k, __uint_as_float(tag));
+                                            slotF4(st, A_SH_C0, slot) = mk4(f, __uint_as_float(tag));
+                                            slotF4(st, A_NEE0, slot) = make_float4(0.0f, 0.0f, 0.0f, pdf);
                                             q0 = true;
                                         } else if (!isZero(f)) {
                                             RayD sr; sr.o = info.p; sr.d = d; sr.tmin = 5e-4f; sr.tmax = PT_INF;
@@ -1424,9 +1433,15 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                                 if constexpr ((M & FEAT_AUX) != 0u) wantVis = auxOn && !recorded;
                                                 if (!isZero(e) || wantVis) {
                                                     f3 lightF = f*e/pdf;                          // (zero for a black e)
-                                                    if (!diracLight)                              // no MIS against a Dirac light (:281-282)
-                                                        lightF = lightF*powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
-                                                    if (FUSE & FUSE_SHADOW) {
+                                                    if (!diracLight) {                            // no MIS against a Dirac light (:281-282)
+                                                        mis0 = powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
+                                                        lightF = lightF*mis0;
+                                                    }
+                                                    if (factors) {
+                                                        slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
+                                                        slotF4(st, A_SH_C0, slot) = mk4(f, __uint_as_float(tag));
+                                                        slotF4(st, A_NEE0, slot) = mk4(e, pdf);
+                                                    } else if (FUSE & FUSE_SHADOW) {
                                                         sr.tmax = lh.t;
                                                         fusedShadow++;
                                                         if (!traverseOccluded<true, true, shadeKinds(M)>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
@@ -1466,8 +1481,13 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                             const float lightPdf = lightDirectPdf<M>(s, light, wog, info.p, lh);
                                             if (!isZero(e)) {
                                                 f3 bsdfF = e*ev.weight;
-                                                bsdfF = bsdfF*powerHeuristic(ev.pdf, lightPdf);
-                                                if (FUSE & FUSE_SHADOW) {
+                                                mis1 = powerHeuristic(ev.pdf, lightPdf);
+                                                bsdfF = bsdfF*mis1;
+                                                if (factors) {
+                                                    slotF4(st, A_SH_D1, slot) = mk4(wog, lh.t);
+                                                    slotF4(st, A_SH_C1, slot) = mk4(ev.weight, __uint_as_float(tag));
+                                                    slotF4(st, A_NEE1, slot) = mk4(e, 0.0f);
+                                                } else if (FUSE & FUSE_SHADOW) {
                                                     sr.tmax = lh.t;
                                                     fusedShadow++;
                                                     if (!traverseOccluded<true, true, shadeKinds(M)>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
@@ -1493,6 +1513,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                 if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
                                 slotF4(st, A_SH_O, slot) = mk4(info.p, 5e-4f);
                                 slotF4(st, A_SH_W, slot) = mk4(throughput, lightWeight);
+                                if (factors) slotF4(st, A_NEE2, slot) = make_float4(mis0, mis1, 0.0f, 0.0f);
                             }
                         }
                     }
@@ -1703,7 +1724,8 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                         transmittance = splat3(0.0f);
                 } else {
                 const bool meshLight = s.objects[endCap].type == TGHIP_OBJ_MESH;
-                f3 meshFactor = splat3(0.0f);                  // mesh emitters: e (light ray) or e*powerHeuristic (bsdf ray)
+                f3 meshE = splat3(0.0f);                       // mesh emitters: the emission the walk found at the light ...
+                float meshMis = 1.0f;                          // ... and, for the bsdf ray, its power-heuristic weight
                 float travelled = 0.0f;
                 if (meshLight) { ray.tmax = PT_INF; remaining = PT_INF; }   // sd.w carries the expected distance / the bsdf pdf
                 for (;;) {
@@ -1729,11 +1751,11 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                             float total = travelled + hit.x;
                             if (r == 0) {
                                 if (total*(1.0f + 1e-3f) < sd.w) { e = splat3(0.0f); visValid = false; }   // a nearer part of the mesh than the sampled point
-                                meshFactor = e;
                             } else {
                                 float directPdf = lengthSq(xyz(so) - li.p)/(-dot(ray.d, li.Ng)*lo.area);
-                                meshFactor = e*powerHeuristic(sd.w, directPdf);
+                                meshMis = powerHeuristic(sd.w, directPdf);
                             }
+                            meshE = e;
                         }
                         break;
                     }
@@ -1765,7 +1787,16 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     ray.tmax = remaining;
                 }
                 shadowT = transmittance;
-                if (meshLight) transmittance = transmittance*meshFactor;
+                // The term in the reference's order of operations (st.nee_factors: the shading kernel left the factors apart): attenuatedEmission
+                // returns shadow*light.evalDirect (TraceBase.cpp:173), lightSample (f*e)/pdf, then *= the power heuristic unless the light is a
+                // Dirac one (:277-282; its weight is stored as 1), bsdfSample (e*weight), then *= the power heuristic (:316-318); the volume
+                // pair likewise (:346-351, 374-378).
+                const bool dark = isZero(transmittance);       // `if (shadow == 0.0f) return Vec3f(0.0f)` (:170-171)
+                const float4 n0 = slotF4(st, A_NEE0, slot), n1 = slotF4(st, A_NEE1, slot), mis = slotF4(st, A_NEE2, slot);
+                const f3 e = transmittance*(meshLight ? meshE : r == 0 ? xyz(n0) : xyz(n1));
+                if (r == 0) transmittance = (xyz(c)*e)/n0.w*mis.x;
+                else        transmittance = (e*xyz(c))*(meshLight ? meshMis : mis.y);
+                if (dark || isZero(e)) transmittance = splat3(0.0f);   // `if (e == 0.0f) return Vec3f(0.0f)` (:273-274, 311-312)
                 }
                 if (!FORWARD) shadowT = transmittance;
                 if (r == 0 && (pp.flags & TGHIP_PASS_AUX)) {   // the visibility output of the vertex that recorded (PathTracer.cpp:93-94)
@@ -1773,8 +1804,8 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     if (isinf(a1.w))
                         a1.w = visValid ? avg3(shadowT) : __uint_as_float(0x7FC00000u);
                 }
-                if (!isZero(transmittance))
-                    result = result + xyz(c)*transmittance;
+                if (FORWARD)                     result = result + transmittance;        // (the whole term, above)
+                else if (!isZero(transmittance)) result = result + xyz(c)*transmittance;
             }
             float4 w = slotF4(st, A_SH_W, slot);
             float4 p = slotF4(st, A_SH_P, slot);

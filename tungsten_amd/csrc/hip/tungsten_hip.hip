@@ -602,7 +602,7 @@ static int ensurePool(tghip_ctx *ctx, uint32_t wantSlots)
     if (strideBytes*groupArrays >= (1ull << 32)) { ctx->error = "path pool too large for 32-bit slot offsets within an array group"; return TGHIP_E_INVALID; }
     if (A_COUNT + walkArrays > groupArrays*PT_POOL_GROUPS) walkArrays = 0;
     ctx->poolWalkArrays = walkArrays;
-    const uint64_t recordBytes = uint64_t(slots)*288u + 256u;   // the record layout: 128 + 128 + 32 bytes per slot
+    const uint64_t recordBytes = uint64_t(slots)*336u + 256u;   // the record layout: 128 + 128 + 80 bytes per slot
     const bool records = ctx->poolRecords && recordBytes < (1ull << 32);
     char *poolBase = nullptr;
     if ((rc = allocArray(ctx, ctx->poolMem, size_t(std::max<uint64_t>(strideBytes*(A_COUNT + walkArrays), records ? recordBytes : 0)), &poolBase)) != TGHIP_OK) return rc;
@@ -1342,6 +1342,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     st.partial = ctx->partial;
     st.abort_flag = ctx->abortFlagDev;
     st.leaf_batch = uint32_t(ctx->leafBatch);
+    st.nee_factors = (ctx->haveForward || ctx->haveMeshLight) ? 1u : 0u;   // launchShadow: the closest-hit shadow walk, k_trace_shadow<., FORWARD>
     st.lds_nodes = ldsNodeCount(ctx);
     st.wide_depth = uint32_t(std::max(ctx->wideDepth, 1));
     st.suspend_lanes = ctx->poolWalkArrays ? uint32_t(ctx->suspendLanes) : 0u;
