@@ -8,8 +8,10 @@ End of round 3: 34 of the 37 cases have no differing sample in 82 944 (36 864 fo
 cornell_fog_interpolated 4 -- none with LIFT=1e-3: a box's bottom face against the floor quad --; cornell_sobol 1: the first Sobol' point of a
 pixel on the image's 45-degree diagonal hits the seam between the ceiling and the left wall exactly (uv = (1, 0.93)), and the two quads tie.
 Of the twins: cornell_bump_no_mesh 4 (a bump-perturbed frame sends the sampled direction INTO the tall box, whose bottom face coincides with
-the floor: the same tie), cornell_fog_smoke_sobol_lifted 7 samples off by ONE ulp in one channel -- paths with several scatter events in the
-smoke box inside the fog; with or without next-event estimation, with either sampler; cause not found --, the other seven none."""
+the floor: the same tie), cornell_fog_smoke_sobol_lifted 7 samples off by one or two ulps in one channel -- round 4 found the cause:
+in the last of the three segments of a shadow ray that crosses the smoke box, Embree's slab test culls the flat bounding box of the very light
+the ray is aimed at (an ulp behind tfar), so the reference integrates the fog's transmittance over the remaining farT where the oracle, which
+finds the quad, integrates it over the hit distance one ulp shorter --, the other seven none."""
 import json
 import os
 import subprocess
