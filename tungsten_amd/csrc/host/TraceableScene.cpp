@@ -86,6 +86,238 @@ SceneAccel buildSceneAccel(std::vector<TgHipPrimRec> &_recs, std::vector<TgHipTr
     return out;
 }
 
+// Scenes with `instances` primitives (include/tungsten_hip.h, the instance-set record).  `recs` / `attrs` / `recBounds` come in as the K
+// non-instance records and go out as the scene's whole record array: [the non-instance and the N instance records in the wide tree's
+// order | one set record per `instances` primitive | the masters' records, each master's in its own trees' order].
+//  * The wide BVH -- any-hit shadow queries -- is built over the non-instance records and the instance records, every instance boxed
+//    tightly (a ray that is to hit an instance passes that box somewhere along its whole length; whether the reference lets it INTO the
+//    instance is the leaf test the walk makes at the record, pt_wavefront.h); it decides the record order.
+//  * The scene's BVH2 -- closest hits -- is built over the non-instance records and one record per `instances` primitive, behind which
+//    the reference's own tree over the instances follows (Instance::prepareForRender, Instance.cpp:392-428: the reference's intersect
+//    keeps the LAST hit in that tree's visiting order -- each instance gets a ray with farT = infinity --, so the tree is restated node
+//    for node, RefInstanceBvh.cpp, and walked in the reference's order).
+//  * Behind the top level: every master's records in master space with a BVH2 subtree and a wide subtree of its own.
+// (TraceableScene::flatten and, for the reference-side flattener of oracle/ref_binding, tgh_accel_build_instanced.)
+InstancedAccel buildInstancedAccel(std::vector<TgHipPrimRec> &_recs, std::vector<TgHipTriAttr> &_triAttrs, const std::vector<Box3f> &recBounds,
+                                   const std::vector<InstanceSetInput> &sets, const std::vector<MasterInput> &masters)
+{
+    InstancedAccel out;
+    std::vector<TgHipBvhNode> &_nodes = out.nodes;
+    std::vector<TgHipWideNode> &_wideNodes = out.wideNodes;
+    std::vector<uint32_t> &_instPrims = out.instPrims;
+    std::vector<float> &_instLeafBoxes = out.instLeafBoxes, &_instTightBoxes = out.instTightBoxes;
+    int &_bvhDepth = out.bvhDepth, &_wideDepth = out.wideDepth;
+
+    struct Set { TgHipPrimRec rec; Box3f bounds; size_t firstInst; RefInstanceBvh tree; };
+    std::vector<Set> instSets;
+    std::vector<TgHipPrimRec> instRecs;
+    std::vector<Box3f> instTightBounds;
+    for (const InstanceSetInput &in : sets) {
+        if (in.recs.empty())
+            continue;
+        if (in.refBounds.size() != in.recs.size() || in.tightBounds.size() != in.recs.size())
+            throw std::runtime_error("instance set: one reference box and one tight box per instance record");
+        Set set;
+        set.firstInst = instRecs.size();
+        for (const TgHipPrimRec &r : in.recs) {
+            uint32_t masterSlot;
+            std::memcpy(&masterSlot, &r.c[0], 4);
+            if (masterSlot >= masters.size() || masters[masterSlot].recs.empty())
+                throw std::runtime_error("instance of a master that does not exist or is empty");
+        }
+        instRecs.insert(instRecs.end(), in.recs.begin(), in.recs.end());
+        instTightBounds.insert(instTightBounds.end(), in.tightBounds.begin(), in.tightBounds.end());
+        set.tree = buildRefInstanceBvh(in.refBounds);
+        set.bounds = set.tree.bounds;
+        std::memset(&set.rec, 0, sizeof(set.rec));
+        copy3(set.rec.a, set.bounds.lo);
+        copy3(set.rec.b, set.bounds.hi);
+        set.rec.meta = (uint32_t(TGHIP_REC_INSTANCE_SET) << 29) | in.objMeta;
+        // every leaf's box as its parent holds it (a tree that is one leaf: the root's bounds), at the leaf's first slot of inst_prims,
+        // and that slot in the leaf's instance records
+        const size_t slotBase = _instLeafBoxes.size()/8;         // (= this set's first slot of inst_prims: one box slot per leaf slot)
+        _instLeafBoxes.resize(_instLeafBoxes.size() + 8*set.tree.primIndices.size(), 0.0f);
+        auto leafBox = [&](uint32_t leafNode, const Box3f &box) {
+            const TgHipInstNode &leaf = set.tree.nodes[leafNode];
+            const uint32_t slot = uint32_t(slotBase + leaf.left);
+            for (int k = 0; k < 3; ++k) { _instLeafBoxes[8*size_t(slot) + k] = box.lo[k]; _instLeafBoxes[8*size_t(slot) + 4 + k] = box.hi[k]; }
+            for (uint32_t k = 0; k < leaf.count; ++k) {
+                const size_t rec = set.firstInst + set.tree.primIndices[leaf.left + k];
+                std::memcpy(&instRecs[rec].c[1], &slot, 4);
+            }
+        };
+        if (set.tree.nodes[0].count != 0) {
+            leafBox(0, set.bounds);
+        } else {
+            for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni) {
+                const TgHipInstNode &n = set.tree.nodes[ni];
+                if (n.count != 0) continue;
+                for (uint32_t c = 0; c < 2; ++c) {
+                    if (set.tree.nodes[n.left + c].count == 0) continue;
+                    Box3f box;
+                    for (int k = 0; k < 3; ++k) { box.lo[k] = n.box[k*4 + c]; box.hi[k] = n.box[k*4 + 2 + c]; }
+                    leafBox(n.left + c, box);
+                }
+            }
+        }
+        instSets.push_back(std::move(set));
+    }
+    const uint32_t numInstances = uint32_t(instRecs.size());
+    if (numInstances == 0)
+        throw std::runtime_error("buildInstancedAccel: no instances");
+    int refDepth = 0;
+    {
+        const size_t K = _recs.size(), N = instRecs.size(), S = instSets.size();
+        std::vector<Box3f> wideBounds(recBounds);
+        for (size_t i = 0; i < N; ++i) {
+            _recs.push_back(instRecs[i]);
+            _triAttrs.emplace_back();
+            std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
+            _triAttrs.back().bsdf = -1;
+            wideBounds.push_back(instTightBounds[i]);
+        }
+        SceneAccel accel = buildSceneAccel(_recs, _triAttrs, wideBounds, true);
+        _wideNodes.swap(accel.wideNodes);
+        _wideDepth = accel.wideDepth;
+        out.sahCost = accel.sahCost;
+        std::vector<uint32_t> slotOf(K + N);                 // caller's record -> its slot
+        for (size_t i = 0; i < accel.order.size(); ++i)
+            slotOf[accel.order[i]] = uint32_t(i);
+        _instTightBoxes.assign(8*(K + N + S), 0.0f);
+        for (size_t i = 0; i < N; ++i)
+            for (int k = 0; k < 3; ++k) {
+                _instTightBoxes[8*size_t(slotOf[K + i]) + k] = instTightBounds[i].lo[k];
+                _instTightBoxes[8*size_t(slotOf[K + i]) + 4 + k] = instTightBounds[i].hi[k];
+            }
+        for (size_t si = 0; si < S; ++si) {
+            _recs.push_back(instSets[si].rec);
+            _triAttrs.emplace_back();
+            std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
+            _triAttrs.back().bsdf = -1;
+        }
+        std::vector<Box3f> sceneBounds(recBounds);
+        for (size_t si = 0; si < S; ++si)
+            sceneBounds.push_back(instSets[si].bounds);
+        BvhBuildResult top = buildBvh(sceneBounds, 1);
+        auto finalSlot = [&](uint32_t input) { return input < K ? slotOf[input] : uint32_t(K + N + (input - K)); };
+        for (TgHipBvhNode &n : top.nodes)
+            for (int32_t *ref : {&n.child0, &n.child1})
+                if (*ref < 0)
+                    *ref = TGHIP_MAKE_LEAF(finalSlot(top.order[TGHIP_LEAF_FIRST(*ref)]), 1);
+        _nodes.swap(top.nodes);
+        _bvhDepth = top.maxDepth;
+        // the reference's trees as BVH2 nodes with its exact child boxes; their leaf references index inst_prims
+        for (size_t si = 0; si < S; ++si) {
+            const Set &set = instSets[si];
+            const uint32_t primBase = uint32_t(_instPrims.size());
+            for (uint32_t id : set.tree.primIndices)
+                _instPrims.push_back(slotOf[K + set.firstInst + id]);
+            // inner nodes only become BVH2 nodes; a leaf is a leaf reference in its parent
+            std::vector<int32_t> nodeIndex(set.tree.nodes.size(), -1);
+            int32_t next = int32_t(_nodes.size());
+            for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni)
+                if (set.tree.nodes[ni].count == 0) nodeIndex[ni] = next++;
+            auto refOf = [&](uint32_t ni) -> int32_t {
+                const TgHipInstNode &n = set.tree.nodes[ni];
+                return n.count == 0 ? nodeIndex[ni] : TGHIP_MAKE_LEAF(primBase + n.left, n.count);
+            };
+            for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni) {
+                const TgHipInstNode &n = set.tree.nodes[ni];
+                if (n.count != 0) continue;
+                TgHipBvhNode b;
+                std::memset(&b, 0, sizeof(b));
+                for (int k = 0; k < 3; ++k) {
+                    b.lo0[k] = n.box[k*4 + 0]; b.lo1[k] = n.box[k*4 + 1];
+                    b.hi0[k] = n.box[k*4 + 2]; b.hi1[k] = n.box[k*4 + 3];
+                }
+                b.child0 = refOf(n.left);
+                b.child1 = refOf(n.left + 1);
+                _nodes.push_back(b);
+            }
+            const int32_t root = refOf(0);
+            std::memcpy(&_recs[K + N + si].c[0], &root, 4);
+            refDepth = std::max(refDepth, set.tree.depth);
+        }
+    }
+    const uint32_t numTopRecs = uint32_t(_recs.size());
+    std::vector<uint32_t> masterRoot(masters.size(), 0), masterWideRoot(masters.size(), 0);
+    int masterDepth = 0, masterWideDepth = 0;
+    for (size_t mi = 0; mi < masters.size(); ++mi) {
+        const std::vector<TgHipPrimRec> &mrecs = masters[mi].recs;
+        const std::vector<TgHipTriAttr> &mattrs = masters[mi].attrs;
+        const std::vector<Box3f> &mbounds = masters[mi].bounds;
+        if (mrecs.empty()) continue;
+        if (mattrs.size() != mrecs.size() || mbounds.size() != mrecs.size())
+            throw std::runtime_error("master: one attribute record and one box per record");
+        BvhBuildResult sub = buildBvh(mbounds, mbounds.size() < (1u << 18) ? 1 : 4);
+        const uint32_t recBase = uint32_t(_recs.size()), nodeBase = uint32_t(_nodes.size());
+        if (uint64_t(recBase) + mrecs.size() >= (1u << 27))
+            throw std::runtime_error("too many primitive records for the 27-bit leaf encoding");
+        // the master's wide subtree (only when the top level has one): built over the master's own records, then moved behind
+        // the wide nodes and records that exist so far
+        std::vector<uint32_t> place(sub.order);              // place[i] = the master's record that goes to slot recBase + i
+        if (!_wideNodes.empty()) {
+            std::vector<Box3f> ordered(mbounds.size());
+            for (size_t i = 0; i < sub.order.size(); ++i)
+                ordered[i] = mbounds[sub.order[i]];
+            WideBvhResult wide = buildWideBvh(sub.nodes, ordered);
+            if (wide.nodes.empty()) {
+                _wideNodes.clear();                          // (a leaf too fat to collapse: the scene walks the BVH2)
+                _wideDepth = 0;
+            } else {
+                for (size_t i = 0; i < wide.order.size(); ++i)
+                    place[i] = sub.order[wide.order[i]];
+                masterWideRoot[mi] = uint32_t(_wideNodes.size());
+                for (TgHipWideNode w : wide.nodes) {
+                    w.child_base += masterWideRoot[mi];
+                    w.rec_base += recBase;
+                    _wideNodes.push_back(w);
+                }
+                masterWideDepth = std::max(masterWideDepth, wide.depth);
+            }
+        }
+        for (size_t i = 0; i < place.size(); ++i) {
+            _recs.push_back(mrecs[place[i]]);
+            _triAttrs.push_back(mattrs[place[i]]);
+        }
+        auto relocate = [&](int32_t ref) -> int32_t {
+            if (ref >= 0) return ref + int32_t(nodeBase);
+            return TGHIP_MAKE_LEAF(TGHIP_LEAF_FIRST(ref) + recBase, TGHIP_LEAF_COUNT(ref));
+        };
+        for (TgHipBvhNode n : sub.nodes) {
+            n.child0 = relocate(n.child0);
+            n.child1 = relocate(n.child1);
+            _nodes.push_back(n);
+        }
+        masterRoot[mi] = nodeBase;
+        masterDepth = std::max(masterDepth, sub.maxDepth);
+    }
+    {
+        for (uint32_t i = 0; i < numTopRecs; ++i) {
+            if (TGHIP_REC_KIND(_recs[i].meta) != TGHIP_REC_INSTANCE) continue;
+            uint32_t slot;
+            std::memcpy(&slot, &_recs[i].c[0], 4);
+            std::memcpy(&_recs[i].c[0], &masterRoot[slot], 4);
+            std::memcpy(&_recs[i].c[2], &masterWideRoot[slot], 4);   // root of the master's wide subtree (0: the scene has no wide BVH)
+        }
+        // the wide walk's stack: the groups of the top level, three entries where an instance is entered, the master's groups
+        if (!_wideNodes.empty()) {
+            _wideDepth += masterWideDepth + 3;
+            if (_wideDepth > TGHIP_MAX_WIDE_DEPTH) { _wideNodes.clear(); _wideDepth = 0; }
+        }
+        // one device stack holds the scene's walk, above it the walk of the reference's instance tree and above that the walk of the
+        // master being visited.  (BinaryBvh::trace keeps the distance at which the ray enters a stacked node and re-checks it when it
+        // pops, bvh/BinaryBvh.hpp:277-283; the device recomputes it for a popped LEAF from inst_leaf_boxes and needs none for a popped
+        // inner node, whose children all fail their own tests exactly when the node's check would: pt_kernels.h)
+        _bvhDepth += refDepth + masterDepth + 3;
+        if (_bvhDepth > TGHIP_MAX_BVH_DEPTH - 1)
+            throw std::runtime_error("instanced BVH deeper than the device traversal stack");
+    }
+    out.numInstances = numInstances;
+    out.numTopRecs = numTopRecs;
+    return out;
+}
+
 void TraceableScene::flatten()
 {
     auto t0 = std::chrono::steady_clock::now();
@@ -225,14 +457,7 @@ void TraceableScene::flatten()
     // ---- objects, light lists, records -------------------------------------------------------
     std::vector<Box3f> recBounds;
     std::vector<std::shared_ptr<Primitive>> masterPrims;   // distinct master meshes of all `instances` primitives
-    uint32_t numInstances = 0;
-    // `instances` primitives (ABI 8): one set record each for the scene's BVH2, their instance records for the wide BVH, and the
-    // reference's own tree over the instances (RefInstanceBvh.hpp) behind the scene's BVH2 nodes
-    struct InstanceSet { TgHipPrimRec rec; Box3f bounds; size_t firstInst; RefInstanceBvh tree; };
-    std::vector<InstanceSet> instSets;
-    std::vector<TgHipPrimRec> instRecs;
-    std::vector<Box3f> instLeafBounds;                    // per instance record: the box of its leaf in the reference's tree
-    std::vector<Box3f> instTightBounds;                   // ... and the tight box of its geometry (Primitive::tightenInstanceBounds)
+    std::vector<InstanceSetInput> instSets;               // one per `instances` primitive that has instances of non-empty masters
     _sceneBounds = Box3f();
     for (size_t pi = 0; pi < _allPrims.size(); ++pi) {
         Primitive &p = *_allPrims[pi];
@@ -347,13 +572,10 @@ void TraceableScene::flatten()
             }
             break;
         } case Primitive::Instances: {
-            // Instance::prepareForRender (Instance.cpp:392-428): a BVH over the instances' boxes.  The reference's intersect keeps the
-            // LAST hit in that tree's visiting order (each instance gets a ray with farT = infinity), so the tree is restated node
-            // for node (RefInstanceBvh.cpp) and walked in the reference's order by the closest-hit queries; the master's index among
-            // `masterPrims` sits in c[0]'s slot until the sub-BVH roots are known (patched below)
-            InstanceSet set;
-            set.firstInst = instRecs.size();
-            std::vector<Box3f> refBoxes;
+            // Instance::prepareForRender (Instance.cpp:392-428): one instance record per instance (position, rotation, its master's index
+            // among `masterPrims`), the reference's box and the tight box of each; the trees are built by buildInstancedAccel below
+            InstanceSetInput set;
+            set.objMeta = objMeta;
             for (size_t i = 0; i < p.instancePos.size(); ++i) {
                 const std::shared_ptr<Primitive> &m = p.masters[p.instanceId[i]];
                 if (m->tris.empty() || m->verts.empty())
@@ -370,49 +592,12 @@ void TraceableScene::flatten()
                 uint32_t masterSlot = uint32_t(mi);
                 std::memcpy(&r.c[0], &masterSlot, 4);
                 r.meta = (uint32_t(TGHIP_REC_INSTANCE) << 29) | objMeta;
-                instRecs.push_back(r);
-                instTightBounds.push_back(p.instanceBounds[i]);
-                refBoxes.push_back(p.instanceRefBounds[i]);
-                numInstances++;
+                set.recs.push_back(r);
+                set.tightBounds.push_back(p.instanceBounds[i]);
+                set.refBounds.push_back(p.instanceRefBounds[i]);
             }
-            if (refBoxes.empty())
-                break;
-            set.tree = buildRefInstanceBvh(refBoxes);
-            set.bounds = set.tree.bounds;
-            std::memset(&set.rec, 0, sizeof(set.rec));
-            copy3(set.rec.a, set.bounds.lo);
-            copy3(set.rec.b, set.bounds.hi);
-            set.rec.meta = (uint32_t(TGHIP_REC_INSTANCE_SET) << 29) | objMeta;
-            // every leaf's box as its parent holds it (a tree that is one leaf: the root's bounds), at the leaf's first slot of inst_prims,
-            // and that slot in the leaf's instance records
-            instLeafBounds.resize(instRecs.size());
-            const size_t slotBase = _instLeafBoxes.size()/8;         // (= this set's first slot of inst_prims: one box slot per leaf slot)
-            _instLeafBoxes.resize(_instLeafBoxes.size() + 8*set.tree.primIndices.size(), 0.0f);
-            auto leafBox = [&](uint32_t leafNode, const Box3f &box) {
-                const TgHipInstNode &leaf = set.tree.nodes[leafNode];
-                const uint32_t slot = uint32_t(slotBase + leaf.left);
-                for (int k = 0; k < 3; ++k) { _instLeafBoxes[8*size_t(slot) + k] = box.lo[k]; _instLeafBoxes[8*size_t(slot) + 4 + k] = box.hi[k]; }
-                for (uint32_t k = 0; k < leaf.count; ++k) {
-                    const size_t rec = set.firstInst + set.tree.primIndices[leaf.left + k];
-                    instLeafBounds[rec] = box;
-                    std::memcpy(&instRecs[rec].c[1], &slot, 4);
-                }
-            };
-            if (set.tree.nodes[0].count != 0) {
-                leafBox(0, set.bounds);
-            } else {
-                for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni) {
-                    const TgHipInstNode &n = set.tree.nodes[ni];
-                    if (n.count != 0) continue;
-                    for (uint32_t c = 0; c < 2; ++c) {
-                        if (set.tree.nodes[n.left + c].count == 0) continue;
-                        Box3f box;
-                        for (int k = 0; k < 3; ++k) { box.lo[k] = n.box[k*4 + c]; box.hi[k] = n.box[k*4 + 2 + c]; }
-                        leafBox(n.left + c, box);
-                    }
-                }
-            }
-            instSets.push_back(std::move(set));
+            if (!set.recs.empty())
+                instSets.push_back(std::move(set));
             break;
         } default:
             break;
@@ -428,7 +613,6 @@ void TraceableScene::flatten()
             addDistribution(_allPrims[size_t(li)]->emission);           // (Skydome::makeSamplable, Skydome.cpp:138-143)
 
     // ---- BVH2 + the 8-wide BVH the single-level traversal kernels walk ----------------------------
-    int refDepth = 0;
     if (instSets.empty()) {
         SceneAccel accel = buildSceneAccel(_recs, _triAttrs, recBounds, false);
         _nodes.swap(accel.nodes);
@@ -436,195 +620,62 @@ void TraceableScene::flatten()
         _bvhDepth = accel.bvhDepth;
         _wideDepth = accel.wideDepth;
         _bvhSah = accel.sahCost;
+        _desc.num_instances = 0;
+        _desc.num_top_recs = uint32_t(_recs.size());
     } else {
-        // Scenes with instances (include/tungsten_hip.h, the instance-set record).  The wide BVH -- any-hit shadow queries -- is built
-        // over the non-instance records and the instance records, every instance boxed tightly (a ray that is to hit an instance passes
-        // that box somewhere along its whole length; whether the reference lets it INTO the instance is the leaf test the walk makes at
-        // the record, pt_wavefront.h); it decides the record order.  The scene's BVH2 -- closest hits -- is
-        // built over the non-instance records and one record per `instances` primitive, behind which the reference's tree follows.
-        const size_t K = _recs.size(), N = instRecs.size(), S = instSets.size();
-        std::vector<Box3f> wideBounds(recBounds);
-        for (size_t i = 0; i < N; ++i) {
-            _recs.push_back(instRecs[i]);
-            _triAttrs.emplace_back();
-            std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
-            _triAttrs.back().bsdf = -1;
-            wideBounds.push_back(instTightBounds[i]);
+        // ---- masters of instanced geometry: records in master space (the reference keeps an Embree scene per master mesh and transforms
+        // the ray into it, Instance.cpp:290-311) ----
+        std::vector<MasterInput> masters(masterPrims.size());
+        for (size_t mi = 0; mi < masterPrims.size(); ++mi) {
+            Primitive &m = *masterPrims[mi];
+            // the master's object record (smooth flag, first bsdf); it is not a scene object of its own unless the scene also lists it
+            size_t objIndex = 0;
+            while (objIndex < _allPrims.size() && _allPrims[objIndex] != masterPrims[mi]) ++objIndex;
+            if (objIndex == _allPrims.size()) {
+                TgHipObject o;
+                std::memset(&o, 0, sizeof(o));
+                o.type = TGHIP_OBJ_MESH;
+                o.int_medium = o.ext_medium = -1;
+                o.bsdf = m.bsdfs.empty() ? -1 : addBsdf(m.bsdfs[0]);
+                o.emission = -1; o.light = -1; o.first_light_tri = -1;
+                o.flags = m.smooth ? TGHIP_OBJF_SMOOTH : 0;
+                o.area = m.area; o.inv_area = m.invArea;
+                objIndex = _objects.size();
+                _objects.push_back(o);
+            }
+            std::vector<int32_t> meshBsdfs;
+            for (auto &b : m.bsdfs) meshBsdfs.push_back(addBsdf(b));
+            MasterInput &mo = masters[mi];
+            for (const MeshTriangle &t : m.tris) {
+                const MeshVertex &a = m.tfVerts[t.v0], &b = m.tfVerts[t.v1], &c = m.tfVerts[t.v2];
+                Vec3f p0(a.pos[0], a.pos[1], a.pos[2]), p1(b.pos[0], b.pos[1], b.pos[2]), p2(c.pos[0], c.pos[1], c.pos[2]);
+                TgHipPrimRec r;
+                std::memset(&r, 0, sizeof(r));
+                copy3(r.a, p0); copy3(r.b, p1 - p0); copy3(r.c, p2 - p0);
+                r.meta = (uint32_t(TGHIP_REC_TRIANGLE) << 29) | uint32_t(objIndex);
+                mo.recs.push_back(r);
+                TgHipTriAttr at;
+                std::memcpy(at.n0, a.normal, 12); std::memcpy(at.n1, b.normal, 12); std::memcpy(at.n2, c.normal, 12);
+                std::memcpy(at.uv0, a.uv, 8); std::memcpy(at.uv1, b.uv, 8); std::memcpy(at.uv2, c.uv, 8);
+                at.bsdf = meshBsdfs[size_t(t.material)];
+                mo.attrs.push_back(at);
+                Box3f bb;
+                bb.grow(p0); bb.grow(p1); bb.grow(p2);
+                mo.bounds.push_back(bb);
+            }
         }
-        SceneAccel accel = buildSceneAccel(_recs, _triAttrs, wideBounds, true);
+        InstancedAccel accel = buildInstancedAccel(_recs, _triAttrs, recBounds, instSets, masters);
+        _nodes.swap(accel.nodes);
         _wideNodes.swap(accel.wideNodes);
+        _instPrims.swap(accel.instPrims);
+        _instLeafBoxes.swap(accel.instLeafBoxes);
+        _instTightBoxes.swap(accel.instTightBoxes);
+        _bvhDepth = accel.bvhDepth;
         _wideDepth = accel.wideDepth;
         _bvhSah = accel.sahCost;
-        std::vector<uint32_t> slotOf(K + N);                 // caller's record -> its slot
-        for (size_t i = 0; i < accel.order.size(); ++i)
-            slotOf[accel.order[i]] = uint32_t(i);
-        _instTightBoxes.assign(8*(K + N + S), 0.0f);
-        for (size_t i = 0; i < N; ++i)
-            for (int k = 0; k < 3; ++k) {
-                _instTightBoxes[8*size_t(slotOf[K + i]) + k] = instTightBounds[i].lo[k];
-                _instTightBoxes[8*size_t(slotOf[K + i]) + 4 + k] = instTightBounds[i].hi[k];
-            }
-        for (size_t si = 0; si < S; ++si) {
-            _recs.push_back(instSets[si].rec);
-            _triAttrs.emplace_back();
-            std::memset(&_triAttrs.back(), 0, sizeof(TgHipTriAttr));
-            _triAttrs.back().bsdf = -1;
-        }
-        std::vector<Box3f> sceneBounds(recBounds);
-        for (size_t si = 0; si < S; ++si)
-            sceneBounds.push_back(instSets[si].bounds);
-        BvhBuildResult top = buildBvh(sceneBounds, 1);
-        auto finalSlot = [&](uint32_t input) { return input < K ? slotOf[input] : uint32_t(K + N + (input - K)); };
-        for (TgHipBvhNode &n : top.nodes)
-            for (int32_t *ref : {&n.child0, &n.child1})
-                if (*ref < 0)
-                    *ref = TGHIP_MAKE_LEAF(finalSlot(top.order[TGHIP_LEAF_FIRST(*ref)]), 1);
-        _nodes.swap(top.nodes);
-        _bvhDepth = top.maxDepth;
-        // the reference's trees as BVH2 nodes with its exact child boxes; their leaf references index inst_prims
-        for (size_t si = 0; si < S; ++si) {
-            const InstanceSet &set = instSets[si];
-            const uint32_t primBase = uint32_t(_instPrims.size());
-            for (uint32_t id : set.tree.primIndices)
-                _instPrims.push_back(slotOf[K + set.firstInst + id]);
-            // inner nodes only become BVH2 nodes; a leaf is a leaf reference in its parent
-            std::vector<int32_t> nodeIndex(set.tree.nodes.size(), -1);
-            int32_t next = int32_t(_nodes.size());
-            for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni)
-                if (set.tree.nodes[ni].count == 0) nodeIndex[ni] = next++;
-            auto refOf = [&](uint32_t ni) -> int32_t {
-                const TgHipInstNode &n = set.tree.nodes[ni];
-                return n.count == 0 ? nodeIndex[ni] : TGHIP_MAKE_LEAF(primBase + n.left, n.count);
-            };
-            for (size_t ni = 0; ni < set.tree.nodes.size(); ++ni) {
-                const TgHipInstNode &n = set.tree.nodes[ni];
-                if (n.count != 0) continue;
-                TgHipBvhNode b;
-                std::memset(&b, 0, sizeof(b));
-                for (int k = 0; k < 3; ++k) {
-                    b.lo0[k] = n.box[k*4 + 0]; b.lo1[k] = n.box[k*4 + 1];
-                    b.hi0[k] = n.box[k*4 + 2]; b.hi1[k] = n.box[k*4 + 3];
-                }
-                b.child0 = refOf(n.left);
-                b.child1 = refOf(n.left + 1);
-                _nodes.push_back(b);
-            }
-            const int32_t root = refOf(0);
-            std::memcpy(&_recs[K + N + si].c[0], &root, 4);
-            refDepth = std::max(refDepth, set.tree.depth);
-        }
+        _desc.num_instances = accel.numInstances;
+        _desc.num_top_recs = accel.numTopRecs;
     }
-    const uint32_t numTopRecs = uint32_t(_recs.size());
-
-    // ---- masters of instanced geometry: records in master space + one BVH2 subtree each, behind the top level ----
-    // (the reference keeps an Embree scene per master mesh and transforms the ray into it, Instance.cpp:290-311)
-    std::vector<uint32_t> masterRoot(masterPrims.size(), 0), masterWideRoot(masterPrims.size(), 0);
-    int masterDepth = 0, masterWideDepth = 0;
-    for (size_t mi = 0; mi < masterPrims.size(); ++mi) {
-        Primitive &m = *masterPrims[mi];
-        // the master's object record (smooth flag, first bsdf); it is not a scene object of its own unless the scene also lists it
-        size_t objIndex = 0;
-        while (objIndex < _allPrims.size() && _allPrims[objIndex] != masterPrims[mi]) ++objIndex;
-        if (objIndex == _allPrims.size()) {
-            TgHipObject o;
-            std::memset(&o, 0, sizeof(o));
-            o.type = TGHIP_OBJ_MESH;
-            o.int_medium = o.ext_medium = -1;
-            o.bsdf = m.bsdfs.empty() ? -1 : addBsdf(m.bsdfs[0]);
-            o.emission = -1; o.light = -1; o.first_light_tri = -1;
-            o.flags = m.smooth ? TGHIP_OBJF_SMOOTH : 0;
-            o.area = m.area; o.inv_area = m.invArea;
-            objIndex = _objects.size();
-            _objects.push_back(o);
-        }
-        std::vector<int32_t> meshBsdfs;
-        for (auto &b : m.bsdfs) meshBsdfs.push_back(addBsdf(b));
-        std::vector<TgHipPrimRec> mrecs;
-        std::vector<TgHipTriAttr> mattrs;
-        std::vector<Box3f> mbounds;
-        for (const MeshTriangle &t : m.tris) {
-            const MeshVertex &a = m.tfVerts[t.v0], &b = m.tfVerts[t.v1], &c = m.tfVerts[t.v2];
-            Vec3f p0(a.pos[0], a.pos[1], a.pos[2]), p1(b.pos[0], b.pos[1], b.pos[2]), p2(c.pos[0], c.pos[1], c.pos[2]);
-            TgHipPrimRec r;
-            std::memset(&r, 0, sizeof(r));
-            copy3(r.a, p0); copy3(r.b, p1 - p0); copy3(r.c, p2 - p0);
-            r.meta = (uint32_t(TGHIP_REC_TRIANGLE) << 29) | uint32_t(objIndex);
-            mrecs.push_back(r);
-            TgHipTriAttr at;
-            std::memcpy(at.n0, a.normal, 12); std::memcpy(at.n1, b.normal, 12); std::memcpy(at.n2, c.normal, 12);
-            std::memcpy(at.uv0, a.uv, 8); std::memcpy(at.uv1, b.uv, 8); std::memcpy(at.uv2, c.uv, 8);
-            at.bsdf = meshBsdfs[size_t(t.material)];
-            mattrs.push_back(at);
-            Box3f bb;
-            bb.grow(p0); bb.grow(p1); bb.grow(p2);
-            mbounds.push_back(bb);
-        }
-        BvhBuildResult sub = buildBvh(mbounds, mbounds.size() < (1u << 18) ? 1 : 4);
-        const uint32_t recBase = uint32_t(_recs.size()), nodeBase = uint32_t(_nodes.size());
-        if (uint64_t(recBase) + mrecs.size() >= (1u << 27))
-            throw std::runtime_error("too many primitive records for the 27-bit leaf encoding");
-        // the master's wide subtree (only when the top level has one): built over the master's own records, then moved behind
-        // the wide nodes and records that exist so far
-        std::vector<uint32_t> place(sub.order);              // place[i] = the master's record that goes to slot recBase + i
-        if (!_wideNodes.empty()) {
-            std::vector<Box3f> ordered(mbounds.size());
-            for (size_t i = 0; i < sub.order.size(); ++i)
-                ordered[i] = mbounds[sub.order[i]];
-            WideBvhResult wide = buildWideBvh(sub.nodes, ordered);
-            if (wide.nodes.empty()) {
-                _wideNodes.clear();                          // (a leaf too fat to collapse: the scene walks the BVH2)
-                _wideDepth = 0;
-            } else {
-                for (size_t i = 0; i < wide.order.size(); ++i)
-                    place[i] = sub.order[wide.order[i]];
-                masterWideRoot[mi] = uint32_t(_wideNodes.size());
-                for (TgHipWideNode w : wide.nodes) {
-                    w.child_base += masterWideRoot[mi];
-                    w.rec_base += recBase;
-                    _wideNodes.push_back(w);
-                }
-                masterWideDepth = std::max(masterWideDepth, wide.depth);
-            }
-        }
-        for (size_t i = 0; i < place.size(); ++i) {
-            _recs.push_back(mrecs[place[i]]);
-            _triAttrs.push_back(mattrs[place[i]]);
-        }
-        auto relocate = [&](int32_t ref) -> int32_t {
-            if (ref >= 0) return ref + int32_t(nodeBase);
-            return TGHIP_MAKE_LEAF(TGHIP_LEAF_FIRST(ref) + recBase, TGHIP_LEAF_COUNT(ref));
-        };
-        for (TgHipBvhNode n : sub.nodes) {
-            n.child0 = relocate(n.child0);
-            n.child1 = relocate(n.child1);
-            _nodes.push_back(n);
-        }
-        masterRoot[mi] = nodeBase;
-        masterDepth = std::max(masterDepth, sub.maxDepth);
-    }
-    if (numInstances) {
-        for (uint32_t i = 0; i < numTopRecs; ++i) {
-            if (TGHIP_REC_KIND(_recs[i].meta) != TGHIP_REC_INSTANCE) continue;
-            uint32_t slot;
-            std::memcpy(&slot, &_recs[i].c[0], 4);
-            std::memcpy(&_recs[i].c[0], &masterRoot[slot], 4);
-            std::memcpy(&_recs[i].c[2], &masterWideRoot[slot], 4);   // root of the master's wide subtree (0: the scene has no wide BVH)
-        }
-        // the wide walk's stack: the groups of the top level, three entries where an instance is entered, the master's groups
-        if (!_wideNodes.empty()) {
-            _wideDepth += masterWideDepth + 3;
-            if (_wideDepth > TGHIP_MAX_WIDE_DEPTH) { _wideNodes.clear(); _wideDepth = 0; }
-        }
-        // one device stack holds the scene's walk, above it the walk of the reference's instance tree and above that the walk of the
-        // master being visited.  (BinaryBvh::trace keeps the distance at which the ray enters a stacked node and re-checks it when it
-        // pops, bvh/BinaryBvh.hpp:277-283; the device recomputes it for a popped LEAF from inst_leaf_boxes and needs none for a popped
-        // inner node, whose children all fail their own tests exactly when the node's check would: pt_kernels.h)
-        _bvhDepth += refDepth + masterDepth + 3;
-        if (_bvhDepth > TGHIP_MAX_BVH_DEPTH - 1)
-            throw std::runtime_error("instanced BVH deeper than the device traversal stack");
-    }
-    _desc.num_instances = numInstances;
-    _desc.num_top_recs = numTopRecs;
 
     // ---- camera / settings -------------------------------------------------------------------
     const Camera &cam = _scene.camera;

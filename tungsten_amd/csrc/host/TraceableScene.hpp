@@ -28,6 +28,36 @@ struct SceneAccel
 };
 SceneAccel buildSceneAccel(std::vector<TgHipPrimRec> &recs, std::vector<TgHipTriAttr> &attrs, const std::vector<Box3f> &recBounds, bool haveInstances);
 
+// Scenes with `instances` primitives: the inputs and the result of buildInstancedAccel (TraceableScene.cpp), which builds the scene's BVH2
+// with the reference's own tree over the instances behind it, the wide BVH over the tight boxes, and the masters' subtrees.
+struct InstanceSetInput
+{
+    uint32_t objMeta = 0;                  // the `instances` primitive's object index
+    std::vector<TgHipPrimRec> recs;        // one TGHIP_REC_INSTANCE record per instance: a = position, p0 | b = rotation (w | x y z), c[0] = its master's index, meta
+    std::vector<Box3f> refBounds;          // per instance: the box of its master box's eight rotated corners (Instance.cpp:409-421)
+    std::vector<Box3f> tightBounds;        // per instance: the box of its geometry (Primitive::tightenInstanceBounds)
+};
+struct MasterInput                          // one master mesh: its triangle records (meta = the master's object index) in master space
+{
+    std::vector<TgHipPrimRec> recs;
+    std::vector<TgHipTriAttr> attrs;
+    std::vector<Box3f> bounds;
+};
+struct InstancedAccel
+{
+    std::vector<TgHipBvhNode> nodes;
+    std::vector<TgHipWideNode> wideNodes;
+    std::vector<uint32_t> instPrims;       // TgHipSceneDesc::inst_prims
+    std::vector<float> instLeafBoxes;      // TgHipSceneDesc::inst_leaf_boxes
+    std::vector<float> instTightBoxes;     // TgHipSceneDesc::inst_tight_boxes
+    uint32_t numTopRecs = 0, numInstances = 0;
+    int bvhDepth = 0, wideDepth = 0;
+    double sahCost = 0.0;
+};
+// recs / attrs: in, the non-instance records (recBounds: their boxes); out, the scene's whole record array
+InstancedAccel buildInstancedAccel(std::vector<TgHipPrimRec> &recs, std::vector<TgHipTriAttr> &attrs, const std::vector<Box3f> &recBounds,
+                                   const std::vector<InstanceSetInput> &sets, const std::vector<MasterInput> &masters);
+
 class TraceableScene
 {
     Scene &_scene;
