@@ -98,6 +98,40 @@ const TgHipBvhNode  *tgh_accel_nodes(tgh_accel *a, uint32_t *num_nodes);
 const TgHipWideNode *tgh_accel_wide_nodes(tgh_accel *a, uint32_t *num_wide_nodes);   /* NULL / 0: walk the BVH2 */
 void tgh_accel_free(tgh_accel *a);
 
+/* The same for a scene with `instances` primitives (Instance.cpp): the trees of include/tungsten_hip.h's instance-set layout -- the scene's
+ * BVH2 with the reference's own tree over the instances behind it (restated node for node: the walk's visiting order is the reference's),
+ * the wide BVH over the non-instance and the instance records, every master's two subtrees -- from plain arrays.
+ *   recs / tri_attrs / bounds (num_recs, may be 0): the scene's non-instance records;
+ *   sets: one per `instances` primitive -- its TGHIP_REC_INSTANCE records (a = position, p0 | b = rotation quaternion w | x y z, c[0] = index
+ *         into `masters` as uint32 bits, meta = kind | the primitive's object index), and per instance the reference's box (the master box's
+ *         eight rotated corners, Instance.cpp:409-421) and the tight box of its geometry (tgh_instance_tight_bounds);
+ *   masters: each master mesh's triangle records in master space (meta = kind | the master's object index), attributes and boxes.
+ * The result's record array (tgh_accel_recs / tgh_accel_tri_attrs) is the scene's whole array in the trees' order. */
+typedef struct {
+    uint32_t object, num_instances;
+    const TgHipPrimRec *recs;
+    const float *ref_bounds;        /* 6 floats per instance: lo.xyz, hi.xyz */
+    const float *tight_bounds;      /* 6 floats per instance */
+} TghInstanceSet;
+typedef struct {
+    const TgHipPrimRec *recs;
+    const TgHipTriAttr *tri_attrs;
+    const float *bounds;            /* 6 floats per record */
+    uint32_t num_recs;
+} TghMaster;
+tgh_accel *tgh_accel_build_instanced(const TgHipPrimRec *recs, const TgHipTriAttr *tri_attrs, const float *bounds, uint32_t num_recs,
+                                     const TghInstanceSet *sets, uint32_t num_sets, const TghMaster *masters, uint32_t num_masters,
+                                     char *err, size_t errlen);
+const TgHipPrimRec *tgh_accel_recs(tgh_accel *a, uint32_t *num_recs);                 /* instanced builds only (else NULL / 0) */
+const TgHipTriAttr *tgh_accel_tri_attrs(tgh_accel *a);
+const uint32_t *tgh_accel_inst_prims(tgh_accel *a, uint32_t *num_inst_prims);          /* TgHipSceneDesc::inst_prims */
+const float *tgh_accel_inst_leaf_boxes(tgh_accel *a);                                  /* 8 floats per inst_prims slot */
+const float *tgh_accel_inst_tight_boxes(tgh_accel *a);                                 /* 8 floats per top-level record */
+void tgh_accel_counts(tgh_accel *a, uint32_t *num_top_recs, uint32_t *num_instances);
+/* master_verts: 3 floats every stride_floats, in master space; rot = w x y z; ref_bounds / out = lo.xyz, hi.xyz */
+void tgh_instance_tight_bounds(const float *master_verts, uint32_t stride_floats, uint32_t num_verts, const float pos[3], const float rot[4],
+                               const float ref_bounds[6], float out[6]);
+
 /* file-format helpers used by the tests */
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h);
 int tgh_load_hdr(const char *path, float *rgb /* may be NULL to query size */, int *w, int *h);

@@ -35,6 +35,7 @@
 #include "primitives/Cylinder.hpp"
 #include "primitives/Point.hpp"
 #include "primitives/InfiniteSphereCap.hpp"
+#include "primitives/Instance.hpp"
 #include "media/Medium.hpp"
 #include "media/HomogeneousMedium.hpp"
 #include "transmittances/ExponentialTransmittance.hpp"
@@ -329,8 +330,11 @@ void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, cons
     TgHipObject o;
     std::memset(&o, 0, sizeof(o));
     Primitive &mp = const_cast<Primitive &>(p);          // (Primitive::bsdf(int) is not const)
-    o.bsdf = p.numBsdfs() > 0 ? addBsdf(mp.bsdf(0).get()) : -1;
-    for (int i = 1; i < p.numBsdfs(); ++i) addBsdf(mp.bsdf(i).get());
+    const bool isInstances = dynamic_cast<const Instance *>(&p) != nullptr;
+    // (Instance::bsdf(i) is its i-th master's first bsdf; the masters' bsdfs are added with the masters, behind every primitive's)
+    o.bsdf = (p.numBsdfs() > 0 && !isInstances) ? addBsdf(mp.bsdf(0).get()) : -1;
+    for (int i = 1; i < p.numBsdfs() && !isInstances; ++i) addBsdf(mp.bsdf(i).get());
+    _objectIndex[&p] = pi;
     const bool emissive = p.isEmissive();
     o.emission = emissive ? addTexture(p._emission.get()) : -1;
     o.light = -1;
@@ -465,8 +469,12 @@ void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, cons
         copy3(o.normal, cap->_capDir);
         copy3(o.scale, Vec3f(cap->_cosCapAngle, 0.0f, 0.0f));
         copy3(o.edge0, cap->_capFrame.tangent); copy3(o.edge1, cap->_capFrame.bitangent);
+    } else if (isInstances) {                                                  // Instance.cpp:392-428
+        if (emissive) refuse("an emissive 'instances' primitive");
+        o.type = TGHIP_OBJ_INSTANCES;
+        addInstances(p, pi);
     } else {
-        refuse("a primitive that is not a quad, cube, sphere, disk, cylinder, triangle mesh, point, infinite sphere, infinite sphere cap or skydome");
+        refuse("a primitive that is not a quad, cube, sphere, disk, cylinder, triangle mesh, instances, point, infinite sphere, infinite sphere cap or skydome");
     }
 
     if (emissive) {
@@ -479,6 +487,67 @@ void HipSceneFlattener::addPrimitive(const Primitive &p, bool defaultLight, cons
             _infiniteLights.push_back(int32_t(pi));
     }
     _objects.push_back(o);
+}
+
+// One `instances` primitive: its instance records (position, rotation, master), the box the reference gives every instance -- the eight rotated
+// corners of its master's box, Instance.cpp:409-421, computed here with the reference's own vector classes -- and the tight box of its geometry
+// (the product library's tgh_instance_tight_bounds).  An unmodified `tungsten` never reads the triangles of master meshes named in JSON
+// (Instance::loadResources, Instance.cpp:265-282, reads the instance file only and Scene::loadResources walks the scene's own primitives):
+// they are loaded here, as oracle/ref_harness.cpp loads them before it renders the goldens and as code that builds an Instance in memory would.
+void HipSceneFlattener::addInstances(const Primitive &p, size_t objectIndex)
+{
+    const Instance &inst = static_cast<const Instance &>(p);
+    for (const std::shared_ptr<Primitive> &mp : inst._master) {
+        TriangleMesh *m = dynamic_cast<TriangleMesh *>(mp.get());
+        if (!m) refuse("an 'instances' master that is not a triangle mesh");
+        if (m->_tris.empty() && m->_path) {
+            m->loadResources();
+            m->prepareForRender();
+        }
+    }
+    InstanceSet set;
+    set.object = uint32_t(objectIndex);
+    Box3f bounds;
+    for (uint32 i = 0; i < inst._instanceCount; ++i) {
+        if (inst._instanceId[i] >= inst._master.size()) refuse("an instance of a master that does not exist");
+        TriangleMesh *m = static_cast<TriangleMesh *>(inst._master[inst._instanceId[i]].get());
+        if (m->_tris.empty() || m->_verts.empty())
+            continue;                               // an empty master is never hit
+        size_t mi = 0;
+        while (mi < _masters.size() && _masters[mi] != m) ++mi;
+        if (mi == _masters.size())
+            _masters.push_back(m);
+        const Vec3f pos = inst._instancePos[i];
+        const QuaternionF rot = inst._instanceRot[i];
+        TgHipPrimRec r;
+        std::memset(&r, 0, sizeof(r));
+        copy3(r.a, pos);
+        r.p0 = rot[0];
+        r.b[0] = rot[1]; r.b[1] = rot[2]; r.b[2] = rot[3];
+        const uint32_t masterSlot = uint32_t(mi);
+        std::memcpy(&r.c[0], &masterSlot, 4);
+        r.meta = (uint32_t(TGHIP_REC_INSTANCE) << 29) | uint32_t(objectIndex);
+        set.recs.push_back(r);
+        const Box3f bLocal = m->bounds();
+        Box3f bGlobal;
+        for (float x : {0, 1})
+            for (float y : {0, 1})
+                for (float z : {0, 1})
+                    bGlobal.grow(pos + rot*lerp(bLocal.min(), bLocal.max(), Vec3f(x, y, z)));
+        bounds.grow(bGlobal);
+        float ref[6], tight[6];
+        for (int k = 0; k < 3; ++k) { ref[k] = bGlobal.min()[k]; ref[3 + k] = bGlobal.max()[k]; }
+        const float q[4] = {rot[0], rot[1], rot[2], rot[3]}, t[3] = {pos[0], pos[1], pos[2]};
+        static_assert(sizeof(Vertex) == 32, "Vertex is position, normal, uv");
+        tgh_instance_tight_bounds(reinterpret_cast<const float *>(m->_tfVerts.data()), uint32_t(sizeof(Vertex)/sizeof(float)), uint32_t(m->_tfVerts.size()), t, q, ref, tight);
+        set.refBounds.insert(set.refBounds.end(), ref, ref + 6);
+        set.tightBounds.insert(set.tightBounds.end(), tight, tight + 6);
+    }
+    std::vector<float> box(6);
+    for (int k = 0; k < 3; ++k) { box[size_t(k)] = bounds.min()[k]; box[size_t(3 + k)] = bounds.max()[k]; }
+    _instanceBox[&p] = box;
+    if (!set.recs.empty())
+        _instanceSets.push_back(std::move(set));
 }
 
 void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settings, bool enableVolumeLightSampling)
@@ -496,8 +565,12 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     Box3f sceneBounds;
     for (const std::shared_ptr<Primitive> &p : scene._primitives) {
         addPrimitive(*p, false, sampled);
-        if (!p->isInfinite() && !p->isDirac())
+        if (_instanceBox.count(p.get())) {           // (Instance::bounds() was computed before its masters were loaded)
+            const std::vector<float> &b = _instanceBox[p.get()];
+            sceneBounds.grow(Box3f(Vec3f(b[0], b[1], b[2]), Vec3f(b[3], b[4], b[5])));
+        } else if (!p->isInfinite() && !p->isDirac()) {
             sceneBounds.grow(p->bounds());
+        }
     }
     // the default white environment TraceableScene adds to its light lists when the scene has no emitter (TraceableScene.hpp:97-102)
     for (const std::shared_ptr<Primitive> &l : scene._infiniteLights) {
@@ -506,7 +579,7 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
         if (!listed)
             addPrimitive(*l, true, sampled);
     }
-    if (_recs.empty())
+    if (_recs.empty() && _instanceSets.empty())
         refuse("a scene without finite primitives");
 
     // sampled lights need their 2-D distribution
@@ -518,9 +591,71 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     }
 
     char err[512] = {0};
-    _accel = tgh_accel_build(_recs.data(), _triAttrs.data(), _recBounds.data(), uint32_t(_recs.size()), err, sizeof(err));
-    if (!_accel)
-        throw std::runtime_error(std::string("path_tracer_hip: tgh_accel_build: ") + err);
+    if (_instanceSets.empty()) {
+        _accel = tgh_accel_build(_recs.data(), _triAttrs.data(), _recBounds.data(), uint32_t(_recs.size()), err, sizeof(err));
+        if (!_accel)
+            throw std::runtime_error(std::string("path_tracer_hip: tgh_accel_build: ") + err);
+    } else {
+        // the masters: an object record each (unless the scene lists the mesh as a primitive of its own), their bsdfs, their triangles in master space
+        struct MasterArrays { std::vector<TgHipPrimRec> recs; std::vector<TgHipTriAttr> attrs; std::vector<float> bounds; };
+        std::vector<MasterArrays> arrays(_masters.size());
+        for (size_t mi = 0; mi < _masters.size(); ++mi) {
+            TriangleMesh *m = static_cast<TriangleMesh *>(_masters[mi]);
+            size_t objIndex;
+            if (_objectIndex.count(m)) {
+                objIndex = _objectIndex[m];
+            } else {
+                TgHipObject o;
+                std::memset(&o, 0, sizeof(o));
+                o.type = TGHIP_OBJ_MESH;
+                o.int_medium = o.ext_medium = -1;
+                o.bsdf = m->_bsdfs.empty() ? -1 : addBsdf(m->_bsdfs[0].get());
+                o.emission = -1; o.light = -1; o.first_light_tri = -1;
+                o.flags = m->_smoothed ? TGHIP_OBJF_SMOOTH : 0u;
+                o.area = m->_totalArea; o.inv_area = 1.0f/m->_totalArea;
+                objIndex = _objects.size();
+                _objects.push_back(o);
+            }
+            std::vector<int32_t> meshBsdfs;
+            for (const std::shared_ptr<Bsdf> &b : m->_bsdfs) meshBsdfs.push_back(addBsdf(b.get()));
+            MasterArrays &out = arrays[mi];
+            for (const TriangleI &t : m->_tris) {
+                const Vertex &a = m->_tfVerts[t.v0], &b = m->_tfVerts[t.v1], &c = m->_tfVerts[t.v2];
+                TgHipPrimRec r;
+                std::memset(&r, 0, sizeof(r));
+                copy3(r.a, a.pos()); copy3(r.b, b.pos() - a.pos()); copy3(r.c, c.pos() - a.pos());
+                r.meta = (uint32_t(TGHIP_REC_TRIANGLE) << 29) | uint32_t(objIndex);
+                out.recs.push_back(r);
+                TgHipTriAttr at;
+                copy3(at.n0, a.normal()); copy3(at.n1, b.normal()); copy3(at.n2, c.normal());
+                at.uv0[0] = a.uv().x(); at.uv0[1] = a.uv().y();
+                at.uv1[0] = b.uv().x(); at.uv1[1] = b.uv().y();
+                at.uv2[0] = c.uv().x(); at.uv2[1] = c.uv().y();
+                at.bsdf = meshBsdfs[size_t(t.material)];
+                out.attrs.push_back(at);
+                Box3f bb;
+                bb.grow(a.pos()); bb.grow(b.pos()); bb.grow(c.pos());
+                for (int k = 0; k < 3; ++k) out.bounds.push_back(bb.min()[k]);
+                for (int k = 0; k < 3; ++k) out.bounds.push_back(bb.max()[k]);
+            }
+        }
+        std::vector<TghInstanceSet> sets;
+        for (const InstanceSet &s : _instanceSets)
+            sets.push_back(TghInstanceSet{s.object, uint32_t(s.recs.size()), s.recs.data(), s.refBounds.data(), s.tightBounds.data()});
+        std::vector<TghMaster> masters;
+        for (const MasterArrays &a : arrays)
+            masters.push_back(TghMaster{a.recs.data(), a.attrs.data(), a.bounds.data(), uint32_t(a.recs.size())});
+        _accel = tgh_accel_build_instanced(_recs.data(), _triAttrs.data(), _recBounds.data(), uint32_t(_recs.size()), sets.data(), uint32_t(sets.size()),
+                                           masters.data(), uint32_t(masters.size()), err, sizeof(err));
+        if (!_accel)
+            throw std::runtime_error(std::string("path_tracer_hip: tgh_accel_build_instanced: ") + err);
+        // the scene's whole record array, in the trees' order
+        uint32_t numRecs = 0;
+        const TgHipPrimRec *recs = tgh_accel_recs(_accel, &numRecs);
+        const TgHipTriAttr *attrs = tgh_accel_tri_attrs(_accel);
+        _recs.assign(recs, recs + numRecs);
+        _triAttrs.assign(attrs, attrs + numRecs);
+    }
 
     // ---- camera (PinholeCamera.cpp:28-35, Camera.cpp:37-68, ReconstructionFilter.cpp:34-58) ----
     const PinholeCamera *pin = dynamic_cast<const PinholeCamera *>(&scene._cam);
@@ -596,6 +731,16 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     _desc.num_wide_nodes = numWide;
     _desc.num_recs = uint32_t(_recs.size());
     _desc.num_top_recs = uint32_t(_recs.size());
+    if (!_instanceSets.empty()) {
+        uint32_t numTop = 0, numInstances = 0, numInstPrims = 0;
+        tgh_accel_counts(_accel, &numTop, &numInstances);
+        _desc.num_top_recs = numTop;
+        _desc.num_instances = numInstances;
+        _desc.inst_prims = tgh_accel_inst_prims(_accel, &numInstPrims);
+        _desc.num_inst_prims = numInstPrims;
+        _desc.inst_leaf_boxes = tgh_accel_inst_leaf_boxes(_accel);
+        _desc.inst_tight_boxes = tgh_accel_inst_tight_boxes(_accel);
+    }
     _desc.num_objects = uint32_t(_objects.size());
     _desc.num_lights = uint32_t(_lights.size());
     _desc.num_infinite_lights = uint32_t(_infiniteLights.size());

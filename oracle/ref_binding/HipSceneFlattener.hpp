@@ -48,6 +48,14 @@ class HipSceneFlattener
     std::map<const Bsdf *, int32_t> _bsdfIndex;
     tgh_accel *_accel = nullptr;
     TgHipSceneDesc _desc;
+    // `instances` primitives (primitives/Instance.cpp): per primitive its instance records with the reference's and the tight box of every
+    // instance, the distinct master meshes in the order the instances meet them, and the box the primitive has once its masters are loaded
+    struct InstanceSet { uint32_t object; std::vector<TgHipPrimRec> recs; std::vector<float> refBounds, tightBounds; };
+    std::vector<InstanceSet> _instanceSets;
+    std::vector<Primitive *> _masters;
+    std::map<const Primitive *, std::vector<float>> _instanceBox;     // lo.xyz, hi.xyz
+    std::map<const Primitive *, size_t> _objectIndex;
+    void addInstances(const Primitive &p, size_t objectIndex);
 
     int32_t addTexture(const Texture *t);
     void addDistribution(const Texture *t);

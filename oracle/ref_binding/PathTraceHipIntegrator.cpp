@@ -161,6 +161,11 @@ void PathTraceHipIntegrator::prepareForRender(TraceableScene &scene, uint32 seed
         put("sobol", d.sobol_matrices, d.num_sobol_words*4u);
         put("media", d.media, uint64_t(d.num_media)*sizeof(TgHipMedium));
         put("light_tris", d.light_tris, d.num_light_tri_floats*4u);
+        put("inst_prims", d.inst_prims, uint64_t(d.num_inst_prims)*4u);
+        put("inst_leaf_boxes", d.inst_leaf_boxes, uint64_t(d.num_inst_prims)*32u);
+        put("inst_tight_boxes", d.inst_tight_boxes, d.num_instances ? uint64_t(d.num_top_recs)*32u : 0u);
+        const uint32_t counts[2] = {d.num_top_recs, d.num_instances};
+        put("counts", counts, sizeof(counts));
     }
 
     // test hook (tests/test_ref_binding.py, no GPU): the plumbing around the device -- the pass loop, Integrator::saveRenderResumeData /

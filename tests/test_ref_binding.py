@@ -75,6 +75,10 @@ def own_desc(path):
         "sobol": arr(d.sobol_matrices, d.num_sobol_words, 4),
         "media": arr(d.media, d.num_media, C.sizeof(capi.TgHipMedium)),
         "light_tris": arr(d.light_tris, d.num_light_tri_floats, 4),
+        "inst_prims": arr(d.inst_prims, d.num_inst_prims, 4),
+        "inst_leaf_boxes": arr(d.inst_leaf_boxes, d.num_inst_prims, 32),
+        "inst_tight_boxes": arr(d.inst_tight_boxes, d.num_top_recs if d.num_instances else 0, 32),
+        "counts": struct.pack("<II", d.num_top_recs, d.num_instances),
     }
     flat.close()
     return own
@@ -91,16 +95,17 @@ CASES = {
     "bump": lambda tmp: scenes.GOLDEN_CASES["cornell_bump"][0](tmp, **dict(scenes.GOLDEN_CASES["cornell_bump"][1], resolution=(96, 54), spp=2)),
     "skydome": lambda tmp: scenes.GOLDEN_CASES["cornell_skydome"][0](tmp, **dict(scenes.GOLDEN_CASES["cornell_skydome"][1], resolution=(96, 54), spp=2)),
 }
-# round 4: everything else the device renders (but `instances`) -- the analytic primitives and emitters, mesh emitters, media with every
-# transmittance and phase function on primitives and on the camera, the thin-lens camera with its three apertures
+# round 4: everything else the device renders -- the analytic primitives and emitters, mesh emitters, media with every transmittance and
+# phase function on primitives and on the camera, the thin-lens camera with its three apertures, `instances` (whose master meshes the
+# plugin loads itself: an unmodified `tungsten` never reads them, Instance.cpp:265-282)
 for _name in ("cornell_disks", "cornell_cylinders", "cornell_point_lights", "cornell_sun_sky", "cornell_mesh_light", "cornell_mesh_and_quad_light",
               "cornell_fog", "cornell_smoke", "cornell_fog_smoke_sobol", "cornell_fog_rayleigh", "cornell_fog_davis", "cornell_fog_davis_weinstein",
               "cornell_fog_interpolated", "volumetric_caustic", "non_exponential_linear", "non_exponential_pulse", "non_exponential_erlang",
               "non_exponential_double_exponential", "non_exponential_quadratic", "cornell_thinlens", "cornell_thinlens_cateye", "cornell_thinlens_blade5",
-              "cornell_thinlens_pivot", "cornell_thinlens_bitmap"):
+              "cornell_thinlens_pivot", "cornell_thinlens_bitmap", "cornell_instances"):
     CASES[_name] = (lambda n: lambda tmp: scenes.GOLDEN_CASES[n][0](tmp, **dict(scenes.GOLDEN_CASES[n][1], resolution=(96, 54), spp=2)))(_name)
 WIDENED = ["cornell_disks", "cornell_cylinders", "cornell_point_lights", "cornell_sun_sky", "cornell_mesh_light", "cornell_fog_smoke_sobol", "volumetric_caustic",
-           "non_exponential_pulse", "cornell_thinlens_blade5", "cornell_thinlens_cateye"]
+           "non_exponential_pulse", "cornell_thinlens_blade5", "cornell_thinlens_cateye", "cornell_instances"]
 
 
 @pytest.mark.parametrize("case", sorted(CASES))

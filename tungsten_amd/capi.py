@@ -199,6 +199,14 @@ PROTOTYPES = {
     "tgh_accel_nodes": (VP, [VP, C.POINTER(C.c_uint32)]),
     "tgh_accel_wide_nodes": (VP, [VP, C.POINTER(C.c_uint32)]),
     "tgh_accel_free": (None, [VP]),
+    "tgh_accel_build_instanced": (VP, [VP, VP, VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32, C.c_char_p, C.c_size_t]),
+    "tgh_accel_recs": (VP, [VP, C.POINTER(C.c_uint32)]),
+    "tgh_accel_tri_attrs": (VP, [VP]),
+    "tgh_accel_inst_prims": (VP, [VP, C.POINTER(C.c_uint32)]),
+    "tgh_accel_inst_leaf_boxes": (VP, [VP]),
+    "tgh_accel_inst_tight_boxes": (VP, [VP]),
+    "tgh_accel_counts": (None, [VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "tgh_instance_tight_bounds": (None, [VP, C.c_uint32, C.c_uint32, VP, VP, VP, VP]),
     "tgh_save_pfm": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
     "tgh_load_hdr": (C.c_int, [C.c_char_p, VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

@@ -899,6 +899,24 @@ void Primitive::loadResources(const std::string &sceneDir)
 // for the rounding of the device's own world -> master transform, never larger than the reference's) only says which of those instances
 // the ray can hit at all: an instance whose tight box the ray misses is not walked (pt_kernels.h), and the wide BVH of the any-hit queries
 // is built from the tight boxes.  `bounds` (the primitive's, which the scene bounds are made of) stays the reference's.
+Box3f tightInstanceBox(const float *vertexPositions, size_t strideFloats, size_t numVertices, const QuaternionF &q, const Vec3f &pos, const Box3f &refBox)
+{
+    const Vec3f cx = q*Vec3f(1.0f, 0.0f, 0.0f), cy = q*Vec3f(0.0f, 1.0f, 0.0f), cz = q*Vec3f(0.0f, 0.0f, 1.0f);
+    Vec3f lo(std::numeric_limits<float>::max()), hi(-std::numeric_limits<float>::max());
+    for (size_t vi = 0; vi < numVertices; ++vi) {
+        const float *v = vertexPositions + vi*strideFloats;
+        Vec3f p = cx*v[0] + cy*v[1] + cz*v[2];
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+    }
+    Box3f tight;
+    for (int k = 0; k < 3; ++k) {
+        float pad = 1e-5f*(std::max(std::fabs(lo[k]), std::fabs(hi[k])) + std::fabs(pos[k])) + 1e-6f*(hi[k] - lo[k]);
+        tight.lo[k] = std::max(lo[k] + pos[k] - pad, refBox.lo[k]);
+        tight.hi[k] = std::min(hi[k] + pos[k] + pad, refBox.hi[k]);
+    }
+    return tight;
+}
+
 void Primitive::tightenInstanceBounds()
 {
     const size_t n = instancePos.size();
@@ -907,20 +925,8 @@ void Primitive::tightenInstanceBounds()
             const Primitive &m = *masters[instanceId[i]];
             if (m.tris.empty() || m.tfVerts.empty())
                 continue;
-            const QuaternionF &q = instanceRot[i];
-            const Vec3f cx = q*Vec3f(1.0f, 0.0f, 0.0f), cy = q*Vec3f(0.0f, 1.0f, 0.0f), cz = q*Vec3f(0.0f, 0.0f, 1.0f);
-            Vec3f lo(std::numeric_limits<float>::max()), hi(-std::numeric_limits<float>::max());
-            for (const MeshVertex &v : m.tfVerts) {
-                Vec3f p = cx*v.pos[0] + cy*v.pos[1] + cz*v.pos[2];
-                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
-            }
-            Box3f tight;
-            for (int k = 0; k < 3; ++k) {
-                float pad = 1e-5f*(std::max(std::fabs(lo[k]), std::fabs(hi[k])) + std::fabs(instancePos[i][k])) + 1e-6f*(hi[k] - lo[k]);
-                tight.lo[k] = std::max(lo[k] + instancePos[i][k] - pad, instanceBounds[i].lo[k]);
-                tight.hi[k] = std::min(hi[k] + instancePos[i][k] + pad, instanceBounds[i].hi[k]);
-            }
-            instanceBounds[i] = tight;
+            static_assert(sizeof(MeshVertex) % sizeof(float) == 0, "MeshVertex is a record of floats");
+            instanceBounds[i] = tightInstanceBox(m.tfVerts[0].pos, sizeof(MeshVertex)/sizeof(float), m.tfVerts.size(), instanceRot[i], instancePos[i], instanceBounds[i]);
         }
     };
     size_t cost = 0;

@@ -98,6 +98,11 @@ struct Medium   // media/HomogeneousMedium.{hpp,cpp} + Medium.cpp + transmittanc
 struct MeshVertex { float pos[3], normal[3], uv[2]; };          // Vertex.hpp:10-13 (32 B, .wo3 layout)
 struct MeshTriangle { uint32_t v0, v1, v2; int32_t material; };  // Triangle.hpp:14-28 (16 B)
 
+// The box of an instance's geometry: the master's vertices (3 floats every strideFloats) rotated by q, translated by pos, padded for the rounding
+// of the device's own world -> master transform, never larger than the reference's box of the instance (Primitive::tightenInstanceBounds;
+// tgh_instance_tight_bounds for the reference-side flattener)
+Box3f tightInstanceBox(const float *vertexPositions, size_t strideFloats, size_t numVertices, const QuaternionF &q, const Vec3f &pos, const Box3f &refBox);
+
 struct Primitive
 {
     // (the values of the first ten are TGHIP_OBJ_*; a Skydome is flattened to TGHIP_OBJ_INFINITE_SPHERE | TGHIP_OBJF_SKYDOME)

@@ -28,6 +28,10 @@ struct tgh_scheduler
 struct tgh_accel
 {
     SceneAccel accel;
+    // tgh_accel_build_instanced: the trees (nodes / wide nodes moved into `accel`) and the scene's whole record array
+    InstancedAccel inst;
+    std::vector<TgHipPrimRec> recs;
+    std::vector<TgHipTriAttr> attrs;
 };
 
 struct tgh_renderer
@@ -314,6 +318,92 @@ const TgHipWideNode *tgh_accel_wide_nodes(tgh_accel *a, uint32_t *num_wide_nodes
 void tgh_accel_free(tgh_accel *a)
 {
     delete a;
+}
+
+static std::vector<Box3f> boxesOf(const float *bounds, size_t n)
+{
+    std::vector<Box3f> b(n);
+    for (size_t i = 0; i < n; ++i) {
+        b[i].lo = Vec3f(bounds[6*i + 0], bounds[6*i + 1], bounds[6*i + 2]);
+        b[i].hi = Vec3f(bounds[6*i + 3], bounds[6*i + 4], bounds[6*i + 5]);
+    }
+    return b;
+}
+
+tgh_accel *tgh_accel_build_instanced(const TgHipPrimRec *recs, const TgHipTriAttr *tri_attrs, const float *bounds, uint32_t num_recs,
+                                     const TghInstanceSet *sets, uint32_t num_sets, const TghMaster *masters, uint32_t num_masters,
+                                     char *err, size_t errlen)
+{
+    try {
+        if (num_recs && (!recs || !tri_attrs || !bounds))
+            throw std::runtime_error("tgh_accel_build_instanced: records without attributes or bounds");
+        if (!sets || num_sets == 0 || !masters || num_masters == 0)
+            throw std::runtime_error("tgh_accel_build_instanced: no instance sets or no masters");
+        std::unique_ptr<tgh_accel> out(new tgh_accel());
+        out->recs.assign(recs, recs + num_recs);
+        out->attrs.assign(tri_attrs, tri_attrs + num_recs);
+        std::vector<InstanceSetInput> in(num_sets);
+        for (uint32_t i = 0; i < num_sets; ++i) {
+            if (sets[i].num_instances && (!sets[i].recs || !sets[i].ref_bounds || !sets[i].tight_bounds))
+                throw std::runtime_error("tgh_accel_build_instanced: an instance set without records or bounds");
+            in[i].objMeta = sets[i].object;
+            in[i].recs.assign(sets[i].recs, sets[i].recs + sets[i].num_instances);
+            in[i].refBounds = boxesOf(sets[i].ref_bounds, sets[i].num_instances);
+            in[i].tightBounds = boxesOf(sets[i].tight_bounds, sets[i].num_instances);
+        }
+        std::vector<MasterInput> ms(num_masters);
+        for (uint32_t i = 0; i < num_masters; ++i) {
+            if (masters[i].num_recs && (!masters[i].recs || !masters[i].tri_attrs || !masters[i].bounds))
+                throw std::runtime_error("tgh_accel_build_instanced: a master without records, attributes or bounds");
+            ms[i].recs.assign(masters[i].recs, masters[i].recs + masters[i].num_recs);
+            ms[i].attrs.assign(masters[i].tri_attrs, masters[i].tri_attrs + masters[i].num_recs);
+            ms[i].bounds = boxesOf(masters[i].bounds, masters[i].num_recs);
+        }
+        out->inst = buildInstancedAccel(out->recs, out->attrs, boxesOf(bounds, num_recs), in, ms);
+        out->accel.nodes.swap(out->inst.nodes);
+        out->accel.wideNodes.swap(out->inst.wideNodes);
+        out->accel.bvhDepth = out->inst.bvhDepth;
+        out->accel.wideDepth = out->inst.wideDepth;
+        out->accel.sahCost = out->inst.sahCost;
+        return out.release();
+    } catch (const std::exception &e) {
+        setErr(err, errlen, e.what());
+        return nullptr;
+    }
+}
+
+const TgHipPrimRec *tgh_accel_recs(tgh_accel *a, uint32_t *num_recs)
+{
+    if (num_recs) *num_recs = a ? uint32_t(a->recs.size()) : 0u;
+    return (a && !a->recs.empty()) ? a->recs.data() : nullptr;
+}
+
+const TgHipTriAttr *tgh_accel_tri_attrs(tgh_accel *a) { return (a && !a->attrs.empty()) ? a->attrs.data() : nullptr; }
+
+const uint32_t *tgh_accel_inst_prims(tgh_accel *a, uint32_t *num_inst_prims)
+{
+    if (num_inst_prims) *num_inst_prims = a ? uint32_t(a->inst.instPrims.size()) : 0u;
+    return (a && !a->inst.instPrims.empty()) ? a->inst.instPrims.data() : nullptr;
+}
+
+const float *tgh_accel_inst_leaf_boxes(tgh_accel *a) { return (a && !a->inst.instLeafBoxes.empty()) ? a->inst.instLeafBoxes.data() : nullptr; }
+const float *tgh_accel_inst_tight_boxes(tgh_accel *a) { return (a && !a->inst.instTightBoxes.empty()) ? a->inst.instTightBoxes.data() : nullptr; }
+
+void tgh_accel_counts(tgh_accel *a, uint32_t *num_top_recs, uint32_t *num_instances)
+{
+    if (num_top_recs) *num_top_recs = a ? a->inst.numTopRecs : 0u;
+    if (num_instances) *num_instances = a ? a->inst.numInstances : 0u;
+}
+
+void tgh_instance_tight_bounds(const float *master_verts, uint32_t stride_floats, uint32_t num_verts, const float pos[3], const float rot[4],
+                               const float ref_bounds[6], float out[6])
+{
+    Box3f ref;
+    ref.lo = Vec3f(ref_bounds[0], ref_bounds[1], ref_bounds[2]);
+    ref.hi = Vec3f(ref_bounds[3], ref_bounds[4], ref_bounds[5]);
+    QuaternionF q(rot[0], rot[1], rot[2], rot[3]);
+    Box3f t = tightInstanceBox(master_verts, stride_floats, num_verts, q, Vec3f(pos[0], pos[1], pos[2]), ref);
+    for (int k = 0; k < 3; ++k) { out[k] = t.lo[k]; out[3 + k] = t.hi[k]; }
 }
 
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h)
