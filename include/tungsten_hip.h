@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 8
+#define TGHIP_ABI_VERSION 9
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -202,7 +202,15 @@ enum { TGHIP_BSDF_LAMBERT = 0, TGHIP_BSDF_NULL = 1, TGHIP_BSDF_ROUGH_CONDUCTOR =
        TGHIP_BSDF_SMOOTH_COAT = 3, TGHIP_BSDF_DIELECTRIC = 4, TGHIP_BSDF_ROUGH_DIELECTRIC = 5,
        TGHIP_BSDF_MIRROR = 6, TGHIP_BSDF_CONDUCTOR = 7, TGHIP_BSDF_PLASTIC = 8,
        TGHIP_BSDF_ROUGH_PLASTIC = 9, TGHIP_BSDF_MIXED = 10, TGHIP_BSDF_TRANSPARENCY = 11,
-       TGHIP_BSDF_FORWARD = 12, TGHIP_BSDF_ERROR = 13 };
+       TGHIP_BSDF_FORWARD = 12, TGHIP_BSDF_ERROR = 13,
+       /* ABI 9: the five remaining non-fibre types of bsdfs/BsdfFactory.cpp:29-51.  Their own parameters:
+        *   DIFFUSE_TRANSMISSION  eta[0] = _transmittance (0.5: the reference has no JSON key for it)
+        *   PHONG                 eta[0] = _exponent, eta[1] = _diffuseRatio, k[0] = _invExponent, k[1] = _pdfFactor, k[2] = _brdfFactor (PhongBsdf.cpp:126-132)
+        *   THINSHEET             ior, tex1 = _thickness (scalar texture), sigma_a, enable_refraction = _enableInterference
+        *   OREN_NAYAR            roughness (scalar texture)
+        *   ROUGH_COAT            ior, thickness, sigma_a, scaled_sigma_a, avg_transmittance, distribution, roughness, sub0 = _substrate */
+       TGHIP_BSDF_DIFFUSE_TRANSMISSION = 14, TGHIP_BSDF_PHONG = 15, TGHIP_BSDF_THINSHEET = 16, TGHIP_BSDF_OREN_NAYAR = 17,
+       TGHIP_BSDF_ROUGH_COAT = 18 };
 enum { TGHIP_DIST_BECKMANN = 0, TGHIP_DIST_PHONG = 1, TGHIP_DIST_GGX = 2 };
 /* lobe bits, identical to bsdfs/BsdfLobes.hpp:13-33 */
 enum { TGHIP_LOBE_GLOSSY_R = 1, TGHIP_LOBE_GLOSSY_T = 2, TGHIP_LOBE_DIFFUSE_R = 4, TGHIP_LOBE_DIFFUSE_T = 8,

@@ -171,6 +171,12 @@ static v3 cosineHemisphere(float xi0, float xi1)   /* SampleWarp.hpp:42-52 */
     return V(cosf(phi)*r, sinf(phi)*r, sqrtf(fmaxf(1.0f - xi1, 0.0f)));
 }
 static inline float cosineHemispherePdf(v3 p) { return fabsf(p.z)*O_INV_PI; }   /* :54-57 */
+static v3 uniformHemisphere(float xi0, float xi1)  /* SampleWarp.hpp:25-30 */
+{
+    float phi = O_TWO_PI*xi0;
+    float r = sqrtf(fmaxf(1.0f - xi1*xi1, 0.0f));
+    return V(cosf(phi)*r, sinf(phi)*r, xi1);
+}
 static v3 uniformSphere(float xi0, float xi1)      /* SampleWarp.hpp:96-107 */
 {
     float phi = xi0*O_TWO_PI;
@@ -328,6 +334,43 @@ static float dielectricReflectanceT(float eta, float cosThetaI, float *cosThetaT
     return (Rs*Rs + Rp*Rp)*0.5f;
 }
 static float dielectricReflectance(float eta, float cosThetaI) { float t; return dielectricReflectanceT(eta, cosThetaI, &t); }
+/* Fresnel::thinFilmReflectance (Fresnel.hpp:15-28) */
+static float thinFilmReflectance(float eta, float cosThetaI, float *cosThetaT)
+{
+    float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+    if (sinThetaTSq > 1.0f) {
+        *cosThetaT = 0.0f;
+        return 1.0f;
+    }
+    *cosThetaT = sqrtf(fmaxf(1.0f - sinThetaTSq, 0.0f));
+    float Rs = sqr((eta*cosThetaI - *cosThetaT)/(eta*cosThetaI + *cosThetaT));
+    float Rp = sqr((eta*(*cosThetaT) - cosThetaI)/(eta*(*cosThetaT) + cosThetaI));
+    return 1.0f - ((1.0f - Rs)/(1.0f + Rs) + (1.0f - Rp)/(1.0f + Rp))*0.5f;
+}
+/* Fresnel::thinFilmReflectanceInterference (Fresnel.hpp:39-67): `thickness` in nanometres */
+static v3 thinFilmReflectanceInterference(float eta, float cosThetaI, float thickness, float *cosThetaT)
+{
+    const v3 invLambdas = V(1.0f/650.0f, 1.0f/510.0f, 1.0f/475.0f);
+    float cosThetaISq = cosThetaI*cosThetaI;
+    float sinThetaISq = 1.0f - cosThetaISq;
+    float invEta = 1.0f/eta;
+    float sinThetaTSq = eta*eta*sinThetaISq;
+    if (sinThetaTSq > 1.0f) {
+        *cosThetaT = 0.0f;
+        return vs(1.0f);
+    }
+    *cosThetaT = sqrtf(1.0f - sinThetaTSq);
+    float Ts = 4.0f*eta*cosThetaI*(*cosThetaT)/sqr(eta*cosThetaI + *cosThetaT);
+    float Tp = 4.0f*eta*cosThetaI*(*cosThetaT)/sqr(eta*(*cosThetaT) + cosThetaI);
+    float Rs = 1.0f - Ts;
+    float Rp = 1.0f - Tp;
+    v3 phi = vscale(invLambdas, thickness*(*cosThetaT)*O_FOUR_PI*invEta);
+    v3 cosPhi = V(cosf(phi.x), cosf(phi.y), cosf(phi.z));
+    float a = sqr(Rs) + 1.0f, b2 = 2.0f*Rs, c = sqr(Rp) + 1.0f, d2 = 2.0f*Rp, ts = sqr(Ts), tp = sqr(Tp);
+    v3 tS = V(ts/(a - b2*cosPhi.x), ts/(a - b2*cosPhi.y), ts/(a - b2*cosPhi.z));
+    v3 tP = V(tp/(c - d2*cosPhi.x), tp/(c - d2*cosPhi.y), tp/(c - d2*cosPhi.z));
+    return V(1.0f - (tS.x + tP.x)*0.5f, 1.0f - (tS.y + tP.y)*0.5f, 1.0f - (tS.z + tP.z)*0.5f);
+}
 
 static float conductorReflectance1(float eta, float k, float cosThetaI)
 {
@@ -724,6 +767,103 @@ static v3 bsdf_eval(const TgHipSceneDesc *s, int bi, const Event *e)
         v3 f0 = bsdf_eval(s, b->sub0, e), f1 = bsdf_eval(s, b->sub1, e);
         return vmul(bsdf_albedo(s, b, e), vadd(vscale(f0, ratio), vscale(f1, 1.0f - ratio)));
     }
+    case TGHIP_BSDF_DIFFUSE_TRANSMISSION: { /* DiffuseTransmissionBsdf.cpp:50-57 */
+        if (!(e->requested & TGHIP_LOBE_DIFFUSE_T)) return vs(0.0f);
+        float factor = e->wi.z*e->wo.z < 0.0f ? b->eta[0] : 1.0f - b->eta[0];
+        return vscale(vscale(vscale(bsdf_albedo(s, b, e), factor), O_INV_PI), fabsf(e->wo.z));
+    }
+    case TGHIP_BSDF_PHONG: { /* PhongBsdf.cpp:79-99 */
+        int evalGlossy = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0, evalDiffuse = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        if (!evalGlossy && !evalDiffuse) return vs(0.0f);
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vs(0.0f);
+        float result = 0.0f;
+        if (evalDiffuse)
+            result += b->eta[1]*O_INV_PI;
+        if (evalGlossy) {
+            float cosTheta = vdot(V(-e->wi.x, -e->wi.y, e->wi.z), e->wo);
+            if (cosTheta > 0.0f)
+                result += powf(cosTheta, b->eta[0])*b->k[2]*(1.0f - b->eta[1]);
+        }
+        return vscale(vscale(bsdf_albedo(s, b, e), e->wo.z), result);
+    }
+    case TGHIP_BSDF_THINSHEET: { /* ThinSheetBsdf.cpp:83-104 */
+        if (e->requested != TGHIP_LOBE_FORWARD || -e->wi.x != e->wo.x || -e->wi.y != e->wo.y || -e->wi.z != e->wo.z)
+            return vs(0.0f);
+        float thickness = texture_eval(s, b->tex1, e->u, e->v).x;
+        float cosThetaT;
+        v3 transmittance;
+        if (b->enable_refraction) {
+            v3 r = thinFilmReflectanceInterference(1.0f/b->ior, fabsf(e->wi.z), thickness*500.0f, &cosThetaT);
+            transmittance = V(1.0f - r.x, 1.0f - r.y, 1.0f - r.z);
+        } else {
+            transmittance = vs(1.0f - thinFilmReflectance(1.0f/b->ior, fabsf(e->wi.z), &cosThetaT));
+        }
+        v3 sa = ld3(b->sigma_a);
+        if (!(sa.x == 0.0f && sa.y == 0.0f && sa.z == 0.0f) && cosThetaT > 0.0f)
+            transmittance = vmul(transmittance, vexp(vscale(vneg(sa), thickness*2.0f/cosThetaT)));
+        return transmittance;
+    }
+    case TGHIP_BSDF_OREN_NAYAR: { /* OrenNayarBsdf.cpp:61-100 */
+        if (!(e->requested & TGHIP_LOBE_DIFFUSE_R)) return vs(0.0f);
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vs(0.0f);
+        v3 wi = e->wi, wo = e->wo;
+        float thetaR = acosf(wo.z);
+        float thetaI = acosf(wi.z);
+        float alpha = thetaR > thetaI ? thetaR : thetaI;       /* Tungsten::max / min (a < b ? b : a) */
+        float beta = thetaR < thetaI ? thetaR : thetaI;
+        float sinAlpha = sinf(alpha);
+        float denom = (wi.x*wi.x + wi.y*wi.y)*(wo.x*wo.x + wo.y*wo.y);
+        float cosDeltaPhi;
+        if (denom == 0.0f)
+            cosDeltaPhi = 1.0f;
+        else
+            cosDeltaPhi = (wi.x*wo.x + wi.y*wo.y)/sqrtf(denom);
+        const float RoughnessToSigma = 1.0f/sqrtf(2.0f);
+        float sigma = RoughnessToSigma*bsdf_roughness(s, b, e);
+        float sigmaSq = sigma*sigma;
+        float C1 = 1.0f - 0.5f*sigmaSq/(sigmaSq + 0.33f);
+        float C2 = 0.45f*sigmaSq/(sigmaSq + 0.09f);
+        if (cosDeltaPhi >= 0.0f) {
+            C2 *= sinAlpha;
+        } else {
+            float q = (2.0f*O_INV_PI)*beta;
+            C2 *= sinAlpha - q*q*q;
+        }
+        float C3 = 0.125f*(sigmaSq/(sigmaSq + 0.09f))*sqr((4.0f*O_INV_PI*O_INV_PI)*alpha*beta);
+        float fr1 = (C1 + cosDeltaPhi*C2*tanf(beta) + (1.0f - fabsf(cosDeltaPhi))*C3*tanf(0.5f*(alpha + beta)));
+        float fr2 = 0.17f*sigmaSq/(sigmaSq + 0.13f)*(1.0f - cosDeltaPhi*sqr((2.0f*O_INV_PI)*beta));
+        v3 diffuseAlbedo = bsdf_albedo(s, b, e);
+        return vscale(vscale(vadd(vscale(diffuseAlbedo, fr1), vscale(vmul(diffuseAlbedo, diffuseAlbedo), fr2)), wo.z), O_INV_PI);
+    }
+    case TGHIP_BSDF_ROUGH_COAT: { /* RoughCoatBsdf.cpp:161-199 */
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & s->bsdfs[b->sub0].lobes) != 0;
+        if (!sampleT && !sampleR) return vs(0.0f);
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return vs(0.0f);
+        v3 glossyR = vs(0.0f);
+        if (sampleR)
+            glossyR = rd_evalBase(e, 1, 0, bsdf_roughness(s, b, e), b->ior, b->distribution);
+        v3 substrateR = vs(0.0f);
+        if (sampleT) {
+            v3 wi = e->wi, wo = e->wo;
+            float eta = 1.0f/b->ior;
+            float cosThetaTi, cosThetaTo;
+            float Fi = dielectricReflectanceT(eta, wi.z, &cosThetaTi);
+            float Fo = dielectricReflectanceT(eta, wo.z, &cosThetaTo);
+            if (Fi == 1.0f || Fo == 1.0f)
+                return glossyR;
+            Event q = *e;
+            q.wi = V(wi.x*eta, wi.y*eta, copysignf(cosThetaTi, wi.z));
+            q.wo = V(wo.x*eta, wo.y*eta, copysignf(cosThetaTo, wo.z));
+            float compressionProjection = eta*eta*wo.z/cosThetaTo;
+            v3 substrateF = bsdf_eval(s, b->sub0, &q);
+            v3 ssa = ld3(b->scaled_sigma_a);
+            if (vmax3(ssa) > 0.0f)
+                substrateF = vmul(substrateF, vexp(vscale(ssa, -1.0f/cosThetaTo - 1.0f/cosThetaTi)));
+            substrateR = vscale(substrateF, compressionProjection*(1.0f - Fi)*(1.0f - Fo));
+        }
+        return vadd(glossyR, substrateR);
+    }
     case TGHIP_BSDF_TRANSPARENCY: /* TransparencyBsdf.cpp:48-54 */
         if (e->requested == TGHIP_LOBE_FORWARD)
             return (-e->wi.x == e->wo.x && -e->wi.y == e->wo.y && -e->wi.z == e->wo.z)
@@ -984,6 +1124,166 @@ static int bsdf_sample(const TgHipSceneDesc *s, int bi, Event *e)
         e->weight = vmul(e->weight, bsdf_albedo(s, b, e));
         return 1;
     }
+    case TGHIP_BSDF_DIFFUSE_TRANSMISSION: { /* DiffuseTransmissionBsdf.cpp:29-48 */
+        int sampleR = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0, sampleT = (e->requested & TGHIP_LOBE_DIFFUSE_T) != 0;
+        if (!sampleR && !sampleT) return 0;
+        const float T = b->eta[0];
+        float transmittanceProbability = sampleR && sampleT ? T : (sampleR ? 0.0f : 1.0f);
+        int transmit = nextBoolean(e->sampler, transmittanceProbability);
+        float weight = sampleR && sampleT ? 1.0f : (transmit ? T : 1.0f - T);
+        float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+        e->wo = cosineHemisphere(xi0, xi1);
+        e->wo.z = copysignf(e->wo.z, e->wi.z);
+        if (transmit)
+            e->wo.z = -e->wo.z;
+        e->pdf = cosineHemispherePdf(e->wo);
+        e->weight = vscale(bsdf_albedo(s, b, e), weight);
+        e->sampled = TGHIP_LOBE_DIFFUSE_T;
+        return 1;
+    }
+    case TGHIP_BSDF_PHONG: { /* PhongBsdf.cpp:39-77 */
+        int evalGlossy = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0, evalDiffuse = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        if (!evalGlossy && !evalDiffuse) return 0;
+        if (e->wi.z <= 0.0f) return 0;
+        int sampleGlossy;
+        if (evalGlossy && evalDiffuse)
+            sampleGlossy = nextBoolean(e->sampler, 1.0f - b->eta[1]);
+        else
+            sampleGlossy = evalGlossy;
+        if (sampleGlossy) {
+            float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+            float phi = xi0*O_TWO_PI;
+            float cosTheta = powf(xi1, b->k[0]);
+            float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta*cosTheta));
+            v3 woLocal = V(cosf(phi)*sinTheta, sinf(phi)*sinTheta, cosTheta);
+            Frame lobe = frame_from_normal(V(-e->wi.x, -e->wi.y, e->wi.z));
+            e->wo = toGlobal(&lobe, woLocal);
+            if (e->wo.z < 0.0f)
+                return 0;
+            e->sampled = TGHIP_LOBE_GLOSSY_R;
+        } else {
+            float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+            e->wo = cosineHemisphere(xi0, xi1);
+            e->sampled = TGHIP_LOBE_DIFFUSE_R;
+        }
+        e->pdf = bsdf_pdf(s, bi, e);
+        e->weight = vdivs(bsdf_eval(s, bi, e), e->pdf);
+        return 1;
+    }
+    case TGHIP_BSDF_THINSHEET: { /* ThinSheetBsdf.cpp:49-81 */
+        if (!(e->requested & TGHIP_LOBE_SPECULAR_R)) return 0;
+        e->wo = V(-e->wi.x, -e->wi.y, e->wi.z);
+        e->pdf = 1.0f;
+        e->sampled = TGHIP_LOBE_SPECULAR_R;
+        v3 sa = ld3(b->sigma_a);
+        const int absorbing = !(sa.x == 0.0f && sa.y == 0.0f && sa.z == 0.0f);
+        if (!absorbing && !b->enable_refraction) {
+            e->weight = vs(1.0f);                           /* "fast path / early out" */
+            return 1;
+        }
+        float thickness = texture_eval(s, b->tex1, e->u, e->v).x;
+        float cosThetaT;
+        if (b->enable_refraction)
+            e->weight = thinFilmReflectanceInterference(1.0f/b->ior, fabsf(e->wi.z), thickness*500.0f, &cosThetaT);
+        else
+            e->weight = vs(thinFilmReflectance(1.0f/b->ior, fabsf(e->wi.z), &cosThetaT));
+        v3 transmittance = V(1.0f - e->weight.x, 1.0f - e->weight.y, 1.0f - e->weight.z);
+        if (absorbing && cosThetaT > 0.0f)
+            transmittance = vmul(transmittance, vexp(vscale(vneg(sa), thickness*2.0f/cosThetaT)));
+        e->weight = vdivs(e->weight, 1.0f - vavg(transmittance));
+        return 1;
+    }
+    case TGHIP_BSDF_OREN_NAYAR: { /* OrenNayarBsdf.cpp:41-59 */
+        if (!(e->requested & TGHIP_LOBE_DIFFUSE_R)) return 0;
+        if (e->wi.z <= 0.0f) return 0;
+        float roughness = bsdf_roughness(s, b, e);
+        float ratio = fminf(fmaxf(roughness, 0.01f), 1.0f);       /* clamp(val, 0.01f, 1.0f) */
+        if (nextBoolean(e->sampler, ratio)) {
+            float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+            e->wo = uniformHemisphere(xi0, xi1);
+        } else {
+            float xi0 = next1D(e->sampler), xi1 = next1D(e->sampler);
+            e->wo = cosineHemisphere(xi0, xi1);
+        }
+        e->pdf = O_INV_TWO_PI*ratio + cosineHemispherePdf(e->wo)*(1.0f - ratio);
+        e->weight = vdivs(bsdf_eval(s, bi, e), e->pdf);
+        e->sampled = TGHIP_LOBE_DIFFUSE_R;
+        return e->wo.z > 0.0f;
+    }
+    case TGHIP_BSDF_ROUGH_COAT: { /* RoughCoatBsdf.cpp:82-159 */
+        if (e->wi.z <= 0.0f) return 0;
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & s->bsdfs[b->sub0].lobes) != 0;
+        if (!sampleR && !sampleT) return 0;
+        v3 wi = e->wi;
+        float eta = 1.0f/b->ior;
+        float cosThetaTi;
+        float Fi = dielectricReflectanceT(eta, wi.z, &cosThetaTi);
+        float substrateWeight = b->avg_transmittance*(1.0f - Fi);
+        float specularWeight = Fi;
+        float specularProbability = specularWeight/(specularWeight + substrateWeight);
+        v3 ssa = ld3(b->scaled_sigma_a);
+        if (sampleR && (nextBoolean(e->sampler, specularProbability) || !sampleT)) {
+            float roughness = bsdf_roughness(s, b, e);
+            if (!rd_sampleBase(e, 1, 0, roughness, b->ior, b->distribution))
+                return 0;
+            if (sampleT) {
+                v3 brdfSpecular = vscale(e->weight, e->pdf);
+                float pdfSpecular = e->pdf*specularProbability;
+                /* substrateEvalAndPdf (:58-80) */
+                v3 brdfSubstrate; float pdfSubstrate;
+                float cosThetaTo;
+                float Fo = dielectricReflectanceT(eta, e->wo.z, &cosThetaTo);
+                if (Fi == 1.0f || Fo == 1.0f) {
+                    pdfSubstrate = 0.0f;
+                    brdfSubstrate = vs(0.0f);
+                } else {
+                    Event q = *e;
+                    q.wi = V(wi.x*eta, wi.y*eta, copysignf(cosThetaTi, wi.z));
+                    q.wo = V(e->wo.x*eta, e->wo.y*eta, copysignf(cosThetaTo, e->wo.z));
+                    pdfSubstrate = bsdf_pdf(s, b->sub0, &q);
+                    pdfSubstrate *= eta*eta*fabsf(e->wo.z/cosThetaTo);
+                    float compressionProjection = eta*eta*e->wo.z/cosThetaTo;
+                    v3 substrateF = bsdf_eval(s, b->sub0, &q);
+                    if (vmax3(ssa) > 0.0f)
+                        substrateF = vmul(substrateF, vexp(vscale(ssa, -1.0f/cosThetaTo - 1.0f/cosThetaTi)));
+                    brdfSubstrate = vscale(substrateF, compressionProjection*(1.0f - Fi)*(1.0f - Fo));
+                }
+                pdfSubstrate *= 1.0f - specularProbability;
+                e->weight = vdivs(vadd(brdfSpecular, brdfSubstrate), pdfSpecular + pdfSubstrate);
+                e->pdf = pdfSpecular + pdfSubstrate;
+            }
+            return 1;
+        } else {
+            v3 originalWi = wi;
+            v3 wiSubstrate = V(wi.x*eta, wi.y*eta, cosThetaTi);
+            e->wi = wiSubstrate;
+            int success = bsdf_sample(s, b->sub0, e);
+            e->wi = originalWi;
+            if (!success) return 0;
+            float cosThetaTo;
+            float Fo = dielectricReflectanceT(b->ior, e->wo.z, &cosThetaTo);
+            if (Fo == 1.0f) return 0;
+            float cosThetaSubstrate = e->wo.z;
+            e->wo = V(e->wo.x*b->ior, e->wo.y*b->ior, cosThetaTo);
+            e->weight = vscale(e->weight, (1.0f - Fi)*(1.0f - Fo));
+            if (vmax3(ssa) > 0.0f)
+                e->weight = vmul(e->weight, vexp(vscale(ssa, -1.0f/cosThetaSubstrate - 1.0f/cosThetaTi)));
+            e->weight = vscale(e->weight, originalWi.z/wiSubstrate.z);
+            e->pdf *= eta*eta*cosThetaTo/cosThetaSubstrate;
+            if (sampleR) {
+                v3 brdfSubstrate = vscale(e->weight, e->pdf);
+                float pdfSubstrate = e->pdf*(1.0f - specularProbability);
+                float r = bsdf_roughness(s, b, e);
+                v3 brdfSpecular = rd_evalBase(e, 1, 0, r, b->ior, b->distribution);
+                float pdfSpecular = rd_pdfBase(e, 1, 0, r, b->ior, b->distribution);
+                pdfSpecular *= specularProbability;
+                e->weight = vdivs(vadd(brdfSpecular, brdfSubstrate), pdfSpecular + pdfSubstrate);
+                e->pdf = pdfSpecular + pdfSubstrate;
+            }
+        }
+        return 1;
+    }
     case TGHIP_BSDF_TRANSPARENCY: /* TransparencyBsdf.cpp:43-46 */
         return bsdf_sample(s, b->sub0, e);
     }
@@ -1100,6 +1400,70 @@ static float bsdf_pdf(const TgHipSceneDesc *s, int bi, const Event *e)
         float ratio;
         if (!mixed_adjustedRatio(s, b, e, &ratio)) return 0.0f;
         return bsdf_pdf(s, b->sub0, e)*ratio + bsdf_pdf(s, b->sub1, e)*(1.0f - ratio);
+    }
+    case TGHIP_BSDF_DIFFUSE_TRANSMISSION: { /* DiffuseTransmissionBsdf.cpp:77-88 */
+        int sampleR = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0, sampleT = (e->requested & TGHIP_LOBE_DIFFUSE_T) != 0;
+        if (!sampleR && !sampleT) return 0.0f;
+        float transmittanceProbability = sampleR && sampleT ? b->eta[0] : (sampleR ? 0.0f : 1.0f);
+        float factor = e->wi.z*e->wo.z < 0.0f ? transmittanceProbability : 1.0f - transmittanceProbability;
+        return factor*cosineHemispherePdf(e->wo);
+    }
+    case TGHIP_BSDF_PHONG: { /* PhongBsdf.cpp:101-124 */
+        int evalGlossy = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0, evalDiffuse = (e->requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+        if (!evalGlossy && !evalDiffuse) return 0.0f;
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+        float result = 0.0f;
+        if (evalGlossy) {
+            float cosTheta = vdot(V(-e->wi.x, -e->wi.y, e->wi.z), e->wo);
+            if (cosTheta > 0.0f)
+                result += powf(cosTheta, b->eta[0])*b->k[1];
+        }
+        if (evalDiffuse && evalGlossy)
+            result = result*(1.0f - b->eta[1]) + b->eta[1]*cosineHemispherePdf(e->wo);
+        else if (evalDiffuse)
+            result = cosineHemispherePdf(e->wo);
+        return result;
+    }
+    case TGHIP_BSDF_THINSHEET: /* ThinSheetBsdf.cpp:112-119 */
+        return ((e->requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e->wi, e->wo)) ? 1.0f : 0.0f;
+    case TGHIP_BSDF_OREN_NAYAR: { /* OrenNayarBsdf.cpp:125-135 */
+        if (!(e->requested & TGHIP_LOBE_DIFFUSE_R)) return 0.0f;
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+        float ratio = fminf(fmaxf(bsdf_roughness(s, b, e), 0.01f), 1.0f);
+        return O_INV_TWO_PI*ratio + cosineHemispherePdf(e->wo)*(1.0f - ratio);
+    }
+    case TGHIP_BSDF_ROUGH_COAT: { /* RoughCoatBsdf.cpp:259-298 */
+        int sampleR = (e->requested & TGHIP_LOBE_GLOSSY_R) != 0;
+        int sampleT = (e->requested & s->bsdfs[b->sub0].lobes) != 0;
+        if (!sampleT && !sampleR) return 0.0f;
+        if (e->wi.z <= 0.0f || e->wo.z <= 0.0f) return 0.0f;
+        v3 wi = e->wi, wo = e->wo;
+        float eta = 1.0f/b->ior;
+        float cosThetaTi, cosThetaTo;
+        float Fi = dielectricReflectanceT(eta, wi.z, &cosThetaTi);
+        float Fo = dielectricReflectanceT(eta, wo.z, &cosThetaTo);
+        float specularProbability;
+        if (sampleR && sampleT) {
+            float substrateWeight = b->avg_transmittance*(1.0f - Fi);
+            float specularWeight = Fi;
+            specularProbability = specularWeight/(specularWeight + substrateWeight);
+        } else {
+            specularProbability = sampleR ? 1.0f : 0.0f;
+        }
+        float glossyPdf = 0.0f;
+        if (sampleR)
+            glossyPdf = rd_pdfBase(e, 1, 0, bsdf_roughness(s, b, e), b->ior, b->distribution);
+        float substratePdf = 0.0f;
+        if (sampleT) {
+            if (Fi < 1.0f && Fo < 1.0f) {
+                Event q = *e;
+                q.wi = V(wi.x*eta, wi.y*eta, copysignf(cosThetaTi, wi.z));
+                q.wo = V(wo.x*eta, wo.y*eta, copysignf(cosThetaTo, wo.z));
+                substratePdf = bsdf_pdf(s, b->sub0, &q);
+                substratePdf *= eta*eta*fabsf(wo.z/cosThetaTo);
+            }
+        }
+        return glossyPdf*specularProbability + substratePdf*(1.0f - specularProbability);
     }
     case TGHIP_BSDF_TRANSPARENCY:
         return bsdf_pdf(s, b->sub0, e);

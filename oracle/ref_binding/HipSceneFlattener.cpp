@@ -65,6 +65,11 @@
 #include "bsdfs/TransparencyBsdf.hpp"
 #include "bsdfs/ForwardBsdf.hpp"
 #include "bsdfs/ErrorBsdf.hpp"
+#include "bsdfs/DiffuseTransmissionBsdf.hpp"
+#include "bsdfs/PhongBsdf.hpp"
+#include "bsdfs/ThinSheetBsdf.hpp"
+#include "bsdfs/OrenNayarBsdf.hpp"
+#include "bsdfs/RoughCoatBsdf.hpp"
 #include "textures/ConstantTexture.hpp"
 #include "textures/CheckerTexture.hpp"
 #include "textures/BitmapTexture.hpp"
@@ -255,6 +260,30 @@ int32_t HipSceneFlattener::addBsdf(const Bsdf *b)
         d.type = TGHIP_BSDF_TRANSPARENCY;
         d.sub0 = addBsdf(c->_base.get());
         d.tex1 = addTexture(c->_opacity.get());
+    } else if (const DiffuseTransmissionBsdf *c = dynamic_cast<const DiffuseTransmissionBsdf *>(b)) {
+        d.type = TGHIP_BSDF_DIFFUSE_TRANSMISSION;
+        d.eta[0] = c->_transmittance; d.eta[1] = d.eta[2] = 0.0f;
+        d.k[0] = d.k[1] = d.k[2] = 0.0f;
+    } else if (const PhongBsdf *c = dynamic_cast<const PhongBsdf *>(b)) {
+        d.type = TGHIP_BSDF_PHONG;
+        d.eta[0] = c->_exponent; d.eta[1] = c->_diffuseRatio; d.eta[2] = 0.0f;
+        d.k[0] = c->_invExponent; d.k[1] = c->_pdfFactor; d.k[2] = c->_brdfFactor;
+    } else if (const ThinSheetBsdf *c = dynamic_cast<const ThinSheetBsdf *>(b)) {
+        d.type = TGHIP_BSDF_THINSHEET;
+        d.ior = c->_ior; d.enable_refraction = c->_enableInterference ? 1 : 0;
+        d.tex1 = addTexture(c->_thickness.get());
+        copy3(d.sigma_a, c->_sigmaA);
+    } else if (const OrenNayarBsdf *c = dynamic_cast<const OrenNayarBsdf *>(b)) {
+        d.type = TGHIP_BSDF_OREN_NAYAR;
+        d.roughness = addTexture(c->_roughness.get());
+    } else if (const RoughCoatBsdf *c = dynamic_cast<const RoughCoatBsdf *>(b)) {
+        d.type = TGHIP_BSDF_ROUGH_COAT;
+        d.distribution = distributionOf(c->_distribution);
+        d.roughness = addTexture(c->_roughness.get());
+        d.ior = c->_ior; d.thickness = c->_thickness;
+        d.avg_transmittance = c->_avgTransmittance;
+        copy3(d.sigma_a, c->_sigmaA); copy3(d.scaled_sigma_a, c->_scaledSigmaA);
+        d.sub0 = addBsdf(c->_substrate.get());
     } else if (dynamic_cast<const ForwardBsdf *>(b)) {
         d.type = TGHIP_BSDF_FORWARD;
     } else if (dynamic_cast<const ErrorBsdf *>(b)) {

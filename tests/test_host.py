@@ -70,7 +70,7 @@ def test_cornell_flattening(tmp_path):
     flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(64, 36), spp=4))
     d = flat.desc.contents
     assert (flat.width, flat.height) == (64, 36)
-    assert d.abi_version == 8
+    assert d.abi_version == 9
     assert d.num_objects == 8 and d.num_lights == 1 and d.num_infinite_lights == 0
     assert d.num_recs == 8                       # 6 quads + 2 cubes, analytic records (Quad.cpp / Cube.cpp)
     light = d.objects[d.lights[0]]

@@ -112,6 +112,18 @@ def main():
     tmp = tempfile.mkdtemp(prefix="tg_golden_")
     g = lambda n: os.path.join(scenes.GOLDEN, n)
     try:
+        if len(sys.argv) > 1:
+            # python tools/make_golden.py case ...: the per-sample goldens of the named cases only (and the unit answers of named zoo scenes)
+            for name in sys.argv[1:]:
+                mk, kw = scenes.GOLDEN_CASES[name] if name in scenes.GOLDEN_CASES else scenes.LIFTED_CASES[name]
+                p = mk(tmp, name=name + ".json", **kw)
+                with open(p) as f:
+                    sc = json.load(f)
+                w, h = sc["camera"]["resolution"]
+                samples(p, w, h, sc["renderer"]["spp"], g(name + "_samples.npz"))
+                if name in scenes.ZOO:
+                    units(scenes.cornell_zoo(tmp, name, name="u_%s.json" % name, resolution=(96, 54), spp=1), g(name + "_units.json"))
+            return
         for name, (mk, kw) in list(scenes.GOLDEN_CASES.items()) + list(scenes.LIFTED_CASES.items()):
             p = mk(tmp, name=name + ".json", **kw)
             with open(p) as f:
@@ -122,7 +134,7 @@ def main():
             integrate(mk(tmp, name=name + ".json", **kw), g(name + "_integrate.npz"))
         units(scenes.cornell(tmp, name="u_cornell.json", resolution=(96, 54), spp=1), g("cornell_units.json"))
         units(scenes.materialtest(tmp, name="u_materialtest.json", resolution=(96, 54), spp=1), g("materialtest_units.json"))
-        for which in ("zoo_a", "zoo_b", "zoo_c", "zoo_d"):
+        for which in ("zoo_a", "zoo_b", "zoo_c", "zoo_d", "zoo_e", "zoo_f"):
             units(scenes.cornell_zoo(tmp, which, name="u_%s.json" % which, resolution=(96, 54), spp=1), g(which + "_units.json"))
         converged(scenes.cornell(tmp, name="c_cornell.json", resolution=(64, 36), spp=4096), 4096, g("cornell_converged.npz"), tmp)
         converged(scenes.materialtest(tmp, name="c_materialtest.json", resolution=(64, 36), spp=1024), 1024,

@@ -423,6 +423,22 @@ void Bsdf::prepareForRender()
     case Transparency:    lobes = FWD | sub0->lobes; break;
     case Forward:         lobes = FWD; break;
     case Error:           lobes = DR; break;
+    case DiffuseTransmission:   // DiffuseTransmissionBsdf.cpp:15-19: _transmittance = 0.5 (no JSON key reads it); TgHipBsdf::eta[0]
+        lobes = DT | DR;
+        eta = Vec3f(0.5f, 0.0f, 0.0f); k = Vec3f(0.0f);
+        break;
+    case Phong:           // PhongBsdf.cpp:126-132; TgHipBsdf: eta = {exponent, diffuse ratio, -}, k = {_invExponent, _pdfFactor, _brdfFactor}
+        lobes = GR | DR;
+        eta = Vec3f(exponent, diffuseRatio, 0.0f);
+        k = Vec3f(1.0f/(1.0f + exponent), (exponent + 1.0f)*INV_TWO_PI, (exponent + 2.0f)*INV_TWO_PI);
+        break;
+    case ThinSheet:       lobes = SR | FWD; break;       // ThinSheetBsdf.cpp:20-27 (enableRefraction carries _enableInterference, tex1 the thickness)
+    case OrenNayar:       lobes = DR; break;             // OrenNayarBsdf.cpp:18-22
+    case RoughCoat:       // RoughCoatBsdf.cpp:300-305
+        scaledSigmaA = thickness*sigmaA;
+        avgTransmittance = std::exp(-2.0f*scaledSigmaA.avg());
+        lobes = GR | sub0->lobes;
+        break;
     }
 }
 
@@ -580,6 +596,41 @@ std::shared_ptr<Bsdf> Scene::instantiateBsdf(const JsonValue &v) const
         b->sub1 = fetchBsdf(v["bsdf1"]);
         if (const JsonValue &r = v["ratio"]) b->tex1 = fetchTexture(r, false);
         else b->tex1 = constantTexture(0.5f);
+    } else if (type == "diffuse_transmission") {   // DiffuseTransmissionBsdf.cpp (no fromJson of its own)
+        b->type = Bsdf::DiffuseTransmission;
+    } else if (type == "phong") {                  // PhongBsdf.cpp:24-29
+        b->type = Bsdf::Phong;
+        v.getField("exponent", b->exponent);
+        v.getField("diffuse_ratio", b->diffuseRatio);
+    } else if (type == "thinsheet") {              // ThinSheetBsdf.cpp:29-37
+        b->type = Bsdf::ThinSheet;
+        b->enableRefraction = false;               // _enableInterference
+        v.getField("ior", b->ior);
+        v.getField("enable_interference", b->enableRefraction);
+        getVec3(v, "sigma_a", b->sigmaA);
+        if (const JsonValue &t = v["thickness"]) b->tex1 = fetchTexture(t, false);
+        else b->tex1 = constantTexture(0.5f);
+    } else if (type == "oren_nayar") {             // OrenNayarBsdf.cpp:24-30
+        b->type = Bsdf::OrenNayar;
+        if (const JsonValue &r = v["roughness"]) b->roughness = fetchTexture(r, false);
+        else b->roughness = constantTexture(1.0f);
+    } else if (type == "rough_coat") {             // RoughCoatBsdf.cpp:26-35
+        b->type = Bsdf::RoughCoat;
+        b->ior = 1.3f;
+        v.getField("ior", b->ior);
+        v.getField("thickness", b->thickness);
+        getVec3(v, "sigma_a", b->sigmaA);
+        b->distribution = parseDistribution(v, 2);
+        if (const JsonValue &r = v["roughness"]) b->roughness = fetchTexture(r, false);
+        else b->roughness = constantTexture(0.02f);
+        if (const JsonValue &sub = v["substrate"]) {
+            b->sub0 = fetchBsdf(sub);
+        } else {
+            b->sub0 = std::make_shared<Bsdf>();
+            b->sub0->type = Bsdf::RoughConductor;
+            b->sub0->albedo = constantTexture(1.0f);
+            b->sub0->roughness = constantTexture(0.1f);
+        }
     } else if (type == "transparency") {
         b->type = Bsdf::Transparency;
         if (const JsonValue &base = v["base"]) b->sub0 = fetchBsdf(base);

@@ -55,7 +55,7 @@ struct Bsdf
 {
     enum Type { Lambert = 0, Null = 1, RoughConductor = 2, SmoothCoat = 3, Dielectric = 4, RoughDielectric = 5,
                 Mirror = 6, Conductor = 7, Plastic = 8, RoughPlastic = 9, Mixed = 10, Transparency = 11,
-                Forward = 12, Error = 13 };
+                Forward = 12, Error = 13, DiffuseTransmission = 14, Phong = 15, ThinSheet = 16, OrenNayar = 17, RoughCoat = 18 };
     std::string name;
     Type type = Lambert;
     unsigned lobes = 0;
@@ -68,6 +68,7 @@ struct Bsdf
     Vec3f eta = Vec3f(0.200438f, 0.924033f, 1.10221f), k = Vec3f(3.91295f, 2.45285f, 2.14219f);
     Vec3f sigmaA = Vec3f(0.0f), scaledSigmaA = Vec3f(0.0f);
     float avgTransmittance = 1.0f, diffuseFresnel = 0.0f;
+    float exponent = 64.0f, diffuseRatio = 0.2f;   // PhongBsdf (PhongBsdf.hpp: defaults of its constructor)
     bool prepared = false;
 
     bool unnamed() const { return name.empty(); }
