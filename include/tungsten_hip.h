@@ -487,7 +487,7 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
  * rcppsIntel).  The GPU tests compare y with the host libm / the oracle's restatement bit for bit. */
 enum { TGHIP_LIBM_SINF = 0, TGHIP_LIBM_COSF = 1, TGHIP_LIBM_LOGF = 2, TGHIP_LIBM_EXPF = 3, TGHIP_LIBM_SINCOS_SIN = 4, TGHIP_LIBM_SINCOS_COS = 5,
        TGHIP_LIBM_ACOSF = 6, TGHIP_LIBM_ATAN2F = 7, TGHIP_LIBM_POWF = 8, TGHIP_LIBM_CBRTF = 9,
-       TGHIP_LIBM_EMBREE_RCP = 10, TGHIP_LIBM_RCPPS = 11 };
+       TGHIP_LIBM_EMBREE_RCP = 10, TGHIP_LIBM_RCPPS = 11, TGHIP_LIBM_TANF = 12 };
 int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);

@@ -20,6 +20,7 @@ extern "C" void libm_host_eval(int fn, const float *x, float *y, size_t n)
         case 3: y[i] = ptlibm::expfAll(x[i]); break;
         case 7: y[i] = ptlibm::atanfCore(x[i]); break;
         case 8: y[i] = ptlibm::cbrtfCore(x[i]); break;
+        case 12: y[i] = ptlibm::tanfCore(x[i]); break;
         case 4: case 5:
             if (ptlibm::sincosInRange(x[i])) { ptlibm::sincosfCore(x[i], s, c); y[i] = fn == 4 ? s : c; } else y[i] = nan;
             break;
@@ -41,7 +42,7 @@ extern "C" void libm_host_ref(int fn, const float *x, float *y, size_t n)
     }
     for (size_t i = 0; i < n; ++i)
         y[i] = fn == 0 || fn == 4 ? sinf(x[i]) : fn == 1 || fn == 5 ? cosf(x[i]) : fn == 2 ? logf(x[i]) : fn == 3 ? expf(x[i]) : fn == 7 ? atanf(x[i])
-             : fn == 8 ? cbrtf(x[i]) : acosf(x[i]);
+             : fn == 8 ? cbrtf(x[i]) : fn == 12 ? tanf(x[i]) : acosf(x[i]);
 }
 
 // every stride-th float in [lo, hi] (as bit patterns, sign bit as given) against the host libm: returns the number of mismatches
@@ -62,6 +63,7 @@ extern "C" unsigned long long libm_host_sweep(int fn, unsigned int lo, unsigned 
         case 3: got = ptlibm::expfAll(x); want = expf(x); if (got != got && want != want) continue; break;
         case 7: got = ptlibm::atanfCore(x); want = atanf(x); if (got != got && want != want) continue; break;
         case 8: got = ptlibm::cbrtfCore(x); want = cbrtf(x); if (got != got && want != want) continue; break;
+        case 12: { if ((u & 0x7fffffffu) > 0x3f490fdau && !ptlibm::sincosInRange(x)) continue; got = ptlibm::tanfCore(x); want = tanf(x); if (got != got && want != want) continue; break; }
         case 4: if (!ptlibm::sincosInRange(x)) continue; ptlibm::sincosfCore(x, got, t); want = sinf(x); break;
         default: if (!ptlibm::sincosInRange(x)) continue; ptlibm::sincosfCore(x, t, got); want = cosf(x); break;
         }

@@ -79,6 +79,14 @@ def test_device_libm_is_the_host_libm_bit_for_bit(tmp_path):
         host.libm_host_ref(8, x.ctypes.data, want.ctypes.data, x.size)
         bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
         assert not bad.any(), "cbrtf: %d of %d differ, first x = %r: device %r, host %r" % (int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
+    # tanf (the Oren-Nayar BSDF's tan(beta), tan((alpha + beta)/2): angles in [0, pi/2]; restated for |x| < 120 -- host id 12)
+    for x in (xi*np.float32(1.5707964), grid*np.float32(1.5707964), d1*np.float32(3.0), d1*np.float32(100.0), xi*np.float32(1e-5), np.float32(1.5707964) - xi*np.float32(1e-3)):
+        x = np.ascontiguousarray(x, np.float32)
+        got = r.debug_libm(capi.TGHIP_LIBM_TANF, x)
+        want = np.empty_like(x)
+        host.libm_host_ref(12, x.ctypes.data, want.ctypes.data, x.size)
+        bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
+        assert not bad.any(), "tanf: %d of %d differ, first x = %r: device %r, host %r" % (int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
     # Embree's rcp() of its triangle test (pt_scene.h: rcppsIntel / embreeRcp) against the oracle's restatement (oracle.c: intel_rcpps / embree_rcp,
     # itself held to the instruction by tests/test_host.py): every exponent x every table index x low mantissa bits, both signs, random patterns
     import oracle_lib

@@ -533,11 +533,11 @@ def _libm_host():
 
 
 def test_libm_restatements_match_the_host_libm():
-    """csrc/hip/pt_libm.h -- glibc's sinf / cosf / logf / expf (and atanf / atan2f / powf / cbrtf) restated for the kernels -- compiled for the host (oracle/libm_host.cpp) against
+    """csrc/hip/pt_libm.h -- glibc's sinf / cosf / logf / expf (and atanf / atan2f / powf / cbrtf / tanf) restated for the kernels -- compiled for the host (oracle/libm_host.cpp) against
     the image's libm, bit for bit: every 5th float of either sign (the full sweep, stride 1, is `python tools/libm_sweep.py`: zero
     mismatches over all 2^32 bit patterns inside the functions' ranges), and the array entry points the GPU test uses."""
     lib = _libm_host()
-    for fn in (0, 1, 2, 3, 4, 5, 7, 8):           # sinf, cosf, logf, expf, sincos (sin), sincos (cos), atanf, cbrtf
+    for fn in (0, 1, 2, 3, 4, 5, 7, 8, 12):       # sinf, cosf, logf, expf, sincos (sin), sincos (cos), atanf, cbrtf, tanf (|x| < 120)
         for lo, hi in ((0x00000000, 0x7F800000), (0x80000000, 0xFF800000)):
             assert lib.libm_host_sweep(fn, lo + fn, hi, 5) == 0, (fn, hex(lo))
     # the two-argument ones: atan2f and powf on 2 x 10^7 pseudo-random pairs each

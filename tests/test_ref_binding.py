@@ -90,6 +90,8 @@ CASES = {
     "materialtest": lambda tmp: scenes.materialtest(tmp, resolution=(160, 90), spp=4),
     "zoo_a": lambda tmp: scenes.GOLDEN_CASES["zoo_a"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_a"][1], resolution=(96, 54), spp=2)),
     "zoo_b": lambda tmp: scenes.GOLDEN_CASES["zoo_b"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_b"][1], resolution=(96, 54), spp=2)),
+    "zoo_e": lambda tmp: scenes.GOLDEN_CASES["zoo_e"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_e"][1], resolution=(96, 54), spp=2)),
+    "zoo_f": lambda tmp: scenes.GOLDEN_CASES["zoo_f"][0](tmp, **dict(scenes.GOLDEN_CASES["zoo_f"][1], resolution=(96, 54), spp=2)),
     # the procedural sky: the reference-side flattener hands over the image Tungsten's own Skydome baked, the own loader bakes it itself
     # bump-mapped bsdfs sharing one .png at several scales: the reference's TextureCache decides which scale serves them all
     "bump": lambda tmp: scenes.GOLDEN_CASES["cornell_bump"][0](tmp, **dict(scenes.GOLDEN_CASES["cornell_bump"][1], resolution=(96, 54), spp=2)),
@@ -105,7 +107,7 @@ for _name in ("cornell_disks", "cornell_cylinders", "cornell_point_lights", "cor
               "cornell_thinlens_pivot", "cornell_thinlens_bitmap", "cornell_instances"):
     CASES[_name] = (lambda n: lambda tmp: scenes.GOLDEN_CASES[n][0](tmp, **dict(scenes.GOLDEN_CASES[n][1], resolution=(96, 54), spp=2)))(_name)
 WIDENED = ["cornell_disks", "cornell_cylinders", "cornell_point_lights", "cornell_sun_sky", "cornell_mesh_light", "cornell_fog_smoke_sobol", "volumetric_caustic",
-           "non_exponential_pulse", "cornell_thinlens_blade5", "cornell_thinlens_cateye", "cornell_instances"]
+           "non_exponential_pulse", "cornell_thinlens_blade5", "cornell_thinlens_cateye", "cornell_instances", "zoo_e"]
 
 
 @pytest.mark.parametrize("case", sorted(CASES))

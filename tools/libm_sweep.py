@@ -13,5 +13,5 @@ for fn, name in ((0, "atan2f"), (1, "powf")):
     tested = C.c_ulonglong(0)
     bad = lib.libm_host_sweep2(fn, 400000000, 1, C.byref(tested))
     print("%-12s mismatches: %d of %d pseudo-random pairs" % (name, bad, tested.value))
-for fn, name in ((0, "sinf"), (1, "cosf"), (2, "logf"), (3, "expf"), (4, "sincos: sin"), (5, "sincos: cos"), (7, "atanf"), (8, "cbrtf")):
+for fn, name in ((0, "sinf"), (1, "cosf"), (2, "logf"), (3, "expf"), (4, "sincos: sin"), (5, "sincos: cos"), (7, "atanf"), (8, "cbrtf"), (12, "tanf")):
     print("%-12s mismatches: %d (x >= 0), %d (x < 0)" % (name, lib.libm_host_sweep(fn, 0, 0x7F800000, 1), lib.libm_host_sweep(fn, 0x80000000, 0xFF800000, 1)))

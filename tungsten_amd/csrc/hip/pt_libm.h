@@ -304,6 +304,72 @@ PT_LIBM_FN float cbrtfCore(float x)
     return (f2u(x) >> 31) ? -scaled : scaled;
 }
 
+// ---- tanf: s_tanf.c + k_tanf.c (glibc 2.35: fdlibm's float kernel, no FMA variant) behind the double-precision quadrant reduction of
+// s_sincosf.h, head and tail handed to the kernel as two floats (read off the image's libm: `objdump -d libm.so.6`, tanf) -- the Oren-Nayar
+// BSDF's tan(beta) and tan((alpha + beta)/2) with 0 <= beta <= alpha <= pi/2 (OrenNayarBsdf.cpp:95).  |x| >= 120: NaN (no call site).
+PT_LIBM_FN float kernelTanf(float x, float y, int iy)
+{
+    const float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f, T4 = 8.8632395491e-03f,
+                T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f, T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f,
+                T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f, T12 = 2.5907305826e-05f;
+    const float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) {                          // |x| < 2^-13
+        if ((int)x == 0) {
+            if ((ix | (iy + 1)) == 0) return 1.0f/__builtin_fabsf(x);
+            else if (iy == 1) return x;
+            else return -1.0f/x;
+        }
+    }
+    if (ix >= 0x3f2ca140) {                         // |x| >= 0.6744
+        if (hx < 0) { x = -x; y = -y; }
+        const float z0 = pio4 - x;
+        const float w0 = pio4lo - y;
+        x = z0 + w0; y = 0.0f;
+        if (__builtin_fabsf(x) < 0x1p-13f)
+            return (float)(1 - ((hx >> 30) & 2))*(float)iy*(1.0f - 2.0f*(float)iy*x);
+    }
+    float z = x*x;
+    float w = z*z;
+    float r = T1 + w*(T3 + w*(T5 + w*(T7 + w*(T9 + w*T11))));
+    float v = z*(T2 + w*(T4 + w*(T6 + w*(T8 + w*(T10 + w*T12)))));
+    float s = z*x;
+    r = y + z*(s*(r + v) + y);
+    r += T0*s;
+    w = x + r;
+    if (ix >= 0x3f2ca140) {
+        v = (float)iy;
+        return (float)(1 - ((hx >> 30) & 2))*(v - 2.0f*(x - (w*w/(w + v) - r)));
+    }
+    if (iy == 1)
+        return w;
+    // -1/(x + r), accurately
+    z = u2f(f2u(w) & 0xfffff000u);
+    v = r - (z - x);
+    const float a = -1.0f/w;
+    const float t = u2f(f2u(a) & 0xfffff000u);
+    s = 1.0f + t*z;
+    return t + a*(s + t*v);
+}
+PT_LIBM_FN float tanfCore(float x)
+{
+    const int32_t hx = (int32_t)f2u(x);
+    const int32_t ix = hx & 0x7fffffff;
+    if (ix <= 0x3f490fda)                           // |x| <= pi/4
+        return kernelTanf(x, 0.0f, 1);
+    if (!sincosInRange(x))                          // |x| >= 120 (and inf / NaN): glibc's large-argument reduction is not restated
+        return u2f(0x7fc00000u);
+    // the quadrant reduction of s_sincosf.h (reduce_fast) in double, WITHOUT fusing (tanf has no FMA variant); head and tail as floats
+    const double hpiInv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double xd = (double)x;
+    const int n = ((int32_t)(xd*hpiInv) + 0x800000) >> 24;
+    const double y = xd - (double)n*hpi;
+    const float head = (float)y;
+    const float tail = (float)(y - (double)head);
+    return kernelTanf(head, tail, 1 - ((n & 1) << 1));
+}
+
 }  // namespace ptlibm
 
 #endif

@@ -111,6 +111,7 @@ PT_DEV float expfH(float x) { return ptlibm::expfAll(x); }
 PT_DEV float atan2fH(float y, float x) { return ptlibm::atan2fCore(y, x); }
 PT_DEV float powfH(float x, float y) { float r; return (ptlibm::powInRange(x, y) && ptlibm::powfCore(x, y, r)) ? r : powf(x, y); }
 PT_DEV float cbrtfH(float x) { return ptlibm::cbrtfCore(x); }
+PT_DEV float tanfH(float x) { return ptlibm::tanfCore(x); }      // |x| < 120 (OrenNayarBsdf: angles in [0, pi/2])
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 splat3(float s) { return mk3(s, s, s); }
@@ -263,6 +264,12 @@ PT_DEV f3 cosineHemisphere(float xi0, float xi1)
     return mk3(cosPhi*r, sinPhi*r, sqrtf(fmaxf(1.0f - xi1, 0.0f)));
 }
 PT_DEV float cosineHemispherePdf(f3 p) { return fabsf(p.z)*PT_INV_PI; }
+PT_DEV f3 uniformHemisphere(float xi0, float xi1)      /* SampleWarp.hpp:25-30 */
+{
+    float phi = PT_TWO_PI*xi0;
+    float r = sqrtf(fmaxf(1.0f - xi1*xi1, 0.0f));
+    return mk3(cosfH(phi)*r, sinfH(phi)*r, xi1);
+}
 PT_DEV f3 uniformSphere(float xi0, float xi1)
 {
     float phi = xi0*PT_TWO_PI;

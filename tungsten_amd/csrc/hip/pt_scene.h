@@ -248,6 +248,42 @@ PT_DEV float dielectricReflectance(float eta, float cosThetaI, float &cosThetaT)
     float Rp = (eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI);
     return (Rs*Rs + Rp*Rp)*0.5f;
 }
+// Fresnel::thinFilmReflectance / thinFilmReflectanceInterference (Fresnel.hpp:15-28, 39-67; `thickness` in nanometres)
+PT_DEV float thinFilmReflectance(float eta, float cosThetaI, float &cosThetaT)
+{
+    float sinThetaTSq = eta*eta*(1.0f - cosThetaI*cosThetaI);
+    if (sinThetaTSq > 1.0f) {
+        cosThetaT = 0.0f;
+        return 1.0f;
+    }
+    cosThetaT = sqrtf(fmaxf(1.0f - sinThetaTSq, 0.0f));
+    float Rs = sqr((eta*cosThetaI - cosThetaT)/(eta*cosThetaI + cosThetaT));
+    float Rp = sqr((eta*cosThetaT - cosThetaI)/(eta*cosThetaT + cosThetaI));
+    return 1.0f - ((1.0f - Rs)/(1.0f + Rs) + (1.0f - Rp)/(1.0f + Rp))*0.5f;
+}
+PT_DEV f3 thinFilmReflectanceInterference(float eta, float cosThetaI, float thickness, float &cosThetaT)
+{
+    const f3 invLambdas = mk3(1.0f/650.0f, 1.0f/510.0f, 1.0f/475.0f);
+    float cosThetaISq = cosThetaI*cosThetaI;
+    float sinThetaISq = 1.0f - cosThetaISq;
+    float invEta = 1.0f/eta;
+    float sinThetaTSq = eta*eta*sinThetaISq;
+    if (sinThetaTSq > 1.0f) {
+        cosThetaT = 0.0f;
+        return splat3(1.0f);
+    }
+    cosThetaT = sqrtf(1.0f - sinThetaTSq);
+    float Ts = 4.0f*eta*cosThetaI*cosThetaT/sqr(eta*cosThetaI + cosThetaT);
+    float Tp = 4.0f*eta*cosThetaI*cosThetaT/sqr(eta*cosThetaT + cosThetaI);
+    float Rs = 1.0f - Ts;
+    float Rp = 1.0f - Tp;
+    f3 phi = invLambdas*(thickness*cosThetaT*PT_FOUR_PI*invEta);
+    f3 cosPhi = mk3(cosfH(phi.x), cosfH(phi.y), cosfH(phi.z));
+    float a = sqr(Rs) + 1.0f, b2 = 2.0f*Rs, c = sqr(Rp) + 1.0f, d2 = 2.0f*Rp, ts = sqr(Ts), tp = sqr(Tp);
+    f3 tS = mk3(ts/(a - b2*cosPhi.x), ts/(a - b2*cosPhi.y), ts/(a - b2*cosPhi.z));
+    f3 tP = mk3(tp/(c - d2*cosPhi.x), tp/(c - d2*cosPhi.y), tp/(c - d2*cosPhi.z));
+    return mk3(1.0f - (tS.x + tP.x)*0.5f, 1.0f - (tS.y + tP.y)*0.5f, 1.0f - (tS.z + tP.z)*0.5f);
+}
 PT_DEV float dielectricReflectance(float eta, float cosThetaI) { float t; return dielectricReflectance(eta, cosThetaI, t); }
 
 PT_DEV float conductorReflectance1(float eta, float k, float cosThetaI)
@@ -584,6 +620,102 @@ struct BsdfOps {
             f3 f0 = Next::eval(s, b.sub0, e), f1 = Next::eval(s, b.sub1, e);
             return bsdfAlbedo<M>(s, b, e)*(f0*ratio + f1*(1.0f - ratio));
         }
+        case TGHIP_BSDF_DIFFUSE_TRANSMISSION: {                /* DiffuseTransmissionBsdf.cpp:50-57 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_DIFFUSE_TRANSMISSION))) return splat3(0.0f);
+            if (!(e.requested & TGHIP_LOBE_DIFFUSE_T)) return splat3(0.0f);
+            float factor = e.wi.z*e.wo.z < 0.0f ? b.eta[0] : 1.0f - b.eta[0];
+            return bsdfAlbedo<M>(s, b, e)*factor*PT_INV_PI*fabsf(e.wo.z);
+        }
+        case TGHIP_BSDF_PHONG: {                               /* PhongBsdf.cpp:79-99 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_PHONG))) return splat3(0.0f);
+            bool evalGlossy = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0, evalDiffuse = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+            if (!evalGlossy && !evalDiffuse) return splat3(0.0f);
+            if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
+            float result = 0.0f;
+            if (evalDiffuse)
+                result += b.eta[1]*PT_INV_PI;
+            if (evalGlossy) {
+                float cosTheta = dot(mk3(-e.wi.x, -e.wi.y, e.wi.z), e.wo);
+                if (cosTheta > 0.0f)
+                    result += powfH(cosTheta, b.eta[0])*b.k[2]*(1.0f - b.eta[1]);
+            }
+            return bsdfAlbedo<M>(s, b, e)*e.wo.z*result;
+        }
+        case TGHIP_BSDF_THINSHEET: {                           /* ThinSheetBsdf.cpp:83-104 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_THINSHEET))) return splat3(0.0f);
+            if (e.requested != TGHIP_LOBE_FORWARD || !isExactReverse(e.wi, e.wo))
+                return splat3(0.0f);
+            float thickness = textureEval<M>(s, b.tex1, e.u, e.v).x;
+            float cosThetaT;
+            f3 transmittance;
+            if (b.enable_refraction)                           /* _enableInterference */
+                transmittance = splat3(1.0f) - thinFilmReflectanceInterference(1.0f/b.ior, fabsf(e.wi.z), thickness*500.0f, cosThetaT);
+            else
+                transmittance = splat3(1.0f - thinFilmReflectance(1.0f/b.ior, fabsf(e.wi.z), cosThetaT));
+            f3 sa = ld3(b.sigma_a);
+            if (!(sa.x == 0.0f && sa.y == 0.0f && sa.z == 0.0f) && cosThetaT > 0.0f)
+                transmittance = transmittance*exp3((-sa)*(thickness*2.0f/cosThetaT));
+            return transmittance;
+        }
+        case TGHIP_BSDF_OREN_NAYAR: {                          /* OrenNayarBsdf.cpp:61-100 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_OREN_NAYAR))) return splat3(0.0f);
+            if (!(e.requested & TGHIP_LOBE_DIFFUSE_R)) return splat3(0.0f);
+            if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
+            const f3 wi = e.wi, wo = e.wo;
+            float thetaR = acosfExact(wo.z);
+            float thetaI = acosfExact(wi.z);
+            float alpha = thetaR > thetaI ? thetaR : thetaI;
+            float beta = thetaR < thetaI ? thetaR : thetaI;
+            float sinAlpha = sinfH(alpha);
+            float denom = (wi.x*wi.x + wi.y*wi.y)*(wo.x*wo.x + wo.y*wo.y);
+            float cosDeltaPhi;
+            if (denom == 0.0f)
+                cosDeltaPhi = 1.0f;
+            else
+                cosDeltaPhi = (wi.x*wo.x + wi.y*wo.y)/sqrtf(denom);
+            const float RoughnessToSigma = 1.0f/sqrtf(2.0f);
+            float sigma = RoughnessToSigma*bsdfRoughness<M>(s, b, e);
+            float sigmaSq = sigma*sigma;
+            float C1 = 1.0f - 0.5f*sigmaSq/(sigmaSq + 0.33f);
+            float C2 = 0.45f*sigmaSq/(sigmaSq + 0.09f);
+            if (cosDeltaPhi >= 0.0f) {
+                C2 *= sinAlpha;
+            } else {
+                float q = (2.0f*PT_INV_PI)*beta;
+                C2 *= sinAlpha - q*q*q;
+            }
+            float C3 = 0.125f*(sigmaSq/(sigmaSq + 0.09f))*sqr((4.0f*PT_INV_PI*PT_INV_PI)*alpha*beta);
+            float fr1 = (C1 + cosDeltaPhi*C2*tanfH(beta) + (1.0f - fabsf(cosDeltaPhi))*C3*tanfH(0.5f*(alpha + beta)));
+            float fr2 = 0.17f*sigmaSq/(sigmaSq + 0.13f)*(1.0f - cosDeltaPhi*sqr((2.0f*PT_INV_PI)*beta));
+            f3 diffuseAlbedo = bsdfAlbedo<M>(s, b, e);
+            return (diffuseAlbedo*fr1 + diffuseAlbedo*diffuseAlbedo*fr2)*wo.z*PT_INV_PI;
+        }
+        case TGHIP_BSDF_ROUGH_COAT: {                          /* RoughCoatBsdf.cpp:161-199 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_ROUGH_COAT))) return splat3(0.0f);
+            bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
+            bool sampleT = (e.requested & s.bsdfs[b.sub0].lobes) != 0;
+            if (!sampleT && !sampleR) return splat3(0.0f);
+            if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return splat3(0.0f);
+            f3 glossyR = splat3(0.0f);
+            if (sampleR)
+                glossyR = rdEvalBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution));
+            f3 substrateR = splat3(0.0f);
+            if (sampleT) {
+                float eta = 1.0f/b.ior;
+                float cosThetaTi, cosThetaTo;
+                float Fi = dielectricReflectance(eta, e.wi.z, cosThetaTi);
+                float Fo = dielectricReflectance(eta, e.wo.z, cosThetaTo);
+                if (Fi == 1.0f || Fo == 1.0f)
+                    return glossyR;
+                Event q = e;
+                q.wi = mk3(e.wi.x*eta, e.wi.y*eta, copysignf(cosThetaTi, e.wi.z));
+                q.wo = mk3(e.wo.x*eta, e.wo.y*eta, copysignf(cosThetaTo, e.wo.z));
+                float compressionProjection = eta*eta*e.wo.z/cosThetaTo;
+                f3 substrateF = absorb(b, Next::eval(s, b.sub0, q), cosThetaTo, cosThetaTi);
+                substrateR = substrateF*(compressionProjection*(1.0f - Fi)*(1.0f - Fo));
+            }
+            return glossyR + substrateR;
+        }
         case TGHIP_BSDF_TRANSPARENCY:                          /* TransparencyBsdf.cpp:48-54 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_TRANSPARENCY)))) return splat3(0.0f);
             if (e.requested == TGHIP_LOBE_FORWARD)
@@ -822,6 +954,153 @@ struct BsdfOps {
             e.weight = e.weight*bsdfAlbedo<M>(s, b, e);
             return true;
         }
+        case TGHIP_BSDF_DIFFUSE_TRANSMISSION: {                /* DiffuseTransmissionBsdf.cpp:29-48 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_DIFFUSE_TRANSMISSION))) return false;
+            bool sampleR = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0, sampleT = (e.requested & TGHIP_LOBE_DIFFUSE_T) != 0;
+            if (!sampleR && !sampleT) return false;
+            const float T = b.eta[0];
+            float transmittanceProbability = sampleR && sampleT ? T : (sampleR ? 0.0f : 1.0f);
+            bool transmit = rngNextBoolean(*e.rng, transmittanceProbability);
+            float weight = sampleR && sampleT ? 1.0f : (transmit ? T : 1.0f - T);
+            float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
+            e.wo = cosineHemisphere(xi0, xi1);
+            e.wo.z = copysignf(e.wo.z, e.wi.z);
+            if (transmit)
+                e.wo.z = -e.wo.z;
+            e.pdf = cosineHemispherePdf(e.wo);
+            e.weight = bsdfAlbedo<M>(s, b, e)*weight;
+            e.sampled = TGHIP_LOBE_DIFFUSE_T;
+            return true;
+        }
+        case TGHIP_BSDF_PHONG: {                               /* PhongBsdf.cpp:39-77 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_PHONG))) return false;
+            bool evalGlossy = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0, evalDiffuse = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+            if (!evalGlossy && !evalDiffuse) return false;
+            if (e.wi.z <= 0.0f) return false;
+            bool sampleGlossy;
+            if (evalGlossy && evalDiffuse)
+                sampleGlossy = rngNextBoolean(*e.rng, 1.0f - b.eta[1]);
+            else
+                sampleGlossy = evalGlossy;
+            float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
+            if (sampleGlossy) {
+                float phi = xi0*PT_TWO_PI;
+                float cosTheta = powfH(xi1, b.k[0]);
+                float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta*cosTheta));
+                f3 woLocal = mk3(cosfH(phi)*sinTheta, sinfH(phi)*sinTheta, cosTheta);
+                e.wo = toGlobal(frameFromNormal(mk3(-e.wi.x, -e.wi.y, e.wi.z)), woLocal);
+                if (e.wo.z < 0.0f)
+                    return false;
+                e.sampled = TGHIP_LOBE_GLOSSY_R;
+            } else {
+                e.wo = cosineHemisphere(xi0, xi1);
+                e.sampled = TGHIP_LOBE_DIFFUSE_R;
+            }
+            e.pdf = pdf(s, bi, e);
+            e.weight = eval(s, bi, e)/e.pdf;
+            return true;
+        }
+        case TGHIP_BSDF_THINSHEET: {                           /* ThinSheetBsdf.cpp:49-81 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_THINSHEET))) return false;
+            if (!(e.requested & TGHIP_LOBE_SPECULAR_R)) return false;
+            e.wo = mk3(-e.wi.x, -e.wi.y, e.wi.z);
+            e.pdf = 1.0f;
+            e.sampled = TGHIP_LOBE_SPECULAR_R;
+            f3 sa = ld3(b.sigma_a);
+            const bool absorbing = !(sa.x == 0.0f && sa.y == 0.0f && sa.z == 0.0f);
+            if (!absorbing && !b.enable_refraction) {
+                e.weight = splat3(1.0f);
+                return true;
+            }
+            float thickness = textureEval<M>(s, b.tex1, e.u, e.v).x;
+            float cosThetaT;
+            if (b.enable_refraction)
+                e.weight = thinFilmReflectanceInterference(1.0f/b.ior, fabsf(e.wi.z), thickness*500.0f, cosThetaT);
+            else
+                e.weight = splat3(thinFilmReflectance(1.0f/b.ior, fabsf(e.wi.z), cosThetaT));
+            f3 transmittance = splat3(1.0f) - e.weight;
+            if (absorbing && cosThetaT > 0.0f)
+                transmittance = transmittance*exp3((-sa)*(thickness*2.0f/cosThetaT));
+            e.weight = e.weight/(1.0f - avg3(transmittance));
+            return true;
+        }
+        case TGHIP_BSDF_OREN_NAYAR: {                          /* OrenNayarBsdf.cpp:41-59 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_OREN_NAYAR))) return false;
+            if (!(e.requested & TGHIP_LOBE_DIFFUSE_R)) return false;
+            if (e.wi.z <= 0.0f) return false;
+            float ratio = fminf(fmaxf(bsdfRoughness<M>(s, b, e), 0.01f), 1.0f);
+            const bool uniform = rngNextBoolean(*e.rng, ratio);
+            float xi0 = RNG1D(*e.rng), xi1 = RNG1D(*e.rng);
+            e.wo = uniform ? uniformHemisphere(xi0, xi1) : cosineHemisphere(xi0, xi1);
+            e.pdf = PT_INV_TWO_PI*ratio + cosineHemispherePdf(e.wo)*(1.0f - ratio);
+            e.weight = eval(s, bi, e)/e.pdf;
+            e.sampled = TGHIP_LOBE_DIFFUSE_R;
+            return e.wo.z > 0.0f;
+        }
+        case TGHIP_BSDF_ROUGH_COAT: {                          /* RoughCoatBsdf.cpp:82-159 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_ROUGH_COAT))) return false;
+            if (e.wi.z <= 0.0f) return false;
+            bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
+            bool sampleT = (e.requested & s.bsdfs[b.sub0].lobes) != 0;
+            if (!sampleR && !sampleT) return false;
+            const f3 wi = e.wi;
+            float eta = 1.0f/b.ior;
+            float cosThetaTi;
+            float Fi = dielectricReflectance(eta, wi.z, cosThetaTi);
+            float substrateWeight = b.avg_transmittance*(1.0f - Fi);
+            float specularProbability = Fi/(Fi + substrateWeight);
+            if (sampleR && (rngNextBoolean(*e.rng, specularProbability) || !sampleT)) {
+                if (!rdSampleBase<M>(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution)))
+                    return false;
+                if (sampleT) {
+                    f3 brdfSpecular = e.weight*e.pdf;
+                    float pdfSpecular = e.pdf*specularProbability;
+                    f3 brdfSubstrate = splat3(0.0f);           /* substrateEvalAndPdf (:58-80) */
+                    float pdfSubstrate = 0.0f;
+                    float cosThetaTo;
+                    float Fo = dielectricReflectance(eta, e.wo.z, cosThetaTo);
+                    if (!(Fi == 1.0f || Fo == 1.0f)) {
+                        Event q = e;
+                        q.wi = mk3(wi.x*eta, wi.y*eta, copysignf(cosThetaTi, wi.z));
+                        q.wo = mk3(e.wo.x*eta, e.wo.y*eta, copysignf(cosThetaTo, e.wo.z));
+                        pdfSubstrate = Next::pdf(s, b.sub0, q);
+                        pdfSubstrate *= eta*eta*fabsf(e.wo.z/cosThetaTo);
+                        float compressionProjection = eta*eta*e.wo.z/cosThetaTo;
+                        f3 substrateF = absorb(b, Next::eval(s, b.sub0, q), cosThetaTo, cosThetaTi);
+                        brdfSubstrate = substrateF*(compressionProjection*(1.0f - Fi)*(1.0f - Fo));
+                    }
+                    pdfSubstrate *= 1.0f - specularProbability;
+                    e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+                    e.pdf = pdfSpecular + pdfSubstrate;
+                }
+                return true;
+            }
+            const f3 wiSubstrate = mk3(wi.x*eta, wi.y*eta, cosThetaTi);
+            e.wi = wiSubstrate;
+            bool success = Next::sample(s, b.sub0, e);
+            e.wi = wi;
+            if (!success) return false;
+            float cosThetaTo;
+            float Fo = dielectricReflectance(b.ior, e.wo.z, cosThetaTo);
+            if (Fo == 1.0f) return false;
+            float cosThetaSubstrate = e.wo.z;
+            e.wo = mk3(e.wo.x*b.ior, e.wo.y*b.ior, cosThetaTo);
+            e.weight = e.weight*((1.0f - Fi)*(1.0f - Fo));
+            e.weight = absorb(b, e.weight, cosThetaSubstrate, cosThetaTi);
+            e.weight = e.weight*(wi.z/wiSubstrate.z);
+            e.pdf *= eta*eta*cosThetaTo/cosThetaSubstrate;
+            if (sampleR) {
+                f3 brdfSubstrate = e.weight*e.pdf;
+                float pdfSubstrate = e.pdf*(1.0f - specularProbability);
+                float r = bsdfRoughness<M>(s, b, e);
+                f3 brdfSpecular = rdEvalBase(e, true, false, r, b.ior, mfDist<M>(b.distribution));
+                float pdfSpecular = rdPdfBase(e, true, false, r, b.ior, mfDist<M>(b.distribution));
+                pdfSpecular *= specularProbability;
+                e.weight = (brdfSpecular + brdfSubstrate)/(pdfSpecular + pdfSubstrate);
+                e.pdf = pdfSpecular + pdfSubstrate;
+            }
+            return true;
+        }
         case TGHIP_BSDF_TRANSPARENCY:                          /* TransparencyBsdf.cpp:43-46 */
             if (!(M & (BSDF_BIT(TGHIP_BSDF_TRANSPARENCY)))) return false;
             return Next::sample(s, b.sub0, e);
@@ -936,6 +1215,71 @@ struct BsdfOps {
             float ratio;
             if (!mixedRatio(s, b, e, ratio)) return 0.0f;
             return Next::pdf(s, b.sub0, e)*ratio + Next::pdf(s, b.sub1, e)*(1.0f - ratio);
+        }
+        case TGHIP_BSDF_DIFFUSE_TRANSMISSION: {                /* DiffuseTransmissionBsdf.cpp:77-88 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_DIFFUSE_TRANSMISSION))) return 0.0f;
+            bool sampleR = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0, sampleT = (e.requested & TGHIP_LOBE_DIFFUSE_T) != 0;
+            if (!sampleR && !sampleT) return 0.0f;
+            float transmittanceProbability = sampleR && sampleT ? b.eta[0] : (sampleR ? 0.0f : 1.0f);
+            float factor = e.wi.z*e.wo.z < 0.0f ? transmittanceProbability : 1.0f - transmittanceProbability;
+            return factor*cosineHemispherePdf(e.wo);
+        }
+        case TGHIP_BSDF_PHONG: {                               /* PhongBsdf.cpp:101-124 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_PHONG))) return 0.0f;
+            bool evalGlossy = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0, evalDiffuse = (e.requested & TGHIP_LOBE_DIFFUSE_R) != 0;
+            if (!evalGlossy && !evalDiffuse) return 0.0f;
+            if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+            float result = 0.0f;
+            if (evalGlossy) {
+                float cosTheta = dot(mk3(-e.wi.x, -e.wi.y, e.wi.z), e.wo);
+                if (cosTheta > 0.0f)
+                    result += powfH(cosTheta, b.eta[0])*b.k[1];
+            }
+            if (evalDiffuse && evalGlossy)
+                result = result*(1.0f - b.eta[1]) + b.eta[1]*cosineHemispherePdf(e.wo);
+            else if (evalDiffuse)
+                result = cosineHemispherePdf(e.wo);
+            return result;
+        }
+        case TGHIP_BSDF_THINSHEET:                             /* ThinSheetBsdf.cpp:112-119 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_THINSHEET))) return 0.0f;
+            return ((e.requested & TGHIP_LOBE_SPECULAR_R) && checkReflectionConstraint(e.wi, e.wo)) ? 1.0f : 0.0f;
+        case TGHIP_BSDF_OREN_NAYAR: {                          /* OrenNayarBsdf.cpp:125-135 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_OREN_NAYAR))) return 0.0f;
+            if (!(e.requested & TGHIP_LOBE_DIFFUSE_R)) return 0.0f;
+            if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+            float ratio = fminf(fmaxf(bsdfRoughness<M>(s, b, e), 0.01f), 1.0f);
+            return PT_INV_TWO_PI*ratio + cosineHemispherePdf(e.wo)*(1.0f - ratio);
+        }
+        case TGHIP_BSDF_ROUGH_COAT: {                          /* RoughCoatBsdf.cpp:259-298 */
+            if (!(M & BSDF_BIT(TGHIP_BSDF_ROUGH_COAT))) return 0.0f;
+            bool sampleR = (e.requested & TGHIP_LOBE_GLOSSY_R) != 0;
+            bool sampleT = (e.requested & s.bsdfs[b.sub0].lobes) != 0;
+            if (!sampleT && !sampleR) return 0.0f;
+            if (e.wi.z <= 0.0f || e.wo.z <= 0.0f) return 0.0f;
+            float eta = 1.0f/b.ior;
+            float cosThetaTi, cosThetaTo;
+            float Fi = dielectricReflectance(eta, e.wi.z, cosThetaTi);
+            float Fo = dielectricReflectance(eta, e.wo.z, cosThetaTo);
+            float specularProbability;
+            if (sampleR && sampleT) {
+                float substrateWeight = b.avg_transmittance*(1.0f - Fi);
+                specularProbability = Fi/(Fi + substrateWeight);
+            } else {
+                specularProbability = sampleR ? 1.0f : 0.0f;
+            }
+            float glossyPdf = 0.0f;
+            if (sampleR)
+                glossyPdf = rdPdfBase(e, true, false, bsdfRoughness<M>(s, b, e), b.ior, mfDist<M>(b.distribution));
+            float substratePdf = 0.0f;
+            if (sampleT && Fi < 1.0f && Fo < 1.0f) {
+                Event q = e;
+                q.wi = mk3(e.wi.x*eta, e.wi.y*eta, copysignf(cosThetaTi, e.wi.z));
+                q.wo = mk3(e.wo.x*eta, e.wo.y*eta, copysignf(cosThetaTo, e.wo.z));
+                substratePdf = Next::pdf(s, b.sub0, q);
+                substratePdf *= eta*eta*fabsf(e.wo.z/cosThetaTo);
+            }
+            return glossyPdf*specularProbability + substratePdf*(1.0f - specularProbability);
         }
         case TGHIP_BSDF_TRANSPARENCY:
             if (!(M & (BSDF_BIT(TGHIP_BSDF_TRANSPARENCY)))) return 0.0f;

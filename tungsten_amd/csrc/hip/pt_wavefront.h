@@ -71,7 +71,10 @@
    fog / smoke goldens: 216 VGPRs without scratch where BSDF_MASK_ALL spills 292 registers to 848 B of scratch.  (Always the FEAT_QMC twin:
    media passes carry PT_PASS_MEDIA in their flags.) */
 #define MASK_MEDIA   (MASK_SIMPLE | FEAT_MEDIA | FEAT_QMC | BSDF_BIT(TGHIP_BSDF_FORWARD) | BSDF_BIT(TGHIP_BSDF_DIELECTRIC) | BSDF_BIT(TGHIP_BSDF_MIRROR))
-#define MASK_TAIL    (MASK_FULL & ~(FEAT_INSTANCES | FEAT_MESHLIGHT))   /* k_tail: every BSDF type, single-level scenes without mesh emitters */
+/* the five types added last (ABI 9): only the full variants shade them; scenes that use one keep the loop to the end (no k_tail) */
+#define TYPES_LATE   (BSDF_BIT(TGHIP_BSDF_DIFFUSE_TRANSMISSION) | BSDF_BIT(TGHIP_BSDF_PHONG) | BSDF_BIT(TGHIP_BSDF_THINSHEET) | \
+                      BSDF_BIT(TGHIP_BSDF_OREN_NAYAR) | BSDF_BIT(TGHIP_BSDF_ROUGH_COAT))
+#define MASK_TAIL    (MASK_FULL & ~(FEAT_INSTANCES | FEAT_MESHLIGHT | TYPES_LATE))   /* k_tail: the 14 BSDF types of rounds 1-3, single-level scenes without mesh emitters */
 /* the class variants of scenes with instance records (no mesh emitters): hits reached through an instance (FEAT_INSTANCES) */
 #define MASK_COAT_INST    (MASK_COAT | FEAT_INSTANCES)
 #define MASK_GLASS_INST   (MASK_GLASS | FEAT_INSTANCES)

@@ -278,7 +278,7 @@ static int bsdfDepth(const TgHipSceneDesc *s, int bi, int depth)
     if (bi < 0 || depth > 16) return depth;
     const TgHipBsdf &b = s->bsdfs[bi];
     int d = depth + 1;
-    if (b.type == TGHIP_BSDF_SMOOTH_COAT || b.type == TGHIP_BSDF_TRANSPARENCY)
+    if (b.type == TGHIP_BSDF_SMOOTH_COAT || b.type == TGHIP_BSDF_ROUGH_COAT || b.type == TGHIP_BSDF_TRANSPARENCY)
         return bsdfDepth(s, b.sub0, d);
     if (b.type == TGHIP_BSDF_MIXED)
         return std::max(bsdfDepth(s, b.sub0, d), bsdfDepth(s, b.sub1, d));
@@ -291,9 +291,10 @@ static uint32_t bsdfTypeMask(const TgHipSceneDesc *s, int bi, int depth)
     if (bi < 0 || uint32_t(bi) >= s->num_bsdfs || depth > 16) return 0;
     const TgHipBsdf &b = s->bsdfs[bi];
     uint32_t m = 1u << uint32_t(b.type);
-    if ((b.type == TGHIP_BSDF_ROUGH_CONDUCTOR || b.type == TGHIP_BSDF_ROUGH_DIELECTRIC || b.type == TGHIP_BSDF_ROUGH_PLASTIC) && b.distribution == TGHIP_DIST_PHONG)
+    if ((b.type == TGHIP_BSDF_ROUGH_CONDUCTOR || b.type == TGHIP_BSDF_ROUGH_DIELECTRIC || b.type == TGHIP_BSDF_ROUGH_PLASTIC || b.type == TGHIP_BSDF_ROUGH_COAT) &&
+        b.distribution == TGHIP_DIST_PHONG)
         m |= FEAT_PHONG;                     // outside every family mask: such a material is shaded by the full variant (pt_scene.h: mfDist)
-    if (b.type == TGHIP_BSDF_SMOOTH_COAT || b.type == TGHIP_BSDF_TRANSPARENCY)
+    if (b.type == TGHIP_BSDF_SMOOTH_COAT || b.type == TGHIP_BSDF_ROUGH_COAT || b.type == TGHIP_BSDF_TRANSPARENCY)
         m |= bsdfTypeMask(s, b.sub0, depth + 1);
     if (b.type == TGHIP_BSDF_MIXED)
         m |= bsdfTypeMask(s, b.sub0, depth + 1) | bsdfTypeMask(s, b.sub1, depth + 1);
@@ -1155,7 +1156,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         {
             uint32_t allTypes = 0;
             for (int c = 0; c < PT_NUM_CLASSES; ++c) allTypes |= ctx->classMask[c];
-            ctx->mediaSimple = ctx->haveMedia && !ctx->haveInstances && (allTypes & ~MASK_MEDIA & 0x3FFFu) == 0;   // (bits 0 .. 13: the BSDF types)
+            ctx->mediaSimple = ctx->haveMedia && !ctx->haveInstances && (allTypes & ~MASK_MEDIA & 0x7FFFFu) == 0;   // (bits 0 .. 18: the BSDF types)
         }
         bool lean = sd->num_infinite_lights == 0 && sd->num_lights <= 1;
         for (uint32_t i = 0; i < sd->num_textures && lean; ++i) lean = sd->textures[i].type != TGHIP_TEX_BITMAP;
@@ -1419,6 +1420,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     // k_tail runs the wide single-level kernels' bodies: scenes those kernels render, passes without visit counts (per-launch timing does
     // not see it: the few thousand rays it traces are in the counters, its one launch is in none of the three kernel classes)
     const bool tailEligible = ctx->tailOpt && !flat && !ctx->haveInstances && wideClosest(ctx) && wideShadowRays(ctx) && ctx->decoupleOpt && !ctx->haveForward &&
+                              (ctx->complexMask & TYPES_LATE) == 0 &&
                               !ctx->haveMeshLight && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder && !count && !st.records &&
                               st.slots_per_block <= PT_MAX_SLOTS_PER_BLOCK;
     const uint64_t tailThreshold = uint64_t(std::max<long long>(ctx->tailThreshold, 0));
@@ -2211,6 +2213,7 @@ __global__ void k_debug_libm(int fn, const float *x, float *y, uint32_t n)
     case TGHIP_LIBM_CBRTF: r = cbrtfH(v); break;
     case TGHIP_LIBM_EMBREE_RCP: r = embreeRcp(v); break;
     case TGHIP_LIBM_RCPPS: r = rcppsIntel(v); break;
+    case TGHIP_LIBM_TANF: r = tanfH(v); break;
     case TGHIP_LIBM_SINF: r = sinfH(v); break;
     case TGHIP_LIBM_COSF: r = cosfH(v); break;
     case TGHIP_LIBM_LOGF: r = logfH(v); break;
@@ -2226,7 +2229,7 @@ int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n)
 {
     if (!ctx) return TGHIP_E_INVALID;
     if (n == 0) return TGHIP_OK;
-    if (!x || !y || n > 0x3FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_RCPPS) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
+    if (!x || !y || n > 0x3FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_TANF) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *dx = nullptr, *dy = nullptr;
     const size_t nx = (fn == TGHIP_LIBM_ATAN2F || fn == TGHIP_LIBM_POWF) ? 2*n : n;
