@@ -171,13 +171,21 @@ struct PathState {
                                            // +4.. the group stack, two 8-byte entries per array
 };
 
+// PT_POOL_RECORDS_RUNTIME: the record layout of the "pool_layout" experiment (-1 % on k_shade, +6 % on closest-hit: measured and not adopted) as a
+// RUN-TIME option, as rounds 2-4 shipped it -- every slot access then carries the selects between two address computations and the two base
+// pointers (branches and spilled scalars in the refill paths of every kernel).  Without the macro the arrays are the only layout.
+#ifdef PT_POOL_RECORDS_RUNTIME
+#define PT_RECORDS(st) ((st).records != 0u)
+#else
+#define PT_RECORDS(st) false
+#endif
 PT_DEV uint32_t slotOffset(const PathState &st, uint32_t a, uint32_t slot)     // `a` is a literal at every call site: the selects fold
 {
-    if (st.records)
+    if (PT_RECORDS(st))
         return a < A_SH_O ? slot*128u + a*16u : a < A_AUX0 ? st.rec_shadow + slot*128u + (a - A_SH_O)*16u : st.rec_aux + slot*80u + (a - A_AUX0)*16u;
     return (a & ((1u << PT_POOL_GROUP_SHIFT) - 1u))*st.stride + slot*16u;
 }
-PT_DEV char *slotBase(const PathState &st, uint32_t a) { return st.records ? st.poolg[0] : st.poolg[a >> PT_POOL_GROUP_SHIFT]; }
+PT_DEV char *slotBase(const PathState &st, uint32_t a) { return PT_RECORDS(st) ? st.poolg[0] : st.poolg[a >> PT_POOL_GROUP_SHIFT]; }
 PT_DEV float4 &slotF4(const PathState &st, uint32_t a, uint32_t slot)
 {
     return *reinterpret_cast<float4 *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot));

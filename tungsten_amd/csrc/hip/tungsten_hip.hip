@@ -879,7 +879,13 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "leaf_batch") ctx->leafBatch = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "fuse_flat") ctx->fuseFlatOpt = value != 0;
     else if (k == "run_to_completion") ctx->loopOpt = value != 0;
-    else if (k == "pool_layout") { ctx->poolRecords = value != 0; ctx->poolMem.release(); ctx->poolSlots = 0; }
+    else if (k == "pool_layout") {
+#ifdef PT_POOL_RECORDS_RUNTIME
+        ctx->poolRecords = value != 0; ctx->poolMem.release(); ctx->poolSlots = 0;
+#else
+        if (value != 0) { ctx->error = "pool_layout = 1 needs a build with -DPT_POOL_RECORDS_RUNTIME (the record layout was measured and not adopted)"; return TGHIP_E_UNSUPPORTED; }
+#endif
+    }
     else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "wide_node_stride") { if (value != 80 && value != 128) { ctx->error = "wide_node_stride is 80 or 128"; return TGHIP_E_INVALID; } ctx->wideStride = int(value); }
     else if (k == "wide_closest") { ctx->wideClosestOpt = value < 0 ? -1 : value != 0; if (ctx->haveScene) chooseThreads(ctx); }
