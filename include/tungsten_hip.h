@@ -251,8 +251,16 @@ typedef struct TgHipMedium {
     int32_t trans_type;                           /* TGHIP_TRANS_*: Medium::_transmittance (Medium.cpp:14, 27-28) */
     float   trans_p[3];                           /* linear / quadratic: {max_t}; double_exponential: {sigma_a, sigma_b}; pulse: {min, max, num_pulses};
                                                      erlang: {rate}; davis: {alpha}; davis_weinstein: {h, c} */
+    /* ABI 9: media/ExponentialMedium.cpp next to the homogeneous medium -- the density falls off as exp(-falloff_scale (p - unit_point) . falloff_dir);
+       sigma_* are the medium's coefficients at density one; exponential transmittance only (ExponentialMedium::sampleDistance hands the
+       transmittance's eval an `exited` flag it has not set yet, :122-123: only the exponential one does not look at it) */
+    int32_t medium_type;                          /* TGHIP_MEDIUM_* */
+    float   falloff_scale;                        /* _falloffScale */
+    float   unit_point[3];                        /* _unitPoint */
+    float   falloff_dir[3];                       /* _unitFalloffDirection (normalised at prepareForRender) */
     float   pad[3];
-} TgHipMedium;                /* 80 B */
+} TgHipMedium;                /* 112 B */
+enum { TGHIP_MEDIUM_HOMOGENEOUS = 0, TGHIP_MEDIUM_EXPONENTIAL = 1 };
 
 /* ---- textures ------------------------------------------------------------------------- */
 enum { TGHIP_TEX_CONSTANT = 0, TGHIP_TEX_CHECKER = 1, TGHIP_TEX_BITMAP = 2 };

@@ -2602,9 +2602,71 @@ static float trans_sample(const TgHipMedium *m, Sampler *smp, int startOnSurface
 }
 
 /* HomogeneousMedium::sampleDistance (HomogeneousMedium.cpp:66-107); state.firstScatter plays "startOnSurface" */
+/* ExponentialMedium::densityIntegral / inverseOpticalDepth / density (ExponentialMedium.cpp:76-104) */
+static float expmed_densityIntegral(float x, float dx, float tMax)
+{
+    if (tMax == INFINITY)
+        return expf(-x)/dx;
+    else if (dx == 0.0f)
+        return expf(-x)*tMax;
+    else
+        return (expf(-x) - expf(-dx*tMax - x))/dx;
+}
+static float expmed_inverseOpticalDepth(float x, float dx, float tau)
+{
+    if (dx == 0.0f) {
+        return tau/expf(-x);
+    } else {
+        float denom = 1.0f - dx*expf(x)*tau;
+        return denom <= 0.0f ? INFINITY : -logf(denom)/dx;
+    }
+}
+/* ExponentialMedium::sampleDistance (ExponentialMedium.cpp:106-150); exponential transmittance only (include/tungsten_hip.h) */
+static int expmed_sampleDistance(const TgHipMedium *m, int medium, Sampler *smp, const Ray *ray, MediumState *state, MediumSample *ms)
+{
+    if (state->bounce > m->max_bounce)
+        return 0;
+    const v3 sigmaT = ld3(m->sigma_t);
+    float x = m->falloff_scale*vdot(vsub(ray->o, ld3(m->unit_point)), ld3(m->falloff_dir));
+    float dx = m->falloff_scale*vdot(ray->d, ld3(m->falloff_dir));
+    float maxT = ray->tmax;
+    if (m->absorption_only) {
+        if (maxT == INFINITY && dx <= 0.0f)
+            return 0;
+        ms->t = maxT;
+        v3 tau = vscale(sigmaT, expmed_densityIntegral(x, dx, ray->tmax));
+        ms->weight = trans_eval(m, tau, state->firstScatter, 1);
+        ms->exited = 1;
+    } else {
+        int component = (int)(nextSupplemental(smp)*3);           /* sampler.nextDiscrete(3) */
+        float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
+        float tauC = trans_sample(m, smp, state->firstScatter)/sigmaTc;
+        float t = expmed_inverseOpticalDepth(x, dx, tauC);
+        ms->t = fminf(t, maxT);
+        v3 tau = vscale(sigmaT, expmed_densityIntegral(x, dx, ms->t));
+        ms->exited = t >= maxT;
+        ms->weight = trans_eval(m, tau, state->firstScatter, ms->exited);      /* (the exponential transmittance does not look at the flags) */
+        float pdf;
+        if (ms->exited) {
+            pdf = vavg(trans_kernel3(m, state->firstScatter ? 0 : 2, tau));
+        } else {
+            float rho = expf(-(x + dx*ms->t));                      /* density(x, dx, t) */
+            pdf = vavg(vmul(vscale(sigmaT, rho), trans_kernel3(m, state->firstScatter ? 1 : 3, tau)));   /* (rho*_sigmaT*mediumPdf).avg() */
+            ms->weight = vmul(ms->weight, vscale(vscale(ld3(m->sigma_s), rho), trans_sigmaBar(m)));     /* *= rho*_sigmaS*sigmaBar() */
+        }
+        ms->weight = vdivs(ms->weight, pdf);
+        state->firstScatter = 0; state->bounce++;
+    }
+    ms->p = vadd(ray->o, vscale(ray->d, ms->t));
+    ms->medium = medium;
+    return 1;
+}
+
 static int medium_sampleDistance(const TgHipSceneDesc *s, int medium, Sampler *smp, const Ray *ray, MediumState *state, MediumSample *ms)
 {
     const TgHipMedium *m = &s->media[medium];
+    if (m->medium_type == TGHIP_MEDIUM_EXPONENTIAL)
+        return expmed_sampleDistance(m, medium, smp, ray, state, ms);
     if (state->bounce > m->max_bounce)
         return 0;
     float maxT = ray->tmax;
@@ -2639,8 +2701,16 @@ static int medium_sampleDistance(const TgHipSceneDesc *s, int medium, Sampler *s
 }
 
 /* HomogeneousMedium::transmittance (:109-116) */
-static v3 medium_transmittance(const TgHipSceneDesc *s, int medium, float farT, int startOnSurface, int endOnSurface)
+static v3 medium_transmittance(const TgHipSceneDesc *s, int medium, const Ray *ray, float farT, int startOnSurface, int endOnSurface)
 {
+    const TgHipMedium *m = &s->media[medium];
+    if (m->medium_type == TGHIP_MEDIUM_EXPONENTIAL) {             /* ExponentialMedium::transmittance (ExponentialMedium.cpp:151-163) */
+        float x = m->falloff_scale*vdot(vsub(ray->o, ld3(m->unit_point)), ld3(m->falloff_dir));
+        float dx = m->falloff_scale*vdot(ray->d, ld3(m->falloff_dir));
+        if (farT == INFINITY && dx <= 0.0f)
+            return vs(0.0f);
+        return trans_eval(m, vscale(ld3(m->sigma_t), expmed_densityIntegral(x, dx, farT)), startOnSurface, endOnSurface);
+    }
     if (farT == INFINITY)
         return vs(0.0f);
     return trans_eval(&s->media[medium], vscale(ld3(s->media[medium].sigma_t), farT), startOnSurface, endOnSurface);
@@ -2688,6 +2758,31 @@ static void phase_sample(const TgHipMedium *m, Sampler *smp, v3 wi, v3 *w, float
     }
 }
 
+/* Embree's slab test of ONE child box of a BVH4 node as the SSE4.2 single-ray traversal makes it (kernels/bvh/bvh_intersector_node.h:162-195,
+ * TravRay :30-47): rdir = rcp(zero_fix(dir)) with rcp = RCPPS + one Newton step (common/math/vec3fa.h:122-145), planes (bound - org)*rdir,
+ * near / far by the sign of rdir, maxi / mini and the final comparison on the floats' bit patterns as signed integers.  The user-geometry
+ * BVH has one primitive per leaf (object_accel_max_leaf_size = 1, kernels/common/state.cpp:83-84), so the box is the primitive's own. */
+static int embree_maxi(float a, float b) { int32_t ia, ib; memcpy(&ia, &a, 4); memcpy(&ib, &b, 4); return ia > ib; }
+static int embree_box_visible(const Ray *ray, v3 lo, v3 hi)
+{
+    const float o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};
+    const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+    float tNear = fmaxf(ray->tmin, 0.0f), tFar = fmaxf(ray->tmax, 0.0f);
+    float n[3], f[3];
+    for (int k = 0; k < 3; ++k) {
+        float a = fabsf(d[k]) < 1e-18f ? 1e-18f : d[k];           /* zero_fix */
+        float rdir = embree_rcp(a);
+        n[k] = ((rdir >= 0.0f ? l[k] : h[k]) - o[k])*rdir;
+        f[k] = ((rdir >= 0.0f ? h[k] : l[k]) - o[k])*rdir;
+    }
+    /* maxi(maxi(x, y), maxi(z, tnear)), mini likewise */
+    float nxy = embree_maxi(n[0], n[1]) ? n[0] : n[1], nzt = embree_maxi(n[2], tNear) ? n[2] : tNear;
+    float near = embree_maxi(nxy, nzt) ? nxy : nzt;
+    float fxy = embree_maxi(f[0], f[1]) ? f[1] : f[0], fzt = embree_maxi(f[2], tFar) ? tFar : f[2];
+    float far = embree_maxi(fxy, fzt) ? fzt : fxy;
+    return !embree_maxi(near, far);
+}
+
 /* TraceBase::generalizedShadowRay (TraceBase.cpp:62-125).  `endCap` is an object index, `medium` the medium the ray
  * starts in (-1 = none). */
 static v3 generalizedShadowRay(Ctx *c, Ray *ray, int medium, int endCap, int startsOnSurface, int bounce)
@@ -2703,6 +2798,24 @@ static v3 generalizedShadowRay(Ctx *c, Ray *ray, int medium, int endCap, int sta
         if (hitAny) {
             intersection_info(c->s, ray, &hit, &info);
             hitObject = info.object;
+        }
+        if (hitAny && hitObject == endCap && c->s->objects[endCap].type == TGHIP_OBJ_QUAD) {
+            /* The light the ray is aimed at is only FOUND when Embree's slab test lets the ray into its box -- and a quad's box is flat: from
+             * the second segment of a shadow ray on (new origin, remaining farT) the quad may lie an ulp inside farT by Quad::intersect's
+             * arithmetic and an ulp behind it by the slab test's.  Embree then never calls Quad::intersect, info.primitive stays null, the
+             * function returns as it would at the end cap -- but ray.farT() was not shortened to the hit, and the medium's transmittance of
+             * the segment is taken over the remaining distance.  (Quad::bounds, Quad.cpp:281-289; found with the stress render of the
+             * fog + smoke twin, DESIGN.md section 8.  Other light shapes: their boxes are not restated, the light is always found.) */
+            const TgHipObject *o = &c->s->objects[endCap];
+            v3 b = ld3(o->base), e0 = ld3(o->edge0), e1 = ld3(o->edge1);
+            v3 p[4] = {b, vadd(b, e0), vadd(b, e1), vadd(vadd(b, e0), e1)};
+            v3 lo = p[0], hi = p[0];
+            for (int k = 1; k < 4; ++k) {
+                lo = V(fminf(lo.x, p[k].x), fminf(lo.y, p[k].y), fminf(lo.z, p[k].z));
+                hi = V(fmaxf(hi.x, p[k].x), fmaxf(hi.y, p[k].y), fmaxf(hi.z, p[k].z));
+            }
+            if (!embree_box_visible(ray, lo, hi))
+                hitAny = 0;
         }
         int didHit = hitAny && hitObject != endCap;
         if (didHit) {
@@ -2720,7 +2833,7 @@ static v3 generalizedShadowRay(Ctx *c, Ray *ray, int medium, int endCap, int sta
                 return vs(0.0f);
         }
         if (medium >= 0)                                   /* :103-112; ray.farT() is the hit distance when anything was hit */
-            throughput = vmul(throughput, medium_transmittance(c->s, medium, hitAny ? hit.t : ray->tmax, startsOnSurface, 1));   /* endsOnSurface = true (attenuatedEmission) */
+            throughput = vmul(throughput, medium_transmittance(c->s, medium, ray, hitAny ? hit.t : ray->tmax, startsOnSurface, 1));   /* endsOnSurface = true (attenuatedEmission) */
         if (!hitAny || hitObject == endCap)
             return bounce >= c->s->settings.min_bounces ? throughput : vs(0.0f);
         medium = selectMedium(&c->s->objects[info.object], medium, !info.backSide);     /* :115 */

@@ -38,6 +38,7 @@
 #include "primitives/Instance.hpp"
 #include "media/Medium.hpp"
 #include "media/HomogeneousMedium.hpp"
+#include "media/ExponentialMedium.hpp"
 #include "transmittances/ExponentialTransmittance.hpp"
 #include "transmittances/LinearTransmittance.hpp"
 #include "transmittances/QuadraticTransmittance.hpp"
@@ -323,11 +324,21 @@ int32_t HipSceneFlattener::addMedium(const Medium *m)
     for (size_t i = 0; i < _mediumKeys.size(); ++i)
         if (_mediumKeys[i] == m) return int32_t(i);
     const HomogeneousMedium *h = dynamic_cast<const HomogeneousMedium *>(m);
-    if (!h) refuse("a medium that is not homogeneous");
+    const ExponentialMedium *x = dynamic_cast<const ExponentialMedium *>(m);
+    if (!h && !x) refuse("a medium that is neither homogeneous nor exponential");
     TgHipMedium d;
     std::memset(&d, 0, sizeof(d));
-    copy3(d.sigma_a, h->_sigmaA); copy3(d.sigma_s, h->_sigmaS); copy3(d.sigma_t, h->_sigmaT);
-    d.absorption_only = h->_absorptionOnly ? 1 : 0;
+    if (h) {
+        copy3(d.sigma_a, h->_sigmaA); copy3(d.sigma_s, h->_sigmaS); copy3(d.sigma_t, h->_sigmaT);
+        d.absorption_only = h->_absorptionOnly ? 1 : 0;
+    } else {                                        // ExponentialMedium after prepareForRender (ExponentialMedium.cpp:52-59)
+        copy3(d.sigma_a, x->_sigmaA); copy3(d.sigma_s, x->_sigmaS); copy3(d.sigma_t, x->_sigmaT);
+        d.absorption_only = x->_absorptionOnly ? 1 : 0;
+        d.medium_type = TGHIP_MEDIUM_EXPONENTIAL;
+        d.falloff_scale = x->_falloffScale;
+        copy3(d.unit_point, x->_unitPoint);
+        copy3(d.falloff_dir, x->_unitFalloffDirection);
+    }
     d.max_bounce = m->_maxBounce;
     const PhaseFunction *ph = m->_phaseFunction.get();
     if (dynamic_cast<const IsotropicPhaseFunction *>(ph)) d.phase_type = TGHIP_PHASE_ISOTROPIC;
@@ -337,6 +348,8 @@ int32_t HipSceneFlattener::addMedium(const Medium *m)
     int32_t subType[2] = {0, 0};
     float subP[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
     describeTransmittance(m->_transmittance.get(), d.trans_type, d.trans_p, false, subType, subP);
+    if (x && d.trans_type != TGHIP_TRANS_EXPONENTIAL)
+        refuse("an exponential medium with a non-exponential transmittance");
     _mediumKeys.push_back(m);
     _media.push_back(d);
     const int32_t index = int32_t(_media.size() - 1);

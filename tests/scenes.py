@@ -886,6 +886,24 @@ def _interpolated_fog(scene):
 GOLDEN_CASES["cornell_fog_interpolated"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_interpolated_fog))
 GOLDEN_CASES["cornell_fog_davis"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_davis_fog))
 GOLDEN_CASES["cornell_fog_rayleigh"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_rayleigh_fog))
+def _expfog(scene):
+    """media/ExponentialMedium.cpp: the camera's fog thins out upwards (and a little towards the back), density exp(-1.2 (p - unit_point) . dir)."""
+    _fog(scene)
+    scene["media"][-1].update(type="exponential", falloff_scale=1.2, unit_point=[0.0, 0.3, 0.0], falloff_direction=[0.0, 1.0, 0.2], density=1.6)
+
+
+def _expfog_and_smoke(scene):
+    """The exponential fog outside, homogeneous smoke in the tall box and an ABSORPTION-ONLY exponential medium (a tint that fades with height) in the glass box."""
+    _fog_and_smoke(scene)
+    for m in scene["media"]:
+        if m["name"] == "fog":
+            m.update(type="exponential", falloff_scale=0.8, unit_point=[0.0, 1.0, 0.0], falloff_direction=[0.0, -1.0, 0.0])
+        if m["name"] == "tint":
+            m.update(type="exponential", falloff_scale=2.0, unit_point=[0.3, 0.0, 0.3], falloff_direction=[0.0, 1.0, 0.0])
+
+
+GOLDEN_CASES["cornell_expfog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_expfog))
+GOLDEN_CASES["cornell_expfog_smoke_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_expfog_and_smoke, renderer={"stratified_sampler": True}))
 GOLDEN_CASES["cornell_fog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog))
 GOLDEN_CASES["cornell_smoke"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_smoke))
 GOLDEN_CASES["cornell_fog_smoke_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog_and_smoke, renderer={"stratified_sampler": True}))
@@ -971,7 +989,7 @@ def _lifted(base):
     return make, kw
 
 
-LIFTED_CASES = {base + "_lifted": _lifted(base) for base in ("cornell_smoke", "cornell_fog_smoke_sobol", "cornell_fog", "cornell_fog_davis", "cornell_fog_rayleigh",
+LIFTED_CASES = {base + "_lifted": _lifted(base) for base in ("cornell_smoke", "cornell_fog_smoke_sobol", "cornell_expfog", "cornell_expfog_smoke_sobol", "cornell_fog", "cornell_fog_davis", "cornell_fog_rayleigh",
                                                             "cornell_png_scalar", "zoo_a", "zoo_b", "zoo_e", "zoo_f")}
 
 

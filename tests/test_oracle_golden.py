@@ -65,7 +65,7 @@ def _needs_materialtest(name):
 # keeps the LAST hit in the visiting order of its own BVH -- the oracle now walks that very tree, restated node for node, in that order.)
 # The test's bound is 1.5 x the measured count + 5 samples.
 DIVERGING = {"cornell_fog": 1, "cornell_fog_davis": 2, "cornell_fog_rayleigh": 1, "cornell_fog_smoke_sobol": 9, "cornell_png_scalar": 11, "cornell_smoke": 17,
-             "zoo_a": 7, "zoo_b": 8, "zoo_b_sobol": 7, "zoo_e": 20, "zoo_f": 6}
+             "zoo_a": 7, "zoo_b": 8, "zoo_b_sobol": 7, "zoo_e": 20, "zoo_f": 6, "cornell_expfog_smoke_sobol": 10}
 
 
 def diverge_bound(name, samples):

@@ -55,7 +55,8 @@ class TgHipTexture(C.Structure):
 
 class TgHipMedium(C.Structure):
     _fields_ = [("sigma_a", f32*3), ("sigma_s", f32*3), ("sigma_t", f32*3), ("absorption_only", i32), ("max_bounce", i32),
-                ("phase_type", i32), ("phase_g", f32), ("trans_type", i32), ("trans_p", f32*3), ("pad", f32*3)]
+                ("phase_type", i32), ("phase_g", f32), ("trans_type", i32), ("trans_p", f32*3),
+                ("medium_type", i32), ("falloff_scale", f32), ("unit_point", f32*3), ("falloff_dir", f32*3), ("pad", f32*3)]
 
 
 class TgHipCamera(C.Structure):

@@ -659,8 +659,9 @@ std::shared_ptr<Bsdf> Scene::fetchBsdf(const JsonValue &v) const
 // Media: homogeneous medium with exponential transmittance and an isotropic / Henyey-Greenstein phase function
 // (media/HomogeneousMedium.cpp:19-26, Medium.cpp:20-30); everything else is rejected by name
 // ------------------------------------------------------------------------------------------
-void Medium::prepareForRender()   // HomogeneousMedium.cpp:43-49
+void Medium::prepareForRender()   // HomogeneousMedium.cpp:43-49, ExponentialMedium.cpp:52-59
 {
+    unitFalloffDirection = falloffDirection.normalized();
     sigmaA = materialSigmaA*density;
     sigmaS = materialSigmaS*density;
     sigmaT = sigmaA + sigmaS;
@@ -671,9 +672,15 @@ std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
 {
     auto m = std::make_shared<Medium>();
     std::string type = v["type"].asString();
-    if (type != "homogeneous")
-        throw JsonLoadException("medium type '" + type + "' is not supported by path_tracer_hip (homogeneous only)");
+    if (type != "homogeneous" && type != "exponential")
+        throw JsonLoadException("medium type '" + type + "' is not supported by path_tracer_hip (homogeneous and exponential only)");
     v.getField("name", m->name);
+    if (type == "exponential") {                    // ExponentialMedium::fromJson (ExponentialMedium.cpp:22-31)
+        m->mediumType = 1;
+        v.getField("falloff_scale", m->falloffScale);
+        getVec3(v, "unit_point", m->unitPoint);
+        getVec3(v, "falloff_direction", m->falloffDirection);
+    }
     getVec3(v, "sigma_a", m->materialSigmaA);
     getVec3(v, "sigma_s", m->materialSigmaS);
     v.getField("density", m->density);
@@ -727,6 +734,9 @@ std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
     };
     if (const JsonValue &t = v["transmittance"])
         parseTransmittance(t, m->transType, m->transP, false);
+    if (m->mediumType == 1 && m->transType != 0)
+        throw JsonLoadException("an exponential medium with a non-exponential transmittance is not supported by path_tracer_hip (the reference's "
+                                "ExponentialMedium::sampleDistance evaluates the transmittance with a flag it has not set yet)");
     if (const JsonValue &ph = v["phase_function"]) {
         std::string pt = ph.isString() ? ph.asString() : ph["type"].asString();
         if (pt == "isotropic") m->phaseType = 0;

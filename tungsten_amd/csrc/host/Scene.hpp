@@ -82,6 +82,9 @@ struct Medium   // media/HomogeneousMedium.{hpp,cpp} + Medium.cpp + transmittanc
     Vec3f materialSigmaA = Vec3f(0.0f), materialSigmaS = Vec3f(0.0f);
     float density = 1.0f;
     int maxBounce = 1024;
+    int mediumType = 0;         // TGHIP_MEDIUM_*: 0 homogeneous, 1 exponential (media/ExponentialMedium.cpp)
+    float falloffScale = 1.0f;  // ExponentialMedium.cpp:12-19
+    Vec3f unitPoint = Vec3f(0.0f), falloffDirection = Vec3f(0.0f, 1.0f, 0.0f), unitFalloffDirection = Vec3f(0.0f, 1.0f, 0.0f);
     int phaseType = 0;          // 0 isotropic, 1 henyey_greenstein, 2 rayleigh
     float phaseG = 0.0f;
     int transType = 0;          // TGHIP_TRANS_*: exponential, linear, quadratic, double_exponential, pulse, erlang

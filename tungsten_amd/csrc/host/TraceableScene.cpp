@@ -435,6 +435,12 @@ void TraceableScene::flatten()
         d.phase_g = m->phaseG;
         d.trans_type = m->transType;
         for (int k = 0; k < 3; ++k) d.trans_p[k] = m->transP[k];
+        d.medium_type = m->mediumType;
+        if (m->mediumType == TGHIP_MEDIUM_EXPONENTIAL) {
+            d.falloff_scale = m->falloffScale;
+            copy3(d.unit_point, m->unitPoint);
+            copy3(d.falloff_dir, m->unitFalloffDirection);
+        }
         mediumKeys.push_back(m.get());
         _media.push_back(d);
         const int32_t index = int32_t(_media.size() - 1);
