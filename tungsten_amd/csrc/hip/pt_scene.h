@@ -1351,6 +1351,29 @@ PT_DEV float rcppsIntel(float x)
     return __uint_as_float(bits);
 }
 PT_DEV float embreeRcp(float a) { const float r = rcppsIntel(a); return r*(2.0f - r*a); }
+// Embree's slab test of one child box of a BVH4 node as its SSE4.2 single-ray traversal makes it (kernels/bvh/bvh_intersector_node.h:162-195,
+// TravRay :30-47): rdir = rcp(zero_fix(dir)), planes (bound - org)*rdir, near / far by the sign of rdir, maxi / mini and the final comparison on
+// the floats' bit patterns as signed integers.  The user-geometry BVH has one primitive per leaf, so a primitive's own box is the box a ray
+// must pass to reach it (oracle.c: embree_box_visible; used for the light a shadow ray is aimed at, pt_wavefront.h: k_trace_shadow<., FORWARD>).
+PT_DEV bool embreeIntGreater(float a, float b) { return __float_as_int(a) > __float_as_int(b); }
+PT_DEV bool embreeBoxVisible(f3 o, f3 d, float tmin, float tmax, f3 lo, f3 hi)
+{
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+    const float tNear = fmaxf(tmin, 0.0f), tFar = fmaxf(tmax, 0.0f);
+    float n[3], f[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float a = fabsf(dd[k]) < 1e-18f ? 1e-18f : dd[k];
+        const float rdir = embreeRcp(a);
+        n[k] = ((rdir >= 0.0f ? l[k] : h[k]) - oo[k])*rdir;
+        f[k] = ((rdir >= 0.0f ? h[k] : l[k]) - oo[k])*rdir;
+    }
+    const float nxy = embreeIntGreater(n[0], n[1]) ? n[0] : n[1], nzt = embreeIntGreater(n[2], tNear) ? n[2] : tNear;
+    const float nearT = embreeIntGreater(nxy, nzt) ? nxy : nzt;
+    const float fxy = embreeIntGreater(f[0], f[1]) ? f[1] : f[0], fzt = embreeIntGreater(f[2], tFar) ? tFar : f[2];
+    const float farT = embreeIntGreater(fxy, fzt) ? fzt : fxy;
+    return !embreeIntGreater(nearT, farT);
+}
 
 /* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113, finalize() :43-49);
  * Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c. */
@@ -2440,14 +2463,62 @@ PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   
 /* HomogeneousMedium::sampleDistance (:66-107).  maxT = ray.farT(); false = the path ends here ("return emission").
  * MediumState::firstScatter (the "start on a surface" flag of the transmittance) is stateBounce == 0: reset() clears both,
  * advance() clears the flag and counts (Medium.hpp:36-46). */
+/* ExponentialMedium::densityIntegral / inverseOpticalDepth (ExponentialMedium.cpp:81-104): std::exp / std::log on floats = glibc's expf / logf */
+PT_DEV float expMediumDensityIntegral(float x, float dx, float tMax)
+{
+    if (tMax == PT_INF)
+        return expfH(-x)/dx;
+    else if (dx == 0.0f)
+        return expfH(-x)*tMax;
+    else
+        return (expfH(-x) - expfH(-dx*tMax - x))/dx;
+}
+PT_DEV float expMediumInverseOpticalDepth(float x, float dx, float tau)
+{
+    if (dx == 0.0f)
+        return tau/expfH(-x);
+    float denom = 1.0f - dx*expfH(x)*tau;
+    return denom <= 0.0f ? PT_INF : -logfH(denom)/dx;
+}
 template<uint32_t M>
-PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, float maxT, uint32_t &stateBounce, f3 &weight, float &t, bool &exited)
+PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, f3 rayO, f3 rayD, float maxT, uint32_t &stateBounce, f3 &weight, float &t, bool &exited)
 {
     const TgHipMedium &m = s.media[medium];
     if ((int)stateBounce > m.max_bounce)
         return false;
     const bool firstScatter = stateBounce == 0u;
     const f3 sigmaT = ld3(m.sigma_t);
+    if (m.medium_type == TGHIP_MEDIUM_EXPONENTIAL) {             /* ExponentialMedium::sampleDistance (ExponentialMedium.cpp:106-150); exponential transmittance */
+        const float x = m.falloff_scale*dot(rayO - ld3(m.unit_point), ld3(m.falloff_dir));
+        const float dx = m.falloff_scale*dot(rayD, ld3(m.falloff_dir));
+        if (m.absorption_only) {
+            if (maxT == PT_INF && dx <= 0.0f)
+                return false;
+            t = maxT;
+            weight = transEval(m, sigmaT*expMediumDensityIntegral(x, dx, maxT), firstScatter, true);
+            exited = true;
+            return true;
+        }
+        int component = (int)(rngNext1D(rng)*3);
+        float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
+        float tauC = transSample<M>(m, rng, firstScatter)/sigmaTc;
+        float tt = expMediumInverseOpticalDepth(x, dx, tauC);
+        t = fminf(tt, maxT);
+        exited = tt >= maxT;
+        f3 tau = sigmaT*expMediumDensityIntegral(x, dx, t);
+        weight = transEval(m, tau, firstScatter, exited);
+        float pdf;
+        if (exited) {
+            pdf = avg3(transKernel3(m, firstScatter ? 0 : 2, tau));
+        } else {
+            float rho = expfH(-(x + dx*t));
+            pdf = avg3((sigmaT*rho)*transKernel3(m, firstScatter ? 1 : 3, tau));
+            weight = weight*((ld3(m.sigma_s)*rho)*transSigmaBar(m));
+        }
+        weight = weight/pdf;
+        stateBounce++;
+        return true;
+    }
     if (m.absorption_only) {
         if (maxT == PT_INF)
             return false;
@@ -2475,8 +2546,16 @@ PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, flo
     return true;
 }
 
-PT_DEV f3 mediumTransmittance(const DeviceScene &s, int medium, float farT, bool startOnSurface, bool endOnSurface)   /* HomogeneousMedium::transmittance (:109-116) */
+PT_DEV f3 mediumTransmittance(const DeviceScene &s, int medium, f3 rayO, f3 rayD, float farT, bool startOnSurface, bool endOnSurface)   /* HomogeneousMedium::transmittance (:109-116) */
 {
+    const TgHipMedium &m = s.media[medium];
+    if (m.medium_type == TGHIP_MEDIUM_EXPONENTIAL) {             /* ExponentialMedium::transmittance (ExponentialMedium.cpp:151-163) */
+        const float x = m.falloff_scale*dot(rayO - ld3(m.unit_point), ld3(m.falloff_dir));
+        const float dx = m.falloff_scale*dot(rayD, ld3(m.falloff_dir));
+        if (farT == PT_INF && dx <= 0.0f)
+            return splat3(0.0f);
+        return transEval(m, ld3(m.sigma_t)*expMediumDensityIntegral(x, dx, farT), startOnSurface, endOnSurface);
+    }
     if (farT == PT_INF)
         return splat3(0.0f);
     return transEval(s.media[medium], ld3(s.media[medium].sigma_t)*farT, startOnSurface, endOnSurface);

@@ -1220,7 +1220,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                 medBounce = FLAG_MEDIUM_BOUNCE(flags);
                 if (med >= 0) {
                     f3 w; float t; bool exited;
-                    if (!mediumSampleDistance<M>(s, med, rng, __float_as_int(hit.w) >= 0 ? hit.x : PT_INF, medBounce, w, t, exited)) {
+                    if (!mediumSampleDistance<M>(s, med, rng, ray.o, ray.d, __float_as_int(hit.w) >= 0 ? hit.x : PT_INF, medBounce, w, t, exited)) {
                         mediumEnd = true;                    // "return emission"
                     } else {
                         throughput = throughput*w;           // mediumSample.emission = 0
@@ -1741,8 +1741,19 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                     if (ri >= 0)      // geometry reached through an instance belongs to the `instances` primitive (never a light)
                         hitObject = (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)(hitInst >= 0 ? hitInst : ri)*3u).w));
                     if (meshLight && ri < 0) { transmittance = splat3(0.0f); visValid = false; break; }   // the ray never reaches the mesh
+                    // The quad light the ray is aimed at is only FOUND when Embree's slab test lets the ray into its flat box (oracle.c:
+                    // generalizedShadowRay): culled, the function returns as at the end cap, but ray.farT() was not shortened to the hit
+                    bool found = ri >= 0;
+                    if (found && hitObject == endCap && s.objects[endCap].type == TGHIP_OBJ_QUAD) {
+                        const TgHipObject &lo = s.objects[endCap];
+                        const f3 b = ld3(lo.base), e0 = ld3(lo.edge0), e1 = ld3(lo.edge1);
+                        const f3 p1 = b + e0, p2 = b + e1, p3 = (b + e0) + e1;
+                        const f3 bl = mk3(fminf(fminf(b.x, p1.x), fminf(p2.x, p3.x)), fminf(fminf(b.y, p1.y), fminf(p2.y, p3.y)), fminf(fminf(b.z, p1.z), fminf(p2.z, p3.z)));
+                        const f3 bh = mk3(fmaxf(fmaxf(b.x, p1.x), fmaxf(p2.x, p3.x)), fmaxf(fmaxf(b.y, p1.y), fmaxf(p2.y, p3.y)), fmaxf(fmaxf(b.z, p1.z), fmaxf(p2.z, p3.z)));
+                        found = embreeBoxVisible(ray.o, ray.d, ray.tmin, ray.tmax, bl, bh);
+                    }
                     if (medium >= 0)                             // TraceBase.cpp:103-112: ray.farT() is the hit distance when anything was hit
-                        transmittance = transmittance*mediumTransmittance(s, medium, ri >= 0 ? hit.x : ray.tmax, startsOnSurface, true);
+                        transmittance = transmittance*mediumTransmittance(s, medium, ray.o, ray.d, found ? hit.x : ray.tmax, startsOnSurface, true);
                     if (ri < 0 || hitObject == endCap) {
                         if (bounce < s.settings.min_bounces) transmittance = splat3(0.0f);
                         if (meshLight) {

@@ -1034,6 +1034,12 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 ctx->error = "unknown phase function";
                 return TGHIP_E_UNSUPPORTED;
             }
+            if (sd->media[i].medium_type != TGHIP_MEDIUM_HOMOGENEOUS && sd->media[i].medium_type != TGHIP_MEDIUM_EXPONENTIAL) {
+                ctx->error = "unknown medium type"; return TGHIP_E_UNSUPPORTED;
+            }
+            if (sd->media[i].medium_type == TGHIP_MEDIUM_EXPONENTIAL && sd->media[i].trans_type != TGHIP_TRANS_EXPONENTIAL) {
+                ctx->error = "an exponential medium with a non-exponential transmittance is not supported"; return TGHIP_E_UNSUPPORTED;
+            }
             if (sd->media[i].trans_type < TGHIP_TRANS_EXPONENTIAL || sd->media[i].trans_type > TGHIP_TRANS_INTERPOLATED) {
                 ctx->error = "unknown transmittance";
                 return TGHIP_E_UNSUPPORTED;
