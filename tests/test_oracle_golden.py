@@ -3,7 +3,7 @@ itself committed under tests/golden/ (tools/make_golden.py: oracle/ref_harness.c
 libcore.a and drives its PathTracer::traceSample with the shared counter-based random stream).
 
 Tolerances: integers / RNG exact; closest-hit distances exact (Embree's rcp + Newton restated,
-triangle_intersector_moeller.h:45-48); other deterministic floats rel 1e-5; per-sample radiance BIT-IDENTICAL in 49 of the 60
+triangle_intersector_moeller.h:45-48); other deterministic floats rel 1e-5; per-sample radiance BIT-IDENTICAL in 50 of the 62
 cases, and within rel 1e-3 for all but a measured handful of samples in the other ten (coincident faces; the reference's
 instance override) -- the count allowed is stated per case below."""
 import json
