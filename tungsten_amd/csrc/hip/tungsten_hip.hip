@@ -1377,7 +1377,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     // iterations of ~150 us each for the 16-spp passes of the as-shipped materialtest, profiles/README.md; the price is <= 7 empty iterations
     // of ~55 us after the last path has ended)
     const int checkInterval = ctx->checkInterval > 0 ? ctx->checkInterval : (uint64_t(pp.total_items) >= 4ull*st.num_slots ? 16 : 8);
-    const size_t evNeeded = size_t(checkInterval)*3*2;
+    const size_t evNeeded = size_t(checkInterval)*3*2*8;          // (every part's launches are timed: up to eight parts)
     if (timing) {
         while (ctx->evPool.size() < evNeeded) {
             hipEvent_t e = nullptr;
@@ -1386,7 +1386,8 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
         }
     }
     size_t evUsed = 0;
-    auto ticMain = [&]() { if (timing) (void)hipEventRecord(ctx->evPool[evUsed++], ctx->stream); };
+    // (on the stream the launch goes to: ctx->launchStream is the part's own stream inside the split loop)
+    auto ticMain = [&]() { if (timing) (void)hipEventRecord(ctx->evPool[evUsed++], ctx->launchStream); };
     auto tic = ticMain;
 
     // "streams" = N > 1: the workgroups (and with them the slots, queues and work items) are split into N parts that run the same
@@ -1572,14 +1573,16 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             if (timing && !first) {
                 double *acc[3] = {&ctx->counters.ms_trace_closest, &ctx->counters.ms_shade, &ctx->counters.ms_trace_shadow};
-                size_t pairs = size_t(roundIters)*3;
+                // (split loop: EVERY part's launches are bracketed, each on its own stream -- three pairs per part and iteration, in launch
+                // order.  Rounds 2-4 timed part 0 only and counted the others "as long on average": they are not -- the parts whose
+                // streams the hardware queues serve later run ~45 % longer launches (rocprofv3's kernel trace, profiles/README.md) --, so the
+                // per-kernel averages were part 0's, a fifth below the mean)
+                size_t pairs = size_t(roundIters)*3*size_t(parts);
                 for (size_t k = 0; k < pairs; ++k) {
                     float ms = 0.0f;
                     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->evPool[2*k], ctx->evPool[2*k + 1]));
-                    *acc[k % 3] += double(parts)*ms;
+                    *acc[k % 3] += double(ms);
                 }
-                // (split loop: the events bracket the launches of part 0; the other parts' launches, as long on average, are
-                // counted with them so that bytes per launch and time per launch refer to the same part launches)
                 const int perIter = parts;
                 ctx->counters.launches_trace_closest += roundIters*perIter;
                 ctx->counters.launches_trace_shadow += roundIters*perIter;
@@ -1642,7 +1645,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
             if (split) {
                 for (int k = 0; k < parts; ++k) {
                     ctx->launchStream = streamOf[k];
-                    launchIteration(stPart[k], ppPart[k], grid/parts, iterTag, k == 0, k);
+                    launchIteration(stPart[k], ppPart[k], grid/parts, iterTag, true, k);
                 }
                 ctx->launchStream = ctx->stream;
             } else {
