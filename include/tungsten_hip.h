@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TGHIP_ABI_VERSION 9
+#define TGHIP_ABI_VERSION 10
 
 /* ---- error codes ------------------------------------------------------------------ */
 enum {
@@ -88,8 +88,35 @@ typedef struct TgHipBvhNode {
 /* Scenes with at most this many primitive records are intersected as a flat list in record order (every ray
  * tests every record; the wave walks the list uniformly, so record data comes through the scalar cache) instead of
  * through the BVH -- the analogue of the reference's top-level Embree scene over a handful of user-geometry
- * primitives (TraceableScene.hpp:112-134).  The oracle follows the same rule so that visit counts agree. */
+ * primitives (TraceableScene.hpp:112-134).  The oracle follows the same rule so that visit counts agree.
+ * Flat lists with TgHipSceneDesc::top_nodes (scenes whose records are all quads, cubes or spheres): the closest hit is the one the reference's
+ * Embree walk returns where faces coincide -- see TgHipTopNode below. */
 #define TGHIP_FLAT_MAX_RECS    16
+
+/* ---- the reference's top-level tree ----------------------------------------------------------------------------------------------
+ * TraceableScene commits ONE Embree user geometry whose items are the scene's finite primitives (renderer/TraceableScene.hpp:112-134) and
+ * Embree builds a BVH4 with one item per leaf over their bounds().  Where faces coincide -- a block standing ON the floor quad, a light lying
+ * IN the ceiling, a ray into the seam of two walls -- the ORDER in which a ray visits that tree decides which primitive it hits
+ * (kernels/bvh/bvh_intersector1.cpp:60-125, bvh_traverser1.h:41-104):
+ *   - a child counts only if the ray passes its box by the node's slab test (rdir = rcp(dir) by RCPPS + one Newton step, planes
+ *     (bound - org)*rdir, max / min and the comparison on the bit patterns as signed integers), under the hit distance found SO FAR;
+ *   - of the children hit the nearest box entry is descended into first, the others wait on a stack sorted by entry (one hit child: go; two:
+ *     the first only `if (d0 < d1)`; three / four: Embree's sorting networks, stack_item.h:44-60);
+ *   - a child popped behind the hit found so far is skipped -- by its BOX's entry distance, which can lie an ulp behind the distance the
+ *     primitive's own intersect() reports; a quad accepts t <= farT, a cube or sphere t < farT.
+ * The tree is therefore part of the path's arithmetic.  csrc/host/EmbreeTopTree.cpp restates Embree 2.11's builder for it (binned SAH, four
+ * children, leaf size one) node for node; tgh_top_tree_build (tungsten_host.h) produces it, tests/test_top_tree.py holds it to trees read out of
+ * the reference's own Embree.  Scenes that carry it: flat lists of quads, cubes and spheres (item i = record i); every other scene passes
+ * NULL / 0 and is walked as before (triangle meshes live in ONE tree with the other records there; disks / cylinders: bounds not restated).
+ * Node 0 is the root, nodes in preorder.  child[i] >= 0: a node; < 0: the record ~child[i]; TGHIP_TOP_EMPTY: unused slot (its box is
+ * lower = +inf, upper = -inf, as Embree clears it). */
+#define TGHIP_TOP_EMPTY  0x7FFFFFFF
+#define TGHIP_TOP_MAX_DEPTH 7       /* levels of nodes; Embree's tree over <= TGHIP_FLAT_MAX_RECS items has at most 5 (a node has four children or leaves only) */
+typedef struct TgHipTopNode {
+    float   lower[4][3];
+    float   upper[4][3];
+    int32_t child[4];
+} TgHipTopNode;            /* 112 bytes */
 
 /* ---- 8-wide BVH with quantised child boxes ------------------------------------------------------------------------
  * What the traversal kernels of single-level scenes walk (the BVH2 above stays the structure of the two-level
@@ -360,6 +387,8 @@ typedef struct TgHipSceneDesc {
     /* the wide BVH: wide_nodes[0] is the root of the tree over recs[0, num_top_recs); with instances every master's wide
      * subtree follows (its root in the instance records' c[2]).  NULL/0 = the device walks the BVH2 (flat-list scenes do) */
     const TgHipWideNode *wide_nodes;  uint32_t num_wide_nodes;
+    /* the reference's top-level Embree tree over the records of a flat list of quads / cubes / spheres (TgHipTopNode; ABI 10); NULL / 0 otherwise */
+    const TgHipTopNode *top_nodes;  uint32_t num_top_nodes;
     TgHipCamera   camera;
     TgHipSettings settings;
     float         bounds_lo[3], bounds_hi[3];

@@ -132,6 +132,20 @@ void tgh_accel_counts(tgh_accel *a, uint32_t *num_top_recs, uint32_t *num_instan
 void tgh_instance_tight_bounds(const float *master_verts, uint32_t stride_floats, uint32_t num_verts, const float pos[3], const float rot[4],
                                const float ref_bounds[6], float out[6]);
 
+/* The reference's top-level Embree tree (include/tungsten_hip.h: TgHipTopNode) over n items given by their boxes (6 floats each: lower xyz,
+ * upper xyz), as Embree 2.11's BVH4 builder for user geometry builds it (kernels/bvh/bvh_builder_sah.cpp:811-815 -> builders/bvh_builder_sah.h:
+ * 176-282; restated in csrc/host/EmbreeTopTree.cpp).  Writes at most `capacity` nodes and returns the number the tree has (n - 1 at most;
+ * 0 for n < 2 and for boxes Embree would drop as invalid), or -1 when `capacity` is too small. */
+int tgh_top_tree_build(const float *boxes, uint32_t n, TgHipTopNode *nodes, uint32_t capacity);
+/* TgHipSceneDesc::top_nodes for a flattened scene: the tree over the objects that have a record (in object order: the reference's _finites),
+ * leaves naming records, when the scene is a flat list of quads / cubes / spheres; 0 nodes otherwise.  Same return convention. */
+int tgh_top_tree_for_scene(const TgHipObject *objects, uint32_t num_objects, const TgHipPrimRec *recs, uint32_t num_recs,
+                           TgHipTopNode *nodes, uint32_t capacity);
+/* The box the reference's bounds callback reports for a record's primitive (TraceableScene.hpp:116-118): Quad::bounds / Cube::bounds /
+ * Sphere::bounds (primitives/Quad.cpp:281-289, Cube.cpp:333-344, Sphere.cpp:273-276) restated from the flattened object.  1 and the box, 0 for
+ * a record kind (TGHIP_REC_*) whose bounds are not restated. */
+int tgh_leaf_bounds(const TgHipObject *object, uint32_t kind, float lo[3], float hi[3]);
+
 /* file-format helpers used by the tests */
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h);
 int tgh_load_hdr(const char *path, float *rgb /* may be NULL to query size */, int *w, int *h);

@@ -2056,11 +2056,132 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *worldRay, float *tmax,
 void oracle_set_wide_bvh(int on) { g_use_wide = on; }
 
 /* objFilter >= 0: only records of that object are tested (a mesh light's own rtcIntersect, TriangleMesh.cpp:317-335) */
+/* A flat list of quads / cubes / spheres is intersected by WALKING THE REFERENCE'S TREE: TraceableScene::intersect -> rtcIntersect over Embree's
+ * BVH4 with one primitive per leaf (TgHipSceneDesc::top_nodes, include/tungsten_hip.h: TgHipTopNode -- built by csrc/host/EmbreeTopTree.cpp,
+ * which tests/test_top_tree.py holds to trees read out of the reference's own Embree), visited as BVH4Intersector1 visits it
+ * (thirdparty/embree/kernels/bvh/bvh_intersector1.cpp:60-125, bvh_traverser1.h:41-104, common/stack_item.h:39-60):
+ *   - a child counts only when the ray passes its box by the node's slab test (embree_box_near: embree_box_visible's arithmetic) under the hit
+ *     distance found so far (`ray_far = ray.tfar` after every leaf);
+ *   - one child hit: descend; two: the first only `if (d0 < d1)`, the other is pushed; three / four: all pushed, sorted by Embree's
+ *     networks on the entry distances' bit patterns, the nearest popped;
+ *   - a node or leaf popped behind the hit so far is skipped (`stackPtr->dist > ray.tfar`) -- by its BOX's entry distance, which can lie an
+ *     ulp behind the distance the primitive's own intersect() would report.
+ * With coincident faces (the Cornell box's blocks stand ON the floor; a light lies IN the ceiling; a Sobol' point on the image's diagonal sends
+ * its ray into the seam of floor and wall) these rules, not the distance alone, decide which primitive a ray hits: 99 samples in 12 golden cases
+ * and the seam samples of the stress renders followed another path before.
+ * Scenes without top_nodes (triangles have their own Embree geometry and live in ONE tree with the other records here; disks and cylinders:
+ * bounds not restated) keep the plain list / the BVH. */
+static int embree_box_near(const Ray *ray, v3 lo, v3 hi, float *tNearOut)
+{
+    const float o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};
+    const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+    float tNear = fmaxf(ray->tmin, 0.0f), tFar = fmaxf(ray->tmax, 0.0f);
+    float n[3], f[3];
+    for (int k = 0; k < 3; ++k) {
+        float a = fabsf(d[k]) < 1e-18f ? 1e-18f : d[k];           /* zero_fix */
+        float rdir = embree_rcp(a);
+        n[k] = ((rdir >= 0.0f ? l[k] : h[k]) - o[k])*rdir;
+        f[k] = ((rdir >= 0.0f ? h[k] : l[k]) - o[k])*rdir;
+    }
+    int32_t in[3], ifr[3], it, ift;                               /* maxi / mini: on the bit patterns as signed integers */
+    memcpy(in, n, 12); memcpy(ifr, f, 12); memcpy(&it, &tNear, 4); memcpy(&ift, &tFar, 4);
+    int32_t nxy = in[0] > in[1] ? in[0] : in[1], nzt = in[2] > it ? in[2] : it, nn = nxy > nzt ? nxy : nzt;
+    int32_t fxy = ifr[0] > ifr[1] ? ifr[1] : ifr[0], fzt = ifr[2] > ift ? ift : ifr[2], ff = fxy > fzt ? fzt : fxy;
+    memcpy(tNearOut, &nn, 4);
+    return !(nn > ff);
+}
+/* Quad::bounds (Quad.cpp:281-289), Cube::bounds (Cube.cpp:333-344), Sphere::bounds (Sphere.cpp:273-276) from the flattened object; 0 for
+ * a record kind whose bounds are not restated.  (tungsten_hip.hip: referenceLeafBounds is the library's copy.) */
+int oracle_leaf_bounds(const TgHipSceneDesc *s, uint32_t i, float lo3[3], float hi3[3])
+{
+    const TgHipPrimRec *r = &s->recs[i];
+    const TgHipObject *o = &s->objects[TGHIP_REC_OBJECT(r->meta)];
+    v3 p[8]; int n = 0;
+    switch (TGHIP_REC_KIND(r->meta)) {
+    case TGHIP_REC_QUAD: { v3 b = ld3(o->base), e0 = ld3(o->edge0), e1 = ld3(o->edge1); p[0] = b; p[1] = vadd(b, e0); p[2] = vadd(b, e1); p[3] = vadd(vadd(b, e0), e1); n = 4; break; }
+    case TGHIP_REC_CUBE:
+        for (int k = 0; k < 8; ++k)
+            p[k] = vadd(ld3(o->pos), mat3_mul(o->rot, V((k & 1) ? o->scale[0] : -o->scale[0], (k & 2) ? o->scale[1] : -o->scale[1], (k & 4) ? o->scale[2] : -o->scale[2])));
+        n = 8; break;
+    case TGHIP_REC_SPHERE: { v3 c = ld3(o->pos); float rr = o->scale[0]; p[0] = V(c.x - rr, c.y - rr, c.z - rr); p[1] = V(c.x + rr, c.y + rr, c.z + rr); n = 2; break; }
+    default: return 0;
+    }
+    v3 lo = p[0], hi = p[0];
+    for (int k = 1; k < n; ++k) {
+        lo = V(p[k].x < lo.x ? p[k].x : lo.x, p[k].y < lo.y ? p[k].y : lo.y, p[k].z < lo.z ? p[k].z : lo.z);   /* Box::grow: min(_min, p), MathUtil.hpp:33-52 */
+        hi = V(p[k].x > hi.x ? p[k].x : hi.x, p[k].y > hi.y ? p[k].y : hi.y, p[k].z > hi.z ? p[k].z : hi.z);
+    }
+    lo3[0] = lo.x; lo3[1] = lo.y; lo3[2] = lo.z; hi3[0] = hi.x; hi3[1] = hi.y; hi3[2] = hi.z;
+    return 1;
+}
+static int g_flat_order = 1;
+void oracle_set_flat_order(int on) { g_flat_order = on; }     /* 0: the plain list in record order (tests: what the order changes) */
+typedef struct { int32_t ref; uint32_t dist; } TopStackItem;
+static void top_swap(TopStackItem *a, TopStackItem *b) { TopStackItem t = *a; *a = *b; *b = t; }
+static int embree_top_walk(const TgHipSceneDesc *s, const Ray *ray0, Hit *hit, TravStats *st, int objFilter)
+{
+    Ray ray = *ray0;                                                /* ray.tmax is Embree's ray.tfar */
+    float rayFar = fmaxf(ray.tmax, 0.0f);                           /* ray_far: max(ray.tfar, 0) at first, ray.tfar after a leaf */
+    TopStackItem stack[64];
+    int sp = 0;
+    stack[sp].ref = 0; stack[sp].dist = 0xFF800000u; sp++;           /* root, dist = neg_inf */
+    if (st) st->prims += s->num_recs;                                /* the unit both sides count: the list's records, once per ray */
+    while (sp > 0) {
+        --sp;
+        int32_t cur = stack[sp].ref;
+        float popDist; memcpy(&popDist, &stack[sp].dist, 4);
+        if (popDist > ray.tmax) continue;                            /* popped behind the hit so far */
+        int descend = 1;
+        while (cur >= 0) {
+            const TgHipTopNode *n = &s->top_nodes[cur];
+            int hitSlot[4], nh = 0; uint32_t hitDist[4];
+            Ray probe = ray; probe.tmax = rayFar;
+            for (int i = 0; i < 4; ++i) {
+                if (n->child[i] == TGHIP_TOP_EMPTY) continue;
+                float tn;
+                if (!embree_box_near(&probe, ld3(n->lower[i]), ld3(n->upper[i]), &tn)) continue;
+                hitSlot[nh] = i; memcpy(&hitDist[nh], &tn, 4); nh++;
+            }
+            if (nh == 0) { descend = 0; break; }
+            if (nh == 1) { cur = n->child[hitSlot[0]]; continue; }
+            if (nh == 2) {
+                int32_t c0 = n->child[hitSlot[0]], c1 = n->child[hitSlot[1]];
+                if (hitDist[0] < hitDist[1]) { stack[sp].ref = c1; stack[sp].dist = hitDist[1]; sp++; cur = c0; }
+                else                         { stack[sp].ref = c0; stack[sp].dist = hitDist[0]; sp++; cur = c1; }
+                continue;
+            }
+            for (int k = 0; k < nh; ++k) { stack[sp].ref = n->child[hitSlot[k]]; stack[sp].dist = hitDist[k]; sp++; }
+            TopStackItem *s1 = &stack[sp - 1], *s2 = &stack[sp - 2], *s3 = &stack[sp - 3];
+            if (nh == 3) {
+                if (s2->dist < s1->dist) top_swap(s2, s1);
+                if (s3->dist < s2->dist) top_swap(s3, s2);
+                if (s2->dist < s1->dist) top_swap(s2, s1);
+            } else {
+                TopStackItem *s4 = &stack[sp - 4];
+                if (s2->dist < s1->dist) top_swap(s2, s1);
+                if (s4->dist < s3->dist) top_swap(s4, s3);
+                if (s3->dist < s1->dist) top_swap(s3, s1);
+                if (s4->dist < s2->dist) top_swap(s4, s2);
+                if (s3->dist < s2->dist) top_swap(s3, s2);
+            }
+            cur = stack[sp - 1].ref; sp--;
+        }
+        if (!descend) continue;
+        const uint32_t rec = (uint32_t)~cur;
+        if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[rec].meta) == objFilter)
+            test_rec(s, rec, &ray, &ray.tmax, hit, NULL, objFilter, -1);
+        rayFar = ray.tmax;
+    }
+    return hit->rec >= 0;
+}
+
 static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, Hit *hit, TravStats *st, int objFilter)
 {
     float tmax = ray->tmax;
     hit->rec = -1; hit->inst = -1; hit->t = tmax; hit->u = hit->v = 0.0f;
     if (st) st->rays++;
+    if (s->top_nodes && s->num_top_nodes && g_flat_order)
+        return embree_top_walk(s, ray, hit, st, objFilter);
     if (s->num_recs <= TGHIP_FLAT_MAX_RECS && s->num_instances == 0) {           /* flat list (include/tungsten_hip.h) */
         for (uint32_t i = 0; i < s->num_recs; ++i)
             if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
@@ -3933,6 +4054,52 @@ int oracle_trace_rays(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *h
     if (nodes_visited) *nodes_visited = st.nodes;
     if (prims_tested) *prims_tested = st.prims;
     return 0;
+}
+
+/* The DEVICE's shortcut for the walk of the reference's tree (csrc/hip/pt_kernels.h: flatClosestOrdered), restated here so that the CPU suite can
+ * hold its claim against embree_top_walk above on rays chosen to tie (tests/test_flat_order.py): test every record against the ray's own tmax,
+ * keep the nearest hit b and the second nearest distance t2; b is the walk's answer when it is the strict minimum, the ray passes b's leaf box,
+ * and that box is not entered behind t2 -- whatever the tree above the leaves looks like (a box contains its children's, so b's ancestors are
+ * passed and popped no later than b).  Otherwise the device walks the tree as the oracle does.
+ * hits[i] = the answer, decided[i] = 1 when the shortcut applied.  Returns the number of rays on which shortcut and walk differ. */
+static int top_leaf_box(const TgHipSceneDesc *s, int32_t rec, v3 *lo, v3 *hi)
+{
+    for (uint32_t n = 0; n < s->num_top_nodes; ++n)
+        for (int i = 0; i < 4; ++i)
+            if (s->top_nodes[n].child[i] == ~rec) { *lo = ld3(s->top_nodes[n].lower[i]); *hi = ld3(s->top_nodes[n].upper[i]); return 1; }
+    return 0;
+}
+size_t oracle_flat_device_form(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *hits, uint8_t *decided, size_t n)
+{
+    size_t differing = 0;
+    if (!s->top_nodes || !s->num_top_nodes) return (size_t)-1;
+    for (size_t q = 0; q < n; ++q) {
+        Ray ray = {ld3(rays[q].o), ld3(rays[q].d), rays[q].tmin, rays[q].tmax};
+        Hit want, got;
+        want.rec = -1; want.inst = -1; want.t = ray.tmax; want.u = want.v = 0.0f;
+        got = want;
+        embree_top_walk(s, &ray, &want, NULL, -1);
+        float tb = INFINITY, t2 = INFINITY;
+        for (uint32_t i = 0; i < s->num_recs; ++i) {
+            Hit h; float tm = ray.tmax;
+            h.rec = -1; h.inst = -1; h.t = tm; h.u = h.v = 0.0f;
+            test_rec(s, i, &ray, &tm, &h, NULL, -1, -1);
+            if (h.rec >= 0) {
+                if (h.t < tb) { t2 = tb; tb = h.t; got = h; }
+                else t2 = fminf(t2, h.t);
+            }
+        }
+        int dec = 1;
+        if (got.rec >= 0) {
+            v3 lo, hi; float entry;
+            dec = top_leaf_box(s, got.rec, &lo, &hi) && embree_box_near(&ray, lo, hi, &entry) && tb < t2 && entry <= t2;
+            if (!dec) got = want;
+        }
+        if (decided) decided[q] = (uint8_t)dec;
+        if (hits) { hits[q].t = got.t; hits[q].u = got.u; hits[q].v = got.v; hits[q].rec = got.rec; }
+        if (got.rec != want.rec || memcmp(&got.t, &want.t, 4) || memcmp(&got.u, &want.u, 4) || memcmp(&got.v, &want.v, 4)) differing++;
+    }
+    return differing;
 }
 
 /* transmittance kernels and distance samplers on their own (tests/test_media.py): k = 0 SS, 1 SM, 2 MS, 3 MM */

@@ -800,6 +800,14 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     _desc.light_tris = _lightTris.data(); _desc.num_light_tri_floats = _lightTris.size();
     _desc.media = _media.empty() ? nullptr : _media.data();
     _desc.num_media = uint32_t(_media.size());
+    // the top-level Embree tree this very scene committed (TraceableScene.hpp:112-134), in the library's restatement of Embree's builder: where
+    // faces coincide the order in which a ray visits it decides which primitive it hits (include/tungsten_hip.h: TgHipTopNode)
+    _topNodes.assign(_recs.size(), TgHipTopNode());
+    const int numTop = _instanceSets.empty() ? tgh_top_tree_for_scene(_objects.data(), uint32_t(_objects.size()), _recs.data(), uint32_t(_recs.size()),
+                                                                     _topNodes.data(), uint32_t(_topNodes.size())) : 0;
+    _topNodes.resize(size_t(std::max(numTop, 0)));
+    _desc.top_nodes = _topNodes.empty() ? nullptr : _topNodes.data();
+    _desc.num_top_nodes = uint32_t(_topNodes.size());
     if (scene._settings.useSobol()) {
         // the table stays Tungsten's (thirdparty/sobol/sobol.h:30-35)
         _desc.sobol_matrices = reinterpret_cast<const uint32_t *>(sobol::Matrices::matrices);

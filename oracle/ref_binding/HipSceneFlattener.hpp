@@ -43,6 +43,7 @@ class HipSceneFlattener
     std::vector<float> _texels, _dist, _lightTris;
     std::vector<float> _recBounds;
     std::vector<TgHipMedium> _media;
+    std::vector<TgHipTopNode> _topNodes;
     std::vector<const Medium *> _mediumKeys;
     std::map<const Texture *, int32_t> _texIndex;
     std::map<const Bsdf *, int32_t> _bsdfIndex;

@@ -191,3 +191,34 @@ def light_sample(desc, light, p, xi0, xi1):
     dist, pdf = C.c_float(0), C.c_float(0)
     ok = _lib.oracle_light_sample(desc, light, p.ctypes.data, xi0, xi1, d.ctypes.data, C.byref(dist), C.byref(pdf))
     return bool(ok), d, dist.value, pdf.value
+
+
+_lib.oracle_leaf_bounds.argtypes = [DESC_P, C.c_uint32, C.c_void_p, C.c_void_p]
+_lib.oracle_leaf_bounds.restype = C.c_int
+_lib.oracle_flat_device_form.argtypes = [DESC_P, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+_lib.oracle_flat_device_form.restype = C.c_size_t
+_lib.oracle_set_flat_order.argtypes = [C.c_int]
+
+
+def leaf_bounds(desc, rec):
+    """(lo, hi) of the record's leaf box in the reference's Embree BVH, or None for a kind whose bounds are not restated."""
+    lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    return (lo, hi) if _lib.oracle_leaf_bounds(desc, rec, lo.ctypes.data, hi.ctypes.data) else None
+
+
+def flat_device_form(desc, rays):
+    """The device's formulation of the flat-list walk (oracle.c: oracle_flat_device_form): (hits, decided, rays on which it differs from the walk)."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+    hits = np.empty(rays.shape[0], dtype=[("t", np.float32), ("u", np.float32), ("v", np.float32), ("rec", np.int32)])
+    decided = np.zeros(rays.shape[0], np.uint8)
+    differing = _lib.oracle_flat_device_form(desc, rays.ctypes.data, hits.ctypes.data, decided.ctypes.data, rays.shape[0])
+    return hits, decided.astype(bool), int(differing)
+
+
+def trace_rays_plain_list(desc, rays):
+    """Closest hits of the plain list in record order (what flat lists were walked as before the visiting order of Embree's leaves was restated)."""
+    _lib.oracle_set_flat_order(0)
+    try:
+        return trace_rays(desc, rays)[0]
+    finally:
+        _lib.oracle_set_flat_order(1)

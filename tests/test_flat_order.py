@@ -1,0 +1,113 @@
+"""Flat lists of quads / cubes / spheres in the visiting order of Embree's one-primitive leaves (include/tungsten_hip.h: TGHIP_FLAT_MAX_RECS,
+oracle.c: embree_ordered_flat, pt_kernels.h: flatClosestOrdered).  The golden cases pin the ORDER against the reference (tests/
+test_oracle_golden.py: not one of 549 504 samples off since it was restated); here the CPU suite holds the device's FORMULATION of it -- test
+every record, decide from the nearest and the second nearest hit, walk the list leaf by leaf only when that cannot decide -- against the walk,
+on rays made to tie: origins on surfaces and inside blocks, directions along faces, at seams, edges and corners, tmax exactly at a hit."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenes
+import tungsten_amd as tg
+
+
+def tie_rays(desc, seed=5, n=6000):
+    """Rays of the kinds a path produces in a box of coincident faces, as (n, 8) float32: o, tmin, d, tmax."""
+    rs = np.random.RandomState(seed)
+    boxes = [oracle_lib.leaf_bounds(desc, i) for i in range(desc.contents.num_recs)]
+    assert all(b is not None for b in boxes)
+    lo = np.min([b[0] for b in boxes], axis=0)
+    hi = np.max([b[1] for b in boxes], axis=0)
+
+    def norm(v):
+        return v/np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-30)
+
+    def pack(o, d, tmin, tmax):
+        return np.concatenate([o, np.full((len(o), 1), tmin), d, np.reshape(tmax, (-1, 1))*np.ones((len(o), 1))], axis=1).astype(np.float32)
+
+    def box_points(k):
+        """points on corners, edges and faces of random leaf boxes"""
+        b = [boxes[i] for i in rs.randint(len(boxes), size=k)]
+        w = rs.choice([0.0, 1.0, 0.5, -1.0], size=(k, 3), p=[0.3, 0.3, 0.1, 0.3])
+        w = np.where(w < 0, rs.rand(k, 3), w)
+        return np.array([bb[0] + ww*(bb[1] - bb[0]) for bb, ww in zip(b, w)], np.float32)
+
+    out = []
+    # camera-like rays at seams, edges and corners
+    eye = np.array([[0.0, 1.0, 6.8]], np.float32)*np.ones((n, 1), np.float32)
+    out.append(pack(eye, norm(box_points(n) - eye), 1e-4, np.inf))
+    # second-generation rays: from the hit points of the first, random / axis-parallel / aimed at box features, some with tmax AT a hit
+    first = out[0]
+    hits = oracle_lib.trace_rays(desc, first)[0]
+    ok = hits["rec"] >= 0
+    p = (first[ok, 0:3] + first[ok, 4:7]*hits["t"][ok, None]).astype(np.float32)
+    d = norm(rs.randn(len(p), 3))
+    axis = np.eye(3, dtype=np.float32)[rs.randint(3, size=len(p))]*rs.choice([-1.0, 1.0], size=(len(p), 1))
+    d = np.where((rs.rand(len(p), 1) < 0.15), axis, d)
+    out.append(pack(p, d, 5e-4, np.inf))
+    aim = box_points(len(p))
+    dist = np.linalg.norm(aim - p, axis=1).astype(np.float32)
+    out.append(pack(p, norm(aim - p), 5e-4, dist))                         # shadow-like: tmax at the point aimed at
+    out.append(pack(p, norm(aim - p), 5e-4, np.inf))
+    # origins INSIDE the blocks (a see-through block's interior), straight and nearly straight down / sideways: bottom face against the floor
+    inside = []
+    for i, b in enumerate(boxes):
+        if (b[1] - b[0]).min() > 1e-3*(hi - lo).max():                      # a solid's box, not a quad's
+            inside.append(b[0] + rs.rand(n//8, 3)*(b[1] - b[0]))
+    if inside:
+        q = np.concatenate(inside).astype(np.float32)
+        dd = norm(np.eye(3, dtype=np.float32)[rs.randint(3, size=len(q))]*rs.choice([-1.0, 1.0], size=(len(q), 1)) + 0.3*rs.randn(len(q), 3)*(rs.rand(len(q), 1) < 0.7))
+        out.append(pack(q, dd, 5e-4, np.inf))
+    rays = np.concatenate(out)
+    # re-trace with tmax exactly at the distance found (a quad accepts t <= farT, a cube t < farT)
+    h2 = oracle_lib.trace_rays(desc, rays)[0]
+    again = rays[h2["rec"] >= 0].copy()
+    again[:, 7] = h2["t"][h2["rec"] >= 0]
+    return np.concatenate([rays, again])
+
+
+CASES = {"cornell": (scenes.cornell, {}), "zoo_d": (scenes.cornell_zoo, {"which": "zoo_d"}),
+         "cornell_smoke": scenes.GOLDEN_CASES["cornell_smoke"], "cornell_png_scalar": scenes.GOLDEN_CASES["cornell_png_scalar"]}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_formulation_is_the_walk(name, tmp_path):
+    mk, kw = CASES[name]
+    flat = tg.FlattenedScene(mk(tmp_path, **dict(kw, resolution=(16, 9), spp=1)))
+    rays = tie_rays(flat.desc)
+    hits, decided, differing = oracle_lib.flat_device_form(flat.desc, rays)
+    walk = oracle_lib.trace_rays(flat.desc, rays)[0]
+    plain = oracle_lib.trace_rays_plain_list(flat.desc, rays)
+    flat.close()
+    assert differing == 0
+    for k in ("rec", "t", "u", "v"):
+        assert (hits[k].view(np.uint32) == walk[k].view(np.uint32)).all()
+    # the rays are what they were made to be: some cannot be decided from the list alone, and on some the order changes the answer
+    assert 0 < (~decided).sum() < 0.2*len(rays), ((~decided).sum(), len(rays))
+    changed = (plain["rec"] != walk["rec"]) | (plain["t"].view(np.uint32) != walk["t"].view(np.uint32))
+    assert not (changed & decided).any()                 # ... never where the shortcut applied: there the walk's answer IS the nearest hit
+    if name != "cornell":
+        assert changed.any()
+    print(name, len(rays), "rays,", int((~decided).sum()), "walked,", int(changed.sum()), "answers changed by the order")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_walks_flat_lists_in_the_oracles_order(name, tmp_path):
+    """The same tie-made rays through tghip_trace_rays: record, t, u, v of every ray are the oracle's walk's, bit for bit -- on the rays the
+    device decides from the list and on the ones it walks."""
+    mk, kw = CASES[name]
+    path = mk(tmp_path, **dict(kw, resolution=(16, 9), spp=1))
+    flat = tg.FlattenedScene(path)
+    rays = tie_rays(flat.desc)
+    walk = oracle_lib.trace_rays(flat.desc, rays)[0]
+    _, decided, _ = oracle_lib.flat_device_form(flat.desc, rays)
+    flat.close()
+    r = tg.Renderer(path)
+    got, _ = r.trace_rays(rays)
+    r.close()
+    assert (got["rec"] == walk["rec"]).all(), "record ids differ on %d rays (%d of them walked)" % ((got["rec"] != walk["rec"]).sum(), ((got["rec"] != walk["rec"]) & ~decided).sum())
+    hit = walk["rec"] >= 0
+    for k in ("t", "u", "v"):
+        assert (got[k][hit].view(np.uint32) == walk[k][hit].view(np.uint32)).all(), k
+    assert (~decided).sum() > 1000

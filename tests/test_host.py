@@ -70,7 +70,7 @@ def test_cornell_flattening(tmp_path):
     flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(64, 36), spp=4))
     d = flat.desc.contents
     assert (flat.width, flat.height) == (64, 36)
-    assert d.abi_version == 9
+    assert d.abi_version == 10
     assert d.num_objects == 8 and d.num_lights == 1 and d.num_infinite_lights == 0
     assert d.num_recs == 8                       # 6 quads + 2 cubes, analytic records (Quad.cpp / Cube.cpp)
     light = d.objects[d.lights[0]]
@@ -587,3 +587,27 @@ def test_oracle_rcpps_is_the_intel_instruction():
     lib.libm_host_rcpps_hw(x.ctypes.data_as(C.c_void_p), hw.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
     same = (hw.view(np.uint32) == est.view(np.uint32))
     assert same.all(), (int((~same).sum()), hex(int(x.view(np.uint32)[~same][0])), hex(int(hw.view(np.uint32)[~same][0])), hex(int(est.view(np.uint32)[~same][0])))
+
+
+def test_leaf_bounds_are_the_oracles(tmp_path):
+    """Quad::bounds / Cube::bounds / Sphere::bounds as the library restates them for the items of the reference's top-level tree
+    (include/tungsten_host.h: tgh_leaf_bounds) against oracle.c's restatement, bit for bit, on scenes with rotated cubes and spheres; a
+    record kind without restated bounds (triangles, disks) answers 0 on both sides."""
+    import oracle_lib
+    lib = capi.load_library()
+    answers = {}
+    cases = [(scenes.cornell, {}), (scenes.cornell_zoo, {"which": "zoo_d"}), scenes.GOLDEN_CASES["cornell_disks"], scenes.GOLDEN_CASES["cornell_bump"]]
+    for mk, kw in cases:
+        flat = tg.FlattenedScene(mk(tmp_path, **dict(kw, resolution=(16, 9), spp=1)))
+        d = flat.desc.contents
+        a = np.zeros((2, 3), np.float32)
+        for i in range(min(d.num_recs, 64)):
+            kind, obj = d.recs[i].meta >> 29, d.recs[i].meta & 0x1FFFFFFF
+            ra = lib.tgh_leaf_bounds(C.byref(d.objects[obj]), kind, a[0].ctypes.data, a[1].ctypes.data)
+            b = oracle_lib.leaf_bounds(flat.desc, i)
+            assert ra == (1 if kind in (1, 2, 3) else 0) and (b is not None) == bool(ra), (kind, ra)
+            answers[kind] = ra
+            if ra:
+                assert (a[0].view(np.uint32) == b[0].view(np.uint32)).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all() and (a[0] <= a[1]).all()
+        flat.close()
+    assert answers == {0: 0, 1: 1, 2: 1, 3: 1, 5: 0}          # triangles, quads, cubes, spheres, disks

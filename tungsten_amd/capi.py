@@ -73,6 +73,13 @@ class TgHipSettings(C.Structure):
                 ("enable_two_sided_shading", i32), ("enable_consistency_checks", i32), ("enable_volume_light_sampling", i32), ("pad", i32*2)]
 
 
+class TgHipTopNode(C.Structure):
+    _fields_ = [("lower", (f32*3)*4), ("upper", (f32*3)*4), ("child", i32*4)]
+
+
+TGHIP_TOP_EMPTY = 0x7FFFFFFF
+
+
 class TgHipSceneDesc(C.Structure):
     _fields_ = [("abi_version", u32), ("num_nodes", u32), ("num_recs", u32), ("num_objects", u32),
                 ("num_lights", u32), ("num_infinite_lights", u32), ("num_bsdfs", u32), ("num_textures", u32),
@@ -89,6 +96,7 @@ class TgHipSceneDesc(C.Structure):
                 ("inst_leaf_boxes", C.POINTER(f32)), ("inst_tight_boxes", C.POINTER(f32)),
                 ("media", C.POINTER(TgHipMedium)), ("num_media", u32),
                 ("wide_nodes", C.POINTER(TgHipWideNode)), ("num_wide_nodes", u32),
+                ("top_nodes", C.POINTER(TgHipTopNode)), ("num_top_nodes", u32),
                 ("camera", TgHipCamera), ("settings", TgHipSettings),
                 ("bounds_lo", f32*3), ("bounds_hi", f32*3)]
 
@@ -208,6 +216,9 @@ PROTOTYPES = {
     "tgh_accel_inst_tight_boxes": (VP, [VP]),
     "tgh_accel_counts": (None, [VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "tgh_instance_tight_bounds": (None, [VP, C.c_uint32, C.c_uint32, VP, VP, VP, VP]),
+    "tgh_top_tree_build": (C.c_int, [VP, C.c_uint32, VP, C.c_uint32]),
+    "tgh_top_tree_for_scene": (C.c_int, [VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32]),
+    "tgh_leaf_bounds": (C.c_int, [VP, C.c_uint32, VP, VP]),
     "tgh_save_pfm": (C.c_int, [C.c_char_p, VP, C.c_int, C.c_int]),
     "tgh_load_hdr": (C.c_int, [C.c_char_p, VP, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

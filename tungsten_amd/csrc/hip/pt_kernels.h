@@ -589,6 +589,134 @@ PT_DEV bool boxTest(f3 lo, f3 hi, const RayD &ray, f3 invD, float tmax, float &t
     return tn <= tf;
 }
 
+// ---- flat lists walked as the reference's tree -----------------------------------------------
+// The reference intersects a scene through Embree's BVH4 over its finite primitives, one per leaf, and with coincident faces (a block
+// standing ON the floor quad, a light lying IN the ceiling, a ray into the seam of two walls) Embree's visiting rules decide which primitive
+// a ray hits (include/tungsten_hip.h: TgHipTopNode has the rules and the citations; oracle.c: embree_top_walk is the test side's copy).
+// Scenes that carry the tree (DeviceScene::top_nodes: flat lists of quads, cubes and spheres) are intersected by flatClosestOrdered.
+struct EmbreeRay { float o[3], rdir[3], tNear, tFar; };
+PT_DEV EmbreeRay embreeRay(const RayD &ray)
+{
+    EmbreeRay e;
+    const float d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    e.o[0] = ray.o.x; e.o[1] = ray.o.y; e.o[2] = ray.o.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        e.rdir[k] = embreeRcp(fabsf(d[k]) < 1e-18f ? 1e-18f : d[k]);
+    e.tNear = fmaxf(ray.tmin, 0.0f); e.tFar = fmaxf(ray.tmax, 0.0f);
+    return e;
+}
+// the node's slab test for one child box (embreeBoxVisible's arithmetic) under e.tFar; entry = the box's entry distance
+PT_DEV bool embreeLeafEntry(const EmbreeRay &e, const float *lo, const float *hi, float &entry)
+{
+    int n[3], f[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool pos = e.rdir[k] >= 0.0f;
+        n[k] = __float_as_int(((pos ? lo[k] : hi[k]) - e.o[k])*e.rdir[k]);
+        f[k] = __float_as_int(((pos ? hi[k] : lo[k]) - e.o[k])*e.rdir[k]);
+    }
+    const int nn = max(max(n[0], n[1]), max(n[2], __float_as_int(e.tNear)));     // maxi / mini: the bit patterns as signed integers
+    const int ff = min(min(f[0], f[1]), min(f[2], __float_as_int(e.tFar)));
+    entry = __int_as_float(nn);
+    return !(nn > ff);
+}
+// BVH4Intersector1::intersect over the tree, in full (bvh_intersector1.cpp:60-125): runs for the few rays flatClosestOrdered cannot decide
+// from the plain list.  The stack holds (child, entry distance as its bit pattern); TOP_STACK bounds what a tree of TGHIP_TOP_MAX_DEPTH levels
+// can leave on it (three waiting children per level) -- tghip_upload_scene refuses deeper trees.
+#define TOP_STACK 24
+template<uint32_t KINDS>
+PT_DEV float4 flatOrderedWalk(const DeviceScene &s, const RayD &ray0, EmbreeRay e)
+{
+    RayD ray = ray0;                                    // ray.tmax is Embree's ray.tfar
+    float4 hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
+    int sref[TOP_STACK];
+    uint32_t sdist[TOP_STACK];
+    int sp = 0;
+    sref[0] = 0; sdist[0] = 0xFF800000u; sp = 1;       // the root, dist = neg_inf
+    while (sp > 0) {
+        --sp;
+        int cur = sref[sp];
+        if (__uint_as_float(sdist[sp]) > ray.tmax) continue;           // popped behind the hit so far
+        bool descend = true;
+        while (cur >= 0) {
+            const float *n = s.top_nodes + (uint32_t)cur*28u;
+            int c[4]; uint32_t d[4]; int nh = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int child = __float_as_int(n[24 + i]);
+                float entry;
+                const bool in = child != TGHIP_TOP_EMPTY && embreeLeafEntry(e, n + 3*i, n + 12 + 3*i, entry);
+                if (in) { c[nh] = child; d[nh] = __float_as_uint(entry); nh++; }
+            }
+            if (nh == 0) { descend = false; break; }
+            if (nh == 1) { cur = c[0]; continue; }
+            if (nh == 2) {
+                if (d[0] < d[1]) { sref[sp] = c[1]; sdist[sp] = d[1]; sp++; cur = c[0]; }
+                else             { sref[sp] = c[0]; sdist[sp] = d[0]; sp++; cur = c[1]; }
+                continue;
+            }
+            // three / four children: pushed in slot order, sorted by Embree's networks (common/stack_item.h:44-60; s1 = the top of the stack)
+            int r1, r2, r3, r4 = 0; uint32_t d1, d2, d3, d4 = 0;
+            auto sw = [](int &ra, uint32_t &da, int &rb, uint32_t &db) { const int r = ra; ra = rb; rb = r; const uint32_t x = da; da = db; db = x; };
+            if (nh == 3) {
+                r1 = c[2]; d1 = d[2]; r2 = c[1]; d2 = d[1]; r3 = c[0]; d3 = d[0];
+                if (d2 < d1) sw(r2, d2, r1, d1);
+                if (d3 < d2) sw(r3, d3, r2, d2);
+                if (d2 < d1) sw(r2, d2, r1, d1);
+                sref[sp] = r3; sdist[sp] = d3; sref[sp + 1] = r2; sdist[sp + 1] = d2; sp += 2;
+            } else {
+                r1 = c[3]; d1 = d[3]; r2 = c[2]; d2 = d[2]; r3 = c[1]; d3 = d[1]; r4 = c[0]; d4 = d[0];
+                if (d2 < d1) sw(r2, d2, r1, d1);
+                if (d4 < d3) sw(r4, d4, r3, d3);
+                if (d3 < d1) sw(r3, d3, r1, d1);
+                if (d4 < d2) sw(r4, d4, r2, d2);
+                if (d3 < d2) sw(r3, d3, r2, d2);
+                sref[sp] = r4; sdist[sp] = d4; sref[sp + 1] = r3; sdist[sp + 1] = d3; sref[sp + 2] = r2; sdist[sp + 2] = d2; sp += 3;
+            }
+            cur = r1;
+        }
+        if (!descend) continue;
+        testRecord<false, KINDS>(s, (uint32_t)~cur, ray, ray.tmax, hit);
+        e.tFar = ray.tmax;                                                // ray_far = ray.tfar
+    }
+    return hit;
+}
+// Every lane tests the whole list against the ray's own tmax (uniform record loads, as the plain walk), keeping the nearest hit b and the
+// distance t2 of the second nearest.  The walk returns b whenever b is the strict minimum, the ray passes b's leaf box, and that box is not
+// entered behind t2: a box contains its children's, so b's ancestors are passed and popped no later than b; no hit before b's turn can make
+// b's pop fail (the hits so far are >= t2 >= entry); b's own test accepts t_b under any of them (t_b < t2); nothing behind t_b is accepted
+// afterwards -- whatever the tree looks like.  Otherwise (ties, an ulp between a box and its primitive) the lane walks the tree.
+template<bool COUNT, uint32_t KINDS>
+PT_DEV float4 flatClosestOrdered(const DeviceScene &s, const RayD &ray, uint32_t &primsTested)
+{
+    const uint32_t n = s.num_recs;
+    float4 hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
+    float tb = PT_INF, t2 = PT_INF;
+    for (uint32_t i = 0; i < n; ++i) {
+        float tm = ray.tmax;
+        float4 h;
+        uint32_t meta;
+        if (testRecord<true, KINDS>(s, i, ray, tm, h, meta)) {
+            const bool nearer = h.x < tb;
+            t2 = nearer ? tb : fminf(t2, h.x);
+            if (nearer) { tb = h.x; hit = h; }
+        }
+    }
+    if (COUNT) primsTested += n;
+    const int ri = __float_as_int(hit.w);
+    if (ri >= 0) {
+        const EmbreeRay e = embreeRay(ray);
+        const float4 lo = at32(s.flat_boxes, 2u*(uint32_t)ri), hi = at32(s.flat_boxes, 2u*(uint32_t)ri + 1u);
+        const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
+        float entry;
+        const bool decided = embreeLeafEntry(e, l, h, entry) && tb < t2 && entry <= t2;
+        if (!decided)
+            hit = flatOrderedWalk<KINDS>(s, ray, e);
+    }
+    return hit;
+}
+
 // `stack` is this lane's column of the workgroup's LDS stack: stack[level*stride]
 // FLAT: the scene has <= TGHIP_FLAT_MAX_RECS records; every lane walks the whole record list in step, so the
 // record (and quad/cube object) loads have wave-uniform addresses and go through the scalar cache.
@@ -599,6 +727,8 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
     float tmax = ray.tmax;
     float4 hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
     if (FLAT) {
+        if (s.top_nodes)                             // the scene carries the reference's tree: its visiting order decides ties
+            return flatClosestOrdered<COUNT, KINDS>(s, ray, primsTested);
         const uint32_t n = s.num_recs;
         for (uint32_t i = 0; i < n; ++i)
             testRecord<true, KINDS>(s, i, ray, tmax, hit);
@@ -650,6 +780,13 @@ PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, 
     float4 hit;
     uint32_t meta;
     if (FLAT) {
+        if (s.top_nodes) {
+            // generalizedShadowRay asks for the CLOSEST hit and compares it with the light (TraceBase.cpp:79,114-115): with coincident faces at
+            // the light, which record that is follows from the visiting order (flatClosestOrdered), so the any-hit shortcut does not apply
+            const float4 h = flatClosestOrdered<COUNT, KINDS>(s, ray, primsTested);
+            const int ri = __float_as_int(h.w);
+            return ri >= 0 && (int)TGHIP_REC_OBJECT(__float_as_uint(at32(s.recs, (uint32_t)ri*3u).w)) != endCap;
+        }
         const uint32_t n = s.num_recs;
         bool occluded = false;
         for (uint32_t i = 0; i < n; ++i) {

@@ -1194,6 +1194,45 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         if ((rc = uploadArray(ctx, ctx->sceneMem, reinterpret_cast<const float4 *>(sd->inst_tight_boxes), size_t(sd->num_top_recs)*2, &tight)) != TGHIP_OK) return rc;
         s.inst_tight_boxes = tight;
     }
+    s.top_nodes = nullptr;
+    s.flat_boxes = nullptr;
+    if (sd->top_nodes && sd->num_top_nodes) {
+        // the reference's top-level Embree tree (TgHipTopNode): flat lists only, every record exactly one leaf, children behind their parents
+        // (preorder: no cycles), no deeper than the walk's stack allows (pt_kernels.h: flatOrderedWalk)
+        const uint32_t nn = sd->num_top_nodes;
+        bool ok = sd->num_recs >= 2 && sd->num_recs <= TGHIP_FLAT_MAX_RECS && !sd->num_instances && nn < sd->num_recs;
+        std::vector<float4> boxes(size_t(sd->num_recs)*2);
+        std::vector<int> leafOf(sd->num_recs, 0), depth(nn, 0), parents(nn, 0);
+        if (ok) depth[0] = 1;
+        for (uint32_t n = 0; n < nn && ok; ++n) {
+            ok = depth[n] >= 1 && depth[n] <= TGHIP_TOP_MAX_DEPTH && (n == 0 || parents[n] == 1);
+            for (int i = 0; i < 4 && ok; ++i) {
+                const int32_t c = sd->top_nodes[n].child[i];
+                if (c == TGHIP_TOP_EMPTY) continue;
+                if (c >= 0) {
+                    ok = uint32_t(c) > n && uint32_t(c) < nn;
+                    if (ok) { depth[c] = depth[n] + 1; parents[c]++; }
+                } else {
+                    const uint32_t r = uint32_t(~c);
+                    ok = r < sd->num_recs && leafOf[r]++ == 0;
+                    if (ok) {
+                        const TgHipTopNode &t = sd->top_nodes[n];
+                        boxes[2*r] = make_float4(t.lower[i][0], t.lower[i][1], t.lower[i][2], 0.0f);
+                        boxes[2*r + 1] = make_float4(t.upper[i][0], t.upper[i][1], t.upper[i][2], 0.0f);
+                    }
+                }
+            }
+        }
+        for (uint32_t r = 0; r < sd->num_recs && ok; ++r) {
+            const uint32_t kind = TGHIP_REC_KIND(sd->recs[r].meta);
+            ok = leafOf[r] == 1 && (kind == TGHIP_REC_QUAD || kind == TGHIP_REC_CUBE || kind == TGHIP_REC_SPHERE);
+        }
+        if (!ok) { ctx->error = "top_nodes: not the tree of a flat list (every record one leaf, preorder, depth <= TGHIP_TOP_MAX_DEPTH)"; return TGHIP_E_INVALID; }
+        static_assert(sizeof(TgHipTopNode) == 28*sizeof(float), "TgHipTopNode layout");
+        if ((rc = uploadArray(ctx, ctx->sceneMem, reinterpret_cast<const float *>(sd->top_nodes), size_t(nn)*28, &s.top_nodes)) != TGHIP_OK) return rc;
+        if ((rc = uploadArray(ctx, ctx->sceneMem, boxes.data(), boxes.size(), &s.flat_boxes)) != TGHIP_OK) return rc;
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // boxes goes out of scope
+    }
     s.media = nullptr;
     s.num_media = sd->num_media;
     if (sd->num_media && (rc = uploadArray(ctx, ctx->sceneMem, sd->media, size_t(sd->num_media), &s.media)) != TGHIP_OK) return rc;

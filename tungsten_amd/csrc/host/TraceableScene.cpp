@@ -1,4 +1,5 @@
 #include "TraceableScene.hpp"
+#include "EmbreeTopTree.hpp"
 #include "Sampling.hpp"
 #include "BvhBuilder.hpp"
 #include "WideBvh.hpp"
@@ -755,6 +756,12 @@ void TraceableScene::flatten()
     _desc.inst_tight_boxes = _instTightBoxes.empty() ? nullptr : _instTightBoxes.data();
     _desc.wide_nodes = _wideNodes.empty() ? nullptr : _wideNodes.data();
     _desc.num_wide_nodes = uint32_t(_wideNodes.size());
+    // the reference's top-level Embree tree, for flat lists of quads / cubes / spheres (EmbreeTopTree.hpp): the visiting order where faces coincide
+    _topNodes.clear();
+    if (_instPrims.empty())
+        _topNodes = buildSceneTopTree(_objects.data(), uint32_t(_objects.size()), _recs.data(), uint32_t(_recs.size()));
+    _desc.top_nodes = _topNodes.empty() ? nullptr : _topNodes.data();
+    _desc.num_top_nodes = uint32_t(_topNodes.size());
     _desc.num_media = uint32_t(_media.size());
     _desc.texels = _texels.data(); _desc.num_texel_floats = _texels.size();
     _desc.dist = _dist.data();     _desc.num_dist_floats = _dist.size();

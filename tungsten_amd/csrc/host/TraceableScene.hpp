@@ -66,6 +66,7 @@ class TraceableScene
 
     std::vector<TgHipBvhNode> _nodes;
     std::vector<TgHipWideNode> _wideNodes;
+    std::vector<TgHipTopNode> _topNodes;
     std::vector<TgHipPrimRec> _recs;
     std::vector<TgHipTriAttr> _triAttrs;
     std::vector<TgHipObject> _objects;

@@ -1,6 +1,7 @@
 // extern "C" view of the host classes (include/tungsten_host.h).
 #include "../../../include/tungsten_host.h"
 
+#include "EmbreeTopTree.hpp"
 #include "ImageIO.hpp"
 #include "Integrator.hpp"
 #include "Sampling.hpp"
@@ -404,6 +405,33 @@ void tgh_instance_tight_bounds(const float *master_verts, uint32_t stride_floats
     QuaternionF q(rot[0], rot[1], rot[2], rot[3]);
     Box3f t = tightInstanceBox(master_verts, stride_floats, num_verts, q, Vec3f(pos[0], pos[1], pos[2]), ref);
     for (int k = 0; k < 3; ++k) { out[k] = t.lo[k]; out[3 + k] = t.hi[k]; }
+}
+
+int tgh_top_tree_build(const float *boxes, uint32_t n, TgHipTopNode *nodes, uint32_t capacity)
+{
+    if (!boxes && n) return -1;
+    std::vector<TopBox> in(n);
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) { in[i].lo[k] = boxes[6*i + k]; in[i].hi[k] = boxes[6*i + 3 + k]; }
+    const std::vector<TgHipTopNode> tree = buildEmbreeTopTree(in);
+    if (tree.size() > capacity || (!tree.empty() && !nodes)) return -1;
+    if (!tree.empty()) std::memcpy(nodes, tree.data(), tree.size()*sizeof(TgHipTopNode));
+    return int(tree.size());
+}
+
+int tgh_top_tree_for_scene(const TgHipObject *objects, uint32_t num_objects, const TgHipPrimRec *recs, uint32_t num_recs,
+                           TgHipTopNode *nodes, uint32_t capacity)
+{
+    if ((!objects && num_objects) || (!recs && num_recs)) return -1;
+    const std::vector<TgHipTopNode> tree = buildSceneTopTree(objects, num_objects, recs, num_recs);
+    if (tree.size() > capacity || (!tree.empty() && !nodes)) return -1;
+    if (!tree.empty()) std::memcpy(nodes, tree.data(), tree.size()*sizeof(TgHipTopNode));
+    return int(tree.size());
+}
+
+int tgh_leaf_bounds(const TgHipObject *object, uint32_t kind, float lo[3], float hi[3])
+{
+    return (object && lo && hi && referenceLeafBounds(*object, kind, lo, hi)) ? 1 : 0;
 }
 
 int tgh_save_pfm(const char *path, const float *rgb, int w, int h)
