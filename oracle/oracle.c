@@ -4057,10 +4057,11 @@ int oracle_trace_rays(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *h
 }
 
 /* The DEVICE's shortcut for the walk of the reference's tree (csrc/hip/pt_kernels.h: flatClosestOrdered), restated here so that the CPU suite can
- * hold its claim against embree_top_walk above on rays chosen to tie (tests/test_flat_order.py): test every record against the ray's own tmax,
- * keep the nearest hit b and the second nearest distance t2; b is the walk's answer when it is the strict minimum, the ray passes b's leaf box,
- * and that box is not entered behind t2 -- whatever the tree above the leaves looks like (a box contains its children's, so b's ancestors are
- * passed and popped no later than b).  Otherwise the device walks the tree as the oracle does.
+ * hold its claim against embree_top_walk above on rays chosen to tie (tests/test_flat_order.py): test every record against the ray's own tmax;
+ * of the records hit whose leaf box the ray passes (a box missed under the ray's own tmax is never reached by the walk) keep the nearest hit b
+ * and the second nearest distance t2; b is the walk's answer when it is the strict minimum and its box is not entered behind t2 -- whatever the
+ * tree above the leaves looks like (a box contains its children's, so b's ancestors are passed and popped no later than b); with no such record
+ * the walk finds nothing.  Otherwise the device walks the tree as the oracle does.
  * hits[i] = the answer, decided[i] = 1 when the shortcut applied.  Returns the number of rays on which shortcut and walk differ. */
 static int top_leaf_box(const TgHipSceneDesc *s, int32_t rec, v3 *lo, v3 *hi)
 {
@@ -4079,22 +4080,19 @@ size_t oracle_flat_device_form(const TgHipSceneDesc *s, const TgHipRay *rays, Tg
         want.rec = -1; want.inst = -1; want.t = ray.tmax; want.u = want.v = 0.0f;
         got = want;
         embree_top_walk(s, &ray, &want, NULL, -1);
-        float tb = INFINITY, t2 = INFINITY;
+        float tb = INFINITY, t2 = INFINITY, entryB = 0.0f;
         for (uint32_t i = 0; i < s->num_recs; ++i) {
             Hit h; float tm = ray.tmax;
             h.rec = -1; h.inst = -1; h.t = tm; h.u = h.v = 0.0f;
             test_rec(s, i, &ray, &tm, &h, NULL, -1, -1);
-            if (h.rec >= 0) {
-                if (h.t < tb) { t2 = tb; tb = h.t; got = h; }
+            v3 lo, hi; float entry;
+            if (h.rec >= 0 && top_leaf_box(s, (int32_t)i, &lo, &hi) && embree_box_near(&ray, lo, hi, &entry)) {
+                if (h.t < tb) { t2 = tb; tb = h.t; got = h; entryB = entry; }
                 else t2 = fminf(t2, h.t);
             }
         }
-        int dec = 1;
-        if (got.rec >= 0) {
-            v3 lo, hi; float entry;
-            dec = top_leaf_box(s, got.rec, &lo, &hi) && embree_box_near(&ray, lo, hi, &entry) && tb < t2 && entry <= t2;
-            if (!dec) got = want;
-        }
+        int dec = got.rec < 0 || (tb < t2 && entryB <= t2);
+        if (!dec) got = want;
         if (decided) decided[q] = (uint8_t)dec;
         if (hits) { hits[q].t = got.t; hits[q].u = got.u; hits[q].v = got.v; hits[q].rec = got.rec; }
         if (got.rec != want.rec || memcmp(&got.t, &want.t, 4) || memcmp(&got.u, &want.u, 4) || memcmp(&got.v, &want.v, 4)) differing++;

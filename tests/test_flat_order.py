@@ -1,8 +1,9 @@
-"""Flat lists of quads / cubes / spheres in the visiting order of Embree's one-primitive leaves (include/tungsten_hip.h: TGHIP_FLAT_MAX_RECS,
-oracle.c: embree_ordered_flat, pt_kernels.h: flatClosestOrdered).  The golden cases pin the ORDER against the reference (tests/
-test_oracle_golden.py: not one of 549 504 samples off since it was restated); here the CPU suite holds the device's FORMULATION of it -- test
-every record, decide from the nearest and the second nearest hit, walk the list leaf by leaf only when that cannot decide -- against the walk,
-on rays made to tie: origins on surfaces and inside blocks, directions along faces, at seams, edges and corners, tmax exactly at a hit."""
+"""Flat lists of quads / cubes / spheres intersected by walking the reference's top-level Embree tree (include/tungsten_hip.h: TgHipTopNode,
+oracle.c: embree_top_walk, pt_kernels.h: flatClosestOrdered).  tests/test_top_tree.py pins the TREE against the reference's own Embree, the
+golden cases pin the WALK against the reference (tests/test_oracle_golden.py: not one of 549 504 samples off since it was restated); here the
+CPU suite holds the device's SHORTCUT -- test every record, decide from the nearest and the second nearest hit among the records whose leaf box
+the ray passes, walk the tree only when that cannot decide -- against the walk, on rays made to tie: origins on surfaces and inside blocks,
+directions along faces, at seams, edges and corners, tmax exactly at a hit."""
 import numpy as np
 import pytest
 
@@ -85,7 +86,7 @@ def test_device_formulation_is_the_walk(name, tmp_path):
     # the rays are what they were made to be: some cannot be decided from the list alone, and on some the order changes the answer
     assert 0 < (~decided).sum() < 0.2*len(rays), ((~decided).sum(), len(rays))
     changed = (plain["rec"] != walk["rec"]) | (plain["t"].view(np.uint32) != walk["t"].view(np.uint32))
-    assert not (changed & decided).any()                 # ... never where the shortcut applied: there the walk's answer IS the nearest hit
+    assert (changed & decided).any() or name == "zoo_d"   # (decided without a walk too: a hit primitive whose flat box the ray misses an ulp behind tmax)
     if name != "cornell":
         assert changed.any()
     print(name, len(rays), "rays,", int((~decided).sum()), "walked,", int(changed.sum()), "answers changed by the order")

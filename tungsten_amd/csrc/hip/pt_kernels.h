@@ -624,11 +624,19 @@ PT_DEV bool embreeLeafEntry(const EmbreeRay &e, const float *lo, const float *hi
 // BVH4Intersector1::intersect over the tree, in full (bvh_intersector1.cpp:60-125): runs for the few rays flatClosestOrdered cannot decide
 // from the plain list.  The stack holds (child, entry distance as its bit pattern); TOP_STACK bounds what a tree of TGHIP_TOP_MAX_DEPTH levels
 // can leave on it (three waiting children per level) -- tghip_upload_scene refuses deeper trees.
+// NOT inlined: one ray in a few thousand comes here, and inlined the walk's stack and sorting networks cost every variant of the fused
+// shading kernels registers (and the 168-register variants hundreds of spills) on the path every ray takes.  The function gets what it reads
+// as plain pointers -- a reference to the kernel's DeviceScene would have to be materialised in memory for the call.
 #define TOP_STACK 24
 template<uint32_t KINDS>
-PT_DEV float4 flatOrderedWalk(const DeviceScene &s, const RayD &ray0, EmbreeRay e)
+__device__ __attribute__((noinline)) float4 flatOrderedWalk(const float *topNodes, const float4 *recs, const TgHipObject *objects,
+                                                            float ox, float oy, float oz, float tmin, float dx, float dy, float dz, float tmax)
 {
-    RayD ray = ray0;                                    // ray.tmax is Embree's ray.tfar
+    DeviceScene s;                                      // (only what testRecord reads)
+    s.top_nodes = topNodes; s.recs = recs; s.objects = objects;
+    RayD ray;                                           // ray.tmax is Embree's ray.tfar
+    ray.o = mk3(ox, oy, oz); ray.d = mk3(dx, dy, dz); ray.tmin = tmin; ray.tmax = tmax;
+    EmbreeRay e = embreeRay(ray);
     float4 hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
     int sref[TOP_STACK];
     uint32_t sdist[TOP_STACK];
@@ -682,38 +690,39 @@ PT_DEV float4 flatOrderedWalk(const DeviceScene &s, const RayD &ray0, EmbreeRay 
     }
     return hit;
 }
-// Every lane tests the whole list against the ray's own tmax (uniform record loads, as the plain walk), keeping the nearest hit b and the
-// distance t2 of the second nearest.  The walk returns b whenever b is the strict minimum, the ray passes b's leaf box, and that box is not
-// entered behind t2: a box contains its children's, so b's ancestors are passed and popped no later than b; no hit before b's turn can make
-// b's pop fail (the hits so far are >= t2 >= entry); b's own test accepts t_b under any of them (t_b < t2); nothing behind t_b is accepted
-// afterwards -- whatever the tree looks like.  Otherwise (ties, an ulp between a box and its primitive) the lane walks the tree.
+// Every lane tests the whole list against the ray's own tmax (uniform record loads, as the plain walk) and keeps, of the records it hits
+// AND whose leaf box it passes (a leaf whose box the ray misses under its own tmax is never reached by the walk: the slab test only gets
+// stricter as the hit distance shrinks -- the light a shadow ray ends on is the usual case, its flat box an ulp behind tmax), the nearest hit
+// b and the distance t2 of the second nearest.  The walk returns b whenever b is the strict minimum and its box is not entered behind t2: a
+// box contains its children's, so b's ancestors are passed and popped no later than b; no hit before b's turn can make b's pop fail (the hits
+// so far are >= t2 >= entry); b's own test accepts t_b under any of them (t_b < t2); nothing behind t_b is accepted afterwards -- whatever
+// the tree looks like.  With no such record the walk finds nothing.  Otherwise (ties, a box entered an ulp behind another primitive's hit)
+// the lane walks the tree.
 template<bool COUNT, uint32_t KINDS>
 PT_DEV float4 flatClosestOrdered(const DeviceScene &s, const RayD &ray, uint32_t &primsTested)
 {
     const uint32_t n = s.num_recs;
     float4 hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
-    float tb = PT_INF, t2 = PT_INF;
+    float tb = PT_INF, t2 = PT_INF, entryB = 0.0f;
+    const EmbreeRay e = embreeRay(ray);
     for (uint32_t i = 0; i < n; ++i) {
         float tm = ray.tmax;
         float4 h;
         uint32_t meta;
         if (testRecord<true, KINDS>(s, i, ray, tm, h, meta)) {
-            const bool nearer = h.x < tb;
-            t2 = nearer ? tb : fminf(t2, h.x);
-            if (nearer) { tb = h.x; hit = h; }
+            const PT_CONST_AS float *b = asConst(reinterpret_cast<const float *>(s.flat_boxes)) + 8u*i;     // (uniform: scalar loads)
+            const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[4], b[5], b[6]};
+            float entry;
+            if (embreeLeafEntry(e, lo, hi, entry)) {
+                const bool nearer = h.x < tb;
+                t2 = nearer ? tb : fminf(t2, h.x);
+                if (nearer) { tb = h.x; hit = h; entryB = entry; }
+            }
         }
     }
     if (COUNT) primsTested += n;
-    const int ri = __float_as_int(hit.w);
-    if (ri >= 0) {
-        const EmbreeRay e = embreeRay(ray);
-        const float4 lo = at32(s.flat_boxes, 2u*(uint32_t)ri), hi = at32(s.flat_boxes, 2u*(uint32_t)ri + 1u);
-        const float l[3] = {lo.x, lo.y, lo.z}, h[3] = {hi.x, hi.y, hi.z};
-        float entry;
-        const bool decided = embreeLeafEntry(e, l, h, entry) && tb < t2 && entry <= t2;
-        if (!decided)
-            hit = flatOrderedWalk<KINDS>(s, ray, e);
-    }
+    if (__float_as_int(hit.w) >= 0 && !(tb < t2 && entryB <= t2))
+        hit = flatOrderedWalk<KINDS>(s.top_nodes, s.recs, s.objects, ray.o.x, ray.o.y, ray.o.z, ray.tmin, ray.d.x, ray.d.y, ray.d.z, ray.tmax);
     return hit;
 }
 
