@@ -4,12 +4,11 @@ compared with the reference's own per-sample output (tests/golden/*_samples.npz,
 shared counter-based random stream) AND with the oracle's, by the metric tests/test_oracle_golden.py uses: a sample agrees when every
 channel is within 1e-3 of the other's (relative to the sample's largest channel).
 
-Measured in round 4 (profiles/r4_device_diverge.jsonl, tools/device_vs_oracle.py), with every libm function the path calls and Embree's
-triangle arithmetic restated on the device: in NONE of the 549 504 samples of the 62 cases does the device leave the ORACLE's path, and in 50
-of the cases -- every one with a triangle mesh and the instanced one among them -- neither leaves the REFERENCE's.  What is left are the oracle's own twelve cases
-(coincident faces: test_oracle_golden.DIVERGING), where the device's count is the oracle's.  The bounds
-below are 1.5 x the measured count + 5 samples; BIT_EQUAL_REFERENCE lists the cases in which the device's float32 radiance is the reference's
-bit for bit in every sample."""
+Measured at the end of round 4 (profiles/r4_device_diverge_top_tree.jsonl), with every libm function the path calls, Embree's triangle
+arithmetic and the reference's top-level Embree tree (builder and walk) restated on the device: in NONE of the 549 504 samples of the 62 cases
+does the device leave the oracle's path or the reference's, and its float32 radiance is BOTH's bit for bit in every sample.  No case is
+listed in test_oracle_golden.DIVERGING any more (a case listed there would be held to 1.5 x its measured count + 5 samples), so every case
+asserts bit-equality with the oracle and with the reference."""
 import json
 import os
 

@@ -4,14 +4,11 @@ the reference's own per-sample radiance from the harness against oracle.c, float
 
     python tools/oracle_stress.py [case ...]          LIFT=1e-3 python tools/oracle_stress.py case    (every solid lifted off the floor)
 
-End of round 3: 34 of the 37 cases have no differing sample in 82 944 (36 864 for the 32 x 18 cases); cornell_fog_davis_weinstein 6 and
-cornell_fog_interpolated 4 -- none with LIFT=1e-3: a box's bottom face against the floor quad --; cornell_sobol 1: the first Sobol' point of a
-pixel on the image's 45-degree diagonal hits the seam between the ceiling and the left wall exactly (uv = (1, 0.93)), and the two quads tie.
-Of the twins: cornell_bump_no_mesh 4 (a bump-perturbed frame sends the sampled direction INTO the tall box, whose bottom face coincides with
-the floor: the same tie), cornell_fog_smoke_sobol_lifted 7 samples off by one or two ulps in one channel -- round 4 found the cause:
-in the last of the three segments of a shadow ray that crosses the smoke box, Embree's slab test culls the flat bounding box of the very light
-the ray is aimed at (an ulp behind tfar), so the reference integrates the fog's transmittance over the remaining farT where the oracle, which
-finds the quad, integrates it over the hit distance one ulp shorter --, the other seven none."""
+End of round 4, with the reference's top-level Embree tree restated: 73 of the 75 cases and twins have no differing
+sample in 36 864-147 456 (profiles/r4_oracle_stress_top_tree.txt); cornell_bump 5 -- the tall box's bottom face against the floor quad in a
+scene that, having a mesh, carries no top-level tree here --, mesh1m 1.  (Before the tree: box-bottom ties in the fog cases, the seam of floor
+and wall under the Sobol' sampler's diagonal points, and -- until Embree's leaf test was restated -- one-ulp differences where Embree culls the
+flat box of the light a multi-segment shadow ray ends on.)"""
 import json
 import os
 import subprocess
