@@ -2090,8 +2090,8 @@ static int embree_box_near(const Ray *ray, v3 lo, v3 hi, float *tNearOut)
     memcpy(tNearOut, &nn, 4);
     return !(nn > ff);
 }
-/* Quad::bounds (Quad.cpp:281-289), Cube::bounds (Cube.cpp:333-344), Sphere::bounds (Sphere.cpp:273-276) from the flattened object; 0 for
- * a record kind whose bounds are not restated.  (tungsten_hip.hip: referenceLeafBounds is the library's copy.) */
+/* Quad::bounds (Quad.cpp:281-289), Cube::bounds (Cube.cpp:333-344), Sphere::bounds (Sphere.cpp:273-276), Disk::bounds, Cylinder::bounds from the
+ * flattened object; 0 for a record kind whose bounds are not restated (triangles).  (csrc/host/EmbreeTopTree.cpp: referenceLeafBounds is the library's copy.) */
 int oracle_leaf_bounds(const TgHipSceneDesc *s, uint32_t i, float lo3[3], float hi3[3])
 {
     const TgHipPrimRec *r = &s->recs[i];
@@ -2104,6 +2104,12 @@ int oracle_leaf_bounds(const TgHipSceneDesc *s, uint32_t i, float lo3[3], float 
             p[k] = vadd(ld3(o->pos), mat3_mul(o->rot, V((k & 1) ? o->scale[0] : -o->scale[0], (k & 2) ? o->scale[1] : -o->scale[1], (k & 4) ? o->scale[2] : -o->scale[2])));
         n = 8; break;
     case TGHIP_REC_SPHERE: { v3 c = ld3(o->pos); float rr = o->scale[0]; p[0] = V(c.x - rr, c.y - rr, c.z - rr); p[1] = V(c.x + rr, c.y + rr, c.z + rr); n = 2; break; }
+    case TGHIP_REC_DISK: {          /* Disk::bounds (Disk.cpp:298-306): _center -+ _frame.tangent*_r -+ _frame.bitangent*_r */
+        v3 c = ld3(o->pos), t = vscale(ld3(o->edge0), o->scale[0]), b = vscale(ld3(o->edge1), o->scale[0]);
+        p[0] = vsub(vsub(c, t), b); p[1] = vsub(vadd(c, t), b); p[2] = vadd(vadd(c, t), b); p[3] = vadd(vsub(c, t), b); n = 4; break; }
+    case TGHIP_REC_CYLINDER: {      /* Cylinder::bounds (Cylinder.cpp:272-279): _pos +- _axis*_halfHeight, then grow(_radius); _axis = the second column of _rot (Mat4f.cpp:40-47) */
+        v3 c = ld3(o->pos), a = vscale(V(o->rot[1], o->rot[4], o->rot[7]), o->scale[1]);
+        p[0] = vadd(c, a); p[1] = vsub(c, a); n = 2; break; }
     default: return 0;
     }
     v3 lo = p[0], hi = p[0];
@@ -2111,6 +2117,7 @@ int oracle_leaf_bounds(const TgHipSceneDesc *s, uint32_t i, float lo3[3], float 
         lo = V(p[k].x < lo.x ? p[k].x : lo.x, p[k].y < lo.y ? p[k].y : lo.y, p[k].z < lo.z ? p[k].z : lo.z);   /* Box::grow: min(_min, p), MathUtil.hpp:33-52 */
         hi = V(p[k].x > hi.x ? p[k].x : hi.x, p[k].y > hi.y ? p[k].y : hi.y, p[k].z > hi.z ? p[k].z : hi.z);
     }
+    if (TGHIP_REC_KIND(r->meta) == TGHIP_REC_CYLINDER) { float rr = o->scale[0]; lo = V(lo.x - rr, lo.y - rr, lo.z - rr); hi = V(hi.x + rr, hi.y + rr, hi.z + rr); }
     lo3[0] = lo.x; lo3[1] = lo.y; lo3[2] = lo.z; hi3[0] = hi.x; hi3[1] = hi.y; hi3[2] = hi.z;
     return 1;
 }

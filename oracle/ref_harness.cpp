@@ -22,6 +22,8 @@
 //       the 1024 x 52 generator matrices of the Sobol' sequence (sobol::Matrices::matrices) as u32.
 //   ref_harness sky-image <scene.json> <out.bin>
 //       the sky image the scene's skydome baked (512 x 256 x 3 float32).
+//   ref_harness bounds <scene.json> <out.txt>
+//       bounds() of every finite primitive in scene order: the items' boxes of the reference's top-level Embree geometry.
 //
 // Nothing here is copied from the reference; it only calls its public classes.
 #include <atomic>
@@ -410,6 +412,27 @@ static int cmdSkyImage(int argc, char **argv)
     return 1;
 }
 
+// ref_harness bounds <scene.json> <out.txt>: per finite primitive, in scene order (the items of TraceableScene's user geometry,
+// renderer/TraceableScene.hpp:101-107), its bounds() after prepareForRender as six float bit patterns -- what the library's and the oracle's
+// restatements of Quad / Cube / Sphere / Disk / Cylinder::bounds are held to (tests/golden/prim_bounds.json, tests/test_top_tree.py)
+static int cmdBounds(int argc, char **argv)
+{
+    if (argc < 4) return 2;
+    ThreadUtils::startThreads(1);
+    Loaded l;
+    if (!loadScene(argv[2], 0xBA5EBA11u, l)) return 1;
+    FILE *f = std::fopen(argv[3], "w");
+    if (!f) return 1;
+    for (const std::shared_ptr<Primitive> &p : l.scene->primitives()) {
+        if (p->isInfinite() || p->isDirac()) continue;
+        const Box3f b = p->bounds();
+        const float v[6] = {b.min().x(), b.min().y(), b.min().z(), b.max().x(), b.max().y(), b.max().z()};
+        for (int k = 0; k < 6; ++k) { unsigned u; std::memcpy(&u, &v[k], 4); std::fprintf(f, "%08x%s", u, k == 5 ? "\n" : " "); }
+    }
+    std::fclose(f);
+    return 0;
+}
+
 static int cmdUnits(int argc, char **argv)
 {
     if (argc < 4) return 2;
@@ -599,6 +622,7 @@ int main(int argc, char **argv)
     else if (cmd == "sobol-table") rc = cmdSobolTable(argc, argv);
     else if (cmd == "draws") rc = cmdDraws(argc, argv);
     else if (cmd == "sky-image") rc = cmdSkyImage(argc, argv);
+    else if (cmd == "bounds") rc = cmdBounds(argc, argv);
     if (rc == 2) std::fprintf(stderr, "ref_harness: bad arguments\n");
     return rc;
 }

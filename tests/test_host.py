@@ -592,11 +592,12 @@ def test_oracle_rcpps_is_the_intel_instruction():
 def test_leaf_bounds_are_the_oracles(tmp_path):
     """Quad::bounds / Cube::bounds / Sphere::bounds as the library restates them for the items of the reference's top-level tree
     (include/tungsten_host.h: tgh_leaf_bounds) against oracle.c's restatement, bit for bit, on scenes with rotated cubes and spheres; a
-    record kind without restated bounds (triangles, disks) answers 0 on both sides."""
+    record kind without restated bounds (triangles) answers 0 on both sides.  (tests/test_top_tree.py holds the library's to the reference's own.)"""
     import oracle_lib
     lib = capi.load_library()
     answers = {}
-    cases = [(scenes.cornell, {}), (scenes.cornell_zoo, {"which": "zoo_d"}), scenes.GOLDEN_CASES["cornell_disks"], scenes.GOLDEN_CASES["cornell_bump"]]
+    cases = [(scenes.cornell, {}), (scenes.cornell_zoo, {"which": "zoo_d"}), scenes.GOLDEN_CASES["cornell_disks"], scenes.GOLDEN_CASES["cornell_cylinders"],
+             scenes.GOLDEN_CASES["cornell_bump"]]
     for mk, kw in cases:
         flat = tg.FlattenedScene(mk(tmp_path, **dict(kw, resolution=(16, 9), spp=1)))
         d = flat.desc.contents
@@ -605,9 +606,9 @@ def test_leaf_bounds_are_the_oracles(tmp_path):
             kind, obj = d.recs[i].meta >> 29, d.recs[i].meta & 0x1FFFFFFF
             ra = lib.tgh_leaf_bounds(C.byref(d.objects[obj]), kind, a[0].ctypes.data, a[1].ctypes.data)
             b = oracle_lib.leaf_bounds(flat.desc, i)
-            assert ra == (1 if kind in (1, 2, 3) else 0) and (b is not None) == bool(ra), (kind, ra)
+            assert ra == (1 if kind in (1, 2, 3, 5, 6) else 0) and (b is not None) == bool(ra), (kind, ra)
             answers[kind] = ra
             if ra:
                 assert (a[0].view(np.uint32) == b[0].view(np.uint32)).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all() and (a[0] <= a[1]).all()
         flat.close()
-    assert answers == {0: 0, 1: 1, 2: 1, 3: 1, 5: 0}          # triangles, quads, cubes, spheres, disks
+    assert answers == {0: 0, 1: 1, 2: 1, 3: 1, 5: 1, 6: 1}    # triangles, quads, cubes, spheres, disks, cylinders

@@ -84,8 +84,19 @@ def test_scene_descriptions_carry_the_tree_of_their_items(name, tmp_path):
     assert text == g["tree"]
 
 
+@pytest.mark.parametrize("name", top_tree_sets.SCENES)
+def test_item_boxes_are_the_references_bounds(name, tmp_path):
+    """Quad / Cube / Sphere / Disk / Cylinder::bounds as the library restates them from the flattened objects (tgh_leaf_bounds), in object order,
+    against the reference's own bounds() of the scene's finite primitives in scene order (oracle/ref_harness.cpp: bounds), bit for bit --
+    the boxes AND the order of the items of the reference's top-level user geometry."""
+    with open(os.path.join(scenes.GOLDEN, "prim_bounds.json")) as f:
+        gold = json.load(f)[name]
+    boxes = top_tree_sets.scene_item_boxes(name, tmp_path)
+    assert [["%08x" % v for v in row] for row in boxes.view(np.uint32).tolist()] == gold
+
+
 def test_scenes_that_are_not_such_lists_carry_no_tree(tmp_path):
-    for mk, kw in (scenes.GOLDEN_CASES["cornell_disks"], scenes.GOLDEN_CASES["cornell_bump"], scenes.GOLDEN_CASES["cornell_instances"]):
+    for mk, kw in (scenes.GOLDEN_CASES["cornell_bump"], scenes.GOLDEN_CASES["cornell_instances"], scenes.GOLDEN_CASES["cornell_mesh_light"]):
         flat = tg.FlattenedScene(mk(tmp_path, **dict(kw, resolution=(16, 9), spp=1)))
         assert flat.desc.contents.num_top_nodes == 0 and not flat.desc.contents.top_nodes
         flat.close()

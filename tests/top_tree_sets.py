@@ -8,8 +8,8 @@ import scenes
 import tungsten_amd as tg
 from tungsten_amd import capi
 
-# flat lists of quads / cubes / spheres among the golden cases, by GOLDEN_CASES name (+ the plain Cornell box and the sphere zoo)
-SCENES = ["cornell", "zoo_d", "cornell_smoke", "cornell_fog", "cornell_png_scalar", "cornell_sobol", "zoo_a", "zoo_e"]
+# flat lists of quads / cubes / spheres / disks / cylinders among the golden cases, by GOLDEN_CASES name (+ the plain Cornell box and the sphere zoo)
+SCENES = ["cornell", "zoo_d", "cornell_smoke", "cornell_fog", "cornell_png_scalar", "cornell_sobol", "zoo_a", "zoo_e", "cornell_disks", "cornell_cylinders"]
 
 
 def _make(name, tmp):
@@ -23,7 +23,7 @@ def _make(name, tmp):
 
 def scene_item_boxes(name, tmp):
     """(n, 6) float32: the boxes of the scene's finite primitives in object order -- the items of the reference's user geometry --
-    from the library's restatement of Quad / Cube / Sphere::bounds (tgh_leaf_bounds)."""
+    from the library's restatement of Quad / Cube / Sphere / Disk / Cylinder::bounds (tgh_leaf_bounds)."""
     lib = capi.load_library()
     flat = tg.FlattenedScene(_make(name, tmp))
     d = flat.desc.contents

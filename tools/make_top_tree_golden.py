@@ -1,5 +1,6 @@
 """TEST INFRASTRUCTURE (build container only: needs oracle/_ref/ref_embree_tree, built by `make -f oracle/Makefile.ref` from the reference's
-vendored Embree).  Writes tests/golden/top_trees.json: item boxes and, for each set, the BVH4 the reference's own Embree built over them
+vendored Embree, and oracle/_ref/ref_harness).  Writes tests/golden/prim_bounds.json -- the reference's own bounds() of the finite primitives of the
+flat-list golden scenes, in scene order -- and tests/golden/top_trees.json: item boxes and, for each set, the BVH4 the reference's own Embree built over them
 (oracle/ref_embree_tree.cpp reads it out of Embree's structures) -- what csrc/host/EmbreeTopTree.cpp restates and tests/test_top_tree.py
 compares.  Sets: the leaf boxes of the flat-list golden scenes in object order, and seeded random sets of four kinds (random boxes; rooms of
 flat quads on grid coordinates with solids inside; duplicated boxes; small-integer coordinates, where SAH costs tie).
@@ -48,6 +49,17 @@ if __name__ == "__main__":
         for k in range(per_kind):
             names.append("random:%d:%d" % (kind, k))
             sets.append(top_tree_sets.random_set(kind, k))
+    # the reference's own bounds() of the scenes' finite primitives (oracle/ref_harness.cpp: bounds), which the scene sets above must equal
+    HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    bounds = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name in top_tree_sets.SCENES:
+            path = top_tree_sets._make(name, tmp)
+            subprocess.check_call([HARNESS, "bounds", path, os.path.join(tmp, "b.txt")], stdout=subprocess.DEVNULL, cwd=os.path.dirname(path))
+            with open(os.path.join(tmp, "b.txt")) as f:
+                bounds[name] = [line.split() for line in f.read().splitlines()]
+    with open(os.path.join(scenes.GOLDEN, "prim_bounds.json"), "w") as f:
+        json.dump(bounds, f, separators=(",", ":"))
     trees = embree_trees(sets)
     assert len(trees) == len(sets)
     out = [{"name": n, "boxes": [["%08x" % v for v in row] for row in np.ascontiguousarray(s, np.float32).view(np.uint32).tolist()], "tree": t.strip()}

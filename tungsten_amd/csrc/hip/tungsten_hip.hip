@@ -1225,7 +1225,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         }
         for (uint32_t r = 0; r < sd->num_recs && ok; ++r) {
             const uint32_t kind = TGHIP_REC_KIND(sd->recs[r].meta);
-            ok = leafOf[r] == 1 && (kind == TGHIP_REC_QUAD || kind == TGHIP_REC_CUBE || kind == TGHIP_REC_SPHERE);
+            ok = leafOf[r] == 1 && (kind == TGHIP_REC_QUAD || kind == TGHIP_REC_CUBE || kind == TGHIP_REC_SPHERE || kind == TGHIP_REC_DISK || kind == TGHIP_REC_CYLINDER);
         }
         if (!ok) { ctx->error = "top_nodes: not the tree of a flat list (every record one leaf, preorder, depth <= TGHIP_TOP_MAX_DEPTH)"; return TGHIP_E_INVALID; }
         static_assert(sizeof(TgHipTopNode) == 28*sizeof(float), "TgHipTopNode layout");

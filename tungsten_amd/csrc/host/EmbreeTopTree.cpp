@@ -271,12 +271,27 @@ bool referenceLeafBounds(const TgHipObject &o, uint32_t kind, float lo[3], float
         for (int k = 0; k < 3; ++k) { p[0][k] = o.pos[k] - o.scale[0]; p[1][k] = o.pos[k] + o.scale[0]; }
         n = 2;
         break;
+    case TGHIP_REC_DISK:                                        // Disk::bounds (Disk.cpp:298-306): pos = _center, edge0 / edge1 = _frame.tangent / bitangent, scale[0] = _r
+        for (int k = 0; k < 3; ++k) {
+            const float t = o.edge0[k]*o.scale[0], b = o.edge1[k]*o.scale[0];
+            p[0][k] = (o.pos[k] - t) - b; p[1][k] = (o.pos[k] + t) - b; p[2][k] = (o.pos[k] + t) + b; p[3][k] = (o.pos[k] - t) + b;
+        }
+        n = 4;
+        break;
+    case TGHIP_REC_CYLINDER:                                    // Cylinder::bounds (Cylinder.cpp:272-279): the axis' end points, grown by the radius;
+        for (int k = 0; k < 3; ++k) {                           //   _axis = _transform.up().normalized() = the second column of _rot (Mat4f.cpp:40-47), scale = {_radius, _halfHeight, .}
+            const float a = o.rot[3*k + 1]*o.scale[1];
+            p[0][k] = o.pos[k] + a; p[1][k] = o.pos[k] - a;
+        }
+        n = 2;
+        break;
     default:
         return false;
     }
     for (int k = 0; k < 3; ++k) {                               // Box::grow: min(_min, p) keeps _min unless p < _min (math/MathUtil.hpp:33-52)
         lo[k] = hi[k] = p[0][k];
         for (int c = 1; c < n; ++c) { lo[k] = p[c][k] < lo[k] ? p[c][k] : lo[k]; hi[k] = p[c][k] > hi[k] ? p[c][k] : hi[k]; }
+        if (kind == TGHIP_REC_CYLINDER) { lo[k] -= o.scale[0]; hi[k] += o.scale[0]; }       // Box::grow(float)
     }
     return true;
 }
