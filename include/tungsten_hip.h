@@ -89,7 +89,7 @@ typedef struct TgHipBvhNode {
  * tests every record; the wave walks the list uniformly, so record data comes through the scalar cache) instead of
  * through the BVH -- the analogue of the reference's top-level Embree scene over a handful of user-geometry
  * primitives (TraceableScene.hpp:112-134).  The oracle follows the same rule so that visit counts agree.
- * Flat lists with TgHipSceneDesc::top_nodes (scenes whose records are all quads, cubes or spheres): the closest hit is the one the reference's
+ * Flat lists with TgHipSceneDesc::top_nodes (scenes whose records are all quads, cubes, spheres, disks or cylinders): the closest hit is the one the reference's
  * Embree walk returns where faces coincide -- see TgHipTopNode below. */
 #define TGHIP_FLAT_MAX_RECS    16
 
@@ -106,8 +106,8 @@ typedef struct TgHipBvhNode {
  *     primitive's own intersect() reports; a quad accepts t <= farT, a cube or sphere t < farT.
  * The tree is therefore part of the path's arithmetic.  csrc/host/EmbreeTopTree.cpp restates Embree 2.11's builder for it (binned SAH, four
  * children, leaf size one) node for node; tgh_top_tree_build (tungsten_host.h) produces it, tests/test_top_tree.py holds it to trees read out of
- * the reference's own Embree.  Scenes that carry it: flat lists of quads, cubes and spheres (item i = record i); every other scene passes
- * NULL / 0 and is walked as before (triangle meshes live in ONE tree with the other records there; disks / cylinders: bounds not restated).
+ * the reference's own Embree.  Scenes that carry it: flat lists of quads, cubes, spheres, disks and cylinders (one item per object that has a record, in
+ * object order); every other scene passes NULL / 0 and is walked as before (a triangle mesh lives in ONE tree with the other records there).
  * Node 0 is the root, nodes in preorder.  child[i] >= 0: a node; < 0: the record ~child[i]; TGHIP_TOP_EMPTY: unused slot (its box is
  * lower = +inf, upper = -inf, as Embree clears it). */
 #define TGHIP_TOP_EMPTY  0x7FFFFFFF
@@ -387,7 +387,7 @@ typedef struct TgHipSceneDesc {
     /* the wide BVH: wide_nodes[0] is the root of the tree over recs[0, num_top_recs); with instances every master's wide
      * subtree follows (its root in the instance records' c[2]).  NULL/0 = the device walks the BVH2 (flat-list scenes do) */
     const TgHipWideNode *wide_nodes;  uint32_t num_wide_nodes;
-    /* the reference's top-level Embree tree over the records of a flat list of quads / cubes / spheres (TgHipTopNode; ABI 10); NULL / 0 otherwise */
+    /* the reference's top-level Embree tree over the records of a flat list of analytic primitives (TgHipTopNode; ABI 10); NULL / 0 otherwise */
     const TgHipTopNode *top_nodes;  uint32_t num_top_nodes;
     TgHipCamera   camera;
     TgHipSettings settings;

@@ -138,11 +138,12 @@ void tgh_instance_tight_bounds(const float *master_verts, uint32_t stride_floats
  * 0 for n < 2 and for boxes Embree would drop as invalid), or -1 when `capacity` is too small. */
 int tgh_top_tree_build(const float *boxes, uint32_t n, TgHipTopNode *nodes, uint32_t capacity);
 /* TgHipSceneDesc::top_nodes for a flattened scene: the tree over the objects that have a record (in object order: the reference's _finites),
- * leaves naming records, when the scene is a flat list of quads / cubes / spheres; 0 nodes otherwise.  Same return convention. */
+ * leaves naming records, when the scene is a flat list of quads / cubes / spheres / disks / cylinders; 0 nodes otherwise.  Same return convention. */
 int tgh_top_tree_for_scene(const TgHipObject *objects, uint32_t num_objects, const TgHipPrimRec *recs, uint32_t num_recs,
                            TgHipTopNode *nodes, uint32_t capacity);
 /* The box the reference's bounds callback reports for a record's primitive (TraceableScene.hpp:116-118): Quad::bounds / Cube::bounds /
- * Sphere::bounds (primitives/Quad.cpp:281-289, Cube.cpp:333-344, Sphere.cpp:273-276) restated from the flattened object.  1 and the box, 0 for
+ * Sphere::bounds / Disk::bounds / Cylinder::bounds (primitives/Quad.cpp:281-289, Cube.cpp:333-344, Sphere.cpp:273-276, Disk.cpp:298-306,
+ * Cylinder.cpp:272-279) restated from the flattened object.  1 and the box, 0 for
  * a record kind (TGHIP_REC_*) whose bounds are not restated. */
 int tgh_leaf_bounds(const TgHipObject *object, uint32_t kind, float lo[3], float hi[3]);
 

@@ -2056,7 +2056,7 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *worldRay, float *tmax,
 void oracle_set_wide_bvh(int on) { g_use_wide = on; }
 
 /* objFilter >= 0: only records of that object are tested (a mesh light's own rtcIntersect, TriangleMesh.cpp:317-335) */
-/* A flat list of quads / cubes / spheres is intersected by WALKING THE REFERENCE'S TREE: TraceableScene::intersect -> rtcIntersect over Embree's
+/* A flat list of analytic primitives (quads, cubes, spheres, disks, cylinders) is intersected by WALKING THE REFERENCE'S TREE: TraceableScene::intersect -> rtcIntersect over Embree's
  * BVH4 with one primitive per leaf (TgHipSceneDesc::top_nodes, include/tungsten_hip.h: TgHipTopNode -- built by csrc/host/EmbreeTopTree.cpp,
  * which tests/test_top_tree.py holds to trees read out of the reference's own Embree), visited as BVH4Intersector1 visits it
  * (thirdparty/embree/kernels/bvh/bvh_intersector1.cpp:60-125, bvh_traverser1.h:41-104, common/stack_item.h:39-60):
@@ -2069,8 +2069,8 @@ void oracle_set_wide_bvh(int on) { g_use_wide = on; }
  * With coincident faces (the Cornell box's blocks stand ON the floor; a light lies IN the ceiling; a Sobol' point on the image's diagonal sends
  * its ray into the seam of floor and wall) these rules, not the distance alone, decide which primitive a ray hits: 99 samples in 12 golden cases
  * and the seam samples of the stress renders followed another path before.
- * Scenes without top_nodes (triangles have their own Embree geometry and live in ONE tree with the other records here; disks and cylinders:
- * bounds not restated) keep the plain list / the BVH. */
+ * Scenes without top_nodes (a triangle mesh is ONE item of the reference's tree with an Embree scene of its own; here its triangles live in ONE
+ * tree with the other records) keep the plain list / the BVH. */
 static int embree_box_near(const Ray *ray, v3 lo, v3 hi, float *tNearOut)
 {
     const float o[3] = {ray->o.x, ray->o.y, ray->o.z}, d[3] = {ray->d.x, ray->d.y, ray->d.z};

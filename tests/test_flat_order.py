@@ -1,4 +1,4 @@
-"""Flat lists of quads / cubes / spheres intersected by walking the reference's top-level Embree tree (include/tungsten_hip.h: TgHipTopNode,
+"""Flat lists of analytic primitives (quads, cubes, spheres, disks, cylinders) intersected by walking the reference's top-level Embree tree (include/tungsten_hip.h: TgHipTopNode,
 oracle.c: embree_top_walk, pt_kernels.h: flatClosestOrdered).  tests/test_top_tree.py pins the TREE against the reference's own Embree, the
 golden cases pin the WALK against the reference (tests/test_oracle_golden.py: not one of 549 504 samples off since it was restated); here the
 CPU suite holds the device's SHORTCUT -- test every record, decide from the nearest and the second nearest hit among the records whose leaf box

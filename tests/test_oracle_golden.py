@@ -60,7 +60,7 @@ def _needs_materialtest(name):
 # (smoke, glass, cut-out, the zoo's transmissive materials) and the floor under it are hit at the same distance, and the traversal order decides
 # which one a ray sees (99 samples in 12 cases: cornell_fog 1, cornell_fog_davis 2, cornell_fog_rayleigh 1, cornell_fog_smoke_sobol 9,
 # cornell_png_scalar 11, cornell_smoke 17, zoo_a 7, zoo_b 8, zoo_b_sobol 7, zoo_e 20, zoo_f 6, cornell_expfog_smoke_sobol 10) -- went when the
-# oracle (and the device) began to visit a flat list of quads / cubes / spheres the way Embree's user-geometry BVH visits its one-primitive
+# oracle (and the device) began to visit a flat list of analytic primitives the way Embree's user-geometry BVH visits its one-primitive
 # leaves: slab test of the primitive's own bounds(), nearest box entry first (equal entries: the later record first), a leaf entered behind the
 # hit so far skipped (oracle.c: embree_ordered_flat).  The `*_lifted` twins below, with every solid a millimetre off the
 # floor, were exact before and still are.

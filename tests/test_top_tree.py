@@ -62,7 +62,7 @@ def test_restated_builder_builds_embrees_trees():
 
 @pytest.mark.parametrize("name", top_tree_sets.SCENES)
 def test_scene_descriptions_carry_the_tree_of_their_items(name, tmp_path):
-    """TgHipSceneDesc::top_nodes of a flat list of quads / cubes / spheres is the tree over the scene's objects in object order (the reference's
+    """TgHipSceneDesc::top_nodes of a flat list of analytic primitives (quads, cubes, spheres, disks, cylinders) is the tree over the scene's objects in object order (the reference's
     _finites), its leaves naming the objects' records; the fixtures hold Embree's tree over those very boxes."""
     with open(os.path.join(scenes.GOLDEN, "top_trees.json")) as f:
         gold = {g["name"]: g for g in json.load(f)}

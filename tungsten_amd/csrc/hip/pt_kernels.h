@@ -593,7 +593,7 @@ PT_DEV bool boxTest(f3 lo, f3 hi, const RayD &ray, f3 invD, float tmax, float &t
 // The reference intersects a scene through Embree's BVH4 over its finite primitives, one per leaf, and with coincident faces (a block
 // standing ON the floor quad, a light lying IN the ceiling, a ray into the seam of two walls) Embree's visiting rules decide which primitive
 // a ray hits (include/tungsten_hip.h: TgHipTopNode has the rules and the citations; oracle.c: embree_top_walk is the test side's copy).
-// Scenes that carry the tree (DeviceScene::top_nodes: flat lists of quads, cubes and spheres) are intersected by flatClosestOrdered.
+// Scenes that carry the tree (DeviceScene::top_nodes: flat lists of analytic primitives) are intersected by flatClosestOrdered.
 struct EmbreeRay { float o[3], rdir[3], tNear, tFar; };
 PT_DEV EmbreeRay embreeRay(const RayD &ray)
 {

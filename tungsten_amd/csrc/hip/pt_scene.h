@@ -43,7 +43,7 @@ struct DeviceScene {
     const uint32_t * __restrict__ inst_prims;  // leaf slots of the reference's instance trees -> instance record (TgHipSceneDesc::inst_prims)
     const float4 * __restrict__ inst_leaf_boxes;   // 2 x float4 per leaf slot: the leaf's box as its parent holds it (lo, hi), at the leaf's first slot
     const float4 * __restrict__ inst_tight_boxes;  // 2 x float4 per top-level record: an instance record's tight world-space box (lo, hi)
-    const float * __restrict__ top_nodes;      // flat lists of quads / cubes / spheres: the reference's top-level Embree tree, 28 floats per TgHipTopNode
+    const float * __restrict__ top_nodes;      // flat lists of analytic primitives: the reference's top-level Embree tree, 28 floats per TgHipTopNode
                                                //   (nullptr: the scene carries none and walks the plain list / the BVH) -- pt_kernels.h: flatClosestOrdered
     const float4 * __restrict__ flat_boxes;    // ... and per record the box of its leaf in that tree (lo, hi)
     const TgHipMedium * __restrict__ media;    // participating media (nullptr / 0: none)

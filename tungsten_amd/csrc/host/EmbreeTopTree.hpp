@@ -19,11 +19,12 @@ struct TopBox { float lo[3], hi[3]; };
 // by Embree's rule (lower <= upper, finite), in which case Embree drops the item and the caller must not use a tree.
 std::vector<TgHipTopNode> buildEmbreeTopTree(const std::vector<TopBox> &boxes);
 
-// Quad::bounds (Quad.cpp:281-289), Cube::bounds (Cube.cpp:333-344), Sphere::bounds (Sphere.cpp:273-276) from the flattened object: the box
-// the reference's bounds callback reports for the record's primitive.  False for a record kind whose bounds are not restated.
+// Quad::bounds (Quad.cpp:281-289), Cube::bounds (Cube.cpp:333-344), Sphere::bounds (Sphere.cpp:273-276), Disk::bounds (Disk.cpp:298-306) and
+// Cylinder::bounds (Cylinder.cpp:272-279) from the flattened object: the box
+// the reference's bounds callback reports for the record's primitive.  False for a record kind whose bounds are not restated (triangles, instances).
 bool referenceLeafBounds(const TgHipObject &o, uint32_t kind, float lo[3], float hi[3]);
 
-// The tree for a flattened scene: a flat list (<= TGHIP_FLAT_MAX_RECS records, no instances) whose records are all quads, cubes or spheres,
+// The tree for a flattened scene: a flat list (<= TGHIP_FLAT_MAX_RECS records, no instances) whose records are all quads, cubes, spheres, disks or cylinders,
 // one per object.  The items are the objects that have a record, in object order -- the order of the reference's _finites --, a leaf names the
 // item's record.  Empty when the scene is not such a list (or has a single record: Embree's root is then the leaf).
 std::vector<TgHipTopNode> buildSceneTopTree(const TgHipObject *objects, uint32_t numObjects, const TgHipPrimRec *recs, uint32_t numRecs);

@@ -756,7 +756,7 @@ void TraceableScene::flatten()
     _desc.inst_tight_boxes = _instTightBoxes.empty() ? nullptr : _instTightBoxes.data();
     _desc.wide_nodes = _wideNodes.empty() ? nullptr : _wideNodes.data();
     _desc.num_wide_nodes = uint32_t(_wideNodes.size());
-    // the reference's top-level Embree tree, for flat lists of quads / cubes / spheres (EmbreeTopTree.hpp): the visiting order where faces coincide
+    // the reference's top-level Embree tree, for flat lists of analytic primitives (EmbreeTopTree.hpp): the visiting order where faces coincide
     _topNodes.clear();
     if (_instPrims.empty())
         _topNodes = buildSceneTopTree(_objects.data(), uint32_t(_objects.size()), _recs.data(), uint32_t(_recs.size()));
