@@ -125,13 +125,14 @@ def test_generate_work_reports_no_work_when_converged():
     assert (rec["sample_index"] == 16).all()
 
 
-@pytest.mark.parametrize("name,exact_passes,min_equal,stats_rtol", [("cornell_adaptive", 3, 0.98, 0.0), ("cornell_adaptive_sobol", 2, 0.6, 0.0),
-                                                                     ("materialtest_as_shipped", 3, 1.0, 1e-3)])
+# (Until the end of round 4 later passes were allowed to drift -- cornell_adaptive after three, the Sobol' case after two passes, materialtest's
+# statistics within 1e-3: a single path on the other side of a coincident-face tie perturbs the stochastic rounding of every following record.
+# With the reference's top-level tree restated, DESIGN.md section 8, no path is: every pass of every case is exact, statistics bit for bit.)
+@pytest.mark.parametrize("name,exact_passes,min_equal,stats_rtol", [("cornell_adaptive", 5, 1.0, 0.0), ("cornell_adaptive_sobol", 4, 1.0, 0.0),
+                                                                     ("materialtest_as_shipped", 3, 1.0, 0.0)])
 def test_oracle_integrate_matches_reference(name, exact_passes, min_equal, stats_rtol, tmp_path):
     """The oracle's whole pass loop (tile seeds -> render with Welford records -> generateWork -> ...) against the
-    reference's.  The first `exact_passes` passes must reproduce the sample schedule exactly; later ones may drift because
-    a single path that diverges (t-ties under the Sobol' sampler, ulp-level differences on materialtest) perturbs the
-    stochastic rounding of every following record."""
+    reference's: every pass reproduces the reference's sample schedule, sample counts and Welford statistics exactly."""
     g = _gold(name)
     path, kw = _case(name, tmp_path)
     flat = tg.FlattenedScene(path)
@@ -141,6 +142,7 @@ def test_oracle_integrate_matches_reference(name, exact_passes, min_equal, stats
     flat.close()
     assert (pass_spp == g["pass_spp"]).all()
     gold = g["records"]
+    assert len(gold) == exact_passes
     for p in range(len(gold)):
         same_schedule = (rec[p]["next_sample_count"] == gold[p]["next_sample_count"]).mean()
         # Welford mean / running variance: bit-equal on the Cornell box (every sample is), within stats_rtol on materialtest
@@ -150,8 +152,8 @@ def test_oracle_integrate_matches_reference(name, exact_passes, min_equal, stats
         if p < exact_passes:
             assert same_schedule == 1.0 and (rec[p]["sample_index"] == gold[p]["sample_index"]).all(), p
             assert (rec[p]["sample_count"] == gold[p]["sample_count"]).all(), p
-        if p < max(exact_passes - 1, 1):
-            assert same_stats >= 0.98, (p, same_stats)
+        if p < exact_passes:
+            assert same_stats == 1.0, (p, same_stats)
         assert same_schedule >= min_equal, (p, same_schedule)
         # the total number of samples of a pass is fixed by the budget, whatever the distribution
         assert abs(int(rec[p]["next_sample_count"].astype(np.int64).sum()) - int(gold[p]["next_sample_count"].astype(np.int64).sum())) <= 2

@@ -77,22 +77,19 @@ def test_gpu_adaptive_pass_loop(name, tmp_path):
     assert np.allclose(per_pass[-1]["mean"], fb_mean, rtol=2e-4, atol=1e-6)
     assert (per_pass[-1]["running_variance"] >= 0).all()
 
-    # ---- against the oracle's pass loop ----
-    first = per_pass[0]
-    assert (first["next_sample_count"] == orec[0]["next_sample_count"]).all() and (first["sample_count"] == orec[0]["sample_count"]).all()
-    ok = np.isclose(first["mean"], orec[0]["mean"], rtol=2e-3, atol=1e-6) & np.isclose(first["running_variance"], orec[0]["running_variance"], rtol=2e-2, atol=1e-6)
-    # (the glass box of the smoke scene stands on the floor: rays leaving through its bottom hit two coincident surfaces, and
-    # which one wins differs between implementations for a fraction of a percent of the samples -- tests/test_oracle_golden.py)
-    assert ok.mean() >= (0.9 if "smoke" in name else 0.98), ok.mean()
+    # ---- against the oracle's pass loop (which is the reference's, pass for pass: tests/test_adaptive_cpu.py) ----
+    # Measured at the end of round 4 (every sample being the oracle's bit for bit, the Welford records fed in the reference's order): schedule, sample
+    # counts, mean and running variance of EVERY record equal the oracle's in EVERY pass of all four cases -- the Sobol' case, the fog + smoke
+    # case with its glass box on the floor and materialtest as it ships among them.  (Rounds 2-3 accepted 50-90 % equal schedules after the
+    # first pass: one path on the other side of a coincident-face tie perturbs the stochastic rounding of every following record.)
     saw_adaptive = False
-    for k in range(1, len(per_pass)):
-        g, o = per_pass[k]["next_sample_count"].astype(np.int64), orec[k]["next_sample_count"].astype(np.int64)
-        saw_adaptive |= bool((g != g.ravel()[0]).any())
-        assert abs(int(g.sum()) - int(o.sum())) <= 2                       # same budget
-        assert np.abs(g - o).max() <= max(3, 0.25*o.max())                   # same distribution up to rounding drift
-        assert (g == o).mean() >= (0.9 if k == 1 and "cornell" in name else 0.5), (k, (g == o).mean())
-        wg, wo = per_pass[k]["adaptive_weight"], orec[k]["adaptive_weight"]
-        assert np.isclose(wg, wo, rtol=5e-2, atol=1e-7).mean() >= 0.95
+    for k in range(len(per_pass)):
+        g, o = per_pass[k], orec[k]
+        saw_adaptive |= bool((g["next_sample_count"] != g["next_sample_count"].ravel()[0]).any())
+        for field in ("next_sample_count", "sample_count", "sample_index"):
+            assert (g[field] == o[field]).all(), (k, field, float((g[field] == o[field]).mean()))
+        for field in ("mean", "running_variance", "adaptive_weight"):
+            assert (g[field].view(np.uint32) == o[field].view(np.uint32)).all(), (k, field, float((g[field] == o[field]).mean()))
     assert saw_adaptive
     omean = osum/np.maximum(ocount, 1)[..., None]
     assert np.allclose(mean.mean(axis=(0, 1)), omean.mean(axis=(0, 1)), rtol=2e-2)
