@@ -8,7 +8,7 @@ import pytest
 import oracle_lib
 import scenes
 import tungsten_amd as tg
-from test_outputs_cpu import CH, NAME, check_against_gold, combined_mean, gold, per_channel
+from test_outputs_cpu import CH, NAME, check_against_gold, check_exactly_against_gold, combined_mean, gold, per_channel
 
 pytestmark = pytest.mark.gpu
 
@@ -28,6 +28,7 @@ def test_gpu_output_buffers_match_reference_and_oracle(tmp_path):
     path = mk(tmp_path, name=NAME + ".json", **kw)
     mean, ssum, count, aux = _render(path, int(g["seed"]))
     check_against_gold(aux["a"], aux["b"], aux["variance"], aux["count"], g, frac_ok=0.96)
+    check_exactly_against_gold(aux["a"], aux["b"], aux["variance"], aux["count"], g)
     flat = tg.FlattenedScene(path)
     osum, ocount, rec, pass_spp, oaux = oracle_lib.integrate_aux(flat.desc, flat.width, flat.height, int(g["seed"]), kw["spp"], kw["spp_step"], False, True)
     flat.close()

@@ -29,6 +29,16 @@ def per_channel(count):
     return np.concatenate([np.repeat(count[..., i:i + 1], c.stop - c.start, axis=2) for i, c in enumerate(CH.values())], axis=2)
 
 
+def check_exactly_against_gold(aux_a, aux_b, aux_var, aux_count, g):
+    """Since the end of round 4 (every sample on the reference's path): the counts, the A / B halves and the variance sums of
+    all five outputs are the reference's in every pixel, float32 bit for bit."""
+    assert (aux_count == g["aux_count"]).all()
+    for name, mine, theirs in (("a", aux_a, g["aux_a"]), ("b", aux_b, g["aux_b"]), ("variance", aux_var, g["aux_variance"])):
+        same = np.asarray(mine, np.float32).view(np.uint32) == np.asarray(theirs, np.float32).view(np.uint32)
+        for out, sl in CH.items():
+            assert same[..., sl].all(), (name, out, float(same[..., sl].all(axis=-1).mean()))
+
+
 def check_against_gold(aux_a, aux_b, aux_var, aux_count, g, frac_ok=0.97):
     """Counts of the outputs every sample records (or deterministically not) exactly up to divergent paths; values per pixel."""
     gc = g["aux_count"]
@@ -59,6 +69,7 @@ def test_oracle_output_buffers_match_the_reference(tmp_path):
     flat.close()
     assert len(rec) == len(g["records"])
     check_against_gold(aux["a"], aux["b"], aux["variance"], aux["count"], g)
+    check_exactly_against_gold(aux["a"], aux["b"], aux["variance"], aux["count"], g)
     # the colour output is the framebuffer: same sample counts, same mean
     assert (aux["count"][..., 0] == count).all()
     cm = combined_mean(aux["a"][..., :3], aux["b"][..., :3], np.repeat(count[..., None], 3, axis=2))
