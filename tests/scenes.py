@@ -936,6 +936,32 @@ GOLDEN_CASES["cornell_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, rende
 GOLDEN_CASES["zoo_b_sobol"] = (lambda t, **kw: cornell_zoo(t, "zoo_b", **kw), dict(resolution=(48, 27), spp=8, renderer=_SOBOL))
 GOLDEN_CASES["materialtest_sobol"] = (materialtest, dict(resolution=(64, 36), spp=4, renderer=_SOBOL))
 
+
+
+def _ties(scene):
+    """Coincident faces on purpose -- what the reference's top-level Embree tree decides: the light lies IN the ceiling's
+    plane; a glass cube sits flush in the back right corner (its faces in the planes of floor, back wall and right wall), a rough-glass slab on
+    top of it shares its top face; the tall block (see-through: a thin sheet) stands on the floor; a glass sphere touches the floor in a point;
+    a mirror decal lies IN the left wall's plane.  Eleven records, every kind of tie: quad against quad, quad against cube face, cube face
+    against cube face, a tangent sphere."""
+    scene["bsdfs"] += [{"name": "glass", "type": "dielectric", "ior": 1.5, "albedo": 1},
+                       {"name": "frosted", "type": "rough_dielectric", "ior": 1.4, "roughness": 0.2, "distribution": "ggx", "albedo": [0.9, 1.0, 0.9]},
+                       {"name": "decal", "type": "mirror", "albedo": [0.9, 0.8, 0.7]}]
+    _replace_bsdf(scene, "tallBox", {"type": "thinsheet", "ior": 1.3, "thickness": 0.4, "sigma_a": [0.2, 0.5, 1.0], "albedo": 1})
+    _prim(scene, "light")["transform"]["position"] = [-0.005, 2.0, -0.03]
+    short = _prim(scene, "shortBox")
+    short["transform"] = {"position": [0.7, 0.3, -0.7], "scale": [0.6, 0.6, 0.6]}
+    short["bsdf"] = "glass"
+    scene["primitives"] += [
+        {"name": "slab", "type": "cube", "bsdf": "frosted", "transform": {"position": [0.7, 0.75, -0.7], "scale": [0.6, 0.3, 0.6]}},
+        {"name": "ball", "type": "sphere", "bsdf": "glass", "transform": {"position": [-0.55, 0.25, 0.55], "scale": 0.5}},
+        {"name": "decal", "type": "quad", "bsdf": "decal", "transform": {"position": [-1, 1, 0.2], "scale": [1, 4, 1], "rotation": [0, 0, 90]}}]
+    scene["integrator"]["max_bounces"] = 16
+
+
+GOLDEN_CASES["cornell_ties"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_ties))
+GOLDEN_CASES["cornell_ties_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_ties, renderer=_SOBOL))
+
 # The reference's own PathTraceIntegrator pass loop (`ref_harness integrate`): SampleRecords after every pass + the image.
 OUTPUT_TYPES = ("color", "depth", "normal", "albedo", "visibility")
 
