@@ -114,3 +114,61 @@ def test_device_walks_flat_lists_in_the_oracles_order(name, tmp_path):
     for k in ("t", "u", "v"):
         assert (got[k][hit].view(np.uint32) == walk[k][hit].view(np.uint32)).all(), k
     assert (~decided).sum() > 1000
+
+
+@pytest.mark.gpu
+def test_upload_refuses_trees_that_are_not_the_lists(tmp_path):
+    """tghip_upload_scene takes TgHipSceneDesc::top_nodes only when it is the tree of the flat list it comes with: every record exactly one leaf,
+    children behind their parents, no deeper than the walk's stack allows -- and renders the same scene without a tree (as a plain list)."""
+    import ctypes as C
+    from tungsten_amd import capi
+    flat = tg.FlattenedScene(scenes.cornell(tmp_path, resolution=(32, 18), spp=1))
+    d = flat.desc.contents
+    n = d.num_top_nodes
+    assert n >= 2
+    ctx = tg.lib.tghip_create(0)
+    assert ctx
+
+    def attempt(mutate):
+        nodes = (capi.TgHipTopNode*n)()
+        C.memmove(nodes, d.top_nodes, C.sizeof(capi.TgHipTopNode)*n)
+        bad = tg.TgHipSceneDesc.from_buffer_copy(d)
+        count = mutate(nodes)
+        bad.top_nodes = C.cast(nodes, C.POINTER(capi.TgHipTopNode))
+        bad.num_top_nodes = n if count is None else count
+        return tg.lib.tghip_upload_scene(ctx, C.byref(bad))
+
+    def leaf_slot(nodes):
+        return next((k, i) for k in range(n) for i in range(4) if nodes[k].child[i] < 0)
+
+    def node_slot(nodes):
+        return next((k, i) for k in range(n) for i in range(4) if 0 <= nodes[k].child[i] != capi.TGHIP_TOP_EMPTY)
+
+    def twice(nodes):                                   # one record in two leaves, another in none
+        k, i = leaf_slot(nodes)
+        other = next((a, b) for a in range(n) for b in range(4) if nodes[a].child[b] < 0 and (a, b) != (k, i))
+        nodes[other[0]].child[other[1]] = nodes[k].child[i]
+
+    def out_of_range(nodes):
+        k, i = leaf_slot(nodes)
+        nodes[k].child[i] = ~int(d.num_recs)
+
+    def cycle(nodes):                                   # a child that is not behind its parent
+        k, i = node_slot(nodes)
+        nodes[k].child[i] = 0
+
+    def dangling(nodes):
+        k, i = node_slot(nodes)
+        nodes[k].child[i] = n
+
+    assert attempt(lambda nodes: None) == 0                                  # the tree as flattened
+    for m in (twice, out_of_range, cycle, dangling, lambda nodes: n - 1):    # ... and a node count that drops the last node
+        assert attempt(m) == -1, m
+        assert b"top_nodes" in tg.lib.tghip_last_error(ctx)
+    # no tree: the plain list
+    bad = tg.TgHipSceneDesc.from_buffer_copy(d)
+    bad.top_nodes = C.cast(None, C.POINTER(capi.TgHipTopNode))
+    bad.num_top_nodes = 0
+    assert tg.lib.tghip_upload_scene(ctx, C.byref(bad)) == 0
+    tg.lib.tghip_destroy(ctx)
+    flat.close()
