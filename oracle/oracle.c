@@ -2182,13 +2182,36 @@ static int embree_top_walk(const TgHipSceneDesc *s, const Ray *ray0, Hit *hit, T
     return hit->rec >= 0;
 }
 
+/* how many of a render's rays the device's shortcut (oracle_flat_device_form below) decides without the walk: tools only */
+static int g_flat_stats = 0;
+static uint64_t g_flat_rays = 0, g_flat_walked = 0;
+static int flat_shortcut_decides(const TgHipSceneDesc *s, const Ray *ray, Hit *got);
+static void flat_stats_count(const TgHipSceneDesc *s, const Ray *ray)
+{
+    Hit h;
+    const int dec = flat_shortcut_decides(s, ray, &h);
+#pragma omp atomic
+    g_flat_rays++;
+    if (!dec) {
+#pragma omp atomic
+        g_flat_walked++;
+    }
+}
+void oracle_flat_stats(int enable, uint64_t *rays, uint64_t *walked)
+{
+    if (rays) *rays = g_flat_rays;
+    if (walked) *walked = g_flat_walked;
+    g_flat_stats = enable; g_flat_rays = 0; g_flat_walked = 0;
+}
 static int scene_intersect_obj(const TgHipSceneDesc *s, const Ray *ray, Hit *hit, TravStats *st, int objFilter)
 {
     float tmax = ray->tmax;
     hit->rec = -1; hit->inst = -1; hit->t = tmax; hit->u = hit->v = 0.0f;
     if (st) st->rays++;
-    if (s->top_nodes && s->num_top_nodes && g_flat_order)
+    if (s->top_nodes && s->num_top_nodes && g_flat_order) {
+        if (g_flat_stats) flat_stats_count(s, ray);
         return embree_top_walk(s, ray, hit, st, objFilter);
+    }
     if (s->num_recs <= TGHIP_FLAT_MAX_RECS && s->num_instances == 0) {           /* flat list (include/tungsten_hip.h) */
         for (uint32_t i = 0; i < s->num_recs; ++i)
             if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[i].meta) == objFilter)
@@ -4077,6 +4100,24 @@ static int top_leaf_box(const TgHipSceneDesc *s, int32_t rec, v3 *lo, v3 *hi)
             if (s->top_nodes[n].child[i] == ~rec) { *lo = ld3(s->top_nodes[n].lower[i]); *hi = ld3(s->top_nodes[n].upper[i]); return 1; }
     return 0;
 }
+/* 1: the shortcut decides, *got = its answer (rec < 0: nothing hit); 0: the device walks the tree */
+static int flat_shortcut_decides(const TgHipSceneDesc *s, const Ray *rayIn, Hit *got)
+{
+    Ray ray = *rayIn;
+    got->rec = -1; got->inst = -1; got->t = ray.tmax; got->u = got->v = 0.0f;
+    float tb = INFINITY, t2 = INFINITY, entryB = 0.0f;
+    for (uint32_t i = 0; i < s->num_recs; ++i) {
+        Hit h; float tm = ray.tmax;
+        h.rec = -1; h.inst = -1; h.t = tm; h.u = h.v = 0.0f;
+        test_rec(s, i, &ray, &tm, &h, NULL, -1, -1);
+        v3 lo, hi; float entry;
+        if (h.rec >= 0 && top_leaf_box(s, (int32_t)i, &lo, &hi) && embree_box_near(&ray, lo, hi, &entry)) {
+            if (h.t < tb) { t2 = tb; tb = h.t; *got = h; entryB = entry; }
+            else t2 = fminf(t2, h.t);
+        }
+    }
+    return got->rec < 0 || (tb < t2 && entryB <= t2);
+}
 size_t oracle_flat_device_form(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *hits, uint8_t *decided, size_t n)
 {
     size_t differing = 0;
@@ -4085,20 +4126,8 @@ size_t oracle_flat_device_form(const TgHipSceneDesc *s, const TgHipRay *rays, Tg
         Ray ray = {ld3(rays[q].o), ld3(rays[q].d), rays[q].tmin, rays[q].tmax};
         Hit want, got;
         want.rec = -1; want.inst = -1; want.t = ray.tmax; want.u = want.v = 0.0f;
-        got = want;
         embree_top_walk(s, &ray, &want, NULL, -1);
-        float tb = INFINITY, t2 = INFINITY, entryB = 0.0f;
-        for (uint32_t i = 0; i < s->num_recs; ++i) {
-            Hit h; float tm = ray.tmax;
-            h.rec = -1; h.inst = -1; h.t = tm; h.u = h.v = 0.0f;
-            test_rec(s, i, &ray, &tm, &h, NULL, -1, -1);
-            v3 lo, hi; float entry;
-            if (h.rec >= 0 && top_leaf_box(s, (int32_t)i, &lo, &hi) && embree_box_near(&ray, lo, hi, &entry)) {
-                if (h.t < tb) { t2 = tb; tb = h.t; got = h; entryB = entry; }
-                else t2 = fminf(t2, h.t);
-            }
-        }
-        int dec = got.rec < 0 || (tb < t2 && entryB <= t2);
+        const int dec = flat_shortcut_decides(s, &ray, &got);
         if (!dec) got = want;
         if (decided) decided[q] = (uint8_t)dec;
         if (hits) { hits[q].t = got.t; hits[q].u = got.u; hits[q].v = got.v; hits[q].rec = got.rec; }
