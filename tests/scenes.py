@@ -959,7 +959,25 @@ def _ties(scene):
     scene["integrator"]["max_bounces"] = 16
 
 
+def _round_ties(scene):
+    """The same with the round primitives, whose boxes are restated last (Disk::bounds, Cylinder::bounds): a disk light IN the ceiling's plane, a
+    capped glass cylinder standing on the floor (its bottom cap in the floor's plane) with a see-through disk lying on its top cap, a mirror disk
+    lying IN the floor with a glass sphere standing on it."""
+    scene["primitives"] = [p for p in scene["primitives"] if p["name"] not in ("shortBox", "tallBox", "light")]
+    scene["bsdfs"] += [{"name": "glass", "type": "dielectric", "ior": 1.5, "albedo": 1},
+                       {"name": "sheet", "type": "thinsheet", "ior": 1.3, "thickness": 0.4, "sigma_a": [0.2, 0.5, 1.0], "albedo": 1},
+                       {"name": "coaster", "type": "mirror", "albedo": [0.9, 0.8, 0.7]}]
+    scene["primitives"] += [
+        {"name": "lamp", "type": "disk", "bsdf": "light", "emission": [30, 22, 8], "transform": {"position": [-0.005, 2.0, -0.03], "scale": 0.35, "rotation": [180, 0, 0]}},
+        {"name": "pillar", "type": "cylinder", "bsdf": "glass", "transform": {"position": [-0.45, 0.4, -0.3], "scale": [0.5, 0.8, 0.5]}},
+        {"name": "lid", "type": "disk", "bsdf": "sheet", "transform": {"position": [-0.45, 0.8, -0.3], "scale": 0.2}},
+        {"name": "coaster", "type": "disk", "bsdf": "coaster", "transform": {"position": [0.4, 0.0, 0.4], "scale": 0.35}},
+        {"name": "ball", "type": "sphere", "bsdf": "glass", "transform": {"position": [0.4, 0.2, 0.4], "scale": 0.4}}]
+    scene["integrator"]["max_bounces"] = 16
+
+
 GOLDEN_CASES["cornell_ties"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_ties))
+GOLDEN_CASES["cornell_round_ties"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_round_ties))
 GOLDEN_CASES["cornell_ties_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_ties, renderer=_SOBOL))
 
 # The reference's own PathTraceIntegrator pass loop (`ref_harness integrate`): SampleRecords after every pass + the image.

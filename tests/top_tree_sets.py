@@ -9,7 +9,7 @@ import tungsten_amd as tg
 from tungsten_amd import capi
 
 # flat lists of quads / cubes / spheres / disks / cylinders among the golden cases, by GOLDEN_CASES name (+ the plain Cornell box and the sphere zoo)
-SCENES = ["cornell", "zoo_d", "cornell_smoke", "cornell_fog", "cornell_png_scalar", "cornell_sobol", "zoo_a", "zoo_e", "cornell_disks", "cornell_cylinders", "cornell_ties"]
+SCENES = ["cornell", "zoo_d", "cornell_smoke", "cornell_fog", "cornell_png_scalar", "cornell_sobol", "zoo_a", "zoo_e", "cornell_disks", "cornell_cylinders", "cornell_ties", "cornell_round_ties"]
 
 
 def _make(name, tmp):
