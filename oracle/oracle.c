@@ -2123,6 +2123,12 @@ int oracle_leaf_bounds(const TgHipSceneDesc *s, uint32_t i, float lo3[3], float 
 }
 static int g_flat_order = 1;
 void oracle_set_flat_order(int on) { g_flat_order = on; }     /* 0: the plain list in record order (tests: what the order changes) */
+/* PROTOTYPE for the next round (tools/top_tree_meshes.py; OFF in every test, the device has no counterpart): scenes WITH triangle meshes walked
+ * as the reference walks them -- the top-level tree over ALL finite primitives, a mesh being one item whose leaf runs the mesh's own closest-hit
+ * query (TriangleMesh::intersect, TriangleMesh.cpp:317-335) under the hit distance so far.  With it on, a leaf of top_nodes names an OBJECT
+ * (~object index) instead of a record.  The mesh's own Embree BVH4 is not restated: inside a mesh this library's BVH2 decides ties. */
+static int g_top_items = 0;
+void oracle_set_top_items(int on) { g_top_items = on; }
 typedef struct { int32_t ref; uint32_t dist; } TopStackItem;
 static void top_swap(TopStackItem *a, TopStackItem *b) { TopStackItem t = *a; *a = *b; *b = t; }
 static int embree_top_walk(const TgHipSceneDesc *s, const Ray *ray0, Hit *hit, TravStats *st, int objFilter)
@@ -2174,6 +2180,22 @@ static int embree_top_walk(const TgHipSceneDesc *s, const Ray *ray0, Hit *hit, T
             cur = stack[sp - 1].ref; sp--;
         }
         if (!descend) continue;
+        if (g_top_items) {                                           /* prototype: the leaf is an object */
+            const int obj = (int)~cur;
+            if (objFilter < 0 || obj == objFilter) {
+                if (s->objects[obj].type == TGHIP_OBJ_MESH) {
+                    bvh_walk(s, 0, &ray, &ray.tmax, hit, NULL, obj, -1);
+                } else {
+                    for (uint32_t r = 0; r < s->num_recs; ++r)          /* (flat scan: the prototype's scenes are small) */
+                        if ((int)TGHIP_REC_OBJECT(s->recs[r].meta) == obj && TGHIP_REC_KIND(s->recs[r].meta) != TGHIP_REC_TRIANGLE) {
+                            test_rec(s, r, &ray, &ray.tmax, hit, NULL, objFilter, -1);
+                            break;
+                        }
+                }
+            }
+            rayFar = ray.tmax;
+            continue;
+        }
         const uint32_t rec = (uint32_t)~cur;
         if (objFilter < 0 || (int)TGHIP_REC_OBJECT(s->recs[rec].meta) == objFilter)
             test_rec(s, rec, &ray, &ray.tmax, hit, NULL, objFilter, -1);
