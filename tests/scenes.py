@@ -1044,3 +1044,33 @@ def _bump_without_the_mesh(scene):
 # cornell_bump without its triangle mesh: bump-mapped frames on the quad, the cube, the sphere and the checkered wall alone -- bit-identical;
 # what is left of the full case's residual is Embree's division in the mesh's triangle test
 LIFTED_CASES["cornell_bump_no_mesh"] = (cornell_bump, dict(resolution=(48, 27), spp=8, edit=_bump_without_the_mesh))
+
+
+def _crowd(scene):
+    """Sixteen records -- the largest flat list -- so that the reference's top-level tree has three levels of nodes: the Cornell box with its
+    light in the ceiling's plane and eight more solids on and against the floor, the walls and each other (glass, mirror, see-through), some flush,
+    some tangent, one pair interpenetrating."""
+    scene["bsdfs"] += [{"name": "glass", "type": "dielectric", "ior": 1.5, "albedo": 1},
+                       {"name": "chrome", "type": "mirror", "albedo": [0.9, 0.9, 0.8]},
+                       {"name": "sheet", "type": "thinsheet", "ior": 1.3, "thickness": 0.4, "sigma_a": [0.2, 0.5, 1.0], "albedo": 1}]
+    _prim(scene, "light")["transform"]["position"] = [-0.005, 2.0, -0.03]
+    _replace_bsdf(scene, "tallBox", {"type": "thinsheet", "ior": 1.3, "thickness": 0.4, "sigma_a": [0.2, 0.5, 1.0], "albedo": 1})
+    _replace_bsdf(scene, "shortBox", {"type": "dielectric", "ior": 1.45, "albedo": 1})
+    add = [("c0", "cube", "glass", [0.8, 0.2, 0.8], [0.4, 0.4, 0.4], None),            # flush in the front right corner of the floor
+           ("c1", "cube", "chrome", [0.8, 0.5, 0.8], [0.4, 0.2, 0.4], None),           # on top of it
+           ("c2", "cube", "sheet", [-0.85, 0.15, 0.6], [0.3, 0.3, 0.3], [0, 30, 0]),   # rotated, on the floor
+           ("s0", "sphere", "glass", [0.0, 0.15, 0.75], 0.3, None),                    # on the floor
+           ("s1", "sphere", "chrome", [0.3, 0.15, 0.75], 0.3, None),                   # tangent to s0 ... and the floor
+           ("s2", "sphere", "glass", [-0.85, 0.45, 0.6], 0.3, None),                   # on c2
+           ("c3", "cube", "glass", [-0.9, 1.0, -0.9], [0.2, 2.0, 0.2], None),          # a column in the back left corner, floor to ceiling
+           ("c4", "cube", "sheet", [0.3, 0.3, 0.45], [0.5, 0.5, 0.3], [0, 15, 0])]     # pushed INTO the short box
+    for name, typ, bsdf, pos, scale, rot in add:
+        tr = {"position": pos, "scale": scale}
+        if rot:
+            tr["rotation"] = rot
+        scene["primitives"].append({"name": name, "type": typ, "bsdf": bsdf, "transform": tr})
+    scene["integrator"]["max_bounces"] = 16
+
+
+GOLDEN_CASES["cornell_crowd"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_crowd))
+GOLDEN_CASES["cornell_crowd_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_crowd, renderer=_SOBOL))

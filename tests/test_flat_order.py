@@ -70,7 +70,8 @@ def tie_rays(desc, seed=5, n=6000):
 CASES = {"cornell": (scenes.cornell, {}), "zoo_d": (scenes.cornell_zoo, {"which": "zoo_d"}),
          "cornell_smoke": scenes.GOLDEN_CASES["cornell_smoke"], "cornell_png_scalar": scenes.GOLDEN_CASES["cornell_png_scalar"],
          "cornell_disks": scenes.GOLDEN_CASES["cornell_disks"], "cornell_cylinders": scenes.GOLDEN_CASES["cornell_cylinders"],
-         "cornell_ties": scenes.GOLDEN_CASES["cornell_ties"], "cornell_round_ties": scenes.GOLDEN_CASES["cornell_round_ties"]}
+         "cornell_ties": scenes.GOLDEN_CASES["cornell_ties"], "cornell_round_ties": scenes.GOLDEN_CASES["cornell_round_ties"],
+         "cornell_crowd": scenes.GOLDEN_CASES["cornell_crowd"]}           # sixteen records: the largest flat list, three levels of nodes
 
 
 @pytest.mark.parametrize("name", sorted(CASES))

@@ -5,7 +5,7 @@ shared counter-based random stream) AND with the oracle's, by the metric tests/t
 channel is within 1e-3 of the other's (relative to the sample's largest channel).
 
 Measured at the end of round 4 (profiles/r4_device_diverge_top_tree.jsonl), with every libm function the path calls, Embree's triangle
-arithmetic and the reference's top-level Embree tree (builder and walk) restated on the device: in NONE of the 549 504 samples of the 62 cases (nor of the 31 104 of the three tie scenes added after the table)
+arithmetic and the reference's top-level Embree tree (builder and walk) restated on the device: in NONE of the 549 504 samples of the 62 cases (nor of the 51 840 of the five tie scenes added after the table)
 does the device leave the oracle's path or the reference's, and its float32 radiance is BOTH's bit for bit in every sample.  No case is
 listed in test_oracle_golden.DIVERGING any more (a case listed there would be held to 1.5 x its measured count + 5 samples), so every case
 asserts bit-equality with the oracle and with the reference."""

@@ -4,7 +4,7 @@ libcore.a and drives its PathTracer::traceSample with the shared counter-based r
 
 Tolerances: integers / RNG exact; closest-hit distances exact (Embree's rcp + Newton restated,
 triangle_intersector_moeller.h:45-48); other deterministic floats rel 1e-5; per-sample radiance BIT-IDENTICAL in every case
-(65 cases, 580 608 samples, since the reference's top-level Embree tree was restated at the end of round 4; DIVERGING below is empty)."""
+(67 cases, 601 344 samples, since the reference's top-level Embree tree was restated at the end of round 4; DIVERGING below is empty)."""
 import json
 import os
 
@@ -74,8 +74,8 @@ def diverge_bound(name, samples):
     return int(1.5*DIVERGING.get(name, 0)) + 5 if name in DIVERGING else 0
 
 
-# Cases in which the oracle's radiance is the reference's BIT FOR BIT in every sample (float32 ==, all three channels) -- every golden case, 65 of
-# 65 with 580 608 samples, since the end of round 4: the whole path -- camera,
+# Cases in which the oracle's radiance is the reference's BIT FOR BIT in every sample (float32 ==, all three channels) -- every golden case, 67 of
+# 67 with 601 344 samples, since the end of round 4: the whole path -- camera,
 # filter, intersections, frames, BSDFs, light selection and sampling, MIS, Russian roulette, media, textures -- restated operation by operation.
 # Since round 4 that includes every case with a triangle mesh (materialtest with all its hero materials, the 998 000-triangle mesh, the water
 # caustic, mesh emitters, the bump-mapped mesh): Embree's triangle test is restated down to its right-associated dot product and its

@@ -9,7 +9,7 @@ import tungsten_amd as tg
 from tungsten_amd import capi
 
 # flat lists of quads / cubes / spheres / disks / cylinders among the golden cases, by GOLDEN_CASES name (+ the plain Cornell box and the sphere zoo)
-SCENES = ["cornell", "zoo_d", "cornell_smoke", "cornell_fog", "cornell_png_scalar", "cornell_sobol", "zoo_a", "zoo_e", "cornell_disks", "cornell_cylinders", "cornell_ties", "cornell_round_ties"]
+SCENES = ["cornell", "zoo_d", "cornell_smoke", "cornell_fog", "cornell_png_scalar", "cornell_sobol", "zoo_a", "zoo_e", "cornell_disks", "cornell_cylinders", "cornell_ties", "cornell_round_ties", "cornell_crowd"]
 
 
 def _make(name, tmp):
@@ -17,7 +17,7 @@ def _make(name, tmp):
         return scenes.cornell(tmp, resolution=(16, 9), spp=1)
     if name == "zoo_d":
         return scenes.cornell_zoo(tmp, which="zoo_d", resolution=(16, 9), spp=1)
-    mk, kw = scenes.GOLDEN_CASES[name]
+    mk, kw = scenes.GOLDEN_CASES[name] if name in scenes.GOLDEN_CASES else scenes.LIFTED_CASES[name]
     return mk(tmp, **dict(kw, resolution=(16, 9), spp=1, name=name + "_tt.json"))
 
 
