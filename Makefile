@@ -24,7 +24,9 @@ HIPHDR   := $(wildcard tungsten_amd/csrc/hip/*.h) include/tungsten_hip.h
 # -ffp-contract=off: no FMA contraction, so device arithmetic rounds like the CPU reference/oracle
 # (DESIGN.md "Numerics"); TG_FAST=1 allows contraction.
 FPFLAGS  := $(if $(TG_FAST),-ffp-contract=fast,-ffp-contract=off)
-HOSTFLAGS:= -std=c++11 -O2 -fPIC -Wall -Wextra -Wno-unused-parameter
+# (-ffp-contract=off: the host restates float32 arithmetic of the reference whose bits matter -- the instance tree and Embree's top-level tree,
+# bounds, CDF tables --, so no flag a packager adds, -march=native say, may fuse a multiply with an add)
+HOSTFLAGS:= -std=c++11 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) -Wno-unused-result $(if $(PROFILE),-DPT_PROFILE,) $(VARFLAGS)
 
 all: $(LIBDIR)/$(LIBNAME) $(if $(PROFILE)$(VARIANT),,$(LIBDIR)/tungsten_hip oracle/liboracle.so oracle/libm_host.so)

@@ -1,3 +1,5 @@
+// Embree 2.11's BVH4 builder for user geometry, restated (see EmbreeTopTree.hpp for what and why; citations are paths under
+// /root/reference/src/thirdparty/embree/).  Scalar float32 throughout, no contraction (Makefile: -ffp-contract=off).
 #include "EmbreeTopTree.hpp"
 #include <algorithm>
 #include <cmath>
