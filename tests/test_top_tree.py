@@ -116,6 +116,15 @@ def test_restated_builder_against_the_references_embree_live():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_top_tree_golden as mk
     sets = [top_tree_sets.random_set(kind, 5000 + k) for kind in range(4) for k in range(250)]
+    # ... and large sets, past the sizes at which Embree's builder spawns tasks (256 items) and bins / partitions in parallel (3072)
+    rs = np.random.RandomState(9)
+    for n in (300, 3100):
+        c, h = rs.rand(n, 3)*10 - 5, rs.rand(n, 3)*0.3
+        sets.append(np.concatenate([c - h, c + h], 1).astype(np.float32))
+        lo = rs.randint(-6, 6, size=(n, 3)).astype(np.float32)
+        sets.append(np.concatenate([lo, lo + rs.randint(0, 3, size=(n, 3))], 1).astype(np.float32))
+    import sys as _sys
+    _sys.setrecursionlimit(20000)
     trees = mk.embree_trees(sets)
     for s, t in zip(sets, trees):
         nodes, count = build(s)
