@@ -28,12 +28,13 @@ import tungsten_amd as tg  # noqa: E402
 
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 LIFT = os.environ.get("LIFT")
+SCALE, SPP = int(os.environ.get("STRESS_SCALE", "2")), int(os.environ.get("STRESS_SPP", "16"))     # STRESS_SCALE=4 STRESS_SPP=32: 64 times the goldens' samples
 names = sys.argv[1:] or sorted(T.BIT_IDENTICAL) + sorted(scenes.LIFTED_CASES)
 for name in names:
     mk, kw = scenes.GOLDEN_CASES[name] if name in scenes.GOLDEN_CASES else scenes.LIFTED_CASES[name]
     w0, h0 = kw["resolution"]
     tmp = tempfile.mkdtemp(prefix="tg_stress_")
-    path = mk(tmp, name=name + ".json", **dict(kw, resolution=(w0*2, h0*2), spp=16))
+    path = mk(tmp, name=name + ".json", **dict(kw, resolution=(w0*SCALE, h0*SCALE), spp=SPP))
     with open(path) as f:
         sc = json.load(f)
     if LIFT:
