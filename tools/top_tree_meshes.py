@@ -25,6 +25,7 @@ import tungsten_amd as tg  # noqa: E402
 from tungsten_amd import capi  # noqa: E402
 
 HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+SCALE, SPP = int(os.environ.get("STRESS_SCALE", "2")), int(os.environ.get("STRESS_SPP", "16"))     # as tools/oracle_stress.py
 
 
 def item_tree(desc):
@@ -63,7 +64,7 @@ def main(names):
         mk, kw = scenes.GOLDEN_CASES[name]
         w0, h0 = kw["resolution"]
         tmp = tempfile.mkdtemp(prefix="tg_items_")
-        path = mk(tmp, name=name + ".json", **dict(kw, resolution=(w0*2, h0*2), spp=16))
+        path = mk(tmp, name=name + ".json", **dict(kw, resolution=(w0*SCALE, h0*SCALE), spp=SPP))
         with open(path) as f:
             sc = json.load(f)
         w, h = sc["camera"]["resolution"]
