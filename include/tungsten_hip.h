@@ -526,7 +526,8 @@ enum { TGHIP_LIBM_SINF = 0, TGHIP_LIBM_COSF = 1, TGHIP_LIBM_LOGF = 2, TGHIP_LIBM
        TGHIP_LIBM_ACOSF = 6, TGHIP_LIBM_ATAN2F = 7, TGHIP_LIBM_POWF = 8, TGHIP_LIBM_CBRTF = 9,
        TGHIP_LIBM_EMBREE_RCP = 10, TGHIP_LIBM_RCPPS = 11, TGHIP_LIBM_TANF = 12 };
 int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n);
-int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ... */
+int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ...; "top_tree" = 0 before an upload:
+                                                                             TgHipSceneDesc::top_nodes is ignored, flat lists are walked in record order */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);
 int tghip_reset_counters(tghip_ctx *ctx);
 

@@ -173,3 +173,28 @@ def test_upload_refuses_trees_that_are_not_the_lists(tmp_path):
     assert tg.lib.tghip_upload_scene(ctx, C.byref(bad)) == 0
     tg.lib.tghip_destroy(ctx)
     flat.close()
+
+
+@pytest.mark.gpu
+def test_top_tree_option_restores_the_plain_list(tmp_path):
+    """tghip_set_option("top_tree", 0) before an upload: top_nodes is ignored and a flat list is walked in record order -- the closest hits of the
+    tie-made rays are the plain list's, not the walk's (profiles/r4_ab_top_tree_cornell.txt has what the tree costs)."""
+    import ctypes as C
+    path = scenes.cornell(tmp_path, resolution=(32, 18), spp=1)
+    flat = tg.FlattenedScene(path)
+    rays = np.ascontiguousarray(tie_rays(flat.desc), np.float32).reshape(-1, 8)
+    plain = oracle_lib.trace_rays_plain_list(flat.desc, rays)
+    walk = oracle_lib.trace_rays(flat.desc, rays)[0]
+    assert (plain["rec"] != walk["rec"]).any()
+    ctx = tg.lib.tghip_create(0)
+    assert ctx
+    assert tg.lib.tghip_set_option(ctx, b"top_tree", 0) == 0
+    assert tg.lib.tghip_upload_scene(ctx, flat.desc) == 0, tg.lib.tghip_last_error(ctx)
+    hits = np.empty(rays.shape[0], dtype=[("t", np.float32), ("u", np.float32), ("v", np.float32), ("rec", np.int32)])
+    ms = C.c_double(0.0)
+    assert tg.lib.tghip_trace_rays(ctx, rays.ctypes.data, hits.ctypes.data, rays.shape[0], 1, C.byref(ms)) == 0, tg.lib.tghip_last_error(ctx)
+    tg.lib.tghip_destroy(ctx)
+    flat.close()
+    assert (hits["rec"] == plain["rec"]).all()
+    hit = plain["rec"] >= 0
+    assert (hits["t"][hit].view(np.uint32) == plain["t"][hit].view(np.uint32)).all()

@@ -119,6 +119,7 @@ struct tghip_ctx {
     bool mediaSimple = false;             // a media scene whose surface BSDFs MASK_MEDIA covers (no instances, no mesh emitters)
     bool mediaLeanOpt = true;             // "media_lean": shade such scenes with k_shade<MASK_MEDIA> instead of <BSDF_MASK_ALL>
     bool foldFinishOpt = true;            // "fold_finish"
+    bool topTreeOpt = true;               // "top_tree": 0 = ignore TgHipSceneDesc::top_nodes at the next upload (flat lists walked in record order: faster, not the reference's ties)
     bool mergeMissOpt = true;             // "merge_miss"
     bool tailOpt = true;
     long long tailThreshold = 8192;
@@ -873,6 +874,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "tail_kernel") ctx->tailOpt = value != 0;
     else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
     else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
+    else if (k == "top_tree") ctx->topTreeOpt = value != 0;
     else if (k == "media_lean") ctx->mediaLeanOpt = value != 0;
     else if (k == "tail_threshold") ctx->tailThreshold = value;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
@@ -1196,7 +1198,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     }
     s.top_nodes = nullptr;
     s.flat_boxes = nullptr;
-    if (sd->top_nodes && sd->num_top_nodes) {
+    if (sd->top_nodes && sd->num_top_nodes && ctx->topTreeOpt) {
         // the reference's top-level Embree tree (TgHipTopNode): flat lists only, every record exactly one leaf, children behind their parents
         // (preorder: no cycles), no deeper than the walk's stack allows (pt_kernels.h: flatOrderedWalk)
         const uint32_t nn = sd->num_top_nodes;
