@@ -4140,6 +4140,52 @@ static int flat_shortcut_decides(const TgHipSceneDesc *s, const Ray *rayIn, Hit 
     }
     return got->rec < 0 || (tb < t2 && entryB <= t2);
 }
+/* A cheaper formulation of the same shortcut, for the next round (the slab test out of the per-record loop; no device
+ * counterpart yet): the loop keeps the THREE nearest hits, boxes or not; afterwards b = the first of them whose box the ray passes, and the second
+ * nearest distance is bounded from below by the next stored hit, or by the third when more than three were hit (every hit not stored lies behind
+ * it).  A lower bound only makes the rule stricter: decided rays stay right, a few more walk. */
+static int flat_shortcut_decides_v2(const TgHipSceneDesc *s, const Ray *rayIn, Hit *got)
+{
+    Ray ray = *rayIn;
+    Hit top[3]; int m = 0, count = 0;
+    got->rec = -1; got->inst = -1; got->t = ray.tmax; got->u = got->v = 0.0f;
+    for (uint32_t i = 0; i < s->num_recs; ++i) {
+        Hit h; float tm = ray.tmax;
+        h.rec = -1; h.inst = -1; h.t = tm; h.u = h.v = 0.0f;
+        test_rec(s, i, &ray, &tm, &h, NULL, -1, -1);
+        if (h.rec < 0) continue;
+        if (h.t != h.t) return 0;                               /* a NaN distance (a ray IN a disk's plane: Disk::intersect divides 0 by 0 and accepts the result,
+                                                                   as the reference does) cannot be ordered: the walk, where the disk's box usually culls it */
+        count++;
+        int k = m < 3 ? m : 3;                                  /* insert by t, equal distances keep their order */
+        while (k > 0 && h.t < top[k - 1].t) { if (k < 3) top[k] = top[k - 1]; --k; }
+        if (k < 3) { top[k] = h; if (m < 3) m++; }
+    }
+    int b = -1; float entryB = 0.0f;
+    for (int k = 0; k < m && b < 0; ++k) {
+        v3 lo, hi; float entry;
+        if (top_leaf_box(s, top[k].rec, &lo, &hi) && embree_box_near(&ray, lo, hi, &entry)) { b = k; entryB = entry; }
+    }
+    if (b < 0) return count <= 3;                               /* nothing the walk can reach among the stored; unknown beyond them */
+    const float t2lb = b + 1 < m ? top[b + 1].t : (count > m ? top[m - 1].t : INFINITY);
+    *got = top[b];
+    return top[b].t < t2lb && entryB <= t2lb;
+}
+size_t oracle_flat_device_form2(const TgHipSceneDesc *s, const TgHipRay *rays, uint8_t *decided, size_t n)
+{
+    size_t differing = 0;
+    if (!s->top_nodes || !s->num_top_nodes) return (size_t)-1;
+    for (size_t q = 0; q < n; ++q) {
+        Ray ray = {ld3(rays[q].o), ld3(rays[q].d), rays[q].tmin, rays[q].tmax};
+        Hit want, got;
+        want.rec = -1; want.inst = -1; want.t = ray.tmax; want.u = want.v = 0.0f;
+        embree_top_walk(s, &ray, &want, NULL, -1);
+        const int dec = flat_shortcut_decides_v2(s, &ray, &got);
+        if (decided) decided[q] = (uint8_t)dec;
+        if (dec && (got.rec != want.rec || (got.rec >= 0 && (memcmp(&got.t, &want.t, 4) || memcmp(&got.u, &want.u, 4) || memcmp(&got.v, &want.v, 4))))) differing++;
+    }
+    return differing;
+}
 size_t oracle_flat_device_form(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *hits, uint8_t *decided, size_t n)
 {
     size_t differing = 0;

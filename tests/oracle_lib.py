@@ -222,3 +222,16 @@ def trace_rays_plain_list(desc, rays):
         return trace_rays(desc, rays)[0]
     finally:
         _lib.oracle_set_flat_order(1)
+
+
+_lib.oracle_flat_device_form2.argtypes = [DESC_P, C.c_void_p, C.c_void_p, C.c_size_t]
+_lib.oracle_flat_device_form2.restype = C.c_size_t
+
+
+def flat_device_form2(desc, rays):
+    """The cheaper shortcut sketched for the next round (oracle.c: flat_shortcut_decides_v2; no device counterpart yet): (decided, rays on which a
+    decided answer differs from the walk)."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 8)
+    decided = np.zeros(rays.shape[0], np.uint8)
+    differing = _lib.oracle_flat_device_form2(desc, rays.ctypes.data, decided.ctypes.data, rays.shape[0])
+    return decided.astype(bool), int(differing)

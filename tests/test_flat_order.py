@@ -95,6 +95,23 @@ def test_device_formulation_is_the_walk(name, tmp_path):
     print(name, len(rays), "rays,", int((~decided).sum()), "walked,", int(changed.sum()), "answers changed by the order")
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_cheaper_shortcut_sketched_for_the_next_round_is_the_walk_too(name, tmp_path):
+    """the slab test out of the per-record loop -- keep the three nearest hits, test boxes afterwards, bound the second nearest
+    distance from below.  Test side only (oracle.c: flat_shortcut_decides_v2): its decided answers are the walk's on the tie-made rays, and it leaves
+    only a few more rays to the walk than the shortcut the device runs.  (Writing it found what a NaN distance does to a sorted list: a ray IN a
+    disk's plane makes Disk::intersect divide 0 by 0 and accept the result, in the reference too; such a hit cannot be ordered and goes to the walk.)"""
+    mk, kw = CASES[name]
+    flat = tg.FlattenedScene(mk(tmp_path, **dict(kw, resolution=(16, 9), spp=1)))
+    rays = tie_rays(flat.desc)
+    _, decided1, _ = oracle_lib.flat_device_form(flat.desc, rays)
+    decided2, differing = oracle_lib.flat_device_form2(flat.desc, rays)
+    flat.close()
+    assert differing == 0
+    assert not (decided2 & ~decided1).any()                      # stricter, never laxer
+    assert (~decided2).sum() <= 1.6*(~decided1).sum() + 10
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_device_walks_flat_lists_in_the_oracles_order(name, tmp_path):
