@@ -31,6 +31,10 @@ typedef struct TgHostSceneInfo {
 tgh_scene *tgh_scene_load(const char *json_path, char *err, size_t errlen);
 const TgHipSceneDesc *tgh_scene_desc(tgh_scene *s);
 int  tgh_scene_info(tgh_scene *s, TgHostSceneInfo *out);
+/* The items of the reference's top-level Embree geometry (renderer/TraceableScene.hpp:101-118): the scene's finite primitives in scene order, each
+ * with the box its bounds() returns after prepareForRender -- restated per primitive class in csrc/host/Scene.cpp, held to the reference's own by
+ * tests/test_top_tree.py -- as 6 floats (lower, upper), and the index of its object.  Returns the number of items; the arrays live as long as `s`. */
+uint32_t tgh_scene_items(tgh_scene *s, const float **boxes, const int32_t **objects);
 void tgh_scene_free(tgh_scene *s);
 
 /* makeTraceable(seed) with the path_tracer_hip integrator (needs a HIP device) */

@@ -2190,7 +2190,8 @@ static int embree_top_walk(const TgHipSceneDesc *s, const Ray *ray0, Hit *hit, T
                     bvh_walk(s, 0, &ray, &ray.tmax, hit, NULL, obj, -1);
                 } else {
                     for (uint32_t r = 0; r < s->num_recs; ++r)          /* (flat scan: the prototype's scenes are small) */
-                        if ((int)TGHIP_REC_OBJECT(s->recs[r].meta) == obj && TGHIP_REC_KIND(s->recs[r].meta) != TGHIP_REC_TRIANGLE) {
+                        if ((int)TGHIP_REC_OBJECT(s->recs[r].meta) == obj && TGHIP_REC_KIND(s->recs[r].meta) != TGHIP_REC_TRIANGLE &&
+                            TGHIP_REC_KIND(s->recs[r].meta) != TGHIP_REC_INSTANCE) {       /* (an `instances` primitive: its set record) */
                             test_rec(s, r, &ray, &ray.tmax, hit, NULL, objFilter, -1);
                             break;
                         }

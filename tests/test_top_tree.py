@@ -95,6 +95,26 @@ def test_item_boxes_are_the_references_bounds(name, tmp_path):
     assert [["%08x" % v for v in row] for row in boxes.view(np.uint32).tolist()] == gold
 
 
+@pytest.mark.parametrize("name", top_tree_sets.SCENES + top_tree_sets.ITEM_SCENES)
+def test_scene_items_are_the_references_finites(name, tmp_path):
+    """tgh_scene_items: the finite primitives of a scene in scene order with their bounds() as csrc/host/Scene.cpp restates them per primitive class
+    -- quads, cubes, spheres, disks, cylinders, triangle meshes (static, emissive, bump-mapped), `instances` -- against the reference's own bounds()
+    of its _finites (oracle/ref_harness.cpp: bounds), bit for bit and in order: the items the reference's top-level Embree tree is built over, for
+    every kind of scene (infinite and Dirac emitters are not among them)."""
+    if name in ("materialtest", "mesh1m") and not scenes.have_materialtest():
+        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+    with open(os.path.join(scenes.GOLDEN, "prim_bounds.json")) as f:
+        gold = json.load(f)[name]
+    flat = tg.FlattenedScene(top_tree_sets._make(name, tmp_path))
+    boxes, objects = flat.items()
+    d = flat.desc.contents
+    assert [["%08x" % v for v in row] for row in boxes.view(np.uint32).tolist()] == gold
+    assert (np.diff(objects) > 0).all() and 0 <= objects[0] and objects[-1] < d.num_objects
+    rec_objects = set(d.recs[r].meta & 0x1FFFFFFF for r in range(min(d.num_recs, 4096)))
+    assert rec_objects <= set(objects.tolist()) or d.num_instances          # every record belongs to an item (masters of instances aside)
+    flat.close()
+
+
 def test_scenes_that_are_not_such_lists_carry_no_tree(tmp_path):
     for mk, kw in (scenes.GOLDEN_CASES["cornell_bump"], scenes.GOLDEN_CASES["cornell_instances"], scenes.GOLDEN_CASES["cornell_mesh_light"]):
         flat = tg.FlattenedScene(mk(tmp_path, **dict(kw, resolution=(16, 9), spp=1)))

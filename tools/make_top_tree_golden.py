@@ -53,7 +53,7 @@ if __name__ == "__main__":
     HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     bounds = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for name in top_tree_sets.SCENES:
+        for name in top_tree_sets.SCENES + top_tree_sets.ITEM_SCENES:
             path = top_tree_sets._make(name, tmp)
             subprocess.check_call([HARNESS, "bounds", path, os.path.join(tmp, "b.txt")], stdout=subprocess.DEVNULL, cwd=os.path.dirname(path))
             with open(os.path.join(tmp, "b.txt")) as f:

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE, a PROTOTYPE for the next round (build container only: needs oracle/_ref/ref_harness).  Scenes WITH triangle meshes keep one
 tree over all their records; the reference has the mesh as ONE item of its top-level Embree tree.  This tool asks what
-walking that tree would buy: it builds the top-level tree over the scene's finite primitives -- analytic ones by their restated bounds(), a mesh by
-the box of its triangles' vertices -- with the library's restatement of Embree's builder (tgh_top_tree_build), hands it to the ORACLE with its
+walking that tree would buy: it builds the top-level tree over the scene's items (tgh_scene_items: the reference's _finites with their bounds(),
+held to the reference's own by tests/test_top_tree.py) with the library's restatement of Embree's builder (tgh_top_tree_build), hands it to the ORACLE with its
 `oracle_set_top_items` switch (a leaf = an object; a mesh leaf runs the mesh's own closest-hit query under the hit distance so far), and compares
 the oracle's per-sample radiance with the reference's at four times the pixels and twice the samples of the goldens, with and without.
 
@@ -28,34 +28,17 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 SCALE, SPP = int(os.environ.get("STRESS_SCALE", "2")), int(os.environ.get("STRESS_SPP", "16"))     # as tools/oracle_stress.py
 
 
-def item_tree(desc):
-    """(nodes, count): the top-level tree over the objects that have records, leaves = ~object index; None when an object's box is unknown."""
+def item_tree(flat):
+    """(nodes, count): the top-level tree over the scene's items (tgh_scene_items: the reference's _finites with their bounds()), leaves = ~object index."""
     lib = capi.load_library()
-    d = desc.contents
-    recs = np.ctypeslib.as_array(C.cast(d.recs, C.POINTER(C.c_float)), shape=(d.num_recs, 12))
-    meta = recs.view(np.uint32)[:, 3]
-    kind, obj = meta >> 29, meta & 0x1FFFFFFF
-    boxes, objs = [], []
-    for o in sorted(set(obj.tolist())):
-        sel = obj == o
-        k = int(kind[sel][0])
-        if k == 0:                                   # triangles: v0, v0 + e1, v0 + e2 (an ulp from the mesh's own vertices at most)
-            a, b, c = recs[sel, 0:3], recs[sel, 4:7], recs[sel, 8:11]
-            v = np.concatenate([a, a + b, a + c])
-            boxes.append(np.concatenate([v.min(axis=0), v.max(axis=0)]))
-        else:
-            lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
-            if lib.tgh_leaf_bounds(C.byref(d.objects[o]), k, lo.ctypes.data, hi.ctypes.data) != 1:
-                return None, 0
-            boxes.append(np.concatenate([lo, hi]))
-        objs.append(o)
+    boxes, objs = flat.items()
     boxes = np.ascontiguousarray(boxes, np.float32)
     nodes = (capi.TgHipTopNode*max(len(boxes), 1))()
     count = lib.tgh_top_tree_build(boxes.ctypes.data, len(boxes), nodes, len(nodes))
     for n in range(count):
         for i in range(4):
             if nodes[n].child[i] < 0:
-                nodes[n].child[i] = ~objs[~nodes[n].child[i]]
+                nodes[n].child[i] = ~int(objs[~nodes[n].child[i]])
     return nodes, count
 
 
@@ -73,7 +56,7 @@ def main(names):
         subprocess.check_call([HARNESS, "samples", path, str(tg.DEFAULT_SEED), str(spp), out], stdout=subprocess.DEVNULL, cwd=tmp)
         ref = np.fromfile(out, np.float32).reshape(h, w, spp, 3)
         flat = tg.FlattenedScene(path)
-        nodes, count = item_tree(flat.desc)
+        nodes, count = item_tree(flat)
         tiles = oracle_lib.dice_tiles(w, h, tg.DEFAULT_SEED)[0] if flat.info.stratified_sampler else None
         res = []
         for items in (False, True):
@@ -104,4 +87,4 @@ def main(names):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["cornell_bump", "cornell_mesh_light", "cornell_mesh_light_flat", "cornell_png_textures", "materialtest", "mesh1m"])
+    main(sys.argv[1:] or ["cornell_bump", "cornell_mesh_light", "cornell_mesh_light_flat", "cornell_png_textures", "cornell_instances", "materialtest", "mesh1m"])

@@ -50,6 +50,15 @@ class FlattenedScene(object):
     def height(self):
         return int(self.info.height)
 
+    def items(self):
+        """The items of the reference's top-level Embree geometry -- the scene's finite primitives in scene order -- as (boxes [n, 6] float32:
+        each one's bounds(), object indices [n] int32)."""
+        boxes, objects = C.POINTER(C.c_float)(), C.POINTER(C.c_int32)()
+        n = lib.tgh_scene_items(self._h, C.byref(boxes), C.byref(objects))
+        if not n:
+            return np.zeros((0, 6), np.float32), np.zeros(0, np.int32)
+        return (np.ctypeslib.as_array(boxes, shape=(n, 6)).copy(), np.ctypeslib.as_array(objects, shape=(n,)).copy())
+
     def close(self):
         if self._h:
             lib.tgh_scene_free(self._h)

@@ -216,6 +216,7 @@ PROTOTYPES = {
     "tgh_accel_inst_tight_boxes": (VP, [VP]),
     "tgh_accel_counts": (None, [VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "tgh_instance_tight_bounds": (None, [VP, C.c_uint32, C.c_uint32, VP, VP, VP, VP]),
+    "tgh_scene_items": (C.c_uint32, [VP, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_int32))]),
     "tgh_top_tree_build": (C.c_int, [VP, C.c_uint32, VP, C.c_uint32]),
     "tgh_top_tree_for_scene": (C.c_int, [VP, C.c_uint32, VP, C.c_uint32, VP, C.c_uint32]),
     "tgh_leaf_bounds": (C.c_int, [VP, C.c_uint32, VP, VP]),

@@ -527,6 +527,9 @@ void TraceableScene::flatten()
 
         if (p.isInfinite() || p.isDirac())
             continue;
+        for (int k = 0; k < 3; ++k) _itemBoxes.push_back(p.bounds.lo[k]);
+        for (int k = 0; k < 3; ++k) _itemBoxes.push_back(p.bounds.hi[k]);
+        _itemObjects.push_back(int32_t(_objects.size() - 1));
         _sceneBounds.grow(p.bounds);
 
         uint32_t objMeta = uint32_t(pi);

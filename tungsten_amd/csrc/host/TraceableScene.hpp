@@ -67,6 +67,8 @@ class TraceableScene
     std::vector<TgHipBvhNode> _nodes;
     std::vector<TgHipWideNode> _wideNodes;
     std::vector<TgHipTopNode> _topNodes;
+    std::vector<float> _itemBoxes;
+    std::vector<int32_t> _itemObjects;
     std::vector<TgHipPrimRec> _recs;
     std::vector<TgHipTriAttr> _triAttrs;
     std::vector<TgHipObject> _objects;
@@ -97,6 +99,10 @@ public:
     const Camera &cam() const { return _scene.camera; }
     const RendererSettings &rendererSettings() const { return _scene.renderer; }
     const Box3f &bounds() const { return _sceneBounds; }
+    // the items of the reference's top-level Embree geometry: its _finites in scene order (TraceableScene.hpp:101-107), each with its bounds()
+    // as Scene.cpp restates them (6 floats: lower, upper) and the index of its object
+    const std::vector<float> &itemBoxes() const { return _itemBoxes; }
+    const std::vector<int32_t> &itemObjects() const { return _itemObjects; }
     int bvhDepth() const { return _bvhDepth; }
     int wideDepth() const { return _wideDepth; }
     double bvhSahCost() const { return _bvhSah; }

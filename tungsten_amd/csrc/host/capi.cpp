@@ -86,6 +86,14 @@ int tgh_scene_info(tgh_scene *s, TgHostSceneInfo *out)
     return 0;
 }
 
+uint32_t tgh_scene_items(tgh_scene *s, const float **boxes, const int32_t **objects)
+{
+    if (!s || !s->flattened) return 0;
+    if (boxes) *boxes = s->flattened->itemBoxes().data();
+    if (objects) *objects = s->flattened->itemObjects().data();
+    return uint32_t(s->flattened->itemObjects().size());
+}
+
 void tgh_scene_free(tgh_scene *s) { delete s; }
 
 tgh_renderer *tgh_renderer_open(const char *json_path, uint32_t seed, int spp_override, int devices,
