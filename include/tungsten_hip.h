@@ -175,7 +175,8 @@ enum { TGHIP_REC_TRIANGLE = 0, TGHIP_REC_QUAD = 1, TGHIP_REC_CUBE = 2, TGHIP_REC
  *             index inst_prims[] (BinaryBvh::_primIndices: the instance records, kind TGHIP_REC_INSTANCE, of the leaf's one
  *             or two instances).  The closest-hit walk reaches the set through the scene's BVH2 (nodes[0]: over the
  *             non-instance records and the sets); the wide BVH -- walked by any-hit shadow queries, for which the order is
- *             immaterial -- holds the instance records themselves, boxed by their leaf of the reference's tree. */
+ *             immaterial -- holds the instance records themselves, built from their tight geometry boxes (inst_tight_boxes, below);
+ *             the box of the instance's leaf in the reference's tree (inst_leaf_boxes) is tested when the record is reached. */
 typedef struct TgHipPrimRec {
     float a[3]; uint32_t meta;
     float b[3]; float p0;

@@ -801,9 +801,10 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     _desc.media = _media.empty() ? nullptr : _media.data();
     _desc.num_media = uint32_t(_media.size());
     // the top-level Embree tree this very scene committed (TraceableScene.hpp:112-134), in the library's restatement of Embree's builder: where
-    // faces coincide the order in which a ray visits it decides which primitive it hits (include/tungsten_hip.h: TgHipTopNode)
+    // faces coincide the order in which a ray visits it decides which primitive it hits (include/tungsten_hip.h: TgHipTopNode); with
+    // renderer.scene_bvh = false the reference asks its finite primitives one after the other (TraceableScene.hpp:175-181): no tree
     _topNodes.assign(_recs.size(), TgHipTopNode());
-    const int numTop = _instanceSets.empty() ? tgh_top_tree_for_scene(_objects.data(), uint32_t(_objects.size()), _recs.data(), uint32_t(_recs.size()),
+    const int numTop = (_instanceSets.empty() && scene._settings.useSceneBvh()) ? tgh_top_tree_for_scene(_objects.data(), uint32_t(_objects.size()), _recs.data(), uint32_t(_recs.size()),
                                                                      _topNodes.data(), uint32_t(_topNodes.size())) : 0;
     _topNodes.resize(size_t(std::max(numTop, 0)));
     _desc.top_nodes = _topNodes.empty() ? nullptr : _topNodes.data();

@@ -124,6 +124,17 @@ def test_scenes_that_are_not_such_lists_carry_no_tree(tmp_path):
     assert build(np.array([[0, 0, 0, 1, 1, 1]], np.float32))[1] == 0
     assert build(np.array([[0, 0, 0, 1, 1, 1], [2, 0, 0, 1, 1, 1]], np.float32))[1] == 0
     assert build(np.array([[0, 0, 0, 1, 1, 1], [0, 0, 0, np.inf, 1, 1]], np.float32))[1] == 0
+    # ... and builds the tree over the others, which keep their ids (Embree's primref pass skips an invalid item): three items, the middle one
+    # invalid -> one node whose two leaves are items 0 and 2
+    nodes3, count3 = build(np.array([[0, 0, 0, 1, 1, 1], [0, 0, 0, np.nan, 1, 1], [4, 0, 0, 5, 1, 1]], np.float32))
+    assert count3 == 1 and sorted(~c for c in nodes3[0].child if c < 0) == [0, 2]
+    # renderer.scene_bvh = false: the reference commits no Embree scene and asks its primitives in scene order (TraceableScene.hpp:175-181)
+    flat = tg.FlattenedScene(scenes.cornell(tmp_path, name="nobvh.json", resolution=(16, 9), spp=1, renderer={"scene_bvh": False}))
+    assert flat.desc.contents.num_top_nodes == 0 and not flat.desc.contents.top_nodes
+    flat.close()
+    flat = tg.FlattenedScene(scenes.cornell(tmp_path, name="bvh.json", resolution=(16, 9), spp=1))
+    assert flat.desc.contents.num_top_nodes > 0
+    flat.close()
     lib = capi.load_library()
     nodes = (capi.TgHipTopNode*1)()
     b = np.array([[0, 0, 0, 1, 1, 1], [2, 0, 0, 3, 1, 1], [4, 0, 0, 5, 1, 1], [6, 0, 0, 7, 1, 1], [8, 0, 0, 9, 1, 1], [10, 0, 0, 11, 1, 1]], np.float32)

@@ -974,15 +974,93 @@ PT_DEV void wideEnterInstance(WideState &w, uint2 *stack, int stride, uint32_t r
     w.node = (int)__float_as_uint(r2.z);
     w.curInst = (int)recIdx;
 }
+// ---- the node as a lane holds it --------------------------------------------------------------------------------------------------
+// PT_WIDE_HALF = 1 (an experiment of round 5, measured and NOT the product's layout): the shim re-encodes the ABI's 80-byte node
+// (include/tungsten_hip.h: TgHipWideNode) at upload into 128 bytes = one cache line whose 48 child planes are IEEE halfs holding the SAME
+// integers 0 .. 255 -- exactly --, one 16-byte row per axis and side:
+//   [0,16) origin.xyz, exp | imask << 24    [16,32) child_base, rec_base, leaf_valid, 0
+//   [32,48) lo x   [48,64) lo y   [64,80) lo z   [80,96) hi x   [96,112) hi y   [112,128) hi z        (8 halfs per row: slots 0 .. 7)
+// The idea: a wave64 v_cvt_f32_ubyteN costs 3.2 cycles of its SIMD and the v_pk_fma_f32 behind it 3.7 per two planes (tools/ubench_valu.hip,
+// profiles/r5_ubench_valu.txt: only fma / mul / add / and / mov run at 2) -- 5.0 per plane --, while v_fma_mix_f32 reads the half and does
+// the same single-rounding f32 fma in 3.2; and the ray's octant picks the ROW it loads as "near" / "far" per axis by address, where the byte
+// layout needs twelve v_cndmask_b32 on the loaded words: ~85 of ~500 issue cycles per node visit less, every plane distance bit-identical
+// (the whole GPU suite passes on it).  The result: 2.7 % SLOWER on the headline (949 against 975 Msamples/s in one session, closest-hit launches
+// 863 -> 890 us, shadow 827 -> 888; mesh1m 610 -> 600; profiles/r5_ab_half_planes.txt) -- eight 16-byte loads per node instead of five, and
+// 128 VGPRs instead of 115 / 125: the walk is bound as much by what it pulls through the vector L1 as by what it issues.
+#ifndef PT_WIDE_HALF
+#define PT_WIDE_HALF 0
+#endif
+// byte offset of node `idx` behind s.wide
+PT_DEV uint32_t wideNodeOff(const DeviceScene &s, uint32_t idx) { return PT_WIDE_HALF ? idx << 7 : idx*s.wide_stride; }
+#if PT_WIDE_HALF
+#define PT_WIDE_NODE_BYTES 128u
+struct WideNodeRegs { float4 q0, q1, nx, ny, nz, fx, fy, fz; };
+// the 16-byte row at byte `off` behind `base` (uniform: s.wide, or the LDS copy of the top of the tree) -- a 32-bit offset, so that the
+// load is `global_load_dwordx4 v, v_off, s[base]` and a lane holds six row offsets, not six 64-bit pointers
+PT_DEV float4 wideRow(const char *base, uint32_t off) { return *reinterpret_cast<const float4 *>(base + (size_t)off); }
+PT_DEV void wideNodeFetch(WideNodeRegs &n, const char *base, uint32_t off, const WideRay &wr)
+{
+    const uint32_t ox = (wr.octInv & 1u) ? 48u : 0u, oy = (wr.octInv & 2u) ? 48u : 0u, oz = (wr.octInv & 4u) ? 48u : 0u;
+    n.q0 = wideRow(base, off); n.q1 = wideRow(base, off + 16u);
+    n.nx = wideRow(base, off + 32u + ox); n.fx = wideRow(base, off + 80u - ox);
+    n.ny = wideRow(base, off + 48u + oy); n.fy = wideRow(base, off + 96u - oy);
+    n.nz = wideRow(base, off + 64u + oz); n.fz = wideRow(base, off + 112u - oz);
+}
+// (the two-level walks load "a node or a record" through one address: the first three rows are in registers when the kind is known)
+PT_DEV void wideNodeFetchRest(WideNodeRegs &n, const char *base, uint32_t off, const WideRay &wr, float4 q0, float4 q1, float4 q2)
+{
+    const uint32_t ox = (wr.octInv & 1u) ? 48u : 0u, oy = (wr.octInv & 2u) ? 48u : 0u, oz = (wr.octInv & 4u) ? 48u : 0u;
+    const float4 hx = wideRow(base, off + 80u);
+    n.q0 = q0; n.q1 = q1;
+    n.nx = ox ? hx : q2; n.fx = ox ? q2 : hx;
+    n.ny = wideRow(base, off + 48u + oy); n.fy = wideRow(base, off + 96u - oy);
+    n.nz = wideRow(base, off + 64u + oz); n.fz = wideRow(base, off + 112u - oz);
+}
+#else
+#define PT_WIDE_NODE_BYTES 80u
+struct WideNodeRegs { float4 q0, q1, q2, q3, q4; };
+PT_DEV float4 wideRow(const char *base, uint32_t off) { return *reinterpret_cast<const float4 *>(base + (size_t)off); }
+PT_DEV void wideNodeFetch(WideNodeRegs &n, const char *base, uint32_t off, const WideRay &)
+{
+    n.q0 = wideRow(base, off); n.q1 = wideRow(base, off + 16u); n.q2 = wideRow(base, off + 32u); n.q3 = wideRow(base, off + 48u); n.q4 = wideRow(base, off + 64u);
+}
+PT_DEV void wideNodeFetchRest(WideNodeRegs &n, const char *base, uint32_t off, const WideRay &, float4 q0, float4 q1, float4 q2)
+{
+    n.q0 = q0; n.q1 = q1; n.q2 = q2; n.q3 = wideRow(base, off + 48u); n.q4 = wideRow(base, off + 64u);
+}
+#endif
 // The node's 80 bytes have arrived: slab-test its eight children against [tmin, tmax], queue the hit ones.  Two children per
 // v_pk_fma_f32; each half is one correctly rounded fma, as in the oracle's scalar fmaf.
 typedef float WideF2 __attribute__((ext_vector_type(2)));
-PT_DEV void wideVisit(WideState &w, float4 q0, float4 q1, float4 q2, float4 q3, float4 q4, f3 o, const WideRay &wr, float tmin, float tmax)
+PT_DEV void wideVisit(WideState &w, const WideNodeRegs &nd, f3 o, const WideRay &wr, float tmin, float tmax)
 {
+    const float4 q0 = nd.q0, q1 = nd.q1;
     const uint32_t ex = __float_as_uint(q0.w);
     const f3 spacing = mk3(__uint_as_float((ex & 0xFFu) << 23), __uint_as_float(((ex >> 8) & 0xFFu) << 23), __uint_as_float(((ex >> 16) & 0xFFu) << 23));
     const f3 adjS = spacing*wr.idir;
     const f3 adjO = (xyz(q0) - o)*wr.idir;
+    uint32_t hitmask = 0u;
+#if PT_WIDE_HALF
+    typedef _Float16 WideH2 __attribute__((ext_vector_type(2)));
+    // plane distance = fma(q, spacing/d, (origin - o)/d) with q read as a half (v_fma_mix_f32): one rounding, as the oracle's fmaf on float(q)
+    auto plane = [](_Float16 q, float s, float o) { return __builtin_fmaf((float)q, s, o); };
+    const float nxw[4] = {nd.nx.x, nd.nx.y, nd.nx.z, nd.nx.w}, nyw[4] = {nd.ny.x, nd.ny.y, nd.ny.z, nd.ny.w}, nzw[4] = {nd.nz.x, nd.nz.y, nd.nz.z, nd.nz.w};
+    const float fxw[4] = {nd.fx.x, nd.fx.y, nd.fx.z, nd.fx.w}, fyw[4] = {nd.fy.x, nd.fy.y, nd.fy.z, nd.fy.w}, fzw[4] = {nd.fz.x, nd.fz.y, nd.fz.z, nd.fz.w};
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {                // children 2 pr and 2 pr + 1: the two halfs of word pr of every row
+        const WideH2 hnx = __builtin_bit_cast(WideH2, nxw[pr]), hny = __builtin_bit_cast(WideH2, nyw[pr]), hnz = __builtin_bit_cast(WideH2, nzw[pr]);
+        const WideH2 hfx = __builtin_bit_cast(WideH2, fxw[pr]), hfy = __builtin_bit_cast(WideH2, fyw[pr]), hfz = __builtin_bit_cast(WideH2, fzw[pr]);
+        const float tnx0 = plane(hnx.x, adjS.x, adjO.x), tnx1 = plane(hnx.y, adjS.x, adjO.x), tfx0 = plane(hfx.x, adjS.x, adjO.x), tfx1 = plane(hfx.y, adjS.x, adjO.x);
+        const float tny0 = plane(hny.x, adjS.y, adjO.y), tny1 = plane(hny.y, adjS.y, adjO.y), tfy0 = plane(hfy.x, adjS.y, adjO.y), tfy1 = plane(hfy.y, adjS.y, adjO.y);
+        const float tnz0 = plane(hnz.x, adjS.z, adjO.z), tnz1 = plane(hnz.y, adjS.z, adjO.z), tfz0 = plane(hfz.x, adjS.z, adjO.z), tfz1 = plane(hfz.y, adjS.z, adjO.z);
+        float tn0 = fmaxf(fmaxf(tnx0, tny0), fmaxf(tnz0, tmin)), tn1 = fmaxf(fmaxf(tnx1, tny1), fmaxf(tnz1, tmin));
+        float tf0 = fminf(fminf(tfx0, tfy0), fminf(tfz0, tmax)), tf1 = fminf(fminf(tfx1, tfy1), fminf(tfz1, tmax));
+        tf0 *= 1.0000004f; tf1 *= 1.0000004f;
+        hitmask |= (tn0 <= tf0) ? (1u << (2*pr)) : 0u;
+        hitmask |= (tn1 <= tf1) ? (2u << (2*pr)) : 0u;
+    }
+#else
+    const float4 q2 = nd.q2, q3 = nd.q3, q4 = nd.q4;
     const WideF2 SX = {adjS.x, adjS.x}, SY = {adjS.y, adjS.y}, SZ = {adjS.z, adjS.z};
     const WideF2 OX = {adjO.x, adjO.x}, OY = {adjO.y, adjO.y}, OZ = {adjO.z, adjO.z};
     // the planes the ray enters (near) and leaves (far) through, per axis: qlo / qhi swapped for negative directions
@@ -993,7 +1071,6 @@ PT_DEV void wideVisit(WideState &w, float4 q0, float4 q1, float4 q2, float4 q3, 
     const uint32_t nearX[2] = {nx ? hx0 : lx0, nx ? hx1 : lx1}, farX[2] = {nx ? lx0 : hx0, nx ? lx1 : hx1};
     const uint32_t nearY[2] = {ny ? hy0 : ly0, ny ? hy1 : ly1}, farY[2] = {ny ? ly0 : hy0, ny ? ly1 : hy1};
     const uint32_t nearZ[2] = {nz ? hz0 : lz0, nz ? hz1 : lz1}, farZ[2] = {nz ? lz0 : hz0, nz ? lz1 : hz1};
-    uint32_t hitmask = 0u;
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {                // children 2 pr and 2 pr + 1
         const int d = pr >> 1, sh = (pr & 1)*16;
@@ -1007,6 +1084,7 @@ PT_DEV void wideVisit(WideState &w, float4 q0, float4 q1, float4 q2, float4 q3, 
         hitmask |= (tn0 <= tf0) ? (1u << (2*pr)) : 0u;
         hitmask |= (tn1 <= tf1) ? (2u << (2*pr)) : 0u;
     }
+#endif
     const uint32_t imask = ex >> 24;
     // the records of the hit leaf children: bit s -> bits 4 s .. 4 s + 3, masked by the records that exist
     uint32_t x = hitmask & ~imask;
@@ -1047,7 +1125,7 @@ PT_DEV void walkRestore(const PathState &st, uint32_t slot, WideState &w, uint2 
         if (l + 1 < w.sp) stack[(l + 1)*stride] = make_uint2(e.z, e.w);
     }
 }
-PT_DEV const float4 *wideNodePtr(const DeviceScene &s, uint32_t idx) { return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)(idx*s.wide_stride)); }
+PT_DEV const float4 *wideNodePtr(const DeviceScene &s, uint32_t idx) { return reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)(wideNodeOff(s, idx))); }
 
 // closest hit through the wide BVH, one ray at a time (tghip_trace_rays); the dynamic-fetch kernels run the same machine
 template<bool COUNT, uint32_t KINDS = KINDS_ALL, bool INST = false>
@@ -1066,10 +1144,10 @@ PT_DEV float4 traverseClosestWide(const DeviceScene &s, const RayD &worldRay, ui
         if (what == 0)
             break;
         if (what == 2) {
-            const float4 *n = wideNodePtr(s, idx);
-            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3], q4 = n[4];
+            WideNodeRegs nd;
+            wideNodeFetch(nd, reinterpret_cast<const char *>(s.wide), wideNodeOff(s, idx), wr);
             if (COUNT) nodesVisited++;
-            wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+            wideVisit(w, nd, ray.o, wr, ray.tmin, tmax);
         } else if (what == 1) {
             if (COUNT) primsTested++;
             float4 r0 = at32(s.recs, idx*3u + 0u), r1 = at32(s.recs, idx*3u + 1u), r2 = at32(s.recs, idx*3u + 2u);

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
 #define WIDE_CLOSEST_BOUNDS __launch_bounds__(512)
 #endif
 #ifndef WIDE_SHADOW_BOUNDS
-#define WIDE_SHADOW_BOUNDS SHADOW_DYN_BOUNDS
+#define WIDE_SHADOW_BOUNDS __launch_bounds__(512)
 #endif
 // The end of a loop turn of the two-level (INST) walks, as an instruction of its own.  Without it every path through the turn -- fourteen
 // of them in k_trace_shadow_wide<., ., INST> -- and the edge of the lanes that sit the turn out meet directly in the loop latch (one block
@@ -845,11 +845,12 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                 if (w.tri2Mask == 0u)            // (room for the records of the node visited now)
                     hasNode = wideNextNode(w, wr.octInv, stack, stride, nodeIdx);
             }
-            float4 r0, r1, r2, q0, q1, q2, q3, q4;
+            float4 r0, r1, r2;
+            WideNodeRegs nd;
             if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
             if (hasNode) {
-                if (nodeIdx < topCount) { const float4 *p = reinterpret_cast<const float4 *>(ldsTop + nodeIdx*s.wide_stride); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
-                else                    { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+                if (nodeIdx < topCount) wideNodeFetch(nd, ldsTop, wideNodeOff(s, nodeIdx), wr);
+                else                    wideNodeFetch(nd, reinterpret_cast<const char *>(s.wide), wideNodeOff(s, nodeIdx), wr);
             }
             if (hasRec) {
                 if (COUNT) prims++;
@@ -859,7 +860,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             if (hasNode) {
                 if (COUNT) nodes++;
                 const uint32_t ob = w.triBase, om = w.triMask, ov = w.triValid;
-                wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+                wideVisit(w, nd, ray.o, wr, ray.tmin, tmax);
                 if (om) { w.tri2Base = w.triBase; w.tri2Mask = w.triMask; w.tri2Valid = w.triValid; w.triBase = ob; w.triMask = om; w.triValid = ov; }
             }
             if (busy && wideWalkOver(w)) {       // (in the turn that looked at the walk's last record / node)
@@ -886,9 +887,10 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                 } else if (what == 2) { hasNode = true; nodeIdx = idx; }
                 else finished = true;
             }
-            float4 r0, r1, r2, q0, q1, q2, q3, q4;
+            float4 r0, r1, r2;
+            WideNodeRegs nd;
             if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
-            if (hasNode) { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+            if (hasNode) wideNodeFetch(nd, reinterpret_cast<const char *>(s.wide), wideNodeOff(s, nodeIdx), wr);
             if (hasRec) {
                 if (COUNT) prims++;
                 uint32_t meta;
@@ -896,7 +898,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             }
             if (hasNode) {
                 if (COUNT) nodes++;
-                wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+                wideVisit(w, nd, ray.o, wr, ray.tmin, tmax);
             }
             if (finished) {
                 // publish the hit and bin the path by shading class
@@ -940,13 +942,14 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                 w.curInst = -1;
             } else if (what != 0) {
                 // one address per lane: a node or a record, both behind s.wide
-                const uint32_t off = what != 1 ? idx*s.wide_stride : s.recs_offset + idx*48u;
+                const uint32_t off = what != 1 ? wideNodeOff(s, idx) : s.recs_offset + idx*48u;
                 const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
                 float4 q0 = p[0], q1 = p[1], q2 = p[2];
                 if (what == 2) {
-                    float4 q3 = p[3], q4 = p[4];
+                    WideNodeRegs nd;
+                    wideNodeFetchRest(nd, reinterpret_cast<const char *>(s.wide), off, wr, q0, q1, q2);
                     if (COUNT) nodes++;
-                    wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, tmax);
+                    wideVisit(w, nd, ray.o, wr, ray.tmin, tmax);
                 } else if (INST && what == 4) {
                     wideResumeRecords(w, idx, q1);
                 } else {
@@ -2187,9 +2190,10 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                     }
                 } else if (what == 2) { hasNode = true; nodeIdx = idx; }
                 else walkOver = true;
-                float4 r0, r1, r2, q0, q1, q2, q3, q4;
+                float4 r0, r1, r2;
+            WideNodeRegs nd;
                 if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
-                if (hasNode) { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+                if (hasNode) wideNodeFetch(nd, reinterpret_cast<const char *>(s.wide), wideNodeOff(s, nodeIdx), wr);
                 bool rayDone = false;
                 if (hasRec) {
                     if (COUNT) prims++;
@@ -2201,7 +2205,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                 }
                 if (!rayDone && hasNode) {
                     if (COUNT) nodes++;
-                    wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, ray.tmax);
+                    wideVisit(w, nd, ray.o, wr, ray.tmin, ray.tmax);
                 }
                 if (!rayDone && walkOver) {
                     result = result + contrib;   // nothing in the way: transmittance 1
@@ -2233,15 +2237,16 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                     wr = wideRaySetup(ray);
                     w.curInst = -1;
                 } else {
-                    const uint32_t off = what != 1 ? idx*s.wide_stride : s.recs_offset + idx*48u;
+                    const uint32_t off = what != 1 ? wideNodeOff(s, idx) : s.recs_offset + idx*48u;
                     const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
                     float4 q0 = p[0], q1 = p[1], q2 = p[2];
                     if (what == 2) {
-                        float4 q3 = p[3], q4 = p[4];
+                        WideNodeRegs nd;
+                        wideNodeFetchRest(nd, reinterpret_cast<const char *>(s.wide), off, wr, q0, q1, q2);
                         if (COUNT) nodes++;
                         // (INST: no far distance for the nodes -- what the reference clips against the ray's farT is the box of an instance's
                         // leaf in ITS tree, tested at the record below; the geometry behind it, and so these boxes, may begin beyond farT)
-                        wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, INST ? PT_INF : ray.tmax);
+                        wideVisit(w, nd, ray.o, wr, ray.tmin, INST ? PT_INF : ray.tmax);
                     } else if (INST && what == 4) {
                         wideResumeRecords(w, idx, q1);
                     } else {
@@ -2475,11 +2480,12 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
             }
             if (w.tri2Mask == 0u)
                 hasNode = wideNextNode(w, wr.octInv, stack, stride, nodeIdx);
-            float4 r0, r1, r2, q0, q1, q2, q3, q4;
+            float4 r0, r1, r2;
+            WideNodeRegs nd;
             if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
             if (hasNode) {
-                if (nodeIdx < topCount) { const float4 *p = reinterpret_cast<const float4 *>(ldsTop + nodeIdx*s.wide_stride); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
-                else                    { const float4 *p = wideNodePtr(s, nodeIdx); q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; q4 = p[4]; }
+                if (nodeIdx < topCount) wideNodeFetch(nd, ldsTop, wideNodeOff(s, nodeIdx), wr);
+                else                    wideNodeFetch(nd, reinterpret_cast<const char *>(s.wide), wideNodeOff(s, nodeIdx), wr);
             }
             bool rayDone = false;
             if (hasRec) {
@@ -2493,7 +2499,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
             if (!rayDone && hasNode) {
                 if (COUNT) nodes++;
                 const uint32_t ob = w.triBase, om = w.triMask, ov = w.triValid;
-                wideVisit(w, q0, q1, q2, q3, q4, ray.o, wr, ray.tmin, ray.tmax);
+                wideVisit(w, nd, ray.o, wr, ray.tmin, ray.tmax);
                 if (om) { w.tri2Base = w.triBase; w.tri2Mask = w.triMask; w.tri2Valid = w.triValid; w.triBase = ob; w.triMask = om; w.triValid = ov; }
             }
             if (!rayDone && wideWalkOver(w)) {

@@ -125,7 +125,7 @@ struct tghip_ctx {
     long long tailThreshold = 8192;
     bool instShadowJoin = true;           // "inst_shadow_join": 0 = the instanced wide shadow kernel without PT_TURN_JOIN (the miscompiled variant; repro tool only)
     bool failReduce = false;              // "fail_reduce" option (fault injection for the reduce's callers)
-    int wideStride = 80;                  // "wide_node_stride" option (80 or 128; takes effect at the next upload)
+    int wideStride = int(PT_WIDE_NODE_BYTES);   // bytes per device node: 128 (pt_kernels.h: PT_WIDE_HALF); the byte layout also takes 80 ("wide_node_stride" option, at the next upload)
     uint32_t width = 0, height = 0;
 
     // framebuffer
@@ -889,7 +889,10 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
 #endif
     }
     else if (k == "pool_pad") { ctx->poolPad = std::max<long long>(value, 0)/16*16; ctx->poolMem.release(); ctx->poolSlots = 0; }
-    else if (k == "wide_node_stride") { if (value != 80 && value != 128) { ctx->error = "wide_node_stride is 80 or 128"; return TGHIP_E_INVALID; } ctx->wideStride = int(value); }
+    else if (k == "wide_node_stride") {
+        if (value != 128 && (PT_WIDE_HALF || value != 80)) { ctx->error = PT_WIDE_HALF ? "wide_node_stride is 128 (half-plane nodes)" : "wide_node_stride is 80 or 128"; return TGHIP_E_INVALID; }
+        ctx->wideStride = int(value);
+    }
     else if (k == "wide_closest") { ctx->wideClosestOpt = value < 0 ? -1 : value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "wide_shadow") { ctx->wideShadowOpt = value < 0 ? -1 : value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "wide_bvh") { ctx->wideOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
@@ -947,6 +950,12 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             if (b.sub0 < -1 || b.sub0 >= nb || b.sub1 < -1 || b.sub1 >= nb) return bad("nested bsdf out of range");
         }
         if (sd->camera.medium < -1 || sd->camera.medium >= int32_t(sd->num_media)) return bad("camera medium out of range");
+        // instanced scenes: bvhDepthOf (level 1) and the tight-box upload index recs[] / inst_tight_boxes[] by num_top_recs
+        if (sd->num_instances != 0) {
+            if (sd->num_top_recs == 0 || sd->num_top_recs > sd->num_recs) return bad("num_top_recs out of range for a scene with instances");
+            if (!sd->inst_tight_boxes) return bad("scene with instances without inst_tight_boxes");
+            if (sd->num_inst_prims && !sd->inst_prims) return bad("scene with instances without inst_prims");
+        }
     }
     int depth = bvhDepthOf(sd);
     if (depth < 0 || depth > TGHIP_MAX_BVH_DEPTH) { ctx->error = "malformed or too deep BVH"; return TGHIP_E_INVALID; }
@@ -989,7 +998,32 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             char *p = nullptr;
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&p), nodeBytes + recBytes));
             ctx->sceneMem.allocs.push_back(p);
+#if PT_WIDE_HALF
+            static_assert(sizeof(TgHipWideNode) == 80 && offsetof(TgHipWideNode, qlo) == 32 && offsetof(TgHipWideNode, qhi) == 56, "TgHipWideNode layout");
+            // the device's node: the ABI's header, then the 48 child planes as halfs, one 16-byte row per axis and side (pt_kernels.h)
+            {
+                auto half = [](uint32_t q) -> uint16_t {          // the integer q <= 255 as an IEEE half (exact)
+                    if (q == 0u) return uint16_t(0);
+                    const uint32_t e = 31u - uint32_t(__builtin_clz(q));
+                    return uint16_t(((e + 15u) << 10) | ((q << (10u - e)) & 0x3FFu));
+                };
+                std::vector<unsigned char> dev(size_t(sd->num_wide_nodes)*stride, 0);
+                for (uint32_t i = 0; i < sd->num_wide_nodes; ++i) {
+                    const TgHipWideNode &n = sd->wide_nodes[i];
+                    unsigned char *d = dev.data() + size_t(i)*stride;
+                    std::memcpy(d, &n, 32);
+                    uint16_t *rows = reinterpret_cast<uint16_t *>(d + 32);
+                    for (int a = 0; a < 3; ++a)
+                        for (int sl = 0; sl < 8; ++sl) {
+                            rows[a*8 + sl] = half(n.qlo[a][sl]);
+                            rows[24 + a*8 + sl] = half(n.qhi[a][sl]);
+                        }
+                }
+                HIP_TRY(ctx, hipMemcpy(p, dev.data(), dev.size(), hipMemcpyHostToDevice));
+            }
+#else
             HIP_TRY(ctx, hipMemcpy2DAsync(p, stride, sd->wide_nodes, sizeof(TgHipWideNode), sizeof(TgHipWideNode), sd->num_wide_nodes, hipMemcpyHostToDevice, ctx->stream));
+#endif
             HIP_TRY(ctx, hipMemcpyAsync(p + nodeBytes, sd->recs, size_t(sd->num_recs)*sizeof(TgHipPrimRec), hipMemcpyHostToDevice, ctx->stream));
             s.wide = reinterpret_cast<const float4 *>(p);
             s.recs_offset = uint32_t(nodeBytes);

@@ -2,6 +2,7 @@
 // /root/reference/src/thirdparty/embree/).  Scalar float32 throughout, no contraction (Makefile: -ffp-contract=off).
 #include "EmbreeTopTree.hpp"
 #include <algorithm>
+#include <cstdio>
 #include <cmath>
 #include <limits>
 
@@ -200,21 +201,33 @@ std::vector<TgHipTopNode> buildEmbreeTopTree(const std::vector<TopBox> &boxes)
     std::vector<TgHipTopNode> nodes;
     if (boxes.size() < 2)
         return nodes;
-    std::vector<PrimRef> prims(boxes.size());
+    // An item whose box is not valid is left out -- with its id kept for the others -- as Embree does: the builder's primref pass skips it
+    // (kernels/common/primref_gen: `if (!mesh->valid(j)) continue`), so no leaf is created and no ray ever reaches that primitive.
+    std::vector<PrimRef> prims;
+    prims.reserve(boxes.size());
     Record root;
-    root.pinfo.begin = 0; root.pinfo.end = boxes.size();
     root.pinfo.geom.clear(); root.pinfo.cent.clear();
     for (size_t i = 0; i < boxes.size(); ++i) {
+        bool valid = true;
+        PrimRef p;
         for (int k = 0; k < 3; ++k) {
             const float lo = boxes[i].lo[k], hi = boxes[i].hi[k];
             // AccelSet::valid -> isvalid(bounds) (kernels/common/accelset.h, common/math/bbox.h): lower <= upper, both within +-FLT_LARGE (1.844E18)
             if (!(lo <= hi) || !(lo > -1.844E18f && hi < 1.844E18f))
-                return nodes;
-            prims[i].b.lo[k] = lo; prims[i].b.hi[k] = hi;
+                valid = false;
+            p.b.lo[k] = lo; p.b.hi[k] = hi;
         }
-        prims[i].id = uint32_t(i);
-        addTo(root.pinfo.geom, root.pinfo.cent, prims[i]);
+        if (!valid)
+            continue;
+        p.id = uint32_t(i);
+        prims.push_back(p);
+        addTo(root.pinfo.geom, root.pinfo.cent, p);
     }
+    // (fewer than two valid items: no tree -- the device walks the plain record list, which differs from Embree only in that the left-out
+    // primitive is still tested; its bounds are NaN or beyond 1.8e18, so is its geometry)
+    if (prims.size() < 2)
+        return nodes;
+    root.pinfo.begin = 0; root.pinfo.end = prims.size();
     root.split = findSplit(prims, root.pinfo);
     recurse(prims, root, nodes);
     return nodes;
@@ -243,10 +256,21 @@ std::vector<TgHipTopNode> buildSceneTopTree(const TgHipObject *objects, uint32_t
         itemRec.push_back(uint32_t(recOf[o]));
     }
     std::vector<TgHipTopNode> nodes = buildEmbreeTopTree(boxes);
+    size_t leaves = 0;
     for (TgHipTopNode &n : nodes)
         for (int i = 0; i < 4; ++i)
-            if (n.child[i] < 0)
+            if (n.child[i] < 0) {
                 n.child[i] = ~int32_t(itemRec[size_t(~n.child[i])]);
+                ++leaves;
+            }
+    if (!nodes.empty() && leaves != boxes.size()) {
+        // an item with invalid bounds (NaN, or beyond 1.8e18): Embree leaves it out of its tree, so the reference never intersects it.  The
+        // device's ordered walk wants every record in one leaf (tghip_upload_scene), so such a scene is walked as a plain list -- said aloud,
+        // because coincident faces may then resolve differently from the reference
+        std::fprintf(stderr, "path_tracer_hip: %zu of %zu primitives have invalid bounds; the scene is walked as a plain list, not in the reference's tree order\n",
+                     boxes.size() - leaves, boxes.size());
+        return none;
+    }
     return nodes;
 }
 

@@ -760,8 +760,10 @@ void TraceableScene::flatten()
     _desc.wide_nodes = _wideNodes.empty() ? nullptr : _wideNodes.data();
     _desc.num_wide_nodes = uint32_t(_wideNodes.size());
     // the reference's top-level Embree tree, for flat lists of analytic primitives (EmbreeTopTree.hpp): the visiting order where faces coincide
+    // (renderer.scene_bvh = false: the reference commits no Embree scene and asks its finite primitives one after the other, in scene order,
+    // renderer/TraceableScene.hpp:175-181 -- the plain record list, no tree)
     _topNodes.clear();
-    if (_instPrims.empty())
+    if (_instPrims.empty() && _scene.renderer.useSceneBvh)
         _topNodes = buildSceneTopTree(_objects.data(), uint32_t(_objects.size()), _recs.data(), uint32_t(_recs.size()));
     _desc.top_nodes = _topNodes.empty() ? nullptr : _topNodes.data();
     _desc.num_top_nodes = uint32_t(_topNodes.size());
