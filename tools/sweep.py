@@ -31,7 +31,7 @@ def main():
     spp = a.spp or (256 if a.scene in ("materialtest", "cornell") else 32)
     ba = argparse.Namespace(gpus=1, steps=a.steps, warmup=a.warmup, scene=a.scene, material=a.material, res="%dx%d" % (w, h), spp=spp,
                             no_cpu_baseline=True, no_extra=True, no_kernel_timing=False, cpu_seconds=0.0, traffic=False, opt=[],
-                            emulate_shards=a.emulate_shards, count_spp=0)
+                            emulate_shards=a.emulate_shards, count_spp=0, exclusive=False)
     b = bench.Bench(ba)
     b.shared_ctx = b.tg.lib.tghip_create(0)      # one context for every option set (options persist: name every swept key in every set)
     try:

@@ -1333,6 +1333,11 @@ PT_DEV bool bsdfSample(const DeviceScene &s, int bi, Event &e)
 // ---------------------------------------------------------------------------------------------
 struct RayD { f3 o, d; float tmin, tmax; };
 
+/* PROVENANCE of the next ~80 lines (dotEmbree, rcpEmbree, the slab test, triangleEmbree) and of pt_kernels.h's flatOrderedWalk: they restate the
+ * ARITHMETIC of Embree 2.11 as the reference vendors it (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h,
+ * kernels/bvh/bvh_intersector_node.h, bvh_traverser1.h, common/simd/sse.h: rcp) operation by operation, because the reference's hit distances
+ * and visiting order are functions of exactly those roundings.  Embree: Copyright 2009-2016 Intel Corporation, Apache License 2.0
+ * (http://www.apache.org/licenses/LICENSE-2.0); derived work distributed under the same terms, "AS IS", without warranties of any kind. */
 /* Embree's arithmetic in its triangle test, bit for bit (oracle/oracle.c: intel_rcpps / embree_rcp / edot has the derivation): the dot product
  * associates from the right (common/math/vec3.h:182), and t / u / v are PRODUCTS with rcp(absDen) = r*(2 - r*a), r = RCPPS(a) -- the Intel
  * instruction's estimate: 2^25/(4097 + 2 i) rounded to an integer for the operand's top 11 mantissa bits i, the operand's exponent negated

@@ -1,3 +1,10 @@
+// PROVENANCE.  This file is a scalar RE-DERIVATION of Embree 2.11's binned-SAH BVH4 builder for user geometry (as vendored by the reference:
+// src/thirdparty/embree/kernels/builders/heuristic_binning.h, heuristic_binning_array_aligned.h, bvh_builder_sah.h, priminfo.h,
+// kernels/common/accelset.h).  It exists because the ORDER in which a ray visits that tree decides which of two coincident faces the reference
+// hits (include/tungsten_hip.h: TgHipTopNode): bit-parity needs the same tree, so the arithmetic and the tie-breaking of the original are
+// followed step by step (in scalar float32 instead of SSE lanes).  Embree is Copyright 2009-2016 Intel Corporation, licensed under the Apache
+// License, Version 2.0 (http://www.apache.org/licenses/LICENSE-2.0); this derived restatement is distributed under the same terms, "AS IS",
+// WITHOUT WARRANTIES OR CONDITIONS OF ANY KIND.  It is checked against trees read out of the reference's own Embree (tests/test_top_tree.py).
 // Embree 2.11's BVH4 builder for user geometry, restated (see EmbreeTopTree.hpp for what and why; citations are paths under
 // /root/reference/src/thirdparty/embree/).  Scalar float32 throughout, no contraction (Makefile: -ffp-contract=off).
 #include "EmbreeTopTree.hpp"

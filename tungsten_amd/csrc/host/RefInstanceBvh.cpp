@@ -1,3 +1,19 @@
+// PROVENANCE.  This file is a RESTATEMENT of reference code, not an independent design: it rebuilds, node for node, the binary BVH that
+// Tungsten's `Instance` primitive builds over its instances (src/core/bvh/BvhBuilder.cpp, FullSahSplitter.hpp, BinnedSahSplitter.hpp,
+// BinaryBvh.hpp), because `Instance::intersect` answers "the LAST hit in THAT tree's visiting order" (src/core/primitives/Instance.cpp:290-311):
+// the tree is part of the arithmetic of the path, and bit-parity with the reference needs the same tree.  Function and variable names follow the
+// reference so that the two can be read side by side.  It is an altered version of that code, plainly marked as such, under its licence:
+//
+//   Tungsten -- Copyright (c) 2014 Benedikt Bitterli <benedikt.bitterli (at) gmail (dot) com>
+//   This software is provided 'as-is', without any express or implied warranty.  In no event will the authors be held liable for any damages
+//   arising from the use of this software.  Permission is granted to anyone to use this software for any purpose, including commercial
+//   applications, and to alter it and redistribute it freely, subject to the following restrictions:
+//     1. The origin of this software must not be misrepresented; you must not claim that you wrote the original software.  If you use this
+//        software in a product, an acknowledgment in the product documentation would be appreciated but is not required.
+//     2. Altered source versions must be plainly marked as such, and must not be misrepresented as being the original software.
+//     3. This notice may not be removed or altered from any source distribution.
+//
+// The pattern is confined to this file and EmbreeTopTree.cpp (set-up code on the host, nothing on the hot path) and is not meant to grow.
 #include "RefInstanceBvh.hpp"
 
 #include <algorithm>
