@@ -691,7 +691,9 @@ static void chooseThreads(tghip_ctx *ctx)
         //  320/256/128/128 556, 256/320/128/128 549, 256/256/256/128 646, 256/256/128/64 623; 4 per CU with 192/256/192/128: 608)
         ctx->thrClosest = pairedInst ? 192 : 256;
         if (!ctx->haveForward && !ctx->haveMeshLight) ctx->thrShadow = 256;
-        ctx->thrShadeSimple = ctx->thrShadeComplex = 128;
+        // (round 5, the same sweep at today's kernels: 128/128 965, 192/192 967, 256/256 979 Msamples/s, three rounds A B C in one session,
+        // profiles/r5_sweep_shade_threads.jsonl -- k_shade's 26 KB of LDS per workgroup then serve four waves instead of two)
+        ctx->thrShadeSimple = ctx->thrShadeComplex = pairedInst ? 128 : 256;
     }
     }
     ctx->thrShadeAll = flat && ctx->blocksPerCuOpt == 0 ? 256 : pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
