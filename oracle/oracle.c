@@ -16,7 +16,7 @@
  * check this file against them.  See DESIGN.md "Oracle".  State at the end of round 4: the per-sample radiance is the reference's bit for bit
  * (float32 ==, three channels) in every one of the 67 golden cases, 601 344 samples, and in the 13 lifted twins; the per-pass records of the
  * reference's own integrator loop and its five output buffers likewise (tests/test_oracle_golden.py, test_adaptive_cpu.py, test_outputs_cpu.py).
- * Two paths in here are prototypes for a next round and off in every test of the device: oracle_set_top_items, flat_shortcut_decides_v2.
+ * Two paths in here are test-side prototypes and off in every test of the device: oracle_set_top_items, flat_shortcut_decides_v2.
  *
  * Numerics: float everywhere, the reference's constants (PI = 3.1415926536f, math/Angle.hpp:8),
  * same operation order where it matters; compiled with -ffp-contract=off.
@@ -4126,26 +4126,36 @@ static int top_leaf_box(const TgHipSceneDesc *s, int32_t rec, v3 *lo, v3 *hi)
             if (s->top_nodes[n].child[i] == ~rec) { *lo = ld3(s->top_nodes[n].lower[i]); *hi = ld3(s->top_nodes[n].upper[i]); return 1; }
     return 0;
 }
-/* 1: the shortcut decides, *got = its answer (rec < 0: nothing hit); 0: the device walks the tree */
+/* 1: the shortcut decides, *got = its answer (rec < 0: nothing hit); 0: the device walks the tree.
+ * Round 5 (pt_kernels.h: flatClosestOrdered): no slab test inside the loop.  The loop keeps the nearest hit b (the first of equal ones), the
+ * distance t2 of the second nearest hit whatever its box -- a lower bound of the second nearest hit the walk can reach: the rule only gets stricter
+ * --, the number of records hit and whether a hit's distance is NaN; ONE slab test afterwards, of b's leaf box. */
 static int flat_shortcut_decides(const TgHipSceneDesc *s, const Ray *rayIn, Hit *got)
 {
     Ray ray = *rayIn;
     got->rec = -1; got->inst = -1; got->t = ray.tmax; got->u = got->v = 0.0f;
-    float tb = INFINITY, t2 = INFINITY, entryB = 0.0f;
+    float tb = INFINITY, t2 = INFINITY;
+    uint32_t count = 0; int unordered = 0;
     for (uint32_t i = 0; i < s->num_recs; ++i) {
         Hit h; float tm = ray.tmax;
         h.rec = -1; h.inst = -1; h.t = tm; h.u = h.v = 0.0f;
         test_rec(s, i, &ray, &tm, &h, NULL, -1, -1);
-        v3 lo, hi; float entry;
-        if (h.rec >= 0 && top_leaf_box(s, (int32_t)i, &lo, &hi) && embree_box_near(&ray, lo, hi, &entry)) {
-            if (h.t < tb) { t2 = tb; tb = h.t; *got = h; entryB = entry; }
-            else t2 = fminf(t2, h.t);
-        }
+        if (h.rec < 0) continue;
+        if (h.t != h.t) unordered = 1;
+        count++;
+        if (h.t < tb) { t2 = tb; tb = h.t; *got = h; }
+        else t2 = fminf(t2, h.t);
     }
-    return got->rec < 0 || (tb < t2 && entryB <= t2);
+    if (unordered) return 0;
+    if (count == 0) return 1;
+    v3 lo, hi; float entry;
+    if (top_leaf_box(s, got->rec, &lo, &hi) && embree_box_near(&ray, lo, hi, &entry))
+        return tb < t2 && entry <= t2;
+    if (count == 1) { got->rec = -1; got->inst = -1; got->t = ray.tmax; got->u = got->v = 0.0f; return 1; }
+    return 0;
 }
-/* A cheaper formulation of the same shortcut, for the next round (the slab test out of the per-record loop; no device
- * counterpart yet): the loop keeps the THREE nearest hits, boxes or not; afterwards b = the first of them whose box the ray passes, and the second
+/* Another formulation of the same idea (round 4's sketch; the device runs the rule above, which keeps ONE hit and decides a subset of what this
+ * one decides): the loop keeps the THREE nearest hits, boxes or not; afterwards b = the first of them whose box the ray passes, and the second
  * nearest distance is bounded from below by the next stored hit, or by the third when more than three were hit (every hit not stored lies behind
  * it).  A lower bound only makes the rule stricter: decided rays stay right, a few more walk. */
 static int flat_shortcut_decides_v2(const TgHipSceneDesc *s, const Ray *rayIn, Hit *got)

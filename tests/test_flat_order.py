@@ -96,20 +96,22 @@ def test_device_formulation_is_the_walk(name, tmp_path):
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_cheaper_shortcut_sketched_for_the_next_round_is_the_walk_too(name, tmp_path):
-    """the slab test out of the per-record loop -- keep the three nearest hits, test boxes afterwards, bound the second nearest
-    distance from below.  Test side only (oracle.c: flat_shortcut_decides_v2): its decided answers are the walk's on the tie-made rays, and it leaves
-    only a few more rays to the walk than the shortcut the device runs.  (Writing it found what a NaN distance does to a sorted list: a ray IN a
-    disk's plane makes Disk::intersect divide 0 by 0 and accept the result, in the reference too; such a hit cannot be ordered and goes to the walk.)"""
+def test_three_hit_formulation_is_the_walk_too_and_decides_what_the_device_decides(name, tmp_path):
+    """the slab test out of the per-record loop.  Round 4 sketched it keeping the THREE nearest hits (oracle.c:
+    flat_shortcut_decides_v2); the device (round 5) keeps ONE hit and the second nearest distance, which decides a subset of what the sketch
+    decides -- both are held to the walk on the tie-made rays, and the device's form leaves only a few more rays to the walk.  (Writing the sketch
+    found what a NaN distance does: a ray IN a disk's plane makes Disk::intersect divide 0 by 0 and accept the result, in the reference too; such
+    a hit cannot be ordered and goes to the walk, in both forms.)"""
     mk, kw = CASES[name]
     flat = tg.FlattenedScene(mk(tmp_path, **dict(kw, resolution=(16, 9), spp=1)))
     rays = tie_rays(flat.desc)
-    _, decided1, _ = oracle_lib.flat_device_form(flat.desc, rays)
-    decided2, differing = oracle_lib.flat_device_form2(flat.desc, rays)
+    _, decided_dev, differing_dev = oracle_lib.flat_device_form(flat.desc, rays)
+    decided3, differing3 = oracle_lib.flat_device_form2(flat.desc, rays)
     flat.close()
-    assert differing == 0
-    assert not (decided2 & ~decided1).any()                      # stricter, never laxer
-    assert (~decided2).sum() <= 1.6*(~decided1).sum() + 10
+    assert differing_dev == 0 and differing3 == 0
+    assert not (decided_dev & ~decided3).any()                   # the device's rule is the stricter one
+    assert (~decided_dev).sum() <= 1.6*(~decided3).sum() + 10
+    print(name, len(rays), "rays: the device's form walks", int((~decided_dev).sum()), ", the three-hit form", int((~decided3).sum()))
 
 
 @pytest.mark.gpu

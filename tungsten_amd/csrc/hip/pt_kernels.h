@@ -701,27 +701,44 @@ __device__ __attribute__((noinline)) float4 flatOrderedWalk(const float *topNode
 template<bool COUNT, uint32_t KINDS>
 PT_DEV float4 flatClosestOrdered(const DeviceScene &s, const RayD &ray, uint32_t &primsTested)
 {
+    // Round 5: the slab test is out of the per-record loop.  The loop keeps the nearest hit b (the first of equal ones), the distance t2 of the
+    // second nearest hit -- whatever the boxes say: a lower bound of the second nearest hit the walk can reach, which only makes the rule
+    // stricter --, the number of records hit, and whether a hit has a NaN distance (a ray IN a disk's plane: Disk::intersect divides 0 by 0 and
+    // accepts it, as the reference does; such a hit cannot be ordered).  ONE slab test afterwards, of b's leaf box:
+    //   nothing hit                          -> nothing
+    //   b's box passed, entered at `entry`   -> b when t_b < t2 strictly and entry <= t2 (the argument of DESIGN.md 4f), else the walk
+    //   b's box missed                       -> nothing when b is the only record hit (the walk cannot reach it); else the walk
+    //   a NaN distance                       -> the walk
+    // (oracle.c: flat_shortcut_decides_v3 is this rule; tests/test_flat_order.py holds it to the walk on rays made to tie)
     const uint32_t n = s.num_recs;
     float4 hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
-    float tb = PT_INF, t2 = PT_INF, entryB = 0.0f;
-    const EmbreeRay e = embreeRay(ray);
+    float tb = PT_INF, t2 = PT_INF;
+    uint32_t count = 0;
+    bool unordered = false;
     for (uint32_t i = 0; i < n; ++i) {
         float tm = ray.tmax;
         float4 h;
         uint32_t meta;
         if (testRecord<true, KINDS>(s, i, ray, tm, h, meta)) {
-            const PT_CONST_AS float *b = asConst(reinterpret_cast<const float *>(s.flat_boxes)) + 8u*i;     // (uniform: scalar loads)
-            const float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[4], b[5], b[6]};
-            float entry;
-            if (embreeLeafEntry(e, lo, hi, entry)) {
-                const bool nearer = h.x < tb;
-                t2 = nearer ? tb : fminf(t2, h.x);
-                if (nearer) { tb = h.x; hit = h; entryB = entry; }
-            }
+            unordered = unordered || h.x != h.x;
+            count++;
+            const bool nearer = h.x < tb;
+            t2 = nearer ? tb : fminf(t2, h.x);
+            if (nearer) { tb = h.x; hit = h; }
         }
     }
     if (COUNT) primsTested += n;
-    if (__float_as_int(hit.w) >= 0 && !(tb < t2 && entryB <= t2))
+    bool walk = unordered;
+    if (count != 0u && !walk) {
+        const float4 blo = s.flat_boxes[2*__float_as_int(hit.w)], bhi = s.flat_boxes[2*__float_as_int(hit.w) + 1];   // (per lane: b differs)
+        const float lo[3] = {blo.x, blo.y, blo.z}, hi[3] = {bhi.x, bhi.y, bhi.z};
+        const EmbreeRay e = embreeRay(ray);
+        float entry;
+        if (embreeLeafEntry(e, lo, hi, entry)) walk = !(tb < t2 && entry <= t2);
+        else if (count == 1u) hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
+        else walk = true;
+    }
+    if (walk)
         hit = flatOrderedWalk<KINDS>(s.top_nodes, s.recs, s.objects, ray.o.x, ray.o.y, ray.o.z, ray.tmin, ray.d.x, ray.d.y, ray.d.z, ray.tmax);
     return hit;
 }

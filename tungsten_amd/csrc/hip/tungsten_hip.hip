@@ -94,6 +94,8 @@ struct tghip_ctx {
     int classStreamsOpt = 0;              // measured: 735-800 Msamples/s against 825-830 with the classes one after the other on the part's stream
     hipStream_t launchStream = nullptr;   // where the launch helpers put their kernels (stream, or the stream of the part being launched)
     hipEvent_t evPart[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, evMain = nullptr;
+    hipEvent_t evRot[8] = {};             // "rotate_streams": the end of a part's last iteration (the part's next one runs on another stream)
+    bool rotateStreamsOpt = false;        // "rotate_streams" option (runBatch)
     int streamsOpt = 0;                   // "streams": 1 .. 4 parts of the pool on as many streams, 0 = the measured default (four for single-level
                                           // BVH scenes; instanced scenes lose 2.5 % with two)
     hipDeviceProp_t prop;
@@ -691,9 +693,13 @@ static void chooseThreads(tghip_ctx *ctx)
         //  320/256/128/128 556, 256/320/128/128 549, 256/256/256/128 646, 256/256/128/64 623; 4 per CU with 192/256/192/128: 608)
         ctx->thrClosest = pairedInst ? 192 : 256;
         if (!ctx->haveForward && !ctx->haveMeshLight) ctx->thrShadow = 256;
-        // (round 5, the same sweep at today's kernels: 128/128 965, 192/192 967, 256/256 979 Msamples/s, three rounds A B C in one session,
-        // profiles/r5_sweep_shade_threads.jsonl -- k_shade's 26 KB of LDS per workgroup then serve four waves instead of two)
-        ctx->thrShadeSimple = ctx->thrShadeComplex = pairedInst ? 128 : 256;
+        ctx->thrShadeSimple = ctx->thrShadeComplex = 128;
+        // (round 5, the same sweep at today's kernels, three rounds A B C in one session, profiles/r5_sweep_shade_threads.jsonl: materialtest
+        // 128/128 965, 192/192 967, 256/256 979 Msamples/s -- k_shade's 26 KB of LDS per workgroup then serve four waves instead of two --, but
+        // mesh1m 604 -> 597, materialtest with a rough dielectric 453 -> 451 / 431, with a dielectric 480 -> 480: 256 threads only for what it
+        // was measured to help, a small tree with the conductor family as its only other shading class)
+        if (!pairedInst && ctx->numWideNodes <= 32768u && ctx->classPresent[1] && !ctx->classPresent[2] && !ctx->classPresent[3])
+            ctx->thrShadeSimple = ctx->thrShadeComplex = 256;
     }
     }
     ctx->thrShadeAll = flat && ctx->blocksPerCuOpt == 0 ? 256 : pickThreads(ctx, k_shade<BSDF_MASK_ALL, 2, 0>, 256, 0);
@@ -754,6 +760,7 @@ tghip_ctx *tghip_create(int device_ordinal)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evPart[k], hipEventDisableTiming);
     for (int k = 0; k < 8; ++k) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evFork[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evRot[k], hipEventDisableTiming);
         for (int a = 0; a < 2; ++a)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->evJoin[k][a], hipEventDisableTiming);
     }
@@ -810,6 +817,7 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->evMain) (void)hipEventDestroy(ctx->evMain);
     for (int k = 0; k < 8; ++k) {
         if (ctx->evFork[k]) (void)hipEventDestroy(ctx->evFork[k]);
+        if (ctx->evRot[k]) (void)hipEventDestroy(ctx->evRot[k]);
         for (int a = 0; a < 2; ++a) {
             if (ctx->evJoin[k][a]) (void)hipEventDestroy(ctx->evJoin[k][a]);
             if (ctx->classStream[k][a]) (void)hipStreamDestroy(ctx->classStream[k][a]);
@@ -875,6 +883,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "fail_reduce") ctx->failReduce = value != 0;   // fault injection: tghip_reduce_framebuffers with this context as a rank fails (the hosts' fallbacks are tested with it)
     else if (k == "tail_kernel") ctx->tailOpt = value != 0;
     else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
+    else if (k == "rotate_streams") ctx->rotateStreamsOpt = value != 0;
     else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
     else if (k == "top_tree") ctx->topTreeOpt = value != 0;
     else if (k == "media_lean") ctx->mediaLeanOpt = value != 0;
@@ -1630,9 +1639,11 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 hipLaunchKernelGGL(k_finish, dim3(grid), dim3(256), 0, ctx->launchStream, s, st, pp, iterTag);
         };
         // folded k_finish: the last iteration's finish as a launch of its own -- before the host reads the liveness word, before k_tail
+        int partStream[8] = {0, 1, 2, 3, 4, 5, 6, 7};   // the stream a part's last iteration ran on ("rotate_streams")
+        bool partRan[8] = {false, false, false, false, false, false, false, false};
         auto finishParts = [&](uint32_t tag) {
             for (int k = 0; k < parts; ++k)
-                hipLaunchKernelGGL(k_finish, dim3(grid/parts), dim3(256), 0, split ? streamOf[k] : ctx->stream, s, split ? stPart[k] : st, split ? ppPart[k] : pp, tag);
+                hipLaunchKernelGGL(k_finish, dim3(grid/parts), dim3(256), 0, split ? streamOf[partStream[k]] : ctx->stream, s, split ? stPart[k] : st, split ? ppPart[k] : pp, tag);
         };
     for (;;) {
         evUsed = 0;
@@ -1720,9 +1731,18 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 continue;
             }
             if (split) {
+                // "rotate_streams": part k's iteration i runs on stream (k + i) mod parts.  The hardware queues do not share the chip evenly --
+                // the parts on the queues served later run ~45 % longer launches (profiles/README.md: "by hardware queue") and finish their
+                // share of the work items last --; rotated, every part spends the same time on every queue.
                 for (int k = 0; k < parts; ++k) {
-                    ctx->launchStream = streamOf[k];
+                    const int sIdx = ctx->rotateStreamsOpt ? int((uint32_t(k) + iterTag) % uint32_t(parts)) : k;
+                    ctx->launchStream = streamOf[sIdx];
+                    if (ctx->rotateStreamsOpt) {
+                        if (partRan[k]) (void)hipStreamWaitEvent(ctx->launchStream, ctx->evRot[k], 0);    // the part's previous iteration, on another stream
+                        partStream[k] = sIdx;
+                    }
                     launchIteration(stPart[k], ppPart[k], grid/parts, iterTag, true, k);
+                    if (ctx->rotateStreamsOpt) { (void)hipEventRecord(ctx->evRot[k], ctx->launchStream); partRan[k] = true; }
                 }
                 ctx->launchStream = ctx->stream;
             } else {
