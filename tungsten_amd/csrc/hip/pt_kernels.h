@@ -709,11 +709,11 @@ PT_DEV float4 flatClosestOrdered(const DeviceScene &s, const RayD &ray, uint32_t
     //   b's box passed, entered at `entry`   -> b when t_b < t2 strictly and entry <= t2 (the argument of DESIGN.md 4f), else the walk
     //   b's box missed                       -> nothing when b is the only record hit (the walk cannot reach it); else the walk
     //   a NaN distance                       -> the walk
-    // (oracle.c: flat_shortcut_decides_v3 is this rule; tests/test_flat_order.py holds it to the walk on rays made to tie)
+    // (oracle.c: flat_shortcut_decides is this rule; tests/test_flat_order.py holds it to the walk on rays made to tie.  The number of records
+    // hit is not counted: none <=> no hit kept, one <=> t2 still infinite -- a hit at a NaN distance leaves t2 alone, but then the lane walks)
     const uint32_t n = s.num_recs;
     float4 hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
     float tb = PT_INF, t2 = PT_INF;
-    uint32_t count = 0;
     bool unordered = false;
     for (uint32_t i = 0; i < n; ++i) {
         float tm = ray.tmax;
@@ -721,7 +721,6 @@ PT_DEV float4 flatClosestOrdered(const DeviceScene &s, const RayD &ray, uint32_t
         uint32_t meta;
         if (testRecord<true, KINDS>(s, i, ray, tm, h, meta)) {
             unordered = unordered || h.x != h.x;
-            count++;
             const bool nearer = h.x < tb;
             t2 = nearer ? tb : fminf(t2, h.x);
             if (nearer) { tb = h.x; hit = h; }
@@ -729,13 +728,15 @@ PT_DEV float4 flatClosestOrdered(const DeviceScene &s, const RayD &ray, uint32_t
     }
     if (COUNT) primsTested += n;
     bool walk = unordered;
-    if (count != 0u && !walk) {
-        const float4 blo = s.flat_boxes[2*__float_as_int(hit.w)], bhi = s.flat_boxes[2*__float_as_int(hit.w) + 1];   // (per lane: b differs)
+    if (__float_as_int(hit.w) >= 0 && !walk) {
+        // (b's box is gathered per lane here; carrying it along from the record's uniform load inside the loop was measured slower -- six more
+        // v_mov per record some lane hits, in a kernel that is bound by what it issues: 2 392 against 2 498 Msamples/s, profiles/r5_ab_flat_shortcut.txt)
+        const float4 blo = s.flat_boxes[2*__float_as_int(hit.w)], bhi = s.flat_boxes[2*__float_as_int(hit.w) + 1];
         const float lo[3] = {blo.x, blo.y, blo.z}, hi[3] = {bhi.x, bhi.y, bhi.z};
         const EmbreeRay e = embreeRay(ray);
         float entry;
         if (embreeLeafEntry(e, lo, hi, entry)) walk = !(tb < t2 && entry <= t2);
-        else if (count == 1u) hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
+        else if (t2 == PT_INF) hit = make_float4(ray.tmax, 0.0f, 0.0f, __int_as_float(-1));
         else walk = true;
     }
     if (walk)
