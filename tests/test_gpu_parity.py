@@ -675,3 +675,26 @@ def test_several_contexts_driven_by_host_threads_on_one_device(scene, adaptive, 
     if adaptive:
         assert count.min() < count.max()                 # (the pass scheduler really moved samples)
     assert (mean == base).all()
+
+
+def test_upload_refuses_instance_descriptors_with_a_bad_top_record_count(tmp_path):
+    """A scene with instances indexes recs[] and inst_tight_boxes[] by num_top_recs (tghip_upload_scene: the instance trees' leaves, the tight-box
+    upload): a count of 0 or beyond num_recs, or missing tight boxes, is refused with TGHIP_E_INVALID before anything is dereferenced."""
+    import ctypes as C
+    mk, kw = scenes.GOLDEN_CASES["cornell_instances"]
+    flat = tg.FlattenedScene(mk(tmp_path, **dict(kw, resolution=(32, 18), spp=1)))
+    d = flat.desc.contents
+    assert d.num_instances > 0 and 0 < d.num_top_recs <= d.num_recs
+    ctx = tg.lib.tghip_create(0)
+    assert ctx
+    assert tg.lib.tghip_upload_scene(ctx, flat.desc) == 0
+    for field, value in (("num_top_recs", 0), ("num_top_recs", d.num_recs + 1), ("inst_tight_boxes", None)):
+        bad = tg.TgHipSceneDesc.from_buffer_copy(d)
+        if value is None:
+            bad.inst_tight_boxes = C.cast(None, type(bad.inst_tight_boxes))
+        else:
+            setattr(bad, field, value)
+        assert tg.lib.tghip_upload_scene(ctx, C.byref(bad)) == -1, (field, value)
+        assert b"malformed scene description" in tg.lib.tghip_last_error(ctx)
+    tg.lib.tghip_destroy(ctx)
+    flat.close()
