@@ -59,10 +59,11 @@ def main():
     ap.add_argument("--json")
     ap.add_argument("--diff")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--objdir", default=os.path.join(ROOT, "build", "obj"), help="directory of the object files (an experiment's build/obj_<variant>)")
     a = ap.parse_args()
     table = {}
     with tempfile.TemporaryDirectory() as tmp:
-        for obj in sorted(glob.glob(os.path.join(ROOT, "build", "obj", "*.o"))):
+        for obj in sorted(glob.glob(os.path.join(a.objdir, "*.o"))):
             for k, v in kernels_of(obj, tmp).items():
                 table[os.path.basename(obj) + ": " + k] = v
     if a.json:

@@ -1096,7 +1096,13 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
     const DeviceScene s = STAGED ? sg : stageSceneTables(sg, ldsTables);
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
+    // PT_EXP_HALF (a compile-only diagnostic, never the product): 1 = the kernel without the continuation sample, 2 = without next-event
+    // estimation -- the register demand of the two halves a split shading stage would consist of (profiles/r5_shade_split_halves.txt)
+#if defined(PT_EXP_HALF) && PT_EXP_HALF == 2
+    const bool nee = false;
+#else
     const bool nee = s.settings.enable_light_sampling != 0;
+#endif
     uint32_t finishedCount = 0, fusedClosest = 0, fusedShadow = 0, fusedPrims = 0, fusedNodes = 0;
     PROF_DECL;
 
@@ -1539,7 +1545,11 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                     // continuation: bsdf.sample(event, adjoint = false) with all lobes (TraceBase.cpp:546-558)
                     ev.requested = LOBE_ALL;
                     ev.weight = splat3(1.0f); ev.pdf = 1.0f;
+#if defined(PT_EXP_HALF) && PT_EXP_HALF == 1
+                    if (true) {
+#else
                     if (!bsdfSample<M>(s, info.bsdf, ev)) {
+#endif
                         alive = false;
                     } else {
                         wo = toGlobal(frame, ev.wo);
