@@ -186,6 +186,38 @@ PT_DEV uint32_t slotOffset(const PathState &st, uint32_t a, uint32_t slot)     /
     return (a & ((1u << PT_POOL_GROUP_SHIFT) - 1u))*st.stride + slot*16u;
 }
 PT_DEV char *slotBase(const PathState &st, uint32_t a) { return PT_RECORDS(st) ? st.poolg[0] : st.poolg[a >> PT_POOL_GROUP_SHIFT]; }
+// PT_NT_STATE (bit 0: loads, bit 1: stores, bit 2: the work items' partial sums and the samples' luminances too): the 16-byte accesses to the
+// path pool carry the non-temporal hint (global_load / global_store ... nt).  A slot's state is written by one launch and read by the next,
+// megabytes of other slots later; written as ordinary stores it is allocated in L2 on its way out and evicts the records, the attributes
+// and the textures that the walks and the shading gathers do hit in.  Measured (profiles/r5_ab_nt_state.txt, two boxes, alternated):
+// stores +5.2 % / +5.8 % on the metric's workload, +4 % on mesh1m, +13 % as shipped; LOADS -1 % alone and -3.5 % next to the stores (a slot's
+// 16 bytes share their 128-byte line with the neighbouring slots other waves read, and a non-temporal load does not keep the line in L1).
+// Hence 6: stores only.  The values moved are the same either way; 0 gives the plain references back.
+#ifndef PT_NT_STATE
+#define PT_NT_STATE 6
+#endif
+#if PT_NT_STATE
+typedef float    PtF4v __attribute__((ext_vector_type(4)));
+typedef uint32_t PtU4v __attribute__((ext_vector_type(4)));
+struct SlotF4Ref {
+    PtF4v *p;
+    PT_DEV operator float4() const { const PtF4v v = (PT_NT_STATE & 1) ? __builtin_nontemporal_load(p) : *p; return make_float4(v.x, v.y, v.z, v.w); }
+    PT_DEV const SlotF4Ref &operator=(float4 v) const { PtF4v t = {v.x, v.y, v.z, v.w}; if (PT_NT_STATE & 2) __builtin_nontemporal_store(t, p); else *p = t; return *this; }
+};
+struct SlotU4Ref {
+    PtU4v *p;
+    PT_DEV operator uint4() const { const PtU4v v = (PT_NT_STATE & 1) ? __builtin_nontemporal_load(p) : *p; return make_uint4(v.x, v.y, v.z, v.w); }
+    PT_DEV const SlotU4Ref &operator=(uint4 v) const { PtU4v t = {v.x, v.y, v.z, v.w}; if (PT_NT_STATE & 2) __builtin_nontemporal_store(t, p); else *p = t; return *this; }
+};
+PT_DEV SlotF4Ref slotF4(const PathState &st, uint32_t a, uint32_t slot)
+{
+    return SlotF4Ref{reinterpret_cast<PtF4v *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot))};
+}
+PT_DEV SlotU4Ref slotU4(const PathState &st, uint32_t a, uint32_t slot)
+{
+    return SlotU4Ref{reinterpret_cast<PtU4v *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot))};
+}
+#else
 PT_DEV float4 &slotF4(const PathState &st, uint32_t a, uint32_t slot)
 {
     return *reinterpret_cast<float4 *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot));
@@ -193,6 +225,16 @@ PT_DEV float4 &slotF4(const PathState &st, uint32_t a, uint32_t slot)
 PT_DEV uint4 &slotU4(const PathState &st, uint32_t a, uint32_t slot)
 {
     return *reinterpret_cast<uint4 *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot));
+}
+#endif
+// one 32-bit word of a slot's 16 bytes (the few places that touch less than the whole vector)
+PT_DEV float &slotW(const PathState &st, uint32_t a, uint32_t slot, uint32_t word)
+{
+    return *reinterpret_cast<float *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot) + word*4u);
+}
+PT_DEV uint32_t &slotUW(const PathState &st, uint32_t a, uint32_t slot, uint32_t word)
+{
+    return *reinterpret_cast<uint32_t *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot) + word*4u);
 }
 
 

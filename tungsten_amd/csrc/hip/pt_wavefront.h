@@ -120,7 +120,14 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
         if (black || isnan(sum3(em)))
             em = splat3(0.0f);
         if (records)   // SampleRecord::addSample(c) input (SampleRecord.hpp:55-58; Vec3f::luminance, math/Vec.hpp:195-199)
-            at32(pp.lum, lumBase + samp.x) = em.x*0.2126f + em.y*0.7152f + em.z*0.0722f;
+            {
+                const float l = em.x*0.2126f + em.y*0.7152f + em.z*0.0722f;
+#if PT_NT_STATE & 4
+                __builtin_nontemporal_store(l, &at32(pp.lum, lumBase + samp.x));
+#else
+                at32(pp.lum, lumBase + samp.x) = l;
+#endif
+            }
         if constexpr (EXT) {
             if (pp.flags & TGHIP_PASS_SAMPLES) {   // what traceSample returned for (pixel, sample)
                 float *dst = pp.samples + ((size_t)pixel*pp.samples_spp + (samp.x - pp.samples_begin))*3u;
@@ -146,7 +153,11 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
         finishedCount++;
         samp.x++;
         if (samp.x >= samp.y || aborted) {
+#if PT_NT_STATE & 4
+            { const PtF4v t = {acc.x, acc.y, acc.z, acc.w}; __builtin_nontemporal_store(t, reinterpret_cast<PtF4v *>(&at32(st.partial, item))); }
+#else
             at32(st.partial, item) = acc;
+#endif
             want = true;
         }
     }
@@ -320,7 +331,7 @@ __global__ __launch_bounds__(512) void k_trace_closest(DeviceScene s, PathState 
             if (INST) {
                 int hitInst;
                 hit = traverseClosestInst<COUNT, INST == 2 ? KINDS_MESH : KINDS_ALL>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims, hitInst);
-                slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
+                slotW(st, A_EMI, slot, 3u) = __int_as_float(hitInst);
             } else {
                 hit = traverseClosest<COUNT, FLAT>(s, ray, ldsStack + threadIdx.x, blockDim.x, nodes, prims);
             }
@@ -664,7 +675,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
                 if (sp == 0) {
                     // finished: publish the hit and bin the path by shading class
                     slotF4(st, A_HIT, slot) = hit;
-                    slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
+                    slotW(st, A_EMI, slot, 3u) = __int_as_float(hitInst);
                     int ri = __float_as_int(hit.w);
                     int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
                     queuePush(true, local, L, shadeQueue(cls));
@@ -696,7 +707,11 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
 #define WIDE_CLOSEST_BOUNDS __launch_bounds__(512)
 #endif
 #ifndef WIDE_SHADOW_BOUNDS
+#if PT_NT_STATE
+#define WIDE_SHADOW_BOUNDS __launch_bounds__(512, 4)   /* (the proxy form of the slot accesses costs the shadow walk 3 VGPRs, 126 -> 129: held to the 128 of 4 waves/SIMD) */
+#else
 #define WIDE_SHADOW_BOUNDS __launch_bounds__(512)
+#endif
 #endif
 // The end of a loop turn of the two-level (INST) walks, as an instruction of its own.  Without it every path through the turn -- fourteen
 // of them in k_trace_shadow_wide<., ., INST> -- and the edge of the lanes that sit the turn out meet directly in the loop latch (one block
@@ -795,7 +810,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                         if (COUNT) wpResumed++;
                         hit = slotF4(st, A_HIT, slot);                      // the best hit so far
                         tmax = hit.x;
-                        slotF4(st, A_RAY_O, slot).w = ray.tmin;             // (the ray is an ordinary one again)
+                        slotW(st, A_RAY_O, slot, 3u) = ray.tmin;             // (the ray is an ordinary one again)
                     }
                     hitInst = -1;
                     age = 0;
@@ -817,7 +832,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                     walkSave(st, slot, w, stack, stride);
                     if (COUNT) wpSuspended++;
                     slotF4(st, A_HIT, slot) = hit;
-                    slotF4(st, A_RAY_O, slot).w = __uint_as_float(__float_as_uint(ray.tmin) | WALK_SUSPENDED_BIT);
+                    slotW(st, A_RAY_O, slot, 3u) = __uint_as_float(__float_as_uint(ray.tmin) | WALK_SUSPENDED_BIT);
                     queuePush(true, local, L, Q_EXT);
                     busy = false;
                 }
@@ -926,7 +941,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                     if (what == 0) {
                         // finished: publish the hit and bin the path by shading class
                         slotF4(st, A_HIT, slot) = hit;
-                        if (INST) slotF4(st, A_EMI, slot).w = __int_as_float(hitInst);
+                        if (INST) slotW(st, A_EMI, slot, 3u) = __int_as_float(hitInst);
                         int ri = __float_as_int(hit.w);
                         int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
                         queuePush(true, local, L, shadeQueue(cls));
@@ -1590,9 +1605,9 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
             if (state == ST_ACTIVE) {
                 slotF4(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
                 slotF4(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
-                *reinterpret_cast<uint2 *>(&slotU4(st, A_MISC, slot)) = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
+                *reinterpret_cast<uint2 *>(&slotUW(st, A_MISC, slot, 0u)) = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                 if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL))
-                    slotU4(st, A_SAMP, slot).z = rng.dim;
+                    slotUW(st, A_SAMP, slot, 2u) = rng.dim;
             }
             if constexpr ((M & FEAT_AUX) != 0u) if (auxOn) {
                 if (!recorded && state != ST_ACTIVE) {       // the sample returned early: it adds nothing (hitDistance is not a depth)
@@ -1615,7 +1630,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                 finished = true;
                 if (FUSE == 0) {                 // k_finish finalises the sample and regenerates the slot (below)
                     slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
-                    slotF4(st, A_SH_P, slot).w = __uint_as_float(newFlags);
+                    slotW(st, A_SH_P, slot, 3u) = __uint_as_float(newFlags);
                 }
             }
             if (survives)
@@ -1827,9 +1842,9 @@ __global__ __launch_bounds__(512) void k_trace_shadow(DeviceScene s, PathState s
                 }
                 if (!FORWARD) shadowT = transmittance;
                 if (r == 0 && (pp.flags & TGHIP_PASS_AUX)) {   // the visibility output of the vertex that recorded (PathTracer.cpp:93-94)
-                    float4 &a1 = slotF4(st, A_AUX1, slot);
-                    if (isinf(a1.w))
-                        a1.w = visValid ? avg3(shadowT) : __uint_as_float(0x7FC00000u);
+                    float &a1w = slotW(st, A_AUX1, slot, 3u);
+                    if (isinf(a1w))
+                        a1w = visValid ? avg3(shadowT) : __uint_as_float(0x7FC00000u);
                 }
                 if (FORWARD)                     result = result + transmittance;        // (the whole term, above)
                 else if (!isZero(transmittance)) result = result + xyz(c)*transmittance;
@@ -2151,7 +2166,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                         if (COUNT) wpResumed++;
                         const float4 part = slotF4(st, st.walk_base + 2u, slot);
                         result = xyz(part); r = __float_as_int(part.w);
-                        slotF4(st, A_SH_O, slot).w = eps;                   // (an ordinary shadow slot again)
+                        slotW(st, A_SH_O, slot, 3u) = eps;                   // (an ordinary shadow slot again)
                         (void)setupRay(true);
                     }
                 }
@@ -2170,7 +2185,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
                     walkSave(st, slot, w, stack, stride);
                     if (COUNT) wpSuspended++;
                     slotF4(st, st.walk_base + 2u, slot) = mk4(result, __int_as_float(r));
-                    slotF4(st, A_SH_O, slot).w = __uint_as_float(__float_as_uint(eps) | WALK_SUSPENDED_BIT);
+                    slotW(st, A_SH_O, slot, 3u) = __uint_as_float(__float_as_uint(eps) | WALK_SUSPENDED_BIT);
                     queuePush(true, local, L, Q_SHADOW);
                     const uint32_t bit = 1u << (local & 31u);
                     if (L.bm[Q_EXT][local >> 5] & bit) {
@@ -2442,7 +2457,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                         if (COUNT) wpResumed++;
                         const float4 part = slotF4(st, st.walk_base + 2u, slot);
                         result = xyz(part); r = __float_as_int(part.w);
-                        slotF4(st, A_SH_O, slot).w = eps;                   // (an ordinary shadow slot again)
+                        slotW(st, A_SH_O, slot, 3u) = eps;                   // (an ordinary shadow slot again)
                         (void)tryRay(r == 0 ? c0 : c1, r == 0 ? d0 : d1, true);
                     }
                 }
@@ -2460,7 +2475,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                 walkSave(st, slot, w, stack, stride);
                 if (COUNT) wpSuspended++;
                 slotF4(st, st.walk_base + 2u, slot) = mk4(result, __int_as_float(r));
-                slotF4(st, A_SH_O, slot).w = __uint_as_float(__float_as_uint(eps) | WALK_SUSPENDED_BIT);
+                slotW(st, A_SH_O, slot, 3u) = __uint_as_float(__float_as_uint(eps) | WALK_SUSPENDED_BIT);
                 queuePush(true, local, L, Q_SHADOW);
                 const uint32_t bit = 1u << (local & 31u);
                 if (L.bm[Q_EXT][local >> 5] & bit) {
@@ -2568,7 +2583,7 @@ PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassPara
             loc = order[i];
             sl = first + loc;
             em = xyz(slotF4(st, A_EMI, sl));
-            black = FLAG_STATE(__float_as_uint(slotF4(st, A_SH_P, sl).w)) == ST_TERMINATED_BLACK;
+            black = FLAG_STATE(__float_as_uint(slotW(st, A_SH_P, sl, 3u))) == ST_TERMINATED_BLACK;
         }
         bool regenerated = nextPath(s, st, pp, fin, false, sl, em, black, &L.cursor, aborted, finishedCount);
         queuePush(regenerated, loc, L, Q_EXTP);
