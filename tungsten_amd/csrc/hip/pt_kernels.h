@@ -196,37 +196,33 @@ PT_DEV char *slotBase(const PathState &st, uint32_t a) { return PT_RECORDS(st) ?
 #ifndef PT_NT_STATE
 #define PT_NT_STATE 6
 #endif
-#if PT_NT_STATE
+#ifndef PT_NT_TAIL
+#define PT_NT_TAIL 0          /* 1: k_tail's bodies keep the hint too (A/B) */
+#endif
 typedef float    PtF4v __attribute__((ext_vector_type(4)));
 typedef uint32_t PtU4v __attribute__((ext_vector_type(4)));
-struct SlotF4Ref {
+// (NT: the PT_NT_STATE bits in force at the call site -- the kernels whose slots are re-read within microseconds, the fused flat-list
+// launches and k_tail, pass 0: there the hint costs 1.3 %, profiles/r5_ab_nt_state.txt)
+template<int NT> struct SlotF4Ref {
     PtF4v *p;
-    PT_DEV operator float4() const { const PtF4v v = (PT_NT_STATE & 1) ? __builtin_nontemporal_load(p) : *p; return make_float4(v.x, v.y, v.z, v.w); }
-    PT_DEV const SlotF4Ref &operator=(float4 v) const { PtF4v t = {v.x, v.y, v.z, v.w}; if (PT_NT_STATE & 2) __builtin_nontemporal_store(t, p); else *p = t; return *this; }
+    PT_DEV operator float4() const { const PtF4v v = (NT & 1) ? __builtin_nontemporal_load(p) : *p; return make_float4(v.x, v.y, v.z, v.w); }
+    PT_DEV const SlotF4Ref &operator=(float4 v) const { PtF4v t = {v.x, v.y, v.z, v.w}; if (NT & 2) __builtin_nontemporal_store(t, p); else *p = t; return *this; }
 };
-struct SlotU4Ref {
+template<int NT> struct SlotU4Ref {
     PtU4v *p;
-    PT_DEV operator uint4() const { const PtU4v v = (PT_NT_STATE & 1) ? __builtin_nontemporal_load(p) : *p; return make_uint4(v.x, v.y, v.z, v.w); }
-    PT_DEV const SlotU4Ref &operator=(uint4 v) const { PtU4v t = {v.x, v.y, v.z, v.w}; if (PT_NT_STATE & 2) __builtin_nontemporal_store(t, p); else *p = t; return *this; }
+    PT_DEV operator uint4() const { const PtU4v v = (NT & 1) ? __builtin_nontemporal_load(p) : *p; return make_uint4(v.x, v.y, v.z, v.w); }
+    PT_DEV const SlotU4Ref &operator=(uint4 v) const { PtU4v t = {v.x, v.y, v.z, v.w}; if (NT & 2) __builtin_nontemporal_store(t, p); else *p = t; return *this; }
 };
-PT_DEV SlotF4Ref slotF4(const PathState &st, uint32_t a, uint32_t slot)
+template<int NT = PT_NT_STATE>
+PT_DEV SlotF4Ref<NT> slotF4(const PathState &st, uint32_t a, uint32_t slot)
 {
-    return SlotF4Ref{reinterpret_cast<PtF4v *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot))};
+    return SlotF4Ref<NT>{reinterpret_cast<PtF4v *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot))};
 }
-PT_DEV SlotU4Ref slotU4(const PathState &st, uint32_t a, uint32_t slot)
+template<int NT = PT_NT_STATE>
+PT_DEV SlotU4Ref<NT> slotU4(const PathState &st, uint32_t a, uint32_t slot)
 {
-    return SlotU4Ref{reinterpret_cast<PtU4v *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot))};
+    return SlotU4Ref<NT>{reinterpret_cast<PtU4v *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot))};
 }
-#else
-PT_DEV float4 &slotF4(const PathState &st, uint32_t a, uint32_t slot)
-{
-    return *reinterpret_cast<float4 *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot));
-}
-PT_DEV uint4 &slotU4(const PathState &st, uint32_t a, uint32_t slot)
-{
-    return *reinterpret_cast<uint4 *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot));
-}
-#endif
 // one 32-bit word of a slot's 16 bytes (the few places that touch less than the whole vector)
 PT_DEV float &slotW(const PathState &st, uint32_t a, uint32_t slot, uint32_t word)
 {

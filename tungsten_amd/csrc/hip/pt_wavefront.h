@@ -100,7 +100,7 @@ PT_DEV void rngStartSobol(Rng &rng, const DeviceScene &s, const PassParams &pp, 
 
 // EXT: the pass may carry TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS state (checked at run time through pp.flags /
 // pp.rec_count); false compiles those paths out (the specialised shading variants, DESIGN.md "Kernels").
-template<bool CONVERGED = true, bool EXT = true>
+template<bool CONVERGED = true, bool EXT = true, int NTS = PT_NT_STATE>
 PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams &pp, bool finished, bool fresh,
                      uint32_t slot, f3 em, bool black, uint32_t *cursor, bool aborted, uint32_t &finishedCount)
 {
@@ -111,10 +111,10 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
     const bool records = EXT && pp.rec_count != nullptr;
     bool want = fresh;
     if (finished) {
-        uint4 sm = slotU4(st, A_SAMP, slot), misc = slotU4(st, A_MISC, slot);
+        uint4 sm = slotU4<NTS>(st, A_SAMP, slot), misc = slotU4<NTS>(st, A_MISC, slot);
         samp = make_uint2(sm.x, sm.y);
         lumBase = EXT ? sm.w : 0u;
-        acc = slotF4(st, A_ACC, slot);
+        acc = slotF4<NTS>(st, A_ACC, slot);
         pixel = misc.z;
         item = misc.w;
         if (black || isnan(sum3(em)))
@@ -122,11 +122,8 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
         if (records)   // SampleRecord::addSample(c) input (SampleRecord.hpp:55-58; Vec3f::luminance, math/Vec.hpp:195-199)
             {
                 const float l = em.x*0.2126f + em.y*0.7152f + em.z*0.0722f;
-#if PT_NT_STATE & 4
-                __builtin_nontemporal_store(l, &at32(pp.lum, lumBase + samp.x));
-#else
-                at32(pp.lum, lumBase + samp.x) = l;
-#endif
+                if constexpr ((NTS & 4) != 0) __builtin_nontemporal_store(l, &at32(pp.lum, lumBase + samp.x));
+                else at32(pp.lum, lumBase + samp.x) = l;
             }
         if constexpr (EXT) {
             if (pp.flags & TGHIP_PASS_SAMPLES) {   // what traceSample returned for (pixel, sample)
@@ -142,7 +139,7 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             if (pp.flags & TGHIP_PASS_AUX) {
                 // the addSample calls of traceSample (PathTracer.cpp:78-96, 133-140), then the colour (PathTraceIntegrator.cpp:152)
                 TgHipAuxPixel &px = pp.aux[pixel];
-                float4 a0 = slotF4(st, A_AUX0, slot), a1 = slotF4(st, A_AUX1, slot);
+                float4 a0 = slotF4<NTS>(st, A_AUX0, slot), a1 = slotF4<NTS>(st, A_AUX1, slot);
                 auxAdd3(px, TGHIP_AUX_DEPTH, 3, 1, a0.w, 0.0f, 0.0f);
                 auxAdd3(px, TGHIP_AUX_NORMAL, 4, 3, a0.x, a0.y, a0.z);
                 auxAdd3(px, TGHIP_AUX_ALBEDO, 7, 3, a1.x, a1.y, a1.z);
@@ -153,11 +150,8 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
         finishedCount++;
         samp.x++;
         if (samp.x >= samp.y || aborted) {
-#if PT_NT_STATE & 4
-            { const PtF4v t = {acc.x, acc.y, acc.z, acc.w}; __builtin_nontemporal_store(t, reinterpret_cast<PtF4v *>(&at32(st.partial, item))); }
-#else
-            at32(st.partial, item) = acc;
-#endif
+            if constexpr ((NTS & 4) != 0) { const PtF4v t = {acc.x, acc.y, acc.z, acc.w}; __builtin_nontemporal_store(t, reinterpret_cast<PtF4v *>(&at32(st.partial, item))); }
+            else at32(st.partial, item) = acc;
             want = true;
         }
     }
@@ -234,7 +228,7 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
     bool push = false;
     if (finished || fresh) {
         if (dead) {
-            slotF4(st, A_THR, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
+            slotF4<NTS>(st, A_THR, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(FLAG_MAKE(0, 0, ST_DONE)));
         } else {
             Rng rng = rngStart(pp.seed, pixel, samp.x);          // PathSampleGenerator::startPath
             const uint32_t px = pixel % pp.width, py = pixel/pp.width;
@@ -248,23 +242,23 @@ PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams
             float xi0 = rngNext1DT<EXT>(rng), xi1 = rngNext1DT<EXT>(rng);
             f3 o, d;
             const bool cameraOk = cameraRay<EXT>(cam, lens, px, py, l0, l1, xi0, xi1, o, d, s.dist);
-            slotF4(st, A_RAY_O, slot) = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
-            slotF4(st, A_RAY_D, slot) = mk4(d, cameraOk ? PT_INF : -1.0f);   // a failed camera sample: the ray can hit nothing ...
-            slotU4(st, A_MISC, slot) = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, item);
-            slotF4(st, A_EMI, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            slotF4<NTS>(st, A_RAY_O, slot) = mk4(o, 1e-4f);                      // Ray ctor default nearT (math/Ray.hpp:24)
+            slotF4<NTS>(st, A_RAY_D, slot) = mk4(d, cameraOk ? PT_INF : -1.0f);   // a failed camera sample: the ray can hit nothing ...
+            slotU4<NTS>(st, A_MISC, slot) = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), pixel, item);
+            slotF4<NTS>(st, A_EMI, slot) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             // ... and carries no throughput, so the escaped path adds nothing: a black sample (PathTracer.cpp:27-28)
             const float t0 = cameraOk ? 1.0f : 0.0f;
             uint32_t f0 = FLAG_MAKE(0, 1, ST_ACTIVE);                       // wasSpecular starts true
             if (EXT && (pp.flags & PT_PASS_MEDIA))
                 f0 |= FLAG_MEDIUM_BITS(cam.medium, 0);                      // _scene->cam().medium(), state.reset() (PathTracer.cpp:38-41)
-            slotF4(st, A_THR, slot) = make_float4(t0, t0, t0, __uint_as_float(f0));
+            slotF4<NTS>(st, A_THR, slot) = make_float4(t0, t0, t0, __uint_as_float(f0));
             if (EXT && (pp.flags & TGHIP_PASS_AUX)) {                          // nothing recorded yet, hitDistance = 0
                 const float nan = __uint_as_float(0x7FC00000u);
-                slotF4(st, A_AUX0, slot) = make_float4(nan, nan, nan, 0.0f);
-                slotF4(st, A_AUX1, slot) = make_float4(nan, nan, nan, nan);
+                slotF4<NTS>(st, A_AUX0, slot) = make_float4(nan, nan, nan, 0.0f);
+                slotF4<NTS>(st, A_AUX1, slot) = make_float4(nan, nan, nan, nan);
             }
-            slotU4(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, EXT ? rng.dim : 0u, lumBase);   // .z: next Sobol' dimension
-            slotF4(st, A_ACC, slot) = acc;
+            slotU4<NTS>(st, A_SAMP, slot) = make_uint4(samp.x, samp.y, EXT ? rng.dim : 0u, lumBase);   // .z: next Sobol' dimension
+            slotF4<NTS>(st, A_ACC, slot) = acc;
             push = true;
         }
     }
@@ -727,7 +721,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
 // needs about max(nodes, records) turns instead of their sum; a node visited before an earlier node's records have shortened the ray
 // may report a few children more (conservative: hits unchanged, visit counts a little above the sequential walk's).
 // (the kernel's body as a function of the workgroup's LDS objects: k_trace_closest_wide below and the tail kernel, k_tail, run it)
-template<bool COUNT, bool SOLIDS, bool INST, bool DECOUPLED>
+template<bool COUNT, bool SOLIDS, bool INST, bool DECOUPLED, int NTS = PT_NT_STATE>
 PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, BlockLds &L, uint32_t &fetchNext, int *ldsDyn)
 {
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
@@ -762,6 +756,9 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
     bool pendingPublish = false;                 // DECOUPLED: the walk is over, its hit is published at the next refill (below)
     bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
     uint32_t age = 0;                            // turns this lane's walk has had in this launch (PathState::suspend_turns)
+#if defined(PT_TRACK_T2)
+    float t2 = PT_INF; uint32_t t2Obj = 0xFFFFFFFFu;
+#endif
     const bool maySuspend = !INST && st.suspend_lanes != 0u && n >= st.suspend_min_queue;
     WALK_PROF_DECL;
     for (;;) {
@@ -772,7 +769,10 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             // instead of one in nearly every turn, sat out by the whole wave.
             if (((!exhausted && __popcll(busyMask) <= 48) || exhausted) && __ballot(pendingPublish) != 0ull) {
                 if (pendingPublish) {
-                    slotF4(st, A_HIT, slot) = hit;
+                    slotF4<NTS>(st, A_HIT, slot) = hit;
+#if defined(PT_TRACK_T2)
+                    if (t2 <= hit.x*1.000001f) slotW(st, A_EMI, slot, 3u) = 1.0f;   // "undecided": a spare word of single-level scenes
+#endif
                     const int ri = __float_as_int(hit.w);
                     const int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
                     queuePush(true, local, L, shadeQueue(cls));
@@ -792,7 +792,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                 if (i < n) {
                     local = order[i];
                     slot = first + local;
-                    float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
+                    float4 ro = slotF4<NTS>(st, A_RAY_O, slot), rd = slotF4<NTS>(st, A_RAY_D, slot);
                     ray.o = xyz(ro); ray.d = xyz(rd); ray.tmin = ro.w; ray.tmax = rd.w;
                     bool resumed = false;
                     if constexpr (!INST) {
@@ -804,11 +804,14 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                         wideStart(w);
                         tmax = ray.tmax;
                         hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+#if defined(PT_TRACK_T2)
+                        t2 = PT_INF; t2Obj = 0xFFFFFFFFu;
+#endif
                         rays++;
                     } else {
                         walkRestore(st, slot, w, stack, stride);
                         if (COUNT) wpResumed++;
-                        hit = slotF4(st, A_HIT, slot);                      // the best hit so far
+                        hit = slotF4<NTS>(st, A_HIT, slot);                      // the best hit so far
                         tmax = hit.x;
                         slotW(st, A_RAY_O, slot, 3u) = ray.tmin;             // (the ray is an ordinary one again)
                     }
@@ -831,7 +834,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                 if (busy && age >= st.suspend_turns) {
                     walkSave(st, slot, w, stack, stride);
                     if (COUNT) wpSuspended++;
-                    slotF4(st, A_HIT, slot) = hit;
+                    slotF4<NTS>(st, A_HIT, slot) = hit;
                     slotW(st, A_RAY_O, slot, 3u) = __uint_as_float(__float_as_uint(ray.tmin) | WALK_SUSPENDED_BIT);
                     queuePush(true, local, L, Q_EXT);
                     busy = false;
@@ -870,7 +873,18 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             if (hasRec) {
                 if (COUNT) prims++;
                 uint32_t meta;
+#if defined(PT_TRACK_T2)
+                // (costing experiment, never the product: what the headline's walk would pay for knowing whether its answer could depend on the
+                // reference's top-level visiting order -- the distance of the nearest hit of ANOTHER scene item)
+                const float told = tmax;
+                if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta)) {
+                    const uint32_t obj = TGHIP_REC_OBJECT(meta);
+                    if (obj != t2Obj) t2 = fminf(t2, told);
+                    t2Obj = obj;
+                }
+#else
                 (void)testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta);
+#endif
             }
             if (hasNode) {
                 if (COUNT) nodes++;
@@ -917,7 +931,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             }
             if (finished) {
                 // publish the hit and bin the path by shading class
-                slotF4(st, A_HIT, slot) = hit;
+                slotF4<NTS>(st, A_HIT, slot) = hit;
                 int ri = __float_as_int(hit.w);
                 int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
                 queuePush(true, local, L, shadeQueue(cls));
@@ -940,7 +954,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                     what = wideNext<INST>(w, wr.octInv, stack, stride, idx);
                     if (what == 0) {
                         // finished: publish the hit and bin the path by shading class
-                        slotF4(st, A_HIT, slot) = hit;
+                        slotF4<NTS>(st, A_HIT, slot) = hit;
                         if (INST) slotW(st, A_EMI, slot, 3u) = __int_as_float(hitInst);
                         int ri = __float_as_int(hit.w);
                         int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
@@ -951,7 +965,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             }
             if (INST && what == 3) {
                 // the master's subtree is done: back to the world-space ray (distances along it did not change)
-                float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
+                float4 ro = slotF4<NTS>(st, A_RAY_O, slot), rd = slotF4<NTS>(st, A_RAY_D, slot);
                 ray.o = xyz(ro); ray.d = xyz(rd);
                 wr = wideRaySetup(ray);
                 w.curInst = -1;
@@ -1004,6 +1018,7 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
 // vertex and regenerates their slots (finishBody, below), then traces its extension rays, the fresh camera rays among them -- one launch per
 // part and iteration less, and the streaming of the regeneration runs inside the issue-bound walk's launch.  The shim launches the stand-alone
 // k_finish only before a host check (the liveness report) and before k_tail.  Single-level scenes on the decoupled walk.
+template<int NTS = PT_NT_STATE>
 PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, unsigned short *order);
 template<bool COUNT, bool SOLIDS>
 __global__ WIDE_CLOSEST_BOUNDS void k_finish_trace_closest_wide(DeviceScene s, PathState st, PassParams pp)
@@ -1096,6 +1111,8 @@ PT_DEV void auxPostLoop(const DeviceScene &s, f3 dir, bool asked, int bounce, fl
 template<uint32_t M, int FUSE, bool STAGED = false>
 PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassParams &pp, int cls, BlockLds &L, unsigned char *ldsTables, unsigned short *order)
 {
+    // (the fused flat-list launches and k_tail -- STAGED -- re-read their slots within microseconds: no non-temporal hint there, pt_kernels.h)
+    constexpr int SNT = (FUSE != 0 || (STAGED && !PT_NT_TAIL)) ? 0 : PT_NT_STATE;
     BlockCtl &ctl = st.ctl[blockIdx.x];
     // (CLS_MISS: the escaped paths.  CLS_0_AND_MISS: class 0, then the escaped paths -- one launch of the variant both run; the expanded list
     // keeps the two runs apart, so at most one wave per workgroup mixes surface shading with escaped paths)
@@ -1153,7 +1170,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
             f3 pendingOut = splat3(0.0f);
             local = DIRECT ? i : order[i];
             slot = first + local;
-            float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot), hit, thr4 = slotF4(st, A_THR, slot);
+            float4 ro = slotF4<SNT>(st, A_RAY_O, slot), rd = slotF4<SNT>(st, A_RAY_D, slot), hit, thr4 = slotF4<SNT>(st, A_THR, slot);
             if (FUSE & FUSE_TRACE) {
                 // TraceableScene::intersect inline: the flat record list, walked uniformly by the wave
                 RayD r0;
@@ -1164,15 +1181,15 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                 complexCls = ri >= 0 ? (int)at32(sg.rec_class, (uint32_t)ri) : 0;
                 toComplex = complexCls != 0;
                 if (toComplex)
-                    slotF4(st, A_HIT, slot) = hit;           // shaded by its class's launch, which follows
+                    slotF4<SNT>(st, A_HIT, slot) = hit;           // shaded by its class's launch, which follows
             } else {
-                hit = slotF4(st, A_HIT, slot);
+                hit = slotF4<SNT>(st, A_HIT, slot);
             }
           if (!toComplex) {
-            float4 em4 = slotF4(st, A_EMI, slot);
+            float4 em4 = slotF4<SNT>(st, A_EMI, slot);
             em = xyz(em4);
             const int hitInst = ((M & FEAT_INSTANCES) && s.num_instances) ? __float_as_int(em4.w) : -1;   // written by k_trace_closest<.., INST>
-            uint4 misc = slotU4(st, A_MISC, slot);
+            uint4 misc = slotU4<SNT>(st, A_MISC, slot);
             uint2 rs = make_uint2(misc.x, misc.y);
             uint32_t pixel = misc.z;
             Rng rng;
@@ -1181,7 +1198,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
             rng.sobol = nullptr;
             rng.scramble = rng.index = rng.dim = 0u;
             if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL)) {
-                uint4 sm = slotU4(st, A_SAMP, slot);             // .x = sample index, .z = next dimension
+                uint4 sm = slotU4<SNT>(st, A_SAMP, slot);             // .x = sample index, .z = next dimension
                 rngStartSobol(rng, s, pp, pixel % pp.width, pixel/pp.width, pixel, sm.x, sm.z);
             }
             RayD ray;
@@ -1199,7 +1216,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
             int loopExit = 0;                                // the while loop was left: 1 = by `break` (bounce not advanced), 2 = bounce limit
             float4 aux0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), aux1 = aux0;
             if constexpr ((M & FEAT_AUX) != 0u) {
-                if (auxOn && !recorded) { aux0 = slotF4(st, A_AUX0, slot); aux1 = slotF4(st, A_AUX1, slot); }
+                if (auxOn && !recorded) { aux0 = slotF4<SNT>(st, A_AUX0, slot); aux1 = slotF4<SNT>(st, A_AUX1, slot); }
             }
             // loop epilogue (PathTracer.cpp:108-126) for a path that goes on from `o` in direction `d`
             auto continuePath = [&](f3 o, f3 d, float tmin) {
@@ -1277,9 +1294,9 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                 float f = phaseEval(mm, ray.d, d);
                                 if (f != 0.0f && meshLight) {
                                     mis0 = powerHeuristic(pdf, f);                         // phase pdf == phase value
-                                    slotF4(st, A_SH_D0, slot) = mk4(d, dist);
-                                    slotF4(st, A_SH_C0, slot) = mk4(splat3(f), __uint_as_float(tag));
-                                    slotF4(st, A_NEE0, slot) = make_float4(0.0f, 0.0f, 0.0f, pdf);
+                                    slotF4<SNT>(st, A_SH_D0, slot) = mk4(d, dist);
+                                    slotF4<SNT>(st, A_SH_C0, slot) = mk4(splat3(f), __uint_as_float(tag));
+                                    slotF4<SNT>(st, A_NEE0, slot) = make_float4(0.0f, 0.0f, 0.0f, pdf);
                                     q0 = true;
                                 } else if (f != 0.0f) {
                                     RayD sr; sr.o = volP; sr.d = d; sr.tmin = 0.0f; sr.tmax = PT_INF;   // parentRay.scatter(p, d, 0.0f)
@@ -1292,9 +1309,9 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                         if (!isZero(e)) {
                                             if (!diracLight)
                                                 mis0 = powerHeuristic(pdf, f);
-                                            slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
-                                            slotF4(st, A_SH_C0, slot) = mk4(splat3(f), __uint_as_float(tag));
-                                            slotF4(st, A_NEE0, slot) = mk4(e, pdf);
+                                            slotF4<SNT>(st, A_SH_D0, slot) = mk4(d, lh.t);
+                                            slotF4<SNT>(st, A_SH_C0, slot) = mk4(splat3(f), __uint_as_float(tag));
+                                            slotF4<SNT>(st, A_NEE0, slot) = mk4(e, pdf);
                                             q0 = true;
                                         }
                                     }
@@ -1305,8 +1322,8 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                             f3 w; float ppdf;
                             phaseSample<M>(mm, rng, ray.d, w, ppdf);
                             if (meshLight) {
-                                slotF4(st, A_SH_D1, slot) = mk4(w, ppdf);                      // directPdf needs the hit
-                                slotF4(st, A_SH_C1, slot) = mk4(splat3(1.0f), __uint_as_float(tag));
+                                slotF4<SNT>(st, A_SH_D1, slot) = mk4(w, ppdf);                      // directPdf needs the hit
+                                slotF4<SNT>(st, A_SH_C1, slot) = mk4(splat3(1.0f), __uint_as_float(tag));
                                 q1 = true;
                             } else {
                                 RayD sr; sr.o = volP; sr.d = w; sr.tmin = 0.0f; sr.tmax = PT_INF;
@@ -1315,9 +1332,9 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                     f3 e = lightEvalDirect<M>(s, light, lh.u, lh.v, lh.backSide);
                                     if (!isZero(e)) {
                                         mis1 = powerHeuristic(ppdf, lightDirectPdf<M>(s, light, w, volP, lh));
-                                        slotF4(st, A_SH_D1, slot) = mk4(w, lh.t);
-                                        slotF4(st, A_SH_C1, slot) = mk4(splat3(1.0f), __uint_as_float(tag));   // phaseSample.weight
-                                        slotF4(st, A_NEE1, slot) = mk4(e, 0.0f);
+                                        slotF4<SNT>(st, A_SH_D1, slot) = mk4(w, lh.t);
+                                        slotF4<SNT>(st, A_SH_C1, slot) = mk4(splat3(1.0f), __uint_as_float(tag));   // phaseSample.weight
+                                        slotF4<SNT>(st, A_NEE1, slot) = mk4(e, 0.0f);
                                         q1 = true;
                                     }
                                 }
@@ -1325,11 +1342,11 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                         }
                         if (q0 || q1) {
                             hasShadow = true;
-                            if (!q0) slotF4(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                            if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                            slotF4(st, A_SH_O, slot) = mk4(volP, 0.0f);
-                            slotF4(st, A_SH_W, slot) = mk4(throughput, lightWeight);
-                            slotF4(st, A_NEE2, slot) = make_float4(mis0, mis1, 0.0f, 0.0f);
+                            if (!q0) slotF4<SNT>(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                            if (!q1) slotF4<SNT>(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                            slotF4<SNT>(st, A_SH_O, slot) = mk4(volP, 0.0f);
+                            slotF4<SNT>(st, A_SH_W, slot) = mk4(throughput, lightWeight);
+                            slotF4<SNT>(st, A_NEE2, slot) = make_float4(mis0, mis1, 0.0f, 0.0f);
                         }
                     }
                 }
@@ -1440,9 +1457,9 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                             // shadow kernel completes f*e/pdf * powerHeuristic from these factors
                                             // (a scene with a mesh emitter always runs with nee_factors)
                                             mis0 = powerHeuristic(pdf, bsdfPdf<M>(s, info.bsdf, ev));
-                                            slotF4(st, A_SH_D0, slot) = mk4(d, dist);
-                                            slotF4(st, A_SH_C0, slot) = mk4(f, __uint_as_float(tag));
-                                            slotF4(st, A_NEE0, slot) = make_float4(0.0f, 0.0f, 0.0f, pdf);
+                                            slotF4<SNT>(st, A_SH_D0, slot) = mk4(d, dist);
+                                            slotF4<SNT>(st, A_SH_C0, slot) = mk4(f, __uint_as_float(tag));
+                                            slotF4<SNT>(st, A_NEE0, slot) = make_float4(0.0f, 0.0f, 0.0f, pdf);
                                             q0 = true;
                                         } else if (!isZero(f)) {
                                             RayD sr; sr.o = info.p; sr.d = d; sr.tmin = 5e-4f; sr.tmax = PT_INF;
@@ -1465,17 +1482,17 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                                         lightF = lightF*mis0;
                                                     }
                                                     if (factors) {
-                                                        slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
-                                                        slotF4(st, A_SH_C0, slot) = mk4(f, __uint_as_float(tag));
-                                                        slotF4(st, A_NEE0, slot) = mk4(e, pdf);
+                                                        slotF4<SNT>(st, A_SH_D0, slot) = mk4(d, lh.t);
+                                                        slotF4<SNT>(st, A_SH_C0, slot) = mk4(f, __uint_as_float(tag));
+                                                        slotF4<SNT>(st, A_NEE0, slot) = mk4(e, pdf);
                                                     } else if (FUSE & FUSE_SHADOW) {
                                                         sr.tmax = lh.t;
                                                         fusedShadow++;
                                                         if (!traverseOccluded<true, true, shadeKinds(M)>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
                                                             inlineResult = inlineResult + lightF;
                                                     } else {
-                                                        slotF4(st, A_SH_D0, slot) = mk4(d, lh.t);
-                                                        slotF4(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
+                                                        slotF4<SNT>(st, A_SH_D0, slot) = mk4(d, lh.t);
+                                                        slotF4<SNT>(st, A_SH_C0, slot) = mk4(lightF, __uint_as_float(tag));
                                                     }
                                                     q0 = true;
                                                 }
@@ -1494,8 +1511,8 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                     if (M & FEAT_MEDIA) tag = mediaTag(wog);
                                     if ((M & FEAT_MESHLIGHT) && meshLight) {
                                         if (isConsistent(ev.wo, wog)) {
-                                            slotF4(st, A_SH_D1, slot) = mk4(wog, ev.pdf);          // directPdf needs the hit
-                                            slotF4(st, A_SH_C1, slot) = mk4(ev.weight, __uint_as_float(tag));
+                                            slotF4<SNT>(st, A_SH_D1, slot) = mk4(wog, ev.pdf);          // directPdf needs the hit
+                                            slotF4<SNT>(st, A_SH_C1, slot) = mk4(ev.weight, __uint_as_float(tag));
                                             q1 = true;
                                         }
                                     } else if (isConsistent(ev.wo, wog)) {
@@ -1511,17 +1528,17 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                                                 mis1 = powerHeuristic(ev.pdf, lightPdf);
                                                 bsdfF = bsdfF*mis1;
                                                 if (factors) {
-                                                    slotF4(st, A_SH_D1, slot) = mk4(wog, lh.t);
-                                                    slotF4(st, A_SH_C1, slot) = mk4(ev.weight, __uint_as_float(tag));
-                                                    slotF4(st, A_NEE1, slot) = mk4(e, 0.0f);
+                                                    slotF4<SNT>(st, A_SH_D1, slot) = mk4(wog, lh.t);
+                                                    slotF4<SNT>(st, A_SH_C1, slot) = mk4(ev.weight, __uint_as_float(tag));
+                                                    slotF4<SNT>(st, A_NEE1, slot) = mk4(e, 0.0f);
                                                 } else if (FUSE & FUSE_SHADOW) {
                                                     sr.tmax = lh.t;
                                                     fusedShadow++;
                                                     if (!traverseOccluded<true, true, shadeKinds(M)>(sg, sr, light, nullptr, 0, fusedNodes, fusedPrims) && bounce + 1 >= minBounces)
                                                         inlineResult = inlineResult + bsdfF;
                                                 } else {
-                                                    slotF4(st, A_SH_D1, slot) = mk4(wog, lh.t);
-                                                    slotF4(st, A_SH_C1, slot) = mk4(bsdfF, __uint_as_float(tag));
+                                                    slotF4<SNT>(st, A_SH_D1, slot) = mk4(wog, lh.t);
+                                                    slotF4<SNT>(st, A_SH_C1, slot) = mk4(bsdfF, __uint_as_float(tag));
                                                 }
                                                 q1 = true;
                                             }
@@ -1536,11 +1553,11 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                             } else if (q0 || q1) {
                                 hasShadow = true;
                                 auxVisPending = q0;
-                                if (!q0) slotF4(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                                if (!q1) slotF4(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
-                                slotF4(st, A_SH_O, slot) = mk4(info.p, 5e-4f);
-                                slotF4(st, A_SH_W, slot) = mk4(throughput, lightWeight);
-                                if (factors) slotF4(st, A_NEE2, slot) = make_float4(mis0, mis1, 0.0f, 0.0f);
+                                if (!q0) slotF4<SNT>(st, A_SH_C0, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                                if (!q1) slotF4<SNT>(st, A_SH_C1, slot) = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0xFFFFFFFFu));
+                                slotF4<SNT>(st, A_SH_O, slot) = mk4(info.p, 5e-4f);
+                                slotF4<SNT>(st, A_SH_W, slot) = mk4(throughput, lightWeight);
+                                if (factors) slotF4<SNT>(st, A_NEE2, slot) = make_float4(mis0, mis1, 0.0f, 0.0f);
                             }
                         }
                     }
@@ -1603,8 +1620,8 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
             }
             PROF(14);
             if (state == ST_ACTIVE) {
-                slotF4(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
-                slotF4(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
+                slotF4<SNT>(st, A_RAY_O, slot) = mk4(ray.o, ray.tmin);
+                slotF4<SNT>(st, A_RAY_D, slot) = mk4(ray.d, ray.tmax);
                 *reinterpret_cast<uint2 *>(&slotUW(st, A_MISC, slot, 0u)) = make_uint2((uint32_t)rng.state, (uint32_t)(rng.state >> 32));
                 if ((M & FEAT_QMC) && (pp.flags & TGHIP_PASS_SOBOL))
                     slotUW(st, A_SAMP, slot, 2u) = rng.dim;
@@ -1614,7 +1631,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
                     aux0.w = __uint_as_float(0x7FC00000u);
                     auxStore = true;
                 }
-                if (auxStore) { slotF4(st, A_AUX0, slot) = aux0; slotF4(st, A_AUX1, slot) = aux1; }
+                if (auxStore) { slotF4<SNT>(st, A_AUX0, slot) = aux0; slotF4<SNT>(st, A_AUX1, slot) = aux1; }
             }
             const uint32_t newFlags = FLAG_MAKE(bounce, wasSpecular, state) | ((M & FEAT_MEDIA) ? FLAG_MEDIUM_BITS(med, medBounce) : 0u)
                                     | (recorded ? FLAG_AUX_RECORDED : 0u);
@@ -1622,19 +1639,19 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
             black = state == ST_TERMINATED_BLACK;
             if (hasShadow) {
                 // k_trace_shadow adds the NEE term, then finishes the path if it ended here
-                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
-                slotF4(st, A_SH_P, slot) = mk4(pendingOut, __uint_as_float(newFlags));
+                slotF4<SNT>(st, A_EMI, slot) = mk4(em, 0.0f);
+                slotF4<SNT>(st, A_SH_P, slot) = mk4(pendingOut, __uint_as_float(newFlags));
             } else if (survives) {
-                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
+                slotF4<SNT>(st, A_EMI, slot) = mk4(em, 0.0f);
             } else {
                 finished = true;
                 if (FUSE == 0) {                 // k_finish finalises the sample and regenerates the slot (below)
-                    slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
+                    slotF4<SNT>(st, A_EMI, slot) = mk4(em, 0.0f);
                     slotW(st, A_SH_P, slot, 3u) = __uint_as_float(newFlags);
                 }
             }
             if (survives)
-                slotF4(st, A_THR, slot) = mk4(throughput, __uint_as_float(newFlags));
+                slotF4<SNT>(st, A_THR, slot) = mk4(throughput, __uint_as_float(newFlags));
             PROF(15);
           }
         }
@@ -1650,7 +1667,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
         // the few of a shading wave whose path happened to end.  The fused flat-list launches regenerate in place.
         bool regenerated = false;
         if constexpr (FUSE != 0)
-            regenerated = nextPath<true, (M & FEAT_QMC) != 0>(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
+            regenerated = nextPath<true, (M & FEAT_QMC) != 0, SNT>(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
         PROF(7);
         if (DIRECT) {
             if (finished && !regenerated) idle |= 1u << turn;   // the work items ran out: nothing left for this slot
@@ -2333,7 +2350,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
 //     once the queue is dry, in the turn they finish), so their loads fly together and once per refill instead of once per turn;
 //   * the walk is the DECOUPLED one of k_trace_closest_wide: a pending record AND the next node per turn.
 // Same queues, same suspended-walk protocol (Q_HOLD), same results as k_trace_shadow_wide.
-template<bool COUNT, bool SOLIDS>
+template<bool COUNT, bool SOLIDS, int NTS = PT_NT_STATE>
 PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, uint32_t &fetchNext, int *ldsDyn)
 {
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
@@ -2410,11 +2427,11 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         if ((refill || exhausted) && __ballot(pendingFinish) != 0ull) {
             if (pendingFinish) {
                 // NEE term -> path radiance; paths that ended at this vertex go on the finished list
-                const float4 wgt = slotF4(st, A_SH_W, slot), p = slotF4(st, A_SH_P, slot), e4 = slotF4(st, A_EMI, slot);
+                const float4 wgt = slotF4<NTS>(st, A_SH_W, slot), p = slotF4<NTS>(st, A_SH_P, slot), e4 = slotF4<NTS>(st, A_EMI, slot);
                 f3 em = xyz(e4);
                 em = em + (result*wgt.w)*xyz(wgt);           // emission += estimateDirect(...)*throughput
                 em = em + xyz(p);
-                slotF4(st, A_EMI, slot) = mk4(em, 0.0f);
+                slotF4<NTS>(st, A_EMI, slot) = mk4(em, 0.0f);
                 queuePush(FLAG_STATE(__float_as_uint(p.w)) != ST_ACTIVE, local, L, Q_FIN);
                 if (held) {                                  // the path's extension ray was held back while this slot was suspended: release it
                     const uint32_t bit = 1u << (local & 31u);
@@ -2438,8 +2455,8 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                 if (i < n) {
                     local = order[i];
                     slot = first + local;
-                    const float4 o4 = slotF4(st, A_SH_O, slot), c0 = slotF4(st, A_SH_C0, slot), d0 = slotF4(st, A_SH_D0, slot);
-                    c1 = slotF4(st, A_SH_C1, slot); d1 = slotF4(st, A_SH_D1, slot);
+                    const float4 o4 = slotF4<NTS>(st, A_SH_O, slot), c0 = slotF4<NTS>(st, A_SH_C0, slot), d0 = slotF4<NTS>(st, A_SH_D0, slot);
+                    c1 = slotF4<NTS>(st, A_SH_C1, slot); d1 = slotF4<NTS>(st, A_SH_D1, slot);
                     so = xyz(o4);
                     const bool resumed = (__float_as_uint(o4.w) & WALK_SUSPENDED_BIT) != 0u;   // a slot an earlier launch suspended (below)
                     eps = __uint_as_float(__float_as_uint(o4.w) & ~WALK_SUSPENDED_BIT);
@@ -2455,7 +2472,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                     } else {
                         walkRestore(st, slot, w, stack, stride);
                         if (COUNT) wpResumed++;
-                        const float4 part = slotF4(st, st.walk_base + 2u, slot);
+                        const float4 part = slotF4<NTS>(st, st.walk_base + 2u, slot);
                         result = xyz(part); r = __float_as_int(part.w);
                         slotW(st, A_SH_O, slot, 3u) = eps;                   // (an ordinary shadow slot again)
                         (void)tryRay(r == 0 ? c0 : c1, r == 0 ? d0 : d1, true);
@@ -2474,7 +2491,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
             if (busy && age >= st.suspend_turns) {
                 walkSave(st, slot, w, stack, stride);
                 if (COUNT) wpSuspended++;
-                slotF4(st, st.walk_base + 2u, slot) = mk4(result, __int_as_float(r));
+                slotF4<NTS>(st, st.walk_base + 2u, slot) = mk4(result, __int_as_float(r));
                 slotW(st, A_SH_O, slot, 3u) = __uint_as_float(__float_as_uint(eps) | WALK_SUSPENDED_BIT);
                 queuePush(true, local, L, Q_SHADOW);
                 const uint32_t bit = 1u << (local & 31u);
@@ -2563,6 +2580,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast(DeviceScene s, PathState 
 // Second half of the dynamic-fetch shadow step: finalises the paths that had ended at the vertex whose shadow rays
 // k_trace_shadow_dyn just resolved (Q_FIN), regenerates their slots and reports whether the workgroup has extension
 // rays for the next iteration (returned; BlockCtl::live_slots = how many of its slots still carry a path).
+template<int NTS>
 PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, unsigned short *order)
 {
     BlockCtl &ctl = st.ctl[blockIdx.x];
@@ -2582,10 +2600,10 @@ PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassPara
         if (fin) {
             loc = order[i];
             sl = first + loc;
-            em = xyz(slotF4(st, A_EMI, sl));
+            em = xyz(slotF4<NTS>(st, A_EMI, sl));
             black = FLAG_STATE(__float_as_uint(slotW(st, A_SH_P, sl, 3u))) == ST_TERMINATED_BLACK;
         }
-        bool regenerated = nextPath(s, st, pp, fin, false, sl, em, black, &L.cursor, aborted, finishedCount);
+        bool regenerated = nextPath<true, true, NTS>(s, st, pp, fin, false, sl, em, black, &L.cursor, aborted, finishedCount);
         queuePush(regenerated, loc, L, Q_EXTP);
     }
     waveAddStat(&L.samples, finishedCount);
@@ -2643,8 +2661,9 @@ __global__ __launch_bounds__(256) void k_tail(DeviceScene s, PathState st, PassP
     __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
     __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
     const DeviceScene staged = stageSceneTables(s, ldsTables);   // (for the shading steps; the traversal steps read the scene's big arrays only)
+    constexpr int TNT = PT_NT_TAIL ? PT_NT_STATE : 0;            // (a tail workgroup re-reads what it wrote a few microseconds ago: plain stores)
     for (;;) {
-        traceClosestWideBody<false, SOLIDS, false, true>(s, st, L, fetchNext, ldsDyn);
+        traceClosestWideBody<false, SOLIDS, false, true, TNT>(s, st, L, fetchNext, ldsDyn);
         __syncthreads();
         for (int c = 0; c < PT_NUM_CLASSES; ++c) {           // class 0 with the escaped paths, then the classes that occur in the scene (bit c of `classes`)
             if (c >= 1 && !((classes >> c) & 1u))
@@ -2652,9 +2671,9 @@ __global__ __launch_bounds__(256) void k_tail(DeviceScene s, PathState st, PassP
             (void)shadeBody<M, 0, true>(staged, st, pp, c == 0 ? CLS_0_AND_MISS : c, L, ldsTables, order);
             __syncthreads();
         }
-        traceShadowFastBody<false, SOLIDS>(s, st, pp, L, fetchNext, ldsDyn);
+        traceShadowFastBody<false, SOLIDS, TNT>(s, st, pp, L, fetchNext, ldsDyn);
         __syncthreads();
-        const bool anyExt = finishBody(s, st, pp, L, order);
+        const bool anyExt = finishBody<TNT>(s, st, pp, L, order);
         __syncthreads();
         if (!anyExt)
             break;
