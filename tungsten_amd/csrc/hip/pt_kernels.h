@@ -196,6 +196,10 @@ PT_DEV char *slotBase(const PathState &st, uint32_t a) { return PT_RECORDS(st) ?
 #ifndef PT_NT_STATE
 #define PT_NT_STATE 6
 #endif
+#ifndef PT_SLOT_EXTLOAD
+#define PT_SLOT_EXTLOAD 1     /* the plain loads of the hinted kernels as ONE 16-byte vector load each (0: through float4, which the compiler narrows to
+                                 global_load_dwordx3 where a kernel does not use the last word -- measured slower, wideRow below) */
+#endif
 #ifndef PT_NT_TAIL
 #define PT_NT_TAIL 0          /* 1: k_tail's bodies keep the hint too (A/B) */
 #endif
@@ -203,15 +207,36 @@ typedef float    PtF4v __attribute__((ext_vector_type(4)));
 typedef uint32_t PtU4v __attribute__((ext_vector_type(4)));
 // (NT: the PT_NT_STATE bits in force at the call site -- the kernels whose slots are re-read within microseconds, the fused flat-list
 // launches and k_tail, pass 0: there the hint costs 1.3 %, profiles/r5_ab_nt_state.txt)
+// (the plain halves go through float4 / uint4 themselves, as the references of rounds 1-4 did: the same code as then where NT = 0)
 template<int NT> struct SlotF4Ref {
     PtF4v *p;
-    PT_DEV operator float4() const { const PtF4v v = (NT & 1) ? __builtin_nontemporal_load(p) : *p; return make_float4(v.x, v.y, v.z, v.w); }
-    PT_DEV const SlotF4Ref &operator=(float4 v) const { PtF4v t = {v.x, v.y, v.z, v.w}; if (NT & 2) __builtin_nontemporal_store(t, p); else *p = t; return *this; }
+    PT_DEV operator float4() const
+    {
+        if constexpr ((NT & 1) != 0) { const PtF4v v = __builtin_nontemporal_load(p); return make_float4(v.x, v.y, v.z, v.w); }
+        else if constexpr (NT != 0 && PT_SLOT_EXTLOAD) { const PtF4v v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+        else return *reinterpret_cast<const float4 *>(p);
+    }
+    PT_DEV const SlotF4Ref &operator=(float4 v) const
+    {
+        if constexpr ((NT & 2) != 0) { const PtF4v t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, p); }
+        else *reinterpret_cast<float4 *>(p) = v;
+        return *this;
+    }
 };
 template<int NT> struct SlotU4Ref {
     PtU4v *p;
-    PT_DEV operator uint4() const { const PtU4v v = (NT & 1) ? __builtin_nontemporal_load(p) : *p; return make_uint4(v.x, v.y, v.z, v.w); }
-    PT_DEV const SlotU4Ref &operator=(uint4 v) const { PtU4v t = {v.x, v.y, v.z, v.w}; if (NT & 2) __builtin_nontemporal_store(t, p); else *p = t; return *this; }
+    PT_DEV operator uint4() const
+    {
+        if constexpr ((NT & 1) != 0) { const PtU4v v = __builtin_nontemporal_load(p); return make_uint4(v.x, v.y, v.z, v.w); }
+        else if constexpr (NT != 0 && PT_SLOT_EXTLOAD) { const PtU4v v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
+        else return *reinterpret_cast<const uint4 *>(p);
+    }
+    PT_DEV const SlotU4Ref &operator=(uint4 v) const
+    {
+        if constexpr ((NT & 2) != 0) { const PtU4v t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, p); }
+        else *reinterpret_cast<uint4 *>(p) = v;
+        return *this;
+    }
 };
 template<int NT = PT_NT_STATE>
 PT_DEV SlotF4Ref<NT> slotF4(const PathState &st, uint32_t a, uint32_t slot)
@@ -806,7 +831,7 @@ PT_DEV float4 traverseClosest(const DeviceScene &s, const RayD &ray, int *stack,
     for (;;) {
         if (cur >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
-            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            float4 n0 = ld4(n, 0u), n1 = ld4(n, 1u), n2 = ld4(n, 2u), n3 = ld4(n, 3u);
             if (COUNT) nodesVisited++;
             float e0, e1;
             bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, tmax, e0);
@@ -872,7 +897,7 @@ PT_DEV bool traverseOccluded(const DeviceScene &s, const RayD &ray, int endCap, 
     for (;;) {
         if (cur >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
-            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            float4 n0 = ld4(n, 0u), n1 = ld4(n, 1u), n2 = ld4(n, 2u), n3 = ld4(n, 3u);
             if (COUNT) nodesVisited++;
             float e0, e1;
             bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, ray.tmax, e0);
@@ -1075,7 +1100,20 @@ PT_DEV void wideNodeFetchRest(WideNodeRegs &n, const char *base, uint32_t off, c
 #else
 #define PT_WIDE_NODE_BYTES 80u
 struct WideNodeRegs { float4 q0, q1, q2, q3, q4; };
-PT_DEV float4 wideRow(const char *base, uint32_t off) { return *reinterpret_cast<const float4 *>(base + (size_t)off); }
+// (a 16-byte row is loaded as ONE vector: read through float4 the compiler narrows the row whose last word the walk does not use -- child base,
+// record base, leaf_valid, - -- to a global_load_dwordx3, and a lane's 12-byte load costs the walk more than the 16-byte one: PT_ROW_X4 = 0 for the A/B)
+#ifndef PT_ROW_X4
+#define PT_ROW_X4 1
+#endif
+PT_DEV float4 wideRow(const char *base, uint32_t off)
+{
+#if PT_ROW_X4
+    const PtF4v v = *reinterpret_cast<const PtF4v *>(base + (size_t)off);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4 *>(base + (size_t)off);
+#endif
+}
 PT_DEV void wideNodeFetch(WideNodeRegs &n, const char *base, uint32_t off, const WideRay &)
 {
     n.q0 = wideRow(base, off); n.q1 = wideRow(base, off + 16u); n.q2 = wideRow(base, off + 32u); n.q3 = wideRow(base, off + 48u); n.q4 = wideRow(base, off + 64u);
@@ -1206,7 +1244,7 @@ PT_DEV float4 traverseClosestWide(const DeviceScene &s, const RayD &worldRay, ui
             wideVisit(w, nd, ray.o, wr, ray.tmin, tmax);
         } else if (what == 1) {
             if (COUNT) primsTested++;
-            float4 r0 = at32(s.recs, idx*3u + 0u), r1 = at32(s.recs, idx*3u + 1u), r2 = at32(s.recs, idx*3u + 2u);
+            float4 r0 = ld4(s.recs, idx*3u + 0u), r1 = ld4(s.recs, idx*3u + 1u), r2 = ld4(s.recs, idx*3u + 2u);
             if (INST && TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE) {
                 wideEnterInstance(w, stack, stride, idx, r0, r1, r2, ray, wr);
             } else {
@@ -1271,7 +1309,7 @@ PT_DEV bool refChildTest(f3 lo, f3 hi, f3 o, f3 d, f3 invD, float nearT, float f
 // the ray in an instance's master space (Instance.cpp:295-296: rotation and translation only, so distances along it are unchanged)
 PT_DEV void instanceLocalRay(const DeviceScene &s, uint32_t ri, const RayD &world, float tmin, float tmax, RayD &local, int &masterRoot)
 {
-    float4 r0 = at32(s.recs, ri*3u + 0u), r1 = at32(s.recs, ri*3u + 1u), r2 = at32(s.recs, ri*3u + 2u);
+    float4 r0 = ld4(s.recs, ri*3u + 0u), r1 = ld4(s.recs, ri*3u + 1u), r2 = ld4(s.recs, ri*3u + 2u);
     f3 qc = -xyz(r1);                                   // conjugate(): the inverse rotation
     local.o = quatRotate(r1.w, qc, world.o - xyz(r0));
     local.d = quatRotate(r1.w, qc, world.d);
@@ -1308,7 +1346,7 @@ template<bool COUNT, uint32_t KINDS>
 PT_DEV void instanceSetIntersect(const DeviceScene &s, uint32_t setRec, const RayD &ray, float &tmax, float4 &hit, int &hitInst,
                                  int *stack, int stride, uint32_t &nodesVisited, uint32_t &primsTested)
 {
-    const float4 s0 = at32(s.recs, setRec*3u + 0u), s1 = at32(s.recs, setRec*3u + 1u), s2 = at32(s.recs, setRec*3u + 2u);
+    const float4 s0 = ld4(s.recs, setRec*3u + 0u), s1 = ld4(s.recs, setRec*3u + 1u), s2 = ld4(s.recs, setRec*3u + 2u);
     if (COUNT) primsTested++;
     float tMin = ray.tmin, tMax = tmax;
     if (!refBboxIntersection(xyz(s0), xyz(s1), ray, tMin, tMax))
@@ -1321,7 +1359,7 @@ PT_DEV void instanceSetIntersect(const DeviceScene &s, uint32_t setRec, const Ra
         bool miss = false;
         while (node >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)node*4u);
-            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            const float4 n0 = ld4(n, 0u), n1 = ld4(n, 1u), n2 = ld4(n, 2u), n3 = ld4(n, 3u);
             if (COUNT) nodesVisited++;
             float e0, e1;
             const bool hitL = refChildTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, ray.d, invD, ray.tmin, farT, e0);
@@ -1373,7 +1411,7 @@ PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &ray, int *st
     for (;;) {
         if (cur >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
-            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            float4 n0 = ld4(n, 0u), n1 = ld4(n, 1u), n2 = ld4(n, 2u), n3 = ld4(n, 3u);
             if (COUNT) nodesVisited++;
             float e0, e1;
             bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, tmax, e0);
@@ -1415,7 +1453,7 @@ PT_DEV float4 traverseClosestInst(const DeviceScene &s, const RayD &ray, int *st
 template<bool COUNT, uint32_t KINDS = KINDS_ALL>
 PT_DEV bool instanceSetOccluded(const DeviceScene &s, uint32_t setRec, const RayD &ray, int *stack, int stride, uint32_t &nodesVisited, uint32_t &primsTested)
 {
-    const float4 s0 = at32(s.recs, setRec*3u + 0u), s1 = at32(s.recs, setRec*3u + 1u), s2 = at32(s.recs, setRec*3u + 2u);
+    const float4 s0 = ld4(s.recs, setRec*3u + 0u), s1 = ld4(s.recs, setRec*3u + 1u), s2 = ld4(s.recs, setRec*3u + 2u);
     if (COUNT) primsTested++;
     float tMin = ray.tmin, tMax = ray.tmax;
     if (!refBboxIntersection(xyz(s0), xyz(s1), ray, tMin, tMax))
@@ -1427,7 +1465,7 @@ PT_DEV bool instanceSetOccluded(const DeviceScene &s, uint32_t setRec, const Ray
         bool miss = false;
         while (node >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)node*4u);
-            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            const float4 n0 = ld4(n, 0u), n1 = ld4(n, 1u), n2 = ld4(n, 2u), n3 = ld4(n, 3u);
             if (COUNT) nodesVisited++;
             float e0, e1;
             const bool hitL = refChildTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray.o, ray.d, invD, ray.tmin, ray.tmax, e0);
@@ -1469,7 +1507,7 @@ PT_DEV bool traverseOccludedInst(const DeviceScene &s, const RayD &ray, int endC
     for (;;) {
         if (cur >= 0) {
             const float4 *n = &at32(s.nodes, (uint32_t)cur*4u);
-            float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            float4 n0 = ld4(n, 0u), n1 = ld4(n, 1u), n2 = ld4(n, 2u), n3 = ld4(n, 3u);
             if (COUNT) nodesVisited++;
             float e0, e1;
             bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, ray.tmax, e0);

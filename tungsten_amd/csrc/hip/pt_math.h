@@ -35,6 +35,23 @@ template<typename T> PT_DEV const T &at32(const T *base, uint32_t idx)
     return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)(idx*(uint32_t)sizeof(T)));
 }
 
+// A float4 table entry read as ONE 16-byte vector load.  Read through `const float4 &` the compiler drops the words a kernel does not use and
+// issues global_load_dwordx3 / x2 instead; a lane's 12-byte load is the slower one on gfx950 (measured on the wide nodes' second row: shadow
+// launches -2 %, profiles/r5_ab_x4_loads.txt).  PT_LD4 = 0 gives the narrowed loads back (A/B).
+#ifndef PT_LD4
+#define PT_LD4 1
+#endif
+typedef float PtLd4v __attribute__((ext_vector_type(4)));
+PT_DEV float4 ld4(const float4 *base, uint32_t idx)
+{
+#if PT_LD4
+    const PtLd4v v = *reinterpret_cast<const PtLd4v *>(reinterpret_cast<const char *>(base) + (size_t)(idx*16u));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + (size_t)(idx*16u));
+#endif
+}
+
 struct f3 { float x, y, z; };
 
 // ---- two library functions restated so that the device computes what the host's libm computes, bit for bit ---------------------

@@ -1649,7 +1649,7 @@ PT_DEV bool testRecord(const DeviceScene &s, uint32_t ri, const RayD &ray, float
         r1 = make_float4(rp[4], rp[5], rp[6], rp[7]);
         r2 = make_float4(rp[8], rp[9], rp[10], rp[11]);
     } else {
-        r0 = at32(s.recs, ri*3u + 0u); r1 = at32(s.recs, ri*3u + 1u); r2 = at32(s.recs, ri*3u + 2u);
+        r0 = ld4(s.recs, ri*3u + 0u); r1 = ld4(s.recs, ri*3u + 1u); r2 = ld4(s.recs, ri*3u + 2u);
     }
     return testRecordLoaded<UNIFORM, KINDS>(s, ri, r0, r1, r2, ray, tmax, hit, hitMeta);
 }
@@ -1691,11 +1691,11 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
 {
     int ri = __float_as_int(hit.w);
     const uint32_t rj = (uint32_t)ri;
-    float4 r0 = at32(s.recs, rj*3u + 0u), r1 = at32(s.recs, rj*3u + 1u), r2 = at32(s.recs, rj*3u + 2u);
+    float4 r0 = ld4(s.recs, rj*3u + 0u), r1 = ld4(s.recs, rj*3u + 1u), r2 = ld4(s.recs, rj*3u + 2u);
     // the attribute gather does not wait for the record to say "triangle": both are issued together (tri_attrs has an entry
     // for every record), which takes one memory round trip out of the shading chain
     float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0, a2 = a0, a3 = a0;
-    if (M & FEAT_TRIANGLES) { a0 = at32(s.tri_attrs, rj*4u + 0u); a1 = at32(s.tri_attrs, rj*4u + 1u); a2 = at32(s.tri_attrs, rj*4u + 2u); a3 = at32(s.tri_attrs, rj*4u + 3u); }
+    if (M & FEAT_TRIANGLES) { a0 = ld4(s.tri_attrs, rj*4u + 0u); a1 = ld4(s.tri_attrs, rj*4u + 1u); a2 = ld4(s.tri_attrs, rj*4u + 2u); a3 = ld4(s.tri_attrs, rj*4u + 3u); }
     uint32_t meta = __float_as_uint(r0.w);
     int objIdx = (int)TGHIP_REC_OBJECT(meta);
     const TgHipObject &o = s.objects[objIdx];
@@ -1708,7 +1708,7 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
         f3 NgU = cross(xyz(r1), xyz(r2));
         f3 dLocal = ray.d;
         if ((M & FEAT_INSTANCES) && hitInst >= 0) {    /* the master was intersected in its own space (Instance.cpp:295-297) */
-            float4 q = at32(s.recs, (uint32_t)hitInst*3u + 1u);
+            float4 q = ld4(s.recs, (uint32_t)hitInst*3u + 1u);
             dLocal = quatRotate(q.w, -xyz(q), ray.d);
         }
         info.backSide = dot(NgU, dLocal) > 0.0f;
@@ -1791,7 +1791,7 @@ PT_DEV void intersectionInfo(const DeviceScene &s, const RayD &ray, float4 hit, 
     if ((M & FEAT_INSTANCES) && hitInst >= 0) {
         /* Instance::intersectionInfo (primitives/Instance.cpp:337-346): normals to world space; info.p -- already the
          * WORLD-space hit point (TraceableScene.hpp:184) -- is transformed once more, as the reference does */
-        float4 i0 = at32(s.recs, (uint32_t)hitInst*3u + 0u), i1 = at32(s.recs, (uint32_t)hitInst*3u + 1u);
+        float4 i0 = ld4(s.recs, (uint32_t)hitInst*3u + 0u), i1 = ld4(s.recs, (uint32_t)hitInst*3u + 1u);
         info.Ng = quatRotate(i1.w, xyz(i1), info.Ng);
         info.Ns = quatRotate(i1.w, xyz(i1), info.Ns);
         info.p = xyz(i0) + quatRotate(i1.w, xyz(i1), info.p);

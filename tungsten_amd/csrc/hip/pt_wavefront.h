@@ -415,7 +415,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_dyn(DeviceScene s, PathSt
         bool pop = false;
         if (busy && cur >= 0) {
             const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
-            float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            float4 n0 = ld4(nd, 0u), n1 = ld4(nd, 1u), n2 = ld4(nd, 2u), n3 = ld4(nd, 3u);
             if (COUNT) nodes++;
             float e0, e1;
             bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, tmax, e0);
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
         // ---- a node: the scene's and the masters' with this library's slab test, the instance tree's with the reference's ----
         if (busy && cur >= 0) {
             const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
-            const float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+            const float4 n0 = ld4(nd, 0u), n1 = ld4(nd, 1u), n2 = ld4(nd, 2u), n3 = ld4(nd, 3u);
             if (COUNT) nodes++;
             const f3 lo0 = mk3(n0.x, n0.y, n0.z), hi0 = mk3(n0.w, n1.x, n1.y), lo1 = mk3(n1.z, n1.w, n2.x), hi1 = mk3(n2.y, n2.z, n2.w);
             const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
@@ -608,10 +608,10 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
                         const uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
                         bool entered = false;
                         if (level == 0) {
-                            const float4 r0 = at32(s.recs, firstRec*3u);
+                            const float4 r0 = ld4(s.recs, firstRec*3u);
                             if (TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE_SET) {   // (alone in its leaf)
                                 if (COUNT) prims++;
-                                const float4 r1 = at32(s.recs, firstRec*3u + 1u), r2 = at32(s.recs, firstRec*3u + 2u);
+                                const float4 r1 = ld4(s.recs, firstRec*3u + 1u), r2 = ld4(s.recs, firstRec*3u + 2u);
                                 float tMin = world.tmin, tMax = tmax;
                                 if (refBboxIntersection(xyz(r0), xyz(r1), world, tMin, tMax)) {
                                     refTMin = tMin; refTMax = tMax; refFarT = tmax;
@@ -701,11 +701,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
 #define WIDE_CLOSEST_BOUNDS __launch_bounds__(512)
 #endif
 #ifndef WIDE_SHADOW_BOUNDS
-#if PT_NT_STATE
-#define WIDE_SHADOW_BOUNDS __launch_bounds__(512, 4)   /* (the proxy form of the slot accesses costs the shadow walk 3 VGPRs, 126 -> 129: held to the 128 of 4 waves/SIMD) */
-#else
-#define WIDE_SHADOW_BOUNDS __launch_bounds__(512)
-#endif
+#define WIDE_SHADOW_BOUNDS __launch_bounds__(512, 4)   /* (with whole-vector slot loads the shadow walk wants 129 VGPRs: held to the 128 of 4 waves/SIMD) */
 #endif
 // The end of a loop turn of the two-level (INST) walks, as an instruction of its own.  Without it every path through the turn -- fourteen
 // of them in k_trace_shadow_wide<., ., INST> -- and the edge of the lanes that sit the turn out meet directly in the loop latch (one block
@@ -756,9 +752,6 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
     bool pendingPublish = false;                 // DECOUPLED: the walk is over, its hit is published at the next refill (below)
     bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
     uint32_t age = 0;                            // turns this lane's walk has had in this launch (PathState::suspend_turns)
-#if defined(PT_TRACK_T2)
-    float t2 = PT_INF; uint32_t t2Obj = 0xFFFFFFFFu;
-#endif
     const bool maySuspend = !INST && st.suspend_lanes != 0u && n >= st.suspend_min_queue;
     WALK_PROF_DECL;
     for (;;) {
@@ -770,9 +763,6 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             if (((!exhausted && __popcll(busyMask) <= 48) || exhausted) && __ballot(pendingPublish) != 0ull) {
                 if (pendingPublish) {
                     slotF4<NTS>(st, A_HIT, slot) = hit;
-#if defined(PT_TRACK_T2)
-                    if (t2 <= hit.x*1.000001f) slotW(st, A_EMI, slot, 3u) = 1.0f;   // "undecided": a spare word of single-level scenes
-#endif
                     const int ri = __float_as_int(hit.w);
                     const int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
                     queuePush(true, local, L, shadeQueue(cls));
@@ -804,9 +794,6 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                         wideStart(w);
                         tmax = ray.tmax;
                         hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
-#if defined(PT_TRACK_T2)
-                        t2 = PT_INF; t2Obj = 0xFFFFFFFFu;
-#endif
                         rays++;
                     } else {
                         walkRestore(st, slot, w, stack, stride);
@@ -873,18 +860,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             if (hasRec) {
                 if (COUNT) prims++;
                 uint32_t meta;
-#if defined(PT_TRACK_T2)
-                // (costing experiment, never the product: what the headline's walk would pay for knowing whether its answer could depend on the
-                // reference's top-level visiting order -- the distance of the nearest hit of ANOTHER scene item)
-                const float told = tmax;
-                if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta)) {
-                    const uint32_t obj = TGHIP_REC_OBJECT(meta);
-                    if (obj != t2Obj) t2 = fminf(t2, told);
-                    t2Obj = obj;
-                }
-#else
                 (void)testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta);
-#endif
             }
             if (hasNode) {
                 if (COUNT) nodes++;
@@ -2007,7 +1983,7 @@ __global__ SHADOW_DYN_BOUNDS void k_trace_shadow_dyn(DeviceScene s, PathState st
             bool pop = true, occluded = false;
             if (cur >= 0) {
                 const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
-                float4 n0 = nd[0], n1 = nd[1], n2 = nd[2], n3 = nd[3];
+                float4 n0 = ld4(nd, 0u), n1 = ld4(nd, 1u), n2 = ld4(nd, 2u), n3 = ld4(nd, 3u);
                 if (COUNT) nodes++;
                 float e0, e1;
                 bool h0 = boxTest(mk3(n0.x, n0.y, n0.z), mk3(n0.w, n1.x, n1.y), ray, invD, ray.tmax, e0);
@@ -2524,7 +2500,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                 hasNode = wideNextNode(w, wr.octInv, stack, stride, nodeIdx);
             float4 r0, r1, r2;
             WideNodeRegs nd;
-            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
+            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }   // (through float4: the walk is at its 128 registers, and the two words a triangle does not use are two VGPRs)
             if (hasNode) {
                 if (nodeIdx < topCount) wideNodeFetch(nd, ldsTop, wideNodeOff(s, nodeIdx), wr);
                 else                    wideNodeFetch(nd, reinterpret_cast<const char *>(s.wide), wideNodeOff(s, nodeIdx), wr);
