@@ -712,6 +712,34 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
 // nothing, so it is not a memory-ordering problem (tools/repro_latch_miscompile.py, profiles/r3_latch_miscompile.txt).
 // With the join the latch has two predecessors.  Costs nothing: no instruction is emitted.
 #define PT_TURN_JOIN() asm volatile("" ::: "memory")
+// The fetch of a decoupled turn: the lane's record (three rows) and its node (five rows), eight independent loads issued back to back.
+// PT_WALK_FETCH_SAFE = 1 (round 5): every lane loads, from entry 0 where it has nothing to fetch -- no divergent region around the loads.
+// With the loads inside `if (hasRec)` / `if (hasNode)` the closest-hit kernel waited for the record's first row (s_waitcnt vmcnt(2) + three
+// copies out of the region) BEFORE it issued the node's loads: two memory round trips per turn where one was meant.  The through-float4 record
+// reads stay narrowable (pt_math.h: ld4).  PT_LDS_TOP = 1 compiles the top-of-tree-in-LDS experiment of round 3 back in (lds_nodes option).
+#ifndef PT_WALK_FETCH_SAFE
+#define PT_WALK_FETCH_SAFE 1
+#endif
+#ifndef PT_LDS_TOP
+#define PT_LDS_TOP 0
+#endif
+#if PT_WALK_FETCH_SAFE
+#define PT_WALK_FETCH(s, st, r0, r1, r2, nd, hasRec, recIdx, hasNode, nodeIdx, wr, topCount, ldsTop) do { \
+        const uint32_t recAt_ = (hasRec) ? (recIdx)*3u : 0u; \
+        const uint32_t nodeAt_ = (hasNode) ? wideNodeOff(s, nodeIdx) : 0u; \
+        r0 = at32((s).recs, recAt_); r1 = at32((s).recs, recAt_ + 1u); r2 = at32((s).recs, recAt_ + 2u); \
+        if (PT_LDS_TOP && (hasNode) && (nodeIdx) < (topCount)) wideNodeFetch(nd, ldsTop, nodeAt_, wr); \
+        else wideNodeFetch(nd, reinterpret_cast<const char *>((s).wide), nodeAt_, wr); \
+    } while (0)
+#else
+#define PT_WALK_FETCH(s, st, r0, r1, r2, nd, hasRec, recIdx, hasNode, nodeIdx, wr, topCount, ldsTop) do { \
+        if (hasRec) { r0 = at32((s).recs, (recIdx)*3u + 0u); r1 = at32((s).recs, (recIdx)*3u + 1u); r2 = at32((s).recs, (recIdx)*3u + 2u); } \
+        if (hasNode) { \
+            if ((nodeIdx) < (topCount)) wideNodeFetch(nd, ldsTop, wideNodeOff(s, nodeIdx), wr); \
+            else                        wideNodeFetch(nd, reinterpret_cast<const char *>((s).wide), wideNodeOff(s, nodeIdx), wr); \
+        } \
+    } while (0)
+#endif
 // DECOUPLED (single-level scenes): a turn tests the lane's next pending record AND visits its next node -- the walk does not wait for
 // the records of the node visited last before it moves on (their outcome only tightens tmax, never what is visited next), so a ray
 // needs about max(nodes, records) turns instead of their sum; a node visited before an earlier node's records have shortened the ray
@@ -852,11 +880,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             }
             float4 r0, r1, r2;
             WideNodeRegs nd;
-            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }
-            if (hasNode) {
-                if (nodeIdx < topCount) wideNodeFetch(nd, ldsTop, wideNodeOff(s, nodeIdx), wr);
-                else                    wideNodeFetch(nd, reinterpret_cast<const char *>(s.wide), wideNodeOff(s, nodeIdx), wr);
-            }
+            PT_WALK_FETCH(s, st, r0, r1, r2, nd, hasRec, recIdx, hasNode, nodeIdx, wr, topCount, ldsTop);
             if (hasRec) {
                 if (COUNT) prims++;
                 uint32_t meta;
@@ -2500,11 +2524,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                 hasNode = wideNextNode(w, wr.octInv, stack, stride, nodeIdx);
             float4 r0, r1, r2;
             WideNodeRegs nd;
-            if (hasRec) { r0 = at32(s.recs, recIdx*3u + 0u); r1 = at32(s.recs, recIdx*3u + 1u); r2 = at32(s.recs, recIdx*3u + 2u); }   // (through float4: the walk is at its 128 registers, and the two words a triangle does not use are two VGPRs)
-            if (hasNode) {
-                if (nodeIdx < topCount) wideNodeFetch(nd, ldsTop, wideNodeOff(s, nodeIdx), wr);
-                else                    wideNodeFetch(nd, reinterpret_cast<const char *>(s.wide), wideNodeOff(s, nodeIdx), wr);
-            }
+            PT_WALK_FETCH(s, st, r0, r1, r2, nd, hasRec, recIdx, hasNode, nodeIdx, wr, topCount, ldsTop);
             bool rayDone = false;
             if (hasRec) {
                 if (COUNT) prims++;

@@ -469,7 +469,7 @@ static size_t dynLdsBytes(const tghip_ctx *ctx, int threads)
 // nodes of the top of the wide tree the DECOUPLED kernels keep in LDS (PathState::lds_nodes): whole levels of the breadth-first array
 static uint32_t ldsNodeCount(const tghip_ctx *ctx)
 {
-    if (!ctx->decoupleOpt || ctx->haveInstances || ctx->ldsNodesOpt == 0) return 0u;
+    if (!PT_LDS_TOP || !ctx->decoupleOpt || ctx->haveInstances || ctx->ldsNodesOpt == 0) return 0u;   // (PT_LDS_TOP = 0, the product: the option is accepted and has no effect)
     const uint32_t n = ctx->scene.wide ? ctx->numWideNodes : 0u;
     return std::min<uint32_t>(n, uint32_t(ctx->ldsNodesOpt));
 }
