@@ -192,13 +192,25 @@ PT_DEV char *slotBase(const PathState &st, uint32_t a) { return PT_RECORDS(st) ?
 // and the textures that the walks and the shading gathers do hit in.  Measured (profiles/r5_ab_nt_state.txt, two boxes, alternated):
 // stores +5.2 % / +5.8 % on the metric's workload, +4 % on mesh1m, +13 % as shipped; LOADS -1 % alone and -3.5 % next to the stores (a slot's
 // 16 bytes share their 128-byte line with the neighbouring slots other waves read, and a non-temporal load does not keep the line in L1).
-// Hence 6: stores only.  The values moved are the same either way; 0 gives the plain references back.
+// Hence 6: stores only.  The values moved are the same either way; 0 gives plain accesses back.
+// WHERE: only the kernels that name NT explicitly -- the wavefront k_shade launches, the decoupled walks' bodies, finishBody / nextPath.
+// Every other kernel (PT_NT_OTHER = 0) stores plainly, and must: with the hint in k_trace_shadow_wide -- one store, a finished slot's
+// radiance, inside the walk's loop -- the two-level shadow walk of instanced scenes lost occluders in 48 % of the pixels of instances10k,
+// differently in every run, and the sequential single-level walk (option decouple = 0) changed its image: the signature of round 3's loop-latch
+// miscompile of that kernel (PT_TURN_JOIN), which the join had cured; without the hint the kernel is exact again
+// (profiles/r5_nt_hazard.txt; tests/test_gpu_parity.py::test_instanced_shadow_walk_agrees_with_the_bvh2_walk and the scheduling test caught it).
 #ifndef PT_NT_STATE
 #define PT_NT_STATE 6
 #endif
 #ifndef PT_SLOT_EXTLOAD
 #define PT_SLOT_EXTLOAD 1     /* the plain loads of the hinted kernels as ONE 16-byte vector load each (0: through float4, which the compiler narrows to
                                  global_load_dwordx3 where a kernel does not use the last word -- measured slower, wideRow below) */
+#endif
+#ifndef PT_NT_OTHER
+#define PT_NT_OTHER 0         /* the kernels that do not pass NT explicitly (flat lists, BVH2 and two-level walks, the sequential wide walks, resolve) */
+#endif
+#ifndef PT_NT_TRAV
+#define PT_NT_TRAV PT_NT_STATE   /* (bisecting aid: the hint in the traversal / finish kernels) */
 #endif
 #ifndef PT_NT_TAIL
 #define PT_NT_TAIL 0          /* 1: k_tail's bodies keep the hint too (A/B) */
@@ -238,12 +250,12 @@ template<int NT> struct SlotU4Ref {
         return *this;
     }
 };
-template<int NT = PT_NT_STATE>
+template<int NT = PT_NT_OTHER>
 PT_DEV SlotF4Ref<NT> slotF4(const PathState &st, uint32_t a, uint32_t slot)
 {
     return SlotF4Ref<NT>{reinterpret_cast<PtF4v *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot))};
 }
-template<int NT = PT_NT_STATE>
+template<int NT = PT_NT_OTHER>
 PT_DEV SlotU4Ref<NT> slotU4(const PathState &st, uint32_t a, uint32_t slot)
 {
     return SlotU4Ref<NT>{reinterpret_cast<PtU4v *>(slotBase(st, a) + (size_t)slotOffset(st, a, slot))};
@@ -328,53 +340,60 @@ PT_DEV uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgc
 // ---- small scene tables in LDS --------------------------------------------------------------------
 // The shading kernels chase object -> bsdf -> texture -> light records per lane.  Those tables are tiny, but the
 // vector L1 is flushed continuously by the streaming path state, so every dependent lookup pays L2 latency.
-// When the tables fit, each workgroup copies them into LDS once and the lookups become LDS reads (through
-// generic pointers; the big arrays -- records, attributes, texels, CDFs -- stay in global memory).
+// Each workgroup copies them into LDS once and the lookups become LDS reads (the big arrays -- records, attributes,
+// texels, CDFs -- stay in global memory).
+// Round 5: the copy is UNCONDITIONAL.  With the run-time fallback "too large: keep the global tables" every table pointer was a select
+// of an LDS and a global address, so the compiler could not infer the address space and every lookup became a flat_load -- 315 of them in
+// the class-0 variant, each behind an `s_waitcnt vmcnt(0) lgkmcnt(0)` that also drains every global load in flight (235 such waits).
+// Whether the tables fit is decided by the host at upload (tungsten_hip.hip: tablesFit, the same arithmetic as below); scenes whose
+// tables do not fit shade with the GLOBAL_TABLES instantiation of the all-features variant, which does not stage at all.  The sampled
+// environment map's marginal tables come along when env_tex >= 0 (the host clears env_tex when they do not fit next to the rest).
 #define PT_LDS_TABLE_BYTES 12288u
-PT_DEV DeviceScene stageSceneTables(const DeviceScene &s, unsigned char *lds)
+struct SceneTableLayout { uint32_t offBsdf, offTex, offLights, offEnv, offEnvG, total; };
+__host__ __device__ inline SceneTableLayout sceneTableLayout(uint32_t numObjects, uint32_t numBsdfs, uint32_t numTextures, uint32_t numLights, uint32_t numInfinite, int envH)
 {
-    const uint32_t szObj = s.num_objects*(uint32_t)sizeof(TgHipObject);
-    const uint32_t szBsdf = s.num_bsdfs*(uint32_t)sizeof(TgHipBsdf);
-    const uint32_t szTex = s.num_textures*(uint32_t)sizeof(TgHipTexture);
-    const uint32_t szLights = (s.num_lights + s.num_infinite_lights)*(uint32_t)sizeof(int32_t);
-    const uint32_t offBsdf = (szObj + 15u) & ~15u;
-    const uint32_t offTex = (offBsdf + szBsdf + 15u) & ~15u;
-    const uint32_t offLights = (offTex + szTex + 15u) & ~15u;
+    SceneTableLayout l;
+    const uint32_t szObj = numObjects*(uint32_t)sizeof(TgHipObject), szBsdf = numBsdfs*(uint32_t)sizeof(TgHipBsdf), szTex = numTextures*(uint32_t)sizeof(TgHipTexture);
+    const uint32_t szLights = (numLights + numInfinite)*(uint32_t)sizeof(int32_t);
+    l.offBsdf = (szObj + 15u) & ~15u;
+    l.offTex = (l.offBsdf + szBsdf + 15u) & ~15u;
+    l.offLights = (l.offTex + szTex + 15u) & ~15u;
     // the marginal tables of the sampled environment map (mpdf[h] mcdf[h + 1], then its 513-entry guide): the head of the
     // envmap-sampling chain becomes LDS reads
-    const uint32_t offEnv = (offLights + szLights + 15u) & ~15u;
-    const uint32_t szEnvF = s.env_tex >= 0 ? (2u*(uint32_t)s.env_h + 1u)*4u : 0u, szEnvG = s.env_tex >= 0 ? (PT_GUIDE_MARGINAL + 1u)*2u : 0u;
-    const uint32_t offEnvG = (offEnv + szEnvF + 3u) & ~3u;
-    const uint32_t totalBase = offLights + szLights;
-    const bool envFits = s.env_tex >= 0 && ((offEnvG + szEnvG + 3u) & ~3u) <= PT_LDS_TABLE_BYTES;
-    const uint32_t total = totalBase;
-    if (total > PT_LDS_TABLE_BYTES)
-        return s;                                            // uniform decision: too large, keep the global tables
+    l.offEnv = (l.offLights + szLights + 15u) & ~15u;
+    const uint32_t szEnvF = envH > 0 ? (2u*(uint32_t)envH + 1u)*4u : 0u, szEnvG = envH > 0 ? (PT_GUIDE_MARGINAL + 1u)*2u : 0u;
+    l.offEnvG = (l.offEnv + szEnvF + 3u) & ~3u;
+    l.total = envH > 0 ? ((l.offEnvG + szEnvG + 3u) & ~3u) : l.offLights + szLights;
+    return l;
+}
+PT_DEV DeviceScene stageSceneTables(const DeviceScene &s, unsigned char *lds)
+{
+    const bool env = s.env_tex >= 0;
+    const SceneTableLayout l = sceneTableLayout(s.num_objects, s.num_bsdfs, s.num_textures, s.num_lights, s.num_infinite_lights, env ? s.env_h : 0);
     uint32_t *dst = reinterpret_cast<uint32_t *>(lds);
     auto copy = [&](uint32_t off, const void *src, uint32_t bytes) {
         const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
         for (uint32_t i = threadIdx.x; i < bytes/4u; i += blockDim.x)
             dst[off/4u + i] = w[i];
     };
-    copy(0, s.objects, szObj);
-    copy(offBsdf, s.bsdfs, szBsdf);
-    copy(offTex, s.textures, szTex);
-    copy(offLights, s.lights, s.num_lights*(uint32_t)sizeof(int32_t));
-    copy(offLights + s.num_lights*(uint32_t)sizeof(int32_t), s.infinite_lights, s.num_infinite_lights*(uint32_t)sizeof(int32_t));
-    if (envFits) {
-        copy(offEnv, s.env_marginal, szEnvF);
-        copy(offEnvG, s.env_guide, (szEnvG + 3u) & ~3u);     // (the guide array is padded to a multiple of 4 bytes at upload)
+    copy(0, s.objects, s.num_objects*(uint32_t)sizeof(TgHipObject));
+    copy(l.offBsdf, s.bsdfs, s.num_bsdfs*(uint32_t)sizeof(TgHipBsdf));
+    copy(l.offTex, s.textures, s.num_textures*(uint32_t)sizeof(TgHipTexture));
+    copy(l.offLights, s.lights, s.num_lights*(uint32_t)sizeof(int32_t));
+    copy(l.offLights + s.num_lights*(uint32_t)sizeof(int32_t), s.infinite_lights, s.num_infinite_lights*(uint32_t)sizeof(int32_t));
+    if (env) {
+        copy(l.offEnv, s.env_marginal, (2u*(uint32_t)s.env_h + 1u)*4u);
+        copy(l.offEnvG, s.env_guide, ((PT_GUIDE_MARGINAL + 1u)*2u + 3u) & ~3u);     // (the guide array is padded to a multiple of 4 bytes at upload)
     }
     __syncthreads();
     DeviceScene r = s;
-    if (envFits) {
-        r.env_marginal = reinterpret_cast<const float *>(lds + offEnv);
-        r.env_guide = reinterpret_cast<const uint16_t *>(lds + offEnvG);
-    }
+    // (unconditionally LDS addresses: without a sampled environment map nothing reads the two env pointers)
+    r.env_marginal = reinterpret_cast<const float *>(lds + l.offEnv);
+    r.env_guide = reinterpret_cast<const uint16_t *>(lds + l.offEnvG);
     r.objects = reinterpret_cast<const TgHipObject *>(lds);
-    r.bsdfs = reinterpret_cast<const TgHipBsdf *>(lds + offBsdf);
-    r.textures = reinterpret_cast<const TgHipTexture *>(lds + offTex);
-    r.lights = reinterpret_cast<const int32_t *>(lds + offLights);
+    r.bsdfs = reinterpret_cast<const TgHipBsdf *>(lds + l.offBsdf);
+    r.textures = reinterpret_cast<const TgHipTexture *>(lds + l.offTex);
+    r.lights = reinterpret_cast<const int32_t *>(lds + l.offLights);
     r.infinite_lights = r.lights + s.num_lights;
     return r;
 }

@@ -159,12 +159,13 @@ PT_DEV float bitmapPdf(const DeviceScene &s, int texIdx, const TgHipTexture &t, 
     column = min(max(column, 0), t.w - 1);
     if (pick && pick->row == row && pick->column == column)
         return pick->pdfRC*pick->mpdfR*t.w*t.h;
-    const float *mpdf = texIdx == s.env_tex ? s.env_marginal : s.dist + t.dist_offset;
+    // (two reads, not one through a selected pointer: the environment map's marginal table is in LDS, the others' in global memory)
+    const float mpdfR = texIdx == s.env_tex ? s.env_marginal[row] : (s.dist + t.dist_offset)[row];
     const int ro = s.tex_rows[texIdx];
     if (ro >= 0)
-        return at32(s.rows, (uint32_t)ro + (uint32_t)row*(uint32_t)(t.w + 1) + (uint32_t)column).y*mpdf[row]*t.w*t.h;
+        return at32(s.rows, (uint32_t)ro + (uint32_t)row*(uint32_t)(t.w + 1) + (uint32_t)column).y*mpdfR*t.w*t.h;
     const float *pdf = s.dist + t.dist_offset + t.h + t.h + 1;
-    return pdf[(size_t)row*t.w + column]*mpdf[row]*t.w*t.h;
+    return pdf[(size_t)row*t.w + column]*mpdfR*t.w*t.h;
 }
 // Guide tables (built by the shim at upload) make the two CDF inversions of Distribution2D::warp short dependent
 // chains instead of 9- and 10-step binary searches over L2-resident arrays: for a CDF a[0..n] and B buckets,
@@ -203,15 +204,23 @@ PT_DEV int upperBoundGuidedPairs(const float2 *a, const uint16_t *g, int buckets
 PT_DEV void bitmapSample(const DeviceScene &s, int texIdx, const TgHipTexture &t, float xi0, float xi1, float &u, float &v, BitmapPick &pick)   /* :433-439 */
 {
     const bool env = texIdx == s.env_tex;
-    const float *mpdf = env ? s.env_marginal : s.dist + t.dist_offset;
-    const float *mcdf = mpdf + t.h;
     const int go = s.tex_guide[texIdx];
     const int ro = s.tex_rows[texIdx];
     int row;
-    if (go >= 0) row = upperBoundGuided(mcdf, env ? s.env_guide : s.guide + go, PT_GUIDE_MARGINAL, xi1) - 1;
-    else         row = upperBoundIdx(mcdf, t.h + 1, xi1) - 1;
-    const float mpdfR = mpdf[row];
-    float nv = clampf((xi1 - mcdf[row])/mpdfR, 0.0f, 1.0f);
+    float mpdfR, mcdfR;
+    // (the sampled environment map's marginal tables are in LDS, every other texture's in global memory: two copies of the search, so that
+    // neither reads through a pointer of unknown address space -- stageSceneTables)
+    if (env) {
+        const float *mpdf = s.env_marginal, *mcdf = mpdf + t.h;
+        row = upperBoundGuided(mcdf, s.env_guide, PT_GUIDE_MARGINAL, xi1) - 1;     // (env_tex >= 0 only for textures with guide tables)
+        mpdfR = mpdf[row]; mcdfR = mcdf[row];
+    } else {
+        const float *mpdf = s.dist + t.dist_offset, *mcdf = mpdf + t.h;
+        if (go >= 0) row = upperBoundGuided(mcdf, s.guide + go, PT_GUIDE_MARGINAL, xi1) - 1;
+        else         row = upperBoundIdx(mcdf, t.h + 1, xi1) - 1;
+        mpdfR = mpdf[row]; mcdfR = mcdf[row];
+    }
+    float nv = clampf((xi1 - mcdfR)/mpdfR, 0.0f, 1.0f);
     int column;
     float cdfC, pdfC;
     if (go >= 0 && ro >= 0) {

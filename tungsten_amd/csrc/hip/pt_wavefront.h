@@ -100,7 +100,7 @@ PT_DEV void rngStartSobol(Rng &rng, const DeviceScene &s, const PassParams &pp, 
 
 // EXT: the pass may carry TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS state (checked at run time through pp.flags /
 // pp.rec_count); false compiles those paths out (the specialised shading variants, DESIGN.md "Kernels").
-template<bool CONVERGED = true, bool EXT = true, int NTS = PT_NT_STATE>
+template<bool CONVERGED = true, bool EXT = true, int NTS = PT_NT_TRAV>
 PT_DEV bool nextPath(const DeviceScene &s, const PathState &st, const PassParams &pp, bool finished, bool fresh,
                      uint32_t slot, f3 em, bool black, uint32_t *cursor, bool aborted, uint32_t &finishedCount)
 {
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
 // needs about max(nodes, records) turns instead of their sum; a node visited before an earlier node's records have shortened the ray
 // may report a few children more (conservative: hits unchanged, visit counts a little above the sequential walk's).
 // (the kernel's body as a function of the workgroup's LDS objects: k_trace_closest_wide below and the tail kernel, k_tail, run it)
-template<bool COUNT, bool SOLIDS, bool INST, bool DECOUPLED, int NTS = PT_NT_STATE>
+template<bool COUNT, bool SOLIDS, bool INST, bool DECOUPLED, int NTS = PT_NT_TRAV>
 PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, BlockLds &L, uint32_t &fetchNext, int *ldsDyn)
 {
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
@@ -1018,7 +1018,7 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
 // vertex and regenerates their slots (finishBody, below), then traces its extension rays, the fresh camera rays among them -- one launch per
 // part and iteration less, and the streaming of the regeneration runs inside the issue-bound walk's launch.  The shim launches the stand-alone
 // k_finish only before a host check (the liveness report) and before k_tail.  Single-level scenes on the decoupled walk.
-template<int NTS = PT_NT_STATE>
+template<int NTS = PT_NT_TRAV>
 PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, unsigned short *order);
 template<bool COUNT, bool SOLIDS>
 __global__ WIDE_CLOSEST_BOUNDS void k_finish_trace_closest_wide(DeviceScene s, PathState st, PassParams pp)
@@ -1108,7 +1108,8 @@ PT_DEV void auxPostLoop(const DeviceScene &s, f3 dir, bool asked, int bounce, fl
 // (the kernel's body as a function of the workgroup's LDS objects: k_shade below and k_tail run it; returns whether the workgroup's
 // extension queues hold work -- the FUSE launches report it)
 // STAGED: sg's small tables are in LDS already (k_tail stages them once for all its iterations)
-template<uint32_t M, int FUSE, bool STAGED = false>
+// GLOBAL_TABLES: the scene's small tables do not fit the LDS copy (stageSceneTables): read them where they are
+template<uint32_t M, int FUSE, bool STAGED = false, bool GLOBAL_TABLES = false>
 PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassParams &pp, int cls, BlockLds &L, unsigned char *ldsTables, unsigned short *order)
 {
     // (the fused flat-list launches and k_tail -- STAGED -- re-read their slots within microseconds: no non-temporal hint there, pt_kernels.h)
@@ -1125,7 +1126,7 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
     queuesBegin(L, st, ctl, qIn, appendMask, order, qIn2, CONCURRENT);
     if (CONCURRENT && L.n == 0u)
         return false;                            // nothing of this class in the workgroup: no bitmap changes, nothing to write back
-    const DeviceScene s = STAGED ? sg : stageSceneTables(sg, ldsTables);
+    const DeviceScene s = (STAGED || GLOBAL_TABLES) ? sg : stageSceneTables(sg, ldsTables);
     const uint32_t first = blockIdx.x*st.slots_per_block;
     const int maxBounces = s.settings.max_bounces, minBounces = s.settings.min_bounces;
     // PT_EXP_HALF (a compile-only diagnostic, never the product): 1 = the kernel without the continuation sample, 2 = without next-event
@@ -1709,13 +1710,13 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
     }
     return anyExt;
 }
-template<uint32_t M, int W, int FUSE>
+template<uint32_t M, int W, int FUSE, bool GLOBAL_TABLES = false>
 __global__ __launch_bounds__(256, W) void k_shade(DeviceScene sg, PathState st, PassParams pp, int cls)
 {
     __shared__ BlockLds L;
-    __shared__ __attribute__((aligned(16))) unsigned char ldsTables[PT_LDS_TABLE_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char ldsTables[GLOBAL_TABLES ? 16u : PT_LDS_TABLE_BYTES];
     __shared__ unsigned short order[PT_MAX_SLOTS_PER_BLOCK];
-    (void)shadeBody<M, FUSE>(sg, st, pp, cls, L, ldsTables, order);
+    (void)shadeBody<M, FUSE, false, GLOBAL_TABLES>(sg, st, pp, cls, L, ldsTables, order);
 }
 
 // TraceBase::generalizedShadowRay (TraceBase.cpp:62-125) for the shadow rays queued by k_shade:
@@ -2350,7 +2351,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
 //     once the queue is dry, in the turn they finish), so their loads fly together and once per refill instead of once per turn;
 //   * the walk is the DECOUPLED one of k_trace_closest_wide: a pending record AND the next node per turn.
 // Same queues, same suspended-walk protocol (Q_HOLD), same results as k_trace_shadow_wide.
-template<bool COUNT, bool SOLIDS, int NTS = PT_NT_STATE>
+template<bool COUNT, bool SOLIDS, int NTS = PT_NT_TRAV>
 PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, uint32_t &fetchNext, int *ldsDyn)
 {
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);

@@ -49,6 +49,7 @@ extern template __global__ void k_shade<MASK_FULL, 2, 2>(DeviceScene, PathState,
 extern template __global__ void k_shade<(MASK_FULL | FEAT_QMC), 2, 2>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<BSDF_MASK_ALL, 2, 0>(DeviceScene, PathState, PassParams, int);
 extern template __global__ void k_shade<MASK_MEDIA, 2, 0>(DeviceScene, PathState, PassParams, int);   // shade_media.hip
+extern template __global__ void k_shade<BSDF_MASK_ALL, 2, 0, true>(DeviceScene, PathState, PassParams, int);   // shade_global.hip
 // k_tail: tail.hip
 extern template __global__ void k_tail<MASK_TAIL, false>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<MASK_TAIL, true>(DeviceScene, PathState, PassParams, uint32_t);
@@ -197,6 +198,7 @@ struct tghip_ctx {
                                           // FEAT_BUMP variant), never fused
     bool haveMedia = false;               // participating media: BSDF_MASK_ALL shading (the only FEAT_MEDIA variant), closest-hit shadow walk, never fused
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
+    bool tablesFit = true;                // objects + bsdfs + textures + light lists fit the shading workgroups' LDS copy (pt_kernels.h: stageSceneTables)
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
     int checkInterval = 0;                // "check_interval": wavefront iterations between host-side liveness checks; 0 = 16 for batches that refill
@@ -1181,6 +1183,13 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             envGuide.assign(guide.begin() + texGuide[size_t(o.emission)], guide.begin() + texGuide[size_t(o.emission)] + PT_GUIDE_MARGINAL + 1);
             envGuide.push_back(0);                            // padded to whole 32-bit words
         }
+        // do the small tables fit the shading workgroups' LDS copy (pt_kernels.h: stageSceneTables)?  Without the environment map's marginal
+        // tables they must, or the scene shades with the GLOBAL_TABLES variant; the marginal tables come along only when there is room
+        ctx->tablesFit = sceneTableLayout(sd->num_objects, sd->num_bsdfs, sd->num_textures, sd->num_lights, sd->num_infinite_lights, 0).total <= PT_LDS_TABLE_BYTES;
+        if (s.env_tex >= 0 && sceneTableLayout(sd->num_objects, sd->num_bsdfs, sd->num_textures, sd->num_lights, sd->num_infinite_lights, s.env_h).total > PT_LDS_TABLE_BYTES) {
+            s.env_tex = -1; s.env_h = 0; s.env_marginal = nullptr;      // (sampled through the texture's own tables in global memory, like any other bitmap)
+            envGuide.clear();
+        }
         if (envGuide.empty()) envGuide.assign(2, 0);
         if ((rc = uploadArray(ctx, ctx->sceneMem, envGuide.data(), envGuide.size(), &s.env_guide)) != TGHIP_OK) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the vectors go out of scope
@@ -1349,6 +1358,12 @@ template<uint32_t M, int FUSE>
 static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, const PassParams &pp, int cls)
 {
     constexpr uint32_t B = M & ~FEAT_QMC;
+    if (!ctx->tablesFit) {
+        // the scene's small tables do not fit the shading workgroups' LDS copy (pt_kernels.h: stageSceneTables): every class shades with the
+        // all-features variant that reads them from global memory (runBatch keeps such scenes off the fused and the tail launches)
+        hipLaunchKernelGGL((k_shade<BSDF_MASK_ALL, 2, 0, true>), dim3(grid), dim3(ctx->thrShadeAll), 0, ctx->launchStream, ctx->scene, st, pp, cls);
+        return;
+    }
     hipLaunchKernelGGL((k_shade<M, ((B == MASK_SIMPLE || B == MASK_SIMPLE_INST) ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
                        dim3((M == BSDF_MASK_ALL || M == MASK_MEDIA) ? ctx->thrShadeAll : (cls >= 1 && cls < PT_NUM_CLASSES) ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->launchStream, ctx->scene, st, pp, cls);
 }
@@ -1452,7 +1467,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = isFlat(ctx);
-    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->auxPass && !ctx->haveCylinder;
+    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->auxPass && !ctx->haveCylinder && ctx->tablesFit;
     const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
@@ -1518,7 +1533,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     }
     // k_tail runs the wide single-level kernels' bodies: scenes those kernels render, passes without visit counts (per-launch timing does
     // not see it: the few thousand rays it traces are in the counters, its one launch is in none of the three kernel classes)
-    const bool tailEligible = ctx->tailOpt && !flat && !ctx->haveInstances && wideClosest(ctx) && wideShadowRays(ctx) && ctx->decoupleOpt && !ctx->haveForward &&
+    const bool tailEligible = ctx->tailOpt && ctx->tablesFit && !flat && !ctx->haveInstances && wideClosest(ctx) && wideShadowRays(ctx) && ctx->decoupleOpt && !ctx->haveForward &&
                               (ctx->complexMask & TYPES_LATE) == 0 &&
                               !ctx->haveMeshLight && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder && !count && !st.records &&
                               st.slots_per_block <= PT_MAX_SLOTS_PER_BLOCK;
@@ -2034,7 +2049,7 @@ int tghip_wait(tghip_ctx *ctx)
         // the run-to-completion kernel (runBatch) gives every thread its own slots for the whole launch: one slot per
         // thread keeps the whole path state (112 B x 0.5 M slots) inside the Infinity Cache -- measured +5 % over four
         const bool flat = isFlat(ctx);
-        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->haveComplex && ctx->loopOpt && !ctx->auxPass && !ctx->haveCylinder;
+        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->haveComplex && ctx->loopOpt && !ctx->auxPass && !ctx->haveCylinder && ctx->tablesFit;
         if (loop && !ctx->maxSlotsSet)
             wantSlots = std::min<uint64_t>(wantSlots, uint64_t(launchGrid(ctx))*uint64_t(ctx->thrShadeSimple));
     }
