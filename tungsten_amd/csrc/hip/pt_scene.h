@@ -87,14 +87,31 @@ struct DeviceScene {
 // ---------------------------------------------------------------------------------------------
 // Textures (ConstantTexture, CheckerTexture.cpp:64-69, BitmapTexture.cpp:298-352)
 // ---------------------------------------------------------------------------------------------
+// One load whatever the format: three floats from the texel's address, a one-channel texture's value taken from the first (the shim leaves
+// 16 readable bytes behind the texel array).  With a branch per format around the load, the four texels of a bilinear lookup were four
+// SEQUENTIAL memory round trips -- each load inside its own divergent region, each followed by s_waitcnt vmcnt(0) -- in every shading variant
+// with bitmap textures; now the four loads are issued back to back (PT_TEXEL_BRANCH = 1 gives the old form back for the A/B).
+#ifndef PT_TEXEL_BRANCH
+#define PT_TEXEL_BRANCH 0
+#endif
+#ifndef PT_TEXEL_STAGES
+#define PT_TEXEL_STAGES 2
+#endif
 PT_DEV f3 bitmapTexel(const DeviceScene &s, const TgHipTexture &t, int x, int y)
 {
     const float *tex = s.texels + t.texel_offset;
+#if PT_TEXEL_BRANCH
     if (t.flags & TGHIP_TEXF_RGB) {
         const float *p = tex + ((size_t)x + (size_t)y*t.w)*3;
         return mk3(p[0], p[1], p[2]);
     }
     return splat3(tex[(size_t)x + (size_t)y*t.w]);
+#else
+    const bool rgb = (t.flags & TGHIP_TEXF_RGB) != 0;
+    const float *p = tex + ((size_t)x + (size_t)y*t.w)*(rgb ? 3u : 1u);
+    const float a = p[0], b = p[1], c = p[2];
+    return mk3(a, rgb ? b : a, rgb ? c : a);
+#endif
 }
 
 // i mod n for n > 0 and any i, result in [0, n): float-reciprocal quotient + fix-up instead of integer division
@@ -135,12 +152,51 @@ PT_DEV f3 textureEval(const DeviceScene &s, int texIdx, float u0, float v0)
         iu0 = min(max(iu0, 0), w - 1); iu1 = min(max(iu1, 0), w - 1);
         iv0 = min(max(iv0, 0), h - 1); iv1 = min(max(iv1, 0), h - 1);
     }
+#if PT_TEXEL_BRANCH
     if (!linear)
         return bitmapTexel(s, t, iu0, iv0);
+#else
+    // (a nearest-neighbour texture fetches its one texel four times -- one cache line -- instead of branching around three of the loads)
+    if (!linear) { iu1 = iu0; iv1 = iv0; }
+#endif
+#if PT_TEXEL_BRANCH
     f3 x00 = bitmapTexel(s, t, iu0, iv0), x01 = bitmapTexel(s, t, iu1, iv0);
     f3 x10 = bitmapTexel(s, t, iu0, iv1), x11 = bitmapTexel(s, t, iu1, iv1);
+#else
+    f3 x00, x01, x10, x11;
+    {
+        // the four texels as four 12-byte loads issued back to back and ONE wait: the empty asm below consumes all twelve words, so every load
+        // is issued before it and nothing that uses a texel is scheduled between the loads (left alone, the scheduler puts the format selects of
+        // each texel right behind its load -- a wait per load, four memory round trips per lookup)
+        const float *tex = s.texels + t.texel_offset;
+        const bool rgb = (t.flags & TGHIP_TEXF_RGB) != 0;
+        const uint32_t st = rgb ? 3u : 1u;
+        const float *p00 = tex + ((size_t)iu0 + (size_t)iv0*t.w)*st, *p01 = tex + ((size_t)iu1 + (size_t)iv0*t.w)*st;
+        const float *p10 = tex + ((size_t)iu0 + (size_t)iv1*t.w)*st, *p11 = tex + ((size_t)iu1 + (size_t)iv1*t.w)*st;
+#if PT_TEXEL_STAGES == 2
+        // (two stages: the two ROWS first -- two cache lines, two misses in flight --, then each row's neighbour, which is in the line that just
+        // arrived; all four at once made the headline 1.3 % slower: the neighbour's request goes to L2 again while its line is still on its way)
+        float a0 = p00[0], b0 = p00[1], c0 = p00[2], a2 = p10[0], b2 = p10[1], c2 = p10[2];
+        asm volatile("" : "+v"(a0), "+v"(b0), "+v"(c0), "+v"(a2), "+v"(b2), "+v"(c2));
+        float a1 = p01[0], b1 = p01[1], c1 = p01[2], a3 = p11[0], b3 = p11[1], c3 = p11[2];
+        asm volatile("" : "+v"(a1), "+v"(b1), "+v"(c1), "+v"(a3), "+v"(b3), "+v"(c3));
+#else
+        float a0 = p00[0], b0 = p00[1], c0 = p00[2], a1 = p01[0], b1 = p01[1], c1 = p01[2];
+        float a2 = p10[0], b2 = p10[1], c2 = p10[2], a3 = p11[0], b3 = p11[1], c3 = p11[2];
+        asm volatile("" : "+v"(a0), "+v"(b0), "+v"(c0), "+v"(a1), "+v"(b1), "+v"(c1), "+v"(a2), "+v"(b2), "+v"(c2), "+v"(a3), "+v"(b3), "+v"(c3));
+#endif
+        x00 = mk3(a0, rgb ? b0 : a0, rgb ? c0 : a0); x01 = mk3(a1, rgb ? b1 : a1, rgb ? c1 : a1);
+        x10 = mk3(a2, rgb ? b2 : a2, rgb ? c2 : a2); x11 = mk3(a3, rgb ? b3 : a3, rgb ? c3 : a3);
+    }
+#endif
     f3 r = (x00*(1.0f - u) + x01*u)*(1.0f - v) + (x10*(1.0f - u) + x11*u)*v;
+#if !PT_TEXEL_BRANCH
+    // (a select, not a branch: the interpolation is computed either way, so that the compiler cannot sink three of the four loads into it)
+    const f3 rs = r*t.scale;
+    return mk3(linear ? rs.x : x00.x, linear ? rs.y : x00.y, linear ? rs.z : x00.z);
+#else
     return r*t.scale;
+#endif
 }
 
 // Distribution2D::warp / pdf (sampling/Distribution2D.hpp:68-83) on the flattened tables

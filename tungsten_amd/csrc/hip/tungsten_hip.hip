@@ -256,9 +256,9 @@ struct tghip_ctx {
     } while (0)
 
 template<typename T, typename P>
-static int uploadArray(tghip_ctx *ctx, DeviceBuffers &mem, const T *src, size_t count, P *dst)   // P = (restrict-qualified) const T *
+static int uploadArray(tghip_ctx *ctx, DeviceBuffers &mem, const T *src, size_t count, P *dst, size_t padBytes = 0)   // P = (restrict-qualified) const T *
 {
-    size_t bytes = std::max<size_t>(count, 1)*sizeof(T);
+    size_t bytes = std::max<size_t>(count, 1)*sizeof(T) + padBytes;   // (padBytes: readable, uninitialised room behind the last element)
     void *p = nullptr;
     HIP_TRY(ctx, hipMalloc(&p, bytes));
     mem.allocs.push_back(p);
@@ -1056,7 +1056,8 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->infinite_lights, sd->num_infinite_lights, &s.infinite_lights)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->bsdfs, sd->num_bsdfs, &s.bsdfs)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->textures, sd->num_textures, &s.textures)) != TGHIP_OK) return rc;
-    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->texels, sd->num_texel_floats, &s.texels)) != TGHIP_OK) return rc;
+    // (16 bytes of room behind the texels: bitmapTexel reads three floats of a one-channel texture's texel too, pt_scene.h)
+    if ((rc = uploadArray(ctx, ctx->sceneMem, sd->texels, sd->num_texel_floats, &s.texels, 16)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->dist, sd->num_dist_floats, &s.dist)) != TGHIP_OK) return rc;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->light_tris, sd->num_light_tri_floats, &s.light_tris)) != TGHIP_OK) return rc;
     ctx->haveMeshLight = false;
