@@ -1028,6 +1028,33 @@ PT_DEV int wideNext(WideState &w, uint32_t octInv, uint2 *stack, int stride, uin
     return 2;
 }
 // The node half of wideNext alone (single-level scenes): the next node of the walk in `idx`, false when group and stack are empty.
+// PT_NEXT_NODE_FLAT = 1 (round 5): the same function with two one-instruction divergent regions (the stack's pop and push, LDS accesses) and selects
+// for the rest, instead of three nested branches whose exec-mask bookkeeping and copies were a tenth of the walk's turn.
+#ifndef PT_NEXT_NODE_FLAT
+#define PT_NEXT_NODE_FLAT 1
+#endif
+#if PT_NEXT_NODE_FLAT
+PT_DEV bool wideNextNode(WideState &w, uint32_t octInv, uint2 *stack, int stride, uint32_t &idx)
+{
+    const bool need = w.node < 0;                            // the next node comes from the group / the stack
+    const bool pop = need && (w.grpMasks & 0xFFu) == 0u && w.sp > 0;
+    if (pop) {                                               // (a stacked group always has hits left)
+        w.sp--;
+        const uint2 e = stack[w.sp*stride];
+        w.grpBase = e.x; w.grpMasks = e.y;
+    }
+    const uint32_t hits = w.grpMasks & 0xFFu, imask = w.grpMasks >> 8;
+    const bool have = need && hits != 0u;
+    const uint32_t slot = (((uint32_t)__ffs((int)hits) - 1u) ^ octInv) & 7u;
+    const uint32_t fromGroup = w.grpBase + (uint32_t)__popc(imask & ((1u << slot) - 1u));
+    const uint32_t rest = hits & (hits - 1u);
+    w.grpMasks = have ? ((imask << 8) | rest) : w.grpMasks;
+    if (have && rest != 0u) { stack[w.sp*stride] = make_uint2(w.grpBase, w.grpMasks); w.sp++; }
+    idx = need ? fromGroup : (uint32_t)w.node;
+    w.node = -1;
+    return !need || have;
+}
+#else
 PT_DEV bool wideNextNode(WideState &w, uint32_t octInv, uint2 *stack, int stride, uint32_t &idx)
 {
     if (w.node < 0) {
@@ -1049,6 +1076,7 @@ PT_DEV bool wideNextNode(WideState &w, uint32_t octInv, uint2 *stack, int stride
     w.node = -1;
     return true;
 }
+#endif
 // nothing left to look at: no record, no node, nothing on the stack
 PT_DEV bool wideWalkOver(const WideState &w) { return w.triMask == 0u && w.tri2Mask == 0u && w.node < 0 && (w.grpMasks & 0xFFu) == 0u && w.sp == 0; }
 // code 4: q1 = the second 16 bytes of node `idx`
