@@ -215,7 +215,7 @@ struct tghip_ctx {
     bool loopOpt = true;                  // "run_to_completion": fused flat-list scenes whose materials are all of class 0 render in ONE launch
     bool fuseFlatOpt = true;              // "fuse_flat": flat-list scenes without forward lobes trace + shadow-test inside k_shade
     // "suspend_lanes" / "suspend_turns" / "suspend_min_queue" (PathState::suspend_*): walk time-slicing of the wide traversal kernels
-    int suspendLanes = 16, suspendTurns = 16, suspendMinQueue = 1024;   // (measured, profiles/README.md: materialtest +0.5 %, mesh1m +4 %)
+    int suspendLanes = 12, suspendTurns = 16, suspendMinQueue = 1024;   // (measured, profiles/README.md: materialtest +0.5 %, mesh1m +4 % over none; round 5 on the final kernels, r5_sweep_final_kernels.txt: 12 lanes +0.5 % / +1 % over 16, 8 lanes +0.8 % / -3 %)
     int ldsNodesOpt = 0;                  // "lds_nodes": nodes of the top of the wide tree kept in LDS by those kernels (9 / 73 / 585 = two / three / four levels; measured: no gain)
     uint32_t numWideNodes = 0;
     int decoupleOpt = 1;                  // "decouple": the wide kernels of single-level scenes test a record AND visit a node per turn (k_trace_closest_wide<.., DECOUPLED>)
