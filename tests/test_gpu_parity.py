@@ -299,6 +299,28 @@ def test_lean_media_shading_variant_is_the_full_one(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "cornell_sun_sky", "cornell_skydome", "cornell_png_textures", "zoo_a", "cornell_fog", "cornell_instances", "materialtest", "cornell_mesh_light", "cornell_bump"])
+def test_table_placement_does_not_change_the_image(name, tmp_path):
+    """The shading kernels read objects / bsdfs / textures / light lists from an LDS copy (pt_kernels.h: stageSceneTables), the sampled environment
+    map's marginal tables included; a scene whose tables do not fit shades with the one GLOBAL_TABLES variant (every class, no fused and no tail
+    launches), and an environment map whose marginal tables do not fit is sampled through its global tables.  Options `lds_tables` = 0 and
+    `env_lds` = 0 force those two paths on scenes that do fit: the same image bit for bit, the same rays."""
+    _skip_mt(name)
+    if name in scenes.GOLDEN_CASES:
+        mk, kw = scenes.GOLDEN_CASES[name]
+        path = mk(tmp_path, name=name + ".json", **dict(kw, resolution=(160, 90)))
+    else:
+        path = getattr(scenes, name)(tmp_path, resolution=(160, 90), spp=8)
+    base, _, cb, kb = gpu_render(path)
+    assert np.isfinite(base).all()
+    for opts in (dict(lds_tables=0), dict(env_lds=0), dict(lds_tables=0, env_lds=0)):
+        img, _, c, k = gpu_render(path, **opts)
+        assert (c == cb).all(), opts
+        assert (img == base).all(), "image changed with %r" % (opts,)
+        assert (k.closest_rays, k.shadow_rays, k.samples) == (kb.closest_rays, kb.shadow_rays, kb.samples), opts
+
+
+@pytest.mark.gpu
 def test_tail_kernel_traces_the_rays_the_loop_traces(tmp_path):
     """k_tail (one launch per part in which every workgroup iterates over its own slots) against the launch-per-step loop: the same image,
     the same samples, the same closest-hit and shadow rays -- entered at the first host check, and half way through the render."""

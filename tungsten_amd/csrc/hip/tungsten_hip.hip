@@ -199,6 +199,8 @@ struct tghip_ctx {
     bool haveMedia = false;               // participating media: BSDF_MASK_ALL shading (the only FEAT_MEDIA variant), closest-hit shadow walk, never fused
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
     bool tablesFit = true;                // objects + bsdfs + textures + light lists fit the shading workgroups' LDS copy (pt_kernels.h: stageSceneTables)
+    bool tablesFitScene = true;           // ... as decided at upload; "lds_tables" = 0 shades as if they did not (the GLOBAL_TABLES variant: tests)
+    int envTexScene = -1;                 // the sampled environment map whose marginal tables ride in LDS; "env_lds" = 0 samples it through its global tables
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
     int checkInterval = 0;                // "check_interval": wavefront iterations between host-side liveness checks; 0 = 16 for batches that refill
@@ -888,6 +890,8 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "rotate_streams") ctx->rotateStreamsOpt = value != 0;
     else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
     else if (k == "top_tree") ctx->topTreeOpt = value != 0;
+    else if (k == "lds_tables") ctx->tablesFit = ctx->tablesFitScene && value != 0;
+    else if (k == "env_lds") ctx->scene.env_tex = value != 0 ? ctx->envTexScene : -1;
     else if (k == "media_lean") ctx->mediaLeanOpt = value != 0;
     else if (k == "tail_threshold") ctx->tailThreshold = value;
     else if (k == "lds_nodes") ctx->ldsNodesOpt = int(std::min<long long>(std::max<long long>(value, 0), 585));
@@ -1191,6 +1195,8 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             s.env_tex = -1; s.env_h = 0; s.env_marginal = nullptr;      // (sampled through the texture's own tables in global memory, like any other bitmap)
             envGuide.clear();
         }
+        ctx->tablesFitScene = ctx->tablesFit;
+        ctx->envTexScene = s.env_tex;
         if (envGuide.empty()) envGuide.assign(2, 0);
         if ((rc = uploadArray(ctx, ctx->sceneMem, envGuide.data(), envGuide.size(), &s.env_guide)) != TGHIP_OK) return rc;
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the vectors go out of scope
