@@ -55,6 +55,8 @@ extern template __global__ void k_tail<MASK_TAIL, false>(DeviceScene, PathState,
 extern template __global__ void k_tail<MASK_TAIL, true>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<(MASK_TAIL | FEAT_QMC), false>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<(MASK_TAIL | FEAT_QMC), true>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_tail<MASK_COAT, false>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_tail<(MASK_COAT | FEAT_QMC), false>(DeviceScene, PathState, PassParams, uint32_t);
 
 // =============================================================================================
 // Host-side shim
@@ -198,6 +200,7 @@ struct tghip_ctx {
                                           // FEAT_BUMP variant), never fused
     bool haveMedia = false;               // participating media: BSDF_MASK_ALL shading (the only FEAT_MEDIA variant), closest-hit shadow walk, never fused
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
+    bool tailFamilyOpt = true;            // "tail_family": k_tail<MASK_COAT> for scenes without class-2 / class-3 materials and without solids
     bool tablesFit = true;                // objects + bsdfs + textures + light lists fit the shading workgroups' LDS copy (pt_kernels.h: stageSceneTables)
     bool tablesFitScene = true;           // ... as decided at upload; "lds_tables" = 0 shades as if they did not (the GLOBAL_TABLES variant: tests)
     int envTexScene = -1;                 // the sampled environment map whose marginal tables ride in LDS; "env_lds" = 0 samples it through its global tables
@@ -886,6 +889,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "inst_shadow_join") ctx->instShadowJoin = value != 0;
     else if (k == "fail_reduce") ctx->failReduce = value != 0;   // fault injection: tghip_reduce_framebuffers with this context as a rank fails (the hosts' fallbacks are tested with it)
     else if (k == "tail_kernel") ctx->tailOpt = value != 0;
+    else if (k == "tail_family") ctx->tailFamilyOpt = value != 0;
     else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
     else if (k == "rotate_streams") ctx->rotateStreamsOpt = value != 0;
     else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
@@ -1550,6 +1554,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     bool tailFits = false;
     if (tailEligible) {
         int nb = 0;
+        // (the conductor-family tail, tailCoat below, needs no more than the all-types one)
         const void *fn = pp.flags ? (ctx->haveSolids ? reinterpret_cast<const void *>(k_tail<(MASK_TAIL | FEAT_QMC), true>) : reinterpret_cast<const void *>(k_tail<(MASK_TAIL | FEAT_QMC), false>))
                                   : (ctx->haveSolids ? reinterpret_cast<const void *>(k_tail<MASK_TAIL, true>) : reinterpret_cast<const void *>(k_tail<MASK_TAIL, false>));
         tailFits = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, wideLdsBytes(ctx, 256)) == hipSuccess && nb >= 1;
@@ -1713,7 +1718,10 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                     if (k) HIP_TRY(ctx, hipStreamWaitEvent(stream, ctx->evMain, 0));   // (after the main stream's check above)
                     else if (split) HIP_TRY(ctx, hipEventRecord(ctx->evMain, ctx->stream));
 #define TAIL_LAUNCH(M, S) hipLaunchKernelGGL((k_tail<M, S>), dim3(grid/parts), dim3(256), ldsTail, stream, s, sp, ppk, classes)
-                    if (pp.flags) { if (ctx->haveSolids) TAIL_LAUNCH((MASK_TAIL | FEAT_QMC), true); else TAIL_LAUNCH((MASK_TAIL | FEAT_QMC), false); }
+                    // scenes of Lambert / null and conductor-family materials only (the metric's): the narrower instantiation, "tail_family" = 0 for the A/B
+                    const bool tailCoat = ctx->tailFamilyOpt && !ctx->haveSolids && !ctx->classPresent[2] && !ctx->classPresent[3];
+                    if (tailCoat) { if (pp.flags) TAIL_LAUNCH((MASK_COAT | FEAT_QMC), false); else TAIL_LAUNCH(MASK_COAT, false); }
+                    else if (pp.flags) { if (ctx->haveSolids) TAIL_LAUNCH((MASK_TAIL | FEAT_QMC), true); else TAIL_LAUNCH((MASK_TAIL | FEAT_QMC), false); }
                     else          { if (ctx->haveSolids) TAIL_LAUNCH(MASK_TAIL, true); else TAIL_LAUNCH(MASK_TAIL, false); }
 #undef TAIL_LAUNCH
                 }
