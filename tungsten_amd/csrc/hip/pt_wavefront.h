@@ -740,6 +740,10 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
         } \
     } while (0)
 #endif
+// busy lanes at or below which a wave of the decoupled walks takes new rays from its workgroup's queue (swept in round 5, r5_sweep_final_kernels.txt: 24 / 32 / 40 / 48 / 56 -- 40 is the shadow walk's optimum, the closest-hit walk is level between 40 and 48)
+#ifndef PT_REFILL_AT
+#define PT_REFILL_AT 40
+#endif
 // DECOUPLED (single-level scenes): a turn tests the lane's next pending record AND visits its next node -- the walk does not wait for
 // the records of the node visited last before it moves on (their outcome only tightens tmax, never what is visited next), so a ray
 // needs about max(nodes, records) turns instead of their sum; a node visited before an earlier node's records have shortened the ray
@@ -788,7 +792,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             // Finished walks publish their hit -- and bin their path by the shading class of the record hit, a dependent load -- together,
             // right before the lanes are refilled (once the queue is dry: in the turn they finish): one memory round trip per refill
             // instead of one in nearly every turn, sat out by the whole wave.
-            if (((!exhausted && __popcll(busyMask) <= 48) || exhausted) && __ballot(pendingPublish) != 0ull) {
+            if (((!exhausted && __popcll(busyMask) <= PT_REFILL_AT) || exhausted) && __ballot(pendingPublish) != 0ull) {
                 if (pendingPublish) {
                     slotF4<NTS>(st, A_HIT, slot) = hit;
                     const int ri = __float_as_int(hit.w);
@@ -798,7 +802,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                 }
             }
         }
-        if (!exhausted && __popcll(busyMask) <= 48) {
+        if (!exhausted && __popcll(busyMask) <= PT_REFILL_AT) {
             unsigned long long want = ~busyMask;
             uint32_t lane = laneId();
             uint32_t base = 0;
@@ -2424,7 +2428,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
     WALK_PROF_DECL;
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
-        const bool refill = !exhausted && __popcll(busyMask) <= 48;
+        const bool refill = !exhausted && __popcll(busyMask) <= PT_REFILL_AT;
         if ((refill || exhausted) && __ballot(pendingFinish) != 0ull) {
             if (pendingFinish) {
                 // NEE term -> path radiance; paths that ended at this vertex go on the finished list
