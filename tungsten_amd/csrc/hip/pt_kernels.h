@@ -1173,7 +1173,8 @@ PT_DEV void wideNodeFetchRest(WideNodeRegs &n, const char *base, uint32_t off, c
 // The node's 80 bytes have arrived: slab-test its eight children against [tmin, tmax], queue the hit ones.  Two children per
 // v_pk_fma_f32; each half is one correctly rounded fma, as in the oracle's scalar fmaf.
 typedef float WideF2 __attribute__((ext_vector_type(2)));
-PT_DEV void wideVisit(WideState &w, const WideNodeRegs &nd, f3 o, const WideRay &wr, float tmin, float tmax)
+// skip (wave-uniform): records named in the node's `reserved` word are not queued (the scene's hoisted quad, DeviceScene::hoisted_rec)
+PT_DEV void wideVisit(WideState &w, const WideNodeRegs &nd, f3 o, const WideRay &wr, float tmin, float tmax, bool skip = false)
 {
     const float4 q0 = nd.q0, q1 = nd.q1;
     const uint32_t ex = __float_as_uint(q0.w);
@@ -1238,6 +1239,7 @@ PT_DEV void wideVisit(WideState &w, const WideNodeRegs &nd, f3 o, const WideRay 
     w.triBase = __float_as_uint(q1.y);
     w.triValid = __float_as_uint(q1.z);
     w.triMask = x & w.triValid;
+    w.triMask &= ~(skip ? __float_as_uint(q1.w) : 0u);
 }
 // ---- suspended walks (PathState::suspend_*) -------------------------------------------------------------------------
 // The flag that a queued ray / shadow slot is a suspended walk is the sign bit of its tmin word (A_RAY_O.w / A_SH_O.w: 1e-4, 5e-4 or 0).

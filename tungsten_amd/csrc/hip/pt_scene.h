@@ -35,6 +35,12 @@ struct DeviceScene {
     const float2 * __restrict__ rows;
     const int32_t * __restrict__ tex_rows;
     int32_t env_tex, env_h;
+    // The scene's ONE quad, in a scene of triangles otherwise (a ground plane under meshes: the metric's scene), or -1.  The decoupled walks test
+    // it once per ray before the walk and skip it inside (its bit in the `reserved` word of the wide node that holds it, set by the shim):
+    // nearly every turn of a wave used to run the quad test -- a dependent load of the quad's normal, a division -- for the one or two lanes
+    // that happened to be at that record.  Same hit: a quad accepts t <= tmax and a triangle t < tmax, so the quad wins a tie whichever is
+    // tested first; with two quads the order between THEM would matter, hence exactly one (tungsten_hip.hip: hoistedRec).
+    int32_t hoisted_rec;
     const float *env_marginal;
     const uint16_t *env_guide;
     const uint32_t * __restrict__ sobol;       // Sobol' generator matrices (nullptr unless the scene carries them)

@@ -826,6 +826,13 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                         wideStart(w);
                         tmax = ray.tmax;
                         hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+                        if constexpr (DECOUPLED && !INST) {
+                            if (s.hoisted_rec >= 0) {            // the scene's one quad, before the walk (DeviceScene::hoisted_rec; uniform loads)
+                                uint32_t meta;
+                                if (COUNT) prims++;
+                                (void)testRecord<true, KIND_BIT(TGHIP_REC_QUAD)>(s, (uint32_t)s.hoisted_rec, ray, tmax, hit, meta);
+                            }
+                        }
                         rays++;
                     } else {
                         walkRestore(st, slot, w, stack, stride);
@@ -893,7 +900,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             if (hasNode) {
                 if (COUNT) nodes++;
                 const uint32_t ob = w.triBase, om = w.triMask, ov = w.triValid;
-                wideVisit(w, nd, ray.o, wr, ray.tmin, tmax);
+                wideVisit(w, nd, ray.o, wr, ray.tmin, tmax, s.hoisted_rec >= 0);
                 if (om) { w.tri2Base = w.triBase; w.tri2Mask = w.triMask; w.tri2Valid = w.triValid; w.triBase = ob; w.triMask = om; w.triValid = ov; }
             }
             if (busy && wideWalkOver(w)) {       // (in the turn that looked at the walk's last record / node)
@@ -2410,6 +2417,14 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         }
         contrib = xyz(c);
         ray.o = so; ray.d = xyz(sd); ray.tmin = eps; ray.tmax = sd.w;
+        if (!resume && s.hoisted_rec >= 0) {     // the scene's one quad, before the walk (DeviceScene::hoisted_rec): occluded by it, the ray adds nothing
+            float tq = ray.tmax;
+            float4 hq;
+            uint32_t meta;
+            if (COUNT) prims++;
+            if (testRecord<true, KIND_BIT(TGHIP_REC_QUAD)>(s, (uint32_t)s.hoisted_rec, ray, tq, hq, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                return false;
+        }
         wr = wideRaySetup(ray);
         if (!resume) wideStart(w);
         return true;
@@ -2542,7 +2557,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
             if (!rayDone && hasNode) {
                 if (COUNT) nodes++;
                 const uint32_t ob = w.triBase, om = w.triMask, ov = w.triValid;
-                wideVisit(w, nd, ray.o, wr, ray.tmin, ray.tmax);
+                wideVisit(w, nd, ray.o, wr, ray.tmin, ray.tmax, s.hoisted_rec >= 0);
                 if (om) { w.tri2Base = w.triBase; w.tri2Mask = w.triMask; w.tri2Valid = w.triValid; w.triBase = ob; w.triMask = om; w.triValid = ov; }
             }
             if (!rayDone && wideWalkOver(w)) {

@@ -200,9 +200,11 @@ struct tghip_ctx {
                                           // FEAT_BUMP variant), never fused
     bool haveMedia = false;               // participating media: BSDF_MASK_ALL shading (the only FEAT_MEDIA variant), closest-hit shadow walk, never fused
     bool haveInstances = false;           // instance records: two-level traversal kernels (INST), MASK_FULL shading, never the flat list
+    bool hoistOpt = true;                 // "hoist_quad": the scene's one quad tested before the decoupled walks instead of inside them (at the next upload)
     bool tailFamilyOpt = true;            // "tail_family": k_tail<MASK_COAT> for scenes without class-2 / class-3 materials and without solids
     bool tablesFit = true;                // objects + bsdfs + textures + light lists fit the shading workgroups' LDS copy (pt_kernels.h: stageSceneTables)
     bool tablesFitScene = true;           // ... as decided at upload; "lds_tables" = 0 shades as if they did not (the GLOBAL_TABLES variant: tests)
+    int hoistedRecScene = -1;             // DeviceScene::hoisted_rec as decided at upload ("hoist_quad" switches it at run time: the skip word stays in the node)
     int envTexScene = -1;                 // the sampled environment map whose marginal tables ride in LDS; "env_lds" = 0 samples it through its global tables
     bool leanScene = false;               // no bitmap texture, no infinite light, <= 1 sampled light, no triangles: k_shade<MASK_LEAN>
     bool countTraversal = false;
@@ -890,6 +892,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "fail_reduce") ctx->failReduce = value != 0;   // fault injection: tghip_reduce_framebuffers with this context as a rank fails (the hosts' fallbacks are tested with it)
     else if (k == "tail_kernel") ctx->tailOpt = value != 0;
     else if (k == "tail_family") ctx->tailFamilyOpt = value != 0;
+    else if (k == "hoist_quad") { ctx->hoistOpt = value != 0; if (!ctx->hoistOpt) ctx->scene.hoisted_rec = -1; else ctx->scene.hoisted_rec = ctx->hoistedRecScene; }
     else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
     else if (k == "rotate_streams") ctx->rotateStreamsOpt = value != 0;
     else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
@@ -1007,6 +1010,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->nodes, sd->num_nodes, &dn)) != TGHIP_OK) return rc;
     ctx->wideDepth = 0;
     ctx->numWideNodes = 0;
+    s.hoisted_rec = -1; ctx->hoistedRecScene = -1;
     if (sd->wide_nodes && sd->num_wide_nodes) {
         // the wide nodes and the primitive records share ONE allocation, so that a lane of the wide kernels addresses
         // "a node or a record" with one base pointer and one 32-bit offset
@@ -1046,6 +1050,37 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             HIP_TRY(ctx, hipMemcpy2DAsync(p, stride, sd->wide_nodes, sizeof(TgHipWideNode), sizeof(TgHipWideNode), sd->num_wide_nodes, hipMemcpyHostToDevice, ctx->stream));
 #endif
             HIP_TRY(ctx, hipMemcpyAsync(p + nodeBytes, sd->recs, size_t(sd->num_recs)*sizeof(TgHipPrimRec), hipMemcpyHostToDevice, ctx->stream));
+            // The scene's one quad, hoisted out of the decoupled walks (pt_scene.h: DeviceScene::hoisted_rec): a single-level scene of triangles and
+            // exactly ONE quad whose wide nodes leave `reserved` zero.  The wide node that holds the quad as a leaf record gets the record's bit of
+            // leaf_valid in its `reserved` word -- on the device copy only; the sequential walks (tghip_trace_rays, "decouple" = 0) do not read it.
+            s.hoisted_rec = -1; ctx->hoistedRecScene = -1;
+            if (!PT_WIDE_HALF && sd->num_instances == 0) {
+                int64_t quad = -1;
+                bool ok = true;
+                for (uint32_t i = 0; i < sd->num_recs && ok; ++i) {
+                    const uint32_t kind = TGHIP_REC_KIND(sd->recs[i].meta);
+                    if (kind == TGHIP_REC_QUAD) { ok = quad < 0; quad = i; }
+                    else if (kind != TGHIP_REC_TRIANGLE) ok = false;
+                }
+                int64_t node = -1;
+                uint32_t bit = 0;
+                for (uint32_t i = 0; i < sd->num_wide_nodes && ok && quad >= 0; ++i) {
+                    const TgHipWideNode &n = sd->wide_nodes[i];
+                    if (n.reserved != 0u) ok = false;
+                    uint32_t rank = 0;
+                    for (uint32_t b = 0; b < 32u; ++b)
+                        if ((n.leaf_valid >> b) & 1u) {
+                            if (int64_t(n.rec_base) + rank == quad) { ok = ok && node < 0; node = i; bit = b; }
+                            ++rank;
+                        }
+                }
+                if (ok && quad >= 0 && node >= 0) {
+                    const uint32_t word = 1u << bit;
+                    HIP_TRY(ctx, hipMemcpy(p + size_t(node)*stride + offsetof(TgHipWideNode, reserved), &word, sizeof(word), hipMemcpyHostToDevice));
+                    s.hoisted_rec = ctx->hoistOpt ? int32_t(quad) : -1;
+                    ctx->hoistedRecScene = int32_t(quad);
+                }
+            }
             s.wide = reinterpret_cast<const float4 *>(p);
             s.recs_offset = uint32_t(nodeBytes);
             s.wide_stride = uint32_t(stride);
