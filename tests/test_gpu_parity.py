@@ -321,6 +321,23 @@ def test_table_placement_does_not_change_the_image(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["materialtest", "mesh1m"])
+def test_hoisted_quad_does_not_change_the_image(name, tmp_path):
+    """A scene of triangles with exactly one quad (the ground plane of materialtest and mesh1m): the decoupled walks test the quad once per ray before
+    the walk and skip it inside (DeviceScene::hoisted_rec); option `hoist_quad` = 0 leaves it in the walk.  A quad accepts t <= tmax and a triangle
+    t < tmax, so the quad wins a tie whichever is tested first: the same image bit for bit, the same rays -- on the loop and on the tail kernel."""
+    _skip_mt(name)
+    path = getattr(scenes, name)(tmp_path, resolution=(320, 180), spp=8)
+    base, _, cb, kb = gpu_render(path, hoist_quad=0)
+    assert np.isfinite(base).all()
+    for opts in (dict(hoist_quad=1), dict(hoist_quad=1, tail_kernel=1, tail_threshold=1 << 30), dict(hoist_quad=1, suspend_lanes=64, suspend_turns=2, suspend_min_queue=0)):
+        img, _, c, k = gpu_render(path, **opts)
+        assert (c == cb).all(), opts
+        assert (img == base).all(), "image changed with %r" % (opts,)
+        assert (k.closest_rays, k.shadow_rays, k.samples) == (kb.closest_rays, kb.shadow_rays, kb.samples), opts
+
+
+@pytest.mark.gpu
 def test_tail_kernel_traces_the_rays_the_loop_traces(tmp_path):
     """k_tail (one launch per part in which every workgroup iterates over its own slots) against the launch-per-step loop: the same image,
     the same samples, the same closest-hit and shadow rays -- entered at the first host check, and half way through the render."""
