@@ -51,6 +51,11 @@ extern template __global__ void k_shade<BSDF_MASK_ALL, 2, 0>(DeviceScene, PathSt
 extern template __global__ void k_shade<MASK_MEDIA, 2, 0>(DeviceScene, PathState, PassParams, int);   // shade_media.hip
 extern template __global__ void k_shade<BSDF_MASK_ALL, 2, 0, true>(DeviceScene, PathState, PassParams, int);   // shade_global.hip
 // k_tail: tail.hip
+// walk_shadow.hip (compiled without SLP vectorisation)
+extern template __global__ void k_trace_shadow_fast<false, false>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_trace_shadow_fast<false, true>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_trace_shadow_fast<true, false>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_trace_shadow_fast<true, true>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<MASK_TAIL, false>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<MASK_TAIL, true>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<(MASK_TAIL | FEAT_QMC), false>(DeviceScene, PathState, PassParams, uint32_t);
