@@ -31,7 +31,7 @@ HOSTFLAGS:= -std=c++11 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-par
 # against 2 x 2.0 for the scalar pair, plus the v_mov that put operands side by side -- and the packing costs registers: the shadow walk 119 -> 98
 # VGPRs (five waves per SIMD instead of four), k_shade's conductor-family variant 43 -> 0 spilled registers.  Same IEEE operations either way.
 # Metric's workload +3.5 %, mesh1m +2 %, instances10k +1.8 %, Cornell box +0.9 % (profiles/r5_ab_no_slp.txt).  SLP=1 gives the vectoriser back.
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC $(FPFLAGS) $(if $(SLP),,-fno-slp-vectorize) -Wno-unused-result $(if $(PROFILE),-DPT_PROFILE,) $(VARFLAGS)
+HIPFLAGS := --offload-arch=$(ARCH) $(if $(HIPOPT),$(HIPOPT),-O3) -std=c++17 -fPIC $(FPFLAGS) $(if $(SLP),,-fno-slp-vectorize) -Wno-unused-result $(if $(PROFILE),-DPT_PROFILE,) $(VARFLAGS)
 
 all: $(LIBDIR)/$(LIBNAME) $(if $(PROFILE)$(VARIANT),,$(LIBDIR)/tungsten_hip oracle/liboracle.so oracle/libm_host.so)
 

@@ -697,8 +697,13 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
 // Dynamic LDS: [expanded queue, 2 B per slot][group stacks, wideDepth x 8 B per thread].
 // INST: the scene has instance records -- the walk enters the masters' wide subtrees (pt_kernels.h: wideEnterInstance); the
 // instance a hit was reached through goes to the spare word A_EMI.w, as k_trace_closest<.., INST> leaves it.
+// (five waves per SIMD: without SLP vectorisation the closest-hit walk fits 96 VGPRs with five spilled registers outside its loop -- 811 -> 768 us per
+// launch, metric's workload +0.9 %, mesh1m +1 %, profiles/r5_sweep_final_kernels.txt; PT_CLOSEST_WAVES = 4 for the A/B)
+#ifndef PT_CLOSEST_WAVES
+#define PT_CLOSEST_WAVES 5
+#endif
 #ifndef WIDE_CLOSEST_BOUNDS
-#define WIDE_CLOSEST_BOUNDS __launch_bounds__(512)
+#define WIDE_CLOSEST_BOUNDS __launch_bounds__(512, PT_CLOSEST_WAVES)
 #endif
 #ifndef WIDE_SHADOW_BOUNDS
 #define WIDE_SHADOW_BOUNDS __launch_bounds__(512, 4)   /* (with whole-vector slot loads the shadow walk wants 129 VGPRs: held to the 128 of 4 waves/SIMD) */
