@@ -528,7 +528,11 @@ enum { TGHIP_LIBM_SINF = 0, TGHIP_LIBM_COSF = 1, TGHIP_LIBM_LOGF = 2, TGHIP_LIBM
        TGHIP_LIBM_EMBREE_RCP = 10, TGHIP_LIBM_RCPPS = 11, TGHIP_LIBM_TANF = 12 };
 int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ...; "top_tree" = 0 before an upload:
-                                                                             TgHipSceneDesc::top_nodes is ignored, flat lists are walked in record order */
+                                                                             TgHipSceneDesc::top_nodes is ignored, flat lists are walked in record order.
+                                                                             Instrumentation that never changes an image (tests hold that): "lds_tables" = 0
+                                                                             shades as if the small tables did not fit the LDS copy, "env_lds" = 0 samples the
+                                                                             environment map through its global tables, "hoist_quad" = 0 leaves a scene's one
+                                                                             quad inside the walks, "tail_family" = 0 runs the all-types tail kernel */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);
 int tghip_reset_counters(tghip_ctx *ctx);
 
