@@ -204,7 +204,7 @@ PT_DEV char *slotBase(const PathState &st, uint32_t a) { return PT_RECORDS(st) ?
 #endif
 #ifndef PT_SLOT_EXTLOAD
 #define PT_SLOT_EXTLOAD 1     /* the plain loads of the hinted kernels as ONE 16-byte vector load each (0: through float4, which the compiler narrows to
-                                 global_load_dwordx3 where a kernel does not use the last word -- measured slower, wideRow below) */
+                                 global_load_dwordx3 where a kernel does not use the last word -- the kernels measured slower, wideRow below) */
 #endif
 #ifndef PT_NT_OTHER
 #define PT_NT_OTHER 0         /* the kernels that do not pass NT explicitly (flat lists, BVH2 and two-level walks, the sequential wide walks, resolve) */
@@ -1148,7 +1148,7 @@ PT_DEV void wideNodeFetchRest(WideNodeRegs &n, const char *base, uint32_t off, c
 #define PT_WIDE_NODE_BYTES 80u
 struct WideNodeRegs { float4 q0, q1, q2, q3, q4; };
 // (a 16-byte row is loaded as ONE vector: read through float4 the compiler narrows the row whose last word the walk does not use -- child base,
-// record base, leaf_valid, - -- to a global_load_dwordx3, and a lane's 12-byte load costs the walk more than the 16-byte one: PT_ROW_X4 = 0 for the A/B)
+// record base, leaf_valid, - -- to a global_load_dwordx3, and the walk built around the 12-byte load is the slower one (pt_math.h: ld4): PT_ROW_X4 = 0 for the A/B)
 #ifndef PT_ROW_X4
 #define PT_ROW_X4 1
 #endif

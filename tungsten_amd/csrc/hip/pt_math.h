@@ -36,8 +36,9 @@ template<typename T> PT_DEV const T &at32(const T *base, uint32_t idx)
 }
 
 // A float4 table entry read as ONE 16-byte vector load.  Read through `const float4 &` the compiler drops the words a kernel does not use and
-// issues global_load_dwordx3 / x2 instead; a lane's 12-byte load is the slower one on gfx950 (measured on the wide nodes' second row: shadow
-// launches -2 %, profiles/r5_ab_x4_loads.txt).  PT_LD4 = 0 gives the narrowed loads back (A/B).
+// issues global_load_dwordx3 / x2 instead.  In isolation the narrow load costs what the wide one costs (tools/ubench_loads.hip), but the kernels
+// built around it are slower -- a three-register destination, the copies behind it, the schedule (measured on the wide nodes' second row: shadow
+// launches -2 %; on the slots: -6.5 %, profiles/r5_ab_x4_loads.txt).  PT_LD4 = 0 gives the narrowed loads back (A/B).
 #ifndef PT_LD4
 #define PT_LD4 1
 #endif
