@@ -14,14 +14,15 @@ Workload at every N: the configuration BASELINE.json's metric is quoted on -- ma
 scene: three meshes, 80 768 triangles, smooth_coat over rough_conductor, HDRI environment + MIS) at 1280x720, 256 spp,
 uniform sampler, adaptive sampling off (fixed total work => "scaling": "strong").  At N = 1 the same line carries, under
 "extra", BASELINE configs[1] (Cornell box 1280x720 at 256 spp, a flat-list scene without BVH traversal) and materialtest as the reference ships it (Sobol + adaptive, 64 spp in 16-spp passes); `--scene cornell`
-makes that the headline workload instead.  Without the materialtest assets (oracle/_ref/data, copied from the reference's
+makes that the headline workload instead.  Without the materialtest assets (assets/, copied from the reference's
 data directory by __graft_entry__.build()) the default run FAILS: there is no silent fallback to another workload.
 
-Prints ONE JSON line (rank 0).  `roofline` describes the kernel CLASS with the largest accumulated time (k_shade on the
-headline workload): achieved = algorithmic bytes per launch / average launch duration, both from the timed region (HIP events
-recorded by the shim on the stream the kernels run on; byte model in DESIGN.md section 5).  `roofline.traversal` holds the
-same for the traversal kernel BASELINE.json's metric names, `roofline.exclusive` the figures of every class with the chip to
-itself (one part on one stream), `roofline.valu` the loop's VALU issue line, plain and priced per instruction category.  `cpu_baseline`
+Prints ONE JSON line (rank 0).  `roofline` describes the traversal kernel BASELINE.json's metric names (the traversal class with the
+largest accumulated time; flat-list scenes: their one fused kernel): achieved = algorithmic bytes per launch / average launch duration,
+both from the timed region (HIP events recorded by the shim on the stream the kernels run on; byte model in DESIGN.md section 5).
+`roofline.dominant_class` holds the same for the class with the largest accumulated time of any kind (k_shade on the headline workload),
+`roofline.exclusive` the figures of every class with the chip to itself (one part on one stream), `roofline.valu` the loop's VALU issue
+line, plain and priced per instruction category, with the enabled lanes per issued instruction and the walks' turn tallies.  `cpu_baseline`
 times the reference itself (oracle/_ref/tungsten, kind "reference") or, when that binary is absent, the
 oracle port, on a bounded sample of the same workload on this box's host cores.
 """
@@ -38,7 +39,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MAX_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max engine clock
@@ -116,7 +116,7 @@ def kernel_bytes(c, flat, fused, node_b=64, node_b_shadow=None, fold_finish=Fals
 
 
 def as_shipped(tmp, tg_mod, repeats=3):
-    import scenes
+    from tungsten_amd import workloads as scenes
     path = scenes.materialtest(tmp, name="as_shipped.json", resolution=(1280, 720), spp=64, spp_step=16,
                                renderer={"adaptive_sampling": True, "stratified_sampler": True})
     best = None
@@ -132,6 +132,23 @@ def as_shipped(tmp, tg_mod, repeats=3):
         if best is None or res["seconds"] < best["seconds"]:
             best = res
     return best
+
+
+def walk_summary(t):
+    """tghip_get_walk_stats of one decoupled walk (the counting variants' tallies, include/tungsten_hip.h) -> what a ray costs in loop turns and
+    how many of a wave's 64 lanes have work in each section of a turn.  A section's instructions are issued for the whole wave whenever ANY lane
+    needs it: `lanes_per_run` / 64 is the section's lane utilisation, `runs_per_turn` how often a turn pays for it."""
+    turns = t[5] + t[6]
+    rays = max(t[21] + t[10], 1)          # walks started + walks resumed
+    def sec(runs, lanes):
+        return {"runs_per_turn": round(runs/max(turns, 1), 4), "lanes_per_run": round(lanes/max(runs, 1), 2), "utilisation": round(lanes/max(runs, 1)/64.0, 4)}
+    return {"wave_launches": t[4], "turns_per_wave_launch": round(turns/max(t[4], 1), 2), "turns_after_queue_dry": round(t[6]/max(turns, 1), 4),
+            "busy_lanes_per_turn": round((t[7] + t[8])/max(turns, 1), 2), "rays": t[21], "walks_resumed": t[10],
+            "turns_per_ray": round((t[7] + t[8])/rays, 3),
+            "record_test": sec(t[12], t[13]), "node_visit": sec(t[14], t[15]), "refill": sec(t[16], t[17]), "publish": sec(t[18], t[19]),
+            "records_per_ray": round(t[13]/rays, 3), "nodes_per_ray": round(t[15]/rays, 3), "hits_accepted_per_ray": round(t[20]/rays, 3),
+            "us_per_wave_launch": {"expand": round(t[0]*0.01/max(t[4], 1), 2), "loop_with_queue": round(t[1]*0.01/max(t[4], 1), 2),
+                                   "loop_dry": round(t[2]*0.01/max(t[4], 1), 2), "wait_writeback": round(t[3]*0.01/max(t[4], 1), 2)}}
 
 
 def counters_dict(c):
@@ -181,12 +198,12 @@ class Bench(object):
     def run(self, scene, w, h, spp, steps, warmup, cpu):
         """Times `steps` renders of `scene`; returns the result dict on rank 0 (None elsewhere)."""
         import numpy as np
-        import scenes
+        from tungsten_amd import workloads as scenes
         from tungsten_amd import dist as tgdist
         a, tg, torch, lib = self.a, self.tg, self.torch, self.tg.lib
         if scene == "materialtest":
             if not scenes.have_materialtest():
-                raise SystemExit("bench.py: materialtest assets missing (oracle/_ref/data; run __graft_entry__.build() where the reference is mounted)")
+                raise SystemExit("bench.py: materialtest assets missing (assets/; run __graft_entry__.build() where the reference is mounted)")
             edit = None
             if a.material == "dielectric":
                 edit = scenes._mt_material({"type": "dielectric", "ior": 1.5, "albedo": 1})
@@ -328,6 +345,12 @@ class Bench(object):
             cc = tg.TgHipCounters()
             lib.tghip_get_counters(ctx, C.byref(cc))
             cc = counters_dict(cc)
+            walk_stats = {}
+            for wi, wname in ((0, "closest_hit"), (1, "shadow")):
+                buf = (C.c_uint64*24)()
+                nw = lib.tghip_get_walk_stats(ctx, wi, buf, 24)
+                if nw >= 22 and buf[4]:
+                    walk_stats[wname] = walk_summary([int(v) for v in buf[:nw]])
             if count_spp != spp:                 # (the first count_spp samples of every pixel stand for all of them)
                 cc = {k: (v*spp//count_spp if isinstance(v, int) else v*spp/count_spp) for k, v in cc.items()}
             check(lib.tghip_set_option(ctx, b"count_traversal", 0), "tghip_set_option")
@@ -353,18 +376,21 @@ class Bench(object):
                                   "bytes_per_launch": round(bytes_per_launch), "gbs": round(bytes_per_launch/avg_s*1e-9, 1)}
             roofline = None
             if kernels:
-                # The headline fields describe the kernel CLASS with the largest accumulated time over the timed region (k_shade on the
-                # metric's workload); `traversal` next to it holds the traversal kernel with the largest accumulated time, the kernel
-                # BASELINE.json's metric asks the achieved GB/s of; flat-list scenes have one fused kernel
+                # The headline fields describe the TRAVERSAL kernel class with the largest accumulated time over the timed region -- the kernel
+                # BASELINE.json's metric asks the achieved GB/s of (rounds 1-4 and 6; round 5's lines had the class with the largest accumulated
+                # time of ANY kind there, k_shade on the metric's workload: that one is under `dominant_class` now).  Flat-list scenes have one
+                # fused kernel, which is both.
                 trav = [k for k in kernels if k.startswith("k_trace")]
                 dom = max(list(kernels), key=lambda k: kernels[k]["ms_total"])
                 dom_trav = max(trav, key=lambda k: kernels[k]["ms_total"]) if trav else None
-                kd = kernels[dom]
-                roofline = {"bound": "hbm", "kernel": dom + (" (trace + shade + shadow fused, flat-list scene)" if fused else ""),
+                head = dom_trav or dom
+                kd = kernels[head]
+                roofline = {"bound": "hbm", "kernel": head + (" (trace + shade + shadow fused, flat-list scene)" if fused else ""),
                             "achieved": kd["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(kd["gbs"]/HBM_PEAK_GBS, 4),
                             "traffic": None, "bytes_per_launch": kd["bytes_per_launch"], "avg_launch_us": kd["avg_us"],
                             "launches": kd["launches"],
-                            "timing": "HIP events per launch on the shim's stream, over the timed region"}
+                            "timing": "HIP events per launch on the shim's stream, over the timed region",
+                            "schema": "r6: top-level fields = the traversal kernel (as rounds 1-4); the class with the largest accumulated time is `dominant_class`"}
                 # The shim runs the pool as P parts on P streams (tungsten_hip.hip: runBatch); launches of different parts share the CUs, so a
                 # launch has a fraction of the chip for its duration.  `loop` prices the whole loop instead: the algorithmic bytes of all
                 # its kernels over the wall time of the timed region.
@@ -378,13 +404,14 @@ class Bench(object):
                 if fused:
                     roofline["note"] = ("instruction-bound, not HBM-bound (profiles/r1/sq_counters.json, profiles/r5_sq_counters.json): exact fp32 division/sqrt/sin/cos "
                                         "and -ffp-contract=off for parity with the CPU reference (DESIGN.md sections 5, 7)")
-                if dom_trav:
-                    kt = kernels[dom_trav]
-                    roofline["traversal"] = {"kernel": dom_trav, "achieved": kt["gbs"], "frac": round(kt["gbs"]/HBM_PEAK_GBS, 4),
-                                             "bytes_per_launch": kt["bytes_per_launch"], "avg_launch_us": kt["avg_us"], "launches": kt["launches"],
-                                             "traffic": None,
-                                             "note": "shared-chip figure: the launches of %d parts of the pool overlap on the CUs; `exclusive` holds the same "
-                                                     "kernel with the chip to itself" % parts}
+                if dom != head:
+                    kt = kernels[dom]
+                    roofline["dominant_class"] = {"kernel": dom, "achieved": kt["gbs"], "frac": round(kt["gbs"]/HBM_PEAK_GBS, 4),
+                                                  "bytes_per_launch": kt["bytes_per_launch"], "avg_launch_us": kt["avg_us"], "launches": kt["launches"],
+                                                  "traffic": None}
+                if parts > 1:
+                    roofline["note"] = ("shared-chip figure: the launches of %d parts of the pool overlap on the CUs, so a launch's duration is residency, not "
+                                        "cost; `exclusive` holds the same kernels with the chip to themselves" % parts)
                 # every kernel class of the loop priced the same way (the headline fields above are the dominant traversal kernel's)
                 roofline["per_kernel"] = {k: {"achieved": kernels[k]["gbs"], "frac": round(kernels[k]["gbs"]/HBM_PEAK_GBS, 4),
                                               "bytes_per_launch": kernels[k]["bytes_per_launch"], "avg_launch_us": kernels[k]["avg_us"],
@@ -396,13 +423,13 @@ class Bench(object):
                         if k in traffic:
                             roofline["per_kernel"][k]["traffic"] = traffic[k]["bytes_per_launch"]
                             roofline["per_kernel"][k]["traffic_launches"] = traffic[k]["launches"]
-                    if dom_trav and dom_trav in traffic:
-                        roofline["traversal"]["traffic"] = traffic[dom_trav]["bytes_per_launch"]
-                    if dom in traffic:
-                        roofline["traffic"] = traffic[dom]["bytes_per_launch"]
+                    if "dominant_class" in roofline and dom in traffic:
+                        roofline["dominant_class"]["traffic"] = traffic[dom]["bytes_per_launch"]
+                    if head in traffic:
+                        roofline["traffic"] = traffic[head]["bytes_per_launch"]
                     elif traffic:
-                        # (a counter file without the dominant kernel is a bug of the name matching, not a measurement)
-                        raise SystemExit("bench.py: no %s dispatches in the counter file; classes seen: %s" % (dom, sorted(traffic)))
+                        # (a counter file without the headline kernel is a bug of the name matching, not a measurement)
+                        raise SystemExit("bench.py: no %s dispatches in the counter file; classes seen: %s" % (head, sorted(traffic)))
                 if a.traffic and self.world == 1 and not fused:
                     # What the loop of a BVH scene IS bound by: none of its kernels moves bytes at a rate worth pricing
                     # against HBM -- the trees are cache-resident -- so two more ceilings are reported next to the HBM line.
@@ -421,6 +448,8 @@ class Bench(object):
                     cats_b = ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64"]
                     va = measure_counters_all(a, scene, w, h, pmc_spp, self.tmp, cats_a, "a")
                     vb = measure_counters_all(a, scene, w, h, pmc_spp, self.tmp, cats_b, "b") if va else None
+                    # enabled lanes per issued VALU instruction (counter_defs.yaml: VALUUtilization; calibrated by tools/ubench_lanes.hip)
+                    vc = measure_counters_all(a, scene, w, h, max(4, pmc_spp//8), self.tmp, ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"], "c") if va else None
                     if va:
                         total = sum(c.get("SQ_INSTS_VALU", 0.0) for c in va.values())
                         per_sample = total/float(w*h*pmc_spp)
@@ -431,6 +460,18 @@ class Bench(object):
                                             "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU + categories (two child passes at %d spp) x the timed region's samples/s; "
                                                       "peak = CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (MI355X_MICROARCH.md: v_fma_f32 = 2 cyc "
                                                       "on the 32-lane SIMD; max clock, sustained clocks are lower, so frac understates)" % pmc_spp}
+                        if vc:
+                            tc = sum(c.get("SQ_THREAD_CYCLES_VALU", 0.0) for c in vc.values())
+                            ta = sum(c.get("SQ_ACTIVE_INST_VALU", 0.0) for c in vc.values())
+                            roofline["valu"]["lane_utilisation"] = {
+                                "loop": round(tc/(64.0*ta), 4) if ta else None,
+                                "per_kernel": {k: round(c["SQ_THREAD_CYCLES_VALU"]/(64.0*c["SQ_ACTIVE_INST_VALU"]), 4)
+                                               for k, c in sorted(vc.items()) if c.get("SQ_ACTIVE_INST_VALU")},
+                                "source": "this run: rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU (one child pass at %d spp): enabled lanes per issued "
+                                          "VALU instruction / 64 (rocprofiler-sdk's VALUUtilization; the counter pair is calibrated by tools/ubench_lanes.hip, "
+                                          "profiles/r6_ubench_lanes.txt)" % max(4, pmc_spp//8)}
+                        if walk_stats:
+                            roofline["valu"]["walk"] = walk_stats
                         # ... and priced: every category at what a wave64 instruction of it occupies its SIMD for (VALU_PRICE above, measured).
                         # SIMD-cycles per sample x samples/s against SIMDs x clock: how much of the chip's VALU time the loop uses.
                         lo = hi = 0.0
@@ -477,6 +518,9 @@ class Bench(object):
                                                 "frac": round(ach/peak, 4), "instructions_per_launch": round(v),
                                                 "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU (one child pass); peak = CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 "
                                                           "instruction (MI355X_MICROARCH.md: v_fma_f32 = 2 cyc on the 32-lane SIMD; max clock, sustained clocks are lower)"}
+                            vc = measure_counters_all(a, scene, w, h, spp, self.tmp, ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU"], "c")
+                            if vc and vc.get(dom, {}).get("SQ_ACTIVE_INST_VALU"):
+                                roofline["valu"]["lane_utilisation"] = round(vc[dom]["SQ_THREAD_CYCLES_VALU"]/(64.0*vc[dom]["SQ_ACTIVE_INST_VALU"]), 4)
                 if self.world == 1 and not fused and parts > 1 and a.exclusive and not a.no_kernel_timing and not a.emulate_shards:
                     # The same kernels with the chip to themselves: the pool as ONE part on one stream ("streams" = 1), so that no launch
                     # overlaps another and, per class, average launch time x launches <= the wall clock of the region (checked below).
@@ -743,6 +787,7 @@ def cpu_baseline(a, scene, path, flat, w, h, spp, tmp):
                 "sample": "%dx%d @ %d spp of the same scene, reference binary `tungsten -t %d`, render-loop wall clock, median of 3 runs per build: "
                           % (w, h, s_spp, cores) + "; ".join("%s %s s => %.2f Msamples/s" % (b, " / ".join("%.2f" % t for t in ts), v)
                                                               for v, b, ts in results)}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))      # (the checker's ctypes wrapper lives with the tests; only this fallback leg uses it)
     import oracle_lib
     s_spp = max(1, s_spp//2)
     t0 = time.time()
@@ -754,14 +799,14 @@ def cpu_baseline(a, scene, path, flat, w, h, spp, tmp):
 
 def main():
     a = parse_args()
-    import scenes
+    from tungsten_amd import workloads as scenes
     b = Bench(a)
     try:
         w, h = [int(v) for v in a.res.split("x")]
         scene = a.scene
         if scene in ("materialtest", "mesh1m") and not scenes.have_materialtest():
             # the headline workload is materialtest: a run without its assets is not a measurement of the metric (no silent fallback)
-            raise SystemExit("bench.py: materialtest assets (oracle/_ref/data/materialtest) missing -- run __graft_entry__.build() where the "
+            raise SystemExit("bench.py: materialtest assets (assets/materialtest) missing -- run __graft_entry__.build() where the "
                              "reference is mounted, or pass --scene cornell explicitly")
         spp = a.spp or (256 if scene in ("cornell", "materialtest") else 32)
         if scene in ("mesh1m", "instances10k") and a.res == "1280x720":
@@ -789,8 +834,8 @@ def main():
                    "n_gpus": b.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                    "data": ("the reference's shipped scene data/materialtest/materialtest.json (meshes, HDRI and materials as shipped; copied by build() into "
-                            "oracle/_ref/data), resolution / spp / sampler set by the bench" if scene == "materialtest" else
-                            "scene description generated in-tree (tests/scenes.py: %s)" % scene) + "; fixed seed 0xBA5EBA11"}
+                            "assets/), resolution / spp / sampler set by the bench" if scene == "materialtest" else
+                            "scene description generated in-tree (tungsten_amd/workloads.py: %s)" % scene) + "; fixed seed 0xBA5EBA11"}
             out.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step")})
             if extra:
                 out["extra"] = extra

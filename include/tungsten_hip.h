@@ -19,6 +19,7 @@
  *                              (src/hdrmanip/hdrmanip.cpp:69-112: load N HDR images, add, divide); here the tile shards of
  *                              one frame, summed on the device side by RCCL over xGMI.
  *   tghip_get_counters      <- (no reference analogue; feeds the roofline model).
+ *   tghip_get_walk_stats    <- (no reference analogue; lane utilisation of the walks).
  *   tghip_debug_libm        <- std::sin / cos / log / exp / acos / atan2 / pow / cbrt on floats as the reference's path calls them (glibc's sinf ... cbrtf):
  *                              the device's restatements evaluated on the device, for the parity tests.
  *
@@ -535,6 +536,14 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "cou
                                                                              quad inside the walks, "tail_family" = 0 runs the all-types tail kernel */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);
 int tghip_reset_counters(tghip_ctx *ctx);
+/* Instrumentation (no reference analogue; bench.py roofline.valu.walk, profiles/r6_lane_util.json): the tallies the counting variants of the
+ * two wide walks keep ("count_traversal" = 1), summed over every wave launch since the last tghip_reset_counters.  walk 0 = closest hit, 1 = shadow.
+ * out[0..n): [0..3] wave time in 10-ns ticks (queue expansion, loop with queue, loop after the queue ran dry, wait + write-back), [4] wave launches,
+ * [5] / [6] loop turns before / after dry, [7] / [8] busy lanes summed over those turns, [9] / [10] walks suspended / resumed, [11] longest loop,
+ * [12] / [13] turns that ran the record test / lanes with a record in them, [14] / [15] the same for the node visit, [16] / [17] refill blocks run /
+ * lanes refilled, [18] / [19] publish (NEE-term) blocks run / lanes in them, [20] record tests accepted, [21] rays walked.  Returns the number of
+ * values written (<= n), or a negative error. */
+int tghip_get_walk_stats(tghip_ctx *ctx, int walk, uint64_t *out, int n);
 
 #ifdef __cplusplus
 }

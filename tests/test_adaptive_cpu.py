@@ -18,7 +18,7 @@ G = scenes.GOLDEN
 
 def _gold(name):
     if "materialtest" in name and not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
     return np.load(os.path.join(G, name + "_integrate.npz"))
 
 

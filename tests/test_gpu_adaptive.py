@@ -26,7 +26,7 @@ LUM = np.array([0.2126, 0.7152, 0.0722], np.float64)
 
 def _skip_mt(name):
     if "materialtest" in name and not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
 
 
 def _pixel_record(w, h):

@@ -30,7 +30,7 @@ CASES = {
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_baseline_configuration_at_full_size(case, tmp_path):
     if not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
     mk, (w, h), spp, (rays_lo, rays_hi), max_bad = CASES[case]
     path = mk(tmp_path, (w, h), spp)
     mean, ssum, count, c = gpu_render(path)

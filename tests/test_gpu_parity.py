@@ -21,9 +21,9 @@ SEED = tg.DEFAULT_SEED
 
 def _skip_mt(name):
     if name == "water_caustic" and not scenes.have_water_caustic():
-        pytest.skip("water-caustic assets (oracle/_ref/data) not present")
+        pytest.skip("water-caustic assets (assets/) not present")
     if ("materialtest" in name or name == "mesh1m") and not scenes.have_materialtest():   # mesh1m is lit by materialtest's HDRI
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
 
 
 def gpu_render(path, seed=SEED, **opts):
@@ -199,7 +199,7 @@ def test_shards_and_batches_round_like_the_whole_pass(adaptive, tmp_path):
     import ctypes as C
     import json
     if not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
     kw = dict(resolution=(192, 108), spp=22)
     if adaptive:
         kw = dict(resolution=(96, 54), spp=44, spp_step=22, renderer={"adaptive_sampling": True, "stratified_sampler": True})
@@ -397,7 +397,7 @@ def test_instanced_shadow_walk_agrees_with_the_bvh2_walk(tmp_path):
     assert (plain == bvh2).all()
     assert (counting == bvh2).all()
     if not scenes.have_materialtest():
-        pytest.skip("instances10k needs the materialtest assets (oracle/_ref/data)")
+        pytest.skip("instances10k needs the materialtest assets (assets/)")
     big = scenes.instances10k(tmp_path, resolution=(1920, 1080), spp=2)
     r = tg.Renderer(big, seed=SEED)
     try:

@@ -36,9 +36,9 @@ ULP_LEVEL = set()
 
 def _skip(name):
     if name == "water_caustic" and not scenes.have_water_caustic():
-        pytest.skip("water-caustic assets (oracle/_ref/data) not present")
+        pytest.skip("water-caustic assets (assets/) not present")
     if ("materialtest" in name or name == "mesh1m") and not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
 
 
 def diverging(got, ref):

@@ -37,7 +37,7 @@ TABLE = os.environ.get("TG_SCALE_TABLE")     # when set: append one JSON line pe
 
 def _needs(name):
     if ("materialtest" in name or name == "mesh1m") and not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
 
 
 @pytest.mark.parametrize("size,name", [(s, n) for s in ("scale8", "scale64") for n in msg.SIZES[s][2]])
@@ -86,7 +86,7 @@ STATED = {
 @pytest.mark.parametrize("case", sorted(STATED))
 def test_last_samples_of_a_baseline_configuration_at_its_stated_spp(case, tmp_path):
     if "cornell" not in case and not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
     mk, (w, h), spp, tail = STATED[case]
     path = mk(tmp_path, (w, h), spp)
     r = tg.Renderer(path, seed=SEED)

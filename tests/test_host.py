@@ -82,7 +82,7 @@ def test_cornell_flattening(tmp_path):
     flat.close()
 
 
-@pytest.mark.skipif(not scenes.have_materialtest(), reason="materialtest assets (oracle/_ref/data) not present")
+@pytest.mark.skipif(not scenes.have_materialtest(), reason="materialtest assets (assets/) not present")
 def test_materialtest_flattening(tmp_path):
     flat = tg.FlattenedScene(scenes.materialtest(tmp_path, resolution=(64, 36), spp=4))
     d = flat.desc.contents
@@ -216,7 +216,7 @@ def check_wide_bvh(desc):
     return int(depth.max()), n
 
 
-@pytest.mark.skipif(not scenes.have_materialtest(), reason="materialtest assets (oracle/_ref/data) not present")
+@pytest.mark.skipif(not scenes.have_materialtest(), reason="materialtest assets (assets/) not present")
 def test_wide_bvh_is_a_conservative_collapse_of_the_bvh2(tmp_path):
     import oracle_lib
     flat = tg.FlattenedScene(scenes.materialtest(tmp_path, resolution=(64, 36), spp=4))

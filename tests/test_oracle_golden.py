@@ -49,9 +49,9 @@ def flat_bsdf_index(scene_json, scene_index):
 
 def _needs_materialtest(name):
     if name == "water_caustic" and not scenes.have_water_caustic():
-        pytest.skip("water-caustic assets (oracle/_ref/data) not present")
+        pytest.skip("water-caustic assets (assets/) not present")
     if ("materialtest" in name or name == "mesh1m") and not scenes.have_materialtest():   # mesh1m is lit by materialtest's HDRI
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
 
 
 # Samples in which the oracle leaves the reference's path (every channel within 1e-3 is "the same path"), per case.  EMPTY since the end of round 4:

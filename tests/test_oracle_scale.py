@@ -23,7 +23,7 @@ MEASURED = {("scale8", "cornell_bump"): 5, ("scale64", "cornell_bump"): 46, ("sc
 @pytest.mark.parametrize("size,name", [(s, n) for s in ("scale8", "scale64") for n in msg.SIZES[s][2]])
 def test_oracle_samples_are_the_references_above_golden_size(size, name, tmp_path):
     if ("materialtest" in name or name == "mesh1m") and not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
     gold = np.load(os.path.join(scenes.GOLDEN, "%s_%s.npz" % (size, name)))
     want, seed = gold["hash"], int(gold["seed"])
     h, w, spp = want.shape

@@ -102,7 +102,7 @@ def test_scene_items_are_the_references_finites(name, tmp_path):
     of its _finites (oracle/ref_harness.cpp: bounds), bit for bit and in order: the items the reference's top-level Embree tree is built over, for
     every kind of scene (infinite and Dirac emitters are not among them)."""
     if name in ("materialtest", "mesh1m") and not scenes.have_materialtest():
-        pytest.skip("materialtest assets (oracle/_ref/data) not present")
+        pytest.skip("materialtest assets (assets/) not present")
     with open(os.path.join(scenes.GOLDEN, "prim_bounds.json")) as f:
         gold = json.load(f)[name]
     flat = tg.FlattenedScene(top_tree_sets._make(name, tmp_path))

@@ -24,6 +24,9 @@ GROUPS = {
     "sqc": ["SQC_DCACHE_REQ", "SQC_DCACHE_HITS", "SQC_DCACHE_MISSES", "SQC_DCACHE_MISSES_DUPLICATE"],
     "tcp": ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_PENDING_STALL_CYCLES_sum"],
     "tcc": ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"],
+    # enabled lanes per issued VALU instruction (counter_defs.yaml: VALUUtilization = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU * 64); the pair is
+    # calibrated by tools/ubench_lanes.hip, profiles/r6_ubench_lanes.txt)
+    "lane": ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_SALU", "SQ_WAIT_ANY"],
 }
 
 
@@ -87,6 +90,8 @@ def main():
                              ("SQ_ACTIVE_INST_VALU", "frac_issuing_valu")):
                 if n in r:
                     r[label] = round(r[n]/float(wave), 4)
+        if r.get("SQ_THREAD_CYCLES_VALU") and r.get("SQ_ACTIVE_INST_VALU"):
+            r["lane_utilisation"] = round(r["SQ_THREAD_CYCLES_VALU"]/(64.0*r["SQ_ACTIVE_INST_VALU"]), 4)
         if r.get("SQC_ICACHE_REQ"):
             r["icache_hit_rate"] = round(r.get("SQC_ICACHE_HITS", 0)/float(r["SQC_ICACHE_REQ"]), 4)
         if r.get("SQC_DCACHE_REQ"):
@@ -97,7 +102,7 @@ def main():
             r["l1_miss_latency_cycles"] = round(r.get("TCP_TCC_READ_REQ_LATENCY_sum", 0)/float(r["TCP_TCC_READ_REQ_sum"]), 1)
         if r.get("TCC_REQ_sum"):
             r["l2_hit_rate"] = round(r.get("TCC_HIT_sum", 0)/float(r["TCC_REQ_sum"]), 4)
-        print("%-70s %s" % (k[:70], {n: v for n, v in r.items() if n.startswith("frac") or n.endswith("rate") or n.endswith("cycles") and n.startswith("l1")}))
+        print("%-70s %s" % (k[:70], {n: v for n, v in r.items() if n.startswith("frac") or n.endswith("rate") or n == "lane_utilisation" or n.endswith("cycles") and n.startswith("l1")}))
     json.dump(data, open(a.out, "w"), indent=1, sort_keys=True)
     shutil.rmtree(tmp, ignore_errors=True)
 

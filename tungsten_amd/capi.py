@@ -177,6 +177,7 @@ PROTOTYPES = {
     "tghip_set_option": (C.c_int, [VP, C.c_char_p, C.c_longlong]),
     "tghip_get_counters": (C.c_int, [VP, C.POINTER(TgHipCounters)]),
     "tghip_reset_counters": (C.c_int, [VP]),
+    "tghip_get_walk_stats": (C.c_int, [VP, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     # include/tungsten_host.h
     "tgh_scene_load": (VP, [C.c_char_p, C.c_char_p, C.c_size_t]),
     "tgh_scene_desc": (C.POINTER(TgHipSceneDesc), [VP]),

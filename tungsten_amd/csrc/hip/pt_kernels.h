@@ -88,14 +88,18 @@ struct BlockCtl {                 // one per persistent workgroup; only that wor
     unsigned long long samples, closest_rays, shadow_rays, shadow_slots;
 };                                // 64 B
 
+#define PT_WALK_STATS 24
 struct BlockStats {               // traversal statistics (count_traversal option), one per workgroup
     unsigned long long nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow;
     unsigned long long prof[16];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds: `make PROFILE=1`, TGHIP_VERBOSE prints them)
     // count_traversal: where the waves of the wide traversal kernels spend their time ([0] closest-hit, [1] shadow), in wall_clock64 ticks
     // (10 ns) summed over waves: 0 queue expansion, 1 loop while the workgroup's queue has rays, 2 loop after it ran dry, 3 waiting for the
     // workgroup's other waves + write-back; 4 waves; 5 / 6 loop turns before / after dry; 7 / 8 busy lanes summed over those turns;
-    // 9 walks suspended, 10 walks resumed, 11 longest loop of a wave (max, ticks)
-    unsigned long long walk[2][12];
+    // 9 walks suspended, 10 walks resumed, 11 longest loop of a wave (max, ticks);
+    // lane utilisation of the decoupled turn's sections (round 6; tghip_get_walk_stats): 12 / 13 wave turns that ran the record test / lanes that had a
+    // record in them, 14 / 15 the same for the node visit, 16 / 17 refill blocks run / lanes refilled in them, 18 / 19 publish (closest hit) or
+    // NEE-term (shadow) blocks run / lanes in them, 20 record tests accepted (a hit: the division and t, u, v), 21 rays (closest) or rays traced (shadow)
+    unsigned long long walk[2][PT_WALK_STATS];
 #ifdef PT_PROFILE
     unsigned long long profCls[PT_NUM_CLASSES + 2][16];   // the same per shading class of the launch (CLS_MISS = escaped paths)
 #endif

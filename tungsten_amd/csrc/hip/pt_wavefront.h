@@ -32,18 +32,26 @@
 #endif
 
 // count_traversal: time and lane-occupancy breakdown of the wide traversal kernels (BlockStats::walk)
-#define WALK_PROF_DECL unsigned long long wpLoop = COUNT ? wall_clock64() : 0ull, wpDry = 0ull, wpLoopEnd = 0ull; uint32_t wpBusy = 0, wpBusyDry = 0, wpSuspended = 0, wpResumed = 0
+#define WALK_PROF_DECL unsigned long long wpLoop = COUNT ? wall_clock64() : 0ull, wpDry = 0ull, wpLoopEnd = 0ull; uint32_t wpBusy = 0, wpBusyDry = 0, wpSuspended = 0, wpResumed = 0, \
+    wpRecTurns = 0, wpRecLanes = 0, wpNodeTurns = 0, wpNodeLanes = 0, wpRefills = 0, wpRefillLanes = 0, wpPubs = 0, wpPubLanes = 0, wpHits = 0, wpRays = 0
+// (wave-uniform tallies of a section: how often the wave ran it, and how many lanes had work in it)
+#define WALK_SECTION(TURNS, LANES, pred) do { if (COUNT) { const unsigned long long m_ = __ballot(pred); if (m_) { TURNS++; LANES += (uint32_t)__popcll(m_); } } } while (0)
 #define WALK_PROF_FLUSH(K, TURNS, DRYTURNS) do { \
         const unsigned long long wpEnd_ = wall_clock64(); \
         if (wpDry == 0ull) wpDry = wpLoopEnd; \
-        uint32_t su_ = wpSuspended, re_ = wpResumed; \
-        for (int off_ = 32; off_ > 0; off_ >>= 1) { su_ += __shfl_down(su_, off_); re_ += __shfl_down(re_, off_); } \
+        uint32_t su_ = wpSuspended, re_ = wpResumed, hi_ = wpHits, ra_ = wpRays; \
+        for (int off_ = 32; off_ > 0; off_ >>= 1) { su_ += __shfl_down(su_, off_); re_ += __shfl_down(re_, off_); hi_ += __shfl_down(hi_, off_); ra_ += __shfl_down(ra_, off_); } \
         if (laneId() == 0) { \
             unsigned long long *wk_ = st.stats[blockIdx.x].walk[K]; \
             atomicAdd(&wk_[0], wpLoop - wpStart); atomicAdd(&wk_[1], wpDry - wpLoop); atomicAdd(&wk_[2], wpLoopEnd - wpDry); atomicAdd(&wk_[3], wpEnd_ - wpLoopEnd); \
             atomicAdd(&wk_[4], 1ull); atomicAdd(&wk_[5], (unsigned long long)(TURNS)); atomicAdd(&wk_[6], (unsigned long long)(DRYTURNS)); \
             atomicAdd(&wk_[7], (unsigned long long)wpBusy); atomicAdd(&wk_[8], (unsigned long long)wpBusyDry); \
             atomicAdd(&wk_[9], (unsigned long long)su_); atomicAdd(&wk_[10], (unsigned long long)re_); atomicMax(&wk_[11], wpLoopEnd - wpLoop); \
+            atomicAdd(&wk_[12], (unsigned long long)wpRecTurns); atomicAdd(&wk_[13], (unsigned long long)wpRecLanes); \
+            atomicAdd(&wk_[14], (unsigned long long)wpNodeTurns); atomicAdd(&wk_[15], (unsigned long long)wpNodeLanes); \
+            atomicAdd(&wk_[16], (unsigned long long)wpRefills); atomicAdd(&wk_[17], (unsigned long long)wpRefillLanes); \
+            atomicAdd(&wk_[18], (unsigned long long)wpPubs); atomicAdd(&wk_[19], (unsigned long long)wpPubLanes); \
+            atomicAdd(&wk_[20], (unsigned long long)hi_); atomicAdd(&wk_[21], (unsigned long long)ra_); \
         } } while (0)
 
 // BSDF type sets of the shading-kernel variants (pt_scene.h BsdfOps<D, M>)
@@ -798,6 +806,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             // right before the lanes are refilled (once the queue is dry: in the turn they finish): one memory round trip per refill
             // instead of one in nearly every turn, sat out by the whole wave.
             if (((!exhausted && __popcll(busyMask) <= PT_REFILL_AT) || exhausted) && __ballot(pendingPublish) != 0ull) {
+                WALK_SECTION(wpPubs, wpPubLanes, pendingPublish);
                 if (pendingPublish) {
                     slotF4<NTS>(st, A_HIT, slot) = hit;
                     const int ri = __float_as_int(hit.w);
@@ -814,6 +823,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             if (lane == 0)
                 base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
             base = __shfl(base, 0);
+            WALK_SECTION(wpRefills, wpRefillLanes, !busy && base + __popcll(want & ((1ull << lane) - 1ull)) < n);
             if (!busy) {
                 uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
                 if (i < n) {
@@ -839,6 +849,7 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
                             }
                         }
                         rays++;
+                        if (COUNT) wpRays++;
                     } else {
                         walkRestore(st, slot, w, stack, stride);
                         if (COUNT) wpResumed++;
@@ -897,10 +908,13 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             float4 r0, r1, r2;
             WideNodeRegs nd;
             PT_WALK_FETCH(s, st, r0, r1, r2, nd, hasRec, recIdx, hasNode, nodeIdx, wr, topCount, ldsTop);
+            WALK_SECTION(wpRecTurns, wpRecLanes, hasRec);
+            WALK_SECTION(wpNodeTurns, wpNodeLanes, hasNode);
             if (hasRec) {
                 if (COUNT) prims++;
                 uint32_t meta;
-                (void)testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta);
+                const bool accepted = testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta);
+                if (COUNT && accepted) wpHits++;
             }
             if (hasNode) {
                 if (COUNT) nodes++;
@@ -2409,6 +2423,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
     uint32_t age = 0;
     const bool maySuspend = st.suspend_lanes != 0u && n >= st.suspend_min_queue;
 
+    WALK_PROF_DECL;
     // the lane takes ray (c, sd) if it has to be traced (k_trace_shadow_wide: setupRay)
     auto tryRay = [&](float4 c, float4 sd, bool resume) -> bool {
         const uint32_t tag = __float_as_uint(c.w);
@@ -2430,6 +2445,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
             if (testRecord<true, KIND_BIT(TGHIP_REC_QUAD)>(s, (uint32_t)s.hoisted_rec, ray, tq, hq, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
                 return false;
         }
+        if (COUNT && !resume) wpRays++;
         wr = wideRaySetup(ray);
         if (!resume) wideStart(w);
         return true;
@@ -2445,11 +2461,11 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         pendingFinish = true;
     };
 
-    WALK_PROF_DECL;
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
         const bool refill = !exhausted && __popcll(busyMask) <= PT_REFILL_AT;
         if ((refill || exhausted) && __ballot(pendingFinish) != 0ull) {
+            WALK_SECTION(wpPubs, wpPubLanes, pendingFinish);
             if (pendingFinish) {
                 // NEE term -> path radiance; paths that ended at this vertex go on the finished list
                 const float4 wgt = slotF4<NTS>(st, A_SH_W, slot), p = slotF4<NTS>(st, A_SH_P, slot), e4 = slotF4<NTS>(st, A_EMI, slot);
@@ -2475,6 +2491,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
             if (lane == 0)
                 base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
             base = __shfl(base, 0);
+            WALK_SECTION(wpRefills, wpRefillLanes, !busy && base + __popcll(want & ((1ull << lane) - 1ull)) < n);
             if (!busy) {
                 uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
                 if (i < n) {
@@ -2550,13 +2567,17 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
             float4 r0, r1, r2;
             WideNodeRegs nd;
             PT_WALK_FETCH(s, st, r0, r1, r2, nd, hasRec, recIdx, hasNode, nodeIdx, wr, topCount, ldsTop);
+            WALK_SECTION(wpRecTurns, wpRecLanes, hasRec);       // (inside `if (busy)`: the ballot covers the lanes that are here)
+            WALK_SECTION(wpNodeTurns, wpNodeLanes, hasNode);
             bool rayDone = false;
             if (hasRec) {
                 if (COUNT) prims++;
                 float tmax = ray.tmax;
                 float4 hit;
                 uint32_t meta;
-                if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta) && (int)TGHIP_REC_OBJECT(meta) != endCap)
+                const bool accepted = testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, recIdx, r0, r1, r2, ray, tmax, hit, meta);
+                if (COUNT && accepted) wpHits++;
+                if (accepted && (int)TGHIP_REC_OBJECT(meta) != endCap)
                     rayDone = true;              // occluded
             }
             if (!rayDone && hasNode) {

@@ -163,6 +163,7 @@ struct tghip_ctx {
     uint32_t poolWalkArrays = 0;          // walk arrays the pool carries behind the A_* ones (0: walks are never suspended)
     uint32_t poolWalkWanted = 0;          // ... and how many the scene it was laid out for asked for (more than fit the 32-bit offsets: none)
     uint32_t *hostLive = nullptr;         // pinned mirror of PathState::live for the loop condition
+    unsigned long long walkStats[2][PT_WALK_STATS] = {{0}, {0}};   // BlockStats::walk summed over workgroups and folds (tghip_get_walk_stats)
     std::vector<BlockCtl> hostCtl;        // scratch for tghip_get_counters
     std::vector<BlockStats> hostStats;
 
@@ -533,6 +534,13 @@ static int foldCounters(tghip_ctx *ctx)
             ctx->counters.nodes_visited_shadow += t.nodes_visited_shadow; ctx->counters.prims_tested_shadow += t.prims_tested_shadow;
         }
     }
+    if (ctx->countTraversal)
+        for (int k = 0; k < 2; ++k)
+            for (size_t b = 0; b < g; ++b)
+                for (int i = 0; i < PT_WALK_STATS; ++i) {
+                    if (i == 11) ctx->walkStats[k][i] = std::max(ctx->walkStats[k][i], ctx->hostStats[b].walk[k][i]);
+                    else ctx->walkStats[k][i] += ctx->hostStats[b].walk[k][i];
+                }
     if (std::getenv("TGHIP_VERBOSE") && ctx->countTraversal) {
         for (int k = 0; k < 2; ++k) {
             unsigned long long t[12] = {0};
@@ -2495,7 +2503,19 @@ int tghip_reset_counters(tghip_ctx *ctx)
     int rc = foldCounters(ctx);
     if (rc != TGHIP_OK) return rc;
     std::memset(&ctx->counters, 0, sizeof(ctx->counters));
+    std::memset(ctx->walkStats, 0, sizeof(ctx->walkStats));
     return TGHIP_OK;
+}
+
+int tghip_get_walk_stats(tghip_ctx *ctx, int walk, uint64_t *out, int n)
+{
+    if (!ctx || !out || walk < 0 || walk > 1 || n < 0) return TGHIP_E_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = foldCounters(ctx);
+    if (rc != TGHIP_OK) return rc;
+    const int m = std::min(n, int(PT_WALK_STATS));
+    for (int i = 0; i < m; ++i) out[i] = ctx->walkStats[walk][i];
+    return m;
 }
 
 } // extern "C"
