@@ -76,6 +76,12 @@ def parse_args():
     ap.add_argument("--count-spp", type=int, default=0,
                     help="spp of the untimed counting pass that feeds the byte model (default: the workload's own spp, i.e. exact counts; a lower "
                          "value scales the counts by spp/count_spp -- for the multi-minute configurations)")
+    ap.add_argument("--reduce", default="product", choices=["product", "torch"],
+                    help="N > 1: the exchange step -- the product's own tghip_reduce_framebuffer_rank (ncclReduce between the ranks' contexts; falls back to "
+                         "torch.distributed.reduce, and says so, if a rank cannot build its communicator) or torch.distributed.reduce on the bound tensors")
+    ap.add_argument("--in-process", action="store_true",
+                    help="N > 1 in ONE process (no torch.distributed.run): the host integrator drives N contexts from N host threads (\"devices\": N) and merges "
+                         "with tghip_reduce_framebuffers; a step = one complete render through tgh_renderer_render, download of the merged image included")
     ap.add_argument("--emulate-shards", type=int, default=0,
                     help="development aid: on ONE GPU render and time EVERY one of N tile shards in turn (what the ranks of an N-GPU run do; "
                          "reports max / mean / min over shards and the fixed cost of the framebuffer reduce)")
@@ -163,7 +169,7 @@ class Bench(object):
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != a.gpus:
+        if self.world != a.gpus and not (a.in_process and self.world == 1):
             raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)" % (a.gpus, self.world))
         if not torch.cuda.is_available() or tg.device_count() < 1:
             raise SystemExit("bench.py: no HIP device visible -- the path tracer has no CPU fallback")
@@ -195,12 +201,10 @@ class Bench(object):
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def run(self, scene, w, h, spp, steps, warmup, cpu):
-        """Times `steps` renders of `scene`; returns the result dict on rank 0 (None elsewhere)."""
-        import numpy as np
+    def make_scene(self, scene, w, h, spp):
+        """Writes the workload's scene description (tungsten_amd/workloads.py) into the run's scratch directory: (path, description)."""
         from tungsten_amd import workloads as scenes
-        from tungsten_amd import dist as tgdist
-        a, tg, torch, lib = self.a, self.tg, self.torch, self.tg.lib
+        a = self.a
         if scene == "materialtest":
             if not scenes.have_materialtest():
                 raise SystemExit("bench.py: materialtest assets missing (assets/; run __graft_entry__.build() where the reference is mounted)")
@@ -223,6 +227,15 @@ class Bench(object):
         else:
             path = scenes.cornell(self.tmp, resolution=(w, h), spp=spp)
             workload = "BASELINE configs[1]: cornell-box (5 quads + 2 cubes + quad light, Lambert) %dx%d @ %d spp" % (w, h, spp)
+        return path, workload
+
+    def run(self, scene, w, h, spp, steps, warmup, cpu):
+        """Times `steps` renders of `scene`; returns the result dict on rank 0 (None elsewhere)."""
+        import numpy as np
+        from tungsten_amd import workloads as scenes
+        from tungsten_amd import dist as tgdist
+        a, tg, torch, lib = self.a, self.tg, self.torch, self.tg.lib
+        path, workload = self.make_scene(scene, w, h, spp)
 
         t0 = time.time()
         flat = tg.FlattenedScene(path)
@@ -249,6 +262,20 @@ class Bench(object):
         fb_cnt = torch.zeros((h, w), dtype=torch.int32, device="cuda")
         check(lib.tghip_bind_framebuffer(ctx, fb_sum.data_ptr(), fb_cnt.data_ptr()), "tghip_bind_framebuffer")
         pass_desc = tgdist.shard_pass(self.rank, self.world, 0, spp, tg.DEFAULT_SEED)
+        # N > 1: the exchange step is the product's own (one ncclComm_t per context, ncclReduce of the framebuffers into a scratch image on rank 0's
+        # device); torch.distributed carries the RCCL id, the barriers and the timing all-reduce.  The rehearsal with ranks sharing a device stays
+        # on gloo: RCCL wants one rank per device.
+        product_reduce, reduce_note = False, None
+        if self.dist is not None:
+            if self.shared:
+                reduce_note = "gloo (rehearsal: ranks share a device)"
+            elif a.reduce == "product":
+                why = tgdist.init_rank_comm(lib, ctx, self.rank, self.world)
+                product_reduce = why is None
+                reduce_note = ("tghip_reduce_framebuffer_rank (the product's ncclReduce between the ranks' contexts)" if product_reduce
+                               else "torch.distributed.reduce -- FALLBACK, the product's communicator could not be built: %s" % why)
+            else:
+                reduce_note = "torch.distributed.reduce (--reduce torch)"
         emulated = None
         if a.emulate_shards > 1 and self.world == 1:
             # what an N-GPU run does, on ONE GPU: every shard 0..N-1 is rendered and timed in turn (a strong-scaling run is as
@@ -291,7 +318,10 @@ class Bench(object):
             check(lib.tghip_wait(ctx), "tghip_wait")
             t_b = time.perf_counter()
             # the exchange step: float framebuffer sum-reduce over xGMI (tile ownership is disjoint -> exact)
-            tgdist.reduce_framebuffer(fb_sum, fb_cnt, dst=0)
+            if product_reduce:
+                check(lib.tghip_reduce_framebuffer_rank(ctx, 0, None, None, w*h), "tghip_reduce_framebuffer_rank")   # (the merged image stays in HBM)
+            else:
+                tgdist.reduce_framebuffer(fb_sum, fb_cnt, dst=0)
             split[0] += t_b - t_a
             split[1] += time.perf_counter() - t_b
 
@@ -326,11 +356,23 @@ class Bench(object):
         timed = counters_dict(timed)
         check(lib.tghip_set_option(ctx, b"time_kernels", 0), "tghip_set_option")
 
+        merged = None
+        if product_reduce:
+            # (outside the timed region: the merged image of the last step, downloaded from rank 0's scratch image -- a collective, every rank calls)
+            hs = np.empty((h, w, 3), np.float32) if self.rank == 0 else None
+            hc = np.empty((h, w), np.uint32) if self.rank == 0 else None
+            check(lib.tghip_reduce_framebuffer_rank(ctx, 0, hs.ctypes.data if hs is not None else None, hc.ctypes.data if hc is not None else None, w*h),
+                  "tghip_reduce_framebuffer_rank")
+            merged = (hs, hc)
         out = None
         if self.rank == 0:
             # sanity of the result of the last timed step (rank 0 holds the reduced image)
-            cnt = fb_cnt.cpu().numpy()
-            img = (fb_sum/fb_cnt.clamp(min=1).unsqueeze(-1)).cpu().numpy()
+            if merged:
+                cnt = merged[1].astype(np.int64)
+                img = merged[0]/np.maximum(cnt, 1)[..., None]
+            else:
+                cnt = fb_cnt.cpu().numpy()
+                img = (fb_sum/fb_cnt.clamp(min=1).unsqueeze(-1)).cpu().numpy()
             ok = bool(((cnt == spp).all() or a.emulate_shards > 1) and np.isfinite(img).all())
             value = float(w)*h*spp*steps/elapsed*1e-6
 
@@ -564,7 +606,7 @@ class Bench(object):
                 "value": round(value, 2), "ms_per_step": round(elapsed/steps*1e3, 3),
                 "config": {"workload": workload, "width": w, "height": h, "spp": spp, "sampler": "uniform (counter-based PCG)",
                            "adaptive_sampling": False, "max_bounces": int(flat.desc.contents.settings.max_bounces),
-                           "parallelism": "tile-shard x%d%s" % (self.world, (" + gloo framebuffer reduce (rehearsal: ranks share a device)" if self.shared else " + RCCL framebuffer reduce") if self.world > 1 else "")},
+                           "parallelism": "tile-shard x%d%s" % (self.world, (" + framebuffer reduce: " + reduce_note) if self.world > 1 else "")},
                 "roofline": roofline,
                 "cpu_baseline": cpu_baseline(a, scene, path, flat, w, h, spp, self.tmp) if cpu else None,
                 "kernels": kernels,
@@ -588,6 +630,35 @@ class Bench(object):
             lib.tghip_destroy(ctx)
         flat.close()
         return out
+
+
+def run_in_process(b, a, scene, w, h, spp):
+    """--in-process: N GPUs driven by ONE process through the host integrator (\"devices\": N -- N contexts on N host threads, each rendering its tile
+    shard of every pass, tghip_reduce_framebuffers = ncclReduce into device 0, download of the merged image): the product's own multi-GPU path end
+    to end, as a Tungsten front end would call it.  A step = tgh_renderer_render of a freshly opened renderer (scene load and upload untimed)."""
+    import numpy as np
+    tg = b.tg
+    if tg.device_count() < a.gpus:
+        raise SystemExit("bench.py --in-process: %d devices visible, --gpus %d" % (tg.device_count(), a.gpus))
+    path, workload = b.make_scene(scene, w, h, spp)
+    secs, ok, img_mean, per_device = [], True, None, None
+    for i in range(a.warmup + a.steps):
+        r = tg.Renderer(path, devices=a.gpus)
+        t = r.render()
+        mean, _, count = r.image()
+        if i >= a.warmup:
+            secs.append(t)
+            ok = ok and bool((count == spp).all() and np.isfinite(mean).all())
+            img_mean = [round(float(v), 6) for v in mean.mean(axis=(0, 1))]
+            per_device = [int(r.counters(d).samples) for d in range(a.gpus)]
+        r.close()
+    total = sum(secs)
+    return {"value": round(float(w)*h*spp*len(secs)/total*1e-6, 2), "ms_per_step": round(total/len(secs)*1e3, 3),
+            "config": {"workload": workload, "width": w, "height": h, "spp": spp, "sampler": "uniform (counter-based PCG)", "adaptive_sampling": False,
+                       "parallelism": "tile-shard x%d in one process: host integrator \"devices\": %d + tghip_reduce_framebuffers (ncclReduce)" % (a.gpus, a.gpus)},
+            "roofline": None, "cpu_baseline": None, "result_ok": ok, "image_mean": img_mean,
+            "per_rank": {"samples_rendered_by_device": per_device, "render_s_per_step": [round(t, 4) for t in secs],
+                         "note": "one process: the step's wall clock covers every device's shard, the reduce and the download of the merged image"}}
 
 
 def kernel_class(name):
@@ -812,9 +883,10 @@ def main():
         if scene in ("mesh1m", "instances10k") and a.res == "1280x720":
             w, h = 1920, 1080
         cpu = not a.no_cpu_baseline and b.world == 1
-        res = b.run(scene, w, h, spp, a.steps, a.warmup, cpu)
+        in_process = a.in_process and a.gpus > 1
+        res = run_in_process(b, a, scene, w, h, spp) if in_process else b.run(scene, w, h, spp, a.steps, a.warmup, cpu)
         extra = None
-        if scene == "materialtest" and b.world == 1 and not a.no_extra:
+        if scene == "materialtest" and b.world == 1 and not a.no_extra and not in_process:
             # BASELINE configs[1] on the same line: a flat-list scene, no traversal kernel (2 steps)
             saved, a.traffic = a.traffic, False
             a.valu_pass = saved                  # (no HBM traffic passes for the extra line, but its VALU-issue roofline)
@@ -831,7 +903,7 @@ def main():
                     extra["materialtest_as_shipped_1280x720_64spp"] = {"error": str(e)}
         if b.rank == 0:
             out = {"metric": "Msamples/s (W*H*spp/s), path_tracer render loop", "value": res["value"], "unit": "Msamples/s",
-                   "n_gpus": b.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+                   "n_gpus": a.gpus if in_process else b.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                    "data": ("the reference's shipped scene data/materialtest/materialtest.json (meshes, HDRI and materials as shipped; copied by build() into "
                             "assets/), resolution / spp / sampler set by the bench" if scene == "materialtest" else

@@ -18,6 +18,8 @@
  *   tghip_reduce_framebuffers <- the merge of per-machine partial renders the reference does offline on the host
  *                              (src/hdrmanip/hdrmanip.cpp:69-112: load N HDR images, add, divide); here the tile shards of
  *                              one frame, summed on the device side by RCCL over xGMI.
+ *   tghip_comm_unique_id / tghip_comm_init_rank / tghip_reduce_framebuffer_rank <- the same merge with one PROCESS per GPU (hdrmanip.cpp:69-112
+ *                              again: there the partial renders come from separate `tungsten` processes).
  *   tghip_get_counters      <- (no reference analogue; feeds the roofline model).
  *   tghip_get_walk_stats    <- (no reference analogue; lane utilisation of the walks).
  *   tghip_debug_libm        <- std::sin / cos / log / exp / acos / atan2 / pow / cbrt on floats as the reference's path calls them (glibc's sinf ... cbrtf):
@@ -518,6 +520,20 @@ int tghip_download_samples(tghip_ctx *ctx, float *rgb, size_t nfloats);
  * contexts' own framebuffers are left as they are, so passes can go on accumulating.  librccl.so is loaded at the first call;
  * TGHIP_E_UNSUPPORTED when it is missing. */
 int tghip_reduce_framebuffers(tghip_ctx *const *ctxs, int n, int root, float *rgb_sum, uint32_t *count, size_t npixels);
+/* The same merge between PROCESSES, one per GPU (how `python -m torch.distributed.run --nproc-per-node N` / mpirun deploy it; the reference's
+ * analogue is one `tungsten` process per machine and `hdrmanip --merge` over their output files, src/hdrmanip/hdrmanip.cpp:69-112):
+ *   rank 0:     tghip_comm_unique_id(id, TGHIP_COMM_ID_BYTES)  -- ncclGetUniqueId; the caller carries the bytes to the other ranks by any means it
+ *               has (a file, a socket, MPI_Bcast, torch.distributed.broadcast_object_list);
+ *   every rank: tghip_comm_init_rank(ctx, id, bytes, nranks, rank)  -- collective: ncclCommInitRank on ctx's device; the communicator belongs to
+ *               the context and is destroyed with it;
+ *   every rank: tghip_reduce_framebuffer_rank(ctx, root, rgb_sum, count, npixels)  -- collective: waits for ctx's pass, then ncclReduce (sum) of the
+ *               radiance sums and sample counts of every rank's framebuffer -- rank r rendered shard r of `nranks`, TgHipPassDesc.shard_* -- into a
+ *               scratch image on the root's device; on the root that image is copied to rgb_sum / count (host; either may be NULL: the reduced
+ *               image then stays in HBM), the other ranks pass NULL.  Exact for the same reason as above; framebuffers are left as they are. */
+#define TGHIP_COMM_ID_BYTES 128
+int tghip_comm_unique_id(void *id, size_t bytes);
+int tghip_comm_init_rank(tghip_ctx *ctx, const void *id, size_t bytes, int nranks, int rank);
+int tghip_reduce_framebuffer_rank(tghip_ctx *ctx, int root, float *rgb_sum, uint32_t *count, size_t npixels);
 int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_t n, int repeats, double *ms_per_launch);
 /* Self-test of the device's libm restatements (csrc/hip/pt_libm.h: glibc's sinf / cosf / logf / expf / atan2f / powf / cbrtf as the shading
  * kernels call them, pt_math.h: acosf): y[i] = fn(x[i]) evaluated ON THE DEVICE, host pointers.  fn: TGHIP_LIBM_*.  The two-argument

@@ -36,6 +36,10 @@ if rank == 0:
     ws, wc = oracle_lib.render(flat.desc, 80, 45, 0, 2, 1234)
     assert (fs.numpy() == ws).all() and (fc.numpy() == wc.astype(np.int32)).all()
     print("DIST_OK")
+# the product's own exchange step (tghip_comm_* behind tgdist.init_rank_comm) cannot be built without a device: every rank must learn that, agree on
+# it through the all-reduce and get the same reason back -- bench.py then falls back to reduce_framebuffer above, and says so
+why = tgdist.init_rank_comm(tg.lib, None, rank, world)
+assert why is not None and "failed on a rank" in why
 dist.barrier()
 dist.destroy_process_group()
 '''

@@ -651,6 +651,39 @@ def test_rccl_framebuffer_reduce_behind_the_c_abi(n, tmp_path):
     flat.close()
 
 
+def test_rank_communicator_reduce_behind_the_c_abi(tmp_path):
+    """tghip_comm_unique_id / tghip_comm_init_rank / tghip_reduce_framebuffer_rank: the exchange step of one process per GPU (bench.py --gpus N under
+    torch.distributed.run) with a world of ONE rank -- the whole RCCL path (id, ncclCommInitRank, grouped ncclReduce into the root's scratch image,
+    download) on the one device every box has; the merged image is the render's, bit for bit, the context's own framebuffer untouched."""
+    import ctypes as C
+    w, h, spp = 200, 120, 4
+    path = scenes.cornell(tmp_path, resolution=(w, h), spp=spp)
+    whole, wsum, wcount, _ = gpu_render(path)
+    flat, ctxs = _shard_contexts(path, 1, spp)
+    ctx, npix = ctxs[0], w*h
+    s, c = np.full((npix, 3), -1, np.float32), np.full(npix, 7, np.uint32)
+    assert tg.lib.tghip_reduce_framebuffer_rank(ctx, 0, s.ctypes.data, c.ctypes.data, npix) == -1          # no communicator yet
+    assert b"tghip_comm_init_rank" in tg.lib.tghip_last_error(ctx)
+    ident = (C.c_ubyte*tg.capi.TGHIP_COMM_ID_BYTES)()
+    assert tg.lib.tghip_comm_unique_id(ident, 64) == -1                                                    # buffer too small
+    assert tg.lib.tghip_comm_unique_id(ident, len(ident)) == 0 and any(ident)
+    assert tg.lib.tghip_comm_init_rank(ctx, ident, len(ident), 1, 1) == -1                                 # rank outside the world
+    assert tg.lib.tghip_comm_init_rank(ctx, ident, len(ident), 1, 0) == 0, tg.lib.tghip_last_error(ctx)
+    assert tg.lib.tghip_reduce_framebuffer_rank(ctx, 0, None, None, npix) == 0                             # (merged image stays in HBM)
+    assert tg.lib.tghip_reduce_framebuffer_rank(ctx, 0, s.ctypes.data, c.ctypes.data, npix) == 0, tg.lib.tghip_last_error(ctx)
+    assert (c.reshape(h, w) == wcount).all() and s.reshape(h, w, 3).tobytes() == wsum.tobytes()
+    assert tg.lib.tghip_reduce_framebuffer_rank(ctx, 1, s.ctypes.data, c.ctypes.data, npix) == -1          # root outside the world
+    assert tg.lib.tghip_reduce_framebuffer_rank(ctx, 0, s.ctypes.data, c.ctypes.data, npix + 1) == -1
+    fs, fc = np.empty((npix, 3), np.float32), np.empty(npix, np.uint32)
+    assert tg.lib.tghip_download_framebuffer(ctx, fs.ctypes.data, fc.ctypes.data, npix) == 0 and fs.tobytes() == wsum.tobytes()
+    # a second communicator on the same context replaces the first
+    assert tg.lib.tghip_comm_unique_id(ident, len(ident)) == 0
+    assert tg.lib.tghip_comm_init_rank(ctx, ident, len(ident), 1, 0) == 0
+    assert tg.lib.tghip_reduce_framebuffer_rank(ctx, 0, s.ctypes.data, c.ctypes.data, npix) == 0 and s.reshape(h, w, 3).tobytes() == wsum.tobytes()
+    tg.lib.tghip_destroy(ctx)
+    flat.close()
+
+
 def test_a_failing_reduce_falls_back_to_the_host_sum(tmp_path, capfd):
     """tghip_reduce_framebuffers made to fail (the "fail_reduce" fault-injection option): the C-ABI call reports TGHIP_E_HIP with a message and
     leaves the shards' framebuffers alone, and the integrator's exchange step (Integrator.cpp: fetchFramebuffer) falls back to per-device

@@ -152,6 +152,8 @@ class TgHostSceneInfo(C.Structure):
 
 # every symbol the two headers declare: name -> (restype, argtypes)
 VP = C.c_void_p
+TGHIP_COMM_ID_BYTES = 128
+
 PROTOTYPES = {
     # include/tungsten_hip.h
     "tghip_create": (VP, [C.c_int]),
@@ -177,6 +179,9 @@ PROTOTYPES = {
     "tghip_set_option": (C.c_int, [VP, C.c_char_p, C.c_longlong]),
     "tghip_get_counters": (C.c_int, [VP, C.POINTER(TgHipCounters)]),
     "tghip_reset_counters": (C.c_int, [VP]),
+    "tghip_comm_unique_id": (C.c_int, [VP, C.c_size_t]),
+    "tghip_comm_init_rank": (C.c_int, [VP, VP, C.c_size_t, C.c_int, C.c_int]),
+    "tghip_reduce_framebuffer_rank": (C.c_int, [VP, C.c_int, VP, VP, C.c_size_t]),
     "tghip_get_walk_stats": (C.c_int, [VP, C.c_int, C.POINTER(C.c_uint64), C.c_int]),
     # include/tungsten_host.h
     "tgh_scene_load": (VP, [C.c_char_p, C.c_char_p, C.c_size_t]),

@@ -191,6 +191,8 @@ struct tghip_ctx {
     bool haveSolids = false;              // cube / sphere / disk records: the dynamic-fetch kernels' SOLIDS variants
     TgHipAuxPixel *dAux = nullptr;        // auxiliary output buffers (allocated by the first TGHIP_PASS_AUX pass)
     float *dSamples = nullptr;            // TGHIP_PASS_SAMPLES: per-sample radiance of the last such pass
+    void *rankComm = nullptr;             // tghip_comm_init_rank: this process's ncclComm_t (one process per GPU); destroyed with the context
+    int rankCount = 0, rankIndex = 0;
     float *redSum = nullptr;              // tghip_reduce_framebuffers: where the reduced image lands when this context is the root
     uint32_t *redCount = nullptr;
     size_t redCap = 0;                    // pixels redSum / redCount were allocated for (a re-upload may change the resolution)
@@ -804,6 +806,7 @@ tghip_ctx *tghip_create(int device_ordinal)
     return ctx;
 }
 
+extern "C++" void tghipDestroyRankComm(void *comm);   // (defined with the RCCL loader below)
 void tghip_destroy(tghip_ctx *ctx)
 {
     if (!ctx) return;
@@ -827,6 +830,7 @@ void tghip_destroy(tghip_ctx *ctx)
     if (ctx->dAux) (void)hipFree(ctx->dAux);
     if (ctx->dSamples) (void)hipFree(ctx->dSamples);
     if (ctx->dOwnedTiles) (void)hipFree(ctx->dOwnedTiles);
+    if (ctx->rankComm) tghipDestroyRankComm(ctx->rankComm);
     if (ctx->redSum) (void)hipFree(ctx->redSum);
     if (ctx->redCount) (void)hipFree(ctx->redCount);
     if (ctx->partial) (void)hipFree(ctx->partial);
@@ -1089,7 +1093,11 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 }
                 if (ok && quad >= 0 && node >= 0) {
                     const uint32_t word = 1u << bit;
-                    HIP_TRY(ctx, hipMemcpy(p + size_t(node)*stride + offsetof(TgHipWideNode, reserved), &word, sizeof(word), hipMemcpyHostToDevice));
+                    // (on ctx->stream, behind the 2-D copy of the nodes queued above: that stream is non-blocking, so a copy on the null stream would
+                    // not wait for it and could be overwritten by it -- the quad would then be tested before AND inside every walk; `word` is on
+                    // the stack, so the copy is waited for here)
+                    HIP_TRY(ctx, hipMemcpyAsync(p + size_t(node)*stride + offsetof(TgHipWideNode, reserved), &word, sizeof(word), hipMemcpyHostToDevice, ctx->stream));
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                     s.hoisted_rec = ctx->hoistOpt ? int32_t(quad) : -1;
                     ctx->hoistedRecScene = int32_t(quad);
                 }
@@ -2302,6 +2310,9 @@ struct RcclApi {
     bool tried = false;
     void *lib = nullptr;
     decltype(&ncclCommInitAll) commInitAll = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
     decltype(&ncclReduce) reduce = nullptr;
     decltype(&ncclGroupStart) groupStart = nullptr;
     decltype(&ncclGroupEnd) groupEnd = nullptr;
@@ -2311,7 +2322,10 @@ struct RcclApi {
     {
         if (tried) return lib != nullptr;
         tried = true;
-        lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        // An RCCL the process already has comes first (RTLD_NOLOAD matches by SONAME): a host program that brought its own -- PyTorch-ROCm ships
+        // one next to libtorch -- and this library must not end up with two copies whose exported symbols resolve into each other.
+        lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!lib) return false;
         commInitAll = reinterpret_cast<decltype(commInitAll)>(dlsym(lib, "ncclCommInitAll"));
@@ -2319,7 +2333,10 @@ struct RcclApi {
         groupStart = reinterpret_cast<decltype(groupStart)>(dlsym(lib, "ncclGroupStart"));
         groupEnd = reinterpret_cast<decltype(groupEnd)>(dlsym(lib, "ncclGroupEnd"));
         errorString = reinterpret_cast<decltype(errorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!commInitAll || !reduce || !groupStart || !groupEnd || !errorString) { dlclose(lib); lib = nullptr; }
+        getUniqueId = reinterpret_cast<decltype(getUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+        commInitRank = reinterpret_cast<decltype(commInitRank)>(dlsym(lib, "ncclCommInitRank"));
+        commDestroy = reinterpret_cast<decltype(commDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        if (!commInitAll || !reduce || !groupStart || !groupEnd || !errorString || !getUniqueId || !commInitRank || !commDestroy) { dlclose(lib); lib = nullptr; }
         return lib != nullptr;
     }
 } g_rccl;
@@ -2435,6 +2452,80 @@ int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n)
     (void)hipFree(dx);
     if (dy) (void)hipFree(dy);
     if (e != hipSuccess) { ctx->error = hipGetErrorString(e); return TGHIP_E_HIP; }
+    return TGHIP_OK;
+}
+
+extern "C++" void tghipDestroyRankComm(void *comm)
+{
+    std::lock_guard<std::mutex> lock(g_rccl.mutex);
+    if (comm && g_rccl.load()) (void)g_rccl.commDestroy(static_cast<ncclComm_t>(comm));
+}
+
+// ---- the same reduce between PROCESSES (one process per GPU, SURVEY.md 8e: torch.distributed.run, mpirun, ...) ----
+int tghip_comm_unique_id(void *id, size_t bytes)
+{
+    static_assert(sizeof(ncclUniqueId) == TGHIP_COMM_ID_BYTES, "TGHIP_COMM_ID_BYTES");
+    if (!id || bytes < sizeof(ncclUniqueId)) return TGHIP_E_INVALID;
+    std::lock_guard<std::mutex> lock(g_rccl.mutex);
+    if (!g_rccl.load()) return TGHIP_E_UNSUPPORTED;
+    ncclUniqueId u;
+    if (g_rccl.getUniqueId(&u) != ncclSuccess) return TGHIP_E_HIP;
+    std::memcpy(id, &u, sizeof(u));
+    return TGHIP_OK;
+}
+
+int tghip_comm_init_rank(tghip_ctx *ctx, const void *id, size_t bytes, int nranks, int rank)
+{
+    if (!ctx || !id || bytes < sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks) return TGHIP_E_INVALID;
+    if (ctx->failReduce) { ctx->error = "tghip_comm_init_rank: forced failure (the \"fail_reduce\" option)"; return TGHIP_E_HIP; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lock(g_rccl.mutex);
+    if (!g_rccl.load()) { ctx->error = "tghip_comm_init_rank: librccl.so could not be loaded"; return TGHIP_E_UNSUPPORTED; }
+    if (ctx->rankComm) { (void)g_rccl.commDestroy(static_cast<ncclComm_t>(ctx->rankComm)); ctx->rankComm = nullptr; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = g_rccl.commInitRank(&comm, nranks, u, rank);
+    if (r != ncclSuccess) { ctx->error = std::string("ncclCommInitRank: ") + g_rccl.errorString(r); return TGHIP_E_HIP; }
+    ctx->rankComm = comm; ctx->rankCount = nranks; ctx->rankIndex = rank;
+    return TGHIP_OK;
+}
+
+int tghip_reduce_framebuffer_rank(tghip_ctx *ctx, int root, float *rgb_sum, uint32_t *count, size_t npixels)
+{
+    if (!ctx) return TGHIP_E_INVALID;
+    if (!ctx->haveScene) return TGHIP_E_NOSCENE;
+    if (!ctx->rankComm) { ctx->error = "tghip_reduce_framebuffer_rank: no communicator (tghip_comm_init_rank)"; return TGHIP_E_INVALID; }
+    if (root < 0 || root >= ctx->rankCount || npixels != size_t(ctx->width)*ctx->height) { ctx->error = "tghip_reduce_framebuffer_rank: root / pixel count mismatch"; return TGHIP_E_INVALID; }
+    if (ctx->failReduce) { ctx->error = "tghip_reduce_framebuffer_rank: forced failure (the \"fail_reduce\" option)"; return TGHIP_E_HIP; }
+    int w = tghip_wait(ctx);
+    if (w != TGHIP_OK && w != TGHIP_E_ABORTED) return w;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool isRoot = ctx->rankIndex == root;
+    if (isRoot && ctx->redCap < npixels) {
+        if (ctx->redSum) (void)hipFree(ctx->redSum);
+        if (ctx->redCount) (void)hipFree(ctx->redCount);
+        ctx->redSum = nullptr; ctx->redCount = nullptr; ctx->redCap = 0;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->redSum), npixels*3*sizeof(float)));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->redCount), npixels*sizeof(uint32_t)));
+        ctx->redCap = npixels;
+    }
+    const float *sum = ctx->extSum ? ctx->extSum : ctx->fbSum;
+    const uint32_t *cnt = ctx->extCount ? ctx->extCount : ctx->fbCount;
+    ncclComm_t comm = static_cast<ncclComm_t>(ctx->rankComm);
+    ncclResult_t r;
+    {
+        std::lock_guard<std::mutex> lock(g_rccl.mutex);
+        r = g_rccl.groupStart();
+        if (r == ncclSuccess) r = g_rccl.reduce(sum, isRoot ? ctx->redSum : nullptr, npixels*3, ncclFloat32, ncclSum, root, comm, ctx->stream);
+        if (r == ncclSuccess) r = g_rccl.reduce(cnt, isRoot ? ctx->redCount : nullptr, npixels, ncclUint32, ncclSum, root, comm, ctx->stream);
+        const ncclResult_t e = g_rccl.groupEnd();
+        if (r == ncclSuccess) r = e;
+    }
+    if (r != ncclSuccess) { ctx->error = std::string("ncclReduce: ") + g_rccl.errorString(r); return TGHIP_E_HIP; }
+    if (isRoot && rgb_sum) HIP_TRY(ctx, hipMemcpyAsync(rgb_sum, ctx->redSum, npixels*3*sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (isRoot && count) HIP_TRY(ctx, hipMemcpyAsync(count, ctx->redCount, npixels*sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return TGHIP_OK;
 }
 

@@ -61,6 +61,33 @@ def reduce_framebuffer(fb_sum, fb_count, dst=0, group=None):
         torch.cuda.current_stream(fb_sum.device).synchronize()
 
 
+def init_rank_comm(lib, ctx, rank, world, group=None):
+    """The product's own exchange step for one process per GPU (include/tungsten_hip.h: tghip_comm_unique_id / tghip_comm_init_rank /
+    tghip_reduce_framebuffer_rank -- ncclReduce between the ranks' contexts, no torch tensor involved).  torch.distributed only carries rank 0's
+    128-byte RCCL id to the other ranks and agrees on the outcome: returns None when EVERY rank has its communicator, otherwise the reason
+    (the same string on every rank) -- the caller then reduces with reduce_framebuffer() above, and says so.  Collective over `group`."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+
+    def all_ok(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(t.item()))
+    n = capi.TGHIP_COMM_ID_BYTES
+    buf = (C.c_ubyte*n)()
+    probe = lib.tghip_comm_unique_id(buf, n)          # (every rank: does RCCL load here?  only rank 0's id is used)
+    if not all_ok(probe == 0):
+        return "tghip_comm_unique_id failed on a rank (librccl.so missing?)"
+    box = [bytes(buf) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    ident = (C.c_ubyte*n).from_buffer_copy(box[0])
+    rc = lib.tghip_comm_init_rank(ctx, ident, n, world, rank)
+    if not all_ok(rc == 0):
+        return "tghip_comm_init_rank failed on a rank: %s" % (lib.tghip_last_error(ctx).decode() if rc != 0 else "(another rank)")
+    return None
+
+
 def merge_records(records, group=None):
     """SampleRecords (TGHIP_PASS_RECORDS) of a tile-sharded pass: every record is non-zero on exactly the rank that owns
     its tile, so an all-reduce(SUM) of the three fields hands every rank the complete, bit-exact set (x + 0).
