@@ -532,7 +532,35 @@ class Bench(object):
                                     mix[n] = mix.get(n, 0.0) + v2
                         simd_hz = prop.multi_processor_count*4*MAX_CLOCK_HZ
                         cyc_lo, cyc_hi = lo/float(w*h*pmc_spp), hi/float(w*h*pmc_spp)
+                        # ONE number instead of the interval: every instantiation's instruction count at the average price of ITS OWN instruction
+                        # mix, read off the library's code object (tools/isa_histogram.py: the kernel's main loop, every opcode at its measured cost)
+                        static = None
+                        try:
+                            sys.path.insert(0, os.path.join(ROOT, "tools"))
+                            import isa_histogram
+                            inst = LAST_VARIANTS.get("a", {})
+                            hist = isa_histogram.kernel_prices(tg.capi.LIB_PATH, sorted(set(re.sub(r"<.*", "", v) for v in inst)))
+                            cyc, per_variant, missing = 0.0, {}, []
+                            for v, c in inst.items():
+                                n = c.get("SQ_INSTS_VALU", 0.0)
+                                hv = hist.get(v)
+                                p = (hv["loop"]["cycles_per_instruction"] or hv["kernel"]["cycles_per_instruction"]) if hv else None
+                                if p is None:
+                                    missing.append(v)
+                                    p = 2.5
+                                cyc += n*p
+                                if n/total >= 0.005:
+                                    per_variant[v] = {"share_of_instructions": round(n/total, 4), "cycles_per_instruction": p}
+                            static = {"simd_cycles_per_sample": round(cyc/float(w*h*pmc_spp), 1),
+                                      "cycles_per_instruction": round(cyc/total, 3),
+                                      "frac_of_simd_time_at_max_clock": round(cyc/float(w*h*pmc_spp)*value*1e6/simd_hz, 4),
+                                      "per_kernel": per_variant, "not_found": missing,
+                                      "source": "tools/isa_histogram.py on %s: VALU opcodes of each kernel's main loop x tools/ubench_valu.hip's cycles "
+                                                "(profiles/r5_ubench_valu.txt, r6_ubench_valu.txt), weighted by this run's SQ_INSTS_VALU per instantiation" % os.path.basename(tg.capi.LIB_PATH)}
+                        except Exception as e:     # (objdump missing on a box: the interval below stays)
+                            static = {"error": str(e)}
                         roofline["valu"]["priced"] = {
+                            "static_mix": static,
                             "simd_cycles_per_sample": [round(cyc_lo, 1), round(cyc_hi, 1)],
                             "frac_of_simd_time_at_max_clock": [round(cyc_lo*value*1e6/simd_hz, 4), round(cyc_hi*value*1e6/simd_hz, 4)],
                             "mix": {n.replace("SQ_INSTS_VALU_", "").lower(): round(v2/total, 4) for n, v2 in sorted(mix.items())},
@@ -751,6 +779,9 @@ def measure_counter_all(a, scene, w, h, spp, tmp, counter):
     return {k: (v, len(ids[k])) for k, v in sums.items()} or None
 
 
+LAST_VARIANTS = {}     # measure_counters_all: the same sums per kernel INSTANTIATION (template arguments kept), by pass tag
+
+
 def measure_counters_all(a, scene, w, h, spp, tmp, counters, tag):
     """Several PMC counters (one pass: at most eight SQ counters fit, MI355X_MICROARCH.md "rocprofv3 PMC slots") summed per kernel class over
     one child run under rocprofv3: {kernel class: {counter: total}}; None on failure."""
@@ -770,7 +801,7 @@ def measure_counters_all(a, scene, w, h, spp, tmp, counters, tag):
     files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
     if p.returncode != 0 or not files:
         return None
-    sums = {}
+    sums, variants = {}, {}
     with open(files[0]) as f:
         for row in csv.DictReader(f):
             k = kernel_class(row["Kernel_Name"])
@@ -778,7 +809,10 @@ def measure_counters_all(a, scene, w, h, spp, tmp, counters, tag):
                 continue
             e = sums.setdefault(k, {})
             e[row["Counter_Name"]] = e.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            v = variants.setdefault(re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "").strip(), {})      # template arguments kept
+            v[row["Counter_Name"]] = v.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
     shutil.rmtree(out, ignore_errors=True)
+    LAST_VARIANTS[tag] = variants
     return sums or None
 
 

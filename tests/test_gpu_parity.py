@@ -413,6 +413,33 @@ def test_instanced_shadow_walk_agrees_with_the_bvh2_walk(tmp_path):
     assert (images["wide, counting"] == images["bvh2"]).all()
 
 
+@pytest.mark.parametrize("scene", ["materialtest", "mesh1m"])
+def test_hinted_kernels_are_deterministic_and_agree_with_the_plain_walks(scene, tmp_path):
+    """The kernels whose path-pool stores carry the non-temporal hint (PT_NT_STATE: the wavefront k_shade launches, the decoupled walks, the folded
+    k_finish) at the size where the pool is megabytes and four parts share the chip: the default build renders the same image twice, bit for
+    bit, and that image is the one of the kernels WITHOUT the hint -- the sequential wide walks (decouple = 0, stand-alone k_finish) and the BVH2
+    walks (wide_bvh = 0).  What the hint may and may not do was measured on the device (tools/ubench_nt_coherence.hip,
+    profiles/r6_ubench_nt_coherence.txt: a plain load after a non-temporal store never reads a stale line, same lane or another wave of the
+    workgroup); this test holds the product's kernels to it (round 5's k_trace_shadow_wide failure showed as run-to-run differences)."""
+    _skip_mt(scene)
+    path = (scenes.materialtest if scene == "materialtest" else scenes.mesh1m)(tmp_path, resolution=(960, 540), spp=4)
+    r = tg.Renderer(path, seed=SEED)
+    try:
+        first = _one_pass(r, 4)
+        again = _one_pass(r, 4)
+        images = {}
+        for name, opts in (("sequential wide walks", dict(decouple=0, fold_finish=0)), ("BVH2 walks", dict(decouple=1, fold_finish=1, wide_bvh=0))):
+            for k, v in opts.items():
+                r.set_option(k, v)
+            images[name] = _one_pass(r, 4)
+    finally:
+        r.close()
+    assert np.isfinite(first).all() and first.mean() > 0.05
+    assert (first == again).all(), "two renders of the default build differ in %.4f %% of the pixels" % (100.0*float((first != again).any(axis=-1).mean()))
+    for name, img in images.items():
+        assert (img == first).all(), "%s: %.4f %% of the pixels differ" % (name, 100.0*float((img != first).any(axis=-1).mean()))
+
+
 def _one_pass(r, spp, seed=SEED):
     """one plain pass [0, spp) into a cleared framebuffer on the renderer's first context; returns the radiance sums"""
     import ctypes as C

@@ -43,7 +43,11 @@ def one_pass(counters, a, tmp, tag):
            "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"] + [x for kv in a.opt for x in ("--opt", kv)]
     if a.res:
         cmd += ["--res", a.res]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=a.timeout)
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=a.timeout)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("pass %s timed out after %d s\n" % (tag, a.timeout))
+        return {}
     files = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
     if p.returncode != 0 or not files:
         sys.stderr.write("pass %s failed (rc %d): %s\n" % (tag, p.returncode, p.stdout[-800:]))

@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <string>
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -54,10 +55,55 @@ static int run(const char *name, uint32_t *out)
     return 0;
 }
 
-int main()
+// the same chain under an arbitrary EXEC mask (a kernel argument): WHICH lanes are enabled, not only how many -- the first run showed a cliff
+// between 16 and 8 enabled lanes (fma 840 -> 233 G wave-instructions/s), which a walk's one- and two-lane divergent regions would sit on
+__global__ __launch_bounds__(256) void k_mask(int iters, uint32_t seed, uint32_t *out, unsigned long long mask, int waves)
+{
+    uint32_t a[8];
+    for (int k = 0; k < 8; ++k) a[k] = seed + threadIdx.x*(k + 1);
+    uint32_t b = seed | 1u, c = seed ^ 0x3f800000u;
+    if (((mask >> (threadIdx.x & 63u)) & 1ull) && (int)(threadIdx.x >> 6) < waves) {
+        for (int i = 0; i < iters; ++i) { BODY4(A_FMA) }
+    }
+    uint32_t r = 0;
+    for (int k = 0; k < 8; ++k) r ^= a[k];
+    if (r == 0x12345u) out[0] = r;
+}
+static int runMask(const char *name, unsigned long long mask, int waves, int blocksPerCu, uint32_t *out)
+{
+    const int iters = 2000, blocks = 256*blocksPerCu;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mask, dim3(blocks), dim3(256), 0, 0, 10, 1u, out, mask, waves);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_mask, dim3(blocks), dim3(256), 0, 0, iters, 1u, out, mask, waves);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double waveInsts = (double)blocks*waves*iters*32.0;
+    std::printf("mask %-34s %016llx (%2d lanes) %d waves/block x %d blocks/CU %8.3f ms  %7.1f G wave-inst/s\n", name, mask, __builtin_popcountll(mask), waves, blocksPerCu, ms, waveInsts/ms*1e-6);
+    return 0;
+}
+
+int main(int argc, char **argv)
 {
     uint32_t *out = nullptr;
     CHECK(hipMalloc(&out, 64));
+    if (argc > 1 && std::string(argv[1]) == "masks") {
+        struct { const char *name; unsigned long long m; } pats[] = {
+            {"all", ~0ull}, {"first 16", 0xFFFFull}, {"first 12", 0xFFFull}, {"first 10", 0x3FFull}, {"first 9", 0x1FFull}, {"first 8", 0xFFull},
+            {"first 4", 0xFull}, {"first 2", 0x3ull}, {"first 1", 0x1ull}, {"lanes 32..39", 0xFFull << 32}, {"lanes 56..63", 0xFFull << 56},
+            {"every 8th (8 lanes)", 0x0101010101010101ull}, {"every 4th (16 lanes)", 0x1111111111111111ull}, {"every 16th (4 lanes)", 0x0001000100010001ull},
+            {"4 + 4 in two halves", 0x0000000F0000000Full}, {"one lane per 16 + first 8", 0x00010001000100FFull}, {"lanes 0..7 and 32..39", 0x000000FF000000FFull},
+        };
+        for (auto &p : pats) if (runMask(p.name, p.m, 4, 8, out)) return 1;
+        // fewer waves per SIMD: is the cliff an issue-rate effect that more waves hide, or a per-instruction cost?
+        for (int bpc : {1, 2, 4}) { if (runMask("all", ~0ull, 4, bpc, out) || runMask("first 8", 0xFFull, 4, bpc, out) || runMask("first 1", 1ull, 4, bpc, out)) return 1; }
+        CHECK(hipFree(out));
+        return 0;
+    }
 #define RUN_ALL(KIND, NAME) \
     if (run<KIND, 64>(NAME, out) || run<KIND, 48>(NAME, out) || run<KIND, 32>(NAME, out) || run<KIND, 16>(NAME, out) || run<KIND, 8>(NAME, out) || run<KIND, 1>(NAME, out)) return 1;
     RUN_ALL(0, "fma")

@@ -64,6 +64,78 @@
 #define A_OR3(k)      asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
 #define A_SUB(k)      asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
 #define A_PKMUL(k)    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2[k]) : "v"(b2));
+// round 6: the opcodes tools/isa_histogram.py found in the kernels that rounds 1-5 had not timed (the division sequence, SGPR-spill lane moves, ...)
+#define A_DIVSCALE(k) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[k]) : "v"(c) : "vcc");
+#define A_DIVFMAS(k)  asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c) : "vcc");
+#define A_DIVFIXUP(k) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(b), "v"(c));
+#define A_READLANE(k) asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(sg[k]) : "v"(a[k]));
+#define A_WRITELANE(k) asm volatile("v_writelane_b32 %0, %1, 3" : "+v"(a[k]) : "s"(sg[k]));
+#define A_XOR(k)      asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define A_LSHR(k)     asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a[k]));
+#define A_BFEI(k)     asm volatile("v_bfe_i32 %0, %0, 3, 8" : "+v"(a[k]));
+#define A_CVT_I32(k)  asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[k]));
+#define A_MIN(k)      asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define A_CMPU(k)     asm volatile("v_cmp_eq_u32 vcc, %0, %1" : : "v"(a[k]), "v"(b) : "vcc");
+#define A_RSQ(k)      asm volatile("v_rsq_f32 %0, %0" : "+v"(a[k]));
+#define A_LDEXP(k)    asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+#define A_MULHI(k)    asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+DEFINE_KERNEL(divscale, A_DIVSCALE)
+DEFINE_KERNEL(divfmas, A_DIVFMAS)
+DEFINE_KERNEL(divfixup, A_DIVFIXUP)
+DEFINE_KERNEL(xor_, A_XOR)
+DEFINE_KERNEL(lshr, A_LSHR)
+DEFINE_KERNEL(bfei, A_BFEI)
+DEFINE_KERNEL(cvt_i32, A_CVT_I32)
+DEFINE_KERNEL(min_, A_MIN)
+DEFINE_KERNEL(cmpu, A_CMPU)
+DEFINE_KERNEL(rsq, A_RSQ)
+DEFINE_KERNEL(ldexp_, A_LDEXP)
+DEFINE_KERNEL(mulhi, A_MULHI)
+__global__ __launch_bounds__(256) void k_readlane(int iters, uint32_t seed, uint32_t *out)
+{
+    uint32_t a[8], sg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 8; ++k) a[k] = seed + threadIdx.x*(k + 1);
+    for (int i = 0; i < iters; ++i) { BODY4(A_READLANE) }
+    uint32_t r = 0;
+    for (int k = 0; k < 8; ++k) r ^= a[k] ^ sg[k];
+    if (r == 0x12345u) out[0] = r;
+}
+__global__ __launch_bounds__(256) void k_writelane(int iters, uint32_t seed, uint32_t *out)
+{
+    uint32_t a[8], sg[8];
+    for (int k = 0; k < 8; ++k) { a[k] = seed + threadIdx.x*(k + 1); sg[k] = seed + k; }
+    for (int i = 0; i < iters; ++i) { BODY4(A_WRITELANE) }
+    uint32_t r = 0;
+    for (int k = 0; k < 8; ++k) r ^= a[k];
+    if (r == 0x12345u) out[0] = r;
+}
+// f64 add / mul (Phong's pow(double) and the libm restatements' double arithmetic)
+__global__ __launch_bounds__(256) void k_add64(int iters, uint32_t seed, uint32_t *out)
+{
+    double a[8];
+    for (int k = 0; k < 8; ++k) a[k] = double(seed + threadIdx.x*(k + 1));
+    double b = 1.0000001;
+    for (int i = 0; i < iters; ++i) {
+#define A_ADD64(k) asm volatile("v_add_f64 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+        BODY4(A_ADD64)
+    }
+    double r = 0.0;
+    for (int k = 0; k < 8; ++k) r += a[k];
+    if (r == 12345.0) out[0] = 1u;
+}
+__global__ __launch_bounds__(256) void k_mul64(int iters, uint32_t seed, uint32_t *out)
+{
+    double a[8];
+    for (int k = 0; k < 8; ++k) a[k] = double(seed + threadIdx.x*(k + 1));
+    double b = 1.0000001;
+    for (int i = 0; i < iters; ++i) {
+#define A_MUL64(k) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a[k]) : "v"(b));
+        BODY4(A_MUL64)
+    }
+    double r = 0.0;
+    for (int k = 0; k < 8; ++k) r += a[k];
+    if (r == 12345.0) out[0] = 1u;
+}
 DEFINE_KERNEL(fmamix, A_FMAMIX)
 DEFINE_KERNEL(fmamixh, A_FMAMIXH)
 DEFINE_KERNEL(cvt_f16, A_CVT_F16)
@@ -144,6 +216,10 @@ int main()
         {"v_cndmask_b32", k_cndmask, 1}, {"v_cmp_lt_f32", k_cmp, 1}, {"v_cmp + v_cndmask", k_cmp_cnd, 2},
         {"v_mul_lo_u32", k_mul_lo, 1}, {"v_mad_u32_u24", k_mad_u24, 1}, {"v_bcnt_u32_b32", k_bcnt, 1}, {"v_ffbl_b32", k_ffbl, 1},
         {"v_rcp_f32", k_rcp, 1}, {"v_sqrt_f32", k_sqrt_, 1},
+        {"v_div_scale_f32", k_divscale, 1}, {"v_div_fmas_f32", k_divfmas, 1}, {"v_div_fixup_f32", k_divfixup, 1}, {"v_readlane_b32", k_readlane, 1},
+        {"v_writelane_b32", k_writelane, 1}, {"v_xor_b32", k_xor_, 1}, {"v_lshrrev_b32", k_lshr, 1}, {"v_bfe_i32", k_bfei, 1}, {"v_cvt_i32_f32", k_cvt_i32, 1},
+        {"v_min_f32", k_min_, 1}, {"v_cmp_eq_u32", k_cmpu, 1}, {"v_rsq_f32", k_rsq, 1}, {"v_ldexp_f32", k_ldexp_, 1}, {"v_mul_hi_u32", k_mulhi, 1},
+        {"v_add_f64", k_add64, 1}, {"v_mul_f64", k_mul64, 1},
     };
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
