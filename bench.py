@@ -26,6 +26,13 @@ line, plain and priced per instruction category, with the enabled lanes per issu
 times the reference itself (oracle/_ref/tungsten, kind "reference") or, when that binary is absent, the
 oracle port, on a bounded sample of the same workload on this box's host cores.
 """
+try:
+    # FIRST, before anything that loads libtungsten_hip.so: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Loaded first, it is the one
+    # copy in the process (the library's DT_NEEDED libamdhip64.so.7 resolves to it by SONAME); loaded second, the process ends up with two HSA
+    # runtimes and the second one finds no device (round 6 lost two GPU sessions to `from tungsten_amd import workloads` ahead of `import torch`).
+    import torch  # noqa: F401
+except ImportError:
+    torch = None
 import argparse
 import ctypes as C
 import json

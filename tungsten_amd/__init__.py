@@ -4,6 +4,9 @@ Python here is only a ctypes convenience layer over the C-ABI (include/tungsten_
 include/tungsten_host.h) for tests and bench.py; all rendering happens in the native library
 (C++11 host + HIP kernels for gfx950).  Importing the package fails if that library is missing:
 there is no Python or CPU fallback.
+
+A process that also uses PyTorch-ROCm must `import torch` BEFORE this package: torch ships its own HIP / HSA runtime, and two copies in one
+process do not share the device (bench.py and the tests' multi-process workers import torch first; nothing here imports it).
 """
 import ctypes as C
 import os
