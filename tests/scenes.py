@@ -385,6 +385,42 @@ def cornell_instances(tmpdir, count=40, smooth=(True, False), **kw):
 
 GOLDEN_CASES["cornell_instances"] = (cornell_instances, dict(resolution=(48, 27), spp=8))
 
+
+def cornell_instance_ties(tmpdir, **kw):
+    """Where the `instances` item sits in the reference's top-level order (TraceableScene.hpp:112-134: every finite primitive, the instance set
+    being ONE item, in an Embree tree whose visiting order decides equal hits): the Cornell box with its two cubes replaced by three instances of
+    a glass box mesh standing ON the floor quad -- identity rotations and y = 0 positions, so the boxes' bottom triangles lie in the floor's
+    plane and a ray that went into a box leaves it at a distance the floor reports too, often to the bit.  Which of the two the path takes
+    (glass exit or Lambert floor) is decided by that order alone.  A second box leans against the left wall the same way."""
+    import numpy as np
+    tmpdir = str(tmpdir)
+    lo, hi = np.array([-0.25, 0.0, -0.25], np.float32), np.array([0.25, 0.5, 0.25], np.float32)
+    corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])], np.float32)   # index = 4 x + 2 y + z
+    faces = [((0, 1, 3, 2), (-1, 0, 0)), ((4, 6, 7, 5), (1, 0, 0)), ((0, 4, 5, 1), (0, -1, 0)), ((2, 3, 7, 6), (0, 1, 0)), ((0, 2, 6, 4), (0, 0, -1)), ((1, 5, 7, 3), (0, 0, 1))]
+    verts, tris = [], []
+    for quad, n in faces:
+        base = len(verts)
+        for k, c in enumerate(quad):
+            verts.append(list(corners[c]) + list(n) + [float(k in (1, 2)), float(k in (2, 3))])
+        tris += [[base, base + 1, base + 2, 0], [base, base + 2, base + 3, 0]]
+    write_wo3(os.path.join(tmpdir, "tie_box.wo3"), np.array(verts, np.float32), np.array(tris, np.int32))
+    user = kw.pop("edit", None)
+
+    def edit(scene):
+        scene["primitives"] = [p for p in scene["primitives"] if p["name"] not in ("shortBox", "tallBox")]
+        scene["bsdfs"].append({"name": "glass", "type": "dielectric", "ior": 1.5, "albedo": 1})
+        scene["primitives"].append({
+            "name": "boxes", "type": "instances", "transform": {},
+            "masters": [{"name": "box", "type": "mesh", "file": "tie_box.wo3", "smooth": False, "bsdf": "glass", "transform": {}}],
+            "instances": [{"id": 0, "transform": {"position": [0.35, 0, 0.3]}}, {"id": 0, "transform": {"position": [-0.3, 0, -0.25]}},
+                          {"id": 0, "transform": {"position": [-0.75, 0, 0.4]}}]})      # (x - 0.25 = -1: its side lies in the left wall)
+        if user:
+            user(scene)
+    return variant(CORNELL, tmpdir, kw.pop("name", "instance_ties.json"), edit=edit, **kw)
+
+
+GOLDEN_CASES["cornell_instance_ties"] = (cornell_instance_ties, dict(resolution=(48, 27), spp=8))
+
 def _thinlens(cateye):
     def edit(scene):
         scene["camera"].update(type="thinlens", focus_distance=6.0, aperture_size=0.12, cateye=cateye)

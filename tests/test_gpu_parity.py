@@ -89,7 +89,9 @@ def test_gpu_matches_oracle_and_reference_golden(name, tmp_path):
         assert 0 <= int(oc.shadow_rays) - int(c.shadow_rays) <= 0.01*oc.shadow_rays + 2
     # ... and against the reference's own per-sample output: the same (tests/test_oracle_golden.py: DIVERGING, the cases in which the oracle
     # leaves the reference's path, has been empty since the reference's top-level tree was restated)
-    from test_oracle_golden import DIVERGING, diverge_bound
+    from test_oracle_golden import DIVERGING, PINNED, diverge_bound
+    if name in PINNED:       # (a residual pinned sample by sample against the reference: tests/test_gpu_samples.py holds the device to it)
+        return
     ref = np.load(os.path.join(scenes.GOLDEN, name + "_samples.npz"))["samples"].mean(axis=2)
     allowed = diverge_bound(name, 0)
     compare(mean, ref, pix_rel=1e-4, max_bad=allowed/float(ref.shape[0]*ref.shape[1]), mean_rel=3e-2 if name in DIVERGING else 1e-5)
@@ -417,8 +419,8 @@ def test_instanced_shadow_walk_agrees_with_the_bvh2_walk(tmp_path):
 def test_hinted_kernels_are_deterministic_and_agree_with_the_plain_walks(scene, tmp_path):
     """The kernels whose path-pool stores carry the non-temporal hint (PT_NT_STATE: the wavefront k_shade launches, the decoupled walks, the folded
     k_finish) at the size where the pool is megabytes and four parts share the chip: the default build renders the same image twice, bit for
-    bit, and that image is the one of the kernels WITHOUT the hint -- the sequential wide walks (decouple = 0, stand-alone k_finish) and the BVH2
-    walks (wide_bvh = 0).  What the hint may and may not do was measured on the device (tools/ubench_nt_coherence.hip,
+    bit, and that image is the one of the kernels WITHOUT the hint -- the sequential wide walks (decouple = 0, stand-alone k_finish), bit for bit, and
+    the BVH2 walks (wide_bvh = 0) but for the few pixels in which two triangles are hit at the same distance.  What the hint may and may not do was measured on the device (tools/ubench_nt_coherence.hip,
     profiles/r6_ubench_nt_coherence.txt: a plain load after a non-temporal store never reads a stale line, same lane or another wave of the
     workgroup); this test holds the product's kernels to it (round 5's k_trace_shadow_wide failure showed as run-to-run differences)."""
     _skip_mt(scene)
@@ -437,7 +439,11 @@ def test_hinted_kernels_are_deterministic_and_agree_with_the_plain_walks(scene, 
     assert np.isfinite(first).all() and first.mean() > 0.05
     assert (first == again).all(), "two renders of the default build differ in %.4f %% of the pixels" % (100.0*float((first != again).any(axis=-1).mean()))
     for name, img in images.items():
-        assert (img == first).all(), "%s: %.4f %% of the pixels differ" % (name, 100.0*float((img != first).any(axis=-1).mean()))
+        differ = (img != first).any(axis=-1)
+        # (the BVH2 walk meets hits at EQUAL distances in another order than the wide walk: one or two pixels of 518 400 take the other triangle of an
+        # edge -- measured 1 / 2 on materialtest / mesh1m, round 6; the wide walks must agree with each other in every pixel)
+        allowed = 4 if name == "BVH2 walks" else 0
+        assert int(differ.sum()) <= allowed, "%s: %d pixels (%.4f %%) differ" % (name, int(differ.sum()), 100.0*float(differ.mean()))
 
 
 def _one_pass(r, spp, seed=SEED):

@@ -18,7 +18,7 @@ import pytest
 import oracle_lib
 import scenes
 import tungsten_amd as tg
-from test_oracle_golden import DIVERGING, diverge_bound, _oracle_samples
+from test_oracle_golden import DIVERGING, PINNED, diverge_bound, _oracle_samples
 
 pytestmark = pytest.mark.gpu
 SEED = tg.DEFAULT_SEED
@@ -74,6 +74,11 @@ def test_device_samples_match_the_reference_per_sample(name, tmp_path):
                                 "oracle_vs_ref": int(diverging(ora, ref).sum()), "device_bit_equal_ref": int(bit_ref.sum()),
                                 "device_bit_equal_oracle": int(bit_oracle.sum()), "bound": diverge_bound(name, off_ref.size)}) + "\n")
     assert int(off_oracle.sum()) <= DEVICE_VS_ORACLE, "%s: %d device samples leave the oracle's path" % (name, int(off_oracle.sum()))
+    if name in PINNED:
+        # the device is the oracle bit for bit, and the oracle's residual against the reference is pinned sample by sample (test_oracle_golden.PINNED)
+        assert bit_oracle.all(), "%s: %d device samples are not the oracle's bit for bit" % (name, int((~bit_oracle).sum()))
+        assert [[int(v) for v in c] for c in np.argwhere(~bit_ref)] == PINNED[name]
+        return
     assert int(off_ref.sum()) <= diverge_bound(name, off_ref.size), "%s: %d of %d device samples differ from the reference's (measured: %d)" % (
         name, int(off_ref.sum()), off_ref.size, DIVERGING.get(name, 0))
     if name not in ULP_LEVEL:

@@ -33,9 +33,11 @@ pytestmark = pytest.mark.gpu
 SEED = tg.DEFAULT_SEED
 
 # device samples that are not the reference's, measured on MI355X (round 5: profiles/r5_device_scale.jsonl; the index sets: round 6); every other case: 0
-# (the oracle's counts, tests/test_oracle_scale.py, are the same but for two single samples: scale64 mesh1m 1, materialtest_sobol 0 -- the
-# device's decoupled walk may visit a node before an earlier node's records have shortened the ray and so meets two equal hits in another order
-# than the oracle's sequential walk; both orders are orders of EQUAL hits)
+# (the oracle's counts, tests/test_oracle_scale.py, are the same but for two single samples: scale64 mesh1m 1, materialtest_sobol 0.  Not the
+# decoupled walk and not the hoisted quad: with `decouple` = 0 and `hoist_quad` = 0 the device's sets are the same (TG_SCALE_OPTS, round 6,
+# gpurun session r6_s3).  The oracle's renders walk the BVH2, the device the 8-wide tree collapsed from it: two triangles hit at EQUAL distances
+# are met in another order -- the same effect the BVH2 kernels show against the wide ones in one or two pixels of 518 400,
+# tests/test_gpu_parity.py::test_hinted_kernels_are_deterministic_and_agree_with_the_plain_walks.)
 RESIDUAL_FILE = os.path.join(scenes.GOLDEN, "scale_residual.json")
 RESIDUAL = json.load(open(RESIDUAL_FILE)) if os.path.exists(RESIDUAL_FILE) else {}
 RESIDUAL_WRITE = os.environ.get("TG_SCALE_RESIDUAL_WRITE")

@@ -67,6 +67,13 @@ def _needs_materialtest(name):
 # keeps the LAST hit in the visiting order of its own BVH -- the oracle walks that very tree, restated node for node, in that order.)
 # A case listed here would be held to 1.5 x its measured count + 5 samples.
 DIVERGING = {}
+# Cases whose residual against the reference is pinned EXACTLY: tests/golden/order_residual.json holds the (y, x, sample) index of every sample
+# in which the oracle's radiance is not the reference's bit for bit; the device must reproduce the ORACLE in every sample (tests/test_gpu_samples.py),
+# so the same set is the device's.  cornell_instance_ties (round 6): glass boxes -- instances of a mesh -- standing on the floor quad and against a
+# wall; where a box's face and the quad behind it are hit at the same distance, the reference's top-level Embree tree over ALL finite primitives
+# (the instance set being one item, TraceableScene.hpp:112-134) decides which one the path sees, and this library walks a BVH2 of its own over the
+# scene-level records there: 18 of 10 368 samples take the other surface.  A different set -- one more, one fewer, another 18 -- fails.
+PINNED = json.load(open(os.path.join(G, "order_residual.json"))) if os.path.exists(os.path.join(G, "order_residual.json")) else {}
 
 
 def diverge_bound(name, samples):
@@ -80,7 +87,7 @@ def diverge_bound(name, samples):
 # Since round 4 that includes every case with a triangle mesh (materialtest with all its hero materials, the 998 000-triangle mesh, the water
 # caustic, mesh emitters, the bump-mapped mesh): Embree's triangle test is restated down to its right-associated dot product and its
 # RCPPS-plus-Newton reciprocal (oracle.c: edot / intel_rcpps / embree_rcp), which was what kept 0.1 - 1.4 % of their samples on other paths.
-BIT_IDENTICAL = set(scenes.GOLDEN_CASES) - set(DIVERGING)
+BIT_IDENTICAL = set(scenes.GOLDEN_CASES) - set(DIVERGING) - set(PINNED)
 
 
 def _oracle_samples(mk, kw, name, tmp_path, ref, seed):
@@ -121,6 +128,10 @@ def test_oracle_matches_reference_per_sample(name, tmp_path):
     got = _oracle_samples(mk, kw, name, tmp_path, ref, seed)
     if name in BIT_IDENTICAL:
         assert (got == ref).all(), "%s: %d samples are not the reference's bit for bit" % (name, int((got != ref).any(axis=-1).sum()))
+    if name in PINNED:
+        where = [[int(v) for v in c] for c in np.argwhere((got.view(np.uint32) != ref.view(np.uint32)).any(axis=-1))]
+        assert where == PINNED[name], "%s: the samples that are not the reference's are not the pinned ones: %s against %s" % (name, where[:6], PINNED[name][:6])
+        return
     err = np.abs(got - ref).max(axis=-1)
     bad = err > 1e-3*(np.abs(ref).max(axis=-1) + 1e-3)
     assert int(bad.sum()) <= diverge_bound(name, bad.size), "%s: %d of %d samples differ from the reference (measured: %d)" % (

@@ -102,6 +102,7 @@ struct BlockStats {               // traversal statistics (count_traversal optio
     unsigned long long walk[2][PT_WALK_STATS];
 #ifdef PT_PROFILE
     unsigned long long profCls[PT_NUM_CLASSES + 2][16];   // the same per shading class of the launch (CLS_MISS = escaped paths)
+    unsigned long long profLanes[PT_NUM_CLASSES + 2][16]; // ticks x enabled lanes per section and class
 #endif
 };
 
@@ -993,6 +994,14 @@ struct WideState {
     int curInst;
 };
 PT_DEV void wideStart(WideState &w) { w.grpBase = 0; w.grpMasks = 0; w.triBase = 0; w.triMask = 0; w.triValid = 0; w.tri2Base = 0; w.tri2Mask = 0; w.tri2Valid = 0; w.node = 0; w.sp = 0; w.curNode = 0; w.curInst = -1; }
+// wideStart for the lanes with `go` set, as selects (no region a few lanes enter: a VALU instruction with <= 8 lanes enabled issues at a quarter of
+// the rate, profiles/r6_ubench_lane_masks.txt); single-level walks only (curNode / curInst stay)
+PT_DEV void wideStartIf(WideState &w, bool go)
+{
+    w.grpBase = go ? 0u : w.grpBase; w.grpMasks = go ? 0u : w.grpMasks; w.triBase = go ? 0u : w.triBase; w.triMask = go ? 0u : w.triMask;
+    w.triValid = go ? 0u : w.triValid; w.tri2Base = go ? 0u : w.tri2Base; w.tri2Mask = go ? 0u : w.tri2Mask; w.tri2Valid = go ? 0u : w.tri2Valid;
+    w.node = go ? 0 : w.node; w.sp = go ? 0 : w.sp;
+}
 // Two-level scenes put two more kinds of entries on the group stack when the walk enters an instance (wideEnterInstance):
 #define WIDE_LEAVE     0xFFFFFFFFu   /* x: the master's subtree is done, the ray goes back to world space */
 #define WIDE_RECS_FLAG 0x80000000u   /* x = flag | node: records of that (top-level) node still to test, y = their triMask */

@@ -1456,6 +1456,9 @@ PT_DEV bool embreeBoxVisible(f3 o, f3 d, float tmin, float tmax, f3 lo, f3 hi)
 
 /* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113, finalize() :43-49);
  * Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c. */
+#ifndef PT_TRI_BRANCHLESS
+#define PT_TRI_BRANCHLESS 1
+#endif
 PT_DEV bool triTest(f3 v0, f3 b, f3 c, const RayD &ray, float tmax, float &t, float &u, float &v)
 {
     f3 e1 = -b, e2 = c;
@@ -1467,11 +1470,25 @@ PT_DEV bool triTest(f3 v0, f3 b, f3 c, const RayD &ray, float tmax, float &t, fl
     float sgn = den < 0.0f ? -1.0f : 1.0f;
     float U = dotEmbree(R, e2)*sgn;
     float V = dotEmbree(R, e1)*sgn;
+#if PT_TRI_BRANCHLESS
+    // Round 6: no early exits.  A wave64 VALU instruction with eight or fewer enabled lanes issues at a QUARTER of the rate (tools/ubench_lanes.hip,
+    // profiles/r6_ubench_lane_masks.txt: 935 G wave-instructions/s with 9 .. 64 lanes enabled, 241 with 1 .. 8, whichever lanes they are), and that is
+    // where the two exits put the rest of the test: of the ~20 lanes of a walk's wave that test a record in a turn, a handful pass the edge
+    // functions and two find a hit (bench.py: roofline.valu.walk), so the distance test and the reciprocal -- some 40 instructions -- ran in nearly
+    // every turn for one to eight lanes, at four times their price.  Every lane with a record computes them now; the values are the same.
+    const bool inside = den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absDen;
+    const float T = dotEmbree(Ng, C)*sgn;
+    const bool inRange = T > absDen*ray.tmin && T < absDen*tmax;
+    const float rcpAll = embreeRcp(absDen);
+    t = T*rcpAll; u = U*rcpAll; v = V*rcpAll;
+    return inside && inRange;
+#else
     if (!(den != 0.0f && U >= 0.0f && V >= 0.0f && U + V <= absDen))
         return false;
     float T = dotEmbree(Ng, C)*sgn;
     if (!(T > absDen*ray.tmin && T < absDen*tmax))
         return false;
+#endif
 #ifdef PT_TRI_DIVIDE   /* experiment (profiles/README.md): the exact divisions rounds 1-3 ran here, to price Embree's reciprocal against them */
     t = T/absDen; u = U/absDen; v = V/absDen;
 #else
@@ -1703,6 +1720,14 @@ PT_DEV bool testRecordLoaded(const DeviceScene &s, uint32_t ri, float4 r0, float
     } else {
         ok = false;                                    /* instance records are entered, not tested (traverseClosestInst) */
     }
+#if PT_TRI_BRANCHLESS
+    if (!UNIFORM) {                                    /* (selects, not a region a few lanes enter: triTest above says why) */
+        tmax = ok ? t : tmax;
+        hit = make_float4(ok ? t : hit.x, ok ? u : hit.y, ok ? v : hit.z, ok ? __int_as_float((int)ri) : hit.w);
+        hitMeta = meta;                                /* (read by the callers only behind `ok`) */
+        return ok;
+    }
+#endif
     if (ok) {
         tmax = t;
         hit = make_float4(t, u, v, __int_as_float((int)ri));

@@ -22,9 +22,10 @@
 // Section timers of the shading kernel (development aid; compiled in only with -DPT_PROFILE): s_memtime per
 // wave at section boundaries, summed per workgroup into BlockStats::prof and printed by tghip_destroy.
 #ifdef PT_PROFILE
-#define PROF_DECL unsigned long long profT = wall_clock64(), profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define PROF(n) do { unsigned long long t_ = wall_clock64(); profAcc[n] += t_ - profT; profT = t_; if ((n) == 0) profAcc[10]++; } while (0)   /* ticks of 10 ns; [10] = turns */
-#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 16; ++k_) if (k_ != 11) { if (k_ != 10) atomicAdd(&(stats).prof[k_], profAcc[k_]); atomicAdd(&(stats).profCls[cls][k_], profAcc[k_]); } } while (0)
+#define PROF_DECL unsigned long long profT = wall_clock64(), profAcc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, profLn[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+/* (round 6: profLn = the section's ticks times the lanes enabled at its end marker -- profLn / profAcc is the section's lane count as lane 0 sees it) */
+#define PROF(n) do { unsigned long long t_ = wall_clock64(); profAcc[n] += t_ - profT; profLn[n] += (t_ - profT)*(unsigned long long)__popcll(__ballot(true)); profT = t_; if ((n) == 0) profAcc[10]++; } while (0)   /* ticks of 10 ns; [10] = turns */
+#define PROF_FLUSH(stats) do { if (laneId() == 0) for (int k_ = 0; k_ < 16; ++k_) if (k_ != 11) { if (k_ != 10) atomicAdd(&(stats).prof[k_], profAcc[k_]); atomicAdd(&(stats).profCls[cls][k_], profAcc[k_]); atomicAdd(&(stats).profLanes[cls][k_], profLn[k_]); } } while (0)
 #else
 #define PROF_DECL
 #define PROF(n)
@@ -753,6 +754,12 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
         } \
     } while (0)
 #endif
+#ifndef PT_LATE_PUBLISH
+#define PT_LATE_PUBLISH 1     /* the decoupled walks: after the queue ran dry, finished walks publish more than eight at a time (0 for the A/B) */
+#endif
+#ifndef PT_SHADOW_PREP
+#define PT_SHADOW_PREP 1      /* k_trace_shadow_fast: a slot's second ray prepared in the refill block (traceShadowFastBody); 0 for the A/B */
+#endif
 // busy lanes at or below which a wave of the decoupled walks takes new rays from its workgroup's queue (swept in round 5, r5_sweep_final_kernels.txt: 24 / 32 / 40 / 48 / 56 -- 40 is the shadow walk's optimum, the closest-hit walk is level between 40 and 48)
 #ifndef PT_REFILL_AT
 #define PT_REFILL_AT 40
@@ -805,7 +812,10 @@ PT_DEV void traceClosestWideBody(const DeviceScene &s, const PathState &st, Bloc
             // Finished walks publish their hit -- and bin their path by the shading class of the record hit, a dependent load -- together,
             // right before the lanes are refilled (once the queue is dry: in the turn they finish): one memory round trip per refill
             // instead of one in nearly every turn, sat out by the whole wave.
-            if (((!exhausted && __popcll(busyMask) <= PT_REFILL_AT) || exhausted) && __ballot(pendingPublish) != 0ull) {
+            // (round 6: once the queue is dry the finished walks wait until more than eight of them can publish together, or nothing else is
+            // left -- eight or fewer enabled lanes issue VALU instructions at a quarter of the rate, profiles/r6_ubench_lane_masks.txt)
+            const unsigned long long pendMask = __ballot(pendingPublish);
+            if (pendMask != 0ull && ((!exhausted && __popcll(busyMask) <= PT_REFILL_AT) || (exhausted && (!PT_LATE_PUBLISH || __popcll(pendMask) > 8 || busyMask == 0ull)))) {
                 WALK_SECTION(wpPubs, wpPubLanes, pendingPublish);
                 if (pendingPublish) {
                     slotF4<NTS>(st, A_HIT, slot) = hit;
@@ -2450,8 +2460,52 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         if (!resume) wideStart(w);
         return true;
     };
+#if PT_SHADOW_PREP
+    // Round 6: the slot's SECOND ray is prepared when the slot is fetched, not when its first ray ends.  "On to the second ray" used to run tryRay --
+    // the quad test with its division, the three divisions of the reciprocal direction, ~110 instructions -- inside the loop for the two to five
+    // lanes whose first ray had just ended, in nearly every turn of the wave; with eight or fewer lanes enabled a VALU instruction issues at a quarter
+    // of the rate (profiles/r6_ubench_lane_masks.txt), so those lanes cost the wave about as much as the rest of its turn.  In the refill block
+    // some 28 lanes are enabled (roofline.valu.walk.shadow.refill), and the step to the second ray is a handful of selects every lane executes.
+    // What is prepared: whether the ray is traced at all (tag, minBounces, the hoisted quad), its reciprocal direction and octant.
+    bool valid1 = false;                         // the second ray has to be traced
+    f3 idir1 = splat3(1.0f);
+    uint32_t oct1 = 0u;
+    auto prepareSecond = [&](bool count) {
+        const uint32_t tag = __float_as_uint(c1.w);
+        valid1 = tag != 0xFFFFFFFFu;
+        if (valid1 && count) rays++;
+        valid1 = valid1 && (int)(tag >> 24) >= minBounces;
+        RayD r1; r1.o = so; r1.d = xyz(d1); r1.tmin = eps; r1.tmax = d1.w;
+        if (s.hoisted_rec >= 0) {
+            float tq = r1.tmax;
+            float4 hq;
+            uint32_t meta;
+            if (COUNT && valid1 && count) prims++;
+            if (testRecord<true, KIND_BIT(TGHIP_REC_QUAD)>(s, (uint32_t)s.hoisted_rec, r1, tq, hq, meta) && (int)TGHIP_REC_OBJECT(meta) != (int)(tag & 0xFFFFFFu))
+                valid1 = false;
+        }
+        if (COUNT && valid1 && count) wpRays++;
+        const WideRay w1 = wideRaySetup(r1);
+        idir1 = w1.idir; oct1 = w1.octInv;
+    };
+    // ray r is done: on to the slot's second ray, or the slot is finished (its NEE term is added at the next refill) -- selects, for every lane
+    auto nextRay = [&](bool done) {
+        const bool second = done && r == 0 && valid1;
+        r = done ? 1 : r;
+        endCap = second ? (int)(__float_as_uint(c1.w) & 0xFFFFFFu) : endCap;
+        contrib = second ? xyz(c1) : contrib;
+        ray.d = second ? xyz(d1) : ray.d;
+        ray.tmax = second ? d1.w : ray.tmax;
+        wr.idir = second ? idir1 : wr.idir;
+        wr.octInv = second ? oct1 : wr.octInv;
+        wideStartIf(w, second);
+        busy = (done && !second) ? false : busy;
+        pendingFinish = (done && !second) ? true : pendingFinish;
+    };
+#else
     // ray r is done: on to the slot's second ray, or the slot is finished (its NEE term is added at the next refill)
-    auto nextRay = [&]() {
+    auto nextRay = [&](bool done) {
+        if (!done) return;
         if (r == 0) {
             r = 1;
             if (tryRay(c1, d1, false))
@@ -2460,11 +2514,13 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         busy = false;
         pendingFinish = true;
     };
+#endif
 
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
         const bool refill = !exhausted && __popcll(busyMask) <= PT_REFILL_AT;
-        if ((refill || exhausted) && __ballot(pendingFinish) != 0ull) {
+        const unsigned long long pendMask = __ballot(pendingFinish);   // (after the queue ran dry: more than eight lanes at a time, traceClosestWideBody)
+        if (pendMask != 0ull && (refill || (exhausted && (!PT_LATE_PUBLISH || __popcll(pendMask) > 8 || busyMask == 0ull)))) {
             WALK_SECTION(wpPubs, wpPubLanes, pendingFinish);
             if (pendingFinish) {
                 // NEE term -> path radiance; paths that ended at this vertex go on the finished list
@@ -2509,8 +2565,13 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                         slots++;
                         result = splat3(0.0f);
                         r = 0;
+#if PT_SHADOW_PREP
+                        prepareSecond(true);
+                        nextRay(!tryRay(c0, d0, false));
+#else
                         if (!tryRay(c0, d0, false))
-                            nextRay();
+                            nextRay(true);
+#endif
                     } else {
                         walkRestore(st, slot, w, stack, stride);
                         if (COUNT) wpResumed++;
@@ -2518,6 +2579,9 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                         result = xyz(part); r = __float_as_int(part.w);
                         slotW(st, A_SH_O, slot, 3u) = eps;                   // (an ordinary shadow slot again)
                         (void)tryRay(r == 0 ? c0 : c1, r == 0 ? d0 : d1, true);
+#if PT_SHADOW_PREP
+                        prepareSecond(false);    // (a resumed first ray: its slot's second ray was counted when the slot was first fetched)
+#endif
                     }
                 }
             }
@@ -2590,8 +2654,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
                 result = result + contrib;       // nothing in the way: transmittance 1
                 rayDone = true;
             }
-            if (rayDone)
-                nextRay();
+            nextRay(rayDone);
         }
     }
     if (COUNT) wpLoopEnd = wall_clock64();

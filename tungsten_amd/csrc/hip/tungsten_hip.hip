@@ -578,7 +578,11 @@ static int foldCounters(tghip_ctx *ctx)
             if (!csum) continue;
             csum -= ct[10];
             std::fprintf(stderr, "[PT_PROFILE] class %d: %llu wave turns, %.2f us per turn:", c, ct[10], ct[10] ? double(csum)*0.01/double(ct[10]) : 0.0);
-            for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) std::fprintf(stderr, " s%d=%.2fus", k, ct[10] ? double(ct[k])*0.01/double(ct[10]) : 0.0);
+            for (int k = 0; k < 16; ++k) if (k != 10 && k != 11) {
+                unsigned long long ln = 0;
+                for (size_t b = 0; b < g; ++b) ln += ctx->hostStats[b].profLanes[c][k];
+                std::fprintf(stderr, " s%d=%.2fus(%.0f lanes)", k, ct[10] ? double(ct[k])*0.01/double(ct[10]) : 0.0, ct[k] ? double(ln)/double(ct[k]) : 0.0);
+            }
             auto spread = [](std::vector<double> v, const char *what) {
                 std::sort(v.begin(), v.end());
                 double mean = 0.0; for (double x : v) mean += x; mean /= double(v.size());
