@@ -151,6 +151,14 @@ def walk_summary(t):
     """tghip_get_walk_stats of one decoupled walk (the counting variants' tallies, include/tungsten_hip.h) -> what a ray costs in loop turns and
     how many of a wave's 64 lanes have work in each section of a turn.  A section's instructions are issued for the whole wave whenever ANY lane
     needs it: `lanes_per_run` / 64 is the section's lane utilisation, `runs_per_turn` how often a turn pays for it."""
+    if len(t) >= 48 and t[24]:            # instanced scenes: runs / lanes of the turn's sections
+        names = ("turn", "node", "node_level1", "leaf", "instance_leaf", "set_entry", "triangle_leaf", "pop", "master_done", "instance_tree_pop", "publish", "refill")
+        if t[22]:                         # k_trace_closest_instw (masters through the wide BVH, phases voted on); else k_trace_closest_inst
+            names = ("turn", "phase_master", "master_record_test", "master_node_visit", "master_done", "phase_tree", "tree_node_step", "tree_leaf_section",
+                     "instance_leaf", "master_entered", "pop", "refill")
+        return {"kernel": "k_trace_closest_instw" if t[22] else "k_trace_closest_inst", "wide_master_nodes": t[23],
+                "wave_launches": t[4], "turns_per_wave_launch": round(t[24]/max(t[4], 1), 2),
+                "sections": {n: {"runs_per_turn": round(t[24 + 2*k]/float(t[24]), 4), "lanes_per_run": round(t[25 + 2*k]/max(t[24 + 2*k], 1), 2)} for k, n in enumerate(names)}}
     turns = t[5] + t[6]
     rays = max(t[21] + t[10], 1)          # walks started + walks resumed
     def sec(runs, lanes):
@@ -396,8 +404,8 @@ class Bench(object):
             cc = counters_dict(cc)
             walk_stats = {}
             for wi, wname in ((0, "closest_hit"), (1, "shadow")):
-                buf = (C.c_uint64*24)()
-                nw = lib.tghip_get_walk_stats(ctx, wi, buf, 24)
+                buf = (C.c_uint64*48)()
+                nw = lib.tghip_get_walk_stats(ctx, wi, buf, 48)
                 if nw >= 22 and buf[4]:
                     walk_stats[wname] = walk_summary([int(v) for v in buf[:nw]])
             if count_spp != spp:                 # (the first count_spp samples of every pixel stand for all of them)
@@ -412,6 +420,8 @@ class Bench(object):
             # single-level BVH scenes on the decoupled wide walk: k_finish is folded into the closest-hit launch (the shim's default)
             fold = wide and not inst and not is_flat and "fold_finish=0" not in a.opt and "decouple=0" not in a.opt
             per_step_bytes = kernel_bytes(cc, is_flat, fused, WIDE_NODE_B if wide and not inst else NODE_B, WIDE_NODE_B if wide else NODE_B, fold)
+            if inst and walk_stats.get("closest_hit", {}).get("wide_master_nodes"):      # (k_trace_closest_instw: the masters' nodes are 80-byte wide nodes)
+                per_step_bytes["k_trace_closest"] += (WIDE_NODE_B - NODE_B)*walk_stats["closest_hit"]["wide_master_nodes"]*(spp//count_spp if count_spp != spp else 1)
 
             kernels = {}
             ms = {"k_trace_closest": timed["ms_trace_closest"], "k_shade": timed["ms_shade"], "k_trace_shadow": timed["ms_trace_shadow"]}
@@ -646,6 +656,7 @@ class Bench(object):
                 "cpu_baseline": cpu_baseline(a, scene, path, flat, w, h, spp, self.tmp) if cpu else None,
                 "kernels": kernels,
                 "count_pass_spp": count_spp,
+                "walk": walk_stats or None,        # (also under roofline.valu.walk when the counter passes ran)
                 "rays_per_sample": round(rays/max(cc["samples"], 1), 3),
                 "nodes_per_ray": round(cc["nodes_visited"]/rays, 2), "prims_per_ray": round(cc["prims_tested"]/rays, 2),
                 "bvh": {"nodes": int(flat.info.num_nodes), "records": int(flat.info.num_recs), "depth": int(flat.info.bvh_depth),

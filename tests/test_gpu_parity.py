@@ -621,6 +621,47 @@ def test_large_passes_are_split_into_batches(tmp_path):
         assert np.allclose(img, base, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.gpu
+def test_instanced_closest_hit_walk_through_wide_masters_agrees_with_the_bvh2_walk(tmp_path):
+    """Round 6: k_trace_closest_instw walks the masters' subtrees through the 8-wide BVH (a nearest-hit query may be any correct one:
+    primitives/Instance.cpp:296-303 fixes the order between instances only) and votes on the phase of its turn.  Same image, bit for bit, as the
+    three-level BVH2 walk (option inst_wide = 0), whatever the vote's threshold and the refill level, with and without the visit counters -- on the
+    crowded instance scene of the goldens, on the tie scene, and on instances10k at 2 spp."""
+    for case in ("cornell_instances", "cornell_instance_ties"):
+        mk, kw = scenes.GOLDEN_CASES[case]
+        path = mk(tmp_path, name=case + ".json", **dict(kw, resolution=(160, 90), spp=8))
+        bvh2, _, cnt, _ = gpu_render(path, inst_wide=0)
+        assert (cnt == 8).all() and bvh2.mean() > 0.01
+        for opts in (dict(), dict(inst_phase_min=1), dict(inst_phase_min=64, inst_refill_at=32), dict(count_traversal=1), dict(inst_dyn=0)):
+            img, _, _, c = gpu_render(path, **opts)
+            assert (img == bvh2).all(), (case, opts, float((img != bvh2).any(axis=-1).mean()))
+    if not scenes.have_materialtest():
+        pytest.skip("instances10k needs the materialtest assets (assets/)")
+    big = scenes.instances10k(tmp_path, resolution=(1920, 1080), spp=2)
+    r = tg.Renderer(big, seed=SEED)
+    try:
+        images = {}
+        for name, opts in (("bvh2", dict(inst_wide=0)), ("wide", dict(inst_wide=1)), ("wide, counting", dict(count_traversal=1)),
+                           ("wide, vote 1", dict(count_traversal=0, inst_phase_min=1)), ("wide, vote 40", dict(inst_phase_min=40, inst_refill_at=56))):
+            for k, v in opts.items():
+                r.set_option(k, v)
+            images[name] = _one_pass(r, 2)
+    finally:
+        r.close()
+    assert images["bvh2"].mean() > 0.1
+    # every variant of the new kernel: one image (a lane's walk is a function of its ray)
+    for name in images:
+        if name != "bvh2":
+            assert (images[name] == images["wide"]).all(), (name, float((images[name] != images["wide"]).any(axis=-1).mean()))
+    # against the BVH2 walk of the masters: 4.1 M paths through 10 000 copies of a lat-long sphere, whose poles are fans of a hundred slivers around one
+    # vertex -- where two triangles of a master answer a ray at distances one rounding apart, the first one tested keeps the hit (triTest accepts
+    # T < |den| tmax and rounds t afterwards), and the two walks test in different orders.  Measured: 63 of 2 073 600 pixels.  (The reference's order
+    # inside a master is Embree's, which neither walk restates: DESIGN.md "ties".)
+    differ = float((images["wide"] != images["bvh2"]).any(axis=-1).mean())
+    assert differ <= 1e-4, differ
+    assert np.allclose(images["wide"].mean(axis=(0, 1)), images["bvh2"].mean(axis=(0, 1)), rtol=1e-5)
+
+
 def test_many_instances_match_oracle(tmp_path):
     """BASELINE configs[4] in small: 2 500 instances of a 1 800-triangle mesh (four masters / materials) -- a deep three-level
     walk (the scene's tree, the reference's own tree over the instances in the reference's order, the master's subtree, on one stack)

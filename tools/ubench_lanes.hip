@@ -69,6 +69,40 @@ __global__ __launch_bounds__(256) void k_mask(int iters, uint32_t seed, uint32_t
     for (int k = 0; k < 8; ++k) r ^= a[k];
     if (r == 0x12345u) out[0] = r;
 }
+// MIXED: is the price of a narrow instruction paid per instruction, or only by code that runs narrow for long?  Every turn of the loop issues 32 fmas
+// with every lane enabled and then 32 with `mask`; and a second form in which the waves of a SIMD differ -- odd waves of the workgroup run wide only.
+__global__ __launch_bounds__(256) void k_mixed(int iters, uint32_t seed, uint32_t *out, unsigned long long mask, int oddWavesWideOnly)
+{
+    uint32_t a[8];
+    for (int k = 0; k < 8; ++k) a[k] = seed + threadIdx.x*(k + 1);
+    uint32_t b = seed | 1u, c = seed ^ 0x3f800000u;
+    const bool narrow = ((mask >> (threadIdx.x & 63u)) & 1ull) && !(oddWavesWideOnly && ((threadIdx.x >> 6) & 1u));
+    for (int i = 0; i < iters; ++i) {
+        BODY4(A_FMA)
+        if (narrow) { BODY4(A_FMA) }
+    }
+    uint32_t r = 0;
+    for (int k = 0; k < 8; ++k) r ^= a[k];
+    if (r == 0x12345u) out[0] = r;
+}
+static int runMixed(const char *name, unsigned long long mask, int oddWide, uint32_t *out)
+{
+    const int iters = 2000, blocks = 256*8;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mixed, dim3(blocks), dim3(256), 0, 0, 10, 1u, out, mask, oddWide);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_mixed, dim3(blocks), dim3(256), 0, 0, iters, 1u, out, mask, oddWide);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    std::printf("mixed %-40s %016llx (%2d lanes) odd waves wide only %d  %8.3f ms  (32 wide + 32 masked fmas per turn; 32 wide alone: see `all` with half the instructions)\n",
+                name, mask, __builtin_popcountll(mask), oddWide, ms);
+    return 0;
+}
+
 static int runMask(const char *name, unsigned long long mask, int waves, int blocksPerCu, uint32_t *out)
 {
     const int iters = 2000, blocks = 256*blocksPerCu;
@@ -101,6 +135,9 @@ int main(int argc, char **argv)
         for (auto &p : pats) if (runMask(p.name, p.m, 4, 8, out)) return 1;
         // fewer waves per SIMD: is the cliff an issue-rate effect that more waves hide, or a per-instruction cost?
         for (int bpc : {1, 2, 4}) { if (runMask("all", ~0ull, 4, bpc, out) || runMask("first 8", 0xFFull, 4, bpc, out) || runMask("first 1", 1ull, 4, bpc, out)) return 1; }
+        for (int odd = 0; odd < 2; ++odd)
+            if (runMixed("wide + all", ~0ull, odd, out) || runMixed("wide + first 16", 0xFFFFull, odd, out) || runMixed("wide + first 8", 0xFFull, odd, out) ||
+                runMixed("wide + first 1", 1ull, odd, out) || runMixed("wide + none", 0ull, odd, out)) return 1;
         CHECK(hipFree(out));
         return 0;
     }

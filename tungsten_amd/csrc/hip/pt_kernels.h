@@ -88,7 +88,7 @@ struct BlockCtl {                 // one per persistent workgroup; only that wor
     unsigned long long samples, closest_rays, shadow_rays, shadow_slots;
 };                                // 64 B
 
-#define PT_WALK_STATS 24
+#define PT_WALK_STATS 48
 struct BlockStats {               // traversal statistics (count_traversal option), one per workgroup
     unsigned long long nodes_visited, prims_tested, nodes_visited_shadow, prims_tested_shadow;
     unsigned long long prof[16];  // wave-cycles per k_shade section (only in -DPT_PROFILE builds: `make PROFILE=1`, TGHIP_VERBOSE prints them)
@@ -159,6 +159,9 @@ struct PathState {
     uint32_t num_slots, slots_per_block;
     uint32_t leaf_batch;                   // dynamic-fetch traversal: lanes waiting at a leaf before the leaf code runs (1 = at once)
     uint32_t leaf_batch_bvh2;              // the same for the BVH2 dynamic-fetch kernels (k_trace_closest_dyn / k_trace_shadow_dyn)
+    // k_trace_closest_instw (instanced scenes, masters through the wide BVH): levels of the BVH2 stack (the scene's tree + the reference's tree over the
+    // instances), lanes a phase of the turn needs to run next to a larger one, busy lanes at or below which the wave refills
+    uint32_t inst_tree_depth, inst_phase_min, inst_refill_at;
     // Suspended walks ("walk time-slicing"): once a workgroup's queue has run dry, a wave of the wide traversal kernels that is
     // down to <= suspend_lanes busy lanes does not run its last, longest walks to the end at a few per cent lane occupancy -- it writes
     // the state of every walk that has had >= suspend_turns turns in this launch (WideState, the group stack, the best hit / the

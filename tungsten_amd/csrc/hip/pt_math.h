@@ -133,6 +133,8 @@ PT_DEV float tanfH(float x) { return ptlibm::tanfCore(x); }      // |x| < 120 (O
 
 PT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 PT_DEV f3 splat3(float s) { return mk3(s, s, s); }
+// c ? a : b per component (`c ? a : b` on two f3 LVALUES selects an address: both objects then live in scratch memory)
+PT_DEV f3 sel3(bool c, f3 a, f3 b) { return mk3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 template<typename P> PT_DEV f3 ld3(P p) { return mk3(p[0], p[1], p[2]); }   // P: pointer to float in any address space
 
 // Pointer into the constant address space: a load through it with a wave-uniform address is a scalar-cache

@@ -1457,7 +1457,7 @@ PT_DEV bool embreeBoxVisible(f3 o, f3 d, float tmin, float tmax, f3 lo, f3 hi)
 /* Embree MoellerTrumboreIntersector1 (thirdparty/embree/kernels/geometry/triangle_intersector_moeller.h:76-113, finalize() :43-49);
  * Embree's e1 = v0 - v1 = -rec.b, e2 = v2 - v0 = rec.c. */
 #ifndef PT_TRI_BRANCHLESS
-#define PT_TRI_BRANCHLESS 1
+#define PT_TRI_BRANCHLESS 0    /* measured, profiles/r6_ab_lane_cliff.txt: level on the metric's workload, the closest-hit walk of mesh1m 528 -> 537 us */
 #endif
 PT_DEV bool triTest(f3 v0, f3 b, f3 c, const RayD &ray, float tmax, float &t, float &u, float &v)
 {

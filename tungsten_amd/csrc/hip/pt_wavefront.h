@@ -518,9 +518,15 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
     float ltmax = 0.0f;
     float4 lhit = hit;
     bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
+    // COUNT: how often the wave runs each section of the turn and how many lanes have work in it (tghip_get_walk_stats, walk 0, [24 + 2 k] / [25 + 2 k]:
+    // k = 0 turns / busy lanes, 1 node section, 2 of it at level 1, 3 leaf section, 4 instance leaf, 5 set entry, 6 triangle leaf, 7 pop section,
+    // 8 master done, 9 instance-tree pop, 10 publish, 11 refill)
+    uint32_t sec[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define INST_SECTION(k, pred) do { if (COUNT) { const unsigned long long m_ = __ballot(pred); if (m_) { sec[2*(k)]++; sec[2*(k) + 1] += (uint32_t)__popcll(m_); } } } while (0)
     for (;;) {
         unsigned long long busyMask = __ballot(busy);
         if (!exhausted && __popcll(busyMask) <= 48) {
+            INST_SECTION(11, !busy);
             unsigned long long want = ~busyMask;
             uint32_t lane = laneId();
             uint32_t base = 0;
@@ -552,6 +558,9 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
         if (busyMask == 0ull)
             break;
         bool pop = false;
+        INST_SECTION(0, busy);
+        INST_SECTION(1, busy && cur >= 0);
+        INST_SECTION(2, busy && cur >= 0 && level == 1);
         // ---- a node: the scene's and the masters' with this library's slab test, the instance tree's with the reference's ----
         if (busy && cur >= 0) {
             const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
@@ -587,6 +596,9 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
             unsigned long long atNode = __ballot(busy && (cur >= 0 || pop));
             // leaves are worked off when a good part of the wave waits at one, or nobody has node work left (k_trace_closest_dyn)
             if (atLeaf != 0ull && ((uint32_t)__popcll(atLeaf) >= st.leaf_batch_bvh2 || atNode == 0ull)) {
+                INST_SECTION(3, busy && cur < 0 && !pop);
+                INST_SECTION(4, busy && cur < 0 && !pop && level == 1);
+                INST_SECTION(6, busy && cur < 0 && !pop && level != 1);
                 if (busy && cur < 0 && !pop) {
                     if (level == 1) {
                         // a leaf of the instance tree: its one or two instances, one per turn
@@ -618,6 +630,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
                         bool entered = false;
                         if (level == 0) {
                             const float4 r0 = ld4(s.recs, firstRec*3u);
+                            INST_SECTION(5, TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE_SET);
                             if (TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE_SET) {   // (alone in its leaf)
                                 if (COUNT) prims++;
                                 const float4 r1 = ld4(s.recs, firstRec*3u + 1u), r2 = ld4(s.recs, firstRec*3u + 2u);
@@ -647,6 +660,8 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
                 }
             }
         }
+        INST_SECTION(7, busy && pop);
+        INST_SECTION(8, busy && pop && level == 2 && sp == instSp + 1);
         if (busy && pop) {
             if (level == 2 && sp == instSp + 1) {
                 // the master's subtree is done: a hit there REPLACES the hit so far (Instance.cpp:297-301); back to the leaf of the instance tree
@@ -663,6 +678,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
                     pop = false;                                        // the leaf's second instance, in a turn of its own
                 }
             }
+            INST_SECTION(9, pop && level == 1);
             if (pop && level == 1) {
                 // BinaryBvh::trace's pop (:277-283): a leaf that begins behind tMax is dropped (inner nodes: refLeafEntry)
                 for (;;) {
@@ -674,6 +690,7 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
                     if (!(refTMax < refTMin)) { pop = false; break; }
                 }
             }
+            INST_SECTION(10, pop && level != 1 && sp == 0);
             if (pop && level != 1) {
                 if (sp == 0) {
                     // finished: publish the hit and bin the path by shading class
@@ -690,6 +707,12 @@ __global__ __launch_bounds__(512) void k_trace_closest_inst(DeviceScene s, PathS
             }
         }
     }
+    if (COUNT && laneId() == 0) {
+        unsigned long long *wk = st.stats[blockIdx.x].walk[0];
+        atomicAdd(&wk[4], 1ull);
+        for (int k = 0; k < 24; ++k) atomicAdd(&wk[24 + k], (unsigned long long)sec[k]);
+    }
+#undef INST_SECTION
     waveAddStat(&L.closest_rays, rays);
     if (COUNT) { waveAddStat(&L.nodes, nodes); waveAddStat(&L.prims, prims); }
     queuesEnd(L, st, Q_EXT, Q_SHADE_MASK, Q_EXTP);
@@ -1069,6 +1092,304 @@ __global__ WIDE_CLOSEST_BOUNDS void k_finish_trace_closest_wide(DeviceScene s, P
     (void)finishBody(s, st, pp, L, reinterpret_cast<unsigned short *>(ldsDyn));   // (the queue area of the dynamic LDS: slots_per_block entries)
     __syncthreads();
     traceClosestWideBody<COUNT, SOLIDS, false, true>(s, st, L, fetchNext, ldsDyn);
+}
+
+// Round 6: k_trace_closest_inst with the masters' subtrees walked through the 8-wide BVH (the DECOUPLED walk of k_trace_closest_wide: a pending
+// record and the next node per turn), and the turn split into two phases a wave votes on.  What the counters said about the kernel above
+// (profiles/r6_sq_counters_instances10k.json, r6_bench_instances10k_sections.json): 0.22 of the lanes of an issued VALU instruction enabled -- every turn
+// runs the node step of two box tests' flavours, the leaf code of three kinds and the pop code, each for the handful of lanes that are there --, and
+// 32.8 BVH2 nodes per ray, nearly all of them inside masters.  Inside a master the walk is a plain nearest-hit query (Instance.cpp:296-303 constrains
+// the order BETWEEN instances only: farT = infinity going in, the master's nearest hit REPLACES the hit so far), so it may be any correct one:
+//   phase M  lanes inside a master (level 2): one decoupled turn of the wide walk over the master's wide subtree (instance record c[2]) with a stack
+//            of its own (uint2 entries: behind the BVH2 stack in the dynamic LDS); a master that is done hands its hit over right there;
+//   phase T  lanes in the scene's BVH2 (level 0) and in the reference's tree over the instances (level 1): the statements of the kernel above --
+//            the reference's child test and pop rule, leaf by leaf in the reference's order, one instance per turn.
+// A phase runs when it has more lanes than the other or at least PathState::inst_phase_min of them; the others keep their state for a later turn.
+// Same hits as the kernel above wherever a master's nearest hit is unique (ties inside a master follow the wide walk's order instead of the
+// BVH2's; the reference's own order there is Embree's, which neither restates: DESIGN.md "ties").
+// (walk statistics, tghip_get_walk_stats walk 0: [22] = wave launches of THIS kernel, [23] = wide nodes visited, [24 + 2 k] / [25 + 2 k] = runs / lanes of
+//  k = 0 turns / busy lanes, 1 phase M, 2 its record test, 3 its node visit, 4 master done, 5 phase T, 6 node step, 7 leaf section, 8 instance leaf,
+//  9 master entered, 10 pop section, 11 refill)
+template<bool COUNT, bool SOLIDS = true>
+__global__ __launch_bounds__(512) void k_trace_closest_instw(DeviceScene s, PathState st)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLdsSmall L;
+    __shared__ uint32_t fetchNext;
+    unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
+    int *stack = ldsDyn + (st.slots_per_block >> 1) + threadIdx.x;
+    const int stride = (int)blockDim.x;
+    // the masters' group stack behind the BVH2 stack (8-byte aligned: inst_tree_depth*blockDim is even, the queue area rounded up)
+    uint2 *wstack = reinterpret_cast<uint2 *>(ldsDyn + (((st.slots_per_block >> 1) + st.inst_tree_depth*blockDim.x + 1u) & ~1u)) + threadIdx.x;
+    BlockCtl &ctl = st.ctl[blockIdx.x];
+    if (threadIdx.x == 0) fetchNext = 0;
+    queuesBegin(L, st, ctl, Q_EXTP, 0u, order, Q_EXT);
+    const uint32_t n = L.n;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    uint32_t nodes = 0, wnodes = 0, prims = 0, rays = 0;
+    constexpr uint32_t KINDS = SOLIDS ? KINDS_ALL : KINDS_MESH;
+    const uint32_t phaseMin = st.inst_phase_min;
+
+    bool busy = false;
+    uint32_t slot = 0, local = 0;
+    RayD world; world.o = splat3(0.0f); world.d = splat3(1.0f); world.tmin = 0.0f; world.tmax = 0.0f;
+    f3 winvD = splat3(1.0f);
+    RayD ray = world;                            // level 2: the ray in the master's space
+    WideRay wr; wr.idir = splat3(1.0f); wr.octInv = 0u;
+    WideState w;
+    wideStart(w);
+    float tmax = 0.0f;                           // the world ray's farT: the hit so far (it may GROW inside an instance set)
+    float4 hit = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    int hitInst = -1;
+    int cur = 0, sp = 0, level = 0;
+    float refTMin = 0.0f, refTMax = 0.0f, refFarT = 0.0f;   // level 1: BinaryBvh::trace's tMin / tMax / nearFar[2..3]
+    int refSp = 0;                               // ... and the stack level the set was entered at
+    uint32_t leafNext = 0, leafEnd = 0;          // the leaf of the instance tree being worked off: its slots [leafNext, leafEnd) of inst_prims
+    int curInst = -1;                            // the instance inside of which the walk is
+    float ltmax = 0.0f;
+    float4 lhit = hit;
+    bool popPending = false;                     // a lane of phase T that has to pop first (its leaf's last master just ended in phase M)
+    bool exhausted = false;                      // wave-uniform: the queue has been handed out completely
+    uint32_t sec[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define INST_SECTION(k, pred) do { if (COUNT) { const unsigned long long m_ = __ballot(pred); if (m_) { sec[2*(k)]++; sec[2*(k) + 1] += (uint32_t)__popcll(m_); } } } while (0)
+    for (;;) {
+        unsigned long long busyMask = __ballot(busy);
+        if (!exhausted && (uint32_t)__popcll(busyMask) <= st.inst_refill_at) {
+            INST_SECTION(11, !busy);
+            unsigned long long want = ~busyMask;
+            uint32_t lane = laneId();
+            uint32_t base = 0;
+            if (lane == 0)
+                base = atomicAdd(&fetchNext, (uint32_t)__popcll(want));
+            base = __shfl(base, 0);
+            if (!busy) {
+                uint32_t i = base + __popcll(want & ((1ull << lane) - 1ull));
+                if (i < n) {
+                    local = order[i];
+                    slot = first + local;
+                    float4 ro = slotF4(st, A_RAY_O, slot), rd = slotF4(st, A_RAY_D, slot);
+                    world.o = xyz(ro); world.d = xyz(rd); world.tmin = ro.w; world.tmax = rd.w;
+                    winvD = mk3(1.0f/world.d.x, 1.0f/world.d.y, 1.0f/world.d.z);
+                    tmax = world.tmax;
+                    hit = make_float4(tmax, 0.0f, 0.0f, __int_as_float(-1));
+                    hitInst = -1;
+                    cur = 0; sp = 0; level = 0;
+                    popPending = false;
+                    busy = true;
+                    rays++;
+                }
+            }
+            if (base + (uint32_t)__popcll(want) >= n)
+                exhausted = true;
+            busyMask = __ballot(busy);
+        }
+        if (busyMask == 0ull)
+            break;
+        // ---- the vote ----
+        const bool inMaster = busy && level == 2;
+        const uint32_t nM = (uint32_t)__popcll(__ballot(inMaster)), nT = (uint32_t)__popcll(busyMask) - nM;
+        const bool runM = nM != 0u && (nM >= nT || nM >= phaseMin);
+        const bool runT = nT != 0u && (nT > nM || nT >= phaseMin);
+        INST_SECTION(0, busy);
+        // ---- phase M: a decoupled turn of the master's wide walk ----
+        if (runM) {
+            INST_SECTION(1, inMaster);
+            uint32_t recIdx = 0, nodeIdx = 0;
+            bool hasRec = false, hasNode = false;
+            if (inMaster) {
+                if (w.triMask == 0u && w.tri2Mask != 0u) { w.triBase = w.tri2Base; w.triMask = w.tri2Mask; w.triValid = w.tri2Valid; w.tri2Mask = 0u; }
+                if (w.triMask) {
+                    const uint32_t b = (uint32_t)__ffs((int)w.triMask) - 1u;
+                    recIdx = w.triBase + (uint32_t)__popc(w.triValid & ((1u << b) - 1u));
+                    w.triMask &= w.triMask - 1u;
+                    hasRec = true;
+                }
+                if (w.tri2Mask == 0u)            // (room for the records of the node visited now)
+                    hasNode = wideNextNode(w, wr.octInv, wstack, stride, nodeIdx);
+            }
+            float4 r0, r1, r2;
+            WideNodeRegs nd;
+            PT_WALK_FETCH(s, st, r0, r1, r2, nd, hasRec, recIdx, hasNode, nodeIdx, wr, 0u, reinterpret_cast<const char *>(s.wide));
+            INST_SECTION(2, hasRec);
+            INST_SECTION(3, hasNode);
+            if (hasRec) {
+                if (COUNT) prims++;
+                uint32_t meta;
+                (void)testRecordLoaded<false, KINDS>(s, recIdx, r0, r1, r2, ray, ltmax, lhit, meta);
+            }
+            if (hasNode) {
+                if (COUNT) wnodes++;
+                const uint32_t ob = w.triBase, om = w.triMask, ov = w.triValid;
+                wideVisit(w, nd, ray.o, wr, ray.tmin, ltmax);
+                if (om) { w.tri2Base = w.triBase; w.tri2Mask = w.triMask; w.tri2Valid = w.triValid; w.triBase = ob; w.triMask = om; w.triValid = ov; }
+            }
+            const bool masterDone = inMaster && wideWalkOver(w);
+            INST_SECTION(4, masterDone);
+            if (masterDone) {
+                // the master's subtree is done: a hit there REPLACES the hit so far (Instance.cpp:297-301); back to the leaf of the instance tree (`cur`)
+                if (__float_as_int(lhit.w) >= 0) { hit = lhit; hitInst = curInst; tmax = lhit.x; }
+                level = 1;
+                if (leafNext == leafEnd) {                              // its last instance: tMax = min(tMax, ray.farT()) (BinaryBvh.hpp:274-275)
+                    refTMax = refMin(refTMax, tmax);
+                    refFarT = refTMax;
+                    leafNext = leafEnd = 0;
+                    popPending = true;
+                }                                                       // (else: the leaf's second instance, in a turn of phase T)
+            }
+        }
+        // ---- phase T: the scene's BVH2 and the reference's tree over the instances (k_trace_closest_inst's statements) ----
+        if (runT) {
+            const bool inTree = busy && level != 2;
+            INST_SECTION(5, inTree);
+            bool pop = inTree && popPending;
+            popPending = inTree ? false : popPending;
+            INST_SECTION(6, inTree && !pop && cur >= 0);
+            if (inTree && !pop && cur >= 0) {
+                const float4 *nd = &at32(s.nodes, (uint32_t)cur*4u);
+                const float4 n0 = ld4(nd, 0u), n1 = ld4(nd, 1u), n2 = ld4(nd, 2u), n3 = ld4(nd, 3u);
+                if (COUNT) nodes++;
+                const f3 lo0 = mk3(n0.x, n0.y, n0.z), hi0 = mk3(n0.w, n1.x, n1.y), lo1 = mk3(n1.z, n1.w, n2.x), hi1 = mk3(n2.y, n2.z, n2.w);
+                const int c0 = __float_as_int(n3.x), c1 = __float_as_int(n3.y);
+                float e0, e1;
+                bool h0, h1, firstIs1;
+                if (level == 1) {
+                    h0 = refChildTest(lo0, hi0, world.o, world.d, winvD, world.tmin, refFarT, e0);
+                    h1 = refChildTest(lo1, hi1, world.o, world.d, winvD, world.tmin, refFarT, e1);
+                    firstIs1 = !(e0 < e1);                              // `minMax[0] < minMax[1]`: the right child first on a tie
+                } else {
+                    h0 = boxTest(lo0, hi0, world, winvD, tmax, e0);
+                    h1 = boxTest(lo1, hi1, world, winvD, tmax, e1);
+                    firstIs1 = e1 < e0;
+                }
+                float entry = 0.0f;
+                if (h0 && h1) {
+                    stack[sp*stride] = firstIs1 ? c0 : c1;
+                    sp++;
+                    cur = firstIs1 ? c1 : c0;
+                    entry = firstIs1 ? e1 : e0;
+                } else if (h0) { cur = c0; entry = e0; }
+                else if (h1) { cur = c1; entry = e1; }
+                else pop = true;
+                if (level == 1 && !pop) refTMin = entry;                // BinaryBvh::trace's tMin: the distance the ray enters the child at
+            }
+            {
+                const unsigned long long atLeaf = __ballot(inTree && cur < 0 && !pop);
+                const unsigned long long atNode = __ballot(inTree && (cur >= 0 || pop));
+                // leaves are worked off when a good part of the wave waits at one, or nobody has node work left (k_trace_closest_dyn)
+                if (atLeaf != 0ull && ((uint32_t)__popcll(atLeaf) >= st.leaf_batch_bvh2 || atNode == 0ull)) {
+                    INST_SECTION(7, inTree && cur < 0 && !pop);
+                    INST_SECTION(8, inTree && cur < 0 && !pop && level == 1);
+                    if (inTree && cur < 0 && !pop) {
+                        if (level == 1) {
+                            // a leaf of the instance tree: its one or two instances, one per turn
+                            if (leafNext == leafEnd) { leafNext = TGHIP_LEAF_FIRST(cur); leafEnd = leafNext + TGHIP_LEAF_COUNT(cur); }
+                            const uint32_t ri = s.inst_prims[leafNext];
+                            leafNext++;
+                            if (COUNT) prims++;
+                            const bool reach = instanceReachable(s, ri, world, winvD, refTMin);
+                            INST_SECTION(9, reach);
+                            if (reach) {
+                                // the ray in the master's space (Instance.cpp:295-296), nearT = the leaf's entry distance, farT = infinity
+                                const float4 q0 = ld4(s.recs, ri*3u + 0u), q1 = ld4(s.recs, ri*3u + 1u), q2 = ld4(s.recs, ri*3u + 2u);
+                                const f3 qc = -xyz(q1);                     // conjugate(): the inverse rotation
+                                ray.o = quatRotate(q1.w, qc, world.o - xyz(q0));
+                                ray.d = quatRotate(q1.w, qc, world.d);
+                                ray.tmin = refTMin; ray.tmax = PT_INF;
+                                wr = wideRaySetup(ray);
+                                wideStart(w);
+                                w.node = (int)__float_as_uint(q2.z);        // the root of the master's wide subtree
+                                ltmax = PT_INF;
+                                lhit = make_float4(PT_INF, 0.0f, 0.0f, __int_as_float(-1));
+                                curInst = (int)ri;
+                                level = 2;                                  // (`cur` stays the leaf: the master's walk has a stack of its own)
+                            } else if (leafNext == leafEnd) {
+                                // the leaf's last instance cannot be hit: the leaf is done (tMax = min(tMax, ray.farT()), BinaryBvh.hpp:274-275)
+                                refTMax = refMin(refTMax, tmax);
+                                refFarT = refTMax;
+                                leafNext = leafEnd = 0;
+                                pop = true;
+                            }                                               // (else: the leaf's second instance, in a turn of its own)
+                        } else {
+                            const uint32_t firstRec = TGHIP_LEAF_FIRST(cur), count = TGHIP_LEAF_COUNT(cur);
+                            bool entered = false;
+                            const float4 r0 = ld4(s.recs, firstRec*3u);
+                            if (TGHIP_REC_KIND(__float_as_uint(r0.w)) == TGHIP_REC_INSTANCE_SET) {   // (alone in its leaf)
+                                if (COUNT) prims++;
+                                const float4 r1 = ld4(s.recs, firstRec*3u + 1u), r2 = ld4(s.recs, firstRec*3u + 2u);
+                                float tMin = world.tmin, tMax = tmax;
+                                if (refBboxIntersection(xyz(r0), xyz(r1), world, tMin, tMax)) {
+                                    refTMin = tMin; refTMax = tMax; refFarT = tmax;
+                                    refSp = sp;
+                                    leafNext = leafEnd = 0;
+                                    cur = __float_as_int(r2.x);
+                                    level = 1;
+                                } else {
+                                    pop = true;
+                                }
+                                entered = true;
+                            }
+                            if (!entered) {
+                                for (uint32_t r = firstRec; r < firstRec + count; ++r) {
+                                    if (COUNT) prims++;
+                                    uint32_t meta;
+                                    if (testRecord<false, KINDS>(s, r, world, tmax, hit, meta)) hitInst = -1;
+                                }
+                                pop = true;
+                            }
+                        }
+                    }
+                }
+            }
+            INST_SECTION(10, inTree && pop);
+            if (inTree && level != 2 && pop) {
+                if (level == 1) {
+                    // BinaryBvh::trace's pop (:277-283): a leaf that begins behind tMax is dropped (inner nodes: refLeafEntry)
+                    for (;;) {
+                        if (sp == refSp) { level = 0; break; }          // the set is done: on with the scene's tree (pop stays set)
+                        sp--;
+                        cur = stack[sp*stride];
+                        if (cur >= 0) { pop = false; break; }
+                        refTMin = refLeafEntry(s, TGHIP_LEAF_FIRST(cur), world.o, world.d, winvD, world.tmin);
+                        if (!(refTMax < refTMin)) { pop = false; break; }
+                    }
+                }
+                if (pop) {                                              // (level 0)
+                    if (sp == 0) {
+                        // finished: publish the hit and bin the path by shading class
+                        slotF4(st, A_HIT, slot) = hit;
+                        slotW(st, A_EMI, slot, 3u) = __int_as_float(hitInst);
+                        int ri = __float_as_int(hit.w);
+                        int cls = ri < 0 ? CLS_MISS : (int)at32(s.rec_class, (uint32_t)ri);
+                        queuePush(true, local, L, shadeQueue(cls));
+                        busy = false;
+                    } else {
+                        sp--;
+                        cur = stack[sp*stride];
+                    }
+                }
+            }
+        }
+        PT_TURN_JOIN();
+    }
+    if (COUNT && laneId() == 0) {
+        unsigned long long *wk = st.stats[blockIdx.x].walk[0];
+        atomicAdd(&wk[4], 1ull);
+        atomicAdd(&wk[22], 1ull);
+        for (int k = 0; k < 24; ++k) atomicAdd(&wk[24 + k], (unsigned long long)sec[k]);
+    }
+#undef INST_SECTION
+    waveAddStat(&L.closest_rays, rays);
+    if (COUNT) {
+        waveAddStat(&L.nodes, nodes + wnodes); waveAddStat(&L.prims, prims);
+        uint32_t wn = wnodes;
+        for (int off = 32; off > 0; off >>= 1) wn += __shfl_down(wn, off);
+        if (laneId() == 0) atomicAdd(&st.stats[blockIdx.x].walk[0][23], (unsigned long long)wn);
+    }
+    queuesEnd(L, st, Q_EXT, Q_SHADE_MASK, Q_EXTP);
+    if (threadIdx.x == 0) {
+        ctl.closest_rays += L.closest_rays;
+        if (COUNT) { st.stats[blockIdx.x].nodes_visited += L.nodes; st.stats[blockIdx.x].prims_tested += L.prims; }
+    }
 }
 
 // stand-alone batched closest-hit query (tghip_trace_rays) on caller rays
@@ -2493,10 +2814,12 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         const bool second = done && r == 0 && valid1;
         r = done ? 1 : r;
         endCap = second ? (int)(__float_as_uint(c1.w) & 0xFFFFFFu) : endCap;
-        contrib = second ? xyz(c1) : contrib;
-        ray.d = second ? xyz(d1) : ray.d;
+        contrib = sel3(second, xyz(c1), contrib);
+        ray.o = sel3(second, so, ray.o);         // (a slot whose FIRST ray is not traced never went through tryRay's assignments)
+        ray.tmin = second ? eps : ray.tmin;
+        ray.d = sel3(second, xyz(d1), ray.d);
         ray.tmax = second ? d1.w : ray.tmax;
-        wr.idir = second ? idir1 : wr.idir;
+        wr.idir = sel3(second, idir1, wr.idir);
         wr.octInv = second ? oct1 : wr.octInv;
         wideStartIf(w, second);
         busy = (done && !second) ? false : busy;

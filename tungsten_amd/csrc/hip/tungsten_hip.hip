@@ -121,6 +121,11 @@ struct tghip_ctx {
     // closest-hit 849 us per launch on the BVH2 against 1061 us on the wide tree -- every instance entered costs the wide
     // walk extra turns --, shadow rays 905 against 517 us)
     int instDynOpt = 1;                   // "inst_dyn": closest-hit rays of instanced scenes on the dynamic-fetch kernel (k_trace_closest_inst) instead of the static one
+    int instWideOpt = 1;                  // "inst_wide": ... with the masters' subtrees walked through the wide BVH (k_trace_closest_instw); 0 = the BVH2 walk of round 5
+    int instPhaseMin = 24;                // "inst_phase_min" / "inst_refill_at" (PathState::inst_*)
+    int instRefillAt = 48;
+    int bvhMasterDepth = 0;               // instanced scenes: the part of bvhDepth that is the deepest master's BVH2 subtree, and the wide walk's levels inside a master
+    int wideMasterDepth = 0;
     int wideClosestOpt = -1, wideShadowOpt = -1;
     // "tail_kernel" / "tail_threshold": once a host check finds at most tail_threshold paths alive in the pool, the rest of the batch runs in
     // k_tail (one launch per part: every workgroup iterates over its own slots until they are done).  The kernel is built for latency, not
@@ -364,8 +369,9 @@ static int subtreeDepth(const TgHipSceneDesc *s, int32_t root, size_t &visited, 
 
 // Stack words the BVH2 traversal needs: the scene's tree; with `instances` primitives, above it the reference's tree over the instances
 // and the deepest master subtree (pt_kernels.h: instanceSetIntersect).
-static int bvhDepthOf(const TgHipSceneDesc *s)
+static int bvhDepthOf(const TgHipSceneDesc *s, int *masterDepthOut = nullptr)
 {
+    if (masterDepthOut) *masterDepthOut = 0;
     size_t visited = 0;
     std::vector<uint32_t> sets;
     int depth = subtreeDepth(s, 0, visited, 0, &sets);
@@ -399,14 +405,16 @@ static int bvhDepthOf(const TgHipSceneDesc *s)
         if (d < 0) return -1;
         master = std::max(master, d);
     }
+    if (masterDepthOut) *masterDepthOut = master;
     return depth + ref + master + 3;
 }
 
 // Validates the wide BVH -- the top-level tree from node 0 and, with instances, the masters' subtrees behind it (roots in the
 // instance records): children behind their parent, every node in one tree, record runs inside the record array -- and returns
 // the stack depth the walk needs (-1 when malformed).
-static int wideDepthOf(const TgHipSceneDesc *s)
+static int wideDepthOf(const TgHipSceneDesc *s, int *masterDepthOut = nullptr)
 {
+    if (masterDepthOut) *masterDepthOut = 0;
     const uint32_t n = s->num_wide_nodes;
     std::vector<uint8_t> depth(n, 0);
     depth[0] = 1;
@@ -443,6 +451,7 @@ static int wideDepthOf(const TgHipSceneDesc *s)
             if (w.exp[a] == 0 || w.exp[a] == 255) return -1;
     }
     const int total = s->num_instances ? topDepth + masterDepth + 3 : topDepth;   // + what entering an instance parks on the stack
+    if (masterDepthOut) *masterDepthOut = masterDepth;
     return total > TGHIP_MAX_WIDE_DEPTH ? -1 : total;
 }
 
@@ -496,6 +505,15 @@ static size_t wideLdsBytes(const tghip_ctx *ctx, int threads)
          + size_t(ldsNodeCount(ctx))*size_t(ctx->wideStride);
 }
 
+// k_trace_closest_instw: expanded queue + the BVH2 stack of the scene's tree and the reference's tree over the instances (no master on it) + the
+// masters' group stack (8-byte entries, 8-byte aligned)
+static int instTreeDepth(const tghip_ctx *ctx) { return std::max(ctx->bvhDepth - ctx->bvhMasterDepth, 1); }
+static size_t instWideLdsBytes(const tghip_ctx *ctx, int threads)
+{
+    const size_t ints = ((size_t(slotCap(ctx)) >> 1) + size_t(instTreeDepth(ctx))*size_t(threads) + 1u) & ~size_t(1);
+    return ints*sizeof(int) + size_t(std::max(ctx->wideMasterDepth, 1))*size_t(threads)*sizeof(uint2);
+}
+static bool instWide(const tghip_ctx *ctx) { return ctx->haveInstances && ctx->instWideOpt && ctx->wideDepth > 0 && ctx->wideMasterDepth > 0 && ctx->wideOpt; }
 static bool wideClosest(const tghip_ctx *ctx) { return useWide(ctx) && (ctx->wideClosestOpt < 0 ? !ctx->haveInstances : ctx->wideClosestOpt != 0); }
 static bool wideShadowRays(const tghip_ctx *ctx) { return useWide(ctx) && ctx->wideShadowOpt != 0; }
 
@@ -503,11 +521,11 @@ static int launchGrid(const tghip_ctx *ctx) { return ctx->prop.multiProcessorCou
 
 // Largest workgroup size (multiple of 64, <= maxThreads) at which `blocksPerCu` workgroups of `kernel` fit on a CU.
 template<typename K>
-static int pickThreads(const tghip_ctx *ctx, K kernel, int maxThreads, int ldsMode)   // 0: no dynamic LDS, 1: traceLdsBytes, 2: dynLdsBytes, 3: wideLdsBytes
+static int pickThreads(const tghip_ctx *ctx, K kernel, int maxThreads, int ldsMode)   // 0: no dynamic LDS, 1: traceLdsBytes, 2: dynLdsBytes, 3: wideLdsBytes, 4: instWideLdsBytes
 {
     for (int t = maxThreads; t >= 128; t -= 64) {
         int nb = 0;
-        size_t lds = ldsMode == 1 ? traceLdsBytes(ctx, t) : ldsMode == 2 ? dynLdsBytes(ctx, t) : ldsMode == 3 ? wideLdsBytes(ctx, t) : 0;
+        size_t lds = ldsMode == 1 ? traceLdsBytes(ctx, t) : ldsMode == 2 ? dynLdsBytes(ctx, t) : ldsMode == 3 ? wideLdsBytes(ctx, t) : ldsMode == 4 ? instWideLdsBytes(ctx, t) : 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kernel), t, lds) == hipSuccess && nb >= ctx->blocksPerCu)
             return t;
     }
@@ -689,6 +707,7 @@ static void chooseThreads(tghip_ctx *ctx)
     ctx->thrClosest = wideC && inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false, true>, 192, 3))
                     : wideC ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_wide<false, true>, 192, 3) : pickThreads(ctx, k_trace_closest_wide<false, false>, 192, 3))
                     : flat ? pickThreads(ctx, k_trace_closest<false, true>, 512, 1)
+                    : (inst && ctx->dynamicFetch && ctx->instDynOpt && instWide(ctx)) ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_instw<false, true>, 320, 4) : pickThreads(ctx, k_trace_closest_instw<false, false>, 320, 4))
                     : (inst && ctx->dynamicFetch && ctx->instDynOpt) ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_inst<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_inst<false, false>, 320, 2))
                     : inst ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest<false, false, 1>, 512, 1) : pickThreads(ctx, k_trace_closest<false, false, 2>, 512, 1))
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
@@ -902,6 +921,9 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     }
     else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
     else if (k == "inst_dyn") { ctx->instDynOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "inst_wide") { ctx->instWideOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "inst_phase_min") ctx->instPhaseMin = int(std::min<long long>(std::max<long long>(value, 1), 64));
+    else if (k == "inst_refill_at") ctx->instRefillAt = int(std::min<long long>(std::max<long long>(value, 0), 63));
     else if (k == "grid_rounds") { ctx->gridRounds = int(std::min<long long>(std::max<long long>(value, 1), 8)); ctx->poolMem.release(); ctx->poolSlots = 0; }
     else if (k == "blocks_per_cu") { ctx->blocksPerCuOpt = int(std::min<long long>(std::max<long long>(value, 0), 8)); if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "leaf_batch_bvh2") ctx->leafBatchBvh2 = int(std::min<long long>(std::max<long long>(value, 0), 64));
@@ -1002,7 +1024,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             if (sd->num_inst_prims && !sd->inst_prims) return bad("scene with instances without inst_prims");
         }
     }
-    int depth = bvhDepthOf(sd);
+    int depth = bvhDepthOf(sd, &ctx->bvhMasterDepth);
     if (depth < 0 || depth > TGHIP_MAX_BVH_DEPTH) { ctx->error = "malformed or too deep BVH"; return TGHIP_E_INVALID; }
     for (uint32_t i = 0; i < sd->num_bsdfs; ++i)
         if (bsdfDepth(sd, int(i), 0) > PT_MAX_BSDF_DEPTH) { ctx->error = "BSDF nesting deeper than 3 is not supported"; return TGHIP_E_UNSUPPORTED; }
@@ -1030,12 +1052,13 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     const TgHipBvhNode *dn; const TgHipPrimRec *dr; const TgHipTriAttr *da;
     if ((rc = uploadArray(ctx, ctx->sceneMem, sd->nodes, sd->num_nodes, &dn)) != TGHIP_OK) return rc;
     ctx->wideDepth = 0;
+    ctx->wideMasterDepth = 0;
     ctx->numWideNodes = 0;
     s.hoisted_rec = -1; ctx->hoistedRecScene = -1;
     if (sd->wide_nodes && sd->num_wide_nodes) {
         // the wide nodes and the primitive records share ONE allocation, so that a lane of the wide kernels addresses
         // "a node or a record" with one base pointer and one 32-bit offset
-        const int wd = wideDepthOf(sd);
+        const int wd = wideDepthOf(sd, &ctx->wideMasterDepth);
         if (wd < 0) { ctx->error = "malformed wide BVH"; return TGHIP_E_INVALID; }
         const size_t stride = size_t(ctx->wideStride);
         const size_t nodeBytes = (size_t(sd->num_wide_nodes)*stride + 127u) & ~size_t(127);
@@ -1527,6 +1550,9 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     st.partial = ctx->partial;
     st.abort_flag = ctx->abortFlagDev;
     st.leaf_batch = uint32_t(ctx->leafBatch);
+    st.inst_tree_depth = uint32_t(instTreeDepth(ctx));
+    st.inst_phase_min = uint32_t(ctx->instPhaseMin);
+    st.inst_refill_at = uint32_t(ctx->instRefillAt);
     st.nee_factors = (ctx->haveForward || ctx->haveMeshLight) ? 1u : 0u;   // launchShadow: the closest-hit shadow walk, k_trace_shadow<., FORWARD>
     st.lds_nodes = ldsNodeCount(ctx);
     st.wide_depth = uint32_t(std::max(ctx->wideDepth, 1));
@@ -1633,8 +1659,10 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                 else       hipLaunchKernelGGL((k_trace_closest<false, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
             } else if (ctx->haveInstances && !wideClosest(ctx) && ctx->dynamicFetch && ctx->instDynOpt) {
                 // the three-level walk with dynamic ray fetch
-                const size_t ldsDyn = dynLdsBytes(ctx, ctx->thrClosest);
-#define CLOSEST_DYN_INST(C, S) hipLaunchKernelGGL((k_trace_closest_inst<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->launchStream, s, st)
+                const bool iw = instWide(ctx);               // the masters through the wide BVH (round 6)
+                const size_t ldsDyn = iw ? instWideLdsBytes(ctx, ctx->thrClosest) : dynLdsBytes(ctx, ctx->thrClosest);
+#define CLOSEST_DYN_INST(C, S) do { if (iw) hipLaunchKernelGGL((k_trace_closest_instw<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->launchStream, s, st); \
+                                    else hipLaunchKernelGGL((k_trace_closest_inst<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsDyn, ctx->launchStream, s, st); } while (0)
                 if (ctx->haveSolids) { if (count) CLOSEST_DYN_INST(true, true); else CLOSEST_DYN_INST(false, true); }
                 else                 { if (count) CLOSEST_DYN_INST(true, false); else CLOSEST_DYN_INST(false, false); }
 #undef CLOSEST_DYN_INST
