@@ -13,8 +13,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import scenes  # noqa: E402
+from tungsten_amd import workloads as scenes  # noqa: E402
 import tungsten_amd as tg  # noqa: E402
 
 

@@ -105,6 +105,14 @@ def converged(path, spp, out, tmp):
     print("%-40s %s mean %s" % (os.path.basename(out), img.shape, img.mean(axis=(0, 1))))
 
 
+def as_shipped_converged(tmp, g):
+    """materialtest AS IT SHIPS -- the Sobol' sampler and adaptive sampling in 16-spp passes -- rendered by the unmodified reference binary at 256x144, 256 spp:
+    the L2 anchor of the Sobol' / supplemental-stream draw order and of the pass loop (every other comparison of that configuration is against the
+    reference with this library's sample stream injected)."""
+    converged(scenes.materialtest(tmp, name="c_materialtest_as_shipped.json", resolution=(256, 144), spp=256, spp_step=16,
+                                  renderer={"adaptive_sampling": True, "stratified_sampler": True}), 256, g("materialtest_as_shipped_converged.npz"), tmp)
+
+
 def main():
     if not os.path.exists(HARNESS):
         raise SystemExit("oracle/_ref/ref_harness missing: run `python -c 'import __graft_entry__ as g; g.build()'` where /root/reference exists")
@@ -112,6 +120,9 @@ def main():
     tmp = tempfile.mkdtemp(prefix="tg_golden_")
     g = lambda n: os.path.join(scenes.GOLDEN, n)
     try:
+        if sys.argv[1:] == ["as_shipped_converged"]:
+            as_shipped_converged(tmp, g)
+            return
         if len(sys.argv) > 1:
             # python tools/make_golden.py case ...: the per-sample goldens of the named cases only (and the unit answers of named zoo scenes)
             for name in sys.argv[1:]:
@@ -139,6 +150,7 @@ def main():
         converged(scenes.cornell(tmp, name="c_cornell.json", resolution=(64, 36), spp=4096), 4096, g("cornell_converged.npz"), tmp)
         converged(scenes.materialtest(tmp, name="c_materialtest.json", resolution=(64, 36), spp=1024), 1024,
                   g("materialtest_converged.npz"), tmp)
+        as_shipped_converged(tmp, g)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
