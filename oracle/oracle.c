@@ -1776,6 +1776,12 @@ static void instance_quat(const TgHipPrimRec *r, float *q) { q[0] = r->p0; q[1] 
 static void instance_inv_quat(const TgHipPrimRec *r, float *q) { q[0] = r->p0; q[1] = -r->b[0]; q[2] = -r->b[1]; q[3] = -r->b[2]; }   /* conjugate() :42-45 */
 
 static void bvh_walk(const TgHipSceneDesc *s, int32_t root, const Ray *ray, float *tmax, Hit *hit, TravStats *st, int objFilter, int32_t inst);
+static void wide_walk_from(const TgHipSceneDesc *s, int32_t startNode, int32_t startInst, const Ray *worldRay, float *tmax, Hit *hit, TravStats *st, int objFilter);
+/* A master's subtree is a plain nearest-hit query (Instance.cpp:296-303 fixes the order BETWEEN instances only; inside, the reference asks the master
+ * mesh's own Embree scene).  The device's render kernels walk it through the master's 8-wide subtree (round 6, k_trace_closest_instw), its stand-alone
+ * ray query (tghip_trace_rays) through the BVH2; the oracle follows: renders the wide subtree when the scene carries one, oracle_trace_rays the BVH2.
+ * Where two triangles of a master answer a ray one rounding apart the first one tested keeps the hit, so the order is part of the answer. */
+static int g_inst_wide = 1;
 
 /* ---- Instance::intersect as the reference computes it (primitives/Instance.cpp:290-311) -------------------------------------------
  * The `instances` primitive walks ITS OWN bvh over the instances (bvh/BinaryBvh.hpp:197-287, restated below statement for statement;
@@ -1865,7 +1871,12 @@ static void instance_set_walk(const TgHipSceneDesc *s, uint32_t setRec, const Ra
                 float localFarT = INFINITY;
                 Hit lh;
                 lh.rec = -1; lh.inst = -1; lh.t = localFarT; lh.u = lh.v = 0.0f;
-                bvh_walk(s, (int32_t)root, &local, &localFarT, &lh, st, -1, (int32_t)ri);
+                uint32_t wideRoot;
+                memcpy(&wideRoot, &r->c[2], 4);
+                if (g_inst_wide && s->wide_nodes && s->num_wide_nodes && wideRoot != 0u)
+                    wide_walk_from(s, (int32_t)wideRoot, (int32_t)ri, &local, &localFarT, &lh, st, -1);
+                else
+                    bvh_walk(s, (int32_t)root, &local, &localFarT, &lh, st, -1, (int32_t)ri);
                 if (lh.rec >= 0) { *hit = lh; *rayFarT = localFarT; }
             }
             tMax = ref_min(tMax, *rayFarT);
@@ -1952,7 +1963,7 @@ static inline float wide_spacing(uint8_t e) { union { uint32_t u; float f; } c; 
 static inline float wide_inv(float d) { return 1.0f/(fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d); }
 #define WIDE_LEAVE     0xFFFFFFFFu
 #define WIDE_RECS_FLAG 0x80000000u
-static void wide_walk(const TgHipSceneDesc *s, const Ray *worldRay, float *tmax, Hit *hit, TravStats *st, int objFilter)
+static void wide_walk_from(const TgHipSceneDesc *s, int32_t startNode, int32_t startInst, const Ray *worldRay, float *tmax, Hit *hit, TravStats *st, int objFilter)
 {
     struct { uint32_t base, masks; } stack[TGHIP_MAX_WIDE_DEPTH + 2];
     int sp = 0;
@@ -1964,7 +1975,7 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *worldRay, float *tmax,
         octInv = (idir[0] < 0.0f ? 1u : 0u) | (idir[1] < 0.0f ? 2u : 0u) | (idir[2] < 0.0f ? 4u : 0u); } while (0)
     WIDE_RAY_SETUP();
     uint32_t grpBase = 0, grpMasks = 0, triBase = 0, triMask = 0, triValid = 0, curNode = 0;
-    int32_t node = 0, curInst = -1;
+    int32_t node = startNode, curInst = startInst;
     for (;;) {
         if (triMask) {
             uint32_t b = (uint32_t)__builtin_ctz(triMask);
@@ -2056,7 +2067,12 @@ static void wide_walk(const TgHipSceneDesc *s, const Ray *worldRay, float *tmax,
     }
 #undef WIDE_RAY_SETUP
 }
+static void wide_walk(const TgHipSceneDesc *s, const Ray *worldRay, float *tmax, Hit *hit, TravStats *st, int objFilter)
+{
+    wide_walk_from(s, 0, -1, worldRay, tmax, hit, st, objFilter);
+}
 void oracle_set_wide_bvh(int on) { g_use_wide = on; }
+void oracle_set_inst_wide(int on) { g_inst_wide = on; }     /* 0: masters of instanced scenes through their BVH2 (the device's option inst_wide = 0) */
 
 /* objFilter >= 0: only records of that object are tested (a mesh light's own rtcIntersect, TriangleMesh.cpp:317-335) */
 /* A flat list of analytic primitives (quads, cubes, spheres, disks, cylinders) is intersected by WALKING THE REFERENCE'S TREE: TraceableScene::intersect -> rtcIntersect over Embree's
@@ -4101,12 +4117,15 @@ int oracle_trace_rays(const TgHipSceneDesc *s, const TgHipRay *rays, TgHipHit *h
                       uint64_t *nodes_visited, uint64_t *prims_tested)
 {
     TravStats st = {0, 0, 0};
+    const int instWide = g_inst_wide;
+    g_inst_wide = 0;                             /* (the device's ray query walks masters through the BVH2) */
     for (size_t i = 0; i < n; ++i) {
         Ray r = {ld3(rays[i].o), ld3(rays[i].d), rays[i].tmin, rays[i].tmax};
         Hit h;
         scene_intersect(s, &r, &h, &st);
         hits[i].t = h.t; hits[i].u = h.u; hits[i].v = h.v; hits[i].rec = h.rec;   /* the instance is not reported */
     }
+    g_inst_wide = instWide;
     if (nodes_visited) *nodes_visited = st.nodes;
     if (prims_tested) *prims_tested = st.prims;
     return 0;
