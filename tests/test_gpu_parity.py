@@ -398,13 +398,18 @@ def test_instanced_shadow_walk_agrees_with_the_bvh2_walk(tmp_path):
     assert (cnt == 8).all() and c.nodes_visited_shadow > 0
     assert (plain == bvh2).all()
     assert (counting == bvh2).all()
+    # (round 6: the default is k_trace_shadow_fast_inst -- the same walk inside the fast kernel's slot handling; inst_shadow_fast = 0: k_trace_shadow_wide<., ., INST>)
+    for opts in (dict(inst_shadow_fast=0), dict(inst_shadow_fast=0, count_traversal=1)):
+        img, _, _, _ = gpu_render(path, **opts)
+        assert (img == bvh2).all(), opts
     if not scenes.have_materialtest():
         pytest.skip("instances10k needs the materialtest assets (assets/)")
     big = scenes.instances10k(tmp_path, resolution=(1920, 1080), spp=2)
     r = tg.Renderer(big, seed=SEED)
     try:
         images = {}
-        for name, opts in (("bvh2", dict(wide_shadow=0)), ("wide", dict(wide_shadow=1)), ("wide, counting", dict(count_traversal=1))):
+        for name, opts in (("bvh2", dict(wide_shadow=0)), ("wide", dict(wide_shadow=1)), ("wide, counting", dict(count_traversal=1)),
+                           ("round 5's kernel", dict(count_traversal=0, inst_shadow_fast=0))):
             for k, v in opts.items():
                 r.set_option(k, v)
             images[name] = _one_pass(r, 2)
@@ -413,6 +418,7 @@ def test_instanced_shadow_walk_agrees_with_the_bvh2_walk(tmp_path):
     assert images["bvh2"].mean() > 0.1
     assert (images["wide"] == images["bvh2"]).all(), float((images["wide"] != images["bvh2"]).any(axis=-1).mean())
     assert (images["wide, counting"] == images["bvh2"]).all()
+    assert (images["round 5's kernel"] == images["bvh2"]).all()
 
 
 @pytest.mark.parametrize("scene", ["materialtest", "mesh1m"])

@@ -2712,7 +2712,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_wide(DeviceScene s, PathState 
 //     once the queue is dry, in the turn they finish), so their loads fly together and once per refill instead of once per turn;
 //   * the walk is the DECOUPLED one of k_trace_closest_wide: a pending record AND the next node per turn.
 // Same queues, same suspended-walk protocol (Q_HOLD), same results as k_trace_shadow_wide.
-template<bool COUNT, bool SOLIDS, int NTS = PT_NT_TRAV>
+template<bool COUNT, bool SOLIDS, int NTS = PT_NT_TRAV, bool INST = false>
 PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, uint32_t &fetchNext, int *ldsDyn)
 {
     unsigned short *order = reinterpret_cast<unsigned short *>(ldsDyn);
@@ -2722,7 +2722,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
     if (threadIdx.x == 0) fetchNext = 0;
     const unsigned long long wpStart = COUNT ? wall_clock64() : 0ull;
     uint32_t turns = 0, dryTurns = 0;
-    const uint32_t appendMask = (1u << Q_FIN) | (st.suspend_lanes != 0u ? (1u << Q_EXT) | (1u << Q_HOLD) : 0u);
+    const uint32_t appendMask = (1u << Q_FIN) | (!INST && st.suspend_lanes != 0u ? (1u << Q_EXT) | (1u << Q_HOLD) : 0u);
     // the top of the tree in LDS, behind the stacks (PathState::lds_nodes; queuesBegin's barriers publish the copy)
     const uint32_t topCount = st.lds_nodes;
     const char *ldsTop = reinterpret_cast<const char *>(ldsDyn) + st.slots_per_block*2u + st.wide_depth*blockDim.x*8u;
@@ -2752,7 +2752,9 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
     int endCap = -1;
     bool exhausted = false;
     uint32_t age = 0;
-    const bool maySuspend = st.suspend_lanes != 0u && n >= st.suspend_min_queue;
+    const bool maySuspend = !INST && st.suspend_lanes != 0u && n >= st.suspend_min_queue;   // (two-level walks are not suspended)
+    f3 wdir = splat3(1.0f);                      // INST: the ray being traced in world space (the walk's `ray` is in a master's space inside an instance)
+    float wtmax = 0.0f;
 
     WALK_PROF_DECL;
     // the lane takes ray (c, sd) if it has to be traced (k_trace_shadow_wide: setupRay)
@@ -2768,6 +2770,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         }
         contrib = xyz(c);
         ray.o = so; ray.d = xyz(sd); ray.tmin = eps; ray.tmax = sd.w;
+        if (INST) { wdir = ray.d; wtmax = ray.tmax; }
         if (!resume && s.hoisted_rec >= 0) {     // the scene's one quad, before the walk (DeviceScene::hoisted_rec): occluded by it, the ray adds nothing
             float tq = ray.tmax;
             float4 hq;
@@ -2822,6 +2825,7 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         wr.idir = sel3(second, idir1, wr.idir);
         wr.octInv = second ? oct1 : wr.octInv;
         wideStartIf(w, second);
+        if (INST) { wdir = sel3(second, xyz(d1), wdir); wtmax = second ? d1.w : wtmax; w.curInst = second ? -1 : w.curInst; w.curNode = second ? 0u : w.curNode; }
         busy = (done && !second) ? false : busy;
         pendingFinish = (done && !second) ? true : pendingFinish;
     };
@@ -2939,6 +2943,69 @@ PT_DEV void traceShadowFastBody(const DeviceScene &s, const PathState &st, const
         }
         age++;
         if (COUNT) { turns++; dryTurns += exhausted ? 1u : 0u; if (exhausted) wpBusyDry += (uint32_t)__popcll(busyMask); else wpBusy += (uint32_t)__popcll(busyMask); }
+        if constexpr (INST) {
+            // Two-level scenes: the walk of k_trace_shadow_wide<., ., INST> -- one node or one record per lane and turn, a vote on which of the two a
+            // turn runs, instance records entered by the reference's leaf test -- inside this kernel's slot handling: both rays of a slot fetched at
+            // the refill, the second one prepared there, finished slots added to their paths in one go (round 6; that kernel set up a slot's next ray
+            // and finished slots with global loads in divergent code, for the one to five lanes that had just got there, in nearly every turn: 0.19
+            // of the lanes of an issued VALU instruction enabled, profiles/r6_sq_counters_instances10k.json).
+            bool go = busy;
+            if (busy && st.leaf_batch != 1u) {           // phase vote, as in k_trace_closest_wide
+                const bool wantsRecord = w.triMask != 0u;
+                const uint32_t nRec = (uint32_t)__popcll(__ballot(wantsRecord)), nNode = (uint32_t)__popcll(__ballot(!wantsRecord));
+                go = (nRec*st.leaf_batch >= nNode*2u) == wantsRecord;
+            }
+            bool rayDone = false;
+            if (go) {
+                uint32_t idx = 0;
+                const int what = wideNext<true>(w, wr.octInv, stack, stride, idx);
+                if (what == 0) {
+                    result = result + contrib;       // nothing in the way: transmittance 1
+                    rayDone = true;
+                } else if (what == 3) {
+                    ray.o = so; ray.d = wdir; ray.tmin = eps; ray.tmax = wtmax;     // back to world space (and to the ray's own [nearT, farT])
+                    wr = wideRaySetup(ray);
+                    w.curInst = -1;
+                } else {
+                    const uint32_t off = what != 1 ? wideNodeOff(s, idx) : s.recs_offset + idx*48u;
+                    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s.wide) + (size_t)off);
+                    float4 q0 = p[0], q1 = p[1], q2 = p[2];
+                    if (what == 2) {
+                        WideNodeRegs nd;
+                        wideNodeFetchRest(nd, reinterpret_cast<const char *>(s.wide), off, wr, q0, q1, q2);
+                        if (COUNT) nodes++;
+                        // (no far distance for the nodes -- what the reference clips against the ray's farT is the box of an instance's leaf in ITS
+                        // tree, tested at the record below; the geometry behind it, and so these boxes, may begin beyond farT)
+                        wideVisit(w, nd, ray.o, wr, ray.tmin, PT_INF);
+                    } else if (what == 4) {
+                        wideResumeRecords(w, idx, q1);
+                    } else {
+                        if (COUNT) prims++;
+                        if (TGHIP_REC_KIND(__float_as_uint(q0.w)) == TGHIP_REC_INSTANCE) {
+                            // Instance::intersect lets the ray into an instance when it passes the box of the instance's LEAF in the reference's own
+                            // tree -- its test, its arithmetic (pt_kernels.h: refChildTest) -- and hands it on with nearT = the entry distance and
+                            // farT = INFINITY: anything the master holds beyond occludes (instanceSetOccluded)
+                            const uint32_t leaf = __float_as_uint(q2.y);
+                            const float4 blo = s.inst_leaf_boxes[2u*leaf], bhi = s.inst_leaf_boxes[2u*leaf + 1u];
+                            float tEntry;
+                            if (refChildTest(xyz(blo), xyz(bhi), ray.o, ray.d, mk3(1.0f/ray.d.x, 1.0f/ray.d.y, 1.0f/ray.d.z), ray.tmin, ray.tmax, tEntry)) {
+                                wideEnterInstance(w, stack, stride, idx, q0, q1, q2, ray, wr);
+                                ray.tmin = tEntry; ray.tmax = PT_INF;
+                            }
+                        } else {
+                            float tmax = ray.tmax;
+                            float4 hit;
+                            uint32_t meta;
+                            // geometry reached through an instance belongs to the `instances` primitive, never the light (traverseOccludedInst)
+                            if (testRecordLoaded<false, SOLIDS ? KINDS_ALL : KINDS_MESH>(s, idx, q0, q1, q2, ray, tmax, hit, meta) && (w.curInst >= 0 || (int)TGHIP_REC_OBJECT(meta) != endCap))
+                                rayDone = true;      // occluded
+                        }
+                    }
+                }
+            }
+            nextRay(busy && rayDone);
+            PT_TURN_JOIN();
+        } else
         if (busy) {
             uint32_t recIdx = 0, nodeIdx = 0;
             bool hasRec = false, hasNode = false;
@@ -3003,6 +3070,15 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast(DeviceScene s, PathState 
     __shared__ BlockLds L;
     __shared__ uint32_t fetchNext;
     traceShadowFastBody<COUNT, SOLIDS>(s, st, pp, L, fetchNext, ldsDyn);
+}
+// ... and for scenes with instance records (round 6): the two-level wide walk inside the same slot handling
+template<bool COUNT, bool SOLIDS = true>
+__global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast_inst(DeviceScene s, PathState st, PassParams pp, uint32_t iterTag)
+{
+    extern __shared__ int ldsDyn[];
+    __shared__ BlockLds L;
+    __shared__ uint32_t fetchNext;
+    traceShadowFastBody<COUNT, SOLIDS, PT_NT_OTHER, true>(s, st, pp, L, fetchNext, ldsDyn);
 }
 
 // Second half of the dynamic-fetch shadow step: finalises the paths that had ended at the vertex whose shadow rays

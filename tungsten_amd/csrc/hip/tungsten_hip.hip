@@ -56,6 +56,10 @@ extern template __global__ void k_trace_shadow_fast<false, false>(DeviceScene, P
 extern template __global__ void k_trace_shadow_fast<false, true>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_trace_shadow_fast<true, false>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_trace_shadow_fast<true, true>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_trace_shadow_fast_inst<false, false>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_trace_shadow_fast_inst<false, true>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_trace_shadow_fast_inst<true, false>(DeviceScene, PathState, PassParams, uint32_t);
+extern template __global__ void k_trace_shadow_fast_inst<true, true>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<MASK_TAIL, false>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<MASK_TAIL, true>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<(MASK_TAIL | FEAT_QMC), false>(DeviceScene, PathState, PassParams, uint32_t);
@@ -138,6 +142,7 @@ struct tghip_ctx {
     bool mergeMissOpt = true;             // "merge_miss"
     bool tailOpt = true;
     long long tailThreshold = 8192;
+    bool instShadowFast = true;           // "inst_shadow_fast": instanced scenes' shadow rays on k_trace_shadow_fast_inst (0: k_trace_shadow_wide<., ., INST>)
     bool instShadowJoin = true;           // "inst_shadow_join": 0 = the instanced wide shadow kernel without PT_TURN_JOIN (the miscompiled variant; repro tool only)
     bool failReduce = false;              // "fail_reduce" option (fault injection for the reduce's callers)
     int wideStride = int(PT_WIDE_NODE_BYTES);   // bytes per device node: 128 (pt_kernels.h: PT_WIDE_HALF); the byte layout also takes 80 ("wide_node_stride" option, at the next upload)
@@ -921,6 +926,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     }
     else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
     else if (k == "inst_dyn") { ctx->instDynOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "inst_shadow_fast") ctx->instShadowFast = value != 0;
     else if (k == "inst_wide") { ctx->instWideOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "inst_phase_min") ctx->instPhaseMin = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "inst_refill_at") ctx->instRefillAt = int(std::min<long long>(std::max<long long>(value, 0), 63));
@@ -1514,6 +1520,10 @@ static bool launchShadow(tghip_ctx *ctx, int grid, const PathState &st, const Pa
             // variant for tools/repro_latch_miscompile.py)
             if (!ctx->instShadowJoin && !ctx->haveSolids && !COUNT)
                 hipLaunchKernelGGL((k_trace_shadow_wide<false, false, true, false>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag);
+            else if (ctx->instShadowFast) {      // round 6: the two-level walk inside the fast kernel's slot handling
+                if (ctx->haveSolids) hipLaunchKernelGGL((k_trace_shadow_fast_inst<COUNT, true>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag);
+                else                 hipLaunchKernelGGL((k_trace_shadow_fast_inst<COUNT, false>), dim3(grid), dim3(ctx->thrShadow), lds, ctx->launchStream, ctx->scene, st, pp, iterTag);
+            }
             else if (ctx->haveSolids) SHADOW_WIDE(true, true); else SHADOW_WIDE(false, true);
         }
         else if (ctx->decoupleOpt) {

@@ -8,3 +8,7 @@ template __global__ void k_trace_shadow_fast<false, false>(DeviceScene, PathStat
 template __global__ void k_trace_shadow_fast<false, true>(DeviceScene, PathState, PassParams, uint32_t);
 template __global__ void k_trace_shadow_fast<true, false>(DeviceScene, PathState, PassParams, uint32_t);
 template __global__ void k_trace_shadow_fast<true, true>(DeviceScene, PathState, PassParams, uint32_t);
+template __global__ void k_trace_shadow_fast_inst<false, false>(DeviceScene, PathState, PassParams, uint32_t);
+template __global__ void k_trace_shadow_fast_inst<false, true>(DeviceScene, PathState, PassParams, uint32_t);
+template __global__ void k_trace_shadow_fast_inst<true, false>(DeviceScene, PathState, PassParams, uint32_t);
+template __global__ void k_trace_shadow_fast_inst<true, true>(DeviceScene, PathState, PassParams, uint32_t);
