@@ -142,6 +142,7 @@ struct tghip_ctx {
     bool mergeMissOpt = true;             // "merge_miss"
     bool tailOpt = true;
     long long tailThreshold = 8192;
+    int shadeLdsPad = 0;                  // "shade_lds_pad": bytes of unused dynamic LDS per k_shade workgroup (an occupancy throttle for experiments: profiles/r6_ab_shade_occupancy.txt)
     bool instShadowFast = true;           // "inst_shadow_fast": instanced scenes' shadow rays on k_trace_shadow_fast_inst (0: k_trace_shadow_wide<., ., INST>)
     bool instShadowJoin = true;           // "inst_shadow_join": 0 = the instanced wide shadow kernel without PT_TURN_JOIN (the miscompiled variant; repro tool only)
     bool failReduce = false;              // "fail_reduce" option (fault injection for the reduce's callers)
@@ -926,6 +927,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     }
     else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
     else if (k == "inst_dyn") { ctx->instDynOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
+    else if (k == "shade_lds_pad") ctx->shadeLdsPad = int(std::min<long long>(std::max<long long>(value, 0), 120*1024));
     else if (k == "inst_shadow_fast") ctx->instShadowFast = value != 0;
     else if (k == "inst_wide") { ctx->instWideOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "inst_phase_min") ctx->instPhaseMin = int(std::min<long long>(std::max<long long>(value, 1), 64));
@@ -1465,7 +1467,7 @@ static void launchShadeVariant(tghip_ctx *ctx, int grid, const PathState &st, co
         return;
     }
     hipLaunchKernelGGL((k_shade<M, ((B == MASK_SIMPLE || B == MASK_SIMPLE_INST) ? SIMPLE_WAVES : B == MASK_LEAN ? LEAN_WAVES : B == MASK_COAT ? COAT_WAVES : 2), FUSE>), dim3(grid),
-                       dim3((M == BSDF_MASK_ALL || M == MASK_MEDIA) ? ctx->thrShadeAll : (cls >= 1 && cls < PT_NUM_CLASSES) ? ctx->thrShadeComplex : ctx->thrShadeSimple), 0, ctx->launchStream, ctx->scene, st, pp, cls);
+                       dim3((M == BSDF_MASK_ALL || M == MASK_MEDIA) ? ctx->thrShadeAll : (cls >= 1 && cls < PT_NUM_CLASSES) ? ctx->thrShadeComplex : ctx->thrShadeSimple), size_t(ctx->shadeLdsPad), ctx->launchStream, ctx->scene, st, pp, cls);
 }
 // TGHIP_PASS_SOBOL / TGHIP_PASS_RECORDS passes run the FEAT_QMC twin of the variant the scene would use anyway
 template<uint32_t M, int FUSE = 0>
