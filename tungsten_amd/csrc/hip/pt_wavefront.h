@@ -68,6 +68,9 @@
                             materialtest 968.3 / 969.4 -> 977.8 / 974.5, mesh1m 616.9 / 614.2 -> 622.7 / 621.7 Msamples/s (two libraries alternated
                             twice in one session, profiles/r4_ab_coat_waves.txt); round 3 had measured 3 waves as neutral at 223 VGPRs */
 #endif
+#ifndef PT_TRACE_AHEAD
+#define PT_TRACE_AHEAD 0     /* 1: the one-launch render (FUSE_LOOP) traces a slot's next ray at the end of the turn (shadeBody) -- measured, slower: profiles/r6_ab_trace_ahead.txt */
+#endif
 #ifndef LEAN_WAVES
 #define LEAN_WAVES   2   /* measured: 2 waves/SIMD without scratch beats 3 with 108 B of scratch (kernel is VALU-bound) */
 #endif
@@ -1506,6 +1509,15 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
     // and every wave leaves the loop on its own -- no barrier, no bitmap traffic between the wavefront iterations.
     constexpr bool DIRECT = (FUSE & FUSE_LOOP) != 0;
     uint32_t idle = 0;
+    // Round 6 experiment (PT_TRACE_AHEAD = 1, not the product): the one-launch render traces a slot's NEXT ray -- the continuation, or the camera ray of the
+    // path that takes the slot over -- at the END of the turn, and a continuation that leaves the scene ends its path right there.  Every path's last visit
+    // is a miss (its ray leaves the Cornell box through the open front; no environment to ask): with 3.9 vertices per path a quarter of a turn's lanes hold
+    // such a path, find that out by tracing, and sit out the shading sections -- 47 of 64 lanes at any spp.  With this a visit starts from a stored hit
+    // (53 lanes: the camera rays beside the box still miss) and the render needs 11 % fewer turns -- of 20.8 us instead of 16.2: a walk of the flat list
+    // costs the WAVE its ~4 us whether 48 or 17 lanes need it, and there are two of them per turn now.  Cornell box 2 545 -> 2 290 Msamples/s; images identical
+    // (the GPU suite passes on it).  profiles/r6_ab_trace_ahead.txt.  Only where a miss has nothing else to do: no infinite lights, media, auxiliary outputs.
+    constexpr bool AHEAD = PT_TRACE_AHEAD && DIRECT && (FUSE & FUSE_TRACE) != 0 && (M & (FEAT_INFINITE | FEAT_MEDIA | FEAT_AUX)) == 0u;
+    uint32_t traced = 0;                         // AHEAD: one bit per owned slot whose A_HIT holds the hit of the ray in the slot
     if (DIRECT) {
         // queuesBegin expanded (and thereby cleared) the extension queues into order[0, L.n): turn that list back into
         // a bitmap of busy slots (in the unused Q_SHADE0 words) each thread can look its own slots up in
@@ -1533,7 +1545,9 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
             local = DIRECT ? i : order[i];
             slot = first + local;
             float4 ro = slotF4<SNT>(st, A_RAY_O, slot), rd = slotF4<SNT>(st, A_RAY_D, slot), hit, thr4 = slotF4<SNT>(st, A_THR, slot);
-            if (FUSE & FUSE_TRACE) {
+            if (AHEAD && ((traced >> turn) & 1u)) {
+                hit = slotF4<SNT>(st, A_HIT, slot);                   // traced at the end of the slot's last visit (class 0 throughout: FUSE_LOOP)
+            } else if (FUSE & FUSE_TRACE) {
                 // TraceableScene::intersect inline: the flat record list, walked uniformly by the wave
                 RayD r0;
                 r0.o = xyz(ro); r0.d = xyz(rd); r0.tmin = ro.w; r0.tmax = rd.w;
@@ -2014,6 +2028,23 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
             }
             if (survives)
                 slotF4<SNT>(st, A_THR, slot) = mk4(throughput, __uint_as_float(newFlags));
+            if constexpr (AHEAD) {
+                bool haveHit = false;
+                if (survives) {
+                    const float4 h = traverseClosest<true, true, shadeKinds(M)>(sg, ray, nullptr, 0, fusedNodes, fusedPrims);
+                    fusedClosest++;
+                    if (__float_as_int(h.w) < 0) {
+                        // the continuation leaves the scene: what the escaped branch above would do with it at the slot's next visit
+                        survives = false;
+                        finished = true;
+                        black = isnan(sum3(throughput) + sum3(em));
+                    } else {
+                        slotF4<SNT>(st, A_HIT, slot) = h;
+                        haveHit = true;
+                    }
+                }
+                traced = haveHit ? (traced | (1u << turn)) : (traced & ~(1u << turn));
+            }
             PROF(15);
           }
         }
@@ -2030,6 +2061,17 @@ PT_DEV bool shadeBody(const DeviceScene &sg, const PathState &st, const PassPara
         bool regenerated = false;
         if constexpr (FUSE != 0)
             regenerated = nextPath<true, (M & FEAT_QMC) != 0, SNT>(s, st, pp, finished, false, slot, em, black, &L.cursor, aborted, finishedCount);
+        if constexpr (AHEAD) {
+            if (regenerated) {                   // the camera ray nextPath just wrote: traced now, its hit (or miss: the next visit ends the path) stored
+                const float4 ro = slotF4<SNT>(st, A_RAY_O, slot), rd = slotF4<SNT>(st, A_RAY_D, slot);
+                RayD r1;
+                r1.o = xyz(ro); r1.d = xyz(rd); r1.tmin = ro.w; r1.tmax = rd.w;
+                const float4 h = traverseClosest<true, true, shadeKinds(M)>(sg, r1, nullptr, 0, fusedNodes, fusedPrims);
+                fusedClosest++;
+                slotF4<SNT>(st, A_HIT, slot) = h;
+                traced |= 1u << turn;
+            }
+        }
         PROF(7);
         if (DIRECT) {
             if (finished && !regenerated) idle |= 1u << turn;   // the work items ran out: nothing left for this slot
