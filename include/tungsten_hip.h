@@ -549,7 +549,13 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "cou
                                                                              Instrumentation that never changes an image (tests hold that): "lds_tables" = 0
                                                                              shades as if the small tables did not fit the LDS copy, "env_lds" = 0 samples the
                                                                              environment map through its global tables, "hoist_quad" = 0 leaves a scene's one
-                                                                             quad inside the walks, "tail_family" = 0 runs the all-types tail kernel */
+                                                                             quad inside the walks, "tail_family" = 0 runs the all-types tail kernel.
+                                                                             Round 6, instanced scenes: "inst_wide" = 0 walks masters through their BVH2 (round 5's
+                                                                             kernel; images differ only where two triangles of a master answer a ray one rounding
+                                                                             apart), "inst_phase_min" / "inst_refill_at" the phase vote's threshold and the refill
+                                                                             level of k_trace_closest_instw, "inst_shadow_fast" = 0 shadow rays on
+                                                                             k_trace_shadow_wide<., ., INST>; "shade_lds_pad" bytes of unused LDS per shading
+                                                                             workgroup (an occupancy throttle for experiments) */
 int tghip_get_counters(tghip_ctx *ctx, TgHipCounters *out);
 int tghip_reset_counters(tghip_ctx *ctx);
 /* Instrumentation (no reference analogue; bench.py roofline.valu.walk, profiles/r6_lane_util.json): the tallies the counting variants of the
@@ -557,7 +563,9 @@ int tghip_reset_counters(tghip_ctx *ctx);
  * out[0..n): [0..3] wave time in 10-ns ticks (queue expansion, loop with queue, loop after the queue ran dry, wait + write-back), [4] wave launches,
  * [5] / [6] loop turns before / after dry, [7] / [8] busy lanes summed over those turns, [9] / [10] walks suspended / resumed, [11] longest loop,
  * [12] / [13] turns that ran the record test / lanes with a record in them, [14] / [15] the same for the node visit, [16] / [17] refill blocks run /
- * lanes refilled, [18] / [19] publish (NEE-term) blocks run / lanes in them, [20] record tests accepted, [21] rays walked.  Returns the number of
+ * lanes refilled, [18] / [19] publish (NEE-term) blocks run / lanes in them, [20] record tests accepted, [21] rays walked.  Instanced scenes (walk 0):
+ * [22] wave launches of k_trace_closest_instw (0: k_trace_closest_inst ran), [23] wide nodes visited inside masters, [24 + 2 k] / [25 + 2 k] runs / lanes
+ * of section k of the turn (pt_wavefront.h lists the twelve sections of either kernel; bench.py: walk_summary names them).  Returns the number of
  * values written (<= n), or a negative error. */
 int tghip_get_walk_stats(tghip_ctx *ctx, int walk, uint64_t *out, int n);
 
