@@ -719,7 +719,8 @@ static void chooseThreads(tghip_ctx *ctx)
                     : dyn ? (ctx->haveSolids ? pickThreads(ctx, k_trace_closest_dyn<false, true>, 320, 2) : pickThreads(ctx, k_trace_closest_dyn<false, false>, 320, 2))   // 20 waves/CU measured best (profiles/README.md)
                                         : pickThreads(ctx, k_trace_closest<false, false>, 512, 1);
     if (wideS && inst && !ctx->haveForward && !ctx->haveMeshLight)
-        ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false, true>, 256, 3);
+        ctx->thrShadow = ctx->instShadowFast ? (ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_fast_inst<false, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_fast_inst<false, false>, 256, 3))
+                                             : (ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false, true>, 256, 3));
     else if (wideS && !ctx->haveForward && !ctx->haveMeshLight)
         ctx->thrShadow = ctx->haveSolids ? pickThreads(ctx, k_trace_shadow_wide<false, true>, 256, 3) : pickThreads(ctx, k_trace_shadow_wide<false, false>, 256, 3);
     else if (!flat && !ctx->haveForward && !ctx->haveMeshLight && dyn)
@@ -928,7 +929,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "inst_simple") ctx->instSimpleOpt = value != 0;
     else if (k == "inst_dyn") { ctx->instDynOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "shade_lds_pad") ctx->shadeLdsPad = int(std::min<long long>(std::max<long long>(value, 0), 120*1024));
-    else if (k == "inst_shadow_fast") ctx->instShadowFast = value != 0;
+    else if (k == "inst_shadow_fast") { ctx->instShadowFast = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "inst_wide") { ctx->instWideOpt = value != 0; if (ctx->haveScene) chooseThreads(ctx); }
     else if (k == "inst_phase_min") ctx->instPhaseMin = int(std::min<long long>(std::max<long long>(value, 1), 64));
     else if (k == "inst_refill_at") ctx->instRefillAt = int(std::min<long long>(std::max<long long>(value, 0), 63));
