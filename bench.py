@@ -49,6 +49,38 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MAX_CLOCK_HZ = 2.4e9       # MI355X_MICROARCH.md: max engine clock
+
+
+class ClockPoller(object):
+    """The shader clock while the timed region runs: `rocm-smi --showclocks` called back to back on a host thread (about six readings a second), the
+    sclk of the busiest visible GPU per reading.  The VALU ceiling below is priced at the MAXIMUM clock; this says how far under it the chip ran."""
+    def __init__(self):
+        import threading
+        self.readings, self.stop_flag = [], False
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self.stop_flag:
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True, timeout=10).stdout
+            except Exception:
+                return
+            mhz = [int(m) for m in re.findall(r"sclk clock level[^(]*\((\d+)Mhz\)", out, re.I)]
+            if mhz:
+                self.readings.append(max(mhz))
+
+    def start(self):
+        self.thread.start()
+        return self
+
+    def stop(self):
+        self.stop_flag = True
+        self.thread.join(timeout=15)
+        r = sorted(v for v in self.readings if v >= 1000)           # (readings taken while the clock ramps up from idle are not the loop's)
+        if not r:
+            return None
+        return {"mhz_median": r[len(r)//2], "mhz_min": r[0], "mhz_max": r[-1], "readings": len(r), "frac_of_max_clock": round(r[len(r)//2]*1e6/MAX_CLOCK_HZ, 4),
+                "source": "rocm-smi --showclocks polled on a host thread during the timed region (sclk of the busiest visible GPU)"}
 VALU_CYCLES_PER_WAVE64 = 2.0   # MI355X_MICROARCH.md "Per-instruction cycle constants": v_fma_f32 (wave64) = 2 cycles (the CDNA4 SIMD is 32 lanes wide)
 # What the OTHER wave64 VALU instructions cost per SIMD, measured against v_fma_f32 = 2 with tools/ubench_valu.hip (profiles/r5_ubench_valu.txt):
 # f32 add / mul / fma, and / or / add_u32 / mov run at 1.8-2.0; min / max (also the 3-operand forms), shifts, bfe, every convert, compares,
@@ -73,6 +105,7 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=0, help="default: 256 (materialtest, cornell) / 32 (mesh1m, instances10k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary Cornell-box run")
+    ap.add_argument("--no-clock", dest="clock", action="store_false", help="do not poll rocm-smi for the shader clock during the timed region (N = 1)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="target CPU time of the cpu_baseline sample (three runs of two builds together)")
     ap.add_argument("--no-traffic", dest="traffic", action="store_false",
@@ -358,11 +391,13 @@ class Bench(object):
         check(lib.tghip_set_option(ctx, b"time_kernels", 0 if a.no_kernel_timing else 1), "tghip_set_option")
         self.fence()
         split[0] = split[1] = 0.0
+        poller = ClockPoller().start() if (self.world == 1 and a.clock and shutil.which("rocm-smi")) else None
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         self.fence()
         elapsed = time.perf_counter() - t0
+        sustained_clock = poller.stop() if poller else None
         per_rank = None
         if self.dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.shared else "cuda")
@@ -666,6 +701,7 @@ class Bench(object):
                            "parallelism": "tile-shard x%d%s" % (self.world, (" + framebuffer reduce: " + reduce_note) if self.world > 1 else "")},
                 "cpu_baseline": cpu_baseline(a, scene, path, flat, w, h, spp, self.tmp) if cpu else None,
                 "roofline": ordered_roofline(roofline),
+                "sustained_clock": sustained_clock,
                 "kernels": kernels,
                 "count_pass_spp": count_spp,
                 "walk": walk_stats or None,        # (also under roofline.valu.walk when the counter passes ran)

@@ -291,7 +291,11 @@ typedef struct TgHipMedium {
     float   falloff_dir[3];                       /* _unitFalloffDirection (normalised at prepareForRender) */
     float   pad[3];
 } TgHipMedium;                /* 112 B */
-enum { TGHIP_MEDIUM_HOMOGENEOUS = 0, TGHIP_MEDIUM_EXPONENTIAL = 1 };
+/* media/AtmosphericMedium.cpp (TGHIP_MEDIUM_ATMOSPHERE): density exp(-s^2 (|p - center|^2 - radius^2)); the fields above are reused --
+   falloff_scale = s = _effectiveFalloffScale (falloff_scale / radius after prepareForRender, :79), unit_point = _center (the pivot primitive's
+   origin when the scene names one, :70-77), falloff_dir[0] = _radius; exponential transmittance only, for the reason given for the exponential
+   medium (AtmosphericMedium::sampleDistance, :150-151) */
+enum { TGHIP_MEDIUM_HOMOGENEOUS = 0, TGHIP_MEDIUM_EXPONENTIAL = 1, TGHIP_MEDIUM_ATMOSPHERE = 2 };
 
 /* ---- textures ------------------------------------------------------------------------- */
 enum { TGHIP_TEX_CONSTANT = 0, TGHIP_TEX_CHECKER = 1, TGHIP_TEX_BITMAP = 2 };

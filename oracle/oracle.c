@@ -2855,11 +2855,164 @@ static int expmed_sampleDistance(const TgHipMedium *m, int medium, Sampler *smp,
     return 1;
 }
 
+/* ---- AtmosphericMedium (media/AtmosphericMedium.cpp): TgHipMedium carries s = _effectiveFalloffScale in falloff_scale, _center in unit_point and
+ * _radius in falloff_dir[0] (include/tungsten_hip.h).  Erf::erfc / erfDifference on floats (math/Erf.hpp:247-283), Erf::erfInv on doubles
+ * (math/Erf.hpp:192-245; its tables: erfinv_table.h, generated by tools/gen_erfinv_tables.py), std::erf / std::exp / std::log = this host's libm. */
+#include "erfinv_table.h"
+#define O_SQRT_PI     1.77245385091f           /* math/Angle.hpp:15-16 */
+#define O_INV_SQRT_PI (1.0f/O_SQRT_PI)
+static float erf_erfc(float x)
+{
+    const float p = 0.32759f;
+    const float as[5] = {0.254829592f, -0.284496736f, 1.421413741f, -1.453152027f, 1.061405429f};
+    float t = 1.0f/(1.0f + p*fabsf(x));
+    float ti = copysignf(t*expf(-x*x), x);
+    float result = 0.0f;
+    for (int i = 0; i < 5; ++i) {
+        result += as[i]*ti;
+        ti *= t;
+    }
+    float constant = 1.0f - copysignf(1.0f, x);
+    return constant + result;
+}
+static float erf_erfDifference(float x0, float x1)
+{
+    const float p = 0.32759f;
+    const float as[5] = {0.254829592f, -0.284496736f, 1.421413741f, -1.453152027f, 1.061405429f};
+    float t0 = 1.0f/(1.0f + p*fabsf(x0));
+    float t1 = 1.0f/(1.0f + p*fabsf(x1));
+    float ti0 = copysignf(t0*expf(-x0*x0), x0);
+    float ti1 = copysignf(t1*expf(-x1*x1), x1);
+    float result = 0.0f;
+    for (int i = 0; i < 5; ++i) {
+        result += as[i]*(ti0 - ti1);
+        ti0 *= t0;
+        ti1 *= t1;
+    }
+    float constant = copysignf(1.0f, x1) - copysignf(1.0f, x0);
+    return constant + result;
+}
+static double poly_eval(int n, double x, const double *P)     /* Polynomial::eval (math/Polynomial.hpp:9-18) */
+{
+    double result = P[n - 1];
+    for (int i = n - 2; i >= 0; --i) {
+        result *= x;
+        result += P[i];
+    }
+    return result;
+}
+static double erf_inv(double z)                                /* Erf::erfInv (math/Erf.hpp:192-245) */
+{
+    double p, q, sgn;
+    if (z < 0) { p = -z; q = 1 - p; sgn = -1; }
+    else       { p = z;  q = 1 - z; sgn = 1; }
+    double result = 0.0;
+    if (p <= 0.5) {
+        double g = p*(p + 10.0);
+        double r = poly_eval(8, p, ERFINV_P1)/poly_eval(10, p, ERFINV_Q1);
+        result = g*ERFINV_Y[0] + g*r;
+    } else if (q >= 0.25) {
+        double g = sqrt(-2.0*log(q));
+        double xs = q - 0.25;
+        double r = poly_eval(9, xs, ERFINV_P2)/poly_eval(9, xs, ERFINV_Q2);
+        result = g/(ERFINV_Y[1] + r);
+    } else {
+        double x = sqrt(-log(q));
+        if (x < 3.0) {
+            double xs = x - 1.125;
+            double R = poly_eval(11, xs, ERFINV_P3)/poly_eval(8, xs, ERFINV_Q3);
+            result = ERFINV_Y[2]*x + R*x;
+        } else if (x < 6.0) {
+            double xs = x - 3;
+            double R = poly_eval(9, xs, ERFINV_P4)/poly_eval(7, xs, ERFINV_Q4);
+            result = ERFINV_Y[3]*x + R*x;
+        } else if (x < 18.0) {
+            double xs = x - 6.0;
+            double R = poly_eval(9, xs, ERFINV_P5)/poly_eval(7, xs, ERFINV_Q5);
+            result = ERFINV_Y[4]*x + R*x;
+        } else if (x < 44.0) {
+            double xs = x - 18.0;
+            double R = poly_eval(8, xs, ERFINV_P6)/poly_eval(7, xs, ERFINV_Q6);
+            result = ERFINV_Y[5]*x + R*x;
+        } else {
+            double xs = x - 44.0;
+            double R = poly_eval(8, xs, ERFINV_P7)/poly_eval(7, xs, ERFINV_Q7);
+            result = ERFINV_Y[6]*x + R*x;
+        }
+    }
+    return sgn*result;
+}
+/* AtmosphericMedium::density(h, t0) / densityIntegral / inverseOpticalDepth (AtmosphericMedium.cpp:99-122) */
+static float atm_density(const TgHipMedium *m, float h, float t0)
+{
+    const float s = m->falloff_scale, radius = m->falloff_dir[0];
+    return expf(-(s*s)*(h*h - radius*radius + t0*t0));
+}
+static float atm_densityIntegral(const TgHipMedium *m, float h, float t0, float t1)
+{
+    const float s = m->falloff_scale, radius = m->falloff_dir[0];
+    if (t1 == INFINITY)
+        return (O_SQRT_PI*0.5f/s)*expf((-h*h + radius*radius)*s*s)*erf_erfc(s*t0);
+    else
+        return (O_SQRT_PI*0.5f/s)*expf((-h*h + radius*radius)*s*s)*erf_erfDifference(s*t0, s*t1);
+}
+static float atm_inverseOpticalDepth(const TgHipMedium *m, double h, double t0, double tau)
+{
+    double s = m->falloff_scale, radius = m->falloff_dir[0];
+    double inner = erf(s*t0) + 2.0*(double)O_INV_SQRT_PI*exp(s*s*(h - radius)*(h + radius))*s*tau;
+    if (inner >= 1.0)
+        return INFINITY;
+    else
+        return (float)(erf_inv(inner)/s);
+}
+/* AtmosphericMedium::sampleDistance (AtmosphericMedium.cpp:124-168); exponential transmittance only (include/tungsten_hip.h) */
+static int atm_sampleDistance(const TgHipMedium *m, int medium, Sampler *smp, const Ray *ray, MediumState *state, MediumSample *ms)
+{
+    if (state->bounce > m->max_bounce)
+        return 0;
+    const v3 sigmaT = ld3(m->sigma_t);
+    v3 p = vsub(ray->o, ld3(m->unit_point));
+    float t0 = vdot(p, ray->d);
+    float h = vlen(vsub(p, vscale(ray->d, t0)));
+    float maxT = ray->tmax + t0;
+    if (m->absorption_only) {
+        ms->t = ray->tmax;
+        v3 tau = vscale(sigmaT, atm_densityIntegral(m, h, t0, maxT));
+        ms->weight = trans_eval(m, tau, state->firstScatter, 1);
+        ms->exited = 1;
+    } else {
+        int component = (int)(nextSupplemental(smp)*3);           /* sampler.nextDiscrete(3) */
+        float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
+        float tauC = trans_sample(m, smp, state->firstScatter)/sigmaTc;
+        float t = atm_inverseOpticalDepth(m, h, t0, tauC);
+        ms->t = fminf(t, maxT);
+        v3 tau = vscale(sigmaT, atm_densityIntegral(m, h, t0, ms->t));
+        ms->exited = t >= maxT;
+        ms->weight = trans_eval(m, tau, state->firstScatter, ms->exited);      /* (the exponential transmittance does not look at the flags) */
+        float pdf;
+        if (ms->exited) {
+            pdf = vavg(trans_kernel3(m, state->firstScatter ? 0 : 2, tau));
+        } else {
+            float rho = atm_density(m, h, ms->t);
+            pdf = vavg(vmul(vscale(sigmaT, rho), trans_kernel3(m, state->firstScatter ? 1 : 3, tau)));
+            ms->weight = vmul(ms->weight, vscale(vscale(ld3(m->sigma_s), rho), trans_sigmaBar(m)));
+        }
+        ms->weight = vdivs(ms->weight, pdf);
+        ms->t -= t0;
+        state->firstScatter = 0; state->bounce++;
+    }
+    ms->p = vadd(ray->o, vscale(ray->d, ms->t));
+    ms->medium = medium;
+    return 1;
+}
+
 static int medium_sampleDistance(const TgHipSceneDesc *s, int medium, Sampler *smp, const Ray *ray, MediumState *state, MediumSample *ms)
 {
     const TgHipMedium *m = &s->media[medium];
     if (m->medium_type == TGHIP_MEDIUM_EXPONENTIAL)
         return expmed_sampleDistance(m, medium, smp, ray, state, ms);
+    if (m->medium_type == TGHIP_MEDIUM_ATMOSPHERE)
+        return atm_sampleDistance(m, medium, smp, ray, state, ms);
     if (state->bounce > m->max_bounce)
         return 0;
     float maxT = ray->tmax;
@@ -2903,6 +3056,13 @@ static v3 medium_transmittance(const TgHipSceneDesc *s, int medium, const Ray *r
         if (farT == INFINITY && dx <= 0.0f)
             return vs(0.0f);
         return trans_eval(m, vscale(ld3(m->sigma_t), expmed_densityIntegral(x, dx, farT)), startOnSurface, endOnSurface);
+    }
+    if (m->medium_type == TGHIP_MEDIUM_ATMOSPHERE) {              /* AtmosphericMedium::transmittance (AtmosphericMedium.cpp:170-180) */
+        v3 p = vsub(ray->o, ld3(m->unit_point));
+        float t0 = vdot(p, ray->d);
+        float t1 = farT + t0;
+        float h = vlen(vsub(p, vscale(ray->d, t0)));
+        return trans_eval(m, vscale(ld3(m->sigma_t), atm_densityIntegral(m, h, t0, t1)), startOnSurface, endOnSurface);
     }
     if (farT == INFINITY)
         return vs(0.0f);

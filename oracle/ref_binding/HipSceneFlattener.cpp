@@ -39,6 +39,7 @@
 #include "media/Medium.hpp"
 #include "media/HomogeneousMedium.hpp"
 #include "media/ExponentialMedium.hpp"
+#include "media/AtmosphericMedium.hpp"
 #include "transmittances/ExponentialTransmittance.hpp"
 #include "transmittances/LinearTransmittance.hpp"
 #include "transmittances/QuadraticTransmittance.hpp"
@@ -325,12 +326,20 @@ int32_t HipSceneFlattener::addMedium(const Medium *m)
         if (_mediumKeys[i] == m) return int32_t(i);
     const HomogeneousMedium *h = dynamic_cast<const HomogeneousMedium *>(m);
     const ExponentialMedium *x = dynamic_cast<const ExponentialMedium *>(m);
-    if (!h && !x) refuse("a medium that is neither homogeneous nor exponential");
+    const AtmosphericMedium *a = dynamic_cast<const AtmosphericMedium *>(m);
+    if (!h && !x && !a) refuse("a medium that is neither homogeneous nor exponential nor atmospheric");
     TgHipMedium d;
     std::memset(&d, 0, sizeof(d));
     if (h) {
         copy3(d.sigma_a, h->_sigmaA); copy3(d.sigma_s, h->_sigmaS); copy3(d.sigma_t, h->_sigmaT);
         d.absorption_only = h->_absorptionOnly ? 1 : 0;
+    } else if (a) {                                 // AtmosphericMedium after prepareForRender (AtmosphericMedium.cpp:66-84)
+        copy3(d.sigma_a, a->_sigmaA); copy3(d.sigma_s, a->_sigmaS); copy3(d.sigma_t, a->_sigmaT);
+        d.absorption_only = a->_absorptionOnly ? 1 : 0;
+        d.medium_type = TGHIP_MEDIUM_ATMOSPHERE;
+        d.falloff_scale = a->_effectiveFalloffScale;
+        copy3(d.unit_point, a->_center);
+        d.falloff_dir[0] = a->_radius;
     } else {                                        // ExponentialMedium after prepareForRender (ExponentialMedium.cpp:52-59)
         copy3(d.sigma_a, x->_sigmaA); copy3(d.sigma_s, x->_sigmaS); copy3(d.sigma_t, x->_sigmaT);
         d.absorption_only = x->_absorptionOnly ? 1 : 0;
@@ -348,8 +357,8 @@ int32_t HipSceneFlattener::addMedium(const Medium *m)
     int32_t subType[2] = {0, 0};
     float subP[2][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
     describeTransmittance(m->_transmittance.get(), d.trans_type, d.trans_p, false, subType, subP);
-    if (x && d.trans_type != TGHIP_TRANS_EXPONENTIAL)
-        refuse("an exponential medium with a non-exponential transmittance");
+    if ((x || a) && d.trans_type != TGHIP_TRANS_EXPONENTIAL)
+        refuse("an exponential or atmospheric medium with a non-exponential transmittance");
     _mediumKeys.push_back(m);
     _media.push_back(d);
     const int32_t index = int32_t(_media.size() - 1);

@@ -752,6 +752,26 @@ def _expfog_and_smoke(scene):
             m.update(type="exponential", falloff_scale=2.0, unit_point=[0.3, 0.0, 0.3], falloff_direction=[0.0, 1.0, 0.0])
 
 
+def _atmosphere(scene):
+    """media/AtmosphericMedium.cpp: the camera's fog is a Gaussian ball of haze around the short box (its pivot; density exp(-s^2 (|p - c|^2 - r^2)),
+    s = falloff_scale/radius) -- scattering distances through std::erf / exp / Boost's erf_inv in double, optical depths through the A&S erfc."""
+    _fog(scene)
+    scene["media"][-1].update(type="atmosphere", falloff_scale=1.3, radius=0.7, pivot="shortBox", density=1.4)
+
+
+def _atmosphere_and_smoke(scene):
+    """The haze outside (centre given, not a pivot), homogeneous smoke in the tall box, an ABSORPTION-ONLY atmospheric medium (a tint densest at the
+    glass box's heart) inside the short one: AtmosphericMedium::sampleDistance's absorption-only branch and ::transmittance on shadow rays."""
+    _fog_and_smoke(scene)
+    for m in scene["media"]:
+        if m["name"] == "fog":
+            m.update(type="atmosphere", falloff_scale=0.9, radius=1.2, center=[0.1, 0.8, -0.2])
+        if m["name"] == "tint":
+            m.update(type="atmosphere", falloff_scale=1.0, radius=0.3, center=[0.33, 0.3, 0.37])
+
+
+GOLDEN_CASES["cornell_atmosphere"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_atmosphere))
+GOLDEN_CASES["cornell_atmosphere_smoke_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_atmosphere_and_smoke, renderer={"stratified_sampler": True}))
 GOLDEN_CASES["cornell_expfog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_expfog))
 GOLDEN_CASES["cornell_expfog_smoke_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_expfog_and_smoke, renderer={"stratified_sampler": True}))
 GOLDEN_CASES["cornell_fog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_fog))

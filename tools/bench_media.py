@@ -13,7 +13,9 @@ import tungsten_amd as tg  # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 tmp = tempfile.mkdtemp(prefix="tg_media_")
-for name, edit in (("cornell", None), ("cornell_fog", scenes._fog), ("cornell_smoke", scenes._smoke), ("cornell_fog_smoke", scenes._fog_and_smoke)):
+for name, edit in (("cornell", None), ("cornell_fog", scenes._fog), ("cornell_smoke", scenes._smoke), ("cornell_fog_smoke", scenes._fog_and_smoke),
+                   ("cornell_expfog", scenes._expfog), ("cornell_expfog_smoke", scenes._expfog_and_smoke)) + (
+                  (("cornell_atmosphere", scenes._atmosphere), ("cornell_atmosphere_smoke", scenes._atmosphere_and_smoke)) if os.environ.get("TG_MEDIA_ATMOSPHERE", "1") != "0" else ()):
     warm = tg.Renderer(scenes.cornell(tmp, name=name + "_warm.json", resolution=(1280, 720), spp=4, edit=edit), seed=tg.DEFAULT_SEED)
     warm.render()                    # warm-up: device context, code objects, allocations
     warm.close()

@@ -8,6 +8,7 @@
 #define TGAMD_PT_SCENE_H_
 
 #include "pt_math.h"
+#include "pt_erfinv_table.h"
 #include "../../../include/tungsten_hip.h"
 
 struct DeviceScene {
@@ -2567,6 +2568,12 @@ PT_DEV float transSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   
 /* HomogeneousMedium::sampleDistance (:66-107).  maxT = ray.farT(); false = the path ends here ("return emission").
  * MediumState::firstScatter (the "start on a surface" flag of the transmittance) is stateBounce == 0: reset() clears both,
  * advance() clears the flag and counts (Medium.hpp:36-46). */
+/* The exponential and the atmospheric medium carry the exponential transmittance only (include/tungsten_hip.h; checked at upload): its four kernels
+ * are all FastMath::exp(-tau), its sigmaBar is one, its two samplers -log(1 - xi) (ExponentialTransmittance.cpp:26-63) -- the general transEval /
+ * transKernel3 / transSample above inline every transmittance type at every call site, which is 50 k instructions per medium type in the media kernels. */
+PT_DEV f3 transExp3(f3 tau) { return mk3(fmathExp(-tau.x), fmathExp(-tau.y), fmathExp(-tau.z)); }
+template<uint32_t M>
+PT_DEV float transExpSample(Rng &rng) { return -logfH(1.0f - RNG1D(rng)); }
 /* ExponentialMedium::densityIntegral / inverseOpticalDepth (ExponentialMedium.cpp:81-104): std::exp / std::log on floats = glibc's expf / logf */
 PT_DEV float expMediumDensityIntegral(float x, float dx, float tMax)
 {
@@ -2584,6 +2591,117 @@ PT_DEV float expMediumInverseOpticalDepth(float x, float dx, float tau)
     float denom = 1.0f - dx*expfH(x)*tau;
     return denom <= 0.0f ? PT_INF : -logfH(denom)/dx;
 }
+/* AtmosphericMedium (media/AtmosphericMedium.cpp): density exp(-s^2 (|p - center|^2 - radius^2)) with s = falloff_scale / radius -- in TgHipMedium:
+ * falloff_scale = s (_effectiveFalloffScale), unit_point = _center, falloff_dir[0] = _radius.  The optical depth along a ray is a difference of error
+ * functions: densityIntegral (:104-111) in float through Abramowitz & Stegun's 7.1.26 as math/Erf.hpp:247-283 writes it (std::exp on floats =
+ * glibc's expf); inverseOpticalDepth (:113-122) in DOUBLE -- std::erf, std::exp and Boost's erf_inv (pt_libm.h: erfInvD).  The device's double erf /
+ * exp / log are ocml's: they agree with glibc's to the last place or one off, and the result is rounded to float, so a scattering distance
+ * differs from the reference's in about one sample in 10^6 (DESIGN.md section 6 states the measured count on the goldens). */
+/* (real calls, not inlined: the atmosphere's double-precision code would otherwise be copied into every call site of the media kernels -- 100 k instructions) */
+#define PT_DEV_CALL __device__ __attribute__((noinline))
+#define PT_SQRT_PI     1.77245385091f           /* math/Angle.hpp:15-16 */
+#define PT_INV_SQRT_PI (1.0f/PT_SQRT_PI)
+PT_DEV float erfcAS(float x)                                   /* Erf::erfc<float> (math/Erf.hpp:249-263) */
+{
+    const float p = 0.32759f;
+    const float as[5] = {0.254829592f, -0.284496736f, 1.421413741f, -1.453152027f, 1.061405429f};
+    float t = 1.0f/(1.0f + p*fabsf(x));
+    float ti = copysignf(t*expfH(-x*x), x);
+    float result = 0.0f;
+    for (int i = 0; i < 5; ++i) {
+        result += as[i]*ti;
+        ti *= t;
+    }
+    float constant = 1.0f - copysignf(1.0f, x);
+    return constant + result;
+}
+PT_DEV float erfDifferenceAS(float x0, float x1)              /* Erf::erfDifference<float> (math/Erf.hpp:265-283) */
+{
+    const float p = 0.32759f;
+    const float as[5] = {0.254829592f, -0.284496736f, 1.421413741f, -1.453152027f, 1.061405429f};
+    float t0 = 1.0f/(1.0f + p*fabsf(x0));
+    float t1 = 1.0f/(1.0f + p*fabsf(x1));
+    float ti0 = copysignf(t0*expfH(-x0*x0), x0);
+    float ti1 = copysignf(t1*expfH(-x1*x1), x1);
+    float result = 0.0f;
+    for (int i = 0; i < 5; ++i) {
+        result += as[i]*(ti0 - ti1);
+        ti0 *= t0;
+        ti1 *= t1;
+    }
+    float constant = copysignf(1.0f, x1) - copysignf(1.0f, x0);
+    return constant + result;
+}
+PT_DEV_CALL float atmDensityIntegral(float s, float radius, float h, float t0, float t1)   /* AtmosphericMedium::densityIntegral (:104-111) */
+{
+    if (t1 == PT_INF)
+        return (PT_SQRT_PI*0.5f/s)*expfH((-h*h + radius*radius)*s*s)*erfcAS(s*t0);
+    else
+        return (PT_SQRT_PI*0.5f/s)*expfH((-h*h + radius*radius)*s*s)*erfDifferenceAS(s*t0, s*t1);
+}
+PT_DEV float atmDensity(float s, float radius, float h, float t0)                     /* AtmosphericMedium::density(h, t0) (:99-102) */
+{
+    return expfH(-(s*s)*(h*h - radius*radius + t0*t0));
+}
+template<int N>
+PT_DEV double polyEvalD(double x, const double *P)             /* Polynomial::eval<Size> (math/Polynomial.hpp:9-18): Horner, no fused operations */
+{
+    double result = P[N - 1];
+    for (int i = N - 2; i >= 0; --i) {
+        result *= x;
+        result += P[i];
+    }
+    return result;
+}
+PT_DEV double erfInvD(double z)                                 /* Erf::erfInv (math/Erf.hpp:192-245); tables: pt_erfinv_table.h */
+{
+    double p, q, sgn;
+    if (z < 0) { p = -z; q = 1 - p; sgn = -1; }
+    else       { p = z;  q = 1 - z; sgn = 1; }
+    double result;
+    if (p <= 0.5) {
+        double g = p*(p + 10.0);
+        double r = polyEvalD<8>(p, g_erfInvP1)/polyEvalD<10>(p, g_erfInvQ1);
+        result = g*g_erfInvY[0] + g*r;
+    } else if (q >= 0.25) {
+        double g = ::sqrt(-2.0*::log(q));
+        double xs = q - 0.25;
+        double r = polyEvalD<9>(xs, g_erfInvP2)/polyEvalD<9>(xs, g_erfInvQ2);
+        result = g/(g_erfInvY[1] + r);
+    } else {
+        double x = ::sqrt(-::log(q));
+        if (x < 3.0) {
+            double xs = x - 1.125;
+            double R = polyEvalD<11>(xs, g_erfInvP3)/polyEvalD<8>(xs, g_erfInvQ3);
+            result = g_erfInvY[2]*x + R*x;
+        } else if (x < 6.0) {
+            double xs = x - 3;
+            double R = polyEvalD<9>(xs, g_erfInvP4)/polyEvalD<7>(xs, g_erfInvQ4);
+            result = g_erfInvY[3]*x + R*x;
+        } else if (x < 18.0) {
+            double xs = x - 6.0;
+            double R = polyEvalD<9>(xs, g_erfInvP5)/polyEvalD<7>(xs, g_erfInvQ5);
+            result = g_erfInvY[4]*x + R*x;
+        } else if (x < 44.0) {
+            double xs = x - 18.0;
+            double R = polyEvalD<8>(xs, g_erfInvP6)/polyEvalD<7>(xs, g_erfInvQ6);
+            result = g_erfInvY[5]*x + R*x;
+        } else {
+            double xs = x - 44.0;
+            double R = polyEvalD<8>(xs, g_erfInvP7)/polyEvalD<7>(xs, g_erfInvQ7);
+            result = g_erfInvY[6]*x + R*x;
+        }
+    }
+    return sgn*result;
+}
+PT_DEV_CALL float atmInverseOpticalDepth(float sF, float radiusF, double h, double t0, double tau)   /* AtmosphericMedium::inverseOpticalDepth (:113-122) */
+{
+    const double s = sF, radius = radiusF;
+    const double inner = ::erf(s*t0) + 2.0*double(PT_INV_SQRT_PI)*::exp(s*s*(h - radius)*(h + radius))*s*tau;
+    if (inner >= 1.0)
+        return PT_INF;
+    return float(erfInvD(inner)/s);
+}
 template<uint32_t M>
 PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, f3 rayO, f3 rayD, float maxT, uint32_t &stateBounce, f3 &weight, float &t, bool &exited)
 {
@@ -2599,27 +2717,60 @@ PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, f3 
             if (maxT == PT_INF && dx <= 0.0f)
                 return false;
             t = maxT;
-            weight = transEval(m, sigmaT*expMediumDensityIntegral(x, dx, maxT), firstScatter, true);
+            weight = transExp3(sigmaT*expMediumDensityIntegral(x, dx, maxT));
             exited = true;
             return true;
         }
         int component = (int)(rngNext1D(rng)*3);
         float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
-        float tauC = transSample<M>(m, rng, firstScatter)/sigmaTc;
+        float tauC = transExpSample<M>(rng)/sigmaTc;
         float tt = expMediumInverseOpticalDepth(x, dx, tauC);
         t = fminf(tt, maxT);
         exited = tt >= maxT;
         f3 tau = sigmaT*expMediumDensityIntegral(x, dx, t);
-        weight = transEval(m, tau, firstScatter, exited);
+        weight = transExp3(tau);
         float pdf;
         if (exited) {
-            pdf = avg3(transKernel3(m, firstScatter ? 0 : 2, tau));
+            pdf = avg3(transExp3(tau));
         } else {
             float rho = expfH(-(x + dx*t));
-            pdf = avg3((sigmaT*rho)*transKernel3(m, firstScatter ? 1 : 3, tau));
-            weight = weight*((ld3(m.sigma_s)*rho)*transSigmaBar(m));
+            pdf = avg3((sigmaT*rho)*transExp3(tau));
+            weight = weight*((ld3(m.sigma_s)*rho)*1.0f);
         }
         weight = weight/pdf;
+        stateBounce++;
+        return true;
+    }
+    if (m.medium_type == TGHIP_MEDIUM_ATMOSPHERE) {              /* AtmosphericMedium::sampleDistance (AtmosphericMedium.cpp:124-168); exponential transmittance */
+        const float sc = m.falloff_scale, radius = m.falloff_dir[0];
+        const f3 p = rayO - ld3(m.unit_point);
+        const float t0 = dot(p, rayD);
+        const float h = length(p - rayD*t0);
+        const float maxTa = maxT + t0;
+        if (m.absorption_only) {
+            t = maxT;
+            weight = transExp3(sigmaT*atmDensityIntegral(sc, radius, h, t0, maxTa));
+            exited = true;
+            return true;
+        }
+        int component = (int)(rngNext1D(rng)*3);
+        float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
+        float tauC = transExpSample<M>(rng)/sigmaTc;
+        float tt = atmInverseOpticalDepth(sc, radius, h, t0, tauC);
+        t = fminf(tt, maxTa);
+        exited = tt >= maxTa;
+        f3 tau = sigmaT*atmDensityIntegral(sc, radius, h, t0, t);
+        weight = transExp3(tau);
+        float pdf;
+        if (exited) {
+            pdf = avg3(transExp3(tau));
+        } else {
+            float rho = atmDensity(sc, radius, h, t);
+            pdf = avg3((sigmaT*rho)*transExp3(tau));
+            weight = weight*((ld3(m.sigma_s)*rho)*1.0f);
+        }
+        weight = weight/pdf;
+        t -= t0;
         stateBounce++;
         return true;
     }
@@ -2658,7 +2809,14 @@ PT_DEV f3 mediumTransmittance(const DeviceScene &s, int medium, f3 rayO, f3 rayD
         const float dx = m.falloff_scale*dot(rayD, ld3(m.falloff_dir));
         if (farT == PT_INF && dx <= 0.0f)
             return splat3(0.0f);
-        return transEval(m, ld3(m.sigma_t)*expMediumDensityIntegral(x, dx, farT), startOnSurface, endOnSurface);
+        return transExp3(ld3(m.sigma_t)*expMediumDensityIntegral(x, dx, farT));
+    }
+    if (m.medium_type == TGHIP_MEDIUM_ATMOSPHERE) {              /* AtmosphericMedium::transmittance (AtmosphericMedium.cpp:170-180) */
+        const f3 p = rayO - ld3(m.unit_point);
+        const float t0 = dot(p, rayD);
+        const float t1 = farT + t0;
+        const float h = length(p - rayD*t0);
+        return transExp3(ld3(m.sigma_t)*atmDensityIntegral(m.falloff_scale, m.falloff_dir[0], h, t0, t1));
     }
     if (farT == PT_INF)
         return splat3(0.0f);

@@ -1184,11 +1184,14 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
                 ctx->error = "unknown phase function";
                 return TGHIP_E_UNSUPPORTED;
             }
-            if (sd->media[i].medium_type != TGHIP_MEDIUM_HOMOGENEOUS && sd->media[i].medium_type != TGHIP_MEDIUM_EXPONENTIAL) {
+            if (sd->media[i].medium_type < TGHIP_MEDIUM_HOMOGENEOUS || sd->media[i].medium_type > TGHIP_MEDIUM_ATMOSPHERE) {
                 ctx->error = "unknown medium type"; return TGHIP_E_UNSUPPORTED;
             }
-            if (sd->media[i].medium_type == TGHIP_MEDIUM_EXPONENTIAL && sd->media[i].trans_type != TGHIP_TRANS_EXPONENTIAL) {
-                ctx->error = "an exponential medium with a non-exponential transmittance is not supported"; return TGHIP_E_UNSUPPORTED;
+            if (sd->media[i].medium_type != TGHIP_MEDIUM_HOMOGENEOUS && sd->media[i].trans_type != TGHIP_TRANS_EXPONENTIAL) {
+                ctx->error = "an exponential or atmospheric medium with a non-exponential transmittance is not supported"; return TGHIP_E_UNSUPPORTED;
+            }
+            if (sd->media[i].medium_type == TGHIP_MEDIUM_ATMOSPHERE && !(sd->media[i].falloff_scale > 0.0f && sd->media[i].falloff_dir[0] > 0.0f)) {
+                ctx->error = "an atmospheric medium needs a positive falloff scale and radius"; return TGHIP_E_INVALID;
             }
             if (sd->media[i].trans_type < TGHIP_TRANS_EXPONENTIAL || sd->media[i].trans_type > TGHIP_TRANS_INTERPOLATED) {
                 ctx->error = "unknown transmittance";

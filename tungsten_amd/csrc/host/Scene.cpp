@@ -659,9 +659,10 @@ std::shared_ptr<Bsdf> Scene::fetchBsdf(const JsonValue &v) const
 // Media: homogeneous medium with exponential transmittance and an isotropic / Henyey-Greenstein phase function
 // (media/HomogeneousMedium.cpp:19-26, Medium.cpp:20-30); everything else is rejected by name
 // ------------------------------------------------------------------------------------------
-void Medium::prepareForRender()   // HomogeneousMedium.cpp:43-49, ExponentialMedium.cpp:52-59
+void Medium::prepareForRender()   // HomogeneousMedium.cpp:43-49, ExponentialMedium.cpp:52-59, AtmosphericMedium.cpp:66-84 (the pivot: TraceableScene::flatten)
 {
     unitFalloffDirection = falloffDirection.normalized();
+    effectiveFalloffScale = falloffScale/radius;
     sigmaA = materialSigmaA*density;
     sigmaS = materialSigmaS*density;
     sigmaT = sigmaA + sigmaS;
@@ -672,9 +673,16 @@ std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
 {
     auto m = std::make_shared<Medium>();
     std::string type = v["type"].asString();
-    if (type != "homogeneous" && type != "exponential")
-        throw JsonLoadException("medium type '" + type + "' is not supported by path_tracer_hip (homogeneous and exponential only)");
+    if (type != "homogeneous" && type != "exponential" && type != "atmosphere")
+        throw JsonLoadException("medium type '" + type + "' is not supported by path_tracer_hip (homogeneous, exponential and atmosphere only)");
     v.getField("name", m->name);
+    if (type == "atmosphere") {                     // AtmosphericMedium::fromJson (AtmosphericMedium.cpp:25-38)
+        m->mediumType = 2;
+        v.getField("pivot", m->pivot);
+        v.getField("falloff_scale", m->falloffScale);
+        v.getField("radius", m->radius);
+        getVec3(v, "center", m->center);
+    }
     if (type == "exponential") {                    // ExponentialMedium::fromJson (ExponentialMedium.cpp:22-31)
         m->mediumType = 1;
         v.getField("falloff_scale", m->falloffScale);
@@ -734,9 +742,9 @@ std::shared_ptr<Medium> Scene::instantiateMedium(const JsonValue &v) const
     };
     if (const JsonValue &t = v["transmittance"])
         parseTransmittance(t, m->transType, m->transP, false);
-    if (m->mediumType == 1 && m->transType != 0)
-        throw JsonLoadException("an exponential medium with a non-exponential transmittance is not supported by path_tracer_hip (the reference's "
-                                "ExponentialMedium::sampleDistance evaluates the transmittance with a flag it has not set yet)");
+    if (m->mediumType != 0 && m->transType != 0)
+        throw JsonLoadException("an exponential or atmospheric medium with a non-exponential transmittance is not supported by path_tracer_hip (the "
+                                "reference's ExponentialMedium / AtmosphericMedium::sampleDistance evaluate the transmittance with a flag they have not set yet)");
     if (const JsonValue &ph = v["phase_function"]) {
         std::string pt = ph.isString() ? ph.asString() : ph["type"].asString();
         if (pt == "isotropic") m->phaseType = 0;

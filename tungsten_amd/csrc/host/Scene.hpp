@@ -82,7 +82,11 @@ struct Medium   // media/HomogeneousMedium.{hpp,cpp} + Medium.cpp + transmittanc
     Vec3f materialSigmaA = Vec3f(0.0f), materialSigmaS = Vec3f(0.0f);
     float density = 1.0f;
     int maxBounce = 1024;
-    int mediumType = 0;         // TGHIP_MEDIUM_*: 0 homogeneous, 1 exponential (media/ExponentialMedium.cpp)
+    int mediumType = 0;         // TGHIP_MEDIUM_*: 0 homogeneous, 1 exponential (media/ExponentialMedium.cpp), 2 atmosphere (media/AtmosphericMedium.cpp)
+    float radius = 1.0f;        // AtmosphericMedium.cpp:14-23: _radius, _center, the pivot primitive's name (its origin replaces _center, :68-77)
+    Vec3f center = Vec3f(0.0f);
+    std::string pivot;
+    float effectiveFalloffScale = 1.0f;   // _falloffScale/_radius (:79)
     float falloffScale = 1.0f;  // ExponentialMedium.cpp:12-19
     Vec3f unitPoint = Vec3f(0.0f), falloffDirection = Vec3f(0.0f, 1.0f, 0.0f), unitFalloffDirection = Vec3f(0.0f, 1.0f, 0.0f);
     int phaseType = 0;          // 0 isotropic, 1 henyey_greenstein, 2 rayleigh

@@ -441,6 +441,21 @@ void TraceableScene::flatten()
             d.falloff_scale = m->falloffScale;
             copy3(d.unit_point, m->unitPoint);
             copy3(d.falloff_dir, m->unitFalloffDirection);
+        } else if (m->mediumType == TGHIP_MEDIUM_ATMOSPHERE) {
+            // AtmosphericMedium::prepareForRender (AtmosphericMedium.cpp:66-84): the named pivot primitive's origin is the centre
+            Vec3f center = m->center;
+            if (!m->pivot.empty()) {
+                const Primitive *pivot = nullptr;
+                for (const auto &p : _scene.primitives)
+                    if (p->name == m->pivot) { pivot = p.get(); break; }
+                if (pivot)
+                    center = pivot->transform*Vec3f(0.0f);
+                else
+                    std::fprintf(stderr, "Note: unable to find pivot object '%s' for atmospheric medium\n", m->pivot.c_str());
+            }
+            d.falloff_scale = m->effectiveFalloffScale;
+            copy3(d.unit_point, center);
+            d.falloff_dir[0] = m->radius;
         }
         mediumKeys.push_back(m.get());
         _media.push_back(d);
