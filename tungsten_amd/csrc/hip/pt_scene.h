@@ -2370,6 +2370,9 @@ PT_DEV int selectMedium(const TgHipObject &o, int current, bool geometricBacksid
  * 3 = mediumMedium (transmittances/{Exponential,Linear,Quadratic,DoubleExponential,Pulse,Erlang}Transmittance.cpp) */
 PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
 {
+#ifdef PT_EXP_TRANS_ONLY     /* compile-only / A-B diagnostic: what the media kernels cost without the eight non-exponential transmittances */
+    return fmathExp(-tau);
+#endif
     const float p0 = m.trans_p[0], p1 = m.trans_p[1], p2 = m.trans_p[2];
     switch (m.trans_type) {
     case TGHIP_TRANS_LINEAR: {                          /* LinearTransmittance.cpp:32-57 */
@@ -2450,6 +2453,9 @@ PT_DEV float transLeafKernel(const TgHipMedium &m, int k, float tau)
 }
 PT_DEV float transLeafSigmaBar(const TgHipMedium &m)
 {
+#ifdef PT_EXP_TRANS_ONLY
+    return 1.0f;
+#endif
     switch (m.trans_type) {
     case TGHIP_TRANS_LINEAR: return 1.0f/m.trans_p[0];
     case TGHIP_TRANS_QUADRATIC: return 2.0f/m.trans_p[0];
@@ -2499,6 +2505,9 @@ PT_DEV f3 transEval(const TgHipMedium &m, f3 tau, bool startOnSurface, bool endO
 template<uint32_t M>
 PT_DEV float transLeafSample(const TgHipMedium &m, Rng &rng, bool startOnSurface)   /* sampleSurface / sampleMedium */
 {
+#ifdef PT_EXP_TRANS_ONLY
+    return -logfH(1.0f - RNG1D(rng));
+#endif
     const float p0 = m.trans_p[0], p1 = m.trans_p[1], p2 = m.trans_p[2];
     switch (m.trans_type) {
     case TGHIP_TRANS_LINEAR:
@@ -2774,6 +2783,33 @@ PT_DEV bool mediumSampleDistance(const DeviceScene &s, int medium, Rng &rng, f3 
         stateBounce++;
         return true;
     }
+    if (m.trans_type == TGHIP_TRANS_EXPONENTIAL) {               /* the usual medium, without the transmittance switch at five call sites (same arithmetic) */
+        if (m.absorption_only) {
+            if (maxT == PT_INF)
+                return false;
+            t = maxT;
+            weight = transExp3(sigmaT*t);
+            exited = true;
+            return true;
+        }
+        int component = (int)(rngNext1D(rng)*3);
+        float sigmaTc = component == 0 ? sigmaT.x : component == 1 ? sigmaT.y : sigmaT.z;
+        float tt = transExpSample<M>(rng)/sigmaTc;
+        t = fminf(tt, maxT);
+        exited = tt >= maxT;
+        f3 tau = sigmaT*t;
+        weight = transExp3(tau);
+        float pdf;
+        if (exited) {
+            pdf = avg3(transExp3(tau));
+        } else {
+            pdf = avg3(sigmaT*transExp3(tau));
+            weight = weight*(ld3(m.sigma_s)*1.0f);
+        }
+        weight = weight/pdf;
+        stateBounce++;
+        return true;
+    }
     if (m.absorption_only) {
         if (maxT == PT_INF)
             return false;
@@ -2820,7 +2856,9 @@ PT_DEV f3 mediumTransmittance(const DeviceScene &s, int medium, f3 rayO, f3 rayD
     }
     if (farT == PT_INF)
         return splat3(0.0f);
-    return transEval(s.media[medium], ld3(s.media[medium].sigma_t)*farT, startOnSurface, endOnSurface);
+    if (m.trans_type == TGHIP_TRANS_EXPONENTIAL)
+        return transExp3(ld3(m.sigma_t)*farT);
+    return transEval(m, ld3(m.sigma_t)*farT, startOnSurface, endOnSurface);
 }
 
 /* PhaseFunction::eval == pdf (IsotropicPhaseFunction.cpp:17-41, HenyeyGreensteinPhaseFunction.cpp:16-43, 80-83) */
