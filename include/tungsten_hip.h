@@ -546,7 +546,9 @@ int tghip_trace_rays(tghip_ctx *ctx, const TgHipRay *rays, TgHipHit *hits, size_
  * rcppsIntel).  The GPU tests compare y with the host libm / the oracle's restatement bit for bit. */
 enum { TGHIP_LIBM_SINF = 0, TGHIP_LIBM_COSF = 1, TGHIP_LIBM_LOGF = 2, TGHIP_LIBM_EXPF = 3, TGHIP_LIBM_SINCOS_SIN = 4, TGHIP_LIBM_SINCOS_COS = 5,
        TGHIP_LIBM_ACOSF = 6, TGHIP_LIBM_ATAN2F = 7, TGHIP_LIBM_POWF = 8, TGHIP_LIBM_CBRTF = 9,
-       TGHIP_LIBM_EMBREE_RCP = 10, TGHIP_LIBM_RCPPS = 11, TGHIP_LIBM_TANF = 12 };
+       TGHIP_LIBM_EMBREE_RCP = 10, TGHIP_LIBM_RCPPS = 11, TGHIP_LIBM_TANF = 12,
+       /* double precision (AtmosphericMedium::inverseOpticalDepth: std::exp / log / erf / sqrt on doubles): x and y then point to n DOUBLES */
+       TGHIP_LIBM_EXPD = 13, TGHIP_LIBM_LOGD = 14, TGHIP_LIBM_ERFD = 15, TGHIP_LIBM_SQRTD = 16 };
 int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n);
 int tghip_set_option(tghip_ctx *ctx, const char *key, long long value);  /* "count_traversal", "max_slots", ...; "top_tree" = 0 before an upload:
                                                                              TgHipSceneDesc::top_nodes is ignored, flat lists are walked in record order.

@@ -130,3 +130,46 @@ extern "C" void libm_host_rcpps_hw(const float *x, float *y, size_t n)
     for (size_t i = 0; i < n; ++i)
         y[i] = _mm_cvtss_f32(_mm_rcp_ps(_mm_set1_ps(x[i])));
 }
+
+// ---- double precision (round 6): pt_libm.h's expD / logD / erfD against the host libm's exp / log / erf ------------------------------------
+// fn: 0 exp, 1 log, 2 erf; libm_host_refd also 3 = sqrt (what the device's sqrt is compared with)
+extern "C" void libm_host_evald(int fn, const double *x, double *y, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        y[i] = fn == 0 ? ptlibm::expD(x[i]) : fn == 1 ? ptlibm::logD(x[i]) : ptlibm::erfD(x[i]);
+}
+extern "C" void libm_host_refd(int fn, const double *x, double *y, size_t n)
+{
+    for (size_t i = 0; i < n; ++i)
+        y[i] = fn == 0 ? exp(x[i]) : fn == 1 ? log(x[i]) : fn == 2 ? erf(x[i]) : sqrt(x[i]);
+}
+// n pseudo-random arguments (xorshift, 64 streams from `seed`), a quarter each: arbitrary bit patterns; the range the function is interesting on
+// (exp: [-750, 715]; log: (0, 2) and near one; erf: [-7, 7]); small magnitudes; the call sites' ranges (exp of -(s t)^2 - 0.5625 and of small
+// negative numbers, log of q in (0, 1/2], erf of s t0 in [-4, 4]).  Returns the number of mismatches (NaN against NaN is a match).
+extern "C" unsigned long long libm_host_sweepd(int fn, unsigned long long n, unsigned long long seed, unsigned long long *tested)
+{
+    unsigned long long bad = 0, done = 0;
+#pragma omp parallel for reduction(+:bad, done)
+    for (int t = 0; t < 64; ++t) {
+        unsigned long long s = seed*0x9E3779B97F4A7C15ull + (unsigned long long)(t + 1)*0xD1B54A32D192ED03ull;
+        for (int k = 0; k < 8; ++k) xorshift(&s);
+        for (unsigned long long i = 0; i < n/64; ++i) {
+            const unsigned long long r = xorshift(&s), r2 = xorshift(&s);
+            const double u = (double)(r2 >> 11)*0x1p-53;           // [0, 1)
+            double x;
+            switch (i & 3) {
+            case 0: memcpy(&x, &r, 8); break;
+            case 1: x = fn == 0 ? u*1465.0 - 750.0 : fn == 1 ? ((r & 1) ? u*2.0 : 0.9 + u*0.2) : u*14.0 - 7.0; break;
+            case 2: x = (u - 0.5)*((r & 1) ? 1e-3 : 1e-12); if (fn == 1) x = __builtin_fabs(x); break;
+            default: x = fn == 0 ? ((r & 1) ? -u*40.0 : -u) : fn == 1 ? ((r & 1) ? u*0.5 : u*u*u*u*0.5) : u*8.0 - 4.0; break;
+            }
+            const double got = fn == 0 ? ptlibm::expD(x) : fn == 1 ? ptlibm::logD(x) : ptlibm::erfD(x);
+            const double want = fn == 0 ? exp(x) : fn == 1 ? log(x) : erf(x);
+            done++;
+            if (got != got && want != want) continue;
+            if (memcmp(&got, &want, 8) != 0) bad++;
+        }
+    }
+    if (tested) *tested = done;
+    return bad;
+}

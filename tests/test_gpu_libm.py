@@ -101,6 +101,27 @@ def test_device_libm_is_the_host_libm_bit_for_bit(tmp_path):
         oracle_lib._lib.oracle_embree_rcp(raw, x.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
         bad = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
         assert not bad.any(), "rcp fn %d: %d of %d differ, first x = %r: device %r, oracle %r" % (fn, int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
+    # double precision (round 6: AtmosphericMedium::inverseOpticalDepth -- std::erf(s t0), std::exp of s^2 (h - r)(h + r), Erf::erfInv's std::log(q) and std::sqrt):
+    # pt_libm.h's expD / logD / erfD and the device's correctly rounded sqrt against the host libm (oracle/libm_host.cpp: libm_host_refd, 0 exp, 1 log, 2 erf, 3 sqrt)
+    host.libm_host_refd.restype = None
+    host.libm_host_refd.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    u = rng.random(n)
+    bits64 = rng.integers(0, 1 << 63, n, dtype=np.uint64).view(np.float64)          # arbitrary non-negative bit patterns (subnormals, infinities, NaNs among them)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, 2.2e-308, 1.7e308, 709.78, 709.79, -708.4, -745.1, -745.2, 1 - 2.0**-53, 1 + 2.0**-52, 0.9375, 1.0647, 0.5, 0.25, 6.0, -6.0, 0.84375, 1.25, 2.857142857142857], np.float64)
+    dcases = [
+        (capi.TGHIP_LIBM_EXPD, 0, [u*1465.0 - 750.0, -u*40.0, -u, (u - 0.5)*1e-12, -u*u*30.0 - 0.5625, bits64, -bits64, special]),
+        (capi.TGHIP_LIBM_LOGD, 1, [u*0.5, u**4*0.5, 0.9 + u*0.2, u*2.0, u*1e300, u*1e-300, bits64, special]),
+        (capi.TGHIP_LIBM_ERFD, 2, [u*8.0 - 4.0, u*14.0 - 7.0, (u - 0.5)*1e-6, (u - 0.5)*1e-300, bits64, -bits64, special]),
+        (capi.TGHIP_LIBM_SQRTD, 3, [u, u*60.0, -2.0*np.log(np.maximum(u, 1e-300)), bits64, special]),
+    ]
+    for fn, host_fn, arrays in dcases:
+        for x in arrays:
+            x = np.ascontiguousarray(x, np.float64)
+            got = r.debug_libm(fn, x)
+            want = np.empty_like(x)
+            host.libm_host_refd(host_fn, x.ctypes.data, want.ctypes.data, x.size)
+            bad = (got.view(np.uint64) != want.view(np.uint64)) & ~(np.isnan(got) & np.isnan(want))
+            assert not bad.any(), "double fn %d: %d of %d differ, first x = %r: device %r, host %r" % (fn, int(bad.sum()), x.size, x[bad][0], got[bad][0], want[bad][0])
     # logf / expf are glibc's for EVERY float (pt_libm.h: logfAll / expfAll, all 2^32 bit patterns checked on the host); here the special cases
     # whose results are not subnormal: zeros, negatives, infinities, NaN, the overflow / underflow thresholds
     for fn, x in ((capi.TGHIP_LIBM_LOGF, [0.0, -0.0, -1.0, -1e-30, np.inf, -np.inf, np.nan, 1.0, 3.4e38, 1.2e-38]),

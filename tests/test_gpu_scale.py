@@ -49,6 +49,15 @@ def _needs(name):
         pytest.skip("materialtest assets (assets/) not present")
 
 
+@pytest.mark.parametrize("opts", ["hoist_quad=0", "decouple=0"])
+@pytest.mark.parametrize("size,name", [("scale8", "mesh1m"), ("scale8", "materialtest"), ("scale64", "materialtest_sobol")])
+def test_residuals_do_not_depend_on_the_hoisted_quad_or_the_decoupled_walk(size, name, opts, tmp_path, monkeypatch):
+    """The scenes with the ground quad under the meshes (the quad that is tested before the walk) rendered with the quad back inside
+    the walk and with the sequential walk: the same samples -- the same pinned residual against the reference's hashes -- as the default kernels."""
+    monkeypatch.setenv("TG_SCALE_OPTS", opts)
+    test_device_samples_are_the_references_above_golden_size(size, name, tmp_path)
+
+
 @pytest.mark.parametrize("size,name", [(s, n) for s in ("scale8", "scale64") for n in msg.SIZES[s][2]])
 def test_device_samples_are_the_references_above_golden_size(size, name, tmp_path):
     _needs(name)

@@ -555,6 +555,26 @@ def test_libm_restatements_match_the_host_libm():
         assert ok.mean() > 0.99 and (got[ok].view(np.uint32) == want[ok].view(np.uint32)).all(), fn
 
 
+def test_double_libm_restatements_match_the_host_libm():
+    """pt_libm.h: expD / logD / erfD -- glibc 2.35's double-precision exp, log and erf as AtmosphericMedium::inverseOpticalDepth calls them (media/AtmosphericMedium.cpp:
+    113-122, math/Erf.hpp:192-245), the fused operations of its FMA builds spelt out -- compiled for the host against the image's libm, bit for bit, on 3 x 10^7
+    pseudo-random arguments each: arbitrary bit patterns (special cases, subnormal results, overflow), the functions' ranges, tiny arguments, the call sites' ranges."""
+    import ctypes as C
+    lib = _libm_host()
+    lib.libm_host_sweepd.restype = C.c_ulonglong
+    lib.libm_host_sweepd.argtypes = [C.c_int, C.c_ulonglong, C.c_ulonglong, C.POINTER(C.c_ulonglong)]
+    for fn in (0, 1, 2):
+        tested = C.c_ulonglong(0)
+        assert lib.libm_host_sweepd(fn, 30000000, 5 + fn, C.byref(tested)) == 0 and tested.value >= 29999000, fn
+    # the array entry points the GPU test compares the device with
+    x = np.array([-745.2, -708.5, -1e-20, 0.3, 1.0, 709.7, 710.0, -800.0, np.inf, -np.inf, np.nan, 5e-324, 0.96, 1.04, 0.25, 3.7], np.float64)
+    for fn in (0, 1, 2):
+        got, want = np.empty_like(x), np.empty_like(x)
+        lib.libm_host_evald(fn, x.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+        lib.libm_host_refd(fn, x.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+        assert ((got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))).all(), fn
+
+
 def test_oracle_rcpps_is_the_intel_instruction():
     """oracle/oracle.c: intel_rcpps -- the rule behind Embree's rcp() in its triangle test (simd/vfloat4_sse2.h:166-173: RCPPS + one Newton step),
     restated in integer arithmetic because the instruction's result is the vendor's, not IEEE's -- against the instruction itself on a host that

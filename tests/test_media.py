@@ -83,6 +83,40 @@ def test_gpu_scattering_between_bounds(tmp_path):
     _single_scatter_is_darker_and_not_black(_gpu_image, tmp_path, (320, 180), 64)
 
 
+def _atmosphere_optical_depth(render, tmp_path, res):
+    """media/AtmosphericMedium.cpp, absorption only (no random numbers drawn, :137-142): seen through a Gaussian ball of haze, density
+    exp(-s^2 (|p - c|^2 - r^2)) with s = falloff_scale / radius, the panel's radiance is exp(-sigma_a * integral of the density along the ray) --
+    the integral the medium evaluates in closed form through Abramowitz & Stegun's erfc (math/Erf.hpp:247-283; absolute error 1.5e-7) against
+    scipy's quadrature of the density along the view axis."""
+    from scipy import integrate
+    centre, radius, falloff = np.array([0.0, 1.0, 3.0]), 1.5, 1.2
+
+    def ball(scene):
+        _panel(SIGMA)(scene)
+        scene["media"][0].update(type="atmosphere", center=[float(v) for v in centre], radius=radius, falloff_scale=falloff)
+    clear = render(scenes.cornell(tmp_path, name="clear.json", resolution=res, spp=1, edit=_panel(None)), 1)
+    hazy = render(scenes.cornell(tmp_path, name="ball.json", resolution=res, spp=1, edit=ball), 1)
+    depth = -np.log(hazy/clear)/np.array(SIGMA)[None, None]
+    assert np.allclose(depth[..., 0], depth[..., 1], rtol=5e-4) and np.allclose(depth[..., 0], depth[..., 2], rtol=5e-4)   # one integral, three coefficients
+    s = falloff/radius
+    eye = np.array([0.0, 1.0, 6.8])                        # the Cornell camera looks down -z at the panel's plane z = 0
+    want, _ = integrate.quad(lambda t: np.exp(-s*s*(((eye + t*np.array([0.0, 0.0, -1.0]) - centre)**2).sum() - radius*radius)), 0.0, 6.8)
+    h, w = depth.shape[:2]
+    got = depth[h//2 - 1:h//2 + 1, w//2 - 1:w//2 + 1, 0].mean()
+    assert abs(got - want) < 5e-3*want, (got, want)
+    # off the axis the ray passes the centre at a distance: the depth falls off like the Gaussian it is
+    assert depth[h//2, 0, 0] < 0.8*got and depth[0, w//2, 0] < got
+
+
+def test_oracle_atmosphere_optical_depth(tmp_path):
+    _atmosphere_optical_depth(_oracle_image, tmp_path, (48, 27))
+
+
+@pytest.mark.gpu
+def test_gpu_atmosphere_optical_depth_full_size(tmp_path):
+    _atmosphere_optical_depth(_gpu_image, tmp_path, (1280, 720))
+
+
 def test_unsupported_media_are_rejected(tmp_path):
     def voxel(scene):
         scene["media"] = [{"name": "v", "type": "voxel", "sigma_a": 1, "sigma_s": 1}]

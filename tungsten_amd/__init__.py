@@ -141,9 +141,10 @@ class Renderer(object):
 
     def debug_libm(self, fn, x, device=0):
         """The device's restatement of a host libm function (capi.TGHIP_LIBM_*) evaluated on the device: float32 in, float32 out."""
-        x = np.ascontiguousarray(x, np.float32).reshape(-1)
+        dbl = int(fn) >= capi.TGHIP_LIBM_EXPD                                 # the double-precision functions: float64 in, float64 out
+        x = np.ascontiguousarray(x, np.float64 if dbl else np.float32).reshape(-1)
         two = int(fn) in (capi.TGHIP_LIBM_ATAN2F, capi.TGHIP_LIBM_POWF)      # operands interleaved: x[2i], x[2i+1]
-        y = np.empty(x.size//2 if two else x.size, np.float32)
+        y = np.empty(x.size//2 if two else x.size, x.dtype)
         rc = lib.tghip_debug_libm(self.context(device), int(fn), x.ctypes.data, y.ctypes.data, y.size)
         if rc != 0:
             raise TungstenError(lib.tghip_last_error(self.context(device)).decode())

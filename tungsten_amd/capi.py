@@ -103,7 +103,8 @@ class TgHipSceneDesc(C.Structure):
 
 TGHIP_PASS_SOBOL, TGHIP_PASS_RECORDS, TGHIP_PASS_AUX, TGHIP_PASS_SAMPLES = 1, 2, 4, 8
 (TGHIP_LIBM_SINF, TGHIP_LIBM_COSF, TGHIP_LIBM_LOGF, TGHIP_LIBM_EXPF, TGHIP_LIBM_SINCOS_SIN, TGHIP_LIBM_SINCOS_COS,
- TGHIP_LIBM_ACOSF, TGHIP_LIBM_ATAN2F, TGHIP_LIBM_POWF, TGHIP_LIBM_CBRTF, TGHIP_LIBM_EMBREE_RCP, TGHIP_LIBM_RCPPS, TGHIP_LIBM_TANF) = range(13)
+ TGHIP_LIBM_ACOSF, TGHIP_LIBM_ATAN2F, TGHIP_LIBM_POWF, TGHIP_LIBM_CBRTF, TGHIP_LIBM_EMBREE_RCP, TGHIP_LIBM_RCPPS, TGHIP_LIBM_TANF,
+ TGHIP_LIBM_EXPD, TGHIP_LIBM_LOGD, TGHIP_LIBM_ERFD, TGHIP_LIBM_SQRTD) = range(17)
 
 
 class TgHipAuxPixel(C.Structure):

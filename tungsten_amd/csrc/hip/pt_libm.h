@@ -370,6 +370,196 @@ PT_LIBM_FN float tanfCore(float x)
     return kernelTanf(head, tail, 1 - ((n & 1) << 1));
 }
 
+// ---- double precision (round 6): exp, log, erf as glibc 2.35 computes them on an x86-64 host with FMA3 -----------------------------------
+// media/AtmosphericMedium.cpp:113-122 inverts its optical depth in double: std::erf, std::exp, and -- inside Erf::erfInv -- std::log and std::sqrt.
+// exp and log are the "optimized routines" algorithms (e_exp.c, e_log.c; N = 128 tables) in their __ieee754_exp_fma / __ieee754_log_fma builds:
+// which operations those fuse was read off the disassembly of libm-2.35.a's e_exp-fma.o / e_log-fma.o (every a*b + c of the source is one fma;
+// exp's subnormal branch keeps scale*tmp as a product because it is used twice).  erf is fdlibm's s_erf.c in glibc's regrouped evaluation
+// (built without FMA: no variant of it exists), calling that exp.  Tables and coefficients: pt_libm_dtables.h, read out of the image's libm by
+// tools/gen_libm_double_tables.py.  Matched against the host libm on 10^9 arguments per function (oracle/libm_host.cpp: libm_host_sweepd;
+// tests/test_host.py), on the device by tests/test_gpu_libm.py.  sqrt is the hardware's / the compiler's correctly rounded one on both sides.
+#include "pt_libm_dtables.h"
+
+PT_LIBM_FN double expDSpecial(double tmp, uint64_t sbits, uint64_t ki)   // e_exp.c: specialcase (the result over- or underflows the scale's exponent)
+{
+    if ((ki & 0x80000000ull) == 0) {                                     // k > 0
+        sbits -= 1009ull << 52;
+        const double scale = u2d(sbits);
+        return 0x1p1009*__builtin_fma(scale, tmp, scale);
+    }
+    sbits += 1022ull << 52;                                              // k < 0: care in the subnormal range
+    const double scale = u2d(sbits);
+    const double st = scale*tmp;
+    double y = scale + st;
+    if (y < 1.0) {
+        double lo = (scale - y) + st;
+        const double hi = 1.0 + y;
+        lo = ((1.0 - hi) + y) + lo;
+        y = (hi + lo) - 1.0;
+        if (y == 0.0) y = 0.0;
+    }
+    return 0x1p-1022*y;
+}
+PT_LIBM_FN double expD(double x)
+{
+    const uint64_t ix = d2u(x);
+    uint32_t abstop = (uint32_t)(ix >> 52) & 0x7ffu;
+    if (abstop - 0x3c9u >= 0x3fu) {                                      // |x| < 2^-54 or >= 512, inf, NaN
+        if (abstop - 0x3c9u >= 0x80000000u)
+            return 1.0 + x;
+        if (abstop >= 0x409u) {                                          // |x| >= 1024
+            if (ix == 0xfff0000000000000ull) return 0.0;
+            if (abstop >= 0x7ffu) return 1.0 + x;
+            return (ix >> 63) ? 0.0 : u2d(0x7ff0000000000000ull);        // __math_uflow / __math_oflow
+        }
+        abstop = 0;                                                      // large |x|: through expDSpecial
+    }
+    const double Shift = g_expD[1];
+    double kd = __builtin_fma(g_expD[0], x, Shift);
+    const uint64_t ki = d2u(kd);
+    kd -= Shift;
+    double r = __builtin_fma(kd, g_expD[2], x);
+    r = __builtin_fma(kd, g_expD[3], r);
+    const uint64_t idx = 2u*(ki & 127u);
+    const uint64_t top = ki << 45;
+    const double tail = u2d(g_expDTab[idx]);
+    const uint64_t sbits = g_expDTab[idx + 1] + top;
+    const double r2 = r*r;
+    const double p23 = __builtin_fma(r, g_expD[5], g_expD[4]);
+    const double p45 = __builtin_fma(r, g_expD[7], g_expD[6]);
+    double tmp = __builtin_fma(p23, r2, tail + r);
+    tmp = __builtin_fma(r2*r2, p45, tmp);
+    if (abstop == 0)
+        return expDSpecial(tmp, sbits, ki);
+    const double scale = u2d(sbits);
+    return __builtin_fma(scale, tmp, scale);
+}
+PT_LIBM_FN double logD(double x)
+{
+    uint64_t ix = d2u(x);
+    const uint32_t top = (uint32_t)(ix >> 48);
+    const double *A = g_logD + 2, *B = g_logD + 7;
+    if (ix - 0x3fee000000000000ull < 0x3090000000000ull) {               // 1 - 2^-4 <= x < 1 + 0x1.09p-4
+        if (ix == 0x3ff0000000000000ull)
+            return 0.0;
+        const double r = x - 1.0;
+        const double r2 = r*r, r3 = r*r2;
+        double a = __builtin_fma(r, B[2], B[1]), b = __builtin_fma(r, B[5], B[4]), c = __builtin_fma(r, B[8], B[7]);
+        a = __builtin_fma(r2, B[3], a);
+        b = __builtin_fma(r2, B[6], b);
+        c = __builtin_fma(r2, B[9], c);
+        c = __builtin_fma(r3, B[10], c);
+        double P = __builtin_fma(c, r3, b);
+        P = __builtin_fma(P, r3, a);
+        const double w1 = __builtin_fma(r, 0x1p27, r);
+        const double rhi = __builtin_fma(-0x1p27, r, w1);
+        const double rlo = r - rhi;
+        const double rhi2 = rhi*rhi;
+        const double hi = __builtin_fma(rhi2, B[0], r);
+        double lo = __builtin_fma(rhi2, B[0], r - hi);
+        lo = __builtin_fma(B[0]*rlo, rhi + r, lo);
+        const double y = __builtin_fma(P, r3, lo);
+        return hi + y;
+    }
+    if (top - 0x10u >= 0x7ff0u - 0x10u) {                                // zero, subnormal, negative, inf, NaN
+        if (ix*2 == 0)
+            return -u2d(0x7ff0000000000000ull);
+        if (ix == 0x7ff0000000000000ull)
+            return x;
+        if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u)
+            return u2d(0x7ff8000000000000ull)*((x != x) ? 1.0 : -1.0);   // __math_invalid: a NaN (its sign is not looked at by any caller)
+        ix = d2u(x*0x1p52);
+        ix -= 52ull << 52;
+    }
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+    const int32_t k = (int32_t)((int64_t)tmp >> 52);
+    const uint64_t iz = ix - (tmp & (0xfffull << 52));
+    const double invc = g_logDTab[i][0], logc = g_logDTab[i][1];
+    const double z = u2d(iz);
+    const double r = __builtin_fma(z, invc, -1.0);
+    const double kd = (double)k;
+    const double w = __builtin_fma(kd, g_logD[0], logc);
+    const double hi = w + r;
+    const double lo = __builtin_fma(kd, g_logD[1], (w - hi) + r);
+    const double r2 = r*r, r3 = r*r2;
+    const double p12 = __builtin_fma(r, A[2], A[1]), p34 = __builtin_fma(r, A[4], A[3]);
+    const double t = __builtin_fma(r2, A[0], lo);
+    const double q = __builtin_fma(p34, r2, p12);
+    return __builtin_fma(r3, q, t) + hi;
+}
+PT_LIBM_FN double erfD(double x)                                         // s_erf.c: __erf
+{
+    const int32_t hx = (int32_t)(d2u(x) >> 32);
+    const int32_t ix = hx & 0x7fffffff;
+    const double *pp = g_erfD_pp, *qq = g_erfD_qq, *pa = g_erfD_pa, *qa = g_erfD_qa, *ra = g_erfD_ra, *sa = g_erfD_sa, *rb = g_erfD_rb, *sb = g_erfD_sb;
+    if (ix >= 0x7ff00000) {                                              // erf(nan) = nan, erf(+-inf) = +-1
+        const int32_t i = (int32_t)((uint32_t)hx >> 31) << 1;
+        return (double)(1 - i) + 1.0/x;
+    }
+    if (ix < 0x3feb0000) {                                               // |x| < 0.84375
+        if (ix < 0x3e300000) {                                           // |x| < 2^-28
+            if (ix < 0x00800000)
+                return 0.0625*(16.0*x + (16.0*g_erfD_efx)*x);
+            return x + g_erfD_efx*x;
+        }
+        const double z = x*x;
+        const double r1 = pp[0] + z*pp[1], z2 = z*z;
+        const double r2 = pp[2] + z*pp[3], z4 = z2*z2;
+        const double s1 = 1.0 + z*qq[1];
+        const double s2 = qq[2] + z*qq[3];
+        const double s3 = qq[4] + z*qq[5];
+        const double r = r1 + z2*r2 + z4*pp[4];
+        const double s = s1 + z2*s2 + z4*s3;
+        const double y = r/s;
+        return x + x*y;
+    }
+    if (ix < 0x3ff40000) {                                               // 0.84375 <= |x| < 1.25
+        const double s = __builtin_fabs(x) - 1.0;
+        const double P1 = pa[0] + s*pa[1], s2 = s*s;
+        const double Q1 = 1.0 + s*qa[1], s4 = s2*s2;
+        const double P2 = pa[2] + s*pa[3], s6 = s4*s2;
+        const double Q2 = qa[2] + s*qa[3];
+        const double P3 = pa[4] + s*pa[5];
+        const double Q3 = qa[4] + s*qa[5];
+        const double P4 = pa[6];
+        const double Q4 = qa[6];
+        const double P = P1 + s2*P2 + s4*P3 + s6*P4;
+        const double Q = Q1 + s2*Q2 + s4*Q3 + s6*Q4;
+        return hx >= 0 ? g_erfD_erx + P/Q : -g_erfD_erx - P/Q;
+    }
+    if (ix >= 0x40180000)                                                // |x| >= 6
+        return hx >= 0 ? 1.0 - 1e-300 : 1e-300 - 1.0;
+    const double ax = __builtin_fabs(x);
+    const double s = 1.0/(ax*ax);
+    double R, S;
+    if (ix < 0x4006DB6E) {                                               // |x| < 1/0.35
+        const double R1 = ra[0] + s*ra[1], s2 = s*s;
+        const double S1 = 1.0 + s*sa[1], s4 = s2*s2;
+        const double R2 = ra[2] + s*ra[3], s6 = s4*s2;
+        const double S2 = sa[2] + s*sa[3], s8 = s4*s4;
+        const double R3 = ra[4] + s*ra[5];
+        const double S3 = sa[4] + s*sa[5];
+        const double R4 = ra[6] + s*ra[7];
+        const double S4 = sa[6] + s*sa[7];
+        R = R1 + s2*R2 + s4*R3 + s6*R4;
+        S = S1 + s2*S2 + s4*S3 + s6*S4 + s8*sa[8];
+    } else {
+        const double R1 = rb[0] + s*rb[1], s2 = s*s;
+        const double S1 = 1.0 + s*sb[1], s4 = s2*s2;
+        const double R2 = rb[2] + s*rb[3], s6 = s4*s2;
+        const double S2 = sb[2] + s*sb[3];
+        const double R3 = rb[4] + s*rb[5];
+        const double S3 = sb[4] + s*sb[5];
+        const double S4 = sb[6] + s*sb[7];
+        R = R1 + s2*R2 + s4*R3 + s6*rb[6];
+        S = S1 + s2*S2 + s4*S3 + s6*S4;
+    }
+    const double z = u2d(d2u(ax) & 0xffffffff00000000ull);
+    const double r = expD(-z*z - 0.5625)*expD((z - ax)*(z + ax) + R/S);
+    return hx >= 0 ? 1.0 - r/ax : r/ax - 1.0;
+}
+
 }  // namespace ptlibm
 
 #endif

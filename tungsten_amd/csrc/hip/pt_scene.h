@@ -2603,10 +2603,9 @@ PT_DEV float expMediumInverseOpticalDepth(float x, float dx, float tau)
 /* AtmosphericMedium (media/AtmosphericMedium.cpp): density exp(-s^2 (|p - center|^2 - radius^2)) with s = falloff_scale / radius -- in TgHipMedium:
  * falloff_scale = s (_effectiveFalloffScale), unit_point = _center, falloff_dir[0] = _radius.  The optical depth along a ray is a difference of error
  * functions: densityIntegral (:104-111) in float through Abramowitz & Stegun's 7.1.26 as math/Erf.hpp:247-283 writes it (std::exp on floats =
- * glibc's expf); inverseOpticalDepth (:113-122) in DOUBLE -- std::erf, std::exp and Boost's erf_inv (pt_libm.h: erfInvD).  The device's double erf /
- * exp / log are ocml's: they agree with glibc's to the last place or one off, and the result is rounded to float, so a scattering distance
- * differs from the reference's in about one sample in 10^6 (DESIGN.md section 6 states the measured count on the goldens). */
-/* (real calls, not inlined: the atmosphere's double-precision code would otherwise be copied into every call site of the media kernels -- 100 k instructions) */
+ * glibc's expf); inverseOpticalDepth (:113-122) in DOUBLE -- std::erf, std::exp, and Boost's erf_inv over std::log and std::sqrt: glibc's double erf /
+ * exp / log restated (pt_libm.h: erfD, expD, logD -- matched against the host libm on 10^9 arguments each), the correctly rounded square root. */
+/* (real calls, not inlined: the atmosphere's double-precision code would otherwise be copied into every call site of the media kernels) */
 #define PT_DEV_CALL __device__ __attribute__((noinline))
 #define PT_SQRT_PI     1.77245385091f           /* math/Angle.hpp:15-16 */
 #define PT_INV_SQRT_PI (1.0f/PT_SQRT_PI)
@@ -2662,6 +2661,7 @@ PT_DEV double polyEvalD(double x, const double *P)             /* Polynomial::ev
     }
     return result;
 }
+PT_DEV double sqrtD(double x) { return __dsqrt_rn(x); }        /* std::sqrt on a double: IEEE, round to nearest */
 PT_DEV double erfInvD(double z)                                 /* Erf::erfInv (math/Erf.hpp:192-245); tables: pt_erfinv_table.h */
 {
     double p, q, sgn;
@@ -2673,12 +2673,12 @@ PT_DEV double erfInvD(double z)                                 /* Erf::erfInv (
         double r = polyEvalD<8>(p, g_erfInvP1)/polyEvalD<10>(p, g_erfInvQ1);
         result = g*g_erfInvY[0] + g*r;
     } else if (q >= 0.25) {
-        double g = ::sqrt(-2.0*::log(q));
+        double g = sqrtD(-2.0*ptlibm::logD(q));
         double xs = q - 0.25;
         double r = polyEvalD<9>(xs, g_erfInvP2)/polyEvalD<9>(xs, g_erfInvQ2);
         result = g/(g_erfInvY[1] + r);
     } else {
-        double x = ::sqrt(-::log(q));
+        double x = sqrtD(-ptlibm::logD(q));
         if (x < 3.0) {
             double xs = x - 1.125;
             double R = polyEvalD<11>(xs, g_erfInvP3)/polyEvalD<8>(xs, g_erfInvQ3);
@@ -2706,7 +2706,7 @@ PT_DEV double erfInvD(double z)                                 /* Erf::erfInv (
 PT_DEV_CALL float atmInverseOpticalDepth(float sF, float radiusF, double h, double t0, double tau)   /* AtmosphericMedium::inverseOpticalDepth (:113-122) */
 {
     const double s = sF, radius = radiusF;
-    const double inner = ::erf(s*t0) + 2.0*double(PT_INV_SQRT_PI)*::exp(s*s*(h - radius)*(h + radius))*s*tau;
+    const double inner = ptlibm::erfD(s*t0) + 2.0*double(PT_INV_SQRT_PI)*ptlibm::expD(s*s*(h - radius)*(h + radius))*s*tau;
     if (inner >= 1.0)
         return PT_INF;
     return float(erfInvD(inner)/s);

@@ -2480,22 +2480,33 @@ __global__ void k_debug_libm(int fn, const float *x, float *y, uint32_t n)
     y[i] = r;
 }
 
+// ... and the double-precision ones of the atmospheric medium (pt_libm.h: expD / logD / erfD; pt_scene.h: sqrtD)
+__global__ void k_debug_libmd(int fn, const double *x, double *y, uint32_t n)
+{
+    const uint32_t i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    y[i] = fn == TGHIP_LIBM_EXPD ? ptlibm::expD(v) : fn == TGHIP_LIBM_LOGD ? ptlibm::logD(v) : fn == TGHIP_LIBM_ERFD ? ptlibm::erfD(v) : sqrtD(v);
+}
+
 int tghip_debug_libm(tghip_ctx *ctx, int fn, const float *x, float *y, size_t n)
 {
     if (!ctx) return TGHIP_E_INVALID;
     if (n == 0) return TGHIP_OK;
-    if (!x || !y || n > 0x3FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_TANF) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
+    if (!x || !y || n > 0x3FFFFFFFu || fn < TGHIP_LIBM_SINF || fn > TGHIP_LIBM_SQRTD) { ctx->error = "invalid libm self-test arguments"; return TGHIP_E_INVALID; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     float *dx = nullptr, *dy = nullptr;
-    const size_t nx = (fn == TGHIP_LIBM_ATAN2F || fn == TGHIP_LIBM_POWF) ? 2*n : n;
+    const bool dbl = fn >= TGHIP_LIBM_EXPD;                       // n doubles in, n doubles out
+    const size_t nx = (fn == TGHIP_LIBM_ATAN2F || fn == TGHIP_LIBM_POWF || dbl) ? 2*n : n, ny = dbl ? 2*n : n;
     HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&dx), nx*sizeof(float)));
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dy), n*sizeof(float));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dy), ny*sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(dx, x, nx*sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_libm, dim3(uint32_t((n + 255)/256)), dim3(256), 0, ctx->stream, fn, dx, dy, uint32_t(n));
+        if (dbl) hipLaunchKernelGGL(k_debug_libmd, dim3(uint32_t((n + 255)/256)), dim3(256), 0, ctx->stream, fn, reinterpret_cast<const double *>(dx), reinterpret_cast<double *>(dy), uint32_t(n));
+        else     hipLaunchKernelGGL(k_debug_libm, dim3(uint32_t((n + 255)/256)), dim3(256), 0, ctx->stream, fn, dx, dy, uint32_t(n));
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(y, dy, n*sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(y, dy, ny*sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(dx);
     if (dy) (void)hipFree(dy);
