@@ -98,19 +98,37 @@ static float errorEstimate(const TgHostSampleRecord &r)
 
 float PassScheduler::errorPercentile95()
 {
-    std::vector<float> errors;
-    errors.reserve(_samples.size());
+    // The element std::sort would leave at position (n*95)/100 of the positive error estimates (PathTraceIntegrator.cpp:44-59).  Positive floats order
+    // like their bit patterns, so the element is found by counting: a histogram over the high 16 bits locates the bin that holds it, the bin's few
+    // members are then selected among -- the same value std::nth_element finds, in a third of its time (this runs between two passes, with the
+    // device idle: profiles/r5_as_shipped_timeline.txt).
+    std::vector<uint32_t> &bits = _errorBits, &bins = _errorBins;
+    bits.clear();
+    bits.reserve(_samples.size());
+    bins.assign(1u << 16, 0u);
     for (TgHostSampleRecord &r : _samples) {
         r.adaptive_weight = errorEstimate(r);
-        if (r.adaptive_weight > 0.0f)
-            errors.push_back(r.adaptive_weight);
+        if (r.adaptive_weight > 0.0f) {                  // (NaN estimates fail the comparison, as in the reference)
+            uint32_t b;
+            std::memcpy(&b, &r.adaptive_weight, sizeof(b));
+            bits.push_back(b);
+            bins[b >> 16]++;
+        }
     }
-    if (errors.empty())
+    if (bits.empty())
         return 0.0f;
-    // the element std::sort would leave at this position (PathTraceIntegrator.cpp:57-59), without ordering the rest
-    const size_t k = (errors.size()*95)/100;
-    std::nth_element(errors.begin(), errors.begin() + std::ptrdiff_t(k), errors.end());
-    return errors[k];
+    size_t k = (bits.size()*95)/100;
+    uint32_t bin = 0;
+    while (k >= bins[bin])
+        k -= bins[bin++];
+    size_t n = 0;                                        // the bin's members, compacted to the front of the list itself
+    for (uint32_t b : bits)
+        if ((b >> 16) == bin)
+            bits[n++] = b;
+    std::nth_element(bits.begin(), bits.begin() + std::ptrdiff_t(k), bits.begin() + std::ptrdiff_t(n));
+    float result;
+    std::memcpy(&result, &bits[k], sizeof(result));
+    return result;
 }
 
 static inline float maxOf(float a, float b) { return a > b ? a : b; }   // MathUtil.hpp:23-26
@@ -142,15 +160,15 @@ void PassScheduler::distributeAdaptiveSamples(int spp)
     int budgetPerTile = adaptiveBudget/int(VarianceTileSize*VarianceTileSize);
     float weightToSampleFactor = float(double(budgetPerTile)/totalWeight);
 
+    // (PathTraceIntegrator.cpp:121-132.  The comparison's outcome is a coin toss, so it is taken without a branch: x - 0.0f is x.)
     float pixelPdf = 0.0f;
     for (TgHostSampleRecord &r : _samples) {
         float fractionalSamples = r.adaptive_weight*weightToSampleFactor;
         int adaptiveSamples = int(fractionalSamples);
         pixelPdf += fractionalSamples - float(adaptiveSamples);
-        if (_sampler.next1D() < pixelPdf) {
-            adaptiveSamples++;
-            pixelPdf -= 1.0f;
-        }
+        const bool extra = _sampler.next1D() < pixelPdf;
+        adaptiveSamples += extra ? 1 : 0;
+        pixelPdf -= extra ? 1.0f : 0.0f;
         r.next_sample_count = uint32_t(adaptiveSamples + 1);
     }
 }

@@ -50,6 +50,7 @@ class PassScheduler
     std::vector<TgHostSampleRecord> _samples;
 
     float errorPercentile95();
+    std::vector<uint32_t> _errorBits, _errorBins;   // scratch of errorPercentile95 (kept between passes: the host's turn is on the render's critical path)
     void dilateAdaptiveWeights();
     void distributeAdaptiveSamples(int spp);
 
