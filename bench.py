@@ -391,7 +391,9 @@ class Bench(object):
         check(lib.tghip_set_option(ctx, b"time_kernels", 0 if a.no_kernel_timing else 1), "tghip_set_option")
         self.fence()
         split[0] = split[1] = 0.0
-        poller = ClockPoller().start() if (self.world == 1 and a.clock and shutil.which("rocm-smi")) else None
+        # (never in the counter passes' child runs -- they pass --no-clock: a rocm-smi process started under rocprofv3's preloaded tool library takes the run down)
+        poller = ClockPoller().start() if (self.world == 1 and a.clock and a.steps > 0 and shutil.which("rocm-smi") and "ROCPROFILER" not in " ".join(os.environ)
+                                           and "rocprof" not in os.environ.get("LD_PRELOAD", "")) else None
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
@@ -693,6 +695,12 @@ class Bench(object):
                         ex.update({"kernel": dom_trav, "achieved": ex["per_kernel"][dom_trav]["achieved"], "frac": ex["per_kernel"][dom_trav]["frac"],
                                    "avg_launch_us": ex["per_kernel"][dom_trav]["avg_launch_us"]})
                     roofline["exclusive"] = ex
+            if sustained_clock and isinstance(roofline.get("valu"), dict) and roofline["valu"].get("frac"):
+                # the VALU ceiling at the clock the chip actually ran at during the timed region (the line's `peak` is priced at the maximum clock)
+                roofline["valu"]["frac_at_sustained_clock"] = round(roofline["valu"]["frac"]/sustained_clock["frac_of_max_clock"], 4)
+                st = (roofline["valu"].get("priced") or {}).get("static_mix") or {}
+                if st.get("frac_of_simd_time_at_max_clock"):
+                    st["frac_of_simd_time_at_sustained_clock"] = round(st["frac_of_simd_time_at_max_clock"]/sustained_clock["frac_of_max_clock"], 4)
             rays = max(cc["closest_rays"] + cc["shadow_rays"], 1)
             out = {
                 "value": round(value, 2), "ms_per_step": round(elapsed/steps*1e3, 3),
@@ -785,7 +793,7 @@ def measure_traffic(a, scene, w, h, spp, tmp):
         out = os.path.join(tmp, "pmc_" + counter)
         cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
                "--scene", scene, "--material", a.material, "--res", "%dx%d" % (w, h), "--spp", str(pmc_spp), "--steps", "1", "--warmup", "0",
-               "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"] + [x for kv in a.opt for x in ("--opt", kv)]
+               "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic", "--no-clock"] + [x for kv in a.opt for x in ("--opt", kv)]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
             p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp", env=env, timeout=300)
@@ -824,7 +832,7 @@ def measure_counter_all(a, scene, w, h, spp, tmp, counter):
     out = os.path.join(tmp, "pmc_all_" + counter)
     cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
            "--scene", scene, "--material", a.material, "--res", "%dx%d" % (w, h), "--spp", str(spp), "--steps", "1", "--warmup", "0",
-           "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"] + [x for kv in a.opt for x in ("--opt", kv)]
+           "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic", "--no-clock"] + [x for kv in a.opt for x in ("--opt", kv)]
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp",
                            env=dict(os.environ, TMPDIR="/tmp"), timeout=300)
@@ -858,7 +866,7 @@ def measure_counters_all(a, scene, w, h, spp, tmp, counters, tag):
     out = os.path.join(tmp, "pmc_multi_" + tag)
     cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
            "--scene", scene, "--material", a.material, "--res", "%dx%d" % (w, h), "--spp", str(spp), "--steps", "1", "--warmup", "0",
-           "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"] + [x for kv in a.opt for x in ("--opt", kv)]
+           "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic", "--no-clock"] + [x for kv in a.opt for x in ("--opt", kv)]
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp",
                            env=dict(os.environ, TMPDIR="/tmp"), timeout=300)
@@ -891,7 +899,7 @@ def measure_counter(a, scene, w, h, spp, kernel, tmp, counter):
     out = os.path.join(tmp, "pmc_" + counter)
     cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
            "--scene", scene, "--material", a.material, "--res", "%dx%d" % (w, h), "--spp", str(spp), "--steps", "1", "--warmup", "0",
-           "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic"]
+           "--no-cpu-baseline", "--no-extra", "--no-kernel-timing", "--no-traffic", "--no-clock"]
     try:
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, cwd="/tmp",
                            env=dict(os.environ, TMPDIR="/tmp"), timeout=300)
