@@ -3776,6 +3776,15 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
     Ray ray;
     ray.o = lensP;
     ray.d = mat3_mul(cam->xf, localD);
+    if (cam->type == TGHIP_CAMERA_EQUIRECTANGULAR) {
+        /* EquirectangularCamera::sampleDirection / uvToDirection (cameras/EquirectangularCamera.cpp:26-36, 70-83): inv_xf holds _rot and 1 / res_y */
+        float u = ((float)px + 0.5f + fu)*cam->pixel_size_x, v = ((float)py + 0.5f + fv)*cam->inv_xf[9];
+        float phi = (u - 0.5f)*O_TWO_PI, theta = (1.0f - v)*O_PI;
+        float sinTheta = sinf(theta);
+        v3 l = V(cosf(phi)*sinTheta, -cosf(theta), sinf(phi)*sinTheta);
+        const float *m = cam->inv_xf;
+        ray.d = V(m[0]*l.x + m[1]*l.y + m[2]*l.z + 0.0f, m[3]*l.x + m[4]*l.y + m[5]*l.z + 0.0f, m[6]*l.x + m[7]*l.y + m[8]*l.z + 0.0f);
+    }
     ray.tmin = 1e-4f; ray.tmax = INFINITY;            /* Ray ctor defaults, math/Ray.hpp:24 */
 
     v3 throughput = vs(1.0f), emission = vs(0.0f);

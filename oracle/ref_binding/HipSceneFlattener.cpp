@@ -79,6 +79,7 @@
 #include "cameras/Camera.hpp"
 #include "cameras/PinholeCamera.hpp"
 #include "cameras/ThinlensCamera.hpp"
+#include "cameras/EquirectangularCamera.hpp"
 #include "textures/DiskTexture.hpp"
 #include "textures/BladeTexture.hpp"
 #include "cameras/ReconstructionFilter.hpp"
@@ -711,13 +712,14 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     // ---- camera (PinholeCamera.cpp:28-35, Camera.cpp:37-68, ReconstructionFilter.cpp:34-58) ----
     const PinholeCamera *pin = dynamic_cast<const PinholeCamera *>(&scene._cam);
     const ThinlensCamera *lens = dynamic_cast<const ThinlensCamera *>(&scene._cam);
-    if (!pin && !lens)
-        refuse("a camera other than the pinhole and the thin-lens camera");
+    const EquirectangularCamera *equi = dynamic_cast<const EquirectangularCamera *>(&scene._cam);
+    if (!pin && !lens && !equi)
+        refuse("a camera other than the pinhole, the thin-lens and the equirectangular camera");
     const Camera *cam = &scene._cam;
     TgHipCamera &c = _desc.camera;
     std::memset(&c, 0, sizeof(c));
     copy3(c.pos, cam->_pos);
-    c.plane_dist = pin ? pin->_planeDist : lens->_planeDist;
+    c.plane_dist = pin ? pin->_planeDist : lens ? lens->_planeDist : 0.0f;
     copyRot(c.xf, cam->_transform);
     c.ratio = cam->_ratio;
     c.pixel_size_x = cam->_pixelSize.x();
@@ -729,7 +731,7 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     c.filter_bin_size = f._binSize;
     if (c.filter_type == TGHIP_FILTER_TABULATED)
         for (int i = 0; i < 32; ++i) c.filter_cdf[i] = f._cdf[i];
-    c.type = pin ? TGHIP_CAMERA_PINHOLE : TGHIP_CAMERA_THINLENS;
+    c.type = pin ? TGHIP_CAMERA_PINHOLE : lens ? TGHIP_CAMERA_THINLENS : TGHIP_CAMERA_EQUIRECTANGULAR;
     // (a pinhole camera's thin-lens fields keep the values the stand-alone host's Camera has for it)
     c.focus_dist = 1.0f; c.aperture_size = 0.001f; c.cat_eye = 0.0f;
     c.aperture_type = TGHIP_APERTURE_DISK;
@@ -765,6 +767,11 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     }
     for (int r = 0; r < 3; ++r)
         for (int k = 0; k < 4; ++k) c.inv_xf[r*4 + k] = cam->_invTransform[r*4 + k];
+    if (equi) {                                        // EquirectangularCamera::prepareForRender has run (TraceableScene's constructor): _rot; Camera::_pixelSize.y
+        for (int k = 0; k < 12; ++k) c.inv_xf[k] = 0.0f;
+        copyRot(c.inv_xf, equi->_rot);
+        c.inv_xf[9] = cam->_pixelSize.y();
+    }
     c.medium = addMedium(cam->_medium.get());
 
     _desc.settings.min_bounces = settings.minBounces;

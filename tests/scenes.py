@@ -770,6 +770,23 @@ def _atmosphere_and_smoke(scene):
             m.update(type="atmosphere", falloff_scale=1.0, radius=0.3, center=[0.33, 0.3, 0.37])
 
 
+def _equirectangular(scene):
+    """cameras/EquirectangularCamera.cpp: the full sphere seen from a point inside the box (off its axes, rolled a little), longitude across the image."""
+    cam = scene["camera"]
+    cam["type"] = "equirectangular"
+    cam.pop("fov", None)
+    cam["transform"] = {"position": [0.15, 0.85, 0.3], "look_at": [-0.4, 0.6, -1.0], "up": [0.1, 1.0, 0.05]}
+
+
+def _mt_equirectangular(scene):
+    """The metric's scene through the equirectangular camera, from where its own camera stands: the BVH scenes' launches (k_camera_rays in front of the wide walk)."""
+    scene["camera"]["type"] = "equirectangular"
+    scene["camera"].pop("fov", None)
+
+
+GOLDEN_CASES["materialtest_equirectangular"] = (materialtest, dict(resolution=(64, 32), spp=4, edit=_mt_equirectangular))
+GOLDEN_CASES["cornell_equirectangular"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_equirectangular))
+GOLDEN_CASES["cornell_equirectangular_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_equirectangular, renderer={"stratified_sampler": True}))
 GOLDEN_CASES["cornell_atmosphere"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_atmosphere))
 GOLDEN_CASES["cornell_atmosphere_smoke_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_atmosphere_and_smoke, renderer={"stratified_sampler": True}))
 GOLDEN_CASES["cornell_expfog"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_expfog))

@@ -67,6 +67,44 @@ extern template __global__ void k_tail<(MASK_TAIL | FEAT_QMC), true>(DeviceScene
 extern template __global__ void k_tail<MASK_COAT, false>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<(MASK_COAT | FEAT_QMC), false>(DeviceScene, PathState, PassParams, uint32_t);
 
+// cameras/EquirectangularCamera.cpp (TGHIP_CAMERA_EQUIRECTANGULAR): the full sphere around the camera's position.  nextPath writes every fresh camera path
+// with the pinhole's ray; for this camera the direction is replaced here, in a launch in front of every closest-hit launch, for the slots of the
+// workgroup's Q_EXTP (the freshly generated camera rays) -- from the same two random numbers: the path's stream restarted at (seed, pixel, sample) or
+// at Sobol' dimension 0, as nextPath drew them (EquirectangularCamera::sampleDirection draws its filter offset exactly where the pinhole's does,
+// :70-83).  Keeps the camera's sine and cosine out of every kernel that holds nextPath -- the metric's closest-hit kernel among them.  Idempotent.
+__global__ __launch_bounds__(256) void k_camera_rays(DeviceScene s, PathState st, PassParams pp)
+{
+    const uint32_t W = st.slots_per_block >> 5;
+    const uint32_t first = blockIdx.x*st.slots_per_block;
+    CameraRef cam = *asConst(s.camera);
+    for (uint32_t local = threadIdx.x; local < st.slots_per_block; local += blockDim.x) {
+        const uint32_t word = st.bm[(uint32_t)Q_EXTP*st.bmStride + blockIdx.x*W + (local >> 5)];
+        if (!((word >> (local & 31u)) & 1u))
+            continue;
+        const uint32_t slot = first + local;
+        const uint4 misc = slotU4(st, A_MISC, slot), sm = slotU4(st, A_SAMP, slot);
+        const uint32_t pixel = misc.z, px = pixel % pp.width, py = pixel/pp.width;
+        Rng rng = rngStart(pp.seed, pixel, sm.x);
+        if (pp.flags & TGHIP_PASS_SOBOL)
+            rngStartSobol(rng, s, pp, px, py, pixel, sm.x, 0u);
+        const float xi0 = rngNext1DT<true>(rng), xi1 = rngNext1DT<true>(rng);
+        float fu = 0.0f, fv = 0.0f;
+        if (cam.filter_type == TGHIP_FILTER_BOX) { fu = xi0 - 0.5f; fv = xi1 - 0.5f; }
+        else if (cam.filter_type == TGHIP_FILTER_TABULATED) { fu = filterSample1D(cam, xi0); fv = filterSample1D(cam, xi1); }
+        // uvToDirection (:26-36); inv_xf holds _rot and 1 / res_y (include/tungsten_hip.h)
+        const float u = ((float)px + 0.5f + fu)*cam.pixel_size_x, v = ((float)py + 0.5f + fv)*cam.inv_xf[9];
+        const float phi = (u - 0.5f)*PT_TWO_PI, theta = (1.0f - v)*PT_PI;
+        const float sinTheta = sinfH(theta);
+        const f3 l = mk3(cosfH(phi)*sinTheta, -cosfH(theta), sinfH(phi)*sinTheta);
+        const f3 d = mk3(cam.inv_xf[0]*l.x + cam.inv_xf[1]*l.y + cam.inv_xf[2]*l.z + 0.0f,      // Mat4f*Vec3f: the (zero) translation column is added
+                         cam.inv_xf[3]*l.x + cam.inv_xf[4]*l.y + cam.inv_xf[5]*l.z + 0.0f,
+                         cam.inv_xf[6]*l.x + cam.inv_xf[7]*l.y + cam.inv_xf[8]*l.z + 0.0f);
+        const float4 rd = slotF4(st, A_RAY_D, slot);
+        slotF4(st, A_RAY_D, slot) = mk4(d, rd.w);
+    }
+}
+
+
 // =============================================================================================
 // Host-side shim
 // =============================================================================================
@@ -199,6 +237,7 @@ struct tghip_ctx {
     bool haveForward = false;             // some BSDF has a forward lobe (shadow rays attenuate instead of stop)
     bool haveMeshLight = false;           // a triangle mesh is a sampled light: closest-hit shadow walk, MASK_FULL shading
     bool thinlens = false;                // thin-lens camera: passes run the EXT kernel variants (PT_PASS_THINLENS)
+    bool cameraFix = false;               // equirectangular camera: k_camera_rays rewrites the fresh camera rays before they are traced
     bool haveSolids = false;              // cube / sphere / disk records: the dynamic-fetch kernels' SOLIDS variants
     TgHipAuxPixel *dAux = nullptr;        // auxiliary output buffers (allocated by the first TGHIP_PASS_AUX pass)
     float *dSamples = nullptr;            // TGHIP_PASS_SAMPLES: per-sample radiance of the last such pass
@@ -1205,8 +1244,11 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
         }
     }
     ctx->thinlens = sd->camera.type == TGHIP_CAMERA_THINLENS;
-    if (sd->camera.type != TGHIP_CAMERA_PINHOLE && sd->camera.type != TGHIP_CAMERA_THINLENS) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
-    if (ctx->thinlens && sd->camera.aperture_type == TGHIP_APERTURE_BITMAP) {
+    // the equirectangular camera's rays are written by a launch of their own in front of every closest-hit launch (k_camera_rays): the kernels that
+    // generate a camera ray and trace it in one go -- the folded finish, the flat lists' fused launches, k_tail -- are not used for such scenes
+    ctx->cameraFix = sd->camera.type == TGHIP_CAMERA_EQUIRECTANGULAR;
+    if (sd->camera.type < TGHIP_CAMERA_PINHOLE || sd->camera.type > TGHIP_CAMERA_EQUIRECTANGULAR) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
+    if (sd->camera.type == TGHIP_CAMERA_THINLENS && sd->camera.aperture_type == TGHIP_APERTURE_BITMAP) {
         // the aperture's Distribution2D: marginalPdf[h] marginalCdf[h + 1] pdf[w h] cdf[(w + 1) h] inside dist[]
         const uint64_t aw = uint64_t(std::max(sd->camera.aperture_w, 0)), ah = uint64_t(std::max(sd->camera.aperture_h, 0));
         if (aw == 0 || ah == 0 || !sd->dist || uint64_t(sd->camera.aperture_dist) + ah + ah + 1 + aw*ah + (aw + 1)*ah > sd->num_dist_floats) {
@@ -1222,7 +1264,7 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
             ctx->error = "the bitmap aperture's distribution is not a CDF (zero total weight or non-finite entries)";
             return TGHIP_E_INVALID;
         }
-    } else if (ctx->thinlens && sd->camera.aperture_type != TGHIP_APERTURE_DISK && sd->camera.aperture_type != TGHIP_APERTURE_BLADE) {
+    } else if (sd->camera.type == TGHIP_CAMERA_THINLENS && sd->camera.aperture_type != TGHIP_APERTURE_DISK && sd->camera.aperture_type != TGHIP_APERTURE_BLADE) {
         ctx->error = "unknown aperture type";
         return TGHIP_E_UNSUPPORTED;
     }
@@ -1580,7 +1622,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     const int grid = int(ctx->poolGrid);
     const bool count = ctx->countTraversal;
     const bool flat = isFlat(ctx);
-    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->auxPass && !ctx->haveCylinder && ctx->tablesFit;
+    const bool fused = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->auxPass && !ctx->haveCylinder && ctx->tablesFit && !ctx->cameraFix;
     const bool runToCompletion = fused && !ctx->haveComplex && ctx->loopOpt;   // one launch renders the whole batch
     const size_t ldsBytes = traceLdsBytes(ctx, ctx->thrClosest);
 
@@ -1646,7 +1688,7 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
     }
     // k_tail runs the wide single-level kernels' bodies: scenes those kernels render, passes without visit counts (per-launch timing does
     // not see it: the few thousand rays it traces are in the counters, its one launch is in none of the three kernel classes)
-    const bool tailEligible = ctx->tailOpt && ctx->tablesFit && !flat && !ctx->haveInstances && wideClosest(ctx) && wideShadowRays(ctx) && ctx->decoupleOpt && !ctx->haveForward &&
+    const bool tailEligible = ctx->tailOpt && !ctx->cameraFix && ctx->tablesFit && !flat && !ctx->haveInstances && wideClosest(ctx) && wideShadowRays(ctx) && ctx->decoupleOpt && !ctx->haveForward &&
                               (ctx->complexMask & TYPES_LATE) == 0 &&
                               !ctx->haveMeshLight && !ctx->haveMedia && !ctx->auxPass && !ctx->haveCylinder && !count && !st.records &&
                               st.slots_per_block <= PT_MAX_SLOTS_PER_BLOCK;
@@ -1662,13 +1704,15 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
         tailFits = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, wideLdsBytes(ctx, 256)) == hipSuccess && nb >= 1;
     }
     // "fold_finish": k_finish rides in front of the next iteration's closest-hit launch (single-level scenes on the decoupled wide walk)
-    const bool foldFinish = ctx->foldFinishOpt && !flat && !ctx->haveInstances && wideClosest(ctx) && ctx->decoupleOpt;
+    const bool foldFinish = ctx->foldFinishOpt && !ctx->cameraFix && !flat && !ctx->haveInstances && wideClosest(ctx) && ctx->decoupleOpt;
     uint32_t iterTag = 1;                        // k_start publishes tag 1 when it queued anything
     bool first = true;
     int roundIters = checkInterval;              // launches of the wavefront loop between two host checks
         // the launches of one wavefront iteration over the workgroups [0, grid) of `st` (the whole pool, or one part of it)
         auto launchIteration = [&](const PathState &st, const PassParams &pp, int grid, uint32_t iterTag, bool timed, int part) {
             auto tic = [&]() { if (timed) ticMain(); };
+            if (ctx->cameraFix)                  // (the fresh camera rays of the previous iteration's finish / of k_start, before they are traced)
+                hipLaunchKernelGGL(k_camera_rays, dim3(grid), dim3(256), 0, ctx->launchStream, s, st, pp);
             tic();
             if (flat) {
                 if (count) hipLaunchKernelGGL((k_trace_closest<true, true>), dim3(grid), dim3(ctx->thrClosest), ldsBytes, ctx->launchStream, s, st);
@@ -2189,7 +2233,7 @@ int tghip_wait(tghip_ctx *ctx)
         // the run-to-completion kernel (runBatch) gives every thread its own slots for the whole launch: one slot per
         // thread keeps the whole path state (112 B x 0.5 M slots) inside the Infinity Cache -- measured +5 % over four
         const bool flat = isFlat(ctx);
-        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->haveComplex && ctx->loopOpt && !ctx->auxPass && !ctx->haveCylinder && ctx->tablesFit;
+        const bool loop = flat && !ctx->haveForward && !ctx->haveMeshLight && ctx->fuseFlatOpt && !ctx->cameraFix && !ctx->haveComplex && ctx->loopOpt && !ctx->auxPass && !ctx->haveCylinder && ctx->tablesFit;
         if (loop && !ctx->maxSlotsSet)
             wantSlots = std::min<uint64_t>(wantSlots, uint64_t(launchGrid(ctx))*uint64_t(ctx->thrShadeSimple));
     }

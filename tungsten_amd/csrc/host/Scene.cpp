@@ -1259,6 +1259,8 @@ void Camera::fromJson(const JsonValue &v, const Scene &scene)
                     throw JsonLoadException("thinlens apertures other than the 'disk' and 'blade' textures and bitmaps are outside the path_tracer_hip hot-path scope");
             }
         }
+    } else if (type == "equirectangular") {        // EquirectangularCamera::fromJson = Camera::fromJson (no parameters of its own)
+        equirectangular = true;
     } else if (type != "pinhole") {
         throw JsonLoadException("Camera type '" + type + "' is outside the path_tracer_hip hot-path scope");
     }

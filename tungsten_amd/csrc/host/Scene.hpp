@@ -174,6 +174,7 @@ struct Camera
     float fovDeg = 60.0f;
     // cameras/ThinlensCamera.cpp:16-27 (type "thinlens"; the aperture is the default DiskTexture)
     bool thinlens = false;
+    bool equirectangular = false;                   // cameras/EquirectangularCamera.cpp (type "equirectangular")
     float focusDist = 1.0f, apertureSize = 0.001f, catEye = 0.0f;
     // "aperture": {"type": "blade", "blades": n, "angle": a} (textures/BladeTexture.cpp:14-41); 0 blades = the disk
     int blades = 0;
