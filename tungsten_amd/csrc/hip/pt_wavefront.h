@@ -1084,15 +1084,17 @@ __global__ WIDE_CLOSEST_BOUNDS void k_trace_closest_wide(DeviceScene s, PathStat
 // vertex and regenerates their slots (finishBody, below), then traces its extension rays, the fresh camera rays among them -- one launch per
 // part and iteration less, and the streaming of the regeneration runs inside the issue-bound walk's launch.  The shim launches the stand-alone
 // k_finish only before a host check (the liveness report) and before k_tail.  Single-level scenes on the decoupled walk.
-template<int NTS = PT_NT_TRAV>
+// EXT = false: the pass carries none of nextPath's run-time extras (Sobol' sampler, SampleRecords, auxiliary outputs, per-sample output, thin lens, media:
+// pp.flags == 0 -- the metric's passes): the finish in front of the walk is nextPath's lean variant, as in the specialised shading kernels.
+template<int NTS = PT_NT_TRAV, bool EXT = true>
 PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, unsigned short *order);
-template<bool COUNT, bool SOLIDS>
+template<bool COUNT, bool SOLIDS, bool EXT = true>
 __global__ WIDE_CLOSEST_BOUNDS void k_finish_trace_closest_wide(DeviceScene s, PathState st, PassParams pp)
 {
     extern __shared__ int ldsDyn[];
     __shared__ BlockLds L;
     __shared__ uint32_t fetchNext;
-    (void)finishBody(s, st, pp, L, reinterpret_cast<unsigned short *>(ldsDyn));   // (the queue area of the dynamic LDS: slots_per_block entries)
+    (void)finishBody<PT_NT_TRAV, EXT>(s, st, pp, L, reinterpret_cast<unsigned short *>(ldsDyn));   // (the queue area of the dynamic LDS: slots_per_block entries)
     __syncthreads();
     traceClosestWideBody<COUNT, SOLIDS, false, true>(s, st, L, fetchNext, ldsDyn);
 }
@@ -3126,7 +3128,7 @@ __global__ WIDE_SHADOW_BOUNDS void k_trace_shadow_fast_inst(DeviceScene s, PathS
 // Second half of the dynamic-fetch shadow step: finalises the paths that had ended at the vertex whose shadow rays
 // k_trace_shadow_dyn just resolved (Q_FIN), regenerates their slots and reports whether the workgroup has extension
 // rays for the next iteration (returned; BlockCtl::live_slots = how many of its slots still carry a path).
-template<int NTS>
+template<int NTS, bool EXT>
 PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassParams &pp, BlockLds &L, unsigned short *order)
 {
     BlockCtl &ctl = st.ctl[blockIdx.x];
@@ -3149,7 +3151,7 @@ PT_DEV bool finishBody(const DeviceScene &s, const PathState &st, const PassPara
             em = xyz(slotF4<NTS>(st, A_EMI, sl));
             black = FLAG_STATE(__float_as_uint(slotW(st, A_SH_P, sl, 3u))) == ST_TERMINATED_BLACK;
         }
-        bool regenerated = nextPath<true, true, NTS>(s, st, pp, fin, false, sl, em, black, &L.cursor, aborted, finishedCount);
+        bool regenerated = nextPath<true, EXT, NTS>(s, st, pp, fin, false, sl, em, black, &L.cursor, aborted, finishedCount);
         queuePush(regenerated, loc, L, Q_EXTP);
     }
     waveAddStat(&L.samples, finishedCount);

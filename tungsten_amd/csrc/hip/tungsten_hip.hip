@@ -176,6 +176,7 @@ struct tghip_ctx {
     bool mediaSimple = false;             // a media scene whose surface BSDFs MASK_MEDIA covers (no instances, no mesh emitters)
     bool mediaLeanOpt = true;             // "media_lean": shade such scenes with k_shade<MASK_MEDIA> instead of <BSDF_MASK_ALL>
     bool foldFinishOpt = true;            // "fold_finish"
+    bool finishLeanOpt = false;           // "finish_lean" = 1: the folded finish of flag-less passes through nextPath's lean variant -- measured SLOWER (profiles/r6_ab_finish_lean.txt), off
     bool topTreeOpt = true;               // "top_tree": 0 = ignore TgHipSceneDesc::top_nodes at the next upload (flat lists walked in record order: faster, not the reference's ties)
     bool mergeMissOpt = true;             // "merge_miss"
     bool tailOpt = true;
@@ -987,6 +988,7 @@ int tghip_set_option(tghip_ctx *ctx, const char *key, long long value)
     else if (k == "merge_miss") ctx->mergeMissOpt = value != 0;
     else if (k == "rotate_streams") ctx->rotateStreamsOpt = value != 0;
     else if (k == "fold_finish") ctx->foldFinishOpt = value != 0;
+    else if (k == "finish_lean") ctx->finishLeanOpt = value != 0;
     else if (k == "top_tree") ctx->topTreeOpt = value != 0;
     else if (k == "lds_tables") ctx->tablesFit = ctx->tablesFitScene && value != 0;
     else if (k == "env_lds") ctx->scene.env_tex = value != 0 ? ctx->envTexScene : -1;
@@ -1739,9 +1741,14 @@ static int runBatch(tghip_ctx *ctx, const PassParams &pp)
                     else                 { if (count) CLOSEST_WIDE(true, false, true, false); else CLOSEST_WIDE(false, false, true, false); }
                 } else if (ctx->decoupleOpt && foldFinish) {
                     // (k_finish's work of the previous iteration in front of the walk, pt_wavefront.h)
-#define CLOSEST_FIN(C, S) hipLaunchKernelGGL((k_finish_trace_closest_wide<C, S>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->launchStream, s, st, pp)
-                    if (ctx->haveSolids) { if (count) CLOSEST_FIN(true, true); else CLOSEST_FIN(false, true); }
-                    else                 { if (count) CLOSEST_FIN(true, false); else CLOSEST_FIN(false, false); }
+#define CLOSEST_FIN(C, S, E) hipLaunchKernelGGL((k_finish_trace_closest_wide<C, S, E>), dim3(grid), dim3(ctx->thrClosest), ldsWide, ctx->launchStream, s, st, pp)
+                    // ("finish_lean" = 1, an experiment: passes without flags -- uniform sampler, no records, no auxiliary or per-sample output, pinhole, no media: the metric's --
+                    // finish through nextPath's lean variant, 4 220 instead of 6 436 instructions in the kernel; 0.45 % SLOWER on the metric, three alternations: the walk's
+                    // code around it comes out differently.  Off by default; profiles/r6_ab_finish_lean.txt)
+                    const bool leanFinish = ctx->finishLeanOpt && pp.flags == 0u && pp.rec_count == nullptr && !count;
+                    if (leanFinish)           { if (ctx->haveSolids) CLOSEST_FIN(false, true, false); else CLOSEST_FIN(false, false, false); }
+                    else if (ctx->haveSolids) { if (count) CLOSEST_FIN(true, true, true); else CLOSEST_FIN(false, true, true); }
+                    else                      { if (count) CLOSEST_FIN(true, false, true); else CLOSEST_FIN(false, false, true); }
 #undef CLOSEST_FIN
                 } else if (ctx->decoupleOpt) {
                     if (ctx->haveSolids) { if (count) CLOSEST_WIDE(true, true, false, true); else CLOSEST_WIDE(false, true, false, true); }
