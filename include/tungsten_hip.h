@@ -322,7 +322,8 @@ typedef struct TgHipTexture {
 /* ---- camera (cameras/PinholeCamera.cpp:28-86, Camera.cpp:44-68, ReconstructionFilter) ---- */
 enum { TGHIP_FILTER_DIRAC = 0, TGHIP_FILTER_BOX = 1, TGHIP_FILTER_TABULATED = 2 };
 enum { TGHIP_CAMERA_PINHOLE = 0, TGHIP_CAMERA_THINLENS = 1,     /* cameras/PinholeCamera.cpp, cameras/ThinlensCamera.cpp */
-       TGHIP_CAMERA_EQUIRECTANGULAR = 2 };                       /* cameras/EquirectangularCamera.cpp: the full sphere around pos, longitude across the image, latitude down it;
+       TGHIP_CAMERA_EQUIRECTANGULAR = 2, TGHIP_CAMERA_CUBEMAP = 3 };   /* cameras/CubemapCamera.cpp: six 90-degree faces laid out as a cross, a row or a column; inv_xf as for the
+                                                                    equirectangular camera, blade_count = CubemapCamera::ProjectionMode (0 horizontal_cross, 1 vertical_cross, 2 row, 3 column) */                       /* cameras/EquirectangularCamera.cpp: the full sphere around pos, longitude across the image, latitude down it;
                                                                     inv_xf[0..8] then holds _rot = _transform.extractRotation() row-major (EquirectangularCamera.cpp:129-134) and
                                                                     inv_xf[9] = 1 / res_y (Camera::_pixelSize.y; pixel_size_x = 1 / res_x as for every camera) */
 enum { TGHIP_APERTURE_DISK = 0, TGHIP_APERTURE_BLADE = 1,       /* textures/DiskTexture.cpp:78-81, textures/BladeTexture.cpp:110-130 */

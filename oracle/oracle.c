@@ -3785,6 +3785,33 @@ static v3 traceSample(Ctx *c, uint32_t px, uint32_t py)
         const float *m = cam->inv_xf;
         ray.d = V(m[0]*l.x + m[1]*l.y + m[2]*l.z + 0.0f, m[3]*l.x + m[4]*l.y + m[5]*l.z + 0.0f, m[6]*l.x + m[7]*l.y + m[8]*l.z + 0.0f);
     }
+    if (cam->type == TGHIP_CAMERA_CUBEMAP) {
+        /* CubemapCamera::sampleDirection (cameras/CubemapCamera.cpp:153-166) with uvToFace (:95-106), uvToDirection (:107-112), faceToDirection (:74-80), the layout
+         * tables of :10-46 and prepareForRender (:217-232); blade_count = the projection mode */
+        static const int ResU[4] = {4, 3, 6, 1}, ResV[4] = {3, 4, 1, 6};
+        static const int OffsetU[4][6] = {{2, 0, 1, 1, 1, 3}, {1, 1, 1, 1, 0, 2}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 0, 0, 0}};
+        static const int OffsetV[4][6] = {{1, 1, 0, 2, 1, 1}, {1, 3, 0, 2, 1, 1}, {0, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5}};
+        static const int BasisU[4][6] = {{5, 4, 0, 0, 0, 1}, {5, 5, 5, 5, 0, 1}, {5, 4, 0, 0, 0, 1}, {5, 4, 0, 0, 0, 1}};
+        static const int BasisV[4][6] = {{3, 3, 4, 5, 3, 3}, {3, 2, 0, 1, 3, 3}, {3, 3, 4, 5, 3, 3}, {3, 3, 4, 5, 3, 3}};
+        static const float Basis[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+        const int mode = cam->blade_count;
+        const float faceW = 1.0f/(float)ResU[mode], faceH = 1.0f/(float)ResV[mode];
+        float u = ((float)px + 0.5f)*cam->pixel_size_x, v = ((float)py + 0.5f)*cam->inv_xf[9];
+        int face = -1;
+        for (int i = 0; i < 6 && face < 0; ++i) {
+            float dx = u - (float)OffsetU[mode][i]*faceW, dy = v - (float)OffsetV[mode][i]*faceH;
+            if (dx >= 0.0f && dy >= 0.0f && dx <= faceW && dy <= faceH) face = i;
+        }
+        if (face < 0)
+            return vs(0.0f);                              /* sampleDirection fails: PathTracer.cpp:27-28 */
+        u += fu*cam->pixel_size_x; v += fv*cam->inv_xf[9];
+        float dx = u - (float)OffsetU[mode][face]*faceW, dy = v - (float)OffsetV[mode][face]*faceH;
+        float ox = dx/faceW, oy = dy/faceH;
+        const float *b = Basis[face], *bu = Basis[BasisU[mode][face]], *bv = Basis[BasisV[mode][face]];
+        v3 l = vnorm(vadd(vadd(V(b[0], b[1], b[2]), vscale(V(bu[0], bu[1], bu[2]), ox*2.0f - 1.0f)), vscale(V(bv[0], bv[1], bv[2]), oy*2.0f - 1.0f)));
+        const float *m = cam->inv_xf;
+        ray.d = V(m[0]*l.x + m[1]*l.y + m[2]*l.z + 0.0f, m[3]*l.x + m[4]*l.y + m[5]*l.z + 0.0f, m[6]*l.x + m[7]*l.y + m[8]*l.z + 0.0f);
+    }
     ray.tmin = 1e-4f; ray.tmax = INFINITY;            /* Ray ctor defaults, math/Ray.hpp:24 */
 
     v3 throughput = vs(1.0f), emission = vs(0.0f);

@@ -80,6 +80,7 @@
 #include "cameras/PinholeCamera.hpp"
 #include "cameras/ThinlensCamera.hpp"
 #include "cameras/EquirectangularCamera.hpp"
+#include "cameras/CubemapCamera.hpp"
 #include "textures/DiskTexture.hpp"
 #include "textures/BladeTexture.hpp"
 #include "cameras/ReconstructionFilter.hpp"
@@ -713,8 +714,9 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     const PinholeCamera *pin = dynamic_cast<const PinholeCamera *>(&scene._cam);
     const ThinlensCamera *lens = dynamic_cast<const ThinlensCamera *>(&scene._cam);
     const EquirectangularCamera *equi = dynamic_cast<const EquirectangularCamera *>(&scene._cam);
-    if (!pin && !lens && !equi)
-        refuse("a camera other than the pinhole, the thin-lens and the equirectangular camera");
+    const CubemapCamera *cube = dynamic_cast<const CubemapCamera *>(&scene._cam);
+    if (!pin && !lens && !equi && !cube)
+        refuse("a camera other than the pinhole, the thin-lens, the equirectangular and the cubemap camera");
     const Camera *cam = &scene._cam;
     TgHipCamera &c = _desc.camera;
     std::memset(&c, 0, sizeof(c));
@@ -731,7 +733,7 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
     c.filter_bin_size = f._binSize;
     if (c.filter_type == TGHIP_FILTER_TABULATED)
         for (int i = 0; i < 32; ++i) c.filter_cdf[i] = f._cdf[i];
-    c.type = pin ? TGHIP_CAMERA_PINHOLE : lens ? TGHIP_CAMERA_THINLENS : TGHIP_CAMERA_EQUIRECTANGULAR;
+    c.type = pin ? TGHIP_CAMERA_PINHOLE : lens ? TGHIP_CAMERA_THINLENS : equi ? TGHIP_CAMERA_EQUIRECTANGULAR : TGHIP_CAMERA_CUBEMAP;
     // (a pinhole camera's thin-lens fields keep the values the stand-alone host's Camera has for it)
     c.focus_dist = 1.0f; c.aperture_size = 0.001f; c.cat_eye = 0.0f;
     c.aperture_type = TGHIP_APERTURE_DISK;
@@ -771,6 +773,12 @@ void HipSceneFlattener::build(TraceableScene &scene, const TraceSettings &settin
         for (int k = 0; k < 12; ++k) c.inv_xf[k] = 0.0f;
         copyRot(c.inv_xf, equi->_rot);
         c.inv_xf[9] = cam->_pixelSize.y();
+    }
+    if (cube) {                                        // CubemapCamera::prepareForRender (cameras/CubemapCamera.cpp:217-232)
+        for (int k = 0; k < 12; ++k) c.inv_xf[k] = 0.0f;
+        copyRot(c.inv_xf, cube->_rot);
+        c.inv_xf[9] = cam->_pixelSize.y();
+        c.blade_count = int(cube->_mode);
     }
     c.medium = addMedium(cam->_medium.get());
 

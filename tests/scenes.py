@@ -785,6 +785,18 @@ def _mt_equirectangular(scene):
 
 
 GOLDEN_CASES["materialtest_equirectangular"] = (materialtest, dict(resolution=(64, 32), spp=4, edit=_mt_equirectangular))
+def _cubemap(mode):
+    """cameras/CubemapCamera.cpp: six 90-degree faces around the same point inside the box; the cross layouts leave pixels outside every face (failed camera samples: black)."""
+    def edit(scene):
+        _equirectangular(scene)
+        scene["camera"]["type"] = "cubemap"
+        scene["camera"]["mode"] = mode
+    return edit
+
+
+GOLDEN_CASES["cornell_cubemap_cross"] = (cornell, dict(resolution=(48, 36), spp=8, edit=_cubemap("horizontal_cross")))
+GOLDEN_CASES["cornell_cubemap_vertical_sobol"] = (cornell, dict(resolution=(36, 48), spp=8, edit=_cubemap("vertical_cross"), renderer={"stratified_sampler": True}))
+GOLDEN_CASES["cornell_cubemap_row"] = (cornell, dict(resolution=(72, 12), spp=8, edit=_cubemap("row")))
 GOLDEN_CASES["cornell_equirectangular"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_equirectangular))
 GOLDEN_CASES["cornell_equirectangular_sobol"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_equirectangular, renderer={"stratified_sampler": True}))
 GOLDEN_CASES["cornell_atmosphere"] = (cornell, dict(resolution=(48, 27), spp=8, edit=_atmosphere))

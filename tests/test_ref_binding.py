@@ -104,10 +104,10 @@ for _name in ("cornell_disks", "cornell_cylinders", "cornell_point_lights", "cor
               "cornell_fog", "cornell_smoke", "cornell_fog_smoke_sobol", "cornell_fog_rayleigh", "cornell_fog_davis", "cornell_fog_davis_weinstein",
               "cornell_fog_interpolated", "volumetric_caustic", "non_exponential_linear", "non_exponential_pulse", "non_exponential_erlang",
               "non_exponential_double_exponential", "non_exponential_quadratic", "cornell_thinlens", "cornell_thinlens_cateye", "cornell_thinlens_blade5",
-              "cornell_thinlens_pivot", "cornell_thinlens_bitmap", "cornell_instances", "cornell_expfog", "cornell_expfog_smoke_sobol", "cornell_atmosphere", "cornell_atmosphere_smoke_sobol", "cornell_equirectangular"):
+              "cornell_thinlens_pivot", "cornell_thinlens_bitmap", "cornell_instances", "cornell_expfog", "cornell_expfog_smoke_sobol", "cornell_atmosphere", "cornell_atmosphere_smoke_sobol", "cornell_equirectangular", "cornell_cubemap_cross"):
     CASES[_name] = (lambda n: lambda tmp: scenes.GOLDEN_CASES[n][0](tmp, **dict(scenes.GOLDEN_CASES[n][1], resolution=(96, 54), spp=2)))(_name)
 WIDENED = ["cornell_disks", "cornell_cylinders", "cornell_point_lights", "cornell_sun_sky", "cornell_mesh_light", "cornell_fog_smoke_sobol", "volumetric_caustic",
-           "non_exponential_pulse", "cornell_thinlens_blade5", "cornell_thinlens_cateye", "cornell_instances", "zoo_e", "cornell_expfog_smoke_sobol", "cornell_atmosphere_smoke_sobol", "cornell_equirectangular"]
+           "non_exponential_pulse", "cornell_thinlens_blade5", "cornell_thinlens_cateye", "cornell_instances", "zoo_e", "cornell_expfog_smoke_sobol", "cornell_atmosphere_smoke_sobol", "cornell_equirectangular", "cornell_cubemap_cross"]
 
 
 @pytest.mark.parametrize("case", sorted(CASES))

@@ -67,6 +67,14 @@ extern template __global__ void k_tail<(MASK_TAIL | FEAT_QMC), true>(DeviceScene
 extern template __global__ void k_tail<MASK_COAT, false>(DeviceScene, PathState, PassParams, uint32_t);
 extern template __global__ void k_tail<(MASK_COAT | FEAT_QMC), false>(DeviceScene, PathState, PassParams, uint32_t);
 
+// CubemapCamera's layout tables (cameras/CubemapCamera.cpp:10-46), indexed by projection mode and face
+__device__ const int g_cubeResU[4] = {4, 3, 6, 1}, g_cubeResV[4] = {3, 4, 1, 6};
+__device__ const int g_cubeOffsetU[4][6] = {{2, 0, 1, 1, 1, 3}, {1, 1, 1, 1, 0, 2}, {0, 1, 2, 3, 4, 5}, {0, 0, 0, 0, 0, 0}};
+__device__ const int g_cubeOffsetV[4][6] = {{1, 1, 0, 2, 1, 1}, {1, 3, 0, 2, 1, 1}, {0, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5}};
+__device__ const int g_cubeBasisU[4][6] = {{5, 4, 0, 0, 0, 1}, {5, 5, 5, 5, 0, 1}, {5, 4, 0, 0, 0, 1}, {5, 4, 0, 0, 0, 1}};     // indices of +x -x +y -y +z -z
+__device__ const int g_cubeBasisV[4][6] = {{3, 3, 4, 5, 3, 3}, {3, 2, 0, 1, 3, 3}, {3, 3, 4, 5, 3, 3}, {3, 3, 4, 5, 3, 3}};
+PT_DEV f3 cubeBasis(int i) { const float sgn = (i & 1) ? -1.0f : 1.0f; return mk3((i >> 1) == 0 ? sgn : 0.0f, (i >> 1) == 1 ? sgn : 0.0f, (i >> 1) == 2 ? sgn : 0.0f); }
+
 // cameras/EquirectangularCamera.cpp (TGHIP_CAMERA_EQUIRECTANGULAR): the full sphere around the camera's position.  nextPath writes every fresh camera path
 // with the pinhole's ray; for this camera the direction is replaced here, in a launch in front of every closest-hit launch, for the slots of the
 // workgroup's Q_EXTP (the freshly generated camera rays) -- from the same two random numbers: the path's stream restarted at (seed, pixel, sample) or
@@ -91,16 +99,47 @@ __global__ __launch_bounds__(256) void k_camera_rays(DeviceScene s, PathState st
         float fu = 0.0f, fv = 0.0f;
         if (cam.filter_type == TGHIP_FILTER_BOX) { fu = xi0 - 0.5f; fv = xi1 - 0.5f; }
         else if (cam.filter_type == TGHIP_FILTER_TABULATED) { fu = filterSample1D(cam, xi0); fv = filterSample1D(cam, xi1); }
+        f3 l;
+        bool ok = true;
+        if (cam.type == TGHIP_CAMERA_CUBEMAP) {
+            // CubemapCamera::sampleDirection / uvToFace / uvToDirection / faceToDirection (cameras/CubemapCamera.cpp:153-166, 95-112, 74-80) with the tables of
+            // :10-46 and prepareForRender (:217-232); blade_count = the projection mode.  A pixel outside the six faces: the sample fails (black, PathTracer.cpp:27-28)
+            const int mode = cam.blade_count;
+            const float faceW = 1.0f/(float)g_cubeResU[mode], faceH = 1.0f/(float)g_cubeResV[mode];
+            float u = ((float)px + 0.5f)*cam.pixel_size_x, v = ((float)py + 0.5f)*cam.inv_xf[9];
+            int face = -1;
+            for (int i = 0; i < 6 && face < 0; ++i) {
+                const float dx = u - (float)g_cubeOffsetU[mode][i]*faceW, dy = v - (float)g_cubeOffsetV[mode][i]*faceH;
+                if (dx >= 0.0f && dy >= 0.0f && dx <= faceW && dy <= faceH) face = i;
+            }
+            ok = face >= 0;
+            if (ok) {
+                u += fu*cam.pixel_size_x; v += fv*cam.inv_xf[9];
+                const float dx = u - (float)g_cubeOffsetU[mode][face]*faceW, dy = v - (float)g_cubeOffsetV[mode][face]*faceH;
+                const float ox = dx/faceW, oy = dy/faceH;
+                const f3 b = cubeBasis(face), bu = cubeBasis(g_cubeBasisU[mode][face]), bv = cubeBasis(g_cubeBasisV[mode][face]);
+                l = normalized(b + bu*(ox*2.0f - 1.0f) + bv*(oy*2.0f - 1.0f));
+            } else {
+                l = mk3(0.0f, 0.0f, 1.0f);
+            }
+        } else {
         // uvToDirection (:26-36); inv_xf holds _rot and 1 / res_y (include/tungsten_hip.h)
         const float u = ((float)px + 0.5f + fu)*cam.pixel_size_x, v = ((float)py + 0.5f + fv)*cam.inv_xf[9];
         const float phi = (u - 0.5f)*PT_TWO_PI, theta = (1.0f - v)*PT_PI;
         const float sinTheta = sinfH(theta);
-        const f3 l = mk3(cosfH(phi)*sinTheta, -cosfH(theta), sinfH(phi)*sinTheta);
+        l = mk3(cosfH(phi)*sinTheta, -cosfH(theta), sinfH(phi)*sinTheta);
+        }
         const f3 d = mk3(cam.inv_xf[0]*l.x + cam.inv_xf[1]*l.y + cam.inv_xf[2]*l.z + 0.0f,      // Mat4f*Vec3f: the (zero) translation column is added
                          cam.inv_xf[3]*l.x + cam.inv_xf[4]*l.y + cam.inv_xf[5]*l.z + 0.0f,
                          cam.inv_xf[6]*l.x + cam.inv_xf[7]*l.y + cam.inv_xf[8]*l.z + 0.0f);
-        const float4 rd = slotF4(st, A_RAY_D, slot);
-        slotF4(st, A_RAY_D, slot) = mk4(d, rd.w);
+        if (ok) {
+            const float4 rd = slotF4(st, A_RAY_D, slot);
+            slotF4(st, A_RAY_D, slot) = mk4(d, rd.w);
+        } else {                                 // as nextPath leaves a failed camera sample: a ray that can hit nothing, no throughput
+            slotF4(st, A_RAY_D, slot) = mk4(d, -1.0f);
+            const float4 thr = slotF4(st, A_THR, slot);
+            slotF4(st, A_THR, slot) = make_float4(0.0f, 0.0f, 0.0f, thr.w);
+        }
     }
 }
 
@@ -1248,8 +1287,9 @@ int tghip_upload_scene(tghip_ctx *ctx, const TgHipSceneDesc *sd)
     ctx->thinlens = sd->camera.type == TGHIP_CAMERA_THINLENS;
     // the equirectangular camera's rays are written by a launch of their own in front of every closest-hit launch (k_camera_rays): the kernels that
     // generate a camera ray and trace it in one go -- the folded finish, the flat lists' fused launches, k_tail -- are not used for such scenes
-    ctx->cameraFix = sd->camera.type == TGHIP_CAMERA_EQUIRECTANGULAR;
-    if (sd->camera.type < TGHIP_CAMERA_PINHOLE || sd->camera.type > TGHIP_CAMERA_EQUIRECTANGULAR) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
+    ctx->cameraFix = sd->camera.type == TGHIP_CAMERA_EQUIRECTANGULAR || sd->camera.type == TGHIP_CAMERA_CUBEMAP;
+    if (sd->camera.type == TGHIP_CAMERA_CUBEMAP && (sd->camera.blade_count < 0 || sd->camera.blade_count > 3)) { ctx->error = "unknown cubemap projection mode"; return TGHIP_E_INVALID; }
+    if (sd->camera.type < TGHIP_CAMERA_PINHOLE || sd->camera.type > TGHIP_CAMERA_CUBEMAP) { ctx->error = "unknown camera type"; return TGHIP_E_UNSUPPORTED; }
     if (sd->camera.type == TGHIP_CAMERA_THINLENS && sd->camera.aperture_type == TGHIP_APERTURE_BITMAP) {
         // the aperture's Distribution2D: marginalPdf[h] marginalCdf[h + 1] pdf[w h] cdf[(w + 1) h] inside dist[]
         const uint64_t aw = uint64_t(std::max(sd->camera.aperture_w, 0)), ah = uint64_t(std::max(sd->camera.aperture_h, 0));

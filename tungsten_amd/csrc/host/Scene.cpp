@@ -1261,6 +1261,12 @@ void Camera::fromJson(const JsonValue &v, const Scene &scene)
         }
     } else if (type == "equirectangular") {        // EquirectangularCamera::fromJson = Camera::fromJson (no parameters of its own)
         equirectangular = true;
+    } else if (type == "cubemap") {                // CubemapCamera::fromJson (cameras/CubemapCamera.cpp:126-130; the constructor's mode is the horizontal cross)
+        std::string mode = "horizontal_cross";
+        v.getField("mode", mode);
+        cubemapMode = mode == "horizontal_cross" ? 0 : mode == "vertical_cross" ? 1 : mode == "row" ? 2 : mode == "column" ? 3 : -1;
+        if (cubemapMode < 0)
+            throw JsonLoadException("Invalid projection mode: '" + mode + "'");
     } else if (type != "pinhole") {
         throw JsonLoadException("Camera type '" + type + "' is outside the path_tracer_hip hot-path scope");
     }

@@ -175,6 +175,7 @@ struct Camera
     // cameras/ThinlensCamera.cpp:16-27 (type "thinlens"; the aperture is the default DiskTexture)
     bool thinlens = false;
     bool equirectangular = false;                   // cameras/EquirectangularCamera.cpp (type "equirectangular")
+    int cubemapMode = -1;                           // cameras/CubemapCamera.cpp (type "cubemap"): 0 horizontal_cross, 1 vertical_cross, 2 row, 3 column; -1 = not a cubemap camera
     float focusDist = 1.0f, apertureSize = 0.001f, catEye = 0.0f;
     // "aperture": {"type": "blade", "blades": n, "angle": a} (textures/BladeTexture.cpp:14-41); 0 blades = the disk
     int blades = 0;

@@ -715,7 +715,7 @@ void TraceableScene::flatten()
     c.filter_width = cam.filterWidth;
     c.filter_bin_size = cam.filterBinSize;
     std::memcpy(c.filter_cdf, cam.filterCdf, sizeof(c.filter_cdf));
-    c.type = cam.thinlens ? TGHIP_CAMERA_THINLENS : cam.equirectangular ? TGHIP_CAMERA_EQUIRECTANGULAR : TGHIP_CAMERA_PINHOLE;
+    c.type = cam.thinlens ? TGHIP_CAMERA_THINLENS : cam.equirectangular ? TGHIP_CAMERA_EQUIRECTANGULAR : cam.cubemapMode >= 0 ? TGHIP_CAMERA_CUBEMAP : TGHIP_CAMERA_PINHOLE;
     c.focus_dist = cam.focusDist;
     c.aperture_size = cam.apertureSize;
     c.cat_eye = cam.catEye;
@@ -739,12 +739,13 @@ void TraceableScene::flatten()
     c.blade_angle = cam.bladeAngle; c.blade_step = cam.bladeStep;
     c.blade_edge[0] = cam.bladeEdge[0]; c.blade_edge[1] = cam.bladeEdge[1];
     for (int i = 0; i < 12; ++i) c.inv_xf[i] = cam.invTransform[i];
-    if (cam.equirectangular) {
+    if (cam.equirectangular || cam.cubemapMode >= 0) {
         // EquirectangularCamera::prepareForRender (cameras/EquirectangularCamera.cpp:129-134): _rot = _transform.extractRotation(); Camera::_pixelSize.y
         c.plane_dist = 0.0f;
         for (int i = 0; i < 12; ++i) c.inv_xf[i] = 0.0f;
         copyRot(c.inv_xf, cam.transform.extractRotation());
         c.inv_xf[9] = 1.0f/cam.resY;
+        if (cam.cubemapMode >= 0) c.blade_count = cam.cubemapMode;     // (CubemapCamera.cpp:217-232: the face tables follow from the mode)
     }
     c.medium = addMedium(cam.medium);
 
