@@ -880,9 +880,22 @@ tghip_ctx *tghip_create(int device_ordinal)
             if (!pool.empty()) { set = pool.back(); pool.pop_back(); reused = true; }
         }
         if (!reused) {
-            if (e == hipSuccess) e = hipStreamCreateWithFlags(&set.main, hipStreamNonBlocking);
+            // TGHIP_STREAM_PRIORITIES="p0,p1,..." (an experiment's hook, profiles/r6_ab_stream_priorities.txt): HIP stream priorities of the main stream and the part
+            // streams, in creation order (lower = served first; the device's range is clamped by HIP); unset: plain streams
+            int prio[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            bool withPrio = false;
+            if (const char *env = std::getenv("TGHIP_STREAM_PRIORITIES")) {
+                withPrio = true;
+                int k = 0;
+                for (const char *c = env; *c && k < 8; ) {
+                    prio[k++] = int(std::strtol(c, const_cast<char **>(&c), 10));
+                    while (*c == ',' || *c == ' ') ++c;
+                }
+            }
+            auto create = [&](hipStream_t *st, int p) { return withPrio ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, p) : hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
+            if (e == hipSuccess) e = create(&set.main, prio[0]);
             for (int k = 0; k < 7; ++k)
-                if (e == hipSuccess) e = hipStreamCreateWithFlags(&set.part[k], hipStreamNonBlocking);
+                if (e == hipSuccess) e = create(&set.part[k], prio[k + 1]);
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&set.abort, hipStreamNonBlocking);
         }
         ctx->stream = set.main;
