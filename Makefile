@@ -39,6 +39,12 @@ $(OBJDIR)/host_%.o: tungsten_amd/csrc/host/%.cpp $(wildcard tungsten_amd/csrc/ho
 	@mkdir -p $(OBJDIR)
 	g++ $(HOSTFLAGS) -c $< -o $@
 
+# shade_simple.hip -- the Cornell box's one-launch kernel (k_shade<MASK_LEAN, ., FUSE_TRACE | FUSE_SHADOW | FUSE_LOOP>) and the class-0 shading variants -- is scheduled with
+# the AMDGPU back end's max-ilp strategy: Cornell box 2 551 -> 2 600 Msamples/s (+1.9 %, two alternations, images identical), the metric's workload and mesh1m level
+# (profiles/r6_ab_sched_max_ilp.txt; on the traversal and the other shading translation units the strategy changes nothing, round 5 and the same file).  SCHED= gives the default back.
+SCHED ?= max-ilp
+$(OBJDIR)/shade_simple.o: HIPFLAGS += $(if $(SCHED),-mllvm -amdgpu-sched-strategy=$(SCHED),)
+
 $(OBJDIR)/%.o: tungsten_amd/csrc/hip/%.hip $(HIPHDR)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
