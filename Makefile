@@ -44,6 +44,10 @@ $(OBJDIR)/host_%.o: tungsten_amd/csrc/host/%.cpp $(wildcard tungsten_amd/csrc/ho
 # (profiles/r6_ab_sched_max_ilp.txt; on the traversal and the other shading translation units the strategy changes nothing, round 5 and the same file).  SCHED= gives the default back.
 SCHED ?= max-ilp
 $(OBJDIR)/shade_simple.o: HIPFLAGS += $(if $(SCHED),-mllvm -amdgpu-sched-strategy=$(SCHED),)
+# tail.hip -- k_tail, one latency-bound launch per part at the end of every pass (a sixth of a 16-spp pass of the as-shipped materialtest) -- is built -Os: 264 -> 234 VGPRs,
+# as shipped 743 -> 750 Msamples/s in three alternations (profiles/r6_ab_sched_max_ilp.txt, session 55); the throughput kernels keep -O3.  TAILOPT=-O3 gives it back.
+TAILOPT ?= -Os
+$(OBJDIR)/tail.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(TAILOPT),$(HIPFLAGS)))
 
 $(OBJDIR)/%.o: tungsten_amd/csrc/hip/%.hip $(HIPHDR)
 	@mkdir -p $(OBJDIR)
