@@ -48,6 +48,11 @@ $(OBJDIR)/shade_simple.o: HIPFLAGS += $(if $(SCHED),-mllvm -amdgpu-sched-strateg
 # as shipped 743 -> 750 Msamples/s in three alternations (profiles/r6_ab_sched_max_ilp.txt, session 55); the throughput kernels keep -O3.  TAILOPT=-O3 gives it back.
 TAILOPT ?= -Os
 $(OBJDIR)/tail.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(TAILOPT),$(HIPFLAGS)))
+# tungsten_hip.hip and walk_shadow.hip -- the closest-hit and shadow walks and the small kernels around them -- are built -Os as well: the metric's workload 1 167 -> 1 175 Msamples/s
+# (+0.7 %, better in seven of seven alternations), mesh1m +0.5 %, instances10k level (profiles/r6_ab_sched_max_ilp.txt, sessions 57 / 58; -O2 had read level to +0.6 % in session 49).
+# The shading units keep -O3 (-Os: level or slower).  WALKOPT=-O3 gives it back.
+WALKOPT ?= -Os
+$(OBJDIR)/tungsten_hip.o $(OBJDIR)/walk_shadow.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(WALKOPT),$(HIPFLAGS)))
 
 $(OBJDIR)/%.o: tungsten_amd/csrc/hip/%.hip $(HIPHDR)
 	@mkdir -p $(OBJDIR)
