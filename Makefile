@@ -41,15 +41,15 @@ $(OBJDIR)/host_%.o: tungsten_amd/csrc/host/%.cpp $(wildcard tungsten_amd/csrc/ho
 
 # shade_simple.hip -- the Cornell box's one-launch kernel (k_shade<MASK_LEAN, ., FUSE_TRACE | FUSE_SHADOW | FUSE_LOOP>) and the class-0 shading variants -- is scheduled with
 # the AMDGPU back end's max-ilp strategy: Cornell box 2 551 -> 2 600 Msamples/s (+1.9 %, two alternations, images identical), the metric's workload and mesh1m level
-# (profiles/r6_ab_sched_max_ilp.txt; on the traversal and the other shading translation units the strategy changes nothing, round 5 and the same file).  SCHED= gives the default back.
+# (profiles/r6_ab_compiler_options.txt; on the traversal and the other shading translation units the strategy changes nothing, round 5 and the same file).  SCHED= gives the default back.
 SCHED ?= max-ilp
 $(OBJDIR)/shade_simple.o: HIPFLAGS += $(if $(SCHED),-mllvm -amdgpu-sched-strategy=$(SCHED),)
 # tail.hip -- k_tail, one latency-bound launch per part at the end of every pass (a sixth of a 16-spp pass of the as-shipped materialtest) -- is built -Os: 264 -> 234 VGPRs,
-# as shipped 743 -> 750 Msamples/s in three alternations (profiles/r6_ab_sched_max_ilp.txt, session 55); the throughput kernels keep -O3.  TAILOPT=-O3 gives it back.
+# as shipped 743 -> 750 Msamples/s in three alternations (profiles/r6_ab_compiler_options.txt, session 55); the throughput kernels keep -O3.  TAILOPT=-O3 gives it back.
 TAILOPT ?= -Os
 $(OBJDIR)/tail.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(TAILOPT),$(HIPFLAGS)))
 # tungsten_hip.hip and walk_shadow.hip -- the closest-hit and shadow walks and the small kernels around them -- are built -Os as well: the metric's workload 1 167 -> 1 175 Msamples/s
-# (+0.7 %, better in seven of seven alternations), mesh1m +0.5 %, instances10k level (profiles/r6_ab_sched_max_ilp.txt, sessions 57 / 58; -O2 had read level to +0.6 % in session 49).
+# (+0.7 %, better in seven of seven alternations), mesh1m +0.5 %, instances10k level (profiles/r6_ab_compiler_options.txt, sessions 57 / 58; -O2 had read level to +0.6 % in session 49).
 # The shading units keep -O3 (-Os: level or slower).  WALKOPT=-O3 gives it back.
 WALKOPT ?= -Os
 $(OBJDIR)/tungsten_hip.o $(OBJDIR)/walk_shadow.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(WALKOPT),$(HIPFLAGS)))
