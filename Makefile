@@ -51,8 +51,11 @@ $(OBJDIR)/tail.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(TAILOPT),
 # tungsten_hip.hip and walk_shadow.hip -- the closest-hit and shadow walks and the small kernels around them -- are built -Os as well: the metric's workload 1 167 -> 1 175 Msamples/s
 # (+0.7 %, better in seven of seven alternations), mesh1m +0.5 %, instances10k level (profiles/r6_ab_compiler_options.txt, sessions 57 / 58; -O2 had read level to +0.6 % in session 49).
 # The shading units keep -O3 (-Os: level or slower).  WALKOPT=-O3 gives it back.
+# walk_shadow.hip alone reads another 0.3 % at -O1 (its launches 603 -> 596 us; the metric better in five of five alternations, session 62; mesh1m level): SHADOWOPT.
 WALKOPT ?= -Os
-$(OBJDIR)/tungsten_hip.o $(OBJDIR)/walk_shadow.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(WALKOPT),$(HIPFLAGS)))
+SHADOWOPT ?= -O1
+$(OBJDIR)/tungsten_hip.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(WALKOPT),$(HIPFLAGS)))
+$(OBJDIR)/walk_shadow.o: HIPFLAGS := $(if $(HIPOPT),$(HIPFLAGS),$(subst -O3,$(SHADOWOPT),$(HIPFLAGS)))
 
 $(OBJDIR)/%.o: tungsten_amd/csrc/hip/%.hip $(HIPHDR)
 	@mkdir -p $(OBJDIR)
